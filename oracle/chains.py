@@ -1,0 +1,197 @@
+"""Oracle: the per-realization chains of BASELINE.json's configs.  TEST INFRASTRUCTURE.
+
+Each ``chain_*`` composes the oracle operators in the order (and with the RNG draw
+order) of the reference's own template simulators:
+  C1  apps/awgn_modulators/simulate_psk.py:51-115
+  C2  notebooks/Transmission_with_Rayleigh_and_AWGN_channels.ipynb cell 8 +
+      pyphysim/channels/singleuser.py:48-81,130-151
+  C3  notebooks/TDL_and_OFDM.ipynb (OfdmTdlSimulator._run_simulation) /
+      apps/ofdm/ofdm_tdlchannel.py:30-80
+  C4  apps/mimo/simulate_mimo.py:68-142 (+ per-antenna OFDM)
+and returns every intermediate so that HIP kernels can be fed injected inputs.
+
+Randomness is pluggable:
+  LegacyRng(seed)          NumPy legacy MT19937, i.e. what ``np.random.seed(seed)``
+                           gives the reference (container parity / golden vectors)
+  PhiloxRng(seed, r)       the mcle-philox-v1 contract (oracle/philox.py), i.e. what
+                           the HIP pipelines draw on-chip (common random numbers)
+"""
+import math
+
+import numpy as np
+
+from . import channels as och
+from . import mimo as omimo
+from . import modem as omodem
+from . import ofdm as oofdm
+from . import philox
+
+
+class LegacyRng:
+    """Sequential draws from one legacy MT19937 stream, as the reference does."""
+    legacy = True
+
+    def __init__(self, seed):
+        self.rs = np.random.RandomState(seed)
+
+    def symbols(self, n, M):
+        return self.rs.randint(0, M, n)
+
+    def cn(self, stream, *shape):
+        # util/misc.py:354-355: all real parts are drawn before all imaginary parts
+        re = self.rs.randn(*shape)
+        im = self.rs.randn(*shape)
+        return (1.0 / math.sqrt(2.0)) * (re + 1j * im)
+
+    def uniform(self, *shape):
+        return self.rs.rand(*shape)
+
+
+class PhiloxRng:
+    """Position-addressed draws; each stream keeps its own running position."""
+    legacy = False
+
+    def __init__(self, seed, realization):
+        self.seed, self.r = seed, realization
+        self.pos = {}
+
+    def _advance(self, stream, n):
+        p = self.pos.get(stream, 0)
+        self.pos[stream] = p + n
+        return p
+
+    def symbols(self, n, M):
+        return philox.symbols(self.seed, self.r, n, M, offset=self._advance(philox.STREAM_DATA, n))
+
+    def cn(self, stream, *shape):
+        n = int(np.prod(shape))
+        z = philox.cnormal(self.seed, self.r, n, stream, offset=self._advance(stream, n))
+        return z.reshape(shape)
+
+    def uniform(self, *shape):
+        n = int(np.prod(shape))
+        u = philox.uniforms(self.seed, self.r, n, offset=self._advance(philox.STREAM_PHASE, n))
+        return u.reshape(shape)
+
+
+def constellation(mod, M):
+    if mod == 'qam':
+        return omodem.qam_constellation(M)
+    if mod == 'psk':
+        return omodem.psk_constellation(M)
+    if mod == 'qpsk':
+        return omodem.psk_constellation(4, math.pi / 4.0)
+    if mod == 'bpsk':
+        return omodem.bpsk_constellation()
+    raise ValueError(mod)
+
+
+def _counts(out, idx, dec, M):
+    out['decisions'] = dec
+    out['symbol_errors'] = omodem.count_symbol_errors(idx, dec)
+    out['bit_errors'] = int(omodem.count_bit_errors(idx, dec))
+    out['num_symbols'] = int(idx.size)
+    out['num_bits'] = int(idx.size) * omodem.level2bits(M)
+    return out
+
+
+def chain_awgn(rng, mod='qam', M=16, N=10000, snr_db=10.0):
+    """C1: idx -> modulate -> + sqrt(1/snr) * randn_c -> demodulate -> counts."""
+    table = constellation(mod, M)
+    noise_var = 1.0 / float(omodem.dB2Linear(snr_db))
+    idx = rng.symbols(N, M)
+    tx = omodem.modulate(table, idx)
+    noise = rng.cn(philox.STREAM_NOISE, N)
+    rx = tx + math.sqrt(noise_var) * noise
+    dec = omodem.demodulate(table, rx)
+    return _counts(dict(table=table, idx=idx, tx=tx, noise=noise, rx=rx, noise_var=noise_var),
+                   idx, dec, M)
+
+
+def _jakes_phases(rng, L, shape):
+    """phi then psi, each 2*pi*rand(L, *shape, 1) (fading_generators.py:421-425)."""
+    phi = 2 * np.pi * rng.uniform(L, *shape, 1)
+    psi = 2 * np.pi * rng.uniform(L, *shape, 1)
+    return phi, psi
+
+
+def chain_flat_jakes(rng, mod='qam', M=64, N=100000, snr_db=20.0, Fd=100.0, Ts=1e-3, L=8):
+    """C2: flat fading SuChannel(JakesSampleGenerator(Fd, Ts, L)); y = h*s + n; equalise y/h."""
+    table = constellation(mod, M)
+    noise_var = 1.0 / float(omodem.dB2Linear(snr_db))
+    idx = rng.symbols(N, M)
+    tx = omodem.modulate(table, idx)
+    if rng.legacy:
+        # Jakes ctor: phi/psi of shape (L, 1) used for one discarded sample at t = 0
+        # (fading_generators.py:348-351,413-414)
+        rng.uniform(L, 1)
+        rng.uniform(L, 1)
+    # TdlChannel ctor sets the generator shape to (num_taps,) -> re-draw (fading.py:796-798)
+    phi, psi = _jakes_phases(rng, L, (1,))
+    t, _ = och.jakes_time_axis(Ts, Ts, N)            # ctor consumed t = 0, so t0 = Ts
+    h = och.jakes_samples(phi, psi, Fd, t)            # [1, N]
+    p_lin, d_idx = och.discretize_profile(np.zeros(1), np.zeros(1), Ts)
+    taps = och.tdl_taps(h, p_lin)
+    faded = och.tdl_apply(tx, taps, d_idx)
+    noise = rng.cn(philox.STREAM_NOISE, N)
+    rx = faded + math.sqrt(noise_var) * noise
+    eq = rx / taps[0]
+    dec = omodem.demodulate(table, eq)
+    return _counts(dict(table=table, idx=idx, tx=tx, phi=phi, psi=psi, t=t, h=taps, faded=faded,
+                        noise=noise, rx=rx, eq=eq, noise_var=noise_var), idx, dec, M)
+
+
+def chain_ofdm_tdl(rng, mod='qpsk', M=4, fft_size=1024, cp_size=16, num_used=None, n_ofdm_sym=1,
+                   snr_db=20.0, Fd=10.0, Ts=1.0 / (15e3 * 1024), L=8,
+                   tap_powers_dB=(0.0, -3.0, -6.0, -9.0, -12.0), tap_delays_samples=(0, 1, 2, 3, 4)):
+    """C3: OFDM over a time-varying Jakes TDL channel with a one-tap equaliser."""
+    table = constellation(mod, M)
+    num_used = oofdm.check_params(fft_size, cp_size, num_used)
+    noise_var = 1.0 / float(omodem.dB2Linear(snr_db))
+    n_data = num_used * n_ofdm_sym
+    idx = rng.symbols(n_data, M)
+    sym = omodem.modulate(table, idx)
+    tx = oofdm.modulate(sym, fft_size, cp_size, num_used)
+    p_lin, d_idx = och.discretize_profile(np.asarray(tap_powers_dB, dtype=float),
+                                          np.asarray(tap_delays_samples, dtype=float) * Ts, Ts)
+    ntaps = len(d_idx)
+    if rng.legacy:
+        rng.uniform(L, 1)
+        rng.uniform(L, 1)
+    phi, psi = _jakes_phases(rng, L, (ntaps,))
+    t, _ = och.jakes_time_axis(Ts, Ts, tx.size)
+    fading = och.jakes_samples(phi, psi, Fd, t)       # [taps, n]
+    taps = och.tdl_taps(fading, p_lin)
+    faded = och.tdl_apply(tx, taps, d_idx)            # n + max_delay samples
+    noise = rng.cn(philox.STREAM_NOISE, faded.size)
+    rx = faded + math.sqrt(noise_var) * noise
+    demod = oofdm.demodulate(rx[:tx.size].copy(), fft_size, cp_size, num_used)
+    eq = oofdm.onetap_equalize(demod, taps, d_idx, fft_size, cp_size, num_used)
+    dec = omodem.demodulate(table, eq)
+    return _counts(dict(table=table, idx=idx, sym=sym, tx=tx, phi=phi, psi=psi, t=t, taps=taps,
+                        tap_powers_linear=p_lin, delay_indexes=d_idx, faded=faded, noise=noise,
+                        rx=rx, demod=demod, eq=eq, noise_var=noise_var), idx, dec, M)
+
+
+def chain_mimo_ofdm(rng, mod='qam', M=64, nt=4, nr=4, fft_size=1024, cp_size=16, num_used=None,
+                    n_ofdm_sym=1, snr_db=25.0, mmse=True):
+    """C4: flat H = randn_c(Nr, Nt) per realization, Blast encode, per-antenna OFDM,
+    R = H T + noise, per-antenna OFDM demodulate, Blast MMSE (or ZF) decode."""
+    table = constellation(mod, M)
+    num_used = oofdm.check_params(fft_size, cp_size, num_used)
+    noise_var = 1.0 / float(omodem.dB2Linear(snr_db))
+    H = rng.cn(philox.STREAM_CHAN, nr, nt)
+    n_data = nt * num_used * n_ofdm_sym
+    idx = rng.symbols(n_data, M)
+    sym = omodem.modulate(table, idx)
+    X = omimo.blast_encode(sym, nt)                                        # [nt, n/nt]
+    T = np.stack([oofdm.modulate(X[a], fft_size, cp_size, num_used) for a in range(nt)])
+    noise = rng.cn(philox.STREAM_NOISE, nr, T.shape[1])
+    R = H @ T + math.sqrt(noise_var) * noise
+    Y = np.stack([oofdm.demodulate(R[a].copy(), fft_size, cp_size, num_used) for a in range(nr)])
+    nv_filter = noise_var if mmse else 0.0
+    G = omimo.blast_receive_filter(H, nv_filter)
+    est = (G @ Y).reshape(-1, order='F')
+    dec = omodem.demodulate(table, est)
+    return _counts(dict(table=table, H=H, idx=idx, sym=sym, X=X, T=T, noise=noise, R=R, Y=Y, G=G,
+                        est=est, noise_var=noise_var), idx, dec, M)

@@ -1,0 +1,314 @@
+#!/usr/bin/env python3
+"""Pin the oracle to the reference and mint tests/golden/*.npz.  CONTAINER-ONLY TOOL.
+
+Run:  python oracle/make_golden.py            (needs /root/reference; read-only)
+
+It imports the reference (darcamo/pyphysim v0.7.2) with the two stub modules in
+oracle/ref_shim (numba, validate) and a `numpy.int` alias, then for every chain:
+  1. runs the REFERENCE's own operators, composed as its apps / notebooks do,
+     under ``np.random.seed(base + r)``;
+  2. runs the oracle chain under ``LegacyRng(base + r)`` (same MT19937 stream);
+  3. asserts equality (integers exactly, floats to 1e-12 relative);
+  4. stores the reference's inputs / intermediates / counters as the fixture.
+The fixtures are data only (arrays); no reference source text is stored.
+"""
+import math
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+REF = os.environ.get("PYPHYSIM_REFERENCE", "/root/reference")
+sys.path.insert(0, os.path.join(HERE, "ref_shim"))
+sys.path.insert(0, REF)
+sys.path.insert(0, REPO)
+np.int = int  # removed in numpy >= 1.24; the reference's results.py:558 still uses it
+
+from pyphysim.channels import fading as rfading  # noqa: E402
+from pyphysim.channels import fading_generators as rfg  # noqa: E402
+from pyphysim.channels import singleuser as rsu  # noqa: E402
+from pyphysim.mimo import mimo as rmimo  # noqa: E402
+from pyphysim.modulators import fundamental as rmod  # noqa: E402
+from pyphysim.modulators import ofdm as rofdm  # noqa: E402
+from pyphysim.util import misc as rmisc  # noqa: E402
+from pyphysim.util.conversion import dB2Linear  # noqa: E402
+
+from oracle import chains, channels as och, modem as omodem, ofdm as oofdm  # noqa: E402
+
+GOLD = os.path.join(REPO, "tests", "golden")
+BASE_SEED = 20260927
+
+
+def close(a, b, tol=1e-12, what=""):
+    a = np.asarray(a)
+    b = np.asarray(b)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    if a.dtype.kind in "iub" and b.dtype.kind in "iub":
+        assert np.array_equal(a, b), what
+        return 0.0
+    scale = max(1.0, float(np.max(np.abs(b))) if b.size else 1.0)
+    err = float(np.max(np.abs(a - b))) / scale if a.size else 0.0
+    assert err <= tol, (what, err)
+    return err
+
+
+def ref_counts(idx, dec, M):
+    return dict(symbol_errors=int(np.sum(idx != dec)),
+                bit_errors=int(rmisc.count_bit_errors(idx, dec)),
+                num_symbols=int(idx.size), num_bits=int(idx.size * rmisc.level2bits(M)))
+
+
+def ref_modulator(mod, M):
+    return {"qam": lambda: rmod.QAM(M), "psk": lambda: rmod.PSK(M), "qpsk": rmod.QPSK,
+            "bpsk": rmod.BPSK}[mod]()
+
+
+# ----------------------------------------------------------------------------- operators
+def golden_operators():
+    out = {}
+    for M in (4, 16, 64, 256):
+        t = rmod.QAM(M).symbols
+        close(omodem.qam_constellation(M), t, 0, "qam%d" % M)
+        out["qam%d" % M] = t
+    for M in (2, 4, 8, 16):
+        t = rmod.PSK(M).symbols
+        close(omodem.psk_constellation(M), t, 0, "psk%d" % M)
+        out["psk%d" % M] = t
+    t = rmod.QPSK().symbols
+    close(omodem.psk_constellation(4, math.pi / 4), t, 0, "qpsk")
+    out["qpsk"] = t
+    out["bpsk"] = np.asarray(rmod.BPSK().symbols, dtype=complex)
+    close(omodem.bpsk_constellation(), out["bpsk"], 0, "bpsk")
+
+    # demodulate + slicer on noisy symbols
+    rs = np.random.RandomState(BASE_SEED)
+    for M in (4, 16, 64, 256):
+        q = rmod.QAM(M)
+        idx = rs.randint(0, M, 3000)
+        rx = q.modulate(idx) + 0.25 * (rs.randn(3000) + 1j * rs.randn(3000)) / math.sqrt(M) * 4
+        dec = q.demodulate(rx)
+        close(omodem.demodulate(q.symbols, rx), dec, 0, "demod qam%d" % M)
+        close(omodem.qam_slicer(M, rx), dec, 0, "slicer qam%d" % M)
+        assert int(rmisc.count_bit_errors(idx, dec)) == int(omodem.count_bit_errors(idx, dec))
+        out["demod_qam%d_rx" % M] = rx
+        out["demod_qam%d_idx" % M] = idx
+        out["demod_qam%d_dec" % M] = dec
+        out["demod_qam%d_biterr" % M] = np.int64(rmisc.count_bit_errors(idx, dec))
+    p = rmod.PSK(8)
+    idx = rs.randint(0, 8, 3000)
+    rx = p.modulate(idx) + 0.3 * (rs.randn(3000) + 1j * rs.randn(3000))
+    out["demod_psk8_rx"], out["demod_psk8_idx"], out["demod_psk8_dec"] = rx, idx, p.demodulate(rx)
+    close(omodem.demodulate(p.symbols, rx), out["demod_psk8_dec"], 0, "demod psk8")
+
+    # OFDM maps, scale, modulate / demodulate
+    for (fft, cp, used) in ((16, 4, 10), (16, 4, 14), (64, 16, 52), (64, 0, 64), (1024, 16, 1024),
+                            (1024, 72, 600)):
+        o = rofdm.OFDM(fft, cp, used)
+        close(oofdm.used_subcarrier_indexes(fft, used), o.get_used_subcarrier_indexes(), 0, "map")
+        x = rs.randn(2 * used - 3) + 1j * rs.randn(2 * used - 3)      # forces zero padding
+        tx = o.modulate(x)
+        close(oofdm.modulate(x, fft, cp, used), tx, 1e-13, "ofdm.mod")
+        back = o.demodulate(tx.copy())
+        close(oofdm.demodulate(tx, fft, cp, used), back, 1e-13, "ofdm.demod")
+        key = "ofdm_%d_%d_%d" % (fft, cp, used)
+        out[key + "_map"] = o.get_used_subcarrier_indexes()
+        out[key + "_x"], out[key + "_tx"], out[key + "_back"] = x, tx, back
+
+    # TDL profile discretisation (COST259 TU at Ts = 3.255e-8 -> 15 taps over 67)
+    Ts = 3.255e-8
+    prof = rfading.COST259_TUx.get_discretize_profile(Ts)
+    p_lin, d_idx = och.discretize_profile(*och.COST259_TU, Ts)
+    close(d_idx, prof.tap_delays, 0, "tu delays")
+    close(p_lin, prof.tap_powers_linear, 1e-15, "tu powers")
+    out["tu_Ts"], out["tu_delays"], out["tu_powers_linear"] = Ts, prof.tap_delays, prof.tap_powers_linear
+    for name, pr, mine in (("ra", rfading.COST259_RAx, och.COST259_RA), ("ht", rfading.COST259_HTx, och.COST259_HT)):
+        prof = pr.get_discretize_profile(Ts)
+        p_lin, d_idx = och.discretize_profile(*mine, Ts)
+        close(d_idx, prof.tap_delays, 0, name)
+        close(p_lin, prof.tap_powers_linear, 1e-15, name)
+
+    # Blast encode / decode
+    H = rmisc.randn_c(4, 4)
+    b = rmimo.Blast(H)
+    x = rs.randn(40) + 1j * rs.randn(40)
+    enc = b.encode(x)
+    from oracle import mimo as omimo
+    close(omimo.blast_encode(x, 4), enc, 0, "blast.encode")
+    y = H @ enc
+    zf = b.decode(y)
+    close(omimo.blast_decode(y, H, 0.0), zf, 1e-12, "blast zf")
+    b.set_noise_var(0.05)
+    mm = b.decode(y)
+    close(omimo.blast_decode(y, H, 0.05), mm, 1e-12, "blast mmse")
+    out["blast_H"], out["blast_x"], out["blast_enc"], out["blast_y"] = H, x, enc, y
+    out["blast_zf"], out["blast_mmse"], out["blast_nv"] = zf, mm, 0.05
+    np.savez_compressed(os.path.join(GOLD, "operators.npz"), **out)
+    print("operators: ok (%d arrays)" % len(out))
+
+
+
+
+# ----------------------------------------------------------------------------- chains
+def ref_chain_awgn(seed, mod, M, N, snr_db):
+    np.random.seed(seed)
+    m = ref_modulator(mod, M)
+    noise_var = 1.0 / dB2Linear(snr_db)
+    idx = np.random.randint(0, M, N)
+    tx = m.modulate(idx)
+    noise = rmisc.randn_c(N)
+    rx = tx + noise * math.sqrt(noise_var)
+    dec = m.demodulate(rx)
+    return dict(table=np.asarray(m.symbols, dtype=complex), idx=idx, tx=np.asarray(tx, dtype=complex),
+                noise=noise, rx=rx, decisions=dec, noise_var=noise_var, **ref_counts(idx, dec, M))
+
+
+def ref_chain_flat_jakes(seed, mod, M, N, snr_db, Fd, Ts, L):
+    np.random.seed(seed)
+    m = ref_modulator(mod, M)
+    noise_var = 1.0 / dB2Linear(snr_db)
+    idx = np.random.randint(0, M, N)
+    tx = m.modulate(idx)
+    jakes = rfg.JakesSampleGenerator(Fd, Ts, L)
+    chan = rsu.SuChannel(jakes)
+    faded = chan.corrupt_data(tx)
+    ir = chan.get_last_impulse_response()
+    h = ir.tap_values_sparse                                  # [1, N]
+    noise = rmisc.randn_c(N)
+    rx = faded + noise * math.sqrt(noise_var)
+    eq = rx / h[0]
+    dec = m.demodulate(eq)
+    return dict(table=m.symbols, idx=idx, tx=tx, phi=jakes._phi_l, psi=jakes._psi_l, h=h, faded=faded,
+                noise=noise, rx=rx, eq=eq, decisions=dec, noise_var=noise_var, **ref_counts(idx, dec, M))
+
+
+def ref_chain_ofdm_tdl(seed, mod, M, fft, cp, used, nsym, snr_db, Fd, Ts, L, powers_dB, delays):
+    np.random.seed(seed)
+    m = ref_modulator(mod, M)
+    o = rofdm.OFDM(fft, cp, used)
+    eqz = rofdm.OfdmOneTapEqualizer(o)
+    noise_var = 1.0 / dB2Linear(snr_db)
+    idx = np.random.randint(0, M, o.num_used_subcarriers * nsym)
+    sym = m.modulate(idx)
+    tx = o.modulate(sym)
+    jakes = rfg.JakesSampleGenerator(Fd, Ts, L)
+    tdl = rfading.TdlChannel(jakes, tap_powers_dB=np.asarray(powers_dB, dtype=float),
+                             tap_delays=np.asarray(delays, dtype=float) * Ts)
+    faded = tdl.corrupt_data(tx)
+    ir = tdl.get_last_impulse_response()
+    noise = rmisc.randn_c(faded.size)
+    rx = faded + noise * math.sqrt(noise_var)
+    demod = o.demodulate(rx[:tx.size].copy())
+    eq = eqz.equalize_data(demod, ir)
+    dec = m.demodulate(eq)
+    return dict(table=m.symbols, idx=idx, sym=sym, tx=tx, phi=jakes._phi_l, psi=jakes._psi_l,
+                taps=ir.tap_values_sparse, delay_indexes=ir.tap_indexes_sparse,
+                tap_powers_linear=tdl.channel_profile.tap_powers_linear, faded=faded, noise=noise,
+                rx=rx, demod=demod, eq=eq, decisions=dec, noise_var=noise_var,
+                **ref_counts(idx, dec, M))
+
+
+def ref_chain_mimo_ofdm(seed, mod, M, nt, nr, fft, cp, used, nsym, snr_db, mmse):
+    np.random.seed(seed)
+    m = ref_modulator(mod, M)
+    o = rofdm.OFDM(fft, cp, used)
+    noise_var = 1.0 / dB2Linear(snr_db)
+    H = rmisc.randn_c(nr, nt)
+    blast = rmimo.Blast(H)
+    if mmse:
+        blast.set_noise_var(noise_var)
+    idx = np.random.randint(0, M, nt * o.num_used_subcarriers * nsym)
+    sym = m.modulate(idx)
+    X = blast.encode(sym)
+    T = np.stack([o.modulate(X[a]) for a in range(nt)])
+    noise = rmisc.randn_c(nr, T.shape[1])
+    R = np.dot(H, T) + noise * math.sqrt(noise_var)
+    Y = np.stack([o.demodulate(R[a].copy()) for a in range(nr)])
+    est = blast.decode(Y)
+    dec = m.demodulate(est)
+    G = blast._calc_receive_filter(H, noise_var if mmse else 0.0)
+    return dict(table=m.symbols, H=H, idx=idx, sym=sym, X=X, T=T, noise=noise, R=R, Y=Y, G=G, est=est,
+                decisions=dec, noise_var=noise_var, **ref_counts(idx, dec, M))
+
+
+CHAINS = {
+    # name: (reference runner, oracle chain, [(kwargs for oracle, args for ref)], n realizations)
+    "c1_awgn": [dict(mod="qam", M=16, N=10000, snr_db=10.0)]
+    + [dict(mod="qam", M=16, N=2048, snr_db=s) for s in (0.0, 20.0)]
+    + [dict(mod="psk", M=8, N=2048, snr_db=8.0), dict(mod="bpsk", M=2, N=2048, snr_db=3.0),
+       dict(mod="qam", M=256, N=2048, snr_db=24.0)],
+    "c2_flat_jakes": [dict(mod="qam", M=64, N=4096, snr_db=20.0, Fd=100.0, Ts=1e-3, L=8),
+                      dict(mod="qam", M=16, N=1024, snr_db=12.0, Fd=30.0, Ts=5e-4, L=16)],
+    "c3_ofdm_tdl": [dict(mod="qpsk", M=4, fft_size=1024, cp_size=16, num_used=None, n_ofdm_sym=1,
+                         snr_db=20.0, Fd=10.0, Ts=1.0 / (15e3 * 1024), L=8,
+                         tap_powers_dB=(0.0, -3.0, -6.0, -9.0, -12.0), tap_delays_samples=(0, 1, 2, 3, 4)),
+                    dict(mod="qam", M=16, fft_size=64, cp_size=16, num_used=52, n_ofdm_sym=3,
+                         snr_db=25.0, Fd=50.0, Ts=1e-6, L=8,
+                         tap_powers_dB=(0.0, -5.0, -10.0), tap_delays_samples=(0, 3, 7))],
+    "c4_mimo_ofdm": [dict(mod="qam", M=64, nt=4, nr=4, fft_size=1024, cp_size=16, num_used=None,
+                          n_ofdm_sym=1, snr_db=25.0, mmse=True),
+                     dict(mod="qam", M=16, nt=2, nr=2, fft_size=64, cp_size=8, num_used=48,
+                          n_ofdm_sym=2, snr_db=15.0, mmse=False)],
+}
+
+
+def run_ref(name, kw, seed):
+    if name == "c1_awgn":
+        return ref_chain_awgn(seed, kw["mod"], kw["M"], kw["N"], kw["snr_db"])
+    if name == "c2_flat_jakes":
+        return ref_chain_flat_jakes(seed, kw["mod"], kw["M"], kw["N"], kw["snr_db"], kw["Fd"], kw["Ts"], kw["L"])
+    if name == "c3_ofdm_tdl":
+        return ref_chain_ofdm_tdl(seed, kw["mod"], kw["M"], kw["fft_size"], kw["cp_size"], kw["num_used"],
+                                  kw["n_ofdm_sym"], kw["snr_db"], kw["Fd"], kw["Ts"], kw["L"],
+                                  kw["tap_powers_dB"], kw["tap_delays_samples"])
+    if name == "c4_mimo_ofdm":
+        return ref_chain_mimo_ofdm(seed, kw["mod"], kw["M"], kw["nt"], kw["nr"], kw["fft_size"], kw["cp_size"],
+                                   kw["num_used"], kw["n_ofdm_sym"], kw["snr_db"], kw["mmse"])
+    raise KeyError(name)
+
+
+ORACLE = {"c1_awgn": chains.chain_awgn, "c2_flat_jakes": chains.chain_flat_jakes,
+          "c3_ofdm_tdl": chains.chain_ofdm_tdl, "c4_mimo_ofdm": chains.chain_mimo_ofdm}
+INT_KEYS = ("idx", "decisions", "symbol_errors", "bit_errors", "num_symbols", "num_bits", "delay_indexes")
+# realizations stored per case (kept small: fixtures are KBs)
+N_REAL = {"c1_awgn": 2, "c2_flat_jakes": 2, "c3_ofdm_tdl": 2, "c4_mimo_ofdm": 2}
+# derivable float arrays that are checked against the reference above but not stored
+SKIP_STORE = {"c1_awgn": ("tx",), "c2_flat_jakes": ("tx", "faded"), "c3_ofdm_tdl": ("sym", "faded"),
+              "c4_mimo_ofdm": ("sym", "X", "R")}
+
+
+def golden_chains():
+    import json
+    for name, cases in CHAINS.items():
+        store = {}
+        worst = 0.0
+        for ci, kw in enumerate(cases):
+            for r in range(N_REAL[name]):
+                seed = BASE_SEED + 1000 * ci + r
+                ref = run_ref(name, kw, seed)
+                mine = ORACLE[name](chains.LegacyRng(seed), **kw)
+                for k, v in ref.items():
+                    tol = 0 if k in INT_KEYS else 1e-12
+                    worst = max(worst, close(mine[k], v, tol, "%s[%d] r%d %s" % (name, ci, r, k)))
+                    arr = np.asarray(v)
+                    if k in SKIP_STORE[name] or (r > 0 and arr.size > 4096 and ci == 0):
+                        continue                       # keep fixtures small; re-derivable
+                    if arr.dtype.kind == "i" and arr.size > 1:
+                        arr = arr.astype(np.int32)
+                    store["case%d_r%d_%s" % (ci, r, k)] = arr
+                store["case%d_r%d_seed" % (ci, r)] = np.int64(seed)
+            store["case%d_kwargs" % ci] = np.array(json.dumps(kw))
+        store["n_cases"] = np.int64(len(cases))
+        store["n_real"] = np.int64(N_REAL[name])
+        np.savez_compressed(os.path.join(GOLD, name + ".npz"), **store)
+        print("%s: oracle == reference on %d cases x %d realizations (worst float err %.2e)"
+              % (name, len(cases), N_REAL[name], worst))
+
+
+if __name__ == "__main__":
+    os.makedirs(GOLD, exist_ok=True)
+    golden_operators()
+    golden_chains()
+    for f in sorted(os.listdir(GOLD)):
+        print("%8.1f KB  %s" % (os.path.getsize(os.path.join(GOLD, f)) / 1024.0, f))
