@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""bench.py -- Monte Carlo realizations/s of the fused HIP link pipeline on MI355X.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched by
+torch.distributed.run with one rank per GPU (RCCL).  Prints ONE JSON line on rank 0.
+
+Workload (BASELINE.json north_star target, configs[3] geometry on ONE GPU per rank):
+  4x4 MIMO (Blast, MMSE) + 64-QAM + OFDM-1024 (cp 16, all bins used), flat H ~ randn_c(4,4) per
+  realization, SNR 25 dB; a "step" = one batch of --batch realizations per GPU through
+  mcle_run_mimo_ofdm (data, channel and noise drawn on-chip from (seed, realization index)).
+  Realization index ranges are disjoint across ranks and steps ("weak" scaling); the only
+  exchange is one all-reduce (RCCL) of the 8-word integer counter block at the end.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+# algorithmic bytes per realization in the staged (operator-granular)
+# model, complex64 samples / uint8 indices.
+B_ALG = {"c2": 7_600_000, "c3": 211_360, "c4": 412_160}
+HBM_PEAK_GBPS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
+SEED = 20260927
+SNR_DB = {"c1": 10.0, "c2": 20.0, "c3": 20.0, "c4": 25.0}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="c4", choices=["c2", "c3", "c4"])
+    ap.add_argument("--batch", type=int, default=0, help="realizations per GPU per step")
+    ap.add_argument("--demod", default="slicer", choices=["slicer", "mindist"])
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg")
+    ap.add_argument("--no-cpu", action="store_true")
+    return ap.parse_args()
+
+
+def make_runner(eng, cfg, demod, dtype):
+    """-> (run(first, count, counters), units per realization, description)"""
+    from pyphysim_amd.modulators import constellation  # product-side tables (no oracle import here)
+    from pyphysim_amd import _lib
+    method = _lib.DEMOD_QAM_SLICER if demod == "slicer" else _lib.DEMOD_MINDIST
+    nv = 1.0 / (10.0 ** (SNR_DB[cfg] / 10.0))
+    if cfg == "c4":
+        eng.set_constellation(constellation("qam", 64), _lib.CONST_QAM)
+
+        def run(first, count, counters):
+            eng.run_mimo_ofdm(4, 4, 1024, 16, 1024, 1, nv, SEED, first, count, mmse=True, method=method,
+                              dtype=dtype, counters=counters)
+        return run, 4096, "4x4 Blast-MMSE + 64-QAM + OFDM(1024, cp 16), flat randn_c H, SNR 25 dB (config 4)"
+    if cfg == "c2":
+        eng.set_constellation(constellation("qam", 64), _lib.CONST_QAM)
+
+        def run(first, count, counters):
+            eng.run_flat_fading(100000, nv, SEED, first, count, Fd=100.0, Ts=1e-3, L=8, method=method, dtype=dtype,
+                                counters=counters)
+        return run, 100000, "64-QAM over flat Jakes fading (Fd 100 Hz, Ts 1 ms, L 8), 1e5 symbols, SNR 20 dB (config 2)"
+    eng.set_constellation(constellation("qpsk", 4), _lib.CONST_GENERIC)
+    from pyphysim_amd.channels import discretize_profile
+    Ts = 1.0 / (15e3 * 1024)
+    p_lin, d_idx = discretize_profile(np.array([0.0, -3.0, -6.0, -9.0, -12.0]), np.arange(5) * Ts, Ts)
+
+    def run(first, count, counters):
+        eng.run_ofdm_tdl(1024, 16, 1024, 1, nv, p_lin, d_idx, SEED, first, count, Fd=10.0, Ts=Ts, L=8,
+                         method=_lib.DEMOD_MINDIST, dtype=dtype, counters=counters)
+    return run, 1024, "QPSK + OFDM(1024, cp 16) over 5-tap Jakes TDL (Fd 10 Hz), one-tap EQ, SNR 20 dB (config 3)"
+
+
+def cpu_baseline(cfg, budget_s, gpu_first_counts):
+    """Time the NumPy oracle (a port of the reference's chain, oracle/chains.py) on ONE host core
+    for about `budget_s` seconds on the same workload and the same (seed, realization) keying;
+    also returns |SER_gpu - SER_oracle| on the realizations both sides computed."""
+    from oracle import chains
+    fn, kw = {
+        "c4": (chains.chain_mimo_ofdm, dict(mod="qam", M=64, nt=4, nr=4, fft_size=1024, cp_size=16, num_used=None,
+                                           n_ofdm_sym=1, snr_db=25.0, mmse=True)),
+        "c2": (chains.chain_flat_jakes, dict(mod="qam", M=64, N=100000, snr_db=20.0, Fd=100.0, Ts=1e-3, L=8)),
+        "c3": (chains.chain_ofdm_tdl, dict(mod="qpsk", M=4, fft_size=1024, cp_size=16, num_used=None, n_ofdm_sym=1,
+                                           snr_db=20.0, Fd=10.0, Ts=1.0 / (15e3 * 1024), L=8)),
+    }[cfg]
+    se = []
+    t0 = time.perf_counter()
+    r = 0
+    while True:
+        out = fn(chains.PhiloxRng(SEED, r), **kw)
+        se.append(out["symbol_errors"])
+        r += 1
+        if time.perf_counter() - t0 >= budget_s or r >= len(gpu_first_counts):
+            break
+    dt = time.perf_counter() - t0
+    n = len(se)
+    ser_cpu = float(np.sum(se)) / (n * out["num_symbols"])
+    ser_gpu = float(np.sum(gpu_first_counts[:n])) / (n * out["num_symbols"])
+    return {"value": n / dt, "unit": "realizations/s", "cores": 1, "kind": "port",
+            "sample": "%d realizations of the same workload, NumPy oracle (oracle/chains.py), 1 thread, %.1f s"
+                      % (n, dt)}, abs(ser_gpu - ser_cpu), n
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    for v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+        os.environ.setdefault(v, "1")
+    from pyphysim_amd.engine import Engine   # loads libmcle (shares torch's HIP runtime)
+    import torch
+    import torch.distributed as dist
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    eng = Engine(local_rank, args.dtype)
+    run, units, workload = make_runner(eng, args.config, args.demod, args.dtype)
+    batch = args.batch or {"c4": 65536, "c3": 131072, "c2": 512}[args.config]
+
+    def barrier():
+        eng.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    counters = eng.new_counters()
+    # realization index space: warmup uses a disjoint range far away from the timed one
+    for w in range(args.warmup):
+        run((1 << 40) + (w * world + rank) * batch, batch, counters)
+    barrier()
+    counters.zero()
+    barrier()
+    t0 = time.perf_counter()
+    eng.timer_start()
+    for s in range(args.steps):
+        run((s * world + rank) * batch, batch, counters)
+    kernel_ms = eng.timer_stop_ms()            # HIP events on the stream the kernels ran on
+    local = eng.read_counters(counters)
+    vec = torch.tensor([local[k] for k in ("n_realizations", "n_skipped", "sym_errors", "sym_errors_sq",
+                                           "bit_errors", "bit_errors_sq")], dtype=torch.int64, device="cuda")
+    if world > 1:
+        dist.all_reduce(vec, op=dist.ReduceOp.SUM)     # RCCL over xGMI: the path's only exchange step
+    barrier()
+    elapsed = time.perf_counter() - t0
+    tmax = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed, kernel_ms = float(tmax[0]), float(tmax[1])
+    tot = [int(v) for v in vec.tolist()]
+    n_real = tot[0] + tot[1]
+    assert n_real == args.steps * batch * world, (n_real, args.steps, batch, world)
+
+    if rank == 0:
+        value = n_real / elapsed
+        per_launch_s = kernel_ms * 1e-3 / args.steps
+        balg = B_ALG[args.config]
+        achieved = balg * batch / per_launch_s / 1e9
+        traffic = None
+        tpath = os.path.join(REPO, "profiles", "traffic_%s.json" % args.config)
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Monte Carlo realizations/sec (whole node) + SER abs-error vs ref",
+            "value": value, "unit": "realizations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": workload, "realizations_per_step_per_gpu": batch, "demod": args.demod,
+                       "symbols_per_realization": units, "parallelism": "realization-sharded x%d" % world,
+                       "rng": "Philox4x32-10 keyed by (seed, realization)"},
+            "ser": tot[2] / float(max(1, tot[0]) * units), "ber": tot[4] / float(max(1, tot[0]) * units * 6)
+            if args.config != "c3" else tot[4] / float(max(1, tot[0]) * units * 2),
+            "n_skipped": tot[1],
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "kernel": "k_run_mimo_ofdm" if args.config == "c4" else
+                         ("k_run_flat" if args.config == "c2" else "k_run_ofdm_tdl"),
+                         "kernel_ms_per_launch": per_launch_s * 1e3,
+                         "algorithmic_bytes_per_realization": balg,
+                         "note": "fused kernel: achieved = staged-model algorithmic bytes / measured launch time; "
+                                 "measured HBM traffic is far below it (data never leaves LDS), see DESIGN.md"},
+        }
+        if world == 1 and not args.no_cpu:
+            # per-realization counts of the first realizations for the SER cross-check
+            res, se, be = eng_first_counts(eng, args, 4096 if args.config != "c2" else 64)
+            cb, ser_err, n_chk = cpu_baseline(args.config, args.cpu_seconds, se)
+            cb["host_cpu_count"] = os.cpu_count()
+            out["cpu_baseline"] = cb
+            out["ser_abs_err_vs_oracle"] = ser_err
+            out["ser_check_realizations"] = n_chk
+            out["speedup_vs_cpu_core"] = value / cb["value"]
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    eng.close()
+
+
+def eng_first_counts(eng, args, n):
+    from pyphysim_amd import _lib
+    method = _lib.DEMOD_QAM_SLICER if args.demod == "slicer" else _lib.DEMOD_MINDIST
+    nv = 1.0 / (10.0 ** (SNR_DB[args.config] / 10.0))
+    if args.config == "c4":
+        return eng.run_mimo_ofdm(4, 4, 1024, 16, 1024, 1, nv, SEED, 0, n, method=method, dtype=args.dtype,
+                                 per_realization=True)
+    if args.config == "c2":
+        return eng.run_flat_fading(100000, nv, SEED, 0, n, method=method, dtype=args.dtype, per_realization=True)
+    from pyphysim_amd.channels import discretize_profile
+    Ts = 1.0 / (15e3 * 1024)
+    p_lin, d_idx = discretize_profile(np.array([0.0, -3.0, -6.0, -9.0, -12.0]), np.arange(5) * Ts, Ts)
+    return eng.run_ofdm_tdl(1024, 16, 1024, 1, nv, p_lin, d_idx, SEED, 0, n, Fd=10.0, Ts=Ts, L=8, dtype=args.dtype,
+                            per_realization=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,206 @@
+/*
+ * mcle.h -- C ABI of libmcle: the MI355X (gfx950) Monte Carlo link-level engine.
+ *
+ * The reference (darcamo/pyphysim v0.7.2) is pure Python/NumPy and has no FFI; its
+ * "operator interface" for the hot path is a set of Python method signatures.  Each entry
+ * point below names the reference method it stands in for (paths relative to the reference).
+ * A maintainer-side ctypes binding is sketched in INTEGRATION.md.
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 on error (MCLE_E_*); mcle_last_error() gives the
+ *     message for the calling thread.  No exception crosses the ABI.
+ *   - `d_` arguments are DEVICE pointers (hipMalloc'ed by anyone: mcle_malloc, PyTorch, ...);
+ *     everything else is host memory or passed by value.
+ *   - complex arrays are interleaved (re, im) of the context dtype: MCLE_F32 -> float,
+ *     MCLE_F64 -> double (the parity instantiation; reference arithmetic is complex128).
+ *   - symbol indices are int32 on the device (the reference uses int64 on the host).
+ *   - all work is enqueued on the context's stream; only mcle_ctx_sync / mcle_memcpy_d2h and
+ *     the *_host helpers block.  A context is not thread-safe; distinct contexts are.
+ */
+#ifndef MCLE_H
+#define MCLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MCLE_VERSION 1
+
+enum { MCLE_OK = 0, MCLE_E_INVAL = -1, MCLE_E_HIP = -2, MCLE_E_NOMEM = -3, MCLE_E_STATE = -4 };
+enum { MCLE_F32 = 0, MCLE_F64 = 1 };
+/* demodulation method: exhaustive minimum distance over the constellation held in LDS
+ * (any constellation), or the per-axis slicer (square Gray QAM only; same decisions). */
+enum { MCLE_DEMOD_MINDIST = 0, MCLE_DEMOD_QAM_SLICER = 1 };
+/* constellation kinds (tell the library what structure it may exploit) */
+enum { MCLE_CONST_GENERIC = 0, MCLE_CONST_QAM = 1, MCLE_CONST_BPSK = 2 };
+
+typedef struct mcle_ctx mcle_ctx;
+
+/* Integer result block of one parameter variation.  Every field is an exact integer sum over
+ * realizations, so reductions are order-independent and identical for any GPU count.  It carries
+ * what Result.update()/merge() accumulate (simulations/results.py:469-623): value = sum of
+ * errors, total = n_realizations * units per realization, sum / sum-of-squares of the
+ * per-realization ratio = {sum, sum_sq} / units^k. */
+typedef struct mcle_counters {
+    uint64_t n_realizations;
+    uint64_t n_skipped;        /* SkipThisOne analogue (runner.py:151-185): singular filter etc. */
+    uint64_t sym_errors;       /* sum_r e_r          */
+    uint64_t sym_errors_sq;    /* sum_r e_r^2        */
+    uint64_t bit_errors;
+    uint64_t bit_errors_sq;
+    uint64_t n_symbols;        /* symbols per realization (constant)  */
+    uint64_t n_bits;           /* bits per realization (constant)     */
+} mcle_counters;
+
+/* ---- context, stream, memory -------------------------------------------------------- */
+const char* mcle_last_error(void);
+int mcle_version(void);
+int mcle_device_count(int* count);
+int mcle_ctx_create(int device_id, mcle_ctx** out);
+int mcle_ctx_destroy(mcle_ctx* ctx);
+/* adopt an external hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = own */
+int mcle_ctx_set_stream(mcle_ctx* ctx, void* hip_stream);
+int mcle_ctx_get_stream(mcle_ctx* ctx, void** hip_stream);
+int mcle_ctx_sync(mcle_ctx* ctx);
+int mcle_ctx_device_info(mcle_ctx* ctx, int* n_cu, int* lds_bytes, char* name, int name_len);
+int mcle_malloc(mcle_ctx* ctx, size_t bytes, void** d_ptr);
+int mcle_free(mcle_ctx* ctx, void* d_ptr);
+int mcle_memset(mcle_ctx* ctx, void* d_ptr, int value, size_t bytes);
+int mcle_memcpy_h2d(mcle_ctx* ctx, void* d_dst, const void* src, size_t bytes);
+int mcle_memcpy_d2h(mcle_ctx* ctx, void* dst, const void* d_src, size_t bytes); /* blocks */
+/* kernel timing on the context stream with HIP events (used by bench.py's roofline leg) */
+int mcle_timer_start(mcle_ctx* ctx);
+int mcle_timer_stop_ms(mcle_ctx* ctx, float* ms);                               /* blocks */
+
+/* ---- constellation (a1: modulators/fundamental.py:131-146 setConstellation, :396-448 PSK,
+ *      :659-777 QAM; the table itself is built by the host mirror) ----------------------- */
+int mcle_set_constellation(mcle_ctx* ctx, const double* re_im, int M, int kind);
+
+/* ---- a2/a3/a4: Modulator.modulate / demodulate (fundamental.py:175-248), count_bit_errors
+ *      (util/misc.py:519-566) and the symbol-error count of user code --------------------- */
+int mcle_modulate(mcle_ctx* ctx, int dtype, const int32_t* d_idx, void* d_out, size_t n);
+int mcle_demodulate(mcle_ctx* ctx, int dtype, int method, const void* d_rx, int32_t* d_idx,
+                    size_t n);
+/* n_real blocks of n_per_real indices each; adds into d_counters[0] (may be NULL) and, when
+ * non-NULL, writes per-realization counts d_sym_err[n_real] / d_bit_err[n_real]. */
+int mcle_count_errors(mcle_ctx* ctx, const int32_t* d_tx_idx, const int32_t* d_rx_idx,
+                      size_t n_per_real, size_t n_real, int bits_per_symbol,
+                      mcle_counters* d_counters, uint32_t* d_sym_err, uint32_t* d_bit_err);
+/* fused demodulate + count (no index array written) */
+int mcle_demod_count(mcle_ctx* ctx, int dtype, int method, const void* d_rx,
+                     const int32_t* d_tx_idx, size_t n_per_real, size_t n_real,
+                     mcle_counters* d_counters, uint32_t* d_sym_err, uint32_t* d_bit_err);
+
+/* ---- a5: randn_c (util/misc.py:327-355) under the mcle-philox-v1 contract, and AWGN ----- */
+/* out[i] = sqrt(variance) * CN(0,1) sample (first_sample + i) of (seed, realization, stream) */
+int mcle_randn_c(mcle_ctx* ctx, int dtype, uint64_t seed, uint64_t realization, uint32_t stream,
+                 uint64_t first_sample, double variance, void* d_out, size_t n);
+int mcle_rand_symbols(mcle_ctx* ctx, uint64_t seed, uint64_t realization, uint64_t first_symbol,
+                      int M, int32_t* d_idx, size_t n);
+/* y = x + sqrt(noise_var) * noise (injected noise array: parity against golden vectors) */
+int mcle_awgn_add(mcle_ctx* ctx, int dtype, const void* d_x, const void* d_noise,
+                  double noise_var, void* d_y, size_t n);
+
+/* ---- a6/a9: JakesSampleGenerator (channels/fading_generators.py:289-553) and
+ *      TdlChannel.corrupt_data (channels/fading.py:1046-1124) --------------------------- */
+/* h[s, n] = L^-1/2 sum_l exp(j(2 pi Fd cos(phi[l,s]) t_n + psi[l,s])) * sqrt(tap_power[s]),
+ * t_n = t0 + n*dt.  phi/psi: host doubles [L, n_streams]; tap_power: host [n_streams] or NULL. */
+int mcle_jakes_generate(mcle_ctx* ctx, int dtype, const double* phi, const double* psi, int L,
+                        int n_streams, double Fd, double t0, double dt, const double* tap_power,
+                        void* d_h, size_t n_samples);
+/* SISO time-varying sparse convolution: y[d_i + n] += g[i, n] x[n]; y has n + max_delay */
+int mcle_tdl_apply(mcle_ctx* ctx, int dtype, const void* d_x, const void* d_taps,
+                   const int32_t* delays, int n_taps, void* d_y, size_t n);
+/* element-wise complex divide (flat-fading equalisation y / h of the C2 template) */
+int mcle_cdiv(mcle_ctx* ctx, int dtype, const void* d_num, const void* d_den, void* d_out,
+              size_t n);
+
+/* ---- a11/a10: OFDM.modulate / demodulate (modulators/ofdm.py:394-466) and
+ *      OfdmOneTapEqualizer.equalize_data (ofdm.py:515-552) ------------------------------- */
+/* n_in data symbols (zero padded to n_sym*num_used) -> n_sym*(fft+cp) samples; batch rows */
+int mcle_ofdm_modulate(mcle_ctx* ctx, int dtype, const void* d_in, size_t n_in, int fft_size,
+                       int cp_size, int num_used, void* d_out, size_t batch);
+/* n_sym*(fft+cp) samples -> n_sym*num_used symbols; batch rows */
+int mcle_ofdm_demodulate(mcle_ctx* ctx, int dtype, const void* d_in, size_t n_sym, int fft_size,
+                         int cp_size, int num_used, void* d_out, size_t batch);
+/* d_taps [n_taps, n_sym*(fft+cp)] sparse taps of the samples the OFDM symbols rode on */
+int mcle_onetap_equalize(mcle_ctx* ctx, int dtype, const void* d_data, const void* d_taps,
+                         const int32_t* delays, int n_taps, size_t n_sym, int fft_size,
+                         int cp_size, int num_used, void* d_out);
+
+/* ---- a12: Blast (mimo/mimo.py:465-660) --------------------------------------------------- */
+/* x[n] -> X[a, c] = x[c*nt + a] / sqrt(nt)   (encode, :639-641); batch rows of n */
+int mcle_blast_encode(mcle_ctx* ctx, int dtype, const void* d_x, int nt, size_t n, void* d_X,
+                      size_t batch);
+/* G = sqrt(nt) * solve(H^H H + noise_var I, H^H) per batch item (noise_var = 0: ZF / pinv for
+ * full column rank); d_H [batch, nr, nt] row-major, d_G [batch, nt, nr]; d_skipped[batch]
+ * flags singular systems (may be NULL). */
+int mcle_blast_filter(mcle_ctx* ctx, int dtype, const void* d_H, int nr, int nt,
+                      double noise_var, void* d_G, uint32_t* d_skipped, size_t batch);
+/* est[c*nt + a] = sum_r G[a, r] Y[r, c]      (decode, :658-660) */
+int mcle_blast_decode(mcle_ctx* ctx, int dtype, const void* d_G, const void* d_Y, int nr, int nt,
+                      size_t ns, void* d_est, size_t batch);
+/* Y = H X  (+ sqrt(noise_var) * noise when d_noise != NULL): apps/mimo/simulate_mimo.py:96-98 */
+int mcle_mimo_channel(mcle_ctx* ctx, int dtype, const void* d_H, const void* d_X,
+                      const void* d_noise, double noise_var, int nr, int nt, size_t ns, void* d_Y,
+                      size_t batch);
+
+/* ---- fused pipelines: whole realizations on-chip (randomness: mcle-philox-v1) ----------- */
+typedef struct mcle_awgn_cfg {          /* C1: apps/awgn_modulators/simulate_psk.py:51-115 */
+    int32_t n_symbols;
+    int32_t demod_method;
+    double noise_var;
+} mcle_awgn_cfg;
+
+typedef struct mcle_flat_cfg {          /* C2: flat Jakes fading, y = h s + n, equalise y/h */
+    int32_t n_symbols;
+    int32_t demod_method;
+    double noise_var;
+    double Fd, Ts;
+    int32_t L;
+    int32_t rayleigh_iid;               /* 1: h ~ randn_c per sample (RayleighSampleGenerator) */
+} mcle_flat_cfg;
+
+#define MCLE_MAX_TAPS 24
+typedef struct mcle_ofdm_tdl_cfg {      /* C3: notebooks/TDL_and_OFDM.ipynb OfdmTdlSimulator */
+    int32_t fft_size, cp_size, num_used, n_ofdm_sym;
+    int32_t demod_method;
+    int32_t n_taps;
+    int32_t L;
+    int32_t reserved;
+    double noise_var;
+    double Fd, Ts;
+    double tap_power[MCLE_MAX_TAPS];    /* linear, discretised profile (sum 1) */
+    int32_t tap_delay[MCLE_MAX_TAPS];   /* sample indexes, increasing */
+} mcle_ofdm_tdl_cfg;
+
+typedef struct mcle_mimo_ofdm_cfg {     /* C4: apps/mimo/simulate_mimo.py:68-142 + OFDM */
+    int32_t nt, nr;
+    int32_t fft_size, cp_size, num_used, n_ofdm_sym;
+    int32_t demod_method;
+    int32_t mmse;                       /* 1: Blast.set_noise_var(noise_var); 0: zero forcing */
+    double noise_var;
+} mcle_mimo_ofdm_cfg;
+
+/* Each run_* processes realizations [first, first+count) of `seed`, ADDS into d_counters[0]
+ * and, when non-NULL, writes per-realization d_sym_err / d_bit_err [count]. */
+int mcle_run_awgn(mcle_ctx* ctx, int dtype, const mcle_awgn_cfg* cfg, uint64_t seed,
+                  uint64_t first, uint64_t count, mcle_counters* d_counters,
+                  uint32_t* d_sym_err, uint32_t* d_bit_err);
+int mcle_run_flat_fading(mcle_ctx* ctx, int dtype, const mcle_flat_cfg* cfg, uint64_t seed,
+                         uint64_t first, uint64_t count, mcle_counters* d_counters,
+                         uint32_t* d_sym_err, uint32_t* d_bit_err);
+int mcle_run_ofdm_tdl(mcle_ctx* ctx, int dtype, const mcle_ofdm_tdl_cfg* cfg, uint64_t seed,
+                      uint64_t first, uint64_t count, mcle_counters* d_counters,
+                      uint32_t* d_sym_err, uint32_t* d_bit_err);
+int mcle_run_mimo_ofdm(mcle_ctx* ctx, int dtype, const mcle_mimo_ofdm_cfg* cfg, uint64_t seed,
+                       uint64_t first, uint64_t count, mcle_counters* d_counters,
+                       uint32_t* d_sym_err, uint32_t* d_bit_err);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MCLE_H */

@@ -1,0 +1,179 @@
+"""ctypes binding of libmcle.so (the C ABI declared in include/mcle.h).
+
+There is no CPU fallback: every compute entry point needs the HIP library and a gfx950
+device, and raises :class:`McleError` otherwise.
+"""
+import ctypes
+import importlib.util
+import os
+from ctypes import (POINTER, Structure, byref, c_char_p, c_double, c_float, c_int, c_int32, c_size_t,
+                    c_uint32, c_uint64, c_void_p)
+
+import numpy as np
+
+MCLE_F32, MCLE_F64 = 0, 1
+DEMOD_MINDIST, DEMOD_QAM_SLICER = 0, 1
+CONST_GENERIC, CONST_QAM, CONST_BPSK = 0, 1, 2
+MAX_TAPS = 24
+STREAM_DATA, STREAM_NOISE, STREAM_CHAN, STREAM_PHASE = 0, 1, 2, 3
+
+LIB_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+LIB_PATH = os.path.join(LIB_DIR, "libmcle.so")
+
+
+class McleError(RuntimeError):
+    """Any failure reported by libmcle (message from mcle_last_error)."""
+
+
+class Counters(Structure):
+    _fields_ = [(n, c_uint64) for n in ("n_realizations", "n_skipped", "sym_errors", "sym_errors_sq",
+                                        "bit_errors", "bit_errors_sq", "n_symbols", "n_bits")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+COUNTER_FIELDS = [n for n, _ in Counters._fields_]
+
+
+class AwgnCfg(Structure):
+    _fields_ = [("n_symbols", c_int32), ("demod_method", c_int32), ("noise_var", c_double)]
+
+
+class FlatCfg(Structure):
+    _fields_ = [("n_symbols", c_int32), ("demod_method", c_int32), ("noise_var", c_double),
+                ("Fd", c_double), ("Ts", c_double), ("L", c_int32), ("rayleigh_iid", c_int32)]
+
+
+class OfdmTdlCfg(Structure):
+    _fields_ = [("fft_size", c_int32), ("cp_size", c_int32), ("num_used", c_int32), ("n_ofdm_sym", c_int32),
+                ("demod_method", c_int32), ("n_taps", c_int32), ("L", c_int32), ("reserved", c_int32),
+                ("noise_var", c_double), ("Fd", c_double), ("Ts", c_double),
+                ("tap_power", c_double * MAX_TAPS), ("tap_delay", c_int32 * MAX_TAPS)]
+
+
+class MimoOfdmCfg(Structure):
+    _fields_ = [("nt", c_int32), ("nr", c_int32), ("fft_size", c_int32), ("cp_size", c_int32),
+                ("num_used", c_int32), ("n_ofdm_sym", c_int32), ("demod_method", c_int32), ("mmse", c_int32),
+                ("noise_var", c_double)]
+
+
+_P = c_void_p
+_PROTOS = {
+    "mcle_last_error": (c_char_p, []),
+    "mcle_version": (c_int, []),
+    "mcle_device_count": (c_int, [POINTER(c_int)]),
+    "mcle_ctx_create": (c_int, [c_int, POINTER(_P)]),
+    "mcle_ctx_destroy": (c_int, [_P]),
+    "mcle_ctx_set_stream": (c_int, [_P, _P]),
+    "mcle_ctx_get_stream": (c_int, [_P, POINTER(_P)]),
+    "mcle_ctx_sync": (c_int, [_P]),
+    "mcle_ctx_device_info": (c_int, [_P, POINTER(c_int), POINTER(c_int), c_char_p, c_int]),
+    "mcle_malloc": (c_int, [_P, c_size_t, POINTER(_P)]),
+    "mcle_free": (c_int, [_P, _P]),
+    "mcle_memset": (c_int, [_P, _P, c_int, c_size_t]),
+    "mcle_memcpy_h2d": (c_int, [_P, _P, _P, c_size_t]),
+    "mcle_memcpy_d2h": (c_int, [_P, _P, _P, c_size_t]),
+    "mcle_timer_start": (c_int, [_P]),
+    "mcle_timer_stop_ms": (c_int, [_P, POINTER(c_float)]),
+    "mcle_set_constellation": (c_int, [_P, POINTER(c_double), c_int, c_int]),
+    "mcle_modulate": (c_int, [_P, c_int, _P, _P, c_size_t]),
+    "mcle_demodulate": (c_int, [_P, c_int, c_int, _P, _P, c_size_t]),
+    "mcle_count_errors": (c_int, [_P, _P, _P, c_size_t, c_size_t, c_int, _P, _P, _P]),
+    "mcle_demod_count": (c_int, [_P, c_int, c_int, _P, _P, c_size_t, c_size_t, _P, _P, _P]),
+    "mcle_randn_c": (c_int, [_P, c_int, c_uint64, c_uint64, c_uint32, c_uint64, c_double, _P, c_size_t]),
+    "mcle_rand_symbols": (c_int, [_P, c_uint64, c_uint64, c_uint64, c_int, _P, c_size_t]),
+    "mcle_awgn_add": (c_int, [_P, c_int, _P, _P, c_double, _P, c_size_t]),
+    "mcle_jakes_generate": (c_int, [_P, c_int, POINTER(c_double), POINTER(c_double), c_int, c_int, c_double,
+                                    c_double, c_double, POINTER(c_double), _P, c_size_t]),
+    "mcle_tdl_apply": (c_int, [_P, c_int, _P, _P, POINTER(c_int32), c_int, _P, c_size_t]),
+    "mcle_cdiv": (c_int, [_P, c_int, _P, _P, _P, c_size_t]),
+    "mcle_ofdm_modulate": (c_int, [_P, c_int, _P, c_size_t, c_int, c_int, c_int, _P, c_size_t]),
+    "mcle_ofdm_demodulate": (c_int, [_P, c_int, _P, c_size_t, c_int, c_int, c_int, _P, c_size_t]),
+    "mcle_onetap_equalize": (c_int, [_P, c_int, _P, _P, POINTER(c_int32), c_int, c_size_t, c_int, c_int, c_int,
+                                     _P]),
+    "mcle_blast_encode": (c_int, [_P, c_int, _P, c_int, c_size_t, _P, c_size_t]),
+    "mcle_blast_filter": (c_int, [_P, c_int, _P, c_int, c_int, c_double, _P, _P, c_size_t]),
+    "mcle_blast_decode": (c_int, [_P, c_int, _P, _P, c_int, c_int, c_size_t, _P, c_size_t]),
+    "mcle_mimo_channel": (c_int, [_P, c_int, _P, _P, _P, c_double, c_int, c_int, c_size_t, _P, c_size_t]),
+    "mcle_run_awgn": (c_int, [_P, c_int, POINTER(AwgnCfg), c_uint64, c_uint64, c_uint64, _P, _P, _P]),
+    "mcle_run_flat_fading": (c_int, [_P, c_int, POINTER(FlatCfg), c_uint64, c_uint64, c_uint64, _P, _P, _P]),
+    "mcle_run_ofdm_tdl": (c_int, [_P, c_int, POINTER(OfdmTdlCfg), c_uint64, c_uint64, c_uint64, _P, _P, _P]),
+    "mcle_run_mimo_ofdm": (c_int, [_P, c_int, POINTER(MimoOfdmCfg), c_uint64, c_uint64, c_uint64, _P, _P, _P]),
+}
+
+_lib = None
+
+
+def _preload_hip_runtime():
+    """Make libmcle share PyTorch's HIP runtime when PyTorch is installed.
+
+    torch ships its own libamdhip64.so (soname libamdhip64.so.7, same as /opt/rocm's).  Loading
+    that copy first lets the dynamic loader satisfy libmcle's NEEDED entry by soname, so torch
+    tensors, torch streams and libmcle kernels live in ONE runtime.  MCLE_HIP_RUNTIME=system skips it.
+    """
+    if os.environ.get("MCLE_HIP_RUNTIME", "torch") != "torch":
+        return None
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return None
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if not os.path.exists(cand):
+        return None
+    try:
+        return ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+    except OSError:
+        return None
+
+
+def load():
+    """Load libmcle.so (once) and attach prototypes.  Raises McleError if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise McleError("libmcle.so is not built (%s missing): run `make -C pyphysim_amd/csrc` or "
+                        "`python -c 'import __graft_entry__ as g; g.build()'`; there is no CPU fallback"
+                        % LIB_PATH)
+    _preload_hip_runtime()
+    try:
+        lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    except OSError as exc:
+        raise McleError("cannot load %s: %s" % (LIB_PATH, exc))
+    for name, (res, args) in _PROTOS.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def exported_symbols():
+    return sorted(_PROTOS)
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().mcle_last_error()
+        raise McleError((msg or b"unknown error").decode("utf-8", "replace"))
+
+
+def device_count():
+    n = c_int(0)
+    check(load().mcle_device_count(byref(n)))
+    return n.value
+
+
+def np_complex(dtype):
+    return np.complex64 if dtype == MCLE_F32 else np.complex128
+
+
+def dtype_code(dtype):
+    if dtype in (MCLE_F32, "f32", "float32", np.float32, np.complex64, "complex64"):
+        return MCLE_F32
+    if dtype in (MCLE_F64, "f64", "float64", np.float64, np.complex128, "complex128", complex, float):
+        return MCLE_F64
+    raise ValueError("dtype must be 'f32' or 'f64' (got %r)" % (dtype,))

@@ -1,0 +1,353 @@
+"""Host mirror of pyphysim.channels for the hot path: TdlChannelProfile (+ COST259 profiles),
+JakesSampleGenerator, RayleighSampleGenerator, TdlImpulseResponse, TdlChannel (SISO) and
+SuChannel, with the reference's names, arguments, state evolution and errors
+(reference channels/fading_generators.py, channels/fading.py, channels/singleuser.py).
+
+Host side = object state (phases, time bookkeeping, profile discretisation); the sample
+generation (sum of sinusoids) and the time-varying convolution run in libmcle's HIP kernels.
+"""
+import math
+
+import numpy as np
+
+from . import util
+from .engine import DeviceArray, get_engine
+
+
+def discretize_profile(tap_powers_dB, tap_delays, Ts):
+    """reference fading.py:272-304 plus the dB round trip of the discretised profile's ctor
+    (:77-78): delays -> rounded sample indexes (merged), powers summed per index and normalised
+    to sum 1.  Returns (tap_powers_linear, delay_indexes)."""
+    tap_powers_dB = np.asarray(tap_powers_dB, dtype=float)
+    tap_delays = np.asarray(tap_delays, dtype=float)
+    idx, inv = np.unique(np.round(tap_delays / Ts).astype(int).flatten(), return_inverse=True)
+    acc = np.zeros(idx.size)
+    np.add.at(acc, inv, util.dB2Linear(tap_powers_dB))
+    acc /= np.sum(acc)
+    return util.dB2Linear(util.linear2dB(acc)), idx
+
+
+class TdlChannelProfile:
+    """reference fading.py:28-315."""
+
+    def __init__(self, tap_powers_dB=None, tap_delays=None, name="custom"):
+        self._name = name
+        if tap_powers_dB is None and tap_delays is None:
+            tap_powers_dB = np.zeros(1)
+            tap_delays = np.zeros(1)
+        tap_powers_dB = np.asarray(tap_powers_dB, dtype=float)
+        self._tap_powers_dB = tap_powers_dB.copy()
+        self._tap_powers_linear = util.dB2Linear(tap_powers_dB)
+        self._tap_delays = np.asarray(tap_delays).copy()
+        self._num_taps = self._tap_delays.size
+        lin = self._tap_powers_linear
+        self._mean_excess_delay = np.sum(lin * self._tap_delays) / np.sum(lin)
+        second = np.sum(lin * self._tap_delays ** 2) / np.sum(lin)
+        self._rms_delay_spread = math.sqrt(max(second - self._mean_excess_delay ** 2, 0.0))
+        self._Ts = None
+        for a in (self._tap_powers_dB, self._tap_powers_linear, self._tap_delays):
+            a.flags["WRITEABLE"] = False
+
+    name = property(lambda self: self._name)
+    tap_powers_dB = property(lambda self: self._tap_powers_dB)
+    tap_powers_linear = property(lambda self: self._tap_powers_linear)
+    tap_delays = property(lambda self: self._tap_delays)
+    num_taps = property(lambda self: self._num_taps)
+    mean_excess_delay = property(lambda self: self._mean_excess_delay)
+    rms_delay_spread = property(lambda self: self._rms_delay_spread)
+    Ts = property(lambda self: self._Ts)
+    is_discretized = property(lambda self: self._Ts is not None)
+
+    @property
+    def num_taps_with_padding(self):
+        if not self.is_discretized:
+            raise RuntimeError("TdlChannelProfile is not discretized")
+        return int(self._tap_delays[-1]) + 1
+
+    def get_discretize_profile(self, Ts):
+        if self.is_discretized:
+            raise RuntimeError("Trying to discretize a TdlChannelProfile that is already discretized.")
+        lin, idx = discretize_profile(self._tap_powers_dB, self._tap_delays, Ts)
+        prof = TdlChannelProfile(util.linear2dB(lin), idx, self._name)
+        prof._Ts = Ts
+        return prof
+
+    def __repr__(self):
+        return "<TdlChannelProfile: {0} taps>".format(self._num_taps)
+
+
+COST259_TUx = TdlChannelProfile(
+    np.array([-5.7, -7.6, -10.1, -10.2, -10.2, -11.5, -13.4, -16.3, -16.9, -17.1, -17.4, -19, -19, -19.8, -21.5,
+              -21.6, -22.1, -22.6, -23.5, -24.3]),
+    np.array([0, 217, 512, 514, 517, 674, 882, 1230, 1287, 1311, 1349, 1533, 1535, 1622, 1818, 1836, 1884, 1943,
+              2048, 2140]) * 1e-9, "COST259_TU")
+COST259_RAx = TdlChannelProfile(
+    np.array([-5.2, -6.4, -8.4, -9.3, -10.0, -13.1, -15.3, -18.5, -20.4, -22.4]),
+    np.array([0., 42., 101., 129., 149., 245., 312., 410., 469., 528]) * 1e-9, "COST259_RA")
+COST259_HTx = TdlChannelProfile(
+    np.array([-3.6, -8.9, -10.2, -11.5, -11.8, -12.7, -13.0, -16.2, -17.3, -17.7, -17.6, -22.7, -24.1, -25.8,
+              -25.8, -26.2, -29.0, -29.9, -30.0, -30.7]),
+    np.array([0., 356., 441., 528., 546., 609., 625., 842., 916., 941., 15000., 16172., 16492., 16876., 16882.,
+              16978., 17615., 17827., 17849., 18016.]) * 1e-9, "COST259_HT")
+
+
+class FadingSampleGenerator:
+    """reference fading_generators.py:101-205."""
+
+    def __init__(self, shape=None):
+        self._shape = None
+        self._samples = None
+        if shape is not None:
+            self._shape = (shape,) if isinstance(shape, int) else tuple(shape)
+
+    @property
+    def shape(self):
+        return self._shape
+
+    @shape.setter
+    def shape(self, new_shape):
+        self._shape = None if new_shape is None else ((new_shape,) if isinstance(new_shape, int)
+                                                      else tuple(new_shape))
+
+    def get_samples(self):
+        return self._samples
+
+    def skip_samples_for_next_generation(self, num_samples):
+        raise NotImplementedError
+
+    def generate_more_samples(self, num_samples=None):
+        raise NotImplementedError
+
+
+class RayleighSampleGenerator(FadingSampleGenerator):
+    """reference fading_generators.py:208-282: i.i.d. CN(0,1) samples (drawn on the GPU)."""
+
+    def __init__(self, shape=None):
+        super().__init__(shape)
+        self.generate_more_samples()
+
+    def generate_more_samples(self, num_samples=None):
+        if self._shape is None:
+            shape = () if num_samples is None else (num_samples,)
+        else:
+            shape = tuple(self._shape) + (() if num_samples is None else (num_samples,))
+        self._samples = util.randn_c(*shape) if shape else util.randn_c(1)[0]
+
+    def skip_samples_for_next_generation(self, num_samples):
+        pass
+
+    def get_similar_fading_generator(self):
+        return RayleighSampleGenerator(self._shape)
+
+
+class JakesSampleGenerator(FadingSampleGenerator):
+    """reference fading_generators.py:289-553.  phi/psi are drawn on the host from ``RS`` exactly
+    as the reference does (2*pi*RS.rand(L, *shape, 1), phi first; re-drawn whenever ``shape`` is
+    set), time advances the same way, and the L x streams x samples sum of sinusoids runs on the
+    GPU with the phase accumulated in f64."""
+
+    def __init__(self, Fd=100, Ts=1e-3, L=8, shape=None, RS=None, engine=None, dtype=None):
+        super().__init__(shape)
+        self._Fd, self._Ts, self._L = Fd, Ts, L
+        self._phi_l = self._psi_l = None
+        self.RS = np.random if RS is None else RS
+        self._engine, self.dtype = engine, dtype
+        self._current_time = 0.0
+        self._set_phi_and_psi_according_to_shape()
+        self.generate_more_samples()
+
+    L = property(lambda self: self._L)
+    Ts = property(lambda self: self._Ts)
+    Fd = property(lambda self: self._Fd)
+
+    @property
+    def engine(self):
+        if self._engine is None:
+            self._engine = get_engine()
+        return self._engine
+
+    @property
+    def shape(self):
+        return self._shape
+
+    @shape.setter
+    def shape(self, new_shape):
+        FadingSampleGenerator.shape.fset(self, new_shape)
+        self._set_phi_and_psi_according_to_shape()
+
+    def _set_phi_and_psi_according_to_shape(self):
+        dims = [self._L] + ([] if self._shape is None else list(self._shape)) + [1]
+        self._phi_l = 2 * np.pi * self.RS.rand(*dims)
+        self._psi_l = 2 * np.pi * self.RS.rand(*dims)
+
+    def _next_time_axis(self, num_samples):
+        """(t0, delta) of np.arange(t0, n*Ts + t0, Ts*1.0000000001) and the state update of
+        fading_generators.py:459-467 (t_k = t0 + k*delta, delta = fl(fl(t0 + step) - t0))."""
+        n = 1 if num_samples is None else int(num_samples)
+        t = np.arange(self._current_time, n * self._Ts + self._current_time, self._Ts * 1.0000000001)
+        t0 = self._current_time
+        delta = float(t[1] - t[0]) if t.size > 1 else self._Ts * 1.0000000001
+        self._current_time = t[-1] + self._Ts
+        return t0, delta, t.size
+
+    def generate_more_samples(self, num_samples=None):
+        t0, delta, n = self._next_time_axis(num_samples)
+        streams = int(np.prod(self._shape)) if self._shape else 1
+        h = self.engine.jakes_generate(self._phi_l.reshape(self._L, streams), self._psi_l.reshape(self._L, streams),
+                                       self._Fd, t0, delta, n, dtype=self.dtype)
+        self._samples = h.reshape((tuple(self._shape) if self._shape else (1,)) + (n,))
+        if self._shape is None:
+            self._samples = self._samples.reshape(1, n)[0] if num_samples is None else self._samples.reshape(n)
+
+    def skip_samples_for_next_generation(self, num_samples):
+        self._current_time += num_samples * self._Ts
+
+    def get_similar_fading_generator(self):
+        return JakesSampleGenerator(self._Fd, self._Ts, self._L, self._shape, engine=self._engine, dtype=self.dtype)
+
+
+class TdlImpulseResponse:
+    """reference fading.py:356-698 (the parts the hot path touches)."""
+
+    def __init__(self, tap_values, channel_profile):
+        self._channel_profile = channel_profile
+        self._tap_values_sparse = tap_values
+        self._tap_values_dense = None
+
+    tap_values_sparse = property(lambda self: self._tap_values_sparse)
+    channel_profile = property(lambda self: self._channel_profile)
+
+    @property
+    def tap_indexes_sparse(self):
+        return self._channel_profile.tap_delays
+
+    @property
+    def tap_delays_sparse(self):
+        return self._channel_profile.tap_delays
+
+    @property
+    def Ts(self):
+        return self._channel_profile.Ts
+
+    @property
+    def num_samples(self):
+        return self._tap_values_sparse.shape[-1]
+
+    @property
+    def tap_values(self):
+        """dense [max_delay + 1, ..., n] copy with zeros at the unused delays (fading.py:482-511)."""
+        if self._tap_values_dense is None:
+            sp = np.asarray(self._tap_values_sparse)
+            dense = np.zeros((int(self.tap_indexes_sparse[-1]) + 1,) + sp.shape[1:], dtype=complex)
+            dense[np.asarray(self.tap_indexes_sparse)] = sp
+            dense.flags["WRITEABLE"] = False
+            self._tap_values_dense = dense
+        return self._tap_values_dense
+
+    def get_freq_response(self, fft_size):
+        """fading.py:513-536.  Host FFT of the dense taps: an analysis helper, off the hot path
+        (the equaliser kernel never materialises it)."""
+        return np.fft.fft(self.tap_values, fft_size, axis=0)
+
+
+class TdlChannel:
+    """reference fading.py:701-1287, SISO branch.  corrupt_data = time-varying sparse convolution
+    with one impulse response per sample, executed on the GPU."""
+
+    def __init__(self, fading_generator, channel_profile=None, tap_powers_dB=None, tap_delays=None, Ts=None,
+                 engine=None, dtype=None):
+        if isinstance(fading_generator, JakesSampleGenerator):
+            if Ts is None:
+                Ts = fading_generator.Ts
+            elif Ts != fading_generator.Ts:
+                raise RuntimeError("The provided sampling interval Ts is different from the one in the Jakes "
+                                   "sample generator.")
+        if channel_profile is None:
+            channel_profile = TdlChannelProfile(tap_powers_dB, tap_delays)
+        elif not isinstance(channel_profile, TdlChannelProfile):
+            raise AssertionError("channel_profile must be an obj of the TdlChannelProfile class")
+        if not channel_profile.is_discretized:
+            if isinstance(fading_generator, RayleighSampleGenerator) and Ts is None:
+                Ts = 1.0
+            assert Ts is not None
+            channel_profile = channel_profile.get_discretize_profile(Ts)
+        elif channel_profile.Ts != Ts and Ts is not None:
+            raise RuntimeError("Channel profile is already discretized, but it does not agree with the "
+                               "discretized parameter Ts")
+        self._channel_profile = channel_profile
+        self._fading_generator = fading_generator
+        self._engine = engine if engine is not None else getattr(fading_generator, "_engine", None)
+        self.dtype = dtype if dtype is not None else getattr(fading_generator, "dtype", None)
+        # the generator produces one stream per tap: shape (num_taps,) [+ MIMO dims]; assigning the
+        # shape re-draws the Jakes phases (fading.py:796-798, fading_generators.py:381-386)
+        base = fading_generator.shape
+        if base is not None and len(base) > 0:
+            raise NotImplementedError("MIMO TdlChannel is not part of this round's hot path (SURVEY 8f.1)")
+        self._fading_generator.shape = (self.num_taps,)
+        self._last_impulse_response = None
+
+    channel_profile = property(lambda self: self._channel_profile)
+    num_taps = property(lambda self: self._channel_profile.num_taps)
+    num_taps_with_padding = property(lambda self: self._channel_profile.num_taps_with_padding)
+
+    @property
+    def engine(self):
+        if self._engine is None:
+            self._engine = get_engine()
+        return self._engine
+
+    def generate_impulse_response(self, num_samples=1):
+        self._fading_generator.generate_more_samples(num_samples)
+        fading = np.asarray(self._fading_generator.get_samples()).reshape(self.num_taps, -1)
+        amp = np.sqrt(self._channel_profile.tap_powers_linear).reshape(-1, 1)
+        self._last_impulse_response = TdlImpulseResponse(fading * amp, self._channel_profile)
+
+    def get_last_impulse_response(self):
+        return self._last_impulse_response
+
+    def corrupt_data(self, signal):
+        signal = np.asarray(signal)
+        if signal.ndim != 1:
+            raise NotImplementedError("only SISO signals (1-D) in this round")
+        self.generate_impulse_response(signal.shape[-1])
+        ir = self._last_impulse_response
+        return self.engine.tdl_apply(signal, ir.tap_values_sparse, ir.tap_indexes_sparse, dtype=self.dtype)
+
+
+class SuChannel:
+    """reference singleuser.py:19-359: TdlChannel + optional path loss; default = flat fading."""
+
+    def __init__(self, fading_generator=None, channel_profile=None, tap_powers_dB=None, tap_delays=None, Ts=None,
+                 engine=None, dtype=None):
+        if fading_generator is None:
+            fading_generator = RayleighSampleGenerator()
+            if channel_profile is None and Ts is None:
+                Ts = 1.0
+        if channel_profile is None and tap_powers_dB is None and tap_delays is None:
+            self._tdlchannel = TdlChannel(fading_generator, tap_powers_dB=np.zeros(1), tap_delays=np.zeros(1),
+                                          Ts=Ts, engine=engine, dtype=dtype)
+        else:
+            self._tdlchannel = TdlChannel(fading_generator, channel_profile, tap_powers_dB, tap_delays, Ts,
+                                          engine=engine, dtype=dtype)
+        self._pathloss_value = None
+
+    def set_pathloss(self, pathloss_value=None):
+        if pathloss_value is not None and (pathloss_value < 0 or pathloss_value > 1):
+            raise ValueError("Pathloss must be between 0 and 1")
+        self._pathloss_value = pathloss_value
+
+    num_taps = property(lambda self: self._tdlchannel.num_taps)
+    num_taps_with_padding = property(lambda self: self._tdlchannel.num_taps_with_padding)
+    channel_profile = property(lambda self: self._tdlchannel.channel_profile)
+
+    def corrupt_data(self, signal):
+        out = self._tdlchannel.corrupt_data(signal)
+        if self._pathloss_value is not None:
+            out = out * math.sqrt(self._pathloss_value)
+        return out
+
+    def get_last_impulse_response(self):
+        ir = self._tdlchannel.get_last_impulse_response()
+        if self._pathloss_value is None or ir is None:
+            return ir
+        return TdlImpulseResponse(ir.tap_values_sparse * math.sqrt(self._pathloss_value), ir.channel_profile)

@@ -1,0 +1,300 @@
+// capi.hip -- context, stream, memory and constellation management of libmcle.
+#include <cmath>
+#include <cstdarg>
+
+#include "common.hpp"
+
+namespace mcle {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+}  // namespace mcle
+
+using namespace mcle;
+
+int mcle_ctx::bind() const {
+    MCLE_HIP(hipSetDevice(device));
+    return MCLE_OK;
+}
+
+int mcle_ctx::scratch(size_t bytes, void** d_ptr) {
+    if (bytes > scratch_bytes) {
+        if (d_scratch) MCLE_HIP(hipFree(d_scratch));  // hipFree synchronises with in-flight work
+        d_scratch = nullptr;
+        scratch_bytes = 0;
+        size_t want = bytes < (1u << 20) ? (1u << 20) : bytes + bytes / 4;
+        MCLE_HIP(hipMalloc(&d_scratch, want));
+        scratch_bytes = want;
+    }
+    *d_ptr = d_scratch;
+    return MCLE_OK;
+}
+
+// w[k] = exp(-2 pi i k / n) computed in double on the host (then rounded once for f32)
+int mcle_ctx::get_twiddles(int n, int dtype, void** d_tw) {
+    TwiddleKey key{n, dtype};
+    auto it = twiddles.find(key);
+    if (it != twiddles.end()) {
+        *d_tw = it->second;
+        return MCLE_OK;
+    }
+    const double two_pi = 6.283185307179586476925286766559;
+    void* d = nullptr;
+    if (dtype == MCLE_F64) {
+        std::vector<double2> h(n);
+        for (int k = 0; k < n; ++k) {
+            h[k].x = std::cos(two_pi * k / n);
+            h[k].y = -std::sin(two_pi * k / n);
+        }
+        MCLE_HIP(hipMalloc(&d, n * sizeof(double2)));
+        MCLE_HIP(hipMemcpy(d, h.data(), n * sizeof(double2), hipMemcpyHostToDevice));
+    } else {
+        std::vector<float2> h(n);
+        for (int k = 0; k < n; ++k) {
+            h[k].x = (float)std::cos(two_pi * k / n);
+            h[k].y = (float)-std::sin(two_pi * k / n);
+        }
+        MCLE_HIP(hipMalloc(&d, n * sizeof(float2)));
+        MCLE_HIP(hipMemcpy(d, h.data(), n * sizeof(float2), hipMemcpyHostToDevice));
+    }
+    twiddles[key] = d;
+    *d_tw = d;
+    return MCLE_OK;
+}
+
+extern "C" {
+
+const char* mcle_last_error(void) { return g_err; }
+
+int mcle_version(void) { return MCLE_VERSION; }
+
+int mcle_device_count(int* count) {
+    MCLE_REQUIRE(count != nullptr, "null output pointer");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        n = 0;
+    }
+    *count = n;
+    return MCLE_OK;
+}
+
+int mcle_ctx_create(int device_id, mcle_ctx** out) {
+    MCLE_REQUIRE(out != nullptr, "null output pointer");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        set_error("no HIP device available (hipGetDeviceCount: %s); libmcle has no CPU fallback",
+                  e == hipSuccess ? "0 devices" : hipGetErrorString(e));
+        return MCLE_E_HIP;
+    }
+    MCLE_REQUIRE(device_id >= 0 && device_id < n, "device_id %d out of range [0, %d)", device_id, n);
+    MCLE_HIP(hipSetDevice(device_id));
+    hipDeviceProp_t prop;
+    MCLE_HIP(hipGetDeviceProperties(&prop, device_id));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_error("device %d is %s; libmcle is built for gfx950 (MI355X) only", device_id, prop.gcnArchName);
+        return MCLE_E_HIP;
+    }
+    mcle_ctx* ctx = new (std::nothrow) mcle_ctx();
+    if (!ctx) {
+        set_error("out of host memory");
+        return MCLE_E_NOMEM;
+    }
+    ctx->device = device_id;
+    ctx->n_cu = prop.multiProcessorCount;
+    ctx->lds_bytes = (int)prop.sharedMemPerBlock;
+    ctx->name = prop.name;
+    hipError_t es = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (es != hipSuccess) {
+        set_error("hipStreamCreate failed: %s", hipGetErrorString(es));
+        delete ctx;
+        return MCLE_E_HIP;
+    }
+    ctx->own_stream = true;
+    (void)hipEventCreate(&ctx->ev0);
+    (void)hipEventCreate(&ctx->ev1);
+    *out = ctx;
+    return MCLE_OK;
+}
+
+int mcle_ctx_destroy(mcle_ctx* ctx) {
+    if (!ctx) return MCLE_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& kv : ctx->twiddles) (void)hipFree(kv.second);
+    if (ctx->d_table_f32) (void)hipFree(ctx->d_table_f32);
+    if (ctx->d_table_f64) (void)hipFree(ctx->d_table_f64);
+    if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return MCLE_OK;
+}
+
+int mcle_ctx_set_stream(mcle_ctx* ctx, void* hip_stream) {
+    MCLE_REQUIRE(ctx != nullptr, "null context");
+    MCLE_HIP(hipSetDevice(ctx->device));
+    MCLE_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->own_stream && ctx->stream) MCLE_HIP(hipStreamDestroy(ctx->stream));
+    if (hip_stream) {
+        ctx->stream = (hipStream_t)hip_stream;
+        ctx->own_stream = false;
+    } else {
+        MCLE_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+        ctx->own_stream = true;
+    }
+    return MCLE_OK;
+}
+
+int mcle_ctx_get_stream(mcle_ctx* ctx, void** hip_stream) {
+    MCLE_REQUIRE(ctx != nullptr && hip_stream != nullptr, "null argument");
+    *hip_stream = (void*)ctx->stream;
+    return MCLE_OK;
+}
+
+int mcle_ctx_sync(mcle_ctx* ctx) {
+    MCLE_REQUIRE(ctx != nullptr, "null context");
+    MCLE_HIP(hipSetDevice(ctx->device));
+    MCLE_HIP(hipStreamSynchronize(ctx->stream));
+    return MCLE_OK;
+}
+
+int mcle_ctx_device_info(mcle_ctx* ctx, int* n_cu, int* lds_bytes, char* name, int name_len) {
+    MCLE_REQUIRE(ctx != nullptr, "null context");
+    if (n_cu) *n_cu = ctx->n_cu;
+    if (lds_bytes) *lds_bytes = ctx->lds_bytes;
+    if (name && name_len > 0) {
+        std::strncpy(name, ctx->name.c_str(), name_len - 1);
+        name[name_len - 1] = 0;
+    }
+    return MCLE_OK;
+}
+
+int mcle_malloc(mcle_ctx* ctx, size_t bytes, void** d_ptr) {
+    MCLE_REQUIRE(ctx != nullptr && d_ptr != nullptr, "null argument");
+    MCLE_HIP(hipSetDevice(ctx->device));
+    *d_ptr = nullptr;
+    if (bytes == 0) return MCLE_OK;
+    hipError_t e = hipMalloc(d_ptr, bytes);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+        return MCLE_E_NOMEM;
+    }
+    return MCLE_OK;
+}
+
+int mcle_free(mcle_ctx* ctx, void* d_ptr) {
+    MCLE_REQUIRE(ctx != nullptr, "null context");
+    if (!d_ptr) return MCLE_OK;
+    MCLE_HIP(hipSetDevice(ctx->device));
+    MCLE_HIP(hipFree(d_ptr));
+    return MCLE_OK;
+}
+
+int mcle_memset(mcle_ctx* ctx, void* d_ptr, int value, size_t bytes) {
+    MCLE_REQUIRE(ctx != nullptr, "null context");
+    if (bytes == 0) return MCLE_OK;
+    MCLE_HIP(hipSetDevice(ctx->device));
+    MCLE_HIP(hipMemsetAsync(d_ptr, value, bytes, ctx->stream));
+    return MCLE_OK;
+}
+
+int mcle_memcpy_h2d(mcle_ctx* ctx, void* d_dst, const void* src, size_t bytes) {
+    MCLE_REQUIRE(ctx != nullptr, "null context");
+    if (bytes == 0) return MCLE_OK;
+    MCLE_HIP(hipSetDevice(ctx->device));
+    // pageable source: hipMemcpyAsync stages and returns once the source is consumed
+    MCLE_HIP(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    MCLE_HIP(hipStreamSynchronize(ctx->stream));
+    return MCLE_OK;
+}
+
+int mcle_memcpy_d2h(mcle_ctx* ctx, void* dst, const void* d_src, size_t bytes) {
+    MCLE_REQUIRE(ctx != nullptr, "null context");
+    if (bytes == 0) return MCLE_OK;
+    MCLE_HIP(hipSetDevice(ctx->device));
+    MCLE_HIP(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    MCLE_HIP(hipStreamSynchronize(ctx->stream));
+    return MCLE_OK;
+}
+
+int mcle_timer_start(mcle_ctx* ctx) {
+    MCLE_REQUIRE(ctx != nullptr, "null context");
+    MCLE_HIP(hipSetDevice(ctx->device));
+    MCLE_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    return MCLE_OK;
+}
+
+int mcle_timer_stop_ms(mcle_ctx* ctx, float* ms) {
+    MCLE_REQUIRE(ctx != nullptr && ms != nullptr, "null argument");
+    MCLE_HIP(hipSetDevice(ctx->device));
+    MCLE_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+    MCLE_HIP(hipEventSynchronize(ctx->ev1));
+    MCLE_HIP(hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+    return MCLE_OK;
+}
+
+// a1: the table comes from the host mirror (QAM / PSK / BPSK classes or setConstellation).  For
+// kind == MCLE_CONST_QAM the library re-derives the square Gray QAM layout of the reference
+// (modulators/fundamental.py:697-777) and refuses tables that do not match it, because the slicer
+// fast path relies on that structure.
+int mcle_set_constellation(mcle_ctx* ctx, const double* re_im, int M, int kind) {
+    MCLE_REQUIRE(ctx != nullptr && re_im != nullptr, "null argument");
+    MCLE_REQUIRE(M >= 2 && M <= 1024 && (M & (M - 1)) == 0, "M must be a power of two in [2, 1024] (got %d)", M);
+    MCLE_REQUIRE(kind == MCLE_CONST_GENERIC || kind == MCLE_CONST_QAM || kind == MCLE_CONST_BPSK,
+                 "unknown constellation kind %d", kind);
+    int bits = 0;
+    while ((1 << bits) < M) ++bits;
+    double scale = 0.0;
+    int L = 0;
+    if (kind == MCLE_CONST_QAM) {
+        MCLE_REQUIRE(bits % 2 == 0, "M must be a square power of 2");
+        L = 1 << (bits / 2);
+        scale = std::sqrt((M - 1) * 2.0 / 3.0);
+        for (int r = 0; r < L; ++r)
+            for (int c = 0; c < L; ++c) {
+                const int label = (r << (bits / 2)) | c;
+                const int gi = r ^ (r >> 1), gj = c ^ (c >> 1);
+                const double re = (-(L - 1) + 2 * gj) / scale, im = ((L - 1) - 2 * gi) / scale;
+                MCLE_REQUIRE(std::fabs(re_im[2 * label] - re) < 1e-12 && std::fabs(re_im[2 * label + 1] - im) < 1e-12,
+                             "table is not the reference's square Gray %d-QAM (label %d)", M, label);
+            }
+    }
+    MCLE_HIP(hipSetDevice(ctx->device));
+    MCLE_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->d_table_f32) MCLE_HIP(hipFree(ctx->d_table_f32));
+    if (ctx->d_table_f64) MCLE_HIP(hipFree(ctx->d_table_f64));
+    ctx->d_table_f32 = nullptr;
+    ctx->d_table_f64 = nullptr;
+    ctx->M = 0;
+    std::vector<float2> h32(M);
+    for (int m = 0; m < M; ++m) {
+        h32[m].x = (float)re_im[2 * m];
+        h32[m].y = (float)re_im[2 * m + 1];
+    }
+    MCLE_HIP(hipMalloc((void**)&ctx->d_table_f32, M * sizeof(float2)));
+    MCLE_HIP(hipMalloc((void**)&ctx->d_table_f64, M * sizeof(double2)));
+    MCLE_HIP(hipMemcpy(ctx->d_table_f32, h32.data(), M * sizeof(float2), hipMemcpyHostToDevice));
+    MCLE_HIP(hipMemcpy(ctx->d_table_f64, re_im, M * sizeof(double2), hipMemcpyHostToDevice));
+    ctx->M = M;
+    ctx->bits = bits;
+    ctx->kind = kind;
+    ctx->qam_scale = scale;
+    ctx->qam_L = L;
+    return MCLE_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,148 @@
+// common.hpp -- shared host/device helpers of libmcle (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/mcle.h"
+
+namespace mcle {
+
+// ---- error plumbing -----------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+
+#define MCLE_HIP(expr)                                                                    \
+    do {                                                                                  \
+        hipError_t _e = (expr);                                                           \
+        if (_e != hipSuccess) {                                                           \
+            ::mcle::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),      \
+                              __FILE__, __LINE__);                                        \
+            return MCLE_E_HIP;                                                            \
+        }                                                                                 \
+    } while (0)
+
+#define MCLE_REQUIRE(cond, ...)                 \
+    do {                                        \
+        if (!(cond)) {                          \
+            ::mcle::set_error(__VA_ARGS__);     \
+            return MCLE_E_INVAL;                \
+        }                                       \
+    } while (0)
+
+#define MCLE_LAUNCH_CHECK() MCLE_HIP(hipGetLastError())
+
+// ---- complex arithmetic on (re, im) pairs -------------------------------------------------
+template <typename T> struct cx_of;
+template <> struct cx_of<float> { using type = float2; };
+template <> struct cx_of<double> { using type = double2; };
+template <typename T> using cx = typename cx_of<T>::type;
+
+template <typename T> __host__ __device__ __forceinline__ cx<T> mk(T re, T im) {
+    cx<T> r;
+    r.x = re;
+    r.y = im;
+    return r;
+}
+template <typename C> __host__ __device__ __forceinline__ C cadd(C a, C b) {
+    a.x += b.x;
+    a.y += b.y;
+    return a;
+}
+template <typename C> __host__ __device__ __forceinline__ C csub(C a, C b) {
+    a.x -= b.x;
+    a.y -= b.y;
+    return a;
+}
+template <typename C> __host__ __device__ __forceinline__ C cmul(C a, C b) {
+    C r;
+    r.x = a.x * b.x - a.y * b.y;
+    r.y = a.x * b.y + a.y * b.x;
+    return r;
+}
+// a * conj(b)
+template <typename C> __host__ __device__ __forceinline__ C cmulc(C a, C b) {
+    C r;
+    r.x = a.x * b.x + a.y * b.y;
+    r.y = a.y * b.x - a.x * b.y;
+    return r;
+}
+// acc + a*b
+template <typename C> __host__ __device__ __forceinline__ C cfma(C a, C b, C acc) {
+    acc.x += a.x * b.x - a.y * b.y;
+    acc.y += a.x * b.y + a.y * b.x;
+    return acc;
+}
+template <typename C> __host__ __device__ __forceinline__ C cconj(C a) {
+    a.y = -a.y;
+    return a;
+}
+template <typename C, typename T> __host__ __device__ __forceinline__ C cscale(C a, T s) {
+    a.x *= s;
+    a.y *= s;
+    return a;
+}
+template <typename C> __host__ __device__ __forceinline__ C cdivide(C a, C b) {
+    auto d = b.x * b.x + b.y * b.y;
+    C r;
+    r.x = (a.x * b.x + a.y * b.y) / d;
+    r.y = (a.y * b.x - a.x * b.y) / d;
+    return r;
+}
+
+// ---- wave64 reductions ---------------------------------------------------------------------
+__device__ __forceinline__ unsigned wave_sum_u32(unsigned v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// ---- context --------------------------------------------------------------------------------
+struct TwiddleKey {
+    int n;
+    int dtype;
+    bool operator<(const TwiddleKey& o) const { return n != o.n ? n < o.n : dtype < o.dtype; }
+};
+
+}  // namespace mcle
+
+struct mcle_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = true;
+    int n_cu = 0;
+    int lds_bytes = 0;
+    std::string name;
+    // constellation
+    int M = 0;
+    int bits = 0;
+    int kind = MCLE_CONST_GENERIC;
+    float2* d_table_f32 = nullptr;
+    double2* d_table_f64 = nullptr;
+    double qam_scale = 0.0;  // sqrt(2(M-1)/3) for square QAM
+    int qam_L = 0;
+    // twiddle tables w[k] = exp(-2 pi i k / n), k < n, per (n, dtype)
+    std::map<mcle::TwiddleKey, void*> twiddles;
+    // scratch for host->device parameter blocks
+    void* d_scratch = nullptr;
+    size_t scratch_bytes = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+    int bind() const;
+    int get_twiddles(int n, int dtype, void** d_tw);
+    int scratch(size_t bytes, void** d_ptr);
+};
+
+namespace mcle {
+inline int grid_for(const mcle_ctx* ctx, size_t work_items, int block, int blocks_per_cu = 8) {
+    size_t need = (work_items + block - 1) / block;
+    size_t cap = (size_t)(ctx->n_cu > 0 ? ctx->n_cu : 256) * blocks_per_cu;
+    if (need < 1) need = 1;
+    return (int)(need < cap ? need : cap);
+}
+}  // namespace mcle

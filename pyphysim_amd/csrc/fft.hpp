@@ -1,0 +1,154 @@
+// fft.hpp -- workgroup-cooperative, in-place, in-LDS complex FFT for power-of-two sizes.
+//
+// Stands in for np.fft.fft / np.fft.ifft as used by OFDM.modulate / demodulate (reference
+// modulators/ofdm.py:421-422,456-457).  Radix-4 butterflies with one trailing radix-2 stage when
+// log2(N) is odd.  Two forms that chain WITHOUT any reordering pass:
+//     fft_dif : natural-order input  -> digit-reversed output   (decimation in frequency)
+//     fft_dit : digit-reversed input -> natural-order output    (decimation in time)
+// so an OFDM link does IFFT(dif) on the transmitter, per-sample channel work on the scrambled
+// time samples (position p holds time index fft_index_of_pos(p)), and FFT(dit) at the receiver.
+// `nf` independent transforms (antennas) sit side by side in LDS, `pitch` elements apart; the
+// whole workgroup shares every stage.  Twiddles w[k] = exp(-2 pi i k / N) come from an LDS (or
+// global) table of N entries built in double precision on the host.
+#pragma once
+#include "common.hpp"
+
+namespace mcle {
+
+template <int N> struct FftShape {
+    static_assert(N >= 4 && (N & (N - 1)) == 0, "power of two >= 4");
+    static constexpr int log2n() {
+        int l = 0;
+        for (int v = N; v > 1; v >>= 1) ++l;
+        return l;
+    }
+    static constexpr int LOG2 = log2n();
+    static constexpr int N4 = LOG2 / 2;     // radix-4 stages
+    static constexpr bool HAS2 = LOG2 & 1;  // trailing radix-2 stage (span 1)
+};
+
+// natural index f  ->  position after fft_dif (where bin / sample f ends up)
+template <int N> __host__ __device__ __forceinline__ int fft_pos_of_index(int f) {
+    int pos = 0, size = N;
+#pragma unroll
+    for (int s = 0; s < FftShape<N>::N4; ++s) {
+        size >>= 2;
+        pos += (f & 3) * size;
+        f >>= 2;
+    }
+    if (FftShape<N>::HAS2) pos += (f & 1);
+    return pos;
+}
+// position p -> natural index held there after fft_dif (inverse of the above)
+template <int N> __host__ __device__ __forceinline__ int fft_index_of_pos(int p) {
+    int f = 0, size = N, mul = 1;
+#pragma unroll
+    for (int s = 0; s < FftShape<N>::N4; ++s) {
+        size >>= 2;
+        const int q = p / size;
+        p -= q * size;
+        f += q * mul;
+        mul <<= 2;
+    }
+    if (FftShape<N>::HAS2) f += p * mul;
+    return f;
+}
+
+// OFDM data position d in [0, num_used) -> FFT bin (reference modulators/ofdm.py:188-224): full
+// band puts data k on bin (k + N/2) mod N; otherwise the first half rides the negative bins
+// [N-h, N-1] and the second half the positive bins [1, h] (DC and band edges unused).
+__host__ __device__ __forceinline__ int ofdm_bin(int d, int n, int num_used) {
+    if (num_used == n) return (d + n / 2) & (n - 1);
+    const int h = num_used / 2;
+    return d < h ? n - h + d : 1 + (d - h);
+}
+
+template <typename T, bool INV> __device__ __forceinline__ cx<T> tw_get(const cx<T>* tw, int i) {
+    cx<T> w = tw[i];
+    if (INV) w.y = -w.y;
+    return w;
+}
+// multiply by -i (forward) or +i (inverse)
+template <typename T, bool INV> __device__ __forceinline__ cx<T> rot(cx<T> a) {
+    return INV ? mk<T>(-a.y, a.x) : mk<T>(a.y, -a.x);
+}
+
+// ---- decimation in frequency: natural -> digit-reversed ----------------------------------------
+// Caller has written s_data and synchronised.  Returns synchronised.
+template <typename T, int N, bool INV>
+__device__ __forceinline__ void fft_dif(cx<T>* s_data, int nf, int pitch, const cx<T>* tw) {
+    constexpr int NB = N / 4;
+    int s = N / 4;
+#pragma unroll
+    for (int st = 0; st < FftShape<N>::N4; ++st, s >>= 2) {
+        const int twstep = N / (4 * s);
+        for (int b = threadIdx.x; b < nf * NB; b += blockDim.x) {
+            const int f = b / NB, bb = b - f * NB;
+            const int k = bb & (s - 1), g = bb / s;
+            cx<T>* p = s_data + f * pitch + g * 4 * s + k;
+            const cx<T> x0 = p[0], x1 = p[s], x2 = p[2 * s], x3 = p[3 * s];
+            const cx<T> a0 = cadd(x0, x2), a1 = csub(x0, x2), a2 = cadd(x1, x3), a3 = rot<T, INV>(csub(x1, x3));
+            cx<T> y0 = cadd(a0, a2), y1 = cadd(a1, a3), y2 = csub(a0, a2), y3 = csub(a1, a3);
+            if (s > 1) {
+                y1 = cmul(y1, tw_get<T, INV>(tw, k * twstep));
+                y2 = cmul(y2, tw_get<T, INV>(tw, 2 * k * twstep));
+                y3 = cmul(y3, tw_get<T, INV>(tw, 3 * k * twstep));
+            }
+            p[0] = y0;
+            p[s] = y1;
+            p[2 * s] = y2;
+            p[3 * s] = y3;
+        }
+        __syncthreads();
+    }
+    if (FftShape<N>::HAS2) {
+        for (int b = threadIdx.x; b < nf * (N / 2); b += blockDim.x) {
+            const int f = b / (N / 2), bb = b - f * (N / 2);
+            cx<T>* p = s_data + f * pitch + 2 * bb;
+            const cx<T> x0 = p[0], x1 = p[1];
+            p[0] = cadd(x0, x1);
+            p[1] = csub(x0, x1);
+        }
+        __syncthreads();
+    }
+}
+
+// ---- decimation in time: digit-reversed -> natural ------------------------------------------------
+template <typename T, int N, bool INV>
+__device__ __forceinline__ void fft_dit(cx<T>* s_data, int nf, int pitch, const cx<T>* tw) {
+    constexpr int NB = N / 4;
+    if (FftShape<N>::HAS2) {
+        for (int b = threadIdx.x; b < nf * (N / 2); b += blockDim.x) {
+            const int f = b / (N / 2), bb = b - f * (N / 2);
+            cx<T>* p = s_data + f * pitch + 2 * bb;
+            const cx<T> x0 = p[0], x1 = p[1];
+            p[0] = cadd(x0, x1);
+            p[1] = csub(x0, x1);
+        }
+        __syncthreads();
+    }
+    int s = FftShape<N>::HAS2 ? 2 : 1;
+#pragma unroll
+    for (int st = 0; st < FftShape<N>::N4; ++st, s <<= 2) {
+        const int twstep = N / (4 * s);
+        for (int b = threadIdx.x; b < nf * NB; b += blockDim.x) {
+            const int f = b / NB, bb = b - f * NB;
+            const int k = bb & (s - 1), g = bb / s;
+            cx<T>* p = s_data + f * pitch + g * 4 * s + k;
+            cx<T> u0 = p[0], u1 = p[s], u2 = p[2 * s], u3 = p[3 * s];
+            if (s > 1) {
+                u1 = cmul(u1, tw_get<T, INV>(tw, k * twstep));
+                u2 = cmul(u2, tw_get<T, INV>(tw, 2 * k * twstep));
+                u3 = cmul(u3, tw_get<T, INV>(tw, 3 * k * twstep));
+            }
+            const cx<T> a0 = cadd(u0, u2), a1 = csub(u0, u2), a2 = cadd(u1, u3), a3 = rot<T, INV>(csub(u1, u3));
+            p[0] = cadd(a0, a2);
+            p[s] = cadd(a1, a3);
+            p[2 * s] = csub(a0, a2);
+            p[3 * s] = csub(a1, a3);
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace mcle

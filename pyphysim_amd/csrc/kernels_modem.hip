@@ -1,0 +1,375 @@
+// kernels_modem.hip -- per-operator kernels: modulate, demodulate, error counting, AWGN, RNG.
+// HBM-streaming kernels (one pass over the symbol stream, 16 B/lane where the layout allows);
+// the constellation lives in LDS.  Reference operators: modulators/fundamental.py:175-248,
+// util/misc.py:327-355,519-566.
+#include "modem.hpp"
+#include "philox.hpp"
+
+namespace mcle {
+
+constexpr int kBlock = 256;
+constexpr int kMaxM = 1024;
+
+template <typename T> ModemParams<T> modem_params(const mcle_ctx* ctx, int method);
+template <> ModemParams<float> modem_params<float>(const mcle_ctx* ctx, int method) {
+    ModemParams<float> p;
+    p.g_table = ctx->d_table_f32;
+    p.M = ctx->M;
+    p.bits = ctx->bits;
+    p.method = method;
+    p.qam_scale = (float)ctx->qam_scale;
+    p.qam_L = ctx->qam_L;
+    p.half_bits = ctx->bits / 2;
+    return p;
+}
+template <> ModemParams<double> modem_params<double>(const mcle_ctx* ctx, int method) {
+    ModemParams<double> p;
+    p.g_table = ctx->d_table_f64;
+    p.M = ctx->M;
+    p.bits = ctx->bits;
+    p.method = method;
+    p.qam_scale = ctx->qam_scale;
+    p.qam_L = ctx->qam_L;
+    p.half_bits = ctx->bits / 2;
+    return p;
+}
+
+// ---- modulate: out[i] = table[idx[i]] (negative indices wrap like NumPy; idx >= M flags) -----
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_modulate(ModemParams<T> mp, const int32_t* __restrict__ idx,
+                                                     cx<T>* __restrict__ out, size_t n,
+                                                     unsigned* __restrict__ status) {
+    __shared__ cx<T> s_table[kMaxM];
+    load_table(mp, s_table);
+    __syncthreads();
+    bool bad = false;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        int v = idx[i];
+        if (v < 0) v += mp.M;
+        if (v < 0 || v >= mp.M) {
+            bad = true;
+            v = 0;
+        }
+        out[i] = s_table[v];
+    }
+    if (bad) atomicOr(status, 1u);
+}
+
+// ---- demodulate ----------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_demodulate(ModemParams<T> mp, const cx<T>* __restrict__ rx,
+                                                       int32_t* __restrict__ idx, size_t n) {
+    __shared__ cx<T> s_table[kMaxM];
+    load_table(mp, s_table);
+    __syncthreads();
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        idx[i] = demod_one(mp, s_table, rx[i]);
+}
+
+// ---- error counting --------------------------------------------------------------------------
+// grid = (chunks, realizations-in-flight); per-realization partials land in ws[r] = {sym, bit}.
+template <typename T, bool DEMOD>
+__global__ __launch_bounds__(kBlock) void k_count(ModemParams<T> mp, const cx<T>* __restrict__ rx,
+                                                  const int32_t* __restrict__ a, const int32_t* __restrict__ b,
+                                                  size_t n_per_real, size_t n_real, unsigned* __restrict__ ws) {
+    __shared__ cx<T> s_table[DEMOD ? kMaxM : 1];
+    __shared__ unsigned s_part[2 * (kBlock / 64)];
+    if (DEMOD) {
+        load_table(mp, s_table);
+        __syncthreads();
+    }
+    for (size_t r = blockIdx.y; r < n_real; r += gridDim.y) {
+        unsigned se = 0, be = 0;
+        const size_t base = r * n_per_real;
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_per_real;
+             i += (size_t)gridDim.x * blockDim.x) {
+            const int tx = a[base + i];
+            const int dec = DEMOD ? demod_one(mp, s_table, rx[base + i]) : b[base + i];
+            const unsigned x = (unsigned)(tx ^ dec);
+            se += (x != 0u);
+            be += __popc(x);
+        }
+        se = wave_sum_u32(se);
+        be = wave_sum_u32(be);
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        if (lane == 0) {
+            s_part[2 * wave] = se;
+            s_part[2 * wave + 1] = be;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned s = 0, t = 0;
+            for (int w = 0; w < kBlock / 64; ++w) {
+                s += s_part[2 * w];
+                t += s_part[2 * w + 1];
+            }
+            if (s | t) {
+                atomicAdd(&ws[2 * r], s);
+                atomicAdd(&ws[2 * r + 1], t);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// fold per-realization {sym, bit} into the counter block (exact integer sums) and publish them
+__global__ __launch_bounds__(kBlock) void k_count_finalize(const unsigned* __restrict__ ws, size_t n_real,
+                                                           size_t n_per_real, int bits, mcle_counters* counters,
+                                                           uint32_t* __restrict__ sym_out,
+                                                           uint32_t* __restrict__ bit_out) {
+    unsigned long long se = 0, se2 = 0, be = 0, be2 = 0;
+    for (size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_real; r += (size_t)gridDim.x * blockDim.x) {
+        const unsigned long long s = ws[2 * r], t = ws[2 * r + 1];
+        if (sym_out) sym_out[r] = (uint32_t)s;
+        if (bit_out) bit_out[r] = (uint32_t)t;
+        se += s;
+        se2 += s * s;
+        be += t;
+        be2 += t * t;
+    }
+    if (!counters) return;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        se += __shfl_xor(se, off, 64);
+        se2 += __shfl_xor(se2, off, 64);
+        be += __shfl_xor(be, off, 64);
+        be2 += __shfl_xor(be2, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd((unsigned long long*)&counters->sym_errors, se);
+        atomicAdd((unsigned long long*)&counters->sym_errors_sq, se2);
+        atomicAdd((unsigned long long*)&counters->bit_errors, be);
+        atomicAdd((unsigned long long*)&counters->bit_errors_sq, be2);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        atomicAdd((unsigned long long*)&counters->n_realizations, (unsigned long long)n_real);
+        counters->n_symbols = n_per_real;
+        counters->n_bits = n_per_real * (unsigned long long)bits;
+    }
+}
+
+// ---- AWGN / element-wise -----------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_awgn_add(const cx<T>* __restrict__ x, const cx<T>* __restrict__ nz,
+                                                     T sigma, cx<T>* __restrict__ y, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const cx<T> a = x[i], b = nz[i];
+        y[i] = mk<T>(a.x + sigma * b.x, a.y + sigma * b.y);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_cdiv(const cx<T>* __restrict__ a, const cx<T>* __restrict__ b,
+                                                 cx<T>* __restrict__ o, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        o[i] = cdivide(a[i], b[i]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_randn_c(Rng rng, uint32_t stream, uint64_t first, T sigma,
+                                                    cx<T>* __restrict__ out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        out[i] = cn_sample<T>(rng, stream, first + i, sigma);
+}
+
+__global__ __launch_bounds__(kBlock) void k_rand_symbols(Rng rng, uint64_t first, uint32_t mask,
+                                                         int32_t* __restrict__ out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        out[i] = (int32_t)symbol_at(rng, first + i, mask);
+}
+
+int check_modem(const mcle_ctx* ctx, int dtype, int method) {
+    MCLE_REQUIRE(ctx != nullptr, "null context");
+    MCLE_REQUIRE(ctx->M > 0, "no constellation set (mcle_set_constellation)");
+    MCLE_REQUIRE(ctx->M <= kMaxM, "constellation too large for the LDS table (%d > %d)", ctx->M, kMaxM);
+    MCLE_REQUIRE(dtype == MCLE_F32 || dtype == MCLE_F64, "dtype must be MCLE_F32 or MCLE_F64");
+    MCLE_REQUIRE(method == MCLE_DEMOD_MINDIST || method == MCLE_DEMOD_QAM_SLICER, "bad demodulation method");
+    MCLE_REQUIRE(method != MCLE_DEMOD_QAM_SLICER || ctx->kind == MCLE_CONST_QAM,
+                 "the slicer needs a square Gray QAM constellation (kind MCLE_CONST_QAM)");
+    return MCLE_OK;
+}
+
+template <typename T, bool DEMOD>
+int count_impl(mcle_ctx* ctx, int method, const void* d_rx, const int32_t* d_a, const int32_t* d_b,
+               size_t n_per_real, size_t n_real, int bits, mcle_counters* d_counters, uint32_t* d_sym,
+               uint32_t* d_bit) {
+    if (n_real == 0) return MCLE_OK;
+    void* ws = nullptr;
+    int rc = ctx->scratch(n_real * 2 * sizeof(unsigned), &ws);
+    if (rc) return rc;
+    MCLE_HIP(hipMemsetAsync(ws, 0, n_real * 2 * sizeof(unsigned), ctx->stream));
+    ModemParams<T> mp = modem_params<T>(ctx, method);
+    const size_t chunks_needed = (n_per_real + kBlock - 1) / kBlock;
+    size_t cap = (size_t)ctx->n_cu * 8;
+    size_t gy = n_real < cap ? n_real : cap;
+    size_t gx = cap / gy;
+    if (gx < 1) gx = 1;
+    if (gx > chunks_needed) gx = chunks_needed;
+    if (gx < 1) gx = 1;
+    dim3 grid((unsigned)gx, (unsigned)gy);
+    hipLaunchKernelGGL((k_count<T, DEMOD>), grid, dim3(kBlock), 0, ctx->stream, mp, (const cx<T>*)d_rx, d_a, d_b,
+                       n_per_real, n_real, (unsigned*)ws);
+    MCLE_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_count_finalize, dim3(grid_for(ctx, n_real, kBlock, 1)), dim3(kBlock), 0, ctx->stream,
+                       (const unsigned*)ws, n_real, n_per_real, bits, d_counters, d_sym, d_bit);
+    MCLE_LAUNCH_CHECK();
+    return MCLE_OK;
+}
+
+}  // namespace mcle
+
+using namespace mcle;
+
+extern "C" {
+
+int mcle_modulate(mcle_ctx* ctx, int dtype, const int32_t* d_idx, void* d_out, size_t n) {
+    int rc = check_modem(ctx, dtype, MCLE_DEMOD_MINDIST);
+    if (rc) return rc;
+    MCLE_REQUIRE(ctx->M <= kMaxM, "constellation too large for the LDS table (%d > %d)", ctx->M, kMaxM);
+    if (n == 0) return MCLE_OK;
+    if ((rc = ctx->bind())) return rc;
+    void* st = nullptr;
+    if ((rc = ctx->scratch(sizeof(unsigned), &st))) return rc;
+    MCLE_HIP(hipMemsetAsync(st, 0, sizeof(unsigned), ctx->stream));
+    const int grid = grid_for(ctx, n, kBlock);
+    if (dtype == MCLE_F32)
+        hipLaunchKernelGGL(k_modulate<float>, dim3(grid), dim3(kBlock), 0, ctx->stream, modem_params<float>(ctx, 0),
+                           d_idx, (float2*)d_out, n, (unsigned*)st);
+    else
+        hipLaunchKernelGGL(k_modulate<double>, dim3(grid), dim3(kBlock), 0, ctx->stream, modem_params<double>(ctx, 0),
+                           d_idx, (double2*)d_out, n, (unsigned*)st);
+    MCLE_LAUNCH_CHECK();
+    unsigned flag = 0;
+    MCLE_HIP(hipMemcpyAsync(&flag, st, sizeof(flag), hipMemcpyDeviceToHost, ctx->stream));
+    MCLE_HIP(hipStreamSynchronize(ctx->stream));
+    // reference: IndexError -> ValueError("Input data must be between 0 and 2^M") fundamental.py:196-199
+    MCLE_REQUIRE(flag == 0, "Input data must be between 0 and 2^M");
+    return MCLE_OK;
+}
+
+int mcle_demodulate(mcle_ctx* ctx, int dtype, int method, const void* d_rx, int32_t* d_idx, size_t n) {
+    int rc = check_modem(ctx, dtype, method);
+    if (rc) return rc;
+    if (n == 0) return MCLE_OK;
+    if ((rc = ctx->bind())) return rc;
+    const int grid = grid_for(ctx, n, kBlock);
+    if (dtype == MCLE_F32)
+        hipLaunchKernelGGL(k_demodulate<float>, dim3(grid), dim3(kBlock), 0, ctx->stream,
+                           modem_params<float>(ctx, method), (const float2*)d_rx, d_idx, n);
+    else
+        hipLaunchKernelGGL(k_demodulate<double>, dim3(grid), dim3(kBlock), 0, ctx->stream,
+                           modem_params<double>(ctx, method), (const double2*)d_rx, d_idx, n);
+    MCLE_LAUNCH_CHECK();
+    return MCLE_OK;
+}
+
+int mcle_count_errors(mcle_ctx* ctx, const int32_t* d_tx_idx, const int32_t* d_rx_idx, size_t n_per_real,
+                      size_t n_real, int bits_per_symbol, mcle_counters* d_counters, uint32_t* d_sym_err,
+                      uint32_t* d_bit_err) {
+    MCLE_REQUIRE(ctx != nullptr, "null context");
+    MCLE_REQUIRE(bits_per_symbol >= 1 && bits_per_symbol <= 31, "bits_per_symbol out of range");
+    int rc = ctx->bind();
+    if (rc) return rc;
+    ModemParams<float> dummy{};  // unused on the index-vs-index path (no constellation needed)
+    if (n_real == 0) return MCLE_OK;
+    void* ws = nullptr;
+    if ((rc = ctx->scratch(n_real * 2 * sizeof(unsigned), &ws))) return rc;
+    MCLE_HIP(hipMemsetAsync(ws, 0, n_real * 2 * sizeof(unsigned), ctx->stream));
+    const size_t chunks_needed = (n_per_real + kBlock - 1) / kBlock;
+    size_t cap = (size_t)ctx->n_cu * 8;
+    size_t gy = n_real < cap ? n_real : cap;
+    size_t gx = cap / gy;
+    if (gx > chunks_needed) gx = chunks_needed;
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL((k_count<float, false>), dim3((unsigned)gx, (unsigned)gy), dim3(kBlock), 0, ctx->stream,
+                       dummy, (const float2*)nullptr, d_tx_idx, d_rx_idx, n_per_real, n_real, (unsigned*)ws);
+    MCLE_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_count_finalize, dim3(grid_for(ctx, n_real, kBlock, 1)), dim3(kBlock), 0, ctx->stream,
+                       (const unsigned*)ws, n_real, n_per_real, bits_per_symbol, d_counters, d_sym_err, d_bit_err);
+    MCLE_LAUNCH_CHECK();
+    return MCLE_OK;
+}
+
+int mcle_demod_count(mcle_ctx* ctx, int dtype, int method, const void* d_rx, const int32_t* d_tx_idx,
+                     size_t n_per_real, size_t n_real, mcle_counters* d_counters, uint32_t* d_sym_err,
+                     uint32_t* d_bit_err) {
+    int rc = check_modem(ctx, dtype, method);
+    if (rc) return rc;
+    if ((rc = ctx->bind())) return rc;
+    if (dtype == MCLE_F32)
+        return count_impl<float, true>(ctx, method, d_rx, d_tx_idx, nullptr, n_per_real, n_real, ctx->bits,
+                                       d_counters, d_sym_err, d_bit_err);
+    return count_impl<double, true>(ctx, method, d_rx, d_tx_idx, nullptr, n_per_real, n_real, ctx->bits, d_counters,
+                                    d_sym_err, d_bit_err);
+}
+
+int mcle_randn_c(mcle_ctx* ctx, int dtype, uint64_t seed, uint64_t realization, uint32_t stream,
+                 uint64_t first_sample, double variance, void* d_out, size_t n) {
+    MCLE_REQUIRE(ctx != nullptr, "null context");
+    MCLE_REQUIRE(dtype == MCLE_F32 || dtype == MCLE_F64, "dtype must be MCLE_F32 or MCLE_F64");
+    MCLE_REQUIRE(variance >= 0.0, "variance must be non-negative");
+    if (n == 0) return MCLE_OK;
+    int rc = ctx->bind();
+    if (rc) return rc;
+    Rng rng(seed, realization);
+    const int grid = grid_for(ctx, n, kBlock);
+    if (dtype == MCLE_F32)
+        hipLaunchKernelGGL(k_randn_c<float>, dim3(grid), dim3(kBlock), 0, ctx->stream, rng, stream, first_sample,
+                           (float)sqrt(variance), (float2*)d_out, n);
+    else
+        hipLaunchKernelGGL(k_randn_c<double>, dim3(grid), dim3(kBlock), 0, ctx->stream, rng, stream, first_sample,
+                           sqrt(variance), (double2*)d_out, n);
+    MCLE_LAUNCH_CHECK();
+    return MCLE_OK;
+}
+
+int mcle_rand_symbols(mcle_ctx* ctx, uint64_t seed, uint64_t realization, uint64_t first_symbol, int M,
+                      int32_t* d_idx, size_t n) {
+    MCLE_REQUIRE(ctx != nullptr, "null context");
+    MCLE_REQUIRE(M >= 2 && M <= 256 && (M & (M - 1)) == 0, "M must be a power of two in [2, 256]");
+    if (n == 0) return MCLE_OK;
+    int rc = ctx->bind();
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_rand_symbols, dim3(grid_for(ctx, n, kBlock)), dim3(kBlock), 0, ctx->stream,
+                       Rng(seed, realization), first_symbol, (uint32_t)(M - 1), d_idx, n);
+    MCLE_LAUNCH_CHECK();
+    return MCLE_OK;
+}
+
+int mcle_awgn_add(mcle_ctx* ctx, int dtype, const void* d_x, const void* d_noise, double noise_var, void* d_y,
+                  size_t n) {
+    MCLE_REQUIRE(ctx != nullptr, "null context");
+    MCLE_REQUIRE(dtype == MCLE_F32 || dtype == MCLE_F64, "dtype must be MCLE_F32 or MCLE_F64");
+    MCLE_REQUIRE(noise_var >= 0.0, "noise variance must be non-negative");
+    if (n == 0) return MCLE_OK;
+    int rc = ctx->bind();
+    if (rc) return rc;
+    const int grid = grid_for(ctx, n, kBlock);
+    if (dtype == MCLE_F32)
+        hipLaunchKernelGGL(k_awgn_add<float>, dim3(grid), dim3(kBlock), 0, ctx->stream, (const float2*)d_x,
+                           (const float2*)d_noise, (float)sqrt(noise_var), (float2*)d_y, n);
+    else
+        hipLaunchKernelGGL(k_awgn_add<double>, dim3(grid), dim3(kBlock), 0, ctx->stream, (const double2*)d_x,
+                           (const double2*)d_noise, sqrt(noise_var), (double2*)d_y, n);
+    MCLE_LAUNCH_CHECK();
+    return MCLE_OK;
+}
+
+int mcle_cdiv(mcle_ctx* ctx, int dtype, const void* d_num, const void* d_den, void* d_out, size_t n) {
+    MCLE_REQUIRE(ctx != nullptr, "null context");
+    MCLE_REQUIRE(dtype == MCLE_F32 || dtype == MCLE_F64, "dtype must be MCLE_F32 or MCLE_F64");
+    if (n == 0) return MCLE_OK;
+    int rc = ctx->bind();
+    if (rc) return rc;
+    const int grid = grid_for(ctx, n, kBlock);
+    if (dtype == MCLE_F32)
+        hipLaunchKernelGGL(k_cdiv<float>, dim3(grid), dim3(kBlock), 0, ctx->stream, (const float2*)d_num,
+                           (const float2*)d_den, (float2*)d_out, n);
+    else
+        hipLaunchKernelGGL(k_cdiv<double>, dim3(grid), dim3(kBlock), 0, ctx->stream, (const double2*)d_num,
+                           (const double2*)d_den, (double2*)d_out, n);
+    MCLE_LAUNCH_CHECK();
+    return MCLE_OK;
+}
+
+}  // extern "C"

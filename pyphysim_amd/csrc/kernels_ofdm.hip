@@ -1,0 +1,231 @@
+// kernels_ofdm.hip -- OFDM.modulate / demodulate and the one-tap equaliser as batched kernels.
+// One workgroup per OFDM symbol; the transform runs in LDS (fft.hpp).  Global traffic is one
+// coalesced read and one coalesced write of the sample stream (the digit-reversal scatter /
+// gather happens on the LDS side).  Reference: modulators/ofdm.py:188-224 (subcarrier map),
+// :370-392 (power scale), :394-466 (modulate / demodulate), :515-552 (equaliser).
+#include "fft.hpp"
+
+namespace mcle {
+
+constexpr int kOfdmBlock = 256;
+
+// in [batch][n_in] -> out [batch][n_sym*(N+cp)]
+template <typename T, int N>
+__global__ __launch_bounds__(kOfdmBlock) void k_ofdm_mod(const cx<T>* __restrict__ in, size_t n_in, int cp,
+                                                         int num_used, int n_sym, T scale,
+                                                         const cx<T>* __restrict__ tw, cx<T>* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cx<T>* s = reinterpret_cast<cx<T>*>(smem);
+    const size_t row = blockIdx.y;
+    for (int sym = blockIdx.x; sym < n_sym; sym += gridDim.x) {
+        for (int p = threadIdx.x; p < N; p += blockDim.x) s[p] = mk<T>(0, 0);
+        __syncthreads();
+        const cx<T>* src = in + row * n_in + (size_t)sym * num_used;
+        const size_t left = n_in > (size_t)sym * num_used ? n_in - (size_t)sym * num_used : 0;  // zero padding
+        for (int d = threadIdx.x; d < num_used; d += blockDim.x)
+            if ((size_t)d < left) s[fft_pos_of_index<N>(ofdm_bin(d, N, num_used))] = src[d];
+        __syncthreads();
+        fft_dit<T, N, true>(s, 1, N, tw);
+        cx<T>* dst = out + (row * n_sym + sym) * (size_t)(N + cp);
+        for (int j = threadIdx.x; j < N + cp; j += blockDim.x) {
+            const int n = j < cp ? N - cp + j : j - cp;
+            dst[j] = cscale(s[n], scale);
+        }
+        __syncthreads();
+    }
+}
+
+// in [batch][n_sym*(N+cp)] -> out [batch][n_sym*num_used]
+template <typename T, int N>
+__global__ __launch_bounds__(kOfdmBlock) void k_ofdm_demod(const cx<T>* __restrict__ in, int cp, int num_used,
+                                                           int n_sym, T scale, const cx<T>* __restrict__ tw,
+                                                           cx<T>* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cx<T>* s = reinterpret_cast<cx<T>*>(smem);
+    const size_t row = blockIdx.y;
+    for (int sym = blockIdx.x; sym < n_sym; sym += gridDim.x) {
+        const cx<T>* src = in + (row * n_sym + sym) * (size_t)(N + cp) + cp;
+        for (int n = threadIdx.x; n < N; n += blockDim.x) s[n] = src[n];
+        __syncthreads();
+        fft_dif<T, N, false>(s, 1, N, tw);
+        cx<T>* dst = out + (row * n_sym + sym) * (size_t)num_used;
+        for (int d = threadIdx.x; d < num_used; d += blockDim.x)
+            dst[d] = cscale(s[fft_pos_of_index<N>(ofdm_bin(d, N, num_used))], scale);
+        __syncthreads();
+    }
+}
+
+// One workgroup per OFDM symbol: mean of each sparse tap over the symbol's N+cp samples (CP
+// included, ofdm.py:545-547), then H[k] = sum_i mean_i w^(k d_i) (== mean over samples of the
+// per-sample FFTs of fading.py:513-536, by linearity), then data / H on the used bins.
+struct TapDelays {
+    int32_t d[MCLE_MAX_TAPS];
+};
+template <typename T>
+__global__ __launch_bounds__(kOfdmBlock) void k_onetap_eq(const cx<T>* __restrict__ data,
+                                                          const cx<T>* __restrict__ taps, TapDelays delays,
+                                                          int n_taps, size_t n_sym, int n, int cp, int num_used,
+                                                          const cx<T>* __restrict__ tw, cx<T>* __restrict__ out) {
+    __shared__ cx<T> s_part[MCLE_MAX_TAPS][kOfdmBlock / 64];
+    __shared__ cx<T> s_mean[MCLE_MAX_TAPS];
+    const size_t total = n_sym * (size_t)(n + cp);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (size_t sym = blockIdx.x; sym < n_sym; sym += gridDim.x) {
+        for (int i = 0; i < n_taps; ++i) {
+            const cx<T>* g = taps + (size_t)i * total + sym * (size_t)(n + cp);
+            T re = 0, im = 0;
+            for (int j = threadIdx.x; j < n + cp; j += blockDim.x) {
+                re += g[j].x;
+                im += g[j].y;
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                re += __shfl_xor(re, off, 64);
+                im += __shfl_xor(im, off, 64);
+            }
+            if (lane == 0) s_part[i][wave] = mk<T>(re, im);
+        }
+        __syncthreads();
+        if (threadIdx.x < n_taps) {
+            T re = 0, im = 0;
+            for (int w = 0; w < kOfdmBlock / 64; ++w) {
+                re += s_part[threadIdx.x][w].x;
+                im += s_part[threadIdx.x][w].y;
+            }
+            s_mean[threadIdx.x] = mk<T>(re / (T)(n + cp), im / (T)(n + cp));
+        }
+        __syncthreads();
+        for (int d = threadIdx.x; d < num_used; d += blockDim.x) {
+            const int k = ofdm_bin(d, n, num_used);
+            cx<T> h = mk<T>(0, 0);
+            for (int i = 0; i < n_taps; ++i) h = cfma(s_mean[i], tw[(k * delays.d[i]) & (n - 1)], h);
+            const size_t o = sym * (size_t)num_used + d;
+            out[o] = cdivide(data[o], h);
+        }
+        __syncthreads();
+    }
+}
+
+int check_ofdm(const mcle_ctx* ctx, int dtype, int fft_size, int cp_size, int num_used) {
+    MCLE_REQUIRE(ctx != nullptr, "null context");
+    MCLE_REQUIRE(dtype == MCLE_F32 || dtype == MCLE_F64, "dtype must be MCLE_F32 or MCLE_F64");
+    MCLE_REQUIRE(fft_size >= 16 && fft_size <= 4096 && (fft_size & (fft_size - 1)) == 0,
+                 "fft_size must be a power of two in [16, 4096] (got %d)", fft_size);
+    // same messages as OFDM.set_parameters (ofdm.py:75-90)
+    MCLE_REQUIRE(cp_size >= 0 && cp_size <= fft_size,
+                 "cp_size must be nonnegative and cannot be greater than fft_size");
+    MCLE_REQUIRE(num_used <= fft_size, "Number of used subcarriers cannot be greater than the fft_size");
+    MCLE_REQUIRE(num_used >= 2 && num_used % 2 == 0, "Number of used subcarriers must be a multiple of 2");
+    return MCLE_OK;
+}
+
+template <typename T, int N>
+int launch_mod(mcle_ctx* ctx, const void* d_in, size_t n_in, int cp, int num_used, int n_sym, double scale,
+               const void* tw, void* d_out, size_t batch) {
+    const unsigned gx = (unsigned)(n_sym < 4096 ? n_sym : 4096);
+    hipLaunchKernelGGL((k_ofdm_mod<T, N>), dim3(gx, (unsigned)batch), dim3(kOfdmBlock), N * sizeof(cx<T>),
+                       ctx->stream, (const cx<T>*)d_in, n_in, cp, num_used, n_sym, (T)scale, (const cx<T>*)tw,
+                       (cx<T>*)d_out);
+    MCLE_LAUNCH_CHECK();
+    return MCLE_OK;
+}
+template <typename T, int N>
+int launch_demod(mcle_ctx* ctx, const void* d_in, int cp, int num_used, int n_sym, double scale, const void* tw,
+                 void* d_out, size_t batch) {
+    const unsigned gx = (unsigned)(n_sym < 4096 ? n_sym : 4096);
+    hipLaunchKernelGGL((k_ofdm_demod<T, N>), dim3(gx, (unsigned)batch), dim3(kOfdmBlock), N * sizeof(cx<T>),
+                       ctx->stream, (const cx<T>*)d_in, cp, num_used, n_sym, (T)scale, (const cx<T>*)tw,
+                       (cx<T>*)d_out);
+    MCLE_LAUNCH_CHECK();
+    return MCLE_OK;
+}
+
+#define MCLE_FFT_SWITCH(N_, CALL)                              \
+    switch (N_) {                                              \
+        case 16: { constexpr int NN = 16; CALL; } break;       \
+        case 32: { constexpr int NN = 32; CALL; } break;       \
+        case 64: { constexpr int NN = 64; CALL; } break;       \
+        case 128: { constexpr int NN = 128; CALL; } break;     \
+        case 256: { constexpr int NN = 256; CALL; } break;     \
+        case 512: { constexpr int NN = 512; CALL; } break;     \
+        case 1024: { constexpr int NN = 1024; CALL; } break;   \
+        case 2048: { constexpr int NN = 2048; CALL; } break;   \
+        case 4096: { constexpr int NN = 4096; CALL; } break;   \
+        default: set_error("unsupported fft size %d", N_); rc = MCLE_E_INVAL; \
+    }
+
+}  // namespace mcle
+
+using namespace mcle;
+
+extern "C" {
+
+int mcle_ofdm_modulate(mcle_ctx* ctx, int dtype, const void* d_in, size_t n_in, int fft_size, int cp_size,
+                       int num_used, void* d_out, size_t batch) {
+    int rc = check_ofdm(ctx, dtype, fft_size, cp_size, num_used);
+    if (rc) return rc;
+    MCLE_REQUIRE(batch <= 65535, "batch too large (%zu > 65535)", batch);
+    if (n_in == 0 || batch == 0) return MCLE_OK;
+    if ((rc = ctx->bind())) return rc;
+    void* tw = nullptr;
+    if ((rc = ctx->get_twiddles(fft_size, dtype, &tw))) return rc;
+    const int n_sym = (int)((n_in + num_used - 1) / num_used);
+    // sqrt(fft^2/(used+cp)) * (1/fft of numpy's ifft)   (ofdm.py:390-391,421-422)
+    const double scale = std::sqrt((double)fft_size * fft_size / ((double)num_used + cp_size)) / fft_size;
+    if (dtype == MCLE_F32) {
+        MCLE_FFT_SWITCH(fft_size, rc = (launch_mod<float, NN>(ctx, d_in, n_in, cp_size, num_used, n_sym, scale, tw,
+                                                               d_out, batch)));
+    } else {
+        MCLE_FFT_SWITCH(fft_size, rc = (launch_mod<double, NN>(ctx, d_in, n_in, cp_size, num_used, n_sym, scale, tw,
+                                                                d_out, batch)));
+    }
+    return rc;
+}
+
+int mcle_ofdm_demodulate(mcle_ctx* ctx, int dtype, const void* d_in, size_t n_sym, int fft_size, int cp_size,
+                         int num_used, void* d_out, size_t batch) {
+    int rc = check_ofdm(ctx, dtype, fft_size, cp_size, num_used);
+    if (rc) return rc;
+    MCLE_REQUIRE(batch <= 65535, "batch too large (%zu > 65535)", batch);
+    if (n_sym == 0 || batch == 0) return MCLE_OK;
+    if ((rc = ctx->bind())) return rc;
+    void* tw = nullptr;
+    if ((rc = ctx->get_twiddles(fft_size, dtype, &tw))) return rc;
+    const double scale = 1.0 / std::sqrt((double)fft_size * fft_size / ((double)num_used + cp_size));
+    if (dtype == MCLE_F32) {
+        MCLE_FFT_SWITCH(fft_size, rc = (launch_demod<float, NN>(ctx, d_in, cp_size, num_used, (int)n_sym, scale, tw,
+                                                                 d_out, batch)));
+    } else {
+        MCLE_FFT_SWITCH(fft_size, rc = (launch_demod<double, NN>(ctx, d_in, cp_size, num_used, (int)n_sym, scale,
+                                                                  tw, d_out, batch)));
+    }
+    return rc;
+}
+
+int mcle_onetap_equalize(mcle_ctx* ctx, int dtype, const void* d_data, const void* d_taps, const int32_t* delays,
+                         int n_taps, size_t n_sym, int fft_size, int cp_size, int num_used, void* d_out) {
+    int rc = check_ofdm(ctx, dtype, fft_size, cp_size, num_used);
+    if (rc) return rc;
+    MCLE_REQUIRE(delays != nullptr, "null delays");
+    MCLE_REQUIRE(n_taps >= 1 && n_taps <= MCLE_MAX_TAPS, "n_taps must be in [1, %d]", MCLE_MAX_TAPS);
+    if (n_sym == 0) return MCLE_OK;
+    if ((rc = ctx->bind())) return rc;
+    void* tw = nullptr;
+    if ((rc = ctx->get_twiddles(fft_size, dtype, &tw))) return rc;
+    TapDelays td;
+    for (int i = 0; i < MCLE_MAX_TAPS; ++i) td.d[i] = i < n_taps ? delays[i] : 0;
+    for (int i = 0; i < n_taps; ++i) MCLE_REQUIRE(td.d[i] >= 0, "negative tap delay");
+    const unsigned grid = (unsigned)(n_sym < 8192 ? n_sym : 8192);
+    if (dtype == MCLE_F32)
+        hipLaunchKernelGGL(k_onetap_eq<float>, dim3(grid), dim3(kOfdmBlock), 0, ctx->stream, (const float2*)d_data,
+                           (const float2*)d_taps, td, n_taps, n_sym, fft_size, cp_size, num_used, (const float2*)tw,
+                           (float2*)d_out);
+    else
+        hipLaunchKernelGGL(k_onetap_eq<double>, dim3(grid), dim3(kOfdmBlock), 0, ctx->stream, (const double2*)d_data,
+                           (const double2*)d_taps, td, n_taps, n_sym, fft_size, cp_size, num_used,
+                           (const double2*)tw, (double2*)d_out);
+    MCLE_LAUNCH_CHECK();
+    return MCLE_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,111 @@
+// philox.hpp -- the "mcle-philox-v1" randomness contract, device side.
+//
+// Philox4x32-10 (Salmon et al. SC'11; rocRAND's philox4x32_10) as a pure function:
+//   key = (seed_lo, seed_hi), counter = (block, stream, realization_lo, realization_hi)
+// == rocrand_init(seed, subsequence = realization, offset = 4*(stream*2^32 + block)).
+// Replaces the reference's global NumPy MT19937 draws (util/misc.py:327-355 randn_c,
+// np.random.randint in apps/awgn_modulators/simulate_psk.py:65) on the fused GPU path; the
+// injected-input operator kernels take the reference's own draws instead.
+//
+// Derived draws (the NumPy statement of the same rules lives in the test oracle):
+//   symbols   n -> block n/16, word (n/4)%4, byte n%4, & (M-1)
+//   uniform   i -> block i/4, word i%4, * 2^-32                         (double)
+//   CN(0,1)   i -> block i/2, words (2(i%2), 2(i%2)+1) = (x0, x1):
+//             sqrt(-ln((x0+.5) 2^-32)) * exp(2 pi j x1 2^-32)            (Box-Muller)
+#pragma once
+#include "common.hpp"
+
+namespace mcle {
+
+enum : uint32_t { STREAM_DATA = 0, STREAM_NOISE = 1, STREAM_CHAN = 2, STREAM_PHASE = 3 };
+
+struct Words4 {
+    uint32_t w[4];
+};
+
+__host__ __device__ __forceinline__ Words4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2,
+                                                         uint32_t c3, uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (uint32_t)p1;
+        c3 = (uint32_t)p0;
+        c0 = n0;
+        c2 = n2;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    Words4 o;
+    o.w[0] = c0;
+    o.w[1] = c1;
+    o.w[2] = c2;
+    o.w[3] = c3;
+    return o;
+}
+
+struct Rng {
+    uint32_t k0, k1, r0, r1;
+    __host__ __device__ Rng(uint64_t seed, uint64_t realization)
+        : k0((uint32_t)seed), k1((uint32_t)(seed >> 32)), r0((uint32_t)realization),
+          r1((uint32_t)(realization >> 32)) {}
+    __host__ __device__ __forceinline__ Words4 block(uint32_t stream, uint32_t blk) const {
+        return philox4x32_10(blk, stream, r0, r1, k0, k1);
+    }
+};
+
+// ---- Box-Muller ---------------------------------------------------------------------------
+// sigma = sqrt(variance of the complex sample); returns sigma * CN(0,1)
+__device__ __forceinline__ float2 cn_from_words(uint32_t x0, uint32_t x1, float sigma) {
+    const float u = fmaf((float)x0, 0x1p-32f, 0x1p-33f);
+    const float v = (float)x1 * 0x1p-32f;  // revolutions
+    // -ln(u) = -log2(u) * ln2 ; v_log_f32 / v_sqrt_f32 / v_sin_f32 / v_cos_f32 (input in turns)
+    const float rad = sigma * __builtin_amdgcn_sqrtf(-0.69314718055994531f * __builtin_amdgcn_logf(u));
+    float2 z;
+    z.x = rad * __builtin_amdgcn_cosf(v);
+    z.y = rad * __builtin_amdgcn_sinf(v);
+    return z;
+}
+__device__ __forceinline__ double2 cn_from_words(uint32_t x0, uint32_t x1, double sigma) {
+    const double u = ((double)x0 + 0.5) * 0x1p-32;
+    const double ang = 2.0 * 3.14159265358979323846 * ((double)x1 * 0x1p-32);
+    const double rad = sigma * sqrt(-log(u));
+    double s, c;
+    sincos(ang, &s, &c);
+    double2 z;
+    z.x = rad * c;
+    z.y = rad * s;
+    return z;
+}
+
+// complex sample i of (stream): one Philox call, half of it used
+template <typename T>
+__device__ __forceinline__ cx<T> cn_sample(const Rng& rng, uint32_t stream, uint64_t i, T sigma) {
+    const Words4 b = rng.block(stream, (uint32_t)(i >> 1));
+    const int h = (int)(i & 1) * 2;
+    return cn_from_words(b.w[h], b.w[h + 1], sigma);
+}
+
+// samples 2*blk and 2*blk+1 from one Philox call
+template <typename T>
+__device__ __forceinline__ void cn_pair(const Rng& rng, uint32_t stream, uint32_t blk, T sigma,
+                                        cx<T>& z0, cx<T>& z1) {
+    const Words4 b = rng.block(stream, blk);
+    z0 = cn_from_words(b.w[0], b.w[1], sigma);
+    z1 = cn_from_words(b.w[2], b.w[3], sigma);
+}
+
+__device__ __forceinline__ double uniform_at(const Rng& rng, uint32_t stream, uint64_t i) {
+    const Words4 b = rng.block(stream, (uint32_t)(i >> 2));
+    return (double)b.w[i & 3] * 0x1p-32;
+}
+
+// symbol n of the data stream
+__device__ __forceinline__ uint32_t symbol_at(const Rng& rng, uint64_t n, uint32_t mask) {
+    const Words4 b = rng.block(STREAM_DATA, (uint32_t)(n >> 4));
+    return (b.w[(n >> 2) & 3] >> ((n & 3) * 8)) & mask;
+}
+
+}  // namespace mcle

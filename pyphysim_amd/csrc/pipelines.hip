@@ -1,0 +1,738 @@
+// pipelines.hip -- fused Monte Carlo pipelines: whole realizations generated, pushed through the
+// link and scored on-chip; only integer counters leave the GPU.
+//
+//   run_awgn         C1  apps/awgn_modulators/simulate_psk.py:51-115
+//   run_flat_fading  C2  SuChannel(JakesSampleGenerator) flat fading, y = h s + n, equalise y / h
+//   run_ofdm_tdl     C3  notebooks/TDL_and_OFDM.ipynb OfdmTdlSimulator._run_simulation
+//   run_mimo_ofdm    C4  apps/mimo/simulate_mimo.py:68-142 with per-antenna OFDM
+//
+// Randomness follows the mcle-philox-v1 contract (philox.hpp), keyed by the GLOBAL realization
+// index, so counters do not depend on grid shape, batch split or GPU count.  Draw ledger:
+//   DATA   symbol n of the realization (C4: n = c*Nt + a, the reference's flat index order)
+//   CHAN   C4: H[r][a] = sample r*Nt + a
+//   PHASE  C2/C3: phi[l][s] = uniform l*S + s, psi[l][s] = uniform L*S + l*S + s   (S taps)
+//   NOISE  C1/C2: sample n; C3: sample j of the faded stream; C4: sample r*row + j, row = n_sym*(N+cp)
+#include "fft.hpp"
+#include "jakes.hpp"
+#include "mimo.hpp"
+#include "modem.hpp"
+#include "philox.hpp"
+
+namespace mcle {
+
+constexpr int kPipeBlock = 256;
+constexpr int kMaxTable = 256;  // Philox symbols are bytes
+
+// per-realization {sym, bit} error partials -> counter block (exact integer sums)
+__global__ __launch_bounds__(256) void k_fold_counters(const unsigned* __restrict__ ws,
+                                                       const unsigned* __restrict__ skipped, size_t n_real,
+                                                       unsigned long long n_sym, unsigned long long n_bits,
+                                                       mcle_counters* counters, uint32_t* __restrict__ sym_out,
+                                                       uint32_t* __restrict__ bit_out) {
+    unsigned long long se = 0, se2 = 0, be = 0, be2 = 0, ok = 0, sk = 0;
+    for (size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_real; r += (size_t)gridDim.x * blockDim.x) {
+        const bool skip = skipped && skipped[r];
+        const unsigned long long s = ws[2 * r], t = ws[2 * r + 1];
+        if (sym_out) sym_out[r] = skip ? 0xFFFFFFFFu : (uint32_t)s;
+        if (bit_out) bit_out[r] = skip ? 0xFFFFFFFFu : (uint32_t)t;
+        if (skip) {
+            ++sk;
+            continue;
+        }
+        ++ok;
+        se += s;
+        se2 += s * s;
+        be += t;
+        be2 += t * t;
+    }
+    if (!counters) return;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        se += __shfl_xor(se, off, 64);
+        se2 += __shfl_xor(se2, off, 64);
+        be += __shfl_xor(be, off, 64);
+        be2 += __shfl_xor(be2, off, 64);
+        ok += __shfl_xor(ok, off, 64);
+        sk += __shfl_xor(sk, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd((unsigned long long*)&counters->sym_errors, se);
+        atomicAdd((unsigned long long*)&counters->sym_errors_sq, se2);
+        atomicAdd((unsigned long long*)&counters->bit_errors, be);
+        atomicAdd((unsigned long long*)&counters->bit_errors_sq, be2);
+        atomicAdd((unsigned long long*)&counters->n_realizations, ok);
+        atomicAdd((unsigned long long*)&counters->n_skipped, sk);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        counters->n_symbols = n_sym;
+        counters->n_bits = n_bits;
+    }
+}
+
+// workgroup-wide sum of two unsigned values; result valid in thread 0
+__device__ __forceinline__ void block_sum2(unsigned& a, unsigned& b, unsigned* s_red) {
+    a = wave_sum_u32(a);
+    b = wave_sum_u32(b);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) {
+        s_red[2 * wave] = a;
+        s_red[2 * wave + 1] = b;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        a = 0;
+        b = 0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) {
+            a += s_red[2 * w];
+            b += s_red[2 * w + 1];
+        }
+    }
+}
+
+// =================================================================================================
+// C1 / C2: single-carrier links.  Work item = (realization, chunk of kChunk symbols); one workgroup
+// per item, 16 symbols per thread per pass (one Philox DATA block + eight NOISE blocks).
+// =================================================================================================
+constexpr int kChunk = 16384;
+constexpr int kMaxRays = 64;
+
+struct FlatParams {
+    int n_symbols;
+    int L;             // 0: pure AWGN (h = 1); > 0: Jakes rays
+    int rayleigh_iid;  // h ~ CN(0,1) per sample from the CHAN stream
+    double Fd, t0, dt;
+    double noise_sigma;
+};
+
+template <typename T>
+__global__ __launch_bounds__(kPipeBlock) void k_run_flat(FlatParams fp, ModemParams<T> mp, uint64_t seed,
+                                                         uint64_t first, uint64_t count, unsigned* __restrict__ ws) {
+    __shared__ cx<T> s_table[kMaxTable];
+    __shared__ double s_w[kMaxRays], s_psi[kMaxRays];
+    __shared__ unsigned s_red[2 * (kPipeBlock / 64)];
+    load_table(mp, s_table);
+    const int chunks = (fp.n_symbols + kChunk - 1) / kChunk;
+    const uint64_t items = count * (uint64_t)chunks;
+    const T sigma = (T)fp.noise_sigma;
+    const T amp = fp.L > 0 ? (T)sqrt(1.0 / (double)fp.L) : (T)1;
+    const uint32_t mask = (uint32_t)(mp.M - 1);
+    for (uint64_t item = blockIdx.x; item < items; item += gridDim.x) {
+        const uint64_t rl = item / chunks;
+        const int chunk = (int)(item - rl * chunks);
+        const Rng rng(seed, first + rl);
+        __syncthreads();
+        if (fp.L > 0 && (int)threadIdx.x < fp.L) {
+            // fading_generators.py:421-425: phi then psi, 2*pi*rand(L, 1, 1)
+            const double two_pi = 6.283185307179586476925286766559;
+            const double phi = two_pi * uniform_at(rng, STREAM_PHASE, threadIdx.x);
+            const double psi = two_pi * uniform_at(rng, STREAM_PHASE, fp.L + threadIdx.x);
+            if (sizeof(T) == 8) {
+                s_w[threadIdx.x] = two_pi * fp.Fd * cos(phi);
+                s_psi[threadIdx.x] = psi;
+            } else {
+                s_w[threadIdx.x] = fp.Fd * cos(phi);
+                s_psi[threadIdx.x] = psi / two_pi;
+            }
+        }
+        __syncthreads();
+        unsigned se = 0, be = 0;
+        const int n_begin = chunk * kChunk;
+        const int n_end = min(n_begin + kChunk, fp.n_symbols);
+        for (int g0 = n_begin + (int)threadIdx.x * 16; g0 < n_end; g0 += kPipeBlock * 16) {
+            const Words4 dw = rng.block(STREAM_DATA, (uint32_t)(g0 >> 4));
+#pragma unroll
+            for (int pr = 0; pr < 8; ++pr) {
+                cx<T> z[2];
+                cn_pair<T>(rng, STREAM_NOISE, (uint32_t)((g0 >> 1) + pr), sigma, z[0], z[1]);
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int j = 2 * pr + e, n = g0 + j;
+                    if (n < n_end) {
+                        const int tx = (int)((dw.w[j >> 2] >> ((j & 3) * 8)) & mask);
+                        const cx<T> s = s_table[tx];
+                        cx<T> r;
+                        if (fp.L > 0) {
+                            const double t = jakes_time(fp.t0, fp.dt, (double)n);
+                            T hr = 0, hi = 0;
+                            for (int l = 0; l < fp.L; ++l) {
+                                const cx<T> ray = jakes_ray<T>(s_w[l], s_psi[l], t);
+                                hr += ray.x;
+                                hi += ray.y;
+                            }
+                            const cx<T> h = mk<T>(amp * hr, amp * hi);
+                            r = cdivide(cadd(cmul(h, s), z[e]), h);
+                        } else if (fp.rayleigh_iid) {
+                            const cx<T> h = cn_sample<T>(rng, STREAM_CHAN, (uint64_t)n, (T)1);
+                            r = cdivide(cadd(cmul(h, s), z[e]), h);
+                        } else {
+                            r = cadd(s, z[e]);
+                        }
+                        const unsigned x = (unsigned)(tx ^ demod_one(mp, s_table, r));
+                        se += (x != 0u);
+                        be += __popc(x);
+                    }
+                }
+            }
+        }
+        block_sum2(se, be, s_red);
+        if (threadIdx.x == 0 && (se | be)) {
+            atomicAdd(&ws[2 * rl], se);
+            atomicAdd(&ws[2 * rl + 1], be);
+        }
+    }
+}
+
+// =================================================================================================
+// C4: NA x NA flat MIMO + per-antenna OFDM.  One workgroup per realization; the NA antenna streams
+// of one OFDM symbol live in LDS and are transformed together.
+// =================================================================================================
+struct MimoParams {
+    int cp, num_used, n_ofdm_sym;
+    int mmse;
+    double noise_var;
+};
+
+template <typename T, int N, int NA>
+__global__ __launch_bounds__(kPipeBlock) void k_run_mimo_ofdm(MimoParams pp, ModemParams<T> mp, uint64_t seed,
+                                                              uint64_t first, uint64_t count,
+                                                              const cx<T>* __restrict__ g_tw,
+                                                              unsigned* __restrict__ ws,
+                                                              unsigned* __restrict__ skipped) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cx<T>* s_x = reinterpret_cast<cx<T>*>(smem);        // [NA][N]
+    cx<T>* s_tw = s_x + NA * N;                          // [N]
+    cx<T>* s_table = s_tw + N;                           // [kMaxTable]
+    cx<T>* s_H = s_table + kMaxTable;                    // [NA*NA]
+    cx<T>* s_G = s_H + NA * NA;                          // [NA*NA]
+    unsigned* s_red = reinterpret_cast<unsigned*>(s_G + NA * NA);  // [8] + flag
+    unsigned char* s_idx = reinterpret_cast<unsigned char*>(s_red + 16);  // [NA*num_used]
+
+    const int tid = threadIdx.x;
+    for (int k = tid; k < N; k += kPipeBlock) s_tw[k] = g_tw[k];
+    load_table(mp, s_table);
+    const int U = pp.num_used, cp = pp.cp;
+    const int per_sym = U * NA;                       // data symbols per OFDM symbol (all antennas)
+    const uint64_t row = (uint64_t)pp.n_ofdm_sym * (N + cp);
+    const T sigma = (T)sqrt(pp.noise_var);
+    const T tx_scale = (T)(1.0 / sqrt((double)NA) / sqrt((double)(U + cp)));  // encode / sqrt(Nt), ifft power scale
+    const double rx_scale = sqrt((double)(U + cp)) / (double)N;               // fft / sqrt(power scale)
+    const uint32_t mask = (uint32_t)(mp.M - 1);
+
+    for (uint64_t rl = blockIdx.x; rl < count; rl += gridDim.x) {
+        const Rng rng(seed, first + rl);
+        __syncthreads();
+        if (tid < NA * NA) s_H[tid] = cn_sample<T>(rng, STREAM_CHAN, (uint64_t)tid, (T)1);
+        __syncthreads();
+        if (tid == 0) {
+            double2 H[NA][NA], G[NA][NA];
+#pragma unroll
+            for (int r = 0; r < NA; ++r)
+#pragma unroll
+                for (int a = 0; a < NA; ++a) H[r][a] = mk<double>((double)s_H[r * NA + a].x, (double)s_H[r * NA + a].y);
+            const bool ok = blast_filter<NA, NA>(H, pp.mmse ? pp.noise_var : 0.0, G);
+#pragma unroll
+            for (int a = 0; a < NA; ++a)
+#pragma unroll
+                for (int r = 0; r < NA; ++r)
+                    s_G[a * NA + r] = mk<T>((T)(G[a][r].x * rx_scale), (T)(G[a][r].y * rx_scale));
+            s_red[15] = ok ? 0u : 1u;
+        }
+        cx<T> H[NA][NA];
+#pragma unroll
+        for (int r = 0; r < NA; ++r)
+#pragma unroll
+            for (int a = 0; a < NA; ++a) H[r][a] = s_H[r * NA + a];
+
+        unsigned se = 0, be = 0;
+        for (int os = 0; os < pp.n_ofdm_sym; ++os) {
+            // ---- transmit: symbols -> bins (Blast.encode's F-order split + OFDM subcarrier map) ----
+            if (U != N) {
+                for (int p = tid; p < NA * N; p += kPipeBlock) s_x[p] = mk<T>(0, 0);
+                __syncthreads();
+            }
+            const uint64_t n_first = (uint64_t)os * per_sym;
+            const uint64_t n_last = n_first + per_sym;
+            for (uint64_t blk = (n_first >> 4) + tid; blk <= ((n_last - 1) >> 4); blk += kPipeBlock) {
+                const Words4 dw = rng.block(STREAM_DATA, (uint32_t)blk);
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const uint64_t n = (blk << 4) + j;
+                    if (n >= n_first && n < n_last) {
+                        const int tx = (int)((dw.w[j >> 2] >> ((j & 3) * 8)) & mask);
+                        const int nl = (int)(n - n_first);
+                        const int a = nl % NA, d = nl / NA;
+                        s_idx[nl] = (unsigned char)tx;
+                        s_x[a * N + ofdm_bin(d, N, U)] = cscale(s_table[tx], tx_scale);
+                    }
+                }
+            }
+            __syncthreads();
+            fft_dif<T, N, true>(s_x, NA, N, s_tw);  // time samples, digit-reversed positions
+            // ---- channel: R = H T + noise on the samples that survive CP removal ----
+            for (int j = tid; j < N / 2; j += kPipeBlock) {
+                const int half = j / (N / 4), rest = j - half * (N / 4);
+                const int p0 = 2 * half * (N / 4) + rest, p1 = p0 + N / 4;
+                const int m0 = fft_index_of_pos<N>(p0);  // even; position p1 holds m0 + 1
+                cx<T> x0[NA], x1[NA];
+#pragma unroll
+                for (int a = 0; a < NA; ++a) {
+                    x0[a] = s_x[a * N + p0];
+                    x1[a] = s_x[a * N + p1];
+                }
+#pragma unroll
+                for (int r = 0; r < NA; ++r) {
+                    const uint64_t i0 = (uint64_t)r * row + (uint64_t)os * (N + cp) + cp + m0;
+                    cx<T> z0, z1;
+                    if ((i0 & 1) == 0) {
+                        cn_pair<T>(rng, STREAM_NOISE, (uint32_t)(i0 >> 1), sigma, z0, z1);
+                    } else {
+                        z0 = cn_sample<T>(rng, STREAM_NOISE, i0, sigma);
+                        z1 = cn_sample<T>(rng, STREAM_NOISE, i0 + 1, sigma);
+                    }
+#pragma unroll
+                    for (int a = 0; a < NA; ++a) {
+                        z0 = cfma(H[r][a], x0[a], z0);
+                        z1 = cfma(H[r][a], x1[a], z1);
+                    }
+                    s_x[r * N + p0] = z0;
+                    s_x[r * N + p1] = z1;
+                }
+            }
+            __syncthreads();
+            fft_dit<T, N, false>(s_x, NA, N, s_tw);  // bins, natural order
+            // ---- receive: Blast decode (G already carries the FFT scale), demodulate, count ----
+            cx<T> G[NA][NA];
+#pragma unroll
+            for (int a = 0; a < NA; ++a)
+#pragma unroll
+                for (int r = 0; r < NA; ++r) G[a][r] = s_G[a * NA + r];
+            for (int d = tid; d < U; d += kPipeBlock) {
+                const int bin = ofdm_bin(d, N, U);
+                cx<T> y[NA];
+#pragma unroll
+                for (int r = 0; r < NA; ++r) y[r] = s_x[r * N + bin];
+#pragma unroll
+                for (int a = 0; a < NA; ++a) {
+                    cx<T> est = mk<T>(0, 0);
+#pragma unroll
+                    for (int r = 0; r < NA; ++r) est = cfma(G[a][r], y[r], est);
+                    const unsigned x = (unsigned)((int)s_idx[d * NA + a] ^ demod_one(mp, s_table, est));
+                    se += (x != 0u);
+                    be += __popc(x);
+                }
+            }
+            __syncthreads();
+        }
+        block_sum2(se, be, s_red);
+        if (tid == 0) {
+            ws[2 * rl] = se;
+            ws[2 * rl + 1] = be;
+            skipped[rl] = s_red[15];
+        }
+    }
+}
+
+// =================================================================================================
+// C3: SISO OFDM over a time-varying Jakes TDL channel with the one-tap equaliser.  One workgroup
+// (BLOCK threads) per realization.  LDS: current / previous time-domain symbol + receive buffer.
+// =================================================================================================
+struct TdlParams {
+    int cp, num_used, n_ofdm_sym;
+    int n_taps, L;
+    double noise_var, Fd, Ts, dt;
+    double tap_amp[MCLE_MAX_TAPS];   // sqrt(p_i / L)
+    int tap_delay[MCLE_MAX_TAPS];
+};
+
+template <typename T, int N, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_run_ofdm_tdl(TdlParams pp, ModemParams<T> mp, uint64_t seed,
+                                                        uint64_t first, uint64_t count,
+                                                        const cx<T>* __restrict__ g_tw, unsigned* __restrict__ ws) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cx<T>* s_a = reinterpret_cast<cx<T>*>(smem);   // [N] time-domain symbol (ping)
+    cx<T>* s_b = s_a + N;                           // [N] time-domain symbol (pong)
+    cx<T>* s_y = s_b + N;                           // [N] received symbol
+    cx<T>* s_tw = s_y + N;                          // [N]
+    cx<T>* s_table = s_tw + N;                      // [kMaxTable]
+    cx<T>* s_mean = s_table + kMaxTable;            // [MCLE_MAX_TAPS]
+    cx<T>* s_part = s_mean + MCLE_MAX_TAPS;         // [MCLE_MAX_TAPS][BLOCK/64]
+    double* s_w = reinterpret_cast<double*>(s_part + MCLE_MAX_TAPS * (BLOCK / 64));  // [taps*L]
+    double* s_psi = s_w + MCLE_MAX_TAPS * kMaxRays / 4;                              // [taps*L]
+    unsigned* s_red = reinterpret_cast<unsigned*>(s_psi + MCLE_MAX_TAPS * kMaxRays / 4);
+    unsigned char* s_idx = reinterpret_cast<unsigned char*>(s_red + 16);             // [num_used]
+
+    const int tid = threadIdx.x;
+    for (int k = tid; k < N; k += BLOCK) s_tw[k] = g_tw[k];
+    load_table(mp, s_table);
+    const int U = pp.num_used, cp = pp.cp, S = pp.n_taps, L = pp.L;
+    const int dmax = pp.tap_delay[S - 1];
+    const T sigma = (T)sqrt(pp.noise_var);
+    const T tx_scale = (T)(1.0 / sqrt((double)(U + cp)));
+    const T rx_scale = (T)(sqrt((double)(U + cp)) / (double)N);
+    const uint32_t mask = (uint32_t)(mp.M - 1);
+    const int lane = tid & 63, wave = tid >> 6;
+
+    for (uint64_t rl = blockIdx.x; rl < count; rl += gridDim.x) {
+        const Rng rng(seed, first + rl);
+        __syncthreads();
+        // Jakes phases for (L, taps): TdlChannel ctor re-draw, fading.py:796-798
+        for (int q = tid; q < S * L; q += BLOCK) {
+            const int l = q / S, s = q - l * S;
+            const double two_pi = 6.283185307179586476925286766559;
+            const double phi = two_pi * uniform_at(rng, STREAM_PHASE, (uint64_t)(l * S + s));
+            const double psi = two_pi * uniform_at(rng, STREAM_PHASE, (uint64_t)(L * S + l * S + s));
+            if (sizeof(T) == 8) {
+                s_w[s * L + l] = two_pi * pp.Fd * cos(phi);
+                s_psi[s * L + l] = psi;
+            } else {
+                s_w[s * L + l] = pp.Fd * cos(phi);
+                s_psi[s * L + l] = psi / two_pi;
+            }
+        }
+        cx<T>* cur = s_a;
+        cx<T>* prev = s_b;
+        unsigned se = 0, be = 0;
+        for (int os = 0; os < pp.n_ofdm_sym; ++os) {
+            for (int p = tid; p < N; p += BLOCK) cur[p] = mk<T>(0, 0);
+            __syncthreads();
+            const uint64_t n_first = (uint64_t)os * U, n_last = n_first + U;
+            for (uint64_t blk = (n_first >> 4) + tid; blk <= ((n_last - 1) >> 4); blk += BLOCK) {
+                const Words4 dw = rng.block(STREAM_DATA, (uint32_t)blk);
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const uint64_t n = (blk << 4) + j;
+                    if (n >= n_first && n < n_last) {
+                        const int tx = (int)((dw.w[j >> 2] >> ((j & 3) * 8)) & mask);
+                        const int d = (int)(n - n_first);
+                        s_idx[d] = (unsigned char)tx;
+                        cur[ofdm_bin(d, N, U)] = cscale(s_table[tx], tx_scale);
+                    }
+                }
+            }
+            __syncthreads();
+            fft_dif<T, N, true>(cur, 1, N, s_tw);
+            // ---- channel + noise for the N samples kept after CP removal; tap means on the fly ----
+            const uint64_t sym0 = (uint64_t)os * (N + cp);  // absolute index of this symbol's first sample
+            for (int i = 0; i < S; ++i) {
+                T are = 0, aim = 0;
+                // samples j' in [0, N+cp) of this symbol contribute to the mean of tap i (ofdm.py:545-547)
+                for (int jp = tid; jp < N + cp; jp += BLOCK) {
+                    const double t = jakes_time(pp.Ts, pp.dt, (double)(sym0 + jp));
+                    T gr = 0, gi = 0;
+                    for (int l = 0; l < L; ++l) {
+                        const cx<T> ray = jakes_ray<T>(s_w[i * L + l], s_psi[i * L + l], t);
+                        gr += ray.x;
+                        gi += ray.y;
+                    }
+                    are += gr;
+                    aim += gi;
+                }
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) {
+                    are += __shfl_xor(are, off, 64);
+                    aim += __shfl_xor(aim, off, 64);
+                }
+                if (lane == 0) s_part[i * (BLOCK / 64) + wave] = mk<T>(are, aim);
+            }
+            __syncthreads();
+            if (tid < S) {
+                T re = 0, im = 0;
+                for (int w = 0; w < BLOCK / 64; ++w) {
+                    re += s_part[tid * (BLOCK / 64) + w].x;
+                    im += s_part[tid * (BLOCK / 64) + w].y;
+                }
+                const T a = (T)pp.tap_amp[tid] / (T)(N + cp);
+                s_mean[tid] = mk<T>(re * a, im * a);
+            }
+            for (int m = tid; m < N; m += BLOCK) {
+                const uint64_t jabs = sym0 + cp + m;  // absolute sample index of output sample m
+                cx<T> acc = cn_sample<T>(rng, STREAM_NOISE, jabs, sigma);
+                cx<T> sig = mk<T>(0, 0);
+                for (int i = 0; i < S; ++i) {
+                    const int d = pp.tap_delay[i];
+                    const long long jsrc = (long long)jabs - d;  // sample the tap multiplies
+                    if (jsrc < 0) continue;                      // before the start of the stream
+                    const int q = cp + m - d;                    // its index inside this OFDM symbol
+                    cx<T> xs;
+                    if (q >= 0) {
+                        xs = cur[fft_pos_of_index<N>((m - d + N) & (N - 1))];
+                    } else {
+                        // inter-symbol interference: sample N+cp+q of the previous symbol
+                        const int qp = N + cp + q;
+                        xs = qp >= cp ? prev[fft_pos_of_index<N>(qp - cp)] : prev[fft_pos_of_index<N>(N - cp + qp)];
+                    }
+                    const double t = jakes_time(pp.Ts, pp.dt, (double)jsrc);
+                    T gr = 0, gi = 0;
+                    for (int l = 0; l < L; ++l) {
+                        const cx<T> ray = jakes_ray<T>(s_w[i * L + l], s_psi[i * L + l], t);
+                        gr += ray.x;
+                        gi += ray.y;
+                    }
+                    const T a = (T)pp.tap_amp[i];
+                    sig = cadd(sig, cmul(mk<T>(a * gr, a * gi), xs));
+                }
+                s_y[fft_pos_of_index<N>(m)] = cadd(sig, acc);
+            }
+            __syncthreads();
+            fft_dit<T, N, false>(s_y, 1, N, s_tw);
+            for (int d = tid; d < U; d += BLOCK) {
+                const int bin = ofdm_bin(d, N, U);
+                cx<T> h = mk<T>(0, 0);
+                for (int i = 0; i < S; ++i) h = cfma(s_mean[i], s_tw[(bin * pp.tap_delay[i]) & (N - 1)], h);
+                const cx<T> eq = cdivide(cscale(s_y[bin], rx_scale), h);
+                const unsigned x = (unsigned)((int)s_idx[d] ^ demod_one(mp, s_table, eq));
+                se += (x != 0u);
+                be += __popc(x);
+            }
+            __syncthreads();
+            cx<T>* tmp = cur;
+            cur = prev;
+            prev = tmp;
+        }
+        (void)dmax;
+        block_sum2(se, be, s_red);
+        if (tid == 0) {
+            ws[2 * rl] = se;
+            ws[2 * rl + 1] = be;
+        }
+    }
+}
+
+// ---- host side -----------------------------------------------------------------------------------
+template <typename T> ModemParams<T> pipe_modem(const mcle_ctx* ctx, int method) {
+    ModemParams<T> p;
+    if (sizeof(T) == 8)
+        p.g_table = reinterpret_cast<const cx<T>*>(ctx->d_table_f64);
+    else
+        p.g_table = reinterpret_cast<const cx<T>*>(ctx->d_table_f32);
+    p.M = ctx->M;
+    p.bits = ctx->bits;
+    p.method = method;
+    p.qam_scale = (T)ctx->qam_scale;
+    p.qam_L = ctx->qam_L;
+    p.half_bits = ctx->bits / 2;
+    return p;
+}
+
+int check_pipe(const mcle_ctx* ctx, int dtype, int method, const void* cfg) {
+    MCLE_REQUIRE(ctx != nullptr && cfg != nullptr, "null argument");
+    MCLE_REQUIRE(dtype == MCLE_F32 || dtype == MCLE_F64, "dtype must be MCLE_F32 or MCLE_F64");
+    MCLE_REQUIRE(ctx->M > 0, "no constellation set (mcle_set_constellation)");
+    MCLE_REQUIRE(ctx->M <= kMaxTable, "fused pipelines draw symbols as bytes: M <= %d", kMaxTable);
+    MCLE_REQUIRE(method == MCLE_DEMOD_MINDIST || method == MCLE_DEMOD_QAM_SLICER, "bad demodulation method");
+    MCLE_REQUIRE(method != MCLE_DEMOD_QAM_SLICER || ctx->kind == MCLE_CONST_QAM,
+                 "the slicer needs a square Gray QAM constellation (kind MCLE_CONST_QAM)");
+    return MCLE_OK;
+}
+
+// workspace = [2*count] error partials + [count] skip flags, zeroed
+int pipe_workspace(mcle_ctx* ctx, uint64_t count, unsigned** ws, unsigned** skipped) {
+    void* p = nullptr;
+    int rc = ctx->scratch((size_t)count * 3 * sizeof(unsigned), &p);
+    if (rc) return rc;
+    MCLE_HIP(hipMemsetAsync(p, 0, (size_t)count * 3 * sizeof(unsigned), ctx->stream));
+    *ws = (unsigned*)p;
+    *skipped = (unsigned*)p + 2 * count;
+    return MCLE_OK;
+}
+
+int pipe_fold(mcle_ctx* ctx, const unsigned* ws, const unsigned* skipped, uint64_t count, uint64_t n_sym,
+              mcle_counters* d_counters, uint32_t* d_sym, uint32_t* d_bit) {
+    hipLaunchKernelGGL(k_fold_counters, dim3(grid_for(ctx, count, 256, 1)), dim3(256), 0, ctx->stream, ws, skipped,
+                       (size_t)count, (unsigned long long)n_sym, (unsigned long long)n_sym * ctx->bits, d_counters,
+                       d_sym, d_bit);
+    MCLE_LAUNCH_CHECK();
+    return MCLE_OK;
+}
+
+template <typename T>
+int run_flat_impl(mcle_ctx* ctx, const FlatParams& fp, int method, uint64_t seed, uint64_t first, uint64_t count,
+                  mcle_counters* d_counters, uint32_t* d_sym, uint32_t* d_bit) {
+    unsigned *ws = nullptr, *sk = nullptr;
+    int rc = pipe_workspace(ctx, count, &ws, &sk);
+    if (rc) return rc;
+    const uint64_t items = count * (uint64_t)((fp.n_symbols + kChunk - 1) / kChunk);
+    const uint64_t cap = (uint64_t)ctx->n_cu * 8;
+    const unsigned grid = (unsigned)(items < cap ? items : cap);
+    hipLaunchKernelGGL(k_run_flat<T>, dim3(grid), dim3(kPipeBlock), 0, ctx->stream, fp, pipe_modem<T>(ctx, method),
+                       seed, first, count, ws);
+    MCLE_LAUNCH_CHECK();
+    return pipe_fold(ctx, ws, nullptr, count, (uint64_t)fp.n_symbols, d_counters, d_sym, d_bit);
+}
+
+template <typename T, int N, int NA>
+int run_mimo_impl(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, uint64_t seed, uint64_t first, uint64_t count,
+                  mcle_counters* d_counters, uint32_t* d_sym, uint32_t* d_bit) {
+    unsigned *ws = nullptr, *sk = nullptr;
+    int rc = pipe_workspace(ctx, count, &ws, &sk);
+    if (rc) return rc;
+    void* tw = nullptr;
+    if ((rc = ctx->get_twiddles(N, sizeof(T) == 8 ? MCLE_F64 : MCLE_F32, &tw))) return rc;
+    MimoParams pp{cfg->cp_size, cfg->num_used, cfg->n_ofdm_sym, cfg->mmse, cfg->noise_var};
+    const size_t lds = (size_t)(NA * N + N + kMaxTable + 2 * NA * NA) * sizeof(cx<T>) + 16 * sizeof(unsigned) +
+                       (size_t)NA * cfg->num_used;
+    auto kern = k_run_mimo_ofdm<T, N, NA>;
+    MCLE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int per_cu = (int)((size_t)160 * 1024 / (lds + 512));  // gfx950: 160 KiB of LDS per CU
+    if (per_cu < 1) per_cu = 1;
+    if (per_cu > 8) per_cu = 8;
+    const uint64_t cap = (uint64_t)ctx->n_cu * per_cu;
+    const unsigned grid = (unsigned)(count < cap ? count : cap);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kPipeBlock), lds, ctx->stream, pp, pipe_modem<T>(ctx, cfg->demod_method),
+                       seed, first, count, (const cx<T>*)tw, ws, sk);
+    MCLE_LAUNCH_CHECK();
+    return pipe_fold(ctx, ws, sk, count, (uint64_t)NA * cfg->num_used * cfg->n_ofdm_sym, d_counters, d_sym, d_bit);
+}
+
+template <typename T, int N>
+int run_tdl_impl(mcle_ctx* ctx, const mcle_ofdm_tdl_cfg* cfg, uint64_t seed, uint64_t first, uint64_t count,
+                 mcle_counters* d_counters, uint32_t* d_sym, uint32_t* d_bit) {
+    constexpr int BLOCK = N >= 1024 ? 256 : (N >= 256 ? 128 : 64);
+    unsigned *ws = nullptr, *sk = nullptr;
+    int rc = pipe_workspace(ctx, count, &ws, &sk);
+    if (rc) return rc;
+    void* tw = nullptr;
+    if ((rc = ctx->get_twiddles(N, sizeof(T) == 8 ? MCLE_F64 : MCLE_F32, &tw))) return rc;
+    TdlParams pp;
+    pp.cp = cfg->cp_size;
+    pp.num_used = cfg->num_used;
+    pp.n_ofdm_sym = cfg->n_ofdm_sym;
+    pp.n_taps = cfg->n_taps;
+    pp.L = cfg->L;
+    pp.noise_var = cfg->noise_var;
+    pp.Fd = cfg->Fd;
+    pp.Ts = cfg->Ts;
+    // numpy.arange(t0, ..., Ts*1.0000000001): delta = fl(fl(t0 + step) - t0), t0 = Ts (fading_generators.py:459-462)
+    {
+        volatile double step = cfg->Ts * 1.0000000001;
+        volatile double nxt = cfg->Ts + step;
+        pp.dt = nxt - cfg->Ts;
+    }
+    for (int i = 0; i < MCLE_MAX_TAPS; ++i) {
+        pp.tap_amp[i] = i < cfg->n_taps ? std::sqrt(cfg->tap_power[i]) * std::sqrt(1.0 / (double)cfg->L) : 0.0;
+        pp.tap_delay[i] = i < cfg->n_taps ? cfg->tap_delay[i] : 0;
+    }
+    const size_t lds = (size_t)(4 * N + kMaxTable + MCLE_MAX_TAPS + MCLE_MAX_TAPS * (BLOCK / 64)) * sizeof(cx<T>) +
+                       2 * (size_t)(MCLE_MAX_TAPS * kMaxRays / 4) * sizeof(double) + 16 * sizeof(unsigned) +
+                       (size_t)cfg->num_used + 16;
+    auto kern = k_run_ofdm_tdl<T, N, BLOCK>;
+    MCLE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int per_cu = (int)((size_t)160 * 1024 / (lds + 512));
+    if (per_cu < 1) per_cu = 1;
+    if (per_cu > 2048 / BLOCK) per_cu = 2048 / BLOCK;
+    const uint64_t cap = (uint64_t)ctx->n_cu * per_cu;
+    const unsigned grid = (unsigned)(count < cap ? count : cap);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(BLOCK), lds, ctx->stream, pp, pipe_modem<T>(ctx, cfg->demod_method), seed,
+                       first, count, (const cx<T>*)tw, ws);
+    MCLE_LAUNCH_CHECK();
+    return pipe_fold(ctx, ws, nullptr, count, (uint64_t)cfg->num_used * cfg->n_ofdm_sym, d_counters, d_sym, d_bit);
+}
+
+}  // namespace mcle
+
+using namespace mcle;
+
+extern "C" {
+
+int mcle_run_awgn(mcle_ctx* ctx, int dtype, const mcle_awgn_cfg* cfg, uint64_t seed, uint64_t first, uint64_t count,
+                  mcle_counters* d_counters, uint32_t* d_sym_err, uint32_t* d_bit_err) {
+    int rc = check_pipe(ctx, dtype, cfg ? cfg->demod_method : 0, cfg);
+    if (rc) return rc;
+    MCLE_REQUIRE(cfg->n_symbols >= 1, "n_symbols must be positive");
+    MCLE_REQUIRE(cfg->noise_var >= 0.0, "noise variance must be non-negative");
+    MCLE_REQUIRE(count <= 0x7fffffffull, "at most 2^31-1 realizations per call");
+    if (count == 0) return MCLE_OK;
+    if ((rc = ctx->bind())) return rc;
+    FlatParams fp{cfg->n_symbols, 0, 0, 0.0, 0.0, 0.0, std::sqrt(cfg->noise_var)};
+    if (dtype == MCLE_F32)
+        return run_flat_impl<float>(ctx, fp, cfg->demod_method, seed, first, count, d_counters, d_sym_err, d_bit_err);
+    return run_flat_impl<double>(ctx, fp, cfg->demod_method, seed, first, count, d_counters, d_sym_err, d_bit_err);
+}
+
+int mcle_run_flat_fading(mcle_ctx* ctx, int dtype, const mcle_flat_cfg* cfg, uint64_t seed, uint64_t first,
+                         uint64_t count, mcle_counters* d_counters, uint32_t* d_sym_err, uint32_t* d_bit_err) {
+    int rc = check_pipe(ctx, dtype, cfg ? cfg->demod_method : 0, cfg);
+    if (rc) return rc;
+    MCLE_REQUIRE(cfg->n_symbols >= 1, "n_symbols must be positive");
+    MCLE_REQUIRE(cfg->noise_var >= 0.0, "noise variance must be non-negative");
+    MCLE_REQUIRE(cfg->rayleigh_iid || (cfg->L >= 1 && cfg->L <= kMaxRays), "L must be in [1, %d]", kMaxRays);
+    MCLE_REQUIRE(cfg->rayleigh_iid || cfg->Ts > 0.0, "Ts must be positive");
+    MCLE_REQUIRE(count <= 0x7fffffffull, "at most 2^31-1 realizations per call");
+    if (count == 0) return MCLE_OK;
+    if ((rc = ctx->bind())) return rc;
+    FlatParams fp;
+    fp.n_symbols = cfg->n_symbols;
+    fp.L = cfg->rayleigh_iid ? 0 : cfg->L;
+    fp.rayleigh_iid = cfg->rayleigh_iid ? 1 : 0;
+    fp.Fd = cfg->Fd;
+    fp.t0 = cfg->Ts;  // the Jakes ctor consumed t = 0 (fading_generators.py:348-351)
+    {
+        volatile double step = cfg->Ts * 1.0000000001;
+        volatile double nxt = cfg->Ts + step;
+        fp.dt = nxt - cfg->Ts;
+    }
+    fp.noise_sigma = std::sqrt(cfg->noise_var);
+    if (dtype == MCLE_F32)
+        return run_flat_impl<float>(ctx, fp, cfg->demod_method, seed, first, count, d_counters, d_sym_err, d_bit_err);
+    return run_flat_impl<double>(ctx, fp, cfg->demod_method, seed, first, count, d_counters, d_sym_err, d_bit_err);
+}
+
+int mcle_run_mimo_ofdm(mcle_ctx* ctx, int dtype, const mcle_mimo_ofdm_cfg* cfg, uint64_t seed, uint64_t first,
+                       uint64_t count, mcle_counters* d_counters, uint32_t* d_sym_err, uint32_t* d_bit_err) {
+    int rc = check_pipe(ctx, dtype, cfg ? cfg->demod_method : 0, cfg);
+    if (rc) return rc;
+    MCLE_REQUIRE(cfg->nt == cfg->nr && (cfg->nt == 2 || cfg->nt == 4), "fused MIMO pipeline supports 2x2 and 4x4");
+    MCLE_REQUIRE(cfg->cp_size >= 0 && cfg->cp_size <= cfg->fft_size,
+                 "cp_size must be nonnegative and cannot be greater than fft_size");
+    MCLE_REQUIRE(cfg->num_used >= 2 && cfg->num_used % 2 == 0 && cfg->num_used <= cfg->fft_size,
+                 "Number of used subcarriers must be a multiple of 2 and at most fft_size");
+    MCLE_REQUIRE(cfg->n_ofdm_sym >= 1, "n_ofdm_sym must be positive");
+    MCLE_REQUIRE(cfg->noise_var >= 0.0, "Noise variance must be a non-negative value.");
+    MCLE_REQUIRE(count <= 0x7fffffffull, "at most 2^31-1 realizations per call");
+    if (count == 0) return MCLE_OK;
+    if ((rc = ctx->bind())) return rc;
+#define MCLE_RUN(N_, NA_)                                                                                         \
+    if (cfg->fft_size == N_ && cfg->nt == NA_)                                                                    \
+        return dtype == MCLE_F32                                                                                  \
+                   ? run_mimo_impl<float, N_, NA_>(ctx, cfg, seed, first, count, d_counters, d_sym_err, d_bit_err) \
+                   : run_mimo_impl<double, N_, NA_>(ctx, cfg, seed, first, count, d_counters, d_sym_err, d_bit_err);
+    MCLE_RUN(64, 2) MCLE_RUN(64, 4) MCLE_RUN(256, 2) MCLE_RUN(256, 4) MCLE_RUN(1024, 2) MCLE_RUN(1024, 4)
+#undef MCLE_RUN
+    set_error("fused MIMO pipeline supports fft_size in {64, 256, 1024} (got %d)", cfg->fft_size);
+    return MCLE_E_INVAL;
+}
+
+int mcle_run_ofdm_tdl(mcle_ctx* ctx, int dtype, const mcle_ofdm_tdl_cfg* cfg, uint64_t seed, uint64_t first,
+                      uint64_t count, mcle_counters* d_counters, uint32_t* d_sym_err, uint32_t* d_bit_err) {
+    int rc = check_pipe(ctx, dtype, cfg ? cfg->demod_method : 0, cfg);
+    if (rc) return rc;
+    MCLE_REQUIRE(cfg->cp_size >= 0 && cfg->cp_size <= cfg->fft_size,
+                 "cp_size must be nonnegative and cannot be greater than fft_size");
+    MCLE_REQUIRE(cfg->num_used >= 2 && cfg->num_used % 2 == 0 && cfg->num_used <= cfg->fft_size,
+                 "Number of used subcarriers must be a multiple of 2 and at most fft_size");
+    MCLE_REQUIRE(cfg->n_ofdm_sym >= 1, "n_ofdm_sym must be positive");
+    MCLE_REQUIRE(cfg->n_taps >= 1 && cfg->n_taps <= MCLE_MAX_TAPS, "n_taps must be in [1, %d]", MCLE_MAX_TAPS);
+    MCLE_REQUIRE(cfg->L >= 1 && cfg->n_taps * cfg->L <= MCLE_MAX_TAPS * kMaxRays / 4, "too many rays (taps * L <= %d)",
+                 MCLE_MAX_TAPS * kMaxRays / 4);
+    MCLE_REQUIRE(cfg->Ts > 0.0 && cfg->noise_var >= 0.0, "Ts must be positive and noise_var non-negative");
+    for (int i = 0; i < cfg->n_taps; ++i) {
+        MCLE_REQUIRE(cfg->tap_delay[i] >= 0 && (i == 0 || cfg->tap_delay[i] > cfg->tap_delay[i - 1]),
+                     "tap delays must be non-negative and strictly increasing");
+        MCLE_REQUIRE(cfg->tap_delay[i] <= cfg->fft_size, "tap delay beyond one OFDM symbol is not supported");
+    }
+    MCLE_REQUIRE(count <= 0x7fffffffull, "at most 2^31-1 realizations per call");
+    if (count == 0) return MCLE_OK;
+    if ((rc = ctx->bind())) return rc;
+#define MCLE_RUN(N_)                                                                                        \
+    if (cfg->fft_size == N_)                                                                                \
+        return dtype == MCLE_F32                                                                            \
+                   ? run_tdl_impl<float, N_>(ctx, cfg, seed, first, count, d_counters, d_sym_err, d_bit_err) \
+                   : run_tdl_impl<double, N_>(ctx, cfg, seed, first, count, d_counters, d_sym_err, d_bit_err);
+    MCLE_RUN(64) MCLE_RUN(128) MCLE_RUN(256) MCLE_RUN(512) MCLE_RUN(1024) MCLE_RUN(2048)
+#undef MCLE_RUN
+    set_error("fused OFDM/TDL pipeline supports fft_size in {64, ..., 2048} (got %d)", cfg->fft_size);
+    return MCLE_E_INVAL;
+}
+
+}  // extern "C"

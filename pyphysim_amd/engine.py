@@ -1,0 +1,428 @@
+"""Engine: one libmcle context (one GPU, one stream) with device arrays and typed wrappers.
+
+Everything here is plumbing around the C ABI (include/mcle.h); the arithmetic runs in the HIP
+kernels under pyphysim_amd/csrc.  NumPy arrays passed to an operator are copied to the device
+and the result is copied back (drop-in behaviour, PCIe-bound); :class:`DeviceArray` arguments
+stay resident and results come back as DeviceArray.
+"""
+import ctypes
+import math
+from ctypes import byref, c_double, c_float, c_int, c_int32, c_void_p
+
+import numpy as np
+
+from . import _lib
+from ._lib import (CONST_BPSK, CONST_GENERIC, CONST_QAM, DEMOD_MINDIST, DEMOD_QAM_SLICER, MCLE_F32, MCLE_F64,
+                   AwgnCfg, Counters, FlatCfg, McleError, MimoOfdmCfg, OfdmTdlCfg, check)
+
+
+class DeviceArray:
+    """A typed, shaped view of device memory owned by an Engine."""
+
+    def __init__(self, engine, shape, dtype):
+        self.engine = engine
+        self.shape = tuple(int(s) for s in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+        self.dtype = np.dtype(dtype)
+        self.size = int(np.prod(self.shape)) if self.shape else 1
+        self.nbytes = self.size * self.dtype.itemsize
+        self._ptr = c_void_p(0)
+        if self.nbytes:
+            check(engine.lib.mcle_malloc(engine.ctx, self.nbytes, byref(self._ptr)))
+
+    @property
+    def ptr(self):
+        return self._ptr
+
+    def reshape(self, *shape):
+        shape = shape[0] if len(shape) == 1 and isinstance(shape[0], (tuple, list)) else shape
+        view = DeviceArray.__new__(DeviceArray)
+        view.engine, view.dtype, view.size, view.nbytes = self.engine, self.dtype, self.size, self.nbytes
+        view.shape = tuple(np.empty(self.shape, dtype=np.bool_).reshape(shape).shape)
+        view._ptr, view._base = self._ptr, self
+        return view
+
+    def get(self):
+        out = np.empty(self.shape, dtype=self.dtype)
+        if self.nbytes:
+            check(self.engine.lib.mcle_memcpy_d2h(self.engine.ctx, out.ctypes.data_as(c_void_p), self._ptr,
+                                                  self.nbytes))
+        return out
+
+    def set(self, host):
+        host = np.ascontiguousarray(host, dtype=self.dtype)
+        if host.size != self.size:
+            raise ValueError("size mismatch: %d vs %d" % (host.size, self.size))
+        if self.nbytes:
+            check(self.engine.lib.mcle_memcpy_h2d(self.engine.ctx, self._ptr, host.ctypes.data_as(c_void_p),
+                                                  self.nbytes))
+        return self
+
+    def zero(self):
+        if self.nbytes:
+            check(self.engine.lib.mcle_memset(self.engine.ctx, self._ptr, 0, self.nbytes))
+        return self
+
+    def __del__(self):
+        try:
+            if getattr(self, "_base", None) is None and self._ptr and self._ptr.value and self.engine.ctx:
+                self.engine.lib.mcle_free(self.engine.ctx, self._ptr)
+                self._ptr = c_void_p(0)
+        except Exception:
+            pass
+
+
+class Engine:
+    """One context on one MI355X.  ``dtype`` ('f64' parity / 'f32' throughput) is the default
+    arithmetic of the operator calls; every call can override it."""
+
+    def __init__(self, device=0, dtype="f64"):
+        self.lib = _lib.load()
+        self.ctx = c_void_p(0)
+        self.dtype = _lib.dtype_code(dtype)
+        ctx = c_void_p(0)
+        check(self.lib.mcle_ctx_create(int(device), byref(ctx)))
+        self.ctx = ctx
+        self.device = int(device)
+        self.M = 0
+        self._table_key = None
+        n_cu, lds = c_int(0), c_int(0)
+        name = ctypes.create_string_buffer(128)
+        check(self.lib.mcle_ctx_device_info(self.ctx, byref(n_cu), byref(lds), name, 128))
+        self.n_cu, self.device_name = n_cu.value, name.value.decode()
+
+    def close(self):
+        if self.ctx:
+            self.lib.mcle_ctx_destroy(self.ctx)
+            self.ctx = c_void_p(0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- plumbing ---------------------------------------------------------------------------
+    def sync(self):
+        check(self.lib.mcle_ctx_sync(self.ctx))
+
+    def use_stream(self, hip_stream_handle):
+        """Adopt an external hipStream_t, e.g. ``torch.cuda.current_stream().cuda_stream``."""
+        check(self.lib.mcle_ctx_set_stream(self.ctx, c_void_p(int(hip_stream_handle) if hip_stream_handle else 0)))
+
+    def empty(self, shape, dtype):
+        return DeviceArray(self, shape, dtype)
+
+    def zeros(self, shape, dtype):
+        return DeviceArray(self, shape, dtype).zero()
+
+    def to_device(self, host, dtype=None):
+        host = np.ascontiguousarray(host, dtype=dtype)
+        return DeviceArray(self, host.shape, host.dtype).set(host)
+
+    def timer_start(self):
+        check(self.lib.mcle_timer_start(self.ctx))
+
+    def timer_stop_ms(self):
+        ms = c_float(0)
+        check(self.lib.mcle_timer_stop_ms(self.ctx, byref(ms)))
+        return ms.value
+
+    def _dt(self, dtype):
+        return self.dtype if dtype is None else _lib.dtype_code(dtype)
+
+    def _cin(self, x, dt):
+        """complex input -> (DeviceArray, was_host)"""
+        if isinstance(x, DeviceArray):
+            if x.dtype != np.dtype(_lib.np_complex(dt)):
+                raise TypeError("device array is %s but the call runs in %s" % (x.dtype, _lib.np_complex(dt)))
+            return x, False
+        return self.to_device(np.asarray(x), _lib.np_complex(dt)), True
+
+    def _iin(self, x):
+        if isinstance(x, DeviceArray):
+            if x.dtype != np.dtype(np.int32):
+                raise TypeError("index device arrays must be int32")
+            return x, False
+        return self.to_device(np.asarray(x), np.int32), True
+
+    @staticmethod
+    def _out(arr, host, as_dtype=None):
+        if not host:
+            return arr
+        res = arr.get()
+        return res.astype(as_dtype) if as_dtype is not None else res
+
+    # ---- constellation ----------------------------------------------------------------------
+    def set_constellation(self, symbols, kind=CONST_GENERIC):
+        symbols = np.ascontiguousarray(symbols, dtype=np.complex128).reshape(-1)
+        key = (symbols.tobytes(), kind)
+        if key == self._table_key:
+            return
+        view = symbols.view(np.float64)
+        check(self.lib.mcle_set_constellation(self.ctx, view.ctypes.data_as(ctypes.POINTER(c_double)),
+                                              symbols.size, int(kind)))
+        self._table_key, self.M = key, symbols.size
+
+    # ---- a2/a3/a4 ---------------------------------------------------------------------------
+    def modulate(self, idx, dtype=None):
+        dt = self._dt(dtype)
+        d_idx, host = self._iin(idx)
+        out = self.empty(d_idx.shape, _lib.np_complex(dt))
+        rc = self.lib.mcle_modulate(self.ctx, dt, d_idx.ptr, out.ptr, d_idx.size)
+        if rc:
+            msg = self.lib.mcle_last_error().decode()
+            if "between 0 and 2^M" in msg:
+                raise ValueError(msg)
+            raise McleError(msg)
+        return self._out(out, host)
+
+    def demodulate(self, rx, method=DEMOD_MINDIST, dtype=None):
+        dt = self._dt(dtype)
+        d_rx, host = self._cin(rx, dt)
+        out = self.empty(d_rx.shape, np.int32)
+        check(self.lib.mcle_demodulate(self.ctx, dt, int(method), d_rx.ptr, out.ptr, d_rx.size))
+        return self._out(out, host, np.int64)
+
+    def count_errors(self, tx_idx, rx_idx, bits_per_symbol, n_real=1):
+        """-> (counters dict, per-realization symbol errors, per-realization bit errors)."""
+        a, _ = self._iin(tx_idx)
+        b, _ = self._iin(rx_idx)
+        if a.size != b.size or a.size % n_real:
+            raise ValueError("size mismatch")
+        cnt = self.zeros(1, np.dtype((np.void, ctypes.sizeof(Counters))))
+        se, be = self.empty(n_real, np.uint32), self.empty(n_real, np.uint32)
+        check(self.lib.mcle_count_errors(self.ctx, a.ptr, b.ptr, a.size // n_real, n_real, int(bits_per_symbol),
+                                         cnt.ptr, se.ptr, be.ptr))
+        return self._counters(cnt), se.get(), be.get()
+
+    def demod_count(self, rx, tx_idx, n_real=1, method=DEMOD_MINDIST, dtype=None):
+        dt = self._dt(dtype)
+        d_rx, _ = self._cin(rx, dt)
+        a, _ = self._iin(tx_idx)
+        if a.size != d_rx.size or a.size % n_real:
+            raise ValueError("size mismatch")
+        cnt = self.zeros(1, np.dtype((np.void, ctypes.sizeof(Counters))))
+        se, be = self.empty(n_real, np.uint32), self.empty(n_real, np.uint32)
+        check(self.lib.mcle_demod_count(self.ctx, dt, int(method), d_rx.ptr, a.ptr, a.size // n_real, n_real,
+                                        cnt.ptr, se.ptr, be.ptr))
+        return self._counters(cnt), se.get(), be.get()
+
+    def _counters(self, cnt):
+        raw = cnt.get().tobytes()
+        return Counters.from_buffer_copy(raw).as_dict()
+
+    # ---- a5 ---------------------------------------------------------------------------------
+    def randn_c(self, n, seed, realization, stream=_lib.STREAM_NOISE, first=0, variance=1.0, dtype=None,
+                device=False):
+        dt = self._dt(dtype)
+        out = self.empty(n, _lib.np_complex(dt))
+        check(self.lib.mcle_randn_c(self.ctx, dt, int(seed), int(realization), int(stream), int(first),
+                                    float(variance), out.ptr, out.size))
+        return out if device else out.get()
+
+    def rand_symbols(self, n, M, seed, realization, first=0, device=False):
+        out = self.empty(n, np.int32)
+        check(self.lib.mcle_rand_symbols(self.ctx, int(seed), int(realization), int(first), int(M), out.ptr,
+                                         out.size))
+        return out if device else out.get().astype(np.int64)
+
+    def awgn_add(self, x, noise, noise_var, dtype=None):
+        dt = self._dt(dtype)
+        d_x, host = self._cin(x, dt)
+        d_n, _ = self._cin(noise, dt)
+        if d_x.size != d_n.size:
+            raise ValueError("size mismatch")
+        out = self.empty(d_x.shape, _lib.np_complex(dt))
+        check(self.lib.mcle_awgn_add(self.ctx, dt, d_x.ptr, d_n.ptr, float(noise_var), out.ptr, d_x.size))
+        return self._out(out, host)
+
+    def cdiv(self, num, den, dtype=None):
+        dt = self._dt(dtype)
+        a, host = self._cin(num, dt)
+        b, _ = self._cin(den, dt)
+        if a.size != b.size:
+            raise ValueError("size mismatch")
+        out = self.empty(a.shape, _lib.np_complex(dt))
+        check(self.lib.mcle_cdiv(self.ctx, dt, a.ptr, b.ptr, out.ptr, a.size))
+        return self._out(out, host)
+
+    # ---- a6/a9 ------------------------------------------------------------------------------
+    def jakes_generate(self, phi, psi, Fd, t0, dt_step, n_samples, tap_power=None, dtype=None, device=False):
+        """phi, psi: [L, n_streams]; returns h [n_streams, n_samples]."""
+        dt = self._dt(dtype)
+        phi = np.ascontiguousarray(phi, dtype=np.float64)
+        psi = np.ascontiguousarray(psi, dtype=np.float64)
+        L, S = phi.shape
+        out = self.empty((S, n_samples), _lib.np_complex(dt))
+        pw = None
+        if tap_power is not None:
+            pw_arr = np.ascontiguousarray(tap_power, dtype=np.float64)
+            pw = pw_arr.ctypes.data_as(ctypes.POINTER(c_double))
+        dp = ctypes.POINTER(c_double)
+        check(self.lib.mcle_jakes_generate(self.ctx, dt, phi.ctypes.data_as(dp), psi.ctypes.data_as(dp), L, S,
+                                           float(Fd), float(t0), float(dt_step), pw, out.ptr, int(n_samples)))
+        return out if device else out.get()
+
+    def tdl_apply(self, x, taps, delays, dtype=None):
+        dt = self._dt(dtype)
+        d_x, host = self._cin(x, dt)
+        d_g, _ = self._cin(taps, dt)
+        delays = np.ascontiguousarray(delays, dtype=np.int32)
+        n = d_x.size
+        if d_g.size != n * delays.size:
+            raise ValueError("taps must be [n_taps, n]")
+        out = self.empty(n + int(delays[-1]), _lib.np_complex(dt))
+        check(self.lib.mcle_tdl_apply(self.ctx, dt, d_x.ptr, d_g.ptr, delays.ctypes.data_as(ctypes.POINTER(c_int32)),
+                                      delays.size, out.ptr, n))
+        return self._out(out, host)
+
+    # ---- a10/a11 ----------------------------------------------------------------------------
+    def ofdm_modulate(self, x, fft_size, cp_size, num_used, batch=1, dtype=None):
+        dt = self._dt(dtype)
+        d_x, host = self._cin(x, dt)
+        n_in = d_x.size // batch
+        n_sym = -(-n_in // num_used)
+        out = self.empty((batch, n_sym * (fft_size + cp_size)), _lib.np_complex(dt))
+        rc = self.lib.mcle_ofdm_modulate(self.ctx, dt, d_x.ptr, n_in, fft_size, cp_size, num_used, out.ptr, batch)
+        self._raise_value(rc)
+        return self._out(out, host)
+
+    def ofdm_demodulate(self, y, fft_size, cp_size, num_used, batch=1, dtype=None):
+        dt = self._dt(dtype)
+        d_y, host = self._cin(y, dt)
+        n_sym = (d_y.size // batch) // (fft_size + cp_size)
+        out = self.empty((batch, n_sym * num_used), _lib.np_complex(dt))
+        rc = self.lib.mcle_ofdm_demodulate(self.ctx, dt, d_y.ptr, n_sym, fft_size, cp_size, num_used, out.ptr, batch)
+        self._raise_value(rc)
+        return self._out(out, host)
+
+    def onetap_equalize(self, data, taps, delays, fft_size, cp_size, num_used, dtype=None):
+        dt = self._dt(dtype)
+        d_d, host = self._cin(data, dt)
+        d_g, _ = self._cin(taps, dt)
+        delays = np.ascontiguousarray(delays, dtype=np.int32)
+        n_sym = d_d.size // num_used
+        if d_g.size != delays.size * n_sym * (fft_size + cp_size):
+            raise ValueError("taps must be [n_taps, n_sym*(fft+cp)]")
+        out = self.empty(d_d.size, _lib.np_complex(dt))
+        check(self.lib.mcle_onetap_equalize(self.ctx, dt, d_d.ptr, d_g.ptr,
+                                            delays.ctypes.data_as(ctypes.POINTER(c_int32)), delays.size, n_sym,
+                                            fft_size, cp_size, num_used, out.ptr))
+        return self._out(out, host)
+
+    def _raise_value(self, rc):
+        if rc:
+            msg = self.lib.mcle_last_error().decode()
+            if rc == -1:
+                raise ValueError(msg)
+            raise McleError(msg)
+
+    # ---- a12 --------------------------------------------------------------------------------
+    def blast_encode(self, x, nt, batch=1, dtype=None):
+        dt = self._dt(dtype)
+        d_x, host = self._cin(x, dt)
+        n = d_x.size // batch
+        out = self.empty((batch, nt, n // nt if nt else 0), _lib.np_complex(dt))
+        self._raise_value(self.lib.mcle_blast_encode(self.ctx, dt, d_x.ptr, nt, n, out.ptr, batch))
+        return self._out(out, host)
+
+    def blast_filter(self, H, noise_var, dtype=None):
+        """H [batch, nr, nt] -> (G [batch, nt, nr], skipped [batch])."""
+        dt = self._dt(dtype)
+        d_H, host = self._cin(H, dt)
+        b, nr, nt = d_H.shape
+        G = self.empty((b, nt, nr), _lib.np_complex(dt))
+        sk = self.empty(b, np.uint32)
+        self._raise_value(self.lib.mcle_blast_filter(self.ctx, dt, d_H.ptr, nr, nt, float(noise_var), G.ptr, sk.ptr,
+                                                     b))
+        return self._out(G, host), sk.get()
+
+    def blast_decode(self, G, Y, dtype=None):
+        """G [batch, nt, nr], Y [batch, nr, ns] -> est [batch, nt*ns] (Fortran interleave)."""
+        dt = self._dt(dtype)
+        d_G, _ = self._cin(G, dt)
+        d_Y, host = self._cin(Y, dt)
+        b, nt, nr = d_G.shape
+        ns = d_Y.shape[-1]
+        out = self.empty((b, nt * ns), _lib.np_complex(dt))
+        self._raise_value(self.lib.mcle_blast_decode(self.ctx, dt, d_G.ptr, d_Y.ptr, nr, nt, ns, out.ptr, b))
+        return self._out(out, host)
+
+    def mimo_channel(self, H, X, noise=None, noise_var=0.0, dtype=None):
+        dt = self._dt(dtype)
+        d_H, _ = self._cin(H, dt)
+        d_X, host = self._cin(X, dt)
+        b, nr, nt = d_H.shape
+        ns = d_X.shape[-1]
+        d_n = None
+        if noise is not None:
+            d_n, _ = self._cin(noise, dt)
+        out = self.empty((b, nr, ns), _lib.np_complex(dt))
+        self._raise_value(self.lib.mcle_mimo_channel(self.ctx, dt, d_H.ptr, d_X.ptr, d_n.ptr if d_n else None,
+                                                     float(noise_var), nr, nt, ns, out.ptr, b))
+        return self._out(out, host)
+
+    # ---- fused pipelines --------------------------------------------------------------------
+    def _run(self, fn, cfg, seed, first, count, dtype, per_realization, counters=None):
+        dt = self._dt(dtype)
+        cnt = counters if counters is not None else self.zeros(1, np.dtype((np.void, ctypes.sizeof(Counters))))
+        se = be = None
+        if per_realization:
+            se, be = self.empty(count, np.uint32), self.empty(count, np.uint32)
+        check(fn(self.ctx, dt, byref(cfg), int(seed), int(first), int(count), cnt.ptr,
+                 se.ptr if se else None, be.ptr if be else None))
+        if counters is not None:
+            return None
+        res = self._counters(cnt)
+        if per_realization:
+            return res, se.get(), be.get()
+        return res
+
+    def new_counters(self):
+        return self.zeros(1, np.dtype((np.void, ctypes.sizeof(Counters))))
+
+    def read_counters(self, cnt):
+        return self._counters(cnt)
+
+    def run_awgn(self, n_symbols, noise_var, seed, first, count, method=DEMOD_MINDIST, dtype=None,
+                 per_realization=False, counters=None):
+        cfg = AwgnCfg(int(n_symbols), int(method), float(noise_var))
+        return self._run(self.lib.mcle_run_awgn, cfg, seed, first, count, dtype, per_realization, counters)
+
+    def run_flat_fading(self, n_symbols, noise_var, seed, first, count, Fd=100.0, Ts=1e-3, L=8,
+                        rayleigh_iid=False, method=DEMOD_MINDIST, dtype=None, per_realization=False,
+                        counters=None):
+        cfg = FlatCfg(int(n_symbols), int(method), float(noise_var), float(Fd), float(Ts), int(L),
+                      1 if rayleigh_iid else 0)
+        return self._run(self.lib.mcle_run_flat_fading, cfg, seed, first, count, dtype, per_realization, counters)
+
+    def run_ofdm_tdl(self, fft_size, cp_size, num_used, n_ofdm_sym, noise_var, tap_power, tap_delay, seed, first,
+                     count, Fd=10.0, Ts=1.0 / (15e3 * 1024), L=8, method=DEMOD_MINDIST, dtype=None,
+                     per_realization=False, counters=None):
+        cfg = OfdmTdlCfg()
+        cfg.fft_size, cfg.cp_size, cfg.num_used, cfg.n_ofdm_sym = int(fft_size), int(cp_size), int(num_used), int(
+            n_ofdm_sym)
+        cfg.demod_method, cfg.n_taps, cfg.L = int(method), len(tap_delay), int(L)
+        cfg.noise_var, cfg.Fd, cfg.Ts = float(noise_var), float(Fd), float(Ts)
+        if len(tap_delay) > _lib.MAX_TAPS or len(tap_power) != len(tap_delay):
+            raise ValueError("at most %d taps; powers and delays must match" % _lib.MAX_TAPS)
+        for i, (p, d) in enumerate(zip(tap_power, tap_delay)):
+            cfg.tap_power[i], cfg.tap_delay[i] = float(p), int(d)
+        return self._run(self.lib.mcle_run_ofdm_tdl, cfg, seed, first, count, dtype, per_realization, counters)
+
+    def run_mimo_ofdm(self, nt, nr, fft_size, cp_size, num_used, n_ofdm_sym, noise_var, seed, first, count,
+                      mmse=True, method=DEMOD_MINDIST, dtype=None, per_realization=False, counters=None):
+        cfg = MimoOfdmCfg(int(nt), int(nr), int(fft_size), int(cp_size), int(num_used), int(n_ofdm_sym),
+                          int(method), 1 if mmse else 0, float(noise_var))
+        return self._run(self.lib.mcle_run_mimo_ofdm, cfg, seed, first, count, dtype, per_realization, counters)
+
+
+_default = {}
+
+
+def get_engine(device=0):
+    """Process-wide default engine per device (created on first use)."""
+    eng = _default.get(device)
+    if eng is None:
+        eng = _default[device] = Engine(device)
+    return eng

@@ -1,0 +1,253 @@
+"""GPU: every per-operator HIP kernel (through the C ABI) against the reference-minted golden
+vectors and the NumPy oracle.  f64 instantiation: integers bit-exact, floats <= 1e-11 relative;
+f32 instantiation: floats <= 2e-5 relative, decisions allowed to differ only on boundary cases."""
+import numpy as np
+import pytest
+
+from helpers import golden_cases, relerr
+from oracle import channels as och, modem as omodem, ofdm as oofdm, philox as P
+from pyphysim_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+F64_TOL, F32_TOL = 1e-11, 2e-5
+TOL = {"f64": F64_TOL, "f32": F32_TOL}
+
+
+@pytest.mark.parametrize("M", [4, 16, 64, 256])
+@pytest.mark.parametrize("dt", ["f64", "f32"])
+def test_modulate_demodulate_qam(engine, golden_ops, M, dt):
+    table = golden_ops["qam%d" % M]
+    rx, idx, dec = (golden_ops["demod_qam%d_%s" % (M, k)] for k in ("rx", "idx", "dec"))
+    engine.set_constellation(table, _lib.CONST_QAM)
+    tx = engine.modulate(idx, dtype=dt)
+    assert relerr(tx, table[idx]) <= (0 if dt == "f64" else 1e-7)
+    got = engine.demodulate(rx, dtype=dt)
+    sl = engine.demodulate(rx, method=_lib.DEMOD_QAM_SLICER, dtype=dt)
+    if dt == "f64":
+        assert np.array_equal(got, dec) and np.array_equal(sl, dec)
+    else:
+        assert np.count_nonzero(got != dec) <= 2 and np.count_nonzero(sl != dec) <= 2
+    assert got.dtype == np.int64 and got.shape == dec.shape
+    cnt, se, be = engine.count_errors(idx, dec, int(np.log2(M)))
+    assert int(se[0]) == int(np.sum(idx != dec)) and int(be[0]) == int(golden_ops["demod_qam%d_biterr" % M])
+    assert cnt["sym_errors"] == int(se[0]) and cnt["bit_errors_sq"] == int(be[0]) ** 2
+    cnt2, se2, be2 = engine.demod_count(rx, idx, dtype="f64")
+    assert (int(se2[0]), int(be2[0])) == (int(se[0]), int(be[0]))
+
+
+def test_demodulate_psk_and_bpsk(engine, golden_ops):
+    engine.set_constellation(golden_ops["psk8"])
+    assert np.array_equal(engine.demodulate(golden_ops["demod_psk8_rx"]), golden_ops["demod_psk8_dec"])
+    engine.set_constellation(golden_ops["bpsk"], _lib.CONST_BPSK)
+    rx = np.array([0.3, -0.2, 1.7, -4.0, 0.0]) + 0j
+    assert list(engine.demodulate(rx)) == [0, 1, 0, 1, 0]
+    assert np.array_equal(engine.modulate(np.array([0, 1, 1, 0])), np.array([1, -1, -1, 1]) + 0j)
+
+
+def test_modulate_errors_and_edges(engine, golden_ops):
+    engine.set_constellation(golden_ops["qam16"], _lib.CONST_QAM)
+    with pytest.raises(ValueError):            # fundamental.py:196-199
+        engine.modulate(np.array([0, 16, 3]))
+    assert np.array_equal(engine.modulate(np.array([-1])), golden_ops["qam16"][[-1]])   # negatives wrap
+    assert engine.modulate(np.zeros(0, dtype=int)).shape == (0,)
+    assert engine.demodulate(np.zeros((0,), dtype=complex)).shape == (0,)
+    assert engine.demodulate(golden_ops["qam16"].reshape(4, 4)).shape == (4, 4)
+    engine.set_constellation(golden_ops["psk8"])
+    with pytest.raises(_lib.McleError):        # slicer needs a QAM table
+        engine.demodulate(np.ones(4, dtype=complex), method=_lib.DEMOD_QAM_SLICER)
+    with pytest.raises(_lib.McleError):        # and a QAM claim is verified against the reference layout
+        engine.set_constellation(golden_ops["psk16"], _lib.CONST_QAM)
+
+
+def test_count_errors_ragged_batches(engine):
+    rs = np.random.RandomState(3)
+    for n_real, n in ((1, 1), (7, 13), (300, 257), (3, 100003)):
+        a = rs.randint(0, 64, (n_real, n))
+        b = np.where(rs.rand(n_real, n) < 0.1, rs.randint(0, 64, (n_real, n)), a)
+        cnt, se, be = engine.count_errors(a, b, 6, n_real)
+        want_s = (a != b).sum(axis=1)
+        want_b = omodem.count_bit_errors(a, b, 1)
+        assert np.array_equal(se, want_s) and np.array_equal(be, want_b)
+        assert cnt["sym_errors"] == want_s.sum() and cnt["sym_errors_sq"] == int((want_s.astype(np.int64) ** 2).sum())
+        assert cnt["bit_errors"] == want_b.sum() and cnt["n_realizations"] == n_real
+        assert cnt["n_symbols"] == n and cnt["n_bits"] == 6 * n
+
+
+@pytest.mark.parametrize("dt", ["f64", "f32"])
+def test_philox_draws(engine, dt):
+    seed, r = 20260927, 123456789012
+    z = engine.randn_c(1001, seed, r, _lib.STREAM_NOISE, first=5, variance=0.25, dtype=dt)
+    want = 0.5 * P.cnormal(seed, r, 1001, P.STREAM_NOISE, offset=5)
+    assert relerr(z, want) <= (1e-13 if dt == "f64" else 3e-6)
+    s = engine.rand_symbols(999, 64, seed, r, first=3)
+    assert np.array_equal(s, P.symbols(seed, r, 999, 64, offset=3))
+
+
+@pytest.mark.parametrize("dt", ["f64", "f32"])
+def test_awgn_chain_injected(engine, dt):
+    """C1 with the reference's own draws injected: decisions / counters bit-exact (f64)."""
+    for kw, reals in golden_cases("c1_awgn"):
+        for g in reals:
+            if "noise" not in g:
+                continue
+            kind = _lib.CONST_QAM if kw["mod"] == "qam" else _lib.CONST_GENERIC
+            engine.set_constellation(g["table"], kind)
+            tx = engine.modulate(g["idx"], dtype=dt)
+            rx = engine.awgn_add(tx, g["noise"], float(g["noise_var"]), dtype=dt)
+            assert relerr(rx, g["rx"]) <= TOL[dt]
+            dec = engine.demodulate(rx, dtype=dt)
+            cnt, se, be = engine.count_errors(g["idx"], dec, omodem.level2bits(kw["M"]))
+            if dt == "f64":
+                assert np.array_equal(dec, g["decisions"])
+                assert (int(se[0]), int(be[0])) == (int(g["symbol_errors"]), int(g["bit_errors"]))
+            else:
+                assert abs(int(se[0]) - int(g["symbol_errors"])) <= 2
+
+
+@pytest.mark.parametrize("fft,cp,used", [(16, 4, 10), (64, 16, 52), (64, 0, 64), (1024, 16, 1024), (1024, 72, 600)])
+@pytest.mark.parametrize("dt", ["f64", "f32"])
+def test_ofdm_mod_demod(engine, golden_ops, fft, cp, used, dt):
+    key = "ofdm_%d_%d_%d" % (fft, cp, used)
+    x, tx, back = golden_ops[key + "_x"], golden_ops[key + "_tx"], golden_ops[key + "_back"]
+    got = engine.ofdm_modulate(x, fft, cp, used, dtype=dt).reshape(-1)
+    assert got.shape == tx.shape and relerr(got, tx) <= TOL[dt]
+    got_b = engine.ofdm_demodulate(tx, fft, cp, used, dtype=dt).reshape(-1)
+    assert got_b.shape == back.shape and relerr(got_b, back) <= TOL[dt] * 10
+    # round trip recovers the (zero padded) input: reference tests/modulators_package_test.py:606-650
+    assert relerr(got_b[:x.size], x) <= TOL[dt] * 10 and np.max(np.abs(got_b[x.size:])) <= TOL[dt] * 10
+
+
+def test_ofdm_sizes_batches_and_errors(engine):
+    rs = np.random.RandomState(5)
+    for fft in (16, 32, 128, 256, 512, 2048, 4096):
+        x = rs.randn(3, fft * 2) + 1j * rs.randn(3, fft * 2)
+        tx = engine.ofdm_modulate(x, fft, fft // 8, fft, batch=3)
+        want = np.stack([oofdm.modulate(x[b], fft, fft // 8, fft) for b in range(3)])
+        assert relerr(tx, want) <= F64_TOL
+        back = engine.ofdm_demodulate(tx, fft, fft // 8, fft, batch=3)
+        assert relerr(back, x) <= F64_TOL * 10
+    with pytest.raises(ValueError):
+        engine.ofdm_modulate(np.ones(8, dtype=complex), 16, 17, 16)      # ofdm.py:75-78
+    with pytest.raises(ValueError):
+        engine.ofdm_modulate(np.ones(8, dtype=complex), 16, 4, 18)       # ofdm.py:83-86
+    with pytest.raises(ValueError):
+        engine.ofdm_modulate(np.ones(8, dtype=complex), 16, 4, 7)        # ofdm.py:87-90
+
+
+@pytest.mark.parametrize("dt", ["f64", "f32"])
+def test_jakes_tdl_equalizer_injected(engine, dt):
+    """C2 / C3 with the reference's phi, psi and noise injected."""
+    for kw, reals in golden_cases("c2_flat_jakes"):
+        for g in reals:
+            if "noise" not in g:
+                continue
+            n = g["idx"].size
+            t, _ = och.jakes_time_axis(kw["Ts"], kw["Ts"], n)
+            dt_step = float(t[1] - t[0])
+            phi, psi = g["phi"].reshape(kw["L"], 1), g["psi"].reshape(kw["L"], 1)
+            h = engine.jakes_generate(phi, psi, kw["Fd"], kw["Ts"], dt_step, n, dtype=dt)
+            assert relerr(h, g["h"]) <= (1e-9 if dt == "f64" else 3e-5)
+            engine.set_constellation(g["table"], _lib.CONST_QAM)
+            tx = engine.modulate(g["idx"], dtype=dt)
+            faded = engine.tdl_apply(tx, h, [0], dtype=dt)
+            rx = engine.awgn_add(faded, g["noise"], float(g["noise_var"]), dtype=dt)
+            eq = engine.cdiv(rx, h.reshape(-1), dtype=dt)
+            assert relerr(eq, g["eq"]) <= (1e-8 if dt == "f64" else 2e-3)
+            dec = engine.demodulate(eq, dtype=dt)
+            if dt == "f64":
+                assert np.array_equal(dec, g["decisions"])
+            else:
+                assert np.count_nonzero(dec != g["decisions"]) <= 3
+    for kw, reals in golden_cases("c3_ofdm_tdl"):
+        for g in reals:
+            fft, cp = kw["fft_size"], kw["cp_size"]
+            used = kw["num_used"] or fft
+            n = g["tx"].size
+            S = len(g["delay_indexes"])
+            t, _ = och.jakes_time_axis(kw["Ts"], kw["Ts"], n)
+            phi, psi = g["phi"].reshape(kw["L"], S), g["psi"].reshape(kw["L"], S)
+            taps = engine.jakes_generate(phi, psi, kw["Fd"], kw["Ts"], float(t[1] - t[0]), n,
+                                         tap_power=g["tap_powers_linear"], dtype=dt)
+            assert relerr(taps, g["taps"]) <= (1e-9 if dt == "f64" else 3e-5)
+            faded = engine.tdl_apply(g["tx"], taps, g["delay_indexes"], dtype=dt)
+            assert faded.size == n + int(g["delay_indexes"][-1])
+            rx = engine.awgn_add(faded, g["noise"], float(g["noise_var"]), dtype=dt)
+            assert relerr(rx, g["rx"]) <= (1e-9 if dt == "f64" else 3e-5)
+            demod = engine.ofdm_demodulate(rx[:n], fft, cp, used, dtype=dt).reshape(-1)
+            assert relerr(demod, g["demod"]) <= (1e-9 if dt == "f64" else 1e-4)
+            eq = engine.onetap_equalize(demod, taps, g["delay_indexes"], fft, cp, used, dtype=dt)
+            assert relerr(eq, g["eq"]) <= (1e-8 if dt == "f64" else 2e-3)
+            engine.set_constellation(g["table"])
+            dec = engine.demodulate(eq, dtype=dt)
+            if dt == "f64":
+                assert np.array_equal(dec, g["decisions"])
+            else:
+                assert np.count_nonzero(dec != g["decisions"]) <= 3
+
+
+def test_tdl_matches_explicit_shifted_sum(engine):
+    """Property test of reference tests/channels_package_test.py:821-890 on random taps."""
+    rs = np.random.RandomState(11)
+    n, delays = 777, np.array([0, 3, 4, 19])
+    x = rs.randn(n) + 1j * rs.randn(n)
+    g = rs.randn(4, n) + 1j * rs.randn(4, n)
+    want = och.tdl_apply(x, g, delays)
+    assert relerr(engine.tdl_apply(x, g, delays), want) <= 1e-14
+
+
+@pytest.mark.parametrize("dt", ["f64", "f32"])
+def test_blast_injected(engine, golden_ops, dt):
+    H, x, nv = golden_ops["blast_H"], golden_ops["blast_x"], float(golden_ops["blast_nv"])
+    enc = engine.blast_encode(x, 4, dtype=dt)[0]
+    assert relerr(enc, golden_ops["blast_enc"]) <= (0 if dt == "f64" else 1e-7)
+    y = engine.mimo_channel(H[None], enc[None], dtype=dt)[0]
+    assert relerr(y, golden_ops["blast_y"]) <= TOL[dt]
+    for var, key in ((0.0, "blast_zf"), (nv, "blast_mmse")):
+        G, skipped = engine.blast_filter(H[None], var, dtype=dt)
+        assert skipped[0] == 0
+        est = engine.blast_decode(G, y[None], dtype=dt)[0]
+        assert relerr(est, golden_ops[key]) <= (1e-10 if dt == "f64" else 2e-4)
+    with pytest.raises(ValueError):                       # mimo.py:633-637
+        engine.blast_encode(x[:7], 4)
+    G, skipped = engine.blast_filter(np.ones((1, 4, 4), dtype=complex), 0.0)   # rank 1 -> flagged
+    assert skipped[0] == 1
+
+
+def test_blast_shapes(engine):
+    rs = np.random.RandomState(2)
+    from oracle import mimo as omimo
+    for nr, nt in ((1, 1), (2, 1), (2, 2), (3, 2), (3, 3), (4, 2), (4, 3), (4, 4)):
+        H = (rs.randn(5, nr, nt) + 1j * rs.randn(5, nr, nt)) / np.sqrt(2)
+        for nv in (0.0, 0.1):
+            G, sk = engine.blast_filter(H, nv)
+            want = np.stack([omimo.blast_receive_filter(H[b], nv) for b in range(5)])
+            assert relerr(G, want) <= 1e-10 and not sk.any()
+
+
+@pytest.mark.parametrize("dt", ["f64", "f32"])
+def test_mimo_ofdm_chain_injected(engine, dt):
+    """C4 staged operator by operator with the reference's H, data and noise injected."""
+    for kw, reals in golden_cases("c4_mimo_ofdm"):
+        for g in reals:
+            if "noise" not in g:
+                continue
+            nt, nr, fft, cp = kw["nt"], kw["nr"], kw["fft_size"], kw["cp_size"]
+            used = kw["num_used"] or fft
+            engine.set_constellation(g["table"], _lib.CONST_QAM)
+            sym = engine.modulate(g["idx"], dtype=dt)
+            X = engine.blast_encode(sym, nt, dtype=dt)[0]
+            T = engine.ofdm_modulate(X, fft, cp, used, batch=nt, dtype=dt)
+            assert relerr(T, g["T"]) <= TOL[dt]
+            R = engine.mimo_channel(g["H"][None], T[None], g["noise"][None], float(g["noise_var"]), dtype=dt)[0]
+            Y = engine.ofdm_demodulate(R, fft, cp, used, batch=nr, dtype=dt)
+            assert relerr(Y, g["Y"]) <= TOL[dt] * 10
+            G, sk = engine.blast_filter(g["H"][None], float(g["noise_var"]) if kw["mmse"] else 0.0, dtype=dt)
+            assert relerr(G[0], g["G"]) <= (1e-9 if dt == "f64" else 5e-4)
+            est = engine.blast_decode(G, Y[None], dtype=dt)[0]
+            assert relerr(est, g["est"]) <= (1e-9 if dt == "f64" else 2e-3)
+            dec = engine.demodulate(est, dtype=dt)
+            if dt == "f64":
+                assert np.array_equal(dec, g["decisions"])
+            else:
+                assert np.count_nonzero(dec != g["decisions"]) <= 4

@@ -1,0 +1,178 @@
+"""GPU: the fused on-chip pipelines against the NumPy oracle under COMMON RANDOM NUMBERS
+(identical mcle-philox-v1 keying on both sides), plus size-independent properties at the full
+BASELINE.json sizes.  f64 instantiation: per-realization error counts bit-exact; f32: |dSER| and
+|dBER| <= 1e-4 absolute (north_star tolerance)."""
+import numpy as np
+import pytest
+
+from oracle import chains, channels as och, modem as omodem
+from pyphysim_amd import _lib
+
+pytestmark = pytest.mark.gpu
+SEED = 20260927
+
+
+def oracle_counts(fn, first, count, **kw):
+    se, be = [], []
+    for r in range(first, first + count):
+        out = fn(chains.PhiloxRng(SEED, r), **kw)
+        se.append(out["symbol_errors"])
+        be.append(out["bit_errors"])
+    return np.array(se), np.array(be), out["num_symbols"], out["num_bits"]
+
+
+def check(res, se, be, want_se, want_be, nsym, nbits, exact):
+    cnt = res
+    assert cnt["n_realizations"] == len(want_se) and cnt["n_skipped"] == 0
+    assert cnt["n_symbols"] == nsym and cnt["n_bits"] == nbits
+    assert cnt["sym_errors"] == int(se.sum()) and cnt["bit_errors"] == int(be.sum())
+    assert cnt["sym_errors_sq"] == int((se.astype(np.int64) ** 2).sum())
+    assert cnt["bit_errors_sq"] == int((be.astype(np.int64) ** 2).sum())
+    if exact:
+        assert np.array_equal(se, want_se) and np.array_equal(be, want_be)
+    else:
+        n = len(want_se)
+        assert abs(int(se.sum()) - int(want_se.sum())) / (n * nsym) <= 1e-4
+        assert abs(int(be.sum()) - int(want_be.sum())) / (n * nbits) <= 1e-4
+
+
+@pytest.mark.parametrize("dt,exact", [("f64", True), ("f32", False)])
+@pytest.mark.parametrize("mod,M,N,snr", [("qam", 16, 10000, 10.0), ("qam", 64, 777, 18.0), ("psk", 8, 4096, 9.0),
+                                         ("bpsk", 2, 50, 2.0)])
+def test_awgn_pipeline(engine, dt, exact, mod, M, N, snr):
+    table = chains.constellation(mod, M)
+    engine.set_constellation(table, _lib.CONST_QAM if mod == "qam" else _lib.CONST_GENERIC)
+    first, count = 1000003, 6
+    want_se, want_be, nsym, nbits = oracle_counts(chains.chain_awgn, first, count, mod=mod, M=M, N=N, snr_db=snr)
+    nv = 1.0 / omodem.dB2Linear(snr)
+    res, se, be = engine.run_awgn(N, nv, SEED, first, count, dtype=dt, per_realization=True)
+    check(res, se, be, want_se, want_be, nsym, nbits, exact)
+    if mod == "qam":
+        res2, se2, be2 = engine.run_awgn(N, nv, SEED, first, count, method=_lib.DEMOD_QAM_SLICER, dtype=dt,
+                                         per_realization=True)
+        assert np.array_equal(se2, se) and np.array_equal(be2, be)
+
+
+@pytest.mark.parametrize("dt,exact", [("f64", True), ("f32", False)])
+def test_flat_fading_pipeline(engine, dt, exact):
+    kw = dict(mod="qam", M=64, N=20000, snr_db=20.0, Fd=100.0, Ts=1e-3, L=8)
+    engine.set_constellation(chains.constellation("qam", 64), _lib.CONST_QAM)
+    first, count = 77, 3
+    want_se, want_be, nsym, nbits = oracle_counts(chains.chain_flat_jakes, first, count, **kw)
+    res, se, be = engine.run_flat_fading(kw["N"], 1.0 / omodem.dB2Linear(20.0), SEED, first, count, Fd=100.0,
+                                         Ts=1e-3, L=8, dtype=dt, per_realization=True)
+    check(res, se, be, want_se, want_be, nsym, nbits, exact)
+
+
+@pytest.mark.parametrize("dt,exact", [("f64", True), ("f32", False)])
+@pytest.mark.parametrize("case", [0, 1])
+def test_ofdm_tdl_pipeline(engine, dt, exact, case):
+    kws = [dict(mod="qpsk", M=4, fft_size=1024, cp_size=16, num_used=None, n_ofdm_sym=1, snr_db=20.0, Fd=10.0,
+                Ts=1.0 / (15e3 * 1024), L=8, tap_powers_dB=(0.0, -3.0, -6.0, -9.0, -12.0),
+                tap_delays_samples=(0, 1, 2, 3, 4)),
+           dict(mod="qam", M=16, fft_size=64, cp_size=16, num_used=52, n_ofdm_sym=3, snr_db=25.0, Fd=50.0, Ts=1e-6,
+                L=8, tap_powers_dB=(0.0, -5.0, -10.0), tap_delays_samples=(0, 3, 7))]
+    kw = kws[case]
+    engine.set_constellation(chains.constellation(kw["mod"], kw["M"]),
+                             _lib.CONST_QAM if kw["mod"] == "qam" else _lib.CONST_GENERIC)
+    first, count = 5, 8
+    want_se, want_be, nsym, nbits = oracle_counts(chains.chain_ofdm_tdl, first, count, **kw)
+    p_lin, d_idx = och.discretize_profile(np.array(kw["tap_powers_dB"]), np.array(kw["tap_delays_samples"]) * kw["Ts"],
+                                          kw["Ts"])
+    res, se, be = engine.run_ofdm_tdl(kw["fft_size"], kw["cp_size"], kw["num_used"] or kw["fft_size"],
+                                      kw["n_ofdm_sym"], 1.0 / omodem.dB2Linear(kw["snr_db"]), p_lin, d_idx, SEED,
+                                      first, count, Fd=kw["Fd"], Ts=kw["Ts"], L=kw["L"], dtype=dt,
+                                      per_realization=True)
+    check(res, se, be, want_se, want_be, nsym, nbits, exact)
+
+
+@pytest.mark.parametrize("dt,exact", [("f64", True), ("f32", False)])
+@pytest.mark.parametrize("case", [0, 1, 2])
+def test_mimo_ofdm_pipeline(engine, dt, exact, case):
+    kws = [dict(mod="qam", M=64, nt=4, nr=4, fft_size=1024, cp_size=16, num_used=None, n_ofdm_sym=1, snr_db=25.0,
+                mmse=True),
+           dict(mod="qam", M=16, nt=2, nr=2, fft_size=64, cp_size=8, num_used=48, n_ofdm_sym=2, snr_db=15.0,
+                mmse=False),
+           dict(mod="qam", M=16, nt=4, nr=4, fft_size=256, cp_size=7, num_used=200, n_ofdm_sym=2, snr_db=18.0,
+                mmse=True)]
+    kw = kws[case]
+    engine.set_constellation(chains.constellation(kw["mod"], kw["M"]), _lib.CONST_QAM)
+    first, count = 31, 6
+    want_se, want_be, nsym, nbits = oracle_counts(chains.chain_mimo_ofdm, first, count, **kw)
+    res, se, be = engine.run_mimo_ofdm(kw["nt"], kw["nr"], kw["fft_size"], kw["cp_size"],
+                                       kw["num_used"] or kw["fft_size"], kw["n_ofdm_sym"],
+                                       1.0 / omodem.dB2Linear(kw["snr_db"]), SEED, first, count, mmse=kw["mmse"],
+                                       dtype=dt, per_realization=True)
+    check(res, se, be, want_se, want_be, nsym, nbits, exact)
+    res2, se2, be2 = engine.run_mimo_ofdm(kw["nt"], kw["nr"], kw["fft_size"], kw["cp_size"],
+                                          kw["num_used"] or kw["fft_size"], kw["n_ofdm_sym"],
+                                          1.0 / omodem.dB2Linear(kw["snr_db"]), SEED, first, count, mmse=kw["mmse"],
+                                          method=_lib.DEMOD_QAM_SLICER, dtype=dt, per_realization=True)
+    assert np.array_equal(se2, se) and np.array_equal(be2, be)
+
+
+def test_full_size_properties_c4(engine):
+    """BASELINE config 4 shape (4x4, 64-QAM, OFDM-1024) at batch sizes the oracle cannot reach."""
+    engine.set_constellation(chains.constellation("qam", 64), _lib.CONST_QAM)
+    args = dict(nt=4, nr=4, fft_size=1024, cp_size=16, num_used=1024, n_ofdm_sym=1)
+    nv = 1.0 / omodem.dB2Linear(25.0)
+    n = 20000
+    whole, se, be = engine.run_mimo_ofdm(noise_var=nv, seed=SEED, first=0, count=n, dtype="f32",
+                                         per_realization=True, **args)
+    # (1) shard invariance: any split of the realization range gives identical integer counters
+    parts = [engine.run_mimo_ofdm(noise_var=nv, seed=SEED, first=a, count=b - a, dtype="f32", **args)
+             for a, b in ((0, 1), (1, 7777), (7777, n))]
+    for k in ("n_realizations", "sym_errors", "sym_errors_sq", "bit_errors", "bit_errors_sq", "n_skipped"):
+        assert whole[k] == sum(p[k] for p in parts), k
+    # (2) same call twice is bit-identical (no order-dependent arithmetic in the counters)
+    again = engine.run_mimo_ofdm(noise_var=nv, seed=SEED, first=0, count=n, dtype="f32", **args)
+    assert again == whole
+    # (3) slicer and exhaustive minimum distance agree on every realization
+    _, se_s, be_s = engine.run_mimo_ofdm(noise_var=nv, seed=SEED, first=0, count=n, dtype="f32",
+                                         method=_lib.DEMOD_QAM_SLICER, per_realization=True, **args)
+    assert np.array_equal(se, se_s) and np.array_equal(be, be_s)
+    # (4) round trip: without noise zero forcing recovers every symbol
+    clean = engine.run_mimo_ofdm(noise_var=0.0, seed=SEED, first=0, count=2000, dtype="f32", mmse=False, **args)
+    assert clean["sym_errors"] == 0 and clean["bit_errors"] == 0 and clean["n_realizations"] + clean["n_skipped"] == 2000
+    # (5) sanity of the statistic itself: SER at 25 dB for this chain is ~0.27
+    ser = whole["sym_errors"] / (whole["n_realizations"] * whole["n_symbols"])
+    assert 0.2 < ser < 0.35 and whole["bit_errors"] >= whole["sym_errors"]
+    # (6) a different seed gives different counters, a different first index too
+    other = engine.run_mimo_ofdm(noise_var=nv, seed=SEED + 1, first=0, count=n, dtype="f32", **args)
+    assert other["sym_errors"] != whole["sym_errors"]
+
+
+def test_full_size_properties_c2_c3(engine):
+    engine.set_constellation(chains.constellation("qam", 64), _lib.CONST_QAM)
+    nv = 1.0 / omodem.dB2Linear(20.0)
+    a = engine.run_flat_fading(100000, nv, SEED, 0, 24, dtype="f32")
+    b = engine.run_flat_fading(100000, nv, SEED, 0, 10, dtype="f32")
+    c = engine.run_flat_fading(100000, nv, SEED, 10, 14, dtype="f32")
+    for k in ("sym_errors", "sym_errors_sq", "bit_errors", "bit_errors_sq", "n_realizations"):
+        assert a[k] == b[k] + c[k]
+    ser = a["sym_errors"] / (24 * 100000)
+    assert 0.1 < ser < 0.35                              # 0.22 at 20 dB
+    clean = engine.run_flat_fading(100000, 0.0, SEED, 0, 4, dtype="f32")
+    assert clean["sym_errors"] == 0
+    engine.set_constellation(chains.constellation("qpsk", 4))
+    p_lin, d_idx = och.discretize_profile(np.array([0.0, -3, -6, -9, -12]), np.arange(5) / (15e3 * 1024),
+                                          1.0 / (15e3 * 1024))
+    w = engine.run_ofdm_tdl(1024, 16, 1024, 1, nv, p_lin, d_idx, SEED, 0, 30000, dtype="f32")
+    w1 = engine.run_ofdm_tdl(1024, 16, 1024, 1, nv, p_lin, d_idx, SEED, 0, 12345, dtype="f32")
+    w2 = engine.run_ofdm_tdl(1024, 16, 1024, 1, nv, p_lin, d_idx, SEED, 12345, 30000 - 12345, dtype="f32")
+    for k in ("sym_errors", "sym_errors_sq", "bit_errors", "bit_errors_sq", "n_realizations"):
+        assert w[k] == w1[k] + w2[k]
+    assert 0.001 < w["sym_errors"] / (30000 * 1024) < 0.05   # 0.009
+    clean = engine.run_ofdm_tdl(1024, 16, 1024, 1, 0.0, p_lin, d_idx, SEED, 0, 500, dtype="f32")
+    assert clean["sym_errors"] == 0
+
+
+def test_pipeline_argument_errors(engine):
+    engine.set_constellation(chains.constellation("qam", 16), _lib.CONST_QAM)
+    with pytest.raises(_lib.McleError):
+        engine.run_mimo_ofdm(3, 3, 1024, 16, 1024, 1, 0.1, SEED, 0, 4)
+    with pytest.raises(_lib.McleError):
+        engine.run_mimo_ofdm(4, 4, 1024, 2000, 1024, 1, 0.1, SEED, 0, 4)
+    with pytest.raises(_lib.McleError):
+        engine.run_awgn(0, 0.1, SEED, 0, 4)
+    assert engine.run_awgn(100, 0.1, SEED, 0, 0)["n_realizations"] == 0

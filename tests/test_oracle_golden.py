@@ -1,0 +1,124 @@
+"""CPU: the oracle reproduces the reference-minted golden vectors (tests/golden/*.npz).
+
+The fixtures were written by oracle/make_golden.py from the reference itself
+(np.random.seed(seed) on the reference side, LegacyRng(seed) on the oracle side)."""
+import math
+
+import numpy as np
+import pytest
+
+from oracle import chains, channels as och, mimo as omimo, modem as omodem, ofdm as oofdm
+from helpers import golden_cases, relerr
+
+INT_KEYS = ("idx", "decisions", "symbol_errors", "bit_errors", "num_symbols", "num_bits", "delay_indexes")
+
+
+@pytest.mark.parametrize("M", [4, 16, 64, 256])
+def test_qam_tables(golden_ops, M):
+    assert np.array_equal(omodem.qam_constellation(M), golden_ops["qam%d" % M])
+    assert abs(np.mean(np.abs(golden_ops["qam%d" % M]) ** 2) - 1.0) < 1e-12
+
+
+@pytest.mark.parametrize("M", [2, 4, 8, 16])
+def test_psk_tables(golden_ops, M):
+    assert np.array_equal(omodem.psk_constellation(M), golden_ops["psk%d" % M])
+
+
+def test_known_constellations():
+    # reference tests/modulators_package_test.py:45-70,218-230 known answers
+    np.testing.assert_array_almost_equal(omodem.psk_constellation(4), [1, 1j, -1j, -1], decimal=8)
+    s = math.sqrt(2) / 2
+    np.testing.assert_array_almost_equal(omodem.psk_constellation(4, math.pi / 4),
+                                         [s + s * 1j, -s + s * 1j, s - s * 1j, -s - s * 1j], decimal=8)
+    np.testing.assert_array_almost_equal(
+        omodem.qam_constellation(4),
+        np.array([-1 + 1j, 1 + 1j, -1 - 1j, 1 - 1j]) / math.sqrt(2), decimal=8)
+    assert list(omodem.binary2gray(np.arange(8))) == [0, 1, 3, 2, 6, 7, 5, 4]
+    assert list(omodem.gray2binary(omodem.binary2gray(np.arange(10)))) == list(range(10))
+    assert [omodem.level2bits(n) for n in range(1, 20)] == [1, 1, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 4, 4, 4, 4, 5, 5, 5]
+
+
+@pytest.mark.parametrize("M", [4, 16, 64, 256])
+def test_demod_and_slicer(golden_ops, M):
+    rx, idx, dec = (golden_ops["demod_qam%d_%s" % (M, k)] for k in ("rx", "idx", "dec"))
+    table = golden_ops["qam%d" % M]
+    assert np.array_equal(omodem.demodulate(table, rx), dec)
+    assert np.array_equal(omodem.qam_slicer(M, rx), dec)
+    assert int(omodem.count_bit_errors(idx, dec)) == int(golden_ops["demod_qam%d_biterr" % M])
+
+
+def test_count_bit_errors_doc_example():
+    # reference util/misc.py:548-558
+    first = np.array([[2, 3, 3, 0], [1, 3, 1, 2]])
+    second = np.array([[0, 3, 2, 0], [2, 0, 1, 2]])
+    assert omodem.count_bit_errors(first, second) == 6
+    assert list(omodem.count_bit_errors(first, second, 0)) == [3, 2, 1, 0]
+    assert list(omodem.count_bit_errors(first, second, 1)) == [2, 4]
+
+
+@pytest.mark.parametrize("fft,cp,used", [(16, 4, 10), (16, 4, 14), (64, 16, 52), (64, 0, 64), (1024, 16, 1024),
+                                         (1024, 72, 600)])
+def test_ofdm(golden_ops, fft, cp, used):
+    key = "ofdm_%d_%d_%d" % (fft, cp, used)
+    assert np.array_equal(oofdm.used_subcarrier_indexes(fft, used), golden_ops[key + "_map"])
+    assert relerr(oofdm.modulate(golden_ops[key + "_x"], fft, cp, used), golden_ops[key + "_tx"]) < 1e-13
+    assert relerr(oofdm.demodulate(golden_ops[key + "_tx"], fft, cp, used), golden_ops[key + "_back"]) < 1e-13
+
+
+def test_ofdm_known_maps():
+    # reference modulators/ofdm.py:208-213 doc examples
+    assert list(oofdm.used_subcarrier_indexes(16, 10)) == [11, 12, 13, 14, 15, 1, 2, 3, 4, 5]
+    assert list(oofdm.used_subcarrier_indexes(16, 14)) == [9, 10, 11, 12, 13, 14, 15, 1, 2, 3, 4, 5, 6, 7]
+    with pytest.raises(ValueError):
+        oofdm.check_params(16, 17, 16)
+    with pytest.raises(ValueError):
+        oofdm.check_params(16, 4, 18)
+    with pytest.raises(ValueError):
+        oofdm.check_params(16, 4, 7)
+
+
+def test_tu_profile(golden_ops):
+    p, d = och.discretize_profile(*och.COST259_TU, float(golden_ops["tu_Ts"]))
+    assert np.array_equal(d, golden_ops["tu_delays"])
+    assert relerr(p, golden_ops["tu_powers_linear"]) < 1e-15
+    # reference tests/channels_package_test.py:745-746,782-783: 15 taps spanning 67 samples
+    assert d.size == 15 and d[-1] + 1 == 67 and list(d[:3]) == [0, 7, 16] and d[-1] == 66
+    assert abs(p.sum() - 1.0) < 1e-12
+
+
+def test_blast(golden_ops):
+    H, x = golden_ops["blast_H"], golden_ops["blast_x"]
+    assert np.array_equal(omimo.blast_encode(x, 4), golden_ops["blast_enc"])
+    assert relerr(omimo.blast_decode(golden_ops["blast_y"], H, 0.0), golden_ops["blast_zf"]) < 1e-12
+    assert relerr(omimo.blast_decode(golden_ops["blast_y"], H, float(golden_ops["blast_nv"])),
+                  golden_ops["blast_mmse"]) < 1e-12
+    assert relerr(golden_ops["blast_zf"], x) < 1e-10        # ZF recovers the data without noise
+    with pytest.raises(ValueError):
+        omimo.blast_encode(x[:7], 4)
+
+
+CHAIN_FN = {"c1_awgn": chains.chain_awgn, "c2_flat_jakes": chains.chain_flat_jakes,
+            "c3_ofdm_tdl": chains.chain_ofdm_tdl, "c4_mimo_ofdm": chains.chain_mimo_ofdm}
+
+
+@pytest.mark.parametrize("name", sorted(CHAIN_FN))
+def test_chain_matches_reference(name):
+    for kw, reals in golden_cases(name):
+        for g in reals:
+            mine = CHAIN_FN[name](chains.LegacyRng(int(g["seed"])), **kw)
+            for k, v in g.items():
+                if k == "seed":
+                    continue
+                if k in INT_KEYS:
+                    assert np.array_equal(np.asarray(mine[k]), np.asarray(v)), (name, k)
+                else:
+                    assert relerr(mine[k], v) <= 1e-12, (name, k)
+
+
+def test_onetap_fast_form_equals_literal():
+    kw, reals = golden_cases("c3_ofdm_tdl")[1]
+    g = reals[0]
+    a = oofdm.onetap_equalize(g["demod"], g["taps"], g["delay_indexes"], kw["fft_size"], kw["cp_size"], kw["num_used"])
+    b = oofdm.onetap_equalize_fast(g["demod"], g["taps"], g["delay_indexes"], kw["fft_size"], kw["cp_size"],
+                                   kw["num_used"])
+    assert relerr(a, g["eq"]) < 1e-12 and relerr(b, a) < 1e-12
