@@ -312,3 +312,51 @@ if __name__ == "__main__":
     golden_chains()
     for f in sorted(os.listdir(GOLD)):
         print("%8.1f KB  %s" % (os.path.getsize(os.path.join(GOLD, f)) / 1024.0, f))
+
+
+# ----------------------------------------------------------------------------- host logic
+def golden_framework():
+    """Known answers for the Result / SimulationParameters bookkeeping, from the reference."""
+    import json
+    from pyphysim.simulations.parameters import SimulationParameters as RP
+    from pyphysim.simulations.results import Result as RR
+    rs = np.random.RandomState(BASE_SEED + 5)
+    out = {}
+    vals = [int(v) for v in rs.randint(0, 50, 12)]
+    tots = [int(v) for v in rs.randint(60, 90, 12)]
+    r = RR("ser", RR.RATIOTYPE)
+    for v, t in zip(vals, tots):
+        r.update(v, t)
+    out["ratio"] = dict(values=vals, totals=tots, result=r.get_result(), mean=r.get_result_mean(),
+                        var=r.get_result_var(), ci95=list(r.get_confidence_interval(95)),
+                        ci99=list(r.get_confidence_interval(99)), state=[r._value, r._total, r._result_sum,
+                                                                        r._result_squared_sum, r.num_updates])
+    s = RR("errs", RR.SUMTYPE)
+    for v in vals:
+        s.update(v)
+    s2 = RR("errs", RR.SUMTYPE)
+    for v in tots:
+        s2.update(v)
+    s.merge(s2)
+    out["sum_merge"] = dict(a=vals, b=tots, state=[s._value, s._total, s._result_sum, s._result_squared_sum,
+                                                   s.num_updates], var=s.get_result_var())
+    c = RR.create("choice", RR.CHOICETYPE, 2, 4)
+    for v in (0, 3, 3, 1, 3):
+        c.update(v)
+    out["choice"] = dict(updates=[2, 0, 3, 3, 1, 3], result=[float(x) for x in c.get_result()])
+    p = RP.create({"SNR": np.array([0, 5, 10]), "M": [4, 16], "alpha": 0.5, "name": "x"})
+    p.set_unpack_parameter("SNR")
+    p.set_unpack_parameter("M")
+    lst = p.get_unpacked_params_list()
+    out["params"] = dict(order=[[int(q["M"]), int(q["SNR"])] for q in lst], n=p.get_num_unpacked_variations(),
+                         idx_snr5=[int(i) for i in p.get_pack_indexes({"SNR": 5})],
+                         idx_m16=[int(i) for i in p.get_pack_indexes({"M": 16})],
+                         idx_both=[int(i) for i in p.get_pack_indexes({"M": 16, "SNR": 10})],
+                         unpack_index=[q.unpack_index for q in lst])
+    with open(os.path.join(GOLD, "framework.json"), "w") as fh:
+        json.dump(out, fh, indent=1)
+    print("framework: ok")
+
+
+if __name__ == "__main__":
+    golden_framework()

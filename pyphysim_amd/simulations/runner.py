@@ -1,0 +1,361 @@
+"""SimulationRunner: the Monte Carlo repetition loop of the reference (simulations/runner.py:1076-1948)
+with the same overridables, plus BatchedSimulationRunner, which advances the loop by whole GPU
+batches of realizations and (optionally) shards every batch over torch.distributed ranks.
+
+Kept surface: rep_max, params, results, runned_reps, elapsed_time, set_results_filename,
+partial-result save / resume, progressbar_message, update_progress_function_style,
+_run_simulation, _keep_going, _on_simulate_start / finish, _on_simulate_current_params_start /
+finish, simulate(param_variation_index=None), SkipThisOne.  Not carried over (out of the hot
+path): configobj files, command-line parsing, ipyparallel,
+progress-bar widgets.
+"""
+import os
+import pickle
+import time
+
+from .parameters import SimulationParameters
+from .results import Result, SimulationResults
+
+
+class SkipThisOne(Exception):
+    """Raise inside _run_simulation to discard the current realization (runner.py:151-185)."""
+
+    def __init__(self, msg):
+        super().__init__()
+        self.msg = msg
+
+    def __str__(self):
+        return "SkipThisOne: {0}".format(self.msg)
+
+
+def _pretty_time(seconds):
+    seconds = int(round(seconds))
+    h, rem = divmod(seconds, 3600)
+    m, s = divmod(rem, 60)
+    if h:
+        return "%dh:%02dm:%02ds" % (h, m, s)
+    if m:
+        return "%dm:%02ds" % (m, s)
+    return "%ds" % s
+
+
+class SimulationRunner:
+    def __init__(self, default_config_file=None, config_spec=None, read_command_line_args=True,
+                 save_parsed_file=False):
+        if default_config_file is not None:
+            raise NotImplementedError("configobj parameter files are outside this package's scope; fill "
+                                      "runner.params programmatically")
+        self.rep_max = 1
+        self._runned_reps = []
+        self._params = SimulationParameters()
+        self._results = SimulationResults()
+        self._results_filename = None
+        self.delete_partial_results_bool = False
+        self.partial_results_folder = "partial_results"
+        self.progressbar_message = "Progress"
+        self.update_progress_function_style = "text2"
+        self.progress_output_type = "screen"
+        self.partial_save_every_reps = 500        # runner.py:109-145
+        self.partial_save_every_seconds = 300.0
+        self._last_partial_save = 0.0
+        self._tic = self._toc = 0.0
+        self._partial_files = []
+
+    # ---- properties of the reference --------------------------------------------------------
+    params = property(lambda self: self._params)
+    results = property(lambda self: self._results)
+    runned_reps = property(lambda self: self._runned_reps)
+    results_filename = property(lambda self: None if self._results_filename is None
+                                else self._results_filename + ".pickle")
+
+    @property
+    def elapsed_time(self):
+        return _pretty_time(self._toc - self._tic)
+
+    def __repr__(self):
+        return "{0}(rep_max={1}, num_params_variations={2})".format(
+            self.__class__.__name__, self.rep_max, self.params.get_num_unpacked_variations())
+
+    def set_results_filename(self, filename=None):
+        """Base name (no extension); '{param}' fields are replaced when saving (runner.py:1216)."""
+        self._results_filename = filename
+
+    def clear(self):
+        self._runned_reps = []
+        self._results = SimulationResults()
+        self._partial_files = []
+
+    # ---- what a simulator overrides ---------------------------------------------------------
+    def _run_simulation(self, current_parameters):
+        raise NotImplementedError("'_run_simulation' must be implemented in a subclass of SimulationRunner")
+
+    def _keep_going(self, current_params, current_sim_results, current_rep):
+        return True
+
+    def _on_simulate_start(self):
+        pass
+
+    def _on_simulate_finish(self):
+        pass
+
+    def _on_simulate_current_params_start(self, current_params):
+        pass
+
+    def _on_simulate_current_params_finish(self, current_params, current_params_sim_results):
+        pass
+
+    # ---- partial results (runner.py:926-1069) -----------------------------------------------
+    def _partial_name(self, current_params):
+        if self._results_filename is None:
+            return None
+        base = self._results.get_filename_with_replaced_params(os.path.basename(self._results_filename))
+        folder = os.path.join(os.path.dirname(self._results_filename) or ".", self.partial_results_folder)
+        return os.path.join(folder, "{0}_unpack_{1:0>2}.pickle".format(base, max(current_params.unpack_index, 0)))
+
+    def _save_partial(self, current_rep, current_params, current_sim_results):
+        name = self._partial_name(current_params)
+        if name is None:
+            return None
+        os.makedirs(os.path.dirname(name), exist_ok=True)
+        current_sim_results.current_rep = current_rep
+        current_sim_results.set_parameters(current_params)
+        with open(name, "wb") as fh:
+            pickle.dump(current_sim_results, fh, protocol=2)
+        self._last_partial_save = time.time()
+        if name not in self._partial_files:
+            self._partial_files.append(name)
+        return name
+
+    def _save_partial_maybe(self, current_rep, current_params, current_sim_results):
+        if self._results_filename is None:
+            return
+        if (current_rep % self.partial_save_every_reps == 0
+                or time.time() - self._last_partial_save > self.partial_save_every_seconds):
+            self._save_partial(current_rep, current_params, current_sim_results)
+
+    def _load_partial(self, current_params):
+        name = self._partial_name(current_params)
+        if name is None or not os.path.exists(name):
+            return None
+        with open(name, "rb") as fh:
+            partial = pickle.load(fh)
+        if partial.params != current_params:
+            raise ValueError("Partial results loaded from file does not match current parameters. \n"
+                             "File: {0}".format(name))
+        return partial
+
+    # ---- the repetition loop (runner.py:1435-1539) ------------------------------------------
+    def _timed_run(self, current_params):
+        tic = time.time()
+        res = self._run_simulation(current_params)
+        res.add_result(Result.create("elapsed_time", Result.SUMTYPE, time.time() - tic))
+        return res
+
+    def _simulate_for_current_params(self, current_params):
+        self._on_simulate_current_params_start(current_params)
+        current_sim_results = self._load_partial(current_params)
+        if current_sim_results is None:
+            # NB: like the reference, the first repetition is outside the SkipThisOne guard
+            current_sim_results = self._timed_run(current_params)
+            current_rep = 1
+        else:
+            current_rep = current_sim_results.current_rep
+        current_sim_results.add_new_result("num_skipped_reps", Result.SUMTYPE, 0)
+        while self._keep_going(current_params, current_sim_results, current_rep) and current_rep < self.rep_max:
+            try:
+                current_sim_results.merge_all_results(self._timed_run(current_params))
+                current_rep += 1
+            except SkipThisOne:
+                current_sim_results["num_skipped_reps"][-1].update(1)
+            self._save_partial_maybe(current_rep, current_params, current_sim_results)
+        self._on_simulate_current_params_finish(current_params, current_sim_results)
+        self._save_partial(current_rep, current_params, current_sim_results)
+        return current_rep, current_sim_results
+
+    def _common_setup(self):
+        self.clear()
+        self.params.parameters.setdefault("rep_max", self.rep_max)
+        self._results.set_parameters(self.params)
+        self._tic = time.time()
+        self._last_partial_save = time.time()
+        self._on_simulate_start()
+
+    def _common_cleanup(self):
+        self._on_simulate_finish()
+        self._toc = time.time()
+        self._results.runned_reps = self._runned_reps
+        if self._results_filename is not None:
+            self._results.save_to_file(self._results_filename + ".pickle")
+            if self.delete_partial_results_bool:
+                for name in self._partial_files:
+                    if os.path.exists(name):
+                        os.remove(name)
+                folder = os.path.join(os.path.dirname(self._results_filename) or ".", self.partial_results_folder)
+                if os.path.isdir(folder) and not os.listdir(folder):
+                    os.rmdir(folder)
+
+    def simulate(self, param_variation_index=None):
+        """All parameter variations (or only variation `param_variation_index`, whose partial results
+        are stored for a later combine step; that mode needs a results filename)."""
+        self._common_setup()
+        variations = self.params.get_unpacked_params_list()
+        if param_variation_index is None:
+            for current_params in variations:
+                reps, res = self._simulate_for_current_params(current_params)
+                self._runned_reps.append(reps)
+                self._results.append_all_results(res)
+            self._common_cleanup()
+            return
+        if self._results_filename is None:
+            raise RuntimeError('The results filename must be set before calling the "simulate" method.')
+        index = int(param_variation_index)
+        if 0 <= index < len(variations):
+            reps, _ = self._simulate_for_current_params(variations[index])
+            self._runned_reps = reps
+        self._toc = time.time()
+
+
+class BatchedSimulationRunner(SimulationRunner):
+    """Repetition loop in units of GPU batches.
+
+    A subclass implements ``_run_batch(current_parameters, first_rep, count) -> dict`` returning the
+    integer counter block of realizations [first_rep, first_rep + count) (the dict produced by
+    ``Engine.run_*``: n_realizations, n_skipped, sym_errors, sym_errors_sq, bit_errors,
+    bit_errors_sq, n_symbols, n_bits) and may override ``_results_from_counters``.
+
+    * realization index == repetition index: results depend only on (seed, index), never on the
+      batch size, the number of ranks or a resume point;
+    * with ``world_size > 1`` (torch.distributed initialised) each batch is split contiguously
+      over the ranks and the integer counters are all-reduced (exact, order independent) once
+      per parameter variation -- or once per batch when ``_keep_going`` is overridden;
+    * skipped realizations (singular channel etc.) count into 'num_skipped_reps' and are replaced
+      by later indices, like SkipThisOne in the serial loop.
+    """
+    COUNTER_KEYS = ("n_realizations", "n_skipped", "sym_errors", "sym_errors_sq", "bit_errors", "bit_errors_sq")
+
+    def __init__(self, batch_size=4096, process_group=None):
+        super().__init__(read_command_line_args=False)
+        self.batch_size = int(batch_size)
+        self.process_group = process_group
+        self.first_rep = 0
+
+    def _run_batch(self, current_parameters, first_rep, count):
+        raise NotImplementedError("'_run_batch' must be implemented in a subclass of BatchedSimulationRunner")
+
+    def _run_simulation(self, current_parameters):
+        c = self._run_batch(current_parameters, self.first_rep, 1)
+        return self._results_from_counters(current_parameters, c)
+
+    def _results_from_counters(self, current_parameters, c):
+        """The Result set of the reference's link simulators (apps/awgn_modulators/simulate_psk.py:
+        90-112, apps/mimo/simulate_mimo.py:117-139)."""
+        n = c["n_realizations"]
+        res = SimulationResults()
+        res.add_result(Result.from_counters("symbol_errors", Result.SUMTYPE, c["sym_errors"], c["sym_errors_sq"], 1, n))
+        res.add_result(Result.from_batch("num_symbols", Result.SUMTYPE, c["n_symbols"] * n, 0, float(c["n_symbols"] * n),
+                                         float(c["n_symbols"]) ** 2 * n, n))
+        res.add_result(Result.from_counters("bit_errors", Result.SUMTYPE, c["bit_errors"], c["bit_errors_sq"], 1, n))
+        res.add_result(Result.from_batch("num_bits", Result.SUMTYPE, c["n_bits"] * n, 0, float(c["n_bits"] * n),
+                                         float(c["n_bits"]) ** 2 * n, n))
+        res.add_result(Result.from_counters("ber", Result.RATIOTYPE, c["bit_errors"], c["bit_errors_sq"], c["n_bits"], n))
+        res.add_result(Result.from_counters("ser", Result.RATIOTYPE, c["sym_errors"], c["sym_errors_sq"],
+                                            c["n_symbols"], n))
+        return res
+
+    # ---- sharding ---------------------------------------------------------------------------
+    def _dist(self):
+        try:
+            import torch.distributed as dist
+        except ImportError:
+            return None, 0, 1
+        if not (dist.is_available() and dist.is_initialized()):
+            return None, 0, 1
+        return dist, dist.get_rank(self.process_group), dist.get_world_size(self.process_group)
+
+    @staticmethod
+    def shard_range(first, count, rank, world):
+        """Contiguous split of [first, first + count) -> (first_r, count_r) of `rank`."""
+        lo = first + (count * rank) // world
+        hi = first + (count * (rank + 1)) // world
+        return lo, hi - lo
+
+    def _allreduce(self, c):
+        dist, rank, world = self._dist()
+        if world == 1:
+            return c
+        import torch
+        backend = dist.get_backend(self.process_group)
+        dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+        vec = torch.tensor([int(c[k]) for k in self.COUNTER_KEYS], dtype=torch.int64, device=dev)
+        dist.all_reduce(vec, op=dist.ReduceOp.SUM, group=self.process_group)     # the path's only exchange
+        shape = torch.tensor([int(c["n_symbols"]), int(c["n_bits"])], dtype=torch.int64, device=dev)
+        dist.all_reduce(shape, op=dist.ReduceOp.MAX, group=self.process_group)   # ranks with an empty shard
+        out = {k: int(v) for k, v in zip(self.COUNTER_KEYS, vec.tolist())}
+        out["n_symbols"], out["n_bits"] = int(shape[0]), int(shape[1])
+        return out
+
+    @staticmethod
+    def _add(acc, c):
+        if acc is None:
+            return dict(c)
+        for k in BatchedSimulationRunner.COUNTER_KEYS:
+            acc[k] += c[k]
+        acc["n_symbols"] = max(acc.get("n_symbols", 0), c.get("n_symbols", 0))
+        acc["n_bits"] = max(acc.get("n_bits", 0), c.get("n_bits", 0))
+        return acc
+
+    # ---- the batched loop -------------------------------------------------------------------
+    def _simulate_for_current_params(self, current_params):
+        self._on_simulate_current_params_start(current_params)
+        dist, rank, world = self._dist()
+        partial = self._load_partial(current_params)
+        if partial is not None:
+            total, next_index, elapsed = partial._batched_state
+            total = dict(total)
+        else:
+            total, next_index, elapsed = self._zero_like(None), self.first_rep, 0.0
+        batches = 0
+        while total["n_realizations"] < self.rep_max:
+            if total["n_realizations"] > 0:
+                # the reference evaluates _keep_going before every repetition after the first
+                # (runner.py:1491); here it is evaluated before every batch after the first
+                snapshot = self._finish_results(current_params, total, elapsed)
+                if not self._keep_going(current_params, snapshot, total["n_realizations"]):
+                    break
+            want = min(self.batch_size * world, self.rep_max - total["n_realizations"])
+            lo, cnt = self.shard_range(next_index, want, rank, world)
+            tic = time.time()
+            c = self._run_batch(current_params, lo, cnt) if cnt > 0 else self._zero_like(None)
+            elapsed += time.time() - tic
+            next_index += want
+            batches += 1
+            total = self._add(total, self._allreduce(c))
+            if (self._results_filename is not None and rank == 0
+                    and (batches % max(1, self.partial_save_every_reps // max(1, self.batch_size)) == 0
+                         or time.time() - self._last_partial_save > self.partial_save_every_seconds)):
+                snap = self._finish_results(current_params, total, elapsed)
+                snap._batched_state = (dict(total), next_index, elapsed)
+                self._save_partial(total["n_realizations"], current_params, snap)
+        final = self._finish_results(current_params, total, elapsed)
+        self._on_simulate_current_params_finish(current_params, final)
+        if rank == 0:
+            final._batched_state = (dict(total), next_index, elapsed)
+            self._save_partial(total["n_realizations"], current_params, final)
+        return total["n_realizations"], final
+
+    @staticmethod
+    def _zero_like(c):
+        z = {k: 0 for k in BatchedSimulationRunner.COUNTER_KEYS}
+        z["n_symbols"] = 0 if c is None else c["n_symbols"]
+        z["n_bits"] = 0 if c is None else c["n_bits"]
+        return z
+
+    def _finish_results(self, current_params, total, elapsed):
+        n = max(int(total["n_realizations"]), 1)
+        res = self._results_from_counters(current_params, total)
+        # one 'elapsed_time' update per realization in the reference; here the batch time is spread evenly
+        res.add_result(Result.from_batch("elapsed_time", Result.SUMTYPE, elapsed, 0, elapsed, elapsed * elapsed / n, n))
+        res.add_result(Result.from_batch("num_skipped_reps", Result.SUMTYPE, int(total["n_skipped"]), 0,
+                                         float(total["n_skipped"]), float(total["n_skipped"]),
+                                         1 + int(total["n_skipped"])))
+        return res

@@ -1,0 +1,150 @@
+"""Ready-made link simulators on the fused GPU pipelines, shaped like the reference's own template
+simulators (apps/awgn_modulators/simulate_psk.py, apps/mimo/simulate_mimo.py,
+notebooks/TDL_and_OFDM.ipynb) but advancing by batches: subclasses of BatchedSimulationRunner
+whose ``_run_batch`` is one call into libmcle.
+
+    sim = MimoOfdmSimulator(SNR=[15, 20, 25], rep_max=100000)
+    sim.simulate()
+    sim.results.get_result_values_list('ser')
+"""
+import numpy as np
+
+from . import _lib
+from .channels import discretize_profile
+from .engine import get_engine
+from .modulators import BPSK, PSK, QAM, QPSK, dB2Linear
+from .simulations import BatchedSimulationRunner
+
+_GOLDEN = 0x9E3779B97F4A7C15
+
+
+def make_modulator(name, M=None, engine=None):
+    name = name.lower()
+    if name == "qam":
+        return QAM(M, engine=engine)
+    if name == "psk":
+        return PSK(M, engine=engine)
+    if name == "qpsk":
+        return QPSK(engine=engine)
+    if name == "bpsk":
+        return BPSK(engine=engine)
+    raise ValueError("unknown modulator %r" % (name,))
+
+
+class _LinkSimulator(BatchedSimulationRunner):
+    """Common part: SNR sweep ('SNR' unpacked), modulator, seed handling, engine binding."""
+
+    def __init__(self, SNR, modulator="qam", M=16, rep_max=1000, seed=0, batch_size=4096, dtype="f32",
+                 demod="auto", engine=None, common_random_numbers=False, process_group=None):
+        super().__init__(batch_size=batch_size, process_group=process_group)
+        self.rep_max = rep_max
+        self.seed = int(seed)
+        self.dtype = dtype
+        self.common_random_numbers = common_random_numbers
+        self._engine = engine
+        self.modulator = make_modulator(modulator, M, engine) if isinstance(modulator, str) else modulator
+        if demod == "auto":
+            demod = "slicer" if isinstance(self.modulator, QAM) else "mindist"
+        self.demod_method = _lib.DEMOD_QAM_SLICER if demod == "slicer" else _lib.DEMOD_MINDIST
+        self.params.add("SNR", np.atleast_1d(np.asarray(SNR, dtype=float)))
+        self.params.set_unpack_parameter("SNR")
+        self.params.add("modulator", self.modulator.name)
+
+    @property
+    def engine(self):
+        if self._engine is None:
+            self._engine = get_engine()
+        return self._engine
+
+    def _seed_for(self, current_parameters):
+        """Independent randomness per parameter variation (the reference keeps drawing from one
+        global stream) unless common_random_numbers asks for the same draws at every SNR."""
+        if self.common_random_numbers:
+            return self.seed
+        return (self.seed + (max(current_parameters.unpack_index, 0) + 1) * _GOLDEN) & 0xFFFFFFFFFFFFFFFF
+
+    def _bind(self):
+        self.modulator._engine = self.engine
+        return self.modulator._bind()
+
+    @staticmethod
+    def _noise_var(current_parameters):
+        return 1.0 / float(dB2Linear(current_parameters["SNR"]))
+
+
+class AwgnSimulator(_LinkSimulator):
+    """Config 1: apps/awgn_modulators/simulate_psk.py:51-115."""
+
+    def __init__(self, SNR, modulator="qam", M=16, NSymbs=10000, **kw):
+        super().__init__(SNR, modulator, M, **kw)
+        self.params.add("NSymbs", int(NSymbs))
+
+    def _run_batch(self, current_parameters, first_rep, count):
+        eng = self._bind()
+        return eng.run_awgn(current_parameters["NSymbs"], self._noise_var(current_parameters),
+                            self._seed_for(current_parameters), first_rep, count, method=self.demod_method,
+                            dtype=self.dtype)
+
+
+class FlatFadingSimulator(_LinkSimulator):
+    """Config 2: flat fading SuChannel(JakesSampleGenerator(Fd, Ts, L)) (or i.i.d. Rayleigh),
+    receiver equalises with the known channel."""
+
+    def __init__(self, SNR, modulator="qam", M=64, NSymbs=100000, Fd=100.0, Ts=1e-3, L=8, rayleigh_iid=False, **kw):
+        super().__init__(SNR, modulator, M, **kw)
+        for k, v in (("NSymbs", int(NSymbs)), ("Fd", float(Fd)), ("Ts", float(Ts)), ("L", int(L)),
+                     ("rayleigh_iid", bool(rayleigh_iid))):
+            self.params.add(k, v)
+
+    def _run_batch(self, current_parameters, first_rep, count):
+        p = current_parameters
+        eng = self._bind()
+        return eng.run_flat_fading(p["NSymbs"], self._noise_var(p), self._seed_for(p), first_rep, count, Fd=p["Fd"],
+                                   Ts=p["Ts"], L=p["L"], rayleigh_iid=p["rayleigh_iid"], method=self.demod_method,
+                                   dtype=self.dtype)
+
+
+class OfdmTdlSimulator(_LinkSimulator):
+    """Config 3: notebooks/TDL_and_OFDM.ipynb OfdmTdlSimulator (OFDM over a Jakes TDL channel with
+    the one-tap equaliser)."""
+
+    def __init__(self, SNR, modulator="qpsk", M=4, fft_size=1024, cp_size=16, num_used_subcarriers=None,
+                 num_ofdm_symbols=1, Fd=10.0, Ts=1.0 / (15e3 * 1024), L=8,
+                 tap_powers_dB=(0.0, -3.0, -6.0, -9.0, -12.0), tap_delays=None, **kw):
+        super().__init__(SNR, modulator, M, **kw)
+        if tap_delays is None:
+            tap_delays = np.arange(len(tap_powers_dB)) * Ts
+        self._tap_power, self._tap_delay = discretize_profile(np.asarray(tap_powers_dB, dtype=float),
+                                                               np.asarray(tap_delays, dtype=float), Ts)
+        for k, v in (("fft_size", int(fft_size)), ("cp_size", int(cp_size)),
+                     ("num_used_subcarriers", int(num_used_subcarriers or fft_size)),
+                     ("num_ofdm_symbols", int(num_ofdm_symbols)), ("Fd", float(Fd)), ("Ts", float(Ts)),
+                     ("L", int(L))):
+            self.params.add(k, v)
+
+    def _run_batch(self, current_parameters, first_rep, count):
+        p = current_parameters
+        eng = self._bind()
+        return eng.run_ofdm_tdl(p["fft_size"], p["cp_size"], p["num_used_subcarriers"], p["num_ofdm_symbols"],
+                                self._noise_var(p), self._tap_power, self._tap_delay, self._seed_for(p), first_rep,
+                                count, Fd=p["Fd"], Ts=p["Ts"], L=p["L"], method=self.demod_method, dtype=self.dtype)
+
+
+class MimoOfdmSimulator(_LinkSimulator):
+    """Config 4: apps/mimo/simulate_mimo.py:68-142 (Blast, flat H = randn_c(Nr, Nt) per
+    realization) with per-antenna OFDM; MMSE (set_noise_var) or zero forcing."""
+
+    def __init__(self, SNR, modulator="qam", M=64, Nt=4, Nr=4, fft_size=1024, cp_size=16,
+                 num_used_subcarriers=None, num_ofdm_symbols=1, mmse=True, **kw):
+        super().__init__(SNR, modulator, M, **kw)
+        for k, v in (("Nt", int(Nt)), ("Nr", int(Nr)), ("fft_size", int(fft_size)), ("cp_size", int(cp_size)),
+                     ("num_used_subcarriers", int(num_used_subcarriers or fft_size)),
+                     ("num_ofdm_symbols", int(num_ofdm_symbols)), ("mmse", bool(mmse))):
+            self.params.add(k, v)
+
+    def _run_batch(self, current_parameters, first_rep, count):
+        p = current_parameters
+        eng = self._bind()
+        return eng.run_mimo_ofdm(p["Nt"], p["Nr"], p["fft_size"], p["cp_size"], p["num_used_subcarriers"],
+                                 p["num_ofdm_symbols"], self._noise_var(p), self._seed_for(p), first_rep, count,
+                                 mmse=p["mmse"], method=self.demod_method, dtype=self.dtype)

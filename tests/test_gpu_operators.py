@@ -161,6 +161,8 @@ def test_jakes_tdl_equalizer_injected(engine, dt):
                 assert np.count_nonzero(dec != g["decisions"]) <= 3
     for kw, reals in golden_cases("c3_ofdm_tdl"):
         for g in reals:
+            if "taps" not in g or "noise" not in g:
+                continue                       # large arrays are stored for one realization only
             fft, cp = kw["fft_size"], kw["cp_size"]
             used = kw["num_used"] or fft
             n = g["tx"].size
@@ -230,7 +232,7 @@ def test_mimo_ofdm_chain_injected(engine, dt):
     """C4 staged operator by operator with the reference's H, data and noise injected."""
     for kw, reals in golden_cases("c4_mimo_ofdm"):
         for g in reals:
-            if "noise" not in g:
+            if "noise" not in g or "T" not in g:
                 continue
             nt, nr, fft, cp = kw["nt"], kw["nr"], kw["fft_size"], kw["cp_size"]
             used = kw["num_used"] or fft
