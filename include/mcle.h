@@ -185,6 +185,13 @@ typedef struct mcle_mimo_ofdm_cfg {     /* C4: apps/mimo/simulate_mimo.py:68-142
     double noise_var;
 } mcle_mimo_ofdm_cfg;
 
+typedef struct mcle_ia_cfg {            /* C5: apps/ia/simulate_ia.py:94-245, ClosedFormIASolver */
+    int32_t K, nr, nt, ns;              /* supported: K = 3, nr = nt = 2, ns = 1 */
+    int32_t n_symbols;                  /* NSymbs per stream */
+    int32_t demod_method;
+    double noise_var;
+} mcle_ia_cfg;
+
 /* Each run_* processes realizations [first, first+count) of `seed`, ADDS into d_counters[0]
  * and, when non-NULL, writes per-realization d_sym_err / d_bit_err [count]. */
 int mcle_run_awgn(mcle_ctx* ctx, int dtype, const mcle_awgn_cfg* cfg, uint64_t seed,
@@ -199,6 +206,18 @@ int mcle_run_ofdm_tdl(mcle_ctx* ctx, int dtype, const mcle_ofdm_tdl_cfg* cfg, ui
 int mcle_run_mimo_ofdm(mcle_ctx* ctx, int dtype, const mcle_mimo_ofdm_cfg* cfg, uint64_t seed,
                        uint64_t first, uint64_t count, mcle_counters* d_counters,
                        uint32_t* d_sym_err, uint32_t* d_bit_err);
+
+/* d_sum_capacity (may be NULL): per-realization sum_k log2(1 + SINR_k) of the chosen solution */
+int mcle_run_ia(mcle_ctx* ctx, int dtype, const mcle_ia_cfg* cfg, uint64_t seed, uint64_t first,
+                uint64_t count, mcle_counters* d_counters, uint32_t* d_sym_err, uint32_t* d_bit_err,
+                double* d_sum_capacity);
+
+/* ---- a15: ClosedFormIASolver.solve (ia/algorithms.py:194-265) on injected channels, f64 only:
+ *      d_bigH [batch][6][6] (MultiUserChannelMatrix.big_H, K = 3, 2x2) -> precoders d_F
+ *      [batch][3][2] (full_F, P = 1), receive filters d_U [batch][3][2] (full_W_H), per-user SINR
+ *      d_sinr [batch][3] and sum capacity d_capacity [batch] (both may be NULL) ------------------ */
+int mcle_ia_closed_form(mcle_ctx* ctx, const void* d_bigH, double noise_var, void* d_F, void* d_U,
+                        double* d_sinr, double* d_capacity, uint32_t* d_skipped, size_t batch);
 
 #ifdef __cplusplus
 }

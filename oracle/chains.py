@@ -21,6 +21,7 @@ import math
 import numpy as np
 
 from . import channels as och
+from . import ia as oia
 from . import mimo as omimo
 from . import modem as omodem
 from . import ofdm as oofdm
@@ -45,6 +46,22 @@ class LegacyRng:
 
     def uniform(self, *shape):
         return self.rs.rand(*shape)
+
+
+class LegacyRng3(LegacyRng):
+    """Config 5 draws from three legacy streams: the channel's and the noise's own RandomState
+    (multiuser.py:670-709) and the global one for the data -- all seeded alike by the harness."""
+
+    def __init__(self, seed):
+        super().__init__(seed)
+        self.by_stream = {philox.STREAM_CHAN: np.random.RandomState(seed),
+                          philox.STREAM_NOISE: np.random.RandomState(seed)}
+
+    def cn(self, stream, *shape):
+        rs = self.by_stream[stream]
+        re = rs.randn(*shape)
+        im = rs.randn(*shape)
+        return (1.0 / math.sqrt(2.0)) * (re + 1j * im)
 
 
 class PhiloxRng:
@@ -195,3 +212,28 @@ def chain_mimo_ofdm(rng, mod='qam', M=64, nt=4, nr=4, fft_size=1024, cp_size=16,
     dec = omodem.demodulate(table, est)
     return _counts(dict(table=table, H=H, idx=idx, sym=sym, X=X, T=T, noise=noise, R=R, Y=Y, G=G,
                         est=est, noise_var=noise_var), idx, dec, M)
+
+
+def chain_ia(rng, mod='qam', M=16, K=3, nr=2, nt=2, Ns=1, NSymbs=200, snr_db=20.0):
+    """C5: apps/ia/simulate_ia.py:94-245 with ClosedFormIASolver(use_best_init=True)."""
+    assert K == 3
+    table = constellation(mod, M)
+    noise_var = 1.0 / float(omodem.dB2Linear(snr_db))
+    big_H = rng.cn(philox.STREAM_CHAN, K * nr, K * nt)
+    H = oia.split_blocks(big_H, K, nr, nt)
+    F, U, cap, sinr = oia.closed_form_solve(H, Ns, noise_var)
+    if rng.legacy:
+        idx = rng.rs.randint(0, M, [K * Ns, NSymbs])
+    else:
+        idx = rng.symbols(K * Ns * NSymbs, M).reshape(K * Ns, NSymbs)
+    sym = omodem.modulate(table, idx)
+    X = np.vstack([F[k] @ sym[k * Ns:(k + 1) * Ns] for k in range(K)])
+    noise = rng.cn(philox.STREAM_NOISE, K * nr, NSymbs)
+    Y = oia.mu_corrupt(big_H, X, noise, noise_var)
+    est = np.vstack([U[k] @ Y[k * nr:(k + 1) * nr] for k in range(K)])
+    dec = omodem.demodulate(table, est)
+    out = dict(table=table, big_H=big_H, idx=idx, noise=noise, est=est, noise_var=noise_var, sum_capacity=cap,
+               F=np.stack([f.reshape(-1) for f in F]) if Ns == 1 else None,
+               U=np.stack([u.reshape(-1) for u in U]) if Ns == 1 else None,
+               sinr=np.concatenate(sinr))
+    return _counts(out, idx, dec, M)

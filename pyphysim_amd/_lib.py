@@ -58,6 +58,11 @@ class MimoOfdmCfg(Structure):
                 ("noise_var", c_double)]
 
 
+class IaCfg(Structure):
+    _fields_ = [("K", c_int32), ("nr", c_int32), ("nt", c_int32), ("ns", c_int32), ("n_symbols", c_int32),
+                ("demod_method", c_int32), ("noise_var", c_double)]
+
+
 _P = c_void_p
 _PROTOS = {
     "mcle_last_error": (c_char_p, []),
@@ -100,6 +105,8 @@ _PROTOS = {
     "mcle_run_flat_fading": (c_int, [_P, c_int, POINTER(FlatCfg), c_uint64, c_uint64, c_uint64, _P, _P, _P]),
     "mcle_run_ofdm_tdl": (c_int, [_P, c_int, POINTER(OfdmTdlCfg), c_uint64, c_uint64, c_uint64, _P, _P, _P]),
     "mcle_run_mimo_ofdm": (c_int, [_P, c_int, POINTER(MimoOfdmCfg), c_uint64, c_uint64, c_uint64, _P, _P, _P]),
+    "mcle_run_ia": (c_int, [_P, c_int, POINTER(IaCfg), c_uint64, c_uint64, c_uint64, _P, _P, _P, _P]),
+    "mcle_ia_closed_form": (c_int, [_P, _P, c_double, _P, _P, _P, _P, _P, c_size_t]),
 }
 
 _lib = None

@@ -1,0 +1,310 @@
+// kernels_ia.hip -- closed-form interference alignment for the 3-user 2x2 MIMO interference channel
+// (one stream per user) and the fused config-5 pipeline.
+//
+// Reference: ia/algorithms.py:73-96 (_calc_E), :98-191 (_updateF / _updateW), :194-265 (solve with
+// use_best_init), ia/iabase.py:188-200,299-327 (full_F / full_W_H), :768-789,897-996 (SINR),
+// channels/multiuser.py:1003-1044,1179-1262 (randomize / corrupt_data), apps/ia/simulate_ia.py:94-245.
+//
+// Everything is 2x2 and solved in closed form in f64 registers (the solver is ~10^3 flops per
+// realization).  np.linalg.eig's eigenvectors come from LAPACK zgeev, which scales each vector to
+// unit 2-norm with its largest-magnitude component real and positive; the 2x2 closed form below
+// applies the same normalisation, so F_0 -- whose phase rotates the post-filter noise -- matches.
+#include "modem.hpp"
+#include "philox.hpp"
+
+namespace mcle {
+
+using cd = double2;
+
+struct M2 {
+    cd a, b, c, d;  // [[a, b], [c, d]]
+};
+struct V2 {
+    cd x, y;
+};
+
+__device__ __forceinline__ cd cdiv_(cd p, cd q) { return cdivide(p, q); }
+__device__ __forceinline__ double cabs2(cd z) { return z.x * z.x + z.y * z.y; }
+__device__ __forceinline__ cd csqrt_(cd z) {
+    const double r = sqrt(sqrt(cabs2(z)));
+    const double th = 0.5 * atan2(z.y, z.x);
+    double s, c;
+    sincos(th, &s, &c);
+    return mk<double>(r * c, r * s);
+}
+__device__ __forceinline__ M2 mmul(const M2& p, const M2& q) {
+    M2 r;
+    r.a = cadd(cmul(p.a, q.a), cmul(p.b, q.c));
+    r.b = cadd(cmul(p.a, q.b), cmul(p.b, q.d));
+    r.c = cadd(cmul(p.c, q.a), cmul(p.d, q.c));
+    r.d = cadd(cmul(p.c, q.b), cmul(p.d, q.d));
+    return r;
+}
+__device__ __forceinline__ V2 mvec(const M2& p, const V2& v) {
+    V2 r;
+    r.x = cadd(cmul(p.a, v.x), cmul(p.b, v.y));
+    r.y = cadd(cmul(p.c, v.x), cmul(p.d, v.y));
+    return r;
+}
+__device__ __forceinline__ M2 minv(const M2& p, bool& ok) {
+    const cd det = csub(cmul(p.a, p.d), cmul(p.b, p.c));
+    ok = ok && (cabs2(det) > 1e-280);
+    M2 r;
+    r.a = cdiv_(p.d, det);
+    r.b = cdiv_(mk<double>(-p.b.x, -p.b.y), det);
+    r.c = cdiv_(mk<double>(-p.c.x, -p.c.y), det);
+    r.d = cdiv_(p.a, det);
+    return r;
+}
+__device__ __forceinline__ V2 vnormalize(V2 v) {
+    const double n = 1.0 / sqrt(cabs2(v.x) + cabs2(v.y));
+    v.x = cscale(v.x, n);
+    v.y = cscale(v.y, n);
+    return v;
+}
+// LAPACK zgeev convention: unit norm, largest-magnitude component real positive (first max on ties)
+__device__ __forceinline__ V2 lapack_normalize(V2 v) {
+    v = vnormalize(v);
+    const cd piv = cabs2(v.y) > cabs2(v.x) ? v.y : v.x;
+    const double m = sqrt(cabs2(piv));
+    const cd ph = mk<double>(piv.x / m, -piv.y / m);  // conj(piv)/|piv|
+    v.x = cmul(v.x, ph);
+    v.y = cmul(v.y, ph);
+    return v;
+}
+// eigenvector of E for eigenvalue lam: the better conditioned of the two rows of (E - lam I)
+__device__ __forceinline__ V2 eigvec2(const M2& E, cd lam) {
+    const V2 v1{E.b, csub(lam, E.a)};
+    const V2 v2{csub(lam, E.d), E.c};
+    const double n1 = cabs2(v1.x) + cabs2(v1.y), n2 = cabs2(v2.x) + cabs2(v2.y);
+    return lapack_normalize(n1 >= n2 ? v1 : v2);
+}
+
+struct IaSolution {
+    V2 F[3];    // precoders (column vectors, unit norm)
+    V2 U[3];    // receive filters full_W_H (row vectors)
+    double sinr[3];
+    double capacity;
+    bool ok;
+};
+
+// H[k][l]: channel from transmitter l to receiver k
+__device__ __forceinline__ void ia_candidate(const M2 (&H)[3][3], const M2& invH32, const M2& invH23, V2 F0,
+                                             double nv, IaSolution& s) {
+    s.F[0] = vnormalize(F0);
+    s.F[1] = vnormalize(mvec(invH32, mvec(H[2][0], F0)));
+    s.F[2] = vnormalize(mvec(invH23, mvec(H[1][0], F0)));
+    const V2 a[3] = {mvec(H[0][1], s.F[1]), mvec(H[1][0], s.F[0]), mvec(H[2][0], s.F[0])};
+    s.capacity = 0.0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        // W_k spans the null space of a a^H:  W^H = [a_y, -a_x] / |a|
+        const double n = 1.0 / sqrt(cabs2(a[k].x) + cabs2(a[k].y));
+        const V2 wh{cscale(a[k].y, n), cscale(mk<double>(-a[k].x.x, -a[k].x.y), n)};
+        const V2 hf = mvec(H[k][k], s.F[k]);
+        const cd eq = cadd(cmul(wh.x, hf.x), cmul(wh.y, hf.y));  // W^H H_kk F_k
+        s.U[k].x = cdiv_(wh.x, eq);
+        s.U[k].y = cdiv_(wh.y, eq);
+        double den = nv * (cabs2(s.U[k].x) + cabs2(s.U[k].y));
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            if (j == k) continue;
+            const V2 g = mvec(H[k][j], s.F[j]);
+            den += cabs2(cadd(cmul(s.U[k].x, g.x), cmul(s.U[k].y, g.y)));
+        }
+        s.sinr[k] = 1.0 / den;
+        s.capacity += log2(1.0 + s.sinr[k]);
+    }
+}
+
+__device__ __forceinline__ IaSolution ia_closed_form(const M2 (&H)[3][3], double nv) {
+    bool ok = true;
+    const M2 i31 = minv(H[2][0], ok), i12 = minv(H[0][1], ok), i23 = minv(H[1][2], ok), i32 = minv(H[2][1], ok);
+    // E = H31^-1 H32 . (H12^-1 H13 . (H23^-1 H21))
+    const M2 E = mmul(mmul(i31, H[2][1]), mmul(mmul(i12, H[0][2]), mmul(i23, H[1][0])));
+    const cd tr = cadd(E.a, E.d);
+    const cd det = csub(cmul(E.a, E.d), cmul(E.b, E.c));
+    const cd disc = csqrt_(csub(cmul(tr, tr), cscale(det, 4.0)));
+    const cd l0 = cscale(cadd(tr, disc), 0.5), l1 = cscale(csub(tr, disc), 0.5);
+    IaSolution s0, s1;
+    ia_candidate(H, i32, i23, eigvec2(E, l0), nv, s0);
+    ia_candidate(H, i32, i23, eigvec2(E, l1), nv, s1);
+    // strict '>' keeps the first candidate on ties, like algorithms.py:250; LAPACK's eigenvalue
+    // ORDER is not reproduced (it only matters on exact ties)
+    IaSolution s = (s1.capacity > s0.capacity) ? s1 : s0;
+    s.ok = ok && (s.capacity == s.capacity);
+    return s;
+}
+
+__device__ __forceinline__ void load_blocks(const cd* bigH, M2 (&H)[3][3]) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int l = 0; l < 3; ++l) {
+            H[k][l].a = bigH[(2 * k) * 6 + 2 * l];
+            H[k][l].b = bigH[(2 * k) * 6 + 2 * l + 1];
+            H[k][l].c = bigH[(2 * k + 1) * 6 + 2 * l];
+            H[k][l].d = bigH[(2 * k + 1) * 6 + 2 * l + 1];
+        }
+}
+
+// operator-level solver on injected channels: bigH [batch][6][6] (f64)
+__global__ __launch_bounds__(64) void k_ia_closed_form(const cd* __restrict__ bigH, double nv, cd* __restrict__ F,
+                                                       cd* __restrict__ U, double* __restrict__ sinr,
+                                                       double* __restrict__ cap, uint32_t* __restrict__ skipped,
+                                                       size_t batch) {
+    for (size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x; b < batch; b += (size_t)gridDim.x * blockDim.x) {
+        M2 H[3][3];
+        load_blocks(bigH + b * 36, H);
+        const IaSolution s = ia_closed_form(H, nv);
+        for (int k = 0; k < 3; ++k) {
+            F[(b * 3 + k) * 2] = s.F[k].x;
+            F[(b * 3 + k) * 2 + 1] = s.F[k].y;
+            U[(b * 3 + k) * 2] = s.U[k].x;
+            U[(b * 3 + k) * 2 + 1] = s.U[k].y;
+            if (sinr) sinr[b * 3 + k] = s.sinr[k];
+        }
+        if (cap) cap[b] = s.capacity;
+        if (skipped) skipped[b] = s.ok ? 0u : 1u;
+    }
+}
+
+// fused config 5: one wavefront per realization
+template <typename T>
+__global__ __launch_bounds__(64) void k_run_ia(ModemParams<T> mp, int n_symbols, double noise_var, uint64_t seed,
+                                               uint64_t first, uint64_t count, unsigned* __restrict__ ws,
+                                               unsigned* __restrict__ skipped, double* __restrict__ cap_out) {
+    __shared__ cx<T> s_table[256];
+    __shared__ cd s_H[36];
+    load_table(mp, s_table);
+    const int lane = threadIdx.x;
+    const T sigma = (T)sqrt(noise_var);
+    const uint32_t mask = (uint32_t)(mp.M - 1);
+    for (uint64_t rl = blockIdx.x; rl < count; rl += gridDim.x) {
+        const Rng rng(seed, first + rl);
+        __syncthreads();
+        if (lane < 36) s_H[lane] = cn_sample<double>(rng, STREAM_CHAN, (uint64_t)lane, 1.0);  // big_H row-major
+        __syncthreads();
+        M2 H[3][3];
+        load_blocks(s_H, H);
+        const IaSolution s = ia_closed_form(H, noise_var);  // every lane solves the same 2x2 systems
+        cx<T> Hs[6][6], F[3][2], U[3][2];
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) Hs[i][j] = mk<T>((T)s_H[i * 6 + j].x, (T)s_H[i * 6 + j].y);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            F[k][0] = mk<T>((T)s.F[k].x.x, (T)s.F[k].x.y);
+            F[k][1] = mk<T>((T)s.F[k].y.x, (T)s.F[k].y.y);
+            U[k][0] = mk<T>((T)s.U[k].x.x, (T)s.U[k].x.y);
+            U[k][1] = mk<T>((T)s.U[k].y.x, (T)s.U[k].y.y);
+        }
+        unsigned se = 0, be = 0;
+        for (int t = lane; t < n_symbols; t += 64) {
+            int tx[3];
+            cx<T> X[6];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                tx[k] = (int)symbol_at(rng, (uint64_t)k * n_symbols + t, mask);  // randint(0, M, [3, NSymbs])
+                const cx<T> x = s_table[tx[k]];
+                X[2 * k] = cmul(F[k][0], x);
+                X[2 * k + 1] = cmul(F[k][1], x);
+            }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                cx<T> y[2];
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    const int row = 2 * k + a;
+                    cx<T> acc = cn_sample<T>(rng, STREAM_NOISE, (uint64_t)row * n_symbols + t, sigma);
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) acc = cfma(Hs[row][j], X[j], acc);
+                    y[a] = acc;
+                }
+                const cx<T> est = cadd(cmul(U[k][0], y[0]), cmul(U[k][1], y[1]));
+                const unsigned x = (unsigned)(tx[k] ^ demod_one(mp, s_table, est));
+                se += (x != 0u);
+                be += __popc(x);
+            }
+        }
+        se = wave_sum_u32(se);
+        be = wave_sum_u32(be);
+        if (lane == 0) {
+            ws[2 * rl] = se;
+            ws[2 * rl + 1] = be;
+            skipped[rl] = s.ok ? 0u : 1u;
+            if (cap_out) cap_out[rl] = s.capacity;
+        }
+    }
+}
+
+// defined in pipelines.hip
+int check_pipe(const mcle_ctx* ctx, int dtype, int method, const void* cfg);
+int pipe_workspace(mcle_ctx* ctx, uint64_t count, unsigned** ws, unsigned** skipped);
+int pipe_fold(mcle_ctx* ctx, const unsigned* ws, const unsigned* skipped, uint64_t count, uint64_t n_sym,
+              mcle_counters* d_counters, uint32_t* d_sym, uint32_t* d_bit);
+
+template <typename T> static ModemParams<T> ia_modem(const mcle_ctx* ctx, int method) {
+    ModemParams<T> p;
+    if (sizeof(T) == 8)
+        p.g_table = reinterpret_cast<const cx<T>*>(ctx->d_table_f64);
+    else
+        p.g_table = reinterpret_cast<const cx<T>*>(ctx->d_table_f32);
+    p.M = ctx->M;
+    p.bits = ctx->bits;
+    p.method = method;
+    p.qam_scale = (T)ctx->qam_scale;
+    p.qam_L = ctx->qam_L;
+    p.half_bits = ctx->bits / 2;
+    return p;
+}
+
+}  // namespace mcle
+
+using namespace mcle;
+
+extern "C" {
+
+int mcle_ia_closed_form(mcle_ctx* ctx, const void* d_bigH, double noise_var, void* d_F, void* d_U, double* d_sinr,
+                        double* d_capacity, uint32_t* d_skipped, size_t batch) {
+    MCLE_REQUIRE(ctx != nullptr && d_bigH != nullptr && d_F != nullptr && d_U != nullptr, "null argument");
+    MCLE_REQUIRE(noise_var >= 0.0, "noise variance must be non-negative");
+    if (batch == 0) return MCLE_OK;
+    int rc = ctx->bind();
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_ia_closed_form, dim3(grid_for(ctx, batch, 64, 16)), dim3(64), 0, ctx->stream,
+                       (const double2*)d_bigH, noise_var, (double2*)d_F, (double2*)d_U, d_sinr, d_capacity, d_skipped,
+                       batch);
+    MCLE_LAUNCH_CHECK();
+    return MCLE_OK;
+}
+
+int mcle_run_ia(mcle_ctx* ctx, int dtype, const mcle_ia_cfg* cfg, uint64_t seed, uint64_t first, uint64_t count,
+                mcle_counters* d_counters, uint32_t* d_sym_err, uint32_t* d_bit_err, double* d_sum_capacity) {
+    int rc = check_pipe(ctx, dtype, cfg ? cfg->demod_method : 0, cfg);
+    if (rc) return rc;
+    // ClosedFormIASolver.solve asserts K == 3 (algorithms.py:210); this kernel is its 2x2, Ns = 1 case
+    MCLE_REQUIRE(cfg->K == 3, "The ClosedFormIASolver class only works in a MIMO-IC scenario with 3 users.");
+    MCLE_REQUIRE(cfg->nr == 2 && cfg->nt == 2 && cfg->ns == 1, "fused IA pipeline supports Nr = Nt = 2, Ns = 1");
+    MCLE_REQUIRE(cfg->n_symbols >= 1, "n_symbols must be positive");
+    MCLE_REQUIRE(cfg->noise_var >= 0.0, "noise variance must be non-negative");
+    MCLE_REQUIRE(count <= 0x7fffffffull, "at most 2^31-1 realizations per call");
+    if (count == 0) return MCLE_OK;
+    if ((rc = ctx->bind())) return rc;
+    unsigned *ws = nullptr, *sk = nullptr;
+    if ((rc = pipe_workspace(ctx, count, &ws, &sk))) return rc;
+    const uint64_t cap = (uint64_t)ctx->n_cu * 16;
+    const unsigned grid = (unsigned)(count < cap ? count : cap);
+    if (dtype == MCLE_F32)
+        hipLaunchKernelGGL(k_run_ia<float>, dim3(grid), dim3(64), 0, ctx->stream, ia_modem<float>(ctx, cfg->demod_method),
+                           cfg->n_symbols, cfg->noise_var, seed, first, count, ws, sk, d_sum_capacity);
+    else
+        hipLaunchKernelGGL(k_run_ia<double>, dim3(grid), dim3(64), 0, ctx->stream,
+                           ia_modem<double>(ctx, cfg->demod_method), cfg->n_symbols, cfg->noise_var, seed, first, count,
+                           ws, sk, d_sum_capacity);
+    MCLE_LAUNCH_CHECK();
+    return pipe_fold(ctx, ws, sk, count, (uint64_t)3 * cfg->n_symbols, d_counters, d_sym_err, d_bit_err);
+}
+
+}  // extern "C"

@@ -13,7 +13,7 @@ import numpy as np
 
 from . import _lib
 from ._lib import (CONST_BPSK, CONST_GENERIC, CONST_QAM, DEMOD_MINDIST, DEMOD_QAM_SLICER, MCLE_F32, MCLE_F64,
-                   AwgnCfg, Counters, FlatCfg, McleError, MimoOfdmCfg, OfdmTdlCfg, check)
+                   AwgnCfg, Counters, FlatCfg, IaCfg, McleError, MimoOfdmCfg, OfdmTdlCfg, check)
 
 
 class DeviceArray:
@@ -415,6 +415,44 @@ class Engine:
         cfg = MimoOfdmCfg(int(nt), int(nr), int(fft_size), int(cp_size), int(num_used), int(n_ofdm_sym),
                           int(method), 1 if mmse else 0, float(noise_var))
         return self._run(self.lib.mcle_run_mimo_ofdm, cfg, seed, first, count, dtype, per_realization, counters)
+
+
+
+    def run_ia(self, n_symbols, noise_var, seed, first, count, method=DEMOD_MINDIST, dtype=None,
+               per_realization=False, counters=None):
+        """Config 5 (K = 3, 2x2, one stream per user).  Returns the counter dict with the extra key
+        'sum_capacity' = per-realization sum capacities summed in index order (host side), and with
+        per_realization=True also (sym_err, bit_err, capacities)."""
+        dt = self._dt(dtype)
+        cfg = IaCfg(3, 2, 2, 1, int(n_symbols), int(method), float(noise_var))
+        cnt = counters if counters is not None else self.new_counters()
+        se, be = self.empty(count, np.uint32), self.empty(count, np.uint32)
+        cap = self.empty(count, np.float64)
+        check(self.lib.mcle_run_ia(self.ctx, dt, byref(cfg), int(seed), int(first), int(count), cnt.ptr, se.ptr,
+                                   be.ptr, cap.ptr))
+        caps = cap.get()
+        sev = se.get()
+        valid = sev != 0xFFFFFFFF
+        if counters is not None:
+            return caps[valid]
+        res = self._counters(cnt)
+        res["sum_capacity"] = float(np.sum(caps[valid]))
+        res["sum_capacity_sq"] = float(np.sum(caps[valid] ** 2))
+        if per_realization:
+            return res, sev, be.get(), caps
+        return res
+
+    def ia_closed_form(self, big_H, noise_var):
+        """big_H [batch, 6, 6] complex128 -> dict(F [batch,3,2], U [batch,3,2], sinr [batch,3],
+        capacity [batch], skipped [batch])."""
+        H = np.ascontiguousarray(big_H, dtype=np.complex128).reshape(-1, 6, 6)
+        b = H.shape[0]
+        d_H = self.to_device(H)
+        F, U = self.empty((b, 3, 2), np.complex128), self.empty((b, 3, 2), np.complex128)
+        sinr, cap, sk = self.empty((b, 3), np.float64), self.empty(b, np.float64), self.empty(b, np.uint32)
+        check(self.lib.mcle_ia_closed_form(self.ctx, d_H.ptr, float(noise_var), F.ptr, U.ptr, sinr.ptr, cap.ptr,
+                                           sk.ptr, b))
+        return dict(F=F.get(), U=U.get(), sinr=sinr.get(), capacity=cap.get(), skipped=sk.get())
 
 
 _default = {}

@@ -148,3 +148,34 @@ class MimoOfdmSimulator(_LinkSimulator):
         return eng.run_mimo_ofdm(p["Nt"], p["Nr"], p["fft_size"], p["cp_size"], p["num_used_subcarriers"],
                                  p["num_ofdm_symbols"], self._noise_var(p), self._seed_for(p), first_rep, count,
                                  mmse=p["mmse"], method=self.demod_method, dtype=self.dtype)
+
+
+class IaSimulator(_LinkSimulator):
+    """Config 5: apps/ia/simulate_ia.py:94-245 with ClosedFormIASolver(use_best_init=True) on a
+    3-user 2x2 interference channel, one stream per user.  Adds the 'sum_capacity' RATIO(x, 1)
+    Result of the reference app next to the error-rate Results."""
+
+    def __init__(self, SNR, modulator="qam", M=16, NSymbs=200, **kw):
+        super().__init__(SNR, modulator, M, **kw)
+        for k, v in (("NSymbs", int(NSymbs)), ("K", 3), ("Nr", 2), ("Nt", 2), ("Ns", 1)):
+            self.params.add(k, v)
+        self.COUNTER_KEYS = tuple(self.COUNTER_KEYS)
+
+    def _run_batch(self, current_parameters, first_rep, count):
+        eng = self._bind()
+        res = eng.run_ia(current_parameters["NSymbs"], self._noise_var(current_parameters),
+                         self._seed_for(current_parameters), first_rep, count, method=self.demod_method,
+                         dtype=self.dtype)
+        self._cap = getattr(self, "_cap", 0.0) + res["sum_capacity"]
+        self._cap_sq = getattr(self, "_cap_sq", 0.0) + res["sum_capacity_sq"]
+        return res
+
+    def _on_simulate_current_params_start(self, current_params):
+        self._cap = self._cap_sq = 0.0
+
+    def _results_from_counters(self, current_parameters, c):
+        from .simulations import Result
+        res = super()._results_from_counters(current_parameters, c)
+        n = max(int(c["n_realizations"]), 1)
+        res.add_result(Result.from_batch("sum_capacity", Result.RATIOTYPE, self._cap, n, self._cap, self._cap_sq, n))
+        return res

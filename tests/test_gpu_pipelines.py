@@ -181,3 +181,55 @@ def test_pipeline_argument_errors(engine):
     with pytest.raises(_lib.McleError):
         engine.run_awgn(0, 0.1, SEED, 0, 4)
     assert engine.run_awgn(100, 0.1, SEED, 0, 0)["n_realizations"] == 0
+
+
+# ---- config 5: closed-form interference alignment ------------------------------------------------
+def test_ia_closed_form_injected(engine):
+    """ClosedFormIASolver on the reference's own channels: precoders, filters, SINR, capacity and --
+    through the staged operators -- the decisions of apps/ia/simulate_ia.py."""
+    from helpers import golden_cases, relerr
+    for kw, reals in golden_cases("c5_ia"):
+        H = np.stack([g["big_H"] for g in reals])
+        nv = float(reals[0]["noise_var"])
+        sol = engine.ia_closed_form(H, nv)
+        assert not sol["skipped"].any()
+        for b, g in enumerate(reals):
+            assert relerr(sol["F"][b], g["F"]) <= 1e-9 and relerr(sol["U"][b], g["U"]) <= 1e-9
+            assert relerr(sol["sinr"][b], g["sinr"]) <= 1e-8 and abs(sol["capacity"][b] - g["sum_capacity"]) <= 1e-8
+            # interference alignment property (reference tests/ia_package_test.py:977-1034)
+            for k in range(3):
+                for j in range(3):
+                    Hkj = g["big_H"][2 * k:2 * k + 2, 2 * j:2 * j + 2]
+                    val = sol["U"][b, k] @ Hkj @ sol["F"][b, j]
+                    assert abs(val - (1.0 if j == k else 0.0)) < 1e-8
+            # staged chain with injected data and noise -> identical decisions
+            engine.set_constellation(g["table"], _lib.CONST_QAM)
+            sym = engine.modulate(g["idx"].reshape(-1)).reshape(3, -1)
+            X = np.vstack([np.outer(sol["F"][b, k], sym[k]) for k in range(3)])
+            Y = engine.mimo_channel(g["big_H"][None], X[None], g["noise"][None], nv)[0]
+            est = np.vstack([sol["U"][b, k] @ Y[2 * k:2 * k + 2] for k in range(3)])
+            assert relerr(est, g["est"]) <= 1e-8
+            assert np.array_equal(engine.demodulate(est), g["decisions"])
+
+
+@pytest.mark.parametrize("dt,exact", [("f64", True), ("f32", False)])
+def test_ia_pipeline(engine, dt, exact):
+    kw = dict(mod="qam", M=16, K=3, nr=2, nt=2, Ns=1, NSymbs=200, snr_db=20.0)
+    engine.set_constellation(chains.constellation("qam", 16), _lib.CONST_QAM)
+    first, count = 9, 40
+    want = [chains.chain_ia(chains.PhiloxRng(SEED, r), **kw) for r in range(first, first + count)]
+    want_se = np.array([w["symbol_errors"] for w in want])
+    want_be = np.array([w["bit_errors"] for w in want])
+    want_cap = np.array([w["sum_capacity"] for w in want])
+    res, se, be, cap = engine.run_ia(200, 1.0 / omodem.dB2Linear(20.0), SEED, first, count, dtype=dt,
+                                     per_realization=True)
+    check(res, se, be, want_se, want_be, 600, 2400, exact)
+    assert np.max(np.abs(cap - want_cap)) <= 1e-7 and abs(res["sum_capacity"] - want_cap.sum()) <= 1e-6
+    # shard invariance at the BASELINE size (1e5 realizations of 600 symbols)
+    a = engine.run_ia(200, 0.01, SEED, 0, 100000, dtype="f32", method=_lib.DEMOD_QAM_SLICER)
+    b = engine.run_ia(200, 0.01, SEED, 0, 33333, dtype="f32", method=_lib.DEMOD_QAM_SLICER)
+    c = engine.run_ia(200, 0.01, SEED, 33333, 66667, dtype="f32", method=_lib.DEMOD_QAM_SLICER)
+    for k in ("sym_errors", "sym_errors_sq", "bit_errors", "bit_errors_sq", "n_realizations", "n_skipped"):
+        assert a[k] == b[k] + c[k]
+    assert 0.005 < a["sym_errors"] / (a["n_realizations"] * 600) < 0.08        # SURVEY App. A.3: 0.023
+    assert engine.run_ia(200, 0.0, SEED, 0, 2000, dtype="f32")["sym_errors"] == 0
