@@ -124,7 +124,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     eng = Engine(local_rank, args.dtype)
     run, units, workload = make_runner(eng, args.config, args.demod, args.dtype)
-    batch = args.batch or {"c4": 65536, "c3": 131072, "c2": 512}[args.config]
+    batch = args.batch or {"c4": 65536, "c3": 131072, "c2": 4096}[args.config]
 
     def barrier():
         eng.sync()

@@ -75,14 +75,19 @@ template <typename T, bool INV> __device__ __forceinline__ cx<T> rot(cx<T> a) {
 
 // ---- decimation in frequency: natural -> digit-reversed ----------------------------------------
 // Caller has written s_data and synchronised.  Returns synchronised.
-template <typename T, int N, bool INV>
+// NTHREADS > 0: the workgroup size is a compile-time constant, so the per-stage butterfly loops
+// unroll (independent LDS round trips in flight; with nf*N/4 a multiple of NTHREADS and N/4 ==
+// NTHREADS every lane runs the SAME butterfly of each transform and shares its twiddles).
+template <typename T, int N, bool INV, int NTHREADS = 0>
 __device__ __forceinline__ void fft_dif(cx<T>* s_data, int nf, int pitch, const cx<T>* tw) {
     constexpr int NB = N / 4;
+    const int nthreads = NTHREADS > 0 ? NTHREADS : (int)blockDim.x;
     int s = N / 4;
 #pragma unroll
     for (int st = 0; st < FftShape<N>::N4; ++st, s >>= 2) {
         const int twstep = N / (4 * s);
-        for (int b = threadIdx.x; b < nf * NB; b += blockDim.x) {
+#pragma unroll 4
+        for (int b = threadIdx.x; b < nf * NB; b += nthreads) {
             const int f = b / NB, bb = b - f * NB;
             const int k = bb & (s - 1), g = bb / s;
             cx<T>* p = s_data + f * pitch + g * 4 * s + k;
@@ -102,7 +107,7 @@ __device__ __forceinline__ void fft_dif(cx<T>* s_data, int nf, int pitch, const 
         __syncthreads();
     }
     if (FftShape<N>::HAS2) {
-        for (int b = threadIdx.x; b < nf * (N / 2); b += blockDim.x) {
+        for (int b = threadIdx.x; b < nf * (N / 2); b += nthreads) {
             const int f = b / (N / 2), bb = b - f * (N / 2);
             cx<T>* p = s_data + f * pitch + 2 * bb;
             const cx<T> x0 = p[0], x1 = p[1];
@@ -114,11 +119,12 @@ __device__ __forceinline__ void fft_dif(cx<T>* s_data, int nf, int pitch, const 
 }
 
 // ---- decimation in time: digit-reversed -> natural ------------------------------------------------
-template <typename T, int N, bool INV>
+template <typename T, int N, bool INV, int NTHREADS = 0>
 __device__ __forceinline__ void fft_dit(cx<T>* s_data, int nf, int pitch, const cx<T>* tw) {
     constexpr int NB = N / 4;
+    const int nthreads = NTHREADS > 0 ? NTHREADS : (int)blockDim.x;
     if (FftShape<N>::HAS2) {
-        for (int b = threadIdx.x; b < nf * (N / 2); b += blockDim.x) {
+        for (int b = threadIdx.x; b < nf * (N / 2); b += nthreads) {
             const int f = b / (N / 2), bb = b - f * (N / 2);
             cx<T>* p = s_data + f * pitch + 2 * bb;
             const cx<T> x0 = p[0], x1 = p[1];
@@ -131,7 +137,8 @@ __device__ __forceinline__ void fft_dit(cx<T>* s_data, int nf, int pitch, const 
 #pragma unroll
     for (int st = 0; st < FftShape<N>::N4; ++st, s <<= 2) {
         const int twstep = N / (4 * s);
-        for (int b = threadIdx.x; b < nf * NB; b += blockDim.x) {
+#pragma unroll 4
+        for (int b = threadIdx.x; b < nf * NB; b += nthreads) {
             const int f = b / NB, bb = b - f * NB;
             const int k = bb & (s - 1), g = bb / s;
             cx<T>* p = s_data + f * pitch + g * 4 * s + k;

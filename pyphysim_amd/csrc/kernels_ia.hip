@@ -11,6 +11,7 @@
 // applies the same normalisation, so F_0 -- whose phase rotates the post-filter noise -- matches.
 #include "modem.hpp"
 #include "philox.hpp"
+#include "totals.hpp"
 
 namespace mcle {
 
@@ -172,14 +173,16 @@ __global__ __launch_bounds__(64) void k_ia_closed_form(const cd* __restrict__ bi
 // fused config 5: one wavefront per realization
 template <typename T>
 __global__ __launch_bounds__(64) void k_run_ia(ModemParams<T> mp, int n_symbols, double noise_var, uint64_t seed,
-                                               uint64_t first, uint64_t count, unsigned* __restrict__ ws,
-                                               unsigned* __restrict__ skipped, double* __restrict__ cap_out) {
+                                               uint64_t first, uint64_t count, mcle_counters* counters,
+                                               uint32_t* __restrict__ sym_out, uint32_t* __restrict__ bit_out,
+                                               double* __restrict__ cap_out) {
     __shared__ cx<T> s_table[256];
     __shared__ cd s_H[36];
     load_table(mp, s_table);
     const int lane = threadIdx.x;
     const T sigma = (T)sqrt(noise_var);
     const uint32_t mask = (uint32_t)(mp.M - 1);
+    WgTotals totals;
     for (uint64_t rl = blockIdx.x; rl < count; rl += gridDim.x) {
         const Rng rng(seed, first + rl);
         __syncthreads();
@@ -231,19 +234,16 @@ __global__ __launch_bounds__(64) void k_run_ia(ModemParams<T> mp, int n_symbols,
         se = wave_sum_u32(se);
         be = wave_sum_u32(be);
         if (lane == 0) {
-            ws[2 * rl] = se;
-            ws[2 * rl + 1] = be;
-            skipped[rl] = s.ok ? 0u : 1u;
+            wg_account(totals, se, be, !s.ok, rl, sym_out, bit_out);
             if (cap_out) cap_out[rl] = s.capacity;
         }
     }
+    if (lane == 0)
+        wg_flush(totals, counters, 3ull * (unsigned long long)n_symbols, 3ull * (unsigned long long)n_symbols * mp.bits);
 }
 
 // defined in pipelines.hip
 int check_pipe(const mcle_ctx* ctx, int dtype, int method, const void* cfg);
-int pipe_workspace(mcle_ctx* ctx, uint64_t count, unsigned** ws, unsigned** skipped);
-int pipe_fold(mcle_ctx* ctx, const unsigned* ws, const unsigned* skipped, uint64_t count, uint64_t n_sym,
-              mcle_counters* d_counters, uint32_t* d_sym, uint32_t* d_bit);
 
 template <typename T> static ModemParams<T> ia_modem(const mcle_ctx* ctx, int method) {
     ModemParams<T> p;
@@ -292,19 +292,18 @@ int mcle_run_ia(mcle_ctx* ctx, int dtype, const mcle_ia_cfg* cfg, uint64_t seed,
     MCLE_REQUIRE(count <= 0x7fffffffull, "at most 2^31-1 realizations per call");
     if (count == 0) return MCLE_OK;
     if ((rc = ctx->bind())) return rc;
-    unsigned *ws = nullptr, *sk = nullptr;
-    if ((rc = pipe_workspace(ctx, count, &ws, &sk))) return rc;
     const uint64_t cap = (uint64_t)ctx->n_cu * 16;
     const unsigned grid = (unsigned)(count < cap ? count : cap);
     if (dtype == MCLE_F32)
         hipLaunchKernelGGL(k_run_ia<float>, dim3(grid), dim3(64), 0, ctx->stream, ia_modem<float>(ctx, cfg->demod_method),
-                           cfg->n_symbols, cfg->noise_var, seed, first, count, ws, sk, d_sum_capacity);
+                           cfg->n_symbols, cfg->noise_var, seed, first, count, d_counters, d_sym_err, d_bit_err,
+                           d_sum_capacity);
     else
         hipLaunchKernelGGL(k_run_ia<double>, dim3(grid), dim3(64), 0, ctx->stream,
                            ia_modem<double>(ctx, cfg->demod_method), cfg->n_symbols, cfg->noise_var, seed, first, count,
-                           ws, sk, d_sum_capacity);
+                           d_counters, d_sym_err, d_bit_err, d_sum_capacity);
     MCLE_LAUNCH_CHECK();
-    return pipe_fold(ctx, ws, sk, count, (uint64_t)3 * cfg->n_symbols, d_counters, d_sym_err, d_bit_err);
+    return MCLE_OK;
 }
 
 }  // extern "C"

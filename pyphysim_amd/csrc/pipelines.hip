@@ -17,6 +17,7 @@
 #include "mimo.hpp"
 #include "modem.hpp"
 #include "philox.hpp"
+#include "totals.hpp"
 
 namespace mcle {
 
@@ -105,11 +106,17 @@ struct FlatParams {
     double noise_sigma;
 };
 
-template <typename T>
+// LR > 0 (f32 only, fp.L == LR): the LR ray phasors are evaluated exactly (f64 phase) at the first of
+// a lane's 16 consecutive symbols and advanced by one complex rotation per symbol after that
+// (e^{j 2 pi w_l dt}, rounded once from f64); 15 rotations add < 1e-6 of phase error, below the
+// v_sin/v_cos error.  LR == 0: every sample evaluated from the closed form (any L, and f64).
+template <typename T, int LR>
 __global__ __launch_bounds__(kPipeBlock) void k_run_flat(FlatParams fp, ModemParams<T> mp, uint64_t seed,
                                                          uint64_t first, uint64_t count, unsigned* __restrict__ ws) {
+    constexpr bool kRec = (LR > 0) && (sizeof(T) == 4);
     __shared__ cx<T> s_table[kMaxTable];
     __shared__ double s_w[kMaxRays], s_psi[kMaxRays];
+    __shared__ float2 s_rot[kMaxRays];
     __shared__ unsigned s_red[2 * (kPipeBlock / 64)];
     load_table(mp, s_table);
     const int chunks = (fp.n_symbols + kChunk - 1) / kChunk;
@@ -131,8 +138,12 @@ __global__ __launch_bounds__(kPipeBlock) void k_run_flat(FlatParams fp, ModemPar
                 s_w[threadIdx.x] = two_pi * fp.Fd * cos(phi);
                 s_psi[threadIdx.x] = psi;
             } else {
-                s_w[threadIdx.x] = fp.Fd * cos(phi);
+                const double w = fp.Fd * cos(phi);
+                s_w[threadIdx.x] = w;
                 s_psi[threadIdx.x] = psi / two_pi;
+                double rs, rc;
+                sincos(two_pi * (w * fp.dt), &rs, &rc);
+                s_rot[threadIdx.x] = make_float2((float)rc, (float)rs);
             }
         }
         __syncthreads();
@@ -141,6 +152,15 @@ __global__ __launch_bounds__(kPipeBlock) void k_run_flat(FlatParams fp, ModemPar
         const int n_end = min(n_begin + kChunk, fp.n_symbols);
         for (int g0 = n_begin + (int)threadIdx.x * 16; g0 < n_end; g0 += kPipeBlock * 16) {
             const Words4 dw = rng.block(STREAM_DATA, (uint32_t)(g0 >> 4));
+            float2 ray[kRec ? LR : 1], rot[kRec ? LR : 1];
+            if (kRec) {
+                const double t = jakes_time(fp.t0, fp.dt, (double)g0);
+#pragma unroll
+                for (int l = 0; l < (kRec ? LR : 1); ++l) {
+                    ray[l] = jakes_ray<float>(s_w[l], s_psi[l], t);
+                    rot[l] = s_rot[l];
+                }
+            }
 #pragma unroll
             for (int pr = 0; pr < 8; ++pr) {
                 cx<T> z[2];
@@ -152,13 +172,23 @@ __global__ __launch_bounds__(kPipeBlock) void k_run_flat(FlatParams fp, ModemPar
                         const int tx = (int)((dw.w[j >> 2] >> ((j & 3) * 8)) & mask);
                         const cx<T> s = s_table[tx];
                         cx<T> r;
-                        if (fp.L > 0) {
+                        if (kRec) {
+                            float hr = 0, hi = 0;
+#pragma unroll
+                            for (int l = 0; l < (kRec ? LR : 1); ++l) {
+                                hr += ray[l].x;
+                                hi += ray[l].y;
+                                ray[l] = cmul(ray[l], rot[l]);
+                            }
+                            const cx<T> h = mk<T>((T)(amp * hr), (T)(amp * hi));
+                            r = cdivide(cadd(cmul(h, s), z[e]), h);
+                        } else if (fp.L > 0) {
                             const double t = jakes_time(fp.t0, fp.dt, (double)n);
                             T hr = 0, hi = 0;
                             for (int l = 0; l < fp.L; ++l) {
-                                const cx<T> ray = jakes_ray<T>(s_w[l], s_psi[l], t);
-                                hr += ray.x;
-                                hi += ray.y;
+                                const cx<T> rr = jakes_ray<T>(s_w[l], s_psi[l], t);
+                                hr += rr.x;
+                                hi += rr.y;
                             }
                             const cx<T> h = mk<T>(amp * hr, amp * hi);
                             r = cdivide(cadd(cmul(h, s), z[e]), h);
@@ -194,11 +224,12 @@ struct MimoParams {
 };
 
 template <typename T, int N, int NA>
-__global__ __launch_bounds__(kPipeBlock) void k_run_mimo_ofdm(MimoParams pp, ModemParams<T> mp, uint64_t seed,
+__global__ __launch_bounds__(kPipeBlock, sizeof(T) == 4 ? 3 : 1) void k_run_mimo_ofdm(MimoParams pp, ModemParams<T> mp, uint64_t seed,
                                                               uint64_t first, uint64_t count,
                                                               const cx<T>* __restrict__ g_tw,
-                                                              unsigned* __restrict__ ws,
-                                                              unsigned* __restrict__ skipped) {
+                                                              mcle_counters* counters,
+                                                              uint32_t* __restrict__ sym_out,
+                                                              uint32_t* __restrict__ bit_out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cx<T>* s_x = reinterpret_cast<cx<T>*>(smem);        // [NA][N]
     cx<T>* s_tw = s_x + NA * N;                          // [N]
@@ -218,6 +249,7 @@ __global__ __launch_bounds__(kPipeBlock) void k_run_mimo_ofdm(MimoParams pp, Mod
     const T tx_scale = (T)(1.0 / sqrt((double)NA) / sqrt((double)(U + cp)));  // encode / sqrt(Nt), ifft power scale
     const double rx_scale = sqrt((double)(U + cp)) / (double)N;               // fft / sqrt(power scale)
     const uint32_t mask = (uint32_t)(mp.M - 1);
+    WgTotals totals;
 
     for (uint64_t rl = blockIdx.x; rl < count; rl += gridDim.x) {
         const Rng rng(seed, first + rl);
@@ -268,7 +300,7 @@ __global__ __launch_bounds__(kPipeBlock) void k_run_mimo_ofdm(MimoParams pp, Mod
                 }
             }
             __syncthreads();
-            fft_dif<T, N, true>(s_x, NA, N, s_tw);  // time samples, digit-reversed positions
+            fft_dif<T, N, true, kPipeBlock>(s_x, NA, N, s_tw);  // time samples, digit-reversed positions
             // ---- channel: R = H T + noise on the samples that survive CP removal ----
             for (int j = tid; j < N / 2; j += kPipeBlock) {
                 const int half = j / (N / 4), rest = j - half * (N / 4);
@@ -300,7 +332,7 @@ __global__ __launch_bounds__(kPipeBlock) void k_run_mimo_ofdm(MimoParams pp, Mod
                 }
             }
             __syncthreads();
-            fft_dit<T, N, false>(s_x, NA, N, s_tw);  // bins, natural order
+            fft_dit<T, N, false, kPipeBlock>(s_x, NA, N, s_tw);  // bins, natural order
             // ---- receive: Blast decode (G already carries the FFT scale), demodulate, count ----
             cx<T> G[NA][NA];
 #pragma unroll
@@ -325,12 +357,11 @@ __global__ __launch_bounds__(kPipeBlock) void k_run_mimo_ofdm(MimoParams pp, Mod
             __syncthreads();
         }
         block_sum2(se, be, s_red);
-        if (tid == 0) {
-            ws[2 * rl] = se;
-            ws[2 * rl + 1] = be;
-            skipped[rl] = s_red[15];
-        }
+        if (tid == 0) wg_account(totals, se, be, s_red[15] != 0u, rl, sym_out, bit_out);
     }
+    if (tid == 0)
+        wg_flush(totals, counters, (unsigned long long)per_sym * pp.n_ofdm_sym,
+                 (unsigned long long)per_sym * pp.n_ofdm_sym * mp.bits);
 }
 
 // =================================================================================================
@@ -348,7 +379,9 @@ struct TdlParams {
 template <typename T, int N, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_run_ofdm_tdl(TdlParams pp, ModemParams<T> mp, uint64_t seed,
                                                         uint64_t first, uint64_t count,
-                                                        const cx<T>* __restrict__ g_tw, unsigned* __restrict__ ws) {
+                                                        const cx<T>* __restrict__ g_tw, mcle_counters* counters,
+                                                        uint32_t* __restrict__ sym_out,
+                                                        uint32_t* __restrict__ bit_out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cx<T>* s_a = reinterpret_cast<cx<T>*>(smem);   // [N] time-domain symbol (ping)
     cx<T>* s_b = s_a + N;                           // [N] time-domain symbol (pong)
@@ -359,7 +392,9 @@ __global__ __launch_bounds__(BLOCK) void k_run_ofdm_tdl(TdlParams pp, ModemParam
     cx<T>* s_part = s_mean + MCLE_MAX_TAPS;         // [MCLE_MAX_TAPS][BLOCK/64]
     double* s_w = reinterpret_cast<double*>(s_part + MCLE_MAX_TAPS * (BLOCK / 64));  // [taps*L]
     double* s_psi = s_w + MCLE_MAX_TAPS * kMaxRays / 4;                              // [taps*L]
-    unsigned* s_red = reinterpret_cast<unsigned*>(s_psi + MCLE_MAX_TAPS * kMaxRays / 4);
+    double2* s_rayD = reinterpret_cast<double2*>(s_psi + MCLE_MAX_TAPS * kMaxRays / 4);   // [taps*L] ray sums
+    float2* s_rotB = reinterpret_cast<float2*>(s_rayD + MCLE_MAX_TAPS * kMaxRays / 4);     // [taps*L] BLOCK-step rotations
+    unsigned* s_red = reinterpret_cast<unsigned*>(s_rotB + MCLE_MAX_TAPS * kMaxRays / 4);
     unsigned char* s_idx = reinterpret_cast<unsigned char*>(s_red + 16);             // [num_used]
 
     const int tid = threadIdx.x;
@@ -372,6 +407,7 @@ __global__ __launch_bounds__(BLOCK) void k_run_ofdm_tdl(TdlParams pp, ModemParam
     const T rx_scale = (T)(sqrt((double)(U + cp)) / (double)N);
     const uint32_t mask = (uint32_t)(mp.M - 1);
     const int lane = tid & 63, wave = tid >> 6;
+    WgTotals totals;
 
     for (uint64_t rl = blockIdx.x; rl < count; rl += gridDim.x) {
         const Rng rng(seed, first + rl);
@@ -386,8 +422,12 @@ __global__ __launch_bounds__(BLOCK) void k_run_ofdm_tdl(TdlParams pp, ModemParam
                 s_w[s * L + l] = two_pi * pp.Fd * cos(phi);
                 s_psi[s * L + l] = psi;
             } else {
-                s_w[s * L + l] = pp.Fd * cos(phi);
+                const double w = pp.Fd * cos(phi);
+                s_w[s * L + l] = w;
                 s_psi[s * L + l] = psi / two_pi;
+                double rs, rc;
+                sincos(two_pi * (w * pp.dt * BLOCK), &rs, &rc);
+                s_rotB[s * L + l] = make_float2((float)rc, (float)rs);
             }
         }
         cx<T>* cur = s_a;
@@ -411,71 +451,130 @@ __global__ __launch_bounds__(BLOCK) void k_run_ofdm_tdl(TdlParams pp, ModemParam
                 }
             }
             __syncthreads();
-            fft_dif<T, N, true>(cur, 1, N, s_tw);
-            // ---- channel + noise for the N samples kept after CP removal; tap means on the fly ----
+            fft_dif<T, N, true, BLOCK>(cur, 1, N, s_tw);
+            // ---- channel + noise for the N samples kept after CP removal, and the tap means ----
             const uint64_t sym0 = (uint64_t)os * (N + cp);  // absolute index of this symbol's first sample
-            for (int i = 0; i < S; ++i) {
-                T are = 0, aim = 0;
-                // samples j' in [0, N+cp) of this symbol contribute to the mean of tap i (ofdm.py:545-547)
-                for (int jp = tid; jp < N + cp; jp += BLOCK) {
-                    const double t = jakes_time(pp.Ts, pp.dt, (double)(sym0 + jp));
-                    T gr = 0, gi = 0;
+            // the sample (q within this symbol, or of the previous one) that tap delay d feeds into output m
+            auto tx_sample = [&](int m, int d) -> cx<T> {
+                const int q = cp + m - d;
+                if (q >= 0) return cur[fft_pos_of_index<N>((m - d + N) & (N - 1))];
+                const int qp = N + cp + q;  // inter-symbol interference: sample qp of the previous symbol
+                return qp >= cp ? prev[fft_pos_of_index<N>(qp - cp)] : prev[fft_pos_of_index<N>(N - cp + qp)];
+            };
+            if constexpr (sizeof(T) == 4) {
+                // f32 path.  (1) mean of every ray over the symbol's N+cp samples in closed form (f64):
+                //   sum_{j<W} e^{2 pi i (th0 + a j)} = e^{2 pi i (th0 + a (W-1)/2)} sin(pi a W) / sin(pi a)
+                const int Wn = N + cp;
+                for (int q = tid; q < S * L; q += BLOCK) {
+                    const double pi = 3.14159265358979323846;
+                    const double w = s_w[q], a = w * pp.dt;
+                    const double th0 = fma(w, jakes_time(pp.Ts, pp.dt, (double)sym0), s_psi[q]);
+                    const double den = sin(pi * a);
+                    const double ratio = fabs(den) > 1e-300 ? sin(pi * a * Wn) / den : (double)Wn;
+                    double sn, cs;
+                    const double th = th0 + 0.5 * a * (Wn - 1);
+                    sincos(2.0 * pi * (th - floor(th)), &sn, &cs);
+                    s_rayD[q] = mk<double>(ratio * cs, ratio * sn);
+                }
+                __syncthreads();
+                if (tid < S) {
+                    double re = 0, im = 0;
                     for (int l = 0; l < L; ++l) {
-                        const cx<T> ray = jakes_ray<T>(s_w[i * L + l], s_psi[i * L + l], t);
-                        gr += ray.x;
-                        gi += ray.y;
+                        re += s_rayD[tid * L + l].x;
+                        im += s_rayD[tid * L + l].y;
                     }
-                    are += gr;
-                    aim += gi;
+                    const double a = pp.tap_amp[tid] / (double)Wn;
+                    s_mean[tid] = mk<T>((T)(re * a), (T)(im * a));
                 }
+                // (2) channel: lane handles samples m = tid + BLOCK*k; every ray is evaluated once from
+                // the closed form (f64 phase) and stepped by the rotation e^{2 pi i w dt BLOCK}
+                constexpr int KS = N / BLOCK;
+                cx<T> sig[KS];
 #pragma unroll
-                for (int off = 32; off > 0; off >>= 1) {
-                    are += __shfl_xor(are, off, 64);
-                    aim += __shfl_xor(aim, off, 64);
-                }
-                if (lane == 0) s_part[i * (BLOCK / 64) + wave] = mk<T>(are, aim);
-            }
-            __syncthreads();
-            if (tid < S) {
-                T re = 0, im = 0;
-                for (int w = 0; w < BLOCK / 64; ++w) {
-                    re += s_part[tid * (BLOCK / 64) + w].x;
-                    im += s_part[tid * (BLOCK / 64) + w].y;
-                }
-                const T a = (T)pp.tap_amp[tid] / (T)(N + cp);
-                s_mean[tid] = mk<T>(re * a, im * a);
-            }
-            for (int m = tid; m < N; m += BLOCK) {
-                const uint64_t jabs = sym0 + cp + m;  // absolute sample index of output sample m
-                cx<T> acc = cn_sample<T>(rng, STREAM_NOISE, jabs, sigma);
-                cx<T> sig = mk<T>(0, 0);
+                for (int k = 0; k < KS; ++k) sig[k] = mk<T>(0, 0);
                 for (int i = 0; i < S; ++i) {
                     const int d = pp.tap_delay[i];
-                    const long long jsrc = (long long)jabs - d;  // sample the tap multiplies
-                    if (jsrc < 0) continue;                      // before the start of the stream
-                    const int q = cp + m - d;                    // its index inside this OFDM symbol
-                    cx<T> xs;
-                    if (q >= 0) {
-                        xs = cur[fft_pos_of_index<N>((m - d + N) & (N - 1))];
-                    } else {
-                        // inter-symbol interference: sample N+cp+q of the previous symbol
-                        const int qp = N + cp + q;
-                        xs = qp >= cp ? prev[fft_pos_of_index<N>(qp - cp)] : prev[fft_pos_of_index<N>(N - cp + qp)];
-                    }
-                    const double t = jakes_time(pp.Ts, pp.dt, (double)jsrc);
-                    T gr = 0, gi = 0;
+                    const long long j0 = (long long)(sym0 + cp + tid) - d;
+                    const double t = jakes_time(pp.Ts, pp.dt, (double)j0);
+                    cx<T> g[KS];
+#pragma unroll
+                    for (int k = 0; k < KS; ++k) g[k] = mk<T>(0, 0);
                     for (int l = 0; l < L; ++l) {
-                        const cx<T> ray = jakes_ray<T>(s_w[i * L + l], s_psi[i * L + l], t);
-                        gr += ray.x;
-                        gi += ray.y;
+                        cx<T> ph = jakes_ray<T>(s_w[i * L + l], s_psi[i * L + l], t);
+                        const cx<T> rot = s_rotB[i * L + l];
+#pragma unroll
+                        for (int k = 0; k < KS; ++k) {
+                            g[k] = cadd(g[k], ph);
+                            ph = cmul(ph, rot);
+                        }
                     }
                     const T a = (T)pp.tap_amp[i];
-                    sig = cadd(sig, cmul(mk<T>(a * gr, a * gi), xs));
+#pragma unroll
+                    for (int k = 0; k < KS; ++k)
+                        if (j0 + (long long)BLOCK * k >= 0)  // before the start of the stream: nothing to add
+                            sig[k] = cadd(sig[k], cmul(cscale(g[k], a), tx_sample(tid + BLOCK * k, d)));
                 }
-                s_y[fft_pos_of_index<N>(m)] = cadd(sig, acc);
+#pragma unroll
+                for (int k = 0; k < KS; ++k) {
+                    const int m = tid + BLOCK * k;
+                    s_y[fft_pos_of_index<N>(m)] = cadd(sig[k], cn_sample<T>(rng, STREAM_NOISE, sym0 + cp + m, sigma));
+                }
+            } else {
+                // f64 parity path: every tap gain from the closed form at its own sample time, the mean
+                // as the explicit sum over the symbol's samples (ofdm.py:545-547)
+                for (int i = 0; i < S; ++i) {
+                    T are = 0, aim = 0;
+                    for (int jp = tid; jp < N + cp; jp += BLOCK) {
+                        const double t = jakes_time(pp.Ts, pp.dt, (double)(sym0 + jp));
+                        T gr = 0, gi = 0;
+                        for (int l = 0; l < L; ++l) {
+                            const cx<T> ray = jakes_ray<T>(s_w[i * L + l], s_psi[i * L + l], t);
+                            gr += ray.x;
+                            gi += ray.y;
+                        }
+                        are += gr;
+                        aim += gi;
+                    }
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) {
+                        are += __shfl_xor(are, off, 64);
+                        aim += __shfl_xor(aim, off, 64);
+                    }
+                    if (lane == 0) s_part[i * (BLOCK / 64) + wave] = mk<T>(are, aim);
+                }
+                __syncthreads();
+                if (tid < S) {
+                    T re = 0, im = 0;
+                    for (int w = 0; w < BLOCK / 64; ++w) {
+                        re += s_part[tid * (BLOCK / 64) + w].x;
+                        im += s_part[tid * (BLOCK / 64) + w].y;
+                    }
+                    const T a = (T)pp.tap_amp[tid] / (T)(N + cp);
+                    s_mean[tid] = mk<T>(re * a, im * a);
+                }
+                for (int m = tid; m < N; m += BLOCK) {
+                    const uint64_t jabs = sym0 + cp + m;  // absolute sample index of output sample m
+                    const cx<T> acc = cn_sample<T>(rng, STREAM_NOISE, jabs, sigma);
+                    cx<T> sig = mk<T>(0, 0);
+                    for (int i = 0; i < S; ++i) {
+                        const int d = pp.tap_delay[i];
+                        const long long jsrc = (long long)jabs - d;  // sample the tap multiplies
+                        if (jsrc < 0) continue;                      // before the start of the stream
+                        const double t = jakes_time(pp.Ts, pp.dt, (double)jsrc);
+                        T gr = 0, gi = 0;
+                        for (int l = 0; l < L; ++l) {
+                            const cx<T> ray = jakes_ray<T>(s_w[i * L + l], s_psi[i * L + l], t);
+                            gr += ray.x;
+                            gi += ray.y;
+                        }
+                        const T a = (T)pp.tap_amp[i];
+                        sig = cadd(sig, cmul(mk<T>(a * gr, a * gi), tx_sample(m, d)));
+                    }
+                    s_y[fft_pos_of_index<N>(m)] = cadd(sig, acc);
+                }
             }
             __syncthreads();
-            fft_dit<T, N, false>(s_y, 1, N, s_tw);
+            fft_dit<T, N, false, BLOCK>(s_y, 1, N, s_tw);
             for (int d = tid; d < U; d += BLOCK) {
                 const int bin = ofdm_bin(d, N, U);
                 cx<T> h = mk<T>(0, 0);
@@ -492,11 +591,11 @@ __global__ __launch_bounds__(BLOCK) void k_run_ofdm_tdl(TdlParams pp, ModemParam
         }
         (void)dmax;
         block_sum2(se, be, s_red);
-        if (tid == 0) {
-            ws[2 * rl] = se;
-            ws[2 * rl + 1] = be;
-        }
+        if (tid == 0) wg_account(totals, se, be, false, rl, sym_out, bit_out);
     }
+    if (tid == 0)
+        wg_flush(totals, counters, (unsigned long long)U * pp.n_ofdm_sym,
+                 (unsigned long long)U * pp.n_ofdm_sym * mp.bits);
 }
 
 // ---- host side -----------------------------------------------------------------------------------
@@ -555,8 +654,15 @@ int run_flat_impl(mcle_ctx* ctx, const FlatParams& fp, int method, uint64_t seed
     const uint64_t items = count * (uint64_t)((fp.n_symbols + kChunk - 1) / kChunk);
     const uint64_t cap = (uint64_t)ctx->n_cu * 8;
     const unsigned grid = (unsigned)(items < cap ? items : cap);
-    hipLaunchKernelGGL(k_run_flat<T>, dim3(grid), dim3(kPipeBlock), 0, ctx->stream, fp, pipe_modem<T>(ctx, method),
-                       seed, first, count, ws);
+    if (sizeof(T) == 4 && fp.L == 8)
+        hipLaunchKernelGGL((k_run_flat<T, 8>), dim3(grid), dim3(kPipeBlock), 0, ctx->stream, fp,
+                           pipe_modem<T>(ctx, method), seed, first, count, ws);
+    else if (sizeof(T) == 4 && fp.L == 16)
+        hipLaunchKernelGGL((k_run_flat<T, 16>), dim3(grid), dim3(kPipeBlock), 0, ctx->stream, fp,
+                           pipe_modem<T>(ctx, method), seed, first, count, ws);
+    else
+        hipLaunchKernelGGL((k_run_flat<T, 0>), dim3(grid), dim3(kPipeBlock), 0, ctx->stream, fp,
+                           pipe_modem<T>(ctx, method), seed, first, count, ws);
     MCLE_LAUNCH_CHECK();
     return pipe_fold(ctx, ws, nullptr, count, (uint64_t)fp.n_symbols, d_counters, d_sym, d_bit);
 }
@@ -564,9 +670,7 @@ int run_flat_impl(mcle_ctx* ctx, const FlatParams& fp, int method, uint64_t seed
 template <typename T, int N, int NA>
 int run_mimo_impl(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, uint64_t seed, uint64_t first, uint64_t count,
                   mcle_counters* d_counters, uint32_t* d_sym, uint32_t* d_bit) {
-    unsigned *ws = nullptr, *sk = nullptr;
-    int rc = pipe_workspace(ctx, count, &ws, &sk);
-    if (rc) return rc;
+    int rc;
     void* tw = nullptr;
     if ((rc = ctx->get_twiddles(N, sizeof(T) == 8 ? MCLE_F64 : MCLE_F32, &tw))) return rc;
     MimoParams pp{cfg->cp_size, cfg->num_used, cfg->n_ofdm_sym, cfg->mmse, cfg->noise_var};
@@ -580,18 +684,16 @@ int run_mimo_impl(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, uint64_t seed, u
     const uint64_t cap = (uint64_t)ctx->n_cu * per_cu;
     const unsigned grid = (unsigned)(count < cap ? count : cap);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kPipeBlock), lds, ctx->stream, pp, pipe_modem<T>(ctx, cfg->demod_method),
-                       seed, first, count, (const cx<T>*)tw, ws, sk);
+                       seed, first, count, (const cx<T>*)tw, d_counters, d_sym, d_bit);
     MCLE_LAUNCH_CHECK();
-    return pipe_fold(ctx, ws, sk, count, (uint64_t)NA * cfg->num_used * cfg->n_ofdm_sym, d_counters, d_sym, d_bit);
+    return MCLE_OK;
 }
 
 template <typename T, int N>
 int run_tdl_impl(mcle_ctx* ctx, const mcle_ofdm_tdl_cfg* cfg, uint64_t seed, uint64_t first, uint64_t count,
                  mcle_counters* d_counters, uint32_t* d_sym, uint32_t* d_bit) {
     constexpr int BLOCK = N >= 1024 ? 256 : (N >= 256 ? 128 : 64);
-    unsigned *ws = nullptr, *sk = nullptr;
-    int rc = pipe_workspace(ctx, count, &ws, &sk);
-    if (rc) return rc;
+    int rc;
     void* tw = nullptr;
     if ((rc = ctx->get_twiddles(N, sizeof(T) == 8 ? MCLE_F64 : MCLE_F32, &tw))) return rc;
     TdlParams pp;
@@ -614,7 +716,8 @@ int run_tdl_impl(mcle_ctx* ctx, const mcle_ofdm_tdl_cfg* cfg, uint64_t seed, uin
         pp.tap_delay[i] = i < cfg->n_taps ? cfg->tap_delay[i] : 0;
     }
     const size_t lds = (size_t)(4 * N + kMaxTable + MCLE_MAX_TAPS + MCLE_MAX_TAPS * (BLOCK / 64)) * sizeof(cx<T>) +
-                       2 * (size_t)(MCLE_MAX_TAPS * kMaxRays / 4) * sizeof(double) + 16 * sizeof(unsigned) +
+                       (size_t)(MCLE_MAX_TAPS * kMaxRays / 4) * (2 * sizeof(double) + sizeof(double2) + sizeof(float2)) +
+                       16 * sizeof(unsigned) +
                        (size_t)cfg->num_used + 16;
     auto kern = k_run_ofdm_tdl<T, N, BLOCK>;
     MCLE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -624,9 +727,9 @@ int run_tdl_impl(mcle_ctx* ctx, const mcle_ofdm_tdl_cfg* cfg, uint64_t seed, uin
     const uint64_t cap = (uint64_t)ctx->n_cu * per_cu;
     const unsigned grid = (unsigned)(count < cap ? count : cap);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(BLOCK), lds, ctx->stream, pp, pipe_modem<T>(ctx, cfg->demod_method), seed,
-                       first, count, (const cx<T>*)tw, ws);
+                       first, count, (const cx<T>*)tw, d_counters, d_sym, d_bit);
     MCLE_LAUNCH_CHECK();
-    return pipe_fold(ctx, ws, nullptr, count, (uint64_t)cfg->num_used * cfg->n_ofdm_sym, d_counters, d_sym, d_bit);
+    return MCLE_OK;
 }
 
 }  // namespace mcle

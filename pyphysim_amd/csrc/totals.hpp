@@ -1,0 +1,43 @@
+// totals.hpp -- per-workgroup running totals of the fused pipelines and their flush into the
+// exact-integer mcle_counters block (what Result.update / merge accumulate, reference
+// simulations/results.py:469-623).
+#pragma once
+#include "common.hpp"
+
+namespace mcle {
+
+// Running totals of one workgroup (held by thread 0), flushed with six atomics at kernel end:
+// the counter block is exact integer sums, so the order of the atomics is irrelevant.
+struct WgTotals {
+    unsigned long long se = 0, se2 = 0, be = 0, be2 = 0, ok = 0, skip = 0;
+};
+__device__ __forceinline__ void wg_account(WgTotals& t, unsigned se, unsigned be, bool skipped, uint64_t rl,
+                                           uint32_t* __restrict__ sym_out, uint32_t* __restrict__ bit_out) {
+    if (sym_out) sym_out[rl] = skipped ? 0xFFFFFFFFu : se;
+    if (bit_out) bit_out[rl] = skipped ? 0xFFFFFFFFu : be;
+    if (skipped) {
+        ++t.skip;
+    } else {
+        ++t.ok;
+        t.se += se;
+        t.se2 += (unsigned long long)se * se;
+        t.be += be;
+        t.be2 += (unsigned long long)be * be;
+    }
+}
+__device__ __forceinline__ void wg_flush(const WgTotals& t, mcle_counters* counters, unsigned long long n_sym,
+                                         unsigned long long n_bits) {
+    if (!counters) return;
+    atomicAdd((unsigned long long*)&counters->sym_errors, t.se);
+    atomicAdd((unsigned long long*)&counters->sym_errors_sq, t.se2);
+    atomicAdd((unsigned long long*)&counters->bit_errors, t.be);
+    atomicAdd((unsigned long long*)&counters->bit_errors_sq, t.be2);
+    atomicAdd((unsigned long long*)&counters->n_realizations, t.ok);
+    atomicAdd((unsigned long long*)&counters->n_skipped, t.skip);
+    if (blockIdx.x == 0) {
+        counters->n_symbols = n_sym;
+        counters->n_bits = n_bits;
+    }
+}
+
+}  // namespace mcle

@@ -1,0 +1,34 @@
+#!/bin/bash
+# Runs on the GPU box (via gpurun): GPU test-suite, then the bench for every config.
+# usage: bash scripts/gpu_check.sh [quick|full|prof]
+mode=${1:-quick}
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+timeout 1200 python -m pytest tests -m gpu -q --timeout=900 > gpurun_out/pytest_gpu.log 2>&1
+echo "pytest rc=$?" >> gpurun_out/pytest_gpu.log
+tail -5 gpurun_out/pytest_gpu.log
+for cfg in "c4 --demod slicer" "c4 --demod mindist" "c3" "c2"; do
+  name=${cfg// /_}; name=${name//--demod_/}
+  timeout 600 python bench.py --steps 10 --warmup 2 --no-cpu --config $cfg > gpurun_out/bench_$name.json 2> gpurun_out/bench_$name.err
+  echo "== $cfg rc=$?"; python - "gpurun_out/bench_$name.json" <<'PY'
+import json, sys
+try:
+    d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    print("   %.4g realizations/s  ms/step %.3f  kernel ms %.3f  frac %.3f  ser %.5f" % (
+        d["value"], d["ms_per_step"], d["roofline"]["kernel_ms_per_launch"], d["roofline"]["frac"], d["ser"]))
+except Exception as e:
+    print("   (no json)", e)
+PY
+done
+if [ "$mode" = "full" ] || [ "$mode" = "prof" ]; then
+  timeout 600 python bench.py --steps 20 --warmup 3 > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err
+  echo "default bench rc=$?"; tail -c 1500 gpurun_out/bench_default.json
+fi
+if [ "$mode" = "prof" ]; then
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_stats -o c4 -- python bench.py --steps 10 --warmup 2 --no-cpu > gpurun_out/prof_stats.log 2>&1
+  for pmc in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_LDS" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_SALU SQ_WAIT_INST_LDS"; do
+    tag=$(echo $pmc | cut -d' ' -f1)
+    timeout 600 rocprofv3 --pmc $pmc --output-format csv -d gpurun_out/prof_$tag -o c4 -- python bench.py --steps 3 --warmup 1 --no-cpu > gpurun_out/prof_$tag.log 2>&1
+    echo "pmc $tag rc=$?"
+  done
+fi
