@@ -63,6 +63,18 @@ __host__ __device__ __forceinline__ int ofdm_bin(int d, int n, int num_used) {
     return d < h ? n - h + d : 1 + (d - h);
 }
 
+// LDS bank swizzle for the in-place radix-4 stages.  A wave64 ds_read/write_b64 is serviced per
+// half-wave of 32 lanes over 32 eight-byte slots; stages with span s < 64 touch s-element runs that
+// are 4s apart, which piles 2 (s = 16) or 4 (s = 4, 1) lanes on a slot.  XOR-ing index bits 5..6
+// into bits 0..3 and bit 6 into bit 4 makes every stage's four accesses -- and every contiguous
+// aligned run -- hit 32 distinct slots (checked exhaustively in tests/test_fft_layout.py).
+// SWZ = false keeps the linear layout (operator kernels with global-memory twiddles).
+template <bool SWZ> __host__ __device__ __forceinline__ int lds_swz(int e) {
+    if (!SWZ) return e;
+    const int r = (e >> 5) & 3;
+    return e ^ (r * 5) ^ ((e >> 2) & 16);
+}
+
 template <typename T, bool INV> __device__ __forceinline__ cx<T> tw_get(const cx<T>* tw, int i) {
     cx<T> w = tw[i];
     if (INV) w.y = -w.y;
@@ -78,7 +90,7 @@ template <typename T, bool INV> __device__ __forceinline__ cx<T> rot(cx<T> a) {
 // NTHREADS > 0: the workgroup size is a compile-time constant, so the per-stage butterfly loops
 // unroll (independent LDS round trips in flight; with nf*N/4 a multiple of NTHREADS and N/4 ==
 // NTHREADS every lane runs the SAME butterfly of each transform and shares its twiddles).
-template <typename T, int N, bool INV, int NTHREADS = 0>
+template <typename T, int N, bool INV, int NTHREADS = 0, bool SWZ = false>
 __device__ __forceinline__ void fft_dif(cx<T>* s_data, int nf, int pitch, const cx<T>* tw) {
     constexpr int NB = N / 4;
     const int nthreads = NTHREADS > 0 ? NTHREADS : (int)blockDim.x;
@@ -90,8 +102,11 @@ __device__ __forceinline__ void fft_dif(cx<T>* s_data, int nf, int pitch, const 
         for (int b = threadIdx.x; b < nf * NB; b += nthreads) {
             const int f = b / NB, bb = b - f * NB;
             const int k = bb & (s - 1), g = bb / s;
-            cx<T>* p = s_data + f * pitch + g * 4 * s + k;
-            const cx<T> x0 = p[0], x1 = p[s], x2 = p[2 * s], x3 = p[3 * s];
+            cx<T>* p = s_data + f * pitch;
+            const int e0 = g * 4 * s + k;
+            const int i0 = lds_swz<SWZ>(e0), i1 = lds_swz<SWZ>(e0 + s), i2 = lds_swz<SWZ>(e0 + 2 * s),
+                      i3 = lds_swz<SWZ>(e0 + 3 * s);
+            const cx<T> x0 = p[i0], x1 = p[i1], x2 = p[i2], x3 = p[i3];
             const cx<T> a0 = cadd(x0, x2), a1 = csub(x0, x2), a2 = cadd(x1, x3), a3 = rot<T, INV>(csub(x1, x3));
             cx<T> y0 = cadd(a0, a2), y1 = cadd(a1, a3), y2 = csub(a0, a2), y3 = csub(a1, a3);
             if (s > 1) {
@@ -99,37 +114,39 @@ __device__ __forceinline__ void fft_dif(cx<T>* s_data, int nf, int pitch, const 
                 y2 = cmul(y2, tw_get<T, INV>(tw, 2 * k * twstep));
                 y3 = cmul(y3, tw_get<T, INV>(tw, 3 * k * twstep));
             }
-            p[0] = y0;
-            p[s] = y1;
-            p[2 * s] = y2;
-            p[3 * s] = y3;
+            p[i0] = y0;
+            p[i1] = y1;
+            p[i2] = y2;
+            p[i3] = y3;
         }
         __syncthreads();
     }
     if (FftShape<N>::HAS2) {
         for (int b = threadIdx.x; b < nf * (N / 2); b += nthreads) {
             const int f = b / (N / 2), bb = b - f * (N / 2);
-            cx<T>* p = s_data + f * pitch + 2 * bb;
-            const cx<T> x0 = p[0], x1 = p[1];
-            p[0] = cadd(x0, x1);
-            p[1] = csub(x0, x1);
+            cx<T>* p = s_data + f * pitch;
+            const int i0 = lds_swz<SWZ>(2 * bb), i1 = lds_swz<SWZ>(2 * bb + 1);
+            const cx<T> x0 = p[i0], x1 = p[i1];
+            p[i0] = cadd(x0, x1);
+            p[i1] = csub(x0, x1);
         }
         __syncthreads();
     }
 }
 
 // ---- decimation in time: digit-reversed -> natural ------------------------------------------------
-template <typename T, int N, bool INV, int NTHREADS = 0>
+template <typename T, int N, bool INV, int NTHREADS = 0, bool SWZ = false>
 __device__ __forceinline__ void fft_dit(cx<T>* s_data, int nf, int pitch, const cx<T>* tw) {
     constexpr int NB = N / 4;
     const int nthreads = NTHREADS > 0 ? NTHREADS : (int)blockDim.x;
     if (FftShape<N>::HAS2) {
         for (int b = threadIdx.x; b < nf * (N / 2); b += nthreads) {
             const int f = b / (N / 2), bb = b - f * (N / 2);
-            cx<T>* p = s_data + f * pitch + 2 * bb;
-            const cx<T> x0 = p[0], x1 = p[1];
-            p[0] = cadd(x0, x1);
-            p[1] = csub(x0, x1);
+            cx<T>* p = s_data + f * pitch;
+            const int i0 = lds_swz<SWZ>(2 * bb), i1 = lds_swz<SWZ>(2 * bb + 1);
+            const cx<T> x0 = p[i0], x1 = p[i1];
+            p[i0] = cadd(x0, x1);
+            p[i1] = csub(x0, x1);
         }
         __syncthreads();
     }
@@ -141,18 +158,21 @@ __device__ __forceinline__ void fft_dit(cx<T>* s_data, int nf, int pitch, const 
         for (int b = threadIdx.x; b < nf * NB; b += nthreads) {
             const int f = b / NB, bb = b - f * NB;
             const int k = bb & (s - 1), g = bb / s;
-            cx<T>* p = s_data + f * pitch + g * 4 * s + k;
-            cx<T> u0 = p[0], u1 = p[s], u2 = p[2 * s], u3 = p[3 * s];
+            cx<T>* p = s_data + f * pitch;
+            const int e0 = g * 4 * s + k;
+            const int i0 = lds_swz<SWZ>(e0), i1 = lds_swz<SWZ>(e0 + s), i2 = lds_swz<SWZ>(e0 + 2 * s),
+                      i3 = lds_swz<SWZ>(e0 + 3 * s);
+            cx<T> u0 = p[i0], u1 = p[i1], u2 = p[i2], u3 = p[i3];
             if (s > 1) {
                 u1 = cmul(u1, tw_get<T, INV>(tw, k * twstep));
                 u2 = cmul(u2, tw_get<T, INV>(tw, 2 * k * twstep));
                 u3 = cmul(u3, tw_get<T, INV>(tw, 3 * k * twstep));
             }
             const cx<T> a0 = cadd(u0, u2), a1 = csub(u0, u2), a2 = cadd(u1, u3), a3 = rot<T, INV>(csub(u1, u3));
-            p[0] = cadd(a0, a2);
-            p[s] = cadd(a1, a3);
-            p[2 * s] = csub(a0, a2);
-            p[3 * s] = csub(a1, a3);
+            p[i0] = cadd(a0, a2);
+            p[i1] = cadd(a1, a3);
+            p[i2] = csub(a0, a2);
+            p[i3] = csub(a1, a3);
         }
         __syncthreads();
     }

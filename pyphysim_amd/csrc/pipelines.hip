@@ -295,22 +295,23 @@ __global__ __launch_bounds__(kPipeBlock, sizeof(T) == 4 ? 3 : 1) void k_run_mimo
                         const int nl = (int)(n - n_first);
                         const int a = nl % NA, d = nl / NA;
                         s_idx[nl] = (unsigned char)tx;
-                        s_x[a * N + ofdm_bin(d, N, U)] = cscale(s_table[tx], tx_scale);
+                        s_x[a * N + lds_swz<true>(ofdm_bin(d, N, U))] = cscale(s_table[tx], tx_scale);
                     }
                 }
             }
             __syncthreads();
-            fft_dif<T, N, true, kPipeBlock>(s_x, NA, N, s_tw);  // time samples, digit-reversed positions
+            fft_dif<T, N, true, kPipeBlock, true>(s_x, NA, N, s_tw);  // time samples, digit-reversed positions
             // ---- channel: R = H T + noise on the samples that survive CP removal ----
             for (int j = tid; j < N / 2; j += kPipeBlock) {
                 const int half = j / (N / 4), rest = j - half * (N / 4);
                 const int p0 = 2 * half * (N / 4) + rest, p1 = p0 + N / 4;
                 const int m0 = fft_index_of_pos<N>(p0);  // even; position p1 holds m0 + 1
+                const int q0 = lds_swz<true>(p0), q1 = lds_swz<true>(p1);
                 cx<T> x0[NA], x1[NA];
 #pragma unroll
                 for (int a = 0; a < NA; ++a) {
-                    x0[a] = s_x[a * N + p0];
-                    x1[a] = s_x[a * N + p1];
+                    x0[a] = s_x[a * N + q0];
+                    x1[a] = s_x[a * N + q1];
                 }
 #pragma unroll
                 for (int r = 0; r < NA; ++r) {
@@ -327,12 +328,12 @@ __global__ __launch_bounds__(kPipeBlock, sizeof(T) == 4 ? 3 : 1) void k_run_mimo
                         z0 = cfma(H[r][a], x0[a], z0);
                         z1 = cfma(H[r][a], x1[a], z1);
                     }
-                    s_x[r * N + p0] = z0;
-                    s_x[r * N + p1] = z1;
+                    s_x[r * N + q0] = z0;
+                    s_x[r * N + q1] = z1;
                 }
             }
             __syncthreads();
-            fft_dit<T, N, false, kPipeBlock>(s_x, NA, N, s_tw);  // bins, natural order
+            fft_dit<T, N, false, kPipeBlock, true>(s_x, NA, N, s_tw);  // bins, natural order
             // ---- receive: Blast decode (G already carries the FFT scale), demodulate, count ----
             cx<T> G[NA][NA];
 #pragma unroll
@@ -340,7 +341,7 @@ __global__ __launch_bounds__(kPipeBlock, sizeof(T) == 4 ? 3 : 1) void k_run_mimo
 #pragma unroll
                 for (int r = 0; r < NA; ++r) G[a][r] = s_G[a * NA + r];
             for (int d = tid; d < U; d += kPipeBlock) {
-                const int bin = ofdm_bin(d, N, U);
+                const int bin = lds_swz<true>(ofdm_bin(d, N, U));
                 cx<T> y[NA];
 #pragma unroll
                 for (int r = 0; r < NA; ++r) y[r] = s_x[r * N + bin];

@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Condense gpurun_out/ (rocprofv3 csv + bench json) into the tracked profiles/<round>/ summaries.
+
+usage: python scripts/collect_profiles.py r01
+Also writes profiles/traffic_c4.json, which bench.py reads for roofline.traffic:
+hbm_bytes_per_launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024, following
+/opt/skills/guides/MI355X_MICROARCH.md (rocprofv3 counts KiB; on gfx950 FETCH_SIZE reports half of
+a coalesced stream's bytes, WRITE_SIZE is uncalibrated).
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src = os.path.join(REPO, "gpurun_out")
+dst = os.path.join(REPO, "profiles", rnd)
+os.makedirs(dst, exist_ok=True)
+
+stats = os.path.join(src, "prof_stats", "c4_kernel_stats.csv")
+if os.path.exists(stats):
+    shutil.copy(stats, os.path.join(dst, "c4_kernel_stats.csv"))
+
+summary = {}
+meta = {}
+for path in sorted(glob.glob(os.path.join(src, "prof_*", "c4_counter_collection.csv"))):
+    agg = collections.defaultdict(list)
+    for row in csv.DictReader(open(path)):
+        if "k_run_mimo_ofdm" in row["Kernel_Name"]:
+            agg[row["Counter_Name"]].append(float(row["Counter_Value"]))
+            meta = {k: row[k] for k in ("Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count",
+                                        "Accum_VGPR_Count", "SGPR_Count", "Scratch_Size")}
+    for name, vals in agg.items():
+        summary[name] = {"launches": len(vals), "mean_per_launch": sum(vals) / len(vals), "min": min(vals),
+                         "max": max(vals)}
+if summary:
+    g = lambda k: summary.get(k, {}).get("mean_per_launch")
+    derived = {}
+    if g("SQ_ACTIVE_INST_VALU") and g("SQ_WAVE_CYCLES"):
+        derived["valu_active_per_wave"] = g("SQ_ACTIVE_INST_VALU") / g("SQ_WAVE_CYCLES")
+    if g("SQ_LDS_BANK_CONFLICT") and g("SQ_LDS_IDX_ACTIVE"):
+        derived["lds_bank_conflict_frac"] = g("SQ_LDS_BANK_CONFLICT") / g("SQ_LDS_IDX_ACTIVE")
+    if g("SQ_WAIT_INST_ANY") and g("SQ_WAVE_CYCLES"):
+        derived["wait_inst_any_frac"] = g("SQ_WAIT_INST_ANY") / g("SQ_WAVE_CYCLES")
+    if g("FETCH_SIZE") is not None and g("WRITE_SIZE") is not None:
+        derived["hbm_bytes_per_launch"] = (2.0 * g("FETCH_SIZE") + g("WRITE_SIZE")) * 1024.0
+    summary["_derived"] = derived
+    summary["_kernel"] = "k_run_mimo_ofdm<float,1024,4>, 65536 realizations per launch (bench.py default workload)"
+    summary["_dispatch"] = meta
+    json.dump(summary, open(os.path.join(dst, "c4_pmc_summary.json"), "w"), indent=1)
+    if "hbm_bytes_per_launch" in derived:
+        json.dump({"hbm_bytes_per_launch": derived["hbm_bytes_per_launch"], "realizations_per_launch": 65536,
+                   "source": "profiles/%s/c4_pmc_summary.json" % rnd,
+                   "rule": "(2*FETCH_SIZE + WRITE_SIZE) KiB per MI355X_MICROARCH.md"},
+                  open(os.path.join(REPO, "profiles", "traffic_c4.json"), "w"), indent=1)
+
+for path in sorted(glob.glob(os.path.join(src, "bench_*.json"))):
+    lines = [l for l in open(path).read().strip().splitlines() if l.startswith("{")]
+    if lines:
+        open(os.path.join(dst, os.path.basename(path)), "w").write(lines[-1] + "\n")
+print("wrote", sorted(os.listdir(dst)))
+if summary:
+    print(json.dumps(summary["_derived"], indent=1), json.dumps(meta))
