@@ -219,6 +219,27 @@ int mcle_run_ia(mcle_ctx* ctx, int dtype, const mcle_ia_cfg* cfg, uint64_t seed,
 int mcle_ia_closed_form(mcle_ctx* ctx, const void* d_bigH, double noise_var, void* d_F, void* d_U,
                         double* d_sinr, double* d_capacity, uint32_t* d_skipped, size_t batch);
 
+/* ---- same-seed parity mode: NumPy's legacy global RandomState replayed on the device -------
+ * Realization r receives exactly what the reference draws after np.random.seed(seed_base + r)
+ * (legacy MT19937; util/misc.py:327-355 randn_c = randn real block then imag block, and
+ * np.random.randint of apps/awgn_modulators/simulate_psk.py:65).  A program is a sequence of
+ * segments: kind 0 = randint(0, range, n) with `range` a power of two -> int32 outputs,
+ * kind 1 = randn(n) -> float64 outputs (the polar method's cached value carries over between
+ * segments like NumPy's), kind 2 = rand(n) -> float64 uniforms in [0, 1).  Rows: d_int [count][n_int], d_dbl [count][n_dbl]; d_status[count] is
+ * set to 1 if the word budget of a realization was exhausted (never observed; may be NULL). */
+typedef struct mcle_legacy_seg {
+    int32_t kind;
+    int32_t n;
+    uint32_t range;
+    uint32_t reserved;
+} mcle_legacy_seg;
+int mcle_legacy_draws(mcle_ctx* ctx, const mcle_legacy_seg* segs, int n_segs, uint32_t seed_base,
+                      uint64_t first, uint64_t count, int32_t* d_int, size_t n_int, double* d_dbl,
+                      size_t n_dbl, uint32_t* d_status);
+/* out = scale * (re + 1j*im): assembles randn_c from the two randn blocks */
+int mcle_complex_from_parts(mcle_ctx* ctx, int dtype, const double* d_re, const double* d_im,
+                            double scale, void* d_out, size_t n);
+
 #ifdef __cplusplus
 }
 #endif

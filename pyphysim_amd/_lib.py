@@ -63,6 +63,10 @@ class IaCfg(Structure):
                 ("demod_method", c_int32), ("noise_var", c_double)]
 
 
+class LegacySeg(Structure):
+    _fields_ = [("kind", c_int32), ("n", c_int32), ("range", c_uint32), ("reserved", c_uint32)]
+
+
 _P = c_void_p
 _PROTOS = {
     "mcle_last_error": (c_char_p, []),
@@ -107,6 +111,9 @@ _PROTOS = {
     "mcle_run_mimo_ofdm": (c_int, [_P, c_int, POINTER(MimoOfdmCfg), c_uint64, c_uint64, c_uint64, _P, _P, _P]),
     "mcle_run_ia": (c_int, [_P, c_int, POINTER(IaCfg), c_uint64, c_uint64, c_uint64, _P, _P, _P, _P]),
     "mcle_ia_closed_form": (c_int, [_P, _P, c_double, _P, _P, _P, _P, _P, c_size_t]),
+    "mcle_legacy_draws": (c_int, [_P, POINTER(LegacySeg), c_int, c_uint32, c_uint64, c_uint64, _P, c_size_t, _P,
+                                  c_size_t, _P]),
+    "mcle_complex_from_parts": (c_int, [_P, c_int, _P, _P, c_double, _P, c_size_t]),
 }
 
 _lib = None

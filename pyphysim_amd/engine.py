@@ -13,7 +13,7 @@ import numpy as np
 
 from . import _lib
 from ._lib import (CONST_BPSK, CONST_GENERIC, CONST_QAM, DEMOD_MINDIST, DEMOD_QAM_SLICER, MCLE_F32, MCLE_F64,
-                   AwgnCfg, Counters, FlatCfg, IaCfg, McleError, MimoOfdmCfg, OfdmTdlCfg, check)
+                   AwgnCfg, Counters, FlatCfg, IaCfg, LegacySeg, McleError, MimoOfdmCfg, OfdmTdlCfg, check)
 
 
 class DeviceArray:
@@ -453,6 +453,40 @@ class Engine:
         check(self.lib.mcle_ia_closed_form(self.ctx, d_H.ptr, float(noise_var), F.ptr, U.ptr, sinr.ptr, cap.ptr,
                                            sk.ptr, b))
         return dict(F=F.get(), U=U.get(), sinr=sinr.get(), capacity=cap.get(), skipped=sk.get())
+
+    # ---- same-seed parity mode (NumPy legacy RandomState on the device) ----------------------
+    def legacy_draws(self, program, seed_base, first, count):
+        """program: list of ('randint', n, range) / ('randn', n) / ('rand', n).  Realization r gets
+        what NumPy draws after np.random.seed(seed_base + first + r).  Returns (ints DeviceArray
+        [count, n_int] int32, doubles DeviceArray [count, n_dbl] float64)."""
+        kinds = {"randint": 0, "randn": 1, "rand": 2}
+        segs = (LegacySeg * len(program))()
+        n_int = n_dbl = 0
+        for i, item in enumerate(program):
+            k = kinds[item[0]]
+            segs[i].kind, segs[i].n = k, int(item[1])
+            segs[i].range = int(item[2]) if k == 0 else 0
+            if k == 0:
+                n_int += int(item[1])
+            else:
+                n_dbl += int(item[1])
+        ints = self.empty((count, max(n_int, 1)), np.int32)
+        dbls = self.empty((count, max(n_dbl, 1)), np.float64)
+        status = self.zeros(count, np.uint32)
+        check(self.lib.mcle_legacy_draws(self.ctx, segs, len(program), int(seed_base) & 0xFFFFFFFF, int(first),
+                                         int(count), ints.ptr, max(n_int, 1), dbls.ptr, max(n_dbl, 1), status.ptr))
+        if status.get().any():
+            raise McleError("legacy draw program ran out of words")
+        return ints, dbls
+
+    def complex_from_parts(self, re, im, scale=1.0, dtype=None):
+        """scale * (re + 1j*im) on the device from two float64 arrays (host or device)."""
+        dt = self._dt(dtype)
+        d_re = re if isinstance(re, DeviceArray) else self.to_device(np.asarray(re), np.float64)
+        d_im = im if isinstance(im, DeviceArray) else self.to_device(np.asarray(im), np.float64)
+        out = self.empty(d_re.shape, _lib.np_complex(dt))
+        check(self.lib.mcle_complex_from_parts(self.ctx, dt, d_re.ptr, d_im.ptr, float(scale), out.ptr, d_re.size))
+        return out
 
 
 _default = {}
