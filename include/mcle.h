@@ -148,6 +148,23 @@ int mcle_mimo_channel(mcle_ctx* ctx, int dtype, const void* d_H, const void* d_X
                       const void* d_noise, double noise_var, int nr, int nt, size_t ns, void* d_Y,
                       size_t batch);
 
+/* ---- a13: further MIMO schemes of mimo/mimo.py ---------------------------------------------- */
+/* Alamouti (mimo.py:1168-1269): x [batch][n] -> X [batch][2][n] (n even); decode with H [batch][nr][2] */
+int mcle_alamouti_encode(mcle_ctx* ctx, int dtype, const void* d_x, size_t n, void* d_X,
+                         size_t batch);
+int mcle_alamouti_decode(mcle_ctx* ctx, int dtype, const void* d_H, const void* d_Y, int nr, size_t n,
+                         void* d_out, size_t batch);
+/* MRT (mimo.py:666-783), MISO h [batch][nt]: X = exp(-1j angle(h)).T / sqrt(nt) * x; decode y * sqrt(nt)/sum|h| */
+int mcle_mrt_encode(mcle_ctx* ctx, int dtype, const void* d_h, const void* d_x, int nt, size_t n,
+                    void* d_X, size_t batch);
+int mcle_mrt_decode(mcle_ctx* ctx, int dtype, const void* d_h, const void* d_y, int nt, size_t n,
+                    void* d_out, size_t batch);
+/* SVDMimo (mimo.py:833-946), square H [batch][n][n]: W = V/sqrt(n) (precoder), G = diag(1/S) U^H sqrt(n)
+ * (receive filter), S descending (d_S may be NULL).  encode = W @ x.reshape(n,-1), decode = G @ Y via
+ * mcle_mimo_channel. */
+int mcle_svd_filters(mcle_ctx* ctx, int dtype, const void* d_H, int n_ant, void* d_W, void* d_G,
+                     double* d_S, size_t batch);
+
 /* ---- fused pipelines: whole realizations on-chip (randomness: mcle-philox-v1) ----------- */
 typedef struct mcle_awgn_cfg {          /* C1: apps/awgn_modulators/simulate_psk.py:51-115 */
     int32_t n_symbols;

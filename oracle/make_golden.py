@@ -144,6 +144,32 @@ def golden_operators():
     close(omimo.blast_decode(y, H, 0.05), mm, 1e-12, "blast mmse")
     out["blast_H"], out["blast_x"], out["blast_enc"], out["blast_y"] = H, x, enc, y
     out["blast_zf"], out["blast_mmse"], out["blast_nv"] = zf, mm, 0.05
+    # Alamouti / MRT / SVD (mimo.py:666-1287)
+    Ha = rmisc.randn_c(3, 2)
+    ala = rmimo.Alamouti(Ha)
+    xa = rs.randn(24) + 1j * rs.randn(24)
+    ea = ala.encode(xa)
+    close(omimo.alamouti_encode(xa), ea, 0, "alamouti.encode")
+    ya = Ha @ ea + 0.05 * rmisc.randn_c(3, 24)
+    da = ala.decode(ya)
+    close(omimo.alamouti_decode(ya, Ha), da, 1e-13, "alamouti.decode")
+    hm = rmisc.randn_c(4)
+    mrt = rmimo.MRT(hm)
+    xm = rs.randn(20) + 1j * rs.randn(20)
+    em = mrt.encode(xm)
+    close(omimo.mrt_encode(xm, hm), em, 0, "mrt.encode")
+    ym = (hm.reshape(1, -1) @ em).reshape(-1) + 0.05 * rmisc.randn_c(20)
+    dm = mrt.decode(ym.reshape(1, -1).copy())
+    close(omimo.mrt_decode(ym, hm), dm, 1e-14, "mrt.decode")
+    Hs = rmisc.randn_c(4, 4)
+    svd = rmimo.SVDMimo(Hs)
+    xs = rs.randn(40) + 1j * rs.randn(40)
+    es = svd.encode(xs)
+    close(omimo.svd_encode(xs, Hs), es, 1e-13, "svd.encode")
+    ds = svd.decode(Hs @ es)
+    close(omimo.svd_decode(Hs @ es, Hs), ds, 1e-12, "svd.decode")
+    out.update(ala_H=Ha, ala_x=xa, ala_enc=ea, ala_y=ya, ala_dec=da, mrt_h=hm, mrt_x=xm, mrt_enc=em, mrt_y=ym,
+               mrt_dec=dm, svd_H=Hs, svd_x=xs, svd_S=np.linalg.svd(Hs)[1], svd_dec=ds)
     np.savez_compressed(os.path.join(GOLD, "operators.npz"), **out)
     print("operators: ok (%d arrays)" % len(out))
 

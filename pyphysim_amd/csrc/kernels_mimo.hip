@@ -81,6 +81,157 @@ __global__ __launch_bounds__(kMimoBlock) void k_mimo_channel(const cx<T>* __rest
     }
 }
 
+// ---- Alamouti (mimo.py:1168-1269): x[2i], x[2i+1] -> [[x0, -x1*], [x1, x0*]] / sqrt(2) --------------
+template <typename T>
+__global__ __launch_bounds__(kMimoBlock) void k_alamouti_encode(const cx<T>* __restrict__ x, size_t n, T scale,
+                                                                cx<T>* __restrict__ X) {
+    const size_t b = blockIdx.y;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n / 2; i += (size_t)gridDim.x * blockDim.x) {
+        const cx<T> s0 = x[b * n + 2 * i], s1 = x[b * n + 2 * i + 1];
+        cx<T>* r0 = X + (b * 2) * n;
+        cx<T>* r1 = r0 + n;
+        r0[2 * i] = cscale(s0, scale);
+        r0[2 * i + 1] = cscale(mk<T>(-s1.x, s1.y), scale);
+        r1[2 * i] = cscale(s1, scale);
+        r1[2 * i + 1] = cscale(cconj(s0), scale);
+    }
+}
+
+// d[2i] = h0^H y[:,2i] + h1^T conj(y[:,2i+1]);  d[2i+1] = h1^H y[:,2i] - h0^T conj(y[:,2i+1]);  / |H|_F^2 * sqrt(2)
+template <typename T>
+__global__ __launch_bounds__(kMimoBlock) void k_alamouti_decode(const cx<T>* __restrict__ H, const cx<T>* __restrict__ Y,
+                                                                int nr, size_t n, T root2, cx<T>* __restrict__ out) {
+    const size_t b = blockIdx.y;
+    const cx<T>* Hb = H + b * (size_t)nr * 2;
+    const cx<T>* Yb = Y + b * (size_t)nr * n;
+    // numpy: norm(H, 'fro')**2 = (sqrt(sum |h|^2))^2
+    T acc = 0;
+    for (int r = 0; r < nr; ++r)
+        for (int a = 0; a < 2; ++a) acc += Hb[r * 2 + a].x * Hb[r * 2 + a].x + Hb[r * 2 + a].y * Hb[r * 2 + a].y;
+    const T nrm = sqrt(acc);
+    const T fro2 = nrm * nrm;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n / 2; i += (size_t)gridDim.x * blockDim.x) {
+        cx<T> a0 = mk<T>(0, 0), a1 = mk<T>(0, 0), b0 = mk<T>(0, 0), b1 = mk<T>(0, 0);
+        for (int r = 0; r < nr; ++r) {
+            const cx<T> h0 = Hb[r * 2], h1 = Hb[r * 2 + 1];
+            const cx<T> y0 = Yb[(size_t)r * n + 2 * i], y1c = cconj(Yb[(size_t)r * n + 2 * i + 1]);
+            a0 = cadd(a0, cmul(cconj(h0), y0));
+            a1 = cadd(a1, cmul(h1, y1c));
+            b0 = cadd(b0, cmul(cconj(h1), y0));
+            b1 = cadd(b1, cmul(mk<T>(-h0.x, -h0.y), y1c));
+        }
+        const cx<T> d0 = cadd(a0, a1), d1 = cadd(b0, b1);
+        out[b * n + 2 * i] = mk<T>(d0.x / fro2 * root2, d0.y / fro2 * root2);
+        out[b * n + 2 * i + 1] = mk<T>(d1.x / fro2 * root2, d1.y / fro2 * root2);
+    }
+}
+
+// ---- MRT (mimo.py:666-783), MISO 1 x Nt: W = exp(-1j angle(h)).T / sqrt(Nt); G = sqrt(Nt) / sum|h| ------
+template <typename T>
+__global__ __launch_bounds__(kMimoBlock) void k_mrt_encode(const cx<T>* __restrict__ h, const cx<T>* __restrict__ x,
+                                                           int nt, size_t n, cx<T>* __restrict__ X) {
+    const size_t b = blockIdx.y;
+    const double inv = 1.0 / sqrt((double)nt);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n * nt; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t a = i / n, c = i - a * n;
+        const cx<T> ha = h[b * nt + a];
+        double sn, cs;
+        sincos(-atan2((double)ha.y, (double)ha.x), &sn, &cs);
+        const cx<T> w = mk<T>((T)(cs * inv), (T)(sn * inv));
+        X[b * n * nt + i] = cmul(w, x[b * n + c]);
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(kMimoBlock) void k_mrt_decode(const cx<T>* __restrict__ h, const cx<T>* __restrict__ y,
+                                                           int nt, size_t n, cx<T>* __restrict__ out) {
+    const size_t b = blockIdx.y;
+    T sum = 0;
+    for (int a = 0; a < nt; ++a) sum += sqrt(h[b * nt + a].x * h[b * nt + a].x + h[b * nt + a].y * h[b * nt + a].y);
+    const T g = (T)sqrt((double)nt) / sum;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        out[b * n + i] = cscale(y[b * n + i], g);
+}
+
+// ---- SVDMimo (mimo.py:833-946): W = V / sqrt(Nt), G = diag(1/S) U^H sqrt(Nt) for square H, by one-sided
+// (Hestenes) Jacobi in f64.  Singular vectors carry the usual per-pair phase freedom: W and G are a
+// consistent pair (G H W = I), not LAPACK's particular choice.
+template <typename T, int NA>
+__global__ __launch_bounds__(64) void k_svd_filters(const cx<T>* __restrict__ Hg, cx<T>* __restrict__ Wg,
+                                                    cx<T>* __restrict__ Gg, double* __restrict__ Sg, size_t batch) {
+    for (size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x; b < batch; b += (size_t)gridDim.x * blockDim.x) {
+        double2 A[NA][NA], V[NA][NA];
+#pragma unroll
+        for (int r = 0; r < NA; ++r)
+#pragma unroll
+            for (int c = 0; c < NA; ++c) {
+                const cx<T> v = Hg[(b * NA + r) * NA + c];
+                A[r][c] = mk<double>((double)v.x, (double)v.y);
+                V[r][c] = mk<double>(r == c ? 1.0 : 0.0, 0.0);
+            }
+        for (int sweep = 0; sweep < 30; ++sweep) {
+            double off = 0.0;
+#pragma unroll
+            for (int p = 0; p < NA - 1; ++p)
+#pragma unroll
+                for (int q = p + 1; q < NA; ++q) {
+                    double alpha = 0, beta = 0;
+                    double2 gam = mk<double>(0, 0);
+#pragma unroll
+                    for (int r = 0; r < NA; ++r) {
+                        alpha += A[r][p].x * A[r][p].x + A[r][p].y * A[r][p].y;
+                        beta += A[r][q].x * A[r][q].x + A[r][q].y * A[r][q].y;
+                        gam = cadd(gam, cmulc(A[r][q], A[r][p]));  // a_p^H a_q
+                    }
+                    const double g = sqrt(gam.x * gam.x + gam.y * gam.y);
+                    off = fmax(off, g / (sqrt(alpha * beta) + 1e-300));
+                    if (g < 1e-300) continue;
+                    const double2 ph = mk<double>(gam.x / g, gam.y / g);  // e^{j phi}
+                    const double zeta = (beta - alpha) / (2.0 * g);
+                    const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                    const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+#pragma unroll
+                    for (int r = 0; r < NA; ++r) {
+                        const double2 ap = A[r][p], aq = cmul(A[r][q], cconj(ph));
+                        A[r][p] = csub(cscale(ap, c), cscale(aq, s));
+                        A[r][q] = cadd(cscale(ap, s), cscale(aq, c));
+                        const double2 vp = V[r][p], vq = cmul(V[r][q], cconj(ph));
+                        V[r][p] = csub(cscale(vp, c), cscale(vq, s));
+                        V[r][q] = cadd(cscale(vp, s), cscale(vq, c));
+                    }
+                }
+            if (off < 1e-15) break;
+        }
+        double S[NA];
+        int order[NA];
+#pragma unroll
+        for (int c = 0; c < NA; ++c) {
+            double n2 = 0;
+#pragma unroll
+            for (int r = 0; r < NA; ++r) n2 += A[r][c].x * A[r][c].x + A[r][c].y * A[r][c].y;
+            S[c] = sqrt(n2);
+            order[c] = c;
+        }
+        for (int i = 0; i < NA; ++i)  // descending singular values, like LAPACK
+            for (int j = i + 1; j < NA; ++j)
+                if (S[order[j]] > S[order[i]]) {
+                    const int t = order[i];
+                    order[i] = order[j];
+                    order[j] = t;
+                }
+        const double root = sqrt((double)NA);
+        for (int i = 0; i < NA; ++i) {
+            const int c = order[i];
+            if (Sg) Sg[b * NA + i] = S[c];
+            for (int r = 0; r < NA; ++r) {
+                // W[:, i] = V[:, c] / sqrt(Nt);  G[i, :] = conj(U[:, c]) * sqrt(Nt) / S = conj(A[:, c]) sqrt(Nt) / S^2
+                Wg[(b * NA + r) * NA + i] = mk<T>((T)(V[r][c].x / root), (T)(V[r][c].y / root));
+                const double k = root / (S[c] * S[c]);
+                Gg[(b * NA + i) * NA + r] = mk<T>((T)(A[r][c].x * k), (T)(-A[r][c].y * k));
+            }
+        }
+    }
+}
+
 template <typename T, int NT, int NR>
 int launch_filter(mcle_ctx* ctx, const void* d_H, double nv, void* d_G, uint32_t* d_skipped, size_t batch) {
     hipLaunchKernelGGL((k_blast_filter<T, NT, NR>), dim3(grid_for(ctx, batch, 64, 16)), dim3(64), 0, ctx->stream,
@@ -182,6 +333,102 @@ int mcle_mimo_channel(mcle_ctx* ctx, int dtype, const void* d_H, const void* d_X
         hipLaunchKernelGGL(k_mimo_channel<double>, grid, dim3(kMimoBlock), 0, ctx->stream, (const double2*)d_H,
                            (const double2*)d_X, (const double2*)d_noise, std::sqrt(noise_var), nr, nt, ns,
                            (double2*)d_Y);
+    MCLE_LAUNCH_CHECK();
+    return MCLE_OK;
+}
+
+int mcle_alamouti_encode(mcle_ctx* ctx, int dtype, const void* d_x, size_t n, void* d_X, size_t batch) {
+    int rc = check_mimo(ctx, dtype, 1, 2, batch);
+    if (rc) return rc;
+    MCLE_REQUIRE(n % 2 == 0, "Alamouti needs an even number of symbols");
+    if (n == 0 || batch == 0) return MCLE_OK;
+    if ((rc = ctx->bind())) return rc;
+    dim3 grid((unsigned)grid_for(ctx, n / 2, kMimoBlock, 4), (unsigned)batch);
+    const double s = 1.0 / std::sqrt(2.0);
+    if (dtype == MCLE_F32)
+        hipLaunchKernelGGL(k_alamouti_encode<float>, grid, dim3(kMimoBlock), 0, ctx->stream, (const float2*)d_x, n,
+                           (float)s, (float2*)d_X);
+    else
+        hipLaunchKernelGGL(k_alamouti_encode<double>, grid, dim3(kMimoBlock), 0, ctx->stream, (const double2*)d_x, n, s,
+                           (double2*)d_X);
+    MCLE_LAUNCH_CHECK();
+    return MCLE_OK;
+}
+
+int mcle_alamouti_decode(mcle_ctx* ctx, int dtype, const void* d_H, const void* d_Y, int nr, size_t n, void* d_out,
+                         size_t batch) {
+    int rc = check_mimo(ctx, dtype, nr, 2, batch);
+    if (rc) return rc;
+    MCLE_REQUIRE(n % 2 == 0, "Alamouti needs an even number of symbols");
+    if (n == 0 || batch == 0) return MCLE_OK;
+    if ((rc = ctx->bind())) return rc;
+    dim3 grid((unsigned)grid_for(ctx, n / 2, kMimoBlock, 4), (unsigned)batch);
+    if (dtype == MCLE_F32)
+        hipLaunchKernelGGL(k_alamouti_decode<float>, grid, dim3(kMimoBlock), 0, ctx->stream, (const float2*)d_H,
+                           (const float2*)d_Y, nr, n, (float)std::sqrt(2.0), (float2*)d_out);
+    else
+        hipLaunchKernelGGL(k_alamouti_decode<double>, grid, dim3(kMimoBlock), 0, ctx->stream, (const double2*)d_H,
+                           (const double2*)d_Y, nr, n, std::sqrt(2.0), (double2*)d_out);
+    MCLE_LAUNCH_CHECK();
+    return MCLE_OK;
+}
+
+int mcle_mrt_encode(mcle_ctx* ctx, int dtype, const void* d_h, const void* d_x, int nt, size_t n, void* d_X,
+                    size_t batch) {
+    int rc = check_mimo(ctx, dtype, 1, nt, batch);
+    if (rc) return rc;
+    if (n == 0 || batch == 0) return MCLE_OK;
+    if ((rc = ctx->bind())) return rc;
+    dim3 grid((unsigned)grid_for(ctx, n * nt, kMimoBlock, 4), (unsigned)batch);
+    if (dtype == MCLE_F32)
+        hipLaunchKernelGGL(k_mrt_encode<float>, grid, dim3(kMimoBlock), 0, ctx->stream, (const float2*)d_h,
+                           (const float2*)d_x, nt, n, (float2*)d_X);
+    else
+        hipLaunchKernelGGL(k_mrt_encode<double>, grid, dim3(kMimoBlock), 0, ctx->stream, (const double2*)d_h,
+                           (const double2*)d_x, nt, n, (double2*)d_X);
+    MCLE_LAUNCH_CHECK();
+    return MCLE_OK;
+}
+
+int mcle_mrt_decode(mcle_ctx* ctx, int dtype, const void* d_h, const void* d_y, int nt, size_t n, void* d_out,
+                    size_t batch) {
+    int rc = check_mimo(ctx, dtype, 1, nt, batch);
+    if (rc) return rc;
+    if (n == 0 || batch == 0) return MCLE_OK;
+    if ((rc = ctx->bind())) return rc;
+    dim3 grid((unsigned)grid_for(ctx, n, kMimoBlock, 4), (unsigned)batch);
+    if (dtype == MCLE_F32)
+        hipLaunchKernelGGL(k_mrt_decode<float>, grid, dim3(kMimoBlock), 0, ctx->stream, (const float2*)d_h,
+                           (const float2*)d_y, nt, n, (float2*)d_out);
+    else
+        hipLaunchKernelGGL(k_mrt_decode<double>, grid, dim3(kMimoBlock), 0, ctx->stream, (const double2*)d_h,
+                           (const double2*)d_y, nt, n, (double2*)d_out);
+    MCLE_LAUNCH_CHECK();
+    return MCLE_OK;
+}
+
+int mcle_svd_filters(mcle_ctx* ctx, int dtype, const void* d_H, int n_ant, void* d_W, void* d_G, double* d_S,
+                     size_t batch) {
+    MCLE_REQUIRE(ctx != nullptr, "null context");
+    MCLE_REQUIRE(dtype == MCLE_F32 || dtype == MCLE_F64, "dtype must be MCLE_F32 or MCLE_F64");
+    MCLE_REQUIRE(n_ant >= 2 && n_ant <= 4, "SVD filters support square channels with 2 <= N <= 4 (got %d)", n_ant);
+    if (batch == 0) return MCLE_OK;
+    int rc = ctx->bind();
+    if (rc) return rc;
+    const dim3 grid(grid_for(ctx, batch, 64, 16));
+#define MCLE_SVD(T_, N_)                                                                                       \
+    hipLaunchKernelGGL((k_svd_filters<T_, N_>), grid, dim3(64), 0, ctx->stream, (const cx<T_>*)d_H, (cx<T_>*)d_W, \
+                       (cx<T_>*)d_G, d_S, batch)
+    if (dtype == MCLE_F32) {
+        if (n_ant == 2) MCLE_SVD(float, 2);
+        else if (n_ant == 3) MCLE_SVD(float, 3);
+        else MCLE_SVD(float, 4);
+    } else {
+        if (n_ant == 2) MCLE_SVD(double, 2);
+        else if (n_ant == 3) MCLE_SVD(double, 3);
+        else MCLE_SVD(double, 4);
+    }
+#undef MCLE_SVD
     MCLE_LAUNCH_CHECK();
     return MCLE_OK;
 }

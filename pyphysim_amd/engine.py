@@ -362,6 +362,57 @@ class Engine:
                                                      float(noise_var), nr, nt, ns, out.ptr, b))
         return self._out(out, host)
 
+    # ---- a13: Alamouti / MRT / SVD ----------------------------------------------------------
+    def alamouti_encode(self, x, batch=1, dtype=None):
+        dt = self._dt(dtype)
+        d_x, host = self._cin(x, dt)
+        n = d_x.size // batch
+        out = self.empty((batch, 2, n), _lib.np_complex(dt))
+        self._raise_value(self.lib.mcle_alamouti_encode(self.ctx, dt, d_x.ptr, n, out.ptr, batch))
+        return self._out(out, host)
+
+    def alamouti_decode(self, H, Y, dtype=None):
+        """H [batch, nr, 2], Y [batch, nr, n] -> [batch, n]."""
+        dt = self._dt(dtype)
+        d_H, _ = self._cin(H, dt)
+        d_Y, host = self._cin(Y, dt)
+        b, nr, _two = d_H.shape
+        n = d_Y.shape[-1]
+        out = self.empty((b, n), _lib.np_complex(dt))
+        self._raise_value(self.lib.mcle_alamouti_decode(self.ctx, dt, d_H.ptr, d_Y.ptr, nr, n, out.ptr, b))
+        return self._out(out, host)
+
+    def mrt_encode(self, h, x, dtype=None):
+        """h [batch, nt], x [batch, n] -> [batch, nt, n]."""
+        dt = self._dt(dtype)
+        d_h, _ = self._cin(h, dt)
+        d_x, host = self._cin(x, dt)
+        b, nt = d_h.shape
+        n = d_x.size // b
+        out = self.empty((b, nt, n), _lib.np_complex(dt))
+        self._raise_value(self.lib.mcle_mrt_encode(self.ctx, dt, d_h.ptr, d_x.ptr, nt, n, out.ptr, b))
+        return self._out(out, host)
+
+    def mrt_decode(self, h, y, dtype=None):
+        dt = self._dt(dtype)
+        d_h, _ = self._cin(h, dt)
+        d_y, host = self._cin(y, dt)
+        b, nt = d_h.shape
+        n = d_y.size // b
+        out = self.empty((b, n), _lib.np_complex(dt))
+        self._raise_value(self.lib.mcle_mrt_decode(self.ctx, dt, d_h.ptr, d_y.ptr, nt, n, out.ptr, b))
+        return self._out(out, host)
+
+    def svd_filters(self, H, dtype=None):
+        """H [batch, n, n] -> (W [batch, n, n] precoder, G [batch, n, n] receive filter, S [batch, n])."""
+        dt = self._dt(dtype)
+        d_H, host = self._cin(H, dt)
+        b, n, _n = d_H.shape
+        W, G = self.empty((b, n, n), _lib.np_complex(dt)), self.empty((b, n, n), _lib.np_complex(dt))
+        S = self.empty((b, n), np.float64)
+        self._raise_value(self.lib.mcle_svd_filters(self.ctx, dt, d_H.ptr, n, W.ptr, G.ptr, S.ptr, b))
+        return self._out(W, host), self._out(G, host), S.get()
+
     # ---- fused pipelines --------------------------------------------------------------------
     def _run(self, fn, cfg, seed, first, count, dtype, per_realization, counters=None):
         dt = self._dt(dtype)

@@ -1,6 +1,7 @@
 """Host mirror of pyphysim.mimo.Blast / MRC (reference mimo/mimo.py:30-660, 789-827): same
 methods, argument meaning and errors; encode / filter / decode run in libmcle's HIP kernels."""
 import math
+import warnings
 
 import numpy as np
 
@@ -50,8 +51,9 @@ class Blast(MimoBase):
         channel = np.asarray(channel)
         if channel.ndim == 2:
             Nr, Nt = channel.shape
-            if Nt > Nr:
-                raise ValueError("Blast scheme requires at least as many receive antennas as transmit antennas")
+            if Nt > Nr:       # the reference only warns (mimo.py:505-515)
+                warnings.warn("The number of transmit antennas for {0} should not be greater than the number "
+                              "of receive antennas.".format(self.__class__.__name__))
         super().set_channel_matrix(channel)
 
     def getNumberOfLayers(self):
@@ -90,3 +92,77 @@ class Blast(MimoBase):
 
 class MRC(Blast):
     """reference mimo.py:789-827: Blast with a (possibly 1-D) channel."""
+
+
+class MRT(MimoBase):
+    """reference mimo.py:666-783 (MISO: one receive antenna).  Phase-only transmit precoder."""
+
+    def set_channel_matrix(self, channel):
+        channel = np.asarray(channel)
+        if channel.ndim == 1:
+            channel = channel[np.newaxis, :]
+        elif channel.shape[0] != 1:
+            raise ValueError("The MRT scheme is only defined for the scenario with a single receive antenna")
+        self._channel = channel
+
+    def getNumberOfLayers(self):
+        return 1
+
+    def encode(self, transmit_data):
+        x = np.asarray(transmit_data).reshape(1, -1)
+        return self.engine.mrt_encode(self._channel.reshape(1, -1), x, dtype=self.dtype)[0]
+
+    def decode(self, received_data):
+        y = np.asarray(received_data).reshape(1, -1)
+        return self.engine.mrt_decode(self._channel.reshape(1, -1), y, dtype=self.dtype)[0]
+
+
+class SVDMimo(Blast):
+    """reference mimo.py:833-946: precoder V / sqrt(Nt), receive filter diag(1/S) U^H sqrt(Nt); square
+    channels up to 4x4 (Jacobi SVD in f64 on the GPU).  W and G are a consistent singular-vector
+    pair; LAPACK's particular phase choice is not reproduced (G H W = I either way)."""
+
+    def _filters(self):
+        W, G, S = self.engine.svd_filters(self._channel[np.newaxis], dtype=self.dtype)
+        return W[0], G[0], S[0]
+
+    def encode(self, transmit_data):
+        x = np.asarray(transmit_data).reshape(-1)
+        if x.size % self.Nt != 0:
+            raise ValueError("Input array number of elements must be a multiple of the number of transmit antennas")
+        W, _, _ = self._filters()
+        return self.engine.mimo_channel(W[np.newaxis], x.reshape(1, self.Nt, -1), dtype=self.dtype)[0]
+
+    def decode(self, received_data):
+        _, G, _ = self._filters()
+        Y = np.asarray(received_data)
+        return self.engine.mimo_channel(G[np.newaxis], Y[np.newaxis], dtype=self.dtype)[0].reshape(-1)
+
+
+class Alamouti(MimoBase):
+    """reference mimo.py:1073-1287: 2 transmit antennas, any number of receive antennas."""
+
+    def set_channel_matrix(self, channel):
+        channel = np.asarray(channel)
+        if channel.ndim == 1:
+            channel = channel[np.newaxis, :]
+        elif channel.shape[1] != 2:
+            raise ValueError("The number of transmit antennas must be equal to 2 for the {0} scheme".format(
+                self.__class__.__name__))
+        self._channel = channel
+
+    def getNumberOfLayers(self):
+        return 1
+
+    def calc_linear_SINRs(self, noise_var):
+        return np.linalg.norm(self._channel, "fro") ** 2 / noise_var
+
+    def encode(self, transmit_data):
+        x = np.asarray(transmit_data).reshape(-1)
+        return self.engine.alamouti_encode(x, dtype=self.dtype)[0]
+
+    def decode(self, received_data):
+        Y = np.asarray(received_data)
+        if Y.ndim == 1:
+            Y = Y[np.newaxis, :]
+        return self.engine.alamouti_decode(self._channel[np.newaxis], Y[np.newaxis], dtype=self.dtype)[0]

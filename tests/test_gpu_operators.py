@@ -253,3 +253,118 @@ def test_mimo_ofdm_chain_injected(engine, dt):
                 assert np.array_equal(dec, g["decisions"])
             else:
                 assert np.count_nonzero(dec != g["decisions"]) <= 4
+
+
+# ---- a13: Alamouti, MRT, SVDMimo (reference mimo/mimo.py:666-1287) --------------------------------
+@pytest.mark.parametrize("dt", ["f64", "f32"])
+def test_alamouti_mrt_injected(engine, golden_ops, dt):
+    g = golden_ops
+    enc = engine.alamouti_encode(g["ala_x"], dtype=dt)[0]
+    assert relerr(enc, g["ala_enc"]) <= (0 if dt == "f64" else 1e-7)
+    dec = engine.alamouti_decode(g["ala_H"][None], g["ala_y"][None], dtype=dt)[0]
+    assert relerr(dec, g["ala_dec"]) <= (1e-13 if dt == "f64" else 2e-6)
+    clean = engine.alamouti_decode(g["ala_H"][None], (g["ala_H"] @ g["ala_enc"])[None], dtype=dt)[0]
+    assert relerr(clean, g["ala_x"]) <= (1e-12 if dt == "f64" else 1e-5)      # tests/mimo_package_test.py:610-637
+    em = engine.mrt_encode(g["mrt_h"][None], g["mrt_x"][None], dtype=dt)[0]
+    assert relerr(em, g["mrt_enc"]) <= (1e-15 if dt == "f64" else 1e-6)
+    dm = engine.mrt_decode(g["mrt_h"][None], g["mrt_y"][None], dtype=dt)[0]
+    assert relerr(dm, g["mrt_dec"]) <= (1e-14 if dt == "f64" else 1e-6)
+    with pytest.raises(ValueError):
+        engine.alamouti_encode(np.ones(3, dtype=complex))
+
+
+def test_svd_filters(engine, golden_ops):
+    """Singular values equal LAPACK's; W and G form a consistent pair: W unitary / sqrt(n), G H W = I,
+    so SVDMimo.decode(H @ SVDMimo.encode(x)) == x (reference tests/mimo_package_test.py SVD cases)."""
+    rs = np.random.RandomState(8)
+    for n in (2, 3, 4):
+        H = (rs.randn(6, n, n) + 1j * rs.randn(6, n, n)) / np.sqrt(2)
+        W, G, S = engine.svd_filters(H)
+        for b in range(6):
+            assert relerr(S[b], np.linalg.svd(H[b])[1]) <= 1e-12
+            assert relerr(W[b].conj().T @ W[b] * n, np.eye(n)) <= 1e-12
+            assert relerr(G[b] @ H[b] @ W[b], np.eye(n)) <= 1e-10
+            assert relerr(G[b] @ G[b].conj().T, n * np.diag(1.0 / S[b] ** 2)) <= 1e-9
+    from pyphysim_amd.mimo import SVDMimo
+    m = SVDMimo(golden_ops["svd_H"], engine=engine)
+    x = golden_ops["svd_x"]
+    assert relerr(m.decode(golden_ops["svd_H"] @ m.encode(x)), x) <= 1e-10
+    assert relerr(golden_ops["svd_dec"], x) <= 1e-10                               # the reference recovers x too
+    assert relerr(engine.svd_filters(golden_ops["svd_H"][None])[2][0], golden_ops["svd_S"]) <= 1e-12
+
+
+def test_host_mirror_classes(engine, golden_ops):
+    """The drop-in classes (same names / arguments / exceptions as the reference) on the HIP path."""
+    from pyphysim_amd import channels, mimo, modulators, util
+    q = modulators.QAM(16, engine=engine)
+    assert q.name == "16-QAM" and q.M == 16 and q.K == 4
+    idx = golden_ops["demod_qam16_idx"]
+    assert np.array_equal(q.modulate(idx), golden_ops["qam16"][idx])
+    assert np.array_equal(q.demodulate(golden_ops["demod_qam16_rx"]), golden_ops["demod_qam16_dec"])
+    assert np.array_equal(q.demodulate(golden_ops["demod_qam16_rx"], method=_lib.DEMOD_QAM_SLICER),
+                          golden_ops["demod_qam16_dec"])
+    with pytest.raises(ValueError):
+        q.modulate(np.array([16]))
+    with pytest.raises(ValueError):
+        modulators.QAM(32)
+    # theory curves: values computed with the reference's own classes (fundamental.py:462-501,780-857)
+    assert abs(q.calcTheoreticalSER(10.0) - 0.22203085027243796) < 1e-15
+    assert abs(q.calcTheoreticalBER(10.0) - 0.058987202643856936) < 1e-15
+    assert abs(modulators.PSK(8, engine=engine).calcTheoreticalSER(10.0) - 0.08700502129401143) < 1e-15
+    assert abs(modulators.PSK(8, engine=engine).calcTheoreticalBER(10.0) - 0.029001673764670475) < 1e-15
+    assert abs(modulators.BPSK(engine=engine).calcTheoreticalSER(3.0) - 0.022878407561085334) < 1e-15
+    q64 = modulators.QAM(64, engine=engine)
+    assert abs(q64.calcTheoreticalPER(20.0, 100) - 0.5735518487383953) < 1e-12
+    assert abs(q64.calcTheoreticalSpectralEfficiency(20.0, 100) - 2.5586889075696284) < 1e-12
+    assert modulators.BPSK(engine=engine).name == "BPSK"
+    assert np.array_equal(modulators.BPSK(engine=engine).modulate(np.array([0, 1, 1])), [1.0, -1.0, -1.0])
+    p = modulators.PSK(8, engine=engine)
+    assert np.array_equal(p.demodulate(golden_ops["demod_psk8_rx"]), golden_ops["demod_psk8_dec"])
+    o = modulators.OFDM(64, 16, 52, engine=engine)
+    key = "ofdm_64_16_52"
+    assert np.array_equal(o.get_used_subcarrier_indexes(), golden_ops[key + "_map"])
+    assert relerr(o.modulate(golden_ops[key + "_x"]), golden_ops[key + "_tx"]) <= 1e-12
+    assert relerr(o.demodulate(golden_ops[key + "_tx"]), golden_ops[key + "_back"]) <= 1e-11
+    with pytest.raises(ValueError):
+        modulators.OFDM(64, 65)
+    b = mimo.Blast(golden_ops["blast_H"], engine=engine)
+    assert np.array_equal(b.encode(golden_ops["blast_x"]), golden_ops["blast_enc"])
+    assert relerr(b.decode(golden_ops["blast_y"]), golden_ops["blast_zf"]) <= 1e-10
+    b.set_noise_var(float(golden_ops["blast_nv"]))
+    assert relerr(b.decode(golden_ops["blast_y"]), golden_ops["blast_mmse"]) <= 1e-10
+    with pytest.raises(ValueError):
+        b.set_noise_var(-1.0)
+    a = mimo.Alamouti(golden_ops["ala_H"], engine=engine)
+    assert relerr(a.decode(golden_ops["ala_y"]), golden_ops["ala_dec"]) <= 1e-12
+    with pytest.raises(ValueError):
+        mimo.Alamouti(np.ones((2, 3), dtype=complex))
+    m = mimo.MRT(golden_ops["mrt_h"], engine=engine)
+    assert relerr(m.encode(golden_ops["mrt_x"]), golden_ops["mrt_enc"]) <= 1e-14
+    # channels: Jakes bookkeeping (tests/channels_package_test.py:244-290) and the TDL property test
+    rs = np.random.RandomState(5)
+    jk = channels.JakesSampleGenerator(Fd=5, Ts=1e-3, L=16, RS=rs, engine=engine)
+    jk.generate_more_samples(100)
+    first = jk.get_samples().copy()
+    assert first.shape == (100,) and abs(jk._current_time - 101e-3) < 1e-9
+    jk.skip_samples_for_next_generation(50)
+    assert abs(jk._current_time - 151e-3) < 1e-9
+    tdl = channels.TdlChannel(channels.JakesSampleGenerator(Fd=5, Ts=3.255e-8, L=16, RS=rs, engine=engine),
+                              channels.COST259_TUx, engine=engine)
+    assert tdl.num_taps == 15 and tdl.num_taps_with_padding == 67
+    x = rs.randn(300) + 1j * rs.randn(300)
+    y = tdl.corrupt_data(x)
+    ir = tdl.get_last_impulse_response()
+    want = np.zeros(366, dtype=complex)
+    for i, d in enumerate(ir.tap_indexes_sparse):
+        want[d:d + 300] += ir.tap_values_sparse[i] * x
+    assert y.shape == (366,) and relerr(y, want) <= 1e-13
+    assert ir.tap_values.shape == (67, 300) and ir.get_freq_response(128).shape == (128, 300)
+    su = channels.SuChannel(channels.JakesSampleGenerator(RS=rs, engine=engine), engine=engine)
+    assert su.corrupt_data(x).shape == (300,) and su.num_taps == 1
+    util.seed(7, 3)
+    z = util.randn_c(4, 5, engine=engine)
+    assert z.shape == (4, 5) and z.dtype == np.complex128
+    assert util.count_bit_errors(np.array([[2, 3, 3, 0], [1, 3, 1, 2]]), np.array([[0, 3, 2, 0], [2, 0, 1, 2]]),
+                                 engine=engine) == 6
+    assert list(util.count_bit_errors(np.array([[2, 3, 3, 0], [1, 3, 1, 2]]), np.array([[0, 3, 2, 0], [2, 0, 1, 2]]),
+                                      1, engine=engine)) == [2, 4]
