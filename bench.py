@@ -120,7 +120,10 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or "RANK" in os.environ        # any torch.distributed.run launch, even with 1 rank
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     eng = Engine(local_rank, args.dtype)
     run, units, workload = make_runner(eng, args.config, args.demod, args.dtype)
@@ -129,7 +132,7 @@ def main():
     def barrier():
         eng.sync()
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     counters = eng.new_counters()
@@ -147,12 +150,12 @@ def main():
     local = eng.read_counters(counters)
     vec = torch.tensor([local[k] for k in ("n_realizations", "n_skipped", "sym_errors", "sym_errors_sq",
                                            "bit_errors", "bit_errors_sq")], dtype=torch.int64, device="cuda")
-    if world > 1:
+    if use_dist:
         dist.all_reduce(vec, op=dist.ReduceOp.SUM)     # RCCL over xGMI: the path's only exchange step
     barrier()
     elapsed = time.perf_counter() - t0
     tmax = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cuda")
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed, kernel_ms = float(tmax[0]), float(tmax[1])
     tot = [int(v) for v in vec.tolist()]
@@ -188,12 +191,15 @@ def main():
                          ("k_run_flat" if args.config == "c2" else "k_run_ofdm_tdl"),
                          "kernel_ms_per_launch": per_launch_s * 1e3,
                          "algorithmic_bytes_per_realization": balg,
+                         "traffic_source": "profiles/traffic_%s.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
+                         % args.config if traffic is not None else None,
                          "note": "fused kernel: achieved = staged-model algorithmic bytes / measured launch time; "
-                                 "measured HBM traffic is far below it (data never leaves LDS), see DESIGN.md"},
+                                 "measured HBM traffic is far below it (data never leaves LDS); the kernel is "
+                                 "VALU-issue bound, see DESIGN.md section 5.3"},
         }
         if world == 1 and not args.no_cpu:
             # per-realization counts of the first realizations for the SER cross-check
-            res, se, be = eng_first_counts(eng, args, 4096 if args.config != "c2" else 64)
+            res, se, be = eng_first_counts(eng, args, 16384 if args.config != "c2" else 128)
             cb, ser_err, n_chk = cpu_baseline(args.config, args.cpu_seconds, se)
             cb["host_cpu_count"] = os.cpu_count()
             out["cpu_baseline"] = cb
@@ -201,7 +207,7 @@ def main():
             out["ser_check_realizations"] = n_chk
             out["speedup_vs_cpu_core"] = value / cb["value"]
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
     eng.close()
 
