@@ -165,6 +165,12 @@ int mcle_mrt_decode(mcle_ctx* ctx, int dtype, const void* d_h, const void* d_y, 
 int mcle_svd_filters(mcle_ctx* ctx, int dtype, const void* d_H, int n_ant, void* d_W, void* d_G,
                      double* d_S, size_t batch);
 
+/* GMDMimo (mimo.py:952-1067) + util.misc.gmd (misc.py:18-159), square H: W = P/sqrt(n), G = Blast filter
+ * (ZF for noise_var = 0, else MMSE) on the equivalent channel Q R; d_R [batch][n][n] (real upper
+ * triangular with constant diagonal; may be NULL). */
+int mcle_gmd_filters(mcle_ctx* ctx, int dtype, const void* d_H, int n_ant, double noise_var, void* d_W,
+                     void* d_G, double* d_R, uint32_t* d_skipped, size_t batch);
+
 /* ---- fused pipelines: whole realizations on-chip (randomness: mcle-philox-v1) ----------- */
 typedef struct mcle_awgn_cfg {          /* C1: apps/awgn_modulators/simulate_psk.py:51-115 */
     int32_t n_symbols;

@@ -168,6 +168,12 @@ def golden_operators():
     close(omimo.svd_encode(xs, Hs), es, 1e-13, "svd.encode")
     ds = svd.decode(Hs @ es)
     close(omimo.svd_decode(Hs @ es, Hs), ds, 1e-12, "svd.decode")
+    gm = rmimo.GMDMimo(Hs)
+    Ug, Sg, Vg = np.linalg.svd(Hs)
+    Qg, Rg, Pg = rmisc.gmd(Ug, Sg, Vg)
+    close(Qg @ Rg @ Pg.conj().T, Hs, 1e-12, "gmd reconstructs H")
+    dg = gm.decode(Hs @ gm.encode(xs))
+    out.update(gmd_R=Rg, gmd_dec=dg)
     out.update(ala_H=Ha, ala_x=xa, ala_enc=ea, ala_y=ya, ala_dec=da, mrt_h=hm, mrt_x=xm, mrt_enc=em, mrt_y=ym,
                mrt_dec=dm, svd_H=Hs, svd_x=xs, svd_S=np.linalg.svd(Hs)[1], svd_dec=ds)
     np.savez_compressed(os.path.join(GOLD, "operators.npz"), **out)

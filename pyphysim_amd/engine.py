@@ -413,6 +413,17 @@ class Engine:
         self._raise_value(self.lib.mcle_svd_filters(self.ctx, dt, d_H.ptr, n, W.ptr, G.ptr, S.ptr, b))
         return self._out(W, host), self._out(G, host), S.get()
 
+    def gmd_filters(self, H, noise_var=0.0, dtype=None):
+        """H [batch, n, n] -> (W precoder, G receive filter, R [batch, n, n] real upper triangular)."""
+        dt = self._dt(dtype)
+        d_H, host = self._cin(H, dt)
+        b, n, _n = d_H.shape
+        W, G = self.empty((b, n, n), _lib.np_complex(dt)), self.empty((b, n, n), _lib.np_complex(dt))
+        R, sk = self.empty((b, n, n), np.float64), self.empty(b, np.uint32)
+        self._raise_value(self.lib.mcle_gmd_filters(self.ctx, dt, d_H.ptr, n, float(noise_var), W.ptr, G.ptr, R.ptr,
+                                                    sk.ptr, b))
+        return self._out(W, host), self._out(G, host), R.get()
+
     # ---- fused pipelines --------------------------------------------------------------------
     def _run(self, fn, cfg, seed, first, count, dtype, per_realization, counters=None):
         dt = self._dt(dtype)

@@ -139,6 +139,27 @@ class SVDMimo(Blast):
         return self.engine.mimo_channel(G[np.newaxis], Y[np.newaxis], dtype=self.dtype)[0].reshape(-1)
 
 
+class GMDMimo(Blast):
+    """reference mimo.py:952-1067: geometric mean decomposition precoder (util.misc.gmd) and Blast's
+    ZF / MMSE filter on the equivalent channel Q R; square channels up to 4x4."""
+
+    def _filters(self):
+        W, G, R = self.engine.gmd_filters(self._channel[np.newaxis], self._noise_var, dtype=self.dtype)
+        return W[0], G[0], R[0]
+
+    def encode(self, transmit_data):
+        x = np.asarray(transmit_data).reshape(-1)
+        if x.size % self.Nt != 0:
+            raise ValueError("Input array number of elements must be a multiple of the number of transmit antennas")
+        W, _, _ = self._filters()
+        return self.engine.mimo_channel(W[np.newaxis], x.reshape(1, self.Nt, -1), dtype=self.dtype)[0]
+
+    def decode(self, received_data):
+        _, G, _ = self._filters()
+        Y = np.asarray(received_data)
+        return self.engine.mimo_channel(G[np.newaxis], Y[np.newaxis], dtype=self.dtype)[0].reshape(-1)
+
+
 class Alamouti(MimoBase):
     """reference mimo.py:1073-1287: 2 transmit antennas, any number of receive antennas."""
 

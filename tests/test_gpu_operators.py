@@ -368,3 +368,30 @@ def test_host_mirror_classes(engine, golden_ops):
                                  engine=engine) == 6
     assert list(util.count_bit_errors(np.array([[2, 3, 3, 0], [1, 3, 1, 2]]), np.array([[0, 3, 2, 0], [2, 0, 1, 2]]),
                                       1, engine=engine)) == [2, 4]
+
+
+def test_gmd_filters(engine, golden_ops):
+    """GMDMimo: R (a function of the singular values only) equals the reference's util.misc.gmd output;
+    W = P/sqrt(n) is unitary/sqrt(n); the zero-forcing filter on Q R inverts H W (H = Q R P^H)."""
+    H = golden_ops["svd_H"]
+    W, G, R = engine.gmd_filters(H[None], 0.0)
+    assert relerr(R[0], golden_ops["gmd_R"]) <= 1e-11
+    assert np.allclose(np.tril(R[0], -1), 0) and relerr(np.diag(R[0]), np.full(4, np.prod(golden_ops["svd_S"]) ** 0.25)) <= 1e-12
+    assert relerr(W[0].conj().T @ W[0] * 4, np.eye(4)) <= 1e-12
+    assert relerr(G[0] @ H @ W[0], np.eye(4)) <= 1e-9
+    QR = H @ (W[0] * 2.0)                                   # = Q R
+    assert relerr(np.abs(np.linalg.qr(QR)[1]), np.abs(R[0])) <= 1e-9      # same triangular factor up to phases
+    from pyphysim_amd.mimo import GMDMimo
+    m = GMDMimo(H, engine=engine)
+    x = golden_ops["svd_x"]
+    assert relerr(m.decode(H @ m.encode(x)), x) <= 1e-9 and relerr(golden_ops["gmd_dec"], x) <= 1e-9
+    rs = np.random.RandomState(3)
+    for n in (2, 3, 4):
+        Hn = (rs.randn(5, n, n) + 1j * rs.randn(5, n, n)) / np.sqrt(2)
+        Wn, Gn, Rn = engine.gmd_filters(Hn, 0.05)
+        for b in range(5):
+            S = np.linalg.svd(Hn[b])[1]
+            assert relerr(np.diag(Rn[b]), np.full(n, np.prod(S) ** (1.0 / n))) <= 1e-11
+            Heq = Hn[b] @ (Wn[b] * np.sqrt(n))
+            want = np.sqrt(n) * np.linalg.solve(Heq.conj().T @ Heq + 0.05 * np.eye(n), Heq.conj().T)
+            assert relerr(Gn[b], want) <= 1e-9             # Blast's MMSE on the equivalent channel
