@@ -114,6 +114,16 @@ int mcle_jakes_generate(mcle_ctx* ctx, int dtype, const double* phi, const doubl
 /* SISO time-varying sparse convolution: y[d_i + n] += g[i, n] x[n]; y has n + max_delay */
 int mcle_tdl_apply(mcle_ctx* ctx, int dtype, const void* d_x, const void* d_taps,
                    const int32_t* delays, int n_taps, void* d_y, size_t n);
+/* MIMO branch of corrupt_data (fading.py:1107-1117): x [nt][n], taps [n_taps][nr][nt][n] ->
+ * y [nr][n + max_delay] */
+int mcle_tdl_apply_mimo(mcle_ctx* ctx, int dtype, const void* d_x, const void* d_taps,
+                        const int32_t* delays, int n_taps, int nr, int nt, void* d_y, size_t n);
+/* per-OFDM-symbol mean frequency response on the used subcarriers for n_links parallel links:
+ * taps [n_taps][n_links][n_sym*(fft+cp)] -> H [n_sym][num_used][n_links]
+ * (TdlImpulseResponse.get_freq_response fading.py:513-536 averaged like ofdm.py:545-547) */
+int mcle_tdl_mean_freq_response(mcle_ctx* ctx, int dtype, const void* d_taps, const int32_t* delays,
+                                int n_taps, int n_links, size_t n_sym, int fft_size, int cp_size,
+                                int num_used, void* d_H);
 /* element-wise complex divide (flat-fading equalisation y / h of the C2 template) */
 int mcle_cdiv(mcle_ctx* ctx, int dtype, const void* d_num, const void* d_den, void* d_out,
               size_t n);
@@ -143,6 +153,9 @@ int mcle_blast_filter(mcle_ctx* ctx, int dtype, const void* d_H, int nr, int nt,
 /* est[c*nt + a] = sum_r G[a, r] Y[r, c]      (decode, :658-660) */
 int mcle_blast_decode(mcle_ctx* ctx, int dtype, const void* d_G, const void* d_Y, int nr, int nt,
                       size_t ns, void* d_est, size_t batch);
+/* one receive filter per column (per-subcarrier MMSE): G [ns][nt][nr], Y [nr][ns] -> est[c*nt + a] */
+int mcle_blast_decode_per_subcarrier(mcle_ctx* ctx, int dtype, const void* d_G, const void* d_Y,
+                                     int nr, int nt, size_t ns, void* d_est);
 /* Y = H X  (+ sqrt(noise_var) * noise when d_noise != NULL): apps/mimo/simulate_mimo.py:96-98 */
 int mcle_mimo_channel(mcle_ctx* ctx, int dtype, const void* d_H, const void* d_X,
                       const void* d_noise, double noise_var, int nr, int nt, size_t ns, void* d_Y,

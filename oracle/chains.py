@@ -237,3 +237,42 @@ def chain_ia(rng, mod='qam', M=16, K=3, nr=2, nt=2, Ns=1, NSymbs=200, snr_db=20.
                U=np.stack([u.reshape(-1) for u in U]) if Ns == 1 else None,
                sinr=np.concatenate(sinr))
     return _counts(out, idx, dec, M)
+
+
+def chain_mimo_ofdm_tdl(rng, mod='qam', M=16, nt=2, nr=2, fft_size=64, cp_size=16, num_used=None, n_ofdm_sym=2,
+                        snr_db=20.0, Fd=50.0, Ts=1e-6, L=8, tap_powers_dB=(0.0, -4.0, -9.0),
+                        tap_delays_samples=(0, 2, 5)):
+    """spatial multiplexing over a frequency-selective MIMO TDL channel
+    (TdlMimoChannel, fading.py:1290-1333 + the MIMO branch of corrupt_data :1107-1117), per-antenna OFDM
+    and one MMSE receive filter per subcarrier built from the per-symbol mean frequency response
+    (get_freq_response :513-536; Blast._calc_receive_filter mimo.py:577-607 on every used bin)."""
+    table = constellation(mod, M)
+    used = oofdm.check_params(fft_size, cp_size, num_used)
+    noise_var = 1.0 / float(omodem.dB2Linear(snr_db))
+    idx = rng.symbols(nt * used * n_ofdm_sym, M)
+    sym = omodem.modulate(table, idx)
+    X = omimo.blast_encode(sym, nt)
+    T = np.stack([oofdm.modulate(X[a], fft_size, cp_size, used) for a in range(nt)])
+    p_lin, d_idx = och.discretize_profile(np.asarray(tap_powers_dB, dtype=float),
+                                          np.asarray(tap_delays_samples, dtype=float) * Ts, Ts)
+    S = len(d_idx)
+    if rng.legacy:
+        rng.uniform(L, nr, nt, 1)      # Jakes ctor with shape (nr, nt): one discarded sample
+        rng.uniform(L, nr, nt, 1)
+    phi, psi = _jakes_phases(rng, L, (S, nr, nt))
+    n = T.shape[1]
+    t, _ = och.jakes_time_axis(Ts, Ts, n)
+    fading = och.jakes_samples(phi, psi, Fd, t)                  # [S, nr, nt, n]
+    taps = och.tdl_taps(fading, p_lin)
+    faded = och.tdl_apply_mimo(T, taps, d_idx)                   # [nr, n + dmax]
+    noise = rng.cn(philox.STREAM_NOISE, nr, faded.shape[1])
+    R = faded + math.sqrt(noise_var) * noise
+    Y = np.stack([oofdm.demodulate(R[r, :n].copy(), fft_size, cp_size, used) for r in range(nr)])   # [nr, ns]
+    Hm = och.mean_freq_response(taps, d_idx, fft_size, cp_size, n_ofdm_sym)      # [n_sym, fft, nr, nt]
+    Hu = Hm[:, oofdm.used_subcarrier_indexes(fft_size, used)].reshape(-1, nr, nt)  # [ns, nr, nt]
+    G = np.stack([omimo.blast_receive_filter(Hu[c], noise_var) for c in range(Hu.shape[0])])
+    est = np.einsum('car,rc->ca', G, Y).reshape(-1)               # est[c*nt + a]
+    dec = omodem.demodulate(table, est)
+    return _counts(dict(table=table, idx=idx, T=T, phi=phi, psi=psi, taps=taps, delay_indexes=d_idx,
+                        tap_powers_linear=p_lin, faded=faded, noise=noise, Y=Y, Hu=Hu, G=G, est=est,
+                        noise_var=noise_var), idx, dec, M)

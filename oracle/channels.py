@@ -83,3 +83,14 @@ def tdl_apply_mimo(signal, taps, delay_indexes):
         for tx in range(nt):
             out[:, d:d + n] += taps[i, :, tx, :] * signal[tx]
     return out
+
+
+def mean_freq_response(taps, delay_indexes, fft_size, cp_size, n_sym):
+    """Per-OFDM-symbol mean of TdlImpulseResponse.get_freq_response (fading.py:513-536; the averaging of
+    ofdm.py:545-547 generalised to MIMO).  taps [S, ..., n_sym*(fft+cp)] -> [n_sym, fft, ...]."""
+    n_pad = int(delay_indexes[-1]) + 1
+    dense = np.zeros((n_pad,) + taps.shape[1:], dtype=complex)
+    dense[np.asarray(delay_indexes)] = taps
+    fr = np.fft.fft(dense, fft_size, axis=0)                                   # [fft, ..., n]
+    fr = fr.reshape(fr.shape[:-1] + (n_sym, fft_size + cp_size)).mean(axis=-1)  # [fft, ..., n_sym]
+    return np.moveaxis(fr, -1, 0)                                               # [n_sym, fft, ...]

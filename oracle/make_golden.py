@@ -295,6 +295,38 @@ def ref_chain_ia(seed, mod, M, K, nr, nt, Ns, NSymbs, snr_db):
                 sinr=np.concatenate([np.asarray(s, dtype=float) for s in sinr]), **ref_counts(idx, dec, M))
 
 
+def ref_chain_mimo_ofdm_tdl(seed, mod, M, nt, nr, fft_size, cp_size, num_used, n_ofdm_sym, snr_db, Fd, Ts, L,
+                            tap_powers_dB, tap_delays_samples):
+    np.random.seed(seed)
+    m = ref_modulator(mod, M)
+    o = rofdm.OFDM(fft_size, cp_size, num_used)
+    used = o.num_used_subcarriers
+    noise_var = 1.0 / dB2Linear(snr_db)
+    idx = np.random.randint(0, M, nt * used * n_ofdm_sym)
+    sym = m.modulate(idx)
+    X = rmimo.Blast(np.ones((nr, nt), dtype=complex)).encode(sym)
+    T = np.stack([o.modulate(X[a]) for a in range(nt)])
+    jakes = rfg.JakesSampleGenerator(Fd, Ts, L, shape=(nr, nt))
+    tdl = rfading.TdlMimoChannel(jakes, tap_powers_dB=np.asarray(tap_powers_dB, dtype=float),
+                                 tap_delays=np.asarray(tap_delays_samples, dtype=float) * Ts)
+    faded = tdl.corrupt_data(T)
+    ir = tdl.get_last_impulse_response()
+    noise = rmisc.randn_c(nr, faded.shape[1])
+    R = faded + noise * math.sqrt(noise_var)
+    n = T.shape[1]
+    Y = np.stack([o.demodulate(R[r, :n].copy()) for r in range(nr)])
+    fr = ir.get_freq_response(fft_size)                                     # [fft, nr, nt, n]
+    fr = fr.reshape(fft_size, nr, nt, n_ofdm_sym, fft_size + cp_size).mean(axis=-1)
+    Hu = np.moveaxis(fr, -1, 0)[:, o.get_used_subcarrier_indexes()].reshape(-1, nr, nt)
+    G = np.stack([rmimo.Blast._calc_receive_filter(Hu[c], noise_var) for c in range(Hu.shape[0])])
+    est = np.stack([G[c] @ Y[:, c] for c in range(Hu.shape[0])]).reshape(-1)
+    dec = m.demodulate(est)
+    return dict(table=m.symbols, idx=idx, T=T, phi=jakes._phi_l, psi=jakes._psi_l, taps=ir.tap_values_sparse,
+                delay_indexes=ir.tap_indexes_sparse, tap_powers_linear=tdl.channel_profile.tap_powers_linear,
+                faded=faded, noise=noise, Y=Y, Hu=Hu, G=G, est=est, decisions=dec, noise_var=noise_var,
+                **ref_counts(idx, dec, M))
+
+
 CHAINS = {
     # name: (reference runner, oracle chain, [(kwargs for oracle, args for ref)], n realizations)
     "c1_awgn": [dict(mod="qam", M=16, N=10000, snr_db=10.0)]
@@ -313,6 +345,12 @@ CHAINS = {
                           n_ofdm_sym=1, snr_db=25.0, mmse=True),
                      dict(mod="qam", M=16, nt=2, nr=2, fft_size=64, cp_size=8, num_used=48,
                           n_ofdm_sym=2, snr_db=15.0, mmse=False)],
+    "f1_mimo_ofdm_tdl": [dict(mod="qam", M=16, nt=2, nr=2, fft_size=64, cp_size=16, num_used=None, n_ofdm_sym=2,
+                              snr_db=20.0, Fd=50.0, Ts=1e-6, L=8, tap_powers_dB=(0.0, -4.0, -9.0),
+                              tap_delays_samples=(0, 2, 5)),
+                         dict(mod="qam", M=64, nt=4, nr=4, fft_size=256, cp_size=32, num_used=200, n_ofdm_sym=1,
+                              snr_db=30.0, Fd=100.0, Ts=5e-7, L=8, tap_powers_dB=(0.0, -3.0, -6.0, -9.0),
+                              tap_delays_samples=(0, 1, 4, 9))],
     "c5_ia": [dict(mod="qam", M=16, K=3, nr=2, nt=2, Ns=1, NSymbs=200, snr_db=20.0),
               dict(mod="qam", M=4, K=3, nr=2, nt=2, Ns=1, NSymbs=50, snr_db=8.0)],
 }
@@ -321,6 +359,8 @@ CHAINS = {
 def run_ref(name, kw, seed):
     if name == "c5_ia":
         return ref_chain_ia(seed, **kw)
+    if name == "f1_mimo_ofdm_tdl":
+        return ref_chain_mimo_ofdm_tdl(seed, **kw)
     if name == "c1_awgn":
         return ref_chain_awgn(seed, kw["mod"], kw["M"], kw["N"], kw["snr_db"])
     if name == "c2_flat_jakes":
@@ -336,13 +376,15 @@ def run_ref(name, kw, seed):
 
 
 ORACLE = {"c1_awgn": chains.chain_awgn, "c2_flat_jakes": chains.chain_flat_jakes,
-          "c3_ofdm_tdl": chains.chain_ofdm_tdl, "c4_mimo_ofdm": chains.chain_mimo_ofdm, "c5_ia": chains.chain_ia}
+          "c3_ofdm_tdl": chains.chain_ofdm_tdl, "c4_mimo_ofdm": chains.chain_mimo_ofdm, "c5_ia": chains.chain_ia,
+          "f1_mimo_ofdm_tdl": chains.chain_mimo_ofdm_tdl}
 INT_KEYS = ("idx", "decisions", "symbol_errors", "bit_errors", "num_symbols", "num_bits", "delay_indexes")
 # realizations stored per case (kept small: fixtures are KBs)
-N_REAL = {"c1_awgn": 2, "c2_flat_jakes": 2, "c3_ofdm_tdl": 2, "c4_mimo_ofdm": 2, "c5_ia": 4}
+N_REAL = {"c1_awgn": 2, "c2_flat_jakes": 2, "c3_ofdm_tdl": 2, "c4_mimo_ofdm": 2, "c5_ia": 4, "f1_mimo_ofdm_tdl": 1}
 # derivable float arrays that are checked against the reference above but not stored
 SKIP_STORE = {"c1_awgn": ("tx",), "c2_flat_jakes": ("tx", "faded"), "c3_ofdm_tdl": ("sym", "faded"),
-              "c4_mimo_ofdm": ("sym", "X", "R"), "c5_ia": ()}
+              "c4_mimo_ofdm": ("sym", "X", "R"), "c5_ia": (),
+              "f1_mimo_ofdm_tdl": ("faded", "G")}
 
 
 def golden_chains():
@@ -356,7 +398,7 @@ def golden_chains():
                 ref = run_ref(name, kw, seed)
                 mine = ORACLE[name]((chains.LegacyRng3 if name == "c5_ia" else chains.LegacyRng)(seed), **kw)
                 for k, v in ref.items():
-                    tol = 0 if k in INT_KEYS else (1e-9 if name == "c5_ia" else 1e-12)
+                    tol = 0 if k in INT_KEYS else (1e-9 if name in ("c5_ia", "f1_mimo_ofdm_tdl") else 1e-12)
                     worst = max(worst, close(mine[k], v, tol, "%s[%d] r%d %s" % (name, ci, r, k)))
                     arr = np.asarray(v)
                     if k in SKIP_STORE[name] or (r > 0 and arr.size > 4096 and ci == 0):

@@ -278,13 +278,12 @@ class TdlChannel:
         self._fading_generator = fading_generator
         self._engine = engine if engine is not None else getattr(fading_generator, "_engine", None)
         self.dtype = dtype if dtype is not None else getattr(fading_generator, "dtype", None)
-        # the generator produces one stream per tap: shape (num_taps,) [+ MIMO dims]; assigning the
+        # the generator produces one stream per tap: shape (num_taps,) [+ (Nr, Nt)]; assigning the
         # shape re-draws the Jakes phases (fading.py:796-798, fading_generators.py:381-386)
         base = fading_generator.shape
-        if base is not None and len(base) > 0:
-            raise NotImplementedError("MIMO TdlChannel is not part of this round's hot path (SURVEY 8f.1)")
-        self._fading_generator.shape = (self.num_taps,)
+        self._set_fading_generator_shape(tuple(base) if base else None)
         self._last_impulse_response = None
+        self._switched_direction = False
 
     channel_profile = property(lambda self: self._channel_profile)
     num_taps = property(lambda self: self._channel_profile.num_taps)
@@ -296,22 +295,76 @@ class TdlChannel:
             self._engine = get_engine()
         return self._engine
 
+    def _set_fading_generator_shape(self, new_shape):
+        """(num_taps,) + new_shape (fading.py:854-868)."""
+        self._fading_generator.shape = (self.num_taps,) + (tuple(new_shape) if new_shape else ())
+
+    def set_num_antennas(self, num_rx_antennas, num_tx_antennas):
+        self._set_fading_generator_shape((num_rx_antennas, num_tx_antennas))
+
+    @property
+    def num_tx_antennas(self):
+        shp = self._fading_generator.shape
+        return -1 if shp is None or len(shp) == 1 else shp[2]
+
+    @property
+    def num_rx_antennas(self):
+        shp = self._fading_generator.shape
+        return -1 if shp is None or len(shp) == 1 else shp[1]
+
+    @property
+    def switched_direction(self):
+        return self._switched_direction
+
+    @switched_direction.setter
+    def switched_direction(self, value):
+        if not isinstance(value, bool):
+            raise TypeError("switched_direction must be a boolean value")
+        self._switched_direction = value
+
     def generate_impulse_response(self, num_samples=1):
         self._fading_generator.generate_more_samples(num_samples)
-        fading = np.asarray(self._fading_generator.get_samples()).reshape(self.num_taps, -1)
-        amp = np.sqrt(self._channel_profile.tap_powers_linear).reshape(-1, 1)
+        fading = np.asarray(self._fading_generator.get_samples())
+        fading = fading.reshape(tuple(self._fading_generator.shape) + (-1,))
+        amp = np.sqrt(self._channel_profile.tap_powers_linear).reshape((-1,) + (1,) * (fading.ndim - 1))
         self._last_impulse_response = TdlImpulseResponse(fading * amp, self._channel_profile)
 
     def get_last_impulse_response(self):
         return self._last_impulse_response
 
     def corrupt_data(self, signal):
+        """fading.py:1046-1124: SISO (generator shape (taps,)) or MIMO (shape (taps, Nr, Nt))."""
         signal = np.asarray(signal)
-        if signal.ndim != 1:
-            raise NotImplementedError("only SISO signals (1-D) in this round")
+        shp = self._fading_generator.shape
+        if len(shp) == 1:
+            if signal.ndim != 1:
+                raise ValueError("a SISO TdlChannel takes a 1-D signal")
+            self.generate_impulse_response(signal.shape[-1])
+            ir = self._last_impulse_response
+            return self.engine.tdl_apply(signal, ir.tap_values_sparse, ir.tap_indexes_sparse, dtype=self.dtype)
+        if len(shp) != 3:
+            raise RuntimeError("Shape of the fading generator of the TdlChannel class must have either 1 (SISO) "
+                               "or 3 (MIMO) dimensions")
+        _, nr, nt = shp
+        if self._switched_direction:
+            raise NotImplementedError("switched_direction (reverse link) is not offloaded yet")
+        if nt == 1 and signal.ndim == 1:
+            signal = signal.reshape(1, -1)
         self.generate_impulse_response(signal.shape[-1])
         ir = self._last_impulse_response
-        return self.engine.tdl_apply(signal, ir.tap_values_sparse, ir.tap_indexes_sparse, dtype=self.dtype)
+        return self.engine.tdl_apply_mimo(signal, ir.tap_values_sparse, ir.tap_indexes_sparse, dtype=self.dtype)
+
+
+class TdlMimoChannel(TdlChannel):
+    """reference fading.py:1290-1333: the generator must carry a (Nr, Nt) shape."""
+
+    def __init__(self, fading_generator, channel_profile=None, tap_powers_dB=None, tap_delays=None, Ts=None,
+                 engine=None, dtype=None):
+        if fading_generator.shape is None or len(fading_generator.shape) != 2:
+            raise RuntimeError("The provided fading_generator for the TdlMimoChannel class must have a shape with "
+                               "two values")
+        super().__init__(fading_generator, channel_profile, tap_powers_dB, tap_delays, Ts, engine=engine,
+                         dtype=dtype)
 
 
 class SuChannel:
@@ -351,3 +404,20 @@ class SuChannel:
         if self._pathloss_value is None or ir is None:
             return ir
         return TdlImpulseResponse(ir.tap_values_sparse * math.sqrt(self._pathloss_value), ir.channel_profile)
+
+
+class SuMimoChannel(SuChannel):
+    """reference singleuser.py:154-359: SuChannel whose generator carries (N, N) antennas."""
+
+    def __init__(self, num_antennas, fading_generator=None, channel_profile=None, tap_powers_dB=None,
+                 tap_delays=None, Ts=None, engine=None, dtype=None):
+        if fading_generator is None:
+            fading_generator = RayleighSampleGenerator()
+            if channel_profile is None and Ts is None:
+                Ts = 1.0
+        fading_generator.shape = (num_antennas, num_antennas)
+        super().__init__(fading_generator, channel_profile, tap_powers_dB, tap_delays, Ts, engine=engine,
+                         dtype=dtype)
+
+    num_tx_antennas = property(lambda self: self._tdlchannel.num_tx_antennas)
+    num_rx_antennas = property(lambda self: self._tdlchannel.num_rx_antennas)

@@ -1,6 +1,7 @@
 // kernels_channel.hip -- Jakes sum-of-sinusoids fading and the time-varying TDL convolution.
 // Reference: channels/fading_generators.py:427-523 (time axis, h = L^-1/2 sum_l exp(j(...))),
 // channels/fading.py:949-956 (tap = fading * sqrt(power)), :1080-1090 (SISO corrupt_data).
+#include "fft.hpp"
 #include "jakes.hpp"
 
 namespace mcle {
@@ -48,6 +49,67 @@ __global__ __launch_bounds__(kChBlock) void k_tdl_apply(const cx<T>* __restrict_
             }
         }
         y[m] = acc;
+    }
+}
+
+// MIMO branch of TdlChannel.corrupt_data (fading.py:1107-1117):
+//   y[r][m] = sum_i sum_t g[i][r][t][m - d_i] x[t][m - d_i], taps outer / transmit antennas inner (the
+//   reference's accumulation order).  x [nt][n], g [S][nr][nt][n], y [nr][n + dmax].
+template <typename T>
+__global__ __launch_bounds__(kChBlock) void k_tdl_apply_mimo(const cx<T>* __restrict__ x, const cx<T>* __restrict__ g,
+                                                             Delays dl, int n_taps, int nr, int nt,
+                                                             cx<T>* __restrict__ y, size_t n, size_t n_out) {
+    for (int r = blockIdx.y; r < nr; r += gridDim.y)
+        for (size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x; m < n_out;
+             m += (size_t)gridDim.x * blockDim.x) {
+            cx<T> acc = mk<T>(0, 0);
+            for (int i = 0; i < n_taps; ++i) {
+                const long long k = (long long)m - dl.d[i];
+                if (k < 0 || (size_t)k >= n) continue;
+                for (int t = 0; t < nt; ++t)
+                    acc = cadd(acc, cmul(g[(((size_t)i * nr + r) * nt + t) * n + k], x[(size_t)t * n + k]));
+            }
+            y[(size_t)r * n_out + m] = acc;
+        }
+}
+
+// Mean frequency response per OFDM symbol on the used subcarriers, for P parallel links (P = nr*nt):
+//   Hm[sym][d][p] = sum_i mean_{j in symbol}(g[i][p][j]) w^(bin(d) d_i)
+// (TdlImpulseResponse.get_freq_response, fading.py:513-536, averaged over the symbol's fft+cp samples
+// as OfdmOneTapEqualizer does, ofdm.py:545-547).  g [S][P][n_sym*(fft+cp)].
+template <typename T>
+__global__ __launch_bounds__(kChBlock) void k_mean_freq_response(const cx<T>* __restrict__ g, Delays dl, int n_taps,
+                                                                 int P, size_t n_sym, int n, int cp, int num_used,
+                                                                 const cx<T>* __restrict__ tw,
+                                                                 cx<T>* __restrict__ Hm) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cx<T>* s_mean = reinterpret_cast<cx<T>*>(smem);  // [n_taps][P]
+    const size_t total = n_sym * (size_t)(n + cp);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+    for (size_t sym = blockIdx.x; sym < n_sym; sym += gridDim.x) {
+        __syncthreads();
+        for (int q = wave; q < n_taps * P; q += nwave) {  // one wavefront per (tap, link) mean
+            const cx<T>* src = g + (size_t)q * total + sym * (size_t)(n + cp);
+            T re = 0, im = 0;
+            for (int j = lane; j < n + cp; j += 64) {
+                re += src[j].x;
+                im += src[j].y;
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                re += __shfl_xor(re, off, 64);
+                im += __shfl_xor(im, off, 64);
+            }
+            if (lane == 0) s_mean[q] = mk<T>(re / (T)(n + cp), im / (T)(n + cp));
+        }
+        __syncthreads();
+        for (size_t e = threadIdx.x; e < (size_t)num_used * P; e += blockDim.x) {
+            const int d = (int)(e / P), p = (int)(e - (size_t)d * P);
+            const int k = ofdm_bin(d, n, num_used);
+            cx<T> h = mk<T>(0, 0);
+            for (int i = 0; i < n_taps; ++i) h = cfma(s_mean[i * P + p], tw[(k * dl.d[i]) & (n - 1)], h);
+            Hm[(sym * num_used + d) * P + p] = h;
+        }
     }
 }
 
@@ -115,6 +177,68 @@ int mcle_tdl_apply(mcle_ctx* ctx, int dtype, const void* d_x, const void* d_taps
     else
         hipLaunchKernelGGL(k_tdl_apply<double>, dim3(grid), dim3(kChBlock), 0, ctx->stream, (const double2*)d_x,
                            (const double2*)d_taps, dl, n_taps, (double2*)d_y, n, n_out);
+    MCLE_LAUNCH_CHECK();
+    return MCLE_OK;
+}
+
+int mcle_tdl_apply_mimo(mcle_ctx* ctx, int dtype, const void* d_x, const void* d_taps, const int32_t* delays,
+                        int n_taps, int nr, int nt, void* d_y, size_t n) {
+    MCLE_REQUIRE(ctx != nullptr && delays != nullptr, "null argument");
+    MCLE_REQUIRE(dtype == MCLE_F32 || dtype == MCLE_F64, "dtype must be MCLE_F32 or MCLE_F64");
+    MCLE_REQUIRE(n_taps >= 1 && n_taps <= MCLE_MAX_TAPS, "n_taps must be in [1, %d]", MCLE_MAX_TAPS);
+    MCLE_REQUIRE(nr >= 1 && nt >= 1 && nr <= 64 && nt <= 64, "bad antenna counts");
+    Delays dl;
+    int maxd = 0;
+    for (int i = 0; i < MCLE_MAX_TAPS; ++i) {
+        dl.d[i] = i < n_taps ? delays[i] : 0;
+        MCLE_REQUIRE(dl.d[i] >= 0, "negative tap delay");
+        if (dl.d[i] > maxd) maxd = dl.d[i];
+    }
+    if (n == 0) return MCLE_OK;
+    int rc = ctx->bind();
+    if (rc) return rc;
+    const size_t n_out = n + (size_t)maxd;
+    dim3 grid((unsigned)grid_for(ctx, n_out, kChBlock, 4), (unsigned)nr);
+    if (dtype == MCLE_F32)
+        hipLaunchKernelGGL(k_tdl_apply_mimo<float>, grid, dim3(kChBlock), 0, ctx->stream, (const float2*)d_x,
+                           (const float2*)d_taps, dl, n_taps, nr, nt, (float2*)d_y, n, n_out);
+    else
+        hipLaunchKernelGGL(k_tdl_apply_mimo<double>, grid, dim3(kChBlock), 0, ctx->stream, (const double2*)d_x,
+                           (const double2*)d_taps, dl, n_taps, nr, nt, (double2*)d_y, n, n_out);
+    MCLE_LAUNCH_CHECK();
+    return MCLE_OK;
+}
+
+int mcle_tdl_mean_freq_response(mcle_ctx* ctx, int dtype, const void* d_taps, const int32_t* delays, int n_taps,
+                                int n_links, size_t n_sym, int fft_size, int cp_size, int num_used, void* d_H) {
+    MCLE_REQUIRE(ctx != nullptr && delays != nullptr, "null argument");
+    MCLE_REQUIRE(dtype == MCLE_F32 || dtype == MCLE_F64, "dtype must be MCLE_F32 or MCLE_F64");
+    MCLE_REQUIRE(n_taps >= 1 && n_taps <= MCLE_MAX_TAPS, "n_taps must be in [1, %d]", MCLE_MAX_TAPS);
+    MCLE_REQUIRE(n_links >= 1 && n_links <= 64, "n_links must be in [1, 64]");
+    MCLE_REQUIRE(fft_size >= 16 && fft_size <= 4096 && (fft_size & (fft_size - 1)) == 0, "bad fft_size %d", fft_size);
+    MCLE_REQUIRE(cp_size >= 0 && cp_size <= fft_size && num_used >= 2 && num_used <= fft_size && num_used % 2 == 0,
+                 "bad OFDM parameters");
+    Delays dl;
+    for (int i = 0; i < MCLE_MAX_TAPS; ++i) {
+        dl.d[i] = i < n_taps ? delays[i] : 0;
+        MCLE_REQUIRE(dl.d[i] >= 0, "negative tap delay");
+    }
+    if (n_sym == 0) return MCLE_OK;
+    int rc = ctx->bind();
+    if (rc) return rc;
+    void* tw = nullptr;
+    if ((rc = ctx->get_twiddles(fft_size, dtype, &tw))) return rc;
+    const unsigned grid = (unsigned)(n_sym < 4096 ? n_sym : 4096);
+    const size_t esz = dtype == MCLE_F32 ? sizeof(float2) : sizeof(double2);
+    const size_t lds = (size_t)n_taps * n_links * esz;
+    if (dtype == MCLE_F32)
+        hipLaunchKernelGGL(k_mean_freq_response<float>, dim3(grid), dim3(kChBlock), lds, ctx->stream,
+                           (const float2*)d_taps, dl, n_taps, n_links, n_sym, fft_size, cp_size, num_used,
+                           (const float2*)tw, (float2*)d_H);
+    else
+        hipLaunchKernelGGL(k_mean_freq_response<double>, dim3(grid), dim3(kChBlock), lds, ctx->stream,
+                           (const double2*)d_taps, dl, n_taps, n_links, n_sym, fft_size, cp_size, num_used,
+                           (const double2*)tw, (double2*)d_H);
     MCLE_LAUNCH_CHECK();
     return MCLE_OK;
 }

@@ -58,6 +58,21 @@ __global__ __launch_bounds__(kMimoBlock) void k_blast_decode(const cx<T>* __rest
     }
 }
 
+// per-subcarrier decode: est[c*nt + a] = sum_r G[c][a][r] Y[r][c]  (one receive filter per column c)
+template <typename T>
+__global__ __launch_bounds__(kMimoBlock) void k_blast_decode_persc(const cx<T>* __restrict__ G,
+                                                                   const cx<T>* __restrict__ Y, int nr, int nt,
+                                                                   size_t ns, cx<T>* __restrict__ est) {
+    for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < ns; c += (size_t)gridDim.x * blockDim.x) {
+        const cx<T>* Gc = G + c * (size_t)nt * nr;
+        for (int a = 0; a < nt; ++a) {
+            cx<T> acc = mk<T>(0, 0);
+            for (int r = 0; r < nr; ++r) acc = cfma(Gc[a * nr + r], Y[(size_t)r * ns + c], acc);
+            est[c * nt + a] = acc;
+        }
+    }
+}
+
 // Y[b][r][c] = sum_a H[b][r][a] X[b][a][c] (+ sigma * noise[b][r][c])
 template <typename T>
 __global__ __launch_bounds__(kMimoBlock) void k_mimo_channel(const cx<T>* __restrict__ H, const cx<T>* __restrict__ X,
@@ -588,6 +603,23 @@ int mcle_svd_filters(mcle_ctx* ctx, int dtype, const void* d_H, int n_ant, void*
         else MCLE_SVD(double, 4);
     }
 #undef MCLE_SVD
+    MCLE_LAUNCH_CHECK();
+    return MCLE_OK;
+}
+
+int mcle_blast_decode_per_subcarrier(mcle_ctx* ctx, int dtype, const void* d_G, const void* d_Y, int nr, int nt,
+                                     size_t ns, void* d_est) {
+    int rc = check_mimo(ctx, dtype, nr, nt, 1);
+    if (rc) return rc;
+    if (ns == 0) return MCLE_OK;
+    if ((rc = ctx->bind())) return rc;
+    const dim3 grid(grid_for(ctx, ns, kMimoBlock, 4));
+    if (dtype == MCLE_F32)
+        hipLaunchKernelGGL(k_blast_decode_persc<float>, grid, dim3(kMimoBlock), 0, ctx->stream, (const float2*)d_G,
+                           (const float2*)d_Y, nr, nt, ns, (float2*)d_est);
+    else
+        hipLaunchKernelGGL(k_blast_decode_persc<double>, grid, dim3(kMimoBlock), 0, ctx->stream, (const double2*)d_G,
+                           (const double2*)d_Y, nr, nt, ns, (double2*)d_est);
     MCLE_LAUNCH_CHECK();
     return MCLE_OK;
 }

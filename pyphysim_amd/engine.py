@@ -276,6 +276,45 @@ class Engine:
                                       delays.size, out.ptr, n))
         return self._out(out, host)
 
+    def tdl_apply_mimo(self, x, taps, delays, dtype=None):
+        """x [nt, n], taps [S, nr, nt, n] -> y [nr, n + max delay] (fading.py:1107-1117)."""
+        dt = self._dt(dtype)
+        d_x, host = self._cin(x, dt)
+        d_g, _ = self._cin(taps, dt)
+        delays = np.ascontiguousarray(delays, dtype=np.int32)
+        S, nr, nt, n = d_g.shape
+        if d_x.shape != (nt, n) or S != delays.size:
+            raise ValueError("x must be [nt, n] and taps [n_taps, nr, nt, n]")
+        out = self.empty((nr, n + int(delays.max())), _lib.np_complex(dt))
+        self._raise_value(self.lib.mcle_tdl_apply_mimo(self.ctx, dt, d_x.ptr, d_g.ptr,
+                                                       delays.ctypes.data_as(ctypes.POINTER(c_int32)), S, nr, nt,
+                                                       out.ptr, n))
+        return self._out(out, host)
+
+    def tdl_mean_freq_response(self, taps, delays, n_sym, fft_size, cp_size, num_used, dtype=None):
+        """taps [S, *links, n_sym*(fft+cp)] -> H [n_sym, num_used, *links]."""
+        dt = self._dt(dtype)
+        d_g, host = self._cin(taps, dt)
+        delays = np.ascontiguousarray(delays, dtype=np.int32)
+        links = d_g.shape[1:-1]
+        P = int(np.prod(links)) if links else 1
+        out = self.empty((n_sym, num_used) + tuple(links), _lib.np_complex(dt))
+        self._raise_value(self.lib.mcle_tdl_mean_freq_response(
+            self.ctx, dt, d_g.ptr, delays.ctypes.data_as(ctypes.POINTER(c_int32)), delays.size, P, n_sym, fft_size,
+            cp_size, num_used, out.ptr))
+        return self._out(out, host)
+
+    def blast_decode_per_subcarrier(self, G, Y, dtype=None):
+        """G [ns, nt, nr], Y [nr, ns] -> est [ns*nt] with est[c*nt + a]."""
+        dt = self._dt(dtype)
+        d_G, _ = self._cin(G, dt)
+        d_Y, host = self._cin(Y, dt)
+        ns, nt, nr = d_G.shape
+        out = self.empty(ns * nt, _lib.np_complex(dt))
+        self._raise_value(self.lib.mcle_blast_decode_per_subcarrier(self.ctx, dt, d_G.ptr, d_Y.ptr, nr, nt, ns,
+                                                                    out.ptr))
+        return self._out(out, host)
+
     # ---- a10/a11 ----------------------------------------------------------------------------
     def ofdm_modulate(self, x, fft_size, cp_size, num_used, batch=1, dtype=None):
         dt = self._dt(dtype)
