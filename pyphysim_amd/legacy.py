@@ -22,11 +22,6 @@ from .modulators import constellation, dB2Linear, level2bits
 INV_SQRT2 = 1.0 / math.sqrt(2.0)
 
 
-def _device_slice(eng, arr, row, start, n, dtype):
-    """Copy a slice of a device row into a fresh device array (via the host: parity tool, not hot)."""
-    return eng.to_device(arr.get()[row, start:start + n], dtype)
-
-
 def _table(mod, M):
     kind = {"qam": _lib.CONST_QAM, "bpsk": _lib.CONST_BPSK}.get(mod, _lib.CONST_GENERIC)
     return constellation(mod, M) if mod in ("qam", "psk") else constellation(mod), kind
