@@ -182,7 +182,8 @@ __global__ __launch_bounds__(64) void k_run_ia(ModemParams<T> mp, int n_symbols,
     const int lane = threadIdx.x;
     const T sigma = (T)sqrt(noise_var);
     const uint32_t mask = (uint32_t)(mp.M - 1);
-    WgTotals totals;
+    __shared__ WgTotals totals;
+    if (threadIdx.x == 0) wg_zero(totals);
     for (uint64_t rl = blockIdx.x; rl < count; rl += gridDim.x) {
         const Rng rng(seed, first + rl);
         __syncthreads();

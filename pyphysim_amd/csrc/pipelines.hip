@@ -249,7 +249,8 @@ __global__ __launch_bounds__(kPipeBlock, sizeof(T) == 4 ? 3 : 1) void k_run_mimo
     const T tx_scale = (T)(1.0 / sqrt((double)NA) / sqrt((double)(U + cp)));  // encode / sqrt(Nt), ifft power scale
     const double rx_scale = sqrt((double)(U + cp)) / (double)N;               // fft / sqrt(power scale)
     const uint32_t mask = (uint32_t)(mp.M - 1);
-    WgTotals totals;
+    __shared__ WgTotals totals;
+    if (threadIdx.x == 0) wg_zero(totals);
 
     for (uint64_t rl = blockIdx.x; rl < count; rl += gridDim.x) {
         const Rng rng(seed, first + rl);
@@ -408,7 +409,8 @@ __global__ __launch_bounds__(BLOCK) void k_run_ofdm_tdl(TdlParams pp, ModemParam
     const T rx_scale = (T)(sqrt((double)(U + cp)) / (double)N);
     const uint32_t mask = (uint32_t)(mp.M - 1);
     const int lane = tid & 63, wave = tid >> 6;
-    WgTotals totals;
+    __shared__ WgTotals totals;
+    if (threadIdx.x == 0) wg_zero(totals);
 
     for (uint64_t rl = blockIdx.x; rl < count; rl += gridDim.x) {
         const Rng rng(seed, first + rl);

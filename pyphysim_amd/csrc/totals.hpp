@@ -8,9 +8,14 @@ namespace mcle {
 
 // Running totals of one workgroup (held by thread 0), flushed with six atomics at kernel end:
 // the counter block is exact integer sums, so the order of the atomics is irrelevant.
+// Lives in LDS (a `__shared__ WgTotals`): thread 0 touches it once per realization, and keeping six
+// 64-bit accumulators in VGPRs across the whole kernel made the allocator spill them to scratch.
 struct WgTotals {
-    unsigned long long se = 0, se2 = 0, be = 0, be2 = 0, ok = 0, skip = 0;
+    unsigned long long se, se2, be, be2, ok, skip;
 };
+__device__ __forceinline__ void wg_zero(WgTotals& t) {
+    t.se = t.se2 = t.be = t.be2 = t.ok = t.skip = 0ull;
+}
 __device__ __forceinline__ void wg_account(WgTotals& t, unsigned se, unsigned be, bool skipped, uint64_t rl,
                                            uint32_t* __restrict__ sym_out, uint32_t* __restrict__ bit_out) {
     if (sym_out) sym_out[rl] = skipped ? 0xFFFFFFFFu : se;
