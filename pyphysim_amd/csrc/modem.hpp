@@ -36,6 +36,42 @@ __device__ __forceinline__ int demod_mindist(const cx<T>* __restrict__ s_table, 
     return idx;
 }
 
+// K symbols against the same table in one sweep (one LDS read per candidate serves all K).  For f32
+// the ordering metric is |c|^2/2 - Re(r conj(c)) (two FMAs per candidate; argmin-equivalent to
+// |c - r|^2 since |r|^2 is common), read from a float4 table {c.re, c.im, |c|^2/2, 0}; f64 keeps the
+// literal |c - r|^2 of the parity path.  First minimum wins, as in demod_mindist.
+template <int K>
+__device__ __forceinline__ void demod_mindist_multi(const float4* __restrict__ s_tab4, int M, const float2 (&r)[K],
+                                                    int (&idx)[K]) {
+    float best[K];
+    {
+        const float4 c = s_tab4[0];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            best[k] = fmaf(-r[k].y, c.y, fmaf(-r[k].x, c.x, c.z));
+            idx[k] = 0;
+        }
+    }
+#pragma unroll 4
+    for (int m = 1; m < M; ++m) {
+        const float4 c = s_tab4[m];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const float d = fmaf(-r[k].y, c.y, fmaf(-r[k].x, c.x, c.z));
+            if (d < best[k]) {
+                best[k] = d;
+                idx[k] = m;
+            }
+        }
+    }
+}
+template <int K>
+__device__ __forceinline__ void demod_mindist_multi(const double2* __restrict__ s_table, int M, const double2 (&r)[K],
+                                                    int (&idx)[K]) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) idx[k] = demod_mindist<double>(s_table, M, r[k]);
+}
+
 __device__ __forceinline__ int gray2binary8(int g) {
     g ^= g >> 4;
     g ^= g >> 2;

@@ -236,12 +236,17 @@ __global__ __launch_bounds__(kPipeBlock, sizeof(T) == 4 ? 3 : 1) void k_run_mimo
     cx<T>* s_table = s_tw + N;                           // [kMaxTable]
     cx<T>* s_H = s_table + kMaxTable;                    // [NA*NA]
     cx<T>* s_G = s_H + NA * NA;                          // [NA*NA]
-    unsigned* s_red = reinterpret_cast<unsigned*>(s_G + NA * NA);  // [8] + flag
+    float4* s_tab4 = reinterpret_cast<float4*>(s_G + NA * NA);     // [kMaxTable] {re, im, |c|^2/2, 0} (f32 min-distance)
+    unsigned* s_red = reinterpret_cast<unsigned*>(s_tab4 + kMaxTable);  // [8] + flag
     unsigned char* s_idx = reinterpret_cast<unsigned char*>(s_red + 16);  // [NA*num_used]
 
     const int tid = threadIdx.x;
     for (int k = tid; k < N; k += kPipeBlock) s_tw[k] = g_tw[k];
     load_table(mp, s_table);
+    for (int m = tid; m < mp.M; m += kPipeBlock) {
+        const cx<T> c = mp.g_table[m];
+        s_tab4[m] = make_float4((float)c.x, (float)c.y, (float)(0.5 * (c.x * c.x + c.y * c.y)), 0.f);
+    }
     const int U = pp.num_used, cp = pp.cp;
     const int per_sym = U * NA;                       // data symbols per OFDM symbol (all antennas)
     const uint64_t row = (uint64_t)pp.n_ofdm_sym * (N + cp);
@@ -346,12 +351,25 @@ __global__ __launch_bounds__(kPipeBlock, sizeof(T) == 4 ? 3 : 1) void k_run_mimo
                 cx<T> y[NA];
 #pragma unroll
                 for (int r = 0; r < NA; ++r) y[r] = s_x[r * N + bin];
+                cx<T> est[NA];
+                int dec[NA];
 #pragma unroll
                 for (int a = 0; a < NA; ++a) {
-                    cx<T> est = mk<T>(0, 0);
+                    est[a] = mk<T>(0, 0);
 #pragma unroll
-                    for (int r = 0; r < NA; ++r) est = cfma(G[a][r], y[r], est);
-                    const unsigned x = (unsigned)((int)s_idx[d * NA + a] ^ demod_one(mp, s_table, est));
+                    for (int r = 0; r < NA; ++r) est[a] = cfma(G[a][r], y[r], est[a]);
+                }
+                if (mp.method == MCLE_DEMOD_QAM_SLICER) {
+#pragma unroll
+                    for (int a = 0; a < NA; ++a) dec[a] = demod_qam_slicer<T>(est[a], mp.qam_scale, mp.qam_L, mp.half_bits);
+                } else if constexpr (sizeof(T) == 4) {
+                    demod_mindist_multi<NA>(s_tab4, mp.M, est, dec);
+                } else {
+                    demod_mindist_multi<NA>(s_table, mp.M, est, dec);
+                }
+#pragma unroll
+                for (int a = 0; a < NA; ++a) {
+                    const unsigned x = (unsigned)((int)s_idx[d * NA + a] ^ dec[a]);
                     se += (x != 0u);
                     be += __popc(x);
                 }
@@ -677,8 +695,8 @@ int run_mimo_impl(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, uint64_t seed, u
     void* tw = nullptr;
     if ((rc = ctx->get_twiddles(N, sizeof(T) == 8 ? MCLE_F64 : MCLE_F32, &tw))) return rc;
     MimoParams pp{cfg->cp_size, cfg->num_used, cfg->n_ofdm_sym, cfg->mmse, cfg->noise_var};
-    const size_t lds = (size_t)(NA * N + N + kMaxTable + 2 * NA * NA) * sizeof(cx<T>) + 16 * sizeof(unsigned) +
-                       (size_t)NA * cfg->num_used;
+    const size_t lds = (size_t)(NA * N + N + kMaxTable + 2 * NA * NA) * sizeof(cx<T>) + kMaxTable * sizeof(float4) +
+                       16 * sizeof(unsigned) + (size_t)NA * cfg->num_used;
     auto kern = k_run_mimo_ofdm<T, N, NA>;
     MCLE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int per_cu = (int)((size_t)160 * 1024 / (lds + 512));  // gfx950: 160 KiB of LDS per CU
