@@ -462,9 +462,38 @@ def golden_framework():
                          idx_m16=[int(i) for i in p.get_pack_indexes({"M": 16})],
                          idx_both=[int(i) for i in p.get_pack_indexes({"M": 16, "SNR": 10})],
                          unpack_index=[q.unpack_index for q in lst])
+    # a results archive written by the reference (pickle protocol 2) and the proof that the reference
+    # reads archives written by pyphysim_amd.simulations.compat
+    from pyphysim.simulations.results import SimulationResults as RSR
+    from pyphysim_amd.simulations import Result as MyResult, SimulationParameters as MyParams
+    from pyphysim_amd.simulations import SimulationResults as MyResults
+    from pyphysim_amd.simulations import compat
+    rsr = RSR()
+    rsr.set_parameters(p)
+    for i in range(6):
+        rr = RR("ser", RR.RATIOTYPE)
+        ss = RR("symbol_errors", RR.SUMTYPE)
+        for v, t in zip(vals[i:i + 5], tots[i:i + 5]):
+            rr.update(v, t)
+            ss.update(v)
+        rsr.append_result(rr)
+        rsr.append_result(ss)
+    rsr.runned_reps = [5] * 6
+    ref_file = os.path.join(GOLD, "reference_results.pickle")
+    rsr.save_to_file(ref_file)
+    out["archive"] = dict(ser=[float(x) for x in rsr.get_result_values_list("ser")],
+                          symbol_errors=[int(x) for x in rsr.get_result_values_list("symbol_errors")],
+                          ser_m16=[float(x) for x in rsr.get_result_values_list("ser", {"M": 16})])
+    mine = compat.load_reference_results(ref_file)
+    assert mine.get_result_values_list("ser") == rsr.get_result_values_list("ser")
+    tmp = os.path.join("/tmp", "written_by_mcle.pickle")
+    compat.save_for_reference(mine, tmp)
+    back = RSR.load_from_file(tmp)                      # the REFERENCE reads our archive
+    assert isinstance(back, RSR) and back.get_result_values_list("ser") == rsr.get_result_values_list("ser")
+    assert back.params == rsr.params and back["ser"][2].get_confidence_interval() == rsr["ser"][2].get_confidence_interval()
     with open(os.path.join(GOLD, "framework.json"), "w") as fh:
         json.dump(out, fh, indent=1)
-    print("framework: ok")
+    print("framework: ok (reference <-> mcle result archives interoperate)")
 
 
 if __name__ == "__main__":

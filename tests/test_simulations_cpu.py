@@ -264,3 +264,25 @@ def test_shard_range_partitions():
         for lo, c in parts:
             assert lo == pos
             pos += c
+
+
+def test_reference_result_archives_interoperate(tmp_path):
+    """an archive written by the reference (tests/golden/reference_results.pickle,
+    pickle protocol 2) loads without the reference installed, and what compat.save_for_reference
+    writes names the reference's classes (the reverse direction is asserted against the reference
+    itself in oracle/make_golden.py)."""
+    from pyphysim_amd.simulations import compat
+    path = os.path.join(os.path.dirname(__file__), "golden", "reference_results.pickle")
+    res = compat.load_reference_results(path)
+    g = G["archive"]
+    assert res.get_result_values_list("ser") == g["ser"]
+    assert res.get_result_values_list("symbol_errors") == g["symbol_errors"]
+    assert res.get_result_values_list("ser", {"M": 16}) == g["ser_m16"]
+    assert res.params.get_num_unpacked_variations() == 6 and res.runned_reps == [5] * 6
+    lo, hi = res["ser"][0].get_confidence_interval(95)
+    assert lo < res["ser"][0].get_result_mean() < hi
+    out = compat.save_for_reference(res, str(tmp_path / "w.pickle"))
+    raw = open(out, "rb").read()
+    assert b"pyphysim.simulations.results\nSimulationResults" in raw and b"pyphysim_amd" not in raw
+    again = compat.load_reference_results(out)
+    assert again.get_result_values_list("ser") == g["ser"] and again.params == res.params
