@@ -65,13 +65,16 @@ def test_flat_fading_pipeline(engine, dt, exact):
 
 
 @pytest.mark.parametrize("dt,exact", [("f64", True), ("f32", False)])
-@pytest.mark.parametrize("case", [0, 1])
+@pytest.mark.parametrize("case", [0, 1, 2])
 def test_ofdm_tdl_pipeline(engine, dt, exact, case):
     kws = [dict(mod="qpsk", M=4, fft_size=1024, cp_size=16, num_used=None, n_ofdm_sym=1, snr_db=20.0, Fd=10.0,
                 Ts=1.0 / (15e3 * 1024), L=8, tap_powers_dB=(0.0, -3.0, -6.0, -9.0, -12.0),
                 tap_delays_samples=(0, 1, 2, 3, 4)),
            dict(mod="qam", M=16, fft_size=64, cp_size=16, num_used=52, n_ofdm_sym=3, snr_db=25.0, Fd=50.0, Ts=1e-6,
-                L=8, tap_powers_dB=(0.0, -5.0, -10.0), tap_delays_samples=(0, 3, 7))]
+                L=8, tap_powers_dB=(0.0, -5.0, -10.0), tap_delays_samples=(0, 3, 7)),
+           # delays beyond the cyclic prefix: inter-symbol interference from the previous OFDM symbol
+           dict(mod="qam", M=16, fft_size=128, cp_size=4, num_used=100, n_ofdm_sym=4, snr_db=30.0, Fd=200.0, Ts=2e-6,
+                L=12, tap_powers_dB=(0.0, -2.0, -6.0, -12.0), tap_delays_samples=(0, 3, 9, 20))]
     kw = kws[case]
     engine.set_constellation(chains.constellation(kw["mod"], kw["M"]),
                              _lib.CONST_QAM if kw["mod"] == "qam" else _lib.CONST_GENERIC)
