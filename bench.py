@@ -25,10 +25,10 @@ if REPO not in sys.path:
 
 # algorithmic bytes per realization in the staged (operator-granular)
 # model, complex64 samples / uint8 indices.
-B_ALG = {"c2": 7_600_000, "c3": 211_360, "c4": 412_160}
+B_ALG = {"c2": 7_600_000, "c3": 211_360, "c4": 412_160, "c5": 62_000}
 HBM_PEAK_GBPS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
 SEED = 20260927
-SNR_DB = {"c1": 10.0, "c2": 20.0, "c3": 20.0, "c4": 25.0}
+SNR_DB = {"c1": 10.0, "c2": 20.0, "c3": 20.0, "c4": 25.0, "c5": 20.0}
 
 
 def parse():
@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="c4", choices=["c2", "c3", "c4"])
+    ap.add_argument("--config", default="c4", choices=["c2", "c3", "c4", "c5"])
     ap.add_argument("--batch", type=int, default=0, help="realizations per GPU per step")
     ap.add_argument("--demod", default="slicer", choices=["slicer", "mindist"])
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
@@ -65,6 +65,12 @@ def make_runner(eng, cfg, demod, dtype):
             eng.run_flat_fading(100000, nv, SEED, first, count, Fd=100.0, Ts=1e-3, L=8, method=method, dtype=dtype,
                                 counters=counters)
         return run, 100000, "64-QAM over flat Jakes fading (Fd 100 Hz, Ts 1 ms, L 8), 1e5 symbols, SNR 20 dB (config 2)"
+    if cfg == "c5":
+        eng.set_constellation(constellation("qam", 16), _lib.CONST_QAM)
+
+        def run(first, count, counters):
+            eng.run_ia(200, nv, SEED, first, count, method=method, dtype=dtype, counters=counters)
+        return run, 600, "K=3 2x2 closed-form interference alignment + 16-QAM, 200 symbols/stream, SNR 20 dB (config 5)"
     eng.set_constellation(constellation("qpsk", 4), _lib.CONST_GENERIC)
     from pyphysim_amd.channels import discretize_profile
     Ts = 1.0 / (15e3 * 1024)
@@ -87,6 +93,7 @@ def cpu_baseline(cfg, budget_s, gpu_first_counts):
         "c2": (chains.chain_flat_jakes, dict(mod="qam", M=64, N=100000, snr_db=20.0, Fd=100.0, Ts=1e-3, L=8)),
         "c3": (chains.chain_ofdm_tdl, dict(mod="qpsk", M=4, fft_size=1024, cp_size=16, num_used=None, n_ofdm_sym=1,
                                            snr_db=20.0, Fd=10.0, Ts=1.0 / (15e3 * 1024), L=8)),
+        "c5": (chains.chain_ia, dict(mod="qam", M=16, K=3, nr=2, nt=2, Ns=1, NSymbs=200, snr_db=20.0)),
     }[cfg]
     se = []
     t0 = time.perf_counter()
@@ -127,7 +134,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     eng = Engine(local_rank, args.dtype)
     run, units, workload = make_runner(eng, args.config, args.demod, args.dtype)
-    batch = args.batch or {"c4": 65536, "c3": 131072, "c2": 4096}[args.config]
+    batch = args.batch or {"c4": 65536, "c3": 131072, "c2": 4096, "c5": 262144}[args.config]
 
     def barrier():
         eng.sync()
@@ -182,13 +189,13 @@ def main():
             "config": {"workload": workload, "realizations_per_step_per_gpu": batch, "demod": args.demod,
                        "symbols_per_realization": units, "parallelism": "realization-sharded x%d" % world,
                        "rng": "Philox4x32-10 keyed by (seed, realization)"},
-            "ser": tot[2] / float(max(1, tot[0]) * units), "ber": tot[4] / float(max(1, tot[0]) * units * 6)
-            if args.config != "c3" else tot[4] / float(max(1, tot[0]) * units * 2),
+            "ser": tot[2] / float(max(1, tot[0]) * units),
+            "ber": tot[4] / float(max(1, tot[0]) * units * {"c2": 6, "c3": 2, "c4": 6, "c5": 4}[args.config]),
             "n_skipped": tot[1],
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": "k_run_mimo_ofdm" if args.config == "c4" else
-                         ("k_run_flat" if args.config == "c2" else "k_run_ofdm_tdl"),
+                         "kernel": {"c4": "k_run_mimo_ofdm", "c2": "k_run_flat", "c3": "k_run_ofdm_tdl",
+                                    "c5": "k_run_ia"}[args.config],
                          "kernel_ms_per_launch": per_launch_s * 1e3,
                          "algorithmic_bytes_per_realization": balg,
                          "traffic_source": "profiles/traffic_%s.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
@@ -221,6 +228,8 @@ def eng_first_counts(eng, args, n):
                                  per_realization=True)
     if args.config == "c2":
         return eng.run_flat_fading(100000, nv, SEED, 0, n, method=method, dtype=args.dtype, per_realization=True)
+    if args.config == "c5":
+        return eng.run_ia(200, nv, SEED, 0, n, method=method, dtype=args.dtype, per_realization=True)[:3]
     from pyphysim_amd.channels import discretize_profile
     Ts = 1.0 / (15e3 * 1024)
     p_lin, d_idx = discretize_profile(np.array([0.0, -3.0, -6.0, -9.0, -12.0]), np.arange(5) * Ts, Ts)

@@ -531,11 +531,11 @@ class Engine:
         cap = self.empty(count, np.float64)
         check(self.lib.mcle_run_ia(self.ctx, dt, byref(cfg), int(seed), int(first), int(count), cnt.ptr, se.ptr,
                                    be.ptr, cap.ptr))
+        if counters is not None:
+            return None
         caps = cap.get()
         sev = se.get()
         valid = sev != 0xFFFFFFFF
-        if counters is not None:
-            return caps[valid]
         res = self._counters(cnt)
         res["sum_capacity"] = float(np.sum(caps[valid]))
         res["sum_capacity_sq"] = float(np.sum(caps[valid] ** 2))
