@@ -233,14 +233,42 @@ class BatchedSimulationRunner(SimulationRunner):
     """
     COUNTER_KEYS = ("n_realizations", "n_skipped", "sym_errors", "sym_errors_sq", "bit_errors", "bit_errors_sq")
 
-    def __init__(self, batch_size=4096, process_group=None):
+    def __init__(self, batch_size=4096, process_group=None, exact_early_stop=False):
         super().__init__(read_command_line_args=False)
         self.batch_size = int(batch_size)
         self.process_group = process_group
         self.first_rep = 0
+        # True: a custom _keep_going is consulted after EVERY realization, like the reference's loop
+        # (runner.py:1491), by replaying the batch's per-realization counts on the host; the batch is
+        # cut at the realization where the rule first says stop (single rank only).
+        self.exact_early_stop = bool(exact_early_stop)
 
     def _run_batch(self, current_parameters, first_rep, count):
         raise NotImplementedError("'_run_batch' must be implemented in a subclass of BatchedSimulationRunner")
+
+    def _run_batch_detailed(self, current_parameters, first_rep, count):
+        """-> (counters, sym_err[count], bit_err[count]) with 0xFFFFFFFF marking skipped realizations;
+        needed only for exact_early_stop."""
+        raise NotImplementedError("exact_early_stop needs '_run_batch_detailed'")
+
+    def _replay(self, current_params, total, elapsed, c, se, be):
+        """Feed the batch realization by realization; returns (totals, stopped)."""
+        n_sym, n_bits = c["n_symbols"], c["n_bits"]
+        for s, b in zip(se.tolist(), be.tolist()):
+            one = self._zero_like(c)
+            if s == 0xFFFFFFFF:
+                one["n_skipped"] = 1
+            else:
+                one.update(n_realizations=1, sym_errors=s, sym_errors_sq=s * s, bit_errors=b, bit_errors_sq=b * b)
+            one["n_symbols"], one["n_bits"] = n_sym, n_bits
+            total = self._add(total, one)
+            if total["n_realizations"] >= self.rep_max:
+                return total, True
+            if s != 0xFFFFFFFF and not self._keep_going(current_params,
+                                                        self._finish_results(current_params, total, elapsed),
+                                                        total["n_realizations"]):
+                return total, True
+        return total, False
 
     def _run_simulation(self, current_parameters):
         c = self._run_batch(current_parameters, self.first_rep, 1)
@@ -315,7 +343,20 @@ class BatchedSimulationRunner(SimulationRunner):
         else:
             total, next_index, elapsed = self._zero_like(None), self.first_rep, 0.0
         batches = 0
-        while total["n_realizations"] < self.rep_max:
+        custom_stop = type(self)._keep_going is not SimulationRunner._keep_going
+        exact = self.exact_early_stop and custom_stop
+        if exact and world > 1:
+            raise RuntimeError("exact_early_stop replays realizations in index order and is single-rank only")
+        stopped = False
+        while total["n_realizations"] < self.rep_max and not stopped:
+            if exact:
+                want = min(self.batch_size, self.rep_max - total["n_realizations"])
+                tic = time.time()
+                c, se, be = self._run_batch_detailed(current_params, next_index, want)
+                elapsed += time.time() - tic
+                next_index += want
+                total, stopped = self._replay(current_params, total, elapsed, c, se, be)
+                continue
             if total["n_realizations"] > 0:
                 # the reference evaluates _keep_going before every repetition after the first
                 # (runner.py:1491); here it is evaluated before every batch after the first

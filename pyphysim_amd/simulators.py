@@ -35,8 +35,9 @@ class _LinkSimulator(BatchedSimulationRunner):
     """Common part: SNR sweep ('SNR' unpacked), modulator, seed handling, engine binding."""
 
     def __init__(self, SNR, modulator="qam", M=16, rep_max=1000, seed=0, batch_size=4096, dtype="f32",
-                 demod="auto", engine=None, common_random_numbers=False, process_group=None):
-        super().__init__(batch_size=batch_size, process_group=process_group)
+                 demod="auto", engine=None, common_random_numbers=False, process_group=None,
+                 exact_early_stop=False):
+        super().__init__(batch_size=batch_size, process_group=process_group, exact_early_stop=exact_early_stop)
         self.rep_max = rep_max
         self.seed = int(seed)
         self.dtype = dtype
@@ -71,6 +72,15 @@ class _LinkSimulator(BatchedSimulationRunner):
     def _noise_var(current_parameters):
         return 1.0 / float(dB2Linear(current_parameters["SNR"]))
 
+    def _launch(self, current_parameters, first_rep, count, per_realization):
+        raise NotImplementedError
+
+    def _run_batch(self, current_parameters, first_rep, count):
+        return self._launch(current_parameters, first_rep, count, False)
+
+    def _run_batch_detailed(self, current_parameters, first_rep, count):
+        return self._launch(current_parameters, first_rep, count, True)[:3]
+
 
 class AwgnSimulator(_LinkSimulator):
     """Config 1: apps/awgn_modulators/simulate_psk.py:51-115."""
@@ -79,11 +89,11 @@ class AwgnSimulator(_LinkSimulator):
         super().__init__(SNR, modulator, M, **kw)
         self.params.add("NSymbs", int(NSymbs))
 
-    def _run_batch(self, current_parameters, first_rep, count):
+    def _launch(self, current_parameters, first_rep, count, per_realization):
         eng = self._bind()
         return eng.run_awgn(current_parameters["NSymbs"], self._noise_var(current_parameters),
                             self._seed_for(current_parameters), first_rep, count, method=self.demod_method,
-                            dtype=self.dtype)
+                            dtype=self.dtype, per_realization=per_realization)
 
 
 class FlatFadingSimulator(_LinkSimulator):
@@ -96,12 +106,12 @@ class FlatFadingSimulator(_LinkSimulator):
                      ("rayleigh_iid", bool(rayleigh_iid))):
             self.params.add(k, v)
 
-    def _run_batch(self, current_parameters, first_rep, count):
+    def _launch(self, current_parameters, first_rep, count, per_realization):
         p = current_parameters
         eng = self._bind()
         return eng.run_flat_fading(p["NSymbs"], self._noise_var(p), self._seed_for(p), first_rep, count, Fd=p["Fd"],
                                    Ts=p["Ts"], L=p["L"], rayleigh_iid=p["rayleigh_iid"], method=self.demod_method,
-                                   dtype=self.dtype)
+                                   dtype=self.dtype, per_realization=per_realization)
 
 
 class OfdmTdlSimulator(_LinkSimulator):
@@ -122,12 +132,13 @@ class OfdmTdlSimulator(_LinkSimulator):
                      ("L", int(L))):
             self.params.add(k, v)
 
-    def _run_batch(self, current_parameters, first_rep, count):
+    def _launch(self, current_parameters, first_rep, count, per_realization):
         p = current_parameters
         eng = self._bind()
         return eng.run_ofdm_tdl(p["fft_size"], p["cp_size"], p["num_used_subcarriers"], p["num_ofdm_symbols"],
                                 self._noise_var(p), self._tap_power, self._tap_delay, self._seed_for(p), first_rep,
-                                count, Fd=p["Fd"], Ts=p["Ts"], L=p["L"], method=self.demod_method, dtype=self.dtype)
+                                count, Fd=p["Fd"], Ts=p["Ts"], L=p["L"], method=self.demod_method, dtype=self.dtype,
+                                per_realization=per_realization)
 
 
 class MimoOfdmSimulator(_LinkSimulator):
@@ -142,12 +153,13 @@ class MimoOfdmSimulator(_LinkSimulator):
                      ("num_ofdm_symbols", int(num_ofdm_symbols)), ("mmse", bool(mmse))):
             self.params.add(k, v)
 
-    def _run_batch(self, current_parameters, first_rep, count):
+    def _launch(self, current_parameters, first_rep, count, per_realization):
         p = current_parameters
         eng = self._bind()
         return eng.run_mimo_ofdm(p["Nt"], p["Nr"], p["fft_size"], p["cp_size"], p["num_used_subcarriers"],
                                  p["num_ofdm_symbols"], self._noise_var(p), self._seed_for(p), first_rep, count,
-                                 mmse=p["mmse"], method=self.demod_method, dtype=self.dtype)
+                                 mmse=p["mmse"], method=self.demod_method, dtype=self.dtype,
+                                 per_realization=per_realization)
 
 
 class IaSimulator(_LinkSimulator):

@@ -455,3 +455,36 @@ def test_mimo_tdl_mirror_classes(engine):
         channels.TdlMimoChannel(channels.JakesSampleGenerator(RS=rs, engine=engine))
     su = channels.SuMimoChannel(2, channels.JakesSampleGenerator(RS=rs, engine=engine), engine=engine)
     assert su.corrupt_data(x).shape == (2, 100) and su.num_tx_antennas == 2
+
+
+def test_large_and_degenerate_operator_inputs(engine, golden_ops):
+    rs = np.random.RandomState(17)
+    n = 1 << 22
+    engine.set_constellation(golden_ops["qam64"], _lib.CONST_QAM)
+    idx = rs.randint(0, 64, n)
+    tx = engine.modulate(idx, dtype="f32")
+    assert tx.shape == (n,) and np.array_equal(tx, golden_ops["qam64"][idx].astype(np.complex64))
+    back = engine.demodulate(tx, dtype="f32")                      # noiseless: exact recovery, 4M symbols
+    assert np.array_equal(back, idx)
+    assert np.array_equal(engine.demodulate(tx, method=_lib.DEMOD_QAM_SLICER, dtype="f32"), idx)
+    cnt, se, be = engine.count_errors(idx, np.roll(idx, 1), 6)
+    assert int(se[0]) == int(np.sum(idx != np.roll(idx, 1))) and int(be[0]) == int(omodem.count_bit_errors(idx, np.roll(idx, 1)))
+    # the largest table the operator kernels accept (setConstellation with an arbitrary point set)
+    big = (rs.randn(1024) + 1j * rs.randn(1024))
+    engine.set_constellation(big)
+    pick = rs.randint(0, 1024, 5000)
+    assert np.array_equal(engine.demodulate(engine.modulate(pick)), omodem.demodulate(big, big[pick]))
+    with pytest.raises(_lib.McleError):
+        engine.set_constellation(np.ones(3, dtype=complex))        # not a power of two
+    # many short OFDM symbols in one launch, more rows than the grid cap
+    x = rs.randn(300, 16 * 9) + 1j * rs.randn(300, 16 * 9)
+    tx = engine.ofdm_modulate(x, 16, 2, 16, batch=300)
+    assert relerr(tx[123], oofdm.modulate(x[123], 16, 2, 16)) <= 1e-13
+    assert relerr(engine.ofdm_demodulate(tx, 16, 2, 16, batch=300), x) <= 1e-12
+    # empty inputs flow through every operator
+    e = np.zeros(0, dtype=complex)
+    assert engine.awgn_add(e, e, 0.1).size == 0 and engine.cdiv(e, e).size == 0
+    assert engine.randn_c(0, 1, 2).size == 0 and engine.rand_symbols(0, 4, 1, 2).size == 0
+    # Philox positions beyond 2^32 samples stay addressable (block index = sample >> 1)
+    z = engine.randn_c(8, 3, 4, first=(1 << 32) + 10, dtype="f64")
+    assert relerr(z, P.cnormal(3, 4, 8, P.STREAM_NOISE, offset=(1 << 32) + 10)) <= 1e-13

@@ -236,3 +236,26 @@ def test_ia_pipeline(engine, dt, exact):
         assert a[k] == b[k] + c[k]
     assert 0.005 < a["sym_errors"] / (a["n_realizations"] * 600) < 0.08        # 0.023
     assert engine.run_ia(200, 0.0, SEED, 0, 2000, dtype="f32")["sym_errors"] == 0
+
+
+def test_edge_cases_and_large_indices(engine):
+    """64-bit realization indices and seeds, single realizations, odd lengths, big batches."""
+    engine.set_constellation(chains.constellation("qam", 16), _lib.CONST_QAM)
+    big_first, big_seed = (1 << 40) + 12345, 0xFEDCBA9876543210
+    want = chains.chain_awgn(chains.PhiloxRng(big_seed, big_first), "qam", 16, 1001, 9.0)
+    res, se, be = engine.run_awgn(1001, 1.0 / omodem.dB2Linear(9.0), big_seed, big_first, 1, dtype="f64",
+                                  per_realization=True)
+    assert int(se[0]) == want["symbol_errors"] and int(be[0]) == want["bit_errors"] and res["n_realizations"] == 1
+    # one symbol per realization, many realizations (more work items than the persistent grid)
+    res = engine.run_awgn(1, 0.5, SEED, 0, 300000, dtype="f32")
+    assert res["n_realizations"] == 300000 and 0 < res["sym_errors"] < 300000 and res["n_symbols"] == 1
+    assert res["sym_errors_sq"] == res["sym_errors"]                  # e_r in {0, 1}
+    # MIMO-OFDM: a single realization and a count that is not a multiple of the grid size
+    engine.set_constellation(chains.constellation("qam", 64), _lib.CONST_QAM)
+    a = engine.run_mimo_ofdm(4, 4, 1024, 16, 1024, 1, 0.01, SEED, 7, 1, dtype="f32")
+    b = engine.run_mimo_ofdm(4, 4, 1024, 16, 1024, 1, 0.01, SEED, 0, 769, dtype="f32", per_realization=True)
+    assert a["n_realizations"] == 1 and a["sym_errors"] == int(b[1][7]) and b[0]["n_realizations"] == 769
+    assert b[0]["sym_errors"] == int(b[1].astype(np.int64).sum())
+    # a rank-deficient "channel" cannot occur with Gaussian draws; zero forcing at huge SNR must not skip
+    z = engine.run_mimo_ofdm(2, 2, 64, 8, 48, 2, 0.0, SEED, 0, 5000, mmse=False, dtype="f64")
+    assert z["n_skipped"] == 0 and z["sym_errors"] == 0

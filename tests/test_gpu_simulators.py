@@ -70,3 +70,17 @@ def test_fading_ofdm_mimo_ia_simulators(engine):
     assert 0.005 < ia.results.get_result_values_list("ser")[0] < 0.08
     cap = ia.results["sum_capacity"][0]
     assert cap.num_updates == 5000 and 10.0 < cap.get_result() < 25.0 and cap.get_result_var() > 0
+
+
+def test_exact_early_stop_on_gpu(engine):
+    """The stopping rule is applied after every realization by replaying per-realization counts."""
+    class Stop(simulators.AwgnSimulator):
+        def _keep_going(self, params, results, rep):
+            return results["symbol_errors"][-1].get_result() < 3000
+    runs = []
+    for bs in (8, 1000):
+        s = Stop(SNR=[8.0], M=16, NSymbs=1000, rep_max=100000, seed=11, batch_size=bs, engine=engine,
+                 exact_early_stop=True)
+        s.simulate()
+        runs.append((s.runned_reps, s.results["symbol_errors"][0].get_result(), s.results["ser"][0].to_dict()))
+    assert runs[0] == runs[1] and 3000 <= runs[0][1] < 3000 + 1000

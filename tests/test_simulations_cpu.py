@@ -286,3 +286,29 @@ def test_reference_result_archives_interoperate(tmp_path):
     assert b"pyphysim.simulations.results\nSimulationResults" in raw and b"pyphysim_amd" not in raw
     again = compat.load_reference_results(out)
     assert again.get_result_values_list("ser") == g["ser"] and again.params == res.params
+
+
+def test_exact_early_stop_replays_every_realization():
+    """With exact_early_stop the stopping rule sees the state after EVERY realization, like the
+    reference's serial loop (runner.py:1491-1517): the result equals a batch-size-1 run."""
+    class Exact(FakeBatched):
+        def _run_batch_detailed(self, p, first, count):
+            c = fake_counters(first, count)
+            r = np.arange(first, first + count, dtype=np.uint64)
+            e = ((r * np.uint64(2654435761)) % np.uint64(97)).astype(np.int64)
+            skip = (r % np.uint64(50) == np.uint64(49))
+            se = np.where(skip, 0xFFFFFFFF, e).astype(np.uint32)
+            be = np.where(skip, 0xFFFFFFFF, 2 * e).astype(np.uint32)
+            return c, se, be
+
+        def _keep_going(self, p, res, rep):
+            return res["symbol_errors"][-1].get_result() < 5000
+    outs = []
+    for bs in (1, 37, 1000):
+        e = Exact(bs)
+        e.exact_early_stop = True
+        e.simulate()
+        outs.append(([r.to_dict() for r in e.results["ser"]], e.runned_reps))
+    assert outs[0] == outs[1] == outs[2]
+    errs = [d["value"] for d in outs[0][0]]
+    assert all(5000 <= v < 5000 + 97 for v in errs)          # stopped at the first realization crossing the rule
