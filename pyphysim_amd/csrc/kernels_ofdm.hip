@@ -15,21 +15,23 @@ __global__ __launch_bounds__(kOfdmBlock) void k_ofdm_mod(const cx<T>* __restrict
                                                          int num_used, int n_sym, T scale,
                                                          const cx<T>* __restrict__ tw, cx<T>* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    cx<T>* s = reinterpret_cast<cx<T>*>(smem);
+    cx<T>* s = reinterpret_cast<cx<T>*>(smem);   // [N] samples (bank-swizzled positions)
+    cx<T>* s_tw = s + N;                         // [N] twiddles
     const size_t row = blockIdx.y;
+    for (int k = threadIdx.x; k < N; k += kOfdmBlock) s_tw[k] = tw[k];
     for (int sym = blockIdx.x; sym < n_sym; sym += gridDim.x) {
-        for (int p = threadIdx.x; p < N; p += blockDim.x) s[p] = mk<T>(0, 0);
+        for (int p = threadIdx.x; p < N; p += kOfdmBlock) s[p] = mk<T>(0, 0);
         __syncthreads();
         const cx<T>* src = in + row * n_in + (size_t)sym * num_used;
         const size_t left = n_in > (size_t)sym * num_used ? n_in - (size_t)sym * num_used : 0;  // zero padding
-        for (int d = threadIdx.x; d < num_used; d += blockDim.x)
-            if ((size_t)d < left) s[fft_pos_of_index<N>(ofdm_bin(d, N, num_used))] = src[d];
+        for (int d = threadIdx.x; d < num_used; d += kOfdmBlock)
+            if ((size_t)d < left) s[lds_swz<true>(fft_pos_of_index<N>(ofdm_bin(d, N, num_used)))] = src[d];
         __syncthreads();
-        fft_dit<T, N, true>(s, 1, N, tw);
+        fft_dit<T, N, true, kOfdmBlock, true>(s, 1, N, s_tw);
         cx<T>* dst = out + (row * n_sym + sym) * (size_t)(N + cp);
-        for (int j = threadIdx.x; j < N + cp; j += blockDim.x) {
+        for (int j = threadIdx.x; j < N + cp; j += kOfdmBlock) {
             const int n = j < cp ? N - cp + j : j - cp;
-            dst[j] = cscale(s[n], scale);
+            dst[j] = cscale(s[lds_swz<true>(n)], scale);
         }
         __syncthreads();
     }
@@ -42,15 +44,17 @@ __global__ __launch_bounds__(kOfdmBlock) void k_ofdm_demod(const cx<T>* __restri
                                                            cx<T>* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cx<T>* s = reinterpret_cast<cx<T>*>(smem);
+    cx<T>* s_tw = s + N;
     const size_t row = blockIdx.y;
+    for (int k = threadIdx.x; k < N; k += kOfdmBlock) s_tw[k] = tw[k];
     for (int sym = blockIdx.x; sym < n_sym; sym += gridDim.x) {
         const cx<T>* src = in + (row * n_sym + sym) * (size_t)(N + cp) + cp;
-        for (int n = threadIdx.x; n < N; n += blockDim.x) s[n] = src[n];
+        for (int n = threadIdx.x; n < N; n += kOfdmBlock) s[lds_swz<true>(n)] = src[n];
         __syncthreads();
-        fft_dif<T, N, false>(s, 1, N, tw);
+        fft_dif<T, N, false, kOfdmBlock, true>(s, 1, N, s_tw);
         cx<T>* dst = out + (row * n_sym + sym) * (size_t)num_used;
-        for (int d = threadIdx.x; d < num_used; d += blockDim.x)
-            dst[d] = cscale(s[fft_pos_of_index<N>(ofdm_bin(d, N, num_used))], scale);
+        for (int d = threadIdx.x; d < num_used; d += kOfdmBlock)
+            dst[d] = cscale(s[lds_swz<true>(fft_pos_of_index<N>(ofdm_bin(d, N, num_used)))], scale);
         __syncthreads();
     }
 }
@@ -123,7 +127,9 @@ template <typename T, int N>
 int launch_mod(mcle_ctx* ctx, const void* d_in, size_t n_in, int cp, int num_used, int n_sym, double scale,
                const void* tw, void* d_out, size_t batch) {
     const unsigned gx = (unsigned)(n_sym < 4096 ? n_sym : 4096);
-    hipLaunchKernelGGL((k_ofdm_mod<T, N>), dim3(gx, (unsigned)batch), dim3(kOfdmBlock), N * sizeof(cx<T>),
+    MCLE_HIP(hipFuncSetAttribute((const void*)k_ofdm_mod<T, N>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)(2 * N * sizeof(cx<T>))));
+    hipLaunchKernelGGL((k_ofdm_mod<T, N>), dim3(gx, (unsigned)batch), dim3(kOfdmBlock), 2 * N * sizeof(cx<T>),
                        ctx->stream, (const cx<T>*)d_in, n_in, cp, num_used, n_sym, (T)scale, (const cx<T>*)tw,
                        (cx<T>*)d_out);
     MCLE_LAUNCH_CHECK();
@@ -133,7 +139,9 @@ template <typename T, int N>
 int launch_demod(mcle_ctx* ctx, const void* d_in, int cp, int num_used, int n_sym, double scale, const void* tw,
                  void* d_out, size_t batch) {
     const unsigned gx = (unsigned)(n_sym < 4096 ? n_sym : 4096);
-    hipLaunchKernelGGL((k_ofdm_demod<T, N>), dim3(gx, (unsigned)batch), dim3(kOfdmBlock), N * sizeof(cx<T>),
+    MCLE_HIP(hipFuncSetAttribute((const void*)k_ofdm_demod<T, N>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)(2 * N * sizeof(cx<T>))));
+    hipLaunchKernelGGL((k_ofdm_demod<T, N>), dim3(gx, (unsigned)batch), dim3(kOfdmBlock), 2 * N * sizeof(cx<T>),
                        ctx->stream, (const cx<T>*)d_in, cp, num_used, n_sym, (T)scale, (const cx<T>*)tw,
                        (cx<T>*)d_out);
     MCLE_LAUNCH_CHECK();

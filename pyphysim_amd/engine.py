@@ -27,7 +27,7 @@ class DeviceArray:
         self.nbytes = self.size * self.dtype.itemsize
         self._ptr = c_void_p(0)
         if self.nbytes:
-            check(engine.lib.mcle_malloc(engine.ctx, self.nbytes, byref(self._ptr)))
+            self._ptr = engine._alloc(self.nbytes)
 
     @property
     def ptr(self):
@@ -65,7 +65,7 @@ class DeviceArray:
     def __del__(self):
         try:
             if getattr(self, "_base", None) is None and self._ptr and self._ptr.value and self.engine.ctx:
-                self.engine.lib.mcle_free(self.engine.ctx, self._ptr)
+                self.engine._release(self._ptr, self.nbytes)
                 self._ptr = c_void_p(0)
         except Exception:
             pass
@@ -85,13 +85,43 @@ class Engine:
         self.device = int(device)
         self.M = 0
         self._table_key = None
+        # size-keyed free list: operator calls allocate their outputs, and hipMalloc / hipFree of large
+        # buffers cost far more than the kernels; all work is on one stream, so reuse is stream-ordered
+        self._pool, self._pool_bytes, self.pool_limit = {}, 0, 8 << 30
         n_cu, lds = c_int(0), c_int(0)
         name = ctypes.create_string_buffer(128)
         check(self.lib.mcle_ctx_device_info(self.ctx, byref(n_cu), byref(lds), name, 128))
         self.n_cu, self.device_name = n_cu.value, name.value.decode()
 
+    def _alloc(self, nbytes):
+        free = self._pool.get(nbytes)
+        if free:
+            self._pool_bytes -= nbytes
+            return free.pop()
+        ptr = c_void_p(0)
+        rc = self.lib.mcle_malloc(self.ctx, nbytes, byref(ptr))
+        if rc and self._pool_bytes:
+            self.empty_pool()
+            rc = self.lib.mcle_malloc(self.ctx, nbytes, byref(ptr))
+        check(rc)
+        return ptr
+
+    def _release(self, ptr, nbytes):
+        if self._pool_bytes + nbytes <= self.pool_limit:
+            self._pool.setdefault(nbytes, []).append(ptr)
+            self._pool_bytes += nbytes
+        else:
+            self.lib.mcle_free(self.ctx, ptr)
+
+    def empty_pool(self):
+        for free in self._pool.values():
+            for ptr in free:
+                self.lib.mcle_free(self.ctx, ptr)
+        self._pool, self._pool_bytes = {}, 0
+
     def close(self):
         if self.ctx:
+            self.empty_pool()
             self.lib.mcle_ctx_destroy(self.ctx)
             self.ctx = c_void_p(0)
 
