@@ -111,6 +111,10 @@ int mcle_awgn_add(mcle_ctx* ctx, int dtype, const void* d_x, const void* d_noise
 int mcle_jakes_generate(mcle_ctx* ctx, int dtype, const double* phi, const double* psi, int L,
                         int n_streams, double Fd, double t0, double dt, const double* tap_power,
                         void* d_h, size_t n_samples);
+/* same, at explicit sample times (block-static use of TdlChannel.corrupt_data_in_freq_domain) */
+int mcle_jakes_generate_at(mcle_ctx* ctx, int dtype, const double* phi, const double* psi, int L,
+                           int n_streams, double Fd, const double* times, const double* tap_power,
+                           void* d_h, size_t n_samples);
 /* SISO time-varying sparse convolution: y[d_i + n] += g[i, n] x[n]; y has n + max_delay */
 int mcle_tdl_apply(mcle_ctx* ctx, int dtype, const void* d_x, const void* d_taps,
                    const int32_t* delays, int n_taps, void* d_y, size_t n);
@@ -120,10 +124,14 @@ int mcle_tdl_apply_mimo(mcle_ctx* ctx, int dtype, const void* d_x, const void* d
                         const int32_t* delays, int n_taps, int nr, int nt, void* d_y, size_t n);
 /* per-OFDM-symbol mean frequency response on the used subcarriers for n_links parallel links:
  * taps [n_taps][n_links][n_sym*(fft+cp)] -> H [n_sym][num_used][n_links]
- * (TdlImpulseResponse.get_freq_response fading.py:513-536 averaged like ofdm.py:545-547) */
+ * (TdlImpulseResponse.get_freq_response fading.py:513-536 averaged like ofdm.py:545-547).
+ * num_used = -g (g >= 1): all fft_size bins in natural order, averaging groups of g samples
+ * (taps [n_taps][n_links][n_sym*g]); g = 1 is the per-block response of corrupt_data_in_freq_domain. */
 int mcle_tdl_mean_freq_response(mcle_ctx* ctx, int dtype, const void* d_taps, const int32_t* delays,
                                 int n_taps, int n_links, size_t n_sym, int fft_size, int cp_size,
                                 int num_used, void* d_H);
+/* element-wise complex product (frequency-domain channel application, fading.py:1259) */
+int mcle_cmul(mcle_ctx* ctx, int dtype, const void* d_a, const void* d_b, void* d_out, size_t n);
 /* element-wise complex divide (flat-fading equalisation y / h of the C2 template) */
 int mcle_cdiv(mcle_ctx* ctx, int dtype, const void* d_num, const void* d_den, void* d_out,
               size_t n);

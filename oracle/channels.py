@@ -94,3 +94,29 @@ def mean_freq_response(taps, delay_indexes, fft_size, cp_size, n_sym):
     fr = np.fft.fft(dense, fft_size, axis=0)                                   # [fft, ..., n]
     fr = fr.reshape(fr.shape[:-1] + (n_sym, fft_size + cp_size)).mean(axis=-1)  # [fft, ..., n_sym]
     return np.moveaxis(fr, -1, 0)                                               # [n_sym, fft, ...]
+
+
+def corrupt_data_in_freq_domain(signal, taps_per_block, delay_indexes, fft_size, carrier_indexes=None):
+    """fading.py:1126-1287: block i uses the frequency response of impulse response i (taps_per_block
+    [S, ..., n_blocks]) on `carrier_indexes` (None = all bins, natural order)."""
+    n_blocks = taps_per_block.shape[-1]
+    n_pad = int(delay_indexes[-1]) + 1
+    dense = np.zeros((n_pad,) + taps_per_block.shape[1:], dtype=complex)
+    dense[np.asarray(delay_indexes)] = taps_per_block
+    fr = np.fft.fft(dense, fft_size, axis=0)                     # [fft, ..., n_blocks]
+    pick = slice(None) if carrier_indexes is None else carrier_indexes
+    signal = np.asarray(signal)
+    if taps_per_block.ndim == 2:
+        bs = signal.size // n_blocks
+        out = np.empty(signal.size, dtype=complex)
+        for i in range(n_blocks):
+            out[i * bs:(i + 1) * bs] = fr[pick, i] * signal[i * bs:(i + 1) * bs]
+        return out
+    nr, nt = taps_per_block.shape[1:3]
+    bs = signal.shape[-1] // n_blocks
+    out = np.zeros((signal.shape[-1], nr), dtype=complex)
+    for i in range(n_blocks):
+        f = fr[pick, :, :, i]
+        for tx in range(nt):
+            out[i * bs:(i + 1) * bs, :] += f[:, :, tx] * signal[tx, i * bs:(i + 1) * bs, np.newaxis]
+    return out.T

@@ -144,6 +144,24 @@ def golden_operators():
     close(omimo.blast_decode(y, H, 0.05), mm, 1e-12, "blast mmse")
     out["blast_H"], out["blast_x"], out["blast_enc"], out["blast_y"] = H, x, enc, y
     out["blast_zf"], out["blast_mmse"], out["blast_nv"] = zf, mm, 0.05
+    # TdlChannel.corrupt_data_in_freq_domain (fading.py:1126-1287), SISO and MIMO, Jakes fading
+    rsf = np.random.RandomState(BASE_SEED + 77)
+    jk = rfg.JakesSampleGenerator(Fd=40.0, Ts=1e-5, L=8, RS=rsf)
+    td = rfading.TdlChannel(jk, tap_powers_dB=np.array([0.0, -3.0, -7.0]), tap_delays=np.array([0, 2, 5]) * 1e-5)
+    sig = rs.randn(3 * 24) + 1j * rs.randn(3 * 24)
+    car = np.r_[1:13, 20:32]
+    fo = td.corrupt_data_in_freq_domain(sig, 32, car)
+    tb = td.get_last_impulse_response().tap_values_sparse                      # [3, 3 blocks]
+    close(och.corrupt_data_in_freq_domain(sig, tb, td.channel_profile.tap_delays, 32, car), fo, 1e-13, "fd siso")
+    jm = rfg.JakesSampleGenerator(Fd=40.0, Ts=1e-5, L=8, shape=(2, 3), RS=rsf)
+    tm = rfading.TdlMimoChannel(jm, tap_powers_dB=np.array([0.0, -3.0, -7.0]), tap_delays=np.array([0, 2, 5]) * 1e-5)
+    sigm = rs.randn(3, 2 * 16) + 1j * rs.randn(3, 2 * 16)
+    fm = tm.corrupt_data_in_freq_domain(sigm, 16)
+    tbm = tm.get_last_impulse_response().tap_values_sparse                     # [3, 2, 3, 2 blocks]
+    close(och.corrupt_data_in_freq_domain(sigm, tbm, tm.channel_profile.tap_delays, 16), fm, 1e-13, "fd mimo")
+    out.update(fd_sig=sig, fd_car=car, fd_out=fo, fd_taps=tb, fd_phi=jk._phi_l, fd_psi=jk._psi_l,
+               fd_delays=td.channel_profile.tap_delays, fd_powers=td.channel_profile.tap_powers_linear,
+               fdm_sig=sigm, fdm_out=fm, fdm_taps=tbm, fdm_phi=jm._phi_l, fdm_psi=jm._psi_l)
     # Alamouti / MRT / SVD (mimo.py:666-1287)
     Ha = rmisc.randn_c(3, 2)
     ala = rmimo.Alamouti(Ha)

@@ -95,6 +95,9 @@ _PROTOS = {
     "mcle_awgn_add": (c_int, [_P, c_int, _P, _P, c_double, _P, c_size_t]),
     "mcle_jakes_generate": (c_int, [_P, c_int, POINTER(c_double), POINTER(c_double), c_int, c_int, c_double,
                                     c_double, c_double, POINTER(c_double), _P, c_size_t]),
+    "mcle_jakes_generate_at": (c_int, [_P, c_int, POINTER(c_double), POINTER(c_double), c_int, c_int, c_double,
+                                       POINTER(c_double), POINTER(c_double), _P, c_size_t]),
+    "mcle_cmul": (c_int, [_P, c_int, _P, _P, _P, c_size_t]),
     "mcle_tdl_apply": (c_int, [_P, c_int, _P, _P, POINTER(c_int32), c_int, _P, c_size_t]),
     "mcle_tdl_apply_mimo": (c_int, [_P, c_int, _P, _P, POINTER(c_int32), c_int, c_int, c_int, _P, c_size_t]),
     "mcle_tdl_mean_freq_response": (c_int, [_P, c_int, _P, POINTER(c_int32), c_int, c_int, c_size_t, c_int, c_int,

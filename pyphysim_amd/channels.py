@@ -136,6 +136,12 @@ class RayleighSampleGenerator(FadingSampleGenerator):
     def skip_samples_for_next_generation(self, num_samples):
         pass
 
+    def generate_block_samples(self, num_blocks, skip):
+        self.generate_more_samples(num_blocks)
+        self._samples = np.asarray(self._samples).reshape((tuple(self._shape) if self._shape else (1,))
+                                                          + (num_blocks,))
+        return self._samples
+
     def get_similar_fading_generator(self):
         return RayleighSampleGenerator(self._shape)
 
@@ -201,6 +207,20 @@ class JakesSampleGenerator(FadingSampleGenerator):
 
     def skip_samples_for_next_generation(self, num_samples):
         self._current_time += num_samples * self._Ts
+
+    def generate_block_samples(self, num_blocks, skip):
+        """`num_blocks` x [generate_more_samples(1); skip_samples_for_next_generation(skip)] in one launch:
+        the sample times follow the same floating-point recurrence as the two reference calls."""
+        times = np.empty(num_blocks)
+        for i in range(num_blocks):
+            times[i] = self._current_time
+            self._current_time = self._current_time + self._Ts
+            self._current_time += skip * self._Ts
+        streams = int(np.prod(self._shape)) if self._shape else 1
+        h = self.engine.jakes_generate(self._phi_l.reshape(self._L, streams), self._psi_l.reshape(self._L, streams),
+                                       self._Fd, 0.0, 0.0, num_blocks, dtype=self.dtype, times=times)
+        self._samples = h.reshape((tuple(self._shape) if self._shape else (1,)) + (num_blocks,))
+        return self._samples
 
     def get_similar_fading_generator(self):
         return JakesSampleGenerator(self._Fd, self._Ts, self._L, self._shape, engine=self._engine, dtype=self.dtype)
@@ -353,6 +373,47 @@ class TdlChannel:
         self.generate_impulse_response(signal.shape[-1])
         ir = self._last_impulse_response
         return self.engine.tdl_apply_mimo(signal, ir.tap_values_sparse, ir.tap_indexes_sparse, dtype=self.dtype)
+
+
+    def corrupt_data_in_freq_domain(self, signal, fft_size, carrier_indexes=None):
+        """fading.py:1126-1287: block-static channel applied per subcarrier -- one impulse response per
+        block of `fft_size` samples (the generator skips fft_size - 1 samples between blocks)."""
+        signal = np.asarray(signal)
+        num_symbols = signal.shape[-1]
+        if carrier_indexes is None:
+            block_size, pick = fft_size, None
+        elif isinstance(carrier_indexes, slice):
+            lo, hi, st = carrier_indexes.indices(fft_size)
+            block_size, pick = (hi - lo) // st, np.arange(fft_size)[carrier_indexes]
+        else:
+            pick = np.asarray(carrier_indexes)
+            block_size = len(pick)
+        if num_symbols % block_size != 0:
+            raise ValueError("The num of elements in `signal` must be a multiple of number of sent elements per "
+                             "`fft_size`.")
+        shp = self._fading_generator.shape
+        if len(shp) not in (1, 3):
+            raise RuntimeError("Shape of the fading generator of the TdlChannel class must have either 1 (SISO) "
+                               "or 3 (MIMO) dimensions")
+        if self._switched_direction:
+            raise NotImplementedError("switched_direction (reverse link) is not offloaded yet")
+        n_blocks = num_symbols // block_size
+        fading = np.asarray(self._fading_generator.generate_block_samples(n_blocks, fft_size - 1))
+        fading = fading.reshape(tuple(shp) + (n_blocks,))
+        amp = np.sqrt(self._channel_profile.tap_powers_linear).reshape((-1,) + (1,) * (fading.ndim - 1))
+        taps = fading * amp
+        self._last_impulse_response = TdlImpulseResponse(taps, self._channel_profile)
+        H = self.engine.tdl_mean_freq_response(taps, self._channel_profile.tap_delays, n_blocks, fft_size, 0, 0,
+                                               dtype=self.dtype, group=1)          # [blocks, fft, (nr, nt)]
+        if pick is not None:
+            H = H[:, pick]
+        if len(shp) == 1:
+            return self.engine.cmul(H.reshape(-1), signal.reshape(-1), dtype=self.dtype)
+        _, nr, nt = shp
+        if nt == 1 and signal.ndim == 1:
+            signal = signal.reshape(1, -1)
+        out = self.engine.blast_decode_per_subcarrier(H.reshape(num_symbols, nr, nt), signal, dtype=self.dtype)
+        return out.reshape(num_symbols, nr).T
 
 
 class TdlMimoChannel(TdlChannel):

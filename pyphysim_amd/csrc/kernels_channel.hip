@@ -11,14 +11,14 @@ constexpr int kChBlock = 256;
 // d_par: [2*L*n_streams] doubles = {w[l,s]} then {psi[l,s]} (see jakes.hpp for the meaning of w)
 template <typename T>
 __global__ __launch_bounds__(kChBlock) void k_jakes(const double* __restrict__ par, int L, int n_streams,
-                                                    double t0, double dt, const double* __restrict__ amp,
-                                                    cx<T>* __restrict__ h, size_t n) {
+                                                    double t0, double dt, const double* __restrict__ times,
+                                                    const double* __restrict__ amp, cx<T>* __restrict__ h, size_t n) {
     const double* w = par;
     const double* psi = par + (size_t)L * n_streams;
     for (int s = blockIdx.y; s < n_streams; s += gridDim.y) {
         const T a = (T)amp[s];
         for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-            const double t = jakes_time(t0, dt, (double)i);
+            const double t = times ? times[i] : jakes_time(t0, dt, (double)i);
             T re = 0, im = 0;
             for (int l = 0; l < L; ++l) {
                 const cx<T> e = jakes_ray<T>(w[(size_t)l * n_streams + s], psi[(size_t)l * n_streams + s], t);
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(kChBlock) void k_tdl_apply_mimo(const cx<T>* __rest
 template <typename T>
 __global__ __launch_bounds__(kChBlock) void k_mean_freq_response(const cx<T>* __restrict__ g, Delays dl, int n_taps,
                                                                  int P, size_t n_sym, int n, int cp, int num_used,
-                                                                 const cx<T>* __restrict__ tw,
+                                                                 bool natural, const cx<T>* __restrict__ tw,
                                                                  cx<T>* __restrict__ Hm) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cx<T>* s_mean = reinterpret_cast<cx<T>*>(smem);  // [n_taps][P]
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(kChBlock) void k_mean_freq_response(const cx<T>* __
         __syncthreads();
         for (size_t e = threadIdx.x; e < (size_t)num_used * P; e += blockDim.x) {
             const int d = (int)(e / P), p = (int)(e - (size_t)d * P);
-            const int k = ofdm_bin(d, n, num_used);
+            const int k = natural ? d : ofdm_bin(d, n, num_used);
             cx<T> h = mk<T>(0, 0);
             for (int i = 0; i < n_taps; ++i) h = cfma(s_mean[i * P + p], tw[(k * dl.d[i]) & (n - 1)], h);
             Hm[(sym * num_used + d) * P + p] = h;
@@ -119,8 +119,24 @@ using namespace mcle;
 
 extern "C" {
 
+static int jakes_impl(mcle_ctx* ctx, int dtype, const double* phi, const double* psi, int L, int n_streams, double Fd,
+                      double t0, double dt, const double* times, const double* tap_power, void* d_h,
+                      size_t n_samples);
+
 int mcle_jakes_generate(mcle_ctx* ctx, int dtype, const double* phi, const double* psi, int L, int n_streams,
                         double Fd, double t0, double dt, const double* tap_power, void* d_h, size_t n_samples) {
+    return jakes_impl(ctx, dtype, phi, psi, L, n_streams, Fd, t0, dt, nullptr, tap_power, d_h, n_samples);
+}
+
+int mcle_jakes_generate_at(mcle_ctx* ctx, int dtype, const double* phi, const double* psi, int L, int n_streams,
+                           double Fd, const double* times, const double* tap_power, void* d_h, size_t n_samples) {
+    MCLE_REQUIRE(times != nullptr, "null times");
+    return jakes_impl(ctx, dtype, phi, psi, L, n_streams, Fd, 0.0, 0.0, times, tap_power, d_h, n_samples);
+}
+
+static int jakes_impl(mcle_ctx* ctx, int dtype, const double* phi, const double* psi, int L, int n_streams, double Fd,
+                      double t0, double dt, const double* times, const double* tap_power, void* d_h,
+                      size_t n_samples) {
     MCLE_REQUIRE(ctx != nullptr && phi != nullptr && psi != nullptr, "null argument");
     MCLE_REQUIRE(dtype == MCLE_F32 || dtype == MCLE_F64, "dtype must be MCLE_F32 or MCLE_F64");
     MCLE_REQUIRE(L >= 1 && L <= 1024 && n_streams >= 1 && n_streams <= 65535, "bad L / n_streams");
@@ -128,7 +144,9 @@ int mcle_jakes_generate(mcle_ctx* ctx, int dtype, const double* phi, const doubl
     int rc = ctx->bind();
     if (rc) return rc;
     const size_t np = (size_t)L * n_streams;
-    std::vector<double> host(2 * np + n_streams);
+    std::vector<double> host(2 * np + n_streams + (times ? n_samples : 0));
+    if (times)
+        for (size_t i = 0; i < n_samples; ++i) host[2 * np + n_streams + i] = times[i];
     for (size_t i = 0; i < np; ++i) {
         host[i] = jakes_w(dtype, Fd, phi[i]);
         host[np + i] = jakes_psi(dtype, psi[i]);
@@ -141,14 +159,15 @@ int mcle_jakes_generate(mcle_ctx* ctx, int dtype, const double* phi, const doubl
     MCLE_HIP(hipMemcpyAsync(d_par, host.data(), host.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     MCLE_HIP(hipStreamSynchronize(ctx->stream));  // `host` goes out of scope
     const double* d_amp = (const double*)d_par + 2 * np;
+    const double* d_times = times ? d_amp + n_streams : nullptr;
     unsigned gx = (unsigned)grid_for(ctx, n_samples, kChBlock, 4);
     dim3 grid(gx, (unsigned)(n_streams < 64 ? n_streams : 64));
     if (dtype == MCLE_F32)
         hipLaunchKernelGGL(k_jakes<float>, grid, dim3(kChBlock), 0, ctx->stream, (const double*)d_par, L, n_streams,
-                           t0, dt, d_amp, (float2*)d_h, n_samples);
+                           t0, dt, d_times, d_amp, (float2*)d_h, n_samples);
     else
         hipLaunchKernelGGL(k_jakes<double>, grid, dim3(kChBlock), 0, ctx->stream, (const double*)d_par, L, n_streams,
-                           t0, dt, d_amp, (double2*)d_h, n_samples);
+                           t0, dt, d_times, d_amp, (double2*)d_h, n_samples);
     MCLE_LAUNCH_CHECK();
     return MCLE_OK;
 }
@@ -216,7 +235,16 @@ int mcle_tdl_mean_freq_response(mcle_ctx* ctx, int dtype, const void* d_taps, co
     MCLE_REQUIRE(n_taps >= 1 && n_taps <= MCLE_MAX_TAPS, "n_taps must be in [1, %d]", MCLE_MAX_TAPS);
     MCLE_REQUIRE(n_links >= 1 && n_links <= 64, "n_links must be in [1, 64]");
     MCLE_REQUIRE(fft_size >= 16 && fft_size <= 4096 && (fft_size & (fft_size - 1)) == 0, "bad fft_size %d", fft_size);
-    MCLE_REQUIRE(cp_size >= 0 && cp_size <= fft_size && num_used >= 2 && num_used <= fft_size && num_used % 2 == 0,
+    // num_used < 0: all fft_size bins in natural order with groups of -num_used samples averaged (1 = the
+    // block-static response of corrupt_data_in_freq_domain, fading.py:1126-1287)
+    const bool natural = num_used < 0;
+    if (natural) {
+        MCLE_REQUIRE(-num_used >= 1, "bad group size");
+        cp_size = -num_used - fft_size;   // kernel averages fft+cp samples per group
+        num_used = fft_size;
+    }
+    MCLE_REQUIRE(natural || (cp_size >= 0 && cp_size <= fft_size && num_used >= 2 && num_used <= fft_size &&
+                             num_used % 2 == 0),
                  "bad OFDM parameters");
     Delays dl;
     for (int i = 0; i < MCLE_MAX_TAPS; ++i) {
@@ -233,11 +261,11 @@ int mcle_tdl_mean_freq_response(mcle_ctx* ctx, int dtype, const void* d_taps, co
     const size_t lds = (size_t)n_taps * n_links * esz;
     if (dtype == MCLE_F32)
         hipLaunchKernelGGL(k_mean_freq_response<float>, dim3(grid), dim3(kChBlock), lds, ctx->stream,
-                           (const float2*)d_taps, dl, n_taps, n_links, n_sym, fft_size, cp_size, num_used,
+                           (const float2*)d_taps, dl, n_taps, n_links, n_sym, fft_size, cp_size, num_used, natural,
                            (const float2*)tw, (float2*)d_H);
     else
         hipLaunchKernelGGL(k_mean_freq_response<double>, dim3(grid), dim3(kChBlock), lds, ctx->stream,
-                           (const double2*)d_taps, dl, n_taps, n_links, n_sym, fft_size, cp_size, num_used,
+                           (const double2*)d_taps, dl, n_taps, n_links, n_sym, fft_size, cp_size, num_used, natural,
                            (const double2*)tw, (double2*)d_H);
     MCLE_LAUNCH_CHECK();
     return MCLE_OK;

@@ -166,6 +166,13 @@ __global__ __launch_bounds__(kBlock) void k_cdiv(const cx<T>* __restrict__ a, co
 }
 
 template <typename T>
+__global__ __launch_bounds__(kBlock) void k_cmul(const cx<T>* __restrict__ a, const cx<T>* __restrict__ b,
+                                                 cx<T>* __restrict__ o, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        o[i] = cmul(a[i], b[i]);
+}
+
+template <typename T>
 __global__ __launch_bounds__(kBlock) void k_randn_c(Rng rng, uint32_t stream, uint64_t first, T sigma,
                                                     cx<T>* __restrict__ out, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
@@ -351,6 +358,23 @@ int mcle_awgn_add(mcle_ctx* ctx, int dtype, const void* d_x, const void* d_noise
     else
         hipLaunchKernelGGL(k_awgn_add<double>, dim3(grid), dim3(kBlock), 0, ctx->stream, (const double2*)d_x,
                            (const double2*)d_noise, sqrt(noise_var), (double2*)d_y, n);
+    MCLE_LAUNCH_CHECK();
+    return MCLE_OK;
+}
+
+int mcle_cmul(mcle_ctx* ctx, int dtype, const void* d_a, const void* d_b, void* d_out, size_t n) {
+    MCLE_REQUIRE(ctx != nullptr, "null context");
+    MCLE_REQUIRE(dtype == MCLE_F32 || dtype == MCLE_F64, "dtype must be MCLE_F32 or MCLE_F64");
+    if (n == 0) return MCLE_OK;
+    int rc = ctx->bind();
+    if (rc) return rc;
+    const int grid = grid_for(ctx, n, kBlock);
+    if (dtype == MCLE_F32)
+        hipLaunchKernelGGL(k_cmul<float>, dim3(grid), dim3(kBlock), 0, ctx->stream, (const float2*)d_a,
+                           (const float2*)d_b, (float2*)d_out, n);
+    else
+        hipLaunchKernelGGL(k_cmul<double>, dim3(grid), dim3(kBlock), 0, ctx->stream, (const double2*)d_a,
+                           (const double2*)d_b, (double2*)d_out, n);
     MCLE_LAUNCH_CHECK();
     return MCLE_OK;
 }

@@ -266,6 +266,16 @@ class Engine:
         check(self.lib.mcle_awgn_add(self.ctx, dt, d_x.ptr, d_n.ptr, float(noise_var), out.ptr, d_x.size))
         return self._out(out, host)
 
+    def cmul(self, a, b, dtype=None):
+        dt = self._dt(dtype)
+        d_a, host = self._cin(a, dt)
+        d_b, _ = self._cin(b, dt)
+        if d_a.size != d_b.size:
+            raise ValueError("size mismatch")
+        out = self.empty(d_a.shape, _lib.np_complex(dt))
+        check(self.lib.mcle_cmul(self.ctx, dt, d_a.ptr, d_b.ptr, out.ptr, d_a.size))
+        return self._out(out, host)
+
     def cdiv(self, num, den, dtype=None):
         dt = self._dt(dtype)
         a, host = self._cin(num, dt)
@@ -277,8 +287,10 @@ class Engine:
         return self._out(out, host)
 
     # ---- a6/a9 ------------------------------------------------------------------------------
-    def jakes_generate(self, phi, psi, Fd, t0, dt_step, n_samples, tap_power=None, dtype=None, device=False):
-        """phi, psi: [L, n_streams]; returns h [n_streams, n_samples]."""
+    def jakes_generate(self, phi, psi, Fd, t0, dt_step, n_samples, tap_power=None, dtype=None, device=False,
+                       times=None):
+        """phi, psi: [L, n_streams]; returns h [n_streams, n_samples] at t0 + k*dt_step, or at the explicit
+        sample times `times` (float64 [n_samples])."""
         dt = self._dt(dtype)
         phi = np.ascontiguousarray(phi, dtype=np.float64)
         psi = np.ascontiguousarray(psi, dtype=np.float64)
@@ -289,8 +301,15 @@ class Engine:
             pw_arr = np.ascontiguousarray(tap_power, dtype=np.float64)
             pw = pw_arr.ctypes.data_as(ctypes.POINTER(c_double))
         dp = ctypes.POINTER(c_double)
-        check(self.lib.mcle_jakes_generate(self.ctx, dt, phi.ctypes.data_as(dp), psi.ctypes.data_as(dp), L, S,
-                                           float(Fd), float(t0), float(dt_step), pw, out.ptr, int(n_samples)))
+        if times is not None:
+            tt = np.ascontiguousarray(times, dtype=np.float64)
+            if tt.size != n_samples:
+                raise ValueError("times must have n_samples entries")
+            check(self.lib.mcle_jakes_generate_at(self.ctx, dt, phi.ctypes.data_as(dp), psi.ctypes.data_as(dp), L, S,
+                                                  float(Fd), tt.ctypes.data_as(dp), pw, out.ptr, int(n_samples)))
+        else:
+            check(self.lib.mcle_jakes_generate(self.ctx, dt, phi.ctypes.data_as(dp), psi.ctypes.data_as(dp), L, S,
+                                               float(Fd), float(t0), float(dt_step), pw, out.ptr, int(n_samples)))
         return out if device else out.get()
 
     def tdl_apply(self, x, taps, delays, dtype=None):
@@ -321,14 +340,18 @@ class Engine:
                                                        out.ptr, n))
         return self._out(out, host)
 
-    def tdl_mean_freq_response(self, taps, delays, n_sym, fft_size, cp_size, num_used, dtype=None):
-        """taps [S, *links, n_sym*(fft+cp)] -> H [n_sym, num_used, *links]."""
+    def tdl_mean_freq_response(self, taps, delays, n_sym, fft_size, cp_size, num_used, dtype=None, group=None):
+        """taps [S, *links, n_sym*(fft+cp)] -> H [n_sym, num_used, *links] on the used subcarriers; with
+        ``group=g`` instead: taps [S, *links, n_sym*g] -> H [n_sym, fft_size, *links], all bins in natural
+        order, each averaged over g consecutive samples (g = 1: per-sample response)."""
         dt = self._dt(dtype)
         d_g, host = self._cin(taps, dt)
         delays = np.ascontiguousarray(delays, dtype=np.int32)
         links = d_g.shape[1:-1]
         P = int(np.prod(links)) if links else 1
-        out = self.empty((n_sym, num_used) + tuple(links), _lib.np_complex(dt))
+        if group is not None:
+            num_used, cp_size = -int(group), 0
+        out = self.empty((n_sym, fft_size if group is not None else num_used) + tuple(links), _lib.np_complex(dt))
         self._raise_value(self.lib.mcle_tdl_mean_freq_response(
             self.ctx, dt, d_g.ptr, delays.ctypes.data_as(ctypes.POINTER(c_int32)), delays.size, P, n_sym, fft_size,
             cp_size, num_used, out.ptr))

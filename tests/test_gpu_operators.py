@@ -488,3 +488,34 @@ def test_large_and_degenerate_operator_inputs(engine, golden_ops):
     # Philox positions beyond 2^32 samples stay addressable (block index = sample >> 1)
     z = engine.randn_c(8, 3, 4, first=(1 << 32) + 10, dtype="f64")
     assert relerr(z, P.cnormal(3, 4, 8, P.STREAM_NOISE, offset=(1 << 32) + 10)) <= 1e-13
+
+
+def test_corrupt_data_in_freq_domain(engine, golden_ops):
+    """TdlChannel.corrupt_data_in_freq_domain (fading.py:1126-1287) through the mirror classes: the mirror
+    Jakes generator is handed the reference's phases, then block times, tap gains, per-block frequency
+    response and the per-carrier products run on the GPU."""
+    from pyphysim_amd import channels
+    g = golden_ops
+
+    def jakes_with(phi, psi, shape):
+        jk = channels.JakesSampleGenerator(Fd=40.0, Ts=1e-5, L=8, shape=shape, RS=np.random.RandomState(0),
+                                           engine=engine)
+        return jk
+
+    jk = jakes_with(g["fd_phi"], g["fd_psi"], None)
+    td = channels.TdlChannel(jk, tap_powers_dB=np.array([0.0, -3.0, -7.0]), tap_delays=np.array([0, 2, 5]) * 1e-5,
+                             engine=engine)
+    jk._phi_l, jk._psi_l = g["fd_phi"].copy(), g["fd_psi"].copy()      # the reference's draws (after the re-draw)
+    out = td.corrupt_data_in_freq_domain(g["fd_sig"], 32, g["fd_car"])
+    assert relerr(td.get_last_impulse_response().tap_values_sparse, g["fd_taps"]) <= 1e-10
+    assert relerr(out, g["fd_out"]) <= 1e-10
+    assert relerr(och.corrupt_data_in_freq_domain(g["fd_sig"], g["fd_taps"], g["fd_delays"], 32, g["fd_car"]),
+                  g["fd_out"]) <= 1e-13
+    jm = jakes_with(g["fdm_phi"], g["fdm_psi"], (2, 3))
+    tm = channels.TdlMimoChannel(jm, tap_powers_dB=np.array([0.0, -3.0, -7.0]), tap_delays=np.array([0, 2, 5]) * 1e-5,
+                                 engine=engine)
+    jm._phi_l, jm._psi_l = g["fdm_phi"].copy(), g["fdm_psi"].copy()
+    outm = tm.corrupt_data_in_freq_domain(g["fdm_sig"], 16)
+    assert outm.shape == (2, 32) and relerr(outm, g["fdm_out"]) <= 1e-10
+    with pytest.raises(ValueError):
+        td.corrupt_data_in_freq_domain(g["fd_sig"][:-1], 32, g["fd_car"])
