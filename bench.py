@@ -17,7 +17,10 @@ import os
 import sys
 import time
 
-import numpy as np
+for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):   # before NumPy loads its BLAS:
+    os.environ.setdefault(_v, "1")                                        # the CPU legs are per-core figures
+
+import numpy as np  # noqa: E402
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
@@ -41,6 +44,8 @@ def parse():
     ap.add_argument("--demod", default="slicer", choices=["slicer", "mindist"])
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg")
+    ap.add_argument("--cpu-multicore-seconds", type=float, default=6.0,
+                    help="budget of the all-cores CPU leg (0 disables it)")
     ap.add_argument("--no-cpu", action="store_true")
     return ap.parse_args()
 
@@ -111,6 +116,46 @@ def cpu_baseline(cfg, budget_s, gpu_first_counts):
     return {"value": n / dt, "unit": "realizations/s", "cores": 1, "kind": "port",
             "sample": "%d realizations of the same workload, NumPy oracle (oracle/chains.py), 1 thread, %.1f s"
                       % (n, dt)}, abs(ser_gpu - ser_cpu), n
+
+
+def _cpu_worker(job):
+    """One process of the multi-core CPU leg: `n` realizations starting at `first` (NumPy oracle)."""
+    cfg, first, n = job
+    for v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+        os.environ[v] = "1"
+    from oracle import chains
+    fn, kw = {
+        "c4": (chains.chain_mimo_ofdm, dict(mod="qam", M=64, nt=4, nr=4, fft_size=1024, cp_size=16, num_used=None,
+                                           n_ofdm_sym=1, snr_db=25.0, mmse=True)),
+        "c2": (chains.chain_flat_jakes, dict(mod="qam", M=64, N=100000, snr_db=20.0, Fd=100.0, Ts=1e-3, L=8)),
+        "c3": (chains.chain_ofdm_tdl, dict(mod="qpsk", M=4, fft_size=1024, cp_size=16, num_used=None, n_ofdm_sym=1,
+                                           snr_db=20.0, Fd=10.0, Ts=1.0 / (15e3 * 1024), L=8)),
+        "c5": (chains.chain_ia, dict(mod="qam", M=16, K=3, nr=2, nt=2, Ns=1, NSymbs=200, snr_db=20.0)),
+    }[cfg]
+    t0 = time.perf_counter()
+    err = 0
+    for r in range(first, first + n):
+        err += fn(chains.PhiloxRng(SEED, r), **kw)["symbol_errors"]
+    return n, time.perf_counter() - t0, err
+
+
+def cpu_baseline_multicore(cfg, single_core_rate, budget_s):
+    """The same oracle on every host core at once (one process per core, disjoint realization ranges),
+    sized from the single-core rate to take about `budget_s` seconds."""
+    import multiprocessing as mp
+    cores = os.cpu_count() or 1
+    workers = max(1, min(cores // 2 if cores >= 4 else cores, 64))     # one per physical core, capped
+    per = max(1, int(single_core_rate * budget_s * 0.7))
+    ctx = mp.get_context("spawn")
+    t0 = time.perf_counter()
+    with ctx.Pool(workers) as pool:
+        done = pool.map(_cpu_worker, [(cfg, (1 << 30) + w * per, per) for w in range(workers)])
+    wall = time.perf_counter() - t0
+    n = sum(d[0] for d in done)
+    busy = max(d[1] for d in done)
+    return {"value": n / busy, "unit": "realizations/s", "cores": workers, "kind": "port",
+            "sample": "%d realizations over %d processes (spawn), slowest worker %.1f s, wall %.1f s incl. start-up"
+                      % (n, workers, busy, wall)}
 
 
 def main():
@@ -213,6 +258,24 @@ def main():
             out["ser_abs_err_vs_oracle"] = ser_err
             out["ser_check_realizations"] = n_chk
             out["speedup_vs_cpu_core"] = value / cb["value"]
+            if args.cpu_multicore_seconds > 0:
+                try:
+                    mc = cpu_baseline_multicore(args.config, cb["value"], args.cpu_multicore_seconds)
+                    out["cpu_baseline_all_cores"] = mc
+                    out["speedup_vs_cpu_host"] = value / mc["value"]
+                except Exception as exc:          # never let the optional leg break the bench line
+                    out["cpu_baseline_all_cores"] = {"error": repr(exc)}
+            if args.config == "c4" and args.demod == "slicer":
+                # transparency: the same kernel with the exhaustive LDS-table demodulator
+                run_md, _, _ = make_runner(eng, "c4", "mindist", args.dtype)
+                cnt2 = eng.new_counters()
+                run_md(1 << 41, batch, cnt2)
+                eng.sync()
+                t1 = time.perf_counter()
+                for s2 in range(5):
+                    run_md((1 << 41) + (s2 + 1) * batch, batch, cnt2)
+                eng.sync()
+                out["mindist_demod_realizations_per_s"] = 5 * batch / (time.perf_counter() - t1)
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()
