@@ -71,6 +71,9 @@ int mcle_free(mcle_ctx* ctx, void* d_ptr);
 int mcle_memset(mcle_ctx* ctx, void* d_ptr, int value, size_t bytes);
 int mcle_memcpy_h2d(mcle_ctx* ctx, void* d_dst, const void* src, size_t bytes);
 int mcle_memcpy_d2h(mcle_ctx* ctx, void* dst, const void* d_src, size_t bytes); /* blocks */
+/* device-to-device strided row copy (rows of row_bytes; pitches in bytes), enqueued on the stream */
+int mcle_memcpy_2d(mcle_ctx* ctx, void* d_dst, size_t dst_pitch, const void* d_src, size_t src_pitch,
+                   size_t row_bytes, size_t rows);
 /* kernel timing on the context stream with HIP events (used by bench.py's roofline leg) */
 int mcle_timer_start(mcle_ctx* ctx);
 int mcle_timer_stop_ms(mcle_ctx* ctx, float* ms);                               /* blocks */
@@ -121,7 +124,8 @@ int mcle_tdl_apply(mcle_ctx* ctx, int dtype, const void* d_x, const void* d_taps
 /* MIMO branch of corrupt_data (fading.py:1107-1117): x [nt][n], taps [n_taps][nr][nt][n] ->
  * y [nr][n + max_delay] */
 int mcle_tdl_apply_mimo(mcle_ctx* ctx, int dtype, const void* d_x, const void* d_taps,
-                        const int32_t* delays, int n_taps, int nr, int nt, void* d_y, size_t n);
+                        const int32_t* delays, int n_taps, int nr, int nt, void* d_y, size_t n,
+                        size_t batch);
 /* per-OFDM-symbol mean frequency response on the used subcarriers for n_links parallel links:
  * taps [n_taps][n_links][n_sym*(fft+cp)] -> H [n_sym][num_used][n_links]
  * (TdlImpulseResponse.get_freq_response fading.py:513-536 averaged like ofdm.py:545-547).
@@ -129,7 +133,18 @@ int mcle_tdl_apply_mimo(mcle_ctx* ctx, int dtype, const void* d_x, const void* d
  * (taps [n_taps][n_links][n_sym*g]); g = 1 is the per-block response of corrupt_data_in_freq_domain. */
 int mcle_tdl_mean_freq_response(mcle_ctx* ctx, int dtype, const void* d_taps, const int32_t* delays,
                                 int n_taps, int n_links, size_t n_sym, int fft_size, int cp_size,
-                                int num_used, void* d_H);
+                                int num_used, void* d_H, size_t batch);
+/* batched Jakes taps with the phases drawn on-chip (PHASE stream of realization first + r, draw order of
+ * fading_generators.py:421-425): taps [count][n_streams][n]; stream_amp = sqrt(tap power / L) per stream */
+int mcle_jakes_taps_philox(mcle_ctx* ctx, int dtype, uint64_t seed, uint64_t first, uint64_t count,
+                           int L, int n_streams, double Fd, double t0, double dt,
+                           const double* stream_amp, void* d_taps, size_t n_samples);
+/* y[r][i] = x[r][i] + sqrt(noise_var) * CN(0,1) sample i of (seed, first + r, NOISE); rows of row_len */
+int mcle_awgn_philox(mcle_ctx* ctx, int dtype, const void* d_x, uint64_t seed, uint64_t first,
+                     uint64_t count, size_t row_len, double noise_var, void* d_y);
+/* d_idx[r][i] = symbol i of realization first_realization + r (DATA stream) */
+int mcle_rand_symbols_batch(mcle_ctx* ctx, uint64_t seed, uint64_t first_realization, uint64_t count,
+                            int M, int32_t* d_idx, size_t n);
 /* element-wise complex product (frequency-domain channel application, fading.py:1259) */
 int mcle_cmul(mcle_ctx* ctx, int dtype, const void* d_a, const void* d_b, void* d_out, size_t n);
 /* element-wise complex divide (flat-fading equalisation y / h of the C2 template) */
@@ -161,9 +176,9 @@ int mcle_blast_filter(mcle_ctx* ctx, int dtype, const void* d_H, int nr, int nt,
 /* est[c*nt + a] = sum_r G[a, r] Y[r, c]      (decode, :658-660) */
 int mcle_blast_decode(mcle_ctx* ctx, int dtype, const void* d_G, const void* d_Y, int nr, int nt,
                       size_t ns, void* d_est, size_t batch);
-/* one receive filter per column (per-subcarrier MMSE): G [ns][nt][nr], Y [nr][ns] -> est[c*nt + a] */
+/* one receive filter per column (per-subcarrier MMSE): G [b][ns][nt][nr], Y [b][nr][ns] -> est[b][c*nt + a] */
 int mcle_blast_decode_per_subcarrier(mcle_ctx* ctx, int dtype, const void* d_G, const void* d_Y,
-                                     int nr, int nt, size_t ns, void* d_est);
+                                     int nr, int nt, size_t ns, void* d_est, size_t batch);
 /* Y = H X  (+ sqrt(noise_var) * noise when d_noise != NULL): apps/mimo/simulate_mimo.py:96-98 */
 int mcle_mimo_channel(mcle_ctx* ctx, int dtype, const void* d_H, const void* d_X,
                       const void* d_noise, double noise_var, int nr, int nt, size_t ns, void* d_Y,

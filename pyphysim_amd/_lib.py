@@ -83,6 +83,7 @@ _PROTOS = {
     "mcle_memset": (c_int, [_P, _P, c_int, c_size_t]),
     "mcle_memcpy_h2d": (c_int, [_P, _P, _P, c_size_t]),
     "mcle_memcpy_d2h": (c_int, [_P, _P, _P, c_size_t]),
+    "mcle_memcpy_2d": (c_int, [_P, _P, c_size_t, _P, c_size_t, c_size_t, c_size_t]),
     "mcle_timer_start": (c_int, [_P]),
     "mcle_timer_stop_ms": (c_int, [_P, POINTER(c_float)]),
     "mcle_set_constellation": (c_int, [_P, POINTER(c_double), c_int, c_int]),
@@ -99,10 +100,15 @@ _PROTOS = {
                                        POINTER(c_double), POINTER(c_double), _P, c_size_t]),
     "mcle_cmul": (c_int, [_P, c_int, _P, _P, _P, c_size_t]),
     "mcle_tdl_apply": (c_int, [_P, c_int, _P, _P, POINTER(c_int32), c_int, _P, c_size_t]),
-    "mcle_tdl_apply_mimo": (c_int, [_P, c_int, _P, _P, POINTER(c_int32), c_int, c_int, c_int, _P, c_size_t]),
+    "mcle_tdl_apply_mimo": (c_int, [_P, c_int, _P, _P, POINTER(c_int32), c_int, c_int, c_int, _P, c_size_t,
+                                    c_size_t]),
     "mcle_tdl_mean_freq_response": (c_int, [_P, c_int, _P, POINTER(c_int32), c_int, c_int, c_size_t, c_int, c_int,
-                                            c_int, _P]),
-    "mcle_blast_decode_per_subcarrier": (c_int, [_P, c_int, _P, _P, c_int, c_int, c_size_t, _P]),
+                                            c_int, _P, c_size_t]),
+    "mcle_jakes_taps_philox": (c_int, [_P, c_int, c_uint64, c_uint64, c_uint64, c_int, c_int, c_double, c_double,
+                                       c_double, POINTER(c_double), _P, c_size_t]),
+    "mcle_awgn_philox": (c_int, [_P, c_int, _P, c_uint64, c_uint64, c_uint64, c_size_t, c_double, _P]),
+    "mcle_rand_symbols_batch": (c_int, [_P, c_uint64, c_uint64, c_uint64, c_int, _P, c_size_t]),
+    "mcle_blast_decode_per_subcarrier": (c_int, [_P, c_int, _P, _P, c_int, c_int, c_size_t, _P, c_size_t]),
     "mcle_cdiv": (c_int, [_P, c_int, _P, _P, _P, c_size_t]),
     "mcle_ofdm_modulate": (c_int, [_P, c_int, _P, c_size_t, c_int, c_int, c_int, _P, c_size_t]),
     "mcle_ofdm_demodulate": (c_int, [_P, c_int, _P, c_size_t, c_int, c_int, c_int, _P, c_size_t]),

@@ -231,6 +231,17 @@ int mcle_memcpy_d2h(mcle_ctx* ctx, void* dst, const void* d_src, size_t bytes) {
     return MCLE_OK;
 }
 
+int mcle_memcpy_2d(mcle_ctx* ctx, void* d_dst, size_t dst_pitch, const void* d_src, size_t src_pitch,
+                   size_t row_bytes, size_t rows) {
+    MCLE_REQUIRE(ctx != nullptr, "null context");
+    MCLE_REQUIRE(row_bytes <= dst_pitch && row_bytes <= src_pitch, "row_bytes exceeds a pitch");
+    if (row_bytes == 0 || rows == 0) return MCLE_OK;
+    MCLE_HIP(hipSetDevice(ctx->device));
+    MCLE_HIP(hipMemcpy2DAsync(d_dst, dst_pitch, d_src, src_pitch, row_bytes, rows, hipMemcpyDeviceToDevice,
+                              ctx->stream));
+    return MCLE_OK;
+}
+
 int mcle_timer_start(mcle_ctx* ctx) {
     MCLE_REQUIRE(ctx != nullptr, "null context");
     MCLE_HIP(hipSetDevice(ctx->device));

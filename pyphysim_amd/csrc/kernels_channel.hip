@@ -3,6 +3,7 @@
 // channels/fading.py:949-956 (tap = fading * sqrt(power)), :1080-1090 (SISO corrupt_data).
 #include "fft.hpp"
 #include "jakes.hpp"
+#include "philox.hpp"
 
 namespace mcle {
 
@@ -34,6 +35,60 @@ struct Delays {
     int32_t d[MCLE_MAX_TAPS];
 };
 
+// Batched Jakes taps with the phases drawn on-chip (mcle-philox-v1 PHASE stream): realization r,
+// stream s: phi[l] = 2 pi u(l*S + s), psi[l] = 2 pi u(L*S + l*S + s) -- the (L, *shape, 1) row-major
+// draw order of fading_generators.py:421-425.  taps [count][S][n]; one workgroup per (tile, s, r).
+template <typename T>
+__global__ __launch_bounds__(kChBlock) void k_jakes_philox(uint64_t seed, uint64_t first, int L, int S, double Fd,
+                                                           double t0, double dt, const double* __restrict__ amp,
+                                                           cx<T>* __restrict__ taps, size_t n) {
+    __shared__ double s_w[64], s_psi[64];
+    const int s = blockIdx.y;
+    const uint64_t rl = blockIdx.z;
+    const Rng rng(seed, first + rl);
+    if ((int)threadIdx.x < L) {
+        const double two_pi = 6.283185307179586476925286766559;
+        const double phi = two_pi * uniform_at(rng, STREAM_PHASE, (uint64_t)threadIdx.x * S + s);
+        const double psi = two_pi * uniform_at(rng, STREAM_PHASE, (uint64_t)L * S + (uint64_t)threadIdx.x * S + s);
+        if (sizeof(T) == 8) {
+            s_w[threadIdx.x] = two_pi * Fd * cos(phi);
+            s_psi[threadIdx.x] = psi;
+        } else {
+            s_w[threadIdx.x] = Fd * cos(phi);
+            s_psi[threadIdx.x] = psi / two_pi;
+        }
+    }
+    __syncthreads();
+    const T a = (T)amp[s];
+    cx<T>* out = taps + ((size_t)rl * S + s) * n;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const double t = jakes_time(t0, dt, (double)i);
+        T re = 0, im = 0;
+        for (int l = 0; l < L; ++l) {
+            const cx<T> e = jakes_ray<T>(s_w[l], s_psi[l], t);
+            re += e.x;
+            im += e.y;
+        }
+        out[i] = mk<T>(a * re, a * im);
+    }
+}
+
+// y[r][i] = x[r][i] + sigma * CN(0,1) sample i of (seed, first + r, NOISE)
+template <typename T>
+__global__ __launch_bounds__(kChBlock) void k_awgn_philox(const cx<T>* __restrict__ x, uint64_t seed, uint64_t first,
+                                                          size_t row_len, T sigma, cx<T>* __restrict__ y) {
+    const uint64_t rl = blockIdx.y;
+    const Rng rng(seed, first + rl);
+    const size_t pairs = (row_len + 1) / 2;
+    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < pairs; p += (size_t)gridDim.x * blockDim.x) {
+        cx<T> z0, z1;
+        cn_pair<T>(rng, STREAM_NOISE, (uint32_t)p, sigma, z0, z1);
+        const size_t o = rl * row_len + 2 * p;
+        y[o] = cadd(x[o], z0);
+        if (2 * p + 1 < row_len) y[o + 1] = cadd(x[o + 1], z1);
+    }
+}
+
 // y[m] = sum_i g_i[m - d_i] x[m - d_i], accumulated in tap order like the reference's `+=` loop
 template <typename T>
 __global__ __launch_bounds__(kChBlock) void k_tdl_apply(const cx<T>* __restrict__ x, const cx<T>* __restrict__ g,
@@ -59,6 +114,9 @@ template <typename T>
 __global__ __launch_bounds__(kChBlock) void k_tdl_apply_mimo(const cx<T>* __restrict__ x, const cx<T>* __restrict__ g,
                                                              Delays dl, int n_taps, int nr, int nt,
                                                              cx<T>* __restrict__ y, size_t n, size_t n_out) {
+    x += (size_t)blockIdx.z * nt * n;
+    g += (size_t)blockIdx.z * n_taps * nr * nt * n;
+    y += (size_t)blockIdx.z * nr * n_out;
     for (int r = blockIdx.y; r < nr; r += gridDim.y)
         for (size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x; m < n_out;
              m += (size_t)gridDim.x * blockDim.x) {
@@ -85,6 +143,8 @@ __global__ __launch_bounds__(kChBlock) void k_mean_freq_response(const cx<T>* __
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cx<T>* s_mean = reinterpret_cast<cx<T>*>(smem);  // [n_taps][P]
     const size_t total = n_sym * (size_t)(n + cp);
+    g += (size_t)blockIdx.y * n_taps * P * total;               // batch item
+    Hm += (size_t)blockIdx.y * n_sym * num_used * P;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
     for (size_t sym = blockIdx.x; sym < n_sym; sym += gridDim.x) {
         __syncthreads();
@@ -201,8 +261,9 @@ int mcle_tdl_apply(mcle_ctx* ctx, int dtype, const void* d_x, const void* d_taps
 }
 
 int mcle_tdl_apply_mimo(mcle_ctx* ctx, int dtype, const void* d_x, const void* d_taps, const int32_t* delays,
-                        int n_taps, int nr, int nt, void* d_y, size_t n) {
+                        int n_taps, int nr, int nt, void* d_y, size_t n, size_t batch) {
     MCLE_REQUIRE(ctx != nullptr && delays != nullptr, "null argument");
+    MCLE_REQUIRE(batch <= 65535, "batch too large (%zu > 65535)", batch);
     MCLE_REQUIRE(dtype == MCLE_F32 || dtype == MCLE_F64, "dtype must be MCLE_F32 or MCLE_F64");
     MCLE_REQUIRE(n_taps >= 1 && n_taps <= MCLE_MAX_TAPS, "n_taps must be in [1, %d]", MCLE_MAX_TAPS);
     MCLE_REQUIRE(nr >= 1 && nt >= 1 && nr <= 64 && nt <= 64, "bad antenna counts");
@@ -213,11 +274,11 @@ int mcle_tdl_apply_mimo(mcle_ctx* ctx, int dtype, const void* d_x, const void* d
         MCLE_REQUIRE(dl.d[i] >= 0, "negative tap delay");
         if (dl.d[i] > maxd) maxd = dl.d[i];
     }
-    if (n == 0) return MCLE_OK;
+    if (n == 0 || batch == 0) return MCLE_OK;
     int rc = ctx->bind();
     if (rc) return rc;
     const size_t n_out = n + (size_t)maxd;
-    dim3 grid((unsigned)grid_for(ctx, n_out, kChBlock, 4), (unsigned)nr);
+    dim3 grid((unsigned)grid_for(ctx, n_out, kChBlock, 4), (unsigned)nr, (unsigned)batch);
     if (dtype == MCLE_F32)
         hipLaunchKernelGGL(k_tdl_apply_mimo<float>, grid, dim3(kChBlock), 0, ctx->stream, (const float2*)d_x,
                            (const float2*)d_taps, dl, n_taps, nr, nt, (float2*)d_y, n, n_out);
@@ -229,8 +290,10 @@ int mcle_tdl_apply_mimo(mcle_ctx* ctx, int dtype, const void* d_x, const void* d
 }
 
 int mcle_tdl_mean_freq_response(mcle_ctx* ctx, int dtype, const void* d_taps, const int32_t* delays, int n_taps,
-                                int n_links, size_t n_sym, int fft_size, int cp_size, int num_used, void* d_H) {
+                                int n_links, size_t n_sym, int fft_size, int cp_size, int num_used, void* d_H,
+                                size_t batch) {
     MCLE_REQUIRE(ctx != nullptr && delays != nullptr, "null argument");
+    MCLE_REQUIRE(batch <= 65535, "batch too large (%zu > 65535)", batch);
     MCLE_REQUIRE(dtype == MCLE_F32 || dtype == MCLE_F64, "dtype must be MCLE_F32 or MCLE_F64");
     MCLE_REQUIRE(n_taps >= 1 && n_taps <= MCLE_MAX_TAPS, "n_taps must be in [1, %d]", MCLE_MAX_TAPS);
     MCLE_REQUIRE(n_links >= 1 && n_links <= 64, "n_links must be in [1, 64]");
@@ -251,22 +314,68 @@ int mcle_tdl_mean_freq_response(mcle_ctx* ctx, int dtype, const void* d_taps, co
         dl.d[i] = i < n_taps ? delays[i] : 0;
         MCLE_REQUIRE(dl.d[i] >= 0, "negative tap delay");
     }
-    if (n_sym == 0) return MCLE_OK;
+    if (n_sym == 0 || batch == 0) return MCLE_OK;
     int rc = ctx->bind();
     if (rc) return rc;
     void* tw = nullptr;
     if ((rc = ctx->get_twiddles(fft_size, dtype, &tw))) return rc;
-    const unsigned grid = (unsigned)(n_sym < 4096 ? n_sym : 4096);
+    const dim3 grid((unsigned)(n_sym < 4096 ? n_sym : 4096), (unsigned)batch);
     const size_t esz = dtype == MCLE_F32 ? sizeof(float2) : sizeof(double2);
     const size_t lds = (size_t)n_taps * n_links * esz;
     if (dtype == MCLE_F32)
-        hipLaunchKernelGGL(k_mean_freq_response<float>, dim3(grid), dim3(kChBlock), lds, ctx->stream,
+        hipLaunchKernelGGL(k_mean_freq_response<float>, grid, dim3(kChBlock), lds, ctx->stream,
                            (const float2*)d_taps, dl, n_taps, n_links, n_sym, fft_size, cp_size, num_used, natural,
                            (const float2*)tw, (float2*)d_H);
     else
-        hipLaunchKernelGGL(k_mean_freq_response<double>, dim3(grid), dim3(kChBlock), lds, ctx->stream,
+        hipLaunchKernelGGL(k_mean_freq_response<double>, grid, dim3(kChBlock), lds, ctx->stream,
                            (const double2*)d_taps, dl, n_taps, n_links, n_sym, fft_size, cp_size, num_used, natural,
                            (const double2*)tw, (double2*)d_H);
+    MCLE_LAUNCH_CHECK();
+    return MCLE_OK;
+}
+
+int mcle_jakes_taps_philox(mcle_ctx* ctx, int dtype, uint64_t seed, uint64_t first, uint64_t count, int L,
+                           int n_streams, double Fd, double t0, double dt, const double* stream_amp, void* d_taps,
+                           size_t n_samples) {
+    MCLE_REQUIRE(ctx != nullptr && stream_amp != nullptr, "null argument");
+    MCLE_REQUIRE(dtype == MCLE_F32 || dtype == MCLE_F64, "dtype must be MCLE_F32 or MCLE_F64");
+    MCLE_REQUIRE(L >= 1 && L <= 64, "L must be in [1, 64]");
+    MCLE_REQUIRE(n_streams >= 1 && n_streams <= 65535 && count <= 65535, "n_streams / count out of range");
+    if (n_samples == 0 || count == 0) return MCLE_OK;
+    int rc = ctx->bind();
+    if (rc) return rc;
+    void* d_amp = nullptr;
+    if ((rc = ctx->scratch(n_streams * sizeof(double), &d_amp))) return rc;
+    MCLE_HIP(hipMemcpyAsync(d_amp, stream_amp, n_streams * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    MCLE_HIP(hipStreamSynchronize(ctx->stream));
+    dim3 grid((unsigned)grid_for(ctx, n_samples, kChBlock, 1), (unsigned)n_streams, (unsigned)count);
+    if (grid.x > 64) grid.x = 64;
+    if (dtype == MCLE_F32)
+        hipLaunchKernelGGL(k_jakes_philox<float>, grid, dim3(kChBlock), 0, ctx->stream, seed, first, L, n_streams, Fd,
+                           t0, dt, (const double*)d_amp, (float2*)d_taps, n_samples);
+    else
+        hipLaunchKernelGGL(k_jakes_philox<double>, grid, dim3(kChBlock), 0, ctx->stream, seed, first, L, n_streams, Fd,
+                           t0, dt, (const double*)d_amp, (double2*)d_taps, n_samples);
+    MCLE_LAUNCH_CHECK();
+    return MCLE_OK;
+}
+
+int mcle_awgn_philox(mcle_ctx* ctx, int dtype, const void* d_x, uint64_t seed, uint64_t first, uint64_t count,
+                     size_t row_len, double noise_var, void* d_y) {
+    MCLE_REQUIRE(ctx != nullptr, "null context");
+    MCLE_REQUIRE(dtype == MCLE_F32 || dtype == MCLE_F64, "dtype must be MCLE_F32 or MCLE_F64");
+    MCLE_REQUIRE(noise_var >= 0.0, "noise variance must be non-negative");
+    MCLE_REQUIRE(count <= 65535, "at most 65535 realizations per call");
+    if (row_len == 0 || count == 0) return MCLE_OK;
+    int rc = ctx->bind();
+    if (rc) return rc;
+    dim3 grid((unsigned)grid_for(ctx, (row_len + 1) / 2, kChBlock, 2), (unsigned)count);
+    if (dtype == MCLE_F32)
+        hipLaunchKernelGGL(k_awgn_philox<float>, grid, dim3(kChBlock), 0, ctx->stream, (const float2*)d_x, seed, first,
+                           row_len, (float)std::sqrt(noise_var), (float2*)d_y);
+    else
+        hipLaunchKernelGGL(k_awgn_philox<double>, grid, dim3(kChBlock), 0, ctx->stream, (const double2*)d_x, seed,
+                           first, row_len, std::sqrt(noise_var), (double2*)d_y);
     MCLE_LAUNCH_CHECK();
     return MCLE_OK;
 }

@@ -63,6 +63,9 @@ template <typename T>
 __global__ __launch_bounds__(kMimoBlock) void k_blast_decode_persc(const cx<T>* __restrict__ G,
                                                                    const cx<T>* __restrict__ Y, int nr, int nt,
                                                                    size_t ns, cx<T>* __restrict__ est) {
+    G += (size_t)blockIdx.y * ns * nt * nr;    // batch item: G [b][ns][nt][nr], Y [b][nr][ns], est [b][ns*nt]
+    Y += (size_t)blockIdx.y * nr * ns;
+    est += (size_t)blockIdx.y * ns * nt;
     for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < ns; c += (size_t)gridDim.x * blockDim.x) {
         const cx<T>* Gc = G + c * (size_t)nt * nr;
         for (int a = 0; a < nt; ++a) {
@@ -608,12 +611,13 @@ int mcle_svd_filters(mcle_ctx* ctx, int dtype, const void* d_H, int n_ant, void*
 }
 
 int mcle_blast_decode_per_subcarrier(mcle_ctx* ctx, int dtype, const void* d_G, const void* d_Y, int nr, int nt,
-                                     size_t ns, void* d_est) {
+                                     size_t ns, void* d_est, size_t batch) {
     int rc = check_mimo(ctx, dtype, nr, nt, 1);
     if (rc) return rc;
-    if (ns == 0) return MCLE_OK;
+    MCLE_REQUIRE(batch <= 65535, "batch too large (%zu > 65535)", batch);
+    if (ns == 0 || batch == 0) return MCLE_OK;
     if ((rc = ctx->bind())) return rc;
-    const dim3 grid(grid_for(ctx, ns, kMimoBlock, 4));
+    const dim3 grid(grid_for(ctx, ns, kMimoBlock, 4), (unsigned)batch);
     if (dtype == MCLE_F32)
         hipLaunchKernelGGL(k_blast_decode_persc<float>, grid, dim3(kMimoBlock), 0, ctx->stream, (const float2*)d_G,
                            (const float2*)d_Y, nr, nt, ns, (float2*)d_est);

@@ -185,6 +185,15 @@ __global__ __launch_bounds__(kBlock) void k_rand_symbols(Rng rng, uint64_t first
         out[i] = (int32_t)symbol_at(rng, first + i, mask);
 }
 
+// out[r][i] = symbol i of realization first_real + r
+__global__ __launch_bounds__(kBlock) void k_rand_symbols_batch(uint64_t seed, uint64_t first_real, uint32_t mask,
+                                                               int32_t* __restrict__ out, size_t n) {
+    const Rng rng(seed, first_real + blockIdx.y);
+    int32_t* row = out + (size_t)blockIdx.y * n;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        row[i] = (int32_t)symbol_at(rng, i, mask);
+}
+
 int check_modem(const mcle_ctx* ctx, int dtype, int method) {
     MCLE_REQUIRE(ctx != nullptr, "null context");
     MCLE_REQUIRE(ctx->M > 0, "no constellation set (mcle_set_constellation)");
@@ -339,6 +348,21 @@ int mcle_rand_symbols(mcle_ctx* ctx, uint64_t seed, uint64_t realization, uint64
     if (rc) return rc;
     hipLaunchKernelGGL(k_rand_symbols, dim3(grid_for(ctx, n, kBlock)), dim3(kBlock), 0, ctx->stream,
                        Rng(seed, realization), first_symbol, (uint32_t)(M - 1), d_idx, n);
+    MCLE_LAUNCH_CHECK();
+    return MCLE_OK;
+}
+
+int mcle_rand_symbols_batch(mcle_ctx* ctx, uint64_t seed, uint64_t first_realization, uint64_t count, int M,
+                            int32_t* d_idx, size_t n) {
+    MCLE_REQUIRE(ctx != nullptr, "null context");
+    MCLE_REQUIRE(M >= 2 && M <= 256 && (M & (M - 1)) == 0, "M must be a power of two in [2, 256]");
+    MCLE_REQUIRE(count <= 65535, "at most 65535 realizations per call");
+    if (n == 0 || count == 0) return MCLE_OK;
+    int rc = ctx->bind();
+    if (rc) return rc;
+    dim3 grid((unsigned)grid_for(ctx, n, kBlock, 2), (unsigned)count);
+    hipLaunchKernelGGL(k_rand_symbols_batch, grid, dim3(kBlock), 0, ctx->stream, seed, first_realization,
+                       (uint32_t)(M - 1), d_idx, n);
     MCLE_LAUNCH_CHECK();
     return MCLE_OK;
 }

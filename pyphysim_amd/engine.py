@@ -37,7 +37,17 @@ class DeviceArray:
         shape = shape[0] if len(shape) == 1 and isinstance(shape[0], (tuple, list)) else shape
         view = DeviceArray.__new__(DeviceArray)
         view.engine, view.dtype, view.size, view.nbytes = self.engine, self.dtype, self.size, self.nbytes
-        view.shape = tuple(np.empty(self.shape, dtype=np.bool_).reshape(shape).shape)
+        shape = [int(v) for v in shape]
+        if shape.count(-1) > 1:
+            raise ValueError("can only specify one unknown dimension")
+        if -1 in shape:
+            known = int(np.prod([v for v in shape if v != -1])) if len(shape) > 1 else 1
+            if known == 0 or self.size % known:
+                raise ValueError("cannot reshape array of size %d into shape %s" % (self.size, tuple(shape)))
+            shape[shape.index(-1)] = self.size // known
+        if int(np.prod(shape)) != self.size:
+            raise ValueError("cannot reshape array of size %d into shape %s" % (self.size, tuple(shape)))
+        view.shape = tuple(shape)
         view._ptr, view._base = self._ptr, self
         return view
 
@@ -331,41 +341,85 @@ class Engine:
         d_x, host = self._cin(x, dt)
         d_g, _ = self._cin(taps, dt)
         delays = np.ascontiguousarray(delays, dtype=np.int32)
-        S, nr, nt, n = d_g.shape
-        if d_x.shape != (nt, n) or S != delays.size:
+        batched = len(d_g.shape) == 5            # [batch, S, nr, nt, n] with x [batch, nt, n]
+        b = d_g.shape[0] if batched else 1
+        S, nr, nt, n = d_g.shape[-4:]
+        if tuple(d_x.shape[-2:]) != (nt, n) or S != delays.size or d_x.size != b * nt * n:
             raise ValueError("x must be [nt, n] and taps [n_taps, nr, nt, n]")
-        out = self.empty((nr, n + int(delays.max())), _lib.np_complex(dt))
+        shape = (nr, n + int(delays.max()))
+        out = self.empty(((b,) + shape) if batched else shape, _lib.np_complex(dt))
         self._raise_value(self.lib.mcle_tdl_apply_mimo(self.ctx, dt, d_x.ptr, d_g.ptr,
                                                        delays.ctypes.data_as(ctypes.POINTER(c_int32)), S, nr, nt,
-                                                       out.ptr, n))
+                                                       out.ptr, n, b))
         return self._out(out, host)
 
-    def tdl_mean_freq_response(self, taps, delays, n_sym, fft_size, cp_size, num_used, dtype=None, group=None):
+    def tdl_mean_freq_response(self, taps, delays, n_sym, fft_size, cp_size, num_used, dtype=None, group=None,
+                               batch=None):
         """taps [S, *links, n_sym*(fft+cp)] -> H [n_sym, num_used, *links] on the used subcarriers; with
         ``group=g`` instead: taps [S, *links, n_sym*g] -> H [n_sym, fft_size, *links], all bins in natural
         order, each averaged over g consecutive samples (g = 1: per-sample response)."""
         dt = self._dt(dtype)
         d_g, host = self._cin(taps, dt)
         delays = np.ascontiguousarray(delays, dtype=np.int32)
-        links = d_g.shape[1:-1]
+        links = d_g.shape[1:-1] if batch is None else d_g.shape[2:-1]   # batch: taps [batch, S, *links, n]
         P = int(np.prod(links)) if links else 1
         if group is not None:
             num_used, cp_size = -int(group), 0
-        out = self.empty((n_sym, fft_size if group is not None else num_used) + tuple(links), _lib.np_complex(dt))
+        shape = (n_sym, fft_size if group is not None else num_used) + tuple(links)
+        out = self.empty(shape if batch is None else (batch,) + shape, _lib.np_complex(dt))
         self._raise_value(self.lib.mcle_tdl_mean_freq_response(
             self.ctx, dt, d_g.ptr, delays.ctypes.data_as(ctypes.POINTER(c_int32)), delays.size, P, n_sym, fft_size,
-            cp_size, num_used, out.ptr))
+            cp_size, num_used, out.ptr, 1 if batch is None else int(batch)))
         return self._out(out, host)
 
+    def jakes_taps_philox(self, seed, first, count, L, Fd, t0, dt_step, stream_amp, n_samples, dtype=None):
+        """Device-resident Jakes taps [count, n_streams, n_samples] with the phases of realization first + r
+        drawn on-chip (PHASE stream); stream_amp[s] = sqrt(tap power / L)."""
+        dt = self._dt(dtype)
+        amp = np.ascontiguousarray(stream_amp, dtype=np.float64)
+        out = self.empty((count, amp.size, n_samples), _lib.np_complex(dt))
+        self._raise_value(self.lib.mcle_jakes_taps_philox(
+            self.ctx, dt, int(seed), int(first), int(count), int(L), amp.size, float(Fd), float(t0), float(dt_step),
+            amp.ctypes.data_as(ctypes.POINTER(c_double)), out.ptr, int(n_samples)))
+        return out
+
+    def awgn_philox(self, x, seed, first, count, noise_var, dtype=None):
+        """x [count, ...] (device or host) + sqrt(noise_var) * CN(0,1) of (seed, first + r, NOISE), row-major."""
+        dt = self._dt(dtype)
+        d_x, host = self._cin(x, dt)
+        out = self.empty(d_x.shape, _lib.np_complex(dt))
+        self._raise_value(self.lib.mcle_awgn_philox(self.ctx, dt, d_x.ptr, int(seed), int(first), int(count),
+                                                    d_x.size // max(int(count), 1), float(noise_var), out.ptr))
+        return self._out(out, host)
+
+    def rand_symbols_batch(self, n, M, seed, first, count):
+        """Device int32 [count, n]: symbol i of realization first + r."""
+        out = self.empty((count, n), np.int32)
+        self._raise_value(self.lib.mcle_rand_symbols_batch(self.ctx, int(seed), int(first), int(count), int(M),
+                                                           out.ptr, int(n)))
+        return out
+
+    def slice_rows(self, x, row_len):
+        """Device copy of x[..., :row_len] (x contiguous [..., n])."""
+        n = x.shape[-1]
+        rows = x.size // n
+        out = self.empty(tuple(x.shape[:-1]) + (row_len,), x.dtype)
+        isz = np.dtype(x.dtype).itemsize
+        check(self.lib.mcle_memcpy_2d(self.ctx, out.ptr, row_len * isz, x.ptr, n * isz, row_len * isz, rows))
+        return out
+
     def blast_decode_per_subcarrier(self, G, Y, dtype=None):
-        """G [ns, nt, nr], Y [nr, ns] -> est [ns*nt] with est[c*nt + a]."""
+        """G [ns, nt, nr], Y [nr, ns] -> est [ns*nt] with est[c*nt + a]; or batched G [b, ns, nt, nr],
+        Y [b, nr, ns] -> est [b, ns*nt]."""
         dt = self._dt(dtype)
         d_G, _ = self._cin(G, dt)
         d_Y, host = self._cin(Y, dt)
-        ns, nt, nr = d_G.shape
-        out = self.empty(ns * nt, _lib.np_complex(dt))
+        batched = len(d_G.shape) == 4
+        ns, nt, nr = d_G.shape[-3:]
+        b = d_G.shape[0] if batched else 1
+        out = self.empty((b, ns * nt) if batched else ns * nt, _lib.np_complex(dt))
         self._raise_value(self.lib.mcle_blast_decode_per_subcarrier(self.ctx, dt, d_G.ptr, d_Y.ptr, nr, nt, ns,
-                                                                    out.ptr))
+                                                                    out.ptr, b))
         return self._out(out, host)
 
     # ---- a10/a11 ----------------------------------------------------------------------------

@@ -162,6 +162,67 @@ class MimoOfdmSimulator(_LinkSimulator):
                                  per_realization=per_realization)
 
 
+class MimoOfdmTdlSimulator(_LinkSimulator):
+    """spatial multiplexing over a frequency-selective MIMO TDL channel
+    (TdlMimoChannel fading.py:1290-1333, MIMO branch of corrupt_data :1107-1117), per-antenna OFDM and one
+    MMSE/ZF receive filter per used subcarrier from the per-symbol mean frequency response (:513-536).
+
+    Unlike configs 1-5 this chain is STAGED: a batch of realizations flows through the batched operator
+    kernels with every intermediate resident in HBM (symbols -> modulate -> Blast -> OFDM -> Jakes taps ->
+    TDL -> AWGN -> OFDM^-1 -> mean response -> filters -> decode -> demod+count); nothing but the counters
+    returns to the host.  Draw layout: the mcle-philox-v1 streams of realization r (DATA symbols, PHASE
+    (L, S, Nr, Nt) phi then psi, NOISE [Nr, n + max delay])."""
+
+    def __init__(self, SNR, modulator="qam", M=16, Nt=2, Nr=2, fft_size=64, cp_size=16, num_used_subcarriers=None,
+                 num_ofdm_symbols=2, Fd=50.0, Ts=1e-6, L=8, tap_powers_dB=(0.0, -4.0, -9.0), tap_delays=None,
+                 mmse=True, **kw):
+        kw.setdefault("batch_size", 256)
+        super().__init__(SNR, modulator, M, **kw)
+        if tap_delays is None:
+            tap_delays = np.asarray((0, 2, 5)[:len(tap_powers_dB)], dtype=float) * Ts
+        self._tap_power, self._tap_delay = discretize_profile(np.asarray(tap_powers_dB, dtype=float),
+                                                               np.asarray(tap_delays, dtype=float), Ts)
+        for k, v in (("Nt", int(Nt)), ("Nr", int(Nr)), ("fft_size", int(fft_size)), ("cp_size", int(cp_size)),
+                     ("num_used_subcarriers", int(num_used_subcarriers or fft_size)),
+                     ("num_ofdm_symbols", int(num_ofdm_symbols)), ("Fd", float(Fd)), ("Ts", float(Ts)),
+                     ("L", int(L)), ("mmse", bool(mmse))):
+            self.params.add(k, v)
+
+    def _launch(self, current_parameters, first_rep, count, per_realization):
+        p = current_parameters
+        eng = self._bind()
+        dt = self.dtype
+        nt, nr, fft, cp, used = p["Nt"], p["Nr"], p["fft_size"], p["cp_size"], p["num_used_subcarriers"]
+        n_sym, L, Ts = p["num_ofdm_symbols"], p["L"], p["Ts"]
+        noise_var, seed = self._noise_var(p), self._seed_for(p)
+        ns = used * n_sym                      # data symbols per antenna
+        n = n_sym * (fft + cp)                 # time samples per antenna
+        delays = np.asarray(self._tap_delay, dtype=np.int32)
+        S = delays.size
+        if count == 0:
+            c = eng.read_counters(eng.new_counters())
+            return (c, None, None) if per_realization else c
+        idx = eng.rand_symbols_batch(nt * ns, self.modulator.M, seed, first_rep, count)
+        X = eng.blast_encode(eng.modulate(idx, dtype=dt), nt, batch=count, dtype=dt)           # [count, nt, ns]
+        T = eng.ofdm_modulate(X, fft, cp, used, batch=count * nt, dtype=dt).reshape(count, nt, n)
+        # Jakes time axis of a fresh generator (fading_generators.py:459-467): t_k = Ts + k*delta
+        step = Ts * 1.0000000001
+        delta = float(np.float64(Ts + step) - np.float64(Ts))
+        amp = np.repeat(np.sqrt(np.asarray(self._tap_power, dtype=float)), nr * nt) * np.sqrt(1.0 / L)
+        taps = eng.jakes_taps_philox(seed, first_rep, count, L, p["Fd"], Ts, delta, amp, n, dtype=dt)
+        taps5 = taps.reshape(count, S, nr, nt, n)
+        faded = eng.tdl_apply_mimo(T, taps5, delays, dtype=dt)                                  # [count, nr, n+dmax]
+        R = eng.awgn_philox(faded, seed, first_rep, count, noise_var, dtype=dt)
+        Rn = eng.slice_rows(R, n) if R.shape[-1] != n else R
+        Y = eng.ofdm_demodulate(Rn, fft, cp, used, batch=count * nr, dtype=dt).reshape(count, nr, ns)
+        Hm = eng.tdl_mean_freq_response(taps5, delays, n_sym, fft, cp, used, dtype=dt, batch=count)
+        G, skipped = eng.blast_filter(Hm.reshape(count * ns, nr, nt), noise_var if p["mmse"] else 0.0, dtype=dt)
+        est = eng.blast_decode_per_subcarrier(G.reshape(count, ns, nt, nr), Y, dtype=dt)        # [count, ns*nt]
+        c, se, be = eng.demod_count(est, idx, n_real=count, method=self.demod_method, dtype=dt)
+        c["n_skipped"] = int(np.count_nonzero(skipped))
+        return (c, se, be) if per_realization else c
+
+
 class IaSimulator(_LinkSimulator):
     """Config 5: apps/ia/simulate_ia.py:94-245 with ClosedFormIASolver(use_best_init=True) on a
     3-user 2x2 interference channel, one stream per user.  Adds the 'sum_capacity' RATIO(x, 1)

@@ -1,8 +1,11 @@
 """GPU: the ready-made simulators (BatchedSimulationRunner + fused pipelines) end to end through the
 kept SimulationRunner / SimulationResults surface."""
+import math
+
 import numpy as np
 import pytest
 
+from helpers import relerr
 from oracle import chains
 from pyphysim_amd import simulators
 from pyphysim_amd.modulators import QAM
@@ -84,3 +87,82 @@ def test_exact_early_stop_on_gpu(engine):
         s.simulate()
         runs.append((s.runned_reps, s.results["symbol_errors"][0].get_result(), s.results["ser"][0].to_dict()))
     assert runs[0] == runs[1] and 3000 <= runs[0][1] < 3000 + 1000
+
+
+# ---- SURVEY 8(f).1 as a staged device-resident simulator -------------------------------------------------
+F1_KW = dict(mod="qam", M=16, nt=2, nr=2, fft_size=64, cp_size=16, num_used=52, n_ofdm_sym=2, snr_db=14.0,
+             Fd=50.0, Ts=1e-6, L=8, tap_powers_dB=(0.0, -4.0, -9.0), tap_delays_samples=(0, 2, 5))
+
+
+def _f1_sim(dtype, **over):
+    from pyphysim_amd.simulators import MimoOfdmTdlSimulator
+    kw = dict(F1_KW, **over)
+    return MimoOfdmTdlSimulator(
+        SNR=[kw["snr_db"]], modulator=kw["mod"], M=kw["M"], Nt=kw["nt"], Nr=kw["nr"], fft_size=kw["fft_size"],
+        cp_size=kw["cp_size"], num_used_subcarriers=kw["num_used"], num_ofdm_symbols=kw["n_ofdm_sym"], Fd=kw["Fd"],
+        Ts=kw["Ts"], L=kw["L"], tap_powers_dB=kw["tap_powers_dB"],
+        tap_delays=np.asarray(kw["tap_delays_samples"], dtype=float) * kw["Ts"], seed=77,
+        common_random_numbers=True, dtype=dtype, demod="mindist", rep_max=8, batch_size=8)
+
+
+@pytest.mark.parametrize("over", [dict(), dict(nt=4, nr=4, fft_size=256, num_used=200, n_ofdm_sym=1, M=64, snr_db=24.0),
+                                  dict(nt=2, nr=3, num_used=None, tap_powers_dB=(0.0,), tap_delays_samples=(0,))])
+def test_mimo_ofdm_tdl_staged_matches_oracle(over):
+    """Every realization of the staged HBM-resident chain against the oracle chain on the same Philox draws:
+    f64 counts are equal, f32 within a handful of near-tie decisions."""
+    from oracle import chains
+    kw = dict(F1_KW, **over)
+    want_se, want_be = [], []
+    for r in range(8):
+        o = chains.chain_mimo_ofdm_tdl(chains.PhiloxRng(77, r), **kw)
+        want_se.append(o["symbol_errors"])
+        want_be.append(o["bit_errors"])
+    sim = _f1_sim("f64", **over)
+    p = next(iter(sim.params.get_unpacked_params_list()))
+    c, se, be = sim._run_batch_detailed(p, 0, 8)
+    assert np.array_equal(se, want_se) and np.array_equal(be, want_be)
+    assert c["sym_errors"] == sum(want_se) and c["bit_errors"] == sum(want_be)
+    assert c["sym_errors_sq"] == sum(v * v for v in want_se)
+    assert c["n_symbols"] == o["num_symbols"] and c["n_realizations"] == 8
+    # split batches address the same realizations
+    c2, se2, _ = sim._run_batch_detailed(p, 3, 4)
+    assert np.array_equal(se2, want_se[3:7])
+    sim32 = _f1_sim("f32", **over)
+    c32, se32, _ = sim32._run_batch_detailed(p, 0, 8)
+    assert abs(int(c32["sym_errors"]) - sum(want_se)) <= 6
+    assert np.abs(se32.astype(int) - np.asarray(want_se)).max() <= 3
+
+
+def test_mimo_ofdm_tdl_simulator_runs_sweep():
+    from pyphysim_amd.simulators import MimoOfdmTdlSimulator
+    sim = MimoOfdmTdlSimulator(SNR=[5.0, 25.0], M=16, Nt=2, Nr=2, fft_size=64, cp_size=16, num_ofdm_symbols=2,
+                               rep_max=512, batch_size=256, seed=5)
+    sim.simulate()
+    ser = sim.results.get_result_values_list("ser")
+    assert ser[0] > ser[1] > 0 or ser[1] == 0
+    assert sim.results.get_result_values_list("ser")[0] < 0.7
+
+
+def test_batched_philox_operators(engine):
+    """jakes_taps_philox / awgn_philox / rand_symbols_batch against the oracle draws."""
+    from oracle import chains, philox
+    from oracle import channels as och
+    seed, first, count, L, S, n = 31, 5, 3, 8, 6, 200
+    amp = np.linspace(0.3, 1.0, S)
+    Ts, Fd = 1e-5, 120.0
+    t, _ = och.jakes_time_axis(Ts, Ts, n)
+    for dt, tol in (("f64", 1e-10), ("f32", 3e-5)):
+        taps = engine.jakes_taps_philox(seed, first, count, L, Fd, Ts, float(t[1] - t[0]), amp, n, dtype=dt).get()
+        for r in range(count):
+            rng = chains.PhiloxRng(seed, first + r)
+            phi, psi = chains._jakes_phases(rng, L, (S,))
+            want = och.jakes_samples(phi, psi, Fd, t) * math.sqrt(L) * amp[:, None]
+            assert relerr(taps[r], want) <= tol
+        x = (np.arange(count * 7 * 11).reshape(count, 7, 11) * (0.5 - 0.25j)).astype(complex)
+        y = engine.awgn_philox(x, seed, first, count, 0.37, dtype=dt)
+        for r in range(count):
+            z = philox.cnormal(seed, first + r, 77, philox.STREAM_NOISE).reshape(7, 11)
+            assert relerr(y[r], x[r] + math.sqrt(0.37) * z) <= (1e-12 if dt == "f64" else 1e-5)
+    idx = engine.rand_symbols_batch(1001, 64, seed, first, count).get()
+    for r in range(count):
+        assert np.array_equal(idx[r], philox.symbols(seed, first + r, 1001, 64))
