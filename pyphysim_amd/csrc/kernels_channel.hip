@@ -37,39 +37,75 @@ struct Delays {
 
 // Batched Jakes taps with the phases drawn on-chip (mcle-philox-v1 PHASE stream): realization r,
 // stream s: phi[l] = 2 pi u(l*S + s), psi[l] = 2 pi u(L*S + l*S + s) -- the (L, *shape, 1) row-major
-// draw order of fading_generators.py:421-425.  taps [count][S][n]; one workgroup per (tile, s, r).
+// draw order of fading_generators.py:421-425.  taps [count][S][n].  One workgroup per (block of `sb`
+// streams, realization): sb*L threads set the rays up in parallel (f64 cos / sincos, the expensive part),
+// then all threads sweep the sb rows.
 template <typename T>
-__global__ __launch_bounds__(kChBlock) void k_jakes_philox(uint64_t seed, uint64_t first, int L, int S, double Fd,
-                                                           double t0, double dt, const double* __restrict__ amp,
-                                                           cx<T>* __restrict__ taps, size_t n) {
-    __shared__ double s_w[64], s_psi[64];
-    const int s = blockIdx.y;
+__global__ __launch_bounds__(kChBlock) void k_jakes_philox(uint64_t seed, uint64_t first, int L, int S, int sb,
+                                                           double Fd, double t0, double dt,
+                                                           const double* __restrict__ amp, cx<T>* __restrict__ taps,
+                                                           size_t n) {
+    __shared__ double s_w[kChBlock], s_psi[kChBlock];
+    __shared__ float2 s_rot[kChBlock];
+    const int s0 = blockIdx.y * sb;
+    const int ns = (S - s0) < sb ? (S - s0) : sb;          // streams of this workgroup
     const uint64_t rl = blockIdx.z;
     const Rng rng(seed, first + rl);
-    if ((int)threadIdx.x < L) {
+    if ((int)threadIdx.x < ns * L) {
+        const int sl = threadIdx.x / L, l = threadIdx.x % L, s = s0 + sl;
         const double two_pi = 6.283185307179586476925286766559;
-        const double phi = two_pi * uniform_at(rng, STREAM_PHASE, (uint64_t)threadIdx.x * S + s);
-        const double psi = two_pi * uniform_at(rng, STREAM_PHASE, (uint64_t)L * S + (uint64_t)threadIdx.x * S + s);
+        const double phi = two_pi * uniform_at(rng, STREAM_PHASE, (uint64_t)l * S + s);
+        const double psi = two_pi * uniform_at(rng, STREAM_PHASE, (uint64_t)L * S + (uint64_t)l * S + s);
         if (sizeof(T) == 8) {
             s_w[threadIdx.x] = two_pi * Fd * cos(phi);
             s_psi[threadIdx.x] = psi;
         } else {
             s_w[threadIdx.x] = Fd * cos(phi);
             s_psi[threadIdx.x] = psi / two_pi;
+            double sn, cs;                                   // one-sample rotation of this ray, exact in f64
+            sincos(two_pi * Fd * cos(phi) * dt, &sn, &cs);
+            s_rot[threadIdx.x] = make_float2((float)cs, (float)sn);
         }
     }
     __syncthreads();
-    const T a = (T)amp[s];
-    cx<T>* out = taps + ((size_t)rl * S + s) * n;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const double t = jakes_time(t0, dt, (double)i);
-        T re = 0, im = 0;
+    // f32: each thread owns kRun consecutive samples; the ray phasor is evaluated exactly (f64 phase) at the
+    // first and advanced by the per-sample rotation for the rest (|drift| < 1e-6 over the run).  f64: kRun = 1.
+    constexpr int kRun = sizeof(T) == 4 ? 4 : 1;
+    const size_t groups = (n + kRun - 1) / kRun;
+    for (size_t w = threadIdx.x; w < (size_t)ns * groups; w += blockDim.x) {
+        const int sl = (int)(w / groups);
+        const size_t i0 = (w - (size_t)sl * groups) * kRun;
+        const T a = (T)amp[s0 + sl];
+        cx<T>* out = taps + ((size_t)rl * S + s0 + sl) * n;
+        const double t = jakes_time(t0, dt, (double)i0);
+        T re[kRun], im[kRun];
+#pragma unroll
+        for (int k = 0; k < kRun; ++k) re[k] = im[k] = 0;
         for (int l = 0; l < L; ++l) {
-            const cx<T> e = jakes_ray<T>(s_w[l], s_psi[l], t);
-            re += e.x;
-            im += e.y;
+            cx<T> e = jakes_ray<T>(s_w[sl * L + l], s_psi[sl * L + l], t);
+            re[0] += e.x;
+            im[0] += e.y;
+            if constexpr (kRun > 1) {
+                const float2 rot = s_rot[sl * L + l];
+#pragma unroll
+                for (int k = 1; k < kRun; ++k) {
+                    e = cmul(e, rot);
+                    re[k] += e.x;
+                    im[k] += e.y;
+                }
+            }
         }
-        out[i] = mk<T>(a * re, a * im);
+        if constexpr (kRun == 4) {
+            if (i0 + kRun <= n && (n % 2 == 0)) {
+                float4* o4 = reinterpret_cast<float4*>(out + i0);     // rows start 16-byte aligned when n is even
+                o4[0] = make_float4(a * re[0], a * im[0], a * re[1], a * im[1]);
+                o4[1] = make_float4(a * re[2], a * im[2], a * re[3], a * im[3]);
+                continue;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kRun; ++k)
+            if (i0 + k < n) out[i0 + k] = mk<T>(a * re[k], a * im[k]);
     }
 }
 
@@ -348,14 +384,16 @@ int mcle_jakes_taps_philox(mcle_ctx* ctx, int dtype, uint64_t seed, uint64_t fir
     if ((rc = ctx->scratch(n_streams * sizeof(double), &d_amp))) return rc;
     MCLE_HIP(hipMemcpyAsync(d_amp, stream_amp, n_streams * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     MCLE_HIP(hipStreamSynchronize(ctx->stream));
-    dim3 grid((unsigned)grid_for(ctx, n_samples, kChBlock, 1), (unsigned)n_streams, (unsigned)count);
-    if (grid.x > 64) grid.x = 64;
+    int sb = kChBlock / L;                                    // streams per workgroup
+    if (sb > 16) sb = 16;
+    if (sb > n_streams) sb = n_streams;
+    dim3 grid(1u, (unsigned)((n_streams + sb - 1) / sb), (unsigned)count);
     if (dtype == MCLE_F32)
-        hipLaunchKernelGGL(k_jakes_philox<float>, grid, dim3(kChBlock), 0, ctx->stream, seed, first, L, n_streams, Fd,
-                           t0, dt, (const double*)d_amp, (float2*)d_taps, n_samples);
+        hipLaunchKernelGGL(k_jakes_philox<float>, grid, dim3(kChBlock), 0, ctx->stream, seed, first, L, n_streams, sb,
+                           Fd, t0, dt, (const double*)d_amp, (float2*)d_taps, n_samples);
     else
-        hipLaunchKernelGGL(k_jakes_philox<double>, grid, dim3(kChBlock), 0, ctx->stream, seed, first, L, n_streams, Fd,
-                           t0, dt, (const double*)d_amp, (double2*)d_taps, n_samples);
+        hipLaunchKernelGGL(k_jakes_philox<double>, grid, dim3(kChBlock), 0, ctx->stream, seed, first, L, n_streams,
+                           sb, Fd, t0, dt, (const double*)d_amp, (double2*)d_taps, n_samples);
     MCLE_LAUNCH_CHECK();
     return MCLE_OK;
 }

@@ -66,13 +66,15 @@ __global__ __launch_bounds__(kMimoBlock) void k_blast_decode_persc(const cx<T>* 
     G += (size_t)blockIdx.y * ns * nt * nr;    // batch item: G [b][ns][nt][nr], Y [b][nr][ns], est [b][ns*nt]
     Y += (size_t)blockIdx.y * nr * ns;
     est += (size_t)blockIdx.y * ns * nt;
-    for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < ns; c += (size_t)gridDim.x * blockDim.x) {
-        const cx<T>* Gc = G + c * (size_t)nt * nr;
-        for (int a = 0; a < nt; ++a) {
-            cx<T> acc = mk<T>(0, 0);
-            for (int r = 0; r < nr; ++r) acc = cfma(Gc[a * nr + r], Y[(size_t)r * ns + c], acc);
-            est[c * nt + a] = acc;
-        }
+    // one thread per output (c, a): its filter row G[c][a][:] is contiguous and consecutive threads read
+    // consecutive rows, so the G stream (the bulk of the traffic) is fully coalesced
+    const size_t total = ns * (size_t)nt;
+    for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (size_t)gridDim.x * blockDim.x) {
+        const size_t c = o / nt;
+        const cx<T>* Ga = G + o * (size_t)nr;
+        cx<T> acc = mk<T>(0, 0);
+        for (int r = 0; r < nr; ++r) acc = cfma(Ga[r], Y[(size_t)r * ns + c], acc);
+        est[o] = acc;
     }
 }
 
@@ -617,7 +619,7 @@ int mcle_blast_decode_per_subcarrier(mcle_ctx* ctx, int dtype, const void* d_G, 
     MCLE_REQUIRE(batch <= 65535, "batch too large (%zu > 65535)", batch);
     if (ns == 0 || batch == 0) return MCLE_OK;
     if ((rc = ctx->bind())) return rc;
-    const dim3 grid(grid_for(ctx, ns, kMimoBlock, 4), (unsigned)batch);
+    const dim3 grid(grid_for(ctx, ns * (size_t)nt, kMimoBlock, 4), (unsigned)batch);
     if (dtype == MCLE_F32)
         hipLaunchKernelGGL(k_blast_decode_persc<float>, grid, dim3(kMimoBlock), 0, ctx->stream, (const float2*)d_G,
                            (const float2*)d_Y, nr, nt, ns, (float2*)d_est);

@@ -472,8 +472,9 @@ class Engine:
         self._raise_value(self.lib.mcle_blast_encode(self.ctx, dt, d_x.ptr, nt, n, out.ptr, batch))
         return self._out(out, host)
 
-    def blast_filter(self, H, noise_var, dtype=None):
-        """H [batch, nr, nt] -> (G [batch, nt, nr], skipped [batch])."""
+    def blast_filter(self, H, noise_var, dtype=None, read_skipped=True):
+        """H [batch, nr, nt] -> (G [batch, nt, nr], skipped [batch]); read_skipped=False leaves the flags on the
+        device (returned as a DeviceArray) and saves the blocking copy."""
         dt = self._dt(dtype)
         d_H, host = self._cin(H, dt)
         b, nr, nt = d_H.shape
@@ -481,7 +482,7 @@ class Engine:
         sk = self.empty(b, np.uint32)
         self._raise_value(self.lib.mcle_blast_filter(self.ctx, dt, d_H.ptr, nr, nt, float(noise_var), G.ptr, sk.ptr,
                                                      b))
-        return self._out(G, host), sk.get()
+        return self._out(G, host), (sk.get() if read_skipped else sk)
 
     def blast_decode(self, G, Y, dtype=None):
         """G [batch, nt, nr], Y [batch, nr, ns] -> est [batch, nt*ns] (Fortran interleave)."""

@@ -216,10 +216,13 @@ class MimoOfdmTdlSimulator(_LinkSimulator):
         Rn = eng.slice_rows(R, n) if R.shape[-1] != n else R
         Y = eng.ofdm_demodulate(Rn, fft, cp, used, batch=count * nr, dtype=dt).reshape(count, nr, ns)
         Hm = eng.tdl_mean_freq_response(taps5, delays, n_sym, fft, cp, used, dtype=dt, batch=count)
-        G, skipped = eng.blast_filter(Hm.reshape(count * ns, nr, nt), noise_var if p["mmse"] else 0.0, dtype=dt)
+        # MMSE Gram matrices are positive definite: the singular-matrix flags are only read back for ZF
+        G, skipped = eng.blast_filter(Hm.reshape(count * ns, nr, nt), noise_var if p["mmse"] else 0.0, dtype=dt,
+                                      read_skipped=not p["mmse"])
         est = eng.blast_decode_per_subcarrier(G.reshape(count, ns, nt, nr), Y, dtype=dt)        # [count, ns*nt]
         c, se, be = eng.demod_count(est, idx, n_real=count, method=self.demod_method, dtype=dt)
-        c["n_skipped"] = int(np.count_nonzero(skipped))
+        if not p["mmse"]:
+            c["n_singular_subcarriers"] = int(np.count_nonzero(skipped))
         return (c, se, be) if per_realization else c
 
 
