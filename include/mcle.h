@@ -29,7 +29,8 @@ extern "C" {
 
 #define MCLE_VERSION 1
 
-enum { MCLE_OK = 0, MCLE_E_INVAL = -1, MCLE_E_HIP = -2, MCLE_E_NOMEM = -3, MCLE_E_STATE = -4 };
+enum { MCLE_OK = 0, MCLE_E_INVAL = -1, MCLE_E_HIP = -2, MCLE_E_NOMEM = -3, MCLE_E_STATE = -4,
+       MCLE_E_UNSUPPORTED = -5 /* valid request outside a fused kernel's envelope: use the staged operators */ };
 enum { MCLE_F32 = 0, MCLE_F64 = 1 };
 /* demodulation method: exhaustive minimum distance over the constellation held in LDS
  * (any constellation), or the per-axis slicer (square Gray QAM only; same decisions). */
@@ -244,6 +245,18 @@ typedef struct mcle_mimo_ofdm_cfg {     /* C4: apps/mimo/simulate_mimo.py:68-142
     double noise_var;
 } mcle_mimo_ofdm_cfg;
 
+typedef struct mcle_mimo_ofdm_tdl_cfg { /* TdlMimoChannel (fading.py:1290-1333) + per-antenna OFDM +
+                                         * one Blast filter per used subcarrier (mimo.py:577-607) */
+    int32_t nt, nr;                     /* supported: nt == nr in {2, 4} */
+    int32_t fft_size, cp_size, num_used, n_ofdm_sym;
+    int32_t demod_method;
+    int32_t mmse;                       /* 1: MMSE with noise_var; 0: zero forcing */
+    int32_t n_taps, L;                  /* discretised profile taps; Jakes rays per fading process */
+    double noise_var, Fd, Ts;
+    double tap_power[MCLE_MAX_TAPS];    /* linear */
+    int32_t tap_delay[MCLE_MAX_TAPS];   /* samples, ascending, < fft_size */
+} mcle_mimo_ofdm_tdl_cfg;
+
 typedef struct mcle_ia_cfg {            /* C5: apps/ia/simulate_ia.py:94-245, ClosedFormIASolver */
     int32_t K, nr, nt, ns;              /* supported: K = 3, nr = nt = 2, ns = 1 */
     int32_t n_symbols;                  /* NSymbs per stream */
@@ -265,6 +278,12 @@ int mcle_run_ofdm_tdl(mcle_ctx* ctx, int dtype, const mcle_ofdm_tdl_cfg* cfg, ui
 int mcle_run_mimo_ofdm(mcle_ctx* ctx, int dtype, const mcle_mimo_ofdm_cfg* cfg, uint64_t seed,
                        uint64_t first, uint64_t count, mcle_counters* d_counters,
                        uint32_t* d_sym_err, uint32_t* d_bit_err);
+
+/* Fused frequency-selective MIMO-OFDM.  Returns MCLE_E_UNSUPPORTED (and touches nothing) when the Doppler phase
+ * across half an OFDM symbol is beyond the kernel's polynomial tap model: run the staged operators then. */
+int mcle_run_mimo_ofdm_tdl(mcle_ctx* ctx, int dtype, const mcle_mimo_ofdm_tdl_cfg* cfg, uint64_t seed,
+                           uint64_t first, uint64_t count, mcle_counters* d_counters,
+                           uint32_t* d_sym_err, uint32_t* d_bit_err);
 
 /* d_sum_capacity (may be NULL): per-realization sum_k log2(1 + SINR_k) of the chosen solution */
 int mcle_run_ia(mcle_ctx* ctx, int dtype, const mcle_ia_cfg* cfg, uint64_t seed, uint64_t first,

@@ -25,6 +25,10 @@ class McleError(RuntimeError):
     """Any failure reported by libmcle (message from mcle_last_error)."""
 
 
+class McleUnsupported(McleError):
+    """A valid request outside a fused kernel's envelope (MCLE_E_UNSUPPORTED): use the staged operators."""
+
+
 class Counters(Structure):
     _fields_ = [(n, c_uint64) for n in ("n_realizations", "n_skipped", "sym_errors", "sym_errors_sq",
                                         "bit_errors", "bit_errors_sq", "n_symbols", "n_bits")]
@@ -56,6 +60,14 @@ class MimoOfdmCfg(Structure):
     _fields_ = [("nt", c_int32), ("nr", c_int32), ("fft_size", c_int32), ("cp_size", c_int32),
                 ("num_used", c_int32), ("n_ofdm_sym", c_int32), ("demod_method", c_int32), ("mmse", c_int32),
                 ("noise_var", c_double)]
+
+
+class MimoOfdmTdlCfg(Structure):
+    _fields_ = [("nt", c_int32), ("nr", c_int32), ("fft_size", c_int32), ("cp_size", c_int32),
+                ("num_used", c_int32), ("n_ofdm_sym", c_int32), ("demod_method", c_int32), ("mmse", c_int32),
+                ("n_taps", c_int32), ("L", c_int32),
+                ("noise_var", c_double), ("Fd", c_double), ("Ts", c_double),
+                ("tap_power", c_double * MAX_TAPS), ("tap_delay", c_int32 * MAX_TAPS)]
 
 
 class IaCfg(Structure):
@@ -128,6 +140,8 @@ _PROTOS = {
     "mcle_run_flat_fading": (c_int, [_P, c_int, POINTER(FlatCfg), c_uint64, c_uint64, c_uint64, _P, _P, _P]),
     "mcle_run_ofdm_tdl": (c_int, [_P, c_int, POINTER(OfdmTdlCfg), c_uint64, c_uint64, c_uint64, _P, _P, _P]),
     "mcle_run_mimo_ofdm": (c_int, [_P, c_int, POINTER(MimoOfdmCfg), c_uint64, c_uint64, c_uint64, _P, _P, _P]),
+    "mcle_run_mimo_ofdm_tdl": (c_int, [_P, c_int, POINTER(MimoOfdmTdlCfg), c_uint64, c_uint64, c_uint64, _P, _P,
+                                       _P]),
     "mcle_run_ia": (c_int, [_P, c_int, POINTER(IaCfg), c_uint64, c_uint64, c_uint64, _P, _P, _P, _P]),
     "mcle_ia_closed_form": (c_int, [_P, _P, c_double, _P, _P, _P, _P, _P, c_size_t]),
     "mcle_legacy_draws": (c_int, [_P, POINTER(LegacySeg), c_int, c_uint32, c_uint64, c_uint64, _P, c_size_t, _P,
@@ -191,7 +205,7 @@ def exported_symbols():
 def check(rc):
     if rc != 0:
         msg = load().mcle_last_error()
-        raise McleError((msg or b"unknown error").decode("utf-8", "replace"))
+        raise (McleUnsupported if rc == -5 else McleError)((msg or b"unknown error").decode("utf-8", "replace"))
 
 
 def device_count():

@@ -12,6 +12,7 @@
 #include "modem.hpp"
 #include "philox.hpp"
 #include "totals.hpp"
+#include "pipe_common.hpp"
 
 namespace mcle {
 
@@ -243,8 +244,6 @@ __global__ __launch_bounds__(64) void k_run_ia(ModemParams<T> mp, int n_symbols,
         wg_flush(totals, counters, 3ull * (unsigned long long)n_symbols, 3ull * (unsigned long long)n_symbols * mp.bits);
 }
 
-// defined in pipelines.hip
-int check_pipe(const mcle_ctx* ctx, int dtype, int method, const void* cfg);
 
 template <typename T> static ModemParams<T> ia_modem(const mcle_ctx* ctx, int method) {
     ModemParams<T> p;

@@ -11,15 +11,19 @@
 namespace mcle {
 
 // H: NR x NT (row-major), G: NT x NR.  Returns false if H^H H + nv I is not positive definite.
-template <int NT, int NR>
-__device__ __forceinline__ bool blast_filter(const double2 (&H)[NR][NT], double nv, double2 (&G)[NT][NR]) {
-    double2 L[NT][NT];  // lower Cholesky factor of A = H^H H + nv I (strict upper part unused)
+// R = double everywhere one filter serves a whole realization; R = float only where a filter is needed per
+// subcarrier (frequency-selective pipeline, f32 instantiation).
+template <typename R, int NT, int NR>
+__device__ __forceinline__ bool blast_filter_t(const cx<R> (&H)[NR][NT], R nv, cx<R> (&G)[NT][NR]) {
+    typedef cx<R> C;
+    C L[NT][NT];  // lower Cholesky factor of A = H^H H + nv I (strict upper part unused)
+    R invd[NT];   // 1 / L[j][j]
     bool ok = true;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
 #pragma unroll
         for (int i = j; i < NT; ++i) {
-            double2 a = mk<double>(0, 0);
+            C a = mk<R>(0, 0);
 #pragma unroll
             for (int r = 0; r < NR; ++r) a = cadd(a, cmulc(H[r][j], H[r][i]));  // conj(H[r][i]) * H[r][j]
             // a = A[i][j]
@@ -27,35 +31,41 @@ __device__ __forceinline__ bool blast_filter(const double2 (&H)[NR][NT], double 
 #pragma unroll
             for (int k = 0; k < j; ++k) a = csub(a, cmulc(L[i][k], L[j][k]));
             if (i == j) {
-                ok = ok && (a.x > 1e-300);
-                L[j][j] = mk<double>(sqrt(a.x), 0.0);
+                ok = ok && (a.x > (R)(sizeof(R) == 8 ? 1e-300 : 1e-30));
+                L[j][j] = mk<R>(sqrt(a.x), (R)0);
+                invd[j] = (R)1 / L[j][j].x;
             } else {
-                L[i][j] = cscale(a, 1.0 / L[j][j].x);
+                L[i][j] = cscale(a, invd[j]);
             }
         }
     }
-    const double root_nt = sqrt((double)NT);
+    const R root_nt = (R)sqrt((double)NT);
 #pragma unroll
     for (int c = 0; c < NR; ++c) {
-        double2 z[NT];
+        C z[NT];
 #pragma unroll
         for (int i = 0; i < NT; ++i) {  // L z = H^H[:, c]
-            double2 v = cconj(H[c][i]);
+            C v = cconj(H[c][i]);
 #pragma unroll
             for (int k = 0; k < i; ++k) v = csub(v, cmul(L[i][k], z[k]));
-            z[i] = cscale(v, 1.0 / L[i][i].x);
+            z[i] = cscale(v, invd[i]);
         }
 #pragma unroll
         for (int i = NT - 1; i >= 0; --i) {  // L^H w = z
-            double2 v = z[i];
+            C v = z[i];
 #pragma unroll
             for (int k = i + 1; k < NT; ++k) v = csub(v, cmul(cconj(L[k][i]), z[k]));
-            z[i] = cscale(v, 1.0 / L[i][i].x);
+            z[i] = cscale(v, invd[i]);
         }
 #pragma unroll
         for (int i = 0; i < NT; ++i) G[i][c] = cscale(z[i], root_nt);
     }
     return ok;
+}
+
+template <int NT, int NR>
+__device__ __forceinline__ bool blast_filter(const double2 (&H)[NR][NT], double nv, double2 (&G)[NT][NR]) {
+    return blast_filter_t<double, NT, NR>(H, nv, G);
 }
 
 }  // namespace mcle

@@ -1,0 +1,59 @@
+// pipe_common.hpp -- pieces shared by the fused pipeline translation units.
+#pragma once
+#include "common.hpp"
+#include "modem.hpp"
+
+namespace mcle {
+
+constexpr int kPipeBlock = 256;
+constexpr int kMaxTable = 256;  // Philox symbols are bytes
+
+// workgroup-wide sum of two unsigned values; result valid in thread 0
+__device__ __forceinline__ void block_sum2(unsigned& a, unsigned& b, unsigned* s_red) {
+    a = wave_sum_u32(a);
+    b = wave_sum_u32(b);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) {
+        s_red[2 * wave] = a;
+        s_red[2 * wave + 1] = b;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        a = 0;
+        b = 0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) {
+            a += s_red[2 * w];
+            b += s_red[2 * w + 1];
+        }
+    }
+}
+
+// ---- host side -----------------------------------------------------------------------------------
+template <typename T> ModemParams<T> pipe_modem(const mcle_ctx* ctx, int method) {
+    ModemParams<T> p;
+    if (sizeof(T) == 8)
+        p.g_table = reinterpret_cast<const cx<T>*>(ctx->d_table_f64);
+    else
+        p.g_table = reinterpret_cast<const cx<T>*>(ctx->d_table_f32);
+    p.M = ctx->M;
+    p.bits = ctx->bits;
+    p.method = method;
+    p.qam_scale = (T)ctx->qam_scale;
+    p.qam_L = ctx->qam_L;
+    p.half_bits = ctx->bits / 2;
+    return p;
+}
+
+inline int check_pipe(const mcle_ctx* ctx, int dtype, int method, const void* cfg) {
+    MCLE_REQUIRE(ctx != nullptr && cfg != nullptr, "null argument");
+    MCLE_REQUIRE(dtype == MCLE_F32 || dtype == MCLE_F64, "dtype must be MCLE_F32 or MCLE_F64");
+    MCLE_REQUIRE(ctx->M > 0, "no constellation set (mcle_set_constellation)");
+    MCLE_REQUIRE(ctx->M <= kMaxTable, "fused pipelines draw symbols as bytes: M <= %d", kMaxTable);
+    MCLE_REQUIRE(method == MCLE_DEMOD_MINDIST || method == MCLE_DEMOD_QAM_SLICER, "bad demodulation method");
+    MCLE_REQUIRE(method != MCLE_DEMOD_QAM_SLICER || ctx->kind == MCLE_CONST_QAM,
+                 "the slicer needs a square Gray QAM constellation (kind MCLE_CONST_QAM)");
+    return MCLE_OK;
+}
+
+}  // namespace mcle

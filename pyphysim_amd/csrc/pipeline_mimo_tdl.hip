@@ -1,0 +1,453 @@
+// pipeline_mimo_tdl.hip -- fused pipeline for SURVEY.md section 8(f).1: spatial multiplexing with per-antenna
+// OFDM over a frequency-selective, time-varying MIMO TDL channel and one MMSE (or ZF) receive filter per used
+// subcarrier.  One workgroup of 256 threads per realization; nothing but integer counters leaves the chip.
+//
+// Reference path (restated by oracle/chains.py::chain_mimo_ofdm_tdl):
+//   TdlMimoChannel / corrupt_data MIMO branch      channels/fading.py:1290-1333, :1107-1117
+//   Jakes taps, time axis                          channels/fading_generators.py:421-425, :459-467, :519-522
+//   per-symbol mean frequency response             channels/fading.py:513-536 (+ modulators/ofdm.py:545-547)
+//   Blast receive filter on every used bin         mimo/mimo.py:577-607
+//
+// What makes the fusion possible: the staged chain moves the tap tensor g[s][r][a][j] (taps x Nr x Nt x
+// samples, 84 % of its HBM bytes) through memory three times.  Here each of the S*Nr*Nt fading processes is
+// represented, for one OFDM symbol, by a short polynomial in the sample index,
+//     g(x) = amp * sum_l e_l exp(j th_l x) = sum_m c_m x^m,   c_m = amp * sum_l e_l (j th_l)^m / m!,
+// x counted from the middle of the symbol, th_l = 2 pi Fd cos(phi_l) dt the per-sample phase advance of ray l
+// (~1e-6 rad).  The host picks the order K so that the truncation error (max |th x|)^(K+1)/(K+1)! is below
+// the rounding level of the instantiation (K = 3 at config-4 size in f32) and refuses configurations where
+// K would exceed kMaxOrder (Doppler phase of > ~0.5 rad across half a symbol) -- callers then use the staged
+// operator chain.  The per-symbol tap mean is the same polynomial against precomputed moments of x.
+//
+// Draw ledger (mcle-philox-v1): DATA symbol n = c*Nt + a; PHASE phi = uniform l*P + p, psi = uniform
+// L*P + l*P + p with p = (s*Nr + r)*Nt + a, P = S*Nr*Nt; NOISE sample r*(n + dmax) + j of the faded stream.
+#include "fft.hpp"
+#include "jakes.hpp"
+#include "mimo.hpp"
+#include "modem.hpp"
+#include "philox.hpp"
+#include "pipe_common.hpp"
+#include "totals.hpp"
+
+namespace mcle {
+
+constexpr int kMaxOrder = 12;
+
+struct MimoTdlParams {
+    int cp, num_used, n_ofdm_sym, mmse;
+    int n_taps, L, K, dmax;
+    double noise_var, Fd, Ts, dt;
+    double tap_amp[MCLE_MAX_TAPS];   // sqrt(p_s / L)
+    int tap_delay[MCLE_MAX_TAPS];
+    double mom[kMaxOrder + 1];       // mean over the symbol's N+cp samples of x^m, x = j - (N+cp-1)/2
+};
+
+template <typename T, int N, int NA>
+__global__ __launch_bounds__(kPipeBlock, sizeof(T) == 4 ? 2 : 1) void k_run_mimo_ofdm_tdl(
+    MimoTdlParams pp, ModemParams<T> mp, uint64_t seed, uint64_t first, uint64_t count,
+    const cx<T>* __restrict__ g_tw, mcle_counters* counters, uint32_t* __restrict__ sym_out,
+    uint32_t* __restrict__ bit_out) {
+    constexpr int P1 = NA * NA;                 // fading processes per tap
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int S = pp.n_taps, L = pp.L, K = pp.K, dmax = pp.dmax;
+    const int PS = S * P1;                      // fading processes
+    cx<T>* s_x = reinterpret_cast<cx<T>*>(smem);       // [NA][N]
+    cx<T>* s_tw = s_x + NA * N;                         // [N]
+    cx<T>* s_coef = s_tw + N;                           // [PS][K+1]
+    cx<T>* s_mean = s_coef + PS * (K + 1);              // [PS]
+    cx<T>* s_tail = s_mean + PS;                        // [2][NA][dmax] last samples of the previous symbol
+    float4* s_tab4 = reinterpret_cast<float4*>(s_tail + 2 * NA * (dmax > 0 ? dmax : 1));  // [kMaxTable]
+    cx<T>* s_table = reinterpret_cast<cx<T>*>(s_tab4);  // f64: the plain table lives in the same place
+    unsigned* s_red = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(s_tab4) +
+                                                  kMaxTable * (sizeof(T) == 4 ? sizeof(float4) : sizeof(cx<T>)));
+    unsigned char* s_idx = reinterpret_cast<unsigned char*>(s_red + 16);   // [NA*num_used]
+
+    const int tid = threadIdx.x;
+    for (int k = tid; k < N; k += kPipeBlock) s_tw[k] = g_tw[k];
+    for (int m = tid; m < mp.M; m += kPipeBlock) {
+        const cx<T> c = mp.g_table[m];
+        if constexpr (sizeof(T) == 4)
+            s_tab4[m] = make_float4((float)c.x, (float)c.y, (float)(0.5 * (c.x * c.x + c.y * c.y)), 0.f);
+        else
+            s_table[m] = c;
+    }
+    auto table_at = [&](int m) -> cx<T> {
+        if constexpr (sizeof(T) == 4) {
+            const float4 c = s_tab4[m];
+            return mk<T>(c.x, c.y);
+        } else {
+            return s_table[m];
+        }
+    };
+    const int U = pp.num_used, cp = pp.cp, W = N + cp;
+    const int per_sym = U * NA;
+    const uint64_t n_total = (uint64_t)pp.n_ofdm_sym * W;        // samples per antenna
+    const uint64_t noise_row = n_total + (uint64_t)dmax;          // noise is drawn for the whole faded stream
+    const T sigma = (T)sqrt(pp.noise_var);
+    const T tx_scale = (T)(1.0 / sqrt((double)NA) / sqrt((double)(U + cp)));
+    const T rx_scale = (T)(sqrt((double)(U + cp)) / (double)N);
+    const T nv_filter = (T)(pp.mmse ? pp.noise_var : 0.0);
+    const uint32_t mask = (uint32_t)(mp.M - 1);
+    const double xc = 0.5 * (double)(W - 1);                      // centre of the symbol in local sample units
+    // rays of one process are split over RP adjacent lanes
+    const int RP = (PS * 4 <= kPipeBlock && L >= 4) ? 4 : ((PS * 2 <= kPipeBlock && L >= 2) ? 2 : 1);
+    __shared__ WgTotals totals;
+    if (tid == 0) wg_zero(totals);
+
+    for (uint64_t rl = blockIdx.x; rl < count; rl += gridDim.x) {
+        const Rng rng(seed, first + rl);
+        unsigned se = 0, be = 0;
+        for (int os = 0; os < pp.n_ofdm_sym; ++os) {
+            const uint64_t sym0 = (uint64_t)os * W;
+            __syncthreads();
+            // ---- polynomial coefficients of every fading process around the middle of this symbol ----
+            {
+                const double two_pi = 6.283185307179586476925286766559;
+                const double tc = pp.Ts + pp.dt * ((double)sym0 + xc);
+                const int items = PS * RP;
+                const int rounds = (items + kPipeBlock - 1) / kPipeBlock;
+                for (int it = 0; it < rounds; ++it) {
+                    const int q = it * kPipeBlock + tid;
+                    const bool live = q < items;
+                    const int p = live ? q / RP : 0, part = q % RP;
+                    T cr[kMaxOrder + 1], ci[kMaxOrder + 1];
+#pragma unroll
+                    for (int m = 0; m <= kMaxOrder; ++m) cr[m] = ci[m] = 0;
+                    if (live) {
+                        for (int l = part; l < L; l += RP) {
+                            const double phi = two_pi * uniform_at(rng, STREAM_PHASE, (uint64_t)l * PS + p);
+                            const double psi_t = uniform_at(rng, STREAM_PHASE, (uint64_t)L * PS + (uint64_t)l * PS + p);
+                            const double w = pp.Fd * cos(phi);                  // Hz
+                            const double ph = fma(w, tc, psi_t);                 // turns
+                            const double fr = ph - floor(ph);
+                            T er, ei;
+                            if constexpr (sizeof(T) == 8) {
+                                double sn, cs;
+                                sincos(two_pi * fr, &sn, &cs);
+                                er = cs;
+                                ei = sn;
+                            } else {
+                                er = __builtin_amdgcn_cosf((float)fr);
+                                ei = __builtin_amdgcn_sinf((float)fr);
+                            }
+                            const T th = (T)(two_pi * w * pp.dt);                // rad per sample
+#pragma unroll
+                            for (int m = 0; m <= kMaxOrder; ++m) {
+                                if (m <= K) {
+                                    cr[m] += er;
+                                    ci[m] += ei;
+                                    const T s = th * (T)(1.0 / (m + 1));         // next term: * (j th) / (m + 1)
+                                    const T nr = -ei * s, ni = er * s;
+                                    er = nr;
+                                    ei = ni;
+                                }
+                            }
+                        }
+                    }
+                    // fold the RP partial sums (adjacent lanes), fixed order
+                    for (int off = 1; off < RP; off <<= 1) {
+#pragma unroll
+                        for (int m = 0; m <= kMaxOrder; ++m) {
+                            if (m <= K) {
+                                cr[m] += __shfl_xor(cr[m], off, 64);
+                                ci[m] += __shfl_xor(ci[m], off, 64);
+                            }
+                        }
+                    }
+                    if (live && part == 0) {
+                        const T amp = (T)pp.tap_amp[p / P1];
+                        T mr = 0, mi = 0;
+#pragma unroll
+                        for (int m = 0; m <= kMaxOrder; ++m) {
+                            if (m <= K) {
+                                s_coef[p * (K + 1) + m] = mk<T>(amp * cr[m], amp * ci[m]);
+                                mr += cr[m] * (T)pp.mom[m];
+                                mi += ci[m] * (T)pp.mom[m];
+                            }
+                        }
+                        s_mean[p] = mk<T>(amp * mr, amp * mi);
+                    }
+                }
+            }
+            // ---- transmit: symbols -> bins (Blast.encode's F-order split + OFDM subcarrier map) ----
+            if (U != N) {
+                for (int p = tid; p < NA * N; p += kPipeBlock) s_x[p] = mk<T>(0, 0);
+                __syncthreads();
+            }
+            const uint64_t n_first = (uint64_t)os * per_sym;
+            const uint64_t n_last = n_first + per_sym;
+            for (uint64_t blk = (n_first >> 4) + tid; blk <= ((n_last - 1) >> 4); blk += kPipeBlock) {
+                const Words4 dw = rng.block(STREAM_DATA, (uint32_t)blk);
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const uint64_t n = (blk << 4) + j;
+                    if (n >= n_first && n < n_last) {
+                        const int tx = (int)((dw.w[j >> 2] >> ((j & 3) * 8)) & mask);
+                        const int nl = (int)(n - n_first);
+                        const int a = nl % NA, d = nl / NA;
+                        s_idx[nl] = (unsigned char)tx;
+                        s_x[a * N + lds_swz<true>(ofdm_bin(d, N, U))] = cscale(table_at(tx), tx_scale);
+                    }
+                }
+            }
+            __syncthreads();
+            fft_dif<T, N, true, kPipeBlock, true>(s_x, NA, N, s_tw);   // time samples, digit-reversed positions
+            auto time_sample = [&](int a, int i) -> cx<T> {             // IFFT output i of antenna a
+                return s_x[a * N + lds_swz<true>(fft_pos_of_index<N>(i & (N - 1)))];
+            };
+            // the last dmax samples of this symbol feed the head of the next one
+            cx<T>* tail_prev = s_tail + (size_t)(os & 1) * NA * dmax;
+            cx<T>* tail_next = s_tail + (size_t)((os + 1) & 1) * NA * dmax;
+            if (os + 1 < pp.n_ofdm_sym)
+                for (int q = tid; q < NA * dmax; q += kPipeBlock) {
+                    const int a = q / dmax, i = q - a * dmax;
+                    tail_next[q] = time_sample(a, N - dmax + i);
+                }
+            // ---- channel: y[r][m] = sum_s sum_a g[s][r][a](j) T[a][j],  j = cp + m - d_s (input sample) ----
+            constexpr int PAIRS = (N / 2 + kPipeBlock - 1) / kPipeBlock;   // sample pairs per thread
+            cx<T> y[NA][PAIRS][2];
+#pragma unroll
+            for (int r = 0; r < NA; ++r)
+#pragma unroll
+                for (int k = 0; k < PAIRS; ++k) y[r][k][0] = y[r][k][1] = mk<T>(0, 0);
+            for (int s = 0; s < S; ++s) {
+                const int d = pp.tap_delay[s];
+#pragma unroll
+                for (int a = 0; a < NA; ++a) {
+                    cx<T> xv[PAIRS][2];
+                    T xx[PAIRS][2];
+#pragma unroll
+                    for (int k = 0; k < PAIRS; ++k)
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            const int m = 2 * (tid + kPipeBlock * k) + e;
+                            const int q = cp + m - d;            // local index of the input sample
+                            xx[k][e] = (T)((double)q - xc);
+                            if (m >= N) {
+                                xv[k][e] = mk<T>(0, 0);
+                            } else if (q >= 0) {
+                                xv[k][e] = time_sample(a, m - d + N);
+                            } else if (os > 0) {
+                                xv[k][e] = tail_prev[a * dmax + (dmax + q)];    // sample W + q of the previous symbol
+                            } else {
+                                xv[k][e] = mk<T>(0, 0);                        // before the start of the stream
+                            }
+                        }
+#pragma unroll
+                    for (int r = 0; r < NA; ++r) {
+                        const cx<T>* c = s_coef + ((s * NA + r) * NA + a) * (K + 1);
+                        cx<T> g[PAIRS][2];
+                        const cx<T> top = c[K];
+#pragma unroll
+                        for (int k = 0; k < PAIRS; ++k) g[k][0] = g[k][1] = top;
+                        for (int m = K - 1; m >= 0; --m) {
+                            const cx<T> cm = c[m];
+#pragma unroll
+                            for (int k = 0; k < PAIRS; ++k)
+#pragma unroll
+                                for (int e = 0; e < 2; ++e) {
+                                    g[k][e].x = fma(g[k][e].x, xx[k][e], cm.x);
+                                    g[k][e].y = fma(g[k][e].y, xx[k][e], cm.y);
+                                }
+                        }
+#pragma unroll
+                        for (int k = 0; k < PAIRS; ++k)
+#pragma unroll
+                            for (int e = 0; e < 2; ++e) y[r][k][e] = cfma(g[k][e], xv[k][e], y[r][k][e]);
+                    }
+                }
+            }
+            // noise of the samples that survive CP removal
+#pragma unroll
+            for (int k = 0; k < PAIRS; ++k) {
+                const int m0 = 2 * (tid + kPipeBlock * k);
+                if (m0 < N) {
+#pragma unroll
+                    for (int r = 0; r < NA; ++r) {
+                        const uint64_t i0 = (uint64_t)r * noise_row + sym0 + cp + m0;
+                        cx<T> z0, z1;
+                        if ((i0 & 1) == 0) {
+                            cn_pair<T>(rng, STREAM_NOISE, (uint32_t)(i0 >> 1), sigma, z0, z1);
+                        } else {
+                            z0 = cn_sample<T>(rng, STREAM_NOISE, i0, sigma);
+                            z1 = cn_sample<T>(rng, STREAM_NOISE, i0 + 1, sigma);
+                        }
+                        y[r][k][0] = cadd(y[r][k][0], z0);
+                        y[r][k][1] = cadd(y[r][k][1], z1);
+                    }
+                }
+            }
+            __syncthreads();   // every read of the transmit samples is done: overwrite in place
+#pragma unroll
+            for (int k = 0; k < PAIRS; ++k) {
+                const int m0 = 2 * (tid + kPipeBlock * k);
+                if (m0 < N) {
+                    const int q0 = lds_swz<true>(fft_pos_of_index<N>(m0));
+                    const int q1 = lds_swz<true>(fft_pos_of_index<N>(m0 + 1));
+#pragma unroll
+                    for (int r = 0; r < NA; ++r) {
+                        s_x[r * N + q0] = y[r][k][0];
+                        s_x[r * N + q1] = y[r][k][1];
+                    }
+                }
+            }
+            __syncthreads();
+            fft_dit<T, N, false, kPipeBlock, true>(s_x, NA, N, s_tw);   // bins, natural order
+            // ---- receive: frequency response, filter, decode, demodulate, count -- one subcarrier per thread ----
+            for (int d = tid; d < U; d += kPipeBlock) {
+                const int f = ofdm_bin(d, N, U);
+                cx<T> H[NA][NA];
+#pragma unroll
+                for (int r = 0; r < NA; ++r)
+#pragma unroll
+                    for (int a = 0; a < NA; ++a) H[r][a] = mk<T>(0, 0);
+                for (int s = 0; s < S; ++s) {
+                    const cx<T> w = s_tw[(f * pp.tap_delay[s]) & (N - 1)];
+#pragma unroll
+                    for (int r = 0; r < NA; ++r)
+#pragma unroll
+                        for (int a = 0; a < NA; ++a) H[r][a] = cfma(s_mean[(s * NA + r) * NA + a], w, H[r][a]);
+                }
+                cx<T> G[NA][NA];
+                const bool ok = blast_filter_t<T, NA, NA>(H, nv_filter, G);
+                const int bin = lds_swz<true>(f);
+                cx<T> yb[NA];
+#pragma unroll
+                for (int r = 0; r < NA; ++r) yb[r] = s_x[r * N + bin];
+                cx<T> est[NA];
+                int dec[NA];
+#pragma unroll
+                for (int a = 0; a < NA; ++a) {
+                    cx<T> acc = mk<T>(0, 0);
+#pragma unroll
+                    for (int r = 0; r < NA; ++r) acc = cfma(G[a][r], yb[r], acc);
+                    est[a] = ok ? cscale(acc, rx_scale) : mk<T>(0, 0);    // singular (ZF only): zero filter
+                }
+                if (mp.method == MCLE_DEMOD_QAM_SLICER) {
+#pragma unroll
+                    for (int a = 0; a < NA; ++a) dec[a] = demod_qam_slicer<T>(est[a], mp.qam_scale, mp.qam_L, mp.half_bits);
+                } else if constexpr (sizeof(T) == 4) {
+                    demod_mindist_multi<NA>(s_tab4, mp.M, est, dec);
+                } else {
+                    demod_mindist_multi<NA>(s_table, mp.M, est, dec);
+                }
+#pragma unroll
+                for (int a = 0; a < NA; ++a) {
+                    const unsigned x = (unsigned)((int)s_idx[d * NA + a] ^ dec[a]);
+                    se += (x != 0u);
+                    be += __popc(x);
+                }
+            }
+        }
+        block_sum2(se, be, s_red);
+        if (tid == 0) wg_account(totals, se, be, false, rl, sym_out, bit_out);
+    }
+    if (tid == 0)
+        wg_flush(totals, counters, (unsigned long long)per_sym * pp.n_ofdm_sym,
+                 (unsigned long long)per_sym * pp.n_ofdm_sym * mp.bits);
+}
+
+template <typename T, int N, int NA>
+int run_mimo_tdl_impl(mcle_ctx* ctx, const MimoTdlParams& pp, int method, uint64_t seed, uint64_t first,
+                      uint64_t count, mcle_counters* d_counters, uint32_t* d_sym, uint32_t* d_bit) {
+    int rc;
+    void* tw = nullptr;
+    if ((rc = ctx->get_twiddles(N, sizeof(T) == 8 ? MCLE_F64 : MCLE_F32, &tw))) return rc;
+    const size_t PS = (size_t)pp.n_taps * NA * NA;
+    const size_t lds = (size_t)(NA * N + N + PS * (pp.K + 1) + PS + 2 * NA * (pp.dmax > 0 ? pp.dmax : 1)) * sizeof(cx<T>) +
+                       kMaxTable * (sizeof(T) == 4 ? sizeof(float4) : sizeof(cx<T>)) + 16 * sizeof(unsigned) +
+                       (size_t)NA * pp.num_used + 16;
+    MCLE_REQUIRE(lds <= 160 * 1024, "configuration needs %zu bytes of LDS (limit 160 KiB)", lds);
+    auto kern = k_run_mimo_ofdm_tdl<T, N, NA>;
+    MCLE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int per_cu = (int)((size_t)160 * 1024 / (lds + 512));
+    if (per_cu < 1) per_cu = 1;
+    if (per_cu > 8) per_cu = 8;
+    const uint64_t cap = (uint64_t)ctx->n_cu * per_cu;
+    const unsigned grid = (unsigned)(count < cap ? count : cap);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kPipeBlock), lds, ctx->stream, pp, pipe_modem<T>(ctx, method), seed, first,
+                       count, (const cx<T>*)tw, d_counters, d_sym, d_bit);
+    MCLE_LAUNCH_CHECK();
+    return MCLE_OK;
+}
+
+}  // namespace mcle
+
+using namespace mcle;
+
+extern "C" int mcle_run_mimo_ofdm_tdl(mcle_ctx* ctx, int dtype, const mcle_mimo_ofdm_tdl_cfg* cfg, uint64_t seed,
+                                      uint64_t first, uint64_t count, mcle_counters* d_counters,
+                                      uint32_t* d_sym_err, uint32_t* d_bit_err) {
+    int rc = check_pipe(ctx, dtype, cfg ? cfg->demod_method : 0, cfg);
+    if (rc) return rc;
+    MCLE_REQUIRE(cfg->nt == cfg->nr && (cfg->nt == 2 || cfg->nt == 4),
+                 "fused MIMO-TDL pipeline supports 2x2 and 4x4 (use the staged operators otherwise)");
+    MCLE_REQUIRE(cfg->cp_size >= 0 && cfg->cp_size <= cfg->fft_size,
+                 "cp_size must be nonnegative and cannot be greater than fft_size");
+    MCLE_REQUIRE(cfg->num_used >= 2 && cfg->num_used % 2 == 0 && cfg->num_used <= cfg->fft_size,
+                 "Number of used subcarriers must be a multiple of 2 and at most fft_size");
+    MCLE_REQUIRE(cfg->n_ofdm_sym >= 1, "n_ofdm_sym must be positive");
+    MCLE_REQUIRE(cfg->noise_var >= 0.0, "Noise variance must be a non-negative value.");
+    MCLE_REQUIRE(cfg->n_taps >= 1 && cfg->n_taps <= MCLE_MAX_TAPS, "n_taps must be in [1, %d]", MCLE_MAX_TAPS);
+    MCLE_REQUIRE(cfg->L >= 1 && cfg->L <= 64, "L must be in [1, 64]");
+    MCLE_REQUIRE(cfg->Ts > 0.0 && cfg->Fd >= 0.0, "Ts must be positive and Fd non-negative");
+    MCLE_REQUIRE(count <= 0x7fffffffull, "at most 2^31-1 realizations per call");
+    MimoTdlParams pp;
+    pp.cp = cfg->cp_size;
+    pp.num_used = cfg->num_used;
+    pp.n_ofdm_sym = cfg->n_ofdm_sym;
+    pp.mmse = cfg->mmse;
+    pp.n_taps = cfg->n_taps;
+    pp.L = cfg->L;
+    pp.noise_var = cfg->noise_var;
+    pp.Fd = cfg->Fd;
+    pp.Ts = cfg->Ts;
+    {   // numpy.arange(t0, ..., Ts*1.0000000001): delta = fl(fl(t0 + step) - t0), t0 = Ts (fading_generators.py:459-462)
+        volatile double step = cfg->Ts * 1.0000000001;
+        volatile double nxt = cfg->Ts + step;
+        pp.dt = nxt - cfg->Ts;
+    }
+    pp.dmax = 0;
+    for (int i = 0; i < MCLE_MAX_TAPS; ++i) {
+        pp.tap_amp[i] = i < cfg->n_taps ? std::sqrt(cfg->tap_power[i]) * std::sqrt(1.0 / (double)cfg->L) : 0.0;
+        pp.tap_delay[i] = i < cfg->n_taps ? cfg->tap_delay[i] : 0;
+        if (i < cfg->n_taps) {
+            MCLE_REQUIRE(cfg->tap_delay[i] >= 0 && cfg->tap_delay[i] < cfg->fft_size,
+                         "tap delays must be in [0, fft_size) samples");
+            if (cfg->tap_delay[i] > pp.dmax) pp.dmax = cfg->tap_delay[i];
+        }
+    }
+    // polynomial order: truncation (max |theta x|)^(K+1) / (K+1)! below the rounding level of the dtype
+    const int W = cfg->fft_size + cfg->cp_size;
+    const double xc = 0.5 * (double)(W - 1);
+    const double z = 2.0 * 3.14159265358979323846 * cfg->Fd * pp.dt * (xc + (double)pp.dmax);
+    const double tol = dtype == MCLE_F32 ? 1e-8 : 1e-17;
+    int K = 1;
+    double term = z * z / 2.0;          // (K+1 = 2)
+    while (term > tol && K < kMaxOrder + 1) {
+        ++K;
+        term *= z / (double)(K + 1);
+    }
+    if (K > kMaxOrder) {
+        set_error("Doppler phase across half an OFDM symbol is %.3g rad: beyond the fused pipeline's tap model "
+                  "(use the staged operator chain)", z);
+        return MCLE_E_UNSUPPORTED;
+    }
+    pp.K = K;
+    for (int m = 0; m <= kMaxOrder; ++m) {
+        long double acc = 0.0L;
+        for (int j = 0; j < W; ++j) acc += std::pow((long double)j - (long double)xc, m);
+        pp.mom[m] = (double)(acc / (long double)W);
+    }
+    if (count == 0) return MCLE_OK;
+    if ((rc = ctx->bind())) return rc;
+#define MCLE_RUN(N_, NA_)                                                                                       \
+    if (cfg->fft_size == N_ && cfg->nt == NA_)                                                                  \
+        return dtype == MCLE_F32 ? run_mimo_tdl_impl<float, N_, NA_>(ctx, pp, cfg->demod_method, seed, first,   \
+                                                                     count, d_counters, d_sym_err, d_bit_err)   \
+                                 : run_mimo_tdl_impl<double, N_, NA_>(ctx, pp, cfg->demod_method, seed, first,  \
+                                                                      count, d_counters, d_sym_err, d_bit_err);
+    MCLE_RUN(64, 2) MCLE_RUN(64, 4) MCLE_RUN(256, 2) MCLE_RUN(256, 4) MCLE_RUN(1024, 2) MCLE_RUN(1024, 4)
+#undef MCLE_RUN
+    set_error("fused MIMO-TDL pipeline supports fft_size in {64, 256, 1024} (got %d)", cfg->fft_size);
+    return MCLE_E_INVAL;
+}

@@ -625,6 +625,22 @@ class Engine:
                           int(method), 1 if mmse else 0, float(noise_var))
         return self._run(self.lib.mcle_run_mimo_ofdm, cfg, seed, first, count, dtype, per_realization, counters)
 
+    def run_mimo_ofdm_tdl(self, nt, nr, fft_size, cp_size, num_used, n_ofdm_sym, noise_var, tap_power, tap_delay,
+                          seed, first, count, Fd=10.0, Ts=1.0 / (15e3 * 1024), L=8, mmse=True, method=DEMOD_MINDIST,
+                          dtype=None, per_realization=False, counters=None):
+        """Fused frequency-selective MIMO-OFDM.  Raises _lib.McleUnsupported when the Doppler is
+        beyond the kernel's tap model; `simulators.MimoOfdmTdlSimulator` then runs the staged chain."""
+        cfg = _lib.MimoOfdmTdlCfg()
+        cfg.nt, cfg.nr, cfg.fft_size, cfg.cp_size = int(nt), int(nr), int(fft_size), int(cp_size)
+        cfg.num_used, cfg.n_ofdm_sym, cfg.demod_method = int(num_used), int(n_ofdm_sym), int(method)
+        cfg.mmse, cfg.n_taps, cfg.L = (1 if mmse else 0), len(tap_delay), int(L)
+        cfg.noise_var, cfg.Fd, cfg.Ts = float(noise_var), float(Fd), float(Ts)
+        if len(tap_delay) > _lib.MAX_TAPS or len(tap_power) != len(tap_delay):
+            raise ValueError("at most %d taps; powers and delays must match" % _lib.MAX_TAPS)
+        for i, (p, d) in enumerate(zip(tap_power, tap_delay)):
+            cfg.tap_power[i], cfg.tap_delay[i] = float(p), int(d)
+        return self._run(self.lib.mcle_run_mimo_ofdm_tdl, cfg, seed, first, count, dtype, per_realization, counters)
+
 
 
     def run_ia(self, n_symbols, noise_var, seed, first, count, method=DEMOD_MINDIST, dtype=None,

@@ -175,8 +175,9 @@ class MimoOfdmTdlSimulator(_LinkSimulator):
 
     def __init__(self, SNR, modulator="qam", M=16, Nt=2, Nr=2, fft_size=64, cp_size=16, num_used_subcarriers=None,
                  num_ofdm_symbols=2, Fd=50.0, Ts=1e-6, L=8, tap_powers_dB=(0.0, -4.0, -9.0), tap_delays=None,
-                 mmse=True, **kw):
-        kw.setdefault("batch_size", 256)
+                 mmse=True, fused="auto", **kw):
+        self.fused = fused                    # "auto": fused kernel when it supports the configuration
+        kw.setdefault("batch_size", 4096 if fused else 256)
         super().__init__(SNR, modulator, M, **kw)
         if tap_delays is None:
             tap_delays = np.asarray((0, 2, 5)[:len(tap_powers_dB)], dtype=float) * Ts
@@ -188,8 +189,26 @@ class MimoOfdmTdlSimulator(_LinkSimulator):
                      ("L", int(L)), ("mmse", bool(mmse))):
             self.params.add(k, v)
 
+    _FUSED_FFT = (64, 256, 1024)
+
     def _launch(self, current_parameters, first_rep, count, per_realization):
         p = current_parameters
+        if self.fused and p["Nt"] == p["Nr"] and p["Nt"] in (2, 4) and p["fft_size"] in self._FUSED_FFT:
+            try:
+                eng = self._bind()
+                return eng.run_mimo_ofdm_tdl(
+                    p["Nt"], p["Nr"], p["fft_size"], p["cp_size"], p["num_used_subcarriers"], p["num_ofdm_symbols"],
+                    self._noise_var(p), self._tap_power, self._tap_delay, self._seed_for(p), first_rep, count,
+                    Fd=p["Fd"], Ts=p["Ts"], L=p["L"], mmse=p["mmse"], method=self.demod_method, dtype=self.dtype,
+                    per_realization=per_realization)
+            except _lib.McleUnsupported:
+                if self.fused is True:
+                    raise
+        elif self.fused is True:
+            raise ValueError("the fused pipeline supports Nt == Nr in {2, 4} and fft_size in {64, 256, 1024}")
+        return self._launch_staged(p, first_rep, count, per_realization)
+
+    def _launch_staged(self, p, first_rep, count, per_realization):
         eng = self._bind()
         dt = self.dtype
         nt, nr, fft, cp, used = p["Nt"], p["Nr"], p["fft_size"], p["cp_size"], p["num_used_subcarriers"]

@@ -94,7 +94,7 @@ F1_KW = dict(mod="qam", M=16, nt=2, nr=2, fft_size=64, cp_size=16, num_used=52, 
              Fd=50.0, Ts=1e-6, L=8, tap_powers_dB=(0.0, -4.0, -9.0), tap_delays_samples=(0, 2, 5))
 
 
-def _f1_sim(dtype, **over):
+def _f1_sim(dtype, fused=False, **over):
     from pyphysim_amd.simulators import MimoOfdmTdlSimulator
     kw = dict(F1_KW, **over)
     return MimoOfdmTdlSimulator(
@@ -102,7 +102,7 @@ def _f1_sim(dtype, **over):
         cp_size=kw["cp_size"], num_used_subcarriers=kw["num_used"], num_ofdm_symbols=kw["n_ofdm_sym"], Fd=kw["Fd"],
         Ts=kw["Ts"], L=kw["L"], tap_powers_dB=kw["tap_powers_dB"],
         tap_delays=np.asarray(kw["tap_delays_samples"], dtype=float) * kw["Ts"], seed=77,
-        common_random_numbers=True, dtype=dtype, demod="mindist", rep_max=8, batch_size=8)
+        common_random_numbers=True, dtype=dtype, demod="mindist", rep_max=8, batch_size=8, fused=fused)
 
 
 @pytest.mark.parametrize("over", [dict(), dict(nt=4, nr=4, fft_size=256, num_used=200, n_ofdm_sym=1, M=64, snr_db=24.0),
@@ -166,3 +166,53 @@ def test_batched_philox_operators(engine):
     idx = engine.rand_symbols_batch(1001, 64, seed, first, count).get()
     for r in range(count):
         assert np.array_equal(idx[r], philox.symbols(seed, first + r, 1001, 64))
+
+
+@pytest.mark.parametrize("over", [dict(), dict(cp_size=4), dict(n_ofdm_sym=3, tap_delays_samples=(0, 7, 19), cp_size=8),
+                                  dict(nt=4, nr=4, fft_size=256, num_used=200, n_ofdm_sym=1, M=64, snr_db=24.0),
+                                  dict(nt=4, nr=4, fft_size=1024, cp_size=16, num_used=None, n_ofdm_sym=1, M=64,
+                                       snr_db=25.0, Fd=10.0, Ts=1.0 / (15e3 * 1024),
+                                       tap_powers_dB=(0.0, -3.0, -6.0, -9.0, -12.0),
+                                       tap_delays_samples=(0, 1, 2, 3, 4)),
+                                  dict(Fd=70.0, Ts=1e-5)])
+def test_mimo_ofdm_tdl_fused_matches_oracle(over):
+    """The fused kernel (polynomial tap model) against the oracle chain on the same Philox draws: equal
+    per-realization counts in f64 (incl. inter-symbol interference through the CP, cp < max delay, and a
+    Doppler high enough for a higher polynomial order), a few near-tie flips in f32; equal to the staged chain."""
+    from oracle import chains
+    kw = dict(F1_KW, **over)
+    n = 4 if kw["fft_size"] >= 1024 else 8
+    want_se, want_be = [], []
+    for r in range(n):
+        o = chains.chain_mimo_ofdm_tdl(chains.PhiloxRng(77, r), **kw)
+        want_se.append(o["symbol_errors"])
+        want_be.append(o["bit_errors"])
+    sim = _f1_sim("f64", fused=True, **over)
+    p = next(iter(sim.params.get_unpacked_params_list()))
+    c, se, be = sim._run_batch_detailed(p, 0, n)
+    assert np.array_equal(se, want_se) and np.array_equal(be, want_be)
+    assert c["sym_errors"] == sum(want_se) and c["n_symbols"] == o["num_symbols"] and c["n_realizations"] == n
+    c2, se2, _ = sim._run_batch_detailed(p, 1, n - 2)
+    assert np.array_equal(se2, want_se[1:n - 1])
+    sim32 = _f1_sim("f32", fused=True, **over)
+    c32, se32, _ = sim32._run_batch_detailed(p, 0, n)
+    assert np.abs(se32.astype(int) - np.asarray(want_se)).max() <= 3
+    st32 = _f1_sim("f32", fused=False, **over)
+    _, se_st, _ = st32._run_batch_detailed(p, 0, n)
+    assert np.abs(se32.astype(int) - se_st.astype(int)).max() <= 3
+
+
+def test_mimo_ofdm_tdl_fused_envelope():
+    """Beyond the tap model's Doppler envelope the C ABI reports MCLE_E_UNSUPPORTED; 'auto' falls back to
+    the staged chain (same counts as the oracle), fused=True raises."""
+    from oracle import chains
+    from pyphysim_amd._lib import McleUnsupported
+    over = dict(Fd=30000.0, Ts=1e-5)
+    kw = dict(F1_KW, **over)
+    want = [chains.chain_mimo_ofdm_tdl(chains.PhiloxRng(77, r), **kw)["symbol_errors"] for r in range(4)]
+    sim = _f1_sim("f64", fused="auto", **over)
+    p = next(iter(sim.params.get_unpacked_params_list()))
+    _, se, _ = sim._run_batch_detailed(p, 0, 4)
+    assert np.array_equal(se, want)
+    with pytest.raises(McleUnsupported):
+        _f1_sim("f64", fused=True, **over)._run_batch_detailed(p, 0, 4)
