@@ -63,6 +63,56 @@ __device__ __forceinline__ bool blast_filter_t(const cx<R> (&H)[NR][NT], R nv, c
     return ok;
 }
 
+// x = sqrt(NT) (H^H H + nv I)^-1 H^H y without forming the filter: one right-hand side instead of NR.  For
+// callers that need a filter per column (frequency-selective channels) -- same decisions as G y.
+template <typename R, int NT, int NR>
+__device__ __forceinline__ bool blast_solve_t(const cx<R> (&H)[NR][NT], R nv, const cx<R> (&y)[NR], cx<R> (&x)[NT]) {
+    typedef cx<R> C;
+    C L[NT][NT];
+    R invd[NT];
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+#pragma unroll
+        for (int i = j; i < NT; ++i) {
+            C a = mk<R>(0, 0);
+#pragma unroll
+            for (int r = 0; r < NR; ++r) a = cadd(a, cmulc(H[r][j], H[r][i]));
+            if (i == j) a.x += nv;
+#pragma unroll
+            for (int k = 0; k < j; ++k) a = csub(a, cmulc(L[i][k], L[j][k]));
+            if (i == j) {
+                ok = ok && (a.x > (R)(sizeof(R) == 8 ? 1e-300 : 1e-30));
+                L[j][j] = mk<R>(sqrt(a.x), (R)0);
+                invd[j] = (R)1 / L[j][j].x;
+            } else {
+                L[i][j] = cscale(a, invd[j]);
+            }
+        }
+    }
+    C z[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {  // L z = H^H y
+        C v = mk<R>(0, 0);
+#pragma unroll
+        for (int r = 0; r < NR; ++r) v = cadd(v, cmulc(y[r], H[r][i]));   // conj(H[r][i]) * y[r]
+#pragma unroll
+        for (int k = 0; k < i; ++k) v = csub(v, cmul(L[i][k], z[k]));
+        z[i] = cscale(v, invd[i]);
+    }
+    const R root_nt = (R)sqrt((double)NT);
+#pragma unroll
+    for (int i = NT - 1; i >= 0; --i) {  // L^H w = z
+        C v = z[i];
+#pragma unroll
+        for (int k = i + 1; k < NT; ++k) v = csub(v, cmul(cconj(L[k][i]), z[k]));
+        z[i] = cscale(v, invd[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < NT; ++i) x[i] = cscale(z[i], root_nt);
+    return ok;
+}
+
 template <int NT, int NR>
 __device__ __forceinline__ bool blast_filter(const double2 (&H)[NR][NT], double nv, double2 (&G)[NT][NR]) {
     return blast_filter_t<double, NT, NR>(H, nv, G);

@@ -35,6 +35,7 @@ constexpr int kMaxOrder = 12;
 struct MimoTdlParams {
     int cp, num_used, n_ofdm_sym, mmse;
     int n_taps, L, K, dmax;
+    int x_elems;                     // complex elements of the sample buffer (>= NA*N; also holds the ray scratch)
     double noise_var, Fd, Ts, dt;
     double tap_amp[MCLE_MAX_TAPS];   // sqrt(p_s / L)
     int tap_delay[MCLE_MAX_TAPS];
@@ -50,8 +51,8 @@ __global__ __launch_bounds__(kPipeBlock, sizeof(T) == 4 ? 2 : 1) void k_run_mimo
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int S = pp.n_taps, L = pp.L, K = pp.K, dmax = pp.dmax;
     const int PS = S * P1;                      // fading processes
-    cx<T>* s_x = reinterpret_cast<cx<T>*>(smem);       // [NA][N]
-    cx<T>* s_tw = s_x + NA * N;                         // [N]
+    cx<T>* s_x = reinterpret_cast<cx<T>*>(smem);       // [NA][N] (+ slack for the ray scratch of small FFTs)
+    cx<T>* s_tw = s_x + pp.x_elems;                     // [N]
     cx<T>* s_coef = s_tw + N;                           // [PS][K+1]
     cx<T>* s_mean = s_coef + PS * (K + 1);              // [PS]
     cx<T>* s_tail = s_mean + PS;                        // [2][NA][dmax] last samples of the previous symbol
@@ -88,8 +89,6 @@ __global__ __launch_bounds__(kPipeBlock, sizeof(T) == 4 ? 2 : 1) void k_run_mimo
     const T nv_filter = (T)(pp.mmse ? pp.noise_var : 0.0);
     const uint32_t mask = (uint32_t)(mp.M - 1);
     const double xc = 0.5 * (double)(W - 1);                      // centre of the symbol in local sample units
-    // rays of one process are split over RP adjacent lanes
-    const int RP = (PS * 4 <= kPipeBlock && L >= 4) ? 4 : ((PS * 2 <= kPipeBlock && L >= 2) ? 2 : 1);
     __shared__ WgTotals totals;
     if (tid == 0) wg_zero(totals);
 
@@ -100,73 +99,69 @@ __global__ __launch_bounds__(kPipeBlock, sizeof(T) == 4 ? 2 : 1) void k_run_mimo
             const uint64_t sym0 = (uint64_t)os * W;
             __syncthreads();
             // ---- polynomial coefficients of every fading process around the middle of this symbol ----
+            // (1) one ray per thread: phasor at the symbol centre and phase advance per sample, parked in the
+            //     (currently idle) sample buffer; (2) one (process, order) per thread folds the rays.
             {
                 const double two_pi = 6.283185307179586476925286766559;
                 const double tc = pp.Ts + pp.dt * ((double)sym0 + xc);
-                const int items = PS * RP;
-                const int rounds = (items + kPipeBlock - 1) / kPipeBlock;
-                for (int it = 0; it < rounds; ++it) {
-                    const int q = it * kPipeBlock + tid;
-                    const bool live = q < items;
-                    const int p = live ? q / RP : 0, part = q % RP;
-                    T cr[kMaxOrder + 1], ci[kMaxOrder + 1];
-#pragma unroll
-                    for (int m = 0; m <= kMaxOrder; ++m) cr[m] = ci[m] = 0;
-                    if (live) {
-                        for (int l = part; l < L; l += RP) {
-                            const double phi = two_pi * uniform_at(rng, STREAM_PHASE, (uint64_t)l * PS + p);
-                            const double psi_t = uniform_at(rng, STREAM_PHASE, (uint64_t)L * PS + (uint64_t)l * PS + p);
-                            const double w = pp.Fd * cos(phi);                  // Hz
-                            const double ph = fma(w, tc, psi_t);                 // turns
-                            const double fr = ph - floor(ph);
-                            T er, ei;
-                            if constexpr (sizeof(T) == 8) {
-                                double sn, cs;
-                                sincos(two_pi * fr, &sn, &cs);
-                                er = cs;
-                                ei = sn;
-                            } else {
-                                er = __builtin_amdgcn_cosf((float)fr);
-                                ei = __builtin_amdgcn_sinf((float)fr);
-                            }
-                            const T th = (T)(two_pi * w * pp.dt);                // rad per sample
-#pragma unroll
-                            for (int m = 0; m <= kMaxOrder; ++m) {
-                                if (m <= K) {
-                                    cr[m] += er;
-                                    ci[m] += ei;
-                                    const T s = th * (T)(1.0 / (m + 1));         // next term: * (j th) / (m + 1)
-                                    const T nr = -ei * s, ni = er * s;
-                                    er = nr;
-                                    ei = ni;
-                                }
-                            }
-                        }
+                T* s_ray = reinterpret_cast<T*>(s_x);                    // [PS*L][3] = {re, im, theta}
+                for (int q = tid; q < PS * L; q += kPipeBlock) {
+                    const int l = q / PS, p = q - l * PS;                 // q is the PHASE-stream index of phi
+                    const double phi = two_pi * uniform_at(rng, STREAM_PHASE, (uint64_t)q);
+                    const double psi_t = uniform_at(rng, STREAM_PHASE, (uint64_t)L * PS + q);
+                    const double w = pp.Fd * cos(phi);                    // Hz
+                    const double ph = fma(w, tc, psi_t);                  // turns
+                    const double fr = ph - floor(ph);
+                    T er, ei;
+                    if constexpr (sizeof(T) == 8) {
+                        double sn, cs;
+                        sincos(two_pi * fr, &sn, &cs);
+                        er = cs;
+                        ei = sn;
+                    } else {
+                        er = __builtin_amdgcn_cosf((float)fr);
+                        ei = __builtin_amdgcn_sinf((float)fr);
                     }
-                    // fold the RP partial sums (adjacent lanes), fixed order
-                    for (int off = 1; off < RP; off <<= 1) {
-#pragma unroll
-                        for (int m = 0; m <= kMaxOrder; ++m) {
-                            if (m <= K) {
-                                cr[m] += __shfl_xor(cr[m], off, 64);
-                                ci[m] += __shfl_xor(ci[m], off, 64);
-                            }
-                        }
-                    }
-                    if (live && part == 0) {
-                        const T amp = (T)pp.tap_amp[p / P1];
-                        T mr = 0, mi = 0;
-#pragma unroll
-                        for (int m = 0; m <= kMaxOrder; ++m) {
-                            if (m <= K) {
-                                s_coef[p * (K + 1) + m] = mk<T>(amp * cr[m], amp * ci[m]);
-                                mr += cr[m] * (T)pp.mom[m];
-                                mi += ci[m] * (T)pp.mom[m];
-                            }
-                        }
-                        s_mean[p] = mk<T>(amp * mr, amp * mi);
-                    }
+                    T* o = s_ray + 3 * (p * L + l);
+                    o[0] = er;
+                    o[1] = ei;
+                    o[2] = (T)(two_pi * w * pp.dt);                       // rad per sample
                 }
+                __syncthreads();
+                for (int q = tid; q < PS * (K + 1); q += kPipeBlock) {
+                    const int p = q / (K + 1), m = q - p * (K + 1);
+                    T inv_fact = 1;
+                    for (int i = 2; i <= m; ++i) inv_fact /= (T)i;
+                    T ar = 0, ai = 0;
+                    for (int l = 0; l < L; ++l) {
+                        const T* o = s_ray + 3 * (p * L + l);
+                        T pw = inv_fact;
+                        for (int i = 0; i < m; ++i) pw *= o[2];
+                        ar += o[0] * pw;
+                        ai += o[1] * pw;
+                    }
+                    // times j^m
+                    T cr, ci;
+                    switch (m & 3) {
+                        case 0: cr = ar; ci = ai; break;
+                        case 1: cr = -ai; ci = ar; break;
+                        case 2: cr = -ar; ci = -ai; break;
+                        default: cr = ai; ci = -ar; break;
+                    }
+                    const T amp = (T)pp.tap_amp[p / P1];
+                    s_coef[q] = mk<T>(amp * cr, amp * ci);
+                }
+                __syncthreads();
+                for (int p = tid; p < PS; p += kPipeBlock) {
+                    T mr = 0, mi = 0;
+                    for (int m = 0; m <= K; ++m) {
+                        const cx<T> c = s_coef[p * (K + 1) + m];
+                        mr += c.x * (T)pp.mom[m];
+                        mi += c.y * (T)pp.mom[m];
+                    }
+                    s_mean[p] = mk<T>(mr, mi);
+                }
+                __syncthreads();   // the ray scratch is dead: the sample buffer may be refilled
             }
             // ---- transmit: symbols -> bins (Blast.encode's F-order split + OFDM subcarrier map) ----
             if (U != N) {
@@ -211,26 +206,32 @@ __global__ __launch_bounds__(kPipeBlock, sizeof(T) == 4 ? 2 : 1) void k_run_mimo
                 for (int k = 0; k < PAIRS; ++k) y[r][k][0] = y[r][k][1] = mk<T>(0, 0);
             for (int s = 0; s < S; ++s) {
                 const int d = pp.tap_delay[s];
+                // where the input sample of every output of this thread sits (same for all antennas)
+                int pos[PAIRS][2];          // >= 0: offset in an antenna's sample row; -1: zero; <= -2: tail slot -2-i
+                T xx[PAIRS][2];
 #pragma unroll
+                for (int k = 0; k < PAIRS; ++k)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int m = 2 * (tid + kPipeBlock * k) + e;
+                        const int q = cp + m - d;                // local index of the input sample
+                        xx[k][e] = (T)((double)q - xc);
+                        if (m >= N)
+                            pos[k][e] = -1;
+                        else if (q >= 0)
+                            pos[k][e] = lds_swz<true>(fft_pos_of_index<N>((m - d + N) & (N - 1)));
+                        else
+                            pos[k][e] = os > 0 ? -2 - (dmax + q) : -1;   // sample W + q of the previous symbol
+                    }
+#pragma nounroll   // unrolled, the four antennas' loads and Horner chains are hoisted together: > 100 VGPRs spill
                 for (int a = 0; a < NA; ++a) {
                     cx<T> xv[PAIRS][2];
-                    T xx[PAIRS][2];
 #pragma unroll
                     for (int k = 0; k < PAIRS; ++k)
 #pragma unroll
                         for (int e = 0; e < 2; ++e) {
-                            const int m = 2 * (tid + kPipeBlock * k) + e;
-                            const int q = cp + m - d;            // local index of the input sample
-                            xx[k][e] = (T)((double)q - xc);
-                            if (m >= N) {
-                                xv[k][e] = mk<T>(0, 0);
-                            } else if (q >= 0) {
-                                xv[k][e] = time_sample(a, m - d + N);
-                            } else if (os > 0) {
-                                xv[k][e] = tail_prev[a * dmax + (dmax + q)];    // sample W + q of the previous symbol
-                            } else {
-                                xv[k][e] = mk<T>(0, 0);                        // before the start of the stream
-                            }
+                            const int ps = pos[k][e];
+                            xv[k][e] = ps >= 0 ? s_x[a * N + ps] : (ps == -1 ? mk<T>(0, 0) : tail_prev[a * dmax + (-2 - ps)]);
                         }
 #pragma unroll
                     for (int r = 0; r < NA; ++r) {
@@ -307,21 +308,15 @@ __global__ __launch_bounds__(kPipeBlock, sizeof(T) == 4 ? 2 : 1) void k_run_mimo
 #pragma unroll
                         for (int a = 0; a < NA; ++a) H[r][a] = cfma(s_mean[(s * NA + r) * NA + a], w, H[r][a]);
                 }
-                cx<T> G[NA][NA];
-                const bool ok = blast_filter_t<T, NA, NA>(H, nv_filter, G);
                 const int bin = lds_swz<true>(f);
                 cx<T> yb[NA];
 #pragma unroll
                 for (int r = 0; r < NA; ++r) yb[r] = s_x[r * N + bin];
                 cx<T> est[NA];
                 int dec[NA];
+                const bool ok = blast_solve_t<T, NA, NA>(H, nv_filter, yb, est);   // filter applied, never formed
 #pragma unroll
-                for (int a = 0; a < NA; ++a) {
-                    cx<T> acc = mk<T>(0, 0);
-#pragma unroll
-                    for (int r = 0; r < NA; ++r) acc = cfma(G[a][r], yb[r], acc);
-                    est[a] = ok ? cscale(acc, rx_scale) : mk<T>(0, 0);    // singular (ZF only): zero filter
-                }
+                for (int a = 0; a < NA; ++a) est[a] = ok ? cscale(est[a], rx_scale) : mk<T>(0, 0);   // singular: ZF only
                 if (mp.method == MCLE_DEMOD_QAM_SLICER) {
 #pragma unroll
                     for (int a = 0; a < NA; ++a) dec[a] = demod_qam_slicer<T>(est[a], mp.qam_scale, mp.qam_L, mp.half_bits);
@@ -347,13 +342,15 @@ __global__ __launch_bounds__(kPipeBlock, sizeof(T) == 4 ? 2 : 1) void k_run_mimo
 }
 
 template <typename T, int N, int NA>
-int run_mimo_tdl_impl(mcle_ctx* ctx, const MimoTdlParams& pp, int method, uint64_t seed, uint64_t first,
+int run_mimo_tdl_impl(mcle_ctx* ctx, MimoTdlParams pp, int method, uint64_t seed, uint64_t first,
                       uint64_t count, mcle_counters* d_counters, uint32_t* d_sym, uint32_t* d_bit) {
     int rc;
     void* tw = nullptr;
     if ((rc = ctx->get_twiddles(N, sizeof(T) == 8 ? MCLE_F64 : MCLE_F32, &tw))) return rc;
     const size_t PS = (size_t)pp.n_taps * NA * NA;
-    const size_t lds = (size_t)(NA * N + N + PS * (pp.K + 1) + PS + 2 * NA * (pp.dmax > 0 ? pp.dmax : 1)) * sizeof(cx<T>) +
+    const size_t ray_elems = (PS * pp.L * 3 + 1) / 2;            // {re, im, theta} per ray, in complex elements
+    pp.x_elems = (int)(ray_elems > (size_t)NA * N ? ray_elems : (size_t)NA * N);
+    const size_t lds = (size_t)(pp.x_elems + N + PS * (pp.K + 1) + PS + 2 * NA * (pp.dmax > 0 ? pp.dmax : 1)) * sizeof(cx<T>) +
                        kMaxTable * (sizeof(T) == 4 ? sizeof(float4) : sizeof(cx<T>)) + 16 * sizeof(unsigned) +
                        (size_t)NA * pp.num_used + 16;
     MCLE_REQUIRE(lds <= 160 * 1024, "configuration needs %zu bytes of LDS (limit 160 KiB)", lds);

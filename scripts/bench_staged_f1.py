@@ -39,12 +39,15 @@ def main():
     ap.add_argument("--batch", type=int, default=512)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--dtype", default="f32")
+    ap.add_argument("--fused", action="store_true", help="the fused kernel instead of the staged chain")
+    ap.add_argument("--demod", default="slicer")
     args = ap.parse_args()
     from pyphysim_amd.simulators import MimoOfdmTdlSimulator
     Ts = 1.0 / (15e3 * 1024)
     sim = MimoOfdmTdlSimulator(SNR=[25.0], modulator="qam", M=64, Nt=4, Nr=4, fft_size=1024, cp_size=16,
                                num_ofdm_symbols=1, Fd=10.0, Ts=Ts, L=8, tap_powers_dB=(0.0, -3.0, -6.0, -9.0, -12.0),
-                               tap_delays=np.arange(5) * Ts, dtype=args.dtype, batch_size=args.batch, seed=1)
+                               tap_delays=np.arange(5) * Ts, dtype=args.dtype, batch_size=args.batch, seed=1,
+                               fused=True if args.fused else False, demod=args.demod)
     p = next(iter(sim.params.get_unpacked_params_list()))
     sim._launch(p, 1 << 30, args.batch, False)
     sim.engine.sync()
@@ -56,7 +59,8 @@ def main():
     dt = time.perf_counter() - t0
     n = args.steps * args.batch
     bytes_per = staged_bytes(4, 4, 5, 1024, 16, 1024, 1, 4, 8 if args.dtype == "f32" else 16)
-    print(json.dumps({"workload": "4x4 MMSE + 64-QAM + OFDM(1024,16) over 5-tap Jakes MIMO TDL (staged, 8f.1)",
+    print(json.dumps({"workload": "4x4 MMSE + 64-QAM + OFDM(1024,16) over 5-tap Jakes MIMO TDL (%s, 8f.1)"
+                                  % ("fused" if args.fused else "staged"),
                       "realizations_per_s": n / dt, "batch": args.batch, "dtype": args.dtype,
                       "ser": se / float(n * 4096), "staged_bytes_per_realization": bytes_per,
                       "achieved_GBps": bytes_per * n / dt / 1e9}))
