@@ -43,7 +43,7 @@ struct MimoTdlParams {
 };
 
 template <typename T, int N, int NA>
-__global__ __launch_bounds__(kPipeBlock, sizeof(T) == 4 ? 2 : 1) void k_run_mimo_ofdm_tdl(
+__global__ __launch_bounds__(kPipeBlock, sizeof(T) == 4 ? 3 : 1) void k_run_mimo_ofdm_tdl(
     MimoTdlParams pp, ModemParams<T> mp, uint64_t seed, uint64_t first, uint64_t count,
     const cx<T>* __restrict__ g_tw, mcle_counters* counters, uint32_t* __restrict__ sym_out,
     uint32_t* __restrict__ bit_out) {
@@ -430,10 +430,17 @@ extern "C" int mcle_run_mimo_ofdm_tdl(mcle_ctx* ctx, int dtype, const mcle_mimo_
         return MCLE_E_UNSUPPORTED;
     }
     pp.K = K;
-    for (int m = 0; m <= kMaxOrder; ++m) {
-        long double acc = 0.0L;
-        for (int j = 0; j < W; ++j) acc += std::pow((long double)j - (long double)xc, m);
-        pp.mom[m] = (double)(acc / (long double)W);
+    {
+        long double acc[kMaxOrder + 1] = {0.0L};
+        for (int j = 0; j < W; ++j) {
+            const long double x = (long double)j - (long double)xc;
+            long double xp = 1.0L;
+            for (int m = 0; m <= K; ++m) {
+                acc[m] += xp;
+                xp *= x;
+            }
+        }
+        for (int m = 0; m <= kMaxOrder; ++m) pp.mom[m] = m <= K ? (double)(acc[m] / (long double)W) : 0.0;
     }
     if (count == 0) return MCLE_OK;
     if ((rc = ctx->bind())) return rc;

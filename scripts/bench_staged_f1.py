@@ -51,6 +51,18 @@ def main():
     p = next(iter(sim.params.get_unpacked_params_list()))
     sim._launch(p, 1 << 30, args.batch, False)
     sim.engine.sync()
+    kernel_ms = None
+    if args.fused:                      # kernel-only time (HIP events on the engine's stream), counters stay on device
+        cnt = sim.engine.new_counters()
+        run = lambda first: sim.engine.run_mimo_ofdm_tdl(
+            4, 4, 1024, 16, 1024, 1, sim._noise_var(p), sim._tap_power, sim._tap_delay, sim._seed_for(p), first,
+            args.batch, Fd=10.0, Ts=Ts, L=8, method=sim.demod_method, dtype=args.dtype, counters=cnt)
+        run(1 << 31)
+        sim.engine.sync()
+        sim.engine.timer_start()
+        for s in range(args.steps):
+            run((1 << 32) + s * args.batch)
+        kernel_ms = sim.engine.timer_stop_ms() / args.steps
     t0 = time.perf_counter()
     se = 0
     for s in range(args.steps):
@@ -63,7 +75,9 @@ def main():
                                   % ("fused" if args.fused else "staged"),
                       "realizations_per_s": n / dt, "batch": args.batch, "dtype": args.dtype,
                       "ser": se / float(n * 4096), "staged_bytes_per_realization": bytes_per,
-                      "achieved_GBps": bytes_per * n / dt / 1e9}))
+                      "achieved_GBps": bytes_per * n / dt / 1e9,
+                      "kernel_ms_per_launch": kernel_ms,
+                      "kernel_realizations_per_s": (args.batch / (kernel_ms * 1e-3)) if kernel_ms else None}))
 
 
 if __name__ == "__main__":
