@@ -78,6 +78,15 @@ template <typename C> __host__ __device__ __forceinline__ C cfma(C a, C b, C acc
     acc.y += a.x * b.y + a.y * b.x;
     return acc;
 }
+// f32: four chained FMAs -- the shape the backend turns into two v_pk_fma_f32 (op_sel / neg modifiers); the
+// product-then-add form above costs v_pk_mul + v_pk_fma + v_mov + v_pk_add.  f64 keeps NumPy's association.
+__host__ __device__ __forceinline__ float2 cfma(float2 a, float2 b, float2 acc) {
+    acc.x = fmaf(a.x, b.x, acc.x);
+    acc.x = fmaf(-a.y, b.y, acc.x);
+    acc.y = fmaf(a.x, b.y, acc.y);
+    acc.y = fmaf(a.y, b.x, acc.y);
+    return acc;
+}
 template <typename C> __host__ __device__ __forceinline__ C cconj(C a) {
     a.y = -a.y;
     return a;
