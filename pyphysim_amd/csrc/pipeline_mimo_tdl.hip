@@ -20,6 +20,8 @@
 //
 // Draw ledger (mcle-philox-v1): DATA symbol n = c*Nt + a; PHASE phi = uniform l*P + p, psi = uniform
 // L*P + l*P + p with p = (s*Nr + r)*Nt + a, P = S*Nr*Nt; NOISE sample r*(n + dmax) + j of the faded stream.
+#include <type_traits>
+
 #include "fft.hpp"
 #include "jakes.hpp"
 #include "mimo.hpp"
@@ -107,9 +109,8 @@ __global__ __launch_bounds__(kPipeBlock, sizeof(T) == 4 ? 3 : 1) void k_run_mimo
                 T* s_ray = reinterpret_cast<T*>(s_x);                    // [PS*L][3] = {re, im, theta}
                 for (int q = tid; q < PS * L; q += kPipeBlock) {
                     const int l = q / PS, p = q - l * PS;                 // q is the PHASE-stream index of phi
-                    const double phi = two_pi * uniform_at(rng, STREAM_PHASE, (uint64_t)q);
                     const double psi_t = uniform_at(rng, STREAM_PHASE, (uint64_t)L * PS + q);
-                    const double w = pp.Fd * cos(phi);                    // Hz
+                    const double w = pp.Fd * cospi(2.0 * uniform_at(rng, STREAM_PHASE, (uint64_t)q));   // Hz; cos(phi), phi = 2 pi u
                     const double ph = fma(w, tc, psi_t);                  // turns
                     const double fr = ph - floor(ph);
                     T er, ei;
@@ -204,57 +205,97 @@ __global__ __launch_bounds__(kPipeBlock, sizeof(T) == 4 ? 3 : 1) void k_run_mimo
             for (int r = 0; r < NA; ++r)
 #pragma unroll
                 for (int k = 0; k < PAIRS; ++k) y[r][k][0] = y[r][k][1] = mk<T>(0, 0);
-            for (int s = 0; s < S; ++s) {
-                const int d = pp.tap_delay[s];
-                // where the input sample of every output of this thread sits (same for all antennas)
-                int pos[PAIRS][2];          // >= 0: offset in an antenna's sample row; -1: zero; <= -2: tail slot -2-i
-                T xx[PAIRS][2];
-#pragma unroll
-                for (int k = 0; k < PAIRS; ++k)
-#pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        const int m = 2 * (tid + kPipeBlock * k) + e;
-                        const int q = cp + m - d;                // local index of the input sample
-                        xx[k][e] = (T)((double)q - xc);
-                        if (m >= N)
-                            pos[k][e] = -1;
-                        else if (q >= 0)
-                            pos[k][e] = lds_swz<true>(fft_pos_of_index<N>((m - d + N) & (N - 1)));
-                        else
-                            pos[k][e] = os > 0 ? -2 - (dmax + q) : -1;   // sample W + q of the previous symbol
-                    }
-#pragma nounroll   // unrolled, the four antennas' loads and Horner chains are hoisted together: > 100 VGPRs spill
-                for (int a = 0; a < NA; ++a) {
-                    cx<T> xv[PAIRS][2];
+            // FAST: every input sample lies in this symbol (cp >= max delay) and every thread owns PAIRS full
+            // pairs -- no per-sample predicates.  KT > 0: polynomial order known at compile time (Horner unrolled,
+            // coefficients fetched together); KT = 0: run-time order.
+            auto channel = [&](auto fast_tag, auto k_tag) {
+                constexpr bool FAST = decltype(fast_tag)::value;
+                constexpr int KT = decltype(k_tag)::value;
+                for (int s = 0; s < S; ++s) {
+                    const int d = pp.tap_delay[s];
+                    int pos[PAIRS][2];      // >= 0: offset in an antenna's sample row; -1: zero; <= -2: tail slot -2-i
+                    T xx[PAIRS][2];
 #pragma unroll
                     for (int k = 0; k < PAIRS; ++k)
 #pragma unroll
                         for (int e = 0; e < 2; ++e) {
-                            const int ps = pos[k][e];
-                            xv[k][e] = ps >= 0 ? s_x[a * N + ps] : (ps == -1 ? mk<T>(0, 0) : tail_prev[a * dmax + (-2 - ps)]);
+                            const int m = 2 * (tid + kPipeBlock * k) + e;
+                            const int q = cp + m - d;                // local index of the input sample
+                            xx[k][e] = (T)((double)q - xc);
+                            if (FAST || (m < N && q >= 0))
+                                pos[k][e] = lds_swz<true>(fft_pos_of_index<N>((m - d + N) & (N - 1)));
+                            else if (m >= N)
+                                pos[k][e] = -1;
+                            else
+                                pos[k][e] = os > 0 ? -2 - (dmax + q) : -1;   // sample W + q of the previous symbol
                         }
-#pragma unroll
-                    for (int r = 0; r < NA; ++r) {
-                        const cx<T>* c = s_coef + ((s * NA + r) * NA + a) * (K + 1);
-                        cx<T> g[PAIRS][2];
-                        const cx<T> top = c[K];
-#pragma unroll
-                        for (int k = 0; k < PAIRS; ++k) g[k][0] = g[k][1] = top;
-                        for (int m = K - 1; m >= 0; --m) {
-                            const cx<T> cm = c[m];
-#pragma unroll
-                            for (int k = 0; k < PAIRS; ++k)
-#pragma unroll
-                                for (int e = 0; e < 2; ++e) {
-                                    g[k][e].x = fma(g[k][e].x, xx[k][e], cm.x);
-                                    g[k][e].y = fma(g[k][e].y, xx[k][e], cm.y);
-                                }
-                        }
+#pragma nounroll   // unrolled, the four antennas' loads and Horner chains are hoisted together: > 100 VGPRs spill
+                    for (int a = 0; a < NA; ++a) {
+                        cx<T> xv[PAIRS][2];
 #pragma unroll
                         for (int k = 0; k < PAIRS; ++k)
 #pragma unroll
-                            for (int e = 0; e < 2; ++e) y[r][k][e] = cfma(g[k][e], xv[k][e], y[r][k][e]);
+                            for (int e = 0; e < 2; ++e) {
+                                const int ps = pos[k][e];
+                                if (FAST)
+                                    xv[k][e] = s_x[a * N + ps];
+                                else
+                                    xv[k][e] = ps >= 0 ? s_x[a * N + ps]
+                                                       : (ps == -1 ? mk<T>(0, 0) : tail_prev[a * dmax + (-2 - ps)]);
+                            }
+#pragma unroll
+                        for (int r = 0; r < NA; ++r) {
+                            const cx<T>* c = s_coef + ((s * NA + r) * NA + a) * (K + 1);
+                            cx<T> g[PAIRS][2];
+                            if constexpr (KT > 0) {
+                                cx<T> cc[KT + 1];
+#pragma unroll
+                                for (int m = 0; m <= KT; ++m) cc[m] = c[m];
+#pragma unroll
+                                for (int k = 0; k < PAIRS; ++k)
+#pragma unroll
+                                    for (int e = 0; e < 2; ++e) {
+                                        cx<T> v = cc[KT];
+#pragma unroll
+                                        for (int m = KT - 1; m >= 0; --m) {
+                                            v.x = fma(v.x, xx[k][e], cc[m].x);
+                                            v.y = fma(v.y, xx[k][e], cc[m].y);
+                                        }
+                                        g[k][e] = v;
+                                    }
+                            } else {
+                                const cx<T> top = c[K];
+#pragma unroll
+                                for (int k = 0; k < PAIRS; ++k) g[k][0] = g[k][1] = top;
+                                for (int m = K - 1; m >= 0; --m) {
+                                    const cx<T> cm = c[m];
+#pragma unroll
+                                    for (int k = 0; k < PAIRS; ++k)
+#pragma unroll
+                                        for (int e = 0; e < 2; ++e) {
+                                            g[k][e].x = fma(g[k][e].x, xx[k][e], cm.x);
+                                            g[k][e].y = fma(g[k][e].y, xx[k][e], cm.y);
+                                        }
+                                }
+                            }
+#pragma unroll
+                            for (int k = 0; k < PAIRS; ++k)
+#pragma unroll
+                                for (int e = 0; e < 2; ++e) y[r][k][e] = cfma(g[k][e], xv[k][e], y[r][k][e]);
+                        }
                     }
+                }
+            };
+            {
+                const bool fast = cp >= dmax && (N / 2) % kPipeBlock == 0;
+                typedef std::integral_constant<int, 0> k_any;
+                typedef std::integral_constant<int, 2> k_two;
+                if (fast) {
+                    if (K == 2) channel(std::true_type{}, k_two{});
+                    else channel(std::true_type{}, k_any{});
+                } else {
+                    if (K == 2) channel(std::false_type{}, k_two{});
+                    else channel(std::false_type{}, k_any{});
                 }
             }
             // noise of the samples that survive CP removal
@@ -429,6 +470,7 @@ extern "C" int mcle_run_mimo_ofdm_tdl(mcle_ctx* ctx, int dtype, const mcle_mimo_
                   "(use the staged operator chain)", z);
         return MCLE_E_UNSUPPORTED;
     }
+    if (K < 2) K = 2;                   // order 2 is the unrolled fast path
     pp.K = K;
     {
         long double acc[kMaxOrder + 1] = {0.0L};
