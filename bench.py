@@ -28,10 +28,12 @@ if REPO not in sys.path:
 
 # algorithmic bytes per realization in the staged (operator-granular)
 # model, complex64 samples / uint8 indices.
-B_ALG = {"c2": 7_600_000, "c3": 211_360, "c4": 412_160, "c5": 62_000}
+B_ALG = {"c2": 7_600_000, "c3": 211_360, "c4": 412_160, "c5": 62_000, "f1": 3_099_008}
 HBM_PEAK_GBPS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
 SEED = 20260927
-SNR_DB = {"c1": 10.0, "c2": 20.0, "c3": 20.0, "c4": 25.0, "c5": 20.0}
+SNR_DB = {"c1": 10.0, "c2": 20.0, "c3": 20.0, "c4": 25.0, "c5": 20.0, "f1": 25.0}
+F1_TS = 1.0 / (15e3 * 1024)
+F1_TAPS_DB = (0.0, -3.0, -6.0, -9.0, -12.0)
 
 
 def parse():
@@ -39,7 +41,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="c4", choices=["c2", "c3", "c4", "c5"])
+    ap.add_argument("--config", default="c4", choices=["c2", "c3", "c4", "c5", "f1"])
     ap.add_argument("--batch", type=int, default=0, help="realizations per GPU per step")
     ap.add_argument("--demod", default="slicer", choices=["slicer", "mindist"])
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
@@ -70,6 +72,16 @@ def make_runner(eng, cfg, demod, dtype):
             eng.run_flat_fading(100000, nv, SEED, first, count, Fd=100.0, Ts=1e-3, L=8, method=method, dtype=dtype,
                                 counters=counters)
         return run, 100000, "64-QAM over flat Jakes fading (Fd 100 Hz, Ts 1 ms, L 8), 1e5 symbols, SNR 20 dB (config 2)"
+    if cfg == "f1":
+        eng.set_constellation(constellation("qam", 64), _lib.CONST_QAM)
+        from pyphysim_amd.channels import discretize_profile
+        p_lin, d_idx = discretize_profile(np.array(F1_TAPS_DB), np.arange(5) * F1_TS, F1_TS)
+
+        def run(first, count, counters):
+            eng.run_mimo_ofdm_tdl(4, 4, 1024, 16, 1024, 1, nv, p_lin, d_idx, SEED, first, count, Fd=10.0, Ts=F1_TS,
+                                  L=8, mmse=True, method=method, dtype=dtype, counters=counters)
+        return run, 4096, ("4x4 MMSE per subcarrier + 64-QAM + OFDM(1024, cp 16) over a 5-tap Jakes MIMO TDL channel "
+                           "(Fd 10 Hz), SNR 25 dB (SURVEY 8(f).1)")
     if cfg == "c5":
         eng.set_constellation(constellation("qam", 16), _lib.CONST_QAM)
 
@@ -98,6 +110,9 @@ def cpu_baseline(cfg, budget_s, gpu_first_counts):
         "c2": (chains.chain_flat_jakes, dict(mod="qam", M=64, N=100000, snr_db=20.0, Fd=100.0, Ts=1e-3, L=8)),
         "c3": (chains.chain_ofdm_tdl, dict(mod="qpsk", M=4, fft_size=1024, cp_size=16, num_used=None, n_ofdm_sym=1,
                                            snr_db=20.0, Fd=10.0, Ts=1.0 / (15e3 * 1024), L=8)),
+        "f1": (chains.chain_mimo_ofdm_tdl, dict(mod="qam", M=64, nt=4, nr=4, fft_size=1024, cp_size=16, num_used=None,
+                                                n_ofdm_sym=1, snr_db=25.0, Fd=10.0, Ts=F1_TS, L=8,
+                                                tap_powers_dB=F1_TAPS_DB, tap_delays_samples=(0, 1, 2, 3, 4))),
         "c5": (chains.chain_ia, dict(mod="qam", M=16, K=3, nr=2, nt=2, Ns=1, NSymbs=200, snr_db=20.0)),
     }[cfg]
     se = []
@@ -130,6 +145,9 @@ def _cpu_worker(job):
         "c2": (chains.chain_flat_jakes, dict(mod="qam", M=64, N=100000, snr_db=20.0, Fd=100.0, Ts=1e-3, L=8)),
         "c3": (chains.chain_ofdm_tdl, dict(mod="qpsk", M=4, fft_size=1024, cp_size=16, num_used=None, n_ofdm_sym=1,
                                            snr_db=20.0, Fd=10.0, Ts=1.0 / (15e3 * 1024), L=8)),
+        "f1": (chains.chain_mimo_ofdm_tdl, dict(mod="qam", M=64, nt=4, nr=4, fft_size=1024, cp_size=16, num_used=None,
+                                                n_ofdm_sym=1, snr_db=25.0, Fd=10.0, Ts=F1_TS, L=8,
+                                                tap_powers_dB=F1_TAPS_DB, tap_delays_samples=(0, 1, 2, 3, 4))),
         "c5": (chains.chain_ia, dict(mod="qam", M=16, K=3, nr=2, nt=2, Ns=1, NSymbs=200, snr_db=20.0)),
     }[cfg]
     t0 = time.perf_counter()
@@ -179,7 +197,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     eng = Engine(local_rank, args.dtype)
     run, units, workload = make_runner(eng, args.config, args.demod, args.dtype)
-    batch = args.batch or {"c4": 65536, "c3": 131072, "c2": 4096, "c5": 262144}[args.config]
+    batch = args.batch or {"c4": 65536, "c3": 131072, "c2": 4096, "c5": 262144, "f1": 98304}[args.config]
 
     def barrier():
         eng.sync()
@@ -235,12 +253,12 @@ def main():
                        "symbols_per_realization": units, "parallelism": "realization-sharded x%d" % world,
                        "rng": "Philox4x32-10 keyed by (seed, realization)"},
             "ser": tot[2] / float(max(1, tot[0]) * units),
-            "ber": tot[4] / float(max(1, tot[0]) * units * {"c2": 6, "c3": 2, "c4": 6, "c5": 4}[args.config]),
+            "ber": tot[4] / float(max(1, tot[0]) * units * {"c2": 6, "c3": 2, "c4": 6, "c5": 4, "f1": 6}[args.config]),
             "n_skipped": tot[1],
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "kernel": {"c4": "k_run_mimo_ofdm", "c2": "k_run_flat", "c3": "k_run_ofdm_tdl",
-                                    "c5": "k_run_ia"}[args.config],
+                                    "c5": "k_run_ia", "f1": "k_run_mimo_ofdm_tdl"}[args.config],
                          "kernel_ms_per_launch": per_launch_s * 1e3,
                          "algorithmic_bytes_per_realization": balg,
                          "traffic_source": "profiles/traffic_%s.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
@@ -291,6 +309,11 @@ def eng_first_counts(eng, args, n):
                                  per_realization=True)
     if args.config == "c2":
         return eng.run_flat_fading(100000, nv, SEED, 0, n, method=method, dtype=args.dtype, per_realization=True)
+    if args.config == "f1":
+        from pyphysim_amd.channels import discretize_profile
+        p_lin, d_idx = discretize_profile(np.array(F1_TAPS_DB), np.arange(5) * F1_TS, F1_TS)
+        return eng.run_mimo_ofdm_tdl(4, 4, 1024, 16, 1024, 1, nv, p_lin, d_idx, SEED, 0, n, Fd=10.0, Ts=F1_TS, L=8,
+                                     method=method, dtype=args.dtype, per_realization=True)
     if args.config == "c5":
         return eng.run_ia(200, nv, SEED, 0, n, method=method, dtype=args.dtype, per_realization=True)[:3]
     from pyphysim_amd.channels import discretize_profile

@@ -105,6 +105,14 @@ template <typename C> __host__ __device__ __forceinline__ C cdivide(C a, C b) {
 }
 
 // ---- wave64 reductions ---------------------------------------------------------------------
+// Hides a value's provenance from the optimiser.  Used on the thread index at the top of a phase so that the
+// LDS addresses derived from it are recomputed there (a few integer ops) instead of being hoisted out of the
+// realization loop and kept alive across every other phase, where they spill.
+__device__ __forceinline__ int opaque(int v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
 __device__ __forceinline__ unsigned wave_sum_u32(unsigned v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);

@@ -90,7 +90,10 @@ template <typename T, bool INV> __device__ __forceinline__ cx<T> rot(cx<T> a) {
 // NTHREADS > 0: the workgroup size is a compile-time constant, so the per-stage butterfly loops
 // unroll (independent LDS round trips in flight; with nf*N/4 a multiple of NTHREADS and N/4 ==
 // NTHREADS every lane runs the SAME butterfly of each transform and shares its twiddles).
-template <typename T, int N, bool INV, int NTHREADS = 0, bool SWZ = false>
+// FRESH: re-derive the butterfly addresses from an opaque thread index in every stage.  Without it the
+// optimiser hoists all stages' addresses out of the caller's realization loop -- faster as long as they fit
+// in registers (C3 / C4), a source of spills in kernels with fatter phases around the transforms.
+template <typename T, int N, bool INV, int NTHREADS = 0, bool SWZ = false, bool FRESH = false>
 __device__ __forceinline__ void fft_dif(cx<T>* s_data, int nf, int pitch, const cx<T>* tw) {
     constexpr int NB = N / 4;
     const int nthreads = NTHREADS > 0 ? NTHREADS : (int)blockDim.x;
@@ -99,7 +102,7 @@ __device__ __forceinline__ void fft_dif(cx<T>* s_data, int nf, int pitch, const 
     for (int st = 0; st < FftShape<N>::N4; ++st, s >>= 2) {
         const int twstep = N / (4 * s);
 #pragma unroll 4
-        for (int b = threadIdx.x; b < nf * NB; b += nthreads) {
+        for (int b = FRESH ? opaque((int)threadIdx.x) : (int)threadIdx.x; b < nf * NB; b += nthreads) {
             const int f = b / NB, bb = b - f * NB;
             const int k = bb & (s - 1), g = bb / s;
             cx<T>* p = s_data + f * pitch;
@@ -122,7 +125,7 @@ __device__ __forceinline__ void fft_dif(cx<T>* s_data, int nf, int pitch, const 
         __syncthreads();
     }
     if (FftShape<N>::HAS2) {
-        for (int b = threadIdx.x; b < nf * (N / 2); b += nthreads) {
+        for (int b = FRESH ? opaque((int)threadIdx.x) : (int)threadIdx.x; b < nf * (N / 2); b += nthreads) {
             const int f = b / (N / 2), bb = b - f * (N / 2);
             cx<T>* p = s_data + f * pitch;
             const int i0 = lds_swz<SWZ>(2 * bb), i1 = lds_swz<SWZ>(2 * bb + 1);
@@ -135,12 +138,12 @@ __device__ __forceinline__ void fft_dif(cx<T>* s_data, int nf, int pitch, const 
 }
 
 // ---- decimation in time: digit-reversed -> natural ------------------------------------------------
-template <typename T, int N, bool INV, int NTHREADS = 0, bool SWZ = false>
+template <typename T, int N, bool INV, int NTHREADS = 0, bool SWZ = false, bool FRESH = false>
 __device__ __forceinline__ void fft_dit(cx<T>* s_data, int nf, int pitch, const cx<T>* tw) {
     constexpr int NB = N / 4;
     const int nthreads = NTHREADS > 0 ? NTHREADS : (int)blockDim.x;
     if (FftShape<N>::HAS2) {
-        for (int b = threadIdx.x; b < nf * (N / 2); b += nthreads) {
+        for (int b = FRESH ? opaque((int)threadIdx.x) : (int)threadIdx.x; b < nf * (N / 2); b += nthreads) {
             const int f = b / (N / 2), bb = b - f * (N / 2);
             cx<T>* p = s_data + f * pitch;
             const int i0 = lds_swz<SWZ>(2 * bb), i1 = lds_swz<SWZ>(2 * bb + 1);
@@ -155,7 +158,7 @@ __device__ __forceinline__ void fft_dit(cx<T>* s_data, int nf, int pitch, const 
     for (int st = 0; st < FftShape<N>::N4; ++st, s <<= 2) {
         const int twstep = N / (4 * s);
 #pragma unroll 4
-        for (int b = threadIdx.x; b < nf * NB; b += nthreads) {
+        for (int b = FRESH ? opaque((int)threadIdx.x) : (int)threadIdx.x; b < nf * NB; b += nthreads) {
             const int f = b / NB, bb = b - f * NB;
             const int k = bb & (s - 1), g = bb / s;
             cx<T>* p = s_data + f * pitch;

@@ -33,6 +33,9 @@
 namespace mcle {
 
 constexpr int kMaxOrder = 12;
+#ifndef FFT_FRESH
+#define FFT_FRESH true
+#endif
 
 struct MimoTdlParams {
     int cp, num_used, n_ofdm_sym, mmse;
@@ -64,9 +67,9 @@ __global__ __launch_bounds__(kPipeBlock, sizeof(T) == 4 ? 3 : 1) void k_run_mimo
                                                   kMaxTable * (sizeof(T) == 4 ? sizeof(float4) : sizeof(cx<T>)));
     unsigned char* s_idx = reinterpret_cast<unsigned char*>(s_red + 16);   // [NA*num_used]
 
-    const int tid = threadIdx.x;
-    for (int k = tid; k < N; k += kPipeBlock) s_tw[k] = g_tw[k];
-    for (int m = tid; m < mp.M; m += kPipeBlock) {
+    const int tid0 = threadIdx.x;
+    for (int k = tid0; k < N; k += kPipeBlock) s_tw[k] = g_tw[k];
+    for (int m = tid0; m < mp.M; m += kPipeBlock) {
         const cx<T> c = mp.g_table[m];
         if constexpr (sizeof(T) == 4)
             s_tab4[m] = make_float4((float)c.x, (float)c.y, (float)(0.5 * (c.x * c.x + c.y * c.y)), 0.f);
@@ -92,13 +95,14 @@ __global__ __launch_bounds__(kPipeBlock, sizeof(T) == 4 ? 3 : 1) void k_run_mimo
     const uint32_t mask = (uint32_t)(mp.M - 1);
     const double xc = 0.5 * (double)(W - 1);                      // centre of the symbol in local sample units
     __shared__ WgTotals totals;
-    if (tid == 0) wg_zero(totals);
+    if (tid0 == 0) wg_zero(totals);
 
     for (uint64_t rl = blockIdx.x; rl < count; rl += gridDim.x) {
         const Rng rng(seed, first + rl);
         unsigned se = 0, be = 0;
         for (int os = 0; os < pp.n_ofdm_sym; ++os) {
             const uint64_t sym0 = (uint64_t)os * W;
+            const int tid = opaque(tid0);
             __syncthreads();
             // ---- polynomial coefficients of every fading process around the middle of this symbol ----
             // (1) one ray per thread: phasor at the symbol centre and phase advance per sample, parked in the
@@ -186,15 +190,16 @@ __global__ __launch_bounds__(kPipeBlock, sizeof(T) == 4 ? 3 : 1) void k_run_mimo
                 }
             }
             __syncthreads();
-            fft_dif<T, N, true, kPipeBlock, true>(s_x, NA, N, s_tw);   // time samples, digit-reversed positions
+            fft_dif<T, N, true, kPipeBlock, true, FFT_FRESH>(s_x, NA, N, s_tw);   // time samples, digit-reversed positions
             auto time_sample = [&](int a, int i) -> cx<T> {             // IFFT output i of antenna a
                 return s_x[a * N + lds_swz<true>(fft_pos_of_index<N>(i & (N - 1)))];
             };
+            const int tid_c = opaque(tid0);      // channel phase: nothing derived from it outlives the next FFT
             // the last dmax samples of this symbol feed the head of the next one
             cx<T>* tail_prev = s_tail + (size_t)(os & 1) * NA * dmax;
             cx<T>* tail_next = s_tail + (size_t)((os + 1) & 1) * NA * dmax;
             if (os + 1 < pp.n_ofdm_sym)
-                for (int q = tid; q < NA * dmax; q += kPipeBlock) {
+                for (int q = tid_c; q < NA * dmax; q += kPipeBlock) {
                     const int a = q / dmax, i = q - a * dmax;
                     tail_next[q] = time_sample(a, N - dmax + i);
                 }
@@ -219,7 +224,7 @@ __global__ __launch_bounds__(kPipeBlock, sizeof(T) == 4 ? 3 : 1) void k_run_mimo
                     for (int k = 0; k < PAIRS; ++k)
 #pragma unroll
                         for (int e = 0; e < 2; ++e) {
-                            const int m = 2 * (tid + kPipeBlock * k) + e;
+                            const int m = 2 * (tid_c + kPipeBlock * k) + e;
                             const int q = cp + m - d;                // local index of the input sample
                             xx[k][e] = (T)((double)q - xc);
                             if (FAST || (m < N && q >= 0))
@@ -301,7 +306,7 @@ __global__ __launch_bounds__(kPipeBlock, sizeof(T) == 4 ? 3 : 1) void k_run_mimo
             // noise of the samples that survive CP removal
 #pragma unroll
             for (int k = 0; k < PAIRS; ++k) {
-                const int m0 = 2 * (tid + kPipeBlock * k);
+                const int m0 = 2 * (tid_c + kPipeBlock * k);
                 if (m0 < N) {
 #pragma unroll
                     for (int r = 0; r < NA; ++r) {
@@ -321,7 +326,7 @@ __global__ __launch_bounds__(kPipeBlock, sizeof(T) == 4 ? 3 : 1) void k_run_mimo
             __syncthreads();   // every read of the transmit samples is done: overwrite in place
 #pragma unroll
             for (int k = 0; k < PAIRS; ++k) {
-                const int m0 = 2 * (tid + kPipeBlock * k);
+                const int m0 = 2 * (tid_c + kPipeBlock * k);
                 if (m0 < N) {
                     const int q0 = lds_swz<true>(fft_pos_of_index<N>(m0));
                     const int q1 = lds_swz<true>(fft_pos_of_index<N>(m0 + 1));
@@ -333,9 +338,10 @@ __global__ __launch_bounds__(kPipeBlock, sizeof(T) == 4 ? 3 : 1) void k_run_mimo
                 }
             }
             __syncthreads();
-            fft_dit<T, N, false, kPipeBlock, true>(s_x, NA, N, s_tw);   // bins, natural order
+            fft_dit<T, N, false, kPipeBlock, true, FFT_FRESH>(s_x, NA, N, s_tw);   // bins, natural order
             // ---- receive: frequency response, filter, decode, demodulate, count -- one subcarrier per thread ----
-            for (int d = tid; d < U; d += kPipeBlock) {
+            const int tid_r = opaque(tid0);
+            for (int d = tid_r; d < U; d += kPipeBlock) {
                 const int f = ofdm_bin(d, N, U);
                 cx<T> H[NA][NA];
 #pragma unroll
@@ -375,9 +381,9 @@ __global__ __launch_bounds__(kPipeBlock, sizeof(T) == 4 ? 3 : 1) void k_run_mimo
             }
         }
         block_sum2(se, be, s_red);
-        if (tid == 0) wg_account(totals, se, be, false, rl, sym_out, bit_out);
+        if (tid0 == 0) wg_account(totals, se, be, false, rl, sym_out, bit_out);
     }
-    if (tid == 0)
+    if (tid0 == 0)
         wg_flush(totals, counters, (unsigned long long)per_sym * pp.n_ofdm_sym,
                  (unsigned long long)per_sym * pp.n_ofdm_sym * mp.bits);
 }

@@ -2,7 +2,8 @@
 """Condense gpurun_out/ (rocprofv3 csv + bench json) into the tracked profiles/<round>/ summaries.
 
 usage: python scripts/collect_profiles.py r01
-Also writes profiles/traffic_c4.json, which bench.py reads for roofline.traffic:
+For each profiled config (c4: k_run_mimo_ofdm, f1: k_run_mimo_ofdm_tdl) writes <cfg>_kernel_stats.csv,
+<cfg>_pmc_summary.json and profiles/traffic_<cfg>.json, which bench.py reads for roofline.traffic:
 hbm_bytes_per_launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024, following
 /opt/skills/guides/MI355X_MICROARCH.md (rocprofv3 counts KiB; on gfx950 FETCH_SIZE reports half of
 a coalesced stream's bytes, WRITE_SIZE is uncalibrated).
@@ -21,23 +22,41 @@ src = os.path.join(REPO, "gpurun_out")
 dst = os.path.join(REPO, "profiles", rnd)
 os.makedirs(dst, exist_ok=True)
 
-stats = os.path.join(src, "prof_stats", "c4_kernel_stats.csv")
-if os.path.exists(stats):
-    shutil.copy(stats, os.path.join(dst, "c4_kernel_stats.csv"))
+CONFIGS = {
+    "c4": ("k_run_mimo_ofdm<", "k_run_mimo_ofdm<float,1024,4>, %d realizations per launch (bench.py default workload)"),
+    "f1": ("k_run_mimo_ofdm_tdl<", "k_run_mimo_ofdm_tdl<float,1024,4>, %d realizations per launch (bench.py --config f1)"),
+}
 
-summary = {}
-meta = {}
-for path in sorted(glob.glob(os.path.join(src, "prof_*", "c4_counter_collection.csv"))):
-    agg = collections.defaultdict(list)
-    for row in csv.DictReader(open(path)):
-        if "k_run_mimo_ofdm" in row["Kernel_Name"]:
-            agg[row["Counter_Name"]].append(float(row["Counter_Value"]))
-            meta = {k: row[k] for k in ("Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count",
-                                        "Accum_VGPR_Count", "SGPR_Count", "Scratch_Size")}
-    for name, vals in agg.items():
-        summary[name] = {"launches": len(vals), "mean_per_launch": sum(vals) / len(vals), "min": min(vals),
-                         "max": max(vals)}
-if summary:
+
+def first(pattern):
+    hits = sorted(glob.glob(pattern, recursive=True))
+    return hits[0] if hits else None
+
+
+for cfg, (needle, label) in CONFIGS.items():
+    stats = first(os.path.join(src, "prof_%s_stats" % cfg, "**", "%s_kernel_stats.csv" % cfg))
+    if stats:
+        shutil.copy(stats, os.path.join(dst, "%s_kernel_stats.csv" % cfg))
+    summary, meta = {}, {}
+    for path in sorted(glob.glob(os.path.join(src, "prof_%s_*" % cfg, "**", "%s_counter_collection.csv" % cfg),
+                                 recursive=True)):
+        agg = collections.defaultdict(list)
+        for row in csv.DictReader(open(path)):
+            if needle in row["Kernel_Name"]:
+                agg[row["Counter_Name"]].append(float(row["Counter_Value"]))
+                meta = {k: row[k] for k in ("Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count",
+                                            "Accum_VGPR_Count", "SGPR_Count", "Scratch_Size")}
+        for name, vals in agg.items():
+            summary[name] = {"launches": len(vals), "mean_per_launch": sum(vals) / len(vals), "min": min(vals),
+                             "max": max(vals)}
+    if not summary:
+        continue
+    per_launch = 65536
+    bj = os.path.join(src, "bench_%s.json" % ("c4_slicer" if cfg == "c4" else cfg))
+    try:
+        per_launch = json.loads(open(bj).read().strip().splitlines()[-1])["config"]["realizations_per_step_per_gpu"]
+    except Exception:
+        pass
     g = lambda k: summary.get(k, {}).get("mean_per_launch")
     derived = {}
     if g("SQ_ACTIVE_INST_VALU") and g("SQ_WAVE_CYCLES"):
@@ -48,20 +67,29 @@ if summary:
         derived["wait_inst_any_frac"] = g("SQ_WAIT_INST_ANY") / g("SQ_WAVE_CYCLES")
     if g("FETCH_SIZE") is not None and g("WRITE_SIZE") is not None:
         derived["hbm_bytes_per_launch"] = (2.0 * g("FETCH_SIZE") + g("WRITE_SIZE")) * 1024.0
+        derived["hbm_bytes_per_realization"] = derived["hbm_bytes_per_launch"] / per_launch
     summary["_derived"] = derived
-    summary["_kernel"] = "k_run_mimo_ofdm<float,1024,4>, 65536 realizations per launch (bench.py default workload)"
+    summary["_kernel"] = label % per_launch
     summary["_dispatch"] = meta
-    json.dump(summary, open(os.path.join(dst, "c4_pmc_summary.json"), "w"), indent=1)
+    json.dump(summary, open(os.path.join(dst, "%s_pmc_summary.json" % cfg), "w"), indent=1)
     if "hbm_bytes_per_launch" in derived:
-        json.dump({"hbm_bytes_per_launch": derived["hbm_bytes_per_launch"], "realizations_per_launch": 65536,
-                   "source": "profiles/%s/c4_pmc_summary.json" % rnd,
+        json.dump({"hbm_bytes_per_launch": derived["hbm_bytes_per_launch"], "realizations_per_launch": per_launch,
+                   "source": "profiles/%s/%s_pmc_summary.json" % (rnd, cfg),
                    "rule": "(2*FETCH_SIZE + WRITE_SIZE) KiB per MI355X_MICROARCH.md"},
-                  open(os.path.join(REPO, "profiles", "traffic_c4.json"), "w"), indent=1)
+                  open(os.path.join(REPO, "profiles", "traffic_%s.json" % cfg), "w"), indent=1)
+    print(cfg, json.dumps(derived, indent=1), json.dumps(meta))
+
+staged = first(os.path.join(src, "prof_f1staged_stats", "**", "f1staged_kernel_stats.csv"))
+if staged:
+    shutil.copy(staged, os.path.join(dst, "staged_f1_kernel_stats.csv"))
+sj = os.path.join(src, "staged_f1.json")
+if os.path.exists(sj):
+    lines = [l for l in open(sj).read().strip().splitlines() if l.startswith("{")]
+    if lines:
+        open(os.path.join(dst, "staged_f1.json"), "w").write(lines[-1] + "\n")
 
 for path in sorted(glob.glob(os.path.join(src, "bench_*.json"))):
     lines = [l for l in open(path).read().strip().splitlines() if l.startswith("{")]
     if lines:
         open(os.path.join(dst, os.path.basename(path)), "w").write(lines[-1] + "\n")
 print("wrote", sorted(os.listdir(dst)))
-if summary:
-    print(json.dumps(summary["_derived"], indent=1), json.dumps(meta))

@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 timeout 1200 python -m pytest tests -m gpu -q --timeout=900 > gpurun_out/pytest_gpu.log 2>&1
 echo "pytest rc=$?" >> gpurun_out/pytest_gpu.log
 tail -5 gpurun_out/pytest_gpu.log
-for cfg in "c4 --demod slicer" "c4 --demod mindist" "c3" "c2" "c5"; do
+for cfg in "c4 --demod slicer" "c4 --demod mindist" "c3" "c2" "c5" "f1"; do
   name=${cfg// /_}; name=${name//--demod_/}
   timeout 600 python bench.py --steps 10 --warmup 2 --no-cpu --config $cfg > gpurun_out/bench_$name.json 2> gpurun_out/bench_$name.err
   echo "== $cfg rc=$?"; python - "gpurun_out/bench_$name.json" <<'PY'
@@ -25,10 +25,13 @@ if [ "$mode" = "full" ] || [ "$mode" = "prof" ]; then
   echo "default bench rc=$?"; tail -c 1500 gpurun_out/bench_default.json
 fi
 if [ "$mode" = "prof" ]; then
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_stats -o c4 -- python bench.py --steps 10 --warmup 2 --no-cpu > gpurun_out/prof_stats.log 2>&1
-  for pmc in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_LDS" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_SALU SQ_WAIT_INST_LDS"; do
-    tag=$(echo $pmc | cut -d' ' -f1)
-    timeout 600 rocprofv3 --pmc $pmc --output-format csv -d gpurun_out/prof_$tag -o c4 -- python bench.py --steps 3 --warmup 1 --no-cpu > gpurun_out/prof_$tag.log 2>&1
-    echo "pmc $tag rc=$?"
+  for cfg in c4 f1; do
+    timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${cfg}_stats -o $cfg -- python bench.py --config $cfg --steps 10 --warmup 2 --no-cpu > gpurun_out/prof_${cfg}_stats.log 2>&1
+    for pmc in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_LDS" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_SALU SQ_WAIT_INST_LDS"; do
+      tag=$(echo $pmc | cut -d' ' -f1)
+      timeout 600 rocprofv3 --pmc $pmc --output-format csv -d gpurun_out/prof_${cfg}_$tag -o $cfg -- python bench.py --config $cfg --steps 3 --warmup 1 --no-cpu > gpurun_out/prof_${cfg}_$tag.log 2>&1
+      echo "pmc $cfg $tag rc=$?"
+    done
   done
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_f1staged_stats -o f1staged -- python scripts/bench_staged_f1.py --batch 2048 --steps 5 > gpurun_out/staged_f1.json 2> gpurun_out/prof_f1staged.log
 fi
