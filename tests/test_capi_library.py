@@ -45,6 +45,19 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(_lib.MimoOfdmCfg) == 40
     assert ctypes.sizeof(_lib.IaCfg) == 32
     assert ctypes.sizeof(_lib.OfdmTdlCfg) == 32 + 24 + 24 * 8 + 24 * 4
+    assert ctypes.sizeof(_lib.MimoOfdmTdlCfg) == 40 + 24 + 24 * 8 + 24 * 4
+
+
+def test_integration_map_names_every_entry_point():
+    """INTEGRATION.md is the maintainer's map: every exported function has to appear in it."""
+    text = open(os.path.join(REPO, "INTEGRATION.md")).read()
+    groups = {"mcle_ctx_create": "mcle_ctx_create", "mcle_malloc": "mcle_malloc", "mcle_free": "`mcle_malloc` / `free`",
+              "mcle_memcpy_h2d": "memcpy_*", "mcle_memcpy_d2h": "memcpy_*", "mcle_memset": "`memset`",
+              "mcle_ctx_destroy": "`destroy`", "mcle_ctx_set_stream": "`set_stream`",
+              "mcle_ctx_get_stream": "`get_stream`", "mcle_ctx_sync": "`sync`",
+              "mcle_ctx_device_info": "`device_info`", "mcle_timer_stop_ms": "`stop_ms`"}
+    missing = [n for n in header_functions() if n not in text and groups.get(n, "\0") not in text]
+    assert not missing, missing
 
 
 def test_no_device_is_a_loud_error():
