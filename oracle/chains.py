@@ -55,7 +55,8 @@ class LegacyRng3(LegacyRng):
     def __init__(self, seed):
         super().__init__(seed)
         self.by_stream = {philox.STREAM_CHAN: np.random.RandomState(seed),
-                          philox.STREAM_NOISE: np.random.RandomState(seed)}
+                          philox.STREAM_NOISE: np.random.RandomState(seed),
+                          3: np.random.RandomState(seed)}       # the iterative solvers' own RandomState
 
     def cn(self, stream, *shape):
         rs = self.by_stream[stream]
@@ -236,6 +237,40 @@ def chain_ia(rng, mod='qam', M=16, K=3, nr=2, nt=2, Ns=1, NSymbs=200, snr_db=20.
                F=np.stack([f.reshape(-1) for f in F]) if Ns == 1 else None,
                U=np.stack([u.reshape(-1) for u in U]) if Ns == 1 else None,
                sinr=np.concatenate(sinr))
+    return _counts(out, idx, dec, M)
+
+
+STREAM_INIT = 3    # the solver's own RandomState (iabase.py:95); shares the PHASE stream id, unused in config 5
+
+
+def chain_ia_iterative(rng, algo='alt_min', mod='qam', M=16, K=3, nr=2, nt=2, Ns=1, NSymbs=200, snr_db=20.0,
+                       max_iterations=50, relative_factor=1e-6):
+    """apps/ia/simulate_ia.py:94-245 with an iterative solver
+    (AlternatingMinIASolver / MinLeakageIASolver / MaxSinrIASolver, initialize_with='random')."""
+    table = constellation(mod, M)
+    noise_var = 1.0 / float(omodem.dB2Linear(snr_db))
+    big_H = rng.cn(philox.STREAM_CHAN, K * nr, K * nt)
+    H = oia.split_blocks(big_H, K, nr, nt)
+    F_init = []
+    for k in range(K):                       # randomizeF (iabase.py:538-540): normalized(randn_c_RS(rs, Nt, Ns))
+        f = rng.cn(STREAM_INIT, nt, Ns)
+        F_init.append(f / np.linalg.norm(f, "fro"))
+    F, U, cap, sinr, runned = oia.iterative_solve(algo, H, F_init, noise_var, max_iterations, relative_factor)
+    if rng.legacy:
+        idx = rng.rs.randint(0, M, [K * Ns, NSymbs])
+    else:
+        idx = rng.symbols(K * Ns * NSymbs, M).reshape(K * Ns, NSymbs)
+    sym = omodem.modulate(table, idx)
+    X = np.vstack([F[k] @ sym[k * Ns:(k + 1) * Ns] for k in range(K)])
+    noise = rng.cn(philox.STREAM_NOISE, K * nr, NSymbs)
+    Y = oia.mu_corrupt(big_H, X, noise, noise_var)
+    est = np.vstack([U[k] @ Y[k * nr:(k + 1) * nr] for k in range(K)])
+    dec = omodem.demodulate(table, est)
+    out = dict(table=table, big_H=big_H, idx=idx, noise=noise, est=est, noise_var=noise_var, sum_capacity=cap,
+               F_init=np.stack([f.reshape(-1) for f in F_init]) if Ns == 1 else None,
+               F=np.stack([f.reshape(-1) for f in F]) if Ns == 1 else None,
+               U=np.stack([u.reshape(-1) for u in U]) if Ns == 1 else None,
+               sinr=np.concatenate(sinr), runned_iterations=runned)
     return _counts(out, idx, dec, M)
 
 

@@ -97,3 +97,165 @@ def closed_form_solve(H, Ns, noise_var, use_best_init=True):
 def mu_corrupt(big_H, X, noise, noise_var):
     """multiuser.py:1206-1213: big_H @ vstack(X) + sqrt(noise_var) * noise."""
     return big_H @ X + np.sqrt(noise_var) * noise
+
+
+# ---- iterative solvers (SURVEY.md section 8(f).3) -----------------------------------------------------
+# pyphysim/ia/algorithms.py:271-883   IterativeIASolverBaseClass (solve loop, _is_diff_significant)
+# pyphysim/ia/algorithms.py:885-1129  AlternatingMinIASolver (_updateC / _updateF / _updateW)
+# pyphysim/ia/algorithms.py:1132-1240 MinLeakageIASolver
+# pyphysim/ia/algorithms.py:1243-1507 MaxSinrIASolver
+# pyphysim/ia/iabase.py:600-667       calc_Q / calc_Q_rev;  channels/multiuser.py:1345-1382 (noise term of Q)
+# pyphysim/util/misc.py:161-255       peig / leig
+# P = 1 for every user (apps/ia/simulate_ia.py:120 calls solve(Ns) without P), so full_F = F.
+def peig(A, n):
+    D, V = np.linalg.eig(A)
+    order = np.argsort(D.real)[::-1]
+    return V[:, order[0:n]], D[order[0:n]]
+
+
+def _calc_Q(H, F, k, noise_var):
+    """interference covariance at receiver k (+ noise_var I: multiuser.py:1376-1380)."""
+    K = len(F)
+    Q = np.zeros((H[k][k].shape[0],) * 2, dtype=complex)
+    for l in range(K):
+        if l != k:
+            a = H[k][l] @ F[l]
+            Q = Q + a @ a.conj().T
+    if noise_var is not None:
+        Q = Q + np.eye(Q.shape[0]) * noise_var
+    return Q
+
+
+def _calc_Q_rev(H, W, k):
+    K = len(W)
+    Q = np.zeros((H[k][k].shape[1],) * 2, dtype=complex)
+    for l in range(K):
+        if l != k:
+            a = H[l][k].conj().T @ W[l]
+            Q = Q + a @ a.conj().T
+    return Q
+
+
+def is_diff_significant(F_old, F_new, relative_factor):
+    for fo, fn in zip(F_old, F_new):
+        if np.abs(fn - fo).max() > np.abs(fn).min() * relative_factor:
+            return True
+    return False
+
+
+def _iterate(F, step, max_iterations, relative_factor):
+    """algorithms.py:857-869."""
+    old_F = F
+    runned = 0
+    state = None
+    for _ in range(max_iterations):
+        runned += 1
+        F, state = step(F, state)
+        if not is_diff_significant(old_F, F, relative_factor):
+            break
+        old_F = F
+    return F, state, runned
+
+
+def alt_min_solve(H, F_init, noise_var, max_iterations=50, relative_factor=1e-6):
+    """-> (F, W_H rows, runned_iterations); Ns taken from F_init."""
+    K = len(F_init)
+    Ns = [f.shape[1] for f in F_init]
+    Nr = [H[k][k].shape[0] for k in range(K)]
+
+    def update_C(F):
+        return [peig(_calc_Q(H, F, k, noise_var), Nr[k] - Ns[k])[0] for k in range(K)]
+
+    def step(F, C):
+        if C is None:
+            C = update_C(F)                    # _before_initialize_W_func of the initialisation
+        Y = [np.eye(Nr[k], dtype=complex) - C[k] @ C[k].conj().T for k in range(K)]
+        newF = [0] * K
+        for (l, k) in itertools.permutations(range(K), 2):
+            newF[l] = newF[l] + H[k][l].conj().T @ Y[k] @ H[k][l]
+        F = []
+        for k in range(K):
+            f = leig(newF[k], Ns[k])[0]
+            F.append(f / np.linalg.norm(f, "fro"))
+        return F, update_C(F)
+
+    F0 = [np.asarray(f, dtype=complex) for f in F_init]
+    F, C, runned = _iterate(F0, step, max_iterations, relative_factor)
+    if C is None:
+        C = update_C(F)
+    W_H = [np.linalg.inv(np.hstack([H[k][k] @ F[k], C[k]]))[0:Ns[k]] for k in range(K)]
+    return F, W_H, runned
+
+
+def min_leakage_solve(H, F_init, noise_var, max_iterations=50, relative_factor=1e-6):
+    K = len(F_init)
+    Ns = [f.shape[1] for f in F_init]
+
+    def update_W(F):
+        return [leig(_calc_Q(H, F, k, noise_var), Ns[k])[0] for k in range(K)]
+
+    def step(F, W):
+        if W is None:
+            W = update_W(F)
+        F = [leig(_calc_Q_rev(H, W, k), Ns[k])[0] for k in range(K)]
+        return F, update_W(F)
+
+    F0 = [np.asarray(f, dtype=complex) for f in F_init]
+    F, W, runned = _iterate(F0, step, max_iterations, relative_factor)
+    if W is None:
+        W = update_W(F)
+    return F, [w.conj().T for w in W], runned
+
+
+def max_sinr_solve(H, F_init, noise_var, max_iterations=50, relative_factor=1e-6):
+    """Ns = 1 per user is what the kernel covers; the restatement keeps the per-stream loop."""
+    K = len(F_init)
+
+    def calc_U(Hkk_of, V, chan):
+        """chan(k, j): channel seen by 'receiver' k from 'transmitter' j in the (possibly reversed) network."""
+        out = []
+        for k in range(K):
+            first = 0.0
+            for j in range(K):
+                a = chan(k, j) @ V[j]
+                first = first + a @ a.conj().T
+            Hkk = Hkk_of(k)
+            U = np.zeros((Hkk.shape[0], V[k].shape[1]), dtype=complex)
+            for l in range(V[k].shape[1]):
+                v = V[k][:, l:l + 1]
+                a = Hkk @ v
+                B = first - a @ a.conj().T + noise_var * np.eye(Hkk.shape[0])
+                u = np.linalg.solve(B, Hkk @ v)
+                U[:, l] = (u / np.linalg.norm(u, "fro"))[:, 0]
+            out.append(U / np.linalg.norm(U, "fro"))
+        return out
+
+    fwd = lambda k, j: H[k][j]
+    rev = lambda k, j: H[j][k].conj().T
+
+    def update_W(F):
+        return calc_U(lambda k: H[k][k], F, fwd)
+
+    def step(F, W):
+        if W is None:
+            W = update_W(F)
+        F = calc_U(lambda k: H[k][k].conj().T, W, rev)
+        return F, update_W(F)
+
+    F0 = [np.asarray(f, dtype=complex) for f in F_init]
+    F, W, runned = _iterate(F0, step, max_iterations, relative_factor)
+    if W is None:
+        W = update_W(F)
+    return F, [w.conj().T for w in W], runned
+
+
+ITERATIVE = {"alt_min": alt_min_solve, "min_leakage": min_leakage_solve, "max_sinr": max_sinr_solve}
+
+
+def iterative_solve(algo, H, F_init, noise_var, max_iterations=50, relative_factor=1e-6):
+    """-> (F, U = full_W_H, sum capacity, SINRs, runned_iterations)."""
+    F, W_H, runned = ITERATIVE[algo](H, F_init, noise_var, max_iterations, relative_factor)
+    U = [np.linalg.solve(W_H[k] @ (H[k][k] @ F[k]), W_H[k]) for k in range(len(F))]
+    sinr = calc_SINR(H, F, U, noise_var)
+    cap = float(np.sum([np.sum(np.log2(1 + s)) for s in sinr]))
+    return F, U, cap, sinr, runned

@@ -98,7 +98,7 @@ def test_blast(golden_ops):
 
 
 CHAIN_FN = {"c1_awgn": chains.chain_awgn, "c2_flat_jakes": chains.chain_flat_jakes,
-            "c3_ofdm_tdl": chains.chain_ofdm_tdl, "c4_mimo_ofdm": chains.chain_mimo_ofdm, "c5_ia": chains.chain_ia,
+            "c3_ofdm_tdl": chains.chain_ofdm_tdl, "c4_mimo_ofdm": chains.chain_mimo_ofdm, "c5_ia": chains.chain_ia, "f3_ia_iterative": chains.chain_ia_iterative,
             "f1_mimo_ofdm_tdl": chains.chain_mimo_ofdm_tdl}
 
 
@@ -106,7 +106,7 @@ CHAIN_FN = {"c1_awgn": chains.chain_awgn, "c2_flat_jakes": chains.chain_flat_jak
 def test_chain_matches_reference(name):
     for kw, reals in golden_cases(name):
         for g in reals:
-            rng_cls = chains.LegacyRng3 if name == "c5_ia" else chains.LegacyRng
+            rng_cls = chains.LegacyRng3 if name in ("c5_ia", "f3_ia_iterative") else chains.LegacyRng
             mine = CHAIN_FN[name](rng_cls(int(g["seed"])), **kw)
             for k, v in g.items():
                 if k == "seed":
@@ -114,7 +114,8 @@ def test_chain_matches_reference(name):
                 if k in INT_KEYS:
                     assert np.array_equal(np.asarray(mine[k]), np.asarray(v)), (name, k)
                 else:
-                    assert relerr(mine[k], v) <= (1e-9 if name in ("c5_ia", "f1_mimo_ofdm_tdl") else 1e-12), (name, k)
+                    tol = 1e-7 if name == "f3_ia_iterative" else (1e-9 if name in ("c5_ia", "f1_mimo_ofdm_tdl") else 1e-12)
+                    assert relerr(mine[k], v) <= tol, (name, k)
 
 
 def test_onetap_fast_form_equals_literal():
