@@ -257,11 +257,19 @@ typedef struct mcle_mimo_ofdm_tdl_cfg { /* TdlMimoChannel (fading
     int32_t tap_delay[MCLE_MAX_TAPS];   /* samples, ascending, < fft_size */
 } mcle_mimo_ofdm_tdl_cfg;
 
+enum { MCLE_IA_CLOSED_FORM = 0,  /* ClosedFormIASolver      ia/algorithms.py:42-265    */
+       MCLE_IA_ALT_MIN = 1,      /* AlternatingMinIASolver  ia/algorithms.py:885-1129  */
+       MCLE_IA_MIN_LEAKAGE = 2,  /* MinLeakageIASolver      ia/algorithms.py:1132-1240 */
+       MCLE_IA_MAX_SINR = 3 };   /* MaxSinrIASolver         ia/algorithms.py:1243-1507 */
+
 typedef struct mcle_ia_cfg {            /* C5: apps/ia/simulate_ia.py:94-245, ClosedFormIASolver */
     int32_t K, nr, nt, ns;              /* supported: K = 3, nr = nt = 2, ns = 1 */
     int32_t n_symbols;                  /* NSymbs per stream */
     int32_t demod_method;
     double noise_var;
+    int32_t solver;                     /* MCLE_IA_*: closed form or an iterative solver (initialize_with='random') */
+    int32_t max_iterations;             /* iterative solvers: IterativeIASolverBaseClass.max_iterations */
+    double relative_factor;             /* ... and .relative_factor (algorithms.py:316-322) */
 } mcle_ia_cfg;
 
 /* Each run_* processes realizations [first, first+count) of `seed`, ADDS into d_counters[0]
@@ -286,9 +294,11 @@ int mcle_run_mimo_ofdm_tdl(mcle_ctx* ctx, int dtype, const mcle_mimo_ofdm_tdl_cf
                            uint32_t* d_sym_err, uint32_t* d_bit_err);
 
 /* d_sum_capacity (may be NULL): per-realization sum_k log2(1 + SINR_k) of the chosen solution */
+/* d_iterations (may be NULL): per-realization runned_iterations of an iterative solver.  Iterative solvers
+ * draw their random initial precoders (randomizeF, iabase.py:538-540) from stream 3 of the realization. */
 int mcle_run_ia(mcle_ctx* ctx, int dtype, const mcle_ia_cfg* cfg, uint64_t seed, uint64_t first,
                 uint64_t count, mcle_counters* d_counters, uint32_t* d_sym_err, uint32_t* d_bit_err,
-                double* d_sum_capacity);
+                double* d_sum_capacity, uint32_t* d_iterations);
 
 /* ---- a15: ClosedFormIASolver.solve (ia/algorithms.py:194-265) on injected channels, f64 only:
  *      d_bigH [batch][6][6] (MultiUserChannelMatrix.big_H, K = 3, 2x2) -> precoders d_F
@@ -296,6 +306,12 @@ int mcle_run_ia(mcle_ctx* ctx, int dtype, const mcle_ia_cfg* cfg, uint64_t seed,
  *      d_sinr [batch][3] and sum capacity d_capacity [batch] (both may be NULL) ------------------ */
 int mcle_ia_closed_form(mcle_ctx* ctx, const void* d_bigH, double noise_var, void* d_F, void* d_U,
                         double* d_sinr, double* d_capacity, uint32_t* d_skipped, size_t batch);
+/* Iterative solvers (solver = MCLE_IA_ALT_MIN / MIN_LEAKAGE / MAX_SINR) from injected initial precoders
+ * d_F_init [batch][3][2] (unit norm; initialize_with='fix'): IterativeIASolverBaseClass.solve
+ * (algorithms.py:802-883).  d_iterations [batch] (may be NULL) = runned_iterations. */
+int mcle_ia_iterative(mcle_ctx* ctx, int solver, const void* d_bigH, const void* d_F_init, double noise_var,
+                      int max_iterations, double relative_factor, void* d_F, void* d_U, double* d_sinr,
+                      double* d_capacity, uint32_t* d_iterations, uint32_t* d_skipped, size_t batch);
 
 /* ---- same-seed parity mode: NumPy's legacy global RandomState replayed on the device -------
  * Realization r receives exactly what the reference draws after np.random.seed(seed_base + r)

@@ -72,7 +72,11 @@ class MimoOfdmTdlCfg(Structure):
 
 class IaCfg(Structure):
     _fields_ = [("K", c_int32), ("nr", c_int32), ("nt", c_int32), ("ns", c_int32), ("n_symbols", c_int32),
-                ("demod_method", c_int32), ("noise_var", c_double)]
+                ("demod_method", c_int32), ("noise_var", c_double), ("solver", c_int32),
+                ("max_iterations", c_int32), ("relative_factor", c_double)]
+
+
+IA_SOLVERS = {"closed_form": 0, "alt_min": 1, "min_leakage": 2, "max_sinr": 3}
 
 
 class LegacySeg(Structure):
@@ -142,7 +146,8 @@ _PROTOS = {
     "mcle_run_mimo_ofdm": (c_int, [_P, c_int, POINTER(MimoOfdmCfg), c_uint64, c_uint64, c_uint64, _P, _P, _P]),
     "mcle_run_mimo_ofdm_tdl": (c_int, [_P, c_int, POINTER(MimoOfdmTdlCfg), c_uint64, c_uint64, c_uint64, _P, _P,
                                        _P]),
-    "mcle_run_ia": (c_int, [_P, c_int, POINTER(IaCfg), c_uint64, c_uint64, c_uint64, _P, _P, _P, _P]),
+    "mcle_run_ia": (c_int, [_P, c_int, POINTER(IaCfg), c_uint64, c_uint64, c_uint64, _P, _P, _P, _P, _P]),
+    "mcle_ia_iterative": (c_int, [_P, c_int, _P, _P, c_double, c_int, c_double, _P, _P, _P, _P, _P, _P, c_size_t]),
     "mcle_ia_closed_form": (c_int, [_P, _P, c_double, _P, _P, _P, _P, _P, c_size_t]),
     "mcle_legacy_draws": (c_int, [_P, POINTER(LegacySeg), c_int, c_uint32, c_uint64, c_uint64, _P, c_size_t, _P,
                                   c_size_t, _P]),

@@ -138,6 +138,184 @@ __device__ __forceinline__ IaSolution ia_closed_form(const M2 (&H)[3][3], double
     return s;
 }
 
+// ---- iterative solvers on the same 2x2 / one-stream geometry ----------------------
+// Reference: ia/algorithms.py:802-883 (solve loop, _is_diff_significant :755-800), :1010-1129 (alternating
+// minimisation), :1173-1240 (minimum leakage), :1265-1507 (max SINR); ia/iabase.py:600-667 (Q, Q_rev).
+// Eigenvectors follow the LAPACK convention above, so the precoder phases -- which rotate the post-filter
+// noise -- are the reference's.  The noise_var * I term the reference adds to Q (multiuser.py:1376-1380) only
+// shifts the eigenvalues and is left out.
+enum { IA_CLOSED_FORM = 0, IA_ALT_MIN = 1, IA_MIN_LEAKAGE = 2, IA_MAX_SINR = 3 };
+
+__device__ __forceinline__ M2 outer2(const V2& a) {  // a a^H
+    M2 r;
+    r.a = mk<double>(cabs2(a.x), 0.0);
+    r.b = cmulc(a.x, a.y);   // a.x conj(a.y)
+    r.c = cconj(r.b);
+    r.d = mk<double>(cabs2(a.y), 0.0);
+    return r;
+}
+__device__ __forceinline__ M2 madd2(const M2& p, const M2& q) {
+    return M2{cadd(p.a, q.a), cadd(p.b, q.b), cadd(p.c, q.c), cadd(p.d, q.d)};
+}
+__device__ __forceinline__ M2 mherm(const M2& p) { return M2{cconj(p.a), cconj(p.c), cconj(p.b), cconj(p.d)}; }
+__device__ __forceinline__ M2 mzero() {
+    const cd z = mk<double>(0, 0);
+    return M2{z, z, z, z};
+}
+// eigenvectors of a Hermitian 2x2: [0] smallest eigenvalue (leig), [1] largest (peig)
+__device__ __forceinline__ void heig2(const M2& A, V2& v_small, V2& v_large) {
+    const double a = A.a.x, d = A.d.x;
+    const double half = 0.5 * (a - d);
+    const double r = sqrt(half * half + cabs2(A.b));
+    const double mid = 0.5 * (a + d);
+    v_small = eigvec2(A, mk<double>(mid - r, 0.0));
+    v_large = eigvec2(A, mk<double>(mid + r, 0.0));
+}
+__device__ __forceinline__ bool ia_diff_significant(const V2 (&Fo)[3], const V2 (&Fn)[3], double rel) {
+    bool sig = false;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const double mn = sqrt(fmin(cabs2(Fn[k].x), cabs2(Fn[k].y)));
+        const double dx = sqrt(cabs2(csub(Fn[k].x, Fo[k].x))), dy = sqrt(cabs2(csub(Fn[k].y, Fo[k].y)));
+        sig = sig || (fmax(dx, dy) > mn * rel);
+    }
+    return sig;
+}
+
+// F: in = initial precoders (unit norm), out = solution; Wh = rows W^H.  Returns the iterations run.
+__device__ __forceinline__ int ia_iterate(const M2 (&H)[3][3], int algo, double nv, int max_iter, double rel,
+                                          V2 (&F)[3], V2 (&Wh)[3], bool& ok) {
+    V2 W[3];    // alt-min: C_k (interference subspace); otherwise the receive vectors W_k
+    auto interference = [&](int k, const V2 (&P)[3], bool reversed) {
+        M2 Q = mzero();
+#pragma unroll
+        for (int l = 0; l < 3; ++l) {
+            if (l == k) continue;
+            Q = madd2(Q, outer2(reversed ? mvec(mherm(H[l][k]), P[l]) : mvec(H[k][l], P[l])));
+        }
+        return Q;
+    };
+    auto update_W = [&]() {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            M2 Q = interference(k, F, false);
+            if (algo == IA_MAX_SINR) {
+                Q.a.x += nv;
+                Q.d.x += nv;
+                W[k] = vnormalize(mvec(minv(Q, ok), mvec(H[k][k], F[k])));
+            } else {
+                V2 lo, hi;
+                heig2(Q, lo, hi);
+                W[k] = algo == IA_ALT_MIN ? hi : lo;
+            }
+        }
+    };
+    auto update_F = [&]() {
+        if (algo == IA_ALT_MIN) {
+            M2 Y[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const M2 cc = outer2(W[k]);
+                Y[k] = M2{mk<double>(1.0 - cc.a.x, 0.0), mk<double>(-cc.b.x, -cc.b.y), mk<double>(-cc.c.x, -cc.c.y),
+                          mk<double>(1.0 - cc.d.x, 0.0)};
+            }
+#pragma unroll
+            for (int l = 0; l < 3; ++l) {
+                M2 M = mzero();
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    if (k == l) continue;
+                    M = madd2(M, mmul(mmul(mherm(H[k][l]), Y[k]), H[k][l]));
+                }
+                M.a.y = M.d.y = 0.0;             // Hermitian by construction
+                M.c = cconj(M.b);
+                V2 lo, hi;
+                heig2(M, lo, hi);
+                F[l] = lo;
+            }
+        } else {
+            V2 Fn[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                M2 Q = interference(k, W, true);
+                if (algo == IA_MAX_SINR) {
+                    Q.a.x += nv;
+                    Q.d.x += nv;
+                    Fn[k] = vnormalize(mvec(minv(Q, ok), mvec(mherm(H[k][k]), W[k])));
+                } else {
+                    V2 lo, hi;
+                    heig2(Q, lo, hi);
+                    Fn[k] = lo;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) F[k] = Fn[k];
+        }
+    };
+    update_W();          // initialisation: _before_initialize_W_func / _updateW on the random precoder
+    int runned = 0;
+    for (int it = 0; it < max_iter; ++it) {
+        V2 Fo[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) Fo[k] = F[k];
+        ++runned;
+        update_F();
+        update_W();
+        if (!ia_diff_significant(Fo, F, rel)) break;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        if (algo == IA_ALT_MIN) {
+            // first row of inv([H_kk F_k, C_k])
+            const V2 a = mvec(H[k][k], F[k]);
+            const cd det = csub(cmul(a.x, W[k].y), cmul(W[k].x, a.y));
+            ok = ok && (cabs2(det) > 1e-280);
+            Wh[k].x = cdiv_(W[k].y, det);
+            Wh[k].y = cdiv_(mk<double>(-W[k].x.x, -W[k].x.y), det);
+        } else {
+            Wh[k].x = cconj(W[k].x);
+            Wh[k].y = cconj(W[k].y);
+        }
+    }
+    return runned;
+}
+
+// full_W_H (iabase.py:299-327), SINR (:768-789, :897-996) and sum capacity of a (F, W^H) pair, P = 1
+__device__ __forceinline__ void ia_finish(const M2 (&H)[3][3], const V2 (&F)[3], const V2 (&Wh)[3], double nv,
+                                          IaSolution& s) {
+    s.capacity = 0.0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        s.F[k] = F[k];
+        const V2 hf = mvec(H[k][k], F[k]);
+        const cd eq = cadd(cmul(Wh[k].x, hf.x), cmul(Wh[k].y, hf.y));
+        s.U[k].x = cdiv_(Wh[k].x, eq);
+        s.U[k].y = cdiv_(Wh[k].y, eq);
+        double den = nv * (cabs2(s.U[k].x) + cabs2(s.U[k].y));
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            if (j == k) continue;
+            const V2 g = mvec(H[k][j], F[j]);
+            den += cabs2(cadd(cmul(s.U[k].x, g.x), cmul(s.U[k].y, g.y)));
+        }
+        s.sinr[k] = 1.0 / den;
+        s.capacity += log2(1.0 + s.sinr[k]);
+    }
+}
+
+__device__ __forceinline__ IaSolution ia_iterative(const M2 (&H)[3][3], int algo, double nv, int max_iter, double rel,
+                                                   const V2 (&F_init)[3], int& runned) {
+    V2 F[3], Wh[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) F[k] = F_init[k];
+    bool ok = true;
+    runned = ia_iterate(H, algo, nv, max_iter, rel, F, Wh, ok);
+    IaSolution s;
+    ia_finish(H, F, Wh, nv, s);
+    s.ok = ok && (s.capacity == s.capacity);
+    return s;
+}
+
 __device__ __forceinline__ void load_blocks(const cd* bigH, M2 (&H)[3][3]) {
 #pragma unroll
     for (int k = 0; k < 3; ++k)
@@ -171,12 +349,39 @@ __global__ __launch_bounds__(64) void k_ia_closed_form(const cd* __restrict__ bi
     }
 }
 
+// operator-level iterative solver on injected channels and initial precoders: F_init [batch][3][2]
+__global__ __launch_bounds__(64) void k_ia_iterative(const cd* __restrict__ bigH, const cd* __restrict__ F_init, int algo,
+                                                     double nv, int max_iter, double rel, cd* __restrict__ F,
+                                                     cd* __restrict__ U, double* __restrict__ sinr,
+                                                     double* __restrict__ cap, uint32_t* __restrict__ iters,
+                                                     uint32_t* __restrict__ skipped, size_t batch) {
+    for (size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x; b < batch; b += (size_t)gridDim.x * blockDim.x) {
+        M2 H[3][3];
+        load_blocks(bigH + b * 36, H);
+        V2 F0[3];
+        for (int k = 0; k < 3; ++k) F0[k] = V2{F_init[(b * 3 + k) * 2], F_init[(b * 3 + k) * 2 + 1]};
+        int runned = 0;
+        const IaSolution s = ia_iterative(H, algo, nv, max_iter, rel, F0, runned);
+        for (int k = 0; k < 3; ++k) {
+            F[(b * 3 + k) * 2] = s.F[k].x;
+            F[(b * 3 + k) * 2 + 1] = s.F[k].y;
+            U[(b * 3 + k) * 2] = s.U[k].x;
+            U[(b * 3 + k) * 2 + 1] = s.U[k].y;
+            if (sinr) sinr[b * 3 + k] = s.sinr[k];
+        }
+        if (cap) cap[b] = s.capacity;
+        if (iters) iters[b] = (uint32_t)runned;
+        if (skipped) skipped[b] = s.ok ? 0u : 1u;
+    }
+}
+
 // fused config 5: one wavefront per realization
 template <typename T>
-__global__ __launch_bounds__(64) void k_run_ia(ModemParams<T> mp, int n_symbols, double noise_var, uint64_t seed,
-                                               uint64_t first, uint64_t count, mcle_counters* counters,
+__global__ __launch_bounds__(64) void k_run_ia(ModemParams<T> mp, int n_symbols, double noise_var, int solver,
+                                               int max_iter, double rel, uint64_t seed, uint64_t first,
+                                               uint64_t count, mcle_counters* counters,
                                                uint32_t* __restrict__ sym_out, uint32_t* __restrict__ bit_out,
-                                               double* __restrict__ cap_out) {
+                                               double* __restrict__ cap_out, uint32_t* __restrict__ iter_out) {
     __shared__ cx<T> s_table[256];
     __shared__ cd s_H[36];
     load_table(mp, s_table);
@@ -192,7 +397,19 @@ __global__ __launch_bounds__(64) void k_run_ia(ModemParams<T> mp, int n_symbols,
         __syncthreads();
         M2 H[3][3];
         load_blocks(s_H, H);
-        const IaSolution s = ia_closed_form(H, noise_var);  // every lane solves the same 2x2 systems
+        IaSolution s;                       // every lane solves the same 2x2 systems
+        int runned = 0;
+        if (solver == IA_CLOSED_FORM) {
+            s = ia_closed_form(H, noise_var);
+        } else {
+            // randomizeF (iabase.py:538-540): F_k = normalized(randn_c(Nt, Ns)) from the solver's own stream
+            V2 F0[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                F0[k] = vnormalize(V2{cn_sample<double>(rng, STREAM_PHASE, (uint64_t)(2 * k), 1.0),
+                                      cn_sample<double>(rng, STREAM_PHASE, (uint64_t)(2 * k + 1), 1.0)});
+            s = ia_iterative(H, solver, noise_var, max_iter, rel, F0, runned);
+        }
         cx<T> Hs[6][6], F[3][2], U[3][2];
 #pragma unroll
         for (int i = 0; i < 6; ++i)
@@ -238,6 +455,7 @@ __global__ __launch_bounds__(64) void k_run_ia(ModemParams<T> mp, int n_symbols,
         if (lane == 0) {
             wg_account(totals, se, be, !s.ok, rl, sym_out, bit_out);
             if (cap_out) cap_out[rl] = s.capacity;
+            if (iter_out) iter_out[rl] = (uint32_t)runned;
         }
     }
     if (lane == 0)
@@ -280,15 +498,39 @@ int mcle_ia_closed_form(mcle_ctx* ctx, const void* d_bigH, double noise_var, voi
     return MCLE_OK;
 }
 
+int mcle_ia_iterative(mcle_ctx* ctx, int solver, const void* d_bigH, const void* d_F_init, double noise_var,
+                      int max_iterations, double relative_factor, void* d_F, void* d_U, double* d_sinr,
+                      double* d_capacity, uint32_t* d_iterations, uint32_t* d_skipped, size_t batch) {
+    MCLE_REQUIRE(ctx != nullptr && d_bigH != nullptr && d_F_init != nullptr && d_F != nullptr && d_U != nullptr,
+                 "null argument");
+    MCLE_REQUIRE(solver >= MCLE_IA_ALT_MIN && solver <= MCLE_IA_MAX_SINR, "solver must be one of the iterative MCLE_IA_*");
+    MCLE_REQUIRE(noise_var >= 0.0, "noise variance must be non-negative");
+    MCLE_REQUIRE(max_iterations >= 1, "max_iterations must be positive");
+    if (batch == 0) return MCLE_OK;
+    int rc = ctx->bind();
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_ia_iterative, dim3(grid_for(ctx, batch, 64, 16)), dim3(64), 0, ctx->stream,
+                       (const double2*)d_bigH, (const double2*)d_F_init, solver, noise_var, max_iterations,
+                       relative_factor, (double2*)d_F, (double2*)d_U, d_sinr, d_capacity, d_iterations, d_skipped,
+                       batch);
+    MCLE_LAUNCH_CHECK();
+    return MCLE_OK;
+}
+
 int mcle_run_ia(mcle_ctx* ctx, int dtype, const mcle_ia_cfg* cfg, uint64_t seed, uint64_t first, uint64_t count,
-                mcle_counters* d_counters, uint32_t* d_sym_err, uint32_t* d_bit_err, double* d_sum_capacity) {
+                mcle_counters* d_counters, uint32_t* d_sym_err, uint32_t* d_bit_err, double* d_sum_capacity,
+                uint32_t* d_iterations) {
     int rc = check_pipe(ctx, dtype, cfg ? cfg->demod_method : 0, cfg);
     if (rc) return rc;
     // ClosedFormIASolver.solve asserts K == 3 (algorithms.py:210); this kernel is its 2x2, Ns = 1 case
-    MCLE_REQUIRE(cfg->K == 3, "The ClosedFormIASolver class only works in a MIMO-IC scenario with 3 users.");
+    MCLE_REQUIRE(cfg->K == 3, cfg->solver == MCLE_IA_CLOSED_FORM
+                                  ? "The ClosedFormIASolver class only works in a MIMO-IC scenario with 3 users."
+                                  : "fused IA pipeline supports K = 3 users");
     MCLE_REQUIRE(cfg->nr == 2 && cfg->nt == 2 && cfg->ns == 1, "fused IA pipeline supports Nr = Nt = 2, Ns = 1");
     MCLE_REQUIRE(cfg->n_symbols >= 1, "n_symbols must be positive");
     MCLE_REQUIRE(cfg->noise_var >= 0.0, "noise variance must be non-negative");
+    MCLE_REQUIRE(cfg->solver >= MCLE_IA_CLOSED_FORM && cfg->solver <= MCLE_IA_MAX_SINR, "unknown IA solver %d", cfg->solver);
+    MCLE_REQUIRE(cfg->solver == MCLE_IA_CLOSED_FORM || cfg->max_iterations >= 1, "max_iterations must be positive");
     MCLE_REQUIRE(count <= 0x7fffffffull, "at most 2^31-1 realizations per call");
     if (count == 0) return MCLE_OK;
     if ((rc = ctx->bind())) return rc;
@@ -296,12 +538,13 @@ int mcle_run_ia(mcle_ctx* ctx, int dtype, const mcle_ia_cfg* cfg, uint64_t seed,
     const unsigned grid = (unsigned)(count < cap ? count : cap);
     if (dtype == MCLE_F32)
         hipLaunchKernelGGL(k_run_ia<float>, dim3(grid), dim3(64), 0, ctx->stream, ia_modem<float>(ctx, cfg->demod_method),
-                           cfg->n_symbols, cfg->noise_var, seed, first, count, d_counters, d_sym_err, d_bit_err,
-                           d_sum_capacity);
+                           cfg->n_symbols, cfg->noise_var, cfg->solver, cfg->max_iterations, cfg->relative_factor, seed,
+                           first, count, d_counters, d_sym_err, d_bit_err, d_sum_capacity, d_iterations);
     else
         hipLaunchKernelGGL(k_run_ia<double>, dim3(grid), dim3(64), 0, ctx->stream,
-                           ia_modem<double>(ctx, cfg->demod_method), cfg->n_symbols, cfg->noise_var, seed, first, count,
-                           d_counters, d_sym_err, d_bit_err, d_sum_capacity);
+                           ia_modem<double>(ctx, cfg->demod_method), cfg->n_symbols, cfg->noise_var, cfg->solver,
+                           cfg->max_iterations, cfg->relative_factor, seed, first, count, d_counters, d_sym_err,
+                           d_bit_err, d_sum_capacity, d_iterations);
     MCLE_LAUNCH_CHECK();
     return MCLE_OK;
 }

@@ -644,28 +644,54 @@ class Engine:
 
 
     def run_ia(self, n_symbols, noise_var, seed, first, count, method=DEMOD_MINDIST, dtype=None,
-               per_realization=False, counters=None):
-        """Config 5 (K = 3, 2x2, one stream per user).  Returns the counter dict with the extra key
-        'sum_capacity' = per-realization sum capacities summed in index order (host side), and with
-        per_realization=True also (sym_err, bit_err, capacities)."""
+               per_realization=False, counters=None, solver="closed_form", max_iterations=50, relative_factor=1e-6):
+        """Config 5 (K = 3, 2x2, one stream per user) with the closed-form solver or one of the iterative
+        ones ('alt_min', 'min_leakage', 'max_sinr'; random initial precoders).  Returns the counter dict with
+        the extra keys 'sum_capacity' (+ '_sq') and 'ia_runned_iterations' (+ '_sq') = per-realization values
+        summed in index order (host side), and with per_realization=True also (sym_err, bit_err, capacities,
+        iterations)."""
         dt = self._dt(dtype)
-        cfg = IaCfg(3, 2, 2, 1, int(n_symbols), int(method), float(noise_var))
+        cfg = IaCfg(3, 2, 2, 1, int(n_symbols), int(method), float(noise_var), _lib.IA_SOLVERS[solver],
+                    int(max_iterations), float(relative_factor))
         cnt = counters if counters is not None else self.new_counters()
         se, be = self.empty(count, np.uint32), self.empty(count, np.uint32)
         cap = self.empty(count, np.float64)
+        its = self.empty(count, np.uint32)
         check(self.lib.mcle_run_ia(self.ctx, dt, byref(cfg), int(seed), int(first), int(count), cnt.ptr, se.ptr,
-                                   be.ptr, cap.ptr))
+                                   be.ptr, cap.ptr, its.ptr))
         if counters is not None:
             return None
         caps = cap.get()
         sev = se.get()
+        iters = its.get().astype(np.int64)
         valid = sev != 0xFFFFFFFF
         res = self._counters(cnt)
         res["sum_capacity"] = float(np.sum(caps[valid]))
         res["sum_capacity_sq"] = float(np.sum(caps[valid] ** 2))
+        res["ia_runned_iterations"] = int(np.sum(iters[valid]))
+        res["ia_runned_iterations_sq"] = int(np.sum(iters[valid] ** 2))
         if per_realization:
-            return res, sev, be.get(), caps
+            return res, sev, be.get(), caps, iters
         return res
+
+    def ia_iterative(self, solver, big_H, F_init, noise_var, max_iterations=50, relative_factor=1e-6):
+        """IterativeIASolverBaseClass.solve (algorithms.py:802-883) with initialize_with='fix': big_H
+        [batch, 6, 6], F_init [batch, 3, 2] (unit-norm initial precoders) -> dict(F, U = full_W_H, sinr,
+        capacity, iterations, skipped)."""
+        H = np.ascontiguousarray(big_H, dtype=np.complex128).reshape(-1, 6, 6)
+        F0 = np.ascontiguousarray(F_init, dtype=np.complex128).reshape(-1, 3, 2)
+        b = H.shape[0]
+        if F0.shape[0] != b:
+            raise ValueError("big_H and F_init must have the same batch size")
+        d_H, d_F0 = self.to_device(H), self.to_device(F0)
+        F, U = self.empty((b, 3, 2), np.complex128), self.empty((b, 3, 2), np.complex128)
+        sinr, cap = self.empty((b, 3), np.float64), self.empty(b, np.float64)
+        its, sk = self.empty(b, np.uint32), self.empty(b, np.uint32)
+        self._raise_value(self.lib.mcle_ia_iterative(
+            self.ctx, _lib.IA_SOLVERS[solver], d_H.ptr, d_F0.ptr, float(noise_var), int(max_iterations),
+            float(relative_factor), F.ptr, U.ptr, sinr.ptr, cap.ptr, its.ptr, sk.ptr, b))
+        return dict(F=F.get(), U=U.get(), sinr=sinr.get(), capacity=cap.get(), iterations=its.get(),
+                    skipped=sk.get())
 
     def ia_closed_form(self, big_H, noise_var):
         """big_H [batch, 6, 6] complex128 -> dict(F [batch,3,2], U [batch,3,2], sinr [batch,3],

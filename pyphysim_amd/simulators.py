@@ -250,27 +250,44 @@ class IaSimulator(_LinkSimulator):
     3-user 2x2 interference channel, one stream per user.  Adds the 'sum_capacity' RATIO(x, 1)
     Result of the reference app next to the error-rate Results."""
 
-    def __init__(self, SNR, modulator="qam", M=16, NSymbs=200, **kw):
+    def __init__(self, SNR, modulator="qam", M=16, NSymbs=200, solver="closed_form", max_iterations=60,
+                 relative_factor=1e-6, **kw):
+        """solver: 'closed_form' (ClosedFormIASolver, use_best_init) or 'alt_min' / 'min_leakage' / 'max_sinr'
+        (AlternatingMinIASolver / MinLeakageIASolver / MaxSinrIASolver with initialize_with='random';
+        max_iterations defaults to the app's 60, apps/ia/simulate_ia.py:330)."""
         super().__init__(SNR, modulator, M, **kw)
-        for k, v in (("NSymbs", int(NSymbs)), ("K", 3), ("Nr", 2), ("Nt", 2), ("Ns", 1)):
+        if solver not in _lib.IA_SOLVERS:
+            raise ValueError("unknown IA solver %r" % (solver,))
+        for k, v in (("NSymbs", int(NSymbs)), ("K", 3), ("Nr", 2), ("Nt", 2), ("Ns", 1), ("solver", solver)):
             self.params.add(k, v)
+        if solver != "closed_form":
+            self.params.add("max_iterations", int(max_iterations))
+        self.relative_factor = float(relative_factor)
         self.COUNTER_KEYS = tuple(self.COUNTER_KEYS)
 
     def _run_batch(self, current_parameters, first_rep, count):
         eng = self._bind()
-        res = eng.run_ia(current_parameters["NSymbs"], self._noise_var(current_parameters),
-                         self._seed_for(current_parameters), first_rep, count, method=self.demod_method,
-                         dtype=self.dtype)
+        p = current_parameters
+        res = eng.run_ia(p["NSymbs"], self._noise_var(p), self._seed_for(p), first_rep, count,
+                         method=self.demod_method, dtype=self.dtype, solver=p["solver"],
+                         max_iterations=p["max_iterations"] if p["solver"] != "closed_form" else 1,
+                         relative_factor=self.relative_factor)
         self._cap = getattr(self, "_cap", 0.0) + res["sum_capacity"]
         self._cap_sq = getattr(self, "_cap_sq", 0.0) + res["sum_capacity_sq"]
+        self._its = getattr(self, "_its", 0) + res["ia_runned_iterations"]
+        self._its_sq = getattr(self, "_its_sq", 0) + res["ia_runned_iterations_sq"]
         return res
 
     def _on_simulate_current_params_start(self, current_params):
         self._cap = self._cap_sq = 0.0
+        self._its = self._its_sq = 0
 
     def _results_from_counters(self, current_parameters, c):
         from .simulations import Result
         res = super()._results_from_counters(current_parameters, c)
         n = max(int(c["n_realizations"]), 1)
         res.add_result(Result.from_batch("sum_capacity", Result.RATIOTYPE, self._cap, n, self._cap, self._cap_sq, n))
+        if current_parameters["solver"] != "closed_form":
+            res.add_result(Result.from_batch("ia_runned_iterations", Result.RATIOTYPE, self._its, n, self._its,
+                                             self._its_sq, n))
         return res

@@ -224,8 +224,8 @@ def test_ia_pipeline(engine, dt, exact):
     want_se = np.array([w["symbol_errors"] for w in want])
     want_be = np.array([w["bit_errors"] for w in want])
     want_cap = np.array([w["sum_capacity"] for w in want])
-    res, se, be, cap = engine.run_ia(200, 1.0 / omodem.dB2Linear(20.0), SEED, first, count, dtype=dt,
-                                     per_realization=True)
+    res, se, be, cap, _ = engine.run_ia(200, 1.0 / omodem.dB2Linear(20.0), SEED, first, count, dtype=dt,
+                                        per_realization=True)
     check(res, se, be, want_se, want_be, 600, 2400, exact)
     assert np.max(np.abs(cap - want_cap)) <= 1e-7 and abs(res["sum_capacity"] - want_cap.sum()) <= 1e-6
     # shard invariance at the BASELINE size (1e5 realizations of 600 symbols)
@@ -236,6 +236,62 @@ def test_ia_pipeline(engine, dt, exact):
         assert a[k] == b[k] + c[k]
     assert 0.005 < a["sym_errors"] / (a["n_realizations"] * 600) < 0.08        # 0.023
     assert engine.run_ia(200, 0.0, SEED, 0, 2000, dtype="f32")["sym_errors"] == 0
+
+
+# ---- iterative interference alignment -------------------------------------------------------
+def test_ia_iterative_injected(engine):
+    """AlternatingMin / MinLeakage / MaxSinr on the reference's own channels and random initial precoders:
+    iteration counts, precoders, filters, SINR, capacity and the decisions of apps/ia/simulate_ia.py."""
+    from helpers import golden_cases, relerr
+    seen = set()
+    for kw, reals in golden_cases("f3_ia_iterative"):
+        seen.add(kw["algo"])
+        H = np.stack([g["big_H"] for g in reals])
+        F0 = np.stack([g["F_init"] for g in reals])
+        nv = float(reals[0]["noise_var"])
+        sol = engine.ia_iterative(kw["algo"], H, F0, nv, kw["max_iterations"], kw["relative_factor"])
+        assert not sol["skipped"].any()
+        for b, g in enumerate(reals):
+            assert int(sol["iterations"][b]) == int(g["runned_iterations"]), (kw["algo"], b)
+            assert relerr(sol["F"][b], g["F"]) <= 1e-7 and relerr(sol["U"][b], g["U"]) <= 1e-7
+            assert relerr(sol["sinr"][b], g["sinr"]) <= 1e-6 and abs(sol["capacity"][b] - g["sum_capacity"]) <= 1e-6
+            engine.set_constellation(g["table"], _lib.CONST_QAM)
+            sym = engine.modulate(g["idx"].reshape(-1)).reshape(3, -1)
+            X = np.vstack([np.outer(sol["F"][b, k], sym[k]) for k in range(3)])
+            Y = engine.mimo_channel(g["big_H"][None], X[None], g["noise"][None], nv)[0]
+            est = np.vstack([sol["U"][b, k] @ Y[2 * k:2 * k + 2] for k in range(3)])
+            assert relerr(est, g["est"]) <= 1e-6
+            assert np.array_equal(engine.demodulate(est), g["decisions"])
+    assert seen == {"alt_min", "min_leakage", "max_sinr"}
+    with pytest.raises(ValueError):
+        engine.ia_iterative("alt_min", H, F0[:1], nv)
+    with pytest.raises(ValueError):
+        engine.ia_iterative("alt_min", H, F0, nv, max_iterations=0)
+
+
+@pytest.mark.parametrize("algo", ["alt_min", "min_leakage", "max_sinr"])
+@pytest.mark.parametrize("dt,exact", [("f64", True), ("f32", False)])
+def test_ia_iterative_pipeline(engine, algo, dt, exact):
+    kw = dict(algo=algo, mod="qam", M=16, K=3, nr=2, nt=2, Ns=1, NSymbs=100, snr_db=18.0, max_iterations=40)
+    engine.set_constellation(chains.constellation("qam", 16), _lib.CONST_QAM)
+    first, count = 3, 24
+    want = [chains.chain_ia_iterative(chains.PhiloxRng(SEED, r), **kw) for r in range(first, first + count)]
+    want_se = np.array([w["symbol_errors"] for w in want])
+    want_be = np.array([w["bit_errors"] for w in want])
+    want_cap = np.array([w["sum_capacity"] for w in want])
+    want_it = np.array([w["runned_iterations"] for w in want])
+    res, se, be, cap, its = engine.run_ia(100, 1.0 / omodem.dB2Linear(18.0), SEED, first, count, dtype=dt,
+                                          per_realization=True, solver=algo, max_iterations=40)
+    check(res, se, be, want_se, want_be, 300, 1200, exact)
+    assert np.array_equal(its, want_it) and res["ia_runned_iterations"] == int(want_it.sum())
+    assert np.max(np.abs(cap - want_cap)) <= 1e-6
+    # shard invariance and sanity at scale
+    a = engine.run_ia(100, 0.01, SEED, 0, 20000, dtype="f32", solver=algo, max_iterations=20)
+    b = engine.run_ia(100, 0.01, SEED, 0, 7777, dtype="f32", solver=algo, max_iterations=20)
+    c = engine.run_ia(100, 0.01, SEED, 7777, 12223, dtype="f32", solver=algo, max_iterations=20)
+    for k in ("sym_errors", "sym_errors_sq", "bit_errors", "n_realizations", "ia_runned_iterations"):
+        assert a[k] == b[k] + c[k]
+    assert a["sym_errors"] / (a["n_realizations"] * 300) < 0.15
 
 
 def test_edge_cases_and_large_indices(engine):

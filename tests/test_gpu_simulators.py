@@ -216,3 +216,21 @@ def test_mimo_ofdm_tdl_fused_envelope():
     assert np.array_equal(se, want)
     with pytest.raises(McleUnsupported):
         _f1_sim("f64", fused=True, **over)._run_batch_detailed(p, 0, 4)
+
+
+def test_ia_simulator_iterative(engine):
+    """IaSimulator with an iterative solver: same Result surface as the reference app incl.
+    'ia_runned_iterations' (apps/ia/simulate_ia.py:185-189); max SINR beats closed form at low SNR."""
+    out = {}
+    for solver in ("closed_form", "max_sinr", "alt_min"):
+        sim = simulators.IaSimulator(SNR=[0.0, 20.0], M=4, modulator="psk", NSymbs=100, rep_max=4000, batch_size=4000,
+                                     seed=3, engine=engine, solver=solver, max_iterations=30)
+        sim.simulate()
+        out[solver] = sim.results
+        assert "sum_capacity" in sim.results.get_result_names()
+        assert ("ia_runned_iterations" in sim.results.get_result_names()) == (solver != "closed_form")
+    its = out["alt_min"].get_result_values_list("ia_runned_iterations")
+    assert all(1.0 <= v <= 30.0 for v in its)
+    cap = {k: v.get_result_values_list("sum_capacity") for k, v in out.items()}
+    assert cap["max_sinr"][0] > cap["closed_form"][0]            # noise-aware filters win at 0 dB
+    assert abs(cap["alt_min"][1] - cap["closed_form"][1]) < 0.15 * cap["closed_form"][1]   # both align at 20 dB
