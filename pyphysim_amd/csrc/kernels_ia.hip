@@ -93,6 +93,7 @@ struct IaSolution {
 // H[k][l]: channel from transmitter l to receiver k
 __device__ __forceinline__ void ia_candidate(const M2 (&H)[3][3], const M2& invH32, const M2& invH23, V2 F0,
                                              double nv, IaSolution& s) {
+    s.ok = true;
     s.F[0] = vnormalize(F0);
     s.F[1] = vnormalize(mvec(invH32, mvec(H[2][0], F0)));
     s.F[2] = vnormalize(mvec(invH23, mvec(H[1][0], F0)));
@@ -119,7 +120,8 @@ __device__ __forceinline__ void ia_candidate(const M2 (&H)[3][3], const M2& invH
     }
 }
 
-__device__ __forceinline__ IaSolution ia_closed_form(const M2 (&H)[3][3], double nv) {
+// not inlined: one compiled body serves the operator kernel and both instantiations of the pipeline
+__device__ __noinline__ IaSolution ia_closed_form(const M2 (&H)[3][3], double nv) {
     bool ok = true;
     const M2 i31 = minv(H[2][0], ok), i12 = minv(H[0][1], ok), i23 = minv(H[1][2], ok), i32 = minv(H[2][1], ok);
     // E = H31^-1 H32 . (H12^-1 H13 . (H23^-1 H21))
@@ -303,7 +305,7 @@ __device__ __forceinline__ void ia_finish(const M2 (&H)[3][3], const V2 (&F)[3],
     }
 }
 
-__device__ __forceinline__ IaSolution ia_iterative(const M2 (&H)[3][3], int algo, double nv, int max_iter, double rel,
+__device__ __noinline__ IaSolution ia_iterative(const M2 (&H)[3][3], int algo, double nv, int max_iter, double rel,
                                                    const V2 (&F_init)[3], int& runned) {
     V2 F[3], Wh[3];
 #pragma unroll
@@ -375,7 +377,10 @@ __global__ __launch_bounds__(64) void k_ia_iterative(const cd* __restrict__ bigH
     }
 }
 
-// fused config 5: one wavefront per realization
+// fused config 5: one wavefront per CHUNK of 64 realizations.  Phase 1: lane i solves realization i of the chunk
+// (channel draw, solver -- closed form or iterative -- in f64 registers) and parks H, F, U in LDS.  Phase 2:
+// the whole wave runs each realization's symbols (lanes stride over the symbol columns).  With one solve per
+// lane instead of the same solve on all 64 lanes the iterative solvers cost 1/64 of a wave per realization.
 template <typename T>
 __global__ __launch_bounds__(64) void k_run_ia(ModemParams<T> mp, int n_symbols, double noise_var, int solver,
                                                int max_iter, double rel, uint64_t seed, uint64_t first,
@@ -383,79 +388,108 @@ __global__ __launch_bounds__(64) void k_run_ia(ModemParams<T> mp, int n_symbols,
                                                uint32_t* __restrict__ sym_out, uint32_t* __restrict__ bit_out,
                                                double* __restrict__ cap_out, uint32_t* __restrict__ iter_out) {
     __shared__ cx<T> s_table[256];
-    __shared__ cd s_H[36];
+    __shared__ cx<T> s_Hs[64][36 + 1];      // +1: lanes write their own row -- keep the rows off one bank
+    __shared__ cx<T> s_F[64][6 + 1];
+    __shared__ cx<T> s_U[64][6 + 1];
+    __shared__ unsigned s_ok[64];
     load_table(mp, s_table);
     const int lane = threadIdx.x;
     const T sigma = (T)sqrt(noise_var);
     const uint32_t mask = (uint32_t)(mp.M - 1);
     __shared__ WgTotals totals;
     if (threadIdx.x == 0) wg_zero(totals);
-    for (uint64_t rl = blockIdx.x; rl < count; rl += gridDim.x) {
-        const Rng rng(seed, first + rl);
+    const uint64_t n_chunks = (count + 63) / 64;
+    for (uint64_t ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
         __syncthreads();
-        if (lane < 36) s_H[lane] = cn_sample<double>(rng, STREAM_CHAN, (uint64_t)lane, 1.0);  // big_H row-major
-        __syncthreads();
-        M2 H[3][3];
-        load_blocks(s_H, H);
-        IaSolution s;                       // every lane solves the same 2x2 systems
-        int runned = 0;
-        if (solver == IA_CLOSED_FORM) {
-            s = ia_closed_form(H, noise_var);
-        } else {
-            // randomizeF (iabase.py:538-540): F_k = normalized(randn_c(Nt, Ns)) from the solver's own stream
-            V2 F0[3];
+        // ---- phase 1: one realization per lane ----
+        {
+            const uint64_t rl = ch * 64 + lane;
+            if (rl < count) {
+                const Rng rng(seed, first + rl);
+                cd bigH[36];
 #pragma unroll
-            for (int k = 0; k < 3; ++k)
-                F0[k] = vnormalize(V2{cn_sample<double>(rng, STREAM_PHASE, (uint64_t)(2 * k), 1.0),
-                                      cn_sample<double>(rng, STREAM_PHASE, (uint64_t)(2 * k + 1), 1.0)});
-            s = ia_iterative(H, solver, noise_var, max_iter, rel, F0, runned);
-        }
-        cx<T> Hs[6][6], F[3][2], U[3][2];
+                for (int i = 0; i < 18; ++i)            // big_H row-major, two CN samples per Philox block
+                    cn_pair<double>(rng, STREAM_CHAN, (uint32_t)i, 1.0, bigH[2 * i], bigH[2 * i + 1]);
+                M2 H[3][3];
+                load_blocks(bigH, H);
+                IaSolution s;
+                int runned = 0;
+                if (solver == IA_CLOSED_FORM) {
+                    s = ia_closed_form(H, noise_var);
+                } else {
+                    // randomizeF (iabase.py:538-540): F_k = normalized(randn_c(Nt, Ns)) from the solver's own stream
+                    V2 F0[3];
 #pragma unroll
-        for (int i = 0; i < 6; ++i)
-#pragma unroll
-            for (int j = 0; j < 6; ++j) Hs[i][j] = mk<T>((T)s_H[i * 6 + j].x, (T)s_H[i * 6 + j].y);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            F[k][0] = mk<T>((T)s.F[k].x.x, (T)s.F[k].x.y);
-            F[k][1] = mk<T>((T)s.F[k].y.x, (T)s.F[k].y.y);
-            U[k][0] = mk<T>((T)s.U[k].x.x, (T)s.U[k].x.y);
-            U[k][1] = mk<T>((T)s.U[k].y.x, (T)s.U[k].y.y);
-        }
-        unsigned se = 0, be = 0;
-        for (int t = lane; t < n_symbols; t += 64) {
-            int tx[3];
-            cx<T> X[6];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                tx[k] = (int)symbol_at(rng, (uint64_t)k * n_symbols + t, mask);  // randint(0, M, [3, NSymbs])
-                const cx<T> x = s_table[tx[k]];
-                X[2 * k] = cmul(F[k][0], x);
-                X[2 * k + 1] = cmul(F[k][1], x);
-            }
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                cx<T> y[2];
-#pragma unroll
-                for (int a = 0; a < 2; ++a) {
-                    const int row = 2 * k + a;
-                    cx<T> acc = cn_sample<T>(rng, STREAM_NOISE, (uint64_t)row * n_symbols + t, sigma);
-#pragma unroll
-                    for (int j = 0; j < 6; ++j) acc = cfma(Hs[row][j], X[j], acc);
-                    y[a] = acc;
+                    for (int k = 0; k < 3; ++k) {
+                        cd a, b;
+                        cn_pair<double>(rng, STREAM_PHASE, (uint32_t)k, 1.0, a, b);
+                        F0[k] = vnormalize(V2{a, b});
+                    }
+                    s = ia_iterative(H, solver, noise_var, max_iter, rel, F0, runned);
                 }
-                const cx<T> est = cadd(cmul(U[k][0], y[0]), cmul(U[k][1], y[1]));
-                const unsigned x = (unsigned)(tx[k] ^ demod_one(mp, s_table, est));
-                se += (x != 0u);
-                be += __popc(x);
+#pragma unroll
+                for (int i = 0; i < 36; ++i) s_Hs[lane][i] = mk<T>((T)bigH[i].x, (T)bigH[i].y);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    s_F[lane][2 * k] = mk<T>((T)s.F[k].x.x, (T)s.F[k].x.y);
+                    s_F[lane][2 * k + 1] = mk<T>((T)s.F[k].y.x, (T)s.F[k].y.y);
+                    s_U[lane][2 * k] = mk<T>((T)s.U[k].x.x, (T)s.U[k].x.y);
+                    s_U[lane][2 * k + 1] = mk<T>((T)s.U[k].y.x, (T)s.U[k].y.y);
+                }
+                s_ok[lane] = s.ok ? 1u : 0u;
+                if (cap_out) cap_out[rl] = s.capacity;
+                if (iter_out) iter_out[rl] = (uint32_t)runned;
             }
         }
-        se = wave_sum_u32(se);
-        be = wave_sum_u32(be);
-        if (lane == 0) {
-            wg_account(totals, se, be, !s.ok, rl, sym_out, bit_out);
-            if (cap_out) cap_out[rl] = s.capacity;
-            if (iter_out) iter_out[rl] = (uint32_t)runned;
+        __syncthreads();
+        // ---- phase 2: the wave walks the chunk's realizations ----
+        const int in_chunk = (int)((count - ch * 64) < 64 ? (count - ch * 64) : 64);
+        for (int j = 0; j < in_chunk; ++j) {
+            const uint64_t rl = ch * 64 + j;
+            const Rng rng(seed, first + rl);
+            cx<T> Hs[6][6], F[3][2], U[3][2];
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int c = 0; c < 6; ++c) Hs[i][c] = s_Hs[j][i * 6 + c];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                F[k][0] = s_F[j][2 * k];
+                F[k][1] = s_F[j][2 * k + 1];
+                U[k][0] = s_U[j][2 * k];
+                U[k][1] = s_U[j][2 * k + 1];
+            }
+            unsigned se = 0, be = 0;
+            for (int t = lane; t < n_symbols; t += 64) {
+                int tx[3];
+                cx<T> X[6];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    tx[k] = (int)symbol_at(rng, (uint64_t)k * n_symbols + t, mask);  // randint(0, M, [3, NSymbs])
+                    const cx<T> x = s_table[tx[k]];
+                    X[2 * k] = cmul(F[k][0], x);
+                    X[2 * k + 1] = cmul(F[k][1], x);
+                }
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    cx<T> y[2];
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) {
+                        const int row = 2 * k + a;
+                        cx<T> acc = cn_sample<T>(rng, STREAM_NOISE, (uint64_t)row * n_symbols + t, sigma);
+#pragma unroll
+                        for (int c = 0; c < 6; ++c) acc = cfma(Hs[row][c], X[c], acc);
+                        y[a] = acc;
+                    }
+                    const cx<T> est = cadd(cmul(U[k][0], y[0]), cmul(U[k][1], y[1]));
+                    const unsigned x = (unsigned)(tx[k] ^ demod_one(mp, s_table, est));
+                    se += (x != 0u);
+                    be += __popc(x);
+                }
+            }
+            se = wave_sum_u32(se);
+            be = wave_sum_u32(be);
+            if (lane == 0) wg_account(totals, se, be, s_ok[j] == 0u, rl, sym_out, bit_out);
         }
     }
     if (lane == 0)
@@ -535,7 +569,8 @@ int mcle_run_ia(mcle_ctx* ctx, int dtype, const mcle_ia_cfg* cfg, uint64_t seed,
     if (count == 0) return MCLE_OK;
     if ((rc = ctx->bind())) return rc;
     const uint64_t cap = (uint64_t)ctx->n_cu * 16;
-    const unsigned grid = (unsigned)(count < cap ? count : cap);
+    const uint64_t chunks = (count + 63) / 64;       // one wavefront per 64 realizations
+    const unsigned grid = (unsigned)(chunks < cap ? chunks : cap);
     if (dtype == MCLE_F32)
         hipLaunchKernelGGL(k_run_ia<float>, dim3(grid), dim3(64), 0, ctx->stream, ia_modem<float>(ctx, cfg->demod_method),
                            cfg->n_symbols, cfg->noise_var, cfg->solver, cfg->max_iterations, cfg->relative_factor, seed,
