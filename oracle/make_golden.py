@@ -566,9 +566,22 @@ def golden_framework():
     back = RSR.load_from_file(tmp)                      # the REFERENCE reads our archive
     assert isinstance(back, RSR) and back.get_result_values_list("ser") == rsr.get_result_values_list("ser")
     assert back.params == rsr.params and back["ser"][2].get_confidence_interval() == rsr["ser"][2].get_confidence_interval()
+    # JSON archives (results.py:1475-1486,1564-1569; util/serialize.py tagged arrays / sets), both directions
+    from pyphysim_amd.simulations import SimulationResults as MSR
+    ref_json = os.path.join(GOLD, "reference_results.json")
+    rsr.save_to_file(ref_json)
+    mine_j = MSR.load_from_file(ref_json)                # we read the reference's JSON
+    assert mine_j.get_result_values_list("ser") == rsr.get_result_values_list("ser")
+    assert mine_j.get_result_values_list("ser", {"M": 16}) == rsr.get_result_values_list("ser", {"M": 16})
+    tmpj = os.path.join("/tmp", "written_by_mcle.json")
+    mine_j.save_to_file(tmpj)
+    backj = RSR.load_from_file(tmpj)                     # the REFERENCE reads our JSON
+    assert backj.get_result_values_list("ser") == rsr.get_result_values_list("ser")
+    assert backj.params == rsr.params and backj.runned_reps == rsr.runned_reps
+    assert backj["ser"][2].get_confidence_interval() == rsr["ser"][2].get_confidence_interval()
     with open(os.path.join(GOLD, "framework.json"), "w") as fh:
         json.dump(out, fh, indent=1)
-    print("framework: ok (reference <-> mcle result archives interoperate)")
+    print("framework: ok (reference <-> mcle result archives interoperate, pickle and JSON)")
 
 
 if __name__ == "__main__":

@@ -140,7 +140,7 @@ class SimulationParameters:
 
     def to_dict(self):
         orig = None if self._original_sim_params is None else self._original_sim_params.to_dict()
-        return {"parameters": self.parameters, "unpacked_parameters_set": sorted(self._unpacked_parameters_set),
+        return {"parameters": self.parameters, "unpacked_parameters_set": set(self._unpacked_parameters_set),
                 "unpack_index": self._unpack_index, "original_sim_params": orig}
 
     @staticmethod
@@ -158,7 +158,7 @@ class SimulationParameters:
 
     @staticmethod
     def from_json(text):
-        return SimulationParameters.from_dict(json.loads(text))
+        return SimulationParameters.from_dict(json.loads(text, object_hook=_json_object_hook))
 
     def to_dataframe(self):
         import pandas as pd
@@ -167,12 +167,28 @@ class SimulationParameters:
 
 
 def _json_default(obj):
+    """The reference's NumpyOrSetEncoder (util/serialize.py:18-70): arrays and sets as tagged dicts, so JSON
+    archives written here load in pyphysim and vice versa.  (NumPy floats are written as floats; the reference
+    truncates them to int, :62-63.)"""
     if isinstance(obj, np.ndarray):
-        return obj.tolist()
+        return {"data": obj.tolist(), "dtype": str(obj.dtype), "_is_numpy_array": True, "shape": list(obj.shape)}
     if isinstance(obj, (np.integer,)):
         return int(obj)
     if isinstance(obj, (np.floating,)):
         return float(obj)
     if isinstance(obj, set):
-        return sorted(obj)
+        return {"data": sorted(obj), "_is_set": True}
     raise TypeError("not JSON serialisable: %r" % (type(obj),))
+
+
+def _json_object_hook(dct):
+    """json_numpy_or_set_obj_hook of the reference (util/serialize.py:73-110)."""
+    if "_is_numpy_array" in dct:
+        if dct["_is_numpy_array"] is True:
+            return np.array(dct["data"], dtype=dct["dtype"]).reshape(dct["shape"])
+        raise ValueError('Json representation contains the "_is_numpy_array" key but its value is not True')
+    if "_is_set" in dct:
+        if dct["_is_set"] is True:
+            return set(dct["data"])
+        raise ValueError('Json representation contains the "_is_set" key but its value is not True')
+    return dct

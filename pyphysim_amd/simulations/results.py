@@ -14,7 +14,7 @@ from collections.abc import Iterable
 
 import numpy as np
 
-from .parameters import SimulationParameters, _json_default
+from .parameters import SimulationParameters, _json_default, _json_object_hook
 
 _CI_TABLE = {50: 0.674, 60: 0.842, 70: 1.036, 80: 1.282, 90: 1.645, 95: 1.96, 98: 2.326, 99: 2.576, 99.5: 2.807,
              99.8: 3.090, 99.9: 3.291}
@@ -224,7 +224,7 @@ class Result:
 
     @staticmethod
     def from_json(text):
-        return Result.from_dict(json.loads(text))
+        return Result.from_dict(json.loads(text, object_hook=_json_object_hook))
 
 
 class SimulationResults:
@@ -348,7 +348,7 @@ class SimulationResults:
 
     @staticmethod
     def from_json(text):
-        return SimulationResults.from_dict(json.loads(text))
+        return SimulationResults.from_dict(json.loads(text, object_hook=_json_object_hook))
 
     def save_to_file(self, filename):
         ext = os.path.splitext(filename)[-1]

@@ -312,3 +312,37 @@ def test_exact_early_stop_replays_every_realization():
     assert outs[0] == outs[1] == outs[2]
     errs = [d["value"] for d in outs[0][0]]
     assert all(5000 <= v < 5000 + 97 for v in errs)          # stopped at the first realization crossing the rule
+
+
+def test_reference_json_archives_interoperate(tmp_path):
+    """the reference's JSON archives (results.py:1475-1486; arrays and sets as the tagged dicts
+    of util/serialize.py) load here, and what we write uses the same encoding (the reference reading it back is
+    asserted in oracle/make_golden.py)."""
+    import json
+    from pyphysim_amd.simulations import SimulationParameters, SimulationResults
+    path = os.path.join(os.path.dirname(__file__), "golden", "reference_results.json")
+    res = SimulationResults.load_from_file(path)
+    g = G["archive"]
+    assert res.get_result_values_list("ser") == g["ser"]
+    assert res.get_result_values_list("symbol_errors") == g["symbol_errors"]
+    assert res.get_result_values_list("ser", {"M": 16}) == g["ser_m16"]
+    assert res.params.get_num_unpacked_variations() == 6 and res.runned_reps == [5] * 6
+    assert isinstance(res.params["SNR"], np.ndarray)
+    out = res.save_to_file(str(tmp_path / "w.json"))
+    doc = json.loads(open(out).read())
+    want = json.loads(open(path).read())
+    assert doc["params"]["parameters"].keys() == want["params"]["parameters"].keys()
+    for k, v in want["params"]["parameters"].items():
+        if isinstance(v, dict):
+            assert doc["params"]["parameters"][k]["_is_numpy_array"] is True
+            assert doc["params"]["parameters"][k]["data"] == v["data"] and doc["params"]["parameters"][k]["dtype"] == v["dtype"]
+    assert doc["params"]["unpacked_parameters_set"]["_is_set"] is True
+    assert sorted(doc["params"]["unpacked_parameters_set"]["data"]) == sorted(want["params"]["unpacked_parameters_set"]["data"])
+    assert doc["results"]["ser"] == want["results"]["ser"]
+    again = SimulationResults.load_from_file(out)
+    assert again.get_result_values_list("ser") == g["ser"] and again.params == res.params
+    # SimulationParameters on its own
+    p = SimulationParameters.create({"a": np.arange(3.0), "b": 2, "c": np.array([1, 5])})
+    p.set_unpack_parameter("a")
+    q = SimulationParameters.from_json(p.to_json())
+    assert q == p and q.get_num_unpacked_variations() == 3 and q["c"].dtype == p["c"].dtype
