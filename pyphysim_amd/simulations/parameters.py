@@ -166,6 +166,88 @@ class SimulationParameters:
         return pd.DataFrame({name: [r[name] for r in rows] for name in self})
 
 
+def get_range_representation(array, filename_mode=False):
+    """'first:step:last' ('first_(step)_last' in file names) for an arithmetic progression of at least four
+    values, a comma list for fewer, None otherwise (reference util/misc.py:911-960)."""
+    array = np.asarray(array)
+    if array.size < 4:
+        return ",".join(array.astype(str))
+    step = array[1] - array[0]
+    if step.dtype == int:
+        step = int(step)
+    elif step.dtype == float:
+        step = round(float(step), 12)
+    if np.allclose(array[1:] - step, array[0:-1]):
+        return ("{0}_({1})_{2}" if filename_mode else "{0}:{1}:{2}").format(array[0], step, array[-1])
+    return None
+
+
+def get_mixed_range_representation(array, filename_mode=False):
+    """Comma-joined range representations of the constant-step stretches of `array`, cut where the step
+    changes exactly as the reference cuts them (util/misc.py:963-1054) -- result file names depend on it."""
+    array = np.asarray(array)
+    if len(array) < 2:
+        return "{0}".format(array[0])
+    step_into = np.diff(array)
+    step_into = np.concatenate([step_into[:1], step_into])     # step_into[i]: step that leads to element i
+    pieces = []                                                  # [begin, end) index pairs
+    begin, n = 0, len(step_into)
+    while begin < n:
+        end = begin
+        while end < n and np.allclose(step_into[end], step_into[begin]):
+            end += 1
+        pieces.append([begin, end])
+        begin = end
+    # a stretch of more than three elements also claims the element before it when that one continues its step
+    for i in range(1, len(pieces)):
+        lo, hi = pieces[i]
+        if hi - lo > 3:
+            step = array[lo + 1] - array[lo]
+            if np.allclose(array[lo] - array[pieces[i - 1][1] - 1], step):
+                pieces[i - 1][1] -= 1
+                pieces[i][0] -= 1
+    out = []
+    for lo, hi in pieces:
+        text = get_range_representation(array[lo:hi], filename_mode)
+        assert text is not None
+        if text != "":
+            out.append(text)
+    return ",".join(out)
+
+
+def replace_dict_values(name, dictionary, filename_mode=False):
+    """`name.format(**dictionary)` with arrays shown as '[<mixed range representation>]'
+    (reference util/misc.py:1057-1115)."""
+    shown = {}
+    for key, value in dictionary.items():
+        if isinstance(value, np.ndarray):
+            value = "[{0}]".format(get_mixed_range_representation(value, filename_mode))
+        shown[key] = value
+    return name.format(**shown)
+
+
+def combine_simulation_parameters(params1, params2):
+    """Union of two SimulationParameters that differ only in the VALUES of their unpacked parameters
+    (reference simulations/parameters.py:55-107)."""
+    if set(params1.parameters.keys()) != set(params2.parameters.keys()):
+        raise RuntimeError("Both SimulationParameters objects must have the same parameters.")
+    if set(params1.unpacked_parameters) != set(params2.unpacked_parameters):
+        raise RuntimeError("Both SimulationParameters objects must have the same unpacked parameters (only the "
+                           "values should can be different).")
+    fixed = params1.fixed_parameters
+    for key in fixed:
+        if params1[key] != params2[key]:
+            raise RuntimeError("The fixed parameters in both SimulationParameters objects must have the same value.")
+    union = SimulationParameters()
+    for key in fixed:
+        union.add(key, copy.copy(params1[key]))
+    for key in params1.unpacked_parameters:
+        union.add(key, np.union1d(params1[key], params2[key]))
+    for key in params1.unpacked_parameters:
+        union.set_unpack_parameter(key)
+    return union
+
+
 def _json_default(obj):
     """The reference's NumpyOrSetEncoder (util/serialize.py:18-70): arrays and sets as tagged dicts, so JSON
     archives written here load in pyphysim and vice versa.  (NumPy floats are written as floats; the reference

@@ -14,7 +14,8 @@ from collections.abc import Iterable
 
 import numpy as np
 
-from .parameters import SimulationParameters, _json_default, _json_object_hook
+from .parameters import (SimulationParameters, _json_default, _json_object_hook, combine_simulation_parameters,
+                         replace_dict_values)
 
 _CI_TABLE = {50: 0.674, 60: 0.842, 70: 1.036, 80: 1.282, 90: 1.645, 95: 1.96, 98: 2.326, 99: 2.576, 99.5: 2.807,
              99.8: 3.090, 99.9: 3.291}
@@ -325,7 +326,7 @@ class SimulationResults:
     # ---- persistence ------------------------------------------------------------------------
     def get_filename_with_replaced_params(self, filename):
         try:
-            return filename.format(**self.params.parameters)
+            return replace_dict_values(filename, self.params.parameters, filename_mode=True)
         except (KeyError, IndexError, ValueError):
             return filename
 
@@ -390,3 +391,29 @@ class SimulationResults:
         if self.runned_reps is not None:
             data["runned_reps"] = self.runned_reps
         return pd.DataFrame(data)
+
+
+def combine_simulation_results(simresults1, simresults2):
+    """Merge two SimulationResults whose parameters differ only in the values of the unpacked ones: Results
+    of variations present in both are merged, the others carried over (reference simulations/results.py:51-122;
+    the bin/combine_results.py workflow)."""
+    combined_params = combine_simulation_parameters(simresults1.params, simresults2.params)
+    result_names = simresults1.get_result_names()
+    if set(result_names) != set(simresults2.get_result_names()):
+        raise RuntimeError("Both SimulationResults objects must have the same results.")
+    union = SimulationResults()
+    union.set_parameters(combined_params)
+    for name in result_names:
+        list1, list2 = simresults1[name], simresults2[name]
+        type_code = list1[0].type_code
+        for unpack in combined_params.get_unpacked_params_list():
+            result_object = Result(name, type_code)
+            fixed_parameters = unpack.parameters
+            for sim, lst in ((simresults1, list1), (simresults2, list2)):
+                try:
+                    index = sim.params.get_pack_indexes(fixed_parameters)
+                    result_object.merge(lst[index[0]])
+                except ValueError:
+                    pass
+            union.append_result(result_object)
+    return union

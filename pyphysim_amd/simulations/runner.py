@@ -17,6 +17,18 @@ from .parameters import SimulationParameters
 from .results import Result, SimulationResults
 
 
+def get_partial_results_filename(results_base_filename, current_params, partial_results_folder=None):
+    """'<base>_unpack_<index, zero-padded to the digits of the number of variations>.pickle' inside
+    `partial_results_folder` (reference simulations/runner.py:109-145)."""
+    total_unpacks = current_params.get_num_unpacked_variations()
+    num_digits = len(str(total_unpacks))
+    unpack_index_str = str(current_params.unpack_index).zfill(num_digits)
+    name = "{0}_unpack_{1}.pickle".format(results_base_filename, unpack_index_str)
+    if partial_results_folder is not None:
+        name = os.path.join(partial_results_folder, name)
+    return name
+
+
 class SkipThisOne(Exception):
     """Raise inside _run_simulation to discard the current realization (runner.py:151-185)."""
 
@@ -110,7 +122,7 @@ class SimulationRunner:
             return None
         base = self._results.get_filename_with_replaced_params(os.path.basename(self._results_filename))
         folder = os.path.join(os.path.dirname(self._results_filename) or ".", self.partial_results_folder)
-        return os.path.join(folder, "{0}_unpack_{1:0>2}.pickle".format(base, max(current_params.unpack_index, 0)))
+        return get_partial_results_filename(base, current_params, folder)
 
     def _save_partial(self, current_rep, current_params, current_sim_results):
         name = self._partial_name(current_params)
