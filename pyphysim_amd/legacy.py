@@ -144,3 +144,95 @@ def run_mimo_ofdm(eng, seed_base, first, count, mod="qam", M=64, nt=4, nr=4, fft
     est = eng.blast_decode(G, Y.reshape(count, nr, used * n_ofdm_sym), dtype="f64")
     cnt, se, be = eng.demod_count(est, ints, n_real=count, dtype="f64")
     return cnt, se, be
+
+
+def run_ia(eng, seed_base, first, count, mod="qam", M=16, K=3, nr=2, nt=2, Ns=1, NSymbs=200, snr_db=20.0,
+           algo="closed_form", max_iterations=50, relative_factor=1e-6):
+    """Config 5 / SURVEY 8(f).3 template (apps/ia/simulate_ia.py:94-245).  The reference draws from separate
+    RandomStates -- the channel's (multiuser.py:670-709: randn_c(6, 6)), the noise's (randn_c(6, NSymbs)), the
+    iterative solvers' own (iabase.py:95,538-540: randn_c(2, 1) per user) and the global one (randint(0, M,
+    [3, NSymbs])) -- all seeded with seed_base + r by the harness that minted the fixtures."""
+    if (K, nr, nt, Ns) != (3, 2, 2, 1):
+        raise ValueError("the IA kernels cover K = 3, 2x2, one stream per user")
+    table, kind = _table(mod, M)
+    eng.set_constellation(table, kind)
+    noise_var = 1.0 / float(dB2Linear(snr_db))
+    _, ch = eng.legacy_draws([("randn", 36), ("randn", 36)], seed_base, first, count)
+    _, nz = eng.legacy_draws([("randn", 6 * NSymbs), ("randn", 6 * NSymbs)], seed_base, first, count)
+    ints, _ = eng.legacy_draws([("randint", 3 * NSymbs, M)], seed_base, first, count)
+    hc = ch.get()
+    big_H = INV_SQRT2 * (hc[:, :36] + 1j * hc[:, 36:]).reshape(count, 6, 6)
+    if algo == "closed_form":
+        sol = eng.ia_closed_form(big_H, noise_var)
+    else:
+        _, fi = eng.legacy_draws([("randn", 2), ("randn", 2)] * 3, seed_base, first, count)
+        hf = fi.get().reshape(count, 3, 2, 2)                    # [r, user, re/im block, antenna]
+        F0 = INV_SQRT2 * (hf[:, :, 0, :] + 1j * hf[:, :, 1, :])
+        F0 = F0 / np.linalg.norm(F0, axis=2, keepdims=True)
+        sol = eng.ia_iterative(algo, big_H, F0, noise_var, max_iterations, relative_factor)
+    # precoding and receive filtering as block matrices through the multi-user channel kernel
+    Fbig = np.zeros((count, 6, 3), dtype=complex)
+    Ubig = np.zeros((count, 3, 6), dtype=complex)
+    for k in range(3):
+        Fbig[:, 2 * k:2 * k + 2, k] = sol["F"][:, k]
+        Ubig[:, k, 2 * k:2 * k + 2] = sol["U"][:, k]
+    hn = nz.get()
+    n6 = 6 * NSymbs
+    noise = eng.complex_from_parts(hn[:, :n6].copy(), hn[:, n6:].copy(), INV_SQRT2, dtype="f64").reshape(count, 6, NSymbs)
+    sym = eng.modulate(ints, dtype="f64").reshape(count, 3, NSymbs)
+    X = eng.mimo_channel(eng.to_device(Fbig), sym, dtype="f64")
+    Y = eng.mimo_channel(eng.to_device(big_H), X, noise, noise_var, dtype="f64")
+    est = eng.mimo_channel(eng.to_device(Ubig), Y, dtype="f64")
+    cnt, se, be = eng.demod_count(est.reshape(count, 3 * NSymbs), ints, n_real=count, dtype="f64")
+    return cnt, sol, se, be
+
+
+def run_mimo_ofdm_tdl(eng, seed_base, first, count, mod="qam", M=16, nt=2, nr=2, fft_size=64, cp_size=16, num_used=None,
+                      n_ofdm_sym=2, snr_db=20.0, Fd=50.0, Ts=1e-6, L=8, tap_powers_dB=(0.0, -4.0, -9.0),
+                      tap_delays_samples=(0, 2, 5)):
+    """SURVEY 8(f).1 template: randint(nt * used * n_sym); Jakes ctor with shape (nr, nt): rand(L, nr, nt, 1) x2
+    (one discarded sample); TdlMimoChannel ctor: rand(L, taps, nr, nt, 1) x2; randn_c(nr, n + max delay)."""
+    table, kind = _table(mod, M)
+    eng.set_constellation(table, kind)
+    used = num_used or fft_size
+    noise_var = 1.0 / float(dB2Linear(snr_db))
+    p_lin, d_idx = discretize_profile(np.asarray(tap_powers_dB, dtype=float),
+                                      np.asarray(tap_delays_samples, dtype=float) * Ts, Ts)
+    S = len(d_idx)
+    P = S * nr * nt
+    ns = used * n_ofdm_sym
+    n = n_ofdm_sym * (fft_size + cp_size)
+    n_out = n + int(d_idx[-1])
+    prog = [("randint", nt * ns, M), ("rand", 2 * L * nr * nt), ("rand", 2 * L * P), ("randn", nr * n_out),
+            ("randn", nr * n_out)]
+    ints, dbls = eng.legacy_draws(prog, seed_base, first, count)
+    h_d = dbls.get()
+    step = Ts * 1.0000000001
+    dt = (Ts + step) - Ts
+    sym = eng.modulate(ints, dtype="f64")
+    X = eng.blast_encode(sym, nt, batch=count, dtype="f64")
+    T = eng.ofdm_modulate(X, fft_size, cp_size, used, batch=count * nt, dtype="f64").reshape(count, nt, n)
+    T_h = T.get()
+    se, be = [], []
+    for r in range(count):
+        row = h_d[r]
+        o = 2 * L * nr * nt
+        phi = 2 * np.pi * row[o:o + L * P].reshape(L, P)
+        psi = 2 * np.pi * row[o + L * P:o + 2 * L * P].reshape(L, P)
+        o += 2 * L * P
+        noise = eng.complex_from_parts(row[o:o + nr * n_out].copy(), row[o + nr * n_out:o + 2 * nr * n_out].copy(),
+                                       INV_SQRT2, dtype="f64").reshape(nr, n_out)
+        taps = eng.jakes_generate(phi, psi, Fd, Ts, dt, n, tap_power=np.repeat(p_lin, nr * nt), dtype="f64",
+                                  device=True).reshape(S, nr, nt, n)
+        faded = eng.tdl_apply_mimo(eng.to_device(T_h[r]), taps, d_idx, dtype="f64")
+        R = eng.awgn_add(faded, noise, noise_var, dtype="f64")
+        Rn = eng.slice_rows(R, n) if n_out != n else R
+        Y = eng.ofdm_demodulate(Rn, fft_size, cp_size, used, batch=nr, dtype="f64").reshape(nr, ns)
+        Hu = eng.tdl_mean_freq_response(taps, d_idx, n_ofdm_sym, fft_size, cp_size, used, dtype="f64")
+        G, _ = eng.blast_filter(Hu.reshape(ns, nr, nt), noise_var, dtype="f64")
+        est = eng.blast_decode_per_subcarrier(G, Y, dtype="f64")
+        idx_r = eng.to_device(ints.get()[r], np.int32)
+        _, s, b = eng.demod_count(est, idx_r, n_real=1, dtype="f64")
+        se.append(int(s[0]))
+        be.append(int(b[0]))
+    return np.array(se), np.array(be)

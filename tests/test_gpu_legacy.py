@@ -54,3 +54,25 @@ def test_ofdm_tdl_same_seed_as_reference(engine):
 
 def test_mimo_ofdm_same_seed_as_reference(engine):
     _check("c4_mimo_ofdm", lambda s, n, kw: legacy.run_mimo_ofdm(engine, s, 0, n, **kw))
+
+
+def test_ia_same_seed_as_reference(engine):
+    """Config 5: three RandomStates (channel, noise, data) replayed on the device."""
+    _check("c5_ia", lambda s, n, kw: legacy.run_ia(engine, s, 0, n, **kw))
+
+
+def test_ia_iterative_same_seed_as_reference(engine):
+    """plus the iterative solvers' own RandomState for the initial precoders; error counts,
+    iteration counts and capacities equal the reference run with the same seeds."""
+    for kw, reals in golden_cases("f3_ia_iterative"):
+        seeds = [int(g["seed"]) for g in reals]
+        cnt, sol, se, be = legacy.run_ia(engine, seeds[0], 0, len(seeds), **kw)
+        assert [int(v) for v in se] == [int(g["symbol_errors"]) for g in reals], kw
+        assert [int(v) for v in be] == [int(g["bit_errors"]) for g in reals], kw
+        assert [int(v) for v in sol["iterations"]] == [int(g["runned_iterations"]) for g in reals], kw
+        assert np.allclose(sol["capacity"], [float(g["sum_capacity"]) for g in reals], rtol=0, atol=1e-6)
+
+
+def test_mimo_ofdm_tdl_same_seed_as_reference(engine):
+    """SURVEY 8(f).1 (frequency-selective MIMO-OFDM) under np.random.seed."""
+    _check("f1_mimo_ofdm_tdl", lambda s, n, kw: legacy.run_mimo_ofdm_tdl(engine, s, 0, n, **kw))
