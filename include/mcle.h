@@ -83,6 +83,13 @@ int mcle_timer_stop_ms(mcle_ctx* ctx, float* ms);                               
  *      :659-777 QAM; the table itself is built by the host mirror) ----------------------- */
 int mcle_set_constellation(mcle_ctx* ctx, const double* re_im, int M, int kind);
 
+/* Host only (no device needed): the candidate grid the f32 min-distance kernels search instead of all M points
+ * (DESIGN.md section 5.1).  cells [32*32] receives G*G words: byte 0 = number of candidates (0xFF: search
+ * everything), bytes 1..7 = candidate indices in ascending order; cell (ix, iy) covers
+ * [x0 + ix*h, x0 + (ix+1)*h) x [y0 + iy*h, ...), border cells extending to infinity.  2 <= M <= 256. */
+int mcle_build_demod_grid(const double* re_im, int M, int* G, double* x0, double* y0, double* h,
+                          unsigned long long* cells);
+
 /* ---- a2/a3/a4: Modulator.modulate / demodulate (fundamental.py:175-248), count_bit_errors
  *      (util/misc.py:519-566) and the symbol-error count of user code --------------------- */
 int mcle_modulate(mcle_ctx* ctx, int dtype, const int32_t* d_idx, void* d_out, size_t n);

@@ -103,6 +103,8 @@ _PROTOS = {
     "mcle_timer_start": (c_int, [_P]),
     "mcle_timer_stop_ms": (c_int, [_P, POINTER(c_float)]),
     "mcle_set_constellation": (c_int, [_P, POINTER(c_double), c_int, c_int]),
+    "mcle_build_demod_grid": (c_int, [POINTER(c_double), c_int, POINTER(c_int), POINTER(c_double), POINTER(c_double),
+                                      POINTER(c_double), POINTER(c_uint64)]),
     "mcle_modulate": (c_int, [_P, c_int, _P, _P, c_size_t]),
     "mcle_demodulate": (c_int, [_P, c_int, c_int, _P, _P, c_size_t]),
     "mcle_count_errors": (c_int, [_P, _P, _P, c_size_t, c_size_t, c_int, _P, _P, _P]),

@@ -135,6 +135,7 @@ int mcle_ctx_destroy(mcle_ctx* ctx) {
     for (auto& kv : ctx->twiddles) (void)hipFree(kv.second);
     if (ctx->d_table_f32) (void)hipFree(ctx->d_table_f32);
     if (ctx->d_table_f64) (void)hipFree(ctx->d_table_f64);
+    if (ctx->d_grid) (void)hipFree(ctx->d_grid);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -262,6 +263,71 @@ int mcle_timer_stop_ms(mcle_ctx* ctx, float* ms) {
 // kind == MCLE_CONST_QAM the library re-derives the square Gray QAM layout of the reference
 // (modulators/fundamental.py:697-777) and refuses tables that do not match it, because the slicer
 // fast path relies on that structure.
+// Candidate grid of the pruned min-distance search (modem.hpp: DemodGrid), built in f64.
+// For every cell: c* = nearest point to the (clamped) cell centre; a point c stays on the list unless c* is
+// closer than c by more than `margin` EVERYWHERE in the cell.  f(p) = |p - c*|^2 - |p - c|^2 is linear in p, so
+// its supremum over the (possibly unbounded) rectangle sits at a corner or is +inf.  Any point that can win
+// the exhaustive search somewhere in the cell must beat c* there, hence is on the list.
+int mcle_build_demod_grid(const double* re_im, int M, int* G_out, double* x0_out, double* y0_out, double* h_out,
+                          unsigned long long* cells) {
+    MCLE_REQUIRE(re_im != nullptr && G_out != nullptr && x0_out != nullptr && y0_out != nullptr && h_out != nullptr &&
+                     cells != nullptr, "null argument");
+    MCLE_REQUIRE(M >= 2 && M <= 256, "the candidate grid covers 2 <= M <= 256 (byte indices)");
+    int G = 8;
+    while (G < 32 && G * G < 4 * M) G *= 2;              // about 2 sqrt(M) cells per axis, in {8, 16, 32}
+    double maxabs = 0.0;
+    for (int m = 0; m < 2 * M; ++m) maxabs = std::max(maxabs, std::fabs(re_im[m]));
+    MCLE_REQUIRE(maxabs > 0.0, "degenerate constellation");
+    const double half = 1.2345 * maxabs;                  // off the Voronoi edges of the regular constellations
+    const double h = 2.0 * half / G, x0 = -half, y0 = -half;
+    const double R = 1.5 * (half + maxabs);
+    const double margin = 1e-5 * R * R;                   // >> f32 rounding of either metric inside the box
+    for (int iy = 0; iy < G; ++iy)
+        for (int ix = 0; ix < G; ++ix) {
+            const double xl = x0 + ix * h, xh = xl + h, yl = y0 + iy * h, yh = yl + h;
+            const double cx_ = 0.5 * (xl + xh), cy_ = 0.5 * (yl + yh);
+            int best = 0;
+            double bd = 1e300;
+            for (int m = 0; m < M; ++m) {
+                const double dx = cx_ - re_im[2 * m], dy = cy_ - re_im[2 * m + 1];
+                const double d = dx * dx + dy * dy;
+                if (d < bd) {
+                    bd = d;
+                    best = m;
+                }
+            }
+            const double sx = re_im[2 * best], sy = re_im[2 * best + 1];
+            unsigned long long word = 0;
+            int n = 0;
+            for (int m = 0; m < M && n <= 7; ++m) {
+                bool keep = (m == best);
+                if (!keep) {
+                    const double px = re_im[2 * m], py = re_im[2 * m + 1];
+                    const double bx = 2.0 * (px - sx), by = 2.0 * (py - sy);   // f(p) = K + b . p
+                    const double K = (sx * sx + sy * sy) - (px * px + py * py);
+                    const bool inf_x = (bx > 0.0 && ix == G - 1) || (bx < 0.0 && ix == 0);
+                    const bool inf_y = (by > 0.0 && iy == G - 1) || (by < 0.0 && iy == 0);
+                    if (inf_x || inf_y) {
+                        keep = true;
+                    } else {
+                        const double sup = K + bx * (bx > 0.0 ? xh : xl) + by * (by > 0.0 ? yh : yl);
+                        keep = sup >= -margin;
+                    }
+                }
+                if (keep) {
+                    if (n < 7) word |= (unsigned long long)m << (8 * (n + 1));
+                    ++n;
+                }
+            }
+            cells[iy * G + ix] = n > 7 ? 0xFFull : (word | (unsigned long long)n);
+        }
+    *G_out = G;
+    *x0_out = x0;
+    *y0_out = y0;
+    *h_out = h;
+    return MCLE_OK;
+}
+
 int mcle_set_constellation(mcle_ctx* ctx, const double* re_im, int M, int kind) {
     MCLE_REQUIRE(ctx != nullptr && re_im != nullptr, "null argument");
     MCLE_REQUIRE(M >= 2 && M <= 1024 && (M & (M - 1)) == 0, "M must be a power of two in [2, 1024] (got %d)", M);
@@ -300,6 +366,20 @@ int mcle_set_constellation(mcle_ctx* ctx, const double* re_im, int M, int kind) 
     MCLE_HIP(hipMalloc((void**)&ctx->d_table_f64, M * sizeof(double2)));
     MCLE_HIP(hipMemcpy(ctx->d_table_f32, h32.data(), M * sizeof(float2), hipMemcpyHostToDevice));
     MCLE_HIP(hipMemcpy(ctx->d_table_f64, re_im, M * sizeof(double2), hipMemcpyHostToDevice));
+    ctx->grid_G = 0;
+    if (M <= 256) {
+        std::vector<unsigned long long> cells(32 * 32);
+        int G = 0;
+        double x0 = 0, y0 = 0, h = 0;
+        int rc = mcle_build_demod_grid(re_im, M, &G, &x0, &y0, &h, cells.data());
+        if (rc) return rc;
+        if (!ctx->d_grid) MCLE_HIP(hipMalloc((void**)&ctx->d_grid, 32 * 32 * sizeof(unsigned long long)));
+        MCLE_HIP(hipMemcpy(ctx->d_grid, cells.data(), (size_t)G * G * sizeof(unsigned long long), hipMemcpyHostToDevice));
+        ctx->grid_G = G;
+        ctx->grid_x0 = (float)x0;
+        ctx->grid_y0 = (float)y0;
+        ctx->grid_inv_h = (float)(1.0 / h);
+    }
     ctx->M = M;
     ctx->bits = bits;
     ctx->kind = kind;

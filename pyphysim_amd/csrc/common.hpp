@@ -143,6 +143,10 @@ struct mcle_ctx {
     double2* d_table_f64 = nullptr;
     double qam_scale = 0.0;  // sqrt(2(M-1)/3) for square QAM
     int qam_L = 0;
+    // candidate grid of the pruned f32 min-distance search (modem.hpp: DemodGrid); grid_G == 0: none
+    unsigned long long* d_grid = nullptr;
+    int grid_G = 0;
+    float grid_x0 = 0.f, grid_y0 = 0.f, grid_inv_h = 0.f;
     // twiddle tables w[k] = exp(-2 pi i k / n), k < n, per (n, dtype)
     std::map<mcle::TwiddleKey, void*> twiddles;
     // scratch for host->device parameter blocks

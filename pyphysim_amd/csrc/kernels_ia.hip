@@ -392,7 +392,9 @@ __global__ __launch_bounds__(64) void k_run_ia(ModemParams<T> mp, int n_symbols,
     __shared__ cx<T> s_F[64][6 + 1];
     __shared__ cx<T> s_U[64][6 + 1];
     __shared__ unsigned s_ok[64];
+    __shared__ unsigned long long s_grid[sizeof(T) == 4 ? kMaxGridCells : 1];
     load_table(mp, s_table);
+    if (sizeof(T) == 4) load_grid(mp, s_grid);
     const int lane = threadIdx.x;
     const T sigma = (T)sqrt(noise_var);
     const uint32_t mask = (uint32_t)(mp.M - 1);
@@ -482,7 +484,7 @@ __global__ __launch_bounds__(64) void k_run_ia(ModemParams<T> mp, int n_symbols,
                         y[a] = acc;
                     }
                     const cx<T> est = cadd(cmul(U[k][0], y[0]), cmul(U[k][1], y[1]));
-                    const unsigned x = (unsigned)(tx[k] ^ demod_one(mp, s_table, est));
+                    const unsigned x = (unsigned)(tx[k] ^ demod_one(mp, s_table, s_grid, est));
                     se += (x != 0u);
                     be += __popc(x);
                 }
@@ -499,6 +501,7 @@ __global__ __launch_bounds__(64) void k_run_ia(ModemParams<T> mp, int n_symbols,
 
 template <typename T> static ModemParams<T> ia_modem(const mcle_ctx* ctx, int method) {
     ModemParams<T> p;
+    p.grid = context_grid<T>(ctx);
     if (sizeof(T) == 8)
         p.g_table = reinterpret_cast<const cx<T>*>(ctx->d_table_f64);
     else

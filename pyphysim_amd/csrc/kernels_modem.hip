@@ -13,6 +13,7 @@ constexpr int kMaxM = 1024;
 template <typename T> ModemParams<T> modem_params(const mcle_ctx* ctx, int method);
 template <> ModemParams<float> modem_params<float>(const mcle_ctx* ctx, int method) {
     ModemParams<float> p;
+    p.grid = context_grid<float>(ctx);
     p.g_table = ctx->d_table_f32;
     p.M = ctx->M;
     p.bits = ctx->bits;
@@ -24,6 +25,7 @@ template <> ModemParams<float> modem_params<float>(const mcle_ctx* ctx, int meth
 }
 template <> ModemParams<double> modem_params<double>(const mcle_ctx* ctx, int method) {
     ModemParams<double> p;
+    p.grid = context_grid<double>(ctx);
     p.g_table = ctx->d_table_f64;
     p.M = ctx->M;
     p.bits = ctx->bits;
@@ -60,10 +62,12 @@ template <typename T>
 __global__ __launch_bounds__(kBlock) void k_demodulate(ModemParams<T> mp, const cx<T>* __restrict__ rx,
                                                        int32_t* __restrict__ idx, size_t n) {
     __shared__ cx<T> s_table[kMaxM];
+    __shared__ unsigned long long s_grid[sizeof(T) == 4 ? kMaxGridCells : 1];
     load_table(mp, s_table);
+    if (sizeof(T) == 4) load_grid(mp, s_grid);
     __syncthreads();
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-        idx[i] = demod_one(mp, s_table, rx[i]);
+        idx[i] = demod_one(mp, s_table, s_grid, rx[i]);
 }
 
 // ---- error counting --------------------------------------------------------------------------
@@ -73,9 +77,11 @@ __global__ __launch_bounds__(kBlock) void k_count(ModemParams<T> mp, const cx<T>
                                                   const int32_t* __restrict__ a, const int32_t* __restrict__ b,
                                                   size_t n_per_real, size_t n_real, unsigned* __restrict__ ws) {
     __shared__ cx<T> s_table[DEMOD ? kMaxM : 1];
+    __shared__ unsigned long long s_grid[DEMOD && sizeof(T) == 4 ? kMaxGridCells : 1];
     __shared__ unsigned s_part[2 * (kBlock / 64)];
     if (DEMOD) {
         load_table(mp, s_table);
+        if (sizeof(T) == 4) load_grid(mp, s_grid);
         __syncthreads();
     }
     for (size_t r = blockIdx.y; r < n_real; r += gridDim.y) {
@@ -84,7 +90,7 @@ __global__ __launch_bounds__(kBlock) void k_count(ModemParams<T> mp, const cx<T>
         for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_per_real;
              i += (size_t)gridDim.x * blockDim.x) {
             const int tx = a[base + i];
-            const int dec = DEMOD ? demod_one(mp, s_table, rx[base + i]) : b[base + i];
+            const int dec = DEMOD ? demod_one(mp, s_table, s_grid, rx[base + i]) : b[base + i];
             const unsigned x = (unsigned)(tx ^ dec);
             se += (x != 0u);
             be += __popc(x);

@@ -6,7 +6,21 @@
 
 namespace mcle {
 
+// Pruned exhaustive search (f32 instantiations).  The plane is cut into G x G cells (border cells extend to
+// infinity); each cell lists, in ascending index order, every constellation point that can be the nearest one
+// -- within a rounding margin -- somewhere in the cell (built on the host in f64: capi.hip build_demod_grid).
+// Searching the list with the same metric and the same strict '<' gives the decision of the full sweep over
+// all M points, tie rule included, at a few candidates per symbol.  Cell word: byte 0 = count (0xFF: sweep
+// everything), bytes 1..7 = candidates.
+constexpr int kMaxGridCells = 32 * 32;
+struct DemodGrid {
+    const unsigned long long* cells;   // device [G*G]
+    int G;                             // 0: no grid (M > 256 or f64)
+    float x0, y0, inv_h;
+};
+
 template <typename T> struct ModemParams {
+    DemodGrid grid;
     const cx<T>* g_table;  // global constellation table [M]
     int M;
     int bits;        // log2(M)
@@ -72,6 +86,75 @@ __device__ __forceinline__ void demod_mindist_multi(const double2* __restrict__ 
     for (int k = 0; k < K; ++k) idx[k] = demod_mindist<double>(s_table, M, r[k]);
 }
 
+__device__ __forceinline__ unsigned long long grid_cell(const unsigned long long* __restrict__ s_grid, const DemodGrid& g,
+                                                        float x, float y) {
+    int ix = (int)floorf((x - g.x0) * g.inv_h), iy = (int)floorf((y - g.y0) * g.inv_h);
+    ix = ix < 0 ? 0 : (ix >= g.G ? g.G - 1 : ix);
+    iy = iy < 0 ? 0 : (iy >= g.G ? g.G - 1 : iy);
+    return s_grid[iy * g.G + ix];
+}
+// literal |c - r|^2 metric on the plain table (operator kernels); same decisions as demod_mindist<float>
+__device__ __forceinline__ int demod_grid(const float2* __restrict__ s_table, const unsigned long long* __restrict__ s_grid,
+                                          const DemodGrid& g, int M, float2 r) {
+    unsigned long long w = grid_cell(s_grid, g, r.x, r.y);
+    const int n = (int)(w & 0xFFull);
+    if (n == 0xFF) return demod_mindist<float>(s_table, M, r);
+    w >>= 8;
+    int idx = (int)(w & 0xFFull);
+    float best;
+    {
+        const float2 c = s_table[idx];
+        best = (r.x - c.x) * (r.x - c.x) + (r.y - c.y) * (r.y - c.y);
+    }
+    for (int j = 1; j < n; ++j) {
+        w >>= 8;
+        const int m = (int)(w & 0xFFull);
+        const float2 c = s_table[m];
+        const float dx = r.x - c.x, dy = r.y - c.y;
+        const float d = dx * dx + dy * dy;
+        if (d < best) {
+            best = d;
+            idx = m;
+        }
+    }
+    return idx;
+}
+// two-FMA metric on the {re, im, |c|^2/2} table (fused pipelines); same decisions as demod_mindist_multi<float>
+__device__ __forceinline__ int demod_grid4(const float4* __restrict__ s_tab4, const unsigned long long* __restrict__ s_grid,
+                                           const DemodGrid& g, int M, float2 r) {
+    unsigned long long w = grid_cell(s_grid, g, r.x, r.y);
+    int n = (int)(w & 0xFFull);
+    if (n == 0xFF) {
+        const float2 rr[1] = {r};
+        int out[1];
+        demod_mindist_multi<1>(s_tab4, M, rr, out);
+        return out[0];
+    }
+    w >>= 8;
+    int idx = (int)(w & 0xFFull);
+    float best;
+    {
+        const float4 c = s_tab4[idx];
+        best = fmaf(-r.y, c.y, fmaf(-r.x, c.x, c.z));
+    }
+    for (int j = 1; j < n; ++j) {
+        w >>= 8;
+        const int m = (int)(w & 0xFFull);
+        const float4 c = s_tab4[m];
+        const float d = fmaf(-r.y, c.y, fmaf(-r.x, c.x, c.z));
+        if (d < best) {
+            best = d;
+            idx = m;
+        }
+    }
+    return idx;
+}
+template <typename T>
+__device__ __forceinline__ void load_grid(const ModemParams<T>& mp, unsigned long long* s_grid) {
+    const int cells = mp.grid.G * mp.grid.G;
+    for (int i = threadIdx.x; i < cells; i += blockDim.x) s_grid[i] = mp.grid.cells[i];
+}
+
 __device__ __forceinline__ int gray2binary8(int g) {
     g ^= g >> 4;
     g ^= g >> 2;
@@ -95,6 +178,27 @@ template <typename T>
 __device__ __forceinline__ int demod_one(const ModemParams<T>& mp, const cx<T>* s_table, cx<T> r) {
     if (mp.method == MCLE_DEMOD_QAM_SLICER) return demod_qam_slicer<T>(r, mp.qam_scale, mp.qam_L, mp.half_bits);
     return demod_mindist<T>(s_table, mp.M, r);
+}
+// with the candidate grid in LDS (s_grid may be anything when mp.grid.G == 0 or T = double)
+template <typename T>
+__device__ __forceinline__ int demod_one(const ModemParams<T>& mp, const cx<T>* s_table,
+                                         const unsigned long long* s_grid, cx<T> r) {
+    if (mp.method == MCLE_DEMOD_QAM_SLICER) return demod_qam_slicer<T>(r, mp.qam_scale, mp.qam_L, mp.half_bits);
+    if constexpr (sizeof(T) == 4) {
+        if (mp.grid.G > 0) return demod_grid(s_table, s_grid, mp.grid, mp.M, r);
+    }
+    return demod_mindist<T>(s_table, mp.M, r);
+}
+
+// host: candidate grid of the context for the f32 instantiation, none for f64 (parity path sweeps everything)
+template <typename T> inline DemodGrid context_grid(const mcle_ctx* ctx) {
+    DemodGrid g;
+    g.cells = ctx->d_grid;
+    g.G = (sizeof(T) == 4 && ctx->d_grid != nullptr) ? ctx->grid_G : 0;
+    g.x0 = ctx->grid_x0;
+    g.y0 = ctx->grid_y0;
+    g.inv_h = ctx->grid_inv_h;
+    return g;
 }
 
 // cooperative copy of the constellation into LDS (call before a __syncthreads())

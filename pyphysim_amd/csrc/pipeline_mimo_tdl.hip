@@ -65,10 +65,12 @@ __global__ __launch_bounds__(kPipeBlock, sizeof(T) == 4 ? 3 : 1) void k_run_mimo
     cx<T>* s_table = reinterpret_cast<cx<T>*>(s_tab4);  // f64: the plain table lives in the same place
     unsigned* s_red = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(s_tab4) +
                                                   kMaxTable * (sizeof(T) == 4 ? sizeof(float4) : sizeof(cx<T>)));
-    unsigned char* s_idx = reinterpret_cast<unsigned char*>(s_red + 16);   // [NA*num_used]
+    unsigned long long* s_grid = reinterpret_cast<unsigned long long*>(s_red + 16);   // [G*G] candidate grid (f32)
+    unsigned char* s_idx = reinterpret_cast<unsigned char*>(s_grid + mp.grid.G * mp.grid.G);   // [NA*num_used]
 
     const int tid0 = threadIdx.x;
     for (int k = tid0; k < N; k += kPipeBlock) s_tw[k] = g_tw[k];
+    load_grid(mp, s_grid);
     for (int m = tid0; m < mp.M; m += kPipeBlock) {
         const cx<T> c = mp.g_table[m];
         if constexpr (sizeof(T) == 4)
@@ -368,7 +370,12 @@ __global__ __launch_bounds__(kPipeBlock, sizeof(T) == 4 ? 3 : 1) void k_run_mimo
 #pragma unroll
                     for (int a = 0; a < NA; ++a) dec[a] = demod_qam_slicer<T>(est[a], mp.qam_scale, mp.qam_L, mp.half_bits);
                 } else if constexpr (sizeof(T) == 4) {
-                    demod_mindist_multi<NA>(s_tab4, mp.M, est, dec);
+                    if (mp.grid.G > 0) {
+#pragma unroll
+                        for (int a = 0; a < NA; ++a) dec[a] = demod_grid4(s_tab4, s_grid, mp.grid, mp.M, est[a]);
+                    } else {
+                        demod_mindist_multi<NA>(s_tab4, mp.M, est, dec);
+                    }
                 } else {
                     demod_mindist_multi<NA>(s_table, mp.M, est, dec);
                 }
@@ -394,12 +401,13 @@ int run_mimo_tdl_impl(mcle_ctx* ctx, MimoTdlParams pp, int method, uint64_t seed
     int rc;
     void* tw = nullptr;
     if ((rc = ctx->get_twiddles(N, sizeof(T) == 8 ? MCLE_F64 : MCLE_F32, &tw))) return rc;
+    const ModemParams<T> mp = pipe_modem<T>(ctx, method);
     const size_t PS = (size_t)pp.n_taps * NA * NA;
     const size_t ray_elems = (PS * pp.L * 3 + 1) / 2;            // {re, im, theta} per ray, in complex elements
     pp.x_elems = (int)(ray_elems > (size_t)NA * N ? ray_elems : (size_t)NA * N);
     const size_t lds = (size_t)(pp.x_elems + N + PS * (pp.K + 1) + PS + 2 * NA * (pp.dmax > 0 ? pp.dmax : 1)) * sizeof(cx<T>) +
                        kMaxTable * (sizeof(T) == 4 ? sizeof(float4) : sizeof(cx<T>)) + 16 * sizeof(unsigned) +
-                       (size_t)NA * pp.num_used + 16;
+                       (size_t)mp.grid.G * mp.grid.G * sizeof(unsigned long long) + (size_t)NA * pp.num_used + 16;
     MCLE_REQUIRE(lds <= 160 * 1024, "configuration needs %zu bytes of LDS (limit 160 KiB)", lds);
     auto kern = k_run_mimo_ofdm_tdl<T, N, NA>;
     MCLE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -408,8 +416,8 @@ int run_mimo_tdl_impl(mcle_ctx* ctx, MimoTdlParams pp, int method, uint64_t seed
     if (per_cu > 8) per_cu = 8;
     const uint64_t cap = (uint64_t)ctx->n_cu * per_cu;
     const unsigned grid = (unsigned)(count < cap ? count : cap);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kPipeBlock), lds, ctx->stream, pp, pipe_modem<T>(ctx, method), seed, first,
-                       count, (const cx<T>*)tw, d_counters, d_sym, d_bit);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kPipeBlock), lds, ctx->stream, pp, mp, seed, first, count,
+                       (const cx<T>*)tw, d_counters, d_sym, d_bit);
     MCLE_LAUNCH_CHECK();
     return MCLE_OK;
 }

@@ -93,10 +93,12 @@ __global__ __launch_bounds__(kPipeBlock) void k_run_flat(FlatParams fp, ModemPar
                                                          uint64_t first, uint64_t count, unsigned* __restrict__ ws) {
     constexpr bool kRec = (LR > 0) && (sizeof(T) == 4);
     __shared__ cx<T> s_table[kMaxTable];
+    __shared__ unsigned long long s_grid[sizeof(T) == 4 ? kMaxGridCells : 1];
     __shared__ double s_w[kMaxRays], s_psi[kMaxRays];
     __shared__ float2 s_rot[kMaxRays];
     __shared__ unsigned s_red[2 * (kPipeBlock / 64)];
     load_table(mp, s_table);
+    if (sizeof(T) == 4) load_grid(mp, s_grid);
     const int chunks = (fp.n_symbols + kChunk - 1) / kChunk;
     const uint64_t items = count * (uint64_t)chunks;
     const T sigma = (T)fp.noise_sigma;
@@ -176,7 +178,7 @@ __global__ __launch_bounds__(kPipeBlock) void k_run_flat(FlatParams fp, ModemPar
                         } else {
                             r = cadd(s, z[e]);
                         }
-                        const unsigned x = (unsigned)(tx ^ demod_one(mp, s_table, r));
+                        const unsigned x = (unsigned)(tx ^ demod_one(mp, s_table, s_grid, r));
                         se += (x != 0u);
                         be += __popc(x);
                     }
@@ -216,11 +218,13 @@ __global__ __launch_bounds__(kPipeBlock, sizeof(T) == 4 ? 3 : 1) void k_run_mimo
     cx<T>* s_G = s_H + NA * NA;                          // [NA*NA]
     float4* s_tab4 = reinterpret_cast<float4*>(s_G + NA * NA);     // [kMaxTable] {re, im, |c|^2/2, 0} (f32 min-distance)
     unsigned* s_red = reinterpret_cast<unsigned*>(s_tab4 + kMaxTable);  // [8] + flag
-    unsigned char* s_idx = reinterpret_cast<unsigned char*>(s_red + 16);  // [NA*num_used]
+    unsigned long long* s_grid = reinterpret_cast<unsigned long long*>(s_red + 16);   // [G*G] candidate grid (f32)
+    unsigned char* s_idx = reinterpret_cast<unsigned char*>(s_grid + mp.grid.G * mp.grid.G);  // [NA*num_used]
 
     const int tid = threadIdx.x;
     for (int k = tid; k < N; k += kPipeBlock) s_tw[k] = g_tw[k];
     load_table(mp, s_table);
+    load_grid(mp, s_grid);
     for (int m = tid; m < mp.M; m += kPipeBlock) {
         const cx<T> c = mp.g_table[m];
         s_tab4[m] = make_float4((float)c.x, (float)c.y, (float)(0.5 * (c.x * c.x + c.y * c.y)), 0.f);
@@ -341,7 +345,12 @@ __global__ __launch_bounds__(kPipeBlock, sizeof(T) == 4 ? 3 : 1) void k_run_mimo
 #pragma unroll
                     for (int a = 0; a < NA; ++a) dec[a] = demod_qam_slicer<T>(est[a], mp.qam_scale, mp.qam_L, mp.half_bits);
                 } else if constexpr (sizeof(T) == 4) {
-                    demod_mindist_multi<NA>(s_tab4, mp.M, est, dec);
+                    if (mp.grid.G > 0) {
+#pragma unroll
+                        for (int a = 0; a < NA; ++a) dec[a] = demod_grid4(s_tab4, s_grid, mp.grid, mp.M, est[a]);
+                    } else {
+                        demod_mindist_multi<NA>(s_tab4, mp.M, est, dec);
+                    }
                 } else {
                     demod_mindist_multi<NA>(s_table, mp.M, est, dec);
                 }
@@ -393,11 +402,13 @@ __global__ __launch_bounds__(BLOCK) void k_run_ofdm_tdl(TdlParams pp, ModemParam
     double2* s_rayD = reinterpret_cast<double2*>(s_psi + MCLE_MAX_TAPS * kMaxRays / 4);   // [taps*L] ray sums
     float2* s_rotB = reinterpret_cast<float2*>(s_rayD + MCLE_MAX_TAPS * kMaxRays / 4);     // [taps*L] BLOCK-step rotations
     unsigned* s_red = reinterpret_cast<unsigned*>(s_rotB + MCLE_MAX_TAPS * kMaxRays / 4);
-    unsigned char* s_idx = reinterpret_cast<unsigned char*>(s_red + 16);             // [num_used]
+    unsigned long long* s_grid = reinterpret_cast<unsigned long long*>(s_red + 16);  // [G*G] candidate grid (f32)
+    unsigned char* s_idx = reinterpret_cast<unsigned char*>(s_grid + mp.grid.G * mp.grid.G);   // [num_used]
 
     const int tid = threadIdx.x;
     for (int k = tid; k < N; k += BLOCK) s_tw[k] = g_tw[k];
     load_table(mp, s_table);
+    load_grid(mp, s_grid);
     const int U = pp.num_used, cp = pp.cp, S = pp.n_taps, L = pp.L;
     const int dmax = pp.tap_delay[S - 1];
     const T sigma = (T)sqrt(pp.noise_var);
@@ -579,7 +590,7 @@ __global__ __launch_bounds__(BLOCK) void k_run_ofdm_tdl(TdlParams pp, ModemParam
                 cx<T> h = mk<T>(0, 0);
                 for (int i = 0; i < S; ++i) h = cfma(s_mean[i], s_tw[(bin * pp.tap_delay[i]) & (N - 1)], h);
                 const cx<T> eq = cdivide(cscale(s_y[bin], rx_scale), h);
-                const unsigned x = (unsigned)((int)s_idx[d] ^ demod_one(mp, s_table, eq));
+                const unsigned x = (unsigned)((int)s_idx[d] ^ demod_one(mp, s_table, s_grid, eq));
                 se += (x != 0u);
                 be += __popc(x);
             }
@@ -647,8 +658,10 @@ int run_mimo_impl(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, uint64_t seed, u
     void* tw = nullptr;
     if ((rc = ctx->get_twiddles(N, sizeof(T) == 8 ? MCLE_F64 : MCLE_F32, &tw))) return rc;
     MimoParams pp{cfg->cp_size, cfg->num_used, cfg->n_ofdm_sym, cfg->mmse, cfg->noise_var};
+    const ModemParams<T> mp = pipe_modem<T>(ctx, cfg->demod_method);
     const size_t lds = (size_t)(NA * N + N + kMaxTable + 2 * NA * NA) * sizeof(cx<T>) + kMaxTable * sizeof(float4) +
-                       16 * sizeof(unsigned) + (size_t)NA * cfg->num_used;
+                       16 * sizeof(unsigned) + (size_t)mp.grid.G * mp.grid.G * sizeof(unsigned long long) +
+                       (size_t)NA * cfg->num_used;
     auto kern = k_run_mimo_ofdm<T, N, NA>;
     MCLE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int per_cu = (int)((size_t)160 * 1024 / (lds + 512));  // gfx950: 160 KiB of LDS per CU
@@ -656,8 +669,8 @@ int run_mimo_impl(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, uint64_t seed, u
     if (per_cu > 8) per_cu = 8;
     const uint64_t cap = (uint64_t)ctx->n_cu * per_cu;
     const unsigned grid = (unsigned)(count < cap ? count : cap);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kPipeBlock), lds, ctx->stream, pp, pipe_modem<T>(ctx, cfg->demod_method),
-                       seed, first, count, (const cx<T>*)tw, d_counters, d_sym, d_bit);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kPipeBlock), lds, ctx->stream, pp, mp, seed, first, count,
+                       (const cx<T>*)tw, d_counters, d_sym, d_bit);
     MCLE_LAUNCH_CHECK();
     return MCLE_OK;
 }
@@ -688,9 +701,10 @@ int run_tdl_impl(mcle_ctx* ctx, const mcle_ofdm_tdl_cfg* cfg, uint64_t seed, uin
         pp.tap_amp[i] = i < cfg->n_taps ? std::sqrt(cfg->tap_power[i]) * std::sqrt(1.0 / (double)cfg->L) : 0.0;
         pp.tap_delay[i] = i < cfg->n_taps ? cfg->tap_delay[i] : 0;
     }
+    const ModemParams<T> mp = pipe_modem<T>(ctx, cfg->demod_method);
     const size_t lds = (size_t)(4 * N + kMaxTable + MCLE_MAX_TAPS + MCLE_MAX_TAPS * (BLOCK / 64)) * sizeof(cx<T>) +
                        (size_t)(MCLE_MAX_TAPS * kMaxRays / 4) * (2 * sizeof(double) + sizeof(double2) + sizeof(float2)) +
-                       16 * sizeof(unsigned) +
+                       16 * sizeof(unsigned) + (size_t)mp.grid.G * mp.grid.G * sizeof(unsigned long long) +
                        (size_t)cfg->num_used + 16;
     auto kern = k_run_ofdm_tdl<T, N, BLOCK>;
     MCLE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -699,8 +713,8 @@ int run_tdl_impl(mcle_ctx* ctx, const mcle_ofdm_tdl_cfg* cfg, uint64_t seed, uin
     if (per_cu > 2048 / BLOCK) per_cu = 2048 / BLOCK;
     const uint64_t cap = (uint64_t)ctx->n_cu * per_cu;
     const unsigned grid = (unsigned)(count < cap ? count : cap);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(BLOCK), lds, ctx->stream, pp, pipe_modem<T>(ctx, cfg->demod_method), seed,
-                       first, count, (const cx<T>*)tw, d_counters, d_sym, d_bit);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(BLOCK), lds, ctx->stream, pp, mp, seed, first, count, (const cx<T>*)tw,
+                       d_counters, d_sym, d_bit);
     MCLE_LAUNCH_CHECK();
     return MCLE_OK;
 }
