@@ -49,11 +49,34 @@ __global__ __launch_bounds__(kMimoBlock) void k_blast_decode(const cx<T>* __rest
     const cx<T>* Gb = G + b * (size_t)nt * nr;
     const cx<T>* Yb = Y + b * (size_t)nr * ns;
     cx<T>* eb = est + b * (size_t)nt * ns;
+    // one thread per column; the nt interleaved results of a column are contiguous in memory and leave as
+    // 16-byte stores (four strided 8-byte streams per wave were the bottleneck of the first version)
     for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < ns; c += (size_t)gridDim.x * blockDim.x) {
-        for (int a = 0; a < nt; ++a) {
-            cx<T> acc = mk<T>(0, 0);
-            for (int r = 0; r < nr; ++r) acc = cfma(Gb[a * nr + r], Yb[(size_t)r * ns + c], acc);
-            eb[c * nt + a] = acc;
+        if (nt == 4 && nr == 4) {
+            cx<T> y[4], e[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) y[r] = Yb[(size_t)r * ns + c];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                cx<T> acc = mk<T>(0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc = cfma(Gb[a * 4 + r], y[r], acc);
+                e[a] = acc;
+            }
+            if constexpr (sizeof(T) == 4) {
+                float4* o4 = reinterpret_cast<float4*>(eb + c * 4);
+                o4[0] = make_float4(e[0].x, e[0].y, e[1].x, e[1].y);
+                o4[1] = make_float4(e[2].x, e[2].y, e[3].x, e[3].y);
+            } else {
+#pragma unroll
+                for (int a = 0; a < 4; ++a) eb[c * 4 + a] = e[a];
+            }
+        } else {
+            for (int a = 0; a < nt; ++a) {
+                cx<T> acc = mk<T>(0, 0);
+                for (int r = 0; r < nr; ++r) acc = cfma(Gb[a * nr + r], Yb[(size_t)r * ns + c], acc);
+                eb[c * nt + a] = acc;
+            }
         }
     }
 }
