@@ -40,34 +40,63 @@ template <> ModemParams<double> modem_params<double>(const mcle_ctx* ctx, int me
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_modulate(ModemParams<T> mp, const int32_t* __restrict__ idx,
                                                      cx<T>* __restrict__ out, size_t n,
-                                                     unsigned* __restrict__ status) {
+                                                     unsigned* __restrict__ status, int vec) {
     __shared__ cx<T> s_table[kMaxM];
     load_table(mp, s_table);
     __syncthreads();
     bool bad = false;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        int v = idx[i];
+    auto lookup = [&](int v) -> cx<T> {
         if (v < 0) v += mp.M;
         if (v < 0 || v >= mp.M) {
             bad = true;
             v = 0;
         }
-        out[i] = s_table[v];
+        return s_table[v];
+    };
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+    bool done = false;
+    if constexpr (sizeof(T) == 4) {
+        if (vec) {                       // two symbols per thread: 8-byte index load, 16-byte sample store
+            const int2* idx2 = reinterpret_cast<const int2*>(idx);
+            float4* out4 = reinterpret_cast<float4*>(out);
+            for (size_t p = tid; p < n / 2; p += stride) {
+                const int2 v = idx2[p];
+                const float2 a = lookup(v.x), b = lookup(v.y);
+                out4[p] = make_float4(a.x, a.y, b.x, b.y);
+            }
+            if ((n & 1) && tid == 0) out[n - 1] = lookup(idx[n - 1]);
+            done = true;
+        }
     }
+    if (!done)
+        for (size_t i = tid; i < n; i += stride) out[i] = lookup(idx[i]);
     if (bad) atomicOr(status, 1u);
 }
 
 // ---- demodulate ----------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_demodulate(ModemParams<T> mp, const cx<T>* __restrict__ rx,
-                                                       int32_t* __restrict__ idx, size_t n) {
+                                                       int32_t* __restrict__ idx, size_t n, int vec) {
     __shared__ cx<T> s_table[kMaxM];
     __shared__ unsigned long long s_grid[sizeof(T) == 4 ? kMaxGridCells : 1];
     load_table(mp, s_table);
     if (sizeof(T) == 4) load_grid(mp, s_grid);
     __syncthreads();
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-        idx[i] = demod_one(mp, s_table, s_grid, rx[i]);
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+    if constexpr (sizeof(T) == 4) {
+        if (vec) {                       // two symbols per thread: 16-byte sample load, 8-byte index store
+            const float4* rx4 = reinterpret_cast<const float4*>(rx);
+            int2* idx2 = reinterpret_cast<int2*>(idx);
+            for (size_t p = tid; p < n / 2; p += stride) {
+                const float4 v = rx4[p];
+                idx2[p] = make_int2(demod_one(mp, s_table, s_grid, make_float2(v.x, v.y)),
+                                    demod_one(mp, s_table, s_grid, make_float2(v.z, v.w)));
+            }
+            if ((n & 1) && tid == 0) idx[n - 1] = demod_one(mp, s_table, s_grid, rx[n - 1]);
+            return;
+        }
+    }
+    for (size_t i = tid; i < n; i += stride) idx[i] = demod_one(mp, s_table, s_grid, rx[i]);
 }
 
 // ---- error counting --------------------------------------------------------------------------
@@ -155,27 +184,56 @@ __global__ __launch_bounds__(kBlock) void k_count_finalize(const unsigned* __res
 }
 
 // ---- AWGN / element-wise -----------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(kBlock) void k_awgn_add(const cx<T>* __restrict__ x, const cx<T>* __restrict__ nz,
-                                                     T sigma, cx<T>* __restrict__ y, size_t n) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const cx<T> a = x[i], b = nz[i];
-        y[i] = mk<T>(a.x + sigma * b.x, a.y + sigma * b.y);
+// Element-wise binary operators on complex streams.  f32: two samples per thread through 16-byte loads and
+// stores when the three pointers are 16-byte aligned (`vec`); the odd tail and unaligned buffers go one by one.
+struct OpAwgn {
+    template <typename T> __device__ __forceinline__ cx<T> operator()(cx<T> a, cx<T> b, T sigma) const {
+        return mk<T>(a.x + sigma * b.x, a.y + sigma * b.y);
     }
+};
+struct OpDiv {
+    template <typename T> __device__ __forceinline__ cx<T> operator()(cx<T> a, cx<T> b, T) const { return cdivide(a, b); }
+};
+struct OpMul {
+    template <typename T> __device__ __forceinline__ cx<T> operator()(cx<T> a, cx<T> b, T) const { return cmul(a, b); }
+};
+
+template <typename T, typename Op>
+__global__ __launch_bounds__(kBlock) void k_binary(const cx<T>* __restrict__ x, const cx<T>* __restrict__ z, T param,
+                                                   cx<T>* __restrict__ y, size_t n, int vec) {
+    const Op op{};
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+    if constexpr (sizeof(T) == 4) {
+        if (vec) {
+            const size_t pairs = n / 2;
+            const float4* x4 = reinterpret_cast<const float4*>(x);
+            const float4* z4 = reinterpret_cast<const float4*>(z);
+            float4* y4 = reinterpret_cast<float4*>(y);
+            for (size_t p = tid; p < pairs; p += stride) {
+                const float4 a = x4[p], b = z4[p];
+                const float2 r0 = op(make_float2(a.x, a.y), make_float2(b.x, b.y), param);
+                const float2 r1 = op(make_float2(a.z, a.w), make_float2(b.z, b.w), param);
+                y4[p] = make_float4(r0.x, r0.y, r1.x, r1.y);
+            }
+            if ((n & 1) && tid == 0) y[n - 1] = op(x[n - 1], z[n - 1], param);
+            return;
+        }
+    }
+    for (size_t i = tid; i < n; i += stride) y[i] = op(x[i], z[i], param);
 }
 
-template <typename T>
-__global__ __launch_bounds__(kBlock) void k_cdiv(const cx<T>* __restrict__ a, const cx<T>* __restrict__ b,
-                                                 cx<T>* __restrict__ o, size_t n) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-        o[i] = cdivide(a[i], b[i]);
-}
-
-template <typename T>
-__global__ __launch_bounds__(kBlock) void k_cmul(const cx<T>* __restrict__ a, const cx<T>* __restrict__ b,
-                                                 cx<T>* __restrict__ o, size_t n) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-        o[i] = cmul(a[i], b[i]);
+template <typename Op>
+int launch_binary(mcle_ctx* ctx, int dtype, const void* d_a, const void* d_b, double param, void* d_out, size_t n) {
+    const int vec = ((((uintptr_t)d_a) | ((uintptr_t)d_b) | ((uintptr_t)d_out)) & 15u) == 0;
+    const int grid = grid_for(ctx, dtype == MCLE_F32 && vec ? (n + 1) / 2 : n, kBlock);
+    if (dtype == MCLE_F32)
+        hipLaunchKernelGGL((k_binary<float, Op>), dim3(grid), dim3(kBlock), 0, ctx->stream, (const float2*)d_a,
+                           (const float2*)d_b, (float)param, (float2*)d_out, n, vec);
+    else
+        hipLaunchKernelGGL((k_binary<double, Op>), dim3(grid), dim3(kBlock), 0, ctx->stream, (const double2*)d_a,
+                           (const double2*)d_b, param, (double2*)d_out, n, 0);
+    MCLE_LAUNCH_CHECK();
+    return MCLE_OK;
 }
 
 template <typename T>
@@ -253,13 +311,14 @@ int mcle_modulate(mcle_ctx* ctx, int dtype, const int32_t* d_idx, void* d_out, s
     void* st = nullptr;
     if ((rc = ctx->scratch(sizeof(unsigned), &st))) return rc;
     MCLE_HIP(hipMemsetAsync(st, 0, sizeof(unsigned), ctx->stream));
-    const int grid = grid_for(ctx, n, kBlock);
+    const int vec = dtype == MCLE_F32 && (((uintptr_t)d_idx & 7u) | ((uintptr_t)d_out & 15u)) == 0;
+    const int grid = grid_for(ctx, vec ? (n + 1) / 2 : n, kBlock);
     if (dtype == MCLE_F32)
         hipLaunchKernelGGL(k_modulate<float>, dim3(grid), dim3(kBlock), 0, ctx->stream, modem_params<float>(ctx, 0),
-                           d_idx, (float2*)d_out, n, (unsigned*)st);
+                           d_idx, (float2*)d_out, n, (unsigned*)st, vec);
     else
         hipLaunchKernelGGL(k_modulate<double>, dim3(grid), dim3(kBlock), 0, ctx->stream, modem_params<double>(ctx, 0),
-                           d_idx, (double2*)d_out, n, (unsigned*)st);
+                           d_idx, (double2*)d_out, n, (unsigned*)st, 0);
     MCLE_LAUNCH_CHECK();
     unsigned flag = 0;
     MCLE_HIP(hipMemcpyAsync(&flag, st, sizeof(flag), hipMemcpyDeviceToHost, ctx->stream));
@@ -274,13 +333,14 @@ int mcle_demodulate(mcle_ctx* ctx, int dtype, int method, const void* d_rx, int3
     if (rc) return rc;
     if (n == 0) return MCLE_OK;
     if ((rc = ctx->bind())) return rc;
-    const int grid = grid_for(ctx, n, kBlock);
+    const int vec = dtype == MCLE_F32 && (((uintptr_t)d_rx & 15u) | ((uintptr_t)d_idx & 7u)) == 0;
+    const int grid = grid_for(ctx, vec ? (n + 1) / 2 : n, kBlock);
     if (dtype == MCLE_F32)
         hipLaunchKernelGGL(k_demodulate<float>, dim3(grid), dim3(kBlock), 0, ctx->stream,
-                           modem_params<float>(ctx, method), (const float2*)d_rx, d_idx, n);
+                           modem_params<float>(ctx, method), (const float2*)d_rx, d_idx, n, vec);
     else
         hipLaunchKernelGGL(k_demodulate<double>, dim3(grid), dim3(kBlock), 0, ctx->stream,
-                           modem_params<double>(ctx, method), (const double2*)d_rx, d_idx, n);
+                           modem_params<double>(ctx, method), (const double2*)d_rx, d_idx, n, 0);
     MCLE_LAUNCH_CHECK();
     return MCLE_OK;
 }
@@ -381,15 +441,7 @@ int mcle_awgn_add(mcle_ctx* ctx, int dtype, const void* d_x, const void* d_noise
     if (n == 0) return MCLE_OK;
     int rc = ctx->bind();
     if (rc) return rc;
-    const int grid = grid_for(ctx, n, kBlock);
-    if (dtype == MCLE_F32)
-        hipLaunchKernelGGL(k_awgn_add<float>, dim3(grid), dim3(kBlock), 0, ctx->stream, (const float2*)d_x,
-                           (const float2*)d_noise, (float)sqrt(noise_var), (float2*)d_y, n);
-    else
-        hipLaunchKernelGGL(k_awgn_add<double>, dim3(grid), dim3(kBlock), 0, ctx->stream, (const double2*)d_x,
-                           (const double2*)d_noise, sqrt(noise_var), (double2*)d_y, n);
-    MCLE_LAUNCH_CHECK();
-    return MCLE_OK;
+    return launch_binary<OpAwgn>(ctx, dtype, d_x, d_noise, sqrt(noise_var), d_y, n);
 }
 
 int mcle_cmul(mcle_ctx* ctx, int dtype, const void* d_a, const void* d_b, void* d_out, size_t n) {
@@ -398,15 +450,7 @@ int mcle_cmul(mcle_ctx* ctx, int dtype, const void* d_a, const void* d_b, void* 
     if (n == 0) return MCLE_OK;
     int rc = ctx->bind();
     if (rc) return rc;
-    const int grid = grid_for(ctx, n, kBlock);
-    if (dtype == MCLE_F32)
-        hipLaunchKernelGGL(k_cmul<float>, dim3(grid), dim3(kBlock), 0, ctx->stream, (const float2*)d_a,
-                           (const float2*)d_b, (float2*)d_out, n);
-    else
-        hipLaunchKernelGGL(k_cmul<double>, dim3(grid), dim3(kBlock), 0, ctx->stream, (const double2*)d_a,
-                           (const double2*)d_b, (double2*)d_out, n);
-    MCLE_LAUNCH_CHECK();
-    return MCLE_OK;
+    return launch_binary<OpMul>(ctx, dtype, d_a, d_b, 0.0, d_out, n);
 }
 
 int mcle_cdiv(mcle_ctx* ctx, int dtype, const void* d_num, const void* d_den, void* d_out, size_t n) {
@@ -415,15 +459,7 @@ int mcle_cdiv(mcle_ctx* ctx, int dtype, const void* d_num, const void* d_den, vo
     if (n == 0) return MCLE_OK;
     int rc = ctx->bind();
     if (rc) return rc;
-    const int grid = grid_for(ctx, n, kBlock);
-    if (dtype == MCLE_F32)
-        hipLaunchKernelGGL(k_cdiv<float>, dim3(grid), dim3(kBlock), 0, ctx->stream, (const float2*)d_num,
-                           (const float2*)d_den, (float2*)d_out, n);
-    else
-        hipLaunchKernelGGL(k_cdiv<double>, dim3(grid), dim3(kBlock), 0, ctx->stream, (const double2*)d_num,
-                           (const double2*)d_den, (double2*)d_out, n);
-    MCLE_LAUNCH_CHECK();
-    return MCLE_OK;
+    return launch_binary<OpDiv>(ctx, dtype, d_num, d_den, 0.0, d_out, n);
 }
 
 }  // extern "C"

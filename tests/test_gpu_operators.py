@@ -519,3 +519,22 @@ def test_corrupt_data_in_freq_domain(engine, golden_ops):
     assert outm.shape == (2, 32) and relerr(outm, g["fdm_out"]) <= 1e-10
     with pytest.raises(ValueError):
         td.corrupt_data_in_freq_domain(g["fd_sig"][:-1], 32, g["fd_car"])
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 1001, 4096, 65537])
+def test_elementwise_vector_paths_handle_any_length(engine, n):
+    """f32 element-wise kernels move two samples per thread; odd lengths and the last sample go one by one."""
+    rs = np.random.RandomState(n)
+    table = omodem.qam_constellation(16)
+    engine.set_constellation(table, _lib.CONST_QAM)
+    idx = rs.randint(0, 16, n)
+    a = (rs.randn(n) + 1j * rs.randn(n)).astype(np.complex64)
+    b = (rs.randn(n) + 1j * rs.randn(n) + 3).astype(np.complex64)
+    assert relerr(engine.modulate(idx, dtype="f32"), table[idx]) <= 1e-6
+    assert relerr(engine.awgn_add(a, b, 0.25, dtype="f32"), a + 0.5 * b) <= 1e-6
+    assert relerr(engine.cmul(a, b, dtype="f32"), a * b) <= 1e-6
+    assert relerr(engine.cdiv(a, b, dtype="f32"), a / b) <= 1e-6
+    rx = (table[idx] + 0.05 * a).astype(np.complex64)
+    want = np.argmin(np.abs(rx[:, None] - table[None, :].astype(np.complex64)), axis=1)
+    assert np.array_equal(engine.demodulate(rx, dtype="f32"), want)
+    assert np.array_equal(engine.demodulate(rx, method=_lib.DEMOD_QAM_SLICER, dtype="f32"), want)
