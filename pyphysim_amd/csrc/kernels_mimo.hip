@@ -105,10 +105,43 @@ __global__ __launch_bounds__(kMimoBlock) void k_blast_decode_persc(const cx<T>* 
 template <typename T>
 __global__ __launch_bounds__(kMimoBlock) void k_mimo_channel(const cx<T>* __restrict__ H, const cx<T>* __restrict__ X,
                                                              const cx<T>* __restrict__ nz, T sigma, int nr, int nt,
-                                                             size_t ns, cx<T>* __restrict__ Y) {
+                                                             size_t ns, cx<T>* __restrict__ Y, int vec) {
     const size_t b = blockIdx.y;
     const cx<T>* Hb = H + b * (size_t)nr * nt;
     const cx<T>* Xb = X + b * (size_t)nt * ns;
+    if constexpr (sizeof(T) == 4) {
+        if (vec) {   // 4x4, even ns, 16-byte aligned rows: two columns per thread, every stream in 16-byte accesses
+            float2 Hr[4][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int a = 0; a < 4; ++a) Hr[r][a] = Hb[r * 4 + a];
+            for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < ns / 2; p += (size_t)gridDim.x * blockDim.x) {
+                float4 x[4];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) x[a] = reinterpret_cast<const float4*>(Xb + (size_t)a * ns)[p];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float2 a0 = make_float2(0.f, 0.f), a1 = make_float2(0.f, 0.f);
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        a0 = cfma(Hr[r][a], make_float2(x[a].x, x[a].y), a0);
+                        a1 = cfma(Hr[r][a], make_float2(x[a].z, x[a].w), a1);
+                    }
+                    const size_t row = (b * 4 + r) * ns;
+                    if (nz) {
+                        const float4 w = reinterpret_cast<const float4*>(nz + row)[p];
+                        a0.x += sigma * w.x;
+                        a0.y += sigma * w.y;
+                        a1.x += sigma * w.z;
+                        a1.y += sigma * w.w;
+                    }
+                    reinterpret_cast<float4*>(Y + row)[p] = make_float4(a0.x, a0.y, a1.x, a1.y);
+                }
+            }
+            return;
+        }
+    }
     for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < ns; c += (size_t)gridDim.x * blockDim.x) {
         for (int r = 0; r < nr; ++r) {
             cx<T> acc = mk<T>(0, 0);
@@ -526,15 +559,17 @@ int mcle_mimo_channel(mcle_ctx* ctx, int dtype, const void* d_H, const void* d_X
     MCLE_REQUIRE(noise_var >= 0.0, "noise variance must be non-negative");
     if (ns == 0 || batch == 0) return MCLE_OK;
     if ((rc = ctx->bind())) return rc;
-    dim3 grid((unsigned)grid_for(ctx, ns, kMimoBlock, 4), (unsigned)batch);
+    const int vec = dtype == MCLE_F32 && nr == 4 && nt == 4 && ns % 2 == 0 &&
+                    ((((uintptr_t)d_X) | ((uintptr_t)d_Y) | ((uintptr_t)d_noise)) & 15u) == 0;
+    dim3 grid((unsigned)grid_for(ctx, vec ? ns / 2 : ns, kMimoBlock, 4), (unsigned)batch);
     if (dtype == MCLE_F32)
         hipLaunchKernelGGL(k_mimo_channel<float>, grid, dim3(kMimoBlock), 0, ctx->stream, (const float2*)d_H,
                            (const float2*)d_X, (const float2*)d_noise, (float)std::sqrt(noise_var), nr, nt, ns,
-                           (float2*)d_Y);
+                           (float2*)d_Y, vec);
     else
         hipLaunchKernelGGL(k_mimo_channel<double>, grid, dim3(kMimoBlock), 0, ctx->stream, (const double2*)d_H,
                            (const double2*)d_X, (const double2*)d_noise, std::sqrt(noise_var), nr, nt, ns,
-                           (double2*)d_Y);
+                           (double2*)d_Y, 0);
     MCLE_LAUNCH_CHECK();
     return MCLE_OK;
 }
