@@ -209,6 +209,11 @@ def main():
     # realization index space: warmup uses a disjoint range far away from the timed one
     for w in range(args.warmup):
         run((1 << 40) + (w * world + rank) * batch, batch, counters)
+    if use_dist:        # bring the communicator up outside the timed region (same shape / dtype as the real exchange)
+        warm = torch.zeros(6, dtype=torch.int64, device="cuda")
+        dist.all_reduce(warm, op=dist.ReduceOp.SUM)
+        warm2 = torch.zeros(2, dtype=torch.float64, device="cuda")
+        dist.all_reduce(warm2, op=dist.ReduceOp.MAX)
     barrier()
     counters.zero()
     barrier()
