@@ -12,6 +12,8 @@
 //   CHAN   C4: H[r][a] = sample r*Nt + a
 //   PHASE  C2/C3: phi[l][s] = uniform l*S + s, psi[l][s] = uniform L*S + l*S + s   (S taps)
 //   NOISE  C1/C2: sample n; C3: sample j of the faded stream; C4: sample r*row + j, row = n_sym*(N+cp)
+#include <cstdlib>
+
 #include "fft.hpp"
 #include "jakes.hpp"
 #include "mimo.hpp"
@@ -721,6 +723,12 @@ int run_tdl_impl(mcle_ctx* ctx, const mcle_ofdm_tdl_cfg* cfg, uint64_t seed, uin
 
 }  // namespace mcle
 
+namespace mcle {
+// pipeline_siso_tdl.hip
+int run_ofdm_tdl_batched(mcle_ctx* ctx, int dtype, const mcle_ofdm_tdl_cfg* cfg, uint64_t seed, uint64_t first,
+                         uint64_t count, mcle_counters* d_counters, uint32_t* d_sym, uint32_t* d_bit);
+}  // namespace mcle
+
 using namespace mcle;
 
 extern "C" {
@@ -814,6 +822,12 @@ int mcle_run_ofdm_tdl(mcle_ctx* ctx, int dtype, const mcle_ofdm_tdl_cfg* cfg, ui
     MCLE_REQUIRE(count <= 0x7fffffffull, "at most 2^31-1 realizations per call");
     if (count == 0) return MCLE_OK;
     if ((rc = ctx->bind())) return rc;
+    // four realizations per workgroup pass with polynomial taps (pipeline_siso_tdl.hip) where that kernel's
+    // envelope allows (FFT 64 / 256 / 1024, moderate Doppler); MCLE_SINGLE_TDL=1 forces the kernel below
+    if (!std::getenv("MCLE_SINGLE_TDL")) {
+        rc = run_ofdm_tdl_batched(ctx, dtype, cfg, seed, first, count, d_counters, d_sym_err, d_bit_err);
+        if (rc != MCLE_E_UNSUPPORTED) return rc;
+    }
 #define MCLE_RUN(N_)                                                                                        \
     if (cfg->fft_size == N_)                                                                                \
         return dtype == MCLE_F32                                                                            \
