@@ -262,7 +262,7 @@ def main():
             "n_skipped": tot[1],
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": {"c4": "k_run_mimo_ofdm", "c2": "k_run_flat", "c3": "k_run_ofdm_tdl",
+                         "kernel": {"c4": "k_run_mimo_ofdm", "c2": "k_run_flat", "c3": "k_run_ofdm_tdl_batch",
                                     "c5": "k_run_ia", "f1": "k_run_mimo_ofdm_tdl"}[args.config],
                          "kernel_ms_per_launch": per_launch_s * 1e3,
                          "algorithmic_bytes_per_realization": balg,

@@ -65,7 +65,7 @@ def test_flat_fading_pipeline(engine, dt, exact):
 
 
 @pytest.mark.parametrize("dt,exact", [("f64", True), ("f32", False)])
-@pytest.mark.parametrize("case", [0, 1, 2])
+@pytest.mark.parametrize("case", [0, 1, 2, 3, 4])
 def test_ofdm_tdl_pipeline(engine, dt, exact, case):
     kws = [dict(mod="qpsk", M=4, fft_size=1024, cp_size=16, num_used=None, n_ofdm_sym=1, snr_db=20.0, Fd=10.0,
                 Ts=1.0 / (15e3 * 1024), L=8, tap_powers_dB=(0.0, -3.0, -6.0, -9.0, -12.0),
@@ -74,11 +74,17 @@ def test_ofdm_tdl_pipeline(engine, dt, exact, case):
                 L=8, tap_powers_dB=(0.0, -5.0, -10.0), tap_delays_samples=(0, 3, 7)),
            # delays beyond the cyclic prefix: inter-symbol interference from the previous OFDM symbol
            dict(mod="qam", M=16, fft_size=128, cp_size=4, num_used=100, n_ofdm_sym=4, snr_db=30.0, Fd=200.0, Ts=2e-6,
-                L=12, tap_powers_dB=(0.0, -2.0, -6.0, -12.0), tap_delays_samples=(0, 3, 9, 20))]
+                L=12, tap_powers_dB=(0.0, -2.0, -6.0, -12.0), tap_delays_samples=(0, 3, 9, 20)),
+           # the same through the four-realizations-per-pass kernel (FFT 256): ISI via its tail buffer
+           dict(mod="qam", M=16, fft_size=256, cp_size=4, num_used=200, n_ofdm_sym=3, snr_db=30.0, Fd=200.0, Ts=2e-6,
+                L=12, tap_powers_dB=(0.0, -2.0, -6.0, -12.0), tap_delays_samples=(0, 3, 9, 20)),
+           # Doppler beyond the polynomial tap model: falls back to the single-realization kernel
+           dict(mod="psk", M=8, fft_size=64, cp_size=8, num_used=None, n_ofdm_sym=2, snr_db=22.0, Fd=3000.0, Ts=1e-5,
+                L=8, tap_powers_dB=(0.0, -6.0), tap_delays_samples=(0, 2))]
     kw = kws[case]
     engine.set_constellation(chains.constellation(kw["mod"], kw["M"]),
                              _lib.CONST_QAM if kw["mod"] == "qam" else _lib.CONST_GENERIC)
-    first, count = 5, 8
+    first, count = 5, 7              # not a multiple of the four slots of a pass
     want_se, want_be, nsym, nbits = oracle_counts(chains.chain_ofdm_tdl, first, count, **kw)
     p_lin, d_idx = och.discretize_profile(np.array(kw["tap_powers_dB"]), np.array(kw["tap_delays_samples"]) * kw["Ts"],
                                           kw["Ts"])
@@ -87,6 +93,37 @@ def test_ofdm_tdl_pipeline(engine, dt, exact, case):
                                       first, count, Fd=kw["Fd"], Ts=kw["Ts"], L=kw["L"], dtype=dt,
                                       per_realization=True)
     check(res, se, be, want_se, want_be, nsym, nbits, exact)
+
+
+def test_ofdm_tdl_batched_kernel_equals_single(engine, monkeypatch):
+    """Config 3 runs four realizations per workgroup pass (pipeline_siso_tdl.hip); MCLE_SINGLE_TDL=1 forces the
+    single-realization kernel.  Same per-realization counts in f64 for every count mod 4, near-identical in f32,
+    and sums independent of how a range is split."""
+    engine.set_constellation(chains.constellation("qpsk", 4), _lib.CONST_GENERIC)
+    Ts = 1.0 / (15e3 * 1024)
+    p_lin, d_idx = och.discretize_profile(np.array([0.0, -3.0, -6.0, -9.0, -12.0]), np.arange(5) * Ts, Ts)
+    args = (1024, 16, 1024, 1, 0.01, p_lin, d_idx, SEED)
+
+    def run(first, count, dt, single):
+        if single:
+            monkeypatch.setenv("MCLE_SINGLE_TDL", "1")
+        else:
+            monkeypatch.delenv("MCLE_SINGLE_TDL", raising=False)
+        return engine.run_ofdm_tdl(*args, first, count, Fd=10.0, Ts=Ts, L=8, dtype=dt, per_realization=True)
+    for count in (1, 2, 3, 4, 5, 1027):
+        rb, sb, bb = run(11, count, "f64", False)
+        rs, ss, bs = run(11, count, "f64", True)
+        assert np.array_equal(sb, ss) and np.array_equal(bb, bs) and rb["n_realizations"] == count
+        assert rb["sym_errors"] == rs["sym_errors"] and rb["sym_errors_sq"] == rs["sym_errors_sq"]
+    rb, sb, _ = run(0, 4099, "f32", False)
+    rs, ss, _ = run(0, 4099, "f32", True)
+    assert np.abs(sb.astype(int) - ss.astype(int)).max() <= 2
+    assert abs(rb["sym_errors"] - rs["sym_errors"]) <= 1e-4 * 4099 * 1024
+    a = run(0, 4099, "f32", False)[0]
+    b = run(0, 1234, "f32", False)[0]
+    c = run(1234, 2865, "f32", False)[0]
+    for k in ("sym_errors", "sym_errors_sq", "bit_errors", "n_realizations"):
+        assert a[k] == b[k] + c[k]
 
 
 @pytest.mark.parametrize("dt,exact", [("f64", True), ("f32", False)])
