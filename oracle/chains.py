@@ -240,6 +240,42 @@ def chain_ia(rng, mod='qam', M=16, K=3, nr=2, nt=2, Ns=1, NSymbs=200, snr_db=20.
     return _counts(out, idx, dec, M)
 
 
+def chain_mimo_scheme(rng, scheme='blast', mod='qam', M=16, nt=2, nr=2, NSymbs=200, snr_db=15.0):
+    """apps/mimo/simulate_mimo.py:68-142: flat channel randn_c(Nr, Nt) per realization, one of the six MIMO
+    schemes (Alamouti / Blast / MRC / MRT / SVDMimo / GMDMimo -- set_channel_matrix only, i.e. zero forcing),
+    NSymbs symbols per layer, single carrier."""
+    table = constellation(mod, M)
+    noise_var = 1.0 / float(omodem.dB2Linear(snr_db))
+    H = rng.cn(philox.STREAM_CHAN, nr, nt)
+    layers = {'blast': nt, 'mrc': nt, 'svd': nt, 'gmd': nt, 'alamouti': 1, 'mrt': 1}[scheme]
+    idx = rng.symbols(NSymbs * layers, M)
+    sym = omodem.modulate(table, idx)
+    if scheme in ('blast', 'mrc'):
+        X = omimo.blast_encode(sym, nt)
+    elif scheme == 'alamouti':
+        X = omimo.alamouti_encode(sym)
+    elif scheme == 'mrt':
+        X = omimo.mrt_encode(sym, H)
+    elif scheme == 'svd':
+        X = omimo.svd_encode(sym, H)
+    else:
+        X = omimo.gmd_encode(sym, H)
+    noise = rng.cn(philox.STREAM_NOISE, nr, NSymbs)
+    Y = H @ X + math.sqrt(noise_var) * noise
+    if scheme in ('blast', 'mrc'):
+        est = omimo.blast_decode(Y, H, 0.0)
+    elif scheme == 'alamouti':
+        est = omimo.alamouti_decode(Y, H)
+    elif scheme == 'mrt':
+        est = omimo.mrt_decode(Y, H)
+    elif scheme == 'svd':
+        est = omimo.svd_decode(Y, H)
+    else:
+        est = omimo.gmd_decode(Y, H, 0.0)
+    dec = omodem.demodulate(table, est)
+    return _counts(dict(table=table, H=H, idx=idx, noise=noise, est=est, noise_var=noise_var), idx, dec, M)
+
+
 STREAM_INIT = 3    # the solver's own RandomState (iabase.py:95); shares the PHASE stream id, unused in config 5
 
 

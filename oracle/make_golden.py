@@ -360,6 +360,27 @@ def ref_chain_ia_iterative(seed, algo, mod, M, K, nr, nt, Ns, NSymbs, snr_db, ma
                 runned_iterations=int(runned), **ref_counts(idx, dec, M))
 
 
+def ref_chain_mimo_scheme(seed, scheme, mod, M, nt, nr, NSymbs, snr_db):
+    """apps/mimo/simulate_mimo.py:68-100 with the reference's own scheme classes."""
+    np.random.seed(seed)
+    m = ref_modulator(mod, M)
+    cls = {"blast": rmimo.Blast, "mrc": rmimo.MRC, "mrt": rmimo.MRT, "alamouti": rmimo.Alamouti,
+           "svd": rmimo.SVDMimo, "gmd": rmimo.GMDMimo}[scheme]
+    obj = cls()
+    H = rmisc.randn_c(nr, nt)
+    obj.set_channel_matrix(H)
+    layers = obj.getNumberOfLayers()
+    idx = np.random.randint(0, M, NSymbs * layers)
+    X = obj.encode(m.modulate(idx))
+    noise_var = 1.0 / dB2Linear(snr_db)
+    noise = rmisc.randn_c(nr, NSymbs)
+    Y = np.dot(H, X) + noise * np.sqrt(noise_var)
+    est = obj.decode(Y)
+    dec = m.demodulate(est)
+    return dict(table=m.symbols, H=H, idx=idx, noise=noise, est=est, decisions=dec, noise_var=noise_var,
+                **ref_counts(idx, dec, M))
+
+
 def ref_chain_mimo_ofdm_tdl(seed, mod, M, nt, nr, fft_size, cp_size, num_used, n_ofdm_sym, snr_db, Fd, Ts, L,
                             tap_powers_dB, tap_delays_samples):
     np.random.seed(seed)
@@ -410,6 +431,12 @@ CHAINS = {
                           n_ofdm_sym=1, snr_db=25.0, mmse=True),
                      dict(mod="qam", M=16, nt=2, nr=2, fft_size=64, cp_size=8, num_used=48,
                           n_ofdm_sym=2, snr_db=15.0, mmse=False)],
+    "f5_mimo_schemes": [dict(scheme=sc, mod="qam", M=16, nt=a, nr=b, NSymbs=64, snr_db=snr)
+                        for sc, a, b, snr in (("blast", 2, 2, 18.0), ("blast", 3, 4, 14.0), ("blast", 4, 4, 22.0),
+                                              ("mrc", 1, 3, 6.0), ("mrt", 3, 1, 8.0), ("mrt", 4, 1, 6.0),
+                                              ("alamouti", 2, 1, 10.0), ("alamouti", 2, 3, 4.0),
+                                              ("svd", 2, 2, 18.0), ("svd", 4, 4, 22.0), ("gmd", 2, 2, 16.0),
+                                              ("gmd", 3, 3, 18.0), ("gmd", 4, 4, 20.0))],
     "f3_ia_iterative": [dict(algo=a, mod="qam", M=16, K=3, nr=2, nt=2, Ns=1, NSymbs=120, snr_db=snr,
                              max_iterations=it, relative_factor=1e-6)
                         for a, snr, it in (("alt_min", 20.0, 50), ("alt_min", 8.0, 7), ("min_leakage", 20.0, 50),
@@ -430,6 +457,8 @@ def run_ref(name, kw, seed):
         return ref_chain_ia(seed, **kw)
     if name == "f3_ia_iterative":
         return ref_chain_ia_iterative(seed, **kw)
+    if name == "f5_mimo_schemes":
+        return ref_chain_mimo_scheme(seed, **kw)
     if name == "f1_mimo_ofdm_tdl":
         return ref_chain_mimo_ofdm_tdl(seed, **kw)
     if name == "c1_awgn":
@@ -448,16 +477,17 @@ def run_ref(name, kw, seed):
 
 ORACLE = {"c1_awgn": chains.chain_awgn, "c2_flat_jakes": chains.chain_flat_jakes,
           "c3_ofdm_tdl": chains.chain_ofdm_tdl, "c4_mimo_ofdm": chains.chain_mimo_ofdm, "c5_ia": chains.chain_ia,
-          "f1_mimo_ofdm_tdl": chains.chain_mimo_ofdm_tdl, "f3_ia_iterative": chains.chain_ia_iterative}
+          "f1_mimo_ofdm_tdl": chains.chain_mimo_ofdm_tdl, "f3_ia_iterative": chains.chain_ia_iterative,
+          "f5_mimo_schemes": chains.chain_mimo_scheme}
 INT_KEYS = ("idx", "decisions", "symbol_errors", "bit_errors", "num_symbols", "num_bits", "delay_indexes",
             "runned_iterations")
 # realizations stored per case (kept small: fixtures are KBs)
 N_REAL = {"c1_awgn": 2, "c2_flat_jakes": 2, "c3_ofdm_tdl": 2, "c4_mimo_ofdm": 2, "c5_ia": 4, "f1_mimo_ofdm_tdl": 1,
-          "f3_ia_iterative": 3}
+          "f3_ia_iterative": 3, "f5_mimo_schemes": 2}
 # derivable float arrays that are checked against the reference above but not stored
 SKIP_STORE = {"c1_awgn": ("tx",), "c2_flat_jakes": ("tx", "faded"), "c3_ofdm_tdl": ("sym", "faded"),
               "c4_mimo_ofdm": ("sym", "X", "R"), "c5_ia": (),
-              "f1_mimo_ofdm_tdl": ("faded", "G"), "f3_ia_iterative": ()}
+              "f1_mimo_ofdm_tdl": ("faded", "G"), "f3_ia_iterative": (), "f5_mimo_schemes": ()}
 
 
 def golden_chains():
@@ -473,7 +503,8 @@ def golden_chains():
                                      else chains.LegacyRng)(seed), **kw)
                 for k, v in ref.items():
                     tol = 0 if k in INT_KEYS else (1e-9 if name in ("c5_ia", "f1_mimo_ofdm_tdl") else
-                                                   (1e-7 if name == "f3_ia_iterative" else 1e-12))
+                                                   (1e-7 if name == "f3_ia_iterative" else
+                                                    (1e-9 if name == "f5_mimo_schemes" else 1e-12)))
                     worst = max(worst, close(mine[k], v, tol, "%s[%d] r%d %s" % (name, ci, r, k)))
                     arr = np.asarray(v)
                     if k in SKIP_STORE[name] or (r > 0 and arr.size > 4096 and ci == 0):

@@ -81,3 +81,68 @@ def svd_decode(Y, H):
     nt = H.shape[1]
     U, S, _ = np.linalg.svd(H)
     return ((np.diag(1.0 / S) @ U.conj().T * math.sqrt(nt)) @ Y).reshape(-1)
+
+
+# ---- GMDMimo (pyphysim/mimo/mimo.py:952-1067) with util.misc.gmd (pyphysim/util/misc.py:18-159) ----------
+def gmd(U, S, V_H):
+    """Geometric mean decomposition H = Q R P^H from an SVD: R upper triangular with the geometric mean of the
+    singular values on its diagonal (Jiang, Hager, Li).  Planar rotations applied pair by pair."""
+    m, n = U.shape[0], V_H.shape[0]
+    p = int(np.sum(S >= 0.0))
+    R = np.zeros((m, n))
+    P = V_H.conj().T.copy()
+    Q = U.copy()
+    d = np.array(S, dtype=float)
+    if p < 2:
+        R[0, 0] = d[0]
+    z = np.zeros(p - 1)
+    large, small = 1, p - 1
+    perm = np.arange(p)
+    invperm = np.arange(p)
+    sigma_bar = float(np.prod(S[0:p]) ** (1.0 / p))
+    for k in range(p - 1):
+        flag = False
+        if d[k] >= sigma_bar:
+            i = perm[small]
+            small -= 1
+            flag = d[i] >= sigma_bar
+        else:
+            i = perm[large]
+            large += 1
+            flag = d[i] <= sigma_bar
+        k1 = k + 1
+        if i != k1:
+            d[k1], d[i] = d[i], d[k1]
+            j = invperm[k1]
+            perm[j] = i
+            invperm[i] = j
+            Q[:, [k1, i]] = Q[:, [i, k1]]
+            P[:, [k1, i]] = P[:, [i, k1]]
+        d1, d2 = d[k], d[k1]
+        if flag:
+            c, s = 1.0, 0.0
+        else:
+            c = math.sqrt((sigma_bar ** 2 - d2 ** 2) / (d1 ** 2 - d2 ** 2))
+            s = math.sqrt(1 - c ** 2)
+        d[k1] = d1 * d2 / sigma_bar
+        z[k] = s * c * (d2 ** 2 - d1 ** 2) / sigma_bar
+        R[k, k] = sigma_bar
+        if k > 0:
+            R[0:k, k] = z[0:k] * c
+            z[0:k] = -z[0:k] * s
+        P[:, [k, k1]] = P[:, [k, k1]] @ np.array([[c, -s], [s, c]])
+        Q[:, [k, k1]] = Q[:, [k, k1]] @ ((1.0 / sigma_bar) * np.array([[c * d1, -s * d2], [s * d2, c * d1]]))
+    R[p - 1, p - 1] = sigma_bar
+    R[0:p - 1, p - 1] = z
+    return Q, R, P
+
+
+def gmd_encode(x, H):
+    nt = H.shape[1]
+    _, _, P = gmd(*np.linalg.svd(H))
+    return (P / math.sqrt(nt)) @ np.asarray(x).reshape(nt, -1)
+
+
+def gmd_decode(Y, H, noise_var=0.0):
+    Q, R, _ = gmd(*np.linalg.svd(H))
+    return (blast_receive_filter(Q @ R, noise_var) @ Y).reshape(-1)
