@@ -264,6 +264,22 @@ typedef struct mcle_mimo_ofdm_tdl_cfg { /* TdlMimoChannel (fading
     int32_t tap_delay[MCLE_MAX_TAPS];   /* samples, ascending, < fft_size */
 } mcle_mimo_ofdm_tdl_cfg;
 
+enum { MCLE_MIMO_BLAST = 0,     /* mimo.Blast     mimo/mimo.py:463-660   (Nt <= Nr <= 4) */
+       MCLE_MIMO_MRC = 1,       /* mimo.MRC       mimo/mimo.py:789-830   (Nt = 1)        */
+       MCLE_MIMO_MRT = 2,       /* mimo.MRT       mimo/mimo.py:666-783   (Nr = 1)        */
+       MCLE_MIMO_ALAMOUTI = 3,  /* mimo.Alamouti  mimo/mimo.py:1073-1287 (Nt = 2)        */
+       MCLE_MIMO_SVD = 4,       /* mimo.SVDMimo   mimo/mimo.py:833-946   (square, 2..4)  */
+       MCLE_MIMO_GMD = 5 };     /* mimo.GMDMimo   mimo/mimo.py:952-1067  (square, 2..4)  */
+
+typedef struct mcle_mimo_flat_cfg {     /* apps/mimo/simulate_mimo.py:68-142: flat H = randn_c(Nr, Nt), single carrier */
+    int32_t scheme;                     /* MCLE_MIMO_* */
+    int32_t nt, nr;
+    int32_t n_symbols;                  /* NSymbs per layer (layers: Nt for Blast / MRC / SVD / GMD, 1 otherwise) */
+    int32_t demod_method;
+    int32_t mmse;                       /* Blast / MRC / GMD: 1 = set_noise_var(noise_var); 0 = zero forcing (the app) */
+    double noise_var;
+} mcle_mimo_flat_cfg;
+
 enum { MCLE_IA_CLOSED_FORM = 0,  /* ClosedFormIASolver      ia/algorithms.py:42-265    */
        MCLE_IA_ALT_MIN = 1,      /* AlternatingMinIASolver  ia/algorithms.py:885-1129  */
        MCLE_IA_MIN_LEAKAGE = 2,  /* MinLeakageIASolver      ia/algorithms.py:1132-1240 */
@@ -291,6 +307,11 @@ int mcle_run_ofdm_tdl(mcle_ctx* ctx, int dtype, const mcle_ofdm_tdl_cfg* cfg, ui
                       uint64_t first, uint64_t count, mcle_counters* d_counters,
                       uint32_t* d_sym_err, uint32_t* d_bit_err);
 int mcle_run_mimo_ofdm(mcle_ctx* ctx, int dtype, const mcle_mimo_ofdm_cfg* cfg, uint64_t seed,
+                       uint64_t first, uint64_t count, mcle_counters* d_counters,
+                       uint32_t* d_sym_err, uint32_t* d_bit_err);
+
+/* The reference's MIMO application, any of its six schemes, fused. */
+int mcle_run_mimo_flat(mcle_ctx* ctx, int dtype, const mcle_mimo_flat_cfg* cfg, uint64_t seed,
                        uint64_t first, uint64_t count, mcle_counters* d_counters,
                        uint32_t* d_sym_err, uint32_t* d_bit_err);
 

@@ -70,6 +70,14 @@ class MimoOfdmTdlCfg(Structure):
                 ("tap_power", c_double * MAX_TAPS), ("tap_delay", c_int32 * MAX_TAPS)]
 
 
+class MimoFlatCfg(Structure):
+    _fields_ = [("scheme", c_int32), ("nt", c_int32), ("nr", c_int32), ("n_symbols", c_int32),
+                ("demod_method", c_int32), ("mmse", c_int32), ("noise_var", c_double)]
+
+
+MIMO_SCHEMES = {"blast": 0, "mrc": 1, "mrt": 2, "alamouti": 3, "svd": 4, "gmd": 5}
+
+
 class IaCfg(Structure):
     _fields_ = [("K", c_int32), ("nr", c_int32), ("nt", c_int32), ("ns", c_int32), ("n_symbols", c_int32),
                 ("demod_method", c_int32), ("noise_var", c_double), ("solver", c_int32),
@@ -146,6 +154,7 @@ _PROTOS = {
     "mcle_run_flat_fading": (c_int, [_P, c_int, POINTER(FlatCfg), c_uint64, c_uint64, c_uint64, _P, _P, _P]),
     "mcle_run_ofdm_tdl": (c_int, [_P, c_int, POINTER(OfdmTdlCfg), c_uint64, c_uint64, c_uint64, _P, _P, _P]),
     "mcle_run_mimo_ofdm": (c_int, [_P, c_int, POINTER(MimoOfdmCfg), c_uint64, c_uint64, c_uint64, _P, _P, _P]),
+    "mcle_run_mimo_flat": (c_int, [_P, c_int, POINTER(MimoFlatCfg), c_uint64, c_uint64, c_uint64, _P, _P, _P]),
     "mcle_run_mimo_ofdm_tdl": (c_int, [_P, c_int, POINTER(MimoOfdmTdlCfg), c_uint64, c_uint64, c_uint64, _P, _P,
                                        _P]),
     "mcle_run_ia": (c_int, [_P, c_int, POINTER(IaCfg), c_uint64, c_uint64, c_uint64, _P, _P, _P, _P, _P]),

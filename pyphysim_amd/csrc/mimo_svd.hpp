@@ -29,8 +29,11 @@ __device__ __forceinline__ void jacobi_svd(double2 (&A)[NA][NA], double2 (&V)[NA
                     gam = cadd(gam, cmulc(A[r][q], A[r][p]));  // a_p^H a_q
                 }
                 const double g = sqrt(gam.x * gam.x + gam.y * gam.y);
-                off = fmax(off, g / (sqrt(alpha * beta) + 1e-300));
-                if (g < 1e-300) continue;
+                const double rel = g / (sqrt(alpha * beta) + 1e-300);
+                off = fmax(off, rel);
+                // a pair that is orthogonal to rounding is left alone: its inner product is noise, and rotating
+                // by the PHASE of noise would turn the column by an arbitrary angle
+                if (rel < 1e-15) continue;
                 const double2 ph = mk<double>(gam.x / g, gam.y / g);  // e^{j phi}
                 const double zeta = (beta - alpha) / (2.0 * g);
                 const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
@@ -53,6 +56,29 @@ __device__ __forceinline__ void jacobi_svd(double2 (&A)[NA][NA], double2 (&V)[NA
 #pragma unroll
         for (int r = 0; r < NA; ++r) n2 += A[r][c].x * A[r][c].x + A[r][c].y * A[r][c].y;
         S[c] = sqrt(n2);
+    }
+    // canonical phases: the largest-magnitude entry of every right singular vector real and positive (first on
+    // ties), the left vector turned with it -- the pair (U, V) then depends continuously on H, so two builds of
+    // this routine (operator kernel, fused pipeline) agree to rounding
+#pragma unroll
+    for (int c = 0; c < NA; ++c) {
+        double best = -1.0;
+        double2 piv = mk<double>(1.0, 0.0);
+#pragma unroll
+        for (int r = 0; r < NA; ++r) {
+            const double m2 = V[r][c].x * V[r][c].x + V[r][c].y * V[r][c].y;
+            if (m2 > best * (1.0 + 1e-12)) {
+                best = m2;
+                piv = V[r][c];
+            }
+        }
+        const double m = sqrt(piv.x * piv.x + piv.y * piv.y);
+        const double2 rot = mk<double>(piv.x / m, -piv.y / m);   // conj(piv) / |piv|
+#pragma unroll
+        for (int r = 0; r < NA; ++r) {
+            V[r][c] = cmul(V[r][c], rot);
+            A[r][c] = cmul(A[r][c], rot);
+        }
     }
     // selection sort of the columns, descending S (predicated swaps keep everything in registers)
 #pragma unroll

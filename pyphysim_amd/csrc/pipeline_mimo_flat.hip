@@ -1,0 +1,317 @@
+// pipeline_mimo_flat.hip -- fused pipeline of the reference's MIMO application (apps/mimo/simulate_mimo.py:68-142):
+// per realization a flat channel H = randn_c(Nr, Nt), one of the six schemes
+//   Blast (mimo/mimo.py:463-660), MRC (:789-830), MRT (:666-783), Alamouti (:1073-1287), SVDMimo (:833-946),
+//   GMDMimo (:952-1067, util/misc.py:18-159)
+// NSymbs symbols per layer on a single carrier, Y = H X + sqrt(noise_var) N, decode, demodulate, count.
+//
+// One wavefront per chunk of 64 realizations (the layout of kernels_ia.hip): phase 1, lane i draws the channel of
+// realization i and builds the scheme's precoder W [Nt][layers] and receive filter G [layers][Nr] in f64 registers
+// (Cholesky / one-sided Jacobi SVD / GMD rotations) and parks H, W, G in LDS; phase 2, the whole wave runs each
+// realization's symbol columns.
+// Draw ledger (mcle-philox-v1): CHAN sample r*Nt + a = H[r][a]; DATA symbol n = the reference's flat index
+// (Blast / MRC: n = t*Nt + a, Fortran order; SVD / GMD: n = a*NSymbs + t, C order; MRT / Alamouti: n = t);
+// NOISE sample r*NSymbs + t.
+#include "mimo_svd.hpp"
+#include "modem.hpp"
+#include "philox.hpp"
+#include "pipe_common.hpp"
+#include "totals.hpp"
+
+namespace mcle {
+
+constexpr int kFlatMax = 4;   // antennas per side
+
+struct FlatSetup {
+    double2 H[kFlatMax][kFlatMax];   // [r][a]
+    double2 W[kFlatMax][kFlatMax];   // [a][l]
+    double2 G[kFlatMax][kFlatMax];   // [l][r]
+    double aux;                      // Alamouti: sqrt(2) / |H|_F^2
+    bool ok;
+};
+
+template <int NT, int NR>
+__device__ __forceinline__ bool flat_blast(const FlatSetup& s, double nv, double2 (&Gout)[kFlatMax][kFlatMax]) {
+    double2 Hs[NR][NT], Gs[NT][NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+#pragma unroll
+        for (int a = 0; a < NT; ++a) Hs[r][a] = s.H[r][a];
+    const bool ok = blast_filter<NT, NR>(Hs, nv, Gs);
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int r = 0; r < NR; ++r) Gout[a][r] = Gs[a][r];
+    return ok;
+}
+template <int NA> __device__ __forceinline__ void flat_svd(FlatSetup& s) {
+    double2 A[NA][NA], W[NA][NA], G[NA][NA];
+    double S[NA];
+#pragma unroll
+    for (int r = 0; r < NA; ++r)
+#pragma unroll
+        for (int c = 0; c < NA; ++c) A[r][c] = s.H[r][c];
+    svd_filters_dev<NA>(A, W, G, S);
+#pragma unroll
+    for (int r = 0; r < NA; ++r)
+#pragma unroll
+        for (int c = 0; c < NA; ++c) {
+            s.W[r][c] = W[r][c];
+            s.G[r][c] = G[r][c];
+        }
+}
+template <int NA> __device__ __forceinline__ void flat_gmd(FlatSetup& s, double nv) {
+    double2 Hs[NA][NA], W[NA][NA], G[NA][NA];
+    double R[NA][NA];
+#pragma unroll
+    for (int r = 0; r < NA; ++r)
+#pragma unroll
+        for (int c = 0; c < NA; ++c) Hs[r][c] = s.H[r][c];
+    s.ok = gmd_filters_dev<NA>(Hs, nv, W, G, R);
+#pragma unroll
+    for (int r = 0; r < NA; ++r)
+#pragma unroll
+        for (int c = 0; c < NA; ++c) {
+            s.W[r][c] = W[r][c];
+            s.G[r][c] = G[r][c];
+        }
+}
+
+// precoder and receive filter of one realization; not inlined: one compiled body for both instantiations
+__device__ __noinline__ void flat_setup(int scheme, int nt, int nr, double nv, FlatSetup& s) {
+    const double2 zero = mk<double>(0, 0);
+#pragma unroll
+    for (int i = 0; i < kFlatMax; ++i)
+#pragma unroll
+        for (int j = 0; j < kFlatMax; ++j) s.W[i][j] = s.G[i][j] = zero;
+    s.aux = 0.0;
+    s.ok = true;
+    if (scheme == MCLE_MIMO_BLAST || scheme == MCLE_MIMO_MRC) {
+        const double w = 1.0 / sqrt((double)nt);
+#pragma unroll
+        for (int a = 0; a < kFlatMax; ++a) s.W[a][a] = mk<double>(a < nt ? w : 0.0, 0.0);
+#define MCLE_FB(NT_, NR_) \
+    if (nt == NT_ && nr == NR_) s.ok = flat_blast<NT_, NR_>(s, nv, s.G);
+        MCLE_FB(1, 1) MCLE_FB(1, 2) MCLE_FB(1, 3) MCLE_FB(1, 4) MCLE_FB(2, 2) MCLE_FB(2, 3) MCLE_FB(2, 4) MCLE_FB(3, 3)
+        MCLE_FB(3, 4) MCLE_FB(4, 4)
+#undef MCLE_FB
+    } else if (scheme == MCLE_MIMO_MRT) {
+        double sum = 0.0;
+        const double w = 1.0 / sqrt((double)nt);
+#pragma unroll
+        for (int a = 0; a < kFlatMax; ++a)
+            if (a < nt) {
+                const double m = sqrt(s.H[0][a].x * s.H[0][a].x + s.H[0][a].y * s.H[0][a].y);
+                sum += m;
+                s.W[a][0] = mk<double>(s.H[0][a].x / m * w, -s.H[0][a].y / m * w);   // exp(-j angle(h)) / sqrt(Nt)
+            }
+        s.G[0][0] = mk<double>(sqrt((double)nt) / sum, 0.0);
+    } else if (scheme == MCLE_MIMO_ALAMOUTI) {
+        double f = 0.0;
+#pragma unroll
+        for (int r = 0; r < kFlatMax; ++r)
+            if (r < nr) f += s.H[r][0].x * s.H[r][0].x + s.H[r][0].y * s.H[r][0].y + s.H[r][1].x * s.H[r][1].x +
+                             s.H[r][1].y * s.H[r][1].y;
+        s.aux = sqrt(2.0) / f;
+    } else if (scheme == MCLE_MIMO_SVD) {
+        if (nt == 2) flat_svd<2>(s);
+        else if (nt == 3) flat_svd<3>(s);
+        else flat_svd<4>(s);
+    } else {
+        if (nt == 2) flat_gmd<2>(s, nv);
+        else if (nt == 3) flat_gmd<3>(s, nv);
+        else flat_gmd<4>(s, nv);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void k_run_mimo_flat(ModemParams<T> mp, int scheme, int nt, int nr, int n_symbols,
+                                                      double noise_var, double filter_nv, uint64_t seed,
+                                                      uint64_t first, uint64_t count, mcle_counters* counters,
+                                                      uint32_t* __restrict__ sym_out, uint32_t* __restrict__ bit_out) {
+    constexpr int PITCH = kFlatMax * kFlatMax + 1;
+    __shared__ cx<T> s_table[256];
+    __shared__ unsigned long long s_grid[sizeof(T) == 4 ? kMaxGridCells : 1];
+    __shared__ cx<T> s_H[64][PITCH], s_W[64][PITCH], s_G[64][PITCH];
+    __shared__ T s_aux[64];
+    __shared__ unsigned s_ok[64];
+    load_table(mp, s_table);
+    if (sizeof(T) == 4) load_grid(mp, s_grid);
+    const int lane = threadIdx.x;
+    const T sigma = (T)sqrt(noise_var);
+    const uint32_t mask = (uint32_t)(mp.M - 1);
+    const int layers = (scheme == MCLE_MIMO_ALAMOUTI || scheme == MCLE_MIMO_MRT) ? 1 : nt;
+    const bool c_order = scheme == MCLE_MIMO_SVD || scheme == MCLE_MIMO_GMD;
+    __shared__ WgTotals totals;
+    if (threadIdx.x == 0) wg_zero(totals);
+    const uint64_t n_chunks = (count + 63) / 64;
+    for (uint64_t ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
+        __syncthreads();
+        // ---- phase 1: one realization per lane ----
+        {
+            const uint64_t rl = ch * 64 + lane;
+            if (rl < count) {
+                const Rng rng(seed, first + rl);
+                FlatSetup st;
+#pragma unroll
+                for (int r = 0; r < kFlatMax; ++r)
+#pragma unroll
+                    for (int a = 0; a < kFlatMax; ++a)
+                        st.H[r][a] = (r < nr && a < nt) ? cn_sample<double>(rng, STREAM_CHAN, (uint64_t)(r * nt + a), 1.0)
+                                                        : mk<double>(0, 0);
+                flat_setup(scheme, nt, nr, filter_nv, st);
+#pragma unroll
+                for (int i = 0; i < kFlatMax; ++i)
+#pragma unroll
+                    for (int j = 0; j < kFlatMax; ++j) {
+                        s_H[lane][i * kFlatMax + j] = mk<T>((T)st.H[i][j].x, (T)st.H[i][j].y);
+                        s_W[lane][i * kFlatMax + j] = mk<T>((T)st.W[i][j].x, (T)st.W[i][j].y);
+                        s_G[lane][i * kFlatMax + j] = mk<T>((T)st.G[i][j].x, (T)st.G[i][j].y);
+                    }
+                s_aux[lane] = (T)st.aux;
+                s_ok[lane] = st.ok ? 1u : 0u;
+            }
+        }
+        __syncthreads();
+        // ---- phase 2: the wave walks the chunk's realizations ----
+        const int in_chunk = (int)((count - ch * 64) < 64 ? (count - ch * 64) : 64);
+        for (int j = 0; j < in_chunk; ++j) {
+            const uint64_t rl = ch * 64 + j;
+            const Rng rng(seed, first + rl);
+            cx<T> H[kFlatMax][kFlatMax], W[kFlatMax][kFlatMax], G[kFlatMax][kFlatMax];
+#pragma unroll
+            for (int i = 0; i < kFlatMax; ++i)
+#pragma unroll
+                for (int c = 0; c < kFlatMax; ++c) {
+                    H[i][c] = s_H[j][i * kFlatMax + c];
+                    W[i][c] = s_W[j][i * kFlatMax + c];
+                    G[i][c] = s_G[j][i * kFlatMax + c];
+                }
+            unsigned se = 0, be = 0;
+            if (scheme == MCLE_MIMO_ALAMOUTI) {
+                const T scale = s_aux[j];
+                const T inv_root2 = (T)0.70710678118654752440;
+                for (int p = lane; p < n_symbols / 2; p += 64) {
+                    const int tx0 = (int)symbol_at(rng, (uint64_t)(2 * p), mask);
+                    const int tx1 = (int)symbol_at(rng, (uint64_t)(2 * p + 1), mask);
+                    const cx<T> s0 = cscale(s_table[tx0], inv_root2), s1 = cscale(s_table[tx1], inv_root2);
+                    cx<T> o0 = mk<T>(0, 0), o1 = mk<T>(0, 0);
+#pragma unroll
+                    for (int r = 0; r < kFlatMax; ++r)
+                        if (r < nr) {
+                            // slot 2p: (s0, s1); slot 2p+1: (-conj s1, conj s0)
+                            cx<T> y0 = cn_sample<T>(rng, STREAM_NOISE, (uint64_t)r * n_symbols + 2 * p, sigma);
+                            cx<T> y1 = cn_sample<T>(rng, STREAM_NOISE, (uint64_t)r * n_symbols + 2 * p + 1, sigma);
+                            y0 = cfma(H[r][0], s0, y0);
+                            y0 = cfma(H[r][1], s1, y0);
+                            y1 = cfma(H[r][0], mk<T>(-s1.x, s1.y), y1);
+                            y1 = cfma(H[r][1], cconj(s0), y1);
+                            o0 = cfma(cconj(H[r][0]), y0, o0);
+                            o0 = cfma(H[r][1], cconj(y1), o0);
+                            o1 = cfma(cconj(H[r][1]), y0, o1);
+                            o1 = csub(o1, cmul(H[r][0], cconj(y1)));
+                        }
+                    const unsigned x0 = (unsigned)(tx0 ^ demod_one(mp, s_table, s_grid, cscale(o0, scale)));
+                    const unsigned x1 = (unsigned)(tx1 ^ demod_one(mp, s_table, s_grid, cscale(o1, scale)));
+                    se += (x0 != 0u) + (x1 != 0u);
+                    be += __popc(x0) + __popc(x1);
+                }
+            } else {
+                for (int t = lane; t < n_symbols; t += 64) {
+                    int tx[kFlatMax];
+                    cx<T> d[kFlatMax], x[kFlatMax], y[kFlatMax];
+#pragma unroll
+                    for (int l = 0; l < kFlatMax; ++l) {
+                        tx[l] = 0;
+                        d[l] = mk<T>(0, 0);
+                        if (l < layers) {
+                            const uint64_t n = c_order ? (uint64_t)l * n_symbols + t : (uint64_t)t * layers + l;
+                            tx[l] = (int)symbol_at(rng, n, mask);
+                            d[l] = s_table[tx[l]];
+                        }
+                    }
+#pragma unroll
+                    for (int a = 0; a < kFlatMax; ++a) {
+                        x[a] = mk<T>(0, 0);
+#pragma unroll
+                        for (int l = 0; l < kFlatMax; ++l) x[a] = cfma(W[a][l], d[l], x[a]);   // unused entries are 0
+                    }
+#pragma unroll
+                    for (int r = 0; r < kFlatMax; ++r) {
+                        y[r] = mk<T>(0, 0);
+                        if (r < nr) {
+                            y[r] = cn_sample<T>(rng, STREAM_NOISE, (uint64_t)r * n_symbols + t, sigma);
+#pragma unroll
+                            for (int a = 0; a < kFlatMax; ++a) y[r] = cfma(H[r][a], x[a], y[r]);
+                        }
+                    }
+#pragma unroll
+                    for (int l = 0; l < kFlatMax; ++l)
+                        if (l < layers) {
+                            cx<T> est = mk<T>(0, 0);
+#pragma unroll
+                            for (int r = 0; r < kFlatMax; ++r) est = cfma(G[l][r], y[r], est);
+                            const unsigned xr = (unsigned)(tx[l] ^ demod_one(mp, s_table, s_grid, est));
+                            se += (xr != 0u);
+                            be += __popc(xr);
+                        }
+                }
+            }
+            se = wave_sum_u32(se);
+            be = wave_sum_u32(be);
+            if (lane == 0) wg_account(totals, se, be, s_ok[j] == 0u, rl, sym_out, bit_out);
+        }
+    }
+    if (lane == 0)
+        wg_flush(totals, counters, (unsigned long long)layers * n_symbols,
+                 (unsigned long long)layers * n_symbols * mp.bits);
+}
+
+}  // namespace mcle
+
+using namespace mcle;
+
+extern "C" int mcle_run_mimo_flat(mcle_ctx* ctx, int dtype, const mcle_mimo_flat_cfg* cfg, uint64_t seed, uint64_t first,
+                                  uint64_t count, mcle_counters* d_counters, uint32_t* d_sym_err,
+                                  uint32_t* d_bit_err) {
+    int rc = check_pipe(ctx, dtype, cfg ? cfg->demod_method : 0, cfg);
+    if (rc) return rc;
+    const int nt = cfg->nt, nr = cfg->nr;
+    MCLE_REQUIRE(cfg->scheme >= MCLE_MIMO_BLAST && cfg->scheme <= MCLE_MIMO_GMD, "unknown MIMO scheme %d", cfg->scheme);
+    MCLE_REQUIRE(nt >= 1 && nt <= kFlatMax && nr >= 1 && nr <= kFlatMax, "antenna counts must be in [1, %d]", kFlatMax);
+    MCLE_REQUIRE(cfg->n_symbols >= 1, "n_symbols must be positive");
+    MCLE_REQUIRE(cfg->noise_var >= 0.0, "Noise variance must be a non-negative value.");
+    switch (cfg->scheme) {
+        case MCLE_MIMO_BLAST:
+            MCLE_REQUIRE(nt <= nr, "the fused Blast pipeline needs Nt <= Nr (got %dx%d)", nr, nt);
+            break;
+        case MCLE_MIMO_MRC:
+            MCLE_REQUIRE(nt == 1, "MRC is the single-transmit-antenna case of Blast (Nt = 1)");
+            break;
+        case MCLE_MIMO_MRT:   // MisoBase.set_channel_matrix, mimo.py:418-441
+            MCLE_REQUIRE(nr == 1, "MISO schemes are only defined for a single receive antenna");
+            break;
+        case MCLE_MIMO_ALAMOUTI:   // Alamouti.set_channel_matrix, mimo.py:1110-1131
+            MCLE_REQUIRE(nt == 2, "The number of transmit antennas must be equal to 2 for the Alamouti scheme");
+            MCLE_REQUIRE(cfg->n_symbols % 2 == 0, "Alamouti needs an even number of symbols");
+            break;
+        default:
+            MCLE_REQUIRE(nt == nr && nt >= 2, "SVD / GMD filters support square channels with 2 <= N <= 4");
+    }
+    MCLE_REQUIRE(count <= 0x7fffffffull, "at most 2^31-1 realizations per call");
+    if (count == 0) return MCLE_OK;
+    if ((rc = ctx->bind())) return rc;
+    const double filter_nv = cfg->mmse ? cfg->noise_var : 0.0;
+    const uint64_t cap = (uint64_t)ctx->n_cu * 16;
+    const uint64_t chunks = (count + 63) / 64;
+    const unsigned grid = (unsigned)(chunks < cap ? chunks : cap);
+    if (dtype == MCLE_F32)
+        hipLaunchKernelGGL(k_run_mimo_flat<float>, dim3(grid), dim3(64), 0, ctx->stream,
+                           pipe_modem<float>(ctx, cfg->demod_method), cfg->scheme, nt, nr, cfg->n_symbols,
+                           cfg->noise_var, filter_nv, seed, first, count, d_counters, d_sym_err, d_bit_err);
+    else
+        hipLaunchKernelGGL(k_run_mimo_flat<double>, dim3(grid), dim3(64), 0, ctx->stream,
+                           pipe_modem<double>(ctx, cfg->demod_method), cfg->scheme, nt, nr, cfg->n_symbols,
+                           cfg->noise_var, filter_nv, seed, first, count, d_counters, d_sym_err, d_bit_err);
+    MCLE_LAUNCH_CHECK();
+    return MCLE_OK;
+}

@@ -625,6 +625,14 @@ class Engine:
                           int(method), 1 if mmse else 0, float(noise_var))
         return self._run(self.lib.mcle_run_mimo_ofdm, cfg, seed, first, count, dtype, per_realization, counters)
 
+    def run_mimo_flat(self, scheme, nt, nr, n_symbols, noise_var, seed, first, count, mmse=False,
+                      method=DEMOD_MINDIST, dtype=None, per_realization=False, counters=None):
+        """The reference's MIMO application (apps/mimo/simulate_mimo.py:68-142) fused: flat H per realization and
+        one of 'blast', 'mrc', 'mrt', 'alamouti', 'svd', 'gmd'; n_symbols per layer."""
+        cfg = _lib.MimoFlatCfg(_lib.MIMO_SCHEMES[scheme], int(nt), int(nr), int(n_symbols), int(method),
+                               1 if mmse else 0, float(noise_var))
+        return self._run(self.lib.mcle_run_mimo_flat, cfg, seed, first, count, dtype, per_realization, counters)
+
     def run_mimo_ofdm_tdl(self, nt, nr, fft_size, cp_size, num_used, n_ofdm_sym, noise_var, tap_power, tap_delay,
                           seed, first, count, Fd=10.0, Ts=1.0 / (15e3 * 1024), L=8, mmse=True, method=DEMOD_MINDIST,
                           dtype=None, per_realization=False, counters=None):

@@ -236,3 +236,35 @@ def run_mimo_ofdm_tdl(eng, seed_base, first, count, mod="qam", M=16, nt=2, nr=2,
         se.append(int(s[0]))
         be.append(int(b[0]))
     return np.array(se), np.array(be)
+
+
+def run_mimo_scheme(eng, seed_base, first, count, scheme="blast", mod="qam", M=16, nt=2, nr=2, NSymbs=200, snr_db=15.0):
+    """apps/mimo/simulate_mimo.py:68-100 under np.random.seed(seed_base + r): randn_c(Nr, Nt); randint(0, M,
+    NSymbs * layers); randn_c(Nr, NSymbs).  Encode / decode through the mirror classes (per-operator kernels, f64).
+    Blast, MRC, MRT and Alamouti reproduce the reference's counts; SVD / GMD only statistically (their
+    singular-vector phases are LAPACK's choice there, the Jacobi routine's here)."""
+    from . import mimo as mm
+    table, kind = _table(mod, M)
+    eng.set_constellation(table, kind)
+    noise_var = 1.0 / float(dB2Linear(snr_db))
+    cls = {"blast": mm.Blast, "mrc": mm.MRC, "mrt": mm.MRT, "alamouti": mm.Alamouti, "svd": mm.SVDMimo,
+           "gmd": mm.GMDMimo}[scheme]
+    layers = 1 if scheme in ("alamouti", "mrt") else nt
+    prog = [("randn", nr * nt), ("randn", nr * nt), ("randint", NSymbs * layers, M), ("randn", nr * NSymbs),
+            ("randn", nr * NSymbs)]
+    ints, dbls = eng.legacy_draws(prog, seed_base, first, count)
+    h, idx = dbls.get(), ints.get()
+    se, be = [], []
+    o = 2 * nr * nt
+    for r in range(count):
+        H = INV_SQRT2 * (h[r, :nr * nt] + 1j * h[r, nr * nt:o]).reshape(nr, nt)
+        noise = INV_SQRT2 * (h[r, o:o + nr * NSymbs] + 1j * h[r, o + nr * NSymbs:o + 2 * nr * NSymbs]).reshape(nr, NSymbs)
+        obj = cls(H, engine=eng, dtype="f64")
+        sym = eng.modulate(idx[r], dtype="f64")
+        X = np.asarray(obj.encode(sym))
+        Y = eng.mimo_channel(H[np.newaxis], X.reshape(1, nt, -1), noise[np.newaxis], noise_var, dtype="f64")[0]
+        est = np.asarray(obj.decode(Y)).reshape(-1)
+        _, s, b = eng.demod_count(est, idx[r], n_real=1, dtype="f64")
+        se.append(int(s[0]))
+        be.append(int(b[0]))
+    return np.array(se), np.array(be)

@@ -162,6 +162,27 @@ class MimoOfdmSimulator(_LinkSimulator):
                                  per_realization=per_realization)
 
 
+class MimoSimulator(_LinkSimulator):
+    """apps/mimo/simulate_mimo.py:22-142 (MIMOSimulationRunner and its Alamouti / Blast / MRC / MRT / SVDMimo /
+    GMDMimo subclasses): flat channel per realization, NSymbs symbols per layer, single carrier.  `mmse=True`
+    is Blast.set_noise_var(noise_var) (the app itself runs zero forcing)."""
+
+    def __init__(self, SNR, scheme="blast", modulator="qam", M=16, Nt=2, Nr=2, NSymbs=200, mmse=False, **kw):
+        super().__init__(SNR, modulator, M, **kw)
+        if scheme not in _lib.MIMO_SCHEMES:
+            raise ValueError("unknown MIMO scheme %r" % (scheme,))
+        for k, v in (("scheme", scheme), ("Nt", int(Nt)), ("Nr", int(Nr)), ("NSymbs", int(NSymbs)),
+                     ("mmse", bool(mmse))):
+            self.params.add(k, v)
+
+    def _launch(self, current_parameters, first_rep, count, per_realization):
+        p = current_parameters
+        eng = self._bind()
+        return eng.run_mimo_flat(p["scheme"], p["Nt"], p["Nr"], p["NSymbs"], self._noise_var(p), self._seed_for(p),
+                                 first_rep, count, mmse=p["mmse"], method=self.demod_method, dtype=self.dtype,
+                                 per_realization=per_realization)
+
+
 class MimoOfdmTdlSimulator(_LinkSimulator):
     """spatial multiplexing over a frequency-selective MIMO TDL channel
     (TdlMimoChannel fading.py:1290-1333, MIMO branch of corrupt_data :1107-1117), per-antenna OFDM and one

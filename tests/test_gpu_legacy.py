@@ -76,3 +76,17 @@ def test_ia_iterative_same_seed_as_reference(engine):
 def test_mimo_ofdm_tdl_same_seed_as_reference(engine):
     """SURVEY 8(f).1 (frequency-selective MIMO-OFDM) under np.random.seed."""
     _check("f1_mimo_ofdm_tdl", lambda s, n, kw: legacy.run_mimo_ofdm_tdl(engine, s, 0, n, **kw))
+
+
+def test_mimo_schemes_same_seed_as_reference(engine):
+    """apps/mimo/simulate_mimo.py with Blast / MRC / MRT / Alamouti under np.random.seed: the reference's counts."""
+    seen = set()
+    for kw, reals in golden_cases("f5_mimo_schemes"):
+        if kw["scheme"] in ("svd", "gmd"):
+            continue                              # LAPACK's singular-vector phases are not reproducible
+        seen.add(kw["scheme"])
+        seeds = [int(g["seed"]) for g in reals]
+        se, be = legacy.run_mimo_scheme(engine, seeds[0], 0, len(seeds), **kw)
+        assert [int(v) for v in se] == [int(g["symbol_errors"]) for g in reals], kw
+        assert [int(v) for v in be] == [int(g["bit_errors"]) for g in reals], kw
+    assert seen == {"blast", "mrc", "mrt", "alamouti"}

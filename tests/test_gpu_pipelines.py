@@ -352,3 +352,74 @@ def test_edge_cases_and_large_indices(engine):
     # a rank-deficient "channel" cannot occur with Gaussian draws; zero forcing at huge SNR must not skip
     z = engine.run_mimo_ofdm(2, 2, 64, 8, 48, 2, 0.0, SEED, 0, 5000, mmse=False, dtype="f64")
     assert z["n_skipped"] == 0 and z["sym_errors"] == 0
+
+
+# ---- the reference's MIMO application: six schemes over a flat channel -----------------------------------------
+FLAT_EXACT = [("blast", 2, 2, 18.0), ("blast", 3, 4, 14.0), ("blast", 4, 4, 22.0), ("blast", 1, 1, 12.0),
+              ("mrc", 1, 3, 6.0), ("mrt", 3, 1, 8.0), ("mrt", 4, 1, 6.0), ("alamouti", 2, 1, 10.0),
+              ("alamouti", 2, 3, 4.0), ("alamouti", 2, 4, 2.0)]
+
+
+@pytest.mark.parametrize("dt,exact", [("f64", True), ("f32", False)])
+@pytest.mark.parametrize("scheme,nt,nr,snr", FLAT_EXACT)
+def test_mimo_flat_pipeline(engine, dt, exact, scheme, nt, nr, snr):
+    kw = dict(scheme=scheme, mod="qam", M=16, nt=nt, nr=nr, NSymbs=128, snr_db=snr)
+    engine.set_constellation(chains.constellation("qam", 16), _lib.CONST_QAM)
+    first, count = 3, 70                      # more than one 64-realization chunk
+    want_se, want_be, nsym, nbits = oracle_counts(chains.chain_mimo_scheme, first, count, **kw)
+    res, se, be = engine.run_mimo_flat(scheme, nt, nr, 128, 1.0 / omodem.dB2Linear(snr), SEED, first, count, dtype=dt,
+                                       per_realization=True)
+    check(res, se, be, want_se, want_be, nsym, nbits, exact)
+
+
+@pytest.mark.parametrize("scheme,n", [("svd", 2), ("svd", 4), ("gmd", 2), ("gmd", 3), ("gmd", 4)])
+def test_mimo_flat_svd_gmd(engine, scheme, n):
+    """Singular-vector phases are implementation-defined (LAPACK vs Jacobi), so per-realization decisions are
+    compared with the staged operator classes (the same device SVD / GMD, validated against the reference on
+    injected data) driven by the same Philox draws; statistics are compared with the oracle chain."""
+    from oracle import philox as P
+    from pyphysim_amd import mimo as mmimo
+    snr, NS, count = 16.0, 64, 12
+    nv = 1.0 / omodem.dB2Linear(snr)
+    table = chains.constellation("qam", 16)
+    engine.set_constellation(table, _lib.CONST_QAM)
+    res, se, be = engine.run_mimo_flat(scheme, n, n, NS, nv, SEED, 0, count, dtype="f64", per_realization=True)
+    cls = mmimo.SVDMimo if scheme == "svd" else mmimo.GMDMimo
+    for r in range(count):
+        H = P.cnormal(SEED, r, n * n, P.STREAM_CHAN).reshape(n, n)
+        idx = P.symbols(SEED, r, n * NS, 16)
+        noise = P.cnormal(SEED, r, n * NS, P.STREAM_NOISE).reshape(n, NS)
+        obj = cls(H, engine=engine, dtype="f64")
+        X = obj.encode(table[idx])
+        est = obj.decode(H @ X + np.sqrt(nv) * noise)
+        dec = np.argmin(np.abs(est[:, None] - table[None, :]), axis=1)
+        assert int(se[r]) == int(np.count_nonzero(dec != idx)), (scheme, n, r)
+    # statistics against the oracle chain (numpy.linalg.svd inside): same SER within Monte Carlo noise
+    big = engine.run_mimo_flat(scheme, n, n, NS, nv, SEED, 0, 20000, dtype="f32", method=_lib.DEMOD_QAM_SLICER)
+    want = [chains.chain_mimo_scheme(chains.PhiloxRng(SEED, r), scheme, "qam", 16, n, n, NS, snr)["symbol_errors"]
+            for r in range(400)]
+    ser_gpu = big["sym_errors"] / (20000.0 * n * NS)
+    ser_ref = np.sum(want) / (400.0 * n * NS)
+    assert abs(ser_gpu - ser_ref) < 0.25 * ser_ref + 2e-3
+    assert engine.run_mimo_flat(scheme, n, n, NS, 0.0, SEED, 0, 500, dtype="f32")["sym_errors"] == 0
+
+
+def test_mimo_flat_errors_and_shards(engine):
+    engine.set_constellation(chains.constellation("qam", 16), _lib.CONST_QAM)
+    for bad in (("blast", 4, 2), ("mrc", 2, 2), ("mrt", 2, 2), ("alamouti", 3, 2), ("svd", 2, 3), ("gmd", 1, 1),
+                ("blast", 5, 5)):
+        with pytest.raises(_lib.McleError):
+            engine.run_mimo_flat(bad[0], bad[1], bad[2], 64, 0.1, SEED, 0, 4)
+    with pytest.raises(_lib.McleError):
+        engine.run_mimo_flat("alamouti", 2, 2, 63, 0.1, SEED, 0, 4)
+    with pytest.raises(KeyError):
+        engine.run_mimo_flat("vblast", 2, 2, 64, 0.1, SEED, 0, 4)
+    a = engine.run_mimo_flat("blast", 4, 4, 200, 0.01, SEED, 0, 100000, dtype="f32", method=_lib.DEMOD_QAM_SLICER)
+    b = engine.run_mimo_flat("blast", 4, 4, 200, 0.01, SEED, 0, 33333, dtype="f32", method=_lib.DEMOD_QAM_SLICER)
+    c = engine.run_mimo_flat("blast", 4, 4, 200, 0.01, SEED, 33333, 66667, dtype="f32", method=_lib.DEMOD_QAM_SLICER)
+    for k in ("sym_errors", "sym_errors_sq", "bit_errors", "bit_errors_sq", "n_realizations", "n_skipped"):
+        assert a[k] == b[k] + c[k]
+    # MMSE beats zero forcing at low SNR
+    zf = engine.run_mimo_flat("blast", 4, 4, 100, 1.0, SEED, 0, 20000, dtype="f32")
+    mm = engine.run_mimo_flat("blast", 4, 4, 100, 1.0, SEED, 0, 20000, dtype="f32", mmse=True)
+    assert mm["sym_errors"] < zf["sym_errors"]

@@ -234,3 +234,22 @@ def test_ia_simulator_iterative(engine):
     cap = {k: v.get_result_values_list("sum_capacity") for k, v in out.items()}
     assert cap["max_sinr"][0] > cap["closed_form"][0]            # noise-aware filters win at 0 dB
     assert abs(cap["alt_min"][1] - cap["closed_form"][1]) < 0.15 * cap["closed_form"][1]   # both align at 20 dB
+
+
+def test_mimo_simulator_schemes(engine):
+    """MimoSimulator = the reference's MIMO application (apps/mimo/simulate_mimo.py) for its six schemes:
+    diversity orders show in the SER ordering, SVD / GMD / Blast all resolve Nt layers."""
+    ser = {}
+    for scheme, nt, nr in (("blast", 2, 2), ("alamouti", 2, 2), ("mrc", 1, 2), ("mrt", 2, 1), ("svd", 2, 2),
+                           ("gmd", 2, 2)):
+        sim = simulators.MimoSimulator(SNR=[10.0], scheme=scheme, M=4, modulator="psk", Nt=nt, Nr=nr, NSymbs=100,
+                                       rep_max=20000, batch_size=20000, seed=9, engine=engine)
+        sim.simulate()
+        ser[scheme] = sim.results.get_result_values_list("ser")[0]
+        layers = 1 if scheme in ("alamouti", "mrt") else nt
+        assert sim.results.get_result_values_list("num_symbols")[0] == 20000 * 100 * layers
+    assert ser["alamouti"] < ser["mrc"] < ser["blast"]        # diversity 4 > 2 > 1 (ZF 2x2)
+    assert ser["alamouti"] < ser["mrt"]
+    assert 0 < ser["gmd"] and 0 < ser["svd"] < 0.5
+    with pytest.raises(ValueError):
+        simulators.MimoSimulator(SNR=[10.0], scheme="stbc")
