@@ -85,6 +85,21 @@ template <typename T, bool INV> __device__ __forceinline__ cx<T> rot(cx<T> a) {
     return INV ? mk<T>(-a.y, a.x) : mk<T>(a.y, -a.x);
 }
 
+// Synchronisation between two radix-4 stages.  With a compile-time workgroup size that is a multiple of 64 the
+// s butterflies that share a 4s-point region sit on s consecutive threads, and no region straddles a wavefront
+// once s <= 64: such a stage only has to be ordered against the SAME wavefront's earlier LDS traffic, which
+// executes in order -- a fence for the compiler and the counters, no workgroup barrier.  (`s` is the span of
+// the stage whose s threads exchange data: the producing stage in DIF, the consuming one in DIT.)
+template <int NTHREADS> __device__ __forceinline__ void fft_stage_sync(int s) {
+    if (NTHREADS > 0 && NTHREADS % 64 == 0 && s <= 64) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    } else {
+        __syncthreads();
+    }
+}
+
 // ---- decimation in frequency: natural -> digit-reversed ----------------------------------------
 // Caller has written s_data and synchronised.  Returns synchronised.
 // NTHREADS > 0: the workgroup size is a compile-time constant, so the per-stage butterfly loops
@@ -122,7 +137,10 @@ __device__ __forceinline__ void fft_dif(cx<T>* s_data, int nf, int pitch, const 
             p[i2] = y2;
             p[i3] = y3;
         }
-        __syncthreads();
+        if (st + 1 < FftShape<N>::N4)
+            fft_stage_sync<NTHREADS>(s);   // the next stage reads what THIS stage's s-thread groups wrote
+        else
+            __syncthreads();               // leave (or enter the radix-2 stage) workgroup-synchronised
     }
     if (FftShape<N>::HAS2) {
         for (int b = FRESH ? opaque((int)threadIdx.x) : (int)threadIdx.x; b < nf * (N / 2); b += nthreads) {
@@ -177,7 +195,10 @@ __device__ __forceinline__ void fft_dit(cx<T>* s_data, int nf, int pitch, const 
             p[i2] = csub(a0, a2);
             p[i3] = csub(a1, a3);
         }
-        __syncthreads();
+        if (st + 1 < FftShape<N>::N4)
+            fft_stage_sync<NTHREADS>(4 * s);   // the next stage's 4s-thread groups read what was written here
+        else
+            __syncthreads();
     }
 }
 

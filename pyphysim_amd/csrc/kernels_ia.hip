@@ -501,7 +501,7 @@ __global__ __launch_bounds__(64) void k_run_ia(ModemParams<T> mp, int n_symbols,
 
 template <typename T> static ModemParams<T> ia_modem(const mcle_ctx* ctx, int method) {
     ModemParams<T> p;
-    p.grid = context_grid<T>(ctx);
+    p.grid = context_grid<T>(ctx, method);
     if (sizeof(T) == 8)
         p.g_table = reinterpret_cast<const cx<T>*>(ctx->d_table_f64);
     else

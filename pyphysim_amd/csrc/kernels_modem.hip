@@ -13,7 +13,7 @@ constexpr int kMaxM = 1024;
 template <typename T> ModemParams<T> modem_params(const mcle_ctx* ctx, int method);
 template <> ModemParams<float> modem_params<float>(const mcle_ctx* ctx, int method) {
     ModemParams<float> p;
-    p.grid = context_grid<float>(ctx);
+    p.grid = context_grid<float>(ctx, method);
     p.g_table = ctx->d_table_f32;
     p.M = ctx->M;
     p.bits = ctx->bits;
@@ -25,7 +25,7 @@ template <> ModemParams<float> modem_params<float>(const mcle_ctx* ctx, int meth
 }
 template <> ModemParams<double> modem_params<double>(const mcle_ctx* ctx, int method) {
     ModemParams<double> p;
-    p.grid = context_grid<double>(ctx);
+    p.grid = context_grid<double>(ctx, method);
     p.g_table = ctx->d_table_f64;
     p.M = ctx->M;
     p.bits = ctx->bits;

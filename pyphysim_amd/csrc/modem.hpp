@@ -191,10 +191,10 @@ __device__ __forceinline__ int demod_one(const ModemParams<T>& mp, const cx<T>* 
 }
 
 // host: candidate grid of the context for the f32 instantiation, none for f64 (parity path sweeps everything)
-template <typename T> inline DemodGrid context_grid(const mcle_ctx* ctx) {
+template <typename T> inline DemodGrid context_grid(const mcle_ctx* ctx, int method = MCLE_DEMOD_MINDIST) {
     DemodGrid g;
     g.cells = ctx->d_grid;
-    g.G = (sizeof(T) == 4 && ctx->d_grid != nullptr) ? ctx->grid_G : 0;
+    g.G = (sizeof(T) == 4 && ctx->d_grid != nullptr && method == MCLE_DEMOD_MINDIST) ? ctx->grid_G : 0;   // the slicer needs none
     g.x0 = ctx->grid_x0;
     g.y0 = ctx->grid_y0;
     g.inv_h = ctx->grid_inv_h;

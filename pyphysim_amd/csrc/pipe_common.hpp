@@ -32,7 +32,7 @@ __device__ __forceinline__ void block_sum2(unsigned& a, unsigned& b, unsigned* s
 // ---- host side -----------------------------------------------------------------------------------
 template <typename T> ModemParams<T> pipe_modem(const mcle_ctx* ctx, int method) {
     ModemParams<T> p;
-    p.grid = context_grid<T>(ctx);
+    p.grid = context_grid<T>(ctx, method);
     if (sizeof(T) == 8)
         p.g_table = reinterpret_cast<const cx<T>*>(ctx->d_table_f64);
     else

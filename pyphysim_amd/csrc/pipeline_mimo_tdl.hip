@@ -61,10 +61,11 @@ __global__ __launch_bounds__(kPipeBlock, sizeof(T) == 4 ? 3 : 1) void k_run_mimo
     cx<T>* s_coef = s_tw + N;                           // [PS][K+1]
     cx<T>* s_mean = s_coef + PS * (K + 1);              // [PS]
     cx<T>* s_tail = s_mean + PS;                        // [2][NA][dmax] last samples of the previous symbol
-    float4* s_tab4 = reinterpret_cast<float4*>(s_tail + 2 * NA * (dmax > 0 ? dmax : 1));  // [kMaxTable]
+    float4* s_tab4 = reinterpret_cast<float4*>(s_tail + 2 * NA * (dmax > 0 ? dmax : 1));  // [M rounded up to 16]
     cx<T>* s_table = reinterpret_cast<cx<T>*>(s_tab4);  // f64: the plain table lives in the same place
+    const int table_len = (mp.M + 15) & ~15;            // the table region is sized by the constellation
     unsigned* s_red = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(s_tab4) +
-                                                  kMaxTable * (sizeof(T) == 4 ? sizeof(float4) : sizeof(cx<T>)));
+                                                  table_len * (sizeof(T) == 4 ? sizeof(float4) : sizeof(cx<T>)));
     unsigned long long* s_grid = reinterpret_cast<unsigned long long*>(s_red + 16);   // [G*G] candidate grid (f32)
     unsigned char* s_idx = reinterpret_cast<unsigned char*>(s_grid + mp.grid.G * mp.grid.G);   // [NA*num_used]
 
@@ -406,7 +407,8 @@ int run_mimo_tdl_impl(mcle_ctx* ctx, MimoTdlParams pp, int method, uint64_t seed
     const size_t ray_elems = (PS * pp.L * 3 + 1) / 2;            // {re, im, theta} per ray, in complex elements
     pp.x_elems = (int)(ray_elems > (size_t)NA * N ? ray_elems : (size_t)NA * N);
     const size_t lds = (size_t)(pp.x_elems + N + PS * (pp.K + 1) + PS + 2 * NA * (pp.dmax > 0 ? pp.dmax : 1)) * sizeof(cx<T>) +
-                       kMaxTable * (sizeof(T) == 4 ? sizeof(float4) : sizeof(cx<T>)) + 16 * sizeof(unsigned) +
+                       (size_t)((mp.M + 15) & ~15) * (sizeof(T) == 4 ? sizeof(float4) : sizeof(cx<T>)) +
+                       16 * sizeof(unsigned) +
                        (size_t)mp.grid.G * mp.grid.G * sizeof(unsigned long long) + (size_t)NA * pp.num_used + 16;
     MCLE_REQUIRE(lds <= 160 * 1024, "configuration needs %zu bytes of LDS (limit 160 KiB)", lds);
     auto kern = k_run_mimo_ofdm_tdl<T, N, NA>;
