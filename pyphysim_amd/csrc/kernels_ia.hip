@@ -392,9 +392,9 @@ __global__ __launch_bounds__(64) void k_run_ia(ModemParams<T> mp, int n_symbols,
     __shared__ cx<T> s_F[64][6 + 1];
     __shared__ cx<T> s_U[64][6 + 1];
     __shared__ unsigned s_ok[64];
-    __shared__ unsigned long long s_grid[sizeof(T) == 4 ? kMaxGridCells : 1];
+    extern __shared__ unsigned long long s_grid[];       // [G*G] candidate grid (min-distance demodulation, f32)
     load_table(mp, s_table);
-    if (sizeof(T) == 4) load_grid(mp, s_grid);
+    load_grid(mp, s_grid);
     const int lane = threadIdx.x;
     const T sigma = (T)sqrt(noise_var);
     const uint32_t mask = (uint32_t)(mp.M - 1);
@@ -574,8 +574,11 @@ int mcle_run_ia(mcle_ctx* ctx, int dtype, const mcle_ia_cfg* cfg, uint64_t seed,
     const uint64_t cap = (uint64_t)ctx->n_cu * 16;
     const uint64_t chunks = (count + 63) / 64;       // one wavefront per 64 realizations
     const unsigned grid = (unsigned)(chunks < cap ? chunks : cap);
+    const size_t lds = dtype == MCLE_F32 ? (size_t)ia_modem<float>(ctx, cfg->demod_method).grid.G *
+                                               ia_modem<float>(ctx, cfg->demod_method).grid.G * sizeof(unsigned long long)
+                                         : 0;
     if (dtype == MCLE_F32)
-        hipLaunchKernelGGL(k_run_ia<float>, dim3(grid), dim3(64), 0, ctx->stream, ia_modem<float>(ctx, cfg->demod_method),
+        hipLaunchKernelGGL(k_run_ia<float>, dim3(grid), dim3(64), lds, ctx->stream, ia_modem<float>(ctx, cfg->demod_method),
                            cfg->n_symbols, cfg->noise_var, cfg->solver, cfg->max_iterations, cfg->relative_factor, seed,
                            first, count, d_counters, d_sym_err, d_bit_err, d_sum_capacity, d_iterations);
     else

@@ -130,12 +130,12 @@ __global__ __launch_bounds__(64) void k_run_mimo_flat(ModemParams<T> mp, int sch
                                                       uint32_t* __restrict__ sym_out, uint32_t* __restrict__ bit_out) {
     constexpr int PITCH = kFlatMax * kFlatMax + 1;
     __shared__ cx<T> s_table[256];
-    __shared__ unsigned long long s_grid[sizeof(T) == 4 ? kMaxGridCells : 1];
+    extern __shared__ unsigned long long s_grid[];       // [G*G] candidate grid (min-distance demodulation, f32)
     __shared__ cx<T> s_H[64][PITCH], s_W[64][PITCH], s_G[64][PITCH];
     __shared__ T s_aux[64];
     __shared__ unsigned s_ok[64];
     load_table(mp, s_table);
-    if (sizeof(T) == 4) load_grid(mp, s_grid);
+    load_grid(mp, s_grid);
     const int lane = threadIdx.x;
     const T sigma = (T)sqrt(noise_var);
     const uint32_t mask = (uint32_t)(mp.M - 1);
@@ -304,9 +304,10 @@ extern "C" int mcle_run_mimo_flat(mcle_ctx* ctx, int dtype, const mcle_mimo_flat
     const uint64_t cap = (uint64_t)ctx->n_cu * 16;
     const uint64_t chunks = (count + 63) / 64;
     const unsigned grid = (unsigned)(chunks < cap ? chunks : cap);
+    const ModemParams<float> mp32 = pipe_modem<float>(ctx, cfg->demod_method);
+    const size_t lds = (size_t)mp32.grid.G * mp32.grid.G * sizeof(unsigned long long);
     if (dtype == MCLE_F32)
-        hipLaunchKernelGGL(k_run_mimo_flat<float>, dim3(grid), dim3(64), 0, ctx->stream,
-                           pipe_modem<float>(ctx, cfg->demod_method), cfg->scheme, nt, nr, cfg->n_symbols,
+        hipLaunchKernelGGL(k_run_mimo_flat<float>, dim3(grid), dim3(64), lds, ctx->stream, mp32, cfg->scheme, nt, nr, cfg->n_symbols,
                            cfg->noise_var, filter_nv, seed, first, count, d_counters, d_sym_err, d_bit_err);
     else
         hipLaunchKernelGGL(k_run_mimo_flat<double>, dim3(grid), dim3(64), 0, ctx->stream,

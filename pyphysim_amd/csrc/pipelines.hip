@@ -95,12 +95,12 @@ __global__ __launch_bounds__(kPipeBlock) void k_run_flat(FlatParams fp, ModemPar
                                                          uint64_t first, uint64_t count, unsigned* __restrict__ ws) {
     constexpr bool kRec = (LR > 0) && (sizeof(T) == 4);
     __shared__ cx<T> s_table[kMaxTable];
-    __shared__ unsigned long long s_grid[sizeof(T) == 4 ? kMaxGridCells : 1];
+    extern __shared__ unsigned long long s_grid[];       // [G*G] candidate grid (min-distance demodulation, f32)
     __shared__ double s_w[kMaxRays], s_psi[kMaxRays];
     __shared__ float2 s_rot[kMaxRays];
     __shared__ unsigned s_red[2 * (kPipeBlock / 64)];
     load_table(mp, s_table);
-    if (sizeof(T) == 4) load_grid(mp, s_grid);
+    load_grid(mp, s_grid);
     const int chunks = (fp.n_symbols + kChunk - 1) / kChunk;
     const uint64_t items = count * (uint64_t)chunks;
     const T sigma = (T)fp.noise_sigma;
@@ -640,15 +640,17 @@ int run_flat_impl(mcle_ctx* ctx, const FlatParams& fp, int method, uint64_t seed
     const uint64_t items = count * (uint64_t)((fp.n_symbols + kChunk - 1) / kChunk);
     const uint64_t cap = (uint64_t)ctx->n_cu * 8;
     const unsigned grid = (unsigned)(items < cap ? items : cap);
+    const ModemParams<T> mp = pipe_modem<T>(ctx, method);
+    const size_t lds = (size_t)mp.grid.G * mp.grid.G * sizeof(unsigned long long);
     if (sizeof(T) == 4 && fp.L == 8)
-        hipLaunchKernelGGL((k_run_flat<T, 8>), dim3(grid), dim3(kPipeBlock), 0, ctx->stream, fp,
-                           pipe_modem<T>(ctx, method), seed, first, count, ws);
+        hipLaunchKernelGGL((k_run_flat<T, 8>), dim3(grid), dim3(kPipeBlock), lds, ctx->stream, fp, mp, seed, first, count,
+                           ws);
     else if (sizeof(T) == 4 && fp.L == 16)
-        hipLaunchKernelGGL((k_run_flat<T, 16>), dim3(grid), dim3(kPipeBlock), 0, ctx->stream, fp,
-                           pipe_modem<T>(ctx, method), seed, first, count, ws);
+        hipLaunchKernelGGL((k_run_flat<T, 16>), dim3(grid), dim3(kPipeBlock), lds, ctx->stream, fp, mp, seed, first,
+                           count, ws);
     else
-        hipLaunchKernelGGL((k_run_flat<T, 0>), dim3(grid), dim3(kPipeBlock), 0, ctx->stream, fp,
-                           pipe_modem<T>(ctx, method), seed, first, count, ws);
+        hipLaunchKernelGGL((k_run_flat<T, 0>), dim3(grid), dim3(kPipeBlock), lds, ctx->stream, fp, mp, seed, first, count,
+                           ws);
     MCLE_LAUNCH_CHECK();
     return pipe_fold(ctx, ws, nullptr, count, (uint64_t)fp.n_symbols, d_counters, d_sym, d_bit);
 }
