@@ -285,6 +285,10 @@ enum { MCLE_IA_CLOSED_FORM = 0,  /* ClosedFormIASolver      ia/algorithms.py:42-
        MCLE_IA_MIN_LEAKAGE = 2,  /* MinLeakageIASolver      ia/algorithms.py:1132-1240 */
        MCLE_IA_MAX_SINR = 3 };   /* MaxSinrIASolver         ia/algorithms.py:1243-1507 */
 
+enum { MCLE_IA_INIT_GIVEN = 0,        /* 'random' (pipelines: drawn on-chip) or 'fix' (operator: injected) */
+       MCLE_IA_INIT_CLOSED_FORM = 1,  /* 'closed_form': F and W of ClosedFormIASolver                      */
+       MCLE_IA_INIT_ALT_MIN = 2 };    /* 'alt_min': AlternatingMinIASolver run first, same max_iterations */
+
 typedef struct mcle_ia_cfg {            /* C5: apps/ia/simulate_ia.py:94-245, ClosedFormIASolver */
     int32_t K, nr, nt, ns;              /* supported: K = 3, nr = nt = 2, ns = 1 */
     int32_t n_symbols;                  /* NSymbs per stream */
@@ -293,6 +297,8 @@ typedef struct mcle_ia_cfg {            /* C5: apps/ia/simulate_ia.py:94-245, Cl
     int32_t solver;                     /* MCLE_IA_*: closed form or an iterative solver (initialize_with='random') */
     int32_t max_iterations;             /* iterative solvers: IterativeIASolverBaseClass.max_iterations */
     double relative_factor;             /* ... and .relative_factor (algorithms.py:316-322) */
+    int32_t initialize_with;            /* MCLE_IA_INIT_*: 'random' / 'closed_form' / 'alt_min' (algorithms.py:633-663) */
+    int32_t reserved;
 } mcle_ia_cfg;
 
 /* Each run_* processes realizations [first, first+count) of `seed`, ADDS into d_counters[0]
@@ -335,11 +341,14 @@ int mcle_run_ia(mcle_ctx* ctx, int dtype, const mcle_ia_cfg* cfg, uint64_t seed,
 int mcle_ia_closed_form(mcle_ctx* ctx, const void* d_bigH, double noise_var, void* d_F, void* d_U,
                         double* d_sinr, double* d_capacity, uint32_t* d_skipped, size_t batch);
 /* Iterative solvers (solver = MCLE_IA_ALT_MIN / MIN_LEAKAGE / MAX_SINR) from injected initial precoders
- * d_F_init [batch][3][2] (unit norm; initialize_with='fix'): IterativeIASolverBaseClass.solve
- * (algorithms.py:802-883).  d_iterations [batch] (may be NULL) = runned_iterations. */
-int mcle_ia_iterative(mcle_ctx* ctx, int solver, const void* d_bigH, const void* d_F_init, double noise_var,
-                      int max_iterations, double relative_factor, void* d_F, void* d_U, double* d_sinr,
-                      double* d_capacity, uint32_t* d_iterations, uint32_t* d_skipped, size_t batch);
+ * d_F_init [batch][3][2] (unit norm): the starting precoders for MCLE_IA_INIT_GIVEN ('fix' / a captured
+ * 'random' start), the alternating-minimisation solver's start for MCLE_IA_INIT_ALT_MIN, ignored for
+ * MCLE_IA_INIT_CLOSED_FORM.  IterativeIASolverBaseClass.solve (algorithms.py:802-883).  d_iterations [batch]
+ * (may be NULL) = runned_iterations. */
+int mcle_ia_iterative(mcle_ctx* ctx, int solver, int initialize_with, const void* d_bigH,
+                      const void* d_F_init, double noise_var, int max_iterations, double relative_factor,
+                      void* d_F, void* d_U, double* d_sinr, double* d_capacity, uint32_t* d_iterations,
+                      uint32_t* d_skipped, size_t batch);
 
 /* ---- same-seed parity mode: NumPy's legacy global RandomState replayed on the device -------
  * Realization r receives exactly what the reference draws after np.random.seed(seed_base + r)

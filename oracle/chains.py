@@ -280,7 +280,7 @@ STREAM_INIT = 3    # the solver's own RandomState (iabase.py:95); shares the PHA
 
 
 def chain_ia_iterative(rng, algo='alt_min', mod='qam', M=16, K=3, nr=2, nt=2, Ns=1, NSymbs=200, snr_db=20.0,
-                       max_iterations=50, relative_factor=1e-6):
+                       max_iterations=50, relative_factor=1e-6, initialize_with='random'):
     """apps/ia/simulate_ia.py:94-245 with an iterative solver
     (AlternatingMinIASolver / MinLeakageIASolver / MaxSinrIASolver, initialize_with='random')."""
     table = constellation(mod, M)
@@ -288,10 +288,17 @@ def chain_ia_iterative(rng, algo='alt_min', mod='qam', M=16, K=3, nr=2, nt=2, Ns
     big_H = rng.cn(philox.STREAM_CHAN, K * nr, K * nt)
     H = oia.split_blocks(big_H, K, nr, nt)
     F_init = []
-    for k in range(K):                       # randomizeF (iabase.py:538-540): normalized(randn_c_RS(rs, Nt, Ns))
-        f = rng.cn(STREAM_INIT, nt, Ns)
-        F_init.append(f / np.linalg.norm(f, "fro"))
-    F, U, cap, sinr, runned = oia.iterative_solve(algo, H, F_init, noise_var, max_iterations, relative_factor)
+    if initialize_with == 'closed_form':
+        F_init = [np.zeros((nt, Ns), dtype=complex)] * K       # shape only: no random start is drawn
+    else:
+        # randomizeF (iabase.py:538-540): normalized(randn_c_RS(rs, Nt, Ns)) -- drawn by the solver itself
+        # ('random') or by the alternating-minimisation solver it starts from ('alt_min'), each from the
+        # beginning of its own RandomState
+        for k in range(K):
+            f = rng.cn(STREAM_INIT, nt, Ns)
+            F_init.append(f / np.linalg.norm(f, "fro"))
+    F, U, cap, sinr, runned = oia.iterative_solve(algo, H, F_init, noise_var, max_iterations, relative_factor,
+                                                  initialize_with)
     if rng.legacy:
         idx = rng.rs.randint(0, M, [K * Ns, NSymbs])
     else:

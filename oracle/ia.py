@@ -74,8 +74,8 @@ def calc_SINR(H, F, U, noise_var):
     return sinr
 
 
-def closed_form_solve(H, Ns, noise_var, use_best_init=True):
-    """-> (F list, U = full_W_H list, sum capacity, SINRs)."""
+def closed_form_solve(H, Ns, noise_var, use_best_init=True, with_W=False):
+    """-> (F list, U = full_W_H list, sum capacity, SINRs) [+ W list when with_W]."""
     vecs = np.linalg.eig(calc_E(H))[1]
     if use_best_init:
         subsets = [vecs[:, c] for c in itertools.combinations(range(vecs.shape[1]), Ns)]
@@ -90,7 +90,7 @@ def closed_form_solve(H, Ns, noise_var, use_best_init=True):
         sinr = calc_SINR(H, F, U, noise_var)
         cap = float(np.sum([np.sum(np.log2(1 + s)) for s in sinr]))
         if cap > best_cap or not use_best_init:
-            best_cap, best = cap, (F, U, cap, sinr)
+            best_cap, best = cap, ((F, U, cap, sinr, W) if with_W else (F, U, cap, sinr))
     return best
 
 
@@ -143,11 +143,10 @@ def is_diff_significant(F_old, F_new, relative_factor):
     return False
 
 
-def _iterate(F, step, max_iterations, relative_factor):
-    """algorithms.py:857-869."""
+def _iterate(F, step, max_iterations, relative_factor, state=None):
+    """algorithms.py:857-869; `state` = receive filters handed over by an initialisation other than 'random'."""
     old_F = F
     runned = 0
-    state = None
     for _ in range(max_iterations):
         runned += 1
         F, state = step(F, state)
@@ -157,8 +156,9 @@ def _iterate(F, step, max_iterations, relative_factor):
     return F, state, runned
 
 
-def alt_min_solve(H, F_init, noise_var, max_iterations=50, relative_factor=1e-6):
-    """-> (F, W_H rows, runned_iterations); Ns taken from F_init."""
+def alt_min_solve(H, F_init, noise_var, max_iterations=50, relative_factor=1e-6, W_init=None):
+    """-> (F, W_H rows, runned_iterations); Ns taken from F_init.  (W_init is ignored: the algorithm derives
+    its state C from F in _before_initialize_W_func and W only when it finishes.)"""
     K = len(F_init)
     Ns = [f.shape[1] for f in F_init]
     Nr = [H[k][k].shape[0] for k in range(K)]
@@ -187,7 +187,7 @@ def alt_min_solve(H, F_init, noise_var, max_iterations=50, relative_factor=1e-6)
     return F, W_H, runned
 
 
-def min_leakage_solve(H, F_init, noise_var, max_iterations=50, relative_factor=1e-6):
+def min_leakage_solve(H, F_init, noise_var, max_iterations=50, relative_factor=1e-6, W_init=None):
     K = len(F_init)
     Ns = [f.shape[1] for f in F_init]
 
@@ -201,13 +201,13 @@ def min_leakage_solve(H, F_init, noise_var, max_iterations=50, relative_factor=1
         return F, update_W(F)
 
     F0 = [np.asarray(f, dtype=complex) for f in F_init]
-    F, W, runned = _iterate(F0, step, max_iterations, relative_factor)
+    F, W, runned = _iterate(F0, step, max_iterations, relative_factor, W_init)
     if W is None:
         W = update_W(F)
     return F, [w.conj().T for w in W], runned
 
 
-def max_sinr_solve(H, F_init, noise_var, max_iterations=50, relative_factor=1e-6):
+def max_sinr_solve(H, F_init, noise_var, max_iterations=50, relative_factor=1e-6, W_init=None):
     """Ns = 1 per user is what the kernel covers; the restatement keeps the per-stream loop."""
     K = len(F_init)
 
@@ -243,7 +243,7 @@ def max_sinr_solve(H, F_init, noise_var, max_iterations=50, relative_factor=1e-6
         return F, update_W(F)
 
     F0 = [np.asarray(f, dtype=complex) for f in F_init]
-    F, W, runned = _iterate(F0, step, max_iterations, relative_factor)
+    F, W, runned = _iterate(F0, step, max_iterations, relative_factor, W_init)
     if W is None:
         W = update_W(F)
     return F, [w.conj().T for w in W], runned
@@ -252,9 +252,22 @@ def max_sinr_solve(H, F_init, noise_var, max_iterations=50, relative_factor=1e-6
 ITERATIVE = {"alt_min": alt_min_solve, "min_leakage": min_leakage_solve, "max_sinr": max_sinr_solve}
 
 
-def iterative_solve(algo, H, F_init, noise_var, max_iterations=50, relative_factor=1e-6):
-    """-> (F, U = full_W_H, sum capacity, SINRs, runned_iterations)."""
-    F, W_H, runned = ITERATIVE[algo](H, F_init, noise_var, max_iterations, relative_factor)
+def iterative_solve(algo, H, F_init, noise_var, max_iterations=50, relative_factor=1e-6, initialize_with='random'):
+    """-> (F, U = full_W_H, sum capacity, SINRs, runned_iterations).  initialize_with (algorithms.py:633-663):
+    'random' / 'fix': F_init are the starting precoders; 'closed_form' (:572-597): start from the closed-form
+    solution's F and W; 'alt_min' (:599-632): run the alternating-minimisation solver first (its own random
+    start = F_init, the same max_iterations) and start from its F and its normalised receive filters."""
+    W_init = None
+    if initialize_with == 'closed_form':
+        Ns = F_init[0].shape[1]
+        F_init, _, _, _, W_init = closed_form_solve(H, Ns, noise_var, True, with_W=True)
+    elif initialize_with == 'alt_min':
+        if algo == 'alt_min':
+            raise RuntimeError("Can't use 'alt_min' initialization with 'AlternatingMinIASolver' class 'alt_min'")
+        Fa, WHa, _ = alt_min_solve(H, F_init, noise_var, max_iterations, relative_factor)
+        F_init = Fa
+        W_init = [w.conj().T / np.linalg.norm(w, 'fro') for w in WHa]
+    F, W_H, runned = ITERATIVE[algo](H, F_init, noise_var, max_iterations, relative_factor, W_init)
     U = [np.linalg.solve(W_H[k] @ (H[k][k] @ F[k]), W_H[k]) for k in range(len(F))]
     sinr = calc_SINR(H, F, U, noise_var)
     cap = float(np.sum([np.sum(np.log2(1 + s)) for s in sinr]))

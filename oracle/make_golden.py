@@ -313,7 +313,8 @@ def ref_chain_ia(seed, mod, M, K, nr, nt, Ns, NSymbs, snr_db):
                 sinr=np.concatenate([np.asarray(s, dtype=float) for s in sinr]), **ref_counts(idx, dec, M))
 
 
-def ref_chain_ia_iterative(seed, algo, mod, M, K, nr, nt, Ns, NSymbs, snr_db, max_iterations, relative_factor):
+def ref_chain_ia_iterative(seed, algo, mod, M, K, nr, nt, Ns, NSymbs, snr_db, max_iterations, relative_factor,
+                           initialize_with="random"):
     from pyphysim.channels import multiuser as rmu
     from pyphysim.ia import algorithms as ralg
     np.random.seed(seed)
@@ -328,18 +329,22 @@ def ref_chain_ia_iterative(seed, algo, mod, M, K, nr, nt, Ns, NSymbs, snr_db, ma
     solver._rs = np.random.RandomState(seed)      # the reference leaves this one unseeded (iabase.py:95)
     solver.max_iterations = max_iterations
     solver.relative_factor = relative_factor
-    solver.initialize_with = "random"
+    solver.initialize_with = initialize_with
+    if solver._alt_min_ia_solver is not None:
+        solver._alt_min_ia_solver._rs = np.random.RandomState(seed)   # its own, equally unseeded, RandomState
     muc.randomize(nr, nt, K)
     muc.noise_var = noise_var
     solver.clear()
     # capture the random initial precoder: randomizeF is the first thing solve() does
-    F_init = {}
-    orig = solver.randomizeF
+    F_init = {"F": [np.zeros((nt, Ns), dtype=complex)] * K}
+    drawer = solver if initialize_with == "random" else solver._alt_min_ia_solver
+    if initialize_with in ("random", "alt_min"):
+        orig = drawer.randomizeF
 
-    def spy(Ns_, P=None):
-        orig(Ns_, P)
-        F_init["F"] = [np.array(f) for f in solver._F]
-    solver.randomizeF = spy
+        def spy(Ns_, P=None):
+            orig(Ns_, P)
+            F_init["F"] = [np.array(f) for f in drawer._F]
+        drawer.randomizeF = spy
     runned = solver.solve(Ns)
     cumNs = np.cumsum(solver.Ns)
     idx = np.random.randint(0, M, [np.sum(solver.Ns), NSymbs])
@@ -440,7 +445,12 @@ CHAINS = {
     "f3_ia_iterative": [dict(algo=a, mod="qam", M=16, K=3, nr=2, nt=2, Ns=1, NSymbs=120, snr_db=snr,
                              max_iterations=it, relative_factor=1e-6)
                         for a, snr, it in (("alt_min", 20.0, 50), ("alt_min", 8.0, 7), ("min_leakage", 20.0, 50),
-                                           ("max_sinr", 20.0, 50), ("max_sinr", 5.0, 12))],
+                                           ("max_sinr", 20.0, 50), ("max_sinr", 5.0, 12))]
+    + [dict(algo=a, mod="qam", M=16, K=3, nr=2, nt=2, Ns=1, NSymbs=120, snr_db=snr, max_iterations=it,
+            relative_factor=1e-6, initialize_with=init)
+       for a, snr, it, init in (("max_sinr", 15.0, 20, "alt_min"), ("min_leakage", 15.0, 20, "alt_min"),
+                                ("max_sinr", 10.0, 15, "closed_form"), ("min_leakage", 20.0, 10, "closed_form"),
+                                ("alt_min", 20.0, 10, "closed_form"))],
     "f1_mimo_ofdm_tdl": [dict(mod="qam", M=16, nt=2, nr=2, fft_size=64, cp_size=16, num_used=None, n_ofdm_sym=2,
                               snr_db=20.0, Fd=50.0, Ts=1e-6, L=8, tap_powers_dB=(0.0, -4.0, -9.0),
                               tap_delays_samples=(0, 2, 5)),

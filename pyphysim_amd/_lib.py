@@ -81,9 +81,11 @@ MIMO_SCHEMES = {"blast": 0, "mrc": 1, "mrt": 2, "alamouti": 3, "svd": 4, "gmd": 
 class IaCfg(Structure):
     _fields_ = [("K", c_int32), ("nr", c_int32), ("nt", c_int32), ("ns", c_int32), ("n_symbols", c_int32),
                 ("demod_method", c_int32), ("noise_var", c_double), ("solver", c_int32),
-                ("max_iterations", c_int32), ("relative_factor", c_double)]
+                ("max_iterations", c_int32), ("relative_factor", c_double), ("initialize_with", c_int32),
+                ("reserved", c_int32)]
 
 
+IA_INITS = {"random": 0, "fix": 0, "closed_form": 1, "alt_min": 2}
 IA_SOLVERS = {"closed_form": 0, "alt_min": 1, "min_leakage": 2, "max_sinr": 3}
 
 
@@ -158,7 +160,8 @@ _PROTOS = {
     "mcle_run_mimo_ofdm_tdl": (c_int, [_P, c_int, POINTER(MimoOfdmTdlCfg), c_uint64, c_uint64, c_uint64, _P, _P,
                                        _P]),
     "mcle_run_ia": (c_int, [_P, c_int, POINTER(IaCfg), c_uint64, c_uint64, c_uint64, _P, _P, _P, _P, _P]),
-    "mcle_ia_iterative": (c_int, [_P, c_int, _P, _P, c_double, c_int, c_double, _P, _P, _P, _P, _P, _P, c_size_t]),
+    "mcle_ia_iterative": (c_int, [_P, c_int, c_int, _P, _P, c_double, c_int, c_double, _P, _P, _P, _P, _P, _P,
+                                  c_size_t]),
     "mcle_ia_closed_form": (c_int, [_P, _P, c_double, _P, _P, _P, _P, _P, c_size_t]),
     "mcle_legacy_draws": (c_int, [_P, POINTER(LegacySeg), c_int, c_uint32, c_uint64, c_uint64, _P, c_size_t, _P,
                                   c_size_t, _P]),

@@ -186,7 +186,7 @@ __device__ __forceinline__ bool ia_diff_significant(const V2 (&Fo)[3], const V2 
 
 // F: in = initial precoders (unit norm), out = solution; Wh = rows W^H.  Returns the iterations run.
 __device__ __forceinline__ int ia_iterate(const M2 (&H)[3][3], int algo, double nv, int max_iter, double rel,
-                                          V2 (&F)[3], V2 (&Wh)[3], bool& ok) {
+                                          V2 (&F)[3], V2 (&Wh)[3], bool& ok, const V2* W_init = nullptr) {
     V2 W[3];    // alt-min: C_k (interference subspace); otherwise the receive vectors W_k
     auto interference = [&](int k, const V2 (&P)[3], bool reversed) {
         M2 Q = mzero();
@@ -254,7 +254,12 @@ __device__ __forceinline__ int ia_iterate(const M2 (&H)[3][3], int algo, double 
             for (int k = 0; k < 3; ++k) F[k] = Fn[k];
         }
     };
-    update_W();          // initialisation: _before_initialize_W_func / _updateW on the random precoder
+    if (W_init != nullptr && algo != IA_ALT_MIN) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) W[k] = W_init[k];    // receive filters handed over by the initialisation
+    } else {
+        update_W();      // _before_initialize_W_func / _updateW on the initial precoder
+    }
     int runned = 0;
     for (int it = 0; it < max_iter; ++it) {
         V2 Fo[3];
@@ -305,13 +310,40 @@ __device__ __forceinline__ void ia_finish(const M2 (&H)[3][3], const V2 (&F)[3],
     }
 }
 
+// init (IterativeIASolverBaseClass._solve_init, algorithms.py:633-663): IA_INIT_GIVEN = start from F_init
+// ('random' / 'fix'); IA_INIT_CLOSED_FORM = F and W of the closed-form solution (:572-597); IA_INIT_ALT_MIN = run
+// the alternating-minimisation solver from F_init with the same max_iterations and start from its F and its
+// normalised receive filters (:599-632).
+enum { IA_INIT_GIVEN = 0, IA_INIT_CLOSED_FORM = 1, IA_INIT_ALT_MIN = 2 };
+
 __device__ __noinline__ IaSolution ia_iterative(const M2 (&H)[3][3], int algo, double nv, int max_iter, double rel,
-                                                   const V2 (&F_init)[3], int& runned) {
-    V2 F[3], Wh[3];
+                                                int init, const V2 (&F_init)[3], int& runned) {
+    V2 F[3], Wh[3], W0[3];
+    const V2* W_init = nullptr;
+    bool ok = true;
 #pragma unroll
     for (int k = 0; k < 3; ++k) F[k] = F_init[k];
-    bool ok = true;
-    runned = ia_iterate(H, algo, nv, max_iter, rel, F, Wh, ok);
+    if (init == IA_INIT_CLOSED_FORM) {
+        const IaSolution c = ia_closed_form(H, nv);
+        ok = c.ok;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) F[k] = c.F[k];
+        // W_k = leig of the interference at receiver k (rank one after alignment), LAPACK normalisation
+        const V2 a[3] = {mvec(H[0][1], F[1]), mvec(H[1][0], F[0]), mvec(H[2][0], F[0])};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            V2 hi;
+            heig2(outer2(a[k]), W0[k], hi);
+        }
+        W_init = W0;
+    } else if (init == IA_INIT_ALT_MIN) {
+        V2 Wha[3];
+        ia_iterate(H, IA_ALT_MIN, nv, max_iter, rel, F, Wha, ok);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) W0[k] = vnormalize(V2{cconj(Wha[k].x), cconj(Wha[k].y)});
+        W_init = W0;
+    }
+    runned = ia_iterate(H, algo, nv, max_iter, rel, F, Wh, ok, W_init);
     IaSolution s;
     ia_finish(H, F, Wh, nv, s);
     s.ok = ok && (s.capacity == s.capacity);
@@ -353,7 +385,7 @@ __global__ __launch_bounds__(64) void k_ia_closed_form(const cd* __restrict__ bi
 
 // operator-level iterative solver on injected channels and initial precoders: F_init [batch][3][2]
 __global__ __launch_bounds__(64) void k_ia_iterative(const cd* __restrict__ bigH, const cd* __restrict__ F_init, int algo,
-                                                     double nv, int max_iter, double rel, cd* __restrict__ F,
+                                                     int init, double nv, int max_iter, double rel, cd* __restrict__ F,
                                                      cd* __restrict__ U, double* __restrict__ sinr,
                                                      double* __restrict__ cap, uint32_t* __restrict__ iters,
                                                      uint32_t* __restrict__ skipped, size_t batch) {
@@ -363,7 +395,7 @@ __global__ __launch_bounds__(64) void k_ia_iterative(const cd* __restrict__ bigH
         V2 F0[3];
         for (int k = 0; k < 3; ++k) F0[k] = V2{F_init[(b * 3 + k) * 2], F_init[(b * 3 + k) * 2 + 1]};
         int runned = 0;
-        const IaSolution s = ia_iterative(H, algo, nv, max_iter, rel, F0, runned);
+        const IaSolution s = ia_iterative(H, algo, nv, max_iter, rel, init, F0, runned);
         for (int k = 0; k < 3; ++k) {
             F[(b * 3 + k) * 2] = s.F[k].x;
             F[(b * 3 + k) * 2 + 1] = s.F[k].y;
@@ -382,7 +414,7 @@ __global__ __launch_bounds__(64) void k_ia_iterative(const cd* __restrict__ bigH
 // the whole wave runs each realization's symbols (lanes stride over the symbol columns).  With one solve per
 // lane instead of the same solve on all 64 lanes the iterative solvers cost 1/64 of a wave per realization.
 template <typename T>
-__global__ __launch_bounds__(64) void k_run_ia(ModemParams<T> mp, int n_symbols, double noise_var, int solver,
+__global__ __launch_bounds__(64) void k_run_ia(ModemParams<T> mp, int n_symbols, double noise_var, int solver, int init,
                                                int max_iter, double rel, uint64_t seed, uint64_t first,
                                                uint64_t count, mcle_counters* counters,
                                                uint32_t* __restrict__ sym_out, uint32_t* __restrict__ bit_out,
@@ -427,7 +459,7 @@ __global__ __launch_bounds__(64) void k_run_ia(ModemParams<T> mp, int n_symbols,
                         cn_pair<double>(rng, STREAM_PHASE, (uint32_t)k, 1.0, a, b);
                         F0[k] = vnormalize(V2{a, b});
                     }
-                    s = ia_iterative(H, solver, noise_var, max_iter, rel, F0, runned);
+                    s = ia_iterative(H, solver, noise_var, max_iter, rel, init, F0, runned);
                 }
 #pragma unroll
                 for (int i = 0; i < 36; ++i) s_Hs[lane][i] = mk<T>((T)bigH[i].x, (T)bigH[i].y);
@@ -535,19 +567,24 @@ int mcle_ia_closed_form(mcle_ctx* ctx, const void* d_bigH, double noise_var, voi
     return MCLE_OK;
 }
 
-int mcle_ia_iterative(mcle_ctx* ctx, int solver, const void* d_bigH, const void* d_F_init, double noise_var,
-                      int max_iterations, double relative_factor, void* d_F, void* d_U, double* d_sinr,
-                      double* d_capacity, uint32_t* d_iterations, uint32_t* d_skipped, size_t batch) {
+int mcle_ia_iterative(mcle_ctx* ctx, int solver, int initialize_with, const void* d_bigH, const void* d_F_init,
+                      double noise_var, int max_iterations, double relative_factor, void* d_F, void* d_U,
+                      double* d_sinr, double* d_capacity, uint32_t* d_iterations, uint32_t* d_skipped, size_t batch) {
     MCLE_REQUIRE(ctx != nullptr && d_bigH != nullptr && d_F_init != nullptr && d_F != nullptr && d_U != nullptr,
                  "null argument");
     MCLE_REQUIRE(solver >= MCLE_IA_ALT_MIN && solver <= MCLE_IA_MAX_SINR, "solver must be one of the iterative MCLE_IA_*");
     MCLE_REQUIRE(noise_var >= 0.0, "noise variance must be non-negative");
     MCLE_REQUIRE(max_iterations >= 1, "max_iterations must be positive");
+    MCLE_REQUIRE(initialize_with >= MCLE_IA_INIT_GIVEN && initialize_with <= MCLE_IA_INIT_ALT_MIN,
+                 "unknown initialisation %d", initialize_with);
+    // AlternatingMinIASolver.initialize_with setter, algorithms.py:928-935
+    MCLE_REQUIRE(!(solver == MCLE_IA_ALT_MIN && initialize_with == MCLE_IA_INIT_ALT_MIN),
+                 "Can't use 'alt_min' initialization with 'AlternatingMinIASolver' class 'alt_min'");
     if (batch == 0) return MCLE_OK;
     int rc = ctx->bind();
     if (rc) return rc;
     hipLaunchKernelGGL(k_ia_iterative, dim3(grid_for(ctx, batch, 64, 16)), dim3(64), 0, ctx->stream,
-                       (const double2*)d_bigH, (const double2*)d_F_init, solver, noise_var, max_iterations,
+                       (const double2*)d_bigH, (const double2*)d_F_init, solver, initialize_with, noise_var, max_iterations,
                        relative_factor, (double2*)d_F, (double2*)d_U, d_sinr, d_capacity, d_iterations, d_skipped,
                        batch);
     MCLE_LAUNCH_CHECK();
@@ -568,6 +605,10 @@ int mcle_run_ia(mcle_ctx* ctx, int dtype, const mcle_ia_cfg* cfg, uint64_t seed,
     MCLE_REQUIRE(cfg->noise_var >= 0.0, "noise variance must be non-negative");
     MCLE_REQUIRE(cfg->solver >= MCLE_IA_CLOSED_FORM && cfg->solver <= MCLE_IA_MAX_SINR, "unknown IA solver %d", cfg->solver);
     MCLE_REQUIRE(cfg->solver == MCLE_IA_CLOSED_FORM || cfg->max_iterations >= 1, "max_iterations must be positive");
+    MCLE_REQUIRE(cfg->initialize_with >= MCLE_IA_INIT_GIVEN && cfg->initialize_with <= MCLE_IA_INIT_ALT_MIN,
+                 "unknown initialisation %d", cfg->initialize_with);
+    MCLE_REQUIRE(!(cfg->solver == MCLE_IA_ALT_MIN && cfg->initialize_with == MCLE_IA_INIT_ALT_MIN),
+                 "Can't use 'alt_min' initialization with 'AlternatingMinIASolver' class 'alt_min'");
     MCLE_REQUIRE(count <= 0x7fffffffull, "at most 2^31-1 realizations per call");
     if (count == 0) return MCLE_OK;
     if ((rc = ctx->bind())) return rc;
@@ -579,13 +620,14 @@ int mcle_run_ia(mcle_ctx* ctx, int dtype, const mcle_ia_cfg* cfg, uint64_t seed,
                                          : 0;
     if (dtype == MCLE_F32)
         hipLaunchKernelGGL(k_run_ia<float>, dim3(grid), dim3(64), lds, ctx->stream, ia_modem<float>(ctx, cfg->demod_method),
-                           cfg->n_symbols, cfg->noise_var, cfg->solver, cfg->max_iterations, cfg->relative_factor, seed,
-                           first, count, d_counters, d_sym_err, d_bit_err, d_sum_capacity, d_iterations);
+                           cfg->n_symbols, cfg->noise_var, cfg->solver, cfg->initialize_with, cfg->max_iterations,
+                           cfg->relative_factor, seed, first, count, d_counters, d_sym_err, d_bit_err, d_sum_capacity,
+                           d_iterations);
     else
         hipLaunchKernelGGL(k_run_ia<double>, dim3(grid), dim3(64), 0, ctx->stream,
                            ia_modem<double>(ctx, cfg->demod_method), cfg->n_symbols, cfg->noise_var, cfg->solver,
-                           cfg->max_iterations, cfg->relative_factor, seed, first, count, d_counters, d_sym_err,
-                           d_bit_err, d_sum_capacity, d_iterations);
+                           cfg->initialize_with, cfg->max_iterations, cfg->relative_factor, seed, first, count,
+                           d_counters, d_sym_err, d_bit_err, d_sum_capacity, d_iterations);
     MCLE_LAUNCH_CHECK();
     return MCLE_OK;
 }

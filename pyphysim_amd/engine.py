@@ -652,7 +652,8 @@ class Engine:
 
 
     def run_ia(self, n_symbols, noise_var, seed, first, count, method=DEMOD_MINDIST, dtype=None,
-               per_realization=False, counters=None, solver="closed_form", max_iterations=50, relative_factor=1e-6):
+               per_realization=False, counters=None, solver="closed_form", max_iterations=50, relative_factor=1e-6,
+               initialize_with="random"):
         """Config 5 (K = 3, 2x2, one stream per user) with the closed-form solver or one of the iterative
         ones ('alt_min', 'min_leakage', 'max_sinr'; random initial precoders).  Returns the counter dict with
         the extra keys 'sum_capacity' (+ '_sq') and 'ia_runned_iterations' (+ '_sq') = per-realization values
@@ -660,7 +661,7 @@ class Engine:
         iterations)."""
         dt = self._dt(dtype)
         cfg = IaCfg(3, 2, 2, 1, int(n_symbols), int(method), float(noise_var), _lib.IA_SOLVERS[solver],
-                    int(max_iterations), float(relative_factor))
+                    int(max_iterations), float(relative_factor), _lib.IA_INITS[initialize_with], 0)
         cnt = counters if counters is not None else self.new_counters()
         se, be = self.empty(count, np.uint32), self.empty(count, np.uint32)
         cap = self.empty(count, np.float64)
@@ -682,7 +683,8 @@ class Engine:
             return res, sev, be.get(), caps, iters
         return res
 
-    def ia_iterative(self, solver, big_H, F_init, noise_var, max_iterations=50, relative_factor=1e-6):
+    def ia_iterative(self, solver, big_H, F_init, noise_var, max_iterations=50, relative_factor=1e-6,
+                     initialize_with="fix"):
         """IterativeIASolverBaseClass.solve (algorithms.py:802-883) with initialize_with='fix': big_H
         [batch, 6, 6], F_init [batch, 3, 2] (unit-norm initial precoders) -> dict(F, U = full_W_H, sinr,
         capacity, iterations, skipped)."""
@@ -696,7 +698,8 @@ class Engine:
         sinr, cap = self.empty((b, 3), np.float64), self.empty(b, np.float64)
         its, sk = self.empty(b, np.uint32), self.empty(b, np.uint32)
         self._raise_value(self.lib.mcle_ia_iterative(
-            self.ctx, _lib.IA_SOLVERS[solver], d_H.ptr, d_F0.ptr, float(noise_var), int(max_iterations),
+            self.ctx, _lib.IA_SOLVERS[solver], _lib.IA_INITS[initialize_with], d_H.ptr, d_F0.ptr, float(noise_var),
+            int(max_iterations),
             float(relative_factor), F.ptr, U.ptr, sinr.ptr, cap.ptr, its.ptr, sk.ptr, b))
         return dict(F=F.get(), U=U.get(), sinr=sinr.get(), capacity=cap.get(), iterations=its.get(),
                     skipped=sk.get())

@@ -147,7 +147,7 @@ def run_mimo_ofdm(eng, seed_base, first, count, mod="qam", M=64, nt=4, nr=4, fft
 
 
 def run_ia(eng, seed_base, first, count, mod="qam", M=16, K=3, nr=2, nt=2, Ns=1, NSymbs=200, snr_db=20.0,
-           algo="closed_form", max_iterations=50, relative_factor=1e-6):
+           algo="closed_form", max_iterations=50, relative_factor=1e-6, initialize_with="random"):
     """Config 5 / SURVEY 8(f).3 template (apps/ia/simulate_ia.py:94-245).  The reference draws from separate
     RandomStates -- the channel's (multiuser.py:670-709: randn_c(6, 6)), the noise's (randn_c(6, NSymbs)), the
     iterative solvers' own (iabase.py:95,538-540: randn_c(2, 1) per user) and the global one (randint(0, M,
@@ -169,7 +169,8 @@ def run_ia(eng, seed_base, first, count, mod="qam", M=16, K=3, nr=2, nt=2, Ns=1,
         hf = fi.get().reshape(count, 3, 2, 2)                    # [r, user, re/im block, antenna]
         F0 = INV_SQRT2 * (hf[:, :, 0, :] + 1j * hf[:, :, 1, :])
         F0 = F0 / np.linalg.norm(F0, axis=2, keepdims=True)
-        sol = eng.ia_iterative(algo, big_H, F0, noise_var, max_iterations, relative_factor)
+        sol = eng.ia_iterative(algo, big_H, F0, noise_var, max_iterations, relative_factor,
+                               "fix" if initialize_with == "random" else initialize_with)
     # precoding and receive filtering as block matrices through the multi-user channel kernel
     Fbig = np.zeros((count, 6, 3), dtype=complex)
     Ubig = np.zeros((count, 3, 6), dtype=complex)

@@ -272,7 +272,7 @@ class IaSimulator(_LinkSimulator):
     Result of the reference app next to the error-rate Results."""
 
     def __init__(self, SNR, modulator="qam", M=16, NSymbs=200, solver="closed_form", max_iterations=60,
-                 relative_factor=1e-6, **kw):
+                 relative_factor=1e-6, initialize_with="random", **kw):
         """solver: 'closed_form' (ClosedFormIASolver, use_best_init) or 'alt_min' / 'min_leakage' / 'max_sinr'
         (AlternatingMinIASolver / MinLeakageIASolver / MaxSinrIASolver with initialize_with='random';
         max_iterations defaults to the app's 60, apps/ia/simulate_ia.py:330)."""
@@ -282,7 +282,10 @@ class IaSimulator(_LinkSimulator):
         for k, v in (("NSymbs", int(NSymbs)), ("K", 3), ("Nr", 2), ("Nt", 2), ("Ns", 1), ("solver", solver)):
             self.params.add(k, v)
         if solver != "closed_form":
+            if initialize_with not in ("random", "closed_form", "alt_min"):
+                raise ValueError("initialize_with must be 'random', 'closed_form' or 'alt_min'")
             self.params.add("max_iterations", int(max_iterations))
+            self.params.add("initialize_with", initialize_with)
         self.relative_factor = float(relative_factor)
         self.COUNTER_KEYS = tuple(self.COUNTER_KEYS)
 
@@ -292,7 +295,8 @@ class IaSimulator(_LinkSimulator):
         res = eng.run_ia(p["NSymbs"], self._noise_var(p), self._seed_for(p), first_rep, count,
                          method=self.demod_method, dtype=self.dtype, solver=p["solver"],
                          max_iterations=p["max_iterations"] if p["solver"] != "closed_form" else 1,
-                         relative_factor=self.relative_factor)
+                         relative_factor=self.relative_factor,
+                         initialize_with=p["initialize_with"] if p["solver"] != "closed_form" else "random")
         self._cap = getattr(self, "_cap", 0.0) + res["sum_capacity"]
         self._cap_sq = getattr(self, "_cap_sq", 0.0) + res["sum_capacity_sq"]
         self._its = getattr(self, "_its", 0) + res["ia_runned_iterations"]

@@ -43,7 +43,7 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(_lib.AwgnCfg) == 16
     assert ctypes.sizeof(_lib.FlatCfg) == 40
     assert ctypes.sizeof(_lib.MimoOfdmCfg) == 40
-    assert ctypes.sizeof(_lib.IaCfg) == 48
+    assert ctypes.sizeof(_lib.IaCfg) == 56
     assert ctypes.sizeof(_lib.MimoFlatCfg) == 32
     assert ctypes.sizeof(_lib.OfdmTdlCfg) == 32 + 24 + 24 * 8 + 24 * 4
     assert ctypes.sizeof(_lib.MimoOfdmTdlCfg) == 40 + 24 + 24 * 8 + 24 * 4

@@ -286,7 +286,9 @@ def test_ia_iterative_injected(engine):
         H = np.stack([g["big_H"] for g in reals])
         F0 = np.stack([g["F_init"] for g in reals])
         nv = float(reals[0]["noise_var"])
-        sol = engine.ia_iterative(kw["algo"], H, F0, nv, kw["max_iterations"], kw["relative_factor"])
+        init = kw.get("initialize_with", "random")
+        sol = engine.ia_iterative(kw["algo"], H, F0, nv, kw["max_iterations"], kw["relative_factor"],
+                                  "fix" if init == "random" else init)
         assert not sol["skipped"].any()
         for b, g in enumerate(reals):
             assert int(sol["iterations"][b]) == int(g["runned_iterations"]), (kw["algo"], b)
@@ -301,15 +303,20 @@ def test_ia_iterative_injected(engine):
             assert np.array_equal(engine.demodulate(est), g["decisions"])
     assert seen == {"alt_min", "min_leakage", "max_sinr"}
     with pytest.raises(ValueError):
+        engine.ia_iterative("alt_min", H, F0, nv, initialize_with="alt_min")   # algorithms.py:928-935
+    with pytest.raises(ValueError):
         engine.ia_iterative("alt_min", H, F0[:1], nv)
     with pytest.raises(ValueError):
         engine.ia_iterative("alt_min", H, F0, nv, max_iterations=0)
 
 
-@pytest.mark.parametrize("algo", ["alt_min", "min_leakage", "max_sinr"])
+@pytest.mark.parametrize("algo,init", [("alt_min", "random"), ("min_leakage", "random"), ("max_sinr", "random"),
+                                       ("max_sinr", "alt_min"), ("min_leakage", "closed_form"),
+                                       ("max_sinr", "closed_form"), ("alt_min", "closed_form")])
 @pytest.mark.parametrize("dt,exact", [("f64", True), ("f32", False)])
-def test_ia_iterative_pipeline(engine, algo, dt, exact):
-    kw = dict(algo=algo, mod="qam", M=16, K=3, nr=2, nt=2, Ns=1, NSymbs=100, snr_db=18.0, max_iterations=40)
+def test_ia_iterative_pipeline(engine, algo, init, dt, exact):
+    kw = dict(algo=algo, mod="qam", M=16, K=3, nr=2, nt=2, Ns=1, NSymbs=100, snr_db=18.0, max_iterations=40,
+              initialize_with=init)
     engine.set_constellation(chains.constellation("qam", 16), _lib.CONST_QAM)
     first, count = 3, 24
     want = [chains.chain_ia_iterative(chains.PhiloxRng(SEED, r), **kw) for r in range(first, first + count)]
@@ -318,14 +325,14 @@ def test_ia_iterative_pipeline(engine, algo, dt, exact):
     want_cap = np.array([w["sum_capacity"] for w in want])
     want_it = np.array([w["runned_iterations"] for w in want])
     res, se, be, cap, its = engine.run_ia(100, 1.0 / omodem.dB2Linear(18.0), SEED, first, count, dtype=dt,
-                                          per_realization=True, solver=algo, max_iterations=40)
+                                          per_realization=True, solver=algo, max_iterations=40, initialize_with=init)
     check(res, se, be, want_se, want_be, 300, 1200, exact)
     assert np.array_equal(its, want_it) and res["ia_runned_iterations"] == int(want_it.sum())
     assert np.max(np.abs(cap - want_cap)) <= 1e-6
     # shard invariance and sanity at scale
-    a = engine.run_ia(100, 0.01, SEED, 0, 20000, dtype="f32", solver=algo, max_iterations=20)
-    b = engine.run_ia(100, 0.01, SEED, 0, 7777, dtype="f32", solver=algo, max_iterations=20)
-    c = engine.run_ia(100, 0.01, SEED, 7777, 12223, dtype="f32", solver=algo, max_iterations=20)
+    a = engine.run_ia(100, 0.01, SEED, 0, 20000, dtype="f32", solver=algo, max_iterations=20, initialize_with=init)
+    b = engine.run_ia(100, 0.01, SEED, 0, 7777, dtype="f32", solver=algo, max_iterations=20, initialize_with=init)
+    c = engine.run_ia(100, 0.01, SEED, 7777, 12223, dtype="f32", solver=algo, max_iterations=20, initialize_with=init)
     for k in ("sym_errors", "sym_errors_sq", "bit_errors", "n_realizations", "ia_runned_iterations"):
         assert a[k] == b[k] + c[k]
     assert a["sym_errors"] / (a["n_realizations"] * 300) < 0.15
