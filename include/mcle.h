@@ -283,7 +283,8 @@ typedef struct mcle_mimo_flat_cfg {     /* apps/mimo/simulate_mimo.py:68-142: fl
 enum { MCLE_IA_CLOSED_FORM = 0,  /* ClosedFormIASolver      ia/algorithms.py:42-265    */
        MCLE_IA_ALT_MIN = 1,      /* AlternatingMinIASolver  ia/algorithms.py:885-1129  */
        MCLE_IA_MIN_LEAKAGE = 2,  /* MinLeakageIASolver      ia/algorithms.py:1132-1240 */
-       MCLE_IA_MAX_SINR = 3 };   /* MaxSinrIASolver         ia/algorithms.py:1243-1507 */
+       MCLE_IA_MAX_SINR = 3,     /* MaxSinrIASolver         ia/algorithms.py:1243-1507 */
+       MCLE_IA_MMSE = 4 };       /* MMSEIASolver            ia/algorithms.py:1510-1850 */
 
 enum { MCLE_IA_INIT_GIVEN = 0,        /* 'random' (pipelines: drawn on-chip) or 'fix' (operator: injected) */
        MCLE_IA_INIT_CLOSED_FORM = 1,  /* 'closed_form': F and W of ClosedFormIASolver                      */
@@ -340,7 +341,7 @@ int mcle_run_ia(mcle_ctx* ctx, int dtype, const mcle_ia_cfg* cfg, uint64_t seed,
  *      d_sinr [batch][3] and sum capacity d_capacity [batch] (both may be NULL) ------------------ */
 int mcle_ia_closed_form(mcle_ctx* ctx, const void* d_bigH, double noise_var, void* d_F, void* d_U,
                         double* d_sinr, double* d_capacity, uint32_t* d_skipped, size_t batch);
-/* Iterative solvers (solver = MCLE_IA_ALT_MIN / MIN_LEAKAGE / MAX_SINR) from injected initial precoders
+/* Iterative solvers (solver = MCLE_IA_ALT_MIN / MIN_LEAKAGE / MAX_SINR / MMSE) from injected initial precoders
  * d_F_init [batch][3][2] (unit norm): the starting precoders for MCLE_IA_INIT_GIVEN ('fix' / a captured
  * 'random' start), the alternating-minimisation solver's start for MCLE_IA_INIT_ALT_MIN, ignored for
  * MCLE_IA_INIT_CLOSED_FORM.  IterativeIASolverBaseClass.solve (algorithms.py:802-883).  d_iterations [batch]

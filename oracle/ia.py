@@ -272,3 +272,66 @@ def iterative_solve(algo, H, F_init, noise_var, max_iterations=50, relative_fact
     sinr = calc_SINR(H, F, U, noise_var)
     cap = float(np.sum([np.sum(np.log2(1 + s)) for s in sinr]))
     return F, U, cap, sinr, runned
+
+
+# ---- MMSEIASolver (pyphysim/ia/algorithms.py:1510-1850) -----------------------------------------------------
+def mmse_solve(H, F_init, noise_var, max_iterations=50, relative_factor=1e-6, W_init=None):
+    """-> (full_F, W_H rows, runned_iterations).  Precoders V_i = (sum_k H_ki^H U_k U_k^H H_ki + mu_i I)^-1 H_ii^H U_i
+    with the Lagrange multiplier mu_i >= 0 found by scipy.optimize.newton (secant) as in the reference
+    (:1660-1825); receive filters U_k = (sum_i H_ki V_i V_i^H H_ki^H + sigma^2 I)^-1 H_kk V_k (:1560-1600).
+    The iteration test compares the NORMALISED precoders (_F), transmission uses full_F = V."""
+    from scipy import optimize
+    K = len(F_init)
+    P = np.ones(K)
+
+    def calc_U(full_F):
+        out = []
+        for k in range(K):
+            acc = 0
+            for i in range(K):
+                a = H[k][i] @ full_F[i]
+                acc = acc + a @ a.conj().T
+            out.append(np.linalg.solve(acc + noise_var * np.eye(H[k][k].shape[0]), H[k][k] @ full_F[k]))
+        return out
+
+    def v_for_mu(sum_term, mu, HhU):
+        return np.linalg.solve(sum_term + mu * np.eye(sum_term.shape[0]), HhU)
+
+    def calc_V(W, i):
+        HhU = H[i][i].conj().T @ W[i]
+        sum_term = np.array([0.0])
+        for k in range(K):
+            a = H[k][i].conj().T @ W[k]
+            sum_term = sum_term + a @ a.conj().T
+        S = np.linalg.svd(sum_term)[1]
+        if S.max() / S.min() > 5e4:
+            sum_term = sum_term + np.eye(sum_term.shape[0]) * (S.mean() / 100.0)
+
+        def func(mu, st, hu, p):
+            return np.linalg.norm(v_for_mu(st, mu, hu), 'fro') ** 2 - p
+        scale = np.linalg.norm(HhU)
+        HhU = HhU / scale
+        sum_term = sum_term / scale
+        if func(0.0, sum_term, HhU, P[i]) <= 0:
+            return v_for_mu(sum_term, 0.0, HhU)
+        mu = optimize.newton(func, 0.0, args=(sum_term, HhU, P[i]), maxiter=200)
+        if abs(mu) > 1e20:
+            mu = optimize.newton(func, 0.0, args=(sum_term * 10, HhU * 10, P[i]), maxiter=200) / 10.0
+        return v_for_mu(sum_term, mu, HhU)
+
+    full_F = [np.asarray(f, dtype=complex) for f in F_init]
+    W = W_init if W_init is not None else calc_U(full_F)
+    F = [f / np.linalg.norm(f, 'fro') for f in full_F]
+    old_F, runned = F, 0
+    for _ in range(max_iterations):
+        runned += 1
+        full_F = [calc_V(W, i) for i in range(K)]
+        F = [v / np.linalg.norm(v, 'fro') for v in full_F]
+        W = calc_U(full_F)
+        if not is_diff_significant(old_F, F, relative_factor):
+            break
+        old_F = F
+    return full_F, [w.conj().T for w in W], runned
+
+
+ITERATIVE["mmse"] = mmse_solve

@@ -324,7 +324,7 @@ def ref_chain_ia_iterative(seed, algo, mod, M, K, nr, nt, Ns, NSymbs, snr_db, ma
     muc.set_channel_seed(seed)
     muc.set_noise_seed(seed)
     cls = {"alt_min": ralg.AlternatingMinIASolver, "min_leakage": ralg.MinLeakageIASolver,
-           "max_sinr": ralg.MaxSinrIASolver}[algo]
+           "max_sinr": ralg.MaxSinrIASolver, "mmse": ralg.MMSEIASolver}[algo]
     solver = cls(muc)
     solver._rs = np.random.RandomState(seed)      # the reference leaves this one unseeded (iabase.py:95)
     solver.max_iterations = max_iterations
@@ -450,7 +450,9 @@ CHAINS = {
             relative_factor=1e-6, initialize_with=init)
        for a, snr, it, init in (("max_sinr", 15.0, 20, "alt_min"), ("min_leakage", 15.0, 20, "alt_min"),
                                 ("max_sinr", 10.0, 15, "closed_form"), ("min_leakage", 20.0, 10, "closed_form"),
-                                ("alt_min", 20.0, 10, "closed_form"))],
+                                ("alt_min", 20.0, 10, "closed_form"), ("mmse", 20.0, 30, "random"),
+                                ("mmse", 6.0, 12, "random"), ("mmse", 14.0, 15, "alt_min"),
+                                ("mmse", 25.0, 10, "closed_form"))],
     "f1_mimo_ofdm_tdl": [dict(mod="qam", M=16, nt=2, nr=2, fft_size=64, cp_size=16, num_used=None, n_ofdm_sym=2,
                               snr_db=20.0, Fd=50.0, Ts=1e-6, L=8, tap_powers_dB=(0.0, -4.0, -9.0),
                               tap_delays_samples=(0, 2, 5)),

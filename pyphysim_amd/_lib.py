@@ -86,7 +86,7 @@ class IaCfg(Structure):
 
 
 IA_INITS = {"random": 0, "fix": 0, "closed_form": 1, "alt_min": 2}
-IA_SOLVERS = {"closed_form": 0, "alt_min": 1, "min_leakage": 2, "max_sinr": 3}
+IA_SOLVERS = {"closed_form": 0, "alt_min": 1, "min_leakage": 2, "max_sinr": 3, "mmse": 4}
 
 
 class LegacySeg(Structure):

@@ -146,7 +146,7 @@ __device__ __noinline__ IaSolution ia_closed_form(const M2 (&H)[3][3], double nv
 // Eigenvectors follow the LAPACK convention above, so the precoder phases -- which rotate the post-filter
 // noise -- are the reference's.  The noise_var * I term the reference adds to Q (multiuser.py:1376-1380) only
 // shifts the eigenvalues and is left out.
-enum { IA_CLOSED_FORM = 0, IA_ALT_MIN = 1, IA_MIN_LEAKAGE = 2, IA_MAX_SINR = 3 };
+enum { IA_CLOSED_FORM = 0, IA_ALT_MIN = 1, IA_MIN_LEAKAGE = 2, IA_MAX_SINR = 3, IA_MMSE = 4 };
 
 __device__ __forceinline__ M2 outer2(const V2& a) {  // a a^H
     M2 r;
@@ -184,10 +184,55 @@ __device__ __forceinline__ bool ia_diff_significant(const V2 (&Fo)[3], const V2 
     return sig;
 }
 
-// F: in = initial precoders (unit norm), out = solution; Wh = rows W^H.  Returns the iterations run.
+// MMSEIASolver._calc_Vi (algorithms.py:1660-1825) for a 2x2 Hermitian A = sum_k H_ki^H U_k U_k^H H_ki and
+// b = H_ii^H U_i: V = (A + mu I)^-1 b with the smallest mu >= 0 giving |V|^2 <= P = 1.  The reference finds mu with
+// scipy's secant iteration (tolerance 1.5e-8); here Newton on the secular function
+// g(mu) = |c-|^2 / (l- + mu)^2 + |c+|^2 / (l+ + mu)^2 - 1 in the eigenbasis of A, convex and decreasing, so the
+// iterates rise monotonically to the root from mu = 0.
+__device__ __forceinline__ V2 ia_mmse_precoder(M2 A, const V2& b) {
+    const double half = 0.5 * (A.a.x - A.d.x);
+    const double r = sqrt(half * half + cabs2(A.b));
+    const double mid = 0.5 * (A.a.x + A.d.x);
+    double lm = mid - r, lp = mid + r;
+    if (lp > 5e4 * lm) {                      // diagonal loading of an ill-conditioned sum (:1688-1692)
+        const double load = 0.5 * (lm + lp) / 100.0;
+        A.a.x += load;
+        A.d.x += load;
+        lm += load;
+        lp += load;
+    }
+    V2 um, up;
+    heig2(A, um, up);
+    const double cm = cabs2(cadd(cmulc(b.x, um.x), cmulc(b.y, um.y)));   // |u-^H b|^2
+    const double cp = cabs2(cadd(cmulc(b.x, up.x), cmulc(b.y, up.y)));
+    double mu = 0.0;
+    if (cm / (lm * lm) + cp / (lp * lp) > 1.0) {
+        for (int it = 0; it < 100; ++it) {
+            const double dm = lm + mu, dp = lp + mu;
+            const double g = cm / (dm * dm) + cp / (dp * dp) - 1.0;
+            const double gp = -2.0 * (cm / (dm * dm * dm) + cp / (dp * dp * dp));
+            const double step = -g / gp;
+            mu += step;
+            if (fabs(step) <= 1e-16 * (mu + lp)) break;
+        }
+    }
+    // V = adj(A + mu I) b / det(A + mu I)
+    const cd a = mk<double>(A.a.x + mu, 0.0), d = mk<double>(A.d.x + mu, 0.0);
+    const double det = a.x * d.x - cabs2(A.b);
+    V2 v;
+    v.x = cscale(csub(cmul(d, b.x), cmul(A.b, b.y)), 1.0 / det);
+    v.y = cscale(csub(cmul(a, b.y), cmul(A.c, b.x)), 1.0 / det);
+    return v;
+}
+
+// F: in = initial precoders (unit norm), out = solution (unit norm except for the MMSE solver, whose full_F
+// carries the power constraint); Wh = rows W^H.  Returns the iterations run.
 __device__ __forceinline__ int ia_iterate(const M2 (&H)[3][3], int algo, double nv, int max_iter, double rel,
                                           V2 (&F)[3], V2 (&Wh)[3], bool& ok, const V2* W_init = nullptr) {
     V2 W[3];    // alt-min: C_k (interference subspace); otherwise the receive vectors W_k
+    V2 Fn[3];   // normalised precoders (what _is_diff_significant compares); F holds full_F
+#pragma unroll
+    for (int k = 0; k < 3; ++k) Fn[k] = F[k];
     auto interference = [&](int k, const V2 (&P)[3], bool reversed) {
         M2 Q = mzero();
 #pragma unroll
@@ -201,7 +246,12 @@ __device__ __forceinline__ int ia_iterate(const M2 (&H)[3][3], int algo, double 
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             M2 Q = interference(k, F, false);
-            if (algo == IA_MAX_SINR) {
+            if (algo == IA_MMSE) {            // all K terms + sigma^2 I, not normalised (:1560-1600)
+                Q = madd2(Q, outer2(mvec(H[k][k], F[k])));
+                Q.a.x += nv;
+                Q.d.x += nv;
+                W[k] = mvec(minv(Q, ok), mvec(H[k][k], F[k]));
+            } else if (algo == IA_MAX_SINR) {
                 Q.a.x += nv;
                 Q.d.x += nv;
                 W[k] = vnormalize(mvec(minv(Q, ok), mvec(H[k][k], F[k])));
@@ -236,23 +286,31 @@ __device__ __forceinline__ int ia_iterate(const M2 (&H)[3][3], int algo, double 
                 F[l] = lo;
             }
         } else {
-            V2 Fn[3];
+            V2 Fx[3];
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 M2 Q = interference(k, W, true);
-                if (algo == IA_MAX_SINR) {
+                if (algo == IA_MMSE) {
+                    const V2 b = mvec(mherm(H[k][k]), W[k]);
+                    Q = madd2(Q, outer2(b));
+                    Q.a.y = Q.d.y = 0.0;
+                    Q.c = cconj(Q.b);
+                    Fx[k] = ia_mmse_precoder(Q, b);
+                } else if (algo == IA_MAX_SINR) {
                     Q.a.x += nv;
                     Q.d.x += nv;
-                    Fn[k] = vnormalize(mvec(minv(Q, ok), mvec(mherm(H[k][k]), W[k])));
+                    Fx[k] = vnormalize(mvec(minv(Q, ok), mvec(mherm(H[k][k]), W[k])));
                 } else {
                     V2 lo, hi;
                     heig2(Q, lo, hi);
-                    Fn[k] = lo;
+                    Fx[k] = lo;
                 }
             }
 #pragma unroll
-            for (int k = 0; k < 3; ++k) F[k] = Fn[k];
+            for (int k = 0; k < 3; ++k) F[k] = Fx[k];
         }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) Fn[k] = algo == IA_MMSE ? vnormalize(F[k]) : F[k];
     };
     if (W_init != nullptr && algo != IA_ALT_MIN) {
 #pragma unroll
@@ -264,11 +322,11 @@ __device__ __forceinline__ int ia_iterate(const M2 (&H)[3][3], int algo, double 
     for (int it = 0; it < max_iter; ++it) {
         V2 Fo[3];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) Fo[k] = F[k];
+        for (int k = 0; k < 3; ++k) Fo[k] = Fn[k];
         ++runned;
         update_F();
         update_W();
-        if (!ia_diff_significant(Fo, F, rel)) break;
+        if (!ia_diff_significant(Fo, Fn, rel)) break;
     }
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -572,7 +630,7 @@ int mcle_ia_iterative(mcle_ctx* ctx, int solver, int initialize_with, const void
                       double* d_sinr, double* d_capacity, uint32_t* d_iterations, uint32_t* d_skipped, size_t batch) {
     MCLE_REQUIRE(ctx != nullptr && d_bigH != nullptr && d_F_init != nullptr && d_F != nullptr && d_U != nullptr,
                  "null argument");
-    MCLE_REQUIRE(solver >= MCLE_IA_ALT_MIN && solver <= MCLE_IA_MAX_SINR, "solver must be one of the iterative MCLE_IA_*");
+    MCLE_REQUIRE(solver >= MCLE_IA_ALT_MIN && solver <= MCLE_IA_MMSE, "solver must be one of the iterative MCLE_IA_*");
     MCLE_REQUIRE(noise_var >= 0.0, "noise variance must be non-negative");
     MCLE_REQUIRE(max_iterations >= 1, "max_iterations must be positive");
     MCLE_REQUIRE(initialize_with >= MCLE_IA_INIT_GIVEN && initialize_with <= MCLE_IA_INIT_ALT_MIN,
@@ -603,7 +661,7 @@ int mcle_run_ia(mcle_ctx* ctx, int dtype, const mcle_ia_cfg* cfg, uint64_t seed,
     MCLE_REQUIRE(cfg->nr == 2 && cfg->nt == 2 && cfg->ns == 1, "fused IA pipeline supports Nr = Nt = 2, Ns = 1");
     MCLE_REQUIRE(cfg->n_symbols >= 1, "n_symbols must be positive");
     MCLE_REQUIRE(cfg->noise_var >= 0.0, "noise variance must be non-negative");
-    MCLE_REQUIRE(cfg->solver >= MCLE_IA_CLOSED_FORM && cfg->solver <= MCLE_IA_MAX_SINR, "unknown IA solver %d", cfg->solver);
+    MCLE_REQUIRE(cfg->solver >= MCLE_IA_CLOSED_FORM && cfg->solver <= MCLE_IA_MMSE, "unknown IA solver %d", cfg->solver);
     MCLE_REQUIRE(cfg->solver == MCLE_IA_CLOSED_FORM || cfg->max_iterations >= 1, "max_iterations must be positive");
     MCLE_REQUIRE(cfg->initialize_with >= MCLE_IA_INIT_GIVEN && cfg->initialize_with <= MCLE_IA_INIT_ALT_MIN,
                  "unknown initialisation %d", cfg->initialize_with);

@@ -301,7 +301,7 @@ def test_ia_iterative_injected(engine):
             est = np.vstack([sol["U"][b, k] @ Y[2 * k:2 * k + 2] for k in range(3)])
             assert relerr(est, g["est"]) <= 1e-6
             assert np.array_equal(engine.demodulate(est), g["decisions"])
-    assert seen == {"alt_min", "min_leakage", "max_sinr"}
+    assert seen == {"alt_min", "min_leakage", "max_sinr", "mmse"}
     with pytest.raises(ValueError):
         engine.ia_iterative("alt_min", H, F0, nv, initialize_with="alt_min")   # algorithms.py:928-935
     with pytest.raises(ValueError):
@@ -312,7 +312,8 @@ def test_ia_iterative_injected(engine):
 
 @pytest.mark.parametrize("algo,init", [("alt_min", "random"), ("min_leakage", "random"), ("max_sinr", "random"),
                                        ("max_sinr", "alt_min"), ("min_leakage", "closed_form"),
-                                       ("max_sinr", "closed_form"), ("alt_min", "closed_form")])
+                                       ("max_sinr", "closed_form"), ("alt_min", "closed_form"), ("mmse", "random"),
+                                       ("mmse", "alt_min"), ("mmse", "closed_form")])
 @pytest.mark.parametrize("dt,exact", [("f64", True), ("f32", False)])
 def test_ia_iterative_pipeline(engine, algo, init, dt, exact):
     kw = dict(algo=algo, mod="qam", M=16, K=3, nr=2, nt=2, Ns=1, NSymbs=100, snr_db=18.0, max_iterations=40,
