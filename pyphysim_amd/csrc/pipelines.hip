@@ -292,7 +292,7 @@ __global__ __launch_bounds__(kPipeBlock, sizeof(T) == 4 ? 3 : 1) void k_run_mimo
             __syncthreads();
             fft_dif<T, N, true, kPipeBlock, true>(s_x, NA, N, s_tw);  // time samples, digit-reversed positions
             // ---- channel: R = H T + noise on the samples that survive CP removal ----
-            for (int j = tid; j < N / 2; j += kPipeBlock) {
+            for (int j = opaque(tid); j < N / 2; j += kPipeBlock) {   // phase-local addresses (see fft.hpp FRESH)
                 const int half = j / (N / 4), rest = j - half * (N / 4);
                 const int p0 = 2 * half * (N / 4) + rest, p1 = p0 + N / 4;
                 const int m0 = fft_index_of_pos<N>(p0);  // even; position p1 holds m0 + 1
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(kPipeBlock, sizeof(T) == 4 ? 3 : 1) void k_run_mimo
             for (int a = 0; a < NA; ++a)
 #pragma unroll
                 for (int r = 0; r < NA; ++r) G[a][r] = s_G[a * NA + r];
-            for (int d = tid; d < U; d += kPipeBlock) {
+            for (int d = opaque(tid); d < U; d += kPipeBlock) {
                 const int bin = lds_swz<true>(ofdm_bin(d, N, U));
                 cx<T> y[NA];
 #pragma unroll
