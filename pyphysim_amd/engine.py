@@ -670,15 +670,23 @@ class Engine:
                                    be.ptr, cap.ptr, its.ptr))
         if counters is not None:
             return None
-        caps = cap.get()
-        sev = se.get()
-        iters = its.get().astype(np.int64)
-        valid = sev != 0xFFFFFFFF
         res = self._counters(cnt)
-        res["sum_capacity"] = float(np.sum(caps[valid]))
-        res["sum_capacity_sq"] = float(np.sum(caps[valid] ** 2))
-        res["ia_runned_iterations"] = int(np.sum(iters[valid]))
-        res["ia_runned_iterations_sq"] = int(np.sum(iters[valid] ** 2))
+        caps = cap.get()
+        iterative = solver != "closed_form"
+        iters = its.get().astype(np.int64) if (iterative or per_realization) else None
+        if res["n_skipped"] or per_realization:
+            sev = se.get()
+            valid = sev != 0xFFFFFFFF
+            if not valid.all():
+                caps_v, iters_v = caps[valid], (iters[valid] if iters is not None else None)
+            else:
+                caps_v, iters_v = caps, iters
+        else:                                   # nothing was skipped: no masks, no per-realization error arrays
+            sev, caps_v, iters_v = None, caps, iters
+        res["sum_capacity"] = float(caps_v.sum())
+        res["sum_capacity_sq"] = float(np.square(caps_v).sum())     # (no BLAS: its thread pool costs more than the sum)
+        res["ia_runned_iterations"] = int(iters_v.sum()) if iters_v is not None else 0
+        res["ia_runned_iterations_sq"] = int(np.square(iters_v).sum()) if iters_v is not None else 0
         if per_realization:
             return res, sev, be.get(), caps, iters
         return res
