@@ -249,6 +249,18 @@ def main():
                 traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        valu = None        # what actually binds the fused kernels: VALU issue slots (last rocprofv3 PMC pass)
+        ppath = os.path.join(REPO, "profiles", "r01", "%s_pmc_summary.json" % args.config)
+        if os.path.exists(ppath):
+            try:
+                pm = json.load(open(ppath))
+                waves_per_simd = 3
+                valu = {"valu_busy_per_wave": pm["_derived"]["valu_active_per_wave"],
+                        "waves_per_simd": waves_per_simd,
+                        "valu_issue_frac": pm["_derived"]["valu_active_per_wave"] * waves_per_simd,
+                        "source": "profiles/r01/%s_pmc_summary.json (SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES)" % args.config}
+            except Exception:
+                valu = None
         out = {
             "metric": "Monte Carlo realizations/sec (whole node) + SER abs-error vs ref",
             "value": value, "unit": "realizations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -265,6 +277,7 @@ def main():
                          "kernel": {"c4": "k_run_mimo_ofdm", "c2": "k_run_flat", "c3": "k_run_ofdm_tdl_batch",
                                     "c5": "k_run_ia", "f1": "k_run_mimo_ofdm_tdl"}[args.config],
                          "kernel_ms_per_launch": per_launch_s * 1e3,
+                         "valu": valu,
                          "algorithmic_bytes_per_realization": balg,
                          "traffic_source": "profiles/traffic_%s.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
                          % args.config if traffic is not None else None,
