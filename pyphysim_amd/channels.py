@@ -366,13 +366,16 @@ class TdlChannel:
             raise RuntimeError("Shape of the fading generator of the TdlChannel class must have either 1 (SISO) "
                                "or 3 (MIMO) dimensions")
         _, nr, nt = shp
-        if self._switched_direction:
-            raise NotImplementedError("switched_direction (reverse link) is not offloaded yet")
-        if nt == 1 and signal.ndim == 1:
+        n_in = nr if self._switched_direction else nt
+        if n_in == 1 and signal.ndim == 1:
             signal = signal.reshape(1, -1)
         self.generate_impulse_response(signal.shape[-1])
         ir = self._last_impulse_response
-        return self.engine.tdl_apply_mimo(signal, ir.tap_values_sparse, ir.tap_indexes_sparse, dtype=self.dtype)
+        taps = ir.tap_values_sparse
+        if self._switched_direction:
+            # reverse link (fading.py:1098-1106): the same taps seen from the other side -- antenna axes swapped
+            taps = np.ascontiguousarray(np.swapaxes(np.asarray(taps), 1, 2))
+        return self.engine.tdl_apply_mimo(signal, taps, ir.tap_indexes_sparse, dtype=self.dtype)
 
 
     def corrupt_data_in_freq_domain(self, signal, fft_size, carrier_indexes=None):
@@ -395,8 +398,6 @@ class TdlChannel:
         if len(shp) not in (1, 3):
             raise RuntimeError("Shape of the fading generator of the TdlChannel class must have either 1 (SISO) "
                                "or 3 (MIMO) dimensions")
-        if self._switched_direction:
-            raise NotImplementedError("switched_direction (reverse link) is not offloaded yet")
         n_blocks = num_symbols // block_size
         fading = np.asarray(self._fading_generator.generate_block_samples(n_blocks, fft_size - 1))
         fading = fading.reshape(tuple(shp) + (n_blocks,))
@@ -410,9 +411,13 @@ class TdlChannel:
         if len(shp) == 1:
             return self.engine.cmul(H.reshape(-1), signal.reshape(-1), dtype=self.dtype)
         _, nr, nt = shp
+        H = np.asarray(H).reshape(num_symbols, nr, nt)
+        if self._switched_direction:          # fading.py:1254-1258: out[:, t] = sum_r H[:, r, t] * signal[r]
+            H = np.ascontiguousarray(np.swapaxes(H, 1, 2))
+            nr, nt = nt, nr
         if nt == 1 and signal.ndim == 1:
             signal = signal.reshape(1, -1)
-        out = self.engine.blast_decode_per_subcarrier(H.reshape(num_symbols, nr, nt), signal, dtype=self.dtype)
+        out = self.engine.blast_decode_per_subcarrier(H, signal, dtype=self.dtype)
         return out.reshape(num_symbols, nr).T
 
 

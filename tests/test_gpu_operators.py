@@ -455,6 +455,29 @@ def test_mimo_tdl_mirror_classes(engine):
         channels.TdlMimoChannel(channels.JakesSampleGenerator(RS=rs, engine=engine))
     su = channels.SuMimoChannel(2, channels.JakesSampleGenerator(RS=rs, engine=engine), engine=engine)
     assert su.corrupt_data(x).shape == (2, 100) and su.num_tx_antennas == 2
+    # reverse link (reference tests/channels_package_test.py:1277-1407, :1526-1600): Nr-antenna signal in,
+    # Nt-antenna signal out through the transposed taps
+    with pytest.raises(TypeError):
+        tdl.switched_direction = 1
+    tdl.switched_direction = True
+    xr = rs.randn(3, 64) + 1j * rs.randn(3, 64)
+    yr = tdl.corrupt_data(xr)
+    ir = tdl.get_last_impulse_response()
+    want = np.zeros((2, 64 + 7), dtype=complex)
+    for i, d in enumerate(ir.tap_indexes_sparse):
+        for r in range(3):
+            want[:, d:d + 64] += ir.tap_values_sparse[i, r, :, :] * xr[r]
+    assert yr.shape == (2, 71) and relerr(yr, want) <= 1e-13
+    # block-static shortcut in the same direction (fading.py:1254-1258)
+    xf = rs.randn(3, 4 * 16) + 1j * rs.randn(3, 4 * 16)
+    yf = tdl.corrupt_data_in_freq_domain(xf, 16)
+    ir = tdl.get_last_impulse_response()
+    fr = ir.get_freq_response(16)                                   # [16, 3, 2, 4]
+    wantf = np.zeros((4 * 16, 2), dtype=complex)
+    for b in range(4):
+        for r in range(3):
+            wantf[b * 16:(b + 1) * 16, :] += fr[:, r, :, b] * xf[r, b * 16:(b + 1) * 16, None]
+    assert yf.shape == (2, 64) and relerr(yf, wantf.T) <= 1e-12
 
 
 def test_large_and_degenerate_operator_inputs(engine, golden_ops):
