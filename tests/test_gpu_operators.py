@@ -561,3 +561,55 @@ def test_elementwise_vector_paths_handle_any_length(engine, n):
     want = np.argmin(np.abs(rx[:, None] - table[None, :].astype(np.complex64)), axis=1)
     assert np.array_equal(engine.demodulate(rx, dtype="f32"), want)
     assert np.array_equal(engine.demodulate(rx, method=_lib.DEMOD_QAM_SLICER, dtype="f32"), want)
+
+
+def test_ia_class_mirrors_run_the_reference_app(engine):
+    """apps/ia/simulate_ia.py:94-245 written against the mirror classes (multiuser.MultiUserChannelMatrix +
+    ia.*IASolver) with the reference's seeding: precoders, filters, iteration counts and decisions of the
+    reference run (tests/golden/c5_ia.npz, f3_ia_iterative.npz)."""
+    from pyphysim_amd import ia, multiuser
+    from pyphysim_amd.modulators import QAM
+    classes = {"closed_form": ia.ClosedFormIASolver, "alt_min": ia.AlternatingMinIASolver,
+               "min_leakage": ia.MinLeakageIASolver, "max_sinr": ia.MaxSinrIASolver, "mmse": ia.MMSEIASolver}
+    for name in ("c5_ia", "f3_ia_iterative"):
+        for kw, reals in golden_cases(name):
+            algo = kw.get("algo", "closed_form")
+            for g in reals:
+                seed = int(g["seed"])
+                np.random.seed(seed)
+                m = QAM(kw["M"], engine=engine)
+                muc = multiuser.MultiUserChannelMatrix(engine=engine)
+                muc.set_channel_seed(seed)
+                muc.set_noise_seed(seed)
+                solver = classes[algo](muc)
+                if algo != "closed_form":
+                    solver._rs = np.random.RandomState(seed)
+                    solver._alt_min_rs = np.random.RandomState(seed)
+                    solver.max_iterations = kw["max_iterations"]
+                    solver.relative_factor = kw["relative_factor"]
+                    solver.initialize_with = kw.get("initialize_with", "random")
+                muc.randomize(kw["nr"], kw["nt"], kw["K"])
+                muc.noise_var = float(g["noise_var"])
+                assert relerr(muc.big_H, g["big_H"]) == 0.0
+                solver.clear()
+                solver.solve(kw["Ns"])
+                if algo != "closed_form":
+                    assert solver.runned_iterations == int(g["runned_iterations"])
+                idx = np.random.randint(0, kw["M"], [3, kw["NSymbs"]])
+                assert np.array_equal(idx, g["idx"])
+                tx = np.split(m.modulate(idx), [1, 2])
+                pre = [np.dot(f, x) for f, x in zip(solver.full_F, tx)]
+                rx = muc.corrupt_data(pre)
+                est = np.vstack([np.dot(u, y) for u, y in zip(solver.full_W_H, rx)])
+                assert relerr(est, g["est"]) <= 1e-6
+                assert np.array_equal(m.demodulate(est), g["decisions"])
+                sinr = np.concatenate(list(solver.calc_SINR()))
+                assert relerr(sinr, g["sinr"]) <= 1e-6
+    muc = multiuser.MultiUserChannelMatrix(engine=engine)
+    muc.randomize(3, 3, 3)
+    with pytest.raises(ValueError):
+        ia.MaxSinrIASolver(muc).solve(1)
+    with pytest.raises(RuntimeError):
+        ia.AlternatingMinIASolver(muc).initialize_with = "alt_min"
+    with pytest.raises(ValueError):
+        muc.init_from_channel_matrix(np.zeros((4, 4)), 2, 2, 3)
