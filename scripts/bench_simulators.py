@@ -10,6 +10,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pyphysim_amd import simulators  # noqa: E402
 
 CASES = [
+    ("AwgnSimulator (config 1)", lambda: simulators.AwgnSimulator(SNR=[10.0], M=16, NSymbs=10000, rep_max=1 << 21,
+                                                                batch_size=1 << 19)),
     ("MimoOfdmSimulator (config 4)", lambda: simulators.MimoOfdmSimulator(SNR=[25.0], M=64, rep_max=1 << 21, batch_size=65536)),
     ("OfdmTdlSimulator (config 3)", lambda: simulators.OfdmTdlSimulator(SNR=[20.0], rep_max=1 << 22, batch_size=131072)),
     ("FlatFadingSimulator (config 2)", lambda: simulators.FlatFadingSimulator(SNR=[20.0], M=64, rep_max=1 << 15, batch_size=4096)),
