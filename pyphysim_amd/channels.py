@@ -68,7 +68,7 @@ class TdlChannelProfile:
         if self.is_discretized:
             raise RuntimeError("Trying to discretize a TdlChannelProfile that is already discretized.")
         lin, idx = discretize_profile(self._tap_powers_dB, self._tap_delays, Ts)
-        prof = TdlChannelProfile(util.linear2dB(lin), idx, self._name)
+        prof = TdlChannelProfile(util.linear2dB(lin), idx, self._name + " (discretized)")
         prof._Ts = Ts
         return prof
 
@@ -350,6 +350,9 @@ class TdlChannel:
         self._last_impulse_response = TdlImpulseResponse(fading * amp, self._channel_profile)
 
     def get_last_impulse_response(self):
+        """fading.py:991-1007: raises until an impulse response has been generated."""
+        if self._last_impulse_response is None:
+            raise RuntimeError("No impulse response was generated yet")
         return self._last_impulse_response
 
     def corrupt_data(self, signal):
@@ -467,7 +470,7 @@ class SuChannel:
 
     def get_last_impulse_response(self):
         ir = self._tdlchannel.get_last_impulse_response()
-        if self._pathloss_value is None or ir is None:
+        if self._pathloss_value is None:
             return ir
         return TdlImpulseResponse(ir.tap_values_sparse * math.sqrt(self._pathloss_value), ir.channel_profile)
 

@@ -58,9 +58,28 @@ template <int N> __host__ __device__ __forceinline__ int fft_index_of_pos(int p)
 // band puts data k on bin (k + N/2) mod N; otherwise the first half rides the negative bins
 // [N-h, N-1] and the second half the positive bins [1, h] (DC and band edges unused).
 __host__ __device__ __forceinline__ int ofdm_bin(int d, int n, int num_used) {
-    if (num_used == n) return (d + n / 2) & (n - 1);
+    if (num_used == n) {   // n even here (num_used is); no power-of-two assumption
+        const int t = d + n / 2;
+        return t >= n ? t - n : t;
+    }
     const int h = num_used / 2;
     return d < h ? n - h + d : 1 + (d - h);
+}
+
+// twiddle index (prod mod n): mask = n-1 for powers of two, -1 otherwise (uniform branch)
+__host__ __device__ __forceinline__ int tw_index(int prod, int n, int mask) {
+    return mask >= 0 ? (prod & mask) : (int)((unsigned)prod % (unsigned)n);
+}
+__host__ __forceinline__ int tw_mask_of(int n) { return (n & (n - 1)) == 0 ? n - 1 : -1; }
+// sizes the radix-4 LDS kernels are instantiated for
+__host__ __forceinline__ bool fft_is_radix4_size(int n) { return n >= 16 && n <= 4096 && (n & (n - 1)) == 0; }
+// N = N1 * N2 with N1 <= N2 the divisor pair closest to sqrt(N) (N1 = 1 for primes)
+__host__ __forceinline__ void dft_any_split(int n, int* n1, int* n2) {
+    int best = 1;
+    for (int d = 1; d * d <= n; ++d)
+        if (n % d == 0) best = d;
+    *n1 = best;
+    *n2 = n / best;
 }
 
 // LDS bank swizzle for the in-place radix-4 stages.  A wave64 ds_read/write_b64 is serviced per

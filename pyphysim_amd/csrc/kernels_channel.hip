@@ -174,7 +174,8 @@ __global__ __launch_bounds__(kChBlock) void k_tdl_apply_mimo(const cx<T>* __rest
 template <typename T>
 __global__ __launch_bounds__(kChBlock) void k_mean_freq_response(const cx<T>* __restrict__ g, Delays dl, int n_taps,
                                                                  int P, size_t n_sym, int n, int cp, int num_used,
-                                                                 bool natural, const cx<T>* __restrict__ tw,
+                                                                 bool natural, int mask,
+                                                                 const cx<T>* __restrict__ tw,
                                                                  cx<T>* __restrict__ Hm) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cx<T>* s_mean = reinterpret_cast<cx<T>*>(smem);  // [n_taps][P]
@@ -203,7 +204,7 @@ __global__ __launch_bounds__(kChBlock) void k_mean_freq_response(const cx<T>* __
             const int d = (int)(e / P), p = (int)(e - (size_t)d * P);
             const int k = natural ? d : ofdm_bin(d, n, num_used);
             cx<T> h = mk<T>(0, 0);
-            for (int i = 0; i < n_taps; ++i) h = cfma(s_mean[i * P + p], tw[(k * dl.d[i]) & (n - 1)], h);
+            for (int i = 0; i < n_taps; ++i) h = cfma(s_mean[i * P + p], tw[tw_index(k * dl.d[i], n, mask)], h);
             Hm[(sym * num_used + d) * P + p] = h;
         }
     }
@@ -333,7 +334,7 @@ int mcle_tdl_mean_freq_response(mcle_ctx* ctx, int dtype, const void* d_taps, co
     MCLE_REQUIRE(dtype == MCLE_F32 || dtype == MCLE_F64, "dtype must be MCLE_F32 or MCLE_F64");
     MCLE_REQUIRE(n_taps >= 1 && n_taps <= MCLE_MAX_TAPS, "n_taps must be in [1, %d]", MCLE_MAX_TAPS);
     MCLE_REQUIRE(n_links >= 1 && n_links <= 64, "n_links must be in [1, 64]");
-    MCLE_REQUIRE(fft_size >= 16 && fft_size <= 4096 && (fft_size & (fft_size - 1)) == 0, "bad fft_size %d", fft_size);
+    MCLE_REQUIRE(fft_size >= 2 && fft_size <= 4096, "fft_size must be in [2, 4096] (got %d)", fft_size);
     // num_used < 0: all fft_size bins in natural order with groups of -num_used samples averaged (1 = the
     // block-static response of corrupt_data_in_freq_domain, fading.py:1126-1287)
     const bool natural = num_used < 0;
@@ -361,11 +362,11 @@ int mcle_tdl_mean_freq_response(mcle_ctx* ctx, int dtype, const void* d_taps, co
     if (dtype == MCLE_F32)
         hipLaunchKernelGGL(k_mean_freq_response<float>, grid, dim3(kChBlock), lds, ctx->stream,
                            (const float2*)d_taps, dl, n_taps, n_links, n_sym, fft_size, cp_size, num_used, natural,
-                           (const float2*)tw, (float2*)d_H);
+                           tw_mask_of(fft_size), (const float2*)tw, (float2*)d_H);
     else
         hipLaunchKernelGGL(k_mean_freq_response<double>, grid, dim3(kChBlock), lds, ctx->stream,
                            (const double2*)d_taps, dl, n_taps, n_links, n_sym, fft_size, cp_size, num_used, natural,
-                           (const double2*)tw, (double2*)d_H);
+                           tw_mask_of(fft_size), (const double2*)tw, (double2*)d_H);
     MCLE_LAUNCH_CHECK();
     return MCLE_OK;
 }

@@ -136,6 +136,62 @@ def test_ofdm_sizes_batches_and_errors(engine):
 
 
 @pytest.mark.parametrize("dt", ["f64", "f32"])
+def test_ofdm_any_fft_size(engine, dt):
+    """np.fft takes any length (the reference's equaliser test uses 24 subcarriers,
+    tests/modulators_package_test.py:659-712): non power-of-two sizes -- composite, prime, tiny, the
+    LTE 1536 grid, the largest odd size -- run the two-pass DFT kernels and agree with the oracle."""
+    rs = np.random.RandomState(11)
+    tol = F64_TOL * 50 if dt == "f64" else 2e-5
+    for fft, cp, used in ((24, 8, 24), (2, 0, 2), (8, 2, 6), (12, 3, 10), (97, 10, 60), (600, 40, 512),
+                          (1536, 108, 1200), (4095, 17, 4000), (3000, 0, 3000)):
+        n_in = 2 * used + used // 2            # third symbol is zero padded
+        x = rs.randn(2, n_in) + 1j * rs.randn(2, n_in)
+        tx = engine.ofdm_modulate(x, fft, cp, used, batch=2, dtype=dt)
+        want = np.stack([oofdm.modulate(x[b], fft, cp, used) for b in range(2)])
+        assert tx.shape == want.shape and relerr(tx, want) <= tol, (fft, relerr(tx, want))
+        back = engine.ofdm_demodulate(want, fft, cp, used, batch=2, dtype=dt)
+        wantb = np.stack([oofdm.demodulate(want[b], fft, cp, used) for b in range(2)])
+        assert relerr(back, wantb) <= tol, (fft, relerr(back, wantb))
+        assert relerr(back[:, :n_in], x) <= tol * 10
+    # one-tap equaliser and mean responses on the 24-subcarrier grid of the reference's test
+    fft, cp, used, n_sym = 24, 8, 24, 3
+    delays = np.array([0, 1, 3, 5], dtype=np.int32)
+    taps = (rs.randn(4, n_sym * (fft + cp)) + 1j * rs.randn(4, n_sym * (fft + cp))) * 0.5
+    data = rs.randn(n_sym * used) + 1j * rs.randn(n_sym * used)
+    got = engine.onetap_equalize(data, taps, delays, fft, cp, used, dtype=dt)
+    want = oofdm.onetap_equalize(data, taps, delays, fft, cp, used)
+    assert relerr(got, want) <= tol * 20
+    H = engine.tdl_mean_freq_response(taps, delays, n_sym, fft, cp, used, dtype=dt)
+    idx = oofdm.used_subcarrier_indexes(fft, used)
+    for s in range(n_sym):
+        mean = taps[:, s * (fft + cp):(s + 1) * (fft + cp)].mean(axis=1)
+        full = np.zeros(fft, dtype=complex)
+        full[delays] = mean
+        assert relerr(H[s], np.fft.fft(full)[idx]) <= tol * 20
+
+
+def test_equalizer_app_of_the_reference_on_24_subcarriers(engine):
+    """The reference's OfdmOneTapEqualizer test as an application of the mirror classes
+    (tests/modulators_package_test.py:659-712): noiseless QPSK over a Jakes/TU channel, 24-point OFDM,
+    one-tap equalisation recovers every symbol."""
+    from pyphysim_amd import channels, modulators
+    rs = np.random.RandomState(3)
+    n_sc = 24
+    ofdm_obj = modulators.OFDM(n_sc, cp_size=8, engine=engine)
+    eq = modulators.OfdmOneTapEqualizer(ofdm_obj)
+    qam = modulators.QAM(4, engine=engine)
+    data = rs.randint(0, 4, size=2 * n_sc)
+    tx = ofdm_obj.modulate(qam.modulate(data))
+    jakes = channels.JakesSampleGenerator(50, 1.0 / (55e3 * n_sc), 16, shape=None, RS=rs, engine=engine)
+    tdl = channels.TdlChannel(jakes, tap_powers_dB=channels.COST259_TUx.tap_powers_dB,
+                              tap_delays=channels.COST259_TUx.tap_delays)
+    memory = tdl.num_taps_with_padding - 1
+    rx = tdl.corrupt_data(tx)
+    got = eq.equalize_data(ofdm_obj.demodulate(rx[:-memory]), tdl.get_last_impulse_response())
+    assert np.array_equal(qam.demodulate(got), data)
+
+
+@pytest.mark.parametrize("dt", ["f64", "f32"])
 def test_jakes_tdl_equalizer_injected(engine, dt):
     """C2 / C3 with the reference's phi, psi and noise injected."""
     for kw, reals in golden_cases("c2_flat_jakes"):
@@ -351,6 +407,19 @@ def test_host_mirror_classes(engine, golden_ops):
     tdl = channels.TdlChannel(channels.JakesSampleGenerator(Fd=5, Ts=3.255e-8, L=16, RS=rs, engine=engine),
                               channels.COST259_TUx, engine=engine)
     assert tdl.num_taps == 15 and tdl.num_taps_with_padding == 67
+    # constructor known answers and errors (tests/channels_package_test.py:740-790)
+    with pytest.raises(RuntimeError):
+        tdl.get_last_impulse_response()          # nothing generated yet
+    jk2 = channels.JakesSampleGenerator(Fd=5, Ts=3.255e-8, L=16, RS=rs, engine=engine)
+    far = channels.TdlChannel(jk2, tap_powers_dB=channels.COST259_TUx.tap_powers_dB,
+                              tap_delays=10 * channels.COST259_TUx.tap_delays)
+    assert far.num_taps == 20 and far.num_taps_with_padding == 658 and far.channel_profile.Ts == 3.255e-8
+    with pytest.raises(RuntimeError):             # Ts differs from the Jakes generator's
+        channels.TdlChannel(jk2, channels.COST259_TUx, Ts=0.002)
+    with pytest.raises(RuntimeError):             # profile discretised with another Ts
+        channels.TdlChannel(jk2, channels.COST259_TUx.get_discretize_profile(0.002))
+    ray = channels.TdlChannel(channels.RayleighSampleGenerator(), channels.COST259_TUx, Ts=3.255e-8)
+    assert ray.num_taps == 15 and ray.num_taps_with_padding == 67
     x = rs.randn(300) + 1j * rs.randn(300)
     y = tdl.corrupt_data(x)
     ir = tdl.get_last_impulse_response()
