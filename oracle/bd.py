@@ -1,0 +1,171 @@
+"""TEST INFRASTRUCTURE ONLY (never imported by the product path).
+
+CPU restatement of the reference's block diagonalisation (SURVEY.md section 8(f).3 tail):
+    pyphysim/comm/waterfilling.py:15-92            doWF
+    pyphysim/comm/blockdiagonalization.py:272-363  _calc_BD_matrix_no_power_scaling
+                                         :365-401  global water-filling power scaling
+                                         :403-464  normalised power scaling
+                                         :466-508  block_diagonalize
+                                         :510-566  block_diagonalize_no_waterfilling
+                                         :568-585  calc_receive_filter (pinv)
+    pyphysim/util/misc.py:590-662                  least_right_singular_vectors
+
+Pinned against the reference in this container by oracle/make_golden.py -> tests/golden/f6_block_diag.npz
+(tests/test_oracle_golden.py).
+
+`block_diagonalize` follows the reference's own arithmetic (two numpy SVDs per user), so its singular
+vectors carry LAPACK's phases.  `block_diagonalize_closed` is the formulation the HIP kernels use (one
+inverse + one small Hermitian eigen-decomposition per user, canonical phases); both give the same
+precoder up to a unit-modulus factor per column, which `canonical_columns` removes.
+"""
+import numpy as np
+
+
+def waterfilling(gains, total_power, noise_var=1.0, Es=1.0):
+    """waterfilling.py:15-92.  gains = channel POWER gains; returns (powers, water level)."""
+    gains = np.asarray(gains, dtype=float)
+    order = np.argsort(gains)[::-1]
+    g = gains[order]
+    n, removed = g.size, 0
+    mu_min = float(noise_var) / (Es * g[n - 1])
+    Ps = mu_min - float(noise_var) / (Es * g[:n])
+    while sum(Ps) > total_power and removed < n:
+        removed += 1
+        mu_min = float(noise_var) / (Es * g[n - removed - 1])
+        Ps = mu_min - float(noise_var) / (Es * g[:n - removed])
+    kept = n - removed
+    P_kept = (total_power - np.sum(Ps)) / kept + Ps
+    P = np.zeros(n)
+    P[order[:kept]] = P_kept
+    return P, P_kept[0] + float(noise_var) / g[0]
+
+
+def least_right_singular_vectors(A, n):
+    """misc.py:590-662: (V0 = the n least right singular vectors, V1 = the rest, S of the rest), every
+    group in ASCENDING singular-value order (numpy's order reversed)."""
+    _, S, V_H = np.linalg.svd(A, full_matrices=True)
+    V = V_H.conj().T
+    rev = list(reversed(range(V.shape[0])))
+    return V[:, rev[:n]], V[:, rev[n:]], S[rev[n:]]
+
+
+def _user_rows(K, nr_total, user):
+    r = nr_total // K
+    return list(range(r * user, r * (user + 1)))
+
+
+def bd_no_power_scaling(H, K):
+    """blockdiagonalization.py:272-363 -> (Ms_bad [Nt, sum streams], Sigma [sum streams])."""
+    H = np.asarray(H)
+    nr = H.shape[0]
+    assert nr % K == 0
+    r = nr // K
+    Ms, Sigma = [], []
+    for user in range(K):
+        others = [i for u in range(K) if u != user for i in _user_rows(K, nr, u)]
+        tilde_H = H[others, :]
+        n_streams = nr - np.linalg.matrix_rank(tilde_H)
+        tilde_V0 = least_right_singular_vectors(tilde_H, n_streams)[0]
+        _, V1, S = least_right_singular_vectors(H[_user_rows(K, nr, user), :] @ tilde_V0, r - n_streams)
+        Ms.append(tilde_V0 @ V1)
+        Sigma.extend(S)
+    return np.hstack(Ms), np.array(Sigma)
+
+
+def global_waterfilling_scaling(Ms_bad, Sigma, K, iPu, noise_var):
+    """:365-401."""
+    P = waterfilling(Sigma ** 2, K * iPu, noise_var)[0]
+    return Ms_bad @ np.diag(np.sqrt(P))
+
+
+def normalized_waterfilling_scaling(Ms_bad, Sigma, K, iPu, noise_var):
+    """:403-464: global water-filling, then one common factor so the strongest user block meets iPu."""
+    n_u = Sigma.size // K
+    Ms = global_waterfilling_scaling(Ms_bad, Sigma, K, iPu, noise_var)
+    max_sqrt_P = 0
+    for user in range(K):
+        cur = np.linalg.norm(Ms[:, user * n_u:(user + 1) * n_u], 'fro')
+        if cur > max_sqrt_P:
+            max_sqrt_P = cur
+    return Ms * np.sqrt(iPu) / max_sqrt_P
+
+
+def block_diagonalize(H, K, iPu, noise_var):
+    """:466-508 -> (newH, Ms_good)."""
+    Ms_bad, Sigma = bd_no_power_scaling(H, K)
+    Ms = normalized_waterfilling_scaling(Ms_bad, Sigma, K, iPu, noise_var)
+    return H @ Ms, Ms
+
+
+def block_diagonalize_no_waterfilling(H, K, iPu):
+    """:510-566: each user's block scaled to Frobenius norm sqrt(iPu)."""
+    H = np.asarray(H)
+    n_u = H.shape[1] // K
+    Ms_bad, _ = bd_no_power_scaling(H, K)
+    Ms = np.empty(Ms_bad.shape, dtype=complex)
+    for user in range(K):
+        blk = Ms_bad[:, user * n_u:(user + 1) * n_u]
+        Ms[:, user * n_u:(user + 1) * n_u] = blk * np.sqrt(iPu) / np.linalg.norm(blk, 'fro')
+    return H @ Ms, Ms
+
+
+def calc_receive_filter(newH):
+    """:568-585."""
+    return np.linalg.pinv(newH)
+
+
+# ---------------------------------------------------------------------------------------------
+# the kernels' formulation (square channel: Nt == K * r)
+# ---------------------------------------------------------------------------------------------
+def canonical_columns(M):
+    """Rotate every column so that its largest-magnitude entry is real and positive (first one wins ties):
+    the representative of the per-column phase freedom that singular vectors have."""
+    M = np.array(M, dtype=complex)
+    for j in range(M.shape[1]):
+        i = int(np.argmax(np.abs(M[:, j])))
+        if abs(M[i, j]) > 0:
+            M[:, j] *= np.conj(M[i, j]) / abs(M[i, j])
+    return M
+
+
+def bd_no_power_scaling_closed(H, K):
+    """Same (Ms_bad, Sigma) as bd_no_power_scaling up to column phases, for square H, without any SVD:
+    with Z = H^-1 and Z_k its columns of user k, the Gram block D_k = Z_k^H Z_k = [(H H^H)^-1]_kk is the
+    inverse of the Schur complement H_k P0_k H_k^H (P0_k = projector on the null space of the other users'
+    rows), so D_k = U diag(1/sigma^2) U^H gives the singular values of the equivalent channel H_k V0_k and
+    its right singular vectors are V_k = Z_k U diag(sigma); columns in ascending sigma like the reference,
+    canonical phase per column."""
+    H = np.asarray(H, dtype=complex)
+    n = H.shape[0]
+    assert H.shape[1] == n and n % K == 0
+    r = n // K
+    Z = np.linalg.inv(H)
+    Ms, Sigma = [], []
+    for k in range(K):
+        Zk = Z[:, k * r:(k + 1) * r]
+        lam, U = np.linalg.eigh(Zk.conj().T @ Zk)       # ascending lam == descending sigma
+        sig = 1.0 / np.sqrt(lam[::-1])                   # ascending sigma
+        V = Zk @ U[:, ::-1] * sig[None, :]
+        Ms.append(canonical_columns(V))
+        Sigma.extend(sig)
+    return np.hstack(Ms), np.array(Sigma)
+
+
+def block_diagonalize_closed(H, K, iPu, noise_var, waterfill=True):
+    """(newH, Ms, W) the way the kernels compute them; W = pinv(newH) built block by block (rows of streams
+    that the water-filling switched off are zero, as numpy's pinv returns for a zero column)."""
+    H = np.asarray(H, dtype=complex)
+    n = H.shape[0]
+    r = n // K
+    Ms_bad, Sigma = bd_no_power_scaling_closed(H, K)
+    if waterfill:
+        Ms = normalized_waterfilling_scaling(Ms_bad, Sigma, K, iPu, noise_var)
+    else:
+        Ms = np.hstack([Ms_bad[:, k * r:(k + 1) * r] * np.sqrt(iPu) / np.linalg.norm(Ms_bad[:, k * r:(k + 1) * r])
+                        for k in range(K)])
+    newH = H @ Ms
+    W = np.zeros((n, n), dtype=complex)
+    for k in range(K):
+        blk = newH[k * r:(k + 1) * r, k * r:(k + 1) * r]
+        W[k * r:(k + 1) * r, k * r:(k + 1) * r] = np.linalg.pinv(blk)
+    return newH, Ms, W

@@ -22,6 +22,7 @@ import numpy as np
 
 from . import channels as och
 from . import ia as oia
+from . import bd as obd
 from . import mimo as omimo
 from . import modem as omodem
 from . import ofdm as oofdm
@@ -274,6 +275,44 @@ def chain_mimo_scheme(rng, scheme='blast', mod='qam', M=16, nt=2, nr=2, NSymbs=2
         est = omimo.gmd_decode(Y, H, 0.0)
     dec = omodem.demodulate(table, est)
     return _counts(dict(table=table, H=H, idx=idx, noise=noise, est=est, noise_var=noise_var), idx, dec, M)
+
+
+def apply_pathloss(big_H, K, pathloss):
+    """multiuser.py:256-292: block (rx k, tx l) of the channel scaled by sqrt(pathloss[k, l])."""
+    if pathloss is None:
+        return big_H
+    pl = np.asarray(pathloss, dtype=float)
+    nr, nt = big_H.shape[0] // K, big_H.shape[1] // K
+    return big_H * np.kron(np.sqrt(pl), np.ones((nr, nt)))
+
+
+def chain_bd(rng, mod='psk', M=4, K=3, nr=2, NSymbs=500, iPu=1.0, noise_var=0.03, bd_noise_var=1e-50,
+             pathloss=None, waterfill=True, canonical=False):
+    """SURVEY.md section 8(f).3 tail: apps/comp_BD/simulate_comp_simple.py:95-140 without external
+    interference -- K cells of nr x nr antennas transmit jointly, block diagonalisation of the (K nr) x
+    (K nr) channel (path loss applied per block), zero-forcing pinv(newH) at the receivers.
+    canonical=True uses the kernels' formulation (canonical singular-vector phases) instead of numpy's SVD:
+    the same precoder up to one phase per stream, hence the same statistics but not the same decisions."""
+    table = constellation(mod, M)
+    n = K * nr
+    big_H = apply_pathloss(rng.cn(philox.STREAM_CHAN, n, n), K, pathloss)
+    if rng.legacy:
+        idx = rng.rs.randint(0, M, [n, NSymbs])
+    else:
+        idx = rng.symbols(n * NSymbs, M).reshape(n, NSymbs)
+    sym = omodem.modulate(table, idx)
+    if canonical:
+        newH, Ms, W = obd.block_diagonalize_closed(big_H, K, iPu, bd_noise_var, waterfill)
+    else:
+        newH, Ms = (obd.block_diagonalize(big_H, K, iPu, bd_noise_var) if waterfill
+                    else obd.block_diagonalize_no_waterfilling(big_H, K, iPu))
+        W = obd.calc_receive_filter(newH)
+    noise = rng.cn(philox.STREAM_NOISE, n, NSymbs)
+    Y = oia.mu_corrupt(big_H, Ms @ sym, noise, noise_var)
+    est = W @ Y
+    dec = omodem.demodulate(table, est)
+    return _counts(dict(table=table, big_H=big_H, idx=idx, noise=noise, est=est, noise_var=noise_var, Ms=Ms,
+                        newH=newH, W=W), idx, dec, M)
 
 
 STREAM_INIT = 3    # the solver's own RandomState (iabase.py:95); shares the PHASE stream id, unused in config 5

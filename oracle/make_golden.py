@@ -418,6 +418,35 @@ def ref_chain_mimo_ofdm_tdl(seed, mod, M, nt, nr, fft_size, cp_size, num_used, n
                 **ref_counts(idx, dec, M))
 
 
+def ref_chain_bd(seed, mod, M, K, nr, NSymbs, iPu, noise_var, bd_noise_var, pathloss, waterfill):
+    """apps/comp_BD/simulate_comp_simple.py:95-140 composed from the reference's own operators (no external
+    interference source)."""
+    from pyphysim.channels import multiuser as rmu
+    from pyphysim.comm import blockdiagonalization as rbd
+    np.random.seed(seed)
+    m = ref_modulator(mod, M)
+    muc = rmu.MultiUserChannelMatrix()
+    muc.set_channel_seed(seed)
+    muc.set_noise_seed(seed)
+    muc.randomize(nr, nr, K)
+    if pathloss is not None:
+        muc.set_pathloss(np.asarray(pathloss, dtype=float))
+    muc.noise_var = noise_var
+    idx = np.random.randint(0, M, [K * nr, NSymbs])
+    sym = m.modulate(idx)
+    big_H = np.array(muc.big_H)
+    if waterfill:
+        newH, Ms = rbd.block_diagonalize(big_H, K, iPu, bd_noise_var)
+    else:
+        newH, Ms = rbd.BlockDiagonalizer(K, iPu, bd_noise_var).block_diagonalize_no_waterfilling(big_H)
+    Y = muc.corrupt_concatenated_data(np.dot(Ms, sym))
+    W = rbd.calc_receive_filter(newH)
+    est = np.dot(W, Y)
+    dec = m.demodulate(est)
+    return dict(table=m.symbols, big_H=big_H, idx=idx, noise=muc.last_noise / math.sqrt(noise_var), est=est,
+                decisions=dec, noise_var=noise_var, Ms=Ms, newH=newH, W=W, **ref_counts(idx, dec, M))
+
+
 CHAINS = {
     # name: (reference runner, oracle chain, [(kwargs for oracle, args for ref)], n realizations)
     "c1_awgn": [dict(mod="qam", M=16, N=10000, snr_db=10.0)]
@@ -459,6 +488,18 @@ CHAINS = {
                          dict(mod="qam", M=64, nt=4, nr=4, fft_size=256, cp_size=32, num_used=200, n_ofdm_sym=1,
                               snr_db=30.0, Fd=100.0, Ts=5e-7, L=8, tap_powers_dB=(0.0, -3.0, -6.0, -9.0),
                               tap_delays_samples=(0, 1, 4, 9))],
+    "f6_block_diag": [dict(mod="psk", M=4, K=3, nr=2, NSymbs=100, iPu=1.0, noise_var=0.03, bd_noise_var=1e-50,
+                           pathloss=None, waterfill=True),
+                      dict(mod="qam", M=16, K=3, nr=2, NSymbs=60, iPu=2.0, noise_var=0.01, bd_noise_var=0.5,
+                           pathloss=((1.0, 0.2, 0.05), (0.3, 1.0, 0.1), (0.02, 0.4, 1.0)), waterfill=True),
+                      dict(mod="qam", M=16, K=2, nr=2, NSymbs=60, iPu=1.0, noise_var=0.02, bd_noise_var=3.0,
+                           pathloss=None, waterfill=True),
+                      dict(mod="psk", M=8, K=4, nr=2, NSymbs=40, iPu=1.5, noise_var=0.01, bd_noise_var=1e-3,
+                           pathloss=None, waterfill=False),
+                      dict(mod="qam", M=16, K=2, nr=3, NSymbs=40, iPu=1.0, noise_var=0.01, bd_noise_var=0.1,
+                           pathloss=None, waterfill=True),
+                      dict(mod="qam", M=4, K=4, nr=1, NSymbs=40, iPu=1.0, noise_var=0.05, bd_noise_var=0.2,
+                           pathloss=None, waterfill=True)],
     "c5_ia": [dict(mod="qam", M=16, K=3, nr=2, nt=2, Ns=1, NSymbs=200, snr_db=20.0),
               dict(mod="qam", M=4, K=3, nr=2, nt=2, Ns=1, NSymbs=50, snr_db=8.0)],
 }
@@ -467,6 +508,8 @@ CHAINS = {
 def run_ref(name, kw, seed):
     if name == "c5_ia":
         return ref_chain_ia(seed, **kw)
+    if name == "f6_block_diag":
+        return ref_chain_bd(seed, **kw)
     if name == "f3_ia_iterative":
         return ref_chain_ia_iterative(seed, **kw)
     if name == "f5_mimo_schemes":
@@ -490,31 +533,34 @@ def run_ref(name, kw, seed):
 ORACLE = {"c1_awgn": chains.chain_awgn, "c2_flat_jakes": chains.chain_flat_jakes,
           "c3_ofdm_tdl": chains.chain_ofdm_tdl, "c4_mimo_ofdm": chains.chain_mimo_ofdm, "c5_ia": chains.chain_ia,
           "f1_mimo_ofdm_tdl": chains.chain_mimo_ofdm_tdl, "f3_ia_iterative": chains.chain_ia_iterative,
-          "f5_mimo_schemes": chains.chain_mimo_scheme}
+          "f5_mimo_schemes": chains.chain_mimo_scheme, "f6_block_diag": chains.chain_bd}
 INT_KEYS = ("idx", "decisions", "symbol_errors", "bit_errors", "num_symbols", "num_bits", "delay_indexes",
             "runned_iterations")
 # realizations stored per case (kept small: fixtures are KBs)
 N_REAL = {"c1_awgn": 2, "c2_flat_jakes": 2, "c3_ofdm_tdl": 2, "c4_mimo_ofdm": 2, "c5_ia": 4, "f1_mimo_ofdm_tdl": 1,
-          "f3_ia_iterative": 3, "f5_mimo_schemes": 2}
+          "f3_ia_iterative": 3, "f5_mimo_schemes": 2, "f6_block_diag": 3}
 # derivable float arrays that are checked against the reference above but not stored
 SKIP_STORE = {"c1_awgn": ("tx",), "c2_flat_jakes": ("tx", "faded"), "c3_ofdm_tdl": ("sym", "faded"),
               "c4_mimo_ofdm": ("sym", "X", "R"), "c5_ia": (),
-              "f1_mimo_ofdm_tdl": ("faded", "G"), "f3_ia_iterative": (), "f5_mimo_schemes": ()}
+              "f1_mimo_ofdm_tdl": ("faded", "G"), "f3_ia_iterative": (), "f5_mimo_schemes": (),
+              "f6_block_diag": ()}
 
 
-def golden_chains():
+def golden_chains(only=None):
     import json
     for name, cases in CHAINS.items():
+        if only and name not in only:
+            continue
         store = {}
         worst = 0.0
         for ci, kw in enumerate(cases):
             for r in range(N_REAL[name]):
                 seed = BASE_SEED + 1000 * ci + r
                 ref = run_ref(name, kw, seed)
-                mine = ORACLE[name]((chains.LegacyRng3 if name in ("c5_ia", "f3_ia_iterative")
+                mine = ORACLE[name]((chains.LegacyRng3 if name in ("c5_ia", "f3_ia_iterative", "f6_block_diag")
                                      else chains.LegacyRng)(seed), **kw)
                 for k, v in ref.items():
-                    tol = 0 if k in INT_KEYS else (1e-9 if name in ("c5_ia", "f1_mimo_ofdm_tdl") else
+                    tol = 0 if k in INT_KEYS else (1e-9 if name in ("c5_ia", "f1_mimo_ofdm_tdl", "f6_block_diag") else
                                                    (1e-7 if name == "f3_ia_iterative" else
                                                     (1e-9 if name == "f5_mimo_schemes" else 1e-12)))
                     worst = max(worst, close(mine[k], v, tol, "%s[%d] r%d %s" % (name, ci, r, k)))
@@ -535,8 +581,10 @@ def golden_chains():
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
-    golden_operators()
-    golden_chains()
+    only = set(sys.argv[1:])          # e.g. `make_golden.py f6_block_diag` regenerates one fixture
+    if not only:
+        golden_operators()
+    golden_chains(only)
     for f in sorted(os.listdir(GOLD)):
         print("%8.1f KB  %s" % (os.path.getsize(os.path.join(GOLD, f)) / 1024.0, f))
 
@@ -682,4 +730,5 @@ def golden_framework():
 
 
 if __name__ == "__main__":
-    golden_framework()
+    if not set(sys.argv[1:]):
+        golden_framework()

@@ -99,14 +99,14 @@ def test_blast(golden_ops):
 
 CHAIN_FN = {"c1_awgn": chains.chain_awgn, "c2_flat_jakes": chains.chain_flat_jakes,
             "c3_ofdm_tdl": chains.chain_ofdm_tdl, "c4_mimo_ofdm": chains.chain_mimo_ofdm, "c5_ia": chains.chain_ia, "f3_ia_iterative": chains.chain_ia_iterative, "f5_mimo_schemes": chains.chain_mimo_scheme,
-            "f1_mimo_ofdm_tdl": chains.chain_mimo_ofdm_tdl}
+            "f1_mimo_ofdm_tdl": chains.chain_mimo_ofdm_tdl, "f6_block_diag": chains.chain_bd}
 
 
 @pytest.mark.parametrize("name", sorted(CHAIN_FN))
 def test_chain_matches_reference(name):
     for kw, reals in golden_cases(name):
         for g in reals:
-            rng_cls = chains.LegacyRng3 if name in ("c5_ia", "f3_ia_iterative") else chains.LegacyRng
+            rng_cls = chains.LegacyRng3 if name in ("c5_ia", "f3_ia_iterative", "f6_block_diag") else chains.LegacyRng
             mine = CHAIN_FN[name](rng_cls(int(g["seed"])), **kw)
             for k, v in g.items():
                 if k == "seed":
@@ -114,7 +114,7 @@ def test_chain_matches_reference(name):
                 if k in INT_KEYS:
                     assert np.array_equal(np.asarray(mine[k]), np.asarray(v)), (name, k)
                 else:
-                    tol = 1e-7 if name == "f3_ia_iterative" else (1e-9 if name in ("c5_ia", "f1_mimo_ofdm_tdl", "f5_mimo_schemes") else 1e-12)
+                    tol = 1e-7 if name == "f3_ia_iterative" else (1e-9 if name in ("c5_ia", "f1_mimo_ofdm_tdl", "f5_mimo_schemes", "f6_block_diag") else 1e-12)
                     assert relerr(mine[k], v) <= tol, (name, k)
 
 
@@ -125,3 +125,40 @@ def test_onetap_fast_form_equals_literal():
     b = oofdm.onetap_equalize_fast(g["demod"], g["taps"], g["delay_indexes"], kw["fft_size"], kw["cp_size"],
                                    kw["num_used"])
     assert relerr(a, g["eq"]) < 1e-12 and relerr(b, a) < 1e-12
+
+
+def test_block_diagonalisation_without_svd_equals_the_reference_up_to_stream_phases():
+    """The kernels' formulation (inverse + small Hermitian eigen-problems, oracle/bd.py) against the
+    reference's precoders stored in the fixture: same singular values, same columns once each column's
+    phase is made canonical, block-diagonal newH, and W = pinv(newH) including switched-off streams."""
+    from oracle import bd
+    dropped = 0
+    for kw, reals in golden_cases("f6_block_diag"):
+        K = kw["K"]
+        for g in reals:
+            H, Ms_ref = g["big_H"], g["Ms"]
+            newH, Ms, W = bd.block_diagonalize_closed(H, K, kw["iPu"], kw["bd_noise_var"], kw["waterfill"])
+            assert relerr(bd.canonical_columns(Ms_ref), Ms) <= 1e-9
+            assert relerr(np.abs(newH), np.abs(g["newH"])) <= 1e-9
+            assert relerr(np.abs(W), np.abs(g["W"])) <= 1e-8 * max(1.0, np.max(np.abs(g["W"])))
+            r = H.shape[0] // K
+            off = newH.copy()
+            for k in range(K):
+                off[k * r:(k + 1) * r, k * r:(k + 1) * r] = 0
+            assert np.max(np.abs(off)) <= 1e-10 * np.max(np.abs(newH))
+            dropped += int(np.sum(np.sum(np.abs(Ms), axis=0) == 0))
+    assert dropped > 0          # the fixture exercises water-filling that switches streams off
+
+
+def test_waterfilling_known_answers():
+    """doWF known answer of the reference (tests/comm_package_test.py:47-85) plus two hand-checked cases."""
+    from oracle import bd
+    gains = np.array([1.90, 1.76, 1.76, 1.35, 1.35, .733, .733, .100]) ** 2
+    P, mu = bd.waterfilling(gains, 8.0, 0.181)
+    assert abs(P.sum() - 8.0) < 1e-12 and abs(mu - 1.29134061296) < 1e-9
+    np.testing.assert_array_almost_equal(P, [1.24120211, 1.23290828, 1.23290828, 1.19202648, 1.19202648,
+                                             0.95446418, 0.95446418, 0.])
+    P, mu = bd.waterfilling(np.array([1.0, 0.5, 0.25]), 3.0, 1.0)
+    assert np.allclose(P, [2.0, 1.0, 0.0]) and abs(mu - 3.0) < 1e-12
+    P, mu = bd.waterfilling(np.array([0.01, 1.0]), 1.0, 1.0)
+    assert np.array_equal(P, [0.0, 1.0]) and mu == 2.0
