@@ -351,6 +351,43 @@ int mcle_ia_iterative(mcle_ctx* ctx, int solver, int initialize_with, const void
                       void* d_F, void* d_U, double* d_sinr, double* d_capacity, uint32_t* d_iterations,
                       uint32_t* d_skipped, size_t batch);
 
+/* ---- block diagonalisation of a multi-user downlink (SURVEY 8(f).3 tail) --------------------
+ * comm/waterfilling.py:15-92 doWF: d_gains [batch][n] channel POWER gains -> optimum powers
+ * d_powers [batch][n] (same order) and the water level d_mu [batch] (may be NULL); n <= 64. */
+int mcle_waterfilling(mcle_ctx* ctx, const double* d_gains, int n, double total_power, double noise_var,
+                      double* d_powers, double* d_mu, size_t batch);
+/* comm/blockdiagonalization.py:466-508 BlockDiagonalizer.block_diagonalize (waterfilling = 1: water-filling
+ * over all streams normalised to the strongest user block, :403-464) or :510-566
+ * block_diagonalize_no_waterfilling (waterfilling = 0), plus :568-585 calc_receive_filter, f64 only, on
+ * injected channels d_H [batch][n][n] (row-major, n = num_users * n_rx_per_user <= 8, square: as many
+ * transmit as receive antennas).  Outputs (each may be NULL): precoder d_Ms [batch][n][n], d_newH = H Ms
+ * [batch][n][n], zero-forcing filter d_W = pinv(newH) [batch][n][n], singular values of the users'
+ * equivalent channels d_sigma [batch][n] (ascending per user, the reference's Sigma), d_skipped [batch] =
+ * 1 for a numerically singular channel.  Singular vectors are unique up to one phase per stream; this
+ * entry point returns the representative whose largest entry per Ms column is real positive. */
+int mcle_block_diagonalize(mcle_ctx* ctx, const void* d_H, int num_users, int n_rx_per_user, double iPu,
+                           double noise_var, int waterfilling, void* d_Ms, void* d_newH, void* d_W,
+                           double* d_sigma, uint32_t* d_skipped, size_t batch);
+
+/* np.linalg.pinv (the receive filter of blockdiagonalization.py:568-585 for any newH): d_A [batch][m][n] ->
+ * d_out [batch][n][m], f64, m, n <= 8; singular values <= rcond * max are dropped (numpy's default 1e-15). */
+int mcle_pinv(mcle_ctx* ctx, const void* d_A, int m, int n, double rcond, void* d_out, size_t batch);
+
+typedef struct mcle_bd_cfg {            /* apps/comp_BD/simulate_comp_simple.py:95-140 (no external interference) */
+    int32_t K, nr;                      /* K cells/users of nr x nr antennas: channel (K nr) x (K nr), K nr <= 8 */
+    int32_t n_symbols;                  /* NSymbs per stream (K nr streams) */
+    int32_t demod_method;
+    int32_t waterfilling;               /* 1: block_diagonalize, 0: block_diagonalize_no_waterfilling */
+    int32_t has_pathloss;               /* 1: block (rx k, tx l) scaled by sqrt(pathloss[k*K + l]) (multiuser.py:256-292) */
+    double iPu;                         /* power per user */
+    double noise_var;                   /* channel noise variance */
+    double bd_noise_var;                /* noise variance handed to the water-filling (the app passes 1e-50) */
+    double pathloss[16];
+} mcle_bd_cfg;
+/* Fused: channel draw, block diagonalisation, precoding, channel + noise, zero forcing, demodulation, counts. */
+int mcle_run_bd(mcle_ctx* ctx, int dtype, const mcle_bd_cfg* cfg, uint64_t seed, uint64_t first,
+                uint64_t count, mcle_counters* d_counters, uint32_t* d_sym_err, uint32_t* d_bit_err);
+
 /* ---- same-seed parity mode: NumPy's legacy global RandomState replayed on the device -------
  * Realization r receives exactly what the reference draws after np.random.seed(seed_base + r)
  * (legacy MT19937; util/misc.py:327-355 randn_c = randn real block then imag block, and

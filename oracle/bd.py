@@ -152,8 +152,7 @@ def bd_no_power_scaling_closed(H, K):
 
 
 def block_diagonalize_closed(H, K, iPu, noise_var, waterfill=True):
-    """(newH, Ms, W) the way the kernels compute them; W = pinv(newH) built block by block (rows of streams
-    that the water-filling switched off are zero, as numpy's pinv returns for a zero column)."""
+    """(newH, Ms, W) the way the kernels compute them; W = pinv(newH) built stream by stream."""
     H = np.asarray(H, dtype=complex)
     n = H.shape[0]
     r = n // K
@@ -164,8 +163,13 @@ def block_diagonalize_closed(H, K, iPu, noise_var, waterfill=True):
         Ms = np.hstack([Ms_bad[:, k * r:(k + 1) * r] * np.sqrt(iPu) / np.linalg.norm(Ms_bad[:, k * r:(k + 1) * r])
                         for k in range(K)])
     newH = H @ Ms
+    # inside a user's block the columns of newH are orthogonal (H_k V_k = U Sigma), so pinv is the scaled
+    # conjugate transpose; a switched-off stream (zero column) gets the zero row numpy's pinv returns
     W = np.zeros((n, n), dtype=complex)
     for k in range(K):
-        blk = newH[k * r:(k + 1) * r, k * r:(k + 1) * r]
-        W[k * r:(k + 1) * r, k * r:(k + 1) * r] = np.linalg.pinv(blk)
+        for j in range(k * r, (k + 1) * r):
+            b = newH[k * r:(k + 1) * r, j]
+            n2 = float(np.sum(np.abs(b) ** 2))
+            if n2 > 0.0:
+                W[j, k * r:(k + 1) * r] = np.conj(b) / n2
     return newH, Ms, W

@@ -85,6 +85,12 @@ class IaCfg(Structure):
                 ("reserved", c_int32)]
 
 
+class BdCfg(Structure):
+    _fields_ = [("K", c_int32), ("nr", c_int32), ("n_symbols", c_int32), ("demod_method", c_int32),
+                ("waterfilling", c_int32), ("has_pathloss", c_int32), ("iPu", c_double), ("noise_var", c_double),
+                ("bd_noise_var", c_double), ("pathloss", c_double * 16)]
+
+
 IA_INITS = {"random": 0, "fix": 0, "closed_form": 1, "alt_min": 2}
 IA_SOLVERS = {"closed_form": 0, "alt_min": 1, "min_leakage": 2, "max_sinr": 3, "mmse": 4}
 
@@ -163,6 +169,10 @@ _PROTOS = {
     "mcle_ia_iterative": (c_int, [_P, c_int, c_int, _P, _P, c_double, c_int, c_double, _P, _P, _P, _P, _P, _P,
                                   c_size_t]),
     "mcle_ia_closed_form": (c_int, [_P, _P, c_double, _P, _P, _P, _P, _P, c_size_t]),
+    "mcle_waterfilling": (c_int, [_P, _P, c_int, c_double, c_double, _P, _P, c_size_t]),
+    "mcle_block_diagonalize": (c_int, [_P, _P, c_int, c_int, c_double, c_double, c_int, _P, _P, _P, _P, _P, c_size_t]),
+    "mcle_pinv": (c_int, [_P, _P, c_int, c_int, c_double, _P, c_size_t]),
+    "mcle_run_bd": (c_int, [_P, c_int, POINTER(BdCfg), c_uint64, c_uint64, c_uint64, _P, _P, _P]),
     "mcle_legacy_draws": (c_int, [_P, POINTER(LegacySeg), c_int, c_uint32, c_uint64, c_uint64, _P, c_size_t, _P,
                                   c_size_t, _P]),
     "mcle_complex_from_parts": (c_int, [_P, c_int, _P, _P, c_double, _P, c_size_t]),

@@ -1,0 +1,535 @@
+// kernels_bd.hip -- block diagonalisation of a multi-user MIMO downlink, water-filling, and the fused
+// CoMP pipeline built on them.
+//
+// Reference: comm/waterfilling.py:15-92 (doWF); comm/blockdiagonalization.py:272-363
+// (_calc_BD_matrix_no_power_scaling), :365-464 (global / normalised water-filling power scaling), :466-508
+// (block_diagonalize), :510-566 (block_diagonalize_no_waterfilling), :568-585 (calc_receive_filter);
+// channels/multiuser.py:256-292 (path loss), :1179-1221 (corrupt_concatenated_data);
+// apps/comp_BD/simulate_comp_simple.py:95-140 (the application).
+//
+// The reference takes two SVDs per user (null space of the other users' rows, then the equivalent
+// channel).  For the square case (as many transmit as receive antennas -- the only one in which the
+// reference's stream count, blockdiagonalization.py:332, equals the null-space dimension) the same
+// precoder follows from ONE LQ factorisation H = L Q shared by all users:
+//     H^-1 = Q^H M,  M = L^-1 (lower triangular);   Z_k = Q^H M_k  (columns of user k)
+//     Z_k^H Z_k = M_k^H M_k = [(H H^H)^-1]_kk = (H_k P0_k H_k^H)^-1      (Schur complement)
+// so with the thin SVD M_k = U S V^H (one-sided Jacobi on r <= 4 columns) the right singular vectors of
+// the equivalent channel H_k V0_k are Q^H U and its singular values 1 / S.  Singular vectors are
+// unique up to a phase per column; the largest entry of every precoder column is made real positive
+// (oracle/bd.py: canonical_columns).  newH = H Ms has orthogonal columns inside each user's block, so
+// pinv(newH) is its scaled conjugate transpose, with zero rows for streams the water-filling switched off
+// (what numpy's pinv returns for a zero column).
+#include "modem.hpp"
+#include "philox.hpp"
+#include "pipe_common.hpp"
+#include "totals.hpp"
+
+namespace mcle {
+
+using cd = double2;
+constexpr int kBdMaxN = 8;                      // total antennas per side
+constexpr int kBdMaxR = 4;                      // antennas per user
+constexpr int kWfMaxN = 64;
+
+__device__ __forceinline__ double bd_abs2(cd z) { return z.x * z.x + z.y * z.y; }
+
+// doWF (waterfilling.py:15-92).  Channels sorted by descending gain (ascending stable sort reversed, which is
+// what np.argsort(...)[::-1] gives for these sizes); the worst channel is dropped until the powers that
+// touch its level fit the budget; the remainder is shared equally.  Sums run left to right like Python's sum.
+__device__ __noinline__ void bd_waterfill(const double* gains, int n, double total_power, double nv, double* P,
+                                          double* mu) {
+    int ord[kWfMaxN];
+    for (int i = 0; i < n; ++i) ord[i] = i;
+    for (int i = 1; i < n; ++i) {               // insertion sort, ascending, stable
+        const int v = ord[i];
+        int j = i - 1;
+        while (j >= 0 && gains[ord[j]] > gains[v]) {
+            ord[j + 1] = ord[j];
+            --j;
+        }
+        ord[j + 1] = v;
+    }
+    // descending position p <-> ord[n - 1 - p]
+    int removed = 0;
+    double sum = 0.0, level = 0.0;
+    for (;;) {
+        const int m = n - removed;
+        level = nv / gains[ord[n - m]];         // worst of the remaining channels: descending position m - 1
+        sum = 0.0;
+        for (int p = 0; p < m; ++p) sum += level - nv / gains[ord[n - 1 - p]];
+        if (sum > total_power && removed < n - 1)
+            ++removed;
+        else
+            break;
+    }
+    const int kept = n - removed;
+    const double share = (total_power - sum) / kept;
+    for (int i = 0; i < n; ++i) P[i] = 0.0;
+    for (int p = 0; p < kept; ++p) P[ord[n - 1 - p]] = share + (level - nv / gains[ord[n - 1 - p]]);
+    if (mu) *mu = P[ord[n - 1]] + nv / gains[ord[n - 1]];
+}
+
+// One-sided (Hestenes) Jacobi on the columns of A [rows x cols, row-major]: on return the columns are mutually
+// orthogonal (A <- A V); V [cols x cols] (may be NULL) accumulates the rotations.
+__device__ __noinline__ void bd_jacobi(cd* A, int rows, int cols, cd* V) {
+    if (V)
+        for (int i = 0; i < cols; ++i)
+            for (int c = 0; c < cols; ++c) V[i * cols + c] = mk<double>(i == c ? 1.0 : 0.0, 0.0);
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        double off = 0.0;
+        for (int p = 0; p < cols - 1; ++p)
+            for (int q = p + 1; q < cols; ++q) {
+                double alpha = 0, beta = 0;
+                cd gam = mk<double>(0, 0);
+                for (int i = 0; i < rows; ++i) {
+                    alpha += bd_abs2(A[i * cols + p]);
+                    beta += bd_abs2(A[i * cols + q]);
+                    gam = cadd(gam, cmulc(A[i * cols + q], A[i * cols + p]));     // a_p^H a_q
+                }
+                const double g = sqrt(bd_abs2(gam));
+                const double rel = g / (sqrt(alpha * beta) + 1e-300);
+                off = fmax(off, rel);
+                // orthogonal to rounding (or a zero column): leave the pair alone
+                if (!(rel >= 1e-15) || !(g > 0.0)) continue;
+                const cd ph = mk<double>(gam.x / g, -gam.y / g);                  // e^{-j phi}
+                const double zeta = (beta - alpha) / (2.0 * g);
+                const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+                for (int i = 0; i < rows; ++i) {
+                    const cd ap = A[i * cols + p], aq = cmul(A[i * cols + q], ph);
+                    A[i * cols + p] = csub(cscale(ap, c), cscale(aq, s));
+                    A[i * cols + q] = cadd(cscale(ap, s), cscale(aq, c));
+                }
+                if (V)
+                    for (int i = 0; i < cols; ++i) {
+                        const cd vp = V[i * cols + p], vq = cmul(V[i * cols + q], ph);
+                        V[i * cols + p] = csub(cscale(vp, c), cscale(vq, s));
+                        V[i * cols + q] = cadd(cscale(vp, s), cscale(vq, c));
+                    }
+            }
+        if (off < 1e-15) break;
+    }
+}
+
+// Block diagonalisation of H [n x n row-major], n = K * r.  On return Ms [n x n] is the power-scaled precoder
+// and sigma [n] the singular values of the users' equivalent channels (ascending inside each user).
+// Q and L are n*n scratch.  Returns false for a numerically singular channel.
+__device__ __noinline__ bool bd_solve(const cd* H, int K, int r, double iPu, double nv, int waterfill, cd* Q, cd* L,
+                                      cd* Ms, double* sigma) {
+    const int n = K * r;
+    bool ok = true;
+    // ---- LQ by modified Gram-Schmidt on the rows, orthogonalised twice ----
+    for (int i = 0; i < n; ++i) {
+        double h2 = 0.0;
+        for (int c = 0; c < n; ++c) {
+            Q[i * n + c] = H[i * n + c];
+            h2 += bd_abs2(H[i * n + c]);
+        }
+        for (int j = 0; j < n; ++j) L[i * n + j] = mk<double>(0, 0);
+        for (int pass = 0; pass < 2; ++pass)
+            for (int j = 0; j < i; ++j) {
+                cd d = mk<double>(0, 0);
+                for (int c = 0; c < n; ++c) d = cadd(d, cmulc(Q[i * n + c], Q[j * n + c]));   // v . conj(q_j)
+                for (int c = 0; c < n; ++c) Q[i * n + c] = csub(Q[i * n + c], cmul(d, Q[j * n + c]));
+                L[i * n + j] = cadd(L[i * n + j], d);
+            }
+        double v2 = 0.0;
+        for (int c = 0; c < n; ++c) v2 += bd_abs2(Q[i * n + c]);
+        if (!(v2 > 1e-26 * h2) || !(h2 > 0.0)) {
+            ok = false;
+            v2 = 1.0;
+        }
+        const double nrm = sqrt(v2), inv = 1.0 / nrm;
+        L[i * n + i] = mk<double>(nrm, 0.0);
+        for (int c = 0; c < n; ++c) Q[i * n + c] = cscale(Q[i * n + c], inv);
+    }
+    // ---- M = L^-1 in place, column by column ----
+    for (int j = 0; j < n; ++j) {
+        L[j * n + j] = mk<double>(1.0 / L[j * n + j].x, 0.0);
+        for (int i = j + 1; i < n; ++i) {
+            cd acc = cmul(L[i * n + j], L[j * n + j]);                 // m = j term: L[i][j] * M[j][j]
+            for (int m = j + 1; m < i; ++m) acc = cadd(acc, cmul(L[i * n + m], L[m * n + j]));
+            const double inv = -1.0 / L[i * n + i].x;                  // L[i][i] still the original diagonal
+            L[i * n + j] = cscale(acc, inv);
+        }
+    }
+    // ---- per user: thin SVD of M_k by one-sided Jacobi, precoder columns Q^H u ----
+    for (int k = 0; k < K; ++k) {
+        cd A[kBdMaxN * kBdMaxR];               // rows k*r .. n-1 of M's columns k*r .. k*r+r-1 (the rest is zero)
+        const int r0 = k * r, rows = n - r0;
+        for (int i = 0; i < rows; ++i)
+            for (int c = 0; c < r; ++c) A[i * r + c] = (r0 + i >= r0 + c) ? L[(r0 + i) * n + r0 + c] : mk<double>(0, 0);
+        bd_jacobi(A, rows, r, nullptr);
+        double S[kBdMaxR];
+        int col[kBdMaxR];
+        for (int c = 0; c < r; ++c) {
+            double n2 = 0;
+            for (int i = 0; i < rows; ++i) n2 += bd_abs2(A[i * r + c]);
+            S[c] = sqrt(n2);
+            col[c] = c;
+        }
+        for (int i = 0; i < r - 1; ++i)                                         // descending S == ascending sigma
+            for (int j = i + 1; j < r; ++j)
+                if (S[col[j]] > S[col[i]]) {
+                    const int t = col[i];
+                    col[i] = col[j];
+                    col[j] = t;
+                }
+        for (int jj = 0; jj < r; ++jj) {
+            const int c = col[jj];
+            const double inv = 1.0 / S[c];
+            sigma[r0 + jj] = inv;
+            // v = Q^H u, u = A[:, c] / S[c] living on rows r0 ..
+            double best = -1.0;
+            cd piv = mk<double>(1.0, 0.0);
+            for (int m = 0; m < n; ++m) {
+                cd v = mk<double>(0, 0);
+                for (int i = 0; i < rows; ++i) v = cadd(v, cmulc(A[i * r + c], Q[(r0 + i) * n + m]));  // u_i conj(Q[i][m])
+                v = cscale(v, inv);
+                Ms[m * n + r0 + jj] = v;
+                const double m2 = bd_abs2(v);
+                if (m2 > best * (1.0 + 1e-12)) {
+                    best = m2;
+                    piv = v;
+                }
+            }
+            const double pm = sqrt(bd_abs2(piv));
+            const cd rot = mk<double>(piv.x / pm, -piv.y / pm);
+            for (int m = 0; m < n; ++m) Ms[m * n + r0 + jj] = cmul(Ms[m * n + r0 + jj], rot);
+        }
+    }
+    // ---- power scaling ----
+    if (waterfill) {
+        double gains[kBdMaxN], P[kBdMaxN];
+        for (int j = 0; j < n; ++j) gains[j] = sigma[j] * sigma[j];
+        bd_waterfill(gains, n, K * iPu, nv, P, nullptr);
+        double worst = 0.0;
+        for (int k = 0; k < K; ++k) {
+            double f2 = 0.0;
+            for (int j = k * r; j < (k + 1) * r; ++j) {
+                const double a = sqrt(P[j]);
+                for (int m = 0; m < n; ++m) {
+                    Ms[m * n + j] = cscale(Ms[m * n + j], a);
+                    f2 += bd_abs2(Ms[m * n + j]);
+                }
+            }
+            worst = fmax(worst, sqrt(f2));
+        }
+        const double scale = sqrt(iPu) / worst;
+        for (int e = 0; e < n * n; ++e) Ms[e] = cscale(Ms[e], scale);
+    } else {
+        for (int k = 0; k < K; ++k) {
+            double f2 = 0.0;
+            for (int j = k * r; j < (k + 1) * r; ++j)
+                for (int m = 0; m < n; ++m) f2 += bd_abs2(Ms[m * n + j]);
+            const double scale = sqrt(iPu) / sqrt(f2);
+            for (int j = k * r; j < (k + 1) * r; ++j)
+                for (int m = 0; m < n; ++m) Ms[m * n + j] = cscale(Ms[m * n + j], scale);
+        }
+    }
+    return ok;
+}
+
+// W = pinv(H Ms) [n x n, block diagonal]: row s = conj(newH[block rows, s]) / |.|^2, zero for a zero column.
+__device__ __noinline__ void bd_receive_filter(const cd* H, const cd* Ms, int K, int r, cd* W) {
+    const int n = K * r;
+    for (int e = 0; e < n * n; ++e) W[e] = mk<double>(0, 0);
+    for (int k = 0; k < K; ++k)
+        for (int j = 0; j < r; ++j) {
+            const int s = k * r + j;
+            cd b[kBdMaxR];
+            double n2 = 0.0;
+            for (int a = 0; a < r; ++a) {
+                cd acc = mk<double>(0, 0);
+                for (int m = 0; m < n; ++m) acc = cadd(acc, cmul(H[(k * r + a) * n + m], Ms[m * n + s]));
+                b[a] = acc;
+                n2 += bd_abs2(acc);
+            }
+            if (n2 > 0.0)
+                for (int a = 0; a < r; ++a) W[s * n + k * r + a] = mk<double>(b[a].x / n2, -b[a].y / n2);
+        }
+}
+
+__global__ __launch_bounds__(64) void k_waterfilling(const double* __restrict__ gains, int n, double total_power,
+                                                     double nv, double* __restrict__ P, double* __restrict__ mu,
+                                                     size_t batch) {
+    for (size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x; b < batch; b += (size_t)gridDim.x * blockDim.x) {
+        double g[kWfMaxN], p[kWfMaxN], level;
+        for (int i = 0; i < n; ++i) g[i] = gains[b * n + i];
+        bd_waterfill(g, n, total_power, nv, p, &level);
+        for (int i = 0; i < n; ++i) P[b * n + i] = p[i];
+        if (mu) mu[b] = level;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_block_diagonalize(const cd* __restrict__ Hin, int K, int r, double iPu, double nv,
+                                                          int waterfill, cd* __restrict__ Ms_out,
+                                                          cd* __restrict__ newH_out, cd* __restrict__ W_out,
+                                                          double* __restrict__ sigma_out,
+                                                          uint32_t* __restrict__ skipped, size_t batch) {
+    const int n = K * r, nn = n * n;
+    for (size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x; b < batch; b += (size_t)gridDim.x * blockDim.x) {
+        cd H[kBdMaxN * kBdMaxN], Q[kBdMaxN * kBdMaxN], L[kBdMaxN * kBdMaxN], Ms[kBdMaxN * kBdMaxN];
+        double sigma[kBdMaxN];
+        for (int e = 0; e < nn; ++e) H[e] = Hin[b * nn + e];
+        const bool ok = bd_solve(H, K, r, iPu, nv, waterfill, Q, L, Ms, sigma);
+        if (Ms_out)
+            for (int e = 0; e < nn; ++e) Ms_out[b * nn + e] = Ms[e];
+        if (newH_out)
+            for (int i = 0; i < n; ++i)
+                for (int c = 0; c < n; ++c) {
+                    cd acc = mk<double>(0, 0);
+                    for (int m = 0; m < n; ++m) acc = cadd(acc, cmul(H[i * n + m], Ms[m * n + c]));
+                    newH_out[b * nn + i * n + c] = acc;
+                }
+        if (W_out) {
+            bd_receive_filter(H, Ms, K, r, Q);              // Q is free again
+            for (int e = 0; e < nn; ++e) W_out[b * nn + e] = Q[e];
+        }
+        if (sigma_out)
+            for (int j = 0; j < n; ++j) sigma_out[b * n + j] = sigma[j];
+        if (skipped) skipped[b] = ok ? 0u : 1u;
+    }
+}
+
+// np.linalg.pinv for small matrices: A [m x n] -> [n x m] = V diag(1/s) U^H over the singular values above
+// rcond * max(s) (numpy's default cut-off 1e-15).  With A V = U S from the column Jacobi: pinv = V S^-2 (A V)^H.
+__global__ __launch_bounds__(64) void k_pinv(const cd* __restrict__ Ain, int m, int n, double rcond,
+                                             cd* __restrict__ out, size_t batch) {
+    for (size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x; b < batch; b += (size_t)gridDim.x * blockDim.x) {
+        cd A[kBdMaxN * kBdMaxN], V[kBdMaxN * kBdMaxN];
+        double s2[kBdMaxN];
+        for (int e = 0; e < m * n; ++e) A[e] = Ain[b * m * n + e];
+        bd_jacobi(A, m, n, V);
+        double top = 0.0;
+        for (int c = 0; c < n; ++c) {
+            double v = 0.0;
+            for (int i = 0; i < m; ++i) v += bd_abs2(A[i * n + c]);
+            s2[c] = v;
+            top = fmax(top, v);
+        }
+        const double cut = rcond * rcond * top;
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < m; ++j) {
+                cd acc = mk<double>(0, 0);
+                for (int c = 0; c < n; ++c)
+                    if (s2[c] > cut && s2[c] > 0.0) acc = cadd(acc, cscale(cmulc(V[i * n + c], A[j * n + c]), 1.0 / s2[c]));
+                out[b * n * m + i * m + j] = acc;
+            }
+    }
+}
+
+struct BdParams {
+    int K, r, n_symbols, waterfill, has_pathloss;
+    double iPu, noise_var, bd_noise_var;
+    double root_pl[16];
+};
+
+// Fused CoMP application: one wavefront per chunk of 64 realizations (as k_run_ia).  Phase 1: lane i draws the
+// channel of realization i, block-diagonalises it in f64 and parks two n x n matrices in LDS: C = W H Ms (the
+// end-to-end map from the transmitted symbols to the estimates; the identity on the active streams up to
+// rounding) and W.  Phase 2: the wave runs the realization's symbol columns: est = C s + W (sigma n).
+template <typename T>
+__global__ __launch_bounds__(64) void k_run_bd(ModemParams<T> mp, BdParams pp, uint64_t seed, uint64_t first,
+                                               uint64_t count, mcle_counters* counters,
+                                               uint32_t* __restrict__ sym_out, uint32_t* __restrict__ bit_out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int n = pp.K * pp.r, nn = n * n;
+    const int stride = 2 * nn + 1;                               // per-realization record, odd: lanes on distinct banks
+    cx<T>* s_rec = reinterpret_cast<cx<T>*>(smem);               // [64][stride]: C then W
+    unsigned long long* s_grid = reinterpret_cast<unsigned long long*>(s_rec + 64 * stride);
+    __shared__ cx<T> s_table[256];
+    __shared__ unsigned s_ok[64];
+    __shared__ WgTotals totals;
+    load_table(mp, s_table);
+    load_grid(mp, s_grid);
+    const int lane = threadIdx.x;
+    const T sigma = (T)sqrt(pp.noise_var);
+    const uint32_t mask = (uint32_t)(mp.M - 1);
+    const int NS = pp.n_symbols;
+    if (threadIdx.x == 0) wg_zero(totals);
+    const uint64_t n_chunks = (count + 63) / 64;
+    for (uint64_t ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
+        __syncthreads();
+        {
+            const uint64_t rl = ch * 64 + lane;
+            if (rl < count) {
+                const Rng rng(seed, first + rl);
+                cd H[kBdMaxN * kBdMaxN], Q[kBdMaxN * kBdMaxN], L[kBdMaxN * kBdMaxN], Ms[kBdMaxN * kBdMaxN];
+                double sg[kBdMaxN];
+                for (int i = 0; i < n; ++i)
+                    for (int c = 0; c < n; ++c) {
+                        cd h = cn_sample<double>(rng, STREAM_CHAN, (uint64_t)(i * n + c), 1.0);
+                        if (pp.has_pathloss) h = cscale(h, pp.root_pl[(i / pp.r) * pp.K + c / pp.r]);
+                        H[i * n + c] = h;
+                    }
+                const bool ok = bd_solve(H, pp.K, pp.r, pp.iPu, pp.bd_noise_var, pp.waterfill, Q, L, Ms, sg);
+                bd_receive_filter(H, Ms, pp.K, pp.r, Q);         // W in Q
+                cx<T>* rec = s_rec + lane * stride;
+                for (int s = 0; s < n; ++s) {
+                    cd t[kBdMaxN];                               // t = W[s, :] H
+                    for (int m = 0; m < n; ++m) {
+                        cd acc = mk<double>(0, 0);
+                        for (int a = 0; a < n; ++a) acc = cadd(acc, cmul(Q[s * n + a], H[a * n + m]));
+                        t[m] = acc;
+                    }
+                    for (int c = 0; c < n; ++c) {
+                        cd acc = mk<double>(0, 0);
+                        for (int m = 0; m < n; ++m) acc = cadd(acc, cmul(t[m], Ms[m * n + c]));
+                        rec[s * n + c] = mk<T>((T)acc.x, (T)acc.y);
+                        rec[nn + s * n + c] = mk<T>((T)Q[s * n + c].x, (T)Q[s * n + c].y);
+                    }
+                }
+                s_ok[lane] = ok ? 1u : 0u;
+            }
+        }
+        __syncthreads();
+        const int in_chunk = (int)((count - ch * 64) < 64 ? (count - ch * 64) : 64);
+        for (int j = 0; j < in_chunk; ++j) {
+            const uint64_t rl = ch * 64 + j;
+            const Rng rng(seed, first + rl);
+            const cx<T>* C = s_rec + j * stride;
+            const cx<T>* W = C + nn;
+            unsigned se = 0, be = 0;
+            for (int t = lane; t < NS; t += 64) {
+                int tx[kBdMaxN];
+                cx<T> sym[kBdMaxN], nz[kBdMaxN];
+#pragma unroll
+                for (int a = 0; a < kBdMaxN; ++a)
+                    if (a < n) {
+                        tx[a] = (int)symbol_at(rng, (uint64_t)a * NS + t, mask);      // randint(0, M, [n, NSymbs])
+                        sym[a] = s_table[tx[a]];
+                        nz[a] = cn_sample<T>(rng, STREAM_NOISE, (uint64_t)a * NS + t, sigma);
+                    }
+#pragma unroll
+                for (int s = 0; s < kBdMaxN; ++s)
+                    if (s < n) {
+                        cx<T> est = mk<T>(0, 0);
+#pragma unroll
+                        for (int a = 0; a < kBdMaxN; ++a)
+                            if (a < n) {
+                                est = cfma(C[s * n + a], sym[a], est);
+                                est = cfma(W[s * n + a], nz[a], est);
+                            }
+                        const unsigned x = (unsigned)(tx[s] ^ demod_one(mp, s_table, s_grid, est));
+                        se += (x != 0u);
+                        be += __popc(x);
+                    }
+            }
+            se = wave_sum_u32(se);
+            be = wave_sum_u32(be);
+            if (lane == 0) wg_account(totals, se, be, s_ok[j] == 0u, rl, sym_out, bit_out);
+        }
+    }
+    if (lane == 0)
+        wg_flush(totals, counters, (unsigned long long)n * NS, (unsigned long long)n * NS * mp.bits);
+}
+
+static int check_bd_dims(int K, int r) {
+    MCLE_REQUIRE(K >= 1 && r >= 1 && r <= kBdMaxR && K * r <= kBdMaxN,
+                 "block diagonalisation supports num_users * antennas <= %d with at most %d antennas per user "
+                 "(got %d users x %d)", kBdMaxN, kBdMaxR, K, r);
+    return MCLE_OK;
+}
+
+}  // namespace mcle
+
+using namespace mcle;
+
+extern "C" {
+
+int mcle_waterfilling(mcle_ctx* ctx, const double* d_gains, int n, double total_power, double noise_var,
+                      double* d_powers, double* d_mu, size_t batch) {
+    MCLE_REQUIRE(ctx != nullptr && d_gains != nullptr && d_powers != nullptr, "null argument");
+    MCLE_REQUIRE(n >= 1 && n <= kWfMaxN, "number of parallel channels must be in [1, %d] (got %d)", kWfMaxN, n);
+    MCLE_REQUIRE(total_power > 0.0 && noise_var >= 0.0, "total power must be positive and the noise variance "
+                                                        "non-negative");
+    if (batch == 0) return MCLE_OK;
+    int rc = ctx->bind();
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_waterfilling, dim3(grid_for(ctx, batch, 64, 16)), dim3(64), 0, ctx->stream, d_gains, n,
+                       total_power, noise_var, d_powers, d_mu, batch);
+    MCLE_LAUNCH_CHECK();
+    return MCLE_OK;
+}
+
+int mcle_block_diagonalize(mcle_ctx* ctx, const void* d_H, int num_users, int n_rx_per_user, double iPu,
+                           double noise_var, int waterfilling, void* d_Ms, void* d_newH, void* d_W, double* d_sigma,
+                           uint32_t* d_skipped, size_t batch) {
+    MCLE_REQUIRE(ctx != nullptr && d_H != nullptr, "null argument");
+    int rc = check_bd_dims(num_users, n_rx_per_user);
+    if (rc) return rc;
+    MCLE_REQUIRE(iPu > 0.0, "the power per user must be positive");
+    MCLE_REQUIRE(noise_var >= 0.0, "noise variance must be non-negative");
+    if (batch == 0) return MCLE_OK;
+    if ((rc = ctx->bind())) return rc;
+    hipLaunchKernelGGL(k_block_diagonalize, dim3(grid_for(ctx, batch, 64, 16)), dim3(64), 0, ctx->stream,
+                       (const double2*)d_H, num_users, n_rx_per_user, iPu, noise_var, waterfilling ? 1 : 0,
+                       (double2*)d_Ms, (double2*)d_newH, (double2*)d_W, d_sigma, d_skipped, batch);
+    MCLE_LAUNCH_CHECK();
+    return MCLE_OK;
+}
+
+int mcle_pinv(mcle_ctx* ctx, const void* d_A, int m, int n, double rcond, void* d_out, size_t batch) {
+    MCLE_REQUIRE(ctx != nullptr && d_A != nullptr && d_out != nullptr, "null argument");
+    MCLE_REQUIRE(m >= 1 && n >= 1 && m <= kBdMaxN && n <= kBdMaxN, "pinv supports matrices up to %d x %d (got %d x %d)",
+                 kBdMaxN, kBdMaxN, m, n);
+    MCLE_REQUIRE(rcond >= 0.0, "rcond must be non-negative");
+    if (batch == 0) return MCLE_OK;
+    int rc = ctx->bind();
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_pinv, dim3(grid_for(ctx, batch, 64, 16)), dim3(64), 0, ctx->stream, (const double2*)d_A, m, n,
+                       rcond, (double2*)d_out, batch);
+    MCLE_LAUNCH_CHECK();
+    return MCLE_OK;
+}
+
+int mcle_run_bd(mcle_ctx* ctx, int dtype, const mcle_bd_cfg* cfg, uint64_t seed, uint64_t first, uint64_t count,
+                mcle_counters* d_counters, uint32_t* d_sym_err, uint32_t* d_bit_err) {
+    int rc = check_pipe(ctx, dtype, cfg ? cfg->demod_method : 0, cfg);
+    if (rc) return rc;
+    if ((rc = check_bd_dims(cfg->K, cfg->nr))) return rc;
+    MCLE_REQUIRE(cfg->n_symbols >= 1, "n_symbols must be positive");
+    MCLE_REQUIRE(cfg->iPu > 0.0, "the power per user must be positive");
+    MCLE_REQUIRE(cfg->noise_var >= 0.0 && cfg->bd_noise_var >= 0.0, "noise variances must be non-negative");
+    MCLE_REQUIRE(count <= 0x7fffffffull, "at most 2^31-1 realizations per call");
+    BdParams pp;
+    pp.K = cfg->K;
+    pp.r = cfg->nr;
+    pp.n_symbols = cfg->n_symbols;
+    pp.waterfill = cfg->waterfilling ? 1 : 0;
+    pp.has_pathloss = cfg->has_pathloss ? 1 : 0;
+    pp.iPu = cfg->iPu;
+    pp.noise_var = cfg->noise_var;
+    pp.bd_noise_var = cfg->bd_noise_var;
+    for (int i = 0; i < 16; ++i) {
+        const bool used = pp.has_pathloss && i < cfg->K * cfg->K;      // [K][K] row-major: rx user, tx user
+        if (used) MCLE_REQUIRE(cfg->pathloss[i] >= 0.0, "path loss must be non-negative");
+        pp.root_pl[i] = used ? std::sqrt(cfg->pathloss[i]) : 1.0;
+    }
+    if (count == 0) return MCLE_OK;
+    if ((rc = ctx->bind())) return rc;
+    const int n = cfg->K * cfg->nr;
+    const size_t esz = dtype == MCLE_F32 ? sizeof(float2) : sizeof(double2);
+    const size_t rec = (size_t)64 * (2 * n * n + 1);
+    const int G = dtype == MCLE_F32 ? pipe_modem<float>(ctx, cfg->demod_method).grid.G : 0;
+    const size_t lds = rec * esz + (size_t)G * G * sizeof(unsigned long long);
+    const uint64_t cap = (uint64_t)ctx->n_cu * 16;
+    const uint64_t chunks = (count + 63) / 64;
+    const unsigned grid = (unsigned)(chunks < cap ? chunks : cap);
+    if (dtype == MCLE_F32) {
+        MCLE_HIP(hipFuncSetAttribute((const void*)k_run_bd<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_run_bd<float>, dim3(grid), dim3(64), lds, ctx->stream,
+                           pipe_modem<float>(ctx, cfg->demod_method), pp, seed, first, count, d_counters, d_sym_err,
+                           d_bit_err);
+    } else {
+        MCLE_HIP(hipFuncSetAttribute((const void*)k_run_bd<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_run_bd<double>, dim3(grid), dim3(64), lds, ctx->stream,
+                           pipe_modem<double>(ctx, cfg->demod_method), pp, seed, first, count, d_counters, d_sym_err,
+                           d_bit_err);
+    }
+    MCLE_LAUNCH_CHECK();
+    return MCLE_OK;
+}
+
+}  // extern "C"

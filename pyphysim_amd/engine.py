@@ -724,6 +724,65 @@ class Engine:
                                            sk.ptr, b))
         return dict(F=F.get(), U=U.get(), sinr=sinr.get(), capacity=cap.get(), skipped=sk.get())
 
+    # ---- block diagonalisation (comm/blockdiagonalization.py, comm/waterfilling.py) -------------
+    def waterfilling(self, gains, total_power, noise_var=1.0):
+        """doWF (waterfilling.py:15-92) on gains [batch, n] (or [n]) -> (powers, water levels)."""
+        g = np.ascontiguousarray(gains, dtype=np.float64)
+        single = g.ndim == 1
+        g = g.reshape(1, -1) if single else g.reshape(g.shape[0], -1)
+        b, n = g.shape
+        d_g = self.to_device(g)
+        P, mu = self.empty((b, n), np.float64), self.empty(b, np.float64)
+        self._raise_value(self.lib.mcle_waterfilling(self.ctx, d_g.ptr, n, float(total_power), float(noise_var),
+                                                     P.ptr, mu.ptr, b))
+        P, mu = P.get(), mu.get()
+        return (P[0], float(mu[0])) if single else (P, mu)
+
+    def block_diagonalize(self, H, num_users, iPu, noise_var, waterfilling=True):
+        """BlockDiagonalizer.block_diagonalize / block_diagonalize_no_waterfilling + calc_receive_filter on
+        H [batch, n, n] (n = num_users * antennas per user) -> dict(Ms, newH, W, sigma, skipped)."""
+        H = np.ascontiguousarray(H, dtype=np.complex128)
+        if H.ndim == 2:
+            H = H[None]
+        b, n, n2 = H.shape
+        if n != n2 or n % int(num_users):
+            raise ValueError("block diagonalisation needs a square channel whose size is a multiple of num_users")
+        d_H = self.to_device(H)
+        Ms, newH, W = (self.empty((b, n, n), np.complex128) for _ in range(3))
+        sg, sk = self.empty((b, n), np.float64), self.empty(b, np.uint32)
+        self._raise_value(self.lib.mcle_block_diagonalize(self.ctx, d_H.ptr, int(num_users), n // int(num_users),
+                                                          float(iPu), float(noise_var), 1 if waterfilling else 0,
+                                                          Ms.ptr, newH.ptr, W.ptr, sg.ptr, sk.ptr, b))
+        return dict(Ms=Ms.get(), newH=newH.get(), W=W.get(), sigma=sg.get(), skipped=sk.get())
+
+    def pinv(self, A, rcond=1e-15):
+        """np.linalg.pinv for small matrices [batch, m, n] (or [m, n]), m, n <= 8."""
+        A = np.ascontiguousarray(A, dtype=np.complex128)
+        single = A.ndim == 2
+        if single:
+            A = A[None]
+        b, m, n = A.shape
+        d_A, out = self.to_device(A), self.empty((b, n, m), np.complex128)
+        self._raise_value(self.lib.mcle_pinv(self.ctx, d_A.ptr, m, n, float(rcond), out.ptr, b))
+        out = out.get()
+        return out[0] if single else out
+
+    def run_bd(self, K, nr, n_symbols, iPu, noise_var, seed, first, count, bd_noise_var=1e-50, pathloss=None,
+               waterfilling=True, method=DEMOD_MINDIST, dtype=None, per_realization=False, counters=None):
+        """apps/comp_BD/simulate_comp_simple.py:95-140 fused (no external interference): K cells of nr x nr
+        antennas, joint block-diagonalising precoder, zero forcing at the users; n_symbols per stream."""
+        cfg = _lib.BdCfg()
+        cfg.K, cfg.nr, cfg.n_symbols, cfg.demod_method = int(K), int(nr), int(n_symbols), int(method)
+        cfg.waterfilling, cfg.has_pathloss = (1 if waterfilling else 0), (0 if pathloss is None else 1)
+        cfg.iPu, cfg.noise_var, cfg.bd_noise_var = float(iPu), float(noise_var), float(bd_noise_var)
+        if pathloss is not None:
+            pl = np.asarray(pathloss, dtype=np.float64)
+            if pl.shape != (K, K) or K > 4:
+                raise ValueError("pathloss must be a [K, K] matrix (rx user, tx user), K <= 4")
+            for i, v in enumerate(pl.reshape(-1)):
+                cfg.pathloss[i] = float(v)
+        return self._run(self.lib.mcle_run_bd, cfg, seed, first, count, dtype, per_realization, counters)
+
     # ---- same-seed parity mode (NumPy legacy RandomState on the device) ----------------------
     def legacy_draws(self, program, seed_base, first, count):
         """program: list of ('randint', n, range) / ('randn', n) / ('rand', n).  Realization r gets

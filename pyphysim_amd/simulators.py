@@ -183,6 +183,32 @@ class MimoSimulator(_LinkSimulator):
                                  per_realization=per_realization)
 
 
+class BdSimulator(_LinkSimulator):
+    """apps/comp_BD/simulate_comp_simple.py:22-140 (no external interference source): K cells with Nr x Nr antennas
+    each transmit jointly through a block-diagonalising precoder (water-filling normalised to the strongest cell,
+    BlockDiagonalizer.block_diagonalize) and every user zero-forces with pinv(newH).  As in the app the noise
+    power is fixed and SNR sets the transmit power: iPu = dB2Linear(SNR) * noise_var / path_loss_border."""
+
+    def __init__(self, SNR, modulator="psk", M=4, K=3, Nr=2, NSymbs=500, noise_var=None, path_loss_border=1.0,
+                 pathloss=None, bd_noise_var=1e-50, waterfilling=True, **kw):
+        super().__init__(SNR, modulator, M, **kw)
+        for k, v in (("K", int(K)), ("Nr", int(Nr)), ("NSymbs", int(NSymbs)), ("waterfilling", bool(waterfilling))):
+            self.params.add(k, v)
+        # conversion.dBm2Linear(-116.4): the app's N0 (simulate_comp_simple.py:42,62)
+        self.noise_var = float(noise_var) if noise_var is not None else 10.0 ** ((-116.4 - 30.0) / 10.0)
+        self.path_loss_border = float(path_loss_border)
+        self.pathloss = None if pathloss is None else np.asarray(pathloss, dtype=float)
+        self.bd_noise_var = float(bd_noise_var)
+
+    def _launch(self, current_parameters, first_rep, count, per_realization):
+        p = current_parameters
+        eng = self._bind()
+        iPu = float(dB2Linear(p["SNR"])) * self.noise_var / self.path_loss_border
+        return eng.run_bd(p["K"], p["Nr"], p["NSymbs"], iPu, self.noise_var, self._seed_for(p), first_rep, count,
+                          bd_noise_var=self.bd_noise_var, pathloss=self.pathloss, waterfilling=p["waterfilling"],
+                          method=self.demod_method, dtype=self.dtype, per_realization=per_realization)
+
+
 class MimoOfdmTdlSimulator(_LinkSimulator):
     """spatial multiplexing over a frequency-selective MIMO TDL channel
     (TdlMimoChannel fading.py:1290-1333, MIMO branch of corrupt_data :1107-1117), per-antenna OFDM and one
