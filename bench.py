@@ -28,10 +28,12 @@ if REPO not in sys.path:
 
 # algorithmic bytes per realization in the staged (operator-granular)
 # model, complex64 samples / uint8 indices.
-B_ALG = {"c2": 7_600_000, "c3": 211_360, "c4": 412_160, "c5": 62_000, "f1": 3_099_008}
+B_ALG = {"c2": 7_600_000, "c3": 211_360, "c4": 412_160, "c5": 62_000, "f1": 3_099_008,
+         # f6 (6 streams x 500 symbols): gen+mod 27 000; precode, channel, filter 48 000 each; demod 27 000; count 6 000
+         "f6": 204_000}
 HBM_PEAK_GBPS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
 SEED = 20260927
-SNR_DB = {"c1": 10.0, "c2": 20.0, "c3": 20.0, "c4": 25.0, "c5": 20.0, "f1": 25.0}
+SNR_DB = {"c1": 10.0, "c2": 20.0, "c3": 20.0, "c4": 25.0, "c5": 20.0, "f1": 25.0, "f6": 15.0}
 F1_TS = 1.0 / (15e3 * 1024)
 F1_TAPS_DB = (0.0, -3.0, -6.0, -9.0, -12.0)
 
@@ -41,7 +43,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="c4", choices=["c2", "c3", "c4", "c5", "f1"])
+    ap.add_argument("--config", default="c4", choices=["c2", "c3", "c4", "c5", "f1", "f6"])
     ap.add_argument("--batch", type=int, default=0, help="realizations per GPU per step")
     ap.add_argument("--demod", default="slicer", choices=["slicer", "mindist"])
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
@@ -82,6 +84,14 @@ def make_runner(eng, cfg, demod, dtype):
                                   L=8, mmse=True, method=method, dtype=dtype, counters=counters)
         return run, 4096, ("4x4 MMSE per subcarrier + 64-QAM + OFDM(1024, cp 16) over a 5-tap Jakes MIMO TDL channel "
                            "(Fd 10 Hz), SNR 25 dB (SURVEY 8(f).1)")
+    if cfg == "f6":
+        eng.set_constellation(constellation("psk", 4), _lib.CONST_GENERIC)
+
+        def run(first, count, counters):
+            eng.run_bd(3, 2, 500, 1.0, nv, SEED, first, count, method=_lib.DEMOD_MINDIST, dtype=dtype,
+                       counters=counters)
+        return run, 3000, ("K=3 cells of 2x2 antennas, block-diagonalising precoder (water-filling) + zero forcing, "
+                           "4-PSK, 500 symbols/stream, SNR 15 dB (apps/comp_BD/simulate_comp_simple.py; SURVEY 8(f).3)")
     if cfg == "c5":
         eng.set_constellation(constellation("qam", 16), _lib.CONST_QAM)
 
@@ -99,12 +109,10 @@ def make_runner(eng, cfg, demod, dtype):
     return run, 1024, "QPSK + OFDM(1024, cp 16) over 5-tap Jakes TDL (Fd 10 Hz), one-tap EQ, SNR 20 dB (config 3)"
 
 
-def cpu_baseline(cfg, budget_s, gpu_first_counts):
-    """Time the NumPy oracle (a port of the reference's chain, oracle/chains.py) on ONE host core
-    for about `budget_s` seconds on the same workload and the same (seed, realization) keying;
-    also returns |SER_gpu - SER_oracle| on the realizations both sides computed."""
+def _oracle_chain(cfg):
+    """(oracle chain, kwargs) of a bench configuration -- used by the cpu_baseline legs only."""
     from oracle import chains
-    fn, kw = {
+    return {
         "c4": (chains.chain_mimo_ofdm, dict(mod="qam", M=64, nt=4, nr=4, fft_size=1024, cp_size=16, num_used=None,
                                            n_ofdm_sym=1, snr_db=25.0, mmse=True)),
         "c2": (chains.chain_flat_jakes, dict(mod="qam", M=64, N=100000, snr_db=20.0, Fd=100.0, Ts=1e-3, L=8)),
@@ -114,7 +122,17 @@ def cpu_baseline(cfg, budget_s, gpu_first_counts):
                                                 n_ofdm_sym=1, snr_db=25.0, Fd=10.0, Ts=F1_TS, L=8,
                                                 tap_powers_dB=F1_TAPS_DB, tap_delays_samples=(0, 1, 2, 3, 4))),
         "c5": (chains.chain_ia, dict(mod="qam", M=16, K=3, nr=2, nt=2, Ns=1, NSymbs=200, snr_db=20.0)),
+        "f6": (chains.chain_bd, dict(mod="psk", M=4, K=3, nr=2, NSymbs=500, iPu=1.0,
+                                     noise_var=1.0 / (10.0 ** (SNR_DB["f6"] / 10.0)), canonical=True)),
     }[cfg]
+
+
+def cpu_baseline(cfg, budget_s, gpu_first_counts):
+    """Time the NumPy oracle (a port of the reference's chain, oracle/chains.py) on ONE host core
+    for about `budget_s` seconds on the same workload and the same (seed, realization) keying;
+    also returns |SER_gpu - SER_oracle| on the realizations both sides computed."""
+    from oracle import chains
+    fn, kw = _oracle_chain(cfg)
     se = []
     t0 = time.perf_counter()
     r = 0
@@ -139,17 +157,7 @@ def _cpu_worker(job):
     for v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
         os.environ[v] = "1"
     from oracle import chains
-    fn, kw = {
-        "c4": (chains.chain_mimo_ofdm, dict(mod="qam", M=64, nt=4, nr=4, fft_size=1024, cp_size=16, num_used=None,
-                                           n_ofdm_sym=1, snr_db=25.0, mmse=True)),
-        "c2": (chains.chain_flat_jakes, dict(mod="qam", M=64, N=100000, snr_db=20.0, Fd=100.0, Ts=1e-3, L=8)),
-        "c3": (chains.chain_ofdm_tdl, dict(mod="qpsk", M=4, fft_size=1024, cp_size=16, num_used=None, n_ofdm_sym=1,
-                                           snr_db=20.0, Fd=10.0, Ts=1.0 / (15e3 * 1024), L=8)),
-        "f1": (chains.chain_mimo_ofdm_tdl, dict(mod="qam", M=64, nt=4, nr=4, fft_size=1024, cp_size=16, num_used=None,
-                                                n_ofdm_sym=1, snr_db=25.0, Fd=10.0, Ts=F1_TS, L=8,
-                                                tap_powers_dB=F1_TAPS_DB, tap_delays_samples=(0, 1, 2, 3, 4))),
-        "c5": (chains.chain_ia, dict(mod="qam", M=16, K=3, nr=2, nt=2, Ns=1, NSymbs=200, snr_db=20.0)),
-    }[cfg]
+    fn, kw = _oracle_chain(cfg)
     t0 = time.perf_counter()
     err = 0
     for r in range(first, first + n):
@@ -197,7 +205,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     eng = Engine(local_rank, args.dtype)
     run, units, workload = make_runner(eng, args.config, args.demod, args.dtype)
-    batch = args.batch or {"c4": 65536, "c3": 131072, "c2": 4096, "c5": 262144, "f1": 98304}[args.config]
+    batch = args.batch or {"c4": 65536, "c3": 131072, "c2": 4096, "c5": 262144, "f1": 98304, "f6": 131072}[args.config]
 
     def barrier():
         eng.sync()
@@ -270,12 +278,12 @@ def main():
                        "symbols_per_realization": units, "parallelism": "realization-sharded x%d" % world,
                        "rng": "Philox4x32-10 keyed by (seed, realization)"},
             "ser": tot[2] / float(max(1, tot[0]) * units),
-            "ber": tot[4] / float(max(1, tot[0]) * units * {"c2": 6, "c3": 2, "c4": 6, "c5": 4, "f1": 6}[args.config]),
+            "ber": tot[4] / float(max(1, tot[0]) * units * {"c2": 6, "c3": 2, "c4": 6, "c5": 4, "f1": 6, "f6": 2}[args.config]),
             "n_skipped": tot[1],
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "kernel": {"c4": "k_run_mimo_ofdm", "c2": "k_run_flat", "c3": "k_run_ofdm_tdl_batch",
-                                    "c5": "k_run_ia", "f1": "k_run_mimo_ofdm_tdl"}[args.config],
+                                    "c5": "k_run_ia", "f1": "k_run_mimo_ofdm_tdl", "f6": "k_run_bd"}[args.config],
                          "kernel_ms_per_launch": per_launch_s * 1e3,
                          "valu": valu,
                          "algorithmic_bytes_per_realization": balg,
@@ -334,6 +342,9 @@ def eng_first_counts(eng, args, n):
                                      method=method, dtype=args.dtype, per_realization=True)
     if args.config == "c5":
         return eng.run_ia(200, nv, SEED, 0, n, method=method, dtype=args.dtype, per_realization=True)[:3]
+    if args.config == "f6":
+        return eng.run_bd(3, 2, 500, 1.0, nv, SEED, 0, n, method=_lib.DEMOD_MINDIST, dtype=args.dtype,
+                          per_realization=True)
     from pyphysim_amd.channels import discretize_profile
     Ts = 1.0 / (15e3 * 1024)
     p_lin, d_idx = discretize_profile(np.array([0.0, -3.0, -6.0, -9.0, -12.0]), np.arange(5) * Ts, Ts)

@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 timeout 1200 python -m pytest tests -m gpu -q --timeout=900 > gpurun_out/pytest_gpu.log 2>&1
 echo "pytest rc=$?" >> gpurun_out/pytest_gpu.log
 tail -5 gpurun_out/pytest_gpu.log
-for cfg in "c4 --demod slicer" "c4 --demod mindist" "c3" "c2" "c5" "f1"; do
+for cfg in "c4 --demod slicer" "c4 --demod mindist" "c3" "c2" "c5" "f1" "f6"; do
   name=${cfg// /_}; name=${name//--demod_/}
   timeout 600 python bench.py --steps 10 --warmup 2 --no-cpu --config $cfg > gpurun_out/bench_$name.json 2> gpurun_out/bench_$name.err
   echo "== $cfg rc=$?"; python - "gpurun_out/bench_$name.json" <<'PY'
