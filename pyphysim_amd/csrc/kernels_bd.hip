@@ -23,6 +23,7 @@
 #include "philox.hpp"
 #include "pipe_common.hpp"
 #include "totals.hpp"
+#include "wave_draws.hpp"
 
 namespace mcle {
 
@@ -326,17 +327,21 @@ struct BdParams {
 };
 
 // Fused CoMP application: one wavefront per chunk of 64 realizations (as k_run_ia).  Phase 1: lane i draws the
-// channel of realization i, block-diagonalises it in f64 and parks two n x n matrices in LDS: C = W H Ms (the
-// end-to-end map from the transmitted symbols to the estimates; the identity on the active streams up to
-// rounding) and W.  Phase 2: the wave runs the realization's symbol columns: est = C s + W (sigma n).
-template <typename T>
+// channel of realization i, block-diagonalises it in f64 and parks the receive side of the link in LDS: the
+// user's block of W = pinv(H Ms) for each stream (R entries) and d_s = (W H Ms)_ss -- 1 on an active stream
+// up to rounding, 0 on a stream the water-filling switched off.  The off-diagonal entries of W H Ms are the
+// rounding residue of an exact block diagonalisation (<= 1e-15 |d|) and are not carried.  Phase 2: the wave runs
+// the realization's symbol columns: est_s = d_s x_s + W_s . (sigma n_user), demodulate, count.
+// R = antennas per user (compile time: every register index below is static).
+template <typename T, int R>
 __global__ __launch_bounds__(64) void k_run_bd(ModemParams<T> mp, BdParams pp, uint64_t seed, uint64_t first,
                                                uint64_t count, mcle_counters* counters,
                                                uint32_t* __restrict__ sym_out, uint32_t* __restrict__ bit_out) {
+    constexpr int KMAX = kBdMaxN / R;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int n = pp.K * pp.r, nn = n * n;
-    const int stride = 2 * nn + 1;                               // per-realization record, odd: lanes on distinct banks
-    cx<T>* s_rec = reinterpret_cast<cx<T>*>(smem);               // [64][stride]: C then W
+    const int K = pp.K, n = K * R;
+    const int stride = (n * (R + 1)) | 1;                        // per-realization record, odd: lanes on distinct banks
+    cx<T>* s_rec = reinterpret_cast<cx<T>*>(smem);               // [64][stride]: d[n] then W[n][R]
     unsigned long long* s_grid = reinterpret_cast<unsigned long long*>(s_rec + 64 * stride);
     __shared__ cx<T> s_table[256];
     __shared__ unsigned s_ok[64];
@@ -360,25 +365,22 @@ __global__ __launch_bounds__(64) void k_run_bd(ModemParams<T> mp, BdParams pp, u
                 for (int i = 0; i < n; ++i)
                     for (int c = 0; c < n; ++c) {
                         cd h = cn_sample<double>(rng, STREAM_CHAN, (uint64_t)(i * n + c), 1.0);
-                        if (pp.has_pathloss) h = cscale(h, pp.root_pl[(i / pp.r) * pp.K + c / pp.r]);
+                        if (pp.has_pathloss) h = cscale(h, pp.root_pl[(i / R) * K + c / R]);
                         H[i * n + c] = h;
                     }
-                const bool ok = bd_solve(H, pp.K, pp.r, pp.iPu, pp.bd_noise_var, pp.waterfill, Q, L, Ms, sg);
-                bd_receive_filter(H, Ms, pp.K, pp.r, Q);         // W in Q
+                const bool ok = bd_solve(H, K, R, pp.iPu, pp.bd_noise_var, pp.waterfill, Q, L, Ms, sg);
+                bd_receive_filter(H, Ms, K, R, Q);               // W in Q
                 cx<T>* rec = s_rec + lane * stride;
                 for (int s = 0; s < n; ++s) {
-                    cd t[kBdMaxN];                               // t = W[s, :] H
-                    for (int m = 0; m < n; ++m) {
-                        cd acc = mk<double>(0, 0);
-                        for (int a = 0; a < n; ++a) acc = cadd(acc, cmul(Q[s * n + a], H[a * n + m]));
-                        t[m] = acc;
+                    const int r0 = (s / R) * R;
+                    cd d = mk<double>(0, 0);                     // (W H Ms)_ss
+                    for (int a = 0; a < R; ++a) {
+                        cd hm = mk<double>(0, 0);
+                        for (int m = 0; m < n; ++m) hm = cadd(hm, cmul(H[(r0 + a) * n + m], Ms[m * n + s]));
+                        d = cadd(d, cmul(Q[s * n + r0 + a], hm));
+                        rec[n + s * R + a] = mk<T>((T)Q[s * n + r0 + a].x, (T)Q[s * n + r0 + a].y);
                     }
-                    for (int c = 0; c < n; ++c) {
-                        cd acc = mk<double>(0, 0);
-                        for (int m = 0; m < n; ++m) acc = cadd(acc, cmul(t[m], Ms[m * n + c]));
-                        rec[s * n + c] = mk<T>((T)acc.x, (T)acc.y);
-                        rec[nn + s * n + c] = mk<T>((T)Q[s * n + c].x, (T)Q[s * n + c].y);
-                    }
+                    rec[s] = mk<T>((T)d.x, (T)d.y);
                 }
                 s_ok[lane] = ok ? 1u : 0u;
             }
@@ -388,33 +390,55 @@ __global__ __launch_bounds__(64) void k_run_bd(ModemParams<T> mp, BdParams pp, u
         for (int j = 0; j < in_chunk; ++j) {
             const uint64_t rl = ch * 64 + j;
             const Rng rng(seed, first + rl);
-            const cx<T>* C = s_rec + j * stride;
-            const cx<T>* W = C + nn;
+            const cx<T>* D = s_rec + j * stride;
+            const cx<T>* W = D + n;
             unsigned se = 0, be = 0;
-            for (int t = lane; t < NS; t += 64) {
-                int tx[kBdMaxN];
-                cx<T> sym[kBdMaxN], nz[kBdMaxN];
+            // one symbol column
+            auto column = [&](const int (&tx)[kBdMaxN], const cx<T> (&nz)[kBdMaxN]) {
 #pragma unroll
-                for (int a = 0; a < kBdMaxN; ++a)
-                    if (a < n) {
-                        tx[a] = (int)symbol_at(rng, (uint64_t)a * NS + t, mask);      // randint(0, M, [n, NSymbs])
-                        sym[a] = s_table[tx[a]];
-                        nz[a] = cn_sample<T>(rng, STREAM_NOISE, (uint64_t)a * NS + t, sigma);
+                for (int k = 0; k < KMAX; ++k)
+                    if (k < K) {
+#pragma unroll
+                        for (int jj = 0; jj < R; ++jj) {
+                            const int s = k * R + jj;
+                            cx<T> est = cmul(D[s], s_table[tx[s]]);
+#pragma unroll
+                            for (int a = 0; a < R; ++a) est = cfma(W[s * R + a], nz[k * R + a], est);
+                            const unsigned x = (unsigned)(tx[s] ^ demod_one(mp, s_table, s_grid, est));
+                            se += (x != 0u);
+                            be += __popc(x);
+                        }
                     }
-#pragma unroll
-                for (int s = 0; s < kBdMaxN; ++s)
-                    if (s < n) {
-                        cx<T> est = mk<T>(0, 0);
+            };
+            if ((NS & 1) == 0) {
+                // two columns per lane and pass: whole Philox blocks, symbol blocks shared across the wave
+                for (int t0 = 0; t0 < NS; t0 += kPairCols) {
+                    const int t = t0 + 2 * lane;
+                    int ta[kBdMaxN], tb[kBdMaxN];
+                    wave_symbol_pairs<kBdMaxN>(rng, n, (uint32_t)NS, (uint32_t)t0, mask, lane, ta, tb);
+                    if (t < NS) {
+                        cx<T> za[kBdMaxN], zb[kBdMaxN];
 #pragma unroll
                         for (int a = 0; a < kBdMaxN; ++a)
-                            if (a < n) {
-                                est = cfma(C[s * n + a], sym[a], est);
-                                est = cfma(W[s * n + a], nz[a], est);
-                            }
-                        const unsigned x = (unsigned)(tx[s] ^ demod_one(mp, s_table, s_grid, est));
-                        se += (x != 0u);
-                        be += __popc(x);
+                            if (a < n)
+                                cn_pair<T>(rng, STREAM_NOISE, ((uint32_t)a * (uint32_t)NS + (uint32_t)t) >> 1, sigma,
+                                           za[a], zb[a]);
+                        column(ta, za);
+                        column(tb, zb);
                     }
+                }
+            } else {
+                for (int t = lane; t < NS; t += 64) {
+                    int tx[kBdMaxN];
+                    cx<T> nz[kBdMaxN];
+#pragma unroll
+                    for (int a = 0; a < kBdMaxN; ++a)
+                        if (a < n) {
+                            tx[a] = (int)symbol_at(rng, (uint64_t)a * NS + t, mask);   // randint(0, M, [n, NSymbs])
+                            nz[a] = cn_sample<T>(rng, STREAM_NOISE, (uint64_t)a * NS + t, sigma);
+                        }
+                    column(tx, nz);
+                }
             }
             se = wave_sum_u32(se);
             be = wave_sum_u32(be);
@@ -423,6 +447,22 @@ __global__ __launch_bounds__(64) void k_run_bd(ModemParams<T> mp, BdParams pp, u
     }
     if (lane == 0)
         wg_flush(totals, counters, (unsigned long long)n * NS, (unsigned long long)n * NS * mp.bits);
+}
+
+template <typename T, int R>
+static int launch_run_bd(mcle_ctx* ctx, const mcle_bd_cfg* cfg, const BdParams& pp, uint64_t seed, uint64_t first,
+                         uint64_t count, mcle_counters* d_counters, uint32_t* d_sym_err, uint32_t* d_bit_err) {
+    const int n = cfg->K * R;
+    const ModemParams<T> mp = pipe_modem<T>(ctx, cfg->demod_method);
+    const size_t lds = (size_t)64 * ((n * (R + 1)) | 1) * sizeof(cx<T>) + (size_t)mp.grid.G * mp.grid.G * sizeof(unsigned long long);
+    const uint64_t cap = (uint64_t)ctx->n_cu * 16;
+    const uint64_t chunks = (count + 63) / 64;
+    const unsigned grid = (unsigned)(chunks < cap ? chunks : cap);
+    MCLE_HIP(hipFuncSetAttribute((const void*)k_run_bd<T, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_run_bd<T, R>), dim3(grid), dim3(64), lds, ctx->stream, mp, pp, seed, first, count, d_counters,
+                       d_sym_err, d_bit_err);
+    MCLE_LAUNCH_CHECK();
+    return MCLE_OK;
 }
 
 static int check_bd_dims(int K, int r) {
@@ -509,27 +549,16 @@ int mcle_run_bd(mcle_ctx* ctx, int dtype, const mcle_bd_cfg* cfg, uint64_t seed,
     }
     if (count == 0) return MCLE_OK;
     if ((rc = ctx->bind())) return rc;
-    const int n = cfg->K * cfg->nr;
-    const size_t esz = dtype == MCLE_F32 ? sizeof(float2) : sizeof(double2);
-    const size_t rec = (size_t)64 * (2 * n * n + 1);
-    const int G = dtype == MCLE_F32 ? pipe_modem<float>(ctx, cfg->demod_method).grid.G : 0;
-    const size_t lds = rec * esz + (size_t)G * G * sizeof(unsigned long long);
-    const uint64_t cap = (uint64_t)ctx->n_cu * 16;
-    const uint64_t chunks = (count + 63) / 64;
-    const unsigned grid = (unsigned)(chunks < cap ? chunks : cap);
-    if (dtype == MCLE_F32) {
-        MCLE_HIP(hipFuncSetAttribute((const void*)k_run_bd<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_run_bd<float>, dim3(grid), dim3(64), lds, ctx->stream,
-                           pipe_modem<float>(ctx, cfg->demod_method), pp, seed, first, count, d_counters, d_sym_err,
-                           d_bit_err);
-    } else {
-        MCLE_HIP(hipFuncSetAttribute((const void*)k_run_bd<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_run_bd<double>, dim3(grid), dim3(64), lds, ctx->stream,
-                           pipe_modem<double>(ctx, cfg->demod_method), pp, seed, first, count, d_counters, d_sym_err,
-                           d_bit_err);
+    switch (cfg->nr * 2 + (dtype == MCLE_F64)) {
+        case 2: return launch_run_bd<float, 1>(ctx, cfg, pp, seed, first, count, d_counters, d_sym_err, d_bit_err);
+        case 3: return launch_run_bd<double, 1>(ctx, cfg, pp, seed, first, count, d_counters, d_sym_err, d_bit_err);
+        case 4: return launch_run_bd<float, 2>(ctx, cfg, pp, seed, first, count, d_counters, d_sym_err, d_bit_err);
+        case 5: return launch_run_bd<double, 2>(ctx, cfg, pp, seed, first, count, d_counters, d_sym_err, d_bit_err);
+        case 6: return launch_run_bd<float, 3>(ctx, cfg, pp, seed, first, count, d_counters, d_sym_err, d_bit_err);
+        case 7: return launch_run_bd<double, 3>(ctx, cfg, pp, seed, first, count, d_counters, d_sym_err, d_bit_err);
+        case 8: return launch_run_bd<float, 4>(ctx, cfg, pp, seed, first, count, d_counters, d_sym_err, d_bit_err);
+        default: return launch_run_bd<double, 4>(ctx, cfg, pp, seed, first, count, d_counters, d_sym_err, d_bit_err);
     }
-    MCLE_LAUNCH_CHECK();
-    return MCLE_OK;
 }
 
 }  // extern "C"

@@ -13,6 +13,7 @@
 #include "philox.hpp"
 #include "totals.hpp"
 #include "pipe_common.hpp"
+#include "wave_draws.hpp"
 
 namespace mcle {
 
@@ -468,9 +469,11 @@ __global__ __launch_bounds__(64) void k_ia_iterative(const cd* __restrict__ bigH
 }
 
 // fused config 5: one wavefront per CHUNK of 64 realizations.  Phase 1: lane i solves realization i of the chunk
-// (channel draw, solver -- closed form or iterative -- in f64 registers) and parks H, F, U in LDS.  Phase 2:
-// the whole wave runs each realization's symbols (lanes stride over the symbol columns).  With one solve per
-// lane instead of the same solve on all 64 lanes the iterative solvers cost 1/64 of a wave per realization.
+// (channel draw, solver -- closed form or iterative -- in f64 registers) and parks the end-to-end link in LDS:
+// G[k][l] = U_k H_kl F_l (symbol of user l -> estimate of user k: the wanted gain on the diagonal, the residual
+// interference off it) and the receive filters U_k.  Phase 2: the whole wave runs each realization's symbols,
+// est_k = sum_l G_kl x_l + U_k . n_k, two columns per lane and pass (wave_draws.hpp).  With one solve per lane
+// instead of the same solve on all 64 lanes the iterative solvers cost 1/64 of a wave per realization.
 template <typename T>
 __global__ __launch_bounds__(64) void k_run_ia(ModemParams<T> mp, int n_symbols, double noise_var, int solver, int init,
                                                int max_iter, double rel, uint64_t seed, uint64_t first,
@@ -478,8 +481,7 @@ __global__ __launch_bounds__(64) void k_run_ia(ModemParams<T> mp, int n_symbols,
                                                uint32_t* __restrict__ sym_out, uint32_t* __restrict__ bit_out,
                                                double* __restrict__ cap_out, uint32_t* __restrict__ iter_out) {
     __shared__ cx<T> s_table[256];
-    __shared__ cx<T> s_Hs[64][36 + 1];      // +1: lanes write their own row -- keep the rows off one bank
-    __shared__ cx<T> s_F[64][6 + 1];
+    __shared__ cx<T> s_G[64][9];            // odd row length: lanes write their own row on distinct banks
     __shared__ cx<T> s_U[64][6 + 1];
     __shared__ unsigned s_ok[64];
     extern __shared__ unsigned long long s_grid[];       // [G*G] candidate grid (min-distance demodulation, f32)
@@ -520,11 +522,13 @@ __global__ __launch_bounds__(64) void k_run_ia(ModemParams<T> mp, int n_symbols,
                     s = ia_iterative(H, solver, noise_var, max_iter, rel, init, F0, runned);
                 }
 #pragma unroll
-                for (int i = 0; i < 36; ++i) s_Hs[lane][i] = mk<T>((T)bigH[i].x, (T)bigH[i].y);
-#pragma unroll
                 for (int k = 0; k < 3; ++k) {
-                    s_F[lane][2 * k] = mk<T>((T)s.F[k].x.x, (T)s.F[k].x.y);
-                    s_F[lane][2 * k + 1] = mk<T>((T)s.F[k].y.x, (T)s.F[k].y.y);
+#pragma unroll
+                    for (int l = 0; l < 3; ++l) {
+                        const V2 hf = mvec(H[k][l], s.F[l]);
+                        const cd g = cadd(cmul(s.U[k].x, hf.x), cmul(s.U[k].y, hf.y));
+                        s_G[lane][3 * k + l] = mk<T>((T)g.x, (T)g.y);
+                    }
                     s_U[lane][2 * k] = mk<T>((T)s.U[k].x.x, (T)s.U[k].x.y);
                     s_U[lane][2 * k + 1] = mk<T>((T)s.U[k].y.x, (T)s.U[k].y.y);
                 }
@@ -539,44 +543,54 @@ __global__ __launch_bounds__(64) void k_run_ia(ModemParams<T> mp, int n_symbols,
         for (int j = 0; j < in_chunk; ++j) {
             const uint64_t rl = ch * 64 + j;
             const Rng rng(seed, first + rl);
-            cx<T> Hs[6][6], F[3][2], U[3][2];
-#pragma unroll
-            for (int i = 0; i < 6; ++i)
-#pragma unroll
-                for (int c = 0; c < 6; ++c) Hs[i][c] = s_Hs[j][i * 6 + c];
+            cx<T> G[3][3], U[3][2];
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                F[k][0] = s_F[j][2 * k];
-                F[k][1] = s_F[j][2 * k + 1];
+#pragma unroll
+                for (int l = 0; l < 3; ++l) G[k][l] = s_G[j][3 * k + l];
                 U[k][0] = s_U[j][2 * k];
                 U[k][1] = s_U[j][2 * k + 1];
             }
             unsigned se = 0, be = 0;
-            for (int t = lane; t < n_symbols; t += 64) {
-                int tx[3];
-                cx<T> X[6];
+            auto column = [&](const int (&tx)[3], const cx<T> (&nz)[6]) {
+                cx<T> x[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) x[k] = s_table[tx[k]];
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
-                    tx[k] = (int)symbol_at(rng, (uint64_t)k * n_symbols + t, mask);  // randint(0, M, [3, NSymbs])
-                    const cx<T> x = s_table[tx[k]];
-                    X[2 * k] = cmul(F[k][0], x);
-                    X[2 * k + 1] = cmul(F[k][1], x);
+                    cx<T> est = cmul(U[k][0], nz[2 * k]);
+                    est = cfma(U[k][1], nz[2 * k + 1], est);
+#pragma unroll
+                    for (int l = 0; l < 3; ++l) est = cfma(G[k][l], x[l], est);
+                    const unsigned e = (unsigned)(tx[k] ^ demod_one(mp, s_table, s_grid, est));
+                    se += (e != 0u);
+                    be += __popc(e);
                 }
+            };
+            if ((n_symbols & 1) == 0) {
+                for (int t0 = 0; t0 < n_symbols; t0 += kPairCols) {
+                    const int t = t0 + 2 * lane;
+                    int ta[3], tb[3];
+                    wave_symbol_pairs<3>(rng, 3, (uint32_t)n_symbols, (uint32_t)t0, mask, lane, ta, tb);   // randint(0, M, [3, NSymbs])
+                    if (t < n_symbols) {
+                        cx<T> za[6], zb[6];
 #pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    cx<T> y[2];
-#pragma unroll
-                    for (int a = 0; a < 2; ++a) {
-                        const int row = 2 * k + a;
-                        cx<T> acc = cn_sample<T>(rng, STREAM_NOISE, (uint64_t)row * n_symbols + t, sigma);
-#pragma unroll
-                        for (int c = 0; c < 6; ++c) acc = cfma(Hs[row][c], X[c], acc);
-                        y[a] = acc;
+                        for (int a = 0; a < 6; ++a)
+                            cn_pair<T>(rng, STREAM_NOISE, ((uint32_t)a * (uint32_t)n_symbols + (uint32_t)t) >> 1, sigma,
+                                       za[a], zb[a]);
+                        column(ta, za);
+                        column(tb, zb);
                     }
-                    const cx<T> est = cadd(cmul(U[k][0], y[0]), cmul(U[k][1], y[1]));
-                    const unsigned x = (unsigned)(tx[k] ^ demod_one(mp, s_table, s_grid, est));
-                    se += (x != 0u);
-                    be += __popc(x);
+                }
+            } else {
+                for (int t = lane; t < n_symbols; t += 64) {
+                    int tx[3];
+                    cx<T> nz[6];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) tx[k] = (int)symbol_at(rng, (uint64_t)k * n_symbols + t, mask);
+#pragma unroll
+                    for (int a = 0; a < 6; ++a) nz[a] = cn_sample<T>(rng, STREAM_NOISE, (uint64_t)a * n_symbols + t, sigma);
+                    column(tx, nz);
                 }
             }
             se = wave_sum_u32(se);
