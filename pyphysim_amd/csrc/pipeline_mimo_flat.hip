@@ -16,6 +16,7 @@
 #include "philox.hpp"
 #include "pipe_common.hpp"
 #include "totals.hpp"
+#include "wave_draws.hpp"
 
 namespace mcle {
 
@@ -131,7 +132,8 @@ __global__ __launch_bounds__(64) void k_run_mimo_flat(ModemParams<T> mp, int sch
     constexpr int PITCH = kFlatMax * kFlatMax + 1;
     __shared__ cx<T> s_table[256];
     extern __shared__ unsigned long long s_grid[];       // [G*G] candidate grid (min-distance demodulation, f32)
-    __shared__ cx<T> s_H[64][PITCH], s_W[64][PITCH], s_G[64][PITCH];
+    // per realization: A = G H W (symbols -> estimates; Alamouti keeps H here) and the receive filter G
+    __shared__ cx<T> s_A[64][PITCH], s_G[64][PITCH];
     __shared__ T s_aux[64];
     __shared__ unsigned s_ok[64];
     load_table(mp, s_table);
@@ -159,14 +161,35 @@ __global__ __launch_bounds__(64) void k_run_mimo_flat(ModemParams<T> mp, int sch
                         st.H[r][a] = (r < nr && a < nt) ? cn_sample<double>(rng, STREAM_CHAN, (uint64_t)(r * nt + a), 1.0)
                                                         : mk<double>(0, 0);
                 flat_setup(scheme, nt, nr, filter_nv, st);
+                if (scheme == MCLE_MIMO_ALAMOUTI) {
 #pragma unroll
-                for (int i = 0; i < kFlatMax; ++i)
+                    for (int i = 0; i < kFlatMax; ++i)
 #pragma unroll
-                    for (int j = 0; j < kFlatMax; ++j) {
-                        s_H[lane][i * kFlatMax + j] = mk<T>((T)st.H[i][j].x, (T)st.H[i][j].y);
-                        s_W[lane][i * kFlatMax + j] = mk<T>((T)st.W[i][j].x, (T)st.W[i][j].y);
-                        s_G[lane][i * kFlatMax + j] = mk<T>((T)st.G[i][j].x, (T)st.G[i][j].y);
-                    }
+                        for (int j = 0; j < kFlatMax; ++j)
+                            s_A[lane][i * kFlatMax + j] = mk<T>((T)st.H[i][j].x, (T)st.H[i][j].y);
+                } else {
+                    // A = G (H W) in f64; rows / columns beyond the layers are zero (W, G are zero there)
+                    double2 HW[kFlatMax][kFlatMax];
+#pragma unroll
+                    for (int r = 0; r < kFlatMax; ++r)
+#pragma unroll
+                        for (int l = 0; l < kFlatMax; ++l) {
+                            double2 acc = mk<double>(0, 0);
+#pragma unroll
+                            for (int a = 0; a < kFlatMax; ++a) acc = cadd(acc, cmul(st.H[r][a], st.W[a][l]));
+                            HW[r][l] = acc;
+                        }
+#pragma unroll
+                    for (int i = 0; i < kFlatMax; ++i)
+#pragma unroll
+                        for (int l = 0; l < kFlatMax; ++l) {
+                            double2 acc = mk<double>(0, 0);
+#pragma unroll
+                            for (int r = 0; r < kFlatMax; ++r) acc = cadd(acc, cmul(st.G[i][r], HW[r][l]));
+                            s_A[lane][i * kFlatMax + l] = mk<T>((T)acc.x, (T)acc.y);
+                            s_G[lane][i * kFlatMax + l] = mk<T>((T)st.G[i][l].x, (T)st.G[i][l].y);
+                        }
+                }
                 s_aux[lane] = (T)st.aux;
                 s_ok[lane] = st.ok ? 1u : 0u;
             }
@@ -177,83 +200,131 @@ __global__ __launch_bounds__(64) void k_run_mimo_flat(ModemParams<T> mp, int sch
         for (int j = 0; j < in_chunk; ++j) {
             const uint64_t rl = ch * 64 + j;
             const Rng rng(seed, first + rl);
-            cx<T> H[kFlatMax][kFlatMax], W[kFlatMax][kFlatMax], G[kFlatMax][kFlatMax];
+            cx<T> A[kFlatMax][kFlatMax], G[kFlatMax][kFlatMax];     // Alamouti: A holds H
 #pragma unroll
             for (int i = 0; i < kFlatMax; ++i)
 #pragma unroll
                 for (int c = 0; c < kFlatMax; ++c) {
-                    H[i][c] = s_H[j][i * kFlatMax + c];
-                    W[i][c] = s_W[j][i * kFlatMax + c];
+                    A[i][c] = s_A[j][i * kFlatMax + c];
                     G[i][c] = s_G[j][i * kFlatMax + c];
                 }
             unsigned se = 0, be = 0;
             if (scheme == MCLE_MIMO_ALAMOUTI) {
                 const T scale = s_aux[j];
                 const T inv_root2 = (T)0.70710678118654752440;
-                for (int p = lane; p < n_symbols / 2; p += 64) {
-                    const int tx0 = (int)symbol_at(rng, (uint64_t)(2 * p), mask);
-                    const int tx1 = (int)symbol_at(rng, (uint64_t)(2 * p + 1), mask);
-                    const cx<T> s0 = cscale(s_table[tx0], inv_root2), s1 = cscale(s_table[tx1], inv_root2);
-                    cx<T> o0 = mk<T>(0, 0), o1 = mk<T>(0, 0);
+                // slot pair p = symbols 2p, 2p+1 (one word of a DATA block, blocks shared across the wave) and the
+                // noise samples 2p, 2p+1 of every receive row (one NOISE block each); n_symbols is even
+                for (int p0 = 0; p0 < n_symbols / 2; p0 += 64) {
+                    const int p = p0 + lane;
+                    int ta[1], tb[1];
+                    wave_symbol_pairs<1>(rng, 1, 0u, (uint32_t)(2 * p0), mask, lane, ta, tb);
+                    if (p < n_symbols / 2) {
+                        const int tx0 = ta[0], tx1 = tb[0];
+                        const cx<T> s0 = cscale(s_table[tx0], inv_root2), s1 = cscale(s_table[tx1], inv_root2);
+                        cx<T> o0 = mk<T>(0, 0), o1 = mk<T>(0, 0);
 #pragma unroll
-                    for (int r = 0; r < kFlatMax; ++r)
-                        if (r < nr) {
-                            // slot 2p: (s0, s1); slot 2p+1: (-conj s1, conj s0)
-                            cx<T> y0 = cn_sample<T>(rng, STREAM_NOISE, (uint64_t)r * n_symbols + 2 * p, sigma);
-                            cx<T> y1 = cn_sample<T>(rng, STREAM_NOISE, (uint64_t)r * n_symbols + 2 * p + 1, sigma);
-                            y0 = cfma(H[r][0], s0, y0);
-                            y0 = cfma(H[r][1], s1, y0);
-                            y1 = cfma(H[r][0], mk<T>(-s1.x, s1.y), y1);
-                            y1 = cfma(H[r][1], cconj(s0), y1);
-                            o0 = cfma(cconj(H[r][0]), y0, o0);
-                            o0 = cfma(H[r][1], cconj(y1), o0);
-                            o1 = cfma(cconj(H[r][1]), y0, o1);
-                            o1 = csub(o1, cmul(H[r][0], cconj(y1)));
-                        }
-                    const unsigned x0 = (unsigned)(tx0 ^ demod_one(mp, s_table, s_grid, cscale(o0, scale)));
-                    const unsigned x1 = (unsigned)(tx1 ^ demod_one(mp, s_table, s_grid, cscale(o1, scale)));
-                    se += (x0 != 0u) + (x1 != 0u);
-                    be += __popc(x0) + __popc(x1);
+                        for (int r = 0; r < kFlatMax; ++r)
+                            if (r < nr) {
+                                // slot 2p: (s0, s1); slot 2p+1: (-conj s1, conj s0)
+                                cx<T> y0, y1;
+                                cn_pair<T>(rng, STREAM_NOISE, ((uint32_t)r * (uint32_t)n_symbols + 2u * (uint32_t)p) >> 1, sigma,
+                                           y0, y1);
+                                y0 = cfma(A[r][0], s0, y0);
+                                y0 = cfma(A[r][1], s1, y0);
+                                y1 = cfma(A[r][0], mk<T>(-s1.x, s1.y), y1);
+                                y1 = cfma(A[r][1], cconj(s0), y1);
+                                o0 = cfma(cconj(A[r][0]), y0, o0);
+                                o0 = cfma(A[r][1], cconj(y1), o0);
+                                o1 = cfma(cconj(A[r][1]), y0, o1);
+                                o1 = csub(o1, cmul(A[r][0], cconj(y1)));
+                            }
+                        const unsigned x0 = (unsigned)(tx0 ^ demod_one(mp, s_table, s_grid, cscale(o0, scale)));
+                        const unsigned x1 = (unsigned)(tx1 ^ demod_one(mp, s_table, s_grid, cscale(o1, scale)));
+                        se += (x0 != 0u) + (x1 != 0u);
+                        be += __popc(x0) + __popc(x1);
+                    }
                 }
             } else {
-                for (int t = lane; t < n_symbols; t += 64) {
-                    int tx[kFlatMax];
-                    cx<T> d[kFlatMax], x[kFlatMax], y[kFlatMax];
+                // one symbol column: est = A d + G n
+                auto column = [&](const int (&tx)[kFlatMax], const cx<T> (&nz)[kFlatMax]) {
+                    cx<T> d[kFlatMax];
 #pragma unroll
-                    for (int l = 0; l < kFlatMax; ++l) {
-                        tx[l] = 0;
-                        d[l] = mk<T>(0, 0);
-                        if (l < layers) {
-                            const uint64_t n = c_order ? (uint64_t)l * n_symbols + t : (uint64_t)t * layers + l;
-                            tx[l] = (int)symbol_at(rng, n, mask);
-                            d[l] = s_table[tx[l]];
-                        }
-                    }
-#pragma unroll
-                    for (int a = 0; a < kFlatMax; ++a) {
-                        x[a] = mk<T>(0, 0);
-#pragma unroll
-                        for (int l = 0; l < kFlatMax; ++l) x[a] = cfma(W[a][l], d[l], x[a]);   // unused entries are 0
-                    }
-#pragma unroll
-                    for (int r = 0; r < kFlatMax; ++r) {
-                        y[r] = mk<T>(0, 0);
-                        if (r < nr) {
-                            y[r] = cn_sample<T>(rng, STREAM_NOISE, (uint64_t)r * n_symbols + t, sigma);
-#pragma unroll
-                            for (int a = 0; a < kFlatMax; ++a) y[r] = cfma(H[r][a], x[a], y[r]);
-                        }
-                    }
+                    for (int l = 0; l < kFlatMax; ++l) d[l] = l < layers ? s_table[tx[l]] : mk<T>(0, 0);
 #pragma unroll
                     for (int l = 0; l < kFlatMax; ++l)
                         if (l < layers) {
                             cx<T> est = mk<T>(0, 0);
 #pragma unroll
-                            for (int r = 0; r < kFlatMax; ++r) est = cfma(G[l][r], y[r], est);
+                            for (int c = 0; c < kFlatMax; ++c) {
+                                est = cfma(A[l][c], d[c], est);      // entries beyond the layers / rows are zero
+                                est = cfma(G[l][c], nz[c], est);
+                            }
                             const unsigned xr = (unsigned)(tx[l] ^ demod_one(mp, s_table, s_grid, est));
                             se += (xr != 0u);
                             be += __popc(xr);
                         }
+                };
+                if ((n_symbols & 1) == 0) {
+                    for (int t0 = 0; t0 < n_symbols; t0 += kPairCols) {
+                        const int t = t0 + 2 * lane;
+                        int ta[kFlatMax], tb[kFlatMax];
+#pragma unroll
+                        for (int l = 0; l < kFlatMax; ++l) ta[l] = tb[l] = 0;
+                        if (c_order) {
+                            wave_symbol_pairs<kFlatMax>(rng, layers, (uint32_t)n_symbols, (uint32_t)t0, mask, lane, ta, tb);
+                        } else if (t < n_symbols) {
+                            // Fortran order: the 2 * layers bytes of columns t, t + 1 are consecutive (<= 8 bytes,
+                            // in one block unless layers == 3)
+                            const uint32_t q = (uint32_t)t * (uint32_t)layers;
+                            const Words4 b0 = rng.block(STREAM_DATA, q >> 4);
+                            Words4 b1 = b0;
+                            if ((q & 15u) + 2u * (uint32_t)layers > 16u) b1 = rng.block(STREAM_DATA, (q >> 4) + 1u);
+#pragma unroll
+                            for (int e = 0; e < 2 * kFlatMax; ++e)
+                                if (e < 2 * layers) {
+                                    const uint32_t pos = (q & 15u) + (uint32_t)e;          // 0 .. 31
+                                    const uint32_t wi = (pos >> 2) & 3u;
+                                    const uint32_t lo = wi == 0 ? b0.w[0] : (wi == 1 ? b0.w[1] : (wi == 2 ? b0.w[2] : b0.w[3]));
+                                    const uint32_t hi = wi == 0 ? b1.w[0] : (wi == 1 ? b1.w[1] : (wi == 2 ? b1.w[2] : b1.w[3]));
+                                    const int v = (int)(((pos < 16u ? lo : hi) >> ((pos & 3u) * 8u)) & mask);
+                                    // e = column * layers + layer
+#pragma unroll
+                                    for (int l = 0; l < kFlatMax; ++l) {
+                                        if (e == l) ta[l] = v;
+                                        if (e == layers + l) tb[l] = v;
+                                    }
+                                }
+                        }
+                        if (t < n_symbols) {
+                            cx<T> za[kFlatMax], zb[kFlatMax];
+#pragma unroll
+                            for (int r = 0; r < kFlatMax; ++r) {
+                                za[r] = zb[r] = mk<T>(0, 0);
+                                if (r < nr)
+                                    cn_pair<T>(rng, STREAM_NOISE, ((uint32_t)r * (uint32_t)n_symbols + (uint32_t)t) >> 1, sigma,
+                                               za[r], zb[r]);
+                            }
+                            column(ta, za);
+                            column(tb, zb);
+                        }
+                    }
+                } else {
+                    for (int t = lane; t < n_symbols; t += 64) {
+                        int tx[kFlatMax];
+                        cx<T> nz[kFlatMax];
+#pragma unroll
+                        for (int l = 0; l < kFlatMax; ++l) {
+                            tx[l] = 0;
+                            if (l < layers) {
+                                const uint64_t n = c_order ? (uint64_t)l * n_symbols + t : (uint64_t)t * layers + l;
+                                tx[l] = (int)symbol_at(rng, n, mask);
+                            }
+                        }
+#pragma unroll
+                        for (int r = 0; r < kFlatMax; ++r)
+                            nz[r] = r < nr ? cn_sample<T>(rng, STREAM_NOISE, (uint64_t)r * n_symbols + t, sigma) : mk<T>(0, 0);
+                        column(tx, nz);
+                    }
                 }
             }
             se = wave_sum_u32(se);
