@@ -20,6 +20,8 @@ CASES = [
         SNR=[25.0], M=64, Nt=4, Nr=4, fft_size=1024, cp_size=16, num_ofdm_symbols=1, Fd=10.0, Ts=1.0 / (15e3 * 1024),
         tap_powers_dB=(0.0, -3.0, -6.0, -9.0, -12.0), tap_delays=[i / (15e3 * 1024) for i in range(5)],
         rep_max=98304 * 8, batch_size=98304)),
+    ("BdSimulator (8f.3, comp_BD app)", lambda: simulators.BdSimulator(SNR=[15.0], noise_var=1.0, rep_max=1 << 22,
+                                                                     batch_size=131072)),
     ("MimoSimulator blast 4x4", lambda: simulators.MimoSimulator(SNR=[15.0], scheme="blast", Nt=4, Nr=4, rep_max=1 << 23,
                                                                batch_size=262144)),
 ]

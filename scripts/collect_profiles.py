@@ -25,6 +25,8 @@ os.makedirs(dst, exist_ok=True)
 CONFIGS = {
     "c4": ("k_run_mimo_ofdm<", "k_run_mimo_ofdm<float,1024,4>, %d realizations per launch (bench.py default workload)"),
     "f1": ("k_run_mimo_ofdm_tdl<", "k_run_mimo_ofdm_tdl<float,1024,4>, %d realizations per launch (bench.py --config f1)"),
+    "c5": ("k_run_ia<", "k_run_ia<float>, %d realizations per launch (bench.py --config c5)"),
+    "f6": ("k_run_bd<", "k_run_bd<float,2>, %d realizations per launch (bench.py --config f6)"),
 }
 
 
@@ -87,6 +89,17 @@ if os.path.exists(sj):
     lines = [l for l in open(sj).read().strip().splitlines() if l.startswith("{")]
     if lines:
         open(os.path.join(dst, "staged_f1.json"), "w").write(lines[-1] + "\n")
+
+for name, out_name in (("ia_solvers", "ia_solvers"), ("mimo_schemes", "mimo_schemes"), ("operators", "operators_hbm"),
+                       ("simulators", "simulators")):
+    pj = os.path.join(src, name + ".json")
+    if os.path.exists(pj):
+        text = open(pj).read()
+        try:
+            doc = json.loads(text[text.index("{"):])
+        except ValueError:
+            continue
+        json.dump(doc, open(os.path.join(dst, out_name + ".json"), "w"), indent=1)
 
 for path in sorted(glob.glob(os.path.join(src, "bench_*.json"))):
     lines = [l for l in open(path).read().strip().splitlines() if l.startswith("{")]

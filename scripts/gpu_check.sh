@@ -33,5 +33,14 @@ if [ "$mode" = "prof" ]; then
       echo "pmc $cfg $tag rc=$?"
     done
   done
+  for cfg in c5 f6; do
+    timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${cfg}_stats -o $cfg -- python bench.py --config $cfg --steps 10 --warmup 2 --no-cpu > gpurun_out/prof_${cfg}_stats.log 2>&1
+    timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_LDS --output-format csv -d gpurun_out/prof_${cfg}_SQ_WAVE_CYCLES -o $cfg -- python bench.py --config $cfg --steps 3 --warmup 1 --no-cpu > gpurun_out/prof_${cfg}_SQ.log 2>&1
+    echo "prof $cfg rc=$?"
+  done
+  timeout 300 python scripts/bench_ia_solvers.py > gpurun_out/ia_solvers.json 2> gpurun_out/ia_solvers.err
+  timeout 300 python scripts/bench_mimo_schemes.py > gpurun_out/mimo_schemes.json 2> gpurun_out/mimo_schemes.err
+  timeout 300 python scripts/bench_operators.py > gpurun_out/operators.json 2> gpurun_out/operators.err
+  timeout 300 python scripts/bench_simulators.py > gpurun_out/simulators.json 2> gpurun_out/simulators.err
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_f1staged_stats -o f1staged -- python scripts/bench_staged_f1.py --batch 2048 --steps 5 > gpurun_out/staged_f1.json 2> gpurun_out/prof_f1staged.log
 fi
