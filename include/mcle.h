@@ -288,7 +288,8 @@ enum { MCLE_IA_CLOSED_FORM = 0,  /* ClosedFormIASolver      ia/algorithms.py:42-
 
 enum { MCLE_IA_INIT_GIVEN = 0,        /* 'random' (pipelines: drawn on-chip) or 'fix' (operator: injected) */
        MCLE_IA_INIT_CLOSED_FORM = 1,  /* 'closed_form': F and W of ClosedFormIASolver                      */
-       MCLE_IA_INIT_ALT_MIN = 2 };    /* 'alt_min': AlternatingMinIASolver run first, same max_iterations */
+       MCLE_IA_INIT_ALT_MIN = 2,      /* 'alt_min': AlternatingMinIASolver run first, same max_iterations */
+       MCLE_IA_INIT_SVD = 3 };        /* 'svd': dominant right singular vector of each direct channel (phase: ours) */
 
 typedef struct mcle_ia_cfg {            /* C5: apps/ia/simulate_ia.py:94-245, ClosedFormIASolver */
     int32_t K, nr, nt, ns;              /* supported: K = 3, nr = nt = 2, ns = 1 */
@@ -298,7 +299,7 @@ typedef struct mcle_ia_cfg {            /* C5: apps/ia/simulate_ia.py:94-245, Cl
     int32_t solver;                     /* MCLE_IA_*: closed form or an iterative solver (initialize_with='random') */
     int32_t max_iterations;             /* iterative solvers: IterativeIASolverBaseClass.max_iterations */
     double relative_factor;             /* ... and .relative_factor (algorithms.py:316-322) */
-    int32_t initialize_with;            /* MCLE_IA_INIT_*: 'random' / 'closed_form' / 'alt_min' (algorithms.py:633-663) */
+    int32_t initialize_with;            /* MCLE_IA_INIT_*: 'random' / 'closed_form' / 'alt_min' / 'svd' (algorithms.py:633-663) */
     int32_t reserved;
 } mcle_ia_cfg;
 

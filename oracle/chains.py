@@ -327,7 +327,7 @@ def chain_ia_iterative(rng, algo='alt_min', mod='qam', M=16, K=3, nr=2, nt=2, Ns
     big_H = rng.cn(philox.STREAM_CHAN, K * nr, K * nt)
     H = oia.split_blocks(big_H, K, nr, nt)
     F_init = []
-    if initialize_with == 'closed_form':
+    if initialize_with in ('closed_form', 'svd'):
         F_init = [np.zeros((nt, Ns), dtype=complex)] * K       # shape only: no random start is drawn
     else:
         # randomizeF (iabase.py:538-540): normalized(randn_c_RS(rs, Nt, Ns)) -- drawn by the solver itself

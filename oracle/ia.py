@@ -256,8 +256,17 @@ def iterative_solve(algo, H, F_init, noise_var, max_iterations=50, relative_fact
     """-> (F, U = full_W_H, sum capacity, SINRs, runned_iterations).  initialize_with (algorithms.py:633-663):
     'random' / 'fix': F_init are the starting precoders; 'closed_form' (:572-597): start from the closed-form
     solution's F and W; 'alt_min' (:599-632): run the alternating-minimisation solver first (its own random
-    start = F_init, the same max_iterations) and start from its F and its normalised receive filters."""
+    start = F_init, the same max_iterations) and start from its F and its normalised receive filters; 'svd'
+    (:503-547): the most significant right singular vector(s) of every user's direct channel."""
     W_init = None
+    if initialize_with == 'svd':
+        Ns = F_init[0].shape[1]
+        F_init = []
+        for k in range(len(H)):
+            V = np.linalg.svd(H[k][k], full_matrices=True)[2].conj().T
+            rev = list(reversed(range(V.shape[0])))          # least_right_singular_vectors, misc.py:647-660
+            V1 = V[:, rev[H[k][k].shape[0] - Ns:]]
+            F_init.append(V1 / np.linalg.norm(V1, 'fro'))
     if initialize_with == 'closed_form':
         Ns = F_init[0].shape[1]
         F_init, _, _, _, W_init = closed_form_solve(H, Ns, noise_var, True, with_W=True)

@@ -482,6 +482,12 @@ CHAINS = {
                                 ("alt_min", 20.0, 10, "closed_form"), ("mmse", 20.0, 30, "random"),
                                 ("mmse", 6.0, 12, "random"), ("mmse", 14.0, 15, "alt_min"),
                                 ("mmse", 25.0, 10, "closed_form"))],
+    # initialize_with='svd': the start is a singular vector, unique up to a phase only -- kept apart from the
+    # cases above, whose precoders the kernels reproduce entry by entry
+    "f3b_ia_svd_init": [dict(algo=a, mod="qam", M=16, K=3, nr=2, nt=2, Ns=1, NSymbs=60, snr_db=snr, max_iterations=it,
+                             relative_factor=1e-6, initialize_with="svd")
+                        for a, snr, it in (("alt_min", 20.0, 40), ("max_sinr", 12.0, 25), ("min_leakage", 20.0, 8),
+                                           ("mmse", 16.0, 20))],
     "f1_mimo_ofdm_tdl": [dict(mod="qam", M=16, nt=2, nr=2, fft_size=64, cp_size=16, num_used=None, n_ofdm_sym=2,
                               snr_db=20.0, Fd=50.0, Ts=1e-6, L=8, tap_powers_dB=(0.0, -4.0, -9.0),
                               tap_delays_samples=(0, 2, 5)),
@@ -510,7 +516,7 @@ def run_ref(name, kw, seed):
         return ref_chain_ia(seed, **kw)
     if name == "f6_block_diag":
         return ref_chain_bd(seed, **kw)
-    if name == "f3_ia_iterative":
+    if name in ("f3_ia_iterative", "f3b_ia_svd_init"):
         return ref_chain_ia_iterative(seed, **kw)
     if name == "f5_mimo_schemes":
         return ref_chain_mimo_scheme(seed, **kw)
@@ -533,16 +539,16 @@ def run_ref(name, kw, seed):
 ORACLE = {"c1_awgn": chains.chain_awgn, "c2_flat_jakes": chains.chain_flat_jakes,
           "c3_ofdm_tdl": chains.chain_ofdm_tdl, "c4_mimo_ofdm": chains.chain_mimo_ofdm, "c5_ia": chains.chain_ia,
           "f1_mimo_ofdm_tdl": chains.chain_mimo_ofdm_tdl, "f3_ia_iterative": chains.chain_ia_iterative,
-          "f5_mimo_schemes": chains.chain_mimo_scheme, "f6_block_diag": chains.chain_bd}
+          "f3b_ia_svd_init": chains.chain_ia_iterative, "f5_mimo_schemes": chains.chain_mimo_scheme, "f6_block_diag": chains.chain_bd}
 INT_KEYS = ("idx", "decisions", "symbol_errors", "bit_errors", "num_symbols", "num_bits", "delay_indexes",
             "runned_iterations")
 # realizations stored per case (kept small: fixtures are KBs)
 N_REAL = {"c1_awgn": 2, "c2_flat_jakes": 2, "c3_ofdm_tdl": 2, "c4_mimo_ofdm": 2, "c5_ia": 4, "f1_mimo_ofdm_tdl": 1,
-          "f3_ia_iterative": 3, "f5_mimo_schemes": 2, "f6_block_diag": 3}
+          "f3_ia_iterative": 3, "f3b_ia_svd_init": 3, "f5_mimo_schemes": 2, "f6_block_diag": 3}
 # derivable float arrays that are checked against the reference above but not stored
 SKIP_STORE = {"c1_awgn": ("tx",), "c2_flat_jakes": ("tx", "faded"), "c3_ofdm_tdl": ("sym", "faded"),
               "c4_mimo_ofdm": ("sym", "X", "R"), "c5_ia": (),
-              "f1_mimo_ofdm_tdl": ("faded", "G"), "f3_ia_iterative": (), "f5_mimo_schemes": (),
+              "f1_mimo_ofdm_tdl": ("faded", "G"), "f3_ia_iterative": (), "f3b_ia_svd_init": (), "f5_mimo_schemes": (),
               "f6_block_diag": ()}
 
 
@@ -557,11 +563,11 @@ def golden_chains(only=None):
             for r in range(N_REAL[name]):
                 seed = BASE_SEED + 1000 * ci + r
                 ref = run_ref(name, kw, seed)
-                mine = ORACLE[name]((chains.LegacyRng3 if name in ("c5_ia", "f3_ia_iterative", "f6_block_diag")
+                mine = ORACLE[name]((chains.LegacyRng3 if name in ("c5_ia", "f3_ia_iterative", "f3b_ia_svd_init", "f6_block_diag")
                                      else chains.LegacyRng)(seed), **kw)
                 for k, v in ref.items():
                     tol = 0 if k in INT_KEYS else (1e-9 if name in ("c5_ia", "f1_mimo_ofdm_tdl", "f6_block_diag") else
-                                                   (1e-7 if name == "f3_ia_iterative" else
+                                                   (1e-7 if name in ("f3_ia_iterative", "f3b_ia_svd_init") else
                                                     (1e-9 if name == "f5_mimo_schemes" else 1e-12)))
                     worst = max(worst, close(mine[k], v, tol, "%s[%d] r%d %s" % (name, ci, r, k)))
                     arr = np.asarray(v)

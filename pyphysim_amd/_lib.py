@@ -91,7 +91,7 @@ class BdCfg(Structure):
                 ("bd_noise_var", c_double), ("pathloss", c_double * 16)]
 
 
-IA_INITS = {"random": 0, "fix": 0, "closed_form": 1, "alt_min": 2}
+IA_INITS = {"random": 0, "fix": 0, "closed_form": 1, "alt_min": 2, "svd": 3}
 IA_SOLVERS = {"closed_form": 0, "alt_min": 1, "min_leakage": 2, "max_sinr": 3, "mmse": 4}
 
 

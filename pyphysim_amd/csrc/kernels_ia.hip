@@ -372,8 +372,9 @@ __device__ __forceinline__ void ia_finish(const M2 (&H)[3][3], const V2 (&F)[3],
 // init (IterativeIASolverBaseClass._solve_init, algorithms.py:633-663): IA_INIT_GIVEN = start from F_init
 // ('random' / 'fix'); IA_INIT_CLOSED_FORM = F and W of the closed-form solution (:572-597); IA_INIT_ALT_MIN = run
 // the alternating-minimisation solver from F_init with the same max_iterations and start from its F and its
-// normalised receive filters (:599-632).
-enum { IA_INIT_GIVEN = 0, IA_INIT_CLOSED_FORM = 1, IA_INIT_ALT_MIN = 2 };
+// normalised receive filters (:599-632); IA_INIT_SVD = the most significant right singular vector of every user's
+// direct channel (:503-547; unique up to a phase -- LAPACK's in the reference, the Hermitian eigen-solver's here).
+enum { IA_INIT_GIVEN = 0, IA_INIT_CLOSED_FORM = 1, IA_INIT_ALT_MIN = 2, IA_INIT_SVD = 3 };
 
 __device__ __noinline__ IaSolution ia_iterative(const M2 (&H)[3][3], int algo, double nv, int max_iter, double rel,
                                                 int init, const V2 (&F_init)[3], int& runned) {
@@ -395,6 +396,19 @@ __device__ __noinline__ IaSolution ia_iterative(const M2 (&H)[3][3], int algo, d
             heig2(outer2(a[k]), W0[k], hi);
         }
         W_init = W0;
+    } else if (init == IA_INIT_SVD) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            // H_kk^H H_kk = V diag(s^2) V^H: the eigenvector of the larger eigenvalue
+            const M2& h = H[k][k];
+            M2 g;
+            g.a = mk<double>(cabs2(h.a) + cabs2(h.c), 0.0);
+            g.d = mk<double>(cabs2(h.b) + cabs2(h.d), 0.0);
+            g.b = cadd(cmul(cconj(h.a), h.b), cmul(cconj(h.c), h.d));
+            g.c = cconj(g.b);
+            V2 lo;
+            heig2(g, lo, F[k]);
+        }
     } else if (init == IA_INIT_ALT_MIN) {
         V2 Wha[3];
         ia_iterate(H, IA_ALT_MIN, nv, max_iter, rel, F, Wha, ok);
@@ -647,7 +661,7 @@ int mcle_ia_iterative(mcle_ctx* ctx, int solver, int initialize_with, const void
     MCLE_REQUIRE(solver >= MCLE_IA_ALT_MIN && solver <= MCLE_IA_MMSE, "solver must be one of the iterative MCLE_IA_*");
     MCLE_REQUIRE(noise_var >= 0.0, "noise variance must be non-negative");
     MCLE_REQUIRE(max_iterations >= 1, "max_iterations must be positive");
-    MCLE_REQUIRE(initialize_with >= MCLE_IA_INIT_GIVEN && initialize_with <= MCLE_IA_INIT_ALT_MIN,
+    MCLE_REQUIRE(initialize_with >= MCLE_IA_INIT_GIVEN && initialize_with <= MCLE_IA_INIT_SVD,
                  "unknown initialisation %d", initialize_with);
     // AlternatingMinIASolver.initialize_with setter, algorithms.py:928-935
     MCLE_REQUIRE(!(solver == MCLE_IA_ALT_MIN && initialize_with == MCLE_IA_INIT_ALT_MIN),
@@ -677,7 +691,7 @@ int mcle_run_ia(mcle_ctx* ctx, int dtype, const mcle_ia_cfg* cfg, uint64_t seed,
     MCLE_REQUIRE(cfg->noise_var >= 0.0, "noise variance must be non-negative");
     MCLE_REQUIRE(cfg->solver >= MCLE_IA_CLOSED_FORM && cfg->solver <= MCLE_IA_MMSE, "unknown IA solver %d", cfg->solver);
     MCLE_REQUIRE(cfg->solver == MCLE_IA_CLOSED_FORM || cfg->max_iterations >= 1, "max_iterations must be positive");
-    MCLE_REQUIRE(cfg->initialize_with >= MCLE_IA_INIT_GIVEN && cfg->initialize_with <= MCLE_IA_INIT_ALT_MIN,
+    MCLE_REQUIRE(cfg->initialize_with >= MCLE_IA_INIT_GIVEN && cfg->initialize_with <= MCLE_IA_INIT_SVD,
                  "unknown initialisation %d", cfg->initialize_with);
     MCLE_REQUIRE(!(cfg->solver == MCLE_IA_ALT_MIN && cfg->initialize_with == MCLE_IA_INIT_ALT_MIN),
                  "Can't use 'alt_min' initialization with 'AlternatingMinIASolver' class 'alt_min'");

@@ -125,7 +125,7 @@ class IterativeIASolverBaseClass(IASolverBaseClass):
 
     @initialize_with.setter
     def initialize_with(self, value):
-        if value not in ("random", "alt_min", "closed_form", "fix"):
+        if value not in ("random", "alt_min", "closed_form", "fix", "svd"):
             raise RuntimeError("Invalid initialize_with value: '%s'" % (value,))
         if value == "alt_min" and self._SOLVER == "alt_min":
             raise RuntimeError("Can't use 'alt_min' initialization with '%s' class 'alt_min'" % type(self).__name__)

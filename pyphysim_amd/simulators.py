@@ -308,8 +308,8 @@ class IaSimulator(_LinkSimulator):
         for k, v in (("NSymbs", int(NSymbs)), ("K", 3), ("Nr", 2), ("Nt", 2), ("Ns", 1), ("solver", solver)):
             self.params.add(k, v)
         if solver != "closed_form":
-            if initialize_with not in ("random", "closed_form", "alt_min"):
-                raise ValueError("initialize_with must be 'random', 'closed_form' or 'alt_min'")
+            if initialize_with not in ("random", "closed_form", "alt_min", "svd"):
+                raise ValueError("initialize_with must be 'random', 'closed_form', 'alt_min' or 'svd'")
             self.params.add("max_iterations", int(max_iterations))
             self.params.add("initialize_with", initialize_with)
         self.relative_factor = float(relative_factor)
