@@ -223,24 +223,33 @@ class Engine:
         check(self.lib.mcle_demodulate(self.ctx, dt, int(method), d_rx.ptr, out.ptr, d_rx.size))
         return self._out(out, host, np.int64)
 
-    def count_errors(self, tx_idx, rx_idx, bits_per_symbol, n_real=1):
-        """-> (counters dict, per-realization symbol errors, per-realization bit errors)."""
+    def count_errors(self, tx_idx, rx_idx, bits_per_symbol, n_real=1, counters=None):
+        """-> (counters dict, per-realization symbol errors, per-realization bit errors); with a device-resident
+        `counters` block (new_counters()) the sums are ADDED there and nothing is read back."""
         a, _ = self._iin(tx_idx)
         b, _ = self._iin(rx_idx)
         if a.size != b.size or a.size % n_real:
             raise ValueError("size mismatch")
+        if counters is not None:
+            check(self.lib.mcle_count_errors(self.ctx, a.ptr, b.ptr, a.size // n_real, n_real, int(bits_per_symbol),
+                                             counters.ptr, None, None))
+            return None
         cnt = self.zeros(1, np.dtype((np.void, ctypes.sizeof(Counters))))
         se, be = self.empty(n_real, np.uint32), self.empty(n_real, np.uint32)
         check(self.lib.mcle_count_errors(self.ctx, a.ptr, b.ptr, a.size // n_real, n_real, int(bits_per_symbol),
                                          cnt.ptr, se.ptr, be.ptr))
         return self._counters(cnt), se.get(), be.get()
 
-    def demod_count(self, rx, tx_idx, n_real=1, method=DEMOD_MINDIST, dtype=None):
+    def demod_count(self, rx, tx_idx, n_real=1, method=DEMOD_MINDIST, dtype=None, counters=None):
         dt = self._dt(dtype)
         d_rx, _ = self._cin(rx, dt)
         a, _ = self._iin(tx_idx)
         if a.size != d_rx.size or a.size % n_real:
             raise ValueError("size mismatch")
+        if counters is not None:
+            check(self.lib.mcle_demod_count(self.ctx, dt, int(method), d_rx.ptr, a.ptr, a.size // n_real, n_real,
+                                            counters.ptr, None, None))
+            return None
         cnt = self.zeros(1, np.dtype((np.void, ctypes.sizeof(Counters))))
         se, be = self.empty(n_real, np.uint32), self.empty(n_real, np.uint32)
         check(self.lib.mcle_demod_count(self.ctx, dt, int(method), d_rx.ptr, a.ptr, a.size // n_real, n_real,

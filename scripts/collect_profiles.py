@@ -81,6 +81,9 @@ for cfg, (needle, label) in CONFIGS.items():
                   open(os.path.join(REPO, "profiles", "traffic_%s.json" % cfg), "w"), indent=1)
     print(cfg, json.dumps(derived, indent=1), json.dumps(meta))
 
+ops = first(os.path.join(src, "prof_operators_stats", "**", "operators_kernel_stats.csv"))
+if ops:
+    shutil.copy(ops, os.path.join(dst, "operators_kernel_stats.csv"))
 staged = first(os.path.join(src, "prof_f1staged_stats", "**", "f1staged_kernel_stats.csv"))
 if staged:
     shutil.copy(staged, os.path.join(dst, "staged_f1_kernel_stats.csv"))

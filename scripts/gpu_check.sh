@@ -40,7 +40,7 @@ if [ "$mode" = "prof" ]; then
   done
   timeout 300 python scripts/bench_ia_solvers.py > gpurun_out/ia_solvers.json 2> gpurun_out/ia_solvers.err
   timeout 300 python scripts/bench_mimo_schemes.py > gpurun_out/mimo_schemes.json 2> gpurun_out/mimo_schemes.err
-  timeout 300 python scripts/bench_operators.py > gpurun_out/operators.json 2> gpurun_out/operators.err
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_operators_stats -o operators -- python scripts/bench_operators.py > gpurun_out/operators.json 2> gpurun_out/operators.err
   timeout 300 python scripts/bench_simulators.py > gpurun_out/simulators.json 2> gpurun_out/simulators.err
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_f1staged_stats -o f1staged -- python scripts/bench_staged_f1.py --batch 2048 --steps 5 > gpurun_out/staged_f1.json 2> gpurun_out/prof_f1staged.log
 fi
