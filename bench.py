@@ -109,6 +109,16 @@ def make_runner(eng, cfg, demod, dtype):
     return run, 1024, "QPSK + OFDM(1024, cp 16) over 5-tap Jakes TDL (Fd 10 Hz), one-tap EQ, SNR 20 dB (config 3)"
 
 
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return None
+
+
 def _oracle_chain(cfg):
     """(oracle chain, kwargs) of a bench configuration -- used by the cpu_baseline legs only."""
     from oracle import chains
@@ -285,6 +295,8 @@ def main():
                          "kernel": {"c4": "k_run_mimo_ofdm", "c2": "k_run_flat", "c3": "k_run_ofdm_tdl_batch",
                                     "c5": "k_run_ia", "f1": "k_run_mimo_ofdm_tdl", "f6": "k_run_bd"}[args.config],
                          "kernel_ms_per_launch": per_launch_s * 1e3,
+                         # SURVEY 8(d)'s reporting rule next to the tier's: HBM bytes the launch really moved / time
+                         "hbm_measured_GBps": (traffic / per_launch_s / 1e9) if traffic is not None else None,
                          "valu": valu,
                          "algorithmic_bytes_per_realization": balg,
                          "traffic_source": "profiles/traffic_%s.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
@@ -298,6 +310,7 @@ def main():
             res, se, be = eng_first_counts(eng, args, 16384 if args.config != "c2" else 128)
             cb, ser_err, n_chk = cpu_baseline(args.config, args.cpu_seconds, se)
             cb["host_cpu_count"] = os.cpu_count()
+            cb["host_cpu_model"] = _cpu_model()
             out["cpu_baseline"] = cb
             out["ser_abs_err_vs_oracle"] = ser_err
             out["ser_check_realizations"] = n_chk
