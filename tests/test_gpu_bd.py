@@ -81,6 +81,36 @@ def test_block_diagonalize_matches_the_reference_fixture(engine):
             engine.block_diagonalize(bad[2].astype(complex), bad[0], 1.0, 0.1)
 
 
+def test_block_diagonalize_random_sweep(engine):
+    """Many random channels of every supported geometry, well and badly conditioned: finite output, exact
+    block-diagonal structure, the power constraint, W newH = 1 on the active streams, and agreement with the
+    oracle's SVD-free formulation to a tolerance that scales with the channel's condition number."""
+    rs = np.random.RandomState(21)
+    for K, r in ((2, 1), (8, 1), (2, 2), (3, 2), (4, 2), (2, 3), (2, 4)):
+        n = K * r
+        H = (rs.randn(300, n, n) + 1j * rs.randn(300, n, n)) / np.sqrt(2)
+        H[:40] += 3.0 * (rs.randn(40, n, 1) + 1j * rs.randn(40, n, 1)) * np.ones((1, 1, n))   # nearly rank one
+        for wf, nv in ((True, 0.3), (False, 0.0)):
+            out = engine.block_diagonalize(H, K, 1.7, nv, wf)
+            assert not out["skipped"].any()
+            for key in ("Ms", "newH", "W", "sigma"):
+                assert np.isfinite(out[key]).all(), (K, r, key)
+            mask = np.kron(np.eye(K), np.ones((r, r))).astype(bool)
+            for b in range(0, 300, 7):
+                cond = np.linalg.cond(H[b])
+                tol = 1e-12 * max(cond, 1.0) ** 2 + 1e-11
+                Ms, newH, W = out["Ms"][b], out["newH"][b], out["W"][b]
+                scale = np.max(np.abs(newH))
+                assert np.max(np.abs(newH[~mask])) <= tol * scale, (K, r, b, cond)
+                pw = [np.linalg.norm(Ms[:, u * r:(u + 1) * r]) ** 2 for u in range(K)]
+                assert max(pw) <= 1.7 * (1 + 1e-9) and abs(max(pw) - 1.7) <= 1e-9 * 1.7
+                active = np.sum(np.abs(Ms), axis=0) > 0
+                assert relerr(np.diag(W @ newH)[active], np.ones(int(active.sum()))) <= tol
+                assert np.all(W[~active] == 0)
+                _, Ms_c, _ = obd.block_diagonalize_closed(H[b], K, 1.7, nv, wf)
+                assert relerr(Ms, Ms_c) <= max(tol, 1e-9) * 10, (K, r, b, cond)
+
+
 def test_mirror_classes_pass_the_reference_property_tests(engine):
     """tests/comm_package_test.py:112-332 on the mirror of pyphysim.comm.blockdiagonalization."""
     from pyphysim_amd.comm import blockdiagonalization as mbd, waterfilling as mwf
