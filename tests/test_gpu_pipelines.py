@@ -426,6 +426,27 @@ def test_mimo_flat_pipeline(engine, dt, exact, scheme, nt, nr, snr):
     check(res, se, be, want_se, want_be, nsym, nbits, exact)
 
 
+@pytest.mark.parametrize("NS", [1, 2, 51, 126, 130, 257, 258])
+def test_chunked_pipelines_ragged_symbol_counts(engine, NS):
+    """The one-wave pipelines take two columns per lane and pass when the symbol count is even (whole Philox
+    blocks, wave-shared data blocks: csrc/wave_draws.hpp) and one column per lane otherwise; both paths, with
+    partly filled passes and at every alignment of the rows in the streams, reproduce the oracle's counts."""
+    engine.set_constellation(chains.constellation("qam", 16), _lib.CONST_QAM)
+    first, count = 61, 9
+    kw = dict(mod="qam", M=16, K=3, nr=2, nt=2, Ns=1, NSymbs=NS, snr_db=12.0)
+    want = [chains.chain_ia(chains.PhiloxRng(SEED, r), **kw) for r in range(first, first + count)]
+    res, se, be, _, _ = engine.run_ia(NS, 1.0 / omodem.dB2Linear(12.0), SEED, first, count, dtype="f64",
+                                      per_realization=True)
+    assert np.array_equal(se, [w["symbol_errors"] for w in want]) and np.array_equal(be, [w["bit_errors"] for w in want])
+    for scheme, nt, nr in (("blast", 3, 4), ("blast", 2, 2), ("mrt", 4, 1), ("mrc", 1, 2)) + (
+            (("alamouti", 2, 2),) if NS % 2 == 0 else ()):
+        kw = dict(scheme=scheme, mod="qam", M=16, nt=nt, nr=nr, NSymbs=NS, snr_db=10.0)
+        want_se, want_be, nsym, nbits = oracle_counts(chains.chain_mimo_scheme, first, count, **kw)
+        res, se, be = engine.run_mimo_flat(scheme, nt, nr, NS, 1.0 / omodem.dB2Linear(10.0), SEED, first, count,
+                                           dtype="f64", per_realization=True)
+        check(res, se, be, want_se, want_be, nsym, nbits, True)
+
+
 @pytest.mark.parametrize("scheme,n", [("svd", 2), ("svd", 4), ("gmd", 2), ("gmd", 3), ("gmd", 4)])
 def test_mimo_flat_svd_gmd(engine, scheme, n):
     """Singular-vector phases are implementation-defined (LAPACK vs Jacobi), so per-realization decisions are
