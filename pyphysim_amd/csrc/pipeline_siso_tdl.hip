@@ -159,15 +159,15 @@ __global__ __launch_bounds__(kPipeBlock, sizeof(T) == 4 ? 3 : 1) void k_run_ofdm
                             const int tx = (int)((dw.w[j >> 2] >> ((j & 3) * 8)) & mask);
                             const int d = (int)(n - n_first);
                             s_idx[a * U + d] = (unsigned char)tx;
-                            s_x[a * N + lds_swz<true>(ofdm_bin(d, N, U))] = cscale(s_table[tx], tx_scale);
+                            s_x[a * N + lds_swz<true>(fft_pos_of_index<N>(ofdm_bin(d, N, U)))] = cscale(s_table[tx], tx_scale);
                         }
                     }
                 }
             }
             __syncthreads();
-            fft_dif<T, N, true, kPipeBlock, true, true>(s_x, NB, N, s_tw);   // time samples, digit-reversed positions
+            fft_dit<T, N, true, kPipeBlock, true, true>(s_x, NB, N, s_tw);   // bins scattered digit-reversed -> time samples in natural order
             auto time_sample = [&](int a, int i) -> cx<T> {                   // IFFT output i of slot a
-                return s_x[a * N + lds_swz<true>(fft_pos_of_index<N>(i & (N - 1)))];
+                return s_x[a * N + lds_swz<true>(i & (N - 1))];
             };
             const int tid_c = opaque(tid0);
             cx<T>* tail_prev = s_tail + (size_t)(os & 1) * NB * dmax;
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(kPipeBlock, sizeof(T) == 4 ? 3 : 1) void k_run_ofdm
                             const int q = cp + m - d;                // local index of the input sample
                             xx[k][e] = (T)((double)q - xc);
                             if (FAST || (m < N && q >= 0))
-                                pos[k][e] = lds_swz<true>(fft_pos_of_index<N>((m - d + N) & (N - 1)));
+                                pos[k][e] = lds_swz<true>((m - d + N) & (N - 1));
                             else if (m >= N)
                                 pos[k][e] = -1;
                             else
@@ -283,8 +283,8 @@ __global__ __launch_bounds__(kPipeBlock, sizeof(T) == 4 ? 3 : 1) void k_run_ofdm
             for (int k = 0; k < PAIRS; ++k) {
                 const int m0 = 2 * (tid_c + kPipeBlock * k);
                 if (m0 < N) {
-                    const int q0 = lds_swz<true>(fft_pos_of_index<N>(m0));
-                    const int q1 = lds_swz<true>(fft_pos_of_index<N>(m0 + 1));
+                    const int q0 = lds_swz<true>(m0);
+                    const int q1 = lds_swz<true>(m0 + 1);
 #pragma unroll
                     for (int a = 0; a < NB; ++a) {
                         s_x[a * N + q0] = y[a][k][0];
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(kPipeBlock, sizeof(T) == 4 ? 3 : 1) void k_run_ofdm
                 }
             }
             __syncthreads();
-            fft_dit<T, N, false, kPipeBlock, true, true>(s_x, NB, N, s_tw);   // bins, natural order
+            fft_dif<T, N, false, kPipeBlock, true, true>(s_x, NB, N, s_tw);   // bins, digit-reversed positions
             // ---- receive: one-tap equaliser from the tap means, demodulate, count -- one subcarrier per thread ----
             const int tid_r = opaque(tid0);
             for (int d = tid_r; d < U; d += kPipeBlock) {
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(kPipeBlock, sizeof(T) == 4 ? 3 : 1) void k_run_ofdm
 #pragma unroll
                     for (int a = 0; a < NB; ++a) h[a] = cfma(s_mean[a * S + s], w, h[a]);
                 }
-                const int bin = lds_swz<true>(f);
+                const int bin = lds_swz<true>(fft_pos_of_index<N>(f));
 #pragma unroll
                 for (int a = 0; a < NB; ++a) {
                     const cx<T> eq = cdivide(cscale(s_x[a * N + bin], rx_scale), h[a]);
