@@ -188,14 +188,14 @@ __global__ __launch_bounds__(kPipeBlock, sizeof(T) == 4 ? 3 : 1) void k_run_mimo
                         const int nl = (int)(n - n_first);
                         const int a = nl % NA, d = nl / NA;
                         s_idx[nl] = (unsigned char)tx;
-                        s_x[a * N + lds_swz<true>(ofdm_bin(d, N, U))] = cscale(table_at(tx), tx_scale);
+                        s_x[a * N + lds_swz<true>(fft_pos_of_index<N>(ofdm_bin(d, N, U)))] = cscale(table_at(tx), tx_scale);
                     }
                 }
             }
             __syncthreads();
-            fft_dif<T, N, true, kPipeBlock, true, FFT_FRESH>(s_x, NA, N, s_tw);   // time samples, digit-reversed positions
+            fft_dit<T, N, true, kPipeBlock, true, FFT_FRESH>(s_x, NA, N, s_tw);   // bins scattered digit-reversed -> time samples in natural order
             auto time_sample = [&](int a, int i) -> cx<T> {             // IFFT output i of antenna a
-                return s_x[a * N + lds_swz<true>(fft_pos_of_index<N>(i & (N - 1)))];
+                return s_x[a * N + lds_swz<true>(i & (N - 1))];
             };
             const int tid_c = opaque(tid0);      // channel phase: nothing derived from it outlives the next FFT
             // the last dmax samples of this symbol feed the head of the next one
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(kPipeBlock, sizeof(T) == 4 ? 3 : 1) void k_run_mimo
                             const int q = cp + m - d;                // local index of the input sample
                             xx[k][e] = (T)((double)q - xc);
                             if (FAST || (m < N && q >= 0))
-                                pos[k][e] = lds_swz<true>(fft_pos_of_index<N>((m - d + N) & (N - 1)));
+                                pos[k][e] = lds_swz<true>((m - d + N) & (N - 1));
                             else if (m >= N)
                                 pos[k][e] = -1;
                             else
@@ -331,8 +331,8 @@ __global__ __launch_bounds__(kPipeBlock, sizeof(T) == 4 ? 3 : 1) void k_run_mimo
             for (int k = 0; k < PAIRS; ++k) {
                 const int m0 = 2 * (tid_c + kPipeBlock * k);
                 if (m0 < N) {
-                    const int q0 = lds_swz<true>(fft_pos_of_index<N>(m0));
-                    const int q1 = lds_swz<true>(fft_pos_of_index<N>(m0 + 1));
+                    const int q0 = lds_swz<true>(m0);
+                    const int q1 = lds_swz<true>(m0 + 1);
 #pragma unroll
                     for (int r = 0; r < NA; ++r) {
                         s_x[r * N + q0] = y[r][k][0];
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(kPipeBlock, sizeof(T) == 4 ? 3 : 1) void k_run_mimo
                 }
             }
             __syncthreads();
-            fft_dit<T, N, false, kPipeBlock, true, FFT_FRESH>(s_x, NA, N, s_tw);   // bins, natural order
+            fft_dif<T, N, false, kPipeBlock, true, FFT_FRESH>(s_x, NA, N, s_tw);   // bins, digit-reversed positions
             // ---- receive: frequency response, filter, decode, demodulate, count -- one subcarrier per thread ----
             const int tid_r = opaque(tid0);
             for (int d = tid_r; d < U; d += kPipeBlock) {
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(kPipeBlock, sizeof(T) == 4 ? 3 : 1) void k_run_mimo
 #pragma unroll
                         for (int a = 0; a < NA; ++a) H[r][a] = cfma(s_mean[(s * NA + r) * NA + a], w, H[r][a]);
                 }
-                const int bin = lds_swz<true>(f);
+                const int bin = lds_swz<true>(fft_pos_of_index<N>(f));
                 cx<T> yb[NA];
 #pragma unroll
                 for (int r = 0; r < NA; ++r) yb[r] = s_x[r * N + bin];
