@@ -5,8 +5,11 @@
 // log2(N) is odd.  Two forms that chain WITHOUT any reordering pass:
 //     fft_dif : natural-order input  -> digit-reversed output   (decimation in frequency)
 //     fft_dit : digit-reversed input -> natural-order output    (decimation in time)
-// so an OFDM link does IFFT(dif) on the transmitter, per-sample channel work on the scrambled
-// time samples (position p holds time index fft_index_of_pos(p)), and FFT(dit) at the receiver.
+// so an OFDM link chains the two without a reordering pass, in either order: IFFT(dif) -> per-sample work
+// on scrambled time samples (position p holds time index fft_index_of_pos(p)) -> FFT(dit), used where the
+// channel is memoryless (config 4); or -- symbols scattered straight into digit-reversed bin positions --
+// IFFT(dit) -> time samples in NATURAL order -> FFT(dif) -> bins gathered from digit-reversed positions, used
+// by the tapped-delay-line kernels, whose x[m - d] gathers are then contiguous (conflict-free) LDS reads.
 // `nf` independent transforms (antennas) sit side by side in LDS, `pitch` elements apart; the
 // whole workgroup shares every stage.  Twiddles w[k] = exp(-2 pi i k / N) come from an LDS (or
 // global) table of N entries built in double precision on the host.

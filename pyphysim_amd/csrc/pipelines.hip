@@ -458,20 +458,20 @@ __global__ __launch_bounds__(BLOCK) void k_run_ofdm_tdl(TdlParams pp, ModemParam
                         const int tx = (int)((dw.w[j >> 2] >> ((j & 3) * 8)) & mask);
                         const int d = (int)(n - n_first);
                         s_idx[d] = (unsigned char)tx;
-                        cur[ofdm_bin(d, N, U)] = cscale(s_table[tx], tx_scale);
+                        cur[fft_pos_of_index<N>(ofdm_bin(d, N, U))] = cscale(s_table[tx], tx_scale);
                     }
                 }
             }
             __syncthreads();
-            fft_dif<T, N, true, BLOCK>(cur, 1, N, s_tw);
+            fft_dit<T, N, true, BLOCK>(cur, 1, N, s_tw);   // bins scattered digit-reversed -> time samples in natural order
             // ---- channel + noise for the N samples kept after CP removal, and the tap means ----
             const uint64_t sym0 = (uint64_t)os * (N + cp);  // absolute index of this symbol's first sample
             // the sample (q within this symbol, or of the previous one) that tap delay d feeds into output m
             auto tx_sample = [&](int m, int d) -> cx<T> {
                 const int q = cp + m - d;
-                if (q >= 0) return cur[fft_pos_of_index<N>((m - d + N) & (N - 1))];
+                if (q >= 0) return cur[(m - d + N) & (N - 1)];
                 const int qp = N + cp + q;  // inter-symbol interference: sample qp of the previous symbol
-                return qp >= cp ? prev[fft_pos_of_index<N>(qp - cp)] : prev[fft_pos_of_index<N>(N - cp + qp)];
+                return qp >= cp ? prev[qp - cp] : prev[N - cp + qp];
             };
             if constexpr (sizeof(T) == 4) {
                 // f32 path.  (1) mean of every ray over the symbol's N+cp samples in closed form (f64):
@@ -529,7 +529,7 @@ __global__ __launch_bounds__(BLOCK) void k_run_ofdm_tdl(TdlParams pp, ModemParam
 #pragma unroll
                 for (int k = 0; k < KS; ++k) {
                     const int m = tid + BLOCK * k;
-                    s_y[fft_pos_of_index<N>(m)] = cadd(sig[k], cn_sample<T>(rng, STREAM_NOISE, sym0 + cp + m, sigma));
+                    s_y[m] = cadd(sig[k], cn_sample<T>(rng, STREAM_NOISE, sym0 + cp + m, sigma));
                 }
             } else {
                 // f64 parity path: every tap gain from the closed form at its own sample time, the mean
@@ -582,16 +582,16 @@ __global__ __launch_bounds__(BLOCK) void k_run_ofdm_tdl(TdlParams pp, ModemParam
                         const T a = (T)pp.tap_amp[i];
                         sig = cadd(sig, cmul(mk<T>(a * gr, a * gi), tx_sample(m, d)));
                     }
-                    s_y[fft_pos_of_index<N>(m)] = cadd(sig, acc);
+                    s_y[m] = cadd(sig, acc);
                 }
             }
             __syncthreads();
-            fft_dit<T, N, false, BLOCK>(s_y, 1, N, s_tw);
+            fft_dif<T, N, false, BLOCK>(s_y, 1, N, s_tw);   // bins, digit-reversed positions
             for (int d = tid; d < U; d += BLOCK) {
                 const int bin = ofdm_bin(d, N, U);
                 cx<T> h = mk<T>(0, 0);
                 for (int i = 0; i < S; ++i) h = cfma(s_mean[i], s_tw[(bin * pp.tap_delay[i]) & (N - 1)], h);
-                const cx<T> eq = cdivide(cscale(s_y[bin], rx_scale), h);
+                const cx<T> eq = cdivide(cscale(s_y[fft_pos_of_index<N>(bin)], rx_scale), h);
                 const unsigned x = (unsigned)((int)s_idx[d] ^ demod_one(mp, s_table, s_grid, eq));
                 se += (x != 0u);
                 be += __popc(x);
