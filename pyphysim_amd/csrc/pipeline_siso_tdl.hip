@@ -378,7 +378,6 @@ int run_siso_tdl_batch_impl(mcle_ctx* ctx, SisoTdlParams pp, int method, uint64_
 // (FFT size, Doppler, LDS): the caller (pipelines.hip: mcle_run_ofdm_tdl) then runs the single-realization kernel.
 int run_ofdm_tdl_batched(mcle_ctx* ctx, int dtype, const mcle_ofdm_tdl_cfg* cfg, uint64_t seed, uint64_t first,
                          uint64_t count, mcle_counters* d_counters, uint32_t* d_sym, uint32_t* d_bit) {
-    if (cfg->fft_size != 64 && cfg->fft_size != 256 && cfg->fft_size != 1024) return MCLE_E_UNSUPPORTED;
     SisoTdlParams pp;
     pp.cp = cfg->cp_size;
     pp.num_used = cfg->num_used;
@@ -433,7 +432,7 @@ int run_ofdm_tdl_batched(mcle_ctx* ctx, int dtype, const mcle_ofdm_tdl_cfg* cfg,
                                                                       d_counters, d_sym, d_bit)                        \
                                  : run_siso_tdl_batch_impl<double, N_>(ctx, pp, cfg->demod_method, seed, first, count, \
                                                                        d_counters, d_sym, d_bit);
-    MCLE_RUN(64) MCLE_RUN(256) MCLE_RUN(1024)
+    MCLE_RUN(64) MCLE_RUN(128) MCLE_RUN(256) MCLE_RUN(512) MCLE_RUN(1024) MCLE_RUN(2048)
 #undef MCLE_RUN
     return MCLE_E_UNSUPPORTED;
 }

@@ -126,6 +126,33 @@ def test_ofdm_tdl_batched_kernel_equals_single(engine, monkeypatch):
         assert a[k] == b[k] + c[k]
 
 
+@pytest.mark.parametrize("fft,cp,used,nsym", [(64, 5, 52, 3), (128, 9, 100, 2), (256, 20, 256, 2), (512, 36, 300, 2),
+                                              (2048, 144, 1200, 1)])
+def test_ofdm_tdl_every_fft_size(engine, monkeypatch, fft, cp, used, nsym):
+    """Every power-of-two OFDM size: the batched kernel (64 ... 2048) and the single-realization kernel it falls
+    back to (other sizes, or when the four-realization pass does not fit LDS) give the oracle's counts in f64 --
+    ragged used-subcarrier counts, several OFDM symbols, a CP shorter than the delay spread."""
+    engine.set_constellation(chains.constellation("qam", 16), _lib.CONST_QAM)
+    Ts = 1e-6
+    kw = dict(mod="qam", M=16, fft_size=fft, cp_size=cp, num_used=used, n_ofdm_sym=nsym, snr_db=22.0, Fd=60.0, Ts=Ts,
+              L=8, tap_powers_dB=(0.0, -4.0, -8.0), tap_delays_samples=(0, 3, 7))
+    p_lin, d_idx = och.discretize_profile(np.array(kw["tap_powers_dB"]), np.array(kw["tap_delays_samples"]) * Ts, Ts)
+    first, count = 2, 6
+    want_se, want_be, n_sym, n_bits = oracle_counts(chains.chain_ofdm_tdl, first, count, **kw)
+    for single in (False, True):
+        if single:
+            monkeypatch.setenv("MCLE_SINGLE_TDL", "1")
+        else:
+            monkeypatch.delenv("MCLE_SINGLE_TDL", raising=False)
+        res, se, be = engine.run_ofdm_tdl(fft, cp, used, nsym, 1.0 / omodem.dB2Linear(22.0), p_lin, d_idx, SEED, first,
+                                          count, Fd=60.0, Ts=Ts, L=8, dtype="f64", per_realization=True)
+        check(res, se, be, want_se, want_be, n_sym, n_bits, True)
+    if fft == 64:
+        for bad in (32, 4096, 96):                      # outside the fused kernels: a clear error, never a wrong answer
+            with pytest.raises(Exception, match="fft_size"):
+                engine.run_ofdm_tdl(bad, 8, bad, 1, 0.01, p_lin, d_idx, SEED, 0, 4, Fd=60.0, Ts=Ts, L=8)
+
+
 @pytest.mark.parametrize("dt,exact", [("f64", True), ("f32", False)])
 @pytest.mark.parametrize("case", [0, 1, 2])
 def test_mimo_ofdm_pipeline(engine, dt, exact, case):
