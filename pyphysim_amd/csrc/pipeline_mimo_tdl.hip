@@ -410,7 +410,10 @@ int run_mimo_tdl_impl(mcle_ctx* ctx, MimoTdlParams pp, int method, uint64_t seed
                        (size_t)((mp.M + 15) & ~15) * (sizeof(T) == 4 ? sizeof(float4) : sizeof(cx<T>)) +
                        16 * sizeof(unsigned) +
                        (size_t)mp.grid.G * mp.grid.G * sizeof(unsigned long long) + (size_t)NA * pp.num_used + 16;
-    MCLE_REQUIRE(lds <= 160 * 1024, "configuration needs %zu bytes of LDS (limit 160 KiB)", lds);
+    if (lds > 160 * 1024) {   // the staged operator chain has no such limit
+        set_error("configuration needs %zu bytes of LDS (limit 160 KiB)", lds);
+        return MCLE_E_UNSUPPORTED;
+    }
     auto kern = k_run_mimo_ofdm_tdl<T, N, NA>;
     MCLE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int per_cu = (int)((size_t)160 * 1024 / (lds + 512));
@@ -508,8 +511,9 @@ extern "C" int mcle_run_mimo_ofdm_tdl(mcle_ctx* ctx, int dtype, const mcle_mimo_
                                                                      count, d_counters, d_sym_err, d_bit_err)   \
                                  : run_mimo_tdl_impl<double, N_, NA_>(ctx, pp, cfg->demod_method, seed, first,  \
                                                                       count, d_counters, d_sym_err, d_bit_err);
-    MCLE_RUN(64, 2) MCLE_RUN(64, 4) MCLE_RUN(256, 2) MCLE_RUN(256, 4) MCLE_RUN(1024, 2) MCLE_RUN(1024, 4)
+    MCLE_RUN(64, 2) MCLE_RUN(64, 4) MCLE_RUN(128, 2) MCLE_RUN(128, 4) MCLE_RUN(256, 2) MCLE_RUN(256, 4)
+    MCLE_RUN(512, 2) MCLE_RUN(512, 4) MCLE_RUN(1024, 2) MCLE_RUN(1024, 4) MCLE_RUN(2048, 2) MCLE_RUN(2048, 4)
 #undef MCLE_RUN
-    set_error("fused MIMO-TDL pipeline supports fft_size in {64, 256, 1024} (got %d)", cfg->fft_size);
+    set_error("fused MIMO-TDL pipeline supports fft_size in {64, 128, ..., 2048} (got %d)", cfg->fft_size);
     return MCLE_E_INVAL;
 }

@@ -236,7 +236,7 @@ class MimoOfdmTdlSimulator(_LinkSimulator):
                      ("L", int(L)), ("mmse", bool(mmse))):
             self.params.add(k, v)
 
-    _FUSED_FFT = (64, 256, 1024)
+    _FUSED_FFT = (64, 128, 256, 512, 1024, 2048)
 
     def _launch(self, current_parameters, first_rep, count, per_realization):
         p = current_parameters
@@ -252,7 +252,7 @@ class MimoOfdmTdlSimulator(_LinkSimulator):
                 if self.fused is True:
                     raise
         elif self.fused is True:
-            raise ValueError("the fused pipeline supports Nt == Nr in {2, 4} and fft_size in {64, 256, 1024}")
+            raise ValueError("the fused pipeline supports Nt == Nr in {2, 4} and fft_size in {64, 128, ..., 2048}")
         return self._launch_staged(p, first_rep, count, per_realization)
 
     def _launch_staged(self, p, first_rep, count, per_realization):

@@ -174,7 +174,10 @@ def test_batched_philox_operators(engine):
                                        snr_db=25.0, Fd=10.0, Ts=1.0 / (15e3 * 1024),
                                        tap_powers_dB=(0.0, -3.0, -6.0, -9.0, -12.0),
                                        tap_delays_samples=(0, 1, 2, 3, 4)),
-                                  dict(Fd=70.0, Ts=1e-5)])
+                                  dict(Fd=70.0, Ts=1e-5),
+                                  dict(fft_size=128, num_used=100, cp_size=9),
+                                  dict(nt=4, nr=4, fft_size=512, num_used=300, cp_size=36, n_ofdm_sym=1, M=64, snr_db=24.0),
+                                  dict(fft_size=2048, num_used=1200, cp_size=144, n_ofdm_sym=1, Fd=5.0)])
 def test_mimo_ofdm_tdl_fused_matches_oracle(over):
     """The fused kernel (polynomial tap model) against the oracle chain on the same Philox draws: equal
     per-realization counts in f64 (incl. inter-symbol interference through the CP, cp < max delay, and a
