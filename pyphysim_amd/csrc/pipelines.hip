@@ -666,6 +666,7 @@ int run_mimo_impl(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, uint64_t seed, u
     const size_t lds = (size_t)(NA * N + N + kMaxTable + 2 * NA * NA) * sizeof(cx<T>) + kMaxTable * sizeof(float4) +
                        16 * sizeof(unsigned) + (size_t)mp.grid.G * mp.grid.G * sizeof(unsigned long long) +
                        (size_t)NA * cfg->num_used;
+    MCLE_REQUIRE(lds <= 160 * 1024, "configuration needs %zu bytes of LDS (limit 160 KiB)", lds);
     auto kern = k_run_mimo_ofdm<T, N, NA>;
     MCLE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int per_cu = (int)((size_t)160 * 1024 / (lds + 512));  // gfx950: 160 KiB of LDS per CU
@@ -797,9 +798,10 @@ int mcle_run_mimo_ofdm(mcle_ctx* ctx, int dtype, const mcle_mimo_ofdm_cfg* cfg, 
         return dtype == MCLE_F32                                                                                  \
                    ? run_mimo_impl<float, N_, NA_>(ctx, cfg, seed, first, count, d_counters, d_sym_err, d_bit_err) \
                    : run_mimo_impl<double, N_, NA_>(ctx, cfg, seed, first, count, d_counters, d_sym_err, d_bit_err);
-    MCLE_RUN(64, 2) MCLE_RUN(64, 4) MCLE_RUN(256, 2) MCLE_RUN(256, 4) MCLE_RUN(1024, 2) MCLE_RUN(1024, 4)
+    MCLE_RUN(64, 2) MCLE_RUN(64, 4) MCLE_RUN(128, 2) MCLE_RUN(128, 4) MCLE_RUN(256, 2) MCLE_RUN(256, 4)
+    MCLE_RUN(512, 2) MCLE_RUN(512, 4) MCLE_RUN(1024, 2) MCLE_RUN(1024, 4) MCLE_RUN(2048, 2) MCLE_RUN(2048, 4)
 #undef MCLE_RUN
-    set_error("fused MIMO pipeline supports fft_size in {64, 256, 1024} (got %d)", cfg->fft_size);
+    set_error("fused MIMO pipeline supports fft_size in {64, 128, ..., 2048} (got %d)", cfg->fft_size);
     return MCLE_E_INVAL;
 }
 

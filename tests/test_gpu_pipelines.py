@@ -154,14 +154,20 @@ def test_ofdm_tdl_every_fft_size(engine, monkeypatch, fft, cp, used, nsym):
 
 
 @pytest.mark.parametrize("dt,exact", [("f64", True), ("f32", False)])
-@pytest.mark.parametrize("case", [0, 1, 2])
+@pytest.mark.parametrize("case", [0, 1, 2, 3, 4, 5])
 def test_mimo_ofdm_pipeline(engine, dt, exact, case):
     kws = [dict(mod="qam", M=64, nt=4, nr=4, fft_size=1024, cp_size=16, num_used=None, n_ofdm_sym=1, snr_db=25.0,
                 mmse=True),
            dict(mod="qam", M=16, nt=2, nr=2, fft_size=64, cp_size=8, num_used=48, n_ofdm_sym=2, snr_db=15.0,
                 mmse=False),
            dict(mod="qam", M=16, nt=4, nr=4, fft_size=256, cp_size=7, num_used=200, n_ofdm_sym=2, snr_db=18.0,
-                mmse=True)]
+                mmse=True),
+           dict(mod="qam", M=16, nt=2, nr=2, fft_size=128, cp_size=9, num_used=100, n_ofdm_sym=2, snr_db=16.0,
+                mmse=True),
+           dict(mod="qam", M=64, nt=4, nr=4, fft_size=512, cp_size=36, num_used=300, n_ofdm_sym=1, snr_db=24.0,
+                mmse=True),
+           dict(mod="qam", M=16, nt=2, nr=2, fft_size=2048, cp_size=144, num_used=1200, n_ofdm_sym=1, snr_db=17.0,
+                mmse=False)]
     kw = kws[case]
     engine.set_constellation(chains.constellation(kw["mod"], kw["M"]), _lib.CONST_QAM)
     first, count = 31, 6
