@@ -209,6 +209,7 @@ template <typename T, int N, int NA>
 __global__ __launch_bounds__(kPipeBlock, sizeof(T) == 4 ? 3 : 1) void k_run_mimo_ofdm(MimoParams pp, ModemParams<T> mp, uint64_t seed,
                                                               uint64_t first, uint64_t count,
                                                               const cx<T>* __restrict__ g_tw,
+                                                              cx<T>* g_filters,
                                                               mcle_counters* counters,
                                                               uint32_t* __restrict__ sym_out,
                                                               uint32_t* __restrict__ bit_out) {
@@ -241,25 +242,48 @@ __global__ __launch_bounds__(kPipeBlock, sizeof(T) == 4 ? 3 : 1) void k_run_mimo
     __shared__ WgTotals totals;
     if (threadIdx.x == 0) wg_zero(totals);
 
-    for (uint64_t rl = blockIdx.x; rl < count; rl += gridDim.x) {
+    // Channel draw and receive filter, 64 realizations at a time: lane j of wave 0 prepares the j-th of this
+    // workgroup's next 64 realizations (the f64 Cholesky is ~750 double-precision instructions -- run by one lane
+    // per realization it stalled the other 255 threads for ~9 % of the kernel) and parks H and G in the workgroup's
+    // slice of g_filters [gridDim.x][64][2*NA*NA + 1]; the realization loop then stages one record through LDS.
+    constexpr int kRec = 2 * NA * NA + 1;
+    cx<T>* my_filters = g_filters + (size_t)blockIdx.x * 64 * kRec;
+    uint64_t it = 0;
+    for (uint64_t rl = blockIdx.x; rl < count; rl += gridDim.x, ++it) {
         const Rng rng(seed, first + rl);
+        const int slot = (int)(it & 63);
         __syncthreads();
-        if (tid < NA * NA) s_H[tid] = cn_sample<T>(rng, STREAM_CHAN, (uint64_t)tid, (T)1);
-        __syncthreads();
-        if (tid == 0) {
-            double2 H[NA][NA], G[NA][NA];
-#pragma unroll
-            for (int r = 0; r < NA; ++r)
-#pragma unroll
-                for (int a = 0; a < NA; ++a) H[r][a] = mk<double>((double)s_H[r * NA + a].x, (double)s_H[r * NA + a].y);
-            const bool ok = blast_filter<NA, NA>(H, pp.mmse ? pp.noise_var : 0.0, G);
-#pragma unroll
-            for (int a = 0; a < NA; ++a)
+        if (slot == 0) {
+            const uint64_t rj = rl + (uint64_t)tid * gridDim.x;
+            if (tid < 64 && rj < count) {
+                const Rng rngj(seed, first + rj);
+                cx<T>* rec = my_filters + tid * kRec;
+                double2 H[NA][NA], G[NA][NA];
 #pragma unroll
                 for (int r = 0; r < NA; ++r)
-                    s_G[a * NA + r] = mk<T>((T)(G[a][r].x * rx_scale), (T)(G[a][r].y * rx_scale));
-            s_red[15] = ok ? 0u : 1u;
+#pragma unroll
+                    for (int a = 0; a < NA; ++a) {
+                        const cx<T> h = cn_sample<T>(rngj, STREAM_CHAN, (uint64_t)(r * NA + a), (T)1);
+                        rec[r * NA + a] = h;
+                        H[r][a] = mk<double>((double)h.x, (double)h.y);
+                    }
+                const bool ok = blast_filter<NA, NA>(H, pp.mmse ? pp.noise_var : 0.0, G);
+#pragma unroll
+                for (int a = 0; a < NA; ++a)
+#pragma unroll
+                    for (int r = 0; r < NA; ++r)
+                        rec[NA * NA + a * NA + r] = mk<T>((T)(G[a][r].x * rx_scale), (T)(G[a][r].y * rx_scale));
+                rec[2 * NA * NA] = mk<T>(ok ? (T)0 : (T)1, (T)0);
+            }
+            __threadfence_block();
+            __syncthreads();
         }
+        if (tid < kRec) {                                                      // per-lane addresses: vector loads
+            const cx<T> v = my_filters[slot * kRec + tid];
+            if (tid < 2 * NA * NA) s_H[tid] = v;                               // s_G follows s_H in LDS
+            else s_red[15] = v.x != (T)0 ? 1u : 0u;
+        }
+        __syncthreads();
         cx<T> H[NA][NA];
 #pragma unroll
         for (int r = 0; r < NA; ++r)
@@ -668,14 +692,16 @@ int run_mimo_impl(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, uint64_t seed, u
                        (size_t)NA * cfg->num_used;
     MCLE_REQUIRE(lds <= 160 * 1024, "configuration needs %zu bytes of LDS (limit 160 KiB)", lds);
     auto kern = k_run_mimo_ofdm<T, N, NA>;
+    void* filters = nullptr;
     MCLE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int per_cu = (int)((size_t)160 * 1024 / (lds + 512));  // gfx950: 160 KiB of LDS per CU
     if (per_cu < 1) per_cu = 1;
     if (per_cu > 8) per_cu = 8;
     const uint64_t cap = (uint64_t)ctx->n_cu * per_cu;
     const unsigned grid = (unsigned)(count < cap ? count : cap);
+    if ((rc = ctx->scratch((size_t)grid * 64 * (2 * NA * NA + 1) * sizeof(cx<T>), &filters))) return rc;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kPipeBlock), lds, ctx->stream, pp, mp, seed, first, count,
-                       (const cx<T>*)tw, d_counters, d_sym, d_bit);
+                       (const cx<T>*)tw, (cx<T>*)filters, d_counters, d_sym, d_bit);
     MCLE_LAUNCH_CHECK();
     return MCLE_OK;
 }
