@@ -106,12 +106,19 @@ __global__ __launch_bounds__(kPipeBlock) void k_run_flat(FlatParams fp, ModemPar
     const T sigma = (T)fp.noise_sigma;
     const T amp = fp.L > 0 ? (T)sqrt(1.0 / (double)fp.L) : (T)1;
     const uint32_t mask = (uint32_t)(mp.M - 1);
-    for (uint64_t item = blockIdx.x; item < items; item += gridDim.x) {
+    // every workgroup takes a contiguous run of items: consecutive chunks of one realization share the ray set-up
+    // (two f64 cosines / sincos per ray), which is redone only when the realization changes
+    const uint64_t per_wg = (items + gridDim.x - 1) / gridDim.x;
+    const uint64_t item_end = min((uint64_t)(blockIdx.x + 1) * per_wg, items);
+    uint64_t last_rl = ~0ull;
+    for (uint64_t item = (uint64_t)blockIdx.x * per_wg; item < item_end; ++item) {
         const uint64_t rl = item / chunks;
         const int chunk = (int)(item - rl * chunks);
         const Rng rng(seed, first + rl);
         __syncthreads();
-        if (fp.L > 0 && (int)threadIdx.x < fp.L) {
+        const bool fresh = rl != last_rl;
+        last_rl = rl;
+        if (fresh && fp.L > 0 && (int)threadIdx.x < fp.L) {
             // fading_generators.py:421-425: phi then psi, 2*pi*rand(L, 1, 1)
             const double two_pi = 6.283185307179586476925286766559;
             const double phi = two_pi * uniform_at(rng, STREAM_PHASE, threadIdx.x);
