@@ -224,4 +224,98 @@ __device__ __forceinline__ void fft_dit(cx<T>* s_data, int nf, int pitch, const 
     }
 }
 
+
+// ---- register-resident twiddles ------------------------------------------------------------------
+// With NTHREADS == N/4 every thread runs ONE butterfly position per stage (the same in each of the nf
+// transforms), so its three twiddles per stage are loop invariants of the caller's realization loop:
+// fft_twiddle_regs() loads them once, the *_r transforms take them from registers (no LDS twiddle reads).
+template <int N> struct FftTwRegs {
+    static constexpr int STAGES = FftShape<N>::N4;
+};
+template <typename T, int N, int NTHREADS>
+__device__ __forceinline__ void fft_twiddle_regs(const cx<T>* tw, cx<T> (&r)[FftShape<N>::N4][3]) {
+    static_assert(NTHREADS == N / 4, "one butterfly per thread and stage");
+    int s = N / 4;
+#pragma unroll
+    for (int st = 0; st < FftShape<N>::N4; ++st, s >>= 2) {      // DIF stage order: spans N/4, N/16, ...
+        const int k = (int)threadIdx.x & (s - 1), twstep = N / (4 * s);
+        r[st][0] = tw[k * twstep];
+        r[st][1] = tw[2 * k * twstep];
+        r[st][2] = tw[3 * k * twstep];
+    }
+}
+template <typename T, bool INV> __device__ __forceinline__ cx<T> tw_reg(cx<T> w) {
+    if (INV) w.y = -w.y;
+    return w;
+}
+template <typename T, int N, bool INV, int NTHREADS, bool SWZ>
+__device__ __forceinline__ void fft_dif_r(cx<T>* s_data, int nf, int pitch, const cx<T> (&twr)[FftShape<N>::N4][3]) {
+    static_assert(NTHREADS == N / 4 && !FftShape<N>::HAS2, "radix-4 only, one butterfly per thread and stage");
+    int s = N / 4;
+#pragma unroll
+    for (int st = 0; st < FftShape<N>::N4; ++st, s >>= 2) {
+        const int bb = (int)threadIdx.x;
+        const int k = bb & (s - 1), g = bb / s;
+        const int e0 = g * 4 * s + k;
+        const int i0 = lds_swz<SWZ>(e0), i1 = lds_swz<SWZ>(e0 + s), i2 = lds_swz<SWZ>(e0 + 2 * s),
+                  i3 = lds_swz<SWZ>(e0 + 3 * s);
+        const cx<T> w1 = tw_reg<T, INV>(twr[st][0]), w2 = tw_reg<T, INV>(twr[st][1]), w3 = tw_reg<T, INV>(twr[st][2]);
+#pragma unroll 4
+        for (int f = 0; f < nf; ++f) {
+            cx<T>* p = s_data + f * pitch;
+            const cx<T> x0 = p[i0], x1 = p[i1], x2 = p[i2], x3 = p[i3];
+            const cx<T> a0 = cadd(x0, x2), a1 = csub(x0, x2), a2 = cadd(x1, x3), a3 = rot<T, INV>(csub(x1, x3));
+            cx<T> y0 = cadd(a0, a2), y1 = cadd(a1, a3), y2 = csub(a0, a2), y3 = csub(a1, a3);
+            if (s > 1) {
+                y1 = cmul(y1, w1);
+                y2 = cmul(y2, w2);
+                y3 = cmul(y3, w3);
+            }
+            p[i0] = y0;
+            p[i1] = y1;
+            p[i2] = y2;
+            p[i3] = y3;
+        }
+        if (st + 1 < FftShape<N>::N4)
+            fft_stage_sync<NTHREADS>(s);
+        else
+            __syncthreads();
+    }
+}
+template <typename T, int N, bool INV, int NTHREADS, bool SWZ>
+__device__ __forceinline__ void fft_dit_r(cx<T>* s_data, int nf, int pitch, const cx<T> (&twr)[FftShape<N>::N4][3]) {
+    static_assert(NTHREADS == N / 4 && !FftShape<N>::HAS2, "radix-4 only, one butterfly per thread and stage");
+    int s = 1;
+#pragma unroll
+    for (int st = 0; st < FftShape<N>::N4; ++st, s <<= 2) {
+        const int bb = (int)threadIdx.x;
+        const int k = bb & (s - 1), g = bb / s;
+        const int e0 = g * 4 * s + k;
+        const int i0 = lds_swz<SWZ>(e0), i1 = lds_swz<SWZ>(e0 + s), i2 = lds_swz<SWZ>(e0 + 2 * s),
+                  i3 = lds_swz<SWZ>(e0 + 3 * s);
+        // DIT stage with span s uses the registers of the DIF stage with the same span
+        const int rs = FftShape<N>::N4 - 1 - st;
+        const cx<T> w1 = tw_reg<T, INV>(twr[rs][0]), w2 = tw_reg<T, INV>(twr[rs][1]), w3 = tw_reg<T, INV>(twr[rs][2]);
+#pragma unroll 4
+        for (int f = 0; f < nf; ++f) {
+            cx<T>* p = s_data + f * pitch;
+            cx<T> u0 = p[i0], u1 = p[i1], u2 = p[i2], u3 = p[i3];
+            if (s > 1) {
+                u1 = cmul(u1, w1);
+                u2 = cmul(u2, w2);
+                u3 = cmul(u3, w3);
+            }
+            const cx<T> a0 = cadd(u0, u2), a1 = csub(u0, u2), a2 = cadd(u1, u3), a3 = rot<T, INV>(csub(u1, u3));
+            p[i0] = cadd(a0, a2);
+            p[i1] = cadd(a1, a3);
+            p[i2] = csub(a0, a2);
+            p[i3] = csub(a1, a3);
+        }
+        if (st + 1 < FftShape<N>::N4)
+            fft_stage_sync<NTHREADS>(4 * s);
+        else
+            __syncthreads();
+    }
+}
+
 }  // namespace mcle

@@ -249,6 +249,13 @@ __global__ __launch_bounds__(kPipeBlock, sizeof(T) == 4 ? 3 : 1) void k_run_mimo
     __shared__ WgTotals totals;
     if (threadIdx.x == 0) wg_zero(totals);
 
+    // one butterfly position per thread and stage (N = 4 * threads, radix-4 only): its twiddles live in registers
+    constexpr bool kTwRegs = (N == 4 * kPipeBlock) && !FftShape<N>::HAS2 && sizeof(T) == 4;
+    cx<T> twr[FftShape<N>::N4][3];
+    if constexpr (kTwRegs) {
+        __syncthreads();
+        fft_twiddle_regs<T, N, kPipeBlock>(s_tw, twr);
+    }
     // Channel draw and receive filter, 64 realizations at a time: lane j of wave 0 prepares the j-th of this
     // workgroup's next 64 realizations (the f64 Cholesky is ~750 double-precision instructions -- run by one lane
     // per realization it stalled the other 255 threads for ~9 % of the kernel) and parks H and G in the workgroup's
@@ -321,7 +328,10 @@ __global__ __launch_bounds__(kPipeBlock, sizeof(T) == 4 ? 3 : 1) void k_run_mimo
                 }
             }
             __syncthreads();
-            fft_dif<T, N, true, kPipeBlock, true>(s_x, NA, N, s_tw);  // time samples, digit-reversed positions
+            if constexpr (kTwRegs)
+                fft_dif_r<T, N, true, kPipeBlock, true>(s_x, NA, N, twr);
+            else
+                fft_dif<T, N, true, kPipeBlock, true>(s_x, NA, N, s_tw);  // time samples, digit-reversed positions
             // ---- channel: R = H T + noise on the samples that survive CP removal ----
             for (int j = opaque(tid); j < N / 2; j += kPipeBlock) {   // phase-local addresses (see fft.hpp FRESH)
                 const int half = j / (N / 4), rest = j - half * (N / 4);
@@ -354,7 +364,10 @@ __global__ __launch_bounds__(kPipeBlock, sizeof(T) == 4 ? 3 : 1) void k_run_mimo
                 }
             }
             __syncthreads();
-            fft_dit<T, N, false, kPipeBlock, true>(s_x, NA, N, s_tw);  // bins, natural order
+            if constexpr (kTwRegs)
+                fft_dit_r<T, N, false, kPipeBlock, true>(s_x, NA, N, twr);
+            else
+                fft_dit<T, N, false, kPipeBlock, true>(s_x, NA, N, s_tw);  // bins, natural order
             // ---- receive: Blast decode (G already carries the FFT scale), demodulate, count ----
             cx<T> G[NA][NA];
 #pragma unroll
