@@ -248,13 +248,13 @@ template <typename T, bool INV> __device__ __forceinline__ cx<T> tw_reg(cx<T> w)
     if (INV) w.y = -w.y;
     return w;
 }
-template <typename T, int N, bool INV, int NTHREADS, bool SWZ>
+template <typename T, int N, bool INV, int NTHREADS, bool SWZ, bool FRESH = false>
 __device__ __forceinline__ void fft_dif_r(cx<T>* s_data, int nf, int pitch, const cx<T> (&twr)[FftShape<N>::N4][3]) {
     static_assert(NTHREADS == N / 4 && !FftShape<N>::HAS2, "radix-4 only, one butterfly per thread and stage");
     int s = N / 4;
 #pragma unroll
     for (int st = 0; st < FftShape<N>::N4; ++st, s >>= 2) {
-        const int bb = (int)threadIdx.x;
+        const int bb = FRESH ? opaque((int)threadIdx.x) : (int)threadIdx.x;
         const int k = bb & (s - 1), g = bb / s;
         const int e0 = g * 4 * s + k;
         const int i0 = lds_swz<SWZ>(e0), i1 = lds_swz<SWZ>(e0 + s), i2 = lds_swz<SWZ>(e0 + 2 * s),
@@ -282,13 +282,13 @@ __device__ __forceinline__ void fft_dif_r(cx<T>* s_data, int nf, int pitch, cons
             __syncthreads();
     }
 }
-template <typename T, int N, bool INV, int NTHREADS, bool SWZ>
+template <typename T, int N, bool INV, int NTHREADS, bool SWZ, bool FRESH = false>
 __device__ __forceinline__ void fft_dit_r(cx<T>* s_data, int nf, int pitch, const cx<T> (&twr)[FftShape<N>::N4][3]) {
     static_assert(NTHREADS == N / 4 && !FftShape<N>::HAS2, "radix-4 only, one butterfly per thread and stage");
     int s = 1;
 #pragma unroll
     for (int st = 0; st < FftShape<N>::N4; ++st, s <<= 2) {
-        const int bb = (int)threadIdx.x;
+        const int bb = FRESH ? opaque((int)threadIdx.x) : (int)threadIdx.x;
         const int k = bb & (s - 1), g = bb / s;
         const int e0 = g * 4 * s + k;
         const int i0 = lds_swz<SWZ>(e0), i1 = lds_swz<SWZ>(e0 + s), i2 = lds_swz<SWZ>(e0 + 2 * s),

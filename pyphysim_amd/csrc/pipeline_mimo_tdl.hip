@@ -100,6 +100,13 @@ __global__ __launch_bounds__(kPipeBlock, sizeof(T) == 4 ? 3 : 1) void k_run_mimo
     __shared__ WgTotals totals;
     if (tid0 == 0) wg_zero(totals);
 
+    // one butterfly position per thread and stage (N = 4 * threads, radix-4 only): its twiddles live in registers
+    constexpr bool kTwRegs = (N == 4 * kPipeBlock) && !FftShape<N>::HAS2 && sizeof(T) == 4;
+    cx<T> twr[FftShape<N>::N4][3];
+    if constexpr (kTwRegs) {
+        __syncthreads();
+        fft_twiddle_regs<T, N, kPipeBlock>(s_tw, twr);
+    }
     for (uint64_t rl = blockIdx.x; rl < count; rl += gridDim.x) {
         const Rng rng(seed, first + rl);
         unsigned se = 0, be = 0;
@@ -193,7 +200,10 @@ __global__ __launch_bounds__(kPipeBlock, sizeof(T) == 4 ? 3 : 1) void k_run_mimo
                 }
             }
             __syncthreads();
-            fft_dit<T, N, true, kPipeBlock, true, FFT_FRESH>(s_x, NA, N, s_tw);   // bins scattered digit-reversed -> time samples in natural order
+            if constexpr (kTwRegs)
+                fft_dit_r<T, N, true, kPipeBlock, true, FFT_FRESH>(s_x, NA, N, twr);
+            else
+                fft_dit<T, N, true, kPipeBlock, true, FFT_FRESH>(s_x, NA, N, s_tw);   // bins scattered digit-reversed -> time samples in natural order
             auto time_sample = [&](int a, int i) -> cx<T> {             // IFFT output i of antenna a
                 return s_x[a * N + lds_swz<true>(i & (N - 1))];
             };
@@ -341,7 +351,10 @@ __global__ __launch_bounds__(kPipeBlock, sizeof(T) == 4 ? 3 : 1) void k_run_mimo
                 }
             }
             __syncthreads();
-            fft_dif<T, N, false, kPipeBlock, true, FFT_FRESH>(s_x, NA, N, s_tw);   // bins, digit-reversed positions
+            if constexpr (kTwRegs)
+                fft_dif_r<T, N, false, kPipeBlock, true, FFT_FRESH>(s_x, NA, N, twr);
+            else
+                fft_dif<T, N, false, kPipeBlock, true, FFT_FRESH>(s_x, NA, N, s_tw);   // bins, digit-reversed positions
             // ---- receive: frequency response, filter, decode, demodulate, count -- one subcarrier per thread ----
             const int tid_r = opaque(tid0);
             for (int d = tid_r; d < U; d += kPipeBlock) {

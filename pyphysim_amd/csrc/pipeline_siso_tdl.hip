@@ -68,6 +68,13 @@ __global__ __launch_bounds__(kPipeBlock, sizeof(T) == 4 ? 3 : 1) void k_run_ofdm
     __shared__ WgTotals totals;
     if (tid0 == 0) wg_zero(totals);
 
+    // one butterfly position per thread and stage (N = 4 * threads, radix-4 only): its twiddles live in registers
+    constexpr bool kTwRegs = (N == 4 * kPipeBlock) && !FftShape<N>::HAS2 && sizeof(T) == 4;
+    cx<T> twr[FftShape<N>::N4][3];
+    if constexpr (kTwRegs) {
+        __syncthreads();
+        fft_twiddle_regs<T, N, kPipeBlock>(s_tw, twr);
+    }
     const uint64_t n_pass = (count + NB - 1) / NB;
     for (uint64_t ps = blockIdx.x; ps < n_pass; ps += gridDim.x) {
         const uint64_t base = ps * NB;                  // slot a carries realization base + a (idle past `count`)
@@ -165,7 +172,10 @@ __global__ __launch_bounds__(kPipeBlock, sizeof(T) == 4 ? 3 : 1) void k_run_ofdm
                 }
             }
             __syncthreads();
-            fft_dit<T, N, true, kPipeBlock, true, true>(s_x, NB, N, s_tw);   // bins scattered digit-reversed -> time samples in natural order
+            if constexpr (kTwRegs)
+                fft_dit_r<T, N, true, kPipeBlock, true, true>(s_x, NB, N, twr);
+            else
+                fft_dit<T, N, true, kPipeBlock, true, true>(s_x, NB, N, s_tw);   // bins scattered digit-reversed -> time samples in natural order
             auto time_sample = [&](int a, int i) -> cx<T> {                   // IFFT output i of slot a
                 return s_x[a * N + lds_swz<true>(i & (N - 1))];
             };
@@ -293,7 +303,10 @@ __global__ __launch_bounds__(kPipeBlock, sizeof(T) == 4 ? 3 : 1) void k_run_ofdm
                 }
             }
             __syncthreads();
-            fft_dif<T, N, false, kPipeBlock, true, true>(s_x, NB, N, s_tw);   // bins, digit-reversed positions
+            if constexpr (kTwRegs)
+                fft_dif_r<T, N, false, kPipeBlock, true, true>(s_x, NB, N, twr);
+            else
+                fft_dif<T, N, false, kPipeBlock, true, true>(s_x, NB, N, s_tw);   // bins, digit-reversed positions
             // ---- receive: one-tap equaliser from the tap means, demodulate, count -- one subcarrier per thread ----
             const int tid_r = opaque(tid0);
             for (int d = tid_r; d < U; d += kPipeBlock) {
