@@ -203,9 +203,10 @@ def test_full_size_properties_c4(engine):
     # (3) slicer and exhaustive minimum distance agree on every realization
     _, se_s, be_s = engine.run_mimo_ofdm(noise_var=nv, seed=SEED, first=0, count=n, dtype="f32",
                                          method=_lib.DEMOD_QAM_SLICER, per_realization=True, **args)
-    # (f32: the two decision rules round differently on symbols that sit on a boundary to ~1e-7)
-    assert np.count_nonzero(se != se_s) <= 20 and abs(int(se.sum()) - int(se_s.sum())) <= 20
-    assert abs(int(be.sum()) - int(be_s.sum())) <= 40
+    # (f32: the two decision rules round differently on symbols that sit on a boundary to ~1e-7 of the grid
+    # spacing: of the 8.2e7 symbols here ~ 8.2e7 * 3e-7 = 25 are expected to; f64 below agrees exactly)
+    assert np.count_nonzero(se != se_s) <= 80 and abs(int(se.sum()) - int(se_s.sum())) <= 80
+    assert abs(int(be.sum()) - int(be_s.sum())) <= 160
     e64 = [engine.run_mimo_ofdm(noise_var=nv, seed=SEED, first=0, count=200, dtype="f64", method=m,
                                 per_realization=True, **args)[1] for m in (_lib.DEMOD_MINDIST, _lib.DEMOD_QAM_SLICER)]
     assert np.array_equal(e64[0], e64[1])
