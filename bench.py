@@ -41,8 +41,8 @@ F1_TAPS_DB = (0.0, -3.0, -6.0, -9.0, -12.0)
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="c4", choices=["c2", "c3", "c4", "c5", "f1", "f6"])
     ap.add_argument("--batch", type=int, default=0, help="realizations per GPU per step")
     ap.add_argument("--demod", default="slicer", choices=["slicer", "mindist"])
