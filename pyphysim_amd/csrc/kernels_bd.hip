@@ -480,7 +480,7 @@ extern "C" {
 
 int mcle_waterfilling(mcle_ctx* ctx, const double* d_gains, int n, double total_power, double noise_var,
                       double* d_powers, double* d_mu, size_t batch) {
-    MCLE_REQUIRE(ctx != nullptr && d_gains != nullptr && d_powers != nullptr, "null argument");
+    MCLE_REQUIRE(ctx != nullptr && (batch == 0 || (d_gains != nullptr && d_powers != nullptr)), "null argument");
     MCLE_REQUIRE(n >= 1 && n <= kWfMaxN, "number of parallel channels must be in [1, %d] (got %d)", kWfMaxN, n);
     MCLE_REQUIRE(total_power > 0.0 && noise_var >= 0.0, "total power must be positive and the noise variance "
                                                         "non-negative");
@@ -496,7 +496,7 @@ int mcle_waterfilling(mcle_ctx* ctx, const double* d_gains, int n, double total_
 int mcle_block_diagonalize(mcle_ctx* ctx, const void* d_H, int num_users, int n_rx_per_user, double iPu,
                            double noise_var, int waterfilling, void* d_Ms, void* d_newH, void* d_W, double* d_sigma,
                            uint32_t* d_skipped, size_t batch) {
-    MCLE_REQUIRE(ctx != nullptr && d_H != nullptr, "null argument");
+    MCLE_REQUIRE(ctx != nullptr && (batch == 0 || d_H != nullptr), "null argument");
     int rc = check_bd_dims(num_users, n_rx_per_user);
     if (rc) return rc;
     MCLE_REQUIRE(iPu > 0.0, "the power per user must be positive");
@@ -511,7 +511,7 @@ int mcle_block_diagonalize(mcle_ctx* ctx, const void* d_H, int num_users, int n_
 }
 
 int mcle_pinv(mcle_ctx* ctx, const void* d_A, int m, int n, double rcond, void* d_out, size_t batch) {
-    MCLE_REQUIRE(ctx != nullptr && d_A != nullptr && d_out != nullptr, "null argument");
+    MCLE_REQUIRE(ctx != nullptr && (batch == 0 || (d_A != nullptr && d_out != nullptr)), "null argument");
     MCLE_REQUIRE(m >= 1 && n >= 1 && m <= kBdMaxN && n <= kBdMaxN, "pinv supports matrices up to %d x %d (got %d x %d)",
                  kBdMaxN, kBdMaxN, m, n);
     MCLE_REQUIRE(rcond >= 0.0, "rcond must be non-negative");

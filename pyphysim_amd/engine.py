@@ -738,7 +738,10 @@ class Engine:
         """doWF (waterfilling.py:15-92) on gains [batch, n] (or [n]) -> (powers, water levels)."""
         g = np.ascontiguousarray(gains, dtype=np.float64)
         single = g.ndim == 1
-        g = g.reshape(1, -1) if single else g.reshape(g.shape[0], -1)
+        if single:
+            g = g.reshape(1, -1)
+        elif g.ndim != 2:
+            raise ValueError("gains must be [n] or [batch, n]")
         b, n = g.shape
         d_g = self.to_device(g)
         P, mu = self.empty((b, n), np.float64), self.empty(b, np.float64)

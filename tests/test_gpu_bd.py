@@ -225,6 +225,13 @@ def test_run_bd_noiseless_and_errors(engine):
             _run(engine, dict(BD_CASES[0], **bad), 0, 4, "f32")
     with pytest.raises(ValueError):
         engine.run_bd(3, 2, 10, 1.0, 0.1, SEED, 0, 4, pathloss=np.ones((2, 2)))
+    # an empty range is a no-op on every chunked pipeline
+    z = _run(engine, BD_CASES[0], 0, 0, "f32", per_realization=False)
+    assert z["n_realizations"] == 0 and z["sym_errors"] == 0
+    assert engine.run_ia(200, 0.1, SEED, 7, 0)["n_realizations"] == 0
+    assert engine.run_mimo_flat("blast", 2, 2, 64, 0.1, SEED, 7, 0)["n_realizations"] == 0
+    assert engine.block_diagonalize(np.zeros((0, 4, 4), dtype=complex), 2, 1.0, 0.1)["Ms"].shape == (0, 4, 4)
+    assert engine.waterfilling(np.zeros((0, 3)), 1.0, 1.0)[0].shape == (0, 3)
 
 
 def test_bd_simulator_runs_the_comp_application(engine):
