@@ -617,22 +617,6 @@ __global__ __launch_bounds__(64) void k_run_ia(ModemParams<T> mp, int n_symbols,
 }
 
 
-template <typename T> static ModemParams<T> ia_modem(const mcle_ctx* ctx, int method) {
-    ModemParams<T> p;
-    p.grid = context_grid<T>(ctx, method);
-    if (sizeof(T) == 8)
-        p.g_table = reinterpret_cast<const cx<T>*>(ctx->d_table_f64);
-    else
-        p.g_table = reinterpret_cast<const cx<T>*>(ctx->d_table_f32);
-    p.M = ctx->M;
-    p.bits = ctx->bits;
-    p.method = method;
-    p.qam_scale = (T)ctx->qam_scale;
-    p.qam_L = ctx->qam_L;
-    p.half_bits = ctx->bits / 2;
-    return p;
-}
-
 }  // namespace mcle
 
 using namespace mcle;
@@ -701,17 +685,17 @@ int mcle_run_ia(mcle_ctx* ctx, int dtype, const mcle_ia_cfg* cfg, uint64_t seed,
     const uint64_t cap = (uint64_t)ctx->n_cu * 16;
     const uint64_t chunks = (count + 63) / 64;       // one wavefront per 64 realizations
     const unsigned grid = (unsigned)(chunks < cap ? chunks : cap);
-    const size_t lds = dtype == MCLE_F32 ? (size_t)ia_modem<float>(ctx, cfg->demod_method).grid.G *
-                                               ia_modem<float>(ctx, cfg->demod_method).grid.G * sizeof(unsigned long long)
+    const size_t lds = dtype == MCLE_F32 ? (size_t)pipe_modem<float>(ctx, cfg->demod_method).grid.G *
+                                               pipe_modem<float>(ctx, cfg->demod_method).grid.G * sizeof(unsigned long long)
                                          : 0;
     if (dtype == MCLE_F32)
-        hipLaunchKernelGGL(k_run_ia<float>, dim3(grid), dim3(64), lds, ctx->stream, ia_modem<float>(ctx, cfg->demod_method),
+        hipLaunchKernelGGL(k_run_ia<float>, dim3(grid), dim3(64), lds, ctx->stream, pipe_modem<float>(ctx, cfg->demod_method),
                            cfg->n_symbols, cfg->noise_var, cfg->solver, cfg->initialize_with, cfg->max_iterations,
                            cfg->relative_factor, seed, first, count, d_counters, d_sym_err, d_bit_err, d_sum_capacity,
                            d_iterations);
     else
         hipLaunchKernelGGL(k_run_ia<double>, dim3(grid), dim3(64), 0, ctx->stream,
-                           ia_modem<double>(ctx, cfg->demod_method), cfg->n_symbols, cfg->noise_var, cfg->solver,
+                           pipe_modem<double>(ctx, cfg->demod_method), cfg->n_symbols, cfg->noise_var, cfg->solver,
                            cfg->initialize_with, cfg->max_iterations, cfg->relative_factor, seed, first, count,
                            d_counters, d_sym_err, d_bit_err, d_sum_capacity, d_iterations);
     MCLE_LAUNCH_CHECK();
