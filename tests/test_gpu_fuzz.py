@@ -1,0 +1,125 @@
+"""GPU: seeded random configurations of every fused pipeline against the oracle chains under common random
+numbers (mcle-philox-v1).  The f64 instantiation must reproduce the oracle's per-realization symbol and bit
+error counts exactly, whatever the modulation, the sizes, the SNR or the position of the realization range;
+the f32 instantiation stays within the north-star tolerance on the same draws."""
+import numpy as np
+import pytest
+
+from oracle import chains, channels as och, modem as omodem
+from pyphysim_amd import _lib
+
+pytestmark = pytest.mark.gpu
+SEED = 20260927
+MODS = [("bpsk", 2), ("qpsk", 4), ("psk", 8), ("psk", 16), ("qam", 4), ("qam", 16), ("qam", 64), ("qam", 256)]
+
+
+def _bind(engine, mod, M):
+    engine.set_constellation(chains.constellation(mod, M), _lib.CONST_QAM if mod == "qam" else
+                             (_lib.CONST_BPSK if mod == "bpsk" else _lib.CONST_GENERIC))
+
+
+def _oracle(fn, first, count, **kw):
+    out = [fn(chains.PhiloxRng(SEED, r), **kw) for r in range(first, first + count)]
+    return (np.array([o["symbol_errors"] for o in out]), np.array([o["bit_errors"] for o in out]),
+            out[0]["num_symbols"], out[0]["num_bits"])
+
+
+def _check(res, se, be, want, dt, what):
+    want_se, want_be, nsym, nbits = want
+    n = len(want_se)
+    assert res["n_realizations"] == n and res["n_symbols"] == nsym and res["n_bits"] == nbits, what
+    if dt == "f64":
+        assert np.array_equal(se, want_se) and np.array_equal(be, want_be), what
+        assert res["sym_errors"] == int(want_se.sum()) and res["bit_errors"] == int(want_be.sum()), what
+    else:
+        # a handful of boundary symbols may fall the other way in f32; the tolerance of the north star on rates
+        assert abs(int(se.sum()) - int(want_se.sum())) <= max(3, 1e-4 * n * nsym), what
+        assert abs(int(be.sum()) - int(want_be.sum())) <= max(6, 1e-4 * n * nbits), what
+
+
+def _snr_for(rs, M):
+    return float(rs.uniform(2.0, 10.0) + 3.0 * np.log2(M))
+
+
+@pytest.mark.parametrize("dt", ["f64", "f32"])
+@pytest.mark.parametrize("trial", range(6))
+def test_fuzz_single_carrier(engine, dt, trial):
+    rs = np.random.RandomState(100 + trial)
+    mod, M = MODS[rs.randint(len(MODS))]
+    _bind(engine, mod, M)
+    N = int(rs.choice([1, 15, 16, 17, 1000, 4099, 16384, 16385, 40000]))
+    snr = _snr_for(rs, M)
+    first, count = int(rs.randint(0, 1 << 40)), int(rs.randint(1, 6))
+    nv = 1.0 / omodem.dB2Linear(snr)
+    want = _oracle(chains.chain_awgn, first, count, mod=mod, M=M, N=N, snr_db=snr)
+    _check(*engine.run_awgn(N, nv, SEED, first, count, dtype=dt, per_realization=True), want, dt, ("awgn", mod, M, N))
+    Fd, Ts, L = float(rs.uniform(5, 300)), float(10 ** rs.uniform(-5, -3)), int(rs.choice([4, 8, 16, 23]))
+    want = _oracle(chains.chain_flat_jakes, first, count, mod=mod, M=M, N=N, snr_db=snr, Fd=Fd, Ts=Ts, L=L)
+    _check(*engine.run_flat_fading(N, nv, SEED, first, count, Fd=Fd, Ts=Ts, L=L, dtype=dt, per_realization=True), want,
+           dt, ("jakes", mod, M, N, Fd, Ts, L))
+
+
+@pytest.mark.parametrize("dt", ["f64", "f32"])
+@pytest.mark.parametrize("trial", range(6))
+def test_fuzz_ofdm_chains(engine, dt, trial):
+    rs = np.random.RandomState(200 + trial)
+    mod, M = MODS[1 + rs.randint(len(MODS) - 1)]
+    _bind(engine, mod, M)
+    fft = int(rs.choice([64, 128, 256, 512, 1024]))
+    cp = int(rs.randint(0, fft // 4))
+    used = int(rs.choice([fft, 2 * rs.randint(1, fft // 2)]))
+    n_sym = int(rs.randint(1, 4))
+    snr = _snr_for(rs, M) + 6.0
+    nv = 1.0 / omodem.dB2Linear(snr)
+    first, count = int(rs.randint(0, 1 << 33)), int(rs.randint(1, 7))
+    # SISO OFDM over a Jakes TDL channel with the one-tap equaliser
+    S = int(rs.randint(1, 6))
+    delays = tuple(sorted(rs.choice(np.arange(0, min(fft // 4, 24)), size=S, replace=False).tolist()))
+    powers = tuple(float(v) for v in -np.sort(rs.uniform(0, 15, size=S)))
+    Ts, Fd, L = 1e-6, float(rs.uniform(5, 120)), int(rs.choice([8, 12]))
+    kw = dict(mod=mod, M=M, fft_size=fft, cp_size=cp, num_used=used, n_ofdm_sym=n_sym, snr_db=snr, Fd=Fd, Ts=Ts, L=L,
+              tap_powers_dB=powers, tap_delays_samples=delays)
+    p_lin, d_idx = och.discretize_profile(np.array(powers), np.array(delays) * Ts, Ts)
+    want = _oracle(chains.chain_ofdm_tdl, first, count, **kw)
+    _check(*engine.run_ofdm_tdl(fft, cp, used, n_sym, nv, p_lin, d_idx, SEED, first, count, Fd=Fd, Ts=Ts, L=L, dtype=dt,
+                                per_realization=True), want, dt, ("ofdm_tdl", kw))
+    # spatial multiplexing over a flat channel with per-antenna OFDM
+    na = int(rs.choice([2, 4]))
+    mmse = bool(rs.randint(2))
+    kw = dict(mod=mod, M=M, nt=na, nr=na, fft_size=fft, cp_size=cp, num_used=used, n_ofdm_sym=n_sym, snr_db=snr,
+              mmse=mmse)
+    want = _oracle(chains.chain_mimo_ofdm, first, count, **kw)
+    _check(*engine.run_mimo_ofdm(na, na, fft, cp, used, n_sym, nv, SEED, first, count, mmse=mmse, dtype=dt,
+                                 per_realization=True), want, dt, ("mimo_ofdm", kw))
+
+
+@pytest.mark.parametrize("dt", ["f64", "f32"])
+@pytest.mark.parametrize("trial", range(6))
+def test_fuzz_chunked_pipelines(engine, dt, trial):
+    rs = np.random.RandomState(300 + trial)
+    mod, M = MODS[1 + rs.randint(len(MODS) - 1)]
+    _bind(engine, mod, M)
+    NS = int(rs.choice([2, 7, 64, 100, 128, 129, 200, 500]))
+    snr = _snr_for(rs, M) + 4.0
+    nv = 1.0 / omodem.dB2Linear(snr)
+    first, count = int(rs.randint(0, 1 << 36)), int(rs.randint(1, 70))
+    want = _oracle(chains.chain_ia, first, count, mod=mod, M=M, K=3, nr=2, nt=2, Ns=1, NSymbs=NS, snr_db=snr)
+    res, se, be, _, _ = engine.run_ia(NS, nv, SEED, first, count, dtype=dt, per_realization=True)
+    _check(res, se, be, want, dt, ("ia", mod, M, NS))
+    scheme, nt, nr = [("blast", 2, 3), ("blast", 4, 4), ("mrc", 1, 4), ("mrt", 3, 1), ("alamouti", 2, 2)][rs.randint(5)]
+    ns_flat = NS + (NS & 1) if scheme == "alamouti" else NS
+    want = _oracle(chains.chain_mimo_scheme, first, count, scheme=scheme, mod=mod, M=M, nt=nt, nr=nr, NSymbs=ns_flat,
+                   snr_db=snr)
+    _check(*engine.run_mimo_flat(scheme, nt, nr, ns_flat, nv, SEED, first, count, dtype=dt, per_realization=True), want,
+           dt, ("flat", scheme, nt, nr, ns_flat))
+    K, r = [(2, 1), (3, 1), (2, 2), (3, 2), (4, 2), (2, 3), (2, 4)][rs.randint(7)]
+    # A stream the water-filling switches off is received as exactly 0 (the reference: ~1e-17 of rounding residue):
+    # its "decision" is a tie between all points of equal modulus, broken by the last bit of |c_m|, i.e. undefined
+    # for PSK rings (QAM's innermost points tie exactly and the first wins on both sides).  Keep the water level
+    # low for PSK so that every stream stays on.
+    bd_nv = float(10 ** (rs.uniform(-6, -3) if mod == "psk" else rs.uniform(-6, 0.3)))
+    kw = dict(mod=mod, M=M, K=K, nr=r, NSymbs=NS, iPu=float(rs.uniform(0.5, 3.0)), noise_var=nv,
+              bd_noise_var=bd_nv, pathloss=None, waterfill=bool(rs.randint(2)))
+    want = _oracle(chains.chain_bd, first, count, canonical=True, **kw)
+    _check(*engine.run_bd(K, r, NS, kw["iPu"], nv, SEED, first, count, bd_noise_var=kw["bd_noise_var"],
+                          waterfilling=kw["waterfill"], dtype=dt, per_realization=True), want, dt, ("bd", kw))
