@@ -91,6 +91,16 @@ def test_fuzz_ofdm_chains(engine, dt, trial):
     want = _oracle(chains.chain_mimo_ofdm, first, count, **kw)
     _check(*engine.run_mimo_ofdm(na, na, fft, cp, used, n_sym, nv, SEED, first, count, mmse=mmse, dtype=dt,
                                  per_realization=True), want, dt, ("mimo_ofdm", kw))
+    # the same over the frequency-selective channel, one MMSE / ZF filter per subcarrier (fused kernel)
+    count = min(count, 3)
+    kw = dict(mod=mod, M=M, nt=na, nr=na, fft_size=fft, cp_size=cp, num_used=used, n_ofdm_sym=n_sym, snr_db=snr + 6.0,
+              Fd=Fd, Ts=Ts, L=L, tap_powers_dB=powers, tap_delays_samples=delays)
+    try:
+        got = engine.run_mimo_ofdm_tdl(na, na, fft, cp, used, n_sym, 1.0 / omodem.dB2Linear(snr + 6.0), p_lin, d_idx, SEED,
+                                       first, count, Fd=Fd, Ts=Ts, L=L, mmse=True, dtype=dt, per_realization=True)
+    except _lib.McleUnsupported:
+        return          # Doppler beyond the fused kernel's tap model (the simulator runs the staged chain then)
+    _check(*got, _oracle(chains.chain_mimo_ofdm_tdl, first, count, **kw), dt, ("mimo_ofdm_tdl", kw))
 
 
 @pytest.mark.parametrize("dt", ["f64", "f32"])
@@ -106,6 +116,18 @@ def test_fuzz_chunked_pipelines(engine, dt, trial):
     want = _oracle(chains.chain_ia, first, count, mod=mod, M=M, K=3, nr=2, nt=2, Ns=1, NSymbs=NS, snr_db=snr)
     res, se, be, _, _ = engine.run_ia(NS, nv, SEED, first, count, dtype=dt, per_realization=True)
     _check(res, se, be, want, dt, ("ia", mod, M, NS))
+    algo = ["alt_min", "min_leakage", "max_sinr", "mmse"][rs.randint(4)]
+    init = ["random", "closed_form", "alt_min"][rs.randint(3)] if algo != "alt_min" else "random"
+    n_it = min(count, 12)
+    kw = dict(algo=algo, mod=mod, M=M, K=3, nr=2, nt=2, Ns=1, NSymbs=NS, snr_db=snr, max_iterations=int(rs.randint(3, 40)),
+              initialize_with=init)
+    out = [chains.chain_ia_iterative(chains.PhiloxRng(SEED, r), **kw) for r in range(first, first + n_it)]
+    res, se, be, _, its = engine.run_ia(NS, nv, SEED, first, n_it, dtype=dt, per_realization=True, solver=algo,
+                                        max_iterations=kw["max_iterations"], initialize_with=init)
+    _check(res, se, be, (np.array([o["symbol_errors"] for o in out]), np.array([o["bit_errors"] for o in out]),
+                         out[0]["num_symbols"], out[0]["num_bits"]), dt, ("ia_iterative", kw))
+    if dt == "f64":
+        assert np.array_equal(its, [o["runned_iterations"] for o in out]), kw
     scheme, nt, nr = [("blast", 2, 3), ("blast", 4, 4), ("mrc", 1, 4), ("mrt", 3, 1), ("alamouti", 2, 2)][rs.randint(5)]
     ns_flat = NS + (NS & 1) if scheme == "alamouti" else NS
     want = _oracle(chains.chain_mimo_scheme, first, count, scheme=scheme, mod=mod, M=M, nt=nt, nr=nr, NSymbs=ns_flat,
