@@ -175,3 +175,16 @@ def test_profile_discretisation_known_answers():
     # ten times the TU delays: nothing merges any more (channels_package_test.py:745-757)
     far = channels.TdlChannelProfile(tu.tap_powers_dB, 10 * tu.tap_delays).get_discretize_profile(3.255e-08)
     assert (far.num_taps, far.num_taps_with_padding) == (20, 658)
+
+
+# ---------------------------------------------------------------------------------------------
+# comm mirror: argument checks that precede any device work
+# ---------------------------------------------------------------------------------------------
+def test_block_diagonalizer_argument_errors():
+    from pyphysim_amd.comm import blockdiagonalization as mbd
+    bd = mbd.BlockDiagonalizer(3, 1.0, 0.1)
+    with pytest.raises(AssertionError):        # rows not a multiple of the number of users (the reference's assert)
+        bd.block_diagonalize(np.ones((5, 5), dtype=complex))
+    with pytest.raises(NotImplementedError):   # non-square channels are outside this build
+        bd.block_diagonalize_no_waterfilling(np.ones((6, 9), dtype=complex))
+    assert (bd.num_users, bd.iPu, bd.noise_var) == (3, 1.0, 0.1)
