@@ -333,6 +333,28 @@ def main():
                     run_md((1 << 41) + (s2 + 1) * batch, batch, cnt2)
                 eng.sync()
                 out["mindist_demod_realizations_per_s"] = 5 * batch / (time.perf_counter() - t1)
+            if args.config == "c4" and not args.no_cpu:
+                # the other workloads of SURVEY.md section 8 on the same device, 5 launches each (a second's work):
+                # realizations/s and the kernel time of one launch, so that one bench line documents them all
+                others = {}
+                batches = {"c3": 131072, "c2": 4096, "c5": 262144, "f1": 98304, "f6": 131072}
+                for cfg in ("c2", "c3", "c5", "f1", "f6"):
+                    try:
+                        run_o, units_o, wl_o = make_runner(eng, cfg, "slicer", args.dtype)
+                        cnt_o = eng.new_counters()
+                        run_o(1 << 42, batches[cfg], cnt_o)
+                        eng.sync()
+                        eng.timer_start()
+                        for s2 in range(5):
+                            run_o((1 << 42) + (s2 + 1) * batches[cfg], batches[cfg], cnt_o)
+                        ms_o = eng.timer_stop_ms() / 5
+                        c_o = eng.read_counters(cnt_o)
+                        others[cfg] = {"workload": wl_o, "realizations_per_s": batches[cfg] / ms_o * 1e3,
+                                       "kernel_ms_per_launch": ms_o, "realizations_per_launch": batches[cfg],
+                                       "ser": c_o["sym_errors"] / float(max(1, c_o["n_realizations"]) * units_o)}
+                    except Exception as exc:
+                        others[cfg] = {"error": repr(exc)}
+                out["other_workloads"] = others
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()
