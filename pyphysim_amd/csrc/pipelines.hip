@@ -298,12 +298,6 @@ __global__ __launch_bounds__(kPipeBlock, sizeof(T) == 4 ? 3 : 1) void k_run_mimo
             else s_red[15] = v.x != (T)0 ? 1u : 0u;
         }
         __syncthreads();
-        cx<T> H[NA][NA];
-#pragma unroll
-        for (int r = 0; r < NA; ++r)
-#pragma unroll
-            for (int a = 0; a < NA; ++a) H[r][a] = s_H[r * NA + a];
-
         unsigned se = 0, be = 0;
         for (int os = 0; os < pp.n_ofdm_sym; ++os) {
             // ---- transmit: symbols -> bins (Blast.encode's F-order split + OFDM subcarrier map) ----
@@ -333,6 +327,11 @@ __global__ __launch_bounds__(kPipeBlock, sizeof(T) == 4 ? 3 : 1) void k_run_mimo
             else
                 fft_dif<T, N, true, kPipeBlock, true>(s_x, NA, N, s_tw);  // time samples, digit-reversed positions
             // ---- channel: R = H T + noise on the samples that survive CP removal ----
+            cx<T> H[NA][NA];                                          // loaded here: not live across the transform
+#pragma unroll
+            for (int r = 0; r < NA; ++r)
+#pragma unroll
+                for (int a = 0; a < NA; ++a) H[r][a] = s_H[r * NA + a];
             for (int j = opaque(tid); j < N / 2; j += kPipeBlock) {   // phase-local addresses (see fft.hpp FRESH)
                 const int half = j / (N / 4), rest = j - half * (N / 4);
                 const int p0 = 2 * half * (N / 4) + rest, p1 = p0 + N / 4;
