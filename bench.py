@@ -1,20 +1,30 @@
 #!/usr/bin/env python3
 """bench.py -- Monte Carlo realizations/s of the fused HIP link pipeline on MI355X.
 
-Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched by
-torch.distributed.run with one rank per GPU (RCCL).  Prints ONE JSON line on rank 0.
+Contract (driver): `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on rank 0.
+  * N == 1: runs in this process.
+  * N > 1 and not already under a launcher (no RANK in the environment): bench.py starts its own N ranks,
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same args>`,
+    one rank per GPU over RCCL.  Launched by the driver's own torch.distributed.run it simply reads
+    RANK / LOCAL_RANK / WORLD_SIZE.  Either way WORLD_SIZE must equal --gpus (asserted).
 
 Workload (BASELINE.json north_star target, configs[3] geometry on ONE GPU per rank):
   4x4 MIMO (Blast, MMSE) + 64-QAM + OFDM-1024 (cp 16, all bins used), flat H ~ randn_c(4,4) per
   realization, SNR 25 dB; a "step" = one batch of --batch realizations per GPU through
   mcle_run_mimo_ofdm (data, channel and noise drawn on-chip from (seed, realization index)).
-  Realization index ranges are disjoint across ranks and steps ("weak" scaling); the only
-  exchange is one all-reduce (RCCL) of the 8-word integer counter block at the end.
+  Rank r owns the contiguous realization range [r*K*batch, (r+1)*K*batch) ("weak" scaling); the only
+  exchange is ONE all-reduce (RCCL) of the 6-word integer counter vector, inside the timed region.
+
+`--launch-check` exercises the launcher, the range split and the reduction WITHOUT a GPU (gloo, an integer
+checksum per realization index instead of a kernel; no rate is reported) -- tests/test_bench_launch.py.
 """
 import argparse
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):   # before NumPy loads its BLAS:
@@ -26,16 +36,47 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
+ROUND = "r02"
 # algorithmic bytes per realization in the staged (operator-granular)
 # model, complex64 samples / uint8 indices.
 B_ALG = {"c2": 7_600_000, "c3": 211_360, "c4": 412_160, "c5": 62_000, "f1": 3_099_008,
          # f6 (6 streams x 500 symbols): gen+mod 27 000; precode, channel, filter 48 000 each; demod 27 000; count 6 000
          "f6": 204_000}
-HBM_PEAK_GBPS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
+# Algorithmic floating-point operations per realization (complex MAC = 8, complex add = 2, 5 N log2 N per FFT),
+# SURVEY.md section 8(d) "Flops per realization"; RNG and integer work is NOT counted (listed under "uncounted").
+FLOPS = {
+    "c4": {"H.T (4x4 x 1040 cMAC)": 133_120, "G.Y (4x4 x 1024 cMAC)": 131_072, "8 x FFT-1024": 409_600,
+           "MMSE filter (f64)": 2_000, "slicer (4096 x 10)": 40_960},
+    "c3": {"2 x FFT-1024": 102_400, "TDL 5 taps x 1040 cMAC": 41_600, "Jakes 5 x 8 rays x 1040 (phase, sincos, add)": 249_600,
+           "equaliser (5-tap DFT + divide) x 1024": 55_296, "demod 1024 x 6": 6_144},
+    "c2": {"Jakes 8 rays x 1e5 (phase, sincos, add)": 4_800_000, "fade + equalise 1e5 x 22": 2_200_000,
+           "slicer 1e5 x 10": 1_000_000},
+    "f1": {"8 x FFT-1024": 409_600, "TDL 5 taps x 16 links x 1040 cMAC": 665_600,
+           "H(f) 1024 x 16 x 5 cMAC": 655_360, "MMSE solve per subcarrier 1024 x ~1.1 kflop": 1_126_400,
+           "slicer": 40_960},
+    "c5": {"link 600 x 15 cMAC": 72_000, "closed-form solve (f64)": 6_000, "demod 600 x 10": 6_000},
+    "f6": {"link 3000 x (1 + 2) cMAC": 72_000, "BD solve + pinv (f64)": 20_000, "demod 3000 x 6": 18_000},
+}
+UNCOUNTED = {"c4": "Philox4x32-10: ~2 350 blocks (4 176 CN samples + 4 096 symbol bytes) = ~140 k integer ops; "
+                   "Box-Muller: 4 176 x (log, sqrt, sin, cos) transcendental ops"}
+HBM_PEAK_GBPS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
+HBM_COPY_GBPS = 6290.0      # same guide: measured float4 copy
+FP32_PEAK_TFLOPS = 157.3    # same guide: FP32 vector peak = FP32-input MFMA peak (256 CU x 4 SIMD x 64 flop/clk x 2.4 GHz)
+KERNEL = {"c4": "k_run_mimo_ofdm", "c2": "k_run_flat", "c3": "k_run_ofdm_tdl_batch", "c5": "k_run_ia",
+          "f1": "k_run_mimo_ofdm_tdl", "f6": "k_run_bd"}
+BATCH = {"c4": 65536, "c3": 131072, "c2": 4096, "c5": 262144, "f1": 98304, "f6": 131072}
+BITS = {"c2": 6, "c3": 2, "c4": 6, "c5": 4, "f1": 6, "f6": 2}
 SEED = 20260927
 SNR_DB = {"c1": 10.0, "c2": 20.0, "c3": 20.0, "c4": 25.0, "c5": 20.0, "f1": 25.0, "f6": 15.0}
 F1_TS = 1.0 / (15e3 * 1024)
 F1_TAPS_DB = (0.0, -3.0, -6.0, -9.0, -12.0)
+COUNTER_KEYS = ("n_realizations", "n_skipped", "sym_errors", "sym_errors_sq", "bit_errors", "bit_errors_sq")
+PMC_PASSES = (   # one rocprofv3 --pmc run each (FETCH_SIZE and WRITE_SIZE do not fit one pass, MI355X_MICROARCH.md)
+    ("sq", "SQ_WAVE_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU_MFMA_MOPS_F32 "
+           "SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE"),
+    ("fetch", "FETCH_SIZE"),
+    ("write", "WRITE_SIZE"),
+)
 
 
 def parse():
@@ -45,15 +86,42 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="c4", choices=["c2", "c3", "c4", "c5", "f1", "f6"])
     ap.add_argument("--batch", type=int, default=0, help="realizations per GPU per step")
-    ap.add_argument("--demod", default="slicer", choices=["slicer", "mindist"])
+    ap.add_argument("--demod", default="slicer", choices=["slicer", "mindist"],
+                    help="demodulator `value` is quoted on; the c4 line carries the rate of both")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--cpu-multicore-seconds", type=float, default=6.0,
                     help="budget of the all-cores CPU leg (0 disables it)")
-    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU legs and the other-workload survey")
+    ap.add_argument("--pmc", default="auto", choices=["auto", "on", "off"],
+                    help="collect the VALU / MFMA / HBM counters of the dominant kernel with rocprofv3 child runs "
+                         "(auto: single rank, rocprofv3 on PATH, CPU legs not disabled)")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="no GPU: run the rank launcher, the range split and the reduction on gloo with an integer "
+                         "checksum per realization index instead of a kernel (prints ranges + counters, no rate)")
     return ap.parse_args()
 
 
+# ---- launcher ---------------------------------------------------------------------------------------------------
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this file under torch.distributed.run."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this driver (RCCL needs it)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+# ---- workloads --------------------------------------------------------------------------------------------------
 def make_runner(eng, cfg, demod, dtype):
     """-> (run(first, count, counters), units per realization, description)"""
     from pyphysim_amd.modulators import constellation  # product-side tables (no oracle import here)
@@ -190,23 +258,178 @@ def cpu_baseline_multicore(cfg, single_core_rate, budget_s):
     n = sum(d[0] for d in done)
     busy = max(d[1] for d in done)
     return {"value": n / busy, "unit": "realizations/s", "cores": workers, "kind": "port",
-            "sample": "%d realizations over %d processes (spawn), slowest worker %.1f s, wall %.1f s incl. start-up"
-                      % (n, workers, busy, wall)}
+            "scaling_vs_one_core": (n / busy) / single_core_rate,
+            "sample": "%d realizations over %d processes (spawn), slowest worker %.1f s, wall %.1f s incl. start-up; "
+                      "the box gives far less than %d cores' worth (shared memory bandwidth / boost clocks)"
+                      % (n, workers, busy, wall, workers)}
 
 
+# ---- rocprofv3 counters of the dominant kernel, collected by child runs of this file ----------------------------
+def _parse_pmc_csv(folder, needle):
+    import csv
+    import glob
+    agg = {}
+    for path in glob.glob(os.path.join(folder, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(path)):
+            if needle + "<" in row["Kernel_Name"]:
+                agg.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in agg.items()}
+
+
+def derive_pmc(c, per_launch):
+    """Counter means per launch -> the fractions the bench line quotes.  Shared with scripts/collect_profiles.py.
+    SQ_* cycle counters are in quad-cycles, SQ_VALU_MFMA_BUSY_CYCLES in cycles (MI355X_MICROARCH.md, constants
+    table); GRBM_GUI_ACTIVE sums the 8 XCDs; the chip has 1024 SIMDs.  HBM bytes = (2 x FETCH_SIZE + WRITE_SIZE)
+    KiB: on gfx950 FETCH_SIZE reports half of a coalesced stream's bytes (same guide, HBM section)."""
+    d = {}
+    g = c.get
+    if g("GRBM_GUI_ACTIVE"):
+        simd_cycles = g("GRBM_GUI_ACTIVE") / 8.0 * 1024.0
+        if g("SQ_ACTIVE_INST_VALU") is not None:
+            d["valu_busy_chip"] = 4.0 * g("SQ_ACTIVE_INST_VALU") / simd_cycles
+        if g("SQ_VALU_MFMA_BUSY_CYCLES") is not None:
+            d["mfma_busy_chip"] = g("SQ_VALU_MFMA_BUSY_CYCLES") / simd_cycles
+    if g("SQ_ACTIVE_INST_VALU") is not None and g("SQ_WAVE_CYCLES"):
+        d["valu_active_per_wave"] = g("SQ_ACTIVE_INST_VALU") / g("SQ_WAVE_CYCLES")
+    if g("SQ_WAIT_INST_ANY") is not None and g("SQ_WAVE_CYCLES"):
+        d["wait_inst_any_frac"] = g("SQ_WAIT_INST_ANY") / g("SQ_WAVE_CYCLES")
+    if g("SQ_LDS_BANK_CONFLICT") is not None and g("SQ_LDS_IDX_ACTIVE"):
+        d["lds_bank_conflict_frac"] = g("SQ_LDS_BANK_CONFLICT") / g("SQ_LDS_IDX_ACTIVE")
+    if g("SQ_INSTS_VALU") is not None:
+        d["valu_wave_insts_per_realization"] = g("SQ_INSTS_VALU") / per_launch
+    if g("SQ_INSTS_VALU_MFMA_MOPS_F32") is not None:
+        d["mfma_f32_mops_per_realization"] = g("SQ_INSTS_VALU_MFMA_MOPS_F32") / per_launch
+    if g("FETCH_SIZE") is not None and g("WRITE_SIZE") is not None:
+        d["hbm_bytes_per_launch"] = (2.0 * g("FETCH_SIZE") + g("WRITE_SIZE")) * 1024.0
+        d["hbm_bytes_per_realization"] = d["hbm_bytes_per_launch"] / per_launch
+    return d
+
+
+def collect_pmc_live(args, batch):
+    """Three `rocprofv3 --pmc` child runs of this bench (3 timed launches each) -> counter means per launch."""
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None, "rocprofv3 not on PATH"
+    counters = {}
+    root = tempfile.mkdtemp(prefix="bench_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    for tag, names in PMC_PASSES:
+        out_dir = os.path.join(root, tag)
+        cmd = [exe, "--pmc"] + names.split() + ["--output-format", "csv", "-d", out_dir, "-o", "pmc", "--",
+                                                 sys.executable, os.path.abspath(__file__), "--config", args.config,
+                                                 "--demod", args.demod, "--dtype", args.dtype, "--batch", str(batch),
+                                                 "--steps", "3", "--warmup", "1", "--no-cpu", "--pmc", "off"]
+        try:
+            subprocess.run(cmd, cwd="/tmp", env=env, timeout=180, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            counters.update(_parse_pmc_csv(out_dir, KERNEL[args.config]))
+        except Exception as exc:       # a failed pass must not break the bench line
+            counters["_error_" + tag] = repr(exc)
+    shutil.rmtree(root, ignore_errors=True)
+    if not any(not k.startswith("_") for k in counters):
+        return None, "no counter rows for %s" % KERNEL[args.config]
+    return counters, None
+
+
+def committed_pmc(cfg):
+    path = os.path.join(REPO, "profiles", ROUND, "%s_pmc_summary.json" % cfg)
+    if not os.path.exists(path):
+        return None, None
+    try:
+        doc = json.load(open(path))
+        return {k: v["mean_per_launch"] for k, v in doc.items() if not k.startswith("_")}, os.path.relpath(path, REPO)
+    except Exception:
+        return None, None
+
+
+def roofline_block(args, batch, per_launch_s, rate_kernel, pmc, pmc_source):
+    """What binds the dominant kernel, as fractions in (0, 1]:
+      frac            = algorithmic flops per realization x realizations/s of the kernel / FP32 peak
+      hbm.frac        = min(B_alg, measured HBM bytes) per realization x rate / 8 TB/s   (SURVEY 8(d)'s rule)
+      valu_busy_chip  = VALU-active SIMD-cycles / all SIMD-cycles (rocprofv3 counters)"""
+    flops = FLOPS[args.config]
+    f_total = float(sum(flops.values()))
+    achieved_tf = f_total * rate_kernel / 1e12
+    balg = B_ALG[args.config]
+    d = derive_pmc(pmc, batch) if pmc else {}
+    measured = d.get("hbm_bytes_per_realization")
+    hbm = {"b_alg_bytes_per_realization": balg, "measured_bytes_per_realization": measured,
+           "b_alg_over_measured": (balg / measured) if measured else None}
+    if measured is not None:
+        eff = min(float(balg), measured)
+        hbm.update(achieved_GBps=eff * rate_kernel / 1e9, frac=eff * rate_kernel / 1e9 / HBM_PEAK_GBPS,
+                   frac_of_measured_copy_bw=eff * rate_kernel / 1e9 / HBM_COPY_GBPS, peak_GBps=HBM_PEAK_GBPS,
+                   rule="min(B_alg, measured bytes) x rate (SURVEY.md 8(d)); measured = (2*FETCH_SIZE + WRITE_SIZE) KiB")
+    block = {"bound": "valu", "achieved": achieved_tf, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+             "frac": achieved_tf / FP32_PEAK_TFLOPS,
+             "traffic": d.get("hbm_bytes_per_launch"),
+             "kernel": KERNEL[args.config], "kernel_ms_per_launch": per_launch_s * 1e3,
+             "realizations_per_launch": batch,
+             "flops_per_realization": f_total, "flops_breakdown": flops, "uncounted": UNCOUNTED.get(args.config),
+             "hbm": hbm,
+             "valu_busy_chip": d.get("valu_busy_chip"), "mfma_busy_chip": d.get("mfma_busy_chip"),
+             "valu_wave_insts_per_realization": d.get("valu_wave_insts_per_realization"),
+             "mfma_f32_mops_per_realization": d.get("mfma_f32_mops_per_realization"),
+             "wait_inst_any_frac": d.get("wait_inst_any_frac"),
+             "counters_source": pmc_source,
+             "note": "fused kernel: every intermediate of a realization lives in LDS / registers, so HBM traffic is "
+                     "B_alg / %s of the staged model and the kernel is bound by VALU issue; frac = algorithmic flops "
+                     "(RNG excluded) / FP32 peak" % (("%.0f" % (balg / measured)) if measured else "?")}
+    return block
+
+
+# ---- launcher self-test (no GPU) --------------------------------------------------------------------------------
+def _checksum_counts(first, count):
+    """Integer stand-in for a kernel launch in --launch-check: a pure function of the realization index."""
+    idx = np.arange(first, first + count, dtype=np.uint64)
+    h = (idx * np.uint64(0x9E3779B97F4A7C15)) >> np.uint64(52)             # 12-bit pseudo error count
+    se = h.astype(np.int64)
+    be = (h >> np.uint64(3)).astype(np.int64)
+    return [int(count), 0, int(se.sum()), int((se * se).sum()), int(be.sum()), int((be * be).sum())]
+
+
+def launch_check(args, rank, world):
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29512")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    batch = args.batch or 1024
+    lo = rank * args.steps * batch
+    tot = np.zeros(6, dtype=np.int64)
+    for s in range(args.steps):
+        tot += np.array(_checksum_counts(lo + s * batch, batch), dtype=np.int64)
+    vec = torch.tensor(tot)
+    dist.all_reduce(vec, op=dist.ReduceOp.SUM)
+    ranges = [None] * world
+    dist.all_gather_object(ranges, [int(lo), int(lo + args.steps * batch)])
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": world, "steps": args.steps, "value": None,
+                          "rank_ranges": ranges, "counters": dict(zip(COUNTER_KEYS, [int(v) for v in vec.tolist()])),
+                          "note": "launcher / sharding / reduction self-test on gloo; no kernel ran, no rate"}),
+              flush=True)
+    dist.destroy_process_group()
+
+
+# ---- main -------------------------------------------------------------------------------------------------------
 def main():
     args = parse()
+    if "RANK" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    for v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
-        os.environ.setdefault(v, "1")
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch one rank per GPU)" % (args.gpus, world))
+    if args.launch_check:
+        return launch_check(args, rank, world)
     from pyphysim_amd.engine import Engine   # loads libmcle (shares torch's HIP runtime)
     import torch
     import torch.distributed as dist
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit("bench.py: rank %d has no GPU (%d visible)" % (local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or "RANK" in os.environ        # any torch.distributed.run launch, even with 1 rank
     if use_dist:
@@ -214,8 +437,7 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     eng = Engine(local_rank, args.dtype)
-    run, units, workload = make_runner(eng, args.config, args.demod, args.dtype)
-    batch = args.batch or {"c4": 65536, "c3": 131072, "c2": 4096, "c5": 262144, "f1": 98304, "f6": 131072}[args.config]
+    batch = args.batch or BATCH[args.config]
 
     def barrier():
         eng.sync()
@@ -223,94 +445,101 @@ def main():
         if use_dist:
             dist.barrier()
 
-    counters = eng.new_counters()
-    # realization index space: warmup uses a disjoint range far away from the timed one
-    for w in range(args.warmup):
-        run((1 << 40) + (w * world + rank) * batch, batch, counters)
-    if use_dist:        # bring the communicator up outside the timed region (same shape / dtype as the real exchange)
-        warm = torch.zeros(6, dtype=torch.int64, device="cuda")
-        dist.all_reduce(warm, op=dist.ReduceOp.SUM)
-        warm2 = torch.zeros(2, dtype=torch.float64, device="cuda")
-        dist.all_reduce(warm2, op=dist.ReduceOp.MAX)
-    barrier()
-    counters.zero()
-    barrier()
-    t0 = time.perf_counter()
-    eng.timer_start()
-    for s in range(args.steps):
-        run((s * world + rank) * batch, batch, counters)
-    kernel_ms = eng.timer_stop_ms()            # HIP events on the stream the kernels ran on
-    local = eng.read_counters(counters)
-    vec = torch.tensor([local[k] for k in ("n_realizations", "n_skipped", "sym_errors", "sym_errors_sq",
-                                           "bit_errors", "bit_errors_sq")], dtype=torch.int64, device="cuda")
-    if use_dist:
-        dist.all_reduce(vec, op=dist.ReduceOp.SUM)     # RCCL over xGMI: the path's only exchange step
-    barrier()
-    elapsed = time.perf_counter() - t0
-    tmax = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cuda")
-    if use_dist:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    elapsed, kernel_ms = float(tmax[0]), float(tmax[1])
-    tot = [int(v) for v in vec.tolist()]
+    def timed(demod, base):
+        """W warm-up + exactly K timed steps of the hot path on this rank's contiguous index range starting at
+        `base`, one all-reduce of the counter vector inside the timed region -> (elapsed max over ranks,
+        kernel ms max over ranks, reduced counter totals, workload description, units per realization)."""
+        run, units, workload = make_runner(eng, args.config, demod, args.dtype)
+        counters = eng.new_counters()
+        for w in range(args.warmup):          # warm-up draws from a disjoint index range far away
+            run((1 << 40) + base + (w * world + rank) * batch, batch, counters)
+        if use_dist:   # bring the communicator up outside the timed region (same shape / dtype as the real exchange)
+            dist.all_reduce(torch.zeros(6, dtype=torch.int64, device="cuda"), op=dist.ReduceOp.SUM)
+            dist.all_reduce(torch.zeros(2, dtype=torch.float64, device="cuda"), op=dist.ReduceOp.MAX)
+        barrier()
+        counters.zero()
+        barrier()
+        lo = base + rank * args.steps * batch
+        t0 = time.perf_counter()
+        eng.timer_start()
+        for s in range(args.steps):
+            run(lo + s * batch, batch, counters)
+        kernel_ms = eng.timer_stop_ms()            # HIP events on the stream the kernels ran on
+        local = eng.read_counters(counters)
+        vec = torch.tensor([local[k] for k in COUNTER_KEYS], dtype=torch.int64, device="cuda")
+        if use_dist:
+            dist.all_reduce(vec, op=dist.ReduceOp.SUM)     # RCCL over xGMI: the path's only exchange step
+        barrier()
+        elapsed = time.perf_counter() - t0
+        tmax = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cuda")
+        if use_dist:
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tot = [int(v) for v in vec.tolist()]
+        assert tot[0] + tot[1] == args.steps * batch * world, (tot, args.steps, batch, world)
+        return float(tmax[0]), float(tmax[1]), tot, workload, units
+
+    elapsed, kernel_ms, tot, workload, units = timed(args.demod, 0)
     n_real = tot[0] + tot[1]
-    assert n_real == args.steps * batch * world, (n_real, args.steps, batch, world)
+    other_demod = None
+    if args.config == "c4":       # the same kernel with the other demodulator, timed the same way
+        other = "mindist" if args.demod == "slicer" else "slicer"
+        e2, k2, t2, _, _ = timed(other, 1 << 38)
+        other_demod = (other, (t2[0] + t2[1]) / e2, k2 / args.steps)
 
     if rank == 0:
         value = n_real / elapsed
         per_launch_s = kernel_ms * 1e-3 / args.steps
-        balg = B_ALG[args.config]
-        achieved = balg * batch / per_launch_s / 1e9
-        traffic = None
-        tpath = os.path.join(REPO, "profiles", "traffic_%s.json" % args.config)
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        valu = None        # what actually binds the fused kernels: VALU issue slots (last rocprofv3 PMC pass)
-        ppath = os.path.join(REPO, "profiles", "r01", "%s_pmc_summary.json" % args.config)
-        if os.path.exists(ppath):
-            try:
-                pm = json.load(open(ppath))
-                waves_per_simd = 3
-                valu = {"valu_busy_per_wave": pm["_derived"]["valu_active_per_wave"],
-                        "waves_per_simd": waves_per_simd,
-                        "valu_issue_frac": pm["_derived"]["valu_active_per_wave"] * waves_per_simd,
-                        "source": "profiles/r01/%s_pmc_summary.json (SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES)" % args.config}
-            except Exception:
-                valu = None
+        rate_kernel = batch / per_launch_s            # one GPU's kernel rate (HIP events): what the roofline prices
+        pmc, pmc_source = None, None
+        want_pmc = args.pmc == "on" or (args.pmc == "auto" and world == 1 and not args.no_cpu)
+        if want_pmc:
+            eng.sync()
+            pmc, err = collect_pmc_live(args, batch)
+            pmc_source = ("rocprofv3 --pmc child runs of this command (3 launches per pass: %s)"
+                          % "; ".join(n for _, n in PMC_PASSES)) if pmc else None
+            if pmc is None:
+                pmc_source = "live collection failed (%s); " % err
+        if pmc is None:
+            pmc, src = committed_pmc(args.config)
+            pmc_source = ((pmc_source or "") + ("%s (committed rocprofv3 summary, NOT measured in this run)" % src)
+                          if pmc else (pmc_source or None))
+        demod_rates = {args.demod: value}
+        if other_demod:
+            demod_rates[other_demod[0]] = other_demod[1]
         out = {
             "metric": "Monte Carlo realizations/sec (whole node) + SER abs-error vs ref",
             "value": value, "unit": "realizations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": workload, "realizations_per_step_per_gpu": batch, "demod": args.demod,
+            "config": {"workload": workload, "realizations_per_step_per_gpu": batch,
+                       "demod": args.demod, "value_is": "rate with the %s demodulator" % args.demod,
+                       "demod_rates": demod_rates,
+                       "demod_note": "mindist = min-distance search over the LDS constellation table (north star); "
+                                     "slicer = QAM slicer, decision-identical in f64",
                        "symbols_per_realization": units, "parallelism": "realization-sharded x%d" % world,
+                       "rank_ranges": [[r * args.steps * batch, (r + 1) * args.steps * batch] for r in range(world)],
+                       "exchange": "one all-reduce(SUM) of 6 int64 counters, inside the timed region",
                        "rng": "Philox4x32-10 keyed by (seed, realization)"},
             "ser": tot[2] / float(max(1, tot[0]) * units),
-            "ber": tot[4] / float(max(1, tot[0]) * units * {"c2": 6, "c3": 2, "c4": 6, "c5": 4, "f1": 6, "f6": 2}[args.config]),
+            "ber": tot[4] / float(max(1, tot[0]) * units * BITS[args.config]),
             "n_skipped": tot[1],
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": {"c4": "k_run_mimo_ofdm", "c2": "k_run_flat", "c3": "k_run_ofdm_tdl_batch",
-                                    "c5": "k_run_ia", "f1": "k_run_mimo_ofdm_tdl", "f6": "k_run_bd"}[args.config],
-                         "kernel_ms_per_launch": per_launch_s * 1e3,
-                         # SURVEY 8(d)'s reporting rule next to the tier's: HBM bytes the launch really moved / time
-                         "hbm_measured_GBps": (traffic / per_launch_s / 1e9) if traffic is not None else None,
-                         "valu": valu,
-                         "algorithmic_bytes_per_realization": balg,
-                         "traffic_source": "profiles/traffic_%s.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
-                         % args.config if traffic is not None else None,
-                         "note": "fused kernel: achieved = staged-model algorithmic bytes / measured launch time; "
-                                 "measured HBM traffic is far below it (data never leaves LDS); the kernel is "
-                                 "VALU-issue bound, see DESIGN.md section 5.3"},
+            "roofline": roofline_block(args, batch, per_launch_s, rate_kernel, pmc, pmc_source),
         }
+        if other_demod:
+            out[other_demod[0] + "_demod_realizations_per_s"] = other_demod[1]
+            out[other_demod[0] + "_demod_kernel_ms_per_launch"] = other_demod[2]
         if world == 1 and not args.no_cpu:
             # per-realization counts of the first realizations for the SER cross-check
             res, se, be = eng_first_counts(eng, args, 16384 if args.config != "c2" else 128)
             cb, ser_err, n_chk = cpu_baseline(args.config, args.cpu_seconds, se)
             cb["host_cpu_count"] = os.cpu_count()
             cb["host_cpu_model"] = _cpu_model()
+            cross = os.path.join(REPO, "profiles", "cpu_cross_timing.json")
+            if os.path.exists(cross):
+                try:
+                    cb["reference_vs_port"] = json.load(open(cross)).get("summary")
+                except Exception:
+                    pass
             out["cpu_baseline"] = cb
             out["ser_abs_err_vs_oracle"] = ser_err
             out["ser_check_realizations"] = n_chk
@@ -322,35 +551,26 @@ def main():
                     out["speedup_vs_cpu_host"] = value / mc["value"]
                 except Exception as exc:          # never let the optional leg break the bench line
                     out["cpu_baseline_all_cores"] = {"error": repr(exc)}
-            if args.config == "c4" and args.demod == "slicer":
-                # transparency: the same kernel with the exhaustive LDS-table demodulator
-                run_md, _, _ = make_runner(eng, "c4", "mindist", args.dtype)
-                cnt2 = eng.new_counters()
-                run_md(1 << 41, batch, cnt2)
-                eng.sync()
-                t1 = time.perf_counter()
-                for s2 in range(5):
-                    run_md((1 << 41) + (s2 + 1) * batch, batch, cnt2)
-                eng.sync()
-                out["mindist_demod_realizations_per_s"] = 5 * batch / (time.perf_counter() - t1)
-            if args.config == "c4" and not args.no_cpu:
+            if args.config == "c4":
                 # the other workloads of SURVEY.md section 8 on the same device, 5 launches each (a second's work):
                 # realizations/s and the kernel time of one launch, so that one bench line documents them all
                 others = {}
-                batches = {"c3": 131072, "c2": 4096, "c5": 262144, "f1": 98304, "f6": 131072}
                 for cfg in ("c2", "c3", "c5", "f1", "f6"):
                     try:
                         run_o, units_o, wl_o = make_runner(eng, cfg, "slicer", args.dtype)
                         cnt_o = eng.new_counters()
-                        run_o(1 << 42, batches[cfg], cnt_o)
+                        run_o(1 << 42, BATCH[cfg], cnt_o)
                         eng.sync()
                         eng.timer_start()
                         for s2 in range(5):
-                            run_o((1 << 42) + (s2 + 1) * batches[cfg], batches[cfg], cnt_o)
+                            run_o((1 << 42) + (s2 + 1) * BATCH[cfg], BATCH[cfg], cnt_o)
                         ms_o = eng.timer_stop_ms() / 5
                         c_o = eng.read_counters(cnt_o)
-                        others[cfg] = {"workload": wl_o, "realizations_per_s": batches[cfg] / ms_o * 1e3,
-                                       "kernel_ms_per_launch": ms_o, "realizations_per_launch": batches[cfg],
+                        rate_o = BATCH[cfg] / ms_o * 1e3
+                        others[cfg] = {"workload": wl_o, "realizations_per_s": rate_o,
+                                       "kernel_ms_per_launch": ms_o, "realizations_per_launch": BATCH[cfg],
+                                       "kernel": KERNEL[cfg],
+                                       "fp32_frac": sum(FLOPS[cfg].values()) * rate_o / 1e12 / FP32_PEAK_TFLOPS,
                                        "ser": c_o["sym_errors"] / float(max(1, c_o["n_realizations"]) * units_o)}
                     except Exception as exc:
                         others[cfg] = {"error": repr(exc)}
@@ -363,8 +583,10 @@ def main():
 
 def eng_first_counts(eng, args, n):
     from pyphysim_amd import _lib
+    from pyphysim_amd.modulators import constellation
     method = _lib.DEMOD_QAM_SLICER if args.demod == "slicer" else _lib.DEMOD_MINDIST
     nv = 1.0 / (10.0 ** (SNR_DB[args.config] / 10.0))
+    make_runner(eng, args.config, args.demod, args.dtype)      # (re)binds this configuration's constellation
     if args.config == "c4":
         return eng.run_mimo_ofdm(4, 4, 1024, 16, 1024, 1, nv, SEED, 0, n, method=method, dtype=args.dtype,
                                  per_realization=True)

@@ -160,6 +160,42 @@ def chain_flat_jakes(rng, mod='qam', M=64, N=100000, snr_db=20.0, Fd=100.0, Ts=1
                         noise=noise, rx=rx, eq=eq, noise_var=noise_var), idx, dec, M)
 
 
+def chain_flat_rayleigh(rng, mod='qam', M=16, N=1000, snr_db=15.0, form='suchannel'):
+    """C2b: flat i.i.d. Rayleigh fading, y = h*s + n, equalise y/h, h ~ CN(0, 1) per sample.
+
+    form='suchannel'  SuChannel(RayleighSampleGenerator()) (fading_generators.py:208-249, singleuser.py:48-81):
+                      draws idx; generator ctor randn_c() (:228-229, one discarded sample); the TdlChannel ctor
+                      only sets the shape to (num_taps,) (fading.py:796-798; unlike Jakes the Rayleigh setter does
+                      not re-draw, fading_generators.py:138-154); corrupt_data -> randn_c(1, N) = h
+                      (fading_generators.py:244-249, fading.py:940); then the noise randn_c(N).
+    form='notebook'   notebooks/Transmission_with_Rayleigh_and_AWGN_channels.ipynb cell 8
+                      (RayleighOrAwgnSimulator._run_simulation): idx; noise randn_c(N); h = randn_c(N).
+    Under the Philox contract both forms address the same positions (h = CHAN samples 0..N-1, noise = NOISE
+    samples 0..N-1), so they are the same chain; under a sequential legacy stream the draw order differs."""
+    table = constellation(mod, M)
+    noise_var = 1.0 / float(omodem.dB2Linear(snr_db))
+    idx = rng.symbols(N, M)
+    tx = omodem.modulate(table, idx)
+    if form == 'notebook':
+        noise = rng.cn(philox.STREAM_NOISE, N)
+        h = rng.cn(philox.STREAM_CHAN, N).reshape(1, N)
+        faded = h[0] * tx
+    else:
+        if rng.legacy:
+            rng.cn(philox.STREAM_CHAN)           # RayleighSampleGenerator ctor: one sample, shape None
+        h = rng.cn(philox.STREAM_CHAN, 1, N)     # generate_more_samples(N) with shape (1,)
+        p_lin, d_idx = och.discretize_profile(np.zeros(1), np.zeros(1), 1.0)
+        taps = och.tdl_taps(h, p_lin)
+        faded = och.tdl_apply(tx, taps, d_idx)
+        h = taps
+        noise = rng.cn(philox.STREAM_NOISE, N)
+    rx = faded + math.sqrt(noise_var) * noise
+    eq = rx / h[0]
+    dec = omodem.demodulate(table, eq)
+    return _counts(dict(table=table, idx=idx, tx=tx, h=h, faded=faded, noise=noise, rx=rx, eq=eq,
+                        noise_var=noise_var), idx, dec, M)
+
+
 def chain_ofdm_tdl(rng, mod='qpsk', M=4, fft_size=1024, cp_size=16, num_used=None, n_ofdm_sym=1,
                    snr_db=20.0, Fd=10.0, Ts=1.0 / (15e3 * 1024), L=8,
                    tap_powers_dB=(0.0, -3.0, -6.0, -9.0, -12.0), tap_delays_samples=(0, 1, 2, 3, 4)):

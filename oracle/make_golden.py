@@ -233,6 +233,32 @@ def ref_chain_flat_jakes(seed, mod, M, N, snr_db, Fd, Ts, L):
                 noise=noise, rx=rx, eq=eq, decisions=dec, noise_var=noise_var, **ref_counts(idx, dec, M))
 
 
+def ref_chain_flat_rayleigh(seed, mod, M, N, snr_db, form):
+    """The reference's two statements of flat Rayleigh fading: the channel classes, and the notebook's inline
+    arithmetic (notebooks/Transmission_with_Rayleigh_and_AWGN_channels.ipynb cell 8)."""
+    np.random.seed(seed)
+    m = ref_modulator(mod, M)
+    noise_var = 1.0 / dB2Linear(snr_db)
+    idx = np.random.randint(0, M, N)
+    tx = m.modulate(idx)
+    if form == "notebook":
+        noise = rmisc.randn_c(N)
+        h = rmisc.randn_c(tx.size).reshape(1, N)
+        rx = h[0] * tx + math.sqrt(noise_var) * noise
+        faded = h[0] * tx
+        eq = rx / h[0]
+    else:
+        chan = rsu.SuChannel(rfg.RayleighSampleGenerator())
+        faded = chan.corrupt_data(tx)
+        h = chan.get_last_impulse_response().tap_values_sparse       # [1, N]
+        noise = rmisc.randn_c(N)
+        rx = faded + noise * math.sqrt(noise_var)
+        eq = rx / h[0]
+    dec = m.demodulate(eq)
+    return dict(table=m.symbols, idx=idx, tx=tx, h=h, faded=faded, noise=noise, rx=rx, eq=eq, decisions=dec,
+                noise_var=noise_var, **ref_counts(idx, dec, M))
+
+
 def ref_chain_ofdm_tdl(seed, mod, M, fft, cp, used, nsym, snr_db, Fd, Ts, L, powers_dB, delays):
     np.random.seed(seed)
     m = ref_modulator(mod, M)
@@ -455,6 +481,11 @@ CHAINS = {
        dict(mod="qam", M=256, N=2048, snr_db=24.0)],
     "c2_flat_jakes": [dict(mod="qam", M=64, N=4096, snr_db=20.0, Fd=100.0, Ts=1e-3, L=8),
                       dict(mod="qam", M=16, N=1024, snr_db=12.0, Fd=30.0, Ts=5e-4, L=16)],
+    "c2b_flat_rayleigh": [dict(mod="qam", M=16, N=1000, snr_db=15.0, form="suchannel"),
+                          dict(mod="qam", M=64, N=2048, snr_db=28.0, form="suchannel"),
+                          dict(mod="bpsk", M=2, N=1000, snr_db=6.0, form="notebook"),
+                          dict(mod="qam", M=256, N=1000, snr_db=34.0, form="notebook"),
+                          dict(mod="psk", M=8, N=512, snr_db=18.0, form="suchannel")],
     "c3_ofdm_tdl": [dict(mod="qpsk", M=4, fft_size=1024, cp_size=16, num_used=None, n_ofdm_sym=1,
                          snr_db=20.0, Fd=10.0, Ts=1.0 / (15e3 * 1024), L=8,
                          tap_powers_dB=(0.0, -3.0, -6.0, -9.0, -12.0), tap_delays_samples=(0, 1, 2, 3, 4)),
@@ -526,6 +557,8 @@ def run_ref(name, kw, seed):
         return ref_chain_awgn(seed, kw["mod"], kw["M"], kw["N"], kw["snr_db"])
     if name == "c2_flat_jakes":
         return ref_chain_flat_jakes(seed, kw["mod"], kw["M"], kw["N"], kw["snr_db"], kw["Fd"], kw["Ts"], kw["L"])
+    if name == "c2b_flat_rayleigh":
+        return ref_chain_flat_rayleigh(seed, kw["mod"], kw["M"], kw["N"], kw["snr_db"], kw["form"])
     if name == "c3_ofdm_tdl":
         return ref_chain_ofdm_tdl(seed, kw["mod"], kw["M"], kw["fft_size"], kw["cp_size"], kw["num_used"],
                                   kw["n_ofdm_sym"], kw["snr_db"], kw["Fd"], kw["Ts"], kw["L"],
@@ -537,16 +570,17 @@ def run_ref(name, kw, seed):
 
 
 ORACLE = {"c1_awgn": chains.chain_awgn, "c2_flat_jakes": chains.chain_flat_jakes,
+          "c2b_flat_rayleigh": chains.chain_flat_rayleigh,
           "c3_ofdm_tdl": chains.chain_ofdm_tdl, "c4_mimo_ofdm": chains.chain_mimo_ofdm, "c5_ia": chains.chain_ia,
           "f1_mimo_ofdm_tdl": chains.chain_mimo_ofdm_tdl, "f3_ia_iterative": chains.chain_ia_iterative,
           "f3b_ia_svd_init": chains.chain_ia_iterative, "f5_mimo_schemes": chains.chain_mimo_scheme, "f6_block_diag": chains.chain_bd}
 INT_KEYS = ("idx", "decisions", "symbol_errors", "bit_errors", "num_symbols", "num_bits", "delay_indexes",
             "runned_iterations")
 # realizations stored per case (kept small: fixtures are KBs)
-N_REAL = {"c1_awgn": 2, "c2_flat_jakes": 2, "c3_ofdm_tdl": 2, "c4_mimo_ofdm": 2, "c5_ia": 4, "f1_mimo_ofdm_tdl": 1,
+N_REAL = {"c1_awgn": 2, "c2_flat_jakes": 2, "c2b_flat_rayleigh": 2, "c3_ofdm_tdl": 2, "c4_mimo_ofdm": 2, "c5_ia": 4, "f1_mimo_ofdm_tdl": 1,
           "f3_ia_iterative": 3, "f3b_ia_svd_init": 3, "f5_mimo_schemes": 2, "f6_block_diag": 3}
 # derivable float arrays that are checked against the reference above but not stored
-SKIP_STORE = {"c1_awgn": ("tx",), "c2_flat_jakes": ("tx", "faded"), "c3_ofdm_tdl": ("sym", "faded"),
+SKIP_STORE = {"c1_awgn": ("tx",), "c2_flat_jakes": ("tx", "faded"), "c2b_flat_rayleigh": ("tx", "faded", "rx"), "c3_ofdm_tdl": ("sym", "faded"),
               "c4_mimo_ofdm": ("sym", "X", "R"), "c5_ia": (),
               "f1_mimo_ofdm_tdl": ("faded", "G"), "f3_ia_iterative": (), "f3b_ia_svd_init": (), "f5_mimo_schemes": (),
               "f6_block_diag": ()}

@@ -72,6 +72,35 @@ def run_flat_jakes(eng, seed_base, first, count, mod="qam", M=64, N=100000, snr_
     return np.array(se), np.array(be)
 
 
+def run_flat_rayleigh(eng, seed_base, first, count, mod="qam", M=16, N=1000, snr_db=15.0, form="suchannel"):
+    """Flat i.i.d. Rayleigh fading under np.random.seed(seed_base + r), in either of the
+    reference's two statements of it:
+      'suchannel'  SuChannel(RayleighSampleGenerator()): randint(N); the generator's ctor randn_c() (one discarded
+                   sample = two scalar randn calls, i.e. ONE polar pair); corrupt_data randn_c(1, N) = h; randn_c(N)
+                   noise (fading_generators.py:226-249, singleuser.py:48-81)
+      'notebook'   notebooks/Transmission_with_Rayleigh_and_AWGN_channels.ipynb cell 8: randint(N); noise
+                   randn_c(N); h = randn_c(N)."""
+    table, kind = _table(mod, M)
+    eng.set_constellation(table, kind)
+    noise_var = 1.0 / float(dB2Linear(snr_db))
+    if form == "notebook":
+        prog = [("randint", N, M)] + [("randn", N)] * 4
+        o_noise, o_h = 0, 2 * N
+    else:
+        prog = [("randint", N, M), ("randn", 1), ("randn", 1)] + [("randn", N)] * 4
+        o_h, o_noise = 2, 2 + 2 * N
+    ints, dbls = eng.legacy_draws(prog, seed_base, first, count)
+    d = dbls.get()
+    h = eng.complex_from_parts(d[:, o_h:o_h + N].copy(), d[:, o_h + N:o_h + 2 * N].copy(), INV_SQRT2, dtype="f64")
+    noise = eng.complex_from_parts(d[:, o_noise:o_noise + N].copy(), d[:, o_noise + N:o_noise + 2 * N].copy(),
+                                   INV_SQRT2, dtype="f64")
+    tx = eng.modulate(ints, dtype="f64")
+    rx = eng.awgn_add(eng.cmul(h, tx, dtype="f64"), noise, noise_var, dtype="f64")
+    eq = eng.cdiv(rx, h, dtype="f64")
+    cnt, se, be = eng.demod_count(eq, ints, n_real=count, dtype="f64")
+    return cnt, se, be
+
+
 def run_ofdm_tdl(eng, seed_base, first, count, mod="qpsk", M=4, fft_size=1024, cp_size=16, num_used=None,
                  n_ofdm_sym=1, snr_db=20.0, Fd=10.0, Ts=1.0 / (15e3 * 1024), L=8,
                  tap_powers_dB=(0.0, -3.0, -6.0, -9.0, -12.0), tap_delays_samples=(0, 1, 2, 3, 4)):

@@ -48,6 +48,11 @@ def test_flat_jakes_same_seed_as_reference(engine):
     _check("c2_flat_jakes", lambda s, n, kw: legacy.run_flat_jakes(engine, s, 0, n, **kw))
 
 
+def test_flat_rayleigh_same_seed_as_reference(engine):
+    """a7: both of the reference's statements of i.i.d. Rayleigh fading (channel classes / notebook cell 8)."""
+    _check("c2b_flat_rayleigh", lambda s, n, kw: legacy.run_flat_rayleigh(engine, s, 0, n, **kw))
+
+
 def test_ofdm_tdl_same_seed_as_reference(engine):
     _check("c3_ofdm_tdl", lambda s, n, kw: legacy.run_ofdm_tdl(engine, s, 0, n, **kw))
 

@@ -65,6 +65,33 @@ def test_flat_fading_pipeline(engine, dt, exact):
 
 
 @pytest.mark.parametrize("dt,exact", [("f64", True), ("f32", False)])
+@pytest.mark.parametrize("mod,M,N,snr", [("qam", 16, 1000, 15.0), ("qam", 64, 20000, 28.0), ("psk", 8, 4097, 16.0),
+                                         ("bpsk", 2, 333, 5.0)])
+def test_flat_rayleigh_pipeline(engine, dt, exact, mod, M, N, snr):
+    """a7: the rayleigh_iid branch of the single-carrier kernel against oracle.chains.chain_flat_rayleigh under the
+    same Philox keying (h = CHAN sample n, noise = NOISE sample n): f64 counts exact, f32 |dSER| <= 1e-4; both of
+    the oracle's forms address the same draws; slicer == min-distance on QAM."""
+    engine.set_constellation(chains.constellation(mod, M), _lib.CONST_QAM if mod == "qam" else _lib.CONST_GENERIC)
+    first, count = 900001, 5
+    kw = dict(mod=mod, M=M, N=N, snr_db=snr)
+    want_se, want_be, nsym, nbits = oracle_counts(chains.chain_flat_rayleigh, first, count, **kw)
+    nb_se, nb_be, _, _ = oracle_counts(chains.chain_flat_rayleigh, first, count, form="notebook", **kw)
+    assert np.array_equal(want_se, nb_se) and np.array_equal(want_be, nb_be)
+    nv = 1.0 / omodem.dB2Linear(snr)
+    res, se, be = engine.run_flat_fading(N, nv, SEED, first, count, rayleigh_iid=True, dtype=dt, per_realization=True)
+    check(res, se, be, want_se, want_be, nsym, nbits, exact)
+    if mod == "qam":
+        res2, se2, be2 = engine.run_flat_fading(N, nv, SEED, first, count, rayleigh_iid=True,
+                                                method=_lib.DEMOD_QAM_SLICER, dtype=dt, per_realization=True)
+        assert np.max(np.abs(se2.astype(int) - se.astype(int))) <= (0 if exact else 2)
+    # split invariance: the counters of two half ranges add up to the whole range's
+    a = engine.run_flat_fading(N, nv, SEED, first, 2, rayleigh_iid=True, dtype=dt)
+    b = engine.run_flat_fading(N, nv, SEED, first + 2, 3, rayleigh_iid=True, dtype=dt)
+    assert a["sym_errors"] + b["sym_errors"] == res["sym_errors"]
+    assert a["bit_errors_sq"] + b["bit_errors_sq"] == res["bit_errors_sq"]
+
+
+@pytest.mark.parametrize("dt,exact", [("f64", True), ("f32", False)])
 @pytest.mark.parametrize("case", [0, 1, 2, 3, 4])
 def test_ofdm_tdl_pipeline(engine, dt, exact, case):
     kws = [dict(mod="qpsk", M=4, fft_size=1024, cp_size=16, num_used=None, n_ofdm_sym=1, snr_db=20.0, Fd=10.0,

@@ -98,6 +98,7 @@ def test_blast(golden_ops):
 
 
 CHAIN_FN = {"c1_awgn": chains.chain_awgn, "c2_flat_jakes": chains.chain_flat_jakes,
+            "c2b_flat_rayleigh": chains.chain_flat_rayleigh,
             "c3_ofdm_tdl": chains.chain_ofdm_tdl, "c4_mimo_ofdm": chains.chain_mimo_ofdm, "c5_ia": chains.chain_ia, "f3_ia_iterative": chains.chain_ia_iterative, "f3b_ia_svd_init": chains.chain_ia_iterative, "f5_mimo_schemes": chains.chain_mimo_scheme,
             "f1_mimo_ofdm_tdl": chains.chain_mimo_ofdm_tdl, "f6_block_diag": chains.chain_bd}
 
