@@ -1,12 +1,15 @@
 #!/usr/bin/env python3
 """Condense gpurun_out/ (rocprofv3 csv + bench json) into the tracked profiles/<round>/ summaries.
 
-usage: python scripts/collect_profiles.py r01
-For each profiled config (c4: k_run_mimo_ofdm, f1: k_run_mimo_ofdm_tdl) writes <cfg>_kernel_stats.csv,
-<cfg>_pmc_summary.json and profiles/traffic_<cfg>.json, which bench.py reads for roofline.traffic:
-hbm_bytes_per_launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024, following
+usage: python scripts/collect_profiles.py r02
+For every profiled config (c4, c3, c2, f1, c5, f6) writes <cfg>_kernel_stats.csv and <cfg>_pmc_summary.json
+(counter means per launch + the `_derived` fractions of bench.derive_pmc, the same function bench.py applies
+to its live counters): hbm_bytes_per_launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024, following
 /opt/skills/guides/MI355X_MICROARCH.md (rocprofv3 counts KiB; on gfx950 FETCH_SIZE reports half of
-a coalesced stream's bytes, WRITE_SIZE is uncalibrated).
+a coalesced stream's bytes, WRITE_SIZE is uncalibrated); valu_busy_chip = 4 * SQ_ACTIVE_INST_VALU /
+(GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs); mfma_busy_chip = SQ_VALU_MFMA_BUSY_CYCLES / the same SIMD-cycles.
+The `_dispatch` record is rocprofv3's own (its VGPR_Count is half the real allocation on gfx950 and its
+LDS_Block_Size omits dynamic LDS -- the compiler's numbers are in kernel_resources.json, scripts/kernel_resources.py).
 """
 import collections
 import csv
@@ -17,7 +20,9 @@ import shutil
 import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
+sys.path.insert(0, REPO)
+from bench import BATCH, derive_pmc  # noqa: E402
 src = os.path.join(REPO, "gpurun_out")
 dst = os.path.join(REPO, "profiles", rnd)
 os.makedirs(dst, exist_ok=True)
@@ -25,6 +30,8 @@ os.makedirs(dst, exist_ok=True)
 CONFIGS = {
     "c4": ("k_run_mimo_ofdm<", "k_run_mimo_ofdm<float,1024,4>, %d realizations per launch (bench.py default workload)"),
     "f1": ("k_run_mimo_ofdm_tdl<", "k_run_mimo_ofdm_tdl<float,1024,4>, %d realizations per launch (bench.py --config f1)"),
+    "c3": ("k_run_ofdm_tdl_batch<", "k_run_ofdm_tdl_batch<float,1024,4>, %d realizations per launch (bench.py --config c3)"),
+    "c2": ("k_run_flat<", "k_run_flat<float,8>, %d realizations per launch (bench.py --config c2)"),
     "c5": ("k_run_ia<", "k_run_ia<float>, %d realizations per launch (bench.py --config c5)"),
     "f6": ("k_run_bd<", "k_run_bd<float,2>, %d realizations per launch (bench.py --config f6)"),
 }
@@ -53,26 +60,13 @@ for cfg, (needle, label) in CONFIGS.items():
                              "max": max(vals)}
     if not summary:
         continue
-    per_launch = 65536
-    bj = os.path.join(src, "bench_%s.json" % ("c4_slicer" if cfg == "c4" else cfg))
-    try:
-        per_launch = json.loads(open(bj).read().strip().splitlines()[-1])["config"]["realizations_per_step_per_gpu"]
-    except Exception:
-        pass
-    g = lambda k: summary.get(k, {}).get("mean_per_launch")
-    derived = {}
-    if g("SQ_ACTIVE_INST_VALU") and g("SQ_WAVE_CYCLES"):
-        derived["valu_active_per_wave"] = g("SQ_ACTIVE_INST_VALU") / g("SQ_WAVE_CYCLES")
-    if g("SQ_LDS_BANK_CONFLICT") and g("SQ_LDS_IDX_ACTIVE"):
-        derived["lds_bank_conflict_frac"] = g("SQ_LDS_BANK_CONFLICT") / g("SQ_LDS_IDX_ACTIVE")
-    if g("SQ_WAIT_INST_ANY") and g("SQ_WAVE_CYCLES"):
-        derived["wait_inst_any_frac"] = g("SQ_WAIT_INST_ANY") / g("SQ_WAVE_CYCLES")
-    if g("FETCH_SIZE") is not None and g("WRITE_SIZE") is not None:
-        derived["hbm_bytes_per_launch"] = (2.0 * g("FETCH_SIZE") + g("WRITE_SIZE")) * 1024.0
-        derived["hbm_bytes_per_realization"] = derived["hbm_bytes_per_launch"] / per_launch
+    per_launch = BATCH[cfg]
+    derived = derive_pmc({k: v["mean_per_launch"] for k, v in summary.items()}, per_launch)
     summary["_derived"] = derived
     summary["_kernel"] = label % per_launch
     summary["_dispatch"] = meta
+    summary["_dispatch_note"] = ("rocprofv3's record: VGPR_Count is HALF the allocation on gfx950, LDS_Block_Size omits "
+                                 "dynamic LDS; see kernel_resources.json for the code-object values")
     json.dump(summary, open(os.path.join(dst, "%s_pmc_summary.json" % cfg), "w"), indent=1)
     if "hbm_bytes_per_launch" in derived:
         json.dump({"hbm_bytes_per_launch": derived["hbm_bytes_per_launch"], "realizations_per_launch": per_launch,
