@@ -1,0 +1,501 @@
+// pipeline_mimo_mfma.hip -- config 4 (4x4 Blast + OFDM-1024) with the transforms and the two 4x4 contractions on
+// the matrix cores (gfx950 v_mfma_f32_16x16x4_f32 / v_mfma_f32_4x4x1_16b_f32: exact f32, an fmaf chain per
+// output, issued on the MFMA pipe next to the VALU work of the same and the co-resident waves).
+//
+// Same link, same draw ledger and same results contract as k_run_mimo_ofdm (pipelines.hip; reference
+// apps/mimo/simulate_mimo.py:68-142, mimo/mimo.py:609-660, modulators/ofdm.py:394-466); f32, N = 1024, 4x4 only.
+//
+// FFT-1024 = 16 x 16 x 4.  A 16-point DFT of 16 independent groups is one real matrix product
+//     [Re; Im](out) = [[Wr, -Wi], [Wi, Wr]] [Re; Im](in)
+// after one radix-2 split on the VALU (s = x[e] + x[e+8], d = x[e] - x[e+8]: even outputs = DFT-8 of s, odd
+// outputs = DFT-8 of d with W16^e folded into the matrix), i.e. 2 x (16x16 real) x (16 x 16 groups) = 8 MFMAs per
+// (antenna, 16 groups) instead of 16.  Per wavefront and pass: 4 antennas x 8 MFMAs (32 cycles each).
+//   DIF (transmit, inverse via the re<->im swap identity IDFT(x) = swap(DFT(swap(x)))):
+//     P1  DFT-16 over n1 (positions 64 n1 + n2)        x W1024^{k1 n2}     wave w owns columns n2 in [16w, 16w+16)
+//     P2  DFT-16 over m1 (positions 64 k1 + 4 m1 + m2) x W64^{j1 m2}       wave w owns rows k1 in [4w, 4w+4)
+//     P3  DFT-4  over m2 (positions 64 k1 + 4 j1 + m2)                      thread = one butterfly, same rows
+//     -> position 64 k1 + 4 j1 + j2 holds time sample k1 + 16 j1 + 256 j2
+//   DIT (receive) is the transpose: P3' (DFT-4, x W64), P2' (DFT-16, x W1024), P1' (DFT-16) -> natural bin order.
+// P3, the channel (R = H T + noise, as 4x4x1 MFMAs with the noise as the initial accumulator) and P3' are ONE
+// register-resident stage; the Blast decode (G Y, 4x4x1 MFMAs), the demodulator and the error count consume P1''s
+// accumulators directly.  LDS round trips per OFDM symbol: 5 (+ the symbol scatter) instead of 12.
+//
+// LDS: per antenna a re plane and an im plane of 1024 floats (im plane 16 dwords further: a wave's two planes hit
+// complementary bank halves), position p stored at p ^ (f(p >> 6) << 2), f(k) = (k & 7) ^ ((k & 1) << 3): every
+// access of the passes above is bank-conflict free (tests/test_fft16_layout.py replays all of them; the b128
+// stores of the middle stage are 2-way, below their own issue cost).
+#include <cstdlib>
+
+#include "fft.hpp"
+#include "mimo.hpp"
+#include "modem.hpp"
+#include "philox.hpp"
+#include "totals.hpp"
+#include "pipe_common.hpp"
+
+namespace mcle {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+constexpr int kF16N = 1024;
+constexpr int kF16Plane = 1040;            // dwords from an antenna's re plane to its im plane (== 16 mod 32)
+constexpr int kF16Ant = 2 * kF16Plane;     // dwords per antenna
+
+__host__ __device__ __forceinline__ int f16_swz(int k) { return ((k & 7) ^ ((k & 1) << 3)) << 2; }
+__host__ __device__ __forceinline__ int f16_pos(int p) { return p ^ f16_swz(p >> 6); }
+
+// same-wave LDS hand-off between two passes (the wave's own DS traffic executes in order)
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+__device__ __forceinline__ float dpp_swap1(float v) {   // value of lane ^ 1 (quad_perm [1,0,3,2])
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));
+}
+
+// The two real 16x16 matrices of the split DFT-16, as MFMA A operands: lane (row i = l & 15, k-group g = l >> 4),
+// k-step t < 4 covers element e = 2t + (g >> 1), part g & 1; row i = 2u + part_out.
+struct Dft16Mats {
+    float ae[4], ao[4];
+};
+__device__ __forceinline__ Dft16Mats dft16_mats(const float2* __restrict__ g_tw, int lane) {
+    Dft16Mats m;
+    const int i = lane & 15, g = lane >> 4, u = i >> 1;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int e = 2 * t + (g >> 1);
+        const float2 we = g_tw[(128 * e * u) & 1023];             // W8^{e u}
+        const float2 wo = g_tw[(64 * e * (2 * u + 1)) & 1023];    // W16^{e (2u+1)}
+        if ((i & 1) == 0) {
+            m.ae[t] = (g & 1) ? -we.y : we.x;
+            m.ao[t] = (g & 1) ? -wo.y : wo.x;
+        } else {
+            m.ae[t] = (g & 1) ? we.x : we.y;
+            m.ao[t] = (g & 1) ? wo.x : wo.y;
+        }
+    }
+    return m;
+}
+
+// One DFT-16 pass over one antenna's 16 groups: b[0..7] = this lane's operand values (element 2t + (g >> 1), part
+// g & 1).  Returns out[x] = (re, im) of output 4g + x of group (lane & 15), x = 0..3.
+__device__ __forceinline__ void dft16_mfma(const Dft16Mats& m, const float (&b)[8], float2 (&out)[4]) {
+    f4 ce = {0.f, 0.f, 0.f, 0.f}, co = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        ce = __builtin_amdgcn_mfma_f32_16x16x4f32(m.ae[t], b[t] + b[t + 4], ce, 0, 0, 0);
+        co = __builtin_amdgcn_mfma_f32_16x16x4f32(m.ao[t], b[t] - b[t + 4], co, 0, 0, 0);
+    }
+    out[0] = make_float2(ce[0], ce[1]);   // k = 4g     (u = 2g,     even)
+    out[1] = make_float2(co[0], co[1]);   // k = 4g + 1 (u = 2g,     odd)
+    out[2] = make_float2(ce[2], ce[3]);   // k = 4g + 2 (u = 2g + 1, even)
+    out[3] = make_float2(co[2], co[3]);   // k = 4g + 3
+}
+
+// inverse of ofdm_bin (fft.hpp): data index carried by FFT bin `bin`, or -1
+__device__ __forceinline__ int ofdm_data_index(int bin, int n, int num_used) {
+    if (num_used == n) return (bin + n / 2) & (n - 1);
+    const int h = num_used / 2;
+    if (bin >= n - h) return bin - (n - h);
+    if (bin >= 1 && bin <= h) return h + bin - 1;
+    return -1;
+}
+
+struct MimoParams {
+    int cp, num_used, n_ofdm_sym;
+    int mmse;
+    double noise_var;
+};
+
+__global__ __launch_bounds__(kPipeBlock, 3) void k_run_mimo_ofdm_mfma(MimoParams pp, ModemParams<float> mp,
+                                                                       uint64_t seed, uint64_t first, uint64_t count,
+                                                                       const float2* __restrict__ g_tw,
+                                                                       float2* g_filters, mcle_counters* counters,
+                                                                       uint32_t* __restrict__ sym_out,
+                                                                       uint32_t* __restrict__ bit_out) {
+    constexpr int N = kF16N, NA = 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* s_d = reinterpret_cast<float*>(smem);                        // [NA][re plane | im plane]
+    float2* s_txtab = reinterpret_cast<float2*>(s_d + NA * kF16Ant);    // [kMaxTable] constellation x tx scale
+    float2* s_H = s_txtab + kMaxTable;                                  // [16] H then [16] G
+    float2* s_G = s_H + NA * NA;
+    float4* s_tab4 = reinterpret_cast<float4*>(s_G + NA * NA);          // [kMaxTable] {re, im, |c|^2/2, 0}
+    unsigned* s_red = reinterpret_cast<unsigned*>(s_tab4 + kMaxTable);  // [8] + flag
+    unsigned long long* s_grid = reinterpret_cast<unsigned long long*>(s_red + 16);
+    unsigned char* s_idx = reinterpret_cast<unsigned char*>(s_grid + mp.grid.G * mp.grid.G);   // [NA * num_used]
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int j = lane & 15, g = lane >> 4, gb = g >> 1;
+    const int U = pp.num_used, cp = pp.cp;
+    const int per_sym = U * NA;
+    const uint64_t row = (uint64_t)pp.n_ofdm_sym * (N + cp);
+    const float sigma = (float)sqrt(pp.noise_var);
+    const float tx_scale = (float)(1.0 / sqrt((double)NA) / sqrt((double)(U + cp)));
+    const double rx_scale = sqrt((double)(U + cp)) / (double)N;
+    const uint32_t mask = (uint32_t)(mp.M - 1);
+    const uint32_t mask4 = mask * 0x01010101u;
+
+    for (int m = tid; m < mp.M; m += kPipeBlock) {
+        const float2 c = mp.g_table[m];
+        s_txtab[m] = make_float2(c.x * tx_scale, c.y * tx_scale);
+        s_tab4[m] = make_float4(c.x, c.y, 0.5f * (c.x * c.x + c.y * c.y), 0.f);
+    }
+    load_grid(mp, s_grid);
+    __shared__ WgTotals totals;
+    if (tid == 0) wg_zero(totals);
+
+    // ---- per-thread constants: DFT matrices, twiddles, LDS offsets ---------------------------------------------
+    const Dft16Mats mats = dft16_mats(g_tw, lane);
+    const int n2 = 16 * w + j;                       // P1 / P1': this lane's column
+    const int k1p = 4 * w + (j >> 2), m2p = j & 3;   // P2 / P2': this lane's group (row k1p, residue m2p)
+    // middle stage: lane -> butterfly (row k1m, j1m); lanes l and l ^ 1 hold time samples m and m + 1
+    const int kkm = ((lane >> 5) << 1) | (lane & 1), j1m = (lane >> 1) & 15, k1m = 4 * w + kkm, par = lane & 1;
+    float2 tw1a[4], tw2a[4], tw1b[4], tw2b[3];
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+        tw1a[x] = g_tw[((4 * g + x) * n2) & 1023];                            // P1 : W1024^{k1 n2}
+        tw2a[x] = g_tw[(16 * (4 * g + x) * m2p) & 1023];                      // P2 : W64^{j1 m2} ...
+        if ((k1p & 1) && (m2p & 1)) tw2a[x] = make_float2(-tw2a[x].x, -tw2a[x].y);   // ... x the P3 slot order of odd rows
+        tw1b[x] = g_tw[((4 * (4 * g + x) + m2p) * k1p) & 1023];               // P2': W1024^{(4 m1 + m2) k1}
+    }
+#pragma unroll
+    for (int m2 = 1; m2 < 4; ++m2) {
+        tw2b[m2 - 1] = g_tw[(16 * m2 * j1m) & 1023];                          // P3': W64^{m2 j1} x slot order
+        if (par && (m2 & 1)) tw2b[m2 - 1] = make_float2(-tw2b[m2 - 1].x, -tw2b[m2 - 1].y);
+    }
+    // dword offsets inside an antenna block (re plane; + kF16Plane for the im plane)
+    const int plane_g = (g & 1) * kF16Plane;                                  // this lane's operand part: re / im plane
+    const int p1_ld = 64 * gb + (n2 ^ (gb * 36));                             // element 2t+gb: (p1_ld ^ ((2t & 7) << 2)) + 128 t
+    const int p1_st = 256 * g + (n2 ^ (16 * (g & 1)));                        // output 4g+x : (p1_st ^ ((x << 2) ^ ((x & 1) << 5))) + 64 x
+    const int p2_base = 64 * k1p + (m2p | f16_swz(k1p));
+    const int p2_ld = p2_base ^ (4 * gb);                                     // element 2t+gb: p2_ld ^ (8 t)
+    const int p2_st = p2_base ^ (16 * g);                                     // output 4g+x : p2_st ^ (4 x)
+    const int mid_off = 64 * k1m + ((4 * j1m) ^ f16_swz(k1m));                // 4 consecutive positions of the butterfly
+
+    constexpr int kRec = 2 * NA * NA + 1;
+    float2* my_filters = g_filters + (size_t)blockIdx.x * 64 * kRec;
+    // noise samples pair up in Philox blocks by even / odd sample index; lanes l, l^1 share blocks when the
+    // realization's sample indices keep the parity of the time index
+    const bool pair_ok = ((row & 1) == 0) && (((N + cp) & 1) == 0) && ((cp & 1) == 0);
+    uint64_t it = 0;
+    for (uint64_t rl = blockIdx.x; rl < count; rl += gridDim.x, ++it) {
+        const Rng rng(seed, first + rl);
+        const int slot = (int)(it & 63);
+        __syncthreads();
+        if (slot == 0) {   // channel draw + f64 receive filter for this workgroup's next 64 realizations, one per lane
+            const uint64_t rj = rl + (uint64_t)tid * gridDim.x;
+            if (tid < 64 && rj < count) {
+                const Rng rngj(seed, first + rj);
+                float2* rec = my_filters + tid * kRec;
+                double2 H[NA][NA], G[NA][NA];
+#pragma unroll
+                for (int r = 0; r < NA; ++r)
+#pragma unroll
+                    for (int a = 0; a < NA; ++a) {
+                        const float2 h = cn_sample<float>(rngj, STREAM_CHAN, (uint64_t)(r * NA + a), 1.f);
+                        rec[r * NA + a] = h;
+                        H[r][a] = mk<double>((double)h.x, (double)h.y);
+                    }
+                const bool ok = blast_filter<NA, NA>(H, pp.mmse ? pp.noise_var : 0.0, G);
+#pragma unroll
+                for (int a = 0; a < NA; ++a)
+#pragma unroll
+                    for (int r = 0; r < NA; ++r)
+                        rec[NA * NA + a * NA + r] = make_float2((float)(G[a][r].x * rx_scale), (float)(G[a][r].y * rx_scale));
+                rec[2 * NA * NA] = make_float2(ok ? 0.f : 1.f, 0.f);
+            }
+            __threadfence_block();
+            __syncthreads();
+        }
+        if (tid < kRec) {
+            const float2 v = my_filters[slot * kRec + tid];
+            if (tid < 2 * NA * NA) s_H[tid] = v;          // s_G follows s_H
+            else s_red[15] = v.x != 0.f ? 1u : 0u;
+        }
+        unsigned se = 0, be = 0;
+        for (int os = 0; os < pp.n_ofdm_sym; ++os) {
+            __syncthreads();   // previous symbol's P1' reads done; H / G staged
+            // ---- symbols -> bins, stored re<->im swapped (inverse transform by the swap identity) ----
+            const uint64_t n_first = (uint64_t)os * per_sym;
+            if (U == N) {      // one Philox block per thread: 4 consecutive bins x 4 antennas
+                const Words4 dw = rng.block(STREAM_DATA, (uint32_t)(n_first >> 4) + tid);
+                uint4 idx4 = make_uint4(dw.w[0] & mask4, dw.w[1] & mask4, dw.w[2] & mask4, dw.w[3] & mask4);
+                *reinterpret_cast<uint4*>(s_idx + 16 * tid) = idx4;
+                const int off = f16_pos((4 * tid + N / 2) & (N - 1));
+                const uint32_t wv[4] = {idx4.x, idx4.y, idx4.z, idx4.w};
+                float2 sym[4][NA];
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int a = 0; a < NA; ++a) sym[c][a] = s_txtab[(wv[c] >> (8 * a)) & 0xFFu];
+#pragma unroll
+                for (int a = 0; a < NA; ++a) {
+                    f4 vr = {sym[0][a].y, sym[1][a].y, sym[2][a].y, sym[3][a].y};
+                    f4 vi = {sym[0][a].x, sym[1][a].x, sym[2][a].x, sym[3][a].x};
+                    *reinterpret_cast<f4*>(s_d + a * kF16Ant + off) = vr;
+                    *reinterpret_cast<f4*>(s_d + a * kF16Ant + kF16Plane + off) = vi;
+                }
+            } else {
+                for (int p = tid; p < NA * kF16Ant; p += kPipeBlock) s_d[p] = 0.f;
+                __syncthreads();
+                const uint64_t n_last = n_first + per_sym;
+                for (uint64_t blk = (n_first >> 4) + tid; blk <= ((n_last - 1) >> 4); blk += kPipeBlock) {
+                    const Words4 dw = rng.block(STREAM_DATA, (uint32_t)blk);
+#pragma unroll
+                    for (int jj = 0; jj < 16; ++jj) {
+                        const uint64_t n = (blk << 4) + jj;
+                        if (n >= n_first && n < n_last) {
+                            const int tx = (int)((dw.w[jj >> 2] >> ((jj & 3) * 8)) & mask);
+                            const int nl = (int)(n - n_first);
+                            const int a = nl & 3, d = nl >> 2;
+                            s_idx[nl] = (unsigned char)tx;
+                            const float2 c = s_txtab[tx];
+                            const int off = a * kF16Ant + f16_pos(ofdm_bin(d, N, U));
+                            s_d[off] = c.y;
+                            s_d[off + kF16Plane] = c.x;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            // ---- P1: DFT-16 over n1, x W1024^{k1 n2} ----
+#pragma unroll
+            for (int a = 0; a < NA; ++a) {
+                float* pa = s_d + a * kF16Ant;
+                const float* pl = pa + plane_g;
+                float b[8];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) b[t] = pl[(p1_ld ^ (((2 * t) & 7) << 2)) + 128 * t];
+                float2 o[4];
+                dft16_mfma(mats, b, o);
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    const float2 v = cmul(o[x], tw1a[x]);
+                    const int off = (p1_st ^ ((x << 2) ^ ((x & 1) << 5))) + 64 * x;
+                    pa[off] = v.x;
+                    pa[off + kF16Plane] = v.y;
+                }
+            }
+            __syncthreads();
+            // ---- P2: DFT-16 over m1, x W64^{j1 m2} ----
+#pragma unroll
+            for (int a = 0; a < NA; ++a) {
+                float* pa = s_d + a * kF16Ant;
+                const float* pl = pa + plane_g;
+                float b[8];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) b[t] = pl[p2_ld ^ (8 * t)];
+                float2 o[4];
+                dft16_mfma(mats, b, o);
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    const float2 v = cmul(o[x], tw2a[x]);
+                    pa[p2_st ^ (4 * x)] = v.x;
+                    pa[(p2_st ^ (4 * x)) + kF16Plane] = v.y;
+                }
+            }
+            wave_lds_sync();
+            // ---- middle stage: P3 (DFT-4) -> channel R = H T + noise -> P3' (DFT-4 x W64) ----
+            {
+                float xr[4][NA], xi[4][NA];     // [slot][antenna]: transmitted time samples (slot s = c ^ 2 par)
+#pragma unroll
+                for (int a = 0; a < NA; ++a) {
+                    const f4 R = *reinterpret_cast<const f4*>(s_d + a * kF16Ant + mid_off);
+                    const f4 I = *reinterpret_cast<const f4*>(s_d + a * kF16Ant + kF16Plane + mid_off);
+                    const float t0r = R[0] + R[2], t0i = I[0] + I[2], t1r = R[0] - R[2], t1i = I[0] - I[2];
+                    const float t2r = R[1] + R[3], t2i = I[1] + I[3];
+                    const float t3r = I[1] - I[3], t3i = R[3] - R[1];     // (z1 - z3) * (-i)
+                    // planes hold swap(x): true sample = (im plane, re plane)
+                    xi[0][a] = t0r + t2r; xr[0][a] = t0i + t2i;
+                    xi[1][a] = t1r + t3r; xr[1][a] = t1i + t3i;
+                    xi[2][a] = t0r - t2r; xr[2][a] = t0i - t2i;
+                    xi[3][a] = t1r - t3r; xr[3][a] = t1i - t3i;
+                }
+                // noise: sample index of (r, c) = r*row + os*(N+cp) + cp + m, m = k1 + 16 j1 + 256 c
+                f4 yre[4], yim[4];               // [slot] over r
+                const uint64_t i_base = (uint64_t)os * (N + cp) + cp + (uint64_t)(k1m + 16 * j1m);
+                if (pair_ok) {
+#pragma unroll
+                    for (int cc = 0; cc < 2; ++cc) {
+                        const int c = 2 * par + cc;
+#pragma unroll
+                        for (int r = 0; r < NA; ++r) {
+                            const uint64_t i = (uint64_t)r * row + i_base + 256u * c;
+                            const Words4 b = rng.block(STREAM_NOISE, (uint32_t)(i >> 1));
+                            const uint32_t k0 = par ? b.w[2] : b.w[0], k1 = par ? b.w[3] : b.w[1];
+                            const uint32_t g0 = par ? b.w[0] : b.w[2], g1 = par ? b.w[1] : b.w[3];
+                            const float2 keep = cn_from_words(k0, k1, sigma);
+                            const float2 give = cn_from_words(g0, g1, sigma);
+                            yre[cc][r] = keep.x;
+                            yim[cc][r] = keep.y;
+                            yre[2 + cc][r] = dpp_swap1(give.x);
+                            yim[2 + cc][r] = dpp_swap1(give.y);
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        const int c = s ^ (2 * par);
+#pragma unroll
+                        for (int r = 0; r < NA; ++r) {
+                            const float2 z = cn_sample<float>(rng, STREAM_NOISE, (uint64_t)r * row + i_base + 256u * c, sigma);
+                            yre[s][r] = z.x;
+                            yim[s][r] = z.y;
+                        }
+                    }
+                }
+                {
+                    float hr[NA], hi[NA], nhi[NA];   // A operands: lane (l & 3) = receive antenna r
+#pragma unroll
+                    for (int a = 0; a < NA; ++a) {
+                        const float2 h = s_H[(lane & 3) * NA + a];
+                        hr[a] = h.x;
+                        hi[a] = h.y;
+                        nhi[a] = -h.y;
+                    }
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+#pragma unroll
+                        for (int a = 0; a < NA; ++a) {
+                            yre[s] = __builtin_amdgcn_mfma_f32_4x4x1f32(hr[a], xr[s][a], yre[s], 0, 0, 0);
+                            yim[s] = __builtin_amdgcn_mfma_f32_4x4x1f32(hi[a], xr[s][a], yim[s], 0, 0, 0);
+                            yre[s] = __builtin_amdgcn_mfma_f32_4x4x1f32(nhi[a], xi[s][a], yre[s], 0, 0, 0);
+                            yim[s] = __builtin_amdgcn_mfma_f32_4x4x1f32(hr[a], xi[s][a], yim[s], 0, 0, 0);
+                        }
+                }
+                // P3': DFT-4 over the slots (their order is folded into tw2b), x W64^{m2 j1}
+#pragma unroll
+                for (int r = 0; r < NA; ++r) {
+                    const float t0r = yre[0][r] + yre[2][r], t0i = yim[0][r] + yim[2][r];
+                    const float t1r = yre[0][r] - yre[2][r], t1i = yim[0][r] - yim[2][r];
+                    const float t2r = yre[1][r] + yre[3][r], t2i = yim[1][r] + yim[3][r];
+                    const float t3r = yim[1][r] - yim[3][r], t3i = yre[3][r] - yre[1][r];
+                    const float2 v1 = cmul(make_float2(t1r + t3r, t1i + t3i), tw2b[0]);
+                    const float2 v2 = cmul(make_float2(t0r - t2r, t0i - t2i), tw2b[1]);
+                    const float2 v3 = cmul(make_float2(t1r - t3r, t1i - t3i), tw2b[2]);
+                    const f4 vr = {t0r + t2r, v1.x, v2.x, v3.x};
+                    const f4 vi = {t0i + t2i, v1.y, v2.y, v3.y};
+                    *reinterpret_cast<f4*>(s_d + r * kF16Ant + mid_off) = vr;
+                    *reinterpret_cast<f4*>(s_d + r * kF16Ant + kF16Plane + mid_off) = vi;
+                }
+            }
+            wave_lds_sync();
+            // ---- P2': DFT-16 over j1, x W1024^{(4 m1 + m2) k1} ----
+#pragma unroll
+            for (int a = 0; a < NA; ++a) {
+                float* pa = s_d + a * kF16Ant;
+                const float* pl = pa + plane_g;
+                float b[8];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) b[t] = pl[p2_ld ^ (8 * t)];
+                float2 o[4];
+                dft16_mfma(mats, b, o);
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    const float2 v = cmul(o[x], tw1b[x]);
+                    pa[p2_st ^ (4 * x)] = v.x;
+                    pa[(p2_st ^ (4 * x)) + kF16Plane] = v.y;
+                }
+            }
+            __syncthreads();
+            // ---- P1': DFT-16 over k1 -> bins 64 n1 + n2 (n1 = 4g + x), then Blast decode, demodulate, count ----
+            {
+                float yr[4][NA], yi[4][NA];      // [x][receive antenna]
+#pragma unroll
+                for (int r = 0; r < NA; ++r) {
+                    const float* pl = s_d + r * kF16Ant + plane_g;
+                    float b[8];
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) b[t] = pl[(p1_ld ^ (((2 * t) & 7) << 2)) + 128 * t];
+                    float2 o[4];
+                    dft16_mfma(mats, b, o);
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) {
+                        yr[x][r] = o[x].x;
+                        yi[x][r] = o[x].y;
+                    }
+                }
+                float gr[NA], gi[NA], ngi[NA];   // A operands: lane (l & 3) = stream a; G carries the FFT scale
+#pragma unroll
+                for (int r = 0; r < NA; ++r) {
+                    const float2 gg = s_G[(lane & 3) * NA + r];
+                    gr[r] = gg.x;
+                    gi[r] = gg.y;
+                    ngi[r] = -gg.y;
+                }
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    f4 er = {0.f, 0.f, 0.f, 0.f}, ei = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int r = 0; r < NA; ++r) {
+                        er = __builtin_amdgcn_mfma_f32_4x4x1f32(gr[r], yr[x][r], er, 0, 0, 0);
+                        ei = __builtin_amdgcn_mfma_f32_4x4x1f32(gi[r], yr[x][r], ei, 0, 0, 0);
+                        er = __builtin_amdgcn_mfma_f32_4x4x1f32(ngi[r], yi[x][r], er, 0, 0, 0);
+                        ei = __builtin_amdgcn_mfma_f32_4x4x1f32(gr[r], yi[x][r], ei, 0, 0, 0);
+                    }
+                    const int d = ofdm_data_index(64 * (4 * g + x) + n2, N, U);
+                    if (d >= 0) {
+                        float2 est[NA];
+                        int dec[NA];
+#pragma unroll
+                        for (int a = 0; a < NA; ++a) est[a] = make_float2(er[a], ei[a]);
+                        if (mp.method == MCLE_DEMOD_QAM_SLICER) {
+#pragma unroll
+                            for (int a = 0; a < NA; ++a)
+                                dec[a] = demod_qam_slicer<float>(est[a], mp.qam_scale, mp.qam_L, mp.half_bits);
+                        } else if (mp.grid.G > 0) {
+#pragma unroll
+                            for (int a = 0; a < NA; ++a) dec[a] = demod_grid4(s_tab4, s_grid, mp.grid, mp.M, est[a]);
+                        } else {
+                            demod_mindist_multi<NA>(s_tab4, mp.M, est, dec);
+                        }
+                        const uint32_t sent = *reinterpret_cast<const uint32_t*>(s_idx + 4 * d);
+#pragma unroll
+                        for (int a = 0; a < NA; ++a) {
+                            const unsigned xo = ((sent >> (8 * a)) & 0xFFu) ^ (unsigned)dec[a];
+                            se += (xo != 0u);
+                            be += __popc(xo);
+                        }
+                    }
+                }
+            }
+        }
+        block_sum2(se, be, s_red);
+        if (tid == 0) wg_account(totals, se, be, s_red[15] != 0u, rl, sym_out, bit_out);
+    }
+    if (tid == 0)
+        wg_flush(totals, counters, (unsigned long long)per_sym * pp.n_ofdm_sym,
+                 (unsigned long long)per_sym * pp.n_ofdm_sym * mp.bits);
+}
+
+// host side: 0 = launched, MCLE_E_UNSUPPORTED = outside this kernel's envelope (caller uses k_run_mimo_ofdm)
+int run_mimo_ofdm_mfma(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, uint64_t seed, uint64_t first, uint64_t count,
+                       mcle_counters* d_counters, uint32_t* d_sym, uint32_t* d_bit) {
+    if (cfg->fft_size != kF16N || cfg->nt != 4 || cfg->nr != 4) return MCLE_E_UNSUPPORTED;
+    if (std::getenv("MCLE_NO_MFMA")) return MCLE_E_UNSUPPORTED;
+    int rc;
+    void* tw = nullptr;
+    if ((rc = ctx->get_twiddles(kF16N, MCLE_F32, &tw))) return rc;
+    MimoParams pp{cfg->cp_size, cfg->num_used, cfg->n_ofdm_sym, cfg->mmse, cfg->noise_var};
+    const ModemParams<float> mp = pipe_modem<float>(ctx, cfg->demod_method);
+    const size_t lds = (size_t)4 * kF16Ant * sizeof(float) + (size_t)(kMaxTable + 2 * 16) * sizeof(float2) +
+                       kMaxTable * sizeof(float4) + 16 * sizeof(unsigned) +
+                       (size_t)mp.grid.G * mp.grid.G * sizeof(unsigned long long) + (size_t)4 * cfg->num_used + 16;
+    auto kern = k_run_mimo_ofdm_mfma;
+    MCLE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int per_cu = (int)((size_t)160 * 1024 / (lds + 512));
+    if (per_cu < 1) per_cu = 1;
+    if (per_cu > 3) per_cu = 3;             // __launch_bounds__(256, 3)
+    const uint64_t cap = (uint64_t)ctx->n_cu * per_cu;
+    const unsigned grid = (unsigned)(count < cap ? count : cap);
+    void* filters = nullptr;
+    if ((rc = ctx->scratch((size_t)grid * 64 * 33 * sizeof(float2), &filters))) return rc;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kPipeBlock), lds, ctx->stream, pp, mp, seed, first, count,
+                       (const float2*)tw, (float2*)filters, d_counters, d_sym, d_bit);
+    MCLE_LAUNCH_CHECK();
+    return MCLE_OK;
+}
+
+}  // namespace mcle

@@ -772,6 +772,9 @@ int run_tdl_impl(mcle_ctx* ctx, const mcle_ofdm_tdl_cfg* cfg, uint64_t seed, uin
 }  // namespace mcle
 
 namespace mcle {
+// pipeline_mimo_mfma.hip: f32, FFT 1024, 4x4 on the matrix cores; MCLE_E_UNSUPPORTED outside that envelope
+int run_mimo_ofdm_mfma(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, uint64_t seed, uint64_t first, uint64_t count,
+                       mcle_counters* d_counters, uint32_t* d_sym, uint32_t* d_bit);
 // pipeline_siso_tdl.hip
 int run_ofdm_tdl_batched(mcle_ctx* ctx, int dtype, const mcle_ofdm_tdl_cfg* cfg, uint64_t seed, uint64_t first,
                          uint64_t count, mcle_counters* d_counters, uint32_t* d_sym, uint32_t* d_bit);
@@ -838,6 +841,10 @@ int mcle_run_mimo_ofdm(mcle_ctx* ctx, int dtype, const mcle_mimo_ofdm_cfg* cfg, 
     MCLE_REQUIRE(count <= 0x7fffffffull, "at most 2^31-1 realizations per call");
     if (count == 0) return MCLE_OK;
     if ((rc = ctx->bind())) return rc;
+    if (dtype == MCLE_F32) {   // matrix-core kernel where it applies (MCLE_NO_MFMA=1 keeps the VALU kernel below)
+        rc = run_mimo_ofdm_mfma(ctx, cfg, seed, first, count, d_counters, d_sym_err, d_bit_err);
+        if (rc != MCLE_E_UNSUPPORTED) return rc;
+    }
 #define MCLE_RUN(N_, NA_)                                                                                         \
     if (cfg->fft_size == N_ && cfg->nt == NA_)                                                                    \
         return dtype == MCLE_F32                                                                                  \
