@@ -94,6 +94,54 @@ __device__ __forceinline__ void dft16_mfma(const Dft16Mats& m, const float (&b)[
     out[3] = make_float2(co[2], co[3]);   // k = 4g + 3
 }
 
+// complex product in the shape the backend lowers to v_pk_mul_f32 + v_pk_fma_f32 (two packed ops per product)
+__device__ __forceinline__ float2 cmul_pk(float2 a, float2 w) {
+    const float tx = a.x * w.x, ty = a.x * w.y;
+    return make_float2(fmaf(-a.y, w.y, tx), fmaf(a.y, w.x, ty));
+}
+
+// Packed square-QAM slicer.  A label byte is (binary row << hb) | binary column with binary = gray^-1(level)
+// (reference modulators/fundamental.py:697-777; demod_qam_slicer in modem.hpp).  Working in the LEVEL domain --
+// the sent bytes are stored as levels, level = b ^ (b >> 1) per field -- the four decisions of a subcarrier are
+// rounded, clamped and packed by v_cvt_pk_u8_f32 (round to nearest even, saturating: probed on the device,
+// scripts/experiments/cvt_probe.hip), compared with one XOR, and the bit errors follow from one field-wise prefix
+// XOR of the difference word: popcount(gray^-1(a) ^ gray^-1(b)) = popcount(gray^-1(a ^ b)).
+struct QamPack {
+    float sc, off, lm1;     // level = round(+-coordinate * sc + off), clamped to [0, lm1]
+    uint32_t m1, m2;        // per byte: bits of both fields that have a neighbour 1 / 2 places up inside the field
+    int hb;
+};
+__device__ __forceinline__ QamPack qam_pack(const ModemParams<float>& mp) {
+    QamPack q;
+    q.lm1 = (float)(mp.qam_L - 1);
+    q.sc = 0.5f * mp.qam_scale;
+    q.off = 0.5f * q.lm1;
+    q.hb = mp.half_bits;
+    const uint32_t fm = (1u << q.hb) - 1u;
+    q.m1 = (((fm >> 1) | ((fm >> 1) << q.hb)) & 0xFFu) * 0x01010101u;
+    q.m2 = (((fm >> 2) | ((fm >> 2) << q.hb)) & 0xFFu) * 0x01010101u;
+    return q;
+}
+__device__ __forceinline__ uint32_t labels_to_levels(uint32_t w, const QamPack& q) { return w ^ ((w >> 1) & q.m1); }
+// level word of the four estimates (re[a], im[a]), a = byte index
+__device__ __forceinline__ uint32_t qam_levels4(const f4& re, const f4& im, const QamPack& q) {
+    uint32_t wj = 0u, wi = 0u;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        wj = __builtin_amdgcn_cvt_pk_u8_f32(fminf(fmaf(re[a], q.sc, q.off), q.lm1), a, wj);
+        wi = __builtin_amdgcn_cvt_pk_u8_f32(fminf(fmaf(im[a], -q.sc, q.off), q.lm1), a, wi);
+    }
+    return (wi << q.hb) | wj;
+}
+// x = decided levels ^ sent levels of four symbols -> (+symbol errors, +bit errors)
+__device__ __forceinline__ void qam_count4(uint32_t x, const QamPack& q, unsigned& se, unsigned& be) {
+    const uint32_t t = (((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;
+    se += __popc(t);
+    uint32_t y = x ^ ((x >> 1) & q.m1);
+    y ^= (y >> 2) & q.m2;
+    be += __popc(y);
+}
+
 // inverse of ofdm_bin (fft.hpp): data index carried by FFT bin `bin`, or -1
 __device__ __forceinline__ int ofdm_data_index(int bin, int n, int num_used) {
     if (num_used == n) return (bin + n / 2) & (n - 1);
@@ -109,21 +157,24 @@ struct MimoParams {
     double noise_var;
 };
 
-__global__ __launch_bounds__(kPipeBlock, 3) void k_run_mimo_ofdm_mfma(MimoParams pp, ModemParams<float> mp,
+// WAVES: waves per SIMD the register allocation is sized for (= workgroups per CU); FLAGS bit 0: draw the noise under
+// the P1 / P2 MFMAs instead of inside the middle stage
+template <int WAVES, int FLAGS>
+__global__ __launch_bounds__(kPipeBlock, WAVES) void k_run_mimo_ofdm_mfma(MimoParams pp, ModemParams<float> mp,
                                                                        uint64_t seed, uint64_t first, uint64_t count,
                                                                        const float2* __restrict__ g_tw,
                                                                        float2* g_filters, mcle_counters* counters,
                                                                        uint32_t* __restrict__ sym_out,
                                                                        uint32_t* __restrict__ bit_out) {
     constexpr int N = kF16N, NA = 4;
+    constexpr int kRec = 2 * NA * NA + 1;                               // H, G, skip flag
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* s_d = reinterpret_cast<float*>(smem);                        // [NA][re plane | im plane]
     float2* s_txtab = reinterpret_cast<float2*>(s_d + NA * kF16Ant);    // [kMaxTable] constellation x tx scale
-    float2* s_H = s_txtab + kMaxTable;                                  // [16] H then [16] G
-    float2* s_G = s_H + NA * NA;
-    float4* s_tab4 = reinterpret_cast<float4*>(s_G + NA * NA);          // [kMaxTable] {re, im, |c|^2/2, 0}
-    unsigned* s_red = reinterpret_cast<unsigned*>(s_tab4 + kMaxTable);  // [8] + flag
-    unsigned long long* s_grid = reinterpret_cast<unsigned long long*>(s_red + 16);
+    float2* s_rec = s_txtab + kMaxTable;                                // [2][kRec + 1] H, G, flag of realization it & 1
+    float4* s_tab4 = reinterpret_cast<float4*>(s_rec + 2 * (kRec + 1)); // [kMaxTable] {re, im, |c|^2/2, 0}
+    unsigned* s_part = reinterpret_cast<unsigned*>(s_tab4 + kMaxTable); // [2][4 waves][2] error partials of realization it & 1
+    unsigned long long* s_grid = reinterpret_cast<unsigned long long*>(s_part + 16);
     unsigned char* s_idx = reinterpret_cast<unsigned char*>(s_grid + mp.grid.G * mp.grid.G);   // [NA * num_used]
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -136,6 +187,8 @@ __global__ __launch_bounds__(kPipeBlock, 3) void k_run_mimo_ofdm_mfma(MimoParams
     const double rx_scale = sqrt((double)(U + cp)) / (double)N;
     const uint32_t mask = (uint32_t)(mp.M - 1);
     const uint32_t mask4 = mask * 0x01010101u;
+    const bool slicer = mp.method == MCLE_DEMOD_QAM_SLICER;   // s_idx then holds LEVEL bytes instead of labels
+    const QamPack qp = qam_pack(mp);
 
     for (int m = tid; m < mp.M; m += kPipeBlock) {
         const float2 c = mp.g_table[m];
@@ -173,18 +226,25 @@ __global__ __launch_bounds__(kPipeBlock, 3) void k_run_mimo_ofdm_mfma(MimoParams
     const int p2_ld = p2_base ^ (4 * gb);                                     // element 2t+gb: p2_ld ^ (8 t)
     const int p2_st = p2_base ^ (16 * g);                                     // output 4g+x : p2_st ^ (4 x)
     const int mid_off = 64 * k1m + ((4 * j1m) ^ f16_swz(k1m));                // 4 consecutive positions of the butterfly
+    // symbol scatter, full band: lane (row e = lane >> 2, run = lane & 3) of wave w fills bins 64 e + 16 w + 4 run + (0..3)
+    // of every antenna -- the wave's OWN 16 columns, so scatter -> P1 and P1' -> next scatter stay inside the wavefront
+    const int sc_bin = 64 * (lane >> 2) + 16 * w + 4 * (lane & 3);
+    const int sc_off = f16_pos(sc_bin);
+    const int sc_blk = ((sc_bin + N / 2) & (N - 1)) >> 2;                     // Philox DATA block of those 4 subcarriers
 
-    constexpr int kRec = 2 * NA * NA + 1;
     float2* my_filters = g_filters + (size_t)blockIdx.x * 64 * kRec;
     // noise samples pair up in Philox blocks by even / odd sample index; lanes l, l^1 share blocks when the
     // realization's sample indices keep the parity of the time index
     const bool pair_ok = ((row & 1) == 0) && (((N + cp) & 1) == 0) && ((cp & 1) == 0);
-    uint64_t it = 0;
+    const bool full_band = (U == N);
+    constexpr bool kEarlyNoise = (FLAGS & 1) != 0;
+    uint64_t it = 0, rl_prev = 0;
+    __syncthreads();
     for (uint64_t rl = blockIdx.x; rl < count; rl += gridDim.x, ++it) {
         const Rng rng(seed, first + rl);
-        const int slot = (int)(it & 63);
-        __syncthreads();
+        const int slot = (int)(it & 63), buf = (int)(it & 1);
         if (slot == 0) {   // channel draw + f64 receive filter for this workgroup's next 64 realizations, one per lane
+            __syncthreads();
             const uint64_t rj = rl + (uint64_t)tid * gridDim.x;
             if (tid < 64 && rj < count) {
                 const Rng rngj(seed, first + rj);
@@ -209,21 +269,22 @@ __global__ __launch_bounds__(kPipeBlock, 3) void k_run_mimo_ofdm_mfma(MimoParams
             __threadfence_block();
             __syncthreads();
         }
-        if (tid < kRec) {
-            const float2 v = my_filters[slot * kRec + tid];
-            if (tid < 2 * NA * NA) s_H[tid] = v;          // s_G follows s_H
-            else s_red[15] = v.x != 0.f ? 1u : 0u;
-        }
+        // this realization's record -> s_rec[buf] (read after the next workgroup barrier; its previous reader,
+        // realization it - 2, is two barriers behind)
+        if (tid < kRec) s_rec[buf * (kRec + 1) + tid] = my_filters[slot * kRec + tid];
+        const float2* s_H = s_rec + buf * (kRec + 1);
+        const float2* s_G = s_H + NA * NA;
         unsigned se = 0, be = 0;
         for (int os = 0; os < pp.n_ofdm_sym; ++os) {
-            __syncthreads();   // previous symbol's P1' reads done; H / G staged
             // ---- symbols -> bins, stored re<->im swapped (inverse transform by the swap identity) ----
             const uint64_t n_first = (uint64_t)os * per_sym;
-            if (U == N) {      // one Philox block per thread: 4 consecutive bins x 4 antennas
-                const Words4 dw = rng.block(STREAM_DATA, (uint32_t)(n_first >> 4) + tid);
-                uint4 idx4 = make_uint4(dw.w[0] & mask4, dw.w[1] & mask4, dw.w[2] & mask4, dw.w[3] & mask4);
-                *reinterpret_cast<uint4*>(s_idx + 16 * tid) = idx4;
-                const int off = f16_pos((4 * tid + N / 2) & (N - 1));
+            if (full_band) {   // one Philox block per lane: 4 consecutive bins x 4 antennas, this wave's columns
+                const Words4 dw = rng.block(STREAM_DATA, (uint32_t)(n_first >> 4) + sc_blk);
+                const uint4 idx4 = make_uint4(dw.w[0] & mask4, dw.w[1] & mask4, dw.w[2] & mask4, dw.w[3] & mask4);
+                *reinterpret_cast<uint4*>(s_idx + 16 * sc_blk) =
+                    slicer ? make_uint4(labels_to_levels(idx4.x, qp), labels_to_levels(idx4.y, qp),
+                                        labels_to_levels(idx4.z, qp), labels_to_levels(idx4.w, qp))
+                           : idx4;
                 const uint32_t wv[4] = {idx4.x, idx4.y, idx4.z, idx4.w};
                 float2 sym[4][NA];
 #pragma unroll
@@ -232,12 +293,14 @@ __global__ __launch_bounds__(kPipeBlock, 3) void k_run_mimo_ofdm_mfma(MimoParams
                     for (int a = 0; a < NA; ++a) sym[c][a] = s_txtab[(wv[c] >> (8 * a)) & 0xFFu];
 #pragma unroll
                 for (int a = 0; a < NA; ++a) {
-                    f4 vr = {sym[0][a].y, sym[1][a].y, sym[2][a].y, sym[3][a].y};
-                    f4 vi = {sym[0][a].x, sym[1][a].x, sym[2][a].x, sym[3][a].x};
-                    *reinterpret_cast<f4*>(s_d + a * kF16Ant + off) = vr;
-                    *reinterpret_cast<f4*>(s_d + a * kF16Ant + kF16Plane + off) = vi;
+                    const f4 vr = {sym[0][a].y, sym[1][a].y, sym[2][a].y, sym[3][a].y};
+                    const f4 vi = {sym[0][a].x, sym[1][a].x, sym[2][a].x, sym[3][a].x};
+                    *reinterpret_cast<f4*>(s_d + a * kF16Ant + sc_off) = vr;
+                    *reinterpret_cast<f4*>(s_d + a * kF16Ant + kF16Plane + sc_off) = vi;
                 }
-            } else {
+                wave_lds_sync();
+            } else {           // partial band: zero fill + scatter in block order across the workgroup
+                __syncthreads();
                 for (int p = tid; p < NA * kF16Ant; p += kPipeBlock) s_d[p] = 0.f;
                 __syncthreads();
                 const uint64_t n_last = n_first + per_sym;
@@ -250,7 +313,7 @@ __global__ __launch_bounds__(kPipeBlock, 3) void k_run_mimo_ofdm_mfma(MimoParams
                             const int tx = (int)((dw.w[jj >> 2] >> ((jj & 3) * 8)) & mask);
                             const int nl = (int)(n - n_first);
                             const int a = nl & 3, d = nl >> 2;
-                            s_idx[nl] = (unsigned char)tx;
+                            s_idx[nl] = (unsigned char)(slicer ? labels_to_levels((uint32_t)tx, qp) : (uint32_t)tx);
                             const float2 c = s_txtab[tx];
                             const int off = a * kF16Ant + f16_pos(ofdm_bin(d, N, U));
                             s_d[off] = c.y;
@@ -258,8 +321,25 @@ __global__ __launch_bounds__(kPipeBlock, 3) void k_run_mimo_ofdm_mfma(MimoParams
                         }
                     }
                 }
+                __syncthreads();
             }
-            __syncthreads();
+            // noise of the middle stage: sample index of (r, c) = r*row + os*(N+cp) + cp + m, m = k1 + 16 j1 + 256 c.
+            // Drawn here, one Philox block per antenna iteration of P1 / P2, where the VALU is otherwise idle under
+            // the MFMAs; lanes l, l^1 share each block (even / odd sample) and trade the halves by DPP.
+            f4 yre[4], yim[4];               // [slot] over r; slot s holds c = s ^ 2 par
+            const uint64_t i_base = (uint64_t)os * (N + cp) + cp + (uint64_t)(k1m + 16 * j1m);
+            auto noise_block = [&](int r, int cc) {
+                const uint64_t i = (uint64_t)r * row + i_base + 256u * (2 * par + cc);
+                const Words4 b = rng.block(STREAM_NOISE, (uint32_t)(i >> 1));
+                const uint32_t k0 = par ? b.w[2] : b.w[0], k1 = par ? b.w[3] : b.w[1];
+                const uint32_t g0 = par ? b.w[0] : b.w[2], g1 = par ? b.w[1] : b.w[3];
+                const float2 keep = cn_from_words(k0, k1, sigma);
+                const float2 give = cn_from_words(g0, g1, sigma);
+                yre[cc][r] = keep.x;
+                yim[cc][r] = keep.y;
+                yre[2 + cc][r] = dpp_swap1(give.x);
+                yim[2 + cc][r] = dpp_swap1(give.y);
+            };
             // ---- P1: DFT-16 over n1, x W1024^{k1 n2} ----
 #pragma unroll
             for (int a = 0; a < NA; ++a) {
@@ -270,15 +350,21 @@ __global__ __launch_bounds__(kPipeBlock, 3) void k_run_mimo_ofdm_mfma(MimoParams
                 for (int t = 0; t < 8; ++t) b[t] = pl[(p1_ld ^ (((2 * t) & 7) << 2)) + 128 * t];
                 float2 o[4];
                 dft16_mfma(mats, b, o);
+                if (kEarlyNoise && pair_ok) noise_block(a, 0);
 #pragma unroll
                 for (int x = 0; x < 4; ++x) {
-                    const float2 v = cmul(o[x], tw1a[x]);
+                    const float2 v = cmul_pk(o[x], tw1a[x]);
                     const int off = (p1_st ^ ((x << 2) ^ ((x & 1) << 5))) + 64 * x;
                     pa[off] = v.x;
                     pa[off + kF16Plane] = v.y;
                 }
             }
             __syncthreads();
+            if (tid == 0 && os == 0 && it > 0) {   // every wave is past the previous realization: account it
+                const unsigned* q = s_part + (buf ^ 1) * 8;
+                wg_account(totals, q[0] + q[2] + q[4] + q[6], q[1] + q[3] + q[5] + q[7],
+                           s_rec[(buf ^ 1) * (kRec + 1) + 2 * NA * NA].x != 0.f, rl_prev, sym_out, bit_out);
+            }
             // ---- P2: DFT-16 over m1, x W64^{j1 m2} ----
 #pragma unroll
             for (int a = 0; a < NA; ++a) {
@@ -289,9 +375,10 @@ __global__ __launch_bounds__(kPipeBlock, 3) void k_run_mimo_ofdm_mfma(MimoParams
                 for (int t = 0; t < 8; ++t) b[t] = pl[p2_ld ^ (8 * t)];
                 float2 o[4];
                 dft16_mfma(mats, b, o);
+                if (kEarlyNoise && pair_ok) noise_block(a, 1);
 #pragma unroll
                 for (int x = 0; x < 4; ++x) {
-                    const float2 v = cmul(o[x], tw2a[x]);
+                    const float2 v = cmul_pk(o[x], tw2a[x]);
                     pa[p2_st ^ (4 * x)] = v.x;
                     pa[(p2_st ^ (4 * x)) + kF16Plane] = v.y;
                 }
@@ -313,28 +400,14 @@ __global__ __launch_bounds__(kPipeBlock, 3) void k_run_mimo_ofdm_mfma(MimoParams
                     xi[2][a] = t0r - t2r; xr[2][a] = t0i - t2i;
                     xi[3][a] = t1r - t3r; xr[3][a] = t1i - t3i;
                 }
-                // noise: sample index of (r, c) = r*row + os*(N+cp) + cp + m, m = k1 + 16 j1 + 256 c
-                f4 yre[4], yim[4];               // [slot] over r
-                const uint64_t i_base = (uint64_t)os * (N + cp) + cp + (uint64_t)(k1m + 16 * j1m);
-                if (pair_ok) {
+                if (!kEarlyNoise && pair_ok) {
 #pragma unroll
-                    for (int cc = 0; cc < 2; ++cc) {
-                        const int c = 2 * par + cc;
-#pragma unroll
-                        for (int r = 0; r < NA; ++r) {
-                            const uint64_t i = (uint64_t)r * row + i_base + 256u * c;
-                            const Words4 b = rng.block(STREAM_NOISE, (uint32_t)(i >> 1));
-                            const uint32_t k0 = par ? b.w[2] : b.w[0], k1 = par ? b.w[3] : b.w[1];
-                            const uint32_t g0 = par ? b.w[0] : b.w[2], g1 = par ? b.w[1] : b.w[3];
-                            const float2 keep = cn_from_words(k0, k1, sigma);
-                            const float2 give = cn_from_words(g0, g1, sigma);
-                            yre[cc][r] = keep.x;
-                            yim[cc][r] = keep.y;
-                            yre[2 + cc][r] = dpp_swap1(give.x);
-                            yim[2 + cc][r] = dpp_swap1(give.y);
-                        }
+                    for (int r = 0; r < NA; ++r) {
+                        noise_block(r, 0);
+                        noise_block(r, 1);
                     }
-                } else {
+                }
+                if (!pair_ok) {
 #pragma unroll
                     for (int s = 0; s < 4; ++s) {
                         const int c = s ^ (2 * par);
@@ -372,9 +445,9 @@ __global__ __launch_bounds__(kPipeBlock, 3) void k_run_mimo_ofdm_mfma(MimoParams
                     const float t1r = yre[0][r] - yre[2][r], t1i = yim[0][r] - yim[2][r];
                     const float t2r = yre[1][r] + yre[3][r], t2i = yim[1][r] + yim[3][r];
                     const float t3r = yim[1][r] - yim[3][r], t3i = yre[3][r] - yre[1][r];
-                    const float2 v1 = cmul(make_float2(t1r + t3r, t1i + t3i), tw2b[0]);
-                    const float2 v2 = cmul(make_float2(t0r - t2r, t0i - t2i), tw2b[1]);
-                    const float2 v3 = cmul(make_float2(t1r - t3r, t1i - t3i), tw2b[2]);
+                    const float2 v1 = cmul_pk(make_float2(t1r + t3r, t1i + t3i), tw2b[0]);
+                    const float2 v2 = cmul_pk(make_float2(t0r - t2r, t0i - t2i), tw2b[1]);
+                    const float2 v3 = cmul_pk(make_float2(t1r - t3r, t1i - t3i), tw2b[2]);
                     const f4 vr = {t0r + t2r, v1.x, v2.x, v3.x};
                     const f4 vi = {t0i + t2i, v1.y, v2.y, v3.y};
                     *reinterpret_cast<f4*>(s_d + r * kF16Ant + mid_off) = vr;
@@ -394,7 +467,7 @@ __global__ __launch_bounds__(kPipeBlock, 3) void k_run_mimo_ofdm_mfma(MimoParams
                 dft16_mfma(mats, b, o);
 #pragma unroll
                 for (int x = 0; x < 4; ++x) {
-                    const float2 v = cmul(o[x], tw1b[x]);
+                    const float2 v = cmul_pk(o[x], tw1b[x]);
                     pa[p2_st ^ (4 * x)] = v.x;
                     pa[(p2_st ^ (4 * x)) + kF16Plane] = v.y;
                 }
@@ -437,37 +510,50 @@ __global__ __launch_bounds__(kPipeBlock, 3) void k_run_mimo_ofdm_mfma(MimoParams
                     }
                     const int d = ofdm_data_index(64 * (4 * g + x) + n2, N, U);
                     if (d >= 0) {
-                        float2 est[NA];
-                        int dec[NA];
-#pragma unroll
-                        for (int a = 0; a < NA; ++a) est[a] = make_float2(er[a], ei[a]);
-                        if (mp.method == MCLE_DEMOD_QAM_SLICER) {
-#pragma unroll
-                            for (int a = 0; a < NA; ++a)
-                                dec[a] = demod_qam_slicer<float>(est[a], mp.qam_scale, mp.qam_L, mp.half_bits);
-                        } else if (mp.grid.G > 0) {
-#pragma unroll
-                            for (int a = 0; a < NA; ++a) dec[a] = demod_grid4(s_tab4, s_grid, mp.grid, mp.M, est[a]);
-                        } else {
-                            demod_mindist_multi<NA>(s_tab4, mp.M, est, dec);
-                        }
                         const uint32_t sent = *reinterpret_cast<const uint32_t*>(s_idx + 4 * d);
+                        if (slicer) {
+                            qam_count4(qam_levels4(er, ei, qp) ^ sent, qp, se, be);
+                        } else {
+                            float2 est[NA];
+                            int dec[NA];
 #pragma unroll
-                        for (int a = 0; a < NA; ++a) {
-                            const unsigned xo = ((sent >> (8 * a)) & 0xFFu) ^ (unsigned)dec[a];
-                            se += (xo != 0u);
-                            be += __popc(xo);
+                            for (int a = 0; a < NA; ++a) est[a] = make_float2(er[a], ei[a]);
+                            if (mp.grid.G > 0) {
+#pragma unroll
+                                for (int a = 0; a < NA; ++a) dec[a] = demod_grid4(s_tab4, s_grid, mp.grid, mp.M, est[a]);
+                            } else {
+                                demod_mindist_multi<NA>(s_tab4, mp.M, est, dec);
+                            }
+#pragma unroll
+                            for (int a = 0; a < NA; ++a) {
+                                const unsigned xo = ((sent >> (8 * a)) & 0xFFu) ^ (unsigned)dec[a];
+                                se += (xo != 0u);
+                                be += __popc(xo);
+                            }
                         }
                     }
                 }
             }
         }
-        block_sum2(se, be, s_red);
-        if (tid == 0) wg_account(totals, se, be, s_red[15] != 0u, rl, sym_out, bit_out);
+        se = wave_sum_u32(se);
+        be = wave_sum_u32(be);
+        if (lane == 0) {
+            s_part[buf * 8 + 2 * w] = se;
+            s_part[buf * 8 + 2 * w + 1] = be;
+        }
+        rl_prev = rl;
     }
-    if (tid == 0)
+    __syncthreads();
+    if (tid == 0) {
+        if (it > 0) {
+            const int buf = (int)((it - 1) & 1);
+            const unsigned* q = s_part + buf * 8;
+            wg_account(totals, q[0] + q[2] + q[4] + q[6], q[1] + q[3] + q[5] + q[7],
+                       s_rec[buf * (kRec + 1) + 2 * NA * NA].x != 0.f, rl_prev, sym_out, bit_out);
+        }
         wg_flush(totals, counters, (unsigned long long)per_sym * pp.n_ofdm_sym,
                  (unsigned long long)per_sym * pp.n_ofdm_sym * mp.bits);
+    }
 }
 
 // host side: 0 = launched, MCLE_E_UNSUPPORTED = outside this kernel's envelope (caller uses k_run_mimo_ofdm)
@@ -480,14 +566,18 @@ int run_mimo_ofdm_mfma(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, uint64_t se
     if ((rc = ctx->get_twiddles(kF16N, MCLE_F32, &tw))) return rc;
     MimoParams pp{cfg->cp_size, cfg->num_used, cfg->n_ofdm_sym, cfg->mmse, cfg->noise_var};
     const ModemParams<float> mp = pipe_modem<float>(ctx, cfg->demod_method);
-    const size_t lds = (size_t)4 * kF16Ant * sizeof(float) + (size_t)(kMaxTable + 2 * 16) * sizeof(float2) +
+    const size_t lds = (size_t)4 * kF16Ant * sizeof(float) + (size_t)(kMaxTable + 2 * 34) * sizeof(float2) +
                        kMaxTable * sizeof(float4) + 16 * sizeof(unsigned) +
                        (size_t)mp.grid.G * mp.grid.G * sizeof(unsigned long long) + (size_t)4 * cfg->num_used + 16;
-    auto kern = k_run_mimo_ofdm_mfma;
+    int variant = 31;
+    if (const char* v = std::getenv("MCLE_MFMA_VARIANT")) variant = std::atoi(v);
+    const int waves = variant / 10;
+    auto kern = variant == 30 ? k_run_mimo_ofdm_mfma<3, 0> : variant == 20 ? k_run_mimo_ofdm_mfma<2, 0>
+              : variant == 21 ? k_run_mimo_ofdm_mfma<2, 1> : k_run_mimo_ofdm_mfma<3, 1>;
     MCLE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int per_cu = (int)((size_t)160 * 1024 / (lds + 512));
     if (per_cu < 1) per_cu = 1;
-    if (per_cu > 3) per_cu = 3;             // __launch_bounds__(256, 3)
+    if (per_cu > waves) per_cu = waves;     // __launch_bounds__(256, WAVES)
     const uint64_t cap = (uint64_t)ctx->n_cu * per_cu;
     const unsigned grid = (unsigned)(count < cap ? count : cap);
     void* filters = nullptr;

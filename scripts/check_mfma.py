@@ -52,9 +52,16 @@ print("oracle ", want.tolist())
 print("mfma   ", se_new.tolist())
 print("valu   ", se_old.tolist())
 # timing
-for name, mfma, method in (("valu_slicer", False, _lib.DEMOD_QAM_SLICER), ("mfma_slicer", True, _lib.DEMOD_QAM_SLICER),
-                           ("valu_mindist", False, _lib.DEMOD_MINDIST), ("mfma_mindist", True, _lib.DEMOD_MINDIST)):
+VARIANTS = [v for v in os.environ.get("MFMA_VARIANTS", "").split(",") if v]
+cases = [("valu_slicer", False, _lib.DEMOD_QAM_SLICER, None), ("mfma_slicer", True, _lib.DEMOD_QAM_SLICER, None),
+         ("valu_mindist", False, _lib.DEMOD_MINDIST, None), ("mfma_mindist", True, _lib.DEMOD_MINDIST, None)]
+cases += [("mfma_slicer_v" + v, True, _lib.DEMOD_QAM_SLICER, v) for v in VARIANTS]
+for name, mfma, method, variant in cases:
     cnt = eng.new_counters()
+    if variant:
+        os.environ["MCLE_MFMA_VARIANT"] = variant
+    else:
+        os.environ.pop("MCLE_MFMA_VARIANT", None)
     if mfma:
         os.environ.pop("MCLE_NO_MFMA", None)
     else:
