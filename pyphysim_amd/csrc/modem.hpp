@@ -149,6 +149,53 @@ __device__ __forceinline__ int demod_grid4(const float4* __restrict__ s_tab4, co
     }
     return idx;
 }
+// K symbols through the candidate grid in lockstep: the K cell words are fetched together, then up to four candidates
+// per symbol are evaluated as K independent LDS round trips per step (a symbol with fewer candidates re-evaluates its
+// current best, which the strict '<' ignores).  Cells with more than four candidates, or the 0xFF "sweep
+// everything" marker, take demod_grid4's loop.  Same decisions as demod_grid4 / demod_mindist_multi.
+template <int K>
+__device__ __forceinline__ void demod_grid4_multi(const float4* __restrict__ s_tab4,
+                                                  const unsigned long long* __restrict__ s_grid, const DemodGrid& g, int M,
+                                                  const float2 (&r)[K], int (&idx)[K]) {
+    unsigned long long w[K];
+    int n[K];
+    float best[K];
+    bool slow = false;
+#pragma unroll
+    for (int k = 0; k < K; ++k) w[k] = grid_cell(s_grid, g, r[k].x, r[k].y);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        n[k] = (int)(w[k] & 0xFFull);
+        slow = slow || n[k] > 4;
+        idx[k] = (int)((w[k] >> 8) & 0xFFull);
+        const float4 c = s_tab4[idx[k]];
+        best[k] = fmaf(-r[k].y, c.y, fmaf(-r[k].x, c.x, c.z));
+    }
+#pragma unroll
+    for (int j = 1; j < 4; ++j) {
+        int m[K];
+        float4 c[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            m[k] = j < n[k] ? (int)((w[k] >> (8 * (j + 1))) & 0xFFull) : idx[k];
+            c[k] = s_tab4[m[k]];
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const float d = fmaf(-r[k].y, c[k].y, fmaf(-r[k].x, c[k].x, c[k].z));
+            if (d < best[k]) {
+                best[k] = d;
+                idx[k] = m[k];
+            }
+        }
+    }
+    if (slow) {
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+            if (n[k] > 4) idx[k] = demod_grid4(s_tab4, s_grid, g, M, r[k]);
+    }
+}
+
 template <typename T>
 __device__ __forceinline__ void load_grid(const ModemParams<T>& mp, unsigned long long* s_grid) {
     const int cells = mp.grid.G * mp.grid.G;

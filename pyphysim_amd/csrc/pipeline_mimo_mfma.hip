@@ -142,6 +142,42 @@ __device__ __forceinline__ void qam_count4(uint32_t x, const QamPack& q, unsigne
     be += __popc(y);
 }
 
+
+// The four antennas of one DFT-16 pass: all operand loads first (the pass is in place per wavefront, so nothing it
+// stores is read again inside it), the 32 MFMAs as 8 independent accumulator chains, then twiddle and store.
+template <typename LoadOff, typename StoreOff, typename Fill>
+__device__ __forceinline__ void dft16_pass4(float* s_d, int plane_g, const Dft16Mats& m, const float2 (&tw)[4],
+                                            LoadOff ld, StoreOff st, Fill fill) {
+    float b[4][8];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int t = 0; t < 8; ++t) b[a][t] = s_d[a * kF16Ant + plane_g + ld(t)];
+    f4 ce[4], co[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) ce[a] = co[a] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            ce[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(m.ae[t], b[a][t] + b[a][t + 4], ce[a], 0, 0, 0);
+            co[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(m.ao[t], b[a][t] - b[a][t + 4], co[a], 0, 0, 0);
+        }
+    fill();
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const float2 o[4] = {make_float2(ce[a][0], ce[a][1]), make_float2(co[a][0], co[a][1]),
+                             make_float2(ce[a][2], ce[a][3]), make_float2(co[a][2], co[a][3])};
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            const float2 v = cmul_pk(o[x], tw[x]);
+            const int off = a * kF16Ant + st(x);
+            s_d[off] = v.x;
+            s_d[off + kF16Plane] = v.y;
+        }
+    }
+}
+
 // inverse of ofdm_bin (fft.hpp): data index carried by FFT bin `bin`, or -1
 __device__ __forceinline__ int ofdm_data_index(int bin, int n, int num_used) {
     if (num_used == n) return (bin + n / 2) & (n - 1);
@@ -341,6 +377,17 @@ __global__ __launch_bounds__(kPipeBlock, WAVES) void k_run_mimo_ofdm_mfma(MimoPa
                 yim[2 + cc][r] = dpp_swap1(give.y);
             };
             // ---- P1: DFT-16 over n1, x W1024^{k1 n2} ----
+            if constexpr ((FLAGS & 2) != 0) {
+                dft16_pass4(s_d, plane_g, mats, tw1a,
+                            [&](int t) { return (p1_ld ^ (((2 * t) & 7) << 2)) + 128 * t; },
+                            [&](int x) { return (p1_st ^ ((x << 2) ^ ((x & 1) << 5))) + 64 * x; },
+                            [&]() {
+                                if (kEarlyNoise && pair_ok) {
+#pragma unroll
+                                    for (int r = 0; r < NA; ++r) noise_block(r, 0);
+                                }
+                            });
+            } else {
 #pragma unroll
             for (int a = 0; a < NA; ++a) {
                 float* pa = s_d + a * kF16Ant;
@@ -359,6 +406,7 @@ __global__ __launch_bounds__(kPipeBlock, WAVES) void k_run_mimo_ofdm_mfma(MimoPa
                     pa[off + kF16Plane] = v.y;
                 }
             }
+            }
             __syncthreads();
             if (tid == 0 && os == 0 && it > 0) {   // every wave is past the previous realization: account it
                 const unsigned* q = s_part + (buf ^ 1) * 8;
@@ -366,6 +414,16 @@ __global__ __launch_bounds__(kPipeBlock, WAVES) void k_run_mimo_ofdm_mfma(MimoPa
                            s_rec[(buf ^ 1) * (kRec + 1) + 2 * NA * NA].x != 0.f, rl_prev, sym_out, bit_out);
             }
             // ---- P2: DFT-16 over m1, x W64^{j1 m2} ----
+            if constexpr ((FLAGS & 2) != 0) {
+                dft16_pass4(s_d, plane_g, mats, tw2a, [&](int t) { return p2_ld ^ (8 * t); },
+                            [&](int x) { return p2_st ^ (4 * x); },
+                            [&]() {
+                                if (kEarlyNoise && pair_ok) {
+#pragma unroll
+                                    for (int r = 0; r < NA; ++r) noise_block(r, 1);
+                                }
+                            });
+            } else {
 #pragma unroll
             for (int a = 0; a < NA; ++a) {
                 float* pa = s_d + a * kF16Ant;
@@ -382,6 +440,7 @@ __global__ __launch_bounds__(kPipeBlock, WAVES) void k_run_mimo_ofdm_mfma(MimoPa
                     pa[p2_st ^ (4 * x)] = v.x;
                     pa[(p2_st ^ (4 * x)) + kF16Plane] = v.y;
                 }
+            }
             }
             wave_lds_sync();
             // ---- middle stage: P3 (DFT-4) -> channel R = H T + noise -> P3' (DFT-4 x W64) ----
@@ -456,6 +515,10 @@ __global__ __launch_bounds__(kPipeBlock, WAVES) void k_run_mimo_ofdm_mfma(MimoPa
             }
             wave_lds_sync();
             // ---- P2': DFT-16 over j1, x W1024^{(4 m1 + m2) k1} ----
+            if constexpr ((FLAGS & 2) != 0) {
+                dft16_pass4(s_d, plane_g, mats, tw1b, [&](int t) { return p2_ld ^ (8 * t); },
+                            [&](int x) { return p2_st ^ (4 * x); }, [&]() {});
+            } else {
 #pragma unroll
             for (int a = 0; a < NA; ++a) {
                 float* pa = s_d + a * kF16Ant;
@@ -471,6 +534,7 @@ __global__ __launch_bounds__(kPipeBlock, WAVES) void k_run_mimo_ofdm_mfma(MimoPa
                     pa[p2_st ^ (4 * x)] = v.x;
                     pa[(p2_st ^ (4 * x)) + kF16Plane] = v.y;
                 }
+            }
             }
             __syncthreads();
             // ---- P1': DFT-16 over k1 -> bins 64 n1 + n2 (n1 = 4g + x), then Blast decode, demodulate, count ----
@@ -519,8 +583,7 @@ __global__ __launch_bounds__(kPipeBlock, WAVES) void k_run_mimo_ofdm_mfma(MimoPa
 #pragma unroll
                             for (int a = 0; a < NA; ++a) est[a] = make_float2(er[a], ei[a]);
                             if (mp.grid.G > 0) {
-#pragma unroll
-                                for (int a = 0; a < NA; ++a) dec[a] = demod_grid4(s_tab4, s_grid, mp.grid, mp.M, est[a]);
+                                demod_grid4_multi<NA>(s_tab4, s_grid, mp.grid, mp.M, est, dec);
                             } else {
                                 demod_mindist_multi<NA>(s_tab4, mp.M, est, dec);
                             }
@@ -569,11 +632,14 @@ int run_mimo_ofdm_mfma(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, uint64_t se
     const size_t lds = (size_t)4 * kF16Ant * sizeof(float) + (size_t)(kMaxTable + 2 * 34) * sizeof(float2) +
                        kMaxTable * sizeof(float4) + 16 * sizeof(unsigned) +
                        (size_t)mp.grid.G * mp.grid.G * sizeof(unsigned long long) + (size_t)4 * cfg->num_used + 16;
-    int variant = 31;
+    // variants kept for A/B runs (MCLE_MFMA_VARIANT = 10 * waves + flags): 32 = 3 waves per SIMD, noise drawn in the
+    // middle stage, operand loads of the four antennas first (default; fastest with either demodulator);
+    // 30 = antenna-by-antenna passes; 21 = 2 waves per SIMD (256 VGPRs, no spills) with the noise under P1 / P2
+    int variant = 32;
     if (const char* v = std::getenv("MCLE_MFMA_VARIANT")) variant = std::atoi(v);
-    const int waves = variant / 10;
-    auto kern = variant == 30 ? k_run_mimo_ofdm_mfma<3, 0> : variant == 20 ? k_run_mimo_ofdm_mfma<2, 0>
-              : variant == 21 ? k_run_mimo_ofdm_mfma<2, 1> : k_run_mimo_ofdm_mfma<3, 1>;
+    const int waves = variant / 10 == 2 ? 2 : 3;
+    auto kern = variant == 30 ? k_run_mimo_ofdm_mfma<3, 0> : variant == 21 ? k_run_mimo_ofdm_mfma<2, 1>
+                                                             : k_run_mimo_ofdm_mfma<3, 2>;
     MCLE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int per_cu = (int)((size_t)160 * 1024 / (lds + 512));
     if (per_cu < 1) per_cu = 1;

@@ -56,6 +56,7 @@ VARIANTS = [v for v in os.environ.get("MFMA_VARIANTS", "").split(",") if v]
 cases = [("valu_slicer", False, _lib.DEMOD_QAM_SLICER, None), ("mfma_slicer", True, _lib.DEMOD_QAM_SLICER, None),
          ("valu_mindist", False, _lib.DEMOD_MINDIST, None), ("mfma_mindist", True, _lib.DEMOD_MINDIST, None)]
 cases += [("mfma_slicer_v" + v, True, _lib.DEMOD_QAM_SLICER, v) for v in VARIANTS]
+cases += [("mfma_mindist_v" + v, True, _lib.DEMOD_MINDIST, v) for v in VARIANTS]
 for name, mfma, method, variant in cases:
     cnt = eng.new_counters()
     if variant:

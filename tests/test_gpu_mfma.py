@@ -1,0 +1,96 @@
+"""GPU: the matrix-core config-4 kernel (csrc/pipeline_mimo_mfma.hip: f32, FFT 1024, 4x4) against the oracle chain under
+the same Philox keying and against the VALU kernel it replaces (MCLE_NO_MFMA=1 selects that one at launch time).
+
+The MFMA kernel evaluates the same link with a different (equally f32) association of the sums, so per-realization
+counts may differ from the VALU kernel's by a rounding-level tie now and then, never systematically; against the f64
+oracle both sit inside the same |dSER| <= 1e-4 band."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import chains, modem as omodem
+from pyphysim_amd import _lib
+
+pytestmark = pytest.mark.gpu
+SEED = 424242
+
+
+def _run(engine, first, count, mfma=True, variant=None, **kw):
+    old = {k: os.environ.get(k) for k in ("MCLE_NO_MFMA", "MCLE_MFMA_VARIANT")}
+    try:
+        os.environ.pop("MCLE_NO_MFMA", None)
+        os.environ.pop("MCLE_MFMA_VARIANT", None)
+        if not mfma:
+            os.environ["MCLE_NO_MFMA"] = "1"
+        if variant:
+            os.environ["MCLE_MFMA_VARIANT"] = str(variant)
+        nv = 1.0 / omodem.dB2Linear(kw.get("snr_db", 25.0))
+        return engine.run_mimo_ofdm(4, 4, 1024, kw.get("cp_size", 16), kw.get("num_used") or 1024,
+                                    kw.get("n_ofdm_sym", 1), nv, SEED, first, count, mmse=kw.get("mmse", True),
+                                    method=kw.get("method", _lib.DEMOD_QAM_SLICER), dtype="f32", per_realization=True)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+CASES = [dict(M=64, snr_db=25.0),
+         dict(M=64, snr_db=25.0, num_used=600, n_ofdm_sym=2),          # partial band, two OFDM symbols
+         dict(M=16, snr_db=18.0, cp_size=7, mmse=False),               # odd CP: unpaired noise draws; zero forcing
+         dict(M=256, snr_db=32.0, cp_size=0),
+         dict(M=4, snr_db=8.0, num_used=1022)]
+
+
+@pytest.mark.parametrize("case", range(len(CASES)))
+@pytest.mark.parametrize("variant", [32, 30, 21])
+def test_mfma_kernel_against_the_oracle_and_the_valu_kernel(engine, case, variant):
+    kw = dict(CASES[case])
+    M = kw.pop("M")
+    engine.set_constellation(chains.constellation("qam", M), _lib.CONST_QAM)
+    first, count = 31337, 24
+    okw = dict(mod="qam", M=M, nt=4, nr=4, fft_size=1024, cp_size=kw.get("cp_size", 16), num_used=kw.get("num_used"),
+               n_ofdm_sym=kw.get("n_ofdm_sym", 1), snr_db=kw["snr_db"], mmse=kw.get("mmse", True))
+    want = [chains.chain_mimo_ofdm(chains.PhiloxRng(SEED, r), **okw) for r in range(first, first + count)]
+    want_se = np.array([w["symbol_errors"] for w in want], dtype=np.int64)
+    want_be = np.array([w["bit_errors"] for w in want], dtype=np.int64)
+    nsym, nbits = want[0]["num_symbols"], want[0]["num_bits"]
+    res, se, be = _run(engine, first, count, variant=variant, **kw)
+    assert res["n_symbols"] == nsym and res["n_bits"] == nbits and res["n_realizations"] + res["n_skipped"] == count
+    ok = se != 0xFFFFFFFF
+    assert abs(int(se[ok].sum()) - int(want_se[ok].sum())) <= 1e-4 * count * nsym + 2
+    assert abs(int(be[ok].sum()) - int(want_be[ok].sum())) <= 1e-4 * count * nbits + 2
+    assert np.max(np.abs(se[ok].astype(np.int64) - want_se[ok])) <= 3          # boundary ties only
+    res_v, se_v, be_v = _run(engine, first, count, mfma=False, **kw)
+    assert np.array_equal(se == 0xFFFFFFFF, se_v == 0xFFFFFFFF)
+    assert np.max(np.abs(se[ok].astype(np.int64) - se_v[ok].astype(np.int64))) <= 3
+    assert res["sym_errors_sq"] == int((se[ok].astype(np.int64) ** 2).sum())
+    assert res["bit_errors"] == int(be[ok].astype(np.int64).sum())
+
+
+def test_mfma_kernel_min_distance_equals_slicer_and_is_split_invariant(engine):
+    engine.set_constellation(chains.constellation("qam", 64), _lib.CONST_QAM)
+    first, count = 1 << 33, 700            # more realizations than one workgroup's 64-record filter batch
+    res_s, se_s, be_s = _run(engine, first, count)
+    res_m, se_m, be_m = _run(engine, first, count, method=_lib.DEMOD_MINDIST)
+    assert np.max(np.abs(se_s.astype(np.int64) - se_m.astype(np.int64))) <= 2
+    assert abs(int(se_s.astype(np.int64).sum()) - int(se_m.astype(np.int64).sum())) <= 1e-5 * count * 4096 + 2
+    # bit-identical from run to run and under any split of the realization range
+    res_2, se_2, be_2 = _run(engine, first, count)
+    assert np.array_equal(se_s, se_2) and np.array_equal(be_s, be_2)
+    a = _run(engine, first, 123)
+    b = _run(engine, first + 123, count - 123)
+    assert np.array_equal(np.concatenate([a[1], b[1]]), se_s) and np.array_equal(np.concatenate([a[2], b[2]]), be_s)
+    assert a[0]["sym_errors"] + b[0]["sym_errors"] == res_s["sym_errors"]
+
+
+def test_zero_noise_round_trip(engine):
+    """No noise, zero forcing: every symbol of every stream comes back (transforms, channel and decode are exact to
+    f32 rounding, far inside the decision regions)."""
+    engine.set_constellation(chains.constellation("qam", 64), _lib.CONST_QAM)
+    res = engine.run_mimo_ofdm(4, 4, 1024, 16, 1024, 1, 0.0, SEED, 5, 4096, mmse=False, method=_lib.DEMOD_QAM_SLICER,
+                               dtype="f32")
+    assert res["n_realizations"] > 4000
+    assert res["sym_errors"] <= 1e-6 * res["n_realizations"] * 4096       # ill-conditioned H now and then
