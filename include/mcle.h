@@ -79,6 +79,27 @@ int mcle_memcpy_2d(mcle_ctx* ctx, void* d_dst, size_t dst_pitch, const void* d_s
 int mcle_timer_start(mcle_ctx* ctx);
 int mcle_timer_stop_ms(mcle_ctx* ctx, float* ms);                               /* blocks */
 
+/* ---- multi-GPU: realization sharding + ONE all-reduce of the integer counters.
+ *      The reference's only multi-process mechanism is ipyparallel, one parameter variation per engine
+ *      (simulations/runner.py:1836-1846 simulate_in_parallel); here every rank takes a slice of every
+ *      variation (realizations are addressed by index) and the exact integer sums are reduced over RCCL / xGMI.
+ *      One process and one context per GPU.  RCCL is bound at run time (dlopen), so a host without it can still
+ *      load the library; mcle_comm_load names the librccl to use (NULL: librccl.so.1 as the loader finds it --
+ *      the copy PyTorch has loaded, if any). ------------------------------------------------------------------ */
+int mcle_comm_load(const char* rccl_path);
+/* rank 0 draws the 128-byte id (ncclGetUniqueId) and hands it to the other ranks by any means (a socket, a file,
+ * MPI, torch.distributed ...); every rank then joins.  world == 1 is allowed (all-reduces become no-ops). */
+int mcle_comm_unique_id(void* id_out, size_t bytes);
+int mcle_comm_init(mcle_ctx* ctx, const void* unique_id, int rank, int world);
+int mcle_comm_destroy(mcle_ctx* ctx);
+int mcle_comm_info(mcle_ctx* ctx, int* rank, int* world);
+/* in place, on the context stream: words 0..5 of each of the n blocks are summed over the ranks
+ * (ncclUint64 / ncclSum -- exact, order independent), n_symbols / n_bits take the maximum (they are
+ * per-realization constants, zero on a rank whose shard was empty).  No-op without a communicator. */
+int mcle_counters_allreduce(mcle_ctx* ctx, mcle_counters* d_counters, int n);
+/* sum of n doubles over the ranks, in place (the 'sum_capacity' style side results of the IA application) */
+int mcle_allreduce_f64(mcle_ctx* ctx, double* d_values, size_t n);
+
 /* ---- constellation (a1: modulators/fundamental.py:131-146 setConstellation, :396-448 PSK,
  *      :659-777 QAM; the table itself is built by the host mirror) ----------------------- */
 int mcle_set_constellation(mcle_ctx* ctx, const double* re_im, int M, int kind);

@@ -118,6 +118,13 @@ _PROTOS = {
     "mcle_memcpy_2d": (c_int, [_P, _P, c_size_t, _P, c_size_t, c_size_t, c_size_t]),
     "mcle_timer_start": (c_int, [_P]),
     "mcle_timer_stop_ms": (c_int, [_P, POINTER(c_float)]),
+    "mcle_comm_load": (c_int, [c_char_p]),
+    "mcle_comm_unique_id": (c_int, [_P, c_size_t]),
+    "mcle_comm_init": (c_int, [_P, _P, c_int, c_int]),
+    "mcle_comm_destroy": (c_int, [_P]),
+    "mcle_comm_info": (c_int, [_P, POINTER(c_int), POINTER(c_int)]),
+    "mcle_counters_allreduce": (c_int, [_P, _P, c_int]),
+    "mcle_allreduce_f64": (c_int, [_P, _P, c_size_t]),
     "mcle_set_constellation": (c_int, [_P, POINTER(c_double), c_int, c_int]),
     "mcle_build_demod_grid": (c_int, [POINTER(c_double), c_int, POINTER(c_int), POINTER(c_double), POINTER(c_double),
                                       POINTER(c_double), POINTER(c_uint64)]),
@@ -225,6 +232,18 @@ def load():
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+def torch_rccl_path():
+    """Path of the librccl.so PyTorch bundles (so that libmcle and torch.distributed share one RCCL), or None."""
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return None
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "librccl.so")
+    return cand if os.path.exists(cand) else None
 
 
 def exported_symbols():

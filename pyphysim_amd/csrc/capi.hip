@@ -132,6 +132,8 @@ int mcle_ctx_destroy(mcle_ctx* ctx) {
     if (!ctx) return MCLE_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    (void)mcle_comm_destroy(ctx);
+    if (ctx->d_comm_buf) (void)hipFree(ctx->d_comm_buf);
     for (auto& kv : ctx->twiddles) (void)hipFree(kv.second);
     if (ctx->d_table_f32) (void)hipFree(ctx->d_table_f32);
     if (ctx->d_table_f64) (void)hipFree(ctx->d_table_f64);

@@ -153,6 +153,11 @@ struct mcle_ctx {
     void* d_scratch = nullptr;
     size_t scratch_bytes = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // RCCL communicator of the realization-sharded runs (comm.hip); null: single rank
+    void* comm = nullptr;
+    int comm_rank = 0, comm_world = 1;
+    void* d_comm_buf = nullptr;
+    size_t comm_buf_words = 0;
 
     int bind() const;
     int get_twiddles(int n, int dtype, void** d_tw);

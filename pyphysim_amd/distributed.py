@@ -1,0 +1,156 @@
+"""Rank plumbing for realization-sharded runs: who am I, how many are we, and ONE all-reduce of the counters.
+
+Two interchangeable back ends with the same small surface (rank, world, allreduce_counters, allreduce_floats,
+broadcast_ints), used by simulations.BatchedSimulationRunner:
+
+  NativeComm   libmcle's own RCCL communicator (csrc/comm.hip: mcle_comm_init / mcle_counters_allreduce) -- the
+               route a C caller has.  The 128-byte RCCL id travels from rank 0 to the others over a plain TCP
+               socket at MASTER_ADDR:MASTER_PORT (127.0.0.1 by default); torch.distributed is not involved.
+  TorchComm    an initialised torch.distributed process group (backend nccl = RCCL on GPUs, gloo on CPU hosts
+               and in the CPU tests).
+
+The reference has nothing of the kind: its parallel mode farms whole parameter variations out to ipyparallel
+engines (simulations/runner.py:1836-1846).
+"""
+import os
+import socket
+import struct
+import time
+
+import numpy as np
+
+COUNTER_KEYS = ("n_realizations", "n_skipped", "sym_errors", "sym_errors_sq", "bit_errors", "bit_errors_sq")
+
+
+def env_rank_world():
+    """(rank, local_rank, world) from the launcher's environment (torch.distributed.run, mpirun, srun)."""
+    for r, l, w in (("RANK", "LOCAL_RANK", "WORLD_SIZE"), ("OMPI_COMM_WORLD_RANK", "OMPI_COMM_WORLD_LOCAL_RANK",
+                                                          "OMPI_COMM_WORLD_SIZE"),
+                    ("SLURM_PROCID", "SLURM_LOCALID", "SLURM_NTASKS")):
+        if r in os.environ and w in os.environ:
+            return int(os.environ[r]), int(os.environ.get(l, os.environ[r])), int(os.environ[w])
+    return 0, 0, 1
+
+
+def _exchange_id(make_id, rank, world, addr, port, timeout=120.0):
+    """Rank 0 serves the id to the world - 1 peers that connect; returns the id on every rank."""
+    if world == 1:
+        return make_id()
+    if rank == 0:
+        payload = make_id()
+        srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+        srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+        srv.bind((addr, port))
+        srv.listen(world)
+        srv.settimeout(timeout)
+        seen = set()
+        try:
+            while len(seen) < world - 1:
+                conn, _ = srv.accept()
+                with conn:
+                    peer = struct.unpack("<i", conn.recv(4))[0]
+                    conn.sendall(payload)
+                    seen.add(peer)
+        finally:
+            srv.close()
+        return payload
+    deadline = time.time() + timeout
+    while True:
+        try:
+            with socket.create_connection((addr, port), timeout=5.0) as conn:
+                conn.sendall(struct.pack("<i", rank))
+                buf = b""
+                while len(buf) < 128:
+                    chunk = conn.recv(128 - len(buf))
+                    if not chunk:
+                        raise ConnectionError("short id")
+                    buf += chunk
+                return buf
+        except (ConnectionError, OSError):
+            if time.time() > deadline:
+                raise
+            time.sleep(0.2)
+
+
+class NativeComm:
+    """libmcle's RCCL communicator on `engine`'s context."""
+
+    def __init__(self, engine, rank=None, world=None, master_addr=None, master_port=None):
+        env_rank, _, env_world = env_rank_world()
+        self.engine = engine
+        self.rank = env_rank if rank is None else int(rank)
+        self.world = env_world if world is None else int(world)
+        addr = master_addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
+        port = int(master_port or os.environ.get("MCLE_COMM_PORT", int(os.environ.get("MASTER_PORT", "29500")) + 17))
+        uid = _exchange_id(engine.comm_unique_id, self.rank, self.world, addr, port)
+        engine.comm_init(uid, self.rank, self.world)
+        self._cnt = engine.new_counters()
+
+    def close(self):
+        self.engine.comm_destroy()
+
+    def allreduce_counters(self, c):
+        """dict with COUNTER_KEYS + n_symbols / n_bits -> the same dict reduced over the ranks (exact integers)."""
+        from . import _lib
+        words = np.array([int(c.get(k, 0)) for k in _lib.COUNTER_FIELDS], dtype=np.uint64)
+        self._cnt.set(words.view(self._cnt.dtype))
+        self.engine.counters_allreduce(self._cnt, 1)
+        out = self.engine.read_counters(self._cnt)
+        return {k: int(out[k]) for k in _lib.COUNTER_FIELDS}
+
+    def allreduce_floats(self, values):
+        return [float(v) for v in self.engine.allreduce_f64(np.asarray(values, dtype=np.float64))]
+
+    def broadcast_ints(self, values, src=0):
+        """Rank `src`'s integer list on every rank (an all-reduce of a vector that is zero elsewhere)."""
+        v = np.asarray(values if self.rank == src else [0] * len(values), dtype=np.float64)
+        return [int(round(x)) for x in self.engine.allreduce_f64(v)]
+
+
+class TorchComm:
+    """An initialised torch.distributed process group (None = the default group)."""
+
+    def __init__(self, process_group=None):
+        import torch.distributed as dist
+        self._dist, self.group = dist, process_group
+        self.rank, self.world = dist.get_rank(process_group), dist.get_world_size(process_group)
+
+    def _device(self):
+        import torch
+        if self._dist.get_backend(self.group) == "nccl":
+            return torch.device("cuda", torch.cuda.current_device())
+        return torch.device("cpu")
+
+    def allreduce_counters(self, c):
+        import torch
+        dist = self._dist
+        vec = torch.tensor([int(c[k]) for k in COUNTER_KEYS], dtype=torch.int64, device=self._device())
+        dist.all_reduce(vec, op=dist.ReduceOp.SUM, group=self.group)              # the path's only exchange
+        shape = torch.tensor([int(c.get("n_symbols", 0)), int(c.get("n_bits", 0))], dtype=torch.int64, device=self._device())
+        dist.all_reduce(shape, op=dist.ReduceOp.MAX, group=self.group)            # ranks with an empty shard
+        out = {k: int(v) for k, v in zip(COUNTER_KEYS, vec.tolist())}
+        out["n_symbols"], out["n_bits"] = int(shape[0]), int(shape[1])
+        return out
+
+    def allreduce_floats(self, values):
+        import torch
+        vec = torch.tensor([float(v) for v in values], dtype=torch.float64, device=self._device())
+        self._dist.all_reduce(vec, op=self._dist.ReduceOp.SUM, group=self.group)
+        return [float(v) for v in vec.tolist()]
+
+    def broadcast_ints(self, values, src=0):
+        import torch
+        vec = torch.tensor([int(v) for v in values], dtype=torch.int64, device=self._device())
+        self._dist.broadcast(vec, src=src, group=self.group)
+        return [int(v) for v in vec.tolist()]
+
+
+def default_comm(process_group=None):
+    """TorchComm when torch.distributed is initialised, else None (single rank)."""
+    try:
+        import torch.distributed as dist
+    except ImportError:
+        return None
+    if dist.is_available() and dist.is_initialized():
+        return TorchComm(process_group)
+    return None

@@ -596,6 +596,39 @@ class Engine:
             return res, se.get(), be.get()
         return res
 
+    # ---- multi-GPU exchange (csrc/comm.hip): one RCCL all-reduce of the counter blocks ----------------
+    def comm_unique_id(self):
+        """128-byte RCCL id, drawn by rank 0 and handed to the other ranks by the caller (pyphysim_amd.distributed)."""
+        path = _lib.torch_rccl_path()
+        check(self.lib.mcle_comm_load(path.encode() if path else None))
+        buf = ctypes.create_string_buffer(128)
+        check(self.lib.mcle_comm_unique_id(buf, 128))
+        return buf.raw
+
+    def comm_init(self, unique_id, rank, world):
+        path = _lib.torch_rccl_path()
+        check(self.lib.mcle_comm_load(path.encode() if path else None))
+        check(self.lib.mcle_comm_init(self.ctx, ctypes.c_char_p(bytes(unique_id)), int(rank), int(world)))
+
+    def comm_destroy(self):
+        check(self.lib.mcle_comm_destroy(self.ctx))
+
+    def comm_info(self):
+        r, w = ctypes.c_int(0), ctypes.c_int(1)
+        check(self.lib.mcle_comm_info(self.ctx, byref(r), byref(w)))
+        return r.value, w.value
+
+    def counters_allreduce(self, cnt, n=1):
+        """In place on the stream: sums of words 0..5, maxima of n_symbols / n_bits, over the ranks."""
+        check(self.lib.mcle_counters_allreduce(self.ctx, cnt.ptr, int(n)))
+
+    def allreduce_f64(self, values):
+        """Sum of a small float64 vector over the ranks -> NumPy array."""
+        v = np.ascontiguousarray(values, dtype=np.float64).reshape(-1)
+        d = self.to_device(v)
+        check(self.lib.mcle_allreduce_f64(self.ctx, d.ptr, v.size))
+        return d.get()
+
     def new_counters(self):
         return self.zeros(1, np.dtype((np.void, ctypes.sizeof(Counters))))
 
@@ -833,8 +866,32 @@ class Engine:
 _default = {}
 
 
-def get_engine(device=0):
-    """Process-wide default engine per device (created on first use)."""
+def default_device():
+    """Device of this process: torch's current device once torch.distributed is initialised (the launcher set it
+    per rank), else LOCAL_RANK of the launcher's environment, else 0 -- so that the mirror classes and simulators
+    of every rank compute on that rank's GPU instead of all piling onto GPU 0."""
+    try:
+        import torch
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and torch.cuda.is_available():
+            return int(torch.cuda.current_device())
+    except ImportError:
+        pass
+    import os
+    for key in ("LOCAL_RANK", "OMPI_COMM_WORLD_LOCAL_RANK", "SLURM_LOCALID"):
+        if key in os.environ:
+            try:
+                n = _lib.device_count()
+            except McleError:
+                n = 0
+            return int(os.environ[key]) % n if n > 0 else 0
+    return 0
+
+
+def get_engine(device=None):
+    """Process-wide default engine per device (created on first use); device None = default_device()."""
+    if device is None:
+        device = default_device()
     eng = _default.get(device)
     if eng is None:
         eng = _default[device] = Engine(device)

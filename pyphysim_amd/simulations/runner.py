@@ -233,27 +233,39 @@ class BatchedSimulationRunner(SimulationRunner):
     A subclass implements ``_run_batch(current_parameters, first_rep, count) -> dict`` returning the
     integer counter block of realizations [first_rep, first_rep + count) (the dict produced by
     ``Engine.run_*``: n_realizations, n_skipped, sym_errors, sym_errors_sq, bit_errors,
-    bit_errors_sq, n_symbols, n_bits) and may override ``_results_from_counters``.
+    bit_errors_sq, n_symbols, n_bits; plus any ``EXTRA_KEYS`` it declares, summed like the counters)
+    and may override ``_results_from_counters``.
 
     * realization index == repetition index: results depend only on (seed, index), never on the
       batch size, the number of ranks or a resume point;
-    * with ``world_size > 1`` (torch.distributed initialised) each batch is split contiguously
-      over the ranks and the integer counters are all-reduced (exact, order independent) once
-      per parameter variation -- or once per batch when ``_keep_going`` is overridden;
+    * with more than one rank (``comm=``: a pyphysim_amd.distributed.NativeComm / TorchComm; default: the
+      initialised torch.distributed group, if any) every batch is split contiguously over the ranks and the
+      counters are all-reduced (exact integers, order independent) ONCE per parameter variation -- every rank
+      runs its share of all the batches first.  Only a simulator that overrides ``_keep_going`` needs the
+      global counters to decide whether to go on, and reduces after every batch;
     * skipped realizations (singular channel etc.) count into 'num_skipped_reps' and are replaced
-      by later indices, like SkipThisOne in the serial loop.
+      by later indices, like SkipThisOne in the serial loop (one more round of batches, and one more
+      reduction, per round of replacements);
+    * partial results are written and removed by rank 0 only; a resume point read by rank 0 is broadcast.
     """
     COUNTER_KEYS = ("n_realizations", "n_skipped", "sym_errors", "sym_errors_sq", "bit_errors", "bit_errors_sq")
+    EXTRA_KEYS = ()          # further per-batch sums a subclass carries (floats or integers), reduced as float64
+    EXTRA_INT_KEYS = ()      # the subset of EXTRA_KEYS that holds integers
 
-    def __init__(self, batch_size=4096, process_group=None, exact_early_stop=False):
+    def __init__(self, batch_size=4096, process_group=None, exact_early_stop=False, comm=None):
         super().__init__(read_command_line_args=False)
         self.batch_size = int(batch_size)
         self.process_group = process_group
+        self.comm = comm
         self.first_rep = 0
         # True: a custom _keep_going is consulted after EVERY realization, like the reference's loop
         # (runner.py:1491), by replaying the batch's per-realization counts on the host; the batch is
         # cut at the realization where the rule first says stop (single rank only).
         self.exact_early_stop = bool(exact_early_stop)
+        # a configuration whose every realization is skipped (e.g. zero forcing on a rank-deficient set-up)
+        # would never reach rep_max: give up after this many consecutive batches without one good realization
+        self.max_all_skipped_batches = 64
+        self.n_reductions = 0    # all-reduces issued by the last simulate() (diagnostics, tests)
 
     def _run_batch(self, current_parameters, first_rep, count):
         raise NotImplementedError("'_run_batch' must be implemented in a subclass of BatchedSimulationRunner")
@@ -303,14 +315,15 @@ class BatchedSimulationRunner(SimulationRunner):
         return res
 
     # ---- sharding ---------------------------------------------------------------------------
-    def _dist(self):
-        try:
-            import torch.distributed as dist
-        except ImportError:
+    def _comm(self):
+        """-> (comm or None, rank, world)"""
+        comm = self.comm
+        if comm is None:
+            from ..distributed import default_comm
+            comm = default_comm(self.process_group)
+        if comm is None:
             return None, 0, 1
-        if not (dist.is_available() and dist.is_initialized()):
-            return None, 0, 1
-        return dist, dist.get_rank(self.process_group), dist.get_world_size(self.process_group)
+        return comm, comm.rank, comm.world
 
     @staticmethod
     def shard_range(first, count, rank, world):
@@ -320,45 +333,103 @@ class BatchedSimulationRunner(SimulationRunner):
         return lo, hi - lo
 
     def _allreduce(self, c):
-        dist, rank, world = self._dist()
+        comm, rank, world = self._comm()
         if world == 1:
             return c
-        import torch
-        backend = dist.get_backend(self.process_group)
-        dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
-        vec = torch.tensor([int(c[k]) for k in self.COUNTER_KEYS], dtype=torch.int64, device=dev)
-        dist.all_reduce(vec, op=dist.ReduceOp.SUM, group=self.process_group)     # the path's only exchange
-        shape = torch.tensor([int(c["n_symbols"]), int(c["n_bits"])], dtype=torch.int64, device=dev)
-        dist.all_reduce(shape, op=dist.ReduceOp.MAX, group=self.process_group)   # ranks with an empty shard
-        out = {k: int(v) for k, v in zip(self.COUNTER_KEYS, vec.tolist())}
-        out["n_symbols"], out["n_bits"] = int(shape[0]), int(shape[1])
+        self.n_reductions += 1
+        out = comm.allreduce_counters(c)                 # the path's only exchange: exact integer sums
+        if self.EXTRA_KEYS:
+            vals = comm.allreduce_floats([float(c.get(k, 0)) for k in self.EXTRA_KEYS])
+            for k, v in zip(self.EXTRA_KEYS, vals):
+                out[k] = int(round(v)) if k in self.EXTRA_INT_KEYS else v
         return out
 
-    @staticmethod
-    def _add(acc, c):
+    def _add(self, acc, c):
         if acc is None:
             return dict(c)
-        for k in BatchedSimulationRunner.COUNTER_KEYS:
-            acc[k] += c[k]
+        for k in self.COUNTER_KEYS + tuple(self.EXTRA_KEYS):
+            acc[k] = acc.get(k, 0) + c.get(k, 0)
         acc["n_symbols"] = max(acc.get("n_symbols", 0), c.get("n_symbols", 0))
         acc["n_bits"] = max(acc.get("n_bits", 0), c.get("n_bits", 0))
         return acc
 
+    def _zero_like(self, c):
+        z = {k: 0 for k in self.COUNTER_KEYS + tuple(self.EXTRA_KEYS)}
+        z["n_symbols"] = 0 if c is None else c["n_symbols"]
+        z["n_bits"] = 0 if c is None else c["n_bits"]
+        return z
+
+    # ---- files: rank 0 only -----------------------------------------------------------------
+    def _common_setup(self):
+        self.n_reductions = 0
+        super()._common_setup()
+
+    def _common_cleanup(self):
+        _, rank, _ = self._comm()
+        if rank == 0:
+            return super()._common_cleanup()
+        self._on_simulate_finish()
+        self._toc = time.time()
+        self._results.runned_reps = self._runned_reps
+
+    def _resume_state(self, current_params):
+        """(total, next_index, elapsed) of a partial-results file -- read by rank 0, the same on every rank."""
+        comm, rank, world = self._comm()
+        state, error = None, None
+        if rank == 0:
+            try:
+                partial = self._load_partial(current_params)
+            except ValueError as exc:                    # parameters of the file do not match (runner.py:1058-1063)
+                if world == 1:
+                    raise
+                partial, error = None, exc
+            if partial is not None:
+                state = partial._batched_state
+        if world == 1:
+            return state
+        keys = self.COUNTER_KEYS + ("n_symbols", "n_bits")
+        if rank == 0 and error is not None:
+            ints = [2, 0] + [0] * len(keys)
+            floats = [0.0] * (1 + len(self.EXTRA_KEYS))
+        elif rank == 0 and state is not None:
+            ints = [1, int(state[1])] + [int(state[0].get(k, 0)) for k in keys]
+            floats = [float(state[2])] + [float(state[0].get(k, 0)) for k in self.EXTRA_KEYS]
+        else:
+            ints = [0, 0] + [0] * len(keys)
+            floats = [0.0] * (1 + len(self.EXTRA_KEYS))
+        ints = comm.broadcast_ints(ints, src=0)
+        floats = comm.allreduce_floats(floats)           # zero everywhere but rank 0
+        if ints[0] == 2:                                 # every rank fails together instead of deadlocking
+            raise error if error is not None else ValueError(
+                "Partial results loaded from file does not match current parameters (reported by rank 0)")
+        if not ints[0]:
+            return None
+        total = dict(zip(keys, ints[2:]))
+        for k, v in zip(self.EXTRA_KEYS, floats[1:]):
+            total[k] = int(round(v)) if k in self.EXTRA_INT_KEYS else v
+        return total, ints[1], floats[0]
+
+    def _save_state(self, current_params, total, next_index, elapsed):
+        snap = self._finish_results(current_params, total, elapsed)
+        snap._batched_state = (dict(total), next_index, elapsed)
+        self._save_partial(total["n_realizations"], current_params, snap)
+
     # ---- the batched loop -------------------------------------------------------------------
     def _simulate_for_current_params(self, current_params):
         self._on_simulate_current_params_start(current_params)
-        dist, rank, world = self._dist()
-        partial = self._load_partial(current_params)
-        if partial is not None:
-            total, next_index, elapsed = partial._batched_state
-            total = dict(total)
+        comm, rank, world = self._comm()
+        state = self._resume_state(current_params)
+        if state is not None:
+            total, next_index, elapsed = dict(state[0]), state[1], state[2]
         else:
             total, next_index, elapsed = self._zero_like(None), self.first_rep, 0.0
-        batches = 0
         custom_stop = type(self)._keep_going is not SimulationRunner._keep_going
         exact = self.exact_early_stop and custom_stop
         if exact and world > 1:
             raise RuntimeError("exact_early_stop replays realizations in index order and is single-rank only")
+        saving = self._results_filename is not None and rank == 0
+        last_saved_reps = total["n_realizations"]
+        barren = 0           # consecutive batches without a single good realization
         stopped = False
         while total["n_realizations"] < self.rep_max and not stopped:
             if exact:
@@ -367,41 +438,52 @@ class BatchedSimulationRunner(SimulationRunner):
                 c, se, be = self._run_batch_detailed(current_params, next_index, want)
                 elapsed += time.time() - tic
                 next_index += want
+                before = total["n_realizations"]
                 total, stopped = self._replay(current_params, total, elapsed, c, se, be)
-                continue
-            if total["n_realizations"] > 0:
-                # the reference evaluates _keep_going before every repetition after the first
-                # (runner.py:1491); here it is evaluated before every batch after the first
-                snapshot = self._finish_results(current_params, total, elapsed)
-                if not self._keep_going(current_params, snapshot, total["n_realizations"]):
-                    break
-            want = min(self.batch_size * world, self.rep_max - total["n_realizations"])
-            lo, cnt = self.shard_range(next_index, want, rank, world)
-            tic = time.time()
-            c = self._run_batch(current_params, lo, cnt) if cnt > 0 else self._zero_like(None)
-            elapsed += time.time() - tic
-            next_index += want
-            batches += 1
-            total = self._add(total, self._allreduce(c))
-            if (self._results_filename is not None and rank == 0
-                    and (batches % max(1, self.partial_save_every_reps // max(1, self.batch_size)) == 0
-                         or time.time() - self._last_partial_save > self.partial_save_every_seconds)):
-                snap = self._finish_results(current_params, total, elapsed)
-                snap._batched_state = (dict(total), next_index, elapsed)
-                self._save_partial(total["n_realizations"], current_params, snap)
+                barren = 0 if total["n_realizations"] > before else barren + 1
+            else:
+                if custom_stop and total["n_realizations"] > 0:
+                    # the reference evaluates _keep_going before every repetition after the first
+                    # (runner.py:1491); here it is evaluated before every batch after the first
+                    snapshot = self._finish_results(current_params, total, elapsed)
+                    if not self._keep_going(current_params, snapshot, total["n_realizations"]):
+                        break
+                # one round: every batch still owed (a single one when a stopping rule needs global numbers)
+                owed = self.rep_max - total["n_realizations"]
+                n_batches = 1 if custom_stop else -(-owed // (self.batch_size * world))
+                local = self._zero_like(None)
+                for _ in range(n_batches):
+                    want = min(self.batch_size * world, owed)
+                    lo, cnt = self.shard_range(next_index, want, rank, world)
+                    tic = time.time()
+                    if cnt > 0:
+                        local = self._add(local, self._run_batch(current_params, lo, cnt))
+                    elapsed += time.time() - tic
+                    next_index += want
+                    owed -= want
+                    if saving and world == 1 and (
+                            total["n_realizations"] + local["n_realizations"] - last_saved_reps >= self.partial_save_every_reps
+                            or time.time() - self._last_partial_save > self.partial_save_every_seconds):
+                        # single rank: the running totals are global, a resume point can be written mid-round
+                        so_far = self._add(dict(total), local)
+                        self._save_state(current_params, so_far, next_index, elapsed)
+                        last_saved_reps = so_far["n_realizations"]
+                got = self._allreduce(local)
+                barren = 0 if got["n_realizations"] > 0 else barren + n_batches
+                total = self._add(total, got)
+                if saving and (total["n_realizations"] - last_saved_reps >= self.partial_save_every_reps
+                               or time.time() - self._last_partial_save > self.partial_save_every_seconds):
+                    self._save_state(current_params, total, next_index, elapsed)
+                    last_saved_reps = total["n_realizations"]
+            if barren >= self.max_all_skipped_batches:
+                raise RuntimeError("every realization of the last %d batches was skipped (%d skipped in total): this "
+                                   "configuration cannot produce a valid realization" % (barren, total["n_skipped"]))
         final = self._finish_results(current_params, total, elapsed)
         self._on_simulate_current_params_finish(current_params, final)
         if rank == 0:
             final._batched_state = (dict(total), next_index, elapsed)
             self._save_partial(total["n_realizations"], current_params, final)
         return total["n_realizations"], final
-
-    @staticmethod
-    def _zero_like(c):
-        z = {k: 0 for k in BatchedSimulationRunner.COUNTER_KEYS}
-        z["n_symbols"] = 0 if c is None else c["n_symbols"]
-        z["n_bits"] = 0 if c is None else c["n_bits"]
-        return z
 
     def _finish_results(self, current_params, total, elapsed):
         n = max(int(total["n_realizations"]), 1)

@@ -313,32 +313,31 @@ class IaSimulator(_LinkSimulator):
             self.params.add("max_iterations", int(max_iterations))
             self.params.add("initialize_with", initialize_with)
         self.relative_factor = float(relative_factor)
-        self.COUNTER_KEYS = tuple(self.COUNTER_KEYS)
+        if self.exact_early_stop:
+            raise ValueError("IaSimulator carries per-batch capacity / iteration sums and does not replay single "
+                             "realizations: exact_early_stop is not supported")
+
+    # per-batch sums carried next to the integer counters: added over batches, all-reduced over ranks and kept in
+    # the partial-results state, so 'sum_capacity' / 'ia_runned_iterations' are right under sharding and resume
+    EXTRA_KEYS = ("sum_capacity", "sum_capacity_sq", "ia_runned_iterations", "ia_runned_iterations_sq")
+    EXTRA_INT_KEYS = ("ia_runned_iterations", "ia_runned_iterations_sq")
 
     def _run_batch(self, current_parameters, first_rep, count):
         eng = self._bind()
         p = current_parameters
-        res = eng.run_ia(p["NSymbs"], self._noise_var(p), self._seed_for(p), first_rep, count,
-                         method=self.demod_method, dtype=self.dtype, solver=p["solver"],
-                         max_iterations=p["max_iterations"] if p["solver"] != "closed_form" else 1,
-                         relative_factor=self.relative_factor,
-                         initialize_with=p["initialize_with"] if p["solver"] != "closed_form" else "random")
-        self._cap = getattr(self, "_cap", 0.0) + res["sum_capacity"]
-        self._cap_sq = getattr(self, "_cap_sq", 0.0) + res["sum_capacity_sq"]
-        self._its = getattr(self, "_its", 0) + res["ia_runned_iterations"]
-        self._its_sq = getattr(self, "_its_sq", 0) + res["ia_runned_iterations_sq"]
-        return res
-
-    def _on_simulate_current_params_start(self, current_params):
-        self._cap = self._cap_sq = 0.0
-        self._its = self._its_sq = 0
+        return eng.run_ia(p["NSymbs"], self._noise_var(p), self._seed_for(p), first_rep, count,
+                          method=self.demod_method, dtype=self.dtype, solver=p["solver"],
+                          max_iterations=p["max_iterations"] if p["solver"] != "closed_form" else 1,
+                          relative_factor=self.relative_factor,
+                          initialize_with=p["initialize_with"] if p["solver"] != "closed_form" else "random")
 
     def _results_from_counters(self, current_parameters, c):
         from .simulations import Result
         res = super()._results_from_counters(current_parameters, c)
         n = max(int(c["n_realizations"]), 1)
-        res.add_result(Result.from_batch("sum_capacity", Result.RATIOTYPE, self._cap, n, self._cap, self._cap_sq, n))
+        cap, cap_sq = float(c.get("sum_capacity", 0.0)), float(c.get("sum_capacity_sq", 0.0))
+        res.add_result(Result.from_batch("sum_capacity", Result.RATIOTYPE, cap, n, cap, cap_sq, n))
         if current_parameters["solver"] != "closed_form":
-            res.add_result(Result.from_batch("ia_runned_iterations", Result.RATIOTYPE, self._its, n, self._its,
-                                             self._its_sq, n))
+            its, its_sq = int(c.get("ia_runned_iterations", 0)), int(c.get("ia_runned_iterations_sq", 0))
+            res.add_result(Result.from_batch("ia_runned_iterations", Result.RATIOTYPE, its, n, its, its_sq, n))
         return res

@@ -41,7 +41,8 @@ def _worker(rank, world, port, out_path, batch_size, early):
         state = {n: [r.to_dict() for r in sim.results[n]] for n in ("ser", "ber", "symbol_errors", "bit_errors",
                                                                      "num_symbols", "num_bits", "num_skipped_reps")}
         with open("%s.%d" % (out_path, rank), "w") as fh:
-            json.dump({"state": state, "reps": sim.runned_reps, "calls": sim.calls}, fh)
+            json.dump({"state": state, "reps": sim.runned_reps, "calls": sim.calls, "n_reductions": sim.n_reductions},
+                      fh)
     finally:
         dist.destroy_process_group()
 
@@ -63,6 +64,10 @@ def test_two_ranks_equal_one_rank(tmp_path):
     a, b = two[0]["calls"], two[1]["calls"]
     assert len(a) == len(b) and all(x[0] + x[1] == y[0] for x, y in zip(a, b))
     assert sum(c for _, c in a) + sum(c for _, c in b) == sum(c for _, c in one["calls"])
+    # ONE reduction per parameter variation and round of batches (a second / third round only replaces the
+    # realizations the first one skipped) -- not one per batch: 2 variations x 24 batches here
+    assert one["n_reductions"] == 0
+    assert two[0]["n_reductions"] == two[1]["n_reductions"] <= 2 * 3 and len(a) >= 2 * 12
 
 
 @pytest.mark.timeout(300)
@@ -71,3 +76,47 @@ def test_two_ranks_early_stop_is_consistent(tmp_path):
     two = _run(2, tmp_path, "e2", 50, early=True)
     assert two[0]["state"] == two[1]["state"] == one["state"]
     assert two[0]["reps"] == one["reps"] and all(r < 1500 for r in one["reps"])
+    # a stopping rule needs the global counters before every batch: one reduction per batch
+    assert two[0]["n_reductions"] == len(two[0]["calls"])
+
+
+def _worker_files(rank, world, port, folder, phase):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import torch.distributed as dist
+    from test_simulations_cpu import FakeBatchedExtra
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sim = FakeBatchedExtra(50, rep_max=400 if phase == 0 else 1200)
+        sim.partial_save_every_reps = 100
+        sim.set_results_filename(os.path.join(folder, "shared"))
+        sim.simulate()
+        with open(os.path.join(folder, "out.%d.%d" % (phase, rank)), "w") as fh:
+            json.dump({"cap": [r.to_dict() for r in sim.results["cap"]], "ser": [r.to_dict() for r in sim.results["ser"]],
+                       "first_call": sim.calls[0], "reps": sim.runned_reps}, fh)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_ranks_files_resume_and_float_side_sums(tmp_path):
+    """Rank-safe files (ADVICE r01): only rank 0 writes / removes, a resume point is read by rank 0 and broadcast;
+    float side sums (the IA application's sum capacity) are all-reduced and survive the resume."""
+    import torch.multiprocessing as mp
+    from test_simulations_cpu import FakeBatchedExtra
+    folder = str(tmp_path)
+    mp.spawn(_worker_files, args=(2, _free_port(), folder, 0), nprocs=2, join=True)
+    files = sorted(os.listdir(os.path.join(folder, "partial_results")))
+    assert len(files) == 2 and os.path.exists(os.path.join(folder, "shared.pickle"))    # one per variation, once
+    mp.spawn(_worker_files, args=(2, _free_port(), folder, 1), nprocs=2, join=True)
+    outs = [json.load(open(os.path.join(folder, "out.1.%d" % r))) for r in range(2)]
+    assert outs[0]["cap"] == outs[1]["cap"] and outs[0]["ser"] == outs[1]["ser"]
+    assert outs[0]["reps"] == [1200, 1200]
+    assert outs[0]["first_call"][0] >= 400                  # resumed past the first run's indices
+    ref = FakeBatchedExtra(64, rep_max=1200)                # single rank, no files, one go
+    ref.simulate()
+    assert [r.to_dict() for r in ref.results["ser"]] == outs[0]["ser"]
+    got, want = outs[0]["cap"], [r.to_dict() for r in ref.results["cap"]]
+    for g, w in zip(got, want):
+        assert g["num_updates"] == w["num_updates"] and abs(g["value"] - w["value"]) <= 1e-9 * abs(w["value"])

@@ -1,0 +1,110 @@
+"""GPU: the multi-rank path on what one GPU can show.
+
+  * libmcle's own RCCL communicator (csrc/comm.hip) with a world of one: id, init, counter all-reduce, destroy;
+  * two PROCESSES sharing device 0, exchanging through gloo (RCCL refuses two ranks on one device), running the real
+    fused pipelines through BatchedSimulationRunner: integer counters and every Result identical to the one-rank
+    run (identical integer counters for any device count), with ONE reduction per SNR."""
+import json
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def test_native_rccl_communicator_single_rank(engine):
+    from pyphysim_amd.distributed import NativeComm
+    comm = NativeComm(engine, rank=0, world=1)
+    try:
+        assert engine.comm_info() == (0, 1)
+        c = dict(n_realizations=7, n_skipped=1, sym_errors=123, sym_errors_sq=4567, bit_errors=89, bit_errors_sq=1011,
+                 n_symbols=4096, n_bits=24576)
+        assert comm.allreduce_counters(c) == c
+        assert comm.allreduce_floats([1.5, -2.25]) == [1.5, -2.25]
+        assert comm.broadcast_ints([3, 1 << 40]) == [3, 1 << 40]
+        with pytest.raises(Exception):
+            engine.comm_init(b"\0" * 128, 0, 1)             # a context holds one communicator
+    finally:
+        comm.close()
+    assert engine.comm_info() == (0, 1)
+    # the id is 128 opaque bytes and differs from call to call
+    a, b = engine.comm_unique_id(), engine.comm_unique_id()
+    assert len(a) == len(b) == 128 and a != b
+
+
+def _worker(rank, world, port, out_path, which):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0")
+    sys.path.insert(0, REPO)
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pyphysim_amd import simulators
+        if which == "mimo":
+            sim = simulators.MimoOfdmSimulator([18.0, 25.0], M=64, rep_max=3000, batch_size=512 // world, seed=11,
+                                               dtype="f32")
+            names = ("ser", "ber", "symbol_errors", "bit_errors", "num_symbols", "num_skipped_reps")
+        else:
+            sim = simulators.IaSimulator([10.0, 20.0], M=16, NSymbs=100, solver="max_sinr", max_iterations=20,
+                                         rep_max=4000, batch_size=1024 // world, seed=5, dtype="f32")
+            names = ("ser", "ber", "symbol_errors", "sum_capacity", "ia_runned_iterations")
+        sim.simulate()
+        state = {n: [r.to_dict() for r in sim.results[n]] for n in names}
+        with open("%s.%d" % (out_path, rank), "w") as fh:
+            json.dump({"state": state, "reps": sim.runned_reps, "n_reductions": sim.n_reductions}, fh)
+    finally:
+        if world > 1:
+            dist.destroy_process_group()
+
+
+def _run(world, tmp_path, which):
+    import torch.multiprocessing as mp
+    out = str(tmp_path / ("%s%d" % (which, world)))
+    mp.spawn(_worker, args=(world, _free_port(), out, which), nprocs=world, join=True)
+    return [json.load(open("%s.%d" % (out, r))) for r in range(world)]
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_of_the_fused_config4_pipeline_equal_one_rank(tmp_path):
+    one = _run(1, tmp_path, "mimo")[0]
+    two = _run(2, tmp_path, "mimo")
+    assert two[0]["state"] == two[1]["state"] == one["state"]
+    assert two[0]["reps"] == one["reps"] == [3000, 3000]
+    assert two[0]["n_reductions"] == 2                      # one all-reduce per SNR point
+
+
+def _close(a, b):
+    if isinstance(a, dict):
+        return all(_close(a[k], b[k]) for k in a)
+    if isinstance(a, float):
+        return abs(a - b) <= 1e-9 * max(1.0, abs(b))
+    return a == b
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_of_the_ia_pipeline_keep_the_capacity_results(tmp_path):
+    """sum_capacity / ia_runned_iterations are carried with the counters, so sharding no
+    longer divides a local sum by the global realization count."""
+    one = _run(1, tmp_path, "ia")[0]
+    two = _run(2, tmp_path, "ia")
+    for name in ("ser", "ber", "symbol_errors", "ia_runned_iterations"):
+        assert two[0]["state"][name] == one["state"][name], name
+    for a, b in zip(two[0]["state"]["sum_capacity"], one["state"]["sum_capacity"]):
+        assert _close(a, b), (a, b)                         # float sums: association differs, value does not
+    cap = one["state"]["sum_capacity"][1]
+    assert cap["num_updates"] == 4000 and 5.0 < cap["value"] / cap["total"] < 40.0

@@ -220,6 +220,79 @@ class FakeBatched(BatchedSimulationRunner):
         return fake_counters(first_rep, count)
 
 
+class FakeBatchedExtra(FakeBatched):
+    """Carries a float side sum next to the counters, like IaSimulator's sum capacity."""
+    EXTRA_KEYS = ("cap", "cap_sq", "its")
+    EXTRA_INT_KEYS = ("its",)
+
+    def _run_batch(self, current_parameters, first_rep, count):
+        c = super()._run_batch(current_parameters, first_rep, count)
+        idx = np.arange(first_rep, first_rep + count)
+        good = idx % 50 != 49                      # fake_counters skips every 50th index
+        vals = 1.0 + (idx[good] % 7) * 0.125
+        c.update(cap=float(vals.sum()), cap_sq=float((vals ** 2).sum()), its=int((idx[good] % 5).sum()))
+        return c
+
+    def _results_from_counters(self, current_parameters, c):
+        res = super()._results_from_counters(current_parameters, c)
+        n = max(int(c["n_realizations"]), 1)
+        res.add_result(Result.from_batch("cap", Result.RATIOTYPE, c.get("cap", 0.0), n, c.get("cap", 0.0),
+                                         c.get("cap_sq", 0.0), n))
+        return res
+
+
+class AllSkipped(BatchedSimulationRunner):
+    def __init__(self):
+        super().__init__(batch_size=10)
+        self.rep_max = 100
+        self.params.add("SNR", np.array([0.0]))
+        self.params.set_unpack_parameter("SNR")
+
+    def _run_batch(self, current_parameters, first_rep, count):
+        return dict(n_realizations=0, n_skipped=count, sym_errors=0, sym_errors_sq=0, bit_errors=0, bit_errors_sq=0,
+                    n_symbols=8, n_bits=16)
+
+
+def test_a_configuration_that_skips_everything_is_an_error_not_a_hang():
+    sim = AllSkipped()
+    sim.max_all_skipped_batches = 5
+    with pytest.raises(RuntimeError, match="skipped"):
+        sim.simulate()
+
+
+def test_extra_sums_are_batch_size_invariant_and_resume(tmp_path):
+    outs = []
+    for bs in (1000, 37):
+        f = FakeBatchedExtra(bs)
+        f.simulate()
+        outs.append([r.to_dict() for r in f.results["cap"]])
+    assert outs[0][0]["num_updates"] == 1000
+    for a, b in zip(outs[0], outs[1]):
+        assert abs(a["value"] - b["value"]) < 1e-9 and a["total"] == b["total"]
+    g = FakeBatchedExtra(100, rep_max=300)
+    g.set_results_filename(str(tmp_path / "fx"))
+    g.simulate()
+    h = FakeBatchedExtra(100, rep_max=1000)
+    h.set_results_filename(str(tmp_path / "fx"))
+    h.simulate()
+    for a, b in zip(outs[0], [r.to_dict() for r in h.results["cap"]]):
+        assert abs(a["value"] - b["value"]) < 1e-9 and a["num_updates"] == b["num_updates"]
+
+
+def test_partial_saves_follow_realizations_not_batches(tmp_path, monkeypatch):
+    """with a results file set, a resume point is written every `partial_save_every_reps` realizations,
+    not after every GPU batch."""
+    f = FakeBatched(10, rep_max=1000)
+    f.partial_save_every_reps = 400
+    f.set_results_filename(str(tmp_path / "cad"))
+    saves = []
+    orig = f._save_partial
+    monkeypatch.setattr(f, "_save_partial", lambda *a, **k: (saves.append(a[0]), orig(*a, **k))[1])
+    f.simulate()
+    per_variation = len(saves) / 2
+    assert 2 <= per_variation <= 5, saves            # ~1000 / 400 mid-run saves + the final one, not 100
+
+
 def test_batched_runner_is_batch_size_invariant(tmp_path):
     outs = []
     for bs in (1000, 64, 7):
