@@ -367,13 +367,18 @@ def roofline_block(args, batch, per_launch_s, rate_kernel, pmc, pmc_source):
              "flops_per_realization": f_total, "flops_breakdown": flops, "uncounted": UNCOUNTED.get(args.config),
              "hbm": hbm,
              "valu_busy_chip": d.get("valu_busy_chip"), "mfma_busy_chip": d.get("mfma_busy_chip"),
+             # f32-input MFMA and VALU instructions share one FP32 datapath per SIMD on gfx950 (measured:
+             # scripts/experiments/mfma_valu_overlap.hip, profiles/r02/mfma_valu_overlap.txt), so the two add up
+             "fp32_datapath_busy_chip": (d["valu_busy_chip"] + d["mfma_busy_chip"])
+             if d.get("valu_busy_chip") is not None and d.get("mfma_busy_chip") is not None else None,
              "valu_wave_insts_per_realization": d.get("valu_wave_insts_per_realization"),
              "mfma_f32_mops_per_realization": d.get("mfma_f32_mops_per_realization"),
              "wait_inst_any_frac": d.get("wait_inst_any_frac"),
              "counters_source": pmc_source,
              "note": "fused kernel: every intermediate of a realization lives in LDS / registers, so HBM traffic is "
-                     "B_alg / %s of the staged model and the kernel is bound by VALU issue; frac = algorithmic flops "
-                     "(RNG excluded) / FP32 peak" % (("%.0f" % (balg / measured)) if measured else "?")}
+                     "B_alg / %s of the staged model and the kernel is bound by the SIMDs' FP32 datapath (VALU + f32 MFMA "
+                     "instructions, which do not overlap on gfx950); frac = algorithmic flops (RNG excluded) / FP32 peak"
+                     % (("%.0f" % (balg / measured)) if measured else "?")}
     return block
 
 
