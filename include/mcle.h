@@ -236,6 +236,12 @@ int mcle_svd_filters(mcle_ctx* ctx, int dtype, const void* d_H, int n_ant, void*
  * triangular with constant diagonal; may be NULL). */
 int mcle_gmd_filters(mcle_ctx* ctx, int dtype, const void* d_H, int n_ant, double noise_var, void* d_W,
                      void* d_G, double* d_R, uint32_t* d_skipped, size_t batch);
+/* calc_post_processing_linear_SINRs (mimo/mimo.py:62-118; MimoBase.calc_linear_SINRs :311-345): complex128
+ * H [batch][nr][nt], precoder W [batch][nt][ns], receive filter G_H [batch][ns][nr] -> linear SINR [batch][ns]:
+ * |E_ii|^2 / (|sum_{j != i} E_ij|^2 + noise_var ||G_H row i||^2) with E = G_H H W (the reference's formula,
+ * modulus of the summed off-diagonal entries included). */
+int mcle_post_processing_sinrs(mcle_ctx* ctx, const void* d_H, const void* d_W, const void* d_G, double noise_var,
+                               int nr, int nt, int ns, double* d_sinr, size_t batch);
 
 /* ---- fused pipelines: whole realizations on-chip (randomness: mcle-philox-v1) ----------- */
 typedef struct mcle_awgn_cfg {          /* C1: apps/awgn_modulators/simulate_psk.py:51-115 */

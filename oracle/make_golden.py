@@ -164,6 +164,25 @@ def golden_operators():
     out.update(fd_sig=sig, fd_car=car, fd_out=fo, fd_taps=tb, fd_phi=jk._phi_l, fd_psi=jk._psi_l,
                fd_delays=td.channel_profile.tap_delays, fd_powers=td.channel_profile.tap_powers_linear,
                fdm_sig=sigm, fdm_out=fm, fdm_taps=tbm, fdm_phi=jm._phi_l, fdm_psi=jm._psi_l)
+    # post-processing SINRs (mimo.py:33-118, MimoBase.calc_linear_SINRs :311-345) -- own RandomState: the global
+    # stream's position must not move for the arrays drawn below
+    rsp = np.random.RandomState(BASE_SEED + 91)
+    cn = lambda *shape: (rsp.randn(*shape) + 1j * rsp.randn(*shape)) / math.sqrt(2.0)
+    Hp, Wp, Gp, nvp = cn(4, 5), cn(5, 3), cn(3, 4), 0.07
+    ref_s = rmimo.calc_post_processing_linear_SINRs(Hp, Wp, Gp, nvp)
+    close(omimo.post_processing_linear_sinrs(Hp, Wp, Gp, nvp), ref_s, 1e-13, "post sinr")
+    close(rmimo.calc_post_processing_SINRs(Hp, Wp, Gp, nvp), 10 * np.log10(ref_s), 1e-12, "post sinr dB")
+    out.update(psinr_H=Hp, psinr_W=Wp, psinr_G=Gp, psinr_nv=nvp, psinr_lin=ref_s)
+    Hq = cn(4, 4)
+    bq = rmimo.Blast(Hq)
+    out.update(psinr_Hq=Hq, psinr_blast_zf=bq.calc_linear_SINRs(0.0), psinr_blast_mmse=bq.calc_linear_SINRs(0.05),
+               psinr_svd=rmimo.SVDMimo(Hq).calc_linear_SINRs(0.05), psinr_gmd=rmimo.GMDMimo(Hq).calc_linear_SINRs(0.05),
+               psinr_gmd_zf=rmimo.GMDMimo(Hq).calc_linear_SINRs(0.0))
+    hq = cn(4)
+    out.update(psinr_mrt_h=hq, psinr_mrt=np.atleast_1d(rmimo.MRT(hq).calc_linear_SINRs(0.05)),
+               psinr_mrc=rmimo.MRC(hq).calc_linear_SINRs(0.05),
+               psinr_ala_H=cn(3, 2))
+    out["psinr_ala"] = np.atleast_1d(rmimo.Alamouti(out["psinr_ala_H"]).calc_linear_SINRs(0.05))
     # Alamouti / MRT / SVD (mimo.py:666-1287)
     Ha = rmisc.randn_c(3, 2)
     ala = rmimo.Alamouti(Ha)

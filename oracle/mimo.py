@@ -146,3 +146,14 @@ def gmd_encode(x, H):
 def gmd_decode(Y, H, noise_var=0.0):
     Q, R, _ = gmd(*np.linalg.svd(H))
     return (blast_receive_filter(Q @ R, noise_var) @ Y).reshape(-1)
+
+
+def post_processing_linear_sinrs(channel, W, G_H, noise_var=0.0):
+    """mimo/mimo.py:62-118 calc_post_processing_linear_SINRs: |E_ii|^2 / (|sum_{j != i} E_ij|^2 + nv ||G_H row i||^2),
+    E = G_H channel W (note: the modulus of the SUMMED off-diagonal row entries, as the reference computes it)."""
+    G_H = np.atleast_2d(np.asarray(G_H, dtype=complex))
+    E = G_H @ (np.asarray(channel, dtype=complex) @ np.asarray(W, dtype=complex))
+    s = np.diag(E)
+    i = np.sum(E, axis=1) - s
+    N = (noise_var or 0.0) * np.linalg.norm(G_H, axis=1) ** 2
+    return np.abs(s) ** 2 / (np.abs(i) ** 2 + N)

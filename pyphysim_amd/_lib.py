@@ -165,6 +165,7 @@ _PROTOS = {
     "mcle_mrt_decode": (c_int, [_P, c_int, _P, _P, c_int, c_size_t, _P, c_size_t]),
     "mcle_svd_filters": (c_int, [_P, c_int, _P, c_int, _P, _P, _P, c_size_t]),
     "mcle_gmd_filters": (c_int, [_P, c_int, _P, c_int, c_double, _P, _P, _P, _P, c_size_t]),
+    "mcle_post_processing_sinrs": (c_int, [_P, _P, _P, _P, c_double, c_int, c_int, c_int, _P, c_size_t]),
     "mcle_run_awgn": (c_int, [_P, c_int, POINTER(AwgnCfg), c_uint64, c_uint64, c_uint64, _P, _P, _P]),
     "mcle_run_flat_fading": (c_int, [_P, c_int, POINTER(FlatCfg), c_uint64, c_uint64, c_uint64, _P, _P, _P]),
     "mcle_run_ofdm_tdl": (c_int, [_P, c_int, POINTER(OfdmTdlCfg), c_uint64, c_uint64, c_uint64, _P, _P, _P]),

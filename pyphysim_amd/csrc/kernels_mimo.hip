@@ -314,6 +314,39 @@ int check_mimo(const mcle_ctx* ctx, int dtype, int nr, int nt, size_t batch) {
 
 }  // namespace mcle
 
+namespace mcle {
+// calc_post_processing_linear_SINRs (reference mimo/mimo.py:62-118): per channel of the batch, E = G_H H W (ns x ns);
+// stream i: S = |E_ii|^2, I = |sum_{j != i} E_ij|^2 (the reference takes the modulus of the SUM of the off-diagonal
+// row entries), N = noise_var * ||row i of G_H||^2; SINR = S / (I + N).  One thread per (channel, stream), f64.
+__global__ __launch_bounds__(256) void k_post_sinr(const double2* __restrict__ H, const double2* __restrict__ W,
+                                                   const double2* __restrict__ G, double noise_var, int nr, int nt,
+                                                   int ns, double* __restrict__ sinr, size_t batch) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= batch * (size_t)ns) return;
+    const size_t b = idx / ns;
+    const int i = (int)(idx - b * ns);
+    const double2* Hb = H + b * nr * nt;
+    const double2* Wb = W + b * nt * ns;
+    const double2* Gi = G + (b * ns + i) * nr;
+    double2 diag = mk<double>(0, 0), row = mk<double>(0, 0);
+    double gn = 0.0;
+    for (int r = 0; r < nr; ++r) gn += Gi[r].x * Gi[r].x + Gi[r].y * Gi[r].y;
+    for (int j = 0; j < ns; ++j) {
+        double2 e = mk<double>(0, 0);
+        for (int a = 0; a < nt; ++a) {
+            double2 hw = mk<double>(0, 0);            // (G_H H)_{i a}
+            for (int r = 0; r < nr; ++r) hw = cadd(hw, cmul(Gi[r], Hb[r * nt + a]));
+            e = cadd(e, cmul(hw, Wb[a * ns + j]));
+        }
+        row = cadd(row, e);
+        if (j == i) diag = e;
+    }
+    const double2 off = csub(row, diag);
+    const double S = diag.x * diag.x + diag.y * diag.y, I = off.x * off.x + off.y * off.y;
+    sinr[idx] = S / (I + noise_var * gn);
+}
+}  // namespace mcle
+
 using namespace mcle;
 
 extern "C" {
@@ -528,6 +561,23 @@ int mcle_gmd_filters(mcle_ctx* ctx, int dtype, const void* d_H, int n_ant, doubl
         else MCLE_GMD(double, 4);
     }
 #undef MCLE_GMD
+    MCLE_LAUNCH_CHECK();
+    return MCLE_OK;
+}
+
+int mcle_post_processing_sinrs(mcle_ctx* ctx, const void* d_H, const void* d_W, const void* d_G, double noise_var,
+                               int nr, int nt, int ns, double* d_sinr, size_t batch) {
+    MCLE_REQUIRE(ctx != nullptr && d_H != nullptr && d_W != nullptr && d_G != nullptr && d_sinr != nullptr,
+                 "null argument");
+    MCLE_REQUIRE(nr >= 1 && nt >= 1 && ns >= 1 && nr <= 64 && nt <= 64 && ns <= 64, "dimensions must be in [1, 64]");
+    MCLE_REQUIRE(noise_var >= 0.0, "Noise variance must be a non-negative value.");
+    if (batch == 0) return MCLE_OK;
+    int rc = ctx->bind();
+    if (rc) return rc;
+    const size_t items = batch * (size_t)ns;
+    hipLaunchKernelGGL(k_post_sinr, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (const double2*)d_H, (const double2*)d_W, (const double2*)d_G, noise_var, nr, nt, ns, d_sinr,
+                       batch);
     MCLE_LAUNCH_CHECK();
     return MCLE_OK;
 }

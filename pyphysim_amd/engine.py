@@ -580,6 +580,22 @@ class Engine:
                                                     sk.ptr, b))
         return self._out(W, host), self._out(G, host), R.get()
 
+    def post_processing_sinrs(self, H, W, G_H, noise_var):
+        """calc_post_processing_linear_SINRs (mimo.py:62-118), batched: H [b, nr, nt], W [b, nt, ns],
+        G_H [b, ns, nr] (complex128) -> linear SINRs [b, ns]."""
+        H = np.ascontiguousarray(H, dtype=np.complex128)
+        W = np.ascontiguousarray(W, dtype=np.complex128)
+        G = np.ascontiguousarray(G_H, dtype=np.complex128)
+        b, nr, nt = H.shape
+        ns = W.shape[2]
+        if W.shape != (b, nt, ns) or G.shape != (b, ns, nr):
+            raise ValueError("shapes must be H [b, nr, nt], W [b, nt, ns], G_H [b, ns, nr]")
+        out = self.empty((b, ns), np.float64)
+        dH, dW, dG = self.to_device(H), self.to_device(W), self.to_device(G)
+        self._raise_value(self.lib.mcle_post_processing_sinrs(self.ctx, dH.ptr, dW.ptr, dG.ptr, float(noise_var or 0.0),
+                                                              nr, nt, ns, out.ptr, b))
+        return out.get()
+
     # ---- fused pipelines --------------------------------------------------------------------
     def _run(self, fn, cfg, seed, first, count, dtype, per_realization, counters=None):
         dt = self._dt(dtype)

@@ -8,8 +8,38 @@ import numpy as np
 from .engine import DeviceArray, get_engine
 
 
+def calc_post_processing_linear_SINRs(channel, W, G_H, noise_var=None, engine=None):
+    """reference mimo.py:62-118: linear SINR of every stream of precoder W / receive filter G_H on `channel`."""
+    eng = engine if engine is not None else get_engine()
+    G = np.atleast_2d(np.asarray(G_H, dtype=complex))
+    Wm = np.asarray(W, dtype=complex)
+    if Wm.ndim == 1:
+        Wm = Wm[:, np.newaxis]
+    H = np.atleast_2d(np.asarray(channel, dtype=complex))
+    return eng.post_processing_sinrs(H[np.newaxis], Wm[np.newaxis], G[np.newaxis], noise_var or 0.0)[0]
+
+
+def calc_post_processing_SINRs(channel, W, G_H, noise_var=None, engine=None):
+    """reference mimo.py:33-59: the same in dB."""
+    return 10.0 * np.log10(calc_post_processing_linear_SINRs(channel, W, G_H, noise_var, engine))
+
+
 class MimoBase:
     """reference mimo.py:30-459 (the pieces Blast needs)."""
+
+    def _precoder_and_filter(self, noise_var):
+        raise NotImplementedError("this MIMO scheme has no linear precoder / receive filter pair")
+
+    def calc_linear_SINRs(self, noise_var):
+        """reference mimo.py:311-326: post-processing SINRs of the scheme's own precoder and receive filter.
+        Drop-in includes the reference's quirk: despite its name the method returns calc_post_processing_SINRs,
+        i.e. values in dB (mimo.py:325), and calc_SINRs applies linear2dB once more (mimo.py:345)."""
+        W, G_H = self._precoder_and_filter(noise_var)
+        return calc_post_processing_SINRs(self._channel, W, G_H, noise_var, self.engine)
+
+    def calc_SINRs(self, noise_var):
+        """reference mimo.py:328-345."""
+        return 10.0 * np.log10(self.calc_linear_SINRs(noise_var))
 
     def __init__(self, channel=None, engine=None, dtype=None):
         self._channel = None
@@ -58,6 +88,11 @@ class Blast(MimoBase):
 
     def getNumberOfLayers(self):
         return self.Nt
+
+    def _precoder_and_filter(self, noise_var):
+        """mimo.py:556-607: W = I / sqrt(Nt); G_H = sqrt(Nt) x (MMSE if noise_var > 0 else zero forcing)."""
+        G, _ = self.engine.blast_filter(self._channel[np.newaxis], noise_var or 0.0, dtype="f64")
+        return np.eye(self.Nt) / math.sqrt(self.Nt), G[0]
 
     def set_noise_var(self, noise_var):
         """None / 0 -> zero forcing; > 0 -> MMSE (mimo.py:529-553)."""
@@ -108,6 +143,11 @@ class MRT(MimoBase):
     def getNumberOfLayers(self):
         return 1
 
+    def _precoder_and_filter(self, noise_var):
+        """mimo.py:687-731: phase-only precoder, scalar receive gain."""
+        W = np.exp(-1j * np.angle(self._channel)).T / math.sqrt(self.Nt)
+        return W, np.array([[math.sqrt(self.Nt) / np.sum(np.abs(self._channel))]])
+
     def encode(self, transmit_data):
         x = np.asarray(transmit_data).reshape(1, -1)
         return self.engine.mrt_encode(self._channel.reshape(1, -1), x, dtype=self.dtype)[0]
@@ -125,6 +165,10 @@ class SVDMimo(Blast):
     def _filters(self):
         W, G, S = self.engine.svd_filters(self._channel[np.newaxis], dtype=self.dtype)
         return W[0], G[0], S[0]
+
+    def _precoder_and_filter(self, noise_var):
+        W, G, _ = self.engine.svd_filters(self._channel[np.newaxis], dtype="f64")
+        return W[0], G[0]
 
     def encode(self, transmit_data):
         x = np.asarray(transmit_data).reshape(-1)
@@ -146,6 +190,10 @@ class GMDMimo(Blast):
     def _filters(self):
         W, G, R = self.engine.gmd_filters(self._channel[np.newaxis], self._noise_var, dtype=self.dtype)
         return W[0], G[0], R[0]
+
+    def _precoder_and_filter(self, noise_var):
+        W, G, _ = self.engine.gmd_filters(self._channel[np.newaxis], noise_var or 0.0, dtype="f64")
+        return W[0], G[0]
 
     def encode(self, transmit_data):
         x = np.asarray(transmit_data).reshape(-1)
@@ -176,6 +224,7 @@ class Alamouti(MimoBase):
         return 1
 
     def calc_linear_SINRs(self, noise_var):
+        """mimo.py:1147-1166."""
         return np.linalg.norm(self._channel, "fro") ** 2 / noise_var
 
     def encode(self, transmit_data):

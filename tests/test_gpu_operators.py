@@ -725,3 +725,34 @@ def test_ia_class_mirrors_run_the_reference_app(engine):
         ia.AlternatingMinIASolver(muc).initialize_with = "alt_min"
     with pytest.raises(ValueError):
         muc.init_from_channel_matrix(np.zeros((4, 4)), 2, 2, 3)
+
+
+def test_post_processing_sinrs(engine, golden_ops):
+    """calc_post_processing_(linear_)SINRs and every scheme's calc_linear_SINRs (reference mimo/mimo.py:33-118,
+    311-345, 1147-1166) against the reference's own numbers."""
+    from oracle import mimo as omimo
+    from pyphysim_amd import mimo
+    g = golden_ops
+    got = mimo.calc_post_processing_linear_SINRs(g["psinr_H"], g["psinr_W"], g["psinr_G"], float(g["psinr_nv"]),
+                                                 engine=engine)
+    assert relerr(got, g["psinr_lin"]) <= 1e-12
+    assert relerr(mimo.calc_post_processing_SINRs(g["psinr_H"], g["psinr_W"], g["psinr_G"], float(g["psinr_nv"]),
+                                                  engine=engine), 10 * np.log10(g["psinr_lin"])) <= 1e-12
+    batch = np.stack([g["psinr_H"], 2 * g["psinr_H"], g["psinr_H"].conj()])
+    out = engine.post_processing_sinrs(batch, np.stack([g["psinr_W"]] * 3), np.stack([g["psinr_G"]] * 3), 0.07)
+    for b in range(3):
+        assert relerr(out[b], omimo.post_processing_linear_sinrs(batch[b], g["psinr_W"], g["psinr_G"], 0.07)) <= 1e-12
+    # the schemes' own methods, the reference's quirk included: MimoBase.calc_linear_SINRs returns dB (mimo.py:325)
+    Hq = g["psinr_Hq"]
+    assert np.all(mimo.Blast(Hq, engine=engine).calc_linear_SINRs(0.0) > 250.0)         # zero forcing, no noise:
+    assert np.all(g["psinr_blast_zf"] > 250.0)                                            # rounding residue only
+    assert relerr(mimo.Blast(Hq, engine=engine).calc_linear_SINRs(0.05), g["psinr_blast_mmse"]) <= 1e-8
+    assert relerr(mimo.SVDMimo(Hq, engine=engine).calc_linear_SINRs(0.05), g["psinr_svd"]) <= 1e-7
+    assert relerr(mimo.GMDMimo(Hq, engine=engine).calc_linear_SINRs(0.05), g["psinr_gmd"]) <= 1e-7
+    assert relerr(mimo.MRT(g["psinr_mrt_h"], engine=engine).calc_linear_SINRs(0.05), g["psinr_mrt"]) <= 1e-10
+    assert relerr(mimo.MRC(g["psinr_mrt_h"], engine=engine).calc_linear_SINRs(0.05), g["psinr_mrc"]) <= 1e-8
+    assert relerr(np.atleast_1d(mimo.Alamouti(g["psinr_ala_H"], engine=engine).calc_linear_SINRs(0.05)),
+                  g["psinr_ala"]) <= 1e-12
+    want_db = 10 * np.log10(np.abs(g["psinr_blast_mmse"]))
+    got_db = mimo.Blast(Hq, engine=engine).calc_SINRs(0.05)
+    assert relerr(got_db[np.isfinite(want_db)], want_db[np.isfinite(want_db)]) <= 1e-7
