@@ -380,6 +380,32 @@ int mcle_ia_iterative(mcle_ctx* ctx, int solver, int initialize_with, const void
                       void* d_F, void* d_U, double* d_sinr, double* d_capacity, uint32_t* d_iterations,
                       uint32_t* d_skipped, size_t batch);
 
+/* ---- iterative interference alignment for general geometries (SURVEY 8(f).3 tail): K <= 4 users with
+ *      Nr x Nt <= 4 x 4 antennas each and per-user stream counts; AlternatingMinIASolver / MinLeakageIASolver /
+ *      MaxSinrIASolver .solve (ia/algorithms.py:802-883, 885-1507) from injected precoders ('fix') or the 'svd'
+ *      start (:503-547, Nr == Nt), optionally inside GreedStreamIASolver.solve (:1905-2010: drop the worst stream
+ *      while the sum capacity grows) or BruteForceStreamIASolver.solve (:2147-2260: every stream combination up to
+ *      ns[], 'svd' start, best sum capacity).  One lane per channel realization, f64.
+ *      d_bigH [batch][K nr][K nt]; d_F_init [batch][4][4][4] = user k's nt x ns[k] start in the top-left corner
+ *      (ignored for 'svd' and for brute force).  Outputs, same padded layout: d_F (nt x ns, unit Frobenius norm =
+ *      full_F for P = 1), d_U (full_W_H, ns x nr), d_sinr [batch][4][4] (linear, per stream), d_capacity [batch],
+ *      d_iterations [batch] (all runs of a selection wrapper added up), d_ns [batch][4] (streams kept per user),
+ *      d_skipped [batch] (a singular system met on the way); every output but d_F / d_U may be NULL.
+ *      Eigenvector phases are ours, not LAPACK's: SINRs, capacity and decisions do not depend on them. */
+typedef struct mcle_ia_general_cfg {
+    int32_t K, nr, nt;
+    int32_t ns[4];
+    int32_t solver;             /* MCLE_IA_ALT_MIN / MCLE_IA_MIN_LEAKAGE / MCLE_IA_MAX_SINR */
+    int32_t initialize_with;    /* MCLE_IA_INIT_GIVEN or MCLE_IA_INIT_SVD */
+    int32_t max_iterations;
+    int32_t stream_selection;   /* 0: none, 1: greedy, 2: brute force */
+    int32_t reserved;
+    double noise_var, relative_factor;
+} mcle_ia_general_cfg;
+int mcle_ia_solve_general(mcle_ctx* ctx, const mcle_ia_general_cfg* cfg, const void* d_bigH, const void* d_F_init,
+                          void* d_F, void* d_U, double* d_sinr, double* d_capacity, uint32_t* d_iterations,
+                          int32_t* d_ns, uint32_t* d_skipped, size_t batch);
+
 /* ---- block diagonalisation of a multi-user downlink (SURVEY 8(f).3 tail) --------------------
  * comm/waterfilling.py:15-92 doWF: d_gains [batch][n] channel POWER gains -> optimum powers
  * d_powers [batch][n] (same order) and the water level d_mu [batch] (may be NULL); n <= 64. */

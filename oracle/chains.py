@@ -392,6 +392,45 @@ def chain_ia_iterative(rng, algo='alt_min', mod='qam', M=16, K=3, nr=2, nt=2, Ns
     return _counts(out, idx, dec, M)
 
 
+def chain_ia_general(rng, algo, mod, M, K, nr, nt, Ns, NSymbs, snr_db, max_iterations, relative_factor,
+                      initialize_with="random", select=None):
+    """SURVEY.md section 8(f).3 tail: iterative IA on general geometries (per-user stream counts, 'svd' start,
+    GreedStreamIASolver / BruteForceStreamIASolver; ia/algorithms.py:802-883, 885-1507, 1853-2260) and the link run
+    with the solution found (apps/ia/simulate_ia.py:94-245).  Legacy streams only (fixture pinning)."""
+    table = constellation(mod, M)
+    noise_var = 1.0 / float(omodem.dB2Linear(snr_db))
+    big_H = rng.cn(philox.STREAM_CHAN, K * nr, K * nt)
+    H = oia.split_blocks(big_H, K, nr, nt)
+    Ns_l = [int(Ns)] * K if np.isscalar(Ns) else [int(n) for n in Ns]
+    F_init = None
+    if initialize_with == "random" and select != "brute":
+        F_init = []
+        for k in range(K):
+            f = rng.cn(STREAM_INIT, nt, Ns_l[k])            # the solver's own RandomState
+            F_init.append(f / np.linalg.norm(f, "fro"))
+    sol = oia.general_solve(algo, H, Ns_l, noise_var, max_iterations, relative_factor, F_init, select)
+    Ns_fin = sol["Ns"]
+    idx = rng.rs.randint(0, M, [int(np.sum(Ns_fin)), NSymbs])
+    sym = omodem.modulate(table, idx)
+    cum = np.cumsum(Ns_fin)
+    tx = np.split(sym, cum[:-1])
+    X = np.vstack([sol["F"][k] @ tx[k] for k in range(K)])
+    noise = rng.cn(philox.STREAM_NOISE, K * nr, NSymbs)
+    Y = oia.mu_corrupt(big_H, X, noise, noise_var)
+    est = np.vstack([sol["U"][k] @ Y[k * nr:(k + 1) * nr] for k in range(K)])
+    dec = omodem.demodulate(table, est)
+    pad = lambda mats, r, c: np.stack([np.pad(np.asarray(a), ((0, r - a.shape[0]), (0, c - a.shape[1]))) for a in mats])
+    out = dict(table=table, big_H=big_H, idx=idx, noise=noise, est=est, decisions=dec, noise_var=noise_var,
+               sum_capacity=sol["cap"], Ns_final=np.array(Ns_fin, dtype=int),
+               PF=np.stack([f @ f.conj().T for f in sol["F"]]), PU=np.stack([u.conj().T @ u for u in sol["U"]]),
+               sinr=np.concatenate([np.asarray(s, dtype=float) for s in sol["sinr"]]),
+               runned_iterations=int(sol["runned"]), symbol_errors=omodem.count_symbol_errors(idx, dec), bit_errors=int(omodem.count_bit_errors(idx, dec)),
+               num_symbols=int(idx.size), num_bits=int(idx.size) * omodem.level2bits(M))
+    if F_init is not None:
+        out["F_init"] = pad(F_init, 4, 4)
+    return out
+
+
 def chain_mimo_ofdm_tdl(rng, mod='qam', M=16, nt=2, nr=2, fft_size=64, cp_size=16, num_used=None, n_ofdm_sym=2,
                         snr_db=20.0, Fd=50.0, Ts=1e-6, L=8, tap_powers_dB=(0.0, -4.0, -9.0),
                         tap_delays_samples=(0, 2, 5)):

@@ -156,7 +156,7 @@ def _iterate(F, step, max_iterations, relative_factor, state=None):
     return F, state, runned
 
 
-def alt_min_solve(H, F_init, noise_var, max_iterations=50, relative_factor=1e-6, W_init=None):
+def alt_min_solve(H, F_init, noise_var, max_iterations=50, relative_factor=1e-6, W_init=None, full_F_first=None):
     """-> (F, W_H rows, runned_iterations); Ns taken from F_init.  (W_init is ignored: the algorithm derives
     its state C from F in _before_initialize_W_func and W only when it finishes.)"""
     K = len(F_init)
@@ -168,7 +168,8 @@ def alt_min_solve(H, F_init, noise_var, max_iterations=50, relative_factor=1e-6,
 
     def step(F, C):
         if C is None:
-            C = update_C(F)                    # _before_initialize_W_func of the initialisation
+            # _before_initialize_W_func of the initialisation (calc_Q reads full_F: see general_solve's greedy branch)
+            C = update_C(F if full_F_first is None else full_F_first)
         Y = [np.eye(Nr[k], dtype=complex) - C[k] @ C[k].conj().T for k in range(K)]
         newF = [0] * K
         for (l, k) in itertools.permutations(range(K), 2):
@@ -187,7 +188,7 @@ def alt_min_solve(H, F_init, noise_var, max_iterations=50, relative_factor=1e-6,
     return F, W_H, runned
 
 
-def min_leakage_solve(H, F_init, noise_var, max_iterations=50, relative_factor=1e-6, W_init=None):
+def min_leakage_solve(H, F_init, noise_var, max_iterations=50, relative_factor=1e-6, W_init=None, full_F_first=None):
     K = len(F_init)
     Ns = [f.shape[1] for f in F_init]
 
@@ -196,7 +197,7 @@ def min_leakage_solve(H, F_init, noise_var, max_iterations=50, relative_factor=1
 
     def step(F, W):
         if W is None:
-            W = update_W(F)
+            W = update_W(F if full_F_first is None else full_F_first)
         F = [leig(_calc_Q_rev(H, W, k), Ns[k])[0] for k in range(K)]
         return F, update_W(F)
 
@@ -207,24 +208,28 @@ def min_leakage_solve(H, F_init, noise_var, max_iterations=50, relative_factor=1
     return F, [w.conj().T for w in W], runned
 
 
-def max_sinr_solve(H, F_init, noise_var, max_iterations=50, relative_factor=1e-6, W_init=None):
+def max_sinr_solve(H, F_init, noise_var, max_iterations=50, relative_factor=1e-6, W_init=None, full_F_first=None):
     """Ns = 1 per user is what the kernel covers; the restatement keeps the per-stream loop."""
     K = len(F_init)
 
-    def calc_U(Hkk_of, V, chan):
-        """chan(k, j): channel seen by 'receiver' k from 'transmitter' j in the (possibly reversed) network."""
+    def calc_U(Hkk_of, V, chan, per_stream_power, V_cov=None):
+        """chan(k, j): channel seen by 'receiver' k from 'transmitter' j in the (possibly reversed) network.
+        per_stream_power: the reverse network weighs every transmitter's term by P/Ns (algorithms.py:1290-1345),
+        the forward one uses full_F as it is (iabase.py:828-894)."""
         out = []
         for k in range(K):
             first = 0.0
+            Vc = V if V_cov is None else V_cov            # the covariances read full_F, the directions F
             for j in range(K):
-                a = chan(k, j) @ V[j]
-                first = first + a @ a.conj().T
+                a = chan(k, j) @ Vc[j]
+                first = first + (a @ a.conj().T) * (1.0 / V[j].shape[1] if per_stream_power else 1.0)
             Hkk = Hkk_of(k)
             U = np.zeros((Hkk.shape[0], V[k].shape[1]), dtype=complex)
             for l in range(V[k].shape[1]):
                 v = V[k][:, l:l + 1]
-                a = Hkk @ v
-                B = first - a @ a.conj().T + noise_var * np.eye(Hkk.shape[0])
+                a = Hkk @ Vc[k][:, l:l + 1]
+                second = (a @ a.conj().T) * (1.0 / V[k].shape[1] if per_stream_power else 1.0)
+                B = first - second + noise_var * np.eye(Hkk.shape[0])
                 u = np.linalg.solve(B, Hkk @ v)
                 U[:, l] = (u / np.linalg.norm(u, "fro"))[:, 0]
             out.append(U / np.linalg.norm(U, "fro"))
@@ -233,13 +238,13 @@ def max_sinr_solve(H, F_init, noise_var, max_iterations=50, relative_factor=1e-6
     fwd = lambda k, j: H[k][j]
     rev = lambda k, j: H[j][k].conj().T
 
-    def update_W(F):
-        return calc_U(lambda k: H[k][k], F, fwd)
+    def update_W(F, F_cov=None):
+        return calc_U(lambda k: H[k][k], F, fwd, False, F_cov)
 
     def step(F, W):
         if W is None:
-            W = update_W(F)
-        F = calc_U(lambda k: H[k][k].conj().T, W, rev)
+            W = update_W(F, full_F_first)
+        F = calc_U(lambda k: H[k][k].conj().T, W, rev, True)
         return F, update_W(F)
 
     F0 = [np.asarray(f, dtype=complex) for f in F_init]
@@ -344,3 +349,100 @@ def mmse_solve(H, F_init, noise_var, max_iterations=50, relative_factor=1e-6, W_
 
 
 ITERATIVE["mmse"] = mmse_solve
+
+
+# ---- general geometries: per-user stream counts, 'svd' start, greedy / brute-force stream selection -------------
+# pyphysim/ia/algorithms.py:503-547 (_initialize_with_svd), :1853-2075 GreedStreamIASolver, :2057-2260
+# BruteForceStreamIASolver.  P = 1 for every user.
+def svd_init(H, Ns):
+    """Most significant right singular vectors of every direct channel, in the column order of
+    util/misc.py:647-660 least_right_singular_vectors' reversed index list."""
+    F = []
+    for k in range(len(H)):
+        V = np.linalg.svd(H[k][k], full_matrices=True)[2].conj().T
+        rev = list(reversed(range(V.shape[0])))
+        V1 = V[:, rev[H[k][k].shape[0] - Ns[k]:]]
+        F.append(V1 / np.linalg.norm(V1, 'fro'))
+    return F
+
+
+def evaluate(H, F, W_H, noise_var):
+    """-> (U = full_W_H, per-user SINR arrays, sum capacity) of a precoder / receive-filter set."""
+    U = [np.linalg.solve(W_H[k] @ (H[k][k] @ F[k]), W_H[k]) for k in range(len(F))]
+    sinr = calc_SINR(H, F, U, noise_var)
+    return U, sinr, float(np.sum([np.sum(np.log2(1 + s)) for s in sinr]))
+
+
+def principal_components(A, n):
+    """util/misc.py:870-905 get_principal_component_matrix."""
+    U, S, V_H = np.linalg.svd(A)
+    newS = np.zeros(U.shape[0], dtype=A.dtype)
+    newS[:n] = S[:n]
+    newS = np.diag(newS)[:, :V_H.shape[1]]
+    return U @ (newS @ V_H[:, :n])
+
+
+def solve_finalize(F, W_H):
+    """algorithms.py:665-735 _solve_finalize: a precoder with more than one stream whose condition number exceeds
+    1e4 has dead dimensions (an over-loaded stream allocation collapses onto fewer streams): keep the singular
+    directions above max/1e4 in the precoder (renormalised) and in the receive filter.  -> (F, W_H, Ns)"""
+    F, W_H = [np.array(f) for f in F], [np.array(w) for w in W_H]
+    for k in range(len(F)):
+        if F[k].shape[1] > 1:
+            S = np.linalg.svd(F[k])[1]
+            if S.max() / S.min() > 1e4:
+                n = int(np.count_nonzero(S > S.max() / 1.0e4))
+                f = principal_components(F[k], n)
+                F[k] = f / np.linalg.norm(f, 'fro')
+                W_H[k] = principal_components(W_H[k].conj().T, n).conj().T
+    return F, W_H, [f.shape[1] for f in F]
+
+
+def general_solve(algo, H, Ns, noise_var, max_iterations=50, relative_factor=1e-6, F_init=None, select=None):
+    """-> dict(F, U, sinr, cap, Ns, runned).  F_init None = 'svd' start; select in (None, 'greedy', 'brute').
+    `runned` follows the reference's bookkeeping: the brute-force wrapper clears the solver before every run and
+    adds the runs up; the greedy wrapper re-solves with initialize_with = 'fix', which does NOT reset the solver's
+    counter, and adds the solver's (cumulative) return values (algorithms.py:1936, 1979)."""
+    K = len(H)
+    Ns = [int(Ns)] * K if np.isscalar(Ns) else [int(n) for n in Ns]
+    run = ITERATIVE[algo]
+
+    def solve(F0, full_F_first=None):
+        F, W_H, runned = run(H, F0, noise_var, max_iterations, relative_factor, None, full_F_first)
+        F, W_H, ns = solve_finalize(F, W_H)
+        U, sinr, cap = evaluate(H, F, W_H, noise_var)
+        return dict(F=F, U=U, sinr=sinr, cap=cap, Ns=ns), runned
+
+    if select == 'brute':
+        best, total = None, 0
+        for comb in itertools.product(*[range(1, n + 1) for n in Ns]):
+            sol, runned = solve(svd_init(H, comb))
+            total += runned
+            if best is None or sol["cap"] > best["cap"]:
+                best = sol
+        best["runned"] = total
+        return best
+    sol, counter = solve(svd_init(H, Ns) if F_init is None else [np.asarray(f, dtype=complex) for f in F_init])
+    total = counter
+    while select == 'greedy' and any(n > 1 for n in sol["Ns"]):
+        old = sol
+        sinr, ns = sol["sinr"], sol["Ns"]
+        mins = [int(np.argmin(s)) for s in sinr]
+        order = [int(i) for i in np.argsort([sinr[i][mins[i]] for i in range(K)]) if ns[i] > 1]
+        user, stream = order[0], mins[order[0]]
+        # the wrapper deletes the column from F AND from full_F but renormalises only F (algorithms.py:1962-1975);
+        # the re-solve's first receive-filter update builds its covariances from that stale full_F
+        F = [f.copy() for f in sol["F"]]
+        full_F = [f.copy() for f in sol["F"]]
+        F[user] = np.delete(F[user], stream, 1)
+        full_F[user] = F[user].copy()
+        F[user] = F[user] / np.linalg.norm(F[user], 'fro')
+        sol, runned = solve(F, full_F)
+        counter += runned
+        total += counter
+        if old["cap"] > sol["cap"]:
+            sol = old
+            break
+    sol = dict(sol)
+    sol["runned"] = total
+    return sol

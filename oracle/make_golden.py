@@ -412,6 +412,69 @@ def ref_chain_ia_iterative(seed, algo, mod, M, K, nr, nt, Ns, NSymbs, snr_db, ma
                 runned_iterations=int(runned), **ref_counts(idx, dec, M))
 
 
+def ref_ia_general(seed, algo, mod, M, K, nr, nt, Ns, NSymbs, snr_db, max_iterations, relative_factor,
+                   initialize_with="random", select=None):
+    """General-geometry IA (per-user stream counts, 'svd' start, greedy / brute-force stream selection) on the
+    reference's own classes; the link is run with the solution it found."""
+    from pyphysim.channels import multiuser as rmu
+    from pyphysim.ia import algorithms as ralg
+    np.random.seed(seed)
+    m = ref_modulator(mod, M)
+    noise_var = 1.0 / dB2Linear(snr_db)
+    muc = rmu.MultiUserChannelMatrix()
+    muc.set_channel_seed(seed)
+    muc.set_noise_seed(seed)
+    cls = {"alt_min": ralg.AlternatingMinIASolver, "min_leakage": ralg.MinLeakageIASolver,
+           "max_sinr": ralg.MaxSinrIASolver}[algo]
+    solver = cls(muc)
+    solver._rs = np.random.RandomState(seed)
+    solver.max_iterations = max_iterations
+    solver.relative_factor = relative_factor
+    solver.initialize_with = initialize_with
+    muc.randomize(nr, nt, K)
+    muc.noise_var = noise_var
+    solver.clear()
+    Ns_arr = np.ones(K, dtype=int) * Ns if np.isscalar(Ns) else np.array(Ns, dtype=int)
+    F_init = {"F": None}
+    if initialize_with == "random" and select != "brute":
+        orig = solver.randomizeF
+
+        def spy(Ns_, P=None):
+            orig(Ns_, P)
+            if F_init["F"] is None:
+                F_init["F"] = [np.array(f) for f in solver._F]
+        solver.randomizeF = spy
+    if select == "greedy":
+        wrapper = ralg.GreedStreamIASolver(solver)
+        runned = wrapper.solve(Ns_arr.copy())
+    elif select == "brute":
+        wrapper = ralg.BruteForceStreamIASolver(solver)
+        runned = wrapper.solve(Ns_arr.copy())
+    else:
+        runned = solver.solve(Ns_arr.copy())
+    Ns_fin = np.array(solver.Ns, dtype=int)
+    cumNs = np.cumsum(Ns_fin)
+    idx = np.random.randint(0, M, [int(np.sum(Ns_fin)), NSymbs])
+    sym = m.modulate(idx)
+    tx = np.split(sym, cumNs[:-1])
+    pre = [np.dot(f, x) for f, x in zip(solver.full_F, tx)]
+    rx = muc.corrupt_data(pre)
+    est = np.vstack([np.dot(u, y) for u, y in zip(solver.full_W_H, rx)])
+    dec = m.demodulate(est)
+    sinr = solver.calc_SINR()
+    cap = float(np.sum([np.sum(np.log2(1 + s)) for s in sinr]))
+    pad = lambda mats, r, c: np.stack([np.pad(np.asarray(a), ((0, r - a.shape[0]), (0, c - a.shape[1]))) for a in mats])
+    out = dict(table=m.symbols, big_H=np.array(muc.big_H), idx=idx, noise=muc.last_noise / math.sqrt(noise_var),
+               est=est, decisions=dec, noise_var=noise_var, sum_capacity=cap, Ns_final=Ns_fin,
+               PF=np.stack([np.asarray(f) @ np.asarray(f).conj().T for f in solver.full_F]),
+               PU=np.stack([np.asarray(u).conj().T @ np.asarray(u) for u in solver.full_W_H]),
+               sinr=np.concatenate([np.asarray(s, dtype=float) for s in sinr]),
+               runned_iterations=int(runned), **ref_counts(idx, dec, M))
+    if F_init["F"] is not None:
+        out["F_init"] = pad(F_init["F"], 4, 4)
+    return out
+
+
 def ref_chain_mimo_scheme(seed, scheme, mod, M, nt, nr, NSymbs, snr_db):
     """apps/mimo/simulate_mimo.py:68-100 with the reference's own scheme classes."""
     np.random.seed(seed)
@@ -540,6 +603,26 @@ CHAINS = {
                              relative_factor=1e-6, initialize_with="svd")
                         for a, snr, it in (("alt_min", 20.0, 40), ("max_sinr", 12.0, 25), ("min_leakage", 20.0, 8),
                                            ("mmse", 16.0, 20))],
+    # general geometries (reference apps/ia/greedy_config_file.txt: K = 3, 3x3, up to 3 streams), both regimes of the
+    # iteration count: relative_factor 0 (the loop always runs max_iterations) and the default early stop
+    "f3c_ia_general": [dict(algo=a, mod="psk", M=4, K=3, nr=nr, nt=nt, Ns=Ns, NSymbs=40, snr_db=snr, max_iterations=it,
+                            relative_factor=rel, initialize_with=init, select=sel)
+                       for a, nr, nt, Ns, snr, it, rel, init, sel in (
+                           ("alt_min", 3, 3, 1, 20.0, 25, 0.0, "random", None),
+                           ("alt_min", 4, 4, 2, 20.0, 25, 0.0, "random", None),
+                           ("min_leakage", 3, 3, 1, 15.0, 20, 0.0, "random", None),
+                           ("min_leakage", 4, 4, 1, 25.0, 20, 0.0, "random", None),   # (Ns > 1: the reference asserts, iabase.py:663)
+                           ("max_sinr", 3, 3, (2, 1, 1), 15.0, 20, 0.0, "random", None),
+                           ("max_sinr", 4, 4, 2, 10.0, 15, 0.0, "svd", None),
+                           ("max_sinr", 2, 4, 1, 12.0, 15, 0.0, "random", None),
+                           ("alt_min", 4, 2, 1, 18.0, 15, 0.0, "random", None),
+                           ("max_sinr", 3, 3, 1, 20.0, 60, 1e-6, "random", None),
+                           ("min_leakage", 4, 4, 1, 20.0, 80, 1e-6, "svd", None),
+                           ("max_sinr", 3, 3, 3, 10.0, 12, 0.0, "random", "greedy"),
+                           ("max_sinr", 3, 3, 2, 25.0, 12, 0.0, "random", "greedy"),
+                           ("alt_min", 4, 4, 2, 15.0, 10, 0.0, "random", "greedy"),
+                           ("max_sinr", 3, 3, 2, 12.0, 8, 0.0, "svd", "brute"),
+                           ("min_leakage", 2, 2, 1, 20.0, 10, 0.0, "svd", "brute"))],
     "f1_mimo_ofdm_tdl": [dict(mod="qam", M=16, nt=2, nr=2, fft_size=64, cp_size=16, num_used=None, n_ofdm_sym=2,
                               snr_db=20.0, Fd=50.0, Ts=1e-6, L=8, tap_powers_dB=(0.0, -4.0, -9.0),
                               tap_delays_samples=(0, 2, 5)),
@@ -572,6 +655,8 @@ def run_ref(name, kw, seed):
         return ref_chain_ia_iterative(seed, **kw)
     if name == "f5_mimo_schemes":
         return ref_chain_mimo_scheme(seed, **kw)
+    if name == "f3c_ia_general":
+        return ref_ia_general(seed, **kw)
     if name == "f1_mimo_ofdm_tdl":
         return ref_chain_mimo_ofdm_tdl(seed, **kw)
     if name == "c1_awgn":
@@ -594,16 +679,16 @@ ORACLE = {"c1_awgn": chains.chain_awgn, "c2_flat_jakes": chains.chain_flat_jakes
           "c2b_flat_rayleigh": chains.chain_flat_rayleigh,
           "c3_ofdm_tdl": chains.chain_ofdm_tdl, "c4_mimo_ofdm": chains.chain_mimo_ofdm, "c5_ia": chains.chain_ia,
           "f1_mimo_ofdm_tdl": chains.chain_mimo_ofdm_tdl, "f3_ia_iterative": chains.chain_ia_iterative,
-          "f3b_ia_svd_init": chains.chain_ia_iterative, "f5_mimo_schemes": chains.chain_mimo_scheme, "f6_block_diag": chains.chain_bd}
+          "f3b_ia_svd_init": chains.chain_ia_iterative, "f3c_ia_general": chains.chain_ia_general, "f5_mimo_schemes": chains.chain_mimo_scheme, "f6_block_diag": chains.chain_bd}
 INT_KEYS = ("idx", "decisions", "symbol_errors", "bit_errors", "num_symbols", "num_bits", "delay_indexes",
-            "runned_iterations")
+            "runned_iterations", "Ns_final")
 # realizations stored per case (kept small: fixtures are KBs)
 N_REAL = {"c1_awgn": 2, "c2_flat_jakes": 2, "c2b_flat_rayleigh": 2, "c3_ofdm_tdl": 2, "c4_mimo_ofdm": 2, "c5_ia": 4, "f1_mimo_ofdm_tdl": 1,
-          "f3_ia_iterative": 3, "f3b_ia_svd_init": 3, "f5_mimo_schemes": 2, "f6_block_diag": 3}
+          "f3_ia_iterative": 3, "f3b_ia_svd_init": 3, "f3c_ia_general": 2, "f5_mimo_schemes": 2, "f6_block_diag": 3}
 # derivable float arrays that are checked against the reference above but not stored
 SKIP_STORE = {"c1_awgn": ("tx",), "c2_flat_jakes": ("tx", "faded"), "c2b_flat_rayleigh": ("tx", "faded", "rx"), "c3_ofdm_tdl": ("sym", "faded"),
               "c4_mimo_ofdm": ("sym", "X", "R"), "c5_ia": (),
-              "f1_mimo_ofdm_tdl": ("faded", "G"), "f3_ia_iterative": (), "f3b_ia_svd_init": (), "f5_mimo_schemes": (),
+              "f1_mimo_ofdm_tdl": ("faded", "G"), "f3_ia_iterative": (), "f3b_ia_svd_init": (), "f3c_ia_general": (), "f5_mimo_schemes": (),
               "f6_block_diag": ()}
 
 
@@ -618,11 +703,11 @@ def golden_chains(only=None):
             for r in range(N_REAL[name]):
                 seed = BASE_SEED + 1000 * ci + r
                 ref = run_ref(name, kw, seed)
-                mine = ORACLE[name]((chains.LegacyRng3 if name in ("c5_ia", "f3_ia_iterative", "f3b_ia_svd_init", "f6_block_diag")
+                mine = ORACLE[name]((chains.LegacyRng3 if name in ("c5_ia", "f3_ia_iterative", "f3b_ia_svd_init", "f3c_ia_general", "f6_block_diag")
                                      else chains.LegacyRng)(seed), **kw)
                 for k, v in ref.items():
                     tol = 0 if k in INT_KEYS else (1e-9 if name in ("c5_ia", "f1_mimo_ofdm_tdl", "f6_block_diag") else
-                                                   (1e-7 if name in ("f3_ia_iterative", "f3b_ia_svd_init") else
+                                                   (1e-7 if name in ("f3_ia_iterative", "f3b_ia_svd_init", "f3c_ia_general") else
                                                     (1e-9 if name == "f5_mimo_schemes" else 1e-12)))
                     worst = max(worst, close(mine[k], v, tol, "%s[%d] r%d %s" % (name, ci, r, k)))
                     arr = np.asarray(v)

@@ -91,6 +91,13 @@ class BdCfg(Structure):
                 ("bd_noise_var", c_double), ("pathloss", c_double * 16)]
 
 
+class IaGeneralCfg(Structure):
+    _fields_ = [("K", c_int32), ("nr", c_int32), ("nt", c_int32), ("ns", c_int32 * 4), ("solver", c_int32),
+                ("initialize_with", c_int32), ("max_iterations", c_int32), ("stream_selection", c_int32),
+                ("reserved", c_int32), ("noise_var", c_double), ("relative_factor", c_double)]
+
+
+IA_STREAM_SELECTION = {None: 0, "none": 0, "greedy": 1, "brute": 2}
 IA_INITS = {"random": 0, "fix": 0, "closed_form": 1, "alt_min": 2, "svd": 3}
 IA_SOLVERS = {"closed_form": 0, "alt_min": 1, "min_leakage": 2, "max_sinr": 3, "mmse": 4}
 
@@ -165,6 +172,7 @@ _PROTOS = {
     "mcle_mrt_decode": (c_int, [_P, c_int, _P, _P, c_int, c_size_t, _P, c_size_t]),
     "mcle_svd_filters": (c_int, [_P, c_int, _P, c_int, _P, _P, _P, c_size_t]),
     "mcle_gmd_filters": (c_int, [_P, c_int, _P, c_int, c_double, _P, _P, _P, _P, c_size_t]),
+    "mcle_ia_solve_general": (c_int, [_P, POINTER(IaGeneralCfg), _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t]),
     "mcle_post_processing_sinrs": (c_int, [_P, _P, _P, _P, c_double, c_int, c_int, c_int, _P, c_size_t]),
     "mcle_run_awgn": (c_int, [_P, c_int, POINTER(AwgnCfg), c_uint64, c_uint64, c_uint64, _P, _P, _P]),
     "mcle_run_flat_fading": (c_int, [_P, c_int, POINTER(FlatCfg), c_uint64, c_uint64, c_uint64, _P, _P, _P]),

@@ -786,6 +786,48 @@ class Engine:
         return dict(F=F.get(), U=U.get(), sinr=sinr.get(), capacity=cap.get(), iterations=its.get(),
                     skipped=sk.get())
 
+    def ia_solve_general(self, solver, big_H, K, nr, nt, Ns, noise_var, max_iterations=50, relative_factor=1e-6,
+                         F_init=None, select=None):
+        """Iterative IA for general geometries (csrc/kernels_ia_general.hip; reference ia/algorithms.py:802-883,
+        885-1507, 1853-2260): K <= 4 users with nr x nt <= 4 x 4 antennas, Ns = streams per user (int or list).
+        big_H [batch, K nr, K nt].  F_init: [batch, K, 4, 4] padded initial precoders ('fix' / a captured random
+        start) or None for the 'svd' start.  select: None, 'greedy' (GreedStreamIASolver) or 'brute'
+        (BruteForceStreamIASolver, always from 'svd').  -> dict of padded arrays: F [b, K, 4, 4] (nt x ns in the
+        top-left corner), U = full_W_H [b, K, 4, 4] (ns x nr), sinr [b, K, 4], capacity [b], iterations [b],
+        Ns [b, K], skipped [b]."""
+        H = np.ascontiguousarray(big_H, dtype=np.complex128)
+        if H.ndim == 2:
+            H = H[np.newaxis]
+        b = H.shape[0]
+        if H.shape[1:] != (K * nr, K * nt):
+            raise ValueError("big_H must be [batch, K*nr, K*nt]")
+        cfg = _lib.IaGeneralCfg()
+        cfg.K, cfg.nr, cfg.nt = int(K), int(nr), int(nt)
+        ns_list = [int(Ns)] * K if np.isscalar(Ns) else [int(n) for n in Ns]
+        if len(ns_list) != K:
+            raise ValueError("Ns must be an int or one value per user")
+        for k in range(4):
+            cfg.ns[k] = ns_list[k] if k < K else 0
+        cfg.solver = _lib.IA_SOLVERS[solver]
+        cfg.initialize_with = 0 if (F_init is not None and select != "brute") else 3
+        cfg.max_iterations = int(max_iterations)
+        cfg.stream_selection = _lib.IA_STREAM_SELECTION[select]
+        cfg.noise_var, cfg.relative_factor = float(noise_var), float(relative_factor)
+        d_H = self.to_device(H)
+        d_F0 = None
+        if cfg.initialize_with == 0:
+            F0 = np.ascontiguousarray(F_init, dtype=np.complex128)
+            if F0.shape != (b, 4, 4, 4):
+                raise ValueError("F_init must be [batch, 4, 4, 4] (user, nt, ns; zero padded)")
+            d_F0 = self.to_device(F0)
+        F, U = self.empty((b, 4, 4, 4), np.complex128), self.empty((b, 4, 4, 4), np.complex128)
+        sinr, cap = self.empty((b, 4, 4), np.float64), self.empty(b, np.float64)
+        its, ns, sk = self.empty(b, np.uint32), self.empty((b, 4), np.int32), self.empty(b, np.uint32)
+        self._raise_value(self.lib.mcle_ia_solve_general(self.ctx, byref(cfg), d_H.ptr, d_F0.ptr if d_F0 else None,
+                                                         F.ptr, U.ptr, sinr.ptr, cap.ptr, its.ptr, ns.ptr, sk.ptr, b))
+        return dict(F=F.get()[:, :K], U=U.get()[:, :K], sinr=sinr.get()[:, :K], capacity=cap.get(),
+                    iterations=its.get().astype(np.int64), Ns=ns.get()[:, :K], skipped=sk.get())
+
     def ia_closed_form(self, big_H, noise_var):
         """big_H [batch, 6, 6] complex128 -> dict(F [batch,3,2], U [batch,3,2], sinr [batch,3],
         capacity [batch], skipped [batch])."""

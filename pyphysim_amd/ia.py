@@ -1,8 +1,15 @@
 """Mirror of the interference-alignment solvers of pyphysim.ia (reference ia/iabase.py:26-1019 and
-ia/algorithms.py:42-1850) for the geometry the GPU kernels cover: K = 3 users, 2x2 channels, one stream per user,
-unit power.  `solve` runs `ia_closed_form` / `ia_iterative` (csrc/kernels_ia.hip) on the channel of a
-`multiuser.MultiUserChannelMatrix`; precoders, receive filters, SINRs and iteration counts are the reference's
-(tests/golden/c5_ia.npz, f3_ia_iterative.npz).  Other geometries raise ValueError with the reason.
+ia/algorithms.py:42-2260), unit power per user.
+
+* K = 3 users, 2x2 channels, one stream per user: `solve` runs `ia_closed_form` / `ia_iterative`
+  (csrc/kernels_ia.hip, the register-resident kernels of config 5); precoders, receive filters, SINRs and iteration
+  counts are the reference's entry by entry (tests/golden/c5_ia.npz, f3_ia_iterative.npz).
+* any other geometry with K <= 4 users and Nr, Nt <= 4 (equal across users), per-user stream counts: the iterative
+  solvers (alt-min, min-leakage, max-SINR) run `ia_solve_general` (csrc/kernels_ia_general.hip) from a 'random' /
+  'fix' / 'svd' start, and `GreedStreamIASolver` / `BruteForceStreamIASolver` wrap them like the reference's
+  (tests/golden/f3c_ia_general.npz).  Eigenvector phases are the kernel's, not LAPACK's: SINRs, capacity, F F^H
+  and U^H U equal the reference's; the individual entries of F and U differ by one phase per stream.
+Anything else raises ValueError with the reason.
 """
 import numpy as np
 
@@ -70,10 +77,36 @@ class IASolverBaseClass:
 
     def calc_SINR(self):
         """iabase.py:768-789: one array of per-stream SINRs (linear) per user."""
-        return np.array([np.array([s]) for s in self._sinr] + [None], dtype=object)[:-1]
+        return np.array([np.atleast_1d(np.asarray(s, dtype=float)) for s in self._sinr] + [None], dtype=object)[:-1]
 
     def calc_sum_capacity(self):
         return float(self._capacity)
+
+    def _is_special(self, Ns_arr):
+        return (self.K == 3 and list(self.Nr) == [2, 2, 2] and list(self.Nt) == [2, 2, 2]
+                and list(Ns_arr) == [1, 1, 1])
+
+    def _general_dims(self, Ns):
+        """-> (Ns array, nr, nt) for the general kernel, or ValueError."""
+        Ns_arr = np.ones(self.K, dtype=int) * Ns if isinstance(Ns, (int, np.integer)) else np.asarray(Ns, dtype=int)
+        nr, nt = int(self.Nr[0]), int(self.Nt[0])
+        if (self.K < 2 or self.K > 4 or any(int(v) != nr for v in self.Nr) or any(int(v) != nt for v in self.Nt)
+                or nr > 4 or nt > 4 or len(Ns_arr) != self.K or np.any(Ns_arr < 1) or np.any(Ns_arr > min(nr, nt))):
+            raise ValueError("the GPU interference-alignment kernels cover K <= 4 users with the same Nr, Nt <= 4 for "
+                             "every user and 1 <= Ns <= min(Nr, Nt) (got K = %d, Nr = %s, Nt = %s, Ns = %s)"
+                             % (self.K, list(self.Nr), list(self.Nt), list(Ns_arr)))
+        return Ns_arr, nr, nt
+
+    def _store_general(self, sol, nr, nt):
+        ns = [int(n) for n in sol["Ns"][0]]
+        self._Ns = np.array(ns, dtype=int)
+        obj = lambda items: np.array(list(items) + [None], dtype=object)[:-1]
+        self._full_F = obj(np.array(sol["F"][0, k][:nt, :ns[k]]) for k in range(self.K))
+        self._F = obj(f / np.linalg.norm(f, "fro") for f in self._full_F)
+        self._full_W_H = obj(np.array(sol["U"][0, k][:ns[k], :nr]) for k in range(self.K))
+        self._W_H = obj(u / np.linalg.norm(u, "fro") for u in self._full_W_H)
+        self._sinr = [np.array(sol["sinr"][0, k][:ns[k]]) for k in range(self.K)]
+        self._capacity = sol["capacity"][0]
 
     def _check_geometry(self, Ns):
         Ns_arr = np.ones(self.K, dtype=int) * Ns if isinstance(Ns, (int, np.integer)) else np.asarray(Ns, dtype=int)
@@ -135,20 +168,66 @@ class IterativeIASolverBaseClass(IASolverBaseClass):
 
     def randomizeF(self, Ns, P=None):
         """iabase.py:511-545: F_k = normalized(randn_c_RS(rs, Nt, Ns))."""
-        Ns_arr = self._check_geometry(Ns)
+        Ns_arr, nr, nt = self._general_dims(Ns)
         self.P = P
         self._runned_iterations = 0
-        self._F = np.array([self._draw(self._rs) for _ in range(3)] + [None], dtype=object)[:-1]
+        self._F = np.array([self._draw(self._rs, nt, int(Ns_arr[k])) for k in range(self.K)] + [None],
+                           dtype=object)[:-1]
         self._full_F = self._F
         self._Ns = Ns_arr
 
     @staticmethod
-    def _draw(rs):
-        f = (1.0 / np.sqrt(2.0)) * (rs.randn(2, 1) + 1j * rs.randn(2, 1))
+    def _draw(rs, nt=2, ns=1):
+        f = (1.0 / np.sqrt(2.0)) * (rs.randn(nt, ns) + 1j * rs.randn(nt, ns))
         return f / np.linalg.norm(f, "fro")
+
+    _SELECT = None      # set by the stream-selection wrappers for the duration of their solve
+
+    def _solve_general(self, Ns, P, select=None):
+        """Geometries beyond K = 3, 2x2, one stream (algorithms.py:802-883 on csrc/kernels_ia_general.hip)."""
+        Ns_arr, nr, nt = self._general_dims(Ns)
+        if self._SOLVER not in ("alt_min", "min_leakage", "max_sinr"):
+            raise ValueError("%s runs on the K = 3, 2x2, one-stream kernel only" % type(self).__name__)
+        if self._SOLVER == "min_leakage" and np.any(Ns_arr > 1):
+            # the reference asserts here too: calc_Q_rev wants unit-norm receive filters (iabase.py:663)
+            raise ValueError("MinLeakageIASolver supports one stream per user (the reference's calc_Q_rev asserts "
+                             "||W|| = 1, iabase.py:663)")
+        self.P = P
+        init = self._initialize_with
+        F0 = None
+        if select == "brute" or init == "svd":
+            if nr != nt:
+                raise ValueError("the 'svd' start is defined for Nr == Nt")
+        elif init == "random":
+            self.randomizeF(Ns_arr, P)
+            F0 = self._F
+        elif init == "fix":
+            if self._F is None:
+                raise RuntimeError("The precoder must be manually set, since you specified the 'fix' initialize_with "
+                                   "option.")
+            F0 = self._F
+            Ns_arr = np.array([f.shape[1] for f in F0], dtype=int)
+        else:
+            raise ValueError("initialize_with = %r is available on the K = 3, 2x2, one-stream kernel only" % (init,))
+        pad = None
+        if F0 is not None:
+            pad = np.zeros((1, 4, 4, 4), dtype=complex)
+            for k in range(self.K):
+                f = np.asarray(F0[k])
+                pad[0, k, :f.shape[0], :f.shape[1]] = f
+        sol = self.engine.ia_solve_general(self._SOLVER, np.asarray(self._multiUserChannel.big_H), self.K, nr, nt,
+                                           [int(n) for n in Ns_arr], self.noise_var, self.max_iterations,
+                                           self.relative_factor, F_init=pad, select=select)
+        self._store_general(sol, nr, nt)
+        self._runned_iterations = int(sol["iterations"][0])
+        return self._runned_iterations
 
     def solve(self, Ns, P=None):
         """algorithms.py:802-883."""
+        Ns_probe = np.ones(self.K, dtype=int) * Ns if isinstance(Ns, (int, np.integer)) else np.asarray(Ns, dtype=int)
+        if not self._is_special(Ns_probe) or (self._initialize_with == "fix" and self._F is not None
+                                               and any(np.asarray(f).shape != (2, 1) for f in self._F)):
+            return self._solve_general(Ns, P)
         Ns_arr = self._check_geometry(Ns)
         self.P = P
         init = self._initialize_with
@@ -191,3 +270,57 @@ class MaxSinrIASolver(IterativeIASolverBaseClass):
 class MMSEIASolver(IterativeIASolverBaseClass):
     """algorithms.py:1510-1850."""
     _SOLVER = "mmse"
+
+
+class GreedStreamIASolver:
+    """algorithms.py:1853-2050: solve for the asked stream counts, then keep removing the stream with the worst SINR
+    (re-solving from the remaining precoders) while the sum capacity grows.  The whole procedure runs inside one
+    kernel launch (csrc/kernels_ia_general.hip, stream_selection = greedy); the wrapped solver ends up holding the
+    best solution, as in the reference."""
+
+    def __init__(self, iasolver_obj):
+        if not isinstance(iasolver_obj, IterativeIASolverBaseClass):
+            raise TypeError("iasolver_obj must be an iterative IA solver")
+        self._iasolver = iasolver_obj
+        self._runned_iterations = 0
+
+    runned_iterations = property(lambda self: self._runned_iterations)
+
+    def clear(self):
+        self._iasolver.clear()
+        self._runned_iterations = 0
+
+    def solve(self, Ns, P=None):
+        self._iasolver.clear()
+        self._runned_iterations = self._iasolver._solve_general(Ns, P, select="greedy")
+        self._iasolver._initialize_with = "fix"          # what the reference leaves behind (algorithms.py:1977)
+        return self._runned_iterations
+
+    def __getattr__(self, name):                         # F, W_H, Ns, calc_SINR ... of the wrapped solver
+        return getattr(self._iasolver, name)
+
+
+class BruteForceStreamIASolver:
+    """algorithms.py:2057-2260: every combination of 1..Ns[k] streams per user from the 'svd' start, best sum
+    capacity wins (one kernel launch, stream_selection = brute)."""
+
+    def __init__(self, iasolver_obj):
+        if not isinstance(iasolver_obj, IterativeIASolverBaseClass):
+            raise TypeError("iasolver_obj must be an iterative IA solver")
+        self._iasolver = iasolver_obj
+        self._runned_iterations = 0
+
+    runned_iterations = property(lambda self: self._runned_iterations)
+
+    def clear(self):
+        self._iasolver.clear()
+        self._runned_iterations = 0
+
+    def solve(self, Ns, P=None):
+        self._iasolver.clear()
+        self._iasolver._initialize_with = "svd"
+        self._runned_iterations = self._iasolver._solve_general(Ns, P, select="brute")
+        return self._runned_iterations
+
+    def __getattr__(self, name):
+        return getattr(self._iasolver, name)

@@ -719,8 +719,10 @@ def test_ia_class_mirrors_run_the_reference_app(engine):
                 assert relerr(sinr, g["sinr"]) <= 1e-6
     muc = multiuser.MultiUserChannelMatrix(engine=engine)
     muc.randomize(3, 3, 3)
+    muc.noise_var = 0.01
+    assert ia.MaxSinrIASolver(muc).solve(1) >= 1        # 3x3 runs on the general-geometry kernel since round 2
     with pytest.raises(ValueError):
-        ia.MaxSinrIASolver(muc).solve(1)
+        ia.ClosedFormIASolver(muc).solve(1)             # the closed form stays K = 3, 2x2, one stream
     with pytest.raises(RuntimeError):
         ia.AlternatingMinIASolver(muc).initialize_with = "alt_min"
     with pytest.raises(ValueError):

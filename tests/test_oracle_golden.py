@@ -99,7 +99,7 @@ def test_blast(golden_ops):
 
 CHAIN_FN = {"c1_awgn": chains.chain_awgn, "c2_flat_jakes": chains.chain_flat_jakes,
             "c2b_flat_rayleigh": chains.chain_flat_rayleigh,
-            "c3_ofdm_tdl": chains.chain_ofdm_tdl, "c4_mimo_ofdm": chains.chain_mimo_ofdm, "c5_ia": chains.chain_ia, "f3_ia_iterative": chains.chain_ia_iterative, "f3b_ia_svd_init": chains.chain_ia_iterative, "f5_mimo_schemes": chains.chain_mimo_scheme,
+            "c3_ofdm_tdl": chains.chain_ofdm_tdl, "c4_mimo_ofdm": chains.chain_mimo_ofdm, "c5_ia": chains.chain_ia, "f3_ia_iterative": chains.chain_ia_iterative, "f3b_ia_svd_init": chains.chain_ia_iterative, "f3c_ia_general": chains.chain_ia_general, "f5_mimo_schemes": chains.chain_mimo_scheme,
             "f1_mimo_ofdm_tdl": chains.chain_mimo_ofdm_tdl, "f6_block_diag": chains.chain_bd}
 
 
@@ -107,7 +107,7 @@ CHAIN_FN = {"c1_awgn": chains.chain_awgn, "c2_flat_jakes": chains.chain_flat_jak
 def test_chain_matches_reference(name):
     for kw, reals in golden_cases(name):
         for g in reals:
-            rng_cls = chains.LegacyRng3 if name in ("c5_ia", "f3_ia_iterative", "f3b_ia_svd_init", "f6_block_diag") else chains.LegacyRng
+            rng_cls = chains.LegacyRng3 if name in ("c5_ia", "f3_ia_iterative", "f3b_ia_svd_init", "f3c_ia_general", "f6_block_diag") else chains.LegacyRng
             mine = CHAIN_FN[name](rng_cls(int(g["seed"])), **kw)
             for k, v in g.items():
                 if k == "seed":
@@ -115,7 +115,7 @@ def test_chain_matches_reference(name):
                 if k in INT_KEYS:
                     assert np.array_equal(np.asarray(mine[k]), np.asarray(v)), (name, k)
                 else:
-                    tol = 1e-7 if name in ("f3_ia_iterative", "f3b_ia_svd_init") else (1e-9 if name in ("c5_ia", "f1_mimo_ofdm_tdl", "f5_mimo_schemes", "f6_block_diag") else 1e-12)
+                    tol = 1e-7 if name in ("f3_ia_iterative", "f3b_ia_svd_init", "f3c_ia_general") else (1e-9 if name in ("c5_ia", "f1_mimo_ofdm_tdl", "f5_mimo_schemes", "f6_block_diag") else 1e-12)
                     assert relerr(mine[k], v) <= tol, (name, k)
 
 
