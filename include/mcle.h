@@ -380,6 +380,29 @@ int mcle_ia_iterative(mcle_ctx* ctx, int solver, int initialize_with, const void
                       void* d_F, void* d_U, double* d_sinr, double* d_capacity, uint32_t* d_iterations,
                       uint32_t* d_skipped, size_t batch);
 
+/* ---- block diagonalisation with external interference (comm/blockdiagonalization.py:666-1469): WhiteningBD
+ *      (:722-836: whiten every user's rows with the interference-plus-noise covariance, block-diagonalise, receive
+ *      filter = pinv(newH) x whitening filter) and EnhancedBD (:839-1469: BD directions, then per user a stream
+ *      reduction onto the directions least hit by the external interference; number of streams fixed ('naive',
+ *      'fixed') or chosen per user by a metric).  The channel is MultiUserChannelMatrixExtInt.big_H
+ *      (channels/multiuser.py:2011-2520): d_bigH [batch][K r][K r + n_ext], the last n_ext columns being the
+ *      interferers' antennas; covariance = pe H_ext H_ext^H + noise_var I (:2469-2520).
+ *      Outputs, zero padded: d_Ms [batch][K][K r][r] (user k's precoder MsPk, K r x Ns), d_W [batch][K][r][r]
+ *      (receive filter, Ns x r), d_ns [batch][K]; d_cand_sinr [batch][K][r][r] (metric 4 only: row ns-1 = the
+ *      post-filter SINRs with ns streams, EnhancedBD._calc_linear_SINRs :1101-1138, for caller-side metrics such
+ *      as 'effective_throughput').  Singular-vector phases are ours (see mcle_block_diagonalize). */
+typedef struct mcle_bd_extint_cfg {
+    int32_t num_users, n_ant_per_user, n_ext;
+    int32_t method;             /* 0: WhiteningBD, 1: EnhancedBD */
+    int32_t metric;             /* EnhancedBD: 0 None, 1 'naive', 2 'fixed', 3 'capacity', 4 report candidate SINRs,
+                                   5 stream counts given per user (ns_user) */
+    int32_t num_streams;        /* 'naive' / 'fixed' */
+    int32_t ns_user[4];
+    double iPu, noise_var, pe;
+} mcle_bd_extint_cfg;
+int mcle_bd_extint(mcle_ctx* ctx, const mcle_bd_extint_cfg* cfg, const void* d_bigH, void* d_Ms, void* d_W,
+                   int32_t* d_ns, double* d_cand_sinr, uint32_t* d_skipped, size_t batch);
+
 /* ---- iterative interference alignment for general geometries (SURVEY 8(f).3 tail): K <= 4 users with
  *      Nr x Nt <= 4 x 4 antennas each and per-user stream counts; AlternatingMinIASolver / MinLeakageIASolver /
  *      MaxSinrIASolver .solve (ia/algorithms.py:802-883, 885-1507) from injected precoders ('fix') or the 'svd'

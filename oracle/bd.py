@@ -173,3 +173,120 @@ def block_diagonalize_closed(H, K, iPu, noise_var, waterfill=True):
             if n2 > 0.0:
                 W[j, k * r:(k + 1) * r] = np.conj(b) / n2
     return newH, Ms, W
+
+
+# ---------------------------------------------------------------------------------------------
+# block diagonalisation with external interference (comm/blockdiagonalization.py:666-1469)
+#   BDWithExtIntBase.calc_whitening_matrices :690-720, WhiteningBD :722-836, EnhancedBD :839-1469
+#   channels/multiuser.py:2469-2520 calc_cov_matrix_extint_(without|plus)_noise
+#   util/misc.py:1167-1200 calc_whitening_matrix, subspace/projections.py:96-130 calcProjectionMatrix
+# A channel with external interference is the plain multi-user channel plus extra COLUMNS (the interferers'
+# antennas): big_H = [big_H_no_ext_int | H_ext].
+# ---------------------------------------------------------------------------------------------
+def cov_extint_plus_noise(big_H, K, nr, n_tx_total, pe, noise_var):
+    """R_k = pe H_ext,k H_ext,k^H + noise_var I for every user (multiuser.py:2469-2520)."""
+    out = []
+    for k in range(K):
+        ext = big_H[k * nr:(k + 1) * nr, n_tx_total:]
+        R = pe * ext @ ext.conj().T
+        if noise_var is not None:
+            R = R + np.eye(nr) * noise_var
+        out.append(R)
+    return out
+
+
+def whitening_matrix(cov):
+    """misc.py:1167-1200: W = V diag(L^-1/2) from eig(cov); W^H cov W = I."""
+    L, V = np.linalg.eig(cov)
+    return V @ np.diag(1.0 / (L ** 0.5))
+
+
+def whitening_bd(big_H, K, nr, nt, iPu, noise_var, pe):
+    """WhiteningBD.block_diagonalize_no_waterfilling (:781-836) -> (Ms per user [K nt, nt], W per user [nt.., nr])."""
+    n_tx = K * nt
+    H = big_H[:, :n_tx]
+    R = cov_extint_plus_noise(big_H, K, nr, n_tx, pe, noise_var)
+    from scipy.linalg import block_diag
+    big_wf = block_diag(*[whitening_matrix(R[k]).conj().T for k in range(K)])
+    newH, Ms = block_diagonalize_no_waterfilling(big_wf @ H, K, iPu)
+    big_W = calc_receive_filter(newH) @ big_wf
+    Ms_k = [Ms[:, k * nt:(k + 1) * nt] for k in range(K)]
+    W_k = [big_W[k * nt:(k + 1) * nt, k * nr:(k + 1) * nr] for k in range(K)]
+    return Ms_k, W_k, [nt] * K
+
+
+def projection_matrix(A):
+    Ah = A.conj().T
+    return A @ np.linalg.inv(Ah @ A) @ Ah
+
+
+def stream_reduction_matrix(Re_k, kept):
+    """:120-145: the `kept` right singular vectors of Re_k with the SMALLEST singular values."""
+    return least_right_singular_vectors(Re_k, kept)[0]
+
+
+def ebd_receive_filter(Heq_red, P=None):
+    """EnhancedBD.calc_receive_filter_user_k (:1056-1099)."""
+    if P is None:
+        return np.linalg.pinv(Heq_red)
+    Pb = projection_matrix(P)
+    return np.linalg.pinv(Pb @ Heq_red) @ Pb
+
+
+def ebd_linear_sinrs(Heq_red, W, Re_k):
+    """EnhancedBD._calc_linear_SINRs (:1101-1138)."""
+    mtP = W @ Heq_red
+    desired = np.abs(np.diagonal(mtP)) ** 2
+    internal = np.sum(np.abs(mtP - np.diagflat(np.diagonal(mtP))) ** 2, 1)
+    ext = np.diagonal(W @ Re_k @ W.conj().T).real
+    return desired / (internal + np.abs(ext))
+
+
+def enhanced_bd(big_H, K, nr, nt, iPu, noise_var, pe, metric=None, num_streams=None, metric_func=None, Ms_bad=None):
+    """EnhancedBD.block_diagonalize_no_waterfilling (:1413-1469) for metric in (None, 'naive', 'fixed', 'capacity',
+    'effective_throughput' [metric_func(sinrs) supplied by the caller]).
+    -> (MsPk per user [K nt, Ns_k], W per user [Ns_k, nr], Ns per user).
+    Ms_bad: the unit-norm BD directions to reduce (default: the reference's own, from numpy's SVDs).  The reduction
+    MsPk = Ms_k Pk mixes the COLUMNS of Ms_k, whose phases are whatever the SVD returned -- so a stream-reduced
+    solution is only defined relative to a particular Ms_bad (true of the reference itself, which inherits LAPACK's
+    phases); tests hand the kernel's Ms_bad in here to pin the reduction arithmetic."""
+    n_tx = K * nt
+    H = big_H[:, :n_tx]
+    if metric is None:
+        newH, Ms = block_diagonalize_no_waterfilling(H, K, iPu)
+        Ms_k = [Ms[:, k * nt:(k + 1) * nt] for k in range(K)]
+        W_k = [np.linalg.pinv(newH[k * nr:(k + 1) * nr, k * nt:(k + 1) * nt]) for k in range(K)]
+        return Ms_k, W_k, [nt] * K
+    Re = cov_extint_plus_noise(big_H, K, nr, n_tx, pe, noise_var)
+    if Ms_bad is None:
+        Ms_bad, _ = bd_no_power_scaling(H, K)
+    Ms_out, W_out, Ns_out = [], [], []
+    for k in range(K):
+        Msk = Ms_bad[:, k * nt:(k + 1) * nt]
+        Heq = H[k * nr:(k + 1) * nr, :] @ Msk
+        if metric in ('naive', 'fixed'):
+            cands = [num_streams]
+        else:
+            cands = list(range(1, nt + 1))
+        best = None
+        for ns in cands:
+            if metric == 'naive':
+                Pk = np.eye(nt)[:, 0:ns]
+            elif metric == 'fixed' or ns < nt:
+                Pk = stream_reduction_matrix(Re[k], ns)
+            else:
+                Pk = np.eye(nt)
+            norm_term = np.linalg.norm(Msk @ Pk, 'fro') / np.sqrt(iPu)
+            Heq_red = Heq @ (Pk / norm_term)
+            W = ebd_receive_filter(Heq_red, Pk)
+            if metric in ('naive', 'fixed'):
+                value = 0.0
+            else:
+                sinrs = ebd_linear_sinrs(Heq_red, W, Re[k])
+                value = float(np.sum(np.log2(1 + sinrs))) if metric == 'capacity' else float(metric_func(sinrs))
+            if best is None or value > best[0]:                 # np.argmax: first maximum
+                best = (value, Msk @ Pk / norm_term, W, Pk.shape[1])
+        Ms_out.append(best[1])
+        W_out.append(best[2])
+        Ns_out.append(best[3])
+    return Ms_out, W_out, Ns_out

@@ -221,6 +221,62 @@ def golden_operators():
 
 
 
+def golden_bd_extint():
+    """tests/golden/f6b_bd_extint.npz: WhiteningBD and EnhancedBD (every metric) of the reference on seeded
+    MultiUserChannelMatrixExtInt channels, with the oracle (oracle/bd.py) asserted equal first.  Stored per case:
+    big_H and the phase-free invariants of the solution (Ms Ms^H, W^H W, the equivalent channel W H_k MsPk, Ns)."""
+    from pyphysim.channels import multiuser as rmu
+    from pyphysim.comm import blockdiagonalization as rbd
+    from oracle import bd as obd
+    cases = [dict(K=3, r=2, next=(2,), iPu=1.5, nv=0.01, pe=0.7), dict(K=2, r=3, next=(1, 2), iPu=1.0, nv=0.05, pe=1.3),
+             dict(K=2, r=4, next=(4,), iPu=2.0, nv=0.02, pe=0.5), dict(K=4, r=2, next=(1,), iPu=1.0, nv=0.1, pe=2.0)]
+    mod = rmod.QAM(16)
+    store, worst = {}, 0.0
+    for ci, c in enumerate(cases):
+        K, r, nv = c["K"], c["r"], c["nv"]
+        muc = rmu.MultiUserChannelMatrixExtInt()
+        muc.set_channel_seed(BASE_SEED + 50 + ci)
+        muc.randomize(r, r, K, np.array(c["next"]))
+        muc.noise_var = nv
+        big_H = np.array(muc.big_H)
+        store["case%d_big_H" % ci] = big_H
+        store["case%d_cfg" % ci] = np.array([K, r, int(np.sum(c["next"]))], dtype=np.int64)
+        store["case%d_par" % ci] = np.array([c["iPu"], nv, c["pe"]])
+        variants = [("whitening", None, None), ("enhanced", None, None), ("enhanced", "naive", 1), ("enhanced", "fixed", 1),
+                    ("enhanced", "capacity", None), ("enhanced", "effective_throughput", None)]
+        if r > 2:
+            variants.append(("enhanced", "fixed", 2))
+        for vi, (method, metric, ns) in enumerate(variants):
+            if method == "whitening":
+                sol = rbd.WhiteningBD(K, c["iPu"], nv, c["pe"]).block_diagonalize_no_waterfilling(muc)
+                mine = obd.whitening_bd(big_H, K, r, r, c["iPu"], nv, c["pe"])
+            else:
+                e = rbd.EnhancedBD(K, c["iPu"], nv, c["pe"])
+                extra = {"num_streams": ns} if metric in ("naive", "fixed") else (
+                    {"modulator": mod, "packet_length": 120} if metric == "effective_throughput" else None)
+                e.set_ext_int_handling_metric(metric, extra)
+                sol = e.block_diagonalize_no_waterfilling(muc)
+                mf = (lambda s: rbd._calc_effective_throughput(s, mod, 120)) if metric == "effective_throughput" else None
+                mine = obd.enhanced_bd(big_H, K, r, r, c["iPu"], nv, c["pe"], metric, ns, mf)
+            Ms, W, Ns = sol
+            assert [int(n) for n in Ns] == [int(n) for n in mine[2]], (ci, method, metric)
+            tag = "case%d_v%d_" % (ci, vi)
+            store[tag + "name"] = np.array("%s/%s/%s" % (method, metric, ns))
+            store[tag + "Ns"] = np.array([int(n) for n in Ns], dtype=np.int64)
+            for k in range(K):
+                Hk = big_H[k * r:(k + 1) * r, :K * r]
+                inv = dict(PM=np.asarray(Ms[k]) @ np.asarray(Ms[k]).conj().T, PW=np.asarray(W[k]).conj().T @ np.asarray(W[k]),
+                           EQ=np.abs(np.asarray(W[k]) @ Hk @ np.asarray(Ms[k])))
+                oinv = dict(PM=mine[0][k] @ mine[0][k].conj().T, PW=mine[1][k].conj().T @ mine[1][k],
+                            EQ=np.abs(mine[1][k] @ Hk @ mine[0][k]))
+                for name in inv:
+                    worst = max(worst, close(oinv[name], inv[name], 1e-9, "bd extint %s %s" % (tag, name)))
+                    store[tag + "u%d_%s" % (k, name)] = inv[name]
+    store["n_cases"] = np.int64(len(cases))
+    np.savez_compressed(os.path.join(GOLD, "f6b_bd_extint.npz"), **store)
+    print("f6b_bd_extint: oracle == reference on %d channels x 6-7 variants (worst %.2e)" % (len(cases), worst))
+
+
 # ----------------------------------------------------------------------------- chains
 def ref_chain_awgn(seed, mod, M, N, snr_db):
     np.random.seed(seed)
@@ -730,6 +786,11 @@ if __name__ == "__main__":
     only = set(sys.argv[1:])          # e.g. `make_golden.py f6_block_diag` regenerates one fixture
     if not only or "operators" in only:
         golden_operators()
+    if not only or "f6b_bd_extint" in only:
+        golden_bd_extint()
+    only = only - {"f6b_bd_extint"} if only else only
+    if only == set() and "f6b_bd_extint" in sys.argv[1:]:
+        sys.exit(0)
     if not only or only - {"operators"}:
         golden_chains(only - {"operators"})
     for f in sorted(os.listdir(GOLD)):

@@ -91,6 +91,15 @@ class BdCfg(Structure):
                 ("bd_noise_var", c_double), ("pathloss", c_double * 16)]
 
 
+class BdExtIntCfg(Structure):
+    _fields_ = [("num_users", c_int32), ("n_ant_per_user", c_int32), ("n_ext", c_int32), ("method", c_int32),
+                ("metric", c_int32), ("num_streams", c_int32), ("ns_user", c_int32 * 4), ("iPu", c_double),
+                ("noise_var", c_double), ("pe", c_double)]
+
+
+BD_METRICS = {None: 0, "None": 0, "naive": 1, "fixed": 2, "capacity": 3, "candidates": 4, "per_user": 5}
+
+
 class IaGeneralCfg(Structure):
     _fields_ = [("K", c_int32), ("nr", c_int32), ("nt", c_int32), ("ns", c_int32 * 4), ("solver", c_int32),
                 ("initialize_with", c_int32), ("max_iterations", c_int32), ("stream_selection", c_int32),
@@ -172,6 +181,7 @@ _PROTOS = {
     "mcle_mrt_decode": (c_int, [_P, c_int, _P, _P, c_int, c_size_t, _P, c_size_t]),
     "mcle_svd_filters": (c_int, [_P, c_int, _P, c_int, _P, _P, _P, c_size_t]),
     "mcle_gmd_filters": (c_int, [_P, c_int, _P, c_int, c_double, _P, _P, _P, _P, c_size_t]),
+    "mcle_bd_extint": (c_int, [_P, POINTER(BdExtIntCfg), _P, _P, _P, _P, _P, _P, c_size_t]),
     "mcle_ia_solve_general": (c_int, [_P, POINTER(IaGeneralCfg), _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t]),
     "mcle_post_processing_sinrs": (c_int, [_P, _P, _P, _P, c_double, c_int, c_int, c_int, _P, c_size_t]),
     "mcle_run_awgn": (c_int, [_P, c_int, POINTER(AwgnCfg), c_uint64, c_uint64, c_uint64, _P, _P, _P]),

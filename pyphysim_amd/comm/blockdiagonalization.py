@@ -5,13 +5,14 @@ reference's names, arguments and errors (comm/blockdiagonalization.py:62-118, 18
 The precoder's columns are singular vectors, unique up to one phase per stream; the kernels return the
 representative whose largest entry per column is real and positive, the reference returns LAPACK's.  Every
 quantity the reference's tests pin (block-diagonal newH, power constraints, W newH = I, singular values)
-is the same; so are error statistics.  The variants with external-interference handling (WhiteningBD,
-EnhancedBD) are not part of this build."""
+is the same; so are error statistics.  `WhiteningBD` and `EnhancedBD` (external-interference handling,
+blockdiagonalization.py:666-1469) take a `multiuser.MultiUserChannelMatrixExtInt` and run `k_bd_extint`."""
 import numpy as np
 
 from ..engine import get_engine
 
-__all__ = ["block_diagonalize", "calc_receive_filter", "BlockDiagonalizer"]
+__all__ = ["block_diagonalize", "calc_receive_filter", "BlockDiagonalizer", "BDWithExtIntBase", "WhiteningBD",
+           "EnhancedBD"]
 
 
 def block_diagonalize(mtChannel, num_users, iPu, noise_var, engine=None):
@@ -87,3 +88,112 @@ class BlockDiagonalizer:
     def calc_receive_filter(newH, engine=None):
         eng = engine if engine is not None else get_engine()
         return eng.pinv(np.asarray(newH))
+
+
+
+class BDWithExtIntBase(BlockDiagonalizer):
+    """blockdiagonalization.py:666-720."""
+
+    def __init__(self, num_users, iPu, noise_var, pe, engine=None):
+        super().__init__(num_users, iPu, noise_var, engine=engine)
+        self.pe = pe
+
+    def _geometry(self, mu_channel):
+        K = int(mu_channel.K)
+        Nr, Nt = [int(v) for v in mu_channel.Nr], [int(v) for v in mu_channel.Nt]
+        if K != self.num_users or len(set(Nr + Nt)) != 1:
+            raise NotImplementedError("the external-interference kernels cover the same number of antennas on both "
+                                      "sides of every user (got Nr = %s, Nt = %s)" % (Nr, Nt))
+        return K, Nr[0], int(np.sum(mu_channel.extIntNt))
+
+    def _run(self, mu_channel, method, metric=None, num_streams=0, ns_user=None):
+        K, r, n_ext = self._geometry(mu_channel)
+        out = self.engine.bd_extint(np.asarray(mu_channel.big_H), K, r, n_ext, self.iPu, mu_channel.noise_var,
+                                    self.pe, method, metric, num_streams, ns_user)
+        if out["skipped"][0]:
+            raise np.linalg.LinAlgError("Singular matrix")
+        return out, K, r
+
+    @staticmethod
+    def _unpack(out, K, r):
+        ns = [int(n) for n in out["Ns"][0]]
+        obj = lambda items: np.array(list(items) + [None], dtype=object)[:-1]
+        return (obj(np.array(out["Ms"][0, k][:, :ns[k]]) for k in range(K)),
+                obj(np.array(out["W"][0, k][:ns[k], :]) for k in range(K)), np.array(ns, dtype=int))
+
+    def calc_whitening_matrices(self, mu_channel):
+        """:690-720: W_k^H with W_k = V diag(L^-1/2) of eig(R_k) (util/misc.py:1167-1200); any such factor whitens
+        (W_k^H R_k W_k = I) -- the eigenvector phases are NumPy's here, computed on the host from the covariances."""
+        R = mu_channel.calc_cov_matrix_extint_plus_noise(self.pe)
+        out = []
+        for k in range(int(mu_channel.K)):
+            L, V = np.linalg.eigh(R[k])
+            out.append((V @ np.diag(1.0 / np.sqrt(L))).conj().T)
+        return out
+
+
+class WhiteningBD(BDWithExtIntBase):
+    """blockdiagonalization.py:722-836."""
+
+    def block_diagonalize_no_waterfilling(self, mu_channel):
+        """-> (Ms_all_users, Wk_all_users, Ns_all_users)."""
+        out, K, r = self._run(mu_channel, "whitening")
+        return self._unpack(out, K, r)
+
+
+class EnhancedBD(BDWithExtIntBase):
+    """blockdiagonalization.py:839-1469."""
+
+    def __init__(self, num_users, iPu, noise_var, pe, engine=None):
+        super().__init__(num_users, iPu, noise_var, pe, engine=engine)
+        self._metric_func_name = "None"
+        self._metric_func_extra_args = {}
+
+    metric_name = property(lambda self: self._metric_func_name)
+
+    def set_ext_int_handling_metric(self, metric, metric_func_extra_args_dict=None):
+        """:887-1042, the reference's messages."""
+        extra = metric_func_extra_args_dict or {}
+        if metric is None or metric == "None":
+            self._metric_func_name, self._metric_func_extra_args = "None", {}
+        elif metric == "capacity":
+            self._metric_func_name, self._metric_func_extra_args = "capacity", {}
+        elif metric in ("naive", "fixed"):
+            if "num_streams" not in extra:
+                raise AttributeError("The '%s' metric requires that metric_func_extra_args_dict is provided and has "
+                                     "the 'num_streams' key" % metric)
+            self._metric_func_name, self._metric_func_extra_args = metric, {"num_streams": extra["num_streams"]}
+        elif metric == "effective_throughput":
+            if "modulator" not in extra or "packet_length" not in extra:
+                raise AttributeError("The 'effective_throughput' metric requires that metric_func_extra_args_dict is "
+                                     "provided and has the 'modulator' and package_length' keys")
+            self._metric_func_name = "effective_throughput"
+            self._metric_func_extra_args = {k: extra[k] for k in ("modulator", "packet_length")}
+        else:
+            raise AttributeError("The `metric` attribute can only be one of {None, 'capacity', "
+                                 "'effective_throughput'}")
+
+    def block_diagonalize_no_waterfilling(self, mu_channel):
+        """:1413-1469 -> (MsPk_all_users, Wk_all_users, Ns_all_users)."""
+        name = self._metric_func_name
+        if name == "None":
+            out, K, r = self._run(mu_channel, "enhanced", None)
+        elif name in ("naive", "fixed"):
+            out, K, r = self._run(mu_channel, "enhanced", name, self._metric_func_extra_args["num_streams"])
+        elif name == "capacity":
+            out, K, r = self._run(mu_channel, "enhanced", "capacity")
+        else:
+            # effective throughput (:147-180 _calc_effective_throughput): the kernel reports the post-filter SINRs of
+            # every stream count, the modulator's theoretical spectral efficiency picks one per user (np.argmax: the
+            # first maximum), a second launch builds that solution
+            cand, K, r = self._run(mu_channel, "enhanced", "candidates")
+            mod, plen = self._metric_func_extra_args["modulator"], self._metric_func_extra_args["packet_length"]
+            ns_user = []
+            for k in range(K):
+                vals = []
+                for ns in range(1, r + 1):
+                    sinrs = cand["cand_sinr"][0, k, ns - 1, :ns]
+                    vals.append(float(np.sum(mod.calcTheoreticalSpectralEfficiency(10.0 * np.log10(sinrs), plen))))
+                ns_user.append(int(np.argmax(vals)) + 1)
+            out, K, r = self._run(mu_channel, "enhanced", "per_user", ns_user=ns_user)
+        return self._unpack(out, K, r)

@@ -320,6 +320,261 @@ __global__ __launch_bounds__(64) void k_pinv(const cd* __restrict__ Ain, int m, 
     }
 }
 
+// ---- block diagonalisation with external interference (blockdiagonalization.py:666-1469) --------------------------
+// BDWithExtIntBase.calc_whitening_matrices :690-720, WhiteningBD :722-836, EnhancedBD :839-1469;
+// channels/multiuser.py:2469-2520 calc_cov_matrix_extint_plus_noise; util/misc.py:1167-1200 calc_whitening_matrix;
+// subspace/projections.py:96-130 calcProjectionMatrix.  One lane per channel realization, f64.
+struct BdExtParams {
+    int K, r, n_ext;        // users, antennas per user (both sides), total antennas of the external interferers
+    int method;             // 0: WhiteningBD, 1: EnhancedBD
+    int metric;             // EnhancedBD: 0 None, 1 'naive', 2 'fixed', 3 'capacity', 4 report the SINRs of every stream
+                            // count (caller-side metrics such as 'effective_throughput'), 5 stream counts given per user
+    int num_streams;        // 'naive' / 'fixed'
+    int ns_user[4];         // metric 5
+    double iPu, nv, pe;
+};
+
+// eigen-decomposition of a Hermitian positive semi-definite R [r x r] by one-sided Jacobi on its columns:
+// w ascending, eigenvectors in the columns of V (R V = V diag(w)); largest component of each vector real positive
+__device__ __noinline__ void bd_heig_psd(const cd* R, int r, double* w, cd* V) {
+    cd A[kBdMaxR * kBdMaxR], Vt[kBdMaxR * kBdMaxR];
+    for (int e = 0; e < r * r; ++e) A[e] = R[e];
+    bd_jacobi(A, r, r, Vt);
+    double val[kBdMaxR];
+    int ord[kBdMaxR];
+    for (int c = 0; c < r; ++c) {
+        double n2 = 0.0;
+        for (int i = 0; i < r; ++i) n2 += bd_abs2(A[i * r + c]);
+        val[c] = sqrt(n2);
+        ord[c] = c;
+    }
+    for (int i = 0; i < r - 1; ++i)
+        for (int j = i + 1; j < r; ++j)
+            if (val[ord[j]] < val[ord[i]]) {
+                const int t = ord[i];
+                ord[i] = ord[j];
+                ord[j] = t;
+            }
+    for (int c = 0; c < r; ++c) {
+        w[c] = val[ord[c]];
+        double best = -1.0;
+        cd piv = mk<double>(1.0, 0.0);
+        for (int i = 0; i < r; ++i) {
+            const cd v = Vt[i * r + ord[c]];
+            if (bd_abs2(v) > best * (1.0 + 1e-12)) {
+                best = bd_abs2(v);
+                piv = v;
+            }
+        }
+        const double pm = sqrt(bd_abs2(piv));
+        const cd rot = mk<double>(piv.x / pm, -piv.y / pm);
+        for (int i = 0; i < r; ++i) V[i * r + c] = cmul(Vt[i * r + ord[c]], rot);
+    }
+}
+
+// out [n x m] = pinv(A [m x n]) (numpy's cut-off); the k_pinv arithmetic as a device function
+__device__ __noinline__ void bd_pinv_small(const cd* Ain, int m, int n, cd* out) {
+    cd A[kBdMaxR * kBdMaxR], V[kBdMaxR * kBdMaxR];
+    double s2[kBdMaxR];
+    for (int e = 0; e < m * n; ++e) A[e] = Ain[e];
+    bd_jacobi(A, m, n, V);
+    double top = 0.0;
+    for (int c = 0; c < n; ++c) {
+        double v = 0.0;
+        for (int i = 0; i < m; ++i) v += bd_abs2(A[i * n + c]);
+        s2[c] = v;
+        top = fmax(top, v);
+    }
+    const double cut = 1e-30 * top;
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < m; ++j) {
+            cd acc = mk<double>(0, 0);
+            for (int c = 0; c < n; ++c)
+                if (s2[c] > cut && s2[c] > 0.0) acc = cadd(acc, cscale(cmulc(V[i * n + c], A[j * n + c]), 1.0 / s2[c]));
+            out[i * m + j] = acc;
+        }
+}
+
+// Outputs per realization b and user k, zero padded: Ms [b][K][n][r] (the user's precoder MsPk: n x Ns),
+// W [b][K][r][r] (receive filter, Ns x r), Ns [b][K], cand [b][K][r][r] (metric 4: row ns-1 = the SINRs with ns streams)
+__global__ __launch_bounds__(64) void k_bd_extint(BdExtParams pp, const cd* __restrict__ bigH, cd* __restrict__ Ms_out,
+                                                  cd* __restrict__ W_out, int32_t* __restrict__ ns_out,
+                                                  double* __restrict__ cand_out, uint32_t* __restrict__ skipped,
+                                                  size_t batch) {
+    const int K = pp.K, r = pp.r, n = K * r, cols = n + pp.n_ext;
+    for (size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x; b < batch; b += (size_t)gridDim.x * blockDim.x) {
+        const cd* Hb = bigH + b * (size_t)n * cols;
+        cd H[kBdMaxN * kBdMaxN], Q[kBdMaxN * kBdMaxN], L[kBdMaxN * kBdMaxN], Ms[kBdMaxN * kBdMaxN];
+        double sigma[kBdMaxN];
+        bool ok = true;
+        for (int i = 0; i < n; ++i)
+            for (int c = 0; c < n; ++c) H[i * n + c] = Hb[(size_t)i * cols + c];
+        auto cov = [&](int k, cd* Re) {       // Re_k = pe H_ext,k H_ext,k^H + nv I
+            for (int i = 0; i < r; ++i)
+                for (int j = 0; j < r; ++j) {
+                    cd acc = mk<double>(0, 0);
+                    for (int e = 0; e < pp.n_ext; ++e)
+                        acc = cadd(acc, cmulc(Hb[(size_t)(k * r + i) * cols + n + e], Hb[(size_t)(k * r + j) * cols + n + e]));
+                    acc = cscale(acc, pp.pe);
+                    if (i == j) acc.x += pp.nv;
+                    Re[i * r + j] = acc;
+                }
+        };
+        auto emit = [&](int k, const cd* MsPk, const cd* W, int ns) {     // MsPk [n x ns], W [ns x r]
+            cd* mo = Ms_out + ((b * K + k) * (size_t)n) * r;
+            cd* wo = W_out + ((b * K + k) * (size_t)r) * r;
+            for (int m = 0; m < n; ++m)
+                for (int c = 0; c < r; ++c) mo[m * r + c] = c < ns ? MsPk[m * ns + c] : mk<double>(0, 0);
+            for (int i = 0; i < r; ++i)
+                for (int c = 0; c < r; ++c) wo[i * r + c] = i < ns ? W[i * r + c] : mk<double>(0, 0);
+            if (ns_out) ns_out[b * K + k] = ns;
+        };
+        if (pp.method == 0) {
+            // WhiteningBD: whiten every user's rows with W_k^H = diag(L^-1/2) V^H of eig(Re_k), block-diagonalise the
+            // whitened channel, receive filter = pinv(newH) x whitening filter (:781-836)
+            cd Wf[4][kBdMaxR * kBdMaxR];
+            cd Heq[kBdMaxN * kBdMaxN];
+            for (int k = 0; k < K; ++k) {
+                cd Re[kBdMaxR * kBdMaxR], V[kBdMaxR * kBdMaxR];
+                double w[kBdMaxR];
+                cov(k, Re);
+                bd_heig_psd(Re, r, w, V);
+                for (int i = 0; i < r; ++i) {
+                    ok = ok && w[i] > 0.0;
+                    const double s = 1.0 / sqrt(w[i] > 0.0 ? w[i] : 1.0);
+                    for (int j = 0; j < r; ++j) Wf[k][i * r + j] = cscale(cconj(V[j * r + i]), s);
+                }
+                for (int i = 0; i < r; ++i)
+                    for (int c = 0; c < n; ++c) {
+                        cd acc = mk<double>(0, 0);
+                        for (int j = 0; j < r; ++j) acc = cadd(acc, cmul(Wf[k][i * r + j], H[(k * r + j) * n + c]));
+                        Heq[(k * r + i) * n + c] = acc;
+                    }
+            }
+            ok = bd_solve(Heq, K, r, pp.iPu, pp.nv, 0, Q, L, Ms, sigma) && ok;
+            bd_receive_filter(Heq, Ms, K, r, Q);                 // pinv(newH), block diagonal
+            for (int k = 0; k < K; ++k) {
+                cd MsPk[kBdMaxN * kBdMaxR], W[kBdMaxR * kBdMaxR];
+                for (int m = 0; m < n; ++m)
+                    for (int c = 0; c < r; ++c) MsPk[m * r + c] = Ms[m * n + k * r + c];
+                for (int i = 0; i < r; ++i)
+                    for (int c = 0; c < r; ++c) {
+                        cd acc = mk<double>(0, 0);
+                        for (int j = 0; j < r; ++j) acc = cadd(acc, cmul(Q[(k * r + i) * n + k * r + j], Wf[k][j * r + c]));
+                        W[i * r + c] = acc;
+                    }
+                emit(k, MsPk, W, r);
+            }
+        } else if (pp.metric == 0) {
+            // EnhancedBD without a metric: plain BD, every user inverts its own block (:1140-1195)
+            ok = bd_solve(H, K, r, pp.iPu, pp.nv, 0, Q, L, Ms, sigma);
+            bd_receive_filter(H, Ms, K, r, Q);
+            for (int k = 0; k < K; ++k) {
+                cd MsPk[kBdMaxN * kBdMaxR], W[kBdMaxR * kBdMaxR];
+                for (int m = 0; m < n; ++m)
+                    for (int c = 0; c < r; ++c) MsPk[m * r + c] = Ms[m * n + k * r + c];
+                for (int i = 0; i < r; ++i)
+                    for (int c = 0; c < r; ++c) W[i * r + c] = Q[(k * r + i) * n + k * r + c];
+                emit(k, MsPk, W, r);
+            }
+        } else {
+            // EnhancedBD with stream reduction (:1197-1411): unit-norm BD directions Ms_bad, then per user a reduction
+            // matrix Pk onto the directions least hit by the external interference, power renormalised, receive filter
+            // pinv(Pbar Heq_red) Pbar with Pbar the projector onto span(Pk)
+            ok = bd_solve(H, K, r, (double)r, pp.nv, 0, Q, L, Ms, sigma);
+            for (int k = 0; k < K; ++k) {
+                cd Re[kBdMaxR * kBdMaxR], V[kBdMaxR * kBdMaxR], Heq[kBdMaxR * kBdMaxR];
+                double w[kBdMaxR];
+                cov(k, Re);
+                bd_heig_psd(Re, r, w, V);                        // ascending: column 0 = least interfered direction
+                for (int i = 0; i < r; ++i)
+                    for (int c = 0; c < r; ++c) {
+                        cd acc = mk<double>(0, 0);
+                        for (int m = 0; m < n; ++m) acc = cadd(acc, cmul(H[(k * r + i) * n + m], Ms[m * n + k * r + c]));
+                        Heq[i * r + c] = acc;
+                    }
+                int lo = 1, hi = r;
+                if (pp.metric == 1 || pp.metric == 2) lo = hi = pp.num_streams;
+                if (pp.metric == 5) lo = hi = pp.ns_user[k];
+                double best_val = -1e300;
+                int best_ns = 0;
+                cd best_Ms[kBdMaxN * kBdMaxR], best_W[kBdMaxR * kBdMaxR];
+                for (int ns = lo; ns <= hi; ++ns) {
+                    cd Pk[kBdMaxR * kBdMaxR];                    // r x ns
+                    const bool identity = pp.metric == 1 || (pp.metric != 2 && ns == r);
+                    for (int i = 0; i < r; ++i)
+                        for (int c = 0; c < ns; ++c)
+                            Pk[i * ns + c] = identity ? mk<double>(i == c ? 1.0 : 0.0, 0.0) : V[i * r + c];
+                    cd MsPk[kBdMaxN * kBdMaxR];
+                    double f2 = 0.0;
+                    for (int m = 0; m < n; ++m)
+                        for (int c = 0; c < ns; ++c) {
+                            cd acc = mk<double>(0, 0);
+                            for (int j = 0; j < r; ++j) acc = cadd(acc, cmul(Ms[m * n + k * r + j], Pk[j * ns + c]));
+                            MsPk[m * ns + c] = acc;
+                            f2 += bd_abs2(acc);
+                        }
+                    const double inv_norm = sqrt(pp.iPu) / sqrt(f2);
+                    for (int e = 0; e < n * ns; ++e) MsPk[e] = cscale(MsPk[e], inv_norm);
+                    cd Hred[kBdMaxR * kBdMaxR], Pbar[kBdMaxR * kBdMaxR], PH[kBdMaxR * kBdMaxR], Pi[kBdMaxR * kBdMaxR];
+                    for (int i = 0; i < r; ++i)
+                        for (int c = 0; c < ns; ++c) {
+                            cd acc = mk<double>(0, 0);
+                            for (int j = 0; j < r; ++j) acc = cadd(acc, cmul(Heq[i * r + j], Pk[j * ns + c]));
+                            Hred[i * ns + c] = cscale(acc, inv_norm);
+                        }
+                    for (int i = 0; i < r; ++i)                  // Pk has orthonormal columns: Pbar = Pk Pk^H
+                        for (int j = 0; j < r; ++j) {
+                            cd acc = mk<double>(0, 0);
+                            for (int c = 0; c < ns; ++c) acc = cadd(acc, cmulc(Pk[i * ns + c], Pk[j * ns + c]));
+                            Pbar[i * r + j] = acc;
+                        }
+                    for (int i = 0; i < r; ++i)
+                        for (int c = 0; c < ns; ++c) {
+                            cd acc = mk<double>(0, 0);
+                            for (int j = 0; j < r; ++j) acc = cadd(acc, cmul(Pbar[i * r + j], Hred[j * ns + c]));
+                            PH[i * ns + c] = acc;
+                        }
+                    bd_pinv_small(PH, r, ns, Pi);                // ns x r
+                    cd W[kBdMaxR * kBdMaxR];
+                    for (int i = 0; i < ns; ++i)
+                        for (int c = 0; c < r; ++c) {
+                            cd acc = mk<double>(0, 0);
+                            for (int j = 0; j < r; ++j) acc = cadd(acc, cmul(Pi[i * r + j], Pbar[j * r + c]));
+                            W[i * r + c] = acc;
+                        }
+                    double value = 0.0;
+                    if (pp.metric == 3 || pp.metric == 4) {      // EnhancedBD._calc_linear_SINRs (:1101-1138)
+                        for (int i = 0; i < ns; ++i) {
+                            double desired = 0.0, internal = 0.0;
+                            for (int c = 0; c < ns; ++c) {
+                                cd acc = mk<double>(0, 0);
+                                for (int j = 0; j < r; ++j) acc = cadd(acc, cmul(W[i * r + j], Hred[j * ns + c]));
+                                if (c == i) desired = bd_abs2(acc);
+                                else internal += bd_abs2(acc);
+                            }
+                            double ext = 0.0;
+                            for (int p = 0; p < r; ++p)
+                                for (int q = 0; q < r; ++q) ext += cmul(cmul(W[i * r + p], Re[p * r + q]), cconj(W[i * r + q])).x;
+                            const double sinr = desired / (internal + fabs(ext));
+                            value += log2(1.0 + sinr);
+                            if (cand_out && pp.metric == 4) cand_out[((b * K + k) * (size_t)r + (ns - 1)) * r + i] = sinr;
+                        }
+                    }
+                    if (ns == lo || value > best_val) {          // np.argmax: the first maximum
+                        best_val = value;
+                        best_ns = ns;
+                        for (int e = 0; e < n * ns; ++e) best_Ms[e] = MsPk[e];
+                        for (int e = 0; e < ns * r; ++e) best_W[e] = W[e];
+                    }
+                }
+                emit(k, best_Ms, best_W, best_ns);
+            }
+        }
+        if (skipped) skipped[b] = ok ? 0u : 1u;
+    }
+}
+
 struct BdParams {
     int K, r, n_symbols, waterfill, has_pathloss;
     double iPu, noise_var, bd_noise_var;
@@ -520,6 +775,47 @@ int mcle_pinv(mcle_ctx* ctx, const void* d_A, int m, int n, double rcond, void* 
     if (rc) return rc;
     hipLaunchKernelGGL(k_pinv, dim3(grid_for(ctx, batch, 64, 16)), dim3(64), 0, ctx->stream, (const double2*)d_A, m, n,
                        rcond, (double2*)d_out, batch);
+    MCLE_LAUNCH_CHECK();
+    return MCLE_OK;
+}
+
+int mcle_bd_extint(mcle_ctx* ctx, const mcle_bd_extint_cfg* cfg, const void* d_bigH, void* d_Ms, void* d_W,
+                   int32_t* d_ns, double* d_cand_sinr, uint32_t* d_skipped, size_t batch) {
+    MCLE_REQUIRE(ctx != nullptr && cfg != nullptr && d_bigH != nullptr && d_Ms != nullptr && d_W != nullptr, "null argument");
+    MCLE_REQUIRE(cfg->num_users >= 1 && cfg->num_users <= 4 && cfg->n_ant_per_user >= 1 && cfg->n_ant_per_user <= kBdMaxR &&
+                     cfg->num_users * cfg->n_ant_per_user <= kBdMaxN,
+                 "block diagonalisation covers up to 4 users x 4 antennas with at most %d antennas in total", kBdMaxN);
+    MCLE_REQUIRE(cfg->n_ext >= 0 && cfg->n_ext <= 8, "at most 8 external-interference antennas");
+    MCLE_REQUIRE(cfg->method == 0 || cfg->method == 1, "method: 0 = WhiteningBD, 1 = EnhancedBD");
+    MCLE_REQUIRE(cfg->metric >= 0 && cfg->metric <= 5, "metric must be in [0, 5]");
+    MCLE_REQUIRE(cfg->iPu > 0.0 && cfg->noise_var >= 0.0 && cfg->pe >= 0.0, "iPu must be positive, noise_var and pe non-negative");
+    MCLE_REQUIRE(cfg->method == 1 || cfg->noise_var > 0.0 || cfg->n_ext >= cfg->n_ant_per_user,
+                 "whitening needs a positive definite interference-plus-noise covariance");
+    if (cfg->method == 1 && (cfg->metric == 1 || cfg->metric == 2))
+        MCLE_REQUIRE(cfg->num_streams >= 1 && cfg->num_streams <= cfg->n_ant_per_user,
+                     "num_streams must be in [1, %d]", cfg->n_ant_per_user);
+    if (cfg->method == 1 && cfg->metric == 5)
+        for (int k = 0; k < cfg->num_users; ++k)
+            MCLE_REQUIRE(cfg->ns_user[k] >= 1 && cfg->ns_user[k] <= cfg->n_ant_per_user, "ns_user[%d] out of range", k);
+    MCLE_REQUIRE(cfg->metric != 4 || d_cand_sinr != nullptr, "metric 4 reports the candidate SINRs: d_cand_sinr is required");
+    if (batch == 0) return MCLE_OK;
+    int rc = ctx->bind();
+    if (rc) return rc;
+    BdExtParams pp;
+    pp.K = cfg->num_users;
+    pp.r = cfg->n_ant_per_user;
+    pp.n_ext = cfg->n_ext;
+    pp.method = cfg->method;
+    pp.metric = cfg->metric;
+    pp.num_streams = cfg->num_streams;
+    for (int k = 0; k < 4; ++k) pp.ns_user[k] = cfg->ns_user[k];
+    pp.iPu = cfg->iPu;
+    pp.nv = cfg->noise_var;
+    pp.pe = cfg->pe;
+    if (d_cand_sinr)
+        MCLE_HIP(hipMemsetAsync(d_cand_sinr, 0, batch * (size_t)pp.K * pp.r * pp.r * sizeof(double), ctx->stream));
+    hipLaunchKernelGGL(k_bd_extint, dim3(grid_for(ctx, batch, 64, 16)), dim3(64), 0, ctx->stream, pp, (const cd*)d_bigH,
+                       (cd*)d_Ms, (cd*)d_W, d_ns, d_cand_sinr, d_skipped, batch);
     MCLE_LAUNCH_CHECK();
     return MCLE_OK;
 }

@@ -874,6 +874,36 @@ class Engine:
                                                           Ms.ptr, newH.ptr, W.ptr, sg.ptr, sk.ptr, b))
         return dict(Ms=Ms.get(), newH=newH.get(), W=W.get(), sigma=sg.get(), skipped=sk.get())
 
+    def bd_extint(self, big_H, num_users, n_ant, n_ext, iPu, noise_var, pe, method="whitening", metric=None,
+                  num_streams=0, ns_user=None):
+        """Block diagonalisation with external interference (csrc/kernels_bd.hip k_bd_extint; reference
+        comm/blockdiagonalization.py:666-1469).  big_H [batch, K r, K r + n_ext] (MultiUserChannelMatrixExtInt.big_H);
+        method 'whitening' (WhiteningBD) or 'enhanced' (EnhancedBD with metric None / 'naive' / 'fixed' / 'capacity' /
+        'candidates' (report the SINRs of every stream count) / 'per_user' (ns_user given)).
+        -> dict(Ms [b, K, K r, r], W [b, K, r, r], Ns [b, K], cand_sinr [b, K, r, r] or None, skipped [b])."""
+        H = np.ascontiguousarray(big_H, dtype=np.complex128)
+        if H.ndim == 2:
+            H = H[np.newaxis]
+        b, n = H.shape[0], num_users * n_ant
+        if H.shape[1:] != (n, n + n_ext):
+            raise ValueError("big_H must be [batch, K*r, K*r + n_ext]")
+        cfg = _lib.BdExtIntCfg()
+        cfg.num_users, cfg.n_ant_per_user, cfg.n_ext = int(num_users), int(n_ant), int(n_ext)
+        cfg.method = {"whitening": 0, "enhanced": 1}[method]
+        cfg.metric = _lib.BD_METRICS[metric]
+        cfg.num_streams = int(num_streams or 0)
+        for k in range(4):
+            cfg.ns_user[k] = int(ns_user[k]) if (ns_user is not None and k < len(ns_user)) else 0
+        cfg.iPu, cfg.noise_var, cfg.pe = float(iPu), float(noise_var or 0.0), float(pe)
+        d_H = self.to_device(H)
+        Ms, W = self.empty((b, num_users, n, n_ant), np.complex128), self.empty((b, num_users, n_ant, n_ant), np.complex128)
+        ns, sk = self.empty((b, num_users), np.int32), self.empty(b, np.uint32)
+        cand = self.empty((b, num_users, n_ant, n_ant), np.float64) if cfg.metric == 4 else None
+        self._raise_value(self.lib.mcle_bd_extint(self.ctx, byref(cfg), d_H.ptr, Ms.ptr, W.ptr, ns.ptr,
+                                                  cand.ptr if cand is not None else None, sk.ptr, b))
+        return dict(Ms=Ms.get(), W=W.get(), Ns=ns.get(), cand_sinr=None if cand is None else cand.get(),
+                    skipped=sk.get())
+
     def pinv(self, A, rcond=1e-15):
         """np.linalg.pinv for small matrices [batch, m, n] (or [m, n]), m, n <= 8."""
         A = np.ascontiguousarray(A, dtype=np.complex128)

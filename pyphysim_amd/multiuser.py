@@ -154,3 +154,60 @@ class MultiUserChannelMatrix:
         for k in range(self._K):
             res[k] = out[cum[k]:cum[k + 1], :]
         return res
+
+
+class MultiUserChannelMatrixExtInt(MultiUserChannelMatrix):
+    """reference channels/multiuser.py:2011-2520 (what the block-diagonalisation variants with external interference
+    read): the plain multi-user channel plus the columns of `extIntK` external interferers with `extIntNt` antennas
+    each (they have no receive antennas, so big_H is [sum Nr, sum Nt + sum extIntNt])."""
+
+    def __init__(self, engine=None, dtype="f64"):
+        super().__init__(engine, dtype)
+        self._extIntK = 0
+        self._extIntNt = np.array([], dtype=int)
+
+    extIntK = property(lambda self: self._extIntK)
+    extIntNt = property(lambda self: self._extIntNt)
+    K = property(lambda self: self._K - self._extIntK)
+    Nr = property(lambda self: self._Nr[:self._K - self._extIntK])
+    Nt = property(lambda self: self._Nt[:self._K - self._extIntK])
+
+    @property
+    def big_H_no_ext_int(self):
+        """multiuser.py:2097-2122."""
+        return self._big_H[:, :int(np.sum(self.Nt))]
+
+    @staticmethod
+    def _prepare(Nr, Nt, K, NtE):
+        NtE = np.atleast_1d(np.asarray(NtE, dtype=int)) if not isinstance(NtE, (int, np.integer)) else np.array([NtE])
+        Nr = np.ones(K, dtype=int) * Nr if isinstance(Nr, (int, np.integer)) else np.asarray(Nr, dtype=int)
+        Nt = np.ones(K, dtype=int) * Nt if isinstance(Nt, (int, np.integer)) else np.asarray(Nt, dtype=int)
+        return (np.hstack([Nr, np.zeros(NtE.size, dtype=int)]), np.hstack([Nt, NtE]), K + NtE.size, NtE.size, NtE)
+
+    def randomize(self, Nr, Nt, K, NtE):
+        """multiuser.py:2379-2420: one randn_c draw of the full [sum Nr, sum Nt + sum NtE] matrix."""
+        full_Nr, full_Nt, full_K, self._extIntK, self._extIntNt = self._prepare(Nr, Nt, K, NtE)
+        MultiUserChannelMatrix.randomize(self, full_Nr, full_Nt, full_K)
+
+    def init_from_channel_matrix(self, channel_matrix, Nr, Nt, K, NtE):
+        """multiuser.py:2335-2377."""
+        full_Nr, full_Nt, full_K, self._extIntK, self._extIntNt = self._prepare(Nr, Nt, K, NtE)
+        MultiUserChannelMatrix.init_from_channel_matrix(self, channel_matrix, full_Nr, full_Nt, full_K)
+
+    def calc_cov_matrix_extint_without_noise(self, pe=1.0):
+        """multiuser.py:2469-2494."""
+        n_tx = int(np.sum(self.Nt))
+        out = np.empty(self.K, dtype=np.ndarray)
+        cum = np.hstack([0, np.cumsum(self.Nr)])
+        for k in range(self.K):
+            ext = self._big_H[cum[k]:cum[k + 1], n_tx:]
+            out[k] = pe * np.dot(ext, ext.conj().T)
+        return out
+
+    def calc_cov_matrix_extint_plus_noise(self, pe=1.0):
+        """multiuser.py:2496-2520."""
+        out = self.calc_cov_matrix_extint_without_noise(pe)
+        if self.noise_var is not None:
+            for k in range(self.K):
+                out[k] = out[k] + np.eye(int(self.Nr[k])) * self.noise_var
+        return out
