@@ -29,6 +29,7 @@ os.makedirs(dst, exist_ok=True)
 
 CONFIGS = {
     "c4": ("k_run_mimo_ofdm_mfma<", "k_run_mimo_ofdm_mfma<3,2> (f32, FFT 1024, 4x4), %d realizations per launch (bench.py default workload)"),
+    "c4md": ("k_run_mimo_ofdm_mfma<", "k_run_mimo_ofdm_mfma<3,2> with the min-distance demodulator over the LDS table (bench.py --demod mindist), %d realizations per launch"),
     "f1": ("k_run_mimo_ofdm_tdl<", "k_run_mimo_ofdm_tdl<float,1024,4>, %d realizations per launch (bench.py --config f1)"),
     "c3": ("k_run_ofdm_tdl_batch<", "k_run_ofdm_tdl_batch<float,1024,4>, %d realizations per launch (bench.py --config c3)"),
     "c2": ("k_run_flat<", "k_run_flat<float,8>, %d realizations per launch (bench.py --config c2)"),
@@ -60,7 +61,7 @@ for cfg, (needle, label) in CONFIGS.items():
                              "max": max(vals)}
     if not summary:
         continue
-    per_launch = BATCH[cfg]
+    per_launch = BATCH[cfg[:2]]
     derived = derive_pmc({k: v["mean_per_launch"] for k, v in summary.items()}, per_launch)
     summary["_derived"] = derived
     summary["_kernel"] = label % per_launch
@@ -68,7 +69,7 @@ for cfg, (needle, label) in CONFIGS.items():
     summary["_dispatch_note"] = ("rocprofv3's record: VGPR_Count is HALF the allocation on gfx950, LDS_Block_Size omits "
                                  "dynamic LDS; see kernel_resources.json for the code-object values")
     json.dump(summary, open(os.path.join(dst, "%s_pmc_summary.json" % cfg), "w"), indent=1)
-    if "hbm_bytes_per_launch" in derived:
+    if "hbm_bytes_per_launch" in derived and cfg in BATCH:
         json.dump({"hbm_bytes_per_launch": derived["hbm_bytes_per_launch"], "realizations_per_launch": per_launch,
                    "source": "profiles/%s/%s_pmc_summary.json" % (rnd, cfg),
                    "rule": "(2*FETCH_SIZE + WRITE_SIZE) KiB per MI355X_MICROARCH.md"},
