@@ -27,6 +27,7 @@
 #include <cstdlib>
 
 #include "fft.hpp"
+#include "fft16.hpp"
 #include "mimo.hpp"
 #include "modem.hpp"
 #include "philox.hpp"
@@ -34,71 +35,6 @@
 #include "pipe_common.hpp"
 
 namespace mcle {
-
-typedef float f4 __attribute__((ext_vector_type(4)));
-
-constexpr int kF16N = 1024;
-constexpr int kF16Plane = 1040;            // dwords from an antenna's re plane to its im plane (== 16 mod 32)
-constexpr int kF16Ant = 2 * kF16Plane;     // dwords per antenna
-
-__host__ __device__ __forceinline__ int f16_swz(int k) { return ((k & 7) ^ ((k & 1) << 3)) << 2; }
-__host__ __device__ __forceinline__ int f16_pos(int p) { return p ^ f16_swz(p >> 6); }
-
-// same-wave LDS hand-off between two passes (the wave's own DS traffic executes in order)
-__device__ __forceinline__ void wave_lds_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
-
-__device__ __forceinline__ float dpp_swap1(float v) {   // value of lane ^ 1 (quad_perm [1,0,3,2])
-    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));
-}
-
-// The two real 16x16 matrices of the split DFT-16, as MFMA A operands: lane (row i = l & 15, k-group g = l >> 4),
-// k-step t < 4 covers element e = 2t + (g >> 1), part g & 1; row i = 2u + part_out.
-struct Dft16Mats {
-    float ae[4], ao[4];
-};
-__device__ __forceinline__ Dft16Mats dft16_mats(const float2* __restrict__ g_tw, int lane) {
-    Dft16Mats m;
-    const int i = lane & 15, g = lane >> 4, u = i >> 1;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int e = 2 * t + (g >> 1);
-        const float2 we = g_tw[(128 * e * u) & 1023];             // W8^{e u}
-        const float2 wo = g_tw[(64 * e * (2 * u + 1)) & 1023];    // W16^{e (2u+1)}
-        if ((i & 1) == 0) {
-            m.ae[t] = (g & 1) ? -we.y : we.x;
-            m.ao[t] = (g & 1) ? -wo.y : wo.x;
-        } else {
-            m.ae[t] = (g & 1) ? we.x : we.y;
-            m.ao[t] = (g & 1) ? wo.x : wo.y;
-        }
-    }
-    return m;
-}
-
-// One DFT-16 pass over one antenna's 16 groups: b[0..7] = this lane's operand values (element 2t + (g >> 1), part
-// g & 1).  Returns out[x] = (re, im) of output 4g + x of group (lane & 15), x = 0..3.
-__device__ __forceinline__ void dft16_mfma(const Dft16Mats& m, const float (&b)[8], float2 (&out)[4]) {
-    f4 ce = {0.f, 0.f, 0.f, 0.f}, co = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        ce = __builtin_amdgcn_mfma_f32_16x16x4f32(m.ae[t], b[t] + b[t + 4], ce, 0, 0, 0);
-        co = __builtin_amdgcn_mfma_f32_16x16x4f32(m.ao[t], b[t] - b[t + 4], co, 0, 0, 0);
-    }
-    out[0] = make_float2(ce[0], ce[1]);   // k = 4g     (u = 2g,     even)
-    out[1] = make_float2(co[0], co[1]);   // k = 4g + 1 (u = 2g,     odd)
-    out[2] = make_float2(ce[2], ce[3]);   // k = 4g + 2 (u = 2g + 1, even)
-    out[3] = make_float2(co[2], co[3]);   // k = 4g + 3
-}
-
-// complex product in the shape the backend lowers to v_pk_mul_f32 + v_pk_fma_f32 (two packed ops per product)
-__device__ __forceinline__ float2 cmul_pk(float2 a, float2 w) {
-    const float tx = a.x * w.x, ty = a.x * w.y;
-    return make_float2(fmaf(-a.y, w.y, tx), fmaf(a.y, w.x, ty));
-}
 
 // Packed square-QAM slicer.  A label byte is (binary row << hb) | binary column with binary = gray^-1(level)
 // (reference modulators/fundamental.py:697-777; demod_qam_slicer in modem.hpp).  Working in the LEVEL domain --
@@ -142,50 +78,6 @@ __device__ __forceinline__ void qam_count4(uint32_t x, const QamPack& q, unsigne
     be += __popc(y);
 }
 
-
-// The four antennas of one DFT-16 pass: all operand loads first (the pass is in place per wavefront, so nothing it
-// stores is read again inside it), the 32 MFMAs as 8 independent accumulator chains, then twiddle and store.
-template <typename LoadOff, typename StoreOff, typename Fill>
-__device__ __forceinline__ void dft16_pass4(float* s_d, int plane_g, const Dft16Mats& m, const float2 (&tw)[4],
-                                            LoadOff ld, StoreOff st, Fill fill) {
-    float b[4][8];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int t = 0; t < 8; ++t) b[a][t] = s_d[a * kF16Ant + plane_g + ld(t)];
-    f4 ce[4], co[4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a) ce[a] = co[a] = f4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            ce[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(m.ae[t], b[a][t] + b[a][t + 4], ce[a], 0, 0, 0);
-            co[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(m.ao[t], b[a][t] - b[a][t + 4], co[a], 0, 0, 0);
-        }
-    fill();
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-        const float2 o[4] = {make_float2(ce[a][0], ce[a][1]), make_float2(co[a][0], co[a][1]),
-                             make_float2(ce[a][2], ce[a][3]), make_float2(co[a][2], co[a][3])};
-#pragma unroll
-        for (int x = 0; x < 4; ++x) {
-            const float2 v = cmul_pk(o[x], tw[x]);
-            const int off = a * kF16Ant + st(x);
-            s_d[off] = v.x;
-            s_d[off + kF16Plane] = v.y;
-        }
-    }
-}
-
-// inverse of ofdm_bin (fft.hpp): data index carried by FFT bin `bin`, or -1
-__device__ __forceinline__ int ofdm_data_index(int bin, int n, int num_used) {
-    if (num_used == n) return (bin + n / 2) & (n - 1);
-    const int h = num_used / 2;
-    if (bin >= n - h) return bin - (n - h);
-    if (bin >= 1 && bin <= h) return h + bin - 1;
-    return -1;
-}
 
 struct MimoParams {
     int cp, num_used, n_ofdm_sym;

@@ -14,9 +14,11 @@
 // channels/fading_generators.py:421-425,459-467,519-522.
 // Draw ledger per realization (mcle-philox-v1): DATA symbol n = os*U + d; PHASE phi = uniform l*S + s,
 // psi = uniform L*S + l*S + s; NOISE sample j of the faded stream.
+#include <cstdlib>
 #include <type_traits>
 
 #include "fft.hpp"
+#include "fft16.hpp"
 #include "jakes.hpp"
 #include "modem.hpp"
 #include "philox.hpp"
@@ -30,6 +32,7 @@ constexpr int kSisoMaxOrder = 12;
 struct SisoTdlParams {
     int cp, num_used, n_ofdm_sym;
     int n_taps, L, K, dmax;
+    int ablate;                      // experiment knob (MCLE_TDL_ABLATE): stages switched off, results meaningless
     int x_elems;                     // complex elements of the sample buffer (>= NB*N; also holds the ray scratch)
     double noise_var, Fd, Ts, dt;
     double tap_amp[MCLE_MAX_TAPS];   // sqrt(p_s / L)
@@ -357,11 +360,494 @@ __global__ __launch_bounds__(kPipeBlock, sizeof(T) == 4 ? 3 : 1) void k_run_ofdm
                  (unsigned long long)U * pp.n_ofdm_sym * mp.bits);
 }
 
+
+// ---- the same pass on the matrix cores: f32, N = 1024, every delayed sample inside the symbol's own cyclic prefix ----
+// The four slots take the place of the four antennas of pipeline_mimo_mfma.hip (fft16.hpp: 16 x 16 x 4 transform, two
+// DFT-16 passes as MFMAs).  What differs is the middle: a tap delay line needs its neighbours' time samples, so P3 parks
+// the samples in LDS in a time layout -- in place, each wavefront inside the quarter of the planes it has just read:
+// sample m = k + 16 q at k * 64 + (q ^ ((k & 3) << 4)), bank-conflict free for a wavefront's own samples and for
+// any common delay -- and the channel reads x[m - d] from there.  Four workgroup barriers per OFDM symbol (after P1,
+// after the time samples are parked, after the delayed reads, after P2') instead of fourteen; the rays of the symbol
+// are drawn before P1 and folded into tap polynomials by the first wavefront between the first two barriers.
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 ld2(const float2* p) {
+    const float2 v = *p;
+    return f2{v.x, v.y};
+}
+
+template <int WAVES>
+__global__ __launch_bounds__(kPipeBlock, WAVES) void k_run_ofdm_tdl_mfma(
+    SisoTdlParams pp, ModemParams<float> mp, uint64_t seed, uint64_t first, uint64_t count,
+    const float2* __restrict__ g_tw, mcle_counters* counters, uint32_t* __restrict__ sym_out,
+    uint32_t* __restrict__ bit_out) {
+    constexpr int N = kF16N, NB = 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int S = pp.n_taps, L = pp.L, K = pp.K;
+    const int PS = S * NB;                                             // fading processes of a pass: slot a, tap s -> a*S + s
+    const int U = pp.num_used, cp = pp.cp, W = N + cp;
+    const int tab_len = (mp.M + 15) & ~15;
+    float* s_d = reinterpret_cast<float*>(smem);                       // [NB][re plane | im plane]
+    float4* s_tab4 = reinterpret_cast<float4*>(s_d + NB * kF16Ant);    // [tab_len] {re, im, |c|^2 / 2, 0} (demodulator)
+    float2* s_txtab = reinterpret_cast<float2*>(s_tab4 + tab_len);     // [tab_len] constellation x tx scale
+    unsigned char* s_idx = reinterpret_cast<unsigned char*>(s_txtab + tab_len);     // [NB][U] sent labels
+    unsigned long long* s_grid = reinterpret_cast<unsigned long long*>(s_idx + ((NB * U + 15) & ~15));
+    float2* s_coef = reinterpret_cast<float2*>(s_grid + mp.grid.G * mp.grid.G);     // [PS][K+1]
+    float2* s_mean = s_coef + PS * (K + 1);                            // [PS]
+    float* s_ray = reinterpret_cast<float*>(s_mean + PS);              // [PS*L][3] = {re, im, theta}
+    unsigned* s_part = reinterpret_cast<unsigned*>(s_ray + ((3 * PS * L + 1) & ~1));   // [2][4 waves][NB][2]
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int j = lane & 15, g = lane >> 4, gb = g >> 1;
+    const float sigma = (float)sqrt(pp.noise_var);
+    const float tx_scale = (float)(1.0 / sqrt((double)(U + cp)));
+    const float rx_scale = (float)(sqrt((double)(U + cp)) / (double)N);
+    const uint32_t mask = (uint32_t)(mp.M - 1);
+    const uint32_t mask4 = mask * 0x01010101u;
+    const double xc = 0.5 * (double)(W - 1);                           // centre of the symbol in local sample units
+
+    for (int m = tid; m < mp.M; m += kPipeBlock) {
+        const float2 c = mp.g_table[m];
+        s_tab4[m] = make_float4(c.x, c.y, 0.5f * (c.x * c.x + c.y * c.y), 0.f);
+        s_txtab[m] = make_float2(c.x * tx_scale, c.y * tx_scale);
+    }
+    load_grid(mp, s_grid);
+    __shared__ WgTotals totals;
+    if (tid == 0) wg_zero(totals);
+
+    // ---- per-thread constants (pipeline_mimo_mfma.hip has the same set) ----
+    const Dft16Mats mats = dft16_mats(g_tw, lane);
+    const int n2 = 16 * w + j;                       // P1 / P1': this lane's column
+    const int k1p = 4 * w + (j >> 2), m2p = j & 3;   // P2 / P2': this lane's group (row k1p, residue m2p)
+    // middle stage: lane -> butterfly (row k1m, j1m); lanes l and l ^ 1 hold time samples m and m + 1
+    const int kkm = ((lane >> 5) << 1) | (lane & 1), j1m = (lane >> 1) & 15, k1m = 4 * w + kkm, par = lane & 1;
+    float2 tw1a[4], tw2a[4], tw1b[4], tw2b[3];
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+        tw1a[x] = g_tw[((4 * g + x) * n2) & 1023];                            // P1 : W1024^{k1 n2}
+        tw2a[x] = g_tw[(16 * (4 * g + x) * m2p) & 1023];                      // P2 : W64^{j1 m2} ...
+        if ((k1p & 1) && (m2p & 1)) tw2a[x] = make_float2(-tw2a[x].x, -tw2a[x].y);   // ... x the P3 slot order of odd rows
+        tw1b[x] = g_tw[((4 * (4 * g + x) + m2p) * k1p) & 1023];               // P2': W1024^{(4 m1 + m2) k1}
+    }
+#pragma unroll
+    for (int m2 = 1; m2 < 4; ++m2) {
+        tw2b[m2 - 1] = g_tw[(16 * m2 * j1m) & 1023];                          // P3': W64^{m2 j1} x slot order
+        if (par && (m2 & 1)) tw2b[m2 - 1] = make_float2(-tw2b[m2 - 1].x, -tw2b[m2 - 1].y);
+    }
+    const int plane_g = (g & 1) * kF16Plane;
+    const int p1_ld = 64 * gb + (n2 ^ (gb * 36));
+    const int p1_st = 256 * g + (n2 ^ (16 * (g & 1)));
+    const int p2_base = 64 * k1p + (m2p | f16_swz(k1p));
+    const int p2_ld = p2_base ^ (4 * gb);
+    const int p2_st = p2_base ^ (16 * g);
+    const int mid_off = 64 * k1m + ((4 * j1m) ^ f16_swz(k1m));
+    const int m0 = k1m + 16 * j1m;                                            // this lane's time samples: m0 + 256 c
+    const int t_sw = (k1m & 3) << 4;
+    // symbol scatter, full band: lane (row e = lane >> 2, slot a = lane & 3) of wave w fills bins 64 e + 16 w + (0..15) of
+    // slot a from one Philox block -- the wave's OWN 16 columns, so scatter -> P1 and P1' -> next scatter stay wave-local
+    const int sc_e = lane >> 2, sc_a = lane & 3;
+    const int sc_d0 = (64 * sc_e + 16 * w + N / 2) & (N - 1);
+    const int sc_sw = f16_swz(sc_e);
+    const bool full_band = (U == N);
+
+    const uint64_t n_pass = (count + NB - 1) / NB;
+    uint64_t it = 0, base_prev = 0;
+    __syncthreads();
+    for (uint64_t ps = blockIdx.x; ps < n_pass; ps += gridDim.x, ++it) {
+        const uint64_t base = ps * NB;                   // slot a carries realization base + a (idle past `count`)
+        const int buf = (int)(it & 1);
+        unsigned se[NB], be[NB];
+#pragma unroll
+        for (int a = 0; a < NB; ++a) se[a] = be[a] = 0;
+        for (int os = 0; os < pp.n_ofdm_sym; ++os) {
+            const uint64_t sym0 = (uint64_t)os * W;
+            // ---- rays of this symbol: phasor at the symbol centre and phase advance per sample, one per thread ----
+            {
+                const double two_pi = 6.283185307179586476925286766559;
+                const double tc = pp.Ts + pp.dt * ((double)sym0 + xc);
+                for (int q = tid; q < PS * L && !((pp.ablate & 1) && it > 0); q += kPipeBlock) {
+                    const int a = q / (S * L), rq = q - a * (S * L);      // rq = l*S + s: PHASE-stream index of phi
+                    const int l = rq / S, s = rq - l * S;
+                    const Rng rng(seed, first + base + a);
+                    const double psi_t = uniform_at(rng, STREAM_PHASE, (uint64_t)L * S + rq);
+                    const double wd = pp.Fd * cospi(2.0 * uniform_at(rng, STREAM_PHASE, (uint64_t)rq));   // Hz
+                    const double ph = fma(wd, tc, psi_t);                 // turns
+                    const double fr = ph - floor(ph);
+                    float* o = s_ray + 3 * ((a * S + s) * L + l);
+                    o[0] = __builtin_amdgcn_cosf((float)fr);
+                    o[1] = __builtin_amdgcn_sinf((float)fr);
+                    o[2] = (float)(two_pi * wd * pp.dt);                  // rad per sample
+                }
+            }
+            // ---- symbols -> bins, stored re<->im swapped (inverse transform by the swap identity) ----
+            const uint64_t n_first = (uint64_t)os * U;
+            if (full_band) {
+                const Rng rng(seed, first + base + sc_a);
+                const Words4 dw = rng.block(STREAM_DATA, (uint32_t)((n_first + sc_d0) >> 4));
+                const uint32_t wv[4] = {dw.w[0] & mask4, dw.w[1] & mask4, dw.w[2] & mask4, dw.w[3] & mask4};
+                *reinterpret_cast<uint4*>(s_idx + sc_a * U + sc_d0) = make_uint4(wv[0], wv[1], wv[2], wv[3]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float2 sym[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) sym[c] = s_txtab[(wv[q] >> (8 * c)) & 0xFFu];
+                    const f4 vr = {sym[0].y, sym[1].y, sym[2].y, sym[3].y};
+                    const f4 vi = {sym[0].x, sym[1].x, sym[2].x, sym[3].x};
+                    const int off = sc_a * kF16Ant + 64 * sc_e + ((16 * w + 4 * q) ^ sc_sw);
+                    *reinterpret_cast<f4*>(s_d + off) = vr;
+                    *reinterpret_cast<f4*>(s_d + off + kF16Plane) = vi;
+                }
+                wave_lds_sync();
+            } else {           // partial band: zero fill + scatter in block order across the workgroup
+                __syncthreads();
+                for (int p = tid; p < NB * kF16Ant; p += kPipeBlock) s_d[p] = 0.f;
+                __syncthreads();
+                const uint64_t n_last = n_first + U;
+#pragma unroll
+                for (int a = 0; a < NB; ++a) {
+                    const Rng rng(seed, first + base + a);
+                    for (uint64_t blk = (n_first >> 4) + tid; blk <= ((n_last - 1) >> 4); blk += kPipeBlock) {
+                        const Words4 dw = rng.block(STREAM_DATA, (uint32_t)blk);
+#pragma unroll
+                        for (int jj = 0; jj < 16; ++jj) {
+                            const uint64_t n = (blk << 4) + jj;
+                            if (n >= n_first && n < n_last) {
+                                const int tx = (int)((dw.w[jj >> 2] >> ((jj & 3) * 8)) & mask);
+                                const int d = (int)(n - n_first);
+                                s_idx[a * U + d] = (unsigned char)tx;
+                                const float2 c = s_txtab[tx];
+                                const int off = a * kF16Ant + f16_pos(ofdm_bin(d, N, U));
+                                s_d[off] = c.y;
+                                s_d[off + kF16Plane] = c.x;
+                            }
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+            // ---- P1: DFT-16 over n1, x W1024^{k1 n2} ----
+            dft16_pass4(s_d, plane_g, mats, tw1a, [&](int t) { return (p1_ld ^ (((2 * t) & 7) << 2)) + 128 * t; },
+                        [&](int x) { return (p1_st ^ ((x << 2) ^ ((x & 1) << 5))) + 64 * x; }, [&]() {});
+            __syncthreads();
+            if (tid == 0 && os == 0 && it > 0) {   // every wave is past the previous pass: account it
+                const unsigned* q = s_part + (buf ^ 1) * 32;
+#pragma unroll
+                for (int a = 0; a < NB; ++a) {
+                    if (base_prev + a >= count) break;
+                    unsigned st = 0, bt = 0;
+#pragma unroll
+                    for (int ww = 0; ww < 4; ++ww) {
+                        st += q[(ww * NB + a) * 2];
+                        bt += q[(ww * NB + a) * 2 + 1];
+                    }
+                    wg_account(totals, st, bt, false, base_prev + a, sym_out, bit_out);
+                }
+            }
+            // ---- tap polynomials around the middle of this symbol: one (process, order) per thread ----
+            if (!((pp.ablate & 2) && it > 0))
+            for (int q = tid; q < PS * (K + 1); q += kPipeBlock) {
+                const int p = q / (K + 1), m = q - p * (K + 1);
+                float inv_fact = 1.f;
+                for (int i = 2; i <= m; ++i) inv_fact /= (float)i;
+                float ar = 0.f, ai = 0.f;
+#pragma unroll 4
+                for (int l = 0; l < L; ++l) {
+                    const float* o = s_ray + 3 * (p * L + l);
+                    float pw = inv_fact;
+                    for (int i = 0; i < m; ++i) pw *= o[2];
+                    ar += o[0] * pw;
+                    ai += o[1] * pw;
+                }
+                float cr, ci;                                             // times j^m
+                switch (m & 3) {
+                    case 0: cr = ar; ci = ai; break;
+                    case 1: cr = -ai; ci = ar; break;
+                    case 2: cr = -ar; ci = -ai; break;
+                    default: cr = ai; ci = -ar; break;
+                }
+                const float amp = (float)pp.tap_amp[p % S];
+                s_coef[q] = make_float2(amp * cr, amp * ci);
+            }
+            // ---- P2: DFT-16 over m1, x W64^{j1 m2} ----
+            dft16_pass4(s_d, plane_g, mats, tw2a, [&](int t) { return p2_ld ^ (8 * t); },
+                        [&](int x) { return p2_st ^ (4 * x); }, [&]() {});
+            wave_lds_sync();
+            // ---- P3 (DFT-4) -> time samples, parked in the time layout inside this wave's own quarter ----
+#pragma unroll
+            for (int a = 0; a < NB; ++a) {
+                const f4 R = *reinterpret_cast<const f4*>(s_d + a * kF16Ant + mid_off);
+                const f4 I = *reinterpret_cast<const f4*>(s_d + a * kF16Ant + kF16Plane + mid_off);
+                const float t0r = R[0] + R[2], t0i = I[0] + I[2], t1r = R[0] - R[2], t1i = I[0] - I[2];
+                const float t2r = R[1] + R[3], t2i = I[1] + I[3];
+                const float t3r = I[1] - I[3], t3i = R[3] - R[1];     // (z1 - z3) * (-i)
+                // planes hold swap(x): true sample = (im plane, re plane); slot s is time index c = s ^ 2 par
+                const float xi[4] = {t0r + t2r, t1r + t3r, t0r - t2r, t1r - t3r};
+                const float xr[4] = {t0i + t2i, t1i + t3i, t0i - t2i, t1i - t3i};
+                __builtin_amdgcn_wave_barrier();                       // every lane of the wave has its operands
+#pragma unroll
+                for (int sl = 0; sl < 4; ++sl) {
+                    const int c = sl ^ (2 * par);
+                    const int off = a * kF16Ant + 64 * k1m + ((j1m + 16 * c) ^ t_sw);
+                    s_d[off] = xr[sl];
+                    s_d[off + kF16Plane] = xi[sl];
+                }
+            }
+            __syncthreads();
+            if (tid < PS) {     // per-symbol tap means (the equaliser's channel estimate), read after two more barriers
+                float mr = 0.f, mi = 0.f;
+                for (int m = 0; m <= K; ++m) {
+                    const float2 c = s_coef[tid * (K + 1) + m];
+                    mr += c.x * (float)pp.mom[m];
+                    mi += c.y * (float)pp.mom[m];
+                }
+                s_mean[tid] = make_float2(mr, mi);
+            }
+            // ---- channel: y[a][m] = sum_s g[a][s](j) T[a][j], j = cp + m - d_s, + noise ----
+            float yr[4][NB], yi[4][NB];            // [slot][realization slot]
+#pragma unroll
+            for (int sl = 0; sl < 4; ++sl)
+#pragma unroll
+                for (int a = 0; a < NB; ++a) yr[sl][a] = yi[sl][a] = 0.f;
+            auto channel = [&](auto k_tag) {      // KT > 0: polynomial order known at compile time
+                constexpr int KT = decltype(k_tag)::value;
+                const int n_taps = (pp.ablate & 8) ? 1 : S;
+                for (int s = 0; s < n_taps; ++s) {
+                    const int d = pp.tap_delay[s];
+                    const int mm = (m0 - d) & (N - 1);
+                    const int kk = mm & 15, q0 = mm >> 4, ksw = (kk & 3) << 4;
+                    int off[4];
+                    f2 xs[4];
+#pragma unroll
+                    for (int sl = 0; sl < 4; ++sl) {
+                        const int c = sl ^ (2 * par);
+                        off[sl] = 64 * kk + (((q0 + 16 * c) & 63) ^ ksw);
+                        const float xv = (float)((double)(cp + m0 + 256 * c - d) - xc);
+                        xs[sl] = f2{xv, xv};
+                    }
+#pragma unroll
+                    for (int a = 0; a < NB; ++a) {
+                        const float2* c = s_coef + (a * S + s) * (K + 1);
+                        const float* pr = s_d + a * kF16Ant;
+                        f2 gq[4];                   // tap value at the four samples: Horner on (re, im) pairs (v_pk_fma_f32)
+                        if constexpr (KT == 2) {
+                            const f2 c0 = ld2(c), c1 = ld2(c + 1), c2 = ld2(c + 2);
+#pragma unroll
+                            for (int sl = 0; sl < 4; ++sl)
+                                gq[sl] = __builtin_elementwise_fma(__builtin_elementwise_fma(c2, xs[sl], c1), xs[sl], c0);
+                        } else {
+                            const f2 top = ld2(c + K);
+#pragma unroll
+                            for (int sl = 0; sl < 4; ++sl) gq[sl] = top;
+                            for (int m = K - 1; m >= 0; --m) {
+                                const f2 cm = ld2(c + m);
+#pragma unroll
+                                for (int sl = 0; sl < 4; ++sl) gq[sl] = __builtin_elementwise_fma(gq[sl], xs[sl], cm);
+                            }
+                        }
+#pragma unroll
+                        for (int sl = 0; sl < 4; ++sl) {
+                            const float2 xv = make_float2(pr[off[sl]], pr[off[sl] + kF16Plane]);
+                            const float2 acc = cfma(make_float2(gq[sl][0], gq[sl][1]), xv, make_float2(yr[sl][a], yi[sl][a]));
+                            yr[sl][a] = acc.x;
+                            yi[sl][a] = acc.y;
+                        }
+                    }
+                }
+            };
+            if (K == 2) channel(std::integral_constant<int, 2>{});
+            else channel(std::integral_constant<int, 0>{});
+            {   // noise of the samples that survive CP removal: sample sym0 + cp + m of every slot's own NOISE stream;
+                // lanes l, l ^ 1 (samples m, m + 1) share a Philox block when that index pair is (even, odd)
+                const uint64_t i_base = sym0 + (uint64_t)cp + (uint64_t)m0;
+                if (pp.ablate & 4) {
+                } else if (((sym0 + (uint64_t)cp) & 1) == 0) {
+#pragma unroll
+                    for (int a = 0; a < NB; ++a) {
+                        const Rng rng(seed, first + base + a);
+#pragma unroll
+                        for (int cc = 0; cc < 2; ++cc) {
+                            const uint64_t i = i_base + 256u * (2 * par + cc);
+                            const Words4 b = rng.block(STREAM_NOISE, (uint32_t)(i >> 1));
+                            const uint32_t k0 = par ? b.w[2] : b.w[0], k1 = par ? b.w[3] : b.w[1];
+                            const uint32_t g0 = par ? b.w[0] : b.w[2], g1 = par ? b.w[1] : b.w[3];
+                            const float2 keep = cn_from_words(k0, k1, sigma);
+                            const float2 give = cn_from_words(g0, g1, sigma);
+                            yr[cc][a] += keep.x;
+                            yi[cc][a] += keep.y;
+                            yr[2 + cc][a] += dpp_swap1(give.x);
+                            yi[2 + cc][a] += dpp_swap1(give.y);
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int a = 0; a < NB; ++a) {
+                        const Rng rng(seed, first + base + a);
+#pragma unroll
+                        for (int sl = 0; sl < 4; ++sl) {
+                            const float2 z = cn_sample<float>(rng, STREAM_NOISE, i_base + 256u * (sl ^ (2 * par)), sigma);
+                            yr[sl][a] += z.x;
+                            yi[sl][a] += z.y;
+                        }
+                    }
+                }
+            }
+            __syncthreads();   // every delayed read is done: the planes take the received samples
+            // ---- P3': DFT-4 over the slots (their order is folded into tw2b), x W64^{m2 j1} ----
+#pragma unroll
+            for (int a = 0; a < NB; ++a) {
+                const float t0r = yr[0][a] + yr[2][a], t0i = yi[0][a] + yi[2][a];
+                const float t1r = yr[0][a] - yr[2][a], t1i = yi[0][a] - yi[2][a];
+                const float t2r = yr[1][a] + yr[3][a], t2i = yi[1][a] + yi[3][a];
+                const float t3r = yi[1][a] - yi[3][a], t3i = yr[3][a] - yr[1][a];
+                const float2 v1 = cmul_pk(make_float2(t1r + t3r, t1i + t3i), tw2b[0]);
+                const float2 v2 = cmul_pk(make_float2(t0r - t2r, t0i - t2i), tw2b[1]);
+                const float2 v3 = cmul_pk(make_float2(t1r - t3r, t1i - t3i), tw2b[2]);
+                const f4 vr = {t0r + t2r, v1.x, v2.x, v3.x};
+                const f4 vi = {t0i + t2i, v1.y, v2.y, v3.y};
+                *reinterpret_cast<f4*>(s_d + a * kF16Ant + mid_off) = vr;
+                *reinterpret_cast<f4*>(s_d + a * kF16Ant + kF16Plane + mid_off) = vi;
+            }
+            wave_lds_sync();
+            // ---- P2': DFT-16 over j1, x W1024^{(4 m1 + m2) k1} ----
+            dft16_pass4(s_d, plane_g, mats, tw1b, [&](int t) { return p2_ld ^ (8 * t); },
+                        [&](int x) { return p2_st ^ (4 * x); }, [&]() {});
+            __syncthreads();
+            // ---- P1': DFT-16 over k1 -> bins 64 n1 + n2 (n1 = 4g + x); one-tap equaliser, demodulate, count ----
+            {
+                float2 yb[4][NB];                 // [x][slot]
+#pragma unroll
+                for (int a = 0; a < NB; ++a) {
+                    const float* pl = s_d + a * kF16Ant + plane_g;
+                    float b[8];
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) b[t] = pl[(p1_ld ^ (((2 * t) & 7) << 2)) + 128 * t];
+                    float2 o[4];
+                    dft16_mfma(mats, b, o);
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) yb[x][a] = o[x];
+                }
+                float2 hq[4][NB];
+#pragma unroll
+                for (int x = 0; x < 4; ++x)
+#pragma unroll
+                    for (int a = 0; a < NB; ++a) hq[x][a] = make_float2(0.f, 0.f);
+                for (int s = 0; s < ((pp.ablate & 16) ? 1 : S); ++s) {
+                    const int d = pp.tap_delay[s];
+                    float2 mean[NB];
+#pragma unroll
+                    for (int a = 0; a < NB; ++a) mean[a] = s_mean[a * S + s];
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) {
+                        const float2 wq = g_tw[((64 * (4 * g + x) + n2) * d) & (N - 1)];
+#pragma unroll
+                        for (int a = 0; a < NB; ++a) hq[x][a] = cfma(mean[a], wq, hq[x][a]);
+                    }
+                }
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    const int d = ofdm_data_index(64 * (4 * g + x) + n2, N, U);
+                    if (d >= 0 && !(pp.ablate & 32)) {
+                        float2 eq[NB];
+                        int dec[NB];
+#pragma unroll
+                        for (int a = 0; a < NB; ++a) {   // y rx_scale / h = y conj(h) (rx_scale / |h|^2), one v_rcp_f32
+                            const float2 h = hq[x][a], y = yb[x][a];
+                            const float r = rx_scale * __builtin_amdgcn_rcpf(fmaf(h.x, h.x, h.y * h.y));
+                            eq[a] = make_float2(fmaf(y.x, h.x, y.y * h.y) * r, fmaf(y.y, h.x, -(y.x * h.y)) * r);
+                        }
+                        if (mp.method == MCLE_DEMOD_QAM_SLICER) {
+#pragma unroll
+                            for (int a = 0; a < NB; ++a)
+                                dec[a] = demod_qam_slicer<float>(eq[a], mp.qam_scale, mp.qam_L, mp.half_bits);
+                        } else if (mp.grid.G > 0 && mp.M > 8) {   // a sweep of <= 8 points beats the cell look-up
+                            demod_grid4_multi<NB>(s_tab4, s_grid, mp.grid, mp.M, eq, dec);
+                        } else {
+                            demod_mindist_multi<NB>(s_tab4, mp.M, eq, dec);
+                        }
+#pragma unroll
+                        for (int a = 0; a < NB; ++a) {
+                            const unsigned xo = (unsigned)((int)s_idx[a * U + d] ^ dec[a]);
+                            se[a] += (xo != 0u);
+                            be[a] += __popc(xo);
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < NB; ++a) {
+            const unsigned s1 = wave_sum_u32(se[a]), b1 = wave_sum_u32(be[a]);
+            if (lane == 0) {
+                s_part[buf * 32 + (w * NB + a) * 2] = s1;
+                s_part[buf * 32 + (w * NB + a) * 2 + 1] = b1;
+            }
+        }
+        base_prev = base;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        if (it > 0) {
+            const unsigned* q = s_part + (int)((it - 1) & 1) * 32;
+            for (int a = 0; a < NB; ++a) {
+                if (base_prev + a >= count) break;
+                unsigned st = 0, bt = 0;
+                for (int ww = 0; ww < 4; ++ww) {
+                    st += q[(ww * NB + a) * 2];
+                    bt += q[(ww * NB + a) * 2 + 1];
+                }
+                wg_account(totals, st, bt, false, base_prev + a, sym_out, bit_out);
+            }
+        }
+        wg_flush(totals, counters, (unsigned long long)U * pp.n_ofdm_sym,
+                 (unsigned long long)U * pp.n_ofdm_sym * mp.bits);
+    }
+}
+
+// host side: 0 = launched, MCLE_E_UNSUPPORTED = outside this kernel's envelope (the caller uses k_run_ofdm_tdl_batch)
+int run_siso_tdl_mfma(mcle_ctx* ctx, const SisoTdlParams& pp, int method, uint64_t seed, uint64_t first, uint64_t count,
+                      mcle_counters* d_counters, uint32_t* d_sym, uint32_t* d_bit) {
+    constexpr int NB = 4;
+    if (pp.cp < pp.dmax || (pp.num_used & 15) != 0) return MCLE_E_UNSUPPORTED;
+    if (std::getenv("MCLE_NO_MFMA")) return MCLE_E_UNSUPPORTED;
+    const size_t PS = (size_t)pp.n_taps * NB;
+    if (PS > kPipeBlock || 3 * PS * pp.L * sizeof(float) > 8192) return MCLE_E_UNSUPPORTED;
+    int rc;
+    void* tw = nullptr;
+    if ((rc = ctx->get_twiddles(kF16N, MCLE_F32, &tw))) return rc;
+    const ModemParams<float> mp = pipe_modem<float>(ctx, method);
+    const size_t tab_len = ((size_t)mp.M + 15) & ~(size_t)15;
+    const size_t lds = (size_t)NB * kF16Ant * sizeof(float) + tab_len * (sizeof(float4) + sizeof(float2)) +
+                       (((size_t)NB * pp.num_used + 15) & ~(size_t)15) +
+                       (size_t)mp.grid.G * mp.grid.G * sizeof(unsigned long long) +
+                       (PS * (pp.K + 1) + PS) * sizeof(float2) + ((3 * PS * pp.L + 1) & ~(size_t)1) * sizeof(float) +
+                       64 * sizeof(unsigned);
+    if (lds + 512 > (size_t)160 * 1024 / 2) return MCLE_E_UNSUPPORTED;
+    SisoTdlParams pq = pp;
+    pq.ablate = 0;
+    if (const char* v = std::getenv("MCLE_TDL_ABLATE")) pq.ablate = std::atoi(v);
+    int waves = 3;                          // A/B runs: MCLE_TDL_MFMA_WAVES=2 -> 256 VGPRs, two workgroups per CU
+    if (const char* v = std::getenv("MCLE_TDL_MFMA_WAVES")) waves = std::atoi(v) == 2 ? 2 : 3;
+    auto kern = waves == 2 ? k_run_ofdm_tdl_mfma<2> : k_run_ofdm_tdl_mfma<3>;
+    MCLE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int per_cu = (int)((size_t)160 * 1024 / (lds + 512));
+    if (per_cu > waves) per_cu = waves;     // __launch_bounds__(256, WAVES)
+    const uint64_t cap = (uint64_t)ctx->n_cu * per_cu;
+    const uint64_t passes = (count + NB - 1) / NB;
+    const unsigned grid = (unsigned)(passes < cap ? passes : cap);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kPipeBlock), lds, ctx->stream, pq, mp, seed, first, count,
+                       (const float2*)tw, d_counters, d_sym, d_bit);
+    MCLE_LAUNCH_CHECK();
+    return MCLE_OK;
+}
+
 template <typename T, int N>
 int run_siso_tdl_batch_impl(mcle_ctx* ctx, SisoTdlParams pp, int method, uint64_t seed, uint64_t first, uint64_t count,
                             mcle_counters* d_counters, uint32_t* d_sym, uint32_t* d_bit) {
     constexpr int NB = 4;
     int rc;
+    if constexpr (sizeof(T) == 4 && N == kF16N) {
+        rc = run_siso_tdl_mfma(ctx, pp, method, seed, first, count, d_counters, d_sym, d_bit);
+        if (rc != MCLE_E_UNSUPPORTED) return rc;
+    }
     void* tw = nullptr;
     if ((rc = ctx->get_twiddles(N, sizeof(T) == 8 ? MCLE_F64 : MCLE_F32, &tw))) return rc;
     const ModemParams<T> mp = pipe_modem<T>(ctx, method);

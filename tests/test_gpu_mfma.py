@@ -94,3 +94,78 @@ def test_zero_noise_round_trip(engine):
                                dtype="f32")
     assert res["n_realizations"] > 4000
     assert res["sym_errors"] <= 1e-6 * res["n_realizations"] * 4096       # ill-conditioned H now and then
+
+
+# ---- config 3 on the matrix cores (csrc/pipeline_siso_tdl.hip: k_run_ofdm_tdl_mfma) ------------------------------------
+def _run_tdl(engine, first, count, mfma=True, waves=None, **kw):
+    from pyphysim_amd.channels import discretize_profile
+    keys = ("MCLE_NO_MFMA", "MCLE_TDL_MFMA_WAVES")
+    old = {k: os.environ.get(k) for k in keys}
+    try:
+        for k in keys:
+            os.environ.pop(k, None)
+        if not mfma:
+            os.environ["MCLE_NO_MFMA"] = "1"
+        if waves:
+            os.environ["MCLE_TDL_MFMA_WAVES"] = str(waves)
+        Ts = kw.get("Ts", 1.0 / (15e3 * 1024))
+        p_lin, d_idx = discretize_profile(np.asarray(kw.get("tap_powers_dB", (0.0, -3.0, -6.0, -9.0, -12.0)), dtype=float),
+                                          np.asarray(kw.get("tap_delays_samples", (0, 1, 2, 3, 4)), dtype=float) * Ts, Ts)
+        nv = 1.0 / omodem.dB2Linear(kw.get("snr_db", 20.0))
+        return engine.run_ofdm_tdl(1024, kw.get("cp_size", 16), kw.get("num_used") or 1024, kw.get("n_ofdm_sym", 1), nv,
+                                   p_lin, d_idx, SEED, first, count, Fd=kw.get("Fd", 10.0), Ts=Ts, L=kw.get("L", 8),
+                                   method=kw.get("method", _lib.DEMOD_MINDIST), dtype="f32", per_realization=True)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+TDL_CASES = [dict(mod="qpsk", M=4, snr_db=20.0),                                            # BASELINE config 3
+             dict(mod="qam", M=16, snr_db=24.0, num_used=608, n_ofdm_sym=2, L=12),          # partial band, 2 symbols
+             dict(mod="qam", M=64, snr_db=30.0, cp_size=9, tap_delays_samples=(0, 2, 5, 9), # odd CP: unpaired noise
+                  tap_powers_dB=(0.0, -2.0, -5.0, -8.0), Fd=200.0),
+             dict(mod="psk", M=8, snr_db=18.0, cp_size=32, tap_delays_samples=(0, 7, 17, 31),
+                  tap_powers_dB=(0.0, -1.0, -3.0, -6.0), Fd=900.0, n_ofdm_sym=3)]           # higher polynomial order
+
+
+@pytest.mark.parametrize("case", range(len(TDL_CASES)))
+@pytest.mark.parametrize("waves", [3, 2])
+def test_tdl_mfma_kernel_against_the_oracle_and_the_valu_kernel(engine, case, waves):
+    kw = dict(TDL_CASES[case])
+    mod, M = kw.pop("mod"), kw.pop("M")
+    kind = _lib.CONST_QAM if mod == "qam" else _lib.CONST_GENERIC
+    engine.set_constellation(chains.constellation(mod, M), kind)
+    first, count = 70001, 22                  # not a multiple of the four slots of a pass
+    okw = dict(mod=mod, M=M, fft_size=1024, cp_size=kw.get("cp_size", 16), num_used=kw.get("num_used"),
+               n_ofdm_sym=kw.get("n_ofdm_sym", 1), snr_db=kw["snr_db"], Fd=kw.get("Fd", 10.0), L=kw.get("L", 8),
+               tap_powers_dB=kw.get("tap_powers_dB", (0.0, -3.0, -6.0, -9.0, -12.0)),
+               tap_delays_samples=kw.get("tap_delays_samples", (0, 1, 2, 3, 4)))
+    want = [chains.chain_ofdm_tdl(chains.PhiloxRng(SEED, r), **okw) for r in range(first, first + count)]
+    want_se = np.array([w["symbol_errors"] for w in want], dtype=np.int64)
+    want_be = np.array([w["bit_errors"] for w in want], dtype=np.int64)
+    nsym, nbits = want[0]["num_symbols"], want[0]["num_bits"]
+    res, se, be = _run_tdl(engine, first, count, waves=waves, **kw)
+    assert res["n_symbols"] == nsym and res["n_bits"] == nbits and res["n_realizations"] == count
+    assert abs(int(se.sum()) - int(want_se.sum())) <= 1e-4 * count * nsym + 2
+    assert abs(int(be.sum()) - int(want_be.sum())) <= 1e-4 * count * nbits + 2
+    assert np.max(np.abs(se.astype(np.int64) - want_se)) <= 3                 # boundary ties only
+    res_v, se_v, be_v = _run_tdl(engine, first, count, mfma=False, **kw)
+    assert np.max(np.abs(se.astype(np.int64) - se_v.astype(np.int64))) <= 3
+    assert res["sym_errors_sq"] == int((se.astype(np.int64) ** 2).sum())
+    assert res["bit_errors"] == int(be.astype(np.int64).sum())
+    # bit-identical from run to run and under any split of the realization range
+    a = _run_tdl(engine, first, 9, waves=waves, **kw)
+    b = _run_tdl(engine, first + 9, count - 9, waves=waves, **kw)
+    assert np.array_equal(np.concatenate([a[1], b[1]]), se) and np.array_equal(np.concatenate([a[2], b[2]]), be)
+
+
+def test_tdl_mfma_zero_noise_round_trip(engine):
+    engine.set_constellation(chains.constellation("qam", 64), _lib.CONST_QAM)
+    res, se, be = _run_tdl(engine, 11, 4099, snr_db=300.0, method=_lib.DEMOD_QAM_SLICER)
+    assert res["n_realizations"] == 4099
+    assert res["sym_errors"] <= 2e-4 * 4099 * 1024                            # deep fades of the one-tap channel only
+    ref, se_v, be_v = _run_tdl(engine, 11, 4099, mfma=False, snr_db=300.0, method=_lib.DEMOD_QAM_SLICER)
+    assert abs(res["sym_errors"] - ref["sym_errors"]) <= 1e-5 * 4099 * 1024 + 2
