@@ -32,7 +32,6 @@ constexpr int kSisoMaxOrder = 12;
 struct SisoTdlParams {
     int cp, num_used, n_ofdm_sym;
     int n_taps, L, K, dmax;
-    int ablate;                      // experiment knob (MCLE_TDL_ABLATE): stages switched off, results meaningless
     int x_elems;                     // complex elements of the sample buffer (>= NB*N; also holds the ray scratch)
     double noise_var, Fd, Ts, dt;
     double tap_amp[MCLE_MAX_TAPS];   // sqrt(p_s / L)
@@ -420,14 +419,24 @@ __global__ __launch_bounds__(kPipeBlock, WAVES) void k_run_ofdm_tdl_mfma(
     const int k1p = 4 * w + (j >> 2), m2p = j & 3;   // P2 / P2': this lane's group (row k1p, residue m2p)
     // middle stage: lane -> butterfly (row k1m, j1m); lanes l and l ^ 1 hold time samples m and m + 1
     const int kkm = ((lane >> 5) << 1) | (lane & 1), j1m = (lane >> 1) & 15, k1m = 4 * w + kkm, par = lane & 1;
-    float2 tw1a[4], tw2a[4], tw1b[4], tw2b[3];
+    // the three sets of pass twiddles are fetched from the (L1-resident) table at the top of their pass instead of
+    // living in 24 registers across the whole loop (1.61 vs 1.63 ms; `opaque` keeps the loads from being hoisted)
+    auto load_tw1a = [&](float2 (&tw)[4], int n2_) {
 #pragma unroll
-    for (int x = 0; x < 4; ++x) {
-        tw1a[x] = g_tw[((4 * g + x) * n2) & 1023];                            // P1 : W1024^{k1 n2}
-        tw2a[x] = g_tw[(16 * (4 * g + x) * m2p) & 1023];                      // P2 : W64^{j1 m2} ...
-        if ((k1p & 1) && (m2p & 1)) tw2a[x] = make_float2(-tw2a[x].x, -tw2a[x].y);   // ... x the P3 slot order of odd rows
-        tw1b[x] = g_tw[((4 * (4 * g + x) + m2p) * k1p) & 1023];               // P2': W1024^{(4 m1 + m2) k1}
-    }
+        for (int x = 0; x < 4; ++x) tw[x] = g_tw[((4 * g + x) * n2_) & 1023];               // P1 : W1024^{k1 n2}
+    };
+    auto load_tw2a = [&](float2 (&tw)[4], int m2_) {
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            tw[x] = g_tw[(16 * (4 * g + x) * m2_) & 1023];                                  // P2 : W64^{j1 m2} ...
+            if ((k1p & 1) && (m2_ & 1)) tw[x] = make_float2(-tw[x].x, -tw[x].y);            // ... x the P3 slot order of odd rows
+        }
+    };
+    auto load_tw1b = [&](float2 (&tw)[4], int k1_) {
+#pragma unroll
+        for (int x = 0; x < 4; ++x) tw[x] = g_tw[((4 * (4 * g + x) + m2p) * k1_) & 1023];   // P2': W1024^{(4 m1 + m2) k1}
+    };
+    float2 tw1a[4], tw2a[4], tw1b[4], tw2b[3];
 #pragma unroll
     for (int m2 = 1; m2 < 4; ++m2) {
         tw2b[m2 - 1] = g_tw[(16 * m2 * j1m) & 1023];                          // P3': W64^{m2 j1} x slot order
@@ -464,7 +473,7 @@ __global__ __launch_bounds__(kPipeBlock, WAVES) void k_run_ofdm_tdl_mfma(
             {
                 const double two_pi = 6.283185307179586476925286766559;
                 const double tc = pp.Ts + pp.dt * ((double)sym0 + xc);
-                for (int q = tid; q < PS * L && !((pp.ablate & 1) && it > 0); q += kPipeBlock) {
+                for (int q = tid; q < PS * L; q += kPipeBlock) {
                     const int a = q / (S * L), rq = q - a * (S * L);      // rq = l*S + s: PHASE-stream index of phi
                     const int l = rq / S, s = rq - l * S;
                     const Rng rng(seed, first + base + a);
@@ -525,6 +534,7 @@ __global__ __launch_bounds__(kPipeBlock, WAVES) void k_run_ofdm_tdl_mfma(
                 __syncthreads();
             }
             // ---- P1: DFT-16 over n1, x W1024^{k1 n2} ----
+            load_tw1a(tw1a, opaque(n2));
             dft16_pass4(s_d, plane_g, mats, tw1a, [&](int t) { return (p1_ld ^ (((2 * t) & 7) << 2)) + 128 * t; },
                         [&](int x) { return (p1_st ^ ((x << 2) ^ ((x & 1) << 5))) + 64 * x; }, [&]() {});
             __syncthreads();
@@ -543,7 +553,6 @@ __global__ __launch_bounds__(kPipeBlock, WAVES) void k_run_ofdm_tdl_mfma(
                 }
             }
             // ---- tap polynomials around the middle of this symbol: one (process, order) per thread ----
-            if (!((pp.ablate & 2) && it > 0))
             for (int q = tid; q < PS * (K + 1); q += kPipeBlock) {
                 const int p = q / (K + 1), m = q - p * (K + 1);
                 float inv_fact = 1.f;
@@ -568,6 +577,7 @@ __global__ __launch_bounds__(kPipeBlock, WAVES) void k_run_ofdm_tdl_mfma(
                 s_coef[q] = make_float2(amp * cr, amp * ci);
             }
             // ---- P2: DFT-16 over m1, x W64^{j1 m2} ----
+            load_tw2a(tw2a, opaque(m2p));
             dft16_pass4(s_d, plane_g, mats, tw2a, [&](int t) { return p2_ld ^ (8 * t); },
                         [&](int x) { return p2_st ^ (4 * x); }, [&]() {});
             wave_lds_sync();
@@ -609,8 +619,7 @@ __global__ __launch_bounds__(kPipeBlock, WAVES) void k_run_ofdm_tdl_mfma(
                 for (int a = 0; a < NB; ++a) yr[sl][a] = yi[sl][a] = 0.f;
             auto channel = [&](auto k_tag) {      // KT > 0: polynomial order known at compile time
                 constexpr int KT = decltype(k_tag)::value;
-                const int n_taps = (pp.ablate & 8) ? 1 : S;
-                for (int s = 0; s < n_taps; ++s) {
+                for (int s = 0; s < S; ++s) {
                     const int d = pp.tap_delay[s];
                     const int mm = (m0 - d) & (N - 1);
                     const int kk = mm & 15, q0 = mm >> 4, ksw = (kk & 3) << 4;
@@ -658,8 +667,7 @@ __global__ __launch_bounds__(kPipeBlock, WAVES) void k_run_ofdm_tdl_mfma(
             {   // noise of the samples that survive CP removal: sample sym0 + cp + m of every slot's own NOISE stream;
                 // lanes l, l ^ 1 (samples m, m + 1) share a Philox block when that index pair is (even, odd)
                 const uint64_t i_base = sym0 + (uint64_t)cp + (uint64_t)m0;
-                if (pp.ablate & 4) {
-                } else if (((sym0 + (uint64_t)cp) & 1) == 0) {
+                if (((sym0 + (uint64_t)cp) & 1) == 0) {
 #pragma unroll
                     for (int a = 0; a < NB; ++a) {
                         const Rng rng(seed, first + base + a);
@@ -708,6 +716,7 @@ __global__ __launch_bounds__(kPipeBlock, WAVES) void k_run_ofdm_tdl_mfma(
             }
             wave_lds_sync();
             // ---- P2': DFT-16 over j1, x W1024^{(4 m1 + m2) k1} ----
+            load_tw1b(tw1b, opaque(k1p));
             dft16_pass4(s_d, plane_g, mats, tw1b, [&](int t) { return p2_ld ^ (8 * t); },
                         [&](int x) { return p2_st ^ (4 * x); }, [&]() {});
             __syncthreads();
@@ -730,7 +739,7 @@ __global__ __launch_bounds__(kPipeBlock, WAVES) void k_run_ofdm_tdl_mfma(
                 for (int x = 0; x < 4; ++x)
 #pragma unroll
                     for (int a = 0; a < NB; ++a) hq[x][a] = make_float2(0.f, 0.f);
-                for (int s = 0; s < ((pp.ablate & 16) ? 1 : S); ++s) {
+                for (int s = 0; s < S; ++s) {
                     const int d = pp.tap_delay[s];
                     float2 mean[NB];
 #pragma unroll
@@ -745,7 +754,7 @@ __global__ __launch_bounds__(kPipeBlock, WAVES) void k_run_ofdm_tdl_mfma(
 #pragma unroll
                 for (int x = 0; x < 4; ++x) {
                     const int d = ofdm_data_index(64 * (4 * g + x) + n2, N, U);
-                    if (d >= 0 && !(pp.ablate & 32)) {
+                    if (d >= 0) {
                         float2 eq[NB];
                         int dec[NB];
 #pragma unroll
@@ -821,11 +830,11 @@ int run_siso_tdl_mfma(mcle_ctx* ctx, const SisoTdlParams& pp, int method, uint64
                        (PS * (pp.K + 1) + PS) * sizeof(float2) + ((3 * PS * pp.L + 1) & ~(size_t)1) * sizeof(float) +
                        64 * sizeof(unsigned);
     if (lds + 512 > (size_t)160 * 1024 / 2) return MCLE_E_UNSUPPORTED;
-    SisoTdlParams pq = pp;
-    pq.ablate = 0;
-    if (const char* v = std::getenv("MCLE_TDL_ABLATE")) pq.ablate = std::atoi(v);
-    int waves = 3;                          // A/B runs: MCLE_TDL_MFMA_WAVES=2 -> 256 VGPRs, two workgroups per CU
-    if (const char* v = std::getenv("MCLE_TDL_MFMA_WAVES")) waves = std::atoi(v) == 2 ? 2 : 3;
+    // two workgroups per CU with 256 VGPRs (13 spilled registers) beat three with 168 (130 spilled): 1.63 vs 2.04 ms per
+    // 131072 realizations (A/B: MCLE_TDL_MFMA_WAVES=3).  The equaliser's W^{f d} from an LDS copy instead of the
+    // L1-resident global table: 1.62 vs 1.63 ms, not kept.
+    int waves = 2;
+    if (const char* v = std::getenv("MCLE_TDL_MFMA_WAVES")) waves = std::atoi(v) == 3 ? 3 : 2;
     auto kern = waves == 2 ? k_run_ofdm_tdl_mfma<2> : k_run_ofdm_tdl_mfma<3>;
     MCLE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int per_cu = (int)((size_t)160 * 1024 / (lds + 512));
@@ -833,7 +842,7 @@ int run_siso_tdl_mfma(mcle_ctx* ctx, const SisoTdlParams& pp, int method, uint64
     const uint64_t cap = (uint64_t)ctx->n_cu * per_cu;
     const uint64_t passes = (count + NB - 1) / NB;
     const unsigned grid = (unsigned)(passes < cap ? passes : cap);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kPipeBlock), lds, ctx->stream, pq, mp, seed, first, count,
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kPipeBlock), lds, ctx->stream, pp, mp, seed, first, count,
                        (const float2*)tw, d_counters, d_sym, d_bit);
     MCLE_LAUNCH_CHECK();
     return MCLE_OK;

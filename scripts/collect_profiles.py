@@ -31,7 +31,7 @@ CONFIGS = {
     "c4": ("k_run_mimo_ofdm_mfma<", "k_run_mimo_ofdm_mfma<3,2> (f32, FFT 1024, 4x4), %d realizations per launch (bench.py default workload)"),
     "c4md": ("k_run_mimo_ofdm_mfma<", "k_run_mimo_ofdm_mfma<3,2> with the min-distance demodulator over the LDS table (bench.py --demod mindist), %d realizations per launch"),
     "f1": ("k_run_mimo_ofdm_tdl<", "k_run_mimo_ofdm_tdl<float,1024,4>, %d realizations per launch (bench.py --config f1)"),
-    "c3": ("k_run_ofdm_tdl_batch<", "k_run_ofdm_tdl_batch<float,1024,4>, %d realizations per launch (bench.py --config c3)"),
+    "c3": ("k_run_ofdm_tdl_mfma<", "k_run_ofdm_tdl_mfma<3> (f32, FFT 1024, 4 realizations per pass), %d realizations per launch (bench.py --config c3)"),
     "c2": ("k_run_flat<", "k_run_flat<float,8>, %d realizations per launch (bench.py --config c2)"),
     "c5": ("k_run_ia<", "k_run_ia<float>, %d realizations per launch (bench.py --config c5)"),
     "f6": ("k_run_bd<", "k_run_bd<float,2>, %d realizations per launch (bench.py --config f6)"),

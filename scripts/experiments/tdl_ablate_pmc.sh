@@ -1,4 +1,7 @@
 #!/bin/bash
+# needs the stage-ablation knob: git apply scripts/experiments/tdl_ablate.patch && make -C pyphysim_amd/csrc (results are
+# meaningless with stages off; the knob is not in the product kernel).  Bits: 1 rays, 2 tap polynomials (both only after the
+# first pass), 4 noise, 8 taps 1.., 16 equaliser taps 1.., 32 equalise + demodulate.
 # dynamic VALU / LDS instruction counts of the config-3 matrix-core kernel with stages switched off (MCLE_TDL_ABLATE)
 export TMPDIR=/tmp; mkdir -p gpurun_out
 for ab in ${ABLATES:-0 1 2 4 8 16 32 63}; do
