@@ -243,6 +243,29 @@ int mcle_gmd_filters(mcle_ctx* ctx, int dtype, const void* d_H, int n_ant, doubl
 int mcle_post_processing_sinrs(mcle_ctx* ctx, const void* d_H, const void* d_W, const void* d_G, double noise_var,
                                int nr, int nt, int ns, double* d_sinr, size_t batch);
 
+/* ---- K-user interference channel: covariance matrices and post-filter SINRs ------------------
+ * MultiUserChannelMatrix / MultiUserChannelMatrixExtInt (channels/multiuser.py): calc_Q / calc_JP_Q (:1314-1450,
+ * :2530-2634), _calc_Bkl_cov_matrix_all_l and its JP form (:1452-1826, :2676-2742), calc_SINR / calc_JP_SINR
+ * (:1828-2008, :2636-2807), calc_cov_matrix_extint_plus_noise (:2469-2520), path loss on the block matrix (:1264-1312).
+ * complex128.  d_bigH [batch][sum nr][sum nt + n_ext]; d_pathloss (may be NULL) [sum nr][sum nt + n_ext] LINEAR power
+ * ratio per entry (the reference's _pathloss_big_matrix; shared by the batch); d_F [batch][K][16][4]: user j's
+ * precoder in the top-left corner (nt[j] x ns[j], or (sum nt) x ns[j] when `joint`); d_U [batch][K][4][4]
+ * (nr[k] x ns[k], may be NULL).  Outputs (each may be NULL), zero padded: d_Q [batch][K][4][4] interference from
+ * the other users + Re_k; d_Re [batch][K][4][4] = pe ext ext^H + noise_var I; d_B [batch][K][4][4][4] (stream l:
+ * everything received minus stream l's own covariance); d_sinr [batch][K][4] (linear). */
+typedef struct mcle_mu_stats_cfg {
+    int32_t K;                  /* users (with receive antennas), <= 4 */
+    int32_t n_ext;              /* external interferer antennas: trailing columns of big_H, <= 8 */
+    int32_t joint;              /* 0: per-link precoders (calc_Q, calc_SINR); 1: joint processing (calc_JP_*) */
+    int32_t reserved;
+    int32_t nr[4], nt[4], ns[4];
+    double noise_var;           /* 0: no noise term */
+    double pe;                  /* power of the external interference */
+} mcle_mu_stats_cfg;
+int mcle_mu_link_stats(mcle_ctx* ctx, const mcle_mu_stats_cfg* cfg, const void* d_bigH, const double* d_pathloss,
+                       const void* d_F, const void* d_U, void* d_Q, void* d_Re, void* d_B, double* d_sinr,
+                       size_t batch);
+
 /* ---- fused pipelines: whole realizations on-chip (randomness: mcle-philox-v1) ----------- */
 typedef struct mcle_awgn_cfg {          /* C1: apps/awgn_modulators/simulate_psk.py:51-115 */
     int32_t n_symbols;

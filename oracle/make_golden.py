@@ -278,6 +278,98 @@ def golden_bd_extint():
 
 
 # ----------------------------------------------------------------------------- chains
+def golden_multiuser_stats():
+    """tests/golden/a14b_multiuser_stats.npz: covariance matrices and SINRs of the reference's MultiUserChannelMatrix and
+    MultiUserChannelMatrixExtInt (path loss, per-link and joint-processing forms) on seeded channels and seeded
+    precoders / filters, with oracle/multiuser.py asserted equal first."""
+    from pyphysim.channels import multiuser as rmu
+    from oracle import multiuser as omu
+    rs = np.random.RandomState(BASE_SEED + 77)
+    cases = [dict(Nr=(2, 2, 2), Nt=(2, 2, 2), Ns=(1, 1, 1), nv=0.05, pl=False, ext=None),
+             dict(Nr=(2, 4, 3), Nt=(3, 2, 4), Ns=(1, 2, 2), nv=0.2, pl=True, ext=None),
+             dict(Nr=(3, 3), Nt=(3, 3), Ns=(2, 3), nv=None, pl=True, ext=None),
+             dict(Nr=(2, 2, 2), Nt=(2, 2, 2), Ns=(1, 2, 1), nv=0.01, pl=False, ext=(2,), pe=0.7),
+             dict(Nr=(4, 2), Nt=(3, 4), Ns=(3, 1), nv=0.1, pl=True, ext=(1, 2), pe=1.6),
+             dict(Nr=(2, 3, 2, 4), Nt=(4, 4, 4, 4), Ns=(2, 2, 1, 3), nv=0.03, pl=True, ext=(3,), pe=0.25)]
+    store, worst = {"n_cases": np.array(len(cases))}, 0.0
+    randc = lambda *shape: (rs.randn(*shape) + 1j * rs.randn(*shape)) / math.sqrt(2.0)
+    for ci, c in enumerate(cases):
+        Nr, Nt, Ns, K = np.array(c["Nr"]), np.array(c["Nt"]), c["Ns"], len(c["Nr"])
+        ext = c["ext"]
+        pe = c.get("pe", 1.0)
+        if ext is None:
+            muc = rmu.MultiUserChannelMatrix()
+            muc.set_channel_seed(BASE_SEED + 80 + ci)
+            muc.randomize(Nr, Nt, K)
+        else:
+            muc = rmu.MultiUserChannelMatrixExtInt()
+            muc.set_channel_seed(BASE_SEED + 80 + ci)
+            muc.randomize(Nr, Nt, K, np.array(ext))
+        muc.noise_var = c["nv"]
+        pl = pl_ext = None
+        if c["pl"]:
+            pl = rs.uniform(0.05, 1.0, (K, K))
+            if ext is None:
+                muc.set_pathloss(pl)
+            else:
+                pl_ext = rs.uniform(0.05, 1.0, (K, len(ext)))
+                muc.set_pathloss(pl, pl_ext)
+        raw_H = np.array(muc._big_H_no_pathloss)
+        n_ext = 0 if ext is None else int(np.sum(ext))
+        full_Nt = Nt if ext is None else np.hstack([Nt, np.array(ext)])
+        pl_big = None
+        if pl is not None:
+            pl_big = omu.pathloss_big(pl if ext is None else np.hstack([pl, pl_ext]), Nr, full_Nt)
+        H_eff = omu.effective_big_H(raw_H, pl_big)
+        assert close(H_eff, np.array(muc.big_H)) < 1e-14
+        pre = "case%d_" % ci
+        store[pre + "Nr"], store[pre + "Nt"], store[pre + "Ns"] = Nr, Nt, np.array(Ns)
+        store[pre + "ext"] = np.array(ext if ext is not None else [], dtype=np.int64)
+        store[pre + "par"] = np.array([c["nv"] if c["nv"] is not None else -1.0, pe])
+        store[pre + "big_H"] = raw_H
+        if pl is not None:
+            store[pre + "pl"] = pl
+            if pl_ext is not None:
+                store[pre + "pl_ext"] = pl_ext
+        for joint in (False, True):
+            tag = pre + ("jp_" if joint else "")
+            F = np.empty(K, dtype=np.ndarray)
+            U = np.empty(K, dtype=np.ndarray)
+            for k in range(K):
+                F[k] = randc(int(np.sum(Nt)) if joint else int(Nt[k]), Ns[k])
+                U[k] = randc(int(Nr[k]), Ns[k])
+                store[tag + "F%d" % k], store[tag + "U%d" % k] = F[k], U[k]
+            kw = {} if ext is None else {"pe": pe}
+            sinr = (muc.calc_JP_SINR if joint else muc.calc_SINR)(F, U, **kw)
+            mine = omu.calc_sinr(H_eff, Nr, full_Nt[:K] if ext is None else Nt, F, U, c["nv"], pe, joint) if ext is None else \
+                omu.calc_sinr(H_eff, Nr, Nt, F, U, c["nv"], pe, joint)
+            for k in range(K):
+                worst = max(worst, close(np.asarray(sinr[k], dtype=float), mine[k], 1e-10, "sinr"))
+                store[tag + "sinr%d" % k] = np.asarray(sinr[k], dtype=float)
+                Q = (muc.calc_JP_Q if joint else muc.calc_Q)(k, F, **kw)
+                myQ = omu.calc_Q(H_eff, Nr, Nt, k, F, c["nv"], pe if ext is not None else 0.0, joint)
+                worst = max(worst, close(Q, myQ, 1e-12, "Q"))
+                store[tag + "Q%d" % k] = np.array(Q)
+            k = K - 1                      # the per-stream covariance matrices of the last user
+            if ext is None:
+                B = (muc._calc_JP_Bkl_cov_matrix_all_l if joint else muc._calc_Bkl_cov_matrix_all_l)(F, k, c["nv"] or 0.0)
+                Rek = np.eye(int(Nr[k])) * (c["nv"] or 0.0)
+            else:
+                Rek = muc.calc_cov_matrix_extint_plus_noise(pe)[k]
+                B = (muc._calc_JP_Bkl_cov_matrix_all_l if joint else muc._calc_Bkl_cov_matrix_all_l)(F, k, Rek)
+            myB = omu.bkl_all_l(H_eff, Nr, Nt, k, F, Rek, joint)
+            for l in range(Ns[k]):
+                worst = max(worst, close(B[l], myB[l], 1e-12, "B"))
+            store[tag + "B_last"] = np.array([np.array(b) for b in B])
+        if ext is not None:
+            Re = muc.calc_cov_matrix_extint_plus_noise(pe)
+            for k in range(K):
+                worst = max(worst, close(Re[k], omu.cov_ext_plus_noise(H_eff, Nr, Nt, k, pe, c["nv"]), 1e-12, "Re"))
+                store[pre + "Re%d" % k] = np.array(Re[k])
+    np.savez_compressed(os.path.join(GOLD, "a14b_multiuser_stats.npz"), **store)
+    print("a14b_multiuser_stats: oracle == reference on %d channels x (per-link, joint) (worst %.2e)" % (len(cases), worst))
+
+
 def ref_chain_awgn(seed, mod, M, N, snr_db):
     np.random.seed(seed)
     m = ref_modulator(mod, M)
@@ -788,8 +880,10 @@ if __name__ == "__main__":
         golden_operators()
     if not only or "f6b_bd_extint" in only:
         golden_bd_extint()
-    only = only - {"f6b_bd_extint"} if only else only
-    if only == set() and "f6b_bd_extint" in sys.argv[1:]:
+    if not only or "a14b_multiuser_stats" in only:
+        golden_multiuser_stats()
+    only = only - {"f6b_bd_extint", "a14b_multiuser_stats"} if only else only
+    if only == set() and set(sys.argv[1:]) & {"f6b_bd_extint", "a14b_multiuser_stats"}:
         sys.exit(0)
     if not only or only - {"operators"}:
         golden_chains(only - {"operators"})

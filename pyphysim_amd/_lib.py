@@ -100,6 +100,11 @@ class BdExtIntCfg(Structure):
 BD_METRICS = {None: 0, "None": 0, "naive": 1, "fixed": 2, "capacity": 3, "candidates": 4, "per_user": 5}
 
 
+class MuStatsCfg(Structure):
+    _fields_ = [("K", c_int32), ("n_ext", c_int32), ("joint", c_int32), ("reserved", c_int32), ("nr", c_int32 * 4),
+                ("nt", c_int32 * 4), ("ns", c_int32 * 4), ("noise_var", c_double), ("pe", c_double)]
+
+
 class IaGeneralCfg(Structure):
     _fields_ = [("K", c_int32), ("nr", c_int32), ("nt", c_int32), ("ns", c_int32 * 4), ("solver", c_int32),
                 ("initialize_with", c_int32), ("max_iterations", c_int32), ("stream_selection", c_int32),
@@ -183,6 +188,7 @@ _PROTOS = {
     "mcle_gmd_filters": (c_int, [_P, c_int, _P, c_int, c_double, _P, _P, _P, _P, c_size_t]),
     "mcle_bd_extint": (c_int, [_P, POINTER(BdExtIntCfg), _P, _P, _P, _P, _P, _P, c_size_t]),
     "mcle_ia_solve_general": (c_int, [_P, POINTER(IaGeneralCfg), _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t]),
+    "mcle_mu_link_stats": (c_int, [_P, POINTER(MuStatsCfg), _P, _P, _P, _P, _P, _P, _P, _P, c_size_t]),
     "mcle_post_processing_sinrs": (c_int, [_P, _P, _P, _P, c_double, c_int, c_int, c_int, _P, c_size_t]),
     "mcle_run_awgn": (c_int, [_P, c_int, POINTER(AwgnCfg), c_uint64, c_uint64, c_uint64, _P, _P, _P]),
     "mcle_run_flat_fading": (c_int, [_P, c_int, POINTER(FlatCfg), c_uint64, c_uint64, c_uint64, _P, _P, _P]),

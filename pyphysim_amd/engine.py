@@ -596,6 +596,77 @@ class Engine:
                                                               nr, nt, ns, out.ptr, b))
         return out.get()
 
+    def mu_link_stats(self, big_H, Nr, Nt, F=None, U=None, noise_var=0.0, pe=1.0, n_ext=0, joint=False, pathloss_big=None,
+                      want=("Q", "Re", "B", "sinr")):
+        """MultiUserChannelMatrix(ExtInt).calc_Q / calc_JP_Q / _calc_Bkl_cov_matrix_all_l / calc_SINR / calc_JP_SINR /
+        calc_cov_matrix_extint_plus_noise (channels/multiuser.py:1314-2008, :2469-2807) for a batch of channels.
+        big_H [b, sum Nr, sum Nt + n_ext]; F: per user [b?, rows, Ns_k] (rows = Nt[k], or sum Nt when `joint`); U: per
+        user [b?, Nr[k], Ns_k].  -> dict of per-user lists: Q[k] [b, Nr_k, Nr_k], Re[k], B[k] [b, Ns_k, Nr_k, Nr_k],
+        sinr[k] [b, Ns_k]."""
+        from ._lib import MuStatsCfg
+        H = np.ascontiguousarray(big_H, dtype=np.complex128)
+        if H.ndim == 2:
+            H = H[None]
+        Nr, Nt = [int(v) for v in Nr], [int(v) for v in Nt]
+        K, b = len(Nr), H.shape[0]
+        if K < 1 or K > 4 or len(Nt) != K or max(Nr + Nt) > 4 or min(Nr + Nt) < 1 or not 0 <= int(n_ext) <= 8:
+            raise ValueError("mu_link_stats covers up to 4 users with up to 4 antennas per node and 8 external antennas")
+        if H.shape[1:] != (sum(Nr), sum(Nt) + int(n_ext)):
+            raise ValueError("big_H must be [sum(Nr), sum(Nt) + n_ext]")
+        cfg = MuStatsCfg()
+        cfg.K, cfg.n_ext, cfg.joint, cfg.noise_var, cfg.pe = K, int(n_ext), 1 if joint else 0, float(noise_var or 0.0), float(pe)
+        ns = [0] * K
+        Fp = np.zeros((b, K, 16, 4), dtype=np.complex128)
+        Up = np.zeros((b, K, 4, 4), dtype=np.complex128)
+        if F is not None:
+            for k in range(K):
+                Fk = np.asarray(F[k], dtype=np.complex128)
+                Fk = Fk.reshape(Fk.shape[0], -1) if Fk.ndim < 3 else Fk
+                rows = sum(Nt) if joint else Nt[k]
+                if Fk.shape[-2] != rows or Fk.shape[-1] > 4:
+                    raise ValueError("precoder of user %d must have %d rows and at most 4 streams" % (k, rows))
+                ns[k] = Fk.shape[-1]
+                Fp[:, k, :rows, :ns[k]] = Fk
+        if U is not None:
+            for k in range(K):
+                Uk = np.asarray(U[k], dtype=np.complex128)
+                Uk = Uk.reshape(Uk.shape[0], -1) if Uk.ndim < 3 else Uk
+                if Uk.shape[-2] != Nr[k] or Uk.shape[-1] != ns[k]:
+                    raise ValueError("receive filter of user %d must be [Nr, Ns] = [%d, %d]" % (k, Nr[k], ns[k]))
+                Up[:, k, :Nr[k], :ns[k]] = Uk
+        for k in range(K):
+            cfg.nr[k], cfg.nt[k], cfg.ns[k] = Nr[k], Nt[k], ns[k]
+        d_pl = None
+        if pathloss_big is not None:
+            pl = np.ascontiguousarray(pathloss_big, dtype=np.float64)
+            if pl.shape != H.shape[1:]:
+                raise ValueError("the path loss matrix must have big_H's shape")
+            d_pl = self.to_device(pl)
+        dQ = self.empty((b, K, 4, 4), np.complex128) if "Q" in want else None
+        dRe = self.empty((b, K, 4, 4), np.complex128) if "Re" in want else None
+        dB = self.empty((b, K, 4, 4, 4), np.complex128) if "B" in want else None
+        dS = self.empty((b, K, 4), np.float64) if ("sinr" in want and U is not None) else None
+        dH, dF = self.to_device(H), self.to_device(Fp)
+        dU = self.to_device(Up) if U is not None else None
+        self._raise_value(self.lib.mcle_mu_link_stats(self.ctx, byref(cfg), dH.ptr, d_pl.ptr if d_pl else None, dF.ptr,
+                                                      dU.ptr if dU else None, dQ.ptr if dQ else None,
+                                                      dRe.ptr if dRe else None, dB.ptr if dB else None,
+                                                      dS.ptr if dS else None, b))
+        out = {"ns": ns}
+        if dQ:
+            q = dQ.get()
+            out["Q"] = [q[:, k, :Nr[k], :Nr[k]] for k in range(K)]
+        if dRe:
+            r = dRe.get()
+            out["Re"] = [r[:, k, :Nr[k], :Nr[k]] for k in range(K)]
+        if dB:
+            bb = dB.get()
+            out["B"] = [bb[:, k, :ns[k], :Nr[k], :Nr[k]] for k in range(K)]
+        if dS:
+            sv = dS.get()
+            out["sinr"] = [sv[:, k, :ns[k]] for k in range(K)]
+        return out
+
     # ---- fused pipelines --------------------------------------------------------------------
     def _run(self, fn, cfg, seed, first, count, dtype, per_realization, counters=None):
         dt = self._dt(dtype)

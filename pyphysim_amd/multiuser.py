@@ -1,9 +1,11 @@
-"""Mirror of pyphysim.channels.multiuser.MultiUserChannelMatrix (reference channels/multiuser.py:586-1262, the part
-the interference-alignment path uses; path loss, external interference and the OFDM variants are out of scope).
+"""Mirror of pyphysim.channels.multiuser.MultiUserChannelMatrix / MultiUserChannelMatrixExtInt (reference
+channels/multiuser.py:586-2807): the K-user block channel with path loss, its covariance matrices (calc_Q, calc_JP_Q,
+_calc_Bkl_cov_matrix_*) and post-filter SINRs (calc_SINR, calc_JP_SINR), with and without external interference.
 
 The channel and noise draws come from the object's own NumPy ``RandomState``s exactly as in the reference
 (:670-709, :1036-1038, :1206-1210), so ``set_channel_seed`` / ``set_noise_seed`` reproduce reference runs; the
-arithmetic ``big_H @ X + noise`` runs in `k_mimo_channel` on the GPU.
+arithmetic runs on the GPU: ``big_H @ X + noise`` in `k_mimo_channel`, everything covariance- or SINR-shaped in
+`k_mu_link_stats` (csrc/kernels_multiuser.hip).
 """
 import math
 
@@ -30,6 +32,8 @@ class MultiUserChannelMatrix:
         self._noise_var = None
         self._W = None
         self._big_W = None
+        self._pathloss_matrix = None
+        self._pathloss_big_matrix = None
 
     @property
     def engine(self):
@@ -52,9 +56,32 @@ class MultiUserChannelMatrix:
     Nr = property(lambda self: self._Nr)
     Nt = property(lambda self: self._Nt)
     K = property(lambda self: self._K)
-    big_H = property(lambda self: self._big_H)
     last_noise = property(lambda self: self._last_noise)
-    pathloss = property(lambda self: None)
+    pathloss = property(lambda self: self._pathloss_matrix)
+
+    @property
+    def big_H(self):
+        """multiuser.py:780-805: the block matrix, times sqrt(path loss) entry by entry when one is set."""
+        if self._pathloss_big_matrix is None:
+            return self._big_H
+        return self._big_H * np.sqrt(self._pathloss_big_matrix)
+
+    @staticmethod
+    def _from_small_matrix_to_big_matrix(small_matrix, Nr, Nt, Kr, Kt=None):
+        """multiuser.py:860-933: entry (k, l) repeated over the Nr[k] x Nt[l] block."""
+        Kt = Kr if Kt is None else Kt
+        small_matrix = np.asarray(small_matrix)
+        rows = [np.hstack([np.ones((int(Nr[k]), int(Nt[l]))) * small_matrix[k, l] for l in range(Kt)]) for k in range(Kr)]
+        return np.vstack(rows)
+
+    def set_pathloss(self, pathloss_matrix=None):
+        """multiuser.py:1264-1312: K x K LINEAR power ratios, transmitter l (column) to receiver k (row)."""
+        self._pathloss_matrix = None if pathloss_matrix is None else np.array(pathloss_matrix, dtype=float)
+        if pathloss_matrix is None:
+            self._pathloss_big_matrix = None
+        else:
+            self._pathloss_big_matrix = self._from_small_matrix_to_big_matrix(self._pathloss_matrix, self._Nr, self._Nt,
+                                                                              self._K)
 
     @property
     def H(self):
@@ -100,11 +127,11 @@ class MultiUserChannelMatrix:
     def get_Hkl(self, k, l):
         """Channel from transmitter l to receiver k (multiuser.py:1046-1089)."""
         r0, t0 = int(np.sum(self._Nr[:k])), int(np.sum(self._Nt[:l]))
-        return self._big_H[r0:r0 + self._Nr[k], t0:t0 + self._Nt[l]]
+        return self.big_H[r0:r0 + self._Nr[k], t0:t0 + self._Nt[l]]
 
     def get_Hk(self, k):
         r0 = int(np.sum(self._Nr[:k]))
-        return self._big_H[r0:r0 + self._Nr[k], :]
+        return self.big_H[r0:r0 + self._Nr[k], :]
 
     # ---- post-processing filters (multiuser.py:1135-1177) --------------------------------------------
     def set_post_filter(self, filters):
@@ -140,7 +167,7 @@ class MultiUserChannelMatrix:
             self._last_noise = noise * math.sqrt(nv)
         else:
             self._last_noise = None
-        out = self.engine.mimo_channel(np.asarray(self._big_H)[np.newaxis], data[np.newaxis],
+        out = self.engine.mimo_channel(np.asarray(self.big_H)[np.newaxis], data[np.newaxis],
                                        None if noise is None else noise[np.newaxis], nv, dtype=self.dtype)[0]
         if self.big_W is not None:
             out = np.dot(self.big_W.conjugate().T, out)
@@ -149,11 +176,56 @@ class MultiUserChannelMatrix:
     def corrupt_data(self, data):
         """multiuser.py:1223-1262: list of per-transmitter arrays in, array of per-receiver arrays out."""
         out = self.corrupt_concatenated_data(np.vstack(list(data)))
-        res = np.zeros(self._K, dtype=np.ndarray)
+        n_users = int(self.K)               # not self._K: the ExtInt subclass counts its external sources there
+        res = np.zeros(n_users, dtype=np.ndarray)
         cum = np.hstack([0, np.cumsum(self._Nr)])
-        for k in range(self._K):
+        for k in range(n_users):
             res[k] = out[cum[k]:cum[k + 1], :]
         return res
+
+    # ---- covariance matrices and SINRs (multiuser.py:1314-2008), evaluated by k_mu_link_stats ------------------------
+    def _stats(self, F=None, U=None, joint=False, pe=0.0, want=("Q",)):
+        n_users = int(self.K)
+        n_ext = int(np.sum(self._Nt)) - int(np.sum(self.Nt))
+        return self.engine.mu_link_stats(self._big_H, self.Nr, self.Nt, F=F, U=U, noise_var=self._noise_var or 0.0, pe=pe,
+                                         n_ext=n_ext, joint=joint, pathloss_big=self._pathloss_big_matrix, want=want), n_users
+
+    def calc_Q(self, k, F_all_users):
+        """Interference-plus-noise covariance at receiver k (:1345-1383)."""
+        return self._stats(F_all_users, want=("Q",))[0]["Q"][k][0]
+
+    def calc_JP_Q(self, k, F_all_users):
+        """Joint-processing form: every precoder spans all transmit antennas (:1416-1450)."""
+        return self._stats(F_all_users, joint=True, want=("Q",))[0]["Q"][k][0]
+
+    def _calc_Bkl_cov_matrix_all_l(self, F_all_users, k, N0_or_Rek=0.0):
+        """:1552-1621 for a scalar noise power (the covariance-matrix argument is the ExtInt class's own path)."""
+        if N0_or_Rek is not None and not np.isscalar(N0_or_Rek):
+            raise ValueError("pass a noise power; covariance matrices enter through MultiUserChannelMatrixExtInt")
+        keep, self._noise_var = self._noise_var, float(N0_or_Rek or 0.0)
+        try:
+            B = self._stats(F_all_users, want=("B",))[0]["B"][k][0]
+        finally:
+            self._noise_var = keep
+        out = np.empty(B.shape[0], dtype=np.ndarray)
+        for l in range(B.shape[0]):
+            out[l] = B[l]
+        return out
+
+    def _sinr(self, F, U, joint, pe=0.0):
+        res, n_users = self._stats(F, U, joint=joint, pe=pe, want=("sinr",))
+        out = np.empty(n_users, dtype=np.ndarray)
+        for k in range(n_users):
+            out[k] = res["sinr"][k][0]
+        return out
+
+    def calc_SINR(self, F, U):
+        """Per-stream SINRs of every user for precoders F and receive filters U (:1869-1899)."""
+        return self._sinr(F, U, False)
+
+    def calc_JP_SINR(self, F, U):
+        """:1978-2008."""
+        return self._sinr(F, U, True)
 
 
 class MultiUserChannelMatrixExtInt(MultiUserChannelMatrix):
@@ -194,20 +266,62 @@ class MultiUserChannelMatrixExtInt(MultiUserChannelMatrix):
         full_Nr, full_Nt, full_K, self._extIntK, self._extIntNt = self._prepare(Nr, Nt, K, NtE)
         MultiUserChannelMatrix.init_from_channel_matrix(self, channel_matrix, full_Nr, full_Nt, full_K)
 
+    def get_Hk_without_ext_int(self, k):
+        """multiuser.py:2191-2239."""
+        return self.get_Hk(k)[:, :int(np.sum(self.Nt))]
+
+    def get_Hk_with_ext_int(self, k):
+        """multiuser.py:2241-2287."""
+        return self.get_Hk(k)
+
+    H_no_ext_int = property(lambda self: self.H[:self.K, :self.K])
+
+    def set_pathloss(self, pathloss_matrix=None, ext_int_pathloss=None):
+        """multiuser.py:2415-2467: K x K between the users plus K x extIntK from the external sources."""
+        if pathloss_matrix is None:
+            self._pathloss_matrix = None
+            self._pathloss_big_matrix = None
+            return
+        full = np.hstack([np.asarray(pathloss_matrix, dtype=float), np.asarray(ext_int_pathloss, dtype=float)])
+        self._pathloss_matrix = full
+        self._pathloss_big_matrix = self._from_small_matrix_to_big_matrix(full, self._Nr, self._Nt, self.K, self._K)
+
+    def corrupt_data(self, data, ext_int_data):
+        """multiuser.py:2130-2160: the users' data followed by the external sources' data."""
+        return MultiUserChannelMatrix.corrupt_data(self, list(data) + list(ext_int_data))
+
     def calc_cov_matrix_extint_without_noise(self, pe=1.0):
         """multiuser.py:2469-2494."""
-        n_tx = int(np.sum(self.Nt))
+        keep, self._noise_var = self._noise_var, None
+        try:
+            Re = self._stats(pe=pe, want=("Re",))[0]["Re"]
+        finally:
+            self._noise_var = keep
         out = np.empty(self.K, dtype=np.ndarray)
-        cum = np.hstack([0, np.cumsum(self.Nr)])
         for k in range(self.K):
-            ext = self._big_H[cum[k]:cum[k + 1], n_tx:]
-            out[k] = pe * np.dot(ext, ext.conj().T)
+            out[k] = Re[k][0]
         return out
 
     def calc_cov_matrix_extint_plus_noise(self, pe=1.0):
         """multiuser.py:2496-2520."""
-        out = self.calc_cov_matrix_extint_without_noise(pe)
-        if self.noise_var is not None:
-            for k in range(self.K):
-                out[k] = out[k] + np.eye(int(self.Nr[k])) * self.noise_var
+        Re = self._stats(pe=pe, want=("Re",))[0]["Re"]
+        out = np.empty(self.K, dtype=np.ndarray)
+        for k in range(self.K):
+            out[k] = Re[k][0]
         return out
+
+    def calc_Q(self, k, F_all_users, pe=1.0):
+        """multiuser.py:2530-2567."""
+        return self._stats(F_all_users, pe=pe, want=("Q",))[0]["Q"][k][0]
+
+    def calc_JP_Q(self, k, F_all_users, pe=1.0):
+        """multiuser.py:2598-2634."""
+        return self._stats(F_all_users, joint=True, pe=pe, want=("Q",))[0]["Q"][k][0]
+
+    def calc_SINR(self, F, U, pe=1.0):
+        """multiuser.py:2636-2674."""
+        return self._sinr(F, U, False, pe)
+
+    def calc_JP_SINR(self, F, U, pe=1.0):
+        """multiuser.py:2771-2807."""
+        return self._sinr(F, U, True, pe)

@@ -49,6 +49,7 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(_lib.MimoOfdmTdlCfg) == 40 + 24 + 24 * 8 + 24 * 4
     assert ctypes.sizeof(_lib.IaGeneralCfg) == 64
     assert ctypes.sizeof(_lib.BdExtIntCfg) == 64
+    assert ctypes.sizeof(_lib.MuStatsCfg) == 80
 
 
 def test_integration_map_names_every_entry_point():

@@ -1,0 +1,103 @@
+"""GPU: the K-user channel's covariance matrices and SINRs (csrc/kernels_multiuser.hip through the
+multiuser.MultiUserChannelMatrix / MultiUserChannelMatrixExtInt mirrors) against the reference's own results on seeded
+channels, precoders and filters (tests/golden/a14b_multiuser_stats.npz, minted by oracle/make_golden.py from
+channels/multiuser.py:1314-2807)."""
+import numpy as np
+import pytest
+
+from helpers import GOLDEN, relerr
+
+pytestmark = pytest.mark.gpu
+Z = np.load(GOLDEN + "/a14b_multiuser_stats.npz", allow_pickle=False)
+
+
+def _channel(engine, ci):
+    from pyphysim_amd import multiuser
+    pre = "case%d_" % ci
+    Nr, Nt, ext = Z[pre + "Nr"], Z[pre + "Nt"], Z[pre + "ext"]
+    nv, pe = [float(v) for v in Z[pre + "par"]]
+    K = len(Nr)
+    if ext.size:
+        muc = multiuser.MultiUserChannelMatrixExtInt(engine=engine)
+        muc.init_from_channel_matrix(Z[pre + "big_H"], Nr, Nt, K, ext)
+    else:
+        muc = multiuser.MultiUserChannelMatrix(engine=engine)
+        muc.init_from_channel_matrix(Z[pre + "big_H"], Nr, Nt, K)
+    muc.noise_var = None if nv < 0 else nv
+    if pre + "pl" in Z.files:
+        if ext.size:
+            muc.set_pathloss(Z[pre + "pl"], Z[pre + "pl_ext"])
+        else:
+            muc.set_pathloss(Z[pre + "pl"])
+    return muc, pre, K, ext, pe
+
+
+@pytest.mark.parametrize("ci", range(int(Z["n_cases"])))
+@pytest.mark.parametrize("joint", [False, True])
+def test_covariances_and_sinrs_against_reference(engine, ci, joint):
+    muc, pre, K, ext, pe = _channel(engine, ci)
+    tag = pre + ("jp_" if joint else "")
+    F = np.empty(K, dtype=np.ndarray)
+    U = np.empty(K, dtype=np.ndarray)
+    for k in range(K):
+        F[k], U[k] = Z[tag + "F%d" % k], Z[tag + "U%d" % k]
+    kw = {"pe": pe} if ext.size else {}
+    sinr = (muc.calc_JP_SINR if joint else muc.calc_SINR)(F, U, **kw)
+    assert sinr.shape == (K,)
+    for k in range(K):
+        assert relerr(sinr[k], Z[tag + "sinr%d" % k]) <= 1e-10
+        Q = (muc.calc_JP_Q if joint else muc.calc_Q)(k, F, **kw)
+        assert relerr(Q, Z[tag + "Q%d" % k]) <= 1e-12
+    if ext.size:
+        Re = muc.calc_cov_matrix_extint_plus_noise(pe)
+        for k in range(K):
+            assert relerr(Re[k], Z[pre + "Re%d" % k]) <= 1e-12
+    elif not joint:
+        nv = float(Z[pre + "par"][0])
+        B = muc._calc_Bkl_cov_matrix_all_l(F, K - 1, max(nv, 0.0))
+        want = Z[tag + "B_last"]
+        assert len(B) == want.shape[0]
+        for l in range(len(B)):
+            assert relerr(B[l], want[l]) <= 1e-12
+
+
+def test_path_loss_reaches_the_data_path_and_a_batch_equals_single_calls(engine):
+    from pyphysim_amd import multiuser
+    muc = multiuser.MultiUserChannelMatrix(engine=engine)
+    muc.set_channel_seed(5)
+    muc.randomize(np.array([2, 3]), np.array([2, 2]), 2)
+    pl = np.array([[1.0, 0.25], [0.04, 1.0]])
+    muc.set_pathloss(pl)
+    assert relerr(muc.get_Hkl(0, 1), np.asarray(muc._big_H)[0:2, 2:4] * 0.5) <= 1e-15
+    assert relerr(muc.get_Hkl(1, 0), np.asarray(muc._big_H)[2:5, 0:2] * 0.2) <= 1e-15
+    rs = np.random.RandomState(3)
+    data = [rs.randn(2, 7) + 1j * rs.randn(2, 7) for _ in range(2)]
+    out = muc.corrupt_data(data)
+    assert relerr(np.vstack(list(out)), np.asarray(muc.big_H) @ np.vstack(data)) <= 1e-13
+    muc.set_pathloss(None)
+    assert muc.pathloss is None and relerr(muc.big_H, muc._big_H) == 0.0
+    # batch through the engine
+    H = np.stack([np.asarray(muc._big_H), 1.5 * np.asarray(muc._big_H)])
+    F = [rs.randn(2, 1) + 1j * rs.randn(2, 1) for _ in range(2)]
+    U = [rs.randn(2, 1) + 1j * rs.randn(2, 1), rs.randn(3, 1) + 1j * rs.randn(3, 1)]
+    both = engine.mu_link_stats(H, [2, 3], [2, 2], F=F, U=U, noise_var=0.1)
+    one = engine.mu_link_stats(H[1], [2, 3], [2, 2], F=F, U=U, noise_var=0.1)
+    for k in range(2):
+        assert relerr(both["sinr"][k][1], one["sinr"][k][0]) <= 1e-13 and relerr(both["Q"][k][1], one["Q"][k][0]) <= 1e-13
+    with pytest.raises(ValueError):
+        engine.mu_link_stats(H, [2, 3], [2, 5], F=F, U=U)
+
+
+def test_extint_data_path(engine):
+    from pyphysim_amd import multiuser
+    muc = multiuser.MultiUserChannelMatrixExtInt(engine=engine)
+    muc.set_channel_seed(11)
+    muc.randomize(2, 2, 3, np.array([1, 2]))
+    assert muc.K == 3 and muc.extIntK == 2 and muc.big_H.shape == (6, 9)
+    rs = np.random.RandomState(4)
+    data = [rs.randn(2, 5) + 1j * rs.randn(2, 5) for _ in range(3)]
+    ext = [rs.randn(1, 5) + 1j * rs.randn(1, 5), rs.randn(2, 5) + 1j * rs.randn(2, 5)]
+    out = muc.corrupt_data(data, ext)
+    assert out.shape == (3,)
+    assert relerr(np.vstack(list(out)), np.asarray(muc.big_H) @ np.vstack(data + ext)) <= 1e-13
+    assert relerr(muc.get_Hk_without_ext_int(1), np.asarray(muc.big_H)[2:4, :6]) == 0.0

@@ -217,3 +217,34 @@ def test_enhanced_bd_stream_reduction_depends_on_the_svd_phases():
     a = obd.enhanced_bd(big_H, K, r, r, iPu, nv, pe, "fixed", 1, Ms_bad=Ms_bad)
     b = obd.enhanced_bd(big_H, K, r, r, iPu, nv, pe, "fixed", 1, Ms_bad=turned)
     assert relerr(proj(a[0][0]), proj(b[0][0])) > 1e-2
+
+
+def _multiuser_cases():
+    z = np.load(GOLDEN + "/a14b_multiuser_stats.npz", allow_pickle=False)
+    for ci in range(int(z["n_cases"])):
+        pre = "case%d_" % ci
+        Nr, Nt, Ns, ext = z[pre + "Nr"], z[pre + "Nt"], z[pre + "Ns"], z[pre + "ext"]
+        nv, pe = [float(v) for v in z[pre + "par"]]
+        pl = z[pre + "pl"] if pre + "pl" in z.files else None
+        pl_ext = z[pre + "pl_ext"] if pre + "pl_ext" in z.files else None
+        yield z, pre, Nr, Nt, Ns, ext, (None if nv < 0 else nv), pe, pl, pl_ext
+
+
+def test_multiuser_covariances_and_sinrs_match_reference():
+    from oracle import multiuser as omu
+    n = 0
+    for z, pre, Nr, Nt, Ns, ext, nv, pe, pl, pl_ext in _multiuser_cases():
+        K = len(Nr)
+        full_Nt = np.hstack([Nt, ext]) if ext.size else Nt
+        pl_big = None if pl is None else omu.pathloss_big(pl if pl_ext is None else np.hstack([pl, pl_ext]), Nr, full_Nt)
+        H = omu.effective_big_H(z[pre + "big_H"], pl_big)
+        for joint in (False, True):
+            tag = pre + ("jp_" if joint else "")
+            F = [z[tag + "F%d" % k] for k in range(K)]
+            U = [z[tag + "U%d" % k] for k in range(K)]
+            sinr = omu.calc_sinr(H, Nr, Nt, F, U, nv, pe, joint)
+            for k in range(K):
+                assert relerr(sinr[k], z[tag + "sinr%d" % k]) <= 1e-10
+                assert relerr(omu.calc_Q(H, Nr, Nt, k, F, nv, pe if ext.size else 0.0, joint), z[tag + "Q%d" % k]) <= 1e-12
+                n += 1
+    assert n == 2 * (3 + 3 + 2 + 3 + 2 + 4)
