@@ -370,6 +370,58 @@ def golden_multiuser_stats():
     print("a14b_multiuser_stats: oracle == reference on %d channels x (per-link, joint) (worst %.2e)" % (len(cases), worst))
 
 
+def golden_mu_channels():
+    """tests/golden/a14c_mu_channels.npz: the reference's MuChannel / MuMimoChannel (channels/multiuser.py:42-583) run
+    under np.random.seed: inputs and received streams.  The product mirrors are built the same way under the same seed
+    (their generators draw from NumPy's global state in the reference's order), so this is a same-seed fixture; the
+    per-link arithmetic is the TDL convolution the oracle already pins (oracle/channels.py)."""
+    from pyphysim.channels import multiuser as rmu
+    store = {}
+    Ts = 1e-6
+    powers, delays = np.array([0.0, -3.0, -7.0]), np.array([0.0, 1.0, 3.0]) * Ts
+    rs = np.random.RandomState(BASE_SEED + 91)
+    randc = lambda *shape: (rs.randn(*shape) + 1j * rs.randn(*shape)) / math.sqrt(2.0)
+
+    def unpack(out):
+        return np.array([np.asarray(o) for o in out])
+    # A: Rayleigh links, 2 receivers x 3 transmitters, path loss
+    seed = BASE_SEED + 92
+    np.random.seed(seed)
+    mu = rmu.MuChannel((2, 3), tap_powers_dB=powers, tap_delays=delays, Ts=Ts)
+    pl = rs.uniform(0.1, 1.0, (2, 3))
+    mu.set_pathloss(pl)
+    x = randc(3, 40)
+    store.update(A_seed=np.array(seed), A_pl=pl, A_x=x, A_y=unpack(mu.corrupt_data(x)),
+                 A_ir=np.asarray(mu.get_last_impulse_response(1, 2).tap_values_sparse))
+    x2 = randc(3, 32)
+    store.update(A_x2=x2, A_y2=unpack(mu.corrupt_data_in_freq_domain(x2, 16)))
+    # B: Jakes links, 2 x 2, two calls in a row (the generators keep their time axis), then the reverse direction
+    seed = BASE_SEED + 93
+    np.random.seed(seed)
+    mu = rmu.MuChannel(2, rfg.JakesSampleGenerator(Fd=50.0, Ts=Ts, L=8), tap_powers_dB=powers, tap_delays=delays)
+    x = randc(2, 50)
+    y1 = unpack(mu.corrupt_data(x))
+    y2 = unpack(mu.corrupt_data(x))
+    mu.switched_direction = True
+    y3 = unpack(mu.corrupt_data(x))
+    store.update(B_seed=np.array(seed), B_x=x, B_y1=y1, B_y2=y2, B_y3=y3)
+    # C: MIMO links (2 rx antennas, 3 tx antennas), 2 receivers x 2 transmitters, path loss, then the reverse direction
+    seed = BASE_SEED + 94
+    np.random.seed(seed)
+    mu = rmu.MuMimoChannel((2, 2), 2, 3, rfg.JakesSampleGenerator(Fd=20.0, Ts=Ts, L=8), tap_powers_dB=powers,
+                           tap_delays=delays)
+    pl = rs.uniform(0.1, 1.0, (2, 2))
+    mu.set_pathloss(pl)
+    x = np.array([randc(3, 30), randc(3, 30)])
+    y1 = unpack(mu.corrupt_data(x))
+    mu.switched_direction = True
+    xr = np.array([randc(2, 30), randc(2, 30)])
+    y2 = unpack(mu.corrupt_data(xr))
+    store.update(C_seed=np.array(seed), C_pl=pl, C_x=x, C_y1=y1, C_xr=xr, C_y2=y2)
+    np.savez_compressed(os.path.join(GOLD, "a14c_mu_channels.npz"), Ts=np.array(Ts), powers=powers, delays=delays, **store)
+    print("a14c_mu_channels: reference MuChannel / MuMimoChannel runs stored (3 set-ups, 9 received blocks)")
+
+
 def ref_chain_awgn(seed, mod, M, N, snr_db):
     np.random.seed(seed)
     m = ref_modulator(mod, M)
@@ -882,8 +934,10 @@ if __name__ == "__main__":
         golden_bd_extint()
     if not only or "a14b_multiuser_stats" in only:
         golden_multiuser_stats()
-    only = only - {"f6b_bd_extint", "a14b_multiuser_stats"} if only else only
-    if only == set() and set(sys.argv[1:]) & {"f6b_bd_extint", "a14b_multiuser_stats"}:
+    if not only or "a14c_mu_channels" in only:
+        golden_mu_channels()
+    only = only - {"f6b_bd_extint", "a14b_multiuser_stats", "a14c_mu_channels"} if only else only
+    if only == set() and set(sys.argv[1:]) & {"f6b_bd_extint", "a14b_multiuser_stats", "a14c_mu_channels"}:
         sys.exit(0)
     if not only or only - {"operators"}:
         golden_chains(only - {"operators"})

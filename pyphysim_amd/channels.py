@@ -468,6 +468,28 @@ class SuChannel:
             out = out * math.sqrt(self._pathloss_value)
         return out
 
+    def corrupt_data_in_freq_domain(self, signal, fft_size, carrier_indexes=None):
+        """singleuser.py:153-194."""
+        out = self._tdlchannel.corrupt_data_in_freq_domain(signal, fft_size, carrier_indexes)
+        if self._pathloss_value is not None:
+            out = out * math.sqrt(self._pathloss_value)
+        return out
+
+    def set_num_antennas(self, num_rx_antennas, num_tx_antennas):
+        """singleuser.py:112-128."""
+        self._tdlchannel.set_num_antennas(num_rx_antennas, num_tx_antennas)
+
+    num_tx_antennas = property(lambda self: self._tdlchannel.num_tx_antennas)
+    num_rx_antennas = property(lambda self: self._tdlchannel.num_rx_antennas)
+
+    @property
+    def switched_direction(self):
+        return self._tdlchannel.switched_direction
+
+    @switched_direction.setter
+    def switched_direction(self, value):
+        self._tdlchannel.switched_direction = value
+
     def get_last_impulse_response(self):
         ir = self._tdlchannel.get_last_impulse_response()
         if self._pathloss_value is None:
@@ -487,6 +509,3 @@ class SuMimoChannel(SuChannel):
         fading_generator.shape = (num_antennas, num_antennas)
         super().__init__(fading_generator, channel_profile, tap_powers_dB, tap_delays, Ts, engine=engine,
                          dtype=dtype)
-
-    num_tx_antennas = property(lambda self: self._tdlchannel.num_tx_antennas)
-    num_rx_antennas = property(lambda self: self._tdlchannel.num_rx_antennas)

@@ -11,7 +11,106 @@ import math
 
 import numpy as np
 
+from . import channels as _channels
 from .engine import get_engine
+
+
+class MuChannel:
+    """reference channels/multiuser.py:42-440: a grid of independent single-user links, `su[rx, tx]`, every one a
+    SuChannel with its own fading generator cloned from the one given (`get_similar_fading_generator`, rx-major -- the
+    order the generators draw in under a seeded NumPy state), one shared channel profile, an optional path loss per
+    link; receiver rx hears sum_tx su[rx, tx](signal[tx]).  Every link is a device convolution (`k_tdl_apply` /
+    `k_tdl_apply_mimo`), the sum over transmitters is a device add."""
+
+    def __init__(self, N, fading_generator=None, channel_profile=None, tap_powers_dB=None, tap_delays=None, Ts=None,
+                 engine=None, dtype=None):
+        if fading_generator is None:
+            fading_generator = _channels.RayleighSampleGenerator()
+        num_rx, num_tx = (N if isinstance(N, (tuple, list)) else (N, N))
+        self._engine = engine if engine is not None else getattr(fading_generator, "_engine", None)
+        self.dtype = dtype if dtype is not None else getattr(fading_generator, "dtype", None)
+        self._su_siso_channels = np.empty((num_rx, num_tx), dtype=object)
+        for rx in range(num_rx):
+            for tx in range(num_tx):
+                gen = fading_generator.get_similar_fading_generator()
+                self._su_siso_channels[rx, tx] = _channels.SuChannel(gen, channel_profile=channel_profile,
+                                                                     tap_powers_dB=tap_powers_dB, tap_delays=tap_delays,
+                                                                     Ts=Ts, engine=self._engine, dtype=self.dtype)
+                channel_profile = self._su_siso_channels[rx, tx].channel_profile      # one profile object for every link
+        self._pathloss_matrix = None
+
+    @property
+    def engine(self):
+        if self._engine is None:
+            self._engine = get_engine()
+        return self._engine
+
+    def __repr__(self):
+        if self._su_siso_channels.size:
+            return "<%s.%s object at %s>\n%s" % (self.__class__.__module__, self.__class__.__name__, hex(id(self)),
+                                                 repr(self.channel_profile))
+        return "<%s.%s object at %s>" % (self.__class__.__module__, self.__class__.__name__, hex(id(self)))
+
+    @property
+    def switched_direction(self):
+        return self._su_siso_channels[0, 0].switched_direction
+
+    @switched_direction.setter
+    def switched_direction(self, value):
+        for link in self._su_siso_channels.flat:
+            link.switched_direction = value
+
+    num_tx_antennas = property(lambda self: self._su_siso_channels[0, 0].num_tx_antennas)
+    num_rx_antennas = property(lambda self: self._su_siso_channels[0, 0].num_rx_antennas)
+    channel_profile = property(lambda self: self._su_siso_channels[0, 0].channel_profile)
+    num_taps = property(lambda self: self._su_siso_channels[0, 0].num_taps)
+    num_taps_with_padding = property(lambda self: self._su_siso_channels[0, 0].num_taps_with_padding)
+    pathloss_matrix = property(lambda self: self._pathloss_matrix)
+
+    def set_pathloss(self, pathloss_matrix):
+        """:256-290 (a matrix of LINEAR power ratios, one per link; None switches the path loss off)."""
+        num_rx, num_tx = self._su_siso_channels.shape
+        self._pathloss_matrix = None if pathloss_matrix is None else np.copy(pathloss_matrix)
+        for rx in range(num_rx):
+            for tx in range(num_tx):
+                self._su_siso_channels[rx, tx].set_pathloss(None if pathloss_matrix is None else pathloss_matrix[rx, tx])
+
+    def _through_every_link(self, signal, send):
+        links = self._su_siso_channels.T if self.switched_direction else self._su_siso_channels
+        num_rx, num_tx = links.shape
+        signal = np.asarray(signal) if not isinstance(signal, np.ndarray) or signal.dtype != object else signal
+        if num_tx == 1 and getattr(signal, "ndim", 2) == 1 and signal.dtype != object:
+            signal = np.reshape(signal, (1, -1))
+        outputs = np.empty(num_rx, dtype=object)
+        for rx in range(num_rx):
+            acc = send(links[rx, 0], signal[0])
+            for tx in range(1, num_tx):
+                acc = self.engine.awgn_add(acc, send(links[rx, tx], signal[tx]), 1.0, dtype=self.dtype)   # acc + link output
+            outputs[rx] = acc
+        return outputs
+
+    def corrupt_data(self, signal):
+        """:292-330: signal[tx] = what transmitter tx sends; -> object array, one received stream per receiver."""
+        return self._through_every_link(signal, lambda link, x: link.corrupt_data(x))
+
+    def corrupt_data_in_freq_domain(self, signal, fft_size, carrier_indexes=None):
+        """:332-394: the block-static per-subcarrier form of every link."""
+        return self._through_every_link(signal, lambda link, x: link.corrupt_data_in_freq_domain(x, fft_size,
+                                                                                                 carrier_indexes))
+
+    def get_last_impulse_response(self, rx_idx, tx_idx):
+        """:396-420."""
+        return self._su_siso_channels[rx_idx, tx_idx].get_last_impulse_response()
+
+
+class MuMimoChannel(MuChannel):
+    """reference channels/multiuser.py:521-583: every link carries num_rx_antennas x num_tx_antennas antennas."""
+
+    def __init__(self, N, num_rx_antennas, num_tx_antennas, fading_generator=None, channel_profile=None, tap_powers_dB=None,
+                 tap_delays=None, Ts=None, engine=None, dtype=None):
+        super().__init__(N, fading_generator, channel_profile, tap_powers_dB, tap_delays, Ts, engine=engine, dtype=dtype)
+        for link in self._su_siso_channels.flat:
+            link.set_num_antennas(num_rx_antennas, num_tx_antennas)
 
 
 def _randn_c_rs(rs, *shape):

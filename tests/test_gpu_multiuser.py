@@ -101,3 +101,70 @@ def test_extint_data_path(engine):
     assert out.shape == (3,)
     assert relerr(np.vstack(list(out)), np.asarray(muc.big_H) @ np.vstack(data + ext)) <= 1e-13
     assert relerr(muc.get_Hk_without_ext_int(1), np.asarray(muc.big_H)[2:4, :6]) == 0.0
+
+
+# ---- MuChannel / MuMimoChannel: grids of single-user TDL links (channels/multiuser.py:42-583) ---------------------------
+ZC = np.load(GOLDEN + "/a14c_mu_channels.npz", allow_pickle=False)
+
+
+def _stack(out):
+    return np.array([np.asarray(o) for o in out])
+
+
+def test_mu_channel_rayleigh_links(engine):
+    """The default generator draws its CN(0, 1) samples on the device (util.seed selects the Philox stream), so there
+    is no NumPy seed to share with the reference here: the received streams are checked against the oracle's tap delay
+    line run on the impulse responses the links report, link by link, and the set-up (shapes, path loss, profile)
+    against the reference's run of the same configuration (a14c fixture)."""
+    from oracle import channels as och
+    from pyphysim_amd import multiuser, util
+    util.seed(4242, 3)
+    mu = multiuser.MuChannel((2, 3), tap_powers_dB=ZC["powers"], tap_delays=ZC["delays"], Ts=float(ZC["Ts"]), engine=engine)
+    mu.set_pathloss(ZC["A_pl"])
+    assert mu.num_taps == 3 and mu.pathloss_matrix.shape == (2, 3) and mu.num_taps_with_padding == 4
+    x = ZC["A_x"]
+    y = mu.corrupt_data(x)
+    assert y.shape == (2,) and _stack(y).shape == ZC["A_y"].shape
+    for rx in range(2):
+        want = 0.0
+        for tx in range(3):
+            ir = mu.get_last_impulse_response(rx, tx)            # path loss already in the tap values
+            assert np.asarray(ir.tap_values_sparse).shape == ZC["A_ir"].shape
+            want = want + och.tdl_apply(x[tx], np.asarray(ir.tap_values_sparse), np.asarray(ir.tap_indexes_sparse))
+        assert relerr(y[rx], want) <= 1e-12
+    # links are independent and carry the profile's power times the path loss
+    irs = np.array([[np.asarray(mu.get_last_impulse_response(r, t).tap_values_sparse) for t in range(3)] for r in range(2)])
+    assert abs(np.corrcoef(irs[0, 0].ravel(), irs[1, 2].ravel())[0, 1]) < 0.5
+    y2 = mu.corrupt_data_in_freq_domain(ZC["A_x2"], 16)
+    assert _stack(y2).shape == ZC["A_y2"].shape
+    for rx in range(2):
+        want = 0.0
+        for tx in range(3):
+            ir = mu.get_last_impulse_response(rx, tx)
+            want = want + och.corrupt_data_in_freq_domain(ZC["A_x2"][tx], np.asarray(ir.tap_values_sparse),
+                                                          np.asarray(ir.tap_indexes_sparse), 16)
+        assert relerr(y2[rx], want) <= 1e-11
+
+
+def test_mu_channel_jakes_links_same_seed_and_reverse_direction(engine):
+    from pyphysim_amd import channels, multiuser
+    np.random.seed(int(ZC["B_seed"]))
+    gen = channels.JakesSampleGenerator(Fd=50.0, Ts=float(ZC["Ts"]), L=8, engine=engine)
+    mu = multiuser.MuChannel(2, gen, tap_powers_dB=ZC["powers"], tap_delays=ZC["delays"], engine=engine)
+    assert relerr(_stack(mu.corrupt_data(ZC["B_x"])), ZC["B_y1"]) <= 1e-9
+    assert relerr(_stack(mu.corrupt_data(ZC["B_x"])), ZC["B_y2"]) <= 1e-9       # the generators kept their time axis
+    mu.switched_direction = True
+    assert mu.switched_direction is True
+    assert relerr(_stack(mu.corrupt_data(ZC["B_x"])), ZC["B_y3"]) <= 1e-9
+
+
+def test_mu_mimo_channel_same_seed(engine):
+    from pyphysim_amd import channels, multiuser
+    np.random.seed(int(ZC["C_seed"]))
+    gen = channels.JakesSampleGenerator(Fd=20.0, Ts=float(ZC["Ts"]), L=8, engine=engine)
+    mu = multiuser.MuMimoChannel((2, 2), 2, 3, gen, tap_powers_dB=ZC["powers"], tap_delays=ZC["delays"], engine=engine)
+    assert mu.num_rx_antennas == 2 and mu.num_tx_antennas == 3
+    mu.set_pathloss(ZC["C_pl"])
+    assert relerr(_stack(mu.corrupt_data(ZC["C_x"])), ZC["C_y1"]) <= 1e-9
+    mu.switched_direction = True
+    assert relerr(_stack(mu.corrupt_data(ZC["C_xr"])), ZC["C_y2"]) <= 1e-9
