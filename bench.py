@@ -62,8 +62,11 @@ UNCOUNTED = {"c4": "Philox4x32-10: ~2 350 blocks (4 176 CN samples + 4 096 symbo
 HBM_PEAK_GBPS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
 HBM_COPY_GBPS = 6290.0      # same guide: measured float4 copy
 FP32_PEAK_TFLOPS = 157.3    # same guide: FP32 vector peak = FP32-input MFMA peak (256 CU x 4 SIMD x 64 flop/clk x 2.4 GHz)
-KERNEL = {"c4": "k_run_mimo_ofdm_mfma", "c2": "k_run_flat", "c3": "k_run_ofdm_tdl_mfma", "c5": "k_run_ia",
-          "f1": "k_run_mimo_ofdm_tdl", "f6": "k_run_bd"}
+KERNEL = {"c4": "k_run_mimo_ofdm_mfma", "c2": "k_run_flat", "c3": "k_run_ofdm_tdl_mfma", "c5": "k_ia_link",
+          "f1": "k_run_mimo_ofdm_tdl", "f6": "k_bd_link"}
+KERNEL_NOTE = {   # configs whose step is two launches: the time spans both, the counters are the named (dominant) kernel's
+    "c5": "a step = k_ia_solve_links (per-lane solve, ~18 % of the time) + k_ia_link (symbol walk); kernel_ms_per_launch spans both",
+    "f6": "a step = k_bd_solve_links (per-lane solve) + k_bd_link (symbol walk); kernel_ms_per_launch spans both"}
 BATCH = {"c4": 65536, "c3": 131072, "c2": 4096, "c5": 262144, "f1": 98304, "f6": 131072}
 BITS = {"c2": 6, "c3": 2, "c4": 6, "c5": 4, "f1": 6, "f6": 2}
 SEED = 20260927
@@ -365,6 +368,7 @@ def roofline_block(args, batch, per_launch_s, rate_kernel, pmc, pmc_source):
              "frac": achieved_tf / FP32_PEAK_TFLOPS,
              "traffic": d.get("hbm_bytes_per_launch"),
              "kernel": KERNEL[args.config], "kernel_ms_per_launch": per_launch_s * 1e3,
+             "kernel_note": KERNEL_NOTE.get(args.config),
              "realizations_per_launch": batch,
              "flops_per_realization": f_total, "flops_breakdown": flops, "uncounted": UNCOUNTED.get(args.config),
              "hbm": hbm,

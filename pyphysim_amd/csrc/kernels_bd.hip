@@ -588,18 +588,55 @@ struct BdParams {
 // rounding residue of an exact block diagonalisation (<= 1e-15 |d|) and are not carried.  Phase 2: the wave runs
 // the realization's symbol columns: est_s = d_s x_s + W_s . (sigma n_user), demodulate, count.
 // R = antennas per user (compile time: every register index below is static).
+// Two launches since round 2 (the same split as the IA pipeline, kernels_ia.hip): the per-lane solve keeps four n x n
+// complex f64 work matrices in scratch and takes every register (one wave per SIMD), the symbol walk is light and wants
+// many resident waves.  The record between them: d[n], W[n][R], flag.
 template <typename T, int R>
-__global__ __launch_bounds__(64) void k_run_bd(ModemParams<T> mp, BdParams pp, uint64_t seed, uint64_t first,
-                                               uint64_t count, mcle_counters* counters,
-                                               uint32_t* __restrict__ sym_out, uint32_t* __restrict__ bit_out) {
+__global__ __launch_bounds__(64) void k_bd_solve_links(BdParams pp, uint64_t seed, uint64_t first, uint64_t count,
+                                                       cx<T>* __restrict__ recs) {
+    const uint64_t rl = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+    if (rl >= count) return;
+    const int K = pp.K, n = K * R;
+    const int stride = n * (R + 1) + 1;
+    const Rng rng(seed, first + rl);
+    cd H[kBdMaxN * kBdMaxN], Q[kBdMaxN * kBdMaxN], L[kBdMaxN * kBdMaxN], Ms[kBdMaxN * kBdMaxN];
+    double sg[kBdMaxN];
+    for (int i = 0; i < n; ++i)
+        for (int c = 0; c < n; ++c) {
+            cd h = cn_sample<double>(rng, STREAM_CHAN, (uint64_t)(i * n + c), 1.0);
+            if (pp.has_pathloss) h = cscale(h, pp.root_pl[(i / R) * K + c / R]);
+            H[i * n + c] = h;
+        }
+    const bool ok = bd_solve(H, K, R, pp.iPu, pp.bd_noise_var, pp.waterfill, Q, L, Ms, sg);
+    bd_receive_filter(H, Ms, K, R, Q);               // W in Q
+    cx<T>* rec = recs + rl * stride;
+    for (int s = 0; s < n; ++s) {
+        const int r0 = (s / R) * R;
+        cd d = mk<double>(0, 0);                     // (W H Ms)_ss
+        for (int a = 0; a < R; ++a) {
+            cd hm = mk<double>(0, 0);
+            for (int m = 0; m < n; ++m) hm = cadd(hm, cmul(H[(r0 + a) * n + m], Ms[m * n + s]));
+            d = cadd(d, cmul(Q[s * n + r0 + a], hm));
+            rec[n + s * R + a] = mk<T>((T)Q[s * n + r0 + a].x, (T)Q[s * n + r0 + a].y);
+        }
+        rec[s] = mk<T>((T)d.x, (T)d.y);
+    }
+    rec[n * (R + 1)] = mk<T>(ok ? (T)1 : (T)0, (T)0);
+}
+
+template <typename T, int R>
+__global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void k_bd_link(ModemParams<T> mp, BdParams pp, uint64_t seed,
+                                                                        uint64_t first, uint64_t count, int per_wave,
+                                                                        const cx<T>* __restrict__ recs,
+                                                                        mcle_counters* counters,
+                                                                        uint32_t* __restrict__ sym_out,
+                                                                        uint32_t* __restrict__ bit_out) {
     constexpr int KMAX = kBdMaxN / R;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int K = pp.K, n = K * R;
-    const int stride = (n * (R + 1)) | 1;                        // per-realization record, odd: lanes on distinct banks
-    cx<T>* s_rec = reinterpret_cast<cx<T>*>(smem);               // [64][stride]: d[n] then W[n][R]
-    unsigned long long* s_grid = reinterpret_cast<unsigned long long*>(s_rec + 64 * stride);
+    const int stride = n * (R + 1) + 1;
+    unsigned long long* s_grid = reinterpret_cast<unsigned long long*>(smem);
     __shared__ cx<T> s_table[256];
-    __shared__ unsigned s_ok[64];
     __shared__ WgTotals totals;
     load_table(mp, s_table);
     load_grid(mp, s_grid);
@@ -608,45 +645,15 @@ __global__ __launch_bounds__(64) void k_run_bd(ModemParams<T> mp, BdParams pp, u
     const uint32_t mask = (uint32_t)(mp.M - 1);
     const int NS = pp.n_symbols;
     if (threadIdx.x == 0) wg_zero(totals);
-    const uint64_t n_chunks = (count + 63) / 64;
+    __syncthreads();
+    const uint64_t n_chunks = (count + per_wave - 1) / per_wave;
     for (uint64_t ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
-        __syncthreads();
-        {
-            const uint64_t rl = ch * 64 + lane;
-            if (rl < count) {
-                const Rng rng(seed, first + rl);
-                cd H[kBdMaxN * kBdMaxN], Q[kBdMaxN * kBdMaxN], L[kBdMaxN * kBdMaxN], Ms[kBdMaxN * kBdMaxN];
-                double sg[kBdMaxN];
-                for (int i = 0; i < n; ++i)
-                    for (int c = 0; c < n; ++c) {
-                        cd h = cn_sample<double>(rng, STREAM_CHAN, (uint64_t)(i * n + c), 1.0);
-                        if (pp.has_pathloss) h = cscale(h, pp.root_pl[(i / R) * K + c / R]);
-                        H[i * n + c] = h;
-                    }
-                const bool ok = bd_solve(H, K, R, pp.iPu, pp.bd_noise_var, pp.waterfill, Q, L, Ms, sg);
-                bd_receive_filter(H, Ms, K, R, Q);               // W in Q
-                cx<T>* rec = s_rec + lane * stride;
-                for (int s = 0; s < n; ++s) {
-                    const int r0 = (s / R) * R;
-                    cd d = mk<double>(0, 0);                     // (W H Ms)_ss
-                    for (int a = 0; a < R; ++a) {
-                        cd hm = mk<double>(0, 0);
-                        for (int m = 0; m < n; ++m) hm = cadd(hm, cmul(H[(r0 + a) * n + m], Ms[m * n + s]));
-                        d = cadd(d, cmul(Q[s * n + r0 + a], hm));
-                        rec[n + s * R + a] = mk<T>((T)Q[s * n + r0 + a].x, (T)Q[s * n + r0 + a].y);
-                    }
-                    rec[s] = mk<T>((T)d.x, (T)d.y);
-                }
-                s_ok[lane] = ok ? 1u : 0u;
-            }
-        }
-        __syncthreads();
-        const int in_chunk = (int)((count - ch * 64) < 64 ? (count - ch * 64) : 64);
-        for (int j = 0; j < in_chunk; ++j) {
-            const uint64_t rl = ch * 64 + j;
+        const uint64_t r_end = (ch + 1) * per_wave < count ? (ch + 1) * per_wave : count;
+        for (uint64_t rl = ch * per_wave; rl < r_end; ++rl) {
             const Rng rng(seed, first + rl);
-            const cx<T>* D = s_rec + j * stride;
+            const cx<T>* D = recs + rl * stride;     // wave-uniform record: scalar loads
             const cx<T>* W = D + n;
+            const bool ok = D[n * (R + 1)].x != (T)0;
             unsigned se = 0, be = 0;
             // one symbol column
             auto column = [&](const int (&tx)[kBdMaxN], const cx<T> (&nz)[kBdMaxN]) {
@@ -697,7 +704,7 @@ __global__ __launch_bounds__(64) void k_run_bd(ModemParams<T> mp, BdParams pp, u
             }
             se = wave_sum_u32(se);
             be = wave_sum_u32(be);
-            if (lane == 0) wg_account(totals, se, be, s_ok[j] == 0u, rl, sym_out, bit_out);
+            if (lane == 0) wg_account(totals, se, be, !ok, rl, sym_out, bit_out);
         }
     }
     if (lane == 0)
@@ -709,13 +716,19 @@ static int launch_run_bd(mcle_ctx* ctx, const mcle_bd_cfg* cfg, const BdParams& 
                          uint64_t count, mcle_counters* d_counters, uint32_t* d_sym_err, uint32_t* d_bit_err) {
     const int n = cfg->K * R;
     const ModemParams<T> mp = pipe_modem<T>(ctx, cfg->demod_method);
-    const size_t lds = (size_t)64 * ((n * (R + 1)) | 1) * sizeof(cx<T>) + (size_t)mp.grid.G * mp.grid.G * sizeof(unsigned long long);
-    const uint64_t cap = (uint64_t)ctx->n_cu * 16;
-    const uint64_t chunks = (count + 63) / 64;
+    int rc;
+    void* recs = nullptr;
+    if ((rc = ctx->scratch((size_t)count * (n * (R + 1) + 1) * sizeof(cx<T>), &recs))) return rc;
+    hipLaunchKernelGGL((k_bd_solve_links<T, R>), dim3((unsigned)((count + 63) / 64)), dim3(64), 0, ctx->stream, pp, seed,
+                       first, count, (cx<T>*)recs);
+    MCLE_LAUNCH_CHECK();
+    const size_t lds = (size_t)mp.grid.G * mp.grid.G * sizeof(unsigned long long);
+    const int per_wave = 8;
+    const uint64_t cap = (uint64_t)ctx->n_cu * 4 * (sizeof(T) == 4 ? 4 : 2);
+    const uint64_t chunks = (count + per_wave - 1) / per_wave;
     const unsigned grid = (unsigned)(chunks < cap ? chunks : cap);
-    MCLE_HIP(hipFuncSetAttribute((const void*)k_run_bd<T, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((k_run_bd<T, R>), dim3(grid), dim3(64), lds, ctx->stream, mp, pp, seed, first, count, d_counters,
-                       d_sym_err, d_bit_err);
+    hipLaunchKernelGGL((k_bd_link<T, R>), dim3(grid), dim3(64), lds, ctx->stream, mp, pp, seed, first, count, per_wave,
+                       (const cx<T>*)recs, d_counters, d_sym_err, d_bit_err);
     MCLE_LAUNCH_CHECK();
     return MCLE_OK;
 }

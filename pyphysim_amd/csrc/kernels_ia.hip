@@ -9,6 +9,7 @@
 // realization).  np.linalg.eig's eigenvectors come from LAPACK zgeev, which scales each vector to
 // unit 2-norm with its largest-magnitude component real and positive; the 2x2 closed form below
 // applies the same normalisation, so F_0 -- whose phase rotates the post-filter noise -- matches.
+#include <cstdlib>
 #include "modem.hpp"
 #include "philox.hpp"
 #include "totals.hpp"
@@ -488,16 +489,68 @@ __global__ __launch_bounds__(64) void k_ia_iterative(const cd* __restrict__ bigH
 // interference off it) and the receive filters U_k.  Phase 2: the whole wave runs each realization's symbols,
 // est_k = sum_l G_kl x_l + U_k . n_k, two columns per lane and pass (wave_draws.hpp).  With one solve per lane
 // instead of the same solve on all 64 lanes the iterative solvers cost 1/64 of a wave per realization.
+// Split in two launches since round 2: the per-lane solve wants every register the SIMD has (384 VGPRs + scratch in
+// f64: one wave per SIMD), the symbol walk wants many resident waves and few registers.  Fused, the walk -- 98 % of the
+// instructions -- ran at the solve's occupancy, VALU-busy 0.54; the record that crosses HBM between the two launches is
+// 16 complex numbers per realization (G, U, flag).
+constexpr int kIaRec = 16;      // G[9], U[6], {ok, 0}
+
 template <typename T>
-__global__ __launch_bounds__(64) void k_run_ia(ModemParams<T> mp, int n_symbols, double noise_var, int solver, int init,
-                                               int max_iter, double rel, uint64_t seed, uint64_t first,
-                                               uint64_t count, mcle_counters* counters,
-                                               uint32_t* __restrict__ sym_out, uint32_t* __restrict__ bit_out,
-                                               double* __restrict__ cap_out, uint32_t* __restrict__ iter_out) {
+__global__ __launch_bounds__(64) void k_ia_solve_links(double noise_var, int solver, int init, int max_iter, double rel,
+                                                       uint64_t seed, uint64_t first, uint64_t count,
+                                                       cx<T>* __restrict__ recs, double* __restrict__ cap_out,
+                                                       uint32_t* __restrict__ iter_out) {
+    const uint64_t rl = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+    if (rl >= count) return;
+    const Rng rng(seed, first + rl);
+    cd bigH[36];
+#pragma unroll
+    for (int i = 0; i < 18; ++i)            // big_H row-major, two CN samples per Philox block
+        cn_pair<double>(rng, STREAM_CHAN, (uint32_t)i, 1.0, bigH[2 * i], bigH[2 * i + 1]);
+    M2 H[3][3];
+    load_blocks(bigH, H);
+    IaSolution s;
+    int runned = 0;
+    if (solver == IA_CLOSED_FORM) {
+        s = ia_closed_form(H, noise_var);
+    } else {
+        // randomizeF (iabase.py:538-540): F_k = normalized(randn_c(Nt, Ns)) from the solver's own stream
+        V2 F0[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            cd a, b;
+            cn_pair<double>(rng, STREAM_PHASE, (uint32_t)k, 1.0, a, b);
+            F0[k] = vnormalize(V2{a, b});
+        }
+        s = ia_iterative(H, solver, noise_var, max_iter, rel, init, F0, runned);
+    }
+    cx<T>* rec = recs + rl * kIaRec;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+#pragma unroll
+        for (int l = 0; l < 3; ++l) {
+            const V2 hf = mvec(H[k][l], s.F[l]);
+            const cd g = cadd(cmul(s.U[k].x, hf.x), cmul(s.U[k].y, hf.y));
+            rec[3 * k + l] = mk<T>((T)g.x, (T)g.y);
+        }
+        rec[9 + 2 * k] = mk<T>((T)s.U[k].x.x, (T)s.U[k].x.y);
+        rec[9 + 2 * k + 1] = mk<T>((T)s.U[k].y.x, (T)s.U[k].y.y);
+    }
+    rec[15] = mk<T>(s.ok ? (T)1 : (T)0, (T)0);
+    if (cap_out) cap_out[rl] = s.capacity;
+    if (iter_out) iter_out[rl] = (uint32_t)runned;
+}
+
+// The symbol walk: one wavefront per `per_wave` consecutive realizations, est_k = sum_l G_kl x_l + U_k . n_k, two
+// columns per lane and pass (wave_draws.hpp).  The record of a realization is wave-uniform (scalar loads).
+template <typename T>
+__global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void k_ia_link(ModemParams<T> mp, int n_symbols, double noise_var,
+                                                                        uint64_t seed, uint64_t first, uint64_t count,
+                                                                        int per_wave, const cx<T>* __restrict__ recs,
+                                                                        mcle_counters* counters,
+                                                                        uint32_t* __restrict__ sym_out,
+                                                                        uint32_t* __restrict__ bit_out) {
     __shared__ cx<T> s_table[256];
-    __shared__ cx<T> s_G[64][9];            // odd row length: lanes write their own row on distinct banks
-    __shared__ cx<T> s_U[64][6 + 1];
-    __shared__ unsigned s_ok[64];
     extern __shared__ unsigned long long s_grid[];       // [G*G] candidate grid (min-distance demodulation, f32)
     load_table(mp, s_table);
     load_grid(mp, s_grid);
@@ -506,65 +559,22 @@ __global__ __launch_bounds__(64) void k_run_ia(ModemParams<T> mp, int n_symbols,
     const uint32_t mask = (uint32_t)(mp.M - 1);
     __shared__ WgTotals totals;
     if (threadIdx.x == 0) wg_zero(totals);
-    const uint64_t n_chunks = (count + 63) / 64;
+    __syncthreads();
+    const uint64_t n_chunks = (count + per_wave - 1) / per_wave;
     for (uint64_t ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
-        __syncthreads();
-        // ---- phase 1: one realization per lane ----
-        {
-            const uint64_t rl = ch * 64 + lane;
-            if (rl < count) {
-                const Rng rng(seed, first + rl);
-                cd bigH[36];
-#pragma unroll
-                for (int i = 0; i < 18; ++i)            // big_H row-major, two CN samples per Philox block
-                    cn_pair<double>(rng, STREAM_CHAN, (uint32_t)i, 1.0, bigH[2 * i], bigH[2 * i + 1]);
-                M2 H[3][3];
-                load_blocks(bigH, H);
-                IaSolution s;
-                int runned = 0;
-                if (solver == IA_CLOSED_FORM) {
-                    s = ia_closed_form(H, noise_var);
-                } else {
-                    // randomizeF (iabase.py:538-540): F_k = normalized(randn_c(Nt, Ns)) from the solver's own stream
-                    V2 F0[3];
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) {
-                        cd a, b;
-                        cn_pair<double>(rng, STREAM_PHASE, (uint32_t)k, 1.0, a, b);
-                        F0[k] = vnormalize(V2{a, b});
-                    }
-                    s = ia_iterative(H, solver, noise_var, max_iter, rel, init, F0, runned);
-                }
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-#pragma unroll
-                    for (int l = 0; l < 3; ++l) {
-                        const V2 hf = mvec(H[k][l], s.F[l]);
-                        const cd g = cadd(cmul(s.U[k].x, hf.x), cmul(s.U[k].y, hf.y));
-                        s_G[lane][3 * k + l] = mk<T>((T)g.x, (T)g.y);
-                    }
-                    s_U[lane][2 * k] = mk<T>((T)s.U[k].x.x, (T)s.U[k].x.y);
-                    s_U[lane][2 * k + 1] = mk<T>((T)s.U[k].y.x, (T)s.U[k].y.y);
-                }
-                s_ok[lane] = s.ok ? 1u : 0u;
-                if (cap_out) cap_out[rl] = s.capacity;
-                if (iter_out) iter_out[rl] = (uint32_t)runned;
-            }
-        }
-        __syncthreads();
-        // ---- phase 2: the wave walks the chunk's realizations ----
-        const int in_chunk = (int)((count - ch * 64) < 64 ? (count - ch * 64) : 64);
-        for (int j = 0; j < in_chunk; ++j) {
-            const uint64_t rl = ch * 64 + j;
+        const uint64_t r_end = (ch + 1) * per_wave < count ? (ch + 1) * per_wave : count;
+        for (uint64_t rl = ch * per_wave; rl < r_end; ++rl) {
             const Rng rng(seed, first + rl);
+            const cx<T>* rec = recs + rl * kIaRec;
             cx<T> G[3][3], U[3][2];
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
 #pragma unroll
-                for (int l = 0; l < 3; ++l) G[k][l] = s_G[j][3 * k + l];
-                U[k][0] = s_U[j][2 * k];
-                U[k][1] = s_U[j][2 * k + 1];
+                for (int l = 0; l < 3; ++l) G[k][l] = rec[3 * k + l];
+                U[k][0] = rec[9 + 2 * k];
+                U[k][1] = rec[9 + 2 * k + 1];
             }
+            const bool ok = rec[15].x != (T)0;
             unsigned se = 0, be = 0;
             auto column = [&](const int (&tx)[3], const cx<T> (&nz)[6]) {
                 cx<T> x[3];
@@ -609,13 +619,34 @@ __global__ __launch_bounds__(64) void k_run_ia(ModemParams<T> mp, int n_symbols,
             }
             se = wave_sum_u32(se);
             be = wave_sum_u32(be);
-            if (lane == 0) wg_account(totals, se, be, s_ok[j] == 0u, rl, sym_out, bit_out);
+            if (lane == 0) wg_account(totals, se, be, !ok, rl, sym_out, bit_out);
         }
     }
     if (lane == 0)
         wg_flush(totals, counters, 3ull * (unsigned long long)n_symbols, 3ull * (unsigned long long)n_symbols * mp.bits);
 }
 
+template <typename T>
+int run_ia_impl(mcle_ctx* ctx, const mcle_ia_cfg* cfg, uint64_t seed, uint64_t first, uint64_t count,
+                mcle_counters* d_counters, uint32_t* d_sym, uint32_t* d_bit, double* d_cap, uint32_t* d_iter) {
+    int rc;
+    void* recs = nullptr;
+    if ((rc = ctx->scratch((size_t)count * kIaRec * sizeof(cx<T>), &recs))) return rc;
+    hipLaunchKernelGGL(k_ia_solve_links<T>, dim3((unsigned)((count + 63) / 64)), dim3(64), 0, ctx->stream, cfg->noise_var,
+                       cfg->solver, cfg->initialize_with, cfg->max_iterations, cfg->relative_factor, seed, first, count,
+                       (cx<T>*)recs, d_cap, d_iter);
+    MCLE_LAUNCH_CHECK();
+    const ModemParams<T> mp = pipe_modem<T>(ctx, cfg->demod_method);
+    const size_t lds = (size_t)mp.grid.G * mp.grid.G * sizeof(unsigned long long);
+    const int per_wave = 16;      // 4 ... 64 realizations per wavefront measured: 1.98-2.05e8 realizations/s, no trend
+    const uint64_t chunks = (count + per_wave - 1) / per_wave;
+    const uint64_t cap = (uint64_t)ctx->n_cu * 4 * (sizeof(T) == 4 ? 4 : 2);
+    const unsigned grid = (unsigned)(chunks < cap ? chunks : cap);
+    hipLaunchKernelGGL(k_ia_link<T>, dim3(grid), dim3(64), lds, ctx->stream, mp, cfg->n_symbols, cfg->noise_var, seed, first,
+                       count, per_wave, (const cx<T>*)recs, d_counters, d_sym, d_bit);
+    MCLE_LAUNCH_CHECK();
+    return MCLE_OK;
+}
 
 }  // namespace mcle
 
@@ -682,24 +713,10 @@ int mcle_run_ia(mcle_ctx* ctx, int dtype, const mcle_ia_cfg* cfg, uint64_t seed,
     MCLE_REQUIRE(count <= 0x7fffffffull, "at most 2^31-1 realizations per call");
     if (count == 0) return MCLE_OK;
     if ((rc = ctx->bind())) return rc;
-    const uint64_t cap = (uint64_t)ctx->n_cu * 16;
-    const uint64_t chunks = (count + 63) / 64;       // one wavefront per 64 realizations
-    const unsigned grid = (unsigned)(chunks < cap ? chunks : cap);
-    const size_t lds = dtype == MCLE_F32 ? (size_t)pipe_modem<float>(ctx, cfg->demod_method).grid.G *
-                                               pipe_modem<float>(ctx, cfg->demod_method).grid.G * sizeof(unsigned long long)
-                                         : 0;
-    if (dtype == MCLE_F32)
-        hipLaunchKernelGGL(k_run_ia<float>, dim3(grid), dim3(64), lds, ctx->stream, pipe_modem<float>(ctx, cfg->demod_method),
-                           cfg->n_symbols, cfg->noise_var, cfg->solver, cfg->initialize_with, cfg->max_iterations,
-                           cfg->relative_factor, seed, first, count, d_counters, d_sym_err, d_bit_err, d_sum_capacity,
-                           d_iterations);
-    else
-        hipLaunchKernelGGL(k_run_ia<double>, dim3(grid), dim3(64), 0, ctx->stream,
-                           pipe_modem<double>(ctx, cfg->demod_method), cfg->n_symbols, cfg->noise_var, cfg->solver,
-                           cfg->initialize_with, cfg->max_iterations, cfg->relative_factor, seed, first, count,
-                           d_counters, d_sym_err, d_bit_err, d_sum_capacity, d_iterations);
-    MCLE_LAUNCH_CHECK();
-    return MCLE_OK;
+    return dtype == MCLE_F32 ? run_ia_impl<float>(ctx, cfg, seed, first, count, d_counters, d_sym_err, d_bit_err,
+                                                  d_sum_capacity, d_iterations)
+                             : run_ia_impl<double>(ctx, cfg, seed, first, count, d_counters, d_sym_err, d_bit_err,
+                                                   d_sum_capacity, d_iterations);
 }
 
 }  // extern "C"

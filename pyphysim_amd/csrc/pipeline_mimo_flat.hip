@@ -124,18 +124,65 @@ __device__ __noinline__ void flat_setup(int scheme, int nt, int nr, double nv, F
     }
 }
 
+// Two launches since round 2 (the split of kernels_ia.hip): the per-lane set-up (Cholesky / Jacobi SVD / GMD in f64)
+// takes every register of the SIMD, the symbol walk wants many resident waves.  Record per realization:
+// A[4][4], G[4][4], {aux, ok}.
+constexpr int kFlatRec = 2 * kFlatMax * kFlatMax + 1;
+
 template <typename T>
-__global__ __launch_bounds__(64) void k_run_mimo_flat(ModemParams<T> mp, int scheme, int nt, int nr, int n_symbols,
-                                                      double noise_var, double filter_nv, uint64_t seed,
-                                                      uint64_t first, uint64_t count, mcle_counters* counters,
-                                                      uint32_t* __restrict__ sym_out, uint32_t* __restrict__ bit_out) {
-    constexpr int PITCH = kFlatMax * kFlatMax + 1;
+__global__ __launch_bounds__(64) void k_mimo_flat_setup(int scheme, int nt, int nr, double filter_nv, uint64_t seed,
+                                                        uint64_t first, uint64_t count, cx<T>* __restrict__ recs) {
+    const uint64_t rl = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+    if (rl >= count) return;
+    cx<T>* rec = recs + rl * kFlatRec;
+    const Rng rng(seed, first + rl);
+    FlatSetup st;
+#pragma unroll
+    for (int r = 0; r < kFlatMax; ++r)
+#pragma unroll
+        for (int a = 0; a < kFlatMax; ++a)
+            st.H[r][a] = (r < nr && a < nt) ? cn_sample<double>(rng, STREAM_CHAN, (uint64_t)(r * nt + a), 1.0)
+                                            : mk<double>(0, 0);
+    flat_setup(scheme, nt, nr, filter_nv, st);
+    if (scheme == MCLE_MIMO_ALAMOUTI) {
+#pragma unroll
+        for (int i = 0; i < kFlatMax; ++i)
+#pragma unroll
+            for (int j = 0; j < kFlatMax; ++j)
+                rec[i * kFlatMax + j] = mk<T>((T)st.H[i][j].x, (T)st.H[i][j].y);
+    } else {
+        // A = G (H W) in f64; rows / columns beyond the layers are zero (W, G are zero there)
+        double2 HW[kFlatMax][kFlatMax];
+#pragma unroll
+        for (int r = 0; r < kFlatMax; ++r)
+#pragma unroll
+            for (int l = 0; l < kFlatMax; ++l) {
+                double2 acc = mk<double>(0, 0);
+#pragma unroll
+                for (int a = 0; a < kFlatMax; ++a) acc = cadd(acc, cmul(st.H[r][a], st.W[a][l]));
+                HW[r][l] = acc;
+            }
+#pragma unroll
+        for (int i = 0; i < kFlatMax; ++i)
+#pragma unroll
+            for (int l = 0; l < kFlatMax; ++l) {
+                double2 acc = mk<double>(0, 0);
+#pragma unroll
+                for (int r = 0; r < kFlatMax; ++r) acc = cadd(acc, cmul(st.G[i][r], HW[r][l]));
+                rec[i * kFlatMax + l] = mk<T>((T)acc.x, (T)acc.y);
+                rec[kFlatMax * kFlatMax + i * kFlatMax + l] = mk<T>((T)st.G[i][l].x, (T)st.G[i][l].y);
+            }
+    }
+    rec[2 * kFlatMax * kFlatMax] = mk<T>((T)st.aux, st.ok ? (T)1 : (T)0);
+}
+
+template <typename T>
+__global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void k_mimo_flat_link(
+    ModemParams<T> mp, int scheme, int nt, int nr, int n_symbols, double noise_var, uint64_t seed, uint64_t first,
+    uint64_t count, int per_wave, const cx<T>* __restrict__ recs, mcle_counters* counters,
+    uint32_t* __restrict__ sym_out, uint32_t* __restrict__ bit_out) {
     __shared__ cx<T> s_table[256];
     extern __shared__ unsigned long long s_grid[];       // [G*G] candidate grid (min-distance demodulation, f32)
-    // per realization: A = G H W (symbols -> estimates; Alamouti keeps H here) and the receive filter G
-    __shared__ cx<T> s_A[64][PITCH], s_G[64][PITCH];
-    __shared__ T s_aux[64];
-    __shared__ unsigned s_ok[64];
     load_table(mp, s_table);
     load_grid(mp, s_grid);
     const int lane = threadIdx.x;
@@ -145,72 +192,24 @@ __global__ __launch_bounds__(64) void k_run_mimo_flat(ModemParams<T> mp, int sch
     const bool c_order = scheme == MCLE_MIMO_SVD || scheme == MCLE_MIMO_GMD;
     __shared__ WgTotals totals;
     if (threadIdx.x == 0) wg_zero(totals);
-    const uint64_t n_chunks = (count + 63) / 64;
+    __syncthreads();
+    const uint64_t n_chunks = (count + per_wave - 1) / per_wave;
     for (uint64_t ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
-        __syncthreads();
-        // ---- phase 1: one realization per lane ----
-        {
-            const uint64_t rl = ch * 64 + lane;
-            if (rl < count) {
-                const Rng rng(seed, first + rl);
-                FlatSetup st;
-#pragma unroll
-                for (int r = 0; r < kFlatMax; ++r)
-#pragma unroll
-                    for (int a = 0; a < kFlatMax; ++a)
-                        st.H[r][a] = (r < nr && a < nt) ? cn_sample<double>(rng, STREAM_CHAN, (uint64_t)(r * nt + a), 1.0)
-                                                        : mk<double>(0, 0);
-                flat_setup(scheme, nt, nr, filter_nv, st);
-                if (scheme == MCLE_MIMO_ALAMOUTI) {
-#pragma unroll
-                    for (int i = 0; i < kFlatMax; ++i)
-#pragma unroll
-                        for (int j = 0; j < kFlatMax; ++j)
-                            s_A[lane][i * kFlatMax + j] = mk<T>((T)st.H[i][j].x, (T)st.H[i][j].y);
-                } else {
-                    // A = G (H W) in f64; rows / columns beyond the layers are zero (W, G are zero there)
-                    double2 HW[kFlatMax][kFlatMax];
-#pragma unroll
-                    for (int r = 0; r < kFlatMax; ++r)
-#pragma unroll
-                        for (int l = 0; l < kFlatMax; ++l) {
-                            double2 acc = mk<double>(0, 0);
-#pragma unroll
-                            for (int a = 0; a < kFlatMax; ++a) acc = cadd(acc, cmul(st.H[r][a], st.W[a][l]));
-                            HW[r][l] = acc;
-                        }
-#pragma unroll
-                    for (int i = 0; i < kFlatMax; ++i)
-#pragma unroll
-                        for (int l = 0; l < kFlatMax; ++l) {
-                            double2 acc = mk<double>(0, 0);
-#pragma unroll
-                            for (int r = 0; r < kFlatMax; ++r) acc = cadd(acc, cmul(st.G[i][r], HW[r][l]));
-                            s_A[lane][i * kFlatMax + l] = mk<T>((T)acc.x, (T)acc.y);
-                            s_G[lane][i * kFlatMax + l] = mk<T>((T)st.G[i][l].x, (T)st.G[i][l].y);
-                        }
-                }
-                s_aux[lane] = (T)st.aux;
-                s_ok[lane] = st.ok ? 1u : 0u;
-            }
-        }
-        __syncthreads();
-        // ---- phase 2: the wave walks the chunk's realizations ----
-        const int in_chunk = (int)((count - ch * 64) < 64 ? (count - ch * 64) : 64);
-        for (int j = 0; j < in_chunk; ++j) {
-            const uint64_t rl = ch * 64 + j;
+        const uint64_t r_end = (ch + 1) * per_wave < count ? (ch + 1) * per_wave : count;
+        for (uint64_t rl = ch * per_wave; rl < r_end; ++rl) {
             const Rng rng(seed, first + rl);
+            const cx<T>* rec = recs + rl * kFlatRec;     // wave-uniform: scalar loads
             cx<T> A[kFlatMax][kFlatMax], G[kFlatMax][kFlatMax];     // Alamouti: A holds H
 #pragma unroll
             for (int i = 0; i < kFlatMax; ++i)
 #pragma unroll
                 for (int c = 0; c < kFlatMax; ++c) {
-                    A[i][c] = s_A[j][i * kFlatMax + c];
-                    G[i][c] = s_G[j][i * kFlatMax + c];
+                    A[i][c] = rec[i * kFlatMax + c];
+                    G[i][c] = rec[kFlatMax * kFlatMax + i * kFlatMax + c];
                 }
             unsigned se = 0, be = 0;
             if (scheme == MCLE_MIMO_ALAMOUTI) {
-                const T scale = s_aux[j];
+                const T scale = rec[2 * kFlatMax * kFlatMax].x;
                 const T inv_root2 = (T)0.70710678118654752440;
                 // slot pair p = symbols 2p, 2p+1 (one word of a DATA block, blocks shared across the wave) and the
                 // noise samples 2p, 2p+1 of every receive row (one NOISE block each); n_symbols is even
@@ -329,7 +328,7 @@ __global__ __launch_bounds__(64) void k_run_mimo_flat(ModemParams<T> mp, int sch
             }
             se = wave_sum_u32(se);
             be = wave_sum_u32(be);
-            if (lane == 0) wg_account(totals, se, be, s_ok[j] == 0u, rl, sym_out, bit_out);
+            if (lane == 0) wg_account(totals, se, be, rec[2 * kFlatMax * kFlatMax].y == (T)0, rl, sym_out, bit_out);
         }
     }
     if (lane == 0)
@@ -372,18 +371,31 @@ extern "C" int mcle_run_mimo_flat(mcle_ctx* ctx, int dtype, const mcle_mimo_flat
     if (count == 0) return MCLE_OK;
     if ((rc = ctx->bind())) return rc;
     const double filter_nv = cfg->mmse ? cfg->noise_var : 0.0;
-    const uint64_t cap = (uint64_t)ctx->n_cu * 16;
-    const uint64_t chunks = (count + 63) / 64;
-    const unsigned grid = (unsigned)(chunks < cap ? chunks : cap);
+    const int per_wave = 16;
+    const uint64_t chunks = (count + per_wave - 1) / per_wave;
     const ModemParams<float> mp32 = pipe_modem<float>(ctx, cfg->demod_method);
     const size_t lds = (size_t)mp32.grid.G * mp32.grid.G * sizeof(unsigned long long);
-    if (dtype == MCLE_F32)
-        hipLaunchKernelGGL(k_run_mimo_flat<float>, dim3(grid), dim3(64), lds, ctx->stream, mp32, cfg->scheme, nt, nr, cfg->n_symbols,
-                           cfg->noise_var, filter_nv, seed, first, count, d_counters, d_sym_err, d_bit_err);
-    else
-        hipLaunchKernelGGL(k_run_mimo_flat<double>, dim3(grid), dim3(64), 0, ctx->stream,
-                           pipe_modem<double>(ctx, cfg->demod_method), cfg->scheme, nt, nr, cfg->n_symbols,
-                           cfg->noise_var, filter_nv, seed, first, count, d_counters, d_sym_err, d_bit_err);
+    void* recs = nullptr;
+    if ((rc = ctx->scratch((size_t)count * kFlatRec * (dtype == MCLE_F32 ? sizeof(float2) : sizeof(double2)), &recs)))
+        return rc;
+    const unsigned sgrid = (unsigned)((count + 63) / 64);
+    if (dtype == MCLE_F32) {
+        const uint64_t cap = (uint64_t)ctx->n_cu * 16;
+        hipLaunchKernelGGL(k_mimo_flat_setup<float>, dim3(sgrid), dim3(64), 0, ctx->stream, cfg->scheme, nt, nr, filter_nv, seed,
+                           first, count, (float2*)recs);
+        MCLE_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_mimo_flat_link<float>, dim3((unsigned)(chunks < cap ? chunks : cap)), dim3(64), lds, ctx->stream,
+                           mp32, cfg->scheme, nt, nr, cfg->n_symbols, cfg->noise_var, seed, first, count, per_wave,
+                           (const float2*)recs, d_counters, d_sym_err, d_bit_err);
+    } else {
+        const uint64_t cap = (uint64_t)ctx->n_cu * 8;
+        hipLaunchKernelGGL(k_mimo_flat_setup<double>, dim3(sgrid), dim3(64), 0, ctx->stream, cfg->scheme, nt, nr, filter_nv, seed,
+                           first, count, (double2*)recs);
+        MCLE_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_mimo_flat_link<double>, dim3((unsigned)(chunks < cap ? chunks : cap)), dim3(64), 0, ctx->stream,
+                           pipe_modem<double>(ctx, cfg->demod_method), cfg->scheme, nt, nr, cfg->n_symbols, cfg->noise_var,
+                           seed, first, count, per_wave, (const double2*)recs, d_counters, d_sym_err, d_bit_err);
+    }
     MCLE_LAUNCH_CHECK();
     return MCLE_OK;
 }
