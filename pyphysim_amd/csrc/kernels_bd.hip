@@ -718,18 +718,25 @@ static int launch_run_bd(mcle_ctx* ctx, const mcle_bd_cfg* cfg, const BdParams& 
     const ModemParams<T> mp = pipe_modem<T>(ctx, cfg->demod_method);
     int rc;
     void* recs = nullptr;
-    if ((rc = ctx->scratch((size_t)count * (n * (R + 1) + 1) * sizeof(cx<T>), &recs))) return rc;
-    hipLaunchKernelGGL((k_bd_solve_links<T, R>), dim3((unsigned)((count + 63) / 64)), dim3(64), 0, ctx->stream, pp, seed,
-                       first, count, (cx<T>*)recs);
-    MCLE_LAUNCH_CHECK();
+    const uint64_t kSlice = 1ull << 20;          // realizations per solve + walk pair: bounds the record buffer
+    const uint64_t slice = count < kSlice ? count : kSlice;
+    const size_t stride = (size_t)(n * (R + 1) + 1);
+    if ((rc = ctx->scratch((size_t)slice * stride * sizeof(cx<T>), &recs))) return rc;
     const size_t lds = (size_t)mp.grid.G * mp.grid.G * sizeof(unsigned long long);
     const int per_wave = 8;
-    const uint64_t cap = (uint64_t)ctx->n_cu * 4 * (sizeof(T) == 4 ? 4 : 2);
-    const uint64_t chunks = (count + per_wave - 1) / per_wave;
-    const unsigned grid = (unsigned)(chunks < cap ? chunks : cap);
-    hipLaunchKernelGGL((k_bd_link<T, R>), dim3(grid), dim3(64), lds, ctx->stream, mp, pp, seed, first, count, per_wave,
-                       (const cx<T>*)recs, d_counters, d_sym_err, d_bit_err);
-    MCLE_LAUNCH_CHECK();
+    for (uint64_t off = 0; off < count; off += slice) {
+        const uint64_t m = count - off < slice ? count - off : slice;
+        hipLaunchKernelGGL((k_bd_solve_links<T, R>), dim3((unsigned)((m + 63) / 64)), dim3(64), 0, ctx->stream, pp, seed,
+                           first + off, m, (cx<T>*)recs);
+        MCLE_LAUNCH_CHECK();
+        const uint64_t cap = (uint64_t)ctx->n_cu * 4 * (sizeof(T) == 4 ? 4 : 2);
+        const uint64_t chunks = (m + per_wave - 1) / per_wave;
+        const unsigned grid = (unsigned)(chunks < cap ? chunks : cap);
+        hipLaunchKernelGGL((k_bd_link<T, R>), dim3(grid), dim3(64), lds, ctx->stream, mp, pp, seed, first + off, m, per_wave,
+                           (const cx<T>*)recs, d_counters, d_sym_err ? d_sym_err + off : nullptr,
+                           d_bit_err ? d_bit_err + off : nullptr);
+        MCLE_LAUNCH_CHECK();
+    }
     return MCLE_OK;
 }
 

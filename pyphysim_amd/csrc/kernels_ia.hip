@@ -626,25 +626,32 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void k_ia_link(ModemPar
         wg_flush(totals, counters, 3ull * (unsigned long long)n_symbols, 3ull * (unsigned long long)n_symbols * mp.bits);
 }
 
+constexpr uint64_t kSolveSlice = 1ull << 20;   // realizations per solve + walk pair: bounds the record buffer (128 MB here)
+
 template <typename T>
 int run_ia_impl(mcle_ctx* ctx, const mcle_ia_cfg* cfg, uint64_t seed, uint64_t first, uint64_t count,
                 mcle_counters* d_counters, uint32_t* d_sym, uint32_t* d_bit, double* d_cap, uint32_t* d_iter) {
     int rc;
     void* recs = nullptr;
-    if ((rc = ctx->scratch((size_t)count * kIaRec * sizeof(cx<T>), &recs))) return rc;
-    hipLaunchKernelGGL(k_ia_solve_links<T>, dim3((unsigned)((count + 63) / 64)), dim3(64), 0, ctx->stream, cfg->noise_var,
-                       cfg->solver, cfg->initialize_with, cfg->max_iterations, cfg->relative_factor, seed, first, count,
-                       (cx<T>*)recs, d_cap, d_iter);
-    MCLE_LAUNCH_CHECK();
+    const uint64_t slice = count < kSolveSlice ? count : kSolveSlice;
+    if ((rc = ctx->scratch((size_t)slice * kIaRec * sizeof(cx<T>), &recs))) return rc;
     const ModemParams<T> mp = pipe_modem<T>(ctx, cfg->demod_method);
     const size_t lds = (size_t)mp.grid.G * mp.grid.G * sizeof(unsigned long long);
     const int per_wave = 16;      // 4 ... 64 realizations per wavefront measured: 1.98-2.05e8 realizations/s, no trend
-    const uint64_t chunks = (count + per_wave - 1) / per_wave;
-    const uint64_t cap = (uint64_t)ctx->n_cu * 4 * (sizeof(T) == 4 ? 4 : 2);
-    const unsigned grid = (unsigned)(chunks < cap ? chunks : cap);
-    hipLaunchKernelGGL(k_ia_link<T>, dim3(grid), dim3(64), lds, ctx->stream, mp, cfg->n_symbols, cfg->noise_var, seed, first,
-                       count, per_wave, (const cx<T>*)recs, d_counters, d_sym, d_bit);
-    MCLE_LAUNCH_CHECK();
+    for (uint64_t off = 0; off < count; off += slice) {
+        const uint64_t n = count - off < slice ? count - off : slice;
+        hipLaunchKernelGGL(k_ia_solve_links<T>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, cfg->noise_var,
+                           cfg->solver, cfg->initialize_with, cfg->max_iterations, cfg->relative_factor, seed, first + off, n,
+                           (cx<T>*)recs, d_cap ? d_cap + off : nullptr, d_iter ? d_iter + off : nullptr);
+        MCLE_LAUNCH_CHECK();
+        const uint64_t chunks = (n + per_wave - 1) / per_wave;
+        const uint64_t cap = (uint64_t)ctx->n_cu * 4 * (sizeof(T) == 4 ? 4 : 2);
+        const unsigned grid = (unsigned)(chunks < cap ? chunks : cap);
+        hipLaunchKernelGGL(k_ia_link<T>, dim3(grid), dim3(64), lds, ctx->stream, mp, cfg->n_symbols, cfg->noise_var, seed,
+                           first + off, n, per_wave, (const cx<T>*)recs, d_counters, d_sym ? d_sym + off : nullptr,
+                           d_bit ? d_bit + off : nullptr);
+        MCLE_LAUNCH_CHECK();
+    }
     return MCLE_OK;
 }
 

@@ -372,30 +372,37 @@ extern "C" int mcle_run_mimo_flat(mcle_ctx* ctx, int dtype, const mcle_mimo_flat
     if ((rc = ctx->bind())) return rc;
     const double filter_nv = cfg->mmse ? cfg->noise_var : 0.0;
     const int per_wave = 16;
-    const uint64_t chunks = (count + per_wave - 1) / per_wave;
     const ModemParams<float> mp32 = pipe_modem<float>(ctx, cfg->demod_method);
     const size_t lds = (size_t)mp32.grid.G * mp32.grid.G * sizeof(unsigned long long);
+    const uint64_t kSlice = 1ull << 20;          // realizations per set-up + walk pair: bounds the record buffer
+    const uint64_t slice = count < kSlice ? count : kSlice;
     void* recs = nullptr;
-    if ((rc = ctx->scratch((size_t)count * kFlatRec * (dtype == MCLE_F32 ? sizeof(float2) : sizeof(double2)), &recs)))
+    if ((rc = ctx->scratch((size_t)slice * kFlatRec * (dtype == MCLE_F32 ? sizeof(float2) : sizeof(double2)), &recs)))
         return rc;
-    const unsigned sgrid = (unsigned)((count + 63) / 64);
-    if (dtype == MCLE_F32) {
-        const uint64_t cap = (uint64_t)ctx->n_cu * 16;
-        hipLaunchKernelGGL(k_mimo_flat_setup<float>, dim3(sgrid), dim3(64), 0, ctx->stream, cfg->scheme, nt, nr, filter_nv, seed,
-                           first, count, (float2*)recs);
+    for (uint64_t off = 0; off < count; off += slice) {
+        const uint64_t m = count - off < slice ? count - off : slice;
+        const uint64_t chunks = (m + per_wave - 1) / per_wave;
+        const unsigned sgrid = (unsigned)((m + 63) / 64);
+        uint32_t* se = d_sym_err ? d_sym_err + off : nullptr;
+        uint32_t* be = d_bit_err ? d_bit_err + off : nullptr;
+        if (dtype == MCLE_F32) {
+            const uint64_t cap = (uint64_t)ctx->n_cu * 16;
+            hipLaunchKernelGGL(k_mimo_flat_setup<float>, dim3(sgrid), dim3(64), 0, ctx->stream, cfg->scheme, nt, nr, filter_nv,
+                               seed, first + off, m, (float2*)recs);
+            MCLE_LAUNCH_CHECK();
+            hipLaunchKernelGGL(k_mimo_flat_link<float>, dim3((unsigned)(chunks < cap ? chunks : cap)), dim3(64), lds,
+                               ctx->stream, mp32, cfg->scheme, nt, nr, cfg->n_symbols, cfg->noise_var, seed, first + off, m,
+                               per_wave, (const float2*)recs, d_counters, se, be);
+        } else {
+            const uint64_t cap = (uint64_t)ctx->n_cu * 8;
+            hipLaunchKernelGGL(k_mimo_flat_setup<double>, dim3(sgrid), dim3(64), 0, ctx->stream, cfg->scheme, nt, nr, filter_nv,
+                               seed, first + off, m, (double2*)recs);
+            MCLE_LAUNCH_CHECK();
+            hipLaunchKernelGGL(k_mimo_flat_link<double>, dim3((unsigned)(chunks < cap ? chunks : cap)), dim3(64), 0,
+                               ctx->stream, pipe_modem<double>(ctx, cfg->demod_method), cfg->scheme, nt, nr, cfg->n_symbols,
+                               cfg->noise_var, seed, first + off, m, per_wave, (const double2*)recs, d_counters, se, be);
+        }
         MCLE_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_mimo_flat_link<float>, dim3((unsigned)(chunks < cap ? chunks : cap)), dim3(64), lds, ctx->stream,
-                           mp32, cfg->scheme, nt, nr, cfg->n_symbols, cfg->noise_var, seed, first, count, per_wave,
-                           (const float2*)recs, d_counters, d_sym_err, d_bit_err);
-    } else {
-        const uint64_t cap = (uint64_t)ctx->n_cu * 8;
-        hipLaunchKernelGGL(k_mimo_flat_setup<double>, dim3(sgrid), dim3(64), 0, ctx->stream, cfg->scheme, nt, nr, filter_nv, seed,
-                           first, count, (double2*)recs);
-        MCLE_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_mimo_flat_link<double>, dim3((unsigned)(chunks < cap ? chunks : cap)), dim3(64), 0, ctx->stream,
-                           pipe_modem<double>(ctx, cfg->demod_method), cfg->scheme, nt, nr, cfg->n_symbols, cfg->noise_var,
-                           seed, first, count, per_wave, (const double2*)recs, d_counters, d_sym_err, d_bit_err);
     }
-    MCLE_LAUNCH_CHECK();
     return MCLE_OK;
 }
