@@ -65,6 +65,8 @@ FP32_PEAK_TFLOPS = 157.3    # same guide: FP32 vector peak = FP32-input MFMA pea
 KERNEL = {"c4": "k_run_mimo_ofdm_mfma", "c2": "k_run_flat", "c3": "k_run_ofdm_tdl_mfma", "c5": "k_ia_link",
           "f1": "k_run_mimo_ofdm_tdl", "f6": "k_bd_link"}
 KERNEL_NOTE = {   # configs whose step is two launches: the time spans both, the counters are the named (dominant) kernel's
+    "c4": "a step = k_mimo_filters (channel draw + f64 receive filter per realization, 13 us = 0.8 % of the time) + k_run_mimo_ofdm_mfma; "
+          "kernel_ms_per_launch spans both",
     "c5": "a step = k_ia_solve_links (per-lane solve, ~18 % of the time) + k_ia_link (symbol walk); kernel_ms_per_launch spans both",
     "f6": "a step = k_bd_solve_links (per-lane solve) + k_bd_link (symbol walk); kernel_ms_per_launch spans both"}
 BATCH = {"c4": 65536, "c3": 131072, "c2": 4096, "c5": 262144, "f1": 98304, "f6": 131072}

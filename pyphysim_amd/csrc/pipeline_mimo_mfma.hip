@@ -85,13 +85,43 @@ struct MimoParams {
     double noise_var;
 };
 
+// The channel draw and the f64 receive filter of every realization, one per lane, in a launch of their own (until round 2
+// thread 0..63 of the main kernel did this for the workgroup's next 64 realizations: 128 f64 registers of work matrices in
+// the middle of a kernel sized for 168 VGPRs -- 40 of its 72 spilled registers).  Record: H[16], G[16] x FFT scale, flag.
+constexpr int kMimoRec = 2 * 4 * 4 + 1;
+__global__ __launch_bounds__(64) void k_mimo_filters(MimoParams pp, uint64_t seed, uint64_t first, uint64_t count,
+                                                     float2* __restrict__ recs) {
+    constexpr int NA = 4;
+    const uint64_t rl = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+    if (rl >= count) return;
+    const double rx_scale = sqrt((double)(pp.num_used + pp.cp)) / (double)kF16N;
+    const Rng rng(seed, first + rl);
+    float2* rec = recs + rl * kMimoRec;
+    double2 H[NA][NA], G[NA][NA];
+#pragma unroll
+    for (int r = 0; r < NA; ++r)
+#pragma unroll
+        for (int a = 0; a < NA; ++a) {
+            const float2 h = cn_sample<float>(rng, STREAM_CHAN, (uint64_t)(r * NA + a), 1.f);
+            rec[r * NA + a] = h;
+            H[r][a] = mk<double>((double)h.x, (double)h.y);
+        }
+    const bool ok = blast_filter<NA, NA>(H, pp.mmse ? pp.noise_var : 0.0, G);
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int r = 0; r < NA; ++r)
+            rec[NA * NA + a * NA + r] = make_float2((float)(G[a][r].x * rx_scale), (float)(G[a][r].y * rx_scale));
+    rec[2 * NA * NA] = make_float2(ok ? 0.f : 1.f, 0.f);
+}
+
 // WAVES: waves per SIMD the register allocation is sized for (= workgroups per CU); FLAGS bit 0: draw the noise under
 // the P1 / P2 MFMAs instead of inside the middle stage
 template <int WAVES, int FLAGS>
 __global__ __launch_bounds__(kPipeBlock, WAVES) void k_run_mimo_ofdm_mfma(MimoParams pp, ModemParams<float> mp,
                                                                        uint64_t seed, uint64_t first, uint64_t count,
                                                                        const float2* __restrict__ g_tw,
-                                                                       float2* g_filters, mcle_counters* counters,
+                                                                       const float2* __restrict__ g_recs, mcle_counters* counters,
                                                                        uint32_t* __restrict__ sym_out,
                                                                        uint32_t* __restrict__ bit_out) {
     constexpr int N = kF16N, NA = 4;
@@ -112,7 +142,6 @@ __global__ __launch_bounds__(kPipeBlock, WAVES) void k_run_mimo_ofdm_mfma(MimoPa
     const uint64_t row = (uint64_t)pp.n_ofdm_sym * (N + cp);
     const float sigma = (float)sqrt(pp.noise_var);
     const float tx_scale = (float)(1.0 / sqrt((double)NA) / sqrt((double)(U + cp)));
-    const double rx_scale = sqrt((double)(U + cp)) / (double)N;
     const uint32_t mask = (uint32_t)(mp.M - 1);
     const uint32_t mask4 = mask * 0x01010101u;
     const bool slicer = mp.method == MCLE_DEMOD_QAM_SLICER;   // s_idx then holds LEVEL bytes instead of labels
@@ -160,7 +189,6 @@ __global__ __launch_bounds__(kPipeBlock, WAVES) void k_run_mimo_ofdm_mfma(MimoPa
     const int sc_off = f16_pos(sc_bin);
     const int sc_blk = ((sc_bin + N / 2) & (N - 1)) >> 2;                     // Philox DATA block of those 4 subcarriers
 
-    float2* my_filters = g_filters + (size_t)blockIdx.x * 64 * kRec;
     // noise samples pair up in Philox blocks by even / odd sample index; lanes l, l^1 share blocks when the
     // realization's sample indices keep the parity of the time index
     const bool pair_ok = ((row & 1) == 0) && (((N + cp) & 1) == 0) && ((cp & 1) == 0);
@@ -170,36 +198,10 @@ __global__ __launch_bounds__(kPipeBlock, WAVES) void k_run_mimo_ofdm_mfma(MimoPa
     __syncthreads();
     for (uint64_t rl = blockIdx.x; rl < count; rl += gridDim.x, ++it) {
         const Rng rng(seed, first + rl);
-        const int slot = (int)(it & 63), buf = (int)(it & 1);
-        if (slot == 0) {   // channel draw + f64 receive filter for this workgroup's next 64 realizations, one per lane
-            __syncthreads();
-            const uint64_t rj = rl + (uint64_t)tid * gridDim.x;
-            if (tid < 64 && rj < count) {
-                const Rng rngj(seed, first + rj);
-                float2* rec = my_filters + tid * kRec;
-                double2 H[NA][NA], G[NA][NA];
-#pragma unroll
-                for (int r = 0; r < NA; ++r)
-#pragma unroll
-                    for (int a = 0; a < NA; ++a) {
-                        const float2 h = cn_sample<float>(rngj, STREAM_CHAN, (uint64_t)(r * NA + a), 1.f);
-                        rec[r * NA + a] = h;
-                        H[r][a] = mk<double>((double)h.x, (double)h.y);
-                    }
-                const bool ok = blast_filter<NA, NA>(H, pp.mmse ? pp.noise_var : 0.0, G);
-#pragma unroll
-                for (int a = 0; a < NA; ++a)
-#pragma unroll
-                    for (int r = 0; r < NA; ++r)
-                        rec[NA * NA + a * NA + r] = make_float2((float)(G[a][r].x * rx_scale), (float)(G[a][r].y * rx_scale));
-                rec[2 * NA * NA] = make_float2(ok ? 0.f : 1.f, 0.f);
-            }
-            __threadfence_block();
-            __syncthreads();
-        }
+        const int buf = (int)(it & 1);
         // this realization's record -> s_rec[buf] (read after the next workgroup barrier; its previous reader,
         // realization it - 2, is two barriers behind)
-        if (tid < kRec) s_rec[buf * (kRec + 1) + tid] = my_filters[slot * kRec + tid];
+        if (tid < kRec) s_rec[buf * (kRec + 1) + tid] = g_recs[rl * kRec + tid];
         const float2* s_H = s_rec + buf * (kRec + 1);
         const float2* s_G = s_H + NA * NA;
         unsigned se = 0, be = 0;
@@ -537,12 +539,21 @@ int run_mimo_ofdm_mfma(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, uint64_t se
     if (per_cu < 1) per_cu = 1;
     if (per_cu > waves) per_cu = waves;     // __launch_bounds__(256, WAVES)
     const uint64_t cap = (uint64_t)ctx->n_cu * per_cu;
-    const unsigned grid = (unsigned)(count < cap ? count : cap);
-    void* filters = nullptr;
-    if ((rc = ctx->scratch((size_t)grid * 64 * 33 * sizeof(float2), &filters))) return rc;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kPipeBlock), lds, ctx->stream, pp, mp, seed, first, count,
-                       (const float2*)tw, (float2*)filters, d_counters, d_sym, d_bit);
-    MCLE_LAUNCH_CHECK();
+    const uint64_t kSlice = 1ull << 18;          // realizations per filter + link pair: bounds the record buffer (69 MB)
+    const uint64_t slice = count < kSlice ? count : kSlice;
+    void* recs = nullptr;
+    if ((rc = ctx->scratch((size_t)slice * kMimoRec * sizeof(float2), &recs))) return rc;
+    for (uint64_t off = 0; off < count; off += slice) {
+        const uint64_t n = count - off < slice ? count - off : slice;
+        hipLaunchKernelGGL(k_mimo_filters, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, pp, seed, first + off, n,
+                           (float2*)recs);
+        MCLE_LAUNCH_CHECK();
+        const unsigned grid = (unsigned)(n < cap ? n : cap);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kPipeBlock), lds, ctx->stream, pp, mp, seed, first + off, n,
+                           (const float2*)tw, (const float2*)recs, d_counters, d_sym ? d_sym + off : nullptr,
+                           d_bit ? d_bit + off : nullptr);
+        MCLE_LAUNCH_CHECK();
+    }
     return MCLE_OK;
 }
 
