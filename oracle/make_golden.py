@@ -422,6 +422,74 @@ def golden_mu_channels():
     print("a14c_mu_channels: reference MuChannel / MuMimoChannel runs stored (3 set-ups, 9 received blocks)")
 
 
+def golden_ia_base():
+    """tests/golden/f3d_ia_base.npz: what IASolverBaseClass offers around a solution (iabase.py:127-921) on the
+    reference itself: user-set precoders / filters -> full_W_H, calc_SINR, calc_Q, calc_Q_rev,
+    calc_remaining_interference_percentage; get_cost of the min-leakage and alt-min solvers after a solve."""
+    from pyphysim.channels import multiuser as rmu
+    from pyphysim.ia import algorithms as ralg
+    rs = np.random.RandomState(BASE_SEED + 61)
+    randc = lambda *shape: (rs.randn(*shape) + 1j * rs.randn(*shape)) / math.sqrt(2.0)
+    store = {}
+    cases = [dict(K=3, nr=2, nt=2, Ns=(1, 1, 1), nv=0.02, P=(1.0, 1.0, 1.0)),
+             dict(K=3, nr=4, nt=4, Ns=(2, 1, 2), nv=0.1, P=(0.5, 2.0, 1.3)),
+             dict(K=2, nr=3, nt=4, Ns=(2, 2), nv=0.0, P=(1.0, 0.7))]
+    for ci, c in enumerate(cases):
+        K, nr, nt, Ns = c["K"], c["nr"], c["nt"], c["Ns"]
+        muc = rmu.MultiUserChannelMatrix()
+        muc.set_channel_seed(BASE_SEED + 62 + ci)
+        muc.randomize(nr, nt, K)
+        muc.noise_var = c["nv"] if c["nv"] > 0 else None
+        sol = ralg.MaxSinrIASolver(muc)
+        F = np.empty(K, dtype=np.ndarray)
+        W_H = np.empty(K, dtype=np.ndarray)
+        for k in range(K):
+            f = randc(nt, Ns[k])
+            F[k] = f / np.linalg.norm(f, "fro")
+            w = randc(Ns[k], nr)
+            W_H[k] = w / np.linalg.norm(w, "fro")
+        sol.set_precoders(F=F, P=np.array(c["P"]))
+        sol.set_receive_filters(W_H=W_H)
+        pre = "case%d_" % ci
+        store[pre + "cfg"] = np.array([K, nr, nt])
+        store[pre + "Ns"], store[pre + "P"], store[pre + "nv"] = np.array(Ns), np.array(c["P"]), np.array(c["nv"])
+        store[pre + "big_H"] = np.array(muc.big_H)
+        sinr = sol.calc_SINR()
+        _ = sol.W                       # calc_Q_rev reads _W, which only this property fills from W_H (iabase.py:252-262, :662)
+        for k in range(K):
+            store[pre + "F%d" % k], store[pre + "WH%d" % k] = F[k], W_H[k]
+            store[pre + "fullWH%d" % k] = np.array(sol.full_W_H[k])
+            store[pre + "sinr%d" % k] = np.asarray(sinr[k], dtype=float)
+            store[pre + "Q%d" % k] = np.array(sol.calc_Q(k))
+            store[pre + "Qrev%d" % k] = np.array(sol.calc_Q_rev(k))
+            store[pre + "rip%d" % k] = np.array(sol.calc_remaining_interference_percentage(k))
+        store[pre + "cap"] = np.array(sol.calc_sum_capacity())
+        store[pre + "sinr_dB0"] = np.asarray(sol.calc_SINR_in_dB()[0], dtype=float)
+    # costs after a solve (K = 3, 2x2, one stream, 'fix' start)
+    muc = rmu.MultiUserChannelMatrix()
+    muc.set_channel_seed(BASE_SEED + 70)
+    muc.randomize(2, 2, 3)
+    muc.noise_var = 0.01
+    F0 = np.empty(3, dtype=np.ndarray)
+    for k in range(3):
+        f = randc(2, 1)
+        F0[k] = f / np.linalg.norm(f, "fro")
+    store["cost_big_H"] = np.array(muc.big_H)
+    for k in range(3):
+        store["cost_F%d" % k] = F0[k]
+    for name, cls in (("min_leakage", ralg.MinLeakageIASolver), ("alt_min", ralg.AlternatingMinIASolver)):
+        sol = cls(muc)
+        sol.set_precoders(F=np.array([f.copy() for f in F0] + [None], dtype=object)[:-1])
+        sol.initialize_with = "fix"
+        sol.max_iterations = 200
+        sol.solve(1)
+        store["cost_" + name] = np.array(float(np.real(sol.get_cost())))
+        store["iters_" + name] = np.array(sol.runned_iterations)
+    np.savez_compressed(os.path.join(GOLD, "f3d_ia_base.npz"), n_cases=np.array(len(cases)), **store)
+    print("f3d_ia_base: reference IASolverBaseClass surface stored (3 user-set solutions, 2 solver costs: %.3e, %.3e)"
+          % (float(store["cost_min_leakage"]), float(store["cost_alt_min"])))
+
+
 def ref_chain_awgn(seed, mod, M, N, snr_db):
     np.random.seed(seed)
     m = ref_modulator(mod, M)
@@ -936,8 +1004,10 @@ if __name__ == "__main__":
         golden_multiuser_stats()
     if not only or "a14c_mu_channels" in only:
         golden_mu_channels()
-    only = only - {"f6b_bd_extint", "a14b_multiuser_stats", "a14c_mu_channels"} if only else only
-    if only == set() and set(sys.argv[1:]) & {"f6b_bd_extint", "a14b_multiuser_stats", "a14c_mu_channels"}:
+    if not only or "f3d_ia_base" in only:
+        golden_ia_base()
+    only = only - {"f6b_bd_extint", "a14b_multiuser_stats", "a14c_mu_channels", "f3d_ia_base"} if only else only
+    if only == set() and set(sys.argv[1:]) & {"f6b_bd_extint", "a14b_multiuser_stats", "a14c_mu_channels", "f3d_ia_base"}:
         sys.exit(0)
     if not only or only - {"operators"}:
         golden_chains(only - {"operators"})

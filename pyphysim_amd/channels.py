@@ -91,6 +91,25 @@ COST259_HTx = TdlChannelProfile(
               16978., 17615., 17827., 17849., 18016.]) * 1e-9, "COST259_HT")
 
 
+def generate_jakes_samples(Fd, Ts=1e-3, NSamples=100, L=8, shape=None, current_time=0, phi_l=None, psi_l=None,
+                           engine=None, dtype=None):
+    """fading_generators.py:15-98, the function form of the Jakes generator -> (new_current_time, h [shape..., NSamples]).
+    phi_l / psi_l default to np.random.rand(L, *shape, 1) as there (NOT times 2 pi: this legacy entry point feeds the
+    unit-interval draws to cos() as they are; JakesSampleGenerator scales them).  Sum of sinusoids on the device."""
+    t = np.arange(current_time, NSamples * Ts + current_time, Ts * 1.0000000001)
+    dims = [L] + ([] if shape is None else list(shape)) + [1]
+    if phi_l is None:
+        phi_l = np.random.rand(*dims)
+    if psi_l is None:
+        psi_l = np.random.rand(*dims)
+    streams = int(np.prod(dims[1:-1])) if len(dims) > 2 else 1
+    eng = engine if engine is not None else get_engine()
+    h = eng.jakes_generate(np.asarray(phi_l).reshape(L, streams), np.asarray(psi_l).reshape(L, streams), Fd, 0.0, 0.0,
+                           t.size, dtype=dtype, times=t)
+    h = np.asarray(h).reshape((tuple(shape) if shape is not None else ()) + (t.size,))
+    return t[-1] + Ts, h
+
+
 class FadingSampleGenerator:
     """reference fading_generators.py:101-205."""
 
@@ -117,6 +136,10 @@ class FadingSampleGenerator:
 
     def generate_more_samples(self, num_samples=None):
         raise NotImplementedError
+
+    def get_similar_fading_generator(self):
+        """fading_generators.py:198-205."""
+        raise NotImplementedError("Implement in a subclass")
 
 
 class RayleighSampleGenerator(FadingSampleGenerator):
@@ -263,6 +286,18 @@ class TdlImpulseResponse:
             dense.flags["WRITEABLE"] = False
             self._tap_values_dense = dense
         return self._tap_values_dense
+
+    @staticmethod
+    def concatenate_samples(impulse_responses):
+        """fading.py:655-698: one impulse response holding the samples of several, in order (same profile object)."""
+        if len(impulse_responses) < 2:
+            if len(impulse_responses) == 1:
+                return impulse_responses[0]
+            raise ValueError("impulse_responses must contain at least two TdlImpulseResponse objects.")
+        if impulse_responses[0].channel_profile is not impulse_responses[1].channel_profile:
+            raise ValueError("TdlImpulseResponse objects must have the same channel profile object")
+        taps = np.concatenate([np.asarray(a.tap_values_sparse) for a in impulse_responses], axis=-1)
+        return TdlImpulseResponse(taps, impulse_responses[0].channel_profile)
 
     def get_freq_response(self, fft_size):
         """fading.py:513-536.  Host FFT of the dense taps: an analysis helper, off the hot path

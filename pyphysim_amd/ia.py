@@ -66,7 +66,6 @@ class IASolverBaseClass:
     F = property(lambda self: self._F)
     full_F = property(lambda self: self._full_F)
     W_H = property(lambda self: self._W_H)
-    full_W_H = property(lambda self: self._full_W_H)
 
     @property
     def W(self):
@@ -75,12 +74,108 @@ class IASolverBaseClass:
     def _get_channel(self, k, l):
         return self._multiUserChannel.get_Hkl(k, l)
 
+    @staticmethod
+    def _objs(items):
+        return np.array(list(items) + [None], dtype=object)[:-1]
+
     def calc_SINR(self):
-        """iabase.py:768-789: one array of per-stream SINRs (linear) per user."""
-        return np.array([np.atleast_1d(np.asarray(s, dtype=float)) for s in self._sinr] + [None], dtype=object)[:-1]
+        """iabase.py:768-789: one array of per-stream SINRs (linear) per user.  After `solve` these are the solver
+        kernel's own; after `set_precoders` / `set_receive_filters` they are evaluated by `k_mu_link_stats` from
+        full_F and full_W_H (the reference's _calc_Bkl_cov_matrix_all_l / _calc_SINR_k, iabase.py:821-921)."""
+        if self._sinr is None:
+            if self._full_F is None or self.full_W_H is None:
+                raise RuntimeError("no solution yet: call solve, or set the precoders and the receive filters")
+            U = [np.asarray(u).conj().T for u in self.full_W_H]
+            self._sinr = list(self._multiUserChannel.calc_SINR(self.full_F, U))
+        return self._objs(np.atleast_1d(np.asarray(s, dtype=float)) for s in self._sinr)
+
+    def calc_SINR_in_dB(self):
+        """iabase.py:791-805."""
+        return self._objs(10.0 * np.log10(s) for s in self.calc_SINR())
 
     def calc_sum_capacity(self):
+        """iabase.py:807-819."""
+        if self._capacity is None:
+            return float(np.sum(np.log2(1.0 + np.hstack(list(self.calc_SINR())))))
         return float(self._capacity)
+
+    def get_cost(self):
+        """iabase.py:127-139: the base class has no cost."""
+        return -1
+
+    # ---- user-supplied solutions (iabase.py:167-327) ---------------------------------------------------------------
+    def set_precoders(self, F=None, full_F=None, P=None):
+        """iabase.py:202-250.  Powers other than 1 are accepted here (only the solver kernels need P = 1)."""
+        if F is None and full_F is None:
+            raise RuntimeError("Either 'F' or 'full_F' must be provided.")
+        self._sinr = self._capacity = None
+        if P is not None:
+            self._P = np.ones(self.K) * P if np.isscalar(P) else np.asarray(P, dtype=float)
+        if F is None:
+            F = [np.asarray(f) / np.linalg.norm(np.asarray(f), "fro") for f in full_F]
+        self._F = self._objs(np.asarray(f) for f in F)
+        self._full_F = (self._objs(np.asarray(f) for f in full_F) if full_F is not None
+                        else self._objs(f * np.sqrt(p) for f, p in zip(self._F, self.P)))
+        self._Ns = np.array([f.shape[1] for f in self._F], dtype=int)
+
+    def set_receive_filters(self, W_H=None, W=None):
+        """iabase.py:329-361."""
+        if W is None and W_H is None:
+            raise RuntimeError("Either 'W' or 'W_H' must be provided.")
+        if W is not None and W_H is not None:
+            raise RuntimeError("Either 'W' or 'W_H' must be provided (but not both of them.")
+        self._sinr = self._capacity = None
+        self._full_W_H = None
+        self._W_H = self._objs(np.asarray(w) for w in W_H) if W_H is not None else self._objs(np.asarray(w).conj().T for w in W)
+
+    @property
+    def full_W_H(self):
+        """iabase.py:299-327: W_H scaled so that full_W_H H_kk full_F = I (solve(W_H H_kk full_F, W_H)); the two small
+        products and the inverse run on the device (mcle_mimo_channel, mcle_pinv)."""
+        if self._full_W_H is None and self._W_H is not None:
+            out = []
+            for k in range(self.K):
+                eq = self.engine.mimo_channel(np.asarray(self._W_H[k])[None],
+                                              self.engine.mimo_channel(np.asarray(self._get_channel(k, k))[None],
+                                                                       np.asarray(self._full_F[k])[None])[0][None])[0]
+                out.append(self.engine.mimo_channel(self.engine.pinv(eq)[None], np.asarray(self._W_H[k])[None])[0])
+            self._full_W_H = self._objs(out)
+        return self._full_W_H
+
+    @property
+    def full_W(self):
+        """iabase.py:320-327."""
+        fw = self.full_W_H
+        return None if fw is None else self._objs(np.asarray(w).conj().T for w in fw)
+
+    def calc_Q(self, k):
+        """iabase.py:618-643: interference-plus-noise covariance at receiver k for full_F (device: k_mu_link_stats)."""
+        return self._multiUserChannel.calc_Q(k, self.full_F)
+
+    def calc_Q_rev(self, k):
+        """iabase.py:645-672: the same in the reverse network (channels H_lk^H, the receive filters as precoders with
+        power P_l, no noise term): the forward routine on the conjugate-transposed block matrix."""
+        W = self.W
+        if W is None:
+            raise RuntimeError("the reverse-network covariance needs the receive filters")
+        for l in range(self.K):
+            if l != k and abs(np.linalg.norm(W[l], "fro") - 1.0) >= 1e-6:
+                raise AssertionError("calc_Q_rev wants unit-norm receive filters (iabase.py:663)")
+        big = np.asarray(self._multiUserChannel.big_H)
+        n_tx = int(np.sum(self.Nt))
+        res = self.engine.mu_link_stats(big[:, :n_tx].conj().T, self.Nt, self.Nr,
+                                        F=[np.asarray(W[l]) * np.sqrt(self.P[l]) for l in range(self.K)], want=("Q",))
+        return res["Q"][k][0]
+
+    def calc_remaining_interference_percentage(self, k, Qk=None):
+        """iabase.py:674-719: share of the interference power left in the Ns[k] least-interfered directions."""
+        if Qk is None:
+            Qk = self.calc_Q(k)
+        ev = np.linalg.eigvalsh(np.asarray(Qk))              # ascending, like leig's sort on the real parts
+        return float(np.sum(np.abs(ev[:int(self.Ns[k])])) / np.trace(np.abs(np.asarray(Qk))))
+
+    def solve(self, Ns, P=None):
+        raise NotImplementedError("solve: Not implemented")
 
     def _is_special(self, Ns_arr):
         return (self.K == 3 and list(self.Nr) == [2, 2, 2] and list(self.Nt) == [2, 2, 2]
@@ -256,8 +351,24 @@ class AlternatingMinIASolver(IterativeIASolverBaseClass):
     """algorithms.py:885-1129."""
     _SOLVER = "alt_min"
 
+    def get_cost(self):
+        """algorithms.py:937-962: interference power outside the (Nr - Ns)-dimensional interference subspace C_k of every
+        receiver.  The reference measures it against the C_k of its last iteration; here C_k is the dominant eigenspace
+        of the final interference covariance (what that iteration converges to), i.e. the sum of the Ns_k smallest
+        eigenvalues of the noise-free Q_k (device: k_mu_link_stats)."""
+        big = np.asarray(self._multiUserChannel.big_H)
+        Q = self.engine.mu_link_stats(big[:, :int(np.sum(self.Nt))], self.Nr, self.Nt, F=list(self.full_F), want=("Q",))["Q"]
+        return float(sum(np.sum(np.abs(np.linalg.eigvalsh(Q[k][0])[:int(self.Ns[k])])) for k in range(self.K)))
 
-class MinLeakageIASolver(IterativeIASolverBaseClass):
+
+class _LeakageCost:
+    def get_cost(self):
+        """algorithms.py:1146-1171: sum_k trace |W_k^H Q_k W_k| (Q_k from the device, W_k the unit-norm filters)."""
+        W = self.W
+        return float(sum(np.trace(np.abs(np.asarray(W[k]).conj().T @ self.calc_Q(k) @ np.asarray(W[k]))) for k in range(self.K)))
+
+
+class MinLeakageIASolver(_LeakageCost, IterativeIASolverBaseClass):
     """algorithms.py:1132-1240."""
     _SOLVER = "min_leakage"
 

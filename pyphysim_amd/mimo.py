@@ -59,6 +59,19 @@ class MimoBase:
             channel = channel[:, np.newaxis]      # MRC-style single column (mimo.py:816-820)
         self._channel = channel
 
+    def getNumberOfLayers(self):          # pragma: no cover
+        """mimo.py:347-355."""
+        raise NotImplementedError("getNumberOfLayers still needs to be implemented in the {0} class".format(
+            self.__class__.__name__))
+
+    def encode(self, transmit_data):      # pragma: no cover
+        """mimo.py:357-370."""
+        raise NotImplementedError("encode still needs to be implemented in the {0} class".format(self.__class__.__name__))
+
+    def decode(self, received_data):      # pragma: no cover
+        """mimo.py:372-385."""
+        raise NotImplementedError("decode still needs to be implemented in the {0} class".format(self.__class__.__name__))
+
     @property
     def Nt(self):
         return int(self._channel.shape[1])
@@ -127,6 +140,23 @@ class Blast(MimoBase):
 
 class MRC(Blast):
     """reference mimo.py:789-827: Blast with a (possibly 1-D) channel."""
+
+    def set_channel_matrix(self, channel):
+        """mimo.py:810-827: a 1-D channel is one transmit antenna seen by len(channel) receive antennas."""
+        channel = np.asarray(channel)
+        super().set_channel_matrix(channel[:, np.newaxis] if channel.ndim == 1 else channel)
+
+
+class MisoBase(MimoBase):
+    """reference mimo.py:388-441: schemes for a single receive antenna (MRT, Alamouti's MISO form)."""
+
+    def set_channel_matrix(self, channel):
+        channel = np.asarray(channel)
+        if channel.ndim == 1:
+            channel = channel[np.newaxis, :]
+        elif channel.shape[0] != 1:
+            raise ValueError("The MRT scheme is only defined for the scenario with a single receive antenna")
+        self._channel = channel
 
 
 class MRT(MimoBase):

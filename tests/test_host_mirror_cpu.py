@@ -188,3 +188,48 @@ def test_block_diagonalizer_argument_errors():
     with pytest.raises(NotImplementedError):   # non-square channels are outside this build
         bd.block_diagonalize_no_waterfilling(np.ones((6, 9), dtype=complex))
     assert (bd.num_users, bd.iPu, bd.noise_var) == (3, 1.0, 0.1)
+
+
+def test_small_util_helpers_known_answers():
+    """util/conversion.py and util/misc.py helpers; the expected values are the reference's own outputs."""
+    from pyphysim_amd import util as u
+    assert u.dBm2Linear(30.0) == 1.0 and abs(u.linear2dBm(0.5) - 26.989700043360187) < 1e-12
+    assert abs(u.SNR_dB_to_EbN0_dB(10.0, 4) - 3.979400086720376) < 1e-12
+    assert abs(u.EbN0_dB_to_SNR_dB(3.0, 6) - 10.781512503836437) < 1e-12
+    assert list(u.binary2gray(np.arange(8))) == [0, 1, 3, 2, 6, 7, 5, 4]
+    assert list(u.gray2binary(np.arange(8))) == [0, 1, 3, 2, 7, 6, 4, 5]
+    assert u.gray2binary(200) == 143 and u.binary2gray(200) == 172 and u.xor(5, 3) == 6
+    assert (u.int2bits(0), u.int2bits(5), u.int2bits(8)) == (1, 3, 4)
+    with pytest.raises(ValueError):
+        u.int2bits(-1)
+    assert (u.pretty_time(3725.4), u.pretty_time(65.2), u.pretty_time(2.345)) == ("1h:02m:05s", "1m:05s", "2.35s")
+    assert u.equal_dicts({"a": 1, "b": 2}, {"a": 1, "b": 3}, ["b"]) and not u.equal_dicts({"a": 1}, {"a": 2}, [])
+    assert u.calc_shannon_sum_capacity(np.array([1.0, 3.0])) == 3.0
+    x = np.array([1.0, 2.0, 0.5, -1.0, 3.0])
+    assert np.allclose(u.calc_unorm_autocorr(x), [15.25, -0.5, 0.0, 5.0, 3.0])
+    assert np.allclose(u.calc_autocorr(x), [1.0, -0.36521739, -0.32282609, 0.20869565, -0.02065217])
+    lo, hi = u.calc_confidence_interval(1.0, 0.5, 100, 95)
+    assert abs(lo - 0.902) < 1e-12 and abs(hi - 1.098) < 1e-12
+    m = np.arange(24).reshape(4, 6)
+    o = u.single_matrix_to_matrix_of_matrices(m, np.array([1, 3]), np.array([2, 4]))
+    assert o.shape == (2, 2) and np.array_equal(o[1, 0], [[6, 7], [12, 13], [18, 19]])
+    assert u.single_matrix_to_matrix_of_matrices(m, None, np.array([2, 4]))[1].shape == (4, 4)
+    assert u.single_matrix_to_matrix_of_matrices(m, np.array([1, 3]))[1].shape == (3, 6)
+    rs1, rs2 = np.random.RandomState(3), np.random.RandomState(3)
+    want = (rs2.randn(2, 3) + 1j * rs2.randn(2, 3)) / np.sqrt(2.0)
+    assert np.array_equal(u.randn_c_RS(rs1, 2, 3), want)
+
+
+def test_mimo_base_surface():
+    from pyphysim_amd import mimo
+    with pytest.raises(ValueError, match="single receive antenna"):
+        mimo.MisoBase.set_channel_matrix(mimo.MisoBase.__new__(mimo.MisoBase), np.ones((2, 3)))
+    b = mimo.MisoBase.__new__(mimo.MisoBase)
+    b.set_channel_matrix(np.ones(3))
+    assert b._channel.shape == (1, 3)
+    r = mimo.MRC.__new__(mimo.MRC)
+    r.set_channel_matrix(np.ones(3))
+    assert r._channel.shape == (3, 1)
+    for name in ("encode", "decode"):
+        with pytest.raises(NotImplementedError):
+            getattr(mimo.MimoBase, name)(b, None)
