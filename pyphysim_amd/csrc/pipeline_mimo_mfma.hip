@@ -162,13 +162,29 @@ __global__ __launch_bounds__(kPipeBlock, WAVES) void k_run_mimo_ofdm_mfma(MimoPa
     const int k1p = 4 * w + (j >> 2), m2p = j & 3;   // P2 / P2': this lane's group (row k1p, residue m2p)
     // middle stage: lane -> butterfly (row k1m, j1m); lanes l and l ^ 1 hold time samples m and m + 1
     const int kkm = ((lane >> 5) << 1) | (lane & 1), j1m = (lane >> 1) & 15, k1m = 4 * w + kkm, par = lane & 1;
-    float2 tw1a[4], tw2a[4], tw1b[4], tw2b[3];
+    // FLAGS bit 2: the three sets of pass twiddles are fetched from the (L1-resident) table at the top of their pass
+    // instead of living in 24 registers across the whole loop (`opaque` keeps the loads from being hoisted)
+    constexpr bool kReloadTw = (FLAGS & 4) != 0;
+    auto load_tw1a = [&](float2 (&tw)[4], int n2_) {
 #pragma unroll
-    for (int x = 0; x < 4; ++x) {
-        tw1a[x] = g_tw[((4 * g + x) * n2) & 1023];                            // P1 : W1024^{k1 n2}
-        tw2a[x] = g_tw[(16 * (4 * g + x) * m2p) & 1023];                      // P2 : W64^{j1 m2} ...
-        if ((k1p & 1) && (m2p & 1)) tw2a[x] = make_float2(-tw2a[x].x, -tw2a[x].y);   // ... x the P3 slot order of odd rows
-        tw1b[x] = g_tw[((4 * (4 * g + x) + m2p) * k1p) & 1023];               // P2': W1024^{(4 m1 + m2) k1}
+        for (int x = 0; x < 4; ++x) tw[x] = g_tw[((4 * g + x) * n2_) & 1023];               // P1 : W1024^{k1 n2}
+    };
+    auto load_tw2a = [&](float2 (&tw)[4], int m2_) {
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            tw[x] = g_tw[(16 * (4 * g + x) * m2_) & 1023];                                  // P2 : W64^{j1 m2} ...
+            if ((k1p & 1) && (m2_ & 1)) tw[x] = make_float2(-tw[x].x, -tw[x].y);            // ... x the P3 slot order of odd rows
+        }
+    };
+    auto load_tw1b = [&](float2 (&tw)[4], int k1_) {
+#pragma unroll
+        for (int x = 0; x < 4; ++x) tw[x] = g_tw[((4 * (4 * g + x) + m2p) * k1_) & 1023];   // P2': W1024^{(4 m1 + m2) k1}
+    };
+    float2 tw1a[4], tw2a[4], tw1b[4], tw2b[3];
+    if constexpr (!kReloadTw) {
+        load_tw1a(tw1a, n2);
+        load_tw2a(tw2a, m2p);
+        load_tw1b(tw1b, k1p);
     }
 #pragma unroll
     for (int m2 = 1; m2 < 4; ++m2) {
@@ -271,6 +287,7 @@ __global__ __launch_bounds__(kPipeBlock, WAVES) void k_run_mimo_ofdm_mfma(MimoPa
                 yim[2 + cc][r] = dpp_swap1(give.y);
             };
             // ---- P1: DFT-16 over n1, x W1024^{k1 n2} ----
+            if constexpr (kReloadTw) load_tw1a(tw1a, opaque(n2));
             if constexpr ((FLAGS & 2) != 0) {
                 dft16_pass4(s_d, plane_g, mats, tw1a,
                             [&](int t) { return (p1_ld ^ (((2 * t) & 7) << 2)) + 128 * t; },
@@ -308,6 +325,7 @@ __global__ __launch_bounds__(kPipeBlock, WAVES) void k_run_mimo_ofdm_mfma(MimoPa
                            s_rec[(buf ^ 1) * (kRec + 1) + 2 * NA * NA].x != 0.f, rl_prev, sym_out, bit_out);
             }
             // ---- P2: DFT-16 over m1, x W64^{j1 m2} ----
+            if constexpr (kReloadTw) load_tw2a(tw2a, opaque(m2p));
             if constexpr ((FLAGS & 2) != 0) {
                 dft16_pass4(s_d, plane_g, mats, tw2a, [&](int t) { return p2_ld ^ (8 * t); },
                             [&](int x) { return p2_st ^ (4 * x); },
@@ -409,6 +427,7 @@ __global__ __launch_bounds__(kPipeBlock, WAVES) void k_run_mimo_ofdm_mfma(MimoPa
             }
             wave_lds_sync();
             // ---- P2': DFT-16 over j1, x W1024^{(4 m1 + m2) k1} ----
+            if constexpr (kReloadTw) load_tw1b(tw1b, opaque(k1p));
             if constexpr ((FLAGS & 2) != 0) {
                 dft16_pass4(s_d, plane_g, mats, tw1b, [&](int t) { return p2_ld ^ (8 * t); },
                             [&](int x) { return p2_st ^ (4 * x); }, [&]() {});
@@ -526,14 +545,15 @@ int run_mimo_ofdm_mfma(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, uint64_t se
     const size_t lds = (size_t)4 * kF16Ant * sizeof(float) + (size_t)(kMaxTable + 2 * 34) * sizeof(float2) +
                        kMaxTable * sizeof(float4) + 16 * sizeof(unsigned) +
                        (size_t)mp.grid.G * mp.grid.G * sizeof(unsigned long long) + (size_t)4 * cfg->num_used + 16;
-    // variants kept for A/B runs (MCLE_MFMA_VARIANT = 10 * waves + flags): 32 = 3 waves per SIMD, noise drawn in the
-    // middle stage, operand loads of the four antennas first (default; fastest with either demodulator);
-    // 30 = antenna-by-antenna passes; 21 = 2 waves per SIMD (256 VGPRs, no spills) with the noise under P1 / P2
-    int variant = 32;
+    // variants kept for A/B runs (MCLE_MFMA_VARIANT = 10 * waves + flags): 36 = 3 waves per SIMD, noise drawn in the
+    // middle stage, operand loads of the four antennas first, pass twiddles fetched per pass (default: 7 spilled
+    // registers, 1.535-1.544 ms per 65 536 realizations); 32 = the same with the twiddles resident (28 spilled, 1.555);
+    // 30 = antenna-by-antenna passes; 21 = 2 waves per SIMD (229 VGPRs, no spills) with the noise under P1 / P2 (1.62)
+    int variant = 36;
     if (const char* v = std::getenv("MCLE_MFMA_VARIANT")) variant = std::atoi(v);
     const int waves = variant / 10 == 2 ? 2 : 3;
     auto kern = variant == 30 ? k_run_mimo_ofdm_mfma<3, 0> : variant == 21 ? k_run_mimo_ofdm_mfma<2, 1>
-                                                             : k_run_mimo_ofdm_mfma<3, 2>;
+                : variant == 32 ? k_run_mimo_ofdm_mfma<3, 2> : k_run_mimo_ofdm_mfma<3, 6>;
     MCLE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int per_cu = (int)((size_t)160 * 1024 / (lds + 512));
     if (per_cu < 1) per_cu = 1;

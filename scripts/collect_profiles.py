@@ -28,8 +28,8 @@ dst = os.path.join(REPO, "profiles", rnd)
 os.makedirs(dst, exist_ok=True)
 
 CONFIGS = {
-    "c4": ("k_run_mimo_ofdm_mfma<", "k_run_mimo_ofdm_mfma<3,2> (f32, FFT 1024, 4x4), %d realizations per launch (bench.py default workload)"),
-    "c4md": ("k_run_mimo_ofdm_mfma<", "k_run_mimo_ofdm_mfma<3,2> with the min-distance demodulator over the LDS table (bench.py --demod mindist), %d realizations per launch"),
+    "c4": ("k_run_mimo_ofdm_mfma<", "k_run_mimo_ofdm_mfma<3,6> (f32, FFT 1024, 4x4), %d realizations per launch (bench.py default workload)"),
+    "c4md": ("k_run_mimo_ofdm_mfma<", "k_run_mimo_ofdm_mfma<3,6> with the min-distance demodulator over the LDS table (bench.py --demod mindist), %d realizations per launch"),
     "f1": ("k_run_mimo_ofdm_tdl<", "k_run_mimo_ofdm_tdl<float,1024,4>, %d realizations per launch (bench.py --config f1)"),
     "c3": ("k_run_ofdm_tdl_mfma<", "k_run_ofdm_tdl_mfma<3> (f32, FFT 1024, 4 realizations per pass), %d realizations per launch (bench.py --config c3)"),
     "c2": ("k_run_flat<", "k_run_flat<float,8>, %d realizations per launch (bench.py --config c2)"),

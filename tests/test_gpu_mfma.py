@@ -45,7 +45,7 @@ CASES = [dict(M=64, snr_db=25.0),
 
 
 @pytest.mark.parametrize("case", range(len(CASES)))
-@pytest.mark.parametrize("variant", [32, 30, 21])
+@pytest.mark.parametrize("variant", [36, 32, 30, 21])
 def test_mfma_kernel_against_the_oracle_and_the_valu_kernel(engine, case, variant):
     kw = dict(CASES[case])
     M = kw.pop("M")
