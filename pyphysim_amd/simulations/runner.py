@@ -227,6 +227,50 @@ class SimulationRunner:
         self._toc = time.time()
 
 
+    # ---- the reference's task-parallel mode (runner.py:1774-1886) -----------------------------------------------
+    def simulate_common_cleaning(self):
+        """runner.py:1621-1634."""
+        self._common_cleanup()
+
+    @staticmethod
+    def _simulate_for_current_params_parallel(obj, current_params, update_progress_func=None):
+        """runner.py:1541-1619: what one engine of the parallel view runs -> (reps, results, partial file name)."""
+        reps, res = obj._simulate_for_current_params(current_params)
+        name = obj._partial_name(current_params) if obj._results_filename is not None else None
+        return reps, res, name
+
+    def simulate_in_parallel(self, view=None, wait=True):
+        """runner.py:1774-1855: one parameter variation per engine of an ipyparallel-style `view` (anything with
+        `map(func, *iterables, block=False)` whose return value has `wait()` and `get()`).  Without a view the
+        reference starts a local ipyparallel cluster; here the variations then simply run one after the other through
+        `simulate()` -- on this engine the parallel axis is the realization index (a BatchedSimulationRunner shards
+        every variation over the ranks of its process group), not the parameter variation."""
+        if view is None:
+            self.simulate()
+            self._async_results = None
+            return
+        self._common_setup()
+        variations = self.params.get_unpacked_params_list()
+        self._async_results = view.map(SimulationRunner._simulate_for_current_params_parallel, [self] * len(variations),
+                                       variations, [None] * len(variations), block=False)
+        if wait:
+            self.wait_parallel_simulation()
+
+    def wait_parallel_simulation(self):
+        """runner.py:1857-1886."""
+        pending = getattr(self, "_async_results", None)
+        if pending is None:
+            return
+        pending.wait()
+        for reps, res, name in pending.get():
+            self._runned_reps.append(reps)
+            self._results.append_all_results(res)
+            if name is not None and name not in self._partial_files:
+                self._partial_files.append(name)
+        self.simulate_common_cleaning()
+        self._async_results = None
+
+
 class BatchedSimulationRunner(SimulationRunner):
     """Repetition loop in units of GPU batches.
 

@@ -474,3 +474,55 @@ def test_combine_and_split_workflows(tmp_path):
         part = SimulationResults.load_from_file(f)
         assert part["ser"][0].get_result() == g["ser"][i] and part.current_rep == u.runned_reps[i]
     assert get_partial_results_filename("base", unpacked[2], "dir") == os.path.join("dir", "base_unpack_2.pickle")
+
+
+class _FakeAsync:
+    def __init__(self, values):
+        self._values, self.waited = values, False
+
+    def wait(self):
+        self.waited = True
+
+    def get(self):
+        return self._values
+
+
+class _FakeView:
+    """An ipyparallel-style view: map(func, *iterables, block=False) -> object with wait() / get()."""
+
+    def __init__(self):
+        self.calls = 0
+
+    def map(self, func, *iterables, block=False):
+        assert block is False
+        out = []
+        for args in zip(*iterables):
+            self.calls += 1
+            out.append(func(*args))
+        return _FakeAsync(out)
+
+
+def test_simulate_in_parallel_mirrors_the_task_parallel_mode(tmp_path):
+    """runner.py:1774-1886: one variation per engine of the view, results appended in variation order; without a view
+    the variations run through simulate()."""
+    serial = _Dummy()
+    serial.simulate()
+    view = _FakeView()
+    par = _Dummy()
+    par.set_results_filename(str(tmp_path / "par"))
+    par.simulate_in_parallel(view)
+    assert view.calls == par.params.get_num_unpacked_variations()
+    assert par.runned_reps == serial.runned_reps
+    for name in serial.results.get_result_names():
+        if name != "elapsed_time":
+            assert [r.to_dict() for r in par.results[name]] == [r.to_dict() for r in serial.results[name]]
+    assert (tmp_path / "par.pickle").exists()
+    par.wait_parallel_simulation()                      # a second call is a no-op
+    lazy = _Dummy()
+    lazy.simulate_in_parallel(_FakeView(), wait=False)
+    assert lazy.runned_reps == []
+    lazy.wait_parallel_simulation()
+    assert lazy.runned_reps == serial.runned_reps
+    plain = _Dummy()
+    plain.simulate_in_parallel()
+    assert plain.runned_reps == serial.runned_reps
