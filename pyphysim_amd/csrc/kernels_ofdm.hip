@@ -205,6 +205,11 @@ __global__ __launch_bounds__(kOfdmBlock) void k_onetap_eq(const cx<T>* __restric
     }
 }
 
+int ofdm_mod_1024_mfma(mcle_ctx* ctx, const void* d_in, size_t n_in, int cp, int num_used, int n_sym, double scale,
+                       void* d_out, size_t batch);          // kernels_ofdm_mfma.hip
+int ofdm_demod_1024_mfma(mcle_ctx* ctx, const void* d_in, int cp, int num_used, int n_sym, double scale, void* d_out,
+                         size_t batch);
+
 int check_ofdm(const mcle_ctx* ctx, int dtype, int fft_size, int cp_size, int num_used) {
     MCLE_REQUIRE(ctx != nullptr, "null context");
     MCLE_REQUIRE(dtype == MCLE_F32 || dtype == MCLE_F64, "dtype must be MCLE_F32 or MCLE_F64");
@@ -315,6 +320,10 @@ int mcle_ofdm_modulate(mcle_ctx* ctx, int dtype, const void* d_in, size_t n_in, 
                    ? launch_mod_any<float>(ctx, d_in, n_in, fft_size, cp_size, num_used, n_sym, scale, tw, d_out, batch)
                    : launch_mod_any<double>(ctx, d_in, n_in, fft_size, cp_size, num_used, n_sym, scale, tw, d_out,
                                             batch);
+    if (dtype == MCLE_F32 && fft_size == 1024) {   // complex64, 1024 points: the matrix-core transform (kernels_ofdm_mfma.hip)
+        rc = ofdm_mod_1024_mfma(ctx, d_in, n_in, cp_size, num_used, n_sym, scale, d_out, batch);
+        if (rc != MCLE_E_UNSUPPORTED) return rc;
+    }
     if (dtype == MCLE_F32) {
         MCLE_FFT_SWITCH(fft_size, rc = (launch_mod<float, NN>(ctx, d_in, n_in, cp_size, num_used, n_sym, scale, tw,
                                                                d_out, batch)));
@@ -340,6 +349,10 @@ int mcle_ofdm_demodulate(mcle_ctx* ctx, int dtype, const void* d_in, size_t n_sy
                                                            tw, d_out, batch)
                                  : launch_demod_any<double>(ctx, d_in, fft_size, cp_size, num_used, (int)n_sym, scale,
                                                             tw, d_out, batch);
+    if (dtype == MCLE_F32 && fft_size == 1024) {
+        rc = ofdm_demod_1024_mfma(ctx, d_in, cp_size, num_used, (int)n_sym, scale, d_out, batch);
+        if (rc != MCLE_E_UNSUPPORTED) return rc;
+    }
     if (dtype == MCLE_F32) {
         MCLE_FFT_SWITCH(fft_size, rc = (launch_demod<float, NN>(ctx, d_in, cp_size, num_used, (int)n_sym, scale, tw,
                                                                  d_out, batch)));

@@ -787,3 +787,26 @@ def test_generate_jakes_samples_function_and_concatenate(engine):
     assert channels.TdlImpulseResponse.concatenate_samples([a]) is a
     with pytest.raises(ValueError):
         channels.TdlImpulseResponse.concatenate_samples([])
+
+
+def test_ofdm_1024_complex64_matrix_core_kernels(engine):
+    """kernels_ofdm_mfma.hip: batches, a zero-padded last symbol, symbol counts that are not a multiple of the four
+    symbols of a pass, partial bands, odd CP -- against the oracle, and against the radix-4 kernels it replaces."""
+    import os
+    rs = np.random.RandomState(21)
+    for batch, n_sym_in, cp, used in ((1, 1, 16, 1024), (3, 5, 16, 1024), (2, 7, 73, 600), (5, 2, 0, 1022), (1, 9, 1024, 2)):
+        n_in = n_sym_in * used - (used // 3 if n_sym_in > 1 else 0)          # the last symbol is zero padded
+        x = (rs.randn(batch, n_in) + 1j * rs.randn(batch, n_in)).astype(np.complex64)
+        tx = engine.ofdm_modulate(x, 1024, cp, used, batch=batch, dtype="f32")
+        want = np.stack([oofdm.modulate(x[b].astype(complex), 1024, cp, used) for b in range(batch)])
+        assert tx.shape == want.shape and relerr(tx, want) <= 2e-6, (batch, n_sym_in, cp, used, relerr(tx, want))
+        back = engine.ofdm_demodulate(want, 1024, cp, used, batch=batch, dtype="f32")
+        wantb = np.stack([oofdm.demodulate(want[b], 1024, cp, used) for b in range(batch)])
+        assert back.shape == wantb.shape and relerr(back, wantb) <= 2e-6
+        os.environ["MCLE_NO_MFMA"] = "1"
+        try:
+            tx_v = engine.ofdm_modulate(x, 1024, cp, used, batch=batch, dtype="f32")
+            back_v = engine.ofdm_demodulate(want, 1024, cp, used, batch=batch, dtype="f32")
+        finally:
+            os.environ.pop("MCLE_NO_MFMA", None)
+        assert relerr(tx, tx_v) <= 2e-6 and relerr(back, back_v) <= 2e-6
