@@ -45,7 +45,7 @@ __device__ __forceinline__ OmGeom om_geom(int tid) {
 }
 
 // in [batch][n_in] complex64 (zero padded to whole OFDM symbols) -> out [batch][n_sym * (1024 + cp)]
-__global__ __launch_bounds__(kOmBlock) void k_ofdm_mod_1024_mfma(const float2* __restrict__ in, size_t n_in, int cp,
+__global__ __launch_bounds__(kOmBlock, 4) void k_ofdm_mod_1024_mfma(const float2* __restrict__ in, size_t n_in, int cp,
                                                                  int num_used, int n_sym, size_t n_total_sym, float scale,
                                                                  const float2* __restrict__ g_tw, float2* __restrict__ out) {
     constexpr int N = kF16N;
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(kOmBlock) void k_ofdm_mod_1024_mfma(const float2* _
 }
 
 // in [batch][n_sym * (1024 + cp)] -> out [batch][n_sym * num_used]
-__global__ __launch_bounds__(kOmBlock) void k_ofdm_demod_1024_mfma(const float2* __restrict__ in, int cp, int num_used,
+__global__ __launch_bounds__(kOmBlock, 4) void k_ofdm_demod_1024_mfma(const float2* __restrict__ in, int cp, int num_used,
                                                                    size_t n_total_sym, float scale,
                                                                    const float2* __restrict__ g_tw,
                                                                    float2* __restrict__ out) {
