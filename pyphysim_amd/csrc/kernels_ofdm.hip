@@ -24,8 +24,20 @@ __global__ __launch_bounds__(kOfdmBlock) void k_ofdm_mod(const cx<T>* __restrict
         __syncthreads();
         const cx<T>* src = in + row * n_in + (size_t)sym * num_used;
         const size_t left = n_in > (size_t)sym * num_used ? n_in - (size_t)sym * num_used : 0;  // zero padding
-        for (int d = threadIdx.x; d < num_used; d += kOfdmBlock)
-            if ((size_t)d < left) s[lds_swz<true>(fft_pos_of_index<N>(ofdm_bin(d, N, num_used)))] = src[d];
+        {   // every global load of the symbol in flight before the first LDS store (one latency instead of PER)
+            constexpr int PER = (N + kOfdmBlock - 1) / kOfdmBlock;
+            cx<T> v[PER];
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const int d = threadIdx.x + kOfdmBlock * i;
+                v[i] = (d < num_used && (size_t)d < left) ? src[d] : mk<T>(0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const int d = threadIdx.x + kOfdmBlock * i;
+                if (d < num_used && (size_t)d < left) s[lds_swz<true>(fft_pos_of_index<N>(ofdm_bin(d, N, num_used)))] = v[i];
+            }
+        }
         __syncthreads();
         fft_dit<T, N, true, kOfdmBlock, true>(s, 1, N, s_tw);
         cx<T>* dst = out + (row * n_sym + sym) * (size_t)(N + cp);
@@ -49,7 +61,20 @@ __global__ __launch_bounds__(kOfdmBlock) void k_ofdm_demod(const cx<T>* __restri
     for (int k = threadIdx.x; k < N; k += kOfdmBlock) s_tw[k] = tw[k];
     for (int sym = blockIdx.x; sym < n_sym; sym += gridDim.x) {
         const cx<T>* src = in + (row * n_sym + sym) * (size_t)(N + cp) + cp;
-        for (int n = threadIdx.x; n < N; n += kOfdmBlock) s[lds_swz<true>(n)] = src[n];
+        {
+            constexpr int PER = (N + kOfdmBlock - 1) / kOfdmBlock;
+            cx<T> v[PER];
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const int n = threadIdx.x + kOfdmBlock * i;
+                v[i] = n < N ? src[n] : mk<T>(0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const int n = threadIdx.x + kOfdmBlock * i;
+                if (n < N) s[lds_swz<true>(n)] = v[i];
+            }
+        }
         __syncthreads();
         fft_dif<T, N, false, kOfdmBlock, true>(s, 1, N, s_tw);
         cx<T>* dst = out + (row * n_sym + sym) * (size_t)num_used;
