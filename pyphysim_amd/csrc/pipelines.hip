@@ -90,6 +90,15 @@ struct FlatParams {
 // a lane's 16 consecutive symbols and advanced by one complex rotation per symbol after that
 // (e^{j 2 pi w_l dt}, rounded once from f64); 15 rotations add < 1e-6 of phase error, below the
 // v_sin/v_cos error.  LR == 0: every sample evaluated from the closed form (any L, and f64).
+// (h s + z) / h, the flat-fading link followed by its one-tap equaliser (singleuser.py:130-151 and the notebooks' `/ h`).
+// f64 (parity instantiation): literally that.  f32: s + z conj(h) / |h|^2 with one v_rcp_f32 -- the same value to
+// rounding, 11 instructions instead of 34 (the two IEEE divisions of cdivide expand to ten instructions each).
+__device__ __forceinline__ double2 flat_equalised(double2 h, double2 s, double2 z) { return cdivide(cadd(cmul(h, s), z), h); }
+__device__ __forceinline__ float2 flat_equalised(float2 h, float2 s, float2 z) {
+    const float inv = __builtin_amdgcn_rcpf(fmaf(h.x, h.x, h.y * h.y));
+    return make_float2(fmaf(fmaf(z.x, h.x, z.y * h.y), inv, s.x), fmaf(fmaf(z.y, h.x, -(z.x * h.y)), inv, s.y));
+}
+
 template <typename T, int LR>
 __global__ __launch_bounds__(kPipeBlock) void k_run_flat(FlatParams fp, ModemParams<T> mp, uint64_t seed,
                                                          uint64_t first, uint64_t count, unsigned* __restrict__ ws) {
@@ -170,7 +179,7 @@ __global__ __launch_bounds__(kPipeBlock) void k_run_flat(FlatParams fp, ModemPar
                                 ray[l] = cmul(ray[l], rot[l]);
                             }
                             const cx<T> h = mk<T>((T)(amp * hr), (T)(amp * hi));
-                            r = cdivide(cadd(cmul(h, s), z[e]), h);
+                            r = flat_equalised(h, s, z[e]);
                         } else if (fp.L > 0) {
                             const double t = jakes_time(fp.t0, fp.dt, (double)n);
                             T hr = 0, hi = 0;
@@ -180,10 +189,10 @@ __global__ __launch_bounds__(kPipeBlock) void k_run_flat(FlatParams fp, ModemPar
                                 hi += rr.y;
                             }
                             const cx<T> h = mk<T>(amp * hr, amp * hi);
-                            r = cdivide(cadd(cmul(h, s), z[e]), h);
+                            r = flat_equalised(h, s, z[e]);
                         } else if (fp.rayleigh_iid) {
                             const cx<T> h = cn_sample<T>(rng, STREAM_CHAN, (uint64_t)n, (T)1);
-                            r = cdivide(cadd(cmul(h, s), z[e]), h);
+                            r = flat_equalised(h, s, z[e]);
                         } else {
                             r = cadd(s, z[e]);
                         }
