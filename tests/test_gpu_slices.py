@@ -38,3 +38,12 @@ def test_flat_mimo_pipeline_across_the_slice_boundary(engine):
                                                     method=_lib.DEMOD_QAM_SLICER, dtype="f32", per_realization=True)
     cut = 1 << 20
     _same(run(50, N), run(50, cut), run(50 + cut, N - cut))
+
+
+def test_mimo_ofdm_pipeline_across_its_slice_boundary(engine):
+    """Config 4's matrix-core kernel reads its filter records in slices of 2^18 realizations."""
+    engine.set_constellation(chains.constellation("qam", 64), _lib.CONST_QAM)
+    run = lambda first, count: engine.run_mimo_ofdm(4, 4, 1024, 16, 1024, 1, 0.003, 17, first, count, mmse=True,
+                                                    method=_lib.DEMOD_QAM_SLICER, dtype="f32", per_realization=True)
+    n, cut = (1 << 18) + 301, (1 << 18) - 2
+    _same(run(9, n), run(9, cut), run(9 + cut, n - cut))
