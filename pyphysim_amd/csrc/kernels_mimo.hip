@@ -143,6 +143,32 @@ __global__ __launch_bounds__(kMimoBlock) void k_mimo_channel(const cx<T>* __rest
             return;
         }
     }
+    if (nr == 4 && nt == 4) {   // H in registers, every column of X read once (the loop below reads it once per output row)
+        cx<T> Hr[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int a = 0; a < 4; ++a) Hr[r][a] = Hb[r * 4 + a];
+        for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < ns; c += (size_t)gridDim.x * blockDim.x) {
+            cx<T> x[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) x[a] = Xb[(size_t)a * ns + c];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                cx<T> acc = mk<T>(0, 0);
+#pragma unroll
+                for (int a = 0; a < 4; ++a) acc = cfma(Hr[r][a], x[a], acc);
+                const size_t o = (b * 4 + r) * ns + c;
+                if (nz) {
+                    const cx<T> w = nz[o];
+                    acc.x += sigma * w.x;
+                    acc.y += sigma * w.y;
+                }
+                Y[o] = acc;
+            }
+        }
+        return;
+    }
     for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < ns; c += (size_t)gridDim.x * blockDim.x) {
         for (int r = 0; r < nr; ++r) {
             cx<T> acc = mk<T>(0, 0);

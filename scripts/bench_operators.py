@@ -14,9 +14,11 @@ from pyphysim_amd import _lib  # noqa: E402
 from pyphysim_amd.engine import Engine  # noqa: E402
 from pyphysim_amd.modulators import constellation  # noqa: E402
 
-eng = Engine(0, "f32")
+DT = "f64" if "--dtype=f64" in sys.argv or os.environ.get("BENCH_OPS_DTYPE") == "f64" else "f32"
+CB = 16 if DT == "f64" else 8     # bytes per complex sample
+eng = Engine(0, DT)
 eng.set_constellation(constellation("qam", 64), _lib.CONST_QAM)
-N = 1 << 26                       # 64 Mi symbols: 512 MiB of complex64, past the 256 MiB Infinity Cache
+N = (1 << 25) if DT == "f64" else (1 << 26)   # 512 MiB of samples either way, past the 256 MiB Infinity Cache
 REP = 5
 rows = []
 
@@ -37,25 +39,25 @@ tx = eng.modulate(idx)
 noise = eng.randn_c(N, 1, 2, device=True)
 rx = eng.awgn_add(tx, noise, 0.01)
 cnt = eng.new_counters()          # device-resident: the counting kernels are timed without a read-back
-timed("modulate (4 B idx -> 8 B sample)", lambda: eng.modulate(idx), N * 12)
-timed("awgn_add (8+8 -> 8)", lambda: eng.awgn_add(tx, noise, 0.01), N * 24)
-timed("demodulate slicer (8 -> 4)", lambda: eng.demodulate(rx, method=_lib.DEMOD_QAM_SLICER), N * 12)
-timed("demodulate mindist M=64 (8 -> 4)", lambda: eng.demodulate(rx), N * 12)
-timed("demod_count slicer (8 + 4 -> counters)", lambda: eng.demod_count(rx, idx, n_real=1024, method=_lib.DEMOD_QAM_SLICER, counters=cnt), N * 12)
+timed("modulate (4 B idx -> 8 B sample)", lambda: eng.modulate(idx), N * (4 + CB))
+timed("awgn_add (8+8 -> 8)", lambda: eng.awgn_add(tx, noise, 0.01), N * 3 * CB)
+timed("demodulate slicer (8 -> 4)", lambda: eng.demodulate(rx, method=_lib.DEMOD_QAM_SLICER), N * (4 + CB))
+timed("demodulate mindist M=64 (8 -> 4)", lambda: eng.demodulate(rx), N * (4 + CB))
+timed("demod_count slicer (8 + 4 -> counters)", lambda: eng.demod_count(rx, idx, n_real=1024, method=_lib.DEMOD_QAM_SLICER, counters=cnt), N * (4 + CB))
 dec = eng.demodulate(rx, method=_lib.DEMOD_QAM_SLICER)
 timed("count_errors (4 + 4 -> counters)", lambda: eng.count_errors(idx, dec, 6, n_real=1024, counters=cnt), N * 8)
-timed("cdiv (8+8 -> 8)", lambda: eng.cdiv(rx, tx), N * 24)
-timed("randn_c Philox (-> 8)", lambda: eng.randn_c(N, 1, 2, device=True), N * 8)
+timed("cdiv (8+8 -> 8)", lambda: eng.cdiv(rx, tx), N * 3 * CB)
+timed("randn_c Philox (-> 8)", lambda: eng.randn_c(N, 1, 2, device=True), N * CB)
 nsym = N // 1024
-timed("ofdm_modulate 1024+16 (8 -> 8.1)", lambda: eng.ofdm_modulate(tx, 1024, 16, 1024), N * 8 + nsym * 1040 * 8)
+timed("ofdm_modulate 1024+16 (8 -> 8.1)", lambda: eng.ofdm_modulate(tx, 1024, 16, 1024), N * CB + nsym * 1040 * CB)
 t = eng.ofdm_modulate(tx, 1024, 16, 1024)
-timed("ofdm_demodulate 1024+16", lambda: eng.ofdm_demodulate(t, 1024, 16, 1024), N * 8 + nsym * 1040 * 8)
+timed("ofdm_demodulate 1024+16", lambda: eng.ofdm_demodulate(t, 1024, 16, 1024), N * CB + nsym * 1040 * CB)
 b = 4096
 ns = N // (4 * b)
 X = tx.reshape(b, 4, ns)
 H = eng.randn_c(b * 16, 3, 4, device=True).reshape(b, 4, 4)
-timed("mimo_channel 4x4 (H X)", lambda: eng.mimo_channel(H, X), b * 4 * ns * 16)
+timed("mimo_channel 4x4 (H X)", lambda: eng.mimo_channel(H, X), b * 4 * ns * 2 * CB)
 G, _ = eng.blast_filter(H, 0.01)
-timed("blast_decode 4x4 (G Y)", lambda: eng.blast_decode(G, X), b * 4 * ns * 16)
-timed("blast_encode (transpose)", lambda: eng.blast_encode(tx, 4, batch=b), N * 16)
-print(json.dumps({"device": eng.device_name, "n_symbols": N, "rows": rows}, indent=1))
+timed("blast_decode 4x4 (G Y)", lambda: eng.blast_decode(G, X), b * 4 * ns * 2 * CB)
+timed("blast_encode (transpose)", lambda: eng.blast_encode(tx, 4, batch=b), N * 2 * CB)
+print(json.dumps({"device": eng.device_name, "dtype": DT, "bytes_per_sample": CB, "n_symbols": N, "rows": rows}, indent=1))
