@@ -25,7 +25,7 @@ template <> ModemParams<float> modem_params<float>(const mcle_ctx* ctx, int meth
 }
 template <> ModemParams<double> modem_params<double>(const mcle_ctx* ctx, int method) {
     ModemParams<double> p;
-    p.grid = context_grid<double>(ctx, method);
+    p.grid = context_grid<double>(ctx, method, true);
     p.g_table = ctx->d_table_f64;
     p.M = ctx->M;
     p.bits = ctx->bits;
@@ -78,9 +78,9 @@ template <typename T>
 __global__ __launch_bounds__(kBlock) void k_demodulate(ModemParams<T> mp, const cx<T>* __restrict__ rx,
                                                        int32_t* __restrict__ idx, size_t n, int vec) {
     __shared__ cx<T> s_table[kMaxM];
-    __shared__ unsigned long long s_grid[sizeof(T) == 4 ? kMaxGridCells : 1];
+    __shared__ unsigned long long s_grid[kMaxGridCells];
     load_table(mp, s_table);
-    if (sizeof(T) == 4) load_grid(mp, s_grid);
+    load_grid(mp, s_grid);
     __syncthreads();
     const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
     if constexpr (sizeof(T) == 4) {
@@ -106,11 +106,11 @@ __global__ __launch_bounds__(kBlock) void k_count(ModemParams<T> mp, const cx<T>
                                                   const int32_t* __restrict__ a, const int32_t* __restrict__ b,
                                                   size_t n_per_real, size_t n_real, unsigned* __restrict__ ws) {
     __shared__ cx<T> s_table[DEMOD ? kMaxM : 1];
-    __shared__ unsigned long long s_grid[DEMOD && sizeof(T) == 4 ? kMaxGridCells : 1];
+    __shared__ unsigned long long s_grid[DEMOD ? kMaxGridCells : 1];
     __shared__ unsigned s_part[2 * (kBlock / 64)];
     if (DEMOD) {
         load_table(mp, s_table);
-        if (sizeof(T) == 4) load_grid(mp, s_grid);
+        load_grid(mp, s_grid);
         __syncthreads();
     }
     for (size_t r = blockIdx.y; r < n_real; r += gridDim.y) {

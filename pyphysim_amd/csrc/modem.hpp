@@ -119,6 +119,34 @@ __device__ __forceinline__ int demod_grid(const float2* __restrict__ s_table, co
     }
     return idx;
 }
+// complex128 operator kernels: the cell is looked up from the float-rounded point (the lists carry a margin far above
+// f32 rounding, so a point a rounding step across a cell edge still finds its nearest neighbour and every near-tie in
+// the list), the metric is the literal f64 |c - r|^2 of demod_mindist<double>: same decisions, first minimum included
+__device__ __forceinline__ int demod_grid(const double2* __restrict__ s_table, const unsigned long long* __restrict__ s_grid,
+                                          const DemodGrid& g, int M, double2 r) {
+    unsigned long long w = grid_cell(s_grid, g, (float)r.x, (float)r.y);
+    const int n = (int)(w & 0xFFull);
+    if (n == 0xFF) return demod_mindist<double>(s_table, M, r);
+    w >>= 8;
+    int idx = (int)(w & 0xFFull);
+    double best;
+    {
+        const double2 c = s_table[idx];
+        best = (r.x - c.x) * (r.x - c.x) + (r.y - c.y) * (r.y - c.y);
+    }
+    for (int j = 1; j < n; ++j) {
+        w >>= 8;
+        const int m = (int)(w & 0xFFull);
+        const double2 c = s_table[m];
+        const double dx = r.x - c.x, dy = r.y - c.y;
+        const double d = dx * dx + dy * dy;
+        if (d < best) {
+            best = d;
+            idx = m;
+        }
+    }
+    return idx;
+}
 // two-FMA metric on the {re, im, |c|^2/2} table (fused pipelines); same decisions as demod_mindist_multi<float>
 __device__ __forceinline__ int demod_grid4(const float4* __restrict__ s_tab4, const unsigned long long* __restrict__ s_grid,
                                            const DemodGrid& g, int M, float2 r) {
@@ -231,17 +259,16 @@ template <typename T>
 __device__ __forceinline__ int demod_one(const ModemParams<T>& mp, const cx<T>* s_table,
                                          const unsigned long long* s_grid, cx<T> r) {
     if (mp.method == MCLE_DEMOD_QAM_SLICER) return demod_qam_slicer<T>(r, mp.qam_scale, mp.qam_L, mp.half_bits);
-    if constexpr (sizeof(T) == 4) {
-        if (mp.grid.G > 0) return demod_grid(s_table, s_grid, mp.grid, mp.M, r);
-    }
+    if (mp.grid.G > 0) return demod_grid(s_table, s_grid, mp.grid, mp.M, r);   // G == 0: no grid bound to this launch
     return demod_mindist<T>(s_table, mp.M, r);
 }
 
-// host: candidate grid of the context for the f32 instantiation, none for f64 (parity path sweeps everything)
-template <typename T> inline DemodGrid context_grid(const mcle_ctx* ctx, int method = MCLE_DEMOD_MINDIST) {
+// host: candidate grid of the context for the f32 instantiation; for f64 only where the caller asks for it (the operator
+// kernels: same decisions as the sweep at a fifth of the cost; the fused f64 parity pipelines sweep everything)
+template <typename T> inline DemodGrid context_grid(const mcle_ctx* ctx, int method = MCLE_DEMOD_MINDIST, bool f64_too = false) {
     DemodGrid g;
     g.cells = ctx->d_grid;
-    g.G = (sizeof(T) == 4 && ctx->d_grid != nullptr && method == MCLE_DEMOD_MINDIST) ? ctx->grid_G : 0;   // the slicer needs none
+    g.G = ((sizeof(T) == 4 || f64_too) && ctx->d_grid != nullptr && method == MCLE_DEMOD_MINDIST) ? ctx->grid_G : 0;   // the slicer needs none
     g.x0 = ctx->grid_x0;
     g.y0 = ctx->grid_y0;
     g.inv_h = ctx->grid_inv_h;

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from helpers import golden_cases, relerr
-from oracle import channels as och, modem as omodem, ofdm as oofdm, philox as P
+from oracle import chains, channels as och, modem as omodem, ofdm as oofdm, philox as P
 from pyphysim_amd import _lib
 
 pytestmark = pytest.mark.gpu
@@ -810,3 +810,33 @@ def test_ofdm_1024_complex64_matrix_core_kernels(engine):
         finally:
             os.environ.pop("MCLE_NO_MFMA", None)
         assert relerr(tx, tx_v) <= 2e-6 and relerr(back, back_v) <= 2e-6
+
+
+@pytest.mark.parametrize("mod,M", [("qam", 16), ("qam", 64), ("qam", 256), ("psk", 8), ("psk", 16), ("qpsk", 4)])
+def test_complex128_pruned_search_equals_the_sweep_on_ties_and_edges(engine, mod, M):
+    """The complex128 demodulator runs the candidate-grid search too (round 2): the nearest constellation point on noise,
+    on exact midpoints between constellation points (ties), on far outliers and on points a rounding step either side of
+    the grid's cell edges."""
+    table = chains.constellation(mod, M)
+    kind = _lib.CONST_QAM if mod == "qam" else _lib.CONST_GENERIC
+    engine.set_constellation(table, kind)
+    rs = np.random.RandomState(M)
+    pts = [0.7 * (rs.randn(20000) + 1j * rs.randn(20000))]
+    mid = 0.5 * (table[:, None] + table[None, :]).ravel()
+    pts += [mid, mid * (1 + 1e-16), mid + 1e-9, 30.0 * (rs.randn(500) + 1j * rs.randn(500))]
+    edges = np.linspace(-2.0, 2.0, 129)
+    ex, ey = np.meshgrid(edges, edges[::7])
+    pts += [(ex + 1j * ey).ravel(), np.nextafter(ex, 9.0).ravel() + 1j * np.nextafter(ey, -9.0).ravel()]
+    r = np.concatenate(pts)
+    d = np.abs(table[None, :] - r[:, None]) ** 2
+    want = np.argmin(d, axis=1)
+    got = engine.demodulate(r, dtype="f64")
+    # away from exact ties the decision is the sweep's; ON a tie (the midpoints) which of the equidistant points wins
+    # depends on the last bit of the metric -- hypot in NumPy, dx*dx + dy*dy (possibly fused) on the device -- so there
+    # the chosen point only has to be one of the nearest
+    rows = np.arange(r.size)
+    gap = d[rows, got] - d[rows, want]
+    assert np.all(gap <= 1e-12 * (1.0 + d[rows, want]))
+    clear = np.partition(d, 1, axis=1)
+    clear = (clear[:, 1] - clear[:, 0]) > 1e-9 * (1.0 + clear[:, 0])
+    assert np.array_equal(got[clear], want[clear]) and clear.sum() > 20000
