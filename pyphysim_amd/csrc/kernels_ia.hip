@@ -122,8 +122,10 @@ __device__ __forceinline__ void ia_candidate(const M2 (&H)[3][3], const M2& invH
     }
 }
 
-// not inlined: one compiled body serves the operator kernel and both instantiations of the pipeline
-__device__ __noinline__ IaSolution ia_closed_form(const M2 (&H)[3][3], double nv) {
+// ia_closed_form: not inlined, one compiled body serves the operator kernel and the iterative solver's 'closed_form'
+// start.  The pipeline's solve kernel inlines the same body (ia_closed_form_inl): behind a call, H and the solution
+// live in scratch (1.3 KB per lane), inlined they stay in registers.
+__device__ __forceinline__ IaSolution ia_closed_form_inl(const M2 (&H)[3][3], double nv) {
     bool ok = true;
     const M2 i31 = minv(H[2][0], ok), i12 = minv(H[0][1], ok), i23 = minv(H[1][2], ok), i32 = minv(H[2][1], ok);
     // E = H31^-1 H32 . (H12^-1 H13 . (H23^-1 H21))
@@ -141,6 +143,7 @@ __device__ __noinline__ IaSolution ia_closed_form(const M2 (&H)[3][3], double nv
     s.ok = ok && (s.capacity == s.capacity);
     return s;
 }
+__device__ __noinline__ IaSolution ia_closed_form(const M2 (&H)[3][3], double nv) { return ia_closed_form_inl(H, nv); }
 
 // ---- iterative solvers on the same 2x2 / one-stream geometry ----------------------
 // Reference: ia/algorithms.py:802-883 (solve loop, _is_diff_significant :755-800), :1010-1129 (alternating
@@ -512,7 +515,7 @@ __global__ __launch_bounds__(64) void k_ia_solve_links(double noise_var, int sol
     IaSolution s;
     int runned = 0;
     if (solver == IA_CLOSED_FORM) {
-        s = ia_closed_form(H, noise_var);
+        s = ia_closed_form_inl(H, noise_var);
     } else {
         // randomizeF (iabase.py:538-540): F_k = normalized(randn_c(Nt, Ns)) from the solver's own stream
         V2 F0[3];
