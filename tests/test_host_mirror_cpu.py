@@ -233,3 +233,17 @@ def test_mimo_base_surface():
     for name in ("encode", "decode"):
         with pytest.raises(NotImplementedError):
             getattr(mimo.MimoBase, name)(b, None)
+
+
+def test_multiuser_pathloss_block_matrix_known_answer():
+    """MultiUserChannelMatrix._from_small_matrix_to_big_matrix: the reference's own docstring example
+    (channels/multiuser.py:902-919)."""
+    from pyphysim_amd.multiuser import MultiUserChannelMatrix
+    big = MultiUserChannelMatrix._from_small_matrix_to_big_matrix(np.array([[1, 2, 3], [4, 5, 6], [7, 8, 9]]),
+                                                                  np.array([2, 4, 6]), np.array([2, 3, 5]), 3)
+    assert big.shape == (12, 10)
+    assert list(big[0]) == [1, 1, 2, 2, 2, 3, 3, 3, 3, 3] and list(big[2]) == [4, 4, 5, 5, 5, 6, 6, 6, 6, 6]
+    assert list(big[-1]) == [7, 7, 8, 8, 8, 9, 9, 9, 9, 9] and np.array_equal(big[6], big[11])
+    # K x (K + external sources): the ExtInt form
+    big = MultiUserChannelMatrix._from_small_matrix_to_big_matrix(np.arange(6).reshape(2, 3), [1, 2], [2, 1, 3], 2, 3)
+    assert big.shape == (3, 6) and list(big[0]) == [0, 0, 1, 2, 2, 2] and list(big[2]) == [3, 3, 4, 5, 5, 5]
