@@ -89,6 +89,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--preroll-ms", type=float, default=250.0,
+                    help="untimed launches (a disjoint index range) before the W warm-up steps until this much wall time "
+                         "has passed: a fresh GPU needs ~0.2 s of work to reach its clocks (first launches of a run were "
+                         "measured 7 %% slower); 0 disables")
     ap.add_argument("--config", default="c4", choices=["c2", "c3", "c4", "c5", "f1", "f6"])
     ap.add_argument("--batch", type=int, default=0, help="realizations per GPU per step")
     ap.add_argument("--single-demod", action="store_true",
@@ -325,7 +329,7 @@ def collect_pmc_live(args, batch):
         cmd = [exe, "--pmc"] + names.split() + ["--output-format", "csv", "-d", out_dir, "-o", "pmc", "--",
                                                  sys.executable, os.path.abspath(__file__), "--config", args.config,
                                                  "--demod", args.demod, "--dtype", args.dtype, "--batch", str(batch),
-                                                 "--steps", "3", "--warmup", "1", "--no-cpu", "--pmc", "off", "--single-demod"]
+                                                 "--steps", "3", "--warmup", "1", "--no-cpu", "--pmc", "off", "--single-demod", "--preroll-ms", "0"]
         try:
             subprocess.run(cmd, cwd="/tmp", env=env, timeout=180, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
             counters.update(_parse_pmc_csv(out_dir, KERNEL[args.config]))
@@ -464,6 +468,12 @@ def main():
         kernel ms max over ranks, reduced counter totals, workload description, units per realization)."""
         run, units, workload = make_runner(eng, args.config, demod, args.dtype)
         counters = eng.new_counters()
+        if args.preroll_ms > 0:               # clock ramp: untimed, results discarded, indices far from everything else
+            t_pre, i_pre = time.perf_counter(), 0
+            while (time.perf_counter() - t_pre) * 1e3 < args.preroll_ms:
+                run((1 << 41) + base + (i_pre * world + rank) * batch, batch, counters)
+                eng.sync()
+                i_pre += 1
         for w in range(args.warmup):          # warm-up draws from a disjoint index range far away
             run((1 << 40) + base + (w * world + rank) * batch, batch, counters)
         if use_dist:   # bring the communicator up outside the timed region (same shape / dtype as the real exchange)
@@ -522,6 +532,7 @@ def main():
         out = {
             "metric": "Monte Carlo realizations/sec (whole node) + SER abs-error vs ref",
             "value": value, "unit": "realizations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "preroll_ms": args.preroll_ms,
             "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": workload, "realizations_per_step_per_gpu": batch,
