@@ -145,3 +145,53 @@ def test_fuzz_chunked_pipelines(engine, dt, trial):
     want = _oracle(chains.chain_bd, first, count, canonical=True, **kw)
     _check(*engine.run_bd(K, r, NS, kw["iPu"], nv, SEED, first, count, bd_noise_var=kw["bd_noise_var"],
                           waterfilling=kw["waterfill"], dtype=dt, per_realization=True), want, dt, ("bd", kw))
+
+
+import os  # noqa: E402
+
+N_MFMA_TRIALS = int(os.environ.get("MCLE_FUZZ_TRIALS", "10"))
+
+
+@pytest.mark.parametrize("trial", range(N_MFMA_TRIALS))
+def test_fuzz_matrix_core_kernels(engine, trial):
+    """f32, FFT 1024: the matrix-core kernels of configs 3 and 4 (and, through them, fft16.hpp) on random CP lengths,
+    band widths, symbol counts, tap sets and realization offsets -- against the oracle on the same draws, and against the
+    VALU kernels they replace (MCLE_NO_MFMA=1)."""
+    rs = np.random.RandomState(700 + trial)
+    mod, M = MODS[1 + rs.randint(len(MODS) - 1)]
+    _bind(engine, mod, M)
+    fft = 1024
+    cp = int(rs.choice([0, 1, 7, 16, 33, 72, 255]))
+    used = int(rs.choice([fft, fft, 2 * rs.randint(1, fft // 2), 16 * rs.randint(1, 64)]))
+    n_sym = int(rs.randint(1, 4))
+    snr = _snr_for(rs, M) + 6.0
+    nv = 1.0 / omodem.dB2Linear(snr)
+    first, count = int(rs.randint(0, 1 << 33)), int(rs.randint(1, 9))
+
+    def both(fn):
+        got = fn()
+        os.environ["MCLE_NO_MFMA"] = "1"
+        try:
+            ref = fn()
+        finally:
+            os.environ.pop("MCLE_NO_MFMA", None)
+        assert np.max(np.abs(got[1].astype(np.int64) - ref[1].astype(np.int64))) <= 4, ("vs the VALU kernel", trial)
+        return got
+
+    S = int(rs.randint(1, 6))
+    dmax = max(1, min(cp, 24)) if rs.randint(4) else 30          # now and then a delay beyond the CP: the VALU kernel's case
+    delays = tuple(sorted(rs.choice(np.arange(0, dmax + 1), size=min(S, dmax + 1), replace=False).tolist()))
+    powers = tuple(float(v) for v in -np.sort(rs.uniform(0, 15, size=len(delays))))
+    Ts, Fd, L = 1e-6, float(rs.uniform(5, 400)), int(rs.choice([4, 8, 12]))
+    kw = dict(mod=mod, M=M, fft_size=fft, cp_size=cp, num_used=used, n_ofdm_sym=n_sym, snr_db=snr, Fd=Fd, Ts=Ts, L=L,
+              tap_powers_dB=powers, tap_delays_samples=delays)
+    p_lin, d_idx = och.discretize_profile(np.array(powers), np.array(delays) * Ts, Ts)
+    want = _oracle(chains.chain_ofdm_tdl, first, count, **kw)
+    _check(*both(lambda: engine.run_ofdm_tdl(fft, cp, used, n_sym, nv, p_lin, d_idx, SEED, first, count, Fd=Fd, Ts=Ts, L=L,
+                                             dtype="f32", per_realization=True)), want, "f32", ("ofdm_tdl", kw))
+    mmse = bool(rs.randint(2))
+    method = _lib.DEMOD_QAM_SLICER if (mod == "qam" and rs.randint(2)) else _lib.DEMOD_MINDIST
+    kw = dict(mod=mod, M=M, nt=4, nr=4, fft_size=fft, cp_size=cp, num_used=used, n_ofdm_sym=n_sym, snr_db=snr, mmse=mmse)
+    want = _oracle(chains.chain_mimo_ofdm, first, count, **kw)
+    _check(*both(lambda: engine.run_mimo_ofdm(4, 4, fft, cp, used, n_sym, nv, SEED, first, count, mmse=mmse, method=method,
+                                              dtype="f32", per_realization=True)), want, "f32", ("mimo_ofdm", kw))
