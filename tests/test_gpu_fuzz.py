@@ -195,3 +195,24 @@ def test_fuzz_matrix_core_kernels(engine, trial):
     want = _oracle(chains.chain_mimo_ofdm, first, count, **kw)
     _check(*both(lambda: engine.run_mimo_ofdm(4, 4, fft, cp, used, n_sym, nv, SEED, first, count, mmse=mmse, method=method,
                                               dtype="f32", per_realization=True)), want, "f32", ("mimo_ofdm", kw))
+
+
+@pytest.mark.parametrize("trial", range(N_MFMA_TRIALS))
+def test_fuzz_ofdm_matrix_core_operators(engine, trial):
+    """complex64 OFDM modulate / demodulate at 1024 points (kernels_ofdm_mfma.hip) on random batches, symbol counts (any
+    remainder modulo the four symbols of a pass), zero-padded tails, CP lengths and band widths."""
+    from oracle import ofdm as oofdm
+    rs = np.random.RandomState(900 + trial)
+    batch, n_sym = int(rs.randint(1, 6)), int(rs.randint(1, 12))
+    cp = int(rs.choice([0, 1, 16, 37, 72, 511, 1024]))
+    used = int(rs.choice([1024, 2 * rs.randint(1, 512)]))
+    n_in = n_sym * used - int(rs.randint(0, used))
+    x = (rs.randn(batch, n_in) + 1j * rs.randn(batch, n_in)).astype(np.complex64)
+    tx = engine.ofdm_modulate(x, 1024, cp, used, batch=batch, dtype="f32")
+    want = np.stack([oofdm.modulate(x[b].astype(complex), 1024, cp, used) for b in range(batch)])
+    err = np.max(np.abs(tx - want)) / max(1e-30, np.max(np.abs(want)))
+    assert tx.shape == want.shape and err <= 3e-6, (batch, n_sym, cp, used, n_in, err)
+    back = engine.ofdm_demodulate(want, 1024, cp, used, batch=batch, dtype="f32")
+    wantb = np.stack([oofdm.demodulate(want[b], 1024, cp, used) for b in range(batch)])
+    errb = np.max(np.abs(back - wantb)) / max(1e-30, np.max(np.abs(wantb)))
+    assert back.shape == wantb.shape and errb <= 3e-6, (batch, n_sym, cp, used, n_in, errb)
