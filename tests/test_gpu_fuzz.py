@@ -8,8 +8,11 @@ import pytest
 from oracle import chains, channels as och, modem as omodem
 from pyphysim_amd import _lib
 
+import os
+
 pytestmark = pytest.mark.gpu
 SEED = 20260927
+N_TRIALS = int(os.environ.get("MCLE_FUZZ_TRIALS_BASE", "6"))        # raise for a long hunt on the GPU box
 MODS = [("bpsk", 2), ("qpsk", 4), ("psk", 8), ("psk", 16), ("qam", 4), ("qam", 16), ("qam", 64), ("qam", 256)]
 
 
@@ -42,7 +45,7 @@ def _snr_for(rs, M):
 
 
 @pytest.mark.parametrize("dt", ["f64", "f32"])
-@pytest.mark.parametrize("trial", range(6))
+@pytest.mark.parametrize("trial", range(N_TRIALS))
 def test_fuzz_single_carrier(engine, dt, trial):
     rs = np.random.RandomState(100 + trial)
     mod, M = MODS[rs.randint(len(MODS))]
@@ -60,7 +63,7 @@ def test_fuzz_single_carrier(engine, dt, trial):
 
 
 @pytest.mark.parametrize("dt", ["f64", "f32"])
-@pytest.mark.parametrize("trial", range(6))
+@pytest.mark.parametrize("trial", range(N_TRIALS))
 def test_fuzz_ofdm_chains(engine, dt, trial):
     rs = np.random.RandomState(200 + trial)
     mod, M = MODS[1 + rs.randint(len(MODS) - 1)]
@@ -104,7 +107,7 @@ def test_fuzz_ofdm_chains(engine, dt, trial):
 
 
 @pytest.mark.parametrize("dt", ["f64", "f32"])
-@pytest.mark.parametrize("trial", range(6))
+@pytest.mark.parametrize("trial", range(N_TRIALS))
 def test_fuzz_chunked_pipelines(engine, dt, trial):
     rs = np.random.RandomState(300 + trial)
     mod, M = MODS[1 + rs.randint(len(MODS) - 1)]
@@ -146,8 +149,6 @@ def test_fuzz_chunked_pipelines(engine, dt, trial):
     _check(*engine.run_bd(K, r, NS, kw["iPu"], nv, SEED, first, count, bd_noise_var=kw["bd_noise_var"],
                           waterfilling=kw["waterfill"], dtype=dt, per_realization=True), want, dt, ("bd", kw))
 
-
-import os  # noqa: E402
 
 N_MFMA_TRIALS = int(os.environ.get("MCLE_FUZZ_TRIALS", "10"))
 
