@@ -436,7 +436,9 @@ int mcle_bd_extint(mcle_ctx* ctx, const mcle_bd_extint_cfg* cfg, const void* d_b
  *      (ignored for 'svd' and for brute force).  Outputs, same padded layout: d_F (nt x ns, unit Frobenius norm =
  *      full_F for P = 1), d_U (full_W_H, ns x nr), d_sinr [batch][4][4] (linear, per stream), d_capacity [batch],
  *      d_iterations [batch] (all runs of a selection wrapper added up), d_ns [batch][4] (streams kept per user),
- *      d_skipped [batch] (a singular system met on the way); every output but d_F / d_U may be NULL.
+ *      d_skipped [batch] (a singular system met on the way), d_every_capacity [batch][256] (brute force only: the sum
+ *      capacity of every stream combination in itertools.product order, last user fastest --
+ *      BruteForceStreamIASolver.every_sum_capacity :2135-2145); every output but d_F / d_U may be NULL.
  *      Eigenvector phases are ours, not LAPACK's: SINRs, capacity and decisions do not depend on them. */
 typedef struct mcle_ia_general_cfg {
     int32_t K, nr, nt;
@@ -450,7 +452,7 @@ typedef struct mcle_ia_general_cfg {
 } mcle_ia_general_cfg;
 int mcle_ia_solve_general(mcle_ctx* ctx, const mcle_ia_general_cfg* cfg, const void* d_bigH, const void* d_F_init,
                           void* d_F, void* d_U, double* d_sinr, double* d_capacity, uint32_t* d_iterations,
-                          int32_t* d_ns, uint32_t* d_skipped, size_t batch);
+                          int32_t* d_ns, uint32_t* d_skipped, double* d_every_capacity, size_t batch);
 
 /* ---- block diagonalisation of a multi-user downlink (SURVEY 8(f).3 tail) --------------------
  * comm/waterfilling.py:15-92 doWF: d_gains [batch][n] channel POWER gains -> optimum powers

@@ -428,6 +428,9 @@ def chain_ia_general(rng, algo, mod, M, K, nr, nt, Ns, NSymbs, snr_db, max_itera
                num_symbols=int(idx.size), num_bits=int(idx.size) * omodem.level2bits(M))
     if F_init is not None:
         out["F_init"] = pad(F_init, 4, 4)
+    if select == "brute":
+        out["every_sum_capacity"] = np.array(sol["every_sum_capacity"], dtype=float)
+        out["stream_combinations"] = np.array(sol["stream_combinations"], dtype=np.int64)
     return out
 
 

@@ -414,13 +414,16 @@ def general_solve(algo, H, Ns, noise_var, max_iterations=50, relative_factor=1e-
         return dict(F=F, U=U, sinr=sinr, cap=cap, Ns=ns), runned
 
     if select == 'brute':
-        best, total = None, 0
+        best, total, every, combos = None, 0, [], []
         for comb in itertools.product(*[range(1, n + 1) for n in Ns]):
             sol, runned = solve(svd_init(H, comb))
             total += runned
+            every.append(sol["cap"])                # every_sum_capacity / stream_combinations (:2122-2145)
+            combos.append(list(comb))
             if best is None or sol["cap"] > best["cap"]:
                 best = sol
         best["runned"] = total
+        best["every_sum_capacity"], best["stream_combinations"] = every, combos
         return best
     sol, counter = solve(svd_init(H, Ns) if F_init is None else [np.asarray(f, dtype=complex) for f in F_init])
     total = counter

@@ -744,6 +744,9 @@ def ref_ia_general(seed, algo, mod, M, K, nr, nt, Ns, NSymbs, snr_db, max_iterat
                runned_iterations=int(runned), **ref_counts(idx, dec, M))
     if F_init["F"] is not None:
         out["F_init"] = pad(F_init["F"], 4, 4)
+    if select == "brute":       # BruteForceStreamIASolver.every_sum_capacity / stream_combinations (:2122-2145)
+        out["every_sum_capacity"] = np.array(wrapper.every_sum_capacity, dtype=float)
+        out["stream_combinations"] = np.array(wrapper.stream_combinations, dtype=np.int64)
     return out
 
 

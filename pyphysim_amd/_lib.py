@@ -187,7 +187,7 @@ _PROTOS = {
     "mcle_svd_filters": (c_int, [_P, c_int, _P, c_int, _P, _P, _P, c_size_t]),
     "mcle_gmd_filters": (c_int, [_P, c_int, _P, c_int, c_double, _P, _P, _P, _P, c_size_t]),
     "mcle_bd_extint": (c_int, [_P, POINTER(BdExtIntCfg), _P, _P, _P, _P, _P, _P, c_size_t]),
-    "mcle_ia_solve_general": (c_int, [_P, POINTER(IaGeneralCfg), _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t]),
+    "mcle_ia_solve_general": (c_int, [_P, POINTER(IaGeneralCfg), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t]),
     "mcle_mu_link_stats": (c_int, [_P, POINTER(MuStatsCfg), _P, _P, _P, _P, _P, _P, _P, _P, c_size_t]),
     "mcle_post_processing_sinrs": (c_int, [_P, _P, _P, _P, c_double, c_int, c_int, c_int, _P, c_size_t]),
     "mcle_run_awgn": (c_int, [_P, c_int, POINTER(AwgnCfg), c_uint64, c_uint64, c_uint64, _P, _P, _P]),

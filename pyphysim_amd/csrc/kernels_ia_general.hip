@@ -542,7 +542,8 @@ __global__ __launch_bounds__(64) void k_ia_general(Params pp, const cd* __restri
                                                    cd* __restrict__ F_out, cd* __restrict__ U_out,
                                                    double* __restrict__ sinr_out, double* __restrict__ cap_out,
                                                    uint32_t* __restrict__ iters_out, int32_t* __restrict__ ns_out,
-                                                   uint32_t* __restrict__ skipped, size_t batch) {
+                                                   uint32_t* __restrict__ skipped, double* __restrict__ combo_cap,
+                                                   size_t batch) {
     const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= batch) return;
     Problem P{bigH + b * (size_t)(pp.K * pp.nr) * (pp.K * pp.nt), pp.K, pp.nr, pp.nt, pp.nv};
@@ -567,12 +568,15 @@ __global__ __launch_bounds__(64) void k_ia_general(Params pp, const cd* __restri
         for (int k = 0; k < P.K; ++k) comb[k] = 1;
         double best_cap = -1.0;
         bool first = true;
+        int n_comb = 0;
         while (true) {
             for (int k = 0; k < P.K; ++k) S.ns[k] = comb[k];
             init_svd(P, S);
             bool okc = true;
             iters += (unsigned)run_solver(P, S, pp.solver, pp.max_iter, pp.rel, okc);
             const double c = finish(P, S, U, sinr, okc);
+            if (combo_cap) combo_cap[b * 256 + n_comb] = c;       // every_sum_capacity, in stream_combinations order
+            ++n_comb;
             if (first || c > best_cap) {
                 best_cap = c;
                 best = S;
@@ -659,7 +663,7 @@ extern "C" {
 
 int mcle_ia_solve_general(mcle_ctx* ctx, const mcle_ia_general_cfg* cfg, const void* d_bigH, const void* d_F_init,
                           void* d_F, void* d_U, double* d_sinr, double* d_capacity, uint32_t* d_iterations,
-                          int32_t* d_ns, uint32_t* d_skipped, size_t batch) {
+                          int32_t* d_ns, uint32_t* d_skipped, double* d_every_capacity, size_t batch) {
     MCLE_REQUIRE(ctx != nullptr && cfg != nullptr && d_bigH != nullptr && d_F != nullptr && d_U != nullptr, "null argument");
     MCLE_REQUIRE(cfg->K >= 2 && cfg->K <= iag::KM, "K must be in [2, %d]", iag::KM);
     MCLE_REQUIRE(cfg->nr >= 1 && cfg->nr <= iag::D && cfg->nt >= 1 && cfg->nt <= iag::D,
@@ -692,7 +696,7 @@ int mcle_ia_solve_general(mcle_ctx* ctx, const mcle_ia_general_cfg* cfg, const v
     pp.rel = cfg->relative_factor;
     hipLaunchKernelGGL(iag::k_ia_general, dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, ctx->stream, pp,
                        (const double2*)d_bigH, (const double2*)d_F_init, (double2*)d_F, (double2*)d_U, d_sinr,
-                       d_capacity, d_iterations, d_ns, d_skipped, batch);
+                       d_capacity, d_iterations, d_ns, d_skipped, d_every_capacity, batch);
     MCLE_LAUNCH_CHECK();
     return MCLE_OK;
 }

@@ -894,10 +894,15 @@ class Engine:
         F, U = self.empty((b, 4, 4, 4), np.complex128), self.empty((b, 4, 4, 4), np.complex128)
         sinr, cap = self.empty((b, 4, 4), np.float64), self.empty(b, np.float64)
         its, ns, sk = self.empty(b, np.uint32), self.empty((b, 4), np.int32), self.empty(b, np.uint32)
+        every = self.empty((b, 256), np.float64) if select == "brute" else None
         self._raise_value(self.lib.mcle_ia_solve_general(self.ctx, byref(cfg), d_H.ptr, d_F0.ptr if d_F0 else None,
-                                                         F.ptr, U.ptr, sinr.ptr, cap.ptr, its.ptr, ns.ptr, sk.ptr, b))
-        return dict(F=F.get()[:, :K], U=U.get()[:, :K], sinr=sinr.get()[:, :K], capacity=cap.get(),
-                    iterations=its.get().astype(np.int64), Ns=ns.get()[:, :K], skipped=sk.get())
+                                                         F.ptr, U.ptr, sinr.ptr, cap.ptr, its.ptr, ns.ptr, sk.ptr,
+                                                         every.ptr if every else None, b))
+        out = dict(F=F.get()[:, :K], U=U.get()[:, :K], sinr=sinr.get()[:, :K], capacity=cap.get(),
+                   iterations=its.get().astype(np.int64), Ns=ns.get()[:, :K], skipped=sk.get())
+        if every:
+            out["every_capacity"] = every.get()[:, :int(np.prod(ns_list))]     # one value per stream combination
+        return out
 
     def ia_closed_form(self, big_H, noise_var):
         """big_H [batch, 6, 6] complex128 -> dict(F [batch,3,2], U [batch,3,2], sinr [batch,3],

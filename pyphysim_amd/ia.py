@@ -314,6 +314,7 @@ class IterativeIASolverBaseClass(IASolverBaseClass):
                                            [int(n) for n in Ns_arr], self.noise_var, self.max_iterations,
                                            self.relative_factor, F_init=pad, select=select)
         self._store_general(sol, nr, nt)
+        self._last_every_capacity = sol["every_capacity"][0] if "every_capacity" in sol else []
         self._runned_iterations = int(sol["iterations"][0])
         return self._runned_iterations
 
@@ -420,17 +421,25 @@ class BruteForceStreamIASolver:
             raise TypeError("iasolver_obj must be an iterative IA solver")
         self._iasolver = iasolver_obj
         self._runned_iterations = 0
+        self._stream_combinations, self._every_sum_capacity = [], []
 
     runned_iterations = property(lambda self: self._runned_iterations)
+    stream_combinations = property(lambda self: self._stream_combinations)       # algorithms.py:2122-2132
+    every_sum_capacity = property(lambda self: self._every_sum_capacity)         # :2134-2145
 
     def clear(self):
         self._iasolver.clear()
         self._runned_iterations = 0
+        self._stream_combinations, self._every_sum_capacity = [], []
 
     def solve(self, Ns, P=None):
+        import itertools
         self._iasolver.clear()
         self._iasolver._initialize_with = "svd"
         self._runned_iterations = self._iasolver._solve_general(Ns, P, select="brute")
+        ns = [int(Ns)] * self._iasolver.K if isinstance(Ns, (int, np.integer)) else [int(n) for n in Ns]
+        self._stream_combinations = list(itertools.product(*[range(1, n + 1) for n in ns]))     # :2176-2189
+        self._every_sum_capacity = [float(c) for c in self._iasolver._last_every_capacity]
         return self._runned_iterations
 
     def __getattr__(self, name):

@@ -121,6 +121,9 @@ def test_class_mirrors_on_general_geometries(engine, case):
         runned = solver.solve(Ns)
     assert runned == int(g["runned_iterations"]) == solver.runned_iterations or kw["select"]
     assert runned == int(g["runned_iterations"])
+    if kw["select"] == "brute":
+        assert [list(c) for c in wrapper.stream_combinations] == g["stream_combinations"].tolist()
+        assert relerr(np.array(wrapper.every_sum_capacity), g["every_sum_capacity"]) <= 1e-6
     assert list(solver.Ns) == [int(n) for n in g["Ns_final"]]
     assert abs(solver.calc_sum_capacity() - float(g["sum_capacity"])) <= 1e-6 * float(g["sum_capacity"])
     assert relerr(np.concatenate(list(solver.calc_SINR())), g["sinr"]) <= 1e-6
