@@ -151,6 +151,17 @@ class EnhancedBD(BDWithExtIntBase):
 
     metric_name = property(lambda self: self._metric_func_name)
 
+    @staticmethod
+    def calc_receive_filter_user_k(Heq_k_P, P=None, engine=None):
+        """:1056-1099: pinv(Heq_k_P), or with a stream-reduction matrix P the filter confined to P's subspace,
+        pinv(Pbar Heq_k_P) Pbar with Pbar = P (P^H P)^-1 P^H = P pinv(P) (products and pseudo-inverses on the device)."""
+        eng = engine if engine is not None else get_engine()
+        if P is None:
+            return eng.pinv(np.asarray(Heq_k_P, dtype=complex))
+        mm = lambda A, B: eng.mimo_channel(np.asarray(A, dtype=complex)[None], np.asarray(B, dtype=complex)[None])[0]
+        Pbar = mm(P, eng.pinv(np.asarray(P, dtype=complex)))
+        return mm(eng.pinv(mm(Pbar, Heq_k_P)), Pbar)
+
     def set_ext_int_handling_metric(self, metric, metric_func_extra_args_dict=None):
         """:887-1042, the reference's messages."""
         extra = metric_func_extra_args_dict or {}
