@@ -65,8 +65,78 @@ __device__ __forceinline__ bool blast_filter_t(const cx<R> (&H)[NR][NT], R nv, c
 
 // x = sqrt(NT) (H^H H + nv I)^-1 H^H y without forming the filter: one right-hand side instead of NR.  For
 // callers that need a filter per column (frequency-selective channels) -- same decisions as G y.
+// f32 instantiation: every complex multiply-accumulate as four chained FMAs (the product-then-add form of the f64 parity
+// code is six operations) and one v_rcp / v_rsq per pivot; same algorithm, rounding-level differences only.
+__device__ __forceinline__ float2 cx_macc(float2 acc, float2 a, float2 b) {    // acc + a conj(b)
+    acc.x = fmaf(a.x, b.x, acc.x);
+    acc.x = fmaf(a.y, b.y, acc.x);
+    acc.y = fmaf(a.y, b.x, acc.y);
+    acc.y = fmaf(-a.x, b.y, acc.y);
+    return acc;
+}
+__device__ __forceinline__ float2 cx_msub(float2 acc, float2 a, float2 b) {    // acc - a b
+    acc.x = fmaf(-a.x, b.x, acc.x);
+    acc.x = fmaf(a.y, b.y, acc.x);
+    acc.y = fmaf(-a.x, b.y, acc.y);
+    acc.y = fmaf(-a.y, b.x, acc.y);
+    return acc;
+}
+__device__ __forceinline__ float2 cx_msubc(float2 acc, float2 a, float2 b) {   // acc - a conj(b)
+    acc.x = fmaf(-a.x, b.x, acc.x);
+    acc.x = fmaf(-a.y, b.y, acc.x);
+    acc.y = fmaf(-a.y, b.x, acc.y);
+    acc.y = fmaf(a.x, b.y, acc.y);
+    return acc;
+}
+template <int NT, int NR>
+__device__ __forceinline__ bool blast_solve_f32(const float2 (&H)[NR][NT], float nv, const float2 (&y)[NR], float2 (&x)[NT]) {
+    float2 L[NT][NT];
+    float invd[NT];
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+#pragma unroll
+        for (int i = j; i < NT; ++i) {
+            float2 a = make_float2(i == j ? nv : 0.f, 0.f);
+#pragma unroll
+            for (int r = 0; r < NR; ++r) a = cx_macc(a, H[r][j], H[r][i]);      // conj(H[r][i]) * H[r][j]
+#pragma unroll
+            for (int k = 0; k < j; ++k) a = cx_msubc(a, L[i][k], L[j][k]);
+            if (i == j) {
+                ok = ok && (a.x > 1e-30f);
+                invd[j] = __builtin_amdgcn_rsqf(a.x);
+                L[j][j] = make_float2(a.x * invd[j], 0.f);
+            } else {
+                L[i][j] = make_float2(a.x * invd[j], a.y * invd[j]);
+            }
+        }
+    }
+    float2 z[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {  // L z = H^H y
+        float2 v = make_float2(0.f, 0.f);
+#pragma unroll
+        for (int r = 0; r < NR; ++r) v = cx_macc(v, y[r], H[r][i]);               // conj(H[r][i]) * y[r]
+#pragma unroll
+        for (int k = 0; k < i; ++k) v = cx_msub(v, L[i][k], z[k]);
+        z[i] = make_float2(v.x * invd[i], v.y * invd[i]);
+    }
+    const float root_nt = (float)sqrt((double)NT);
+#pragma unroll
+    for (int i = NT - 1; i >= 0; --i) {  // L^H w = z
+        float2 v = z[i];
+#pragma unroll
+        for (int k = i + 1; k < NT; ++k) v = cx_msub(v, make_float2(L[k][i].x, -L[k][i].y), z[k]);
+        z[i] = make_float2(v.x * invd[i], v.y * invd[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < NT; ++i) x[i] = make_float2(z[i].x * root_nt, z[i].y * root_nt);
+    return ok;
+}
+
 template <typename R, int NT, int NR>
 __device__ __forceinline__ bool blast_solve_t(const cx<R> (&H)[NR][NT], R nv, const cx<R> (&y)[NR], cx<R> (&x)[NT]) {
+    if constexpr (sizeof(R) == 4) return blast_solve_f32<NT, NR>(H, nv, y, x);
     typedef cx<R> C;
     C L[NT][NT];
     R invd[NT];
