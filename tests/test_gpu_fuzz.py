@@ -13,6 +13,7 @@ import os
 pytestmark = pytest.mark.gpu
 SEED = 20260927
 N_TRIALS = int(os.environ.get("MCLE_FUZZ_TRIALS_BASE", "6"))        # raise for a long hunt on the GPU box
+OFFSET = int(os.environ.get("MCLE_FUZZ_OFFSET", "0"))               # shifts every trial's random configuration
 MODS = [("bpsk", 2), ("qpsk", 4), ("psk", 8), ("psk", 16), ("qam", 4), ("qam", 16), ("qam", 64), ("qam", 256)]
 
 
@@ -35,9 +36,15 @@ def _check(res, se, be, want, dt, what):
         assert np.array_equal(se, want_se) and np.array_equal(be, want_be), what
         assert res["sym_errors"] == int(want_se.sum()) and res["bit_errors"] == int(want_be.sum()), what
     else:
-        # a handful of boundary symbols may fall the other way in f32; the tolerance of the north star on rates
-        assert abs(int(se.sum()) - int(want_se.sum())) <= max(3, 1e-4 * n * nsym), what
-        assert abs(int(be.sum()) - int(want_be.sum())) <= max(6, 1e-4 * n * nbits), what
+        # a handful of boundary symbols may fall the other way in f32; the tolerance of the north star on rates.
+        # A realization in outage (more than half of its symbols wrong: a stream received at next to no power, every
+        # decision a near-tie) gets 2 % of its own error count on top -- found by a seed hunt (MCLE_FUZZ_OFFSET=2:
+        # 331 vs 327 errors of 387 in one block-diagonalisation realization, everything else equal).
+        outage = want_se > nsym // 2
+        slack_s = 0.02 * float(want_se[outage].sum())
+        slack_b = 0.02 * float(want_be[outage].sum())
+        assert abs(int(se.sum()) - int(want_se.sum())) <= max(3, 1e-4 * n * nsym) + slack_s, what
+        assert abs(int(be.sum()) - int(want_be.sum())) <= max(6, 1e-4 * n * nbits) + slack_b, what
 
 
 def _snr_for(rs, M):
@@ -47,7 +54,7 @@ def _snr_for(rs, M):
 @pytest.mark.parametrize("dt", ["f64", "f32"])
 @pytest.mark.parametrize("trial", range(N_TRIALS))
 def test_fuzz_single_carrier(engine, dt, trial):
-    rs = np.random.RandomState(100 + trial)
+    rs = np.random.RandomState(100 + trial + 1000 * OFFSET)
     mod, M = MODS[rs.randint(len(MODS))]
     _bind(engine, mod, M)
     N = int(rs.choice([1, 15, 16, 17, 1000, 4099, 16384, 16385, 40000]))
@@ -65,7 +72,7 @@ def test_fuzz_single_carrier(engine, dt, trial):
 @pytest.mark.parametrize("dt", ["f64", "f32"])
 @pytest.mark.parametrize("trial", range(N_TRIALS))
 def test_fuzz_ofdm_chains(engine, dt, trial):
-    rs = np.random.RandomState(200 + trial)
+    rs = np.random.RandomState(200 + trial + 1000 * OFFSET)
     mod, M = MODS[1 + rs.randint(len(MODS) - 1)]
     _bind(engine, mod, M)
     fft = int(rs.choice([64, 128, 256, 512, 1024]))
@@ -109,7 +116,7 @@ def test_fuzz_ofdm_chains(engine, dt, trial):
 @pytest.mark.parametrize("dt", ["f64", "f32"])
 @pytest.mark.parametrize("trial", range(N_TRIALS))
 def test_fuzz_chunked_pipelines(engine, dt, trial):
-    rs = np.random.RandomState(300 + trial)
+    rs = np.random.RandomState(300 + trial + 1000 * OFFSET)
     mod, M = MODS[1 + rs.randint(len(MODS) - 1)]
     _bind(engine, mod, M)
     NS = int(rs.choice([2, 7, 64, 100, 128, 129, 200, 500]))
@@ -158,7 +165,7 @@ def test_fuzz_matrix_core_kernels(engine, trial):
     """f32, FFT 1024: the matrix-core kernels of configs 3 and 4 (and, through them, fft16.hpp) on random CP lengths,
     band widths, symbol counts, tap sets and realization offsets -- against the oracle on the same draws, and against the
     VALU kernels they replace (MCLE_NO_MFMA=1)."""
-    rs = np.random.RandomState(700 + trial)
+    rs = np.random.RandomState(700 + trial + 1000 * OFFSET)
     mod, M = MODS[1 + rs.randint(len(MODS) - 1)]
     _bind(engine, mod, M)
     fft = 1024
@@ -203,7 +210,7 @@ def test_fuzz_ofdm_matrix_core_operators(engine, trial):
     """complex64 OFDM modulate / demodulate at 1024 points (kernels_ofdm_mfma.hip) on random batches, symbol counts (any
     remainder modulo the four symbols of a pass), zero-padded tails, CP lengths and band widths."""
     from oracle import ofdm as oofdm
-    rs = np.random.RandomState(900 + trial)
+    rs = np.random.RandomState(900 + trial + 1000 * OFFSET)
     batch, n_sym = int(rs.randint(1, 6)), int(rs.randint(1, 12))
     cp = int(rs.choice([0, 1, 16, 37, 72, 511, 1024]))
     used = int(rs.choice([1024, 2 * rs.randint(1, 512)]))
