@@ -28,6 +28,7 @@
 #include "modem.hpp"
 #include "philox.hpp"
 #include "pipe_common.hpp"
+#include "qam_pack.hpp"
 #include "totals.hpp"
 
 namespace mcle {
@@ -380,6 +381,15 @@ __global__ __launch_bounds__(kPipeBlock, sizeof(T) == 4 ? 3 : 1) void k_run_mimo
                 const bool ok = blast_solve_t<T, NA, NA>(H, nv_filter, yb, est);   // filter applied, never formed
 #pragma unroll
                 for (int a = 0; a < NA; ++a) est[a] = ok ? cscale(est[a], rx_scale) : mk<T>(0, 0);   // singular: ZF only
+                if constexpr (sizeof(T) == 4 && NA == 4) {
+                    if (mp.method == MCLE_DEMOD_QAM_SLICER) {   // the four decisions of the bin packed, compared in the level domain
+                        const QamPack qp = qam_pack(mp);
+                        const f4q er = {est[0].x, est[1].x, est[2].x, est[3].x}, ei = {est[0].y, est[1].y, est[2].y, est[3].y};
+                        const uint32_t sent = *reinterpret_cast<const uint32_t*>(s_idx + d * NA);
+                        qam_count4(qam_levels4(er, ei, qp) ^ labels_to_levels(sent, qp), qp, se, be);
+                        continue;
+                    }
+                }
                 if (mp.method == MCLE_DEMOD_QAM_SLICER) {
 #pragma unroll
                     for (int a = 0; a < NA; ++a) dec[a] = demod_qam_slicer<T>(est[a], mp.qam_scale, mp.qam_L, mp.half_bits);
