@@ -14,6 +14,7 @@
 #include "philox.hpp"
 #include "totals.hpp"
 #include "pipe_common.hpp"
+#include "qam_pack.hpp"
 #include "wave_draws.hpp"
 
 namespace mcle {
@@ -560,6 +561,11 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void k_ia_link(ModemPar
     const int lane = threadIdx.x;
     const T sigma = (T)sqrt(noise_var);
     const uint32_t mask = (uint32_t)(mp.M - 1);
+    const bool packed = sizeof(T) == 4 && mp.method == MCLE_DEMOD_QAM_SLICER;
+    QamPack qp{};
+    if constexpr (sizeof(T) == 4) {
+        if (packed) qp = qam_pack(mp);
+    }
     __shared__ WgTotals totals;
     if (threadIdx.x == 0) wg_zero(totals);
     __syncthreads();
@@ -580,16 +586,27 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void k_ia_link(ModemPar
             const bool ok = rec[15].x != (T)0;
             unsigned se = 0, be = 0;
             auto column = [&](const int (&tx)[3], const cx<T> (&nz)[6]) {
-                cx<T> x[3];
+                cx<T> x[3], est[3];
 #pragma unroll
                 for (int k = 0; k < 3; ++k) x[k] = s_table[tx[k]];
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
-                    cx<T> est = cmul(U[k][0], nz[2 * k]);
-                    est = cfma(U[k][1], nz[2 * k + 1], est);
+                    est[k] = cmul(U[k][0], nz[2 * k]);
+                    est[k] = cfma(U[k][1], nz[2 * k + 1], est[k]);
 #pragma unroll
-                    for (int l = 0; l < 3; ++l) est = cfma(G[k][l], x[l], est);
-                    const unsigned e = (unsigned)(tx[k] ^ demod_one(mp, s_table, s_grid, est));
+                    for (int l = 0; l < 3; ++l) est[k] = cfma(G[k][l], x[l], est[k]);
+                }
+                if constexpr (sizeof(T) == 4) {
+                    if (packed) {   // the three decisions of the column in one packed level-domain slice (qam_pack.hpp)
+                        const f4q er = {est[0].x, est[1].x, est[2].x, 0.f}, ei = {est[0].y, est[1].y, est[2].y, 0.f};
+                        const uint32_t sent = (uint32_t)tx[0] | ((uint32_t)tx[1] << 8) | ((uint32_t)tx[2] << 16);
+                        qam_count4((qam_levels4(er, ei, qp) ^ labels_to_levels(sent, qp)) & 0x00FFFFFFu, qp, se, be);
+                        return;
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const unsigned e = (unsigned)(tx[k] ^ demod_one(mp, s_table, s_grid, est[k]));
                     se += (e != 0u);
                     be += __popc(e);
                 }
