@@ -16,6 +16,7 @@
 #include "philox.hpp"
 #include "pipe_common.hpp"
 #include "totals.hpp"
+#include "qam_pack.hpp"
 #include "wave_draws.hpp"
 
 namespace mcle {
@@ -190,6 +191,12 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void k_mimo_flat_link(
     const uint32_t mask = (uint32_t)(mp.M - 1);
     const int layers = (scheme == MCLE_MIMO_ALAMOUTI || scheme == MCLE_MIMO_MRT) ? 1 : nt;
     const bool c_order = scheme == MCLE_MIMO_SVD || scheme == MCLE_MIMO_GMD;
+    const bool packed = sizeof(T) == 4 && mp.method == MCLE_DEMOD_QAM_SLICER;
+    const uint32_t layer_mask = layers >= 4 ? 0xFFFFFFFFu : ((1u << (8 * layers)) - 1u);
+    QamPack qp{};
+    if constexpr (sizeof(T) == 4) {
+        if (packed) qp = qam_pack(mp);
+    }
     __shared__ WgTotals totals;
     if (threadIdx.x == 0) wg_zero(totals);
     __syncthreads();
@@ -249,16 +256,31 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void k_mimo_flat_link(
                     cx<T> d[kFlatMax];
 #pragma unroll
                     for (int l = 0; l < kFlatMax; ++l) d[l] = l < layers ? s_table[tx[l]] : mk<T>(0, 0);
+                    cx<T> est[kFlatMax];
+#pragma unroll
+                    for (int l = 0; l < kFlatMax; ++l) {
+                        est[l] = mk<T>(0, 0);
+                        if (l < layers) {
+#pragma unroll
+                            for (int c = 0; c < kFlatMax; ++c) {
+                                est[l] = cfma(A[l][c], d[c], est[l]);      // entries beyond the layers / rows are zero
+                                est[l] = cfma(G[l][c], nz[c], est[l]);
+                            }
+                        }
+                    }
+                    if constexpr (sizeof(T) == 4) {
+                        if (packed) {   // the column's decisions in one packed level-domain slice (qam_pack.hpp)
+                            const f4q er = {est[0].x, est[1].x, est[2].x, est[3].x}, ei = {est[0].y, est[1].y, est[2].y, est[3].y};
+                            const uint32_t sent = (uint32_t)tx[0] | ((uint32_t)tx[1] << 8) | ((uint32_t)tx[2] << 16) |
+                                                  ((uint32_t)tx[3] << 24);
+                            qam_count4((qam_levels4(er, ei, qp) ^ labels_to_levels(sent, qp)) & layer_mask, qp, se, be);
+                            return;
+                        }
+                    }
 #pragma unroll
                     for (int l = 0; l < kFlatMax; ++l)
                         if (l < layers) {
-                            cx<T> est = mk<T>(0, 0);
-#pragma unroll
-                            for (int c = 0; c < kFlatMax; ++c) {
-                                est = cfma(A[l][c], d[c], est);      // entries beyond the layers / rows are zero
-                                est = cfma(G[l][c], nz[c], est);
-                            }
-                            const unsigned xr = (unsigned)(tx[l] ^ demod_one(mp, s_table, s_grid, est));
+                            const unsigned xr = (unsigned)(tx[l] ^ demod_one(mp, s_table, s_grid, est[l]));
                             se += (xr != 0u);
                             be += __popc(xr);
                         }
