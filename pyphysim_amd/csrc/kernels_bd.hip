@@ -637,13 +637,22 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void k_bd_link(ModemPar
     const int stride = n * (R + 1) + 1;
     unsigned long long* s_grid = reinterpret_cast<unsigned long long*>(smem);
     __shared__ cx<T> s_table[256];
+    __shared__ float4 s_tab4[sizeof(T) == 4 ? 256 : 1];     // {re, im, |c|^2 / 2, 0}: the lockstep searches of modem.hpp
     __shared__ WgTotals totals;
     load_table(mp, s_table);
     load_grid(mp, s_grid);
+    if constexpr (sizeof(T) == 4)
+        for (int m = threadIdx.x; m < mp.M; m += blockDim.x) {
+            const float2 c = mp.g_table[m];
+            s_tab4[m] = make_float4(c.x, c.y, 0.5f * (c.x * c.x + c.y * c.y), 0.f);
+        }
     const int lane = threadIdx.x;
     const T sigma = (T)sqrt(pp.noise_var);
     const uint32_t mask = (uint32_t)(mp.M - 1);
     const int NS = pp.n_symbols;
+    // f32, min-distance: the R streams of a user searched in lockstep -- directly for constellations of <= 8 points,
+    // through the candidate grid otherwise (same decisions as demod_one, one LDS round trip per candidate for all R)
+    const bool lockstep = sizeof(T) == 4 && mp.method == MCLE_DEMOD_MINDIST && (mp.M <= 8 || mp.grid.G > 0);
     if (threadIdx.x == 0) wg_zero(totals);
     __syncthreads();
     const uint64_t n_chunks = (count + per_wave - 1) / per_wave;
@@ -660,13 +669,30 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void k_bd_link(ModemPar
 #pragma unroll
                 for (int k = 0; k < KMAX; ++k)
                     if (k < K) {
+                        cx<T> est[R];
 #pragma unroll
                         for (int jj = 0; jj < R; ++jj) {
                             const int s = k * R + jj;
-                            cx<T> est = cmul(D[s], s_table[tx[s]]);
+                            est[jj] = cmul(D[s], s_table[tx[s]]);
 #pragma unroll
-                            for (int a = 0; a < R; ++a) est = cfma(W[s * R + a], nz[k * R + a], est);
-                            const unsigned x = (unsigned)(tx[s] ^ demod_one(mp, s_table, s_grid, est));
+                            for (int a = 0; a < R; ++a) est[jj] = cfma(W[s * R + a], nz[k * R + a], est[jj]);
+                        }
+                        int dec[R];
+                        bool done = false;
+                        if constexpr (sizeof(T) == 4) {
+                            if (lockstep) {
+                                if (mp.M <= 8) demod_mindist_multi<R>(s_tab4, mp.M, est, dec);
+                                else demod_grid4_multi<R>(s_tab4, s_grid, mp.grid, mp.M, est, dec);
+                                done = true;
+                            }
+                        }
+                        if (!done) {
+#pragma unroll
+                            for (int jj = 0; jj < R; ++jj) dec[jj] = demod_one(mp, s_table, s_grid, est[jj]);
+                        }
+#pragma unroll
+                        for (int jj = 0; jj < R; ++jj) {
+                            const unsigned x = (unsigned)(tx[k * R + jj] ^ dec[jj]);
                             se += (x != 0u);
                             be += __popc(x);
                         }
