@@ -555,9 +555,16 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void k_ia_link(ModemPar
                                                                         uint32_t* __restrict__ sym_out,
                                                                         uint32_t* __restrict__ bit_out) {
     __shared__ cx<T> s_table[256];
+    __shared__ float4 s_tab4[sizeof(T) == 4 ? 256 : 1];     // {re, im, |c|^2 / 2, 0}: the lockstep searches of modem.hpp
     extern __shared__ unsigned long long s_grid[];       // [G*G] candidate grid (min-distance demodulation, f32)
     load_table(mp, s_table);
     load_grid(mp, s_grid);
+    if constexpr (sizeof(T) == 4)
+        for (int m = threadIdx.x; m < mp.M; m += blockDim.x) {
+            const float2 c = mp.g_table[m];
+            s_tab4[m] = make_float4(c.x, c.y, 0.5f * (c.x * c.x + c.y * c.y), 0.f);
+        }
+    const bool lockstep = sizeof(T) == 4 && mp.method == MCLE_DEMOD_MINDIST && (mp.M <= 8 || mp.grid.G > 0);
     const int lane = threadIdx.x;
     const T sigma = (T)sqrt(noise_var);
     const uint32_t mask = (uint32_t)(mp.M - 1);
@@ -604,9 +611,22 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void k_ia_link(ModemPar
                         return;
                     }
                 }
+                int dec[3];
+                bool done = false;
+                if constexpr (sizeof(T) == 4) {
+                    if (lockstep) {       // the three streams searched in lockstep (same decisions as demod_one)
+                        if (mp.M <= 8) demod_mindist_multi<3>(s_tab4, mp.M, est, dec);
+                        else demod_grid4_multi<3>(s_tab4, s_grid, mp.grid, mp.M, est, dec);
+                        done = true;
+                    }
+                }
+                if (!done) {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) dec[k] = demod_one(mp, s_table, s_grid, est[k]);
+                }
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
-                    const unsigned e = (unsigned)(tx[k] ^ demod_one(mp, s_table, s_grid, est[k]));
+                    const unsigned e = (unsigned)(tx[k] ^ dec[k]);
                     se += (e != 0u);
                     be += __popc(e);
                 }

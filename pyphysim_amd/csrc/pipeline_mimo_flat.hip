@@ -183,9 +183,16 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void k_mimo_flat_link(
     uint64_t count, int per_wave, const cx<T>* __restrict__ recs, mcle_counters* counters,
     uint32_t* __restrict__ sym_out, uint32_t* __restrict__ bit_out) {
     __shared__ cx<T> s_table[256];
+    __shared__ float4 s_tab4[sizeof(T) == 4 ? 256 : 1];     // {re, im, |c|^2 / 2, 0}: the lockstep searches of modem.hpp
     extern __shared__ unsigned long long s_grid[];       // [G*G] candidate grid (min-distance demodulation, f32)
     load_table(mp, s_table);
     load_grid(mp, s_grid);
+    if constexpr (sizeof(T) == 4)
+        for (int m = threadIdx.x; m < mp.M; m += blockDim.x) {
+            const float2 c = mp.g_table[m];
+            s_tab4[m] = make_float4(c.x, c.y, 0.5f * (c.x * c.x + c.y * c.y), 0.f);
+        }
+    const bool lockstep = sizeof(T) == 4 && mp.method == MCLE_DEMOD_MINDIST && (mp.M <= 8 || mp.grid.G > 0);
     const int lane = threadIdx.x;
     const T sigma = (T)sqrt(noise_var);
     const uint32_t mask = (uint32_t)(mp.M - 1);
@@ -277,10 +284,23 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void k_mimo_flat_link(
                             return;
                         }
                     }
+                    int dec[kFlatMax];
+                    bool done = false;
+                    if constexpr (sizeof(T) == 4) {
+                        if (lockstep) {   // the layers searched in lockstep; unused layers carry est = 0 and are not counted
+                            if (mp.M <= 8) demod_mindist_multi<kFlatMax>(s_tab4, mp.M, est, dec);
+                            else demod_grid4_multi<kFlatMax>(s_tab4, s_grid, mp.grid, mp.M, est, dec);
+                            done = true;
+                        }
+                    }
+                    if (!done) {
+#pragma unroll
+                        for (int l = 0; l < kFlatMax; ++l) dec[l] = l < layers ? demod_one(mp, s_table, s_grid, est[l]) : 0;
+                    }
 #pragma unroll
                     for (int l = 0; l < kFlatMax; ++l)
                         if (l < layers) {
-                            const unsigned xr = (unsigned)(tx[l] ^ demod_one(mp, s_table, s_grid, est[l]));
+                            const unsigned xr = (unsigned)(tx[l] ^ dec[l]);
                             se += (xr != 0u);
                             be += __popc(xr);
                         }
