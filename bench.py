@@ -62,7 +62,7 @@ UNCOUNTED = {"c4": "Philox4x32-10: ~2 350 blocks (4 176 CN samples + 4 096 symbo
 HBM_PEAK_GBPS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
 HBM_COPY_GBPS = 6290.0      # same guide: measured float4 copy
 FP32_PEAK_TFLOPS = 157.3    # same guide: FP32 vector peak = FP32-input MFMA peak (256 CU x 4 SIMD x 64 flop/clk x 2.4 GHz)
-KERNEL = {"c4": "k_run_mimo_ofdm_mfma", "c2": "k_run_flat", "c3": "k_run_ofdm_tdl_mfma", "c5": "k_ia_link",
+KERNEL = {"c4": "k_run_mimo_ofdm_mfma", "c2": "k_run_flat_mfma", "c3": "k_run_ofdm_tdl_mfma", "c5": "k_ia_link",
           "f1": "k_run_mimo_ofdm_tdl", "f6": "k_bd_link"}
 KERNEL_NOTE = {   # configs whose step is two launches: the time spans both, the counters are the named (dominant) kernel's
     "c4": "a step = k_mimo_filters (channel draw + f64 receive filter per realization, 13 us = 0.8 % of the time) + k_run_mimo_ofdm_mfma; "

@@ -21,6 +21,7 @@
 #include "philox.hpp"
 #include "totals.hpp"
 #include "pipe_common.hpp"
+#include "qam_pack.hpp"
 
 namespace mcle {
 
@@ -197,6 +198,162 @@ __global__ __launch_bounds__(kPipeBlock) void k_run_flat(FlatParams fp, ModemPar
                             r = cadd(s, z[e]);
                         }
                         const unsigned x = (unsigned)(tx ^ demod_one(mp, s_table, s_grid, r));
+                        se += (x != 0u);
+                        be += __popc(x);
+                    }
+                }
+            }
+        }
+        block_sum2(se, be, s_red);
+        if (threadIdx.x == 0 && (se | be)) {
+            atomicAdd(&ws[2 * rl], se);
+            atomicAdd(&ws[2 * rl + 1], be);
+        }
+    }
+}
+
+// C2 on the matrix cores (f32, LR = 8 or 16 rays).  The 16 symbols of a group g share the ray phasors
+// p_l = e^{j (2 pi w_l t_g + psi_l)} taken at the group's first symbol, and the channel at symbol i of the group is
+//     h[i] = amp * sum_l e^{j 2 pi w_l dt i} p_l ,
+// a real [16 x 2 LR] matrix -- constant over a realization, its entries rounded once from f64 -- times the
+// [2 LR x groups] matrix of ray parts: v_mfma_f32_16x16x4_f32, 16 groups per product and LR / 2 products per plane, where
+// k_run_flat<float, LR> spends one complex rotation and one complex add per ray and symbol (6 VALU instructions).
+// Lane (j = lane & 15, b = lane >> 4) of a wavefront evaluates the ray parts 4 s + b (ray 2 s + (b >> 1); cosine or sine
+// by b & 1) of the groups G0 + 16 t + j, t < 4, and receives h for the symbols 4 b .. 4 b + 3 of those four groups: 16
+// symbols per lane and pass as in k_run_flat, in another order.  Data bytes: lane `lane` evaluates the Philox block of
+// group G0 + lane and the 4 x 4 (word, row) transpose by v_permlane32_swap / v_permlane16_swap leaves word b of the four
+// groups with lane (j, b); the noise of symbols 4 b .. 4 b + 3 is two whole Philox blocks.  Same draws and the same
+// decisions as k_run_flat up to f32 rounding (reference: fading_generators.py:421-470, singleuser.py:130-151).
+typedef float f4m __attribute__((ext_vector_type(4)));
+
+template <int LR>
+__global__ __launch_bounds__(kPipeBlock) void k_run_flat_mfma(FlatParams fp, ModemParams<float> mp, uint64_t seed,
+                                                              uint64_t first, uint64_t count, unsigned* __restrict__ ws) {
+    constexpr int KS = LR / 2;                          // k-steps of four ray parts
+    __shared__ float2 s_table[kMaxTable];
+    __shared__ float4 s_tab4[kMaxTable];                 // {re, im, |c|^2 / 2, 0}: the lockstep searches of modem.hpp
+    extern __shared__ unsigned long long s_grid[];       // [G*G] candidate grid (min-distance demodulation)
+    __shared__ double s_w[kMaxRays], s_psi[kMaxRays];
+    __shared__ unsigned s_red[2 * (kPipeBlock / 64)];
+    load_table(mp, s_table);
+    load_grid(mp, s_grid);
+    for (int m = threadIdx.x; m < mp.M; m += kPipeBlock) {
+        const float2 c = mp.g_table[m];
+        s_tab4[m] = make_float4(c.x, c.y, 0.5f * (c.x * c.x + c.y * c.y), 0.f);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, b = lane >> 4;
+    const bool packed = mp.method == MCLE_DEMOD_QAM_SLICER;
+    const bool lockstep = mp.method == MCLE_DEMOD_MINDIST && (mp.M <= 8 || mp.grid.G > 0);
+    QamPack qp{};
+    if (packed) qp = qam_pack(mp);
+    const uint32_t mask4 = (uint32_t)(mp.M - 1) * 0x01010101u;
+    const float sigma = (float)fp.noise_sigma;
+    const double amp = sqrt(1.0 / (double)LR);
+    const double two_pi = 6.283185307179586476925286766559;
+    const int chunks = (fp.n_symbols + kChunk - 1) / kChunk;
+    const uint64_t items = count * (uint64_t)chunks;
+    const uint64_t per_wg = (items + gridDim.x - 1) / gridDim.x;
+    const uint64_t item_end = min((uint64_t)(blockIdx.x + 1) * per_wg, items);
+    uint64_t last_rl = ~0ull;
+    double w[KS], psq[KS];        // this lane's rays: Doppler (Hz) and phase (turns; + 1/4 where the part is the cosine)
+    float a_re[KS], a_im[KS];     // A operands: row j (symbol in the group) x part 4 s + b
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        w[s] = psq[s] = 0.0;
+        a_re[s] = a_im[s] = 0.f;
+    }
+    for (uint64_t item = (uint64_t)blockIdx.x * per_wg; item < item_end; ++item) {
+        const uint64_t rl = item / chunks;
+        const int chunk = (int)(item - rl * chunks);
+        const Rng rng(seed, first + rl);
+        __syncthreads();
+        const bool fresh = rl != last_rl;
+        last_rl = rl;
+        if (fresh && (int)threadIdx.x < LR) {
+            // fading_generators.py:421-425: phi then psi, 2*pi*rand(L, 1, 1)
+            const double phi = two_pi * uniform_at(rng, STREAM_PHASE, threadIdx.x);
+            const double psi = two_pi * uniform_at(rng, STREAM_PHASE, LR + threadIdx.x);
+            s_w[threadIdx.x] = fp.Fd * cos(phi);
+            s_psi[threadIdx.x] = psi / two_pi;
+        }
+        __syncthreads();
+        if (fresh) {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const int l = 2 * s + (b >> 1);
+                w[s] = s_w[l];
+                psq[s] = s_psi[l] + ((b & 1) ? 0.0 : 0.25);
+                double sn, cs;
+                sincos(two_pi * ((w[s] * fp.dt) * (double)j), &sn, &cs);
+                a_re[s] = (float)(amp * ((b & 1) ? -sn : cs));
+                a_im[s] = (float)(amp * ((b & 1) ? cs : sn));
+            }
+        }
+        unsigned se = 0, be = 0;
+        const int n_begin = chunk * kChunk;
+        const int n_end = min(n_begin + kChunk, fp.n_symbols);
+        for (int gw = n_begin + wave * 1024; gw < n_end; gw += kPipeBlock * 16) {    // symbols gw .. gw + 1023
+            const Words4 dw = rng.block(STREAM_DATA, (uint32_t)((gw >> 4) + lane));
+            uint32_t d[4] = {dw.w[0], dw.w[1], dw.w[2], dw.w[3]};
+            {   // d[t] <- word b of the block evaluated by lane 16 t + j
+                auto p = __builtin_amdgcn_permlane32_swap(d[0], d[2], false, false);
+                auto q = __builtin_amdgcn_permlane32_swap(d[1], d[3], false, false);
+                auto r0 = __builtin_amdgcn_permlane16_swap(p[0], q[0], false, false);
+                auto r1 = __builtin_amdgcn_permlane16_swap(p[1], q[1], false, false);
+                d[0] = r0[0];
+                d[1] = r0[1];
+                d[2] = r1[0];
+                d[3] = r1[1];
+            }
+            // one tile of 16 groups per turn (rolled: the two accumulator chains of a tile already keep the matrix
+            // pipe's dependent issues 64 cycles apart, and the body is 4 x smaller in the instruction cache)
+#pragma unroll 1
+            for (int t = 0; t < 4; ++t) {
+                const double tt = jakes_time(fp.t0, fp.dt, (double)(gw + 16 * (16 * t + j)));
+                float bv[KS];
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    const double x = fma(w[s], tt, psq[s]);
+                    bv[s] = __builtin_amdgcn_sinf((float)(x - floor(x)));
+                }
+                f4m hre = {0.f, 0.f, 0.f, 0.f}, him = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    hre = __builtin_amdgcn_mfma_f32_16x16x4f32(a_re[s], bv[s], hre, 0, 0, 0);
+                    him = __builtin_amdgcn_mfma_f32_16x16x4f32(a_im[s], bv[s], him, 0, 0, 0);
+                }
+                const uint32_t dcur = d[0];
+                d[0] = d[1];
+                d[1] = d[2];
+                d[2] = d[3];
+                const int n0 = gw + 16 * (16 * t + j) + 4 * b;
+                if (n0 >= n_end) continue;
+                float2 z[4];
+                cn_pair<float>(rng, STREAM_NOISE, (uint32_t)(n0 >> 1), sigma, z[0], z[1]);
+                cn_pair<float>(rng, STREAM_NOISE, (uint32_t)(n0 >> 1) + 1u, sigma, z[2], z[3]);
+                const uint32_t dwt = dcur & mask4;
+                float2 r[4];
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+                    r[v] = flat_equalised(make_float2(hre[v], him[v]), s_table[(dwt >> (8 * v)) & 0xFFu], z[v]);
+                const int left = n_end - n0;          // >= 1 symbols of this quad exist
+                if (packed) {
+                    const f4q re = {r[0].x, r[1].x, r[2].x, r[3].x}, im = {r[0].y, r[1].y, r[2].y, r[3].y};
+                    uint32_t x = qam_levels4(re, im, qp) ^ labels_to_levels(dwt, qp);
+                    if (left < 4) x &= (1u << (8 * left)) - 1u;
+                    qam_count4(x, qp, se, be);
+                } else {
+                    int dec[4];
+                    if (lockstep) {
+                        if (mp.M <= 8) demod_mindist_multi<4>(s_tab4, mp.M, r, dec);
+                        else demod_grid4_multi<4>(s_tab4, s_grid, mp.grid, mp.M, r, dec);
+                    } else {
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) dec[v] = demod_one(mp, s_table, s_grid, r[v]);
+                    }
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const unsigned x = v < left ? (unsigned)(((dwt >> (8 * v)) & 0xFFu) ^ (unsigned)dec[v]) : 0u;
                         se += (x != 0u);
                         be += __popc(x);
                     }
@@ -694,7 +851,19 @@ int run_flat_impl(mcle_ctx* ctx, const FlatParams& fp, int method, uint64_t seed
     const unsigned grid = (unsigned)(items < cap ? items : cap);
     const ModemParams<T> mp = pipe_modem<T>(ctx, method);
     const size_t lds = (size_t)mp.grid.G * mp.grid.G * sizeof(unsigned long long);
-    if (sizeof(T) == 4 && fp.L == 8)
+    // f32 Jakes links of 8 / 16 rays: the ray sum on the matrix cores (MCLE_NO_MFMA=1 keeps the VALU recurrence below)
+    const bool mfma = sizeof(T) == 4 && !fp.rayleigh_iid && (fp.L == 8 || fp.L == 16) && !std::getenv("MCLE_NO_MFMA");
+    if constexpr (sizeof(T) == 4) {
+        if (mfma && fp.L == 8)
+            hipLaunchKernelGGL((k_run_flat_mfma<8>), dim3(grid), dim3(kPipeBlock), lds, ctx->stream, fp, mp, seed, first,
+                               count, ws);
+        else if (mfma)
+            hipLaunchKernelGGL((k_run_flat_mfma<16>), dim3(grid), dim3(kPipeBlock), lds, ctx->stream, fp, mp, seed, first,
+                               count, ws);
+    }
+    if (mfma)
+        ;
+    else if (sizeof(T) == 4 && fp.L == 8)
         hipLaunchKernelGGL((k_run_flat<T, 8>), dim3(grid), dim3(kPipeBlock), lds, ctx->stream, fp, mp, seed, first, count,
                            ws);
     else if (sizeof(T) == 4 && fp.L == 16)

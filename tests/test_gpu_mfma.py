@@ -169,3 +169,68 @@ def test_tdl_mfma_zero_noise_round_trip(engine):
     assert res["sym_errors"] <= 2e-4 * 4099 * 1024                            # deep fades of the one-tap channel only
     ref, se_v, be_v = _run_tdl(engine, 11, 4099, mfma=False, snr_db=300.0, method=_lib.DEMOD_QAM_SLICER)
     assert abs(res["sym_errors"] - ref["sym_errors"]) <= 1e-5 * 4099 * 1024 + 2
+
+
+# ---- config 2 on the matrix cores (csrc/pipelines.hip: k_run_flat_mfma) -----------------------------------------------
+def _run_flat(engine, first, count, mfma=True, **kw):
+    old = os.environ.get("MCLE_NO_MFMA")
+    try:
+        os.environ.pop("MCLE_NO_MFMA", None)
+        if not mfma:
+            os.environ["MCLE_NO_MFMA"] = "1"
+        nv = 0.0 if kw.get("snr_db") is None else 1.0 / omodem.dB2Linear(kw["snr_db"])
+        return engine.run_flat_fading(kw["N"], nv, SEED, first, count, Fd=kw.get("Fd", 100.0), Ts=kw.get("Ts", 1e-3),
+                                      L=kw.get("L", 8), method=kw.get("method", _lib.DEMOD_MINDIST), dtype="f32",
+                                      per_realization=True)
+    finally:
+        if old is None:
+            os.environ.pop("MCLE_NO_MFMA", None)
+        else:
+            os.environ["MCLE_NO_MFMA"] = old
+
+
+FLAT_CASES = [dict(mod="qam", M=64, N=20000, snr_db=20.0, method=_lib.DEMOD_QAM_SLICER),        # BASELINE config 2, shortened
+              dict(mod="qam", M=64, N=16384 + 1029, snr_db=24.0),                                # candidate grid, ragged tail
+              dict(mod="qam", M=16, N=4099, snr_db=14.0, L=16, Fd=250.0, method=_lib.DEMOD_QAM_SLICER),
+              dict(mod="psk", M=8, N=1000, snr_db=12.0, L=16, Ts=1e-4),                          # direct search, 16 rays
+              dict(mod="bpsk", M=2, N=17, snr_db=3.0),
+              dict(mod="qam", M=256, N=3000, snr_db=30.0, Fd=5.0, Ts=5e-3)]
+
+
+@pytest.mark.parametrize("case", range(len(FLAT_CASES)))
+def test_flat_mfma_kernel_against_the_oracle_and_the_valu_kernel(engine, case):
+    kw = dict(FLAT_CASES[case])
+    mod, M = kw.pop("mod"), kw.pop("M")
+    engine.set_constellation(chains.constellation(mod, M), _lib.CONST_QAM if mod == "qam" else _lib.CONST_GENERIC)
+    first, count = (1 << 33) + 5, 7
+    okw = dict(mod=mod, M=M, N=kw["N"], snr_db=kw["snr_db"], Fd=kw.get("Fd", 100.0), Ts=kw.get("Ts", 1e-3), L=kw.get("L", 8))
+    want = [chains.chain_flat_jakes(chains.PhiloxRng(SEED, r), **okw) for r in range(first, first + count)]
+    want_se = np.array([w["symbol_errors"] for w in want], dtype=np.int64)
+    want_be = np.array([w["bit_errors"] for w in want], dtype=np.int64)
+    nsym, nbits = want[0]["num_symbols"], want[0]["num_bits"]
+    res, se, be = _run_flat(engine, first, count, **kw)
+    assert res["n_symbols"] == nsym and res["n_bits"] == nbits and res["n_realizations"] == count
+    assert abs(int(se.sum()) - int(want_se.sum())) <= 1e-4 * count * nsym + 2
+    assert abs(int(be.sum()) - int(want_be.sum())) <= 1e-4 * count * nbits + 2
+    assert np.max(np.abs(se.astype(np.int64) - want_se)) <= 3                 # boundary ties only
+    res_v, se_v, be_v = _run_flat(engine, first, count, mfma=False, **kw)
+    assert np.max(np.abs(se.astype(np.int64) - se_v.astype(np.int64))) <= 3
+    assert np.max(np.abs(be.astype(np.int64) - be_v.astype(np.int64))) <= 4
+    assert res["sym_errors_sq"] == int((se.astype(np.int64) ** 2).sum())
+    assert res["bit_errors"] == int(be.astype(np.int64).sum())
+    a = _run_flat(engine, first, 3, **kw)                                     # any split of the realization range
+    b = _run_flat(engine, first + 3, count - 3, **kw)
+    assert np.array_equal(np.concatenate([a[1], b[1]]), se) and np.array_equal(np.concatenate([a[2], b[2]]), be)
+
+
+def test_flat_mfma_zero_noise_and_full_size(engine):
+    engine.set_constellation(chains.constellation("qam", 64), _lib.CONST_QAM)
+    for L in (8, 16):
+        for method in (_lib.DEMOD_QAM_SLICER, _lib.DEMOD_MINDIST):
+            res, se, be = _run_flat(engine, 3, 5, N=100000, snr_db=None, L=L, method=method)
+            assert res["n_realizations"] == 5 and res["sym_errors"] == 0      # h s / h = s whatever h is
+    nv = dict(N=100000, snr_db=20.0, method=_lib.DEMOD_QAM_SLICER)
+    res, se, be = _run_flat(engine, 0, 48, **nv)
+    ref, se_v, be_v = _run_flat(engine, 0, 48, mfma=False, **nv)
+    assert abs(res["sym_errors"] - ref["sym_errors"]) <= 1e-5 * 48 * 100000
+    assert np.max(np.abs(se.astype(np.int64) - se_v.astype(np.int64))) <= 6
