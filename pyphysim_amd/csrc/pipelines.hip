@@ -100,7 +100,8 @@ __device__ __forceinline__ float2 flat_equalised(float2 h, float2 s, float2 z) {
     return make_float2(fmaf(fmaf(z.x, h.x, z.y * h.y), inv, s.x), fmaf(fmaf(z.y, h.x, -(z.x * h.y)), inv, s.y));
 }
 
-template <typename T, int LR>
+// MODE (f32): 0 one demod_one per symbol (any method), 1 packed level-domain slicer, 2 lockstep min-distance search
+template <typename T, int LR, int MODE>
 __global__ __launch_bounds__(kPipeBlock) void k_run_flat(FlatParams fp, ModemParams<T> mp, uint64_t seed,
                                                          uint64_t first, uint64_t count, unsigned* __restrict__ ws) {
     constexpr bool kRec = (LR > 0) && (sizeof(T) == 4);
@@ -109,13 +110,21 @@ __global__ __launch_bounds__(kPipeBlock) void k_run_flat(FlatParams fp, ModemPar
     __shared__ double s_w[kMaxRays], s_psi[kMaxRays];
     __shared__ float2 s_rot[kMaxRays];
     __shared__ unsigned s_red[2 * (kPipeBlock / 64)];
+    __shared__ float4 s_tab4[MODE == 2 ? kMaxTable : 1];     // {re, im, |c|^2 / 2, 0}: the lockstep searches of modem.hpp
     load_table(mp, s_table);
     load_grid(mp, s_grid);
+    if constexpr (MODE == 2)
+        for (int m = threadIdx.x; m < mp.M; m += kPipeBlock) {
+            const float2 c = mp.g_table[m];
+            s_tab4[m] = make_float4(c.x, c.y, 0.5f * (c.x * c.x + c.y * c.y), 0.f);
+        }
     const int chunks = (fp.n_symbols + kChunk - 1) / kChunk;
     const uint64_t items = count * (uint64_t)chunks;
     const T sigma = (T)fp.noise_sigma;
     const T amp = fp.L > 0 ? (T)sqrt(1.0 / (double)fp.L) : (T)1;
-    const uint32_t mask = (uint32_t)(mp.M - 1);
+    const uint32_t mask4 = (uint32_t)(mp.M - 1) * 0x01010101u;
+    QamPack qp{};
+    if constexpr (MODE == 1) qp = qam_pack(mp);
     // every workgroup takes a contiguous run of items: consecutive chunks of one realization share the ray set-up
     // (two f64 cosines / sincos per ray), which is redone only when the realization changes
     const uint64_t per_wg = (items + gridDim.x - 1) / gridDim.x;
@@ -161,46 +170,67 @@ __global__ __launch_bounds__(kPipeBlock) void k_run_flat(FlatParams fp, ModemPar
                 }
             }
 #pragma unroll
-            for (int pr = 0; pr < 8; ++pr) {
-                cx<T> z[2];
-                cn_pair<T>(rng, STREAM_NOISE, (uint32_t)((g0 >> 1) + pr), sigma, z[0], z[1]);
+            for (int q = 0; q < 4; ++q) {             // four symbols at a time: two whole noise blocks, one data word
+                const int left = n_end - (g0 + 4 * q);
+                if (left <= 0) break;
+                cx<T> z[4], r[4];
+                cn_pair<T>(rng, STREAM_NOISE, (uint32_t)((g0 >> 1) + 2 * q), sigma, z[0], z[1]);
+                cn_pair<T>(rng, STREAM_NOISE, (uint32_t)((g0 >> 1) + 2 * q + 1), sigma, z[2], z[3]);
+                const uint32_t dwt = dw.w[q] & mask4;
 #pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const int j = 2 * pr + e, n = g0 + j;
-                    if (n < n_end) {
-                        const int tx = (int)((dw.w[j >> 2] >> ((j & 3) * 8)) & mask);
-                        const cx<T> s = s_table[tx];
-                        cx<T> r;
-                        if (kRec) {
-                            float hr = 0, hi = 0;
+                for (int e = 0; e < 4; ++e) {
+                    const int n = g0 + 4 * q + e;
+                    const cx<T> s = s_table[(dwt >> (8 * e)) & 0xFFu];
+                    if (kRec) {
+                        float hr = 0, hi = 0;
 #pragma unroll
-                            for (int l = 0; l < (kRec ? LR : 1); ++l) {
-                                hr += ray[l].x;
-                                hi += ray[l].y;
-                                ray[l] = cmul(ray[l], rot[l]);
-                            }
-                            const cx<T> h = mk<T>((T)(amp * hr), (T)(amp * hi));
-                            r = flat_equalised(h, s, z[e]);
-                        } else if (fp.L > 0) {
-                            const double t = jakes_time(fp.t0, fp.dt, (double)n);
-                            T hr = 0, hi = 0;
-                            for (int l = 0; l < fp.L; ++l) {
-                                const cx<T> rr = jakes_ray<T>(s_w[l], s_psi[l], t);
-                                hr += rr.x;
-                                hi += rr.y;
-                            }
-                            const cx<T> h = mk<T>(amp * hr, amp * hi);
-                            r = flat_equalised(h, s, z[e]);
-                        } else if (fp.rayleigh_iid) {
-                            const cx<T> h = cn_sample<T>(rng, STREAM_CHAN, (uint64_t)n, (T)1);
-                            r = flat_equalised(h, s, z[e]);
-                        } else {
-                            r = cadd(s, z[e]);
+                        for (int l = 0; l < (kRec ? LR : 1); ++l) {
+                            hr += ray[l].x;
+                            hi += ray[l].y;
+                            ray[l] = cmul(ray[l], rot[l]);
                         }
-                        const unsigned x = (unsigned)(tx ^ demod_one(mp, s_table, s_grid, r));
+                        const cx<T> h = mk<T>((T)(amp * hr), (T)(amp * hi));
+                        r[e] = flat_equalised(h, s, z[e]);
+                    } else if (fp.L > 0) {
+                        const double t = jakes_time(fp.t0, fp.dt, (double)n);
+                        T hr = 0, hi = 0;
+                        for (int l = 0; l < fp.L; ++l) {
+                            const cx<T> rr = jakes_ray<T>(s_w[l], s_psi[l], t);
+                            hr += rr.x;
+                            hi += rr.y;
+                        }
+                        const cx<T> h = mk<T>(amp * hr, amp * hi);
+                        r[e] = flat_equalised(h, s, z[e]);
+                    } else if (fp.rayleigh_iid) {
+                        const cx<T> h = cn_sample<T>(rng, STREAM_CHAN, (uint64_t)n, (T)1);
+                        r[e] = flat_equalised(h, s, z[e]);
+                    } else {
+                        r[e] = cadd(s, z[e]);
+                    }
+                }
+                if constexpr (MODE == 1) {   // the four decisions in one packed level-domain slice (qam_pack.hpp)
+                    const f4q re = {r[0].x, r[1].x, r[2].x, r[3].x}, im = {r[0].y, r[1].y, r[2].y, r[3].y};
+                    uint32_t x = qam_levels4(re, im, qp) ^ labels_to_levels(dwt, qp);
+                    if (left < 4) x &= (1u << (8 * left)) - 1u;
+                    qam_count4(x, qp, se, be);
+                } else if constexpr (MODE == 2) {   // the four symbols searched in lockstep (same decisions as demod_one)
+                    int dec[4];
+                    if (mp.M <= 8) demod_mindist_multi<4>(s_tab4, mp.M, r, dec);
+                    else demod_grid4_multi<4>(s_tab4, s_grid, mp.grid, mp.M, r, dec);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const unsigned x = e < left ? (unsigned)(((dwt >> (8 * e)) & 0xFFu) ^ (unsigned)dec[e]) : 0u;
                         se += (x != 0u);
                         be += __popc(x);
                     }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (e < left) {
+                            const unsigned x = (unsigned)(((dwt >> (8 * e)) & 0xFFu) ^ (unsigned)demod_one(mp, s_table, s_grid, r[e]));
+                            se += (x != 0u);
+                            be += __popc(x);
+                        }
                 }
             }
         }
@@ -226,26 +256,25 @@ __global__ __launch_bounds__(kPipeBlock) void k_run_flat(FlatParams fp, ModemPar
 // decisions as k_run_flat up to f32 rounding (reference: fading_generators.py:421-470, singleuser.py:130-151).
 typedef float f4m __attribute__((ext_vector_type(4)));
 
-template <int LR>
+template <int LR, int MODE>
 __global__ __launch_bounds__(kPipeBlock) void k_run_flat_mfma(FlatParams fp, ModemParams<float> mp, uint64_t seed,
                                                               uint64_t first, uint64_t count, unsigned* __restrict__ ws) {
     constexpr int KS = LR / 2;                          // k-steps of four ray parts
     __shared__ float2 s_table[kMaxTable];
-    __shared__ float4 s_tab4[kMaxTable];                 // {re, im, |c|^2 / 2, 0}: the lockstep searches of modem.hpp
+    __shared__ float4 s_tab4[MODE == 2 ? kMaxTable : 1]; // {re, im, |c|^2 / 2, 0}: the lockstep searches of modem.hpp
     extern __shared__ unsigned long long s_grid[];       // [G*G] candidate grid (min-distance demodulation)
     __shared__ double s_w[kMaxRays], s_psi[kMaxRays];
     __shared__ unsigned s_red[2 * (kPipeBlock / 64)];
     load_table(mp, s_table);
     load_grid(mp, s_grid);
-    for (int m = threadIdx.x; m < mp.M; m += kPipeBlock) {
-        const float2 c = mp.g_table[m];
-        s_tab4[m] = make_float4(c.x, c.y, 0.5f * (c.x * c.x + c.y * c.y), 0.f);
-    }
+    if constexpr (MODE == 2)
+        for (int m = threadIdx.x; m < mp.M; m += kPipeBlock) {
+            const float2 c = mp.g_table[m];
+            s_tab4[m] = make_float4(c.x, c.y, 0.5f * (c.x * c.x + c.y * c.y), 0.f);
+        }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, b = lane >> 4;
-    const bool packed = mp.method == MCLE_DEMOD_QAM_SLICER;
-    const bool lockstep = mp.method == MCLE_DEMOD_MINDIST && (mp.M <= 8 || mp.grid.G > 0);
     QamPack qp{};
-    if (packed) qp = qam_pack(mp);
+    if constexpr (MODE == 1) qp = qam_pack(mp);
     const uint32_t mask4 = (uint32_t)(mp.M - 1) * 0x01010101u;
     const float sigma = (float)fp.noise_sigma;
     const double amp = sqrt(1.0 / (double)LR);
@@ -337,14 +366,14 @@ __global__ __launch_bounds__(kPipeBlock) void k_run_flat_mfma(FlatParams fp, Mod
                 for (int v = 0; v < 4; ++v)
                     r[v] = flat_equalised(make_float2(hre[v], him[v]), s_table[(dwt >> (8 * v)) & 0xFFu], z[v]);
                 const int left = n_end - n0;          // >= 1 symbols of this quad exist
-                if (packed) {
+                if constexpr (MODE == 1) {
                     const f4q re = {r[0].x, r[1].x, r[2].x, r[3].x}, im = {r[0].y, r[1].y, r[2].y, r[3].y};
                     uint32_t x = qam_levels4(re, im, qp) ^ labels_to_levels(dwt, qp);
                     if (left < 4) x &= (1u << (8 * left)) - 1u;
                     qam_count4(x, qp, se, be);
                 } else {
                     int dec[4];
-                    if (lockstep) {
+                    if constexpr (MODE == 2) {
                         if (mp.M <= 8) demod_mindist_multi<4>(s_tab4, mp.M, r, dec);
                         else demod_grid4_multi<4>(s_tab4, s_grid, mp.grid, mp.M, r, dec);
                     } else {
@@ -851,27 +880,37 @@ int run_flat_impl(mcle_ctx* ctx, const FlatParams& fp, int method, uint64_t seed
     const unsigned grid = (unsigned)(items < cap ? items : cap);
     const ModemParams<T> mp = pipe_modem<T>(ctx, method);
     const size_t lds = (size_t)mp.grid.G * mp.grid.G * sizeof(unsigned long long);
-    // f32 Jakes links of 8 / 16 rays: the ray sum on the matrix cores (MCLE_NO_MFMA=1 keeps the VALU recurrence below)
+    // f32 Jakes links of 8 / 16 rays: the ray sum on the matrix cores (MCLE_NO_MFMA=1 keeps the VALU recurrence);
+    // the f32 kernels are specialised by demodulator (1 packed slicer, 2 lockstep min-distance search, 0 the rest)
     const bool mfma = sizeof(T) == 4 && !fp.rayleigh_iid && (fp.L == 8 || fp.L == 16) && !std::getenv("MCLE_NO_MFMA");
+    const int mode = sizeof(T) == 8 ? 0
+                     : mp.method == MCLE_DEMOD_QAM_SLICER ? 1
+                     : (mp.method == MCLE_DEMOD_MINDIST && (mp.M <= 8 || mp.grid.G > 0)) ? 2 : 0;
+    const int lr = sizeof(T) == 4 && !fp.rayleigh_iid && (fp.L == 8 || fp.L == 16) ? fp.L : 0;
+#define MCLE_FLAT_LAUNCH(KERN) \
+    hipLaunchKernelGGL((KERN), dim3(grid), dim3(kPipeBlock), lds, ctx->stream, fp, mp, seed, first, count, ws)
     if constexpr (sizeof(T) == 4) {
-        if (mfma && fp.L == 8)
-            hipLaunchKernelGGL((k_run_flat_mfma<8>), dim3(grid), dim3(kPipeBlock), lds, ctx->stream, fp, mp, seed, first,
-                               count, ws);
-        else if (mfma)
-            hipLaunchKernelGGL((k_run_flat_mfma<16>), dim3(grid), dim3(kPipeBlock), lds, ctx->stream, fp, mp, seed, first,
-                               count, ws);
+        switch ((mfma ? 100 : 0) + lr * 3 + mode) {
+            case 100 + 24 + 0: MCLE_FLAT_LAUNCH((k_run_flat_mfma<8, 0>)); break;
+            case 100 + 24 + 1: MCLE_FLAT_LAUNCH((k_run_flat_mfma<8, 1>)); break;
+            case 100 + 24 + 2: MCLE_FLAT_LAUNCH((k_run_flat_mfma<8, 2>)); break;
+            case 100 + 48 + 0: MCLE_FLAT_LAUNCH((k_run_flat_mfma<16, 0>)); break;
+            case 100 + 48 + 1: MCLE_FLAT_LAUNCH((k_run_flat_mfma<16, 1>)); break;
+            case 100 + 48 + 2: MCLE_FLAT_LAUNCH((k_run_flat_mfma<16, 2>)); break;
+            case 24 + 0: MCLE_FLAT_LAUNCH((k_run_flat<T, 8, 0>)); break;
+            case 24 + 1: MCLE_FLAT_LAUNCH((k_run_flat<T, 8, 1>)); break;
+            case 24 + 2: MCLE_FLAT_LAUNCH((k_run_flat<T, 8, 2>)); break;
+            case 48 + 0: MCLE_FLAT_LAUNCH((k_run_flat<T, 16, 0>)); break;
+            case 48 + 1: MCLE_FLAT_LAUNCH((k_run_flat<T, 16, 1>)); break;
+            case 48 + 2: MCLE_FLAT_LAUNCH((k_run_flat<T, 16, 2>)); break;
+            case 1: MCLE_FLAT_LAUNCH((k_run_flat<T, 0, 1>)); break;
+            case 2: MCLE_FLAT_LAUNCH((k_run_flat<T, 0, 2>)); break;
+            default: MCLE_FLAT_LAUNCH((k_run_flat<T, 0, 0>)); break;
+        }
+    } else {
+        MCLE_FLAT_LAUNCH((k_run_flat<T, 0, 0>));
     }
-    if (mfma)
-        ;
-    else if (sizeof(T) == 4 && fp.L == 8)
-        hipLaunchKernelGGL((k_run_flat<T, 8>), dim3(grid), dim3(kPipeBlock), lds, ctx->stream, fp, mp, seed, first, count,
-                           ws);
-    else if (sizeof(T) == 4 && fp.L == 16)
-        hipLaunchKernelGGL((k_run_flat<T, 16>), dim3(grid), dim3(kPipeBlock), lds, ctx->stream, fp, mp, seed, first,
-                           count, ws);
-    else
-        hipLaunchKernelGGL((k_run_flat<T, 0>), dim3(grid), dim3(kPipeBlock), lds, ctx->stream, fp, mp, seed, first, count,
-                           ws);
+#undef MCLE_FLAT_LAUNCH
     MCLE_LAUNCH_CHECK();
     return pipe_fold(ctx, ws, nullptr, count, (uint64_t)fp.n_symbols, d_counters, d_sym, d_bit);
 }
