@@ -69,7 +69,7 @@ KERNEL_NOTE = {   # configs whose step is two launches: the time spans both, the
           "kernel_ms_per_launch spans both",
     "c5": "a step = k_ia_solve_links (per-lane solve, ~18 % of the time) + k_ia_link (symbol walk); kernel_ms_per_launch spans both",
     "f6": "a step = k_bd_solve_links (per-lane solve) + k_bd_link (symbol walk); kernel_ms_per_launch spans both"}
-BATCH = {"c4": 65536, "c3": 131072, "c2": 4096, "c5": 262144, "f1": 98304, "f6": 131072}
+BATCH = {"c4": 65536, "c3": 131072, "c2": 16384, "c5": 262144, "f1": 98304, "f6": 131072}
 BITS = {"c2": 6, "c3": 2, "c4": 6, "c5": 4, "f1": 6, "f6": 2}
 SEED = 20260927
 SNR_DB = {"c1": 10.0, "c2": 20.0, "c3": 20.0, "c4": 25.0, "c5": 20.0, "f1": 25.0, "f6": 15.0}

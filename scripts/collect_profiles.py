@@ -32,7 +32,7 @@ CONFIGS = {
     "c4md": ("k_run_mimo_ofdm_mfma<", "k_run_mimo_ofdm_mfma<3,6> with the min-distance demodulator over the LDS table (bench.py --demod mindist), %d realizations per launch"),
     "f1": ("k_run_mimo_ofdm_tdl<", "k_run_mimo_ofdm_tdl<float,1024,4>, %d realizations per launch (bench.py --config f1)"),
     "c3": ("k_run_ofdm_tdl_mfma<", "k_run_ofdm_tdl_mfma<3> (f32, FFT 1024, 4 realizations per pass), %d realizations per launch (bench.py --config c3)"),
-    "c2": ("k_run_flat<", "k_run_flat<float,8>, %d realizations per launch (bench.py --config c2)"),
+    "c2": ("k_run_flat_mfma<", "k_run_flat_mfma<8,1> (f32, 8 Jakes rays on the matrix cores, packed slicer), %d realizations per launch (bench.py --config c2)"),
     "c5": ("k_ia_link<", "k_ia_link<float> (the symbol walk; k_ia_solve_links<float> runs before it, see c5_kernel_stats.csv), %d realizations per launch (bench.py --config c5)"),
     "f6": ("k_bd_link<", "k_bd_link<float,2> (the symbol walk; k_bd_solve_links<float,2> runs before it, see f6_kernel_stats.csv), %d realizations per launch (bench.py --config f6)"),
 }

@@ -162,7 +162,7 @@ N_MFMA_TRIALS = int(os.environ.get("MCLE_FUZZ_TRIALS", "10"))
 
 @pytest.mark.parametrize("trial", range(N_MFMA_TRIALS))
 def test_fuzz_matrix_core_kernels(engine, trial):
-    """f32, FFT 1024: the matrix-core kernels of configs 3 and 4 (and, through them, fft16.hpp) on random CP lengths,
+    """f32: the matrix-core kernels of configs 2, 3 and 4 (and, through the last two, fft16.hpp) on random CP lengths,
     band widths, symbol counts, tap sets and realization offsets -- against the oracle on the same draws, and against the
     VALU kernels they replace (MCLE_NO_MFMA=1)."""
     rs = np.random.RandomState(700 + trial + 1000 * OFFSET)
@@ -203,6 +203,15 @@ def test_fuzz_matrix_core_kernels(engine, trial):
     want = _oracle(chains.chain_mimo_ofdm, first, count, **kw)
     _check(*both(lambda: engine.run_mimo_ofdm(4, 4, fft, cp, used, n_sym, nv, SEED, first, count, mmse=mmse, method=method,
                                               dtype="f32", per_realization=True)), want, "f32", ("mimo_ofdm", kw))
+    # config 2 (k_run_flat_mfma: 8 / 16 rays): any length (ragged quads, groups, chunks), sampling time and Doppler
+    N = int(rs.choice([rs.randint(1, 70), rs.randint(70, 5000), 16384 + rs.randint(0, 3000)]))
+    Lf, Tsf, Fdf = int(rs.choice([8, 16])), float(10.0 ** rs.uniform(-5, -2.5)), float(rs.uniform(1, 300))
+    method = _lib.DEMOD_QAM_SLICER if (mod == "qam" and rs.randint(2)) else _lib.DEMOD_MINDIST
+    kw = dict(mod=mod, M=M, N=N, snr_db=snr - 6.0, Fd=Fdf, Ts=Tsf, L=Lf)
+    want = _oracle(chains.chain_flat_jakes, first, count, **kw)
+    _check(*both(lambda: engine.run_flat_fading(N, 1.0 / omodem.dB2Linear(snr - 6.0), SEED, first, count, Fd=Fdf, Ts=Tsf,
+                                                L=Lf, method=method, dtype="f32", per_realization=True)),
+           want, "f32", ("flat_jakes", kw))
 
 
 @pytest.mark.parametrize("trial", range(N_MFMA_TRIALS))
