@@ -1,6 +1,7 @@
 // kernels_channel.hip -- Jakes sum-of-sinusoids fading and the time-varying TDL convolution.
 // Reference: channels/fading_generators.py:427-523 (time axis, h = L^-1/2 sum_l exp(j(...))),
 // channels/fading.py:949-956 (tap = fading * sqrt(power)), :1080-1090 (SISO corrupt_data).
+#include <cstdlib>
 #include "fft.hpp"
 #include "jakes.hpp"
 #include "philox.hpp"
@@ -8,6 +9,15 @@
 namespace mcle {
 
 constexpr int kChBlock = 256;
+
+// Up to kParArg doubles of host parameters as a by-value kernel argument (3.5 KiB of the 4 KiB kernarg segment)
+constexpr int kParArg = 448;
+struct ParArg {
+    double v[kParArg];
+};
+__global__ void k_unpack_params(ParArg pa, double* __restrict__ dst, int n) {
+    if ((int)threadIdx.x < n) dst[threadIdx.x] = pa.v[threadIdx.x];
+}
 
 // d_par: [2*L*n_streams] doubles = {w[l,s]} then {psi[l,s]} (see jakes.hpp for the meaning of w)
 template <typename T>
@@ -27,6 +37,157 @@ __global__ __launch_bounds__(kChBlock) void k_jakes(const double* __restrict__ p
                 im += e.y;
             }
             h[(size_t)s * n + i] = mk<T>(a * re, a * im);
+        }
+    }
+}
+
+// The same sum on a uniform time axis (t_i = t0 + i dt) for L <= 16 rays, 128 consecutive samples per wavefront step.
+// Around the centre c = i0 - 1/2 of a block,
+//     e^{j (w_l t_{c +- (i + 1/2)} + psi_l)} = p_l . V_l[i]   resp.   p_l . conj(V_l[i]) ,
+//     p_l = e^{j (w_l t_c + psi_l)} ,   V_l[i] = e^{j w_l dt (i + 1/2)} ,   i < 64 ,
+// so a block needs ONE phasor per ray (evaluated as in k_jakes, at the half-sample time t_c) and the four real products
+// pr Vr, pi Vi, pr Vi, pi Vr of a ray serve the two samples c + (i + 1/2) and c - (i + 1/2) of lane i: four FMAs per ray
+// and PAIR of samples instead of one sincos per ray and sample.  V_l[lane] is L complex values in registers, set up once
+// per wavefront and stream; lane (q, l) = (lane / L, lane % L) evaluates the phasor of ray l for run q of a batch of 64 / L
+// runs of kSteps blocks and advances it from block to block by R_l = e^{j w_l dt 128}; the walk reads each phasor back
+// from LDS with a wave-uniform address (a broadcast read).  complex128, L = 8: 0.10 -> of the 8 TB/s write rate.
+// Values equal k_jakes' up to the rounding of w_l t (the reference's own noise floor, eps |w t|):
+// fading_generators.py:421-470.
+// LT: L rounded up to a multiple of four (rays l >= L carry a zero rotation).
+template <typename T, int LT>
+__global__ __launch_bounds__(kChBlock) void k_jakes_blocks(const double* __restrict__ par, int L, int n_streams,
+                                                           double t0, double dt, const double* __restrict__ amp,
+                                                           cx<T>* __restrict__ h, size_t n) {
+    const double two_pi = 6.283185307179586476925286766559;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
+    constexpr int kSteps = 4;                              // blocks a phasor is advanced over before it is re-evaluated
+    const int Q = 64 / L;                                  // phasors (runs of kSteps blocks) per batch
+    const int q_of = lane / L, l_of = lane - q_of * L;
+    const size_t n_blocks = (n + 127) / 128, n_batches = (n_blocks + (size_t)(Q * kSteps) - 1) / (size_t)(Q * kSteps);
+    const double* w = par;
+    const double* psi = par + (size_t)L * n_streams;
+    __shared__ cx<T> s_V[LT][64];                           // the rotation table of the stream, shared by the waves
+    __shared__ cx<T> s_p[kChBlock / 64][64];                // each wave's phasors of the current step
+    for (int s = blockIdx.y; s < n_streams; s += gridDim.y) {
+        __syncthreads();
+        for (int l = wave; l < LT; l += waves) {
+            const double th = (w[(size_t)(l < L ? l : 0) * n_streams + s] * dt) * ((double)lane + 0.5);   // f64: radians, f32: turns
+            double sn, cs;
+            sincos(sizeof(T) == 8 ? th : two_pi * th, &sn, &cs);
+            s_V[l][lane] = l < L ? mk<T>((T)cs, (T)sn) : mk<T>((T)0, (T)0);
+        }
+        __syncthreads();
+        cx<T> V[LT];
+#pragma unroll
+        for (int l = 0; l < LT; ++l) V[l] = s_V[l][lane];
+        const double wl = w[(size_t)l_of * n_streams + s], pl = psi[(size_t)l_of * n_streams + s];
+        cx<T> R;                                           // e^{j w_l dt 128}: this lane's ray, one block further
+        {
+            const double th = (wl * dt) * 128.0;
+            double sn, cs;
+            sincos(sizeof(T) == 8 ? th : two_pi * th, &sn, &cs);
+            R = mk<T>((T)cs, (T)sn);
+        }
+        const T a = (T)amp[s];
+        cx<T>* out = h + (size_t)s * n;
+        for (size_t bt = (size_t)blockIdx.x * waves + wave; bt < n_batches; bt += (size_t)gridDim.x * waves) {
+            const size_t b0 = bt * (size_t)(Q * kSteps);
+            cx<T> p = jakes_ray<T>(wl, pl, jakes_time(t0, dt, (double)((b0 + (size_t)q_of * kSteps) * 128 + 64) - 0.5));
+            for (int k = 0; k < kSteps; ++k) {
+                // the wave's phasors through LDS (the wave's own DS traffic executes in order; v_readlane into SGPR
+                // pairs cost a VALU -> SALU hand-over per operand and ran at a third of this)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                s_p[wave][lane] = p;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                for (int q = 0; q < Q; ++q) {
+                    const size_t blk = b0 + (size_t)q * kSteps + k;
+                    if (blk * 128 >= n) continue;
+                    T A = 0, B = 0, C = 0, D = 0;          // sums of pr Vr, pi Vi, pr Vi, pi Vr
+#pragma unroll
+                    for (int l = 0; l < LT; ++l) {
+                        const cx<T> pp = s_p[wave][(q * L + l) & 63];       // one address for the whole wave: a broadcast read
+                        A = fma(pp.x, V[l].x, A);
+                        B = fma(pp.y, V[l].y, B);
+                        C = fma(pp.x, V[l].y, C);
+                        D = fma(pp.y, V[l].x, D);
+                    }
+                    const size_t up = blk * 128 + 64 + lane, dn = blk * 128 + 63 - lane;
+                    if (up < n) out[up] = mk<T>(a * (A - B), a * (C + D));
+                    if (dn < n) out[dn] = mk<T>(a * (A + B), a * (D - C));
+                }
+                const T nx = fma(p.x, R.x, -(p.y * R.y)), ny = fma(p.x, R.y, p.y * R.x);
+                p = mk<T>(nx, ny);
+            }
+        }
+    }
+}
+
+// complex64 on the matrix cores (uniform time axis, L <= 16): a tile = 16 groups of 16 consecutive samples;
+//     h[16 g + i] = amp sum_l e^{j 2 pi w_l dt i} e^{j (2 pi w_l t_{16 g} + psi_l)}
+// is a real [16 x 2 LT] matrix (lane's A operands, per wavefront and stream) times the [2 LT x 16] matrix of ray parts
+// at the groups' first samples (one v_sin_f32 per part, f64 phase as everywhere): LT / 2 v_mfma_f32_16x16x4_f32 per plane.
+// Lane (j, b) holds ray parts 4 s + b of group j and receives samples 4 b .. 4 b + 3 of group j: 32 contiguous bytes per
+// lane, 2 KiB per wavefront and tile.  Same construction as k_run_flat_mfma (pipelines.hip).
+typedef float f4j __attribute__((ext_vector_type(4)));
+template <int LT>
+__global__ __launch_bounds__(kChBlock) void k_jakes_mfma(const double* __restrict__ par, int L, int n_streams, double t0,
+                                                         double dt, const double* __restrict__ amp,
+                                                         float2* __restrict__ h, size_t n) {
+    constexpr int KS = LT / 2;
+    const double two_pi = 6.283185307179586476925286766559;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, waves = blockDim.x >> 6, j = lane & 15, b = lane >> 4;
+    const size_t n_tiles = (n + 255) / 256;
+    const double* w = par;
+    const double* psi = par + (size_t)L * n_streams;
+    for (int s = blockIdx.y; s < n_streams; s += gridDim.y) {
+        double wl[KS], pq[KS];
+        float a_re[KS], a_im[KS];
+        const double a = amp[s];
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+            const int l = 2 * k + (b >> 1);
+            const bool live = l < L;
+            wl[k] = live ? w[(size_t)l * n_streams + s] : 0.0;
+            pq[k] = (live ? psi[(size_t)l * n_streams + s] : 0.0) + ((b & 1) ? 0.0 : 0.25);
+            double sn, cs;
+            sincos(two_pi * ((wl[k] * dt) * (double)j), &sn, &cs);
+            a_re[k] = live ? (float)(a * ((b & 1) ? -sn : cs)) : 0.f;
+            a_im[k] = live ? (float)(a * ((b & 1) ? cs : sn)) : 0.f;
+        }
+        float2* out = h + (size_t)s * n;
+        for (size_t tile = (size_t)blockIdx.x * waves + wave; tile < n_tiles; tile += (size_t)gridDim.x * waves) {
+            const size_t g0 = tile * 256 + 16 * (size_t)j;
+            const double tt = jakes_time(t0, dt, (double)g0);
+            float bv[KS];
+#pragma unroll
+            for (int k = 0; k < KS; ++k) {
+                const double x = fma(wl[k], tt, pq[k]);
+                bv[k] = __builtin_amdgcn_sinf((float)(x - floor(x)));
+            }
+            f4j hre = {0.f, 0.f, 0.f, 0.f}, him = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < KS; ++k) {
+                hre = __builtin_amdgcn_mfma_f32_16x16x4f32(a_re[k], bv[k], hre, 0, 0, 0);
+                him = __builtin_amdgcn_mfma_f32_16x16x4f32(a_im[k], bv[k], him, 0, 0, 0);
+            }
+            const size_t i = g0 + 4 * (size_t)b;
+            if (i + 4 <= n) {
+                float4* o = reinterpret_cast<float4*>(out + i);       // 32-byte aligned when n is even; 8-byte always
+                if (((size_t)(out + i) & 15) == 0) {
+                    o[0] = make_float4(hre[0], him[0], hre[1], him[1]);
+                    o[1] = make_float4(hre[2], him[2], hre[3], him[3]);
+                } else {
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) out[i + v] = make_float2(hre[v], him[v]);
+                }
+            } else {
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+                    if (i + v < n) out[i + v] = make_float2(hre[v], him[v]);
+            }
         }
     }
 }
@@ -253,12 +414,63 @@ static int jakes_impl(mcle_ctx* ctx, int dtype, const double* phi, const double*
         host[2 * np + s] = inv_sqrt_L * (tap_power ? std::sqrt(tap_power[s]) : 1.0);
     void* d_par = nullptr;
     if ((rc = ctx->scratch(host.size() * sizeof(double), &d_par))) return rc;
-    MCLE_HIP(hipMemcpyAsync(d_par, host.data(), host.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    MCLE_HIP(hipStreamSynchronize(ctx->stream));  // `host` goes out of scope
+    if (host.size() <= (size_t)kParArg) {   // small parameter sets travel as a kernel argument: no copy to wait for
+        ParArg pa;
+        for (size_t i = 0; i < host.size(); ++i) pa.v[i] = host[i];
+        hipLaunchKernelGGL(k_unpack_params, dim3(1), dim3(kParArg), 0, ctx->stream, pa, (double*)d_par, (int)host.size());
+        MCLE_LAUNCH_CHECK();
+    } else {
+        MCLE_HIP(hipMemcpyAsync(d_par, host.data(), host.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        MCLE_HIP(hipStreamSynchronize(ctx->stream));  // `host` goes out of scope
+    }
     const double* d_amp = (const double*)d_par + 2 * np;
     const double* d_times = times ? d_amp + n_streams : nullptr;
+    const unsigned gy = (unsigned)(n_streams < 64 ? n_streams : 64);
+    if (!times && L <= 16 && n_samples >= 1024 && !std::getenv("MCLE_JAKES_DIRECT")) {
+        // uniform time axis: 64-sample blocks, one phasor per ray and block (k_jakes_blocks / k_jakes_mfma)
+        const int lt = (L + 3) / 4;
+        const size_t cap = (size_t)(ctx->n_cu > 0 ? ctx->n_cu : 256) * 4 / gy + 1;
+        if (dtype == MCLE_F32 && !std::getenv("MCLE_NO_MFMA")) {      // complex64: the matrix-core form
+            const size_t n_tiles = (n_samples + 255) / 256;
+            size_t gxm = (n_tiles + 4 * 16 - 1) / (4 * 16);
+            if (gxm > 2 * cap) gxm = 2 * cap;
+            dim3 gridm((unsigned)gxm, gy);
+#define MCLE_JAKES_MFMA(LTT)                                                                                          \
+    hipLaunchKernelGGL((k_jakes_mfma<LTT>), gridm, dim3(kChBlock), 0, ctx->stream, (const double*)d_par, L, n_streams,  \
+                       t0, dt, d_amp, (float2*)d_h, n_samples)
+            if (lt == 1) MCLE_JAKES_MFMA(4);
+            else if (lt == 2) MCLE_JAKES_MFMA(8);
+            else if (lt == 3) MCLE_JAKES_MFMA(12);
+            else MCLE_JAKES_MFMA(16);
+#undef MCLE_JAKES_MFMA
+            MCLE_LAUNCH_CHECK();
+            return MCLE_OK;
+        }
+        const size_t per_batch = (size_t)(64 / L) * 4;               // blocks of 128 samples per batch (kSteps = 4)
+        const size_t n_batches = ((n_samples + 127) / 128 + per_batch - 1) / per_batch;
+        size_t gxb = (n_batches + 3) / 4;                            // a batch per wavefront, up to 4 waves per SIMD
+        if (gxb > cap) gxb = cap;
+        dim3 gridb((unsigned)gxb, gy);
+#define MCLE_JAKES_BLOCKS(TT, CT, LTT)                                                                                 \
+    hipLaunchKernelGGL((k_jakes_blocks<TT, LTT>), gridb, dim3(kChBlock), 0, ctx->stream, (const double*)d_par, L,        \
+                       n_streams, t0, dt, d_amp, (CT*)d_h, n_samples)
+        if (dtype == MCLE_F32) {
+            if (lt == 1) MCLE_JAKES_BLOCKS(float, float2, 4);
+            else if (lt == 2) MCLE_JAKES_BLOCKS(float, float2, 8);
+            else if (lt == 3) MCLE_JAKES_BLOCKS(float, float2, 12);
+            else MCLE_JAKES_BLOCKS(float, float2, 16);
+        } else {
+            if (lt == 1) MCLE_JAKES_BLOCKS(double, double2, 4);
+            else if (lt == 2) MCLE_JAKES_BLOCKS(double, double2, 8);
+            else if (lt == 3) MCLE_JAKES_BLOCKS(double, double2, 12);
+            else MCLE_JAKES_BLOCKS(double, double2, 16);
+        }
+#undef MCLE_JAKES_BLOCKS
+        MCLE_LAUNCH_CHECK();
+        return MCLE_OK;
+    }
     unsigned gx = (unsigned)grid_for(ctx, n_samples, kChBlock, 4);
-    dim3 grid(gx, (unsigned)(n_streams < 64 ? n_streams : 64));
+    dim3 grid(gx, gy);
     if (dtype == MCLE_F32)
         hipLaunchKernelGGL(k_jakes<float>, grid, dim3(kChBlock), 0, ctx->stream, (const double*)d_par, L, n_streams,
                            t0, dt, d_times, d_amp, (float2*)d_h, n_samples);

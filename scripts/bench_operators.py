@@ -34,6 +34,23 @@ def timed(name, fn, nbytes):
                  "frac_of_8TBps": nbytes / ms / 1e6 / 8000.0})
 
 
+ONLY = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--only=")]
+
+
+def jakes_rows(cases):
+    """The Jakes generator alone: S streams of N / S samples, L rays, written once (no input but 2 L S phases)."""
+    rs = np.random.RandomState(5)
+    for L, S in cases:
+        n = N // S
+        phi, psi = rs.uniform(0, 2 * np.pi, (L, S)), rs.uniform(0, 2 * np.pi, (L, S))
+        timed("jakes_generate L=%d, %d streams (-> %d B)" % (L, S, CB),
+              lambda: eng.jakes_generate(phi, psi, 100.0, 1e-3, 1e-3, n, device=True), N * CB)
+
+
+if ONLY == ["jakes"]:
+    jakes_rows(((8, 16), (16, 16), (12, 16)))
+    print(json.dumps({"device": eng.device_name, "dtype": DT, "bytes_per_sample": CB, "n_symbols": N, "rows": rows}, indent=1))
+    sys.exit(0)
 idx = eng.rand_symbols(N, 64, 1, 2, device=True)
 tx = eng.modulate(idx)
 noise = eng.randn_c(N, 1, 2, device=True)
@@ -48,6 +65,7 @@ dec = eng.demodulate(rx, method=_lib.DEMOD_QAM_SLICER)
 timed("count_errors (4 + 4 -> counters)", lambda: eng.count_errors(idx, dec, 6, n_real=1024, counters=cnt), N * 8)
 timed("cdiv (8+8 -> 8)", lambda: eng.cdiv(rx, tx), N * 3 * CB)
 timed("randn_c Philox (-> 8)", lambda: eng.randn_c(N, 1, 2, device=True), N * CB)
+jakes_rows(((8, 16), (16, 16)))
 nsym = N // 1024
 timed("ofdm_modulate 1024+16 (8 -> 8.1)", lambda: eng.ofdm_modulate(tx, 1024, 16, 1024), N * CB + nsym * 1040 * CB)
 t = eng.ofdm_modulate(tx, 1024, 16, 1024)

@@ -237,6 +237,34 @@ def test_rayleigh_class_mirror_draws(engine):
 
 
 @pytest.mark.parametrize("dt", ["f64", "f32"])
+def test_jakes_block_kernel_equals_the_direct_sum(engine, dt):
+    """k_jakes_blocks (uniform time axis, L <= 16, >= 1024 samples: one phasor per ray and 64-sample block times the lane's
+    rotation) against the closed form sample by sample (NumPy, fading_generators.py:519-522) and against k_jakes
+    (MCLE_JAKES_DIRECT=1), for ray counts around the four instantiations, ragged lengths and late start times."""
+    import os
+    rs = np.random.RandomState(31)
+    tol = 1e-9 if dt == "f64" else 3e-5
+    for L, S, n, t0, step, Fd in ((8, 1, 100000, 1e-3, 1e-3, 100.0), (1, 3, 1024, 0.0, 1e-4, 30.0), (5, 2, 4097, 7.5, 1e-3, 250.0),
+                                  (12, 4, 70001, 1e-3, 2e-5, 900.0), (16, 2, 65536, 123.0, 1e-3, 100.0), (13, 1, 5000, 0.0, 1e-2, 5.0),
+                                  (20, 2, 3000, 0.0, 1e-3, 100.0)):          # L = 20: outside the block kernel, k_jakes runs
+        phi, psi = rs.uniform(0, 2 * np.pi, (L, S)), rs.uniform(0, 2 * np.pi, (L, S))
+        t = t0 + np.arange(n) * step
+        want = och.jakes_samples(phi[:, :, None], psi[:, :, None], Fd, t)
+        pw = rs.uniform(0.1, 1.0, S)
+        h = engine.jakes_generate(phi, psi, Fd, t0, step, n, tap_power=pw, dtype=dt)
+        assert h.shape == (S, n)
+        assert np.max(np.abs(h - np.sqrt(pw)[:, None] * want)) <= tol * max(1.0, 1e3 * abs(t0)), (L, S, n)
+        os.environ["MCLE_JAKES_DIRECT"] = "1"
+        try:
+            ref = engine.jakes_generate(phi, psi, Fd, t0, step, n, tap_power=pw, dtype=dt)
+        finally:
+            os.environ.pop("MCLE_JAKES_DIRECT", None)
+        assert np.max(np.abs(h - ref)) <= tol * max(1.0, 1e3 * abs(t0)), (L, S, n)
+        if L > 16:
+            assert np.array_equal(h, ref)
+
+
+@pytest.mark.parametrize("dt", ["f64", "f32"])
 def test_jakes_tdl_equalizer_injected(engine, dt):
     """C2 / C3 with the reference's phi, psi and noise injected."""
     for kw, reals in golden_cases("c2_flat_jakes"):
