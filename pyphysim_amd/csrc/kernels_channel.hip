@@ -595,8 +595,15 @@ int mcle_jakes_taps_philox(mcle_ctx* ctx, int dtype, uint64_t seed, uint64_t fir
     if (rc) return rc;
     void* d_amp = nullptr;
     if ((rc = ctx->scratch(n_streams * sizeof(double), &d_amp))) return rc;
-    MCLE_HIP(hipMemcpyAsync(d_amp, stream_amp, n_streams * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    MCLE_HIP(hipStreamSynchronize(ctx->stream));
+    if (n_streams <= kParArg) {              // as a kernel argument: nothing to wait for
+        ParArg pa;
+        for (int i = 0; i < n_streams; ++i) pa.v[i] = stream_amp[i];
+        hipLaunchKernelGGL(k_unpack_params, dim3(1), dim3(kParArg), 0, ctx->stream, pa, (double*)d_amp, n_streams);
+        MCLE_LAUNCH_CHECK();
+    } else {
+        MCLE_HIP(hipMemcpyAsync(d_amp, stream_amp, n_streams * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        MCLE_HIP(hipStreamSynchronize(ctx->stream));
+    }
     int sb = kChBlock / L;                                    // streams per workgroup
     if (sb > 16) sb = 16;
     if (sb > n_streams) sb = n_streams;
