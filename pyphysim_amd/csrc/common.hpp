@@ -113,6 +113,35 @@ __device__ __forceinline__ int opaque(int v) {
     return v;
 }
 
+// Sum of `len` consecutive complex samples by one wavefront (every lane gets the total): four independent
+// accumulators per lane, so the loads of a run are in flight together instead of one behind the other.
+template <typename C>
+__device__ __forceinline__ C wave_sum_run(const C* __restrict__ src, int len, int lane) {
+    auto re0 = src[0].x * 0, im0 = re0, re1 = re0, im1 = re0, re2 = re0, im2 = re0, re3 = re0, im3 = re0;
+    int j = lane;
+    for (; j + 192 < len; j += 256) {
+        const C a = src[j], b = src[j + 64], c = src[j + 128], d = src[j + 192];
+        re0 += a.x; im0 += a.y;
+        re1 += b.x; im1 += b.y;
+        re2 += c.x; im2 += c.y;
+        re3 += d.x; im3 += d.y;
+    }
+    for (; j < len; j += 64) {
+        re0 += src[j].x;
+        im0 += src[j].y;
+    }
+    auto re = (re0 + re1) + (re2 + re3), im = (im0 + im1) + (im2 + im3);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        re += __shfl_xor(re, off, 64);
+        im += __shfl_xor(im, off, 64);
+    }
+    C r;
+    r.x = re;
+    r.y = im;
+    return r;
+}
+
 __device__ __forceinline__ unsigned wave_sum_u32(unsigned v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);

@@ -348,16 +348,8 @@ __global__ __launch_bounds__(kChBlock) void k_mean_freq_response(const cx<T>* __
         __syncthreads();
         for (int q = wave; q < n_taps * P; q += nwave) {  // one wavefront per (tap, link) mean
             const cx<T>* src = g + (size_t)q * total + sym * (size_t)(n + cp);
-            T re = 0, im = 0;
-            for (int j = lane; j < n + cp; j += 64) {
-                re += src[j].x;
-                im += src[j].y;
-            }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                re += __shfl_xor(re, off, 64);
-                im += __shfl_xor(im, off, 64);
-            }
+            const cx<T> tot = wave_sum_run(src, n + cp, lane);
+            const T re = tot.x, im = tot.y;
             if (lane == 0) s_mean[q] = mk<T>(re / (T)(n + cp), im / (T)(n + cp));
         }
         __syncthreads();

@@ -200,10 +200,15 @@ __global__ __launch_bounds__(kMimoBlock) void k_alamouti_encode(const cx<T>* __r
     }
 }
 
+template <typename T> struct alignas(2 * sizeof(cx<T>)) CxPair {
+    cx<T> a, b;
+};
+
 // d[2i] = h0^H y[:,2i] + h1^T conj(y[:,2i+1]);  d[2i+1] = h1^H y[:,2i] - h0^T conj(y[:,2i+1]);  / |H|_F^2 * sqrt(2)
 template <typename T>
 __global__ __launch_bounds__(kMimoBlock) void k_alamouti_decode(const cx<T>* __restrict__ H, const cx<T>* __restrict__ Y,
-                                                                int nr, size_t n, T root2, cx<T>* __restrict__ out) {
+                                                                int nr, size_t n, T root2, cx<T>* __restrict__ out,
+                                                                bool vec) {
     const size_t b = blockIdx.y;
     const cx<T>* Hb = H + b * (size_t)nr * 2;
     const cx<T>* Yb = Y + b * (size_t)nr * n;
@@ -213,19 +218,40 @@ __global__ __launch_bounds__(kMimoBlock) void k_alamouti_decode(const cx<T>* __r
         for (int a = 0; a < 2; ++a) acc += Hb[r * 2 + a].x * Hb[r * 2 + a].x + Hb[r * 2 + a].y * Hb[r * 2 + a].y;
     const T nrm = sqrt(acc);
     const T fro2 = nrm * nrm;
+    const T g = root2 / fro2;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n / 2; i += (size_t)gridDim.x * blockDim.x) {
         cx<T> a0 = mk<T>(0, 0), a1 = mk<T>(0, 0), b0 = mk<T>(0, 0), b1 = mk<T>(0, 0);
         for (int r = 0; r < nr; ++r) {
             const cx<T> h0 = Hb[r * 2], h1 = Hb[r * 2 + 1];
-            const cx<T> y0 = Yb[(size_t)r * n + 2 * i], y1c = cconj(Yb[(size_t)r * n + 2 * i + 1]);
+            cx<T> y0, y1c;
+            if (vec) {     // the pair in one 16-byte (32-byte) access: n is even, so a row's pairs are aligned with the base
+                const CxPair<T> yy = reinterpret_cast<const CxPair<T>*>(Yb + (size_t)r * n)[i];
+                y0 = yy.a;
+                y1c = cconj(yy.b);
+            } else {
+                y0 = Yb[(size_t)r * n + 2 * i];
+                y1c = cconj(Yb[(size_t)r * n + 2 * i + 1]);
+            }
             a0 = cadd(a0, cmul(cconj(h0), y0));
             a1 = cadd(a1, cmul(h1, y1c));
             b0 = cadd(b0, cmul(cconj(h1), y0));
             b1 = cadd(b1, cmul(mk<T>(-h0.x, -h0.y), y1c));
         }
         const cx<T> d0 = cadd(a0, a1), d1 = cadd(b0, b1);
-        out[b * n + 2 * i] = mk<T>(d0.x / fro2 * root2, d0.y / fro2 * root2);
-        out[b * n + 2 * i + 1] = mk<T>(d1.x / fro2 * root2, d1.y / fro2 * root2);
+        CxPair<T> o;
+        if (sizeof(T) == 8) {       // the reference's order of operations: / |H|_F^2, then * sqrt(2)
+            o.a = mk<T>(d0.x / fro2 * root2, d0.y / fro2 * root2);
+            o.b = mk<T>(d1.x / fro2 * root2, d1.y / fro2 * root2);
+        } else {
+            o.a = mk<T>(d0.x * g, d0.y * g);
+            o.b = mk<T>(d1.x * g, d1.y * g);
+        }
+        if (vec) {
+            reinterpret_cast<CxPair<T>*>(out + b * n)[i] = o;
+        } else {
+            out[b * n + 2 * i] = o.a;
+            out[b * n + 2 * i + 1] = o.b;
+        }
     }
 }
 
@@ -233,15 +259,19 @@ __global__ __launch_bounds__(kMimoBlock) void k_alamouti_decode(const cx<T>* __r
 template <typename T>
 __global__ __launch_bounds__(kMimoBlock) void k_mrt_encode(const cx<T>* __restrict__ h, const cx<T>* __restrict__ x,
                                                            int nt, size_t n, cx<T>* __restrict__ X) {
+    __shared__ cx<T> s_w[64];                               // nt <= 64 (check_mimo): the precoder, once per workgroup
     const size_t b = blockIdx.y;
-    const double inv = 1.0 / sqrt((double)nt);
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n * nt; i += (size_t)gridDim.x * blockDim.x) {
-        const size_t a = i / n, c = i - a * n;
-        const cx<T> ha = h[b * nt + a];
+    if ((int)threadIdx.x < nt) {
+        const double inv = 1.0 / sqrt((double)nt);
+        const cx<T> ha = h[b * nt + threadIdx.x];
         double sn, cs;
         sincos(-atan2((double)ha.y, (double)ha.x), &sn, &cs);
-        const cx<T> w = mk<T>((T)(cs * inv), (T)(sn * inv));
-        X[b * n * nt + i] = cmul(w, x[b * n + c]);
+        s_w[threadIdx.x] = mk<T>((T)(cs * inv), (T)(sn * inv));
+    }
+    __syncthreads();
+    for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < n; c += (size_t)gridDim.x * blockDim.x) {
+        const cx<T> xv = x[b * n + c];                      // read once, written to every antenna's row
+        for (int a = 0; a < nt; ++a) X[(b * nt + a) * n + c] = cmul(s_w[a], xv);
     }
 }
 template <typename T>
@@ -476,12 +506,14 @@ int mcle_alamouti_decode(mcle_ctx* ctx, int dtype, const void* d_H, const void* 
     if (n == 0 || batch == 0) return MCLE_OK;
     if ((rc = ctx->bind())) return rc;
     dim3 grid((unsigned)grid_for(ctx, n / 2, kMimoBlock, 4), (unsigned)batch);
+    const size_t pair = dtype == MCLE_F32 ? 16 : 32;
+    const bool vec = ((uintptr_t)d_Y % pair) == 0 && ((uintptr_t)d_out % pair) == 0;
     if (dtype == MCLE_F32)
         hipLaunchKernelGGL(k_alamouti_decode<float>, grid, dim3(kMimoBlock), 0, ctx->stream, (const float2*)d_H,
-                           (const float2*)d_Y, nr, n, (float)std::sqrt(2.0), (float2*)d_out);
+                           (const float2*)d_Y, nr, n, (float)std::sqrt(2.0), (float2*)d_out, vec);
     else
         hipLaunchKernelGGL(k_alamouti_decode<double>, grid, dim3(kMimoBlock), 0, ctx->stream, (const double2*)d_H,
-                           (const double2*)d_Y, nr, n, std::sqrt(2.0), (double2*)d_out);
+                           (const double2*)d_Y, nr, n, std::sqrt(2.0), (double2*)d_out, vec);
     MCLE_LAUNCH_CHECK();
     return MCLE_OK;
 }
@@ -492,7 +524,7 @@ int mcle_mrt_encode(mcle_ctx* ctx, int dtype, const void* d_h, const void* d_x, 
     if (rc) return rc;
     if (n == 0 || batch == 0) return MCLE_OK;
     if ((rc = ctx->bind())) return rc;
-    dim3 grid((unsigned)grid_for(ctx, n * nt, kMimoBlock, 4), (unsigned)batch);
+    dim3 grid((unsigned)grid_for(ctx, n, kMimoBlock, 4), (unsigned)batch);
     if (dtype == MCLE_F32)
         hipLaunchKernelGGL(k_mrt_encode<float>, grid, dim3(kMimoBlock), 0, ctx->stream, (const float2*)d_h,
                            (const float2*)d_x, nt, n, (float2*)d_X);

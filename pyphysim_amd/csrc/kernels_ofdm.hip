@@ -190,33 +190,13 @@ __global__ __launch_bounds__(kOfdmBlock) void k_onetap_eq(const cx<T>* __restric
                                                           int n_taps, size_t n_sym, int n, int cp, int num_used,
                                                           int mask, const cx<T>* __restrict__ tw,
                                                           cx<T>* __restrict__ out) {
-    __shared__ cx<T> s_part[MCLE_MAX_TAPS][kOfdmBlock / 64];
     __shared__ cx<T> s_mean[MCLE_MAX_TAPS];
     const size_t total = n_sym * (size_t)(n + cp);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (size_t sym = blockIdx.x; sym < n_sym; sym += gridDim.x) {
-        for (int i = 0; i < n_taps; ++i) {
-            const cx<T>* g = taps + (size_t)i * total + sym * (size_t)(n + cp);
-            T re = 0, im = 0;
-            for (int j = threadIdx.x; j < n + cp; j += blockDim.x) {
-                re += g[j].x;
-                im += g[j].y;
-            }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                re += __shfl_xor(re, off, 64);
-                im += __shfl_xor(im, off, 64);
-            }
-            if (lane == 0) s_part[i][wave] = mk<T>(re, im);
-        }
-        __syncthreads();
-        if (threadIdx.x < n_taps) {
-            T re = 0, im = 0;
-            for (int w = 0; w < kOfdmBlock / 64; ++w) {
-                re += s_part[threadIdx.x][w].x;
-                im += s_part[threadIdx.x][w].y;
-            }
-            s_mean[threadIdx.x] = mk<T>(re / (T)(n + cp), im / (T)(n + cp));
+        for (int i = wave; i < n_taps; i += kOfdmBlock / 64) {     // one wavefront per tap mean
+            const cx<T> tot = wave_sum_run(taps + (size_t)i * total + sym * (size_t)(n + cp), n + cp, lane);
+            if (lane == 0) s_mean[i] = mk<T>(tot.x / (T)(n + cp), tot.y / (T)(n + cp));
         }
         __syncthreads();
         for (int d = threadIdx.x; d < num_used; d += blockDim.x) {

@@ -78,4 +78,29 @@ timed("mimo_channel 4x4 (H X)", lambda: eng.mimo_channel(H, X), b * 4 * ns * 2 *
 G, _ = eng.blast_filter(H, 0.01)
 timed("blast_decode 4x4 (G Y)", lambda: eng.blast_decode(G, X), b * 4 * ns * 2 * CB)
 timed("blast_encode (transpose)", lambda: eng.blast_encode(tx, 4, batch=b), N * 2 * CB)
+# ---- channel-side operators (a9 / a10) and the remaining MIMO schemes (a13) ------------------------------------------------
+n5 = N // 8
+x5 = eng.randn_c(n5, 13, 14, device=True)
+delays5 = np.arange(5, dtype=np.int32)
+taps5 = eng.randn_c(5 * n5, 5, 6, device=True).reshape(5, n5)
+timed("tdl_apply 5 taps (x + 5 taps -> y)", lambda: eng.tdl_apply(x5, taps5, delays5), n5 * 7 * CB)
+nsym5 = n5 // 1040
+d5 = eng.randn_c(nsym5 * 1024, 15, 16, device=True)
+t5 = eng.randn_c(5 * nsym5 * 1040, 17, 18, device=True).reshape(5, nsym5 * 1040)
+timed("onetap_equalize 1024+16, 5 taps (data + taps -> data)", lambda: eng.onetap_equalize(d5, t5, delays5, 1024, 16, 1024),
+      nsym5 * (2 * 1024 + 5 * 1040) * CB)
+timed("tdl_mean_freq_response 1024+16, 5 taps (taps -> H)", lambda: eng.tdl_mean_freq_response(t5, delays5, nsym5, 1024, 16, 1024),
+      nsym5 * (1024 + 5 * 1040) * CB)
+ba, na = 4096, N // (4 * 4096)
+xa = eng.randn_c(ba * 2 * na, 19, 20, device=True)
+Ha = eng.randn_c(ba * 4, 7, 8, device=True).reshape(ba, 2, 2)
+timed("alamouti_encode (x -> 2 antennas)", lambda: eng.alamouti_encode(xa, batch=ba), ba * 2 * na * 3 * CB)
+Ya = eng.alamouti_encode(xa, batch=ba)
+timed("alamouti_decode 2x2 (Y -> x)", lambda: eng.alamouti_decode(Ha, Ya), ba * 2 * na * 3 * CB)
+hm = eng.randn_c(ba * 4, 9, 10, device=True).reshape(ba, 4)
+xm = eng.randn_c(ba * na, 21, 22, device=True)
+timed("mrt_encode 4 antennas (x -> 4 x)", lambda: eng.mrt_encode(hm, xm), ba * na * 5 * CB)
+Hb = eng.randn_c((1 << 20) * 16, 11, 12, device=True).reshape(1 << 20, 4, 4)
+timed("blast_filter 4x4 MMSE (H -> G), 2^20 matrices", lambda: eng.blast_filter(Hb, 0.01, read_skipped=False),
+      (1 << 20) * 32 * CB)
 print(json.dumps({"device": eng.device_name, "dtype": DT, "bytes_per_sample": CB, "n_symbols": N, "rows": rows}, indent=1))
