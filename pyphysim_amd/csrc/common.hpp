@@ -113,22 +113,28 @@ __device__ __forceinline__ int opaque(int v) {
     return v;
 }
 
-// Sum of `len` consecutive complex samples by one wavefront (every lane gets the total): four independent
-// accumulators per lane, so the loads of a run are in flight together instead of one behind the other.
+// Sum of `len` consecutive complex samples by one wavefront (every lane gets the total).  The run is taken 1024 samples
+// at a time with all sixteen loads of a lane issued before the first add: a loop that waits for each load (or each group
+// of four) spends one memory latency per trip -- under load several microseconds -- and that latency, not bandwidth,
+// bounded the tap-mean kernels.
 template <typename C>
 __device__ __forceinline__ C wave_sum_run(const C* __restrict__ src, int len, int lane) {
     auto re0 = src[0].x * 0, im0 = re0, re1 = re0, im1 = re0, re2 = re0, im2 = re0, re3 = re0, im3 = re0;
-    int j = lane;
-    for (; j + 192 < len; j += 256) {
-        const C a = src[j], b = src[j + 64], c = src[j + 128], d = src[j + 192];
-        re0 += a.x; im0 += a.y;
-        re1 += b.x; im1 += b.y;
-        re2 += c.x; im2 += c.y;
-        re3 += d.x; im3 += d.y;
-    }
-    for (; j < len; j += 64) {
-        re0 += src[j].x;
-        im0 += src[j].y;
+    for (int base = 0; base < len; base += 1024) {
+        C v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int j = base + 64 * u + lane;
+            v[u].x = v[u].y = re0 * 0;
+            if (j < len) v[u] = src[j];
+        }
+#pragma unroll
+        for (int u = 0; u < 16; u += 4) {
+            re0 += v[u].x; im0 += v[u].y;
+            re1 += v[u + 1].x; im1 += v[u + 1].y;
+            re2 += v[u + 2].x; im2 += v[u + 2].y;
+            re3 += v[u + 3].x; im3 += v[u + 3].y;
+        }
     }
     auto re = (re0 + re1) + (re2 + re3), im = (im0 + im1) + (im2 + im3);
 #pragma unroll

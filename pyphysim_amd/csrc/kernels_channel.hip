@@ -353,6 +353,7 @@ __global__ __launch_bounds__(kChBlock) void k_mean_freq_response(const cx<T>* __
             if (lane == 0) s_mean[q] = mk<T>(re / (T)(n + cp), im / (T)(n + cp));
         }
         __syncthreads();
+#pragma unroll 4
         for (size_t e = threadIdx.x; e < (size_t)num_used * P; e += blockDim.x) {
             const int d = (int)(e / P), p = (int)(e - (size_t)d * P);
             const int k = natural ? d : ofdm_bin(d, n, num_used);

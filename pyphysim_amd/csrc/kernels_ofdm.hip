@@ -199,12 +199,14 @@ __global__ __launch_bounds__(kOfdmBlock) void k_onetap_eq(const cx<T>* __restric
             if (lane == 0) s_mean[i] = mk<T>(tot.x / (T)(n + cp), tot.y / (T)(n + cp));
         }
         __syncthreads();
-        for (int d = threadIdx.x; d < num_used; d += blockDim.x) {
+#pragma unroll 4
+        for (int d = threadIdx.x; d < num_used; d += blockDim.x) {      // four bins' loads in flight per thread
             const int k = ofdm_bin(d, n, num_used);
+            const size_t o = sym * (size_t)num_used + d;
+            const cx<T> y = data[o];
             cx<T> h = mk<T>(0, 0);
             for (int i = 0; i < n_taps; ++i) h = cfma(s_mean[i], tw[tw_index(k * delays.d[i], n, mask)], h);
-            const size_t o = sym * (size_t)num_used + d;
-            out[o] = cdivide(data[o], h);
+            out[o] = cdivide(y, h);
         }
         __syncthreads();
     }
