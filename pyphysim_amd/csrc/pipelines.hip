@@ -177,6 +177,11 @@ __global__ __launch_bounds__(kPipeBlock) void k_run_flat(FlatParams fp, ModemPar
                 cn_pair<T>(rng, STREAM_NOISE, (uint32_t)((g0 >> 1) + 2 * q), sigma, z[0], z[1]);
                 cn_pair<T>(rng, STREAM_NOISE, (uint32_t)((g0 >> 1) + 2 * q + 1), sigma, z[2], z[3]);
                 const uint32_t dwt = dw.w[q] & mask4;
+                cx<T> hq[4];                             // i.i.d. Rayleigh: the four channel samples are two whole CHAN blocks
+                if (!kRec && fp.L == 0 && fp.rayleigh_iid) {
+                    cn_pair<T>(rng, STREAM_CHAN, (uint32_t)((g0 >> 1) + 2 * q), (T)1, hq[0], hq[1]);
+                    cn_pair<T>(rng, STREAM_CHAN, (uint32_t)((g0 >> 1) + 2 * q + 1), (T)1, hq[2], hq[3]);
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int n = g0 + 4 * q + e;
@@ -202,8 +207,7 @@ __global__ __launch_bounds__(kPipeBlock) void k_run_flat(FlatParams fp, ModemPar
                         const cx<T> h = mk<T>(amp * hr, amp * hi);
                         r[e] = flat_equalised(h, s, z[e]);
                     } else if (fp.rayleigh_iid) {
-                        const cx<T> h = cn_sample<T>(rng, STREAM_CHAN, (uint64_t)n, (T)1);
-                        r[e] = flat_equalised(h, s, z[e]);
+                        r[e] = flat_equalised(hq[e], s, z[e]);
                     } else {
                         r[e] = cadd(s, z[e]);
                     }
