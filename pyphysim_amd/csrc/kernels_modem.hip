@@ -236,17 +236,59 @@ int launch_binary(mcle_ctx* ctx, int dtype, const void* d_a, const void* d_b, do
     return MCLE_OK;
 }
 
+// One thread per Philox block, every word used: block b of the stream holds the complex normals 2b and 2b + 1
+// (philox.hpp), so a thread owns the pair and writes it as one 16-byte store where both fall inside [first, first + n)
+// and the output is aligned (a sample-per-thread form evaluated every block twice).
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_randn_c(Rng rng, uint32_t stream, uint64_t first, T sigma,
                                                     cx<T>* __restrict__ out, size_t n) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-        out[i] = cn_sample<T>(rng, stream, first + i, sigma);
+    const uint64_t b_lo = first >> 1, b_hi = (first + n - 1) >> 1;          // blocks touched
+    const bool vec = sizeof(T) == 4 && ((first & 1) == 0) && (((uintptr_t)out & 15) == 0);
+    for (uint64_t b = b_lo + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b <= b_hi;
+         b += (uint64_t)gridDim.x * blockDim.x) {
+        cx<T> z0, z1;
+        cn_pair<T>(rng, stream, (uint32_t)b, sigma, z0, z1);
+        const uint64_t a0 = 2 * b;                                          // absolute index of z0
+        const bool in0 = a0 >= first, in1 = a0 + 1 < first + n;
+        if constexpr (sizeof(T) == 4) {
+            if (vec && in0 && in1) {
+                *reinterpret_cast<float4*>(out + (a0 - first)) = make_float4(z0.x, z0.y, z1.x, z1.y);
+                continue;
+            }
+        }
+        if (in0) out[a0 - first] = z0;
+        if (in1) out[a0 + 1 - first] = z1;
+    }
 }
 
+// One thread per DATA block: its sixteen bytes are symbols 16 b .. 16 b + 15 (symbol_at); four 16-byte stores.
+__device__ __forceinline__ void symbols_of_block(const Rng& rng, uint64_t b, uint64_t first, uint64_t end, uint32_t mask,
+                                                 int32_t* __restrict__ out) {
+    const Words4 w = rng.block(STREAM_DATA, (uint32_t)b);
+    const uint64_t a0 = 16 * b;
+    const bool whole = a0 >= first && a0 + 16 <= end && ((((uintptr_t)(out + (a0 - first))) & 15) == 0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int4 v = make_int4((int)(w.w[q] & mask), (int)((w.w[q] >> 8) & mask), (int)((w.w[q] >> 16) & mask),
+                                 (int)((w.w[q] >> 24) & mask));
+        if (whole) {
+            *reinterpret_cast<int4*>(out + (a0 - first) + 4 * q) = v;
+        } else {
+            const int e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint64_t a = a0 + 4 * q + k;
+                if (a >= first && a < end) out[a - first] = e[k];
+            }
+        }
+    }
+}
 __global__ __launch_bounds__(kBlock) void k_rand_symbols(Rng rng, uint64_t first, uint32_t mask,
                                                          int32_t* __restrict__ out, size_t n) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-        out[i] = (int32_t)symbol_at(rng, first + i, mask);
+    const uint64_t b_lo = first >> 4, b_hi = (first + n - 1) >> 4;
+    for (uint64_t b = b_lo + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b <= b_hi;
+         b += (uint64_t)gridDim.x * blockDim.x)
+        symbols_of_block(rng, b, first, first + n, mask, out);
 }
 
 // out[r][i] = symbol i of realization first_real + r
@@ -254,8 +296,9 @@ __global__ __launch_bounds__(kBlock) void k_rand_symbols_batch(uint64_t seed, ui
                                                                int32_t* __restrict__ out, size_t n) {
     const Rng rng(seed, first_real + blockIdx.y);
     int32_t* row = out + (size_t)blockIdx.y * n;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-        row[i] = (int32_t)symbol_at(rng, i, mask);
+    for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b <= (uint64_t)((n - 1) >> 4);
+         b += (uint64_t)gridDim.x * blockDim.x)
+        symbols_of_block(rng, b, 0, n, mask, row);
 }
 
 int check_modem(const mcle_ctx* ctx, int dtype, int method) {
@@ -394,7 +437,7 @@ int mcle_randn_c(mcle_ctx* ctx, int dtype, uint64_t seed, uint64_t realization, 
     int rc = ctx->bind();
     if (rc) return rc;
     Rng rng(seed, realization);
-    const int grid = grid_for(ctx, n, kBlock);
+    const int grid = grid_for(ctx, n / 2 + 1, kBlock);
     if (dtype == MCLE_F32)
         hipLaunchKernelGGL(k_randn_c<float>, dim3(grid), dim3(kBlock), 0, ctx->stream, rng, stream, first_sample,
                            (float)sqrt(variance), (float2*)d_out, n);
@@ -412,7 +455,7 @@ int mcle_rand_symbols(mcle_ctx* ctx, uint64_t seed, uint64_t realization, uint64
     if (n == 0) return MCLE_OK;
     int rc = ctx->bind();
     if (rc) return rc;
-    hipLaunchKernelGGL(k_rand_symbols, dim3(grid_for(ctx, n, kBlock)), dim3(kBlock), 0, ctx->stream,
+    hipLaunchKernelGGL(k_rand_symbols, dim3(grid_for(ctx, n / 16 + 1, kBlock)), dim3(kBlock), 0, ctx->stream,
                        Rng(seed, realization), first_symbol, (uint32_t)(M - 1), d_idx, n);
     MCLE_LAUNCH_CHECK();
     return MCLE_OK;
@@ -426,7 +469,7 @@ int mcle_rand_symbols_batch(mcle_ctx* ctx, uint64_t seed, uint64_t first_realiza
     if (n == 0 || count == 0) return MCLE_OK;
     int rc = ctx->bind();
     if (rc) return rc;
-    dim3 grid((unsigned)grid_for(ctx, n, kBlock, 2), (unsigned)count);
+    dim3 grid((unsigned)grid_for(ctx, n / 16 + 1, kBlock, 2), (unsigned)count);
     hipLaunchKernelGGL(k_rand_symbols_batch, grid, dim3(kBlock), 0, ctx->stream, seed, first_realization,
                        (uint32_t)(M - 1), d_idx, n);
     MCLE_LAUNCH_CHECK();

@@ -84,6 +84,17 @@ def test_philox_draws(engine, dt):
     assert relerr(z, want) <= (1e-13 if dt == "f64" else 3e-6)
     s = engine.rand_symbols(999, 64, seed, r, first=3)
     assert np.array_equal(s, P.symbols(seed, r, 999, 64, offset=3))
+    # the generators take one Philox block per thread: every alignment of the window against the blocks
+    for first in (0, 1, 2, 7, 16, 21):
+        for n in (1, 2, 3, 15, 16, 17, 33, 4097):
+            z = engine.randn_c(n, seed, r, _lib.STREAM_CHAN, first=first, dtype=dt)
+            assert relerr(z, P.cnormal(seed, r, n, P.STREAM_CHAN, offset=first)) <= (1e-13 if dt == "f64" else 3e-6), (first, n)
+            if dt == "f64":
+                assert np.array_equal(engine.rand_symbols(n, 16, seed, r, first=first), P.symbols(seed, r, n, 16, offset=first))
+    if dt == "f64":
+        rows = engine.rand_symbols_batch(37, 8, seed, r, 3).get()
+        for k in range(3):
+            assert np.array_equal(rows[k], P.symbols(seed, r + k, 37, 8))
 
 
 @pytest.mark.parametrize("dt", ["f64", "f32"])
