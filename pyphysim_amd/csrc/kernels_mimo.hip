@@ -20,6 +20,31 @@ __global__ __launch_bounds__(kMimoBlock) void k_blast_encode(const cx<T>* __rest
     }
 }
 
+// nt = 2 / 4, ns even, aligned rows: a thread takes two columns -- 2 nt consecutive inputs in 16-byte (32-byte) reads,
+// one pair per antenna row out -- instead of one strided 8-byte read per output.
+template <typename T, int NT>
+__global__ __launch_bounds__(kMimoBlock) void k_blast_encode_pairs(const cx<T>* __restrict__ x, size_t ns, T inv_root_nt,
+                                                                   cx<T>* __restrict__ X) {
+    struct alignas(2 * sizeof(cx<T>)) Pair {
+        cx<T> a, b;
+    };
+    const size_t b = blockIdx.y, n = ns * NT;
+    const Pair* xin = reinterpret_cast<const Pair*>(x + b * n);
+    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < ns / 2; p += (size_t)gridDim.x * blockDim.x) {
+        Pair v[NT];                                   // columns 2p and 2p + 1: inputs (2p) NT .. (2p + 2) NT - 1
+#pragma unroll
+        for (int k = 0; k < NT; ++k) v[k] = xin[p * NT + k];
+        const cx<T>* e = reinterpret_cast<const cx<T>*>(v);
+#pragma unroll
+        for (int a = 0; a < NT; ++a) {
+            Pair o;
+            o.a = cscale(e[a], inv_root_nt);
+            o.b = cscale(e[NT + a], inv_root_nt);
+            reinterpret_cast<Pair*>(X + b * n + (size_t)a * ns)[p] = o;
+        }
+    }
+}
+
 template <typename T, int NT, int NR>
 __global__ __launch_bounds__(64) void k_blast_filter(const cx<T>* __restrict__ Hg, double nv,
                                                      cx<T>* __restrict__ Gg, uint32_t* __restrict__ skipped,
@@ -417,6 +442,24 @@ int mcle_blast_encode(mcle_ctx* ctx, int dtype, const void* d_x, int nt, size_t 
     if ((rc = ctx->bind())) return rc;
     dim3 grid((unsigned)grid_for(ctx, n, kMimoBlock, 4), (unsigned)batch);
     const double s = 1.0 / std::sqrt((double)nt);
+    const size_t ns_ = n / nt, pair_bytes = dtype == MCLE_F32 ? 16 : 32;
+    if ((nt == 2 || nt == 4) && ns_ % 2 == 0 && ((uintptr_t)d_x % pair_bytes) == 0 && ((uintptr_t)d_X % pair_bytes) == 0) {
+        dim3 gridp((unsigned)grid_for(ctx, ns_ / 2, kMimoBlock, 4), (unsigned)batch);
+        if (dtype == MCLE_F32 && nt == 2)
+            hipLaunchKernelGGL((k_blast_encode_pairs<float, 2>), gridp, dim3(kMimoBlock), 0, ctx->stream, (const float2*)d_x,
+                               ns_, (float)s, (float2*)d_X);
+        else if (dtype == MCLE_F32)
+            hipLaunchKernelGGL((k_blast_encode_pairs<float, 4>), gridp, dim3(kMimoBlock), 0, ctx->stream, (const float2*)d_x,
+                               ns_, (float)s, (float2*)d_X);
+        else if (nt == 2)
+            hipLaunchKernelGGL((k_blast_encode_pairs<double, 2>), gridp, dim3(kMimoBlock), 0, ctx->stream,
+                               (const double2*)d_x, ns_, s, (double2*)d_X);
+        else
+            hipLaunchKernelGGL((k_blast_encode_pairs<double, 4>), gridp, dim3(kMimoBlock), 0, ctx->stream,
+                               (const double2*)d_x, ns_, s, (double2*)d_X);
+        MCLE_LAUNCH_CHECK();
+        return MCLE_OK;
+    }
     if (dtype == MCLE_F32)
         hipLaunchKernelGGL(k_blast_encode<float>, grid, dim3(kMimoBlock), 0, ctx->stream, (const float2*)d_x, nt,
                            n / nt, (float)s, (float2*)d_X);
