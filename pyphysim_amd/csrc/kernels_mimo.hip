@@ -67,6 +67,72 @@ __global__ __launch_bounds__(64) void k_blast_filter(const cx<T>* __restrict__ H
     }
 }
 
+// The same filters with coalesced traffic: a wavefront's 64 matrices are one contiguous run of 64 E complex values;
+// the run crosses LDS in 16-byte chunks (matrix stride padded by 4 dwords: lane-per-matrix b128 accesses then hit all
+// 32 banks once per 8 lanes), so every global access is a full 1 KiB wave access instead of 64 strided 8-byte ones.
+// Needs an even number of 4-byte words per matrix pair (E even, or complex128) and 16-byte aligned arrays.
+template <typename T, int NT, int NR>
+__global__ __launch_bounds__(64) void k_blast_filter_staged(const cx<T>* __restrict__ Hg, double nv,
+                                                            cx<T>* __restrict__ Gg, uint32_t* __restrict__ skipped,
+                                                            size_t batch) {
+    constexpr int E = NT * NR;
+    constexpr int DW = E * (int)sizeof(cx<T>) / 4;        // dwords per matrix
+    constexpr int CH = DW / 4;                              // 16-byte chunks per matrix
+    constexpr int STRIDE = DW + 4;
+    static_assert(DW % 4 == 0, "matrix size must be a multiple of 16 bytes");
+    __shared__ __attribute__((aligned(16))) float s_m[64 * STRIDE];
+    const int lane = threadIdx.x;
+    for (size_t b0 = (size_t)blockIdx.x * 64; b0 < batch; b0 += (size_t)gridDim.x * 64) {
+        const size_t left = batch - b0 < 64 ? batch - b0 : 64;          // matrices of this step
+        const float4* src = reinterpret_cast<const float4*>(Hg + b0 * E);
+        float4 in[CH];
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            const int q = k * 64 + lane;
+            in[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if ((size_t)q < left * CH) in[k] = src[q];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            const int q = k * 64 + lane;
+            *reinterpret_cast<float4*>(s_m + (q / CH) * STRIDE + 4 * (q % CH)) = in[k];
+        }
+        __syncthreads();
+        cx<T> hm[E];
+        {
+            float4* d = reinterpret_cast<float4*>(hm);
+#pragma unroll
+            for (int k = 0; k < CH; ++k) d[k] = *reinterpret_cast<const float4*>(s_m + lane * STRIDE + 4 * k);
+        }
+        double2 H[NR][NT], G[NT][NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+#pragma unroll
+            for (int a = 0; a < NT; ++a) H[r][a] = mk<double>((double)hm[r * NT + a].x, (double)hm[r * NT + a].y);
+        const bool ok = blast_filter<NT, NR>(H, nv, G);
+        cx<T> gm[E];
+#pragma unroll
+        for (int a = 0; a < NT; ++a)
+#pragma unroll
+            for (int r = 0; r < NR; ++r) gm[a * NR + r] = mk<T>((T)G[a][r].x, (T)G[a][r].y);
+        __syncthreads();
+        {
+            const float4* d = reinterpret_cast<const float4*>(gm);
+#pragma unroll
+            for (int k = 0; k < CH; ++k) *reinterpret_cast<float4*>(s_m + lane * STRIDE + 4 * k) = d[k];
+        }
+        __syncthreads();
+        float4* dst = reinterpret_cast<float4*>(Gg + b0 * E);
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            const int q = k * 64 + lane;
+            if ((size_t)q < left * CH) dst[q] = *reinterpret_cast<const float4*>(s_m + (q / CH) * STRIDE + 4 * (q % CH));
+        }
+        if (skipped && (size_t)lane < left) skipped[b0 + lane] = ok ? 0u : 1u;
+    }
+}
+
 // est[b][c*nt + a] = sum_r G[b][a][r] Y[b][r][c]
 template <typename T>
 __global__ __launch_bounds__(kMimoBlock) void k_blast_decode(const cx<T>* __restrict__ G, const cx<T>* __restrict__ Y,
@@ -367,6 +433,14 @@ __global__ __launch_bounds__(64) void k_gmd_filters(const cx<T>* __restrict__ Hg
 
 template <typename T, int NT, int NR>
 int launch_filter(mcle_ctx* ctx, const void* d_H, double nv, void* d_G, uint32_t* d_skipped, size_t batch) {
+    if constexpr ((NT * NR * sizeof(cx<T>)) % 16 == 0) {
+        if ((((uintptr_t)d_H | (uintptr_t)d_G) & 15) == 0 && batch >= 64) {
+            hipLaunchKernelGGL((k_blast_filter_staged<T, NT, NR>), dim3(grid_for(ctx, batch, 64, 16)), dim3(64), 0,
+                               ctx->stream, (const cx<T>*)d_H, nv, (cx<T>*)d_G, d_skipped, batch);
+            MCLE_LAUNCH_CHECK();
+            return MCLE_OK;
+        }
+    }
     hipLaunchKernelGGL((k_blast_filter<T, NT, NR>), dim3(grid_for(ctx, batch, 64, 16)), dim3(64), 0, ctx->stream,
                        (const cx<T>*)d_H, nv, (cx<T>*)d_G, d_skipped, batch);
     MCLE_LAUNCH_CHECK();

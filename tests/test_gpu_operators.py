@@ -248,6 +248,26 @@ def test_rayleigh_class_mirror_draws(engine):
 
 
 @pytest.mark.parametrize("dt", ["f64", "f32"])
+def test_blast_filter_staged_equals_the_direct_kernel(engine, dt):
+    """k_blast_filter_staged (>= 64 matrices, 16-byte multiples: coalesced through LDS) gives the values of k_blast_filter
+    (smaller batches) bit for bit, ragged batch tails included."""
+    rs = np.random.RandomState(77)
+    cdt = np.complex128 if dt == "f64" else np.complex64
+    for nr, nt in ((2, 2), (4, 2), (4, 4), (3, 2), (2, 1), (3, 3)):
+        for batch in (64, 131, 257):
+            H = (rs.randn(batch, nr, nt) + 1j * rs.randn(batch, nr, nt)).astype(cdt)
+            H[5] = 0                                            # a singular channel: flagged, not NaN-poisoning its neighbours
+            for nv in (0.0, 0.05):
+                G, sk = engine.blast_filter(H, nv, dtype=dt)
+                parts = [engine.blast_filter(H[i:i + 50], nv, dtype=dt) for i in range(0, batch, 50)]
+                Gp, skp = np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts])
+                assert np.array_equal(sk, skp), (nr, nt, batch, nv)
+                good = sk == 0
+                assert np.array_equal(G[good], Gp[good]), (nr, nt, batch, nv)
+                assert (nv > 0) or sk[5] == 1
+
+
+@pytest.mark.parametrize("dt", ["f64", "f32"])
 def test_jakes_block_kernel_equals_the_direct_sum(engine, dt):
     """k_jakes_blocks (uniform time axis, L <= 16, >= 1024 samples: one phasor per ray and 64-sample block times the lane's
     rotation) against the closed form sample by sample (NumPy, fading_generators.py:519-522) and against k_jakes
