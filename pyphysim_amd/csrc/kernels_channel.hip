@@ -318,11 +318,26 @@ __global__ __launch_bounds__(kChBlock) void k_tdl_apply_mimo(const cx<T>* __rest
         for (size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x; m < n_out;
              m += (size_t)gridDim.x * blockDim.x) {
             cx<T> acc = mk<T>(0, 0);
-            for (int i = 0; i < n_taps; ++i) {
-                const long long k = (long long)m - dl.d[i];
-                if (k < 0 || (size_t)k >= n) continue;
-                for (int t = 0; t < nt; ++t)
-                    acc = cadd(acc, cmul(g[(((size_t)i * nr + r) * nt + t) * n + k], x[(size_t)t * n + k]));
+            if (nt == 4) {        // the eight loads of a tap issued before its four products (same accumulation order)
+#pragma unroll 2
+                for (int i = 0; i < n_taps; ++i) {
+                    const long long k = (long long)m - dl.d[i];
+                    if (k < 0 || (size_t)k >= n) continue;
+                    const cx<T>* gi = g + (((size_t)i * nr + r) * 4) * n + k;
+                    const cx<T> g0 = gi[0], g1 = gi[n], g2 = gi[2 * n], g3 = gi[3 * n];
+                    const cx<T> x0 = x[k], x1 = x[n + k], x2 = x[2 * n + k], x3 = x[3 * n + k];
+                    acc = cadd(acc, cmul(g0, x0));
+                    acc = cadd(acc, cmul(g1, x1));
+                    acc = cadd(acc, cmul(g2, x2));
+                    acc = cadd(acc, cmul(g3, x3));
+                }
+            } else {
+                for (int i = 0; i < n_taps; ++i) {
+                    const long long k = (long long)m - dl.d[i];
+                    if (k < 0 || (size_t)k >= n) continue;
+                    for (int t = 0; t < nt; ++t)
+                        acc = cadd(acc, cmul(g[(((size_t)i * nr + r) * nt + t) * n + k], x[(size_t)t * n + k]));
+                }
             }
             y[(size_t)r * n_out + m] = acc;
         }
