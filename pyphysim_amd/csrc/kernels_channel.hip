@@ -47,10 +47,10 @@ __global__ __launch_bounds__(kChBlock) void k_jakes(const double* __restrict__ p
 //     p_l = e^{j (w_l t_c + psi_l)} ,   V_l[i] = e^{j w_l dt (i + 1/2)} ,   i < 64 ,
 // so a block needs ONE phasor per ray (evaluated as in k_jakes, at the half-sample time t_c) and the four real products
 // pr Vr, pi Vi, pr Vi, pi Vr of a ray serve the two samples c + (i + 1/2) and c - (i + 1/2) of lane i: four FMAs per ray
-// and PAIR of samples instead of one sincos per ray and sample.  V_l[lane] is L complex values in registers, set up once
-// per wavefront and stream; lane (q, l) = (lane / L, lane % L) evaluates the phasor of ray l for run q of a batch of 64 / L
+// and PAIR of samples instead of one sincos per ray and sample.  V_l[lane] is L complex values in registers, computed once
+// per workgroup and stream and shared through LDS; lane (q, l) = (lane / L, lane % L) evaluates the phasor of ray l for run q of a batch of 64 / L
 // runs of kSteps blocks and advances it from block to block by R_l = e^{j w_l dt 128}; the walk reads each phasor back
-// from LDS with a wave-uniform address (a broadcast read).  complex128, L = 8: 0.10 -> of the 8 TB/s write rate.
+// from LDS with a wave-uniform address (a broadcast read).  complex128, L = 8: 0.10 -> 0.54 of the 8 TB/s write rate.
 // Values equal k_jakes' up to the rounding of w_l t (the reference's own noise floor, eps |w t|):
 // fading_generators.py:421-470.
 // LT: L rounded up to a multiple of four (rays l >= L carry a zero rotation).
