@@ -113,23 +113,24 @@ __device__ __forceinline__ int opaque(int v) {
     return v;
 }
 
-// Sum of `len` consecutive complex samples by one wavefront (every lane gets the total).  The run is taken 1024 samples
-// at a time with all sixteen loads of a lane issued before the first add: a loop that waits for each load (or each group
-// of four) spends one memory latency per trip -- under load several microseconds -- and that latency, not bandwidth,
-// bounded the tap-mean kernels.
+// Sum of `len` consecutive complex samples by one wavefront (every lane gets the total).  The run is taken 1280 samples
+// at a time (an OFDM symbol of 1024 + cyclic prefix in one trip) with all twenty loads of a lane issued before the first
+// add: a loop that waits for each load (or each group of four) spends one memory latency per trip -- under load several
+// microseconds -- and that latency, not bandwidth, bounded the tap-mean kernels.
 template <typename C>
 __device__ __forceinline__ C wave_sum_run(const C* __restrict__ src, int len, int lane) {
+    constexpr int kLoads = 20;
     auto re0 = src[0].x * 0, im0 = re0, re1 = re0, im1 = re0, re2 = re0, im2 = re0, re3 = re0, im3 = re0;
-    for (int base = 0; base < len; base += 1024) {
-        C v[16];
+    for (int base = 0; base < len; base += 64 * kLoads) {
+        C v[kLoads];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
+        for (int u = 0; u < kLoads; ++u) {
             const int j = base + 64 * u + lane;
             v[u].x = v[u].y = re0 * 0;
             if (j < len) v[u] = src[j];
         }
 #pragma unroll
-        for (int u = 0; u < 16; u += 4) {
+        for (int u = 0; u < kLoads; u += 4) {
             re0 += v[u].x; im0 += v[u].y;
             re1 += v[u + 1].x; im1 += v[u + 1].y;
             re2 += v[u + 2].x; im2 += v[u + 2].y;
