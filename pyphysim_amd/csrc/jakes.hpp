@@ -43,7 +43,7 @@ template <> __device__ __forceinline__ double2 jakes_ray<double>(double w, doubl
 }
 template <> __device__ __forceinline__ float2 jakes_ray<float>(double w, double psi, double t) {
     const double x = fma(w, t, psi);
-    const float v = (float)(x - floor(x));
+    const float v = (float)__builtin_amdgcn_fract(x);     // x - floor(x) in one v_fract_f64
     float2 r;
     r.x = __builtin_amdgcn_cosf(v);
     r.y = __builtin_amdgcn_sinf(v);

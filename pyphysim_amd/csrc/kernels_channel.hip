@@ -165,7 +165,7 @@ __global__ __launch_bounds__(kChBlock) void k_jakes_mfma(const double* __restric
 #pragma unroll
             for (int k = 0; k < KS; ++k) {
                 const double x = fma(wl[k], tt, pq[k]);
-                bv[k] = __builtin_amdgcn_sinf((float)(x - floor(x)));
+                bv[k] = __builtin_amdgcn_sinf((float)__builtin_amdgcn_fract(x));
             }
             f4j hre = {0.f, 0.f, 0.f, 0.f}, him = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll

@@ -127,7 +127,7 @@ __global__ __launch_bounds__(kPipeBlock, sizeof(T) == 4 ? 3 : 1) void k_run_mimo
                     const double psi_t = uniform_at(rng, STREAM_PHASE, (uint64_t)L * PS + q);
                     const double w = pp.Fd * cospi(2.0 * uniform_at(rng, STREAM_PHASE, (uint64_t)q));   // Hz; cos(phi), phi = 2 pi u
                     const double ph = fma(w, tc, psi_t);                  // turns
-                    const double fr = ph - floor(ph);
+                    const double fr = __builtin_amdgcn_fract(ph);
                     T er, ei;
                     if constexpr (sizeof(T) == 8) {
                         double sn, cs;

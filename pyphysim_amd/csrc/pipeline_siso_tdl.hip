@@ -99,7 +99,7 @@ __global__ __launch_bounds__(kPipeBlock, sizeof(T) == 4 ? 3 : 1) void k_run_ofdm
                     const double psi_t = uniform_at(rng, STREAM_PHASE, (uint64_t)L * S + rq);
                     const double w = pp.Fd * cospi(2.0 * uniform_at(rng, STREAM_PHASE, (uint64_t)rq));   // Hz
                     const double ph = fma(w, tc, psi_t);                  // turns
-                    const double fr = ph - floor(ph);
+                    const double fr = __builtin_amdgcn_fract(ph);
                     T er, ei;
                     if constexpr (sizeof(T) == 8) {
                         double sn, cs;
@@ -480,7 +480,7 @@ __global__ __launch_bounds__(kPipeBlock, WAVES) void k_run_ofdm_tdl_mfma(
                     const double psi_t = uniform_at(rng, STREAM_PHASE, (uint64_t)L * S + rq);
                     const double wd = pp.Fd * cospi(2.0 * uniform_at(rng, STREAM_PHASE, (uint64_t)rq));   // Hz
                     const double ph = fma(wd, tc, psi_t);                 // turns
-                    const double fr = ph - floor(ph);
+                    const double fr = __builtin_amdgcn_fract(ph);
                     float* o = s_ray + 3 * ((a * S + s) * L + l);
                     o[0] = __builtin_amdgcn_cosf((float)fr);
                     o[1] = __builtin_amdgcn_sinf((float)fr);

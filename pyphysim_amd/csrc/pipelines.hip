@@ -347,7 +347,7 @@ __global__ __launch_bounds__(kPipeBlock) void k_run_flat_mfma(FlatParams fp, Mod
 #pragma unroll
                 for (int s = 0; s < KS; ++s) {
                     const double x = fma(w[s], tt, psq[s]);
-                    bv[s] = __builtin_amdgcn_sinf((float)(x - floor(x)));
+                    bv[s] = __builtin_amdgcn_sinf((float)__builtin_amdgcn_fract(x));
                 }
                 f4m hre = {0.f, 0.f, 0.f, 0.f}, him = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
