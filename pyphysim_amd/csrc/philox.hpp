@@ -62,7 +62,8 @@ __device__ __forceinline__ float2 cn_from_words(uint32_t x0, uint32_t x1, float 
     const float u = fmaf((float)x0, 0x1p-32f, 0x1p-33f);
     const float v = (float)x1 * 0x1p-32f;  // revolutions
     // -ln(u) = -log2(u) * ln2 ; v_log_f32 / v_sqrt_f32 / v_sin_f32 / v_cos_f32 (input in turns)
-    const float rad = sigma * __builtin_amdgcn_sqrtf(-0.69314718055994531f * __builtin_amdgcn_logf(u));
+    // sigma sqrt(-ln u) as sqrt((-ln 2 sigma^2) log2 u): the constant is loop-invariant, one multiply less per sample
+    const float rad = __builtin_amdgcn_sqrtf((-0.69314718055994531f * sigma * sigma) * __builtin_amdgcn_logf(u));
     float2 z;
     z.x = rad * __builtin_amdgcn_cosf(v);
     z.y = rad * __builtin_amdgcn_sinf(v);
