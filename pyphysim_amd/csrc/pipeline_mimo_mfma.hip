@@ -516,7 +516,7 @@ int run_mimo_ofdm_mfma(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, uint64_t se
     int per_cu = (int)((size_t)160 * 1024 / (lds + 512));
     if (per_cu < 1) per_cu = 1;
     if (per_cu > waves) per_cu = waves;     // __launch_bounds__(256, WAVES)
-    const uint64_t cap = (uint64_t)ctx->n_cu * per_cu;
+    const uint64_t resident = (uint64_t)ctx->n_cu * per_cu;
     const uint64_t kSlice = 1ull << 18;          // realizations per filter + link pair: bounds the record buffer (69 MB)
     const uint64_t slice = count < kSlice ? count : kSlice;
     void* recs = nullptr;
@@ -526,7 +526,7 @@ int run_mimo_ofdm_mfma(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, uint64_t se
         hipLaunchKernelGGL(k_mimo_filters, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, pp, seed, first + off, n,
                            (float2*)recs);
         MCLE_LAUNCH_CHECK();
-        const unsigned grid = (unsigned)(n < cap ? n : cap);
+        const unsigned grid = (unsigned)oversubscribed_grid(resident, n);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(kPipeBlock), lds, ctx->stream, pp, mp, seed, first + off, n,
                            (const float2*)tw, (const float2*)recs, d_counters, d_sym ? d_sym + off : nullptr,
                            d_bit ? d_bit + off : nullptr);

@@ -839,9 +839,8 @@ int run_siso_tdl_mfma(mcle_ctx* ctx, const SisoTdlParams& pp, int method, uint64
     MCLE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int per_cu = (int)((size_t)160 * 1024 / (lds + 512));
     if (per_cu > waves) per_cu = waves;     // __launch_bounds__(256, WAVES)
-    const uint64_t cap = (uint64_t)ctx->n_cu * per_cu;
     const uint64_t passes = (count + NB - 1) / NB;
-    const unsigned grid = (unsigned)(passes < cap ? passes : cap);
+    const unsigned grid = (unsigned)oversubscribed_grid((uint64_t)ctx->n_cu * per_cu, passes);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kPipeBlock), lds, ctx->stream, pp, mp, seed, first, count,
                        (const float2*)tw, d_counters, d_sym, d_bit);
     MCLE_LAUNCH_CHECK();
@@ -873,9 +872,8 @@ int run_siso_tdl_batch_impl(mcle_ctx* ctx, SisoTdlParams pp, int method, uint64_
     int per_cu = (int)((size_t)160 * 1024 / (lds + 512));
     if (per_cu < 1) per_cu = 1;
     if (per_cu > 8) per_cu = 8;
-    const uint64_t cap = (uint64_t)ctx->n_cu * per_cu;
     const uint64_t passes = (count + NB - 1) / NB;
-    const unsigned grid = (unsigned)(passes < cap ? passes : cap);
+    const unsigned grid = (unsigned)oversubscribed_grid((uint64_t)ctx->n_cu * per_cu, passes);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kPipeBlock), lds, ctx->stream, pp, mp, seed, first, count,
                        (const cx<T>*)tw, d_counters, d_sym, d_bit);
     MCLE_LAUNCH_CHECK();

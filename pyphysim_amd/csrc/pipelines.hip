@@ -880,8 +880,6 @@ int run_flat_impl(mcle_ctx* ctx, const FlatParams& fp, int method, uint64_t seed
     int rc = pipe_workspace(ctx, count, &ws, &sk);
     if (rc) return rc;
     const uint64_t items = count * (uint64_t)((fp.n_symbols + kChunk - 1) / kChunk);
-    const uint64_t cap = (uint64_t)ctx->n_cu * 8;
-    const unsigned grid = (unsigned)(items < cap ? items : cap);
     const ModemParams<T> mp = pipe_modem<T>(ctx, method);
     const size_t lds = (size_t)mp.grid.G * mp.grid.G * sizeof(unsigned long long);
     // f32 Jakes links of 8 / 16 rays: the ray sum on the matrix cores (MCLE_NO_MFMA=1 keeps the VALU recurrence);
@@ -891,6 +889,15 @@ int run_flat_impl(mcle_ctx* ctx, const FlatParams& fp, int method, uint64_t seed
                      : mp.method == MCLE_DEMOD_QAM_SLICER ? 1
                      : (mp.method == MCLE_DEMOD_MINDIST && (mp.M <= 8 || mp.grid.G > 0)) ? 2 : 0;
     const int lr = sizeof(T) == 4 && !fp.rayleigh_iid && (fp.L == 8 || fp.L == 16) ? fp.L : 0;
+    // 64 workgroups per CU although 3 - 5 are resident (164 / 80 registers): the queued ones start as the first finish, which
+    // evens out per-workgroup speed differences and shortens the tail.  Measured (MCLE_FLAT_WGS_PER_CU): AWGN 10^4 symbols
+    // 5.3 / 5.6 / 5.9 / 6.1 / 6.3 / 6.4 e7 realizations/s at 6 / 8 / 16 / 32 / 64 / 512 per CU, config 2 3.89 / 3.98 / 4.03 /
+    // 4.09 / 4.16 / 3.83 e6 (past 64 a workgroup no longer spans a realization's chunks and redoes the ray set-up); a grid
+    // of exactly the resident set was 6 - 9 % slower than 8.
+    int per_cu = 64;
+    if (const char* v = std::getenv("MCLE_FLAT_WGS_PER_CU")) per_cu = std::atoi(v) > 0 ? std::atoi(v) : 64;
+    const uint64_t cap = (uint64_t)ctx->n_cu * (uint64_t)per_cu;
+    const unsigned grid = (unsigned)(items < cap ? items : cap);
 #define MCLE_FLAT_LAUNCH(KERN) \
     hipLaunchKernelGGL((KERN), dim3(grid), dim3(kPipeBlock), lds, ctx->stream, fp, mp, seed, first, count, ws)
     if constexpr (sizeof(T) == 4) {
