@@ -36,12 +36,12 @@ __device__ __forceinline__ void block_sum2(unsigned& a, unsigned& b, unsigned* s
 // as the first ones finish, which evens out per-workgroup speed differences and shortens the tail -- measured on the
 // matrix-core kernels (MCLE_GRID_OVERSUB = 1 / 2 / 4 / 8 / 16 / 32): config 4 1.516 / 1.458 / 1.415 / 1.401 / 1.411 / 2.02 ms
 // per 65 536 realizations, config 3 1.602 / 1.575 / 1.555 / 1.541 / 1.550 / 1.608 ms per 131 072.
-inline uint64_t oversubscribed_grid(uint64_t resident, uint64_t units) {
+inline uint64_t oversubscribed_grid(uint64_t resident, uint64_t units, uint64_t min_units = 8) {
     uint64_t f = 8;
     if (const char* v = std::getenv("MCLE_GRID_OVERSUB")) {
         f = std::atoi(v) > 0 ? (uint64_t)std::atoi(v) : 8;
     } else {
-        while (f > 1 && units < resident * f * 8) f >>= 1;
+        while (f > 1 && units < resident * f * min_units) f >>= 1;
     }
     const uint64_t g = resident * f;
     return units < g ? units : g;
