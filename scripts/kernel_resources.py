@@ -21,12 +21,15 @@ CSRC = os.path.join(REPO, "pyphysim_amd", "csrc")
 LLVM = "/opt/rocm/lib/llvm/bin"
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fno-gpu-rdc", "-fno-hip-fp32-correctly-rounded-divide-sqrt",
          "-ffp-contract=fast", "--cuda-device-only", "-c"]
-SOURCES = {"pipelines.hip": ("k_run_mimo_ofdm", "k_run_flat", "k_run_ofdm_tdl"),
-           "pipeline_siso_tdl.hip": ("k_run_ofdm_tdl_batch",),
+SOURCES = {"pipelines.hip": ("k_run_mimo_ofdm", "k_run_flat", "k_run_flat_mfma", "k_run_ofdm_tdl"),
+           "pipeline_mimo_mfma.hip": ("k_run_mimo_ofdm_mfma", "k_mimo_filters"),
+           "pipeline_siso_tdl.hip": ("k_run_ofdm_tdl_batch", "k_run_ofdm_tdl_mfma"),
            "pipeline_mimo_tdl.hip": ("k_run_mimo_ofdm_tdl",),
-           "pipeline_mimo_flat.hip": ("k_run_mimo_flat",),
-           "kernels_ia.hip": ("k_run_ia",),
-           "kernels_bd.hip": ("k_run_bd",)}
+           "pipeline_mimo_flat.hip": ("k_mimo_flat_setup", "k_mimo_flat_link"),
+           "kernels_ia.hip": ("k_ia_solve_links", "k_ia_link"),
+           "kernels_bd.hip": ("k_bd_solve_links", "k_bd_link"),
+           "kernels_ofdm_mfma.hip": ("k_ofdm_mod_1024_mfma", "k_ofdm_demod_1024_mfma"),
+           "kernels_channel.hip": ("k_jakes_blocks", "k_jakes_mfma")}
 KEYS = (".vgpr_count", ".agpr_count", ".sgpr_count", ".vgpr_spill_count", ".sgpr_spill_count",
         ".private_segment_fixed_size", ".group_segment_fixed_size", ".max_flat_workgroup_size")
 
@@ -69,8 +72,9 @@ def main():
                       "pyphysim_amd/csrc/Makefile", "kernels": dict(sorted(out.items()))}
     json.dump(doc, open(os.path.join(dst, "kernel_resources.json"), "w"), indent=1)
     for k, v in sorted(out.items()):
-        if "1024" in k or "<float>" in k or "float, 8" in k or "float, 2" in k:
-            print(k, v)
+        if "mfma" in k or "<float>" in k or "float, 2>" in k:
+            print(k, v["vgpr_count"], v.get("agpr_count"), "spilled", v.get("vgpr_spill_count"), "scratch", v.get("private_segment_fixed_size"),
+                  "waves/SIMD", v["waves_per_simd_by_registers"])
 
 
 if __name__ == "__main__":
