@@ -107,6 +107,9 @@ def parse():
     ap.add_argument("--pmc", default="auto", choices=["auto", "on", "off"],
                     help="collect the VALU / MFMA / HBM counters of the dominant kernel with rocprofv3 child runs "
                          "(auto: single rank, rocprofv3 on PATH, CPU legs not disabled)")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
+                    help="kernel-selection option of the context (mcle_ctx_set_option; names: pyphysim_amd._lib.OPTIONS), "
+                         "e.g. --opt no_mfma=1 --opt grid_oversub=4; repeatable, for A/B runs")
     ap.add_argument("--launch-check", action="store_true",
                     help="no GPU: run the rank launcher, the range split and the reduction on gloo with an integer "
                          "checksum per realization index instead of a kernel (prints ranges + counters, no rate)")
@@ -330,6 +333,8 @@ def collect_pmc_live(args, batch):
                                                  sys.executable, os.path.abspath(__file__), "--config", args.config,
                                                  "--demod", args.demod, "--dtype", args.dtype, "--batch", str(batch),
                                                  "--steps", "3", "--warmup", "1", "--no-cpu", "--pmc", "off", "--single-demod", "--preroll-ms", "0"]
+        for item in args.opt:
+            cmd += ["--opt", item]
         try:
             subprocess.run(cmd, cwd="/tmp", env=env, timeout=180, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
             counters.update(_parse_pmc_csv(out_dir, KERNEL[args.config]))
@@ -454,6 +459,9 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     eng = Engine(local_rank, args.dtype)
+    for item in args.opt:
+        name, _, val = item.partition("=")
+        eng.set_option(name, int(val))
     batch = args.batch or BATCH[args.config]
 
     def barrier():

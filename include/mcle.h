@@ -75,6 +75,24 @@ int mcle_memcpy_d2h(mcle_ctx* ctx, void* dst, const void* d_src, size_t bytes); 
 /* device-to-device strided row copy (rows of row_bytes; pitches in bytes), enqueued on the stream */
 int mcle_memcpy_2d(mcle_ctx* ctx, void* d_dst, size_t dst_pitch, const void* d_src, size_t src_pitch,
                    size_t row_bytes, size_t rows);
+/* Per-context kernel-selection options (round 3: they used to be environment variables read inside the launch
+ * path, which made a context's behaviour depend on the caller's environment).  Every option is an integer, 0 is the
+ * default, and none of them changes a result beyond the rounding-level differences documented per kernel:
+ * they exist for A/B measurements and for tests that compare the matrix-core kernels with the VALU kernels they
+ * replace.  set: MCLE_E_INVAL for an unknown option or a value outside its range. */
+enum {
+    MCLE_OPT_NO_MFMA = 0,          /* 1: every fused pipeline / operator runs its VALU kernel (no matrix-core form) */
+    MCLE_OPT_MFMA_VARIANT = 1,     /* config-4 matrix-core kernel variant: 0 (= 36), 36, 32, 30, 21 */
+    MCLE_OPT_GRID_OVERSUB = 2,     /* persistent grids = this multiple of the resident set; 0: automatic (<= 8) */
+    MCLE_OPT_FLAT_WGS_PER_CU = 3,  /* single-carrier kernels: workgroups started per CU; 0: 64 */
+    MCLE_OPT_SINGLE_TDL = 4,       /* 1: config 3 on the one-realization-per-workgroup kernel */
+    MCLE_OPT_TDL_MFMA_WAVES = 5,   /* config-3 matrix-core kernel: 0 / 2 = two waves per SIMD, 3 = three */
+    MCLE_OPT_JAKES_DIRECT = 6,     /* 1: jakes_generate evaluates one sincos per ray and sample (k_jakes) */
+    MCLE_OPT_COUNT = 7
+};
+int mcle_ctx_set_option(mcle_ctx* ctx, int option, long long value);
+int mcle_ctx_get_option(mcle_ctx* ctx, int option, long long* value);
+
 /* kernel timing on the context stream with HIP events (used by bench.py's roofline leg) */
 int mcle_timer_start(mcle_ctx* ctx);
 int mcle_timer_stop_ms(mcle_ctx* ctx, float* ms);                               /* blocks */
@@ -172,6 +190,11 @@ int mcle_jakes_taps_philox(mcle_ctx* ctx, int dtype, uint64_t seed, uint64_t fir
 /* y[r][i] = x[r][i] + sqrt(noise_var) * CN(0,1) sample i of (seed, first + r, NOISE); rows of row_len */
 int mcle_awgn_philox(mcle_ctx* ctx, int dtype, const void* d_x, uint64_t seed, uint64_t first,
                      uint64_t count, size_t row_len, double noise_var, void* d_y);
+/* out[r][i] = sqrt(variance) * CN(0,1) sample i of (seed, first + r, stream): mcle_randn_c for a batch of realizations
+ * (e.g. the flat channel matrices H = randn_c(Nr, Nt) of count realizations from the CHAN stream,
+ * apps/mimo/simulate_mimo.py:78) */
+int mcle_randn_c_batch(mcle_ctx* ctx, int dtype, uint64_t seed, uint64_t first, uint64_t count,
+                       uint32_t stream, size_t row_len, double variance, void* d_out);
 /* d_idx[r][i] = symbol i of realization first_realization + r (DATA stream) */
 int mcle_rand_symbols_batch(mcle_ctx* ctx, uint64_t seed, uint64_t first_realization, uint64_t count,
                             int M, int32_t* d_idx, size_t n);
@@ -213,6 +236,12 @@ int mcle_blast_decode_per_subcarrier(mcle_ctx* ctx, int dtype, const void* d_G, 
 int mcle_mimo_channel(mcle_ctx* ctx, int dtype, const void* d_H, const void* d_X,
                       const void* d_noise, double noise_var, int nr, int nt, size_t ns, void* d_Y,
                       size_t batch);
+/* the same with the noise drawn on-chip: Y[b][r][c] = sum_a H[b][r][a] X[b][a][c] + sqrt(noise_var) * CN(0,1)
+ * sample r*ns + c of (seed, first + b, NOISE) -- the (Nr, Ns) row-major randn_c of simulate_mimo.py:97 under the
+ * mcle-philox-v1 contract; one pass over X and Y (the "H T + awgn" operator of SURVEY.md 8(d)'s staged model) */
+int mcle_mimo_channel_philox(mcle_ctx* ctx, int dtype, const void* d_H, const void* d_X, uint64_t seed,
+                             uint64_t first, double noise_var, int nr, int nt, size_t ns, void* d_Y,
+                             size_t batch);
 
 /* ---- a13: further MIMO schemes of mimo/mimo.py ---------------------------------------------- */
 /* Alamouti (mimo.py:1168-1269): x [batch][n] -> X [batch][2][n] (n even); decode with H [batch][nr][2] */

@@ -6,7 +6,7 @@ device, and raises :class:`McleError` otherwise.
 import ctypes
 import importlib.util
 import os
-from ctypes import (POINTER, Structure, byref, c_char_p, c_double, c_float, c_int, c_int32, c_size_t,
+from ctypes import (POINTER, Structure, byref, c_char_p, c_double, c_float, c_int, c_int32, c_longlong, c_size_t,
                     c_uint32, c_uint64, c_void_p)
 
 import numpy as np
@@ -16,6 +16,9 @@ DEMOD_MINDIST, DEMOD_QAM_SLICER = 0, 1
 CONST_GENERIC, CONST_QAM, CONST_BPSK = 0, 1, 2
 MAX_TAPS = 24
 STREAM_DATA, STREAM_NOISE, STREAM_CHAN, STREAM_PHASE = 0, 1, 2, 3
+# mcle_ctx_set_option keys (include/mcle.h MCLE_OPT_*): kernel selection for A/B runs and kernel-vs-kernel tests
+OPTIONS = {"no_mfma": 0, "mfma_variant": 1, "grid_oversub": 2, "flat_wgs_per_cu": 3, "single_tdl": 4,
+           "tdl_mfma_waves": 5, "jakes_direct": 6}
 
 LIB_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(LIB_DIR, "libmcle.so")
@@ -130,6 +133,8 @@ _PROTOS = {
     "mcle_ctx_set_stream": (c_int, [_P, _P]),
     "mcle_ctx_get_stream": (c_int, [_P, POINTER(_P)]),
     "mcle_ctx_sync": (c_int, [_P]),
+    "mcle_ctx_set_option": (c_int, [_P, c_int, c_longlong]),
+    "mcle_ctx_get_option": (c_int, [_P, c_int, POINTER(c_longlong)]),
     "mcle_ctx_device_info": (c_int, [_P, POINTER(c_int), POINTER(c_int), c_char_p, c_int]),
     "mcle_malloc": (c_int, [_P, c_size_t, POINTER(_P)]),
     "mcle_free": (c_int, [_P, _P]),
@@ -170,6 +175,9 @@ _PROTOS = {
                                        c_double, POINTER(c_double), _P, c_size_t]),
     "mcle_awgn_philox": (c_int, [_P, c_int, _P, c_uint64, c_uint64, c_uint64, c_size_t, c_double, _P]),
     "mcle_rand_symbols_batch": (c_int, [_P, c_uint64, c_uint64, c_uint64, c_int, _P, c_size_t]),
+    "mcle_randn_c_batch": (c_int, [_P, c_int, c_uint64, c_uint64, c_uint64, c_uint32, c_size_t, c_double, _P]),
+    "mcle_mimo_channel_philox": (c_int, [_P, c_int, _P, _P, c_uint64, c_uint64, c_double, c_int, c_int, c_size_t, _P,
+                                         c_size_t]),
     "mcle_blast_decode_per_subcarrier": (c_int, [_P, c_int, _P, _P, c_int, c_int, c_size_t, _P, c_size_t]),
     "mcle_cdiv": (c_int, [_P, c_int, _P, _P, _P, c_size_t]),
     "mcle_ofdm_modulate": (c_int, [_P, c_int, _P, c_size_t, c_int, c_int, c_int, _P, c_size_t]),

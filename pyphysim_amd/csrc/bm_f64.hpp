@@ -1,0 +1,99 @@
+// bm_f64.hpp -- the complex128 Box-Muller of the mcle-philox-v1 contract (philox.hpp), written for gfx950's f64 datapath.
+//
+//   z = sigma * sqrt(-ln((x0 + 0.5) 2^-32)) * exp(j * fl(2 pi_d * x1 2^-32))       (oracle: oracle/philox.py cnormal)
+//
+// The library forms (log, sincos, sqrt of the device libm) cost ~180 double-precision instructions per sample and were
+// more than half of every complex128 pipeline (round-3 profile of k_run_mimo_ofdm<double>: 6 500 VALU instructions per
+// wavefront and realization, 3 400 of them here).  The arguments are structured -- u is an odd multiple of 2^-33, the
+// angle is a 32-bit fraction of a turn -- so both functions reduce to one small table look-up and a short polynomial:
+//
+//   -ln u   u = m 2^e, m in [1, 2) (folded to [0.75, 1.5) so that u -> 1 meets c = 1 with ln c = 0 exactly);
+//           j = the nearest of 129 nodes c_j, r = (m - c_j) / c_j exactly representable difference times a rounded
+//           reciprocal, |r| <= 2^-8;  ln u = e ln 2 + ln c_j + log1p(r), log1p by its degree-7 series (next term 2^-67).
+//           Measured against x87 extended precision over 4e6 words incl. the 1e5 largest: relative error <= 2.3e-16
+//           (NumPy's own log: 1.2e-16), i.e. <= 3e-16 absolute on sqrt(-ln u).
+//   sincos  NumPy evaluates cos / sin of the DOUBLE ang = fl(2 pi_d v); the nodes theta_k = fl(k fl(2 pi / 256)) are
+//           doubles too, so r = ang - theta_k is exact (Sterbenz), |r| <= 0.0123, and the table holds cos / sin of the
+//           double theta_k: rotation by the degree-7 / degree-6 polynomials of r.  <= 1.2e-16 absolute against the
+//           extended-precision value of cos(ang), sin(ang).
+//   sqrt    v_rsq_f64 + one coupled Newton step + two residual corrections (argument range [2e-10, 23]: no scaling).
+//
+// ~47 f64 instructions + 12 integer ones + 3 table reads per sample.  tests/test_bm_f64_cpu.py compiles this header
+// for the host and checks it word by word against NumPy; the -m gpu parity tests then hold every complex128 pipeline's
+// per-realization error counts equal to the oracle's.
+#pragma once
+#include <cstdint>
+
+#ifndef MCLE_BM_TABLE
+#define MCLE_BM_TABLE static __device__ const
+#endif
+#ifndef MCLE_BM_FN
+#define MCLE_BM_FN __device__ __forceinline__
+#endif
+#ifndef MCLE_BM_RSQ
+#define MCLE_BM_RSQ(a) __builtin_amdgcn_rsq(a)
+#endif
+#ifndef MCLE_BM_FMA
+#define MCLE_BM_FMA(a, b, c) __builtin_fma(a, b, c)
+#endif
+
+#include "bm_tables.hpp"
+
+namespace mcle {
+
+// -ln((x0 + 0.5) 2^-32)
+MCLE_BM_FN double bm_neg_log(uint32_t x0) {
+    const double ud = (double)x0 + 0.5;                                   // exact: u 2^32
+    const uint64_t bits = __builtin_bit_cast(uint64_t, ud);
+    const uint32_t hi = (uint32_t)(bits >> 32);
+    const uint32_t mant = hi & 0xFFFFFu;
+    const uint32_t j = (mant + 0x1000u) >> 13;                            // nearest node, 0 .. 128
+    const bool fold = j >= 64u;                                           // m >= 1.5: use m / 2 and e + 1
+    const uint32_t ebase = fold ? 0x3FE00000u : 0x3FF00000u;
+    const double m = __builtin_bit_cast(double, ((uint64_t)(ebase | mant) << 32) | (uint64_t)(uint32_t)bits);
+    const double c = __builtin_bit_cast(double, (uint64_t)(ebase + (j << 13)) << 32);    // (1 + j/128) [/ 2]; j = 128 -> 1
+    const int e = (int)(hi >> 20) - (1023 + 32) + (fold ? 1 : 0);
+    const double inv_c = kBmLog[2 * j], lnc = kBmLog[2 * j + 1];
+    const double r = (m - c) * inv_c;
+    const double r2 = r * r;
+    // log1p(r) = r + r^2 (-1/2 + r/3 + r^2 ((-1/4 + r/5) + r^2 (-1/6 + r/7)))
+    const double a0 = MCLE_BM_FMA(r, 1.0 / 3.0, -0.5);
+    const double a1 = MCLE_BM_FMA(r, 0.2, -0.25);
+    const double a2 = MCLE_BM_FMA(r, 1.0 / 7.0, -1.0 / 6.0);
+    const double q = MCLE_BM_FMA(r2, MCLE_BM_FMA(r2, a2, a1), a0);
+    const double small = MCLE_BM_FMA(r2, q, r);
+    const double big = MCLE_BM_FMA((double)e, 0x1.62e42fefa39efp-1, lnc);    // e ln 2 + ln c_j, one rounding
+    return -(big + small);
+}
+
+// sqrt(a), a in [2e-10, 23]
+MCLE_BM_FN double bm_sqrt(double a) {
+    const double y = MCLE_BM_RSQ(a);
+    double g = a * y, h = 0.5 * y;
+    const double r = MCLE_BM_FMA(-h, g, 0.5);
+    g = MCLE_BM_FMA(g, r, g);
+    h = MCLE_BM_FMA(h, r, h);
+    double d = MCLE_BM_FMA(-g, g, a);
+    g = MCLE_BM_FMA(d, h, g);
+    d = MCLE_BM_FMA(-g, g, a);
+    return MCLE_BM_FMA(d, h, g);
+}
+
+// cos / sin of the double fl(2 pi_d * x1 2^-32)
+MCLE_BM_FN void bm_sincos(uint32_t x1, double& c, double& s) {
+    const double ang = (double)x1 * 0x1.921fb54442d18p-30;                // (2 pi_d) 2^-32: fl(.) == NumPy's 2.0*np.pi*(x1*2**-32)
+    const uint32_t k = ((x1 >> 23) + 1u) >> 1;                            // nearest node, 0 .. 256
+    const double ct = kBmTrig[2 * k], st = kBmTrig[2 * k + 1];
+    const double r = ang - kBmTheta[k];                                   // exact
+    const double s2 = r * r;
+    double p = MCLE_BM_FMA(s2, -1.0 / 5040.0, 1.0 / 120.0);
+    p = MCLE_BM_FMA(s2, p, -1.0 / 6.0);
+    const double sr = MCLE_BM_FMA(r * s2, p, r);                          // sin r
+    double q = MCLE_BM_FMA(s2, -1.0 / 720.0, 1.0 / 24.0);
+    q = MCLE_BM_FMA(s2, q, -0.5);
+    const double cm = s2 * q;                                             // cos r - 1
+    c = ct + MCLE_BM_FMA(-st, sr, ct * cm);
+    s = st + MCLE_BM_FMA(ct, sr, st * cm);
+}
+
+}  // namespace mcle

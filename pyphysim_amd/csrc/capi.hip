@@ -167,6 +167,29 @@ int mcle_ctx_get_stream(mcle_ctx* ctx, void** hip_stream) {
     return MCLE_OK;
 }
 
+int mcle_ctx_set_option(mcle_ctx* ctx, int option, long long value) {
+    MCLE_REQUIRE(ctx != nullptr, "null context");
+    MCLE_REQUIRE(option >= 0 && option < MCLE_OPT_COUNT, "unknown option %d", option);
+    bool ok = false;
+    switch (option) {
+        case MCLE_OPT_NO_MFMA: case MCLE_OPT_SINGLE_TDL: case MCLE_OPT_JAKES_DIRECT: ok = value == 0 || value == 1; break;
+        case MCLE_OPT_MFMA_VARIANT: ok = value == 0 || value == 36 || value == 32 || value == 30 || value == 21; break;
+        case MCLE_OPT_GRID_OVERSUB: ok = value >= 0 && value <= 64; break;
+        case MCLE_OPT_FLAT_WGS_PER_CU: ok = value >= 0 && value <= 4096; break;
+        case MCLE_OPT_TDL_MFMA_WAVES: ok = value == 0 || value == 2 || value == 3; break;
+    }
+    MCLE_REQUIRE(ok, "option %d: value %lld out of range", option, value);
+    ctx->opt[option] = value;
+    return MCLE_OK;
+}
+
+int mcle_ctx_get_option(mcle_ctx* ctx, int option, long long* value) {
+    MCLE_REQUIRE(ctx != nullptr && value != nullptr, "null argument");
+    MCLE_REQUIRE(option >= 0 && option < MCLE_OPT_COUNT, "unknown option %d", option);
+    *value = ctx->opt[option];
+    return MCLE_OK;
+}
+
 int mcle_ctx_sync(mcle_ctx* ctx) {
     MCLE_REQUIRE(ctx != nullptr, "null context");
     MCLE_HIP(hipSetDevice(ctx->device));

@@ -195,6 +195,9 @@ struct mcle_ctx {
     void* d_comm_buf = nullptr;
     size_t comm_buf_words = 0;
 
+    // kernel-selection options (mcle_ctx_set_option); 0 = default
+    long long opt[MCLE_OPT_COUNT] = {};
+
     int bind() const;
     int get_twiddles(int n, int dtype, void** d_tw);
     int scratch(size_t bytes, void** d_ptr);

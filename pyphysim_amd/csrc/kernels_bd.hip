@@ -757,7 +757,7 @@ static int launch_run_bd(mcle_ctx* ctx, const mcle_bd_cfg* cfg, const BdParams& 
         MCLE_LAUNCH_CHECK();
         const uint64_t cap = (uint64_t)ctx->n_cu * 4 * (sizeof(T) == 4 ? 4 : 2);
         const uint64_t chunks = (m + per_wave - 1) / per_wave;
-        const unsigned grid = (unsigned)oversubscribed_grid(cap, chunks, 2);     // a chunk is 8-16 realizations; one chunk per workgroup measured 1.5 x slower
+        const unsigned grid = (unsigned)oversubscribed_grid(ctx, cap, chunks, 2);     // a chunk is 8-16 realizations; one chunk per workgroup measured 1.5 x slower
         hipLaunchKernelGGL((k_bd_link<T, R>), dim3(grid), dim3(64), lds, ctx->stream, mp, pp, seed, first + off, m, per_wave,
                            (const cx<T>*)recs, d_counters, d_sym_err ? d_sym_err + off : nullptr,
                            d_bit_err ? d_bit_err + off : nullptr);

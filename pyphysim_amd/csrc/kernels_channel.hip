@@ -273,16 +273,17 @@ __global__ __launch_bounds__(kChBlock) void k_jakes_philox(uint64_t seed, uint64
 // y[r][i] = x[r][i] + sigma * CN(0,1) sample i of (seed, first + r, NOISE)
 template <typename T>
 __global__ __launch_bounds__(kChBlock) void k_awgn_philox(const cx<T>* __restrict__ x, uint64_t seed, uint64_t first,
-                                                          size_t row_len, T sigma, cx<T>* __restrict__ y) {
+                                                          uint32_t stream, size_t row_len, T sigma,
+                                                          cx<T>* __restrict__ y) {
     const uint64_t rl = blockIdx.y;
     const Rng rng(seed, first + rl);
     const size_t pairs = (row_len + 1) / 2;
     for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < pairs; p += (size_t)gridDim.x * blockDim.x) {
         cx<T> z0, z1;
-        cn_pair<T>(rng, STREAM_NOISE, (uint32_t)p, sigma, z0, z1);
+        cn_pair<T>(rng, stream, (uint32_t)p, sigma, z0, z1);
         const size_t o = rl * row_len + 2 * p;
-        y[o] = cadd(x[o], z0);
-        if (2 * p + 1 < row_len) y[o + 1] = cadd(x[o + 1], z1);
+        y[o] = x ? cadd(x[o], z0) : z0;                       // x == nullptr: the draws themselves (mcle_randn_c_batch)
+        if (2 * p + 1 < row_len) y[o + 1] = x ? cadd(x[o + 1], z1) : z1;
     }
 }
 
@@ -434,11 +435,11 @@ static int jakes_impl(mcle_ctx* ctx, int dtype, const double* phi, const double*
     const double* d_amp = (const double*)d_par + 2 * np;
     const double* d_times = times ? d_amp + n_streams : nullptr;
     const unsigned gy = (unsigned)(n_streams < 64 ? n_streams : 64);
-    if (!times && L <= 16 && n_samples >= 1024 && !std::getenv("MCLE_JAKES_DIRECT")) {
+    if (!times && L <= 16 && n_samples >= 1024 && !ctx->opt[MCLE_OPT_JAKES_DIRECT]) {
         // uniform time axis: 64-sample blocks, one phasor per ray and block (k_jakes_blocks / k_jakes_mfma)
         const int lt = (L + 3) / 4;
         const size_t cap = (size_t)(ctx->n_cu > 0 ? ctx->n_cu : 256) * 4 / gy + 1;
-        if (dtype == MCLE_F32 && !std::getenv("MCLE_NO_MFMA")) {      // complex64: the matrix-core form
+        if (dtype == MCLE_F32 && !ctx->opt[MCLE_OPT_NO_MFMA]) {      // complex64: the matrix-core form
             const size_t n_tiles = (n_samples + 255) / 256;
             size_t gxm = (n_tiles + 4 * 16 - 1) / (4 * 16);
             if (gxm > 2 * cap) gxm = 2 * cap;
@@ -626,8 +627,8 @@ int mcle_jakes_taps_philox(mcle_ctx* ctx, int dtype, uint64_t seed, uint64_t fir
     return MCLE_OK;
 }
 
-int mcle_awgn_philox(mcle_ctx* ctx, int dtype, const void* d_x, uint64_t seed, uint64_t first, uint64_t count,
-                     size_t row_len, double noise_var, void* d_y) {
+static int awgn_philox_impl(mcle_ctx* ctx, int dtype, const void* d_x, uint64_t seed, uint64_t first, uint64_t count,
+                            uint32_t stream, size_t row_len, double noise_var, void* d_y) {
     MCLE_REQUIRE(ctx != nullptr, "null context");
     MCLE_REQUIRE(dtype == MCLE_F32 || dtype == MCLE_F64, "dtype must be MCLE_F32 or MCLE_F64");
     MCLE_REQUIRE(noise_var >= 0.0, "noise variance must be non-negative");
@@ -638,12 +639,25 @@ int mcle_awgn_philox(mcle_ctx* ctx, int dtype, const void* d_x, uint64_t seed, u
     dim3 grid((unsigned)grid_for(ctx, (row_len + 1) / 2, kChBlock, 2), (unsigned)count);
     if (dtype == MCLE_F32)
         hipLaunchKernelGGL(k_awgn_philox<float>, grid, dim3(kChBlock), 0, ctx->stream, (const float2*)d_x, seed, first,
-                           row_len, (float)std::sqrt(noise_var), (float2*)d_y);
+                           stream, row_len, (float)std::sqrt(noise_var), (float2*)d_y);
     else
         hipLaunchKernelGGL(k_awgn_philox<double>, grid, dim3(kChBlock), 0, ctx->stream, (const double2*)d_x, seed,
-                           first, row_len, std::sqrt(noise_var), (double2*)d_y);
+                           first, stream, row_len, std::sqrt(noise_var), (double2*)d_y);
     MCLE_LAUNCH_CHECK();
     return MCLE_OK;
+}
+
+int mcle_awgn_philox(mcle_ctx* ctx, int dtype, const void* d_x, uint64_t seed, uint64_t first, uint64_t count,
+                     size_t row_len, double noise_var, void* d_y) {
+    MCLE_REQUIRE(d_x != nullptr && d_y != nullptr, "null argument");
+    return awgn_philox_impl(ctx, dtype, d_x, seed, first, count, mcle::STREAM_NOISE, row_len, noise_var, d_y);
+}
+
+int mcle_randn_c_batch(mcle_ctx* ctx, int dtype, uint64_t seed, uint64_t first, uint64_t count, uint32_t stream,
+                       size_t row_len, double variance, void* d_out) {
+    MCLE_REQUIRE(d_out != nullptr, "null argument");
+    MCLE_REQUIRE(stream <= 3, "stream must be one of the four mcle-philox-v1 streams");
+    return awgn_philox_impl(ctx, dtype, nullptr, seed, first, count, stream, row_len, variance, d_out);
 }
 
 }  // extern "C"

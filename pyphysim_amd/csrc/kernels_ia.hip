@@ -686,7 +686,7 @@ int run_ia_impl(mcle_ctx* ctx, const mcle_ia_cfg* cfg, uint64_t seed, uint64_t f
         MCLE_LAUNCH_CHECK();
         const uint64_t chunks = (n + per_wave - 1) / per_wave;
         const uint64_t cap = (uint64_t)ctx->n_cu * 4 * (sizeof(T) == 4 ? 4 : 2);
-        const unsigned grid = (unsigned)oversubscribed_grid(cap, chunks, 2);     // a chunk is 8-16 realizations; one chunk per workgroup measured 1.5 x slower
+        const unsigned grid = (unsigned)oversubscribed_grid(ctx, cap, chunks, 2);     // a chunk is 8-16 realizations; one chunk per workgroup measured 1.5 x slower
         hipLaunchKernelGGL(k_ia_link<T>, dim3(grid), dim3(64), lds, ctx->stream, mp, cfg->n_symbols, cfg->noise_var, seed,
                            first + off, n, per_wave, (const cx<T>*)recs, d_counters, d_sym ? d_sym + off : nullptr,
                            d_bit ? d_bit + off : nullptr);

@@ -3,6 +3,7 @@
 // :597-607 (filters), apps/mimo/simulate_mimo.py:96-98 (received = H @ X + noise).
 #include "mimo.hpp"
 #include "mimo_svd.hpp"
+#include "philox.hpp"
 
 namespace mcle {
 
@@ -271,6 +272,68 @@ __global__ __launch_bounds__(kMimoBlock) void k_mimo_channel(const cx<T>* __rest
                 acc.y += sigma * w.y;
             }
             Y[o] = acc;
+        }
+    }
+}
+
+// Y[b][r][c] = sum_a H[b][r][a] X[b][a][c] + sigma * CN(0,1) sample r*ns + c of (seed, first + b, NOISE): two columns per
+// thread = one Philox block per (row, thread) when r*ns is even (every word used); 4x4 complex64 in 16-byte accesses
+template <typename T>
+__global__ __launch_bounds__(kMimoBlock) void k_mimo_channel_philox(const cx<T>* __restrict__ H, const cx<T>* __restrict__ X,
+                                                                    uint64_t seed, uint64_t first, T sigma, int nr, int nt,
+                                                                    size_t ns, cx<T>* __restrict__ Y, int vec) {
+    const size_t b = blockIdx.y;
+    const Rng rng(seed, first + b);
+    const cx<T>* Hb = H + b * (size_t)nr * nt;
+    const cx<T>* Xb = X + b * (size_t)nt * ns;
+    if constexpr (sizeof(T) == 4) {
+        if (vec) {
+            float2 Hr[4][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int a = 0; a < 4; ++a) Hr[r][a] = Hb[r * 4 + a];
+            for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < ns / 2; p += (size_t)gridDim.x * blockDim.x) {
+                float4 x[4];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) x[a] = reinterpret_cast<const float4*>(Xb + (size_t)a * ns)[p];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float2 a0, a1;
+                    cn_pair<float>(rng, STREAM_NOISE, (uint32_t)(((size_t)r * ns) / 2 + p), sigma, a0, a1);
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        a0 = cfma(Hr[r][a], make_float2(x[a].x, x[a].y), a0);
+                        a1 = cfma(Hr[r][a], make_float2(x[a].z, x[a].w), a1);
+                    }
+                    reinterpret_cast<float4*>(Y + (b * 4 + r) * ns)[p] = make_float4(a0.x, a0.y, a1.x, a1.y);
+                }
+            }
+            return;
+        }
+    }
+    const size_t pairs = (ns + 1) / 2;
+    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < pairs; p += (size_t)gridDim.x * blockDim.x) {
+        const size_t c0 = 2 * p;
+        const bool two = c0 + 1 < ns;
+        for (int r = 0; r < nr; ++r) {
+            const uint64_t i0 = (uint64_t)r * ns + c0;
+            cx<T> z0, z1;
+            if ((i0 & 1) == 0) {
+                cn_pair<T>(rng, STREAM_NOISE, (uint32_t)(i0 >> 1), sigma, z0, z1);
+            } else {
+                z0 = cn_sample<T>(rng, STREAM_NOISE, i0, sigma);
+                z1 = two ? cn_sample<T>(rng, STREAM_NOISE, i0 + 1, sigma) : z0;
+            }
+            cx<T> acc0 = mk<T>(0, 0), acc1 = mk<T>(0, 0);
+            for (int a = 0; a < nt; ++a) {
+                const cx<T> h = Hb[r * nt + a];
+                acc0 = cfma(h, Xb[(size_t)a * ns + c0], acc0);
+                if (two) acc1 = cfma(h, Xb[(size_t)a * ns + c0 + 1], acc1);
+            }
+            const size_t o = (b * nr + r) * ns + c0;
+            Y[o] = cadd(acc0, z0);
+            if (two) Y[o + 1] = cadd(acc1, z1);
         }
     }
 }
@@ -593,6 +656,28 @@ int mcle_mimo_channel(mcle_ctx* ctx, int dtype, const void* d_H, const void* d_X
         hipLaunchKernelGGL(k_mimo_channel<double>, grid, dim3(kMimoBlock), 0, ctx->stream, (const double2*)d_H,
                            (const double2*)d_X, (const double2*)d_noise, std::sqrt(noise_var), nr, nt, ns,
                            (double2*)d_Y, 0);
+    MCLE_LAUNCH_CHECK();
+    return MCLE_OK;
+}
+
+int mcle_mimo_channel_philox(mcle_ctx* ctx, int dtype, const void* d_H, const void* d_X, uint64_t seed, uint64_t first,
+                             double noise_var, int nr, int nt, size_t ns, void* d_Y, size_t batch) {
+    int rc = check_mimo(ctx, dtype, nr, nt, batch);
+    if (rc) return rc;
+    MCLE_REQUIRE(noise_var >= 0.0, "noise variance must be non-negative");
+    MCLE_REQUIRE(batch <= 65535, "at most 65535 realizations per call");
+    MCLE_REQUIRE((uint64_t)nr * ns < (1ull << 33), "more than 2^33 noise samples per realization");
+    if (ns == 0 || batch == 0) return MCLE_OK;
+    if ((rc = ctx->bind())) return rc;
+    const int vec = dtype == MCLE_F32 && nr == 4 && nt == 4 && ns % 2 == 0 &&
+                    ((((uintptr_t)d_X) | ((uintptr_t)d_Y)) & 15u) == 0;
+    dim3 grid((unsigned)grid_for(ctx, (ns + 1) / 2, kMimoBlock, 4), (unsigned)batch);
+    if (dtype == MCLE_F32)
+        hipLaunchKernelGGL(k_mimo_channel_philox<float>, grid, dim3(kMimoBlock), 0, ctx->stream, (const float2*)d_H,
+                           (const float2*)d_X, seed, first, (float)std::sqrt(noise_var), nr, nt, ns, (float2*)d_Y, vec);
+    else
+        hipLaunchKernelGGL(k_mimo_channel_philox<double>, grid, dim3(kMimoBlock), 0, ctx->stream, (const double2*)d_H,
+                           (const double2*)d_X, seed, first, std::sqrt(noise_var), nr, nt, ns, (double2*)d_Y, 0);
     MCLE_LAUNCH_CHECK();
     return MCLE_OK;
 }

@@ -229,7 +229,7 @@ __global__ __launch_bounds__(kOmBlock, 4) void k_ofdm_demod_1024_mfma(const floa
 // host side: MCLE_OK = launched, MCLE_E_UNSUPPORTED = not this kernel's case (complex64, fft_size 1024)
 int ofdm_mod_1024_mfma(mcle_ctx* ctx, const void* d_in, size_t n_in, int cp, int num_used, int n_sym, double scale,
                        void* d_out, size_t batch) {
-    if (std::getenv("MCLE_NO_MFMA")) return MCLE_E_UNSUPPORTED;
+    if (ctx->opt[MCLE_OPT_NO_MFMA]) return MCLE_E_UNSUPPORTED;
     int rc;
     void* tw = nullptr;
     if ((rc = ctx->get_twiddles(kF16N, MCLE_F32, &tw))) return rc;
@@ -243,7 +243,7 @@ int ofdm_mod_1024_mfma(mcle_ctx* ctx, const void* d_in, size_t n_in, int cp, int
 
 int ofdm_demod_1024_mfma(mcle_ctx* ctx, const void* d_in, int cp, int num_used, int n_sym, double scale, void* d_out,
                          size_t batch) {
-    if (std::getenv("MCLE_NO_MFMA")) return MCLE_E_UNSUPPORTED;
+    if (ctx->opt[MCLE_OPT_NO_MFMA]) return MCLE_E_UNSUPPORTED;
     int rc;
     void* tw = nullptr;
     if ((rc = ctx->get_twiddles(kF16N, MCLE_F32, &tw))) return rc;

@@ -1,6 +1,5 @@
 // pipe_common.hpp -- pieces shared by the fused pipeline translation units.
 #pragma once
-#include <cstdlib>
 #include "common.hpp"
 #include "modem.hpp"
 
@@ -34,12 +33,12 @@ __device__ __forceinline__ void block_sum2(unsigned& a, unsigned& b, unsigned* s
 // Grid of a persistent kernel whose workgroups each take an equal share of `units` (realizations, passes): up to eight
 // times the resident set, as long as a workgroup keeps >= 8 units to spread its set-up over.  The queued workgroups start
 // as the first ones finish, which evens out per-workgroup speed differences and shortens the tail -- measured on the
-// matrix-core kernels (MCLE_GRID_OVERSUB = 1 / 2 / 4 / 8 / 16 / 32): config 4 1.516 / 1.458 / 1.415 / 1.401 / 1.411 / 2.02 ms
+// matrix-core kernels (MCLE_OPT_GRID_OVERSUB = 1 / 2 / 4 / 8 / 16 / 32): config 4 1.516 / 1.458 / 1.415 / 1.401 / 1.411 / 2.02 ms
 // per 65 536 realizations, config 3 1.602 / 1.575 / 1.555 / 1.541 / 1.550 / 1.608 ms per 131 072.
-inline uint64_t oversubscribed_grid(uint64_t resident, uint64_t units, uint64_t min_units = 8) {
+inline uint64_t oversubscribed_grid(const mcle_ctx* ctx, uint64_t resident, uint64_t units, uint64_t min_units = 8) {
     uint64_t f = 8;
-    if (const char* v = std::getenv("MCLE_GRID_OVERSUB")) {
-        f = std::atoi(v) > 0 ? (uint64_t)std::atoi(v) : 8;
+    if (ctx->opt[MCLE_OPT_GRID_OVERSUB] > 0) {
+        f = (uint64_t)ctx->opt[MCLE_OPT_GRID_OVERSUB];
     } else {
         while (f > 1 && units < resident * f * min_units) f >>= 1;
     }

@@ -24,8 +24,6 @@
 // complementary bank halves), position p stored at p ^ (f(p >> 6) << 2), f(k) = (k & 7) ^ ((k & 1) << 3): every
 // access of the passes above is bank-conflict free (tests/test_fft16_layout.py replays all of them; the b128
 // stores of the middle stage are 2-way, below their own issue cost).
-#include <cstdlib>
-
 #include "fft.hpp"
 #include "fft16.hpp"
 #include "qam_pack.hpp"
@@ -494,7 +492,7 @@ __global__ __launch_bounds__(kPipeBlock, WAVES) void k_run_mimo_ofdm_mfma(MimoPa
 int run_mimo_ofdm_mfma(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, uint64_t seed, uint64_t first, uint64_t count,
                        mcle_counters* d_counters, uint32_t* d_sym, uint32_t* d_bit) {
     if (cfg->fft_size != kF16N || cfg->nt != 4 || cfg->nr != 4) return MCLE_E_UNSUPPORTED;
-    if (std::getenv("MCLE_NO_MFMA")) return MCLE_E_UNSUPPORTED;
+    if (ctx->opt[MCLE_OPT_NO_MFMA]) return MCLE_E_UNSUPPORTED;
     int rc;
     void* tw = nullptr;
     if ((rc = ctx->get_twiddles(kF16N, MCLE_F32, &tw))) return rc;
@@ -503,12 +501,11 @@ int run_mimo_ofdm_mfma(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, uint64_t se
     const size_t lds = (size_t)4 * kF16Ant * sizeof(float) + (size_t)(kMaxTable + 2 * 34) * sizeof(float2) +
                        kMaxTable * sizeof(float4) + 16 * sizeof(unsigned) +
                        (size_t)mp.grid.G * mp.grid.G * sizeof(unsigned long long) + (size_t)4 * cfg->num_used + 16;
-    // variants kept for A/B runs (MCLE_MFMA_VARIANT = 10 * waves + flags): 36 = 3 waves per SIMD, noise drawn in the
+    // variants kept for A/B runs (MCLE_OPT_MFMA_VARIANT = 10 * waves + flags): 36 = 3 waves per SIMD, noise drawn in the
     // middle stage, operand loads of the four antennas first, pass twiddles fetched per pass (default: 7 spilled
     // registers, 1.535-1.544 ms per 65 536 realizations); 32 = the same with the twiddles resident (28 spilled, 1.555);
     // 30 = antenna-by-antenna passes; 21 = 2 waves per SIMD (229 VGPRs, no spills) with the noise under P1 / P2 (1.62)
-    int variant = 36;
-    if (const char* v = std::getenv("MCLE_MFMA_VARIANT")) variant = std::atoi(v);
+    const int variant = ctx->opt[MCLE_OPT_MFMA_VARIANT] ? (int)ctx->opt[MCLE_OPT_MFMA_VARIANT] : 36;
     const int waves = variant / 10 == 2 ? 2 : 3;
     auto kern = variant == 30 ? k_run_mimo_ofdm_mfma<3, 0> : variant == 21 ? k_run_mimo_ofdm_mfma<2, 1>
                 : variant == 32 ? k_run_mimo_ofdm_mfma<3, 2> : k_run_mimo_ofdm_mfma<3, 6>;
@@ -526,7 +523,7 @@ int run_mimo_ofdm_mfma(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, uint64_t se
         hipLaunchKernelGGL(k_mimo_filters, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, pp, seed, first + off, n,
                            (float2*)recs);
         MCLE_LAUNCH_CHECK();
-        const unsigned grid = (unsigned)oversubscribed_grid(resident, n);
+        const unsigned grid = (unsigned)oversubscribed_grid(ctx, resident, n);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(kPipeBlock), lds, ctx->stream, pp, mp, seed, first + off, n,
                            (const float2*)tw, (const float2*)recs, d_counters, d_sym ? d_sym + off : nullptr,
                            d_bit ? d_bit + off : nullptr);

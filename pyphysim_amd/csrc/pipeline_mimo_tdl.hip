@@ -442,7 +442,7 @@ int run_mimo_tdl_impl(mcle_ctx* ctx, MimoTdlParams pp, int method, uint64_t seed
     int per_cu = (int)((size_t)160 * 1024 / (lds + 512));
     if (per_cu < 1) per_cu = 1;
     if (per_cu > 8) per_cu = 8;
-    const unsigned grid = (unsigned)oversubscribed_grid((uint64_t)ctx->n_cu * per_cu, count);
+    const unsigned grid = (unsigned)oversubscribed_grid(ctx, (uint64_t)ctx->n_cu * per_cu, count);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kPipeBlock), lds, ctx->stream, pp, mp, seed, first, count,
                        (const cx<T>*)tw, d_counters, d_sym, d_bit);
     MCLE_LAUNCH_CHECK();

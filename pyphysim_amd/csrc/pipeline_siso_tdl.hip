@@ -816,7 +816,7 @@ int run_siso_tdl_mfma(mcle_ctx* ctx, const SisoTdlParams& pp, int method, uint64
                       mcle_counters* d_counters, uint32_t* d_sym, uint32_t* d_bit) {
     constexpr int NB = 4;
     if (pp.cp < pp.dmax || (pp.num_used & 15) != 0) return MCLE_E_UNSUPPORTED;
-    if (std::getenv("MCLE_NO_MFMA")) return MCLE_E_UNSUPPORTED;
+    if (ctx->opt[MCLE_OPT_NO_MFMA]) return MCLE_E_UNSUPPORTED;
     const size_t PS = (size_t)pp.n_taps * NB;
     if (PS > kPipeBlock || 3 * PS * pp.L * sizeof(float) > 8192) return MCLE_E_UNSUPPORTED;
     int rc;
@@ -831,16 +831,15 @@ int run_siso_tdl_mfma(mcle_ctx* ctx, const SisoTdlParams& pp, int method, uint64
                        64 * sizeof(unsigned);
     if (lds + 512 > (size_t)160 * 1024 / 2) return MCLE_E_UNSUPPORTED;
     // two workgroups per CU with 256 VGPRs (13 spilled registers) beat three with 168 (130 spilled): 1.63 vs 2.04 ms per
-    // 131072 realizations (A/B: MCLE_TDL_MFMA_WAVES=3).  The equaliser's W^{f d} from an LDS copy instead of the
+    // 131072 realizations (A/B: MCLE_OPT_TDL_MFMA_WAVES = 3).  The equaliser's W^{f d} from an LDS copy instead of the
     // L1-resident global table: 1.62 vs 1.63 ms, not kept.
-    int waves = 2;
-    if (const char* v = std::getenv("MCLE_TDL_MFMA_WAVES")) waves = std::atoi(v) == 3 ? 3 : 2;
+    const int waves = ctx->opt[MCLE_OPT_TDL_MFMA_WAVES] == 3 ? 3 : 2;
     auto kern = waves == 2 ? k_run_ofdm_tdl_mfma<2> : k_run_ofdm_tdl_mfma<3>;
     MCLE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int per_cu = (int)((size_t)160 * 1024 / (lds + 512));
     if (per_cu > waves) per_cu = waves;     // __launch_bounds__(256, WAVES)
     const uint64_t passes = (count + NB - 1) / NB;
-    const unsigned grid = (unsigned)oversubscribed_grid((uint64_t)ctx->n_cu * per_cu, passes);
+    const unsigned grid = (unsigned)oversubscribed_grid(ctx, (uint64_t)ctx->n_cu * per_cu, passes);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kPipeBlock), lds, ctx->stream, pp, mp, seed, first, count,
                        (const float2*)tw, d_counters, d_sym, d_bit);
     MCLE_LAUNCH_CHECK();
@@ -873,7 +872,7 @@ int run_siso_tdl_batch_impl(mcle_ctx* ctx, SisoTdlParams pp, int method, uint64_
     if (per_cu < 1) per_cu = 1;
     if (per_cu > 8) per_cu = 8;
     const uint64_t passes = (count + NB - 1) / NB;
-    const unsigned grid = (unsigned)oversubscribed_grid((uint64_t)ctx->n_cu * per_cu, passes);
+    const unsigned grid = (unsigned)oversubscribed_grid(ctx, (uint64_t)ctx->n_cu * per_cu, passes);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kPipeBlock), lds, ctx->stream, pp, mp, seed, first, count,
                        (const cx<T>*)tw, d_counters, d_sym, d_bit);
     MCLE_LAUNCH_CHECK();

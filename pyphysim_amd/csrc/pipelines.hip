@@ -882,20 +882,20 @@ int run_flat_impl(mcle_ctx* ctx, const FlatParams& fp, int method, uint64_t seed
     const uint64_t items = count * (uint64_t)((fp.n_symbols + kChunk - 1) / kChunk);
     const ModemParams<T> mp = pipe_modem<T>(ctx, method);
     const size_t lds = (size_t)mp.grid.G * mp.grid.G * sizeof(unsigned long long);
-    // f32 Jakes links of 8 / 16 rays: the ray sum on the matrix cores (MCLE_NO_MFMA=1 keeps the VALU recurrence);
+    // f32 Jakes links of 8 / 16 rays: the ray sum on the matrix cores (MCLE_OPT_NO_MFMA keeps the VALU recurrence);
     // the f32 kernels are specialised by demodulator (1 packed slicer, 2 lockstep min-distance search, 0 the rest)
-    const bool mfma = sizeof(T) == 4 && !fp.rayleigh_iid && (fp.L == 8 || fp.L == 16) && !std::getenv("MCLE_NO_MFMA");
+    const bool mfma = sizeof(T) == 4 && !fp.rayleigh_iid && (fp.L == 8 || fp.L == 16) && !ctx->opt[MCLE_OPT_NO_MFMA];
     const int mode = sizeof(T) == 8 ? 0
                      : mp.method == MCLE_DEMOD_QAM_SLICER ? 1
                      : (mp.method == MCLE_DEMOD_MINDIST && (mp.M <= 8 || mp.grid.G > 0)) ? 2 : 0;
     const int lr = sizeof(T) == 4 && !fp.rayleigh_iid && (fp.L == 8 || fp.L == 16) ? fp.L : 0;
     // 64 workgroups per CU although 3 - 5 are resident (164 / 80 registers): the queued ones start as the first finish, which
-    // evens out per-workgroup speed differences and shortens the tail.  Measured (MCLE_FLAT_WGS_PER_CU): AWGN 10^4 symbols
+    // evens out per-workgroup speed differences and shortens the tail.  Measured (MCLE_OPT_FLAT_WGS_PER_CU): AWGN 10^4 symbols
     // 5.3 / 5.6 / 5.9 / 6.1 / 6.3 / 6.4 e7 realizations/s at 6 / 8 / 16 / 32 / 64 / 512 per CU, config 2 3.89 / 3.98 / 4.03 /
     // 4.09 / 4.16 / 3.83 e6 (past 64 a workgroup no longer spans a realization's chunks and redoes the ray set-up); a grid
     // of exactly the resident set was 6 - 9 % slower than 8.
     int per_cu = 64;
-    if (const char* v = std::getenv("MCLE_FLAT_WGS_PER_CU")) per_cu = std::atoi(v) > 0 ? std::atoi(v) : 64;
+    if (ctx->opt[MCLE_OPT_FLAT_WGS_PER_CU] > 0) per_cu = (int)ctx->opt[MCLE_OPT_FLAT_WGS_PER_CU];
     const uint64_t cap = (uint64_t)ctx->n_cu * (uint64_t)per_cu;
     const unsigned grid = (unsigned)(items < cap ? items : cap);
 #define MCLE_FLAT_LAUNCH(KERN) \
@@ -1069,7 +1069,7 @@ int mcle_run_mimo_ofdm(mcle_ctx* ctx, int dtype, const mcle_mimo_ofdm_cfg* cfg, 
     MCLE_REQUIRE(count <= 0x7fffffffull, "at most 2^31-1 realizations per call");
     if (count == 0) return MCLE_OK;
     if ((rc = ctx->bind())) return rc;
-    if (dtype == MCLE_F32) {   // matrix-core kernel where it applies (MCLE_NO_MFMA=1 keeps the VALU kernel below)
+    if (dtype == MCLE_F32) {   // matrix-core kernel where it applies (MCLE_OPT_NO_MFMA keeps the VALU kernel below)
         rc = run_mimo_ofdm_mfma(ctx, cfg, seed, first, count, d_counters, d_sym_err, d_bit_err);
         if (rc != MCLE_E_UNSUPPORTED) return rc;
     }
@@ -1107,8 +1107,8 @@ int mcle_run_ofdm_tdl(mcle_ctx* ctx, int dtype, const mcle_ofdm_tdl_cfg* cfg, ui
     if (count == 0) return MCLE_OK;
     if ((rc = ctx->bind())) return rc;
     // four realizations per workgroup pass with polynomial taps (pipeline_siso_tdl.hip) where that kernel's
-    // envelope allows (FFT 64 / 256 / 1024, moderate Doppler); MCLE_SINGLE_TDL=1 forces the kernel below
-    if (!std::getenv("MCLE_SINGLE_TDL")) {
+    // envelope allows (FFT 64 / 256 / 1024, moderate Doppler); MCLE_OPT_SINGLE_TDL forces the kernel below
+    if (!ctx->opt[MCLE_OPT_SINGLE_TDL]) {
         rc = run_ofdm_tdl_batched(ctx, dtype, cfg, seed, first, count, d_counters, d_sym_err, d_bit_err);
         if (rc != MCLE_E_UNSUPPORTED) return rc;
     }

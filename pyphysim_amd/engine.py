@@ -5,6 +5,7 @@ kernels under pyphysim_amd/csrc.  NumPy arrays passed to an operator are copied 
 and the result is copied back (drop-in behaviour, PCIe-bound); :class:`DeviceArray` arguments
 stay resident and results come back as DeviceArray.
 """
+import contextlib
 import ctypes
 import math
 from ctypes import byref, c_double, c_float, c_int, c_int32, c_void_p
@@ -144,6 +145,33 @@ class Engine:
     # ---- plumbing ---------------------------------------------------------------------------
     def sync(self):
         check(self.lib.mcle_ctx_sync(self.ctx))
+
+    # ---- kernel-selection options (mcle_ctx_set_option: per context, never read from the environment) ----
+    def set_option(self, name, value):
+        """name: a key of _lib.OPTIONS ('no_mfma', 'mfma_variant', 'grid_oversub', 'flat_wgs_per_cu', 'single_tdl',
+        'tdl_mfma_waves', 'jakes_direct'); 0 restores the default."""
+        if name not in _lib.OPTIONS:
+            raise ValueError("unknown option %r (known: %s)" % (name, ", ".join(sorted(_lib.OPTIONS))))
+        check(self.lib.mcle_ctx_set_option(self.ctx, _lib.OPTIONS[name], int(value)))
+
+    def get_option(self, name):
+        if name not in _lib.OPTIONS:
+            raise ValueError("unknown option %r" % (name,))
+        v = ctypes.c_longlong(0)
+        check(self.lib.mcle_ctx_get_option(self.ctx, _lib.OPTIONS[name], byref(v)))
+        return int(v.value)
+
+    @contextlib.contextmanager
+    def options(self, **kw):
+        """with eng.options(no_mfma=1): ...  -- sets the options for the block and restores the previous values."""
+        old = {k: self.get_option(k) for k in kw}
+        try:
+            for k, v in kw.items():
+                self.set_option(k, v)
+            yield self
+        finally:
+            for k, v in old.items():
+                self.set_option(k, v)
 
     def use_stream(self, hip_stream_handle):
         """Adopt an external hipStream_t, e.g. ``torch.cuda.current_stream().cuda_stream``."""
@@ -517,6 +545,27 @@ class Engine:
         self._raise_value(self.lib.mcle_mimo_channel(self.ctx, dt, d_H.ptr, d_X.ptr, d_n.ptr if d_n else None,
                                                      float(noise_var), nr, nt, ns, out.ptr, b))
         return self._out(out, host)
+
+    def mimo_channel_philox(self, H, X, seed, first, noise_var, dtype=None):
+        """Y[b] = H[b] X[b] + sqrt(noise_var) * CN(0,1) drawn on-chip (NOISE stream of realization first + b, sample
+        r*ns + c): the channel operator of the staged config-4 chain in one pass."""
+        dt = self._dt(dtype)
+        d_H, _ = self._cin(H, dt)
+        d_X, host = self._cin(X, dt)
+        b, nr, nt = d_H.shape
+        ns = d_X.shape[-1]
+        out = self.empty((b, nr, ns), _lib.np_complex(dt))
+        self._raise_value(self.lib.mcle_mimo_channel_philox(self.ctx, dt, d_H.ptr, d_X.ptr, int(seed), int(first),
+                                                            float(noise_var), nr, nt, ns, out.ptr, b))
+        return self._out(out, host)
+
+    def randn_c_batch(self, n, seed, first, count, stream=_lib.STREAM_CHAN, variance=1.0, dtype=None):
+        """Device complex [count, n]: CN(0, variance) sample i of (seed, first + r, stream)."""
+        dt = self._dt(dtype)
+        out = self.empty((count, n), _lib.np_complex(dt))
+        self._raise_value(self.lib.mcle_randn_c_batch(self.ctx, dt, int(seed), int(first), int(count), int(stream),
+                                                      int(n), float(variance), out.ptr))
+        return out
 
     # ---- a13: Alamouti / MRT / SVD ----------------------------------------------------------
     def alamouti_encode(self, x, batch=1, dtype=None):

@@ -153,6 +153,10 @@ class SimulationParameters:
             sp._original_sim_params = SimulationParameters.from_dict(d["original_sim_params"])
         return sp
 
+    # the reference's (private) names, simulations/parameters.py:942,963
+    _to_dict = to_dict
+    _from_dict = from_dict
+
     def to_json(self):
         return json.dumps(self.to_dict(), default=_json_default)
 

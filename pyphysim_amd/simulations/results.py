@@ -344,6 +344,10 @@ class SimulationResults:
         sr._results = {n: [Result.from_dict(r) for r in v] for n, v in d["results"].items()}
         return sr
 
+    # the reference's (private) names, simulations/results.py:1361,1408 -- subclasses written against pyphysim call them
+    _to_dict = to_dict
+    _from_dict = from_dict
+
     def to_json(self):
         return json.dumps(self.to_dict(), default=_json_default)
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """GPU: the matrix-core config-4 kernel (csrc/pipeline_mimo_mfma.hip) against the VALU kernel and the oracle.
-MCLE_NO_MFMA=1 selects the VALU kernel at launch time, so both run in one process on the same draws."""
+The context option no_mfma (mcle_ctx_set_option) selects the VALU kernel, so both run in one process on the same draws."""
 import json
 import os
 import sys
@@ -20,10 +20,7 @@ out = {}
 
 
 def run(first, count, mfma, method=_lib.DEMOD_QAM_SLICER, used=1024, nsym=1, cp=16, snr=25.0, mmse=True, per=True):
-    if mfma:
-        os.environ.pop("MCLE_NO_MFMA", None)
-    else:
-        os.environ["MCLE_NO_MFMA"] = "1"
+    eng.set_option("no_mfma", 0 if mfma else 1)
     nv = 1.0 / (10.0 ** (snr / 10.0))
     return eng.run_mimo_ofdm(4, 4, 1024, cp, used, nsym, nv, SEED, first, count, mmse=mmse, method=method, dtype="f32",
                              per_realization=per)
@@ -59,14 +56,8 @@ cases += [("mfma_slicer_v" + v, True, _lib.DEMOD_QAM_SLICER, v) for v in VARIANT
 cases += [("mfma_mindist_v" + v, True, _lib.DEMOD_MINDIST, v) for v in VARIANTS]
 for name, mfma, method, variant in cases:
     cnt = eng.new_counters()
-    if variant:
-        os.environ["MCLE_MFMA_VARIANT"] = variant
-    else:
-        os.environ.pop("MCLE_MFMA_VARIANT", None)
-    if mfma:
-        os.environ.pop("MCLE_NO_MFMA", None)
-    else:
-        os.environ["MCLE_NO_MFMA"] = "1"
+    eng.set_option("mfma_variant", int(variant or 0))
+    eng.set_option("no_mfma", 0 if mfma else 1)
     nv = 1.0 / (10.0 ** 2.5)
     for _ in range(3):
         eng.run_mimo_ofdm(4, 4, 1024, 16, 1024, 1, nv, SEED, 1 << 30, 65536, method=method, dtype="f32", counters=cnt)

@@ -5,6 +5,6 @@
 # per-bin 4x4 solves, the MFMA glue costs what the radix-4 butterflies did, and the third workgroup per CU is lost.  Not adopted.
 # frequency-selective MIMO-OFDM, one box: matrix-core kernel (2 workgroups per CU, default) / 3 per CU / the VALU kernel
 for rep in 1 2; do
-for v in "MCLE_X=1" "MCLE_F1_MFMA_WAVES=3" "MCLE_NO_MFMA=1"; do
-env $v python bench.py --config f1 --steps 10 --warmup 2 --no-cpu --pmc off 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$v', '%.4g' % d['value'], '%.3f' % d['roofline']['kernel_ms_per_launch'], d['ser'])"
+for v in "grid_oversub=0" "no_mfma=1"; do      # (the patch's own 3-waves knob, MCLE_F1_MFMA_WAVES, is an environment variable of that patch)
+python bench.py --opt $v --config f1 --steps 10 --warmup 2 --no-cpu --pmc off 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$v', '%.4g' % d['value'], '%.3f' % d['roofline']['kernel_ms_per_launch'], d['ser'])"
 done; done

@@ -1,8 +1,8 @@
 # VALU / LDS / MFMA instruction counts of the two f1 kernels (with f1_mfma_kernel.patch applied); see f1_ab.sh
 export TMPDIR=/tmp
-for v in "MCLE_X=1" "MCLE_NO_MFMA=1"; do
+for v in "grid_oversub=0" "no_mfma=1"; do
 rm -rf gpurun_out/f1pmc
-env $v timeout 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_MFMA SQ_WAIT_INST_ANY --output-format csv -d gpurun_out/f1pmc -o f1 -- python bench.py --config f1 --steps 2 --warmup 1 --no-cpu --pmc off > /dev/null 2>&1
+timeout 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_MFMA SQ_WAIT_INST_ANY --output-format csv -d gpurun_out/f1pmc -o f1 -- python bench.py --opt $v --config f1 --steps 2 --warmup 1 --no-cpu --pmc off > /dev/null 2>&1
 python - "$v" <<'PY'
 import csv, glob, sys, collections
 agg = collections.defaultdict(list)

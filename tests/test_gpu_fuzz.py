@@ -164,7 +164,7 @@ N_MFMA_TRIALS = int(os.environ.get("MCLE_FUZZ_TRIALS", "10"))
 def test_fuzz_matrix_core_kernels(engine, trial):
     """f32: the matrix-core kernels of configs 2, 3 and 4 (and, through the last two, fft16.hpp) on random CP lengths,
     band widths, symbol counts, tap sets and realization offsets -- against the oracle on the same draws, and against the
-    VALU kernels they replace (MCLE_NO_MFMA=1)."""
+    VALU kernels they replace (engine option no_mfma)."""
     rs = np.random.RandomState(700 + trial + 1000 * OFFSET)
     mod, M = MODS[1 + rs.randint(len(MODS) - 1)]
     _bind(engine, mod, M)
@@ -178,11 +178,8 @@ def test_fuzz_matrix_core_kernels(engine, trial):
 
     def both(fn):
         got = fn()
-        os.environ["MCLE_NO_MFMA"] = "1"
-        try:
+        with engine.options(no_mfma=1):
             ref = fn()
-        finally:
-            os.environ.pop("MCLE_NO_MFMA", None)
         assert np.max(np.abs(got[1].astype(np.int64) - ref[1].astype(np.int64))) <= 4, ("vs the VALU kernel", trial)
         return got
 

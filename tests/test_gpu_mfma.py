@@ -1,5 +1,5 @@
 """GPU: the matrix-core config-4 kernel (csrc/pipeline_mimo_mfma.hip: f32, FFT 1024, 4x4) against the oracle chain under
-the same Philox keying and against the VALU kernel it replaces (MCLE_NO_MFMA=1 selects that one at launch time).
+the same Philox keying and against the VALU kernel it replaces (engine option no_mfma = mcle_ctx_set_option(MCLE_OPT_NO_MFMA) selects that one).
 
 The MFMA kernel evaluates the same link with a different (equally f32) association of the sums, so per-realization
 counts may differ from the VALU kernel's by a rounding-level tie now and then, never systematically; against the f64
@@ -17,24 +17,11 @@ SEED = 424242
 
 
 def _run(engine, first, count, mfma=True, variant=None, **kw):
-    old = {k: os.environ.get(k) for k in ("MCLE_NO_MFMA", "MCLE_MFMA_VARIANT")}
-    try:
-        os.environ.pop("MCLE_NO_MFMA", None)
-        os.environ.pop("MCLE_MFMA_VARIANT", None)
-        if not mfma:
-            os.environ["MCLE_NO_MFMA"] = "1"
-        if variant:
-            os.environ["MCLE_MFMA_VARIANT"] = str(variant)
+    with engine.options(no_mfma=0 if mfma else 1, mfma_variant=int(variant or 0)):
         nv = 1.0 / omodem.dB2Linear(kw.get("snr_db", 25.0))
         return engine.run_mimo_ofdm(4, 4, 1024, kw.get("cp_size", 16), kw.get("num_used") or 1024,
                                     kw.get("n_ofdm_sym", 1), nv, SEED, first, count, mmse=kw.get("mmse", True),
                                     method=kw.get("method", _lib.DEMOD_QAM_SLICER), dtype="f32", per_realization=True)
-    finally:
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
 
 
 CASES = [dict(M=64, snr_db=25.0),
@@ -99,15 +86,7 @@ def test_zero_noise_round_trip(engine):
 # ---- config 3 on the matrix cores (csrc/pipeline_siso_tdl.hip: k_run_ofdm_tdl_mfma) ------------------------------------
 def _run_tdl(engine, first, count, mfma=True, waves=None, **kw):
     from pyphysim_amd.channels import discretize_profile
-    keys = ("MCLE_NO_MFMA", "MCLE_TDL_MFMA_WAVES")
-    old = {k: os.environ.get(k) for k in keys}
-    try:
-        for k in keys:
-            os.environ.pop(k, None)
-        if not mfma:
-            os.environ["MCLE_NO_MFMA"] = "1"
-        if waves:
-            os.environ["MCLE_TDL_MFMA_WAVES"] = str(waves)
+    with engine.options(no_mfma=0 if mfma else 1, tdl_mfma_waves=int(waves or 0)):
         Ts = kw.get("Ts", 1.0 / (15e3 * 1024))
         p_lin, d_idx = discretize_profile(np.asarray(kw.get("tap_powers_dB", (0.0, -3.0, -6.0, -9.0, -12.0)), dtype=float),
                                           np.asarray(kw.get("tap_delays_samples", (0, 1, 2, 3, 4)), dtype=float) * Ts, Ts)
@@ -115,12 +94,6 @@ def _run_tdl(engine, first, count, mfma=True, waves=None, **kw):
         return engine.run_ofdm_tdl(1024, kw.get("cp_size", 16), kw.get("num_used") or 1024, kw.get("n_ofdm_sym", 1), nv,
                                    p_lin, d_idx, SEED, first, count, Fd=kw.get("Fd", 10.0), Ts=Ts, L=kw.get("L", 8),
                                    method=kw.get("method", _lib.DEMOD_MINDIST), dtype="f32", per_realization=True)
-    finally:
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
 
 
 TDL_CASES = [dict(mod="qpsk", M=4, snr_db=20.0),                                            # BASELINE config 3
@@ -173,20 +146,11 @@ def test_tdl_mfma_zero_noise_round_trip(engine):
 
 # ---- config 2 on the matrix cores (csrc/pipelines.hip: k_run_flat_mfma) -----------------------------------------------
 def _run_flat(engine, first, count, mfma=True, **kw):
-    old = os.environ.get("MCLE_NO_MFMA")
-    try:
-        os.environ.pop("MCLE_NO_MFMA", None)
-        if not mfma:
-            os.environ["MCLE_NO_MFMA"] = "1"
+    with engine.options(no_mfma=0 if mfma else 1):
         nv = 0.0 if kw.get("snr_db") is None else 1.0 / omodem.dB2Linear(kw["snr_db"])
         return engine.run_flat_fading(kw["N"], nv, SEED, first, count, Fd=kw.get("Fd", 100.0), Ts=kw.get("Ts", 1e-3),
                                       L=kw.get("L", 8), method=kw.get("method", _lib.DEMOD_MINDIST), dtype="f32",
                                       per_realization=True)
-    finally:
-        if old is None:
-            os.environ.pop("MCLE_NO_MFMA", None)
-        else:
-            os.environ["MCLE_NO_MFMA"] = old
 
 
 FLAT_CASES = [dict(mod="qam", M=64, N=20000, snr_db=20.0, method=_lib.DEMOD_QAM_SLICER),        # BASELINE config 2, shortened

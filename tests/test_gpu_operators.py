@@ -271,8 +271,7 @@ def test_blast_filter_staged_equals_the_direct_kernel(engine, dt):
 def test_jakes_block_kernel_equals_the_direct_sum(engine, dt):
     """k_jakes_blocks (uniform time axis, L <= 16, >= 1024 samples: one phasor per ray and 64-sample block times the lane's
     rotation) against the closed form sample by sample (NumPy, fading_generators.py:519-522) and against k_jakes
-    (MCLE_JAKES_DIRECT=1), for ray counts around the four instantiations, ragged lengths and late start times."""
-    import os
+    (engine option jakes_direct), for ray counts around the four instantiations, ragged lengths and late start times."""
     rs = np.random.RandomState(31)
     tol = 1e-9 if dt == "f64" else 3e-5
     for L, S, n, t0, step, Fd in ((8, 1, 100000, 1e-3, 1e-3, 100.0), (1, 3, 1024, 0.0, 1e-4, 30.0), (5, 2, 4097, 7.5, 1e-3, 250.0),
@@ -285,11 +284,8 @@ def test_jakes_block_kernel_equals_the_direct_sum(engine, dt):
         h = engine.jakes_generate(phi, psi, Fd, t0, step, n, tap_power=pw, dtype=dt)
         assert h.shape == (S, n)
         assert np.max(np.abs(h - np.sqrt(pw)[:, None] * want)) <= tol * max(1.0, 1e3 * abs(t0)), (L, S, n)
-        os.environ["MCLE_JAKES_DIRECT"] = "1"
-        try:
+        with engine.options(jakes_direct=1):
             ref = engine.jakes_generate(phi, psi, Fd, t0, step, n, tap_power=pw, dtype=dt)
-        finally:
-            os.environ.pop("MCLE_JAKES_DIRECT", None)
         assert np.max(np.abs(h - ref)) <= tol * max(1.0, 1e3 * abs(t0)), (L, S, n)
         if L > 16:
             assert np.array_equal(h, ref)
@@ -862,12 +858,9 @@ def test_ofdm_1024_complex64_matrix_core_kernels(engine):
         back = engine.ofdm_demodulate(want, 1024, cp, used, batch=batch, dtype="f32")
         wantb = np.stack([oofdm.demodulate(want[b], 1024, cp, used) for b in range(batch)])
         assert back.shape == wantb.shape and relerr(back, wantb) <= 2e-6
-        os.environ["MCLE_NO_MFMA"] = "1"
-        try:
+        with engine.options(no_mfma=1):
             tx_v = engine.ofdm_modulate(x, 1024, cp, used, batch=batch, dtype="f32")
             back_v = engine.ofdm_demodulate(want, 1024, cp, used, batch=batch, dtype="f32")
-        finally:
-            os.environ.pop("MCLE_NO_MFMA", None)
         assert relerr(tx, tx_v) <= 2e-6 and relerr(back, back_v) <= 2e-6
 
 

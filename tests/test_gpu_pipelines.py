@@ -122,8 +122,8 @@ def test_ofdm_tdl_pipeline(engine, dt, exact, case):
     check(res, se, be, want_se, want_be, nsym, nbits, exact)
 
 
-def test_ofdm_tdl_batched_kernel_equals_single(engine, monkeypatch):
-    """Config 3 runs four realizations per workgroup pass (pipeline_siso_tdl.hip); MCLE_SINGLE_TDL=1 forces the
+def test_ofdm_tdl_batched_kernel_equals_single(engine):
+    """Config 3 runs four realizations per workgroup pass (pipeline_siso_tdl.hip); the engine option single_tdl forces the
     single-realization kernel.  Same per-realization counts in f64 for every count mod 4, near-identical in f32,
     and sums independent of how a range is split."""
     engine.set_constellation(chains.constellation("qpsk", 4), _lib.CONST_GENERIC)
@@ -132,11 +132,8 @@ def test_ofdm_tdl_batched_kernel_equals_single(engine, monkeypatch):
     args = (1024, 16, 1024, 1, 0.01, p_lin, d_idx, SEED)
 
     def run(first, count, dt, single):
-        if single:
-            monkeypatch.setenv("MCLE_SINGLE_TDL", "1")
-        else:
-            monkeypatch.delenv("MCLE_SINGLE_TDL", raising=False)
-        return engine.run_ofdm_tdl(*args, first, count, Fd=10.0, Ts=Ts, L=8, dtype=dt, per_realization=True)
+        with engine.options(single_tdl=1 if single else 0):
+            return engine.run_ofdm_tdl(*args, first, count, Fd=10.0, Ts=Ts, L=8, dtype=dt, per_realization=True)
     for count in (1, 2, 3, 4, 5, 1027):
         rb, sb, bb = run(11, count, "f64", False)
         rs, ss, bs = run(11, count, "f64", True)
@@ -155,7 +152,7 @@ def test_ofdm_tdl_batched_kernel_equals_single(engine, monkeypatch):
 
 @pytest.mark.parametrize("fft,cp,used,nsym", [(64, 5, 52, 3), (128, 9, 100, 2), (256, 20, 256, 2), (512, 36, 300, 2),
                                               (2048, 144, 1200, 1)])
-def test_ofdm_tdl_every_fft_size(engine, monkeypatch, fft, cp, used, nsym):
+def test_ofdm_tdl_every_fft_size(engine, fft, cp, used, nsym):
     """Every power-of-two OFDM size: the batched kernel (64 ... 2048) and the single-realization kernel it falls
     back to (other sizes, or when the four-realization pass does not fit LDS) give the oracle's counts in f64 --
     ragged used-subcarrier counts, several OFDM symbols, a CP shorter than the delay spread."""
@@ -167,12 +164,9 @@ def test_ofdm_tdl_every_fft_size(engine, monkeypatch, fft, cp, used, nsym):
     first, count = 2, 6
     want_se, want_be, n_sym, n_bits = oracle_counts(chains.chain_ofdm_tdl, first, count, **kw)
     for single in (False, True):
-        if single:
-            monkeypatch.setenv("MCLE_SINGLE_TDL", "1")
-        else:
-            monkeypatch.delenv("MCLE_SINGLE_TDL", raising=False)
-        res, se, be = engine.run_ofdm_tdl(fft, cp, used, nsym, 1.0 / omodem.dB2Linear(22.0), p_lin, d_idx, SEED, first,
-                                          count, Fd=60.0, Ts=Ts, L=8, dtype="f64", per_realization=True)
+        with engine.options(single_tdl=1 if single else 0):
+            res, se, be = engine.run_ofdm_tdl(fft, cp, used, nsym, 1.0 / omodem.dB2Linear(22.0), p_lin, d_idx, SEED, first,
+                                              count, Fd=60.0, Ts=Ts, L=8, dtype="f64", per_realization=True)
         check(res, se, be, want_se, want_be, n_sym, n_bits, True)
     if fft == 64:
         for bad in (32, 4096, 96):                      # outside the fused kernels: a clear error, never a wrong answer

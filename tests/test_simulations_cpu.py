@@ -526,3 +526,28 @@ def test_simulate_in_parallel_mirrors_the_task_parallel_mode(tmp_path):
     plain = _Dummy()
     plain.simulate_in_parallel()
     assert plain.runned_reps == serial.runned_reps
+
+
+def test_private_dict_serialisation_names_of_the_reference():
+    """the reference spells the dict round trip `_to_dict` / `_from_dict` (simulations/results.py:725,747,
+    1361,1408; simulations/parameters.py:942,963); a subclass written against pyphysim calls those names."""
+    p = SimulationParameters.create({"SNR": np.array([0.0, 5.0, 10.0]), "M": 16})
+    p.set_unpack_parameter("SNR")
+    assert SimulationParameters._from_dict(p._to_dict()) == p
+    res = SimulationResults()
+    res.set_parameters(p)
+    for v in (3, 5, 7):
+        r = Result.create("errs", Result.RATIOTYPE, v, 100)
+        assert Result._from_dict(r._to_dict()) == r
+        res.append_result(r)
+    back = SimulationResults._from_dict(res._to_dict())
+    assert back == res and back.params == p
+    assert [r.get_result() for r in back["errs"]] == [0.03, 0.05, 0.07]
+
+    class Mine(SimulationResults):            # the calling pattern of a user subclass
+        def dump(self):
+            return self._to_dict()
+    m = Mine()
+    m.set_parameters(p)
+    m.add_new_result("x", Result.SUMTYPE, 4)
+    assert SimulationResults._from_dict(m.dump())["x"][0].get_result() == 4
