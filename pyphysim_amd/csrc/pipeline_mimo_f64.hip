@@ -1,0 +1,370 @@
+// pipeline_mimo_f64.hip -- config 4 (4x4 Blast + OFDM-1024) in complex128, the reference's own precision
+// (apps/mimo/simulate_mimo.py:68-142, mimo/mimo.py:609-660, modulators/ofdm.py:394-466: complex128 throughout).
+//
+// Same link, same draw ledger (philox.hpp) and same results contract as k_run_mimo_ofdm<double, 1024, 4> (pipelines.hip),
+// whose per-realization counts it reproduces; what changed is how the f64 datapath and the LDS are used (round-3
+// profile of that kernel: one wavefront per SIMD because 86 KiB of LDS allowed one workgroup per CU, VALU busy 0.43, half of
+// all LDS cycles bank conflicts, 6 500 VALU instructions per wavefront and realization of which 3 400 were libm log /
+// sincos):
+//   * PLANAR samples: per antenna a re plane and an im plane of 1024 doubles.  A complex128 element as one 16-byte
+//     access runs into the b128 lane groups (16 lanes over 64 banks), which the radix-4 swizzle of fft.hpp was not made
+//     for; as two 8-byte accesses per element every plane is an array of 8-byte slots, and lds_swz64 (below) keeps every
+//     load AND store of every stage bank-conflict free.
+//   * no LDS twiddle copy (16 KiB in f64): a thread runs the same butterfly position in every realization, so its twelve
+//     twiddles are registers.  64 KiB of planes + tables = 73 KiB -> TWO workgroups per CU.
+//   * the channel draw and the f64 receive filter of every realization in a launch of their own (k_mimo_filters_f64), like
+//     the f32 matrix-core path.
+//   * Box-Muller by table + short polynomial (bm_f64.hpp), the min-distance search through the candidate grid
+//     (decision-identical to the sweep, modem.hpp).
+// No matrix cores here, on purpose: v_mfma_f64_16x16x4_f64 issues in 65 cycles (2048 flops: 31.5 flop/clk/SIMD, measured,
+// scripts/experiments/f64_rates.hip) against 4.8 cycles for a v_fma_f64 (26.7 flop/clk), does NOT overlap with VALU work
+// of the same SIMD, and a dense DFT-16 needs 1024 flops where two radix-4 stages need 224 f64 instructions per 16 points:
+// the matrix-core transform would cost 1.9 x the datapath time of the butterflies.
+#include "fft.hpp"
+#include "mimo.hpp"
+#include "modem.hpp"
+#include "philox.hpp"
+#include "totals.hpp"
+#include "pipe_common.hpp"
+
+namespace mcle {
+
+struct MimoParams {
+    int cp, num_used, n_ofdm_sym;
+    int mmse;
+    double noise_var;
+};
+
+constexpr int kD64N = 1024, kD64NA = 4;
+constexpr int kD64Rec = 2 * kD64NA * kD64NA + 1;     // H, G x FFT scale, skip flag
+
+// LDS swizzle of a plane of doubles.  8-byte accesses obey two bank rules on gfx950: a ds_read_b64 is served per half-wave
+// of 32 lanes over 32 eight-byte slots, a ds_write_b64 per 16 consecutive lanes over 16 slots.  Folding index bits 4..5
+// into bits 0..3 (twice) and bit 6 into bit 4 makes every access of every stage of this kernel -- the four legs of the
+// radix-4 butterflies at spans 256 .. 1, the channel's position pairs, scatter and decode -- meet both
+// (tests/test_f64_layout.py replays all of them; fft.hpp's lds_swz was built for the read rule only and left the stores
+// of the short spans 2-way conflicted: 0.29 of this kernel's LDS cycles in its first version).
+__host__ __device__ __forceinline__ int lds_swz64(int e) { return e ^ (((e >> 4) & 3) * 5) ^ (((e >> 6) & 1) << 4); }
+
+__global__ __launch_bounds__(64) void k_mimo_filters_f64(MimoParams pp, uint64_t seed, uint64_t first, uint64_t count,
+                                                         double2* __restrict__ recs) {
+    constexpr int NA = kD64NA;
+    const uint64_t rl = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+    if (rl >= count) return;
+    const double rx_scale = sqrt((double)(pp.num_used + pp.cp)) / (double)kD64N;
+    const Rng rng(seed, first + rl);
+    double2* rec = recs + rl * kD64Rec;
+    double2 H[NA][NA], G[NA][NA];
+#pragma unroll
+    for (int r = 0; r < NA; ++r)
+#pragma unroll
+        for (int a = 0; a < NA; ++a) {
+            H[r][a] = cn_sample<double>(rng, STREAM_CHAN, (uint64_t)(r * NA + a), 1.0);
+            rec[r * NA + a] = H[r][a];
+        }
+    const bool ok = blast_filter<NA, NA>(H, pp.mmse ? pp.noise_var : 0.0, G);
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int r = 0; r < NA; ++r) rec[NA * NA + a * NA + r] = mk<double>(G[a][r].x * rx_scale, G[a][r].y * rx_scale);
+    rec[2 * NA * NA] = mk<double>(ok ? 0.0 : 1.0, 0.0);
+}
+
+// The three twiddles of this thread's butterfly position at the four spans that have any (256, 64, 16, 4; span 1 has
+// none): w[j][q] = W^{(q+1) k N/(4s)}, k = tid mod s.  A DIF stage and the DIT stage of the same span use the same
+// twelve values (conjugated for the inverse transform), so they live in 48 registers for the whole kernel -- fetched per
+// stage from the global table they sat on the critical path of every stage (three dependent ~600-cycle loads at two
+// wavefronts per SIMD).
+struct TwRegs64 {
+    double2 w[4][3];
+};
+__device__ __forceinline__ TwRegs64 load_tw64(const double2* __restrict__ g_tw, int tid) {
+    TwRegs64 t;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int s = 256 >> (2 * j), k = tid & (s - 1), ts = kD64N / (4 * s);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) t.w[j][q] = g_tw[(q + 1) * k * ts];
+    }
+    return t;
+}
+
+// one radix-4 butterfly position of every antenna, planar LDS.
+// DIF (INV: the transmit IFFT): butterfly, then twiddle; DIT (forward FFT): twiddle, then butterfly.
+template <bool DIF, bool INV, int S>
+__device__ __forceinline__ void r4_stage_planar(double* s_d, const TwRegs64& tw, int bb) {
+    constexpr int N = kD64N, NA = kD64NA, s = S;
+    const int k = bb & (s - 1), g = bb / s;
+    const int e0 = g * 4 * s + k;
+    const int i0 = lds_swz64(e0), i1 = lds_swz64(e0 + s), i2 = lds_swz64(e0 + 2 * s),
+              i3 = lds_swz64(e0 + 3 * s);
+    double2 w1 = mk<double>(1, 0), w2 = w1, w3 = w1;
+    if (s > 1) {
+        constexpr int j = S == 256 ? 0 : S == 64 ? 1 : S == 16 ? 2 : 3;
+        w1 = tw.w[j][0];
+        w2 = tw.w[j][1];
+        w3 = tw.w[j][2];
+        if (INV) {
+            w1.y = -w1.y;
+            w2.y = -w2.y;
+            w3.y = -w3.y;
+        }
+    }
+    double xr[NA][4], xi[NA][4];
+#pragma unroll
+    for (int a = 0; a < NA; ++a) {
+        const double* pr = s_d + (2 * a) * N;
+        const double* pi = pr + N;
+        xr[a][0] = pr[i0]; xr[a][1] = pr[i1]; xr[a][2] = pr[i2]; xr[a][3] = pr[i3];
+        xi[a][0] = pi[i0]; xi[a][1] = pi[i1]; xi[a][2] = pi[i2]; xi[a][3] = pi[i3];
+    }
+#pragma unroll
+    for (int a = 0; a < NA; ++a) {
+        double2 u0 = mk<double>(xr[a][0], xi[a][0]), u1 = mk<double>(xr[a][1], xi[a][1]),
+                u2 = mk<double>(xr[a][2], xi[a][2]), u3 = mk<double>(xr[a][3], xi[a][3]);
+        if (!DIF && s > 1) {
+            u1 = cmul(u1, w1);
+            u2 = cmul(u2, w2);
+            u3 = cmul(u3, w3);
+        }
+        const double2 a0 = cadd(u0, u2), a1 = csub(u0, u2), a2 = cadd(u1, u3), a3 = rot<double, INV>(csub(u1, u3));
+        double2 y0 = cadd(a0, a2), y1 = cadd(a1, a3), y2 = csub(a0, a2), y3 = csub(a1, a3);
+        if (DIF && s > 1) {
+            y1 = cmul(y1, w1);
+            y2 = cmul(y2, w2);
+            y3 = cmul(y3, w3);
+        }
+        double* pr = s_d + (2 * a) * N;
+        double* pi = pr + N;
+        pr[i0] = y0.x; pr[i1] = y1.x; pr[i2] = y2.x; pr[i3] = y3.x;
+        pi[i0] = y0.y; pi[i1] = y1.y; pi[i2] = y2.y; pi[i3] = y3.y;
+    }
+}
+
+__global__ __launch_bounds__(kPipeBlock, 2) void k_run_mimo_ofdm_f64(MimoParams pp, ModemParams<double> mp, uint64_t seed,
+                                                                     uint64_t first, uint64_t count,
+                                                                     const double2* __restrict__ g_tw,
+                                                                     const double2* __restrict__ g_recs,
+                                                                     mcle_counters* counters,
+                                                                     uint32_t* __restrict__ sym_out,
+                                                                     uint32_t* __restrict__ bit_out) {
+    constexpr int N = kD64N, NA = kD64NA, kRec = kD64Rec;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* s_d = reinterpret_cast<double*>(smem);                          // [NA][re plane | im plane][N]
+    double2* s_table = reinterpret_cast<double2*>(s_d + 2 * NA * N);        // [tab_len] constellation
+    double2* s_txtab = s_table + ((mp.M + 1) & ~1);                         // [tab_len] constellation x tx scale
+    double2* s_rec = s_txtab + ((mp.M + 1) & ~1);                           // [2][kRec + 1]
+    unsigned* s_part = reinterpret_cast<unsigned*>(s_rec + 2 * (kRec + 1)); // [2][4 waves][2]
+    unsigned long long* s_grid = reinterpret_cast<unsigned long long*>(s_part + 16);
+    unsigned char* s_idx = reinterpret_cast<unsigned char*>(s_grid + mp.grid.G * mp.grid.G);   // [NA * num_used]
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int U = pp.num_used, cp = pp.cp;
+    const int per_sym = U * NA;
+    const uint64_t row = (uint64_t)pp.n_ofdm_sym * (N + cp);
+    const double sigma = sqrt(pp.noise_var);
+    const double tx_scale = 1.0 / sqrt((double)NA) / sqrt((double)(U + cp));
+    const uint32_t mask = (uint32_t)(mp.M - 1);
+    for (int m = tid; m < mp.M; m += kPipeBlock) {
+        const double2 c = mp.g_table[m];
+        s_table[m] = c;
+        s_txtab[m] = cscale(c, tx_scale);
+    }
+    load_grid(mp, s_grid);
+    __shared__ WgTotals totals;
+    if (tid == 0) wg_zero(totals);
+
+    const TwRegs64 twr = load_tw64(g_tw, tid);
+    uint64_t it = 0, rl_prev = 0;
+    __syncthreads();
+    for (uint64_t rl = blockIdx.x; rl < count; rl += gridDim.x, ++it) {
+        const Rng rng(seed, first + rl);
+        const int buf = (int)(it & 1);
+        // this realization's record -> s_rec[buf] (first read after the next workgroup barrier; its previous reader,
+        // realization it - 2, is many barriers behind)
+        if (tid < kRec) s_rec[buf * (kRec + 1) + tid] = g_recs[rl * kRec + tid];
+        const double2* s_H = s_rec + buf * (kRec + 1);
+        const double2* s_G = s_H + NA * NA;
+        unsigned se = 0, be = 0;
+        for (int os = 0; os < pp.n_ofdm_sym; ++os) {
+            // ---- transmit: symbols -> bins (Blast.encode's F-order split + OFDM subcarrier map) ----
+            if (it > 0 || os > 0) __syncthreads();            // the previous symbol's decode has read the planes
+            if (U != N) {
+                for (int p = tid; p < 2 * NA * N; p += kPipeBlock) s_d[p] = 0.0;
+                __syncthreads();
+            }
+            const uint64_t n_first = (uint64_t)os * per_sym;
+            const uint64_t n_last = n_first + per_sym;
+            for (uint64_t blk = (n_first >> 4) + tid; blk <= ((n_last - 1) >> 4); blk += kPipeBlock) {
+                const Words4 dw = rng.block(STREAM_DATA, (uint32_t)blk);
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const uint64_t n = (blk << 4) + j;
+                    if (n >= n_first && n < n_last) {
+                        const int tx = (int)((dw.w[j >> 2] >> ((j & 3) * 8)) & mask);
+                        const int nl = (int)(n - n_first);
+                        const int a = nl % NA, d = nl / NA;
+                        s_idx[nl] = (unsigned char)tx;
+                        const double2 c = s_txtab[tx];
+                        const int pos = lds_swz64(ofdm_bin(d, N, U));
+                        s_d[(2 * a) * N + pos] = c.x;
+                        s_d[(2 * a + 1) * N + pos] = c.y;
+                    }
+                }
+            }
+            __syncthreads();
+            if (tid == 0 && os == 0 && it > 0) {   // every wave is past the previous realization: account it
+                const unsigned* q = s_part + (buf ^ 1) * 8;
+                wg_account(totals, q[0] + q[2] + q[4] + q[6], q[1] + q[3] + q[5] + q[7],
+                           s_rec[(buf ^ 1) * (kRec + 1) + 2 * NA * NA].x != 0.0, rl_prev, sym_out, bit_out);
+            }
+            // ---- IFFT: radix-4 DIF, natural -> digit-reversed positions ----
+            r4_stage_planar<true, true, 256>(s_d, twr, opaque(tid));
+            __syncthreads();
+            r4_stage_planar<true, true, 64>(s_d, twr, opaque(tid));
+            fft_stage_sync<kPipeBlock>(64);
+            r4_stage_planar<true, true, 16>(s_d, twr, opaque(tid));
+            fft_stage_sync<kPipeBlock>(16);
+            r4_stage_planar<true, true, 4>(s_d, twr, opaque(tid));
+            fft_stage_sync<kPipeBlock>(4);
+            r4_stage_planar<true, true, 1>(s_d, twr, opaque(tid));
+            __syncthreads();
+            // ---- channel: R = H T + noise on the samples that survive CP removal ----
+            {
+                double2 H[NA][NA];
+#pragma unroll
+                for (int r = 0; r < NA; ++r)
+#pragma unroll
+                    for (int a = 0; a < NA; ++a) H[r][a] = s_H[r * NA + a];
+                for (int j = opaque(tid); j < N / 2; j += kPipeBlock) {
+                    const int half = j / (N / 4), rest = j - half * (N / 4);
+                    const int p0 = 2 * half * (N / 4) + rest, p1 = p0 + N / 4;
+                    const int m0 = fft_index_of_pos<N>(p0);  // even; position p1 holds m0 + 1
+                    const int q0 = lds_swz64(p0), q1 = lds_swz64(p1);
+                    double2 x0[NA], x1[NA];
+#pragma unroll
+                    for (int a = 0; a < NA; ++a) {
+                        x0[a] = mk<double>(s_d[(2 * a) * N + q0], s_d[(2 * a + 1) * N + q0]);
+                        x1[a] = mk<double>(s_d[(2 * a) * N + q1], s_d[(2 * a + 1) * N + q1]);
+                    }
+#pragma unroll
+                    for (int r = 0; r < NA; ++r) {
+                        const uint64_t i0 = (uint64_t)r * row + (uint64_t)os * (N + cp) + cp + m0;
+                        double2 z0, z1;
+                        if ((i0 & 1) == 0) {
+                            cn_pair<double>(rng, STREAM_NOISE, (uint32_t)(i0 >> 1), sigma, z0, z1);
+                        } else {
+                            z0 = cn_sample<double>(rng, STREAM_NOISE, i0, sigma);
+                            z1 = cn_sample<double>(rng, STREAM_NOISE, i0 + 1, sigma);
+                        }
+#pragma unroll
+                        for (int a = 0; a < NA; ++a) {
+                            z0 = cfma(H[r][a], x0[a], z0);
+                            z1 = cfma(H[r][a], x1[a], z1);
+                        }
+                        s_d[(2 * r) * N + q0] = z0.x;
+                        s_d[(2 * r + 1) * N + q0] = z0.y;
+                        s_d[(2 * r) * N + q1] = z1.x;
+                        s_d[(2 * r + 1) * N + q1] = z1.y;
+                    }
+                }
+            }
+            __syncthreads();
+            // ---- FFT: radix-4 DIT, digit-reversed -> natural bins ----
+            r4_stage_planar<false, false, 1>(s_d, twr, opaque(tid));
+            fft_stage_sync<kPipeBlock>(4);
+            r4_stage_planar<false, false, 4>(s_d, twr, opaque(tid));
+            fft_stage_sync<kPipeBlock>(16);
+            r4_stage_planar<false, false, 16>(s_d, twr, opaque(tid));
+            fft_stage_sync<kPipeBlock>(64);
+            r4_stage_planar<false, false, 64>(s_d, twr, opaque(tid));
+            __syncthreads();
+            r4_stage_planar<false, false, 256>(s_d, twr, opaque(tid));
+            __syncthreads();
+            // ---- receive: Blast decode (G carries the FFT scale), demodulate, count ----
+            {
+                double2 G[NA][NA];
+#pragma unroll
+                for (int a = 0; a < NA; ++a)
+#pragma unroll
+                    for (int r = 0; r < NA; ++r) G[a][r] = s_G[a * NA + r];
+                for (int d = opaque(tid); d < U; d += kPipeBlock) {
+                    const int bin = lds_swz64(ofdm_bin(d, N, U));
+                    double2 y[NA];
+#pragma unroll
+                    for (int r = 0; r < NA; ++r) y[r] = mk<double>(s_d[(2 * r) * N + bin], s_d[(2 * r + 1) * N + bin]);
+                    const uint32_t sent = *reinterpret_cast<const uint32_t*>(s_idx + 4 * d);
+#pragma unroll
+                    for (int a = 0; a < NA; ++a) {
+                        double2 est = mk<double>(0, 0);
+#pragma unroll
+                        for (int r = 0; r < NA; ++r) est = cfma(G[a][r], y[r], est);
+                        const int dec = demod_one<double>(mp, s_table, s_grid, est);
+                        const unsigned x = ((sent >> (8 * a)) & 0xFFu) ^ (unsigned)dec;
+                        se += (x != 0u);
+                        be += __popc(x);
+                    }
+                }
+            }
+        }
+        se = wave_sum_u32(se);
+        be = wave_sum_u32(be);
+        if (lane == 0) {
+            s_part[buf * 8 + 2 * w] = se;
+            s_part[buf * 8 + 2 * w + 1] = be;
+        }
+        rl_prev = rl;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        if (it > 0) {
+            const int buf = (int)((it - 1) & 1);
+            const unsigned* q = s_part + buf * 8;
+            wg_account(totals, q[0] + q[2] + q[4] + q[6], q[1] + q[3] + q[5] + q[7],
+                       s_rec[buf * (kRec + 1) + 2 * NA * NA].x != 0.0, rl_prev, sym_out, bit_out);
+        }
+        wg_flush(totals, counters, (unsigned long long)per_sym * pp.n_ofdm_sym,
+                 (unsigned long long)per_sym * pp.n_ofdm_sym * mp.bits);
+    }
+}
+
+// host side: 0 = launched, MCLE_E_UNSUPPORTED = outside this kernel's envelope (caller uses k_run_mimo_ofdm<double, ...>)
+int run_mimo_ofdm_f64(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, uint64_t seed, uint64_t first, uint64_t count,
+                      mcle_counters* d_counters, uint32_t* d_sym, uint32_t* d_bit) {
+    if (cfg->fft_size != kD64N || cfg->nt != 4 || cfg->nr != 4) return MCLE_E_UNSUPPORTED;
+    if (ctx->opt[MCLE_OPT_F64_GENERIC]) return MCLE_E_UNSUPPORTED;
+    int rc;
+    void* tw = nullptr;
+    if ((rc = ctx->get_twiddles(kD64N, MCLE_F64, &tw))) return rc;
+    MimoParams pp{cfg->cp_size, cfg->num_used, cfg->n_ofdm_sym, cfg->mmse, cfg->noise_var};
+    ModemParams<double> mp = pipe_modem<double>(ctx, cfg->demod_method);
+    mp.grid = context_grid<double>(ctx, cfg->demod_method, true);      // pruned search, decision-identical to the sweep
+    const size_t tab_len = ((size_t)mp.M + 1) & ~(size_t)1;
+    const size_t lds = (size_t)2 * kD64NA * kD64N * sizeof(double) + (2 * tab_len + 2 * (kD64Rec + 1)) * sizeof(double2) +
+                       16 * sizeof(unsigned) + (size_t)mp.grid.G * mp.grid.G * sizeof(unsigned long long) +
+                       (size_t)4 * cfg->num_used + 16;
+    auto kern = k_run_mimo_ofdm_f64;
+    MCLE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int per_cu = (int)((size_t)160 * 1024 / (lds + 512));
+    if (per_cu < 1) per_cu = 1;
+    if (per_cu > 2) per_cu = 2;             // __launch_bounds__(256, 2)
+    const uint64_t resident = (uint64_t)ctx->n_cu * per_cu;
+    const uint64_t kSlice = 1ull << 18;     // realizations per filter + link pair: bounds the record buffer (138 MB)
+    const uint64_t slice = count < kSlice ? count : kSlice;
+    void* recs = nullptr;
+    if ((rc = ctx->scratch((size_t)slice * kD64Rec * sizeof(double2), &recs))) return rc;
+    for (uint64_t off = 0; off < count; off += slice) {
+        const uint64_t n = count - off < slice ? count - off : slice;
+        hipLaunchKernelGGL(k_mimo_filters_f64, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, pp, seed,
+                           first + off, n, (double2*)recs);
+        MCLE_LAUNCH_CHECK();
+        const unsigned grid = (unsigned)oversubscribed_grid(ctx, resident, n);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kPipeBlock), lds, ctx->stream, pp, mp, seed, first + off, n,
+                           (const double2*)tw, (const double2*)recs, d_counters, d_sym ? d_sym + off : nullptr,
+                           d_bit ? d_bit + off : nullptr);
+        MCLE_LAUNCH_CHECK();
+    }
+    return MCLE_OK;
+}
+
+}  // namespace mcle

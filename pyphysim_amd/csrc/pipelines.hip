@@ -1001,6 +1001,8 @@ int run_tdl_impl(mcle_ctx* ctx, const mcle_ofdm_tdl_cfg* cfg, uint64_t seed, uin
 
 namespace mcle {
 // pipeline_mimo_mfma.hip: f32, FFT 1024, 4x4 on the matrix cores; MCLE_E_UNSUPPORTED outside that envelope
+int run_mimo_ofdm_f64(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, uint64_t seed, uint64_t first, uint64_t count,
+                      mcle_counters* d_counters, uint32_t* d_sym, uint32_t* d_bit);
 int run_mimo_ofdm_mfma(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, uint64_t seed, uint64_t first, uint64_t count,
                        mcle_counters* d_counters, uint32_t* d_sym, uint32_t* d_bit);
 // pipeline_siso_tdl.hip
@@ -1071,6 +1073,9 @@ int mcle_run_mimo_ofdm(mcle_ctx* ctx, int dtype, const mcle_mimo_ofdm_cfg* cfg, 
     if ((rc = ctx->bind())) return rc;
     if (dtype == MCLE_F32) {   // matrix-core kernel where it applies (MCLE_OPT_NO_MFMA keeps the VALU kernel below)
         rc = run_mimo_ofdm_mfma(ctx, cfg, seed, first, count, d_counters, d_sym_err, d_bit_err);
+        if (rc != MCLE_E_UNSUPPORTED) return rc;
+    } else {                   // complex128 at FFT 1024, 4x4: the planar two-workgroups-per-CU kernel (pipeline_mimo_f64.hip)
+        rc = run_mimo_ofdm_f64(ctx, cfg, seed, first, count, d_counters, d_sym_err, d_bit_err);
         if (rc != MCLE_E_UNSUPPORTED) return rc;
     }
 #define MCLE_RUN(N_, NA_)                                                                                         \

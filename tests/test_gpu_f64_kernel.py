@@ -1,0 +1,75 @@
+"""GPU: the complex128 config-4 kernel (csrc/pipeline_mimo_f64.hip: planar LDS, two workgroups per CU, table Box-Muller,
+pruned min-distance search) -- per-realization error counts equal to the oracle chain's under the same Philox keying,
+and equal to the generic radix-4 kernel it replaces (engine option f64_generic), on every corner of its envelope."""
+import numpy as np
+import pytest
+
+from oracle import chains, modem as omodem
+from pyphysim_amd import _lib
+
+pytestmark = pytest.mark.gpu
+SEED = 777001
+
+CASES = [dict(mod="qam", M=64, snr_db=25.0),                                               # BASELINE config 4
+         dict(mod="qam", M=64, snr_db=25.0, num_used=600, n_ofdm_sym=2),                   # partial band, two OFDM symbols
+         dict(mod="qam", M=16, snr_db=18.0, cp_size=7, mmse=False),                        # odd CP: unpaired noise draws; ZF
+         dict(mod="qam", M=256, snr_db=32.0, cp_size=0),
+         dict(mod="psk", M=8, snr_db=14.0, num_used=1022, n_ofdm_sym=3, cp_size=33),       # no slicer: candidate grid only
+         dict(mod="qpsk", M=4, snr_db=8.0, num_used=2)]
+
+
+def _run(engine, kw, first, count, method, generic=False):
+    nv = 1.0 / omodem.dB2Linear(kw["snr_db"])
+    with engine.options(f64_generic=1 if generic else 0):
+        return engine.run_mimo_ofdm(4, 4, 1024, kw.get("cp_size", 16), kw.get("num_used") or 1024, kw.get("n_ofdm_sym", 1),
+                                    nv, SEED, first, count, mmse=kw.get("mmse", True), method=method, dtype="f64",
+                                    per_realization=True)
+
+
+@pytest.mark.parametrize("case", range(len(CASES)))
+def test_f64_kernel_counts_equal_the_oracle(engine, case):
+    kw = CASES[case]
+    kind = _lib.CONST_QAM if kw["mod"] == "qam" else _lib.CONST_GENERIC
+    engine.set_constellation(chains.constellation(kw["mod"], kw["M"]), kind)
+    first, count = (1 << 35) + 17, 5
+    okw = dict(mod=kw["mod"], M=kw["M"], nt=4, nr=4, fft_size=1024, cp_size=kw.get("cp_size", 16),
+               num_used=kw.get("num_used"), n_ofdm_sym=kw.get("n_ofdm_sym", 1), snr_db=kw["snr_db"], mmse=kw.get("mmse", True))
+    want = [chains.chain_mimo_ofdm(chains.PhiloxRng(SEED, r), **okw) for r in range(first, first + count)]
+    want_se = np.array([w["symbol_errors"] for w in want])
+    want_be = np.array([w["bit_errors"] for w in want])
+    methods = [_lib.DEMOD_MINDIST] + ([_lib.DEMOD_QAM_SLICER] if kw["mod"] == "qam" else [])
+    for method in methods:
+        res, se, be = _run(engine, kw, first, count, method)
+        assert np.array_equal(se, want_se) and np.array_equal(be, want_be), (case, method, se, want_se)
+        assert res["n_realizations"] == count and res["sym_errors"] == int(want_se.sum())
+        assert res["n_symbols"] == want[0]["num_symbols"] and res["n_bits"] == want[0]["num_bits"]
+
+
+@pytest.mark.parametrize("case", range(len(CASES)))
+def test_f64_kernel_equals_the_generic_kernel(engine, case):
+    """1 000+ realizations per case against k_run_mimo_ofdm<double, 1024, 4>: the same counts realization by realization
+    (both are complex128 statements of the same link; a rounding-level tie may differ once in ~1e7 symbols), the same
+    sums of squares, any split of the range."""
+    kw = CASES[case]
+    kind = _lib.CONST_QAM if kw["mod"] == "qam" else _lib.CONST_GENERIC
+    engine.set_constellation(chains.constellation(kw["mod"], kw["M"]), kind)
+    n = 1031
+    method = _lib.DEMOD_MINDIST
+    new, se, be = _run(engine, kw, 5, n, method)
+    old, se_o, be_o = _run(engine, kw, 5, n, method, generic=True)
+    assert np.count_nonzero(se != se_o) <= 1 and np.max(np.abs(se.astype(int) - se_o.astype(int))) <= 1
+    assert abs(new["sym_errors"] - old["sym_errors"]) <= 1 and new["n_realizations"] == old["n_realizations"] == n
+    a = _run(engine, kw, 5, 400, method)[0]
+    b = _run(engine, kw, 405, n - 400, method)[0]
+    for k in ("sym_errors", "sym_errors_sq", "bit_errors", "bit_errors_sq", "n_realizations", "n_skipped"):
+        assert new[k] == a[k] + b[k], k
+
+
+def test_f64_kernel_skips_singular_channels_like_the_generic_kernel(engine):
+    """Zero forcing at a very high SNR: no errors, and the skip flag path (non-positive pivot) matches."""
+    engine.set_constellation(chains.constellation("qam", 16), _lib.CONST_QAM)
+    kw = dict(mod="qam", M=16, snr_db=300.0, mmse=False)
+    new = _run(engine, kw, 0, 3000, _lib.DEMOD_QAM_SLICER)[0]
+    old = _run(engine, kw, 0, 3000, _lib.DEMOD_QAM_SLICER, generic=True)[0]
+    assert new["n_skipped"] == old["n_skipped"] and new["n_realizations"] == old["n_realizations"]
+    assert new["sym_errors"] == old["sym_errors"] <= 3
