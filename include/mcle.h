@@ -89,7 +89,8 @@ enum {
     MCLE_OPT_TDL_MFMA_WAVES = 5,   /* config-3 matrix-core kernel: 0 / 2 = two waves per SIMD, 3 = three */
     MCLE_OPT_JAKES_DIRECT = 6,     /* 1: jakes_generate evaluates one sincos per ray and sample (k_jakes) */
     MCLE_OPT_F64_GENERIC = 7,      /* 1: complex128 config 4 on the generic radix-4 kernel instead of k_run_mimo_ofdm_f64 */
-    MCLE_OPT_COUNT = 8
+    MCLE_OPT_F64_THREADS = 8,      /* complex128 config-4 kernel: 0 / 512 = 512-thread workgroups, 256 = 256-thread workgroups */
+    MCLE_OPT_COUNT = 9
 };
 int mcle_ctx_set_option(mcle_ctx* ctx, int option, long long value);
 int mcle_ctx_get_option(mcle_ctx* ctx, int option, long long* value);

@@ -91,19 +91,26 @@ __device__ __forceinline__ TwRegs64 load_tw64(const double2* __restrict__ g_tw, 
 
 // one radix-4 butterfly position of every antenna, planar LDS.
 // DIF (INV: the transmit IFFT): butterfly, then twiddle; DIT (forward FFT): twiddle, then butterfly.
-template <bool DIF, bool INV, int S>
-__device__ __forceinline__ void r4_stage_planar(double* s_d, const TwRegs64& tw, int bb) {
-    constexpr int N = kD64N, NA = kD64NA, s = S;
+template <bool DIF, bool INV, int S, int NA>
+__device__ __forceinline__ void r4_stage_planar(double* s_d, const TwRegs64& tw, const double2* __restrict__ g_tw, int bb) {
+    constexpr int N = kD64N, s = S;
     const int k = bb & (s - 1), g = bb / s;
     const int e0 = g * 4 * s + k;
     const int i0 = lds_swz64(e0), i1 = lds_swz64(e0 + s), i2 = lds_swz64(e0 + 2 * s),
               i3 = lds_swz64(e0 + 3 * s);
     double2 w1 = mk<double>(1, 0), w2 = w1, w3 = w1;
     if (s > 1) {
-        constexpr int j = S == 256 ? 0 : S == 64 ? 1 : S == 16 ? 2 : 3;
-        w1 = tw.w[j][0];
-        w2 = tw.w[j][1];
-        w3 = tw.w[j][2];
+        if constexpr (NA == kD64NA) {                 // 256-thread form: the twelve twiddles are registers
+            constexpr int j = S == 256 ? 0 : S == 64 ? 1 : S == 16 ? 2 : 3;
+            w1 = tw.w[j][0];
+            w2 = tw.w[j][1];
+            w3 = tw.w[j][2];
+        } else {                                      // 512-thread form (128 VGPRs): from the L1-resident table, per stage
+            constexpr int ts = N / (4 * s);
+            w1 = g_tw[k * ts];
+            w2 = g_tw[2 * k * ts];
+            w3 = g_tw[3 * k * ts];
+        }
         if (INV) {
             w1.y = -w1.y;
             w2.y = -w2.y;
@@ -141,7 +148,11 @@ __device__ __forceinline__ void r4_stage_planar(double* s_d, const TwRegs64& tw,
     }
 }
 
-__global__ __launch_bounds__(kPipeBlock, 2) void k_run_mimo_ofdm_f64(MimoParams pp, ModemParams<double> mp, uint64_t seed,
+// AH = antennas per thread in the transform stages: 4 -> 256 threads per workgroup (2 wavefronts per SIMD at two
+// workgroups per CU, up to 256 VGPRs), 2 -> 512 threads (4 wavefronts per SIMD, 128 VGPRs): LDS caps the workgroups per CU
+// at two, so the second form buys latency hiding with threads instead.
+template <int AH>
+__global__ __launch_bounds__(256 * (4 / AH), 2 * (4 / AH)) void k_run_mimo_ofdm_f64(MimoParams pp, ModemParams<double> mp, uint64_t seed,
                                                                      uint64_t first, uint64_t count,
                                                                      const double2* __restrict__ g_tw,
                                                                      const double2* __restrict__ g_recs,
@@ -149,13 +160,14 @@ __global__ __launch_bounds__(kPipeBlock, 2) void k_run_mimo_ofdm_f64(MimoParams 
                                                                      uint32_t* __restrict__ sym_out,
                                                                      uint32_t* __restrict__ bit_out) {
     constexpr int N = kD64N, NA = kD64NA, kRec = kD64Rec;
+    constexpr int TB = 256 * (NA / AH), NW = TB / 64;                       // threads, wavefronts per workgroup
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* s_d = reinterpret_cast<double*>(smem);                          // [NA][re plane | im plane][N]
     double2* s_table = reinterpret_cast<double2*>(s_d + 2 * NA * N);        // [tab_len] constellation
     double2* s_txtab = s_table + ((mp.M + 1) & ~1);                         // [tab_len] constellation x tx scale
     double2* s_rec = s_txtab + ((mp.M + 1) & ~1);                           // [2][kRec + 1]
-    unsigned* s_part = reinterpret_cast<unsigned*>(s_rec + 2 * (kRec + 1)); // [2][4 waves][2]
-    unsigned long long* s_grid = reinterpret_cast<unsigned long long*>(s_part + 16);
+    unsigned* s_part = reinterpret_cast<unsigned*>(s_rec + 2 * (kRec + 1)); // [2][8 waves][2]
+    unsigned long long* s_grid = reinterpret_cast<unsigned long long*>(s_part + 32);
     unsigned char* s_idx = reinterpret_cast<unsigned char*>(s_grid + mp.grid.G * mp.grid.G);   // [NA * num_used]
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -165,7 +177,7 @@ __global__ __launch_bounds__(kPipeBlock, 2) void k_run_mimo_ofdm_f64(MimoParams 
     const double sigma = sqrt(pp.noise_var);
     const double tx_scale = 1.0 / sqrt((double)NA) / sqrt((double)(U + cp));
     const uint32_t mask = (uint32_t)(mp.M - 1);
-    for (int m = tid; m < mp.M; m += kPipeBlock) {
+    for (int m = tid; m < mp.M; m += TB) {
         const double2 c = mp.g_table[m];
         s_table[m] = c;
         s_txtab[m] = cscale(c, tx_scale);
@@ -174,15 +186,25 @@ __global__ __launch_bounds__(kPipeBlock, 2) void k_run_mimo_ofdm_f64(MimoParams 
     __shared__ WgTotals totals;
     if (tid == 0) wg_zero(totals);
 
-    const TwRegs64 twr = load_tw64(g_tw, tid);
+    const int bbt = tid & 255;                                   // this thread's butterfly position
+    double* s_mine = s_d + (tid >> 8) * (2 * AH * N);             // ... of antennas AH (tid >> 8) ...
+    TwRegs64 twr;
+    if constexpr (AH == NA) twr = load_tw64(g_tw, bbt);
     uint64_t it = 0, rl_prev = 0;
+    // the record of a realization is fetched one iteration ahead (one register pair per lane of the first wavefront):
+    // loaded where it is parked, the global-memory latency sat in front of every realization's first barrier
+    double2 rec_next = mk<double>(0, 0);
+    if (tid < kRec && blockIdx.x < count) rec_next = g_recs[(uint64_t)blockIdx.x * kRec + tid];
     __syncthreads();
     for (uint64_t rl = blockIdx.x; rl < count; rl += gridDim.x, ++it) {
         const Rng rng(seed, first + rl);
         const int buf = (int)(it & 1);
         // this realization's record -> s_rec[buf] (first read after the next workgroup barrier; its previous reader,
         // realization it - 2, is many barriers behind)
-        if (tid < kRec) s_rec[buf * (kRec + 1) + tid] = g_recs[rl * kRec + tid];
+        if (tid < kRec) {
+            s_rec[buf * (kRec + 1) + tid] = rec_next;
+            if (rl + gridDim.x < count) rec_next = g_recs[(rl + gridDim.x) * kRec + tid];
+        }
         const double2* s_H = s_rec + buf * (kRec + 1);
         const double2* s_G = s_H + NA * NA;
         unsigned se = 0, be = 0;
@@ -190,12 +212,12 @@ __global__ __launch_bounds__(kPipeBlock, 2) void k_run_mimo_ofdm_f64(MimoParams 
             // ---- transmit: symbols -> bins (Blast.encode's F-order split + OFDM subcarrier map) ----
             if (it > 0 || os > 0) __syncthreads();            // the previous symbol's decode has read the planes
             if (U != N) {
-                for (int p = tid; p < 2 * NA * N; p += kPipeBlock) s_d[p] = 0.0;
+                for (int p = tid; p < 2 * NA * N; p += TB) s_d[p] = 0.0;
                 __syncthreads();
             }
             const uint64_t n_first = (uint64_t)os * per_sym;
             const uint64_t n_last = n_first + per_sym;
-            for (uint64_t blk = (n_first >> 4) + tid; blk <= ((n_last - 1) >> 4); blk += kPipeBlock) {
+            for (uint64_t blk = (n_first >> 4) + tid; blk <= ((n_last - 1) >> 4); blk += TB) {
                 const Words4 dw = rng.block(STREAM_DATA, (uint32_t)blk);
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {
@@ -214,29 +236,29 @@ __global__ __launch_bounds__(kPipeBlock, 2) void k_run_mimo_ofdm_f64(MimoParams 
             }
             __syncthreads();
             if (tid == 0 && os == 0 && it > 0) {   // every wave is past the previous realization: account it
-                const unsigned* q = s_part + (buf ^ 1) * 8;
-                wg_account(totals, q[0] + q[2] + q[4] + q[6], q[1] + q[3] + q[5] + q[7],
-                           s_rec[(buf ^ 1) * (kRec + 1) + 2 * NA * NA].x != 0.0, rl_prev, sym_out, bit_out);
+                const unsigned* q = s_part + (buf ^ 1) * 16;
+                unsigned ts = 0, tb = 0;
+#pragma unroll
+                for (int i = 0; i < NW; ++i) {
+                    ts += q[2 * i];
+                    tb += q[2 * i + 1];
+                }
+                wg_account(totals, ts, tb, s_rec[(buf ^ 1) * (kRec + 1) + 2 * NA * NA].x != 0.0, rl_prev, sym_out, bit_out);
             }
             // ---- IFFT: radix-4 DIF, natural -> digit-reversed positions ----
-            r4_stage_planar<true, true, 256>(s_d, twr, opaque(tid));
+            r4_stage_planar<true, true, 256, AH>(s_mine, twr, g_tw, opaque(bbt));
             __syncthreads();
-            r4_stage_planar<true, true, 64>(s_d, twr, opaque(tid));
-            fft_stage_sync<kPipeBlock>(64);
-            r4_stage_planar<true, true, 16>(s_d, twr, opaque(tid));
-            fft_stage_sync<kPipeBlock>(16);
-            r4_stage_planar<true, true, 4>(s_d, twr, opaque(tid));
-            fft_stage_sync<kPipeBlock>(4);
-            r4_stage_planar<true, true, 1>(s_d, twr, opaque(tid));
+            r4_stage_planar<true, true, 64, AH>(s_mine, twr, g_tw, opaque(bbt));
+            fft_stage_sync<TB>(64);
+            r4_stage_planar<true, true, 16, AH>(s_mine, twr, g_tw, opaque(bbt));
+            fft_stage_sync<TB>(16);
+            r4_stage_planar<true, true, 4, AH>(s_mine, twr, g_tw, opaque(bbt));
+            fft_stage_sync<TB>(4);
+            r4_stage_planar<true, true, 1, AH>(s_mine, twr, g_tw, opaque(bbt));
             __syncthreads();
             // ---- channel: R = H T + noise on the samples that survive CP removal ----
             {
-                double2 H[NA][NA];
-#pragma unroll
-                for (int r = 0; r < NA; ++r)
-#pragma unroll
-                    for (int a = 0; a < NA; ++a) H[r][a] = s_H[r * NA + a];
-                for (int j = opaque(tid); j < N / 2; j += kPipeBlock) {
+                for (int j = opaque(tid); j < N / 2; j += TB) {
                     const int half = j / (N / 4), rest = j - half * (N / 4);
                     const int p0 = 2 * half * (N / 4) + rest, p1 = p0 + N / 4;
                     const int m0 = fft_index_of_pos<N>(p0);  // even; position p1 holds m0 + 1
@@ -259,8 +281,9 @@ __global__ __launch_bounds__(kPipeBlock, 2) void k_run_mimo_ofdm_f64(MimoParams 
                         }
 #pragma unroll
                         for (int a = 0; a < NA; ++a) {
-                            z0 = cfma(H[r][a], x0[a], z0);
-                            z1 = cfma(H[r][a], x1[a], z1);
+                            const double2 h = s_H[r * NA + a];       // wave-uniform address: an LDS broadcast
+                            z0 = cfma(h, x0[a], z0);
+                            z1 = cfma(h, x1[a], z1);
                         }
                         s_d[(2 * r) * N + q0] = z0.x;
                         s_d[(2 * r + 1) * N + q0] = z0.y;
@@ -271,24 +294,19 @@ __global__ __launch_bounds__(kPipeBlock, 2) void k_run_mimo_ofdm_f64(MimoParams 
             }
             __syncthreads();
             // ---- FFT: radix-4 DIT, digit-reversed -> natural bins ----
-            r4_stage_planar<false, false, 1>(s_d, twr, opaque(tid));
-            fft_stage_sync<kPipeBlock>(4);
-            r4_stage_planar<false, false, 4>(s_d, twr, opaque(tid));
-            fft_stage_sync<kPipeBlock>(16);
-            r4_stage_planar<false, false, 16>(s_d, twr, opaque(tid));
-            fft_stage_sync<kPipeBlock>(64);
-            r4_stage_planar<false, false, 64>(s_d, twr, opaque(tid));
+            r4_stage_planar<false, false, 1, AH>(s_mine, twr, g_tw, opaque(bbt));
+            fft_stage_sync<TB>(4);
+            r4_stage_planar<false, false, 4, AH>(s_mine, twr, g_tw, opaque(bbt));
+            fft_stage_sync<TB>(16);
+            r4_stage_planar<false, false, 16, AH>(s_mine, twr, g_tw, opaque(bbt));
+            fft_stage_sync<TB>(64);
+            r4_stage_planar<false, false, 64, AH>(s_mine, twr, g_tw, opaque(bbt));
             __syncthreads();
-            r4_stage_planar<false, false, 256>(s_d, twr, opaque(tid));
+            r4_stage_planar<false, false, 256, AH>(s_mine, twr, g_tw, opaque(bbt));
             __syncthreads();
             // ---- receive: Blast decode (G carries the FFT scale), demodulate, count ----
             {
-                double2 G[NA][NA];
-#pragma unroll
-                for (int a = 0; a < NA; ++a)
-#pragma unroll
-                    for (int r = 0; r < NA; ++r) G[a][r] = s_G[a * NA + r];
-                for (int d = opaque(tid); d < U; d += kPipeBlock) {
+                for (int d = opaque(tid); d < U; d += TB) {
                     const int bin = lds_swz64(ofdm_bin(d, N, U));
                     double2 y[NA];
 #pragma unroll
@@ -298,7 +316,7 @@ __global__ __launch_bounds__(kPipeBlock, 2) void k_run_mimo_ofdm_f64(MimoParams 
                     for (int a = 0; a < NA; ++a) {
                         double2 est = mk<double>(0, 0);
 #pragma unroll
-                        for (int r = 0; r < NA; ++r) est = cfma(G[a][r], y[r], est);
+                        for (int r = 0; r < NA; ++r) est = cfma(s_G[a * NA + r], y[r], est);
                         const int dec = demod_one<double>(mp, s_table, s_grid, est);
                         const unsigned x = ((sent >> (8 * a)) & 0xFFu) ^ (unsigned)dec;
                         se += (x != 0u);
@@ -310,8 +328,8 @@ __global__ __launch_bounds__(kPipeBlock, 2) void k_run_mimo_ofdm_f64(MimoParams 
         se = wave_sum_u32(se);
         be = wave_sum_u32(be);
         if (lane == 0) {
-            s_part[buf * 8 + 2 * w] = se;
-            s_part[buf * 8 + 2 * w + 1] = be;
+            s_part[buf * 16 + 2 * w] = se;
+            s_part[buf * 16 + 2 * w + 1] = be;
         }
         rl_prev = rl;
     }
@@ -319,9 +337,14 @@ __global__ __launch_bounds__(kPipeBlock, 2) void k_run_mimo_ofdm_f64(MimoParams 
     if (tid == 0) {
         if (it > 0) {
             const int buf = (int)((it - 1) & 1);
-            const unsigned* q = s_part + buf * 8;
-            wg_account(totals, q[0] + q[2] + q[4] + q[6], q[1] + q[3] + q[5] + q[7],
-                       s_rec[buf * (kRec + 1) + 2 * NA * NA].x != 0.0, rl_prev, sym_out, bit_out);
+            const unsigned* q = s_part + buf * 16;
+            unsigned ts = 0, tb = 0;
+#pragma unroll
+            for (int i = 0; i < NW; ++i) {
+                ts += q[2 * i];
+                tb += q[2 * i + 1];
+            }
+            wg_account(totals, ts, tb, s_rec[buf * (kRec + 1) + 2 * NA * NA].x != 0.0, rl_prev, sym_out, bit_out);
         }
         wg_flush(totals, counters, (unsigned long long)per_sym * pp.n_ofdm_sym,
                  (unsigned long long)per_sym * pp.n_ofdm_sym * mp.bits);
@@ -341,9 +364,12 @@ int run_mimo_ofdm_f64(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, uint64_t see
     mp.grid = context_grid<double>(ctx, cfg->demod_method, true);      // pruned search, decision-identical to the sweep
     const size_t tab_len = ((size_t)mp.M + 1) & ~(size_t)1;
     const size_t lds = (size_t)2 * kD64NA * kD64N * sizeof(double) + (2 * tab_len + 2 * (kD64Rec + 1)) * sizeof(double2) +
-                       16 * sizeof(unsigned) + (size_t)mp.grid.G * mp.grid.G * sizeof(unsigned long long) +
+                       32 * sizeof(unsigned) + (size_t)mp.grid.G * mp.grid.G * sizeof(unsigned long long) +
                        (size_t)4 * cfg->num_used + 16;
-    auto kern = k_run_mimo_ofdm_f64;
+    // MCLE_OPT_F64_THREADS: 0 / 512 = two antennas per thread, 512-thread workgroups (default); 256 = four antennas per thread
+    const bool wide = ctx->opt[MCLE_OPT_F64_THREADS] != 256;
+    auto kern = wide ? k_run_mimo_ofdm_f64<2> : k_run_mimo_ofdm_f64<4>;
+    const int tb = wide ? 512 : 256;
     MCLE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int per_cu = (int)((size_t)160 * 1024 / (lds + 512));
     if (per_cu < 1) per_cu = 1;
@@ -359,7 +385,7 @@ int run_mimo_ofdm_f64(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, uint64_t see
                            first + off, n, (double2*)recs);
         MCLE_LAUNCH_CHECK();
         const unsigned grid = (unsigned)oversubscribed_grid(ctx, resident, n);
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(kPipeBlock), lds, ctx->stream, pp, mp, seed, first + off, n,
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(tb), lds, ctx->stream, pp, mp, seed, first + off, n,
                            (const double2*)tw, (const double2*)recs, d_counters, d_sym ? d_sym + off : nullptr,
                            d_bit ? d_bit + off : nullptr);
         MCLE_LAUNCH_CHECK();

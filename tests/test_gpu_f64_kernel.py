@@ -18,9 +18,9 @@ CASES = [dict(mod="qam", M=64, snr_db=25.0),                                    
          dict(mod="qpsk", M=4, snr_db=8.0, num_used=2)]
 
 
-def _run(engine, kw, first, count, method, generic=False):
+def _run(engine, kw, first, count, method, generic=False, threads=0):
     nv = 1.0 / omodem.dB2Linear(kw["snr_db"])
-    with engine.options(f64_generic=1 if generic else 0):
+    with engine.options(f64_generic=1 if generic else 0, f64_threads=threads):
         return engine.run_mimo_ofdm(4, 4, 1024, kw.get("cp_size", 16), kw.get("num_used") or 1024, kw.get("n_ofdm_sym", 1),
                                     nv, SEED, first, count, mmse=kw.get("mmse", True), method=method, dtype="f64",
                                     per_realization=True)
@@ -39,10 +39,11 @@ def test_f64_kernel_counts_equal_the_oracle(engine, case):
     want_be = np.array([w["bit_errors"] for w in want])
     methods = [_lib.DEMOD_MINDIST] + ([_lib.DEMOD_QAM_SLICER] if kw["mod"] == "qam" else [])
     for method in methods:
-        res, se, be = _run(engine, kw, first, count, method)
-        assert np.array_equal(se, want_se) and np.array_equal(be, want_be), (case, method, se, want_se)
-        assert res["n_realizations"] == count and res["sym_errors"] == int(want_se.sum())
-        assert res["n_symbols"] == want[0]["num_symbols"] and res["n_bits"] == want[0]["num_bits"]
+        for threads in (512, 256):                 # two antennas per thread (default) / four antennas per thread
+            res, se, be = _run(engine, kw, first, count, method, threads=threads)
+            assert np.array_equal(se, want_se) and np.array_equal(be, want_be), (case, method, threads, se, want_se)
+            assert res["n_realizations"] == count and res["sym_errors"] == int(want_se.sum())
+            assert res["n_symbols"] == want[0]["num_symbols"] and res["n_bits"] == want[0]["num_bits"]
 
 
 @pytest.mark.parametrize("case", range(len(CASES)))
@@ -56,6 +57,8 @@ def test_f64_kernel_equals_the_generic_kernel(engine, case):
     n = 1031
     method = _lib.DEMOD_MINDIST
     new, se, be = _run(engine, kw, 5, n, method)
+    alt, se_a, be_a = _run(engine, kw, 5, n, method, threads=256)
+    assert np.array_equal(se, se_a) and np.array_equal(be, be_a) and new == alt          # same arithmetic, other thread map
     old, se_o, be_o = _run(engine, kw, 5, n, method, generic=True)
     assert np.count_nonzero(se != se_o) <= 1 and np.max(np.abs(se.astype(int) - se_o.astype(int))) <= 1
     assert abs(new["sym_errors"] - old["sym_errors"]) <= 1 and new["n_realizations"] == old["n_realizations"] == n
