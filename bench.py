@@ -36,7 +36,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
-ROUND = "r02"
+ROUND = "r03"
 # algorithmic bytes per realization in the staged (operator-granular)
 # model, complex64 samples / uint8 indices.
 B_ALG = {"c2": 7_600_000, "c3": 211_360, "c4": 412_160, "c5": 62_000, "f1": 3_099_008,
@@ -62,14 +62,31 @@ UNCOUNTED = {"c4": "Philox4x32-10: ~2 350 blocks (4 176 CN samples + 4 096 symbo
 HBM_PEAK_GBPS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
 HBM_COPY_GBPS = 6290.0      # same guide: measured float4 copy
 FP32_PEAK_TFLOPS = 157.3    # same guide: FP32 vector peak = FP32-input MFMA peak (256 CU x 4 SIMD x 64 flop/clk x 2.4 GHz)
+# FP64: 16 lanes x 1 FMA per clock and SIMD = half the guide's FP32 figure (256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz); the guide
+# does not list it, so it was measured (scripts/experiments/f64_rates.hip -> profiles/r03/f64_rates.txt): v_mfma_f64_16x16x4_f64
+# 77.6 TFLOP/s, v_fma_f64 65.9 TFLOP/s, and the two do not overlap on a SIMD.
+FP64_PEAK_TFLOPS = 78.6
+FP64_MEASURED = {"v_mfma_f64_16x16x4_f64": 77.6, "v_fma_f64": 65.9, "source": "profiles/r03/f64_rates.txt"}
+PEAK_TFLOPS = {"f32": FP32_PEAK_TFLOPS, "f64": FP64_PEAK_TFLOPS}
 KERNEL = {"c4": "k_run_mimo_ofdm_mfma", "c2": "k_run_flat_mfma", "c3": "k_run_ofdm_tdl_mfma", "c5": "k_ia_link",
           "f1": "k_run_mimo_ofdm_tdl", "f6": "k_bd_link"}
+KERNEL_F64 = {"c4": "k_run_mimo_ofdm_f64", "c2": "k_run_flat", "c3": "k_run_ofdm_tdl_batch", "c5": "k_ia_link",
+              "f1": "k_run_mimo_ofdm_tdl", "f6": "k_bd_link"}
+
+
+def kernel_name(cfg, dtype):
+    return (KERNEL_F64 if dtype == "f64" else KERNEL)[cfg]
+
 KERNEL_NOTE = {   # configs whose step is two launches: the time spans both, the counters are the named (dominant) kernel's
     "c4": "a step = k_mimo_filters (channel draw + f64 receive filter per realization, 13 us = 0.8 % of the time) + k_run_mimo_ofdm_mfma; "
           "kernel_ms_per_launch spans both",
     "c5": "a step = k_ia_solve_links (per-lane solve, ~18 % of the time) + k_ia_link (symbol walk); kernel_ms_per_launch spans both",
     "f6": "a step = k_bd_solve_links (per-lane solve) + k_bd_link (symbol walk); kernel_ms_per_launch spans both"}
-BATCH = {"c4": 65536, "c3": 131072, "c2": 16384, "c5": 262144, "f1": 98304, "f6": 131072}
+# realizations per GPU and step: sized so that a step is >= 15 ms on the fastest kernel of the configuration -- K = 20 steps
+# then time >= 0.3 s, long enough that one rank's scheduling hiccup of a millisecond is < 0.5 % of an 8-rank run's region
+# (round 2 timed 29 ms in all).  Nothing in BASELINE.json fixes the batch; a step is one call of the pipeline's C entry point.
+BATCH = {"c4": 1048576, "c3": 2097152, "c2": 131072, "c5": 4194304, "f1": 393216, "f6": 1048576}
+BATCH_SURVEY = {"c4": 65536, "c3": 131072, "c2": 16384, "c5": 262144, "f1": 98304, "f6": 131072}   # other_workloads legs
 BITS = {"c2": 6, "c3": 2, "c4": 6, "c5": 4, "f1": 6, "f6": 2}
 SEED = 20260927
 SNR_DB = {"c1": 10.0, "c2": 20.0, "c3": 20.0, "c4": 25.0, "c5": 20.0, "f1": 25.0, "f6": 15.0}
@@ -96,10 +113,13 @@ def parse():
     ap.add_argument("--config", default="c4", choices=["c2", "c3", "c4", "c5", "f1", "f6"])
     ap.add_argument("--batch", type=int, default=0, help="realizations per GPU per step")
     ap.add_argument("--single-demod", action="store_true",
-                    help="c4: time only the --demod demodulator (profiling runs: every launch is then the same kernel work)")
-    ap.add_argument("--demod", default="slicer", choices=["slicer", "mindist"],
-                    help="demodulator `value` is quoted on; the c4 line carries the rate of both")
-    ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
+                    help="time only the --demod / --dtype combination (profiling runs: every launch is then the same kernel work)")
+    ap.add_argument("--demod", default="mindist", choices=["slicer", "mindist"],
+                    help="demodulator `value` is quoted on (mindist = the north star's min-distance search over the LDS "
+                         "constellation table); the c4 line carries the rate of both")
+    ap.add_argument("--dtype", default="f64", choices=["f32", "f64"],
+                    help="arithmetic `value` is quoted on: f64 = complex128, the reference's own precision (default); the "
+                         "line carries the complex64 rate of the same workload next to it (dtype_rates)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--cpu-multicore-seconds", type=float, default=6.0,
                     help="budget of the all-cores CPU leg (0 disables it)")
@@ -319,7 +339,7 @@ def derive_pmc(c, per_launch):
     return d
 
 
-def collect_pmc_live(args, batch):
+def collect_pmc_live(args, batch, dtype, demod):
     """Three `rocprofv3 --pmc` child runs of this bench (3 timed launches each) -> counter means per launch."""
     exe = shutil.which("rocprofv3")
     if exe is None:
@@ -331,42 +351,45 @@ def collect_pmc_live(args, batch):
         out_dir = os.path.join(root, tag)
         cmd = [exe, "--pmc"] + names.split() + ["--output-format", "csv", "-d", out_dir, "-o", "pmc", "--",
                                                  sys.executable, os.path.abspath(__file__), "--config", args.config,
-                                                 "--demod", args.demod, "--dtype", args.dtype, "--batch", str(batch),
+                                                 "--demod", demod, "--dtype", dtype, "--batch", str(batch),
                                                  "--steps", "3", "--warmup", "1", "--no-cpu", "--pmc", "off", "--single-demod", "--preroll-ms", "0"]
         for item in args.opt:
             cmd += ["--opt", item]
         try:
             subprocess.run(cmd, cwd="/tmp", env=env, timeout=180, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-            counters.update(_parse_pmc_csv(out_dir, KERNEL[args.config]))
+            counters.update(_parse_pmc_csv(out_dir, kernel_name(args.config, dtype)))
         except Exception as exc:       # a failed pass must not break the bench line
             counters["_error_" + tag] = repr(exc)
     shutil.rmtree(root, ignore_errors=True)
     if not any(not k.startswith("_") for k in counters):
-        return None, "no counter rows for %s" % KERNEL[args.config]
+        return None, "no counter rows for %s" % kernel_name(args.config, dtype)
     return counters, None
 
 
-def committed_pmc(cfg):
-    path = os.path.join(REPO, "profiles", ROUND, "%s_pmc_summary.json" % cfg)
+def committed_pmc(cfg, dtype):
+    """-> (counter means per launch, path, realizations per launch of that profile)"""
+    path = os.path.join(REPO, "profiles", ROUND, "%s%s_pmc_summary.json" % (cfg, "_f64" if dtype == "f64" else ""))
     if not os.path.exists(path):
-        return None, None
+        return None, None, None
     try:
         doc = json.load(open(path))
-        return {k: v["mean_per_launch"] for k, v in doc.items() if not k.startswith("_")}, os.path.relpath(path, REPO)
+        return ({k: v["mean_per_launch"] for k, v in doc.items() if not k.startswith("_")}, os.path.relpath(path, REPO),
+                int(doc.get("_realizations_per_launch", BATCH_SURVEY[cfg])))
     except Exception:
-        return None, None
+        return None, None, None
 
 
-def roofline_block(args, batch, per_launch_s, rate_kernel, pmc, pmc_source):
+def roofline_block(args, dtype, batch, per_launch_s, rate_kernel, d, pmc_source):
     """What binds the dominant kernel, as fractions in (0, 1]:
-      frac            = algorithmic flops per realization x realizations/s of the kernel / FP32 peak
+      frac            = algorithmic flops per realization x realizations/s of the kernel / peak of the dtype's datapath
       hbm.frac        = min(B_alg, measured HBM bytes) per realization x rate / 8 TB/s   (SURVEY 8(d)'s rule)
       valu_busy_chip  = VALU-active SIMD-cycles / all SIMD-cycles (rocprofv3 counters)"""
     flops = FLOPS[args.config]
     f_total = float(sum(flops.values()))
     achieved_tf = f_total * rate_kernel / 1e12
-    balg = B_ALG[args.config]
-    d = derive_pmc(pmc, batch) if pmc else {}
+    balg = B_ALG[args.config] * (2 if dtype == "f64" else 1)       # complex128 samples: twice the bytes of the staged model
+    peak = PEAK_TFLOPS[dtype]
+    d = d or {}                                   # counters derived per realization (derive_pmc), possibly from a smaller launch
     measured = d.get("hbm_bytes_per_realization")
     hbm = {"b_alg_bytes_per_realization": balg, "measured_bytes_per_realization": measured,
            "b_alg_over_measured": (balg / measured) if measured else None}
@@ -375,10 +398,13 @@ def roofline_block(args, batch, per_launch_s, rate_kernel, pmc, pmc_source):
         hbm.update(achieved_GBps=eff * rate_kernel / 1e9, frac=eff * rate_kernel / 1e9 / HBM_PEAK_GBPS,
                    frac_of_measured_copy_bw=eff * rate_kernel / 1e9 / HBM_COPY_GBPS, peak_GBps=HBM_PEAK_GBPS,
                    rule="min(B_alg, measured bytes) x rate (SURVEY.md 8(d)); measured = (2*FETCH_SIZE + WRITE_SIZE) KiB")
-    block = {"bound": "valu", "achieved": achieved_tf, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-             "frac": achieved_tf / FP32_PEAK_TFLOPS,
-             "traffic": d.get("hbm_bytes_per_launch"),
-             "kernel": KERNEL[args.config], "kernel_ms_per_launch": per_launch_s * 1e3,
+    block = {"bound": "valu", "dtype": dtype, "achieved": achieved_tf, "peak": peak, "unit": "TFLOP/s",
+             "frac": achieved_tf / peak,
+             "peak_note": ("FP64 vector = matrix peak, 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz; measured on this chip: %s"
+                           % json.dumps(FP64_MEASURED)) if dtype == "f64" else
+                          "FP32 vector = f32-input MFMA peak (MI355X_MICROARCH.md)",
+             "traffic": (measured * batch) if measured is not None else None,      # HBM bytes per launch of `batch` realizations
+             "kernel": kernel_name(args.config, dtype), "kernel_ms_per_launch": per_launch_s * 1e3,
              "kernel_note": KERNEL_NOTE.get(args.config),
              "realizations_per_launch": batch,
              "flops_per_realization": f_total, "flops_breakdown": flops, "uncounted": UNCOUNTED.get(args.config),
@@ -387,15 +413,18 @@ def roofline_block(args, batch, per_launch_s, rate_kernel, pmc, pmc_source):
              # f32-input MFMA and VALU instructions share one FP32 datapath per SIMD on gfx950 (measured:
              # scripts/experiments/mfma_valu_overlap.hip, profiles/r02/mfma_valu_overlap.txt), so the two add up
              "fp32_datapath_busy_chip": (d["valu_busy_chip"] + d["mfma_busy_chip"])
-             if d.get("valu_busy_chip") is not None and d.get("mfma_busy_chip") is not None else None,
+             if dtype == "f32" and d.get("valu_busy_chip") is not None and d.get("mfma_busy_chip") is not None else None,
              "valu_wave_insts_per_realization": d.get("valu_wave_insts_per_realization"),
              "mfma_f32_mops_per_realization": d.get("mfma_f32_mops_per_realization"),
              "wait_inst_any_frac": d.get("wait_inst_any_frac"),
              "counters_source": pmc_source,
              "note": "fused kernel: every intermediate of a realization lives in LDS / registers, so HBM traffic is "
-                     "B_alg / %s of the staged model and the kernel is bound by the SIMDs' FP32 datapath (VALU + f32 MFMA "
-                     "instructions, which do not overlap on gfx950); frac = algorithmic flops (RNG excluded) / FP32 peak"
-                     % (("%.0f" % (balg / measured)) if measured else "?")}
+                     "B_alg / %s of the staged model and the kernel is bound by the SIMDs' %s datapath%s; "
+                     "frac = algorithmic flops (RNG excluded) / peak"
+                     % (("%.0f" % (balg / measured)) if measured else "?", "FP64" if dtype == "f64" else "FP32",
+                        " (VALU only: the f64 MFMA forms are no denser than v_fma_f64 here and do not overlap with it, "
+                        "DESIGN.md section 5.5)" if dtype == "f64" else
+                        " (VALU + f32 MFMA instructions, which do not overlap on gfx950)")}
     return block
 
 
@@ -463,6 +492,7 @@ def main():
         name, _, val = item.partition("=")
         eng.set_option(name, int(val))
     batch = args.batch or BATCH[args.config]
+    exchange_calls = {"timed": 0}
 
     def barrier():
         eng.sync()
@@ -470,102 +500,158 @@ def main():
         if use_dist:
             dist.barrier()
 
-    def timed(demod, base):
+    def timed(demod, dtype, base, solo=False):
         """W warm-up + exactly K timed steps of the hot path on this rank's contiguous index range starting at
-        `base`, one all-reduce of the counter vector inside the timed region -> (elapsed max over ranks,
-        kernel ms max over ranks, reduced counter totals, workload description, units per realization)."""
-        run, units, workload = make_runner(eng, args.config, demod, args.dtype)
+        `base`, one all-reduce of the counter vector inside the timed region -> dict(elapsed max over ranks, kernel ms
+        max / min over ranks, reduced counter totals, workload description, units per realization).
+        solo: only rank 0 launches (the other ranks hold the barriers and contribute zeros): the one-GPU rate measured inside
+        the same multi-rank job, so that N-GPU efficiency can be read off one line."""
+        run, units, workload = make_runner(eng, args.config, demod, dtype)
+        active = (not solo) or rank == 0
         counters = eng.new_counters()
-        if args.preroll_ms > 0:               # clock ramp: untimed, results discarded, indices far from everything else
+        n_active = 1 if solo else world
+        r_idx = 0 if solo else rank
+        if active and args.preroll_ms > 0:    # clock ramp: untimed, results discarded, indices far from everything else
             t_pre, i_pre = time.perf_counter(), 0
             while (time.perf_counter() - t_pre) * 1e3 < args.preroll_ms:
-                run((1 << 41) + base + (i_pre * world + rank) * batch, batch, counters)
+                run((1 << 41) + base + (i_pre * n_active + r_idx) * batch, batch, counters)
                 eng.sync()
                 i_pre += 1
-        for w in range(args.warmup):          # warm-up draws from a disjoint index range far away
-            run((1 << 40) + base + (w * world + rank) * batch, batch, counters)
+        if active:
+            for w in range(args.warmup):      # warm-up draws from a disjoint index range far away
+                run((1 << 40) + base + (w * n_active + r_idx) * batch, batch, counters)
         if use_dist:   # bring the communicator up outside the timed region (same shape / dtype as the real exchange)
             dist.all_reduce(torch.zeros(6, dtype=torch.int64, device="cuda"), op=dist.ReduceOp.SUM)
             dist.all_reduce(torch.zeros(2, dtype=torch.float64, device="cuda"), op=dist.ReduceOp.MAX)
         barrier()
         counters.zero()
         barrier()
-        lo = base + rank * args.steps * batch
+        lo = base + r_idx * args.steps * batch
         t0 = time.perf_counter()
-        eng.timer_start()
-        for s in range(args.steps):
-            run(lo + s * batch, batch, counters)
-        kernel_ms = eng.timer_stop_ms()            # HIP events on the stream the kernels ran on
+        kernel_ms = 0.0
+        if active:
+            eng.timer_start()
+            for s in range(args.steps):
+                run(lo + s * batch, batch, counters)
+            kernel_ms = eng.timer_stop_ms()        # HIP events on the stream the kernels ran on
         local = eng.read_counters(counters)
         vec = torch.tensor([local[k] for k in COUNTER_KEYS], dtype=torch.int64, device="cuda")
         if use_dist:
             dist.all_reduce(vec, op=dist.ReduceOp.SUM)     # RCCL over xGMI: the path's only exchange step
+            exchange_calls["timed"] += 1
         barrier()
         elapsed = time.perf_counter() - t0
-        tmax = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([elapsed, kernel_ms, -kernel_ms if active else -1e30], dtype=torch.float64, device="cuda")
         if use_dist:
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tot = [int(v) for v in vec.tolist()]
-        assert tot[0] + tot[1] == args.steps * batch * world, (tot, args.steps, batch, world)
-        return float(tmax[0]), float(tmax[1]), tot, workload, units
+        assert tot[0] + tot[1] == args.steps * batch * n_active, (tot, args.steps, batch, n_active)
+        return {"elapsed": float(tmax[0]), "kernel_ms": float(tmax[1]), "kernel_ms_min": -float(tmax[2]), "tot": tot,
+                "workload": workload, "units": units, "rate": (tot[0] + tot[1]) / float(tmax[0]),
+                "kernel_ms_per_launch": float(tmax[1]) / args.steps}
 
-    elapsed, kernel_ms, tot, workload, units = timed(args.demod, 0)
+    head = timed(args.demod, args.dtype, 0)
+    elapsed, kernel_ms, tot, workload, units = head["elapsed"], head["kernel_ms"], head["tot"], head["workload"], head["units"]
     n_real = tot[0] + tot[1]
-    other_demod = None
-    if args.config == "c4" and not args.single_demod:   # the same kernel with the other demodulator, timed the same way
-        other = "mindist" if args.demod == "slicer" else "slicer"
-        e2, k2, t2, _, _ = timed(other, 1 << 38)
-        other_demod = (other, (t2[0] + t2[1]) / e2, k2 / args.steps)
+    # the same workload in the other arithmetic and with the other demodulator, each timed exactly like the headline
+    rates = {args.dtype: {args.demod: head}}
+    if not args.single_demod:
+        base_i = 1
+        for dt in (args.dtype, "f32" if args.dtype == "f64" else "f64"):
+            for dm in ((args.demod, "slicer" if args.demod == "mindist" else "mindist") if args.config == "c4" else (args.demod,)):
+                if dt == args.dtype and dm == args.demod:
+                    continue
+                rates.setdefault(dt, {})[dm] = timed(dm, dt, base_i << 36)
+                base_i += 1
+    solo = timed(args.demod, args.dtype, 15 << 36, solo=True) if world > 1 else None
+    # who ran: device name and PCI bus id of every rank (RCCL's view of the job next to the launcher's)
+    props = torch.cuda.get_device_properties(local_rank)
+    me = {"rank": rank, "local_rank": local_rank, "device": props.name,
+          "pci_bus_id": "%04x:%02x:%02x" % (getattr(props, "pci_domain_id", 0), getattr(props, "pci_bus_id", 0),
+                                              getattr(props, "pci_device_id", 0)),
+          "kernel_ms_timed_region": head["kernel_ms"] if world == 1 else None}
+    ranks_info = [me]
+    if use_dist:
+        ranks_info = [None] * world
+        dist.all_gather_object(ranks_info, me)
 
     if rank == 0:
         value = n_real / elapsed
-        per_launch_s = kernel_ms * 1e-3 / args.steps
-        rate_kernel = batch / per_launch_s            # one GPU's kernel rate (HIP events): what the roofline prices
-        pmc, pmc_source = None, None
-        want_pmc = args.pmc == "on" or (args.pmc == "auto" and world == 1 and not args.no_cpu)
-        if want_pmc:
-            eng.sync()
-            pmc, err = collect_pmc_live(args, batch)
-            pmc_source = ("rocprofv3 --pmc child runs of this command (3 launches per pass: %s)"
-                          % "; ".join(n for _, n in PMC_PASSES)) if pmc else None
+
+        def roof(dt, dm, res):
+            """roofline block of the (dtype, demod) kernel: live rocprofv3 counters when possible (child runs at a smaller
+            batch: the counters are normalised per realization), else the committed summary"""
+            per_launch_s = res["kernel_ms_per_launch"] * 1e-3
+            pmc, src, pmc_batch = None, None, None
+            want = args.pmc == "on" or (args.pmc == "auto" and world == 1 and not args.no_cpu)
+            if want:
+                eng.sync()
+                pmc_batch = min(batch, BATCH_SURVEY[args.config] * 4)
+                pmc, err = collect_pmc_live(args, pmc_batch, dt, dm)
+                src = ("rocprofv3 --pmc child runs of this command (3 launches of %d realizations per pass: %s)"
+                       % (pmc_batch, "; ".join(n for _, n in PMC_PASSES))) if pmc else "live collection failed (%s); " % err
             if pmc is None:
-                pmc_source = "live collection failed (%s); " % err
-        if pmc is None:
-            pmc, src = committed_pmc(args.config)
-            pmc_source = ((pmc_source or "") + ("%s (committed rocprofv3 summary, NOT measured in this run)" % src)
-                          if pmc else (pmc_source or None))
-        demod_rates = {args.demod: value}
-        if other_demod:
-            demod_rates[other_demod[0]] = other_demod[1]
+                pmc, path, pmc_batch = committed_pmc(args.config, dt)
+                src = ((src or "") + "%s (committed rocprofv3 summary, NOT measured in this run)" % path) if pmc else src
+            d = derive_pmc(pmc, pmc_batch) if pmc else {}
+            blk = roofline_block(args, dt, batch, per_launch_s, batch / per_launch_s, d, src)
+            blk["demod"] = dm
+            blk["counters_realizations_per_launch"] = pmc_batch
+            return blk
+
+        dtype_rates = {dt: r[args.demod]["rate"] for dt, r in rates.items() if args.demod in r}
+        demod_rates = {dm: r["rate"] for dm, r in rates[args.dtype].items()}
         out = {
             "metric": "Monte Carlo realizations/sec (whole node) + SER abs-error vs ref",
             "value": value, "unit": "realizations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "preroll_ms": args.preroll_ms,
             "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "value_is": "%s arithmetic (%s), %s demodulator" % (
+                args.dtype, "complex128 = the reference's own precision" if args.dtype == "f64" else "complex64",
+                "min-distance search over the LDS constellation table (north star)" if args.demod == "mindist" else "QAM slicer"),
+            "timed_region_s": elapsed,
+            "dtype_rates": dtype_rates,
+            "rates": {dt: {dm: r["rate"] for dm, r in v.items()} for dt, v in rates.items()},
+            "kernel_ms_per_launch": {dt: {dm: r["kernel_ms_per_launch"] for dm, r in v.items()} for dt, v in rates.items()},
             "config": {"workload": workload, "realizations_per_step_per_gpu": batch,
-                       "demod": args.demod, "value_is": "rate with the %s demodulator" % args.demod,
-                       "demod_rates": demod_rates,
+                       "demod": args.demod, "demod_rates": demod_rates,
                        "demod_note": "mindist = min-distance search over the LDS constellation table (north star); "
                                      "slicer = QAM slicer, decision-identical in f64",
                        "symbols_per_realization": units, "parallelism": "realization-sharded x%d" % world,
                        "rank_ranges": [[r * args.steps * batch, (r + 1) * args.steps * batch] for r in range(world)],
-                       "exchange": "one all-reduce(SUM) of 6 int64 counters, inside the timed region",
+                       "exchange": ("one all-reduce(SUM) of 6 int64 counters over RCCL, inside the timed region "
+                                    "(%d ranks)" % world) if use_dist else "none (single process, no process group)",
                        "rng": "Philox4x32-10 keyed by (seed, realization)"},
+            "rccl": {"process_group": bool(use_dist), "backend": dist.get_backend() if use_dist else None,
+                     "rccl_world_size": dist.get_world_size() if use_dist else 1,
+                     "allreduce_calls_in_timed_regions": exchange_calls["timed"],
+                     "ranks": ranks_info},
             "ser": tot[2] / float(max(1, tot[0]) * units),
             "ber": tot[4] / float(max(1, tot[0]) * units * BITS[args.config]),
             "n_skipped": tot[1],
-            "roofline": roofline_block(args, batch, per_launch_s, rate_kernel, pmc, pmc_source),
+            "roofline": roof(args.dtype, args.demod, head),
         }
-        if other_demod:
-            out[other_demod[0] + "_demod_realizations_per_s"] = other_demod[1]
-            out[other_demod[0] + "_demod_kernel_ms_per_launch"] = other_demod[2]
+        if world > 1:
+            out["kernel_ms_per_rank"] = {"min": head["kernel_ms_min"], "max": head["kernel_ms"]}
+            out["n1_value"] = solo["rate"]
+            out["n1_note"] = ("rank 0 alone, same job, same K steps and batch, the other ranks holding the barriers; "
+                              "value / (n_gpus * n1_value) = %.4f" % (value / (world * solo["rate"])))
+        for dt, v in rates.items():
+            if dt != args.dtype and args.demod in v:
+                out["roofline_" + dt] = roof(dt, args.demod, v[args.demod])
+        out["roofline_" + args.dtype] = out["roofline"]
+        for dm, r in rates[args.dtype].items():
+            if dm != args.demod:
+                out[dm + "_demod_realizations_per_s"] = r["rate"]
+                out[dm + "_demod_kernel_ms_per_launch"] = r["kernel_ms_per_launch"]
         if world == 1 and not args.no_cpu:
             # per-realization counts of the first realizations for the SER cross-check
             res, se, be = eng_first_counts(eng, args, 16384 if args.config != "c2" else 128)
             cb, ser_err, n_chk = cpu_baseline(args.config, args.cpu_seconds, se)
             cb["host_cpu_count"] = os.cpu_count()
             cb["host_cpu_model"] = _cpu_model()
+            cb["dtype"] = "complex128 (NumPy)"
             cross = os.path.join(REPO, "profiles", "cpu_cross_timing.json")
             if os.path.exists(cross):
                 try:
@@ -585,27 +671,36 @@ def main():
                     out["cpu_baseline_all_cores"] = {"error": repr(exc)}
             if args.config == "c4":
                 # the other workloads of SURVEY.md section 8 on the same device, 5 launches each (a second's work):
-                # realizations/s and the kernel time of one launch, so that one bench line documents them all
+                # realizations/s and the kernel time of one launch in both arithmetics, so that one bench line documents them all
                 others = {}
                 for cfg in ("c2", "c3", "c5", "f1", "f6"):
-                    try:
-                        run_o, units_o, wl_o = make_runner(eng, cfg, "slicer", args.dtype)
-                        cnt_o = eng.new_counters()
-                        run_o(1 << 42, BATCH[cfg], cnt_o)
-                        eng.sync()
-                        eng.timer_start()
-                        for s2 in range(5):
-                            run_o((1 << 42) + (s2 + 1) * BATCH[cfg], BATCH[cfg], cnt_o)
-                        ms_o = eng.timer_stop_ms() / 5
-                        c_o = eng.read_counters(cnt_o)
-                        rate_o = BATCH[cfg] / ms_o * 1e3
-                        others[cfg] = {"workload": wl_o, "realizations_per_s": rate_o,
-                                       "kernel_ms_per_launch": ms_o, "realizations_per_launch": BATCH[cfg],
-                                       "kernel": KERNEL[cfg],
-                                       "fp32_frac": sum(FLOPS[cfg].values()) * rate_o / 1e12 / FP32_PEAK_TFLOPS,
-                                       "ser": c_o["sym_errors"] / float(max(1, c_o["n_realizations"]) * units_o)}
-                    except Exception as exc:
-                        others[cfg] = {"error": repr(exc)}
+                    others[cfg] = {}
+                    for dt in ("f64", "f32"):
+                        try:
+                            run_o, units_o, wl_o = make_runner(eng, cfg, "slicer", dt)
+                            cnt_o = eng.new_counters()
+                            nb = BATCH_SURVEY[cfg]
+                            run_o(1 << 42, nb, cnt_o)
+                            eng.sync()
+                            eng.timer_start()
+                            for s2 in range(5):
+                                run_o((1 << 42) + (s2 + 1) * nb, nb, cnt_o)
+                            ms_o = eng.timer_stop_ms() / 5
+                            c_o = eng.read_counters(cnt_o)
+                            rate_o = nb / ms_o * 1e3
+                            others[cfg][dt] = {"realizations_per_s": rate_o, "kernel_ms_per_launch": ms_o,
+                                               "realizations_per_launch": nb, "kernel": kernel_name(cfg, dt),
+                                               "flop_frac": sum(FLOPS[cfg].values()) * rate_o / 1e12 / PEAK_TFLOPS[dt],
+                                               "ser": c_o["sym_errors"] / float(max(1, c_o["n_realizations"]) * units_o)}
+                            others[cfg]["workload"] = wl_o
+                        except Exception as exc:
+                            others[cfg][dt] = {"error": repr(exc)}
+                try:
+                    sys.path.insert(0, os.path.join(REPO, "scripts"))
+                    import bench_staged_c4
+                    others["c4_staged"] = bench_staged_c4.run(eng, batch=8192, seconds=1.0)
+                except Exception as exc:
+                    others["c4_staged"] = {"error": repr(exc)}
                 out["other_workloads"] = others
         print(json.dumps(out), flush=True)
     if use_dist:

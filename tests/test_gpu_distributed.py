@@ -107,3 +107,35 @@ def test_two_ranks_of_the_ia_pipeline_keep_the_capacity_results(tmp_path):
         assert _close(a, b), (a, b)                         # float sums: association differs, value does not
     cap = one["state"]["sum_capacity"][1]
     assert cap["num_updates"] == 4000 and 5.0 < cap["value"] / cap["total"] < 40.0
+
+
+@pytest.mark.timeout(900)
+def test_bench_under_the_drivers_launch_line_runs_the_rccl_allreduce():
+    """`python -m torch.distributed.run --nproc-per-node 1 ... bench.py --gpus 1` (the driver's multi-GPU launch line with one
+    rank): the RCCL process group comes up, the counter all-reduce runs inside every timed region, and the line says so --
+    while a plain `python bench.py` run reports no exchange at all."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "4096", "--no-cpu", "--pmc", "off",
+              "--preroll-ms", "0", "--single-demod"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                          "--master-addr", "127.0.0.1", "--master-port", "29541", os.path.join(repo, "bench.py")] + common,
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["rccl"]["process_group"] is True and line["rccl"]["backend"] == "nccl"
+    assert line["rccl"]["rccl_world_size"] == 1 and line["rccl"]["allreduce_calls_in_timed_regions"] >= 1
+    assert "RCCL" in line["config"]["exchange"] and line["n_gpus"] == 1 and line["value"] > 0
+    assert line["rccl"]["ranks"][0]["device"]
+    plain = subprocess.run([sys.executable, os.path.join(repo, "bench.py")] + common, env=env, capture_output=True,
+                           text=True, timeout=600)
+    assert plain.returncode == 0, plain.stderr[-3000:]
+    p = json.loads([l for l in plain.stdout.splitlines() if l.startswith("{")][-1])
+    assert p["rccl"]["process_group"] is False and p["rccl"]["allreduce_calls_in_timed_regions"] == 0
+    assert p["config"]["exchange"].startswith("none")
+    # the integer counters behind both lines are the same realizations: same SER to the last digit
+    assert p["ser"] == line["ser"]
