@@ -147,7 +147,10 @@ int mcle_comm_info(mcle_ctx* ctx, int* rank, int* world) {
 
 int mcle_counters_allreduce(mcle_ctx* ctx, mcle_counters* d_counters, int n) {
     MCLE_REQUIRE(ctx != nullptr && d_counters != nullptr && n >= 1, "bad argument");
-    if (ctx->comm == nullptr || ctx->comm_world == 1) return MCLE_OK;     // single rank: nothing to exchange
+    // no communicator: single process, nothing to exchange.  WITH a communicator of one rank the whole path still runs
+    // (pack, the grouped in-place SUM / MAX all-reduces, unpack): RCCL treats it as a copy, and it is the only way a
+    // one-GPU box can execute these kernels and calls (tests/test_gpu_distributed.py).
+    if (ctx->comm == nullptr) return MCLE_OK;
     int rc;
     if ((rc = ctx->bind())) return rc;
     if (!ctx->d_comm_buf || ctx->comm_buf_words < (size_t)8 * n) {
@@ -172,7 +175,7 @@ int mcle_counters_allreduce(mcle_ctx* ctx, mcle_counters* d_counters, int n) {
 
 int mcle_allreduce_f64(mcle_ctx* ctx, double* d_values, size_t n) {
     MCLE_REQUIRE(ctx != nullptr && d_values != nullptr, "null argument");
-    if (ctx->comm == nullptr || ctx->comm_world == 1 || n == 0) return MCLE_OK;
+    if (ctx->comm == nullptr || n == 0) return MCLE_OK;
     int rc;
     if ((rc = ctx->bind())) return rc;
     MCLE_NCCL(g_rccl.AllReduce(d_values, d_values, n, ncclFloat64, ncclSum, static_cast<ncclComm_t>(ctx->comm),

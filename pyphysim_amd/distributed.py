@@ -46,11 +46,23 @@ def _exchange_id(make_id, rank, world, addr, port, timeout=120.0):
         seen = set()
         try:
             while len(seen) < world - 1:
-                conn, _ = srv.accept()
+                conn, _ = srv.accept()                    # socket.timeout after `timeout` s without a connection
                 with conn:
-                    peer = struct.unpack("<i", conn.recv(4))[0]
-                    conn.sendall(payload)
-                    seen.add(peer)
+                    try:                                  # one bad client (port scanner, half-open socket) must not
+                        conn.settimeout(10.0)             # block or abort the server loop
+                        head = b""
+                        while len(head) < 4:
+                            chunk = conn.recv(4 - len(head))
+                            if not chunk:
+                                raise ConnectionError("peer closed before sending its rank")
+                            head += chunk
+                        peer = struct.unpack("<i", head)[0]
+                        if not (1 <= peer < world) or peer in seen:
+                            continue                      # not one of ours, or a duplicate: no id for it
+                        conn.sendall(payload)
+                        seen.add(peer)
+                    except (OSError, ConnectionError, struct.error):
+                        continue
         finally:
             srv.close()
         return payload
@@ -102,9 +114,21 @@ class NativeComm:
         return [float(v) for v in self.engine.allreduce_f64(np.asarray(values, dtype=np.float64))]
 
     def broadcast_ints(self, values, src=0):
-        """Rank `src`'s integer list on every rank (an all-reduce of a vector that is zero elsewhere)."""
-        v = np.asarray(values if self.rank == src else [0] * len(values), dtype=np.float64)
-        return [int(round(x)) for x in self.engine.allreduce_f64(v)]
+        """Rank `src`'s integer list on every rank: the uint64 SUM all-reduce of the counter blocks over a vector that is
+        zero on the other ranks -- exact for every int64 (two's complement wraps back), unlike a float64 reduction, which
+        rounds the squared-error sums of long runs above 2^53."""
+        vals = [int(v) for v in values]
+        n_blocks = max(1, -(-len(vals) // 6))
+        words = np.zeros((n_blocks, 8), dtype=np.uint64)          # words 0..5 of a block are summed, 6..7 take the maximum
+        if self.rank == src:
+            flat = np.zeros(n_blocks * 6, dtype=np.uint64)
+            flat[:len(vals)] = np.array([v & 0xFFFFFFFFFFFFFFFF for v in vals], dtype=np.uint64)
+            words[:, :6] = flat.reshape(n_blocks, 6)
+        cnt = self.engine.zeros(n_blocks, self._cnt.dtype)
+        cnt.set(np.ascontiguousarray(words).view(self._cnt.dtype).reshape(n_blocks))
+        self.engine.counters_allreduce(cnt, n_blocks)
+        back = np.frombuffer(cnt.get().tobytes(), dtype=np.uint64).reshape(n_blocks, 8)[:, :6].reshape(-1)[:len(vals)]
+        return [int(x) - (1 << 64) if int(x) >= (1 << 63) else int(x) for x in back]
 
 
 class TorchComm:

@@ -1099,14 +1099,16 @@ def default_device():
     """Device of this process: torch's current device once torch.distributed is initialised (the launcher set it
     per rank), else LOCAL_RANK of the launcher's environment, else 0 -- so that the mirror classes and simulators
     of every rank compute on that rank's GPU instead of all piling onto GPU 0."""
-    try:
-        import torch
-        import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and torch.cuda.is_available():
-            return int(torch.cuda.current_device())
-    except ImportError:
-        pass
     import os
+    import sys
+    torch = sys.modules.get("torch")          # only if the process uses torch already: importing it here would cost every
+    if torch is not None:                     # torch-free caller seconds and bind torch's bundled HIP / RCCL libraries
+        dist = getattr(torch, "distributed", None)
+        try:
+            if dist is not None and dist.is_available() and dist.is_initialized() and torch.cuda.is_available():
+                return int(torch.cuda.current_device())
+        except Exception:
+            pass
     for key in ("LOCAL_RANK", "OMPI_COMM_WORLD_LOCAL_RANK", "SLURM_LOCALID"):
         if key in os.environ:
             try:

@@ -495,6 +495,12 @@ class BatchedSimulationRunner(SimulationRunner):
                 # one round: every batch still owed (a single one when a stopping rule needs global numbers)
                 owed = self.rep_max - total["n_realizations"]
                 n_batches = 1 if custom_stop else -(-owed // (self.batch_size * world))
+                if world > 1 and self._results_filename is not None:
+                    # a multi-rank run can only write a resume point after a reduction (the totals are global then), so with
+                    # a results file a round ends after about partial_save_every_reps realizations instead of running every
+                    # owed batch: a crash loses one round, not the variation.  Decided from the realization count alone --
+                    # every rank takes the same decision (a wall-clock rule would not).
+                    n_batches = min(n_batches, max(1, -(-self.partial_save_every_reps // (self.batch_size * world))))
                 local = self._zero_like(None)
                 for _ in range(n_batches):
                     want = min(self.batch_size * world, owed)

@@ -31,9 +31,22 @@ def test_native_rccl_communicator_single_rank(engine):
         assert engine.comm_info() == (0, 1)
         c = dict(n_realizations=7, n_skipped=1, sym_errors=123, sym_errors_sq=4567, bit_errors=89, bit_errors_sq=1011,
                  n_symbols=4096, n_bits=24576)
+        # with a communicator -- even of one rank -- mcle_counters_allreduce runs k_counters_pack, the grouped in-place
+        # SUM / MAX ncclAllReduce pair and k_counters_unpack (the early return for world == 1 left all of that
+        # unexecuted on a one-GPU box); several blocks at once, values near 2^64 to catch a mis-typed reduction
         assert comm.allreduce_counters(c) == c
+        rs = np.random.RandomState(4)
+        n = 37
+        host = rs.randint(0, 2 ** 63, size=(n, 8), dtype=np.uint64) * np.uint64(2) + np.uint64(1)
+        cnt = engine.zeros(n, np.dtype((np.void, 64)))
+        cnt.set(np.ascontiguousarray(host).view(np.dtype((np.void, 64))).reshape(n))
+        engine.counters_allreduce(cnt, n)
+        back = np.frombuffer(cnt.get().tobytes(), dtype=np.uint64).reshape(n, 8)
+        assert np.array_equal(back, host)
         assert comm.allreduce_floats([1.5, -2.25]) == [1.5, -2.25]
-        assert comm.broadcast_ints([3, 1 << 40]) == [3, 1 << 40]
+        # integers travel through the uint64 counter reduction: exact beyond 2^53, negatives included
+        big = [3, 1 << 40, (1 << 62) + 12345678901, -7, -(1 << 61) - 1, 0, (1 << 63) - 1, 5, 6, 7, 8, 9, 10]
+        assert comm.broadcast_ints(big) == big
         with pytest.raises(Exception):
             engine.comm_init(b"\0" * 128, 0, 1)             # a context holds one communicator
     finally:
@@ -41,6 +54,45 @@ def test_native_rccl_communicator_single_rank(engine):
     assert engine.comm_info() == (0, 1)
     # (every id drawn starts an RCCL bootstrap listener that lives until all ranks have joined: ids are only drawn
     # to be used -- NativeComm above consumed the one it drew)
+
+
+def _native_worker(rank, world, port, out_path):
+    """One rank of a NativeComm world on ITS OWN GPU: libmcle's RCCL communicator end to end."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    sys.path.insert(0, REPO)
+    from pyphysim_amd.engine import Engine
+    from pyphysim_amd.distributed import NativeComm
+    eng = Engine(rank, "f32")
+    comm = NativeComm(eng, rank=rank, world=world)
+    try:
+        c = dict(n_realizations=10 + rank, n_skipped=rank, sym_errors=100 * (rank + 1), sym_errors_sq=(1 << 60) + rank,
+                 bit_errors=7, bit_errors_sq=9, n_symbols=4096 if rank == 0 else 0, n_bits=24576 if rank == 0 else 0)
+        red = comm.allreduce_counters(c)
+        ints = comm.broadcast_ints([(1 << 62) + 5, -3, 17] if rank == 0 else [0, 0, 0])
+        fl = comm.allreduce_floats([1.0 + rank, 0.5])
+        with open("%s.%d" % (out_path, rank), "w") as fh:
+            json.dump({"red": red, "ints": ints, "fl": fl}, fh)
+    finally:
+        comm.close()
+        eng.close()
+
+
+@pytest.mark.timeout(600)
+def test_native_rccl_communicator_two_ranks_on_two_gpus(tmp_path):
+    """mcle_comm_init / mcle_counters_allreduce / mcle_allreduce_f64 with world = 2, one process per
+    GPU (skipped on a one-GPU box: RCCL refuses two ranks on one device)."""
+    from pyphysim_amd import _lib
+    if _lib.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "native2")
+    mp.spawn(_native_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = [json.load(open("%s.%d" % (out, r))) for r in range(2)]
+    assert got[0] == got[1]
+    assert got[0]["red"] == dict(n_realizations=21, n_skipped=1, sym_errors=300, sym_errors_sq=(1 << 61) + 1, bit_errors=14,
+                                 bit_errors_sq=18, n_symbols=4096, n_bits=24576)
+    assert got[0]["ints"] == [(1 << 62) + 5, -3, 17] and got[0]["fl"] == [3.0, 1.0]
 
 
 def _worker(rank, world, port, out_path, which):
