@@ -310,7 +310,10 @@ def chain_mimo_scheme(rng, scheme='blast', mod='qam', M=16, nt=2, nr=2, NSymbs=2
     else:
         est = omimo.gmd_decode(Y, H, 0.0)
     dec = omodem.demodulate(table, est)
-    return _counts(dict(table=table, H=H, idx=idx, noise=noise, est=est, noise_var=noise_var), idx, dec, M)
+    out = dict(table=table, H=H, idx=idx, noise=noise, est=est, noise_var=noise_var)
+    if scheme in ('svd', 'gmd'):      # the basis-dependent pair (mimo.py:846-890, 965-1011), as minted into the fixture
+        out['W'], out['G_H'] = omimo.scheme_filters(scheme, H)
+    return _counts(out, idx, dec, M)
 
 
 def apply_pathloss(big_H, K, pathloss):

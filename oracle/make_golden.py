@@ -767,8 +767,14 @@ def ref_chain_mimo_scheme(seed, scheme, mod, M, nt, nr, NSymbs, snr_db):
     Y = np.dot(H, X) + noise * np.sqrt(noise_var)
     est = obj.decode(Y)
     dec = m.demodulate(est)
-    return dict(table=m.symbols, H=H, idx=idx, noise=noise, est=est, decisions=dec, noise_var=noise_var,
-                **ref_counts(idx, dec, M))
+    out = dict(table=m.symbols, H=H, idx=idx, noise=noise, est=est, decisions=dec, noise_var=noise_var,
+               **ref_counts(idx, dec, M))
+    if scheme in ("svd", "gmd"):
+        # the reference's OWN precoder / receive filter (mimo.py:846-890, 965-1011): they carry the phase LAPACK gave every
+        # singular vector, which the decisions depend on -- the GPU tests inject this basis and demand the exact decisions
+        out["W"] = cls._calc_precoder(H)
+        out["G_H"] = cls._calc_receive_filter(H, None)
+    return out
 
 
 def ref_chain_mimo_ofdm_tdl(seed, mod, M, nt, nr, fft_size, cp_size, num_used, n_ofdm_sym, snr_db, Fd, Ts, L,

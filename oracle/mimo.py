@@ -137,6 +137,18 @@ def gmd(U, S, V_H):
     return Q, R, P
 
 
+def scheme_filters(scheme, H):
+    """(precoder W, receive filter G_H) of SVDMimo / GMDMimo for channel H with NumPy's (LAPACK's) singular vectors:
+    mimo.py:846-890 (W = V / sqrt(Nt), G_H = diag(1/S) U^H sqrt(Nt)) and :965-1011 (W = P / sqrt(Nt), Blast's zero-forcing
+    filter of Q R)."""
+    nt = H.shape[1]
+    U, S, V_H = np.linalg.svd(H)
+    if scheme == 'svd':
+        return V_H.conj().T / math.sqrt(nt), np.diag(1.0 / S) @ U.conj().T * math.sqrt(nt)
+    Q, R, P = gmd(U, S, V_H)
+    return P / math.sqrt(nt), blast_receive_filter(Q @ R, 0.0)
+
+
 def gmd_encode(x, H):
     nt = H.shape[1]
     _, _, P = gmd(*np.linalg.svd(H))

@@ -192,7 +192,19 @@ class SVDMimo(Blast):
     channels up to 4x4 (Jacobi SVD in f64 on the GPU).  W and G are a consistent singular-vector
     pair; LAPACK's particular phase choice is not reproduced (G H W = I either way)."""
 
+    _injected = None
+
+    def set_filters(self, W, G_H):
+        """Injected basis: use this precoder / receive filter pair instead of the device decomposition's.  An SVD fixes
+        every singular-vector pair only up to a common phase, and the decisions depend on it (the filtered noise is rotated
+        by it); with the reference's own pair (LAPACK's phases) encode / decode reproduce the reference's estimates and
+        decisions exactly (tests/test_gpu_pipelines.py::test_svd_gmd_with_the_references_basis).  None restores the
+        device decomposition."""
+        self._injected = None if W is None else (np.asarray(W, dtype=complex), np.asarray(G_H, dtype=complex))
+
     def _filters(self):
+        if self._injected is not None:
+            return self._injected[0], self._injected[1], None
         W, G, S = self.engine.svd_filters(self._channel[np.newaxis], dtype=self.dtype)
         return W[0], G[0], S[0]
 
@@ -217,7 +229,12 @@ class GMDMimo(Blast):
     """reference mimo.py:952-1067: geometric mean decomposition precoder (util.misc.gmd) and Blast's
     ZF / MMSE filter on the equivalent channel Q R; square channels up to 4x4."""
 
+    _injected = None
+    set_filters = SVDMimo.set_filters
+
     def _filters(self):
+        if self._injected is not None:
+            return self._injected[0], self._injected[1], None
         W, G, R = self.engine.gmd_filters(self._channel[np.newaxis], self._noise_var, dtype=self.dtype)
         return W[0], G[0], R[0]
 
