@@ -90,7 +90,9 @@ enum {
     MCLE_OPT_JAKES_DIRECT = 6,     /* 1: jakes_generate evaluates one sincos per ray and sample (k_jakes) */
     MCLE_OPT_F64_GENERIC = 7,      /* 1: complex128 config 4 on the generic radix-4 kernel instead of k_run_mimo_ofdm_f64 */
     MCLE_OPT_F64_THREADS = 8,      /* complex128 config-4 kernel: 0 / 512 = 512-thread workgroups, 256 = 256-thread workgroups */
-    MCLE_OPT_COUNT = 9
+    MCLE_OPT_BD_RUNTIME_SOLVE = 9, /* 1: the block-diagonalisation pipeline solves with the run-time-sized routine (private
+                                      arrays in scratch) also where the compile-time-sized one (K nr <= 6) applies */
+    MCLE_OPT_COUNT = 10
 };
 int mcle_ctx_set_option(mcle_ctx* ctx, int option, long long value);
 int mcle_ctx_get_option(mcle_ctx* ctx, int option, long long* value);

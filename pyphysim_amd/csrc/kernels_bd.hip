@@ -24,6 +24,7 @@
 #include "pipe_common.hpp"
 #include "totals.hpp"
 #include "wave_draws.hpp"
+#include "bd_static.hpp"
 
 namespace mcle {
 
@@ -624,6 +625,38 @@ __global__ __launch_bounds__(64) void k_bd_solve_links(BdParams pp, uint64_t see
     rec[n * (R + 1)] = mk<T>(ok ? (T)1 : (T)0, (T)0);
 }
 
+// The same record from the compile-time-sized solve of bd_static.hpp (K R <= 6): every matrix in registers, no scratch.
+template <typename T, int K, int R>
+__global__ __launch_bounds__(64) void k_bd_solve_links_static(BdParams pp, uint64_t seed, uint64_t first, uint64_t count,
+                                                              cx<T>* __restrict__ recs) {
+    constexpr int n = K * R, stride = n * (R + 1) + 1;
+    const uint64_t rl = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+    if (rl >= count) return;
+    const Rng rng(seed, first + rl);
+    cd Q[n][n];
+#pragma unroll
+    for (int i = 0; i < n; ++i)
+#pragma unroll
+        for (int c = 0; c < n; ++c) {
+            cd h = cn_sample<double>(rng, STREAM_CHAN, (uint64_t)(i * n + c), 1.0);
+            if (pp.has_pathloss) h = cscale(h, pp.root_pl[(i / R) * K + c / R]);
+            Q[i][c] = h;
+        }
+    cd d[n], Wb[n][R];
+    const bool ok = bd_solve_link_static<K, R>(Q, pp.iPu, pp.bd_noise_var, pp.waterfill, d, Wb);
+    cx<T>* rec = recs + rl * stride;
+#pragma unroll
+    for (int s = 0; s < n; ++s) {
+        rec[s] = mk<T>((T)d[s].x, (T)d[s].y);
+#pragma unroll
+        for (int a = 0; a < R; ++a) rec[n + s * R + a] = mk<T>((T)Wb[s][a].x, (T)Wb[s][a].y);
+    }
+    rec[n * (R + 1)] = mk<T>(ok ? (T)1 : (T)0, (T)0);
+}
+
+// Register budget of the walk: four waves per SIMD (128 VGPRs, 45 of them spilled by the lockstep search) measured against
+// three (168 VGPRs, nothing spilled) on the round-3 box: 1.266 vs 1.355-1.365 ms per 131 072 realizations -- the fourth
+// wave hides more latency than the spills cost; kept at four.
 template <typename T, int R>
 __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void k_bd_link(ModemParams<T> mp, BdParams pp, uint64_t seed,
                                                                         uint64_t first, uint64_t count, int per_wave,
@@ -752,8 +785,21 @@ static int launch_run_bd(mcle_ctx* ctx, const mcle_bd_cfg* cfg, const BdParams& 
     const int per_wave = 8;
     for (uint64_t off = 0; off < count; off += slice) {
         const uint64_t m = count - off < slice ? count - off : slice;
-        hipLaunchKernelGGL((k_bd_solve_links<T, R>), dim3((unsigned)((m + 63) / 64)), dim3(64), 0, ctx->stream, pp, seed,
-                           first + off, m, (cx<T>*)recs);
+        const dim3 sgrid((unsigned)((m + 63) / 64));
+        bool launched = false;
+#define MCLE_BD_STATIC(K_)                                                                                                \
+    if (!launched && cfg->K == K_ && K_ * R <= 6) {                                                                       \
+        hipLaunchKernelGGL((k_bd_solve_links_static<T, K_, (K_ * R <= 6 ? R : 1)>), sgrid, dim3(64), 0, ctx->stream, pp, seed,  \
+                           first + off, m, (cx<T>*)recs);                                                                \
+        launched = true;                                                                                                  \
+    }
+        if (!ctx->opt[MCLE_OPT_BD_RUNTIME_SOLVE]) {       // compile-time-sized solve (registers) where n = K R <= 6
+            MCLE_BD_STATIC(2) MCLE_BD_STATIC(3) MCLE_BD_STATIC(4) MCLE_BD_STATIC(5) MCLE_BD_STATIC(6)
+        }
+#undef MCLE_BD_STATIC
+        if (!launched)
+            hipLaunchKernelGGL((k_bd_solve_links<T, R>), sgrid, dim3(64), 0, ctx->stream, pp, seed, first + off, m,
+                               (cx<T>*)recs);
         MCLE_LAUNCH_CHECK();
         const uint64_t cap = (uint64_t)ctx->n_cu * 4 * (sizeof(T) == 4 ? 4 : 2);
         const uint64_t chunks = (m + per_wave - 1) / per_wave;

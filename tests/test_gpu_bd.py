@@ -248,3 +248,24 @@ def test_bd_simulator_runs_the_comp_application(engine):
             ["symbol_errors"] for r in range(300)]
     ser_ref = np.sum(want) / (300.0 * 600)
     assert abs(ser[1] - ser_ref) <= 0.3 * ser_ref + 2e-3
+
+
+@pytest.mark.parametrize("K,nr", [(3, 2), (2, 2), (2, 3), (4, 1), (6, 1)])
+def test_static_solve_equals_the_runtime_sized_solve(engine, K, nr):
+    """csrc/bd_static.hpp (compile-time sizes, every matrix in registers; K nr <= 6) against the run-time-sized bd_solve it
+    stands in for inside the fused pipeline (engine option bd_runtime_solve): per-realization counts equal in complex128 and
+    complex64, water-filling on and off, with path loss."""
+    from oracle import chains
+    engine.set_constellation(chains.constellation("psk", 4), _lib.CONST_GENERIC)
+    rs = np.random.RandomState(K * 10 + nr)
+    pl = rs.uniform(0.2, 1.0, (K, K))
+    for wf in (True, False):
+        for pathloss in ((None, pl) if K <= 4 else (None,)):
+            for dt in ("f64", "f32"):
+                kw = dict(bd_noise_var=1e-3 if wf else 1e-50, pathloss=pathloss, waterfilling=wf, dtype=dt, per_realization=True)
+                new = engine.run_bd(K, nr, 64, 1.0, 0.05, 555, 7, 700, **kw)
+                with engine.options(bd_runtime_solve=1):
+                    old = engine.run_bd(K, nr, 64, 1.0, 0.05, 555, 7, 700, **kw)
+                assert new[0]["n_realizations"] == old[0]["n_realizations"] and new[0]["n_skipped"] == old[0]["n_skipped"]
+                d = np.abs(new[1].astype(np.int64) - old[1].astype(np.int64))
+                assert np.count_nonzero(d) <= 2 and d.max() <= 1, (K, nr, wf, dt, int(d.sum()))
