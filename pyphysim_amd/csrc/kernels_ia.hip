@@ -499,7 +499,10 @@ __global__ __launch_bounds__(64) void k_ia_iterative(const cd* __restrict__ bigH
 // 16 complex numbers per realization (G, U, flag).
 constexpr int kIaRec = 16;      // G[9], U[6], {ok, 0}
 
-template <typename T>
+// ITER = false: the closed-form solver only (config 5).  One kernel for both used to carry the iterative solvers' call frames
+// (ia_iterative is __noinline__) into the closed-form launches too: 322 VGPRs + 66 AGPRs and 1 792 B of scratch per lane for a
+// solve that needs neither.
+template <typename T, bool ITER>
 __global__ __launch_bounds__(64) void k_ia_solve_links(double noise_var, int solver, int init, int max_iter, double rel,
                                                        uint64_t seed, uint64_t first, uint64_t count,
                                                        cx<T>* __restrict__ recs, double* __restrict__ cap_out,
@@ -515,9 +518,9 @@ __global__ __launch_bounds__(64) void k_ia_solve_links(double noise_var, int sol
     load_blocks(bigH, H);
     IaSolution s;
     int runned = 0;
-    if (solver == IA_CLOSED_FORM) {
+    if (!ITER || solver == IA_CLOSED_FORM) {
         s = ia_closed_form_inl(H, noise_var);
-    } else {
+    } else if constexpr (ITER) {
         // randomizeF (iabase.py:538-540): F_k = normalized(randn_c(Nt, Ns)) from the solver's own stream
         V2 F0[3];
 #pragma unroll
@@ -680,7 +683,8 @@ int run_ia_impl(mcle_ctx* ctx, const mcle_ia_cfg* cfg, uint64_t seed, uint64_t f
     const int per_wave = 16;      // 4 ... 64 realizations per wavefront measured: 1.98-2.05e8 realizations/s, no trend
     for (uint64_t off = 0; off < count; off += slice) {
         const uint64_t n = count - off < slice ? count - off : slice;
-        hipLaunchKernelGGL(k_ia_solve_links<T>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, cfg->noise_var,
+        auto solve = cfg->solver == IA_CLOSED_FORM ? k_ia_solve_links<T, false> : k_ia_solve_links<T, true>;
+        hipLaunchKernelGGL(solve, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, cfg->noise_var,
                            cfg->solver, cfg->initialize_with, cfg->max_iterations, cfg->relative_factor, seed, first + off, n,
                            (cx<T>*)recs, d_cap ? d_cap + off : nullptr, d_iter ? d_iter + off : nullptr);
         MCLE_LAUNCH_CHECK();
