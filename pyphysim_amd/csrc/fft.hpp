@@ -85,16 +85,19 @@ __host__ __forceinline__ void dft_any_split(int n, int* n1, int* n2) {
     *n2 = n / best;
 }
 
-// LDS bank swizzle for the in-place radix-4 stages.  A wave64 ds_read/write_b64 is serviced per
-// half-wave of 32 lanes over 32 eight-byte slots; stages with span s < 64 touch s-element runs that
-// are 4s apart, which piles 2 (s = 16) or 4 (s = 4, 1) lanes on a slot.  XOR-ing index bits 5..6
-// into bits 0..3 and bit 6 into bit 4 makes every stage's four accesses -- and every contiguous
-// aligned run -- hit 32 distinct slots (checked exhaustively in tests/test_fft_layout.py).
+// LDS bank swizzle for the in-place radix-4 stages (8-byte elements: float2, or one plane of doubles).  8-byte accesses
+// obey two bank rules on gfx950: a ds_read_b64 is served per half-wave of 32 lanes over 32 eight-byte slots, a ds_write_b64
+// per 16 consecutive lanes over 16 slots.  Stages with span s < 64 touch s-element runs that are 4s apart, which piles 2
+// (s = 16) or 4 (s = 4, 1) lanes on a slot.  Folding index bits 4..5 into bits 0..3 (twice) and bit 6 into bit 4 makes every
+// stage's four accesses -- loads AND stores -- and every contiguous aligned run conflict free (checked exhaustively in
+// tests/test_fft_layout.py and tests/test_f64_layout.py).  Until round 3 the swizzle was built for the read rule only
+// (bits 5..6 into 0..3, bit 6 into 4): the stores of the spans 16, 4 and 1 were 2- to 4-way conflicted -- 12.8 extra LDS
+// cycles per store instruction averaged over the five stages in the bank model, 0.29 of the LDS cycles of the
+// frequency-selective MIMO kernel in the counters.
 // SWZ = false keeps the linear layout (operator kernels with global-memory twiddles).
 template <bool SWZ> __host__ __device__ __forceinline__ int lds_swz(int e) {
     if (!SWZ) return e;
-    const int r = (e >> 5) & 3;
-    return e ^ (r * 5) ^ ((e >> 2) & 16);
+    return e ^ (((e >> 4) & 3) * 5) ^ (((e >> 6) & 1) << 4);
 }
 
 template <typename T, bool INV> __device__ __forceinline__ cx<T> tw_get(const cx<T>* tw, int i) {

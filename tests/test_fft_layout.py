@@ -20,8 +20,7 @@ def pos_of_index(N, f):
 
 
 def swz(e):
-    r = (e >> 5) & 3
-    return e ^ (r * 5) ^ ((e >> 2) & 16)
+    return e ^ (((e >> 4) & 3) * 5) ^ (((e >> 6) & 1) << 4)
 
 
 def rot(a, inv):
@@ -82,6 +81,8 @@ def test_swizzle_is_a_bijection_and_conflict_free():
             k, g = lanes & (s - 1), lanes // s
             for j in range(4):
                 slots = swz(g * 4 * s + k + j * s) % 32
-                assert len(set(slots.tolist())) == 32, (s, half, j)
+                assert len(set(slots.tolist())) == 32, (s, half, j)                  # ds_read_b64: 32 lanes over 32 slots
+                for q in (0, 16):                                                     # ds_write_b64: 16 lanes over 16 slots
+                    assert len(set((slots[q:q + 16] % 16).tolist())) == 16, (s, half, j, q)
     for base in range(0, N, 32):                          # contiguous aligned runs stay conflict free
         assert len(set((swz(base + np.arange(32)) % 32).tolist())) == 32
