@@ -374,14 +374,74 @@ __device__ __forceinline__ f2 ld2(const float2* p) {
     return f2{v.x, v.y};
 }
 
+// The fading of a symbol, one thread per (realization, OFDM symbol, tap), in a launch of its own (round 3): the L rays of the
+// tap (f64 phase at the symbol centre, PHASE stream), their fold into the tap polynomial c_m = amp sum_l e_l (j theta_l)^m / m!
+// and the per-symbol tap mean sum_m c_m mom_m.  Inside the main kernel this work ran on 160 + 60 + 20 of the 256 threads, in
+// f64, between workgroup barriers the other wavefronts waited at, and its registers were allocated for the whole kernel.
+// Record of (realization, symbol): coef [S][K + 1], mean [S] -- S (K + 2) complex64 (160 B for config 3).
+constexpr int kTdlMaxK = 12;
+__global__ __launch_bounds__(256) void k_tdl_symbol_polys(SisoTdlParams pp, uint64_t seed, uint64_t first, uint64_t count,
+                                                          float2* __restrict__ recs) {
+    const int S = pp.n_taps, L = pp.L, K = pp.K, W = kF16N + pp.cp;
+    const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t per_real = (uint64_t)pp.n_ofdm_sym * S;
+    if (q >= count * per_real) return;
+    const uint64_t rl = q / per_real;
+    const int rem = (int)(q - rl * per_real), os = rem / S, s = rem - os * S;
+    const double xc = 0.5 * (double)(W - 1);
+    const double two_pi = 6.283185307179586476925286766559;
+    const double tc = pp.Ts + pp.dt * ((double)((uint64_t)os * W) + xc);
+    const Rng rng(seed, first + rl);
+    float ar[kTdlMaxK + 1], ai[kTdlMaxK + 1];
+#pragma unroll
+    for (int m = 0; m <= kTdlMaxK; ++m) ar[m] = ai[m] = 0.f;
+    for (int l = 0; l < L; ++l) {
+        const int rq = l * S + s;                                         // PHASE-stream index of phi
+        const double psi_t = uniform_at(rng, STREAM_PHASE, (uint64_t)L * S + rq);
+        const double wd = pp.Fd * cospi(2.0 * uniform_at(rng, STREAM_PHASE, (uint64_t)rq));   // Hz
+        const double ph = fma(wd, tc, psi_t);                             // turns
+        const double fr = __builtin_amdgcn_fract(ph);
+        const float er = __builtin_amdgcn_cosf((float)fr), ei = __builtin_amdgcn_sinf((float)fr);
+        const float th = (float)(two_pi * wd * pp.dt);                    // rad per sample
+#pragma unroll
+        for (int m = 0; m <= kTdlMaxK; ++m)
+            if (m <= K) {
+                float pw = 1.f;                                           // 1 / m! ...
+                for (int i = 2; i <= m; ++i) pw /= (float)i;
+                for (int i = 0; i < m; ++i) pw *= th;                     // ... x theta^m, in the order of the fused kernel
+                ar[m] += er * pw;
+                ai[m] += ei * pw;
+            }
+    }
+    const float amp = (float)pp.tap_amp[s];
+    float2* rec = recs + (rl * pp.n_ofdm_sym + os) * (uint64_t)(S * (K + 2));
+    float mr = 0.f, mi = 0.f;
+#pragma unroll
+    for (int m = 0; m <= kTdlMaxK; ++m)
+        if (m <= K) {
+            float cr, ci;                                                 // times j^m
+            switch (m & 3) {
+                case 0: cr = ar[m]; ci = ai[m]; break;
+                case 1: cr = -ai[m]; ci = ar[m]; break;
+                case 2: cr = -ar[m]; ci = -ai[m]; break;
+                default: cr = ai[m]; ci = -ar[m]; break;
+            }
+            const float2 c = make_float2(amp * cr, amp * ci);
+            rec[s * (K + 1) + m] = c;
+            mr += c.x * (float)pp.mom[m];
+            mi += c.y * (float)pp.mom[m];
+        }
+    rec[S * (K + 1) + s] = make_float2(mr, mi);
+}
+
 template <int WAVES>
 __global__ __launch_bounds__(kPipeBlock, WAVES) void k_run_ofdm_tdl_mfma(
     SisoTdlParams pp, ModemParams<float> mp, uint64_t seed, uint64_t first, uint64_t count,
-    const float2* __restrict__ g_tw, mcle_counters* counters, uint32_t* __restrict__ sym_out,
-    uint32_t* __restrict__ bit_out) {
+    const float2* __restrict__ g_tw, const float2* __restrict__ g_polys, mcle_counters* counters,
+    uint32_t* __restrict__ sym_out, uint32_t* __restrict__ bit_out) {
     constexpr int N = kF16N, NB = 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int S = pp.n_taps, L = pp.L, K = pp.K;
+    const int S = pp.n_taps, K = pp.K;
     const int PS = S * NB;                                             // fading processes of a pass: slot a, tap s -> a*S + s
     const int U = pp.num_used, cp = pp.cp, W = N + cp;
     const int tab_len = (mp.M + 15) & ~15;
@@ -392,8 +452,7 @@ __global__ __launch_bounds__(kPipeBlock, WAVES) void k_run_ofdm_tdl_mfma(
     unsigned long long* s_grid = reinterpret_cast<unsigned long long*>(s_idx + ((NB * U + 15) & ~15));
     float2* s_coef = reinterpret_cast<float2*>(s_grid + mp.grid.G * mp.grid.G);     // [PS][K+1]
     float2* s_mean = s_coef + PS * (K + 1);                            // [PS]
-    float* s_ray = reinterpret_cast<float*>(s_mean + PS);              // [PS*L][3] = {re, im, theta}
-    unsigned* s_part = reinterpret_cast<unsigned*>(s_ray + ((3 * PS * L + 1) & ~1));   // [2][4 waves][NB][2]
+    unsigned* s_part = reinterpret_cast<unsigned*>(s_mean + PS);       // [2][4 waves][NB][2]
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int j = lane & 15, g = lane >> 4, gb = g >> 1;
@@ -469,23 +528,13 @@ __global__ __launch_bounds__(kPipeBlock, WAVES) void k_run_ofdm_tdl_mfma(
         for (int a = 0; a < NB; ++a) se[a] = be[a] = 0;
         for (int os = 0; os < pp.n_ofdm_sym; ++os) {
             const uint64_t sym0 = (uint64_t)os * W;
-            // ---- rays of this symbol: phasor at the symbol centre and phase advance per sample, one per thread ----
-            {
-                const double two_pi = 6.283185307179586476925286766559;
-                const double tc = pp.Ts + pp.dt * ((double)sym0 + xc);
-                for (int q = tid; q < PS * L; q += kPipeBlock) {
-                    const int a = q / (S * L), rq = q - a * (S * L);      // rq = l*S + s: PHASE-stream index of phi
-                    const int l = rq / S, s = rq - l * S;
-                    const Rng rng(seed, first + base + a);
-                    const double psi_t = uniform_at(rng, STREAM_PHASE, (uint64_t)L * S + rq);
-                    const double wd = pp.Fd * cospi(2.0 * uniform_at(rng, STREAM_PHASE, (uint64_t)rq));   // Hz
-                    const double ph = fma(wd, tc, psi_t);                 // turns
-                    const double fr = __builtin_amdgcn_fract(ph);
-                    float* o = s_ray + 3 * ((a * S + s) * L + l);
-                    o[0] = __builtin_amdgcn_cosf((float)fr);
-                    o[1] = __builtin_amdgcn_sinf((float)fr);
-                    o[2] = (float)(two_pi * wd * pp.dt);                  // rad per sample
-                }
+            // ---- this symbol's tap polynomials and tap means (k_tdl_symbol_polys): one value per thread into a register now,
+            //      parked in LDS after the first barrier (the previous symbol's equaliser may still be reading s_mean) ----
+            float2 poly = make_float2(0.f, 0.f);
+            const int rec_len = S * (K + 2);
+            if (tid < NB * rec_len) {
+                const int a = tid / rec_len, e = tid - a * rec_len;
+                if (base + a < count) poly = g_polys[((base + a) * pp.n_ofdm_sym + os) * (uint64_t)rec_len + e];
             }
             // ---- symbols -> bins, stored re<->im swapped (inverse transform by the swap identity) ----
             const uint64_t n_first = (uint64_t)os * U;
@@ -552,29 +601,10 @@ __global__ __launch_bounds__(kPipeBlock, WAVES) void k_run_ofdm_tdl_mfma(
                     wg_account(totals, st, bt, false, base_prev + a, sym_out, bit_out);
                 }
             }
-            // ---- tap polynomials around the middle of this symbol: one (process, order) per thread ----
-            for (int q = tid; q < PS * (K + 1); q += kPipeBlock) {
-                const int p = q / (K + 1), m = q - p * (K + 1);
-                float inv_fact = 1.f;
-                for (int i = 2; i <= m; ++i) inv_fact /= (float)i;
-                float ar = 0.f, ai = 0.f;
-#pragma unroll 4
-                for (int l = 0; l < L; ++l) {
-                    const float* o = s_ray + 3 * (p * L + l);
-                    float pw = inv_fact;
-                    for (int i = 0; i < m; ++i) pw *= o[2];
-                    ar += o[0] * pw;
-                    ai += o[1] * pw;
-                }
-                float cr, ci;                                             // times j^m
-                switch (m & 3) {
-                    case 0: cr = ar; ci = ai; break;
-                    case 1: cr = -ai; ci = ar; break;
-                    case 2: cr = -ar; ci = -ai; break;
-                    default: cr = ai; ci = -ar; break;
-                }
-                const float amp = (float)pp.tap_amp[p % S];
-                s_coef[q] = make_float2(amp * cr, amp * ci);
+            if (tid < NB * rec_len) {             // record -> s_coef [a*S + s][K + 1], s_mean [a*S + s]
+                const int a = tid / rec_len, e = tid - a * rec_len;
+                if (e < S * (K + 1)) s_coef[a * S * (K + 1) + e] = poly;
+                else s_mean[a * S + (e - S * (K + 1))] = poly;
             }
             // ---- P2: DFT-16 over m1, x W64^{j1 m2} ----
             load_tw2a(tw2a, opaque(m2p));
@@ -602,15 +632,6 @@ __global__ __launch_bounds__(kPipeBlock, WAVES) void k_run_ofdm_tdl_mfma(
                 }
             }
             __syncthreads();
-            if (tid < PS) {     // per-symbol tap means (the equaliser's channel estimate), read after two more barriers
-                float mr = 0.f, mi = 0.f;
-                for (int m = 0; m <= K; ++m) {
-                    const float2 c = s_coef[tid * (K + 1) + m];
-                    mr += c.x * (float)pp.mom[m];
-                    mi += c.y * (float)pp.mom[m];
-                }
-                s_mean[tid] = make_float2(mr, mi);
-            }
             // ---- channel: y[a][m] = sum_s g[a][s](j) T[a][j], j = cp + m - d_s, + noise ----
             float yr[4][NB], yi[4][NB];            // [slot][realization slot]
 #pragma unroll
@@ -739,17 +760,26 @@ __global__ __launch_bounds__(kPipeBlock, WAVES) void k_run_ofdm_tdl_mfma(
                 for (int x = 0; x < 4; ++x)
 #pragma unroll
                     for (int a = 0; a < NB; ++a) hq[x][a] = make_float2(0.f, 0.f);
+                // W^{f d_s} of tap s + 1 is fetched (L1-resident table) while tap s is accumulated: one table latency in all
+                // instead of one per tap (the loop over a run-time tap count is not unrolled)
+                float2 wn[4];
+#pragma unroll
+                for (int x = 0; x < 4; ++x) wn[x] = g_tw[((64 * (4 * g + x) + n2) * pp.tap_delay[0]) & (N - 1)];
                 for (int s = 0; s < S; ++s) {
-                    const int d = pp.tap_delay[s];
-                    float2 mean[NB];
+                    float2 wq[4], mean[NB];
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) wq[x] = wn[x];
+                    if (s + 1 < S) {
+                        const int dn = pp.tap_delay[s + 1];
+#pragma unroll
+                        for (int x = 0; x < 4; ++x) wn[x] = g_tw[((64 * (4 * g + x) + n2) * dn) & (N - 1)];
+                    }
 #pragma unroll
                     for (int a = 0; a < NB; ++a) mean[a] = s_mean[a * S + s];
 #pragma unroll
-                    for (int x = 0; x < 4; ++x) {
-                        const float2 wq = g_tw[((64 * (4 * g + x) + n2) * d) & (N - 1)];
+                    for (int x = 0; x < 4; ++x)
 #pragma unroll
-                        for (int a = 0; a < NB; ++a) hq[x][a] = cfma(mean[a], wq, hq[x][a]);
-                    }
+                        for (int a = 0; a < NB; ++a) hq[x][a] = cfma(mean[a], wq[x], hq[x][a]);
                 }
 #pragma unroll
                 for (int x = 0; x < 4; ++x) {
@@ -818,7 +848,8 @@ int run_siso_tdl_mfma(mcle_ctx* ctx, const SisoTdlParams& pp, int method, uint64
     if (pp.cp < pp.dmax || (pp.num_used & 15) != 0) return MCLE_E_UNSUPPORTED;
     if (ctx->opt[MCLE_OPT_NO_MFMA]) return MCLE_E_UNSUPPORTED;
     const size_t PS = (size_t)pp.n_taps * NB;
-    if (PS > kPipeBlock || 3 * PS * pp.L * sizeof(float) > 8192) return MCLE_E_UNSUPPORTED;
+    const size_t rec_len = (size_t)pp.n_taps * (pp.K + 2);
+    if (NB * rec_len > kPipeBlock || pp.K > kTdlMaxK) return MCLE_E_UNSUPPORTED;
     int rc;
     void* tw = nullptr;
     if ((rc = ctx->get_twiddles(kF16N, MCLE_F32, &tw))) return rc;
@@ -827,22 +858,34 @@ int run_siso_tdl_mfma(mcle_ctx* ctx, const SisoTdlParams& pp, int method, uint64
     const size_t lds = (size_t)NB * kF16Ant * sizeof(float) + tab_len * (sizeof(float4) + sizeof(float2)) +
                        (((size_t)NB * pp.num_used + 15) & ~(size_t)15) +
                        (size_t)mp.grid.G * mp.grid.G * sizeof(unsigned long long) +
-                       (PS * (pp.K + 1) + PS) * sizeof(float2) + ((3 * PS * pp.L + 1) & ~(size_t)1) * sizeof(float) +
-                       64 * sizeof(unsigned);
+                       (PS * (pp.K + 1) + PS) * sizeof(float2) + 64 * sizeof(unsigned);
     if (lds + 512 > (size_t)160 * 1024 / 2) return MCLE_E_UNSUPPORTED;
-    // two workgroups per CU with 256 VGPRs (13 spilled registers) beat three with 168 (130 spilled): 1.63 vs 2.04 ms per
-    // 131072 realizations (A/B: MCLE_OPT_TDL_MFMA_WAVES = 3).  The equaliser's W^{f d} from an LDS copy instead of the
-    // L1-resident global table: 1.62 vs 1.63 ms, not kept.
+    // Register budget (A/B: MCLE_OPT_TDL_MFMA_WAVES).  Round 2, with the f64 ray block inside the kernel: two workgroups per
+    // CU at 256 VGPRs (13 spilled) beat three at 168 (130 spilled), 1.63 vs 2.04 ms per 131 072 realizations.
     const int waves = ctx->opt[MCLE_OPT_TDL_MFMA_WAVES] == 3 ? 3 : 2;
     auto kern = waves == 2 ? k_run_ofdm_tdl_mfma<2> : k_run_ofdm_tdl_mfma<3>;
     MCLE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int per_cu = (int)((size_t)160 * 1024 / (lds + 512));
     if (per_cu > waves) per_cu = waves;     // __launch_bounds__(256, WAVES)
-    const uint64_t passes = (count + NB - 1) / NB;
-    const unsigned grid = (unsigned)oversubscribed_grid(ctx, (uint64_t)ctx->n_cu * per_cu, passes);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kPipeBlock), lds, ctx->stream, pp, mp, seed, first, count,
-                       (const float2*)tw, d_counters, d_sym, d_bit);
-    MCLE_LAUNCH_CHECK();
+    const uint64_t per_real = (uint64_t)pp.n_ofdm_sym * rec_len;             // complex64 values per realization
+    uint64_t slice = (64ull << 20) / (per_real * sizeof(float2));            // <= 64 MiB of records per fading + link pair
+    slice = slice < NB ? NB : (slice / NB) * NB;
+    if (slice > count) slice = (count + NB - 1) / NB * NB;
+    void* recs = nullptr;
+    if ((rc = ctx->scratch((size_t)slice * per_real * sizeof(float2), &recs))) return rc;
+    for (uint64_t off = 0; off < count; off += slice) {
+        const uint64_t n = count - off < slice ? count - off : slice;
+        const uint64_t threads = n * (uint64_t)pp.n_ofdm_sym * pp.n_taps;
+        hipLaunchKernelGGL(k_tdl_symbol_polys, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream, pp, seed,
+                           first + off, n, (float2*)recs);
+        MCLE_LAUNCH_CHECK();
+        const uint64_t passes = (n + NB - 1) / NB;
+        const unsigned grid = (unsigned)oversubscribed_grid(ctx, (uint64_t)ctx->n_cu * per_cu, passes);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kPipeBlock), lds, ctx->stream, pp, mp, seed, first + off, n,
+                           (const float2*)tw, (const float2*)recs, d_counters, d_sym ? d_sym + off : nullptr,
+                           d_bit ? d_bit + off : nullptr);
+        MCLE_LAUNCH_CHECK();
+    }
     return MCLE_OK;
 }
 
