@@ -8,17 +8,18 @@
 // angle is a 32-bit fraction of a turn -- so both functions reduce to one small table look-up and a short polynomial:
 //
 //   -ln u   u = m 2^e, m in [1, 2) (folded to [0.75, 1.5) so that u -> 1 meets c = 1 with ln c = 0 exactly);
-//           j = the nearest of 129 nodes c_j, r = (m - c_j) / c_j exactly representable difference times a rounded
-//           reciprocal, |r| <= 2^-8;  ln u = e ln 2 + ln c_j + log1p(r), log1p by its degree-7 series (next term 2^-67).
+//           j = the nearest of 65 nodes c_j, r = (m - c_j) / c_j exactly representable difference times a rounded
+//           reciprocal, |r| <= 2^-7;  ln u = e ln 2 + ln c_j + log1p(r), log1p by its degree-7 series (next term 2^-59).
 //           Measured against x87 extended precision over 4e6 words incl. the 1e5 largest: relative error <= 2.3e-16
 //           (NumPy's own log: 1.2e-16), i.e. <= 3e-16 absolute on sqrt(-ln u).
-//   sincos  NumPy evaluates cos / sin of the DOUBLE ang = fl(2 pi_d v); the nodes theta_k = fl(k fl(2 pi / 256)) are
-//           doubles too, so r = ang - theta_k is exact (Sterbenz), |r| <= 0.0123, and the table holds cos / sin of the
+//   sincos  NumPy evaluates cos / sin of the DOUBLE ang = fl(2 pi_d v); the nodes theta_k = fl(k fl(2 pi / 128)) are
+//           doubles too, so r = ang - theta_k is exact (Sterbenz), |r| <= 0.0246, and the table holds cos / sin of the
 //           double theta_k: rotation by the degree-7 / degree-6 polynomials of r.  <= 1.2e-16 absolute against the
 //           extended-precision value of cos(ang), sin(ang).
 //   sqrt    v_rsq_f64 + one coupled Newton step + two residual corrections (argument range [2e-10, 23]: no scaling).
 //
-// ~47 f64 instructions + 12 integer ones + 3 table reads per sample.  tests/test_bm_f64_cpu.py compiles this header
+// ~47 f64 instructions + 12 integer ones + 3 table reads per sample.  The tables are 4.1 KiB: static device arrays (served
+// from L1) by default, or a kernel's own LDS copy where the latency matters (pipeline_mimo_f64.hip).  tests/test_bm_f64_cpu.py compiles this header
 // for the host and checks it word by word against NumPy; the -m gpu parity tests then hold every complex128 pipeline's
 // per-realization error counts equal to the oracle's.
 #pragma once
@@ -41,19 +42,31 @@
 
 namespace mcle {
 
+constexpr int kBmLogLen = 65 * 2, kBmThetaLen = 129, kBmTrigLen = 129 * 2;     // doubles: 4.1 KiB in all
+
+// A kernel's own LDS copy of the three tables, laid out [kBmLog | kBmTheta | kBmTrig] (call before a barrier)
+constexpr int kBmLdsDoubles = kBmLogLen + kBmThetaLen + kBmTrigLen;
+#ifdef __HIPCC__
+__device__ __forceinline__ void bm_tables_to_lds(double* s_bm, int tid, int nthreads) {
+    for (int i = tid; i < kBmLogLen; i += nthreads) s_bm[i] = kBmLog[i];
+    for (int i = tid; i < kBmThetaLen; i += nthreads) s_bm[kBmLogLen + i] = kBmTheta[i];
+    for (int i = tid; i < kBmTrigLen; i += nthreads) s_bm[kBmLogLen + kBmThetaLen + i] = kBmTrig[i];
+}
+#endif
+
 // -ln((x0 + 0.5) 2^-32)
-MCLE_BM_FN double bm_neg_log(uint32_t x0) {
+MCLE_BM_FN double bm_neg_log(uint32_t x0, const double* tlog = kBmLog) {
     const double ud = (double)x0 + 0.5;                                   // exact: u 2^32
     const uint64_t bits = __builtin_bit_cast(uint64_t, ud);
     const uint32_t hi = (uint32_t)(bits >> 32);
     const uint32_t mant = hi & 0xFFFFFu;
-    const uint32_t j = (mant + 0x1000u) >> 13;                            // nearest node, 0 .. 128
-    const bool fold = j >= 64u;                                           // m >= 1.5: use m / 2 and e + 1
+    const uint32_t j = (mant + 0x2000u) >> 14;                            // nearest node, 0 .. 64
+    const bool fold = j >= 32u;                                           // m >= 1.5: use m / 2 and e + 1
     const uint32_t ebase = fold ? 0x3FE00000u : 0x3FF00000u;
     const double m = __builtin_bit_cast(double, ((uint64_t)(ebase | mant) << 32) | (uint64_t)(uint32_t)bits);
-    const double c = __builtin_bit_cast(double, (uint64_t)(ebase + (j << 13)) << 32);    // (1 + j/128) [/ 2]; j = 128 -> 1
+    const double c = __builtin_bit_cast(double, (uint64_t)(ebase + (j << 14)) << 32);    // (1 + j/64) [/ 2]; j = 64 -> 1
     const int e = (int)(hi >> 20) - (1023 + 32) + (fold ? 1 : 0);
-    const double inv_c = kBmLog[2 * j], lnc = kBmLog[2 * j + 1];
+    const double inv_c = tlog[2 * j], lnc = tlog[2 * j + 1];
     const double r = (m - c) * inv_c;
     const double r2 = r * r;
     // log1p(r) = r + r^2 (-1/2 + r/3 + r^2 ((-1/4 + r/5) + r^2 (-1/6 + r/7)))
@@ -80,11 +93,11 @@ MCLE_BM_FN double bm_sqrt(double a) {
 }
 
 // cos / sin of the double fl(2 pi_d * x1 2^-32)
-MCLE_BM_FN void bm_sincos(uint32_t x1, double& c, double& s) {
+MCLE_BM_FN void bm_sincos(uint32_t x1, double& c, double& s, const double* ttheta = kBmTheta, const double* ttrig = kBmTrig) {
     const double ang = (double)x1 * 0x1.921fb54442d18p-30;                // (2 pi_d) 2^-32: fl(.) == NumPy's 2.0*np.pi*(x1*2**-32)
-    const uint32_t k = ((x1 >> 23) + 1u) >> 1;                            // nearest node, 0 .. 256
-    const double ct = kBmTrig[2 * k], st = kBmTrig[2 * k + 1];
-    const double r = ang - kBmTheta[k];                                   // exact
+    const uint32_t k = ((x1 >> 24) + 1u) >> 1;                            // nearest node, 0 .. 128
+    const double ct = ttrig[2 * k], st = ttrig[2 * k + 1];
+    const double r = ang - ttheta[k];                                     // exact
     const double s2 = r * r;
     double p = MCLE_BM_FMA(s2, -1.0 / 5040.0, 1.0 / 120.0);
     p = MCLE_BM_FMA(s2, p, -1.0 / 6.0);

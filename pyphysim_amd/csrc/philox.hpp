@@ -82,6 +82,17 @@ __device__ __forceinline__ double2 cn_from_words(uint32_t x0, uint32_t x1, doubl
     return z;
 }
 
+// the same with the tables of bm_f64.hpp read from the caller's LDS copy (bm_tables_to_lds)
+__device__ __forceinline__ double2 cn_from_words_lds(uint32_t x0, uint32_t x1, double sigma, const double* s_bm) {
+    const double rad = sigma * bm_sqrt(bm_neg_log(x0, s_bm));
+    double s, c;
+    bm_sincos(x1, c, s, s_bm + kBmLogLen, s_bm + kBmLogLen + kBmThetaLen);
+    double2 z;
+    z.x = rad * c;
+    z.y = rad * s;
+    return z;
+}
+
 // complex sample i of (stream): one Philox call, half of it used
 template <typename T>
 __device__ __forceinline__ cx<T> cn_sample(const Rng& rng, uint32_t stream, uint64_t i, T sigma) {

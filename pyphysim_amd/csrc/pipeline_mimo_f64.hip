@@ -164,7 +164,8 @@ __global__ __launch_bounds__(256 * (4 / AH), 2 * (4 / AH)) void k_run_mimo_ofdm_
     double2* s_txtab = s_table + ((mp.M + 1) & ~1);                         // [tab_len] constellation x tx scale
     double2* s_rec = s_txtab + ((mp.M + 1) & ~1);                           // [2][kRec + 1]
     unsigned* s_part = reinterpret_cast<unsigned*>(s_rec + 2 * (kRec + 1)); // [2][8 waves][2]
-    unsigned long long* s_grid = reinterpret_cast<unsigned long long*>(s_part + 32);
+    double* s_bm = reinterpret_cast<double*>(s_part + 32);                  // [kBmLdsDoubles (+1)] Box-Muller tables
+    unsigned long long* s_grid = reinterpret_cast<unsigned long long*>(s_bm + ((kBmLdsDoubles + 1) & ~1));
     unsigned char* s_idx = reinterpret_cast<unsigned char*>(s_grid + mp.grid.G * mp.grid.G);   // [NA * num_used]
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -180,6 +181,7 @@ __global__ __launch_bounds__(256 * (4 / AH), 2 * (4 / AH)) void k_run_mimo_ofdm_
         s_txtab[m] = cscale(c, tx_scale);
     }
     load_grid(mp, s_grid);
+    bm_tables_to_lds(s_bm, tid, TB);
     __shared__ WgTotals totals;
     if (tid == 0) wg_zero(totals);
 
@@ -270,11 +272,15 @@ __global__ __launch_bounds__(256 * (4 / AH), 2 * (4 / AH)) void k_run_mimo_ofdm_
                     for (int r = 0; r < NA; ++r) {
                         const uint64_t i0 = (uint64_t)r * row + (uint64_t)os * (N + cp) + cp + m0;
                         double2 z0, z1;
-                        if ((i0 & 1) == 0) {
-                            cn_pair<double>(rng, STREAM_NOISE, (uint32_t)(i0 >> 1), sigma, z0, z1);
+                        if ((i0 & 1) == 0) {     // tables of the Box-Muller from this workgroup's LDS copy
+                            const Words4 b = rng.block(STREAM_NOISE, (uint32_t)(i0 >> 1));
+                            z0 = cn_from_words_lds(b.w[0], b.w[1], sigma, s_bm);
+                            z1 = cn_from_words_lds(b.w[2], b.w[3], sigma, s_bm);
                         } else {
-                            z0 = cn_sample<double>(rng, STREAM_NOISE, i0, sigma);
-                            z1 = cn_sample<double>(rng, STREAM_NOISE, i0 + 1, sigma);
+                            const Words4 b0 = rng.block(STREAM_NOISE, (uint32_t)(i0 >> 1));
+                            const Words4 b1 = rng.block(STREAM_NOISE, (uint32_t)((i0 + 1) >> 1));
+                            z0 = cn_from_words_lds(b0.w[2], b0.w[3], sigma, s_bm);
+                            z1 = cn_from_words_lds(b1.w[0], b1.w[1], sigma, s_bm);
                         }
 #pragma unroll
                         for (int a = 0; a < NA; ++a) {
@@ -361,7 +367,8 @@ int run_mimo_ofdm_f64(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, uint64_t see
     mp.grid = context_grid<double>(ctx, cfg->demod_method, true);      // pruned search, decision-identical to the sweep
     const size_t tab_len = ((size_t)mp.M + 1) & ~(size_t)1;
     const size_t lds = (size_t)2 * kD64NA * kD64N * sizeof(double) + (2 * tab_len + 2 * (kD64Rec + 1)) * sizeof(double2) +
-                       32 * sizeof(unsigned) + (size_t)mp.grid.G * mp.grid.G * sizeof(unsigned long long) +
+                       32 * sizeof(unsigned) + (size_t)((kBmLdsDoubles + 1) & ~1) * sizeof(double) +
+                       (size_t)mp.grid.G * mp.grid.G * sizeof(unsigned long long) +
                        (size_t)4 * cfg->num_used + 16;
     // MCLE_OPT_F64_THREADS: 0 / 512 = two antennas per thread, 512-thread workgroups (default); 256 = four antennas per thread
     const bool wide = ctx->opt[MCLE_OPT_F64_THREADS] != 256;

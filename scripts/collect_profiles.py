@@ -20,21 +20,27 @@ import shutil
 import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r03"
 sys.path.insert(0, REPO)
-from bench import BATCH, derive_pmc  # noqa: E402
+from bench import derive_pmc  # noqa: E402
 src = os.path.join(REPO, "gpurun_out")
 dst = os.path.join(REPO, "profiles", rnd)
 os.makedirs(dst, exist_ok=True)
 
+# tag -> (kernel-name needle of the dominant kernel, label); the bench arguments of a tag (config, dtype, demodulator, batch)
+# are recorded by scripts/prof_r03.sh in gpurun_out/prof_<tag>_meta.json
 CONFIGS = {
-    "c4": ("k_run_mimo_ofdm_mfma<", "k_run_mimo_ofdm_mfma<3,6> (f32, FFT 1024, 4x4), %d realizations per launch (bench.py default workload)"),
-    "c4md": ("k_run_mimo_ofdm_mfma<", "k_run_mimo_ofdm_mfma<3,6> with the min-distance demodulator over the LDS table (bench.py --demod mindist), %d realizations per launch"),
-    "f1": ("k_run_mimo_ofdm_tdl<", "k_run_mimo_ofdm_tdl<float,1024,4>, %d realizations per launch (bench.py --config f1)"),
-    "c3": ("k_run_ofdm_tdl_mfma<", "k_run_ofdm_tdl_mfma<3> (f32, FFT 1024, 4 realizations per pass), %d realizations per launch (bench.py --config c3)"),
-    "c2": ("k_run_flat_mfma<", "k_run_flat_mfma<8,1> (f32, 8 Jakes rays on the matrix cores, packed slicer), %d realizations per launch (bench.py --config c2)"),
-    "c5": ("k_ia_link<", "k_ia_link<float> (the symbol walk; k_ia_solve_links<float> runs before it, see c5_kernel_stats.csv), %d realizations per launch (bench.py --config c5)"),
-    "f6": ("k_bd_link<", "k_bd_link<float,2> (the symbol walk; k_bd_solve_links<float,2> runs before it, see f6_kernel_stats.csv), %d realizations per launch (bench.py --config f6)"),
+    "c4_f64": ("k_run_mimo_ofdm_f64<", "k_run_mimo_ofdm_f64<2> (complex128, FFT 1024, 4x4, 512 threads), min-distance demodulator: the bench.py headline"),
+    "c4_f64sl": ("k_run_mimo_ofdm_f64<", "k_run_mimo_ofdm_f64<2> with the QAM slicer"),
+    "c4": ("k_run_mimo_ofdm_mfma<", "k_run_mimo_ofdm_mfma<3,6> (complex64, FFT 1024, 4x4), QAM slicer"),
+    "c4md": ("k_run_mimo_ofdm_mfma<", "k_run_mimo_ofdm_mfma<3,6> with the min-distance demodulator over the LDS table"),
+    "f1": ("k_run_mimo_ofdm_tdl<", "k_run_mimo_ofdm_tdl<float,1024,4> (bench.py --config f1)"),
+    "c3": ("k_run_ofdm_tdl_mfma<", "k_run_ofdm_tdl_mfma<2> (complex64, FFT 1024, 4 realizations per pass; k_tdl_symbol_polys runs before it)"),
+    "c3_f64": ("k_run_ofdm_tdl_batch<", "k_run_ofdm_tdl_batch<double,1024,4> (complex128)"),
+    "c2": ("k_run_flat_mfma<", "k_run_flat_mfma<8,2> (complex64, 8 Jakes rays on the matrix cores)"),
+    "c2_f64": ("k_run_flat<", "k_run_flat<double,8,0> (complex128)"),
+    "c5": ("k_ia_link<", "k_ia_link<float> (the symbol walk; k_ia_solve_links<float,false> runs before it, see c5_kernel_stats.csv)"),
+    "f6": ("k_bd_link<", "k_bd_link<float,2> (the symbol walk; k_bd_solve_links_static<float,3,2> runs before it, see f6_kernel_stats.csv)"),
 }
 
 
@@ -44,6 +50,11 @@ def first(pattern):
 
 
 for cfg, (needle, label) in CONFIGS.items():
+    meta_path = os.path.join(src, "prof_%s_meta.json" % cfg)
+    if not os.path.exists(meta_path):
+        continue
+    bench_args = json.load(open(meta_path))["bench_args"]
+    per_launch = int(bench_args.split("--batch")[1].split()[0])
     stats = first(os.path.join(src, "prof_%s_stats" % cfg, "**", "%s_kernel_stats.csv" % cfg))
     if stats:
         shutil.copy(stats, os.path.join(dst, "%s_kernel_stats.csv" % cfg))
@@ -61,20 +72,25 @@ for cfg, (needle, label) in CONFIGS.items():
                              "max": max(vals)}
     if not summary:
         continue
-    per_launch = BATCH[cfg[:2]]
     derived = derive_pmc({k: v["mean_per_launch"] for k, v in summary.items()}, per_launch)
     summary["_derived"] = derived
-    summary["_kernel"] = label % per_launch
+    summary["_kernel"] = label
+    summary["_bench_args"] = bench_args
+    summary["_realizations_per_launch"] = per_launch
     summary["_dispatch"] = meta
     summary["_dispatch_note"] = ("rocprofv3's record: VGPR_Count is HALF the allocation on gfx950, LDS_Block_Size omits "
                                  "dynamic LDS; see kernel_resources.json for the code-object values")
     json.dump(summary, open(os.path.join(dst, "%s_pmc_summary.json" % cfg), "w"), indent=1)
-    if "hbm_bytes_per_launch" in derived and cfg in BATCH:
-        json.dump({"hbm_bytes_per_launch": derived["hbm_bytes_per_launch"], "realizations_per_launch": per_launch,
-                   "source": "profiles/%s/%s_pmc_summary.json" % (rnd, cfg),
-                   "rule": "(2*FETCH_SIZE + WRITE_SIZE) KiB per MI355X_MICROARCH.md"},
-                  open(os.path.join(REPO, "profiles", "traffic_%s.json" % cfg), "w"), indent=1)
-    print(cfg, json.dumps(derived, indent=1), json.dumps(meta))
+    print(cfg, json.dumps(derived), json.dumps(meta))
+
+for name in ("f64_rates.txt", "staged_c4.json", "staged_c4_f64.json", "bench_default.json", "bench_torchrun_1rank.json",
+             "f64_ablation.txt"):
+    pth = os.path.join(src, name)
+    if os.path.exists(pth):
+        shutil.copy(pth, os.path.join(dst, name))
+st = first(os.path.join(src, "prof_staged_c4", "**", "staged_kernel_stats.csv"))
+if st:
+    shutil.copy(st, os.path.join(dst, "staged_c4_kernel_stats.csv"))
 
 ops = first(os.path.join(src, "prof_operators_stats", "**", "operators_kernel_stats.csv"))
 if ops:
