@@ -224,6 +224,54 @@ __device__ __forceinline__ void demod_grid4_multi(const float4* __restrict__ s_t
     }
 }
 
+// The complex128 form of the lockstep search: the literal |c - r|^2 metric of demod_mindist<double> on the plain table, K
+// symbols at a time (the K cell words, then up to four candidates per symbol as K independent LDS round trips per step).
+// Same decisions as demod_grid(double) / demod_mindist<double>, first minimum included.
+template <int K>
+__device__ __forceinline__ void demod_grid_multi(const double2* __restrict__ s_table,
+                                                 const unsigned long long* __restrict__ s_grid, const DemodGrid& g, int M,
+                                                 const double2 (&r)[K], int (&idx)[K]) {
+    unsigned long long w[K];
+    int n[K];
+    double best[K];
+    bool slow = false;
+#pragma unroll
+    for (int k = 0; k < K; ++k) w[k] = grid_cell(s_grid, g, (float)r[k].x, (float)r[k].y);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        n[k] = (int)(w[k] & 0xFFull);
+        slow = slow || n[k] > 4;
+        idx[k] = n[k] == 0xFF ? 0 : (int)((w[k] >> 8) & 0xFFull);
+        const double2 c = s_table[idx[k]];
+        const double dx = r[k].x - c.x, dy = r[k].y - c.y;
+        best[k] = dx * dx + dy * dy;
+    }
+#pragma unroll
+    for (int j = 1; j < 4; ++j) {
+        int m[K];
+        double2 c[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            m[k] = (j < n[k] && n[k] != 0xFF) ? (int)((w[k] >> (8 * (j + 1))) & 0xFFull) : idx[k];
+            c[k] = s_table[m[k]];
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const double dx = r[k].x - c[k].x, dy = r[k].y - c[k].y;
+            const double d = dx * dx + dy * dy;
+            if (d < best[k]) {
+                best[k] = d;
+                idx[k] = m[k];
+            }
+        }
+    }
+    if (slow) {
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+            if (n[k] > 4) idx[k] = demod_grid(s_table, s_grid, g, M, r[k]);     // long lists and the 0xFF "sweep everything" marker
+    }
+}
+
 template <typename T>
 __device__ __forceinline__ void load_grid(const ModemParams<T>& mp, unsigned long long* s_grid) {
     const int cells = mp.grid.G * mp.grid.G;
