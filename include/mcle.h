@@ -30,7 +30,9 @@ extern "C" {
 #define MCLE_VERSION 1
 
 enum { MCLE_OK = 0, MCLE_E_INVAL = -1, MCLE_E_HIP = -2, MCLE_E_NOMEM = -3, MCLE_E_STATE = -4,
-       MCLE_E_UNSUPPORTED = -5 /* valid request outside a fused kernel's envelope: use the staged operators */ };
+       MCLE_E_UNSUPPORTED = -5 /* valid request outside a fused kernel's envelope and no generic kernel behind the same entry
+                                  point: returned by mcle_run_mimo_ofdm_tdl only (compose the staged operators); every other
+                                  mcle_run_* falls back internally or reports its envelope as MCLE_E_INVAL */ };
 enum { MCLE_F32 = 0, MCLE_F64 = 1 };
 /* demodulation method: exhaustive minimum distance over the constellation held in LDS
  * (any constellation), or the per-axis slicer (square Gray QAM only; same decisions). */

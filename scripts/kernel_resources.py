@@ -7,7 +7,7 @@ rocprofv3's per-dispatch VGPR_Count on gfx950 reports HALF the allocation (granu
 record cannot corroborate occupancy claims; this file can.  Dynamic LDS is added by the host code at launch
 (run_*_impl in csrc/*.hip) and is listed in DESIGN.md.
 
-usage: python scripts/kernel_resources.py r02
+usage: python scripts/kernel_resources.py r03
 """
 import json
 import os
@@ -23,7 +23,8 @@ FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fno-gpu-rdc", "-fno-hip
          "-ffp-contract=fast", "--cuda-device-only", "-c"]
 SOURCES = {"pipelines.hip": ("k_run_mimo_ofdm", "k_run_flat", "k_run_flat_mfma", "k_run_ofdm_tdl"),
            "pipeline_mimo_mfma.hip": ("k_run_mimo_ofdm_mfma", "k_mimo_filters"),
-           "pipeline_siso_tdl.hip": ("k_run_ofdm_tdl_batch", "k_run_ofdm_tdl_mfma"),
+           "pipeline_mimo_f64.hip": ("k_run_mimo_ofdm_f64", "k_mimo_filters_f64"),
+           "pipeline_siso_tdl.hip": ("k_run_ofdm_tdl_batch", "k_run_ofdm_tdl_mfma", "k_tdl_symbol_polys"),
            "pipeline_mimo_tdl.hip": ("k_run_mimo_ofdm_tdl",),
            "pipeline_mimo_flat.hip": ("k_mimo_flat_setup", "k_mimo_flat_link"),
            "kernels_ia.hip": ("k_ia_solve_links", "k_ia_link"),
@@ -40,7 +41,7 @@ def waves_per_simd(vgpr, agpr):
 
 
 def main():
-    rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
+    rnd = sys.argv[1] if len(sys.argv) > 1 else "r03"
     out = {}
     with tempfile.TemporaryDirectory() as tmp:
         for src, kernels in SOURCES.items():
