@@ -40,7 +40,7 @@ struct SisoTdlParams {
 };
 
 template <typename T, int N, int NB>
-__global__ __launch_bounds__(kPipeBlock, sizeof(T) == 4 ? 3 : 1) void k_run_ofdm_tdl_batch(
+__global__ __launch_bounds__(kPipeBlock, sizeof(T) == 4 ? 3 : 2) void k_run_ofdm_tdl_batch(
     SisoTdlParams pp, ModemParams<T> mp, uint64_t seed, uint64_t first, uint64_t count,
     const cx<T>* __restrict__ g_tw, mcle_counters* counters, uint32_t* __restrict__ sym_out,
     uint32_t* __restrict__ bit_out) {
@@ -892,7 +892,7 @@ int run_siso_tdl_mfma(mcle_ctx* ctx, const SisoTdlParams& pp, int method, uint64
 template <typename T, int N>
 int run_siso_tdl_batch_impl(mcle_ctx* ctx, SisoTdlParams pp, int method, uint64_t seed, uint64_t first, uint64_t count,
                             mcle_counters* d_counters, uint32_t* d_sym, uint32_t* d_bit) {
-    constexpr int NB = 4;
+    constexpr int NB = sizeof(T) == 8 ? 2 : 4;    // complex128: two realizations per pass -> half the LDS, two workgroups per CU
     int rc;
     if constexpr (sizeof(T) == 4 && N == kF16N) {
         rc = run_siso_tdl_mfma(ctx, pp, method, seed, first, count, d_counters, d_sym, d_bit);
