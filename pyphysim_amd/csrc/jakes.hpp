@@ -5,13 +5,15 @@
 // Phases reach 2*pi*Fd*t ~ 6e4 rad (Fd = 100 Hz, t <= 100 s), far beyond what f32 argument
 // reduction survives, so the phase is always formed in f64:
 //   f64 path (parity):  w = (2*pi*Fd)*cos(phi) [rad/s];  x = fl(fl(w*t) + psi)  -- the reference's
-//                       own evaluation order, no FMA contraction -- then sincos(x) in f64.
+//                       own evaluation order, no FMA contraction -- then cos / sin of that double (bm_sincos_rad:
+//                       within 1.2e-16 of the exact values, like NumPy's own).
 //   f32 path (speed):   w = Fd*cos(phi) [turns/s], psi/(2*pi) [turns]; x = fma(w, t, psi) in f64,
 //                       fract(x) -> f32 -> v_sin_f32 / v_cos_f32 (their input unit is turns).
 #pragma once
 #include <cmath>
 
 #include "common.hpp"
+#include "bm_f64.hpp"
 
 namespace mcle {
 
@@ -35,7 +37,8 @@ template <typename T> __device__ __forceinline__ cx<T> jakes_ray(double w, doubl
 template <> __device__ __forceinline__ double2 jakes_ray<double>(double w, double psi, double t) {
     const double x = __dadd_rn(__dmul_rn(w, t), psi);
     double s, c;
-    sincos(x, &s, &c);
+    if (fabs(x) <= 0x1p24) bm_sincos_rad(x, c, s);       // table + polynomial form (bm_f64.hpp): a quarter of libm's instructions
+    else sincos(x, &s, &c);                              // phases beyond 1.6e7 rad (t > 7 h at Fd = 100 Hz): the library routine
     double2 r;
     r.x = c;
     r.y = s;

@@ -48,7 +48,9 @@ inline uint64_t oversubscribed_grid(const mcle_ctx* ctx, uint64_t resident, uint
 
 template <typename T> ModemParams<T> pipe_modem(const mcle_ctx* ctx, int method) {
     ModemParams<T> p;
-    p.grid = context_grid<T>(ctx, method);
+    // the candidate grid serves the complex128 kernels too since round 3 (cell from the float-rounded point, the literal f64
+    // metric on the listed points: decision-identical to the sweep, modem.hpp) -- the f64 sweep over 64 points doubled their time
+    p.grid = context_grid<T>(ctx, method, true);
     if (sizeof(T) == 8)
         p.g_table = reinterpret_cast<const cx<T>*>(ctx->d_table_f64);
     else

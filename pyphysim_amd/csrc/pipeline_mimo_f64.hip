@@ -386,8 +386,7 @@ int run_mimo_ofdm_f64(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, uint64_t see
     void* tw = nullptr;
     if ((rc = ctx->get_twiddles(kD64N, MCLE_F64, &tw))) return rc;
     MimoParams pp{cfg->cp_size, cfg->num_used, cfg->n_ofdm_sym, cfg->mmse, cfg->noise_var};
-    ModemParams<double> mp = pipe_modem<double>(ctx, cfg->demod_method);
-    mp.grid = context_grid<double>(ctx, cfg->demod_method, true);      // pruned search, decision-identical to the sweep
+    const ModemParams<double> mp = pipe_modem<double>(ctx, cfg->demod_method);     // with the candidate grid (pruned search)
     const size_t tab_len = ((size_t)mp.M + 1) & ~(size_t)1;
     const size_t lds = (size_t)2 * kD64NA * kD64N * sizeof(double) + (2 * tab_len + 2 * (kD64Rec + 1)) * sizeof(double2) +
                        32 * sizeof(unsigned) + (size_t)((kBmLdsDoubles + 1) & ~1) * sizeof(double) +

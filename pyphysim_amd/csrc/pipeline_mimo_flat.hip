@@ -440,7 +440,7 @@ extern "C" int mcle_run_mimo_flat(mcle_ctx* ctx, int dtype, const mcle_mimo_flat
             hipLaunchKernelGGL(k_mimo_flat_setup<double>, dim3(sgrid), dim3(64), 0, ctx->stream, cfg->scheme, nt, nr, filter_nv,
                                seed, first + off, m, (double2*)recs);
             MCLE_LAUNCH_CHECK();
-            hipLaunchKernelGGL(k_mimo_flat_link<double>, dim3((unsigned)(chunks < cap ? chunks : cap)), dim3(64), 0,
+            hipLaunchKernelGGL(k_mimo_flat_link<double>, dim3((unsigned)(chunks < cap ? chunks : cap)), dim3(64), lds,
                                ctx->stream, pipe_modem<double>(ctx, cfg->demod_method), cfg->scheme, nt, nr, cfg->n_symbols,
                                cfg->noise_var, seed, first + off, m, per_wave, (const double2*)recs, d_counters, se, be);
         }

@@ -400,6 +400,9 @@ __global__ __launch_bounds__(kPipeBlock, sizeof(T) == 4 ? 3 : 1) void k_run_mimo
                     } else {
                         demod_mindist_multi<NA>(s_tab4, mp.M, est, dec);
                     }
+                } else if (mp.grid.G > 0) {
+#pragma unroll
+                    for (int a = 0; a < NA; ++a) dec[a] = demod_grid(s_table, s_grid, mp.grid, mp.M, est[a]);
                 } else {
                     demod_mindist_multi<NA>(s_table, mp.M, est, dec);
                 }

@@ -8,6 +8,7 @@
 #define MCLE_BM_FN static inline
 #define MCLE_BM_RSQ(a) ((double)(1.0f / std::sqrt((float)(a))))
 #define MCLE_BM_FMA(a, b, c) std::fma(a, b, c)
+#define MCLE_BM_RINT(a) std::nearbyint(a)
 #include "../../pyphysim_amd/csrc/bm_f64.hpp"
 
 extern "C" {
@@ -16,6 +17,9 @@ void bm_neg_log_batch(const uint32_t* x0, double* out, size_t n) {
 }
 void bm_sqrt_batch(const double* a, double* out, size_t n) {
     for (size_t i = 0; i < n; ++i) out[i] = mcle::bm_sqrt(a[i]);
+}
+void bm_sincos_rad_batch(const double* x, double* c, double* s, size_t n) {
+    for (size_t i = 0; i < n; ++i) mcle::bm_sincos_rad(x[i], c[i], s[i]);
 }
 void bm_sincos_batch(const uint32_t* x1, double* c, double* s, size_t n) {
     for (size_t i = 0; i < n; ++i) mcle::bm_sincos(x1[i], c[i], s[i]);
