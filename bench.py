@@ -130,6 +130,12 @@ def parse():
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="kernel-selection option of the context (mcle_ctx_set_option; names: pyphysim_amd._lib.OPTIONS), "
                          "e.g. --opt no_mfma=1 --opt grid_oversub=4; repeatable, for A/B runs")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend of a multi-rank run: nccl (= RCCL, the default and what the driver gets); "
+                         "gloo exists so that the N > 1 code path can be executed on a box with fewer GPUs than ranks")
+    ap.add_argument("--share-gpus", action="store_true",
+                    help="rank r uses GPU r mod (visible GPUs) instead of failing when there are fewer GPUs than ranks "
+                         "(tests of the N > 1 path on one GPU, together with --dist-backend gloo; never a scaling figure)")
     ap.add_argument("--launch-check", action="store_true",
                     help="no GPU: run the rank launcher, the range split and the reduction on gloo with an integer "
                          "checksum per realization index instead of a kernel (prints ranges + counters, no rate)")
@@ -479,15 +485,22 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    gpu = local_rank
     if local_rank >= torch.cuda.device_count():
-        raise SystemExit("bench.py: rank %d has no GPU (%d visible)" % (local_rank, torch.cuda.device_count()))
-    torch.cuda.set_device(local_rank)
+        if not args.share_gpus:
+            raise SystemExit("bench.py: rank %d has no GPU (%d visible)" % (local_rank, torch.cuda.device_count()))
+        gpu = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(gpu)
     use_dist = world > 1 or "RANK" in os.environ        # any torch.distributed.run launch, even with 1 rank
+    xdev = "cuda" if args.dist_backend == "nccl" else "cpu"      # where the exchanged tensors live
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    eng = Engine(local_rank, args.dtype)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", gpu))
+        else:
+            dist.init_process_group("gloo")
+    eng = Engine(gpu, args.dtype)
     for item in args.opt:
         name, _, val = item.partition("=")
         eng.set_option(name, int(val))
@@ -521,8 +534,8 @@ def main():
             for w in range(args.warmup):      # warm-up draws from a disjoint index range far away
                 run((1 << 40) + base + (w * n_active + r_idx) * batch, batch, counters)
         if use_dist:   # bring the communicator up outside the timed region (same shape / dtype as the real exchange)
-            dist.all_reduce(torch.zeros(6, dtype=torch.int64, device="cuda"), op=dist.ReduceOp.SUM)
-            dist.all_reduce(torch.zeros(2, dtype=torch.float64, device="cuda"), op=dist.ReduceOp.MAX)
+            dist.all_reduce(torch.zeros(6, dtype=torch.int64, device=xdev), op=dist.ReduceOp.SUM)
+            dist.all_reduce(torch.zeros(2, dtype=torch.float64, device=xdev), op=dist.ReduceOp.MAX)
         barrier()
         counters.zero()
         barrier()
@@ -535,13 +548,13 @@ def main():
                 run(lo + s * batch, batch, counters)
             kernel_ms = eng.timer_stop_ms()        # HIP events on the stream the kernels ran on
         local = eng.read_counters(counters)
-        vec = torch.tensor([local[k] for k in COUNTER_KEYS], dtype=torch.int64, device="cuda")
+        vec = torch.tensor([local[k] for k in COUNTER_KEYS], dtype=torch.int64, device=xdev)
         if use_dist:
             dist.all_reduce(vec, op=dist.ReduceOp.SUM)     # RCCL over xGMI: the path's only exchange step
             exchange_calls["timed"] += 1
         barrier()
         elapsed = time.perf_counter() - t0
-        tmax = torch.tensor([elapsed, kernel_ms, -kernel_ms if active else -1e30], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([elapsed, kernel_ms, -kernel_ms if active else -1e30], dtype=torch.float64, device=xdev)
         if use_dist:
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tot = [int(v) for v in vec.tolist()]
@@ -565,8 +578,8 @@ def main():
                 base_i += 1
     solo = timed(args.demod, args.dtype, 15 << 36, solo=True) if world > 1 else None
     # who ran: device name and PCI bus id of every rank (RCCL's view of the job next to the launcher's)
-    props = torch.cuda.get_device_properties(local_rank)
-    me = {"rank": rank, "local_rank": local_rank, "device": props.name,
+    props = torch.cuda.get_device_properties(gpu)
+    me = {"rank": rank, "local_rank": local_rank, "gpu": gpu, "device": props.name,
           "pci_bus_id": "%04x:%02x:%02x" % (getattr(props, "pci_domain_id", 0), getattr(props, "pci_bus_id", 0),
                                               getattr(props, "pci_device_id", 0)),
           "kernel_ms_timed_region": head["kernel_ms"] if world == 1 else None}

@@ -191,3 +191,35 @@ def test_bench_under_the_drivers_launch_line_runs_the_rccl_allreduce():
     assert p["config"]["exchange"].startswith("none")
     # the integer counters behind both lines are the same realizations: same SER to the last digit
     assert p["ser"] == line["ser"]
+
+
+@pytest.mark.timeout(900)
+def test_bench_two_rank_code_path_on_one_gpu():
+    """The N > 1 branch of bench.py -- disjoint contiguous ranges per rank, the all-reduce inside the timed region, the
+    rank-0-alone leg (n1_value), per-rank devices and kernel times -- executed end to end with two ranks sharing the one GPU
+    (gloo: RCCL refuses two ranks on a device; never a scaling figure).  The reduced counters must be those of the one-rank
+    run over the same index range."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    common = ["--warmup", "1", "--batch", "4096", "--no-cpu", "--pmc", "off", "--preroll-ms", "0", "--single-demod"]
+    two = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "2", "--dist-backend", "gloo",
+                          "--share-gpus"] + common, env=env, capture_output=True, text=True, timeout=800)
+    assert two.returncode == 0, two.stderr[-3000:]
+    lines = [l for l in two.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                                  # ONE JSON line, from rank 0
+    t = json.loads(lines[0])
+    assert t["n_gpus"] == 2 and t["rccl"]["rccl_world_size"] == 2 and t["rccl"]["backend"] == "gloo"
+    assert t["config"]["rank_ranges"] == [[0, 8192], [8192, 16384]]
+    assert [r["rank"] for r in t["rccl"]["ranks"]] == [0, 1] and all(r["device"] for r in t["rccl"]["ranks"])
+    assert t["n1_value"] > 0 and t["kernel_ms_per_rank"]["min"] > 0 and t["kernel_ms_per_rank"]["max"] >= t["kernel_ms_per_rank"]["min"]
+    assert t["rccl"]["allreduce_calls_in_timed_regions"] >= 2               # the two-rank region and the rank-0-alone region
+    one = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "1", "--steps", "4"] + common, env=env,
+                         capture_output=True, text=True, timeout=800)
+    assert one.returncode == 0, one.stderr[-3000:]
+    o = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    assert o["config"]["rank_ranges"] == [[0, 16384]]
+    assert o["ser"] == t["ser"] and o["ber"] == t["ber"]                      # same realizations, same integer counters
