@@ -76,3 +76,34 @@ def test_f64_kernel_skips_singular_channels_like_the_generic_kernel(engine):
     old = _run(engine, kw, 0, 3000, _lib.DEMOD_QAM_SLICER, generic=True)[0]
     assert new["n_skipped"] == old["n_skipped"] and new["n_realizations"] == old["n_realizations"]
     assert new["sym_errors"] == old["sym_errors"] <= 3
+
+
+def test_launch_slices_are_invisible(engine):
+    """The two-launch pipelines bound their record buffers by running (records, link) pairs over slices of the realization
+    range -- 2^18 realizations for the complex128 config-4 kernel, 64 MiB of fading records for config 3: a call that crosses
+    slice boundaries must give the counters of the same range taken in pieces (and per-realization counts in the same
+    order)."""
+    from pyphysim_amd.channels import discretize_profile
+    engine.set_constellation(chains.constellation("qam", 64), _lib.CONST_QAM)
+    nv = 1.0 / omodem.dB2Linear(25.0)
+    n = (1 << 18) + 4099                       # crosses the slice of k_mimo_filters_f64 / k_run_mimo_ofdm_f64
+    whole, se, _ = engine.run_mimo_ofdm(4, 4, 1024, 16, 1024, 1, nv, SEED, 0, n, method=_lib.DEMOD_QAM_SLICER, dtype="f64",
+                                        per_realization=True)
+    a = engine.run_mimo_ofdm(4, 4, 1024, 16, 1024, 1, nv, SEED, 0, 1 << 18, method=_lib.DEMOD_QAM_SLICER, dtype="f64")
+    b, se_b, _ = engine.run_mimo_ofdm(4, 4, 1024, 16, 1024, 1, nv, SEED, 1 << 18, 4099, method=_lib.DEMOD_QAM_SLICER,
+                                      dtype="f64", per_realization=True)
+    for k in ("sym_errors", "sym_errors_sq", "bit_errors", "bit_errors_sq", "n_realizations", "n_skipped"):
+        assert whole[k] == a[k] + b[k], k
+    assert np.array_equal(se[1 << 18:], se_b)
+    # config 3, complex64: 160 B of fading record per realization -> a slice is 419 428 realizations
+    engine.set_constellation(chains.constellation("qpsk", 4), _lib.CONST_GENERIC)
+    Ts = 1.0 / (15e3 * 1024)
+    p_lin, d_idx = discretize_profile(np.array([0.0, -3.0, -6.0, -9.0, -12.0]), np.arange(5) * Ts, Ts)
+    args = (1024, 16, 1024, 1, 0.01, p_lin, d_idx, SEED)
+    n3 = 419428 + 8191
+    w3, s3, _ = engine.run_ofdm_tdl(*args, 3, n3, Fd=10.0, Ts=Ts, L=8, dtype="f32", per_realization=True)
+    a3 = engine.run_ofdm_tdl(*args, 3, 419428, Fd=10.0, Ts=Ts, L=8, dtype="f32")
+    b3, sb3, _ = engine.run_ofdm_tdl(*args, 3 + 419428, 8191, Fd=10.0, Ts=Ts, L=8, dtype="f32", per_realization=True)
+    for k in ("sym_errors", "sym_errors_sq", "bit_errors", "bit_errors_sq", "n_realizations"):
+        assert w3[k] == a3[k] + b3[k], k
+    assert np.array_equal(s3[419428:], sb3)
