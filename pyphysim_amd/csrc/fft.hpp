@@ -94,6 +94,11 @@ __host__ __forceinline__ void dft_any_split(int n, int* n1, int* n2) {
 // (bits 5..6 into 0..3, bit 6 into 4): the stores of the spans 16, 4 and 1 were 2- to 4-way conflicted -- 12.8 extra LDS
 // cycles per store instruction averaged over the five stages in the bank model, 0.29 of the LDS cycles of the
 // frequency-selective MIMO kernel in the counters.
+// (Round 3 also tried folding bits 7..9 in -- bit 0 ^= b7, bit 1 ^= b6, bit 2 ^= b9, bit 3 ^= b8 -- which additionally makes
+// the digit-reversed bin gathers / symbol scatters of the tapped-delay-line kernels conflict free (56 extra LDS cycles per
+// read in the bank model otherwise).  Measured: f1 6.20 -> 6.05 ms, but the generic kernels that recompute their addresses
+// per stage lost 2-9 % to the longer address arithmetic (config 4 VALU kernel 1.93 -> 1.97 ms, complex128 generic 5.37 ->
+// 5.86 ms): the LDS is not what limits them.  Not kept.)
 // SWZ = false keeps the linear layout (operator kernels with global-memory twiddles).
 template <bool SWZ> __host__ __device__ __forceinline__ int lds_swz(int e) {
     if (!SWZ) return e;
