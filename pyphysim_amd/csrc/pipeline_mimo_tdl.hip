@@ -49,7 +49,7 @@ struct MimoTdlParams {
 };
 
 template <typename T, int N, int NA>
-__global__ __launch_bounds__(kPipeBlock, sizeof(T) == 4 ? 3 : 1) void k_run_mimo_ofdm_tdl(
+__global__ __launch_bounds__(kPipeBlock, sizeof(T) == 4 ? 3 : 2) void k_run_mimo_ofdm_tdl(
     MimoTdlParams pp, ModemParams<T> mp, uint64_t seed, uint64_t first, uint64_t count,
     const cx<T>* __restrict__ g_tw, mcle_counters* counters, uint32_t* __restrict__ sym_out,
     uint32_t* __restrict__ bit_out) {
@@ -58,21 +58,31 @@ __global__ __launch_bounds__(kPipeBlock, sizeof(T) == 4 ? 3 : 1) void k_run_mimo
     const int S = pp.n_taps, L = pp.L, K = pp.K, dmax = pp.dmax;
     const int PS = S * P1;                      // fading processes
     cx<T>* s_x = reinterpret_cast<cx<T>*>(smem);       // [NA][N] (+ slack for the ray scratch of small FFTs)
-    cx<T>* s_tw = s_x + pp.x_elems;                     // [N]
-    cx<T>* s_coef = s_tw + N;                           // [PS][K+1]
-    cx<T>* s_mean = s_coef + PS * (K + 1);              // [PS]
+    // complex64 keeps the twiddle table in LDS; complex128 reads it from global (L1/L2 resident) so that a
+    // second workgroup fits next to the 16-byte samples
+    constexpr bool kTwLds = sizeof(T) == 4;
+    cx<T>* s_twbuf = s_x + pp.x_elems;                  // [N] (complex64 only)
+    const cx<T>* s_tw = kTwLds ? s_twbuf : g_tw;
+    cx<T>* s_coef = s_twbuf + (kTwLds ? N : 0);         // [PS][K+1]; complex128: the candidate grid shares it
+    const int GG = mp.grid.G * mp.grid.G;
+    const int coef_elems = kTwLds ? PS * (K + 1) : max(PS * (K + 1), (GG + 1) / 2);
+    cx<T>* s_mean = s_coef + coef_elems;                // [PS]
     cx<T>* s_tail = s_mean + PS;                        // [2][NA][dmax] last samples of the previous symbol
     float4* s_tab4 = reinterpret_cast<float4*>(s_tail + 2 * NA * (dmax > 0 ? dmax : 1));  // [M rounded up to 16]
     cx<T>* s_table = reinterpret_cast<cx<T>*>(s_tab4);  // f64: the plain table lives in the same place
     const int table_len = (mp.M + 15) & ~15;            // the table region is sized by the constellation
     unsigned* s_red = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(s_tab4) +
                                                   table_len * (sizeof(T) == 4 ? sizeof(float4) : sizeof(cx<T>)));
-    unsigned long long* s_grid = reinterpret_cast<unsigned long long*>(s_red + 16);   // [G*G] candidate grid (f32)
-    unsigned char* s_idx = reinterpret_cast<unsigned char*>(s_grid + mp.grid.G * mp.grid.G);   // [NA*num_used]
+    // [G*G] candidate grid.  complex128: in the polynomial-coefficient region, which is dead from the end of the
+    // channel stage to the top of the next symbol (refilled per symbol from the L2-resident copy)
+    unsigned long long* s_grid = kTwLds ? reinterpret_cast<unsigned long long*>(s_red + 16)
+                                        : reinterpret_cast<unsigned long long*>(s_coef);
+    unsigned char* s_idx = reinterpret_cast<unsigned char*>(s_red + 16) + (kTwLds ? GG * 8 : 0);   // [NA*num_used]
 
     const int tid0 = threadIdx.x;
-    for (int k = tid0; k < N; k += kPipeBlock) s_tw[k] = g_tw[k];
-    load_grid(mp, s_grid);
+    if constexpr (kTwLds)
+        for (int k = tid0; k < N; k += kPipeBlock) s_twbuf[k] = g_tw[k];
+    if constexpr (kTwLds) load_grid(mp, s_grid);
     for (int m = tid0; m < mp.M; m += kPipeBlock) {
         const cx<T> c = mp.g_table[m];
         if constexpr (sizeof(T) == 4)
@@ -338,6 +348,7 @@ __global__ __launch_bounds__(kPipeBlock, sizeof(T) == 4 ? 3 : 1) void k_run_mimo
                 }
             }
             __syncthreads();   // every read of the transmit samples is done: overwrite in place
+            if constexpr (!kTwLds) load_grid(mp, s_grid);   // ... and of the coefficients (visible after the transform)
 #pragma unroll
             for (int k = 0; k < PAIRS; ++k) {
                 const int m0 = 2 * (tid_c + kPipeBlock * k);
@@ -432,10 +443,12 @@ int run_mimo_tdl_impl(mcle_ctx* ctx, MimoTdlParams pp, int method, uint64_t seed
     const size_t PS = (size_t)pp.n_taps * NA * NA;
     const size_t ray_elems = (PS * pp.L * 3 + 1) / 2;            // {re, im, theta} per ray, in complex elements
     pp.x_elems = (int)(ray_elems > (size_t)NA * N ? ray_elems : (size_t)NA * N);
-    const size_t lds = (size_t)(pp.x_elems + N + PS * (pp.K + 1) + PS + 2 * NA * (pp.dmax > 0 ? pp.dmax : 1)) * sizeof(cx<T>) +
+    const size_t GG = (size_t)mp.grid.G * mp.grid.G;
+    const size_t coef_elems = sizeof(T) == 4 ? PS * (pp.K + 1) : std::max(PS * (pp.K + 1), (GG + 1) / 2);
+    const size_t lds = (size_t)(pp.x_elems + (sizeof(T) == 4 ? N : 0) + coef_elems + PS + 2 * NA * (pp.dmax > 0 ? pp.dmax : 1)) * sizeof(cx<T>) +
                        (size_t)((mp.M + 15) & ~15) * (sizeof(T) == 4 ? sizeof(float4) : sizeof(cx<T>)) +
                        16 * sizeof(unsigned) +
-                       (size_t)mp.grid.G * mp.grid.G * sizeof(unsigned long long) + (size_t)NA * pp.num_used + 16;
+                       (sizeof(T) == 4 ? GG * sizeof(unsigned long long) : 0) + (size_t)NA * pp.num_used + 16;
     if (lds > 160 * 1024) {   // the staged operator chain has no such limit
         set_error("configuration needs %zu bytes of LDS (limit 160 KiB)", lds);
         return MCLE_E_UNSUPPORTED;

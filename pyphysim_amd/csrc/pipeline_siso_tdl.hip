@@ -48,8 +48,12 @@ __global__ __launch_bounds__(kPipeBlock, sizeof(T) == 4 ? 3 : 2) void k_run_ofdm
     const int S = pp.n_taps, L = pp.L, K = pp.K, dmax = pp.dmax;
     const int PS = S * NB;                              // fading processes of a pass: slot a, tap s -> a*S + s
     cx<T>* s_x = reinterpret_cast<cx<T>*>(smem);       // [NB][N] (+ slack for the ray scratch of small FFTs)
-    cx<T>* s_tw = s_x + pp.x_elems;                     // [N]
-    cx<T>* s_coef = s_tw + N;                           // [PS][K+1]
+    // complex64 keeps the twiddle table in LDS; complex128 reads it from global (L1/L2 resident) so that a
+    // second and third workgroup fit next to the 16-byte samples
+    constexpr bool kTwLds = sizeof(T) == 4;
+    cx<T>* s_twbuf = s_x + pp.x_elems;                  // [N] (complex64 only)
+    const cx<T>* s_tw = kTwLds ? s_twbuf : g_tw;
+    cx<T>* s_coef = s_twbuf + (kTwLds ? N : 0);         // [PS][K+1]
     cx<T>* s_mean = s_coef + PS * (K + 1);              // [PS]
     cx<T>* s_tail = s_mean + PS;                        // [2][NB][dmax] last samples of the previous symbol
     cx<T>* s_table = s_tail + 2 * NB * (dmax > 0 ? dmax : 1);   // [kMaxTable]
@@ -58,7 +62,8 @@ __global__ __launch_bounds__(kPipeBlock, sizeof(T) == 4 ? 3 : 2) void k_run_ofdm
     unsigned char* s_idx = reinterpret_cast<unsigned char*>(s_grid + mp.grid.G * mp.grid.G);   // [NB][num_used]
 
     const int tid0 = threadIdx.x;
-    for (int k = tid0; k < N; k += kPipeBlock) s_tw[k] = g_tw[k];
+    if constexpr (kTwLds)
+        for (int k = tid0; k < N; k += kPipeBlock) s_twbuf[k] = g_tw[k];
     load_table(mp, s_table);
     load_grid(mp, s_grid);
     const int U = pp.num_used, cp = pp.cp, W = N + cp;
@@ -904,7 +909,7 @@ int run_siso_tdl_batch_impl(mcle_ctx* ctx, SisoTdlParams pp, int method, uint64_
     const size_t PS = (size_t)pp.n_taps * NB;
     const size_t ray_elems = (PS * pp.L * 3 + 1) / 2;            // {re, im, theta} per ray, in complex elements
     pp.x_elems = (int)(ray_elems > (size_t)NB * N ? ray_elems : (size_t)NB * N);
-    const size_t lds = (size_t)(pp.x_elems + N + PS * (pp.K + 1) + PS + 2 * NB * (pp.dmax > 0 ? pp.dmax : 1) + kMaxTable) *
+    const size_t lds = (size_t)(pp.x_elems + (sizeof(T) == 4 ? N : 0) + PS * (pp.K + 1) + PS + 2 * NB * (pp.dmax > 0 ? pp.dmax : 1) + kMaxTable) *
                            sizeof(cx<T>) +
                        2 * NB * (kPipeBlock / 64) * sizeof(unsigned) +
                        (size_t)mp.grid.G * mp.grid.G * sizeof(unsigned long long) + (size_t)NB * pp.num_used + 16;
