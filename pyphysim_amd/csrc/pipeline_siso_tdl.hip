@@ -40,7 +40,7 @@ struct SisoTdlParams {
 };
 
 template <typename T, int N, int NB>
-__global__ __launch_bounds__(kPipeBlock, sizeof(T) == 4 ? 3 : 2) void k_run_ofdm_tdl_batch(
+__global__ __launch_bounds__(kPipeBlock, (sizeof(T) == 4 || N <= 1024) ? 3 : 2) void k_run_ofdm_tdl_batch(
     SisoTdlParams pp, ModemParams<T> mp, uint64_t seed, uint64_t first, uint64_t count,
     const cx<T>* __restrict__ g_tw, mcle_counters* counters, uint32_t* __restrict__ sym_out,
     uint32_t* __restrict__ bit_out) {

@@ -102,13 +102,13 @@ __device__ __forceinline__ float2 flat_equalised(float2 h, float2 s, float2 z) {
 
 // MODE (f32): 0 one demod_one per symbol (any method), 1 packed level-domain slicer, 2 lockstep min-distance search
 template <typename T, int LR, int MODE>
-__global__ __launch_bounds__(kPipeBlock) void k_run_flat(FlatParams fp, ModemParams<T> mp, uint64_t seed,
+__global__ __launch_bounds__(kPipeBlock, (sizeof(T) == 8 && LR == 8) ? 2 : 1) void k_run_flat(FlatParams fp, ModemParams<T> mp, uint64_t seed,
                                                          uint64_t first, uint64_t count, unsigned* __restrict__ ws) {
-    constexpr bool kRec = (LR > 0) && (sizeof(T) == 4);
+    constexpr bool kRec = LR > 0;   // ray phasors advanced by rotation inside a thread's run of 16 symbols (exact restart per run)
     __shared__ cx<T> s_table[kMaxTable];
     extern __shared__ unsigned long long s_grid[];       // [G*G] candidate grid (min-distance demodulation, f32)
     __shared__ double s_w[kMaxRays], s_psi[kMaxRays];
-    __shared__ float2 s_rot[kMaxRays];
+    __shared__ cx<T> s_rot[kMaxRays];
     __shared__ unsigned s_red[2 * (kPipeBlock / 64)];
     __shared__ float4 s_tab4[MODE == 2 ? kMaxTable : 1];     // {re, im, |c|^2 / 2, 0}: the lockstep searches of modem.hpp
     load_table(mp, s_table);
@@ -142,16 +142,20 @@ __global__ __launch_bounds__(kPipeBlock) void k_run_flat(FlatParams fp, ModemPar
             const double two_pi = 6.283185307179586476925286766559;
             const double phi = two_pi * uniform_at(rng, STREAM_PHASE, threadIdx.x);
             const double psi = two_pi * uniform_at(rng, STREAM_PHASE, fp.L + threadIdx.x);
-            if (sizeof(T) == 8) {
-                s_w[threadIdx.x] = two_pi * fp.Fd * cos(phi);
+            if constexpr (sizeof(T) == 8) {
+                const double w = two_pi * fp.Fd * cos(phi);
+                s_w[threadIdx.x] = w;
                 s_psi[threadIdx.x] = psi;
+                double rs, rc;
+                sincos(w * fp.dt, &rs, &rc);
+                s_rot[threadIdx.x] = mk<T>(rc, rs);
             } else {
                 const double w = fp.Fd * cos(phi);
                 s_w[threadIdx.x] = w;
                 s_psi[threadIdx.x] = psi / two_pi;
                 double rs, rc;
                 sincos(two_pi * (w * fp.dt), &rs, &rc);
-                s_rot[threadIdx.x] = make_float2((float)rc, (float)rs);
+                s_rot[threadIdx.x] = mk<T>((T)rc, (T)rs);
             }
         }
         __syncthreads();
@@ -160,12 +164,12 @@ __global__ __launch_bounds__(kPipeBlock) void k_run_flat(FlatParams fp, ModemPar
         const int n_end = min(n_begin + kChunk, fp.n_symbols);
         for (int g0 = n_begin + (int)threadIdx.x * 16; g0 < n_end; g0 += kPipeBlock * 16) {
             const Words4 dw = rng.block(STREAM_DATA, (uint32_t)(g0 >> 4));
-            float2 ray[kRec ? LR : 1], rot[kRec ? LR : 1];
+            cx<T> ray[kRec ? LR : 1], rot[kRec ? LR : 1];
             if (kRec) {
                 const double t = jakes_time(fp.t0, fp.dt, (double)g0);
 #pragma unroll
                 for (int l = 0; l < (kRec ? LR : 1); ++l) {
-                    ray[l] = jakes_ray<float>(s_w[l], s_psi[l], t);
+                    ray[l] = jakes_ray<T>(s_w[l], s_psi[l], t);
                     rot[l] = s_rot[l];
                 }
             }
@@ -187,14 +191,14 @@ __global__ __launch_bounds__(kPipeBlock) void k_run_flat(FlatParams fp, ModemPar
                     const int n = g0 + 4 * q + e;
                     const cx<T> s = s_table[(dwt >> (8 * e)) & 0xFFu];
                     if (kRec) {
-                        float hr = 0, hi = 0;
+                        T hr = 0, hi = 0;
 #pragma unroll
                         for (int l = 0; l < (kRec ? LR : 1); ++l) {
                             hr += ray[l].x;
                             hi += ray[l].y;
                             ray[l] = cmul(ray[l], rot[l]);
                         }
-                        const cx<T> h = mk<T>((T)(amp * hr), (T)(amp * hi));
+                        const cx<T> h = mk<T>(amp * hr, amp * hi);
                         r[e] = flat_equalised(h, s, z[e]);
                     } else if (fp.L > 0) {
                         const double t = jakes_time(fp.t0, fp.dt, (double)n);
@@ -228,10 +232,22 @@ __global__ __launch_bounds__(kPipeBlock) void k_run_flat(FlatParams fp, ModemPar
                         be += __popc(x);
                     }
                 } else {
+                    int dec[4];
+                    bool done = false;
+                    if constexpr (sizeof(T) == 8) {   // complex128 grid search: the four symbols in lockstep
+                        if (mp.method == MCLE_DEMOD_MINDIST && mp.grid.G > 0) {
+                            demod_grid_multi<4>(s_table, s_grid, mp.grid, mp.M, r, dec);
+                            done = true;
+                        }
+                    }
+                    if (!done) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) dec[e] = e < left ? demod_one(mp, s_table, s_grid, r[e]) : 0;
+                    }
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         if (e < left) {
-                            const unsigned x = (unsigned)(((dwt >> (8 * e)) & 0xFFu) ^ (unsigned)demod_one(mp, s_table, s_grid, r[e]));
+                            const unsigned x = (unsigned)(((dwt >> (8 * e)) & 0xFFu) ^ (unsigned)dec[e]);
                             se += (x != 0u);
                             be += __popc(x);
                         }
@@ -922,7 +938,14 @@ int run_flat_impl(mcle_ctx* ctx, const FlatParams& fp, int method, uint64_t seed
             default: MCLE_FLAT_LAUNCH((k_run_flat<T, 0, 0>)); break;
         }
     } else {
-        MCLE_FLAT_LAUNCH((k_run_flat<T, 0, 0>));
+        // complex128: the same rotation recurrence over a thread's 16 symbols (15 complex products after an exact
+        // start: <= 3e-15 relative, against 8 or 16 f64 sincos per symbol); MCLE_OPT_JAKES_DIRECT evaluates every sample
+        const int lr64 = !fp.rayleigh_iid && (fp.L == 8 || fp.L == 16) && !ctx->opt[MCLE_OPT_JAKES_DIRECT] ? fp.L : 0;
+        switch (lr64) {
+            case 8: MCLE_FLAT_LAUNCH((k_run_flat<T, 8, 0>)); break;
+            case 16: MCLE_FLAT_LAUNCH((k_run_flat<T, 16, 0>)); break;
+            default: MCLE_FLAT_LAUNCH((k_run_flat<T, 0, 0>)); break;
+        }
     }
 #undef MCLE_FLAT_LAUNCH
     MCLE_LAUNCH_CHECK();
