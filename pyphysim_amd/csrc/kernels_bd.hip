@@ -672,6 +672,8 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void k_bd_link(ModemPar
     __shared__ cx<T> s_table[256];
     __shared__ float4 s_tab4[sizeof(T) == 4 ? 256 : 1];     // {re, im, |c|^2 / 2, 0}: the lockstep searches of modem.hpp
     __shared__ WgTotals totals;
+    __shared__ double s_bm[sizeof(T) == 8 ? kBmLdsDoubles : 1];   // complex128 Box-Muller tables (bm_f64.hpp)
+    if constexpr (sizeof(T) == 8) bm_tables_to_lds(s_bm, (int)threadIdx.x, (int)blockDim.x);
     load_table(mp, s_table);
     load_grid(mp, s_grid);
     if constexpr (sizeof(T) == 4)
@@ -742,8 +744,8 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void k_bd_link(ModemPar
 #pragma unroll
                         for (int a = 0; a < kBdMaxN; ++a)
                             if (a < n)
-                                cn_pair<T>(rng, STREAM_NOISE, ((uint32_t)a * (uint32_t)NS + (uint32_t)t) >> 1, sigma,
-                                           za[a], zb[a]);
+                                cn_pair_lds(rng, STREAM_NOISE, ((uint32_t)a * (uint32_t)NS + (uint32_t)t) >> 1, sigma,
+                                            za[a], zb[a], s_bm);
                         column(ta, za);
                         column(tb, zb);
                     }

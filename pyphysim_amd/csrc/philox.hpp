@@ -110,6 +110,18 @@ __device__ __forceinline__ void cn_pair(const Rng& rng, uint32_t stream, uint32_
     z1 = cn_from_words(b.w[2], b.w[3], sigma);
 }
 
+// the same against the caller's LDS copy of the complex128 tables (complex64 has none and ignores it)
+__device__ __forceinline__ void cn_pair_lds(const Rng& rng, uint32_t stream, uint32_t blk, float sigma, float2& z0,
+                                            float2& z1, const double*) {
+    cn_pair<float>(rng, stream, blk, sigma, z0, z1);
+}
+__device__ __forceinline__ void cn_pair_lds(const Rng& rng, uint32_t stream, uint32_t blk, double sigma, double2& z0,
+                                            double2& z1, const double* s_bm) {
+    const Words4 b = rng.block(stream, blk);
+    z0 = cn_from_words_lds(b.w[0], b.w[1], sigma, s_bm);
+    z1 = cn_from_words_lds(b.w[2], b.w[3], sigma, s_bm);
+}
+
 __device__ __forceinline__ double uniform_at(const Rng& rng, uint32_t stream, uint64_t i) {
     const Words4 b = rng.block(stream, (uint32_t)(i >> 2));
     return (double)b.w[i & 3] * 0x1p-32;

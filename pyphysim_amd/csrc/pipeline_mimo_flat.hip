@@ -185,6 +185,8 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void k_mimo_flat_link(
     __shared__ cx<T> s_table[256];
     __shared__ float4 s_tab4[sizeof(T) == 4 ? 256 : 1];     // {re, im, |c|^2 / 2, 0}: the lockstep searches of modem.hpp
     extern __shared__ unsigned long long s_grid[];       // [G*G] candidate grid (min-distance demodulation, f32)
+    __shared__ double s_bm[sizeof(T) == 8 ? kBmLdsDoubles : 1];   // complex128 Box-Muller tables (bm_f64.hpp)
+    if constexpr (sizeof(T) == 8) bm_tables_to_lds(s_bm, (int)threadIdx.x, (int)blockDim.x);
     load_table(mp, s_table);
     load_grid(mp, s_grid);
     if constexpr (sizeof(T) == 4)
@@ -240,8 +242,8 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void k_mimo_flat_link(
                             if (r < nr) {
                                 // slot 2p: (s0, s1); slot 2p+1: (-conj s1, conj s0)
                                 cx<T> y0, y1;
-                                cn_pair<T>(rng, STREAM_NOISE, ((uint32_t)r * (uint32_t)n_symbols + 2u * (uint32_t)p) >> 1, sigma,
-                                           y0, y1);
+                                cn_pair_lds(rng, STREAM_NOISE, ((uint32_t)r * (uint32_t)n_symbols + 2u * (uint32_t)p) >> 1, sigma,
+                                            y0, y1, s_bm);
                                 y0 = cfma(A[r][0], s0, y0);
                                 y0 = cfma(A[r][1], s1, y0);
                                 y1 = cfma(A[r][0], mk<T>(-s1.x, s1.y), y1);
@@ -342,8 +344,8 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void k_mimo_flat_link(
                             for (int r = 0; r < kFlatMax; ++r) {
                                 za[r] = zb[r] = mk<T>(0, 0);
                                 if (r < nr)
-                                    cn_pair<T>(rng, STREAM_NOISE, ((uint32_t)r * (uint32_t)n_symbols + (uint32_t)t) >> 1, sigma,
-                                               za[r], zb[r]);
+                                    cn_pair_lds(rng, STREAM_NOISE, ((uint32_t)r * (uint32_t)n_symbols + (uint32_t)t) >> 1, sigma,
+                                                za[r], zb[r], s_bm);
                             }
                             column(ta, za);
                             column(tb, zb);

@@ -64,6 +64,8 @@ __global__ __launch_bounds__(kPipeBlock, (sizeof(T) == 4 || N <= 1024) ? 3 : 2) 
     const int tid0 = threadIdx.x;
     if constexpr (kTwLds)
         for (int k = tid0; k < N; k += kPipeBlock) s_twbuf[k] = g_tw[k];
+    __shared__ double s_bm[sizeof(T) == 8 ? kBmLdsDoubles : 1];   // complex128 Box-Muller tables (bm_f64.hpp)
+    if constexpr (sizeof(T) == 8) bm_tables_to_lds(s_bm, tid0, kPipeBlock);
     load_table(mp, s_table);
     load_grid(mp, s_grid);
     const int U = pp.num_used, cp = pp.cp, W = N + cp;
@@ -285,7 +287,7 @@ __global__ __launch_bounds__(kPipeBlock, (sizeof(T) == 4 || N <= 1024) ? 3 : 2) 
                         const Rng rng(seed, first + base + a);
                         cx<T> z0, z1;
                         if ((i0 & 1) == 0) {
-                            cn_pair<T>(rng, STREAM_NOISE, (uint32_t)(i0 >> 1), sigma, z0, z1);
+                            cn_pair_lds(rng, STREAM_NOISE, (uint32_t)(i0 >> 1), sigma, z0, z1, s_bm);
                         } else {
                             z0 = cn_sample<T>(rng, STREAM_NOISE, i0, sigma);
                             z1 = cn_sample<T>(rng, STREAM_NOISE, i0 + 1, sigma);

@@ -111,6 +111,8 @@ __global__ __launch_bounds__(kPipeBlock, (sizeof(T) == 8 && LR == 8) ? 2 : 1) vo
     __shared__ cx<T> s_rot[kMaxRays];
     __shared__ unsigned s_red[2 * (kPipeBlock / 64)];
     __shared__ float4 s_tab4[MODE == 2 ? kMaxTable : 1];     // {re, im, |c|^2 / 2, 0}: the lockstep searches of modem.hpp
+    __shared__ double s_bm[sizeof(T) == 8 ? kBmLdsDoubles : 1];   // complex128 Box-Muller tables (bm_f64.hpp)
+    if constexpr (sizeof(T) == 8) bm_tables_to_lds(s_bm, (int)threadIdx.x, kPipeBlock);
     load_table(mp, s_table);
     load_grid(mp, s_grid);
     if constexpr (MODE == 2)
@@ -178,8 +180,8 @@ __global__ __launch_bounds__(kPipeBlock, (sizeof(T) == 8 && LR == 8) ? 2 : 1) vo
                 const int left = n_end - (g0 + 4 * q);
                 if (left <= 0) break;
                 cx<T> z[4], r[4];
-                cn_pair<T>(rng, STREAM_NOISE, (uint32_t)((g0 >> 1) + 2 * q), sigma, z[0], z[1]);
-                cn_pair<T>(rng, STREAM_NOISE, (uint32_t)((g0 >> 1) + 2 * q + 1), sigma, z[2], z[3]);
+                cn_pair_lds(rng, STREAM_NOISE, (uint32_t)((g0 >> 1) + 2 * q), sigma, z[0], z[1], s_bm);
+                cn_pair_lds(rng, STREAM_NOISE, (uint32_t)((g0 >> 1) + 2 * q + 1), sigma, z[2], z[3], s_bm);
                 const uint32_t dwt = dw.w[q] & mask4;
                 cx<T> hq[4];                             // i.i.d. Rayleigh: the four channel samples are two whole CHAN blocks
                 if (!kRec && fp.L == 0 && fp.rayleigh_iid) {
