@@ -36,9 +36,12 @@ CONFIGS = {
     "c4md": ("k_run_mimo_ofdm_mfma<", "k_run_mimo_ofdm_mfma<3,6> with the min-distance demodulator over the LDS table"),
     "f1": ("k_run_mimo_ofdm_tdl<", "k_run_mimo_ofdm_tdl<float,1024,4> (bench.py --config f1)"),
     "c3": ("k_run_ofdm_tdl_mfma<", "k_run_ofdm_tdl_mfma<2> (complex64, FFT 1024, 4 realizations per pass; k_tdl_symbol_polys runs before it)"),
-    "c3_f64": ("k_run_ofdm_tdl_batch<", "k_run_ofdm_tdl_batch<double,1024,4> (complex128)"),
+    "c3_f64": ("k_run_ofdm_tdl_batch<", "k_run_ofdm_tdl_batch<double,1024,2> (complex128, two realizations per pass, three waves per SIMD)"),
+    "f1_f64": ("k_run_mimo_ofdm_tdl<", "k_run_mimo_ofdm_tdl<double,1024,4> (complex128, two workgroups per CU)"),
+    "c5_f64": ("k_ia_link<", "k_ia_link<double> (complex128 symbol walk)"),
+    "f6_f64": ("k_bd_link<", "k_bd_link<double,2> (complex128 symbol walk)"),
     "c2": ("k_run_flat_mfma<", "k_run_flat_mfma<8,2> (complex64, 8 Jakes rays on the matrix cores)"),
-    "c2_f64": ("k_run_flat<", "k_run_flat<double,8,0> (complex128)"),
+    "c2_f64": ("k_run_flat<", "k_run_flat<double,8,0> (complex128, 16-symbol rotation recurrence of the ray phasors)"),
     "c5": ("k_ia_link<", "k_ia_link<float> (the symbol walk; k_ia_solve_links<float,false> runs before it, see c5_kernel_stats.csv)"),
     "f6": ("k_bd_link<", "k_bd_link<float,2> (the symbol walk; k_bd_solve_links_static<float,3,2> runs before it, see f6_kernel_stats.csv)"),
 }

@@ -16,8 +16,11 @@ declare -A SPEC=(
   [f1]="--config f1 --dtype f32 --demod slicer --batch 393216"
   [c5]="--config c5 --dtype f32 --demod slicer --batch 1048576"
   [f6]="--config f6 --dtype f32 --batch 524288"
+  [f1_f64]="--config f1 --dtype f64 --batch 98304"
+  [c5_f64]="--config c5 --dtype f64 --batch 262144"
+  [f6_f64]="--config f6 --dtype f64 --batch 131072"
 )
-tags=${@:-c4_f64 c4_f64sl c4 c4md c3 c3_f64 c2 c2_f64 f1 c5 f6}
+tags=${@:-c4_f64 c4_f64sl c4 c4md c3 c3_f64 c2 c2_f64 f1 c5 f6 f1_f64 c5_f64 f6_f64}
 for tag in $tags; do
   spec=${SPEC[$tag]}
   echo "{\"tag\": \"$tag\", \"bench_args\": \"$spec\"}" > gpurun_out/prof_${tag}_meta.json

@@ -57,13 +57,14 @@ def test_awgn_pipeline(engine, dt, exact, mod, M, N, snr):
 
 
 @pytest.mark.parametrize("dt,exact", [("f64", True), ("f32", False)])
-def test_flat_fading_pipeline(engine, dt, exact):
-    kw = dict(mod="qam", M=64, N=20000, snr_db=20.0, Fd=100.0, Ts=1e-3, L=8)
+@pytest.mark.parametrize("L", [8, 16, 5])      # 8 / 16: the rotation-recurrence instantiations; 5: one sincos per sample
+def test_flat_fading_pipeline(engine, dt, exact, L):
+    kw = dict(mod="qam", M=64, N=20000, snr_db=20.0, Fd=100.0, Ts=1e-3, L=L)
     engine.set_constellation(chains.constellation("qam", 64), _lib.CONST_QAM)
     first, count = 77, 3
     want_se, want_be, nsym, nbits = oracle_counts(chains.chain_flat_jakes, first, count, **kw)
     res, se, be = engine.run_flat_fading(kw["N"], 1.0 / omodem.dB2Linear(20.0), SEED, first, count, Fd=100.0,
-                                         Ts=1e-3, L=8, dtype=dt, per_realization=True)
+                                         Ts=1e-3, L=L, dtype=dt, per_realization=True)
     check(res, se, be, want_se, want_be, nsym, nbits, exact)
 
 
@@ -81,6 +82,10 @@ def test_flat_fading_pipeline_at_the_full_config2_size(engine):
         res, se, be = engine.run_flat_fading(100000, nv, SEED, first, count, Fd=100.0, Ts=1e-3, L=8, method=method,
                                              dtype="f64", per_realization=True)
         check(res, se, be, want_se, want_be, nsym, nbits, True)
+    with engine.options(jakes_direct=1):    # one sincos per ray and sample instead of the 16-symbol rotation recurrence
+        res, se, be = engine.run_flat_fading(100000, nv, SEED, first, count, Fd=100.0, Ts=1e-3, L=8, dtype="f64",
+                                             per_realization=True)
+    check(res, se, be, want_se, want_be, nsym, nbits, True)
     for no_mfma in (0, 1):
         with engine.options(no_mfma=no_mfma):
             res, se, be = engine.run_flat_fading(100000, nv, SEED, first, count, Fd=100.0, Ts=1e-3, L=8, dtype="f32",
