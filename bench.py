@@ -318,6 +318,7 @@ def _parse_pmc_csv(folder, needle):
 
 def derive_pmc(c, per_launch):
     """Counter means per launch -> the fractions the bench line quotes.  Shared with scripts/collect_profiles.py.
+    `per_launch` = realizations per DISPATCH of the kernel: the profiled batch must not exceed the pipeline's launch slice.
     SQ_* cycle counters are in quad-cycles, SQ_VALU_MFMA_BUSY_CYCLES in cycles (MI355X_MICROARCH.md, constants
     table); GRBM_GUI_ACTIVE sums the 8 XCDs; the chip has 1024 SIMDs.  HBM bytes = (2 x FETCH_SIZE + WRITE_SIZE)
     KiB: on gfx950 FETCH_SIZE reports half of a coalesced stream's bytes (same guide, HBM section)."""

@@ -204,6 +204,11 @@ int mcle_randn_c_batch(mcle_ctx* ctx, int dtype, uint64_t seed, uint64_t first, 
 /* d_idx[r][i] = symbol i of realization first_realization + r (DATA stream) */
 int mcle_rand_symbols_batch(mcle_ctx* ctx, uint64_t seed, uint64_t first_realization, uint64_t count,
                             int M, int32_t* d_idx, size_t n);
+/* mcle_rand_symbols_batch + mcle_modulate in one pass (the "gen + modulate" operator of SURVEY 8(d)'s staged model, one
+ * write of the labels and one of the samples): d_idx[r][i] as above for the bound constellation's M, d_sym[r][i] =
+ * table[d_idx[r][i]] (randint + Modulator.modulate, modulators/fundamental.py:175-199) */
+int mcle_rand_modulate_batch(mcle_ctx* ctx, int dtype, uint64_t seed, uint64_t first_realization, uint64_t count,
+                             int32_t* d_idx, void* d_sym, size_t n);
 /* element-wise complex product (frequency-domain channel application, fading.py:1259) */
 int mcle_cmul(mcle_ctx* ctx, int dtype, const void* d_a, const void* d_b, void* d_out, size_t n);
 /* element-wise complex divide (flat-fading equalisation y / h of the C2 template) */

@@ -204,6 +204,13 @@ struct mcle_ctx {
 };
 
 namespace mcle {
+// same-wave LDS hand-off between two passes (the wave's own DS traffic executes in order)
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
 inline int grid_for(const mcle_ctx* ctx, size_t work_items, int block, int blocks_per_cu = 8) {
     size_t need = (work_items + block - 1) / block;
     size_t cap = (size_t)(ctx->n_cu > 0 ? ctx->n_cu : 256) * blocks_per_cu;

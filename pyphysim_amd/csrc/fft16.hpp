@@ -33,13 +33,6 @@ constexpr int kF16Ant = 2 * kF16Plane;     // dwords per antenna
 __host__ __device__ __forceinline__ int f16_swz(int k) { return ((k & 7) ^ ((k & 1) << 3)) << 2; }
 __host__ __device__ __forceinline__ int f16_pos(int p) { return p ^ f16_swz(p >> 6); }
 
-// same-wave LDS hand-off between two passes (the wave's own DS traffic executes in order)
-__device__ __forceinline__ void wave_lds_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
-
 __device__ __forceinline__ float dpp_swap1(float v) {   // value of lane ^ 1 (quad_perm [1,0,3,2])
     return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));
 }

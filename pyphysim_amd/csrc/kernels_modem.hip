@@ -301,6 +301,66 @@ __global__ __launch_bounds__(kBlock) void k_rand_symbols_batch(uint64_t seed, ui
         symbols_of_block(rng, b, 0, n, mask, row);
 }
 
+// "gen + modulate" of the staged chains in one pass (W N (I + S)).  A thread evaluates one DATA block (sixteen
+// label bytes); the wavefront parks its 1 024 bytes in LDS and walks them back two symbols per lane, so that every store
+// instruction covers a contiguous run (512 B of labels, 1 KiB of complex64 samples) -- sixteen labels and samples stored per
+// lane straight from the block (64 B / 128 B strides across the wave) ran at a third of the rate.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_rand_modulate_batch(ModemParams<T> mp, uint64_t seed, uint64_t first_real,
+                                                                uint32_t mask, int32_t* __restrict__ idx_out,
+                                                                cx<T>* __restrict__ sym_out, size_t n) {
+    __shared__ cx<T> s_table[kMaxM];
+    __shared__ __attribute__((aligned(16))) uint32_t s_lab[kBlock * 4];
+    load_table(mp, s_table);
+    __syncthreads();
+    const Rng rng(seed, first_real + blockIdx.y);
+    int32_t* irow = idx_out + (size_t)blockIdx.y * n;
+    cx<T>* srow = sym_out + (size_t)blockIdx.y * n;
+    const bool vec = (n & 1) == 0;                 // rows start on 8-byte (labels) / 16-byte (samples) boundaries
+    const uint32_t mask4 = mask * 0x01010101u;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned char* bytes = reinterpret_cast<const unsigned char*>(s_lab) + wave * 1024;
+    const uint64_t last_block = (uint64_t)((n - 1) >> 4);
+    for (uint64_t b0 = (uint64_t)blockIdx.x * blockDim.x; b0 <= last_block; b0 += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t b = b0 + threadIdx.x;
+        uint4 lab = make_uint4(0u, 0u, 0u, 0u);
+        if (b <= last_block) {
+            const Words4 w = rng.block(STREAM_DATA, (uint32_t)b);
+            lab = make_uint4(w.w[0] & mask4, w.w[1] & mask4, w.w[2] & mask4, w.w[3] & mask4);
+        }
+        reinterpret_cast<uint4*>(s_lab)[threadIdx.x] = lab;
+        wave_lds_sync();                           // a wavefront reads back only its own kilobyte
+        const uint64_t s_wave = 16 * (b0 + 64u * (uint64_t)wave);
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int o = 128 * it + 2 * lane;
+            const uint64_t a = s_wave + (uint64_t)o;
+            const unsigned pair = *reinterpret_cast<const unsigned short*>(bytes + o);
+            const int e0 = (int)(pair & 0xFFu), e1 = (int)(pair >> 8);
+            if (vec && a + 2 <= n) {
+                *reinterpret_cast<int2*>(irow + a) = make_int2(e0, e1);
+                const cx<T> c0 = s_table[e0], c1 = s_table[e1];
+                if constexpr (sizeof(T) == 4) {
+                    *reinterpret_cast<float4*>(srow + a) = make_float4(c0.x, c0.y, c1.x, c1.y);
+                } else {
+                    srow[a] = c0;
+                    srow[a + 1] = c1;
+                }
+            } else {
+                if (a < n) {
+                    irow[a] = e0;
+                    srow[a] = s_table[e0];
+                }
+                if (a + 1 < n) {
+                    irow[a + 1] = e1;
+                    srow[a + 1] = s_table[e1];
+                }
+            }
+        }
+        wave_lds_sync();                           // the next round overwrites the kilobyte
+    }
+}
+
 int check_modem(const mcle_ctx* ctx, int dtype, int method) {
     MCLE_REQUIRE(ctx != nullptr, "null context");
     MCLE_REQUIRE(ctx->M > 0, "no constellation set (mcle_set_constellation)");
@@ -472,6 +532,28 @@ int mcle_rand_symbols_batch(mcle_ctx* ctx, uint64_t seed, uint64_t first_realiza
     dim3 grid((unsigned)grid_for(ctx, n / 16 + 1, kBlock, 2), (unsigned)count);
     hipLaunchKernelGGL(k_rand_symbols_batch, grid, dim3(kBlock), 0, ctx->stream, seed, first_realization,
                        (uint32_t)(M - 1), d_idx, n);
+    MCLE_LAUNCH_CHECK();
+    return MCLE_OK;
+}
+
+int mcle_rand_modulate_batch(mcle_ctx* ctx, int dtype, uint64_t seed, uint64_t first_realization, uint64_t count,
+                             int32_t* d_idx, void* d_sym, size_t n) {
+    int rc = check_modem(ctx, dtype, MCLE_DEMOD_MINDIST);
+    if (rc) return rc;
+    MCLE_REQUIRE((ctx->M & (ctx->M - 1)) == 0 && ctx->M >= 2, "the bound constellation's size must be a power of two");
+    MCLE_REQUIRE(count <= 65535, "at most 65535 realizations per call");
+    MCLE_REQUIRE(d_idx != nullptr && d_sym != nullptr, "null output");
+    if (n == 0 || count == 0) return MCLE_OK;
+    if ((rc = ctx->bind())) return rc;
+    dim3 grid((unsigned)grid_for(ctx, n / 16 + 1, kBlock, 2), (unsigned)count);
+    if (dtype == MCLE_F32)
+        hipLaunchKernelGGL(k_rand_modulate_batch<float>, grid, dim3(kBlock), 0, ctx->stream,
+                           modem_params<float>(ctx, MCLE_DEMOD_MINDIST), seed, first_realization, (uint32_t)(ctx->M - 1),
+                           d_idx, (float2*)d_sym, n);
+    else
+        hipLaunchKernelGGL(k_rand_modulate_batch<double>, grid, dim3(kBlock), 0, ctx->stream,
+                           modem_params<double>(ctx, MCLE_DEMOD_MINDIST), seed, first_realization, (uint32_t)(ctx->M - 1),
+                           d_idx, (double2*)d_sym, n);
     MCLE_LAUNCH_CHECK();
     return MCLE_OK;
 }

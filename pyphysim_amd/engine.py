@@ -436,6 +436,16 @@ class Engine:
                                                            out.ptr, int(n)))
         return out
 
+    def rand_modulate_batch(self, n, seed, first, count, dtype=None):
+        """(labels int32 [count, n], samples [count, n]) of realizations first .. first + count - 1 for the bound
+        constellation: rand_symbols_batch and modulate in one pass over HBM."""
+        dt = self._dt(dtype)
+        idx = self.empty((count, n), np.int32)
+        sym = self.empty((count, n), _lib.np_complex(dt))
+        self._raise_value(self.lib.mcle_rand_modulate_batch(self.ctx, dt, int(seed), int(first), int(count),
+                                                            idx.ptr, sym.ptr, int(n)))
+        return idx, sym
+
     def slice_rows(self, x, row_len):
         """Device copy of x[..., :row_len] (x contiguous [..., n])."""
         n = x.shape[-1]

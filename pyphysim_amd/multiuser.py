@@ -298,17 +298,21 @@ class MultiUserChannelMatrix:
         return self._stats(F_all_users, joint=True, want=("Q",))[0]["Q"][k][0]
 
     def _calc_Bkl_cov_matrix_all_l(self, F_all_users, k, N0_or_Rek=0.0):
-        """:1552-1621 for a scalar noise power (the covariance-matrix argument is the ExtInt class's own path)."""
+        """:1552-1621: a noise power, or (as the ExtInt class passes it, :2670) receiver k's interference-plus-noise
+        covariance matrix Rek, which enters every B^{[kl]} as an additive term (:1494-1510)."""
+        Rek = None
         if N0_or_Rek is not None and not np.isscalar(N0_or_Rek):
-            raise ValueError("pass a noise power; covariance matrices enter through MultiUserChannelMatrixExtInt")
-        keep, self._noise_var = self._noise_var, float(N0_or_Rek or 0.0)
+            Rek = np.asarray(N0_or_Rek)
+            if Rek.shape != (int(self.Nr[k]), int(self.Nr[k])):
+                raise ValueError("Rek must be a [Nr[k], Nr[k]] matrix")
+        keep, self._noise_var = self._noise_var, (0.0 if Rek is not None else float(N0_or_Rek or 0.0))
         try:
             B = self._stats(F_all_users, want=("B",))[0]["B"][k][0]
         finally:
             self._noise_var = keep
         out = np.empty(B.shape[0], dtype=np.ndarray)
         for l in range(B.shape[0]):
-            out[l] = B[l]
+            out[l] = B[l] if Rek is None else B[l] + Rek
         return out
 
     def _sinr(self, F, U, joint, pe=0.0):

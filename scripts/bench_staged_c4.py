@@ -3,8 +3,8 @@
 streams ... at >= 40 % of the HBM roofline" clause is quoted on (every operator reads its input
 arrays once and writes its output once, B_alg = 412 160 B per realization in complex64):
 
-    rand_symbols_batch -> modulate -> blast_encode -> ofdm_modulate x4 -> randn_c_batch (H) -> mimo_channel_philox (H T + noise)
-    -> ofdm_demodulate x4 -> blast_filter -> blast_decode -> demod_count
+    rand_modulate_batch (gen + modulate) -> blast_encode -> ofdm_modulate x4 -> randn_c_batch (H) -> mimo_channel_philox
+    (H T + noise) -> ofdm_demodulate x4 -> blast_filter -> blast_decode -> demod_count (demodulate + count)
 
 device-resident, a batch of realizations per kernel, the draws of realization r exactly those of the fused kernel (same
 mcle-philox-v1 ledger: DATA symbols, CHAN H row-major, NOISE (Nr, 1040) row-major), so the error counts equal
@@ -35,8 +35,8 @@ def chain(eng, first, count, counters, dtype="f32", method=None, noise_var=None,
     from pyphysim_amd import _lib
     method = _lib.DEMOD_MINDIST if method is None else method
     nv = (1.0 / (10.0 ** (SNR_DB / 10.0))) if noise_var is None else noise_var
-    idx = eng.rand_symbols_batch(4096, M, seed, first, count)                  # [count, 4096] int32
-    X = eng.blast_encode(eng.modulate(idx, dtype=dtype), 4, batch=count, dtype=dtype)       # [count, 4, 1024]
+    idx, sym = eng.rand_modulate_batch(4096, seed, first, count, dtype=dtype)               # [count, 4096] int32, complex
+    X = eng.blast_encode(sym, 4, batch=count, dtype=dtype)                                  # [count, 4, 1024]
     T = eng.ofdm_modulate(X, 1024, 16, 1024, batch=count * 4, dtype=dtype).reshape(count, 4, 1040)
     H = eng.randn_c_batch(16, seed, first, count, stream=_lib.STREAM_CHAN, dtype=dtype).reshape(count, 4, 4)
     R = eng.mimo_channel_philox(H, T, seed, first, nv, dtype=dtype)                         # [count, 4, 1040]

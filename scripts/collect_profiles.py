@@ -91,7 +91,7 @@ for name in ("f64_rates.txt", "staged_c4.json", "staged_c4_f64.json", "bench_def
     pth = os.path.join(src, name)
     if os.path.exists(pth):
         shutil.copy(pth, os.path.join(dst, name))
-st = first(os.path.join(src, "prof_staged_c4", "**", "staged_kernel_stats.csv"))
+st = first(os.path.join(src, "prof_staged_c4", "**", "staged*_kernel_stats.csv"))
 if st:
     shutil.copy(st, os.path.join(dst, "staged_c4_kernel_stats.csv"))
 

@@ -2,6 +2,9 @@
 # Round-3 profiles of every fused pipeline in both arithmetics (runs on the GPU box): per tag a `rocprofv3 --kernel-trace --stats`
 # run and four separate `--pmc` passes (counters are never combined with tracing) of `bench.py --single-demod` on that
 # (config, dtype, demodulator); scripts/collect_profiles.py r03 condenses gpurun_out/prof_<tag>_* into profiles/r03/.
+# Batches are chosen so that a step is ONE dispatch of the dominant kernel (the two-launch pipelines slice their record buffers:
+# config 3 at 64 MiB = 419 430 realizations, complex128 config 4 at 2^18) -- the counter summaries divide per-dispatch means by
+# the batch.
 # usage: bash scripts/prof_r03.sh [tag ...]        (default: all)
 mkdir -p gpurun_out; export TMPDIR=/tmp
 declare -A SPEC=(
@@ -9,7 +12,7 @@ declare -A SPEC=(
   [c4_f64sl]="--config c4 --dtype f64 --demod slicer --batch 262144"
   [c4]="--config c4 --dtype f32 --demod slicer --batch 262144"
   [c4md]="--config c4 --dtype f32 --demod mindist --batch 262144"
-  [c3]="--config c3 --dtype f32 --batch 524288"
+  [c3]="--config c3 --dtype f32 --batch 262144"
   [c3_f64]="--config c3 --dtype f64 --batch 131072"
   [c2]="--config c2 --dtype f32 --batch 65536"
   [c2_f64]="--config c2 --dtype f64 --batch 16384"

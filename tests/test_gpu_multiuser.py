@@ -52,6 +52,19 @@ def test_covariances_and_sinrs_against_reference(engine, ci, joint):
         Re = muc.calc_cov_matrix_extint_plus_noise(pe)
         for k in range(K):
             assert relerr(Re[k], Z[pre + "Re%d" % k]) <= 1e-12
+        if not joint:
+            # the ExtInt class's own use of _calc_Bkl_cov_matrix_all_l (multiuser.py:2670): Rek as the third argument;
+            # the stream SINRs rebuilt from it (multiuser.py:1822-1867) must be the reference's
+            for k in range(K):
+                B = muc._calc_Bkl_cov_matrix_all_l(F, k, Re[k])
+                Hkk = muc.get_Hkl(k, k)
+                for l in range(F[k].shape[1]):
+                    u, f = U[k][:, l:l + 1], F[k][:, l:l + 1]
+                    num = abs((u.conj().T @ Hkk @ f).item()) ** 2
+                    den = abs((u.conj().T @ B[l] @ u).item())
+                    assert abs(num / den - Z[tag + "sinr%d" % k][l]) <= 1e-10 * abs(Z[tag + "sinr%d" % k][l])
+            with pytest.raises(ValueError):
+                muc._calc_Bkl_cov_matrix_all_l(F, 0, np.eye(int(muc.Nr[0]) + 1))
     elif not joint:
         nv = float(Z[pre + "par"][0])
         B = muc._calc_Bkl_cov_matrix_all_l(F, K - 1, max(nv, 0.0))

@@ -98,6 +98,24 @@ def test_philox_draws(engine, dt):
 
 
 @pytest.mark.parametrize("dt", ["f64", "f32"])
+@pytest.mark.parametrize("mod,M", [("qam", 64), ("psk", 8), ("bpsk", 2)])
+def test_rand_modulate_batch_equals_draw_then_modulate(engine, dt, mod, M):
+    """The one-pass "gen + modulate" operator of the staged chains: labels = the oracle's DATA draws, samples = the
+    table looked up at them (modulators/fundamental.py:175-199), for rows with and without whole 16-byte groups."""
+    from oracle import chains
+    table = chains.constellation(mod, M)
+    engine.set_constellation(table, _lib.CONST_QAM if mod == "qam" else _lib.CONST_GENERIC)
+    seed, first = 99, (1 << 33) + 5
+    for n in (4096, 37, 16, 5):
+        idx, sym = engine.rand_modulate_batch(n, seed, first, 3, dtype=dt)
+        idx, sym = idx.get(), sym.get()
+        for k in range(3):
+            want = P.symbols(seed, first + k, n, M)
+            assert np.array_equal(idx[k], want)
+            assert np.array_equal(sym[k], table[want].astype(sym.dtype))
+
+
+@pytest.mark.parametrize("dt", ["f64", "f32"])
 def test_awgn_chain_injected(engine, dt):
     """C1 with the reference's own draws injected: decisions / counters bit-exact (f64)."""
     for kw, reals in golden_cases("c1_awgn"):
