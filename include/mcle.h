@@ -88,7 +88,8 @@ enum {
     MCLE_OPT_GRID_OVERSUB = 2,     /* persistent grids = this multiple of the resident set; 0: automatic (<= 8) */
     MCLE_OPT_FLAT_WGS_PER_CU = 3,  /* single-carrier kernels: workgroups started per CU; 0: 64 */
     MCLE_OPT_SINGLE_TDL = 4,       /* 1: config 3 on the one-realization-per-workgroup kernel */
-    MCLE_OPT_TDL_MFMA_WAVES = 5,   /* config-3 matrix-core kernel: 0 / 2 = two waves per SIMD, 3 = three */
+    MCLE_OPT_TDL_MFMA_WAVES = 5,   /* config-3 matrix-core kernel: 0 / 2 = two waves per SIMD, 3 = three, 32 = three with two
+                                      realizations per pass instead of four */
     MCLE_OPT_JAKES_DIRECT = 6,     /* 1: one sincos per ray and sample (jakes_generate: k_jakes; complex128 flat-fading pipeline: no rotation recurrence) */
     MCLE_OPT_F64_GENERIC = 7,      /* 1: complex128 config 4 on the generic radix-4 kernel instead of k_run_mimo_ofdm_f64 */
     MCLE_OPT_F64_THREADS = 8,      /* complex128 config-4 kernel: 0 / 512 = 512-thread workgroups, 256 = 256-thread workgroups */

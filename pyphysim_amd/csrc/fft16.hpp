@@ -82,29 +82,29 @@ __device__ __forceinline__ float2 cmul_pk(float2 a, float2 w) {
     return make_float2(fmaf(-a.y, w.y, tx), fmaf(a.y, w.x, ty));
 }
 
-// The four antennas of one DFT-16 pass: all operand loads first (the pass is in place per wavefront, so nothing it
-// stores is read again inside it), the 32 MFMAs as 8 independent accumulator chains, then twiddle and store.
-template <typename LoadOff, typename StoreOff, typename Fill>
-__device__ __forceinline__ void dft16_pass4(float* s_d, int plane_g, const Dft16Mats& m, const float2 (&tw)[4],
-                                            LoadOff ld, StoreOff st, Fill fill) {
-    float b[4][8];
+// The NA antennas (or realization slots) of one DFT-16 pass: all operand loads first (the pass is in place per wavefront, so
+// nothing it stores is read again inside it), the 8 NA MFMAs as 2 NA independent accumulator chains, then twiddle and store.
+template <int NA, typename LoadOff, typename StoreOff, typename Fill>
+__device__ __forceinline__ void dft16_pass(float* s_d, int plane_g, const Dft16Mats& m, const float2 (&tw)[4],
+                                           LoadOff ld, StoreOff st, Fill fill) {
+    float b[NA][8];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < NA; ++a)
 #pragma unroll
         for (int t = 0; t < 8; ++t) b[a][t] = s_d[a * kF16Ant + plane_g + ld(t)];
-    f4 ce[4], co[4];
+    f4 ce[NA], co[NA];
 #pragma unroll
-    for (int a = 0; a < 4; ++a) ce[a] = co[a] = f4{0.f, 0.f, 0.f, 0.f};
+    for (int a = 0; a < NA; ++a) ce[a] = co[a] = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int a = 0; a < 4; ++a) {
+        for (int a = 0; a < NA; ++a) {
             ce[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(m.ae[t], b[a][t] + b[a][t + 4], ce[a], 0, 0, 0);
             co[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(m.ao[t], b[a][t] - b[a][t + 4], co[a], 0, 0, 0);
         }
     fill();
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
+    for (int a = 0; a < NA; ++a) {
         const float2 o[4] = {make_float2(ce[a][0], ce[a][1]), make_float2(co[a][0], co[a][1]),
                              make_float2(ce[a][2], ce[a][3]), make_float2(co[a][2], co[a][3])};
 #pragma unroll
@@ -115,6 +115,11 @@ __device__ __forceinline__ void dft16_pass4(float* s_d, int plane_g, const Dft16
             s_d[off + kF16Plane] = v.y;
         }
     }
+}
+template <typename LoadOff, typename StoreOff, typename Fill>
+__device__ __forceinline__ void dft16_pass4(float* s_d, int plane_g, const Dft16Mats& m, const float2 (&tw)[4],
+                                            LoadOff ld, StoreOff st, Fill fill) {
+    dft16_pass<4>(s_d, plane_g, m, tw, ld, st, fill);
 }
 
 // inverse of ofdm_bin (fft.hpp): data index carried by FFT bin `bin`, or -1

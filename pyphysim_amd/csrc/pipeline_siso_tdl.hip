@@ -441,12 +441,13 @@ __global__ __launch_bounds__(256) void k_tdl_symbol_polys(SisoTdlParams pp, uint
     rec[S * (K + 1) + s] = make_float2(mr, mi);
 }
 
-template <int WAVES>
+template <int WAVES, int NB>
 __global__ __launch_bounds__(kPipeBlock, WAVES) void k_run_ofdm_tdl_mfma(
     SisoTdlParams pp, ModemParams<float> mp, uint64_t seed, uint64_t first, uint64_t count,
     const float2* __restrict__ g_tw, const float2* __restrict__ g_polys, mcle_counters* counters,
     uint32_t* __restrict__ sym_out, uint32_t* __restrict__ bit_out) {
-    constexpr int N = kF16N, NB = 4;
+    constexpr int N = kF16N;
+    static_assert(NB == 4 || NB == 2, "realization slots per pass");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int S = pp.n_taps, K = pp.K;
     const int PS = S * NB;                                             // fading processes of a pass: slot a, tap s -> a*S + s
@@ -460,6 +461,7 @@ __global__ __launch_bounds__(kPipeBlock, WAVES) void k_run_ofdm_tdl_mfma(
     float2* s_coef = reinterpret_cast<float2*>(s_grid + mp.grid.G * mp.grid.G);     // [PS][K+1]
     float2* s_mean = s_coef + PS * (K + 1);                            // [PS]
     unsigned* s_part = reinterpret_cast<unsigned*>(s_mean + PS);       // [2][4 waves][NB][2]
+    constexpr int kPart = 8 * NB;                                      // words of one buffer of partials
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int j = lane & 15, g = lane >> 4, gb = g >> 1;
@@ -519,7 +521,10 @@ __global__ __launch_bounds__(kPipeBlock, WAVES) void k_run_ofdm_tdl_mfma(
     const int t_sw = (k1m & 3) << 4;
     // symbol scatter, full band: lane (row e = lane >> 2, slot a = lane & 3) of wave w fills bins 64 e + 16 w + (0..15) of
     // slot a from one Philox block -- the wave's OWN 16 columns, so scatter -> P1 and P1' -> next scatter stay wave-local
-    const int sc_e = lane >> 2, sc_a = lane & 3;
+    // (two slots per pass: rows from lane >> 1, the upper half of the wave has no block to draw)
+    constexpr int kSlotBits = NB == 4 ? 2 : 1;
+    const int sc_e = lane >> kSlotBits, sc_a = lane & (NB - 1);
+    const bool sc_on = sc_e < 16;
     const int sc_d0 = (64 * sc_e + 16 * w + N / 2) & (N - 1);
     const int sc_sw = f16_swz(sc_e);
     const bool full_band = (U == N);
@@ -546,6 +551,7 @@ __global__ __launch_bounds__(kPipeBlock, WAVES) void k_run_ofdm_tdl_mfma(
             // ---- symbols -> bins, stored re<->im swapped (inverse transform by the swap identity) ----
             const uint64_t n_first = (uint64_t)os * U;
             if (full_band) {
+              if (sc_on) {
                 const Rng rng(seed, first + base + sc_a);
                 const Words4 dw = rng.block(STREAM_DATA, (uint32_t)((n_first + sc_d0) >> 4));
                 const uint32_t wv[4] = {dw.w[0] & mask4, dw.w[1] & mask4, dw.w[2] & mask4, dw.w[3] & mask4};
@@ -561,6 +567,7 @@ __global__ __launch_bounds__(kPipeBlock, WAVES) void k_run_ofdm_tdl_mfma(
                     *reinterpret_cast<f4*>(s_d + off) = vr;
                     *reinterpret_cast<f4*>(s_d + off + kF16Plane) = vi;
                 }
+              }
                 wave_lds_sync();
             } else {           // partial band: zero fill + scatter in block order across the workgroup
                 __syncthreads();
@@ -591,11 +598,11 @@ __global__ __launch_bounds__(kPipeBlock, WAVES) void k_run_ofdm_tdl_mfma(
             }
             // ---- P1: DFT-16 over n1, x W1024^{k1 n2} ----
             load_tw1a(tw1a, opaque(n2));
-            dft16_pass4(s_d, plane_g, mats, tw1a, [&](int t) { return (p1_ld ^ (((2 * t) & 7) << 2)) + 128 * t; },
+            dft16_pass<NB>(s_d, plane_g, mats, tw1a, [&](int t) { return (p1_ld ^ (((2 * t) & 7) << 2)) + 128 * t; },
                         [&](int x) { return (p1_st ^ ((x << 2) ^ ((x & 1) << 5))) + 64 * x; }, [&]() {});
             __syncthreads();
             if (tid == 0 && os == 0 && it > 0) {   // every wave is past the previous pass: account it
-                const unsigned* q = s_part + (buf ^ 1) * 32;
+                const unsigned* q = s_part + (buf ^ 1) * kPart;
 #pragma unroll
                 for (int a = 0; a < NB; ++a) {
                     if (base_prev + a >= count) break;
@@ -615,7 +622,7 @@ __global__ __launch_bounds__(kPipeBlock, WAVES) void k_run_ofdm_tdl_mfma(
             }
             // ---- P2: DFT-16 over m1, x W64^{j1 m2} ----
             load_tw2a(tw2a, opaque(m2p));
-            dft16_pass4(s_d, plane_g, mats, tw2a, [&](int t) { return p2_ld ^ (8 * t); },
+            dft16_pass<NB>(s_d, plane_g, mats, tw2a, [&](int t) { return p2_ld ^ (8 * t); },
                         [&](int x) { return p2_st ^ (4 * x); }, [&]() {});
             wave_lds_sync();
             // ---- P3 (DFT-4) -> time samples, parked in the time layout inside this wave's own quarter ----
@@ -745,7 +752,7 @@ __global__ __launch_bounds__(kPipeBlock, WAVES) void k_run_ofdm_tdl_mfma(
             wave_lds_sync();
             // ---- P2': DFT-16 over j1, x W1024^{(4 m1 + m2) k1} ----
             load_tw1b(tw1b, opaque(k1p));
-            dft16_pass4(s_d, plane_g, mats, tw1b, [&](int t) { return p2_ld ^ (8 * t); },
+            dft16_pass<NB>(s_d, plane_g, mats, tw1b, [&](int t) { return p2_ld ^ (8 * t); },
                         [&](int x) { return p2_st ^ (4 * x); }, [&]() {});
             __syncthreads();
             // ---- P1': DFT-16 over k1 -> bins 64 n1 + n2 (n1 = 4g + x); one-tap equaliser, demodulate, count ----
@@ -823,8 +830,8 @@ __global__ __launch_bounds__(kPipeBlock, WAVES) void k_run_ofdm_tdl_mfma(
         for (int a = 0; a < NB; ++a) {
             const unsigned s1 = wave_sum_u32(se[a]), b1 = wave_sum_u32(be[a]);
             if (lane == 0) {
-                s_part[buf * 32 + (w * NB + a) * 2] = s1;
-                s_part[buf * 32 + (w * NB + a) * 2 + 1] = b1;
+                s_part[buf * kPart + (w * NB + a) * 2] = s1;
+                s_part[buf * kPart + (w * NB + a) * 2 + 1] = b1;
             }
         }
         base_prev = base;
@@ -832,7 +839,7 @@ __global__ __launch_bounds__(kPipeBlock, WAVES) void k_run_ofdm_tdl_mfma(
     __syncthreads();
     if (tid == 0) {
         if (it > 0) {
-            const unsigned* q = s_part + (int)((it - 1) & 1) * 32;
+            const unsigned* q = s_part + (int)((it - 1) & 1) * kPart;
             for (int a = 0; a < NB; ++a) {
                 if (base_prev + a >= count) break;
                 unsigned st = 0, bt = 0;
@@ -851,7 +858,10 @@ __global__ __launch_bounds__(kPipeBlock, WAVES) void k_run_ofdm_tdl_mfma(
 // host side: 0 = launched, MCLE_E_UNSUPPORTED = outside this kernel's envelope (the caller uses k_run_ofdm_tdl_batch)
 int run_siso_tdl_mfma(mcle_ctx* ctx, const SisoTdlParams& pp, int method, uint64_t seed, uint64_t first, uint64_t count,
                       mcle_counters* d_counters, uint32_t* d_sym, uint32_t* d_bit) {
-    constexpr int NB = 4;
+    // Register budget and slots per pass (A/B: MCLE_OPT_TDL_MFMA_WAVES): 0 / 2 = two waves per SIMD (256 VGPRs), four
+    // realizations per pass; 3 = three waves (168 VGPRs, spills) with four; 32 = three waves with TWO realizations per pass
+    const long long wopt = ctx->opt[MCLE_OPT_TDL_MFMA_WAVES];
+    const int NB = wopt == 32 ? 2 : 4;
     if (pp.cp < pp.dmax || (pp.num_used & 15) != 0) return MCLE_E_UNSUPPORTED;
     if (ctx->opt[MCLE_OPT_NO_MFMA]) return MCLE_E_UNSUPPORTED;
     const size_t PS = (size_t)pp.n_taps * NB;
@@ -867,16 +877,16 @@ int run_siso_tdl_mfma(mcle_ctx* ctx, const SisoTdlParams& pp, int method, uint64
                        (size_t)mp.grid.G * mp.grid.G * sizeof(unsigned long long) +
                        (PS * (pp.K + 1) + PS) * sizeof(float2) + 64 * sizeof(unsigned);
     if (lds + 512 > (size_t)160 * 1024 / 2) return MCLE_E_UNSUPPORTED;
-    // Register budget (A/B: MCLE_OPT_TDL_MFMA_WAVES).  Round 2, with the f64 ray block inside the kernel: two workgroups per
-    // CU at 256 VGPRs (13 spilled) beat three at 168 (130 spilled), 1.63 vs 2.04 ms per 131 072 realizations.
-    const int waves = ctx->opt[MCLE_OPT_TDL_MFMA_WAVES] == 3 ? 3 : 2;
-    auto kern = waves == 2 ? k_run_ofdm_tdl_mfma<2> : k_run_ofdm_tdl_mfma<3>;
+    // Round 2, with the f64 ray block inside the kernel: two workgroups per CU at 256 VGPRs (13 spilled) beat three at 168
+    // (130 spilled), 1.63 vs 2.04 ms per 131 072 realizations.
+    const int waves = (wopt == 3 || wopt == 32) ? 3 : 2;
+    auto kern = wopt == 32 ? k_run_ofdm_tdl_mfma<3, 2> : waves == 2 ? k_run_ofdm_tdl_mfma<2, 4> : k_run_ofdm_tdl_mfma<3, 4>;
     MCLE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int per_cu = (int)((size_t)160 * 1024 / (lds + 512));
     if (per_cu > waves) per_cu = waves;     // __launch_bounds__(256, WAVES)
     const uint64_t per_real = (uint64_t)pp.n_ofdm_sym * rec_len;             // complex64 values per realization
     uint64_t slice = (64ull << 20) / (per_real * sizeof(float2));            // <= 64 MiB of records per fading + link pair
-    slice = slice < NB ? NB : (slice / NB) * NB;
+    slice = slice < (uint64_t)NB ? (uint64_t)NB : (slice / NB) * NB;
     if (slice > count) slice = (count + NB - 1) / NB * NB;
     void* recs = nullptr;
     if ((rc = ctx->scratch((size_t)slice * per_real * sizeof(float2), &recs))) return rc;

@@ -129,7 +129,7 @@ TDL_CASES = [dict(mod="qpsk", M=4, snr_db=20.0),                                
 
 
 @pytest.mark.parametrize("case", range(len(TDL_CASES)))
-@pytest.mark.parametrize("waves", [2, 3])
+@pytest.mark.parametrize("waves", [2, 3, 32])     # 32: three waves per SIMD with two realizations per pass
 def test_tdl_mfma_kernel_against_the_oracle_and_the_valu_kernel(engine, case, waves):
     kw = dict(TDL_CASES[case])
     mod, M = kw.pop("mod"), kw.pop("M")
