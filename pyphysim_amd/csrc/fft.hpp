@@ -105,6 +105,17 @@ template <bool SWZ> __host__ __device__ __forceinline__ int lds_swz(int e) {
     return e ^ (((e >> 4) & 3) * 5) ^ (((e >> 6) & 1) << 4);
 }
 
+// The four positions e0, e0 + s, e0 + 2s, e0 + 3s of a radix-4 butterfly (e0 = g 4s + k, k < s: the two bits of q s are
+// clear in e0, so e0 + q s = e0 ^ q s) through the swizzle, which is linear over XOR (bit extractions and shifts only):
+// swz(e0 ^ q s) = swz(e0) ^ swz(q s), the second term a compile-time constant per stage -- one swizzle and three XORs where
+// four swizzles cost 28 VALU instructions per butterfly.
+template <bool SWZ> __host__ __device__ __forceinline__ void lds_swz_r4(int e0, int s, int& i0, int& i1, int& i2, int& i3) {
+    i0 = lds_swz<SWZ>(e0);
+    i1 = i0 ^ lds_swz<SWZ>(s);
+    i2 = i0 ^ lds_swz<SWZ>(2 * s);
+    i3 = i0 ^ lds_swz<SWZ>(3 * s);
+}
+
 template <typename T, bool INV> __device__ __forceinline__ cx<T> tw_get(const cx<T>* tw, int i) {
     cx<T> w = tw[i];
     if (INV) w.y = -w.y;
@@ -152,8 +163,8 @@ __device__ __forceinline__ void fft_dif(cx<T>* s_data, int nf, int pitch, const 
             const int k = bb & (s - 1), g = bb / s;
             cx<T>* p = s_data + f * pitch;
             const int e0 = g * 4 * s + k;
-            const int i0 = lds_swz<SWZ>(e0), i1 = lds_swz<SWZ>(e0 + s), i2 = lds_swz<SWZ>(e0 + 2 * s),
-                      i3 = lds_swz<SWZ>(e0 + 3 * s);
+            int i0, i1, i2, i3;
+            lds_swz_r4<SWZ>(e0, s, i0, i1, i2, i3);
             const cx<T> x0 = p[i0], x1 = p[i1], x2 = p[i2], x3 = p[i3];
             const cx<T> a0 = cadd(x0, x2), a1 = csub(x0, x2), a2 = cadd(x1, x3), a3 = rot<T, INV>(csub(x1, x3));
             cx<T> y0 = cadd(a0, a2), y1 = cadd(a1, a3), y2 = csub(a0, a2), y3 = csub(a1, a3);
@@ -211,8 +222,8 @@ __device__ __forceinline__ void fft_dit(cx<T>* s_data, int nf, int pitch, const 
             const int k = bb & (s - 1), g = bb / s;
             cx<T>* p = s_data + f * pitch;
             const int e0 = g * 4 * s + k;
-            const int i0 = lds_swz<SWZ>(e0), i1 = lds_swz<SWZ>(e0 + s), i2 = lds_swz<SWZ>(e0 + 2 * s),
-                      i3 = lds_swz<SWZ>(e0 + 3 * s);
+            int i0, i1, i2, i3;
+            lds_swz_r4<SWZ>(e0, s, i0, i1, i2, i3);
             cx<T> u0 = p[i0], u1 = p[i1], u2 = p[i2], u3 = p[i3];
             if (s > 1) {
                 u1 = cmul(u1, tw_get<T, INV>(tw, k * twstep));
@@ -265,8 +276,8 @@ __device__ __forceinline__ void fft_dif_r(cx<T>* s_data, int nf, int pitch, cons
         const int bb = FRESH ? opaque((int)threadIdx.x) : (int)threadIdx.x;
         const int k = bb & (s - 1), g = bb / s;
         const int e0 = g * 4 * s + k;
-        const int i0 = lds_swz<SWZ>(e0), i1 = lds_swz<SWZ>(e0 + s), i2 = lds_swz<SWZ>(e0 + 2 * s),
-                  i3 = lds_swz<SWZ>(e0 + 3 * s);
+        int i0, i1, i2, i3;
+        lds_swz_r4<SWZ>(e0, s, i0, i1, i2, i3);
         const cx<T> w1 = tw_reg<T, INV>(twr[st][0]), w2 = tw_reg<T, INV>(twr[st][1]), w3 = tw_reg<T, INV>(twr[st][2]);
 #pragma unroll 4
         for (int f = 0; f < nf; ++f) {
@@ -299,8 +310,8 @@ __device__ __forceinline__ void fft_dit_r(cx<T>* s_data, int nf, int pitch, cons
         const int bb = FRESH ? opaque((int)threadIdx.x) : (int)threadIdx.x;
         const int k = bb & (s - 1), g = bb / s;
         const int e0 = g * 4 * s + k;
-        const int i0 = lds_swz<SWZ>(e0), i1 = lds_swz<SWZ>(e0 + s), i2 = lds_swz<SWZ>(e0 + 2 * s),
-                  i3 = lds_swz<SWZ>(e0 + 3 * s);
+        int i0, i1, i2, i3;
+        lds_swz_r4<SWZ>(e0, s, i0, i1, i2, i3);
         // DIT stage with span s uses the registers of the DIF stage with the same span
         const int rs = FftShape<N>::N4 - 1 - st;
         const cx<T> w1 = tw_reg<T, INV>(twr[rs][0]), w2 = tw_reg<T, INV>(twr[rs][1]), w3 = tw_reg<T, INV>(twr[rs][2]);

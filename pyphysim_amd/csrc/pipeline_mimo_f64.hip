@@ -93,8 +93,8 @@ __device__ __forceinline__ void r4_stage_planar(double* s_d, const TwRegs64& tw,
     constexpr int N = kD64N, s = S;
     const int k = bb & (s - 1), g = bb / s;
     const int e0 = g * 4 * s + k;
-    const int i0 = lds_swz64(e0), i1 = lds_swz64(e0 + s), i2 = lds_swz64(e0 + 2 * s),
-              i3 = lds_swz64(e0 + 3 * s);
+    int i0, i1, i2, i3;
+    lds_swz_r4<true>(e0, s, i0, i1, i2, i3);           // one swizzle + three XORs with per-stage constants (fft.hpp)
     double2 w1 = mk<double>(1, 0), w2 = w1, w3 = w1;
     if (s > 1) {
         if constexpr (NA == kD64NA) {                 // 256-thread form: the twelve twiddles are registers
