@@ -80,6 +80,10 @@ def kernel_name(cfg, dtype):
 KERNEL_NOTE = {   # configs whose step is two launches: the time spans both, the counters are the named (dominant) kernel's
     "c4": "a step = k_mimo_filters (channel draw + f64 receive filter per realization, 13 us = 0.8 % of the time) + k_run_mimo_ofdm_mfma; "
           "kernel_ms_per_launch spans both",
+    "f1": "a step = k_mimo_tdl_symbol_polys (the symbols' fading records, one thread per fading process) + k_run_mimo_ofdm_tdl per "
+          "slice of <= 256 MiB of records; kernel_ms_per_launch spans them",
+    "c3": "a step = k_tdl_symbol_polys (fading records) + k_run_ofdm_tdl_mfma per slice of <= 64 MiB of records; "
+          "kernel_ms_per_launch spans them",
     "c5": "a step = k_ia_solve_links (per-lane solve, ~18 % of the time) + k_ia_link (symbol walk); kernel_ms_per_launch spans both",
     "f6": "a step = k_bd_solve_links (per-lane solve) + k_bd_link (symbol walk); kernel_ms_per_launch spans both"}
 # realizations per GPU and step: sized so that a step is >= 15 ms on the fastest kernel of the configuration -- K = 20 steps

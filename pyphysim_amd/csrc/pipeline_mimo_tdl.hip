@@ -48,16 +48,86 @@ struct MimoTdlParams {
     double mom[kMaxOrder + 1];       // mean over the symbol's N+cp samples of x^m, x = j - (N+cp-1)/2
 };
 
+// The fading of one OFDM symbol in its own launch (round 3, as k_tdl_symbol_polys did for config 3): one thread per
+// (realization, symbol, fading process p = (tap s, rx r, tx a)) folds the process's L rays -- phasor at the symbol centre and
+// phase advance per sample, the f64 phase arithmetic of fading_generators.py:427-493 -- into the K + 1 polynomial
+// coefficients of g_p(x) around the centre and their mean over the symbol (the equaliser's tap).  Inside the link kernel this
+// ran on 2.5 rounds of 256 threads between three workgroup barriers per symbol: 10 % of its time for 3 % of its arithmetic.
+// Record per (realization, symbol): [PS][K + 1] coefficients, then [PS] means; same operations in the same order as before.
+template <typename T>
+__global__ __launch_bounds__(256) void k_mimo_tdl_symbol_polys(MimoTdlParams pp, int PS, int P1, int W, uint64_t seed,
+                                                               uint64_t first, uint64_t count, cx<T>* __restrict__ recs) {
+    const int L = pp.L, K = pp.K;
+    const uint64_t per_real = (uint64_t)pp.n_ofdm_sym * PS;
+    const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= count * per_real) return;
+    const uint64_t rl = q / per_real;
+    const int rem = (int)(q - rl * per_real), os = rem / PS, p = rem - os * PS;
+    const double two_pi = 6.283185307179586476925286766559;
+    const double xc = 0.5 * (double)(W - 1);
+    const double tc = pp.Ts + pp.dt * ((double)((uint64_t)os * W) + xc);
+    const Rng rng(seed, first + rl);
+    T ar[kMaxOrder + 1], ai[kMaxOrder + 1];
+#pragma unroll
+    for (int m = 0; m <= kMaxOrder; ++m) ar[m] = ai[m] = 0;
+    for (int l = 0; l < L; ++l) {
+        const uint64_t rq = (uint64_t)l * PS + p;                          // PHASE-stream index of phi
+        const double psi_t = uniform_at(rng, STREAM_PHASE, (uint64_t)L * PS + rq);
+        const double w = pp.Fd * cospi(2.0 * uniform_at(rng, STREAM_PHASE, rq));   // Hz; cos(phi), phi = 2 pi u
+        const double ph = fma(w, tc, psi_t);                               // turns
+        const double fr = __builtin_amdgcn_fract(ph);
+        T er, ei;
+        if constexpr (sizeof(T) == 8) {
+            double sn, cs;
+            sincos(two_pi * fr, &sn, &cs);
+            er = cs;
+            ei = sn;
+        } else {
+            er = __builtin_amdgcn_cosf((float)fr);
+            ei = __builtin_amdgcn_sinf((float)fr);
+        }
+        const T th = (T)(two_pi * w * pp.dt);                              // rad per sample
+#pragma unroll
+        for (int m = 0; m <= kMaxOrder; ++m)
+            if (m <= K) {
+                T pw = 1;                                                  // 1 / m! ...
+                for (int i = 2; i <= m; ++i) pw /= (T)i;
+                for (int i = 0; i < m; ++i) pw *= th;                      // ... x theta^m
+                ar[m] += er * pw;
+                ai[m] += ei * pw;
+            }
+    }
+    const T amp = (T)pp.tap_amp[p / P1];
+    cx<T>* rec = recs + (rl * pp.n_ofdm_sym + os) * (uint64_t)PS * (K + 2);
+    T mr = 0, mi = 0;
+#pragma unroll
+    for (int m = 0; m <= kMaxOrder; ++m)
+        if (m <= K) {
+            T cr, ci;                                                      // times j^m
+            switch (m & 3) {
+                case 0: cr = ar[m]; ci = ai[m]; break;
+                case 1: cr = -ai[m]; ci = ar[m]; break;
+                case 2: cr = -ar[m]; ci = -ai[m]; break;
+                default: cr = ai[m]; ci = -ar[m]; break;
+            }
+            const cx<T> c = mk<T>(amp * cr, amp * ci);
+            rec[p * (K + 1) + m] = c;
+            mr += c.x * (T)pp.mom[m];
+            mi += c.y * (T)pp.mom[m];
+        }
+    rec[PS * (K + 1) + p] = mk<T>(mr, mi);
+}
+
 template <typename T, int N, int NA>
 __global__ __launch_bounds__(kPipeBlock, sizeof(T) == 4 ? 3 : 2) void k_run_mimo_ofdm_tdl(
     MimoTdlParams pp, ModemParams<T> mp, uint64_t seed, uint64_t first, uint64_t count,
-    const cx<T>* __restrict__ g_tw, mcle_counters* counters, uint32_t* __restrict__ sym_out,
-    uint32_t* __restrict__ bit_out) {
+    const cx<T>* __restrict__ g_tw, const cx<T>* __restrict__ g_polys, mcle_counters* counters,
+    uint32_t* __restrict__ sym_out, uint32_t* __restrict__ bit_out) {
     constexpr int P1 = NA * NA;                 // fading processes per tap
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int S = pp.n_taps, L = pp.L, K = pp.K, dmax = pp.dmax;
+    const int S = pp.n_taps, K = pp.K, dmax = pp.dmax;
     const int PS = S * P1;                      // fading processes
-    cx<T>* s_x = reinterpret_cast<cx<T>*>(smem);       // [NA][N] (+ slack for the ray scratch of small FFTs)
+    cx<T>* s_x = reinterpret_cast<cx<T>*>(smem);       // [NA][N]
     // complex64 keeps the twiddle table in LDS; complex128 reads it from global (L1/L2 resident) so that a
     // second workgroup fits next to the 16-byte samples
     constexpr bool kTwLds = sizeof(T) == 4;
@@ -125,69 +195,16 @@ __global__ __launch_bounds__(kPipeBlock, sizeof(T) == 4 ? 3 : 2) void k_run_mimo
             const uint64_t sym0 = (uint64_t)os * W;
             const int tid = opaque(tid0);
             __syncthreads();
-            // ---- polynomial coefficients of every fading process around the middle of this symbol ----
-            // (1) one ray per thread: phasor at the symbol centre and phase advance per sample, parked in the
-            //     (currently idle) sample buffer; (2) one (process, order) per thread folds the rays.
+            // ---- this symbol's tap polynomials and tap means (k_mimo_tdl_symbol_polys): record -> s_coef [PS][K + 1],
+            //      s_mean [PS] (both dead since the previous symbol's demodulation; first read after the transmit transform) ----
             {
-                const double two_pi = 6.283185307179586476925286766559;
-                const double tc = pp.Ts + pp.dt * ((double)sym0 + xc);
-                T* s_ray = reinterpret_cast<T*>(s_x);                    // [PS*L][3] = {re, im, theta}
-                for (int q = tid; q < PS * L; q += kPipeBlock) {
-                    const int l = q / PS, p = q - l * PS;                 // q is the PHASE-stream index of phi
-                    const double psi_t = uniform_at(rng, STREAM_PHASE, (uint64_t)L * PS + q);
-                    const double w = pp.Fd * cospi(2.0 * uniform_at(rng, STREAM_PHASE, (uint64_t)q));   // Hz; cos(phi), phi = 2 pi u
-                    const double ph = fma(w, tc, psi_t);                  // turns
-                    const double fr = __builtin_amdgcn_fract(ph);
-                    T er, ei;
-                    if constexpr (sizeof(T) == 8) {
-                        double sn, cs;
-                        sincos(two_pi * fr, &sn, &cs);
-                        er = cs;
-                        ei = sn;
-                    } else {
-                        er = __builtin_amdgcn_cosf((float)fr);
-                        ei = __builtin_amdgcn_sinf((float)fr);
-                    }
-                    T* o = s_ray + 3 * (p * L + l);
-                    o[0] = er;
-                    o[1] = ei;
-                    o[2] = (T)(two_pi * w * pp.dt);                       // rad per sample
+                const int n_coef = PS * (K + 1), rec_len = n_coef + PS;
+                const cx<T>* rec = g_polys + (rl * pp.n_ofdm_sym + os) * (uint64_t)rec_len;
+                for (int e = tid; e < rec_len; e += kPipeBlock) {
+                    const cx<T> v = rec[e];
+                    if (e < n_coef) s_coef[e] = v;
+                    else s_mean[e - n_coef] = v;
                 }
-                __syncthreads();
-                for (int q = tid; q < PS * (K + 1); q += kPipeBlock) {
-                    const int p = q / (K + 1), m = q - p * (K + 1);
-                    T inv_fact = 1;
-                    for (int i = 2; i <= m; ++i) inv_fact /= (T)i;
-                    T ar = 0, ai = 0;
-                    for (int l = 0; l < L; ++l) {
-                        const T* o = s_ray + 3 * (p * L + l);
-                        T pw = inv_fact;
-                        for (int i = 0; i < m; ++i) pw *= o[2];
-                        ar += o[0] * pw;
-                        ai += o[1] * pw;
-                    }
-                    // times j^m
-                    T cr, ci;
-                    switch (m & 3) {
-                        case 0: cr = ar; ci = ai; break;
-                        case 1: cr = -ai; ci = ar; break;
-                        case 2: cr = -ar; ci = -ai; break;
-                        default: cr = ai; ci = -ar; break;
-                    }
-                    const T amp = (T)pp.tap_amp[p / P1];
-                    s_coef[q] = mk<T>(amp * cr, amp * ci);
-                }
-                __syncthreads();
-                for (int p = tid; p < PS; p += kPipeBlock) {
-                    T mr = 0, mi = 0;
-                    for (int m = 0; m <= K; ++m) {
-                        const cx<T> c = s_coef[p * (K + 1) + m];
-                        mr += c.x * (T)pp.mom[m];
-                        mi += c.y * (T)pp.mom[m];
-                    }
-                    s_mean[p] = mk<T>(mr, mi);
-                }
-                __syncthreads();   // the ray scratch is dead: the sample buffer may be refilled
             }
             // ---- transmit: symbols -> bins (Blast.encode's F-order split + OFDM subcarrier map) ----
             if (U != N) {
@@ -441,8 +458,7 @@ int run_mimo_tdl_impl(mcle_ctx* ctx, MimoTdlParams pp, int method, uint64_t seed
     if ((rc = ctx->get_twiddles(N, sizeof(T) == 8 ? MCLE_F64 : MCLE_F32, &tw))) return rc;
     const ModemParams<T> mp = pipe_modem<T>(ctx, method);
     const size_t PS = (size_t)pp.n_taps * NA * NA;
-    const size_t ray_elems = (PS * pp.L * 3 + 1) / 2;            // {re, im, theta} per ray, in complex elements
-    pp.x_elems = (int)(ray_elems > (size_t)NA * N ? ray_elems : (size_t)NA * N);
+    pp.x_elems = NA * N;
     const size_t GG = (size_t)mp.grid.G * mp.grid.G;
     const size_t coef_elems = sizeof(T) == 4 ? PS * (pp.K + 1) : std::max(PS * (pp.K + 1), (GG + 1) / 2);
     const size_t lds = (size_t)(pp.x_elems + (sizeof(T) == 4 ? N : 0) + coef_elems + PS + 2 * NA * (pp.dmax > 0 ? pp.dmax : 1)) * sizeof(cx<T>) +
@@ -458,10 +474,26 @@ int run_mimo_tdl_impl(mcle_ctx* ctx, MimoTdlParams pp, int method, uint64_t seed
     int per_cu = (int)((size_t)160 * 1024 / (lds + 512));
     if (per_cu < 1) per_cu = 1;
     if (per_cu > 8) per_cu = 8;
-    const unsigned grid = (unsigned)oversubscribed_grid(ctx, (uint64_t)ctx->n_cu * per_cu, count);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kPipeBlock), lds, ctx->stream, pp, mp, seed, first, count,
-                       (const cx<T>*)tw, d_counters, d_sym, d_bit);
-    MCLE_LAUNCH_CHECK();
+    // two launches per slice of realizations: the symbols' fading records (k_mimo_tdl_symbol_polys), then the links; a slice
+    // holds <= 256 MiB of records (at 64 MiB the shorter launches cost more than the split gains; 2.5 KiB per realization and symbol in complex64 at 5 taps of 4 x 4, 7.5 KiB in complex128)
+    const uint64_t per_real = (uint64_t)pp.n_ofdm_sym * PS * (pp.K + 2);     // complex values per realization
+    uint64_t slice = (256ull << 20) / (per_real * sizeof(cx<T>));
+    if (slice < 1) slice = 1;
+    if (slice > count) slice = count;
+    void* recs = nullptr;
+    if ((rc = ctx->scratch((size_t)slice * per_real * sizeof(cx<T>), &recs))) return rc;
+    for (uint64_t off = 0; off < count; off += slice) {
+        const uint64_t n = count - off < slice ? count - off : slice;
+        const uint64_t threads = n * (uint64_t)pp.n_ofdm_sym * PS;
+        hipLaunchKernelGGL(k_mimo_tdl_symbol_polys<T>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream, pp,
+                           (int)PS, NA * NA, N + pp.cp, seed, first + off, n, (cx<T>*)recs);
+        MCLE_LAUNCH_CHECK();
+        const unsigned grid = (unsigned)oversubscribed_grid(ctx, (uint64_t)ctx->n_cu * per_cu, n);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kPipeBlock), lds, ctx->stream, pp, mp, seed, first + off, n,
+                           (const cx<T>*)tw, (const cx<T>*)recs, d_counters, d_sym ? d_sym + off : nullptr,
+                           d_bit ? d_bit + off : nullptr);
+        MCLE_LAUNCH_CHECK();
+    }
     return MCLE_OK;
 }
 
