@@ -3,7 +3,7 @@
 # run and four separate `--pmc` passes (counters are never combined with tracing) of `bench.py --single-demod` on that
 # (config, dtype, demodulator); scripts/collect_profiles.py r03 condenses gpurun_out/prof_<tag>_* into profiles/r03/.
 # Batches are chosen so that a step is ONE dispatch of the dominant kernel (the two-launch pipelines slice their record buffers:
-# config 3 at 64 MiB = 419 430 realizations, complex128 config 4 at 2^18) -- the counter summaries divide per-dispatch means by
+# config 3 at 64 MiB = 419 430 realizations, complex128 config 4 at 2^18, f1 at 256 MiB = 104 857 / 34 952 realizations) -- the counter summaries divide per-dispatch means by
 # the batch.
 # usage: bash scripts/prof_r03.sh [tag ...]        (default: all)
 mkdir -p gpurun_out; export TMPDIR=/tmp
@@ -16,10 +16,10 @@ declare -A SPEC=(
   [c3_f64]="--config c3 --dtype f64 --batch 131072"
   [c2]="--config c2 --dtype f32 --batch 65536"
   [c2_f64]="--config c2 --dtype f64 --batch 16384"
-  [f1]="--config f1 --dtype f32 --demod slicer --batch 393216"
+  [f1]="--config f1 --dtype f32 --demod slicer --batch 98304"
   [c5]="--config c5 --dtype f32 --demod slicer --batch 1048576"
   [f6]="--config f6 --dtype f32 --batch 524288"
-  [f1_f64]="--config f1 --dtype f64 --batch 98304"
+  [f1_f64]="--config f1 --dtype f64 --batch 32768"
   [c5_f64]="--config c5 --dtype f64 --batch 262144"
   [f6_f64]="--config f6 --dtype f64 --batch 131072"
 )
