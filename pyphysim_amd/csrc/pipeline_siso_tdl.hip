@@ -39,13 +39,84 @@ struct SisoTdlParams {
     double mom[kSisoMaxOrder + 1];   // mean over the symbol's N+cp samples of x^m, x = j - (N+cp-1)/2
 };
 
+// The fading of a symbol, one thread per (realization, OFDM symbol, tap), in a launch of its own (round 3): the L rays of the
+// tap (f64 phase at the symbol centre, PHASE stream), their fold into the tap polynomial c_m = amp sum_l e_l (j theta_l)^m / m!
+// and the per-symbol tap mean sum_m c_m mom_m.  Inside the link kernels this work ran on a fraction of the 256 threads between
+// workgroup barriers the other wavefronts waited at, and its registers were allocated for the whole kernel.
+// Record of (realization, symbol): coef [S][K + 1], mean [S] -- S (K + 2) complex values (160 B for config 3 in complex64).
+// W = samples per OFDM symbol (FFT + CP).  Same operations in the same order as the in-kernel form it replaces.
+constexpr int kTdlMaxK = kSisoMaxOrder;
+template <typename T>
+__global__ __launch_bounds__(256) void k_tdl_symbol_polys(SisoTdlParams pp, int W, uint64_t seed, uint64_t first, uint64_t count,
+                                                          cx<T>* __restrict__ recs) {
+    const int S = pp.n_taps, L = pp.L, K = pp.K;
+    const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t per_real = (uint64_t)pp.n_ofdm_sym * S;
+    if (q >= count * per_real) return;
+    const uint64_t rl = q / per_real;
+    const int rem = (int)(q - rl * per_real), os = rem / S, s = rem - os * S;
+    const double xc = 0.5 * (double)(W - 1);
+    const double two_pi = 6.283185307179586476925286766559;
+    const double tc = pp.Ts + pp.dt * ((double)((uint64_t)os * W) + xc);
+    const Rng rng(seed, first + rl);
+    T ar[kTdlMaxK + 1], ai[kTdlMaxK + 1];
+#pragma unroll
+    for (int m = 0; m <= kTdlMaxK; ++m) ar[m] = ai[m] = 0;
+    for (int l = 0; l < L; ++l) {
+        const int rq = l * S + s;                                         // PHASE-stream index of phi
+        const double psi_t = uniform_at(rng, STREAM_PHASE, (uint64_t)L * S + rq);
+        const double wd = pp.Fd * cospi(2.0 * uniform_at(rng, STREAM_PHASE, (uint64_t)rq));   // Hz
+        const double ph = fma(wd, tc, psi_t);                             // turns
+        const double fr = __builtin_amdgcn_fract(ph);
+        T er, ei;
+        if constexpr (sizeof(T) == 8) {
+            double sn, cs;
+            sincos(two_pi * fr, &sn, &cs);
+            er = cs;
+            ei = sn;
+        } else {
+            er = __builtin_amdgcn_cosf((float)fr);
+            ei = __builtin_amdgcn_sinf((float)fr);
+        }
+        const T th = (T)(two_pi * wd * pp.dt);                            // rad per sample
+#pragma unroll
+        for (int m = 0; m <= kTdlMaxK; ++m)
+            if (m <= K) {
+                T pw = 1;                                                 // 1 / m! ...
+                for (int i = 2; i <= m; ++i) pw /= (T)i;
+                for (int i = 0; i < m; ++i) pw *= th;                     // ... x theta^m, in the order of the fused kernel
+                ar[m] += er * pw;
+                ai[m] += ei * pw;
+            }
+    }
+    const T amp = (T)pp.tap_amp[s];
+    cx<T>* rec = recs + (rl * pp.n_ofdm_sym + os) * (uint64_t)(S * (K + 2));
+    T mr = 0, mi = 0;
+#pragma unroll
+    for (int m = 0; m <= kTdlMaxK; ++m)
+        if (m <= K) {
+            T cr, ci;                                                     // times j^m
+            switch (m & 3) {
+                case 0: cr = ar[m]; ci = ai[m]; break;
+                case 1: cr = -ai[m]; ci = ar[m]; break;
+                case 2: cr = -ar[m]; ci = -ai[m]; break;
+                default: cr = ai[m]; ci = -ar[m]; break;
+            }
+            const cx<T> c = mk<T>(amp * cr, amp * ci);
+            rec[s * (K + 1) + m] = c;
+            mr += c.x * (T)pp.mom[m];
+            mi += c.y * (T)pp.mom[m];
+        }
+    rec[S * (K + 1) + s] = mk<T>(mr, mi);
+}
+
 template <typename T, int N, int NB>
 __global__ __launch_bounds__(kPipeBlock, (sizeof(T) == 4 || N <= 1024) ? 3 : 2) void k_run_ofdm_tdl_batch(
     SisoTdlParams pp, ModemParams<T> mp, uint64_t seed, uint64_t first, uint64_t count,
-    const cx<T>* __restrict__ g_tw, mcle_counters* counters, uint32_t* __restrict__ sym_out,
-    uint32_t* __restrict__ bit_out) {
+    const cx<T>* __restrict__ g_tw, const cx<T>* __restrict__ g_polys, mcle_counters* counters,
+    uint32_t* __restrict__ sym_out, uint32_t* __restrict__ bit_out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int S = pp.n_taps, L = pp.L, K = pp.K, dmax = pp.dmax;
+    const int S = pp.n_taps, K = pp.K, dmax = pp.dmax;
     const int PS = S * NB;                              // fading processes of a pass: slot a, tap s -> a*S + s
     cx<T>* s_x = reinterpret_cast<cx<T>*>(smem);       // [NB][N] (+ slack for the ray scratch of small FFTs)
     // complex64 keeps the twiddle table in LDS; complex128 reads it from global (L1/L2 resident) so that a
@@ -94,68 +165,18 @@ __global__ __launch_bounds__(kPipeBlock, (sizeof(T) == 4 || N <= 1024) ? 3 : 2) 
             const uint64_t sym0 = (uint64_t)os * W;
             const int tid = opaque(tid0);
             __syncthreads();
-            // ---- tap polynomials of this symbol: one ray per thread, then one (process, order) per thread ----
+            // ---- this symbol's tap polynomials and tap means (k_tdl_symbol_polys): slot a's record -> s_coef [a S + s][K + 1],
+            //      s_mean [a S + s] (dead since the previous symbol's equaliser; first read after the transmit transform) ----
             {
-                const double two_pi = 6.283185307179586476925286766559;
-                const double tc = pp.Ts + pp.dt * ((double)sym0 + xc);
-                T* s_ray = reinterpret_cast<T*>(s_x);                    // [PS*L][3] = {re, im, theta}
-                for (int q = tid; q < PS * L; q += kPipeBlock) {
-                    const int a = q / (S * L), rq = q - a * (S * L);      // rq = l*S + s: PHASE-stream index of phi
-                    const int l = rq / S, s = rq - l * S;
-                    const Rng rng(seed, first + base + a);
-                    const double psi_t = uniform_at(rng, STREAM_PHASE, (uint64_t)L * S + rq);
-                    const double w = pp.Fd * cospi(2.0 * uniform_at(rng, STREAM_PHASE, (uint64_t)rq));   // Hz
-                    const double ph = fma(w, tc, psi_t);                  // turns
-                    const double fr = __builtin_amdgcn_fract(ph);
-                    T er, ei;
-                    if constexpr (sizeof(T) == 8) {
-                        double sn, cs;
-                        sincos(two_pi * fr, &sn, &cs);
-                        er = cs;
-                        ei = sn;
-                    } else {
-                        er = __builtin_amdgcn_cosf((float)fr);
-                        ei = __builtin_amdgcn_sinf((float)fr);
+                const int n_coef = S * (K + 1), rec_len = n_coef + S;
+                for (int e = tid; e < NB * rec_len; e += kPipeBlock) {
+                    const int a = e / rec_len, r = e - a * rec_len;
+                    if (base + a < count) {
+                        const cx<T> v = g_polys[((base + a) * pp.n_ofdm_sym + os) * (uint64_t)rec_len + r];
+                        if (r < n_coef) s_coef[a * n_coef + r] = v;
+                        else s_mean[a * S + (r - n_coef)] = v;
                     }
-                    T* o = s_ray + 3 * ((a * S + s) * L + l);
-                    o[0] = er;
-                    o[1] = ei;
-                    o[2] = (T)(two_pi * w * pp.dt);                       // rad per sample
                 }
-                __syncthreads();
-                for (int q = tid; q < PS * (K + 1); q += kPipeBlock) {
-                    const int p = q / (K + 1), m = q - p * (K + 1);
-                    T inv_fact = 1;
-                    for (int i = 2; i <= m; ++i) inv_fact /= (T)i;
-                    T ar = 0, ai = 0;
-                    for (int l = 0; l < L; ++l) {
-                        const T* o = s_ray + 3 * (p * L + l);
-                        T pw = inv_fact;
-                        for (int i = 0; i < m; ++i) pw *= o[2];
-                        ar += o[0] * pw;
-                        ai += o[1] * pw;
-                    }
-                    T cr, ci;                                             // times j^m
-                    switch (m & 3) {
-                        case 0: cr = ar; ci = ai; break;
-                        case 1: cr = -ai; ci = ar; break;
-                        case 2: cr = -ar; ci = -ai; break;
-                        default: cr = ai; ci = -ar; break;
-                    }
-                    const T amp = (T)pp.tap_amp[p % S];
-                    s_coef[q] = mk<T>(amp * cr, amp * ci);
-                }
-                __syncthreads();
-                for (int p = tid; p < PS; p += kPipeBlock) {
-                    T mr = 0, mi = 0;
-                    for (int m = 0; m <= K; ++m) {
-                        const cx<T> c = s_coef[p * (K + 1) + m];
-                        mr += c.x * (T)pp.mom[m];
-                        mi += c.y * (T)pp.mom[m];
-                    }
-                    s_mean[p] = mk<T>(mr, mi);
-                }
-                __syncthreads();   // the ray scratch is dead: the sample buffer may be refilled
             }
             // ---- transmit: symbols -> bins, every slot from its own DATA stream ----
             if (U != N) {
@@ -379,66 +400,6 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f2 ld2(const float2* p) {
     const float2 v = *p;
     return f2{v.x, v.y};
-}
-
-// The fading of a symbol, one thread per (realization, OFDM symbol, tap), in a launch of its own (round 3): the L rays of the
-// tap (f64 phase at the symbol centre, PHASE stream), their fold into the tap polynomial c_m = amp sum_l e_l (j theta_l)^m / m!
-// and the per-symbol tap mean sum_m c_m mom_m.  Inside the main kernel this work ran on 160 + 60 + 20 of the 256 threads, in
-// f64, between workgroup barriers the other wavefronts waited at, and its registers were allocated for the whole kernel.
-// Record of (realization, symbol): coef [S][K + 1], mean [S] -- S (K + 2) complex64 (160 B for config 3).
-constexpr int kTdlMaxK = 12;
-__global__ __launch_bounds__(256) void k_tdl_symbol_polys(SisoTdlParams pp, uint64_t seed, uint64_t first, uint64_t count,
-                                                          float2* __restrict__ recs) {
-    const int S = pp.n_taps, L = pp.L, K = pp.K, W = kF16N + pp.cp;
-    const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t per_real = (uint64_t)pp.n_ofdm_sym * S;
-    if (q >= count * per_real) return;
-    const uint64_t rl = q / per_real;
-    const int rem = (int)(q - rl * per_real), os = rem / S, s = rem - os * S;
-    const double xc = 0.5 * (double)(W - 1);
-    const double two_pi = 6.283185307179586476925286766559;
-    const double tc = pp.Ts + pp.dt * ((double)((uint64_t)os * W) + xc);
-    const Rng rng(seed, first + rl);
-    float ar[kTdlMaxK + 1], ai[kTdlMaxK + 1];
-#pragma unroll
-    for (int m = 0; m <= kTdlMaxK; ++m) ar[m] = ai[m] = 0.f;
-    for (int l = 0; l < L; ++l) {
-        const int rq = l * S + s;                                         // PHASE-stream index of phi
-        const double psi_t = uniform_at(rng, STREAM_PHASE, (uint64_t)L * S + rq);
-        const double wd = pp.Fd * cospi(2.0 * uniform_at(rng, STREAM_PHASE, (uint64_t)rq));   // Hz
-        const double ph = fma(wd, tc, psi_t);                             // turns
-        const double fr = __builtin_amdgcn_fract(ph);
-        const float er = __builtin_amdgcn_cosf((float)fr), ei = __builtin_amdgcn_sinf((float)fr);
-        const float th = (float)(two_pi * wd * pp.dt);                    // rad per sample
-#pragma unroll
-        for (int m = 0; m <= kTdlMaxK; ++m)
-            if (m <= K) {
-                float pw = 1.f;                                           // 1 / m! ...
-                for (int i = 2; i <= m; ++i) pw /= (float)i;
-                for (int i = 0; i < m; ++i) pw *= th;                     // ... x theta^m, in the order of the fused kernel
-                ar[m] += er * pw;
-                ai[m] += ei * pw;
-            }
-    }
-    const float amp = (float)pp.tap_amp[s];
-    float2* rec = recs + (rl * pp.n_ofdm_sym + os) * (uint64_t)(S * (K + 2));
-    float mr = 0.f, mi = 0.f;
-#pragma unroll
-    for (int m = 0; m <= kTdlMaxK; ++m)
-        if (m <= K) {
-            float cr, ci;                                                 // times j^m
-            switch (m & 3) {
-                case 0: cr = ar[m]; ci = ai[m]; break;
-                case 1: cr = -ai[m]; ci = ar[m]; break;
-                case 2: cr = -ar[m]; ci = -ai[m]; break;
-                default: cr = ai[m]; ci = -ar[m]; break;
-            }
-            const float2 c = make_float2(amp * cr, amp * ci);
-            rec[s * (K + 1) + m] = c;
-            mr += c.x * (float)pp.mom[m];
-            mi += c.y * (float)pp.mom[m];
-        }
-    rec[S * (K + 1) + s] = make_float2(mr, mi);
 }
 
 template <int WAVES, int NB>
@@ -893,8 +854,8 @@ int run_siso_tdl_mfma(mcle_ctx* ctx, const SisoTdlParams& pp, int method, uint64
     for (uint64_t off = 0; off < count; off += slice) {
         const uint64_t n = count - off < slice ? count - off : slice;
         const uint64_t threads = n * (uint64_t)pp.n_ofdm_sym * pp.n_taps;
-        hipLaunchKernelGGL(k_tdl_symbol_polys, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream, pp, seed,
-                           first + off, n, (float2*)recs);
+        hipLaunchKernelGGL(k_tdl_symbol_polys<float>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream, pp,
+                           kF16N + pp.cp, seed, first + off, n, (float2*)recs);
         MCLE_LAUNCH_CHECK();
         const uint64_t passes = (n + NB - 1) / NB;
         const unsigned grid = (unsigned)oversubscribed_grid(ctx, (uint64_t)ctx->n_cu * per_cu, passes);
@@ -919,8 +880,7 @@ int run_siso_tdl_batch_impl(mcle_ctx* ctx, SisoTdlParams pp, int method, uint64_
     if ((rc = ctx->get_twiddles(N, sizeof(T) == 8 ? MCLE_F64 : MCLE_F32, &tw))) return rc;
     const ModemParams<T> mp = pipe_modem<T>(ctx, method);
     const size_t PS = (size_t)pp.n_taps * NB;
-    const size_t ray_elems = (PS * pp.L * 3 + 1) / 2;            // {re, im, theta} per ray, in complex elements
-    pp.x_elems = (int)(ray_elems > (size_t)NB * N ? ray_elems : (size_t)NB * N);
+    pp.x_elems = NB * N;
     const size_t lds = (size_t)(pp.x_elems + (sizeof(T) == 4 ? N : 0) + PS * (pp.K + 1) + PS + 2 * NB * (pp.dmax > 0 ? pp.dmax : 1) + kMaxTable) *
                            sizeof(cx<T>) +
                        2 * NB * (kPipeBlock / 64) * sizeof(unsigned) +
@@ -931,11 +891,26 @@ int run_siso_tdl_batch_impl(mcle_ctx* ctx, SisoTdlParams pp, int method, uint64_
     int per_cu = (int)((size_t)160 * 1024 / (lds + 512));
     if (per_cu < 1) per_cu = 1;
     if (per_cu > 8) per_cu = 8;
-    const uint64_t passes = (count + NB - 1) / NB;
-    const unsigned grid = (unsigned)oversubscribed_grid(ctx, (uint64_t)ctx->n_cu * per_cu, passes);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kPipeBlock), lds, ctx->stream, pp, mp, seed, first, count,
-                       (const cx<T>*)tw, d_counters, d_sym, d_bit);
-    MCLE_LAUNCH_CHECK();
+    // two launches per slice of realizations: the symbols' fading records (k_tdl_symbol_polys<T>), then the links
+    const uint64_t per_real = (uint64_t)pp.n_ofdm_sym * pp.n_taps * (pp.K + 2);     // complex values per realization
+    uint64_t slice = (64ull << 20) / (per_real * sizeof(cx<T>));                    // <= 64 MiB of records
+    slice = slice < (uint64_t)NB ? (uint64_t)NB : (slice / NB) * NB;
+    if (slice > count) slice = (count + NB - 1) / NB * NB;
+    void* recs = nullptr;
+    if ((rc = ctx->scratch((size_t)slice * per_real * sizeof(cx<T>), &recs))) return rc;
+    for (uint64_t off = 0; off < count; off += slice) {
+        const uint64_t n = count - off < slice ? count - off : slice;
+        const uint64_t threads = n * (uint64_t)pp.n_ofdm_sym * pp.n_taps;
+        hipLaunchKernelGGL(k_tdl_symbol_polys<T>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream, pp,
+                           N + pp.cp, seed, first + off, n, (cx<T>*)recs);
+        MCLE_LAUNCH_CHECK();
+        const uint64_t passes = (n + NB - 1) / NB;
+        const unsigned grid = (unsigned)oversubscribed_grid(ctx, (uint64_t)ctx->n_cu * per_cu, passes);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kPipeBlock), lds, ctx->stream, pp, mp, seed, first + off, n,
+                           (const cx<T>*)tw, (const cx<T>*)recs, d_counters, d_sym ? d_sym + off : nullptr,
+                           d_bit ? d_bit + off : nullptr);
+        MCLE_LAUNCH_CHECK();
+    }
     return MCLE_OK;
 }
 
