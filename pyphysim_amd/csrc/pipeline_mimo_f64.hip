@@ -216,8 +216,27 @@ __global__ __launch_bounds__(256 * (4 / AH), 2 * (4 / AH)) void k_run_mimo_ofdm_
             }
             const uint64_t n_first = (uint64_t)os * per_sym;
             const uint64_t n_last = n_first + per_sym;
+            // full band, symbol boundaries on DATA blocks: a block is the four antennas of four consecutive subcarriers
+            // d0 .. d0 + 3 (d0 a multiple of 4), whose bins differ from bin(d0) in bits 0-1 only, which the swizzle leaves
+            // alone -- one bin and one swizzle per block instead of sixteen
+            const bool aligned_scatter = U == N && (per_sym & 15) == 0;
             for (uint64_t blk = (n_first >> 4) + tid; blk <= ((n_last - 1) >> 4); blk += TB) {
                 const Words4 dw = rng.block(STREAM_DATA, (uint32_t)blk);
+                if (aligned_scatter) {
+                    const int nl0 = (int)((blk << 4) - n_first);
+                    const int pos0 = lds_swz64(ofdm_bin(nl0 / NA, N, U));
+                    *reinterpret_cast<uint4*>(s_idx + nl0) = make_uint4(dw.w[0] & (mask * 0x01010101u), dw.w[1] & (mask * 0x01010101u),
+                                                                        dw.w[2] & (mask * 0x01010101u), dw.w[3] & (mask * 0x01010101u));
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        const int tx = (int)((dw.w[j >> 2] >> ((j & 3) * 8)) & mask);
+                        const double2 c = s_txtab[tx];
+                        const int pos = pos0 ^ (j >> 2);          // NA = 4: antenna j & 3 of subcarrier d0 + (j >> 2)
+                        s_d[(2 * (j & 3)) * N + pos] = c.x;
+                        s_d[(2 * (j & 3) + 1) * N + pos] = c.y;
+                    }
+                    continue;
+                }
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {
                     const uint64_t n = (blk << 4) + j;

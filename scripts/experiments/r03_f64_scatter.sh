@@ -1,0 +1,7 @@
+#!/bin/bash
+# complex128 config-4 kernel: one bin + swizzle per DATA block in the full-band scatter
+export TMPDIR=/tmp
+timeout 900 python -m pytest tests/test_gpu_f64_kernel.py tests/test_gpu_staged_c4.py -m gpu -q --timeout=600 2>&1 | grep -E "passed|failed|FAILED|rror" | tail -3
+run() { python bench.py --steps 10 --warmup 2 --no-cpu --pmc off --single-demod "$@" 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$*', '%.4g' % d['value'], '%.3f ms' % d['roofline']['kernel_ms_per_launch'])"; }
+run --config c4 --dtype f64 --batch 262144 --demod mindist
+run --config c4 --dtype f64 --batch 262144 --demod slicer
