@@ -213,8 +213,23 @@ __global__ __launch_bounds__(kPipeBlock, sizeof(T) == 4 ? 3 : 2) void k_run_mimo
             }
             const uint64_t n_first = (uint64_t)os * per_sym;
             const uint64_t n_last = n_first + per_sym;
+            // full band, symbol boundaries on DATA blocks: the sixteen symbols of a block are the NA antennas of 16 / NA
+            // consecutive subcarriers d0 + t, whose bins are bin(d0) ^ t; digit reversal and swizzle are linear over XOR, so the
+            // block needs ONE position chain and sixteen XORs with compile-time constants
+            const bool aligned_scatter = U == N && (per_sym & 15) == 0;
             for (uint64_t blk = (n_first >> 4) + tid; blk <= ((n_last - 1) >> 4); blk += kPipeBlock) {
                 const Words4 dw = rng.block(STREAM_DATA, (uint32_t)blk);
+                if (aligned_scatter) {
+                    const int nl0 = (int)((blk << 4) - n_first);
+                    const int p0 = lds_swz<true>(fft_pos_of_index<N>(ofdm_bin(nl0 / NA, N, U)));
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        const int tx = (int)((dw.w[j >> 2] >> ((j & 3) * 8)) & mask);
+                        s_idx[nl0 + j] = (unsigned char)tx;
+                        s_x[(j % NA) * N + (p0 ^ lds_swz<true>(fft_pos_of_index<N>(j / NA)))] = cscale(table_at(tx), tx_scale);
+                    }
+                    continue;
+                }
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {
                     const uint64_t n = (blk << 4) + j;

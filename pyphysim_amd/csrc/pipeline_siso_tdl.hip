@@ -189,6 +189,17 @@ __global__ __launch_bounds__(kPipeBlock, (sizeof(T) == 4 || N <= 1024) ? 3 : 2) 
                 const Rng rng(seed, first + base + a);
                 for (uint64_t blk = (n_first >> 4) + tid; blk <= ((n_last - 1) >> 4); blk += kPipeBlock) {
                     const Words4 dw = rng.block(STREAM_DATA, (uint32_t)blk);
+                    if (U == N && (U & 15) == 0) {   // full band on block boundaries: bins bin(d0) ^ j; digit reversal and
+                        const int d0 = (int)((blk << 4) - n_first);      // swizzle are XOR-linear: one chain + 16 constants
+                        const int p0 = lds_swz<true>(fft_pos_of_index<N>(ofdm_bin(d0, N, U)));
+#pragma unroll
+                        for (int j = 0; j < 16; ++j) {
+                            const int tx = (int)((dw.w[j >> 2] >> ((j & 3) * 8)) & mask);
+                            s_idx[a * U + d0 + j] = (unsigned char)tx;
+                            s_x[a * N + (p0 ^ lds_swz<true>(fft_pos_of_index<N>(j)))] = cscale(s_table[tx], tx_scale);
+                        }
+                        continue;
+                    }
 #pragma unroll
                     for (int j = 0; j < 16; ++j) {
                         const uint64_t n = (blk << 4) + j;
