@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256 * (4 / AH), 2 * (4 / AH)) void k_run_mimo_ofdm_
             __syncthreads();
             // ---- channel: R = H T + noise on the samples that survive CP removal ----
             {
-                for (int j = opaque(tid); j < N / 2; j += TB) {
+                for (int j = tid; j < N / 2; j += TB) {
                     const int half = j / (N / 4), rest = j - half * (N / 4);
                     const int p0 = 2 * half * (N / 4) + rest, p1 = p0 + N / 4;
                     const int m0 = fft_index_of_pos<N>(p0);  // even; position p1 holds m0 + 1
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(256 * (4 / AH), 2 * (4 / AH)) void k_run_mimo_ofdm_
             __syncthreads();
             // ---- receive: Blast decode (G carries the FFT scale), demodulate, count ----
             {
-                for (int d = opaque(tid); d < U; d += TB) {
+                for (int d = tid; d < U; d += TB) {
                     const int bin = lds_swz64(ofdm_bin(d, N, U));
                     double2 y[NA];
 #pragma unroll

@@ -524,8 +524,20 @@ __global__ __launch_bounds__(kPipeBlock, sizeof(T) == 4 ? 3 : 1) void k_run_mimo
             }
             const uint64_t n_first = (uint64_t)os * per_sym;
             const uint64_t n_last = n_first + per_sym;
+            const bool aligned_scatter = U == N && (per_sym & 15) == 0 && (16 % NA) == 0;
             for (uint64_t blk = (n_first >> 4) + tid; blk <= ((n_last - 1) >> 4); blk += kPipeBlock) {
                 const Words4 dw = rng.block(STREAM_DATA, (uint32_t)blk);
+                if (aligned_scatter) {   // full band on block boundaries: bins bin(d0) ^ t, the swizzle is XOR-linear
+                    const int nl0 = (int)((blk << 4) - n_first);
+                    const int p0 = lds_swz<true>(ofdm_bin(nl0 / NA, N, U));
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        const int tx = (int)((dw.w[j >> 2] >> ((j & 3) * 8)) & mask);
+                        s_idx[nl0 + j] = (unsigned char)tx;
+                        s_x[(j % NA) * N + (p0 ^ lds_swz<true>(j / NA))] = cscale(s_table[tx], tx_scale);
+                    }
+                    continue;
+                }
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {
                     const uint64_t n = (blk << 4) + j;
