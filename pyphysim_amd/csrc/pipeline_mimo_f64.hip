@@ -88,8 +88,19 @@ __device__ __forceinline__ TwRegs64 load_tw64(const double2* __restrict__ g_tw, 
 
 // one radix-4 butterfly position of every antenna, planar LDS.
 // DIF (INV: the transmit IFFT): butterfly, then twiddle; DIT (forward FFT): twiddle, then butterfly.
+// the three twiddles of butterfly position bb at span S, fetched from the (L1-resident) table
+template <int S> __device__ __forceinline__ void stage_tw_fetch(const double2* __restrict__ g_tw, int bb, double2 (&w)[3]) {
+    constexpr int ts = kD64N / (4 * S);
+    const int k = bb & (S - 1);
+    w[0] = g_tw[k * ts];
+    w[1] = g_tw[2 * k * ts];
+    w[2] = g_tw[3 * k * ts];
+}
+// pre: twiddles fetched ahead by the caller (512-thread form, forward transform: a DIT stage multiplies FIRST, so a fetch
+// issued inside the stage sits on its critical path; issued one stage early it hides behind that stage's butterflies)
 template <bool DIF, bool INV, int S, int NA>
-__device__ __forceinline__ void r4_stage_planar(double* s_d, const TwRegs64& tw, const double2* __restrict__ g_tw, int bb) {
+__device__ __forceinline__ void r4_stage_planar(double* s_d, const TwRegs64& tw, const double2* __restrict__ g_tw, int bb,
+                                                const double2* pre = nullptr) {
     constexpr int N = kD64N, s = S;
     const int k = bb & (s - 1), g = bb / s;
     const int e0 = g * 4 * s + k;
@@ -102,6 +113,10 @@ __device__ __forceinline__ void r4_stage_planar(double* s_d, const TwRegs64& tw,
             w1 = tw.w[j][0];
             w2 = tw.w[j][1];
             w3 = tw.w[j][2];
+        } else if (pre != nullptr) {
+            w1 = pre[0];
+            w2 = pre[1];
+            w3 = pre[2];
         } else {                                      // 512-thread form (128 VGPRs): from the L1-resident table, per stage
             constexpr int ts = N / (4 * s);
             w1 = g_tw[k * ts];
@@ -263,7 +278,8 @@ __global__ __launch_bounds__(256 * (4 / AH), 2 * (4 / AH)) void k_run_mimo_ofdm_
                 }
                 wg_account(totals, ts, tb, s_rec[(buf ^ 1) * (kRec + 1) + 2 * NA * NA].x != 0.0, rl_prev, sym_out, bit_out);
             }
-            // ---- IFFT: radix-4 DIF, natural -> digit-reversed positions ----
+            // ---- IFFT: radix-4 DIF, natural -> digit-reversed positions (a DIF stage multiplies LAST: its twiddle fetch hides
+            //      behind its own butterflies -- fetching a stage ahead as the forward transform does measured no gain) ----
             r4_stage_planar<true, true, 256, AH>(s_mine, twr, g_tw, opaque(bbt));
             __syncthreads();
             r4_stage_planar<true, true, 64, AH>(s_mine, twr, g_tw, opaque(bbt));
@@ -316,15 +332,32 @@ __global__ __launch_bounds__(256 * (4 / AH), 2 * (4 / AH)) void k_run_mimo_ofdm_
             }
             __syncthreads();
             // ---- FFT: radix-4 DIT, digit-reversed -> natural bins ----
-            r4_stage_planar<false, false, 1, AH>(s_mine, twr, g_tw, opaque(bbt));
-            fft_stage_sync<TB>(4);
-            r4_stage_planar<false, false, 4, AH>(s_mine, twr, g_tw, opaque(bbt));
-            fft_stage_sync<TB>(16);
-            r4_stage_planar<false, false, 16, AH>(s_mine, twr, g_tw, opaque(bbt));
-            fft_stage_sync<TB>(64);
-            r4_stage_planar<false, false, 64, AH>(s_mine, twr, g_tw, opaque(bbt));
-            __syncthreads();
-            r4_stage_planar<false, false, 256, AH>(s_mine, twr, g_tw, opaque(bbt));
+            if constexpr (AH == NA) {
+                r4_stage_planar<false, false, 1, AH>(s_mine, twr, g_tw, opaque(bbt));
+                fft_stage_sync<TB>(4);
+                r4_stage_planar<false, false, 4, AH>(s_mine, twr, g_tw, opaque(bbt));
+                fft_stage_sync<TB>(16);
+                r4_stage_planar<false, false, 16, AH>(s_mine, twr, g_tw, opaque(bbt));
+                fft_stage_sync<TB>(64);
+                r4_stage_planar<false, false, 64, AH>(s_mine, twr, g_tw, opaque(bbt));
+                __syncthreads();
+                r4_stage_planar<false, false, 256, AH>(s_mine, twr, g_tw, opaque(bbt));
+            } else {                                  // every stage's twiddles fetched while the previous stage runs
+                double2 wa[3], wb[3];
+                stage_tw_fetch<4>(g_tw, opaque(bbt), wa);
+                r4_stage_planar<false, false, 1, AH>(s_mine, twr, g_tw, opaque(bbt));
+                stage_tw_fetch<16>(g_tw, opaque(bbt), wb);
+                fft_stage_sync<TB>(4);
+                r4_stage_planar<false, false, 4, AH>(s_mine, twr, g_tw, opaque(bbt), wa);
+                stage_tw_fetch<64>(g_tw, opaque(bbt), wa);
+                fft_stage_sync<TB>(16);
+                r4_stage_planar<false, false, 16, AH>(s_mine, twr, g_tw, opaque(bbt), wb);
+                stage_tw_fetch<256>(g_tw, opaque(bbt), wb);
+                fft_stage_sync<TB>(64);
+                r4_stage_planar<false, false, 64, AH>(s_mine, twr, g_tw, opaque(bbt), wa);
+                __syncthreads();
+                r4_stage_planar<false, false, 256, AH>(s_mine, twr, g_tw, opaque(bbt), wb);
+            }
             __syncthreads();
             // ---- receive: Blast decode (G carries the FFT scale), demodulate, count ----
             {
