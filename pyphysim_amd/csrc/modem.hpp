@@ -125,16 +125,38 @@ __device__ __forceinline__ int demod_grid(const float2* __restrict__ s_table, co
 __device__ __forceinline__ int demod_grid(const double2* __restrict__ s_table, const unsigned long long* __restrict__ s_grid,
                                           const DemodGrid& g, int M, double2 r) {
     unsigned long long w = grid_cell(s_grid, g, (float)r.x, (float)r.y);
-    const int n = (int)(w & 0xFFull);
+    const unsigned lo = (unsigned)w, hi = (unsigned)(w >> 32);
+    const int n = (int)(lo & 0xFFu);
     if (n == 0xFF) return demod_mindist<double>(s_table, M, r);
-    w >>= 8;
-    int idx = (int)(w & 0xFFull);
-    double best;
-    {
-        const double2 c = s_table[idx];
-        best = (r.x - c.x) * (r.x - c.x) + (r.y - c.y) * (r.y - c.y);
+    // the first four candidates straight-line, two at a time: their table entries are fetched together (one or two LDS round
+    // trips instead of up to three dependent ones; a wave walks its longest list anyway), short lists padded with the first
+    // candidate, which never beats itself under the strict comparison -- same order, same first minimum as the loop
+    const int idx0 = (int)((lo >> 8) & 0xFFu);
+    int idx = idx0;
+    const int m1 = n > 1 ? (int)((lo >> 16) & 0xFFu) : idx0;
+    const double2 c0 = s_table[idx0], c1 = s_table[m1];
+    double best = (r.x - c0.x) * (r.x - c0.x) + (r.y - c0.y) * (r.y - c0.y);
+    const double d1 = (r.x - c1.x) * (r.x - c1.x) + (r.y - c1.y) * (r.y - c1.y);
+    if (d1 < best) {
+        best = d1;
+        idx = m1;
     }
-    for (int j = 1; j < n; ++j) {
+    if (n > 2) {                           // small constellations rarely get here
+        const int m2 = (int)(lo >> 24), m3 = n > 3 ? (int)(hi & 0xFFu) : idx0;
+        const double2 c2 = s_table[m2], c3 = s_table[m3];
+        const double d2 = (r.x - c2.x) * (r.x - c2.x) + (r.y - c2.y) * (r.y - c2.y);
+        const double d3 = (r.x - c3.x) * (r.x - c3.x) + (r.y - c3.y) * (r.y - c3.y);
+        if (d2 < best) {
+            best = d2;
+            idx = m2;
+        }
+        if (d3 < best) {
+            best = d3;
+            idx = m3;
+        }
+    }
+    w >>= 32;
+    for (int j = 4; j < n; ++j) {          // lists of five to seven: rare (cells at a corner of four regions of a dense set)
         w >>= 8;
         const int m = (int)(w & 0xFFull);
         const double2 c = s_table[m];
