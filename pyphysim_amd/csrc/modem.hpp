@@ -97,16 +97,36 @@ __device__ __forceinline__ unsigned long long grid_cell(const unsigned long long
 __device__ __forceinline__ int demod_grid(const float2* __restrict__ s_table, const unsigned long long* __restrict__ s_grid,
                                           const DemodGrid& g, int M, float2 r) {
     unsigned long long w = grid_cell(s_grid, g, r.x, r.y);
-    const int n = (int)(w & 0xFFull);
+    const unsigned lo = (unsigned)w, hi = (unsigned)(w >> 32);
+    const int n = (int)(lo & 0xFFu);
     if (n == 0xFF) return demod_mindist<float>(s_table, M, r);
-    w >>= 8;
-    int idx = (int)(w & 0xFFull);
-    float best;
-    {
-        const float2 c = s_table[idx];
-        best = (r.x - c.x) * (r.x - c.x) + (r.y - c.y) * (r.y - c.y);
+    // first four candidates straight-line, two at a time (see the complex128 form below)
+    const int idx0 = (int)((lo >> 8) & 0xFFu);
+    int idx = idx0;
+    const int m1 = n > 1 ? (int)((lo >> 16) & 0xFFu) : idx0;
+    const float2 c0 = s_table[idx0], c1 = s_table[m1];
+    float best = (r.x - c0.x) * (r.x - c0.x) + (r.y - c0.y) * (r.y - c0.y);
+    const float d1 = (r.x - c1.x) * (r.x - c1.x) + (r.y - c1.y) * (r.y - c1.y);
+    if (d1 < best) {
+        best = d1;
+        idx = m1;
     }
-    for (int j = 1; j < n; ++j) {
+    if (n > 2) {
+        const int m2 = (int)(lo >> 24), m3 = n > 3 ? (int)(hi & 0xFFu) : idx0;
+        const float2 c2 = s_table[m2], c3 = s_table[m3];
+        const float d2 = (r.x - c2.x) * (r.x - c2.x) + (r.y - c2.y) * (r.y - c2.y);
+        const float d3 = (r.x - c3.x) * (r.x - c3.x) + (r.y - c3.y) * (r.y - c3.y);
+        if (d2 < best) {
+            best = d2;
+            idx = m2;
+        }
+        if (d3 < best) {
+            best = d3;
+            idx = m3;
+        }
+    }
+    w >>= 32;
+    for (int j = 4; j < n; ++j) {
         w >>= 8;
         const int m = (int)(w & 0xFFull);
         const float2 c = s_table[m];
