@@ -416,7 +416,9 @@ int mcle_run_mimo_flat(mcle_ctx* ctx, int dtype, const mcle_mimo_flat_cfg* cfg, 
                        uint32_t* d_sym_err, uint32_t* d_bit_err);
 
 /* Fused frequency-selective MIMO-OFDM.  Returns MCLE_E_UNSUPPORTED (and touches nothing) when the Doppler phase
- * across half an OFDM symbol is beyond the kernel's polynomial tap model: run the staged operators then. */
+ * across half an OFDM symbol is beyond the kernel's polynomial tap model: run the staged operators then.
+ * Device memory: the context's scratch buffer grows to hold the fading records of one launch slice (<= 256 MiB + 25 %;
+ * mcle_run_ofdm_tdl: <= 64 MiB); it is kept until the context is destroyed. */
 int mcle_run_mimo_ofdm_tdl(mcle_ctx* ctx, int dtype, const mcle_mimo_ofdm_tdl_cfg* cfg, uint64_t seed,
                            uint64_t first, uint64_t count, mcle_counters* d_counters,
                            uint32_t* d_sym_err, uint32_t* d_bit_err);
