@@ -86,3 +86,33 @@ def test_swizzle_is_a_bijection_and_conflict_free():
                     assert len(set((slots[q:q + 16] % 16).tolist())) == 16, (s, half, j, q)
     for base in range(0, N, 32):                          # contiguous aligned runs stay conflict free
         assert len(set((swz(base + np.arange(32)) % 32).tolist())) == 32
+
+
+def test_swizzle_and_digit_reversal_are_linear_over_xor():
+    """What lds_swz_r4 (fft.hpp) and the block-aligned symbol scatters of the fused kernels rely on: the swizzle and the
+    digit reversal are bit permutations / XOR folds, so f(a ^ b) = f(a) ^ f(b); a butterfly's four positions are
+    swz(e0) ^ swz(q s) and a DATA block's sixteen bins swz(rev(bin(d0))) ^ swz(rev(t))."""
+    for N in (64, 128, 256, 512, 1024, 2048):
+        a = np.arange(N)
+        sw = np.array([swz(int(e)) for e in a])
+        rv = np.array([pos_of_index(N, int(f)) for f in a])
+        assert sorted(sw) == list(a) and sorted(rv) == list(a)
+        for b in (1, 2, 3, 5, 16, 21, 48, N // 4, N // 2 + 3, N - 1):
+            assert np.array_equal(sw[a ^ b], sw ^ sw[b]), (N, b)
+            assert np.array_equal(rv[a ^ b], rv ^ rv[b]), (N, b)
+        # radix-4 butterfly: e0 = g 4s + k, k < s, has the two bits of q s clear, so e0 + q s = e0 ^ q s
+        s = 1
+        while 4 * s <= N:
+            for bb in range(0, N // 4, 7):
+                k, g = bb & (s - 1), bb // s
+                e0 = g * 4 * s + k
+                for q in range(4):
+                    assert e0 + q * s == e0 ^ (q * s)
+                    assert sw[e0 + q * s] == sw[e0] ^ sw[q * s]
+            s *= 4
+        # full-band scatter on a 16-symbol boundary: bin(d0 + t) = bin(d0) ^ t for d0 a multiple of 16
+        for d0 in range(0, N, 16):
+            b0 = (d0 + N // 2) % N
+            for t in range(16):
+                assert (d0 + t + N // 2) % N == b0 ^ t
+                assert sw[rv[b0 ^ t]] == sw[rv[b0]] ^ sw[rv[t]]
