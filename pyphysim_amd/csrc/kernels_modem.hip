@@ -308,7 +308,7 @@ __global__ __launch_bounds__(kBlock) void k_rand_symbols_batch(uint64_t seed, ui
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_rand_modulate_batch(ModemParams<T> mp, uint64_t seed, uint64_t first_real,
                                                                 uint32_t mask, int32_t* __restrict__ idx_out,
-                                                                cx<T>* __restrict__ sym_out, size_t n) {
+                                                                cx<T>* __restrict__ sym_out, size_t n, int vec_ok) {
     __shared__ cx<T> s_table[kMaxM];
     __shared__ __attribute__((aligned(16))) uint32_t s_lab[kBlock * 4];
     load_table(mp, s_table);
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(kBlock) void k_rand_modulate_batch(ModemParams<T> m
     const Rng rng(seed, first_real + blockIdx.y);
     int32_t* irow = idx_out + (size_t)blockIdx.y * n;
     cx<T>* srow = sym_out + (size_t)blockIdx.y * n;
-    const bool vec = (n & 1) == 0;                 // rows start on 8-byte (labels) / 16-byte (samples) boundaries
+    const bool vec = vec_ok != 0;                  // even rows on 8-byte (labels) / 16-byte (samples) boundaries (host check)
     const uint32_t mask4 = mask * 0x01010101u;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned char* bytes = reinterpret_cast<const unsigned char*>(s_lab) + wave * 1024;
@@ -546,14 +546,15 @@ int mcle_rand_modulate_batch(mcle_ctx* ctx, int dtype, uint64_t seed, uint64_t f
     if (n == 0 || count == 0) return MCLE_OK;
     if ((rc = ctx->bind())) return rc;
     dim3 grid((unsigned)grid_for(ctx, n / 16 + 1, kBlock, 2), (unsigned)count);
+    const int vec_ok = (n & 1) == 0 && ((uintptr_t)d_idx & 7u) == 0 && ((uintptr_t)d_sym & 15u) == 0;
     if (dtype == MCLE_F32)
         hipLaunchKernelGGL(k_rand_modulate_batch<float>, grid, dim3(kBlock), 0, ctx->stream,
                            modem_params<float>(ctx, MCLE_DEMOD_MINDIST), seed, first_realization, (uint32_t)(ctx->M - 1),
-                           d_idx, (float2*)d_sym, n);
+                           d_idx, (float2*)d_sym, n, vec_ok);
     else
         hipLaunchKernelGGL(k_rand_modulate_batch<double>, grid, dim3(kBlock), 0, ctx->stream,
                            modem_params<double>(ctx, MCLE_DEMOD_MINDIST), seed, first_realization, (uint32_t)(ctx->M - 1),
-                           d_idx, (double2*)d_sym, n);
+                           d_idx, (double2*)d_sym, n, vec_ok);
     MCLE_LAUNCH_CHECK();
     return MCLE_OK;
 }
