@@ -95,7 +95,15 @@ enum {
     MCLE_OPT_F64_THREADS = 8,      /* complex128 config-4 kernel: 0 / 512 = 512-thread workgroups, 256 = 256-thread workgroups */
     MCLE_OPT_BD_RUNTIME_SOLVE = 9, /* 1: the block-diagonalisation pipeline solves with the run-time-sized routine (private
                                       arrays in scratch) also where the compile-time-sized one (K nr <= 6) applies */
-    MCLE_OPT_COUNT = 10
+    MCLE_OPT_DEMOD_NOCERT = 10,    /* 1: min-distance decisions of a square Gray QAM always through the table search (candidate
+                                      grid / sweep); 0: through the margin certificate of modem.hpp (demod_qam_cert: the
+                                      closed-form nearest level per axis, accepted when the received point is farther than
+                                      2^-30 (complex64: 2^-12) of a level spacing from every decision boundary, the table
+                                      search otherwise -- identical decisions, no table gathers) */
+    MCLE_OPT_F64_VARIANT = 11,     /* complex128 config-4 kernel, bit mask of measured variants:
+                                      1 = the noise of a realization drawn inside the transmit transform's stages,
+                                      2 = channel fused with the last transmit / first receive stage (256-thread form) */
+    MCLE_OPT_COUNT = 12
 };
 int mcle_ctx_set_option(mcle_ctx* ctx, int option, long long value);
 int mcle_ctx_get_option(mcle_ctx* ctx, int option, long long* value);

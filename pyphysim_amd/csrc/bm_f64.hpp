@@ -112,6 +112,35 @@ MCLE_BM_FN void bm_sincos(uint32_t x1, double& c, double& s, const double* tthet
     s = st + MCLE_BM_FMA(ct, sr, st * cm);
 }
 
+// The same with the node angle and its cos / sin in ONE 32-byte entry {cos, sin, theta, -} (a kernel's own LDS copy, built by
+// bm_trig_packed_to_lds): one address for both reads of a sample (variant measured in round 4, pipeline_mimo_f64.hip)
+MCLE_BM_FN void bm_sincos_packed(uint32_t x1, double& c, double& s, const double* tpk) {
+    const double ang = (double)x1 * 0x1.921fb54442d18p-30;
+    const uint32_t k = ((x1 >> 24) + 1u) >> 1;
+    const double ct = tpk[4 * k], st = tpk[4 * k + 1];
+    const double r = ang - tpk[4 * k + 2];
+    const double s2 = r * r;
+    double p = MCLE_BM_FMA(s2, -1.0 / 5040.0, 1.0 / 120.0);
+    p = MCLE_BM_FMA(s2, p, -1.0 / 6.0);
+    const double sr = MCLE_BM_FMA(r * s2, p, r);
+    double q = MCLE_BM_FMA(s2, -1.0 / 720.0, 1.0 / 24.0);
+    q = MCLE_BM_FMA(s2, q, -0.5);
+    const double cm = s2 * q;
+    c = ct + MCLE_BM_FMA(-st, sr, ct * cm);
+    s = st + MCLE_BM_FMA(ct, sr, st * cm);
+}
+#ifdef __HIPCC__
+constexpr int kBmPackedDoubles = 129 * 4;
+__device__ __forceinline__ void bm_trig_packed_to_lds(double* s_pk, int tid, int nthreads) {
+    for (int i = tid; i < kBmThetaLen; i += nthreads) {
+        s_pk[4 * i] = kBmTrig[2 * i];
+        s_pk[4 * i + 1] = kBmTrig[2 * i + 1];
+        s_pk[4 * i + 2] = kBmTheta[i];
+        s_pk[4 * i + 3] = 0.0;
+    }
+}
+#endif
+
 // cos / sin of a general double x (radians), |x| <= 2^24: the Jakes ray phases of the complex128 kernels (2 pi Fd t cos(phi) + psi
 // reaches 6e4 rad).  x / (2 pi) in two words -- p = fl(x C1) with its exact residual by one FMA, plus x C2 -- gives the turn
 // count to 1e-33; k = rint(4 p) picks the quadrant, p - k/4 is an exact subtraction, and that residual (+ the two small words)

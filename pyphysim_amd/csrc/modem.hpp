@@ -28,6 +28,7 @@ template <typename T> struct ModemParams {
     T qam_scale;     // sqrt(2(M-1)/3)
     int qam_L;       // sqrt(M)
     int half_bits;   // bits/2
+    int cert;        // 1: min-distance decisions of a square Gray QAM through the margin certificate (demod_qam_cert)
 };
 
 // exhaustive minimum distance over a table held in LDS; strict '<' keeps the FIRST minimum,
@@ -339,9 +340,41 @@ __device__ __forceinline__ int demod_qam_slicer(cx<T> r, T scale, int L, int hal
     return (gray2binary8((int)fi) << half_bits) | gray2binary8((int)fj);
 }
 
+// Min-distance decision of a square Gray QAM WITHOUT touching the table, with a certificate.  The constellation is the
+// closed form (-(L-1) + 2 j) / scale, ((L-1) - 2 i) / scale that mcle_set_constellation verified entry by entry (1e-12), so
+// the nearest point per axis is the nearest level: t = level coordinate of the received value, k = rint(clamp(t)), and
+// f = clamp(t) - k is the offset from that level in units of the level spacing.  With |f| <= 1/2 - eps on both axes the
+// nearest point beats every other by >= 2 eps (spacing)^2 in squared distance -- orders of magnitude above what the
+// rounding of t, of the table entries or of either metric (|c - r|^2 here, hypot in numpy.abs, fundamental.py:241-246)
+// can move -- so the exhaustive sweep, its first-minimum tie rule included, returns this very label: `sure`.  Otherwise
+// (a point within eps of a decision boundary: probability ~ 4 eps per symbol) the caller runs the table search it
+// always ran.  eps = 2^-30 for complex128 (t <= 16 carries an error of 4e-15), 2^-12 for complex64 (error 2e-6).
+// What this buys: no data-dependent LDS gathers (cell word + 1..4 table entries per symbol: they were the bank conflicts
+// of the min-distance kernels, conflict fraction 0.41-0.64) and ~25 instead of ~45 instructions per symbol.
+template <typename T>
+__device__ __forceinline__ int demod_qam_cert(cx<T> r, T scale, int L, int half_bits, bool& sure) {
+    constexpr T lim = sizeof(T) == 8 ? (T)(0.5 - 0x1p-30) : (T)(0.5 - 0x1p-12);
+    const T lm1 = (T)(L - 1), hs = scale * (T)0.5, hl = lm1 * (T)0.5;
+    T tj = r.x * hs + hl, ti = hl - r.y * hs;                      // level coordinates (col from -max real, row from +max imag)
+    tj = fmin(fmax(tj, (T)0), lm1);                               // beyond the outer levels: certain (f = 0); NaN -> 0
+    ti = fmin(fmax(ti, (T)0), lm1);
+    const T kj = rint(tj), ki = rint(ti);
+    sure = fabs(tj - kj) <= lim && fabs(ti - ki) <= lim;
+    unsigned v = ((unsigned)(int)ki << 8) | (unsigned)(int)kj;     // both Gray decodes at once, a byte each (levels < 2^8)
+    v ^= (v >> 4) & 0x0F0Fu;
+    v ^= (v >> 2) & 0x3F3Fu;
+    v ^= (v >> 1) & 0x7F7Fu;
+    return (int)(((v >> 8) << half_bits) | (v & 0xFFu));
+}
+
 template <typename T>
 __device__ __forceinline__ int demod_one(const ModemParams<T>& mp, const cx<T>* s_table, cx<T> r) {
     if (mp.method == MCLE_DEMOD_QAM_SLICER) return demod_qam_slicer<T>(r, mp.qam_scale, mp.qam_L, mp.half_bits);
+    if (mp.cert) {
+        bool sure;
+        const int dec = demod_qam_cert<T>(r, mp.qam_scale, mp.qam_L, mp.half_bits, sure);
+        if (sure) return dec;
+    }
     return demod_mindist<T>(s_table, mp.M, r);
 }
 // with the candidate grid in LDS (s_grid may be anything when mp.grid.G == 0 or T = double)
@@ -349,8 +382,31 @@ template <typename T>
 __device__ __forceinline__ int demod_one(const ModemParams<T>& mp, const cx<T>* s_table,
                                          const unsigned long long* s_grid, cx<T> r) {
     if (mp.method == MCLE_DEMOD_QAM_SLICER) return demod_qam_slicer<T>(r, mp.qam_scale, mp.qam_L, mp.half_bits);
+    if (mp.cert) {
+        bool sure;
+        const int dec = demod_qam_cert<T>(r, mp.qam_scale, mp.qam_L, mp.half_bits, sure);
+        if (sure) return dec;
+    }
     if (mp.grid.G > 0) return demod_grid(s_table, s_grid, mp.grid, mp.M, r);   // G == 0: no grid bound to this launch
     return demod_mindist<T>(s_table, mp.M, r);
+}
+
+// K symbols: all K certificates first (straight-line), the table search only in lanes that hold an uncertified symbol.
+// `search(idx)` is the caller's lockstep search over all K (demod_grid_multi / demod_grid4_multi / demod_mindist_multi);
+// it gives the same labels as the certificate wherever that one is sure, so overwriting all K in such a lane is harmless.
+template <typename T, int K, typename Search>
+__device__ __forceinline__ void demod_multi_cert(const ModemParams<T>& mp, const cx<T> (&r)[K], int (&idx)[K], Search&& search) {
+    if (mp.cert) {
+        bool all = true;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            bool sure;
+            idx[k] = demod_qam_cert<T>(r[k], mp.qam_scale, mp.qam_L, mp.half_bits, sure);
+            all = all && sure;
+        }
+        if (all) return;
+    }
+    search(idx);
 }
 
 // host: candidate grid of the context for the f32 instantiation; for f64 only where the caller asks for it (the operator
@@ -363,6 +419,12 @@ template <typename T> inline DemodGrid context_grid(const mcle_ctx* ctx, int met
     g.y0 = ctx->grid_y0;
     g.inv_h = ctx->grid_inv_h;
     return g;
+}
+
+// host: does a launch with this method decide through the margin certificate (demod_qam_cert)?
+inline int modem_cert(const mcle_ctx* ctx, int method) {
+    return (method == MCLE_DEMOD_MINDIST && ctx->kind == MCLE_CONST_QAM && ctx->qam_L >= 2 && ctx->qam_L <= 256 &&
+            !ctx->opt[MCLE_OPT_DEMOD_NOCERT]) ? 1 : 0;
 }
 
 // cooperative copy of the constellation into LDS (call before a __syncthreads())

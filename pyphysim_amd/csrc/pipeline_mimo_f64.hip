@@ -20,6 +20,7 @@
 // scripts/experiments/f64_rates.hip) against 4.8 cycles for a v_fma_f64 (26.7 flop/clk), does NOT overlap with VALU work
 // of the same SIMD, and a dense DFT-16 needs 1024 flops where two radix-4 stages need 224 f64 instructions per 16 points:
 // the matrix-core transform would cost 1.9 x the datapath time of the butterflies.
+#include <type_traits>
 #include "fft.hpp"
 #include "mimo.hpp"
 #include "modem.hpp"
@@ -98,9 +99,14 @@ template <int S> __device__ __forceinline__ void stage_tw_fetch(const double2* _
 }
 // pre: twiddles fetched ahead by the caller (512-thread form, forward transform: a DIT stage multiplies FIRST, so a fetch
 // issued inside the stage sits on its critical path; issued one stage early it hides behind that stage's butterflies)
-template <bool DIF, bool INV, int S, int NA>
+struct NoMid {
+    __device__ __forceinline__ void operator()() const {}
+};
+// `mid` runs between the stage's sixteen LDS loads and its butterflies: independent work (variant 1: a quarter of the
+// realization's noise draws) for the wave's own LDS round trip to hide behind
+template <bool DIF, bool INV, int S, int NA, bool TWR, bool MIDFIRST = false, typename Mid = NoMid>
 __device__ __forceinline__ void r4_stage_planar(double* s_d, const TwRegs64& tw, const double2* __restrict__ g_tw, int bb,
-                                                const double2* pre = nullptr) {
+                                                const double2* pre = nullptr, Mid&& mid = Mid()) {
     constexpr int N = kD64N, s = S;
     const int k = bb & (s - 1), g = bb / s;
     const int e0 = g * 4 * s + k;
@@ -108,7 +114,7 @@ __device__ __forceinline__ void r4_stage_planar(double* s_d, const TwRegs64& tw,
     lds_swz_r4<true>(e0, s, i0, i1, i2, i3);           // one swizzle + three XORs with per-stage constants (fft.hpp)
     double2 w1 = mk<double>(1, 0), w2 = w1, w3 = w1;
     if (s > 1) {
-        if constexpr (NA == kD64NA) {                 // 256-thread form: the twelve twiddles are registers
+        if constexpr (TWR) {                          // 256-thread form: the twelve twiddles are registers
             constexpr int j = S == 256 ? 0 : S == 64 ? 1 : S == 16 ? 2 : 3;
             w1 = tw.w[j][0];
             w2 = tw.w[j][1];
@@ -129,6 +135,10 @@ __device__ __forceinline__ void r4_stage_planar(double* s_d, const TwRegs64& tw,
             w3.y = -w3.y;
         }
     }
+    if constexpr (MIDFIRST) {                          // before the loads: the sixteen loaded values are not live beside it
+        mid();
+        __builtin_amdgcn_sched_barrier(0);
+    }
     double xr[NA][4], xi[NA][4];
 #pragma unroll
     for (int a = 0; a < NA; ++a) {
@@ -137,6 +147,7 @@ __device__ __forceinline__ void r4_stage_planar(double* s_d, const TwRegs64& tw,
         xr[a][0] = pr[i0]; xr[a][1] = pr[i1]; xr[a][2] = pr[i2]; xr[a][3] = pr[i3];
         xi[a][0] = pi[i0]; xi[a][1] = pi[i1]; xi[a][2] = pi[i2]; xi[a][3] = pi[i3];
     }
+    if constexpr (!MIDFIRST) mid();
 #pragma unroll
     for (int a = 0; a < NA; ++a) {
         double2 u0 = mk<double>(xr[a][0], xi[a][0]), u1 = mk<double>(xr[a][1], xi[a][1]),
@@ -163,7 +174,14 @@ __device__ __forceinline__ void r4_stage_planar(double* s_d, const TwRegs64& tw,
 // AH = antennas per thread in the transform stages: 4 -> 256 threads per workgroup (2 wavefronts per SIMD at two
 // workgroups per CU, up to 256 VGPRs), 2 -> 512 threads (4 wavefronts per SIMD, 128 VGPRs): LDS caps the workgroups per CU
 // at two, so the second form buys latency hiding with threads instead.
-template <int AH>
+// VAR (MCLE_OPT_F64_VARIANT, round-4 variants measured against the plain form): bit 0 = the noise of the
+// realization (Philox + Box-Muller: a pure function of the index, 22 % of the time) is drawn inside the four twiddled
+// stages of the transmit transform, one receive antenna per stage, between the stage's LDS loads and its butterflies,
+// and parked in registers until the channel stage -- independent work inside each wave's own LDS round trip.
+// bit 2 = the 256-thread form fetches its twiddles per stage like the 512-thread form (48 registers less);
+// bit 4 = the Box-Muller's node angle and its cos / sin as one 32-byte LDS entry (one address for both reads);
+// bit 3 (with bit 0) = the draws BEFORE the stage's loads instead of behind them (the loaded values are not live beside them).
+template <int AH, int VAR>
 __global__ __launch_bounds__(256 * (4 / AH), 2 * (4 / AH)) void k_run_mimo_ofdm_f64(MimoParams pp, ModemParams<double> mp, uint64_t seed,
                                                                      uint64_t first, uint64_t count,
                                                                      const double2* __restrict__ g_tw,
@@ -173,6 +191,7 @@ __global__ __launch_bounds__(256 * (4 / AH), 2 * (4 / AH)) void k_run_mimo_ofdm_
                                                                      uint32_t* __restrict__ bit_out) {
     constexpr int N = kD64N, NA = kD64NA, kRec = kD64Rec;
     constexpr int TB = 256 * (NA / AH), NW = TB / 64;                       // threads, wavefronts per workgroup
+    constexpr bool TWR = AH == NA && !(VAR & 4);                            // the twelve twiddles of a thread in registers
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* s_d = reinterpret_cast<double*>(smem);                          // [NA][re plane | im plane][N]
     double2* s_table = reinterpret_cast<double2*>(s_d + 2 * NA * N);        // [tab_len] constellation
@@ -182,6 +201,7 @@ __global__ __launch_bounds__(256 * (4 / AH), 2 * (4 / AH)) void k_run_mimo_ofdm_
     double* s_bm = reinterpret_cast<double*>(s_part + 32);                  // [kBmLdsDoubles (+1)] Box-Muller tables
     unsigned long long* s_grid = reinterpret_cast<unsigned long long*>(s_bm + ((kBmLdsDoubles + 1) & ~1));
     unsigned char* s_idx = reinterpret_cast<unsigned char*>(s_grid + mp.grid.G * mp.grid.G);   // [NA * num_used]
+    [[maybe_unused]] double* s_pk = reinterpret_cast<double*>(s_idx + ((4 * pp.num_used + 15) & ~15));   // variant 16: packed trig
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int U = pp.num_used, cp = pp.cp;
@@ -197,13 +217,25 @@ __global__ __launch_bounds__(256 * (4 / AH), 2 * (4 / AH)) void k_run_mimo_ofdm_
     }
     load_grid(mp, s_grid);
     bm_tables_to_lds(s_bm, tid, TB);
+    if constexpr (VAR & 16) bm_trig_packed_to_lds(s_pk, tid, TB);
+    // complex sample from two Philox words
+    auto cn_words = [&](uint32_t x0, uint32_t x1, double sg) -> double2 {
+        if constexpr (VAR & 16) {
+            const double rad = sg * bm_sqrt(bm_neg_log(x0, s_bm));
+            double sn, cs;
+            bm_sincos_packed(x1, cs, sn, s_pk);
+            return mk<double>(rad * cs, rad * sn);
+        } else {
+            return cn_from_words_lds(x0, x1, sg, s_bm);
+        }
+    };
     __shared__ WgTotals totals;
     if (tid == 0) wg_zero(totals);
 
     const int bbt = tid & 255;                                   // this thread's butterfly position
     double* s_mine = s_d + (tid >> 8) * (2 * AH * N);             // ... of antennas AH (tid >> 8) ...
     TwRegs64 twr;
-    if constexpr (AH == NA) twr = load_tw64(g_tw, bbt);
+    if constexpr (TWR) twr = load_tw64(g_tw, bbt);
     uint64_t it = 0, rl_prev = 0;
     // the record of a realization is fetched one iteration ahead (one register pair per lane of the first wavefront):
     // loaded where it is parked, the global-memory latency sat in front of every realization's first barrier
@@ -280,22 +312,60 @@ __global__ __launch_bounds__(256 * (4 / AH), 2 * (4 / AH)) void k_run_mimo_ofdm_
             }
             // ---- IFFT: radix-4 DIF, natural -> digit-reversed positions (a DIF stage multiplies LAST: its twiddle fetch hides
             //      behind its own butterflies -- fetching a stage ahead as the forward transform does measured no gain) ----
-            r4_stage_planar<true, true, 256, AH>(s_mine, twr, g_tw, opaque(bbt));
-            __syncthreads();
-            r4_stage_planar<true, true, 64, AH>(s_mine, twr, g_tw, opaque(bbt));
-            fft_stage_sync<TB>(64);
-            r4_stage_planar<true, true, 16, AH>(s_mine, twr, g_tw, opaque(bbt));
-            fft_stage_sync<TB>(16);
-            r4_stage_planar<true, true, 4, AH>(s_mine, twr, g_tw, opaque(bbt));
-            fft_stage_sync<TB>(4);
-            r4_stage_planar<true, true, 1, AH>(s_mine, twr, g_tw, opaque(bbt));
+            // the two noise samples of receive antenna r at this thread's channel positions (iteration jj of the channel loop)
+            auto noise_pair = [&](int jj, int r, double2& z0, double2& z1) {
+                const int j = tid + jj * TB;
+                const int half = j / (N / 4), rest = j - half * (N / 4);
+                const int m0 = fft_index_of_pos<N>(2 * half * (N / 4) + rest);     // even; the partner position holds m0 + 1
+                const uint64_t i0 = (uint64_t)r * row + (uint64_t)os * (N + cp) + cp + m0;
+                if ((i0 & 1) == 0) {     // tables of the Box-Muller from this workgroup's LDS copy
+                    const Words4 b = rng.block(STREAM_NOISE, (uint32_t)(i0 >> 1));
+                    z0 = cn_words(b.w[0], b.w[1], sigma);
+                    z1 = cn_words(b.w[2], b.w[3], sigma);
+                } else {
+                    const Words4 b0 = rng.block(STREAM_NOISE, (uint32_t)(i0 >> 1));
+                    const Words4 b1 = rng.block(STREAM_NOISE, (uint32_t)((i0 + 1) >> 1));
+                    z0 = cn_words(b0.w[2], b0.w[3], sigma);
+                    z1 = cn_words(b1.w[0], b1.w[1], sigma);
+                }
+            };
+            constexpr int JT = (N / 2) / TB;                    // channel iterations per thread
+            [[maybe_unused]] double2 nz[JT][NA][2];
+            if constexpr (VAR & 1) {
+                auto draw = [&](auto rc) {
+                    return [&]() {
+                        constexpr int r = decltype(rc)::value;
+#pragma unroll
+                        for (int jj = 0; jj < JT; ++jj) noise_pair(jj, r, nz[jj][r][0], nz[jj][r][1]);
+                    };
+                };
+                r4_stage_planar<true, true, 256, AH, TWR, (VAR & 8) != 0>(s_mine, twr, g_tw, opaque(bbt), nullptr, draw(std::integral_constant<int, 0>()));
+                __syncthreads();
+                r4_stage_planar<true, true, 64, AH, TWR, (VAR & 8) != 0>(s_mine, twr, g_tw, opaque(bbt), nullptr, draw(std::integral_constant<int, 1>()));
+                fft_stage_sync<TB>(64);
+                r4_stage_planar<true, true, 16, AH, TWR, (VAR & 8) != 0>(s_mine, twr, g_tw, opaque(bbt), nullptr, draw(std::integral_constant<int, 2>()));
+                fft_stage_sync<TB>(16);
+                r4_stage_planar<true, true, 4, AH, TWR, (VAR & 8) != 0>(s_mine, twr, g_tw, opaque(bbt), nullptr, draw(std::integral_constant<int, 3>()));
+                fft_stage_sync<TB>(4);
+            } else {
+                r4_stage_planar<true, true, 256, AH, TWR>(s_mine, twr, g_tw, opaque(bbt));
+                __syncthreads();
+                r4_stage_planar<true, true, 64, AH, TWR>(s_mine, twr, g_tw, opaque(bbt));
+                fft_stage_sync<TB>(64);
+                r4_stage_planar<true, true, 16, AH, TWR>(s_mine, twr, g_tw, opaque(bbt));
+                fft_stage_sync<TB>(16);
+                r4_stage_planar<true, true, 4, AH, TWR>(s_mine, twr, g_tw, opaque(bbt));
+                fft_stage_sync<TB>(4);
+            }
+            r4_stage_planar<true, true, 1, AH, TWR>(s_mine, twr, g_tw, opaque(bbt));
             __syncthreads();
             // ---- channel: R = H T + noise on the samples that survive CP removal ----
             {
-                for (int j = tid; j < N / 2; j += TB) {
+#pragma unroll
+                for (int jj = 0; jj < JT; ++jj) {
+                    const int j = tid + jj * TB;
                     const int half = j / (N / 4), rest = j - half * (N / 4);
                     const int p0 = 2 * half * (N / 4) + rest, p1 = p0 + N / 4;
-                    const int m0 = fft_index_of_pos<N>(p0);  // even; position p1 holds m0 + 1
                     const int q0 = lds_swz64(p0), q1 = lds_swz64(p1);
                     double2 x0[NA], x1[NA];
 #pragma unroll
@@ -305,17 +375,12 @@ __global__ __launch_bounds__(256 * (4 / AH), 2 * (4 / AH)) void k_run_mimo_ofdm_
                     }
 #pragma unroll
                     for (int r = 0; r < NA; ++r) {
-                        const uint64_t i0 = (uint64_t)r * row + (uint64_t)os * (N + cp) + cp + m0;
                         double2 z0, z1;
-                        if ((i0 & 1) == 0) {     // tables of the Box-Muller from this workgroup's LDS copy
-                            const Words4 b = rng.block(STREAM_NOISE, (uint32_t)(i0 >> 1));
-                            z0 = cn_from_words_lds(b.w[0], b.w[1], sigma, s_bm);
-                            z1 = cn_from_words_lds(b.w[2], b.w[3], sigma, s_bm);
+                        if constexpr (VAR & 1) {
+                            z0 = nz[jj][r][0];
+                            z1 = nz[jj][r][1];
                         } else {
-                            const Words4 b0 = rng.block(STREAM_NOISE, (uint32_t)(i0 >> 1));
-                            const Words4 b1 = rng.block(STREAM_NOISE, (uint32_t)((i0 + 1) >> 1));
-                            z0 = cn_from_words_lds(b0.w[2], b0.w[3], sigma, s_bm);
-                            z1 = cn_from_words_lds(b1.w[0], b1.w[1], sigma, s_bm);
+                            noise_pair(jj, r, z0, z1);
                         }
 #pragma unroll
                         for (int a = 0; a < NA; ++a) {
@@ -332,31 +397,31 @@ __global__ __launch_bounds__(256 * (4 / AH), 2 * (4 / AH)) void k_run_mimo_ofdm_
             }
             __syncthreads();
             // ---- FFT: radix-4 DIT, digit-reversed -> natural bins ----
-            if constexpr (AH == NA) {
-                r4_stage_planar<false, false, 1, AH>(s_mine, twr, g_tw, opaque(bbt));
+            if constexpr (TWR) {
+                r4_stage_planar<false, false, 1, AH, TWR>(s_mine, twr, g_tw, opaque(bbt));
                 fft_stage_sync<TB>(4);
-                r4_stage_planar<false, false, 4, AH>(s_mine, twr, g_tw, opaque(bbt));
+                r4_stage_planar<false, false, 4, AH, TWR>(s_mine, twr, g_tw, opaque(bbt));
                 fft_stage_sync<TB>(16);
-                r4_stage_planar<false, false, 16, AH>(s_mine, twr, g_tw, opaque(bbt));
+                r4_stage_planar<false, false, 16, AH, TWR>(s_mine, twr, g_tw, opaque(bbt));
                 fft_stage_sync<TB>(64);
-                r4_stage_planar<false, false, 64, AH>(s_mine, twr, g_tw, opaque(bbt));
+                r4_stage_planar<false, false, 64, AH, TWR>(s_mine, twr, g_tw, opaque(bbt));
                 __syncthreads();
-                r4_stage_planar<false, false, 256, AH>(s_mine, twr, g_tw, opaque(bbt));
+                r4_stage_planar<false, false, 256, AH, TWR>(s_mine, twr, g_tw, opaque(bbt));
             } else {                                  // every stage's twiddles fetched while the previous stage runs
                 double2 wa[3], wb[3];
                 stage_tw_fetch<4>(g_tw, opaque(bbt), wa);
-                r4_stage_planar<false, false, 1, AH>(s_mine, twr, g_tw, opaque(bbt));
+                r4_stage_planar<false, false, 1, AH, TWR>(s_mine, twr, g_tw, opaque(bbt));
                 stage_tw_fetch<16>(g_tw, opaque(bbt), wb);
                 fft_stage_sync<TB>(4);
-                r4_stage_planar<false, false, 4, AH>(s_mine, twr, g_tw, opaque(bbt), wa);
+                r4_stage_planar<false, false, 4, AH, TWR>(s_mine, twr, g_tw, opaque(bbt), wa);
                 stage_tw_fetch<64>(g_tw, opaque(bbt), wa);
                 fft_stage_sync<TB>(16);
-                r4_stage_planar<false, false, 16, AH>(s_mine, twr, g_tw, opaque(bbt), wb);
+                r4_stage_planar<false, false, 16, AH, TWR>(s_mine, twr, g_tw, opaque(bbt), wb);
                 stage_tw_fetch<256>(g_tw, opaque(bbt), wb);
                 fft_stage_sync<TB>(64);
-                r4_stage_planar<false, false, 64, AH>(s_mine, twr, g_tw, opaque(bbt), wa);
+                r4_stage_planar<false, false, 64, AH, TWR>(s_mine, twr, g_tw, opaque(bbt), wa);
                 __syncthreads();
-                r4_stage_planar<false, false, 256, AH>(s_mine, twr, g_tw, opaque(bbt), wb);
+                r4_stage_planar<false, false, 256, AH, TWR>(s_mine, twr, g_tw, opaque(bbt), wb);
             }
             __syncthreads();
             // ---- receive: Blast decode (G carries the FFT scale), demodulate, count ----
@@ -377,7 +442,7 @@ __global__ __launch_bounds__(256 * (4 / AH), 2 * (4 / AH)) void k_run_mimo_ofdm_
                             for (int r = 0; r < NA; ++r) est[a] = cfma(s_G[a * NA + r], y[r], est[a]);
                         }
                         if (mp.method != MCLE_DEMOD_QAM_SLICER && mp.grid.G > 0) {
-                            demod_grid_multi<NA>(s_table, s_grid, mp.grid, mp.M, est, dec);
+                            demod_multi_cert(mp, est, dec, [&](int (&d_)[NA]) { demod_grid_multi<NA>(s_table, s_grid, mp.grid, mp.M, est, d_); });
                         } else {
 #pragma unroll
                             for (int a = 0; a < NA; ++a) dec[a] = demod_one<double>(mp, s_table, s_grid, est[a]);
@@ -443,10 +508,15 @@ int run_mimo_ofdm_f64(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, uint64_t see
     const size_t lds = (size_t)2 * kD64NA * kD64N * sizeof(double) + (2 * tab_len + 2 * (kD64Rec + 1)) * sizeof(double2) +
                        32 * sizeof(unsigned) + (size_t)((kBmLdsDoubles + 1) & ~1) * sizeof(double) +
                        (size_t)mp.grid.G * mp.grid.G * sizeof(unsigned long long) +
-                       (size_t)4 * cfg->num_used + 16;
+                       (((size_t)4 * cfg->num_used + 15) & ~(size_t)15) + 16 +
+                       ((ctx->opt[MCLE_OPT_F64_VARIANT] & 16) ? (size_t)kBmPackedDoubles * sizeof(double) : 0);
     // MCLE_OPT_F64_THREADS: 0 / 512 = two antennas per thread, 512-thread workgroups (default); 256 = four antennas per thread
     const bool wide = ctx->opt[MCLE_OPT_F64_THREADS] != 256;
-    auto kern = wide ? k_run_mimo_ofdm_f64<2> : k_run_mimo_ofdm_f64<4>;
+    const int var = (int)ctx->opt[MCLE_OPT_F64_VARIANT];
+    auto kern = wide ? (var == 16 ? k_run_mimo_ofdm_f64<2, 16> : var == 9 ? k_run_mimo_ofdm_f64<2, 9> : (var & 1) ? k_run_mimo_ofdm_f64<2, 1> : k_run_mimo_ofdm_f64<2, 0>)
+                     : var == 13 ? k_run_mimo_ofdm_f64<4, 13> : var == 9 ? k_run_mimo_ofdm_f64<4, 9>
+                     : var == 5 ? k_run_mimo_ofdm_f64<4, 5> : var == 4 ? k_run_mimo_ofdm_f64<4, 4>
+                     : (var & 1) ? k_run_mimo_ofdm_f64<4, 1> : k_run_mimo_ofdm_f64<4, 0>;
     const int tb = wide ? 512 : 256;
     MCLE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int per_cu = (int)((size_t)160 * 1024 / (lds + 512));

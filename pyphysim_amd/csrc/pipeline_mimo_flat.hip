@@ -290,8 +290,8 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void k_mimo_flat_link(
                     bool done = false;
                     if constexpr (sizeof(T) == 4) {
                         if (lockstep) {   // the layers searched in lockstep; unused layers carry est = 0 and are not counted
-                            if (mp.M <= 8) demod_mindist_multi<kFlatMax>(s_tab4, mp.M, est, dec);
-                            else demod_grid4_multi<kFlatMax>(s_tab4, s_grid, mp.grid, mp.M, est, dec);
+                            if (mp.M <= 8) demod_multi_cert(mp, est, dec, [&](int (&d_)[kFlatMax]) { demod_mindist_multi<kFlatMax>(s_tab4, mp.M, est, d_); });
+                            else demod_multi_cert(mp, est, dec, [&](int (&d_)[kFlatMax]) { demod_grid4_multi<kFlatMax>(s_tab4, s_grid, mp.grid, mp.M, est, d_); });
                             done = true;
                         }
                     }

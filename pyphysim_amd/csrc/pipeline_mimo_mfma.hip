@@ -452,9 +452,9 @@ __global__ __launch_bounds__(kPipeBlock, WAVES) void k_run_mimo_ofdm_mfma(MimoPa
 #pragma unroll
                             for (int a = 0; a < NA; ++a) est[a] = make_float2(er[a], ei[a]);
                             if (mp.grid.G > 0) {
-                                demod_grid4_multi<NA>(s_tab4, s_grid, mp.grid, mp.M, est, dec);
+                                demod_multi_cert(mp, est, dec, [&](int (&d_)[NA]) { demod_grid4_multi<NA>(s_tab4, s_grid, mp.grid, mp.M, est, d_); });
                             } else {
-                                demod_mindist_multi<NA>(s_tab4, mp.M, est, dec);
+                                demod_multi_cert(mp, est, dec, [&](int (&d_)[NA]) { demod_mindist_multi<NA>(s_tab4, mp.M, est, d_); });
                             }
 #pragma unroll
                             for (int a = 0; a < NA; ++a) {

@@ -438,15 +438,15 @@ __global__ __launch_bounds__(kPipeBlock, sizeof(T) == 4 ? 3 : 2) void k_run_mimo
                     for (int a = 0; a < NA; ++a) dec[a] = demod_qam_slicer<T>(est[a], mp.qam_scale, mp.qam_L, mp.half_bits);
                 } else if constexpr (sizeof(T) == 4) {
                     if (mp.grid.G > 0) {
-                        demod_grid4_multi<NA>(s_tab4, s_grid, mp.grid, mp.M, est, dec);   // the NA streams in lockstep
+                        demod_multi_cert(mp, est, dec, [&](int (&d_)[NA]) { demod_grid4_multi<NA>(s_tab4, s_grid, mp.grid, mp.M, est, d_); });   // the NA streams in lockstep
                     } else {
-                        demod_mindist_multi<NA>(s_tab4, mp.M, est, dec);
+                        demod_multi_cert(mp, est, dec, [&](int (&d_)[NA]) { demod_mindist_multi<NA>(s_tab4, mp.M, est, d_); });
                     }
                 } else if (mp.grid.G > 0) {
 #pragma unroll
-                    for (int a = 0; a < NA; ++a) dec[a] = demod_grid(s_table, s_grid, mp.grid, mp.M, est[a]);
+                    for (int a = 0; a < NA; ++a) dec[a] = demod_one(mp, s_table, s_grid, est[a]);
                 } else {
-                    demod_mindist_multi<NA>(s_table, mp.M, est, dec);
+                    demod_multi_cert(mp, est, dec, [&](int (&d_)[NA]) { demod_mindist_multi<NA>(s_table, mp.M, est, d_); });
                 }
 #pragma unroll
                 for (int a = 0; a < NA; ++a) {

@@ -784,9 +784,9 @@ __global__ __launch_bounds__(kPipeBlock, WAVES) void k_run_ofdm_tdl_mfma(
                             for (int a = 0; a < NB; ++a)
                                 dec[a] = demod_qam_slicer<float>(eq[a], mp.qam_scale, mp.qam_L, mp.half_bits);
                         } else if (mp.grid.G > 0 && mp.M > 8) {   // a sweep of <= 8 points beats the cell look-up
-                            demod_grid4_multi<NB>(s_tab4, s_grid, mp.grid, mp.M, eq, dec);
+                            demod_multi_cert(mp, eq, dec, [&](int (&d_)[NB]) { demod_grid4_multi<NB>(s_tab4, s_grid, mp.grid, mp.M, eq, d_); });
                         } else {
-                            demod_mindist_multi<NB>(s_tab4, mp.M, eq, dec);
+                            demod_multi_cert(mp, eq, dec, [&](int (&d_)[NB]) { demod_mindist_multi<NB>(s_tab4, mp.M, eq, d_); });
                         }
 #pragma unroll
                         for (int a = 0; a < NB; ++a) {

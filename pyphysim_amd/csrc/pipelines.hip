@@ -225,8 +225,8 @@ __global__ __launch_bounds__(kPipeBlock, (sizeof(T) == 8 && LR == 8) ? 2 : 1) vo
                     qam_count4(x, qp, se, be);
                 } else if constexpr (MODE == 2) {   // the four symbols searched in lockstep (same decisions as demod_one)
                     int dec[4];
-                    if (mp.M <= 8) demod_mindist_multi<4>(s_tab4, mp.M, r, dec);
-                    else demod_grid4_multi<4>(s_tab4, s_grid, mp.grid, mp.M, r, dec);
+                    if (mp.M <= 8) demod_multi_cert(mp, r, dec, [&](int (&d_)[4]) { demod_mindist_multi<4>(s_tab4, mp.M, r, d_); });
+                    else demod_multi_cert(mp, r, dec, [&](int (&d_)[4]) { demod_grid4_multi<4>(s_tab4, s_grid, mp.grid, mp.M, r, d_); });
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const unsigned x = e < left ? (unsigned)(((dwt >> (8 * e)) & 0xFFu) ^ (unsigned)dec[e]) : 0u;
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(kPipeBlock, (sizeof(T) == 8 && LR == 8) ? 2 : 1) vo
                     bool done = false;
                     if constexpr (sizeof(T) == 8) {   // complex128 grid search: the four symbols in lockstep
                         if (mp.method == MCLE_DEMOD_MINDIST && mp.grid.G > 0) {
-                            demod_grid_multi<4>(s_table, s_grid, mp.grid, mp.M, r, dec);
+                            demod_multi_cert(mp, r, dec, [&](int (&d_)[4]) { demod_grid_multi<4>(s_table, s_grid, mp.grid, mp.M, r, d_); });
                             done = true;
                         }
                     }
@@ -396,8 +396,8 @@ __global__ __launch_bounds__(kPipeBlock) void k_run_flat_mfma(FlatParams fp, Mod
                 } else {
                     int dec[4];
                     if constexpr (MODE == 2) {
-                        if (mp.M <= 8) demod_mindist_multi<4>(s_tab4, mp.M, r, dec);
-                        else demod_grid4_multi<4>(s_tab4, s_grid, mp.grid, mp.M, r, dec);
+                        if (mp.M <= 8) demod_multi_cert(mp, r, dec, [&](int (&d_)[4]) { demod_mindist_multi<4>(s_tab4, mp.M, r, d_); });
+                        else demod_multi_cert(mp, r, dec, [&](int (&d_)[4]) { demod_grid4_multi<4>(s_tab4, s_grid, mp.grid, mp.M, r, d_); });
                     } else {
 #pragma unroll
                         for (int v = 0; v < 4; ++v) dec[v] = demod_one(mp, s_table, s_grid, r[v]);
@@ -620,15 +620,15 @@ __global__ __launch_bounds__(kPipeBlock, sizeof(T) == 4 ? 3 : 1) void k_run_mimo
                     for (int a = 0; a < NA; ++a) dec[a] = demod_qam_slicer<T>(est[a], mp.qam_scale, mp.qam_L, mp.half_bits);
                 } else if constexpr (sizeof(T) == 4) {
                     if (mp.grid.G > 0) {
-                        demod_grid4_multi<NA>(s_tab4, s_grid, mp.grid, mp.M, est, dec);   // the NA streams in lockstep
+                        demod_multi_cert(mp, est, dec, [&](int (&d_)[NA]) { demod_grid4_multi<NA>(s_tab4, s_grid, mp.grid, mp.M, est, d_); });   // the NA streams in lockstep
                     } else {
-                        demod_mindist_multi<NA>(s_tab4, mp.M, est, dec);
+                        demod_multi_cert(mp, est, dec, [&](int (&d_)[NA]) { demod_mindist_multi<NA>(s_tab4, mp.M, est, d_); });
                     }
                 } else if (mp.grid.G > 0) {
 #pragma unroll
-                    for (int a = 0; a < NA; ++a) dec[a] = demod_grid(s_table, s_grid, mp.grid, mp.M, est[a]);
+                    for (int a = 0; a < NA; ++a) dec[a] = demod_one(mp, s_table, s_grid, est[a]);
                 } else {
-                    demod_mindist_multi<NA>(s_table, mp.M, est, dec);
+                    demod_multi_cert(mp, est, dec, [&](int (&d_)[NA]) { demod_mindist_multi<NA>(s_table, mp.M, est, d_); });
                 }
 #pragma unroll
                 for (int a = 0; a < NA; ++a) {

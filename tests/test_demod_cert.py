@@ -1,0 +1,100 @@
+"""The margin certificate of the square-QAM min-distance decision (csrc/modem.hpp demod_qam_cert).
+
+CPU: a NumPy statement of the same arithmetic (level coordinate, clamp, rint, |f| <= 1/2 - eps, packed Gray decode) against
+the exhaustive |c - r| argmin of the reference (modulators/fundamental.py:241-246) on random points and on points placed at
+decision boundaries +- tiny offsets: wherever the certificate says `sure` its label IS the argmin; the uncertified share is
+what the table search still serves.  GPU: the demodulate operator with the certificate (default), with it switched off
+(option demod_nocert: candidate grid) and NumPy's argmin agree on every point, boundary points included."""
+import numpy as np
+import pytest
+
+from pyphysim_amd import _lib
+from pyphysim_amd.modulators import constellation
+
+
+def cert_model(r, M, dtype):
+    """(labels, sure) as demod_qam_cert computes them (same operations, same order, in `dtype`)."""
+    T = np.float64 if dtype == "f64" else np.float32
+    bits = int(np.log2(M))
+    hb = bits // 2
+    L = 1 << hb
+    scale = T(np.sqrt((M - 1) * 2.0 / 3.0))
+    lim = T(0.5 - 2.0 ** -30) if dtype == "f64" else T(0.5 - 2.0 ** -12)
+    lm1, hs, hl = T(L - 1), scale * T(0.5), T(L - 1) * T(0.5)
+    x, y = r.real.astype(T), r.imag.astype(T)
+    tj = np.minimum(np.maximum(x * hs + hl, T(0)), lm1)
+    ti = np.minimum(np.maximum(hl - y * hs, T(0)), lm1)
+    kj, ki = np.rint(tj), np.rint(ti)
+    sure = (np.abs(tj - kj) <= lim) & (np.abs(ti - ki) <= lim)
+    v = (ki.astype(np.uint32) << 8) | kj.astype(np.uint32)
+    v ^= (v >> 4) & 0x0F0F
+    v ^= (v >> 2) & 0x3F3F
+    v ^= (v >> 1) & 0x7F7F
+    return (((v >> 8) << hb) | (v & 0xFF)).astype(np.int64), sure
+
+
+def adversarial_points(M, rng, n=20000):
+    """random points over and beyond the constellation + points on decision boundaries +- {0, 1e-15 .. 1e-3} spacings."""
+    tab = constellation("qam", M)
+    L = int(np.sqrt(M))
+    spacing = 2.0 / np.sqrt((M - 1) * 2.0 / 3.0)
+    amp = np.abs(tab.real).max()
+    pts = [(rng.uniform(-1.6, 1.6, n) + 1j * rng.uniform(-1.6, 1.6, n)) * amp,
+           tab[rng.integers(0, M, n)] + 0.35 * spacing * (rng.standard_normal(n) + 1j * rng.standard_normal(n))]
+    bounds = (np.arange(L - 1) - (L - 2) / 2.0) * spacing            # the L - 1 decision boundaries of an axis
+    for off in (0.0, 1e-15, 1e-13, 1e-11, 2.0 ** -31, 2.0 ** -29, 1e-8, 1e-6, 2.0 ** -13, 2.0 ** -11, 1e-3):
+        for sgn in (-1.0, 1.0):
+            b = rng.choice(bounds, 500) + sgn * off * spacing
+            other = rng.uniform(-1.3, 1.3, 500) * amp
+            pts.append(b + 1j * other)
+            pts.append(other + 1j * b)
+            pts.append(b + 1j * (rng.choice(bounds, 500) - sgn * off * spacing))    # corners of four regions
+    return tab, np.concatenate(pts)
+
+
+@pytest.mark.parametrize("M", [4, 16, 64, 256])
+def test_certificate_model_equals_the_argmin_where_sure(M):
+    rng = np.random.default_rng(M)
+    tab, r = adversarial_points(M, rng)
+    want = np.argmin(np.abs(tab[None, :] - r[:, None]), axis=1)
+    lab, sure = cert_model(r, M, "f64")
+    assert np.array_equal(lab[sure], want[sure])
+    assert sure.mean() > 0.6                                  # the adversarial set is half boundary points
+    # the random half alone: practically everything certified
+    lab0, sure0 = cert_model(r[:40000], M, "f64")
+    assert sure0.mean() > 1.0 - 1e-4
+    # complex64: same statement against the argmin of the float-rounded point in exact arithmetic
+    r32 = r.astype(np.complex64)
+    want32 = np.argmin(np.abs(tab[None, :] - r32.astype(np.complex128)[:, None]), axis=1)
+    lab32, sure32 = cert_model(r32, M, "f32")
+    assert np.array_equal(lab32[sure32], want32[sure32])
+    assert sure32[:40000].mean() > 1.0 - 4e-3 * np.sqrt(M)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M", [4, 16, 64, 256])
+def test_demodulate_with_and_without_the_certificate(engine, M):
+    rng = np.random.default_rng(100 + M)
+    tab, r = adversarial_points(M, rng)
+    engine.set_constellation(tab, _lib.CONST_QAM)
+    d = np.abs(tab[None, :] - r[:, None])
+    want = np.argmin(d, axis=1)
+    # a point whose two best |c - r| agree to rounding has no decision to be identical to (hypot vs squared metric)
+    part = np.partition(d, 1, axis=1)
+    clear = (part[:, 1] - part[:, 0]) > 1e-13
+    got = engine.demodulate(r, dtype="f64")
+    with engine.options(demod_nocert=1):
+        grid = engine.demodulate(r, dtype="f64")
+    assert np.array_equal(got, grid)                           # certificate == table search, boundary points included
+    assert np.array_equal(got[clear], want[clear])
+    assert clear.mean() > 0.9
+    # complex64: certificate and table search agree wherever the float metric has a clear winner
+    r32 = r.astype(np.complex64)
+    got32 = engine.demodulate(r32, dtype="f32")
+    with engine.options(demod_nocert=1):
+        grid32 = engine.demodulate(r32, dtype="f32")
+    d32 = np.abs(tab[None, :] - r32.astype(np.complex128)[:, None])
+    p32 = np.partition(d32, 1, axis=1)
+    clear32 = (p32[:, 1] - p32[:, 0]) > 1e-5
+    assert np.array_equal(got32[clear32], grid32[clear32])
+    assert np.array_equal(got32[clear32], np.argmin(d32, axis=1)[clear32])
