@@ -30,8 +30,14 @@ __host__ __device__ __forceinline__ Words4 philox4x32_10(uint32_t c0, uint32_t c
     for (int r = 0; r < 10; ++r) {
         const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
         const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+#if defined(__HIP_DEVICE_COMPILE__)
+        // one v_bitop3_b32 (a ^ b ^ c, truth table 0x96) per word: the backend otherwise emits two v_xor_b32 for most of them
+        const uint32_t n0 = __builtin_amdgcn_bitop3_b32((uint32_t)(p1 >> 32), c1, k0, 0x96);
+        const uint32_t n2 = __builtin_amdgcn_bitop3_b32((uint32_t)(p0 >> 32), c3, k1, 0x96);
+#else
         const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
         const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+#endif
         c1 = (uint32_t)p1;
         c3 = (uint32_t)p0;
         c0 = n0;

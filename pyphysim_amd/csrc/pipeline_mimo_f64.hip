@@ -104,7 +104,7 @@ struct NoMid {
 };
 // `mid` runs between the stage's sixteen LDS loads and its butterflies: independent work (variant 1: a quarter of the
 // realization's noise draws) for the wave's own LDS round trip to hide behind
-template <bool DIF, bool INV, int S, int NA, bool TWR, bool MIDFIRST = false, typename Mid = NoMid>
+template <bool DIF, bool INV, int S, int NA, bool TWR, bool MIDFIRST = false, typename Mid = NoMid, bool NOSTORE = false>
 __device__ __forceinline__ void r4_stage_planar(double* s_d, const TwRegs64& tw, const double2* __restrict__ g_tw, int bb,
                                                 const double2* pre = nullptr, Mid&& mid = Mid()) {
     constexpr int N = kD64N, s = S;
@@ -164,6 +164,10 @@ __device__ __forceinline__ void r4_stage_planar(double* s_d, const TwRegs64& tw,
             y2 = cmul(y2, w2);
             y3 = cmul(y3, w3);
         }
+        if constexpr (NOSTORE) {                      // timing bound only (variant 32): results computed, not stored
+            asm volatile("" ::"v"(y0.x), "v"(y0.y), "v"(y1.x), "v"(y1.y), "v"(y2.x), "v"(y2.y), "v"(y3.x), "v"(y3.y));
+            continue;
+        }
         double* pr = s_d + (2 * a) * N;
         double* pi = pr + N;
         pr[i0] = y0.x; pr[i1] = y1.x; pr[i2] = y2.x; pr[i3] = y3.x;
@@ -180,6 +184,8 @@ __device__ __forceinline__ void r4_stage_planar(double* s_d, const TwRegs64& tw,
 // and parked in registers until the channel stage -- independent work inside each wave's own LDS round trip.
 // bit 2 = the 256-thread form fetches its twiddles per stage like the 512-thread form (48 registers less);
 // bit 4 = the Box-Muller's node angle and its cos / sin as one 32-byte LDS entry (one address for both reads);
+// bit 5 = TIMING BOUND ONLY, wrong results: the stores of the last transmit stage and of the channel stage and the two
+// barriers around the channel dropped -- an upper bound of what fusing the channel into its neighbours could save;
 // bit 3 (with bit 0) = the draws BEFORE the stage's loads instead of behind them (the loaded values are not live beside them).
 template <int AH, int VAR>
 __global__ __launch_bounds__(256 * (4 / AH), 2 * (4 / AH)) void k_run_mimo_ofdm_f64(MimoParams pp, ModemParams<double> mp, uint64_t seed,
@@ -357,8 +363,12 @@ __global__ __launch_bounds__(256 * (4 / AH), 2 * (4 / AH)) void k_run_mimo_ofdm_
                 r4_stage_planar<true, true, 4, AH, TWR>(s_mine, twr, g_tw, opaque(bbt));
                 fft_stage_sync<TB>(4);
             }
-            r4_stage_planar<true, true, 1, AH, TWR>(s_mine, twr, g_tw, opaque(bbt));
-            __syncthreads();
+            if constexpr (VAR & 32) {   // bound of variant "channel fused into the adjacent stages": WRONG RESULTS, timing only
+                r4_stage_planar<true, true, 1, AH, TWR, false, NoMid, true>(s_mine, twr, g_tw, opaque(bbt));
+            } else {
+                r4_stage_planar<true, true, 1, AH, TWR>(s_mine, twr, g_tw, opaque(bbt));
+                __syncthreads();
+            }
             // ---- channel: R = H T + noise on the samples that survive CP removal ----
             {
 #pragma unroll
@@ -388,14 +398,18 @@ __global__ __launch_bounds__(256 * (4 / AH), 2 * (4 / AH)) void k_run_mimo_ofdm_
                             z0 = cfma(h, x0[a], z0);
                             z1 = cfma(h, x1[a], z1);
                         }
-                        s_d[(2 * r) * N + q0] = z0.x;
-                        s_d[(2 * r + 1) * N + q0] = z0.y;
-                        s_d[(2 * r) * N + q1] = z1.x;
-                        s_d[(2 * r + 1) * N + q1] = z1.y;
+                        if constexpr (VAR & 32) {
+                            asm volatile("" ::"v"(z0.x), "v"(z0.y), "v"(z1.x), "v"(z1.y));
+                        } else {
+                            s_d[(2 * r) * N + q0] = z0.x;
+                            s_d[(2 * r + 1) * N + q0] = z0.y;
+                            s_d[(2 * r) * N + q1] = z1.x;
+                            s_d[(2 * r + 1) * N + q1] = z1.y;
+                        }
                     }
                 }
             }
-            __syncthreads();
+            if constexpr (!(VAR & 32)) __syncthreads();
             // ---- FFT: radix-4 DIT, digit-reversed -> natural bins ----
             if constexpr (TWR) {
                 r4_stage_planar<false, false, 1, AH, TWR>(s_mine, twr, g_tw, opaque(bbt));
@@ -513,7 +527,7 @@ int run_mimo_ofdm_f64(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, uint64_t see
     // MCLE_OPT_F64_THREADS: 0 / 512 = two antennas per thread, 512-thread workgroups (default); 256 = four antennas per thread
     const bool wide = ctx->opt[MCLE_OPT_F64_THREADS] != 256;
     const int var = (int)ctx->opt[MCLE_OPT_F64_VARIANT];
-    auto kern = wide ? (var == 16 ? k_run_mimo_ofdm_f64<2, 16> : var == 9 ? k_run_mimo_ofdm_f64<2, 9> : (var & 1) ? k_run_mimo_ofdm_f64<2, 1> : k_run_mimo_ofdm_f64<2, 0>)
+    auto kern = wide ? (var == 32 ? k_run_mimo_ofdm_f64<2, 32> : var == 16 ? k_run_mimo_ofdm_f64<2, 16> : var == 9 ? k_run_mimo_ofdm_f64<2, 9> : (var & 1) ? k_run_mimo_ofdm_f64<2, 1> : k_run_mimo_ofdm_f64<2, 0>)
                      : var == 13 ? k_run_mimo_ofdm_f64<4, 13> : var == 9 ? k_run_mimo_ofdm_f64<4, 9>
                      : var == 5 ? k_run_mimo_ofdm_f64<4, 5> : var == 4 ? k_run_mimo_ofdm_f64<4, 4>
                      : (var & 1) ? k_run_mimo_ofdm_f64<4, 1> : k_run_mimo_ofdm_f64<4, 0>;

@@ -85,9 +85,9 @@ def test_demodulate_with_and_without_the_certificate(engine, M):
     got = engine.demodulate(r, dtype="f64")
     with engine.options(demod_nocert=1):
         grid = engine.demodulate(r, dtype="f64")
-    assert np.array_equal(got, grid)                           # certificate == table search, boundary points included
-    assert np.array_equal(got[clear], want[clear])
-    assert clear.mean() > 0.9
+    assert np.array_equal(got, grid), np.flatnonzero(got != grid)[:10]      # certificate == table search, boundary points included
+    assert np.array_equal(got[clear], want[clear]), np.flatnonzero(clear & (got != want))[:10]
+    assert clear.mean() > 0.8, clear.mean()              # (the boundary points at offsets <= 1e-13 are not)
     # complex64: certificate and table search agree wherever the float metric has a clear winner
     r32 = r.astype(np.complex64)
     got32 = engine.demodulate(r32, dtype="f32")
