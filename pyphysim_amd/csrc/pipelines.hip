@@ -1100,7 +1100,8 @@ int mcle_run_mimo_ofdm(mcle_ctx* ctx, int dtype, const mcle_mimo_ofdm_cfg* cfg, 
                        uint64_t count, mcle_counters* d_counters, uint32_t* d_sym_err, uint32_t* d_bit_err) {
     int rc = check_pipe(ctx, dtype, cfg ? cfg->demod_method : 0, cfg);
     if (rc) return rc;
-    MCLE_REQUIRE(cfg->nt == cfg->nr && (cfg->nt == 2 || cfg->nt == 4), "fused MIMO pipeline supports 2x2 and 4x4");
+    MCLE_REQUIRE(cfg->nt >= 1 && cfg->nt <= cfg->nr && cfg->nr <= 4, "fused MIMO pipeline: 1 <= Nt <= Nr <= 4 (got %d x %d)",
+                 cfg->nt, cfg->nr);
     MCLE_REQUIRE(cfg->cp_size >= 0 && cfg->cp_size <= cfg->fft_size,
                  "cp_size must be nonnegative and cannot be greater than fft_size");
     MCLE_REQUIRE(cfg->num_used >= 2 && cfg->num_used % 2 == 0 && cfg->num_used <= cfg->fft_size,
@@ -1113,10 +1114,13 @@ int mcle_run_mimo_ofdm(mcle_ctx* ctx, int dtype, const mcle_mimo_ofdm_cfg* cfg, 
     if (dtype == MCLE_F32) {   // matrix-core kernel where it applies (MCLE_OPT_NO_MFMA keeps the VALU kernel below)
         rc = run_mimo_ofdm_mfma(ctx, cfg, seed, first, count, d_counters, d_sym_err, d_bit_err);
         if (rc != MCLE_E_UNSUPPORTED) return rc;
-    } else {                   // complex128 at FFT 1024, 4x4: the planar two-workgroups-per-CU kernel (pipeline_mimo_f64.hip)
+    } else {                   // complex128: the planar kernel family (pipeline_mimo_f64.hip: FFT 256 .. 2048, 2x2 / 4x4 / 2x4)
         rc = run_mimo_ofdm_f64(ctx, cfg, seed, first, count, d_counters, d_sym_err, d_bit_err);
         if (rc != MCLE_E_UNSUPPORTED) return rc;
     }
+    MCLE_REQUIRE(cfg->nt == cfg->nr && (cfg->nt == 2 || cfg->nt == 4),
+                 "fused MIMO pipeline: %d x %d at fft_size %d is outside the envelope (2x2 / 4x4 at 64 .. 2048 in both arithmetics; "
+                 "2x4 in complex128 at 256 and 1024)", cfg->nt, cfg->nr, cfg->fft_size);
 #define MCLE_RUN(N_, NA_)                                                                                         \
     if (cfg->fft_size == N_ && cfg->nt == NA_)                                                                    \
         return dtype == MCLE_F32                                                                                  \

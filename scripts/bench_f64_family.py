@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Realizations/s of the complex128 MIMO-OFDM kernel family (csrc/pipeline_mimo_f64.hip) per geometry, next to the generic
+radix-4 kernel k_run_mimo_ofdm<double, N, NA> it replaces (context option f64_generic): 64-QAM, cp 16, full band, SNR 25 dB,
+min-distance demodulation (certificate) and slicer.  One JSON object on stdout (profiles/r04/f64_family_rates.json)."""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pyphysim_amd import _lib  # noqa: E402
+from pyphysim_amd.engine import Engine  # noqa: E402
+from pyphysim_amd.modulators import constellation  # noqa: E402
+
+eng = Engine(0, "f64")
+eng.set_constellation(constellation("qam", 64), _lib.CONST_QAM)
+nv = 10 ** -2.5
+out = {}
+for fft, nt, nr in ((256, 2, 2), (256, 4, 4), (512, 2, 2), (512, 4, 4), (1024, 2, 2), (1024, 4, 4), (2048, 2, 2), (2048, 4, 4),
+                    (256, 2, 4), (1024, 2, 4)):
+    n = max(16384, int(262144 * 4096 / (fft * nr)) // 8192 * 8192)
+    n = min(n, 262144)
+    row = {"realizations_per_launch": n}
+    for name, generic, method in (("fast_mindist", 0, _lib.DEMOD_MINDIST), ("fast_slicer", 0, _lib.DEMOD_QAM_SLICER),
+                                  ("generic_mindist", 1, _lib.DEMOD_MINDIST)):
+        if generic and nt != nr:
+            continue
+        cnt = eng.new_counters()
+        with eng.options(f64_generic=generic):
+            run = lambda first: eng.run_mimo_ofdm(nt, nr, fft, 16, fft, 1, nv, 1, first, n, method=method, dtype="f64",
+                                                  counters=cnt)
+            run(1 << 30)
+            eng.sync()
+            eng.timer_start()
+            for s in range(3):
+                run(s * n)
+            ms = eng.timer_stop_ms() / 3
+        c = eng.read_counters(cnt)
+        row[name] = dict(realizations_per_s=n / (ms * 1e-3), ms_per_launch=ms,
+                         ser=c["sym_errors"] / float(c["n_realizations"] * fft * nt))
+    if "generic_mindist" in row:
+        row["fast_over_generic"] = row["fast_mindist"]["realizations_per_s"] / row["generic_mindist"]["realizations_per_s"]
+    out["%dx%dx%d" % (fft, nt, nr)] = row
+print(json.dumps(out, indent=1))

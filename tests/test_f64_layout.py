@@ -63,6 +63,56 @@ def test_every_stage_of_the_f64_kernel_is_conflict_free():
             assert write_conflicts(slots) == 0
 
 
+def _family_spans(N):
+    """radix-4 spans in DIF order (N/4 ... 1, or ... 2 followed by the radix-2 stage on a thread's four positions)"""
+    log2 = N.bit_length() - 1
+    return [(N // 4) >> (2 * st) for st in range(log2 // 2)], bool(log2 & 1)
+
+
+def test_every_stage_of_the_f64_family_is_conflict_free():
+    """round 4: fft_size 256 / 512 / 1024 / 2048, workgroups of (N / 4) x {1, 2} threads (two antennas per thread: one group
+    per antenna pair) -- radix-4 stages, the radix-2 stage of 512 / 2048 (the span-1 access pattern), channel pairs
+    (p0, p0 + N/4), decode bins, scatter blocks of 16 / Nt subcarriers."""
+    for N in (256, 512, 1024, 2048):
+        NB = N // 4
+        spans, has2 = _family_spans(N)
+        assert spans[-1] == (2 if has2 else 1)
+        for groups in (1, 2):
+            TB = NB * groups
+            for wave in range(TB // 64):
+                tid = 64 * wave + np.arange(64)
+                bb = tid & (NB - 1)
+                for s in spans:
+                    k, g = bb & (s - 1), bb // s
+                    e0 = g * 4 * s + k
+                    for q in range(4):
+                        slots = list(swz64(e0 + q * s))
+                        assert read_conflicts(slots) == 0 and write_conflicts(slots) == 0, (N, s, q, wave)
+                if has2:
+                    for q in range(4):
+                        slots = list(swz64(4 * bb + q))
+                        assert read_conflicts(slots) == 0 and write_conflicts(slots) == 0, (N, "r2", q, wave)
+                for j0 in range(0, N // 2, TB):                            # channel
+                    j = tid + j0
+                    half, rest = j // (N // 4), j % (N // 4)
+                    p0 = 2 * half * (N // 4) + rest
+                    for p in (p0, p0 + N // 4):
+                        slots = list(swz64(p))
+                        assert read_conflicts(slots) == 0 and write_conflicts(slots) == 0, (N, "chan", wave)
+                for d0 in range(0, N, TB):                                 # decode (full band)
+                    slots = list(swz64((tid + d0 + N // 2) % N))
+                    assert read_conflicts(slots) == 0, (N, "decode", wave)
+                for nt in (2, 4):                                          # scatter: block t = 16 / nt subcarriers
+                    per = 16 // nt
+                    for c in range(per):
+                        d = per * tid + c
+                        if d.max() < N:
+                            slots = list(swz64((d + N // 2) % N))
+                            # Nt = 4: conflict free.  Nt = 2 (stride 8 across the lanes): 2-way -- 8 LDS-array cycles
+                            # against the 6 a ds_write_b64 takes to issue anyway; 16 of a realization's ~600 LDS accesses
+                            assert write_conflicts(slots) <= (0 if nt == 4 else 32), (N, "scatter", nt, c, wave)
+
+
 def test_the_radix4_swizzle_of_fft_hpp_is_not_enough_for_8_byte_stores():
     """lds_swz (fft.hpp) was built for the read rule; ds_write_b64's 16-lane groups collide on it for spans 4 and 1 --
     the 0.29 conflict fraction the first version of the kernel measured."""

@@ -1,6 +1,7 @@
-"""GPU: the complex128 config-4 kernel (csrc/pipeline_mimo_f64.hip: planar LDS, two workgroups per CU, table Box-Muller,
-pruned min-distance search) -- per-realization error counts equal to the oracle chain's under the same Philox keying,
-and equal to the generic radix-4 kernel it replaces (engine option f64_generic), on every corner of its envelope."""
+"""GPU: the complex128 config-4 kernel family (csrc/pipeline_mimo_f64.hip: planar LDS, table Box-Muller, certified /
+pruned min-distance search; fft_size 256 .. 2048, 2x2 / 4x4 / 2x4) -- per-realization error counts equal to the oracle
+chain's under the same Philox keying, and equal to the generic radix-4 kernel it replaces (engine option f64_generic), on
+every corner of its envelope."""
 import numpy as np
 import pytest
 
@@ -66,6 +67,80 @@ def test_f64_kernel_equals_the_generic_kernel(engine, case):
     b = _run(engine, kw, 405, n - 400, method)[0]
     for k in ("sym_errors", "sym_errors_sq", "bit_errors", "bit_errors_sq", "n_realizations", "n_skipped"):
         assert new[k] == a[k] + b[k], k
+
+
+def test_f64_kernel_against_the_oracle_over_2000_realizations(engine):
+    """The headline geometry (BASELINE config 4: 4x4 MMSE, 64-QAM, OFDM(1024, 16), 25 dB), both thread maps, both demodulators,
+    the certificate on and off: per-realization symbol AND bit error counts equal to the oracle chain's on 2 048 consecutive
+    realizations (8.4e6 symbols; the bench's ser_abs_err_vs_oracle compares sums only)."""
+    engine.set_constellation(chains.constellation("qam", 64), _lib.CONST_QAM)
+    kw = CASES[0]
+    first, count = 123456789, 2048
+    okw = dict(mod="qam", M=64, nt=4, nr=4, fft_size=1024, cp_size=16, num_used=None, n_ofdm_sym=1, snr_db=25.0, mmse=True)
+    want = [chains.chain_mimo_ofdm(chains.PhiloxRng(SEED, r), **okw) for r in range(first, first + count)]
+    want_se = np.array([w["symbol_errors"] for w in want])
+    want_be = np.array([w["bit_errors"] for w in want])
+    assert want_se.sum() > 1e5                                  # a realization in outage is thousands of errors
+    for threads in (512, 256):
+        for method, nocert in ((_lib.DEMOD_MINDIST, 0), (_lib.DEMOD_MINDIST, 1), (_lib.DEMOD_QAM_SLICER, 0)):
+            with engine.options(demod_nocert=nocert):
+                res, se, be = _run(engine, kw, first, count, method, threads=threads)
+            assert np.array_equal(se, want_se), (threads, method, nocert, np.flatnonzero(se != want_se)[:5])
+            assert np.array_equal(be, want_be), (threads, method, nocert)
+            assert res["sym_errors"] == int(want_se.sum()) and res["bit_errors"] == int(want_be.sum())
+
+
+# ---- round 4: the kernel as a family (fft_size 256 .. 2048, 2x2 / 4x4 / 2x4), not a benchmark point ----
+SHAPES = [(256, 2, 2), (256, 4, 4), (512, 2, 2), (512, 4, 4), (1024, 2, 2), (2048, 2, 2), (2048, 4, 4), (1024, 2, 4), (256, 2, 4)]
+SHAPE_CASES = [dict(mod="qam", M=64, snr_db=25.0),
+               dict(mod="qam", M=16, snr_db=17.0, used_frac=0.6, n_ofdm_sym=2, cp_size=7, mmse=False),   # partial band, odd CP, ZF
+               dict(mod="psk", M=8, snr_db=13.0, n_ofdm_sym=2, cp_size=33)]                               # candidate grid only
+
+
+def _shape_kwargs(kw, fft, nt, nr):
+    used = fft if "used_frac" not in kw else 2 * int(kw["used_frac"] * fft / 2)
+    return dict(mod=kw["mod"], M=kw["M"], nt=nt, nr=nr, fft_size=fft, cp_size=kw.get("cp_size", 16), num_used=used,
+                n_ofdm_sym=kw.get("n_ofdm_sym", 1), snr_db=kw["snr_db"], mmse=kw.get("mmse", True))
+
+
+def _run_shape(engine, okw, first, count, method, generic=False):
+    nv = 1.0 / omodem.dB2Linear(okw["snr_db"])
+    with engine.options(f64_generic=1 if generic else 0):
+        return engine.run_mimo_ofdm(okw["nt"], okw["nr"], okw["fft_size"], okw["cp_size"], okw["num_used"], okw["n_ofdm_sym"],
+                                    nv, SEED, first, count, mmse=okw["mmse"], method=method, dtype="f64", per_realization=True)
+
+
+@pytest.mark.parametrize("shape", SHAPES, ids=lambda s: "%dx%dx%d" % s)
+@pytest.mark.parametrize("case", range(len(SHAPE_CASES)))
+def test_f64_family_counts_equal_the_oracle(engine, shape, case):
+    """Every geometry of the family against the oracle chain realization by realization (both demodulators), and -- where
+    the generic kernel k_run_mimo_ofdm<double, N, NA> covers the shape -- against that one over 300 realizations."""
+    fft, nt, nr = shape
+    okw = _shape_kwargs(SHAPE_CASES[case], fft, nt, nr)
+    kind = _lib.CONST_QAM if okw["mod"] == "qam" else _lib.CONST_GENERIC
+    engine.set_constellation(chains.constellation(okw["mod"], okw["M"]), kind)
+    first, count = (1 << 33) + 5, 4
+    want = [chains.chain_mimo_ofdm(chains.PhiloxRng(SEED, r), **okw) for r in range(first, first + count)]
+    want_se = np.array([w["symbol_errors"] for w in want])
+    want_be = np.array([w["bit_errors"] for w in want])
+    methods = [_lib.DEMOD_MINDIST] + ([_lib.DEMOD_QAM_SLICER] if okw["mod"] == "qam" else [])
+    for method in methods:
+        res, se, be = _run_shape(engine, okw, first, count, method)
+        assert np.array_equal(se, want_se) and np.array_equal(be, want_be), (shape, case, method, se, want_se)
+        assert res["n_symbols"] == want[0]["num_symbols"] and res["n_bits"] == want[0]["num_bits"]
+    if nt == nr:
+        n = 300
+        new, se, be = _run_shape(engine, okw, 9, n, _lib.DEMOD_MINDIST)
+        old, se_o, be_o = _run_shape(engine, okw, 9, n, _lib.DEMOD_MINDIST, generic=True)
+        assert np.count_nonzero(se != se_o) <= 1 and np.max(np.abs(se.astype(int) - se_o.astype(int))) <= 1
+        assert new["n_realizations"] == old["n_realizations"] == n and new["n_skipped"] == old["n_skipped"]
+
+
+def test_shapes_outside_the_envelope_are_refused(engine):
+    engine.set_constellation(chains.constellation("qam", 16), _lib.CONST_QAM)
+    for nt, nr, fft, dtype in [(4, 2, 1024, "f64"), (2, 4, 512, "f64"), (2, 4, 1024, "f32"), (3, 3, 1024, "f64"), (2, 2, 96, "f64")]:
+        with pytest.raises((_lib.McleError, ValueError)):
+            engine.run_mimo_ofdm(nt, nr, fft, 16, fft, 1, 0.01, SEED, 0, 4, dtype=dtype)
 
 
 def test_f64_kernel_skips_singular_channels_like_the_generic_kernel(engine):
