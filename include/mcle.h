@@ -68,6 +68,10 @@ int mcle_ctx_destroy(mcle_ctx* ctx);
 int mcle_ctx_set_stream(mcle_ctx* ctx, void* hip_stream);
 int mcle_ctx_get_stream(mcle_ctx* ctx, void** hip_stream);
 int mcle_ctx_sync(mcle_ctx* ctx);
+/* Releases the context's scratch buffer (fading / filter records of the two-launch pipelines: up to 138 MiB for the
+ * complex128 MIMO-OFDM family, 256 MiB + 25 % for mcle_run_mimo_ofdm_tdl; it otherwise lives until mcle_ctx_destroy).
+ * Waits for the stream first.  The next call that needs it allocates again. */
+int mcle_ctx_trim_scratch(mcle_ctx* ctx);
 int mcle_ctx_device_info(mcle_ctx* ctx, int* n_cu, int* lds_bytes, char* name, int name_len);
 int mcle_malloc(mcle_ctx* ctx, size_t bytes, void** d_ptr);
 int mcle_free(mcle_ctx* ctx, void* d_ptr);
@@ -408,12 +412,21 @@ typedef struct mcle_ia_cfg {            /* C5: apps/ia/simulate_ia.py:94-245, Cl
 int mcle_run_awgn(mcle_ctx* ctx, int dtype, const mcle_awgn_cfg* cfg, uint64_t seed,
                   uint64_t first, uint64_t count, mcle_counters* d_counters,
                   uint32_t* d_sym_err, uint32_t* d_bit_err);
+/* Jakes fading (JakesSampleGenerator, fading_generators.py:427-493) in the complex128 instantiation: by default the ray
+ * phasors of a thread's run of 16 symbols advance by a rotation recurrence (one exact sincos per ray and run, then <= 15
+ * complex products: <= 3e-15 relative drift against evaluating sin / cos at every sample, which is what NumPy does).  The
+ * per-realization error counts equal the oracle's on every tested case incl. the full 10^5-symbol config 2, but that is by
+ * test coverage, not by construction: a symbol within 3e-15 of a decision boundary may flip.  MCLE_OPT_JAKES_DIRECT = 1
+ * evaluates every sample (the literal parity statement, 3.3 x slower). */
 int mcle_run_flat_fading(mcle_ctx* ctx, int dtype, const mcle_flat_cfg* cfg, uint64_t seed,
                          uint64_t first, uint64_t count, mcle_counters* d_counters,
                          uint32_t* d_sym_err, uint32_t* d_bit_err);
 int mcle_run_ofdm_tdl(mcle_ctx* ctx, int dtype, const mcle_ofdm_tdl_cfg* cfg, uint64_t seed,
                       uint64_t first, uint64_t count, mcle_counters* d_counters,
                       uint32_t* d_sym_err, uint32_t* d_bit_err);
+/* Envelope: 1 <= Nt <= Nr <= 4.  complex128: fft_size 256 / 512 / 1024 / 2048 with 2x2 and 4x4, 2x4 at 256 and 1024, on the
+ * planar kernel family (pipeline_mimo_f64.hip; 2048 with 4x4 exists there only: 148 KiB of LDS); 2x2 / 4x4 at 64 and 128 on
+ * the generic kernel.  complex64: 2x2 / 4x4 at 64 .. 2048 (1024 with 4x4 on the matrix cores).  Anything else: MCLE_E_INVAL. */
 int mcle_run_mimo_ofdm(mcle_ctx* ctx, int dtype, const mcle_mimo_ofdm_cfg* cfg, uint64_t seed,
                        uint64_t first, uint64_t count, mcle_counters* d_counters,
                        uint32_t* d_sym_err, uint32_t* d_bit_err);
@@ -448,7 +461,14 @@ int mcle_ia_closed_form(mcle_ctx* ctx, const void* d_bigH, double noise_var, voi
  * d_F_init [batch][3][2] (unit norm): the starting precoders for MCLE_IA_INIT_GIVEN ('fix' / a captured
  * 'random' start), the alternating-minimisation solver's start for MCLE_IA_INIT_ALT_MIN, ignored for
  * MCLE_IA_INIT_CLOSED_FORM.  IterativeIASolverBaseClass.solve (algorithms.py:802-883).  d_iterations [batch]
- * (may be NULL) = runned_iterations. */
+ * (may be NULL) = runned_iterations.
+ * Reproducibility against the reference (complex128): the device eigen-solver is a cyclic Jacobi sweep, the reference's is
+ * LAPACK (numpy.linalg.eig / eigh); both are backward stable, so precoders, filters and SINRs agree to <= 1e-9 relative
+ * where the iteration is well conditioned, and the decisions of a link built on them are then identical.  Where the
+ * iteration ends badly conditioned -- a stream in outage, an eighth or more of a realization's symbols wrong -- the
+ * rounding-level difference is amplified over the iterations and decisions at near-ties may differ: bound asserted by
+ * tests/test_gpu_fuzz.py on such realizations: |symbol errors - reference's| <= max(2, 2 %), |bit errors| <= max(8, 4 %);
+ * every other realization is exact.  The closed-form solver (mcle_ia_closed_form) has no such caveat. */
 int mcle_ia_iterative(mcle_ctx* ctx, int solver, int initialize_with, const void* d_bigH,
                       const void* d_F_init, double noise_var, int max_iterations, double relative_factor,
                       void* d_F, void* d_U, double* d_sinr, double* d_capacity, uint32_t* d_iterations,

@@ -134,6 +134,7 @@ _PROTOS = {
     "mcle_ctx_set_stream": (c_int, [_P, _P]),
     "mcle_ctx_get_stream": (c_int, [_P, POINTER(_P)]),
     "mcle_ctx_sync": (c_int, [_P]),
+    "mcle_ctx_trim_scratch": (c_int, [_P]),
     "mcle_ctx_set_option": (c_int, [_P, c_int, c_longlong]),
     "mcle_ctx_get_option": (c_int, [_P, c_int, POINTER(c_longlong)]),
     "mcle_ctx_device_info": (c_int, [_P, POINTER(c_int), POINTER(c_int), c_char_p, c_int]),

@@ -185,6 +185,16 @@ int mcle_ctx_set_option(mcle_ctx* ctx, int option, long long value) {
     return MCLE_OK;
 }
 
+int mcle_ctx_trim_scratch(mcle_ctx* ctx) {
+    MCLE_REQUIRE(ctx != nullptr, "null context");
+    MCLE_HIP(hipSetDevice(ctx->device));
+    MCLE_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->d_scratch) MCLE_HIP(hipFree(ctx->d_scratch));
+    ctx->d_scratch = nullptr;
+    ctx->scratch_bytes = 0;
+    return MCLE_OK;
+}
+
 int mcle_ctx_get_option(mcle_ctx* ctx, int option, long long* value) {
     MCLE_REQUIRE(ctx != nullptr && value != nullptr, "null argument");
     MCLE_REQUIRE(option >= 0 && option < MCLE_OPT_COUNT, "unknown option %d", option);

@@ -633,6 +633,7 @@ static int awgn_philox_impl(mcle_ctx* ctx, int dtype, const void* d_x, uint64_t 
     MCLE_REQUIRE(dtype == MCLE_F32 || dtype == MCLE_F64, "dtype must be MCLE_F32 or MCLE_F64");
     MCLE_REQUIRE(noise_var >= 0.0, "noise variance must be non-negative");
     MCLE_REQUIRE(count <= 65535, "at most 65535 realizations per call");
+    MCLE_REQUIRE((uint64_t)row_len < (1ull << 33), "row_len must stay below 2^33 samples (32-bit Philox block counter, two samples per block)");
     if (row_len == 0 || count == 0) return MCLE_OK;
     int rc = ctx->bind();
     if (rc) return rc;

@@ -542,7 +542,9 @@ int mcle_rand_modulate_batch(mcle_ctx* ctx, int dtype, uint64_t seed, uint64_t f
                              int32_t* d_idx, void* d_sym, size_t n) {
     int rc = check_modem(ctx, dtype, MCLE_DEMOD_MINDIST);
     if (rc) return rc;
-    MCLE_REQUIRE((ctx->M & (ctx->M - 1)) == 0 && ctx->M >= 2, "the bound constellation's size must be a power of two");
+    MCLE_REQUIRE((ctx->M & (ctx->M - 1)) == 0 && ctx->M >= 2 && ctx->M <= 256,
+                 "the bound constellation's size must be a power of two in [2, 256] (labels are Philox bytes, as in "
+                 "mcle_rand_symbols_batch; got %d)", ctx->M);
     MCLE_REQUIRE(count <= 65535, "at most 65535 realizations per call");
     MCLE_REQUIRE(d_idx != nullptr && d_sym != nullptr, "null output");
     if (n == 0 || count == 0) return MCLE_OK;

@@ -57,10 +57,10 @@ def _exchange_id(make_id, rank, world, addr, port, timeout=120.0):
                                 raise ConnectionError("peer closed before sending its rank")
                             head += chunk
                         peer = struct.unpack("<i", head)[0]
-                        if not (1 <= peer < world) or peer in seen:
-                            continue                      # not one of ours, or a duplicate: no id for it
-                        conn.sendall(payload)
-                        seen.add(peer)
+                        if not (1 <= peer < world):
+                            continue                      # not one of ours: no id for it
+                        conn.sendall(payload)             # a rank that retries (its first reply was lost) is served
+                        seen.add(peer)                    # again: the reply is idempotent; counted once, after the send
                     except (OSError, ConnectionError, struct.error):
                         continue
         finally:

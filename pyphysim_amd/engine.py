@@ -125,10 +125,13 @@ class Engine:
             self.lib.mcle_free(self.ctx, ptr)
 
     def empty_pool(self):
+        """Returns the pooled device buffers and the context's scratch buffer (the record buffers of the two-launch
+        pipelines, up to 138-320 MiB) to the allocator."""
         for free in self._pool.values():
             for ptr in free:
                 self.lib.mcle_free(self.ctx, ptr)
         self._pool, self._pool_bytes = {}, 0
+        check(self.lib.mcle_ctx_trim_scratch(self.ctx))
 
     def close(self):
         if self.ctx:
@@ -149,7 +152,8 @@ class Engine:
     # ---- kernel-selection options (mcle_ctx_set_option: per context, never read from the environment) ----
     def set_option(self, name, value):
         """name: a key of _lib.OPTIONS ('no_mfma', 'mfma_variant', 'grid_oversub', 'flat_wgs_per_cu', 'single_tdl',
-        'tdl_mfma_waves', 'jakes_direct'); 0 restores the default."""
+        'tdl_mfma_waves', 'jakes_direct', 'f64_generic', 'f64_threads', 'bd_runtime_solve', 'demod_nocert', 'f64_variant':
+        include/mcle.h MCLE_OPT_* says what each selects); 0 restores the default."""
         if name not in _lib.OPTIONS:
             raise ValueError("unknown option %r (known: %s)" % (name, ", ".join(sorted(_lib.OPTIONS))))
         check(self.lib.mcle_ctx_set_option(self.ctx, _lib.OPTIONS[name], int(value)))

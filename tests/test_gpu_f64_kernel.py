@@ -128,7 +128,7 @@ def test_f64_family_counts_equal_the_oracle(engine, shape, case):
         res, se, be = _run_shape(engine, okw, first, count, method)
         assert np.array_equal(se, want_se) and np.array_equal(be, want_be), (shape, case, method, se, want_se)
         assert res["n_symbols"] == want[0]["num_symbols"] and res["n_bits"] == want[0]["num_bits"]
-    if nt == nr:
+    if nt == nr and (fft, nr) != (2048, 4):       # (the generic complex128 kernel would need 181 KiB of LDS at 2048 x 4)
         n = 300
         new, se, be = _run_shape(engine, okw, 9, n, _lib.DEMOD_MINDIST)
         old, se_o, be_o = _run_shape(engine, okw, 9, n, _lib.DEMOD_MINDIST, generic=True)

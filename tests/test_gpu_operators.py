@@ -115,6 +115,18 @@ def test_rand_modulate_batch_equals_draw_then_modulate(engine, dt, mod, M):
             assert np.array_equal(sym[k], table[want].astype(sym.dtype))
 
 
+def test_rand_modulate_batch_refuses_tables_beyond_a_byte(engine):
+    """Labels are Philox bytes: a 512-point table is outside the operator's envelope (as in mcle_rand_symbols_batch) and must
+    be an error, not wrong labels (the byte mask overflowed silently for M = 512 / 1024)."""
+    import numpy as np
+    table = np.exp(2j * np.pi * np.arange(512) / 512)
+    engine.set_constellation(table, _lib.CONST_GENERIC)
+    with pytest.raises((_lib.McleError, ValueError), match="power of two in"):
+        engine.rand_modulate_batch(64, 1, 0, 2, dtype="f64")
+    with pytest.raises((_lib.McleError, ValueError)):
+        engine.rand_symbols_batch(64, 512, 1, 0, 2)
+
+
 @pytest.mark.parametrize("dt", ["f64", "f32"])
 def test_awgn_chain_injected(engine, dt):
     """C1 with the reference's own draws injected: decisions / counters bit-exact (f64)."""
