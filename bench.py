@@ -36,7 +36,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
-ROUND = "r03"
+ROUND = "r04"
 # algorithmic bytes per realization in the staged (operator-granular)
 # model, complex64 samples / uint8 indices.
 B_ALG = {"c2": 7_600_000, "c3": 211_360, "c4": 412_160, "c5": 62_000, "f1": 3_099_008,
@@ -61,6 +61,7 @@ UNCOUNTED = {"c4": "Philox4x32-10: ~2 350 blocks (4 176 CN samples + 4 096 symbo
                    "Box-Muller: 4 176 x (log, sqrt, sin, cos) transcendental ops"}
 HBM_PEAK_GBPS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
 HBM_COPY_GBPS = 6290.0      # same guide: measured float4 copy
+MEASURED = {"copy_GBps": None}   # the box's copy rate measured in THIS run (scripts/bench_staged_c4.measure_copy_GBps), rank 0
 FP32_PEAK_TFLOPS = 157.3    # same guide: FP32 vector peak = FP32-input MFMA peak (256 CU x 4 SIMD x 64 flop/clk x 2.4 GHz)
 # FP64: 16 lanes x 1 FMA per clock and SIMD = half the guide's FP32 figure (256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz); the guide
 # does not list it, so it was measured (scripts/experiments/f64_rates.hip -> profiles/r03/f64_rates.txt): v_mfma_f64_16x16x4_f64
@@ -80,6 +81,10 @@ def kernel_name(cfg, dtype):
 KERNEL_NOTE = {   # configs whose step is two launches: the time spans both, the counters are the named (dominant) kernel's
     "c4": "a step = k_mimo_filters (channel draw + f64 receive filter per realization, 13 us = 0.8 % of the time) + k_run_mimo_ofdm_mfma; "
           "kernel_ms_per_launch spans both",
+    ("c4", "f64"): "a step = per slice of 2^18 realizations k_mimo_filters_f64 (channel draw + f64 receive filter, one thread per "
+                   "realization, ~1 % of the time) + k_run_mimo_ofdm_f64; kernel_ms_per_launch spans them",
+    ("c3", "f64"): "a step = k_tdl_symbol_polys<double> (fading records) + k_run_ofdm_tdl_batch<double, 1024, 2> per slice of <= 64 MiB "
+                   "of records; kernel_ms_per_launch spans them",
     "f1": "a step = k_mimo_tdl_symbol_polys (the symbols' fading records, one thread per fading process) + k_run_mimo_ofdm_tdl per "
           "slice of <= 256 MiB of records; kernel_ms_per_launch spans them",
     "c3": "a step = k_tdl_symbol_polys (fading records) + k_run_ofdm_tdl_mfma per slice of <= 64 MiB of records; "
@@ -92,6 +97,9 @@ KERNEL_NOTE = {   # configs whose step is two launches: the time spans both, the
 BATCH = {"c4": 1048576, "c3": 2097152, "c2": 131072, "c5": 4194304, "f1": 393216, "f6": 1048576}
 BATCH_SURVEY = {"c4": 65536, "c3": 131072, "c2": 16384, "c5": 262144, "f1": 98304, "f6": 131072}   # other_workloads legs
 BITS = {"c2": 6, "c3": 2, "c4": 6, "c5": 4, "f1": 6, "f6": 2}
+# BASELINE.json's literal realization counts: config 4 "1e6 realizations sharded over 8", config 5 "1e5 realizations on 8" (configs
+# 2 and 3: 1e6 on one GPU) -- what the `strong` block of a multi-rank line splits over the ranks
+STRONG_TOTAL = {"c4": 10 ** 6, "c5": 10 ** 5, "c2": 10 ** 6, "c3": 10 ** 6, "f1": 10 ** 5, "f6": 10 ** 5}
 SEED = 20260927
 SNR_DB = {"c1": 10.0, "c2": 20.0, "c3": 20.0, "c4": 25.0, "c5": 20.0, "f1": 25.0, "f6": 15.0}
 F1_TS = 1.0 / (15e3 * 1024)
@@ -137,9 +145,19 @@ def parse():
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend of a multi-rank run: nccl (= RCCL, the default and what the driver gets); "
                          "gloo exists so that the N > 1 code path can be executed on a box with fewer GPUs than ranks")
+    ap.add_argument("--comm", default="auto", choices=["auto", "native", "torch"],
+                    help="who carries the counter all-reduce of a multi-rank run: native = the product's own exchange, "
+                         "mcle_counters_allreduce (csrc/comm.hip: device-resident counters, one grouped RCCL all-reduce on the "
+                         "context stream; communicator from pyphysim_amd.distributed.NativeComm); torch = read_counters -> "
+                         "torch.distributed.all_reduce; auto = native on the nccl backend when its communicator comes up on "
+                         "every rank, else torch.  The line says which ran (rccl.exchange_impl)")
     ap.add_argument("--share-gpus", action="store_true",
                     help="rank r uses GPU r mod (visible GPUs) instead of failing when there are fewer GPUs than ranks "
                          "(tests of the N > 1 path on one GPU, together with --dist-backend gloo; never a scaling figure)")
+    ap.add_argument("--strong-total", type=int, default=0,
+                    help="total realizations of the strong-scaling leg of a multi-rank run (0: BASELINE.json's literal count "
+                         "for the configuration: config 4 1e6, config 5 1e5); split contiguously over the ranks")
+    ap.add_argument("--strong-reps", type=int, default=5, help="timed repetitions of the strong-scaling leg (median reported)")
     ap.add_argument("--launch-check", action="store_true",
                     help="no GPU: run the rank launcher, the range split and the reduction on gloo with an integer "
                          "checksum per realization index instead of a kernel (prints ranges + counters, no rate)")
@@ -231,6 +249,29 @@ def _cpu_model():
     return None
 
 
+def _physical_cores():
+    """(physical cores, logical CPUs) of the host: distinct (physical id, core id) pairs of /proc/cpuinfo."""
+    logical = os.cpu_count() or 1
+    try:
+        pairs, phys, core = set(), None, None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":", 1)[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    pairs.add((phys, core))
+                phys = core = None
+        if phys is not None and core is not None:
+            pairs.add((phys, core))
+        if pairs:
+            return min(len(pairs), logical), logical
+    except OSError:
+        pass
+    return max(1, logical // 2 if logical >= 4 else logical), logical
+
+
 def _oracle_chain(cfg):
     """(oracle chain, kwargs) of a bench configuration -- used by the cpu_baseline legs only."""
     from oracle import chains
@@ -291,8 +332,12 @@ def cpu_baseline_multicore(cfg, single_core_rate, budget_s):
     """The same oracle on every host core at once (one process per core, disjoint realization ranges),
     sized from the single-core rate to take about `budget_s` seconds."""
     import multiprocessing as mp
-    cores = os.cpu_count() or 1
-    workers = max(1, min(cores // 2 if cores >= 4 else cores, 64))     # one per physical core, capped
+    physical, logical = _physical_cores()
+    try:
+        physical = min(physical, len(os.sched_getaffinity(0)))        # what this process may actually use
+    except (AttributeError, OSError):
+        pass
+    workers = max(1, min(physical, 256))                              # one process per physical core
     per = max(1, int(single_core_rate * budget_s * 0.7))
     ctx = mp.get_context("spawn")
     t0 = time.perf_counter()
@@ -302,10 +347,12 @@ def cpu_baseline_multicore(cfg, single_core_rate, budget_s):
     n = sum(d[0] for d in done)
     busy = max(d[1] for d in done)
     return {"value": n / busy, "unit": "realizations/s", "cores": workers, "kind": "port",
+            "host_physical_cores": physical, "host_logical_cpus": logical,
             "scaling_vs_one_core": (n / busy) / single_core_rate,
-            "sample": "%d realizations over %d processes (spawn), slowest worker %.1f s, wall %.1f s incl. start-up; "
-                      "the box gives far less than %d cores' worth (shared memory bandwidth / boost clocks)"
-                      % (n, workers, busy, wall, workers)}
+            "sample": "%d realizations over %d processes (spawn) = one per physical core of %d (%d logical CPUs), slowest "
+                      "worker %.1f s, wall %.1f s incl. start-up; scaling against the one-core leg %.1f x (shared memory "
+                      "bandwidth / boost clocks)"
+                      % (n, workers, physical, logical, busy, wall, (n / busy) / single_core_rate)}
 
 
 # ---- rocprofv3 counters of the dominant kernel, collected by child runs of this file ----------------------------
@@ -407,7 +454,11 @@ def roofline_block(args, dtype, batch, per_launch_s, rate_kernel, d, pmc_source)
     if measured is not None:
         eff = min(float(balg), measured)
         hbm.update(achieved_GBps=eff * rate_kernel / 1e9, frac=eff * rate_kernel / 1e9 / HBM_PEAK_GBPS,
-                   frac_of_measured_copy_bw=eff * rate_kernel / 1e9 / HBM_COPY_GBPS, peak_GBps=HBM_PEAK_GBPS,
+                   frac_of_measured_copy_bw=eff * rate_kernel / 1e9 / (MEASURED["copy_GBps"] or HBM_COPY_GBPS),
+                   copy_GBps=MEASURED["copy_GBps"] or HBM_COPY_GBPS,
+                   copy_GBps_source="torch copy_ of 1 GiB measured in this run" if MEASURED["copy_GBps"] else
+                                    "MI355X_MICROARCH.md constant (not measured in this run)",
+                   peak_GBps=HBM_PEAK_GBPS,
                    rule="min(B_alg, measured bytes) x rate (SURVEY.md 8(d)); measured = (2*FETCH_SIZE + WRITE_SIZE) KiB")
     block = {"bound": "valu", "dtype": dtype, "achieved": achieved_tf, "peak": peak, "unit": "TFLOP/s",
              "frac": achieved_tf / peak,
@@ -416,7 +467,7 @@ def roofline_block(args, dtype, batch, per_launch_s, rate_kernel, d, pmc_source)
                           "FP32 vector = f32-input MFMA peak (MI355X_MICROARCH.md)",
              "traffic": (measured * batch) if measured is not None else None,      # HBM bytes per launch of `batch` realizations
              "kernel": kernel_name(args.config, dtype), "kernel_ms_per_launch": per_launch_s * 1e3,
-             "kernel_note": KERNEL_NOTE.get(args.config),
+             "kernel_note": KERNEL_NOTE.get((args.config, dtype), KERNEL_NOTE.get(args.config)),
              "realizations_per_launch": batch,
              "flops_per_realization": f_total, "flops_breakdown": flops, "uncounted": UNCOUNTED.get(args.config),
              "hbm": hbm,
@@ -464,9 +515,24 @@ def launch_check(args, rank, world):
     dist.all_reduce(vec, op=dist.ReduceOp.SUM)
     ranges = [None] * world
     dist.all_gather_object(ranges, [int(lo), int(lo + args.steps * batch)])
+    # the strong split of main(): `total` realizations (BASELINE's literal count) cut contiguously, in calls of <= batch
+    s_total = args.strong_total or STRONG_TOTAL[args.config]
+    s_lo, s_hi = (s_total * rank) // world, (s_total * (rank + 1)) // world
+    s_tot = np.zeros(6, dtype=np.int64)
+    pos = s_lo
+    while pos < s_hi:
+        n = min(batch, s_hi - pos)
+        s_tot += np.array(_checksum_counts((17 << 36) + pos, n), dtype=np.int64)
+        pos += n
+    s_vec = torch.tensor(s_tot)
+    dist.all_reduce(s_vec, op=dist.ReduceOp.SUM)
+    s_ranges = [None] * world
+    dist.all_gather_object(s_ranges, [int(s_lo), int(s_hi)])
     if rank == 0:
         print(json.dumps({"launch_check": True, "n_gpus": world, "steps": args.steps, "value": None,
                           "rank_ranges": ranges, "counters": dict(zip(COUNTER_KEYS, [int(v) for v in vec.tolist()])),
+                          "strong": {"total_realizations": s_total, "rank_ranges": s_ranges,
+                                     "counters": dict(zip(COUNTER_KEYS, [int(v) for v in s_vec.tolist()]))},
                           "note": "launcher / sharding / reduction self-test on gloo; no kernel ran, no rate"}),
               flush=True)
     dist.destroy_process_group()
@@ -511,6 +577,31 @@ def main():
         eng.set_option(name, int(val))
     batch = args.batch or BATCH[args.config]
     exchange_calls = {"timed": 0}
+    # ---- who carries the exchange: the product's own RCCL communicator (csrc/comm.hip) or torch.distributed ----
+    native, comm_note = None, None
+    if use_dist and args.comm != "torch":
+        if args.dist_backend != "nccl":
+            comm_note = "native exchange needs one GPU per rank (RCCL): backend is %s" % args.dist_backend
+            if args.comm == "native":
+                raise SystemExit("bench.py: --comm native: " + comm_note)
+        else:
+            from pyphysim_amd.distributed import NativeComm
+            uid, ok, err = None, 1, None
+            try:     # step 1: the 128-byte RCCL id, rank 0 -> everyone over the product's TCP rendezvous
+                uid = NativeComm.rendezvous(eng, rank, world, timeout=60.0)
+            except Exception as exc:
+                ok, err = 0, repr(exc)
+            flag = torch.tensor([ok], dtype=torch.int64, device=xdev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)      # every rank must hold the id before anyone blocks in ncclCommInitRank
+            if int(flag[0]) == 1:
+                native = NativeComm(eng, rank, world, unique_id=uid)      # step 2: mcle_comm_init on the context's device
+            else:
+                comm_note = "NativeComm rendezvous failed on some rank (%s): exchange through torch.distributed" % err
+                if args.comm == "native":
+                    raise SystemExit("bench.py: --comm native: " + comm_note)
+    exchange_impl = ("native: mcle_counters_allreduce (pack kernel + grouped ncclAllReduce uint64 SUM / MAX + unpack on the "
+                     "context stream; the counters never visit the host before the reduction)") if native else \
+                    ("torch: read_counters -> torch.distributed.all_reduce(%s)" % args.dist_backend if use_dist else None)
 
     def barrier():
         eng.sync()
@@ -541,6 +632,8 @@ def main():
         if use_dist:   # bring the communicator up outside the timed region (same shape / dtype as the real exchange)
             dist.all_reduce(torch.zeros(6, dtype=torch.int64, device=xdev), op=dist.ReduceOp.SUM)
             dist.all_reduce(torch.zeros(2, dtype=torch.float64, device=xdev), op=dist.ReduceOp.MAX)
+            if native is not None:
+                eng.counters_allreduce(counters, 1)
         barrier()
         counters.zero()
         barrier()
@@ -552,11 +645,17 @@ def main():
             for s in range(args.steps):
                 run(lo + s * batch, batch, counters)
             kernel_ms = eng.timer_stop_ms()        # HIP events on the stream the kernels ran on
-        local = eng.read_counters(counters)
-        vec = torch.tensor([local[k] for k in COUNTER_KEYS], dtype=torch.int64, device=xdev)
-        if use_dist:
-            dist.all_reduce(vec, op=dist.ReduceOp.SUM)     # RCCL over xGMI: the path's only exchange step
-            exchange_calls["timed"] += 1
+        if native is not None:
+            eng.counters_allreduce(counters, 1)            # RCCL over xGMI, on the context stream, in place: the path's only
+            exchange_calls["timed"] += 1                   # exchange step, as BatchedSimulationRunner + NativeComm run it
+            local = eng.read_counters(counters)            # (blocks on the stream) -- every rank now reads the global sums
+            vec = torch.tensor([local[k] for k in COUNTER_KEYS], dtype=torch.int64, device=xdev)
+        else:
+            local = eng.read_counters(counters)
+            vec = torch.tensor([local[k] for k in COUNTER_KEYS], dtype=torch.int64, device=xdev)
+            if use_dist:
+                dist.all_reduce(vec, op=dist.ReduceOp.SUM)     # RCCL over xGMI: the path's only exchange step
+                exchange_calls["timed"] += 1
         barrier()
         elapsed = time.perf_counter() - t0
         tmax = torch.tensor([elapsed, kernel_ms, -kernel_ms if active else -1e30], dtype=torch.float64, device=xdev)
@@ -567,6 +666,51 @@ def main():
         return {"elapsed": float(tmax[0]), "kernel_ms": float(tmax[1]), "kernel_ms_min": -float(tmax[2]), "tot": tot,
                 "workload": workload, "units": units, "rate": (tot[0] + tot[1]) / float(tmax[0]),
                 "kernel_ms_per_launch": float(tmax[1]) / args.steps}
+
+    def timed_strong(demod, dtype, total, base, solo=False):
+        """The configuration's LITERAL realization count split over the ranks ("strong" scaling): rank r runs the contiguous
+        block [floor(total r / n), floor(total (r + 1) / n)) in calls of <= batch realizations, then the one all-reduce;
+        barrier + synchronize on both sides; --strong-reps repetitions on disjoint index ranges after one untimed one,
+        each repetition's elapsed time = max over ranks."""
+        run, units, workload = make_runner(eng, args.config, demod, dtype)
+        n_active = 1 if solo else world
+        r_idx = 0 if solo else rank
+        active = (not solo) or rank == 0
+        counters = eng.new_counters()
+        times = []
+        for rep in range(args.strong_reps + 1):
+            lo = base + rep * total + (total * r_idx) // n_active
+            hi = base + rep * total + (total * (r_idx + 1)) // n_active
+            barrier()
+            counters.zero()
+            barrier()
+            t0 = time.perf_counter()
+            if active:
+                pos = lo
+                while pos < hi:
+                    n = min(batch, hi - pos)
+                    run(pos, n, counters)
+                    pos += n
+            if native is not None:
+                eng.counters_allreduce(counters, 1)
+                local = eng.read_counters(counters)
+                vec = torch.tensor([local[k] for k in COUNTER_KEYS], dtype=torch.int64, device=xdev)
+            else:
+                local = eng.read_counters(counters)
+                vec = torch.tensor([local[k] for k in COUNTER_KEYS], dtype=torch.int64, device=xdev)
+                if use_dist:
+                    dist.all_reduce(vec, op=dist.ReduceOp.SUM)
+            barrier()
+            el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=xdev)
+            if use_dist:
+                dist.all_reduce(el, op=dist.ReduceOp.MAX)
+            tot_s = [int(v) for v in vec.tolist()]
+            assert tot_s[0] + tot_s[1] == total, (tot_s, total)
+            if rep > 0:
+                times.append(float(el[0]))
+        times.sort()
+        return {"elapsed_s": times[len(times) // 2], "elapsed_min_s": times[0], "elapsed_all_s": times,
+                "ser": tot_s[2] / float(max(1, tot_s[0]) * units)}
 
     head = timed(args.demod, args.dtype, 0)
     elapsed, kernel_ms, tot, workload, units = head["elapsed"], head["kernel_ms"], head["tot"], head["workload"], head["units"]
@@ -582,6 +726,25 @@ def main():
                 rates.setdefault(dt, {})[dm] = timed(dm, dt, base_i << 36)
                 base_i += 1
     solo = timed(args.demod, args.dtype, 15 << 36, solo=True) if world > 1 else None
+    strong = None
+    if use_dist and args.strong_reps > 0:
+        s_total = args.strong_total or STRONG_TOTAL[args.config]
+        s_all = timed_strong(args.demod, args.dtype, s_total, 17 << 36)
+        s_one = timed_strong(args.demod, args.dtype, s_total, 18 << 36, solo=True) if world > 1 else s_all
+        strong = {"scaling": "strong", "total_realizations": s_total,
+                  "per_rank_realizations": [(s_total * (r + 1)) // world - (s_total * r) // world for r in range(world)],
+                  "elapsed_s": s_all["elapsed_s"], "elapsed_min_s": s_all["elapsed_min_s"], "reps": args.strong_reps,
+                  "value": s_total / s_all["elapsed_s"], "unit": "realizations/s",
+                  "n1_elapsed_s": s_one["elapsed_s"], "n1_value": s_total / s_one["elapsed_s"],
+                  "speedup_vs_n1": s_one["elapsed_s"] / s_all["elapsed_s"],
+                  "efficiency": s_one["elapsed_s"] / s_all["elapsed_s"] / world,
+                  "ser": s_all["ser"],
+                  "what": "BASELINE.json's literal realization count for this configuration split contiguously over the ranks, "
+                          "one counter all-reduce, barrier + synchronize on both sides, median of the repetitions; n1 = rank 0 "
+                          "alone on the same total inside the same job",
+                  "note": "at this size a rank's share is %.2f ms of kernel at the one-rank rate: launch latency, the all-reduce and "
+                          "the two barriers are a visible part of the region, so the strong figure sits below the weak one by "
+                          "construction" % (1e3 * s_one["elapsed_s"] / world)}
     # who ran: device name and PCI bus id of every rank (RCCL's view of the job next to the launcher's)
     props = torch.cuda.get_device_properties(gpu)
     me = {"rank": rank, "local_rank": local_rank, "gpu": gpu, "device": props.name,
@@ -595,6 +758,13 @@ def main():
 
     if rank == 0:
         value = n_real / elapsed
+        if world == 1 and not args.no_cpu:
+            try:
+                sys.path.insert(0, os.path.join(REPO, "scripts"))
+                import bench_staged_c4
+                MEASURED["copy_GBps"] = bench_staged_c4.measure_copy_GBps()
+            except Exception:
+                pass
 
         def roof(dt, dm, res):
             """roofline block of the (dtype, demod) kernel: live rocprofv3 counters when possible (child runs at a smaller
@@ -639,9 +809,14 @@ def main():
                        "symbols_per_realization": units, "parallelism": "realization-sharded x%d" % world,
                        "rank_ranges": [[r * args.steps * batch, (r + 1) * args.steps * batch] for r in range(world)],
                        "exchange": ("one all-reduce(SUM) of 6 int64 counters over RCCL, inside the timed region "
-                                    "(%d ranks)" % world) if use_dist else "none (single process, no process group)",
+                                    "(%d ranks; %s)" % (world, "the product's mcle_counters_allreduce" if native is not None
+                                                        else "torch.distributed.all_reduce"))
+                       if use_dist else "none (single process, no process group)",
                        "rng": "Philox4x32-10 keyed by (seed, realization)"},
             "rccl": {"process_group": bool(use_dist), "backend": dist.get_backend() if use_dist else None,
+                     "exchange_impl": exchange_impl, "exchange_note": comm_note,
+                     "native_comm": ({"rank": native.rank, "world": native.world, "info": list(eng.comm_info())}
+                                     if native is not None else None),
                      "rccl_world_size": dist.get_world_size() if use_dist else 1,
                      "allreduce_calls_in_timed_regions": exchange_calls["timed"],
                      "ranks": ranks_info},
@@ -650,6 +825,8 @@ def main():
             "n_skipped": tot[1],
             "roofline": roof(args.dtype, args.demod, head),
         }
+        if strong is not None:
+            out["strong"] = strong
         if world > 1:
             out["kernel_ms_per_rank"] = {"min": head["kernel_ms_min"], "max": head["kernel_ms"]}
             out["n1_value"] = solo["rate"]
@@ -713,14 +890,24 @@ def main():
                             others[cfg]["workload"] = wl_o
                         except Exception as exc:
                             others[cfg][dt] = {"error": repr(exc)}
+                # the north star's HBM clause: config 4 staged through HBM, both arithmetics, with the copy rate of THIS box
+                # measured in THIS run and the bytes the chain really moves (rocprofv3 child runs; SURVEY 8(d)'s min rule)
                 try:
                     sys.path.insert(0, os.path.join(REPO, "scripts"))
                     import bench_staged_c4
-                    others["c4_staged"] = bench_staged_c4.run(eng, batch=8192, seconds=1.0)
+                    copy_bw = MEASURED["copy_GBps"] or bench_staged_c4.measure_copy_GBps()
+                    want_bytes = args.pmc != "off"
+                    others["c4_staged"] = bench_staged_c4.run(eng, batch=8192, seconds=1.0, copy_GBps=copy_bw,
+                                                              hbm_counters=want_bytes)
+                    others["c4_staged_f64"] = bench_staged_c4.run(eng, batch=8192, seconds=1.0, dtype="f64", copy_GBps=copy_bw,
+                                                                  hbm_counters=want_bytes)
+                    out["hbm_copy_GBps_measured_this_run"] = copy_bw
                 except Exception as exc:
                     others["c4_staged"] = {"error": repr(exc)}
                 out["other_workloads"] = others
         print(json.dumps(out), flush=True)
+    if native is not None:
+        native.close()
     if use_dist:
         dist.destroy_process_group()
     eng.close()

@@ -87,16 +87,26 @@ def _exchange_id(make_id, rank, world, addr, port, timeout=120.0):
 class NativeComm:
     """libmcle's RCCL communicator on `engine`'s context."""
 
-    def __init__(self, engine, rank=None, world=None, master_addr=None, master_port=None):
+    def __init__(self, engine, rank=None, world=None, master_addr=None, master_port=None, unique_id=None, timeout=120.0):
+        """unique_id: the 128-byte RCCL id when the caller has already distributed it (NativeComm.rendezvous, or any other
+        channel); None = rendezvous here.  Two steps for callers that want to agree on the outcome of the first before
+        entering the second: ncclCommInitRank blocks until EVERY rank has joined."""
         env_rank, _, env_world = env_rank_world()
         self.engine = engine
         self.rank = env_rank if rank is None else int(rank)
         self.world = env_world if world is None else int(world)
-        addr = master_addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
-        port = int(master_port or os.environ.get("MCLE_COMM_PORT", int(os.environ.get("MASTER_PORT", "29500")) + 17))
-        uid = _exchange_id(engine.comm_unique_id, self.rank, self.world, addr, port)
+        uid = unique_id if unique_id is not None else self.rendezvous(engine, self.rank, self.world, master_addr, master_port,
+                                                                       timeout)
         engine.comm_init(uid, self.rank, self.world)
         self._cnt = engine.new_counters()
+
+    @staticmethod
+    def rendezvous(engine, rank, world, master_addr=None, master_port=None, timeout=120.0):
+        """Rank 0 draws the RCCL id and serves it over TCP at MASTER_ADDR : MCLE_COMM_PORT (default MASTER_PORT + 17);
+        returns the id on every rank, raises after `timeout` seconds."""
+        addr = master_addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
+        port = int(master_port or os.environ.get("MCLE_COMM_PORT", int(os.environ.get("MASTER_PORT", "29500")) + 17))
+        return _exchange_id(engine.comm_unique_id, int(rank), int(world), addr, port, timeout)
 
     def close(self):
         self.engine.comm_destroy()

@@ -52,8 +52,71 @@ def bind(eng, M=64):
     eng.set_constellation(constellation("qam", M), _lib.CONST_QAM)
 
 
-def run(eng, batch=8192, seconds=1.0, dtype="f32", demod="mindist"):
-    """Time the chain for about `seconds` (HIP events around whole passes) -> the dict bench.py embeds."""
+def measure_copy_GBps(nbytes=1 << 30, reps=10):
+    """The box's device-to-device copy rate (read + write bytes per second) measured in THIS run with torch's own copy kernel
+    on a 1 GiB buffer -- the achievable-HBM figure SURVEY.md 8(d) asks to be quoted next to the 8 TB/s peak.  None without torch."""
+    try:
+        import torch
+        a = torch.empty(nbytes // 4, dtype=torch.float32, device="cuda").fill_(1.0)
+        b = torch.empty_like(a)
+        for _ in range(3):
+            b.copy_(a)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            b.copy_(a)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1)
+        del a, b
+        torch.cuda.empty_cache()
+        return 2.0 * nbytes * reps / (ms * 1e-3) / 1e9
+    except Exception:
+        return None
+
+
+def collect_hbm_bytes(dtype, batch, demod="mindist", passes=3):
+    """HBM bytes one pass of the chain really moves, per realization: two `rocprofv3 --pmc` child runs of this file
+    (FETCH_SIZE and WRITE_SIZE do not fit one pass) over exactly `passes` passes without warm-up, every dispatch summed
+    (the nine operator kernels + the small launches), (2 x FETCH_SIZE + WRITE_SIZE) KiB as in bench.py's derive_pmc
+    (gfx950: FETCH_SIZE counts half of a coalesced stream's bytes, MI355X_MICROARCH.md).  -> (bytes, note)"""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None, "rocprofv3 not on PATH"
+    root = tempfile.mkdtemp(prefix="staged_pmc_", dir="/tmp")
+    tot = {}
+    try:
+        for name in ("FETCH_SIZE", "WRITE_SIZE"):
+            out_dir = os.path.join(root, name)
+            cmd = [exe, "--pmc", name, "--output-format", "csv", "-d", out_dir, "-o", "pmc", "--", sys.executable,
+                   os.path.abspath(__file__), "--dtype", dtype, "--batch", str(batch), "--demod", demod, "--passes", str(passes)]
+            subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), timeout=240, stdout=subprocess.DEVNULL,
+                           stderr=subprocess.DEVNULL)
+            v = 0.0
+            for path in glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(path)):
+                    if row["Counter_Name"] == name:
+                        v += float(row["Counter_Value"])
+            tot[name] = v
+    except Exception as exc:
+        return None, repr(exc)
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+    if not tot.get("FETCH_SIZE") or not tot.get("WRITE_SIZE"):
+        return None, "no counter rows"
+    return (2.0 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024.0 / (passes * batch), None
+
+
+def run(eng, batch=8192, seconds=1.0, dtype="f32", demod="mindist", copy_GBps=None, hbm_counters=False):
+    """Time the chain for about `seconds` (HIP events around whole passes) -> the dict bench.py embeds.
+    copy_GBps: the copy rate measured on this box in this run (measure_copy_GBps); hbm_counters: also count the bytes the
+    chain really moves (collect_hbm_bytes) and apply SURVEY 8(d)'s rule min(B_alg, measured) x rate."""
     from pyphysim_amd import _lib
     method = _lib.DEMOD_MINDIST if demod == "mindist" else _lib.DEMOD_QAM_SLICER
     bind(eng)
@@ -78,7 +141,16 @@ def run(eng, batch=8192, seconds=1.0, dtype="f32", demod="mindist"):
     n = steps * batch
     rate = n / (ms * 1e-3)
     balg = sum(B_ALG.values()) * (2 if dtype == "f64" else 1)
-    return {"workload": "config 4 staged through HBM, one kernel per reference operator (SURVEY 8(d) staged model)",
+    measured, mnote = collect_hbm_bytes(dtype, batch, demod) if hbm_counters else (None, "not collected")
+    eff = min(float(balg), measured) if measured else float(balg)
+    extra = {"measured_hbm_bytes_per_realization": measured, "measured_over_b_alg": (measured / balg) if measured else None,
+             "hbm_counter_note": mnote or "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child runs of 3 passes, every dispatch summed; "
+                                          "(2 x FETCH_SIZE + WRITE_SIZE) KiB",
+             "frac_rule": "min(B_alg, measured bytes) x rate / 8 TB/s (SURVEY.md 8(d))",
+             "frac_min_rule": eff * rate / 1e9 / HBM_PEAK_GBPS,
+             "copy_GBps_measured_this_run": copy_GBps,
+             "frac_of_copy_bw_measured_this_run": (eff * rate / 1e9 / copy_GBps) if copy_GBps else None}
+    return {**extra, "workload": "config 4 staged through HBM, one kernel per reference operator (SURVEY 8(d) staged model)",
             "dtype": dtype, "demod": demod, "realizations_per_s": rate, "batch": batch, "passes": steps,
             "ms_per_pass": ms / steps, "wall_s": wall, "b_alg_bytes_per_realization": balg, "b_alg_breakdown": B_ALG,
             "achieved_GBps": balg * rate / 1e9, "frac": balg * rate / 1e9 / HBM_PEAK_GBPS,
@@ -94,10 +166,23 @@ def main():
     ap.add_argument("--seconds", type=float, default=1.0)
     ap.add_argument("--dtype", default="f32")
     ap.add_argument("--demod", default="mindist", choices=["mindist", "slicer"])
+    ap.add_argument("--passes", type=int, default=0,
+                    help="exactly this many passes, no warm-up, no timing (the counter child runs of collect_hbm_bytes)")
+    ap.add_argument("--counters", action="store_true", help="also count HBM bytes (rocprofv3 child runs) and the copy rate")
     args = ap.parse_args()
+    from pyphysim_amd import _lib
     from pyphysim_amd.engine import Engine
     eng = Engine(0, args.dtype)
-    print(json.dumps(run(eng, args.batch, args.seconds, args.dtype, args.demod)))
+    if args.passes > 0:
+        bind(eng)
+        cnt = eng.new_counters()
+        method = _lib.DEMOD_MINDIST if args.demod == "mindist" else _lib.DEMOD_QAM_SLICER
+        for s in range(args.passes):
+            chain(eng, s * args.batch, args.batch, cnt, args.dtype, method)
+        eng.sync()
+    else:
+        copy = measure_copy_GBps() if args.counters else None
+        print(json.dumps(run(eng, args.batch, args.seconds, args.dtype, args.demod, copy_GBps=copy, hbm_counters=args.counters)))
     eng.close()
 
 

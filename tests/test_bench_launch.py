@@ -34,6 +34,21 @@ def test_gpus_flag_launches_that_many_ranks_with_disjoint_ranges():
     assert one["counters"]["n_realizations"] == 3072 and one["counters"]["sym_errors"] > 0
 
 
+@pytest.mark.timeout(600)
+def test_strong_split_covers_the_literal_total_once():
+    """The strong-scaling leg (BASELINE config 4: 10^6 realizations over the ranks; here 10 007 to keep the remainder
+    visible): contiguous blocks floor(T r / N) .. floor(T (r + 1) / N), union = [0, T), reduced counters = the one-rank ones."""
+    one = _bench("--gpus", "1", "--steps", "2", "--batch", "512", "--strong-total", "10007")
+    two = _bench("--gpus", "2", "--steps", "1", "--batch", "512", "--strong-total", "10007")
+    assert one["strong"]["rank_ranges"] == [[0, 10007]]
+    assert two["strong"]["rank_ranges"] == [[0, 5003], [5003, 10007]]
+    assert two["strong"]["counters"] == one["strong"]["counters"]
+    assert one["strong"]["counters"]["n_realizations"] == 10007 and one["strong"]["total_realizations"] == 10007
+    default = _bench("--gpus", "2", "--steps", "1", "--batch", "65536")
+    assert default["strong"]["total_realizations"] == 10 ** 6           # config 4's literal count
+    assert default["strong"]["rank_ranges"] == [[0, 500000], [500000, 1000000]]
+
+
 def test_world_size_must_match_gpus():
     env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
     out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--launch-check", "--gpus", "2"], env=env,

@@ -46,6 +46,11 @@ def test_default_line_carries_every_contract_field():
     st = d["other_workloads"]["c4_staged"]
     assert st["b_alg_bytes_per_realization"] == 412160 and st["realizations_per_s"] > 1e6 and 0.0 < st["frac"] < 1.0
     assert abs(st["frac"] - st["b_alg_bytes_per_realization"] * st["realizations_per_s"] / 8e12) <= 1e-9
+    st64 = d["other_workloads"]["c4_staged_f64"]                  # the HBM clause in the reference's precision, same run
+    assert st64["dtype"] == "f64" and st64["b_alg_bytes_per_realization"] == 2 * 412160 and 0.0 < st64["frac"] < 1.0
+    assert st64["ser"] == d["ser"] or abs(st64["ser"] - d["ser"]) < 0.05      # same link, other index range
+    assert d["hbm_copy_GBps_measured_this_run"] > 1000.0 and st["copy_GBps_measured_this_run"] == d["hbm_copy_GBps_measured_this_run"]
+    assert d["roofline"]["hbm"].get("copy_GBps", 0) > 1000.0 or d["roofline"]["hbm"]["measured_bytes_per_realization"] is None
     for cfg in ("c2", "c3", "c5", "f1", "f6"):
         for dt in ("f64", "f32"):
             assert d["other_workloads"][cfg][dt]["realizations_per_s"] > 0, (cfg, dt)

@@ -182,6 +182,20 @@ def test_bench_under_the_drivers_launch_line_runs_the_rccl_allreduce():
     assert line["rccl"]["process_group"] is True and line["rccl"]["backend"] == "nccl"
     assert line["rccl"]["rccl_world_size"] == 1 and line["rccl"]["allreduce_calls_in_timed_regions"] >= 1
     assert "RCCL" in line["config"]["exchange"] and line["n_gpus"] == 1 and line["value"] > 0
+    # the timed exchange is the PRODUCT's: NativeComm -> mcle_counters_allreduce on the context stream (--comm auto)
+    assert line["rccl"]["exchange_impl"].startswith("native") and line["rccl"]["native_comm"]["world"] == 1
+    assert "mcle_counters_allreduce" in line["config"]["exchange"]
+    # the strong leg: the configuration's literal total (config 4: 10^6) on the one rank
+    st = line["strong"]
+    assert st["total_realizations"] == 10 ** 6 and st["per_rank_realizations"] == [10 ** 6] and st["value"] > 1e6
+    assert abs(st["efficiency"] - 1.0) < 1e-9 and st["ser"] > 0
+    # the alternative exchange is still there and says so
+    alt = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                          "--master-addr", "127.0.0.1", "--master-port", "29543", os.path.join(repo, "bench.py")] + common +
+                         ["--comm", "torch", "--strong-reps", "0"], env=env, capture_output=True, text=True, timeout=600)
+    assert alt.returncode == 0, alt.stderr[-3000:]
+    a = json.loads([l for l in alt.stdout.splitlines() if l.startswith("{")][-1])
+    assert a["rccl"]["exchange_impl"].startswith("torch") and "strong" not in a and a["ser"] == line["ser"]
     assert line["rccl"]["ranks"][0]["device"]
     plain = subprocess.run([sys.executable, os.path.join(repo, "bench.py")] + common, env=env, capture_output=True,
                            text=True, timeout=600)
@@ -207,7 +221,7 @@ def test_bench_two_rank_code_path_on_one_gpu():
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
     common = ["--warmup", "1", "--batch", "4096", "--no-cpu", "--pmc", "off", "--preroll-ms", "0", "--single-demod"]
     two = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "2", "--dist-backend", "gloo",
-                          "--share-gpus"] + common, env=env, capture_output=True, text=True, timeout=800)
+                          "--share-gpus", "--strong-total", "20000", "--strong-reps", "2"] + common, env=env, capture_output=True, text=True, timeout=800)
     assert two.returncode == 0, two.stderr[-3000:]
     lines = [l for l in two.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1                                                  # ONE JSON line, from rank 0
@@ -217,6 +231,10 @@ def test_bench_two_rank_code_path_on_one_gpu():
     assert [r["rank"] for r in t["rccl"]["ranks"]] == [0, 1] and all(r["device"] for r in t["rccl"]["ranks"])
     assert t["n1_value"] > 0 and t["kernel_ms_per_rank"]["min"] > 0 and t["kernel_ms_per_rank"]["max"] >= t["kernel_ms_per_rank"]["min"]
     assert t["rccl"]["allreduce_calls_in_timed_regions"] >= 2               # the two-rank region and the rank-0-alone region
+    assert t["rccl"]["exchange_impl"].startswith("torch")                    # gloo: two ranks share one device, no RCCL
+    st = t["strong"]                                                         # 20 000 realizations cut in two
+    assert st["total_realizations"] == 20000 and st["per_rank_realizations"] == [10000, 10000]
+    assert st["n1_value"] > 0 and st["value"] > 0 and 0.0 < st["efficiency"] < 2.0
     one = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "1", "--steps", "4"] + common, env=env,
                          capture_output=True, text=True, timeout=800)
     assert one.returncode == 0, one.stderr[-3000:]
