@@ -104,9 +104,9 @@ enum {
                                       closed-form nearest level per axis, accepted when the received point is farther than
                                       2^-30 (complex64: 2^-12) of a level spacing from every decision boundary, the table
                                       search otherwise -- identical decisions, no table gathers) */
-    MCLE_OPT_F64_VARIANT = 11,     /* complex128 config-4 kernel, bit mask of measured variants:
-                                      1 = the noise of a realization drawn inside the transmit transform's stages,
-                                      2 = channel fused with the last transmit / first receive stage (256-thread form) */
+    MCLE_OPT_F64_VARIANT = 11,     /* complex128 config-4 kernel (1024, 4x4), TIMING BOUNDS ONLY -- results are wrong by construction:
+                                      bit 0 = the LDS stores of the last transmit stage and of the channel stage dropped, bit 1 =
+                                      the two workgroup barriers around the channel stage dropped */
     MCLE_OPT_COUNT = 12
 };
 int mcle_ctx_set_option(mcle_ctx* ctx, int option, long long value);

@@ -124,7 +124,7 @@ template <int N, int S> __device__ __forceinline__ void stage_tw_fetch(const dou
 // DIF (INV: the transmit IFFT): butterfly, then twiddle; DIT (forward FFT): twiddle, then butterfly.
 // pre: twiddles fetched ahead by the caller (forward transform: a DIT stage multiplies FIRST, so a fetch issued inside
 // the stage sits on its critical path; issued one stage early it hides behind that stage's butterflies)
-template <int N, bool DIF, bool INV, int S, int AH, bool TWR>
+template <int N, bool DIF, bool INV, int S, int AH, bool TWR, bool NOSTORE = false>
 __device__ __forceinline__ void r4_stage_planar(double* s_d, const TwRegs64<N>& tw, const double2* __restrict__ g_tw, int bb,
                                                 const double2* pre = nullptr) {
     constexpr int s = S;
@@ -179,6 +179,10 @@ __device__ __forceinline__ void r4_stage_planar(double* s_d, const TwRegs64<N>& 
             y2 = cmul(y2, w2);
             y3 = cmul(y3, w3);
         }
+        if constexpr (NOSTORE) {                      // timing bound only (MCLE_OPT_F64_VARIANT): computed, not stored
+            asm volatile("" ::"v"(y0.x), "v"(y0.y), "v"(y1.x), "v"(y1.y), "v"(y2.x), "v"(y2.y), "v"(y3.x), "v"(y3.y));
+            continue;
+        }
         double* pr = s_d + (2 * a) * N;
         double* pi = pr + N;
         pr[i0] = y0.x; pr[i1] = y1.x; pr[i2] = y2.x; pr[i3] = y3.x;
@@ -209,7 +213,10 @@ template <int N, int AH> __device__ __forceinline__ void r2_stage_planar(double*
 // benchmark geometry (1024, 4 x 4): AH = 2 -> 512 threads, 4 wavefronts per SIMD at two workgroups per CU, 128 VGPRs;
 // AH = 4 -> 256 threads, 2 per SIMD, up to 256 VGPRs, the twelve twiddles of a thread in registers: LDS caps the workgroups
 // per CU at two, so the first form buys latency hiding with threads instead.
-template <int N, int NT, int NR, int AH, int WPS>
+// VAR (MCLE_OPT_F64_VARIANT; timing bounds ONLY, the results are wrong by construction -- what fusing the channel stage into
+// its neighbouring transform stages could save at most): bit 0 = the stores of the last transmit stage and of
+// the channel stage dropped, bit 1 = the two workgroup barriers around the channel stage dropped.
+template <int N, int NT, int NR, int AH, int WPS, int VAR = 0>
 __global__ __launch_bounds__((N / 4) * (NR / AH), WPS) void k_run_mimo_ofdm_f64(MimoParams pp, ModemParams<double> mp, uint64_t seed,
                                                                      uint64_t first, uint64_t count,
                                                                      const double2* __restrict__ g_tw,
@@ -335,10 +342,10 @@ __global__ __launch_bounds__((N / 4) * (NR / AH), WPS) void k_run_mimo_ofdm_f64(
             //      measured no gain).  Antenna groups beyond Nt have nothing to send and only keep the barriers. ----
             static_for<N4>([&](auto stc) {
                 constexpr int st = decltype(stc)::value, S = SH::span(st);
-                if (tx_grp) r4_stage_planar<N, true, true, S, AH, TWR>(s_mine, twr, g_tw, opaque(bbt));
+                if (tx_grp) r4_stage_planar<N, true, true, S, AH, TWR, (VAR & 1) && st + 1 == N4 && !SH::HAS2>(s_mine, twr, g_tw, opaque(bbt));
                 if constexpr (st + 1 < N4 || SH::HAS2)
                     fft_stage_sync<TB>(S);             // wave-local once the 4 S points of a group sit in one wavefront
-                else
+                else if constexpr (!(VAR & 2))
                     __syncthreads();
             });
             if constexpr (SH::HAS2) {
@@ -378,14 +385,18 @@ __global__ __launch_bounds__((N / 4) * (NR / AH), WPS) void k_run_mimo_ofdm_f64(
                             z0 = cfma(h, x0[a], z0);
                             z1 = cfma(h, x1[a], z1);
                         }
-                        s_d[(2 * r) * N + q0] = z0.x;
-                        s_d[(2 * r + 1) * N + q0] = z0.y;
-                        s_d[(2 * r) * N + q1] = z1.x;
-                        s_d[(2 * r + 1) * N + q1] = z1.y;
+                        if constexpr (VAR & 1) {
+                            asm volatile("" ::"v"(z0.x), "v"(z0.y), "v"(z1.x), "v"(z1.y));
+                        } else {
+                            s_d[(2 * r) * N + q0] = z0.x;
+                            s_d[(2 * r + 1) * N + q0] = z0.y;
+                            s_d[(2 * r) * N + q1] = z1.x;
+                            s_d[(2 * r + 1) * N + q1] = z1.y;
+                        }
                     }
                 }
             }
-            __syncthreads();
+            if constexpr (!(VAR & 2)) __syncthreads();
             // ---- FFT: (the radix-2 stage +) radix-4 DIT, digit-reversed -> natural bins ----
             if constexpr (TWR) {
                 if constexpr (SH::HAS2) {
@@ -496,7 +507,7 @@ __global__ __launch_bounds__((N / 4) * (NR / AH), WPS) void k_run_mimo_ofdm_f64(
 }
 
 // one geometry: filters + link, sliced so that the record buffer stays bounded
-template <int N, int NT, int NR, int AH, int WPS>
+template <int N, int NT, int NR, int AH, int WPS, int VAR = 0>
 static int launch_mimo_ofdm_f64(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, uint64_t seed, uint64_t first, uint64_t count,
                                 mcle_counters* d_counters, uint32_t* d_sym, uint32_t* d_bit) {
     constexpr int kRec = d64_rec<NT, NR>(), TB = (N / 4) * (NR / AH);
@@ -512,7 +523,7 @@ static int launch_mimo_ofdm_f64(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, ui
                        (((size_t)NT * cfg->num_used + 15) & ~(size_t)15) + 16;
     MCLE_REQUIRE(lds + 512 <= (size_t)160 * 1024, "complex128 MIMO-OFDM kernel: %zu B of LDS do not fit (fft_size %d, %d receive antennas)",
                  lds, N, NR);
-    auto kern = k_run_mimo_ofdm_f64<N, NT, NR, AH, WPS>;
+    auto kern = k_run_mimo_ofdm_f64<N, NT, NR, AH, WPS, VAR>;
     MCLE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int per_cu = (int)((size_t)160 * 1024 / (lds + 512));
     const int by_waves = (WPS * 256) / TB > 0 ? (WPS * 256) / TB : 1;          // what __launch_bounds__ allocated registers for
@@ -552,6 +563,13 @@ int run_mimo_ofdm_f64(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, uint64_t see
     // MCLE_OPT_F64_THREADS: 0 / 512 = two antennas per thread, 512-thread workgroups (default); 256 = four antennas per thread
     if (n == 1024 && nt == 4 && nr == 4 && ctx->opt[MCLE_OPT_F64_THREADS] == 256)
         return launch_mimo_ofdm_f64<1024, 4, 4, 4, 2>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
+    if (n == 1024 && nt == 4 && nr == 4 && ctx->opt[MCLE_OPT_F64_VARIANT]) {     // timing bounds (wrong results), see the kernel
+        switch ((int)ctx->opt[MCLE_OPT_F64_VARIANT]) {
+            case 1: return launch_mimo_ofdm_f64<1024, 4, 4, 2, 4, 1>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
+            case 2: return launch_mimo_ofdm_f64<1024, 4, 4, 2, 4, 2>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
+            default: return launch_mimo_ofdm_f64<1024, 4, 4, 2, 4, 3>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
+        }
+    }
     MCLE_F64_GEOM(1024, 4, 4, 2, 4) MCLE_F64_GEOM(1024, 2, 2, 2, 3)
     MCLE_F64_GEOM(2048, 4, 4, 2, 4) MCLE_F64_GEOM(2048, 2, 2, 2, 4)
     MCLE_F64_GEOM(512, 4, 4, 2, 3) MCLE_F64_GEOM(512, 2, 2, 2, 3)
