@@ -163,6 +163,10 @@ int mcle_count_errors(mcle_ctx* ctx, const int32_t* d_tx_idx, const int32_t* d_r
 int mcle_demod_count(mcle_ctx* ctx, int dtype, int method, const void* d_rx,
                      const int32_t* d_tx_idx, size_t n_per_real, size_t n_real,
                      mcle_counters* d_counters, uint32_t* d_sym_err, uint32_t* d_bit_err);
+/* the same against byte labels (mcle_rand_modulate_batch_u8) */
+int mcle_demod_count_u8(mcle_ctx* ctx, int dtype, int method, const void* d_rx,
+                        const uint8_t* d_tx_idx, size_t n_per_real, size_t n_real,
+                        mcle_counters* d_counters, uint32_t* d_sym_err, uint32_t* d_bit_err);
 
 /* ---- a5: randn_c (util/misc.py:327-355) under the mcle-philox-v1 contract, and AWGN ----- */
 /* out[i] = sqrt(variance) * CN(0,1) sample (first_sample + i) of (seed, realization, stream) */
@@ -222,6 +226,10 @@ int mcle_rand_symbols_batch(mcle_ctx* ctx, uint64_t seed, uint64_t first_realiza
  * table[d_idx[r][i]] (randint + Modulator.modulate, modulators/fundamental.py:175-199) */
 int mcle_rand_modulate_batch(mcle_ctx* ctx, int dtype, uint64_t seed, uint64_t first_realization, uint64_t count,
                              int32_t* d_idx, void* d_sym, size_t n);
+/* the same with BYTE labels (M <= 256): SURVEY 8(d)'s staged model counts an index as one byte; the int32 form above moves
+ * four.  Consumed by mcle_demod_count_u8. */
+int mcle_rand_modulate_batch_u8(mcle_ctx* ctx, int dtype, uint64_t seed, uint64_t first_realization, uint64_t count,
+                                uint8_t* d_idx, void* d_sym, size_t n);
 /* element-wise complex product (frequency-domain channel application, fading.py:1259) */
 int mcle_cmul(mcle_ctx* ctx, int dtype, const void* d_a, const void* d_b, void* d_out, size_t n);
 /* element-wise complex divide (flat-fading equalisation y / h of the C2 template) */

@@ -160,6 +160,7 @@ _PROTOS = {
     "mcle_demodulate": (c_int, [_P, c_int, c_int, _P, _P, c_size_t]),
     "mcle_count_errors": (c_int, [_P, _P, _P, c_size_t, c_size_t, c_int, _P, _P, _P]),
     "mcle_demod_count": (c_int, [_P, c_int, c_int, _P, _P, c_size_t, c_size_t, _P, _P, _P]),
+    "mcle_demod_count_u8": (c_int, [_P, c_int, c_int, _P, _P, c_size_t, c_size_t, _P, _P, _P]),
     "mcle_randn_c": (c_int, [_P, c_int, c_uint64, c_uint64, c_uint32, c_uint64, c_double, _P, c_size_t]),
     "mcle_rand_symbols": (c_int, [_P, c_uint64, c_uint64, c_uint64, c_int, _P, c_size_t]),
     "mcle_awgn_add": (c_int, [_P, c_int, _P, _P, c_double, _P, c_size_t]),
@@ -178,6 +179,7 @@ _PROTOS = {
     "mcle_awgn_philox": (c_int, [_P, c_int, _P, c_uint64, c_uint64, c_uint64, c_size_t, c_double, _P]),
     "mcle_rand_symbols_batch": (c_int, [_P, c_uint64, c_uint64, c_uint64, c_int, _P, c_size_t]),
     "mcle_rand_modulate_batch": (c_int, [_P, c_int, c_uint64, c_uint64, c_uint64, _P, _P, c_size_t]),
+    "mcle_rand_modulate_batch_u8": (c_int, [_P, c_int, c_uint64, c_uint64, c_uint64, _P, _P, c_size_t]),
     "mcle_randn_c_batch": (c_int, [_P, c_int, c_uint64, c_uint64, c_uint64, c_uint32, c_size_t, c_double, _P]),
     "mcle_mimo_channel_philox": (c_int, [_P, c_int, _P, _P, c_uint64, c_uint64, c_double, c_int, c_int, c_size_t, _P,
                                          c_size_t]),

@@ -103,9 +103,11 @@ __global__ __launch_bounds__(kBlock) void k_demodulate(ModemParams<T> mp, const 
 
 // ---- error counting --------------------------------------------------------------------------
 // grid = (chunks, realizations-in-flight); per-realization partials land in ws[r] = {sym, bit}.
-template <typename T, bool DEMOD>
+// L: label type of the transmitted / received index arrays (int32_t: the operators' default; uint8_t: the byte labels of
+// the staged chains, SURVEY 8(d)'s I = 1 B -- a quarter of the label traffic)
+template <typename T, bool DEMOD, typename L = int32_t>
 __global__ __launch_bounds__(kBlock) void k_count(ModemParams<T> mp, const cx<T>* __restrict__ rx,
-                                                  const int32_t* __restrict__ a, const int32_t* __restrict__ b,
+                                                  const L* __restrict__ a, const L* __restrict__ b,
                                                   size_t n_per_real, size_t n_real, unsigned* __restrict__ ws) {
     __shared__ cx<T> s_table[DEMOD ? kMaxM : 1];
     __shared__ unsigned long long s_grid[DEMOD ? kMaxGridCells : 1];
@@ -120,8 +122,8 @@ __global__ __launch_bounds__(kBlock) void k_count(ModemParams<T> mp, const cx<T>
         const size_t base = r * n_per_real;
         for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_per_real;
              i += (size_t)gridDim.x * blockDim.x) {
-            const int tx = a[base + i];
-            const int dec = DEMOD ? demod_one(mp, s_table, s_grid, rx[base + i]) : b[base + i];
+            const int tx = (int)a[base + i];
+            const int dec = DEMOD ? demod_one(mp, s_table, s_grid, rx[base + i]) : (int)b[base + i];
             const unsigned x = (unsigned)(tx ^ dec);
             se += (x != 0u);
             be += __popc(x);
@@ -307,16 +309,17 @@ __global__ __launch_bounds__(kBlock) void k_rand_symbols_batch(uint64_t seed, ui
 // label bytes); the wavefront parks its 1 024 bytes in LDS and walks them back two symbols per lane, so that every store
 // instruction covers a contiguous run (512 B of labels, 1 KiB of complex64 samples) -- sixteen labels and samples stored per
 // lane straight from the block (64 B / 128 B strides across the wave) ran at a third of the rate.
-template <typename T>
+template <typename T, typename L = int32_t>
 __global__ __launch_bounds__(kBlock) void k_rand_modulate_batch(ModemParams<T> mp, uint64_t seed, uint64_t first_real,
-                                                                uint32_t mask, int32_t* __restrict__ idx_out,
+                                                                uint32_t mask, L* __restrict__ idx_out,
                                                                 cx<T>* __restrict__ sym_out, size_t n, int vec_ok) {
     __shared__ cx<T> s_table[kMaxM];
     __shared__ __attribute__((aligned(16))) uint32_t s_lab[kBlock * 4];
     load_table(mp, s_table);
     __syncthreads();
     const Rng rng(seed, first_real + blockIdx.y);
-    int32_t* irow = idx_out + (size_t)blockIdx.y * n;
+    L* irow = idx_out + (size_t)blockIdx.y * n;
+    constexpr bool kByte = sizeof(L) == 1;         // byte labels: a thread's sixteen labels ARE its masked Philox block
     cx<T>* srow = sym_out + (size_t)blockIdx.y * n;
     const bool vec = vec_ok != 0;                  // even rows on 8-byte (labels) / 16-byte (samples) boundaries (host check)
     const uint32_t mask4 = mask * 0x01010101u;
@@ -331,6 +334,17 @@ __global__ __launch_bounds__(kBlock) void k_rand_modulate_batch(ModemParams<T> m
             lab = make_uint4(w.w[0] & mask4, w.w[1] & mask4, w.w[2] & mask4, w.w[3] & mask4);
         }
         reinterpret_cast<uint4*>(s_lab)[threadIdx.x] = lab;
+        if constexpr (kByte) {                     // one 16-byte store per lane, contiguous across the wavefront
+            if (b <= last_block) {
+                const uint64_t a0 = 16 * b;
+                if (vec && a0 + 16 <= n) {
+                    *reinterpret_cast<uint4*>(irow + a0) = lab;
+                } else {
+                    const unsigned char* lb = reinterpret_cast<const unsigned char*>(&lab);
+                    for (int e = 0; e < 16 && a0 + e < n; ++e) irow[a0 + e] = (L)lb[e];
+                }
+            }
+        }
         wave_lds_sync();                           // a wavefront reads back only its own kilobyte
         const uint64_t s_wave = 16 * (b0 + 64u * (uint64_t)wave);
 #pragma unroll
@@ -340,7 +354,7 @@ __global__ __launch_bounds__(kBlock) void k_rand_modulate_batch(ModemParams<T> m
             const unsigned pair = *reinterpret_cast<const unsigned short*>(bytes + o);
             const int e0 = (int)(pair & 0xFFu), e1 = (int)(pair >> 8);
             if (vec && a + 2 <= n) {
-                *reinterpret_cast<int2*>(irow + a) = make_int2(e0, e1);
+                if constexpr (!kByte) *reinterpret_cast<int2*>(irow + a) = make_int2(e0, e1);
                 const cx<T> c0 = s_table[e0], c1 = s_table[e1];
                 if constexpr (sizeof(T) == 4) {
                     *reinterpret_cast<float4*>(srow + a) = make_float4(c0.x, c0.y, c1.x, c1.y);
@@ -350,11 +364,11 @@ __global__ __launch_bounds__(kBlock) void k_rand_modulate_batch(ModemParams<T> m
                 }
             } else {
                 if (a < n) {
-                    irow[a] = e0;
+                    if constexpr (!kByte) irow[a] = (L)e0;
                     srow[a] = s_table[e0];
                 }
                 if (a + 1 < n) {
-                    irow[a + 1] = e1;
+                    if constexpr (!kByte) irow[a + 1] = (L)e1;
                     srow[a + 1] = s_table[e1];
                 }
             }
@@ -374,8 +388,8 @@ int check_modem(const mcle_ctx* ctx, int dtype, int method) {
     return MCLE_OK;
 }
 
-template <typename T, bool DEMOD>
-int count_impl(mcle_ctx* ctx, int method, const void* d_rx, const int32_t* d_a, const int32_t* d_b,
+template <typename T, bool DEMOD, typename L = int32_t>
+int count_impl(mcle_ctx* ctx, int method, const void* d_rx, const L* d_a, const L* d_b,
                size_t n_per_real, size_t n_real, int bits, mcle_counters* d_counters, uint32_t* d_sym,
                uint32_t* d_bit) {
     if (n_real == 0) return MCLE_OK;
@@ -392,7 +406,7 @@ int count_impl(mcle_ctx* ctx, int method, const void* d_rx, const int32_t* d_a, 
     if (gx > chunks_needed) gx = chunks_needed;
     if (gx < 1) gx = 1;
     dim3 grid((unsigned)gx, (unsigned)gy);
-    hipLaunchKernelGGL((k_count<T, DEMOD>), grid, dim3(kBlock), 0, ctx->stream, mp, (const cx<T>*)d_rx, d_a, d_b,
+    hipLaunchKernelGGL((k_count<T, DEMOD, L>), grid, dim3(kBlock), 0, ctx->stream, mp, (const cx<T>*)d_rx, d_a, d_b,
                        n_per_real, n_real, (unsigned*)ws);
     MCLE_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_count_finalize, dim3(grid_for(ctx, n_real, kBlock, 1)), dim3(kBlock), 0, ctx->stream,
@@ -484,10 +498,25 @@ int mcle_demod_count(mcle_ctx* ctx, int dtype, int method, const void* d_rx, con
     if (rc) return rc;
     if ((rc = ctx->bind())) return rc;
     if (dtype == MCLE_F32)
-        return count_impl<float, true>(ctx, method, d_rx, d_tx_idx, nullptr, n_per_real, n_real, ctx->bits,
-                                       d_counters, d_sym_err, d_bit_err);
-    return count_impl<double, true>(ctx, method, d_rx, d_tx_idx, nullptr, n_per_real, n_real, ctx->bits, d_counters,
-                                    d_sym_err, d_bit_err);
+        return count_impl<float, true, int32_t>(ctx, method, d_rx, d_tx_idx, (const int32_t*)nullptr, n_per_real, n_real,
+                                                ctx->bits, d_counters, d_sym_err, d_bit_err);
+    return count_impl<double, true, int32_t>(ctx, method, d_rx, d_tx_idx, (const int32_t*)nullptr, n_per_real, n_real,
+                                             ctx->bits, d_counters, d_sym_err, d_bit_err);
+}
+
+int mcle_demod_count_u8(mcle_ctx* ctx, int dtype, int method, const void* d_rx, const uint8_t* d_tx_idx,
+                        size_t n_per_real, size_t n_real, mcle_counters* d_counters, uint32_t* d_sym_err,
+                        uint32_t* d_bit_err) {
+    int rc = check_modem(ctx, dtype, method);
+    if (rc) return rc;
+    MCLE_REQUIRE(ctx->M <= 256, "byte labels: the bound constellation must have M <= 256 (got %d)", ctx->M);
+    if ((rc = ctx->bind())) return rc;
+    const uint8_t* none = nullptr;
+    if (dtype == MCLE_F32)
+        return count_impl<float, true, uint8_t>(ctx, method, d_rx, d_tx_idx, none, n_per_real, n_real, ctx->bits,
+                                                d_counters, d_sym_err, d_bit_err);
+    return count_impl<double, true, uint8_t>(ctx, method, d_rx, d_tx_idx, none, n_per_real, n_real, ctx->bits, d_counters,
+                                             d_sym_err, d_bit_err);
 }
 
 int mcle_randn_c(mcle_ctx* ctx, int dtype, uint64_t seed, uint64_t realization, uint32_t stream,
@@ -557,6 +586,31 @@ int mcle_rand_modulate_batch(mcle_ctx* ctx, int dtype, uint64_t seed, uint64_t f
                            d_idx, (float2*)d_sym, n, vec_ok);
     else
         hipLaunchKernelGGL(k_rand_modulate_batch<double>, grid, dim3(kBlock), 0, ctx->stream,
+                           modem_params<double>(ctx, MCLE_DEMOD_MINDIST), seed, first_realization, (uint32_t)(ctx->M - 1),
+                           d_idx, (double2*)d_sym, n, vec_ok);
+    MCLE_LAUNCH_CHECK();
+    return MCLE_OK;
+}
+
+int mcle_rand_modulate_batch_u8(mcle_ctx* ctx, int dtype, uint64_t seed, uint64_t first_realization, uint64_t count,
+                                uint8_t* d_idx, void* d_sym, size_t n) {
+    int rc = check_modem(ctx, dtype, MCLE_DEMOD_MINDIST);
+    if (rc) return rc;
+    MCLE_REQUIRE((ctx->M & (ctx->M - 1)) == 0 && ctx->M >= 2 && ctx->M <= 256,
+                 "the bound constellation's size must be a power of two in [2, 256] (labels are Philox bytes; got %d)", ctx->M);
+    MCLE_REQUIRE(count <= 65535, "at most 65535 realizations per call");
+    MCLE_REQUIRE(d_idx != nullptr && d_sym != nullptr, "null output");
+    if (n == 0 || count == 0) return MCLE_OK;
+    if ((rc = ctx->bind())) return rc;
+    dim3 grid((unsigned)grid_for(ctx, n / 16 + 1, kBlock, 2), (unsigned)count);
+    // vector stores: rows of whole 16-label groups on 16-byte boundaries (labels and samples)
+    const int vec_ok = (n & 15) == 0 && ((uintptr_t)d_idx & 15u) == 0 && ((uintptr_t)d_sym & 15u) == 0;
+    if (dtype == MCLE_F32)
+        hipLaunchKernelGGL((k_rand_modulate_batch<float, uint8_t>), grid, dim3(kBlock), 0, ctx->stream,
+                           modem_params<float>(ctx, MCLE_DEMOD_MINDIST), seed, first_realization, (uint32_t)(ctx->M - 1),
+                           d_idx, (float2*)d_sym, n, vec_ok);
+    else
+        hipLaunchKernelGGL((k_rand_modulate_batch<double, uint8_t>), grid, dim3(kBlock), 0, ctx->stream,
                            modem_params<double>(ctx, MCLE_DEMOD_MINDIST), seed, first_realization, (uint32_t)(ctx->M - 1),
                            d_idx, (double2*)d_sym, n, vec_ok);
     MCLE_LAUNCH_CHECK();

@@ -260,7 +260,7 @@ __global__ __launch_bounds__((N / 4) * (NR / AH), WPS) void k_run_mimo_ofdm_f64(
     const int bbt = tid & (NB - 1);                               // this thread's butterfly position
     const int grp = tid / NB;                                     // ... of antennas AH grp .. AH grp + AH - 1
     double* s_mine = s_d + grp * (2 * AH * N);
-    const bool tx_grp = grp * AH < NT;                            // wave-uniform: does this group transmit?
+    const bool tx_grp = NT == NR || grp * AH < NT;                // wave-uniform: does this group transmit?
     TwRegs64<N> twr;
     if constexpr (TWR) twr = load_tw64<N>(g_tw, bbt);
     uint64_t it = 0, rl_prev = 0;
@@ -354,7 +354,11 @@ __global__ __launch_bounds__((N / 4) * (NR / AH), WPS) void k_run_mimo_ofdm_f64(
             }
             // ---- channel: R = H T + noise on the samples that survive CP removal ----
             {
-                for (int j = tid; j < N / 2; j += TB) {
+                constexpr int JT = (N / 2) / TB;                // channel iterations per thread: a compile-time count
+                static_assert(JT * TB == N / 2, "channel loop");
+#pragma unroll
+                for (int jj = 0; jj < JT; ++jj) {
+                    const int j = tid + jj * TB;
                     const int half = j / (N / 4), rest = j - half * (N / 4);
                     const int p0 = 2 * half * (N / 4) + rest, p1 = p0 + N / 4;
                     const int m0 = fft_index_of_pos<N>(p0);  // even; position p1 holds m0 + 1

@@ -275,17 +275,19 @@ class Engine:
     def demod_count(self, rx, tx_idx, n_real=1, method=DEMOD_MINDIST, dtype=None, counters=None):
         dt = self._dt(dtype)
         d_rx, _ = self._cin(rx, dt)
-        a, _ = self._iin(tx_idx)
+        if isinstance(tx_idx, DeviceArray) and tx_idx.dtype == np.dtype(np.uint8):     # byte labels (rand_modulate_batch)
+            a, fn = tx_idx, self.lib.mcle_demod_count_u8
+        else:
+            a, _ = self._iin(tx_idx)
+            fn = self.lib.mcle_demod_count
         if a.size != d_rx.size or a.size % n_real:
             raise ValueError("size mismatch")
         if counters is not None:
-            check(self.lib.mcle_demod_count(self.ctx, dt, int(method), d_rx.ptr, a.ptr, a.size // n_real, n_real,
-                                            counters.ptr, None, None))
+            check(fn(self.ctx, dt, int(method), d_rx.ptr, a.ptr, a.size // n_real, n_real, counters.ptr, None, None))
             return None
         cnt = self.zeros(1, np.dtype((np.void, ctypes.sizeof(Counters))))
         se, be = self.empty(n_real, np.uint32), self.empty(n_real, np.uint32)
-        check(self.lib.mcle_demod_count(self.ctx, dt, int(method), d_rx.ptr, a.ptr, a.size // n_real, n_real,
-                                        cnt.ptr, se.ptr, be.ptr))
+        check(fn(self.ctx, dt, int(method), d_rx.ptr, a.ptr, a.size // n_real, n_real, cnt.ptr, se.ptr, be.ptr))
         return self._counters(cnt), se.get(), be.get()
 
     def _counters(self, cnt):
@@ -440,14 +442,18 @@ class Engine:
                                                            out.ptr, int(n)))
         return out
 
-    def rand_modulate_batch(self, n, seed, first, count, dtype=None):
-        """(labels int32 [count, n], samples [count, n]) of realizations first .. first + count - 1 for the bound
-        constellation: rand_symbols_batch and modulate in one pass over HBM."""
+    def rand_modulate_batch(self, n, seed, first, count, dtype=None, labels=np.int32):
+        """(labels [count, n], samples [count, n]) of realizations first .. first + count - 1 for the bound
+        constellation: rand_symbols_batch and modulate in one pass over HBM.  labels: np.int32 (default) or np.uint8
+        (byte labels, M <= 256: a quarter of the label traffic; demod_count takes either)."""
         dt = self._dt(dtype)
-        idx = self.empty((count, n), np.int32)
+        labels = np.dtype(labels)
+        if labels not in (np.dtype(np.int32), np.dtype(np.uint8)):
+            raise ValueError("labels must be int32 or uint8")
+        idx = self.empty((count, n), labels)
         sym = self.empty((count, n), _lib.np_complex(dt))
-        self._raise_value(self.lib.mcle_rand_modulate_batch(self.ctx, dt, int(seed), int(first), int(count),
-                                                            idx.ptr, sym.ptr, int(n)))
+        fn = self.lib.mcle_rand_modulate_batch_u8 if labels == np.dtype(np.uint8) else self.lib.mcle_rand_modulate_batch
+        self._raise_value(fn(self.ctx, dt, int(seed), int(first), int(count), idx.ptr, sym.ptr, int(n)))
         return idx, sym
 
     def slice_rows(self, x, row_len):

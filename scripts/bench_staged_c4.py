@@ -30,12 +30,12 @@ B_ALG = {"H + MMSE filter": 384, "symbols + modulate": 36864, "Blast encode": 65
          "H T + awgn": 66688, "OFDM demodulate x4": 66048, "Blast decode": 65536, "demodulate": 36864, "count": 8192}
 
 
-def chain(eng, first, count, counters, dtype="f32", method=None, noise_var=None, seed=SEED, M=64):
+def chain(eng, first, count, counters, dtype="f32", method=None, noise_var=None, seed=SEED, M=64, labels=np.uint8):
     """One pass of the staged chain over realizations [first, first + count); adds into the device counter block."""
     from pyphysim_amd import _lib
     method = _lib.DEMOD_MINDIST if method is None else method
     nv = (1.0 / (10.0 ** (SNR_DB / 10.0))) if noise_var is None else noise_var
-    idx, sym = eng.rand_modulate_batch(4096, seed, first, count, dtype=dtype)               # [count, 4096] int32, complex
+    idx, sym = eng.rand_modulate_batch(4096, seed, first, count, dtype=dtype, labels=labels)  # [count, 4096] uint8 (I = 1 B), complex
     X = eng.blast_encode(sym, 4, batch=count, dtype=dtype)                                  # [count, 4, 1024]
     T = eng.ofdm_modulate(X, 1024, 16, 1024, batch=count * 4, dtype=dtype).reshape(count, 4, 1040)
     H = eng.randn_c_batch(16, seed, first, count, stream=_lib.STREAM_CHAN, dtype=dtype).reshape(count, 4, 4)

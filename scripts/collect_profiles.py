@@ -20,7 +20,7 @@ import shutil
 import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r03"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r04"
 sys.path.insert(0, REPO)
 from bench import derive_pmc  # noqa: E402
 src = os.path.join(REPO, "gpurun_out")
@@ -28,10 +28,10 @@ dst = os.path.join(REPO, "profiles", rnd)
 os.makedirs(dst, exist_ok=True)
 
 # tag -> (kernel-name needle of the dominant kernel, label); the bench arguments of a tag (config, dtype, demodulator, batch)
-# are recorded by scripts/prof_r03.sh in gpurun_out/prof_<tag>_meta.json
+# are recorded by scripts/prof_r04.sh (prof_r03.sh in round 3) in gpurun_out/prof_<tag>_meta.json
 CONFIGS = {
-    "c4_f64": ("k_run_mimo_ofdm_f64<", "k_run_mimo_ofdm_f64<2> (complex128, FFT 1024, 4x4, 512 threads), min-distance demodulator: the bench.py headline"),
-    "c4_f64sl": ("k_run_mimo_ofdm_f64<", "k_run_mimo_ofdm_f64<2> with the QAM slicer"),
+    "c4_f64": ("k_run_mimo_ofdm_f64<", "k_run_mimo_ofdm_f64<1024, 4, 4, 2, 4> (complex128, FFT 1024, 4x4, 512 threads), min-distance demodulator (margin certificate): the bench.py headline"),
+    "c4_f64sl": ("k_run_mimo_ofdm_f64<", "k_run_mimo_ofdm_f64<1024, 4, 4, 2, 4> with the QAM slicer"),
     "c4": ("k_run_mimo_ofdm_mfma<", "k_run_mimo_ofdm_mfma<3,6> (complex64, FFT 1024, 4x4), QAM slicer"),
     "c4md": ("k_run_mimo_ofdm_mfma<", "k_run_mimo_ofdm_mfma<3,6> with the min-distance demodulator over the LDS table"),
     "f1": ("k_run_mimo_ofdm_tdl<", "k_run_mimo_ofdm_tdl<float,1024,4> (bench.py --config f1)"),

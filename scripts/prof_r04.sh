@@ -1,0 +1,36 @@
+#!/bin/bash
+# Round-4 profiles of every fused pipeline in both arithmetics (runs on the GPU box): per tag a `rocprofv3 --kernel-trace --stats`
+# run and four separate `--pmc` passes (counters are never combined with tracing) of `bench.py --single-demod` on that
+# (config, dtype, demodulator); scripts/collect_profiles.py r04 condenses gpurun_out/prof_<tag>_* into profiles/r03/.
+# Batches are chosen so that a step is ONE dispatch of the dominant kernel (the two-launch pipelines slice their record buffers:
+# config 3 at 64 MiB = 419 430 realizations, complex128 config 4 at 2^18, f1 at 256 MiB = 104 857 / 34 952 realizations) -- the counter summaries divide per-dispatch means by
+# the batch.
+# usage: bash scripts/prof_r04.sh [tag ...]        (default: all)
+mkdir -p gpurun_out; export TMPDIR=/tmp
+declare -A SPEC=(
+  [c4_f64]="--config c4 --dtype f64 --demod mindist --batch 262144"
+  [c4_f64sl]="--config c4 --dtype f64 --demod slicer --batch 262144"
+  [c4]="--config c4 --dtype f32 --demod slicer --batch 262144"
+  [c4md]="--config c4 --dtype f32 --demod mindist --batch 262144"
+  [c3]="--config c3 --dtype f32 --batch 262144"
+  [c3_f64]="--config c3 --dtype f64 --batch 131072"
+  [c2]="--config c2 --dtype f32 --batch 65536"
+  [c2_f64]="--config c2 --dtype f64 --batch 16384"
+  [f1]="--config f1 --dtype f32 --demod slicer --batch 98304"
+  [c5]="--config c5 --dtype f32 --demod slicer --batch 1048576"
+  [f6]="--config f6 --dtype f32 --batch 524288"
+  [f1_f64]="--config f1 --dtype f64 --batch 32768"
+  [c5_f64]="--config c5 --dtype f64 --batch 262144"
+  [f6_f64]="--config f6 --dtype f64 --batch 131072"
+)
+tags=${@:-c4_f64 c4_f64sl c4 c4md c3 c3_f64 c2 c2_f64 f1 c5 f6 f1_f64 c5_f64 f6_f64}
+for tag in $tags; do
+  spec=${SPEC[$tag]}
+  echo "{\"tag\": \"$tag\", \"bench_args\": \"$spec\"}" > gpurun_out/prof_${tag}_meta.json
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag}_stats -o $tag -- python bench.py $spec --steps 10 --warmup 2 --no-cpu --pmc off --single-demod > gpurun_out/prof_${tag}_stats.log 2>&1
+  for pmc in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_WAIT_ANY"; do
+    t=$(echo $pmc | cut -d' ' -f1)
+    timeout 300 rocprofv3 --pmc $pmc --output-format csv -d gpurun_out/prof_${tag}_$t -o $tag -- python bench.py $spec --steps 3 --warmup 1 --no-cpu --pmc off --single-demod --preroll-ms 0 > gpurun_out/prof_${tag}_$t.log 2>&1
+  done
+  echo "profiled $tag"
+done

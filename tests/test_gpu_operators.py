@@ -115,6 +115,29 @@ def test_rand_modulate_batch_equals_draw_then_modulate(engine, dt, mod, M):
             assert np.array_equal(sym[k], table[want].astype(sym.dtype))
 
 
+@pytest.mark.parametrize("dt", ["f64", "f32"])
+def test_byte_label_operators_equal_the_int32_ones(engine, dt):
+    """mcle_rand_modulate_batch_u8 / mcle_demod_count_u8 (SURVEY 8(d)'s I = 1 B): the same labels, samples and error counts
+    as the int32 forms, for rows with and without whole 16-label groups."""
+    import numpy as np
+    from oracle import chains
+    table = chains.constellation("qam", 64)
+    engine.set_constellation(table, _lib.CONST_QAM)
+    seed, first = 5, (1 << 34) + 3
+    rs = np.random.RandomState(1)
+    for n in (4096, 48, 37, 5):
+        i32, s32 = engine.rand_modulate_batch(n, seed, first, 3, dtype=dt)
+        i8, s8 = engine.rand_modulate_batch(n, seed, first, 3, dtype=dt, labels=np.uint8)
+        assert i8.dtype == np.uint8 and np.array_equal(i8.get().astype(np.int32), i32.get())
+        assert np.array_equal(s8.get(), s32.get())
+        noisy = s32.get() + (0.12 * (rs.randn(3, n) + 1j * rs.randn(3, n))).astype(s32.dtype)
+        rx = engine.to_device(noisy, s32.dtype)
+        c32 = engine.demod_count(rx, i32, n_real=3, dtype=dt)
+        c8 = engine.demod_count(rx, i8, n_real=3, dtype=dt)
+        assert c32[0] == c8[0] and np.array_equal(c32[1], c8[1]) and np.array_equal(c32[2], c8[2])
+        assert c32[0]["sym_errors"] > 0 or n < 40
+
+
 def test_rand_modulate_batch_refuses_tables_beyond_a_byte(engine):
     """Labels are Philox bytes: a 512-point table is outside the operator's envelope (as in mcle_rand_symbols_batch) and must
     be an error, not wrong labels (the byte mask overflowed silently for M = 512 / 1024)."""

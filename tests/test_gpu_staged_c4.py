@@ -13,10 +13,10 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 pytestmark = pytest.mark.gpu
 
 
-def _staged(engine, first, count, dtype, method, nv, seed):
+def _staged(engine, first, count, dtype, method, nv, seed, labels=np.uint8):
     import bench_staged_c4 as st
     cnt = engine.new_counters()
-    st.chain(engine, first, count, cnt, dtype, method, noise_var=nv, seed=seed)
+    st.chain(engine, first, count, cnt, dtype, method, noise_var=nv, seed=seed, labels=labels)
     return engine.read_counters(cnt)
 
 
@@ -31,6 +31,7 @@ def test_staged_c4_counts_equal_the_fused_kernel_and_the_oracle(engine, method):
     want_se = sum(w["symbol_errors"] for w in want)
     want_be = sum(w["bit_errors"] for w in want)
     got = _staged(engine, first, count, "f64", method, nv, seed)
+    assert got == _staged(engine, first, count, "f64", method, nv, seed, labels=np.int32)     # byte labels == int32 labels
     assert got["n_realizations"] == count and got["n_symbols"] == 4096
     assert got["sym_errors"] == want_se and got["bit_errors"] == want_be
     assert got["sym_errors_sq"] == sum(w["symbol_errors"] ** 2 for w in want)
