@@ -96,7 +96,9 @@ enum {
                                       realizations per pass instead of four */
     MCLE_OPT_JAKES_DIRECT = 6,     /* 1: one sincos per ray and sample (jakes_generate: k_jakes; complex128 flat-fading pipeline: no rotation recurrence) */
     MCLE_OPT_F64_GENERIC = 7,      /* 1: complex128 config 4 on the generic radix-4 kernel instead of k_run_mimo_ofdm_f64 */
-    MCLE_OPT_F64_THREADS = 8,      /* complex128 config-4 kernel: 0 / 512 = 512-thread workgroups, 256 = 256-thread workgroups */
+    MCLE_OPT_F64_THREADS = 8,      /* complex128 config-4 kernel at (1024, 4x4): 0 = radix-16 passes, one transform per wavefront,
+                                      256-thread workgroups (default); 512 = radix-4 stages, two antennas per thread, 512 threads;
+                                      256 = radix-4 stages, four antennas per thread, 256 threads */
     MCLE_OPT_BD_RUNTIME_SOLVE = 9, /* 1: the block-diagonalisation pipeline solves with the run-time-sized routine (private
                                       arrays in scratch) also where the compile-time-sized one (K nr <= 6) applies */
     MCLE_OPT_DEMOD_NOCERT = 10,    /* 1: min-distance decisions of a square Gray QAM always through the table search (candidate
@@ -104,9 +106,10 @@ enum {
                                       closed-form nearest level per axis, accepted when the received point is farther than
                                       2^-30 (complex64: 2^-12) of a level spacing from every decision boundary, the table
                                       search otherwise -- identical decisions, no table gathers) */
-    MCLE_OPT_F64_VARIANT = 11,     /* complex128 config-4 kernel (1024, 4x4), TIMING BOUNDS ONLY -- results are wrong by construction:
-                                      bit 0 = the LDS stores of the last transmit stage and of the channel stage dropped, bit 1 =
-                                      the two workgroup barriers around the channel stage dropped */
+    MCLE_OPT_F64_VARIANT = 11,     /* complex128 config-4 kernel (1024, 4x4), TIMING BOUNDS ONLY on its 512-thread radix-4 form --
+                                      results are wrong by construction: bit 0 = the LDS stores of the last transmit stage and of
+                                      the channel stage dropped, bit 1 = the two workgroup barriers around the channel stage
+                                      dropped */
     MCLE_OPT_COUNT = 12
 };
 int mcle_ctx_set_option(mcle_ctx* ctx, int option, long long value);

@@ -208,14 +208,167 @@ template <int N, int AH> __device__ __forceinline__ void r2_stage_planar(double*
     }
 }
 
+// ---- radix-16 passes for N = 1024 = 16 x 16 x 4, ONE TRANSFORM PER WAVEFRONT (variant 4 of the 4 x 4 geometry) ----------------
+// Wavefront f owns antenna f's transform; lane gi keeps a 16-point group in registers across two radix-4 layers:
+//   pass A = spans 256, 64: elements gi + 64 q + 256 m
+//   pass B = spans 16, 4:   elements 64 (gi / 4) + gi % 4 + 4 q + 16 m
+//   pass C = span 1:        elements 16 gi + 4 c + m          (four plain radix-4 butterflies)
+// = three LDS round trips per transform instead of five, and -- a transform never leaves its wavefront -- no workgroup
+// barrier inside a transform (only the channel and the decode, which need every antenna of a position, are fenced).
+// The layer-1 twiddle w^((k + 64 q) m) is applied as w^(k m) (a register) times the constant 16th root w^(64 q m).
+// (The complex64 form of this was measured in round 1 at the 168-register bound and lost to spills,
+// scripts/experiments/radix16_fft.patch; complex128 at two workgroups per CU has 256 registers per lane.)
+// LDS swizzle of this variant: index bits 4..8 folded into bits 0..4.  Linear over XOR; meets the 32-lane read rule AND the
+// 16-lane store rule of 8-byte accesses for every shape of the three passes, the channel's position pairs, scatter and
+// decode (tests/test_f64_layout.py derives it: the lane bits of each shape must map to independent slot bits).
+__host__ __device__ __forceinline__ int lds_swz16f(int e) { return e ^ ((e >> 4) & 31); }
+
+struct R16Tw64 {
+    double2 a1[3], a2[3], b1[3], b2[3];     // w^(k m), w^(4 k q) | w^(16 k4 m), w^(64 k4 q);  m, q = 1..3; k = lane, k4 = lane mod 4
+};
+__device__ __forceinline__ R16Tw64 load_r16_tw(const double2* __restrict__ g_tw, int lane) {
+    R16Tw64 r;
+    const int k = lane & 63, k4 = k & 3;
+#pragma unroll
+    for (int j = 1; j <= 3; ++j) {
+        r.a1[j - 1] = g_tw[k * j];
+        r.a2[j - 1] = g_tw[4 * k * j];
+        r.b1[j - 1] = g_tw[16 * k4 * j];
+        r.b2[j - 1] = g_tw[64 * k4 * j];
+    }
+    return r;
+}
+template <bool INV> __device__ __forceinline__ double2 r16_tw(double2 w) {
+    if (INV) w.y = -w.y;
+    return w;
+}
+// v times exp(-2 pi i n / 16) (forward) or its conjugate (inverse), n = q m in {0, 1, 2, 3, 4, 6, 9}
+template <bool INV, int NN> __device__ __forceinline__ double2 r16_root(double2 v) {
+    constexpr double c1 = 0.92387953251128675613, s1 = 0.38268343236508977173, h = 0.70710678118654752440;
+    if constexpr (NN == 0) return v;
+    else if constexpr (NN == 4) return rot<double, INV>(v);
+    else {
+        constexpr double re = NN == 1 ? c1 : NN == 2 ? h : NN == 3 ? s1 : NN == 6 ? -h : -c1;
+        constexpr double im = NN == 1 ? -s1 : NN == 2 ? -h : NN == 3 ? -c1 : NN == 6 ? -h : s1;
+        return cmul(v, mk<double>(re, INV ? -im : im));
+    }
+}
+template <bool INV> __device__ __forceinline__ void r4_inplace(double2& x0, double2& x1, double2& x2, double2& x3) {
+    const double2 a0 = cadd(x0, x2), a1 = csub(x0, x2), a2 = cadd(x1, x3), a3 = rot<double, INV>(csub(x1, x3));
+    x0 = cadd(a0, a2);
+    x1 = cadd(a1, a3);
+    x2 = csub(a0, a2);
+    x3 = csub(a1, a3);
+}
+__device__ __forceinline__ void r16_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+// a 16-point register pass: WHICH = 0 (pass A: offsets 64 q + 256 m, twiddles a1 / a2), 1 (pass B: 4 q + 16 m, b1 / b2).
+// DIF: butterflies over m, twiddle, butterflies over q, twiddle.  DIT: the mirror image, twiddles first.
+template <bool INV, bool DIT, int WHICH>
+__device__ __forceinline__ void r16_pass(double* pr, double* pi, int base_slot, const R16Tw64& tw) {
+    constexpr int QS = WHICH == 0 ? 64 : 4, MS = WHICH == 0 ? 256 : 16;
+    const double2* t1 = WHICH == 0 ? tw.a1 : tw.b1;
+    const double2* t2 = WHICH == 0 ? tw.a2 : tw.b2;
+    double2 v[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int sl = base_slot ^ lds_swz16f(QS * q + MS * m);      // base and offsets occupy disjoint bits: XOR == add
+            v[m][q] = mk<double>(pr[sl], pi[sl]);
+        }
+    if constexpr (!DIT) {
+        static_for<4>([&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+            r4_inplace<INV>(v[0][q], v[1][q], v[2][q], v[3][q]);
+            v[1][q] = r16_root<INV, q * 1>(cmul(v[1][q], r16_tw<INV>(t1[0])));
+            v[2][q] = r16_root<INV, q * 2>(cmul(v[2][q], r16_tw<INV>(t1[1])));
+            v[3][q] = r16_root<INV, q * 3>(cmul(v[3][q], r16_tw<INV>(t1[2])));
+        });
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            r4_inplace<INV>(v[m][0], v[m][1], v[m][2], v[m][3]);
+#pragma unroll
+            for (int q = 1; q < 4; ++q) v[m][q] = cmul(v[m][q], r16_tw<INV>(t2[q - 1]));
+        }
+    } else {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+#pragma unroll
+            for (int q = 1; q < 4; ++q) v[m][q] = cmul(v[m][q], r16_tw<INV>(t2[q - 1]));
+            r4_inplace<INV>(v[m][0], v[m][1], v[m][2], v[m][3]);
+        }
+        static_for<4>([&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+            v[1][q] = r16_root<INV, q * 1>(cmul(v[1][q], r16_tw<INV>(t1[0])));
+            v[2][q] = r16_root<INV, q * 2>(cmul(v[2][q], r16_tw<INV>(t1[1])));
+            v[3][q] = r16_root<INV, q * 3>(cmul(v[3][q], r16_tw<INV>(t1[2])));
+            r4_inplace<INV>(v[0][q], v[1][q], v[2][q], v[3][q]);
+        });
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int sl = base_slot ^ lds_swz16f(QS * q + MS * m);
+            pr[sl] = v[m][q].x;
+            pi[sl] = v[m][q].y;
+        }
+}
+// pass C: the four span-1 butterflies of elements 16 gi + 4 c + m (no twiddles; DIF and DIT share the add / sub network)
+template <bool INV> __device__ __forceinline__ void r16_pass_c(double* pr, double* pi, int gi) {
+    const int base_slot = lds_swz16f(16 * gi);
+    double2 v[4][4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int sl = base_slot ^ lds_swz16f(4 * c + m);
+            v[c][m] = mk<double>(pr[sl], pi[sl]);
+        }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        r4_inplace<INV>(v[c][0], v[c][1], v[c][2], v[c][3]);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int sl = base_slot ^ lds_swz16f(4 * c + m);
+            pr[sl] = v[c][m].x;
+            pi[sl] = v[c][m].y;
+        }
+    }
+}
+// natural -> digit-reversed (the arrangement of the radix-4 DIF stages) / digit-reversed -> natural; one wavefront, one antenna
+template <bool INV> __device__ __forceinline__ void r16_dif(double* pr, double* pi, int lane, const R16Tw64& tw) {
+    int gi = opaque(lane);
+    r16_pass<INV, false, 0>(pr, pi, lds_swz16f(gi), tw);
+    r16_wave_sync();
+    gi = opaque(lane);
+    r16_pass<INV, false, 1>(pr, pi, lds_swz16f(64 * (gi >> 2) + (gi & 3)), tw);
+    r16_wave_sync();
+    r16_pass_c<INV>(pr, pi, opaque(lane));
+}
+template <bool INV> __device__ __forceinline__ void r16_dit(double* pr, double* pi, int lane, const R16Tw64& tw) {
+    r16_pass_c<INV>(pr, pi, opaque(lane));
+    r16_wave_sync();
+    int gi = opaque(lane);
+    r16_pass<INV, true, 1>(pr, pi, lds_swz16f(64 * (gi >> 2) + (gi & 3)), tw);
+    r16_wave_sync();
+    gi = opaque(lane);
+    r16_pass<INV, true, 0>(pr, pi, lds_swz16f(gi), tw);
+}
+
 // N, NT x NR: the geometry.  AH = antennas per thread in the transform stages, TB = (N / 4) (NR / AH) threads per
 // workgroup, WPS = wavefronts per SIMD the register allocation is bounded for (what the LDS lets share a CU).  The
 // benchmark geometry (1024, 4 x 4): AH = 2 -> 512 threads, 4 wavefronts per SIMD at two workgroups per CU, 128 VGPRs;
 // AH = 4 -> 256 threads, 2 per SIMD, up to 256 VGPRs, the twelve twiddles of a thread in registers: LDS caps the workgroups
 // per CU at two, so the first form buys latency hiding with threads instead.
-// VAR (MCLE_OPT_F64_VARIANT; timing bounds ONLY, the results are wrong by construction -- what fusing the channel stage into
-// its neighbouring transform stages could save at most): bit 0 = the stores of the last transmit stage and of
-// the channel stage dropped, bit 1 = the two workgroup barriers around the channel stage dropped.
+// VAR (MCLE_OPT_F64_VARIANT): 1, 2, 3 = timing bounds ONLY, the results are wrong by construction -- what fusing the channel
+// stage into its neighbouring transform stages could save at most, DESIGN.md 5.5: bit 0 = the stores of the last transmit
+// stage and of the channel stage dropped, bit 1 = the two workgroup barriers around the channel stage dropped.
+// 4 = the radix-16 transforms above (256 threads, one transform per wavefront): correct results, same contract.
 template <int N, int NT, int NR, int AH, int WPS, int VAR = 0>
 __global__ __launch_bounds__((N / 4) * (NR / AH), WPS) void k_run_mimo_ofdm_f64(MimoParams pp, ModemParams<double> mp, uint64_t seed,
                                                                      uint64_t first, uint64_t count,
@@ -228,7 +381,10 @@ __global__ __launch_bounds__((N / 4) * (NR / AH), WPS) void k_run_mimo_ofdm_f64(
     static_assert(NT >= 1 && NT <= NR && NR % AH == 0 && N >= 256, "geometry");
     constexpr int kRec = d64_rec<NT, NR>(), NB = SH::NB, N4 = SH::N4;
     constexpr int TB = NB * (NR / AH), NW = TB / 64;                        // threads, wavefronts per workgroup
-    constexpr bool TWR = AH == NR && N == 1024;                             // a thread's twiddles in registers
+    constexpr bool R16 = (VAR & 4) != 0;                                    // radix-16 passes, one transform per wavefront
+    static_assert(!R16 || (N == 1024 && NT == 4 && NR == 4 && AH == 4), "radix-16 variant: 1024, 4 x 4, 256 threads");
+    constexpr bool TWR = AH == NR && N == 1024 && !R16;                     // a thread's twiddles in registers
+    auto swz = [](int e) { return R16 ? lds_swz16f(e) : lds_swz64(e); };
     static_assert(TB % 64 == 0 && TB <= 1024 && TB >= kRec && NW <= 16, "workgroup");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* s_d = reinterpret_cast<double*>(smem);                          // [NR][re plane | im plane][N]
@@ -263,6 +419,10 @@ __global__ __launch_bounds__((N / 4) * (NR / AH), WPS) void k_run_mimo_ofdm_f64(
     const bool tx_grp = NT == NR || grp * AH < NT;                // wave-uniform: does this group transmit?
     TwRegs64<N> twr;
     if constexpr (TWR) twr = load_tw64<N>(g_tw, bbt);
+    [[maybe_unused]] R16Tw64 tw16;
+    if constexpr (R16) tw16 = load_r16_tw(g_tw, lane);
+    [[maybe_unused]] double* s_wave_re = s_d + (2 * w) * N;      // variant 4: wavefront w owns antenna w's transform
+    [[maybe_unused]] double* s_wave_im = s_wave_re + N;
     uint64_t it = 0, rl_prev = 0;
     // the record of a realization is fetched one iteration ahead (one register pair per lane of the first wavefront):
     // loaded where it is parked, the global-memory latency sat in front of every realization's first barrier
@@ -298,7 +458,7 @@ __global__ __launch_bounds__((N / 4) * (NR / AH), WPS) void k_run_mimo_ofdm_f64(
                 const Words4 dw = rng.block(STREAM_DATA, (uint32_t)blk);
                 if (aligned_scatter) {
                     const int nl0 = (int)((blk << 4) - n_first);
-                    const int pos0 = lds_swz64(ofdm_bin(nl0 / NT, N, U));
+                    const int pos0 = swz(ofdm_bin(nl0 / NT, N, U));
                     *reinterpret_cast<uint4*>(s_idx + nl0) = make_uint4(dw.w[0] & (mask * 0x01010101u), dw.w[1] & (mask * 0x01010101u),
                                                                         dw.w[2] & (mask * 0x01010101u), dw.w[3] & (mask * 0x01010101u));
 #pragma unroll
@@ -320,7 +480,7 @@ __global__ __launch_bounds__((N / 4) * (NR / AH), WPS) void k_run_mimo_ofdm_f64(
                         const int a = nl % NT, d = nl / NT;
                         s_idx[nl] = (unsigned char)tx;
                         const double2 c = s_txtab[tx];
-                        const int pos = lds_swz64(ofdm_bin(d, N, U));
+                        const int pos = swz(ofdm_bin(d, N, U));
                         s_d[(2 * a) * N + pos] = c.x;
                         s_d[(2 * a + 1) * N + pos] = c.y;
                     }
@@ -340,6 +500,10 @@ __global__ __launch_bounds__((N / 4) * (NR / AH), WPS) void k_run_mimo_ofdm_f64(
             // ---- IFFT: radix-4 DIF (+ the radix-2 stage), natural -> digit-reversed positions (a DIF stage multiplies LAST:
             //      its twiddle fetch hides behind its own butterflies -- fetching a stage ahead as the forward transform does
             //      measured no gain).  Antenna groups beyond Nt have nothing to send and only keep the barriers. ----
+            if constexpr (R16) {
+                r16_dif<true>(s_wave_re, s_wave_im, lane, tw16);
+                __syncthreads();
+            } else
             static_for<N4>([&](auto stc) {
                 constexpr int st = decltype(stc)::value, S = SH::span(st);
                 if (tx_grp) r4_stage_planar<N, true, true, S, AH, TWR, (VAR & 1) && st + 1 == N4 && !SH::HAS2>(s_mine, twr, g_tw, opaque(bbt));
@@ -362,7 +526,7 @@ __global__ __launch_bounds__((N / 4) * (NR / AH), WPS) void k_run_mimo_ofdm_f64(
                     const int half = j / (N / 4), rest = j - half * (N / 4);
                     const int p0 = 2 * half * (N / 4) + rest, p1 = p0 + N / 4;
                     const int m0 = fft_index_of_pos<N>(p0);  // even; position p1 holds m0 + 1
-                    const int q0 = lds_swz64(p0), q1 = lds_swz64(p1);
+                    const int q0 = swz(p0), q1 = swz(p1);
                     double2 x0[NT], x1[NT];
 #pragma unroll
                     for (int a = 0; a < NT; ++a) {
@@ -402,7 +566,10 @@ __global__ __launch_bounds__((N / 4) * (NR / AH), WPS) void k_run_mimo_ofdm_f64(
             }
             if constexpr (!(VAR & 2)) __syncthreads();
             // ---- FFT: (the radix-2 stage +) radix-4 DIT, digit-reversed -> natural bins ----
-            if constexpr (TWR) {
+            if constexpr (R16) {
+                r16_dit<false>(s_wave_re, s_wave_im, lane, tw16);
+                __syncthreads();
+            } else if constexpr (TWR) {
                 if constexpr (SH::HAS2) {
                     r2_stage_planar<N, AH>(s_mine, opaque(bbt));
                     fft_stage_sync<TB>(2);
@@ -435,7 +602,7 @@ __global__ __launch_bounds__((N / 4) * (NR / AH), WPS) void k_run_mimo_ofdm_f64(
             // ---- receive: Blast decode (G carries the FFT scale), demodulate, count ----
             {
                 for (int d = tid; d < U; d += TB) {
-                    const int bin = lds_swz64(ofdm_bin(d, N, U));
+                    const int bin = swz(ofdm_bin(d, N, U));
                     double2 y[NR];
 #pragma unroll
                     for (int r = 0; r < NR; ++r) y[r] = mk<double>(s_d[(2 * r) * N + bin], s_d[(2 * r + 1) * N + bin]);
@@ -554,7 +721,8 @@ static int launch_mimo_ofdm_f64(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, ui
 
 // host side: 0 = launched, MCLE_E_UNSUPPORTED = outside this family's envelope (caller uses k_run_mimo_ofdm<double, ...>).
 // Geometry table: (fft_size, Nt x Nr) -> antennas per thread AH, threads, workgroups per CU (LDS), wavefronts per SIMD:
-//   1024  4x4   2   512   2   4        2048  4x4   2  1024   1   4        512  4x4   2   256   3   3        256  4x4   2  128  5  3
+//   1024  4x4   radix-16 form: 4 antennas / wave-per-antenna, 256 threads, 2 workgroups per CU, 2 wavefronts per SIMD
+//  (1024  4x4   2   512   2   4  radix-4, option f64_threads=512)   2048  4x4   2  1024   1   4        512  4x4   2   256   3   3        256  4x4   2  128  5  3
 //   1024  2x2   2   256   3   3        2048  2x2   2   512   2   4        512  2x2   2   128   5   3        256  2x2   2   64  8  2
 // Nt < Nr (2x4, 3x4, 1x2, 1x4 ...: mimo/mimo.py:264-309 takes any) run the Nr geometry; antenna groups past Nt idle in the IFFT.
 int run_mimo_ofdm_f64(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, uint64_t seed, uint64_t first, uint64_t count,
@@ -564,17 +732,24 @@ int run_mimo_ofdm_f64(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, uint64_t see
 #define MCLE_F64_GEOM(N_, NT_, NR_, AH_, WPS_)                                                                      \
     if (n == N_ && nt == NT_ && nr == NR_)                                                                          \
         return launch_mimo_ofdm_f64<N_, NT_, NR_, AH_, WPS_>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
-    // MCLE_OPT_F64_THREADS: 0 / 512 = two antennas per thread, 512-thread workgroups (default); 256 = four antennas per thread
-    if (n == 1024 && nt == 4 && nr == 4 && ctx->opt[MCLE_OPT_F64_THREADS] == 256)
-        return launch_mimo_ofdm_f64<1024, 4, 4, 4, 2>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
-    if (n == 1024 && nt == 4 && nr == 4 && ctx->opt[MCLE_OPT_F64_VARIANT]) {     // timing bounds (wrong results), see the kernel
+    // (1024, 4 x 4), the benchmark geometry: radix-16 passes, one transform per wavefront, 256 threads (default since round 4:
+    // 10.66 ms per 262 144 realizations against 11.65 for the 512-thread radix-4 form and 12.15 for the 256-thread one,
+    // profiles/r04/c4_f64_r16_ab.log).  MCLE_OPT_F64_THREADS: 512 = radix-4, two antennas per thread; 256 = radix-4, four
+    // antennas per thread, twiddles in registers.  MCLE_OPT_F64_VARIANT 1 .. 3: timing bounds on the 512-thread form.
+    if (n == 1024 && nt == 4 && nr == 4) {
         switch ((int)ctx->opt[MCLE_OPT_F64_VARIANT]) {
             case 1: return launch_mimo_ofdm_f64<1024, 4, 4, 2, 4, 1>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
             case 2: return launch_mimo_ofdm_f64<1024, 4, 4, 2, 4, 2>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
-            default: return launch_mimo_ofdm_f64<1024, 4, 4, 2, 4, 3>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
+            case 3: return launch_mimo_ofdm_f64<1024, 4, 4, 2, 4, 3>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
+            default: break;
         }
+        if (ctx->opt[MCLE_OPT_F64_THREADS] == 256)
+            return launch_mimo_ofdm_f64<1024, 4, 4, 4, 2>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
+        if (ctx->opt[MCLE_OPT_F64_THREADS] == 512)
+            return launch_mimo_ofdm_f64<1024, 4, 4, 2, 4>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
+        return launch_mimo_ofdm_f64<1024, 4, 4, 4, 2, 4>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
     }
-    MCLE_F64_GEOM(1024, 4, 4, 2, 4) MCLE_F64_GEOM(1024, 2, 2, 2, 3)
+    MCLE_F64_GEOM(1024, 2, 2, 2, 3)
     MCLE_F64_GEOM(2048, 4, 4, 2, 4) MCLE_F64_GEOM(2048, 2, 2, 2, 4)
     MCLE_F64_GEOM(512, 4, 4, 2, 3) MCLE_F64_GEOM(512, 2, 2, 2, 3)
     MCLE_F64_GEOM(256, 4, 4, 2, 3) MCLE_F64_GEOM(256, 2, 2, 2, 2)

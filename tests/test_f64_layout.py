@@ -126,3 +126,117 @@ def test_the_radix4_swizzle_of_fft_hpp_is_not_enough_for_8_byte_stores():
         for q in range(4):
             bad += write_conflicts(list(swz(e0 + q * s)))
     assert bad > 0
+
+
+# ---- variant 4 of the (1024, 4 x 4) kernel: radix-16 passes, one transform per wavefront (csrc/pipeline_mimo_f64.hip) ----
+def swz16f(e):
+    e = np.asarray(e)
+    return e ^ ((e >> 4) & 31)
+
+
+def _rot(x, inv):
+    return x * (1j if inv else -1j)
+
+
+def _r4(x, inv):
+    a0, a1, a2, a3 = x[0] + x[2], x[0] - x[2], x[1] + x[3], _rot(x[1] - x[3], inv)
+    return [a0 + a2, a1 + a3, a0 - a2, a1 - a3]
+
+
+def _r16_passes(p, inv, dit):
+    """The three register passes, lane by lane, with the device's index maps (pass A / B / C of r16_pass, r16_pass_c) and its
+    twiddle factorisation w^((k + 64 q) m) = w^(k m) x (16th root)^(q m)."""
+    N = 1024
+    w = np.exp(-2j * np.pi * np.arange(N) / N)
+    tw = (lambda i: np.conj(w[i % N])) if inv else (lambda i: w[i % N])
+    p = p.copy()
+
+    def pass_c():
+        for gi in range(64):
+            for c in range(4):
+                e = [16 * gi + 4 * c + m for m in range(4)]
+                p[e] = _r4(p[e], inv)
+
+    def pass_16(el, t1, root, t2):
+        v = [[p[el(m, q)] for q in range(4)] for m in range(4)]
+        if not dit:
+            for q in range(4):
+                y = _r4([v[m][q] for m in range(4)], inv)
+                for m in range(4):
+                    v[m][q] = y[m] * tw(t1(m)) * tw(root * q * m)
+            for m in range(4):
+                z = _r4(v[m], inv)
+                for q in range(4):
+                    p[el(m, q)] = z[q] * tw(t2(q))
+        else:
+            for m in range(4):
+                v[m] = _r4([v[m][q] * tw(t2(q)) for q in range(4)], inv)
+            for q in range(4):
+                y = _r4([v[m][q] * tw(t1(m)) * tw(root * q * m) for m in range(4)], inv)
+                for m in range(4):
+                    p[el(m, q)] = y[m]
+
+    def pass_a():
+        for k in range(64):
+            pass_16(lambda m, q: k + 64 * q + 256 * m, lambda m: k * m, 64, lambda q: 4 * k * q)
+
+    def pass_b():
+        for gi in range(64):
+            G, k4 = gi >> 2, gi & 3
+            pass_16(lambda m, q: 64 * G + k4 + 4 * q + 16 * m, lambda m: 16 * k4 * m, 64, lambda q: 64 * k4 * q)
+
+    for step in ((pass_c, pass_b, pass_a) if dit else (pass_a, pass_b, pass_c)):
+        step()
+    return p
+
+
+def _pos_of_index(n, f):
+    pos, size = 0, n
+    while size > 1:
+        size >>= 2
+        pos += (f & 3) * size
+        f >>= 2
+    return pos
+
+
+def test_radix16_passes_are_the_transform_in_the_radix4_arrangement():
+    rs = np.random.RandomState(5)
+    x = rs.randn(1024) + 1j * rs.randn(1024)
+    perm = np.array([_pos_of_index(1024, f) for f in range(1024)])        # fft.hpp fft_pos_of_index<1024>
+    assert np.allclose(_r16_passes(x, False, False)[perm], np.fft.fft(x))
+    assert np.allclose(_r16_passes(x, True, False)[perm], np.fft.ifft(x) * 1024)
+    xs = np.empty(1024, complex)
+    xs[perm] = x
+    assert np.allclose(_r16_passes(xs, False, True), np.fft.fft(x))
+    assert np.allclose(_r16_passes(xs, True, True), np.fft.ifft(x) * 1024)
+
+
+def test_radix16_swizzle_meets_both_bank_rules_for_every_access_shape():
+    assert sorted(swz16f(np.arange(1024))) == list(range(1024))
+    # XOR-linearity (the device adds offsets by XOR on the swizzled base): base and offset occupy disjoint bits
+    for gi in range(64):
+        for q in range(4):
+            for m in range(4):
+                assert swz16f(gi + 64 * q + 256 * m) == swz16f(gi) ^ swz16f(64 * q + 256 * m)
+                b = 64 * (gi >> 2) + (gi & 3)
+                assert swz16f(b + 4 * q + 16 * m) == swz16f(b) ^ swz16f(4 * q + 16 * m)
+                assert swz16f(16 * gi + 4 * q + m) == swz16f(16 * gi) ^ swz16f(4 * q + m)
+    lane = np.arange(64)
+    shapes = []
+    shapes += [lane + 64 * q + 256 * m for q in range(4) for m in range(4)]                               # pass A
+    shapes += [64 * (lane >> 2) + (lane & 3) + 4 * q + 16 * m for q in range(4) for m in range(4)]        # pass B
+    shapes += [16 * lane + 4 * c + m for c in range(4) for m in range(4)]                                 # pass C
+    shapes += [np.arange(b, b + 64) for b in range(0, 1024, 64)]                                          # decode, channel p0
+    shapes += [(2 * (j // 256) * 256 + j % 256) + off for b in range(0, 512, 64) for off in (0, 256)
+               for j in [np.arange(b, b + 64)]]                                                           # channel pairs
+    for e in shapes:
+        slots = list(swz16f(e))
+        assert read_conflicts(slots) == 0 and write_conflicts(slots) == 0
+    for c in range(4):                                                                                    # scatter, Nt = 4
+        for wave in range(4):
+            d = 4 * (64 * wave + lane) + c
+            assert write_conflicts(list(swz16f((d + 512) % 1024))) == 0
+    # the aligned scatter's pos0 ^ t rule: sixteen / Nt consecutive bins from a multiple of it differ in bits the fold leaves alone
+    for bin0 in range(0, 1024, 4):
+        for t in range(4):
+            assert swz16f(bin0 + t) == swz16f(bin0) ^ t

@@ -19,9 +19,9 @@ CASES = [dict(mod="qam", M=64, snr_db=25.0),                                    
          dict(mod="qpsk", M=4, snr_db=8.0, num_used=2)]
 
 
-def _run(engine, kw, first, count, method, generic=False, threads=0):
+def _run(engine, kw, first, count, method, generic=False, threads=0, variant=0):
     nv = 1.0 / omodem.dB2Linear(kw["snr_db"])
-    with engine.options(f64_generic=1 if generic else 0, f64_threads=threads):
+    with engine.options(f64_generic=1 if generic else 0, f64_threads=threads, f64_variant=variant):
         return engine.run_mimo_ofdm(4, 4, 1024, kw.get("cp_size", 16), kw.get("num_used") or 1024, kw.get("n_ofdm_sym", 1),
                                     nv, SEED, first, count, mmse=kw.get("mmse", True), method=method, dtype="f64",
                                     per_realization=True)
@@ -40,9 +40,10 @@ def test_f64_kernel_counts_equal_the_oracle(engine, case):
     want_be = np.array([w["bit_errors"] for w in want])
     methods = [_lib.DEMOD_MINDIST] + ([_lib.DEMOD_QAM_SLICER] if kw["mod"] == "qam" else [])
     for method in methods:
-        for threads in (512, 256):                 # two antennas per thread (default) / four antennas per thread
-            res, se, be = _run(engine, kw, first, count, method, threads=threads)
-            assert np.array_equal(se, want_se) and np.array_equal(be, want_be), (case, method, threads, se, want_se)
+        # radix-16 passes, one transform per wavefront (default) / radix-4: two antennas per thread / four antennas per thread
+        for threads, variant in ((0, 0), (512, 0), (256, 0)):
+            res, se, be = _run(engine, kw, first, count, method, threads=threads, variant=variant)
+            assert np.array_equal(se, want_se) and np.array_equal(be, want_be), (case, method, threads, variant, se, want_se)
             assert res["n_realizations"] == count and res["sym_errors"] == int(want_se.sum())
             assert res["n_symbols"] == want[0]["num_symbols"] and res["n_bits"] == want[0]["num_bits"]
 
@@ -57,16 +58,19 @@ def test_f64_kernel_equals_the_generic_kernel(engine, case):
     engine.set_constellation(chains.constellation(kw["mod"], kw["M"]), kind)
     n = 1031
     method = _lib.DEMOD_MINDIST
-    new, se, be = _run(engine, kw, 5, n, method)
+    new, se, be = _run(engine, kw, 5, n, method, threads=512)
     alt, se_a, be_a = _run(engine, kw, 5, n, method, threads=256)
     assert np.array_equal(se, se_a) and np.array_equal(be, be_a) and new == alt          # same arithmetic, other thread map
+    r16, se_r, be_r = _run(engine, kw, 5, n, method)                # radix-16 passes (default): one more rounding per layer-1 twiddle
+    assert np.count_nonzero(se != se_r) <= 1 and np.max(np.abs(se.astype(int) - se_r.astype(int))) <= 1
+    assert r16["n_realizations"] == new["n_realizations"] and r16["n_skipped"] == new["n_skipped"]
     old, se_o, be_o = _run(engine, kw, 5, n, method, generic=True)
     assert np.count_nonzero(se != se_o) <= 1 and np.max(np.abs(se.astype(int) - se_o.astype(int))) <= 1
     assert abs(new["sym_errors"] - old["sym_errors"]) <= 1 and new["n_realizations"] == old["n_realizations"] == n
     a = _run(engine, kw, 5, 400, method)[0]
     b = _run(engine, kw, 405, n - 400, method)[0]
     for k in ("sym_errors", "sym_errors_sq", "bit_errors", "bit_errors_sq", "n_realizations", "n_skipped"):
-        assert new[k] == a[k] + b[k], k
+        assert r16[k] == a[k] + b[k], k
 
 
 def test_f64_kernel_against_the_oracle_over_2000_realizations(engine):
@@ -81,11 +85,11 @@ def test_f64_kernel_against_the_oracle_over_2000_realizations(engine):
     want_se = np.array([w["symbol_errors"] for w in want])
     want_be = np.array([w["bit_errors"] for w in want])
     assert want_se.sum() > 1e5                                  # a realization in outage is thousands of errors
-    for threads in (512, 256):
+    for threads, variant in ((0, 0), (512, 0), (256, 0)):
         for method, nocert in ((_lib.DEMOD_MINDIST, 0), (_lib.DEMOD_MINDIST, 1), (_lib.DEMOD_QAM_SLICER, 0)):
             with engine.options(demod_nocert=nocert):
-                res, se, be = _run(engine, kw, first, count, method, threads=threads)
-            assert np.array_equal(se, want_se), (threads, method, nocert, np.flatnonzero(se != want_se)[:5])
+                res, se, be = _run(engine, kw, first, count, method, threads=threads, variant=variant)
+            assert np.array_equal(se, want_se), (threads, variant, method, nocert, np.flatnonzero(se != want_se)[:5])
             assert np.array_equal(be, want_be), (threads, method, nocert)
             assert res["sym_errors"] == int(want_se.sum()) and res["bit_errors"] == int(want_be.sum())
 
