@@ -218,10 +218,20 @@ template <int N, int AH> __device__ __forceinline__ void r2_stage_planar(double*
 // The layer-1 twiddle w^((k + 64 q) m) is applied as w^(k m) (a register) times the constant 16th root w^(64 q m).
 // (The complex64 form of this was measured in round 1 at the 168-register bound and lost to spills,
 // scripts/experiments/radix16_fft.patch; complex128 at two workgroups per CU has 256 registers per lane.)
-// LDS swizzle of this variant: index bits 4..8 folded into bits 0..4.  Linear over XOR; meets the 32-lane read rule AND the
-// 16-lane store rule of 8-byte accesses for every shape of the three passes, the channel's position pairs, scatter and
-// decode (tests/test_f64_layout.py derives it: the lane bits of each shape must map to independent slot bits).
-__host__ __device__ __forceinline__ int lds_swz16f(int e) { return e ^ ((e >> 4) & 31); }
+// LDS swizzle of this variant: index bits 4..8 folded into bits 0..4, bit 9 into bit 4 as well.  Linear over XOR; meets the
+// 32-lane read rule AND the 16-lane store rule of 8-byte accesses for every shape of the three passes, the fused middle
+// stage, the channel's position pairs, scatter and decode (tests/test_f64_layout.py derives it: the lane bits of each
+// shape must map to independent slot bits).
+__host__ __device__ __forceinline__ int lds_swz16f(int e) { return e ^ ((e >> 4) & 31) ^ (((e >> 9) & 1) << 4); }
+
+// lanes l and l ^ 32 exchange: (a of the lower half, b of the upper half) stay, the other two cross over --
+// x = {lower: own a, upper: the partner's b}, y = {lower: the partner's a, upper: own b}  (v_permlane32_swap_b32)
+__device__ __forceinline__ void swap32_pair(double a, double b, double& x, double& y) {
+    const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    x = __hiloint2double((int)hi[0], (int)lo[0]);
+    y = __hiloint2double((int)hi[1], (int)lo[1]);
+}
 
 struct R16Tw64 {
     double2 a1[3], a2[3], b1[3], b2[3];     // w^(k m), w^(4 k q) | w^(16 k4 m), w^(64 k4 q);  m, q = 1..3; k = lane, k4 = lane mod 4
@@ -341,18 +351,22 @@ template <bool INV> __device__ __forceinline__ void r16_pass_c(double* pr, doubl
     }
 }
 // natural -> digit-reversed (the arrangement of the radix-4 DIF stages) / digit-reversed -> natural; one wavefront, one antenna
-template <bool INV> __device__ __forceinline__ void r16_dif(double* pr, double* pi, int lane, const R16Tw64& tw) {
+template <bool INV, bool WITH_C = true> __device__ __forceinline__ void r16_dif(double* pr, double* pi, int lane, const R16Tw64& tw) {
     int gi = opaque(lane);
     r16_pass<INV, false, 0>(pr, pi, lds_swz16f(gi), tw);
     r16_wave_sync();
     gi = opaque(lane);
     r16_pass<INV, false, 1>(pr, pi, lds_swz16f(64 * (gi >> 2) + (gi & 3)), tw);
-    r16_wave_sync();
-    r16_pass_c<INV>(pr, pi, opaque(lane));
+    if constexpr (WITH_C) {
+        r16_wave_sync();
+        r16_pass_c<INV>(pr, pi, opaque(lane));
+    }
 }
-template <bool INV> __device__ __forceinline__ void r16_dit(double* pr, double* pi, int lane, const R16Tw64& tw) {
-    r16_pass_c<INV>(pr, pi, opaque(lane));
-    r16_wave_sync();
+template <bool INV, bool WITH_C = true> __device__ __forceinline__ void r16_dit(double* pr, double* pi, int lane, const R16Tw64& tw) {
+    if constexpr (WITH_C) {
+        r16_pass_c<INV>(pr, pi, opaque(lane));
+        r16_wave_sync();
+    }
     int gi = opaque(lane);
     r16_pass<INV, true, 1>(pr, pi, lds_swz16f(64 * (gi >> 2) + (gi & 3)), tw);
     r16_wave_sync();
@@ -382,6 +396,7 @@ __global__ __launch_bounds__((N / 4) * (NR / AH), WPS) void k_run_mimo_ofdm_f64(
     constexpr int kRec = d64_rec<NT, NR>(), NB = SH::NB, N4 = SH::N4;
     constexpr int TB = NB * (NR / AH), NW = TB / 64;                        // threads, wavefronts per workgroup
     constexpr bool R16 = (VAR & 4) != 0;                                    // radix-16 passes, one transform per wavefront
+    constexpr bool FUSED = R16 && (VAR & 8) != 0;                           // ... with pass C, the channel and pass C' as one stage
     static_assert(!R16 || (N == 1024 && NT == 4 && NR == 4 && AH == 4), "radix-16 variant: 1024, 4 x 4, 256 threads");
     constexpr bool TWR = AH == NR && N == 1024 && !R16;                     // a thread's twiddles in registers
     auto swz = [](int e) { return R16 ? lds_swz16f(e) : lds_swz64(e); };
@@ -420,7 +435,7 @@ __global__ __launch_bounds__((N / 4) * (NR / AH), WPS) void k_run_mimo_ofdm_f64(
     TwRegs64<N> twr;
     if constexpr (TWR) twr = load_tw64<N>(g_tw, bbt);
     [[maybe_unused]] R16Tw64 tw16;
-    if constexpr (R16) tw16 = load_r16_tw(g_tw, lane);
+    if constexpr (R16 && !FUSED) tw16 = load_r16_tw(g_tw, lane);     // fused form: fetched at the top of each transform instead (48 registers)
     [[maybe_unused]] double* s_wave_re = s_d + (2 * w) * N;      // variant 4: wavefront w owns antenna w's transform
     [[maybe_unused]] double* s_wave_im = s_wave_re + N;
     uint64_t it = 0, rl_prev = 0;
@@ -501,7 +516,8 @@ __global__ __launch_bounds__((N / 4) * (NR / AH), WPS) void k_run_mimo_ofdm_f64(
             //      its twiddle fetch hides behind its own butterflies -- fetching a stage ahead as the forward transform does
             //      measured no gain).  Antenna groups beyond Nt have nothing to send and only keep the barriers. ----
             if constexpr (R16) {
-                r16_dif<true>(s_wave_re, s_wave_im, lane, tw16);
+                if constexpr (FUSED) tw16 = load_r16_tw(g_tw, opaque(lane));
+                r16_dif<true, !FUSED>(s_wave_re, s_wave_im, lane, tw16);
                 __syncthreads();
             } else
             static_for<N4>([&](auto stc) {
@@ -517,7 +533,79 @@ __global__ __launch_bounds__((N / 4) * (NR / AH), WPS) void k_run_mimo_ofdm_f64(
                 __syncthreads();
             }
             // ---- channel: R = H T + noise on the samples that survive CP removal ----
-            {
+            if constexpr (FUSED) {
+                // ONE register stage: the span-1 butterflies of the transmit transform (pass C), the channel, and the span-1
+                // butterflies of the receive transform (pass C').  A thread holds the four positions 4 g .. 4 g + 3 of all four
+                // antennas; position 4 g + d carries time sample mb + 256 d.  Lanes l and l ^ 32 hold m and m + 1, i.e. the two
+                // samples of every NOISE block: the lower half draws the blocks of receive antennas 0 and 1, the upper half those
+                // of 2 and 3, and one v_permlane32_swap per word hands each half the samples it did not draw -- the draw ledger
+                // is unchanged (every block computed once), two LDS passes and their address work are gone.
+                const int ln = opaque(lane);
+                const int h = (ln >> 5) & 1;
+                const int g = (ln & 15) | (w << 4) | (h << 6) | (((ln >> 4) & 1) << 7);
+                const int base_slot = swz(4 * g);                              // position 4 g + d sits at base_slot ^ d
+                double2 x[NT][4];
+#pragma unroll
+                for (int a = 0; a < NT; ++a)
+#pragma unroll
+                    for (int d = 0; d < 4; ++d)
+                        x[a][d] = mk<double>(s_d[(2 * a) * N + (base_slot ^ d)], s_d[(2 * a + 1) * N + (base_slot ^ d)]);
+#pragma unroll
+                for (int a = 0; a < NT; ++a) r4_inplace<true>(x[a][0], x[a][1], x[a][2], x[a][3]);
+                const int mb = fft_index_of_pos<N>(4 * g);
+                const bool paired = (cp & 1) == 0;                             // every row's first kept sample on a block boundary
+                double2 y[NR][4];
+                auto mix = [&](int d, const double2 (&nz)[NR]) {               // y[.][d] = noise + H x[.][d]
+#pragma unroll
+                    for (int r = 0; r < NR; ++r) {
+                        double2 z = nz[r];
+#pragma unroll
+                        for (int a = 0; a < NT; ++a) z = cfma(s_H[r * NT + a], x[a][d], z);
+                        y[r][d] = z;
+                    }
+                };
+                if (paired) {
+                    static_for<4>([&](auto dc) {
+                        constexpr int d = decltype(dc)::value;
+                        __builtin_amdgcn_sched_barrier(0);                     // one position at a time: its four inputs die as its
+                        double2 nz[NR];                                        // four outputs are born
+#pragma unroll
+                        for (int rr = 0; rr < NR / 2; ++rr) {
+                            const uint64_t i0 = (uint64_t)(rr + (NR / 2) * h) * row + (uint64_t)os * (N + cp) + cp + mb + 256 * d;
+                            const Words4 b = rng.block(STREAM_NOISE, (uint32_t)(i0 >> 1));
+                            const double2 za = cn_from_words_lds(b.w[0], b.w[1], sigma, s_bm);     // the even sample: the lower half's
+                            const double2 zb = cn_from_words_lds(b.w[2], b.w[3], sigma, s_bm);     // the odd sample: the upper half's
+                            swap32_pair(za.x, zb.x, nz[rr].x, nz[rr + NR / 2].x);
+                            swap32_pair(za.y, zb.y, nz[rr].y, nz[rr + NR / 2].y);
+                        }
+                        mix(d, nz);
+                    });
+                } else {                                                       // odd prefix: unpaired draws, half of every block used
+                    static_for<4>([&](auto dc) {
+                        constexpr int d = decltype(dc)::value;
+                        __builtin_amdgcn_sched_barrier(0);
+                        double2 nz[NR];
+#pragma unroll
+                        for (int r = 0; r < NR; ++r) {
+                            const uint64_t i0 = (uint64_t)r * row + (uint64_t)os * (N + cp) + cp + mb + 256 * d;
+                            const Words4 b = rng.block(STREAM_NOISE, (uint32_t)(i0 >> 1));
+                            const uint32_t x0 = (i0 & 1) ? b.w[2] : b.w[0], x1 = (i0 & 1) ? b.w[3] : b.w[1];
+                            nz[r] = cn_from_words_lds(x0, x1, sigma, s_bm);
+                        }
+                        mix(d, nz);
+                    });
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int r = 0; r < NR; ++r) {
+                    r4_inplace<false>(y[r][0], y[r][1], y[r][2], y[r][3]);
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        s_d[(2 * r) * N + (base_slot ^ d)] = y[r][d].x;
+                        s_d[(2 * r + 1) * N + (base_slot ^ d)] = y[r][d].y;
+                    }
+                }
+            } else {
                 constexpr int JT = (N / 2) / TB;                // channel iterations per thread: a compile-time count
                 static_assert(JT * TB == N / 2, "channel loop");
 #pragma unroll
@@ -567,7 +655,8 @@ __global__ __launch_bounds__((N / 4) * (NR / AH), WPS) void k_run_mimo_ofdm_f64(
             if constexpr (!(VAR & 2)) __syncthreads();
             // ---- FFT: (the radix-2 stage +) radix-4 DIT, digit-reversed -> natural bins ----
             if constexpr (R16) {
-                r16_dit<false>(s_wave_re, s_wave_im, lane, tw16);
+                if constexpr (FUSED) tw16 = load_r16_tw(g_tw, opaque(lane));
+                r16_dit<false, !FUSED>(s_wave_re, s_wave_im, lane, tw16);
                 __syncthreads();
             } else if constexpr (TWR) {
                 if constexpr (SH::HAS2) {
@@ -747,7 +836,9 @@ int run_mimo_ofdm_f64(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, uint64_t see
             return launch_mimo_ofdm_f64<1024, 4, 4, 4, 2>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
         if (ctx->opt[MCLE_OPT_F64_THREADS] == 512)
             return launch_mimo_ofdm_f64<1024, 4, 4, 2, 4>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
-        return launch_mimo_ofdm_f64<1024, 4, 4, 4, 2, 4>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
+        if (ctx->opt[MCLE_OPT_F64_THREADS] == 257)      // radix-16 passes with the unfused channel stage (A/B)
+            return launch_mimo_ofdm_f64<1024, 4, 4, 4, 2, 4>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
+        return launch_mimo_ofdm_f64<1024, 4, 4, 4, 2, 12>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
     }
     MCLE_F64_GEOM(1024, 2, 2, 2, 3)
     MCLE_F64_GEOM(2048, 4, 4, 2, 4) MCLE_F64_GEOM(2048, 2, 2, 2, 4)

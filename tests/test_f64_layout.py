@@ -131,7 +131,7 @@ def test_the_radix4_swizzle_of_fft_hpp_is_not_enough_for_8_byte_stores():
 # ---- variant 4 of the (1024, 4 x 4) kernel: radix-16 passes, one transform per wavefront (csrc/pipeline_mimo_f64.hip) ----
 def swz16f(e):
     e = np.asarray(e)
-    return e ^ ((e >> 4) & 31)
+    return e ^ ((e >> 4) & 31) ^ (((e >> 9) & 1) << 4)
 
 
 def _rot(x, inv):
@@ -229,6 +229,12 @@ def test_radix16_swizzle_meets_both_bank_rules_for_every_access_shape():
     shapes += [np.arange(b, b + 64) for b in range(0, 1024, 64)]                                          # decode, channel p0
     shapes += [(2 * (j // 256) * 256 + j % 256) + off for b in range(0, 512, 64) for off in (0, 256)
                for j in [np.arange(b, b + 64)]]                                                           # channel pairs
+    for w in range(4):                                    # the fused middle stage: thread -> group g, positions 4 g + d
+        g = (lane & 15) | (w << 4) | (((lane >> 5) & 1) << 6) | (((lane >> 4) & 1) << 7)
+        assert w > 0 or sorted(set(int(v) for ww in range(4) for v in ((lane & 15) | (ww << 4) | (((lane >> 5) & 1) << 6) |
+                                                                        (((lane >> 4) & 1) << 7)))) == list(range(256))
+        assert np.array_equal(g[32:], g[:32] ^ 64)        # lanes l, l ^ 32: groups g, g ^ 64 = time samples m, m + 1
+        shapes += [4 * g + d for d in range(4)]
     for e in shapes:
         slots = list(swz16f(e))
         assert read_conflicts(slots) == 0 and write_conflicts(slots) == 0

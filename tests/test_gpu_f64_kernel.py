@@ -40,8 +40,9 @@ def test_f64_kernel_counts_equal_the_oracle(engine, case):
     want_be = np.array([w["bit_errors"] for w in want])
     methods = [_lib.DEMOD_MINDIST] + ([_lib.DEMOD_QAM_SLICER] if kw["mod"] == "qam" else [])
     for method in methods:
-        # radix-16 passes, one transform per wavefront (default) / radix-4: two antennas per thread / four antennas per thread
-        for threads, variant in ((0, 0), (512, 0), (256, 0)):
+        # radix-16 passes with the fused middle stage (default) / with the separate channel stage / radix-4: two antennas per
+        # thread / four antennas per thread
+        for threads, variant in ((0, 0), (257, 0), (512, 0), (256, 0)):
             res, se, be = _run(engine, kw, first, count, method, threads=threads, variant=variant)
             assert np.array_equal(se, want_se) and np.array_equal(be, want_be), (case, method, threads, variant, se, want_se)
             assert res["n_realizations"] == count and res["sym_errors"] == int(want_se.sum())
@@ -85,7 +86,7 @@ def test_f64_kernel_against_the_oracle_over_2000_realizations(engine):
     want_se = np.array([w["symbol_errors"] for w in want])
     want_be = np.array([w["bit_errors"] for w in want])
     assert want_se.sum() > 1e5                                  # a realization in outage is thousands of errors
-    for threads, variant in ((0, 0), (512, 0), (256, 0)):
+    for threads, variant in ((0, 0), (257, 0), (512, 0), (256, 0)):
         for method, nocert in ((_lib.DEMOD_MINDIST, 0), (_lib.DEMOD_MINDIST, 1), (_lib.DEMOD_QAM_SLICER, 0)):
             with engine.options(demod_nocert=nocert):
                 res, se, be = _run(engine, kw, first, count, method, threads=threads, variant=variant)
