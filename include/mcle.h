@@ -97,8 +97,10 @@ enum {
     MCLE_OPT_JAKES_DIRECT = 6,     /* 1: one sincos per ray and sample (jakes_generate: k_jakes; complex128 flat-fading pipeline: no rotation recurrence) */
     MCLE_OPT_F64_GENERIC = 7,      /* 1: complex128 config 4 on the generic radix-4 kernel instead of k_run_mimo_ofdm_f64 */
     MCLE_OPT_F64_THREADS = 8,      /* complex128 config-4 kernel at (1024, 4x4): 0 = radix-16 passes, one transform per wavefront,
-                                      256-thread workgroups (default); 512 = radix-4 stages, two antennas per thread, 512 threads;
-                                      256 = radix-4 stages, four antennas per thread, 256 threads */
+                                      the channel fused with the span-1 butterflies, 256-thread workgroups (default); 257 = the same
+                                      with a separate channel stage; 258 = the same as 0 with every layer-1 twiddle from the table;
+                                      512 = radix-4 stages, two antennas per thread, 512 threads; 256 = radix-4 stages, four antennas
+                                      per thread, 256 threads (all five: same results contract; A/B times in DESIGN.md 5.5) */
     MCLE_OPT_BD_RUNTIME_SOLVE = 9, /* 1: the block-diagonalisation pipeline solves with the run-time-sized routine (private
                                       arrays in scratch) also where the compile-time-sized one (K nr <= 6) applies */
     MCLE_OPT_DEMOD_NOCERT = 10,    /* 1: min-distance decisions of a square Gray QAM always through the table search (candidate

@@ -277,11 +277,28 @@ __device__ __forceinline__ void r16_wave_sync() {
 }
 // a 16-point register pass: WHICH = 0 (pass A: offsets 64 q + 256 m, twiddles a1 / a2), 1 (pass B: 4 q + 16 m, b1 / b2).
 // DIF: butterflies over m, twiddle, butterflies over q, twiddle.  DIT: the mirror image, twiddles first.
-template <bool INV, bool DIT, int WHICH>
-__device__ __forceinline__ void r16_pass(double* pr, double* pi, int base_slot, const R16Tw64& tw) {
+// EXACT: the nine layer-1 twiddles of q >= 1, w^((k + 64 q) m) / w^(16 (k4 + 4 q) m), fetched from the (L1-resident) table at the
+// top of the pass instead of formed as register twiddle x constant 16th root: eight complex multiplications less per pass, and
+// the pass becomes the radix-4 stages' arithmetic operation for operation (bit-identical outputs).
+template <bool INV, bool DIT, int WHICH, bool EXACT = false>
+__device__ __forceinline__ void r16_pass(double* pr, double* pi, int base_slot, const R16Tw64& tw,
+                                         const double2* __restrict__ g_tw = nullptr, int kidx = 0) {
     constexpr int QS = WHICH == 0 ? 64 : 4, MS = WHICH == 0 ? 256 : 16;
     const double2* t1 = WHICH == 0 ? tw.a1 : tw.b1;
     const double2* t2 = WHICH == 0 ? tw.a2 : tw.b2;
+    [[maybe_unused]] double2 tq[3][3];                      // [q - 1][m - 1]
+    if constexpr (EXACT) {
+#pragma unroll
+        for (int q = 1; q < 4; ++q)
+#pragma unroll
+            for (int m = 1; m < 4; ++m)
+                tq[q - 1][m - 1] = g_tw[(WHICH == 0 ? (kidx + 64 * q) * m : 16 * (kidx + 4 * q) * m) & 1023];
+    }
+    auto tw1 = [&](auto qc, auto mc) -> double2 {           // layer-1 twiddle of (q, m), m >= 1, conjugated for the inverse
+        constexpr int q = decltype(qc)::value, m = decltype(mc)::value;
+        if constexpr (EXACT && q > 0) return r16_tw<INV>(tq[q - 1][m - 1]);
+        else return r16_tw<INV>(t1[m - 1]);
+    };
     double2 v[4][4];
 #pragma unroll
     for (int m = 0; m < 4; ++m)
@@ -294,9 +311,15 @@ __device__ __forceinline__ void r16_pass(double* pr, double* pi, int base_slot, 
         static_for<4>([&](auto qc) {
             constexpr int q = decltype(qc)::value;
             r4_inplace<INV>(v[0][q], v[1][q], v[2][q], v[3][q]);
-            v[1][q] = r16_root<INV, q * 1>(cmul(v[1][q], r16_tw<INV>(t1[0])));
-            v[2][q] = r16_root<INV, q * 2>(cmul(v[2][q], r16_tw<INV>(t1[1])));
-            v[3][q] = r16_root<INV, q * 3>(cmul(v[3][q], r16_tw<INV>(t1[2])));
+            if constexpr (EXACT) {
+                v[1][q] = cmul(v[1][q], tw1(qc, std::integral_constant<int, 1>()));
+                v[2][q] = cmul(v[2][q], tw1(qc, std::integral_constant<int, 2>()));
+                v[3][q] = cmul(v[3][q], tw1(qc, std::integral_constant<int, 3>()));
+            } else {
+                v[1][q] = r16_root<INV, q * 1>(cmul(v[1][q], r16_tw<INV>(t1[0])));
+                v[2][q] = r16_root<INV, q * 2>(cmul(v[2][q], r16_tw<INV>(t1[1])));
+                v[3][q] = r16_root<INV, q * 3>(cmul(v[3][q], r16_tw<INV>(t1[2])));
+            }
         });
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
@@ -313,9 +336,15 @@ __device__ __forceinline__ void r16_pass(double* pr, double* pi, int base_slot, 
         }
         static_for<4>([&](auto qc) {
             constexpr int q = decltype(qc)::value;
-            v[1][q] = r16_root<INV, q * 1>(cmul(v[1][q], r16_tw<INV>(t1[0])));
-            v[2][q] = r16_root<INV, q * 2>(cmul(v[2][q], r16_tw<INV>(t1[1])));
-            v[3][q] = r16_root<INV, q * 3>(cmul(v[3][q], r16_tw<INV>(t1[2])));
+            if constexpr (EXACT) {
+                v[1][q] = cmul(v[1][q], tw1(qc, std::integral_constant<int, 1>()));
+                v[2][q] = cmul(v[2][q], tw1(qc, std::integral_constant<int, 2>()));
+                v[3][q] = cmul(v[3][q], tw1(qc, std::integral_constant<int, 3>()));
+            } else {
+                v[1][q] = r16_root<INV, q * 1>(cmul(v[1][q], r16_tw<INV>(t1[0])));
+                v[2][q] = r16_root<INV, q * 2>(cmul(v[2][q], r16_tw<INV>(t1[1])));
+                v[3][q] = r16_root<INV, q * 3>(cmul(v[3][q], r16_tw<INV>(t1[2])));
+            }
             r4_inplace<INV>(v[0][q], v[1][q], v[2][q], v[3][q]);
         });
     }
@@ -351,27 +380,29 @@ template <bool INV> __device__ __forceinline__ void r16_pass_c(double* pr, doubl
     }
 }
 // natural -> digit-reversed (the arrangement of the radix-4 DIF stages) / digit-reversed -> natural; one wavefront, one antenna
-template <bool INV, bool WITH_C = true> __device__ __forceinline__ void r16_dif(double* pr, double* pi, int lane, const R16Tw64& tw) {
+template <bool INV, bool WITH_C = true, bool EXACT = false>
+__device__ __forceinline__ void r16_dif(double* pr, double* pi, int lane, const R16Tw64& tw, const double2* __restrict__ g_tw = nullptr) {
     int gi = opaque(lane);
-    r16_pass<INV, false, 0>(pr, pi, lds_swz16f(gi), tw);
+    r16_pass<INV, false, 0, EXACT>(pr, pi, lds_swz16f(gi), tw, g_tw, gi);
     r16_wave_sync();
     gi = opaque(lane);
-    r16_pass<INV, false, 1>(pr, pi, lds_swz16f(64 * (gi >> 2) + (gi & 3)), tw);
+    r16_pass<INV, false, 1, EXACT>(pr, pi, lds_swz16f(64 * (gi >> 2) + (gi & 3)), tw, g_tw, gi & 3);
     if constexpr (WITH_C) {
         r16_wave_sync();
         r16_pass_c<INV>(pr, pi, opaque(lane));
     }
 }
-template <bool INV, bool WITH_C = true> __device__ __forceinline__ void r16_dit(double* pr, double* pi, int lane, const R16Tw64& tw) {
+template <bool INV, bool WITH_C = true, bool EXACT = false>
+__device__ __forceinline__ void r16_dit(double* pr, double* pi, int lane, const R16Tw64& tw, const double2* __restrict__ g_tw = nullptr) {
     if constexpr (WITH_C) {
         r16_pass_c<INV>(pr, pi, opaque(lane));
         r16_wave_sync();
     }
     int gi = opaque(lane);
-    r16_pass<INV, true, 1>(pr, pi, lds_swz16f(64 * (gi >> 2) + (gi & 3)), tw);
+    r16_pass<INV, true, 1, EXACT>(pr, pi, lds_swz16f(64 * (gi >> 2) + (gi & 3)), tw, g_tw, gi & 3);
     r16_wave_sync();
     gi = opaque(lane);
-    r16_pass<INV, true, 0>(pr, pi, lds_swz16f(gi), tw);
+    r16_pass<INV, true, 0, EXACT>(pr, pi, lds_swz16f(gi), tw, g_tw, gi);
 }
 
 // N, NT x NR: the geometry.  AH = antennas per thread in the transform stages, TB = (N / 4) (NR / AH) threads per
@@ -397,6 +428,7 @@ __global__ __launch_bounds__((N / 4) * (NR / AH), WPS) void k_run_mimo_ofdm_f64(
     constexpr int TB = NB * (NR / AH), NW = TB / 64;                        // threads, wavefronts per workgroup
     constexpr bool R16 = (VAR & 4) != 0;                                    // radix-16 passes, one transform per wavefront
     constexpr bool FUSED = R16 && (VAR & 8) != 0;                           // ... with pass C, the channel and pass C' as one stage
+    constexpr bool EXACT = R16 && (VAR & 16) != 0;                          // ... with every layer-1 twiddle from the table
     static_assert(!R16 || (N == 1024 && NT == 4 && NR == 4 && AH == 4), "radix-16 variant: 1024, 4 x 4, 256 threads");
     constexpr bool TWR = AH == NR && N == 1024 && !R16;                     // a thread's twiddles in registers
     auto swz = [](int e) { return R16 ? lds_swz16f(e) : lds_swz64(e); };
@@ -517,7 +549,7 @@ __global__ __launch_bounds__((N / 4) * (NR / AH), WPS) void k_run_mimo_ofdm_f64(
             //      measured no gain).  Antenna groups beyond Nt have nothing to send and only keep the barriers. ----
             if constexpr (R16) {
                 if constexpr (FUSED) tw16 = load_r16_tw(g_tw, opaque(lane));
-                r16_dif<true, !FUSED>(s_wave_re, s_wave_im, lane, tw16);
+                r16_dif<true, !FUSED, EXACT>(s_wave_re, s_wave_im, lane, tw16, g_tw);
                 __syncthreads();
             } else
             static_for<N4>([&](auto stc) {
@@ -656,7 +688,7 @@ __global__ __launch_bounds__((N / 4) * (NR / AH), WPS) void k_run_mimo_ofdm_f64(
             // ---- FFT: (the radix-2 stage +) radix-4 DIT, digit-reversed -> natural bins ----
             if constexpr (R16) {
                 if constexpr (FUSED) tw16 = load_r16_tw(g_tw, opaque(lane));
-                r16_dit<false, !FUSED>(s_wave_re, s_wave_im, lane, tw16);
+                r16_dit<false, !FUSED, EXACT>(s_wave_re, s_wave_im, lane, tw16, g_tw);
                 __syncthreads();
             } else if constexpr (TWR) {
                 if constexpr (SH::HAS2) {
@@ -838,6 +870,8 @@ int run_mimo_ofdm_f64(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, uint64_t see
             return launch_mimo_ofdm_f64<1024, 4, 4, 2, 4>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
         if (ctx->opt[MCLE_OPT_F64_THREADS] == 257)      // radix-16 passes with the unfused channel stage (A/B)
             return launch_mimo_ofdm_f64<1024, 4, 4, 4, 2, 4>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
+        if (ctx->opt[MCLE_OPT_F64_THREADS] == 258)      // every layer-1 twiddle from the table (A/B: 10.95 ms against 10.62 -- the nine
+            return launch_mimo_ofdm_f64<1024, 4, 4, 4, 2, 28>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);   // loads per pass cost more than the eight products)
         return launch_mimo_ofdm_f64<1024, 4, 4, 4, 2, 12>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
     }
     MCLE_F64_GEOM(1024, 2, 2, 2, 3)
