@@ -315,16 +315,19 @@ def cpu_baseline(cfg, budget_s, gpu_first_counts):
 
 
 def _cpu_worker(job):
-    """One process of the multi-core CPU leg: `n` realizations starting at `first` (NumPy oracle)."""
-    cfg, first, n = job
+    """One process of the multi-core CPU leg: realizations from `first` on for `seconds` of wall time (NumPy oracle; a TIME
+    budget, not a count: with every core busy a process runs several times slower than the one-core leg suggests)."""
+    cfg, first, seconds = job
     for v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
         os.environ[v] = "1"
     from oracle import chains
     fn, kw = _oracle_chain(cfg)
+    fn(chains.PhiloxRng(SEED, first), **kw)                 # imports / first-call set-up outside the clock
     t0 = time.perf_counter()
-    err = 0
-    for r in range(first, first + n):
-        err += fn(chains.PhiloxRng(SEED, r), **kw)["symbol_errors"]
+    err, n = 0, 0
+    while time.perf_counter() - t0 < seconds:
+        err += fn(chains.PhiloxRng(SEED, first + 1 + n), **kw)["symbol_errors"]
+        n += 1
     return n, time.perf_counter() - t0, err
 
 
@@ -338,20 +341,19 @@ def cpu_baseline_multicore(cfg, single_core_rate, budget_s):
     except (AttributeError, OSError):
         pass
     workers = max(1, min(physical, 256))                              # one process per physical core
-    per = max(1, int(single_core_rate * budget_s * 0.7))
     ctx = mp.get_context("spawn")
     t0 = time.perf_counter()
     with ctx.Pool(workers) as pool:
-        done = pool.map(_cpu_worker, [(cfg, (1 << 30) + w * per, per) for w in range(workers)])
+        done = pool.map(_cpu_worker, [(cfg, (1 << 30) + w * (1 << 20), budget_s) for w in range(workers)], chunksize=1)
     wall = time.perf_counter() - t0
     n = sum(d[0] for d in done)
     busy = max(d[1] for d in done)
     return {"value": n / busy, "unit": "realizations/s", "cores": workers, "kind": "port",
             "host_physical_cores": physical, "host_logical_cpus": logical,
             "scaling_vs_one_core": (n / busy) / single_core_rate,
-            "sample": "%d realizations over %d processes (spawn) = one per physical core of %d (%d logical CPUs), slowest "
-                      "worker %.1f s, wall %.1f s incl. start-up; scaling against the one-core leg %.1f x (shared memory "
-                      "bandwidth / boost clocks)"
+            "sample": "%d realizations over %d processes (spawn) = one per physical core of %d (%d logical CPUs), each for a "
+                      "fixed %.1f s of wall time, wall %.1f s incl. start-up; scaling against the one-core leg %.1f x (shared "
+                      "memory bandwidth / boost clocks)"
                       % (n, workers, physical, logical, busy, wall, (n / busy) / single_core_rate)}
 
 
