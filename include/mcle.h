@@ -511,14 +511,16 @@ int mcle_bd_extint(mcle_ctx* ctx, const mcle_bd_extint_cfg* cfg, const void* d_b
                    int32_t* d_ns, double* d_cand_sinr, uint32_t* d_skipped, size_t batch);
 
 /* ---- iterative interference alignment for general geometries (SURVEY 8(f).3 tail): K <= 4 users with
- *      Nr x Nt <= 4 x 4 antennas each and per-user stream counts; AlternatingMinIASolver / MinLeakageIASolver /
+ *      Nr x Nt <= 6 x 6 antennas each (the reference's own application runs K = 3, Nr = 5, Nt = 3, Ns = 2,
+ *      apps/ia/IA_Results_NrxNt(Ns).py:130-133) and per-user stream counts; AlternatingMinIASolver / MinLeakageIASolver /
  *      MaxSinrIASolver .solve (ia/algorithms.py:802-883, 885-1507) from injected precoders ('fix') or the 'svd'
  *      start (:503-547, Nr == Nt), optionally inside GreedStreamIASolver.solve (:1905-2010: drop the worst stream
  *      while the sum capacity grows) or BruteForceStreamIASolver.solve (:2147-2260: every stream combination up to
  *      ns[], 'svd' start, best sum capacity).  One lane per channel realization, f64.
- *      d_bigH [batch][K nr][K nt]; d_F_init [batch][4][4][4] = user k's nt x ns[k] start in the top-left corner
+ *      Padded arrays are D x D with D = 4 when max(Nr, Nt) <= 4 and D = 6 otherwise (two instantiations of the solver).
+ *      d_bigH [batch][K nr][K nt]; d_F_init [batch][4][D][D] = user k's nt x ns[k] start in the top-left corner
  *      (ignored for 'svd' and for brute force).  Outputs, same padded layout: d_F (nt x ns, unit Frobenius norm =
- *      full_F for P = 1), d_U (full_W_H, ns x nr), d_sinr [batch][4][4] (linear, per stream), d_capacity [batch],
+ *      full_F for P = 1), d_U (full_W_H, ns x nr), d_sinr [batch][4][D] (linear, per stream), d_capacity [batch],
  *      d_iterations [batch] (all runs of a selection wrapper added up), d_ns [batch][4] (streams kept per user),
  *      d_skipped [batch] (a singular system met on the way), d_every_capacity [batch][256] (brute force only: the sum
  *      capacity of every stream combination in itertools.product order, last user fastest --

@@ -903,7 +903,15 @@ CHAINS = {
                            ("max_sinr", 3, 3, 2, 25.0, 12, 0.0, "random", "greedy"),
                            ("alt_min", 4, 4, 2, 15.0, 10, 0.0, "random", "greedy"),
                            ("max_sinr", 3, 3, 2, 12.0, 8, 0.0, "svd", "brute"),
-                           ("min_leakage", 2, 2, 1, 20.0, 10, 0.0, "svd", "brute"))],
+                           ("min_leakage", 2, 2, 1, 20.0, 10, 0.0, "svd", "brute"),
+                           # round 4: the geometry of the reference's own application, apps/ia/IA_Results_NrxNt(Ns).py:130-133
+                           # (K = 3, Nr = 5, Nt = 3, Ns = 2), and its neighbours -- the 6 x 6 capacity of the solver
+                           ("max_sinr", 5, 3, 2, 15.0, 30, 0.0, "random", None),
+                           ("alt_min", 5, 3, 2, 20.0, 40, 0.0, "random", None),
+                           ("max_sinr", 5, 3, 2, 20.0, 120, 1e-6, "random", None),
+                           ("min_leakage", 5, 3, 1, 20.0, 20, 0.0, "random", None),
+                           ("max_sinr", 6, 6, 3, 12.0, 15, 0.0, "svd", None),
+                           ("max_sinr", 5, 5, (3, 2, 2), 18.0, 10, 0.0, "random", "greedy"))],
     "f1_mimo_ofdm_tdl": [dict(mod="qam", M=16, nt=2, nr=2, fft_size=64, cp_size=16, num_used=None, n_ofdm_sym=2,
                               snr_db=20.0, Fd=50.0, Ts=1e-6, L=8, tap_powers_dB=(0.0, -4.0, -9.0),
                               tap_delays_samples=(0, 2, 5)),

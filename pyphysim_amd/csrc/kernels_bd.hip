@@ -657,16 +657,21 @@ __global__ __launch_bounds__(64) void k_bd_solve_links_static(BdParams pp, uint6
 // Register budget of the walk: four waves per SIMD (128 VGPRs, 45 of them spilled by the lockstep search) measured against
 // three (168 VGPRs, nothing spilled) on the round-3 box: 1.266 vs 1.355-1.365 ms per 131 072 realizations -- the fourth
 // wave hides more latency than the spills cost; kept at four.
-template <typename T, int R>
+// Round 4: KC = the number of users as a compile-time constant (0: run-time, arrays and loops sized for kBdMaxN) and MODE = the
+// demodulator path chosen by the host (0: demod_one per stream -- slicer, certificate, grid or sweep; 1: the R streams of a
+// user swept in lockstep, M <= 8; 2: lockstep through the certificate / candidate grid).  With all three paths and
+// eight-entry arrays in one body the complex64 form spilled 45-52 registers at its 128-register bound (profiles/r03:
+// VALU busy 0.97 on the draw ledger plus spill traffic).
+template <typename T, int R, int KC = 0, int MODE = 0>
 __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void k_bd_link(ModemParams<T> mp, BdParams pp, uint64_t seed,
                                                                         uint64_t first, uint64_t count, int per_wave,
                                                                         const cx<T>* __restrict__ recs,
                                                                         mcle_counters* counters,
                                                                         uint32_t* __restrict__ sym_out,
                                                                         uint32_t* __restrict__ bit_out) {
-    constexpr int KMAX = kBdMaxN / R;
+    constexpr int KMAX = KC ? KC : kBdMaxN / R, NMAX = KC ? KC * R : kBdMaxN;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int K = pp.K, n = K * R;
+    const int K = KC ? KC : pp.K, n = K * R;
     const int stride = n * (R + 1) + 1;
     unsigned long long* s_grid = reinterpret_cast<unsigned long long*>(smem);
     __shared__ cx<T> s_table[256];
@@ -687,7 +692,6 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void k_bd_link(ModemPar
     const int NS = pp.n_symbols;
     // f32, min-distance: the R streams of a user searched in lockstep -- directly for constellations of <= 8 points,
     // through the candidate grid otherwise (same decisions as demod_one, one LDS round trip per candidate for all R)
-    const bool lockstep = sizeof(T) == 4 && mp.method == MCLE_DEMOD_MINDIST && (mp.M <= 8 || mp.grid.G > 0);
     if (threadIdx.x == 0) wg_zero(totals);
     __syncthreads();
     const uint64_t n_chunks = (count + per_wave - 1) / per_wave;
@@ -700,10 +704,10 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void k_bd_link(ModemPar
             const bool ok = D[n * (R + 1)].x != (T)0;
             unsigned se = 0, be = 0;
             // one symbol column
-            auto column = [&](const int (&tx)[kBdMaxN], const cx<T> (&nz)[kBdMaxN]) {
+            auto column = [&](const int (&tx)[NMAX], const cx<T> (&nz)[NMAX]) {
 #pragma unroll
                 for (int k = 0; k < KMAX; ++k)
-                    if (k < K) {
+                    if (KC || k < K) {
                         cx<T> est[R];
 #pragma unroll
                         for (int jj = 0; jj < R; ++jj) {
@@ -713,15 +717,11 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void k_bd_link(ModemPar
                             for (int a = 0; a < R; ++a) est[jj] = cfma(W[s * R + a], nz[k * R + a], est[jj]);
                         }
                         int dec[R];
-                        bool done = false;
-                        if constexpr (sizeof(T) == 4) {
-                            if (lockstep) {
-                                if (mp.M <= 8) demod_multi_cert(mp, est, dec, [&](int (&d_)[R]) { demod_mindist_multi<R>(s_tab4, mp.M, est, d_); });
-                                else demod_multi_cert(mp, est, dec, [&](int (&d_)[R]) { demod_grid4_multi<R>(s_tab4, s_grid, mp.grid, mp.M, est, d_); });
-                                done = true;
-                            }
-                        }
-                        if (!done) {
+                        if constexpr (sizeof(T) == 4 && MODE == 1) {
+                            demod_mindist_multi<R>(s_tab4, mp.M, est, dec);
+                        } else if constexpr (sizeof(T) == 4 && MODE == 2) {
+                            demod_multi_cert(mp, est, dec, [&](int (&d_)[R]) { demod_grid4_multi<R>(s_tab4, s_grid, mp.grid, mp.M, est, d_); });
+                        } else {
 #pragma unroll
                             for (int jj = 0; jj < R; ++jj) dec[jj] = demod_one(mp, s_table, s_grid, est[jj]);
                         }
@@ -737,13 +737,13 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void k_bd_link(ModemPar
                 // two columns per lane and pass: whole Philox blocks, symbol blocks shared across the wave
                 for (int t0 = 0; t0 < NS; t0 += kPairCols) {
                     const int t = t0 + 2 * lane;
-                    int ta[kBdMaxN], tb[kBdMaxN];
-                    wave_symbol_pairs<kBdMaxN>(rng, n, (uint32_t)NS, (uint32_t)t0, mask, lane, ta, tb);
+                    int ta[NMAX], tb[NMAX];
+                    wave_symbol_pairs<NMAX>(rng, n, (uint32_t)NS, (uint32_t)t0, mask, lane, ta, tb);
                     if (t < NS) {
-                        cx<T> za[kBdMaxN], zb[kBdMaxN];
+                        cx<T> za[NMAX], zb[NMAX];
 #pragma unroll
-                        for (int a = 0; a < kBdMaxN; ++a)
-                            if (a < n)
+                        for (int a = 0; a < NMAX; ++a)
+                            if (KC || a < n)
                                 cn_pair_lds(rng, STREAM_NOISE, ((uint32_t)a * (uint32_t)NS + (uint32_t)t) >> 1, sigma,
                                             za[a], zb[a], s_bm);
                         column(ta, za);
@@ -752,11 +752,11 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void k_bd_link(ModemPar
                 }
             } else {
                 for (int t = lane; t < NS; t += 64) {
-                    int tx[kBdMaxN];
-                    cx<T> nz[kBdMaxN];
+                    int tx[NMAX];
+                    cx<T> nz[NMAX];
 #pragma unroll
-                    for (int a = 0; a < kBdMaxN; ++a)
-                        if (a < n) {
+                    for (int a = 0; a < NMAX; ++a)
+                        if (KC || a < n) {
                             tx[a] = (int)symbol_at(rng, (uint64_t)a * NS + t, mask);   // randint(0, M, [n, NSymbs])
                             nz[a] = cn_sample<T>(rng, STREAM_NOISE, (uint64_t)a * NS + t, sigma);
                         }
@@ -806,9 +806,22 @@ static int launch_run_bd(mcle_ctx* ctx, const mcle_bd_cfg* cfg, const BdParams& 
         const uint64_t cap = (uint64_t)ctx->n_cu * 4 * (sizeof(T) == 4 ? 4 : 2);
         const uint64_t chunks = (m + per_wave - 1) / per_wave;
         const unsigned grid = (unsigned)oversubscribed_grid(ctx, cap, chunks, 2);     // a chunk is 8-16 realizations; one chunk per workgroup measured 1.5 x slower
-        hipLaunchKernelGGL((k_bd_link<T, R>), dim3(grid), dim3(64), lds, ctx->stream, mp, pp, seed, first + off, m, per_wave,
-                           (const cx<T>*)recs, d_counters, d_sym_err ? d_sym_err + off : nullptr,
-                           d_bit_err ? d_bit_err + off : nullptr);
+        // demodulator path of the walk (compile-time in the kernel): complex64 min-distance in lockstep -- a sweep for M <= 8,
+        // certificate / candidate grid otherwise; everything else one demod_one per stream
+        const int mode = (sizeof(T) == 4 && mp.method == MCLE_DEMOD_MINDIST) ? (mp.M <= 8 ? 1 : (mp.grid.G > 0 ? 2 : 0)) : 0;
+        bool walked = false;
+#define MCLE_BD_WALK(KC_, MODE_)                                                                                          \
+    if (!walked && (KC_ == 0 || (cfg->K == KC_ && KC_ * R <= kBdMaxN)) && mode == MODE_) {                                  \
+        hipLaunchKernelGGL((k_bd_link<T, R, (KC_ * R <= kBdMaxN ? KC_ : 0), (sizeof(T) == 4 ? MODE_ : 0)>), dim3(grid), dim3(64), lds, \
+                           ctx->stream, mp, pp, seed, first + off, m, per_wave, (const cx<T>*)recs, d_counters,           \
+                           d_sym_err ? d_sym_err + off : nullptr, d_bit_err ? d_bit_err + off : nullptr);                 \
+        walked = true;                                                                                                    \
+    }
+        if constexpr (R <= 2) {                    // users as a compile-time count where the arrays then shrink: K = 2, 3
+            MCLE_BD_WALK(2, 0) MCLE_BD_WALK(2, 1) MCLE_BD_WALK(2, 2) MCLE_BD_WALK(3, 0) MCLE_BD_WALK(3, 1) MCLE_BD_WALK(3, 2)
+        }
+        MCLE_BD_WALK(0, 0) MCLE_BD_WALK(0, 1) MCLE_BD_WALK(0, 2)
+#undef MCLE_BD_WALK
         MCLE_LAUNCH_CHECK();
     }
     return MCLE_OK;

@@ -929,12 +929,14 @@ class Engine:
     def ia_solve_general(self, solver, big_H, K, nr, nt, Ns, noise_var, max_iterations=50, relative_factor=1e-6,
                          F_init=None, select=None):
         """Iterative IA for general geometries (csrc/kernels_ia_general.hip; reference ia/algorithms.py:802-883,
-        885-1507, 1853-2260): K <= 4 users with nr x nt <= 4 x 4 antennas, Ns = streams per user (int or list).
-        big_H [batch, K nr, K nt].  F_init: [batch, K, 4, 4] padded initial precoders ('fix' / a captured random
-        start) or None for the 'svd' start.  select: None, 'greedy' (GreedStreamIASolver) or 'brute'
-        (BruteForceStreamIASolver, always from 'svd').  -> dict of padded arrays: F [b, K, 4, 4] (nt x ns in the
-        top-left corner), U = full_W_H [b, K, 4, 4] (ns x nr), sinr [b, K, 4], capacity [b], iterations [b],
+        885-1507, 1853-2260): K <= 4 users with nr x nt <= 6 x 6 antennas, Ns = streams per user (int or list).
+        big_H [batch, K nr, K nt].  Padded arrays are D x D with D = 4 when max(nr, nt) <= 4, else 6 (the library's two
+        capacities).  F_init: [batch, 4, D, D] (user, nt x ns in the top-left corner; [batch, K, D, D] is padded here)
+        -- 'fix' / a captured random start -- or None for the 'svd' start.  select: None, 'greedy' (GreedStreamIASolver)
+        or 'brute' (BruteForceStreamIASolver, always from 'svd').  -> dict of padded arrays: F [b, K, D, D] (nt x ns in the
+        top-left corner), U = full_W_H [b, K, D, D] (ns x nr), sinr [b, K, D], capacity [b], iterations [b],
         Ns [b, K], skipped [b]."""
+        D = 4 if max(int(nr), int(nt)) <= 4 else 6
         H = np.ascontiguousarray(big_H, dtype=np.complex128)
         if H.ndim == 2:
             H = H[np.newaxis]
@@ -957,11 +959,15 @@ class Engine:
         d_F0 = None
         if cfg.initialize_with == 0:
             F0 = np.ascontiguousarray(F_init, dtype=np.complex128)
-            if F0.shape != (b, 4, 4, 4):
-                raise ValueError("F_init must be [batch, 4, 4, 4] (user, nt, ns; zero padded)")
+            if F0.ndim == 4 and F0.shape[0] == b and F0.shape[1] in (K, 4) and F0.shape[2] <= D and F0.shape[3] <= D:
+                pad = np.zeros((b, 4, D, D), dtype=np.complex128)       # any smaller padding is re-padded to the capacity
+                pad[:, :F0.shape[1], :F0.shape[2], :F0.shape[3]] = F0
+                F0 = pad
+            if F0.shape != (b, 4, D, D):
+                raise ValueError("F_init must be [batch, 4, %d, %d] (user, nt, ns; zero padded)" % (D, D))
             d_F0 = self.to_device(F0)
-        F, U = self.empty((b, 4, 4, 4), np.complex128), self.empty((b, 4, 4, 4), np.complex128)
-        sinr, cap = self.empty((b, 4, 4), np.float64), self.empty(b, np.float64)
+        F, U = self.empty((b, 4, D, D), np.complex128), self.empty((b, 4, D, D), np.complex128)
+        sinr, cap = self.empty((b, 4, D), np.float64), self.empty(b, np.float64)
         its, ns, sk = self.empty(b, np.uint32), self.empty((b, 4), np.int32), self.empty(b, np.uint32)
         every = self.empty((b, 256), np.float64) if select == "brute" else None
         self._raise_value(self.lib.mcle_ia_solve_general(self.ctx, byref(cfg), d_H.ptr, d_F0.ptr if d_F0 else None,

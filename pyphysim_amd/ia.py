@@ -186,8 +186,8 @@ class IASolverBaseClass:
         Ns_arr = np.ones(self.K, dtype=int) * Ns if isinstance(Ns, (int, np.integer)) else np.asarray(Ns, dtype=int)
         nr, nt = int(self.Nr[0]), int(self.Nt[0])
         if (self.K < 2 or self.K > 4 or any(int(v) != nr for v in self.Nr) or any(int(v) != nt for v in self.Nt)
-                or nr > 4 or nt > 4 or len(Ns_arr) != self.K or np.any(Ns_arr < 1) or np.any(Ns_arr > min(nr, nt))):
-            raise ValueError("the GPU interference-alignment kernels cover K <= 4 users with the same Nr, Nt <= 4 for "
+                or nr > 6 or nt > 6 or len(Ns_arr) != self.K or np.any(Ns_arr < 1) or np.any(Ns_arr > min(nr, nt))):
+            raise ValueError("the GPU interference-alignment kernels cover K <= 4 users with the same Nr, Nt <= 6 for "
                              "every user and 1 <= Ns <= min(Nr, Nt) (got K = %d, Nr = %s, Nt = %s, Ns = %s)"
                              % (self.K, list(self.Nr), list(self.Nt), list(Ns_arr)))
         return Ns_arr, nr, nt
@@ -306,7 +306,8 @@ class IterativeIASolverBaseClass(IASolverBaseClass):
             raise ValueError("initialize_with = %r is available on the K = 3, 2x2, one-stream kernel only" % (init,))
         pad = None
         if F0 is not None:
-            pad = np.zeros((1, 4, 4, 4), dtype=complex)
+            D = 4 if max(nr, nt) <= 4 else 6                    # the library's two matrix capacities
+            pad = np.zeros((1, 4, D, D), dtype=complex)
             for k in range(self.K):
                 f = np.asarray(F0[k])
                 pad[0, k, :f.shape[0], :f.shape[1]] = f
