@@ -430,7 +430,8 @@ def chain_ia_general(rng, algo, mod, M, K, nr, nt, Ns, NSymbs, snr_db, max_itera
                runned_iterations=int(sol["runned"]), symbol_errors=omodem.count_symbol_errors(idx, dec), bit_errors=int(omodem.count_bit_errors(idx, dec)),
                num_symbols=int(idx.size), num_bits=int(idx.size) * omodem.level2bits(M))
     if F_init is not None:
-        out["F_init"] = pad(F_init, 4, 4)
+        D = 4 if max(nr, nt) <= 4 else 6          # the solver's two matrix capacities (csrc/kernels_ia_general.hip)
+        out["F_init"] = pad(F_init, D, D)
     if select == "brute":
         out["every_sum_capacity"] = np.array(sol["every_sum_capacity"], dtype=float)
         out["stream_combinations"] = np.array(sol["stream_combinations"], dtype=np.int64)

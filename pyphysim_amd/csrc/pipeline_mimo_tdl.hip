@@ -118,8 +118,12 @@ __global__ __launch_bounds__(256) void k_mimo_tdl_symbol_polys(MimoTdlParams pp,
     rec[PS * (K + 1) + p] = mk<T>(mr, mi);
 }
 
+// wavefronts per SIMD the register allocation is bounded for = workgroups per CU the LDS admits: three (complex64) / two
+// (complex128), but ONE at 2048 x 4 antennas (64 / 128 KiB of samples): bounded for more, those two instantiations spilled
+// 113 / 266 registers (928 B of scratch, profiles/r03/kernel_resources.json) for an occupancy they cannot have
+template <typename T, int N, int NA> constexpr int mimo_tdl_waves() { return (N >= 2048 && NA >= 4) ? 1 : (sizeof(T) == 4 ? 3 : 2); }
 template <typename T, int N, int NA>
-__global__ __launch_bounds__(kPipeBlock, sizeof(T) == 4 ? 3 : 2) void k_run_mimo_ofdm_tdl(
+__global__ __launch_bounds__(kPipeBlock, (mimo_tdl_waves<T, N, NA>())) void k_run_mimo_ofdm_tdl(
     MimoTdlParams pp, ModemParams<T> mp, uint64_t seed, uint64_t first, uint64_t count,
     const cx<T>* __restrict__ g_tw, const cx<T>* __restrict__ g_polys, mcle_counters* counters,
     uint32_t* __restrict__ sym_out, uint32_t* __restrict__ bit_out) {

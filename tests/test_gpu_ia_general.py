@@ -32,14 +32,18 @@ def _unpad(arr, rows, cols):
     return [np.asarray(arr[k][:rows[k], :cols[k]]) for k in range(len(rows))]
 
 
-@pytest.mark.parametrize("case", range(15))
+@pytest.mark.parametrize("case", range(21))
 def test_general_ia_against_reference(engine, case):
+    """cases 15-20 (round 4): the geometry of the reference's own application -- K = 3, Nr = 5, Nt = 3, Ns = 2
+    (apps/ia/IA_Results_NrxNt(Ns).py:130-133) -- and its neighbours (5x5, 6x6) on the solver's 6 x 6 capacity."""
     kw, reals = golden_cases("f3c_ia_general")[case]
     K, nr, nt = kw["K"], kw["nr"], kw["nt"]
+    D = 4 if max(nr, nt) <= 4 else 6
     for g in reals:
         F_init = g["F_init"][np.newaxis] if ("F_init" in g and kw["select"] != "brute") else None
         if F_init is not None:
-            F_init = np.concatenate([F_init, np.zeros((1, 4 - K, 4, 4), dtype=complex)], axis=1)
+            assert F_init.shape[2:] == (D, D)
+            F_init = np.concatenate([F_init, np.zeros((1, 4 - K, D, D), dtype=complex)], axis=1)
         sol = engine.ia_solve_general(kw["algo"], g["big_H"], K, nr, nt, kw["Ns"], float(g["noise_var"]),
                                       kw["max_iterations"], kw["relative_factor"], F_init=F_init, select=kw["select"])
         assert sol["skipped"][0] == 0
@@ -89,9 +93,11 @@ def test_general_ia_batch_and_errors(engine):
         engine.ia_solve_general("max_sinr", H, 3, 3, 3, 4, 0.1)
     with pytest.raises(ValueError, match="svd"):
         engine.ia_solve_general("max_sinr", np.zeros((1, 6, 12), dtype=complex), 3, 2, 4, 1, 0.1)
+    with pytest.raises(ValueError, match=r"\[1, 6\]"):
+        engine.ia_solve_general("max_sinr", np.zeros((1, 21, 9), dtype=complex), 3, 7, 3, 1, 0.1, F_init=np.zeros((1, 4, 6, 6)))
 
 
-@pytest.mark.parametrize("case", [4, 6, 10, 11, 13])
+@pytest.mark.parametrize("case", [4, 6, 10, 11, 13, 15, 20])
 def test_class_mirrors_on_general_geometries(engine, case):
     """ia.MaxSinrIASolver / GreedStreamIASolver / BruteForceStreamIASolver written against like the reference's classes:
     the same seeds give the same channel, random start, stream counts, iteration count, SINRs and sum capacity."""
