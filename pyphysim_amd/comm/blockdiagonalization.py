@@ -46,8 +46,13 @@ class BlockDiagonalizer:
         assert H.shape[0] % self.num_users == 0, ("`block_diagonalize`: Number of rows of the channel must be"
                                                   " a multiple of the number of users.")
         if H.ndim != 2 or H.shape[0] != H.shape[1]:
+            # The reference does not get further either: with more transmit than receive antennas its
+            # least_right_singular_vectors indexes the min(rows, cols) singular values of the wide matrix with the column
+            # indices of the full V (util/misc.py:647-663) and raises IndexError inside _calc_BD_matrix_no_power_scaling
+            # (blockdiagonalization.py:338) -- verified against /root/reference in round 4 (K = 2, 2 antennas per user,
+            # 6 transmit antennas).  There is no reference behaviour to reproduce beyond the square case.
             raise NotImplementedError("this build block-diagonalises square channels (total transmit antennas == "
-                                      "total receive antennas)")
+                                      "total receive antennas), the only case the reference's BlockDiagonalizer completes")
         out = self.engine.block_diagonalize(H, self.num_users, self.iPu if iPu is None else iPu,
                                             self.noise_var if noise_var is None else noise_var, waterfilling)
         if out["skipped"][0]:
