@@ -596,7 +596,28 @@ def main():
             flag = torch.tensor([ok], dtype=torch.int64, device=xdev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)      # every rank must hold the id before anyone blocks in ncclCommInitRank
             if int(flag[0]) == 1:
-                native = NativeComm(eng, rank, world, unique_id=uid)      # step 2: mcle_comm_init on the context's device
+                # step 2: mcle_comm_init (ncclCommInitRank) on the context's device -- on a side thread with a deadline: a rank
+                # whose RCCL bring-up fails or hangs must not leave the other ranks (and the driver's run) blocked for ever
+                import threading
+                box = {}
+
+                def _bring_up():
+                    try:
+                        box["comm"] = NativeComm(eng, rank, world, unique_id=uid)
+                    except Exception as exc:            # noqa: BLE001 -- reported in the line
+                        box["err"] = repr(exc)
+                th = threading.Thread(target=_bring_up, daemon=True)
+                th.start()
+                th.join(timeout=120.0)
+                flag = torch.tensor([1 if "comm" in box else 0], dtype=torch.int64, device=xdev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if int(flag[0]) == 1:
+                    native = box["comm"]
+                else:
+                    comm_note = ("mcle_comm_init did not come up on every rank within 120 s (%s): exchange through "
+                                 "torch.distributed" % box.get("err", "this rank ok" if "comm" in box else "timeout"))
+                    if args.comm == "native":
+                        raise SystemExit("bench.py: --comm native: " + comm_note)
             else:
                 comm_note = "NativeComm rendezvous failed on some rank (%s): exchange through torch.distributed" % err
                 if args.comm == "native":

@@ -437,9 +437,9 @@ int mcle_run_flat_fading(mcle_ctx* ctx, int dtype, const mcle_flat_cfg* cfg, uin
 int mcle_run_ofdm_tdl(mcle_ctx* ctx, int dtype, const mcle_ofdm_tdl_cfg* cfg, uint64_t seed,
                       uint64_t first, uint64_t count, mcle_counters* d_counters,
                       uint32_t* d_sym_err, uint32_t* d_bit_err);
-/* Envelope: 1 <= Nt <= Nr <= 4.  complex128: fft_size 256 / 512 / 1024 / 2048 with 2x2 and 4x4, 2x4 at 256 and 1024, on the
- * planar kernel family (pipeline_mimo_f64.hip; 2048 with 4x4 exists there only: 148 KiB of LDS); 2x2 / 4x4 at 64 and 128 on
- * the generic kernel.  complex64: 2x2 / 4x4 at 64 .. 2048 (1024 with 4x4 on the matrix cores).  Anything else: MCLE_E_INVAL. */
+/* Envelope: 1 <= Nt <= Nr <= 4.  complex128: fft_size 256 / 512 / 1024 / 2048 with every Nt <= Nr (Blast takes any Nr x Nt,
+ * mimo/mimo.py:264-309) on the planar kernel family (pipeline_mimo_f64.hip; 2048 with 4 receive antennas exists there only:
+ * 148 KiB of LDS); 2x2 / 4x4 at 64 and 128 on the generic kernel.  complex64: 2x2 / 4x4 at 64 .. 2048 (1024 with 4x4 on the matrix cores).  Anything else: MCLE_E_INVAL. */
 int mcle_run_mimo_ofdm(mcle_ctx* ctx, int dtype, const mcle_mimo_ofdm_cfg* cfg, uint64_t seed,
                        uint64_t first, uint64_t count, mcle_counters* d_counters,
                        uint32_t* d_sym_err, uint32_t* d_bit_err);

@@ -845,7 +845,8 @@ static int launch_mimo_ofdm_f64(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, ui
 //   1024  4x4   radix-16 form: 4 antennas / wave-per-antenna, 256 threads, 2 workgroups per CU, 2 wavefronts per SIMD
 //  (1024  4x4   2   512   2   4  radix-4, option f64_threads=512)   2048  4x4   2  1024   1   4        512  4x4   2   256   3   3        256  4x4   2  128  5  3
 //   1024  2x2   2   256   3   3        2048  2x2   2   512   2   4        512  2x2   2   128   5   3        256  2x2   2   64  8  2
-// Nt < Nr (2x4, 3x4, 1x2, 1x4 ...: mimo/mimo.py:264-309 takes any) run the Nr geometry; antenna groups past Nt idle in the IFFT.
+// Nt < Nr (mimo/mimo.py:264-309 takes any): every 1 <= Nt <= Nr <= 4 at every size runs the Nr geometry (Nr = 3: three
+// antennas per thread, one group); antenna groups past Nt idle in the IFFT.
 int run_mimo_ofdm_f64(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, uint64_t seed, uint64_t first, uint64_t count,
                       mcle_counters* d_counters, uint32_t* d_sym, uint32_t* d_bit) {
     if (ctx->opt[MCLE_OPT_F64_GENERIC]) return MCLE_E_UNSUPPORTED;
@@ -874,11 +875,16 @@ int run_mimo_ofdm_f64(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, uint64_t see
             return launch_mimo_ofdm_f64<1024, 4, 4, 4, 2, 28>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);   // loads per pass cost more than the eight products)
         return launch_mimo_ofdm_f64<1024, 4, 4, 4, 2, 12>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
     }
-    MCLE_F64_GEOM(1024, 2, 2, 2, 3)
-    MCLE_F64_GEOM(2048, 4, 4, 2, 4) MCLE_F64_GEOM(2048, 2, 2, 2, 4)
-    MCLE_F64_GEOM(512, 4, 4, 2, 3) MCLE_F64_GEOM(512, 2, 2, 2, 3)
-    MCLE_F64_GEOM(256, 4, 4, 2, 3) MCLE_F64_GEOM(256, 2, 2, 2, 2)
-    MCLE_F64_GEOM(1024, 2, 4, 2, 4) MCLE_F64_GEOM(256, 2, 4, 2, 3)
+    // every Nt <= Nr <= 4 at every size: Nr = 2 / 4 two antennas per thread, Nr = 3 three (one group)
+#define MCLE_F64_SIZE(N_, W2_, W4_)                                                                                  \
+    MCLE_F64_GEOM(N_, 1, 2, 2, W2_) MCLE_F64_GEOM(N_, 2, 2, 2, W2_)                                                  \
+    MCLE_F64_GEOM(N_, 1, 3, 3, 2) MCLE_F64_GEOM(N_, 2, 3, 3, 2) MCLE_F64_GEOM(N_, 3, 3, 3, 2)                        \
+    MCLE_F64_GEOM(N_, 1, 4, 2, W4_) MCLE_F64_GEOM(N_, 2, 4, 2, W4_) MCLE_F64_GEOM(N_, 3, 4, 2, W4_)
+    MCLE_F64_SIZE(256, 2, 3) MCLE_F64_GEOM(256, 4, 4, 2, 3)
+    MCLE_F64_SIZE(512, 3, 3) MCLE_F64_GEOM(512, 4, 4, 2, 3)
+    MCLE_F64_SIZE(1024, 3, 4)
+    MCLE_F64_SIZE(2048, 4, 4) MCLE_F64_GEOM(2048, 4, 4, 2, 4)
+#undef MCLE_F64_SIZE
 #undef MCLE_F64_GEOM
     return MCLE_E_UNSUPPORTED;
 }

@@ -1120,7 +1120,7 @@ int mcle_run_mimo_ofdm(mcle_ctx* ctx, int dtype, const mcle_mimo_ofdm_cfg* cfg, 
     }
     MCLE_REQUIRE(cfg->nt == cfg->nr && (cfg->nt == 2 || cfg->nt == 4),
                  "fused MIMO pipeline: %d x %d at fft_size %d is outside the envelope (2x2 / 4x4 at 64 .. 2048 in both arithmetics; "
-                 "2x4 in complex128 at 256 and 1024)", cfg->nt, cfg->nr, cfg->fft_size);
+                 "every 1 <= Nt <= Nr <= 4 in complex128 at 256 .. 2048)", cfg->nt, cfg->nr, cfg->fft_size);
 #define MCLE_RUN(N_, NA_)                                                                                         \
     if (cfg->fft_size == N_ && cfg->nt == NA_)                                                                    \
         return dtype == MCLE_F32                                                                                  \

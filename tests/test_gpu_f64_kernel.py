@@ -96,7 +96,9 @@ def test_f64_kernel_against_the_oracle_over_2000_realizations(engine):
 
 
 # ---- round 4: the kernel as a family (fft_size 256 .. 2048, 2x2 / 4x4 / 2x4), not a benchmark point ----
-SHAPES = [(256, 2, 2), (256, 4, 4), (512, 2, 2), (512, 4, 4), (1024, 2, 2), (2048, 2, 2), (2048, 4, 4), (1024, 2, 4), (256, 2, 4)]
+SHAPES = [(256, 2, 2), (256, 4, 4), (512, 2, 2), (512, 4, 4), (1024, 2, 2), (2048, 2, 2), (2048, 4, 4), (1024, 2, 4), (256, 2, 4),
+          # Nt < Nr and three receive antennas (Blast takes any Nr x Nt, mimo/mimo.py:264-309)
+          (512, 1, 2), (1024, 3, 4), (2048, 1, 4), (256, 2, 3), (1024, 3, 3), (512, 1, 3), (2048, 3, 4)]
 SHAPE_CASES = [dict(mod="qam", M=64, snr_db=25.0),
                dict(mod="qam", M=16, snr_db=17.0, used_frac=0.6, n_ofdm_sym=2, cp_size=7, mmse=False),   # partial band, odd CP, ZF
                dict(mod="psk", M=8, snr_db=13.0, n_ofdm_sym=2, cp_size=33)]                               # candidate grid only
@@ -133,7 +135,7 @@ def test_f64_family_counts_equal_the_oracle(engine, shape, case):
         res, se, be = _run_shape(engine, okw, first, count, method)
         assert np.array_equal(se, want_se) and np.array_equal(be, want_be), (shape, case, method, se, want_se)
         assert res["n_symbols"] == want[0]["num_symbols"] and res["n_bits"] == want[0]["num_bits"]
-    if nt == nr and (fft, nr) != (2048, 4):       # (the generic complex128 kernel would need 181 KiB of LDS at 2048 x 4)
+    if nt == nr and nr != 3 and (fft, nr) != (2048, 4):       # (the generic kernel: 2x2 / 4x4 only, and 181 KiB of LDS at 2048 x 4)
         n = 300
         new, se, be = _run_shape(engine, okw, 9, n, _lib.DEMOD_MINDIST)
         old, se_o, be_o = _run_shape(engine, okw, 9, n, _lib.DEMOD_MINDIST, generic=True)
@@ -143,7 +145,8 @@ def test_f64_family_counts_equal_the_oracle(engine, shape, case):
 
 def test_shapes_outside_the_envelope_are_refused(engine):
     engine.set_constellation(chains.constellation("qam", 16), _lib.CONST_QAM)
-    for nt, nr, fft, dtype in [(4, 2, 1024, "f64"), (2, 4, 512, "f64"), (2, 4, 1024, "f32"), (3, 3, 1024, "f64"), (2, 2, 96, "f64")]:
+    for nt, nr, fft, dtype in [(4, 2, 1024, "f64"), (2, 4, 1024, "f32"), (3, 3, 1024, "f32"), (2, 2, 96, "f64"), (5, 5, 1024, "f64"),
+                               (2, 4, 128, "f64")]:
         with pytest.raises((_lib.McleError, ValueError)):
             engine.run_mimo_ofdm(nt, nr, fft, 16, fft, 1, 0.01, SEED, 0, 4, dtype=dtype)
 
