@@ -429,7 +429,7 @@ __global__ __launch_bounds__((N / 4) * (NR / AH), WPS) void k_run_mimo_ofdm_f64(
     constexpr bool R16 = (VAR & 4) != 0;                                    // radix-16 passes, one transform per wavefront
     constexpr bool FUSED = R16 && (VAR & 8) != 0;                           // ... with pass C, the channel and pass C' as one stage
     constexpr bool EXACT = R16 && (VAR & 16) != 0;                          // ... with every layer-1 twiddle from the table
-    static_assert(!R16 || (N == 1024 && NT == 4 && NR == 4 && AH == 4), "radix-16 variant: 1024, 4 x 4, 256 threads");
+    static_assert(!R16 || (N == 1024 && NR == 4 && AH == 4), "radix-16 variant: 1024, four receive antennas, 256 threads");
     constexpr bool TWR = AH == NR && N == 1024 && !R16;                     // a thread's twiddles in registers
     auto swz = [](int e) { return R16 ? lds_swz16f(e) : lds_swz64(e); };
     static_assert(TB % 64 == 0 && TB <= 1024 && TB >= kRec && NW <= 16, "workgroup");
@@ -549,7 +549,7 @@ __global__ __launch_bounds__((N / 4) * (NR / AH), WPS) void k_run_mimo_ofdm_f64(
             //      measured no gain).  Antenna groups beyond Nt have nothing to send and only keep the barriers. ----
             if constexpr (R16) {
                 if constexpr (FUSED) tw16 = load_r16_tw(g_tw, opaque(lane));
-                r16_dif<true, !FUSED, EXACT>(s_wave_re, s_wave_im, lane, tw16, g_tw);
+                if (NT == NR || w < NT) r16_dif<true, !FUSED, EXACT>(s_wave_re, s_wave_im, lane, tw16, g_tw);   // wavefront = antenna
                 __syncthreads();
             } else
             static_for<N4>([&](auto stc) {
@@ -882,6 +882,11 @@ int run_mimo_ofdm_f64(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, uint64_t see
     MCLE_F64_GEOM(N_, 1, 4, 2, W4_) MCLE_F64_GEOM(N_, 2, 4, 2, W4_) MCLE_F64_GEOM(N_, 3, 4, 2, W4_)
     MCLE_F64_SIZE(256, 2, 3) MCLE_F64_GEOM(256, 4, 4, 2, 3)
     MCLE_F64_SIZE(512, 3, 3) MCLE_F64_GEOM(512, 4, 4, 2, 3)
+    if (n == 1024 && nr == 4 && ctx->opt[MCLE_OPT_F64_THREADS] == 0) {      // Nt < 4 at the benchmark size: the radix-16 form too
+        if (nt == 1) return launch_mimo_ofdm_f64<1024, 1, 4, 4, 2, 12>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
+        if (nt == 2) return launch_mimo_ofdm_f64<1024, 2, 4, 4, 2, 12>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
+        if (nt == 3) return launch_mimo_ofdm_f64<1024, 3, 4, 4, 2, 12>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
+    }
     MCLE_F64_SIZE(1024, 3, 4)
     MCLE_F64_SIZE(2048, 4, 4) MCLE_F64_GEOM(2048, 4, 4, 2, 4)
 #undef MCLE_F64_SIZE
