@@ -106,7 +106,7 @@ enum {
     MCLE_OPT_DEMOD_NOCERT = 10,    /* 1: min-distance decisions of a square Gray QAM always through the table search (candidate
                                       grid / sweep); 0: through the margin certificate of modem.hpp (demod_qam_cert: the
                                       closed-form nearest level per axis, accepted when the received point is farther than
-                                      2^-30 (complex64: 2^-12) of a level spacing from every decision boundary, the table
+                                      2^-30 (complex64: 2^-15) of a level spacing from every decision boundary, the table
                                       search otherwise -- identical decisions, no table gathers) */
     MCLE_OPT_F64_VARIANT = 11,     /* complex128 config-4 kernel (1024, 4x4), TIMING BOUNDS ONLY on its 512-thread radix-4 form --
                                       results are wrong by construction: bit 0 = the LDS stores of the last transmit stage and of

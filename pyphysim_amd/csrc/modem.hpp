@@ -348,12 +348,14 @@ __device__ __forceinline__ int demod_qam_slicer(cx<T> r, T scale, int L, int hal
 // rounding of t, of the table entries or of either metric (|c - r|^2 here, hypot in numpy.abs, fundamental.py:241-246)
 // can move -- so the exhaustive sweep, its first-minimum tie rule included, returns this very label: `sure`.  Otherwise
 // (a point within eps of a decision boundary: probability ~ 4 eps per symbol) the caller runs the table search it
-// always ran.  eps = 2^-30 for complex128 (t <= 16 carries an error of 4e-15), 2^-12 for complex64 (error 2e-6).
+// always ran.  eps = 2^-30 for complex128 (t <= 16 carries an error of 4e-15), 2^-15 for complex64 (t <= 32 carries an error
+// of <= 4e-6: eight times below; a wavefront pass of 256 symbols then takes the table search in 3 % of its passes -- 2^-12,
+// the first setting, sent 40 % of them there and left the complex64 min-distance rate 15 % under the slicer's).
 // What this buys: no data-dependent LDS gathers (cell word + 1..4 table entries per symbol: they were the bank conflicts
 // of the min-distance kernels, conflict fraction 0.41-0.64) and ~25 instead of ~45 instructions per symbol.
 template <typename T>
 __device__ __forceinline__ int demod_qam_cert(cx<T> r, T scale, int L, int half_bits, bool& sure) {
-    constexpr T lim = sizeof(T) == 8 ? (T)(0.5 - 0x1p-30) : (T)(0.5 - 0x1p-12);
+    constexpr T lim = sizeof(T) == 8 ? (T)(0.5 - 0x1p-30) : (T)(0.5 - 0x1p-15);
     const T lm1 = (T)(L - 1), hs = scale * (T)0.5, hl = lm1 * (T)0.5;
     T tj = r.x * hs + hl, ti = hl - r.y * hs;                      // level coordinates (col from -max real, row from +max imag)
     tj = fmin(fmax(tj, (T)0), lm1);                               // beyond the outer levels: certain (f = 0); NaN -> 0

@@ -19,7 +19,7 @@ def cert_model(r, M, dtype):
     hb = bits // 2
     L = 1 << hb
     scale = T(np.sqrt((M - 1) * 2.0 / 3.0))
-    lim = T(0.5 - 2.0 ** -30) if dtype == "f64" else T(0.5 - 2.0 ** -12)
+    lim = T(0.5 - 2.0 ** -30) if dtype == "f64" else T(0.5 - 2.0 ** -15)
     lm1, hs, hl = T(L - 1), scale * T(0.5), T(L - 1) * T(0.5)
     x, y = r.real.astype(T), r.imag.astype(T)
     tj = np.minimum(np.maximum(x * hs + hl, T(0)), lm1)
@@ -68,7 +68,7 @@ def test_certificate_model_equals_the_argmin_where_sure(M):
     want32 = np.argmin(np.abs(tab[None, :] - r32.astype(np.complex128)[:, None]), axis=1)
     lab32, sure32 = cert_model(r32, M, "f32")
     assert np.array_equal(lab32[sure32], want32[sure32])
-    assert sure32[:40000].mean() > 1.0 - 4e-3 * np.sqrt(M)
+    assert sure32[:40000].mean() > 1.0 - 5e-4 * np.sqrt(M)
 
 
 @pytest.mark.gpu
