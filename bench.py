@@ -69,20 +69,29 @@ FP32_PEAK_TFLOPS = 157.3    # same guide: FP32 vector peak = FP32-input MFMA pea
 FP64_PEAK_TFLOPS = 78.6
 FP64_MEASURED = {"v_mfma_f64_16x16x4_f64": 77.6, "v_fma_f64": 65.9, "source": "profiles/r03/f64_rates.txt"}
 PEAK_TFLOPS = {"f32": FP32_PEAK_TFLOPS, "f64": FP64_PEAK_TFLOPS}
-KERNEL = {"c4": "k_run_mimo_ofdm_mfma", "c2": "k_run_flat_mfma", "c3": "k_run_ofdm_tdl_mfma", "c5": "k_ia_link",
+KERNEL = {"c4": "k_run_mimo_ofdm_planar", "c2": "k_run_flat_mfma", "c3": "k_run_ofdm_tdl_mfma", "c5": "k_ia_link",
           "f1": "k_run_mimo_ofdm_tdl", "f6": "k_bd_link"}
-KERNEL_F64 = {"c4": "k_run_mimo_ofdm_f64", "c2": "k_run_flat", "c3": "k_run_ofdm_tdl_batch", "c5": "k_ia_link",
+KERNEL_F64 = {"c4": "k_run_mimo_ofdm_planar", "c2": "k_run_flat", "c3": "k_run_ofdm_tdl_batch", "c5": "k_ia_link",
               "f1": "k_run_mimo_ofdm_tdl", "f6": "k_bd_link"}
 
 
+ACTIVE_OPTS = {}            # --opt name=value of this run (main fills it): some options change which kernel a configuration runs
+
+
 def kernel_name(cfg, dtype):
+    if cfg == "c4" and dtype == "f32" and ACTIVE_OPTS.get("f32_mfma"):
+        return "k_run_mimo_ofdm_mfma"                 # the matrix-core kernel of rounds 2-3 (option f32_mfma = 1)
+    if cfg == "c4" and ACTIVE_OPTS.get("f64_generic") or (cfg == "c4" and dtype == "f32" and ACTIVE_OPTS.get("no_mfma")):
+        return "k_run_mimo_ofdm<"                     # the generic radix-4 kernel
     return (KERNEL_F64 if dtype == "f64" else KERNEL)[cfg]
 
 KERNEL_NOTE = {   # configs whose step is two launches: the time spans both, the counters are the named (dominant) kernel's
-    "c4": "a step = k_mimo_filters (channel draw + f64 receive filter per realization, 13 us = 0.8 % of the time) + k_run_mimo_ofdm_mfma; "
-          "kernel_ms_per_launch spans both",
-    ("c4", "f64"): "a step = per slice of 2^18 realizations k_mimo_filters_f64 (channel draw + f64 receive filter, one thread per "
-                   "realization, ~1 % of the time) + k_run_mimo_ofdm_f64; kernel_ms_per_launch spans them",
+    "c4": "a step = per slice of 2^18 realizations k_mimo_filters_planar<float> (channel draw in float, receive filter in f64, one "
+          "thread per realization, ~1 % of the time) + k_run_mimo_ofdm_planar<float> (radix-16 register passes, one transform per "
+          "wavefront; since round 4 the default ahead of the matrix-core kernel k_run_mimo_ofdm_mfma, option f32_mfma = 1); "
+          "kernel_ms_per_launch spans them",
+    ("c4", "f64"): "a step = per slice of 2^18 realizations k_mimo_filters_planar (channel draw + f64 receive filter, one thread per "
+                   "realization, ~1 % of the time) + k_run_mimo_ofdm_planar; kernel_ms_per_launch spans them",
     ("c3", "f64"): "a step = k_tdl_symbol_polys<double> (fading records) + k_run_ofdm_tdl_batch<double, 1024, 2> per slice of <= 64 MiB "
                    "of records; kernel_ms_per_launch spans them",
     "f1": "a step = k_mimo_tdl_symbol_polys (the symbols' fading records, one thread per fading process) + k_run_mimo_ofdm_tdl per "
@@ -478,6 +487,10 @@ def roofline_block(args, dtype, batch, per_launch_s, rate_kernel, d, pmc_source)
              # scripts/experiments/mfma_valu_overlap.hip, profiles/r02/mfma_valu_overlap.txt), so the two add up
              "fp32_datapath_busy_chip": (d["valu_busy_chip"] + d["mfma_busy_chip"])
              if dtype == "f32" and d.get("valu_busy_chip") is not None and d.get("mfma_busy_chip") is not None else None,
+             "valu_busy_note": "4 x SQ_ACTIVE_INST_VALU / SIMD-cycles: the counter books 4 cycles per wave instruction, while v_add / "
+                               "v_mul / v_fma_f32 and the 32-bit logic ops issue in 2.7 - 3.0 cycles at >= 2 wavefronts per SIMD "
+                               "(scripts/experiments/f32_rates.hip -> profiles/r04/f32_rates.txt), so a kernel made of them reads "
+                               "above 1: >= 1 means the VALU issue is saturated" if dtype == "f32" else None,
              "valu_wave_insts_per_realization": d.get("valu_wave_insts_per_realization"),
              "mfma_f32_mops_per_realization": d.get("mfma_f32_mops_per_realization"),
              "wait_inst_any_frac": d.get("wait_inst_any_frac"),
@@ -488,7 +501,8 @@ def roofline_block(args, dtype, batch, per_launch_s, rate_kernel, d, pmc_source)
                      % (("%.0f" % (balg / measured)) if measured else "?", "FP64" if dtype == "f64" else "FP32",
                         " (VALU only: the f64 MFMA forms are no denser than v_fma_f64 here and do not overlap with it, "
                         "DESIGN.md section 5.5)" if dtype == "f64" else
-                        " (VALU + f32 MFMA instructions, which do not overlap on gfx950)")}
+                        " (VALU; the matrix-core form of this configuration, option f32_mfma, shares that datapath: f32 MFMA and "
+                        "VALU instructions do not overlap on gfx950)")}
     return block
 
 
@@ -577,6 +591,7 @@ def main():
     for item in args.opt:
         name, _, val = item.partition("=")
         eng.set_option(name, int(val))
+        ACTIVE_OPTS[name] = int(val)
     batch = args.batch or BATCH[args.config]
     exchange_calls = {"timed": 0}
     # ---- who carries the exchange: the product's own RCCL communicator (csrc/comm.hip) or torch.distributed ----

@@ -95,12 +95,15 @@ enum {
     MCLE_OPT_TDL_MFMA_WAVES = 5,   /* config-3 matrix-core kernel: 0 / 2 = two waves per SIMD, 3 = three, 32 = three with two
                                       realizations per pass instead of four */
     MCLE_OPT_JAKES_DIRECT = 6,     /* 1: one sincos per ray and sample (jakes_generate: k_jakes; complex128 flat-fading pipeline: no rotation recurrence) */
-    MCLE_OPT_F64_GENERIC = 7,      /* 1: complex128 config 4 on the generic radix-4 kernel instead of k_run_mimo_ofdm_f64 */
+    MCLE_OPT_F64_GENERIC = 7,      /* 1: config 4 on the generic radix-4 kernel instead of the planar family (either arithmetic) */
     MCLE_OPT_F64_THREADS = 8,      /* complex128 config-4 kernel at (1024, 4x4): 0 = radix-16 passes, one transform per wavefront,
                                       the channel fused with the span-1 butterflies, 256-thread workgroups (default); 257 = the same
                                       with a separate channel stage; 258 = the same as 0 with every layer-1 twiddle from the table;
                                       512 = radix-4 stages, two antennas per thread, 512 threads; 256 = radix-4 stages, four antennas
-                                      per thread, 256 threads (all five: same results contract; A/B times in DESIGN.md 5.5) */
+                                      per thread, 256 threads (all five: same results contract; A/B times in DESIGN.md 5.5).
+                                      complex64 (the planar family on planes of floats): 0 = radix-16 passes with a SEPARATE channel
+                                      stage at a four-wavefront register bound (default); 257 = the same at a three-wavefront
+                                      bound; 259 = the fused channel stage; 512 / 256 as above */
     MCLE_OPT_BD_RUNTIME_SOLVE = 9, /* 1: the block-diagonalisation pipeline solves with the run-time-sized routine (private
                                       arrays in scratch) also where the compile-time-sized one (K nr <= 6) applies */
     MCLE_OPT_DEMOD_NOCERT = 10,    /* 1: min-distance decisions of a square Gray QAM always through the table search (candidate
@@ -112,7 +115,11 @@ enum {
                                       results are wrong by construction: bit 0 = the LDS stores of the last transmit stage and of
                                       the channel stage dropped, bit 1 = the two workgroup barriers around the channel stage
                                       dropped */
-    MCLE_OPT_COUNT = 12
+    MCLE_OPT_F32_MFMA = 12,        /* complex64 config 4 at (1024, 4x4): 1 = the matrix-core kernel k_run_mimo_ofdm_mfma (the default of
+                                      rounds 2-3) instead of the planar VALU family (k_run_mimo_ofdm_planar<float>: the complex128
+                                      kernels on planes of floats, 10-20 % faster at this geometry and the only fast complex64 kernel
+                                      at every other one; default since round 4) */
+    MCLE_OPT_COUNT = 13
 };
 int mcle_ctx_set_option(mcle_ctx* ctx, int option, long long value);
 int mcle_ctx_get_option(mcle_ctx* ctx, int option, long long* value);
@@ -437,9 +444,10 @@ int mcle_run_flat_fading(mcle_ctx* ctx, int dtype, const mcle_flat_cfg* cfg, uin
 int mcle_run_ofdm_tdl(mcle_ctx* ctx, int dtype, const mcle_ofdm_tdl_cfg* cfg, uint64_t seed,
                       uint64_t first, uint64_t count, mcle_counters* d_counters,
                       uint32_t* d_sym_err, uint32_t* d_bit_err);
-/* Envelope: 1 <= Nt <= Nr <= 4.  complex128: fft_size 256 / 512 / 1024 / 2048 with every Nt <= Nr (Blast takes any Nr x Nt,
- * mimo/mimo.py:264-309) on the planar kernel family (pipeline_mimo_f64.hip; 2048 with 4 receive antennas exists there only:
- * 148 KiB of LDS); 2x2 / 4x4 at 64 and 128 on the generic kernel.  complex64: 2x2 / 4x4 at 64 .. 2048 (1024 with 4x4 on the matrix cores).  Anything else: MCLE_E_INVAL. */
+/* Envelope: 1 <= Nt <= Nr <= 4, either arithmetic: fft_size 256 / 512 / 1024 / 2048 with every Nt <= Nr (Blast takes any Nr x Nt,
+ * mimo/mimo.py:264-309) on the planar kernel family (pipeline_mimo_planar.hip; in complex128 2048 with 4 receive antennas exists
+ * there only: 148 KiB of LDS); 2x2 / 4x4 at 64 and 128 on the generic kernel.  complex64 at (1024, 4x4): the planar radix-16
+ * kernel by default, the matrix-core kernel with MCLE_OPT_F32_MFMA = 1.  Anything else: MCLE_E_INVAL. */
 int mcle_run_mimo_ofdm(mcle_ctx* ctx, int dtype, const mcle_mimo_ofdm_cfg* cfg, uint64_t seed,
                        uint64_t first, uint64_t count, mcle_counters* d_counters,
                        uint32_t* d_sym_err, uint32_t* d_bit_err);

@@ -19,7 +19,7 @@
 //   sqrt    v_rsq_f64 + one coupled Newton step + two residual corrections (argument range [2e-10, 23]: no scaling).
 //
 // ~47 f64 instructions + 12 integer ones + 3 table reads per sample.  The tables are 4.1 KiB: static device arrays (served
-// from L1) by default, or a kernel's own LDS copy where the latency matters (pipeline_mimo_f64.hip).  tests/test_bm_f64_cpu.py compiles this header
+// from L1) by default, or a kernel's own LDS copy where the latency matters (pipeline_mimo_planar.hip).  tests/test_bm_f64_cpu.py compiles this header
 // for the host and checks it word by word against NumPy; the -m gpu parity tests then hold every complex128 pipeline's
 // per-realization error counts equal to the oracle's.
 #pragma once
@@ -113,7 +113,7 @@ MCLE_BM_FN void bm_sincos(uint32_t x1, double& c, double& s, const double* tthet
 }
 
 // The same with the node angle and its cos / sin in ONE 32-byte entry {cos, sin, theta, -} (a kernel's own LDS copy, built by
-// bm_trig_packed_to_lds): one address for both reads of a sample (variant measured in round 4, pipeline_mimo_f64.hip)
+// bm_trig_packed_to_lds): one address for both reads of a sample (variant measured in round 4, pipeline_mimo_planar.hip)
 MCLE_BM_FN void bm_sincos_packed(uint32_t x1, double& c, double& s, const double* tpk) {
     const double ang = (double)x1 * 0x1.921fb54442d18p-30;
     const uint32_t k = ((x1 >> 24) + 1u) >> 1;

@@ -172,13 +172,13 @@ int mcle_ctx_set_option(mcle_ctx* ctx, int option, long long value) {
     MCLE_REQUIRE(option >= 0 && option < MCLE_OPT_COUNT, "unknown option %d", option);
     bool ok = false;
     switch (option) {
-        case MCLE_OPT_NO_MFMA: case MCLE_OPT_SINGLE_TDL: case MCLE_OPT_JAKES_DIRECT: case MCLE_OPT_F64_GENERIC: case MCLE_OPT_BD_RUNTIME_SOLVE: case MCLE_OPT_DEMOD_NOCERT: ok = value == 0 || value == 1; break;
+        case MCLE_OPT_NO_MFMA: case MCLE_OPT_SINGLE_TDL: case MCLE_OPT_JAKES_DIRECT: case MCLE_OPT_F64_GENERIC: case MCLE_OPT_BD_RUNTIME_SOLVE: case MCLE_OPT_DEMOD_NOCERT: case MCLE_OPT_F32_MFMA: ok = value == 0 || value == 1; break;
         case MCLE_OPT_F64_VARIANT: ok = value >= 0 && value <= 3; break;
         case MCLE_OPT_MFMA_VARIANT: ok = value == 0 || value == 36 || value == 32 || value == 30 || value == 21; break;
         case MCLE_OPT_GRID_OVERSUB: ok = value >= 0 && value <= 64; break;
         case MCLE_OPT_FLAT_WGS_PER_CU: ok = value >= 0 && value <= 4096; break;
         case MCLE_OPT_TDL_MFMA_WAVES: ok = value == 0 || value == 2 || value == 3 || value == 32; break;
-        case MCLE_OPT_F64_THREADS: ok = value == 0 || (value >= 256 && value <= 258) || value == 512; break;
+        case MCLE_OPT_F64_THREADS: ok = value == 0 || (value >= 256 && value <= 259) || value == 512; break;
     }
     MCLE_REQUIRE(ok, "option %d: value %lld out of range", option, value);
     ctx->opt[option] = value;

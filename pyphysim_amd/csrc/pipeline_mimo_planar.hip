@@ -1,5 +1,8 @@
-// pipeline_mimo_f64.hip -- config 4 (Blast + OFDM over a flat MIMO channel) in complex128, the reference's own precision
-// (apps/mimo/simulate_mimo.py:68-142, mimo/mimo.py:609-660, modulators/ofdm.py:394-466: complex128 throughout).
+// pipeline_mimo_planar.hip -- config 4 (Blast + OFDM over a flat MIMO channel) on PLANAR samples: written in round 3 for
+// complex128, the reference's own precision (apps/mimo/simulate_mimo.py:68-142, mimo/mimo.py:609-660,
+// modulators/ofdm.py:394-466: complex128 throughout; the file was pipeline_mimo_f64.hip), a template over the scalar type since
+// the end of round 4: the same kernels on planes of floats are the complex64 family and -- at (1024, 4x4) -- faster than the
+// matrix-core kernel of pipeline_mimo_mfma.hip.  The notes below are the complex128 design notes.
 //
 // Same link, same draw ledger (philox.hpp) and same results contract as k_run_mimo_ofdm<double, N, NA> (pipelines.hip),
 // whose per-realization counts it reproduces; what changed is how the f64 datapath and the LDS are used (round-3
@@ -13,12 +16,12 @@
 //   * no LDS twiddle copy (16 KiB in f64 at N = 1024): twiddles come from the L1-resident global table, fetched one stage
 //     ahead where a stage multiplies first, or live in registers (256-thread form).  64 KiB of planes + tables = 77 KiB
 //     at N = 1024, 4 x 4 -> TWO workgroups per CU.
-//   * the channel draw and the f64 receive filter of every realization in a launch of their own (k_mimo_filters_f64), like
+//   * the channel draw and the f64 receive filter of every realization in a launch of their own (k_mimo_filters_planar), like
 //     the f32 matrix-core path.
 //   * Box-Muller by table + short polynomial (bm_f64.hpp); min-distance decisions of a square QAM through the margin
 //     certificate, of anything else through the candidate grid (both decision-identical to the sweep, modem.hpp).
 // Round 4: a FAMILY, not a benchmark point -- fft_size in {256, 512, 1024, 2048} (a trailing radix-2 stage for 512 / 2048,
-// like fft.hpp), Nt <= Nr in {2, 4} square plus the Nr > Nt shapes listed in run_mimo_ofdm_f64; the reference's OFDM /
+// like fft.hpp), Nt <= Nr in {2, 4} square plus the Nr > Nt shapes listed in run_mimo_ofdm_planar; the reference's OFDM /
 // Blast take any of them (modulators/ofdm.py:52-94, mimo/mimo.py:264-309, :609-660).
 // No matrix cores here, on purpose: v_mfma_f64_16x16x4_f64 issues in 65 cycles (2048 flops: 31.5 flop/clk/SIMD, measured,
 // scripts/experiments/f64_rates.hip) against 4.8 cycles for a v_fma_f64 (26.7 flop/clk), does NOT overlap with VALU work
@@ -52,34 +55,61 @@ template <int COUNT, typename F> __device__ __forceinline__ void static_for(F&& 
     static_for_impl(f, std::make_integer_sequence<int, COUNT>());
 }
 
+// Complex arithmetic of the transforms, the channel and the decode in one place.  A PACKED complex64 specialization (a value =
+// one 64-bit register pair, v_pk_add / v_pk_mul / v_pk_fma_f32 with op_sel swizzles and sign modifiers as inline asm: a radix-4
+// butterfly in 8 instructions instead of 16, a twiddle product in 2 instead of 4) was measured in round 4 and is kept as
+// scripts/experiments/f32_packed_cx_r04.patch: 23 % fewer VALU instructions, no gain in time at the benchmark geometry (4.88 ->
+// 5.06 ms per 262 144 realizations; -18 % .. +15 % over the family) -- on gfx950 a packed f32 op issues in 4.3 - 4.6 cycles
+// against 2.7 - 3.0 for v_add / v_mul / v_fma_f32 (scripts/experiments/f32_rates.hip -> profiles/r04/f32_rates.txt), so packing
+// buys 1.2 - 1.4 x per flop at best, and the asm blocks cost the scheduler its view of the latencies.
+template <typename T> struct CxOps {
+    using C = cx<T>;
+    static __device__ __forceinline__ C add(C a, C b) { return cadd(a, b); }
+    static __device__ __forceinline__ C sub(C a, C b) { return csub(a, b); }
+    template <bool CONJ> static __device__ __forceinline__ C mulw(C a, C w) {       // a w  or  a conj(w)
+        if (CONJ) w.y = -w.y;
+        return cmul(a, w);
+    }
+    static __device__ __forceinline__ C fma(C h, C x, C acc) { return cfma(h, x, acc); }
+    // y0 = (u0 + u2) + (u1 + u3), y2 = (u0 + u2) - (u1 + u3), y1 / y3 = (u0 - u2) +/- r (u1 - u3), r = -i (forward), +i (INV)
+    template <bool INV> static __device__ __forceinline__ void bfly4(C u0, C u1, C u2, C u3, C& y0, C& y1, C& y2, C& y3) {
+        const C a0 = cadd(u0, u2), a1 = csub(u0, u2), a2 = cadd(u1, u3), a3 = rot<T, INV>(csub(u1, u3));
+        y0 = cadd(a0, a2);
+        y1 = cadd(a1, a3);
+        y2 = csub(a0, a2);
+        y3 = csub(a1, a3);
+    }
+};
 // LDS position of element e of a plane of doubles: the 8-byte-slot swizzle of fft.hpp (conflict free for the loads and the
 // stores of every stage of this kernel: the legs of the radix-4 butterflies at every span, the trailing radix-2 stage, the
 // channel's position pairs, scatter and decode, at every size of the family; tests/test_f64_layout.py replays all of them).
 __host__ __device__ __forceinline__ int lds_swz64(int e) { return lds_swz<true>(e); }
 
-template <int N, int NT, int NR>
-__global__ __launch_bounds__(64) void k_mimo_filters_f64(MimoParams pp, uint64_t seed, uint64_t first, uint64_t count,
-                                                         double2* __restrict__ recs) {
+// complex64: the channel is drawn in float (the draw ledger of the complex64 kernels), the filter computed in double and rounded
+template <typename T, int N, int NT, int NR>
+__global__ __launch_bounds__(64) void k_mimo_filters_planar(MimoParams pp, uint64_t seed, uint64_t first, uint64_t count,
+                                                            cx<T>* __restrict__ recs) {
     constexpr int kRec = d64_rec<NT, NR>();
     const uint64_t rl = (uint64_t)blockIdx.x * 64 + threadIdx.x;
     if (rl >= count) return;
     const double rx_scale = sqrt((double)(pp.num_used + pp.cp)) / (double)N;
     const Rng rng(seed, first + rl);
-    double2* rec = recs + rl * kRec;
+    cx<T>* rec = recs + rl * kRec;
     double2 H[NR][NT], G[NT][NR];
 #pragma unroll
     for (int r = 0; r < NR; ++r)
 #pragma unroll
         for (int a = 0; a < NT; ++a) {
-            H[r][a] = cn_sample<double>(rng, STREAM_CHAN, (uint64_t)(r * NT + a), 1.0);
-            rec[r * NT + a] = H[r][a];
+            const cx<T> h = cn_sample<T>(rng, STREAM_CHAN, (uint64_t)(r * NT + a), (T)1);
+            rec[r * NT + a] = h;
+            H[r][a] = mk<double>((double)h.x, (double)h.y);
         }
     const bool ok = blast_filter<NT, NR>(H, pp.mmse ? pp.noise_var : 0.0, G);
 #pragma unroll
     for (int a = 0; a < NT; ++a)
 #pragma unroll
-        for (int r = 0; r < NR; ++r) rec[NT * NR + a * NR + r] = mk<double>(G[a][r].x * rx_scale, G[a][r].y * rx_scale);
-    rec[2 * NT * NR] = mk<double>(ok ? 0.0 : 1.0, 0.0);
+        for (int r = 0; r < NR; ++r) rec[NT * NR + a * NR + r] = mk<T>((T)(G[a][r].x * rx_scale), (T)(G[a][r].y * rx_scale));
+    rec[2 * NT * NR] = mk<T>(ok ? (T)0 : (T)1, (T)0);
 }
 
 // Radix-4 stage spans of an N-point transform in DIF order: N/4, N/16, ... down to 1 (N = 4^k) or 2 (N = 2 4^k, then one
@@ -97,11 +127,11 @@ template <int N> struct F64Shape {
 // (conjugated for the inverse transform); in the 256-thread form of N = 1024 they live in 48 registers for the whole
 // kernel -- fetched per stage from the global table they sat on the critical path of every stage (three dependent
 // ~600-cycle loads at two wavefronts per SIMD).
-template <int N> struct TwRegs64 {
-    double2 w[F64Shape<N>::N4][3];
+template <typename T, int N> struct TwRegs64 {
+    cx<T> w[F64Shape<N>::N4][3];
 };
-template <int N> __device__ __forceinline__ TwRegs64<N> load_tw64(const double2* __restrict__ g_tw, int bb) {
-    TwRegs64<N> t;
+template <typename T, int N> __device__ __forceinline__ TwRegs64<T, N> load_tw64(const cx<T>* __restrict__ g_tw, int bb) {
+    TwRegs64<T, N> t;
 #pragma unroll
     for (int j = 0; j < F64Shape<N>::N4; ++j) {
         const int s = F64Shape<N>::span(j), k = bb & (s - 1), ts = N / (4 * s);
@@ -112,7 +142,7 @@ template <int N> __device__ __forceinline__ TwRegs64<N> load_tw64(const double2*
 }
 
 // the three twiddles of butterfly position bb at span S, fetched from the (L1-resident) table
-template <int N, int S> __device__ __forceinline__ void stage_tw_fetch(const double2* __restrict__ g_tw, int bb, double2 (&w)[3]) {
+template <typename T, int N, int S> __device__ __forceinline__ void stage_tw_fetch(const cx<T>* __restrict__ g_tw, int bb, cx<T> (&w)[3]) {
     constexpr int ts = N / (4 * S);
     const int k = bb & (S - 1);
     w[0] = g_tw[k * ts];
@@ -124,15 +154,15 @@ template <int N, int S> __device__ __forceinline__ void stage_tw_fetch(const dou
 // DIF (INV: the transmit IFFT): butterfly, then twiddle; DIT (forward FFT): twiddle, then butterfly.
 // pre: twiddles fetched ahead by the caller (forward transform: a DIT stage multiplies FIRST, so a fetch issued inside
 // the stage sits on its critical path; issued one stage early it hides behind that stage's butterflies)
-template <int N, bool DIF, bool INV, int S, int AH, bool TWR, bool NOSTORE = false>
-__device__ __forceinline__ void r4_stage_planar(double* s_d, const TwRegs64<N>& tw, const double2* __restrict__ g_tw, int bb,
-                                                const double2* pre = nullptr) {
+template <typename T, int N, bool DIF, bool INV, int S, int AH, bool TWR, bool NOSTORE = false>
+__device__ __forceinline__ void r4_stage_planar(T* s_d, const TwRegs64<T, N>& tw, const cx<T>* __restrict__ g_tw, int bb,
+                                                const cx<T>* pre = nullptr) {
     constexpr int s = S;
     const int k = bb & (s - 1), g = bb / s;
     const int e0 = g * 4 * s + k;
     int i0, i1, i2, i3;
     lds_swz_r4<true>(e0, s, i0, i1, i2, i3);           // one swizzle + three XORs with per-stage constants (fft.hpp)
-    double2 w1 = mk<double>(1, 0), w2 = w1, w3 = w1;
+    cx<T> w1 = mk<T>(1, 0), w2 = w1, w3 = w1;
     if (s > 1) {
         if constexpr (TWR) {                          // the thread's twiddles are registers
             constexpr int j = (FftShape<N>::LOG2 - FftShape<4 * S>::LOG2) / 2;     // DIF stage index of span S
@@ -149,42 +179,37 @@ __device__ __forceinline__ void r4_stage_planar(double* s_d, const TwRegs64<N>& 
             w2 = g_tw[2 * k * ts];
             w3 = g_tw[3 * k * ts];
         }
-        if (INV) {
-            w1.y = -w1.y;
-            w2.y = -w2.y;
-            w3.y = -w3.y;
-        }
     }
-    double xr[AH][4], xi[AH][4];
+    T xr[AH][4], xi[AH][4];
 #pragma unroll
     for (int a = 0; a < AH; ++a) {
-        const double* pr = s_d + (2 * a) * N;
-        const double* pi = pr + N;
+        const T* pr = s_d + (2 * a) * N;
+        const T* pi = pr + N;
         xr[a][0] = pr[i0]; xr[a][1] = pr[i1]; xr[a][2] = pr[i2]; xr[a][3] = pr[i3];
         xi[a][0] = pi[i0]; xi[a][1] = pi[i1]; xi[a][2] = pi[i2]; xi[a][3] = pi[i3];
     }
 #pragma unroll
     for (int a = 0; a < AH; ++a) {
-        double2 u0 = mk<double>(xr[a][0], xi[a][0]), u1 = mk<double>(xr[a][1], xi[a][1]),
-                u2 = mk<double>(xr[a][2], xi[a][2]), u3 = mk<double>(xr[a][3], xi[a][3]);
+        cx<T> u0 = mk<T>(xr[a][0], xi[a][0]), u1 = mk<T>(xr[a][1], xi[a][1]),
+                u2 = mk<T>(xr[a][2], xi[a][2]), u3 = mk<T>(xr[a][3], xi[a][3]);
         if (!DIF && s > 1) {
-            u1 = cmul(u1, w1);
-            u2 = cmul(u2, w2);
-            u3 = cmul(u3, w3);
+            u1 = CxOps<T>::template mulw<INV>(u1, w1);
+            u2 = CxOps<T>::template mulw<INV>(u2, w2);
+            u3 = CxOps<T>::template mulw<INV>(u3, w3);
         }
-        const double2 a0 = cadd(u0, u2), a1 = csub(u0, u2), a2 = cadd(u1, u3), a3 = rot<double, INV>(csub(u1, u3));
-        double2 y0 = cadd(a0, a2), y1 = cadd(a1, a3), y2 = csub(a0, a2), y3 = csub(a1, a3);
+        cx<T> y0, y1, y2, y3;
+        CxOps<T>::template bfly4<INV>(u0, u1, u2, u3, y0, y1, y2, y3);
         if (DIF && s > 1) {
-            y1 = cmul(y1, w1);
-            y2 = cmul(y2, w2);
-            y3 = cmul(y3, w3);
+            y1 = CxOps<T>::template mulw<INV>(y1, w1);
+            y2 = CxOps<T>::template mulw<INV>(y2, w2);
+            y3 = CxOps<T>::template mulw<INV>(y3, w3);
         }
         if constexpr (NOSTORE) {                      // timing bound only (MCLE_OPT_F64_VARIANT): computed, not stored
             asm volatile("" ::"v"(y0.x), "v"(y0.y), "v"(y1.x), "v"(y1.y), "v"(y2.x), "v"(y2.y), "v"(y3.x), "v"(y3.y));
             continue;
         }
-        double* pr = s_d + (2 * a) * N;
-        double* pi = pr + N;
+        T* pr = s_d + (2 * a) * N;
+        T* pi = pr + N;
         pr[i0] = y0.x; pr[i1] = y1.x; pr[i2] = y2.x; pr[i3] = y3.x;
         pi[i0] = y0.y; pi[i1] = y1.y; pi[i2] = y2.y; pi[i3] = y3.y;
     }
@@ -194,15 +219,15 @@ __device__ __forceinline__ void r4_stage_planar(double* s_d, const TwRegs64<N>& 
 // bb takes the two pairs inside ITS four consecutive positions 4 bb .. 4 bb + 3 -- the access pattern of the span-1
 // radix-4 stage, and the points the lane pair (bb, bb ^ 1) exchanged in the span-2 stage next to it, so that the stage
 // is ordered against its neighbour by the wavefront's own in-order LDS traffic (no workgroup barrier).
-template <int N, int AH> __device__ __forceinline__ void r2_stage_planar(double* s_d, int bb) {
+template <typename T, int N, int AH> __device__ __forceinline__ void r2_stage_planar(T* s_d, int bb) {
     int i0, i1, i2, i3;
     lds_swz_r4<true>(4 * bb, 1, i0, i1, i2, i3);
 #pragma unroll
     for (int a = 0; a < AH; ++a) {
-        double* pr = s_d + (2 * a) * N;
-        double* pi = pr + N;
-        const double r0 = pr[i0], r1 = pr[i1], r2 = pr[i2], r3 = pr[i3];
-        const double m0 = pi[i0], m1 = pi[i1], m2 = pi[i2], m3 = pi[i3];
+        T* pr = s_d + (2 * a) * N;
+        T* pi = pr + N;
+        const T r0 = pr[i0], r1 = pr[i1], r2 = pr[i2], r3 = pr[i3];
+        const T m0 = pi[i0], m1 = pi[i1], m2 = pi[i2], m3 = pi[i3];
         pr[i0] = r0 + r1; pr[i1] = r0 - r1; pr[i2] = r2 + r3; pr[i3] = r2 - r3;
         pi[i0] = m0 + m1; pi[i1] = m0 - m1; pi[i2] = m2 + m3; pi[i3] = m2 - m3;
     }
@@ -232,12 +257,24 @@ __device__ __forceinline__ void swap32_pair(double a, double b, double& x, doubl
     x = __hiloint2double((int)hi[0], (int)lo[0]);
     y = __hiloint2double((int)hi[1], (int)lo[1]);
 }
+__device__ __forceinline__ void swap32_pair(float a, float b, float& x, float& y) {
+    const auto v = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    x = __uint_as_float(v[0]);
+    y = __uint_as_float(v[1]);
+}
 
-struct R16Tw64 {
-    double2 a1[3], a2[3], b1[3], b2[3];     // w^(k m), w^(4 k q) | w^(16 k4 m), w^(64 k4 q);  m, q = 1..3; k = lane, k4 = lane mod 4
+// one CN(0, sigma^2) sample from two Philox words: complex128 through the LDS Box-Muller tables, complex64 by the hardware
+// transcendentals (the complex64 kernels' draw)
+__device__ __forceinline__ double2 cn_words(uint32_t x0, uint32_t x1, double sigma, const double* s_bm) {
+    return cn_from_words_lds(x0, x1, sigma, s_bm);
+}
+__device__ __forceinline__ float2 cn_words(uint32_t x0, uint32_t x1, float sigma, const double*) { return cn_from_words(x0, x1, sigma); }
+
+template <typename T> struct R16Tw64 {
+    cx<T> a1[3], a2[3], b1[3], b2[3];     // w^(k m), w^(4 k q) | w^(16 k4 m), w^(64 k4 q);  m, q = 1..3; k = lane, k4 = lane mod 4
 };
-__device__ __forceinline__ R16Tw64 load_r16_tw(const double2* __restrict__ g_tw, int lane) {
-    R16Tw64 r;
+template <typename T> __device__ __forceinline__ R16Tw64<T> load_r16_tw(const cx<T>* __restrict__ g_tw, int lane) {
+    R16Tw64<T> r;
     const int k = lane & 63, k4 = k & 3;
 #pragma unroll
     for (int j = 1; j <= 3; ++j) {
@@ -248,27 +285,19 @@ __device__ __forceinline__ R16Tw64 load_r16_tw(const double2* __restrict__ g_tw,
     }
     return r;
 }
-template <bool INV> __device__ __forceinline__ double2 r16_tw(double2 w) {
-    if (INV) w.y = -w.y;
-    return w;
-}
 // v times exp(-2 pi i n / 16) (forward) or its conjugate (inverse), n = q m in {0, 1, 2, 3, 4, 6, 9}
-template <bool INV, int NN> __device__ __forceinline__ double2 r16_root(double2 v) {
+template <typename T, bool INV, int NN> __device__ __forceinline__ cx<T> r16_root(cx<T> v) {
     constexpr double c1 = 0.92387953251128675613, s1 = 0.38268343236508977173, h = 0.70710678118654752440;
     if constexpr (NN == 0) return v;
-    else if constexpr (NN == 4) return rot<double, INV>(v);
+    else if constexpr (NN == 4) return rot<T, INV>(v);
     else {
         constexpr double re = NN == 1 ? c1 : NN == 2 ? h : NN == 3 ? s1 : NN == 6 ? -h : -c1;
         constexpr double im = NN == 1 ? -s1 : NN == 2 ? -h : NN == 3 ? -c1 : NN == 6 ? -h : s1;
-        return cmul(v, mk<double>(re, INV ? -im : im));
+        return CxOps<T>::template mulw<false>(v, mk<T>((T)re, (T)(INV ? -im : im)));
     }
 }
-template <bool INV> __device__ __forceinline__ void r4_inplace(double2& x0, double2& x1, double2& x2, double2& x3) {
-    const double2 a0 = cadd(x0, x2), a1 = csub(x0, x2), a2 = cadd(x1, x3), a3 = rot<double, INV>(csub(x1, x3));
-    x0 = cadd(a0, a2);
-    x1 = cadd(a1, a3);
-    x2 = csub(a0, a2);
-    x3 = csub(a1, a3);
+template <typename T, bool INV> __device__ __forceinline__ void r4_inplace(cx<T>& x0, cx<T>& x1, cx<T>& x2, cx<T>& x3) {
+    CxOps<T>::template bfly4<INV>(x0, x1, x2, x3, x0, x1, x2, x3);
 }
 __device__ __forceinline__ void r16_wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -280,13 +309,23 @@ __device__ __forceinline__ void r16_wave_sync() {
 // EXACT: the nine layer-1 twiddles of q >= 1, w^((k + 64 q) m) / w^(16 (k4 + 4 q) m), fetched from the (L1-resident) table at the
 // top of the pass instead of formed as register twiddle x constant 16th root: eight complex multiplications less per pass, and
 // the pass becomes the radix-4 stages' arithmetic operation for operation (bit-identical outputs).
-template <bool INV, bool DIT, int WHICH, bool EXACT = false>
-__device__ __forceinline__ void r16_pass(double* pr, double* pi, int base_slot, const R16Tw64& tw,
-                                         const double2* __restrict__ g_tw = nullptr, int kidx = 0) {
+// OWNTW: the pass fetches its six twiddles itself (L1-resident table) instead of taking them from `tw` -- twelve register pairs
+// less to carry through a transform where the register bound is tight (complex64 at four wavefronts per SIMD).
+template <typename T, bool INV, bool DIT, int WHICH, bool EXACT = false, bool OWNTW = false>
+__device__ __forceinline__ void r16_pass(T* pr, T* pi, int base_slot, const R16Tw64<T>& tw,
+                                         const cx<T>* __restrict__ g_tw = nullptr, int kidx = 0) {
     constexpr int QS = WHICH == 0 ? 64 : 4, MS = WHICH == 0 ? 256 : 16;
-    const double2* t1 = WHICH == 0 ? tw.a1 : tw.b1;
-    const double2* t2 = WHICH == 0 ? tw.a2 : tw.b2;
-    [[maybe_unused]] double2 tq[3][3];                      // [q - 1][m - 1]
+    cx<T> own1[3], own2[3];
+    if constexpr (OWNTW) {
+#pragma unroll
+        for (int j = 1; j <= 3; ++j) {
+            own1[j - 1] = g_tw[(WHICH == 0 ? kidx : 16 * kidx) * j];
+            own2[j - 1] = g_tw[(WHICH == 0 ? 4 * kidx : 64 * kidx) * j];
+        }
+    }
+    const cx<T>* t1 = OWNTW ? own1 : WHICH == 0 ? tw.a1 : tw.b1;
+    const cx<T>* t2 = OWNTW ? own2 : WHICH == 0 ? tw.a2 : tw.b2;
+    [[maybe_unused]] cx<T> tq[3][3];                      // [q - 1][m - 1]
     if constexpr (EXACT) {
 #pragma unroll
         for (int q = 1; q < 4; ++q)
@@ -294,58 +333,58 @@ __device__ __forceinline__ void r16_pass(double* pr, double* pi, int base_slot, 
             for (int m = 1; m < 4; ++m)
                 tq[q - 1][m - 1] = g_tw[(WHICH == 0 ? (kidx + 64 * q) * m : 16 * (kidx + 4 * q) * m) & 1023];
     }
-    auto tw1 = [&](auto qc, auto mc) -> double2 {           // layer-1 twiddle of (q, m), m >= 1, conjugated for the inverse
+    auto tw1 = [&](auto qc, auto mc) -> cx<T> {           // layer-1 twiddle of (q, m), m >= 1 (mulw conjugates it for the inverse)
         constexpr int q = decltype(qc)::value, m = decltype(mc)::value;
-        if constexpr (EXACT && q > 0) return r16_tw<INV>(tq[q - 1][m - 1]);
-        else return r16_tw<INV>(t1[m - 1]);
+        if constexpr (EXACT && q > 0) return tq[q - 1][m - 1];
+        else return t1[m - 1];
     };
-    double2 v[4][4];
+    cx<T> v[4][4];
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int sl = base_slot ^ lds_swz16f(QS * q + MS * m);      // base and offsets occupy disjoint bits: XOR == add
-            v[m][q] = mk<double>(pr[sl], pi[sl]);
+            v[m][q] = mk<T>(pr[sl], pi[sl]);
         }
     if constexpr (!DIT) {
         static_for<4>([&](auto qc) {
             constexpr int q = decltype(qc)::value;
-            r4_inplace<INV>(v[0][q], v[1][q], v[2][q], v[3][q]);
+            r4_inplace<T, INV>(v[0][q], v[1][q], v[2][q], v[3][q]);
             if constexpr (EXACT) {
-                v[1][q] = cmul(v[1][q], tw1(qc, std::integral_constant<int, 1>()));
-                v[2][q] = cmul(v[2][q], tw1(qc, std::integral_constant<int, 2>()));
-                v[3][q] = cmul(v[3][q], tw1(qc, std::integral_constant<int, 3>()));
+                v[1][q] = CxOps<T>::template mulw<INV>(v[1][q], tw1(qc, std::integral_constant<int, 1>()));
+                v[2][q] = CxOps<T>::template mulw<INV>(v[2][q], tw1(qc, std::integral_constant<int, 2>()));
+                v[3][q] = CxOps<T>::template mulw<INV>(v[3][q], tw1(qc, std::integral_constant<int, 3>()));
             } else {
-                v[1][q] = r16_root<INV, q * 1>(cmul(v[1][q], r16_tw<INV>(t1[0])));
-                v[2][q] = r16_root<INV, q * 2>(cmul(v[2][q], r16_tw<INV>(t1[1])));
-                v[3][q] = r16_root<INV, q * 3>(cmul(v[3][q], r16_tw<INV>(t1[2])));
+                v[1][q] = r16_root<T, INV, q * 1>(CxOps<T>::template mulw<INV>(v[1][q], t1[0]));
+                v[2][q] = r16_root<T, INV, q * 2>(CxOps<T>::template mulw<INV>(v[2][q], t1[1]));
+                v[3][q] = r16_root<T, INV, q * 3>(CxOps<T>::template mulw<INV>(v[3][q], t1[2]));
             }
         });
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
-            r4_inplace<INV>(v[m][0], v[m][1], v[m][2], v[m][3]);
+            r4_inplace<T, INV>(v[m][0], v[m][1], v[m][2], v[m][3]);
 #pragma unroll
-            for (int q = 1; q < 4; ++q) v[m][q] = cmul(v[m][q], r16_tw<INV>(t2[q - 1]));
+            for (int q = 1; q < 4; ++q) v[m][q] = CxOps<T>::template mulw<INV>(v[m][q], t2[q - 1]);
         }
     } else {
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
 #pragma unroll
-            for (int q = 1; q < 4; ++q) v[m][q] = cmul(v[m][q], r16_tw<INV>(t2[q - 1]));
-            r4_inplace<INV>(v[m][0], v[m][1], v[m][2], v[m][3]);
+            for (int q = 1; q < 4; ++q) v[m][q] = CxOps<T>::template mulw<INV>(v[m][q], t2[q - 1]);
+            r4_inplace<T, INV>(v[m][0], v[m][1], v[m][2], v[m][3]);
         }
         static_for<4>([&](auto qc) {
             constexpr int q = decltype(qc)::value;
             if constexpr (EXACT) {
-                v[1][q] = cmul(v[1][q], tw1(qc, std::integral_constant<int, 1>()));
-                v[2][q] = cmul(v[2][q], tw1(qc, std::integral_constant<int, 2>()));
-                v[3][q] = cmul(v[3][q], tw1(qc, std::integral_constant<int, 3>()));
+                v[1][q] = CxOps<T>::template mulw<INV>(v[1][q], tw1(qc, std::integral_constant<int, 1>()));
+                v[2][q] = CxOps<T>::template mulw<INV>(v[2][q], tw1(qc, std::integral_constant<int, 2>()));
+                v[3][q] = CxOps<T>::template mulw<INV>(v[3][q], tw1(qc, std::integral_constant<int, 3>()));
             } else {
-                v[1][q] = r16_root<INV, q * 1>(cmul(v[1][q], r16_tw<INV>(t1[0])));
-                v[2][q] = r16_root<INV, q * 2>(cmul(v[2][q], r16_tw<INV>(t1[1])));
-                v[3][q] = r16_root<INV, q * 3>(cmul(v[3][q], r16_tw<INV>(t1[2])));
+                v[1][q] = r16_root<T, INV, q * 1>(CxOps<T>::template mulw<INV>(v[1][q], t1[0]));
+                v[2][q] = r16_root<T, INV, q * 2>(CxOps<T>::template mulw<INV>(v[2][q], t1[1]));
+                v[3][q] = r16_root<T, INV, q * 3>(CxOps<T>::template mulw<INV>(v[3][q], t1[2]));
             }
-            r4_inplace<INV>(v[0][q], v[1][q], v[2][q], v[3][q]);
+            r4_inplace<T, INV>(v[0][q], v[1][q], v[2][q], v[3][q]);
         });
     }
 #pragma unroll
@@ -358,19 +397,19 @@ __device__ __forceinline__ void r16_pass(double* pr, double* pi, int base_slot, 
         }
 }
 // pass C: the four span-1 butterflies of elements 16 gi + 4 c + m (no twiddles; DIF and DIT share the add / sub network)
-template <bool INV> __device__ __forceinline__ void r16_pass_c(double* pr, double* pi, int gi) {
+template <typename T, bool INV> __device__ __forceinline__ void r16_pass_c(T* pr, T* pi, int gi) {
     const int base_slot = lds_swz16f(16 * gi);
-    double2 v[4][4];
+    cx<T> v[4][4];
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             const int sl = base_slot ^ lds_swz16f(4 * c + m);
-            v[c][m] = mk<double>(pr[sl], pi[sl]);
+            v[c][m] = mk<T>(pr[sl], pi[sl]);
         }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        r4_inplace<INV>(v[c][0], v[c][1], v[c][2], v[c][3]);
+        r4_inplace<T, INV>(v[c][0], v[c][1], v[c][2], v[c][3]);
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             const int sl = base_slot ^ lds_swz16f(4 * c + m);
@@ -380,29 +419,29 @@ template <bool INV> __device__ __forceinline__ void r16_pass_c(double* pr, doubl
     }
 }
 // natural -> digit-reversed (the arrangement of the radix-4 DIF stages) / digit-reversed -> natural; one wavefront, one antenna
-template <bool INV, bool WITH_C = true, bool EXACT = false>
-__device__ __forceinline__ void r16_dif(double* pr, double* pi, int lane, const R16Tw64& tw, const double2* __restrict__ g_tw = nullptr) {
+template <typename T, bool INV, bool WITH_C = true, bool EXACT = false, bool OWNTW = false>
+__device__ __forceinline__ void r16_dif(T* pr, T* pi, int lane, const R16Tw64<T>& tw, const cx<T>* __restrict__ g_tw = nullptr) {
     int gi = opaque(lane);
-    r16_pass<INV, false, 0, EXACT>(pr, pi, lds_swz16f(gi), tw, g_tw, gi);
+    r16_pass<T, INV, false, 0, EXACT, OWNTW>(pr, pi, lds_swz16f(gi), tw, g_tw, gi);
     r16_wave_sync();
     gi = opaque(lane);
-    r16_pass<INV, false, 1, EXACT>(pr, pi, lds_swz16f(64 * (gi >> 2) + (gi & 3)), tw, g_tw, gi & 3);
+    r16_pass<T, INV, false, 1, EXACT, OWNTW>(pr, pi, lds_swz16f(64 * (gi >> 2) + (gi & 3)), tw, g_tw, gi & 3);
     if constexpr (WITH_C) {
         r16_wave_sync();
-        r16_pass_c<INV>(pr, pi, opaque(lane));
+        r16_pass_c<T, INV>(pr, pi, opaque(lane));
     }
 }
-template <bool INV, bool WITH_C = true, bool EXACT = false>
-__device__ __forceinline__ void r16_dit(double* pr, double* pi, int lane, const R16Tw64& tw, const double2* __restrict__ g_tw = nullptr) {
+template <typename T, bool INV, bool WITH_C = true, bool EXACT = false, bool OWNTW = false>
+__device__ __forceinline__ void r16_dit(T* pr, T* pi, int lane, const R16Tw64<T>& tw, const cx<T>* __restrict__ g_tw = nullptr) {
     if constexpr (WITH_C) {
-        r16_pass_c<INV>(pr, pi, opaque(lane));
+        r16_pass_c<T, INV>(pr, pi, opaque(lane));
         r16_wave_sync();
     }
     int gi = opaque(lane);
-    r16_pass<INV, true, 1, EXACT>(pr, pi, lds_swz16f(64 * (gi >> 2) + (gi & 3)), tw, g_tw, gi & 3);
+    r16_pass<T, INV, true, 1, EXACT, OWNTW>(pr, pi, lds_swz16f(64 * (gi >> 2) + (gi & 3)), tw, g_tw, gi & 3);
     r16_wave_sync();
     gi = opaque(lane);
-    r16_pass<INV, true, 0, EXACT>(pr, pi, lds_swz16f(gi), tw, g_tw, gi);
+    r16_pass<T, INV, true, 0, EXACT, OWNTW>(pr, pi, lds_swz16f(gi), tw, g_tw, gi);
 }
 
 // N, NT x NR: the geometry.  AH = antennas per thread in the transform stages, TB = (N / 4) (NR / AH) threads per
@@ -414,11 +453,11 @@ __device__ __forceinline__ void r16_dit(double* pr, double* pi, int lane, const 
 // stage into its neighbouring transform stages could save at most, DESIGN.md 5.5: bit 0 = the stores of the last transmit
 // stage and of the channel stage dropped, bit 1 = the two workgroup barriers around the channel stage dropped.
 // 4 = the radix-16 transforms above (256 threads, one transform per wavefront): correct results, same contract.
-template <int N, int NT, int NR, int AH, int WPS, int VAR = 0>
-__global__ __launch_bounds__((N / 4) * (NR / AH), WPS) void k_run_mimo_ofdm_f64(MimoParams pp, ModemParams<double> mp, uint64_t seed,
+template <typename T, int N, int NT, int NR, int AH, int WPS, int VAR = 0>
+__global__ __launch_bounds__((N / 4) * (NR / AH), WPS) void k_run_mimo_ofdm_planar(MimoParams pp, ModemParams<T> mp, uint64_t seed,
                                                                      uint64_t first, uint64_t count,
-                                                                     const double2* __restrict__ g_tw,
-                                                                     const double2* __restrict__ g_recs,
+                                                                     const cx<T>* __restrict__ g_tw,
+                                                                     const cx<T>* __restrict__ g_recs,
                                                                      mcle_counters* counters,
                                                                      uint32_t* __restrict__ sym_out,
                                                                      uint32_t* __restrict__ bit_out) {
@@ -429,51 +468,54 @@ __global__ __launch_bounds__((N / 4) * (NR / AH), WPS) void k_run_mimo_ofdm_f64(
     constexpr bool R16 = (VAR & 4) != 0;                                    // radix-16 passes, one transform per wavefront
     constexpr bool FUSED = R16 && (VAR & 8) != 0;                           // ... with pass C, the channel and pass C' as one stage
     constexpr bool EXACT = R16 && (VAR & 16) != 0;                          // ... with every layer-1 twiddle from the table
+    constexpr bool OWNTW = R16 && (VAR & 32) != 0;                          // ... with each pass fetching its own six twiddles
     static_assert(!R16 || (N == 1024 && NR == 4 && AH == 4), "radix-16 variant: 1024, four receive antennas, 256 threads");
     constexpr bool TWR = AH == NR && N == 1024 && !R16;                     // a thread's twiddles in registers
     auto swz = [](int e) { return R16 ? lds_swz16f(e) : lds_swz64(e); };
     static_assert(TB % 64 == 0 && TB <= 1024 && TB >= kRec && NW <= 16, "workgroup");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    double* s_d = reinterpret_cast<double*>(smem);                          // [NR][re plane | im plane][N]
-    double2* s_table = reinterpret_cast<double2*>(s_d + 2 * NR * N);        // [tab_len] constellation
-    double2* s_txtab = s_table + ((mp.M + 1) & ~1);                         // [tab_len] constellation x tx scale
-    double2* s_rec = s_txtab + ((mp.M + 1) & ~1);                           // [2][kRec + 1]
+    T* s_d = reinterpret_cast<T*>(smem);                          // [NR][re plane | im plane][N]
+    cx<T>* s_table = reinterpret_cast<cx<T>*>(s_d + 2 * NR * N);        // [tab_len] constellation
+    cx<T>* s_txtab = s_table + ((mp.M + 1) & ~1);                         // [tab_len] constellation x tx scale
+    cx<T>* s_rec = s_txtab + ((mp.M + 1) & ~1);                           // [2][kRec + 1]
     unsigned* s_part = reinterpret_cast<unsigned*>(s_rec + 2 * (kRec + 1)); // [2][16 waves][2]
-    double* s_bm = reinterpret_cast<double*>(s_part + 64);                  // [kBmLdsDoubles (+1)] Box-Muller tables
-    unsigned long long* s_grid = reinterpret_cast<unsigned long long*>(s_bm + ((kBmLdsDoubles + 1) & ~1));
+    constexpr int kBm = std::is_same<T, double>::value ? ((kBmLdsDoubles + 1) & ~1) : 0;
+    double* s_bm = reinterpret_cast<double*>(s_part + 64);        // [kBm] Box-Muller tables (complex128)
+    unsigned long long* s_grid = reinterpret_cast<unsigned long long*>(s_bm + kBm);
     unsigned char* s_idx = reinterpret_cast<unsigned char*>(s_grid + mp.grid.G * mp.grid.G);   // [NT * num_used]
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int U = pp.num_used, cp = pp.cp;
     const int per_sym = U * NT;
     const uint64_t row = (uint64_t)pp.n_ofdm_sym * (N + cp);
-    const double sigma = sqrt(pp.noise_var);
-    const double tx_scale = 1.0 / sqrt((double)NT) / sqrt((double)(U + cp));
+    const T sigma = (T)sqrt(pp.noise_var);
+    const T tx_scale = (T)(1.0 / sqrt((double)NT) / sqrt((double)(U + cp)));
     const uint32_t mask = (uint32_t)(mp.M - 1);
     for (int m = tid; m < mp.M; m += TB) {
-        const double2 c = mp.g_table[m];
+        const cx<T> c = mp.g_table[m];
         s_table[m] = c;
         s_txtab[m] = cscale(c, tx_scale);
     }
     load_grid(mp, s_grid);
-    bm_tables_to_lds(s_bm, tid, TB);
+    if constexpr (kBm != 0) bm_tables_to_lds(s_bm, tid, TB);
     __shared__ WgTotals totals;
     if (tid == 0) wg_zero(totals);
 
     const int bbt = tid & (NB - 1);                               // this thread's butterfly position
     const int grp = tid / NB;                                     // ... of antennas AH grp .. AH grp + AH - 1
-    double* s_mine = s_d + grp * (2 * AH * N);
+    T* s_mine = s_d + grp * (2 * AH * N);
     const bool tx_grp = NT == NR || grp * AH < NT;                // wave-uniform: does this group transmit?
-    TwRegs64<N> twr;
-    if constexpr (TWR) twr = load_tw64<N>(g_tw, bbt);
-    [[maybe_unused]] R16Tw64 tw16;
-    if constexpr (R16 && !FUSED) tw16 = load_r16_tw(g_tw, lane);     // fused form: fetched at the top of each transform instead (48 registers)
-    [[maybe_unused]] double* s_wave_re = s_d + (2 * w) * N;      // variant 4: wavefront w owns antenna w's transform
-    [[maybe_unused]] double* s_wave_im = s_wave_re + N;
+    TwRegs64<T, N> twr;
+    if constexpr (TWR) twr = load_tw64<T, N>(g_tw, bbt);
+    [[maybe_unused]] R16Tw64<T> tw16;
+    constexpr bool TW16_RELOAD = (FUSED || sizeof(T) == 4) && !OWNTW;               // fetched at the top of each transform instead (24 register pairs
+    if constexpr (R16 && !TW16_RELOAD && !OWNTW) tw16 = load_r16_tw<T>(g_tw, lane);     // that the channel and the decode do not have to carry)
+    [[maybe_unused]] T* s_wave_re = s_d + (2 * w) * N;      // variant 4: wavefront w owns antenna w's transform
+    [[maybe_unused]] T* s_wave_im = s_wave_re + N;
     uint64_t it = 0, rl_prev = 0;
     // the record of a realization is fetched one iteration ahead (one register pair per lane of the first wavefront):
     // loaded where it is parked, the global-memory latency sat in front of every realization's first barrier
-    double2 rec_next = mk<double>(0, 0);
+    cx<T> rec_next = mk<T>(0, 0);
     if (tid < kRec && blockIdx.x < count) rec_next = g_recs[(uint64_t)blockIdx.x * kRec + tid];
     __syncthreads();
     for (uint64_t rl = blockIdx.x; rl < count; rl += gridDim.x, ++it) {
@@ -485,8 +527,8 @@ __global__ __launch_bounds__((N / 4) * (NR / AH), WPS) void k_run_mimo_ofdm_f64(
             s_rec[buf * (kRec + 1) + tid] = rec_next;
             if (rl + gridDim.x < count) rec_next = g_recs[(rl + gridDim.x) * kRec + tid];
         }
-        const double2* s_H = s_rec + buf * (kRec + 1);            // [NR][NT]
-        const double2* s_G = s_H + NT * NR;                       // [NT][NR]
+        const cx<T>* s_H = s_rec + buf * (kRec + 1);            // [NR][NT]
+        const cx<T>* s_G = s_H + NT * NR;                       // [NT][NR]
         unsigned se = 0, be = 0;
         for (int os = 0; os < pp.n_ofdm_sym; ++os) {
             // ---- transmit: symbols -> bins (Blast.encode's F-order split + OFDM subcarrier map) ----
@@ -511,7 +553,7 @@ __global__ __launch_bounds__((N / 4) * (NR / AH), WPS) void k_run_mimo_ofdm_f64(
 #pragma unroll
                     for (int j = 0; j < 16; ++j) {
                         const int tx = (int)((dw.w[j >> 2] >> ((j & 3) * 8)) & mask);
-                        const double2 c = s_txtab[tx];
+                        const cx<T> c = s_txtab[tx];
                         const int pos = pos0 ^ (j / NT);          // antenna j mod NT of subcarrier d0 + j / NT
                         s_d[(2 * (j % NT)) * N + pos] = c.x;
                         s_d[(2 * (j % NT) + 1) * N + pos] = c.y;
@@ -526,7 +568,7 @@ __global__ __launch_bounds__((N / 4) * (NR / AH), WPS) void k_run_mimo_ofdm_f64(
                         const int nl = (int)(n - n_first);
                         const int a = nl % NT, d = nl / NT;
                         s_idx[nl] = (unsigned char)tx;
-                        const double2 c = s_txtab[tx];
+                        const cx<T> c = s_txtab[tx];
                         const int pos = swz(ofdm_bin(d, N, U));
                         s_d[(2 * a) * N + pos] = c.x;
                         s_d[(2 * a + 1) * N + pos] = c.y;
@@ -548,20 +590,20 @@ __global__ __launch_bounds__((N / 4) * (NR / AH), WPS) void k_run_mimo_ofdm_f64(
             //      its twiddle fetch hides behind its own butterflies -- fetching a stage ahead as the forward transform does
             //      measured no gain).  Antenna groups beyond Nt have nothing to send and only keep the barriers. ----
             if constexpr (R16) {
-                if constexpr (FUSED) tw16 = load_r16_tw(g_tw, opaque(lane));
-                if (NT == NR || w < NT) r16_dif<true, !FUSED, EXACT>(s_wave_re, s_wave_im, lane, tw16, g_tw);   // wavefront = antenna
+                if constexpr (TW16_RELOAD) tw16 = load_r16_tw<T>(g_tw, opaque(lane));
+                if (NT == NR || w < NT) r16_dif<T, true, !FUSED, EXACT, OWNTW>(s_wave_re, s_wave_im, lane, tw16, g_tw);   // wavefront = antenna
                 __syncthreads();
             } else
             static_for<N4>([&](auto stc) {
                 constexpr int st = decltype(stc)::value, S = SH::span(st);
-                if (tx_grp) r4_stage_planar<N, true, true, S, AH, TWR, (VAR & 1) && st + 1 == N4 && !SH::HAS2>(s_mine, twr, g_tw, opaque(bbt));
+                if (tx_grp) r4_stage_planar<T, N, true, true, S, AH, TWR, (VAR & 1) && st + 1 == N4 && !SH::HAS2>(s_mine, twr, g_tw, opaque(bbt));
                 if constexpr (st + 1 < N4 || SH::HAS2)
                     fft_stage_sync<TB>(S);             // wave-local once the 4 S points of a group sit in one wavefront
                 else if constexpr (!(VAR & 2))
                     __syncthreads();
             });
             if constexpr (SH::HAS2) {
-                if (tx_grp) r2_stage_planar<N, AH>(s_mine, opaque(bbt));
+                if (tx_grp) r2_stage_planar<T, N, AH>(s_mine, opaque(bbt));
                 __syncthreads();
             }
             // ---- channel: R = H T + noise on the samples that survive CP removal ----
@@ -576,23 +618,23 @@ __global__ __launch_bounds__((N / 4) * (NR / AH), WPS) void k_run_mimo_ofdm_f64(
                 const int h = (ln >> 5) & 1;
                 const int g = (ln & 15) | (w << 4) | (h << 6) | (((ln >> 4) & 1) << 7);
                 const int base_slot = swz(4 * g);                              // position 4 g + d sits at base_slot ^ d
-                double2 x[NT][4];
+                cx<T> x[NT][4];
 #pragma unroll
                 for (int a = 0; a < NT; ++a)
 #pragma unroll
                     for (int d = 0; d < 4; ++d)
-                        x[a][d] = mk<double>(s_d[(2 * a) * N + (base_slot ^ d)], s_d[(2 * a + 1) * N + (base_slot ^ d)]);
+                        x[a][d] = mk<T>(s_d[(2 * a) * N + (base_slot ^ d)], s_d[(2 * a + 1) * N + (base_slot ^ d)]);
 #pragma unroll
-                for (int a = 0; a < NT; ++a) r4_inplace<true>(x[a][0], x[a][1], x[a][2], x[a][3]);
+                for (int a = 0; a < NT; ++a) r4_inplace<T, true>(x[a][0], x[a][1], x[a][2], x[a][3]);
                 const int mb = fft_index_of_pos<N>(4 * g);
                 const bool paired = (cp & 1) == 0;                             // every row's first kept sample on a block boundary
-                double2 y[NR][4];
-                auto mix = [&](int d, const double2 (&nz)[NR]) {               // y[.][d] = noise + H x[.][d]
+                cx<T> y[NR][4];
+                auto mix = [&](int d, const cx<T> (&nz)[NR]) {               // y[.][d] = noise + H x[.][d]
 #pragma unroll
                     for (int r = 0; r < NR; ++r) {
-                        double2 z = nz[r];
+                        cx<T> z = nz[r];
 #pragma unroll
-                        for (int a = 0; a < NT; ++a) z = cfma(s_H[r * NT + a], x[a][d], z);
+                        for (int a = 0; a < NT; ++a) z = CxOps<T>::fma(s_H[r * NT + a], x[a][d], z);
                         y[r][d] = z;
                     }
                 };
@@ -600,13 +642,13 @@ __global__ __launch_bounds__((N / 4) * (NR / AH), WPS) void k_run_mimo_ofdm_f64(
                     static_for<4>([&](auto dc) {
                         constexpr int d = decltype(dc)::value;
                         __builtin_amdgcn_sched_barrier(0);                     // one position at a time: its four inputs die as its
-                        double2 nz[NR];                                        // four outputs are born
+                        cx<T> nz[NR];                                        // four outputs are born
 #pragma unroll
                         for (int rr = 0; rr < NR / 2; ++rr) {
                             const uint64_t i0 = (uint64_t)(rr + (NR / 2) * h) * row + (uint64_t)os * (N + cp) + cp + mb + 256 * d;
                             const Words4 b = rng.block(STREAM_NOISE, (uint32_t)(i0 >> 1));
-                            const double2 za = cn_from_words_lds(b.w[0], b.w[1], sigma, s_bm);     // the even sample: the lower half's
-                            const double2 zb = cn_from_words_lds(b.w[2], b.w[3], sigma, s_bm);     // the odd sample: the upper half's
+                            const cx<T> za = cn_words(b.w[0], b.w[1], sigma, s_bm);     // the even sample: the lower half's
+                            const cx<T> zb = cn_words(b.w[2], b.w[3], sigma, s_bm);     // the odd sample: the upper half's
                             swap32_pair(za.x, zb.x, nz[rr].x, nz[rr + NR / 2].x);
                             swap32_pair(za.y, zb.y, nz[rr].y, nz[rr + NR / 2].y);
                         }
@@ -616,13 +658,13 @@ __global__ __launch_bounds__((N / 4) * (NR / AH), WPS) void k_run_mimo_ofdm_f64(
                     static_for<4>([&](auto dc) {
                         constexpr int d = decltype(dc)::value;
                         __builtin_amdgcn_sched_barrier(0);
-                        double2 nz[NR];
+                        cx<T> nz[NR];
 #pragma unroll
                         for (int r = 0; r < NR; ++r) {
                             const uint64_t i0 = (uint64_t)r * row + (uint64_t)os * (N + cp) + cp + mb + 256 * d;
                             const Words4 b = rng.block(STREAM_NOISE, (uint32_t)(i0 >> 1));
                             const uint32_t x0 = (i0 & 1) ? b.w[2] : b.w[0], x1 = (i0 & 1) ? b.w[3] : b.w[1];
-                            nz[r] = cn_from_words_lds(x0, x1, sigma, s_bm);
+                            nz[r] = cn_words(x0, x1, sigma, s_bm);
                         }
                         mix(d, nz);
                     });
@@ -630,7 +672,7 @@ __global__ __launch_bounds__((N / 4) * (NR / AH), WPS) void k_run_mimo_ofdm_f64(
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int r = 0; r < NR; ++r) {
-                    r4_inplace<false>(y[r][0], y[r][1], y[r][2], y[r][3]);
+                    r4_inplace<T, false>(y[r][0], y[r][1], y[r][2], y[r][3]);
 #pragma unroll
                     for (int d = 0; d < 4; ++d) {
                         s_d[(2 * r) * N + (base_slot ^ d)] = y[r][d].x;
@@ -647,31 +689,31 @@ __global__ __launch_bounds__((N / 4) * (NR / AH), WPS) void k_run_mimo_ofdm_f64(
                     const int p0 = 2 * half * (N / 4) + rest, p1 = p0 + N / 4;
                     const int m0 = fft_index_of_pos<N>(p0);  // even; position p1 holds m0 + 1
                     const int q0 = swz(p0), q1 = swz(p1);
-                    double2 x0[NT], x1[NT];
+                    cx<T> x0[NT], x1[NT];
 #pragma unroll
                     for (int a = 0; a < NT; ++a) {
-                        x0[a] = mk<double>(s_d[(2 * a) * N + q0], s_d[(2 * a + 1) * N + q0]);
-                        x1[a] = mk<double>(s_d[(2 * a) * N + q1], s_d[(2 * a + 1) * N + q1]);
+                        x0[a] = mk<T>(s_d[(2 * a) * N + q0], s_d[(2 * a + 1) * N + q0]);
+                        x1[a] = mk<T>(s_d[(2 * a) * N + q1], s_d[(2 * a + 1) * N + q1]);
                     }
 #pragma unroll
                     for (int r = 0; r < NR; ++r) {
                         const uint64_t i0 = (uint64_t)r * row + (uint64_t)os * (N + cp) + cp + m0;
-                        double2 z0, z1;
+                        cx<T> z0, z1;
                         if ((i0 & 1) == 0) {     // tables of the Box-Muller from this workgroup's LDS copy
                             const Words4 b = rng.block(STREAM_NOISE, (uint32_t)(i0 >> 1));
-                            z0 = cn_from_words_lds(b.w[0], b.w[1], sigma, s_bm);
-                            z1 = cn_from_words_lds(b.w[2], b.w[3], sigma, s_bm);
+                            z0 = cn_words(b.w[0], b.w[1], sigma, s_bm);
+                            z1 = cn_words(b.w[2], b.w[3], sigma, s_bm);
                         } else {
                             const Words4 b0 = rng.block(STREAM_NOISE, (uint32_t)(i0 >> 1));
                             const Words4 b1 = rng.block(STREAM_NOISE, (uint32_t)((i0 + 1) >> 1));
-                            z0 = cn_from_words_lds(b0.w[2], b0.w[3], sigma, s_bm);
-                            z1 = cn_from_words_lds(b1.w[0], b1.w[1], sigma, s_bm);
+                            z0 = cn_words(b0.w[2], b0.w[3], sigma, s_bm);
+                            z1 = cn_words(b1.w[0], b1.w[1], sigma, s_bm);
                         }
 #pragma unroll
                         for (int a = 0; a < NT; ++a) {
-                            const double2 h = s_H[r * NT + a];       // wave-uniform address: an LDS broadcast
-                            z0 = cfma(h, x0[a], z0);
-                            z1 = cfma(h, x1[a], z1);
+                            const cx<T> h = s_H[r * NT + a];       // wave-uniform address: an LDS broadcast
+                            z0 = CxOps<T>::fma(h, x0[a], z0);
+                            z1 = CxOps<T>::fma(h, x1[a], z1);
                         }
                         if constexpr (VAR & 1) {
                             asm volatile("" ::"v"(z0.x), "v"(z0.y), "v"(z1.x), "v"(z1.y));
@@ -687,33 +729,33 @@ __global__ __launch_bounds__((N / 4) * (NR / AH), WPS) void k_run_mimo_ofdm_f64(
             if constexpr (!(VAR & 2)) __syncthreads();
             // ---- FFT: (the radix-2 stage +) radix-4 DIT, digit-reversed -> natural bins ----
             if constexpr (R16) {
-                if constexpr (FUSED) tw16 = load_r16_tw(g_tw, opaque(lane));
-                r16_dit<false, !FUSED, EXACT>(s_wave_re, s_wave_im, lane, tw16, g_tw);
+                if constexpr (TW16_RELOAD) tw16 = load_r16_tw<T>(g_tw, opaque(lane));
+                r16_dit<T, false, !FUSED, EXACT, OWNTW>(s_wave_re, s_wave_im, lane, tw16, g_tw);
                 __syncthreads();
             } else if constexpr (TWR) {
                 if constexpr (SH::HAS2) {
-                    r2_stage_planar<N, AH>(s_mine, opaque(bbt));
+                    r2_stage_planar<T, N, AH>(s_mine, opaque(bbt));
                     fft_stage_sync<TB>(2);
                 }
                 static_for<N4>([&](auto stc) {
                     constexpr int st = decltype(stc)::value, S = SH::span(N4 - 1 - st);
-                    r4_stage_planar<N, false, false, S, AH, TWR>(s_mine, twr, g_tw, opaque(bbt));
+                    r4_stage_planar<T, N, false, false, S, AH, TWR>(s_mine, twr, g_tw, opaque(bbt));
                     if constexpr (st + 1 < N4)
                         fft_stage_sync<TB>(4 * S);     // the next stage's 4 S-thread groups read what was written here
                     else
                         __syncthreads();
                 });
             } else {                                  // every stage's twiddles fetched while the previous stage runs
-                double2 wpre[2][3];
+                cx<T> wpre[2][3];
                 if constexpr (SH::HAS2) {
-                    stage_tw_fetch<N, 2>(g_tw, opaque(bbt), wpre[0]);
-                    r2_stage_planar<N, AH>(s_mine, opaque(bbt));
+                    stage_tw_fetch<T, N, 2>(g_tw, opaque(bbt), wpre[0]);
+                    r2_stage_planar<T, N, AH>(s_mine, opaque(bbt));
                     fft_stage_sync<TB>(2);
                 }
                 static_for<N4>([&](auto stc) {
                     constexpr int st = decltype(stc)::value, S = SH::span(N4 - 1 - st);
-                    if constexpr (st + 1 < N4) stage_tw_fetch<N, 4 * S>(g_tw, opaque(bbt), wpre[(st + 1) & 1]);
-                    r4_stage_planar<N, false, false, S, AH, TWR>(s_mine, twr, g_tw, opaque(bbt), S > 1 ? wpre[st & 1] : nullptr);
+                    if constexpr (st + 1 < N4) stage_tw_fetch<T, N, 4 * S>(g_tw, opaque(bbt), wpre[(st + 1) & 1]);
+                    r4_stage_planar<T, N, false, false, S, AH, TWR>(s_mine, twr, g_tw, opaque(bbt), S > 1 ? wpre[st & 1] : nullptr);
                     if constexpr (st + 1 < N4)
                         fft_stage_sync<TB>(4 * S);
                     else
@@ -724,9 +766,9 @@ __global__ __launch_bounds__((N / 4) * (NR / AH), WPS) void k_run_mimo_ofdm_f64(
             {
                 for (int d = tid; d < U; d += TB) {
                     const int bin = swz(ofdm_bin(d, N, U));
-                    double2 y[NR];
+                    cx<T> y[NR];
 #pragma unroll
-                    for (int r = 0; r < NR; ++r) y[r] = mk<double>(s_d[(2 * r) * N + bin], s_d[(2 * r + 1) * N + bin]);
+                    for (int r = 0; r < NR; ++r) y[r] = mk<T>(s_d[(2 * r) * N + bin], s_d[(2 * r + 1) * N + bin]);
                     uint32_t sent = 0;
                     if constexpr (NT == 4) {
                         sent = *reinterpret_cast<const uint32_t*>(s_idx + 4 * d);
@@ -737,19 +779,26 @@ __global__ __launch_bounds__((N / 4) * (NR / AH), WPS) void k_run_mimo_ofdm_f64(
                         for (int a = 0; a < NT; ++a) sent |= (uint32_t)s_idx[NT * d + a] << (8 * a);
                     }
                     if constexpr (AH == NR && NT == NR) {   // 256-thread form (256 VGPRs): the streams searched in lockstep
-                        double2 est[NT];
+                        cx<T> est[NT];
                         int dec[NT];
 #pragma unroll
                         for (int a = 0; a < NT; ++a) {
-                            est[a] = mk<double>(0, 0);
+                            est[a] = mk<T>(0, 0);
 #pragma unroll
-                            for (int r = 0; r < NR; ++r) est[a] = cfma(s_G[a * NR + r], y[r], est[a]);
+                            for (int r = 0; r < NR; ++r) est[a] = CxOps<T>::fma(s_G[a * NR + r], y[r], est[a]);
                         }
                         if (mp.method != MCLE_DEMOD_QAM_SLICER && mp.grid.G > 0) {
-                            demod_multi_cert(mp, est, dec, [&](int (&d_)[NT]) { demod_grid_multi<NT>(s_table, s_grid, mp.grid, mp.M, est, d_); });
+                            demod_multi_cert(mp, est, dec, [&](int (&d_)[NT]) {
+                                if constexpr (std::is_same<T, double>::value) {
+                                    demod_grid_multi<NT>(s_table, s_grid, mp.grid, mp.M, est, d_);
+                                } else {
+#pragma unroll
+                                    for (int a = 0; a < NT; ++a) d_[a] = demod_grid(s_table, s_grid, mp.grid, mp.M, est[a]);
+                                }
+                            });
                         } else {
 #pragma unroll
-                            for (int a = 0; a < NT; ++a) dec[a] = demod_one<double>(mp, s_table, s_grid, est[a]);
+                            for (int a = 0; a < NT; ++a) dec[a] = demod_one<T>(mp, s_table, s_grid, est[a]);
                         }
 #pragma unroll
                         for (int a = 0; a < NT; ++a) {
@@ -760,10 +809,10 @@ __global__ __launch_bounds__((N / 4) * (NR / AH), WPS) void k_run_mimo_ofdm_f64(
                     } else {                        // stream by stream (the lockstep form spilled 47 registers at the
 #pragma unroll                                      // 128-register bound: 1.83e7 -> 1.60e7 realizations/s)
                         for (int a = 0; a < NT; ++a) {
-                            double2 est = mk<double>(0, 0);
+                            cx<T> est = mk<T>(0, 0);
 #pragma unroll
-                            for (int r = 0; r < NR; ++r) est = cfma(s_G[a * NR + r], y[r], est);
-                            const int dec = demod_one<double>(mp, s_table, s_grid, est);
+                            for (int r = 0; r < NR; ++r) est = CxOps<T>::fma(s_G[a * NR + r], y[r], est);
+                            const int dec = demod_one<T>(mp, s_table, s_grid, est);
                             const unsigned x = ((sent >> (8 * a)) & 0xFFu) ^ (unsigned)dec;
                             se += (x != 0u);
                             be += __popc(x);
@@ -799,23 +848,23 @@ __global__ __launch_bounds__((N / 4) * (NR / AH), WPS) void k_run_mimo_ofdm_f64(
 }
 
 // one geometry: filters + link, sliced so that the record buffer stays bounded
-template <int N, int NT, int NR, int AH, int WPS, int VAR = 0>
-static int launch_mimo_ofdm_f64(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, uint64_t seed, uint64_t first, uint64_t count,
+template <typename T, int N, int NT, int NR, int AH, int WPS, int VAR = 0>
+static int launch_mimo_ofdm_planar(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, uint64_t seed, uint64_t first, uint64_t count,
                                 mcle_counters* d_counters, uint32_t* d_sym, uint32_t* d_bit) {
     constexpr int kRec = d64_rec<NT, NR>(), TB = (N / 4) * (NR / AH);
     int rc;
     void* tw = nullptr;
-    if ((rc = ctx->get_twiddles(N, MCLE_F64, &tw))) return rc;
+    if ((rc = ctx->get_twiddles(N, sizeof(T) == 8 ? MCLE_F64 : MCLE_F32, &tw))) return rc;
     MimoParams pp{cfg->cp_size, cfg->num_used, cfg->n_ofdm_sym, cfg->mmse, cfg->noise_var};
-    const ModemParams<double> mp = pipe_modem<double>(ctx, cfg->demod_method);     // certificate / candidate grid (pruned search)
+    const ModemParams<T> mp = pipe_modem<T>(ctx, cfg->demod_method);     // certificate / candidate grid (pruned search)
     const size_t tab_len = ((size_t)mp.M + 1) & ~(size_t)1;
-    const size_t lds = (size_t)2 * NR * N * sizeof(double) + (2 * tab_len + 2 * (kRec + 1)) * sizeof(double2) +
-                       64 * sizeof(unsigned) + (size_t)((kBmLdsDoubles + 1) & ~1) * sizeof(double) +
+    const size_t lds = (size_t)2 * NR * N * sizeof(T) + (2 * tab_len + 2 * (kRec + 1)) * sizeof(cx<T>) +
+                       64 * sizeof(unsigned) + (sizeof(T) == 8 ? (size_t)((kBmLdsDoubles + 1) & ~1) * sizeof(double) : 0) +
                        (size_t)mp.grid.G * mp.grid.G * sizeof(unsigned long long) +
                        (((size_t)NT * cfg->num_used + 15) & ~(size_t)15) + 16;
-    MCLE_REQUIRE(lds + 512 <= (size_t)160 * 1024, "complex128 MIMO-OFDM kernel: %zu B of LDS do not fit (fft_size %d, %d receive antennas)",
+    MCLE_REQUIRE(lds + 512 <= (size_t)160 * 1024, "planar MIMO-OFDM kernel: %zu B of LDS do not fit (fft_size %d, %d receive antennas)",
                  lds, N, NR);
-    auto kern = k_run_mimo_ofdm_f64<N, NT, NR, AH, WPS, VAR>;
+    auto kern = k_run_mimo_ofdm_planar<T, N, NT, NR, AH, WPS, VAR>;
     MCLE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int per_cu = (int)((size_t)160 * 1024 / (lds + 512));
     const int by_waves = (WPS * 256) / TB > 0 ? (WPS * 256) / TB : 1;          // what __launch_bounds__ allocated registers for
@@ -825,15 +874,15 @@ static int launch_mimo_ofdm_f64(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, ui
     const uint64_t kSlice = 1ull << 18;     // realizations per filter + link pair: bounds the record buffer (138 MB)
     const uint64_t slice = count < kSlice ? count : kSlice;
     void* recs = nullptr;
-    if ((rc = ctx->scratch((size_t)slice * kRec * sizeof(double2), &recs))) return rc;
+    if ((rc = ctx->scratch((size_t)slice * kRec * sizeof(cx<T>), &recs))) return rc;
     for (uint64_t off = 0; off < count; off += slice) {
         const uint64_t n = count - off < slice ? count - off : slice;
-        hipLaunchKernelGGL((k_mimo_filters_f64<N, NT, NR>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, pp, seed,
-                           first + off, n, (double2*)recs);
+        hipLaunchKernelGGL((k_mimo_filters_planar<T, N, NT, NR>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, pp, seed,
+                           first + off, n, (cx<T>*)recs);
         MCLE_LAUNCH_CHECK();
         const unsigned grid = (unsigned)oversubscribed_grid(ctx, resident, n);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(TB), lds, ctx->stream, pp, mp, seed, first + off, n,
-                           (const double2*)tw, (const double2*)recs, d_counters, d_sym ? d_sym + off : nullptr,
+                           (const cx<T>*)tw, (const cx<T>*)recs, d_counters, d_sym ? d_sym + off : nullptr,
                            d_bit ? d_bit + off : nullptr);
         MCLE_LAUNCH_CHECK();
     }
@@ -847,33 +896,55 @@ static int launch_mimo_ofdm_f64(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, ui
 //   1024  2x2   2   256   3   3        2048  2x2   2   512   2   4        512  2x2   2   128   5   3        256  2x2   2   64  8  2
 // Nt < Nr (mimo/mimo.py:264-309 takes any): every 1 <= Nt <= Nr <= 4 at every size runs the Nr geometry (Nr = 3: three
 // antennas per thread, one group); antenna groups past Nt idle in the IFFT.
-int run_mimo_ofdm_f64(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, uint64_t seed, uint64_t first, uint64_t count,
-                      mcle_counters* d_counters, uint32_t* d_sym, uint32_t* d_bit) {
-    if (ctx->opt[MCLE_OPT_F64_GENERIC]) return MCLE_E_UNSUPPORTED;
+// complex64 (round 4): the same kernels on planes of floats.  Half the LDS per workgroup, 80 - 140 registers per thread where
+// complex128 takes 120 - 250: the radix-4 geometries keep the complex128 table's wavefronts-per-SIMD bound (doubling it spilled
+// 10 - 77 registers in every 4-receive-antenna shape), the radix-16 form of the benchmark size runs four workgroups per CU
+// instead of two.
+template <typename T> constexpr int planar_wps(int w64) { return w64; }
+
+template <typename T>
+static int run_mimo_ofdm_planar_t(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, uint64_t seed, uint64_t first, uint64_t count,
+                                  mcle_counters* d_counters, uint32_t* d_sym, uint32_t* d_bit) {
+    constexpr bool F64 = sizeof(T) == 8;
     const int n = cfg->fft_size, nt = cfg->nt, nr = cfg->nr;
 #define MCLE_F64_GEOM(N_, NT_, NR_, AH_, WPS_)                                                                      \
     if (n == N_ && nt == NT_ && nr == NR_)                                                                          \
-        return launch_mimo_ofdm_f64<N_, NT_, NR_, AH_, WPS_>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
+        return launch_mimo_ofdm_planar<T, N_, NT_, NR_, AH_, planar_wps<T>(WPS_)>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
     // (1024, 4 x 4), the benchmark geometry: radix-16 passes, one transform per wavefront, 256 threads (default since round 4:
     // 10.66 ms per 262 144 realizations against 11.65 for the 512-thread radix-4 form and 12.15 for the 256-thread one,
     // profiles/r04/c4_f64_r16_ab.log).  MCLE_OPT_F64_THREADS: 512 = radix-4, two antennas per thread; 256 = radix-4, four
     // antennas per thread, twiddles in registers.  MCLE_OPT_F64_VARIANT 1 .. 3: timing bounds on the 512-thread form.
     if (n == 1024 && nt == 4 && nr == 4) {
-        switch ((int)ctx->opt[MCLE_OPT_F64_VARIANT]) {
-            case 1: return launch_mimo_ofdm_f64<1024, 4, 4, 2, 4, 1>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
-            case 2: return launch_mimo_ofdm_f64<1024, 4, 4, 2, 4, 2>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
-            case 3: return launch_mimo_ofdm_f64<1024, 4, 4, 2, 4, 3>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
-            default: break;
+        if constexpr (F64) {
+            switch ((int)ctx->opt[MCLE_OPT_F64_VARIANT]) {
+                case 1: return launch_mimo_ofdm_planar<T, 1024, 4, 4, 2, 4, 1>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
+                case 2: return launch_mimo_ofdm_planar<T, 1024, 4, 4, 2, 4, 2>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
+                case 3: return launch_mimo_ofdm_planar<T, 1024, 4, 4, 2, 4, 3>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
+                default: break;
+            }
+            if (ctx->opt[MCLE_OPT_F64_THREADS] == 258)  // every layer-1 twiddle from the table (A/B: 10.95 ms against 10.62 -- the nine
+                return launch_mimo_ofdm_planar<T, 1024, 4, 4, 4, 2, 28>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);   // loads per pass cost more than the eight products)
         }
         if (ctx->opt[MCLE_OPT_F64_THREADS] == 256)
-            return launch_mimo_ofdm_f64<1024, 4, 4, 4, 2>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
+            return launch_mimo_ofdm_planar<T, 1024, 4, 4, 4, planar_wps<T>(2)>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
         if (ctx->opt[MCLE_OPT_F64_THREADS] == 512)
-            return launch_mimo_ofdm_f64<1024, 4, 4, 2, 4>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
-        if (ctx->opt[MCLE_OPT_F64_THREADS] == 257)      // radix-16 passes with the unfused channel stage (A/B)
-            return launch_mimo_ofdm_f64<1024, 4, 4, 4, 2, 4>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
-        if (ctx->opt[MCLE_OPT_F64_THREADS] == 258)      // every layer-1 twiddle from the table (A/B: 10.95 ms against 10.62 -- the nine
-            return launch_mimo_ofdm_f64<1024, 4, 4, 4, 2, 28>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);   // loads per pass cost more than the eight products)
-        return launch_mimo_ofdm_f64<1024, 4, 4, 4, 2, 12>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
+            return launch_mimo_ofdm_planar<T, 1024, 4, 4, 2, planar_wps<T>(4)>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
+        if constexpr (!F64) {
+            // complex64: the SEPARATE channel stage at a four-wavefront register bound is the fast form (4.88 ms per 262 144
+            // realizations; fused 5.08; at a three-wavefront bound 5.26 / 5.47; the matrix-core kernel 5.89 -- min-distance
+            // demodulator, profiles/r04/c4_f32_planar_ab.log); 259 = fused, 257 = the three-wavefront bound (A/B)
+            if (ctx->opt[MCLE_OPT_F64_THREADS] == 258)      // each pass fetches its own twiddles (A/B)
+                return launch_mimo_ofdm_planar<T, 1024, 4, 4, 4, 4, 36>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
+            if (ctx->opt[MCLE_OPT_F64_THREADS] == 259)
+                return launch_mimo_ofdm_planar<T, 1024, 4, 4, 4, 4, 12>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
+            if (ctx->opt[MCLE_OPT_F64_THREADS] == 257)
+                return launch_mimo_ofdm_planar<T, 1024, 4, 4, 4, 3, 4>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
+            return launch_mimo_ofdm_planar<T, 1024, 4, 4, 4, 4, 4>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
+        } else {
+            if (ctx->opt[MCLE_OPT_F64_THREADS] == 257)      // radix-16 passes with the unfused channel stage (A/B)
+                return launch_mimo_ofdm_planar<T, 1024, 4, 4, 4, 2, 4>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
+            return launch_mimo_ofdm_planar<T, 1024, 4, 4, 4, 2, 12>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
+        }
     }
     // every Nt <= Nr <= 4 at every size: Nr = 2 / 4 two antennas per thread, Nr = 3 three (one group)
 #define MCLE_F64_SIZE(N_, W2_, W4_)                                                                                  \
@@ -883,15 +954,23 @@ int run_mimo_ofdm_f64(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, uint64_t see
     MCLE_F64_SIZE(256, 2, 3) MCLE_F64_GEOM(256, 4, 4, 2, 3)
     MCLE_F64_SIZE(512, 3, 3) MCLE_F64_GEOM(512, 4, 4, 2, 3)
     if (n == 1024 && nr == 4 && ctx->opt[MCLE_OPT_F64_THREADS] == 0) {      // Nt < 4 at the benchmark size: the radix-16 form too
-        if (nt == 1) return launch_mimo_ofdm_f64<1024, 1, 4, 4, 2, 12>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
-        if (nt == 2) return launch_mimo_ofdm_f64<1024, 2, 4, 4, 2, 12>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
-        if (nt == 3) return launch_mimo_ofdm_f64<1024, 3, 4, 4, 2, 12>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
+        constexpr int WR16 = F64 ? 2 : 4, VR16 = F64 ? 12 : 4;       // complex128: fused, 2 workgroups per CU; complex64: unfused, 4
+        if (nt == 1) return launch_mimo_ofdm_planar<T, 1024, 1, 4, 4, WR16, VR16>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
+        if (nt == 2) return launch_mimo_ofdm_planar<T, 1024, 2, 4, 4, WR16, VR16>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
+        if (nt == 3) return launch_mimo_ofdm_planar<T, 1024, 3, 4, 4, WR16, VR16>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
     }
     MCLE_F64_SIZE(1024, 3, 4)
     MCLE_F64_SIZE(2048, 4, 4) MCLE_F64_GEOM(2048, 4, 4, 2, 4)
 #undef MCLE_F64_SIZE
 #undef MCLE_F64_GEOM
     return MCLE_E_UNSUPPORTED;
+}
+
+int run_mimo_ofdm_planar(mcle_ctx* ctx, int dtype, const mcle_mimo_ofdm_cfg* cfg, uint64_t seed, uint64_t first, uint64_t count,
+                         mcle_counters* d_counters, uint32_t* d_sym, uint32_t* d_bit) {
+    if (ctx->opt[MCLE_OPT_F64_GENERIC]) return MCLE_E_UNSUPPORTED;
+    return dtype == MCLE_F32 ? run_mimo_ofdm_planar_t<float>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit)
+                             : run_mimo_ofdm_planar_t<double>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
 }
 
 }  // namespace mcle

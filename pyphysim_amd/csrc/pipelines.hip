@@ -1040,7 +1040,7 @@ int run_tdl_impl(mcle_ctx* ctx, const mcle_ofdm_tdl_cfg* cfg, uint64_t seed, uin
 
 namespace mcle {
 // pipeline_mimo_mfma.hip: f32, FFT 1024, 4x4 on the matrix cores; MCLE_E_UNSUPPORTED outside that envelope
-int run_mimo_ofdm_f64(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, uint64_t seed, uint64_t first, uint64_t count,
+int run_mimo_ofdm_planar(mcle_ctx* ctx, int dtype, const mcle_mimo_ofdm_cfg* cfg, uint64_t seed, uint64_t first, uint64_t count,
                       mcle_counters* d_counters, uint32_t* d_sym, uint32_t* d_bit);
 int run_mimo_ofdm_mfma(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, uint64_t seed, uint64_t first, uint64_t count,
                        mcle_counters* d_counters, uint32_t* d_sym, uint32_t* d_bit);
@@ -1111,16 +1111,17 @@ int mcle_run_mimo_ofdm(mcle_ctx* ctx, int dtype, const mcle_mimo_ofdm_cfg* cfg, 
     MCLE_REQUIRE(count <= 0x7fffffffull, "at most 2^31-1 realizations per call");
     if (count == 0) return MCLE_OK;
     if ((rc = ctx->bind())) return rc;
-    if (dtype == MCLE_F32) {   // matrix-core kernel where it applies (MCLE_OPT_NO_MFMA keeps the VALU kernel below)
+    if (dtype == MCLE_F32 && ctx->opt[MCLE_OPT_F32_MFMA] && !ctx->opt[MCLE_OPT_NO_MFMA]) {   // matrix-core kernel on request (1024, 4x4)
         rc = run_mimo_ofdm_mfma(ctx, cfg, seed, first, count, d_counters, d_sym_err, d_bit_err);
         if (rc != MCLE_E_UNSUPPORTED) return rc;
-    } else {                   // complex128: the planar kernel family (pipeline_mimo_f64.hip: FFT 256 .. 2048, 2x2 / 4x4 / 2x4)
-        rc = run_mimo_ofdm_f64(ctx, cfg, seed, first, count, d_counters, d_sym_err, d_bit_err);
-        if (rc != MCLE_E_UNSUPPORTED) return rc;
+    }
+    if (!(dtype == MCLE_F32 && ctx->opt[MCLE_OPT_NO_MFMA])) {   // the planar kernel family (pipeline_mimo_planar.hip: FFT 256 .. 2048,
+        rc = run_mimo_ofdm_planar(ctx, dtype, cfg, seed, first, count, d_counters, d_sym_err, d_bit_err);   // 1 <= Nt <= Nr <= 4);
+        if (rc != MCLE_E_UNSUPPORTED) return rc;                // no_mfma = 1 keeps complex64 on the round-1 kernel below
     }
     MCLE_REQUIRE(cfg->nt == cfg->nr && (cfg->nt == 2 || cfg->nt == 4),
                  "fused MIMO pipeline: %d x %d at fft_size %d is outside the envelope (2x2 / 4x4 at 64 .. 2048 in both arithmetics; "
-                 "every 1 <= Nt <= Nr <= 4 in complex128 at 256 .. 2048)", cfg->nt, cfg->nr, cfg->fft_size);
+                 "every 1 <= Nt <= Nr <= 4 at 256 .. 2048)", cfg->nt, cfg->nr, cfg->fft_size);
 #define MCLE_RUN(N_, NA_)                                                                                         \
     if (cfg->fft_size == N_ && cfg->nt == NA_)                                                                    \
         return dtype == MCLE_F32                                                                                  \

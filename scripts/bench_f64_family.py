@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Realizations/s of the complex128 MIMO-OFDM kernel family (csrc/pipeline_mimo_f64.hip) per geometry, next to the generic
-radix-4 kernel k_run_mimo_ofdm<double, N, NA> it replaces (context option f64_generic): 64-QAM, cp 16, full band, SNR 25 dB,
-min-distance demodulation (certificate) and slicer.  One JSON object on stdout (profiles/r04/f64_family_rates.json)."""
+"""Realizations/s of the planar MIMO-OFDM kernel family (csrc/pipeline_mimo_planar.hip) per geometry, next to the generic
+radix-4 kernel k_run_mimo_ofdm<T, N, NA> it replaces (context option f64_generic): 64-QAM, cp 16, full band, SNR 25 dB,
+min-distance demodulation (certificate) and slicer.  --dtype f64 (default) | f32; at (1024, 4x4) in f32 the matrix-core
+kernel is timed too.  One JSON object on stdout (profiles/r04/f64_family_rates.json, f32_family_rates.json)."""
 import json
 import os
 import sys
@@ -11,7 +12,8 @@ from pyphysim_amd import _lib  # noqa: E402
 from pyphysim_amd.engine import Engine  # noqa: E402
 from pyphysim_amd.modulators import constellation  # noqa: E402
 
-eng = Engine(0, "f64")
+DT = sys.argv[sys.argv.index("--dtype") + 1] if "--dtype" in sys.argv else "f64"
+eng = Engine(0, DT)
 eng.set_constellation(constellation("qam", 64), _lib.CONST_QAM)
 nv = 10 ** -2.5
 out = {}
@@ -20,13 +22,16 @@ for fft, nt, nr in ((256, 2, 2), (256, 4, 4), (512, 2, 2), (512, 4, 4), (1024, 2
     n = max(16384, int(262144 * 4096 / (fft * nr)) // 8192 * 8192)
     n = min(n, 262144)
     row = {"realizations_per_launch": n}
-    for name, generic, method in (("fast_mindist", 0, _lib.DEMOD_MINDIST), ("fast_slicer", 0, _lib.DEMOD_QAM_SLICER),
-                                  ("generic_mindist", 1, _lib.DEMOD_MINDIST)):
+    legs = [("fast_mindist", 0, _lib.DEMOD_MINDIST, 1), ("fast_slicer", 0, _lib.DEMOD_QAM_SLICER, 1),
+            ("generic_mindist", 1, _lib.DEMOD_MINDIST, 1)]
+    if DT == "f32" and (fft, nt, nr) == (1024, 4, 4):
+        legs += [("mfma_mindist", 0, _lib.DEMOD_MINDIST, 0), ("mfma_slicer", 0, _lib.DEMOD_QAM_SLICER, 0)]
+    for name, generic, method, planar in legs:
         if generic and (nt != nr or (fft, nr) == (2048, 4)):      # the generic kernel has no such shape (2048 x 4: 181 KiB of LDS)
             continue
         cnt = eng.new_counters()
-        with eng.options(f64_generic=generic):
-            run = lambda first: eng.run_mimo_ofdm(nt, nr, fft, 16, fft, 1, nv, 1, first, n, method=method, dtype="f64",
+        with eng.options(f64_generic=generic, f32_mfma=0 if planar else 1):
+            run = lambda first: eng.run_mimo_ofdm(nt, nr, fft, 16, fft, 1, nv, 1, first, n, method=method, dtype=DT,
                                                   counters=cnt)
             run(1 << 30)
             eng.sync()

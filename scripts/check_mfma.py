@@ -21,6 +21,7 @@ out = {}
 
 def run(first, count, mfma, method=_lib.DEMOD_QAM_SLICER, used=1024, nsym=1, cp=16, snr=25.0, mmse=True, per=True):
     eng.set_option("no_mfma", 0 if mfma else 1)
+    eng.set_option("f32_mfma", 1 if mfma else 0)
     nv = 1.0 / (10.0 ** (snr / 10.0))
     return eng.run_mimo_ofdm(4, 4, 1024, cp, used, nsym, nv, SEED, first, count, mmse=mmse, method=method, dtype="f32",
                              per_realization=per)
@@ -58,6 +59,7 @@ for name, mfma, method, variant in cases:
     cnt = eng.new_counters()
     eng.set_option("mfma_variant", int(variant or 0))
     eng.set_option("no_mfma", 0 if mfma else 1)
+    eng.set_option("f32_mfma", 1 if mfma else 0)
     nv = 1.0 / (10.0 ** 2.5)
     for _ in range(3):
         eng.run_mimo_ofdm(4, 4, 1024, 16, 1024, 1, nv, SEED, 1 << 30, 65536, method=method, dtype="f32", counters=cnt)

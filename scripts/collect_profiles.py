@@ -30,10 +30,12 @@ os.makedirs(dst, exist_ok=True)
 # tag -> (kernel-name needle of the dominant kernel, label); the bench arguments of a tag (config, dtype, demodulator, batch)
 # are recorded by scripts/prof_r04.sh (prof_r03.sh in round 3) in gpurun_out/prof_<tag>_meta.json
 CONFIGS = {
-    "c4_f64": ("k_run_mimo_ofdm_f64<", "k_run_mimo_ofdm_f64<1024, 4, 4, 2, 4> (complex128, FFT 1024, 4x4, 512 threads), min-distance demodulator (margin certificate): the bench.py headline"),
-    "c4_f64sl": ("k_run_mimo_ofdm_f64<", "k_run_mimo_ofdm_f64<1024, 4, 4, 2, 4> with the QAM slicer"),
-    "c4": ("k_run_mimo_ofdm_mfma<", "k_run_mimo_ofdm_mfma<3,6> (complex64, FFT 1024, 4x4), QAM slicer"),
-    "c4md": ("k_run_mimo_ofdm_mfma<", "k_run_mimo_ofdm_mfma<3,6> with the min-distance demodulator over the LDS table"),
+    "c4_f64": ("k_run_mimo_ofdm_planar<", "k_run_mimo_ofdm_planar<1024, 4, 4, 2, 4> (complex128, FFT 1024, 4x4, 512 threads), min-distance demodulator (margin certificate): the bench.py headline"),
+    "c4_f64sl": ("k_run_mimo_ofdm_planar<", "k_run_mimo_ofdm_planar<1024, 4, 4, 2, 4> with the QAM slicer"),
+    "c4": ("k_run_mimo_ofdm_planar<", "k_run_mimo_ofdm_planar<float, 1024, 4, 4, 4, 4, 4> (complex64, FFT 1024, 4x4: radix-16 passes, one transform per wavefront), QAM slicer"),
+    "c4md": ("k_run_mimo_ofdm_planar<", "k_run_mimo_ofdm_planar<float, 1024, 4, 4, 4, 4, 4> with the min-distance demodulator (margin certificate)"),
+    "c4_mfma": ("k_run_mimo_ofdm_mfma<", "k_run_mimo_ofdm_mfma<3,6> (complex64, FFT 1024, 4x4 on the matrix cores: option f32_mfma = 1, the default of rounds 2-3), QAM slicer"),
+    "c4md_mfma": ("k_run_mimo_ofdm_mfma<", "k_run_mimo_ofdm_mfma<3,6> with the min-distance demodulator"),
     "f1": ("k_run_mimo_ofdm_tdl<", "k_run_mimo_ofdm_tdl<float,1024,4> (bench.py --config f1)"),
     "c3": ("k_run_ofdm_tdl_mfma<", "k_run_ofdm_tdl_mfma<2> (complex64, FFT 1024, 4 realizations per pass; k_tdl_symbol_polys runs before it)"),
     "c3_f64": ("k_run_ofdm_tdl_batch<", "k_run_ofdm_tdl_batch<double,1024,2> (complex128, two realizations per pass, three waves per SIMD)"),

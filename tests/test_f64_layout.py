@@ -1,4 +1,4 @@
-"""CPU: the LDS layout of the complex128 config-4 kernel (csrc/pipeline_mimo_f64.hip) -- planar doubles, position e
+"""CPU: the LDS layout of the complex128 config-4 kernel (csrc/pipeline_mimo_planar.hip) -- planar doubles, position e
 stored at lds_swz64(e) -- replayed under gfx950's bank rules for 8-byte accesses (MI355X_MICROARCH.md, LDS table):
   ds_read_b64 : two groups of 32 lanes, bank pair of an 8-byte slot = slot mod 32   -> 32 distinct slots per group
   ds_write_b64: four groups of 16 consecutive lanes, bank = dword mod 32             -> 16 distinct slots mod 16 per group
@@ -128,7 +128,7 @@ def test_the_radix4_swizzle_of_fft_hpp_is_not_enough_for_8_byte_stores():
     assert bad > 0
 
 
-# ---- variant 4 of the (1024, 4 x 4) kernel: radix-16 passes, one transform per wavefront (csrc/pipeline_mimo_f64.hip) ----
+# ---- variant 4 of the (1024, 4 x 4) kernel: radix-16 passes, one transform per wavefront (csrc/pipeline_mimo_planar.hip) ----
 def swz16f(e):
     e = np.asarray(e)
     return e ^ ((e >> 4) & 31) ^ (((e >> 9) & 1) << 4)

@@ -1,4 +1,4 @@
-"""GPU: the complex128 config-4 kernel family (csrc/pipeline_mimo_f64.hip: planar LDS, table Box-Muller, certified /
+"""GPU: the complex128 config-4 kernel family (csrc/pipeline_mimo_planar.hip: planar LDS, table Box-Muller, certified /
 pruned min-distance search; fft_size 256 .. 2048, 2x2 / 4x4 / 2x4) -- per-realization error counts equal to the oracle
 chain's under the same Philox keying, and equal to the generic radix-4 kernel it replaces (engine option f64_generic), on
 every corner of its envelope."""
@@ -145,7 +145,7 @@ def test_f64_family_counts_equal_the_oracle(engine, shape, case):
 
 def test_shapes_outside_the_envelope_are_refused(engine):
     engine.set_constellation(chains.constellation("qam", 16), _lib.CONST_QAM)
-    for nt, nr, fft, dtype in [(4, 2, 1024, "f64"), (2, 4, 1024, "f32"), (3, 3, 1024, "f32"), (2, 2, 96, "f64"), (5, 5, 1024, "f64"),
+    for nt, nr, fft, dtype in [(4, 2, 1024, "f64"), (2, 2, 96, "f64"), (5, 5, 1024, "f64"),
                                (2, 4, 128, "f64")]:
         with pytest.raises((_lib.McleError, ValueError)):
             engine.run_mimo_ofdm(nt, nr, fft, 16, fft, 1, 0.01, SEED, 0, 4, dtype=dtype)
@@ -169,7 +169,7 @@ def test_launch_slices_are_invisible(engine):
     from pyphysim_amd.channels import discretize_profile
     engine.set_constellation(chains.constellation("qam", 64), _lib.CONST_QAM)
     nv = 1.0 / omodem.dB2Linear(25.0)
-    n = (1 << 18) + 4099                       # crosses the slice of k_mimo_filters_f64 / k_run_mimo_ofdm_f64
+    n = (1 << 18) + 4099                       # crosses the slice of k_mimo_filters_planar / k_run_mimo_ofdm_planar
     whole, se, _ = engine.run_mimo_ofdm(4, 4, 1024, 16, 1024, 1, nv, SEED, 0, n, method=_lib.DEMOD_QAM_SLICER, dtype="f64",
                                         per_realization=True)
     a = engine.run_mimo_ofdm(4, 4, 1024, 16, 1024, 1, nv, SEED, 0, 1 << 18, method=_lib.DEMOD_QAM_SLICER, dtype="f64")

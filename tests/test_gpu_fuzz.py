@@ -189,11 +189,18 @@ def test_fuzz_matrix_core_kernels(engine, trial):
     nv = 1.0 / omodem.dB2Linear(snr)
     first, count = int(rs.randint(0, 1 << 33)), int(rs.randint(1, 9))
 
-    def both(fn):
+    def both(fn, **matrix_core):
+        """the default kernel (configs 2, 3: matrix cores; config 4 since round 4: the planar VALU family) against the round-1
+        VALU kernel, and -- config 4 -- the matrix-core kernel (option f32_mfma) against both"""
         got = fn()
         with engine.options(no_mfma=1):
             ref = fn()
         assert np.max(np.abs(got[1].astype(np.int64) - ref[1].astype(np.int64))) <= 4, ("vs the VALU kernel", trial)
+        if matrix_core:
+            with engine.options(**matrix_core):
+                alt = fn()
+            assert np.max(np.abs(got[1].astype(np.int64) - alt[1].astype(np.int64))) <= 4, ("planar vs matrix cores", trial)
+            assert np.array_equal(got[1] == 0xFFFFFFFF, alt[1] == 0xFFFFFFFF)
         return got
 
     S = int(rs.randint(1, 6))
@@ -212,7 +219,7 @@ def test_fuzz_matrix_core_kernels(engine, trial):
     kw = dict(mod=mod, M=M, nt=4, nr=4, fft_size=fft, cp_size=cp, num_used=used, n_ofdm_sym=n_sym, snr_db=snr, mmse=mmse)
     want = _oracle(chains.chain_mimo_ofdm, first, count, **kw)
     _check(*both(lambda: engine.run_mimo_ofdm(4, 4, fft, cp, used, n_sym, nv, SEED, first, count, mmse=mmse, method=method,
-                                              dtype="f32", per_realization=True)), want, "f32", ("mimo_ofdm", kw))
+                                              dtype="f32", per_realization=True), f32_mfma=1), want, "f32", ("mimo_ofdm", kw))
     # config 2 (k_run_flat_mfma: 8 / 16 rays): any length (ragged quads, groups, chunks), sampling time and Doppler
     N = int(rs.choice([rs.randint(1, 70), rs.randint(70, 5000), 16384 + rs.randint(0, 3000)]))
     Lf, Tsf, Fdf = int(rs.choice([8, 16])), float(10.0 ** rs.uniform(-5, -2.5)), float(rs.uniform(1, 300))

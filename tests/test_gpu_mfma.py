@@ -17,7 +17,7 @@ SEED = 424242
 
 
 def _run(engine, first, count, mfma=True, variant=None, **kw):
-    with engine.options(no_mfma=0 if mfma else 1, mfma_variant=int(variant or 0)):
+    with engine.options(no_mfma=0 if mfma else 1, mfma_variant=int(variant or 0), f32_mfma=1 if mfma else 0):
         nv = 1.0 / omodem.dB2Linear(kw.get("snr_db", 25.0))
         return engine.run_mimo_ofdm(4, 4, 1024, kw.get("cp_size", 16), kw.get("num_used") or 1024,
                                     kw.get("n_ofdm_sym", 1), nv, SEED, first, count, mmse=kw.get("mmse", True),

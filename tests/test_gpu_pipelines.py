@@ -300,7 +300,7 @@ def test_full_size_properties_c2_c3(engine):
 def test_pipeline_argument_errors(engine):
     engine.set_constellation(chains.constellation("qam", 16), _lib.CONST_QAM)
     with pytest.raises(_lib.McleError):
-        engine.run_mimo_ofdm(3, 3, 1024, 16, 1024, 1, 0.1, SEED, 0, 4, dtype="f32")     # (complex128 takes 3x3 since round 4)
+        engine.run_mimo_ofdm(3, 3, 128, 16, 128, 1, 0.1, SEED, 0, 4, dtype="f32")       # (3x3: the planar family only, fft_size >= 256)
     with pytest.raises(_lib.McleError):
         engine.run_mimo_ofdm(4, 3, 1024, 16, 1024, 1, 0.1, SEED, 0, 4)                  # more transmit than receive antennas
     with pytest.raises(_lib.McleError):
