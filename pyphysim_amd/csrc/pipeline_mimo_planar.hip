@@ -309,22 +309,12 @@ __device__ __forceinline__ void r16_wave_sync() {
 // EXACT: the nine layer-1 twiddles of q >= 1, w^((k + 64 q) m) / w^(16 (k4 + 4 q) m), fetched from the (L1-resident) table at the
 // top of the pass instead of formed as register twiddle x constant 16th root: eight complex multiplications less per pass, and
 // the pass becomes the radix-4 stages' arithmetic operation for operation (bit-identical outputs).
-// OWNTW: the pass fetches its six twiddles itself (L1-resident table) instead of taking them from `tw` -- twelve register pairs
-// less to carry through a transform where the register bound is tight (complex64 at four wavefronts per SIMD).
-template <typename T, bool INV, bool DIT, int WHICH, bool EXACT = false, bool OWNTW = false>
+template <typename T, bool INV, bool DIT, int WHICH, bool EXACT = false>
 __device__ __forceinline__ void r16_pass(T* pr, T* pi, int base_slot, const R16Tw64<T>& tw,
                                          const cx<T>* __restrict__ g_tw = nullptr, int kidx = 0) {
     constexpr int QS = WHICH == 0 ? 64 : 4, MS = WHICH == 0 ? 256 : 16;
-    cx<T> own1[3], own2[3];
-    if constexpr (OWNTW) {
-#pragma unroll
-        for (int j = 1; j <= 3; ++j) {
-            own1[j - 1] = g_tw[(WHICH == 0 ? kidx : 16 * kidx) * j];
-            own2[j - 1] = g_tw[(WHICH == 0 ? 4 * kidx : 64 * kidx) * j];
-        }
-    }
-    const cx<T>* t1 = OWNTW ? own1 : WHICH == 0 ? tw.a1 : tw.b1;
-    const cx<T>* t2 = OWNTW ? own2 : WHICH == 0 ? tw.a2 : tw.b2;
+    const cx<T>* t1 = WHICH == 0 ? tw.a1 : tw.b1;
+    const cx<T>* t2 = WHICH == 0 ? tw.a2 : tw.b2;
     [[maybe_unused]] cx<T> tq[3][3];                      // [q - 1][m - 1]
     if constexpr (EXACT) {
 #pragma unroll
@@ -419,29 +409,29 @@ template <typename T, bool INV> __device__ __forceinline__ void r16_pass_c(T* pr
     }
 }
 // natural -> digit-reversed (the arrangement of the radix-4 DIF stages) / digit-reversed -> natural; one wavefront, one antenna
-template <typename T, bool INV, bool WITH_C = true, bool EXACT = false, bool OWNTW = false>
+template <typename T, bool INV, bool WITH_C = true, bool EXACT = false>
 __device__ __forceinline__ void r16_dif(T* pr, T* pi, int lane, const R16Tw64<T>& tw, const cx<T>* __restrict__ g_tw = nullptr) {
     int gi = opaque(lane);
-    r16_pass<T, INV, false, 0, EXACT, OWNTW>(pr, pi, lds_swz16f(gi), tw, g_tw, gi);
+    r16_pass<T, INV, false, 0, EXACT>(pr, pi, lds_swz16f(gi), tw, g_tw, gi);
     r16_wave_sync();
     gi = opaque(lane);
-    r16_pass<T, INV, false, 1, EXACT, OWNTW>(pr, pi, lds_swz16f(64 * (gi >> 2) + (gi & 3)), tw, g_tw, gi & 3);
+    r16_pass<T, INV, false, 1, EXACT>(pr, pi, lds_swz16f(64 * (gi >> 2) + (gi & 3)), tw, g_tw, gi & 3);
     if constexpr (WITH_C) {
         r16_wave_sync();
         r16_pass_c<T, INV>(pr, pi, opaque(lane));
     }
 }
-template <typename T, bool INV, bool WITH_C = true, bool EXACT = false, bool OWNTW = false>
+template <typename T, bool INV, bool WITH_C = true, bool EXACT = false>
 __device__ __forceinline__ void r16_dit(T* pr, T* pi, int lane, const R16Tw64<T>& tw, const cx<T>* __restrict__ g_tw = nullptr) {
     if constexpr (WITH_C) {
         r16_pass_c<T, INV>(pr, pi, opaque(lane));
         r16_wave_sync();
     }
     int gi = opaque(lane);
-    r16_pass<T, INV, true, 1, EXACT, OWNTW>(pr, pi, lds_swz16f(64 * (gi >> 2) + (gi & 3)), tw, g_tw, gi & 3);
+    r16_pass<T, INV, true, 1, EXACT>(pr, pi, lds_swz16f(64 * (gi >> 2) + (gi & 3)), tw, g_tw, gi & 3);
     r16_wave_sync();
     gi = opaque(lane);
-    r16_pass<T, INV, true, 0, EXACT, OWNTW>(pr, pi, lds_swz16f(gi), tw, g_tw, gi);
+    r16_pass<T, INV, true, 0, EXACT>(pr, pi, lds_swz16f(gi), tw, g_tw, gi);
 }
 
 // N, NT x NR: the geometry.  AH = antennas per thread in the transform stages, TB = (N / 4) (NR / AH) threads per
@@ -468,7 +458,6 @@ __global__ __launch_bounds__((N / 4) * (NR / AH), WPS) void k_run_mimo_ofdm_plan
     constexpr bool R16 = (VAR & 4) != 0;                                    // radix-16 passes, one transform per wavefront
     constexpr bool FUSED = R16 && (VAR & 8) != 0;                           // ... with pass C, the channel and pass C' as one stage
     constexpr bool EXACT = R16 && (VAR & 16) != 0;                          // ... with every layer-1 twiddle from the table
-    constexpr bool OWNTW = R16 && (VAR & 32) != 0;                          // ... with each pass fetching its own six twiddles
     static_assert(!R16 || (N == 1024 && NR == 4 && AH == 4), "radix-16 variant: 1024, four receive antennas, 256 threads");
     constexpr bool TWR = AH == NR && N == 1024 && !R16;                     // a thread's twiddles in registers
     auto swz = [](int e) { return R16 ? lds_swz16f(e) : lds_swz64(e); };
@@ -508,8 +497,11 @@ __global__ __launch_bounds__((N / 4) * (NR / AH), WPS) void k_run_mimo_ofdm_plan
     TwRegs64<T, N> twr;
     if constexpr (TWR) twr = load_tw64<T, N>(g_tw, bbt);
     [[maybe_unused]] R16Tw64<T> tw16;
-    constexpr bool TW16_RELOAD = (FUSED || sizeof(T) == 4) && !OWNTW;               // fetched at the top of each transform instead (24 register pairs
-    if constexpr (R16 && !TW16_RELOAD && !OWNTW) tw16 = load_r16_tw<T>(g_tw, lane);     // that the channel and the decode do not have to carry)
+    // fused form: fetched at the top of each transform instead (24 register pairs the fused stage does not have to carry).  The
+    // complex64 unfused form keeps them: fetched per transform (or per pass) its spills fall from 29 to 13 registers, all of them
+    // loop invariants parked outside the hot loops, and the loads land on the critical path -- 5.19 against 4.88 ms.
+    constexpr bool TW16_RELOAD = FUSED;
+    if constexpr (R16 && !TW16_RELOAD) tw16 = load_r16_tw<T>(g_tw, lane);
     [[maybe_unused]] T* s_wave_re = s_d + (2 * w) * N;      // variant 4: wavefront w owns antenna w's transform
     [[maybe_unused]] T* s_wave_im = s_wave_re + N;
     uint64_t it = 0, rl_prev = 0;
@@ -591,7 +583,7 @@ __global__ __launch_bounds__((N / 4) * (NR / AH), WPS) void k_run_mimo_ofdm_plan
             //      measured no gain).  Antenna groups beyond Nt have nothing to send and only keep the barriers. ----
             if constexpr (R16) {
                 if constexpr (TW16_RELOAD) tw16 = load_r16_tw<T>(g_tw, opaque(lane));
-                if (NT == NR || w < NT) r16_dif<T, true, !FUSED, EXACT, OWNTW>(s_wave_re, s_wave_im, lane, tw16, g_tw);   // wavefront = antenna
+                if (NT == NR || w < NT) r16_dif<T, true, !FUSED, EXACT>(s_wave_re, s_wave_im, lane, tw16, g_tw);   // wavefront = antenna
                 __syncthreads();
             } else
             static_for<N4>([&](auto stc) {
@@ -730,7 +722,7 @@ __global__ __launch_bounds__((N / 4) * (NR / AH), WPS) void k_run_mimo_ofdm_plan
             // ---- FFT: (the radix-2 stage +) radix-4 DIT, digit-reversed -> natural bins ----
             if constexpr (R16) {
                 if constexpr (TW16_RELOAD) tw16 = load_r16_tw<T>(g_tw, opaque(lane));
-                r16_dit<T, false, !FUSED, EXACT, OWNTW>(s_wave_re, s_wave_im, lane, tw16, g_tw);
+                r16_dit<T, false, !FUSED, EXACT>(s_wave_re, s_wave_im, lane, tw16, g_tw);
                 __syncthreads();
             } else if constexpr (TWR) {
                 if constexpr (SH::HAS2) {
@@ -933,8 +925,6 @@ static int run_mimo_ofdm_planar_t(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, 
             // complex64: the SEPARATE channel stage at a four-wavefront register bound is the fast form (4.88 ms per 262 144
             // realizations; fused 5.08; at a three-wavefront bound 5.26 / 5.47; the matrix-core kernel 5.89 -- min-distance
             // demodulator, profiles/r04/c4_f32_planar_ab.log); 259 = fused, 257 = the three-wavefront bound (A/B)
-            if (ctx->opt[MCLE_OPT_F64_THREADS] == 258)      // each pass fetches its own twiddles (A/B)
-                return launch_mimo_ofdm_planar<T, 1024, 4, 4, 4, 4, 36>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
             if (ctx->opt[MCLE_OPT_F64_THREADS] == 259)
                 return launch_mimo_ofdm_planar<T, 1024, 4, 4, 4, 4, 12>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
             if (ctx->opt[MCLE_OPT_F64_THREADS] == 257)

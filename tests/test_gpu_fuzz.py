@@ -14,6 +14,7 @@ pytestmark = pytest.mark.gpu
 SEED = 20260927
 N_TRIALS = int(os.environ.get("MCLE_FUZZ_TRIALS_BASE", "6"))        # raise for a long hunt on the GPU box
 OFFSET = int(os.environ.get("MCLE_FUZZ_OFFSET", "0"))               # shifts every trial's random configuration
+N_MFMA_TRIALS_EARLY = int(os.environ.get("MCLE_FUZZ_TRIALS", "10"))
 MODS = [("bpsk", 2), ("qpsk", 4), ("psk", 8), ("psk", 16), ("qam", 4), ("qam", 16), ("qam", 64), ("qam", 256)]
 
 
@@ -124,6 +125,39 @@ def test_fuzz_ofdm_chains(engine, dt, trial):
     except _lib.McleUnsupported:
         return          # Doppler beyond the fused kernel's tap model (the simulator runs the staged chain then)
     _check(*got, _oracle(chains.chain_mimo_ofdm_tdl, first, count, **kw), dt, ("mimo_ofdm_tdl", kw))
+
+
+@pytest.mark.parametrize("dt", ["f64", "f32"])
+@pytest.mark.parametrize("trial", range(N_MFMA_TRIALS_EARLY))
+def test_fuzz_planar_family(engine, dt, trial):
+    """The planar MIMO-OFDM kernel family (csrc/pipeline_mimo_planar.hip, both arithmetics): random geometry -- fft_size
+    256 .. 2048, any 1 <= Nt <= Nr <= 4 -- cyclic prefix (odd ones take the unpaired noise draws), band, symbol count,
+    modulation, demodulator, filter and realization offset, against the oracle on the same draws; where the generic radix-4
+    kernel has the shape, against that one too."""
+    rs = np.random.RandomState(900 + trial + 1000 * OFFSET)
+    mod, M = MODS[1 + rs.randint(len(MODS) - 1)]
+    _bind(engine, mod, M)
+    fft = int(rs.choice([256, 512, 1024, 1024, 2048]))
+    nr = int(rs.randint(1, 4)) + 1
+    nt = int(rs.randint(1, nr + 1))
+    cp = int(rs.choice([0, 1, 7, 16, 33, rs.randint(0, fft // 4)]))
+    used = int(rs.choice([fft, fft, 2 * rs.randint(1, fft // 2), 16 * rs.randint(1, fft // 16)]))
+    n_sym = int(rs.randint(1, 4))
+    snr = _snr_for(rs, M) + 6.0
+    nv = 1.0 / omodem.dB2Linear(snr)
+    mmse = bool(rs.randint(2))
+    method = _lib.DEMOD_QAM_SLICER if (mod == "qam" and rs.randint(2)) else _lib.DEMOD_MINDIST
+    first, count = int(rs.randint(0, 1 << 33)), int(rs.randint(1, 5))
+    kw = dict(mod=mod, M=M, nt=nt, nr=nr, fft_size=fft, cp_size=cp, num_used=used, n_ofdm_sym=n_sym, snr_db=snr, mmse=mmse)
+    want = _oracle(chains.chain_mimo_ofdm, first, count, **kw)
+    run = lambda: engine.run_mimo_ofdm(nt, nr, fft, cp, used, n_sym, nv, SEED, first, count, mmse=mmse, method=method, dtype=dt,
+                                       per_realization=True)
+    got = run()
+    _check(*got, want, dt, ("planar", dt, kw, method))
+    if nt == nr and nr in (2, 4) and not (dt == "f64" and (fft, nr) == (2048, 4)):
+        with engine.options(f64_generic=1):
+            ref = run()
+        assert np.max(np.abs(got[1].astype(np.int64) - ref[1].astype(np.int64))) <= (1 if dt == "f64" else 4), ("vs generic", kw)
 
 
 @pytest.mark.parametrize("dt", ["f64", "f32"])
