@@ -69,9 +69,9 @@ FP32_PEAK_TFLOPS = 157.3    # same guide: FP32 vector peak = FP32-input MFMA pea
 FP64_PEAK_TFLOPS = 78.6
 FP64_MEASURED = {"v_mfma_f64_16x16x4_f64": 77.6, "v_fma_f64": 65.9, "source": "profiles/r03/f64_rates.txt"}
 PEAK_TFLOPS = {"f32": FP32_PEAK_TFLOPS, "f64": FP64_PEAK_TFLOPS}
-KERNEL = {"c4": "k_run_mimo_ofdm_planar", "c2": "k_run_flat_mfma", "c3": "k_run_ofdm_tdl_mfma", "c5": "k_ia_link",
+KERNEL = {"c4": "k_run_mimo_ofdm_planar", "c2": "k_run_flat_mfma", "c3": "k_run_ofdm_tdl_wave", "c5": "k_ia_link",
           "f1": "k_run_mimo_ofdm_tdl", "f6": "k_bd_link"}
-KERNEL_F64 = {"c4": "k_run_mimo_ofdm_planar", "c2": "k_run_flat", "c3": "k_run_ofdm_tdl_batch", "c5": "k_ia_link",
+KERNEL_F64 = {"c4": "k_run_mimo_ofdm_planar", "c2": "k_run_flat", "c3": "k_run_ofdm_tdl_wave", "c5": "k_ia_link",
               "f1": "k_run_mimo_ofdm_tdl", "f6": "k_bd_link"}
 
 
@@ -83,6 +83,8 @@ def kernel_name(cfg, dtype):
         return "k_run_mimo_ofdm_mfma"                 # the matrix-core kernel of rounds 2-3 (option f32_mfma = 1)
     if cfg == "c4" and ACTIVE_OPTS.get("f64_generic") or (cfg == "c4" and dtype == "f32" and ACTIVE_OPTS.get("no_mfma")):
         return "k_run_mimo_ofdm<"                     # the generic radix-4 kernel
+    if cfg == "c3" and (ACTIVE_OPTS.get("tdl_kernel") == 1 or ACTIVE_OPTS.get("no_mfma")):
+        return "k_run_ofdm_tdl_batch" if (dtype == "f64" or ACTIVE_OPTS.get("no_mfma")) else "k_run_ofdm_tdl_mfma"
     return (KERNEL_F64 if dtype == "f64" else KERNEL)[cfg]
 
 KERNEL_NOTE = {   # configs whose step is two launches: the time spans both, the counters are the named (dominant) kernel's
@@ -92,11 +94,13 @@ KERNEL_NOTE = {   # configs whose step is two launches: the time spans both, the
           "kernel_ms_per_launch spans them",
     ("c4", "f64"): "a step = per slice of 2^18 realizations k_mimo_filters_planar (channel draw + f64 receive filter, one thread per "
                    "realization, ~1 % of the time) + k_run_mimo_ofdm_planar; kernel_ms_per_launch spans them",
-    ("c3", "f64"): "a step = k_tdl_symbol_polys<double> (fading records) + k_run_ofdm_tdl_batch<double, 1024, 2> per slice of <= 64 MiB "
-                   "of records; kernel_ms_per_launch spans them",
+    ("c3", "f64"): "a step = k_tdl_symbol_polys<double> (fading records) + k_run_ofdm_tdl_wave<double> (one realization per "
+                   "wavefront; option tdl_kernel=1: k_run_ofdm_tdl_batch<double, 1024, 2>) per slice of <= 64 MiB of records; "
+                   "kernel_ms_per_launch spans them",
     "f1": "a step = k_mimo_tdl_symbol_polys (the symbols' fading records, one thread per fading process) + k_run_mimo_ofdm_tdl per "
           "slice of <= 256 MiB of records; kernel_ms_per_launch spans them",
-    "c3": "a step = k_tdl_symbol_polys (fading records) + k_run_ofdm_tdl_mfma per slice of <= 64 MiB of records; "
+    "c3": "a step = k_tdl_symbol_polys (fading records) + k_run_ofdm_tdl_wave<float> (one realization per wavefront, default since "
+          "round 4; option tdl_kernel=1: the matrix-core kernel k_run_ofdm_tdl_mfma) per slice of <= 64 MiB of records; "
           "kernel_ms_per_launch spans them",
     "c5": "a step = k_ia_solve_links (per-lane solve, ~18 % of the time) + k_ia_link (symbol walk); kernel_ms_per_launch spans both",
     "f6": "a step = k_bd_solve_links (per-lane solve) + k_bd_link (symbol walk); kernel_ms_per_launch spans both"}

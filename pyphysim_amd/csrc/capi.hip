@@ -173,6 +173,7 @@ int mcle_ctx_set_option(mcle_ctx* ctx, int option, long long value) {
     bool ok = false;
     switch (option) {
         case MCLE_OPT_NO_MFMA: case MCLE_OPT_SINGLE_TDL: case MCLE_OPT_JAKES_DIRECT: case MCLE_OPT_F64_GENERIC: case MCLE_OPT_BD_RUNTIME_SOLVE: case MCLE_OPT_DEMOD_NOCERT: case MCLE_OPT_F32_MFMA: ok = value == 0 || value == 1; break;
+        case MCLE_OPT_TDL_KERNEL: ok = value == 0 || value == 1 || value == 4; break;
         case MCLE_OPT_F64_VARIANT: ok = value >= 0 && value <= 3; break;
         case MCLE_OPT_MFMA_VARIANT: ok = value == 0 || value == 36 || value == 32 || value == 30 || value == 21; break;
         case MCLE_OPT_GRID_OVERSUB: ok = value >= 0 && value <= 64; break;
@@ -422,6 +423,25 @@ int mcle_set_constellation(mcle_ctx* ctx, const double* re_im, int M, int kind) 
     ctx->kind = kind;
     ctx->qam_scale = scale;
     ctx->qam_L = L;
+    ctx->quad_ok = 0;
+    if (M == 4) {                               // one point per quadrant at (+-a, +-b): decisions by the signs (demod_quad_cert)
+        const double a = std::fabs(re_im[0]), b = std::fabs(re_im[1]);
+        unsigned lut = 0, seen = 0;
+        bool ok = a > 0.0 && b > 0.0;
+        for (int m = 0; m < 4 && ok; ++m) {
+            const double re = re_im[2 * m], im = re_im[2 * m + 1];
+            ok = std::fabs(std::fabs(re) - a) <= 1e-12 * a && std::fabs(std::fabs(im) - b) <= 1e-12 * b;
+            const unsigned q = (re < 0.0 ? 1u : 0u) | (im < 0.0 ? 2u : 0u);
+            seen |= 1u << q;
+            lut |= (unsigned)m << (8 * q);
+        }
+        if (ok && seen == 0xFu) {
+            ctx->quad_ok = 1;
+            ctx->quad_lut = lut;
+            ctx->quad_min = a < b ? a : b;
+            ctx->quad_max = a < b ? b : a;
+        }
+    }
     return MCLE_OK;
 }
 

@@ -179,6 +179,11 @@ struct mcle_ctx {
     double2* d_table_f64 = nullptr;
     double qam_scale = 0.0;  // sqrt(2(M-1)/3) for square QAM
     int qam_L = 0;
+    // four points, one per quadrant, mirror images of one another in both axes (QPSK = PSK(4) with its pi / 4 offset): the
+    // min-distance regions are the quadrants -- modem.hpp: demod_quad_cert.  quad_lut: label of quadrant (re < 0) | (im < 0) << 1
+    int quad_ok = 0;
+    unsigned quad_lut = 0;
+    double quad_min = 0.0, quad_max = 0.0;   // min / max of the points' |re|, |im|
     // candidate grid of the pruned f32 min-distance search (modem.hpp: DemodGrid); grid_G == 0: none
     unsigned long long* d_grid = nullptr;
     int grid_G = 0;

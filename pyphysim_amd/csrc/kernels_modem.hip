@@ -21,7 +21,7 @@ template <> ModemParams<float> modem_params<float>(const mcle_ctx* ctx, int meth
     p.qam_scale = (float)ctx->qam_scale;
     p.qam_L = ctx->qam_L;
     p.half_bits = ctx->bits / 2;
-    p.cert = modem_cert(ctx, method);
+    modem_fill_cert(ctx, method, p);
     return p;
 }
 template <> ModemParams<double> modem_params<double>(const mcle_ctx* ctx, int method) {
@@ -34,7 +34,7 @@ template <> ModemParams<double> modem_params<double>(const mcle_ctx* ctx, int me
     p.qam_scale = ctx->qam_scale;
     p.qam_L = ctx->qam_L;
     p.half_bits = ctx->bits / 2;
-    p.cert = modem_cert(ctx, method);
+    modem_fill_cert(ctx, method, p);
     return p;
 }
 

@@ -28,7 +28,10 @@ template <typename T> struct ModemParams {
     T qam_scale;     // sqrt(2(M-1)/3)
     int qam_L;       // sqrt(M)
     int half_bits;   // bits/2
-    int cert;        // 1: min-distance decisions of a square Gray QAM through the margin certificate (demod_qam_cert)
+    int cert;        // 1: min-distance decisions of a square Gray QAM through the margin certificate (demod_qam_cert);
+                     // 2: of a four-point one-per-quadrant constellation (QPSK) through the quadrant certificate (demod_quad_cert)
+    unsigned quad_lut;   // cert == 2: label of quadrant (re < 0) | (im < 0) << 1, a byte each
+    T quad_lo, quad_hi;  // cert == 2: the certificate holds for lo <= |re|, |im| <= hi
 };
 
 // exhaustive minimum distance over a table held in LDS; strict '<' keeps the FIRST minimum,
@@ -369,12 +372,30 @@ __device__ __forceinline__ int demod_qam_cert(cx<T> r, T scale, int L, int half_
     return (int)(((v >> 8) << half_bits) | (v & 0xFFu));
 }
 
+// Min-distance decision of four points (+-a, +-b), one per quadrant, WITHOUT touching the table: the regions are the quadrants.
+// Two candidates mirrored in an axis differ by 4 a |re| (4 b |im|) in squared distance, by >= a |re| / |d| in distance (NumPy
+// compares |c - r|); with lo = 2^-30 min(a, b) <= |re|, |im| <= hi = 2^8 max(a, b) that is >= 2^-39 a against a rounding of
+// <= 2^-43 a of either metric in complex128 -- the sweep, first-minimum rule included, returns this very label: `sure`.
+// Outside (a point on an axis to 1e-9, or an equaliser output beyond 256 a in a deep fade: both rare) the caller searches the
+// table as before.  complex64: lo = 2^-15 min(a, b), the same figure as the QAM certificate's.
+template <typename T>
+__device__ __forceinline__ int demod_quad_cert(cx<T> r, unsigned lut, T lo, T hi, bool& sure) {
+    const T ax = fabs(r.x), ay = fabs(r.y);
+    sure = ax >= lo && ay >= lo && ax <= hi && ay <= hi;             // NaN: not sure
+    const unsigned q = (r.x < (T)0 ? 8u : 0u) | (r.y < (T)0 ? 16u : 0u);
+    return (int)((lut >> q) & 0xFFu);
+}
+template <typename T> __device__ __forceinline__ int demod_cert_any(const ModemParams<T>& mp, cx<T> r, bool& sure) {
+    if (mp.cert == 2) return demod_quad_cert<T>(r, mp.quad_lut, mp.quad_lo, mp.quad_hi, sure);
+    return demod_qam_cert<T>(r, mp.qam_scale, mp.qam_L, mp.half_bits, sure);
+}
+
 template <typename T>
 __device__ __forceinline__ int demod_one(const ModemParams<T>& mp, const cx<T>* s_table, cx<T> r) {
     if (mp.method == MCLE_DEMOD_QAM_SLICER) return demod_qam_slicer<T>(r, mp.qam_scale, mp.qam_L, mp.half_bits);
     if (mp.cert) {
         bool sure;
-        const int dec = demod_qam_cert<T>(r, mp.qam_scale, mp.qam_L, mp.half_bits, sure);
+        const int dec = demod_cert_any<T>(mp, r, sure);
         if (sure) return dec;
     }
     return demod_mindist<T>(s_table, mp.M, r);
@@ -386,7 +407,7 @@ __device__ __forceinline__ int demod_one(const ModemParams<T>& mp, const cx<T>* 
     if (mp.method == MCLE_DEMOD_QAM_SLICER) return demod_qam_slicer<T>(r, mp.qam_scale, mp.qam_L, mp.half_bits);
     if (mp.cert) {
         bool sure;
-        const int dec = demod_qam_cert<T>(r, mp.qam_scale, mp.qam_L, mp.half_bits, sure);
+        const int dec = demod_cert_any<T>(mp, r, sure);
         if (sure) return dec;
     }
     if (mp.grid.G > 0) return demod_grid(s_table, s_grid, mp.grid, mp.M, r);   // G == 0: no grid bound to this launch
@@ -403,7 +424,7 @@ __device__ __forceinline__ void demod_multi_cert(const ModemParams<T>& mp, const
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             bool sure;
-            idx[k] = demod_qam_cert<T>(r[k], mp.qam_scale, mp.qam_L, mp.half_bits, sure);
+            idx[k] = demod_cert_any<T>(mp, r[k], sure);
             all = all && sure;
         }
         if (all) return;
@@ -425,11 +446,20 @@ template <typename T> inline DemodGrid context_grid(const mcle_ctx* ctx, int met
 
 // host: does a launch with this method decide through the margin certificate (demod_qam_cert)?
 inline int modem_cert(const mcle_ctx* ctx, int method) {
-    return (method == MCLE_DEMOD_MINDIST && ctx->kind == MCLE_CONST_QAM && ctx->qam_L >= 2 && ctx->qam_L <= 256 &&
-            !ctx->opt[MCLE_OPT_DEMOD_NOCERT]) ? 1 : 0;
+    if (method != MCLE_DEMOD_MINDIST || ctx->opt[MCLE_OPT_DEMOD_NOCERT]) return 0;
+    if (ctx->kind == MCLE_CONST_QAM && ctx->qam_L >= 2 && ctx->qam_L <= 256) return 1;
+    return ctx->quad_ok ? 2 : 0;
 }
 
 // cooperative copy of the constellation into LDS (call before a __syncthreads())
+// host: the certificate fields of a launch's modem parameters
+template <typename T> inline void modem_fill_cert(const mcle_ctx* ctx, int method, ModemParams<T>& p) {
+    p.cert = modem_cert(ctx, method);
+    p.quad_lut = ctx->quad_lut;
+    p.quad_lo = (T)(ctx->quad_min * (sizeof(T) == 8 ? 0x1p-30 : 0x1p-15));
+    p.quad_hi = (T)(ctx->quad_max * 256.0);
+}
+
 template <typename T>
 __device__ __forceinline__ void load_table(const ModemParams<T>& mp, cx<T>* s_table) {
     for (int m = threadIdx.x; m < mp.M; m += blockDim.x) s_table[m] = mp.g_table[m];

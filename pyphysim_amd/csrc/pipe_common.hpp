@@ -61,7 +61,7 @@ template <typename T> ModemParams<T> pipe_modem(const mcle_ctx* ctx, int method)
     p.qam_scale = (T)ctx->qam_scale;
     p.qam_L = ctx->qam_L;
     p.half_bits = ctx->bits / 2;
-    p.cert = modem_cert(ctx, method);
+    modem_fill_cert(ctx, method, p);
     return p;
 }
 

@@ -19,6 +19,7 @@
 
 #include "fft.hpp"
 #include "fft16.hpp"
+#include "fft_r16.hpp"
 #include "jakes.hpp"
 #include "modem.hpp"
 #include "philox.hpp"
@@ -878,11 +879,392 @@ int run_siso_tdl_mfma(mcle_ctx* ctx, const SisoTdlParams& pp, int method, uint64
     return MCLE_OK;
 }
 
+
+// ---- config 3, ONE REALIZATION PER WAVEFRONT (round 4, late): FFT 1024, every delayed sample inside the symbol's own prefix ----
+// The batched kernels above share every transform stage between the 256 threads of a workgroup: a dozen (k_run_ofdm_tdl_batch) or
+// four (k_run_ofdm_tdl_mfma) workgroup barriers per OFDM symbol, and the matrix-core kernel -- the default of rounds 2-3 -- left the
+// SIMDs idle a third of the time (VALU busy 0.50 + MFMA busy 0.14, profiles/r04/c3_pmc_summary.json).  Here a wavefront owns a
+// realization from its first data word to its error count: the radix-16 register passes of fft_r16.hpp (one 1024-point transform
+// per wavefront, planar LDS samples, three LDS round trips per transform) make the transforms wave-local, the tap delay line
+// reads x[m - d] from the wavefront's own planes, and NOTHING in the loop is a workgroup barrier -- four (complex128: two) such
+// wavefronts per SIMD run out of step and fill one another's stalls.  Wave-uniform data (the symbol's tap polynomials and
+// tap means) comes through scalar loads.  The noise of samples m, m + 1 -- one NOISE block -- belongs to lanes l, l + 1: the even
+// lane draws the blocks of eight of the sixteen samples a lane holds, the odd lane those of the other eight, and a DPP lane swap
+// hands over the halves (every block computed once: the draw ledger is unchanged).
+// Same arithmetic as k_run_ofdm_tdl_batch operation for operation outside the transforms (polynomial Horner, tap order,
+// equaliser), so complex128 counts equal the oracle's like that kernel's.
+constexpr int kWaveMaxTaps = 8;
+template <typename T> __device__ __forceinline__ T dpp_swap1(T v);
+template <> __device__ __forceinline__ float dpp_swap1<float>(float v) {         // the value of lane l ^ 1
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));
+}
+// lane j's value of a VGPR as a wave-uniform scalar (j wave-uniform)
+__device__ __forceinline__ float lane_value(float v, int j) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), j)); }
+__device__ __forceinline__ double lane_value(double v, int j) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), j), __builtin_amdgcn_readlane(__double2loint(v), j));
+}
+template <> __device__ __forceinline__ double dpp_swap1<double>(double v) {
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0xB1, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0xB1, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+
+template <typename T, int KT, int WPS>
+__global__ __launch_bounds__(256, WPS) void k_run_ofdm_tdl_wave(SisoTdlParams pp, ModemParams<T> mp, uint64_t seed, uint64_t first,
+                                                                uint64_t count, const cx<T>* __restrict__ g_tw,
+                                                                const cx<T>* __restrict__ g_polys, mcle_counters* counters,
+                                                                uint32_t* __restrict__ sym_out, uint32_t* __restrict__ bit_out) {
+    constexpr int N = 1024;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int S = pp.n_taps, K = KT > 0 ? KT : pp.K;
+    const int U = pp.num_used, cp = pp.cp, W = N + cp;
+    // A wavefront's sample memory: two planes of `pitch` = N + P scalars (P = the largest tap delay rounded up to 16).  During
+    // the transforms a plane holds the N swizzled elements (fft_r16.hpp); between them it is the time signal WITH ITS CYCLIC
+    // PREFIX in natural order -- xp[P + m] = x[m], xp[j] = x[N - P + j] -- so that x[m - d] is an unswizzled read at a lane-linear
+    // address (base per tap + a compile-time offset per sample; conflict free: consecutive lanes, consecutive words).
+    const int pitch = pp.x_elems, P = pitch - N;
+    T* s_all = reinterpret_cast<T*>(smem);                                   // [4 wavefronts][2][pitch]
+    cx<T>* s_table = reinterpret_cast<cx<T>*>(s_all + 4 * 2 * pitch);       // [M rounded to 2]   shared, read-only in the loop
+    unsigned long long* s_grid = reinterpret_cast<unsigned long long*>(s_table + ((mp.M + 1) & ~1));   // [G * G]
+    // w^(F(64 k) d_s): the equaliser's twiddle of bin f = F(gi) + F(64 k) is w^(F(gi) d_s) (one gather per lane, tap and symbol)
+    // times this wave-uniform factor (an LDS broadcast) -- sixteen table gathers per lane and tap, 64 cache lines each, kept the
+    // L1 busier than the SIMDs
+    cx<T>* s_twk = reinterpret_cast<cx<T>*>(s_grid + ((mp.grid.G * mp.grid.G + 1) & ~1));   // [16][kWaveMaxTaps]
+    unsigned char* s_idx_all = reinterpret_cast<unsigned char*>(s_twk + 16 * kWaveMaxTaps);        // [4][U rounded to 16]
+    const int idx_pitch = (U + 15) & ~15;
+    T* pr = s_all + w * 2 * pitch;
+    T* pi = pr + pitch;
+    unsigned char* s_idx = s_idx_all + w * idx_pitch;
+    __shared__ double s_bm[sizeof(T) == 8 ? kBmLdsDoubles : 1];             // complex128 Box-Muller tables (bm_f64.hpp)
+    if constexpr (sizeof(T) == 8) bm_tables_to_lds(s_bm, (int)threadIdx.x, 256);
+    load_table(mp, s_table);
+    load_grid(mp, s_grid);
+    __shared__ WgTotals totals[4];
+    if (lane == 0) wg_zero(totals[w]);
+    if (threadIdx.x < 16 * kWaveMaxTaps) {
+        const int k = (int)threadIdx.x / kWaveMaxTaps, ts = (int)threadIdx.x % kWaveMaxTaps;
+        const int fk = ((k & 3) << 2) | (k >> 2);
+        s_twk[threadIdx.x] = ts < S ? g_tw[(fk * pp.tap_delay[ts]) & (N - 1)] : mk<T>(0, 0);
+    }
+    __syncthreads();                                                        // the only workgroup barrier of the kernel
+
+    const T sigma = (T)sqrt(pp.noise_var);
+    const T tx_scale = (T)(1.0 / sqrt((double)(U + cp)));
+    const T rx_scale = (T)(sqrt((double)(U + cp)) / (double)N);
+    const uint32_t mask = (uint32_t)(mp.M - 1);
+    const double xc = 0.5 * (double)(W - 1);                                // centre of the symbol in local sample units
+    const int n_coef = S * (K + 1), rec_len = n_coef + S;
+    const R16Tw64<T> tw16 = load_r16_tw<T>(g_tw, lane);
+    int dly[kWaveMaxTaps];
+#pragma unroll
+    for (int s = 0; s < kWaveMaxTaps; ++s) dly[s] = s < S ? pp.tap_delay[s] : 0;
+
+    const uint64_t n_waves = (uint64_t)gridDim.x * 4;
+    for (uint64_t rl = (uint64_t)blockIdx.x * 4 + w; rl < count; rl += n_waves) {
+        const Rng rng(seed, first + rl);
+        unsigned se = 0, be = 0;
+        for (int os = 0; os < pp.n_ofdm_sym; ++os) {
+            const uint64_t sym0 = (uint64_t)os * W;
+            // the symbol's record (tap polynomials, tap means; rec_len <= 64 values): ONE coalesced load, value j parked in lane j,
+            // fetched here and first used after the transmit transform -- read at its points of use (scalar loads from the
+            // record) its latency stood in front of the channel and the equaliser of every realization
+            int gi = opaque(lane);
+            const cx<T> myrec = gi < rec_len ? g_polys[(rl * pp.n_ofdm_sym + os) * (uint64_t)rec_len + gi] : mk<T>(0, 0);
+            auto rec_at = [&](int j) -> cx<T> { return mk<T>(lane_value(myrec.x, j), lane_value(myrec.y, j)); };
+            r16_wave_sync();                                                // the previous symbol's equaliser has read the planes
+            // ---- transmit: symbols -> bins at digit-reversed positions (the DIT transform takes them from there) ----
+            if (U != N) {
+                for (int p = gi; p < N; p += 64) pr[p] = pi[p] = 0;
+                r16_wave_sync();
+            }
+            const uint64_t n_first = (uint64_t)os * U, n_last = n_first + U;
+            for (uint64_t blk = (n_first >> 4) + gi; blk <= ((n_last - 1) >> 4); blk += 64) {
+                const Words4 dw = rng.block(STREAM_DATA, (uint32_t)blk);
+                if (U == N && (U & 15) == 0) {           // full band on block boundaries: bin(d0 + j) = bin(d0) ^ j, and digit
+                    const int d0 = (int)((blk << 4) - n_first);              // reversal and swizzle are XOR-linear
+                    const int p0 = lds_swz16f(fft_pos_of_index<N>(ofdm_bin(d0, N, U)));
+                    *reinterpret_cast<uint4*>(s_idx + d0) = make_uint4(dw.w[0] & (mask * 0x01010101u), dw.w[1] & (mask * 0x01010101u),
+                                                                       dw.w[2] & (mask * 0x01010101u), dw.w[3] & (mask * 0x01010101u));
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        const int tx = (int)((dw.w[j >> 2] >> ((j & 3) * 8)) & mask);
+                        const cx<T> c = cscale(s_table[tx], tx_scale);
+                        const int pos = p0 ^ lds_swz16f(fft_pos_of_index<N>(j));
+                        pr[pos] = c.x;
+                        pi[pos] = c.y;
+                    }
+                    continue;
+                }
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const uint64_t n = (blk << 4) + j;
+                    if (n >= n_first && n < n_last) {
+                        const int tx = (int)((dw.w[j >> 2] >> ((j & 3) * 8)) & mask);
+                        const int d = (int)(n - n_first);
+                        s_idx[d] = (unsigned char)tx;
+                        const cx<T> c = cscale(s_table[tx], tx_scale);
+                        const int pos = lds_swz16f(fft_pos_of_index<N>(ofdm_bin(d, N, U)));
+                        pr[pos] = c.x;
+                        pi[pos] = c.y;
+                    }
+                }
+            }
+            r16_wave_sync();
+            cx<T> y[16];                                                    // element gi + 64 q + 256 m' in y[q + 4 m']
+            r16_dit<T, true, true, false, true>(pr, pi, lane, tw16, g_tw, y);   // time samples; the last pass leaves them in registers
+            r16_wave_sync();                                                // every lane's reads of the planes are issued
+            gi = opaque(lane);
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {                                  // -> natural order behind the prefix
+                pr[P + gi + 64 * c] = y[c].x;
+                pi[P + gi + 64 * c] = y[c].y;
+            }
+#pragma unroll
+            for (int c = 12; c < 16; ++c)                                   // the prefix: the last P samples once more (P <= 256)
+                if (gi + 64 * c >= N - P) {
+                    pr[gi + 64 * c - (N - P)] = y[c].x;
+                    pi[gi + 64 * c - (N - P)] = y[c].y;
+                }
+            r16_wave_sync();
+            // ---- channel: y[m] = sum_s g_s(j) x[j],  j = cp + m - d_s, for this lane's sixteen samples m = gi + 64 c ----
+#pragma unroll
+            for (int c = 0; c < 16; ++c) y[c] = mk<T>(0, 0);
+            // (the tap loop is unrolled to kWaveMaxTaps with a wave-uniform guard: the delays and every index are compile-time
+            //  register names -- a run-time `pp.tap_delay[s]` is a scalar load from the kernel arguments on the critical path)
+#pragma unroll
+            for (int s = 0; s < kWaveMaxTaps; ++s) {
+                if (s >= S) break;
+                const int d = dly[s];
+                cx<T> cc[KT > 0 ? KT + 1 : 1];
+                if constexpr (KT > 0) {
+#pragma unroll
+                    for (int m = 0; m <= KT; ++m) cc[m] = rec_at(s * (K + 1) + m);
+                }
+                const T* xr = pr + (P + gi - d);                            // x[m - d] = xr[64 c]: d <= P
+                const T* xi = pi + (P + gi - d);
+                // (double) q - xc rounded to T, q = cp + m - d: q and xc are (half-)integers below 2^12 -- exact in float too
+                const T x0 = sizeof(T) == 8 ? (T)((double)(cp + gi - d) - xc) : (T)(cp + gi - d) - (T)xc;
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    const cx<T> xv = mk<T>(xr[64 * c], xi[64 * c]);
+                    const T xx = x0 + (T)(64 * c);                          // exact
+                    cx<T> g;
+                    if constexpr (KT > 0) {
+                        g = cc[KT];
+#pragma unroll
+                        for (int mm = KT - 1; mm >= 0; --mm) {
+                            g.x = fma(g.x, xx, cc[mm].x);
+                            g.y = fma(g.y, xx, cc[mm].y);
+                        }
+                    } else {
+                        g = rec_at(s * (K + 1) + K);
+                        for (int mm = K - 1; mm >= 0; --mm) {
+                            const cx<T> cm = rec_at(s * (K + 1) + mm);
+                            g.x = fma(g.x, xx, cm.x);
+                            g.y = fma(g.y, xx, cm.y);
+                        }
+                    }
+                    y[c] = cfma(g, xv, y[c]);
+                }
+            }
+            // ---- noise: sample sym0 + cp + m of the NOISE stream ----
+            const uint64_t nbase = sym0 + (uint64_t)cp;
+            if ((nbase & 1) == 0) {             // lanes l (even), l + 1 share the block of samples m, m + 1
+                const bool odd = (gi & 1) != 0;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int c = j + (odd ? 8 : 0);
+                    const int m = gi + 64 * (c & 3) + 256 * (c >> 2);
+                    cx<T> za, zb;
+                    cn_pair_lds(rng, STREAM_NOISE, (uint32_t)((nbase + (uint64_t)m) >> 1), sigma, za, zb, s_bm);
+                    const T sx = odd ? za.x : zb.x, sy = odd ? za.y : zb.y;      // what the partner needs
+                    const T rx = dpp_swap1<T>(sx), ry = dpp_swap1<T>(sy);
+                    const cx<T> lo = mk<T>(odd ? rx : za.x, odd ? ry : za.y);    // sample of combination j
+                    const cx<T> hi = mk<T>(odd ? zb.x : rx, odd ? zb.y : ry);    // sample of combination 8 + j
+                    y[j] = cadd(y[j], lo);
+                    y[8 + j] = cadd(y[8 + j], hi);
+                }
+            } else {                            // odd start: a block's samples sit on lanes of different pairs -- half of every block used
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    const int m = gi + 64 * (c & 3) + 256 * (c >> 2);
+                    const uint64_t i0 = nbase + (uint64_t)m;
+                    const Words4 b = rng.block(STREAM_NOISE, (uint32_t)(i0 >> 1));
+                    const uint32_t x0 = (i0 & 1) ? b.w[2] : b.w[0], x1 = (i0 & 1) ? b.w[3] : b.w[1];
+                    cx<T> z;
+                    if constexpr (sizeof(T) == 8) z = cn_from_words_lds(x0, x1, sigma, s_bm);
+                    else z = cn_from_words(x0, x1, sigma);
+                    y[c] = cadd(y[c], z);
+                }
+            }
+            r16_wave_sync();                                                // every lane's reads of the transmit samples are issued
+            // y[q + 4 m'] is element gi + 64 q + 256 m' -- what pass A of the forward transform takes: straight from the registers
+            r16_dif<T, false, true, false, true>(pr, pi, lane, tw16, g_tw, y);   // bins at digit-reversed positions
+            r16_wave_sync();
+            // ---- receive: one-tap equaliser from the tap means, demodulate, count -- POSITIONS gi, gi + 64, ...: position
+            //      p = p4 p3 p2 p1 p0 (base 4) holds bin f = p0 p1 p2 p3 p4, so f = F(gi) + F(64 k) with the second term a constant ----
+            gi = opaque(lane);
+            const int f_lane = ((gi & 3) << 8) | (((gi >> 2) & 3) << 6) | (((gi >> 4) & 3) << 4);
+            const int slot_lane = lds_swz16f(gi);
+            const int hU = U / 2;
+            cx<T> mean[kWaveMaxTaps];                                       // the symbol's tap means (wave-uniform) x w^(F(gi) d_s)
+#pragma unroll
+            for (int s = 0; s < kWaveMaxTaps; ++s)
+                mean[s] = s < S ? cmul(rec_at(n_coef + s), g_tw[(f_lane * dly[s]) & (N - 1)]) : mk<T>(0, 0);
+            // Eight subcarriers at a time as ONE straight-line region (loads batched, no branch per subcarrier): an in-order
+            // wavefront that stops at every table look-up of every subcarrier spent a third of its time in s_waitcnt.  The
+            // certificate's rare "not sure" is collected over the eight and served once, by the table search, behind them.
+            const bool slicer = mp.method == MCLE_DEMOD_QAM_SLICER;
+            const bool certpath = !slicer && mp.cert != 0;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                cx<T> eq[8];
+                int sent[8], dec[8];
+                bool valid[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int k = 8 * half + j;
+                    const int f = f_lane | ((k & 3) << 2) | (k >> 2);
+                    int d;                                                  // data position of bin f (inverse of ofdm_bin)
+                    if (U == N) {
+                        d = (f + N / 2) & (N - 1);
+                        valid[j] = true;
+                    } else {
+                        const bool neg = f >= N - hU, pos = f >= 1 && f <= hU;
+                        d = neg ? f - (N - hU) : (pos ? hU + f - 1 : 0);
+                        valid[j] = neg || pos;
+                    }
+                    const int bin = slot_lane ^ lds_swz16f(64 * k);
+                    eq[j] = cscale(mk<T>(pr[bin], pi[bin]), rx_scale);
+                    sent[j] = (int)s_idx[d];
+                }
+                cx<T> h[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) h[j] = mk<T>(0, 0);
+#pragma unroll
+                for (int s = 0; s < kWaveMaxTaps; ++s) {
+                    if (s >= S) break;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) h[j] = cfma(mean[s], s_twk[(8 * half + j) * kWaveMaxTaps + s], h[j]);
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    if constexpr (sizeof(T) == 8) {
+                        eq[j] = cdivide(eq[j], h[j]);
+                    } else {                    // complex64: one reciprocal instead of two divisions
+                        const T inv = __builtin_amdgcn_rcpf(h[j].x * h[j].x + h[j].y * h[j].y);
+                        eq[j] = mk<T>((eq[j].x * h[j].x + eq[j].y * h[j].y) * inv, (eq[j].y * h[j].x - eq[j].x * h[j].y) * inv);
+                    }
+                }
+                if (slicer) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) dec[j] = demod_qam_slicer<T>(eq[j], mp.qam_scale, mp.qam_L, mp.half_bits);
+                } else if (certpath) {
+                    bool unsure = false;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        bool sure;
+                        dec[j] = demod_cert_any<T>(mp, eq[j], sure);
+                        unsure = unsure || (valid[j] && !sure);
+                    }
+                    if (unsure) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) dec[j] = demod_one(mp, s_table, s_grid, eq[j]);
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) dec[j] = demod_one(mp, s_table, s_grid, eq[j]);
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const unsigned x = valid[j] ? (unsigned)(sent[j] ^ dec[j]) : 0u;
+                    se += (x != 0u);
+                    be += __popc(x);
+                }
+            }
+        }
+        se = wave_sum_u32(se);
+        be = wave_sum_u32(be);
+        if (lane == 0) wg_account(totals[w], se, be, false, rl, sym_out, bit_out);
+    }
+    if (lane == 0)
+        wg_flush(totals[w], counters, (unsigned long long)U * pp.n_ofdm_sym, (unsigned long long)U * pp.n_ofdm_sym * mp.bits);
+}
+
+// host side: 0 = launched, MCLE_E_UNSUPPORTED = outside this kernel's envelope (the caller goes on to the batched kernels)
+template <typename T, int WPS>
+int run_siso_tdl_wave_w(mcle_ctx* ctx, const SisoTdlParams& pp, int method, uint64_t seed, uint64_t first, uint64_t count,
+                      mcle_counters* d_counters, uint32_t* d_sym, uint32_t* d_bit) {
+    constexpr int N = 1024;
+    if (pp.cp < pp.dmax || pp.K > kTdlMaxK) return MCLE_E_UNSUPPORTED;
+    int rc;
+    void* tw = nullptr;
+    if ((rc = ctx->get_twiddles(N, sizeof(T) == 8 ? MCLE_F64 : MCLE_F32, &tw))) return rc;
+    const ModemParams<T> mp = pipe_modem<T>(ctx, method);
+    if (pp.dmax > 256 || pp.n_taps > kWaveMaxTaps || pp.n_taps * (pp.K + 2) > 64) return MCLE_E_UNSUPPORTED;   // (the prefix copy covers the last four 64-sample blocks)
+    SisoTdlParams pw = pp;
+    pw.x_elems = N + ((pp.dmax + 15) & ~15);                                // plane pitch: N + the prefix the taps reach into
+    const size_t lds = (size_t)4 * 2 * pw.x_elems * sizeof(T) + (((size_t)mp.M + 1) & ~(size_t)1) * sizeof(cx<T>) +
+                       (((size_t)mp.grid.G * mp.grid.G + 1) & ~(size_t)1) * sizeof(unsigned long long) + 16 * kWaveMaxTaps * sizeof(cx<T>) +
+                       4 * (((size_t)pp.num_used + 15) & ~(size_t)15) + 16;
+    auto kern = k_run_ofdm_tdl_wave<T, 2, WPS>;      // the polynomial order is a compile-time constant (2 .. 6: Doppler x symbol
+    switch (pp.K) {                                  // length up to ~0.05 turns in complex64; beyond: the batched kernels)
+        case 2: kern = k_run_ofdm_tdl_wave<T, 2, WPS>; break;
+        case 3: kern = k_run_ofdm_tdl_wave<T, 3, WPS>; break;
+        case 4: kern = k_run_ofdm_tdl_wave<T, 4, WPS>; break;
+        case 5: kern = k_run_ofdm_tdl_wave<T, 5, WPS>; break;
+        case 6: kern = k_run_ofdm_tdl_wave<T, 6, WPS>; break;
+        default: return MCLE_E_UNSUPPORTED;
+    }
+    MCLE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int per_cu = (int)((size_t)160 * 1024 / (lds + (sizeof(T) == 8 ? 5 * 1024 : 512)));   // (+ the static Box-Muller tables and totals)
+    if (per_cu < 1) return MCLE_E_UNSUPPORTED;
+    if (per_cu > WPS) per_cu = WPS;
+    const size_t rec_len = (size_t)pp.n_taps * (pp.K + 2);
+    const uint64_t per_real = (uint64_t)pp.n_ofdm_sym * rec_len;             // complex values per realization
+    uint64_t slice = (64ull << 20) / (per_real * sizeof(cx<T>));             // <= 64 MiB of records per fading + link pair
+    slice = slice < 4 ? 4 : (slice / 4) * 4;
+    if (slice > count) slice = count;
+    void* recs = nullptr;
+    if ((rc = ctx->scratch((size_t)slice * per_real * sizeof(cx<T>), &recs))) return rc;
+    for (uint64_t off = 0; off < count; off += slice) {
+        const uint64_t n = count - off < slice ? count - off : slice;
+        const uint64_t threads = n * (uint64_t)pp.n_ofdm_sym * pp.n_taps;
+        hipLaunchKernelGGL(k_tdl_symbol_polys<T>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream, pp, N + pp.cp,
+                           seed, first + off, n, (cx<T>*)recs);
+        MCLE_LAUNCH_CHECK();
+        const unsigned grid = (unsigned)oversubscribed_grid(ctx, (uint64_t)ctx->n_cu * per_cu, (n + 3) / 4);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, ctx->stream, pw, mp, seed, first + off, n, (const cx<T>*)tw,
+                           (const cx<T>*)recs, d_counters, d_sym ? d_sym + off : nullptr, d_bit ? d_bit + off : nullptr);
+        MCLE_LAUNCH_CHECK();
+    }
+    return MCLE_OK;
+}
+
+template <typename T>
+int run_siso_tdl_wave(mcle_ctx* ctx, const SisoTdlParams& pp, int method, uint64_t seed, uint64_t first, uint64_t count,
+                      mcle_counters* d_counters, uint32_t* d_sym, uint32_t* d_bit) {
+    // wavefronts per SIMD the registers are bounded for: complex128 two (LDS: two workgroups per CU); complex64 three
+    // (MCLE_OPT_TDL_KERNEL = 4: four -- the LDS admits a fourth workgroup, but the 128-register bound spills 15 registers:
+    //  3.18 against 2.21 ms per 262 144 realizations)
+    if constexpr (sizeof(T) == 8) return run_siso_tdl_wave_w<T, 2>(ctx, pp, method, seed, first, count, d_counters, d_sym, d_bit);
+    else if (ctx->opt[MCLE_OPT_TDL_KERNEL] == 4) return run_siso_tdl_wave_w<T, 4>(ctx, pp, method, seed, first, count, d_counters, d_sym, d_bit);
+    else return run_siso_tdl_wave_w<T, 3>(ctx, pp, method, seed, first, count, d_counters, d_sym, d_bit);
+}
+
 template <typename T, int N>
 int run_siso_tdl_batch_impl(mcle_ctx* ctx, SisoTdlParams pp, int method, uint64_t seed, uint64_t first, uint64_t count,
                             mcle_counters* d_counters, uint32_t* d_sym, uint32_t* d_bit) {
     constexpr int NB = sizeof(T) == 8 ? 2 : 4;    // complex128: two realizations per pass -> half the LDS, two workgroups per CU
     int rc;
+    if constexpr (N == 1024) {          // one realization per wavefront (default since round 4; MCLE_OPT_TDL_KERNEL = 1: the batched kernels)
+        if (ctx->opt[MCLE_OPT_TDL_KERNEL] != 1 && !ctx->opt[MCLE_OPT_NO_MFMA]) {
+            rc = run_siso_tdl_wave<T>(ctx, pp, method, seed, first, count, d_counters, d_sym, d_bit);
+            if (rc != MCLE_E_UNSUPPORTED) return rc;
+        }
+    }
     if constexpr (sizeof(T) == 4 && N == kF16N) {
         rc = run_siso_tdl_mfma(ctx, pp, method, seed, first, count, d_counters, d_sym, d_bit);
         if (rc != MCLE_E_UNSUPPORTED) return rc;

@@ -16,6 +16,8 @@ declare -A SPEC=(
   [c4md_mfma]="--config c4 --dtype f32 --demod mindist --batch 262144 --opt f32_mfma=1"
   [c3]="--config c3 --dtype f32 --batch 262144"
   [c3_f64]="--config c3 --dtype f64 --batch 131072"
+  [c3_mfma]="--config c3 --dtype f32 --batch 262144 --opt tdl_kernel=1"
+  [c3_f64_batch]="--config c3 --dtype f64 --batch 131072 --opt tdl_kernel=1"
   [c2]="--config c2 --dtype f32 --batch 65536"
   [c2_f64]="--config c2 --dtype f64 --batch 16384"
   [f1]="--config f1 --dtype f32 --demod slicer --batch 98304"
@@ -25,7 +27,7 @@ declare -A SPEC=(
   [c5_f64]="--config c5 --dtype f64 --batch 262144"
   [f6_f64]="--config f6 --dtype f64 --batch 131072"
 )
-tags=${@:-c4_f64 c4_f64sl c4 c4md c4_mfma c4md_mfma c3 c3_f64 c2 c2_f64 f1 c5 f6 f1_f64 c5_f64 f6_f64}
+tags=${@:-c4_f64 c4_f64sl c4 c4md c4_mfma c4md_mfma c3 c3_f64 c3_mfma c3_f64_batch c2 c2_f64 f1 c5 f6 f1_f64 c5_f64 f6_f64}
 for tag in $tags; do
   spec=${SPEC[$tag]}
   echo "{\"tag\": \"$tag\", \"bench_args\": \"$spec\"}" > gpurun_out/prof_${tag}_meta.json

@@ -98,3 +98,68 @@ def test_demodulate_with_and_without_the_certificate(engine, M):
     clear32 = (p32[:, 1] - p32[:, 0]) > 1e-5
     assert np.array_equal(got32[clear32], grid32[clear32])
     assert np.array_equal(got32[clear32], np.argmin(d32, axis=1)[clear32])
+
+
+def quad_cert_model(r, tab, dtype):
+    """csrc/modem.hpp::demod_quad_cert restated: four points (+-a, +-b), one per quadrant -> (label, sure)."""
+    a, b = abs(tab[0].real), abs(tab[0].imag)
+    lut = np.zeros(4, dtype=np.int64)
+    for m, c in enumerate(tab):
+        lut[(1 if c.real < 0 else 0) | (2 if c.imag < 0 else 0)] = m
+    lo = min(a, b) * (2.0 ** -30 if dtype == np.float64 else 2.0 ** -15)
+    hi = max(a, b) * 256.0
+    ax, ay = np.abs(r.real), np.abs(r.imag)
+    sure = (ax >= lo) & (ay >= lo) & (ax <= hi) & (ay <= hi)
+    return lut[(r.real < 0).astype(int) | ((r.imag < 0).astype(int) << 1)], sure
+
+
+def _quad_points(rng, tab, n=20000):
+    a = abs(tab[0].real)
+    r = (rng.standard_normal(n) + 1j * rng.standard_normal(n)) * 1.2 * a
+    k = n // 4                                  # on and next to the axes, the origin, far out (deep-fade equaliser outputs)
+    off = rng.choice([0.0, 1e-16, 1e-13, 1e-10, 2.0 ** -31, 2.0 ** -29, 1e-6, 1e-3], size=k) * a * rng.choice([-1, 1], size=k)
+    r[:k // 2] = off[:k // 2] + 1j * r[:k // 2].imag
+    r[k // 2:k] = r[k // 2:k].real + 1j * off[k // 2:]
+    r[k:k + 8] = [0, 1e-300, a * 1e-20 * (1 + 1j), 300 * a, -300j * a, (255 + 255j) * a, (257 - 1j) * a, -(1e6 + 1e6j) * a]
+    return r
+
+
+def test_quadrant_certificate_model_equals_the_argmin_where_sure():
+    rng = np.random.default_rng(44)
+    for tab in (constellation("qpsk", 4), constellation("psk", 4), constellation("qam", 4)[[2, 0, 3, 1]],
+                np.array([0.3 + 1.1j, -0.3 + 1.1j, 0.3 - 1.1j, -0.3 - 1.1j])):           # (a rectangle: a != b)
+        tab = np.asarray(tab, dtype=np.complex128)
+        if min(abs(tab[0].real), abs(tab[0].imag)) < 1e-9:
+            continue                             # (PSK(4) without offset sits ON the axes: no quadrant certificate for it)
+        r = _quad_points(rng, tab)
+        lab, sure = quad_cert_model(r, tab, np.float64)
+        want = np.argmin(np.abs(tab[None, :] - r[:, None]), axis=1)
+        assert np.array_equal(lab[sure], want[sure])
+        assert 0.7 < sure.mean() < 1.0
+
+
+@pytest.mark.gpu
+def test_qpsk_demodulate_with_and_without_the_quadrant_certificate(engine):
+    rng = np.random.default_rng(45)
+    for mod, kind in (("qpsk", _lib.CONST_GENERIC), ("qam", _lib.CONST_QAM)):
+        tab = np.asarray(constellation(mod, 4), dtype=np.complex128)
+        r = _quad_points(rng, tab)
+        engine.set_constellation(tab, kind)
+        d = np.abs(tab[None, :] - r[:, None])
+        want = np.argmin(d, axis=1)
+        part = np.partition(d, 1, axis=1)
+        clear = (part[:, 1] - part[:, 0]) > 1e-13 * np.maximum(1.0, np.abs(r))
+        got = engine.demodulate(r, dtype="f64")
+        with engine.options(demod_nocert=1):
+            grid = engine.demodulate(r, dtype="f64")
+        assert np.array_equal(got, grid), np.flatnonzero(got != grid)[:10]      # certificate == table search, axes included
+        assert np.array_equal(got[clear], want[clear]), np.flatnonzero(clear & (got != want))[:10]
+        r32 = r.astype(np.complex64)
+        got32 = engine.demodulate(r32, dtype="f32")
+        with engine.options(demod_nocert=1):
+            grid32 = engine.demodulate(r32, dtype="f32")
+        d32 = np.abs(tab[None, :] - r32.astype(np.complex128)[:, None])
+        p32 = np.partition(d32, 1, axis=1)
+        clear32 = (p32[:, 1] - p32[:, 0]) > 1e-5 * np.maximum(1.0, np.abs(r32))
+        assert np.array_equal(got32[clear32], grid32[clear32])
+        assert np.array_equal(got32[clear32], np.argmin(d32, axis=1)[clear32])

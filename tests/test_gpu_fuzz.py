@@ -247,7 +247,7 @@ def test_fuzz_matrix_core_kernels(engine, trial):
     p_lin, d_idx = och.discretize_profile(np.array(powers), np.array(delays) * Ts, Ts)
     want = _oracle(chains.chain_ofdm_tdl, first, count, **kw)
     _check(*both(lambda: engine.run_ofdm_tdl(fft, cp, used, n_sym, nv, p_lin, d_idx, SEED, first, count, Fd=Fd, Ts=Ts, L=L,
-                                             dtype="f32", per_realization=True)), want, "f32", ("ofdm_tdl", kw))
+                                             dtype="f32", per_realization=True), tdl_kernel=1), want, "f32", ("ofdm_tdl", kw))
     mmse = bool(rs.randint(2))
     method = _lib.DEMOD_QAM_SLICER if (mod == "qam" and rs.randint(2)) else _lib.DEMOD_MINDIST
     kw = dict(mod=mod, M=M, nt=4, nr=4, fft_size=fft, cp_size=cp, num_used=used, n_ofdm_sym=n_sym, snr_db=snr, mmse=mmse)

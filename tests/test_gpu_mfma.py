@@ -110,7 +110,7 @@ def test_mfma_kernel_aggregate_ser_against_the_oracle(engine):
 # ---- config 3 on the matrix cores (csrc/pipeline_siso_tdl.hip: k_run_ofdm_tdl_mfma) ------------------------------------
 def _run_tdl(engine, first, count, mfma=True, waves=None, **kw):
     from pyphysim_amd.channels import discretize_profile
-    with engine.options(no_mfma=0 if mfma else 1, tdl_mfma_waves=int(waves or 0)):
+    with engine.options(no_mfma=0 if mfma else 1, tdl_mfma_waves=int(waves or 0), tdl_kernel=1):
         Ts = kw.get("Ts", 1.0 / (15e3 * 1024))
         p_lin, d_idx = discretize_profile(np.asarray(kw.get("tap_powers_dB", (0.0, -3.0, -6.0, -9.0, -12.0)), dtype=float),
                                           np.asarray(kw.get("tap_delays_samples", (0, 1, 2, 3, 4)), dtype=float) * Ts, Ts)

@@ -1,0 +1,104 @@
+"""GPU: config 3 with one realization per WAVEFRONT (csrc/pipeline_siso_tdl.hip: k_run_ofdm_tdl_wave -- radix-16 register
+passes of fft_r16.hpp, no workgroup barrier in the loop, DPP exchange of the noise halves; the default since round 4, option tdl_kernel = 1 selects the
+batched kernels) against the oracle
+chain under the same Philox keying and against the batched kernels it stands beside.  complex128: per-realization counts
+exact; complex64: |dSER| <= 1e-4, boundary ties only (the criteria of the batched kernels' tests)."""
+import numpy as np
+import pytest
+
+from oracle import chains, modem as omodem
+from pyphysim_amd import _lib
+
+pytestmark = pytest.mark.gpu
+SEED = 31415926
+
+
+def _run(engine, first, count, dtype, wave=1, **kw):
+    from pyphysim_amd.channels import discretize_profile
+    with engine.options(tdl_kernel=0 if wave else 1):
+        Ts = kw.get("Ts", 1.0 / (15e3 * 1024))
+        p_lin, d_idx = discretize_profile(np.asarray(kw.get("tap_powers_dB", (0.0, -3.0, -6.0, -9.0, -12.0)), dtype=float),
+                                          np.asarray(kw.get("tap_delays_samples", (0, 1, 2, 3, 4)), dtype=float) * Ts, Ts)
+        nv = 1.0 / omodem.dB2Linear(kw.get("snr_db", 20.0))
+        return engine.run_ofdm_tdl(1024, kw.get("cp_size", 16), kw.get("num_used") or 1024, kw.get("n_ofdm_sym", 1), nv,
+                                   p_lin, d_idx, SEED, first, count, Fd=kw.get("Fd", 10.0), Ts=Ts, L=kw.get("L", 8),
+                                   method=kw.get("method", _lib.DEMOD_MINDIST), dtype=dtype, per_realization=True)
+
+
+CASES = [dict(mod="qpsk", M=4, snr_db=20.0),                                            # BASELINE config 3
+         dict(mod="qam", M=16, snr_db=24.0, num_used=608, n_ofdm_sym=2, L=12),          # partial band, 2 symbols
+         dict(mod="qam", M=64, snr_db=30.0, cp_size=9, tap_delays_samples=(0, 2, 5, 9), # odd CP: unpaired noise draws
+              tap_powers_dB=(0.0, -2.0, -5.0, -8.0), Fd=200.0),
+         dict(mod="psk", M=8, snr_db=18.0, cp_size=32, tap_delays_samples=(0, 7, 17, 31),
+              tap_powers_dB=(0.0, -1.0, -3.0, -6.0), Fd=900.0, n_ofdm_sym=3),           # higher polynomial order
+         dict(mod="qam", M=64, snr_db=28.0, num_used=1000, n_ofdm_sym=3, cp_size=33,    # odd symbol length: the noise pairing
+              tap_delays_samples=(0, 3), tap_powers_dB=(0.0, -4.0), method=_lib.DEMOD_QAM_SLICER),   # alternates per symbol
+         dict(mod="qam", M=256, snr_db=34.0, cp_size=0, tap_delays_samples=(0,), tap_powers_dB=(0.0,))]
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("case", range(len(CASES)))
+def test_wave_kernel_against_the_oracle_and_the_batched_kernels(engine, case, dtype):
+    kw = dict(CASES[case])
+    mod, M = kw.pop("mod"), kw.pop("M")
+    engine.set_constellation(chains.constellation(mod, M), _lib.CONST_QAM if mod == "qam" else _lib.CONST_GENERIC)
+    first, count = (1 << 34) + 70001, 23                  # not a multiple of the four wavefronts of a workgroup
+    okw = dict(mod=mod, M=M, fft_size=1024, cp_size=kw.get("cp_size", 16), num_used=kw.get("num_used"),
+               n_ofdm_sym=kw.get("n_ofdm_sym", 1), snr_db=kw["snr_db"], Fd=kw.get("Fd", 10.0), L=kw.get("L", 8),
+               tap_powers_dB=kw.get("tap_powers_dB", (0.0, -3.0, -6.0, -9.0, -12.0)),
+               tap_delays_samples=kw.get("tap_delays_samples", (0, 1, 2, 3, 4)))
+    want = [chains.chain_ofdm_tdl(chains.PhiloxRng(SEED, r), **okw) for r in range(first, first + count)]
+    want_se = np.array([w["symbol_errors"] for w in want], dtype=np.int64)
+    want_be = np.array([w["bit_errors"] for w in want], dtype=np.int64)
+    nsym, nbits = want[0]["num_symbols"], want[0]["num_bits"]
+    res, se, be = _run(engine, first, count, dtype, **kw)
+    assert res["n_symbols"] == nsym and res["n_bits"] == nbits and res["n_realizations"] == count
+    old, se_o, be_o = _run(engine, first, count, dtype, wave=0, **kw)
+    if dtype == "f64":
+        assert np.array_equal(se, want_se) and np.array_equal(be, want_be), (case, se, want_se)
+        assert np.array_equal(se, se_o) and np.array_equal(be, be_o)
+    else:
+        assert abs(int(se.sum()) - int(want_se.sum())) <= 1e-4 * count * nsym + 2
+        assert abs(int(be.sum()) - int(want_be.sum())) <= 1e-4 * count * nbits + 2
+        assert np.max(np.abs(se.astype(np.int64) - want_se)) <= 3                 # boundary ties only
+        assert np.max(np.abs(se.astype(np.int64) - se_o.astype(np.int64))) <= 3
+    assert res["sym_errors"] == int(se.astype(np.int64).sum()) and res["sym_errors_sq"] == int((se.astype(np.int64) ** 2).sum())
+    assert res["bit_errors"] == int(be.astype(np.int64).sum())
+    # bit-identical from run to run and under any split of the realization range
+    a = _run(engine, first, 9, dtype, **kw)
+    b = _run(engine, first + 9, count - 9, dtype, **kw)
+    assert np.array_equal(np.concatenate([a[1], b[1]]), se) and np.array_equal(np.concatenate([a[2], b[2]]), be)
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_wave_kernel_large_sample_and_zero_noise(engine, dtype):
+    """BASELINE config 3 over 30 000 realizations (more than one grid pass of wavefronts): counters equal to the batched kernel's
+    to the tolerance (complex128: exactly), splits add up; without noise only the deep fades of the one-tap equaliser err."""
+    engine.set_constellation(chains.constellation("qpsk", 4), _lib.CONST_GENERIC)
+    n = 30011
+    new = _run(engine, 0, n, dtype, snr_db=20.0)[0]
+    old = _run(engine, 0, n, dtype, wave=0, snr_db=20.0)[0]
+    assert new["n_realizations"] == old["n_realizations"] == n
+    if dtype == "f64":
+        assert new == old
+    else:
+        assert abs(new["sym_errors"] - old["sym_errors"]) <= 1e-5 * n * 1024 + 2
+    a = _run(engine, 0, 12345, dtype, snr_db=20.0)[0]
+    b = _run(engine, 12345, n - 12345, dtype, snr_db=20.0)[0]
+    for k in ("sym_errors", "sym_errors_sq", "bit_errors", "bit_errors_sq", "n_realizations"):
+        assert new[k] == a[k] + b[k], k
+    engine.set_constellation(chains.constellation("qam", 64), _lib.CONST_QAM)
+    clean = _run(engine, 11, 4099, dtype, snr_db=300.0, method=_lib.DEMOD_QAM_SLICER)[0]
+    ref = _run(engine, 11, 4099, dtype, wave=0, snr_db=300.0, method=_lib.DEMOD_QAM_SLICER)[0]
+    assert clean["n_realizations"] == 4099 and clean["sym_errors"] <= 2e-4 * 4099 * 1024
+    assert abs(clean["sym_errors"] - ref["sym_errors"]) <= 1e-5 * 4099 * 1024 + 2
+
+
+def test_wave_kernel_envelope(engine):
+    """A tap beyond the cyclic prefix is outside the wavefront kernel's envelope: the call falls through to the batched kernels
+    (same counts with the option on and off)."""
+    engine.set_constellation(chains.constellation("qam", 16), _lib.CONST_QAM)
+    kw = dict(snr_db=22.0, cp_size=4, tap_delays_samples=(0, 3, 9), tap_powers_dB=(0.0, -3.0, -6.0), n_ofdm_sym=2)
+    a = _run(engine, 5, 40, "f64", **kw)
+    b = _run(engine, 5, 40, "f64", wave=0, **kw)
+    assert a[0] == b[0] and np.array_equal(a[1], b[1])
