@@ -250,3 +250,98 @@ def test_radix16_swizzle_meets_both_bank_rules_for_every_access_shape():
     for bin0 in range(0, 1024, 4):
         for t in range(4):
             assert swz16f(bin0 + t) == swz16f(bin0) ^ t
+
+
+# ---- config 3 with one realization per wavefront (csrc/pipeline_siso_tdl.hip: k_run_ofdm_tdl_wave): its index maps, restated ----
+def test_wave_kernel_position_to_bin_map_and_inverse_band_map():
+    """The equaliser walks POSITIONS p = lane + 64 k: bin f = F(lane) | F(64 k) with F(64 k) = ((k & 3) << 2) | (k >> 2), and
+    the data index d of bin f is the inverse of fft.hpp's ofdm_bin (full band and partial band)."""
+    def index_of_pos(p):                         # fft.hpp fft_index_of_pos<1024>
+        f, size, mul = 0, 1024, 1
+        for _ in range(5):
+            size >>= 2
+            q, p = divmod(p, size)
+            f += q * mul
+            mul <<= 2
+        return f
+
+    def ofdm_bin(d, n, used):                    # fft.hpp ofdm_bin
+        if used == n:
+            return (d + n // 2) % n
+        h = used // 2
+        return n - h + d if d < h else 1 + (d - h)
+
+    for lane in range(64):
+        f_lane = ((lane & 3) << 8) | (((lane >> 2) & 3) << 6) | (((lane >> 4) & 3) << 4)
+        for k in range(16):
+            f = f_lane | ((k & 3) << 2) | (k >> 2)
+            assert f == index_of_pos(lane + 64 * k)
+            assert _pos_of_index(1024, f) == lane + 64 * k
+            assert swz16f(lane + 64 * k) == swz16f(lane) ^ swz16f(64 * k)
+    N = 1024
+    for U in (1024, 1000, 608, 2):
+        hU, seen = U // 2, []
+        for f in range(N):
+            if U == N:
+                d = (f + N // 2) & (N - 1)
+            elif f >= N - hU:
+                d = f - (N - hU)
+            elif 1 <= f <= hU:
+                d = hU + f - 1
+            else:
+                continue
+            assert ofdm_bin(d, N, U) == f
+            seen.append(d)
+        assert sorted(seen) == list(range(U))
+
+
+def test_wave_kernel_noise_pairing_draws_every_block_once():
+    """Lanes l (even), l + 1 hold samples m, m + 1 of combination c (m = l + 64 c): with an even stream offset they share NOISE
+    block (offset + m) >> 1.  The even lane draws combinations 0 .. 7, the odd lane 8 .. 15; after the swap every (lane,
+    combination) has the half of the block that is its own sample, and every block of the symbol is drawn exactly once."""
+    for nbase in (16, 1040 + 16, 0):             # even offsets (sym0 + cp)
+        drawn = {}
+        got = {}
+        for lane in range(64):
+            odd = lane & 1
+            for j in range(8):
+                c = j + 8 * odd
+                m = lane + 64 * c
+                blk = (nbase + m) >> 1
+                assert blk not in drawn
+                drawn[blk] = (lane, c)
+                za, zb = (blk, 0), (blk, 1)       # the block's first and second sample
+                partner = lane ^ 1
+                if odd:
+                    got[(partner, c)] = za       # sent: the even partner's sample of combination 8 + j
+                    got[(lane, c)] = zb
+                else:
+                    got[(lane, c)] = za
+                    got[(partner, c)] = zb
+        assert len(drawn) == 512 and sorted(drawn) == list(range(nbase >> 1, (nbase >> 1) + 512))
+        for lane in range(64):
+            for c in range(16):
+                i0 = nbase + lane + 64 * c
+                assert got[(lane, c)] == (i0 >> 1, i0 & 1)
+
+
+def test_wave_kernel_prefixed_delay_line():
+    """xp[P + m] = x[m], xp[j] = x[N - P + j] (written by the lanes whose sample index reaches into the last P): the read
+    xp[P + m - d] is x[(m - d) mod N] for every delay d <= P, and the reads of a wavefront are consecutive words."""
+    N = 1024
+    x = np.arange(N)
+    for P in (16, 48, 64, 256):
+        xp = np.full(N + P, -1)
+        for lane in range(64):
+            for c in range(16):
+                m = lane + 64 * c
+                xp[P + m] = x[m]
+                if c >= 12 and m >= N - P:
+                    xp[m - (N - P)] = x[m]
+        assert (xp >= 0).all()
+        for d in (0, 1, P // 2, P):
+            for c in range(16):
+                lanes = np.arange(64)
+                src = P + lanes - d + 64 * c
+                assert np.array_equal(xp[src], x[(lanes + 64 * c - d) % N])
+                assert np.array_equal(np.diff(src), np.ones(63, dtype=int))
