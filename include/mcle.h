@@ -110,7 +110,9 @@ enum {
                                       grid / sweep); 0: through the margin certificate of modem.hpp (demod_qam_cert: the
                                       closed-form nearest level per axis, accepted when the received point is farther than
                                       2^-30 (complex64: 2^-15) of a level spacing from every decision boundary, the table
-                                      search otherwise -- identical decisions, no table gathers) */
+                                      search otherwise -- identical decisions, no table gathers); likewise for a four-point
+                                      constellation with one point per quadrant at (+-a, +-b) -- QPSK -- decided by the signs
+                                      (demod_quad_cert: certified for 2^-30 min(a, b) <= |re|, |im| <= 2^8 max(a, b)) */
     MCLE_OPT_F64_VARIANT = 11,     /* complex128 config-4 kernel (1024, 4x4), TIMING BOUNDS ONLY on its 512-thread radix-4 form --
                                       results are wrong by construction: bit 0 = the LDS stores of the last transmit stage and of
                                       the channel stage dropped, bit 1 = the two workgroup barriers around the channel stage
