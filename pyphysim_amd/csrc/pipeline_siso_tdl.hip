@@ -967,12 +967,17 @@ __global__ __launch_bounds__(256, WPS) void k_run_ofdm_tdl_wave(SisoTdlParams pp
         unsigned se = 0, be = 0;
         for (int os = 0; os < pp.n_ofdm_sym; ++os) {
             const uint64_t sym0 = (uint64_t)os * W;
-            // the symbol's record (tap polynomials, tap means; rec_len <= 64 values): ONE coalesced load, value j parked in lane j,
+            // the symbol's record (tap polynomials, tap means; rec_len <= 128 values): coalesced loads, value j parked in lane j mod 64,
             // fetched here and first used after the transmit transform -- read at its points of use (scalar loads from the
             // record) its latency stood in front of the channel and the equaliser of every realization
             int gi = opaque(lane);
-            const cx<T> myrec = gi < rec_len ? g_polys[(rl * pp.n_ofdm_sym + os) * (uint64_t)rec_len + gi] : mk<T>(0, 0);
-            auto rec_at = [&](int j) -> cx<T> { return mk<T>(lane_value(myrec.x, j), lane_value(myrec.y, j)); };
+            const cx<T>* __restrict__ g_rec = g_polys + (rl * pp.n_ofdm_sym + os) * (uint64_t)rec_len;
+            const cx<T> myrec = gi < rec_len ? g_rec[gi] : mk<T>(0, 0);
+            const cx<T> myrec2 = gi + 64 < rec_len ? g_rec[gi + 64] : mk<T>(0, 0);      // (values 64 .. 127: eight taps of order >= 7)
+            auto rec_at = [&](int j) -> cx<T> {
+                return j < 64 ? mk<T>(lane_value(myrec.x, j), lane_value(myrec.y, j))
+                              : mk<T>(lane_value(myrec2.x, j - 64), lane_value(myrec2.y, j - 64));
+            };
             r16_wave_sync();                                                // the previous symbol's equaliser has read the planes
             // ---- transmit: symbols -> bins at digit-reversed positions (the DIT transform takes them from there) ----
             if (U != N) {
@@ -1203,19 +1208,21 @@ int run_siso_tdl_wave_w(mcle_ctx* ctx, const SisoTdlParams& pp, int method, uint
     void* tw = nullptr;
     if ((rc = ctx->get_twiddles(N, sizeof(T) == 8 ? MCLE_F64 : MCLE_F32, &tw))) return rc;
     const ModemParams<T> mp = pipe_modem<T>(ctx, method);
-    if (pp.dmax > 256 || pp.n_taps > kWaveMaxTaps || pp.n_taps * (pp.K + 2) > 64) return MCLE_E_UNSUPPORTED;   // (the prefix copy covers the last four 64-sample blocks)
+    if (pp.dmax > 256 || pp.n_taps > kWaveMaxTaps || pp.n_taps * (pp.K + 2) > 128) return MCLE_E_UNSUPPORTED;   // (the prefix copy covers the last four 64-sample blocks)
     SisoTdlParams pw = pp;
     pw.x_elems = N + ((pp.dmax + 15) & ~15);                                // plane pitch: N + the prefix the taps reach into
     const size_t lds = (size_t)4 * 2 * pw.x_elems * sizeof(T) + (((size_t)mp.M + 1) & ~(size_t)1) * sizeof(cx<T>) +
                        (((size_t)mp.grid.G * mp.grid.G + 1) & ~(size_t)1) * sizeof(unsigned long long) + 16 * kWaveMaxTaps * sizeof(cx<T>) +
                        4 * (((size_t)pp.num_used + 15) & ~(size_t)15) + 16;
-    auto kern = k_run_ofdm_tdl_wave<T, 2, WPS>;      // the polynomial order is a compile-time constant (2 .. 6: Doppler x symbol
-    switch (pp.K) {                                  // length up to ~0.05 turns in complex64; beyond: the batched kernels)
+    auto kern = k_run_ofdm_tdl_wave<T, 2, WPS>;      // the polynomial order is a compile-time constant (2 .. 8: Doppler x symbol
+    switch (pp.K) {                                  // length up to ~0.1 turns in complex64; beyond: the batched kernels)
         case 2: kern = k_run_ofdm_tdl_wave<T, 2, WPS>; break;
         case 3: kern = k_run_ofdm_tdl_wave<T, 3, WPS>; break;
         case 4: kern = k_run_ofdm_tdl_wave<T, 4, WPS>; break;
         case 5: kern = k_run_ofdm_tdl_wave<T, 5, WPS>; break;
         case 6: kern = k_run_ofdm_tdl_wave<T, 6, WPS>; break;
+        case 7: kern = k_run_ofdm_tdl_wave<T, 7, WPS>; break;
+        case 8: kern = k_run_ofdm_tdl_wave<T, 8, WPS>; break;
         default: return MCLE_E_UNSUPPORTED;
     }
     MCLE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -33,7 +33,14 @@ CASES = [dict(mod="qpsk", M=4, snr_db=20.0),                                    
               tap_powers_dB=(0.0, -1.0, -3.0, -6.0), Fd=900.0, n_ofdm_sym=3),           # higher polynomial order
          dict(mod="qam", M=64, snr_db=28.0, num_used=1000, n_ofdm_sym=3, cp_size=33,    # odd symbol length: the noise pairing
               tap_delays_samples=(0, 3), tap_powers_dB=(0.0, -4.0), method=_lib.DEMOD_QAM_SLICER),   # alternates per symbol
-         dict(mod="qam", M=256, snr_db=34.0, cp_size=0, tap_delays_samples=(0,), tap_powers_dB=(0.0,))]
+         dict(mod="qam", M=256, snr_db=34.0, cp_size=0, tap_delays_samples=(0,), tap_powers_dB=(0.0,)),
+         # the envelope's corners: eight taps reaching 200 samples into a 208-sample prefix (the prefix copy spans four 64-sample
+         # blocks), four symbols; a two-subcarrier band in PSK(2); a Doppler that takes polynomial order 8 in complex64 (complex128: 13 -> the
+         # batched kernel serves it; the 8-tap case takes order 3 / 7)
+         dict(mod="qam", M=16, snr_db=26.0, cp_size=208, n_ofdm_sym=4, L=8, Fd=50.0,
+              tap_delays_samples=(0, 1, 7, 33, 64, 65, 130, 200), tap_powers_dB=(0.0, -1.0, -2.0, -3.0, -4.0, -5.0, -6.0, -7.0)),
+         dict(mod="psk", M=2, snr_db=6.0, num_used=2, cp_size=16, n_ofdm_sym=2),
+         dict(mod="qpsk", M=4, snr_db=16.0, cp_size=64, Fd=2000.0, tap_delays_samples=(0, 5, 40), tap_powers_dB=(0.0, -3.0, -6.0))]
 
 
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
