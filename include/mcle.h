@@ -121,11 +121,13 @@ enum {
                                       rounds 2-3) instead of the planar VALU family (k_run_mimo_ofdm_planar<float>: the complex128
                                       kernels on planes of floats, 10-20 % faster at this geometry and the only fast complex64 kernel
                                       at every other one; default since round 4) */
-    MCLE_OPT_TDL_KERNEL = 13,      /* config 3 at fft_size 1024 with every tap delay inside the cyclic prefix (<= 8 taps, <= 256 samples):
-                                      0 = one realization per WAVEFRONT (k_run_ofdm_tdl_wave: radix-16 register passes, no workgroup
-                                      barrier in the loop; default since round 4), 1 = the batched kernels of rounds 1-3 (four / two
-                                      realizations per workgroup pass; complex64: matrix cores), 4 = the wavefront kernel with the
-                                      complex64 registers bounded for four wavefronts per SIMD instead of three (A/B: it spills) */
+    MCLE_OPT_TDL_KERNEL = 13,      /* config 3 at fft_size 256 / 512 / 1024 / 2048 with every tap delay inside the cyclic prefix (<= 8 taps,
+                                      <= 256 samples, polynomial order <= 8): 0 = one realization per WAVEFRONT (k_run_ofdm_tdl_wave: no
+                                      workgroup barrier in the loop; radix-16 register passes at 1024, radix-4 stages otherwise) WHERE IT
+                                      IS THE FASTER KERNEL (1024; 2048 in complex64; 256 / 512 in complex128 -- default since round 4),
+                                      1 = the batched kernels of rounds 1-3 everywhere (four / two realizations per workgroup pass;
+                                      complex64 at 1024: matrix cores), 2 = the wavefront kernel wherever it exists, 4 = the same with
+                                      the complex64 registers at 1024 bounded for four wavefronts per SIMD instead of three (A/B) */
     MCLE_OPT_COUNT = 14
 };
 int mcle_ctx_set_option(mcle_ctx* ctx, int option, long long value);

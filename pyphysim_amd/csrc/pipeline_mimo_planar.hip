@@ -48,10 +48,6 @@ struct MimoParams {
 
 template <int NT, int NR> constexpr int d64_rec() { return 2 * NT * NR + 1; }     // H, G x FFT scale, skip flag
 
-// LDS position of element e of a plane of doubles: the 8-byte-slot swizzle of fft.hpp (conflict free for the loads and the
-// stores of every stage of this kernel: the legs of the radix-4 butterflies at every span, the trailing radix-2 stage, the
-// channel's position pairs, scatter and decode, at every size of the family; tests/test_f64_layout.py replays all of them).
-__host__ __device__ __forceinline__ int lds_swz64(int e) { return lds_swz<true>(e); }
 
 // complex64: the channel is drawn in float (the draw ledger of the complex64 kernels), the filter computed in double and rounded
 template <typename T, int N, int NT, int NR>
@@ -78,127 +74,6 @@ __global__ __launch_bounds__(64) void k_mimo_filters_planar(MimoParams pp, uint6
 #pragma unroll
         for (int r = 0; r < NR; ++r) rec[NT * NR + a * NR + r] = mk<T>((T)(G[a][r].x * rx_scale), (T)(G[a][r].y * rx_scale));
     rec[2 * NT * NR] = mk<T>(ok ? (T)0 : (T)1, (T)0);
-}
-
-// Radix-4 stage spans of an N-point transform in DIF order: N/4, N/16, ... down to 1 (N = 4^k) or 2 (N = 2 4^k, then one
-// radix-2 stage on adjacent pairs closes the DIF / opens the DIT transform, as in fft.hpp).
-template <int N> struct F64Shape {
-    static constexpr int N4 = FftShape<N>::N4;
-    static constexpr bool HAS2 = FftShape<N>::HAS2;
-    static constexpr int NB = N / 4;                              // radix-4 butterfly positions of one antenna
-    static constexpr int span(int st) { return (N / 4) >> (2 * st); }       // DIF stage st
-    static constexpr int first_dit_span = HAS2 ? 2 : 1;
-};
-
-// The three twiddles of a thread's butterfly position at the radix-4 stages that have any (every span > 1):
-// w[j][q] = W^{(q+1) k N/(4s)}, k = position mod s.  A DIF stage and the DIT stage of the same span use the same values
-// (conjugated for the inverse transform); in the 256-thread form of N = 1024 they live in 48 registers for the whole
-// kernel -- fetched per stage from the global table they sat on the critical path of every stage (three dependent
-// ~600-cycle loads at two wavefronts per SIMD).
-template <typename T, int N> struct TwRegs64 {
-    cx<T> w[F64Shape<N>::N4][3];
-};
-template <typename T, int N> __device__ __forceinline__ TwRegs64<T, N> load_tw64(const cx<T>* __restrict__ g_tw, int bb) {
-    TwRegs64<T, N> t;
-#pragma unroll
-    for (int j = 0; j < F64Shape<N>::N4; ++j) {
-        const int s = F64Shape<N>::span(j), k = bb & (s - 1), ts = N / (4 * s);
-#pragma unroll
-        for (int q = 0; q < 3; ++q) t.w[j][q] = g_tw[(q + 1) * k * ts];
-    }
-    return t;
-}
-
-// the three twiddles of butterfly position bb at span S, fetched from the (L1-resident) table
-template <typename T, int N, int S> __device__ __forceinline__ void stage_tw_fetch(const cx<T>* __restrict__ g_tw, int bb, cx<T> (&w)[3]) {
-    constexpr int ts = N / (4 * S);
-    const int k = bb & (S - 1);
-    w[0] = g_tw[k * ts];
-    w[1] = g_tw[2 * k * ts];
-    w[2] = g_tw[3 * k * ts];
-}
-
-// one radix-4 butterfly position of AH antennas, planar LDS.
-// DIF (INV: the transmit IFFT): butterfly, then twiddle; DIT (forward FFT): twiddle, then butterfly.
-// pre: twiddles fetched ahead by the caller (forward transform: a DIT stage multiplies FIRST, so a fetch issued inside
-// the stage sits on its critical path; issued one stage early it hides behind that stage's butterflies)
-template <typename T, int N, bool DIF, bool INV, int S, int AH, bool TWR, bool NOSTORE = false>
-__device__ __forceinline__ void r4_stage_planar(T* s_d, const TwRegs64<T, N>& tw, const cx<T>* __restrict__ g_tw, int bb,
-                                                const cx<T>* pre = nullptr) {
-    constexpr int s = S;
-    const int k = bb & (s - 1), g = bb / s;
-    const int e0 = g * 4 * s + k;
-    int i0, i1, i2, i3;
-    lds_swz_r4<true>(e0, s, i0, i1, i2, i3);           // one swizzle + three XORs with per-stage constants (fft.hpp)
-    cx<T> w1 = mk<T>(1, 0), w2 = w1, w3 = w1;
-    if (s > 1) {
-        if constexpr (TWR) {                          // the thread's twiddles are registers
-            constexpr int j = (FftShape<N>::LOG2 - FftShape<4 * S>::LOG2) / 2;     // DIF stage index of span S
-            w1 = tw.w[j][0];
-            w2 = tw.w[j][1];
-            w3 = tw.w[j][2];
-        } else if (pre != nullptr) {
-            w1 = pre[0];
-            w2 = pre[1];
-            w3 = pre[2];
-        } else {                                      // from the L1-resident table, per stage
-            constexpr int ts = N / (4 * s);
-            w1 = g_tw[k * ts];
-            w2 = g_tw[2 * k * ts];
-            w3 = g_tw[3 * k * ts];
-        }
-    }
-    T xr[AH][4], xi[AH][4];
-#pragma unroll
-    for (int a = 0; a < AH; ++a) {
-        const T* pr = s_d + (2 * a) * N;
-        const T* pi = pr + N;
-        xr[a][0] = pr[i0]; xr[a][1] = pr[i1]; xr[a][2] = pr[i2]; xr[a][3] = pr[i3];
-        xi[a][0] = pi[i0]; xi[a][1] = pi[i1]; xi[a][2] = pi[i2]; xi[a][3] = pi[i3];
-    }
-#pragma unroll
-    for (int a = 0; a < AH; ++a) {
-        cx<T> u0 = mk<T>(xr[a][0], xi[a][0]), u1 = mk<T>(xr[a][1], xi[a][1]),
-                u2 = mk<T>(xr[a][2], xi[a][2]), u3 = mk<T>(xr[a][3], xi[a][3]);
-        if (!DIF && s > 1) {
-            u1 = CxOps<T>::template mulw<INV>(u1, w1);
-            u2 = CxOps<T>::template mulw<INV>(u2, w2);
-            u3 = CxOps<T>::template mulw<INV>(u3, w3);
-        }
-        cx<T> y0, y1, y2, y3;
-        CxOps<T>::template bfly4<INV>(u0, u1, u2, u3, y0, y1, y2, y3);
-        if (DIF && s > 1) {
-            y1 = CxOps<T>::template mulw<INV>(y1, w1);
-            y2 = CxOps<T>::template mulw<INV>(y2, w2);
-            y3 = CxOps<T>::template mulw<INV>(y3, w3);
-        }
-        if constexpr (NOSTORE) {                      // timing bound only (MCLE_OPT_F64_VARIANT): computed, not stored
-            asm volatile("" ::"v"(y0.x), "v"(y0.y), "v"(y1.x), "v"(y1.y), "v"(y2.x), "v"(y2.y), "v"(y3.x), "v"(y3.y));
-            continue;
-        }
-        T* pr = s_d + (2 * a) * N;
-        T* pi = pr + N;
-        pr[i0] = y0.x; pr[i1] = y1.x; pr[i2] = y2.x; pr[i3] = y3.x;
-        pi[i0] = y0.y; pi[i1] = y1.y; pi[i2] = y2.y; pi[i3] = y3.y;
-    }
-}
-
-// The radix-2 stage of N = 2 4^k (last of the DIF, first of the DIT transform; no twiddles): pairs (2p, 2p + 1).  Thread
-// bb takes the two pairs inside ITS four consecutive positions 4 bb .. 4 bb + 3 -- the access pattern of the span-1
-// radix-4 stage, and the points the lane pair (bb, bb ^ 1) exchanged in the span-2 stage next to it, so that the stage
-// is ordered against its neighbour by the wavefront's own in-order LDS traffic (no workgroup barrier).
-template <typename T, int N, int AH> __device__ __forceinline__ void r2_stage_planar(T* s_d, int bb) {
-    int i0, i1, i2, i3;
-    lds_swz_r4<true>(4 * bb, 1, i0, i1, i2, i3);
-#pragma unroll
-    for (int a = 0; a < AH; ++a) {
-        T* pr = s_d + (2 * a) * N;
-        T* pi = pr + N;
-        const T r0 = pr[i0], r1 = pr[i1], r2 = pr[i2], r3 = pr[i3];
-        const T m0 = pi[i0], m1 = pi[i1], m2 = pi[i2], m3 = pi[i3];
-        pr[i0] = r0 + r1; pr[i1] = r0 - r1; pr[i2] = r2 + r3; pr[i3] = r2 - r3;
-        pi[i0] = m0 + m1; pi[i1] = m0 - m1; pi[i2] = m2 + m3; pi[i3] = m2 - m3;
-    }
 }
 
 // lanes l and l ^ 32 exchange: (a of the lower half, b of the upper half) stay, the other two cross over --

@@ -909,12 +909,17 @@ template <> __device__ __forceinline__ double dpp_swap1<double>(double v) {
     return __hiloint2double(hi, lo);
 }
 
-template <typename T, int KT, int WPS>
+// N = 1024: the radix-16 passes with register hand-over on both sides of the channel.  N = 256 / 512 / 2048: radix-4 stages on the
+// wavefront's planes (fft_r16.hpp: wave_fft_dif / wave_fft_dit, N / 256 butterfly positions per lane and stage), the same
+// hand-over through explicit reads and writes; everything between the transforms is the same code on R = N / 64 samples per lane.
+template <typename T, int N, int KT, int WPS>
 __global__ __launch_bounds__(256, WPS) void k_run_ofdm_tdl_wave(SisoTdlParams pp, ModemParams<T> mp, uint64_t seed, uint64_t first,
                                                                 uint64_t count, const cx<T>* __restrict__ g_tw,
                                                                 const cx<T>* __restrict__ g_polys, mcle_counters* counters,
                                                                 uint32_t* __restrict__ sym_out, uint32_t* __restrict__ bit_out) {
-    constexpr int N = 1024;
+    constexpr int R = N / 64;                                               // samples (positions, subcarriers) per lane
+    constexpr bool R16 = N == 1024;
+    auto swz = [](int e) { return R16 ? lds_swz16f(e) : lds_swz64(e); };
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -931,11 +936,13 @@ __global__ __launch_bounds__(256, WPS) void k_run_ofdm_tdl_wave(SisoTdlParams pp
     // w^(F(64 k) d_s): the equaliser's twiddle of bin f = F(gi) + F(64 k) is w^(F(gi) d_s) (one gather per lane, tap and symbol)
     // times this wave-uniform factor (an LDS broadcast) -- sixteen table gathers per lane and tap, 64 cache lines each, kept the
     // L1 busier than the SIMDs
-    cx<T>* s_twk = reinterpret_cast<cx<T>*>(s_grid + ((mp.grid.G * mp.grid.G + 1) & ~1));   // [16][kWaveMaxTaps]
-    unsigned char* s_idx_all = reinterpret_cast<unsigned char*>(s_twk + 16 * kWaveMaxTaps);        // [4][U rounded to 16]
+    cx<T>* s_twk = reinterpret_cast<cx<T>*>(s_grid + ((mp.grid.G * mp.grid.G + 1) & ~1));   // [R][kWaveMaxTaps]
+    unsigned char* s_idx_all = reinterpret_cast<unsigned char*>(s_twk + R * kWaveMaxTaps);        // [4][U rounded to 16]
     const int idx_pitch = (U + 15) & ~15;
-    T* pr = s_all + w * 2 * pitch;
-    T* pi = pr + pitch;
+    T* pr = s_all + w * 2 * pitch;                                         // transform planes: re [0, N), im [N, 2 N)
+    T* pi = pr + N;
+    T* xr = pr;                                                             // natural-order signal with prefix: re [0, pitch),
+    T* xi = pr + pitch;                                                     // im [pitch, 2 pitch) -- the same memory, never live together
     unsigned char* s_idx = s_idx_all + w * idx_pitch;
     __shared__ double s_bm[sizeof(T) == 8 ? kBmLdsDoubles : 1];             // complex128 Box-Muller tables (bm_f64.hpp)
     if constexpr (sizeof(T) == 8) bm_tables_to_lds(s_bm, (int)threadIdx.x, 256);
@@ -943,9 +950,9 @@ __global__ __launch_bounds__(256, WPS) void k_run_ofdm_tdl_wave(SisoTdlParams pp
     load_grid(mp, s_grid);
     __shared__ WgTotals totals[4];
     if (lane == 0) wg_zero(totals[w]);
-    if (threadIdx.x < 16 * kWaveMaxTaps) {
+    if (threadIdx.x < R * kWaveMaxTaps) {
         const int k = (int)threadIdx.x / kWaveMaxTaps, ts = (int)threadIdx.x % kWaveMaxTaps;
-        const int fk = ((k & 3) << 2) | (k >> 2);
+        const int fk = fft_index_of_pos<N>(64 * k);
         s_twk[threadIdx.x] = ts < S ? g_tw[(fk * pp.tap_delay[ts]) & (N - 1)] : mk<T>(0, 0);
     }
     __syncthreads();                                                        // the only workgroup barrier of the kernel
@@ -956,7 +963,17 @@ __global__ __launch_bounds__(256, WPS) void k_run_ofdm_tdl_wave(SisoTdlParams pp
     const uint32_t mask = (uint32_t)(mp.M - 1);
     const double xc = 0.5 * (double)(W - 1);                                // centre of the symbol in local sample units
     const int n_coef = S * (K + 1), rec_len = n_coef + S;
-    const R16Tw64<T> tw16 = load_r16_tw<T>(g_tw, lane);
+    [[maybe_unused]] R16Tw64<T> tw16;
+    if constexpr (R16) tw16 = load_r16_tw<T>(g_tw, lane);
+    // radix-4 sizes in complex64: the lane's stage twiddles in registers (256: 24 registers, 512: 48; 1.11 -> 1.31e8 realizations/s
+    // at 256.  complex128 keeps fetching them stage by stage: 48 more registers cost it a wavefront per SIMD, 1.39 -> 1.10e8)
+    constexpr int REP4 = N / 256;
+    constexpr bool WTW = !R16 && sizeof(T) == 4 && REP4 * FftShape<N>::N4 * 6 <= 48;
+    [[maybe_unused]] TwRegs64<T, N> twr4[WTW ? REP4 : 1];
+    if constexpr (WTW) {
+#pragma unroll
+        for (int rep = 0; rep < REP4; ++rep) twr4[rep] = load_tw64<T, N>(g_tw, lane + 64 * rep);
+    }
     int dly[kWaveMaxTaps];
 #pragma unroll
     for (int s = 0; s < kWaveMaxTaps; ++s) dly[s] = s < S ? pp.tap_delay[s] : 0;
@@ -981,7 +998,7 @@ __global__ __launch_bounds__(256, WPS) void k_run_ofdm_tdl_wave(SisoTdlParams pp
             r16_wave_sync();                                                // the previous symbol's equaliser has read the planes
             // ---- transmit: symbols -> bins at digit-reversed positions (the DIT transform takes them from there) ----
             if (U != N) {
-                for (int p = gi; p < N; p += 64) pr[p] = pi[p] = 0;
+                for (int p = gi; p < 2 * N; p += 64) pr[p] = 0;
                 r16_wave_sync();
             }
             const uint64_t n_first = (uint64_t)os * U, n_last = n_first + U;
@@ -989,14 +1006,14 @@ __global__ __launch_bounds__(256, WPS) void k_run_ofdm_tdl_wave(SisoTdlParams pp
                 const Words4 dw = rng.block(STREAM_DATA, (uint32_t)blk);
                 if (U == N && (U & 15) == 0) {           // full band on block boundaries: bin(d0 + j) = bin(d0) ^ j, and digit
                     const int d0 = (int)((blk << 4) - n_first);              // reversal and swizzle are XOR-linear
-                    const int p0 = lds_swz16f(fft_pos_of_index<N>(ofdm_bin(d0, N, U)));
+                    const int p0 = swz(fft_pos_of_index<N>(ofdm_bin(d0, N, U)));
                     *reinterpret_cast<uint4*>(s_idx + d0) = make_uint4(dw.w[0] & (mask * 0x01010101u), dw.w[1] & (mask * 0x01010101u),
                                                                        dw.w[2] & (mask * 0x01010101u), dw.w[3] & (mask * 0x01010101u));
 #pragma unroll
                     for (int j = 0; j < 16; ++j) {
                         const int tx = (int)((dw.w[j >> 2] >> ((j & 3) * 8)) & mask);
                         const cx<T> c = cscale(s_table[tx], tx_scale);
-                        const int pos = p0 ^ lds_swz16f(fft_pos_of_index<N>(j));
+                        const int pos = p0 ^ swz(fft_pos_of_index<N>(j));
                         pr[pos] = c.x;
                         pi[pos] = c.y;
                     }
@@ -1010,32 +1027,42 @@ __global__ __launch_bounds__(256, WPS) void k_run_ofdm_tdl_wave(SisoTdlParams pp
                         const int d = (int)(n - n_first);
                         s_idx[d] = (unsigned char)tx;
                         const cx<T> c = cscale(s_table[tx], tx_scale);
-                        const int pos = lds_swz16f(fft_pos_of_index<N>(ofdm_bin(d, N, U)));
+                        const int pos = swz(fft_pos_of_index<N>(ofdm_bin(d, N, U)));
                         pr[pos] = c.x;
                         pi[pos] = c.y;
                     }
                 }
             }
             r16_wave_sync();
-            cx<T> y[16];                                                    // element gi + 64 q + 256 m' in y[q + 4 m']
-            r16_dit<T, true, true, false, true>(pr, pi, lane, tw16, g_tw, y);   // time samples; the last pass leaves them in registers
+            cx<T> y[R];                                                     // element gi + 64 c in y[c]
+            if constexpr (R16) {
+                r16_dit<T, true, true, false, true>(pr, pi, lane, tw16, g_tw, y);   // time samples; the last pass leaves them in registers
+            } else {
+                wave_fft_dit<T, N, true, WTW>(pr, g_tw, lane, twr4);                   // time samples at swizzled natural positions
+                gi = opaque(lane);
+#pragma unroll
+                for (int c = 0; c < R; ++c) {
+                    const int sl = swz(gi) ^ swz(64 * c);
+                    y[c] = mk<T>(pr[sl], pi[sl]);
+                }
+            }
             r16_wave_sync();                                                // every lane's reads of the planes are issued
             gi = opaque(lane);
 #pragma unroll
-            for (int c = 0; c < 16; ++c) {                                  // -> natural order behind the prefix
-                pr[P + gi + 64 * c] = y[c].x;
-                pi[P + gi + 64 * c] = y[c].y;
+            for (int c = 0; c < R; ++c) {                                   // -> natural order behind the prefix
+                xr[P + gi + 64 * c] = y[c].x;
+                xi[P + gi + 64 * c] = y[c].y;
             }
 #pragma unroll
-            for (int c = 12; c < 16; ++c)                                   // the prefix: the last P samples once more (P <= 256)
+            for (int c = (R > 4 ? R - 4 : 0); c < R; ++c)                   // the prefix: the last P samples once more (P <= 256)
                 if (gi + 64 * c >= N - P) {
-                    pr[gi + 64 * c - (N - P)] = y[c].x;
-                    pi[gi + 64 * c - (N - P)] = y[c].y;
+                    xr[gi + 64 * c - (N - P)] = y[c].x;
+                    xi[gi + 64 * c - (N - P)] = y[c].y;
                 }
             r16_wave_sync();
-            // ---- channel: y[m] = sum_s g_s(j) x[j],  j = cp + m - d_s, for this lane's sixteen samples m = gi + 64 c ----
+            // ---- channel: y[m] = sum_s g_s(j) x[j],  j = cp + m - d_s, for this lane's R samples m = gi + 64 c ----
 #pragma unroll
-            for (int c = 0; c < 16; ++c) y[c] = mk<T>(0, 0);
+            for (int c = 0; c < R; ++c) y[c] = mk<T>(0, 0);
             // (the tap loop is unrolled to kWaveMaxTaps with a wave-uniform guard: the delays and every index are compile-time
             //  register names -- a run-time `pp.tap_delay[s]` is a scalar load from the kernel arguments on the critical path)
 #pragma unroll
@@ -1047,13 +1074,13 @@ __global__ __launch_bounds__(256, WPS) void k_run_ofdm_tdl_wave(SisoTdlParams pp
 #pragma unroll
                     for (int m = 0; m <= KT; ++m) cc[m] = rec_at(s * (K + 1) + m);
                 }
-                const T* xr = pr + (P + gi - d);                            // x[m - d] = xr[64 c]: d <= P
-                const T* xi = pi + (P + gi - d);
+                const T* xdr = xr + (P + gi - d);                           // x[m - d] = xdr[64 c]: d <= P
+                const T* xdi = xi + (P + gi - d);
                 // (double) q - xc rounded to T, q = cp + m - d: q and xc are (half-)integers below 2^12 -- exact in float too
                 const T x0 = sizeof(T) == 8 ? (T)((double)(cp + gi - d) - xc) : (T)(cp + gi - d) - (T)xc;
 #pragma unroll
-                for (int c = 0; c < 16; ++c) {
-                    const cx<T> xv = mk<T>(xr[64 * c], xi[64 * c]);
+                for (int c = 0; c < R; ++c) {
+                    const cx<T> xv = mk<T>(xdr[64 * c], xdi[64 * c]);
                     const T xx = x0 + (T)(64 * c);                          // exact
                     cx<T> g;
                     if constexpr (KT > 0) {
@@ -1079,22 +1106,22 @@ __global__ __launch_bounds__(256, WPS) void k_run_ofdm_tdl_wave(SisoTdlParams pp
             if ((nbase & 1) == 0) {             // lanes l (even), l + 1 share the block of samples m, m + 1
                 const bool odd = (gi & 1) != 0;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int c = j + (odd ? 8 : 0);
-                    const int m = gi + 64 * (c & 3) + 256 * (c >> 2);
+                for (int j = 0; j < R / 2; ++j) {
+                    const int c = j + (odd ? R / 2 : 0);
+                    const int m = gi + 64 * c;
                     cx<T> za, zb;
                     cn_pair_lds(rng, STREAM_NOISE, (uint32_t)((nbase + (uint64_t)m) >> 1), sigma, za, zb, s_bm);
                     const T sx = odd ? za.x : zb.x, sy = odd ? za.y : zb.y;      // what the partner needs
                     const T rx = dpp_swap1<T>(sx), ry = dpp_swap1<T>(sy);
                     const cx<T> lo = mk<T>(odd ? rx : za.x, odd ? ry : za.y);    // sample of combination j
-                    const cx<T> hi = mk<T>(odd ? zb.x : rx, odd ? zb.y : ry);    // sample of combination 8 + j
+                    const cx<T> hi = mk<T>(odd ? zb.x : rx, odd ? zb.y : ry);    // sample of combination R / 2 + j
                     y[j] = cadd(y[j], lo);
-                    y[8 + j] = cadd(y[8 + j], hi);
+                    y[R / 2 + j] = cadd(y[R / 2 + j], hi);
                 }
             } else {                            // odd start: a block's samples sit on lanes of different pairs -- half of every block used
 #pragma unroll
-                for (int c = 0; c < 16; ++c) {
-                    const int m = gi + 64 * (c & 3) + 256 * (c >> 2);
+                for (int c = 0; c < R; ++c) {
+                    const int m = gi + 64 * c;
                     const uint64_t i0 = nbase + (uint64_t)m;
                     const Words4 b = rng.block(STREAM_NOISE, (uint32_t)(i0 >> 1));
                     const uint32_t x0 = (i0 & 1) ? b.w[2] : b.w[0], x1 = (i0 & 1) ? b.w[3] : b.w[1];
@@ -1105,14 +1132,26 @@ __global__ __launch_bounds__(256, WPS) void k_run_ofdm_tdl_wave(SisoTdlParams pp
                 }
             }
             r16_wave_sync();                                                // every lane's reads of the transmit samples are issued
-            // y[q + 4 m'] is element gi + 64 q + 256 m' -- what pass A of the forward transform takes: straight from the registers
-            r16_dif<T, false, true, false, true>(pr, pi, lane, tw16, g_tw, y);   // bins at digit-reversed positions
+            if constexpr (R16) {
+                // y[q + 4 m'] is element gi + 64 q + 256 m' -- what pass A of the forward transform takes: straight from the registers
+                r16_dif<T, false, true, false, true>(pr, pi, lane, tw16, g_tw, y);   // bins at digit-reversed positions
+            } else {
+#pragma unroll
+                for (int c = 0; c < R; ++c) {
+                    const int sl = swz(gi) ^ swz(64 * c);
+                    pr[sl] = y[c].x;
+                    pi[sl] = y[c].y;
+                }
+                r16_wave_sync();
+                wave_fft_dif<T, N, false, WTW>(pr, g_tw, lane, twr4);
+            }
             r16_wave_sync();
             // ---- receive: one-tap equaliser from the tap means, demodulate, count -- POSITIONS gi, gi + 64, ...: position
-            //      p = p4 p3 p2 p1 p0 (base 4) holds bin f = p0 p1 p2 p3 p4, so f = F(gi) + F(64 k) with the second term a constant ----
+            //      p = p4 p3 p2 p1 p0 (base 4) holds bin f = p0 p1 p2 p3 p4, so f = F(gi) + F(64 k) with the second term a constant
+            //      (the digit reversal is a bit permutation, gi and 64 k share no bits) ----
             gi = opaque(lane);
-            const int f_lane = ((gi & 3) << 8) | (((gi >> 2) & 3) << 6) | (((gi >> 4) & 3) << 4);
-            const int slot_lane = lds_swz16f(gi);
+            const int f_lane = fft_index_of_pos<N>(gi);
+            const int slot_lane = swz(gi);
             const int hU = U / 2;
             cx<T> mean[kWaveMaxTaps];                                       // the symbol's tap means (wave-uniform) x w^(F(gi) d_s)
 #pragma unroll
@@ -1123,15 +1162,16 @@ __global__ __launch_bounds__(256, WPS) void k_run_ofdm_tdl_wave(SisoTdlParams pp
             // certificate's rare "not sure" is collected over the eight and served once, by the table search, behind them.
             const bool slicer = mp.method == MCLE_DEMOD_QAM_SLICER;
             const bool certpath = !slicer && mp.cert != 0;
+            constexpr int GRP = R < 8 ? R : 8;
 #pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                cx<T> eq[8];
-                int sent[8], dec[8];
-                bool valid[8];
+            for (int half = 0; half < R / GRP; ++half) {
+                cx<T> eq[GRP];
+                int sent[GRP], dec[GRP];
+                bool valid[GRP];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int k = 8 * half + j;
-                    const int f = f_lane | ((k & 3) << 2) | (k >> 2);
+                for (int j = 0; j < GRP; ++j) {
+                    const int k = GRP * half + j;
+                    const int f = f_lane | fft_index_of_pos<N>(64 * k);
                     int d;                                                  // data position of bin f (inverse of ofdm_bin)
                     if (U == N) {
                         d = (f + N / 2) & (N - 1);
@@ -1141,21 +1181,21 @@ __global__ __launch_bounds__(256, WPS) void k_run_ofdm_tdl_wave(SisoTdlParams pp
                         d = neg ? f - (N - hU) : (pos ? hU + f - 1 : 0);
                         valid[j] = neg || pos;
                     }
-                    const int bin = slot_lane ^ lds_swz16f(64 * k);
+                    const int bin = slot_lane ^ swz(64 * k);
                     eq[j] = cscale(mk<T>(pr[bin], pi[bin]), rx_scale);
                     sent[j] = (int)s_idx[d];
                 }
-                cx<T> h[8];
+                cx<T> h[GRP];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) h[j] = mk<T>(0, 0);
+                for (int j = 0; j < GRP; ++j) h[j] = mk<T>(0, 0);
 #pragma unroll
                 for (int s = 0; s < kWaveMaxTaps; ++s) {
                     if (s >= S) break;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) h[j] = cfma(mean[s], s_twk[(8 * half + j) * kWaveMaxTaps + s], h[j]);
+                    for (int j = 0; j < GRP; ++j) h[j] = cfma(mean[s], s_twk[(GRP * half + j) * kWaveMaxTaps + s], h[j]);
                 }
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
+                for (int j = 0; j < GRP; ++j) {
                     if constexpr (sizeof(T) == 8) {
                         eq[j] = cdivide(eq[j], h[j]);
                     } else {                    // complex64: one reciprocal instead of two divisions
@@ -1165,25 +1205,25 @@ __global__ __launch_bounds__(256, WPS) void k_run_ofdm_tdl_wave(SisoTdlParams pp
                 }
                 if (slicer) {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) dec[j] = demod_qam_slicer<T>(eq[j], mp.qam_scale, mp.qam_L, mp.half_bits);
+                    for (int j = 0; j < GRP; ++j) dec[j] = demod_qam_slicer<T>(eq[j], mp.qam_scale, mp.qam_L, mp.half_bits);
                 } else if (certpath) {
                     bool unsure = false;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
+                    for (int j = 0; j < GRP; ++j) {
                         bool sure;
                         dec[j] = demod_cert_any<T>(mp, eq[j], sure);
                         unsure = unsure || (valid[j] && !sure);
                     }
                     if (unsure) {
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) dec[j] = demod_one(mp, s_table, s_grid, eq[j]);
+                        for (int j = 0; j < GRP; ++j) dec[j] = demod_one(mp, s_table, s_grid, eq[j]);
                     }
                 } else {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) dec[j] = demod_one(mp, s_table, s_grid, eq[j]);
+                    for (int j = 0; j < GRP; ++j) dec[j] = demod_one(mp, s_table, s_grid, eq[j]);
                 }
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
+                for (int j = 0; j < GRP; ++j) {
                     const unsigned x = valid[j] ? (unsigned)(sent[j] ^ dec[j]) : 0u;
                     se += (x != 0u);
                     be += __popc(x);
@@ -1199,30 +1239,31 @@ __global__ __launch_bounds__(256, WPS) void k_run_ofdm_tdl_wave(SisoTdlParams pp
 }
 
 // host side: 0 = launched, MCLE_E_UNSUPPORTED = outside this kernel's envelope (the caller goes on to the batched kernels)
-template <typename T, int WPS>
+template <typename T, int N, int WPS>
 int run_siso_tdl_wave_w(mcle_ctx* ctx, const SisoTdlParams& pp, int method, uint64_t seed, uint64_t first, uint64_t count,
-                      mcle_counters* d_counters, uint32_t* d_sym, uint32_t* d_bit) {
-    constexpr int N = 1024;
+                        mcle_counters* d_counters, uint32_t* d_sym, uint32_t* d_bit) {
+    constexpr int R = N / 64;
     if (pp.cp < pp.dmax || pp.K > kTdlMaxK) return MCLE_E_UNSUPPORTED;
     int rc;
     void* tw = nullptr;
     if ((rc = ctx->get_twiddles(N, sizeof(T) == 8 ? MCLE_F64 : MCLE_F32, &tw))) return rc;
     const ModemParams<T> mp = pipe_modem<T>(ctx, method);
-    if (pp.dmax > 256 || pp.n_taps > kWaveMaxTaps || pp.n_taps * (pp.K + 2) > 128) return MCLE_E_UNSUPPORTED;   // (the prefix copy covers the last four 64-sample blocks)
+    // (the prefix copy covers the last four 64-sample blocks; a record is parked in two registers per lane)
+    if (pp.dmax > 256 || pp.dmax > N / 2 || pp.n_taps > kWaveMaxTaps || pp.n_taps * (pp.K + 2) > 128) return MCLE_E_UNSUPPORTED;
     SisoTdlParams pw = pp;
     pw.x_elems = N + ((pp.dmax + 15) & ~15);                                // plane pitch: N + the prefix the taps reach into
     const size_t lds = (size_t)4 * 2 * pw.x_elems * sizeof(T) + (((size_t)mp.M + 1) & ~(size_t)1) * sizeof(cx<T>) +
-                       (((size_t)mp.grid.G * mp.grid.G + 1) & ~(size_t)1) * sizeof(unsigned long long) + 16 * kWaveMaxTaps * sizeof(cx<T>) +
+                       (((size_t)mp.grid.G * mp.grid.G + 1) & ~(size_t)1) * sizeof(unsigned long long) + R * kWaveMaxTaps * sizeof(cx<T>) +
                        4 * (((size_t)pp.num_used + 15) & ~(size_t)15) + 16;
-    auto kern = k_run_ofdm_tdl_wave<T, 2, WPS>;      // the polynomial order is a compile-time constant (2 .. 8: Doppler x symbol
+    auto kern = k_run_ofdm_tdl_wave<T, N, 2, WPS>;   // the polynomial order is a compile-time constant (2 .. 8: Doppler x symbol
     switch (pp.K) {                                  // length up to ~0.1 turns in complex64; beyond: the batched kernels)
-        case 2: kern = k_run_ofdm_tdl_wave<T, 2, WPS>; break;
-        case 3: kern = k_run_ofdm_tdl_wave<T, 3, WPS>; break;
-        case 4: kern = k_run_ofdm_tdl_wave<T, 4, WPS>; break;
-        case 5: kern = k_run_ofdm_tdl_wave<T, 5, WPS>; break;
-        case 6: kern = k_run_ofdm_tdl_wave<T, 6, WPS>; break;
-        case 7: kern = k_run_ofdm_tdl_wave<T, 7, WPS>; break;
-        case 8: kern = k_run_ofdm_tdl_wave<T, 8, WPS>; break;
+        case 2: kern = k_run_ofdm_tdl_wave<T, N, 2, WPS>; break;
+        case 3: kern = k_run_ofdm_tdl_wave<T, N, 3, WPS>; break;
+        case 4: kern = k_run_ofdm_tdl_wave<T, N, 4, WPS>; break;
+        case 5: kern = k_run_ofdm_tdl_wave<T, N, 5, WPS>; break;
+        case 6: kern = k_run_ofdm_tdl_wave<T, N, 6, WPS>; break;
+        case 7: kern = k_run_ofdm_tdl_wave<T, N, 7, WPS>; break;
+        case 8: kern = k_run_ofdm_tdl_wave<T, N, 8, WPS>; break;
         default: return MCLE_E_UNSUPPORTED;
     }
     MCLE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1249,16 +1290,24 @@ int run_siso_tdl_wave_w(mcle_ctx* ctx, const SisoTdlParams& pp, int method, uint
     }
     return MCLE_OK;
 }
-
-template <typename T>
+template <typename T, int N>
 int run_siso_tdl_wave(mcle_ctx* ctx, const SisoTdlParams& pp, int method, uint64_t seed, uint64_t first, uint64_t count,
                       mcle_counters* d_counters, uint32_t* d_sym, uint32_t* d_bit) {
-    // wavefronts per SIMD the registers are bounded for: complex128 two (LDS: two workgroups per CU); complex64 three
+    // wavefronts per SIMD the registers are bounded for.  FFT 1024: complex128 two (LDS: two workgroups per CU); complex64 three
     // (MCLE_OPT_TDL_KERNEL = 4: four -- the LDS admits a fourth workgroup, but the 128-register bound spills 15 registers:
-    //  3.18 against 2.21 ms per 262 144 realizations)
-    if constexpr (sizeof(T) == 8) return run_siso_tdl_wave_w<T, 2>(ctx, pp, method, seed, first, count, d_counters, d_sym, d_bit);
-    else if (ctx->opt[MCLE_OPT_TDL_KERNEL] == 4) return run_siso_tdl_wave_w<T, 4>(ctx, pp, method, seed, first, count, d_counters, d_sym, d_bit);
-    else return run_siso_tdl_wave_w<T, 3>(ctx, pp, method, seed, first, count, d_counters, d_sym, d_bit);
+    //  3.18 against 2.21 ms per 262 144 realizations).  256 / 512: fewer samples per lane, three to six; 2048: complex64 only, two
+    //  (132 KiB of planes per workgroup in complex128: the batched kernel serves that one).
+    if constexpr (N == 2048) {
+        if constexpr (sizeof(T) == 8) return MCLE_E_UNSUPPORTED;
+        else return run_siso_tdl_wave_w<T, N, 2>(ctx, pp, method, seed, first, count, d_counters, d_sym, d_bit);
+    } else if constexpr (N == 1024) {
+        if constexpr (sizeof(T) == 8) return run_siso_tdl_wave_w<T, N, 2>(ctx, pp, method, seed, first, count, d_counters, d_sym, d_bit);
+        else if (ctx->opt[MCLE_OPT_TDL_KERNEL] == 4) return run_siso_tdl_wave_w<T, N, 4>(ctx, pp, method, seed, first, count, d_counters, d_sym, d_bit);
+        else return run_siso_tdl_wave_w<T, N, 3>(ctx, pp, method, seed, first, count, d_counters, d_sym, d_bit);
+    } else {        // registers: 96 / 118 (256), 124 / 158 (512) in complex64 (stage twiddles included) / complex128
+        constexpr int W = N == 256 ? (sizeof(T) == 8 ? 4 : 5) : (sizeof(T) == 8 ? 3 : 4);
+        return run_siso_tdl_wave_w<T, N, W>(ctx, pp, method, seed, first, count, d_counters, d_sym, d_bit);
+    }
 }
 
 template <typename T, int N>
@@ -1266,9 +1315,15 @@ int run_siso_tdl_batch_impl(mcle_ctx* ctx, SisoTdlParams pp, int method, uint64_
                             mcle_counters* d_counters, uint32_t* d_sym, uint32_t* d_bit) {
     constexpr int NB = sizeof(T) == 8 ? 2 : 4;    // complex128: two realizations per pass -> half the LDS, two workgroups per CU
     int rc;
-    if constexpr (N == 1024) {          // one realization per wavefront (default since round 4; MCLE_OPT_TDL_KERNEL = 1: the batched kernels)
-        if (ctx->opt[MCLE_OPT_TDL_KERNEL] != 1 && !ctx->opt[MCLE_OPT_NO_MFMA]) {
-            rc = run_siso_tdl_wave<T>(ctx, pp, method, seed, first, count, d_counters, d_sym, d_bit);
+    if constexpr (N == 256 || N == 512 || N == 1024 || N == 2048) {
+        // one realization per wavefront: the default where it is the faster kernel (profiles/r04/tdl_family_rates.json: 1024 both
+        // arithmetics x1.5, 2048 complex64 x2.7, 256 / 512 complex128 x1.5 / x1.2; the batched complex64 kernels keep 256 / 512, where
+        // the per-stage twiddle fetches of the radix-4 wavefront transform are not hidden: x0.54 / x0.86); MCLE_OPT_TDL_KERNEL = 1: the
+        // batched kernels everywhere, 2: the wavefront kernel wherever it exists
+        const bool faster = N >= 1024 || sizeof(T) == 8;
+        const long long sel = ctx->opt[MCLE_OPT_TDL_KERNEL];
+        if ((sel == 2 || sel == 4 || (sel == 0 && faster)) && !ctx->opt[MCLE_OPT_NO_MFMA]) {
+            rc = run_siso_tdl_wave<T, N>(ctx, pp, method, seed, first, count, d_counters, d_sym, d_bit);
             if (rc != MCLE_E_UNSUPPORTED) return rc;
         }
     }

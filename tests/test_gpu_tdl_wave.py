@@ -13,14 +13,14 @@ pytestmark = pytest.mark.gpu
 SEED = 31415926
 
 
-def _run(engine, first, count, dtype, wave=1, **kw):
+def _run(engine, first, count, dtype, wave=1, fft=1024, **kw):
     from pyphysim_amd.channels import discretize_profile
-    with engine.options(tdl_kernel=0 if wave else 1):
+    with engine.options(tdl_kernel=2 if wave else 1):            # 2: the wavefront kernel wherever it exists
         Ts = kw.get("Ts", 1.0 / (15e3 * 1024))
         p_lin, d_idx = discretize_profile(np.asarray(kw.get("tap_powers_dB", (0.0, -3.0, -6.0, -9.0, -12.0)), dtype=float),
                                           np.asarray(kw.get("tap_delays_samples", (0, 1, 2, 3, 4)), dtype=float) * Ts, Ts)
         nv = 1.0 / omodem.dB2Linear(kw.get("snr_db", 20.0))
-        return engine.run_ofdm_tdl(1024, kw.get("cp_size", 16), kw.get("num_used") or 1024, kw.get("n_ofdm_sym", 1), nv,
+        return engine.run_ofdm_tdl(fft, kw.get("cp_size", 16), kw.get("num_used") or fft, kw.get("n_ofdm_sym", 1), nv,
                                    p_lin, d_idx, SEED, first, count, Fd=kw.get("Fd", 10.0), Ts=Ts, L=kw.get("L", 8),
                                    method=kw.get("method", _lib.DEMOD_MINDIST), dtype=dtype, per_realization=True)
 
@@ -109,3 +109,45 @@ def test_wave_kernel_envelope(engine):
     a = _run(engine, 5, 40, "f64", **kw)
     b = _run(engine, 5, 40, "f64", wave=0, **kw)
     assert a[0] == b[0] and np.array_equal(a[1], b[1])
+
+
+# ---- the other sizes of the wavefront kernel: radix-4 stages on the wavefront's planes (256, 512, 2048; 2048 in complex64) ----
+SIZE_CASES = [dict(mod="qpsk", M=4, snr_db=20.0),
+              dict(mod="qam", M=16, snr_db=24.0, used_frac=0.6, n_ofdm_sym=2, cp_size=9, tap_delays_samples=(0, 2, 5, 9),
+                   tap_powers_dB=(0.0, -2.0, -5.0, -8.0), Fd=200.0),                         # partial band, odd prefix, 2 symbols
+              dict(mod="qam", M=64, snr_db=30.0, cp_size=64, n_ofdm_sym=3, method=_lib.DEMOD_QAM_SLICER,
+                   tap_delays_samples=(0, 1, 7, 20, 33, 50, 63, 64), tap_powers_dB=(0.0, -1.0, -2.0, -3.0, -4.0, -5.0, -6.0, -7.0))]
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("fft", [256, 512, 2048])
+@pytest.mark.parametrize("case", range(len(SIZE_CASES)))
+def test_wave_kernel_other_sizes(engine, case, fft, dtype):
+    kw = dict(SIZE_CASES[case])
+    mod, M = kw.pop("mod"), kw.pop("M")
+    used = fft if "used_frac" not in kw else 2 * int(kw.pop("used_frac") * fft / 2)
+    kw["num_used"] = used
+    engine.set_constellation(chains.constellation(mod, M), _lib.CONST_QAM if mod == "qam" else _lib.CONST_GENERIC)
+    first, count = (1 << 33) + 4242, 13
+    okw = dict(mod=mod, M=M, fft_size=fft, cp_size=kw.get("cp_size", 16), num_used=used,
+               n_ofdm_sym=kw.get("n_ofdm_sym", 1), snr_db=kw["snr_db"], Fd=kw.get("Fd", 10.0), L=kw.get("L", 8),
+               tap_powers_dB=kw.get("tap_powers_dB", (0.0, -3.0, -6.0, -9.0, -12.0)),
+               tap_delays_samples=kw.get("tap_delays_samples", (0, 1, 2, 3, 4)))
+    want = [chains.chain_ofdm_tdl(chains.PhiloxRng(SEED, r), **okw) for r in range(first, first + count)]
+    want_se = np.array([w["symbol_errors"] for w in want], dtype=np.int64)
+    want_be = np.array([w["bit_errors"] for w in want], dtype=np.int64)
+    nsym, nbits = want[0]["num_symbols"], want[0]["num_bits"]
+    res, se, be = _run(engine, first, count, dtype, fft=fft, **kw)
+    old, se_o, be_o = _run(engine, first, count, dtype, wave=0, fft=fft, **kw)
+    assert res["n_symbols"] == nsym and res["n_bits"] == nbits and res["n_realizations"] == count
+    if dtype == "f64":
+        assert np.array_equal(se, want_se) and np.array_equal(be, want_be), (case, fft, se, want_se)
+        assert np.array_equal(se, se_o) and np.array_equal(be, be_o)
+    else:
+        assert abs(int(se.sum()) - int(want_se.sum())) <= 1e-4 * count * nsym + 2
+        assert abs(int(be.sum()) - int(want_be.sum())) <= 1e-4 * count * nbits + 2
+        assert np.max(np.abs(se.astype(np.int64) - want_se)) <= 3
+        assert np.max(np.abs(se.astype(np.int64) - se_o.astype(np.int64))) <= 3
+    a = _run(engine, first, 5, dtype, fft=fft, **kw)
+    b = _run(engine, first + 5, count - 5, dtype, fft=fft, **kw)
+    assert np.array_equal(np.concatenate([a[1], b[1]]), se) and np.array_equal(np.concatenate([a[2], b[2]]), be)
