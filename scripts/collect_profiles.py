@@ -37,8 +37,8 @@ CONFIGS = {
     "c4_mfma": ("k_run_mimo_ofdm_mfma<", "k_run_mimo_ofdm_mfma<3,6> (complex64, FFT 1024, 4x4 on the matrix cores: option f32_mfma = 1, the default of rounds 2-3), QAM slicer"),
     "c4md_mfma": ("k_run_mimo_ofdm_mfma<", "k_run_mimo_ofdm_mfma<3,6> with the min-distance demodulator"),
     "f1": ("k_run_mimo_ofdm_tdl<", "k_run_mimo_ofdm_tdl<float,1024,4> (bench.py --config f1)"),
-    "c3": ("k_run_ofdm_tdl_wave<", "k_run_ofdm_tdl_wave<float, 2, 3> (complex64, FFT 1024, one realization per wavefront; k_tdl_symbol_polys runs before it)"),
-    "c3_f64": ("k_run_ofdm_tdl_wave<", "k_run_ofdm_tdl_wave<double, 5, 2> (complex128, one realization per wavefront)"),
+    "c3": ("k_run_ofdm_tdl_wave<", "k_run_ofdm_tdl_wave<float, 1024, 2, 3> (complex64, FFT 1024, one realization per wavefront; k_tdl_symbol_polys runs before it)"),
+    "c3_f64": ("k_run_ofdm_tdl_wave<", "k_run_ofdm_tdl_wave<double, 1024, 5, 2> (complex128, one realization per wavefront)"),
     "c3_mfma": ("k_run_ofdm_tdl_mfma<", "k_run_ofdm_tdl_mfma<2> (complex64 on the matrix cores, 4 realizations per pass: option tdl_kernel=1, the default of rounds 2-3)"),
     "c3_f64_batch": ("k_run_ofdm_tdl_batch<", "k_run_ofdm_tdl_batch<double,1024,2> (complex128, two realizations per pass: option tdl_kernel=1)"),
     "f1_f64": ("k_run_mimo_ofdm_tdl<", "k_run_mimo_ofdm_tdl<double,1024,4> (complex128, two workgroups per CU)"),
