@@ -880,19 +880,28 @@ int run_siso_tdl_mfma(mcle_ctx* ctx, const SisoTdlParams& pp, int method, uint64
 }
 
 
-// ---- config 3, ONE REALIZATION PER WAVEFRONT (round 4, late): FFT 1024, every delayed sample inside the symbol's own prefix ----
+// ---- config 3, ONE REALIZATION PER WAVEFRONT (round 4, late): every delayed sample inside the symbol's own prefix ----
 // The batched kernels above share every transform stage between the 256 threads of a workgroup: a dozen (k_run_ofdm_tdl_batch) or
 // four (k_run_ofdm_tdl_mfma) workgroup barriers per OFDM symbol, and the matrix-core kernel -- the default of rounds 2-3 -- left the
-// SIMDs idle a third of the time (VALU busy 0.50 + MFMA busy 0.14, profiles/r04/c3_pmc_summary.json).  Here a wavefront owns a
-// realization from its first data word to its error count: the radix-16 register passes of fft_r16.hpp (one 1024-point transform
-// per wavefront, planar LDS samples, three LDS round trips per transform) make the transforms wave-local, the tap delay line
-// reads x[m - d] from the wavefront's own planes, and NOTHING in the loop is a workgroup barrier -- four (complex128: two) such
-// wavefronts per SIMD run out of step and fill one another's stalls.  Wave-uniform data (the symbol's tap polynomials and
-// tap means) comes through scalar loads.  The noise of samples m, m + 1 -- one NOISE block -- belongs to lanes l, l + 1: the even
-// lane draws the blocks of eight of the sixteen samples a lane holds, the odd lane those of the other eight, and a DPP lane swap
-// hands over the halves (every block computed once: the draw ledger is unchanged).
-// Same arithmetic as k_run_ofdm_tdl_batch operation for operation outside the transforms (polynomial Horner, tap order,
-// equaliser), so complex128 counts equal the oracle's like that kernel's.
+// SIMDs idle a third of the time (VALU busy 0.54 + MFMA busy 0.16, profiles/r04/c3_mfma_pmc_summary.json).  Here a wavefront owns a
+// realization from its first data word to its error count:
+//   * transforms wave-local -- fft_r16.hpp: radix-16 register passes at 1024 (three LDS round trips per transform), radix-4 stages
+//     at 256 / 512 / 2048 -- so NOTHING in the loop is a workgroup barrier: the wavefronts of a CU run out of step and fill one
+//     another's stalls;
+//   * the time signal between the transforms in natural order BEHIND ITS CYCLIC PREFIX, in the memory the swizzled planes
+//     occupied (hand-over through registers both ways): x[m - d] is base(tap) + 64 c, immediate offsets, consecutive lanes on
+//     consecutive words;
+//   * the noise of samples m, m + 1 -- one NOISE block -- belongs to lanes l, l + 1: the even lane draws the blocks of half of the
+//     samples a lane holds, the odd lane those of the other half, a DPP lane swap hands over the halves (every block computed
+//     once: the draw ledger is unchanged);
+//   * nothing wave-uniform is fetched at its point of use: the symbol's record is one coalesced load parked across the lanes and
+//     read by v_readlane, tap delays and loop bounds are registers (loops unrolled to kWaveMaxTaps with a uniform guard), the
+//     polynomial order is a template parameter;
+//   * the equaliser walks POSITIONS, eight at a time, branch-free (loads batched; the certificate's rare "not sure" served once
+//     behind the eight); its twiddle w^(f d) = w^(F(lane) d) x w^(F(64 k) d): one gather per lane, tap and symbol + an LDS
+//     broadcast, instead of one gather per subcarrier and tap.
+// Same arithmetic as k_run_ofdm_tdl_batch operation for operation outside the transforms and the equaliser's twiddle product
+// (polynomial Horner, tap order, division), so complex128 counts equal the oracle's like that kernel's (tests/test_gpu_tdl_wave.py).
 constexpr int kWaveMaxTaps = 8;
 template <typename T> __device__ __forceinline__ T dpp_swap1(T v);
 template <> __device__ __forceinline__ float dpp_swap1<float>(float v) {         // the value of lane l ^ 1
