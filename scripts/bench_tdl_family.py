@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Realizations/s of config 3 (SISO OFDM over a 5-tap Jakes TDL channel, QPSK, cp 16, 20 dB) per fft_size and arithmetic: the
-one-realization-per-wavefront kernel (csrc/pipeline_siso_tdl.hip: k_run_ofdm_tdl_wave, default) next to the batched kernels it
+one-realization-per-wavefront kernel (csrc/siso_tdl_wave.hpp: k_run_ofdm_tdl_wave, default) next to the batched kernels it
 replaced (context option tdl_kernel=1).  One JSON object on stdout (profiles/r04/tdl_family_rates.json)."""
 import json
 import os

@@ -24,7 +24,9 @@ FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fno-gpu-rdc", "-fno-hip
 SOURCES = {"pipelines.hip": ("k_run_mimo_ofdm", "k_run_flat", "k_run_flat_mfma", "k_run_ofdm_tdl"),
            "pipeline_mimo_mfma.hip": ("k_run_mimo_ofdm_mfma", "k_mimo_filters"),
            "pipeline_mimo_planar.hip": ("k_run_mimo_ofdm_planar", "k_mimo_filters_planar"),
-           "pipeline_siso_tdl.hip": ("k_run_ofdm_tdl_wave", "k_run_ofdm_tdl_batch", "k_run_ofdm_tdl_mfma", "k_tdl_symbol_polys"),
+           "pipeline_siso_tdl.hip": ("k_run_ofdm_tdl_batch", "k_run_ofdm_tdl_mfma", "k_tdl_symbol_polys"),
+           "pipeline_siso_tdl_wave_f32.hip": ("k_run_ofdm_tdl_wave",),
+           "pipeline_siso_tdl_wave_f64.hip": ("k_run_ofdm_tdl_wave",),
            "pipeline_mimo_tdl.hip": ("k_run_mimo_ofdm_tdl", "k_mimo_tdl_symbol_polys"),
            "pipeline_mimo_flat.hip": ("k_mimo_flat_setup", "k_mimo_flat_link"),
            "kernels_ia.hip": ("k_ia_solve_links", "k_ia_link"),

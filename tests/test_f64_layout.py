@@ -252,7 +252,7 @@ def test_radix16_swizzle_meets_both_bank_rules_for_every_access_shape():
             assert swz16f(bin0 + t) == swz16f(bin0) ^ t
 
 
-# ---- config 3 with one realization per wavefront (csrc/pipeline_siso_tdl.hip: k_run_ofdm_tdl_wave): its index maps, restated ----
+# ---- config 3 with one realization per wavefront (csrc/siso_tdl_wave.hpp: k_run_ofdm_tdl_wave): its index maps, restated ----
 def test_wave_kernel_position_to_bin_map_and_inverse_band_map():
     """The equaliser walks POSITIONS p = lane + 64 k: bin f = F(lane) | F(64 k) with F(64 k) = ((k & 3) << 2) | (k >> 2), and
     the data index d of bin f is the inverse of fft.hpp's ofdm_bin (full band and partial band)."""

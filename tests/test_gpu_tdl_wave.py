@@ -1,4 +1,4 @@
-"""GPU: config 3 with one realization per WAVEFRONT (csrc/pipeline_siso_tdl.hip: k_run_ofdm_tdl_wave -- radix-16 register
+"""GPU: config 3 with one realization per WAVEFRONT (csrc/siso_tdl_wave.hpp: k_run_ofdm_tdl_wave -- radix-16 register
 passes of fft_r16.hpp, no workgroup barrier in the loop, DPP exchange of the noise halves; the default since round 4, option tdl_kernel = 1 selects the
 batched kernels) against the oracle
 chain under the same Philox keying and against the batched kernels it stands beside.  complex128: per-realization counts
