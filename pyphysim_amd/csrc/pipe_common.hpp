@@ -35,8 +35,13 @@ __device__ __forceinline__ void block_sum2(unsigned& a, unsigned& b, unsigned* s
 // as the first ones finish, which evens out per-workgroup speed differences and shortens the tail -- measured on the
 // matrix-core kernels (MCLE_OPT_GRID_OVERSUB = 1 / 2 / 4 / 8 / 16 / 32): config 4 1.516 / 1.458 / 1.415 / 1.401 / 1.411 / 2.02 ms
 // per 65 536 realizations, config 3 1.602 / 1.575 / 1.555 / 1.541 / 1.550 / 1.608 ms per 131 072.
-inline uint64_t oversubscribed_grid(const mcle_ctx* ctx, uint64_t resident, uint64_t units, uint64_t min_units = 8) {
-    uint64_t f = 8;
+// Round 4: the planar config-4 kernels take up to SIXTEEN times the resident set (10.75 -> 10.66 ms complex128, 4.77 -> 4.70 ms
+// complex64 per 262 144 realizations); the wavefront kernels of config 3 need >= 12 units (48 realizations) per workgroup -- their
+// set-up (tables, twiddles, one barrier) is heavier: 2.17 -> 1.94 ms per 262 144, 1.20 -> 0.88 ms per 104 860
+// (scripts/experiments/r04_oversub_probe.py).
+inline uint64_t oversubscribed_grid(const mcle_ctx* ctx, uint64_t resident, uint64_t units, uint64_t min_units = 8,
+                                    uint64_t max_f = 8) {
+    uint64_t f = max_f;
     if (ctx->opt[MCLE_OPT_GRID_OVERSUB] > 0) {
         f = (uint64_t)ctx->opt[MCLE_OPT_GRID_OVERSUB];
     } else {

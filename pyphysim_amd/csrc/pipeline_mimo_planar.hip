@@ -535,7 +535,7 @@ static int launch_mimo_ofdm_planar(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg,
         hipLaunchKernelGGL((k_mimo_filters_planar<T, N, NT, NR>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, pp, seed,
                            first + off, n, (cx<T>*)recs);
         MCLE_LAUNCH_CHECK();
-        const unsigned grid = (unsigned)oversubscribed_grid(ctx, resident, n);
+        const unsigned grid = (unsigned)oversubscribed_grid(ctx, resident, n, 8, 16);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(TB), lds, ctx->stream, pp, mp, seed, first + off, n,
                            (const cx<T>*)tw, (const cx<T>*)recs, d_counters, d_sym ? d_sym + off : nullptr,
                            d_bit ? d_bit + off : nullptr);

@@ -431,7 +431,7 @@ int run_siso_tdl_wave_w(mcle_ctx* ctx, const SisoTdlParams& pp, int method, uint
         hipLaunchKernelGGL(k_tdl_symbol_polys<T>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream, pp, N + pp.cp,
                            seed, first + off, n, (cx<T>*)recs);
         MCLE_LAUNCH_CHECK();
-        const unsigned grid = (unsigned)oversubscribed_grid(ctx, (uint64_t)ctx->n_cu * per_cu, (n + 3) / 4);
+        const unsigned grid = (unsigned)oversubscribed_grid(ctx, (uint64_t)ctx->n_cu * per_cu, (n + 3) / 4, 12);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, ctx->stream, pw, mp, seed, first + off, n, (const cx<T>*)tw,
                            (const cx<T>*)recs, d_counters, d_sym ? d_sym + off : nullptr, d_bit ? d_bit + off : nullptr);
         MCLE_LAUNCH_CHECK();
