@@ -128,7 +128,12 @@ enum {
                                       1 = the batched kernels of rounds 1-3 everywhere (four / two realizations per workgroup pass;
                                       complex64 at 1024: matrix cores), 2 = the wavefront kernel wherever it exists, 4 = the same with
                                       the complex64 registers at 1024 bounded for four wavefronts per SIMD instead of three (A/B) */
-    MCLE_OPT_COUNT = 14
+    MCLE_OPT_MIMO_TDL_KERNEL = 14, /* frequency-selective MIMO-OFDM (mcle_run_mimo_ofdm_tdl) at fft_size 256 / 512 / 1024 / 2048 with every tap
+                                      delay inside the cyclic prefix (<= 8 taps, <= 256 samples): 0 = one receive antenna per WAVEFRONT
+                                      (k_run_mimo_ofdm_tdl_wave, every 1 <= Nt <= Nr <= 4; default since round 5), 1 = the
+                                      workgroup-cooperative kernel of rounds 1-4 (Nt = Nr in {2, 4}), 2 = the wavefront kernels with the
+                                      tap polynomials' order at run time also where the parked-coefficient kernel applies (A/B) */
+    MCLE_OPT_COUNT = 15
 };
 int mcle_ctx_set_option(mcle_ctx* ctx, int option, long long value);
 int mcle_ctx_get_option(mcle_ctx* ctx, int option, long long* value);

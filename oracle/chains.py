@@ -440,7 +440,7 @@ def chain_ia_general(rng, algo, mod, M, K, nr, nt, Ns, NSymbs, snr_db, max_itera
 
 def chain_mimo_ofdm_tdl(rng, mod='qam', M=16, nt=2, nr=2, fft_size=64, cp_size=16, num_used=None, n_ofdm_sym=2,
                         snr_db=20.0, Fd=50.0, Ts=1e-6, L=8, tap_powers_dB=(0.0, -4.0, -9.0),
-                        tap_delays_samples=(0, 2, 5)):
+                        tap_delays_samples=(0, 2, 5), mmse=True, linear_mean=False):
     """spatial multiplexing over a frequency-selective MIMO TDL channel
     (TdlMimoChannel, fading.py:1290-1333 + the MIMO branch of corrupt_data :1107-1117), per-antenna OFDM
     and one MMSE receive filter per subcarrier built from the per-symbol mean frequency response
@@ -467,9 +467,11 @@ def chain_mimo_ofdm_tdl(rng, mod='qam', M=16, nt=2, nr=2, fft_size=64, cp_size=1
     noise = rng.cn(philox.STREAM_NOISE, nr, faded.shape[1])
     R = faded + math.sqrt(noise_var) * noise
     Y = np.stack([oofdm.demodulate(R[r, :n].copy(), fft_size, cp_size, used) for r in range(nr)])   # [nr, ns]
-    Hm = och.mean_freq_response(taps, d_idx, fft_size, cp_size, n_ofdm_sym)      # [n_sym, fft, nr, nt]
+    # linear_mean: the DFT of the per-symbol mean taps instead of the mean of per-sample DFTs (equal by linearity, 30 x cheaper:
+    # och.mean_freq_response_linear; the deep GPU parity tests use it)
+    Hm = (och.mean_freq_response_linear if linear_mean else och.mean_freq_response)(taps, d_idx, fft_size, cp_size, n_ofdm_sym)
     Hu = Hm[:, oofdm.used_subcarrier_indexes(fft_size, used)].reshape(-1, nr, nt)  # [ns, nr, nt]
-    G = np.stack([omimo.blast_receive_filter(Hu[c], noise_var) for c in range(Hu.shape[0])])
+    G = np.stack([omimo.blast_receive_filter(Hu[c], noise_var if mmse else 0.0) for c in range(Hu.shape[0])])
     est = np.einsum('car,rc->ca', G, Y).reshape(-1)               # est[c*nt + a]
     dec = omodem.demodulate(table, est)
     return _counts(dict(table=table, idx=idx, T=T, phi=phi, psi=psi, taps=taps, delay_indexes=d_idx,

@@ -100,7 +100,10 @@ __device__ __forceinline__ void r16_wave_sync() {
 // the pass becomes the radix-4 stages' arithmetic operation for operation (bit-identical outputs).
 // REGIN: the sixteen inputs come from the caller's registers (vin[q + 4 m] = element QS q + MS m) instead of the planes.
 // REGOUT: the sixteen outputs go to the caller's registers (vout[q + 4 m]) instead of the planes.
-template <typename T, bool INV, bool DIT, int WHICH, bool EXACT = false, bool REGIN = false, bool REGOUT = false>
+// BAR: a workgroup barrier between the pass's arithmetic and its stores -- for a caller whose planes are still being READ by the
+// other wavefronts of the workgroup when the pass starts (mimo_tdl_wave.hpp: the receive transform's first pass takes its inputs
+// from registers while the other receive antennas finish their delay-line reads of this antenna's time signal).
+template <typename T, bool INV, bool DIT, int WHICH, bool EXACT = false, bool REGIN = false, bool REGOUT = false, bool BAR = false>
 __device__ __forceinline__ void r16_pass(T* pr, T* pi, int base_slot, const R16Tw64<T>& tw,
                                          const cx<T>* __restrict__ g_tw = nullptr, int kidx = 0, const cx<T>* vin = nullptr,
                                          cx<T>* vout = nullptr) {
@@ -173,6 +176,7 @@ __device__ __forceinline__ void r16_pass(T* pr, T* pi, int base_slot, const R16T
             r4_inplace<T, INV>(v[0][q], v[1][q], v[2][q], v[3][q]);
         });
     }
+    if constexpr (BAR) __syncthreads();
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -210,11 +214,11 @@ template <typename T, bool INV> __device__ __forceinline__ void r16_pass_c(T* pr
 }
 // natural -> digit-reversed (the arrangement of the radix-4 DIF stages) / digit-reversed -> natural; one wavefront, one antenna
 // vin != nullptr (REGIN): pass A takes element gi + 64 q + 256 m of the input from vin[q + 4 m] (the caller's registers)
-template <typename T, bool INV, bool WITH_C = true, bool EXACT = false, bool REGIN = false>
+template <typename T, bool INV, bool WITH_C = true, bool EXACT = false, bool REGIN = false, bool BAR = false>
 __device__ __forceinline__ void r16_dif(T* pr, T* pi, int lane, const R16Tw64<T>& tw, const cx<T>* __restrict__ g_tw = nullptr,
                                         const cx<T>* vin = nullptr) {
     int gi = opaque(lane);
-    r16_pass<T, INV, false, 0, EXACT, REGIN>(pr, pi, lds_swz16f(gi), tw, g_tw, gi, vin);
+    r16_pass<T, INV, false, 0, EXACT, REGIN, false, BAR>(pr, pi, lds_swz16f(gi), tw, g_tw, gi, vin);
     r16_wave_sync();
     gi = opaque(lane);
     r16_pass<T, INV, false, 1, EXACT>(pr, pi, lds_swz16f(64 * (gi >> 2) + (gi & 3)), tw, g_tw, gi & 3);

@@ -183,6 +183,88 @@ __device__ __forceinline__ bool blast_solve_t(const cx<R> (&H)[NR][NT], R nv, co
     return ok;
 }
 
+// The same solve from the Gram matrix: A[i][k] (i >= k: lower triangle, real diagonal in .x) = sum_r conj(H[r][i]) H[r][k] and
+// b[i] = sum_r conj(H[r][i]) y[r] accumulated ROW BY ROW by the caller (blast_gram_row) -- a kernel that forms H(f) one receive
+// antenna at a time (mimo_tdl_wave.hpp) never holds the whole Nr x Nt matrix of a subcarrier, let alone of several.  Same
+// operations in the same order as blast_solve_t (sum over r ascending, then + nv on the diagonal, Cholesky, two substitutions).
+template <typename R, int NT>
+__device__ __forceinline__ void blast_gram_row(const cx<R> (&h)[NT], cx<R> yr, cx<R> (&A)[NT][NT], cx<R> (&b)[NT]) {
+#pragma unroll
+    for (int k = 0; k < NT; ++k) {
+        A[k][k].x += h[k].x * h[k].x + h[k].y * h[k].y;
+#pragma unroll
+        for (int i = k + 1; i < NT; ++i) {
+            if constexpr (sizeof(R) == 4) A[i][k] = cx_macc(A[i][k], h[k], h[i]);
+            else A[i][k] = cadd(A[i][k], cmulc(h[k], h[i]));                  // conj(h[i]) * h[k]
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        if constexpr (sizeof(R) == 4) b[i] = cx_macc(b[i], yr, h[i]);
+        else b[i] = cadd(b[i], cmulc(yr, h[i]));                              // conj(h[i]) * y
+    }
+}
+template <typename R, int NT>
+__device__ __forceinline__ bool blast_solve_gram(const cx<R> (&A)[NT][NT], R nv, const cx<R> (&b)[NT], cx<R> (&x)[NT]) {
+    typedef cx<R> C;
+    C L[NT][NT];
+    R invd[NT];
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+#pragma unroll
+        for (int i = j; i < NT; ++i) {
+            C a = A[i][j];
+            if (i == j) {
+                a.x += nv;
+                a.y = 0;
+            }
+#pragma unroll
+            for (int k = 0; k < j; ++k) {
+                if constexpr (sizeof(R) == 4) a = cx_msubc(a, L[i][k], L[j][k]);
+                else a = csub(a, cmulc(L[i][k], L[j][k]));
+            }
+            if (i == j) {
+                ok = ok && (a.x > (R)(sizeof(R) == 8 ? 1e-300 : 1e-30));
+                if constexpr (sizeof(R) == 4) {
+                    invd[j] = __builtin_amdgcn_rsqf(a.x);
+                    L[j][j] = mk<R>(a.x * invd[j], (R)0);
+                } else {
+                    L[j][j] = mk<R>(sqrt(a.x), (R)0);
+                    invd[j] = (R)1 / L[j][j].x;
+                }
+            } else {
+                L[i][j] = cscale(a, invd[j]);
+            }
+        }
+    }
+    C z[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {  // L z = H^H y
+        C v = b[i];
+#pragma unroll
+        for (int k = 0; k < i; ++k) {
+            if constexpr (sizeof(R) == 4) v = cx_msub(v, L[i][k], z[k]);
+            else v = csub(v, cmul(L[i][k], z[k]));
+        }
+        z[i] = cscale(v, invd[i]);
+    }
+    const R root_nt = (R)sqrt((double)NT);
+#pragma unroll
+    for (int i = NT - 1; i >= 0; --i) {  // L^H w = z
+        C v = z[i];
+#pragma unroll
+        for (int k = i + 1; k < NT; ++k) {
+            if constexpr (sizeof(R) == 4) v = cx_msub(v, mk<R>(L[k][i].x, -L[k][i].y), z[k]);
+            else v = csub(v, cmul(cconj(L[k][i]), z[k]));
+        }
+        z[i] = cscale(v, invd[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < NT; ++i) x[i] = cscale(z[i], root_nt);
+    return ok;
+}
+
 template <int NT, int NR>
 __device__ __forceinline__ bool blast_filter(const double2 (&H)[NR][NT], double nv, double2 (&G)[NT][NR]) {
     return blast_filter_t<double, NT, NR>(H, nv, G);

@@ -1,0 +1,112 @@
+// mimo_tdl.hpp -- what the frequency-selective MIMO-OFDM link kernels share: the parameter block and
+// the kernel that turns a symbol's Jakes rays into tap polynomials (pipeline_mimo_tdl.hip: the workgroup-cooperative kernel of
+// rounds 1-4; mimo_tdl_wave.hpp: one receive antenna per wavefront, round 5).
+#pragma once
+#include "common.hpp"
+#include "jakes.hpp"
+#include "philox.hpp"
+
+namespace mcle {
+
+constexpr int kMaxOrder = 12;
+#ifndef FFT_FRESH
+#define FFT_FRESH true
+#endif
+
+struct MimoTdlParams {
+    int cp, num_used, n_ofdm_sym, mmse;
+    int n_taps, L, K, dmax;
+    int x_elems;                     // complex elements of the sample buffer (>= NA*N; also holds the ray scratch)
+    double noise_var, Fd, Ts, dt;
+    double tap_amp[MCLE_MAX_TAPS];   // sqrt(p_s / L)
+    int tap_delay[MCLE_MAX_TAPS];
+    double mom[kMaxOrder + 1];       // mean over the symbol's N+cp samples of x^m, x = j - (N+cp-1)/2
+};
+
+// The fading of one OFDM symbol in its own launch (round 3, as k_tdl_symbol_polys did for config 3): one thread per
+// (realization, symbol, fading process p = (tap s, rx r, tx a)) folds the process's L rays -- phasor at the symbol centre and
+// phase advance per sample, the f64 phase arithmetic of fading_generators.py:427-493 -- into the K + 1 polynomial
+// coefficients of g_p(x) around the centre and their mean over the symbol (the equaliser's tap).  Inside the link kernel this
+// ran on 2.5 rounds of 256 threads between three workgroup barriers per symbol: 10 % of its time for 3 % of its arithmetic.
+// Record per (realization, symbol): [PS][K + 1] coefficients, then [PS] means; same operations in the same order as before.
+// WAVE (round 5, mimo_tdl_wave.hpp: one receive antenna per wavefront): the coefficients in the order a wavefront parks them
+// across its lanes -- receive antenna r, register q = m / 2, lane 2 (s Nt + a) + m % 2 (P1 = Nr Nt, NT = Nt): record =
+// [Nr][NQ][LW] coefficients, NQ = (K + 2) / 2 registers of LW = 2 S Nt lanes, then the [PS] means; the same values.
+__host__ __device__ __forceinline__ int mimo_tdl_nq(int K) { return (K + 2) / 2; }
+__host__ __device__ __forceinline__ size_t mimo_tdl_wave_rec(int S, int NT, int NR, int K) {
+    return (size_t)NR * mimo_tdl_nq(K) * (2 * S * NT) + (size_t)S * NR * NT;
+}
+template <typename T, bool WAVE = false>
+__global__ __launch_bounds__(256) void k_mimo_tdl_symbol_polys(MimoTdlParams pp, int PS, int P1, int W, uint64_t seed,
+                                                               uint64_t first, uint64_t count, cx<T>* __restrict__ recs,
+                                                               int NT = 0) {
+    const int L = pp.L, K = pp.K;
+    const uint64_t per_real = (uint64_t)pp.n_ofdm_sym * PS;
+    const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= count * per_real) return;
+    const uint64_t rl = q / per_real;
+    const int rem = (int)(q - rl * per_real), os = rem / PS, p = rem - os * PS;
+    const double two_pi = 6.283185307179586476925286766559;
+    const double xc = 0.5 * (double)(W - 1);
+    const double tc = pp.Ts + pp.dt * ((double)((uint64_t)os * W) + xc);
+    const Rng rng(seed, first + rl);
+    T ar[kMaxOrder + 1], ai[kMaxOrder + 1];
+#pragma unroll
+    for (int m = 0; m <= kMaxOrder; ++m) ar[m] = ai[m] = 0;
+    for (int l = 0; l < L; ++l) {
+        const uint64_t rq = (uint64_t)l * PS + p;                          // PHASE-stream index of phi
+        const double psi_t = uniform_at(rng, STREAM_PHASE, (uint64_t)L * PS + rq);
+        const double w = pp.Fd * cospi(2.0 * uniform_at(rng, STREAM_PHASE, rq));   // Hz; cos(phi), phi = 2 pi u
+        const double ph = fma(w, tc, psi_t);                               // turns
+        const double fr = __builtin_amdgcn_fract(ph);
+        T er, ei;
+        if constexpr (sizeof(T) == 8) {
+            double sn, cs;
+            sincos(two_pi * fr, &sn, &cs);
+            er = cs;
+            ei = sn;
+        } else {
+            er = __builtin_amdgcn_cosf((float)fr);
+            ei = __builtin_amdgcn_sinf((float)fr);
+        }
+        const T th = (T)(two_pi * w * pp.dt);                              // rad per sample
+#pragma unroll
+        for (int m = 0; m <= kMaxOrder; ++m)
+            if (m <= K) {
+                T pw = 1;                                                  // 1 / m! ...
+                for (int i = 2; i <= m; ++i) pw /= (T)i;
+                for (int i = 0; i < m; ++i) pw *= th;                      // ... x theta^m
+                ar[m] += er * pw;
+                ai[m] += ei * pw;
+            }
+    }
+    const T amp = (T)pp.tap_amp[p / P1];
+    const int S = PS / P1;
+    [[maybe_unused]] const int NR = WAVE ? P1 / NT : 0, NQ = mimo_tdl_nq(K), LW = WAVE ? 2 * S * NT : 0;
+    cx<T>* rec = recs + (rl * pp.n_ofdm_sym + os) * (WAVE ? (uint64_t)mimo_tdl_wave_rec(S, NT, NR, K) : (uint64_t)PS * (K + 2));
+    T mr = 0, mi = 0;
+#pragma unroll
+    for (int m = 0; m <= kMaxOrder; ++m)
+        if (m <= K) {
+            T cr, ci;                                                      // times j^m
+            switch (m & 3) {
+                case 0: cr = ar[m]; ci = ai[m]; break;
+                case 1: cr = -ai[m]; ci = ar[m]; break;
+                case 2: cr = -ar[m]; ci = -ai[m]; break;
+                default: cr = ai[m]; ci = -ar[m]; break;
+            }
+            const cx<T> c = mk<T>(amp * cr, amp * ci);
+            if constexpr (WAVE) {
+                const int s = p / P1, ra = p - s * P1, r = ra / NT, a = ra - r * NT;
+                rec[(r * NQ + (m >> 1)) * LW + 2 * (s * NT + a) + (m & 1)] = c;
+            } else {
+                rec[p * (K + 1) + m] = c;
+            }
+            mr += c.x * (T)pp.mom[m];
+            mi += c.y * (T)pp.mom[m];
+        }
+    rec[(WAVE ? NR * NQ * LW : PS * (K + 1)) + p] = mk<T>(mr, mi);
+}
+
+
+}  // namespace mcle

@@ -25,6 +25,7 @@
 #include "fft.hpp"
 #include "jakes.hpp"
 #include "mimo.hpp"
+#include "mimo_tdl.hpp"
 #include "modem.hpp"
 #include "philox.hpp"
 #include "pipe_common.hpp"
@@ -32,91 +33,6 @@
 #include "totals.hpp"
 
 namespace mcle {
-
-constexpr int kMaxOrder = 12;
-#ifndef FFT_FRESH
-#define FFT_FRESH true
-#endif
-
-struct MimoTdlParams {
-    int cp, num_used, n_ofdm_sym, mmse;
-    int n_taps, L, K, dmax;
-    int x_elems;                     // complex elements of the sample buffer (>= NA*N; also holds the ray scratch)
-    double noise_var, Fd, Ts, dt;
-    double tap_amp[MCLE_MAX_TAPS];   // sqrt(p_s / L)
-    int tap_delay[MCLE_MAX_TAPS];
-    double mom[kMaxOrder + 1];       // mean over the symbol's N+cp samples of x^m, x = j - (N+cp-1)/2
-};
-
-// The fading of one OFDM symbol in its own launch (round 3, as k_tdl_symbol_polys did for config 3): one thread per
-// (realization, symbol, fading process p = (tap s, rx r, tx a)) folds the process's L rays -- phasor at the symbol centre and
-// phase advance per sample, the f64 phase arithmetic of fading_generators.py:427-493 -- into the K + 1 polynomial
-// coefficients of g_p(x) around the centre and their mean over the symbol (the equaliser's tap).  Inside the link kernel this
-// ran on 2.5 rounds of 256 threads between three workgroup barriers per symbol: 10 % of its time for 3 % of its arithmetic.
-// Record per (realization, symbol): [PS][K + 1] coefficients, then [PS] means; same operations in the same order as before.
-template <typename T>
-__global__ __launch_bounds__(256) void k_mimo_tdl_symbol_polys(MimoTdlParams pp, int PS, int P1, int W, uint64_t seed,
-                                                               uint64_t first, uint64_t count, cx<T>* __restrict__ recs) {
-    const int L = pp.L, K = pp.K;
-    const uint64_t per_real = (uint64_t)pp.n_ofdm_sym * PS;
-    const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= count * per_real) return;
-    const uint64_t rl = q / per_real;
-    const int rem = (int)(q - rl * per_real), os = rem / PS, p = rem - os * PS;
-    const double two_pi = 6.283185307179586476925286766559;
-    const double xc = 0.5 * (double)(W - 1);
-    const double tc = pp.Ts + pp.dt * ((double)((uint64_t)os * W) + xc);
-    const Rng rng(seed, first + rl);
-    T ar[kMaxOrder + 1], ai[kMaxOrder + 1];
-#pragma unroll
-    for (int m = 0; m <= kMaxOrder; ++m) ar[m] = ai[m] = 0;
-    for (int l = 0; l < L; ++l) {
-        const uint64_t rq = (uint64_t)l * PS + p;                          // PHASE-stream index of phi
-        const double psi_t = uniform_at(rng, STREAM_PHASE, (uint64_t)L * PS + rq);
-        const double w = pp.Fd * cospi(2.0 * uniform_at(rng, STREAM_PHASE, rq));   // Hz; cos(phi), phi = 2 pi u
-        const double ph = fma(w, tc, psi_t);                               // turns
-        const double fr = __builtin_amdgcn_fract(ph);
-        T er, ei;
-        if constexpr (sizeof(T) == 8) {
-            double sn, cs;
-            sincos(two_pi * fr, &sn, &cs);
-            er = cs;
-            ei = sn;
-        } else {
-            er = __builtin_amdgcn_cosf((float)fr);
-            ei = __builtin_amdgcn_sinf((float)fr);
-        }
-        const T th = (T)(two_pi * w * pp.dt);                              // rad per sample
-#pragma unroll
-        for (int m = 0; m <= kMaxOrder; ++m)
-            if (m <= K) {
-                T pw = 1;                                                  // 1 / m! ...
-                for (int i = 2; i <= m; ++i) pw /= (T)i;
-                for (int i = 0; i < m; ++i) pw *= th;                      // ... x theta^m
-                ar[m] += er * pw;
-                ai[m] += ei * pw;
-            }
-    }
-    const T amp = (T)pp.tap_amp[p / P1];
-    cx<T>* rec = recs + (rl * pp.n_ofdm_sym + os) * (uint64_t)PS * (K + 2);
-    T mr = 0, mi = 0;
-#pragma unroll
-    for (int m = 0; m <= kMaxOrder; ++m)
-        if (m <= K) {
-            T cr, ci;                                                      // times j^m
-            switch (m & 3) {
-                case 0: cr = ar[m]; ci = ai[m]; break;
-                case 1: cr = -ai[m]; ci = ar[m]; break;
-                case 2: cr = -ar[m]; ci = -ai[m]; break;
-                default: cr = ai[m]; ci = -ar[m]; break;
-            }
-            const cx<T> c = mk<T>(amp * cr, amp * ci);
-            rec[p * (K + 1) + m] = c;
-            mr += c.x * (T)pp.mom[m];
-            mi += c.y * (T)pp.mom[m];
-        }
-    rec[PS * (K + 1) + p] = mk<T>(mr, mi);
-}
 
 // wavefronts per SIMD the register allocation is bounded for = workgroups per CU the LDS admits: three (complex64) / two
 // (complex128), but ONE at 2048 x 4 antennas (64 / 128 KiB of samples): bounded for more, those two instantiations spilled
@@ -515,6 +431,47 @@ int run_mimo_tdl_impl(mcle_ctx* ctx, MimoTdlParams pp, int method, uint64_t seed
     return MCLE_OK;
 }
 
+// one receive antenna per wavefront (mimo_tdl_wave.hpp; pipeline_mimo_tdl_wave_<arithmetic>_<size>[k].hip): 0 = launched,
+// MCLE_E_UNSUPPORTED = outside their envelope
+#define MCLE_MIMO_TDL_WAVE_DECL(NAME)                                                                                         \
+    int NAME(mcle_ctx* ctx, int nt, int nr, const MimoTdlParams& pp, int method, uint64_t seed, uint64_t first, uint64_t count, \
+             mcle_counters* d_counters, uint32_t* d_sym, uint32_t* d_bit);
+MCLE_MIMO_TDL_WAVE_DECL(run_mimo_tdl_wave_f32_256) MCLE_MIMO_TDL_WAVE_DECL(run_mimo_tdl_wave_f32_512)
+MCLE_MIMO_TDL_WAVE_DECL(run_mimo_tdl_wave_f32_1024) MCLE_MIMO_TDL_WAVE_DECL(run_mimo_tdl_wave_f32_1024k)
+MCLE_MIMO_TDL_WAVE_DECL(run_mimo_tdl_wave_f32_2048)
+MCLE_MIMO_TDL_WAVE_DECL(run_mimo_tdl_wave_f64_256) MCLE_MIMO_TDL_WAVE_DECL(run_mimo_tdl_wave_f64_512)
+MCLE_MIMO_TDL_WAVE_DECL(run_mimo_tdl_wave_f64_1024) MCLE_MIMO_TDL_WAVE_DECL(run_mimo_tdl_wave_f64_1024k)
+MCLE_MIMO_TDL_WAVE_DECL(run_mimo_tdl_wave_f64_2048)
+#undef MCLE_MIMO_TDL_WAVE_DECL
+
+// the envelope of the wavefront kernels: fft_size 256 .. 2048, every tap delay inside the cyclic prefix (no inter-symbol
+// interference to carry), <= 8 taps reaching <= 256 samples (and <= N / 2) back
+static bool mimo_tdl_wave_envelope(const MimoTdlParams& pp, int fft_size) {
+    return (fft_size == 256 || fft_size == 512 || fft_size == 1024 || fft_size == 2048) && pp.cp >= pp.dmax && pp.dmax <= 256 &&
+           pp.dmax <= fft_size / 2 && pp.n_taps <= 8;
+}
+// run_time_order: the run-time-order kernels also where the parked-coefficient kernel applies (MCLE_OPT_MIMO_TDL_KERNEL = 2, A/B)
+static int run_mimo_tdl_wave(mcle_ctx* ctx, int dtype, int fft_size, int nt, int nr, const MimoTdlParams& pp, bool run_time_order,
+                             int method, uint64_t seed, uint64_t first, uint64_t count, mcle_counters* d_counters, uint32_t* d_sym,
+                             uint32_t* d_bit) {
+    const bool f32 = dtype == MCLE_F32;
+#define MCLE_WAVE_CALL(NAME) NAME(ctx, nt, nr, pp, method, seed, first, count, d_counters, d_sym, d_bit)
+    switch (fft_size) {
+        case 256: return f32 ? MCLE_WAVE_CALL(run_mimo_tdl_wave_f32_256) : MCLE_WAVE_CALL(run_mimo_tdl_wave_f64_256);
+        case 512: return f32 ? MCLE_WAVE_CALL(run_mimo_tdl_wave_f32_512) : MCLE_WAVE_CALL(run_mimo_tdl_wave_f64_512);
+        case 2048: return f32 ? MCLE_WAVE_CALL(run_mimo_tdl_wave_f32_2048) : MCLE_WAVE_CALL(run_mimo_tdl_wave_f64_2048);
+        case 1024: {
+            if (!run_time_order) {
+                const int rc = f32 ? MCLE_WAVE_CALL(run_mimo_tdl_wave_f32_1024k) : MCLE_WAVE_CALL(run_mimo_tdl_wave_f64_1024k);
+                if (rc != MCLE_E_UNSUPPORTED) return rc;
+            }
+            return f32 ? MCLE_WAVE_CALL(run_mimo_tdl_wave_f32_1024) : MCLE_WAVE_CALL(run_mimo_tdl_wave_f64_1024);
+        }
+        default: return MCLE_E_UNSUPPORTED;
+    }
+#undef MCLE_WAVE_CALL
+}
+
 }  // namespace mcle
 
 using namespace mcle;
@@ -524,8 +481,8 @@ extern "C" int mcle_run_mimo_ofdm_tdl(mcle_ctx* ctx, int dtype, const mcle_mimo_
                                       uint32_t* d_sym_err, uint32_t* d_bit_err) {
     int rc = check_pipe(ctx, dtype, cfg ? cfg->demod_method : 0, cfg);
     if (rc) return rc;
-    MCLE_REQUIRE(cfg->nt == cfg->nr && (cfg->nt == 2 || cfg->nt == 4),
-                 "fused MIMO-TDL pipeline supports 2x2 and 4x4 (use the staged operators otherwise)");
+    MCLE_REQUIRE(cfg->nt >= 1 && cfg->nt <= cfg->nr && cfg->nr <= 4,
+                 "fused MIMO-TDL pipeline: 1 <= Nt <= Nr <= 4 (got %d x %d; use the staged operators otherwise)", cfg->nt, cfg->nr);
     MCLE_REQUIRE(cfg->cp_size >= 0 && cfg->cp_size <= cfg->fft_size,
                  "cp_size must be nonnegative and cannot be greater than fft_size");
     MCLE_REQUIRE(cfg->num_used >= 2 && cfg->num_used % 2 == 0 && cfg->num_used <= cfg->fft_size,
@@ -593,6 +550,21 @@ extern "C" int mcle_run_mimo_ofdm_tdl(mcle_ctx* ctx, int dtype, const mcle_mimo_
     }
     if (count == 0) return MCLE_OK;
     if ((rc = ctx->bind())) return rc;
+    // one receive antenna per wavefront (round 5; every 1 <= Nt <= Nr <= 4 at fft_size 256 .. 2048 with the taps inside the prefix);
+    // MCLE_OPT_MIMO_TDL_KERNEL: 1 = the workgroup-cooperative kernel of rounds 1-4 (Nt = Nr in {2, 4}), 2 = run-time-order kernels
+    const long long sel = ctx->opt[MCLE_OPT_MIMO_TDL_KERNEL];
+    if (sel != 1 && mimo_tdl_wave_envelope(pp, cfg->fft_size)) {
+        rc = run_mimo_tdl_wave(ctx, dtype, cfg->fft_size, cfg->nt, cfg->nr, pp, sel == 2, cfg->demod_method, seed, first, count,
+                               d_counters, d_sym_err, d_bit_err);
+        if (rc != MCLE_E_UNSUPPORTED) return rc;
+    }
+    if (!(cfg->nt == cfg->nr && (cfg->nt == 2 || cfg->nt == 4))) {
+        set_error("fused MIMO-TDL pipeline: %d x %d at fft_size %d with cp %d / largest delay %d / %d taps is outside the wavefront "
+                  "kernels' envelope (fft_size 256 .. 2048, every delay inside the prefix, <= 8 taps) and the cooperative kernel "
+                  "takes Nt = Nr in {2, 4} only (use the staged operator chain)",
+                  cfg->nt, cfg->nr, cfg->fft_size, cfg->cp_size, pp.dmax, cfg->n_taps);
+        return MCLE_E_UNSUPPORTED;
+    }
 #define MCLE_RUN(N_, NA_)                                                                                       \
     if (cfg->fft_size == N_ && cfg->nt == NA_)                                                                  \
         return dtype == MCLE_F32 ? run_mimo_tdl_impl<float, N_, NA_>(ctx, pp, cfg->demod_method, seed, first,   \

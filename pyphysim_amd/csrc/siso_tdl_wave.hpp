@@ -11,6 +11,7 @@
 #include "pipe_common.hpp"
 #include "siso_tdl.hpp"
 #include "totals.hpp"
+#include "wave_lanes.hpp"
 
 namespace mcle {
 
@@ -37,21 +38,6 @@ namespace mcle {
 // Same arithmetic as k_run_ofdm_tdl_batch operation for operation outside the transforms and the equaliser's twiddle product
 // (polynomial Horner, tap order, division), so complex128 counts equal the oracle's like that kernel's (tests/test_gpu_tdl_wave.py).
 constexpr int kWaveMaxTaps = 8;
-template <typename T> __device__ __forceinline__ T dpp_swap1(T v);
-template <> __device__ __forceinline__ float dpp_swap1<float>(float v) {         // the value of lane l ^ 1
-    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));
-}
-// lane j's value of a VGPR as a wave-uniform scalar (j wave-uniform)
-__device__ __forceinline__ float lane_value(float v, int j) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), j)); }
-__device__ __forceinline__ double lane_value(double v, int j) {
-    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), j), __builtin_amdgcn_readlane(__double2loint(v), j));
-}
-template <> __device__ __forceinline__ double dpp_swap1<double>(double v) {
-    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0xB1, 0xF, 0xF, true);
-    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0xB1, 0xF, 0xF, true);
-    return __hiloint2double(hi, lo);
-}
-
 // N = 1024: the radix-16 passes with register hand-over on both sides of the channel.  N = 256 / 512 / 2048: radix-4 stages on the
 // wavefront's planes (fft_r16.hpp: wave_fft_dif / wave_fft_dit, N / 256 butterfly positions per lane and stage), the same
 // hand-over through explicit reads and writes; everything between the transforms is the same code on R = N / 64 samples per lane.

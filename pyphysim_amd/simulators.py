@@ -240,7 +240,9 @@ class MimoOfdmTdlSimulator(_LinkSimulator):
 
     def _launch(self, current_parameters, first_rep, count, per_realization):
         p = current_parameters
-        if self.fused and p["Nt"] == p["Nr"] and p["Nt"] in (2, 4) and p["fft_size"] in self._FUSED_FFT:
+        # fused kernels: every 1 <= Nt <= Nr <= 4 at fft_size 256 .. 2048 with the taps inside the prefix (one receive antenna per
+        # wavefront, round 5), Nt = Nr in {2, 4} at 64 .. 2048 otherwise; the C ABI reports anything else as unsupported
+        if self.fused and 1 <= p["Nt"] <= p["Nr"] <= 4 and p["fft_size"] in self._FUSED_FFT:
             try:
                 eng = self._bind()
                 return eng.run_mimo_ofdm_tdl(
@@ -252,7 +254,7 @@ class MimoOfdmTdlSimulator(_LinkSimulator):
                 if self.fused is True:
                     raise
         elif self.fused is True:
-            raise ValueError("the fused pipeline supports Nt == Nr in {2, 4} and fft_size in {64, 128, ..., 2048}")
+            raise ValueError("the fused pipeline supports 1 <= Nt <= Nr <= 4 and fft_size in {64, 128, ..., 2048}")
         return self._launch_staged(p, first_rep, count, per_realization)
 
     def _launch_staged(self, p, first_rep, count, per_realization):
