@@ -174,7 +174,11 @@ int mcle_ctx_set_option(mcle_ctx* ctx, int option, long long value) {
     switch (option) {
         case MCLE_OPT_NO_MFMA: case MCLE_OPT_SINGLE_TDL: case MCLE_OPT_JAKES_DIRECT: case MCLE_OPT_F64_GENERIC: case MCLE_OPT_BD_RUNTIME_SOLVE: case MCLE_OPT_DEMOD_NOCERT: case MCLE_OPT_F32_MFMA: ok = value == 0 || value == 1; break;
         case MCLE_OPT_TDL_KERNEL: ok = value == 0 || value == 1 || value == 2 || value == 4; break;
+#ifdef MCLE_EXPERIMENTS
+        case MCLE_OPT_MIMO_TDL_KERNEL: ok = value >= 0 && value <= 255; break;
+#else
         case MCLE_OPT_MIMO_TDL_KERNEL: ok = value >= 0 && value <= 2; break;
+#endif
         case MCLE_OPT_F64_VARIANT: ok = value >= 0 && value <= 3; break;
         case MCLE_OPT_MFMA_VARIANT: ok = value == 0 || value == 36 || value == 32 || value == 30 || value == 21; break;
         case MCLE_OPT_GRID_OVERSUB: ok = value >= 0 && value <= 64; break;

@@ -7,6 +7,7 @@
 // ill-conditioned channel (cond(H^H H) ~ 1e4 at 25 dB) out of f32 trouble.
 #pragma once
 #include "common.hpp"
+#include "pkcx.hpp"
 
 namespace mcle {
 
@@ -194,13 +195,13 @@ __device__ __forceinline__ void blast_gram_row(const cx<R> (&h)[NT], cx<R> yr, c
         A[k][k].x += h[k].x * h[k].x + h[k].y * h[k].y;
 #pragma unroll
         for (int i = k + 1; i < NT; ++i) {
-            if constexpr (sizeof(R) == 4) A[i][k] = cx_macc(A[i][k], h[k], h[i]);
+            if constexpr (sizeof(R) == 4) A[i][k] = from_pk(pk_cfma_conj(to_pk(h[k]), to_pk(h[i]), to_pk(A[i][k])));
             else A[i][k] = cadd(A[i][k], cmulc(h[k], h[i]));                  // conj(h[i]) * h[k]
         }
     }
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
-        if constexpr (sizeof(R) == 4) b[i] = cx_macc(b[i], yr, h[i]);
+        if constexpr (sizeof(R) == 4) b[i] = from_pk(pk_cfma_conj(to_pk(yr), to_pk(h[i]), to_pk(b[i])));
         else b[i] = cadd(b[i], cmulc(yr, h[i]));                              // conj(h[i]) * y
     }
 }

@@ -21,6 +21,9 @@ struct MimoTdlParams {
     double tap_amp[MCLE_MAX_TAPS];   // sqrt(p_s / L)
     int tap_delay[MCLE_MAX_TAPS];
     double mom[kMaxOrder + 1];       // mean over the symbol's N+cp samples of x^m, x = j - (N+cp-1)/2
+    // the wavefront kernels (mimo_tdl_wave.hpp): tap s expanded around the symbol centre MINUS its delay, so that the channel stage
+    // evaluates every tap at the output sample's abscissa; mean over the symbol's samples of (j + d_s - (N+cp-1)/2)^m
+    double mom_tap[8][kMaxOrder + 1];
 };
 
 // The fading of one OFDM symbol in its own launch (round 3, as k_tdl_symbol_polys did for config 3): one thread per
@@ -48,7 +51,9 @@ __global__ __launch_bounds__(256) void k_mimo_tdl_symbol_polys(MimoTdlParams pp,
     const int rem = (int)(q - rl * per_real), os = rem / PS, p = rem - os * PS;
     const double two_pi = 6.283185307179586476925286766559;
     const double xc = 0.5 * (double)(W - 1);
-    const double tc = pp.Ts + pp.dt * ((double)((uint64_t)os * W) + xc);
+    // WAVE: the polynomial of tap s in the OUTPUT sample's abscissa x' = x + d_s -- the same rays about the centre minus d_s samples
+    const int tap = p / P1;
+    const double tc = pp.Ts + pp.dt * ((double)((uint64_t)os * W) + (WAVE ? xc - (double)pp.tap_delay[tap] : xc));
     const Rng rng(seed, first + rl);
     T ar[kMaxOrder + 1], ai[kMaxOrder + 1];
 #pragma unroll
@@ -102,8 +107,9 @@ __global__ __launch_bounds__(256) void k_mimo_tdl_symbol_polys(MimoTdlParams pp,
             } else {
                 rec[p * (K + 1) + m] = c;
             }
-            mr += c.x * (T)pp.mom[m];
-            mi += c.y * (T)pp.mom[m];
+            const T mo = (T)(WAVE ? pp.mom_tap[tap & 7][m] : pp.mom[m]);
+            mr += c.x * mo;
+            mi += c.y * mo;
         }
     rec[(WAVE ? NR * NQ * LW : PS * (K + 1)) + p] = mk<T>(mr, mi);
 }

@@ -39,6 +39,7 @@
 #include "modem.hpp"
 #include "philox.hpp"
 #include "pipe_common.hpp"
+#include "pkcx.hpp"
 #include "totals.hpp"
 #include "wave_lanes.hpp"
 
@@ -87,10 +88,41 @@ template <int N, int BQ> __host__ __device__ __forceinline__ int mimo_wave_p0(in
     }
 }
 
+// One (tap, transmit antenna, sample) step of the channel: g = Horner(cc, xx) (a polynomial with complex coefficients in a real
+// abscissa), y += g xv.  complex64: four v_pk_fma_f32 -- Horner one per order on the (re, im) pair, the complex multiply-add two
+// (pkcx.hpp: op_sel / neg modifiers swap and negate the halves); written on clang vector types and explicit instructions because
+// the backend does not form the packed Horner from scalar FMAs with wave-uniform coefficients (4 v_fma + 2 v_pk_fma + 3 v_mov per step).
+template <int KO, bool ASM = true> __device__ __forceinline__ void chan_step(float2& y, const float2 (&cc)[KO + 1], float xx, float2 xv) {
+    pk2 g = {cc[KO].x, cc[KO].y};
+    const pk2 x2 = {xx, xx};
+#pragma unroll
+    for (int mm = KO - 1; mm >= 0; --mm) g = __builtin_elementwise_fma(g, x2, (pk2){cc[mm].x, cc[mm].y});
+    if constexpr (ASM) {
+        y = from_pk(pk_cfma(g, to_pk(xv), to_pk(y)));
+    } else {
+        pk2 acc = {y.x, y.y};
+        acc = __builtin_elementwise_fma((pk2){g.x, g.x}, (pk2){xv.x, xv.y}, acc);
+        acc = __builtin_elementwise_fma((pk2){-g.y, g.y}, (pk2){xv.y, xv.x}, acc);
+        y = from_pk(acc);
+    }
+}
+template <int KO, bool ASM = true> __device__ __forceinline__ void chan_step(double2& y, const double2 (&cc)[KO + 1], double xx, double2 xv) {
+    double2 g = cc[KO];
+#pragma unroll
+    for (int mm = KO - 1; mm >= 0; --mm) {
+        g.x = fma(g.x, xx, cc[mm].x);
+        g.y = fma(g.y, xx, cc[mm].y);
+    }
+    y = cfma(g, xv, y);
+}
+
 // T, N: arithmetic, fft_size.  NT x NR: the geometry (NR wavefronts).  KT: polynomial order of the taps, compile time (> 0: the
 // coefficients parked in (KT + 2) / 2 registers) or 0 = run time (coefficients fetched from the record by wave-uniform loads).
 // BQ: subcarriers per decode work item (1, 2, 4).  WPS: wavefronts per SIMD the registers are bounded for.
-template <typename T, int N, int NT, int NR, int KT, int BQ, int WPS>
+// ABL (builds with -DMCLE_EXPERIMENTS only, option mimo_tdl_kernel = 16 + ABL): stage ablation for TIMING -- wrong results by
+// construction: bit 0 the channel's tap loop, 1 the noise, 2 the Cholesky solves, 3 H(f) and the Gram rows, 4 the demodulator,
+// 5 the four transform passes that are not fused with a hand-over, 6 the scatter's draws.
+template <typename T, int N, int NT, int NR, int KT, int BQ, int WPS, int ABL = 0>
 __global__ __launch_bounds__(64 * NR, WPS) void k_run_mimo_ofdm_tdl_wave(MimoTdlParams pp, ModemParams<T> mp, uint64_t seed, uint64_t first,
                                                                          uint64_t count, const cx<T>* __restrict__ g_tw,
                                                                          const cx<T>* __restrict__ g_polys, mcle_counters* counters,
@@ -102,6 +134,8 @@ __global__ __launch_bounds__(64 * NR, WPS) void k_run_mimo_ofdm_tdl_wave(MimoTdl
     constexpr int TB = 64 * NR;
     constexpr int NQK = KT > 0 ? (KT + 2) / 2 : 1;                          // parked registers (compile-time order)
     constexpr int WI = N / (64 * BQ);                                       // decode work items per symbol
+    // the channel's delayed samples double-buffered: 2 x 32 more registers, which a complex64 wavefront has at two per SIMD
+    constexpr bool CHAN_DB = sizeof(T) == 4 && KT > 0 && WPS <= 2;
     static_assert(WI >= 1, "BQ");
     auto swz = [](int e) { return R16 ? lds_swz16f(e) : lds_swz64(e); };
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -130,8 +164,8 @@ __global__ __launch_bounds__(64 * NR, WPS) void k_run_mimo_ofdm_tdl_wave(MimoTdl
     unsigned* s_part = reinterpret_cast<unsigned*>(s_idx + ((NT * U + 15) & ~15));         // [2][4][2]
     T* pr = s_all + w * 2 * pitch;                                         // transform planes of this antenna: re [0, N), im [N, 2 N)
     T* pi = pr + N;
-    T* xr = pr;                                                             // natural-order signal with prefix: re [0, pitch),
-    T* xi = pr + pitch;                                                     // im [pitch, 2 pitch) -- the same memory, never live together
+    cx<T>* xp = reinterpret_cast<cx<T>*>(pr);                              // natural-order signal with prefix, (re, im) interleaved:
+                                                                            // [0, pitch) -- the same memory, never live together
     __shared__ double s_bm[sizeof(T) == 8 ? kBmLdsDoubles : 1];             // complex128 Box-Muller tables (bm_f64.hpp)
     if constexpr (sizeof(T) == 8) bm_tables_to_lds(s_bm, tid, TB);
     const T sigma = (T)sqrt(pp.noise_var);
@@ -264,50 +298,42 @@ __global__ __launch_bounds__(64 * NR, WPS) void k_run_mimo_ofdm_tdl_wave(MimoTdl
                 r16_wave_sync();                                            // every lane's reads of the planes are issued
                 gi = opaque(lane);
 #pragma unroll
-                for (int c = 0; c < R; ++c) {
-                    xr[P + gi + 64 * c] = y[c].x;
-                    xi[P + gi + 64 * c] = y[c].y;
-                }
+                for (int c = 0; c < R; ++c) xp[P + gi + 64 * c] = y[c];
 #pragma unroll
                 for (int c = (R > 4 ? R - 4 : 0); c < R; ++c)               // the prefix: the last P samples once more (P <= 256)
-                    if (gi + 64 * c >= N - P) {
-                        xr[gi + 64 * c - (N - P)] = y[c].x;
-                        xi[gi + 64 * c - (N - P)] = y[c].y;
-                    }
+                    if (gi + 64 * c >= N - P) xp[gi + 64 * c - (N - P)] = y[c];
             }
             __syncthreads();                                                // B2: every transmit signal is in place
-            // ---- channel: y_r[m] = sum_s sum_a g_sra(j) x_a[j],  j = cp + m - d_s, for this lane's R samples m = gi + 64 c ----
+            // ---- channel: y_r[m] = sum_s sum_a g_sra(x) x_a[m - d_s] for this lane's R samples m = gi + 64 c.  The polynomials of this
+            //      record are expanded around the OUTPUT sample (k_mimo_tdl_symbol_polys<T, true>: tap s about the symbol centre minus
+            //      d_s samples), so one abscissa x = cp + m - xc serves every tap: exact (half-)integers below 2^12, in float too ----
             gi = opaque(lane);
 #pragma unroll
             for (int c = 0; c < R; ++c) y[c] = mk<T>(0, 0);
-            for (int s = 0; s < S; ++s) {
-                const int d = __builtin_amdgcn_readlane(dlyv, s);
-                // (double) q - xc rounded to T, q = cp + m - d: q and xc are (half-)integers below 2^12 -- exact in float too
-                const T x0 = sizeof(T) == 8 ? (T)((double)(cp + gi - d) - xc) : (T)(cp + gi - d) - (T)xc;
-#pragma nounroll   // unrolled, the Nt antennas' loads are hoisted together (4 x 32 registers) and spill
-                for (int a = 0; a < NT; ++a) {
-                    const int ln0 = 2 * (s * NT + a);
-                    const T* xdr = s_all + a * 2 * pitch + (P + gi - d);    // x_a[m - d] = xdr[64 c]: d <= P
-                    const T* xdi = xdr + pitch;
+            {
+                const T x0 = sizeof(T) == 8 ? (T)((double)(cp + gi) - xc) : (T)(cp + gi) - (T)xc;
+                const int NP = (ABL & 1) ? 0 : S * NT;                      // (tap, transmit antenna) pairs, p = s NT + a
+                const cx<T>* xbase = reinterpret_cast<const cx<T>*>(s_all) + (P + gi);
+                // the R delayed samples of pair p: x_a[m - d] = xd[64 c], d <= P -- one address, immediate offsets
+                auto load_pair = [&](int p, cx<T> (&buf)[R]) {
+                    const int s = p / NT, a = p - s * NT;
+                    const cx<T>* xd = xbase + (a * pitch - __builtin_amdgcn_readlane(dlyv, s));
+#pragma unroll
+                    for (int c = 0; c < R; ++c) {
+                        if constexpr (ABL & 64) buf[c] = mk<T>((T)(size_t)xd, x0);   // (timing: the channel stage without its LDS reads)
+                        else buf[c] = xd[64 * c];
+                    }
+                };
+                auto mac_pair = [&](int p, const cx<T> (&buf)[R]) {
                     if constexpr (KT > 0) {
                         cx<T> cc[KT + 1];
 #pragma unroll
                         for (int m = 0; m <= KT; ++m)
-                            cc[m] = mk<T>(lane_value(prk[m >> 1].x, ln0 + (m & 1)), lane_value(prk[m >> 1].y, ln0 + (m & 1)));
+                            cc[m] = mk<T>(lane_value(prk[m >> 1].x, 2 * p + (m & 1)), lane_value(prk[m >> 1].y, 2 * p + (m & 1)));
 #pragma unroll
-                        for (int c = 0; c < R; ++c) {
-                            const cx<T> xv = mk<T>(xdr[64 * c], xdi[64 * c]);
-                            const T xx = x0 + (T)(64 * c);                  // exact
-                            cx<T> g = cc[KT];
-#pragma unroll
-                            for (int mm = KT - 1; mm >= 0; --mm) {
-                                g.x = fma(g.x, xx, cc[mm].x);
-                                g.y = fma(g.y, xx, cc[mm].y);
-                            }
-                            y[c] = cfma(g, xv, y[c]);
-                        }
+                        for (int c = 0; c < R; ++c) chan_step<KT, !(ABL & 128)>(y[c], cc, x0 + (T)(64 * c) /* exact */, buf[c]);
                     } else {                    // run-time order: the coefficients by wave-uniform loads from the record, four
-                        const cx<T>* __restrict__ cb = g_rec + (size_t)w * NQ * LW + ln0;   // samples at a time (registers)
+                        const cx<T>* __restrict__ cb = g_rec + (size_t)w * NQ * LW + 2 * p;   // samples at a time (registers)
                         constexpr int CH = R < 4 ? R : 4;
 #pragma unroll
                         for (int c0 = 0; c0 < R; c0 += CH) {
@@ -325,16 +351,36 @@ __global__ __launch_bounds__(64 * NR, WPS) void k_run_mimo_ofdm_tdl_wave(MimoTdl
                                 }
                             }
 #pragma unroll
-                            for (int c = 0; c < CH; ++c)
-                                y[c0 + c] = cfma(g[c], mk<T>(xdr[64 * (c0 + c)], xdi[64 * (c0 + c)]), y[c0 + c]);
+                            for (int c = 0; c < CH; ++c) y[c0 + c] = cfma(g[c], buf[c0 + c], y[c0 + c]);
                         }
+                    }
+                };
+                if constexpr (CHAN_DB) {        // two sample buffers: the loads of pair p + 1 fly while pair p is consumed
+                    cx<T> xa[R], xb[R];
+                    if (NP > 0) load_pair(0, xa);
+                    int p = 0;
+#pragma nounroll
+                    for (; p + 1 < NP; p += 2) {
+                        load_pair(p + 1, xb);
+                        mac_pair(p, xa);
+                        if (p + 2 < NP) load_pair(p + 2, xa);
+                        mac_pair(p + 1, xb);
+                    }
+                    if (p < NP) mac_pair(p, xa);
+                } else {
+#pragma nounroll
+                    for (int p = 0; p < NP; ++p) {
+                        cx<T> xa[R];
+                        load_pair(p, xa);
+                        mac_pair(p, xa);
                     }
                 }
             }
             if constexpr (R16) tw16 = load_r16_tw<T>(g_tw, opaque(lane));    // in flight behind the noise draws
             // ---- noise: sample w noise_row + sym0 + cp + m of the NOISE stream ----
             const uint64_t nbase = (uint64_t)w * noise_row + sym0 + (uint64_t)cp;
-            if ((nbase & 1) == 0) {             // lanes l (even), l + 1 share the block of samples m, m + 1
+            if constexpr (ABL & 2) {
+            } else if ((nbase & 1) == 0) {      // lanes l (even), l + 1 share the block of samples m, m + 1
                 const bool odd = (gi & 1) != 0;
 #pragma unroll
                 for (int j = 0; j < R / 2; ++j) {
@@ -423,7 +469,7 @@ __global__ __launch_bounds__(64 * NR, WPS) void k_run_mimo_ofdm_tdl_wave(MimoTdl
                         for (int k = 0; k < NT; ++k) A[j][i][k] = mk<T>(0, 0);
                     }
 #pragma unroll
-                for (int r = 0; r < NR; ++r) {
+                for (int r = 0; r < ((ABL & 8) ? 0 : NR); ++r) {
                     cx<T> u[BQ][NT];                                        // sums by delay class, then the BQ bins' row r of H
 #pragma unroll
                     for (int c = 0; c < BQ; ++c)
@@ -434,23 +480,29 @@ __global__ __launch_bounds__(64 * NR, WPS) void k_run_mimo_ofdm_tdl_wave(MimoTdl
                         if (s >= S) break;
                         cx<T> t[NT];
 #pragma unroll
-                        for (int a = 0; a < NT; ++a) t[a] = cmul(s_mean[(s * NR + r) * NT + a], Wt[s]);
-                        const int cls = dly[s] & (BQ - 1);
-#pragma unroll
-                        for (int c = 0; c < BQ; ++c)
-                            if (cls == c) {                                 // wave-uniform
-#pragma unroll
-                                for (int a = 0; a < NT; ++a) u[c][a] = cadd(u[c][a], t[a]);
-                            }
-                    }
-                    if constexpr (BQ == 2) {
-#pragma unroll
                         for (int a = 0; a < NT; ++a) {
-                            const cx<T> e = u[0][a], o = u[1][a];
-                            u[0][a] = cadd(e, o);
-                            u[1][a] = csub(e, o);
+                            if constexpr (sizeof(T) == 4 && !(ABL & 128)) t[a] = from_pk(pk_cmul(to_pk(s_mean[(s * NR + r) * NT + a]), to_pk(Wt[s])));
+                            else t[a] = cmul(s_mean[(s * NR + r) * NT + a], Wt[s]);
                         }
-                    } else if constexpr (BQ == 4) {
+                        if constexpr (BQ == 2) {                            // H(f0) += t, H(f0 + N / 2) += (-1)^d t: no select, no branch
+                            const T sg = (dly[s] & 1) ? (T)-1 : (T)1;
+#pragma unroll
+                            for (int a = 0; a < NT; ++a) {
+                                u[0][a] = cadd(u[0][a], t[a]);
+                                u[1][a].x = fma(sg, t[a].x, u[1][a].x);
+                                u[1][a].y = fma(sg, t[a].y, u[1][a].y);
+                            }
+                        } else {
+                            const int cls = dly[s] & (BQ - 1);
+#pragma unroll
+                            for (int c = 0; c < BQ; ++c)
+                                if (cls == c) {                             // wave-uniform
+#pragma unroll
+                                    for (int a = 0; a < NT; ++a) u[c][a] = cadd(u[c][a], t[a]);
+                                }
+                        }
+                    }
+                    if constexpr (BQ == 4) {
 #pragma unroll
                         for (int a = 0; a < NT; ++a) r4_inplace<T, false>(u[0][a], u[1][a], u[2][a], u[3][a]);
                     }
@@ -465,12 +517,21 @@ __global__ __launch_bounds__(64 * NR, WPS) void k_run_mimo_ofdm_tdl_wave(MimoTdl
 #pragma unroll
                 for (int j = 0; j < BQ; ++j) {
                     cx<T> x[NT];
-                    const bool ok = blast_solve_gram<T, NT>(A[j], nv_filter, b[j], x);      // filter applied, never formed
+                    bool ok = true;
+                    if constexpr (ABL & 4) {
+#pragma unroll
+                        for (int a = 0; a < NT; ++a) x[a] = cadd(b[j][a], A[j][a][0]);
+                    } else {
+                        ok = blast_solve_gram<T, NT>(A[j], nv_filter, b[j], x);            // filter applied, never formed
+                    }
 #pragma unroll
                     for (int a = 0; a < NT; ++a) est[j * NT + a] = ok ? cscale(x[a], rx_scale) : mk<T>(0, 0);   // singular: ZF only
                 }
                 int dec[BQ * NT];
-                if (slicer) {
+                if constexpr (ABL & 16) {
+#pragma unroll
+                    for (int i = 0; i < BQ * NT; ++i) dec[i] = (int)est[i].x & 63;
+                } else if (slicer) {
 #pragma unroll
                     for (int i = 0; i < BQ * NT; ++i) dec[i] = demod_qam_slicer<T>(est[i], mp.qam_scale, mp.qam_L, mp.half_bits);
                 } else if (certpath) {
@@ -523,7 +584,7 @@ __global__ __launch_bounds__(64 * NR, WPS) void k_run_mimo_ofdm_tdl_wave(MimoTdl
 
 // host side: 0 = launched, MCLE_E_UNSUPPORTED = outside this kernel's envelope (the caller goes on to the kernel of rounds 1-4 or
 // reports the configuration as one for the staged operator chain)
-template <typename T, int N, int NT, int NR, int KT, int BQ, int WPS>
+template <typename T, int N, int NT, int NR, int KT, int BQ, int WPS, int ABL = 0>
 int launch_mimo_tdl_wave(mcle_ctx* ctx, const MimoTdlParams& pp, int method, uint64_t seed, uint64_t first, uint64_t count,
                          mcle_counters* d_counters, uint32_t* d_sym, uint32_t* d_bit) {
     int rc;
@@ -540,7 +601,7 @@ int launch_mimo_tdl_wave(mcle_ctx* ctx, const MimoTdlParams& pp, int method, uin
                        (((size_t)NT * pp.num_used + 15) & ~(size_t)15) + 16 * sizeof(unsigned);
     const size_t lds_static = (sizeof(T) == 8 ? (size_t)kBmLdsDoubles * 8 : 8) + sizeof(WgTotals) + 64;
     if (lds + lds_static > (size_t)160 * 1024) return MCLE_E_UNSUPPORTED;
-    auto kern = k_run_mimo_ofdm_tdl_wave<T, N, NT, NR, KT, BQ, WPS>;
+    auto kern = k_run_mimo_ofdm_tdl_wave<T, N, NT, NR, KT, BQ, WPS, ABL>;
     MCLE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int per_cu = (int)((size_t)160 * 1024 / (lds + lds_static + 256));
     const int by_waves = WPS * 4 / NR;                                      // what __launch_bounds__ allocated registers for
@@ -569,6 +630,8 @@ int launch_mimo_tdl_wave(mcle_ctx* ctx, const MimoTdlParams& pp, int method, uin
 
 // wavefronts per SIMD the registers are bounded for (= workgroups of 4 wavefronts per CU the LDS admits at Nr = 4): 1024 and below
 // complex64 3 / complex128 2; 2048: 2 / 1.  Subcarriers per decode work item: 2 where a wavefront has at least two.
+// (complex64 at 1024: three -- 4.47 ms per 83 886 realizations with 12 spilled registers against 4.89 at two, where nothing spills
+//  and the channel's delayed samples are double-buffered, and 4.91 at four: scripts/experiments/r05_call7.sh)
 template <typename T, int N> constexpr int mimo_tdl_wave_wps() { return N >= 2048 ? (sizeof(T) == 8 ? 1 : 2) : (sizeof(T) == 8 ? 2 : 3); }
 template <int N, int NR> constexpr int mimo_tdl_wave_bq() { return N / (64 * NR) >= 2 ? 2 : 1; }
 // the polynomial order whose coefficients are parked in registers (the order of the benchmark's Doppler in each arithmetic);

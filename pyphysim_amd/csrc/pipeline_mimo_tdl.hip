@@ -443,6 +443,10 @@ MCLE_MIMO_TDL_WAVE_DECL(run_mimo_tdl_wave_f64_256) MCLE_MIMO_TDL_WAVE_DECL(run_m
 MCLE_MIMO_TDL_WAVE_DECL(run_mimo_tdl_wave_f64_1024) MCLE_MIMO_TDL_WAVE_DECL(run_mimo_tdl_wave_f64_1024k)
 MCLE_MIMO_TDL_WAVE_DECL(run_mimo_tdl_wave_f64_2048)
 #undef MCLE_MIMO_TDL_WAVE_DECL
+#ifdef MCLE_EXPERIMENTS
+int run_mimo_tdl_wave_f32_experiment(int code, mcle_ctx* ctx, int nt, int nr, const MimoTdlParams& pp, int method, uint64_t seed,
+                                     uint64_t first, uint64_t count, mcle_counters* d_counters, uint32_t* d_sym, uint32_t* d_bit);
+#endif
 
 // the envelope of the wavefront kernels: fft_size 256 .. 2048, every tap delay inside the cyclic prefix (no inter-symbol
 // interference to carry), <= 8 taps reaching <= 256 samples (and <= N / 2) back
@@ -547,12 +551,30 @@ extern "C" int mcle_run_mimo_ofdm_tdl(mcle_ctx* ctx, int dtype, const mcle_mimo_
             }
         }
         for (int m = 0; m <= kMaxOrder; ++m) pp.mom[m] = m <= K ? (double)(acc[m] / (long double)W) : 0.0;
+        for (int s = 0; s < 8; ++s) {           // the wavefront kernels' per-tap moments (mimo_tdl.hpp: mom_tap)
+            long double at[kMaxOrder + 1] = {0.0L};
+            const long double sh = s < cfg->n_taps ? (long double)pp.tap_delay[s] : 0.0L;
+            for (int j = 0; j < W; ++j) {
+                const long double x = (long double)j + sh - (long double)xc;
+                long double xp = 1.0L;
+                for (int m = 0; m <= K; ++m) {
+                    at[m] += xp;
+                    xp *= x;
+                }
+            }
+            for (int m = 0; m <= kMaxOrder; ++m) pp.mom_tap[s][m] = m <= K ? (double)(at[m] / (long double)W) : 0.0;
+        }
     }
     if (count == 0) return MCLE_OK;
     if ((rc = ctx->bind())) return rc;
     // one receive antenna per wavefront (round 5; every 1 <= Nt <= Nr <= 4 at fft_size 256 .. 2048 with the taps inside the prefix);
     // MCLE_OPT_MIMO_TDL_KERNEL: 1 = the workgroup-cooperative kernel of rounds 1-4 (Nt = Nr in {2, 4}), 2 = run-time-order kernels
     const long long sel = ctx->opt[MCLE_OPT_MIMO_TDL_KERNEL];
+#ifdef MCLE_EXPERIMENTS
+    if (sel >= 16 && dtype == MCLE_F32 && cfg->fft_size == 1024 && mimo_tdl_wave_envelope(pp, cfg->fft_size))
+        return run_mimo_tdl_wave_f32_experiment((int)sel - 16, ctx, cfg->nt, cfg->nr, pp, cfg->demod_method, seed, first, count, d_counters,
+                                                d_sym_err, d_bit_err);
+#endif
     if (sel != 1 && mimo_tdl_wave_envelope(pp, cfg->fft_size)) {
         rc = run_mimo_tdl_wave(ctx, dtype, cfg->fft_size, cfg->nt, cfg->nr, pp, sel == 2, cfg->demod_method, seed, first, count,
                                d_counters, d_sym_err, d_bit_err);
