@@ -36,7 +36,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
-ROUND = "r04"
+ROUND = "r05"
 # algorithmic bytes per realization in the staged (operator-granular)
 # model, complex64 samples / uint8 indices.
 B_ALG = {"c2": 7_600_000, "c3": 211_360, "c4": 412_160, "c5": 62_000, "f1": 3_099_008,
@@ -44,10 +44,16 @@ B_ALG = {"c2": 7_600_000, "c3": 211_360, "c4": 412_160, "c5": 62_000, "f1": 3_09
          "f6": 204_000}
 # Algorithmic floating-point operations per realization (complex MAC = 8, complex add = 2, 5 N log2 N per FFT),
 # SURVEY.md section 8(d) "Flops per realization"; RNG and integer work is NOT counted (listed under "uncounted").
+# Polynomial order of the tap model the TDL kernels run at the bench Doppler (host: truncation below 1e-8 in complex64, 1e-17 in
+# complex128 -- csrc/pipeline_siso_tdl.hip, pipeline_mimo_tdl.hip): the order is a template argument of the dispatched kernel
+TAP_ORDER = {"f32": 2, "f64": 5}
 FLOPS = {
     "c4": {"H.T (4x4 x 1040 cMAC)": 133_120, "G.Y (4x4 x 1024 cMAC)": 131_072, "8 x FFT-1024": 409_600,
            "MMSE filter (f64)": 2_000, "slicer (4096 x 10)": 40_960},
-    "c3": {"2 x FFT-1024": 102_400, "TDL 5 taps x 1040 cMAC": 41_600, "Jakes 5 x 8 rays x 1040 (phase, sincos, add)": 249_600,
+    # config 3 / f1: what RUNS -- the rays of a symbol are folded once into order-K tap polynomials (k_tdl_symbol_polys), the link
+    # kernel evaluates them by Horner (4 flops per order: a complex coefficient, a real abscissa) -- see flops_for(); until round 4
+    # the config-3 model counted the literal sum of sinusoids per sample (249 600 flops) that no kernel executes any more
+    "c3": {"2 x FFT-1024": 102_400, "TDL 5 taps x 1040 cMAC": 41_600,
            "equaliser (5-tap DFT + divide) x 1024": 55_296, "demod 1024 x 6": 6_144},
     "c2": {"Jakes 8 rays x 1e5 (phase, sincos, add)": 4_800_000, "fade + equalise 1e5 x 22": 2_200_000,
            "slicer 1e5 x 10": 1_000_000},
@@ -57,11 +63,28 @@ FLOPS = {
     "c5": {"link 600 x 15 cMAC": 72_000, "closed-form solve (f64)": 6_000, "demod 600 x 10": 6_000},
     "f6": {"link 3000 x (1 + 2) cMAC": 72_000, "BD solve + pinv (f64)": 20_000, "demod 3000 x 6": 18_000},
 }
+C3_LITERAL_JAKES_FLOPS = 249_600     # 5 taps x 8 rays x 1040 samples x (phase, sincos, add): the reference's evaluation, not the kernels'
+
+
+def flops_for(cfg, dtype):
+    """Algorithmic flops per realization of what the dispatched kernels execute (dtype picks the tap polynomials' order)."""
+    f = dict(FLOPS[cfg])
+    K = TAP_ORDER[dtype]
+    if cfg == "c3":
+        f["tap polynomials: 5 taps x 1040 samples x order-%d Horner (4 flops per order)" % K] = 5 * 1040 * 4 * K
+        f["fold of 5 x 8 rays into %d coefficients each (phase, sincos, powers)" % (K + 1)] = 40 * (12 + 4 * (K + 1))
+    if cfg == "f1":
+        f["tap polynomials: 80 links x 1040 samples x order-%d Horner (4 flops per order)" % K] = 80 * 1040 * 4 * K
+        f["fold of 80 x 8 rays into %d coefficients each" % (K + 1)] = 640 * (12 + 4 * (K + 1))
+    return f
+
+
 UNCOUNTED = {"c4": "Philox4x32-10: ~2 350 blocks (4 176 CN samples + 4 096 symbol bytes) = ~140 k integer ops; "
                    "Box-Muller: 4 176 x (log, sqrt, sin, cos) transcendental ops"}
 HBM_PEAK_GBPS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
-HBM_COPY_GBPS = 6290.0      # same guide: measured float4 copy
-MEASURED = {"copy_GBps": None}   # the box's copy rate measured in THIS run (scripts/bench_staged_c4.measure_copy_GBps), rank 0
+HBM_COPY_GBPS = 6290.0      # same guide: measured float4 copy (a reference figure; the line quotes what THIS box measures)
+MEASURED = {"copy_GBps": None, "stream": None}   # this box's achievable HBM rate measured in THIS run by the library's own
+                                                 # streaming kernels (scripts/bench_staged_c4.measure_hbm_stream), rank 0
 FP32_PEAK_TFLOPS = 157.3    # same guide: FP32 vector peak = FP32-input MFMA peak (256 CU x 4 SIMD x 64 flop/clk x 2.4 GHz)
 # FP64: 16 lanes x 1 FMA per clock and SIMD = half the guide's FP32 figure (256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz); the guide
 # does not list it, so it was measured (scripts/experiments/f64_rates.hip -> profiles/r03/f64_rates.txt): v_mfma_f64_16x16x4_f64
@@ -70,9 +93,9 @@ FP64_PEAK_TFLOPS = 78.6
 FP64_MEASURED = {"v_mfma_f64_16x16x4_f64": 77.6, "v_fma_f64": 65.9, "source": "profiles/r03/f64_rates.txt"}
 PEAK_TFLOPS = {"f32": FP32_PEAK_TFLOPS, "f64": FP64_PEAK_TFLOPS}
 KERNEL = {"c4": "k_run_mimo_ofdm_planar", "c2": "k_run_flat_mfma", "c3": "k_run_ofdm_tdl_wave", "c5": "k_ia_link",
-          "f1": "k_run_mimo_ofdm_tdl", "f6": "k_bd_link"}
+          "f1": "k_run_mimo_ofdm_tdl_wave", "f6": "k_bd_link"}
 KERNEL_F64 = {"c4": "k_run_mimo_ofdm_planar", "c2": "k_run_flat", "c3": "k_run_ofdm_tdl_wave", "c5": "k_ia_link",
-              "f1": "k_run_mimo_ofdm_tdl", "f6": "k_bd_link"}
+              "f1": "k_run_mimo_ofdm_tdl_wave", "f6": "k_bd_link"}
 
 
 ACTIVE_OPTS = {}            # --opt name=value of this run (main fills it): some options change which kernel a configuration runs
@@ -85,6 +108,8 @@ def kernel_name(cfg, dtype):
         return "k_run_mimo_ofdm<"                     # the generic radix-4 kernel
     if cfg == "c3" and (ACTIVE_OPTS.get("tdl_kernel") == 1 or ACTIVE_OPTS.get("no_mfma")):
         return "k_run_ofdm_tdl_batch" if (dtype == "f64" or ACTIVE_OPTS.get("no_mfma")) else "k_run_ofdm_tdl_mfma"
+    if cfg == "f1" and ACTIVE_OPTS.get("mimo_tdl_kernel") == 1:
+        return "k_run_mimo_ofdm_tdl"                  # the workgroup-cooperative kernel of rounds 1-4
     return (KERNEL_F64 if dtype == "f64" else KERNEL)[cfg]
 
 KERNEL_NOTE = {   # configs whose step is two launches: the time spans both, the counters are the named (dominant) kernel's
@@ -95,12 +120,13 @@ KERNEL_NOTE = {   # configs whose step is two launches: the time spans both, the
     ("c4", "f64"): "a step = per slice of 2^18 realizations k_mimo_filters_planar (channel draw + f64 receive filter, one thread per "
                    "realization, ~1 % of the time) + k_run_mimo_ofdm_planar; kernel_ms_per_launch spans them",
     ("c3", "f64"): "a step = k_tdl_symbol_polys<double> (fading records) + k_run_ofdm_tdl_wave<double> (one realization per "
-                   "wavefront; option tdl_kernel=1: k_run_ofdm_tdl_batch<double, 1024, 2>) per slice of <= 64 MiB of records; "
+                   "wavefront; option tdl_kernel=1: k_run_ofdm_tdl_batch<double, 1024, 2>) per slice of <= 2 GiB of records; "
                    "kernel_ms_per_launch spans them",
-    "f1": "a step = k_mimo_tdl_symbol_polys (the symbols' fading records, one thread per fading process) + k_run_mimo_ofdm_tdl per "
-          "slice of <= 256 MiB of records; kernel_ms_per_launch spans them",
+    "f1": "a step = k_mimo_tdl_symbol_polys<T, true> (the symbols' fading records, one thread per fading process) + "
+          "k_run_mimo_ofdm_tdl_wave (one receive antenna per wavefront, default since round 5; option mimo_tdl_kernel=1: the "
+          "workgroup-cooperative k_run_mimo_ofdm_tdl) per slice of <= 4 GiB of records; kernel_ms_per_launch spans them",
     "c3": "a step = k_tdl_symbol_polys (fading records) + k_run_ofdm_tdl_wave<float> (one realization per wavefront, default since "
-          "round 4; option tdl_kernel=1: the matrix-core kernel k_run_ofdm_tdl_mfma) per slice of <= 64 MiB of records; "
+          "round 4; option tdl_kernel=1: the matrix-core kernel k_run_ofdm_tdl_mfma) per slice of <= 2 GiB of records; "
           "kernel_ms_per_launch spans them",
     "c5": "a step = k_ia_solve_links (per-lane solve, ~18 % of the time) + k_ia_link (symbol walk); kernel_ms_per_launch spans both",
     "f6": "a step = k_bd_solve_links (per-lane solve) + k_bd_link (symbol walk); kernel_ms_per_launch spans both"}
@@ -118,6 +144,7 @@ SNR_DB = {"c1": 10.0, "c2": 20.0, "c3": 20.0, "c4": 25.0, "c5": 20.0, "f1": 25.0
 F1_TS = 1.0 / (15e3 * 1024)
 F1_TAPS_DB = (0.0, -3.0, -6.0, -9.0, -12.0)
 COUNTER_KEYS = ("n_realizations", "n_skipped", "sym_errors", "sym_errors_sq", "bit_errors", "bit_errors_sq")
+PMC_CHILD_STEPS = 4         # steps of a counter child run: --warmup 1 --steps 3, no pre-roll
 PMC_PASSES = (   # one rocprofv3 --pmc run each (FETCH_SIZE and WRITE_SIZE do not fit one pass, MI355X_MICROARCH.md)
     ("sq", "SQ_WAVE_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU_MFMA_MOPS_F32 "
            "SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE"),
@@ -372,19 +399,25 @@ def cpu_baseline_multicore(cfg, single_core_rate, budget_s):
 
 # ---- rocprofv3 counters of the dominant kernel, collected by child runs of this file ----------------------------
 def _parse_pmc_csv(folder, needle):
+    """-> {counter: SUM over every dispatch of the kernel in the run}, plus "_dispatches" (per counter pass the same number)."""
     import csv
     import glob
-    agg = {}
+    agg, n = {}, {}
     for path in glob.glob(os.path.join(folder, "**", "*counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(path)):
             if needle + "<" in row["Kernel_Name"] or needle + "(" in row["Kernel_Name"]:
-                agg.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
-    return {k: sum(v) / len(v) for k, v in agg.items()}
+                agg[row["Counter_Name"]] = agg.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+                n[row["Counter_Name"]] = n.get(row["Counter_Name"], 0) + 1
+    if n:
+        agg["_dispatches"] = max(n.values())
+    return agg
 
 
 def derive_pmc(c, per_launch):
-    """Counter means per launch -> the fractions the bench line quotes.  Shared with scripts/collect_profiles.py.
-    `per_launch` = realizations per DISPATCH of the kernel: the profiled batch must not exceed the pipeline's launch slice.
+    """Counter SUMS over a run's dispatches of the kernel (or means per launch) -> the fractions the bench line quotes.  Shared
+    with scripts/collect_profiles.py.  `per_launch` = the realizations those counters cover: with sums, every realization of the
+    profiled run (steps x batch) -- a pipeline that cuts a step into several dispatches of unequal size (the record-buffer
+    slices of the TDL kernels) is then normalised correctly, which means per launch were not.
     SQ_* cycle counters are in quad-cycles, SQ_VALU_MFMA_BUSY_CYCLES in cycles (MI355X_MICROARCH.md, constants
     table); GRBM_GUI_ACTIVE sums the 8 XCDs; the chip has 1024 SIMDs.  HBM bytes = (2 x FETCH_SIZE + WRITE_SIZE)
     KiB: on gfx950 FETCH_SIZE reports half of a coalesced stream's bytes (same guide, HBM section)."""
@@ -413,7 +446,8 @@ def derive_pmc(c, per_launch):
 
 
 def collect_pmc_live(args, batch, dtype, demod):
-    """Three `rocprofv3 --pmc` child runs of this bench (3 timed launches each) -> counter means per launch."""
+    """Three `rocprofv3 --pmc` child runs of this bench (1 warm-up + 3 timed steps of `batch` realizations each) -> counter SUMS
+    over every dispatch of the dominant kernel: they cover PMC_CHILD_STEPS x batch realizations."""
     exe = shutil.which("rocprofv3")
     if exe is None:
         return None, "rocprofv3 not on PATH"
@@ -430,7 +464,9 @@ def collect_pmc_live(args, batch, dtype, demod):
             cmd += ["--opt", item]
         try:
             subprocess.run(cmd, cwd="/tmp", env=env, timeout=180, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-            counters.update(_parse_pmc_csv(out_dir, kernel_name(args.config, dtype)))
+            got = _parse_pmc_csv(out_dir, kernel_name(args.config, dtype))
+            counters["_dispatches_" + tag] = got.pop("_dispatches", 0)
+            counters.update(got)
         except Exception as exc:       # a failed pass must not break the bench line
             counters["_error_" + tag] = repr(exc)
     shutil.rmtree(root, ignore_errors=True)
@@ -446,6 +482,9 @@ def committed_pmc(cfg, dtype):
         return None, None, None
     try:
         doc = json.load(open(path))
+        if "_realizations_total" in doc:       # round 5 summaries: sums over every dispatch, the realizations they cover
+            return ({k: v["sum"] for k, v in doc.items() if not k.startswith("_")}, os.path.relpath(path, REPO),
+                    int(doc["_realizations_total"]))
         return ({k: v["mean_per_launch"] for k, v in doc.items() if not k.startswith("_")}, os.path.relpath(path, REPO),
                 int(doc.get("_realizations_per_launch", BATCH_SURVEY[cfg])))
     except Exception:
@@ -457,7 +496,7 @@ def roofline_block(args, dtype, batch, per_launch_s, rate_kernel, d, pmc_source)
       frac            = algorithmic flops per realization x realizations/s of the kernel / peak of the dtype's datapath
       hbm.frac        = min(B_alg, measured HBM bytes) per realization x rate / 8 TB/s   (SURVEY 8(d)'s rule)
       valu_busy_chip  = VALU-active SIMD-cycles / all SIMD-cycles (rocprofv3 counters)"""
-    flops = FLOPS[args.config]
+    flops = flops_for(args.config, dtype)
     f_total = float(sum(flops.values()))
     achieved_tf = f_total * rate_kernel / 1e12
     balg = B_ALG[args.config] * (2 if dtype == "f64" else 1)       # complex128 samples: twice the bytes of the staged model
@@ -469,9 +508,10 @@ def roofline_block(args, dtype, batch, per_launch_s, rate_kernel, d, pmc_source)
     if measured is not None:
         eff = min(float(balg), measured)
         hbm.update(achieved_GBps=eff * rate_kernel / 1e9, frac=eff * rate_kernel / 1e9 / HBM_PEAK_GBPS,
-                   frac_of_measured_copy_bw=eff * rate_kernel / 1e9 / (MEASURED["copy_GBps"] or HBM_COPY_GBPS),
+                   frac_of_achievable_hbm=eff * rate_kernel / 1e9 / (MEASURED["copy_GBps"] or HBM_COPY_GBPS),
                    copy_GBps=MEASURED["copy_GBps"] or HBM_COPY_GBPS,
-                   copy_GBps_source="torch copy_ of 1 GiB measured in this run" if MEASURED["copy_GBps"] else
+                   copy_GBps_source="best of the library's copy / read / triad / write kernels over 1 GiB, measured in this run "
+                                    "(mcle_hbm_stream_rate)" if MEASURED["copy_GBps"] else
                                     "MI355X_MICROARCH.md constant (not measured in this run)",
                    peak_GBps=HBM_PEAK_GBPS,
                    rule="min(B_alg, measured bytes) x rate (SURVEY.md 8(d)); measured = (2*FETCH_SIZE + WRITE_SIZE) KiB")
@@ -485,6 +525,9 @@ def roofline_block(args, dtype, batch, per_launch_s, rate_kernel, d, pmc_source)
              "kernel_note": KERNEL_NOTE.get((args.config, dtype), KERNEL_NOTE.get(args.config)),
              "realizations_per_launch": batch,
              "flops_per_realization": f_total, "flops_breakdown": flops, "uncounted": UNCOUNTED.get(args.config),
+             "flops_model": "what the dispatched kernels execute (tap polynomials of order %d in this arithmetic)" % TAP_ORDER[dtype]
+             if args.config in ("c3", "f1") else "SURVEY.md section 8(d)",
+             "frac_literal_jakes_model": ((f_total + C3_LITERAL_JAKES_FLOPS) * rate_kernel / 1e12 / peak) if args.config == "c3" else None,
              "hbm": hbm,
              "valu_busy_chip": d.get("valu_busy_chip"), "mfma_busy_chip": d.get("mfma_busy_chip"),
              # f32-input MFMA and VALU instructions share one FP32 datapath per SIMD on gfx950 (measured:
@@ -498,6 +541,7 @@ def roofline_block(args, dtype, batch, per_launch_s, rate_kernel, d, pmc_source)
              "valu_wave_insts_per_realization": d.get("valu_wave_insts_per_realization"),
              "mfma_f32_mops_per_realization": d.get("mfma_f32_mops_per_realization"),
              "wait_inst_any_frac": d.get("wait_inst_any_frac"),
+             "dispatches_per_step": d.get("dispatches_per_step"),
              "counters_source": pmc_source,
              "note": "fused kernel: every intermediate of a realization lives in LDS / registers, so HBM traffic is "
                      "B_alg / %s of the staged model and the kernel is bound by the SIMDs' %s datapath%s; "
@@ -804,7 +848,8 @@ def main():
             try:
                 sys.path.insert(0, os.path.join(REPO, "scripts"))
                 import bench_staged_c4
-                MEASURED["copy_GBps"] = bench_staged_c4.measure_copy_GBps()
+                MEASURED["stream"] = bench_staged_c4.measure_hbm_stream(eng)
+                MEASURED["copy_GBps"] = MEASURED["stream"]["achievable_GBps"]
             except Exception:
                 pass
 
@@ -818,12 +863,17 @@ def main():
                 eng.sync()
                 pmc_batch = min(batch, BATCH_SURVEY[args.config] * 4)
                 pmc, err = collect_pmc_live(args, pmc_batch, dt, dm)
-                src = ("rocprofv3 --pmc child runs of this command (3 launches of %d realizations per pass: %s)"
-                       % (pmc_batch, "; ".join(n for _, n in PMC_PASSES))) if pmc else "live collection failed (%s); " % err
+                src = ("rocprofv3 --pmc child runs of this command (%d steps of %d realizations per pass, every dispatch of the kernel "
+                       "summed: %s)" % (PMC_CHILD_STEPS, pmc_batch, "; ".join(n for _, n in PMC_PASSES))) if pmc else \
+                    "live collection failed (%s); " % err
             if pmc is None:
                 pmc, path, pmc_batch = committed_pmc(args.config, dt)
                 src = ((src or "") + "%s (committed rocprofv3 summary, NOT measured in this run)" % path) if pmc else src
-            d = derive_pmc(pmc, pmc_batch) if pmc else {}
+            live = src is not None and src.startswith("rocprofv3 --pmc child")
+            d = derive_pmc({k: v for k, v in pmc.items() if not k.startswith("_")},
+                           pmc_batch * (PMC_CHILD_STEPS if live else 1)) if pmc else {}
+            if live and pmc:
+                d["dispatches_per_step"] = pmc.get("_dispatches_sq", 0) / float(PMC_CHILD_STEPS)
             blk = roofline_block(args, dt, batch, per_launch_s, batch / per_launch_s, d, src)
             blk["demod"] = dm
             blk["counters_realizations_per_launch"] = pmc_batch
@@ -927,23 +977,67 @@ def main():
                             rate_o = nb / ms_o * 1e3
                             others[cfg][dt] = {"realizations_per_s": rate_o, "kernel_ms_per_launch": ms_o,
                                                "realizations_per_launch": nb, "kernel": kernel_name(cfg, dt),
-                                               "flop_frac": sum(FLOPS[cfg].values()) * rate_o / 1e12 / PEAK_TFLOPS[dt],
+                                               "flop_frac": sum(flops_for(cfg, dt).values()) * rate_o / 1e12 / PEAK_TFLOPS[dt],
+                                               "flops_per_realization": sum(flops_for(cfg, dt).values()),
                                                "ser": c_o["sym_errors"] / float(max(1, c_o["n_realizations"]) * units_o)}
                             others[cfg]["workload"] = wl_o
                         except Exception as exc:
                             others[cfg][dt] = {"error": repr(exc)}
+                # the north star's matrix-core clause ("MFMA only for the batched Nt x Nr x Ns MIMO contraction ... evidenced by
+                # MFMA-busy"): config 4 in complex64 on the matrix-core kernel (option f32_mfma = 1: H.X / G.Y as
+                # v_mfma_f32_4x4x1, the DFT-16 passes as v_mfma_f32_16x16x4; the planar VALU kernel above is 10-20 % faster and the
+                # default), with its live MFMA-busy and VALU-busy counters, measured in THIS run
+                try:
+                    import copy as _copy
+                    with eng.options(f32_mfma=1):
+                        run_m, units_m, wl_m = make_runner(eng, "c4", args.demod, "f32")
+                        cnt_m = eng.new_counters()
+                        nb = BATCH_SURVEY["c4"]
+                        run_m(1 << 45, nb, cnt_m)
+                        eng.sync()
+                        eng.timer_start()
+                        for s2 in range(5):
+                            run_m((1 << 45) + (s2 + 1) * nb, nb, cnt_m)
+                        ms_m = eng.timer_stop_ms() / 5
+                        c_m = eng.read_counters(cnt_m)
+                    rate_m = nb / ms_m * 1e3
+                    leg = {"realizations_per_s": rate_m, "kernel_ms_per_launch": ms_m, "realizations_per_launch": nb,
+                           "kernel": "k_run_mimo_ofdm_mfma", "option": "f32_mfma=1", "demod": args.demod, "workload": wl_m,
+                           "flop_frac": sum(flops_for("c4", "f32").values()) * rate_m / 1e12 / PEAK_TFLOPS["f32"],
+                           "ser": c_m["sym_errors"] / float(max(1, c_m["n_realizations"]) * units_m)}
+                    if args.pmc != "off":
+                        eng.sync()
+                        args_m = _copy.copy(args)
+                        args_m.opt = list(args.opt) + ["f32_mfma=1"]
+                        ACTIVE_OPTS["f32_mfma"] = 1
+                        try:
+                            pmc_m, err_m = collect_pmc_live(args_m, nb, "f32", args.demod)
+                        finally:
+                            ACTIVE_OPTS.pop("f32_mfma", None)
+                        if pmc_m:
+                            dm_ = derive_pmc({k: v for k, v in pmc_m.items() if not k.startswith("_")}, nb * PMC_CHILD_STEPS)
+                            leg.update(mfma_busy_chip=dm_.get("mfma_busy_chip"), valu_busy_chip=dm_.get("valu_busy_chip"),
+                                       mfma_f32_mops_per_realization=dm_.get("mfma_f32_mops_per_realization"),
+                                       valu_wave_insts_per_realization=dm_.get("valu_wave_insts_per_realization"),
+                                       counters_source="rocprofv3 --pmc child runs of this command with --opt f32_mfma=1")
+                        else:
+                            leg["counters_source"] = "live collection failed (%s)" % err_m
+                    others["c4_f32_mfma"] = leg
+                except Exception as exc:
+                    others["c4_f32_mfma"] = {"error": repr(exc)}
                 # the north star's HBM clause: config 4 staged through HBM, both arithmetics, with the copy rate of THIS box
                 # measured in THIS run and the bytes the chain really moves (rocprofv3 child runs; SURVEY 8(d)'s min rule)
                 try:
                     sys.path.insert(0, os.path.join(REPO, "scripts"))
                     import bench_staged_c4
-                    copy_bw = MEASURED["copy_GBps"] or bench_staged_c4.measure_copy_GBps()
+                    copy_bw = MEASURED["copy_GBps"] or bench_staged_c4.measure_copy_GBps(eng)
                     want_bytes = args.pmc != "off"
                     others["c4_staged"] = bench_staged_c4.run(eng, batch=8192, seconds=1.0, copy_GBps=copy_bw,
                                                               hbm_counters=want_bytes)
                     others["c4_staged_f64"] = bench_staged_c4.run(eng, batch=8192, seconds=1.0, dtype="f64", copy_GBps=copy_bw,
                                                                   hbm_counters=want_bytes)
                     out["hbm_copy_GBps_measured_this_run"] = copy_bw
+                    out["hbm_stream_rates_measured_this_run"] = MEASURED["stream"]
                 except Exception as exc:
                     others["c4_staged"] = {"error": repr(exc)}
                 out["other_workloads"] = others

@@ -142,6 +142,15 @@ int mcle_ctx_get_option(mcle_ctx* ctx, int option, long long* value);
 int mcle_timer_start(mcle_ctx* ctx);
 int mcle_timer_stop_ms(mcle_ctx* ctx, float* ms);                               /* blocks */
 
+/* What the box's HBM delivers to a streaming kernel, measured by the library (csrc/kernels_hbm.hip): `reps` launches of a
+ * 16-byte-per-access grid-stride kernel over arrays of `bytes` bytes each (in the context's scratch), n_cu * blocks_per_cu
+ * workgroups of 256 threads; *gbps = bytes moved (read + written) per second / 1e9.  The denominator of the
+ * "fraction of the achievable HBM rate" figures of bench.py (both the 8 TB/s specification and the rate
+ * measured on the box are quoted).  Nothing in the reference corresponds to it. */
+enum { MCLE_HBM_COPY = 0, MCLE_HBM_READ = 1, MCLE_HBM_TRIAD = 2, MCLE_HBM_WRITE = 3,
+       MCLE_HBM_NONTEMPORAL = 4 /* | : non-temporal loads / stores */, MCLE_HBM_UNROLL8 = 8 /* | : eight accesses in flight per thread instead of four */ };
+int mcle_hbm_stream_rate(mcle_ctx* ctx, int kind, size_t bytes, int reps, int blocks_per_cu, double* gbps);
+
 /* ---- multi-GPU: realization sharding + ONE all-reduce of the integer counters.
  *      The reference's only multi-process mechanism is ipyparallel, one parameter variation per engine
  *      (simulations/runner.py:1836-1846 simulate_in_parallel); here every rank takes a slice of every

@@ -145,6 +145,7 @@ _PROTOS = {
     "mcle_memcpy_h2d": (c_int, [_P, _P, _P, c_size_t]),
     "mcle_memcpy_d2h": (c_int, [_P, _P, _P, c_size_t]),
     "mcle_memcpy_2d": (c_int, [_P, _P, c_size_t, _P, c_size_t, c_size_t, c_size_t]),
+    "mcle_hbm_stream_rate": (c_int, [_P, c_int, c_size_t, c_int, c_int, POINTER(c_double)]),
     "mcle_timer_start": (c_int, [_P]),
     "mcle_timer_stop_ms": (c_int, [_P, POINTER(c_float)]),
     "mcle_comm_load": (c_int, [c_char_p]),

@@ -609,7 +609,11 @@ int launch_mimo_tdl_wave(mcle_ctx* ctx, const MimoTdlParams& pp, int method, uin
     if (per_cu > by_waves) per_cu = by_waves;
     const size_t rec_len = mimo_tdl_wave_rec(S, NT, NR, pp.K);
     const uint64_t per_real = (uint64_t)pp.n_ofdm_sym * rec_len;             // complex values per realization
-    uint64_t slice = (256ull << 20) / (per_real * sizeof(cx<T>));
+    // records of a slice of realizations (k_mimo_tdl_symbol_polys<T, true>), then their links: <= 4 GiB of records per pair of
+    // launches (3.2 / 9 kB per realization and symbol at 4 x 4 and five taps), so that a bench step of 393 216 realizations is ONE
+    // dispatch of each kernel -- the 256 MiB slices of rounds 3-4 cut a step into unequal dispatches, which is what the per-launch
+    // means of the round-4 profiles got wrong; shorter launches were never faster (pipeline_mimo_tdl.hip)
+    uint64_t slice = (4096ull << 20) / (per_real * sizeof(cx<T>));
     if (slice < 1) slice = 1;
     if (slice > count) slice = count;
     void* recs = nullptr;

@@ -406,7 +406,8 @@ int run_siso_tdl_wave_w(mcle_ctx* ctx, const SisoTdlParams& pp, int method, uint
     if (per_cu > WPS) per_cu = WPS;
     const size_t rec_len = (size_t)pp.n_taps * (pp.K + 2);
     const uint64_t per_real = (uint64_t)pp.n_ofdm_sym * rec_len;             // complex values per realization
-    uint64_t slice = (64ull << 20) / (per_real * sizeof(cx<T>));             // <= 64 MiB of records per fading + link pair
+    uint64_t slice = (2048ull << 20) / (per_real * sizeof(cx<T>));           // <= 2 GiB of records per fading + link pair: a bench step
+                                                                             // of 2^21 realizations is one dispatch of each kernel
     slice = slice < 4 ? 4 : (slice / 4) * 4;
     if (slice > count) slice = count;
     void* recs = nullptr;

@@ -191,6 +191,15 @@ class Engine:
         host = np.ascontiguousarray(host, dtype=dtype)
         return DeviceArray(self, host.shape, host.dtype).set(host)
 
+    HBM_KINDS = {"copy": 0, "read": 1, "triad": 2, "write": 3}
+
+    def hbm_stream_rate(self, kind="copy", nbytes=1 << 30, reps=10, blocks_per_cu=8, nontemporal=False, unroll8=False):
+        """GB/s (bytes read + written per second) of the library's 16-byte streaming kernel over arrays of `nbytes` bytes:
+        what this box's HBM delivers (mcle_hbm_stream_rate, csrc/kernels_hbm.hip)."""
+        g = ctypes.c_double(0.0)
+        check(self.lib.mcle_hbm_stream_rate(self.ctx, self.HBM_KINDS[kind] | (4 if nontemporal else 0) | (8 if unroll8 else 0), int(nbytes), int(reps), int(blocks_per_cu), byref(g)))
+        return float(g.value)
+
     def timer_start(self):
         check(self.lib.mcle_timer_start(self.ctx))
 

@@ -52,28 +52,39 @@ def bind(eng, M=64):
     eng.set_constellation(constellation("qam", M), _lib.CONST_QAM)
 
 
-def measure_copy_GBps(nbytes=1 << 30, reps=10):
-    """The box's device-to-device copy rate (read + write bytes per second) measured in THIS run with torch's own copy kernel
-    on a 1 GiB buffer -- the achievable-HBM figure SURVEY.md 8(d) asks to be quoted next to the 8 TB/s peak.  None without torch."""
+def measure_hbm_stream(eng, nbytes=1 << 30, reps=10):
+    """What this box's HBM delivers to a streaming kernel, measured in THIS run by the library's own 16-byte-per-access kernels
+    (mcle_hbm_stream_rate, csrc/kernels_hbm.hip: copy, read, triad, write over 1 GiB arrays, 8 and 16 workgroups per CU) --
+    the achievable-HBM figure SURVEY.md 8(d) asks to be quoted next to the 8 TB/s specification.  `achievable_GBps` is the
+    best of them: the denominator of every `frac_of_achievable_hbm` (until round 4 it was torch's copy_ of 1 GiB, 4.8 TB/s
+    on the driver's box, which the staged chain itself exceeded -- a library copy is not a ceiling)."""
+    out = {}
+    for kind in ("copy", "read", "triad", "write"):
+        best = 0.0
+        for bpc in (4, 8, 32):
+            try:
+                best = max(best, eng.hbm_stream_rate(kind, nbytes, reps, bpc))
+            except Exception:
+                pass
+        out[kind + "_GBps"] = best or None
+    rates = [v for v in out.values() if v]
+    out["achievable_GBps"] = max(rates) if rates else None
+    out["how"] = ("mcle_hbm_stream_rate: float4 grid-stride kernels over %d MiB arrays, %d launches each, best of 4 / 8 / 32 workgroups "
+                  "per CU; GB/s = bytes read + written per second" % (nbytes >> 20, reps))
+    return out
+
+
+def measure_copy_GBps(eng=None, nbytes=1 << 30, reps=10):
+    """(kept name) the achievable HBM rate of this box: measure_hbm_stream(...)['achievable_GBps']"""
+    own = eng is None
+    if own:
+        from pyphysim_amd.engine import Engine
+        eng = Engine(0, "f32")
     try:
-        import torch
-        a = torch.empty(nbytes // 4, dtype=torch.float32, device="cuda").fill_(1.0)
-        b = torch.empty_like(a)
-        for _ in range(3):
-            b.copy_(a)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize()
-        e0.record()
-        for _ in range(reps):
-            b.copy_(a)
-        e1.record()
-        torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1)
-        del a, b
-        torch.cuda.empty_cache()
-        return 2.0 * nbytes * reps / (ms * 1e-3) / 1e9
-    except Exception:
-        return None
+        return measure_hbm_stream(eng, nbytes, reps)["achievable_GBps"]
+    finally:
+        if own:
+            eng.close()
 
 
 def collect_hbm_bytes(dtype, batch, demod="mindist", passes=3):
@@ -115,7 +126,7 @@ def collect_hbm_bytes(dtype, batch, demod="mindist", passes=3):
 
 def run(eng, batch=8192, seconds=1.0, dtype="f32", demod="mindist", copy_GBps=None, hbm_counters=False):
     """Time the chain for about `seconds` (HIP events around whole passes) -> the dict bench.py embeds.
-    copy_GBps: the copy rate measured on this box in this run (measure_copy_GBps); hbm_counters: also count the bytes the
+    copy_GBps: the achievable HBM rate measured on this box in this run (measure_hbm_stream); hbm_counters: also count the bytes the
     chain really moves (collect_hbm_bytes) and apply SURVEY 8(d)'s rule min(B_alg, measured) x rate."""
     from pyphysim_amd import _lib
     method = _lib.DEMOD_MINDIST if demod == "mindist" else _lib.DEMOD_QAM_SLICER
@@ -149,12 +160,15 @@ def run(eng, batch=8192, seconds=1.0, dtype="f32", demod="mindist", copy_GBps=No
              "frac_rule": "min(B_alg, measured bytes) x rate / 8 TB/s (SURVEY.md 8(d))",
              "frac_min_rule": eff * rate / 1e9 / HBM_PEAK_GBPS,
              "copy_GBps_measured_this_run": copy_GBps,
-             "frac_of_copy_bw_measured_this_run": (eff * rate / 1e9 / copy_GBps) if copy_GBps else None}
+             "achievable_hbm_GBps_measured_this_run": copy_GBps,
+             # ONE key, one denominator: min(B_alg, measured bytes) x rate / the best streaming rate the library's own kernels
+             # reach on this box in this run (measure_hbm_stream); None when that was not measured
+             "frac_of_achievable_hbm": (eff * rate / 1e9 / copy_GBps) if copy_GBps else None}
     return {**extra, "workload": "config 4 staged through HBM, one kernel per reference operator (SURVEY 8(d) staged model)",
             "dtype": dtype, "demod": demod, "realizations_per_s": rate, "batch": batch, "passes": steps,
             "ms_per_pass": ms / steps, "wall_s": wall, "b_alg_bytes_per_realization": balg, "b_alg_breakdown": B_ALG,
             "achieved_GBps": balg * rate / 1e9, "frac": balg * rate / 1e9 / HBM_PEAK_GBPS,
-            "frac_of_measured_copy_bw": balg * rate / 1e9 / HBM_COPY_GBPS, "peak_GBps": HBM_PEAK_GBPS,
+            "peak_GBps": HBM_PEAK_GBPS,
             "north_star_clause": ">= 1e6 realizations/s at >= 40 %% of the HBM roofline: %s" % (
                 "met" if rate >= 1e6 and balg * rate / 1e9 / HBM_PEAK_GBPS >= 0.40 else "not met"),
             "ser": c["sym_errors"] / float(max(1, c["n_realizations"]) * 4096), "n_realizations": c["n_realizations"]}
@@ -181,7 +195,7 @@ def main():
             chain(eng, s * args.batch, args.batch, cnt, args.dtype, method)
         eng.sync()
     else:
-        copy = measure_copy_GBps() if args.counters else None
+        copy = measure_copy_GBps(eng) if args.counters else None
         print(json.dumps(run(eng, args.batch, args.seconds, args.dtype, args.demod, copy_GBps=copy, hbm_counters=args.counters)))
     eng.close()
 

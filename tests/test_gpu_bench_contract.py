@@ -50,6 +50,21 @@ def test_default_line_carries_every_contract_field():
     assert st64["dtype"] == "f64" and st64["b_alg_bytes_per_realization"] == 2 * 412160 and 0.0 < st64["frac"] < 1.0
     assert st64["ser"] == d["ser"] or abs(st64["ser"] - d["ser"]) < 0.05      # same link, other index range
     assert d["hbm_copy_GBps_measured_this_run"] > 1000.0 and st["copy_GBps_measured_this_run"] == d["hbm_copy_GBps_measured_this_run"]
+    # ONE achievable-HBM figure (the best of the library's own streaming kernels, measured in this run), one key, below 1
+    sr = d["hbm_stream_rates_measured_this_run"]
+    assert sr["achievable_GBps"] == d["hbm_copy_GBps_measured_this_run"] == max(sr[k] for k in ("copy_GBps", "read_GBps", "triad_GBps", "write_GBps"))
+    assert 3000.0 < sr["achievable_GBps"] < 8000.0
+    for leg in (st, st64):
+        assert 0.0 < leg["frac_of_achievable_hbm"] < 1.0 and "frac_of_measured_copy_bw" not in leg
+        assert "frac_of_copy_bw_measured_this_run" not in leg
+    # the tap-polynomial workloads are priced on what their kernels execute (order 2 / 5 Horner), not on the literal ray sums
+    c3 = d["other_workloads"]["c3"]
+    assert c3["f32"]["flops_per_realization"] == 102400 + 41600 + 55296 + 6144 + 5 * 1040 * 8 + 40 * 24
+    assert c3["f64"]["flops_per_realization"] == 102400 + 41600 + 55296 + 6144 + 5 * 1040 * 20 + 40 * 36
+    assert d["other_workloads"]["f1"]["f32"]["kernel"] == "k_run_mimo_ofdm_tdl_wave"
+    # the matrix-core clause of the north star, driver-run: config 4 on the MFMA kernel (counters need --pmc, off in this test)
+    mf = d["other_workloads"]["c4_f32_mfma"]
+    assert mf["kernel"] == "k_run_mimo_ofdm_mfma" and mf["realizations_per_s"] > 1e6 and abs(mf["ser"] - d["ser"]) < 0.05
     assert d["roofline"]["hbm"].get("copy_GBps", 0) > 1000.0 or d["roofline"]["hbm"]["measured_bytes_per_realization"] is None
     for cfg in ("c2", "c3", "c5", "f1", "f6"):
         for dt in ("f64", "f32"):
