@@ -592,11 +592,30 @@ def launch_check(args, rank, world):
     dist.all_reduce(s_vec, op=dist.ReduceOp.SUM)
     s_ranges = [None] * world
     dist.all_gather_object(s_ranges, [int(s_lo), int(s_hi)])
+    # ... and of BASELINE.json's literal counts of the two multi-GPU configurations (config 4: 10^6, config 5: 10^5), whatever
+    # --config says: what a multi-rank bench line reports as `strong` and `strong_c5`
+    literal = {}
+    for cfg_l in ("c4", "c5"):
+        t_l = STRONG_TOTAL[cfg_l]
+        lo_l, hi_l = (t_l * rank) // world, (t_l * (rank + 1)) // world
+        acc = np.zeros(6, dtype=np.int64)
+        pos = lo_l
+        while pos < hi_l:
+            n = min(1 << 16, hi_l - pos)
+            acc += np.array(_checksum_counts((19 << 36) + pos, n), dtype=np.int64)
+            pos += n
+        v_l = torch.tensor(acc)
+        dist.all_reduce(v_l, op=dist.ReduceOp.SUM)
+        r_l = [None] * world
+        dist.all_gather_object(r_l, [int(lo_l), int(hi_l)])
+        literal[cfg_l] = {"total_realizations": t_l, "rank_ranges": r_l,
+                          "counters": dict(zip(COUNTER_KEYS, [int(v) for v in v_l.tolist()]))}
     if rank == 0:
         print(json.dumps({"launch_check": True, "n_gpus": world, "steps": args.steps, "value": None,
                           "rank_ranges": ranges, "counters": dict(zip(COUNTER_KEYS, [int(v) for v in vec.tolist()])),
                           "strong": {"total_realizations": s_total, "rank_ranges": s_ranges,
                                      "counters": dict(zip(COUNTER_KEYS, [int(v) for v in s_vec.tolist()]))},
+                          "strong_literal": literal,
                           "note": "launcher / sharding / reduction self-test on gloo; no kernel ran, no rate"}),
               flush=True)
     dist.destroy_process_group()
@@ -681,6 +700,19 @@ def main():
                                  "torch.distributed" % box.get("err", "this rank ok" if "comm" in box else "timeout"))
                     if args.comm == "native":
                         raise SystemExit("bench.py: --comm native: " + comm_note)
+                    # fall back cleanly: a rank whose communicator DID come up destroys it (ncclCommDestroy) instead of leaving it
+                    # to interpreter exit; a rank whose bring-up thread is still blocked inside ncclCommInitRank must not share
+                    # that context with the timed path -- it gets a fresh context (the stuck one is abandoned with its thread)
+                    if "comm" in box:
+                        try:
+                            box["comm"].close()
+                        except Exception:          # noqa: BLE001 -- the fallback must go on
+                            pass
+                    elif th.is_alive():
+                        eng = Engine(gpu, args.dtype)
+                        for item in args.opt:
+                            name, _, val = item.partition("=")
+                            eng.set_option(name, int(val))
             else:
                 comm_note = "NativeComm rendezvous failed on some rank (%s): exchange through torch.distributed" % err
                 if args.comm == "native":
@@ -753,12 +785,13 @@ def main():
                 "workload": workload, "units": units, "rate": (tot[0] + tot[1]) / float(tmax[0]),
                 "kernel_ms_per_launch": float(tmax[1]) / args.steps}
 
-    def timed_strong(demod, dtype, total, base, solo=False):
+    def timed_strong(demod, dtype, total, base, solo=False, cfg=None):
         """The configuration's LITERAL realization count split over the ranks ("strong" scaling): rank r runs the contiguous
         block [floor(total r / n), floor(total (r + 1) / n)) in calls of <= batch realizations, then the one all-reduce;
         barrier + synchronize on both sides; --strong-reps repetitions on disjoint index ranges after one untimed one,
-        each repetition's elapsed time = max over ranks."""
-        run, units, workload = make_runner(eng, args.config, demod, dtype)
+        each repetition's elapsed time = max over ranks.  cfg: another configuration than --config (the line's strong_c5 block)."""
+        run, units, workload = make_runner(eng, cfg or args.config, demod, dtype)
+        s_batch = batch if cfg is None else BATCH[cfg]
         n_active = 1 if solo else world
         r_idx = 0 if solo else rank
         active = (not solo) or rank == 0
@@ -774,7 +807,7 @@ def main():
             if active:
                 pos = lo
                 while pos < hi:
-                    n = min(batch, hi - pos)
+                    n = min(s_batch, hi - pos)
                     run(pos, n, counters)
                     pos += n
             if native is not None:
@@ -831,6 +864,24 @@ def main():
                   "note": "at this size a rank's share is %.2f ms of kernel at the one-rank rate: launch latency, the all-reduce and "
                           "the two barriers are a visible part of the region, so the strong figure sits below the weak one by "
                           "construction" % (1e3 * s_one["elapsed_s"] / world)}
+    # BASELINE config 5 ("1e5 realizations on 8 MI355X") gets its strong block on the config-4 line as well: the two configurations
+    # BASELINE.json shards over the node are both on the one line the driver collects per N
+    strong_c5 = None
+    if strong is not None and args.config == "c4":
+        t5 = STRONG_TOTAL["c5"]
+        a5 = timed_strong(args.demod, args.dtype, t5, 21 << 36, cfg="c5")
+        o5 = timed_strong(args.demod, args.dtype, t5, 22 << 36, solo=True, cfg="c5") if world > 1 else a5
+        strong_c5 = {"scaling": "strong", "config": "c5", "total_realizations": t5,
+                     "per_rank_realizations": [(t5 * (r + 1)) // world - (t5 * r) // world for r in range(world)],
+                     "elapsed_s": a5["elapsed_s"], "elapsed_min_s": a5["elapsed_min_s"], "reps": args.strong_reps,
+                     "value": t5 / a5["elapsed_s"], "unit": "realizations/s", "n1_elapsed_s": o5["elapsed_s"],
+                     "n1_value": t5 / o5["elapsed_s"], "speedup_vs_n1": o5["elapsed_s"] / a5["elapsed_s"],
+                     "efficiency": o5["elapsed_s"] / a5["elapsed_s"] / world, "ser": a5["ser"],
+                     "what": "BASELINE config 5 (K=3 2x2 closed-form IA + 16-QAM, 200 symbols per stream, 20 dB): its literal 10^5 "
+                             "realizations split contiguously over the ranks, one counter all-reduce, median of the repetitions",
+                     "note": "10^5 realizations are %.2f ms of kernel at the one-rank rate: the region is launch latency, the "
+                             "all-reduce and two barriers -- a latency figure, not a throughput one" % (1e3 * o5["elapsed_s"])}
+        make_runner(eng, args.config, args.demod, args.dtype)      # back to this line's constellation
     # who ran: device name and PCI bus id of every rank (RCCL's view of the job next to the launcher's)
     props = torch.cuda.get_device_properties(gpu)
     me = {"rank": rank, "local_rank": local_rank, "gpu": gpu, "device": props.name,
@@ -919,6 +970,8 @@ def main():
         }
         if strong is not None:
             out["strong"] = strong
+        if strong_c5 is not None:
+            out["strong_c5"] = strong_c5
         if world > 1:
             out["kernel_ms_per_rank"] = {"min": head["kernel_ms_min"], "max": head["kernel_ms"]}
             out["n1_value"] = solo["rate"]

@@ -113,7 +113,8 @@ enum {
                                       search otherwise -- identical decisions, no table gathers); likewise for a four-point
                                       constellation with one point per quadrant at (+-a, +-b) -- QPSK -- decided by the signs
                                       (demod_quad_cert: certified for 2^-30 min(a, b) <= |re|, |im| <= 2^8 max(a, b)) */
-    MCLE_OPT_F64_VARIANT = 11,     /* complex128 config-4 kernel (1024, 4x4), TIMING BOUNDS ONLY on its 512-thread radix-4 form --
+    MCLE_OPT_F64_VARIANT = 11,     /* (builds with -DMCLE_EXPERIMENTS only; the product library accepts 0 and refuses anything else)
+                                      complex128 config-4 kernel (1024, 4x4), TIMING BOUNDS ONLY on its 512-thread radix-4 form --
                                       results are wrong by construction: bit 0 = the LDS stores of the last transmit stage and of
                                       the channel stage dropped, bit 1 = the two workgroup barriers around the channel stage
                                       dropped */

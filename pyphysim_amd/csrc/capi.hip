@@ -179,7 +179,14 @@ int mcle_ctx_set_option(mcle_ctx* ctx, int option, long long value) {
 #else
         case MCLE_OPT_MIMO_TDL_KERNEL: ok = value >= 0 && value <= 2; break;
 #endif
+#ifdef MCLE_EXPERIMENTS
         case MCLE_OPT_F64_VARIANT: ok = value >= 0 && value <= 3; break;
+#else
+        case MCLE_OPT_F64_VARIANT:      // the timing-bound kernels exist in -DMCLE_EXPERIMENTS builds only (wrong counters by construction)
+            MCLE_REQUIRE(value == 0, "option MCLE_OPT_F64_VARIANT: the timing-bound variants are compiled with -DMCLE_EXPERIMENTS only");
+            ok = true;
+            break;
+#endif
         case MCLE_OPT_MFMA_VARIANT: ok = value == 0 || value == 36 || value == 32 || value == 30 || value == 21; break;
         case MCLE_OPT_GRID_OVERSUB: ok = value >= 0 && value <= 64; break;
         case MCLE_OPT_FLAT_WGS_PER_CU: ok = value >= 0 && value <= 4096; break;

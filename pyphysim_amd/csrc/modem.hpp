@@ -364,7 +364,12 @@ __device__ __forceinline__ int demod_qam_cert(cx<T> r, T scale, int L, int half_
     tj = fmin(fmax(tj, (T)0), lm1);                               // beyond the outer levels: certain (f = 0); NaN -> 0
     ti = fmin(fmax(ti, (T)0), lm1);
     const T kj = rint(tj), ki = rint(ti);
-    sure = fabs(tj - kj) <= lim && fabs(ti - ki) <= lim;
+    // ... and no farther out than `far` level spacings from the centre: beyond the outer levels the clamp makes f = 0 on that axis,
+    // but the margin on the OTHER axis (2 eps spacing^2) only dominates the rounding of the metrics (~ |r|^2 ulp) while |r| stays
+    // below ~2^11 spacings in complex128 and ~20 in complex64 -- a zero-forcing output in a deep fade goes farther
+    constexpr T far = sizeof(T) == 8 ? (T)2048 : (T)16;
+    const T rmax = (far + hl) / hs;                               // wave-uniform
+    sure = fabs(tj - kj) <= lim && fabs(ti - ki) <= lim && fabs(r.x) <= rmax && fabs(r.y) <= rmax;
     unsigned v = ((unsigned)(int)ki << 8) | (unsigned)(int)kj;     // both Gray decodes at once, a byte each (levels < 2^8)
     v ^= (v >> 4) & 0x0F0Fu;
     v ^= (v >> 2) & 0x3F3Fu;

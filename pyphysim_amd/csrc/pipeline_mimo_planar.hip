@@ -571,12 +571,14 @@ static int run_mimo_ofdm_planar_t(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, 
     // antennas per thread, twiddles in registers.  MCLE_OPT_F64_VARIANT 1 .. 3: timing bounds on the 512-thread form.
     if (n == 1024 && nt == 4 && nr == 4) {
         if constexpr (F64) {
+#ifdef MCLE_EXPERIMENTS     // the timing-bound variants give WRONG counters by construction: never in the product build
             switch ((int)ctx->opt[MCLE_OPT_F64_VARIANT]) {
                 case 1: return launch_mimo_ofdm_planar<T, 1024, 4, 4, 2, 4, 1>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
                 case 2: return launch_mimo_ofdm_planar<T, 1024, 4, 4, 2, 4, 2>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
                 case 3: return launch_mimo_ofdm_planar<T, 1024, 4, 4, 2, 4, 3>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
                 default: break;
             }
+#endif
             if (ctx->opt[MCLE_OPT_F64_THREADS] == 258)  // every layer-1 twiddle from the table (A/B: 10.95 ms against 10.62 -- the nine
                 return launch_mimo_ofdm_planar<T, 1024, 4, 4, 4, 2, 28>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);   // loads per pass cost more than the eight products)
         }

@@ -1115,9 +1115,13 @@ int mcle_run_mimo_ofdm(mcle_ctx* ctx, int dtype, const mcle_mimo_ofdm_cfg* cfg, 
         rc = run_mimo_ofdm_mfma(ctx, cfg, seed, first, count, d_counters, d_sym_err, d_bit_err);
         if (rc != MCLE_E_UNSUPPORTED) return rc;
     }
-    if (!(dtype == MCLE_F32 && ctx->opt[MCLE_OPT_NO_MFMA])) {   // the planar kernel family (pipeline_mimo_planar.hip: FFT 256 .. 2048,
-        rc = run_mimo_ofdm_planar(ctx, dtype, cfg, seed, first, count, d_counters, d_sym_err, d_bit_err);   // 1 <= Nt <= Nr <= 4);
-        if (rc != MCLE_E_UNSUPPORTED) return rc;                // no_mfma = 1 keeps complex64 on the round-1 kernel below
+    // the planar kernel family (pipeline_mimo_planar.hip: FFT 256 .. 2048, 1 <= Nt <= Nr <= 4).  no_mfma = 1 keeps complex64 on the
+    // round-1 generic kernel below WHERE THAT ONE EXISTS (Nt = Nr in {2, 4}); every other geometry still runs the planar family --
+    // the option selects a kernel, it does not shrink the envelope
+    const bool generic_has_it = cfg->nt == cfg->nr && (cfg->nt == 2 || cfg->nt == 4);
+    if (!(dtype == MCLE_F32 && ctx->opt[MCLE_OPT_NO_MFMA] && generic_has_it)) {
+        rc = run_mimo_ofdm_planar(ctx, dtype, cfg, seed, first, count, d_counters, d_sym_err, d_bit_err);
+        if (rc != MCLE_E_UNSUPPORTED) return rc;
     }
     MCLE_REQUIRE(cfg->nt == cfg->nr && (cfg->nt == 2 || cfg->nt == 4),
                  "fused MIMO pipeline: %d x %d at fft_size %d is outside the envelope (2x2 / 4x4 at 64 .. 2048 in both arithmetics; "

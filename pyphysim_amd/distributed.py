@@ -59,8 +59,10 @@ def _exchange_id(make_id, rank, world, addr, port, timeout=120.0):
                         peer = struct.unpack("<i", head)[0]
                         if not (1 <= peer < world):
                             continue                      # not one of ours: no id for it
-                        conn.sendall(payload)             # a rank that retries (its first reply was lost) is served
-                        seen.add(peer)                    # again: the reply is idempotent; counted once, after the send
+                        conn.sendall(payload)             # a rank that retries (its first reply was lost) is served again:
+                        ack = conn.recv(1)                # the reply is idempotent.  A peer is counted when it ACKNOWLEDGES the
+                        if ack == b"\x06":                # id (one byte back): sendall returning says nothing about delivery,
+                            seen.add(peer)                # and the listener must outlive every peer that still has to retry
                     except (OSError, ConnectionError, struct.error):
                         continue
         finally:
@@ -77,6 +79,7 @@ def _exchange_id(make_id, rank, world, addr, port, timeout=120.0):
                     if not chunk:
                         raise ConnectionError("short id")
                     buf += chunk
+                conn.sendall(b"\x06")                      # acknowledge: only now does the server count this rank
                 return buf
         except (ConnectionError, OSError):
             if time.time() > deadline:

@@ -49,6 +49,28 @@ def test_strong_split_covers_the_literal_total_once():
     assert default["strong"]["rank_ranges"] == [[0, 500000], [500000, 1000000]]
 
 
+@pytest.mark.timeout(900)
+def test_eight_ranks_cover_what_one_rank_covers():
+    """The driver's N = 8 launch: eight disjoint contiguous ranges whose union is the one-rank range, the
+    strong split of config 4's 10^6 and config 5's 10^5 with their remainders (10^6 / 8 is exact, 10^5 / 8 = 12 500 too; the odd
+    total 100 003 is not), reduced counters equal to one rank's -- launcher, split and reduction on gloo, no GPU."""
+    one = _bench("--gpus", "1", "--steps", "8", "--batch", "512", "--strong-total", "100003")
+    eight = _bench("--gpus", "8", "--steps", "1", "--batch", "512", "--strong-total", "100003")
+    assert eight["n_gpus"] == 8 and len(eight["rank_ranges"]) == 8
+    assert eight["rank_ranges"] == [[512 * r, 512 * (r + 1)] for r in range(8)] and one["rank_ranges"] == [[0, 4096]]
+    assert eight["counters"] == one["counters"] and one["counters"]["n_realizations"] == 4096
+    sr = eight["strong"]["rank_ranges"]
+    assert sr[0][0] == 0 and sr[-1][1] == 100003 and all(a[1] == b[0] for a, b in zip(sr, sr[1:]))
+    assert sr == [[(100003 * r) // 8, (100003 * (r + 1)) // 8] for r in range(8)]
+    assert {hi - lo for lo, hi in sr} == {12500, 12501}                  # the remainder of 3 goes to three ranks
+    assert eight["strong"]["counters"] == one["strong"]["counters"]
+    for cfg, total in (("c4", 10 ** 6), ("c5", 10 ** 5)):                # BASELINE.json's literal counts
+        lit8, lit1 = eight["strong_literal"][cfg], one["strong_literal"][cfg]
+        assert lit8["total_realizations"] == total and lit1["rank_ranges"] == [[0, total]]
+        assert lit8["rank_ranges"] == [[(total * r) // 8, (total * (r + 1)) // 8] for r in range(8)]
+        assert lit8["counters"] == lit1["counters"] and lit1["counters"]["n_realizations"] == total
+
+
 def test_world_size_must_match_gpus():
     env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
     out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--launch-check", "--gpus", "2"], env=env,

@@ -120,3 +120,86 @@ def test_two_ranks_files_resume_and_float_side_sums(tmp_path):
     got, want = outs[0]["cap"], [r.to_dict() for r in ref.results["cap"]]
     for g, w in zip(got, want):
         assert g["num_updates"] == w["num_updates"] and abs(g["value"] - w["value"]) <= 1e-9 * abs(w["value"])
+
+
+# ---- the product's own rendezvous (pyphysim_amd.distributed: the 128-byte RCCL id over TCP), eight ranks, no GPU --------------
+class _StubEngine:
+    """Stands in for Engine where NativeComm only needs the id source and mcle_comm_init: records who joined."""
+    joined = []
+
+    def __init__(self):
+        self.inits = []
+
+    def comm_unique_id(self):
+        return bytes(range(128))
+
+    def comm_init(self, uid, rank, world):
+        assert uid == bytes(range(128))
+        self.inits.append((rank, world))
+        _StubEngine.joined.append(rank)
+
+    def new_counters(self):
+        return None
+
+
+@pytest.mark.timeout(120)
+def test_rendezvous_with_eight_ranks_and_stray_duplicate_and_late_clients():
+    """VERDICT r04 item 8 / ADVICE r04: rank 0 serves the id to seven peers while a port scanner connects and says nothing, a
+    foreign client announces rank 99, one rank's first connection dies before the acknowledgement (it retries: served again, counted
+    once), and one rank shows up two seconds late -- every rank ends with the same id and NativeComm joins 8 of 8."""
+    import struct
+    import threading
+    import time
+    from pyphysim_amd import distributed as D
+    port = _free_port()
+    world = 8
+    ids, errors = {}, []
+    _StubEngine.joined = []
+
+    def rank_main(rank, delay=0.0, drop_first=False):
+        try:
+            time.sleep(delay)
+            if drop_first:           # first attempt: send the rank, read the id, close WITHOUT acknowledging
+                for _ in range(100):
+                    try:
+                        with socket.create_connection(("127.0.0.1", port), timeout=2.0) as c:
+                            c.sendall(struct.pack("<i", rank))
+                            c.recv(128)
+                        break
+                    except OSError:
+                        time.sleep(0.05)
+            eng = _StubEngine()
+            comm = D.NativeComm(eng, rank=rank, world=world, master_addr="127.0.0.1", master_port=port, timeout=30.0)
+            ids[rank] = eng.inits
+            assert comm.rank == rank and comm.world == world
+        except Exception as exc:     # noqa: BLE001 -- reported by the main thread
+            errors.append((rank, repr(exc)))
+
+    def stray(payload):
+        for _ in range(100):
+            try:
+                with socket.create_connection(("127.0.0.1", port), timeout=2.0) as c:
+                    if payload:
+                        c.sendall(payload)
+                        try:
+                            assert c.recv(128) == b""          # not one of ours: no id for it
+                        except OSError:
+                            pass
+                return
+            except OSError:
+                time.sleep(0.05)
+
+    threads = [threading.Thread(target=rank_main, args=(0,))]
+    threads += [threading.Thread(target=rank_main, args=(r,)) for r in (1, 2, 3, 4)]
+    threads += [threading.Thread(target=rank_main, args=(5,), kwargs=dict(drop_first=True))]
+    threads += [threading.Thread(target=rank_main, args=(6,), kwargs=dict(delay=2.0))]
+    threads += [threading.Thread(target=rank_main, args=(7,))]
+    threads += [threading.Thread(target=stray, args=(b"",)), threading.Thread(target=stray, args=(struct.pack("<i", 99),)),
+                threading.Thread(target=stray, args=(b"\x01",))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=60.0)
+    assert not errors, errors
+    assert sorted(ids) == list(range(8)) and all(v == [(r, 8)] for r, v in ids.items())
+    assert sorted(_StubEngine.joined) == list(range(8))
