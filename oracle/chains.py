@@ -198,8 +198,10 @@ def chain_flat_rayleigh(rng, mod='qam', M=16, N=1000, snr_db=15.0, form='suchann
 
 def chain_ofdm_tdl(rng, mod='qpsk', M=4, fft_size=1024, cp_size=16, num_used=None, n_ofdm_sym=1,
                    snr_db=20.0, Fd=10.0, Ts=1.0 / (15e3 * 1024), L=8,
-                   tap_powers_dB=(0.0, -3.0, -6.0, -9.0, -12.0), tap_delays_samples=(0, 1, 2, 3, 4)):
-    """C3: OFDM over a time-varying Jakes TDL channel with a one-tap equaliser."""
+                   tap_powers_dB=(0.0, -3.0, -6.0, -9.0, -12.0), tap_delays_samples=(0, 1, 2, 3, 4), linear_mean=False):
+    """C3: OFDM over a time-varying Jakes TDL channel with a one-tap equaliser.
+    linear_mean: the equaliser's response as the DFT of the per-symbol mean taps (oofdm.onetap_equalize_fast, equal to the literal
+    mean of per-sample DFTs by linearity, 10 x cheaper: the deep GPU parity tests use it)."""
     table = constellation(mod, M)
     num_used = oofdm.check_params(fft_size, cp_size, num_used)
     noise_var = 1.0 / float(omodem.dB2Linear(snr_db))
@@ -221,7 +223,7 @@ def chain_ofdm_tdl(rng, mod='qpsk', M=4, fft_size=1024, cp_size=16, num_used=Non
     noise = rng.cn(philox.STREAM_NOISE, faded.size)
     rx = faded + math.sqrt(noise_var) * noise
     demod = oofdm.demodulate(rx[:tx.size].copy(), fft_size, cp_size, num_used)
-    eq = oofdm.onetap_equalize(demod, taps, d_idx, fft_size, cp_size, num_used)
+    eq = (oofdm.onetap_equalize_fast if linear_mean else oofdm.onetap_equalize)(demod, taps, d_idx, fft_size, cp_size, num_used)
     dec = omodem.demodulate(table, eq)
     return _counts(dict(table=table, idx=idx, sym=sym, tx=tx, phi=phi, psi=psi, t=t, taps=taps,
                         tap_powers_linear=p_lin, delay_indexes=d_idx, faded=faded, noise=noise,

@@ -248,3 +248,24 @@ def test_multiuser_covariances_and_sinrs_match_reference():
                 assert relerr(omu.calc_Q(H, Nr, Nt, k, F, nv, pe if ext.size else 0.0, joint), z[tag + "Q%d" % k]) <= 1e-12
                 n += 1
     assert n == 2 * (3 + 3 + 2 + 3 + 2 + 4)
+
+
+def test_linear_mean_response_equals_the_literal_one():
+    """The deep GPU parity tests (tests/test_gpu_oracle_depth.py, tests/test_gpu_mimo_tdl_wave.py) run the two TDL chains with the
+    DFT of the per-symbol mean taps in place of the mean of per-sample DFTs the reference computes (channels/fading.py:513-536,
+    modulators/ofdm.py:545-547): the same number by linearity of the DFT -- held here to 1e-12 on the equalised symbols / the
+    frequency response, with identical decisions."""
+    from oracle import chains
+    for r in range(3):
+        kw = dict(mod="qam", M=16, fft_size=256, cp_size=20, num_used=200, n_ofdm_sym=2, snr_db=18.0, Fd=120.0, Ts=1e-6, L=8,
+                  tap_powers_dB=(0.0, -3.0, -7.0), tap_delays_samples=(0, 2, 9))
+        a = chains.chain_ofdm_tdl(chains.PhiloxRng(5, r), **kw)
+        b = chains.chain_ofdm_tdl(chains.PhiloxRng(5, r), linear_mean=True, **kw)
+        assert np.max(np.abs(a["eq"] - b["eq"])) <= 1e-12 * max(1.0, np.max(np.abs(a["eq"])))
+        assert a["symbol_errors"] == b["symbol_errors"] and a["bit_errors"] == b["bit_errors"]
+        kw = dict(mod="qam", M=16, nt=2, nr=3, fft_size=128, cp_size=12, num_used=100, n_ofdm_sym=2, snr_db=16.0, Fd=80.0, Ts=1e-6,
+                  L=8, tap_powers_dB=(0.0, -4.0, -9.0), tap_delays_samples=(0, 2, 5))
+        a = chains.chain_mimo_ofdm_tdl(chains.PhiloxRng(6, r), **kw)
+        b = chains.chain_mimo_ofdm_tdl(chains.PhiloxRng(6, r), linear_mean=True, **kw)
+        assert np.max(np.abs(a["Hu"] - b["Hu"])) <= 1e-13 and np.max(np.abs(a["est"] - b["est"])) <= 1e-11
+        assert a["symbol_errors"] == b["symbol_errors"] and a["bit_errors"] == b["bit_errors"]
