@@ -103,7 +103,9 @@ enum {
                                       per thread, 256 threads (all five: same results contract; A/B times in DESIGN.md 5.5).
                                       complex64 (the planar family on planes of floats): 0 = radix-16 passes with a SEPARATE channel
                                       stage at a four-wavefront register bound (default); 257 = the same at a three-wavefront
-                                      bound; 259 = the fused channel stage; 512 / 256 as above */
+                                      bound; 259 = the fused channel stage; 512 / 256 as above.
+                                      fft_size 2048 with four receive antennas and Nt >= 3: 512 = four antennas per thread (512 threads,
+                                      nothing spilled; the default where it is the faster form), 1024 = two antennas per thread */
     MCLE_OPT_BD_RUNTIME_SOLVE = 9, /* 1: the block-diagonalisation pipeline solves with the run-time-sized routine (private
                                       arrays in scratch) also where the compile-time-sized one (K nr <= 6) applies */
     MCLE_OPT_DEMOD_NOCERT = 10,    /* 1: min-distance decisions of a square Gray QAM always through the table search (candidate

@@ -197,7 +197,9 @@ __global__ __launch_bounds__(64 * NR, WPS) void k_run_mimo_ofdm_tdl_wave(MimoTdl
     }
     [[maybe_unused]] R16Tw64<T> tw16;
     constexpr int REP4 = N / 256;
-    constexpr bool WTW = !R16 && sizeof(T) == 4 && REP4 * FftShape<N>::N4 * 6 <= 48;     // radix-4 sizes, complex64: stage twiddles in registers
+    // radix-4 sizes, complex64: the lane's stage twiddles in registers at 256 (24 registers; the 48 of 512 spilled 36 registers
+    // next to the Gram accumulators of the decode)
+    constexpr bool WTW = !R16 && sizeof(T) == 4 && REP4 * FftShape<N>::N4 * 6 <= 24;
     [[maybe_unused]] TwRegs64<T, N> twr4[WTW ? REP4 : 1];
     if constexpr (WTW) {
 #pragma unroll
@@ -314,67 +316,75 @@ __global__ __launch_bounds__(64 * NR, WPS) void k_run_mimo_ofdm_tdl_wave(MimoTdl
                 const T x0 = sizeof(T) == 8 ? (T)((double)(cp + gi) - xc) : (T)(cp + gi) - (T)xc;
                 const int NP = (ABL & 1) ? 0 : S * NT;                      // (tap, transmit antenna) pairs, p = s NT + a
                 const cx<T>* xbase = reinterpret_cast<const cx<T>*>(s_all) + (P + gi);
-                // the R delayed samples of pair p: x_a[m - d] = xd[64 c], d <= P -- one address, immediate offsets
-                auto load_pair = [&](int p, cx<T> (&buf)[R]) {
-                    const int s = p / NT, a = p - s * NT;
-                    const cx<T>* xd = xbase + (a * pitch - __builtin_amdgcn_readlane(dlyv, s));
+                // Sixteen samples of the lane at a time (the whole lane at <= 1024 points; two rounds of the pair loop at 2048, where
+                // 32 accumulators + 32 delayed samples + their abscissae did not fit the registers and the accumulators were
+                // spilled inside the loop)
+                constexpr int CHN = R < 16 ? R : 16;
+                static_for<R / CHN>([&](auto hc) {
+                    constexpr int C0 = decltype(hc)::value * CHN;
+                    // the CHN delayed samples of pair p: x_a[m - d] = xd[64 c], d <= P -- one address, immediate offsets
+                    auto load_pair = [&](int p, cx<T> (&buf)[CHN]) {
+                        const int s = p / NT, a = p - s * NT;
+                        const cx<T>* xd = xbase + (a * pitch - __builtin_amdgcn_readlane(dlyv, s));
 #pragma unroll
-                    for (int c = 0; c < R; ++c) {
-                        if constexpr (ABL & 64) buf[c] = mk<T>((T)(size_t)xd, x0);   // (timing: the channel stage without its LDS reads)
-                        else buf[c] = xd[64 * c];
-                    }
-                };
-                auto mac_pair = [&](int p, const cx<T> (&buf)[R]) {
-                    if constexpr (KT > 0) {
-                        cx<T> cc[KT + 1];
+                        for (int c = 0; c < CHN; ++c) {
+                            if constexpr (ABL & 64) buf[c] = mk<T>((T)(size_t)xd, x0);   // (timing: the channel stage without its LDS reads)
+                            else buf[c] = xd[64 * (C0 + c)];
+                        }
+                    };
+                    auto mac_pair = [&](int p, const cx<T> (&buf)[CHN]) {
+                        if constexpr (KT > 0) {
+                            cx<T> cc[KT + 1];
 #pragma unroll
-                        for (int m = 0; m <= KT; ++m)
-                            cc[m] = mk<T>(lane_value(prk[m >> 1].x, 2 * p + (m & 1)), lane_value(prk[m >> 1].y, 2 * p + (m & 1)));
+                            for (int m = 0; m <= KT; ++m)
+                                cc[m] = mk<T>(lane_value(prk[m >> 1].x, 2 * p + (m & 1)), lane_value(prk[m >> 1].y, 2 * p + (m & 1)));
 #pragma unroll
-                        for (int c = 0; c < R; ++c) chan_step<KT, !(ABL & 128)>(y[c], cc, x0 + (T)(64 * c) /* exact */, buf[c]);
-                    } else {                    // run-time order: the coefficients by wave-uniform loads from the record, four
-                        const cx<T>* __restrict__ cb = g_rec + (size_t)w * NQ * LW + 2 * p;   // samples at a time (registers)
-                        constexpr int CH = R < 4 ? R : 4;
+                            for (int c = 0; c < CHN; ++c)
+                                chan_step<KT, !(ABL & 128)>(y[C0 + c], cc, x0 + (T)(64 * (C0 + c)) /* exact */, buf[c]);
+                        } else {                // run-time order: the coefficients by wave-uniform loads from the record, four
+                            const cx<T>* __restrict__ cb = g_rec + (size_t)w * NQ * LW + 2 * p;   // samples at a time (registers)
+                            constexpr int CH = CHN < 4 ? CHN : 4;
 #pragma unroll
-                        for (int c0 = 0; c0 < R; c0 += CH) {
-                            cx<T> g[CH];
-                            const cx<T> top = cb[(K >> 1) * LW + (K & 1)];
+                            for (int c0 = 0; c0 < CHN; c0 += CH) {
+                                cx<T> g[CH];
+                                const cx<T> top = cb[(K >> 1) * LW + (K & 1)];
 #pragma unroll
-                            for (int c = 0; c < CH; ++c) g[c] = top;
-                            for (int mm = K - 1; mm >= 0; --mm) {
-                                const cx<T> cm = cb[(mm >> 1) * LW + (mm & 1)];
+                                for (int c = 0; c < CH; ++c) g[c] = top;
+                                for (int mm = K - 1; mm >= 0; --mm) {
+                                    const cx<T> cm = cb[(mm >> 1) * LW + (mm & 1)];
 #pragma unroll
-                                for (int c = 0; c < CH; ++c) {
-                                    const T xx = x0 + (T)(64 * (c0 + c));
-                                    g[c].x = fma(g[c].x, xx, cm.x);
-                                    g[c].y = fma(g[c].y, xx, cm.y);
+                                    for (int c = 0; c < CH; ++c) {
+                                        const T xx = x0 + (T)(64 * (C0 + c0 + c));
+                                        g[c].x = fma(g[c].x, xx, cm.x);
+                                        g[c].y = fma(g[c].y, xx, cm.y);
+                                    }
                                 }
-                            }
 #pragma unroll
-                            for (int c = 0; c < CH; ++c) y[c0 + c] = cfma(g[c], buf[c0 + c], y[c0 + c]);
+                                for (int c = 0; c < CH; ++c) y[C0 + c0 + c] = cfma(g[c], buf[c0 + c], y[C0 + c0 + c]);
+                            }
+                        }
+                    };
+                    if constexpr (CHAN_DB) {    // two sample buffers: the loads of pair p + 1 fly while pair p is consumed
+                        cx<T> xa[CHN], xb[CHN];
+                        if (NP > 0) load_pair(0, xa);
+                        int p = 0;
+#pragma nounroll
+                        for (; p + 1 < NP; p += 2) {
+                            load_pair(p + 1, xb);
+                            mac_pair(p, xa);
+                            if (p + 2 < NP) load_pair(p + 2, xa);
+                            mac_pair(p + 1, xb);
+                        }
+                        if (p < NP) mac_pair(p, xa);
+                    } else {
+#pragma nounroll
+                        for (int p = 0; p < NP; ++p) {
+                            cx<T> xa[CHN];
+                            load_pair(p, xa);
+                            mac_pair(p, xa);
                         }
                     }
-                };
-                if constexpr (CHAN_DB) {        // two sample buffers: the loads of pair p + 1 fly while pair p is consumed
-                    cx<T> xa[R], xb[R];
-                    if (NP > 0) load_pair(0, xa);
-                    int p = 0;
-#pragma nounroll
-                    for (; p + 1 < NP; p += 2) {
-                        load_pair(p + 1, xb);
-                        mac_pair(p, xa);
-                        if (p + 2 < NP) load_pair(p + 2, xa);
-                        mac_pair(p + 1, xb);
-                    }
-                    if (p < NP) mac_pair(p, xa);
-                } else {
-#pragma nounroll
-                    for (int p = 0; p < NP; ++p) {
-                        cx<T> xa[R];
-                        load_pair(p, xa);
-                        mac_pair(p, xa);
-                    }
-                }
+                });
             }
             if constexpr (R16) tw16 = load_r16_tw<T>(g_tw, opaque(lane));    // in flight behind the noise draws
             // ---- noise: sample w noise_row + sym0 + cp + m of the NOISE stream ----
@@ -485,7 +495,9 @@ __global__ __launch_bounds__(64 * NR, WPS) void k_run_mimo_ofdm_tdl_wave(MimoTdl
                             else t[a] = cmul(s_mean[(s * NR + r) * NT + a], Wt[s]);
                         }
                         if constexpr (BQ == 2) {                            // H(f0) += t, H(f0 + N / 2) += (-1)^d t: no select, no branch
-                            const T sg = (dly[s] & 1) ? (T)-1 : (T)1;
+                            int dl = dly[s];
+                            asm volatile("" : "+s"(dl));                    // (recomputed here: hoisted, the eight sign pairs were spilled)
+                            const T sg = (dl & 1) ? (T)-1 : (T)1;
 #pragma unroll
                             for (int a = 0; a < NT; ++a) {
                                 u[0][a] = cadd(u[0][a], t[a]);

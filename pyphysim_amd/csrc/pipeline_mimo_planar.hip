@@ -615,6 +615,19 @@ static int run_mimo_ofdm_planar_t(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, 
         if (nt == 3) return launch_mimo_ofdm_planar<T, 1024, 3, 4, 4, WR16, VR16>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
     }
     MCLE_F64_SIZE(1024, 3, 4)
+    // 2048 with four receive antennas: 1 024 threads (two antennas per thread) are four wavefronts per SIMD by themselves, i.e. a
+    // 128-register bound that the complex128 form does not meet (36 / 22 spilled registers at 4 x 4 / 3 x 4, complex64 13 / 0).  Four
+    // antennas per thread (512 threads, 256 registers, nothing spilled) is the default where it is the faster form -- 4 x 4 in both
+    // arithmetics (+7 % / +4 %) and 3 x 4 in complex64 (+3 %); 3 x 4 in complex128 keeps the 1 024-thread form WITH its spills (7.38
+    // against 7.70 ms per 65 536 realizations): profiles/r05/planar_2048_ab.log.  MCLE_OPT_F64_THREADS: 512 / 1024 force either.
+    if (n == 2048 && nr == 4 && (nt == 4 || nt == 3)) {
+        const long long thr = ctx->opt[MCLE_OPT_F64_THREADS];
+        const bool four = thr == 512 || (thr != 1024 && (nt == 4 || !F64));
+        if (four) {
+            if (nt == 4) return launch_mimo_ofdm_planar<T, 2048, 4, 4, 4, 2>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
+            return launch_mimo_ofdm_planar<T, 2048, 3, 4, 4, 2>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
+        }
+    }
     MCLE_F64_SIZE(2048, 4, 4) MCLE_F64_GEOM(2048, 4, 4, 2, 4)
 #undef MCLE_F64_SIZE
 #undef MCLE_F64_GEOM
