@@ -21,6 +21,7 @@
 // (what numpy's pinv returns for a zero column).
 #include "modem.hpp"
 #include "philox.hpp"
+#include "pkcx.hpp"
 #include "pipe_common.hpp"
 #include "totals.hpp"
 #include "wave_draws.hpp"
@@ -663,7 +664,7 @@ __global__ __launch_bounds__(64) void k_bd_solve_links_static(BdParams pp, uint6
 // eight-entry arrays in one body the complex64 form spilled 45-52 registers at its 128-register bound (profiles/r03:
 // VALU busy 0.97 on the draw ledger plus spill traffic).
 template <typename T, int R, int KC = 0, int MODE = 0>
-__global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void k_bd_link(ModemParams<T> mp, BdParams pp, uint64_t seed,
+__global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : (KC ? 3 : 2)) void k_bd_link(ModemParams<T> mp, BdParams pp, uint64_t seed,
                                                                         uint64_t first, uint64_t count, int per_wave,
                                                                         const cx<T>* __restrict__ recs,
                                                                         mcle_counters* counters,
@@ -712,9 +713,16 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void k_bd_link(ModemPar
 #pragma unroll
                         for (int jj = 0; jj < R; ++jj) {
                             const int s = k * R + jj;
-                            est[jj] = cmul(D[s], s_table[tx[s]]);
+                            if constexpr (sizeof(T) == 4) {          // explicit packed forms (pkcx.hpp): 2 + 2 R instructions
+                                pk2 e = pk_cmul(to_pk(D[s]), to_pk(s_table[tx[s]]));
 #pragma unroll
-                            for (int a = 0; a < R; ++a) est[jj] = cfma(W[s * R + a], nz[k * R + a], est[jj]);
+                                for (int a = 0; a < R; ++a) e = pk_cfma(to_pk(W[s * R + a]), to_pk(nz[k * R + a]), e);
+                                est[jj] = from_pk(e);
+                            } else {
+                                est[jj] = cmul(D[s], s_table[tx[s]]);
+#pragma unroll
+                                for (int a = 0; a < R; ++a) est[jj] = cfma(W[s * R + a], nz[k * R + a], est[jj]);
+                            }
                         }
                         int dec[R];
                         if constexpr (sizeof(T) == 4 && MODE == 1) {
@@ -740,14 +748,43 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void k_bd_link(ModemPar
                     int ta[NMAX], tb[NMAX];
                     wave_symbol_pairs<NMAX>(rng, n, (uint32_t)NS, (uint32_t)t0, mask, lane, ta, tb);
                     if (t < NS) {
-                        cx<T> za[NMAX], zb[NMAX];
+                        if constexpr (sizeof(T) == 8) {
+                            // complex128: user by user -- the noise of ONE user's R antennas (both columns), its estimates, its
+                            // decisions -- instead of all K R antennas' draws first: 8 R live noise registers instead of 8 K R,
+                            // so that the registers can be bounded for three wavefronts per SIMD (round 5; k_ia_link alike)
 #pragma unroll
-                        for (int a = 0; a < NMAX; ++a)
-                            if (KC || a < n)
-                                cn_pair_lds(rng, STREAM_NOISE, ((uint32_t)a * (uint32_t)NS + (uint32_t)t) >> 1, sigma,
-                                            za[a], zb[a], s_bm);
-                        column(ta, za);
-                        column(tb, zb);
+                            for (int k = 0; k < KMAX; ++k)
+                                if (KC || k < K) {
+                                    cx<T> za[R], zb[R];
+#pragma unroll
+                                    for (int a = 0; a < R; ++a)
+                                        cn_pair_lds(rng, STREAM_NOISE, ((uint32_t)(k * R + a) * (uint32_t)NS + (uint32_t)t) >> 1, sigma,
+                                                    za[a], zb[a], s_bm);
+#pragma unroll
+                                    for (int jj = 0; jj < R; ++jj) {
+                                        const int s = k * R + jj;
+                                        cx<T> ea = cmul(D[s], s_table[ta[s]]), eb = cmul(D[s], s_table[tb[s]]);
+#pragma unroll
+                                        for (int a = 0; a < R; ++a) {
+                                            ea = cfma(W[s * R + a], za[a], ea);
+                                            eb = cfma(W[s * R + a], zb[a], eb);
+                                        }
+                                        const unsigned da = (unsigned)(ta[s] ^ demod_one(mp, s_table, s_grid, ea));
+                                        const unsigned db = (unsigned)(tb[s] ^ demod_one(mp, s_table, s_grid, eb));
+                                        se += (da != 0u) + (db != 0u);
+                                        be += __popc(da) + __popc(db);
+                                    }
+                                }
+                        } else {
+                            cx<T> za[NMAX], zb[NMAX];
+#pragma unroll
+                            for (int a = 0; a < NMAX; ++a)
+                                if (KC || a < n)
+                                    cn_pair_lds(rng, STREAM_NOISE, ((uint32_t)a * (uint32_t)NS + (uint32_t)t) >> 1, sigma,
+                                                za[a], zb[a], s_bm);
+                            column(ta, za);
+                            column(tb, zb);
+                        }
                     }
                 }
             } else {
@@ -803,12 +840,18 @@ static int launch_run_bd(mcle_ctx* ctx, const mcle_bd_cfg* cfg, const BdParams& 
             hipLaunchKernelGGL((k_bd_solve_links<T, R>), sgrid, dim3(64), 0, ctx->stream, pp, seed, first + off, m,
                                (cx<T>*)recs);
         MCLE_LAUNCH_CHECK();
-        const uint64_t cap = (uint64_t)ctx->n_cu * 4 * (sizeof(T) == 4 ? 4 : 2);
+        // (complex128: three wavefronts per SIMD where the user count is a compile-time constant -- 168 registers, nothing spilled --
+        //  two for the run-time-sized form, which spills 18 - 58 registers at that bound)
+        const bool kc = R <= 2 && (cfg->K == 2 || cfg->K == 3) && cfg->K * R <= kBdMaxN;
+        const uint64_t cap = (uint64_t)ctx->n_cu * 4 * (sizeof(T) == 4 ? 4 : (kc ? 3 : 2));
         const uint64_t chunks = (m + per_wave - 1) / per_wave;
         const unsigned grid = (unsigned)oversubscribed_grid(ctx, cap, chunks, 2);     // a chunk is 8-16 realizations; one chunk per workgroup measured 1.5 x slower
         // demodulator path of the walk (compile-time in the kernel): complex64 min-distance in lockstep -- a sweep for M <= 8,
         // certificate / candidate grid otherwise; everything else one demod_one per stream
-        const int mode = (sizeof(T) == 4 && mp.method == MCLE_DEMOD_MINDIST) ? (mp.M <= 8 ? 1 : (mp.grid.G > 0 ? 2 : 0)) : 0;
+        // (round 5: a constellation WITH a certificate -- square QAM, QPSK -- goes through it whatever its size: the application's
+        //  own 4-PSK was swept point by point in lockstep, ~20 instructions per decision where the quadrant certificate takes 6)
+        const int mode = (sizeof(T) == 4 && mp.method == MCLE_DEMOD_MINDIST)
+                             ? ((mp.cert && mp.grid.G > 0) ? 2 : (mp.M <= 8 ? 1 : (mp.grid.G > 0 ? 2 : 0))) : 0;
         bool walked = false;
 #define MCLE_BD_WALK(KC_, MODE_)                                                                                          \
     if (!walked && (KC_ == 0 || (cfg->K == KC_ && KC_ * R <= kBdMaxN)) && mode == MODE_) {                                  \

@@ -551,7 +551,7 @@ __global__ __launch_bounds__(64) void k_ia_solve_links(double noise_var, int sol
 // The symbol walk: one wavefront per `per_wave` consecutive realizations, est_k = sum_l G_kl x_l + U_k . n_k, two
 // columns per lane and pass (wave_draws.hpp).  The record of a realization is wave-uniform (scalar loads).
 template <typename T>
-__global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void k_ia_link(ModemParams<T> mp, int n_symbols, double noise_var,
+__global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 3) void k_ia_link(ModemParams<T> mp, int n_symbols, double noise_var,
                                                                         uint64_t seed, uint64_t first, uint64_t count,
                                                                         int per_wave, const cx<T>* __restrict__ recs,
                                                                         mcle_counters* counters,
@@ -642,13 +642,45 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void k_ia_link(ModemPar
                     int ta[3], tb[3];
                     wave_symbol_pairs<3>(rng, 3, (uint32_t)n_symbols, (uint32_t)t0, mask, lane, ta, tb);   // randint(0, M, [3, NSymbs])
                     if (t < n_symbols) {
-                        cx<T> za[6], zb[6];
+                        if constexpr (sizeof(T) == 8) {
+                            // complex128: receiver by receiver -- the noise of ONE receiver's two antennas (both columns), its
+                            // estimate, its decisions -- instead of all six antennas' draws first: 16 live noise registers instead
+                            // of 48, which is what lets the registers be bounded for three wavefronts per SIMD (round 5)
+                            cx<T> xa[3], xb[3];
 #pragma unroll
-                        for (int a = 0; a < 6; ++a)
-                            cn_pair_lds(rng, STREAM_NOISE, ((uint32_t)a * (uint32_t)n_symbols + (uint32_t)t) >> 1, sigma,
-                                        za[a], zb[a], s_bm);
-                        column(ta, za);
-                        column(tb, zb);
+                            for (int k = 0; k < 3; ++k) {
+                                xa[k] = s_table[ta[k]];
+                                xb[k] = s_table[tb[k]];
+                            }
+#pragma unroll
+                            for (int k = 0; k < 3; ++k) {
+                                cx<T> za[2], zb[2];
+#pragma unroll
+                                for (int a = 0; a < 2; ++a)
+                                    cn_pair_lds(rng, STREAM_NOISE, ((uint32_t)(2 * k + a) * (uint32_t)n_symbols + (uint32_t)t) >> 1, sigma,
+                                                za[a], zb[a], s_bm);
+                                cx<T> ea = cmul(U[k][0], za[0]), eb = cmul(U[k][0], zb[0]);
+                                ea = cfma(U[k][1], za[1], ea);
+                                eb = cfma(U[k][1], zb[1], eb);
+#pragma unroll
+                                for (int l = 0; l < 3; ++l) {
+                                    ea = cfma(G[k][l], xa[l], ea);
+                                    eb = cfma(G[k][l], xb[l], eb);
+                                }
+                                const unsigned da = (unsigned)(ta[k] ^ demod_one(mp, s_table, s_grid, ea));
+                                const unsigned db = (unsigned)(tb[k] ^ demod_one(mp, s_table, s_grid, eb));
+                                se += (da != 0u) + (db != 0u);
+                                be += __popc(da) + __popc(db);
+                            }
+                        } else {
+                            cx<T> za[6], zb[6];
+#pragma unroll
+                            for (int a = 0; a < 6; ++a)
+                                cn_pair_lds(rng, STREAM_NOISE, ((uint32_t)a * (uint32_t)n_symbols + (uint32_t)t) >> 1, sigma,
+                                            za[a], zb[a], s_bm);
+                            column(ta, za);
+                            column(tb, zb);
+                        }
                     }
                 }
             } else {
@@ -691,7 +723,7 @@ int run_ia_impl(mcle_ctx* ctx, const mcle_ia_cfg* cfg, uint64_t seed, uint64_t f
                            (cx<T>*)recs, d_cap ? d_cap + off : nullptr, d_iter ? d_iter + off : nullptr);
         MCLE_LAUNCH_CHECK();
         const uint64_t chunks = (n + per_wave - 1) / per_wave;
-        const uint64_t cap = (uint64_t)ctx->n_cu * 4 * (sizeof(T) == 4 ? 4 : 2);
+        const uint64_t cap = (uint64_t)ctx->n_cu * 4 * (sizeof(T) == 4 ? 4 : 3);
         const unsigned grid = (unsigned)oversubscribed_grid(ctx, cap, chunks, 2);     // a chunk is 8-16 realizations; one chunk per workgroup measured 1.5 x slower
         hipLaunchKernelGGL(k_ia_link<T>, dim3(grid), dim3(64), lds, ctx->stream, mp, cfg->n_symbols, cfg->noise_var, seed,
                            first + off, n, per_wave, (const cx<T>*)recs, d_counters, d_sym ? d_sym + off : nullptr,
