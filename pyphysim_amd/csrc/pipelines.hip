@@ -94,7 +94,13 @@ struct FlatParams {
 // (h s + z) / h, the flat-fading link followed by its one-tap equaliser (singleuser.py:130-151 and the notebooks' `/ h`).
 // f64 (parity instantiation): literally that.  f32: s + z conj(h) / |h|^2 with one v_rcp_f32 -- the same value to
 // rounding, a dozen instructions fewer per symbol (measured: 157 -> 145 VALU instructions per symbol row).
-__device__ __forceinline__ double2 flat_equalised(double2 h, double2 s, double2 z) { return cdivide(cadd(cmul(h, s), z), h); }
+// (complex128: ONE division -- the reciprocal of |h|^2 -- and two products instead of cdivide's two divisions: a dozen f64
+//  instructions fewer per symbol, the same value to a rounding, round 5)
+__device__ __forceinline__ double2 flat_equalised(double2 h, double2 s, double2 z) {
+    const double2 a = cadd(cmul(h, s), z);
+    const double inv = 1.0 / (h.x * h.x + h.y * h.y);
+    return mk<double>((a.x * h.x + a.y * h.y) * inv, (a.y * h.x - a.x * h.y) * inv);
+}
 __device__ __forceinline__ float2 flat_equalised(float2 h, float2 s, float2 z) {
     const float inv = __builtin_amdgcn_rcpf(fmaf(h.x, h.x, h.y * h.y));
     return make_float2(fmaf(fmaf(z.x, h.x, z.y * h.y), inv, s.x), fmaf(fmaf(z.y, h.x, -(z.x * h.y)), inv, s.y));
@@ -164,15 +170,35 @@ __global__ __launch_bounds__(kPipeBlock, (sizeof(T) == 8 && LR == 8) ? 2 : 1) vo
         unsigned se = 0, be = 0;
         const int n_begin = chunk * kChunk;
         const int n_end = min(n_begin + kChunk, fp.n_symbols);
-        for (int g0 = n_begin + (int)threadIdx.x * 16; g0 < n_end; g0 += kPipeBlock * 16) {
+        // complex128 with the ray recurrence: a thread takes RUN = 4 consecutive DATA blocks (64 symbols) per pass and restarts its
+        // phasors exactly (f64 sincos per ray) once per run instead of once per block: 8 sincos per 64 symbols instead of per 16
+        // (64 rotations accumulate < 1e-14 of relative error); every other form keeps one block per pass
+        // (a FULL chunk only: in the ragged last chunk of a realization 64-symbol runs would leave most of the workgroup idle)
+        constexpr int RUNMAX = (kRec && sizeof(T) == 8) ? 4 : 1;
+        const int RUN = (RUNMAX > 1 && n_end - n_begin == kChunk) ? RUNMAX : 1;
+        for (int gr = n_begin + (int)threadIdx.x * 16 * RUN; gr < n_end; gr += kPipeBlock * 16 * RUN) {
+          cx<T> ray[kRec ? LR : 1], rot[kRec ? LR : 1];
+          for (int bq = 0; bq < RUN; ++bq) {
+            const int g0 = gr + 16 * bq;
+            if (g0 >= n_end) break;
             const Words4 dw = rng.block(STREAM_DATA, (uint32_t)(g0 >> 4));
-            cx<T> ray[kRec ? LR : 1], rot[kRec ? LR : 1];
-            if (kRec) {
+            if (kRec && bq == 0) {
                 const double t = jakes_time(fp.t0, fp.dt, (double)g0);
 #pragma unroll
                 for (int l = 0; l < (kRec ? LR : 1); ++l) {
                     ray[l] = jakes_ray<T>(s_w[l], s_psi[l], t);
-                    rot[l] = s_rot[l];
+                    if constexpr (sizeof(T) == 8) {
+                        // complex128: the per-symbol rotations are wave-uniform -- as scalars (v_readfirstlane) they cost no vector
+                        // registers; as 32 VGPRs next to the 32 of the ray phasors the kernel spilled 14 registers at its
+                        // 256-register bound
+                        const cx<T> v = s_rot[l];
+                        rot[l] = mk<T>(__hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v.x)),
+                                                        __builtin_amdgcn_readfirstlane(__double2loint(v.x))),
+                                       __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v.y)),
+                                                        __builtin_amdgcn_readfirstlane(__double2loint(v.y))));
+                    } else {
+                        rot[l] = s_rot[l];
+                    }
                 }
             }
 #pragma unroll
@@ -255,6 +281,7 @@ __global__ __launch_bounds__(kPipeBlock, (sizeof(T) == 8 && LR == 8) ? 2 : 1) vo
                         }
                 }
             }
+          }
         }
         block_sum2(se, be, s_red);
         if (threadIdx.x == 0 && (se | be)) {
