@@ -30,8 +30,13 @@ template <typename T> struct ModemParams {
     int half_bits;   // bits/2
     int cert;        // 1: min-distance decisions of a square Gray QAM through the margin certificate (demod_qam_cert);
                      // 2: of a four-point one-per-quadrant constellation (QPSK) through the quadrant certificate (demod_quad_cert)
+                     // 3: of an M-PSK, M in {8, 16, 32}, through the sector certificate (demod_psk_cert)
     unsigned quad_lut;   // cert == 2: label of quadrant (re < 0) | (im < 0) << 1, a byte each
     T quad_lo, quad_hi;  // cert == 2: the certificate holds for lo <= |re|, |im| <= hi
+    // cert == 3: label of sector k (a byte each), e^{-j phi0}, cos / sin of the M / 8 sector boundaries inside the first octant,
+    // the magnitude window of the certificate
+    unsigned psk_lut[8];
+    T psk_rot[2], psk_cb[4], psk_sb[4], psk_lo, psk_hi;
 };
 
 // exhaustive minimum distance over a table held in LDS; strict '<' keeps the FIRST minimum,
@@ -390,7 +395,55 @@ __device__ __forceinline__ int demod_quad_cert(cx<T> r, unsigned lut, T lo, T hi
     const unsigned q = (r.x < (T)0 ? 8u : 0u) | (r.y < (T)0 ? 16u : 0u);
     return (int)((lut >> q) & 0xFFu);
 }
+// Min-distance decision of an M-PSK (M = 8, 16, 32: M points of one radius at angles 2 pi k / M + phi0) WITHOUT touching the
+// table: the regions are the M sectors.  u = r e^{-j phi0}; fold into the first octant (hi = max(|re|, |im|), lo = the other); the
+// M / 8 sector boundaries inside the octant sit at theta_j = (2 j + 1) pi / M, and lo cos(theta_j) - hi sin(theta_j) =
+// |u| sin(theta - theta_j) says on which side of boundary j the point lies -- no arctangent, no division.  p = boundaries passed =
+// point index inside the octant; un-fold: swap -> M / 4 - p, re < 0 -> M / 2 - k, im < 0 -> -k (mod M); label = lut[k].  The folds
+// are consistent ON their own borders (the 45-degree line and the axes are point directions, both sides give the same k), so only
+// the sector boundaries need a margin: `sure` iff every |lo cos - hi sin| >= eps hi, i.e. an angular distance >= eps / sqrt 2 from
+// every boundary, and lo_bound <= hi <= hi_bound.  Two neighbouring candidates then differ by >= 2 |r| rho sin(pi / M) eps in
+// squared distance (rho = the radius) against a rounding of ~ (|r|^2 + rho^2) ulp of either metric: eps = 2^-28 inside
+// [2^-8, 2^8] rho in complex128, 2^-12 inside [1/8, 8] rho in complex64 -- the sweep, first-minimum rule included, returns this
+// very label.  Elsewhere (probability ~ M eps / 4 per symbol, or a deep-fade equaliser output) the caller searches the table.
+template <typename T>
+__device__ __forceinline__ int demod_psk_cert(cx<T> r, const ModemParams<T>& mp, bool& sure) {
+    const T ux = r.x * mp.psk_rot[0] - r.y * mp.psk_rot[1], uy = r.x * mp.psk_rot[1] + r.y * mp.psk_rot[0];
+    const T ax = fabs(ux), ay = fabs(uy);
+    const bool sw = ay > ax;
+    const T hi = sw ? ay : ax, lo = sw ? ax : ay;
+    constexpr T eps = sizeof(T) == 8 ? (T)0x1p-28 : (T)0x1p-12;
+    const T tol = eps * hi;
+    const int nb = mp.M >> 3;                                     // boundaries inside an octant: 1, 2, 4
+    int p = 0;
+    bool ok = hi >= mp.psk_lo && hi <= mp.psk_hi;                 // NaN: not sure
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (j < nb) {
+            const T d = lo * mp.psk_cb[j] - hi * mp.psk_sb[j];
+            p += d > (T)0;
+            ok = ok && fabs(d) >= tol;
+        }
+    int k = sw ? (mp.M >> 2) - p : p;
+    k = ux < (T)0 ? (mp.M >> 1) - k : k;
+    k = uy < (T)0 ? -k : k;
+    k &= mp.M - 1;
+    sure = ok;
+    // the label: byte k & 3 of word k >> 2 -- a select tree over the (wave-uniform) words, not an indexed load from the arguments
+    const unsigned* l = mp.psk_lut;
+    unsigned w = (k & 4) ? l[1] : l[0];
+    if (mp.M >= 16) {
+        const unsigned w1 = (k & 4) ? l[3] : l[2];
+        w = (k & 8) ? w1 : w;
+        if (mp.M >= 32) {
+            const unsigned w2 = (k & 4) ? l[5] : l[4], w3 = (k & 4) ? l[7] : l[6];
+            w = (k & 16) ? ((k & 8) ? w3 : w2) : w;
+        }
+    }
+    return (int)((w >> (8 * (k & 3))) & 0xFFu);
+}
 template <typename T> __device__ __forceinline__ int demod_cert_any(const ModemParams<T>& mp, cx<T> r, bool& sure) {
+    if (mp.cert == 3) return demod_psk_cert<T>(r, mp, sure);
     if (mp.cert == 2) return demod_quad_cert<T>(r, mp.quad_lut, mp.quad_lo, mp.quad_hi, sure);
     return demod_qam_cert<T>(r, mp.qam_scale, mp.qam_L, mp.half_bits, sure);
 }
@@ -453,7 +506,8 @@ template <typename T> inline DemodGrid context_grid(const mcle_ctx* ctx, int met
 inline int modem_cert(const mcle_ctx* ctx, int method) {
     if (method != MCLE_DEMOD_MINDIST || ctx->opt[MCLE_OPT_DEMOD_NOCERT]) return 0;
     if (ctx->kind == MCLE_CONST_QAM && ctx->qam_L >= 2 && ctx->qam_L <= 256) return 1;
-    return ctx->quad_ok ? 2 : 0;
+    if (ctx->quad_ok) return 2;
+    return ctx->psk_ok ? 3 : 0;
 }
 
 // cooperative copy of the constellation into LDS (call before a __syncthreads())
@@ -463,6 +517,17 @@ template <typename T> inline void modem_fill_cert(const mcle_ctx* ctx, int metho
     p.quad_lut = ctx->quad_lut;
     p.quad_lo = (T)(ctx->quad_min * (sizeof(T) == 8 ? 0x1p-30 : 0x1p-15));
     p.quad_hi = (T)(ctx->quad_max * 256.0);
+    for (int i = 0; i < 8; ++i) p.psk_lut[i] = ctx->psk_lut[i];
+    p.psk_rot[0] = (T)ctx->psk_rot[0];
+    p.psk_rot[1] = (T)ctx->psk_rot[1];
+    for (int j = 0; j < 4; ++j) {
+        const double th = (2 * j + 1) * 3.14159265358979323846 / (double)(ctx->M > 0 ? ctx->M : 8);
+        p.psk_cb[j] = (T)std::cos(th);
+        p.psk_sb[j] = (T)std::sin(th);
+    }
+    // hi = max(|re|, |im|) >= |u| / sqrt 2: the window on |u| in units of the radius, a factor sqrt 2 inside on the low side
+    p.psk_lo = (T)(ctx->psk_radius * (sizeof(T) == 8 ? 0x1p-8 : 0.125));
+    p.psk_hi = (T)(ctx->psk_radius * (sizeof(T) == 8 ? 0x1p+8 : 8.0));
 }
 
 template <typename T>

@@ -25,7 +25,8 @@ def cert_model(r, M, dtype):
     tj = np.minimum(np.maximum(x * hs + hl, T(0)), lm1)
     ti = np.minimum(np.maximum(hl - y * hs, T(0)), lm1)
     kj, ki = np.rint(tj), np.rint(ti)
-    sure = (np.abs(tj - kj) <= lim) & (np.abs(ti - ki) <= lim)
+    rmax = (T(2048.0 if dtype == "f64" else 16.0) + hl) / hs          # round 5: no certificate far outside the constellation
+    sure = (np.abs(tj - kj) <= lim) & (np.abs(ti - ki) <= lim) & (np.abs(x) <= rmax) & (np.abs(y) <= rmax)
     v = (ki.astype(np.uint32) << 8) | kj.astype(np.uint32)
     v ^= (v >> 4) & 0x0F0F
     v ^= (v >> 2) & 0x3F3F
@@ -163,3 +164,105 @@ def test_qpsk_demodulate_with_and_without_the_quadrant_certificate(engine):
         clear32 = (p32[:, 1] - p32[:, 0]) > 1e-5 * np.maximum(1.0, np.abs(r32))
         assert np.array_equal(got32[clear32], grid32[clear32])
         assert np.array_equal(got32[clear32], np.argmin(d32, axis=1)[clear32])
+
+
+# ---- M-PSK beyond four points: the sector certificate (csrc/modem.hpp demod_psk_cert, round 5) -------------------------------
+def psk_cert_model(r, tab, dtype):
+    """demod_psk_cert restated in NumPy (same operations, same order, in `dtype`) -> (label, sure)."""
+    T = np.float64 if dtype == "f64" else np.float32
+    M = len(tab)
+    rad = abs(tab[0])
+    a0 = np.arctan2(tab[0].imag, tab[0].real)
+    phi0 = np.fmod(a0, 2 * np.pi / M)
+    if phi0 < 0:
+        phi0 += 2 * np.pi / M
+    if 2 * np.pi / M - phi0 < 1e-9:
+        phi0 = 0.0
+    lut = np.zeros(M, dtype=np.int64)
+    for m, c in enumerate(tab):
+        lut[int(np.rint((np.arctan2(c.imag, c.real) - phi0) / (2 * np.pi / M))) % M] = m
+    rc, rs = T(np.cos(phi0)), T(-np.sin(phi0))
+    x, y = r.real.astype(T), r.imag.astype(T)
+    ux, uy = x * rc - y * rs, x * rs + y * rc
+    ax, ay = np.abs(ux), np.abs(uy)
+    sw = ay > ax
+    hi, lo = np.where(sw, ay, ax), np.where(sw, ax, ay)
+    eps = T(2.0 ** -28) if dtype == "f64" else T(2.0 ** -12)
+    tol = eps * hi
+    p = np.zeros(r.shape, dtype=np.int64)
+    ok = (hi >= T(rad * (2.0 ** -8 if dtype == "f64" else 0.125))) & (hi <= T(rad * (2.0 ** 8 if dtype == "f64" else 8.0)))
+    for j in range(M // 8):
+        th = (2 * j + 1) * np.pi / M
+        d = lo * T(np.cos(th)) - hi * T(np.sin(th))
+        p += d > 0
+        ok &= np.abs(d) >= tol
+    k = np.where(sw, M // 4 - p, p)
+    k = np.where(ux < 0, M // 2 - k, k)
+    k = np.where(uy < 0, -k, k) & (M - 1)
+    return lut[k], ok
+
+
+def _psk_points(rng, tab, n=30000):
+    """random points, points next to every sector boundary (angular offsets 0 .. 1e-3 rad), on the fold lines (axes, diagonals),
+    near the origin and far out"""
+    M = len(tab)
+    rad = abs(tab[0])
+    r = (rng.standard_normal(n) + 1j * rng.standard_normal(n)) * rad
+    k = n // 3
+    ang0 = np.angle(tab[0])
+    bnd = ang0 + (2 * rng.integers(0, M, k) + 1) * np.pi / M
+    off = rng.choice([0.0, 1e-16, 1e-13, 1e-10, 2.0 ** -30, 2.0 ** -27, 1e-6, 2.0 ** -13, 2.0 ** -10, 1e-3], size=k) * rng.choice([-1, 1], size=k)
+    r[:k] = rad * rng.uniform(0.05, 3.0, k) * np.exp(1j * (bnd + off))
+    fold = ang0 + rng.integers(0, 8, k // 4) * np.pi / 4 + rng.choice([0.0, 1e-16, -1e-16, 1e-9, -1e-9], size=k // 4)
+    r[k:k + k // 4] = rad * rng.uniform(0.2, 2.0, k // 4) * np.exp(1j * fold)
+    r[-6:] = [0, 1e-300, rad * 1e-12 * (1 + 1j), 1e4 * rad, -1e4j * rad, (300 + 300j) * rad]
+    return r
+
+
+@pytest.mark.parametrize("M,offset", [(8, 0.0), (8, np.pi / 8), (16, 0.0), (16, 0.3), (32, 0.0)])
+def test_psk_sector_certificate_model_equals_the_argmin_where_sure(M, offset):
+    """Wherever the sector certificate says `sure` its label IS the exhaustive |c - r| argmin of the reference
+    (modulators/fundamental.py:241-246) -- sector boundaries at tiny angular offsets, fold lines and extreme magnitudes included."""
+    from oracle import modem as omodem
+    tab = np.asarray(omodem.psk_table(M, offset) if hasattr(omodem, "psk_table") else constellation("psk", M) * np.exp(1j * offset),
+                     dtype=np.complex128)
+    rng = np.random.default_rng(1000 + M)
+    r = _psk_points(rng, tab)
+    want = np.argmin(np.abs(tab[None, :] - r[:, None]), axis=1)
+    lab, sure = psk_cert_model(r, tab, "f64")
+    assert np.array_equal(lab[sure], want[sure]), np.flatnonzero(sure & (lab != want))[:10]
+    assert 0.6 < sure.mean() < 1.0 and sure[20000:].mean() > 0.97          # the random third: nearly everything certified
+    r32 = r.astype(np.complex64)
+    want32 = np.argmin(np.abs(tab[None, :] - r32.astype(np.complex128)[:, None]), axis=1)
+    lab32, sure32 = psk_cert_model(r32, tab, "f32")
+    d32 = np.abs(tab[None, :] - r32.astype(np.complex128)[:, None])
+    p32 = np.partition(d32, 1, axis=1)
+    assert np.array_equal(lab32[sure32], want32[sure32]), np.flatnonzero(sure32 & (lab32 != want32))[:10]
+    assert sure32[20000:].mean() > 0.85
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,offset", [(8, 0.0), (8, np.pi / 8), (16, 0.0), (16, 0.3), (32, 0.0)])
+def test_psk_demodulate_with_and_without_the_sector_certificate(engine, M, offset):
+    tab = np.asarray(constellation("psk", M) * np.exp(1j * offset), dtype=np.complex128)
+    rng = np.random.default_rng(2000 + M)
+    r = _psk_points(rng, tab)
+    engine.set_constellation(tab, _lib.CONST_GENERIC)
+    d = np.abs(tab[None, :] - r[:, None])
+    want = np.argmin(d, axis=1)
+    part = np.partition(d, 1, axis=1)
+    clear = (part[:, 1] - part[:, 0]) > 1e-13
+    got = engine.demodulate(r, dtype="f64")
+    with engine.options(demod_nocert=1):
+        grid = engine.demodulate(r, dtype="f64")
+    assert np.array_equal(got, grid), np.flatnonzero(got != grid)[:10]      # certificate == table search on every point
+    assert np.array_equal(got[clear], want[clear])
+    r32 = r.astype(np.complex64)
+    got32 = engine.demodulate(r32, dtype="f32")
+    with engine.options(demod_nocert=1):
+        grid32 = engine.demodulate(r32, dtype="f32")
+    d32 = np.abs(tab[None, :] - r32.astype(np.complex128)[:, None])
+    p32 = np.partition(d32, 1, axis=1)
+    clear32 = (p32[:, 1] - p32[:, 0]) > 1e-5 * np.maximum(1.0, np.abs(r32))
+    assert np.array_equal(got32[clear32], grid32[clear32])
+    assert np.array_equal(got32[clear32], np.argmin(d32, axis=1)[clear32])
