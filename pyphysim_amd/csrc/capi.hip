@@ -457,7 +457,7 @@ int mcle_set_constellation(mcle_ctx* ctx, const double* re_im, int M, int kind) 
     // M-PSK beyond four points (modulators/fundamental.py:396-448: exp(j (2 pi m / M + phaseOffset)) in Gray order): equal radii,
     // angles on the grid 2 pi k / M + phi0 with every k taken once -> the sector certificate (modem.hpp demod_psk_cert)
     ctx->psk_ok = 0;
-    if ((M == 8 || M == 16 || M == 32) && kind != MCLE_CONST_QAM) {
+    if ((M == 8 || M == 16) && kind != MCLE_CONST_QAM) {
         const double two_pi = 6.283185307179586476925286766559;
         const double rad = std::hypot(re_im[0], re_im[1]);
         bool ok = rad > 0.0;
@@ -468,8 +468,8 @@ int mcle_set_constellation(mcle_ctx* ctx, const double* re_im, int M, int kind) 
             if (phi0 < 0.0) phi0 += two_pi / M;
             if (two_pi / M - phi0 < 1e-9) phi0 = 0.0;
         }
-        unsigned lut[8] = {};
-        unsigned long long seen = 0;
+        unsigned long long lut = 0, seen = 0;
+        const int fw = 64 / M;                                    // label of sector k in bits [k fw, (k + 1) fw)
         for (int m = 0; m < M && ok; ++m) {
             const double re = re_im[2 * m], im = re_im[2 * m + 1];
             ok = std::fabs(std::hypot(re, im) - rad) <= 1e-12 * rad;
@@ -478,11 +478,12 @@ int mcle_set_constellation(mcle_ctx* ctx, const double* re_im, int M, int kind) 
             ok = ok && std::fabs(kk - (double)k) <= 1e-9;
             const int kq = (int)(((k % M) + M) % M);
             seen |= 1ull << kq;
-            lut[kq >> 2] |= (unsigned)m << (8 * (kq & 3));
+            lut |= (unsigned long long)m << (fw * kq);
         }
-        if (ok && seen == (M == 32 ? 0xFFFFFFFFull : ((1ull << M) - 1))) {
+        if (ok && seen == ((1ull << M) - 1)) {
             ctx->psk_ok = 1;
-            for (int i = 0; i < 8; ++i) ctx->psk_lut[i] = lut[i];
+            ctx->psk_lut[0] = (unsigned)lut;
+            ctx->psk_lut[1] = (unsigned)(lut >> 32);
             ctx->psk_rot[0] = std::cos(phi0);
             ctx->psk_rot[1] = -std::sin(phi0);
             ctx->psk_radius = rad;

@@ -184,10 +184,10 @@ struct mcle_ctx {
     int quad_ok = 0;
     unsigned quad_lut = 0;
     double quad_min = 0.0, quad_max = 0.0;   // min / max of the points' |re|, |im|
-    // M-PSK, M in {8, 16, 32}: M points of one radius at angles 2 pi k / M + phi0 (any label order): the min-distance regions are
-    // the M sectors -- modem.hpp: demod_psk_cert.  psk_lut: label of sector k, a byte each; psk_rot = e^{-j phi0}
+    // M-PSK, M in {8, 16}: M points of one radius at angles 2 pi k / M + phi0 (any label order): the min-distance regions are
+    // the M sectors -- modem.hpp: demod_psk_cert.  psk_lut: label of sector k in 64 / M bits each; psk_rot = e^{-j phi0}
     int psk_ok = 0;
-    unsigned psk_lut[8] = {};
+    unsigned psk_lut[2] = {};
     double psk_rot[2] = {1.0, 0.0}, psk_radius = 0.0;
     // candidate grid of the pruned f32 min-distance search (modem.hpp: DemodGrid); grid_G == 0: none
     unsigned long long* d_grid = nullptr;

@@ -30,13 +30,13 @@ template <typename T> struct ModemParams {
     int half_bits;   // bits/2
     int cert;        // 1: min-distance decisions of a square Gray QAM through the margin certificate (demod_qam_cert);
                      // 2: of a four-point one-per-quadrant constellation (QPSK) through the quadrant certificate (demod_quad_cert)
-                     // 3: of an M-PSK, M in {8, 16, 32}, through the sector certificate (demod_psk_cert)
+                     // 3: of an M-PSK, M in {8, 16}, through the sector certificate (demod_psk_cert)
     unsigned quad_lut;   // cert == 2: label of quadrant (re < 0) | (im < 0) << 1, a byte each
     T quad_lo, quad_hi;  // cert == 2: the certificate holds for lo <= |re|, |im| <= hi
-    // cert == 3: label of sector k (a byte each), e^{-j phi0}, cos / sin of the M / 8 sector boundaries inside the first octant,
-    // the magnitude window of the certificate
-    unsigned psk_lut[8];
-    T psk_rot[2], psk_cb[4], psk_sb[4], psk_lo, psk_hi;
+    // cert == 3: label of sector k (64 / M bits each, sector 0 in the low bits), e^{-j phi0}, cos / sin of the M / 8 sector
+    // boundaries inside the first octant, the magnitude window of the certificate
+    unsigned psk_lut[2];
+    T psk_rot[2], psk_cb[2], psk_sb[2], psk_lo, psk_hi;
 };
 
 // exhaustive minimum distance over a table held in LDS; strict '<' keeps the FIRST minimum,
@@ -395,7 +395,7 @@ __device__ __forceinline__ int demod_quad_cert(cx<T> r, unsigned lut, T lo, T hi
     const unsigned q = (r.x < (T)0 ? 8u : 0u) | (r.y < (T)0 ? 16u : 0u);
     return (int)((lut >> q) & 0xFFu);
 }
-// Min-distance decision of an M-PSK (M = 8, 16, 32: M points of one radius at angles 2 pi k / M + phi0) WITHOUT touching the
+// Min-distance decision of an M-PSK (M = 8, 16: M points of one radius at angles 2 pi k / M + phi0) WITHOUT touching the
 // table: the regions are the M sectors.  u = r e^{-j phi0}; fold into the first octant (hi = max(|re|, |im|), lo = the other); the
 // M / 8 sector boundaries inside the octant sit at theta_j = (2 j + 1) pi / M, and lo cos(theta_j) - hi sin(theta_j) =
 // |u| sin(theta - theta_j) says on which side of boundary j the point lies -- no arctangent, no division.  p = boundaries passed =
@@ -406,41 +406,38 @@ __device__ __forceinline__ int demod_quad_cert(cx<T> r, unsigned lut, T lo, T hi
 // squared distance (rho = the radius) against a rounding of ~ (|r|^2 + rho^2) ulp of either metric: eps = 2^-28 inside
 // [2^-8, 2^8] rho in complex128, 2^-12 inside [1/8, 8] rho in complex64 -- the sweep, first-minimum rule included, returns this
 // very label.  Elsewhere (probability ~ M eps / 4 per symbol, or a deep-fade equaliser output) the caller searches the table.
+// (Written without selects: a v_cndmask on a freshly compared mask costs several issue slots on gfx950 (profiles/r04/f32_rates.txt),
+//  and the first form of this function -- five selects and a select tree for the label -- was SLOWER than the candidate-grid search
+//  it replaces (scripts/experiments/r05_psk_rates.py).  The folds are sign masks: m = (sign bit of a difference) >> 31 is 0 or -1,
+//  and "M / 4 - p if swapped" is (p ^ m) + ((M / 4 + 1) & m); the label comes out of a 64-bit word of M fields by one shift.)
+__device__ __forceinline__ int sign_mask(float v) { return __float_as_int(v) >> 31; }
+__device__ __forceinline__ int sign_mask(double v) { return __double2hiint(v) >> 31; }
 template <typename T>
 __device__ __forceinline__ int demod_psk_cert(cx<T> r, const ModemParams<T>& mp, bool& sure) {
     const T ux = r.x * mp.psk_rot[0] - r.y * mp.psk_rot[1], uy = r.x * mp.psk_rot[1] + r.y * mp.psk_rot[0];
     const T ax = fabs(ux), ay = fabs(uy);
-    const bool sw = ay > ax;
-    const T hi = sw ? ay : ax, lo = sw ? ax : ay;
+    const T hi = fmax(ax, ay), lo = fmin(ax, ay);
     constexpr T eps = sizeof(T) == 8 ? (T)0x1p-28 : (T)0x1p-12;
     const T tol = eps * hi;
-    const int nb = mp.M >> 3;                                     // boundaries inside an octant: 1, 2, 4
-    int p = 0;
+    const int nb = mp.M >> 3;                                     // boundaries inside an octant: 1 (8-PSK), 2 (16-PSK)
+    int p = nb;
     bool ok = hi >= mp.psk_lo && hi <= mp.psk_hi;                 // NaN: not sure
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < 2; ++j)
         if (j < nb) {
-            const T d = lo * mp.psk_cb[j] - hi * mp.psk_sb[j];
-            p += d > (T)0;
+            const T d = lo * mp.psk_cb[j] - hi * mp.psk_sb[j];    // |u| sin(theta - theta_j)
+            p += sign_mask(d);                                    // nb - (boundaries NOT passed)
             ok = ok && fabs(d) >= tol;
         }
-    int k = sw ? (mp.M >> 2) - p : p;
-    k = ux < (T)0 ? (mp.M >> 1) - k : k;
-    k = uy < (T)0 ? -k : k;
+    const int ms = sign_mask(ax - ay), mx = sign_mask(ux), my = sign_mask(uy);
+    int k = (p ^ ms) + (((mp.M >> 2) + 1) & ms);                  // swapped: M / 4 - p
+    k = (k ^ mx) + (((mp.M >> 1) + 1) & mx);                      // re < 0: M / 2 - k
+    k = (k ^ my) - my;                                            // im < 0: -k
     k &= mp.M - 1;
     sure = ok;
-    // the label: byte k & 3 of word k >> 2 -- a select tree over the (wave-uniform) words, not an indexed load from the arguments
-    const unsigned* l = mp.psk_lut;
-    unsigned w = (k & 4) ? l[1] : l[0];
-    if (mp.M >= 16) {
-        const unsigned w1 = (k & 4) ? l[3] : l[2];
-        w = (k & 8) ? w1 : w;
-        if (mp.M >= 32) {
-            const unsigned w2 = (k & 4) ? l[5] : l[4], w3 = (k & 4) ? l[7] : l[6];
-            w = (k & 16) ? ((k & 8) ? w3 : w2) : w;
-        }
-    }
-    return (int)((w >> (8 * (k & 3))) & 0xFFu);
+    const unsigned long long lut = ((unsigned long long)mp.psk_lut[1] << 32) | mp.psk_lut[0];   // M fields of 64 / M bits
+    const int fw = mp.M == 8 ? 8 : 4;
+    return (int)((lut >> (k * fw)) & (mp.M == 8 ? 0xFFull : 0xFull));
 }
 template <typename T> __device__ __forceinline__ int demod_cert_any(const ModemParams<T>& mp, cx<T> r, bool& sure) {
     if (mp.cert == 3) return demod_psk_cert<T>(r, mp, sure);
@@ -475,9 +472,12 @@ __device__ __forceinline__ int demod_one(const ModemParams<T>& mp, const cx<T>* 
 // K symbols: all K certificates first (straight-line), the table search only in lanes that hold an uncertified symbol.
 // `search(idx)` is the caller's lockstep search over all K (demod_grid_multi / demod_grid4_multi / demod_mindist_multi);
 // it gives the same labels as the certificate wherever that one is sure, so overwriting all K in such a lane is harmless.
-template <typename T, int K, typename Search>
+// SWEEP8: the caller's search is the packed lockstep sweep of <= 8 points (complex64): it costs what the sector certificate of an
+// 8-PSK costs (~30 instructions per symbol), so that certificate is skipped there (AWGN link, 8-PSK, complex64: 3.16 -> 3.5e7
+// realizations/s, scripts/experiments/r05_psk_rates.py); the QAM / QPSK certificates (6 - 25 instructions) still run first.
+template <typename T, int K, bool SWEEP8 = false, typename Search>
 __device__ __forceinline__ void demod_multi_cert(const ModemParams<T>& mp, const cx<T> (&r)[K], int (&idx)[K], Search&& search) {
-    if (mp.cert) {
+    if (mp.cert && !(SWEEP8 && mp.cert == 3)) {
         bool all = true;
 #pragma unroll
         for (int k = 0; k < K; ++k) {
@@ -517,10 +517,11 @@ template <typename T> inline void modem_fill_cert(const mcle_ctx* ctx, int metho
     p.quad_lut = ctx->quad_lut;
     p.quad_lo = (T)(ctx->quad_min * (sizeof(T) == 8 ? 0x1p-30 : 0x1p-15));
     p.quad_hi = (T)(ctx->quad_max * 256.0);
-    for (int i = 0; i < 8; ++i) p.psk_lut[i] = ctx->psk_lut[i];
+    p.psk_lut[0] = ctx->psk_lut[0];
+    p.psk_lut[1] = ctx->psk_lut[1];
     p.psk_rot[0] = (T)ctx->psk_rot[0];
     p.psk_rot[1] = (T)ctx->psk_rot[1];
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < 2; ++j) {
         const double th = (2 * j + 1) * 3.14159265358979323846 / (double)(ctx->M > 0 ? ctx->M : 8);
         p.psk_cb[j] = (T)std::cos(th);
         p.psk_sb[j] = (T)std::sin(th);
