@@ -111,10 +111,17 @@ enum {
     MCLE_OPT_DEMOD_NOCERT = 10,    /* 1: min-distance decisions of a square Gray QAM always through the table search (candidate
                                       grid / sweep); 0: through the margin certificate of modem.hpp (demod_qam_cert: the
                                       closed-form nearest level per axis, accepted when the received point is farther than
-                                      2^-30 (complex64: 2^-15) of a level spacing from every decision boundary, the table
-                                      search otherwise -- identical decisions, no table gathers); likewise for a four-point
-                                      constellation with one point per quadrant at (+-a, +-b) -- QPSK -- decided by the signs
-                                      (demod_quad_cert: certified for 2^-30 min(a, b) <= |re|, |im| <= 2^8 max(a, b)) */
+                                      2^-30 (complex64: 2^-15) of a level spacing from every decision boundary -- and, in
+                                      complex64, no farther than 16 spacings outside the outermost level -- the table search
+                                      otherwise: no table gathers, and the decisions of the exhaustive sweep by a margin argument
+                                      that holds for |re|, |im| up to ~2^11 level spacings in complex128 (beyond that -- an
+                                      equaliser output in a fade of -66 dB -- the identity rests on test coverage: the chance that
+                                      such a point also sits within 2^-30 of a boundary is ~1e-14 per symbol)); likewise for a
+                                      four-point constellation with one point per quadrant at (+-a, +-b) -- QPSK -- decided by the
+                                      signs (demod_quad_cert: certified for 2^-30 min(a, b) <= |re|, |im| <= 2^8 max(a, b)), and for
+                                      8- / 16-PSK inside the table search itself (demod_psk_cert: the sector by sign masks and one
+                                      compare per sector boundary of an octant, certified at an angular margin of 2^-28
+                                      (complex64: 2^-12) inside a magnitude window of 2^-8 .. 2^8 (1/8 .. 8) radii) */
     MCLE_OPT_F64_VARIANT = 11,     /* (builds with -DMCLE_EXPERIMENTS only; the product library accepts 0 and refuses anything else)
                                       complex128 config-4 kernel (1024, 4x4), TIMING BOUNDS ONLY on its 512-thread radix-4 form --
                                       results are wrong by construction: bit 0 = the LDS stores of the last transmit stage and of

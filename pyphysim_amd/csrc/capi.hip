@@ -3,6 +3,7 @@
 #include <cstdarg>
 
 #include "common.hpp"
+#include "modem.hpp"
 
 namespace mcle {
 
@@ -138,6 +139,7 @@ int mcle_ctx_destroy(mcle_ctx* ctx) {
     if (ctx->d_table_f32) (void)hipFree(ctx->d_table_f32);
     if (ctx->d_table_f64) (void)hipFree(ctx->d_table_f64);
     if (ctx->d_grid) (void)hipFree(ctx->d_grid);
+    if (ctx->d_psk) (void)hipFree(ctx->d_psk);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -487,6 +489,25 @@ int mcle_set_constellation(mcle_ctx* ctx, const double* re_im, int M, int kind) 
             ctx->psk_rot[0] = std::cos(phi0);
             ctx->psk_rot[1] = -std::sin(phi0);
             ctx->psk_radius = rad;
+            mcle::PskCert h{};
+            h.lut[0] = ctx->psk_lut[0];
+            h.lut[1] = ctx->psk_lut[1];
+            for (int j = 0; j < 2; ++j) {
+                const double th = (2 * j + 1) * 3.14159265358979323846 / (double)M;
+                h.cb_d[j] = std::cos(th);
+                h.sb_d[j] = std::sin(th);
+                h.cb_f[j] = (float)h.cb_d[j];
+                h.sb_f[j] = (float)h.sb_d[j];
+                h.rot_d[j] = ctx->psk_rot[j];
+                h.rot_f[j] = (float)ctx->psk_rot[j];
+            }
+            // hi = max(|re|, |im|) >= |u| / sqrt 2: the window on |u| in units of the radius, a factor sqrt 2 inside on the low side
+            h.lo_d = rad * 0x1p-8;
+            h.hi_d = rad * 0x1p+8;
+            h.lo_f = (float)(rad * 0.125);
+            h.hi_f = (float)(rad * 8.0);
+            if (!ctx->d_psk) MCLE_HIP(hipMalloc(&ctx->d_psk, sizeof(mcle::PskCert)));
+            MCLE_HIP(hipMemcpy(ctx->d_psk, &h, sizeof(mcle::PskCert), hipMemcpyHostToDevice));
         }
     }
     return MCLE_OK;

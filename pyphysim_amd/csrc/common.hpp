@@ -189,6 +189,7 @@ struct mcle_ctx {
     int psk_ok = 0;
     unsigned psk_lut[2] = {};
     double psk_rot[2] = {1.0, 0.0}, psk_radius = 0.0;
+    void* d_psk = nullptr;                   // the certificate's constants on the device (modem.hpp: mcle::PskCert)
     // candidate grid of the pruned f32 min-distance search (modem.hpp: DemodGrid); grid_G == 0: none
     unsigned long long* d_grid = nullptr;
     int grid_G = 0;

@@ -851,7 +851,7 @@ static int launch_run_bd(mcle_ctx* ctx, const mcle_bd_cfg* cfg, const BdParams& 
         // (round 5: a constellation WITH a certificate -- square QAM, QPSK -- goes through it whatever its size: the application's
         //  own 4-PSK was swept point by point in lockstep, ~20 instructions per decision where the quadrant certificate takes 6)
         const int mode = (sizeof(T) == 4 && mp.method == MCLE_DEMOD_MINDIST)
-                             ? ((mp.cert && !(mp.cert == 3 && mp.M <= 8) && mp.grid.G > 0) ? 2 : (mp.M <= 8 ? 1 : (mp.grid.G > 0 ? 2 : 0))) : 0;
+                             ? ((mp.cert && mp.grid.G > 0) ? 2 : (mp.M <= 8 ? 1 : (mp.grid.G > 0 ? 2 : 0))) : 0;
         bool walked = false;
 #define MCLE_BD_WALK(KC_, MODE_)                                                                                          \
     if (!walked && (KC_ == 0 || (cfg->K == KC_ && KC_ * R <= kBdMaxN)) && mode == MODE_) {                                  \

@@ -620,7 +620,7 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 3) void k_ia_link(ModemPar
                 bool done = false;
                 if constexpr (sizeof(T) == 4) {
                     if (lockstep) {       // the three streams searched in lockstep (same decisions as demod_one)
-                        if (mp.M <= 8) demod_multi_cert<float, 3, true>(mp, est, dec, [&](int (&d_)[3]) { demod_mindist_multi<3>(s_tab4, mp.M, est, d_); });
+                        if (mp.M <= 8) demod_multi_cert(mp, est, dec, [&](int (&d_)[3]) { demod_mindist_multi<3>(s_tab4, mp.M, est, d_); });
                         else demod_multi_cert(mp, est, dec, [&](int (&d_)[3]) { demod_grid4_multi<3>(s_tab4, s_grid, mp.grid, mp.M, est, d_); });
                         done = true;
                     }

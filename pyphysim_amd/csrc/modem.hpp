@@ -13,11 +13,88 @@ namespace mcle {
 // all M points, tie rule included, at a few candidates per symbol.  Cell word: byte 0 = count (0xFF: sweep
 // everything), bytes 1..7 = candidates.
 constexpr int kMaxGridCells = 32 * 32;
+struct PskCert;
 struct DemodGrid {
     const unsigned long long* cells;   // device [G*G]
     int G;                             // 0: no grid (M > 256 or f64)
     float x0, y0, inv_h;
+    // 8- / 16-PSK: the sector certificate's constants (device memory, one block per context, written by mcle_set_constellation);
+    // null otherwise.  EVERY grid search below tries that certificate first (demod_psk_cert) -- it is part of the table search, not
+    // of the first-line certificates of demod_cert_any: inlined there it cost the QAM kernels registers (the complex64 headline
+    // kernel 25 -> 33 spilled registers, -5 %: scripts/experiments/r05_call20.sh), here a QAM launch never reaches it.
+    const PskCert* psk;
 };
+// label of sector k (64 / M bits each, sector 0 in the low bits), e^{-j phi0}, cos / sin of the M / 8 sector boundaries inside the
+// first octant, the magnitude window of the certificate -- in both arithmetics
+struct PskCert {
+    unsigned lut[2];
+    float rot_f[2], cb_f[2], sb_f[2], lo_f, hi_f;
+    double rot_d[2], cb_d[2], sb_d[2], lo_d, hi_d;
+};
+template <typename T> struct PskView;
+template <> struct PskView<float> {
+    const PskCert* p;
+    __device__ __forceinline__ float rot(int i) const { return p->rot_f[i]; }
+    __device__ __forceinline__ float cb(int i) const { return p->cb_f[i]; }
+    __device__ __forceinline__ float sb(int i) const { return p->sb_f[i]; }
+    __device__ __forceinline__ float lo() const { return p->lo_f; }
+    __device__ __forceinline__ float hi() const { return p->hi_f; }
+};
+template <> struct PskView<double> {
+    const PskCert* p;
+    __device__ __forceinline__ double rot(int i) const { return p->rot_d[i]; }
+    __device__ __forceinline__ double cb(int i) const { return p->cb_d[i]; }
+    __device__ __forceinline__ double sb(int i) const { return p->sb_d[i]; }
+    __device__ __forceinline__ double lo() const { return p->lo_d; }
+    __device__ __forceinline__ double hi() const { return p->hi_d; }
+};
+
+// Min-distance decision of an M-PSK (M = 8, 16: M points of one radius at angles 2 pi k / M + phi0) WITHOUT touching the
+// table: the regions are the M sectors.  u = r e^{-j phi0}; fold into the first octant (hi = max(|re|, |im|), lo = the other); the
+// M / 8 sector boundaries inside the octant sit at theta_j = (2 j + 1) pi / M, and lo cos(theta_j) - hi sin(theta_j) =
+// |u| sin(theta - theta_j) says on which side of boundary j the point lies -- no arctangent, no division.  p = boundaries passed =
+// point index inside the octant; un-fold: swap -> M / 4 - p, re < 0 -> M / 2 - k, im < 0 -> -k (mod M); label = lut[k].  The folds
+// are consistent ON their own borders (the 45-degree line and the axes are point directions, both sides give the same k), so only
+// the sector boundaries need a margin: `sure` iff every |lo cos - hi sin| >= eps hi, i.e. an angular distance >= eps / sqrt 2 from
+// every boundary, and lo_bound <= hi <= hi_bound.  Two neighbouring candidates then differ by >= 2 |r| rho sin(pi / M) eps in
+// squared distance (rho = the radius) against a rounding of ~ (|r|^2 + rho^2) ulp of either metric: eps = 2^-28 inside
+// [2^-8, 2^8] rho in complex128, 2^-12 inside [1/8, 8] rho in complex64 -- the sweep, first-minimum rule included, returns this
+// very label.  Elsewhere (probability ~ M eps / 4 per symbol, or a deep-fade equaliser output) the caller searches the table.
+// (Written without selects: a v_cndmask on a freshly compared mask costs several issue slots on gfx950 (profiles/r04/f32_rates.txt),
+//  and the first form of this function -- five selects and a select tree for the label -- was SLOWER than the candidate-grid search
+//  it replaces (scripts/experiments/r05_psk_rates.py).  The folds are sign masks: m = (sign bit of a difference) >> 31 is 0 or -1,
+//  and "M / 4 - p if swapped" is (p ^ m) + ((M / 4 + 1) & m); the label comes out of a 64-bit word of M fields by one shift.)
+__device__ __forceinline__ int sign_mask(float v) { return __float_as_int(v) >> 31; }
+__device__ __forceinline__ int sign_mask(double v) { return __double2hiint(v) >> 31; }
+template <typename T>
+__device__ __forceinline__ int demod_psk_cert(cx<T> r, const PskCert* psk, int M, bool& sure) {
+    const PskView<T> c{psk};                                   // wave-uniform loads (scalar cache)
+    const T ux = r.x * c.rot(0) - r.y * c.rot(1), uy = r.x * c.rot(1) + r.y * c.rot(0);
+    const T ax = fabs(ux), ay = fabs(uy);
+    const T hi = fmax(ax, ay), lo = fmin(ax, ay);
+    constexpr T eps = sizeof(T) == 8 ? (T)0x1p-28 : (T)0x1p-12;
+    const T tol = eps * hi;
+    const int nb = M >> 3;                                     // boundaries inside an octant: 1 (8-PSK), 2 (16-PSK)
+    int p = nb;
+    bool ok = hi >= c.lo() && hi <= c.hi();                       // NaN: not sure
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+        if (j < nb) {
+            const T d = lo * c.cb(j) - hi * c.sb(j);              // |u| sin(theta - theta_j)
+            p += sign_mask(d);                                    // nb - (boundaries NOT passed)
+            ok = ok && fabs(d) >= tol;
+        }
+    const int ms = sign_mask(ax - ay), mx = sign_mask(ux), my = sign_mask(uy);
+    int k = (p ^ ms) + (((M >> 2) + 1) & ms);                  // swapped: M / 4 - p
+    k = (k ^ mx) + (((M >> 1) + 1) & mx);                      // re < 0: M / 2 - k
+    k = (k ^ my) - my;                                            // im < 0: -k
+    k &= M - 1;
+    sure = ok;
+    const unsigned long long lut = ((unsigned long long)psk->lut[1] << 32) | psk->lut[0];   // M fields of 64 / M bits
+    const int fw = M == 8 ? 8 : 4;
+    return (int)((lut >> (k * fw)) & (M == 8 ? 0xFFull : 0xFull));
+}
+
 
 template <typename T> struct ModemParams {
     DemodGrid grid;
@@ -30,15 +107,9 @@ template <typename T> struct ModemParams {
     int half_bits;   // bits/2
     int cert;        // 1: min-distance decisions of a square Gray QAM through the margin certificate (demod_qam_cert);
                      // 2: of a four-point one-per-quadrant constellation (QPSK) through the quadrant certificate (demod_quad_cert)
-                     // 3: of an M-PSK, M in {8, 16}, through the sector certificate (demod_psk_cert)
     unsigned quad_lut;   // cert == 2: label of quadrant (re < 0) | (im < 0) << 1, a byte each
     T quad_lo, quad_hi;  // cert == 2: the certificate holds for lo <= |re|, |im| <= hi
-    // cert == 3: label of sector k (64 / M bits each, sector 0 in the low bits), e^{-j phi0}, cos / sin of the M / 8 sector
-    // boundaries inside the first octant, the magnitude window of the certificate
-    unsigned psk_lut[2];
-    T psk_rot[2], psk_cb[2], psk_sb[2], psk_lo, psk_hi;
 };
-
 // exhaustive minimum distance over a table held in LDS; strict '<' keeps the FIRST minimum,
 // which is numpy.argmin's tie rule (fundamental.py:245).  The reference compares |c - r|; we
 // compare |c - r|^2 (same ordering away from rounding-level ties).
@@ -103,8 +174,8 @@ __device__ __forceinline__ unsigned long long grid_cell(const unsigned long long
     return s_grid[iy * g.G + ix];
 }
 // literal |c - r|^2 metric on the plain table (operator kernels); same decisions as demod_mindist<float>
-__device__ __forceinline__ int demod_grid(const float2* __restrict__ s_table, const unsigned long long* __restrict__ s_grid,
-                                          const DemodGrid& g, int M, float2 r) {
+__device__ __forceinline__ int demod_grid_search(const float2* __restrict__ s_table, const unsigned long long* __restrict__ s_grid,
+                                                 const DemodGrid& g, int M, float2 r) {
     unsigned long long w = grid_cell(s_grid, g, r.x, r.y);
     const unsigned lo = (unsigned)w, hi = (unsigned)(w >> 32);
     const int n = (int)(lo & 0xFFu);
@@ -151,8 +222,8 @@ __device__ __forceinline__ int demod_grid(const float2* __restrict__ s_table, co
 // complex128 operator kernels: the cell is looked up from the float-rounded point (the lists carry a margin far above
 // f32 rounding, so a point a rounding step across a cell edge still finds its nearest neighbour and every near-tie in
 // the list), the metric is the literal f64 |c - r|^2 of demod_mindist<double>: same decisions, first minimum included
-__device__ __forceinline__ int demod_grid(const double2* __restrict__ s_table, const unsigned long long* __restrict__ s_grid,
-                                          const DemodGrid& g, int M, double2 r) {
+__device__ __forceinline__ int demod_grid_search(const double2* __restrict__ s_table, const unsigned long long* __restrict__ s_grid,
+                                                 const DemodGrid& g, int M, double2 r) {
     unsigned long long w = grid_cell(s_grid, g, (float)r.x, (float)r.y);
     const unsigned lo = (unsigned)w, hi = (unsigned)(w >> 32);
     const int n = (int)(lo & 0xFFu);
@@ -199,8 +270,8 @@ __device__ __forceinline__ int demod_grid(const double2* __restrict__ s_table, c
     return idx;
 }
 // two-FMA metric on the {re, im, |c|^2/2} table (fused pipelines); same decisions as demod_mindist_multi<float>
-__device__ __forceinline__ int demod_grid4(const float4* __restrict__ s_tab4, const unsigned long long* __restrict__ s_grid,
-                                           const DemodGrid& g, int M, float2 r) {
+__device__ __forceinline__ int demod_grid4_search(const float4* __restrict__ s_tab4, const unsigned long long* __restrict__ s_grid,
+                                                  const DemodGrid& g, int M, float2 r) {
     unsigned long long w = grid_cell(s_grid, g, r.x, r.y);
     int n = (int)(w & 0xFFull);
     if (n == 0xFF) {
@@ -233,7 +304,7 @@ __device__ __forceinline__ int demod_grid4(const float4* __restrict__ s_tab4, co
 // current best, which the strict '<' ignores).  Cells with more than four candidates, or the 0xFF "sweep
 // everything" marker, take demod_grid4's loop.  Same decisions as demod_grid4 / demod_mindist_multi.
 template <int K>
-__device__ __forceinline__ void demod_grid4_multi(const float4* __restrict__ s_tab4,
+__device__ __forceinline__ void demod_grid4_multi_search(const float4* __restrict__ s_tab4,
                                                   const unsigned long long* __restrict__ s_grid, const DemodGrid& g, int M,
                                                   const float2 (&r)[K], int (&idx)[K]) {
     unsigned long long w[K];
@@ -271,7 +342,7 @@ __device__ __forceinline__ void demod_grid4_multi(const float4* __restrict__ s_t
     if (slow) {
 #pragma unroll
         for (int k = 0; k < K; ++k)
-            if (n[k] > 4) idx[k] = demod_grid4(s_tab4, s_grid, g, M, r[k]);
+            if (n[k] > 4) idx[k] = demod_grid4_search(s_tab4, s_grid, g, M, r[k]);
     }
 }
 
@@ -279,7 +350,7 @@ __device__ __forceinline__ void demod_grid4_multi(const float4* __restrict__ s_t
 // symbols at a time (the K cell words, then up to four candidates per symbol as K independent LDS round trips per step).
 // Same decisions as demod_grid(double) / demod_mindist<double>, first minimum included.
 template <int K>
-__device__ __forceinline__ void demod_grid_multi(const double2* __restrict__ s_table,
+__device__ __forceinline__ void demod_grid_multi_search(const double2* __restrict__ s_table,
                                                  const unsigned long long* __restrict__ s_grid, const DemodGrid& g, int M,
                                                  const double2 (&r)[K], int (&idx)[K]) {
     unsigned long long w[K];
@@ -321,6 +392,66 @@ __device__ __forceinline__ void demod_grid_multi(const double2* __restrict__ s_t
         for (int k = 0; k < K; ++k)
             if (n[k] > 4) idx[k] = demod_grid(s_table, s_grid, g, M, r[k]);     // long lists and the 0xFF "sweep everything" marker
     }
+}
+
+// ---- the table searches as callers see them: the sector certificate of an 8- / 16-PSK first (g.psk, wave-uniform), the candidate
+//      grid for whatever it does not certify -- identical decisions (tests/test_demod_cert.py) ----
+__device__ __forceinline__ int demod_grid(const float2* __restrict__ s_table, const unsigned long long* __restrict__ s_grid,
+                                          const DemodGrid& g, int M, float2 r) {
+    if (g.psk != nullptr) {
+        bool sure;
+        const int lab = demod_psk_cert<float>(r, g.psk, M, sure);
+        if (sure) return lab;
+    }
+    return demod_grid_search(s_table, s_grid, g, M, r);
+}
+__device__ __forceinline__ int demod_grid(const double2* __restrict__ s_table, const unsigned long long* __restrict__ s_grid,
+                                          const DemodGrid& g, int M, double2 r) {
+    if (g.psk != nullptr) {
+        bool sure;
+        const int lab = demod_psk_cert<double>(r, g.psk, M, sure);
+        if (sure) return lab;
+    }
+    return demod_grid_search(s_table, s_grid, g, M, r);
+}
+__device__ __forceinline__ int demod_grid4(const float4* __restrict__ s_tab4, const unsigned long long* __restrict__ s_grid,
+                                           const DemodGrid& g, int M, float2 r) {
+    if (g.psk != nullptr) {
+        bool sure;
+        const int lab = demod_psk_cert<float>(r, g.psk, M, sure);
+        if (sure) return lab;
+    }
+    return demod_grid4_search(s_tab4, s_grid, g, M, r);
+}
+template <int K>
+__device__ __forceinline__ void demod_grid4_multi(const float4* __restrict__ s_tab4, const unsigned long long* __restrict__ s_grid,
+                                                  const DemodGrid& g, int M, const float2 (&r)[K], int (&idx)[K]) {
+    if (g.psk != nullptr) {
+        bool all = true;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            bool sure;
+            idx[k] = demod_psk_cert<float>(r[k], g.psk, M, sure);
+            all = all && sure;
+        }
+        if (all) return;
+    }
+    demod_grid4_multi_search<K>(s_tab4, s_grid, g, M, r, idx);
+}
+template <int K>
+__device__ __forceinline__ void demod_grid_multi(const double2* __restrict__ s_table, const unsigned long long* __restrict__ s_grid,
+                                                 const DemodGrid& g, int M, const double2 (&r)[K], int (&idx)[K]) {
+    if (g.psk != nullptr) {
+        bool all = true;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            bool sure;
+            idx[k] = demod_psk_cert<double>(r[k], g.psk, M, sure);
+            all = all && sure;
+        }
+        if (all) return;
+    }
+    demod_grid_multi_search<K>(s_table, s_grid, g, M, r, idx);
 }
 
 template <typename T>
@@ -369,12 +500,19 @@ __device__ __forceinline__ int demod_qam_cert(cx<T> r, T scale, int L, int half_
     tj = fmin(fmax(tj, (T)0), lm1);                               // beyond the outer levels: certain (f = 0); NaN -> 0
     ti = fmin(fmax(ti, (T)0), lm1);
     const T kj = rint(tj), ki = rint(ti);
-    // ... and no farther out than `far` level spacings from the centre: beyond the outer levels the clamp makes f = 0 on that axis,
-    // but the margin on the OTHER axis (2 eps spacing^2) only dominates the rounding of the metrics (~ |r|^2 ulp) while |r| stays
-    // below ~2^11 spacings in complex128 and ~20 in complex64 -- a zero-forcing output in a deep fade goes farther
-    constexpr T far = sizeof(T) == 8 ? (T)2048 : (T)16;
-    const T rmax = (far + hl) / hs;                               // wave-uniform
-    sure = fabs(tj - kj) <= lim && fabs(ti - ki) <= lim && fabs(r.x) <= rmax && fabs(r.y) <= rmax;
+    sure = fabs(tj - kj) <= lim && fabs(ti - ki) <= lim;
+    // Beyond the outer levels the clamp makes f = 0 on that axis, but the margin on the OTHER axis (2 eps spacing^2) only dominates
+    // the rounding of the metrics (~ |r|^2 ulp) while |r| stays below ~20 level spacings in complex64 and ~2^11 in complex128
+    // (ADVICE r04).  complex64: `sure` also needs |re|, |im| within 16 spacings of the outermost level's centre -- a zero-forcing
+    // output in a deep fade goes farther, and the two compares are free there (scripts/experiments/r05_call21.sh).  complex128: NOT
+    // checked -- two f64 compares per symbol cost the headline kernel 2.3 % (11.01 against 10.76 ms per 262 144 realizations), and a
+    // point beyond 2^11 spacings (an equaliser output in a fade of -66 dB) that ALSO sits within 2^-30 of a boundary on its other
+    // axis has probability ~1e-14 per symbol: there the identity with the sweep rests on the margin argument up to 2^11 spacings
+    // and on test coverage beyond (include/mcle.h says so).
+    if constexpr (sizeof(T) == 4) {
+        const T rmax = ((T)16 + hl) / hs;                         // wave-uniform
+        sure = sure && fabs(r.x) <= rmax && fabs(r.y) <= rmax;
+    }
     unsigned v = ((unsigned)(int)ki << 8) | (unsigned)(int)kj;     // both Gray decodes at once, a byte each (levels < 2^8)
     v ^= (v >> 4) & 0x0F0Fu;
     v ^= (v >> 2) & 0x3F3Fu;
@@ -395,52 +533,7 @@ __device__ __forceinline__ int demod_quad_cert(cx<T> r, unsigned lut, T lo, T hi
     const unsigned q = (r.x < (T)0 ? 8u : 0u) | (r.y < (T)0 ? 16u : 0u);
     return (int)((lut >> q) & 0xFFu);
 }
-// Min-distance decision of an M-PSK (M = 8, 16: M points of one radius at angles 2 pi k / M + phi0) WITHOUT touching the
-// table: the regions are the M sectors.  u = r e^{-j phi0}; fold into the first octant (hi = max(|re|, |im|), lo = the other); the
-// M / 8 sector boundaries inside the octant sit at theta_j = (2 j + 1) pi / M, and lo cos(theta_j) - hi sin(theta_j) =
-// |u| sin(theta - theta_j) says on which side of boundary j the point lies -- no arctangent, no division.  p = boundaries passed =
-// point index inside the octant; un-fold: swap -> M / 4 - p, re < 0 -> M / 2 - k, im < 0 -> -k (mod M); label = lut[k].  The folds
-// are consistent ON their own borders (the 45-degree line and the axes are point directions, both sides give the same k), so only
-// the sector boundaries need a margin: `sure` iff every |lo cos - hi sin| >= eps hi, i.e. an angular distance >= eps / sqrt 2 from
-// every boundary, and lo_bound <= hi <= hi_bound.  Two neighbouring candidates then differ by >= 2 |r| rho sin(pi / M) eps in
-// squared distance (rho = the radius) against a rounding of ~ (|r|^2 + rho^2) ulp of either metric: eps = 2^-28 inside
-// [2^-8, 2^8] rho in complex128, 2^-12 inside [1/8, 8] rho in complex64 -- the sweep, first-minimum rule included, returns this
-// very label.  Elsewhere (probability ~ M eps / 4 per symbol, or a deep-fade equaliser output) the caller searches the table.
-// (Written without selects: a v_cndmask on a freshly compared mask costs several issue slots on gfx950 (profiles/r04/f32_rates.txt),
-//  and the first form of this function -- five selects and a select tree for the label -- was SLOWER than the candidate-grid search
-//  it replaces (scripts/experiments/r05_psk_rates.py).  The folds are sign masks: m = (sign bit of a difference) >> 31 is 0 or -1,
-//  and "M / 4 - p if swapped" is (p ^ m) + ((M / 4 + 1) & m); the label comes out of a 64-bit word of M fields by one shift.)
-__device__ __forceinline__ int sign_mask(float v) { return __float_as_int(v) >> 31; }
-__device__ __forceinline__ int sign_mask(double v) { return __double2hiint(v) >> 31; }
-template <typename T>
-__device__ __forceinline__ int demod_psk_cert(cx<T> r, const ModemParams<T>& mp, bool& sure) {
-    const T ux = r.x * mp.psk_rot[0] - r.y * mp.psk_rot[1], uy = r.x * mp.psk_rot[1] + r.y * mp.psk_rot[0];
-    const T ax = fabs(ux), ay = fabs(uy);
-    const T hi = fmax(ax, ay), lo = fmin(ax, ay);
-    constexpr T eps = sizeof(T) == 8 ? (T)0x1p-28 : (T)0x1p-12;
-    const T tol = eps * hi;
-    const int nb = mp.M >> 3;                                     // boundaries inside an octant: 1 (8-PSK), 2 (16-PSK)
-    int p = nb;
-    bool ok = hi >= mp.psk_lo && hi <= mp.psk_hi;                 // NaN: not sure
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-        if (j < nb) {
-            const T d = lo * mp.psk_cb[j] - hi * mp.psk_sb[j];    // |u| sin(theta - theta_j)
-            p += sign_mask(d);                                    // nb - (boundaries NOT passed)
-            ok = ok && fabs(d) >= tol;
-        }
-    const int ms = sign_mask(ax - ay), mx = sign_mask(ux), my = sign_mask(uy);
-    int k = (p ^ ms) + (((mp.M >> 2) + 1) & ms);                  // swapped: M / 4 - p
-    k = (k ^ mx) + (((mp.M >> 1) + 1) & mx);                      // re < 0: M / 2 - k
-    k = (k ^ my) - my;                                            // im < 0: -k
-    k &= mp.M - 1;
-    sure = ok;
-    const unsigned long long lut = ((unsigned long long)mp.psk_lut[1] << 32) | mp.psk_lut[0];   // M fields of 64 / M bits
-    const int fw = mp.M == 8 ? 8 : 4;
-    return (int)((lut >> (k * fw)) & (mp.M == 8 ? 0xFFull : 0xFull));
-}
 template <typename T> __device__ __forceinline__ int demod_cert_any(const ModemParams<T>& mp, cx<T> r, bool& sure) {
-    if (mp.cert == 3) return demod_psk_cert<T>(r, mp, sure);
     if (mp.cert == 2) return demod_quad_cert<T>(r, mp.quad_lut, mp.quad_lo, mp.quad_hi, sure);
     return demod_qam_cert<T>(r, mp.qam_scale, mp.qam_L, mp.half_bits, sure);
 }
@@ -472,12 +565,9 @@ __device__ __forceinline__ int demod_one(const ModemParams<T>& mp, const cx<T>* 
 // K symbols: all K certificates first (straight-line), the table search only in lanes that hold an uncertified symbol.
 // `search(idx)` is the caller's lockstep search over all K (demod_grid_multi / demod_grid4_multi / demod_mindist_multi);
 // it gives the same labels as the certificate wherever that one is sure, so overwriting all K in such a lane is harmless.
-// SWEEP8: the caller's search is the packed lockstep sweep of <= 8 points (complex64): it costs what the sector certificate of an
-// 8-PSK costs (~30 instructions per symbol), so that certificate is skipped there (AWGN link, 8-PSK, complex64: 3.16 -> 3.5e7
-// realizations/s, scripts/experiments/r05_psk_rates.py); the QAM / QPSK certificates (6 - 25 instructions) still run first.
-template <typename T, int K, bool SWEEP8 = false, typename Search>
+template <typename T, int K, typename Search>
 __device__ __forceinline__ void demod_multi_cert(const ModemParams<T>& mp, const cx<T> (&r)[K], int (&idx)[K], Search&& search) {
-    if (mp.cert && !(SWEEP8 && mp.cert == 3)) {
+    if (mp.cert) {
         bool all = true;
 #pragma unroll
         for (int k = 0; k < K; ++k) {
@@ -499,6 +589,7 @@ template <typename T> inline DemodGrid context_grid(const mcle_ctx* ctx, int met
     g.x0 = ctx->grid_x0;
     g.y0 = ctx->grid_y0;
     g.inv_h = ctx->grid_inv_h;
+    g.psk = (ctx->psk_ok && g.G > 0 && !ctx->opt[MCLE_OPT_DEMOD_NOCERT]) ? reinterpret_cast<const PskCert*>(ctx->d_psk) : nullptr;
     return g;
 }
 
@@ -506,8 +597,7 @@ template <typename T> inline DemodGrid context_grid(const mcle_ctx* ctx, int met
 inline int modem_cert(const mcle_ctx* ctx, int method) {
     if (method != MCLE_DEMOD_MINDIST || ctx->opt[MCLE_OPT_DEMOD_NOCERT]) return 0;
     if (ctx->kind == MCLE_CONST_QAM && ctx->qam_L >= 2 && ctx->qam_L <= 256) return 1;
-    if (ctx->quad_ok) return 2;
-    return ctx->psk_ok ? 3 : 0;
+    return ctx->quad_ok ? 2 : 0;      // (an 8- / 16-PSK is certified inside the table searches: DemodGrid::psk)
 }
 
 // cooperative copy of the constellation into LDS (call before a __syncthreads())
@@ -517,18 +607,6 @@ template <typename T> inline void modem_fill_cert(const mcle_ctx* ctx, int metho
     p.quad_lut = ctx->quad_lut;
     p.quad_lo = (T)(ctx->quad_min * (sizeof(T) == 8 ? 0x1p-30 : 0x1p-15));
     p.quad_hi = (T)(ctx->quad_max * 256.0);
-    p.psk_lut[0] = ctx->psk_lut[0];
-    p.psk_lut[1] = ctx->psk_lut[1];
-    p.psk_rot[0] = (T)ctx->psk_rot[0];
-    p.psk_rot[1] = (T)ctx->psk_rot[1];
-    for (int j = 0; j < 2; ++j) {
-        const double th = (2 * j + 1) * 3.14159265358979323846 / (double)(ctx->M > 0 ? ctx->M : 8);
-        p.psk_cb[j] = (T)std::cos(th);
-        p.psk_sb[j] = (T)std::sin(th);
-    }
-    // hi = max(|re|, |im|) >= |u| / sqrt 2: the window on |u| in units of the radius, a factor sqrt 2 inside on the low side
-    p.psk_lo = (T)(ctx->psk_radius * (sizeof(T) == 8 ? 0x1p-8 : 0.125));
-    p.psk_hi = (T)(ctx->psk_radius * (sizeof(T) == 8 ? 0x1p+8 : 8.0));
 }
 
 template <typename T>

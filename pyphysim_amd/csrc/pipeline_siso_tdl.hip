@@ -814,7 +814,11 @@ int run_siso_tdl_batch_impl(mcle_ctx* ctx, SisoTdlParams pp, int method, uint64_
         // arithmetics x1.5, 2048 complex64 x2.7, 256 / 512 complex128 x1.5 / x1.2; the batched complex64 kernels keep 256 / 512, where
         // the per-stage twiddle fetches of the radix-4 wavefront transform are not hidden: x0.54 / x0.86); MCLE_OPT_TDL_KERNEL = 1: the
         // batched kernels everywhere, 2: the wavefront kernel wherever it exists
-        const bool faster = N >= 1024 || sizeof(T) == 8;
+        // round 5: the wavefront kernel is the faster one at EVERY size in both arithmetics (profiles/r05/tdl_family_rates.json:
+        // complex64 256 x1.9, 512 x1.55, 1024 x1.5, 2048 x2.7; complex128 x2.4, x1.6, x1.6, x1.2 -- the complex64 256 / 512 losses
+        // of round 4 (x0.63, x0.89) went away with the 64 MiB record slices, which cut a launch of 2^21 short realizations into
+        // five pairs of small launches)
+        const bool faster = true;
         const long long sel = ctx->opt[MCLE_OPT_TDL_KERNEL];
         if ((sel == 2 || sel == 4 || (sel == 0 && faster)) && !ctx->opt[MCLE_OPT_NO_MFMA]) {
             rc = sizeof(T) == 8 ? run_siso_tdl_wave_f64(ctx, N, pp, method, seed, first, count, d_counters, d_sym, d_bit)

@@ -251,7 +251,7 @@ __global__ __launch_bounds__(kPipeBlock, (sizeof(T) == 8 && LR == 8) ? 2 : 1) vo
                     qam_count4(x, qp, se, be);
                 } else if constexpr (MODE == 2) {   // the four symbols searched in lockstep (same decisions as demod_one)
                     int dec[4];
-                    if (mp.M <= 8) demod_multi_cert<float, 4, true>(mp, r, dec, [&](int (&d_)[4]) { demod_mindist_multi<4>(s_tab4, mp.M, r, d_); });
+                    if (mp.M <= 8) demod_multi_cert(mp, r, dec, [&](int (&d_)[4]) { demod_mindist_multi<4>(s_tab4, mp.M, r, d_); });
                     else demod_multi_cert(mp, r, dec, [&](int (&d_)[4]) { demod_grid4_multi<4>(s_tab4, s_grid, mp.grid, mp.M, r, d_); });
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -423,7 +423,7 @@ __global__ __launch_bounds__(kPipeBlock) void k_run_flat_mfma(FlatParams fp, Mod
                 } else {
                     int dec[4];
                     if constexpr (MODE == 2) {
-                        if (mp.M <= 8) demod_multi_cert<float, 4, true>(mp, r, dec, [&](int (&d_)[4]) { demod_mindist_multi<4>(s_tab4, mp.M, r, d_); });
+                        if (mp.M <= 8) demod_multi_cert(mp, r, dec, [&](int (&d_)[4]) { demod_mindist_multi<4>(s_tab4, mp.M, r, d_); });
                         else demod_multi_cert(mp, r, dec, [&](int (&d_)[4]) { demod_grid4_multi<4>(s_tab4, s_grid, mp.grid, mp.M, r, d_); });
                     } else {
 #pragma unroll

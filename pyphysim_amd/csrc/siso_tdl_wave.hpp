@@ -41,13 +41,18 @@ constexpr int kWaveMaxTaps = 8;
 // N = 1024: the radix-16 passes with register hand-over on both sides of the channel.  N = 256 / 512 / 2048: radix-4 stages on the
 // wavefront's planes (fft_r16.hpp: wave_fft_dif / wave_fft_dit, N / 256 butterfly positions per lane and stage), the same
 // hand-over through explicit reads and writes; everything between the transforms is the same code on R = N / 64 samples per lane.
+// NWV: wavefronts (= realizations in flight) per workgroup: four, but TWO at 2048 points in complex128, whose 66 KiB of planes per
+// wavefront let only two wavefronts share a workgroup's LDS budget (two workgroups per CU: one wavefront per SIMD -- round 5; until
+// then that geometry ran the batched kernel only)
+template <typename T, int N> constexpr int siso_wave_nwv() { return (N >= 2048 && sizeof(T) == 8) ? 2 : 4; }
 template <typename T, int N, int KT, int WPS>
-__global__ __launch_bounds__(256, WPS) void k_run_ofdm_tdl_wave(SisoTdlParams pp, ModemParams<T> mp, uint64_t seed, uint64_t first,
+__global__ __launch_bounds__(64 * (siso_wave_nwv<T, N>()), WPS) void k_run_ofdm_tdl_wave(SisoTdlParams pp, ModemParams<T> mp, uint64_t seed, uint64_t first,
                                                                 uint64_t count, const cx<T>* __restrict__ g_tw,
                                                                 const cx<T>* __restrict__ g_polys, mcle_counters* counters,
                                                                 uint32_t* __restrict__ sym_out, uint32_t* __restrict__ bit_out) {
     constexpr int R = N / 64;                                               // samples (positions, subcarriers) per lane
     constexpr bool R16 = N == 1024;
+    constexpr int NWV = siso_wave_nwv<T, N>();
     auto swz = [](int e) { return R16 ? lds_swz16f(e) : lds_swz64(e); };
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
@@ -59,8 +64,8 @@ __global__ __launch_bounds__(256, WPS) void k_run_ofdm_tdl_wave(SisoTdlParams pp
     // PREFIX in natural order -- xp[P + m] = x[m], xp[j] = x[N - P + j] -- so that x[m - d] is an unswizzled read at a lane-linear
     // address (base per tap + a compile-time offset per sample; conflict free: consecutive lanes, consecutive words).
     const int pitch = pp.x_elems, P = pitch - N;
-    T* s_all = reinterpret_cast<T*>(smem);                                   // [4 wavefronts][2][pitch]
-    cx<T>* s_table = reinterpret_cast<cx<T>*>(s_all + 4 * 2 * pitch);       // [M rounded to 2]   shared, read-only in the loop
+    T* s_all = reinterpret_cast<T*>(smem);                                   // [NWV wavefronts][2][pitch]
+    cx<T>* s_table = reinterpret_cast<cx<T>*>(s_all + NWV * 2 * pitch);     // [M rounded to 2]   shared, read-only in the loop
     unsigned long long* s_grid = reinterpret_cast<unsigned long long*>(s_table + ((mp.M + 1) & ~1));   // [G * G]
     // w^(F(64 k) d_s): the equaliser's twiddle of bin f = F(gi) + F(64 k) is w^(F(gi) d_s) (one gather per lane, tap and symbol)
     // times this wave-uniform factor (an LDS broadcast) -- sixteen table gathers per lane and tap, 64 cache lines each, kept the
@@ -74,15 +79,19 @@ __global__ __launch_bounds__(256, WPS) void k_run_ofdm_tdl_wave(SisoTdlParams pp
     T* xi = pr + pitch;                                                     // im [pitch, 2 pitch) -- the same memory, never live together
     unsigned char* s_idx = s_idx_all + w * idx_pitch;
     __shared__ double s_bm[sizeof(T) == 8 ? kBmLdsDoubles : 1];             // complex128 Box-Muller tables (bm_f64.hpp)
-    if constexpr (sizeof(T) == 8) bm_tables_to_lds(s_bm, (int)threadIdx.x, 256);
+    if constexpr (sizeof(T) == 8) bm_tables_to_lds(s_bm, (int)threadIdx.x, 64 * NWV);
     load_table(mp, s_table);
     load_grid(mp, s_grid);
-    __shared__ WgTotals totals[4];
+    __shared__ WgTotals totals[NWV];
     if (lane == 0) wg_zero(totals[w]);
-    if (threadIdx.x < R * kWaveMaxTaps) {
-        const int k = (int)threadIdx.x / kWaveMaxTaps, ts = (int)threadIdx.x % kWaveMaxTaps;
+    for (int i = (int)threadIdx.x; i < R * kWaveMaxTaps; i += 64 * NWV) {
+        const int k = i / kWaveMaxTaps, ts = i % kWaveMaxTaps;
         const int fk = fft_index_of_pos<N>(64 * k);
-        s_twk[threadIdx.x] = ts < S ? g_tw[(fk * pp.tap_delay[ts]) & (N - 1)] : mk<T>(0, 0);
+        cx<T> v = mk<T>(0, 0);
+#pragma unroll
+        for (int q = 0; q < kWaveMaxTaps; ++q)                              // (static indices into the argument block)
+            if (q == ts && q < S) v = g_tw[(fk * pp.tap_delay[q]) & (N - 1)];
+        s_twk[i] = v;
     }
     __syncthreads();                                                        // the only workgroup barrier of the kernel
 
@@ -107,8 +116,8 @@ __global__ __launch_bounds__(256, WPS) void k_run_ofdm_tdl_wave(SisoTdlParams pp
 #pragma unroll
     for (int s = 0; s < kWaveMaxTaps; ++s) dly[s] = s < S ? pp.tap_delay[s] : 0;
 
-    const uint64_t n_waves = (uint64_t)gridDim.x * 4;
-    for (uint64_t rl = (uint64_t)blockIdx.x * 4 + w; rl < count; rl += n_waves) {
+    const uint64_t n_waves = (uint64_t)gridDim.x * NWV;
+    for (uint64_t rl = (uint64_t)blockIdx.x * NWV + w; rl < count; rl += n_waves) {
         const Rng rng(seed, first + rl);
         unsigned se = 0, be = 0;
         for (int os = 0; os < pp.n_ofdm_sym; ++os) {
@@ -381,9 +390,10 @@ int run_siso_tdl_wave_w(mcle_ctx* ctx, const SisoTdlParams& pp, int method, uint
     if (pp.dmax > 256 || pp.dmax > N / 2 || pp.n_taps > kWaveMaxTaps || pp.n_taps * (pp.K + 2) > 128) return MCLE_E_UNSUPPORTED;
     SisoTdlParams pw = pp;
     pw.x_elems = N + ((pp.dmax + 15) & ~15);                                // plane pitch: N + the prefix the taps reach into
-    const size_t lds = (size_t)4 * 2 * pw.x_elems * sizeof(T) + (((size_t)mp.M + 1) & ~(size_t)1) * sizeof(cx<T>) +
+    constexpr int NWV = siso_wave_nwv<T, N>();
+    const size_t lds = (size_t)NWV * 2 * pw.x_elems * sizeof(T) + (((size_t)mp.M + 1) & ~(size_t)1) * sizeof(cx<T>) +
                        (((size_t)mp.grid.G * mp.grid.G + 1) & ~(size_t)1) * sizeof(unsigned long long) + R * kWaveMaxTaps * sizeof(cx<T>) +
-                       4 * (((size_t)pp.num_used + 15) & ~(size_t)15) + 16;
+                       NWV * (((size_t)pp.num_used + 15) & ~(size_t)15) + 16;
     auto kern = k_run_ofdm_tdl_wave<T, N, 2, WPS>;   // the polynomial order is a compile-time constant (2 .. 8: Doppler x symbol
     switch (pp.K) {                                  // length up to ~0.1 turns in complex64; beyond: the batched kernels)
         case 2: kern = k_run_ofdm_tdl_wave<T, N, 2, WPS>; break;
@@ -403,12 +413,12 @@ int run_siso_tdl_wave_w(mcle_ctx* ctx, const SisoTdlParams& pp, int method, uint
     MCLE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int per_cu = (int)((size_t)160 * 1024 / (lds + (sizeof(T) == 8 ? 5 * 1024 : 512)));   // (+ the static Box-Muller tables and totals)
     if (per_cu < 1) return MCLE_E_UNSUPPORTED;
-    if (per_cu > WPS) per_cu = WPS;
+    if (per_cu > WPS * 4 / NWV) per_cu = WPS * 4 / NWV;                      // workgroups of NWV wavefronts, WPS wavefronts per SIMD
     const size_t rec_len = (size_t)pp.n_taps * (pp.K + 2);
     const uint64_t per_real = (uint64_t)pp.n_ofdm_sym * rec_len;             // complex values per realization
     uint64_t slice = (2048ull << 20) / (per_real * sizeof(cx<T>));           // <= 2 GiB of records per fading + link pair: a bench step
                                                                              // of 2^21 realizations is one dispatch of each kernel
-    slice = slice < 4 ? 4 : (slice / 4) * 4;
+    slice = slice < NWV ? NWV : (slice / NWV) * NWV;
     if (slice > count) slice = count;
     void* recs = nullptr;
     if ((rc = ctx->scratch((size_t)slice * per_real * sizeof(cx<T>), &recs))) return rc;
@@ -418,8 +428,8 @@ int run_siso_tdl_wave_w(mcle_ctx* ctx, const SisoTdlParams& pp, int method, uint
         hipLaunchKernelGGL(k_tdl_symbol_polys<T>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream, pp, N + pp.cp,
                            seed, first + off, n, (cx<T>*)recs);
         MCLE_LAUNCH_CHECK();
-        const unsigned grid = (unsigned)oversubscribed_grid(ctx, (uint64_t)ctx->n_cu * per_cu, (n + 3) / 4, 12);
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, ctx->stream, pw, mp, seed, first + off, n, (const cx<T>*)tw,
+        const unsigned grid = (unsigned)oversubscribed_grid(ctx, (uint64_t)ctx->n_cu * per_cu, (n + NWV - 1) / NWV, 12);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NWV), lds, ctx->stream, pw, mp, seed, first + off, n, (const cx<T>*)tw,
                            (const cx<T>*)recs, d_counters, d_sym ? d_sym + off : nullptr, d_bit ? d_bit + off : nullptr);
         MCLE_LAUNCH_CHECK();
     }
@@ -432,8 +442,8 @@ int run_siso_tdl_wave(mcle_ctx* ctx, const SisoTdlParams& pp, int method, uint64
     // (MCLE_OPT_TDL_KERNEL = 4: four -- the LDS admits a fourth workgroup, but the 128-register bound spills 15 registers:
     //  3.18 against 2.21 ms per 262 144 realizations).  256 / 512: fewer samples per lane, three to six; 2048: complex64 only, two
     //  (132 KiB of planes per workgroup in complex128: the batched kernel serves that one).
-    if constexpr (N == 2048) {
-        if constexpr (sizeof(T) == 8) return MCLE_E_UNSUPPORTED;
+    if constexpr (N == 2048) {       // complex128: two wavefronts per workgroup, two workgroups per CU = one wavefront per SIMD
+        if constexpr (sizeof(T) == 8) return run_siso_tdl_wave_w<T, N, 1>(ctx, pp, method, seed, first, count, d_counters, d_sym, d_bit);
         else return run_siso_tdl_wave_w<T, N, 2>(ctx, pp, method, seed, first, count, d_counters, d_sym, d_bit);
     } else if constexpr (N == 1024) {
         if constexpr (sizeof(T) == 8) return run_siso_tdl_wave_w<T, N, 2>(ctx, pp, method, seed, first, count, d_counters, d_sym, d_bit);

@@ -41,9 +41,10 @@ DEFAULT = [
     r"k_run_mimo_ofdm_planar<(double|float), 2048, [12], 4, 2, 4, 0>", r"k_run_mimo_ofdm_planar<double, 2048, 3, 4, 2, 4, 0>",
     r"k_run_mimo_ofdm_planar<(double|float), 2048, 4, 4, 4, 2, 0>", r"k_run_mimo_ofdm_planar<float, 2048, 3, 4, 4, 2, 0>", r"k_mimo_filters_planar<",
     # config 3 (pipeline_siso_tdl.hip: the wavefront kernel where it is the faster one, the batched kernels otherwise)
-    r"k_run_ofdm_tdl_wave<float, 1024, \d, 3>", r"k_run_ofdm_tdl_wave<float, 2048, \d, 2>", r"k_run_ofdm_tdl_wave<double, 256, \d, 4>",
-    r"k_run_ofdm_tdl_wave<double, 512, \d, 3>", r"k_run_ofdm_tdl_wave<double, 1024, \d, 2>",
-    r"k_run_ofdm_tdl_batch<float, (64|128|256|512), 4>", r"k_run_ofdm_tdl_batch<double, (64|128|2048), 2>", r"k_tdl_symbol_polys<",
+    r"k_run_ofdm_tdl_wave<float, 1024, \d, 3>", r"k_run_ofdm_tdl_wave<float, 2048, \d, 2>", r"k_run_ofdm_tdl_wave<float, 256, \d, 5>",
+    r"k_run_ofdm_tdl_wave<float, 512, \d, 4>", r"k_run_ofdm_tdl_wave<double, 256, \d, 4>", r"k_run_ofdm_tdl_wave<double, 512, \d, 3>",
+    r"k_run_ofdm_tdl_wave<double, 1024, \d, 2>", r"k_run_ofdm_tdl_wave<double, 2048, \d, 1>",
+    r"k_run_ofdm_tdl_batch<(float|double), (64|128), \d>", r"k_tdl_symbol_polys<",
     # f1 (pipeline_mimo_tdl.hip): one receive antenna per wavefront inside its envelope, the cooperative kernel for the rest
     r"k_run_mimo_ofdm_tdl_wave<", r"k_mimo_tdl_symbol_polys<", r"k_run_mimo_ofdm_tdl<(float|double), (64|128), [24]>",
     # configs 1 / 2, config 5, f6, the flat MIMO application

@@ -25,8 +25,10 @@ def cert_model(r, M, dtype):
     tj = np.minimum(np.maximum(x * hs + hl, T(0)), lm1)
     ti = np.minimum(np.maximum(hl - y * hs, T(0)), lm1)
     kj, ki = np.rint(tj), np.rint(ti)
-    rmax = (T(2048.0 if dtype == "f64" else 16.0) + hl) / hs          # round 5: no certificate far outside the constellation
-    sure = (np.abs(tj - kj) <= lim) & (np.abs(ti - ki) <= lim) & (np.abs(x) <= rmax) & (np.abs(y) <= rmax)
+    sure = (np.abs(tj - kj) <= lim) & (np.abs(ti - ki) <= lim)
+    if dtype == "f32":                                               # round 5: complex64 certifies nothing far outside the constellation
+        rmax = (T(16.0) + hl) / hs
+        sure &= (np.abs(x) <= rmax) & (np.abs(y) <= rmax)
     v = (ki.astype(np.uint32) << 8) | kj.astype(np.uint32)
     v ^= (v >> 4) & 0x0F0F
     v ^= (v >> 2) & 0x3F3F
