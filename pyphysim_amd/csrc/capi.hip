@@ -182,7 +182,7 @@ int mcle_ctx_set_option(mcle_ctx* ctx, int option, long long value) {
         case MCLE_OPT_MIMO_TDL_KERNEL: ok = value >= 0 && value <= 2; break;
 #endif
 #ifdef MCLE_EXPERIMENTS
-        case MCLE_OPT_F64_VARIANT: ok = value >= 0 && value <= 3; break;
+        case MCLE_OPT_F64_VARIANT: ok = value >= 0 && value <= 2047; break;
 #else
         case MCLE_OPT_F64_VARIANT:      // the timing-bound kernels exist in -DMCLE_EXPERIMENTS builds only (wrong counters by construction)
             MCLE_REQUIRE(value == 0, "option MCLE_OPT_F64_VARIANT: the timing-bound variants are compiled with -DMCLE_EXPERIMENTS only");

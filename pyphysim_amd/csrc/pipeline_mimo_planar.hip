@@ -121,6 +121,10 @@ __global__ __launch_bounds__((N / 4) * (NR / AH), WPS) void k_run_mimo_ofdm_plan
     constexpr bool R16 = (VAR & 4) != 0;                                    // radix-16 passes, one transform per wavefront
     constexpr bool FUSED = R16 && (VAR & 8) != 0;                           // ... with pass C, the channel and pass C' as one stage
     constexpr bool EXACT = R16 && (VAR & 16) != 0;                          // ... with every layer-1 twiddle from the table
+    // section ablation for the instruction-level account of the headline kernel (-DMCLE_EXPERIMENTS builds only, option
+    // f64_variant = 32 .. : WRONG results by construction): 32 = no symbol draws / table look-ups in the scatter, 64 = no transmit
+    // transform, 128 = no noise draws, 256 = no H x products, 512 = no receive transform, 1024 = no decode
+    constexpr int ABL = VAR & ~31;
     static_assert(!R16 || (N == 1024 && NR == 4 && AH == 4), "radix-16 variant: 1024, four receive antennas, 256 threads");
     constexpr bool TWR = AH == NR && N == 1024 && !R16;                     // a thread's twiddles in registers
     auto swz = [](int e) { return R16 ? lds_swz16f(e) : lds_swz64(e); };
@@ -199,7 +203,9 @@ __global__ __launch_bounds__((N / 4) * (NR / AH), WPS) void k_run_mimo_ofdm_plan
             // leaves alone -- one bin and one swizzle per block instead of sixteen
             const bool aligned_scatter = (16 % NT == 0) && U == N && (per_sym & 15) == 0;
             for (uint64_t blk = (n_first >> 4) + tid; blk <= ((n_last - 1) >> 4); blk += TB) {
-                const Words4 dw = rng.block(STREAM_DATA, (uint32_t)blk);
+                Words4 dw;
+                if constexpr (ABL & 32) dw.w[0] = dw.w[1] = dw.w[2] = dw.w[3] = (uint32_t)blk;
+                else dw = rng.block(STREAM_DATA, (uint32_t)blk);
                 if (aligned_scatter) {
                     const int nl0 = (int)((blk << 4) - n_first);
                     const int pos0 = swz(ofdm_bin(nl0 / NT, N, U));
@@ -208,7 +214,7 @@ __global__ __launch_bounds__((N / 4) * (NR / AH), WPS) void k_run_mimo_ofdm_plan
 #pragma unroll
                     for (int j = 0; j < 16; ++j) {
                         const int tx = (int)((dw.w[j >> 2] >> ((j & 3) * 8)) & mask);
-                        const cx<T> c = s_txtab[tx];
+                        const cx<T> c = (ABL & 32) ? mk<T>((T)tx, (T)1) : s_txtab[tx];
                         const int pos = pos0 ^ (j / NT);          // antenna j mod NT of subcarrier d0 + j / NT
                         s_d[(2 * (j % NT)) * N + pos] = c.x;
                         s_d[(2 * (j % NT) + 1) * N + pos] = c.y;
@@ -246,7 +252,8 @@ __global__ __launch_bounds__((N / 4) * (NR / AH), WPS) void k_run_mimo_ofdm_plan
             //      measured no gain).  Antenna groups beyond Nt have nothing to send and only keep the barriers. ----
             if constexpr (R16) {
                 if constexpr (TW16_RELOAD) tw16 = load_r16_tw<T>(g_tw, opaque(lane));
-                if (NT == NR || w < NT) r16_dif<T, true, !FUSED, EXACT>(s_wave_re, s_wave_im, lane, tw16, g_tw);   // wavefront = antenna
+                if constexpr (!(ABL & 64))
+                    if (NT == NR || w < NT) r16_dif<T, true, !FUSED, EXACT>(s_wave_re, s_wave_im, lane, tw16, g_tw);   // wavefront = antenna
                 __syncthreads();
             } else
             static_for<N4>([&](auto stc) {
@@ -288,8 +295,12 @@ __global__ __launch_bounds__((N / 4) * (NR / AH), WPS) void k_run_mimo_ofdm_plan
 #pragma unroll
                     for (int r = 0; r < NR; ++r) {
                         cx<T> z = nz[r];
+                        if constexpr (ABL & 256) {
+                            z = cadd(z, x[r % NT][d]);
+                        } else {
 #pragma unroll
-                        for (int a = 0; a < NT; ++a) z = CxOps<T>::fma(s_H[r * NT + a], x[a][d], z);
+                            for (int a = 0; a < NT; ++a) z = CxOps<T>::fma(s_H[r * NT + a], x[a][d], z);
+                        }
                         y[r][d] = z;
                     }
                 };
@@ -301,9 +312,14 @@ __global__ __launch_bounds__((N / 4) * (NR / AH), WPS) void k_run_mimo_ofdm_plan
 #pragma unroll
                         for (int rr = 0; rr < NR / 2; ++rr) {
                             const uint64_t i0 = (uint64_t)(rr + (NR / 2) * h) * row + (uint64_t)os * (N + cp) + cp + mb + 256 * d;
-                            const Words4 b = rng.block(STREAM_NOISE, (uint32_t)(i0 >> 1));
-                            const cx<T> za = cn_words(b.w[0], b.w[1], sigma, s_bm);     // the even sample: the lower half's
-                            const cx<T> zb = cn_words(b.w[2], b.w[3], sigma, s_bm);     // the odd sample: the upper half's
+                            cx<T> za, zb;
+                            if constexpr (ABL & 128) {
+                                za = zb = mk<T>((T)(uint32_t)i0, sigma);
+                            } else {
+                                const Words4 b = rng.block(STREAM_NOISE, (uint32_t)(i0 >> 1));
+                                za = cn_words(b.w[0], b.w[1], sigma, s_bm);             // the even sample: the lower half's
+                                zb = cn_words(b.w[2], b.w[3], sigma, s_bm);             // the odd sample: the upper half's
+                            }
                             swap32_pair(za.x, zb.x, nz[rr].x, nz[rr + NR / 2].x);
                             swap32_pair(za.y, zb.y, nz[rr].y, nz[rr + NR / 2].y);
                         }
@@ -385,7 +401,7 @@ __global__ __launch_bounds__((N / 4) * (NR / AH), WPS) void k_run_mimo_ofdm_plan
             // ---- FFT: (the radix-2 stage +) radix-4 DIT, digit-reversed -> natural bins ----
             if constexpr (R16) {
                 if constexpr (TW16_RELOAD) tw16 = load_r16_tw<T>(g_tw, opaque(lane));
-                r16_dit<T, false, !FUSED, EXACT>(s_wave_re, s_wave_im, lane, tw16, g_tw);
+                if constexpr (!(ABL & 512)) r16_dit<T, false, !FUSED, EXACT>(s_wave_re, s_wave_im, lane, tw16, g_tw);
                 __syncthreads();
             } else if constexpr (TWR) {
                 if constexpr (SH::HAS2) {
@@ -418,7 +434,7 @@ __global__ __launch_bounds__((N / 4) * (NR / AH), WPS) void k_run_mimo_ofdm_plan
                 });
             }
             // ---- receive: Blast decode (G carries the FFT scale), demodulate, count ----
-            {
+            if constexpr (!(ABL & 1024)) {
                 for (int d = tid; d < U; d += TB) {
                     const int bin = swz(ofdm_bin(d, N, U));
                     cx<T> y[NR];
@@ -576,6 +592,13 @@ static int run_mimo_ofdm_planar_t(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, 
                 case 1: return launch_mimo_ofdm_planar<T, 1024, 4, 4, 2, 4, 1>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
                 case 2: return launch_mimo_ofdm_planar<T, 1024, 4, 4, 2, 4, 2>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
                 case 3: return launch_mimo_ofdm_planar<T, 1024, 4, 4, 2, 4, 3>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
+                default: break;
+            }
+            // section ablation of the headline form (f64_variant = 32 | 64 | ... | 1024, any combination of single sections listed)
+            switch ((int)ctx->opt[MCLE_OPT_F64_VARIANT]) {
+#define MCLE_ABL(V_) case V_: return launch_mimo_ofdm_planar<T, 1024, 4, 4, 4, 2, 12 | V_>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
+                MCLE_ABL(32) MCLE_ABL(64) MCLE_ABL(128) MCLE_ABL(256) MCLE_ABL(512) MCLE_ABL(1024) MCLE_ABL(2016) MCLE_ABL(1920) MCLE_ABL(384)
+#undef MCLE_ABL
                 default: break;
             }
 #endif
