@@ -23,7 +23,8 @@ OPTIONS = {"no_mfma": 0, "mfma_variant": 1, "grid_oversub": 2, "flat_wgs_per_cu"
            "mimo_tdl_kernel": 14}
 
 LIB_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-LIB_PATH = os.path.join(LIB_DIR, "libmcle.so")
+# MCLE_LIBRARY: another build of the same library (A/B runs of two builds on one box, scripts/experiments/)
+LIB_PATH = os.environ.get("MCLE_LIBRARY") or os.path.join(LIB_DIR, "libmcle.so")
 
 
 class McleError(RuntimeError):

@@ -37,6 +37,13 @@ void set_error(const char* fmt, ...);
 
 #define MCLE_LAUNCH_CHECK() MCLE_HIP(hipGetLastError())
 
+// wavefronts per SIMD the complex64 symbol walks k_ia_link and k_mimo_flat_link (one wavefront per workgroup) are bounded for:
+// 4 = 128 registers with 6 / 4 of them spilled, 3 = 168 and none -- four is the faster one on the GPU (config 5: 3.44 against
+// 3.33e8 realizations/s, flat MIMO 1.57 against 1.71 ms; profiles/r05/walk_occupancy_ab.log).  k_bd_link<float> runs at three.
+#ifndef MCLE_F32_WALK_WAVES
+#define MCLE_F32_WALK_WAVES 4
+#endif
+
 // ---- complex arithmetic on (re, im) pairs -------------------------------------------------
 template <typename T> struct cx_of;
 template <> struct cx_of<float> { using type = float2; };

@@ -664,7 +664,7 @@ __global__ __launch_bounds__(64) void k_bd_solve_links_static(BdParams pp, uint6
 // eight-entry arrays in one body the complex64 form spilled 45-52 registers at its 128-register bound (profiles/r03:
 // VALU busy 0.97 on the draw ledger plus spill traffic).
 template <typename T, int R, int KC = 0, int MODE = 0>
-__global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : (KC ? 3 : 2)) void k_bd_link(ModemParams<T> mp, BdParams pp, uint64_t seed,
+__global__ __launch_bounds__(64, (sizeof(T) == 4 || KC) ? 3 : 2) void k_bd_link(ModemParams<T> mp, BdParams pp, uint64_t seed,
                                                                         uint64_t first, uint64_t count, int per_wave,
                                                                         const cx<T>* __restrict__ recs,
                                                                         mcle_counters* counters,

@@ -551,7 +551,7 @@ __global__ __launch_bounds__(64) void k_ia_solve_links(double noise_var, int sol
 // The symbol walk: one wavefront per `per_wave` consecutive realizations, est_k = sum_l G_kl x_l + U_k . n_k, two
 // columns per lane and pass (wave_draws.hpp).  The record of a realization is wave-uniform (scalar loads).
 template <typename T>
-__global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 3) void k_ia_link(ModemParams<T> mp, int n_symbols, double noise_var,
+__global__ __launch_bounds__(64, sizeof(T) == 4 ? MCLE_F32_WALK_WAVES : 3) void k_ia_link(ModemParams<T> mp, int n_symbols, double noise_var,
                                                                         uint64_t seed, uint64_t first, uint64_t count,
                                                                         int per_wave, const cx<T>* __restrict__ recs,
                                                                         mcle_counters* counters,

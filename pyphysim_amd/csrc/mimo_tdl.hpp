@@ -24,6 +24,12 @@ struct MimoTdlParams {
     // the wavefront kernels (mimo_tdl_wave.hpp): tap s expanded around the symbol centre MINUS its delay, so that the channel stage
     // evaluates every tap at the output sample's abscissa; mean over the symbol's samples of (j + d_s - (N+cp-1)/2)^m
     double mom_tap[8][kMaxOrder + 1];
+    // the decode of the wavefront kernels where a lane holds the bins f0 and f0 + N / 2: w^((f0 + N / 2) d) = (-1)^d w^(f0 d), so
+    // the taps are summed by the parity of their delay and the two bins are the sum and the difference.  Class POSITIONS: the
+    // even-delay taps at positions 0 .. cls_ne - 1, the odd-delay ones at 7, 6, .. 8 - cls_no (both loops then index registers
+    // statically); cls_code[p] = tap << 16 | delay, -1 where the position is empty
+    int cls_code[8];
+    int cls_ne, cls_no;
 };
 
 // The fading of one OFDM symbol in its own launch (round 3, as k_tdl_symbol_polys did for config 3): one thread per

@@ -195,7 +195,16 @@ __global__ __launch_bounds__(64 * NR, WPS) void k_run_mimo_ofdm_tdl_wave(MimoTdl
         dly[s] = s < S ? pp.tap_delay[s] : 0;
         if (lane == s) dlyv = dly[s];
     }
+    [[maybe_unused]] int clsv = -1;                                          // lane p < 8: class position p of the decode (mimo_tdl.hpp)
+    if constexpr (BQ == 2 && sizeof(T) == 4) {
+#pragma unroll
+        for (int p = 0; p < 8; ++p)
+            if (lane == p) clsv = pp.cls_code[p];
+    }
     [[maybe_unused]] R16Tw64<T> tw16;
+    // H(f) at two bins per lane by delay-class positions (complex64: +3 % at 1024 4x4, +14 % where one bin per lane takes the same
+    // multiply-add form; complex128 gains nothing and pays five spilled set-up registers: profiles/r05/f1_hf_class_ab.log)
+    constexpr bool CLS2 = BQ == 2 && sizeof(T) == 4 && !(ABL & 256);
     constexpr int REP4 = N / 256;
     // radix-4 sizes, complex64: the lane's stage twiddles in registers at 256 (24 registers; the 48 of 512 spilled 36 registers
     // next to the Gram accumulators of the decode)
@@ -313,7 +322,7 @@ __global__ __launch_bounds__(64 * NR, WPS) void k_run_mimo_ofdm_tdl_wave(MimoTdl
 #pragma unroll
             for (int c = 0; c < R; ++c) y[c] = mk<T>(0, 0);
             {
-                const T x0 = sizeof(T) == 8 ? (T)((double)(cp + gi) - xc) : (T)(cp + gi) - (T)xc;
+                const T x0 = (T)(2 * (cp + gi) - (W - 1)) * (T)0.5;        // (cp + gi) - xc from integers: exact, nothing carried
                 const int NP = (ABL & 1) ? 0 : S * NT;                      // (tap, transmit antenna) pairs, p = s NT + a
                 const cx<T>* xbase = reinterpret_cast<const cx<T>*>(s_all) + (P + gi);
                 // Sixteen samples of the lane at a time (the whole lane at <= 1024 points; two rounds of the pair loop at 2048, where
@@ -443,8 +452,19 @@ __global__ __launch_bounds__(64 * NR, WPS) void k_run_mimo_ofdm_tdl_wave(MimoTdl
                 const int slot0 = swz(p0);
                 const int f0 = fft_index_of_pos<N>(p0);
                 cx<T> Wt[kMimoWaveMaxTaps];                                  // w^(f0 d_s)
+                [[maybe_unused]] int ptap[kMimoWaveMaxTaps];                 // BQ == 2: the tap at class position s
 #pragma unroll
-                for (int s = 0; s < kMimoWaveMaxTaps; ++s) Wt[s] = s < S ? g_tw[(f0 * dly[s]) & (N - 1)] : mk<T>(0, 0);
+                for (int s = 0; s < kMimoWaveMaxTaps; ++s) {
+                    if constexpr (ABL & 2048) {
+                        Wt[s] = mk<T>((T)(f0 + s) * (T)1e-3, (T)(f0 - s) * (T)1e-3);      // (timing: no gathers)
+                    } else if constexpr (CLS2) {                         // class positions: w^(f0 d) of the tap there
+                        const int code = __builtin_amdgcn_readlane(clsv, s);
+                        ptap[s] = code >> 16;
+                        Wt[s] = code >= 0 ? g_tw[(f0 * (code & 0xffff)) & (N - 1)] : mk<T>(0, 0);
+                    } else {
+                        Wt[s] = s < S ? g_tw[(f0 * dly[s]) & (N - 1)] : mk<T>(0, 0);
+                    }
+                }
                 uint32_t sent[BQ];
                 bool valid[BQ];
 #pragma unroll
@@ -480,21 +500,61 @@ __global__ __launch_bounds__(64 * NR, WPS) void k_run_mimo_ofdm_tdl_wave(MimoTdl
                     }
 #pragma unroll
                 for (int r = 0; r < ((ABL & 8) ? 0 : NR); ++r) {
-                    cx<T> u[BQ][NT];                                        // sums by delay class, then the BQ bins' row r of H
+                    static_assert(BQ == 1 || BQ == 2, "a lane decodes one bin or the pair f0, f0 + N / 2");
+                    cx<T> u[BQ][NT];                                        // row r of H at the lane's BQ bins
 #pragma unroll
                     for (int c = 0; c < BQ; ++c)
 #pragma unroll
                         for (int a = 0; a < NT; ++a) u[c][a] = mk<T>(0, 0);
+                    if constexpr (CLS2) {
+                        // two bins per lane: ONE complex multiply-add per entry and tap into the tap's delay class, the bins are
+                        // the sum and the difference of the classes (u[0] = even delays, u[1] = odd delays until the butterfly)
+                        const auto into = [&](cx<T>* uc, int pos) {
+                            const int tap = ptap[pos];
+#pragma unroll
+                            for (int a = 0; a < NT; ++a) {
+                                const cx<T> m = s_mean[(tap * NR + r) * NT + a];
+                                if constexpr (sizeof(T) == 4) uc[a] = from_pk(pk_cfma(to_pk(m), to_pk(Wt[pos]), to_pk(uc[a])));
+                                else uc[a] = cfma(m, Wt[pos], uc[a]);
+                            }
+                        };
+#pragma unroll
+                        for (int k = 0; k < kMimoWaveMaxTaps; ++k) {
+                            if (k >= pp.cls_ne) break;
+                            into(u[0], k);
+                        }
+#pragma unroll
+                        for (int k = 0; k < kMimoWaveMaxTaps; ++k) {
+                            if (k >= pp.cls_no) break;
+                            into(u[1], kMimoWaveMaxTaps - 1 - k);
+                        }
+#pragma unroll
+                        for (int a = 0; a < NT; ++a) {
+                            const cx<T> e = u[0][a];
+                            u[0][a] = cadd(e, u[1][a]);
+                            u[1][a] = csub(e, u[1][a]);
+                        }
+                    } else
 #pragma unroll
                     for (int s = 0; s < kMimoWaveMaxTaps; ++s) {
                         if (s >= S) break;
-                        cx<T> t[NT];
+                        if constexpr (BQ == 1) {                            // one bin per lane: a complex multiply-add per entry and tap
 #pragma unroll
-                        for (int a = 0; a < NT; ++a) {
-                            if constexpr (sizeof(T) == 4 && !(ABL & 128)) t[a] = from_pk(pk_cmul(to_pk(s_mean[(s * NR + r) * NT + a]), to_pk(Wt[s])));
-                            else t[a] = cmul(s_mean[(s * NR + r) * NT + a], Wt[s]);
-                        }
-                        if constexpr (BQ == 2) {                            // H(f0) += t, H(f0 + N / 2) += (-1)^d t: no select, no branch
+                            for (int a = 0; a < NT; ++a) {
+                                const cx<T> m = s_mean[(s * NR + r) * NT + a];
+                                if constexpr (sizeof(T) == 4 && !(ABL & 128)) u[0][a] = from_pk(pk_cfma(to_pk(m), to_pk(Wt[s]), to_pk(u[0][a])));
+                                else u[0][a] = cfma(m, Wt[s], u[0][a]);
+                            }
+                        } else {
+                            // two bins per lane, complex128: t = mean x twiddle once, H(f0) += t, H(f0 + N / 2) += (-1)^d t -- no
+                            // select, no branch (the class-position form above is no faster in complex128)
+                            cx<T> t[NT];
+#pragma unroll
+                            for (int a = 0; a < NT; ++a) {
+                                if constexpr (ABL & 512) t[a] = from_pk(pk_cmul(to_pk(Wt[(s + a + r) % 5]), to_pk(Wt[s])));   // (timing: no LDS reads of the means)
+                                else if constexpr (sizeof(T) == 4 && !(ABL & 128)) t[a] = from_pk(pk_cmul(to_pk(s_mean[(s * NR + r) * NT + a]), to_pk(Wt[s])));
+                                else t[a] = cmul(s_mean[(s * NR + r) * NT + a], Wt[s]);
+                            }
                             int dl = dly[s];
                             asm volatile("" : "+s"(dl));                    // (recomputed here: hoisted, the eight sign pairs were spilled)
                             const T sg = (dl & 1) ? (T)-1 : (T)1;
@@ -504,25 +564,14 @@ __global__ __launch_bounds__(64 * NR, WPS) void k_run_mimo_ofdm_tdl_wave(MimoTdl
                                 u[1][a].x = fma(sg, t[a].x, u[1][a].x);
                                 u[1][a].y = fma(sg, t[a].y, u[1][a].y);
                             }
-                        } else {
-                            const int cls = dly[s] & (BQ - 1);
-#pragma unroll
-                            for (int c = 0; c < BQ; ++c)
-                                if (cls == c) {                             // wave-uniform
-#pragma unroll
-                                    for (int a = 0; a < NT; ++a) u[c][a] = cadd(u[c][a], t[a]);
-                                }
                         }
-                    }
-                    if constexpr (BQ == 4) {
-#pragma unroll
-                        for (int a = 0; a < NT; ++a) r4_inplace<T, false>(u[0][a], u[1][a], u[2][a], u[3][a]);
                     }
                     const T* prr = s_all + r * 2 * pitch;
 #pragma unroll
                     for (int j = 0; j < BQ; ++j) {
                         const int sl = slot0 ^ swz(mimo_wave_posj<N, BQ>(j));
-                        blast_gram_row<T, NT>(u[j], mk<T>(prr[sl], prr[N + sl]), A[j], b[j]);
+                        if constexpr (ABL & 1024) blast_gram_row<T, NT>(u[j], mk<T>((T)sl, (T)(sl + r)), A[j], b[j]);   // (timing: no LDS reads of the bins)
+                        else blast_gram_row<T, NT>(u[j], mk<T>(prr[sl], prr[N + sl]), A[j], b[j]);
                     }
                 }
                 cx<T> est[BQ * NT];

@@ -178,7 +178,7 @@ __global__ __launch_bounds__(64) void k_mimo_flat_setup(int scheme, int nt, int 
 }
 
 template <typename T>
-__global__ __launch_bounds__(64, sizeof(T) == 4 ? 4 : 2) void k_mimo_flat_link(
+__global__ __launch_bounds__(64, sizeof(T) == 4 ? MCLE_F32_WALK_WAVES : 2) void k_mimo_flat_link(
     ModemParams<T> mp, int scheme, int nt, int nr, int n_symbols, double noise_var, uint64_t seed, uint64_t first,
     uint64_t count, int per_wave, const cx<T>* __restrict__ recs, mcle_counters* counters,
     uint32_t* __restrict__ sym_out, uint32_t* __restrict__ bit_out) {

@@ -564,6 +564,13 @@ extern "C" int mcle_run_mimo_ofdm_tdl(mcle_ctx* ctx, int dtype, const mcle_mimo_
             }
             for (int m = 0; m <= kMaxOrder; ++m) pp.mom_tap[s][m] = m <= K ? (double)(at[m] / (long double)W) : 0.0;
         }
+        pp.cls_ne = pp.cls_no = 0;
+        for (int p = 0; p < 8; ++p) pp.cls_code[p] = -1;
+        for (int s = 0; s < cfg->n_taps && s < 8; ++s) {
+            const int code = (s << 16) | pp.tap_delay[s];
+            if (pp.tap_delay[s] & 1) pp.cls_code[7 - pp.cls_no++] = code;
+            else pp.cls_code[pp.cls_ne++] = code;
+        }
     }
     if (count == 0) return MCLE_OK;
     if ((rc = ctx->bind())) return rc;

@@ -16,6 +16,7 @@ int run_mimo_tdl_wave_f32_experiment(int code, MCLE_MIMO_TDL_WAVE_ARGS) {
         return launch_mimo_tdl_wave<float, 1024, 4, 4, 2, BQ_, WPS_, ABL_>(ctx, pp, method, seed, first, count, d_counters, d_sym, d_bit);
     MCLE_EXP(1, 2, 3, 1) MCLE_EXP(2, 2, 3, 2) MCLE_EXP(4, 2, 3, 4) MCLE_EXP(8, 2, 3, 8) MCLE_EXP(16, 2, 3, 16) MCLE_EXP(31, 2, 3, 31)
     MCLE_EXP(40, 2, 2, 0) MCLE_EXP(41, 1, 3, 0) MCLE_EXP(42, 2, 4, 0) MCLE_EXP(43, 2, 3, 0) MCLE_EXP(44, 2, 3, 128) MCLE_EXP(45, 2, 2, 128) MCLE_EXP(64, 2, 3, 64)
+    MCLE_EXP(46, 2, 3, 512) MCLE_EXP(47, 2, 3, 1024) MCLE_EXP(48, 2, 3, 2048) MCLE_EXP(49, 2, 3, 3584) MCLE_EXP(50, 2, 3, 3584 + 8) MCLE_EXP(51, 2, 3, 3584 + 8 + 4 + 16)
 #undef MCLE_EXP
     return MCLE_E_UNSUPPORTED;
 }

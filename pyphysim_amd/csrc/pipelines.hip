@@ -1146,7 +1146,10 @@ int mcle_run_mimo_ofdm(mcle_ctx* ctx, int dtype, const mcle_mimo_ofdm_cfg* cfg, 
     // round-1 generic kernel below WHERE THAT ONE EXISTS (Nt = Nr in {2, 4}); every other geometry still runs the planar family --
     // the option selects a kernel, it does not shrink the envelope
     const bool generic_has_it = cfg->nt == cfg->nr && (cfg->nt == 2 || cfg->nt == 4);
-    if (!(dtype == MCLE_F32 && ctx->opt[MCLE_OPT_NO_MFMA] && generic_has_it)) {
+    // 2x2 at 256 points: the generic kernel (four realizations per 256-thread workgroup) is the faster one -- 1.65 against 1.06e8
+    // realizations/s in complex64, 1.01 against 0.98e8 in complex128 (profiles/r05/f32_family_rates.json, f64_family_rates.json)
+    const bool generic_is_faster = cfg->fft_size == 256 && cfg->nt == 2 && cfg->nr == 2;
+    if (!(dtype == MCLE_F32 && ctx->opt[MCLE_OPT_NO_MFMA] && generic_has_it) && !generic_is_faster) {
         rc = run_mimo_ofdm_planar(ctx, dtype, cfg, seed, first, count, d_counters, d_sym_err, d_bit_err);
         if (rc != MCLE_E_UNSUPPORTED) return rc;
     }
