@@ -94,6 +94,16 @@ __host__ __device__ __forceinline__ float2 cfma(float2 a, float2 b, float2 acc) 
     acc.y = fmaf(a.y, b.x, acc.y);
     return acc;
 }
+// acc + a*b as FOUR CHAINED FMAs in either arithmetic -- the fused pipelines' form.  (The generic cfma above keeps the
+// product-then-add association in complex128: mul + fma + add per component, six operations where four do; the operator kernels
+// that are held bit-exact to the reference on injected data keep that one.)
+template <typename C> __host__ __device__ __forceinline__ C cfma4(C a, C b, C acc) {
+    acc.x = fma(a.x, b.x, acc.x);
+    acc.x = fma(-a.y, b.y, acc.x);
+    acc.y = fma(a.x, b.y, acc.y);
+    acc.y = fma(a.y, b.x, acc.y);
+    return acc;
+}
 template <typename C> __host__ __device__ __forceinline__ C cconj(C a) {
     a.y = -a.y;
     return a;

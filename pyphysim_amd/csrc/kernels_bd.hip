@@ -721,7 +721,7 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 || KC) ? 3 : 2) void k_bd_link(
                             } else {
                                 est[jj] = cmul(D[s], s_table[tx[s]]);
 #pragma unroll
-                                for (int a = 0; a < R; ++a) est[jj] = cfma(W[s * R + a], nz[k * R + a], est[jj]);
+                                for (int a = 0; a < R; ++a) est[jj] = cfma4(W[s * R + a], nz[k * R + a], est[jj]);
                             }
                         }
                         int dec[R];
@@ -766,8 +766,8 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 || KC) ? 3 : 2) void k_bd_link(
                                         cx<T> ea = cmul(D[s], s_table[ta[s]]), eb = cmul(D[s], s_table[tb[s]]);
 #pragma unroll
                                         for (int a = 0; a < R; ++a) {
-                                            ea = cfma(W[s * R + a], za[a], ea);
-                                            eb = cfma(W[s * R + a], zb[a], eb);
+                                            ea = cfma4(W[s * R + a], za[a], ea);
+                                            eb = cfma4(W[s * R + a], zb[a], eb);
                                         }
                                         const unsigned da = (unsigned)(ta[s] ^ demod_one(mp, s_table, s_grid, ea));
                                         const unsigned db = (unsigned)(tb[s] ^ demod_one(mp, s_table, s_grid, eb));

@@ -604,9 +604,9 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? MCLE_F32_WALK_WAVES : 3) void 
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
                     est[k] = cmul(U[k][0], nz[2 * k]);
-                    est[k] = cfma(U[k][1], nz[2 * k + 1], est[k]);
+                    est[k] = cfma4(U[k][1], nz[2 * k + 1], est[k]);
 #pragma unroll
-                    for (int l = 0; l < 3; ++l) est[k] = cfma(G[k][l], x[l], est[k]);
+                    for (int l = 0; l < 3; ++l) est[k] = cfma4(G[k][l], x[l], est[k]);
                 }
                 if constexpr (sizeof(T) == 4) {
                     if (packed) {   // the three decisions of the column in one packed level-domain slice (qam_pack.hpp)
@@ -660,12 +660,12 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? MCLE_F32_WALK_WAVES : 3) void 
                                     cn_pair_lds(rng, STREAM_NOISE, ((uint32_t)(2 * k + a) * (uint32_t)n_symbols + (uint32_t)t) >> 1, sigma,
                                                 za[a], zb[a], s_bm);
                                 cx<T> ea = cmul(U[k][0], za[0]), eb = cmul(U[k][0], zb[0]);
-                                ea = cfma(U[k][1], za[1], ea);
-                                eb = cfma(U[k][1], zb[1], eb);
+                                ea = cfma4(U[k][1], za[1], ea);
+                                eb = cfma4(U[k][1], zb[1], eb);
 #pragma unroll
                                 for (int l = 0; l < 3; ++l) {
-                                    ea = cfma(G[k][l], xa[l], ea);
-                                    eb = cfma(G[k][l], xb[l], eb);
+                                    ea = cfma4(G[k][l], xa[l], ea);
+                                    eb = cfma4(G[k][l], xb[l], eb);
                                 }
                                 const unsigned da = (unsigned)(ta[k] ^ demod_one(mp, s_table, s_grid, ea));
                                 const unsigned db = (unsigned)(tb[k] ^ demod_one(mp, s_table, s_grid, eb));

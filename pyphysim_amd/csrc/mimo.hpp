@@ -68,25 +68,25 @@ __device__ __forceinline__ bool blast_filter_t(const cx<R> (&H)[NR][NT], R nv, c
 // callers that need a filter per column (frequency-selective channels) -- same decisions as G y.
 // f32 instantiation: every complex multiply-accumulate as four chained FMAs (the product-then-add form of the f64 parity
 // code is six operations) and one v_rcp / v_rsq per pivot; same algorithm, rounding-level differences only.
-__device__ __forceinline__ float2 cx_macc(float2 acc, float2 a, float2 b) {    // acc + a conj(b)
-    acc.x = fmaf(a.x, b.x, acc.x);
-    acc.x = fmaf(a.y, b.y, acc.x);
-    acc.y = fmaf(a.y, b.x, acc.y);
-    acc.y = fmaf(-a.x, b.y, acc.y);
+template <typename C> __device__ __forceinline__ C cx_macc(C acc, C a, C b) {    // acc + a conj(b)
+    acc.x = fma(a.x, b.x, acc.x);
+    acc.x = fma(a.y, b.y, acc.x);
+    acc.y = fma(a.y, b.x, acc.y);
+    acc.y = fma(-a.x, b.y, acc.y);
     return acc;
 }
-__device__ __forceinline__ float2 cx_msub(float2 acc, float2 a, float2 b) {    // acc - a b
-    acc.x = fmaf(-a.x, b.x, acc.x);
-    acc.x = fmaf(a.y, b.y, acc.x);
-    acc.y = fmaf(-a.x, b.y, acc.y);
-    acc.y = fmaf(-a.y, b.x, acc.y);
+template <typename C> __device__ __forceinline__ C cx_msub(C acc, C a, C b) {    // acc - a b
+    acc.x = fma(-a.x, b.x, acc.x);
+    acc.x = fma(a.y, b.y, acc.x);
+    acc.y = fma(-a.x, b.y, acc.y);
+    acc.y = fma(-a.y, b.x, acc.y);
     return acc;
 }
-__device__ __forceinline__ float2 cx_msubc(float2 acc, float2 a, float2 b) {   // acc - a conj(b)
-    acc.x = fmaf(-a.x, b.x, acc.x);
-    acc.x = fmaf(-a.y, b.y, acc.x);
-    acc.y = fmaf(-a.y, b.x, acc.y);
-    acc.y = fmaf(a.x, b.y, acc.y);
+template <typename C> __device__ __forceinline__ C cx_msubc(C acc, C a, C b) {   // acc - a conj(b)
+    acc.x = fma(-a.x, b.x, acc.x);
+    acc.x = fma(-a.y, b.y, acc.x);
+    acc.y = fma(-a.y, b.x, acc.y);
+    acc.y = fma(a.x, b.y, acc.y);
     return acc;
 }
 template <int NT, int NR>
@@ -187,22 +187,23 @@ __device__ __forceinline__ bool blast_solve_t(const cx<R> (&H)[NR][NT], R nv, co
 // The same solve from the Gram matrix: A[i][k] (i >= k: lower triangle, real diagonal in .x) = sum_r conj(H[r][i]) H[r][k] and
 // b[i] = sum_r conj(H[r][i]) y[r] accumulated ROW BY ROW by the caller (blast_gram_row) -- a kernel that forms H(f) one receive
 // antenna at a time (mimo_tdl_wave.hpp) never holds the whole Nr x Nt matrix of a subcarrier, let alone of several.  Same
-// operations in the same order as blast_solve_t (sum over r ascending, then + nv on the diagonal, Cholesky, two substitutions).
+// algorithm in the same order as blast_solve_t (sum over r ascending, then + nv on the diagonal, Cholesky, two substitutions), every
+// complex multiply-add as four chained FMAs in both arithmetics (blast_solve_t<double> keeps the product-then-add form).
 template <typename R, int NT>
 __device__ __forceinline__ void blast_gram_row(const cx<R> (&h)[NT], cx<R> yr, cx<R> (&A)[NT][NT], cx<R> (&b)[NT]) {
 #pragma unroll
     for (int k = 0; k < NT; ++k) {
-        A[k][k].x += h[k].x * h[k].x + h[k].y * h[k].y;
+        A[k][k].x = fma(h[k].x, h[k].x, fma(h[k].y, h[k].y, A[k][k].x));
 #pragma unroll
         for (int i = k + 1; i < NT; ++i) {
             if constexpr (sizeof(R) == 4) A[i][k] = from_pk(pk_cfma_conj(to_pk(h[k]), to_pk(h[i]), to_pk(A[i][k])));
-            else A[i][k] = cadd(A[i][k], cmulc(h[k], h[i]));                  // conj(h[i]) * h[k]
+            else A[i][k] = cx_macc(A[i][k], h[k], h[i]);                      // + conj(h[i]) * h[k], four chained FMAs
         }
     }
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
         if constexpr (sizeof(R) == 4) b[i] = from_pk(pk_cfma_conj(to_pk(yr), to_pk(h[i]), to_pk(b[i])));
-        else b[i] = cadd(b[i], cmulc(yr, h[i]));                              // conj(h[i]) * y
+        else b[i] = cx_macc(b[i], yr, h[i]);                                  // + conj(h[i]) * y
     }
 }
 template <typename R, int NT>
@@ -222,8 +223,7 @@ __device__ __forceinline__ bool blast_solve_gram(const cx<R> (&A)[NT][NT], R nv,
             }
 #pragma unroll
             for (int k = 0; k < j; ++k) {
-                if constexpr (sizeof(R) == 4) a = cx_msubc(a, L[i][k], L[j][k]);
-                else a = csub(a, cmulc(L[i][k], L[j][k]));
+                a = cx_msubc(a, L[i][k], L[j][k]);
             }
             if (i == j) {
                 ok = ok && (a.x > (R)(sizeof(R) == 8 ? 1e-300 : 1e-30));
@@ -245,8 +245,7 @@ __device__ __forceinline__ bool blast_solve_gram(const cx<R> (&A)[NT][NT], R nv,
         C v = b[i];
 #pragma unroll
         for (int k = 0; k < i; ++k) {
-            if constexpr (sizeof(R) == 4) v = cx_msub(v, L[i][k], z[k]);
-            else v = csub(v, cmul(L[i][k], z[k]));
+            v = cx_msub(v, L[i][k], z[k]);
         }
         z[i] = cscale(v, invd[i]);
     }
@@ -256,8 +255,7 @@ __device__ __forceinline__ bool blast_solve_gram(const cx<R> (&A)[NT][NT], R nv,
         C v = z[i];
 #pragma unroll
         for (int k = i + 1; k < NT; ++k) {
-            if constexpr (sizeof(R) == 4) v = cx_msub(v, mk<R>(L[k][i].x, -L[k][i].y), z[k]);
-            else v = csub(v, cmul(cconj(L[k][i]), z[k]));
+            v = cx_msub(v, mk<R>(L[k][i].x, -L[k][i].y), z[k]);
         }
         z[i] = cscale(v, invd[i]);
     }

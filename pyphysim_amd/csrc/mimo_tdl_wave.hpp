@@ -113,7 +113,7 @@ template <int KO, bool ASM = true> __device__ __forceinline__ void chan_step(dou
         g.x = fma(g.x, xx, cc[mm].x);
         g.y = fma(g.y, xx, cc[mm].y);
     }
-    y = cfma(g, xv, y);
+    y = cfma4(g, xv, y);
 }
 
 // T, N: arithmetic, fft_size.  NT x NR: the geometry (NR wavefronts).  KT: polynomial order of the taps, compile time (> 0: the
@@ -369,7 +369,7 @@ __global__ __launch_bounds__(64 * NR, WPS) void k_run_mimo_ofdm_tdl_wave(MimoTdl
                                     }
                                 }
 #pragma unroll
-                                for (int c = 0; c < CH; ++c) y[C0 + c0 + c] = cfma(g[c], buf[c0 + c], y[C0 + c0 + c]);
+                                for (int c = 0; c < CH; ++c) y[C0 + c0 + c] = cfma4(g[c], buf[c0 + c], y[C0 + c0 + c]);
                             }
                         }
                     };
@@ -515,7 +515,7 @@ __global__ __launch_bounds__(64 * NR, WPS) void k_run_mimo_ofdm_tdl_wave(MimoTdl
                             for (int a = 0; a < NT; ++a) {
                                 const cx<T> m = s_mean[(tap * NR + r) * NT + a];
                                 if constexpr (sizeof(T) == 4) uc[a] = from_pk(pk_cfma(to_pk(m), to_pk(Wt[pos]), to_pk(uc[a])));
-                                else uc[a] = cfma(m, Wt[pos], uc[a]);
+                                else uc[a] = cfma4(m, Wt[pos], uc[a]);
                             }
                         };
 #pragma unroll
@@ -543,7 +543,7 @@ __global__ __launch_bounds__(64 * NR, WPS) void k_run_mimo_ofdm_tdl_wave(MimoTdl
                             for (int a = 0; a < NT; ++a) {
                                 const cx<T> m = s_mean[(s * NR + r) * NT + a];
                                 if constexpr (sizeof(T) == 4 && !(ABL & 128)) u[0][a] = from_pk(pk_cfma(to_pk(m), to_pk(Wt[s]), to_pk(u[0][a])));
-                                else u[0][a] = cfma(m, Wt[s], u[0][a]);
+                                else u[0][a] = cfma4(m, Wt[s], u[0][a]);
                             }
                         } else {
                             // two bins per lane, complex128: t = mean x twiddle once, H(f0) += t, H(f0 + N / 2) += (-1)^d t -- no

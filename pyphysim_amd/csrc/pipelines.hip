@@ -611,8 +611,8 @@ __global__ __launch_bounds__(kPipeBlock, sizeof(T) == 4 ? 3 : 1) void k_run_mimo
                     }
 #pragma unroll
                     for (int a = 0; a < NA; ++a) {
-                        z0 = cfma(H[r][a], x0[a], z0);
-                        z1 = cfma(H[r][a], x1[a], z1);
+                        z0 = cfma4(H[r][a], x0[a], z0);
+                        z1 = cfma4(H[r][a], x1[a], z1);
                     }
                     s_x[r * N + q0] = z0;
                     s_x[r * N + q1] = z1;
@@ -640,7 +640,7 @@ __global__ __launch_bounds__(kPipeBlock, sizeof(T) == 4 ? 3 : 1) void k_run_mimo
                 for (int a = 0; a < NA; ++a) {
                     est[a] = mk<T>(0, 0);
 #pragma unroll
-                    for (int r = 0; r < NA; ++r) est[a] = cfma(G[a][r], y[r], est[a]);
+                    for (int r = 0; r < NA; ++r) est[a] = cfma4(G[a][r], y[r], est[a]);
                 }
                 if (mp.method == MCLE_DEMOD_QAM_SLICER) {
 #pragma unroll
@@ -891,7 +891,7 @@ __global__ __launch_bounds__(BLOCK) void k_run_ofdm_tdl(TdlParams pp, ModemParam
             for (int d = tid; d < U; d += BLOCK) {
                 const int bin = ofdm_bin(d, N, U);
                 cx<T> h = mk<T>(0, 0);
-                for (int i = 0; i < S; ++i) h = cfma(s_mean[i], s_tw[(bin * pp.tap_delay[i]) & (N - 1)], h);
+                for (int i = 0; i < S; ++i) h = cfma4(s_mean[i], s_tw[(bin * pp.tap_delay[i]) & (N - 1)], h);
                 const cx<T> eq = cdivide(cscale(s_y[fft_pos_of_index<N>(bin)], rx_scale), h);
                 const unsigned x = (unsigned)((int)s_idx[d] ^ demod_one(mp, s_table, s_grid, eq));
                 se += (x != 0u);

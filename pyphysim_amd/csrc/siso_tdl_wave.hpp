@@ -236,7 +236,7 @@ __global__ __launch_bounds__(64 * (siso_wave_nwv<T, N>()), WPS) void k_run_ofdm_
                             g.y = fma(g.y, xx, cm.y);
                         }
                     }
-                    y[c] = cfma(g, xv, y[c]);
+                    y[c] = cfma4(g, xv, y[c]);
                 }
             }
             // ---- noise: sample sym0 + cp + m of the NOISE stream ----
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(64 * (siso_wave_nwv<T, N>()), WPS) void k_run_ofdm_
                 for (int s = 0; s < kWaveMaxTaps; ++s) {
                     if (s >= S) break;
 #pragma unroll
-                    for (int j = 0; j < GRP; ++j) h[j] = cfma(mean[s], s_twk[(GRP * half + j) * kWaveMaxTaps + s], h[j]);
+                    for (int j = 0; j < GRP; ++j) h[j] = cfma4(mean[s], s_twk[(GRP * half + j) * kWaveMaxTaps + s], h[j]);
                 }
 #pragma unroll
                 for (int j = 0; j < GRP; ++j) {

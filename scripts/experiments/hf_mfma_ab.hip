@@ -1,7 +1,8 @@
 // hf_mfma_ab.hip -- A/B of the frequency-response stage of the frequency-selective MIMO-OFDM link (f1) in complex64:
 // H(f)[r][a] = sum_s mean[s][r][a] w^(f d_s) for 1024 bins, 16 entries, 5 taps, as
 //   V   the product's form (csrc/mimo_tdl_wave.hpp): a lane owns the bins f0, f0 + 512; per entry and tap ONE complex multiply-add
-//       (two v_pk_fma_f32) into the tap's delay class (d even / odd), a butterfly behind the loop;
+//       (two v_pk_fma_f32) into the tap's delay class (d even / odd; host-sorted class positions, two straight loops), a butterfly
+//       behind the loops;
 //   M0  the same contraction on the matrix cores: per 16 values of f0 a [16 x K] x [K x 32] real product per delay class
 //       (v_mfma_f32_16x16x4_f32: K = 6 -> 8 for the even delays, 4 for the odd ones: six instructions per 32 bins), results left
 //       in the accumulator layout (16 lanes x 4 bins per column);
@@ -49,11 +50,12 @@ __global__ __launch_bounds__(256, 3) void k_valu(Taps tp, const float2* __restri
         make_means(s_mean, rl);
         for (int wi = w; wi < N / 128; wi += 4) {
             const int f0 = lane + 64 * wi;
-            pk2 Wt[S];
+            pk2 We[4], Wo[4];                                                   // the product's class positions: even delays, odd delays
 #pragma unroll
-            for (int s = 0; s < S; ++s) {
-                const float2 t = g_tw[(f0 * tp.dly[s]) & (N - 1)];
-                Wt[s] = (pk2){t.x, t.y};
+            for (int k = 0; k < 4; ++k) {
+                const float2 te = g_tw[(f0 * tp.dly[tp.ev[k]]) & (N - 1)], to = g_tw[(f0 * tp.dly[tp.od[k]]) & (N - 1)];
+                We[k] = k < tp.ne ? (pk2){te.x, te.y} : (pk2){0, 0};
+                Wo[k] = k < tp.no ? (pk2){to.x, to.y} : (pk2){0, 0};
             }
 #pragma unroll
             for (int r = 0; r < NR; ++r) {
@@ -61,16 +63,16 @@ __global__ __launch_bounds__(256, 3) void k_valu(Taps tp, const float2* __restri
 #pragma unroll
                 for (int a = 0; a < NT; ++a) u[0][a] = u[1][a] = (pk2){0, 0};
 #pragma unroll
-                for (int s = 0; s < S; ++s) {
-                    int dl = tp.dly[s];
-                    asm volatile("" : "+s"(dl));
-                    if (dl & 1) {
+                for (int k = 0; k < 4; ++k) {
+                    if (k >= tp.ne) break;
 #pragma unroll
-                        for (int a = 0; a < NT; ++a) u[1][a] = pk_cfma(s_mean[(s * NR + r) * NT + a], Wt[s], u[1][a]);
-                    } else {
+                    for (int a = 0; a < NT; ++a) u[0][a] = pk_cfma(s_mean[(tp.ev[k] * NR + r) * NT + a], We[k], u[0][a]);
+                }
 #pragma unroll
-                        for (int a = 0; a < NT; ++a) u[0][a] = pk_cfma(s_mean[(s * NR + r) * NT + a], Wt[s], u[0][a]);
-                    }
+                for (int k = 0; k < 4; ++k) {
+                    if (k >= tp.no) break;
+#pragma unroll
+                    for (int a = 0; a < NT; ++a) u[1][a] = pk_cfma(s_mean[(tp.od[k] * NR + r) * NT + a], Wo[k], u[1][a]);
                 }
 #pragma unroll
                 for (int a = 0; a < NT; ++a) {
