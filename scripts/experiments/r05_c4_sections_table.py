@@ -22,7 +22,7 @@ SECTIONS = [
      256 * 62 / 64.0 + 4096 * 1 / 64.0, "256 Philox blocks x 62 instructions (10 rounds x (2 v_mad_u64_u32 + 2 v_bitop3) + counter set-up) + one byte extraction per symbol"),
     ("64", "transmit transform, passes A + B (4 antennas)", 5.2,
      4 * 256 * 4 * 28 / 64.0, "per antenna 4 radix-4 layers x 256 butterflies x (16 real adds + 3 complex products of 4) = 28 672 real operations"),
-    ("128", "noise: 2 048 Philox blocks + 4 096 Box-Muller samples", 4.35,
+    ("128", "noise: 2 048 Philox blocks + 4 096 Box-Muller samples (measured with the H x products out: variants 256 -> 384)", 4.35,
      2048 * 62 / 64.0 + 4096 * 59 / 64.0, "2 048 blocks x 62 + 4 096 samples x (47 f64 + 12 integer instructions, bm_f64.hpp)"),
     ("256", "H x products (16 complex multiply-adds per position)", 5.2,
      1024 * 16 * 4 / 64.0, "1 024 positions x 4 x 4 complex multiply-adds x 4 FMAs"),
@@ -34,8 +34,14 @@ SECTIONS = [
 rows, tot_ms, tot_valu, tot_min = [], 0.0, 0.0, 0.0
 for key, name, cost, vmin, how in SECTIONS:
     v = d[key]
-    dms = b_ms - v["kernel_ms_per_launch"]
-    dvalu = b_valu - v["per_realization"]["SQ_INSTS_VALU"]
+    ref_ms, ref_valu = b_ms, b_valu
+    if key == "128":
+        # the noise is measured next to the H x products compiled out (variants 256 and 384 = 128 + 256): with the noise ALONE
+        # compiled out the H x loop no longer has its draws to hide the LDS reads behind and the kernel gets slower, not faster
+        ref_ms, ref_valu = d["256"]["kernel_ms_per_launch"], d["256"]["per_realization"]["SQ_INSTS_VALU"]
+        v = d["384"]
+    dms = ref_ms - v["kernel_ms_per_launch"]
+    dvalu = ref_valu - v["per_realization"]["SQ_INSTS_VALU"]
     cyc = dms * CYC_PER_MS                                  # cycles per realization on one CU (each of its 4 SIMDs)
     per_simd = dvalu / 4.0
     rows.append(dict(section=name, ms=dms, valu=dvalu, cycles=cyc, cycles_per_inst=cyc / per_simd, issue_cost=cost,
@@ -66,12 +72,16 @@ lines += ["", "How to read it.",
           "  operation takes 5.1).  The remaining %.0f %% are the skeleton's waits (five workgroup barriers and the first LDS round trip of" % (100 * (1 - pred / (b_ms * CYC_PER_MS))),
           "  every stage per symbol, with one other workgroup per CU to cover them) and the transforms' LDS round trips (time / issue 1.25-1.33).",
           "* **instructions / minimum**: the draw ledger (noise + scatter: %.0f %% of the instructions) is AT its minimum -- it is the" % (100 * (rows[0]["valu"] + rows[2]["valu"]) / b_valu),
-          "  mcle-philox-v1 contract (Philox4x32-10 + an f64 Box-Muller within 3e-16 of NumPy's); the H x products at 1.38 carry their",
-          "  position bookkeeping and the lane swap of the paired draws; the decode at 1.5 carries the LDS address arithmetic of four",
-          "  planes and the byte packing; the transforms at 1.37-1.38 carry the radix-16 root products (14 %% of a pass: they buy two LDS",
-          "  round trips per transform, measured +9 %% in round 4) and the swizzled addresses.",
+          "  mcle-philox-v1 contract (Philox4x32-10 + an f64 Box-Muller within 3e-16 of NumPy's).  The first edition of this table (same",
+          "  script, the build of commit c07f5ff: 10.854 ms, 17 838 instructions) read 1.38 for the H x products and 1.52 for the decode, and",
+          "  THAT is what the table was for: the ISA of those two sections showed every complex128 multiply-add as v_mul + v_fma + v_add per",
+          "  component (the generic `cfma` keeps the product-then-add association) where two chained FMAs do -- `cfma4`, common.hpp:",
+          "  10.85 -> %.2f ms, %.0f instructions (profiles/r05/f64_chained_fma_ab.log).  What is left: the H x products (%.2f) carry" % (b_ms, b_valu, rows[3]["inst_over_min"]),
+          "  the lane swap of the paired draws (its ablation leaves the LDS reads and a move per product in, hence below 1); the decode at %.2f the LDS address arithmetic of four planes" % rows[5]["inst_over_min"],
+          "  and the byte packing; the transforms at %.2f the radix-16 root products (14 %% of a pass: they buy two LDS round trips per" % rows[1]["inst_over_min"],
+          "  transform, measured +9 % in round 4) and the swizzled addresses.",
           "* What would still move it: a third wavefront per SIMD (the 64 KiB of complex128 planes per realization allow two workgroups",
           "  per CU: a LDS-capacity bound, not a tuning choice) would cover most of the waits, i.e. <= %.0f %%; nothing in the table is a" % (100 * (1 - pred / (b_ms * CYC_PER_MS))),
-          "  factor.  Round 5 therefore stops here on this kernel (VERDICT r04 item 2, second branch)."]
+          "  factor any more."]
 open(os.path.join(REPO, "profiles", "r05", "c4_f64_section_table.md"), "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
