@@ -113,6 +113,29 @@ template <typename C, typename T> __host__ __device__ __forceinline__ C cscale(C
     a.y *= s;
     return a;
 }
+// 1 / d and (sqrt(a), 1 / sqrt(a)) for the complex128 SYMBOL LOOPS of the fused pipelines: the hardware estimates v_rcp_f64 /
+// v_rsq_f64 + Newton steps -- full precision to a rounding in 5 / 10 instructions, where the IEEE sequences the compiler emits for
+// 1.0 / d and sqrt(a) are 11 and ~15 (v_div_scale x 2, v_rcp, five FMAs, v_div_fmas, v_div_fixup).  Not for d = 0 / inf / subnormal
+// (the callers' pivots and channel gains are guarded or cannot be).
+#ifdef __HIPCC__
+__device__ __forceinline__ double rcp_newton(double d) {
+    double inv = __builtin_amdgcn_rcp(d);
+    inv = fma(fma(-d, inv, 1.0), inv, inv);
+    return fma(fma(-d, inv, 1.0), inv, inv);
+}
+__device__ __forceinline__ void sqrt_rsqrt_newton(double a, double& root, double& inv) {
+    const double y = __builtin_amdgcn_rsq(a);
+    double g = a * y, h = 0.5 * y;
+    double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    g = fma(fma(-g, g, a), h, g);
+    r = fma(-h, g, 0.5);
+    h = fma(h, r, h);
+    root = g;
+    inv = h + h;
+}
+#endif
 template <typename C> __host__ __device__ __forceinline__ C cdivide(C a, C b) {
     auto d = b.x * b.x + b.y * b.y;
     C r;

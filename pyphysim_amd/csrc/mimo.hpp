@@ -230,9 +230,11 @@ __device__ __forceinline__ bool blast_solve_gram(const cx<R> (&A)[NT][NT], R nv,
                 if constexpr (sizeof(R) == 4) {
                     invd[j] = __builtin_amdgcn_rsqf(a.x);
                     L[j][j] = mk<R>(a.x * invd[j], (R)0);
-                } else {
-                    L[j][j] = mk<R>(sqrt(a.x), (R)0);
-                    invd[j] = (R)1 / L[j][j].x;
+                } else {                                                    // sqrt and 1 / sqrt by Newton steps (common.hpp)
+                    double root, inv;
+                    sqrt_rsqrt_newton((double)a.x, root, inv);        // (a failed pivot yields NaNs the caller discards with `ok`)
+                    L[j][j] = mk<R>((R)root, (R)0);
+                    invd[j] = (R)inv;
                 }
             } else {
                 L[i][j] = cscale(a, invd[j]);

@@ -94,12 +94,14 @@ struct FlatParams {
 // (h s + z) / h, the flat-fading link followed by its one-tap equaliser (singleuser.py:130-151 and the notebooks' `/ h`).
 // f64 (parity instantiation): literally that.  f32: s + z conj(h) / |h|^2 with one v_rcp_f32 -- the same value to
 // rounding, a dozen instructions fewer per symbol (measured: 157 -> 145 VALU instructions per symbol row).
-// (complex128: ONE division -- the reciprocal of |h|^2 -- and two products instead of cdivide's two divisions: a dozen f64
-//  instructions fewer per symbol, the same value to a rounding, round 5)
+// (complex128, round 5: the same form as complex64 -- (h s + z) / h = s + z conj(h) / |h|^2, the product h s never formed -- with
+//  the reciprocal as v_rcp_f64 + two Newton steps (rcp_newton, common.hpp; the IEEE division sequence the compiler emits for
+//  1.0 / x is eleven instructions): 13 f64 instructions per symbol instead of 25, the value within a rounding of the reference's
+//  complex division)
 __device__ __forceinline__ double2 flat_equalised(double2 h, double2 s, double2 z) {
-    const double2 a = cadd(cmul(h, s), z);
-    const double inv = 1.0 / (h.x * h.x + h.y * h.y);
-    return mk<double>((a.x * h.x + a.y * h.y) * inv, (a.y * h.x - a.x * h.y) * inv);
+    const double d = fma(h.x, h.x, h.y * h.y);
+    const double inv = rcp_newton(d);
+    return mk<double>(fma(fma(z.x, h.x, z.y * h.y), inv, s.x), fma(fma(z.y, h.x, -(z.x * h.y)), inv, s.y));
 }
 __device__ __forceinline__ float2 flat_equalised(float2 h, float2 s, float2 z) {
     const float inv = __builtin_amdgcn_rcpf(fmaf(h.x, h.x, h.y * h.y));

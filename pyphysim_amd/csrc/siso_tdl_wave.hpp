@@ -334,8 +334,9 @@ __global__ __launch_bounds__(64 * (siso_wave_nwv<T, N>()), WPS) void k_run_ofdm_
                 }
 #pragma unroll
                 for (int j = 0; j < GRP; ++j) {
-                    if constexpr (sizeof(T) == 8) {
-                        eq[j] = cdivide(eq[j], h[j]);
+                    if constexpr (sizeof(T) == 8) {     // one Newton reciprocal (common.hpp) instead of cdivide's two IEEE divisions
+                        const T inv = (T)rcp_newton((double)fma(h[j].x, h[j].x, h[j].y * h[j].y));
+                        eq[j] = mk<T>(fma(eq[j].x, h[j].x, eq[j].y * h[j].y) * inv, fma(eq[j].y, h[j].x, -(eq[j].x * h[j].y)) * inv);
                     } else {                    // complex64: one reciprocal instead of two divisions
                         const T inv = __builtin_amdgcn_rcpf(h[j].x * h[j].x + h[j].y * h[j].y);
                         eq[j] = mk<T>((eq[j].x * h[j].x + eq[j].y * h[j].y) * inv, (eq[j].y * h[j].x - eq[j].x * h[j].y) * inv);
