@@ -411,7 +411,8 @@ typedef struct mcle_mimo_ofdm_cfg {     /* C4: apps/mimo/simulate_mimo.py:68-142
 
 typedef struct mcle_mimo_ofdm_tdl_cfg { /* TdlMimoChannel (fading.py:1290-1333) + per-antenna OFDM +
                                          * one Blast filter per used subcarrier (mimo.py:577-607) */
-    int32_t nt, nr;                     /* supported: nt == nr in {2, 4} */
+    int32_t nt, nr;                     /* fused: every 1 <= nt <= nr <= 4 at fft_size 256 .. 2048 with the taps inside the prefix
+                                         * (cp_size >= last delay <= min(256, fft_size / 2)); nt == nr in {2, 4} at 64 .. 2048 otherwise */
     int32_t fft_size, cp_size, num_used, n_ofdm_sym;
     int32_t demod_method;
     int32_t mmse;                       /* 1: MMSE with noise_var; 0: zero forcing */
@@ -490,10 +491,13 @@ int mcle_run_mimo_flat(mcle_ctx* ctx, int dtype, const mcle_mimo_flat_cfg* cfg, 
                        uint64_t first, uint64_t count, mcle_counters* d_counters,
                        uint32_t* d_sym_err, uint32_t* d_bit_err);
 
-/* Fused frequency-selective MIMO-OFDM.  Returns MCLE_E_UNSUPPORTED (and touches nothing) when the Doppler phase
- * across half an OFDM symbol is beyond the kernel's polynomial tap model: run the staged operators then.
- * Device memory: the context's scratch buffer grows to hold the fading records of one launch slice (<= 256 MiB + 25 %;
- * mcle_run_ofdm_tdl: <= 64 MiB); it is kept until the context is destroyed. */
+/* Fused frequency-selective MIMO-OFDM (round 5: one receive antenna per wavefront, csrc/mimo_tdl_wave.hpp; the workgroup-cooperative
+ * kernel of rounds 1-4 behind MCLE_OPT_MIMO_TDL_KERNEL = 1 and for square geometries outside the wavefront kernel's envelope).
+ * Returns MCLE_E_UNSUPPORTED (and touches nothing) when the Doppler phase across half an OFDM symbol is beyond the kernels'
+ * polynomial tap model, or for a rectangular geometry outside the envelope named at mcle_mimo_ofdm_tdl_cfg: run the staged operators
+ * then.  Device memory: the context's scratch buffer grows to hold the fading records of one launch slice -- 2.5 KiB per
+ * realization and symbol in complex64 at five taps of 4 x 4, 7.5 KiB in complex128, at most 4 GiB (+ 25 %) per slice
+ * (mcle_run_ofdm_tdl: at most 2 GiB) -- and is kept until the context is destroyed. */
 int mcle_run_mimo_ofdm_tdl(mcle_ctx* ctx, int dtype, const mcle_mimo_ofdm_tdl_cfg* cfg, uint64_t seed,
                            uint64_t first, uint64_t count, mcle_counters* d_counters,
                            uint32_t* d_sym_err, uint32_t* d_bit_err);
