@@ -71,6 +71,12 @@ CASES = [
     (5, dict(mod="qam", M=16, fft_size=2048, nt=2, nr=2, snr_db=14.0, num_used=1200, cp_size=144, Fd=5.0)),
     (5, dict(mod="qam", M=64, fft_size=2048, snr_db=25.0, cp_size=17)),
     (5, dict(mod="qam", M=16, fft_size=2048, nt=2, nr=4, snr_db=12.0, n_ofdm_sym=2)),
+    # the decode's delay classes (complex64: host-sorted class positions, mimo_tdl.hpp cls_code): one class empty, one class full
+    (6, dict(mod="qam", M=16, snr_db=22.0, tap_delays_samples=(0, 2, 4, 6, 8), tap_powers_dB=(0.0, -2.0, -4.0, -6.0, -8.0))),
+    (6, dict(mod="qam", M=16, nt=2, nr=4, snr_db=18.0, tap_delays_samples=(1, 3, 5, 7, 9, 11), cp_size=12,
+             tap_powers_dB=(0.0, -1.0, -2.0, -3.0, -4.0, -5.0))),
+    (6, dict(mod="qam", M=64, snr_db=26.0, cp_size=20, tap_delays_samples=(1, 2, 4, 6, 8, 10, 12, 14),   # seven even, one odd
+             tap_powers_dB=(0.0, -1.0, -2.0, -3.0, -4.0, -5.0, -6.0, -7.0))),
 ]
 
 
