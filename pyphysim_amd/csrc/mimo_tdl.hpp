@@ -2,6 +2,7 @@
 // the kernel that turns a symbol's Jakes rays into tap polynomials (pipeline_mimo_tdl.hip: the workgroup-cooperative kernel of
 // rounds 1-4; mimo_tdl_wave.hpp: one receive antenna per wavefront, round 5).
 #pragma once
+#include "bm_f64.hpp"
 #include "common.hpp"
 #include "jakes.hpp"
 #include "philox.hpp"
@@ -73,7 +74,7 @@ __global__ __launch_bounds__(256) void k_mimo_tdl_symbol_polys(MimoTdlParams pp,
         T er, ei;
         if constexpr (sizeof(T) == 8) {
             double sn, cs;
-            sincos(two_pi * fr, &sn, &cs);
+            bm_sincos_rad(two_pi * fr, cs, sn);                            // polynomial form (bm_f64.hpp): a third of the library's instructions
             er = cs;
             ei = sn;
         } else {
