@@ -88,34 +88,6 @@ template <int N, int BQ> __host__ __device__ __forceinline__ int mimo_wave_p0(in
     }
 }
 
-// One (tap, transmit antenna, sample) step of the channel: g = Horner(cc, xx) (a polynomial with complex coefficients in a real
-// abscissa), y += g xv.  complex64: four v_pk_fma_f32 -- Horner one per order on the (re, im) pair, the complex multiply-add two
-// (pkcx.hpp: op_sel / neg modifiers swap and negate the halves); written on clang vector types and explicit instructions because
-// the backend does not form the packed Horner from scalar FMAs with wave-uniform coefficients (4 v_fma + 2 v_pk_fma + 3 v_mov per step).
-template <int KO, bool ASM = true> __device__ __forceinline__ void chan_step(float2& y, const float2 (&cc)[KO + 1], float xx, float2 xv) {
-    pk2 g = {cc[KO].x, cc[KO].y};
-    const pk2 x2 = {xx, xx};
-#pragma unroll
-    for (int mm = KO - 1; mm >= 0; --mm) g = __builtin_elementwise_fma(g, x2, (pk2){cc[mm].x, cc[mm].y});
-    if constexpr (ASM) {
-        y = from_pk(pk_cfma(g, to_pk(xv), to_pk(y)));
-    } else {
-        pk2 acc = {y.x, y.y};
-        acc = __builtin_elementwise_fma((pk2){g.x, g.x}, (pk2){xv.x, xv.y}, acc);
-        acc = __builtin_elementwise_fma((pk2){-g.y, g.y}, (pk2){xv.y, xv.x}, acc);
-        y = from_pk(acc);
-    }
-}
-template <int KO, bool ASM = true> __device__ __forceinline__ void chan_step(double2& y, const double2 (&cc)[KO + 1], double xx, double2 xv) {
-    double2 g = cc[KO];
-#pragma unroll
-    for (int mm = KO - 1; mm >= 0; --mm) {
-        g.x = fma(g.x, xx, cc[mm].x);
-        g.y = fma(g.y, xx, cc[mm].y);
-    }
-    y = cfma4(g, xv, y);
-}
-
 // T, N: arithmetic, fft_size.  NT x NR: the geometry (NR wavefronts).  KT: polynomial order of the taps, compile time (> 0: the
 // coefficients parked in (KT + 2) / 2 registers) or 0 = run time (coefficients fetched from the record by wave-uniform loads).
 // BQ: subcarriers per decode work item (1, 2, 4).  WPS: wavefronts per SIMD the registers are bounded for.

@@ -38,4 +38,32 @@ __device__ __forceinline__ pk2 pk_cfma_conj(pk2 a, pk2 b, pk2 acc) {
     return acc;
 }
 
+// One (tap, [transmit antenna,] sample) step of the delay line of the wavefront kernels (siso_tdl_wave.hpp, mimo_tdl_wave.hpp): g = Horner(cc, xx) (a polynomial with complex coefficients in a real
+// abscissa), y += g xv.  complex64: four v_pk_fma_f32 -- Horner one per order on the (re, im) pair, the complex multiply-add two
+// (pkcx.hpp: op_sel / neg modifiers swap and negate the halves); written on clang vector types and explicit instructions because
+// the backend does not form the packed Horner from scalar FMAs with wave-uniform coefficients (4 v_fma + 2 v_pk_fma + 3 v_mov per step).
+template <int KO, bool ASM = true> __device__ __forceinline__ void chan_step(float2& y, const float2 (&cc)[KO + 1], float xx, float2 xv) {
+    pk2 g = {cc[KO].x, cc[KO].y};
+    const pk2 x2 = {xx, xx};
+#pragma unroll
+    for (int mm = KO - 1; mm >= 0; --mm) g = __builtin_elementwise_fma(g, x2, (pk2){cc[mm].x, cc[mm].y});
+    if constexpr (ASM) {
+        y = from_pk(pk_cfma(g, to_pk(xv), to_pk(y)));
+    } else {
+        pk2 acc = {y.x, y.y};
+        acc = __builtin_elementwise_fma((pk2){g.x, g.x}, (pk2){xv.x, xv.y}, acc);
+        acc = __builtin_elementwise_fma((pk2){-g.y, g.y}, (pk2){xv.y, xv.x}, acc);
+        y = from_pk(acc);
+    }
+}
+template <int KO, bool ASM = true> __device__ __forceinline__ void chan_step(double2& y, const double2 (&cc)[KO + 1], double xx, double2 xv) {
+    double2 g = cc[KO];
+#pragma unroll
+    for (int mm = KO - 1; mm >= 0; --mm) {
+        g.x = fma(g.x, xx, cc[mm].x);
+        g.y = fma(g.y, xx, cc[mm].y);
+    }
+    y = cfma4(g, xv, y);
+}
+
 }  // namespace mcle

@@ -9,6 +9,7 @@
 #include "modem.hpp"
 #include "philox.hpp"
 #include "pipe_common.hpp"
+#include "pkcx.hpp"
 #include "siso_tdl.hpp"
 #include "totals.hpp"
 #include "wave_lanes.hpp"
@@ -221,13 +222,9 @@ __global__ __launch_bounds__(64 * (siso_wave_nwv<T, N>()), WPS) void k_run_ofdm_
                     const cx<T> xv = mk<T>(xdr[64 * c], xdi[64 * c]);
                     const T xx = x0 + (T)(64 * c);                          // exact
                     cx<T> g;
-                    if constexpr (KT > 0) {
-                        g = cc[KT];
-#pragma unroll
-                        for (int mm = KT - 1; mm >= 0; --mm) {
-                            g.x = fma(g.x, xx, cc[mm].x);
-                            g.y = fma(g.y, xx, cc[mm].y);
-                        }
+                    if constexpr (KT > 0) {                                 // Horner + multiply-add: packed in complex64 (pkcx.hpp)
+                        chan_step<KT>(y[c], cc, xx, xv);
+                        continue;
                     } else {
                         g = rec_at(s * (K + 1) + K);
                         for (int mm = K - 1; mm >= 0; --mm) {
