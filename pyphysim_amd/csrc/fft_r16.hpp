@@ -7,6 +7,7 @@
 
 #include "common.hpp"
 #include "fft.hpp"
+#include "pkcx.hpp"
 
 namespace mcle {
 
@@ -33,7 +34,11 @@ template <typename T> struct CxOps {
         if (CONJ) w.y = -w.y;
         return cmul(a, w);
     }
-    static __device__ __forceinline__ C fma(C h, C x, C acc) { return cfma4(h, x, acc); }    // four chained FMAs (common.hpp)
+    // acc + h x: four chained FMAs (common.hpp), or -- PK, complex64 only -- two packed FMAs (pkcx.hpp)
+    template <bool PK = false> static __device__ __forceinline__ C fma(C h, C x, C acc) {
+        if constexpr (PK && sizeof(T) == 4) return from_pk(pk_cfma(to_pk(h), to_pk(x), to_pk(acc)));
+        else return cfma4(h, x, acc);
+    }
     // y0 = (u0 + u2) + (u1 + u3), y2 = (u0 + u2) - (u1 + u3), y1 / y3 = (u0 - u2) +/- r (u1 - u3), r = -i (forward), +i (INV)
     template <bool INV> static __device__ __forceinline__ void bfly4(C u0, C u1, C u2, C u3, C& y0, C& y1, C& y2, C& y3) {
         const C a0 = cadd(u0, u2), a1 = csub(u0, u2), a2 = cadd(u1, u3), a3 = rot<T, INV>(csub(u1, u3));

@@ -177,6 +177,13 @@ __global__ __launch_bounds__(64) void k_mimo_flat_setup(int scheme, int nt, int 
     rec[2 * kFlatMax * kFlatMax] = mk<T>((T)st.aux, st.ok ? (T)1 : (T)0);
 }
 
+// acc + a b in the symbol walk: complex64 as before (cfma(float2): four chained FMAs), complex128 chained as well (cfma4; the generic
+// cfma keeps the product-then-add association, six operations)
+template <typename C> __device__ __forceinline__ C mac(C a, C b, C acc) {
+    if constexpr (sizeof(a.x) == 8) return cfma4(a, b, acc);
+    else return cfma(a, b, acc);
+}
+
 template <typename T>
 __global__ __launch_bounds__(64, sizeof(T) == 4 ? MCLE_F32_WALK_WAVES : 2) void k_mimo_flat_link(
     ModemParams<T> mp, int scheme, int nt, int nr, int n_symbols, double noise_var, uint64_t seed, uint64_t first,
@@ -244,13 +251,13 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? MCLE_F32_WALK_WAVES : 2) void 
                                 cx<T> y0, y1;
                                 cn_pair_lds(rng, STREAM_NOISE, ((uint32_t)r * (uint32_t)n_symbols + 2u * (uint32_t)p) >> 1, sigma,
                                             y0, y1, s_bm);
-                                y0 = cfma(A[r][0], s0, y0);
-                                y0 = cfma(A[r][1], s1, y0);
-                                y1 = cfma(A[r][0], mk<T>(-s1.x, s1.y), y1);
-                                y1 = cfma(A[r][1], cconj(s0), y1);
-                                o0 = cfma(cconj(A[r][0]), y0, o0);
-                                o0 = cfma(A[r][1], cconj(y1), o0);
-                                o1 = cfma(cconj(A[r][1]), y0, o1);
+                                y0 = mac(A[r][0], s0, y0);
+                                y0 = mac(A[r][1], s1, y0);
+                                y1 = mac(A[r][0], mk<T>(-s1.x, s1.y), y1);
+                                y1 = mac(A[r][1], cconj(s0), y1);
+                                o0 = mac(cconj(A[r][0]), y0, o0);
+                                o0 = mac(A[r][1], cconj(y1), o0);
+                                o1 = mac(cconj(A[r][1]), y0, o1);
                                 o1 = csub(o1, cmul(A[r][0], cconj(y1)));
                             }
                         const unsigned x0 = (unsigned)(tx0 ^ demod_one(mp, s_table, s_grid, cscale(o0, scale)));
@@ -272,8 +279,8 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? MCLE_F32_WALK_WAVES : 2) void 
                         if (l < layers) {
 #pragma unroll
                             for (int c = 0; c < kFlatMax; ++c) {
-                                est[l] = cfma(A[l][c], d[c], est[l]);      // entries beyond the layers / rows are zero
-                                est[l] = cfma(G[l][c], nz[c], est[l]);
+                                est[l] = mac(A[l][c], d[c], est[l]);      // entries beyond the layers / rows are zero
+                                est[l] = mac(G[l][c], nz[c], est[l]);
                             }
                         }
                     }

@@ -118,6 +118,10 @@ __global__ __launch_bounds__((N / 4) * (NR / AH), WPS) void k_run_mimo_ofdm_plan
     static_assert(NT >= 1 && NT <= NR && NR % AH == 0 && N >= 256, "geometry");
     constexpr int kRec = d64_rec<NT, NR>(), NB = SH::NB, N4 = SH::N4;
     constexpr int TB = NB * (NR / AH), NW = TB / 64;                        // threads, wavefronts per workgroup
+    // complex64: the H x and G y multiply-adds as two packed FMAs each (pk_cfma) instead of four scalar ones -- level at the benchmark
+    // geometry WITHOUT its 32 spilled registers (123 registers), +21 % at 512 4x4, +38 % at 2048 4x4, -8 % at 256 4x4, which keeps the
+    // scalar form (profiles/r05/c4_f32_packed_mac_ab.log)
+    constexpr bool PKMAC = sizeof(T) == 4 && !(N == 256 && NT == 4);
     constexpr bool R16 = (VAR & 4) != 0;                                    // radix-16 passes, one transform per wavefront
     constexpr bool FUSED = R16 && (VAR & 8) != 0;                           // ... with pass C, the channel and pass C' as one stage
     constexpr bool EXACT = R16 && (VAR & 16) != 0;                          // ... with every layer-1 twiddle from the table
@@ -299,7 +303,7 @@ __global__ __launch_bounds__((N / 4) * (NR / AH), WPS) void k_run_mimo_ofdm_plan
                             z = cadd(z, x[r % NT][d]);
                         } else {
 #pragma unroll
-                            for (int a = 0; a < NT; ++a) z = CxOps<T>::fma(s_H[r * NT + a], x[a][d], z);
+                            for (int a = 0; a < NT; ++a) z = CxOps<T>::template fma<PKMAC>(s_H[r * NT + a], x[a][d], z);
                         }
                         y[r][d] = z;
                     }
@@ -383,8 +387,8 @@ __global__ __launch_bounds__((N / 4) * (NR / AH), WPS) void k_run_mimo_ofdm_plan
 #pragma unroll
                         for (int a = 0; a < NT; ++a) {
                             const cx<T> h = s_H[r * NT + a];       // wave-uniform address: an LDS broadcast
-                            z0 = CxOps<T>::fma(h, x0[a], z0);
-                            z1 = CxOps<T>::fma(h, x1[a], z1);
+                            z0 = CxOps<T>::template fma<PKMAC>(h, x0[a], z0);
+                            z1 = CxOps<T>::template fma<PKMAC>(h, x1[a], z1);
                         }
                         if constexpr (VAR & 1) {
                             asm volatile("" ::"v"(z0.x), "v"(z0.y), "v"(z1.x), "v"(z1.y));
@@ -456,7 +460,7 @@ __global__ __launch_bounds__((N / 4) * (NR / AH), WPS) void k_run_mimo_ofdm_plan
                         for (int a = 0; a < NT; ++a) {
                             est[a] = mk<T>(0, 0);
 #pragma unroll
-                            for (int r = 0; r < NR; ++r) est[a] = CxOps<T>::fma(s_G[a * NR + r], y[r], est[a]);
+                            for (int r = 0; r < NR; ++r) est[a] = CxOps<T>::template fma<PKMAC>(s_G[a * NR + r], y[r], est[a]);
                         }
                         if (mp.method != MCLE_DEMOD_QAM_SLICER && mp.grid.G > 0) {
                             demod_multi_cert(mp, est, dec, [&](int (&d_)[NT]) {
@@ -482,7 +486,7 @@ __global__ __launch_bounds__((N / 4) * (NR / AH), WPS) void k_run_mimo_ofdm_plan
                         for (int a = 0; a < NT; ++a) {
                             cx<T> est = mk<T>(0, 0);
 #pragma unroll
-                            for (int r = 0; r < NR; ++r) est = CxOps<T>::fma(s_G[a * NR + r], y[r], est);
+                            for (int r = 0; r < NR; ++r) est = CxOps<T>::template fma<PKMAC>(s_G[a * NR + r], y[r], est);
                             const int dec = demod_one<T>(mp, s_table, s_grid, est);
                             const unsigned x = ((sent >> (8 * a)) & 0xFFu) ^ (unsigned)dec;
                             se += (x != 0u);
