@@ -168,15 +168,16 @@ __global__ __launch_bounds__(64 * NR, WPS) void k_run_mimo_ofdm_tdl_wave(MimoTdl
         if (lane == s) dlyv = dly[s];
     }
     [[maybe_unused]] int clsv = -1;                                          // lane p < 8: class position p of the decode (mimo_tdl.hpp)
-    if constexpr (BQ == 2 && sizeof(T) == 4) {
+    if constexpr (BQ == 2) {
 #pragma unroll
         for (int p = 0; p < 8; ++p)
             if (lane == p) clsv = pp.cls_code[p];
     }
     [[maybe_unused]] R16Tw64<T> tw16;
-    // H(f) at two bins per lane by delay-class positions (complex64: +3 % at 1024 4x4, +14 % where one bin per lane takes the same
-    // multiply-add form; complex128 gains nothing and pays five spilled set-up registers: profiles/r05/f1_hf_class_ab.log)
-    constexpr bool CLS2 = BQ == 2 && sizeof(T) == 4 && !(ABL & 256);
+    // H(f) at two bins per lane by delay-class positions: complex64 +3 % at 1024 4x4, complex128 +2.5 % (once its multiply-add was the
+    // chained cfma4: level before, and two set-up registers spilled at 4x4 -- stored once, reloaded once per symbol);
+    // profiles/r05/f1_hf_class_ab.log
+    constexpr bool CLS2 = BQ == 2 && !(ABL & 256);
     constexpr int REP4 = N / 256;
     // radix-4 sizes, complex64: the lane's stage twiddles in registers at 256 (24 registers; the 48 of 512 spilled 36 registers
     // next to the Gram accumulators of the decode)
@@ -518,8 +519,8 @@ __global__ __launch_bounds__(64 * NR, WPS) void k_run_mimo_ofdm_tdl_wave(MimoTdl
                                 else u[0][a] = cfma4(m, Wt[s], u[0][a]);
                             }
                         } else {
-                            // two bins per lane, complex128: t = mean x twiddle once, H(f0) += t, H(f0 + N / 2) += (-1)^d t -- no
-                            // select, no branch (the class-position form above is no faster in complex128)
+                            // two bins per lane, the sign form (experiments: ABL & 256): t = mean x twiddle once, H(f0) += t,
+                            // H(f0 + N / 2) += (-1)^d t -- no select, no branch
                             cx<T> t[NT];
 #pragma unroll
                             for (int a = 0; a < NT; ++a) {

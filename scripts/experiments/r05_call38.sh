@@ -1,0 +1,17 @@
+#!/bin/bash
+# round 5, call 38: f1 complex128 with H(f) by delay-class positions (one chained multiply-add = four FMAs per entry and tap instead
+# of the sign form's eight operations) -- level in call 27, when the class form still used the generic six-operation multiply-add --
+# libmcle.so against the previous build; shapes; the f1 suites
+export TMPDIR=/tmp
+L=$PWD/pyphysim_amd/csrc
+one() { lib=$1; tag=$2; shift 2
+  MCLE_LIBRARY=$L/$lib timeout 300 python bench.py --steps 8 --warmup 2 --no-cpu --pmc off --single-demod "$@" 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$lib $tag', '%.4g /s' % d['value'], '%.3f ms' % d['roofline']['kernel_ms_per_launch'], 'ser %.7f' % d['ser'])"; }
+for round in 1 2; do
+  for lib in libmcle_prev.so libmcle.so; do
+    one $lib "f1 f64" --config f1 --dtype f64 --batch 98304
+  done
+done
+for lib in libmcle_prev.so libmcle.so; do MCLE_LIBRARY=$L/$lib timeout 300 python scripts/experiments/r05_f1_shapes.py $lib | grep f64; done
+timeout 1200 python -m pytest tests/test_gpu_mimo_tdl_wave.py tests/test_gpu_fuzz.py tests/test_gpu_simulators.py -q --timeout=900 2>&1 | tail -3
