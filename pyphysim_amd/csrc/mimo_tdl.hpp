@@ -65,10 +65,44 @@ __global__ __launch_bounds__(256) void k_mimo_tdl_symbol_polys(MimoTdlParams pp,
     T ar[kMaxOrder + 1], ai[kMaxOrder + 1];
 #pragma unroll
     for (int m = 0; m <= kMaxOrder; ++m) ar[m] = ai[m] = 0;
+    // PHASE draws: uniform i of the stream is word i % 4 of block i / 4, and the four processes p = 4 g .. 4 g + 3 of a quad of
+    // lanes read the four words of the SAME blocks (PS a multiple of 4).  Each lane of the quad computes ONE of the four blocks
+    // a pair of rays needs -- (phi, psi) of rays l and l + 1 -- and the words travel by DPP quad broadcasts: a quarter of the
+    // Philox work of one block per uniform (the ledger is untouched: the same words reach the same processes).
+    const bool quad = (PS & 3) == 0;
+    const int ql = (int)(threadIdx.x & 3);                                  // = p % 4 (256 and every record boundary are multiples of 4)
+    double u_phi_next = 0.0, u_psi_next = 0.0;
     for (int l = 0; l < L; ++l) {
         const uint64_t rq = (uint64_t)l * PS + p;                          // PHASE-stream index of phi
-        const double psi_t = uniform_at(rng, STREAM_PHASE, (uint64_t)L * PS + rq);
-        const double w = pp.Fd * cospi(2.0 * uniform_at(rng, STREAM_PHASE, rq));   // Hz; cos(phi), phi = 2 pi u
+        double u_phi, u_psi;
+        if (quad && (l & 1) == 0 && l + 1 < L) {
+            const uint64_t mine = (uint64_t)(l + (ql >> 1)) * PS + p + ((ql & 1) ? (uint64_t)L * PS : 0ull);
+            const Words4 b = rng.block(STREAM_PHASE, (uint32_t)(mine >> 2));
+            uint32_t got[4];                                               // word ql of the block lane j of the quad computed
+#define MCLE_QUAD_WORD(J)                                                                                                     \
+    {                                                                                                                         \
+        uint32_t v = 0;                                                                                                       \
+        _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                                                       \
+            const uint32_t t = (uint32_t)__builtin_amdgcn_mov_dpp((int)b.w[k], (J) * 0x55, 0xF, 0xF, true); /* quad_perm [J, J, J, J] */ \
+            v = ql == k ? t : v;                                                                                              \
+        }                                                                                                                     \
+        got[J] = v;                                                                                                           \
+    }
+            MCLE_QUAD_WORD(0) MCLE_QUAD_WORD(1) MCLE_QUAD_WORD(2) MCLE_QUAD_WORD(3)
+#undef MCLE_QUAD_WORD
+            u_phi = (double)got[0] * 0x1p-32;
+            u_psi = (double)got[1] * 0x1p-32;
+            u_phi_next = (double)got[2] * 0x1p-32;
+            u_psi_next = (double)got[3] * 0x1p-32;
+        } else if (quad && (l & 1) == 1) {
+            u_phi = u_phi_next;
+            u_psi = u_psi_next;
+        } else {
+            u_psi = uniform_at(rng, STREAM_PHASE, (uint64_t)L * PS + rq);
+            u_phi = uniform_at(rng, STREAM_PHASE, rq);
+        }
+        const double psi_t = u_psi;
+        const double w = pp.Fd * cospi(2.0 * u_phi);                       // Hz; cos(phi), phi = 2 pi u
         const double ph = fma(w, tc, psi_t);                               // turns
         const double fr = __builtin_amdgcn_fract(ph);
         T er, ei;
