@@ -18,7 +18,7 @@ SEED = 515151
 
 SHAPES = [(256, 2, 2), (256, 4, 4), (512, 2, 2), (512, 4, 4), (1024, 2, 2), (1024, 4, 4), (2048, 2, 2), (2048, 4, 4),
           (1024, 2, 4), (256, 2, 4), (512, 1, 2), (1024, 3, 4), (1024, 1, 4), (2048, 1, 4), (256, 2, 3), (1024, 3, 3), (512, 1, 3),
-          (2048, 3, 4)]
+          (2048, 3, 4), (2048, 2, 4)]
 SHAPE_CASES = [dict(mod="qam", M=64, snr_db=25.0),
                dict(mod="qam", M=16, snr_db=17.0, used_frac=0.6, n_ofdm_sym=2, cp_size=7, mmse=False),   # partial band, odd CP, ZF
                dict(mod="psk", M=8, snr_db=13.0, n_ofdm_sym=2, cp_size=33)]                               # candidate grid only
