@@ -646,15 +646,16 @@ static int run_mimo_ofdm_planar_t(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, 
     // 128-register bound that the complex128 form does not meet (36 / 22 spilled registers at 4 x 4 / 3 x 4, complex64 13 / 0).  Four
     // antennas per thread (512 threads, 256 registers, nothing spilled) is the default where it is the faster form -- 4 x 4 in both
     // arithmetics (+7 % / +4 %) and 3 x 4 in complex64 (+3 %); 3 x 4 in complex128 keeps the 1 024-thread form WITH its spills (7.38
-    // against 7.70 ms per 65 536 realizations), and so does 2 x 4 in complex128 with 12 (5.75 against 6.74 ms; complex64 2 x 4: 2.97 against
-    // 3.71 ms for the 512-thread form): profiles/r05/planar_2048_ab.log.  MCLE_OPT_F64_THREADS: 512 / 1024 force either.
-    if (n == 2048 && nr == 4 && nt >= 2) {
+    // against 7.70 ms per 65 536 realizations), and so does 2 x 4 in complex128 with 12 (5.75 against 6.74 ms; complex64 2 x 4 and 1 x 4: 2.97 against
+    // 3.71 and 2.79 against 3.51 ms for the 512-thread form): profiles/r05/planar_2048_ab.log.  MCLE_OPT_F64_THREADS: 512 / 1024 force either.
+    if (n == 2048 && nr == 4) {
         const long long thr = ctx->opt[MCLE_OPT_F64_THREADS];
-        const bool four = thr == 512 || (thr != 1024 && (nt == 4 || !F64));       // complex64: every Nt >= 2; complex128: 4 x 4 only
+        const bool four = thr == 512 || (thr != 1024 && (nt == 4 || !F64));       // complex64: every Nt; complex128: 4 x 4 only
         if (four) {
             if (nt == 4) return launch_mimo_ofdm_planar<T, 2048, 4, 4, 4, 2>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
             if (nt == 3) return launch_mimo_ofdm_planar<T, 2048, 3, 4, 4, 2>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
-            return launch_mimo_ofdm_planar<T, 2048, 2, 4, 4, 2>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
+            if (nt == 2) return launch_mimo_ofdm_planar<T, 2048, 2, 4, 4, 2>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
+            return launch_mimo_ofdm_planar<T, 2048, 1, 4, 4, 2>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
         }
     }
     MCLE_F64_SIZE(2048, 4, 4) MCLE_F64_GEOM(2048, 4, 4, 2, 4)
