@@ -6,7 +6,8 @@
   * the Gram accumulation row by row (mimo.hpp: blast_gram_row / blast_solve_gram) equals sqrt(Nt) solve(H^H H + nv I, H^H y) for
     every 1 <= Nt <= Nr <= 4 (mimo/mimo.py:287-309, :597-607);
   * the record layout of k_mimo_tdl_symbol_polys<T, true>: every coefficient of a receive antenna on its own (register, lane);
-  * LDS bank conflicts of the decode's reads under the 32-lane read rule (tests/test_f64_layout.py)."""
+  * LDS bank conflicts of the decode's reads under the 32-lane read rule (tests/test_f64_layout.py);
+  * the delay-class POSITIONS of the decode (MimoTdlParams::cls_code) and its two loops + butterfly against the literal H(f)."""
 import numpy as np
 import pytest
 
@@ -168,3 +169,40 @@ def test_wave_record_layout_gives_every_coefficient_its_own_lane(S, nt, nr, K):
     assert len(seen) == S * nr * nt * (K + 1)
     rec = nr * nq * lw + S * nr * nt                  # mimo_tdl_wave_rec: coefficients, then the [S][Nr][Nt] means
     assert rec >= len(seen) + S * nr * nt
+
+
+def class_positions(delays):
+    """MimoTdlParams::cls_code as pipeline_mimo_tdl.hip fills it: even-delay taps at positions 0 .., odd-delay ones at 7, 6, .."""
+    code, ne, no = [-1] * 8, 0, 0
+    for s, d in enumerate(delays):
+        c = (s << 16) | d
+        if d & 1:
+            code[7 - no] = c
+            no += 1
+        else:
+            code[ne] = c
+            ne += 1
+    return code, ne, no
+
+
+@pytest.mark.parametrize("delays", [(0, 1, 2, 3, 4), (0, 2, 4, 6, 8), (1, 3, 5, 7, 9, 11), (1, 2, 4, 6, 8, 10, 12, 14),
+                                    (0, 1, 7, 33, 64, 65, 130, 200), (5,), (0,), (0, 7, 17, 31)])
+def test_class_positions_and_the_two_loops_give_both_bins(delays):
+    """The decode's two straight loops over the class positions (positions 0 .. ne - 1, then 7, 6, .. 8 - no) followed by the
+    butterfly equal the literal frequency response at f0 and f0 + N / 2 for every split of <= 8 taps into delay parities."""
+    rs = np.random.RandomState(len(delays) * 13 + delays[-1])
+    n, S = 1024, len(delays)
+    code, ne, no = class_positions(delays)
+    assert ne + no == S and all(c == -1 for c in code[ne:8 - no])            # the two runs never overlap: ne + no <= 8
+    assert [c >> 16 for c in code[:ne]] == [s for s in range(S) if delays[s] % 2 == 0]
+    assert [code[7 - k] >> 16 for k in range(no)] == [s for s in range(S) if delays[s] % 2 == 1]
+    mean = rs.randn(S, 4, 4) + 1j * rs.randn(S, 4, 4)
+    tw = np.exp(-2j * np.pi * np.arange(n) / n)
+    for f0 in (0, 3, 250, n // 2 - 1):
+        wt = [tw[(f0 * (c & 0xFFFF)) % n] if c >= 0 else 0.0 for c in code]     # Wt[p]: the tap at position p
+        u0 = sum((mean[code[k] >> 16] * wt[k] for k in range(ne)), np.zeros((4, 4), dtype=complex))
+        u1 = sum((mean[code[7 - k] >> 16] * wt[7 - k] for k in range(no)), np.zeros((4, 4), dtype=complex))
+        for j, h in enumerate((u0 + u1, u0 - u1)):
+            f = f0 + j * (n // 2)
+            want = sum(mean[s] * tw[(f * delays[s]) % n] for s in range(S))
+            assert np.allclose(h, want, rtol=0, atol=1e-12)
