@@ -103,8 +103,10 @@ __device__ __forceinline__ double2 cn_from_words_lds(uint32_t x0, uint32_t x1, d
 template <typename T>
 __device__ __forceinline__ cx<T> cn_sample(const Rng& rng, uint32_t stream, uint64_t i, T sigma) {
     const Words4 b = rng.block(stream, (uint32_t)(i >> 1));
-    const int h = (int)(i & 1) * 2;
-    return cn_from_words(b.w[h], b.w[h + 1], sigma);
+    // (selects, not b.w[h]: a lane-dependent index into the four words makes the backend park them in SCRATCH -- a 16-byte store
+    //  and a dependent load per sample inside the symbol walks, round 5)
+    const bool hi = (i & 1) != 0;
+    return cn_from_words(hi ? b.w[2] : b.w[0], hi ? b.w[3] : b.w[1], sigma);
 }
 
 // samples 2*blk and 2*blk+1 from one Philox call
@@ -130,13 +132,15 @@ __device__ __forceinline__ void cn_pair_lds(const Rng& rng, uint32_t stream, uin
 
 __device__ __forceinline__ double uniform_at(const Rng& rng, uint32_t stream, uint64_t i) {
     const Words4 b = rng.block(stream, (uint32_t)(i >> 2));
-    return (double)b.w[i & 3] * 0x1p-32;
+    const uint32_t lo = (i & 1) ? b.w[1] : b.w[0], hi = (i & 1) ? b.w[3] : b.w[2];      // (selects: see cn_sample)
+    return (double)((i & 2) ? hi : lo) * 0x1p-32;
 }
 
 // symbol n of the data stream
 __device__ __forceinline__ uint32_t symbol_at(const Rng& rng, uint64_t n, uint32_t mask) {
     const Words4 b = rng.block(STREAM_DATA, (uint32_t)(n >> 4));
-    return (b.w[(n >> 2) & 3] >> ((n & 3) * 8)) & mask;
+    const uint32_t lo = (n & 4) ? b.w[1] : b.w[0], hi = (n & 4) ? b.w[3] : b.w[2];      // (selects: see cn_sample)
+    return (((n & 8) ? hi : lo) >> ((n & 3) * 8)) & mask;
 }
 
 }  // namespace mcle
