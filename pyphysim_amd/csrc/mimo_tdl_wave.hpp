@@ -669,7 +669,7 @@ int launch_mimo_tdl_wave(mcle_ctx* ctx, const MimoTdlParams& pp, int method, uin
 // wavefronts per SIMD the registers are bounded for (= workgroups of 4 wavefronts per CU the LDS admits at Nr = 4): 1024 and below
 // complex64 3 / complex128 2; 2048: 2 / 1.  Subcarriers per decode work item: 2 where a wavefront has at least two.
 // (complex64 at 1024: three -- 4.47 ms per 83 886 realizations with 12 spilled registers against 4.89 at two, where nothing spills
-//  and the channel's delayed samples are double-buffered, and 4.91 at four: scripts/experiments/r05_call7.sh)
+//  and the channel's delayed samples are double-buffered, and 4.91 at four: scripts/experiments/r05_calls.txt [call 7])
 template <typename T, int N> constexpr int mimo_tdl_wave_wps() { return N >= 2048 ? (sizeof(T) == 8 ? 1 : 2) : (sizeof(T) == 8 ? 2 : 3); }
 template <int N, int NR> constexpr int mimo_tdl_wave_bq() { return N / (64 * NR) >= 2 ? 2 : 1; }
 // the polynomial order whose coefficients are parked in registers (the order of the benchmark's Doppler in each arithmetic);

@@ -21,7 +21,7 @@ struct DemodGrid {
     // 8- / 16-PSK: the sector certificate's constants (device memory, one block per context, written by mcle_set_constellation);
     // null otherwise.  EVERY grid search below tries that certificate first (demod_psk_cert) -- it is part of the table search, not
     // of the first-line certificates of demod_cert_any: inlined there it cost the QAM kernels registers (the complex64 headline
-    // kernel 25 -> 33 spilled registers, -5 %: scripts/experiments/r05_call20.sh), here a QAM launch never reaches it.
+    // kernel 25 -> 33 spilled registers, -5 %: scripts/experiments/r05_calls.txt [call 20]), here a QAM launch never reaches it.
     const PskCert* psk;
 };
 // label of sector k (64 / M bits each, sector 0 in the low bits), e^{-j phi0}, cos / sin of the M / 8 sector boundaries inside the
@@ -504,7 +504,7 @@ __device__ __forceinline__ int demod_qam_cert(cx<T> r, T scale, int L, int half_
     // Beyond the outer levels the clamp makes f = 0 on that axis, but the margin on the OTHER axis (2 eps spacing^2) only dominates
     // the rounding of the metrics (~ |r|^2 ulp) while |r| stays below ~20 level spacings in complex64 and ~2^11 in complex128
     // (ADVICE r04).  complex64: `sure` also needs |re|, |im| within 16 spacings of the outermost level's centre -- a zero-forcing
-    // output in a deep fade goes farther, and the two compares are free there (scripts/experiments/r05_call21.sh).  complex128: NOT
+    // output in a deep fade goes farther, and the two compares are free there (scripts/experiments/r05_calls.txt [call 21]).  complex128: NOT
     // checked -- two f64 compares per symbol cost the headline kernel 2.3 % (11.01 against 10.76 ms per 262 144 realizations), and a
     // point beyond 2^11 spacings (an equaliser output in a fade of -66 dB) that ALSO sits within 2^-30 of a boundary on its other
     // axis has probability ~1e-14 per symbol: there the identity with the sweep rests on the margin argument up to 2^11 spacings
