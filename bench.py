@@ -678,41 +678,41 @@ def main():
             flag = torch.tensor([ok], dtype=torch.int64, device=xdev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)      # every rank must hold the id before anyone blocks in ncclCommInitRank
             if int(flag[0]) == 1:
-                # step 2: mcle_comm_init (ncclCommInitRank) on the context's device -- on a side thread with a deadline: a rank
-                # whose RCCL bring-up fails or hangs must not leave the other ranks (and the driver's run) blocked for ever
+                # step 2: mcle_comm_init (ncclCommInitRank) on the context's device, on THIS thread -- the context is never touched
+                # by two threads (ADVICE r04 #4 / VERDICT r05 item 8: rounds 4-5 ran the bring-up on a side thread and fell back
+                # past a stuck one).  A bring-up that RETURNS an error falls back to torch.distributed on every rank (agreed by the
+                # MIN all-reduce below); one that HANGS is ended loudly by the watchdog: exit code 3 and a line on stderr, so the
+                # launcher tears the job down instead of timing a run whose exchange never came up.
                 import threading
-                box = {}
+                done = threading.Event()
 
-                def _bring_up():
-                    try:
-                        box["comm"] = NativeComm(eng, rank, world, unique_id=uid)
-                    except Exception as exc:            # noqa: BLE001 -- reported in the line
-                        box["err"] = repr(exc)
-                th = threading.Thread(target=_bring_up, daemon=True)
-                th.start()
-                th.join(timeout=120.0)
-                flag = torch.tensor([1 if "comm" in box else 0], dtype=torch.int64, device=xdev)
+                def _watchdog():
+                    if not done.wait(float(os.environ.get("MCLE_BENCH_COMM_DEADLINE_S", "120"))):
+                        sys.stderr.write("bench.py: rank %d: mcle_comm_init (ncclCommInitRank) did not return within its "
+                                         "deadline; aborting the run (exit 3)\n" % rank)
+                        sys.stderr.flush()
+                        os._exit(3)
+                threading.Thread(target=_watchdog, daemon=True).start()
+                comm, cerr = None, None
+                try:
+                    comm = NativeComm(eng, rank, world, unique_id=uid)
+                except Exception as exc:            # noqa: BLE001 -- reported in the line
+                    cerr = repr(exc)
+                done.set()
+                flag = torch.tensor([1 if comm is not None else 0], dtype=torch.int64, device=xdev)
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
                 if int(flag[0]) == 1:
-                    native = box["comm"]
+                    native = comm
                 else:
-                    comm_note = ("mcle_comm_init did not come up on every rank within 120 s (%s): exchange through "
-                                 "torch.distributed" % box.get("err", "this rank ok" if "comm" in box else "timeout"))
+                    comm_note = ("mcle_comm_init failed on some rank (%s): exchange through torch.distributed"
+                                 % (cerr or "this rank ok"))
                     if args.comm == "native":
                         raise SystemExit("bench.py: --comm native: " + comm_note)
-                    # fall back cleanly: a rank whose communicator DID come up destroys it (ncclCommDestroy) instead of leaving it
-                    # to interpreter exit; a rank whose bring-up thread is still blocked inside ncclCommInitRank must not share
-                    # that context with the timed path -- it gets a fresh context (the stuck one is abandoned with its thread)
-                    if "comm" in box:
+                    if comm is not None:               # a rank whose communicator DID come up destroys it (ncclCommDestroy)
                         try:
-                            box["comm"].close()
+                            comm.close()
                         except Exception:          # noqa: BLE001 -- the fallback must go on
                             pass
-                    elif th.is_alive():
-                        eng = Engine(gpu, args.dtype)
-                        for item in args.opt:
-                            name, _, val = item.partition("=")
-                            eng.set_option(name, int(val))
             else:
                 comm_note = "NativeComm rendezvous failed on some rank (%s): exchange through torch.distributed" % err
                 if args.comm == "native":

@@ -30,12 +30,52 @@ int mcle_ctx::scratch(size_t bytes, void** d_ptr) {
         if (d_scratch) MCLE_HIP(hipFree(d_scratch));  // hipFree synchronises with in-flight work
         d_scratch = nullptr;
         scratch_bytes = 0;
-        size_t want = bytes < (1u << 20) ? (1u << 20) : bytes + bytes / 4;
-        MCLE_HIP(hipMalloc(&d_scratch, want));
+        // 25 % headroom against slowly growing requests -- for SMALL buffers only: on top of a multi-GiB record slice it is what
+        // tipped a shared device over; and a request that fails WITH the headroom is retried without it
+        size_t want = bytes < (1u << 20) ? (1u << 20) : (bytes < ((size_t)256 << 20) ? bytes + bytes / 4 : bytes);
+        hipError_t e = hipMalloc(&d_scratch, want);
+        if (e == hipErrorOutOfMemory && want > bytes) {
+            (void)hipGetLastError();
+            want = bytes;
+            e = hipMalloc(&d_scratch, want);
+        }
+        if (e != hipSuccess) {
+            d_scratch = nullptr;
+            MCLE_HIP(e);
+        }
         scratch_bytes = want;
     }
     *d_ptr = d_scratch;
     return MCLE_OK;
+}
+
+int mcle_ctx::scratch_upto(size_t want, size_t floor_bytes, void** d_ptr, size_t* got) {
+    if (want <= scratch_bytes) {
+        *d_ptr = d_scratch;
+        *got = want;
+        return MCLE_OK;
+    }
+    size_t free_b = 0, total_b = 0;
+    // never ask for more than what is free now plus what this context already holds, less a margin for the other allocations of
+    // the call (workspace, counters): saves the failed hipMalloc round trips on a crowded device
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+        const size_t avail = free_b + scratch_bytes;
+        const size_t margin = (size_t)256 << 20;
+        if (avail > margin && want > avail - margin) want = avail - margin;
+    } else {
+        (void)hipGetLastError();
+    }
+    if (want < floor_bytes) want = floor_bytes;
+    for (;;) {
+        const int rc = scratch(want, d_ptr);
+        if (rc == MCLE_OK) {
+            *got = want;
+            return MCLE_OK;
+        }
+        if (want <= floor_bytes) return rc;             // (the message of the failed hipMalloc stays in mcle_last_error)
+        (void)hipGetLastError();
+        want = want / 2 < floor_bytes ? floor_bytes : want / 2;
+    }
 }
 
 // w[k] = exp(-2 pi i k / n) computed in double on the host (then rounded once for f32)
@@ -125,6 +165,8 @@ int mcle_ctx_create(int device_id, mcle_ctx** out) {
     ctx->own_stream = true;
     (void)hipEventCreate(&ctx->ev0);
     (void)hipEventCreate(&ctx->ev1);
+    (void)hipEventCreate(&ctx->ev_probe0);
+    (void)hipEventCreate(&ctx->ev_probe1);
     *out = ctx;
     return MCLE_OK;
 }
@@ -143,6 +185,8 @@ int mcle_ctx_destroy(mcle_ctx* ctx) {
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->ev_probe0) (void)hipEventDestroy(ctx->ev_probe0);
+    if (ctx->ev_probe1) (void)hipEventDestroy(ctx->ev_probe1);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return MCLE_OK;

@@ -239,7 +239,8 @@ struct mcle_ctx {
     // scratch for host->device parameter blocks
     void* d_scratch = nullptr;
     size_t scratch_bytes = 0;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;     // mcle_timer_start / mcle_timer_stop_ms
+    hipEvent_t ev_probe0 = nullptr, ev_probe1 = nullptr;   // mcle_hbm_stream_rate's own pair (a probe between the timer calls must not move them)
     // RCCL communicator of the realization-sharded runs (comm.hip); null: single rank
     void* comm = nullptr;
     int comm_rank = 0, comm_world = 1;
@@ -252,6 +253,9 @@ struct mcle_ctx {
     int bind() const;
     int get_twiddles(int n, int dtype, void** d_tw);
     int scratch(size_t bytes, void** d_ptr);
+    // a record buffer of `want` bytes that may be SMALLER on a crowded device: halves the request on hipErrorOutOfMemory down to
+    // `floor_bytes`, *got = what was obtained (the callers cut their realization slices to it)
+    int scratch_upto(size_t want, size_t floor_bytes, void** d_ptr, size_t* got);
 };
 
 namespace mcle {

@@ -843,7 +843,9 @@ static int launch_run_bd(mcle_ctx* ctx, const mcle_bd_cfg* cfg, const BdParams& 
         // (complex128: three wavefronts per SIMD where the user count is a compile-time constant -- 168 registers, nothing spilled --
         //  two for the run-time-sized form, which spills 18 - 58 registers at that bound)
         const bool kc = R <= 2 && (cfg->K == 2 || cfg->K == 3) && cfg->K * R <= kBdMaxN;
-        const uint64_t cap = (uint64_t)ctx->n_cu * 4 * (sizeof(T) == 4 ? 4 : (kc ? 3 : 2));
+        // the resident set: the wavefronts per SIMD of k_bd_link's __launch_bounds__ (3 for complex64 and the compile-time user
+        // counts, 2 otherwise) -- rounds 4-5 sized the complex64 grid for four and ran a partial second wave of workgroups
+        const uint64_t cap = (uint64_t)ctx->n_cu * 4 * ((sizeof(T) == 4 || kc) ? 3 : 2);
         const uint64_t chunks = (m + per_wave - 1) / per_wave;
         const unsigned grid = (unsigned)oversubscribed_grid(ctx, cap, chunks, 2);     // a chunk is 8-16 realizations; one chunk per workgroup measured 1.5 x slower
         // demodulator path of the walk (compile-time in the kernel): complex64 min-distance in lockstep -- a sweep for M <= 8,

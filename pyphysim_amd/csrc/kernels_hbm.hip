@@ -71,17 +71,24 @@ static int hbm_stream_rate(mcle_ctx* ctx, size_t bytes, int reps, int blocks_per
     MCLE_HIP(hipMemsetAsync(base, 0, 3 * bytes + per_thread, ctx->stream));
     const double moved = (KIND == MCLE_HBM_COPY ? 2.0 : KIND == MCLE_HBM_TRIAD ? 3.0 : 1.0) * (double)(n * sizeof(v4f));
     for (int pass = 0; pass < 2; ++pass) {                  // pass 0 warms the clocks and the page tables
-        if (pass) MCLE_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+        if (pass) MCLE_HIP(hipEventRecord(ctx->ev_probe0, ctx->stream));
         for (int r = 0; r < (pass ? reps : 2); ++r) {
             hipLaunchKernelGGL((k_hbm_stream<KIND, U, NT>), dim3(grid), dim3(256), 0, ctx->stream, a, b, c, n, 1.0f);
             MCLE_LAUNCH_CHECK();
         }
     }
-    MCLE_HIP(hipEventRecord(ctx->ev1, ctx->stream));
-    MCLE_HIP(hipEventSynchronize(ctx->ev1));
+    MCLE_HIP(hipEventRecord(ctx->ev_probe1, ctx->stream));
+    MCLE_HIP(hipEventSynchronize(ctx->ev_probe1));
     float ms = 0.f;
-    MCLE_HIP(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    MCLE_HIP(hipEventElapsedTime(&ms, ctx->ev_probe0, ctx->ev_probe1));
     *gbps = moved * reps / ((double)ms * 1e-3) / 1e9;
+    // the three arrays (3.75 GiB at the default 1 GiB) are not kept for the rest of the run: the next pipeline call
+    // sizes its own scratch
+    if (ctx->scratch_bytes > ((size_t)256 << 20)) {
+        MCLE_HIP(hipFree(ctx->d_scratch));
+        ctx->d_scratch = nullptr;
+        ctx->scratch_bytes = 0;
+    }
     return MCLE_OK;
 }
 

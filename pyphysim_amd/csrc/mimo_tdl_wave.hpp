@@ -1,5 +1,6 @@
 // mimo_tdl_wave.hpp -- SURVEY.md section 8(f).1 (frequency-selective MIMO-OFDM) with ONE RECEIVE ANTENNA PER WAVEFRONT (round 5):
-// k_run_mimo_ofdm_tdl_wave and its launcher; compiled per arithmetic (pipeline_mimo_tdl_wave_f32.hip / _f64.hip).
+// k_run_mimo_ofdm_tdl_wave and its launcher; instantiated per arithmetic AND size in ten translation units
+// (pipeline_mimo_tdl_wave_{f32,f64}_{256,512,1024,1024k,2048}.hip; 1024k = the compile-time polynomial order of the benchmark).
 //
 // Reference path (restated by oracle/chains.py::chain_mimo_ofdm_tdl), as in pipeline_mimo_tdl.hip:
 //   TdlMimoChannel / corrupt_data MIMO branch      channels/fading.py:1290-1333, :1092-1118
@@ -21,10 +22,11 @@
 //     (code size: Nt x 16 samples x (2 K + 4) FMAs per trip), the delays sit in one register's lanes too;
 //   * noise as in the config-3 kernel: one NOISE block per sample pair, lanes l and l + 1 draw half of the blocks each and swap
 //     halves by DPP (ledger unchanged; an odd row start takes unpaired draws);
-//   * the decode takes BQ subcarriers f0 + j N / BQ per work item: w^((f0 + j N / BQ) d) = w^(f0 d) (-i)^(j d) (BQ = 4) or
-//     (-1)^(j d) (BQ = 2), so the S Nr Nt products mean x twiddle are formed ONCE per work item, summed by delay class d mod BQ and
-//     spread over the BQ bins by a radix-BQ butterfly (adds only) -- H(f) costs 240 (BQ = 2) / 152 (BQ = 4) instructions per bin
-//     at 4 x 4 and five taps instead of 320 -- and the tap means are read from LDS once per work item instead of once per bin;
+//   * the decode takes BQ subcarriers f0 + j N / BQ per work item, BQ in {1, 2} (static_assert below; a BQ = 4 form with
+//     (-i)^(j d) classes was planned in the first draft and never built): w^((f0 + N / 2) d) = w^(f0 d) (-1)^d, so the S Nr Nt
+//     products mean x twiddle are formed ONCE per work item, summed by the PARITY of their delay and spread over the two bins as
+//     sum and difference -- H(f) costs 240 instructions per bin at 4 x 4 and five taps instead of 320 -- and the tap means are
+//     read from LDS once per work item instead of once per bin;
 //     H(f) is formed one receive antenna at a time and folded into the Gram matrix H^H H and H^H y (mimo.hpp: blast_gram_row /
 //     blast_solve_gram), so that no thread ever holds BQ whole channel matrices.
 // Same draw ledger (pipeline_mimo_tdl.hip) and the same arithmetic outside the transforms and H(f) (Horner per tap in tap order,
@@ -647,11 +649,16 @@ int launch_mimo_tdl_wave(mcle_ctx* ctx, const MimoTdlParams& pp, int method, uin
     // launches (3.2 / 9 kB per realization and symbol at 4 x 4 and five taps), so that a bench step of 393 216 realizations is ONE
     // dispatch of each kernel -- the 256 MiB slices of rounds 3-4 cut a step into unequal dispatches, which is what the per-launch
     // means of the round-4 profiles got wrong; shorter launches were never faster (pipeline_mimo_tdl.hip)
+    // (a crowded or smaller device gets a smaller slice instead of an out-of-memory error: scratch_upto halves the request down to
+    // 64 realizations' worth)
     uint64_t slice = (4096ull << 20) / (per_real * sizeof(cx<T>));
     if (slice < 1) slice = 1;
     if (slice > count) slice = count;
     void* recs = nullptr;
-    if ((rc = ctx->scratch((size_t)slice * per_real * sizeof(cx<T>), &recs))) return rc;
+    size_t got = 0;
+    const size_t one = (size_t)per_real * sizeof(cx<T>);
+    if ((rc = ctx->scratch_upto((size_t)slice * one, (slice < 64 ? slice : 64) * one, &recs, &got))) return rc;
+    if (got / one < slice) slice = got / one;
     for (uint64_t off = 0; off < count; off += slice) {
         const uint64_t n = count - off < slice ? count - off : slice;
         const uint64_t threads = n * (uint64_t)pp.n_ofdm_sym * PS;

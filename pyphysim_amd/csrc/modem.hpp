@@ -485,7 +485,10 @@ __device__ __forceinline__ int demod_qam_slicer(cx<T> r, T scale, int L, int hal
 // f = clamp(t) - k is the offset from that level in units of the level spacing.  With |f| <= 1/2 - eps on both axes the
 // nearest point beats every other by >= 2 eps (spacing)^2 in squared distance -- orders of magnitude above what the
 // rounding of t, of the table entries or of either metric (|c - r|^2 here, hypot in numpy.abs, fundamental.py:241-246)
-// can move -- so the exhaustive sweep, its first-minimum tie rule included, returns this very label: `sure`.  Otherwise
+// can move -- so the exhaustive sweep, its first-minimum tie rule included, returns this very label: `sure`.  (That margin
+// argument needs |re|, |im| within ~20 (complex64) / ~2^11 (complex128) level spacings: complex64 checks it, complex128 does NOT
+// and is identical to the sweep BY CONSTRUCTION only inside that range; beyond it the identity is a probability bound,
+// <= 1e-14 per symbol, see the note inside the function and include/mcle.h MCLE_OPT_DEMOD_NOCERT.)  Otherwise
 // (a point within eps of a decision boundary: probability ~ 4 eps per symbol) the caller runs the table search it
 // always ran.  eps = 2^-30 for complex128 (t <= 16 carries an error of 4e-15), 2^-15 for complex64 (t <= 32 carries an error
 // of <= 4e-6: eight times below; a wavefront pass of 256 symbols then takes the table search in 3 % of its passes -- 2^-12,

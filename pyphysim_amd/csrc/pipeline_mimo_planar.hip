@@ -19,7 +19,8 @@
 //   * the channel draw and the f64 receive filter of every realization in a launch of their own (k_mimo_filters_planar), like
 //     the f32 matrix-core path.
 //   * Box-Muller by table + short polynomial (bm_f64.hpp); min-distance decisions of a square QAM through the margin
-//     certificate, of anything else through the candidate grid (both decision-identical to the sweep, modem.hpp).
+//     certificate, of anything else through the candidate grid (both decision-identical to the sweep; the complex128
+//     certificate by construction up to 2^11 level spacings and by a <= 1e-14-per-symbol bound beyond, modem.hpp / mcle.h).
 // Round 4: a FAMILY, not a benchmark point -- fft_size in {256, 512, 1024, 2048} (a trailing radix-2 stage for 512 / 2048,
 // like fft.hpp), Nt <= Nr in {2, 4} square plus the Nr > Nt shapes listed in run_mimo_ofdm_planar; the reference's OFDM /
 // Blast take any of them (modulators/ofdm.py:52-94, mimo/mimo.py:264-309, :609-660).

@@ -11,6 +11,13 @@
 #pragma once
 #include "common.hpp"
 
+// libmcle is written for gfx950 only (Makefile: ARCH; mcle_ctx_create refuses any other device).  The packed-f32 VOP3P forms below
+// exist on gfx90a / gfx942 / gfx950; a device pass for anything else stops here with a sentence instead of an assembler error in
+// the middle of thirty translation units.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__) && !defined(__gfx90a__)
+#error "libmcle: pkcx.hpp needs v_pk_fma_f32 / v_pk_mul_f32 (gfx90a, gfx942, gfx950); build with ARCH=gfx950"
+#endif
+
 namespace mcle {
 
 typedef float pk2 __attribute__((ext_vector_type(2)));

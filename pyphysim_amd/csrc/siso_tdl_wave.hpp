@@ -419,7 +419,11 @@ int run_siso_tdl_wave_w(mcle_ctx* ctx, const SisoTdlParams& pp, int method, uint
     slice = slice < NWV ? NWV : (slice / NWV) * NWV;
     if (slice > count) slice = count;
     void* recs = nullptr;
-    if ((rc = ctx->scratch((size_t)slice * per_real * sizeof(cx<T>), &recs))) return rc;
+    size_t got = 0;
+    const size_t one = (size_t)per_real * sizeof(cx<T>);
+    const uint64_t floor_n = slice < 64 * NWV ? slice : 64 * NWV;            // scratch_upto: a smaller slice on a crowded device
+    if ((rc = ctx->scratch_upto((size_t)slice * one, (size_t)floor_n * one, &recs, &got))) return rc;
+    if (got / one < slice) slice = (got / one / NWV) * NWV;
     for (uint64_t off = 0; off < count; off += slice) {
         const uint64_t n = count - off < slice ? count - off : slice;
         const uint64_t threads = n * (uint64_t)pp.n_ofdm_sym * pp.n_taps;

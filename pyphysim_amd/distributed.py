@@ -33,45 +33,73 @@ def env_rank_world():
 
 
 def _exchange_id(make_id, rank, world, addr, port, timeout=120.0):
-    """Rank 0 serves the id to the world - 1 peers that connect; returns the id on every rank."""
+    """Rank 0 serves the id to the world - 1 peers that connect; returns the id on every rank.
+
+    Protocol per connection: peer -> its rank (4 bytes); root -> the 128-byte id; peer -> ACK (0x06); root -> COMMIT (0x04).  The
+    root counts a peer when it reads the ACK and closes its listener once every peer is counted; connections are served
+    CONCURRENTLY (one slow or half-open client does not hold up the others).  A peer that has the id but never saw
+    the COMMIT retries (the reply is idempotent); if the retry finds the listener GONE, the root has counted every peer --
+    this one included -- and the peer returns the id it holds instead of failing while the root proceeds."""
     if world == 1:
         return make_id()
     if rank == 0:
+        import threading
         payload = make_id()
         srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
         srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
         srv.bind((addr, port))
-        srv.listen(world)
-        srv.settimeout(timeout)
-        seen = set()
+        srv.listen(max(world, 16))
+        seen, lock, all_in = set(), threading.Lock(), threading.Event()
+
+        def serve(conn):
+            with conn:
+                try:                                  # one bad client (port scanner, half-open socket) must not
+                    conn.settimeout(10.0)             # block or abort the others
+                    head = b""
+                    while len(head) < 4:
+                        chunk = conn.recv(4 - len(head))
+                        if not chunk:
+                            return
+                        head += chunk
+                    peer = struct.unpack("<i", head)[0]
+                    if not (1 <= peer < world):
+                        return                        # not one of ours: no id for it
+                    conn.sendall(payload)             # a rank that retries (its first reply was lost) is served again
+                    if conn.recv(1) != b"\x06":       # counted when it ACKNOWLEDGES the id: sendall returning says nothing
+                        return                        # about delivery
+                    with lock:
+                        seen.add(peer)
+                        if len(seen) >= world - 1:
+                            all_in.set()
+                    conn.sendall(b"\x04")             # COMMIT: the peer may go on
+                except (OSError, ConnectionError, struct.error):
+                    return
+        deadline = time.time() + timeout
+        workers = []
         try:
-            while len(seen) < world - 1:
-                conn, _ = srv.accept()                    # socket.timeout after `timeout` s without a connection
-                with conn:
-                    try:                                  # one bad client (port scanner, half-open socket) must not
-                        conn.settimeout(10.0)             # block or abort the server loop
-                        head = b""
-                        while len(head) < 4:
-                            chunk = conn.recv(4 - len(head))
-                            if not chunk:
-                                raise ConnectionError("peer closed before sending its rank")
-                            head += chunk
-                        peer = struct.unpack("<i", head)[0]
-                        if not (1 <= peer < world):
-                            continue                      # not one of ours: no id for it
-                        conn.sendall(payload)             # a rank that retries (its first reply was lost) is served again:
-                        ack = conn.recv(1)                # the reply is idempotent.  A peer is counted when it ACKNOWLEDGES the
-                        if ack == b"\x06":                # id (one byte back): sendall returning says nothing about delivery,
-                            seen.add(peer)                # and the listener must outlive every peer that still has to retry
-                    except (OSError, ConnectionError, struct.error):
-                        continue
+            while not all_in.is_set():
+                left = deadline - time.time()
+                if left <= 0:
+                    raise socket.timeout("rendezvous: %d of %d peers after %.0f s" % (len(seen), world - 1, timeout))
+                srv.settimeout(min(left, 0.25))
+                try:
+                    conn, _ = srv.accept()
+                except socket.timeout:
+                    continue
+                th = threading.Thread(target=serve, args=(conn,), daemon=True)
+                th.start()
+                workers.append(th)
         finally:
             srv.close()
+        for th in workers:                            # let the COMMIT bytes of the last handlers go out
+            th.join(timeout=2.0)
         return payload
     deadline = time.time() + timeout
+    held = None                                       # the id of an attempt whose COMMIT never arrived
     while True:
         try:
             with socket.create_connection((addr, port), timeout=5.0) as conn:
+                conn.settimeout(10.0)
                 conn.sendall(struct.pack("<i", rank))
                 buf = b""
                 while len(buf) < 128:
@@ -79,10 +107,21 @@ def _exchange_id(make_id, rank, world, addr, port, timeout=120.0):
                     if not chunk:
                         raise ConnectionError("short id")
                     buf += chunk
-                conn.sendall(b"\x06")                      # acknowledge: only now does the server count this rank
-                return buf
+                conn.sendall(b"\x06")                      # acknowledge: only now does the root count this rank
+                held = buf
+                if conn.recv(1) == b"\x04":
+                    return buf
+                raise ConnectionError("no commit")
+        except ConnectionRefusedError:
+            if held is not None:                           # listener gone AFTER our acknowledgement went out: every peer is counted
+                return held
+            if time.time() > deadline:
+                raise
+            time.sleep(0.2)
         except (ConnectionError, OSError):
             if time.time() > deadline:
+                if held is not None:
+                    return held
                 raise
             time.sleep(0.2)
 

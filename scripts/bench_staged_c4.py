@@ -54,7 +54,7 @@ def bind(eng, M=64):
 
 def measure_hbm_stream(eng, nbytes=1 << 30, reps=10):
     """What this box's HBM delivers to a streaming kernel, measured in THIS run by the library's own 16-byte-per-access kernels
-    (mcle_hbm_stream_rate, csrc/kernels_hbm.hip: copy, read, triad, write over 1 GiB arrays, 8 and 16 workgroups per CU) --
+    (mcle_hbm_stream_rate, csrc/kernels_hbm.hip: copy, read, triad, write over 1 GiB arrays, 4, 8 and 32 workgroups per CU) --
     the achievable-HBM figure SURVEY.md 8(d) asks to be quoted next to the 8 TB/s specification.  `achievable_GBps` is the
     best of them: the denominator of every `frac_of_achievable_hbm` (until round 4 it was torch's copy_ of 1 GiB, 4.8 TB/s
     on the driver's box, which the staged chain itself exceeded -- a library copy is not a ceiling)."""

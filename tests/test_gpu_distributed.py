@@ -241,3 +241,42 @@ def test_bench_two_rank_code_path_on_one_gpu():
     o = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
     assert o["config"]["rank_ranges"] == [[0, 16384]]
     assert o["ser"] == t["ser"] and o["ber"] == t["ber"]                      # same realizations, same integer counters
+
+
+@pytest.mark.timeout(1500)
+def test_bench_eight_rank_code_path_on_one_gpu():
+    """the driver's N = 8 shape with REAL kernels on the one GPU these boxes have -- eight gloo ranks sharing
+    the device, eight contiguous index ranges, the counter all-reduce inside the timed region, and the `strong` blocks of
+    config 4 and config 5 cut in eight.  The reduced counters must be those of a ONE-rank job over the same index ranges (same
+    SER / BER to the last digit, weak leg and both strong legs).  Never a scaling figure."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    common = ["--warmup", "1", "--no-cpu", "--pmc", "off", "--preroll-ms", "0", "--single-demod", "--dist-backend", "gloo",
+              "--strong-total", "20001", "--strong-reps", "1"]
+    eight = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "8", "--steps", "1", "--batch", "2048",
+                            "--share-gpus"] + common, env=env, capture_output=True, text=True, timeout=1400)
+    assert eight.returncode == 0, eight.stderr[-3000:]
+    lines = [l for l in eight.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                                  # ONE JSON line, from rank 0
+    t = json.loads(lines[0])
+    assert t["n_gpus"] == 8 and t["rccl"]["rccl_world_size"] == 8 and t["rccl"]["backend"] == "gloo"
+    assert t["config"]["rank_ranges"] == [[2048 * r, 2048 * (r + 1)] for r in range(8)]
+    assert [r["rank"] for r in t["rccl"]["ranks"]] == list(range(8))
+    assert t["rccl"]["exchange_impl"].startswith("torch")                    # gloo: eight ranks on one device, no RCCL
+    st, s5 = t["strong"], t["strong_c5"]
+    assert st["total_realizations"] == 20001 and len(st["per_rank_realizations"]) == 8 and sum(st["per_rank_realizations"]) == 20001
+    assert max(st["per_rank_realizations"]) - min(st["per_rank_realizations"]) <= 1          # 20001 = 8 x 2500 + 1: a ragged cut
+    assert s5["config"] == "c5" and len(s5["per_rank_realizations"]) == 8 and sum(s5["per_rank_realizations"]) == s5["total_realizations"]
+    # the same index ranges on ONE rank of a torch.distributed job (RANK / WORLD_SIZE set: the strong legs exist there too)
+    env1 = dict(env, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    one = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "1", "--steps", "4", "--batch", "4096"] + common,
+                         env=env1, capture_output=True, text=True, timeout=800)
+    assert one.returncode == 0, one.stderr[-3000:]
+    o = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    assert o["config"]["rank_ranges"] == [[0, 16384]]
+    assert o["ser"] == t["ser"] and o["ber"] == t["ber"]                      # weak leg: same realizations, same integer counters
+    assert o["strong"]["ser"] == st["ser"] and o["strong_c5"]["ser"] == s5["ser"]   # strong legs: 8 shares = the whole

@@ -2,8 +2,8 @@
 a handful of realizations with the oracle and thousands kernel-against-kernel; these compare thousands with the ORACLE
 (oracle/chains.py under the same Philox keying): complex128 per-realization symbol and bit counts exact, complex64 aggregate
 SER within 1e-5 and per-realization differences of boundary ties only.  Oracle budget ~60 s on the box's host (the two TDL
-chains use the linear form of the mean frequency response, held to the literal one in tests/test_oracle_golden.py and
-tests/test_gpu_mimo_tdl_wave.py; f1's 240 realizations live in tests/test_gpu_mimo_tdl_wave.py)."""
+chains use the linear form of the mean frequency response; the LITERAL mean of per-sample DFTs is held at depth by the two
+`..._against_the_literal_mean_of_dfts_...` tests below, 512 / 48 realizations; f1's 240 realizations live in tests/test_gpu_mimo_tdl_wave.py)."""
 import numpy as np
 import pytest
 
@@ -46,6 +46,39 @@ def test_config3_wave_kernel_over_2048_realizations(engine, dtype):
     res, se, be = engine.run_ofdm_tdl(1024, 16, 1024, 1, 1.0 / omodem.dB2Linear(20.0), p_lin, d_idx, SEED, first, count, Fd=10.0, Ts=Ts,
                                       L=8, dtype=dtype, per_realization=True)
     _hold(dtype, res, se, be, want_se, want_be, nsym, nbits)
+
+
+def test_config3_against_the_literal_mean_of_dfts_over_512_realizations(engine):
+    """the 2 048-realization test above runs the oracle with the DFT of the MEAN taps (linearity); the
+    reference takes the mean of the per-sample DFTs (channels/fading.py:513-536, modulators/ofdm.py:545-547) -- equal in exact
+    arithmetic, rounded differently.  Here the LITERAL form, complex128, every per-realization count."""
+    from pyphysim_amd.channels import discretize_profile
+    engine.set_constellation(chains.constellation("qpsk", 4), _lib.CONST_GENERIC)
+    Ts = 1.0 / (15e3 * 1024)
+    kw = dict(mod="qpsk", M=4, fft_size=1024, cp_size=16, num_used=None, n_ofdm_sym=1, snr_db=20.0, Fd=10.0, Ts=Ts, L=8)
+    first, count = 90000, 512
+    want_se, want_be, nsym, nbits = _oracle(chains.chain_ofdm_tdl, first, count, linear_mean=False, **kw)
+    p_lin, d_idx = discretize_profile(np.array([0.0, -3.0, -6.0, -9.0, -12.0]), np.arange(5) * Ts, Ts)
+    res, se, be = engine.run_ofdm_tdl(1024, 16, 1024, 1, 1.0 / omodem.dB2Linear(20.0), p_lin, d_idx, SEED, first, count, Fd=10.0, Ts=Ts,
+                                      L=8, dtype="f64", per_realization=True)
+    _hold("f64", res, se, be, want_se, want_be, nsym, nbits)
+
+
+def test_f1_against_the_literal_mean_of_dfts_over_48_realizations(engine):
+    """The same for the frequency-selective 4 x 4 link at bench.py's f1 geometry (64-QAM, OFDM(1024, 16), five taps, 25 dB):
+    48 realizations of the literal oracle (~0.8 s each), complex128, every per-realization count."""
+    from pyphysim_amd.channels import discretize_profile
+    engine.set_constellation(chains.constellation("qam", 64), _lib.CONST_QAM)
+    Ts = 1.0 / (15e3 * 1024)
+    kw = dict(mod="qam", M=64, nt=4, nr=4, fft_size=1024, cp_size=16, num_used=None, n_ofdm_sym=1, snr_db=25.0, Fd=10.0, Ts=Ts, L=8,
+              tap_powers_dB=(0.0, -3.0, -6.0, -9.0, -12.0), tap_delays_samples=(0, 1, 2, 3, 4), mmse=True)
+    first, count = 123000, 48
+    want_se, want_be, nsym, nbits = _oracle(chains.chain_mimo_ofdm_tdl, first, count, linear_mean=False, **kw)
+    p_lin, d_idx = discretize_profile(np.array([0.0, -3.0, -6.0, -9.0, -12.0]), np.arange(5) * Ts, Ts)
+    res, se, be = engine.run_mimo_ofdm_tdl(4, 4, 1024, 16, 1024, 1, 1.0 / omodem.dB2Linear(25.0), p_lin, d_idx, SEED, first, count,
+                                           Fd=10.0, Ts=Ts, L=8, mmse=True, method=_lib.DEMOD_MINDIST, dtype="f64",
+                                           per_realization=True)
+    _hold("f64", res, se, be, want_se, want_be, nsym, nbits)
 
 
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
