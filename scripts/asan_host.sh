@@ -8,10 +8,11 @@
 set -e
 cd "$(dirname "$0")/.."
 LOG=${1:-profiles/r06/asan_host.log}
-make -C pyphysim_amd/csrc -j8 asan > /tmp/asan_build.log 2>&1
+SAN="-fsanitize=address -fno-gpu-sanitize -shared-libsan"
+make -C pyphysim_amd/csrc -j8 asan SAN="$SAN" > /tmp/asan_build.log 2>&1
 RT=$(/opt/rocm/lib/llvm/bin/clang --print-file-name=libclang_rt.asan-x86_64.so)
 {
-  echo "# scripts/asan_host.sh: $(date -u +%F) host ASAN build of libmcle (hipcc -fsanitize=address -fno-gpu-sanitize -shared-libsan)"
+  echo "# scripts/asan_host.sh: $(date -u +%F) host AddressSanitizer build of libmcle (hipcc, host code only, shared sanitizer runtime)"
   echo "# runtime: $RT"
   MCLE_LIBRARY=$PWD/pyphysim_amd/csrc/asan/libmcle_asan.so LD_PRELOAD=$RT \
   ASAN_OPTIONS=detect_leaks=0:abort_on_error=0:halt_on_error=1:detect_odr_violation=0:protect_shadow_gap=0 \
