@@ -108,7 +108,10 @@ __device__ __forceinline__ void r16_wave_sync() {
 // BAR: a workgroup barrier between the pass's arithmetic and its stores -- for a caller whose planes are still being READ by the
 // other wavefronts of the workgroup when the pass starts (mimo_tdl_wave.hpp: the receive transform's first pass takes its inputs
 // from registers while the other receive antennas finish their delay-line reads of this antenna's time signal).
-template <typename T, bool INV, bool DIT, int WHICH, bool EXACT = false, bool REGIN = false, bool REGOUT = false, bool BAR = false>
+// UNIT: every lane twiddle is 1 (t1 = t2 = 1: a 16-point transform of sixteen CONSECUTIVE elements, the constant 16th roots only) --
+// the second register pass of a 256-point transform (pipeline_mimo_qw.hip)
+template <typename T, bool INV, bool DIT, int WHICH, bool EXACT = false, bool REGIN = false, bool REGOUT = false, bool BAR = false,
+          bool UNIT = false>
 __device__ __forceinline__ void r16_pass(T* pr, T* pi, int base_slot, const R16Tw64<T>& tw,
                                          const cx<T>* __restrict__ g_tw = nullptr, int kidx = 0, const cx<T>* vin = nullptr,
                                          cx<T>* vout = nullptr) {
@@ -149,22 +152,22 @@ __device__ __forceinline__ void r16_pass(T* pr, T* pi, int base_slot, const R16T
                 v[2][q] = CxOps<T>::template mulw<INV>(v[2][q], tw1(qc, std::integral_constant<int, 2>()));
                 v[3][q] = CxOps<T>::template mulw<INV>(v[3][q], tw1(qc, std::integral_constant<int, 3>()));
             } else {
-                v[1][q] = r16_root<T, INV, q * 1>(CxOps<T>::template mulw<INV>(v[1][q], t1[0]));
-                v[2][q] = r16_root<T, INV, q * 2>(CxOps<T>::template mulw<INV>(v[2][q], t1[1]));
-                v[3][q] = r16_root<T, INV, q * 3>(CxOps<T>::template mulw<INV>(v[3][q], t1[2]));
+                v[1][q] = r16_root<T, INV, q * 1>(UNIT ? v[1][q] : CxOps<T>::template mulw<INV>(v[1][q], t1[0]));
+                v[2][q] = r16_root<T, INV, q * 2>(UNIT ? v[2][q] : CxOps<T>::template mulw<INV>(v[2][q], t1[1]));
+                v[3][q] = r16_root<T, INV, q * 3>(UNIT ? v[3][q] : CxOps<T>::template mulw<INV>(v[3][q], t1[2]));
             }
         });
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             r4_inplace<T, INV>(v[m][0], v[m][1], v[m][2], v[m][3]);
 #pragma unroll
-            for (int q = 1; q < 4; ++q) v[m][q] = CxOps<T>::template mulw<INV>(v[m][q], t2[q - 1]);
+            for (int q = 1; q < 4; ++q) if (!UNIT) v[m][q] = CxOps<T>::template mulw<INV>(v[m][q], t2[q - 1]);
         }
     } else {
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
 #pragma unroll
-            for (int q = 1; q < 4; ++q) v[m][q] = CxOps<T>::template mulw<INV>(v[m][q], t2[q - 1]);
+            for (int q = 1; q < 4; ++q) if (!UNIT) v[m][q] = CxOps<T>::template mulw<INV>(v[m][q], t2[q - 1]);
             r4_inplace<T, INV>(v[m][0], v[m][1], v[m][2], v[m][3]);
         }
         static_for<4>([&](auto qc) {
@@ -174,9 +177,9 @@ __device__ __forceinline__ void r16_pass(T* pr, T* pi, int base_slot, const R16T
                 v[2][q] = CxOps<T>::template mulw<INV>(v[2][q], tw1(qc, std::integral_constant<int, 2>()));
                 v[3][q] = CxOps<T>::template mulw<INV>(v[3][q], tw1(qc, std::integral_constant<int, 3>()));
             } else {
-                v[1][q] = r16_root<T, INV, q * 1>(CxOps<T>::template mulw<INV>(v[1][q], t1[0]));
-                v[2][q] = r16_root<T, INV, q * 2>(CxOps<T>::template mulw<INV>(v[2][q], t1[1]));
-                v[3][q] = r16_root<T, INV, q * 3>(CxOps<T>::template mulw<INV>(v[3][q], t1[2]));
+                v[1][q] = r16_root<T, INV, q * 1>(UNIT ? v[1][q] : CxOps<T>::template mulw<INV>(v[1][q], t1[0]));
+                v[2][q] = r16_root<T, INV, q * 2>(UNIT ? v[2][q] : CxOps<T>::template mulw<INV>(v[2][q], t1[1]));
+                v[3][q] = r16_root<T, INV, q * 3>(UNIT ? v[3][q] : CxOps<T>::template mulw<INV>(v[3][q], t1[2]));
             }
             r4_inplace<T, INV>(v[0][q], v[1][q], v[2][q], v[3][q]);
         });

@@ -38,65 +38,9 @@
 #include "philox.hpp"
 #include "totals.hpp"
 #include "pipe_common.hpp"
+#include "mimo_planar_common.hpp"
 
 namespace mcle {
-
-struct MimoParams {
-    int cp, num_used, n_ofdm_sym;
-    int mmse;
-    double noise_var;
-};
-
-template <int NT, int NR> constexpr int d64_rec() { return 2 * NT * NR + 1; }     // H, G x FFT scale, skip flag
-
-
-// complex64: the channel is drawn in float (the draw ledger of the complex64 kernels), the filter computed in double and rounded
-template <typename T, int N, int NT, int NR>
-__global__ __launch_bounds__(64) void k_mimo_filters_planar(MimoParams pp, uint64_t seed, uint64_t first, uint64_t count,
-                                                            cx<T>* __restrict__ recs) {
-    constexpr int kRec = d64_rec<NT, NR>();
-    const uint64_t rl = (uint64_t)blockIdx.x * 64 + threadIdx.x;
-    if (rl >= count) return;
-    const double rx_scale = sqrt((double)(pp.num_used + pp.cp)) / (double)N;
-    const Rng rng(seed, first + rl);
-    cx<T>* rec = recs + rl * kRec;
-    double2 H[NR][NT], G[NT][NR];
-#pragma unroll
-    for (int r = 0; r < NR; ++r)
-#pragma unroll
-        for (int a = 0; a < NT; ++a) {
-            const cx<T> h = cn_sample<T>(rng, STREAM_CHAN, (uint64_t)(r * NT + a), (T)1);
-            rec[r * NT + a] = h;
-            H[r][a] = mk<double>((double)h.x, (double)h.y);
-        }
-    const bool ok = blast_filter<NT, NR>(H, pp.mmse ? pp.noise_var : 0.0, G);
-#pragma unroll
-    for (int a = 0; a < NT; ++a)
-#pragma unroll
-        for (int r = 0; r < NR; ++r) rec[NT * NR + a * NR + r] = mk<T>((T)(G[a][r].x * rx_scale), (T)(G[a][r].y * rx_scale));
-    rec[2 * NT * NR] = mk<T>(ok ? (T)0 : (T)1, (T)0);
-}
-
-// lanes l and l ^ 32 exchange: (a of the lower half, b of the upper half) stay, the other two cross over --
-// x = {lower: own a, upper: the partner's b}, y = {lower: the partner's a, upper: own b}  (v_permlane32_swap_b32)
-__device__ __forceinline__ void swap32_pair(double a, double b, double& x, double& y) {
-    const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
-    const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
-    x = __hiloint2double((int)hi[0], (int)lo[0]);
-    y = __hiloint2double((int)hi[1], (int)lo[1]);
-}
-__device__ __forceinline__ void swap32_pair(float a, float b, float& x, float& y) {
-    const auto v = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-    x = __uint_as_float(v[0]);
-    y = __uint_as_float(v[1]);
-}
-
-// one CN(0, sigma^2) sample from two Philox words: complex128 through the LDS Box-Muller tables, complex64 by the hardware
-// transcendentals (the complex64 kernels' draw)
-__device__ __forceinline__ double2 cn_words(uint32_t x0, uint32_t x1, double sigma, const double* s_bm) {
-    return cn_from_words_lds(x0, x1, sigma, s_bm);
-}
-__device__ __forceinline__ float2 cn_words(uint32_t x0, uint32_t x1, float sigma, const double*) { return cn_from_words(x0, x1, sigma); }
 
 // N, NT x NR: the geometry.  AH = antennas per thread in the transform stages, TB = (N / 4) (NR / AH) threads per
 // workgroup, WPS = wavefronts per SIMD the register allocation is bounded for (what the LDS lets share a CU).  The
@@ -578,6 +522,10 @@ static int launch_mimo_ofdm_planar(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg,
 // instead of two.
 template <typename T> constexpr int planar_wps(int w64) { return w64; }
 
+// pipeline_mimo_qw.hip: the quarter-wave kernel of the benchmark geometry (complex128; MCLE_E_UNSUPPORTED outside its envelope)
+int run_mimo_ofdm_qw(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, uint64_t seed, uint64_t first, uint64_t count,
+                     mcle_counters* d_counters, uint32_t* d_sym, uint32_t* d_bit);
+
 template <typename T>
 static int run_mimo_ofdm_planar_t(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, uint64_t seed, uint64_t first, uint64_t count,
                                   mcle_counters* d_counters, uint32_t* d_sym, uint32_t* d_bit) {
@@ -592,6 +540,12 @@ static int run_mimo_ofdm_planar_t(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, 
     // antennas per thread, twiddles in registers.  MCLE_OPT_F64_VARIANT 1 .. 3: timing bounds on the 512-thread form.
     if (n == 1024 && nt == 4 && nr == 4) {
         if constexpr (F64) {
+            // MCLE_OPT_F64_THREADS 260 / 262: the quarter-wave kernel (three / two wavefronts per SIMD); outside its envelope (partial
+            // band, odd prefix) the request falls through to the planar forms below
+            if (ctx->opt[MCLE_OPT_F64_THREADS] == 260 || ctx->opt[MCLE_OPT_F64_THREADS] == 262) {
+                const int rq = run_mimo_ofdm_qw(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
+                if (rq != MCLE_E_UNSUPPORTED) return rq;
+            }
 #ifdef MCLE_EXPERIMENTS     // the timing-bound variants give WRONG counters by construction: never in the product build
             switch ((int)ctx->opt[MCLE_OPT_F64_VARIANT]) {
                 case 1: return launch_mimo_ofdm_planar<T, 1024, 4, 4, 2, 4, 1>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
