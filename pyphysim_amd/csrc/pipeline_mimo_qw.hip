@@ -46,6 +46,15 @@ __host__ __device__ __forceinline__ int qw_slot(int a, int e) { return a * 272 +
 // time index (within the wavefront's 256 samples) held by register c of lane group h after the second DIF pass
 __host__ __device__ __forceinline__ int qw_mtime(int h, int c) { return (c & 3) * 64 + (c >> 2) * 16 + (h & 3) * 4 + (h >> 2); }
 
+// ordering of a wavefront's OWN LDS traffic (the transpositions through its private plane): the DS queue executes a wavefront's
+// instructions in order, so a store followed by a load of another lane's slot needs no wait -- only the compiler must keep the
+// program order (fft_r16.hpp's r16_wave_sync fences at workgroup scope, i.e. s_waitcnt lgkmcnt(0): a full LDS round trip per phase)
+__device__ __forceinline__ void qw_wave_order() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __device__ __forceinline__ void swap16_pair(double a, double b, double& x, double& y) {
     // rows of 16 lanes: x = {even rows: own a, odd rows: b of lane - 16}, y = {even rows: a of lane + 16, odd rows: own b}
     const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
@@ -243,13 +252,13 @@ __global__ __launch_bounds__(256, WPS) void k_run_mimo_ofdm_qw(MimoParams pp, Mo
                 T xr[16];
 #pragma unroll
                 for (int u = 0; u < 16; ++u) s_mine[wbase + 17 * u] = v[u].x;
-                r16_wave_sync();
+                qw_wave_order();
 #pragma unroll
                 for (int c = 0; c < 16; ++c) xr[c] = s_mine[rbase + c];
-                r16_wave_sync();
+                qw_wave_order();
 #pragma unroll
                 for (int u = 0; u < 16; ++u) s_mine[wbase + 17 * u] = v[u].y;
-                r16_wave_sync();
+                qw_wave_order();
 #pragma unroll
                 for (int c = 0; c < 16; ++c) v[c] = mk<T>(xr[c], s_mine[rbase + c]);
             }
@@ -258,13 +267,18 @@ __global__ __launch_bounds__(256, WPS) void k_run_mimo_ofdm_qw(MimoParams pp, Mo
                 R16Tw64<T> none;
                 r16_pass<T, true, false, 0, false, true, true, false, true>(nullptr, nullptr, 0, none, nullptr, 0, v, v);
             }
-            // ---- channel: lane (a, h) holds T_a at sixteen sample times; R_r = sum_a H[r][a] T_a + noise by a reduce-scatter over
-            //      the lanes (0..3, h) ----
+            // ---- channel: lane (a, h) holds T_a at sixteen sample times, and R_r = sum_a H[r][a] T_a + noise has to end in lane (r, h).
+            //      That IS v_mfma_f64_4x4x4 (four independent 4 x 4 x 4 products per instruction; lane maps measured in round 3,
+            //      profiles/r03/f64_rates.txt: A_b[i][k] <- lane 4 b + i + 16 k, B_b[k][j] <- lane 4 b + j + 16 k, D_b[i][j] -> lane
+            //      4 b + j + 16 i): with k = the transmit antenna (the lane's row), j + 4 b = h and i = the receive antenna, B is the
+            //      lane's own sample, D lands in the receive antenna's row, and A_b[i][k] = H[i][k] for every block -- lane (a, h)
+            //      supplies H[h mod 4][a].  Four instructions per sample time (re / im of H x re / im of T; the noise sample is the
+            //      accumulator's start) where the VALU form was 16 multiply-adds + 6 adds + 12 lane swaps: the batched
+            //      Nt x Nr x Ns contraction on the matrix cores (BASELINE.json north_star). ----
             {
-                const int a = opaque(lane) >> 4;
-                cx<T> Hc[NR];
-#pragma unroll
-                for (int r = 0; r < NR; ++r) Hc[r] = s_H[r * NT + a];
+                const int ln = opaque(lane);
+                const cx<T> hA = s_H[(ln & 3) * NT + (ln >> 4)];                   // H[h mod 4][a]
+                const T hre = hA.x, him = hA.y, nhim = -hA.y;
 #pragma unroll
                 for (int c = 0; c < 16; ++c) {
                     cx<T> z;
@@ -273,22 +287,11 @@ __global__ __launch_bounds__(256, WPS) void k_run_mimo_ofdm_qw(MimoParams pp, Mo
                     if constexpr (ABL & 256) {
                         v[c] = cadd(v[c], z);
                     } else {
-                        cx<T> p[NR];
-#pragma unroll
-                        for (int r = 0; r < NR; ++r) p[r] = cmul(Hc[r], v[c]);
-                        // lanes a and a ^ 2: the lower half keeps the sums of r = 0, 1, the upper half those of r = 2, 3
-                        T x0, y0, x1, y1;
-                        cx<T> s02, s13;
-                        swap32_pair(p[0].x, p[2].x, x0, y0);
-                        swap32_pair(p[0].y, p[2].y, x1, y1);
-                        s02 = mk<T>(x0 + y0, x1 + y1);
-                        swap32_pair(p[1].x, p[3].x, x0, y0);
-                        swap32_pair(p[1].y, p[3].y, x1, y1);
-                        s13 = mk<T>(x0 + y0, x1 + y1);
-                        // lanes a and a ^ 1: the even row keeps the even r, the odd row the odd r -> lane (r, h) holds R_r
-                        swap16_pair(s02.x, s13.x, x0, y0);
-                        swap16_pair(s02.y, s13.y, x1, y1);
-                        v[c] = mk<T>((x0 + y0) + z.x, (x1 + y1) + z.y);
+                        T yr = __builtin_amdgcn_mfma_f64_4x4x4f64(hre, v[c].x, z.x, 0, 0, 0);
+                        T yi = __builtin_amdgcn_mfma_f64_4x4x4f64(him, v[c].x, z.y, 0, 0, 0);
+                        yr = __builtin_amdgcn_mfma_f64_4x4x4f64(nhim, v[c].y, yr, 0, 0, 0);
+                        yi = __builtin_amdgcn_mfma_f64_4x4x4f64(hre, v[c].y, yi, 0, 0, 0);
+                        v[c] = mk<T>(yr, yi);
                     }
                 }
             }
@@ -304,13 +307,13 @@ __global__ __launch_bounds__(256, WPS) void k_run_mimo_ofdm_qw(MimoParams pp, Mo
                 T xr[16];
 #pragma unroll
                 for (int c = 0; c < 16; ++c) s_mine[rbase + c] = v[c].x;
-                r16_wave_sync();
+                qw_wave_order();
 #pragma unroll
                 for (int u = 0; u < 16; ++u) xr[u] = s_mine[wbase + 17 * u];
-                r16_wave_sync();
+                qw_wave_order();
 #pragma unroll
                 for (int c = 0; c < 16; ++c) s_mine[rbase + c] = v[c].y;
-                r16_wave_sync();
+                qw_wave_order();
 #pragma unroll
                 for (int u = 0; u < 16; ++u) v[u] = mk<T>(xr[u], s_mine[wbase + 17 * u]);
             }
