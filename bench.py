@@ -110,6 +110,8 @@ def kernel_name(cfg, dtype):
         return "k_run_ofdm_tdl_batch" if (dtype == "f64" or ACTIVE_OPTS.get("no_mfma")) else "k_run_ofdm_tdl_mfma"
     if cfg == "f1" and ACTIVE_OPTS.get("mimo_tdl_kernel") == 1:
         return "k_run_mimo_ofdm_tdl"                  # the workgroup-cooperative kernel of rounds 1-4
+    if cfg == "c4" and dtype == "f64" and ACTIVE_OPTS.get("f64_threads", 0) in (0, 260, 262):
+        return "k_run_mimo_ofdm_qw"                   # the quarter-wave kernel (round 6; bench.py's workload is inside its envelope)
     return (KERNEL_F64 if dtype == "f64" else KERNEL)[cfg]
 
 KERNEL_NOTE = {   # configs whose step is two launches: the time spans both, the counters are the named (dominant) kernel's
@@ -118,7 +120,10 @@ KERNEL_NOTE = {   # configs whose step is two launches: the time spans both, the
           "wavefront; since round 4 the default ahead of the matrix-core kernel k_run_mimo_ofdm_mfma, option f32_mfma = 1); "
           "kernel_ms_per_launch spans them",
     ("c4", "f64"): "a step = per slice of 2^18 realizations k_mimo_filters_planar (channel draw + f64 receive filter, one thread per "
-                   "realization, ~1 % of the time) + k_run_mimo_ofdm_planar; kernel_ms_per_launch spans them",
+                   "realization, ~1 % of the time) + k_run_mimo_ofdm_qw (round 6: a wavefront owns one time class n mod 4 of all four "
+                   "antennas, samples in registers between radix-16 passes, three workgroups per CU, the channel contraction on "
+                   "v_mfma_f64_4x4x4; option f64_threads=261: the planar kernel k_run_mimo_ofdm_planar of rounds 3-5); "
+                   "kernel_ms_per_launch spans them",
     ("c3", "f64"): "a step = k_tdl_symbol_polys<double> (fading records) + k_run_ofdm_tdl_wave<double> (one realization per "
                    "wavefront; option tdl_kernel=1: k_run_ofdm_tdl_batch<double, 1024, 2>) per slice of <= 2 GiB of records; "
                    "kernel_ms_per_launch spans them",
@@ -547,8 +552,9 @@ def roofline_block(args, dtype, batch, per_launch_s, rate_kernel, d, pmc_source)
                      "B_alg / %s of the staged model and the kernel is bound by the SIMDs' %s datapath%s; "
                      "frac = algorithmic flops (RNG excluded) / peak"
                      % (("%.0f" % (balg / measured)) if measured else "?", "FP64" if dtype == "f64" else "FP32",
-                        " (VALU only: the f64 MFMA forms are no denser than v_fma_f64 here and do not overlap with it, "
-                        "DESIGN.md section 5.5)" if dtype == "f64" else
+                        " (VALU, plus v_mfma_f64_4x4x4 for the H x contraction of the quarter-wave kernel -- mfma_busy_chip; the "
+                        "f64 MFMA forms are no denser than v_fma_f64 and do not overlap with it, DESIGN.md sections 5.5 / 5.10)"
+                        if dtype == "f64" else
                         " (VALU; the matrix-core form of this configuration, option f32_mfma, shares that datapath: f32 MFMA and "
                         "VALU instructions do not overlap on gfx950)")}
     return block

@@ -96,11 +96,17 @@ enum {
                                       realizations per pass instead of four */
     MCLE_OPT_JAKES_DIRECT = 6,     /* 1: one sincos per ray and sample (jakes_generate: k_jakes; complex128 flat-fading pipeline: no rotation recurrence) */
     MCLE_OPT_F64_GENERIC = 7,      /* 1: config 4 on the generic radix-4 kernel instead of the planar family (either arithmetic) */
-    MCLE_OPT_F64_THREADS = 8,      /* complex128 config-4 kernel at (1024, 4x4): 0 = radix-16 passes, one transform per wavefront,
-                                      the channel fused with the span-1 butterflies, 256-thread workgroups (default); 257 = the same
-                                      with a separate channel stage; 258 = the same as 0 with every layer-1 twiddle from the table;
+    MCLE_OPT_F64_THREADS = 8,      /* complex128 config-4 kernel at (1024, 4x4): 0 = the quarter-wave kernel (round 6,
+                                      csrc/pipeline_mimo_qw.hip: a wavefront owns one time class n mod 4 of all antennas, samples in
+                                      registers between radix-16 passes, three workgroups per CU, the channel contraction on
+                                      v_mfma_f64_4x4x4) wherever its envelope holds -- full band, even cyclic prefix, decisions by
+                                      slicer or certificate -- and the planar radix-16 form elsewhere (default); 260 = the same,
+                                      explicit; 262 = quarter-wave bounded for two wavefronts per SIMD; 261 = the planar radix-16
+                                      form (one transform per wavefront, the channel fused with the span-1 butterflies: the default
+                                      of rounds 4-5); 257 = that with a separate channel stage; 258 = 261 with every layer-1 twiddle
+                                      from the table;
                                       512 = radix-4 stages, two antennas per thread, 512 threads; 256 = radix-4 stages, four antennas
-                                      per thread, 256 threads (all five: same results contract; A/B times in DESIGN.md 5.5).
+                                      per thread, 256 threads (all of them: same results contract; A/B times in DESIGN.md 5.5 / 5.10).
                                       complex64 (the planar family on planes of floats): 0 = radix-16 passes with a SEPARATE channel
                                       stage at a four-wavefront register bound (default); 257 = the same at a three-wavefront
                                       bound; 259 = the fused channel stage; 512 / 256 as above.

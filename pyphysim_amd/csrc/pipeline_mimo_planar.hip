@@ -540,11 +540,17 @@ static int run_mimo_ofdm_planar_t(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, 
     // antennas per thread, twiddles in registers.  MCLE_OPT_F64_VARIANT 1 .. 3: timing bounds on the 512-thread form.
     if (n == 1024 && nt == 4 && nr == 4) {
         if constexpr (F64) {
-            // MCLE_OPT_F64_THREADS 260 / 262: the quarter-wave kernel (three / two wavefronts per SIMD); outside its envelope (partial
-            // band, odd prefix) the request falls through to the planar forms below
-            if (ctx->opt[MCLE_OPT_F64_THREADS] == 260 || ctx->opt[MCLE_OPT_F64_THREADS] == 262) {
-                const int rq = run_mimo_ofdm_qw(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
-                if (rq != MCLE_E_UNSUPPORTED) return rq;
+            // The default since round 6: the QUARTER-WAVE kernel (pipeline_mimo_qw.hip: samples in registers between the passes, three
+            // workgroups per CU, the channel contraction on v_mfma_f64_4x4x4) -- 8.82 against 10.49 ms per 262 144 realizations
+            // (profiles/r06/qw_ab.log).  Outside its envelope (partial band, odd prefix, a constellation without a certificate)
+            // the launch stays on the planar forms below.  MCLE_OPT_F64_THREADS: 260 = quarter-wave (the default, explicit),
+            // 262 = the same bounded for two wavefronts per SIMD, 261 = the planar radix-16 form that was the default until round 5.
+            {
+                const long long thr = ctx->opt[MCLE_OPT_F64_THREADS];
+                if (thr == 0 || thr == 260 || thr == 262) {
+                    const int rq = run_mimo_ofdm_qw(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
+                    if (rq != MCLE_E_UNSUPPORTED) return rq;
+                }
             }
 #ifdef MCLE_EXPERIMENTS     // the timing-bound variants give WRONG counters by construction: never in the product build
             switch ((int)ctx->opt[MCLE_OPT_F64_VARIANT]) {

@@ -31,6 +31,10 @@
 // Envelope: fft_size 1024, 4 x 4, full band (num_used = 1024), even cyclic prefix; anything else stays on the planar kernel.
 #include "mimo_planar_common.hpp"
 
+#ifndef MCLE_QW_ROLLED_DECODE
+#define MCLE_QW_ROLLED_DECODE 0      // 1: the four bins of a thread in a rolled loop (A/B, profiles/r06/qw_ab.log)
+#endif
+
 namespace mcle {
 
 constexpr int kQwLabStride = 80;                 // bytes per (antenna, group) row of labels: 64 + 16 (bank rotation, 16-byte aligned)
@@ -368,27 +372,51 @@ __global__ __launch_bounds__(256, WPS) void k_run_mimo_ofdm_qw(MimoParams pp, Mo
 #pragma unroll
                 for (int a = 0; a < NT; ++a)
                     labw[a] = *reinterpret_cast<const uint32_t*>(s_lab + (a * 16 + (t & 15)) * kQwLabStride + 4 * (t >> 4));
+                // Four bins per thread, straight-line: the filter, then the slicer or the margin certificates of the four streams.  A
+                // symbol its certificate does not vouch for (one chance in ~1e8 under the QAM certificate) goes through the plain
+                // SWEEP over the table -- a dozen instructions of rolled loop per stream, not the inlined lockstep candidate-grid search
+                // of the planar kernels: the first edition of this kernel inlined that search four times, 114 KB of decode in a 150 KB
+                // kernel against an instruction cache of 64 KB per two CUs (and a rolled decode loop around one copy of it spilled 63
+                // registers at the 168-register bound).  The launcher sends constellations WITHOUT a certificate to the planar kernel.
+#if MCLE_QW_ROLLED_DECODE
+#pragma unroll 1
+#else
 #pragma unroll
+#endif
                 for (int q = 0; q < 4; ++q) {
                     cx<T> est[NT];
                     int dec[NT];
+                    constexpr bool kRolled = MCLE_QW_ROLLED_DECODE != 0;
+                    const int qi = kRolled ? 0 : q;                          // rolled: the rows of Y move up by one after every bin
 #pragma unroll
                     for (int a = 0; a < NT; ++a) {
                         est[a] = mk<T>(0, 0);
 #pragma unroll
-                        for (int rr = 0; rr < NR; ++rr) est[a] = cfma4(s_G[a * NR + rr], Y[q][rr], est[a]);
+                        for (int rr = 0; rr < NR; ++rr) est[a] = cfma4(s_G[a * NR + rr], Y[qi][rr], est[a]);
                     }
-                    if (mp.method != MCLE_DEMOD_QAM_SLICER && mp.grid.G > 0) {
-                        demod_multi_cert(mp, est, dec, [&](int (&d_)[NT]) { demod_grid_multi<NT>(s_table, s_grid, mp.grid, mp.M, est, d_); });
-                    } else {
+                    if (mp.method == MCLE_DEMOD_QAM_SLICER) {
 #pragma unroll
-                        for (int a = 0; a < NT; ++a) dec[a] = demod_one<T>(mp, s_table, s_grid, est[a]);
+                        for (int a = 0; a < NT; ++a) dec[a] = demod_qam_slicer<T>(est[a], mp.qam_scale, mp.qam_L, mp.half_bits);
+                    } else {
+                        demod_multi_cert(mp, est, dec, [&](int (&d_)[NT]) {
+#pragma unroll 1
+                            for (int a = 0; a < NT; ++a) d_[a] = demod_mindist<T>(s_table, mp.M, est[a]);
+                        });
                     }
 #pragma unroll
                     for (int a = 0; a < NT; ++a) {
-                        const unsigned x = ((labw[a] >> (8 * q)) & 0xFFu) ^ (unsigned)dec[a];
+                        const unsigned x = (labw[a] & 0xFFu) ^ (unsigned)dec[a];
                         se += (x != 0u);
                         be += __popc(x);
+                        labw[a] >>= 8;
+                    }
+                    if constexpr (kRolled) {
+#pragma unroll
+                        for (int rr = 0; rr < NR; ++rr) {
+                            Y[0][rr] = Y[1][rr];
+                            Y[1][rr] = Y[2][rr];
+                            Y[2][rr] = Y[3][rr];
+                        }
                     }
                 }
             } else {
@@ -464,6 +492,8 @@ int run_mimo_ofdm_qw(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, uint64_t seed
     if (!(cfg->fft_size == 1024 && cfg->nt == 4 && cfg->nr == 4 && cfg->num_used == 1024 && (cfg->cp_size & 1) == 0))
         return MCLE_E_UNSUPPORTED;
     if (ctx->M > 256) return MCLE_E_UNSUPPORTED;
+    // min-distance decisions through a certificate (square QAM, QPSK) or the slicer: the sweep behind the certificate is the rare path here
+    if (cfg->demod_method != MCLE_DEMOD_QAM_SLICER && modem_cert(ctx, cfg->demod_method) == 0) return MCLE_E_UNSUPPORTED;
 #ifdef MCLE_EXPERIMENTS
     switch ((int)ctx->opt[MCLE_OPT_F64_VARIANT]) {
 #define MCLE_QW_ABL(V_) case V_: return launch_mimo_ofdm_qw<3, V_>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);

@@ -31,7 +31,7 @@ KEYS = (".vgpr_count", ".agpr_count", ".sgpr_count", ".vgpr_spill_count", ".sgpr
 DEFAULT = [
     # config 4 family (pipeline_mimo_planar.hip: run_mimo_ofdm_planar_t): 1024 with four receive antennas = radix-16 passes
     # (complex128 fused, two per SIMD; complex64 unfused, four), every other shape the radix-4 table
-    r"k_run_mimo_ofdm_planar<double, 1024, [1-4], 4, 4, 2, 12>", r"k_run_mimo_ofdm_planar<float, 1024, [1-4], 4, 4, 4, 4>",
+    r"k_run_mimo_ofdm_qw<3, 0>", r"k_run_mimo_ofdm_planar<double, 1024, [1-4], 4, 4, 2, 12>", r"k_run_mimo_ofdm_planar<float, 1024, [1-4], 4, 4, 4, 4>",
     r"k_run_mimo_ofdm_planar<(double|float), 256, [12], 2, 2, 2, 0>", r"k_run_mimo_ofdm_planar<(double|float), 256, [1-3], 3, 3, 2, 0>",
     r"k_run_mimo_ofdm_planar<(double|float), 256, [1-4], 4, 2, 3, 0>",
     r"k_run_mimo_ofdm_planar<(double|float), 512, [12], 2, 2, 3, 0>", r"k_run_mimo_ofdm_planar<(double|float), 512, [1-3], 3, 3, 2, 0>",

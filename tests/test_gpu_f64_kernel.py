@@ -42,7 +42,7 @@ def test_f64_kernel_counts_equal_the_oracle(engine, case):
     for method in methods:
         # radix-16 passes with the fused middle stage (default) / with the separate channel stage / radix-4: two antennas per
         # thread / four antennas per thread
-        for threads, variant in ((0, 0), (257, 0), (512, 0), (256, 0)):
+        for threads, variant in ((0, 0), (261, 0), (257, 0), (512, 0), (256, 0)):
             res, se, be = _run(engine, kw, first, count, method, threads=threads, variant=variant)
             assert np.array_equal(se, want_se) and np.array_equal(be, want_be), (case, method, threads, variant, se, want_se)
             assert res["n_realizations"] == count and res["sym_errors"] == int(want_se.sum())
@@ -62,7 +62,7 @@ def test_f64_kernel_equals_the_generic_kernel(engine, case):
     new, se, be = _run(engine, kw, 5, n, method, threads=512)
     alt, se_a, be_a = _run(engine, kw, 5, n, method, threads=256)
     assert np.array_equal(se, se_a) and np.array_equal(be, be_a) and new == alt          # same arithmetic, other thread map
-    r16, se_r, be_r = _run(engine, kw, 5, n, method)                # radix-16 passes (default): one more rounding per layer-1 twiddle
+    r16, se_r, be_r = _run(engine, kw, 5, n, method, threads=261)   # radix-16 passes (planar): one more rounding per layer-1 twiddle
     assert np.count_nonzero(se != se_r) <= 1 and np.max(np.abs(se.astype(int) - se_r.astype(int))) <= 1
     assert r16["n_realizations"] == new["n_realizations"] and r16["n_skipped"] == new["n_skipped"]
     old, se_o, be_o = _run(engine, kw, 5, n, method, generic=True)
@@ -86,7 +86,7 @@ def test_f64_kernel_against_the_oracle_over_2000_realizations(engine):
     want_se = np.array([w["symbol_errors"] for w in want])
     want_be = np.array([w["bit_errors"] for w in want])
     assert want_se.sum() > 1e5                                  # a realization in outage is thousands of errors
-    for threads, variant in ((0, 0), (257, 0), (512, 0), (256, 0)):
+    for threads, variant in ((0, 0), (261, 0), (257, 0), (512, 0), (256, 0)):
         for method, nocert in ((_lib.DEMOD_MINDIST, 0), (_lib.DEMOD_MINDIST, 1), (_lib.DEMOD_QAM_SLICER, 0)):
             with engine.options(demod_nocert=nocert):
                 res, se, be = _run(engine, kw, first, count, method, threads=threads, variant=variant)
