@@ -36,7 +36,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
-ROUND = "r05"
+ROUND = "r06"
 # algorithmic bytes per realization in the staged (operator-granular)
 # model, complex64 samples / uint8 indices.
 B_ALG = {"c2": 7_600_000, "c3": 211_360, "c4": 412_160, "c5": 62_000, "f1": 3_099_008,
@@ -58,7 +58,11 @@ FLOPS = {
     "c2": {"Jakes 8 rays x 1e5 (phase, sincos, add)": 4_800_000, "fade + equalise 1e5 x 22": 2_200_000,
            "slicer 1e5 x 10": 1_000_000},
     "f1": {"8 x FFT-1024": 409_600, "TDL 5 taps x 16 links x 1040 cMAC": 665_600,
-           "H(f) 1024 x 16 x 5 cMAC": 655_360, "MMSE solve per subcarrier 1024 x ~1.1 kflop": 1_126_400,
+           "H(f) 1024 x 16 x 5 cMAC": 655_360,
+           # per subcarrier: Hermitian Gram H^H H (10 entries x 4 cMAC = 320) + H^H y (16 cMAC = 128) + diagonal load (4) + complex
+           # Cholesky 4 x 4 (~170 + 4 sqrt / 4 rcp) + two triangular substitutions (2 x 10 cMAC = 160) + slack = ~0.96 kflop
+           # (rounds 3-5 booked ~1.1 kflop: 15 % generous)
+           "MMSE solve per subcarrier 1024 x ~0.96 kflop": 983_040,
            "slicer": 40_960},
     "c5": {"link 600 x 15 cMAC": 72_000, "closed-form solve (f64)": 6_000, "demod 600 x 10": 6_000},
     "f6": {"link 3000 x (1 + 2) cMAC": 72_000, "BD solve + pinv (f64)": 20_000, "demod 3000 x 6": 18_000},
@@ -140,6 +144,44 @@ KERNEL_NOTE = {   # configs whose step is two launches: the time spans both, the
 # (round 2 timed 29 ms in all).  Nothing in BASELINE.json fixes the batch; a step is one call of the pipeline's C entry point.
 BATCH = {"c4": 1048576, "c3": 2097152, "c2": 131072, "c5": 4194304, "f1": 393216, "f6": 1048576}
 BATCH_SURVEY = {"c4": 65536, "c3": 131072, "c2": 16384, "c5": 262144, "f1": 98304, "f6": 131072}   # other_workloads legs
+
+
+def profile_specs():
+    """tag -> the bench arguments (config, dtype, demodulator, batch, options) a committed profile of that tag is taken with, and
+    the dominant kernel's name.  ONE table for scripts/prof_r06.sh and scripts/collect_profiles.py: every `other_workloads` leg is
+    profiled at the batch and the demodulator its leg prints (round 5 profiled config 2 with another
+    demodulator and four configurations at another batch than their legs), the headline at the size of one dispatch of a step
+    (the pipeline cuts a step into slices of 2^18 realizations).  tests/test_bench_launch.py holds the table to BATCH_SURVEY."""
+    specs = {}
+    hl = min(BATCH["c4"], 1 << 18)
+
+    def add(tag, cfg, dtype, demod, batch, opts=(), leg=None, note=None):
+        saved = dict(ACTIVE_OPTS)
+        ACTIVE_OPTS.clear()
+        for o in opts:
+            k, _, v = o.partition("=")
+            ACTIVE_OPTS[k] = int(v)
+        try:
+            needle = kernel_name(cfg, dtype)
+        finally:
+            ACTIVE_OPTS.clear()
+            ACTIVE_OPTS.update(saved)
+        specs[tag] = {"config": cfg, "dtype": dtype, "demod": demod, "batch": batch, "opts": list(opts), "kernel": needle,
+                      "leg": leg, "note": note}
+    add("c4_f64", "c4", "f64", "mindist", hl, leg="value", note="the headline: quarter-wave kernel, min-distance (certificate)")
+    add("c4_f64sl", "c4", "f64", "slicer", hl, leg="rates.f64.slicer")
+    add("c4_f64_planar", "c4", "f64", "mindist", hl, opts=("f64_threads=261",), note="the planar kernel of rounds 3-5 (A/B)")
+    add("c4", "c4", "f32", "slicer", hl, leg="rates.f32.slicer")
+    add("c4md", "c4", "f32", "mindist", hl, leg="rates.f32.mindist")
+    add("c4md_mfma", "c4", "f32", "mindist", BATCH_SURVEY["c4"], opts=("f32_mfma=1",), leg="other_workloads.c4_f32_mfma")
+    for cfg in ("c2", "c3", "c5", "f1", "f6"):
+        for dt in ("f32", "f64"):
+            add(cfg + ("_f64" if dt == "f64" else ""), cfg, dt, "slicer", BATCH_SURVEY[cfg], leg="other_workloads.%s.%s" % (cfg, dt))
+    add("c3_mfma", "c3", "f32", "slicer", BATCH_SURVEY["c3"], opts=("tdl_kernel=1",), note="the matrix-core kernel of rounds 2-3 (A/B)")
+    add("f1_coop", "f1", "f32", "slicer", BATCH_SURVEY["f1"], opts=("mimo_tdl_kernel=1",), note="the cooperative kernel of rounds 1-4 (A/B)")
+    return specs
+
+
 BITS = {"c2": 6, "c3": 2, "c4": 6, "c5": 4, "f1": 6, "f6": 2}
 # BASELINE.json's literal realization counts: config 4 "1e6 realizations sharded over 8", config 5 "1e5 realizations on 8" (configs
 # 2 and 3: 1e6 on one GPU) -- what the `strong` block of a multi-rank line splits over the ranks
@@ -155,7 +197,18 @@ PMC_PASSES = (   # one rocprofv3 --pmc run each (FETCH_SIZE and WRITE_SIZE do no
            "SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE"),
     ("fetch", "FETCH_SIZE"),
     ("write", "WRITE_SIZE"),
+    # the VALU instruction MIX, for an issue-time fraction that cannot exceed 1 (4 x SQ_ACTIVE_INST_VALU / cycles
+    # books four cycles per instruction and read 1.04 - 1.11 for streams of 2.7-cycle f32 / integer instructions)
+    ("mix", "SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_ADD_F32 "
+            "SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32"),
+    ("mix2", "SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_MFMA_F64 SQ_INSTS_VALU_MFMA_F32"),
 )
+# Cheapest MEASURED issue cost of a wave instruction per class, cycles per SIMD at >= 2 wavefronts per SIMD
+# (scripts/experiments/f64_rates.hip -> profiles/r03/f64_rates.txt, f32_rates.hip -> profiles/r04/f32_rates.txt): a LOWER bound of
+# the time the SIMDs spend issuing a counted instruction stream, so sum(count x cost) / SIMD-cycles cannot exceed 1
+ISSUE_COST = {"SQ_INSTS_VALU_ADD_F64": 4.8, "SQ_INSTS_VALU_MUL_F64": 4.8, "SQ_INSTS_VALU_FMA_F64": 4.4, "SQ_INSTS_VALU_TRANS_F64": 16.4,
+              "SQ_INSTS_VALU_ADD_F32": 2.6, "SQ_INSTS_VALU_MUL_F32": 2.6, "SQ_INSTS_VALU_FMA_F32": 2.6, "SQ_INSTS_VALU_TRANS_F32": 8.3,
+              "SQ_INSTS_VALU_INT32": 2.66, "SQ_INSTS_VALU_INT64": 4.3, "SQ_INSTS_VALU_CVT": 4.2, "_other": 2.66}
 
 
 def parse():
@@ -167,6 +220,8 @@ def parse():
                     help="untimed launches (a disjoint index range) before the W warm-up steps until this much wall time "
                          "has passed: a fresh GPU needs ~0.2 s of work to reach its clocks (first launches of a run were "
                          "measured 7 %% slower); 0 disables")
+    ap.add_argument("--profile-spec", default=None, metavar="TAG",
+                    help="print the bench arguments of profile tag TAG (or 'list': every tag) and exit: scripts/prof_r06.sh")
     ap.add_argument("--config", default="c4", choices=["c2", "c3", "c4", "c5", "f1", "f6"])
     ap.add_argument("--batch", type=int, default=0, help="realizations per GPU per step")
     ap.add_argument("--single-demod", action="store_true",
@@ -434,6 +489,16 @@ def derive_pmc(c, per_launch):
             d["valu_busy_chip"] = 4.0 * g("SQ_ACTIVE_INST_VALU") / simd_cycles
         if g("SQ_VALU_MFMA_BUSY_CYCLES") is not None:
             d["mfma_busy_chip"] = g("SQ_VALU_MFMA_BUSY_CYCLES") / simd_cycles
+    # issue-cost-weighted VALU fraction: every counted class at its cheapest measured issue cost, the uncounted rest (moves, selects,
+    # lane swaps, packed forms) at the cheapest 32-bit cost; matrix-core instructions excluded (mfma_busy_chip is their share)
+    if g("GRBM_GUI_ACTIVE") and g("SQ_INSTS_VALU") is not None and all(g(k) is not None for k in ISSUE_COST if k != "_other"):
+        typed = sum(g(k) for k in ISSUE_COST if k != "_other")
+        mfma_n = (g("SQ_INSTS_VALU_MFMA_F64") or 0.0) + (g("SQ_INSTS_VALU_MFMA_F32") or 0.0) or (g("SQ_INSTS_MFMA") or 0.0)
+        other = max(0.0, g("SQ_INSTS_VALU") - typed - mfma_n)
+        cyc = sum(g(k) * c for k, c in ISSUE_COST.items() if k != "_other") + other * ISSUE_COST["_other"]
+        d["valu_issue_frac"] = cyc / (g("GRBM_GUI_ACTIVE") / 8.0 * 1024.0)
+        d["valu_mix_per_realization"] = dict({k.replace("SQ_INSTS_VALU_", "").lower(): g(k) / per_launch for k in ISSUE_COST if k != "_other"},
+                                             other=other / per_launch, mfma=mfma_n / per_launch)
     if g("SQ_ACTIVE_INST_VALU") is not None and g("SQ_WAVE_CYCLES"):
         d["valu_active_per_wave"] = g("SQ_ACTIVE_INST_VALU") / g("SQ_WAVE_CYCLES")
     if g("SQ_WAIT_INST_ANY") is not None and g("SQ_WAVE_CYCLES"):
@@ -533,11 +598,26 @@ def roofline_block(args, dtype, batch, per_launch_s, rate_kernel, d, pmc_source)
              "flops_model": "what the dispatched kernels execute (tap polynomials of order %d in this arithmetic)" % TAP_ORDER[dtype]
              if args.config in ("c3", "f1") else "SURVEY.md section 8(d)",
              "frac_literal_jakes_model": ((f_total + C3_LITERAL_JAKES_FLOPS) * rate_kernel / 1e12 / peak) if args.config == "c3" else None,
+             # the SAME rate on SURVEY-style flops only (FLOPS[cfg]: transforms, delay line, H(f), solves, decisions -- without the
+             # implementation-sized tap polynomials and ray folds flops_for() adds): VERDICT r05 weak 6
+             "frac_survey_flops_model": (sum(FLOPS[args.config].values()) * rate_kernel / 1e12 / peak)
+             if args.config in ("c3", "f1") else None,
              "hbm": hbm,
-             "valu_busy_chip": d.get("valu_busy_chip"), "mfma_busy_chip": d.get("mfma_busy_chip"),
+             # valu_busy_chip: the issue-cost-weighted fraction where the instruction mix was collected (cannot exceed 1); the raw
+             # counter ratio 4 x SQ_ACTIVE_INST_VALU / SIMD-cycles is kept next to it under its own name -- it is NOT a fraction for
+             # streams of sub-4-cycle instructions
+             "valu_busy_chip": d.get("valu_issue_frac") if d.get("valu_issue_frac") is not None
+             else (min(1.0, d["valu_busy_chip"]) if d.get("valu_busy_chip") is not None else None),
+             "valu_busy_definition": "sum over instruction classes of count x cheapest measured issue cost / SIMD-cycles (bench.py "
+                                     "ISSUE_COST)" if d.get("valu_issue_frac") is not None else
+                                     "min(1, 4 x SQ_ACTIVE_INST_VALU / SIMD-cycles): instruction mix not collected",
+             "valu_active_x4_over_simd_cycles": d.get("valu_busy_chip"),
+             "valu_mix_per_realization": d.get("valu_mix_per_realization"),
+             "mfma_busy_chip": d.get("mfma_busy_chip"),
              # f32-input MFMA and VALU instructions share one FP32 datapath per SIMD on gfx950 (measured:
              # scripts/experiments/mfma_valu_overlap.hip, profiles/r02/mfma_valu_overlap.txt), so the two add up
-             "fp32_datapath_busy_chip": (d["valu_busy_chip"] + d["mfma_busy_chip"])
+             "fp32_datapath_busy_chip": ((d.get("valu_issue_frac") if d.get("valu_issue_frac") is not None else min(1.0, d["valu_busy_chip"]))
+                                         + d["mfma_busy_chip"])
              if dtype == "f32" and d.get("valu_busy_chip") is not None and d.get("mfma_busy_chip") is not None else None,
              "valu_busy_note": "4 x SQ_ACTIVE_INST_VALU / SIMD-cycles: the counter books 4 cycles per wave instruction, while v_add / "
                                "v_mul / v_fma_f32 and the 32-bit logic ops issue in 2.7 - 3.0 cycles at >= 2 wavefronts per SIMD "
@@ -630,6 +710,15 @@ def launch_check(args, rank, world):
 # ---- main -------------------------------------------------------------------------------------------------------
 def main():
     args = parse()
+    if args.profile_spec:
+        specs = profile_specs()
+        if args.profile_spec == "list":
+            print(" ".join(specs))
+            return
+        sp = specs[args.profile_spec]
+        print("--config %s --dtype %s --demod %s --batch %d%s" % (sp["config"], sp["dtype"], sp["demod"], sp["batch"],
+                                                                 "".join(" --opt " + o for o in sp["opts"])))
+        return
     if "RANK" not in os.environ and args.gpus > 1:
         sys.exit(self_launch(args))
     rank = int(os.environ.get("RANK", "0"))
@@ -1037,6 +1126,8 @@ def main():
                             others[cfg][dt] = {"realizations_per_s": rate_o, "kernel_ms_per_launch": ms_o,
                                                "realizations_per_launch": nb, "kernel": kernel_name(cfg, dt),
                                                "flop_frac": sum(flops_for(cfg, dt).values()) * rate_o / 1e12 / PEAK_TFLOPS[dt],
+                                               "flop_frac_survey_model": (sum(FLOPS[cfg].values()) * rate_o / 1e12 / PEAK_TFLOPS[dt])
+                                               if cfg in ("c3", "f1") else None,
                                                "flops_per_realization": sum(flops_for(cfg, dt).values()),
                                                "ser": c_o["sym_errors"] / float(max(1, c_o["n_realizations"]) * units_o)}
                             others[cfg]["workload"] = wl_o
@@ -1075,7 +1166,10 @@ def main():
                             ACTIVE_OPTS.pop("f32_mfma", None)
                         if pmc_m:
                             dm_ = derive_pmc({k: v for k, v in pmc_m.items() if not k.startswith("_")}, nb * PMC_CHILD_STEPS)
-                            leg.update(mfma_busy_chip=dm_.get("mfma_busy_chip"), valu_busy_chip=dm_.get("valu_busy_chip"),
+                            leg.update(mfma_busy_chip=dm_.get("mfma_busy_chip"),
+                                       valu_busy_chip=dm_.get("valu_issue_frac") if dm_.get("valu_issue_frac") is not None
+                                       else (min(1.0, dm_["valu_busy_chip"]) if dm_.get("valu_busy_chip") is not None else None),
+                                       valu_active_x4_over_simd_cycles=dm_.get("valu_busy_chip"),
                                        mfma_f32_mops_per_realization=dm_.get("mfma_f32_mops_per_realization"),
                                        valu_wave_insts_per_realization=dm_.get("valu_wave_insts_per_realization"),
                                        counters_source="rocprofv3 --pmc child runs of this command with --opt f32_mfma=1")
@@ -1092,9 +1186,9 @@ def main():
                     copy_bw = MEASURED["copy_GBps"] or bench_staged_c4.measure_copy_GBps(eng)
                     want_bytes = args.pmc != "off"
                     others["c4_staged"] = bench_staged_c4.run(eng, batch=8192, seconds=1.0, copy_GBps=copy_bw,
-                                                              hbm_counters=want_bytes)
+                                                              hbm_counters=want_bytes, stream=MEASURED["stream"])
                     others["c4_staged_f64"] = bench_staged_c4.run(eng, batch=8192, seconds=1.0, dtype="f64", copy_GBps=copy_bw,
-                                                                  hbm_counters=want_bytes)
+                                                                  hbm_counters=want_bytes, stream=MEASURED["stream"])
                     out["hbm_copy_GBps_measured_this_run"] = copy_bw
                     out["hbm_stream_rates_measured_this_run"] = MEASURED["stream"]
                 except Exception as exc:

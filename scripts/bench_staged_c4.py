@@ -87,6 +87,9 @@ def measure_copy_GBps(eng=None, nbytes=1 << 30, reps=10):
             eng.close()
 
 
+PER_KERNEL_BYTES = {}      # filled by collect_hbm_bytes: kernel -> {FETCH_SIZE, WRITE_SIZE} KiB sums of the counter runs
+
+
 def collect_hbm_bytes(dtype, batch, demod="mindist", passes=3):
     """HBM bytes one pass of the chain really moves, per realization: two `rocprofv3 --pmc` child runs of this file
     (FETCH_SIZE and WRITE_SIZE do not fit one pass) over exactly `passes` passes without warm-up, every dispatch summed
@@ -102,6 +105,8 @@ def collect_hbm_bytes(dtype, batch, demod="mindist", passes=3):
         return None, "rocprofv3 not on PATH"
     root = tempfile.mkdtemp(prefix="staged_pmc_", dir="/tmp")
     tot = {}
+    per_kernel = PER_KERNEL_BYTES
+    per_kernel.clear()
     try:
         for name in ("FETCH_SIZE", "WRITE_SIZE"):
             out_dir = os.path.join(root, name)
@@ -114,6 +119,8 @@ def collect_hbm_bytes(dtype, batch, demod="mindist", passes=3):
                 for row in csv.DictReader(open(path)):
                     if row["Counter_Name"] == name:
                         v += float(row["Counter_Value"])
+                        kn = row["Kernel_Name"].split("(")[0].replace("void mcle::", "")
+                        per_kernel.setdefault(kn, {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0})[name] += float(row["Counter_Value"])
             tot[name] = v
     except Exception as exc:
         return None, repr(exc)
@@ -121,10 +128,12 @@ def collect_hbm_bytes(dtype, batch, demod="mindist", passes=3):
         shutil.rmtree(root, ignore_errors=True)
     if not tot.get("FETCH_SIZE") or not tot.get("WRITE_SIZE"):
         return None, "no counter rows"
+    for kn, v in per_kernel.items():      # -> bytes per realization, per kernel of the chain (who moves the surplus over B_alg)
+        v["bytes_per_realization"] = (2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0 / (passes * batch)
     return (2.0 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024.0 / (passes * batch), None
 
 
-def run(eng, batch=8192, seconds=1.0, dtype="f32", demod="mindist", copy_GBps=None, hbm_counters=False):
+def run(eng, batch=8192, seconds=1.0, dtype="f32", demod="mindist", copy_GBps=None, hbm_counters=False, stream=None):
     """Time the chain for about `seconds` (HIP events around whole passes) -> the dict bench.py embeds.
     copy_GBps: the achievable HBM rate measured on this box in this run (measure_hbm_stream); hbm_counters: also count the bytes the
     chain really moves (collect_hbm_bytes) and apply SURVEY 8(d)'s rule min(B_alg, measured) x rate."""
@@ -163,7 +172,16 @@ def run(eng, batch=8192, seconds=1.0, dtype="f32", demod="mindist", copy_GBps=No
              "achievable_hbm_GBps_measured_this_run": copy_GBps,
              # ONE key, one denominator: min(B_alg, measured bytes) x rate / the best streaming rate the library's own kernels
              # reach on this box in this run (measure_hbm_stream); None when that was not measured
-             "frac_of_achievable_hbm": (eff * rate / 1e9 / copy_GBps) if copy_GBps else None}
+             "frac_of_achievable_hbm": (eff * rate / 1e9 / copy_GBps) if copy_GBps else None,
+             # ... and the same numerator against EVERY denominator a reader may prefer: this box's copy /
+             # read / triad / write rates of this run, the guide's float4 copy figure, the 8 TB/s specification
+             "frac_against": dict({k.replace("_GBps", ""): eff * rate / 1e9 / v for k, v in (stream or {}).items()
+                                   if k.endswith("_GBps") and isinstance(v, (int, float)) and v},
+                                  guide_copy_6290=eff * rate / 1e9 / 6290.0, spec_8000=eff * rate / 1e9 / HBM_PEAK_GBPS),
+             # who moves what: bytes per realization of every kernel of the chain (counter runs) next to the model's operator list
+             "measured_bytes_per_kernel": ({k: round(v["bytes_per_realization"], 1) for k, v in
+                                            sorted(PER_KERNEL_BYTES.items(), key=lambda kv: -kv[1].get("bytes_per_realization", 0.0))}
+                                           if measured else None)}
     return {**extra, "workload": "config 4 staged through HBM, one kernel per reference operator (SURVEY 8(d) staged model)",
             "dtype": dtype, "demod": demod, "realizations_per_s": rate, "batch": batch, "passes": steps,
             "ms_per_pass": ms / steps, "wall_s": wall, "b_alg_bytes_per_realization": balg, "b_alg_breakdown": B_ALG,
@@ -195,8 +213,10 @@ def main():
             chain(eng, s * args.batch, args.batch, cnt, args.dtype, method)
         eng.sync()
     else:
-        copy = measure_copy_GBps(eng) if args.counters else None
-        print(json.dumps(run(eng, args.batch, args.seconds, args.dtype, args.demod, copy_GBps=copy, hbm_counters=args.counters)))
+        stream = measure_hbm_stream(eng) if args.counters else None
+        copy = stream["achievable_GBps"] if stream else None
+        print(json.dumps(run(eng, args.batch, args.seconds, args.dtype, args.demod, copy_GBps=copy, hbm_counters=args.counters,
+                             stream=stream)))
     eng.close()
 
 

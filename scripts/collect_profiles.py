@@ -22,7 +22,7 @@ import shutil
 import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r05"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r06"
 sys.path.insert(0, REPO)
 from bench import derive_pmc  # noqa: E402
 src = os.path.join(REPO, "gpurun_out")
@@ -53,6 +53,14 @@ CONFIGS = {
     "c5": ("k_ia_link<", "k_ia_link<float> (the symbol walk; k_ia_solve_links<float,false> runs before it, see c5_kernel_stats.csv)"),
     "f6": ("k_bd_link<", "k_bd_link<float,2> (the symbol walk; k_bd_solve_links_static<float,3,2> runs before it, see f6_kernel_stats.csv)"),
 }
+
+
+if rnd >= "r06":
+    # round 6: ONE table for the profile driver and for this script (bench.py: profile_specs)
+    import bench as _bench
+    CONFIGS = {tag: (sp["kernel"], "%s; bench.py --config %s --dtype %s --demod %s --batch %d%s%s" % (
+        sp["kernel"], sp["config"], sp["dtype"], sp["demod"], sp["batch"], "".join(" --opt " + o for o in sp["opts"]),
+        ("; leg " + sp["leg"]) if sp["leg"] else "")) for tag, sp in _bench.profile_specs().items()}
 
 
 def first(pattern):

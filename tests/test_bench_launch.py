@@ -76,3 +76,28 @@ def test_world_size_must_match_gpus():
     out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--launch-check", "--gpus", "2"], env=env,
                          capture_output=True, text=True, timeout=120)
     assert out.returncode != 0 and "WORLD_SIZE=1" in (out.stderr + out.stdout)
+
+
+def test_profile_table_matches_the_bench_legs():
+    """a committed profile is taken at the batch AND the demodulator of the bench leg it documents.  One
+    table (bench.profile_specs) drives scripts/prof_r06.sh and scripts/collect_profiles.py; here it is held to bench.py's legs:
+    every other_workloads leg (BATCH_SURVEY, slicer), the headline at one dispatch of a step, the matrix-core leg."""
+    sys.path.insert(0, REPO)
+    import bench
+    specs = bench.profile_specs()
+    for cfg in ("c2", "c3", "c5", "f1", "f6"):
+        for dt, tag in (("f32", cfg), ("f64", cfg + "_f64")):
+            sp = specs[tag]
+            assert sp["batch"] == bench.BATCH_SURVEY[cfg] and sp["demod"] == "slicer" and sp["dtype"] == dt and sp["config"] == cfg
+            assert sp["leg"] == "other_workloads.%s.%s" % (cfg, dt) and not sp["opts"]
+    assert specs["c4_f64"]["demod"] == "mindist" and specs["c4_f64"]["batch"] == min(bench.BATCH["c4"], 1 << 18)
+    assert specs["c4_f64"]["kernel"] == "k_run_mimo_ofdm_qw" and specs["c4_f64_planar"]["kernel"] == "k_run_mimo_ofdm_planar"
+    assert specs["c4md_mfma"]["batch"] == bench.BATCH_SURVEY["c4"] and specs["c4md_mfma"]["kernel"] == "k_run_mimo_ofdm_mfma"
+    assert specs["c2"]["kernel"] == "k_run_flat_mfma" and specs["c2_f64"]["kernel"] == "k_run_flat"
+    # the driver script reads the SAME table
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--profile-spec", "c2"], capture_output=True, text=True,
+                         timeout=120)
+    assert out.returncode == 0 and out.stdout.split() == ["--config", "c2", "--dtype", "f32", "--demod", "slicer", "--batch",
+                                                          str(bench.BATCH_SURVEY["c2"])]
+    script = open(os.path.join(REPO, "scripts", "prof_r06.sh")).read()
+    assert "--profile-spec" in script and "--batch" not in script.replace("--batch of", "")

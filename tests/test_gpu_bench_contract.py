@@ -69,3 +69,12 @@ def test_default_line_carries_every_contract_field():
     for cfg in ("c2", "c3", "c5", "f1", "f6"):
         for dt in ("f64", "f32"):
             assert d["other_workloads"][cfg][dt]["realizations_per_s"] > 0, (cfg, dt)
+    # round 6: fractions against every HBM denominator; the SURVEY-style flop fraction next to the implementation-sized one
+    for leg in (st, st64):
+        fa = leg["frac_against"]
+        assert set(("copy", "read", "triad", "write", "achievable", "guide_copy_6290", "spec_8000")) <= set(fa)
+        assert abs(fa["achievable"] - leg["frac_of_achievable_hbm"]) <= 1e-12 and fa["copy"] >= fa["achievable"] > fa["spec_8000"]
+    for dt in ("f64", "f32"):
+        f1 = d["other_workloads"]["f1"][dt]
+        assert 0.0 < f1["flop_frac_survey_model"] < f1["flop_frac"] < 1.0
+    assert d["roofline"]["valu_busy_chip"] is None or 0.0 < d["roofline"]["valu_busy_chip"] <= 1.0
