@@ -312,6 +312,64 @@ __global__ __launch_bounds__(kMimoBlock) void k_mimo_channel_philox(const cx<T>*
             return;
         }
     }
+    if constexpr (sizeof(T) == 8) {
+        // complex128, 4 x 4, even ns: the same shape as the complex64 form above -- the two columns of all four transmit rows are
+        // loaded ONCE (round 6: the generic loop below re-read them per receive row and moved 313 kB per realization of config 4
+        // where the operator's own traffic is 133 kB: the 19 % surplus of the complex128 staged chain)
+        if (vec) {
+            // (the Box-Muller tables from the workgroup's LDS copy, as in the fused pipelines: 8 320 samples x 3 table reads per
+            //  realization went to L2 as scattered 16-byte requests)
+            __shared__ double s_bm[kBmLdsDoubles];
+            bm_tables_to_lds(s_bm, (int)threadIdx.x, (int)blockDim.x);
+            __syncthreads();
+            double2 Hr[4][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int a = 0; a < 4; ++a) Hr[r][a] = Hb[r * 4 + a];
+            // ONE column per lane: a wavefront's load of a transmit row is 1 KiB of consecutive bytes (two columns per lane left every
+            // load instruction using half of each cache line it touched, and the counter showed the rows fetched 2.8 times).  The
+            // columns 2 p and 2 p + 1 of a row are one Philox block: of the lane pair (2 p, 2 p + 1) the even lane evaluates the blocks
+            // of rows 0 and 1, the odd lane those of rows 2 and 3, and a lane exchange hands over the two words the partner needs.
+            const size_t cols = ns;
+            const size_t stride = (size_t)gridDim.x * blockDim.x;                 // even (blockDim.x is)
+            for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < ((cols + stride - 1) / stride) * stride; c += stride) {
+                const bool live = c < cols;                                       // (the exchange needs both lanes of a pair in the loop)
+                const size_t cc = live ? c : cols - 2 + (c & 1);
+                const int odd = (int)(cc & 1);
+                double2 x[4];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) x[a] = Xb[(size_t)a * ns + cc];
+                uint32_t w[4][2];                                                 // [row][2 words] of THIS lane's sample
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int r_mine = 2 * odd + k;                               // the row whose block this lane evaluates
+                    const Words4 blk = rng.block(STREAM_NOISE, (uint32_t)(((size_t)r_mine * ns) / 2 + cc / 2));
+                    const uint32_t keep0 = odd ? blk.w[2] : blk.w[0], keep1 = odd ? blk.w[3] : blk.w[1];
+                    const uint32_t give0 = odd ? blk.w[0] : blk.w[2], give1 = odd ? blk.w[1] : blk.w[3];
+                    const uint32_t got0 = (uint32_t)__shfl_xor((int)give0, 1, 64), got1 = (uint32_t)__shfl_xor((int)give1, 1, 64);
+                    // rows 2 odd + k are mine; the partner evaluated rows 2 (1 - odd) + k and gave me my words of those
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if ((r & 1) == k) {                                       // r = k or k + 2 (compile-time pair, run-time choice)
+                            const bool mine = (r >> 1) == odd;
+                            w[r][0] = mine ? keep0 : got0;
+                            w[r][1] = mine ? keep1 : got1;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double2 z = cn_from_words_lds(w[r][0], w[r][1], sigma, s_bm);
+                    double2 s0 = mk<double>(0, 0);
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) s0 = cfma(Hr[r][a], x[a], s0);
+                    if (live) Y[(b * 4 + r) * ns + cc] = cadd(s0, z);            // (sum first, then the noise: the generic loop's association)
+                }
+            }
+            return;
+        }
+    }
     const size_t pairs = (ns + 1) / 2;
     for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < pairs; p += (size_t)gridDim.x * blockDim.x) {
         const size_t c0 = 2 * p;
@@ -645,7 +703,7 @@ int mcle_mimo_channel(mcle_ctx* ctx, int dtype, const void* d_H, const void* d_X
     MCLE_REQUIRE(noise_var >= 0.0, "noise variance must be non-negative");
     if (ns == 0 || batch == 0) return MCLE_OK;
     if ((rc = ctx->bind())) return rc;
-    const int vec = dtype == MCLE_F32 && nr == 4 && nt == 4 && ns % 2 == 0 &&
+    const int vec = nr == 4 && nt == 4 && ns % 2 == 0 &&
                     ((((uintptr_t)d_X) | ((uintptr_t)d_Y) | ((uintptr_t)d_noise)) & 15u) == 0;
     dim3 grid((unsigned)grid_for(ctx, vec ? ns / 2 : ns, kMimoBlock, 4), (unsigned)batch);
     if (dtype == MCLE_F32)
@@ -671,13 +729,14 @@ int mcle_mimo_channel_philox(mcle_ctx* ctx, int dtype, const void* d_H, const vo
     if ((rc = ctx->bind())) return rc;
     const int vec = dtype == MCLE_F32 && nr == 4 && nt == 4 && ns % 2 == 0 &&
                     ((((uintptr_t)d_X) | ((uintptr_t)d_Y)) & 15u) == 0;
-    dim3 grid((unsigned)grid_for(ctx, (ns + 1) / 2, kMimoBlock, 4), (unsigned)batch);
+    // (complex128 4 x 4: one column per lane; everything else two)
+    dim3 grid((unsigned)grid_for(ctx, (dtype == MCLE_F64 && vec) ? ns : (ns + 1) / 2, kMimoBlock, 4), (unsigned)batch);
     if (dtype == MCLE_F32)
         hipLaunchKernelGGL(k_mimo_channel_philox<float>, grid, dim3(kMimoBlock), 0, ctx->stream, (const float2*)d_H,
                            (const float2*)d_X, seed, first, (float)std::sqrt(noise_var), nr, nt, ns, (float2*)d_Y, vec);
     else
         hipLaunchKernelGGL(k_mimo_channel_philox<double>, grid, dim3(kMimoBlock), 0, ctx->stream, (const double2*)d_H,
-                           (const double2*)d_X, seed, first, std::sqrt(noise_var), nr, nt, ns, (double2*)d_Y, 0);
+                           (const double2*)d_X, seed, first, std::sqrt(noise_var), nr, nt, ns, (double2*)d_Y, vec);
     MCLE_LAUNCH_CHECK();
     return MCLE_OK;
 }
