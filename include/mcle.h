@@ -149,7 +149,12 @@ enum {
                                       (k_run_mimo_ofdm_tdl_wave, every 1 <= Nt <= Nr <= 4; default since round 5), 1 = the
                                       workgroup-cooperative kernel of rounds 1-4 (Nt = Nr in {2, 4}), 2 = the wavefront kernels with the
                                       tap polynomials' order at run time also where the parked-coefficient kernel applies (A/B) */
-    MCLE_OPT_COUNT = 15
+    MCLE_OPT_WALK_LEGACY = 15,     /* complex128 symbol walks of mcle_run_ia / mcle_run_bd with an even number of columns >= 128 (and, for
+                                      block diagonalisation, two or three users of <= 2 antennas): 0 = the packed walk of round 6
+                                      (csrc/walk_f64.hpp: the lane pairs of a chunk of realizations as one index space, decision form
+                                      fixed at compile time, records in LDS), 1 = the per-realization walks of rounds 2-5 (A/B and
+                                      kernel-vs-kernel tests: identical counters) */
+    MCLE_OPT_COUNT = 16
 };
 int mcle_ctx_set_option(mcle_ctx* ctx, int option, long long value);
 int mcle_ctx_get_option(mcle_ctx* ctx, int option, long long* value);

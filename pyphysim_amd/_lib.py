@@ -20,7 +20,7 @@ STREAM_DATA, STREAM_NOISE, STREAM_CHAN, STREAM_PHASE = 0, 1, 2, 3
 OPTIONS = {"no_mfma": 0, "mfma_variant": 1, "grid_oversub": 2, "flat_wgs_per_cu": 3, "single_tdl": 4,
            "tdl_mfma_waves": 5, "jakes_direct": 6, "f64_generic": 7,
            "f64_threads": 8, "bd_runtime_solve": 9, "demod_nocert": 10, "f64_variant": 11, "f32_mfma": 12, "tdl_kernel": 13,
-           "mimo_tdl_kernel": 14}
+           "mimo_tdl_kernel": 14, "walk_legacy": 15}
 
 LIB_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 # MCLE_LIBRARY: another build of the same library (A/B runs of two builds on one box, scripts/experiments/)

@@ -25,6 +25,7 @@
 #include "pipe_common.hpp"
 #include "totals.hpp"
 #include "wave_draws.hpp"
+#include "walk_f64.hpp"
 #include "bd_static.hpp"
 
 namespace mcle {
@@ -862,6 +863,34 @@ static int launch_run_bd(mcle_ctx* ctx, const mcle_bd_cfg* cfg, const BdParams& 
                            d_sym_err ? d_sym_err + off : nullptr, d_bit_err ? d_bit_err + off : nullptr);                 \
         walked = true;                                                                                                    \
     }
+        if constexpr (sizeof(T) == 8 && R <= 2) {
+            // complex128, two or three users, an even number of columns >= 128: the packed walk of walk_f64.hpp (round 6)
+            if (kc && link_walk_f64_fits(cfg->n_symbols) && !ctx->opt[MCLE_OPT_WALK_LEGACY]) {
+#define MCLE_BD_PACKED(KC_, ABL_)                                                                                             \
+    if (!walked && cfg->K == KC_) {                                                                                           \
+        launch_link_walk_f64<BdWalk<KC_, R>, ABL_>(ctx, mp, cfg->n_symbols, pp.noise_var, seed, first + off, m, (const double2*)recs, \
+                                                   d_counters, d_sym_err ? d_sym_err + off : nullptr,                        \
+                                                   d_bit_err ? d_bit_err + off : nullptr);                                   \
+        walked = true;                                                                                                        \
+    }
+#ifdef MCLE_EXPERIMENTS
+                if constexpr (R == 2) {
+                    switch ((int)ctx->opt[MCLE_OPT_F64_VARIANT]) {
+                        case 1: MCLE_BD_PACKED(3, 1) break;
+                        case 2: MCLE_BD_PACKED(3, 2) break;
+                        case 4: MCLE_BD_PACKED(3, 4) break;
+                        case 6: MCLE_BD_PACKED(3, 6) break;
+                        case 8: MCLE_BD_PACKED(3, 8) break;
+                        case 16: MCLE_BD_PACKED(3, 16) break;
+                        case 31: MCLE_BD_PACKED(3, 31) break;
+                        default: break;
+                    }
+                }
+#endif
+                MCLE_BD_PACKED(2, 0) MCLE_BD_PACKED(3, 0)
+#undef MCLE_BD_PACKED
+            }
+        }
         if constexpr (R <= 2) {                    // users as a compile-time count where the arrays then shrink: K = 2, 3
             MCLE_BD_WALK(2, 0) MCLE_BD_WALK(2, 1) MCLE_BD_WALK(2, 2) MCLE_BD_WALK(3, 0) MCLE_BD_WALK(3, 1) MCLE_BD_WALK(3, 2)
         }

@@ -1,0 +1,350 @@
+// walk_f64.hpp -- the complex128 symbol walk of the link pipelines (config 5: kernels_ia.hip, f6: kernels_bd.hip) as ONE kernel
+// body, round 6.  Stands in for the per-realization loop of the reference's applications -- the transmit symbols, the noise, the
+// receive filter and the decisions of ONE channel realization (apps/ia/simulate_ia.py:94-245, apps/comp/simulate_comp.py with
+// comm/blockdiagonalization.py:272-566; MultiUserChannelMatrix.corrupt_data, channels/multiuser.py:1179-1262) -- after the
+// per-lane solve kernels left a record (the effective gains and the receive filters) per realization.
+//
+// What the section tables of the round-5 walks showed (profiles/r06/{c5,f6}_section_table.md; k_ia_link<double> / k_bd_link<double>):
+//   * 17 - 20 % of their vector instructions were v_readlane_b32: the record (60 - 72 scalar registers), the modem parameters of
+//     a run-time demod_one inlined per decision and the Box-Muller constants did not fit the scalar file -- 146 - 178 spilled SGPRs,
+//     every use behind a read-back;
+//   * a decision cost 75 - 85 instructions where the certificate needs ~10 - 25: every demod_one site carried the method switch, the
+//     certificate switch, the candidate-grid search and the sweep, with the spilled parameters re-read around each branch;
+//   * config 5's 200 columns are 100 lane pairs: a pass of 64 and a pass of 36 per realization, 22 % of the lanes idle.
+// Here:
+//   * the decision form is a template parameter (slicer, QAM margin certificate, quadrant certificate, or the generic demod_one);
+//     the certificates of a user's decisions run straight-line and ONE guarded table sweep serves the lanes holding an
+//     uncertified symbol (the literal first-minimum sweep the certificate stands for; ~1e-8 per symbol);
+//   * the records of a chunk of realizations are staged in LDS once per chunk; a coefficient is a ds_read_b128 at its use;
+//   * the lane pairs of a chunk are ONE index space p = realization-in-chunk * (n_symbols / 2) + pair: a pass is 64 consecutive
+//     p whatever realization they belong to (at most two: n_symbols >= 128), so only the chunk's last pass can have idle lanes --
+//     16 realizations of 200 columns are 25 full passes instead of 32.  The Philox counter carries the realization per lane
+//     (the key is the seed), the record pointer is per lane, the per-realization error counts are two masked wave sums per pass;
+//   * symbols: the <= 9 DATA blocks under each (realization segment, stream) run of a pass are evaluated by 9 lanes each in one
+//     Philox call (two calls for more than 3 streams), stored as 16 bytes in LDS, and a lane reads its two labels as ONE 16-bit
+//     word -- instead of four ds_bpermute and a select tree per stream.
+// Draws and arithmetic are position by position those of the round-5 walks (wave_draws.hpp: symbol n = byte n & 15 of DATA
+// block n >> 4, the two columns of a lane = the two samples of one NOISE block; estimates in the same association), so the counts
+// are identical; tests/test_gpu_oracle_depth.py, test_gpu_walk_f64.py.
+#pragma once
+#include <cmath>
+#include "modem.hpp"
+#include "philox.hpp"
+#include "totals.hpp"
+#include "pipe_common.hpp"
+#include "wave_draws.hpp"
+
+namespace mcle {
+
+enum : int { WDEC_GENERIC = 0, WDEC_SLICER = 1, WDEC_QAM_CERT = 2, WDEC_QUAD_CERT = 3 };
+
+// host: the decision form a launch with these modem parameters compiles to
+template <typename T> inline int walk_dec_kind(const ModemParams<T>& mp) {
+    if (mp.method == MCLE_DEMOD_QAM_SLICER) return WDEC_SLICER;
+    if (mp.cert == 1) return WDEC_QAM_CERT;
+    if (mp.cert == 2) return WDEC_QUAD_CERT;
+    return WDEC_GENERIC;
+}
+
+// A wavefront's own LDS instructions execute in order: a store followed by another lane's load needs no wait, only the compiler
+// has to keep the program order (cf. pipeline_mimo_qw.hip).
+__device__ __forceinline__ void walk_wave_order() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// the literal sweep (strict '<': numpy.argmin's first minimum, fundamental.py:241-246), rolled: it runs once in ~1e8 symbols
+__device__ __forceinline__ int walk_sweep(const double2* __restrict__ s_table, int M, double2 r) {
+    double best = (r.x - s_table[0].x) * (r.x - s_table[0].x) + (r.y - s_table[0].y) * (r.y - s_table[0].y);
+    int idx = 0;
+#pragma unroll 1
+    for (int m = 1; m < M; ++m) {
+        const double2 c = s_table[m];
+        const double dx = r.x - c.x, dy = r.y - c.y;
+        const double d = dx * dx + dy * dy;
+        if (d < best) {
+            best = d;
+            idx = m;
+        }
+    }
+    return idx;
+}
+
+// N decisions and their error counts.  DEC fixes the form at compile time; the certificates are those of modem.hpp.
+template <int DEC, int N>
+__device__ __forceinline__ void walk_decide(const ModemParams<double>& mp, const double2* __restrict__ s_table,
+                                            const unsigned long long* __restrict__ s_grid, const double2 (&e)[N],
+                                            const int (&tx)[N], unsigned& se, unsigned& be) {
+    int dec[N];
+    if constexpr (DEC == WDEC_SLICER) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) dec[j] = demod_qam_slicer<double>(e[j], mp.qam_scale, mp.qam_L, mp.half_bits);
+    } else if constexpr (DEC == WDEC_QAM_CERT || DEC == WDEC_QUAD_CERT) {
+        bool sure[N], all = true;
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            if constexpr (DEC == WDEC_QAM_CERT) dec[j] = demod_qam_cert<double>(e[j], mp.qam_scale, mp.qam_L, mp.half_bits, sure[j]);
+            else dec[j] = demod_quad_cert<double>(e[j], mp.quad_lut, mp.quad_lo, mp.quad_hi, sure[j]);
+            all = all && sure[j];
+        }
+        if (!all) {
+#pragma unroll
+            for (int j = 0; j < N; ++j)
+                if (!sure[j]) dec[j] = walk_sweep(s_table, mp.M, e[j]);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < N; ++j) dec[j] = demod_one(mp, s_table, s_grid, e[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        const unsigned x = (unsigned)(tx[j] ^ dec[j]);
+        se += (x != 0u);
+        be += __popc(x);
+    }
+}
+
+// ---- the two link shapes ------------------------------------------------------------------------------------------------------
+// K users; user k has R receive antennas (noise rows k R + a) and J streams (symbol rows k J + jj).  A record is STRIDE complex128
+// values with the validity flag at OK_AT; gain(s, l) / mix(s, a) are the record positions of the coefficient of symbol row l and
+// of noise antenna a in the estimate of stream s.
+struct IaWalk {       // config 5: est_k = U_k0 n_k0 + U_k1 n_k1 + sum_l G_kl x_l  (record of k_ia_solve_links: G[3][3], U[3][2], flag)
+    static constexpr int K = 3, R = 2, J = 1, S = 3, STRIDE = 16, OK_AT = 15, PER_WAVE = 16;
+    static constexpr bool FULL = true;
+    __host__ __device__ static constexpr int gain(int s, int l) { return 3 * s + l; }
+    __host__ __device__ static constexpr int mix(int s, int a) { return 9 + 2 * s + a; }
+};
+template <int KC, int RR> struct BdWalk {   // f6: est_s = d_s x_s + sum_a W_sa n_ka  (record of k_bd_solve_links: d[n], W[n][R], flag)
+    static constexpr int K = KC, R = RR, J = RR, S = KC * RR, STRIDE = S * (RR + 1) + 1, OK_AT = S * (RR + 1), PER_WAVE = 8;
+    static constexpr bool FULL = false;
+    __host__ __device__ static constexpr int gain(int s, int) { return s; }
+    __host__ __device__ static constexpr int mix(int s, int a) { return S + s * RR + a; }
+};
+
+constexpr int kWalkRunBytes = kBlocksPerRun * 16;       // 144: the DATA blocks under <= 128 consecutive positions
+
+// ABL (MCLE_EXPERIMENTS builds, option f64_variant; WRONG results by construction -- the ablations behind the section tables):
+// 1 = no symbol draws, 2 = no noise Philox blocks, 4 = no Box-Muller, 8 = no estimate arithmetic, 16 = no decisions
+template <typename P, int DEC, int ABL = 0>
+__global__ __launch_bounds__(64, 3) void k_link_walk_f64(ModemParams<double> mp, int n_symbols, double sigma, uint64_t seed,
+                                                        uint64_t first, uint64_t count, const double2* __restrict__ recs,
+                                                        mcle_counters* counters, uint32_t* __restrict__ sym_out,
+                                                        uint32_t* __restrict__ bit_out) {
+    constexpr int S = P::S, R = P::R, J = P::J, K = P::K, PW = P::PER_WAVE, RUNS = 2 * S;
+    extern __shared__ __attribute__((aligned(16))) unsigned char walk_smem[];    // [M] constellation, then the candidate grid (generic form)
+    double2* s_table = reinterpret_cast<double2*>(walk_smem);
+    unsigned long long* s_grid = reinterpret_cast<unsigned long long*>(walk_smem + (size_t)mp.M * sizeof(double2));
+    __shared__ double s_bm[kBmLdsDoubles];                 // Box-Muller tables (bm_f64.hpp)
+    __shared__ double2 s_rec[PW * P::STRIDE];              // the chunk's records
+    __shared__ uint4 s_sym[RUNS * kBlocksPerRun];          // the pass's DATA blocks, run by run
+    __shared__ unsigned s_se[PW], s_be[PW];                // error counts of the chunk's realizations
+    __shared__ WgTotals totals;
+    bm_tables_to_lds(s_bm, (int)threadIdx.x, (int)blockDim.x);
+    load_table(mp, s_table);
+    if constexpr (DEC == WDEC_GENERIC) load_grid(mp, s_grid);
+    const int lane = threadIdx.x;
+    const uint32_t NS = (uint32_t)n_symbols, NP = NS >> 1, mask = (uint32_t)(mp.M - 1);
+    if (threadIdx.x == 0) wg_zero(totals);
+    __syncthreads();
+    // producer side of the symbol exchange: lane -> (run, block of the run); run = segment * S + stream
+    const int p_run = lane / kBlocksPerRun, p_blk = lane - p_run * kBlocksPerRun;
+    const uint64_t n_chunks = (count + PW - 1) / PW;
+    for (uint64_t ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
+        const uint64_t rb = ch * PW;
+        const int nr = (int)(count - rb < (uint64_t)PW ? count - rb : (uint64_t)PW);
+        const uint32_t n_pairs = (uint32_t)nr * NP;
+        {
+            const double2* src = recs + rb * P::STRIDE;
+            for (int i = lane; i < nr * P::STRIDE; i += 64) s_rec[i] = src[i];
+            if (lane < PW) {
+                s_se[lane] = 0u;
+                s_be[lane] = 0u;
+            }
+        }
+        walk_wave_order();
+        uint32_t rloc = 0, rem = (uint32_t)lane;           // lane's pair p = p0 + lane = rloc * NP + rem (NP >= 64)
+        for (uint32_t p0 = 0; p0 < n_pairs; p0 += 64) {
+            const bool valid = p0 + (uint32_t)lane < n_pairs;
+            const uint32_t rlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)rloc);
+            const uint32_t t_lo = 2u * (uint32_t)__builtin_amdgcn_readfirstlane((int)rem);
+            const uint32_t seg = rloc - rlo, t = 2u * rem;
+            int ta[S], tb[S];
+            if constexpr (ABL & 1) {
+#pragma unroll
+                for (int k = 0; k < S; ++k) {
+                    ta[k] = (int)((uint32_t)(lane + k) & mask);
+                    tb[k] = (int)((uint32_t)(lane + 2 * k + 1) & mask);
+                }
+            } else {
+#pragma unroll
+                for (int u0 = 0; u0 < RUNS; u0 += kStreamsPerRound) {
+                    const int u = u0 + p_run;
+                    if (p_run < kStreamsPerRound && u < RUNS) {
+                        const int sg = u >= S ? 1 : 0, k = u - sg * S;
+                        const uint32_t base = (uint32_t)k * NS + (sg ? 0u : t_lo);
+                        const Rng rg(seed, first + rb + rlo + (uint32_t)sg);
+                        const Words4 b = rg.block(STREAM_DATA, (base >> 4) + (uint32_t)p_blk);
+                        s_sym[u * kBlocksPerRun + p_blk] = make_uint4(b.w[0], b.w[1], b.w[2], b.w[3]);
+                    }
+                }
+                walk_wave_order();
+                const unsigned char* sym = reinterpret_cast<const unsigned char*>(s_sym);
+#pragma unroll
+                for (int k = 0; k < S; ++k) {
+                    const uint32_t q = (uint32_t)k * NS + t;
+                    const uint32_t base = (uint32_t)k * NS + (seg ? 0u : t_lo);
+                    const uint32_t off = (seg * (uint32_t)S + (uint32_t)k) * (uint32_t)kWalkRunBytes + (q - (base & ~15u));
+                    const uint32_t w = *reinterpret_cast<const unsigned short*>(sym + off);     // labels of columns t, t + 1
+                    ta[k] = (int)(w & mask);
+                    tb[k] = (int)((w >> 8) & mask);
+                }
+                walk_wave_order();
+            }
+            unsigned se = 0, be = 0;
+            if (valid) {
+                const Rng rng(seed, first + rb + rloc);
+                const double2* rc = s_rec + rloc * (uint32_t)P::STRIDE;
+                double2 xa[P::FULL ? S : 1], xb[P::FULL ? S : 1];
+                if constexpr (P::FULL) {
+#pragma unroll
+                    for (int l = 0; l < S; ++l) {
+                        xa[l] = s_table[ta[l]];
+                        xb[l] = s_table[tb[l]];
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    double2 za[R], zb[R];
+#pragma unroll
+                    for (int a = 0; a < R; ++a) {
+                        const uint32_t bi = ((uint32_t)(k * R + a) * NS + t) >> 1;
+                        if constexpr ((ABL & 6) == 0) {
+                            cn_pair_lds(rng, STREAM_NOISE, bi, sigma, za[a], zb[a], s_bm);
+                        } else {
+                            Words4 b;
+                            if constexpr (ABL & 2) b.w[0] = b.w[1] = b.w[2] = b.w[3] = bi * 2654435769u;
+                            else b = rng.block(STREAM_NOISE, bi);
+                            if constexpr (ABL & 4) {
+                                za[a] = mk<double>((double)(int)b.w[0] * 1e-10, (double)(int)b.w[1] * 1e-10);
+                                zb[a] = mk<double>((double)(int)b.w[2] * 1e-10, (double)(int)b.w[3] * 1e-10);
+                            } else {
+                                za[a] = cn_from_words_lds(b.w[0], b.w[1], sigma, s_bm);
+                                zb[a] = cn_from_words_lds(b.w[2], b.w[3], sigma, s_bm);
+                            }
+                        }
+                    }
+                    double2 e[2 * J];
+                    int tx[2 * J];
+#pragma unroll
+                    for (int jj = 0; jj < J; ++jj) {
+                        const int s = k * J + jj;
+                        double2 ea, eb;
+                        if constexpr (ABL & 8) {
+                            ea = cadd(za[jj % R], P::FULL ? xa[s] : s_table[ta[s]]);
+                            eb = cadd(zb[jj % R], P::FULL ? xb[s] : s_table[tb[s]]);
+                        } else if constexpr (P::FULL) {
+                            {
+                                const double2 c = rc[P::mix(s, 0)];
+                                ea = cmul(c, za[0]);
+                                eb = cmul(c, zb[0]);
+                            }
+#pragma unroll
+                            for (int a = 1; a < R; ++a) {
+                                const double2 c = rc[P::mix(s, a)];
+                                ea = cfma4(c, za[a], ea);
+                                eb = cfma4(c, zb[a], eb);
+                            }
+#pragma unroll
+                            for (int l = 0; l < S; ++l) {
+                                const double2 c = rc[P::gain(s, l)];
+                                ea = cfma4(c, xa[l], ea);
+                                eb = cfma4(c, xb[l], eb);
+                            }
+                        } else {
+                            {
+                                const double2 c = rc[P::gain(s, s)];
+                                ea = cmul(c, s_table[ta[s]]);
+                                eb = cmul(c, s_table[tb[s]]);
+                            }
+#pragma unroll
+                            for (int a = 0; a < R; ++a) {
+                                const double2 c = rc[P::mix(s, a)];
+                                ea = cfma4(c, za[a], ea);
+                                eb = cfma4(c, zb[a], eb);
+                            }
+                        }
+                        e[2 * jj] = ea;
+                        e[2 * jj + 1] = eb;
+                        tx[2 * jj] = ta[s];
+                        tx[2 * jj + 1] = tb[s];
+                    }
+                    if constexpr (ABL & 16) {
+#pragma unroll
+                        for (int j = 0; j < 2 * J; j += 2) se += (unsigned)(e[j].x > e[j + 1].y) + (unsigned)(tx[j] > tx[j + 1]);
+                    } else {
+                        walk_decide<DEC, 2 * J>(mp, s_table, s_grid, e, tx, se, be);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);      // user by user: the next user's draws do not start under this one's tail
+                }
+            }
+            // the pass's counts to the (at most two) realizations it covers: per lane se <= 2 S, be <= 16 S, 64 lanes -- 16 bits each
+            {
+                const uint32_t w = se | (be << 16);
+                const uint32_t tot = wave_sum_u32(w);
+                uint32_t hi = 0;
+                if ((uint32_t)__builtin_amdgcn_readlane((int)rloc, 63) != rlo) hi = wave_sum_u32(seg ? w : 0u);
+                if (lane == 0) {
+                    const uint32_t lo = tot - hi;
+                    s_se[rlo] += lo & 0xFFFFu;
+                    s_be[rlo] += lo >> 16;
+                    if (hi) {
+                        s_se[rlo + 1] += hi & 0xFFFFu;
+                        s_be[rlo + 1] += hi >> 16;
+                    }
+                }
+            }
+            rem += 64u;
+            if (rem >= NP) {
+                rem -= NP;
+                ++rloc;
+            }
+        }
+        walk_wave_order();
+        if (lane == 0)
+            for (int i = 0; i < nr; ++i)
+                wg_account(totals, s_se[i], s_be[i], s_rec[i * P::STRIDE + P::OK_AT].x == 0.0, rb + (uint64_t)i, sym_out, bit_out);
+        walk_wave_order();
+    }
+    if (lane == 0)
+        wg_flush(totals, counters, (unsigned long long)S * NS, (unsigned long long)S * NS * (unsigned long long)mp.bits);
+}
+
+// host: does this request fit the kernel above?  (an even number of columns, at least 128 of them: a pass then covers at most
+// two realizations; label bytes: M <= 256)
+inline bool link_walk_f64_fits(int n_symbols) { return (n_symbols & 1) == 0 && n_symbols >= 128; }
+
+template <typename P, int ABL = 0>
+inline void launch_link_walk_f64(mcle_ctx* ctx, const ModemParams<double>& mp_in, int n_symbols, double noise_var, uint64_t seed,
+                                 uint64_t first, uint64_t count, const double2* recs, mcle_counters* d_counters, uint32_t* d_sym,
+                                 uint32_t* d_bit) {
+    ModemParams<double> mp = mp_in;
+    const int dec = walk_dec_kind(mp);
+    if (dec != WDEC_GENERIC) mp.grid.G = 0;
+    const size_t lds = (size_t)mp.M * sizeof(double2) + (size_t)mp.grid.G * mp.grid.G * sizeof(unsigned long long);
+    const uint64_t chunks = (count + P::PER_WAVE - 1) / P::PER_WAVE;
+    const uint64_t cap = (uint64_t)ctx->n_cu * 4 * 3;
+    const unsigned grid = (unsigned)oversubscribed_grid(ctx, cap, chunks, 2);
+    const double sigma = sqrt(noise_var);
+    auto kern = k_link_walk_f64<P, WDEC_GENERIC, ABL>;
+    switch (dec) {
+        case WDEC_SLICER: kern = k_link_walk_f64<P, WDEC_SLICER, ABL>; break;
+        case WDEC_QAM_CERT: kern = k_link_walk_f64<P, WDEC_QAM_CERT, ABL>; break;
+        case WDEC_QUAD_CERT: kern = k_link_walk_f64<P, WDEC_QUAD_CERT, ABL>; break;
+        default: break;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, ctx->stream, mp, n_symbols, sigma, seed, first, count, recs, d_counters,
+                       d_sym, d_bit);
+}
+
+}  // namespace mcle

@@ -152,7 +152,7 @@ class Engine:
     # ---- kernel-selection options (mcle_ctx_set_option: per context, never read from the environment) ----
     def set_option(self, name, value):
         """name: a key of _lib.OPTIONS ('no_mfma', 'mfma_variant', 'grid_oversub', 'flat_wgs_per_cu', 'single_tdl',
-        'tdl_mfma_waves', 'jakes_direct', 'f64_generic', 'f64_threads', 'bd_runtime_solve', 'demod_nocert', 'f64_variant', 'f32_mfma', 'tdl_kernel', 'mimo_tdl_kernel':
+        'tdl_mfma_waves', 'jakes_direct', 'f64_generic', 'f64_threads', 'bd_runtime_solve', 'demod_nocert', 'f64_variant', 'f32_mfma', 'tdl_kernel', 'mimo_tdl_kernel', 'walk_legacy':
         include/mcle.h MCLE_OPT_* says what each selects); 0 restores the default."""
         if name not in _lib.OPTIONS:
             raise ValueError("unknown option %r (known: %s)" % (name, ", ".join(sorted(_lib.OPTIONS))))
