@@ -500,6 +500,27 @@ int mcle_set_constellation(mcle_ctx* ctx, const double* re_im, int M, int kind) 
             ctx->quad_max = a < b ? b : a;
         }
     }
+    ctx->axis_ok = 0;
+    if (M == 4 && !ctx->quad_ok) {              // (+-a, 0), (0, +-a): decisions by the signs of re - im and re + im (demod_axis4_cert)
+        double a = 0.0;
+        for (int i = 0; i < 8; ++i) a = std::fabs(re_im[i]) > a ? std::fabs(re_im[i]) : a;
+        unsigned lut = 0, seen = 0;
+        bool ok = a > 0.0;
+        for (int m = 0; m < 4 && ok; ++m) {
+            const double re = re_im[2 * m], im = re_im[2 * m + 1];
+            const double big = std::fabs(re) > std::fabs(im) ? std::fabs(re) : std::fabs(im);
+            const double small = std::fabs(re) > std::fabs(im) ? std::fabs(im) : std::fabs(re);
+            ok = std::fabs(big - a) <= 1e-12 * a && small <= 1e-12 * a;
+            const unsigned q = (re - im < 0.0 ? 1u : 0u) | (re + im < 0.0 ? 2u : 0u);
+            seen |= 1u << q;
+            lut |= (unsigned)m << (8 * q);
+        }
+        if (ok && seen == 0xFu) {
+            ctx->axis_ok = 1;
+            ctx->axis_lut = lut;
+            ctx->axis_a = a;
+        }
+    }
     // M-PSK beyond four points (modulators/fundamental.py:396-448: exp(j (2 pi m / M + phaseOffset)) in Gray order): equal radii,
     // angles on the grid 2 pi k / M + phi0 with every k taken once -> the sector certificate (modem.hpp demod_psk_cert)
     ctx->psk_ok = 0;

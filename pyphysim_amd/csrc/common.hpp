@@ -224,6 +224,12 @@ struct mcle_ctx {
     int quad_ok = 0;
     unsigned quad_lut = 0;
     double quad_min = 0.0, quad_max = 0.0;   // min / max of the points' |re|, |im|
+    // four points ON the axes, (+-a, 0) and (0, +-a) -- the reference's PSK(4): exp(j 2 pi m / 4), modulators/fundamental.py:396-448 --
+    // whose min-distance regions are bounded by the diagonals: modem.hpp demod_axis4_cert (the complex128 symbol walks, round 6).
+    // axis_lut: label of (re - im < 0) | (re + im < 0) << 1, a byte each
+    int axis_ok = 0;
+    unsigned axis_lut = 0;
+    double axis_a = 0.0;
     // M-PSK, M in {8, 16}: M points of one radius at angles 2 pi k / M + phi0 (any label order): the min-distance regions are
     // the M sectors -- modem.hpp: demod_psk_cert.  psk_lut: label of sector k in 64 / M bits each; psk_rot = e^{-j phi0}
     int psk_ok = 0;

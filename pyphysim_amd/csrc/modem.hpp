@@ -536,6 +536,19 @@ __device__ __forceinline__ int demod_quad_cert(cx<T> r, unsigned lut, T lo, T hi
     const unsigned q = (r.x < (T)0 ? 8u : 0u) | (r.y < (T)0 ? 16u : 0u);
     return (int)((lut >> q) & 0xFFu);
 }
+// The same for four points ON the axes, (+-a, 0) and (0, +-a) (the reference's PSK(4)): the regions are bounded by the diagonals.
+// With u = re - im, v = re + im (their signs are exact in floating point) the nearest point is (a, 0) for u, v > 0, (0, a) for
+// u < 0 < v, (0, -a) for v < 0 < u, (-a, 0) for u, v < 0, and the runner-up is farther by 2 a min(|u|, |v|) in squared distance:
+// with lo = 2^-30 a <= |u|, |v| and |re|, |im| <= hi = 2^8 a that is >= 2^-29 a^2 against a rounding of <= 2^-35 a^2 of either
+// metric in complex128 (|c - r|^2 here, numpy.abs there) -- the sweep, first-minimum rule included, returns this very label: `sure`.
+// lut: label of (u < 0) | (v < 0) << 1, a byte each.  Used by the complex128 symbol walks (walk_f64.hpp, WDEC_AXIS4_CERT).
+template <typename T>
+__device__ __forceinline__ int demod_axis4_cert(cx<T> r, unsigned lut, T lo, T hi, bool& sure) {
+    const T u = r.x - r.y, v = r.x + r.y;
+    sure = fabs(u) >= lo && fabs(v) >= lo && fabs(r.x) <= hi && fabs(r.y) <= hi;      // NaN: not sure
+    const unsigned q = (u < (T)0 ? 8u : 0u) | (v < (T)0 ? 16u : 0u);
+    return (int)((lut >> q) & 0xFFu);
+}
 template <typename T> __device__ __forceinline__ int demod_cert_any(const ModemParams<T>& mp, cx<T> r, bool& sure) {
     if (mp.cert == 2) return demod_quad_cert<T>(r, mp.quad_lut, mp.quad_lo, mp.quad_hi, sure);
     return demod_qam_cert<T>(r, mp.qam_scale, mp.qam_L, mp.half_bits, sure);

@@ -12,7 +12,8 @@
 //     certificate switch, the candidate-grid search and the sweep, with the spilled parameters re-read around each branch;
 //   * config 5's 200 columns are 100 lane pairs: a pass of 64 and a pass of 36 per realization, 22 % of the lanes idle.
 // Here:
-//   * the decision form is a template parameter (slicer, QAM margin certificate, quadrant certificate, or the generic demod_one);
+//   * the decision form is a template parameter (slicer, QAM margin certificate, the quadrant certificate and its on-axis twin
+//     for the reference's PSK(4), or the generic demod_one);
 //     the certificates of a user's decisions run straight-line and ONE guarded table sweep serves the lanes holding an
 //     uncertified symbol (the literal first-minimum sweep the certificate stands for; ~1e-8 per symbol);
 //   * the records of a chunk of realizations are staged in LDS once per chunk; a coefficient is a ds_read_b128 at its use;
@@ -36,13 +37,20 @@
 
 namespace mcle {
 
-enum : int { WDEC_GENERIC = 0, WDEC_SLICER = 1, WDEC_QAM_CERT = 2, WDEC_QUAD_CERT = 3 };
+enum : int { WDEC_GENERIC = 0, WDEC_SLICER = 1, WDEC_QAM_CERT = 2, WDEC_QUAD_CERT = 3, WDEC_AXIS4_CERT = 4 };
 
-// host: the decision form a launch with these modem parameters compiles to
-template <typename T> inline int walk_dec_kind(const ModemParams<T>& mp) {
+// host: the decision form a launch with these modem parameters compiles to (and, for the on-axis four-point form -- the
+// reference's PSK(4), which has no entry in ModemParams::cert -- its constants in the quadrant certificate's fields)
+inline int walk_dec_kind(const mcle_ctx* ctx, ModemParams<double>& mp) {
     if (mp.method == MCLE_DEMOD_QAM_SLICER) return WDEC_SLICER;
     if (mp.cert == 1) return WDEC_QAM_CERT;
     if (mp.cert == 2) return WDEC_QUAD_CERT;
+    if (mp.method == MCLE_DEMOD_MINDIST && ctx->axis_ok && !ctx->opt[MCLE_OPT_DEMOD_NOCERT]) {
+        mp.quad_lut = ctx->axis_lut;
+        mp.quad_lo = ctx->axis_a * 0x1p-30;
+        mp.quad_hi = ctx->axis_a * 0x1p+8;
+        return WDEC_AXIS4_CERT;
+    }
     return WDEC_GENERIC;
 }
 
@@ -71,6 +79,21 @@ __device__ __forceinline__ int walk_sweep(const double2* __restrict__ s_table, i
     return idx;
 }
 
+// demod_qam_slicer<double> (modem.hpp) with the clamp BEFORE the floor (v_max_f64 / v_min_f64: floor and an integer-bounded clamp
+// commute; NaN -> 0 as before) instead of two compares and four selects per axis after it, and both Gray decodes in one register
+// (a byte each, as demod_qam_cert does): ~24 instead of ~36 instructions per decision (profiles/r06/c5_section_table.md).  Same
+// level arithmetic, same labels.
+__device__ __forceinline__ int walk_qam_slicer(double2 r, double scale, int L, int half_bits) {
+    const double lm1 = (double)(L - 1);
+    const double tj = (r.x * scale + lm1) * 0.5 + 0.5, ti = (lm1 - r.y * scale) * 0.5 + 0.5;
+    const int cj = (int)floor(fmin(fmax(tj, 0.0), lm1)), ci = (int)floor(fmin(fmax(ti, 0.0), lm1));
+    unsigned v = ((unsigned)ci << 8) | (unsigned)cj;
+    v ^= (v >> 4) & 0x0F0Fu;
+    v ^= (v >> 2) & 0x3F3Fu;
+    v ^= (v >> 1) & 0x7F7Fu;
+    return (int)(((v >> 8) << half_bits) | (v & 0xFFu));
+}
+
 // N decisions and their error counts.  DEC fixes the form at compile time; the certificates are those of modem.hpp.
 template <int DEC, int N>
 __device__ __forceinline__ void walk_decide(const ModemParams<double>& mp, const double2* __restrict__ s_table,
@@ -79,13 +102,14 @@ __device__ __forceinline__ void walk_decide(const ModemParams<double>& mp, const
     int dec[N];
     if constexpr (DEC == WDEC_SLICER) {
 #pragma unroll
-        for (int j = 0; j < N; ++j) dec[j] = demod_qam_slicer<double>(e[j], mp.qam_scale, mp.qam_L, mp.half_bits);
-    } else if constexpr (DEC == WDEC_QAM_CERT || DEC == WDEC_QUAD_CERT) {
+        for (int j = 0; j < N; ++j) dec[j] = walk_qam_slicer(e[j], mp.qam_scale, mp.qam_L, mp.half_bits);
+    } else if constexpr (DEC == WDEC_QAM_CERT || DEC == WDEC_QUAD_CERT || DEC == WDEC_AXIS4_CERT) {
         bool sure[N], all = true;
 #pragma unroll
         for (int j = 0; j < N; ++j) {
             if constexpr (DEC == WDEC_QAM_CERT) dec[j] = demod_qam_cert<double>(e[j], mp.qam_scale, mp.qam_L, mp.half_bits, sure[j]);
-            else dec[j] = demod_quad_cert<double>(e[j], mp.quad_lut, mp.quad_lo, mp.quad_hi, sure[j]);
+            else if constexpr (DEC == WDEC_QUAD_CERT) dec[j] = demod_quad_cert<double>(e[j], mp.quad_lut, mp.quad_lo, mp.quad_hi, sure[j]);
+            else dec[j] = demod_axis4_cert<double>(e[j], mp.quad_lut, mp.quad_lo, mp.quad_hi, sure[j]);
             all = all && sure[j];
         }
         if (!all) {
@@ -126,8 +150,11 @@ constexpr int kWalkRunBytes = kBlocksPerRun * 16;       // 144: the DATA blocks 
 
 // ABL (MCLE_EXPERIMENTS builds, option f64_variant; WRONG results by construction -- the ablations behind the section tables):
 // 1 = no symbol draws, 2 = no noise Philox blocks, 4 = no Box-Muller, 8 = no estimate arithmetic, 16 = no decisions
+#ifndef MCLE_WALK_F64_WAVES
+#define MCLE_WALK_F64_WAVES 3       // wavefronts per SIMD the registers are bounded for (A/B: profiles/r06/walk_f64_ab.log)
+#endif
 template <typename P, int DEC, int ABL = 0>
-__global__ __launch_bounds__(64, 3) void k_link_walk_f64(ModemParams<double> mp, int n_symbols, double sigma, uint64_t seed,
+__global__ __launch_bounds__(64, MCLE_WALK_F64_WAVES) void k_link_walk_f64(ModemParams<double> mp, int n_symbols, double sigma, uint64_t seed,
                                                         uint64_t first, uint64_t count, const double2* __restrict__ recs,
                                                         mcle_counters* counters, uint32_t* __restrict__ sym_out,
                                                         uint32_t* __restrict__ bit_out) {
@@ -167,6 +194,7 @@ __global__ __launch_bounds__(64, 3) void k_link_walk_f64(ModemParams<double> mp,
         for (uint32_t p0 = 0; p0 < n_pairs; p0 += 64) {
             const bool valid = p0 + (uint32_t)lane < n_pairs;
             const uint32_t rlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)rloc);
+            const bool two_seg = (uint32_t)__builtin_amdgcn_readlane((int)rloc, 63) != rlo;     // (wave-uniform)
             const uint32_t t_lo = 2u * (uint32_t)__builtin_amdgcn_readfirstlane((int)rem);
             const uint32_t seg = rloc - rlo, t = 2u * rem;
             int ta[S], tb[S];
@@ -180,6 +208,7 @@ __global__ __launch_bounds__(64, 3) void k_link_walk_f64(ModemParams<double> mp,
 #pragma unroll
                 for (int u0 = 0; u0 < RUNS; u0 += kStreamsPerRound) {
                     const int u = u0 + p_run;
+                    if (u0 >= S && !two_seg) break;          // runs of a second realization only: most passes have none
                     if (p_run < kStreamsPerRound && u < RUNS) {
                         const int sg = u >= S ? 1 : 0, k = u - sg * S;
                         const uint32_t base = (uint32_t)k * NS + (sg ? 0u : t_lo);
@@ -223,8 +252,14 @@ __global__ __launch_bounds__(64, 3) void k_link_walk_f64(ModemParams<double> mp,
                             cn_pair_lds(rng, STREAM_NOISE, bi, sigma, za[a], zb[a], s_bm);
                         } else {
                             Words4 b;
-                            if constexpr (ABL & 2) b.w[0] = b.w[1] = b.w[2] = b.w[3] = bi * 2654435769u;
-                            else b = rng.block(STREAM_NOISE, bi);
+                            if constexpr (ABL & 2) {      // four DIFFERENT cheap words: the two Box-Muller pairs must not fold into one
+                                b.w[0] = bi * 2654435769u;
+                                b.w[1] = b.w[0] ^ 0x9E3779B9u;
+                                b.w[2] = b.w[0] + 0x7F4A7C15u;
+                                b.w[3] = b.w[2] ^ 0x85EBCA6Bu;
+                            } else {
+                                b = rng.block(STREAM_NOISE, bi);
+                            }
                             if constexpr (ABL & 4) {
                                 za[a] = mk<double>((double)(int)b.w[0] * 1e-10, (double)(int)b.w[1] * 1e-10);
                                 zb[a] = mk<double>((double)(int)b.w[2] * 1e-10, (double)(int)b.w[3] * 1e-10);
@@ -240,9 +275,9 @@ __global__ __launch_bounds__(64, 3) void k_link_walk_f64(ModemParams<double> mp,
                     for (int jj = 0; jj < J; ++jj) {
                         const int s = k * J + jj;
                         double2 ea, eb;
-                        if constexpr (ABL & 8) {
-                            ea = cadd(za[jj % R], P::FULL ? xa[s] : s_table[ta[s]]);
-                            eb = cadd(zb[jj % R], P::FULL ? xb[s] : s_table[tb[s]]);
+                        if constexpr (ABL & 8) {          // every noise sample and the symbol stay alive, the multiply-adds go
+                            ea = cadd(cadd(za[0], za[R - 1]), P::FULL ? xa[s] : s_table[ta[s]]);
+                            eb = cadd(cadd(zb[0], zb[R - 1]), P::FULL ? xb[s] : s_table[tb[s]]);
                         } else if constexpr (P::FULL) {
                             {
                                 const double2 c = rc[P::mix(s, 0)];
@@ -281,7 +316,8 @@ __global__ __launch_bounds__(64, 3) void k_link_walk_f64(ModemParams<double> mp,
                     }
                     if constexpr (ABL & 16) {
 #pragma unroll
-                        for (int j = 0; j < 2 * J; j += 2) se += (unsigned)(e[j].x > e[j + 1].y) + (unsigned)(tx[j] > tx[j + 1]);
+                        for (int j = 0; j < 2 * J; j += 2)      // both components of both estimates stay alive
+                            se += (unsigned)(e[j].x + e[j].y > e[j + 1].x + e[j + 1].y) + (unsigned)(tx[j] > tx[j + 1]);
                     } else {
                         walk_decide<DEC, 2 * J>(mp, s_table, s_grid, e, tx, se, be);
                     }
@@ -293,7 +329,7 @@ __global__ __launch_bounds__(64, 3) void k_link_walk_f64(ModemParams<double> mp,
                 const uint32_t w = se | (be << 16);
                 const uint32_t tot = wave_sum_u32(w);
                 uint32_t hi = 0;
-                if ((uint32_t)__builtin_amdgcn_readlane((int)rloc, 63) != rlo) hi = wave_sum_u32(seg ? w : 0u);
+                if (two_seg) hi = wave_sum_u32(seg ? w : 0u);
                 if (lane == 0) {
                     const uint32_t lo = tot - hi;
                     s_se[rlo] += lo & 0xFFFFu;
@@ -329,11 +365,11 @@ inline void launch_link_walk_f64(mcle_ctx* ctx, const ModemParams<double>& mp_in
                                  uint64_t first, uint64_t count, const double2* recs, mcle_counters* d_counters, uint32_t* d_sym,
                                  uint32_t* d_bit) {
     ModemParams<double> mp = mp_in;
-    const int dec = walk_dec_kind(mp);
+    const int dec = walk_dec_kind(ctx, mp);
     if (dec != WDEC_GENERIC) mp.grid.G = 0;
     const size_t lds = (size_t)mp.M * sizeof(double2) + (size_t)mp.grid.G * mp.grid.G * sizeof(unsigned long long);
     const uint64_t chunks = (count + P::PER_WAVE - 1) / P::PER_WAVE;
-    const uint64_t cap = (uint64_t)ctx->n_cu * 4 * 3;
+    const uint64_t cap = (uint64_t)ctx->n_cu * 4 * MCLE_WALK_F64_WAVES;
     const unsigned grid = (unsigned)oversubscribed_grid(ctx, cap, chunks, 2);
     const double sigma = sqrt(noise_var);
     auto kern = k_link_walk_f64<P, WDEC_GENERIC, ABL>;
@@ -341,6 +377,7 @@ inline void launch_link_walk_f64(mcle_ctx* ctx, const ModemParams<double>& mp_in
         case WDEC_SLICER: kern = k_link_walk_f64<P, WDEC_SLICER, ABL>; break;
         case WDEC_QAM_CERT: kern = k_link_walk_f64<P, WDEC_QAM_CERT, ABL>; break;
         case WDEC_QUAD_CERT: kern = k_link_walk_f64<P, WDEC_QUAD_CERT, ABL>; break;
+        case WDEC_AXIS4_CERT: kern = k_link_walk_f64<P, WDEC_AXIS4_CERT, ABL>; break;
         default: break;
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, ctx->stream, mp, n_symbols, sigma, seed, first, count, recs, d_counters,

@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 6: section ablation of the complex128 symbol walks k_ia_link (config 5) and k_bd_link (f6) at their bench legs' batches
+# round 6: section ablation of the packed complex128 symbol walk k_link_walk_f64 (csrc/walk_f64.hpp; config 5 and f6) at the bench legs' batches
 # (MCLE_EXPERIMENTS build, scripts/build_exp.sh; option f64_variant: 1 = no symbol draws, 2 = no noise Philox, 4 = no Box-Muller,
 # 8 = no estimate arithmetic, 16 = no decisions, 31 = all of them) -> gpurun_out/walk_sections.json
 export TMPDIR=/tmp
@@ -15,7 +15,7 @@ done
 python - <<'PY'
 import json, csv, glob, subprocess, sys
 out = {}
-for cfg, needle in (("c5", "k_ia_link<"), ("f6", "k_bd_link<")):
+for cfg, needle in (("c5", "k_link_walk_f64<"), ("f6", "k_link_walk_f64<")):
     batch = int(subprocess.run([sys.executable, "bench.py", "--profile-spec", cfg + "_f64"], capture_output=True, text=True).stdout.split("--batch")[1].split()[0])
     for v in (0, 1, 2, 4, 6, 8, 16, 31):
         d = json.loads(open("/tmp/wsec/time_%s_%d.json" % (cfg, v)).read())

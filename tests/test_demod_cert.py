@@ -141,6 +141,41 @@ def test_quadrant_certificate_model_equals_the_argmin_where_sure():
         assert 0.7 < sure.mean() < 1.0
 
 
+def axis4_cert_model(r, tab):
+    """csrc/modem.hpp::demod_axis4_cert restated (complex128): four points (+-a, 0), (0, +-a) -> (label, sure)."""
+    a = float(np.max(np.abs(np.concatenate([tab.real, tab.imag]))))
+    lut = np.zeros(4, dtype=np.int64)
+    for m, c in enumerate(tab):
+        lut[(1 if c.real - c.imag < 0 else 0) | (2 if c.real + c.imag < 0 else 0)] = m
+    u, v = r.real - r.imag, r.real + r.imag
+    lo, hi = a * 2.0 ** -30, a * 256.0
+    sure = (np.abs(u) >= lo) & (np.abs(v) >= lo) & (np.abs(r.real) <= hi) & (np.abs(r.imag) <= hi)
+    return lut[(u < 0).astype(int) | ((v < 0).astype(int) << 1)], sure
+
+
+def test_axis_certificate_model_equals_the_argmin_where_sure():
+    """The reference's PSK(4) = exp(j 2 pi m / 4) sits ON the axes (no quadrant certificate): the decision regions are bounded by the
+    diagonals.  Points on and next to the diagonals (offsets from 1e-16 to 1e-3 of a), the origin, far out."""
+    rng = np.random.default_rng(46)
+    for tab in (constellation("psk", 4), constellation("psk", 4)[[3, 1, 0, 2]], 2.5 * np.asarray(constellation("psk", 4))):
+        tab = np.asarray(tab, dtype=np.complex128)
+        a = float(np.max(np.abs(tab.real)))
+        n = 20000
+        r = (rng.standard_normal(n) + 1j * rng.standard_normal(n)) * 1.2 * a
+        k = n // 4
+        off = rng.choice([0.0, 1e-16, 1e-13, 1e-10, 2.0 ** -31, 2.0 ** -29, 1e-6, 1e-3], size=k) * a * rng.choice([-1, 1], size=k)
+        r[:k // 2] = r[:k // 2].real * (1 + 1j) + off[:k // 2]                # next to the diagonal re = im
+        r[k // 2:k] = r[k // 2:k].real * (1 - 1j) + 1j * off[k // 2:]         # next to re = -im
+        r[k:k + 8] = [0, 1e-300, a * 1e-20 * (1 + 1j), 300 * a, -300j * a, (255 + 200j) * a, (257 - 1j) * a, -(1e6 + 2e6j) * a]
+        lab, sure = axis4_cert_model(r, tab)
+        want = np.argmin(np.abs(tab[None, :] - r[:, None]), axis=1)
+        assert np.array_equal(lab[sure], want[sure])
+        assert 0.7 < sure.mean() < 1.0
+        # ... and also with the metric the kernels sweep with, |c - r|^2
+        want2 = np.argmin((tab.real[None, :] - r.real[:, None]) ** 2 + (tab.imag[None, :] - r.imag[:, None]) ** 2, axis=1)
+        assert np.array_equal(lab[sure], want2[sure])
+
+
 @pytest.mark.gpu
 def test_qpsk_demodulate_with_and_without_the_quadrant_certificate(engine):
     rng = np.random.default_rng(45)
