@@ -1,0 +1,347 @@
+// pipeline_mimo_fw.hip -- config 4's link at fft_size 256 (4 x 4 Blast + OFDM(256), complex128) with ONE REALIZATION PER WAVEFRONT
+// ("full-wave", round 6).  Same link, same draw ledger (philox.hpp), same record kernel (k_mimo_filters_planar) and the same
+// results contract as k_run_mimo_ofdm_planar<double, 256, 4, 4, ...>, whose per-realization counts it reproduces (reference:
+// apps/mimo/simulate_mimo.py:68-142, mimo/mimo.py:609-660, modulators/ofdm.py:394-466; any fft_size: modulators/ofdm.py:52-94).
+//
+// Why: off the benchmark size the planar family ran radix-4 stages through LDS planes with a workgroup
+// barrier per stage group -- 0.68 of the quarter-wave kernel's per-subcarrier rate at 256 points.  The quarter-wave kernel
+// (pipeline_mimo_qw.hip) already holds a 256-point transform of all four antennas in ONE wavefront -- lane = (antenna, 16-point
+// group), two radix-16 register passes with one wave-private 16 x 16 transposition between them -- and needs the other three
+// wavefronts only for the radix-4 stage that makes 1024 out of 4 x 256.  At fft_size 256 that stage does not exist, so the whole
+// realization is one wavefront's: NO workgroup barrier, no exchange planes, and
+//   * labels: lane t draws DATA block t (four subcarriers x four antennas); the bytes go through a 1 KiB array [antenna][k mod 16]
+//     [k div 16] and lane (a, g) reads its sixteen labels X_a[g + 16 u] as ONE 16-byte word, which it keeps for the decode;
+//   * transmit: sixteen table look-ups, pass 1 (spans 64, 16), transposition through the wavefront's 8.5 KiB plane (re, then im),
+//     pass 2 (constant roots only) -- fft_r16.hpp: r16_pass from and to registers, as in the quarter-wave kernel;
+//   * noise: register c of lane (r, h) is sample time n = qw_mtime(h, c), so the pair (2 p, 2 p + 1) of a Philox NOISE block is the
+//     lane pair (l, l ^ 4): each evaluates the blocks of eight of the sixteen registers and hands the partner its two words
+//     through the (then idle) plane;
+//   * channel R = H T + noise on v_mfma_f64_4x4x4 (four instructions per sample time, the lane maps of the quarter-wave kernel);
+//   * receive: the mirror image; lane (r, g) ends with Y_r[g + 16 u] -- and the DECODE est_a = sum_r G[a][r] Y_r is the same
+//     contraction over the four lanes of a column: v_mfma_f64_4x4x4 again, lane (r, h) supplying G[h mod 4][r], and stream a's
+//     sixteen estimates land in lane (a, g) -- next to the sixteen labels that lane read at the top.  Decisions: the form fixed at
+//     compile time (slicer, QAM margin certificate, quadrant certificate; walk_f64.hpp: walk_decide), four symbols at a time.
+// A workgroup is four independent wavefronts that share the tables (constellation x 2, Box-Muller): 46 KiB of LDS -> three
+// workgroups per CU, three wavefronts per SIMD at a 168-register bound.
+// Envelope: fft_size 256, 4 x 4, full band (num_used = 256), even cyclic prefix, a constellation with a certificate or the slicer;
+// anything else stays on the planar kernel.
+#include "mimo_planar_common.hpp"
+#include "walk_f64.hpp"
+
+namespace mcle {
+
+constexpr int kFwPlane = 4 * 272;                // doubles per wavefront plane (8 704 B): row stride 17, antenna stride 272
+constexpr int kFwLabBytes = 64 * 16;             // [antenna][k mod 16][k div 16] label bytes of one wavefront
+__host__ __device__ __forceinline__ int fw_slot(int a, int e) { return a * 272 + e + (e >> 4); }
+// sample time held by register c of lane group h after the second DIF pass (= pipeline_mimo_qw.hip: qw_mtime)
+__host__ __device__ __forceinline__ int fw_mtime(int h, int c) { return (c & 3) * 64 + (c >> 2) * 16 + (h & 3) * 4 + (h >> 2); }
+
+// ABL (MCLE_EXPERIMENTS builds only, option f64_variant: WRONG results by construction): 32 = no label draws / look-ups,
+// 64 = no transmit passes, 128 = no noise draws, 256 = no channel products, 512 = no receive passes, 1024 = no decode
+template <int DEC, int WPS, int ABL = 0>
+__global__ __launch_bounds__(256, WPS) void k_run_mimo_ofdm_fw(MimoParams pp, ModemParams<double> mp, uint64_t seed, uint64_t first,
+                                                               uint64_t count, const double2* __restrict__ g_tw,
+                                                               const double2* __restrict__ g_recs, mcle_counters* counters,
+                                                               uint32_t* __restrict__ sym_out, uint32_t* __restrict__ bit_out) {
+    using T = double;
+    constexpr int N = 256, NT = 4, NR = 4, kRec = d64_rec<NT, NR>();
+    extern __shared__ __attribute__((aligned(16))) char fw_smem[];
+    T* s_R = reinterpret_cast<T*>(fw_smem);                                  // [4 wavefronts][kFwPlane]
+    cx<T>* s_table = reinterpret_cast<cx<T>*>(s_R + 4 * kFwPlane);            // [tab_len] constellation
+    cx<T>* s_txtab = s_table + ((mp.M + 1) & ~1);                             // [tab_len] constellation x tx scale
+    cx<T>* s_rec = s_txtab + ((mp.M + 1) & ~1);                               // [4][kRec + 1]
+    constexpr int kBm = (kBmLdsDoubles + 1) & ~1;
+    double* s_bm = reinterpret_cast<double*>(s_rec + 4 * (kRec + 1));         // [kBm] Box-Muller tables
+    unsigned char* s_lab = reinterpret_cast<unsigned char*>(s_bm + kBm);     // [4][kFwLabBytes] (16-byte aligned: everything before is)
+    __shared__ WgTotals totals[4];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cp = pp.cp;
+    const int per_sym = N * NT;
+    const uint64_t row = (uint64_t)pp.n_ofdm_sym * (N + cp);
+    const T sigma = (T)sqrt(pp.noise_var);
+    const T tx_scale = (T)(1.0 / sqrt((double)NT) / sqrt((double)(N + cp)));
+    const uint32_t mask = (uint32_t)(mp.M - 1);
+    for (int m = tid; m < mp.M; m += 256) {
+        const cx<T> c = mp.g_table[m];
+        s_table[m] = c;
+        s_txtab[m] = cscale(c, tx_scale);
+    }
+    bm_tables_to_lds(s_bm, tid, 256);
+    if (lane == 0) wg_zero(totals[w]);
+    __syncthreads();                                                         // the only workgroup barrier: the shared tables
+
+    T* s_mine = s_R + w * kFwPlane;
+    uint2* s_words = reinterpret_cast<uint2*>(s_mine);                      // [16 registers][64 lanes] word pairs (8 KiB of the plane)
+    unsigned char* lab_mine = s_lab + w * kFwLabBytes;
+    cx<T>* rec_mine = s_rec + w * (kRec + 1);
+    const uint64_t stride = (uint64_t)gridDim.x * 4;
+    cx<T> rec_next = mk<T>(0, 0);
+    {
+        const uint64_t r0 = (uint64_t)blockIdx.x * 4 + w;
+        if (lane < kRec && r0 < count) rec_next = g_recs[r0 * kRec + lane];
+    }
+    for (uint64_t rl = (uint64_t)blockIdx.x * 4 + w; rl < count; rl += stride) {
+        const Rng rng(seed, first + rl);
+        walk_wave_order();                                                   // (the previous realization's reads of the record are done)
+        if (lane < kRec) {
+            rec_mine[lane] = rec_next;
+            if (rl + stride < count) rec_next = g_recs[(rl + stride) * kRec + lane];
+        }
+        walk_wave_order();
+        const int ln0 = opaque(lane);
+        const cx<T> hA = rec_mine[(ln0 & 3) * NT + (ln0 >> 4)];               // H[h mod 4][a]: the channel contraction's A operand
+        const cx<T> gA = rec_mine[NT * NR + (ln0 & 3) * NR + (ln0 >> 4)];     // G[h mod 4][r]: the decode's
+        const bool skipped = rec_mine[2 * NT * NR].x != 0.0;
+        unsigned se = 0, be = 0;
+        for (int os = 0; os < pp.n_ofdm_sym; ++os) {
+            // ---- labels: DATA block `lane` of the symbol = subcarriers d = 4 lane .. 4 lane + 3, four antennas each (full band:
+            //      bin k = d ^ 128) -> byte [antenna][k mod 16][k div 16]; lane (a, g) then reads its sixteen as one word ----
+            uint4 L;
+            {
+                const int t = opaque(lane);
+                Words4 dw;
+                if constexpr (ABL & 32) dw.w[0] = dw.w[1] = dw.w[2] = dw.w[3] = (uint32_t)t * 0x01010101u;
+                else dw = rng.block(STREAM_DATA, (uint32_t)(((uint64_t)os * per_sym) >> 4) + (uint32_t)t);
+                const int u = (t >> 2) ^ 8;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const uint32_t wd = dw.w[s] & (mask * 0x01010101u);
+                    const int g = 4 * (t & 3) + s;
+                    unsigned char* dst = lab_mine + g * 16 + u;
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) dst[a * 256] = (unsigned char)(wd >> (8 * a));
+                }
+                walk_wave_order();
+                L = *reinterpret_cast<const uint4*>(lab_mine + t * 16);
+                walk_wave_order();
+            }
+            cx<T> v[16];
+            {
+                const uint32_t wds[4] = {L.x, L.y, L.z, L.w};
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const uint32_t lb = (wds[u >> 2] >> (8 * (u & 3))) & 0xFFu;
+                    if constexpr (ABL & 32) v[u] = mk<T>((T)lb, 1.0);
+                    else v[u] = s_txtab[lb];
+                }
+            }
+            // ---- transmit transform: pass 1 (DIF spans 64, 16), transposition (a, g | u) -> (a, h | c), pass 2 (spans 4, 1) ----
+            if constexpr (!(ABL & 64)) {
+                const int g = opaque(lane) & 15;
+                R16Tw64<T> tw;
+#pragma unroll
+                for (int m = 1; m <= 3; ++m) {
+                    tw.a1[m - 1] = g_tw[g * m];
+                    tw.a2[m - 1] = g_tw[4 * g * m];
+                }
+                r16_pass<T, true, false, 0, false, true, true>(nullptr, nullptr, 0, tw, nullptr, 0, v, v);
+            }
+            {
+                const int ln = opaque(lane);
+                const int a = ln >> 4, g = ln & 15;
+                const int wbase = fw_slot(a, g), rbase = fw_slot(a, 16 * g);
+                T xr[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) s_mine[wbase + 17 * u] = v[u].x;
+                walk_wave_order();
+#pragma unroll
+                for (int c = 0; c < 16; ++c) xr[c] = s_mine[rbase + c];
+                walk_wave_order();
+#pragma unroll
+                for (int u = 0; u < 16; ++u) s_mine[wbase + 17 * u] = v[u].y;
+                walk_wave_order();
+#pragma unroll
+                for (int c = 0; c < 16; ++c) v[c] = mk<T>(xr[c], s_mine[rbase + c]);
+                walk_wave_order();
+            }
+            if constexpr (!(ABL & 64)) {
+                R16Tw64<T> none;
+                r16_pass<T, true, false, 0, false, true, true, false, true>(nullptr, nullptr, 0, none, nullptr, 0, v, v);
+            }
+            // ---- noise words: lanes l and l ^ 4 hold the two samples of every pair; l evaluates the blocks of registers
+            //      8 par .. 8 par + 7 (par = the parity of its sample times), keeps its half, hands over the other ----
+            {
+                const int ln = opaque(lane);
+                const int r = ln >> 4, h = ln & 15, par = (h >> 2) & 1;
+                const uint64_t i0 = (uint64_t)r * row + (uint64_t)os * (N + cp) + cp + (uint64_t)(4 * (h & 3) + ((h >> 2) & 2));   // even
+                uint2* wm = s_words + (8 * par) * 64 + ln;
+                uint2* wp = s_words + (8 * par) * 64 + (ln ^ 4);
+#pragma unroll
+                for (int cc = 0; cc < 8; ++cc) {
+                    // register c = 8 par + cc: block b(c) = i0 / 2 + (c & 3) * 32 + (c >> 2) * 8, and c & 3 = cc & 3, c >> 2 = 2 par + (cc >> 2)
+                    Words4 b;
+                    const uint32_t bi = (uint32_t)(i0 >> 1) + (uint32_t)((cc & 3) * 32 + (cc >> 2) * 8) + (uint32_t)par * 16u;
+                    if constexpr (ABL & 128) b.w[0] = b.w[1] = b.w[2] = b.w[3] = bi;
+                    else b = rng.block(STREAM_NOISE, bi);
+                    const uint2 even = make_uint2(b.w[0], b.w[1]), odd = make_uint2(b.w[2], b.w[3]);
+                    wm[cc * 64] = par ? odd : even;
+                    wp[cc * 64] = par ? even : odd;
+                }
+                walk_wave_order();
+            }
+            // ---- channel: R_r = sum_a H[r][a] T_a + noise on v_mfma_f64_4x4x4 (pipeline_mimo_qw.hip: the lane maps); the word pairs
+            //      of eight registers at a time (sixteen more live registers instead of thirty-two) ----
+            {
+                const T hre = hA.x, him = hA.y, nhim = -hA.y;
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    uint2 nw[8];
+                    const int ln = opaque(lane);
+#pragma unroll
+                    for (int cc = 0; cc < 8; ++cc) nw[cc] = s_words[(8 * half + cc) * 64 + ln];
+#pragma unroll
+                    for (int cc = 0; cc < 8; ++cc) {
+                        const int c = 8 * half + cc;
+                        cx<T> z;
+                        if constexpr (ABL & 128) z = mk<T>((T)nw[cc].x, sigma);
+                        else z = cn_words(nw[cc].x, nw[cc].y, sigma, s_bm);
+                        if constexpr (ABL & 256) {
+                            v[c] = cadd(v[c], z);
+                        } else {
+                            T yr = __builtin_amdgcn_mfma_f64_4x4x4f64(hre, v[c].x, z.x, 0, 0, 0);
+                            T yi = __builtin_amdgcn_mfma_f64_4x4x4f64(him, v[c].x, z.y, 0, 0, 0);
+                            yr = __builtin_amdgcn_mfma_f64_4x4x4f64(nhim, v[c].y, yr, 0, 0, 0);
+                            yi = __builtin_amdgcn_mfma_f64_4x4x4f64(hre, v[c].y, yi, 0, 0, 0);
+                            v[c] = mk<T>(yr, yi);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                walk_wave_order();
+            }
+            // ---- receive transform: pass 2' (DIT spans 1, 4), transposition back, pass 1' (spans 16, 64) ----
+            if constexpr (!(ABL & 512)) {
+                R16Tw64<T> none;
+                r16_pass<T, false, true, 0, false, true, true, false, true>(nullptr, nullptr, 0, none, nullptr, 0, v, v);
+            }
+            {
+                const int ln = opaque(lane);
+                const int a = ln >> 4, g = ln & 15;
+                const int wbase = fw_slot(a, g), rbase = fw_slot(a, 16 * g);
+                T xr[16];
+#pragma unroll
+                for (int c = 0; c < 16; ++c) s_mine[rbase + c] = v[c].x;
+                walk_wave_order();
+#pragma unroll
+                for (int u = 0; u < 16; ++u) xr[u] = s_mine[wbase + 17 * u];
+                walk_wave_order();
+#pragma unroll
+                for (int c = 0; c < 16; ++c) s_mine[rbase + c] = v[c].y;
+                walk_wave_order();
+#pragma unroll
+                for (int u = 0; u < 16; ++u) v[u] = mk<T>(xr[u], s_mine[wbase + 17 * u]);
+                walk_wave_order();
+            }
+            if constexpr (!(ABL & 512)) {
+                const int g = opaque(lane) & 15;
+                R16Tw64<T> tw;
+#pragma unroll
+                for (int m = 1; m <= 3; ++m) {
+                    tw.a1[m - 1] = g_tw[g * m];
+                    tw.a2[m - 1] = g_tw[4 * g * m];
+                }
+                r16_pass<T, false, true, 0, false, true, true>(nullptr, nullptr, 0, tw, nullptr, 0, v, v);
+            }
+            // ---- decode: est_a[k] = sum_r G[a][r] Y_r[k], the contraction over the four lanes of a column again; stream a's sixteen
+            //      estimates land in lane (a, g), whose register L still holds their labels; decisions four at a time ----
+            if constexpr (!(ABL & 1024)) {
+                const T gre = gA.x, gim = gA.y, ngim = -gA.y;
+                const uint32_t wds[4] = {L.x, L.y, L.z, L.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    cx<T> e[4];
+                    int tx[4];
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        const int u = 4 * i + jj;
+                        T er = __builtin_amdgcn_mfma_f64_4x4x4f64(gre, v[u].x, 0.0, 0, 0, 0);
+                        T ei = __builtin_amdgcn_mfma_f64_4x4x4f64(gim, v[u].x, 0.0, 0, 0, 0);
+                        er = __builtin_amdgcn_mfma_f64_4x4x4f64(ngim, v[u].y, er, 0, 0, 0);
+                        ei = __builtin_amdgcn_mfma_f64_4x4x4f64(gre, v[u].y, ei, 0, 0, 0);
+                        e[jj] = mk<T>(er, ei);
+                        tx[jj] = (int)((wds[i] >> (8 * jj)) & 0xFFu);
+                    }
+                    walk_decide<DEC, 4>(mp, s_table, nullptr, e, tx, se, be);
+                }
+            } else {
+                se += (unsigned)(v[0].x + v[15].y == 0.5);
+            }
+        }
+        se = wave_sum_u32(se);
+        be = wave_sum_u32(be);
+        if (lane == 0) wg_account(totals[w], se, be, skipped, rl, sym_out, bit_out);
+    }
+    if (lane == 0)
+        wg_flush(totals[w], counters, (unsigned long long)per_sym * pp.n_ofdm_sym, (unsigned long long)per_sym * pp.n_ofdm_sym * mp.bits);
+}
+
+template <int WPS, int ABL = 0>
+static int launch_mimo_ofdm_fw(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, uint64_t seed, uint64_t first, uint64_t count,
+                               mcle_counters* d_counters, uint32_t* d_sym, uint32_t* d_bit) {
+    using T = double;
+    constexpr int N = 256, NT = 4, NR = 4, kRec = d64_rec<NT, NR>();
+    int rc;
+    void* tw = nullptr;
+    if ((rc = ctx->get_twiddles(N, MCLE_F64, &tw))) return rc;
+    MimoParams pp{cfg->cp_size, cfg->num_used, cfg->n_ofdm_sym, cfg->mmse, cfg->noise_var};
+    ModemParams<T> mp = pipe_modem<T>(ctx, cfg->demod_method);
+    const int dec = walk_dec_kind(ctx, mp);
+    mp.grid.G = 0;
+    const size_t tab_len = ((size_t)mp.M + 1) & ~(size_t)1;
+    const size_t lds = (size_t)4 * kFwPlane * sizeof(T) + (2 * tab_len + 4 * (kRec + 1)) * sizeof(cx<T>) +
+                       (size_t)((kBmLdsDoubles + 1) & ~1) * sizeof(double) + 4 * kFwLabBytes;
+    MCLE_REQUIRE(lds + 512 <= (size_t)160 * 1024, "full-wave MIMO-OFDM kernel: %zu B of LDS do not fit", lds);
+    auto kern = k_run_mimo_ofdm_fw<WDEC_SLICER, WPS, ABL>;
+    switch (dec) {
+        case WDEC_QAM_CERT: kern = k_run_mimo_ofdm_fw<WDEC_QAM_CERT, WPS, ABL>; break;
+        case WDEC_QUAD_CERT: kern = k_run_mimo_ofdm_fw<WDEC_QUAD_CERT, WPS, ABL>; break;
+        case WDEC_AXIS4_CERT: kern = k_run_mimo_ofdm_fw<WDEC_AXIS4_CERT, WPS, ABL>; break;
+        default: break;
+    }
+    MCLE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int per_cu = (int)((size_t)160 * 1024 / (lds + 512));
+    if (per_cu < 1) per_cu = 1;
+    if (per_cu > WPS) per_cu = WPS;                            // 256 threads = one wavefront per SIMD and workgroup
+    const uint64_t resident = (uint64_t)ctx->n_cu * per_cu;
+    const uint64_t kSlice = 1ull << 20;
+    const uint64_t slice = count < kSlice ? count : kSlice;
+    void* recs = nullptr;
+    if ((rc = ctx->scratch((size_t)slice * kRec * sizeof(cx<T>), &recs))) return rc;
+    for (uint64_t off = 0; off < count; off += slice) {
+        const uint64_t n = count - off < slice ? count - off : slice;
+        hipLaunchKernelGGL((k_mimo_filters_planar<T, N, NT, NR>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, pp, seed,
+                           first + off, n, (cx<T>*)recs);
+        MCLE_LAUNCH_CHECK();
+        const unsigned grid = (unsigned)oversubscribed_grid(ctx, resident, (n + 3) / 4, 8, 16);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, ctx->stream, pp, mp, seed, first + off, n, (const cx<T>*)tw,
+                           (const cx<T>*)recs, d_counters, d_sym ? d_sym + off : nullptr, d_bit ? d_bit + off : nullptr);
+        MCLE_LAUNCH_CHECK();
+    }
+    return MCLE_OK;
+}
+
+// 0 = launched; MCLE_E_UNSUPPORTED = outside the envelope (the caller stays on the planar kernel)
+int run_mimo_ofdm_fw(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, uint64_t seed, uint64_t first, uint64_t count,
+                     mcle_counters* d_counters, uint32_t* d_sym, uint32_t* d_bit) {
+    if (!(cfg->fft_size == 256 && cfg->nt == 4 && cfg->nr == 4 && cfg->num_used == 256 && (cfg->cp_size & 1) == 0))
+        return MCLE_E_UNSUPPORTED;
+    if (ctx->M > 256) return MCLE_E_UNSUPPORTED;
+    {
+        ModemParams<double> mp = pipe_modem<double>(ctx, cfg->demod_method);
+        if (walk_dec_kind(ctx, mp) == WDEC_GENERIC) return MCLE_E_UNSUPPORTED;     // no certificate: the planar kernel's candidate grid
+    }
+#ifdef MCLE_EXPERIMENTS
+    switch ((int)ctx->opt[MCLE_OPT_F64_VARIANT]) {
+#define MCLE_FW_ABL(V_) case V_: return launch_mimo_ofdm_fw<3, V_>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
+        MCLE_FW_ABL(32) MCLE_FW_ABL(64) MCLE_FW_ABL(128) MCLE_FW_ABL(256) MCLE_FW_ABL(512) MCLE_FW_ABL(1024) MCLE_FW_ABL(2016)
+#undef MCLE_FW_ABL
+        default: break;
+    }
+#endif
+    if (ctx->opt[MCLE_OPT_F64_THREADS] == 262) return launch_mimo_ofdm_fw<2>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
+    return launch_mimo_ofdm_fw<3>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
+}
+
+}  // namespace mcle

@@ -526,6 +526,10 @@ template <typename T> constexpr int planar_wps(int w64) { return w64; }
 int run_mimo_ofdm_qw(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, uint64_t seed, uint64_t first, uint64_t count,
                      mcle_counters* d_counters, uint32_t* d_sym, uint32_t* d_bit);
 
+// pipeline_mimo_fw.hip: one realization per wavefront at fft_size 256 (complex128, 4 x 4; MCLE_E_UNSUPPORTED outside its envelope)
+int run_mimo_ofdm_fw(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, uint64_t seed, uint64_t first, uint64_t count,
+                     mcle_counters* d_counters, uint32_t* d_sym, uint32_t* d_bit);
+
 template <typename T>
 static int run_mimo_ofdm_planar_t(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, uint64_t seed, uint64_t first, uint64_t count,
                                   mcle_counters* d_counters, uint32_t* d_sym, uint32_t* d_bit) {
@@ -538,6 +542,18 @@ static int run_mimo_ofdm_planar_t(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, 
     // 10.66 ms per 262 144 realizations against 11.65 for the 512-thread radix-4 form and 12.15 for the 256-thread one,
     // profiles/r04/c4_f64_r16_ab.log).  MCLE_OPT_F64_THREADS: 512 = radix-4, two antennas per thread; 256 = radix-4, four
     // antennas per thread, twiddles in registers.  MCLE_OPT_F64_VARIANT 1 .. 3: timing bounds on the 512-thread form.
+    if (n == 256 && nt == 4 && nr == 4) {
+        if constexpr (F64) {
+            // round 6: the FULL-WAVE kernel (pipeline_mimo_fw.hip: a realization is one wavefront -- the quarter-wave kernel's register
+            // passes without its radix-4 exchange stage, channel AND decode on v_mfma_f64_4x4x4, no workgroup barrier).
+            // MCLE_OPT_F64_THREADS = 261: the planar radix-4 form of rounds 3-5; 262: full-wave bounded for two wavefronts per SIMD.
+            const long long thr = ctx->opt[MCLE_OPT_F64_THREADS];
+            if (thr == 0 || thr == 260 || thr == 262) {
+                const int rq = run_mimo_ofdm_fw(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
+                if (rq != MCLE_E_UNSUPPORTED) return rq;
+            }
+        }
+    }
     if (n == 1024 && nt == 4 && nr == 4) {
         if constexpr (F64) {
             // The default since round 6: the QUARTER-WAVE kernel (pipeline_mimo_qw.hip: samples in registers between the passes, three

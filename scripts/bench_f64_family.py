@@ -26,11 +26,14 @@ for fft, nt, nr in ((256, 2, 2), (256, 4, 4), (512, 2, 2), (512, 4, 4), (1024, 2
             ("generic_mindist", 1, _lib.DEMOD_MINDIST, 1)]
     if DT == "f32" and (fft, nt, nr) == (1024, 4, 4):
         legs += [("mfma_mindist", 0, _lib.DEMOD_MINDIST, 0), ("mfma_slicer", 0, _lib.DEMOD_QAM_SLICER, 0)]
+    if DT == "f64" and (fft, nt, nr) in ((256, 4, 4), (1024, 4, 4)):
+        # round 6: the default at these two shapes is the full-wave / quarter-wave kernel; the planar form of rounds 3-5 next to it
+        legs += [("planar_mindist", 0, _lib.DEMOD_MINDIST, 261), ("planar_slicer", 0, _lib.DEMOD_QAM_SLICER, 261)]
     for name, generic, method, planar in legs:
         if generic and (nt != nr or (fft, nr) == (2048, 4)):      # the generic kernel has no such shape (2048 x 4: 181 KiB of LDS)
             continue
         cnt = eng.new_counters()
-        with eng.options(f64_generic=generic, f32_mfma=0 if planar else 1):
+        with eng.options(f64_generic=generic, f32_mfma=0 if planar else 1, f64_threads=261 if planar == 261 else 0):
             run = lambda first: eng.run_mimo_ofdm(nt, nr, fft, 16, fft, 1, nv, 1, first, n, method=method, dtype=DT,
                                                   counters=cnt)
             run(1 << 30)
@@ -45,4 +48,11 @@ for fft, nt, nr in ((256, 2, 2), (256, 4, 4), (512, 2, 2), (512, 4, 4), (1024, 2
     if "generic_mindist" in row:
         row["fast_over_generic"] = row["fast_mindist"]["realizations_per_s"] / row["generic_mindist"]["realizations_per_s"]
     out["%dx%dx%d" % (fft, nt, nr)] = row
+# per-subcarrier rate relative to the (1024, same geometry) row -- VERDICT r05 item 3's measure
+for key, row in out.items():
+    fft, nt, nr = (int(v) for v in key.split("x"))
+    ref = out.get("1024x%dx%d" % (nt, nr))
+    if ref:
+        for leg in ("fast_mindist", "fast_slicer"):
+            row[leg]["per_subcarrier_vs_1024"] = row[leg]["realizations_per_s"] * fft / (ref[leg]["realizations_per_s"] * 1024)
 print(json.dumps(out, indent=1))
