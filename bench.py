@@ -114,8 +114,10 @@ def kernel_name(cfg, dtype):
         return "k_run_ofdm_tdl_batch" if (dtype == "f64" or ACTIVE_OPTS.get("no_mfma")) else "k_run_ofdm_tdl_mfma"
     if cfg == "f1" and ACTIVE_OPTS.get("mimo_tdl_kernel") == 1:
         return "k_run_mimo_ofdm_tdl"                  # the workgroup-cooperative kernel of rounds 1-4
-    if cfg == "c4" and dtype == "f64" and ACTIVE_OPTS.get("f64_threads", 0) in (0, 260, 262):
-        return "k_run_mimo_ofdm_qw"                   # the quarter-wave kernel (round 6; bench.py's workload is inside its envelope)
+    if cfg == "c4" and dtype == "f64" and ACTIVE_OPTS.get("f64_threads", 0) in (0, 263, 264):
+        return "k_run_mimo_ofdm_pw"                   # quarter-wave decomposition, channel AND decode on the matrix cores (round 6, default)
+    if cfg == "c4" and dtype == "f64" and ACTIVE_OPTS.get("f64_threads", 0) in (260, 262):
+        return "k_run_mimo_ofdm_qw"                   # the first quarter-wave kernel (VALU decode)
     if cfg in ("c5", "f6") and dtype == "f64" and not ACTIVE_OPTS.get("walk_legacy"):
         return "k_link_walk_f64"                      # the packed complex128 walk (round 6, csrc/walk_f64.hpp)
     return (KERNEL_F64 if dtype == "f64" else KERNEL)[cfg]
@@ -126,10 +128,10 @@ KERNEL_NOTE = {   # configs whose step is two launches: the time spans both, the
           "wavefront; since round 4 the default ahead of the matrix-core kernel k_run_mimo_ofdm_mfma, option f32_mfma = 1); "
           "kernel_ms_per_launch spans them",
     ("c4", "f64"): "a step = per slice of 2^18 realizations k_mimo_filters_planar (channel draw + f64 receive filter, one thread per "
-                   "realization, ~1 % of the time) + k_run_mimo_ofdm_qw (round 6: a wavefront owns one time class n mod 4 of all four "
-                   "antennas, samples in registers between radix-16 passes, three workgroups per CU, the channel contraction on "
-                   "v_mfma_f64_4x4x4; option f64_threads=261: the planar kernel k_run_mimo_ofdm_planar of rounds 3-5); "
-                   "kernel_ms_per_launch spans them",
+                   "realization, ~1 % of the time) + k_run_mimo_ofdm_pw<4> (round 6: a wavefront owns one time class n mod 4 of all four "
+                   "antennas, samples in registers between radix-16 passes, three workgroups per CU, the channel contraction AND the "
+                   "Blast decode on v_mfma_f64_4x4x4; option f64_threads=260: k_run_mimo_ofdm_qw, the same with the decode on the VALU; "
+                   "261: the planar kernel k_run_mimo_ofdm_planar of rounds 3-5); kernel_ms_per_launch spans them",
     ("c3", "f64"): "a step = k_tdl_symbol_polys<double> (fading records) + k_run_ofdm_tdl_wave<double> (one realization per "
                    "wavefront; option tdl_kernel=1: k_run_ofdm_tdl_batch<double, 1024, 2>) per slice of <= 2 GiB of records; "
                    "kernel_ms_per_launch spans them",
@@ -175,7 +177,8 @@ def profile_specs():
             ACTIVE_OPTS.update(saved)
         specs[tag] = {"config": cfg, "dtype": dtype, "demod": demod, "batch": batch, "opts": list(opts), "kernel": needle,
                       "leg": leg, "note": note}
-    add("c4_f64", "c4", "f64", "mindist", hl, leg="value", note="the headline: quarter-wave kernel, min-distance (certificate)")
+    add("c4_f64", "c4", "f64", "mindist", hl, leg="value", note="the headline: quarter-wave decomposition with channel and decode on the matrix cores, min-distance (certificate)")
+    add("c4_f64_qw", "c4", "f64", "mindist", hl, opts=("f64_threads=260",), note="the first quarter-wave kernel, VALU decode (A/B)")
     add("c4_f64sl", "c4", "f64", "slicer", hl, leg="rates.f64.slicer")
     add("c4_f64_planar", "c4", "f64", "mindist", hl, opts=("f64_threads=261",), note="the planar kernel of rounds 3-5 (A/B)")
     add("c4", "c4", "f32", "slicer", hl, leg="rates.f32.slicer")

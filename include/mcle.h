@@ -111,7 +111,13 @@ enum {
                                       stage at a four-wavefront register bound (default); 257 = the same at a three-wavefront
                                       bound; 259 = the fused channel stage; 512 / 256 as above.
                                       fft_size 2048 with four receive antennas and Nt >= 3: 512 = four antennas per thread (512 threads,
-                                      nothing spilled; the default where it is the faster form), 1024 = two antennas per thread */
+                                      nothing spilled; the default where it is the faster form), 1024 = two antennas per thread.
+                                      complex128 at (256, 4x4) and (512, 4x4), same envelope: 0 / 260 = the full-wave kernel (256:
+                                      csrc/pipeline_mimo_fw.hip, one realization per wavefront) / the half-wave kernel (512:
+                                      csrc/pipeline_mimo_pw.hip, two wavefronts per realization), both with channel AND decode on
+                                      v_mfma_f64_4x4x4; 262 = bounded for two wavefronts per SIMD; 261 = the planar radix-4 form of
+                                      rounds 3-5.  (1024, 4x4): 263 / 264 = the quarter-wave decomposition with the decode on the
+                                      matrix cores (pipeline_mimo_pw.hip, NW = 4; three / two wavefronts per SIMD) */
     MCLE_OPT_BD_RUNTIME_SOLVE = 9, /* 1: the block-diagonalisation pipeline solves with the run-time-sized routine (private
                                       arrays in scratch) also where the compile-time-sized one (K nr <= 6) applies */
     MCLE_OPT_DEMOD_NOCERT = 10,    /* 1: min-distance decisions of a square Gray QAM always through the table search (candidate

@@ -237,7 +237,7 @@ int mcle_ctx_set_option(mcle_ctx* ctx, int option, long long value) {
         case MCLE_OPT_GRID_OVERSUB: ok = value >= 0 && value <= 64; break;
         case MCLE_OPT_FLAT_WGS_PER_CU: ok = value >= 0 && value <= 4096; break;
         case MCLE_OPT_TDL_MFMA_WAVES: ok = value == 0 || value == 2 || value == 3 || value == 32; break;
-        case MCLE_OPT_F64_THREADS: ok = value == 0 || (value >= 256 && value <= 262) || value == 512 || value == 1024; break;
+        case MCLE_OPT_F64_THREADS: ok = value == 0 || (value >= 256 && value <= 264) || value == 512 || value == 1024; break;
     }
     MCLE_REQUIRE(ok, "option %d: value %lld out of range", option, value);
     ctx->opt[option] = value;

@@ -530,6 +530,10 @@ int run_mimo_ofdm_qw(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, uint64_t seed
 int run_mimo_ofdm_fw(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, uint64_t seed, uint64_t first, uint64_t count,
                      mcle_counters* d_counters, uint32_t* d_sym, uint32_t* d_bit);
 
+// pipeline_mimo_pw.hip: 1 / NW of the time samples per wavefront at fft_size 512 (NW = 2) and 1024 (NW = 4), decode on the matrix cores
+int run_mimo_ofdm_pw(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, uint64_t seed, uint64_t first, uint64_t count,
+                     mcle_counters* d_counters, uint32_t* d_sym, uint32_t* d_bit);
+
 template <typename T>
 static int run_mimo_ofdm_planar_t(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, uint64_t seed, uint64_t first, uint64_t count,
                                   mcle_counters* d_counters, uint32_t* d_sym, uint32_t* d_bit) {
@@ -554,8 +558,28 @@ static int run_mimo_ofdm_planar_t(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, 
             }
         }
     }
+    if (n == 512 && nt == 4 && nr == 4) {
+        if constexpr (F64) {
+            // round 6: the HALF-WAVE kernel (pipeline_mimo_pw.hip, NW = 2).  MCLE_OPT_F64_THREADS = 261: the planar radix-4 form.
+            const long long thr = ctx->opt[MCLE_OPT_F64_THREADS];
+            if (thr == 0 || thr == 260 || thr == 262) {
+                const int rq = run_mimo_ofdm_pw(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
+                if (rq != MCLE_E_UNSUPPORTED) return rq;
+            }
+        }
+    }
     if (n == 1024 && nt == 4 && nr == 4) {
         if constexpr (F64) {
+            {   // The default since the end of round 6: the quarter-wave decomposition with the DECODE on the matrix cores as well
+                // (pipeline_mimo_pw.hip, NW = 4: 32.4 against 35.2 ms per 2^20 realizations for pipeline_mimo_qw.hip on the same box,
+                // profiles/r06/pw_ab.log).  MCLE_OPT_F64_THREADS = 263: the same, explicit; 264: registers bounded for two wavefronts
+                // per SIMD; 260 / 262: the quarter-wave kernel of pipeline_mimo_qw.hip (VALU decode, four bins per thread).
+                const long long thr = ctx->opt[MCLE_OPT_F64_THREADS];
+                if (thr == 0 || thr == 263 || thr == 264) {
+                    const int rq = run_mimo_ofdm_pw(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
+                    if (rq != MCLE_E_UNSUPPORTED) return rq;
+                }
+            }
             // The default since round 6: the QUARTER-WAVE kernel (pipeline_mimo_qw.hip: samples in registers between the passes, three
             // workgroups per CU, the channel contraction on v_mfma_f64_4x4x4) -- 8.82 against 10.49 ms per 262 144 realizations
             // (profiles/r06/qw_ab.log).  Outside its envelope (partial band, odd prefix, a constellation without a certificate)
@@ -563,7 +587,7 @@ static int run_mimo_ofdm_planar_t(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, 
             // 262 = the same bounded for two wavefronts per SIMD, 261 = the planar radix-16 form that was the default until round 5.
             {
                 const long long thr = ctx->opt[MCLE_OPT_F64_THREADS];
-                if (thr == 0 || thr == 260 || thr == 262) {
+                if (thr == 0 || thr == 260 || thr == 262) {          // (0: outside the part-wave kernel's envelope nothing reaches this line)
                     const int rq = run_mimo_ofdm_qw(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
                     if (rq != MCLE_E_UNSUPPORTED) return rq;
                 }

@@ -40,7 +40,7 @@ def test_default_line_carries_every_contract_field():
         assert r["unit"] == "TFLOP/s" and r["bound"] == "valu" and r["peak"] > 0
         assert abs(r["frac"] - r["achieved"] / r["peak"]) <= 1e-12 and 0.0 < r["frac"] < 1.0
         assert r["kernel_ms_per_launch"] > 0 and r["realizations_per_launch"] == 16384
-    assert d["roofline"]["kernel"] == "k_run_mimo_ofdm_qw" and d["roofline_f32"]["kernel"] == "k_run_mimo_ofdm_planar"
+    assert d["roofline"]["kernel"] == "k_run_mimo_ofdm_pw" and d["roofline_f32"]["kernel"] == "k_run_mimo_ofdm_planar"
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and cb["unit"] == "realizations/s" and cb["sample"]
     st = d["other_workloads"]["c4_staged"]

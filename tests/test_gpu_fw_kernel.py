@@ -1,7 +1,9 @@
-"""GPU: the full-wave complex128 kernel of config 4's link at fft_size 256 (csrc/pipeline_mimo_fw.hip: one realization per wavefront,
-channel and decode on v_mfma_f64_4x4x4; the default of mcle_run_mimo_ofdm at fft_size 256, 4 x 4, full band, even cyclic prefix,
-decisions by slicer or certificate since round 6; option f64_threads = 260 asks for it explicitly, 262 bounds its registers for two
-wavefronts per SIMD, 261 selects the planar kernel it replaced) -- per-realization symbol AND bit error counts equal to the oracle
+"""GPU: the full-wave and half-wave complex128 kernels of config 4's link at fft_size 256 / 512 (csrc/pipeline_mimo_fw.hip: one
+realization per wavefront; csrc/pipeline_mimo_pw.hip with NW = 2: two wavefronts per realization; channel and decode on
+v_mfma_f64_4x4x4; the defaults of mcle_run_mimo_ofdm at these sizes for 4 x 4, full band, even cyclic prefix, decisions by slicer or
+certificate since round 6; option f64_threads = 260 asks for them explicitly, 262 bounds the registers for two wavefronts per
+SIMD, 261 selects the planar kernel they replaced), and the same decomposition at 1024 with the decode on the matrix cores
+(pipeline_mimo_pw.hip with NW = 4, f64_threads = 263 / 264; the quarter-wave kernel pipeline_mimo_qw.hip stays the default there) -- per-realization symbol AND bit error counts equal to the oracle
 chain's (oracle/chains.py::chain_mimo_ofdm) on every corner of its envelope, equal to the planar kernel's over two thousand
 realizations per case, and requests outside the envelope served by the planar kernel.
 Reference: apps/mimo/simulate_mimo.py:68-142, mimo/mimo.py:609-660, modulators/ofdm.py:52-94, :394-466."""
@@ -31,68 +33,77 @@ def _set(engine, kw):
     engine.set_constellation(chains.constellation(kw["mod"], kw["M"]), _lib.CONST_QAM if kw["mod"] == "qam" else _lib.CONST_GENERIC)
 
 
-def _run(engine, kw, first, count, method, threads):
+def _run(engine, kw, first, count, method, threads, fft=256):
     nv = 1.0 / omodem.dB2Linear(kw["snr_db"])
     with engine.options(f64_threads=threads):
-        return engine.run_mimo_ofdm(4, 4, 256, kw.get("cp_size", 16), kw.get("num_used") or 256, kw.get("n_ofdm_sym", 1), nv, SEED,
+        return engine.run_mimo_ofdm(4, 4, fft, kw.get("cp_size", 16), kw.get("num_used") or fft, kw.get("n_ofdm_sym", 1), nv, SEED,
                                     first, count, mmse=kw.get("mmse", True), method=method, dtype="f64", per_realization=True)
 
 
-def _oracle(kw, first, count):
-    okw = dict(mod=kw["mod"], M=kw["M"], nt=4, nr=4, fft_size=256, cp_size=kw.get("cp_size", 16), num_used=kw.get("num_used"),
+def _oracle(kw, first, count, fft=256):
+    okw = dict(mod=kw["mod"], M=kw["M"], nt=4, nr=4, fft_size=fft, cp_size=kw.get("cp_size", 16), num_used=kw.get("num_used"),
                n_ofdm_sym=kw.get("n_ofdm_sym", 1), snr_db=kw["snr_db"], mmse=kw.get("mmse", True))
     want = [chains.chain_mimo_ofdm(chains.PhiloxRng(SEED, r), **okw) for r in range(first, first + count)]
     return (np.array([w["symbol_errors"] for w in want]), np.array([w["bit_errors"] for w in want]), want[0]["num_symbols"],
             want[0]["num_bits"])
 
 
+# (fft_size, the f64_threads values that select the round-6 kernel there, the planar kernel's)
+SIZES = {256: ((0, 260, 262), 261), 512: ((0, 260, 262), 261), 1024: ((263, 264), 261)}
+
+
+@pytest.mark.parametrize("fft", [256, 512, 1024])
 @pytest.mark.parametrize("case", range(len(INSIDE) + len(OUTSIDE)))
-def test_counts_equal_the_oracle(engine, case):
+def test_counts_equal_the_oracle(engine, case, fft):
     kw = (INSIDE + OUTSIDE)[case]
     _set(engine, kw)
-    first, count = (1 << 36) + 1009, 21
-    want_se, want_be, nsym, nbits = _oracle(kw, first, count)
+    first, count = (1 << 36) + 1009, 21 if fft < 1024 else 6
+    want_se, want_be, nsym, nbits = _oracle(kw, first, count, fft)
     methods = [_lib.DEMOD_MINDIST] + ([_lib.DEMOD_QAM_SLICER] if kw["mod"] == "qam" else [])
     for method in methods:
-        for threads in (0, 260, 262, 261):
-            res, se, be = _run(engine, kw, first, count, method, threads)
+        for threads in SIZES[fft][0] + (SIZES[fft][1],):
+            res, se, be = _run(engine, kw, first, count, method, threads, fft)
             assert np.array_equal(se, want_se) and np.array_equal(be, want_be), (case, method, threads, se, want_se)
             assert res["n_realizations"] == count and res["n_skipped"] == 0 and res["n_symbols"] == nsym and res["n_bits"] == nbits
             assert res["sym_errors"] == int(want_se.sum()) and res["sym_errors_sq"] == int((want_se.astype(np.int64) ** 2).sum())
 
 
+@pytest.mark.parametrize("fft", [256, 512, 1024])
 @pytest.mark.parametrize("case", range(len(INSIDE)))
-def test_equal_to_the_planar_kernel_over_two_thousand_realizations(engine, case):
+def test_equal_to_the_planar_kernel_over_two_thousand_realizations(engine, case, fft):
     """Both are complex128 statements of the same link with differently rounded transforms: a rounding-level tie may differ once
     in ~1e7 symbols.  Same sums of squares under any split of the range (launch slices are invisible)."""
     kw = INSIDE[case]
     _set(engine, kw)
-    n = 2203
+    n = 2203 if fft < 1024 else 1100
+    new = SIZES[fft][0][0]
     for method in [_lib.DEMOD_MINDIST] + ([_lib.DEMOD_QAM_SLICER] if kw["mod"] == "qam" else []):
-        qw, se, be = _run(engine, kw, 77, n, method, 0)
-        pl, se_p, be_p = _run(engine, kw, 77, n, method, 261)
+        qw, se, be = _run(engine, kw, 77, n, method, new, fft)
+        pl, se_p, be_p = _run(engine, kw, 77, n, method, 261, fft)
         assert np.count_nonzero(se != se_p) <= 1 and np.max(np.abs(se.astype(np.int64) - se_p.astype(np.int64))) <= 1
         assert np.count_nonzero(be != be_p) <= 1
         assert qw["n_realizations"] == pl["n_realizations"] == n and qw["n_skipped"] == pl["n_skipped"]
-        a = _run(engine, kw, 77, 300, method, 0)[0]
-        b = _run(engine, kw, 377, n - 300, method, 0)[0]
+        a = _run(engine, kw, 77, 300, method, new, fft)[0]
+        b = _run(engine, kw, 377, n - 300, method, new, fft)[0]
         for k in ("sym_errors", "sym_errors_sq", "bit_errors", "bit_errors_sq", "n_realizations", "n_skipped"):
             assert qw[k] == a[k] + b[k], k
-        again = _run(engine, kw, 77, n, method, 0)
+        again = _run(engine, kw, 77, n, method, new, fft)
         assert np.array_equal(again[1], se) and np.array_equal(again[2], be)             # bit-identical from run to run
 
 
-def test_benchmark_link_at_256_against_the_oracle_over_4096_realizations(engine):
-    """Config 4's link at fft_size 256 (4 x 4 MMSE, 64-QAM, OFDM(256, 16), 25 dB) on the full-wave kernel, both demodulators and both
-    register bounds: every per-realization count of 4 096 consecutive realizations (4.2e6 symbols) equal to the oracle's."""
+@pytest.mark.parametrize("fft", [256, 512, 1024])
+def test_benchmark_link_against_the_oracle_at_depth(engine, fft):
+    """Config 4's link (4 x 4 MMSE, 64-QAM, OFDM(fft, 16), 25 dB) on the round-6 kernel of the size, both demodulators and both register
+    bounds: every per-realization count of 4 096 (256), 2 048 (512), 1 024 (1024) consecutive realizations -- 4.2e6 symbols each -- equal
+    to the oracle's."""
     kw = INSIDE[0]
     _set(engine, kw)
-    first, count = 987654321, 4096
-    want_se, want_be, _, _ = _oracle(kw, first, count)
+    first, count = 987654321, 4096 * 256 // fft
+    want_se, want_be, _, _ = _oracle(kw, first, count, fft)
     assert want_se.sum() > 1e5
-    for threads in (260, 262):
+    for threads in SIZES[fft][0][-2:]:
         for method in (_lib.DEMOD_MINDIST, _lib.DEMOD_QAM_SLICER):
-            res, se, be = _run(engine, kw, first, count, method, threads)
+            res, se, be = _run(engine, kw, first, count, method, threads, fft)
             assert np.array_equal(se, want_se), (threads, method, np.flatnonzero(se != want_se)[:5])
             assert np.array_equal(be, want_be)
             assert res["sym_errors"] == int(want_se.sum()) and res["bit_errors"] == int(want_be.sum())
@@ -102,6 +113,10 @@ def test_singular_channels_are_skipped_like_the_planar_kernel(engine):
     """Zero forcing at infinite SNR over many realizations: whatever the record kernel flags as skipped is skipped by both."""
     kw = dict(mod="qam", M=16, snr_db=300.0, mmse=False)
     _set(engine, kw)
-    a = _run(engine, kw, 0, 4096, _lib.DEMOD_MINDIST, 260)[0]
-    b = _run(engine, kw, 0, 4096, _lib.DEMOD_MINDIST, 261)[0]
+    for fft in (256, 512, 1024):
+        a = _run(engine, kw, 0, 4096, _lib.DEMOD_MINDIST, SIZES[fft][0][0], fft)[0]
+        b = _run(engine, kw, 0, 4096, _lib.DEMOD_MINDIST, 261, fft)[0]
+        assert a["n_skipped"] == b["n_skipped"] and a["n_realizations"] == b["n_realizations"] and a["sym_errors"] == b["sym_errors"]
+    a = _run(engine, kw, 0, 64, _lib.DEMOD_MINDIST, 260)[0]
+    b = _run(engine, kw, 0, 64, _lib.DEMOD_MINDIST, 261)[0]
     assert a["n_skipped"] == b["n_skipped"] and a["n_realizations"] == b["n_realizations"] and a["sym_errors"] == b["sym_errors"]

@@ -1,6 +1,7 @@
-"""GPU: the quarter-wave complex128 config-4 kernel (csrc/pipeline_mimo_qw.hip, the default of mcle_run_mimo_ofdm at fft_size 1024,
-4 x 4, full band, even cyclic prefix, decisions by slicer or certificate since round 6; option f64_threads = 260 asks for it
-explicitly, 261 for the planar kernel it replaced) -- per-realization symbol AND bit error counts equal to the oracle chain's
+"""GPU: the quarter-wave complex128 config-4 kernels at fft_size 1024, 4 x 4, full band, even cyclic prefix, decisions by slicer or
+certificate: csrc/pipeline_mimo_pw.hip with NW = 4 (channel AND decode on the matrix cores: the default of mcle_run_mimo_ofdm since
+the end of round 6, option f64_threads = 0 / 263, 264 = two wavefronts per SIMD) and csrc/pipeline_mimo_qw.hip (the first edition, VALU
+decode: f64_threads = 260 / 262); 261 selects the planar kernel they replaced -- per-realization symbol AND bit error counts equal to the oracle chain's
 (oracle/chains.py::chain_mimo_ofdm, pinned to the reference by tests/golden/c4_mimo_ofdm.npz) on every corner of its envelope,
 equal to the planar kernel's over a thousand realizations per case, and requests outside the envelope served by the planar kernel.
 Reference: apps/mimo/simulate_mimo.py:68-142, mimo/mimo.py:609-660, modulators/ofdm.py:394-466."""
@@ -52,7 +53,7 @@ def test_counts_equal_the_oracle(engine, case):
     want_se, want_be, nsym, nbits = _oracle(kw, first, count)
     methods = [_lib.DEMOD_MINDIST] + ([_lib.DEMOD_QAM_SLICER] if kw["mod"] == "qam" else [])
     for method in methods:
-        for threads in (0, 260, 262, 261):
+        for threads in (0, 263, 264, 260, 262, 261):
             res, se, be = _run(engine, kw, first, count, method, threads)
             assert np.array_equal(se, want_se) and np.array_equal(be, want_be), (case, method, threads, se, want_se)
             assert res["n_realizations"] == count and res["n_skipped"] == 0 and res["n_symbols"] == nsym and res["n_bits"] == nbits
@@ -88,7 +89,7 @@ def test_headline_geometry_against_the_oracle_over_2048_realizations(engine):
     first, count = 987654321, 2048
     want_se, want_be, _, _ = _oracle(kw, first, count)
     assert want_se.sum() > 1e5
-    for threads in (260, 262):
+    for threads in (0, 264, 260, 262):
         for method in (_lib.DEMOD_MINDIST, _lib.DEMOD_QAM_SLICER):
             res, se, be = _run(engine, kw, first, count, method, threads)
             assert np.array_equal(se, want_se), (threads, method, np.flatnonzero(se != want_se)[:5])
