@@ -558,9 +558,10 @@ static int run_mimo_ofdm_planar_t(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, 
             }
         }
     }
-    if (n == 512 && nt == 4 && nr == 4) {
+    if ((n == 512 || n == 2048) && nt == 4 && nr == 4) {
         if constexpr (F64) {
-            // round 6: the HALF-WAVE kernel (pipeline_mimo_pw.hip, NW = 2).  MCLE_OPT_F64_THREADS = 261: the planar radix-4 form.
+            // round 6: the HALF-WAVE / EIGHTH-WAVE kernel (pipeline_mimo_pw.hip, NW = 2 / 8).  MCLE_OPT_F64_THREADS = 261 (and, at 2048,
+            // 512 / 1024): the planar radix-4 forms.
             const long long thr = ctx->opt[MCLE_OPT_F64_THREADS];
             if (thr == 0 || thr == 260 || thr == 262) {
                 const int rq = run_mimo_ofdm_pw(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);

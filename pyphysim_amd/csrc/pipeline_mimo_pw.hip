@@ -1,5 +1,5 @@
-// pipeline_mimo_pw.hip -- config 4's link (4 x 4 Blast + OFDM, complex128) with 1 / NW OF THE TIME SAMPLES PER WAVEFRONT, NW = 2, 4
-// (fft_size 512, 1024): the quarter-wave kernel of pipeline_mimo_qw.hip (NW = 4 there) as a template over the number of
+// pipeline_mimo_pw.hip -- config 4's link (4 x 4 Blast + OFDM, complex128) with 1 / NW OF THE TIME SAMPLES PER WAVEFRONT, NW = 2, 4, 8
+// (fft_size 512, 1024, 2048): the quarter-wave kernel of pipeline_mimo_qw.hip (NW = 4 there) as a template over the number of
 // wavefronts, with the decode on the matrix cores (round 6).  Same link, same draw ledger (philox.hpp), same record kernel
 // (k_mimo_filters_planar) and results contract as k_run_mimo_ofdm_planar<double, N, 4, 4, ...>, whose per-realization counts it
 // reproduces (reference: apps/mimo/simulate_mimo.py:68-142, mimo/mimo.py:609-660, modulators/ofdm.py:52-94, :394-466).
@@ -72,6 +72,53 @@ __device__ __forceinline__ void pw_first_stage(const unsigned char* lab_row, con
                 else v[u] = cmulc(S, g_tw[16 * J * u]);                                // uniform address: a scalar load
             }
         }
+    } else if constexpr (NW == 8) {
+        // sum_q w^(J q) X_q, w = e^(2 pi i / 8), as (A_0 + i^J A_2) + w^J (A_1 + i^J A_3) with A_q0 = X_q0 + (-1)^J X_(q0 + 4)
+        constexpr double kH = 0.70710678118654752440;
+        auto rotJ = [](double2 z) {                               // i^J z
+            if constexpr ((J & 3) == 0) return z;
+            else if constexpr ((J & 3) == 1) return mk<double>(-z.y, z.x);
+            else if constexpr ((J & 3) == 2) return mk<double>(-z.x, -z.y);
+            else return mk<double>(z.y, -z.x);
+        };
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const uint4 L = lab[i];
+            const uint32_t wds[4] = {L.x, L.y, L.z, L.w};
+#pragma unroll
+            for (int uu = 0; uu < 2; ++uu) {
+                const int u = 2 * i + uu;
+                const uint32_t w0 = wds[2 * uu], w1 = wds[2 * uu + 1];
+                double2 X[8];
+                if constexpr (STUB) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) X[q] = mk<double>((double)(w0 + w1), 1.0);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        X[q] = s_txtab[(w0 >> (8 * q)) & 0xFFu];
+                        X[q + 4] = s_txtab[(w1 >> (8 * q)) & 0xFFu];
+                    }
+                }
+                double2 A[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) A[q] = (J & 1) ? csub(X[q], X[q + 4]) : cadd(X[q], X[q + 4]);
+                const double2 B0 = cadd(A[0], rotJ(A[2])), B1 = cadd(A[1], rotJ(A[3]));
+                double2 S;
+                if constexpr (J == 0) S = cadd(B0, B1);
+                else if constexpr (J == 2) S = mk<double>(B0.x - B1.y, B0.y + B1.x);              // + i B1
+                else if constexpr (J == 4) S = csub(B0, B1);
+                else if constexpr (J == 6) S = mk<double>(B0.x + B1.y, B0.y - B1.x);              // - i B1
+                else {
+                    // w^J = (c + i s) / sqrt 2: J = 1: (1, 1), 3: (-1, 1), 5: (-1, -1), 7: (1, -1)
+                    constexpr double c = (J == 1 || J == 7) ? kH : -kH, sn = (J == 1 || J == 3) ? kH : -kH;
+                    S = mk<double>(B0.x + (c * B1.x - sn * B1.y), B0.y + (sn * B1.x + c * B1.y));
+                }
+                if constexpr (J == 0) v[u] = S;
+                else if (u == 0) v[u] = S;
+                else v[u] = cmulc(S, g_tw[16 * J * u]);
+            }
+        }
     } else {
         static_assert(NW == 2, "first stage");
 #pragma unroll
@@ -108,7 +155,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void k_run_mimo_ofdm_pw(MimoParams pp
     using T = double;
     constexpr int N = 256 * NW, NT = 4, NR = 4, kRec = d64_rec<NT, NR>(), TB = 64 * NW, UU = 16 / NW;
     constexpr int kLabStride = pw_lab_stride<NW>();
-    static_assert(NW == 2 || NW == 4, "wavefronts per realization");
+    static_assert(NW == 2 || NW == 4 || NW == 8, "wavefronts per realization");
     extern __shared__ __attribute__((aligned(16))) char pw_smem[];
     T* s_R = reinterpret_cast<T*>(pw_smem);                                  // [NW wavefronts][kPwPlane]: scratch plane of wavefront j
     cx<T>* s_table = reinterpret_cast<cx<T>*>(s_R + NW * kPwPlane);           // [tab_len] constellation
@@ -216,6 +263,17 @@ __global__ __launch_bounds__(64 * NW, WPS) void k_run_mimo_ofdm_pw(MimoParams pp
                         case 1: pw_first_stage<4, 1, (ABL & 32) != 0>(lab, s_txtab, g_tw, v); break;
                         case 2: pw_first_stage<4, 2, (ABL & 32) != 0>(lab, s_txtab, g_tw, v); break;
                         default: pw_first_stage<4, 3, (ABL & 32) != 0>(lab, s_txtab, g_tw, v); break;
+                    }
+                } else if constexpr (NW == 8) {
+                    switch (j) {
+                        case 0: pw_first_stage<8, 0, (ABL & 32) != 0>(lab, s_txtab, g_tw, v); break;
+                        case 1: pw_first_stage<8, 1, (ABL & 32) != 0>(lab, s_txtab, g_tw, v); break;
+                        case 2: pw_first_stage<8, 2, (ABL & 32) != 0>(lab, s_txtab, g_tw, v); break;
+                        case 3: pw_first_stage<8, 3, (ABL & 32) != 0>(lab, s_txtab, g_tw, v); break;
+                        case 4: pw_first_stage<8, 4, (ABL & 32) != 0>(lab, s_txtab, g_tw, v); break;
+                        case 5: pw_first_stage<8, 5, (ABL & 32) != 0>(lab, s_txtab, g_tw, v); break;
+                        case 6: pw_first_stage<8, 6, (ABL & 32) != 0>(lab, s_txtab, g_tw, v); break;
+                        default: pw_first_stage<8, 7, (ABL & 32) != 0>(lab, s_txtab, g_tw, v); break;
                     }
                 } else {
                     if (j == 0) pw_first_stage<2, 0, (ABL & 32) != 0>(lab, s_txtab, g_tw, v);
@@ -357,6 +415,25 @@ __global__ __launch_bounds__(64 * NW, WPS) void k_run_mimo_ofdm_pw(MimoParams pp
                         const cx<T> u2 = cmul(mk<T>(er[2][uu], ei[2][uu]), w2);
                         const cx<T> u3 = cmul(mk<T>(er[3][uu], ei[3][uu]), w3);
                         CxOps<T>::template bfly4<false>(u0, u1, u2, u3, v[4 * uu], v[4 * uu + 1], v[4 * uu + 2], v[4 * uu + 3]);
+                    } else if constexpr (NW == 8) {
+                        // Y_q = E_q + w'^q O_q, Y_(q + 4) = E_q - w'^q O_q, E / O = the 4-point forward transforms of the even / odd
+                        // partial transforms, w' = e^(-2 pi i / 8)
+                        cx<T> x[8];
+                        x[0] = mk<T>(er[0][uu], ei[0][uu]);
+#pragma unroll
+                        for (int jj = 1; jj < 8; ++jj) x[jj] = cmul(mk<T>(er[jj][uu], ei[jj][uu]), g_tw[jj * kp]);
+                        cx<T> E[4], O[4];
+                        CxOps<T>::template bfly4<false>(x[0], x[2], x[4], x[6], E[0], E[1], E[2], E[3]);
+                        CxOps<T>::template bfly4<false>(x[1], x[3], x[5], x[7], O[0], O[1], O[2], O[3]);
+                        constexpr T kH = (T)0.70710678118654752440;
+                        const cx<T> t0 = O[0];
+                        const cx<T> t1 = mk<T>(kH * (O[1].x + O[1].y), kH * (O[1].y - O[1].x));      // (1 - i) / sqrt 2
+                        const cx<T> t2 = mk<T>(O[2].y, -O[2].x);                                     // -i
+                        const cx<T> t3 = mk<T>(kH * (O[3].y - O[3].x), -kH * (O[3].x + O[3].y));     // (-1 - i) / sqrt 2
+                        v[8 * uu + 0] = cadd(E[0], t0); v[8 * uu + 4] = csub(E[0], t0);
+                        v[8 * uu + 1] = cadd(E[1], t1); v[8 * uu + 5] = csub(E[1], t1);
+                        v[8 * uu + 2] = cadd(E[2], t2); v[8 * uu + 6] = csub(E[2], t2);
+                        v[8 * uu + 3] = cadd(E[3], t3); v[8 * uu + 7] = csub(E[3], t3);
                     } else {
                         const cx<T> u0 = mk<T>(er[0][uu], ei[0][uu]);
                         const cx<T> u1 = cmul(mk<T>(er[1][uu], ei[1][uu]), g_tw[kp]);
@@ -462,7 +539,7 @@ static int launch_mimo_ofdm_pw(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, uin
 // 0 = launched; MCLE_E_UNSUPPORTED = outside the envelope (the caller stays on its other kernels)
 int run_mimo_ofdm_pw(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, uint64_t seed, uint64_t first, uint64_t count,
                      mcle_counters* d_counters, uint32_t* d_sym, uint32_t* d_bit) {
-    if (!((cfg->fft_size == 512 || cfg->fft_size == 1024) && cfg->nt == 4 && cfg->nr == 4 && cfg->num_used == cfg->fft_size &&
+    if (!((cfg->fft_size == 512 || cfg->fft_size == 1024 || cfg->fft_size == 2048) && cfg->nt == 4 && cfg->nr == 4 && cfg->num_used == cfg->fft_size &&
           (cfg->cp_size & 1) == 0))
         return MCLE_E_UNSUPPORTED;
     if (ctx->M > 256) return MCLE_E_UNSUPPORTED;
@@ -471,6 +548,8 @@ int run_mimo_ofdm_pw(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, uint64_t seed
         if (walk_dec_kind(ctx, mp) == WDEC_GENERIC) return MCLE_E_UNSUPPORTED;     // no certificate: the planar kernel's candidate grid
     }
     const bool two = ctx->opt[MCLE_OPT_F64_THREADS] == 262 || ctx->opt[MCLE_OPT_F64_THREADS] == 264;
+    if (cfg->fft_size == 2048)       // eight wavefronts = 512 threads: one workgroup per CU (86 KiB of LDS), two wavefronts per SIMD
+        return launch_mimo_ofdm_pw<8, 2>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
     if (cfg->fft_size == 512) {
 #ifdef MCLE_EXPERIMENTS
         switch ((int)ctx->opt[MCLE_OPT_F64_VARIANT]) {

@@ -1,5 +1,5 @@
 """GPU: the full-wave and half-wave complex128 kernels of config 4's link at fft_size 256 / 512 (csrc/pipeline_mimo_fw.hip: one
-realization per wavefront; csrc/pipeline_mimo_pw.hip with NW = 2: two wavefronts per realization; channel and decode on
+realization per wavefront; csrc/pipeline_mimo_pw.hip with NW = 2 / 8: two / eight wavefronts per realization at 512 / 2048; channel and decode on
 v_mfma_f64_4x4x4; the defaults of mcle_run_mimo_ofdm at these sizes for 4 x 4, full band, even cyclic prefix, decisions by slicer or
 certificate since round 6; option f64_threads = 260 asks for them explicitly, 262 bounds the registers for two wavefronts per
 SIMD, 261 selects the planar kernel they replaced), and the same decomposition at 1024 with the decode on the matrix cores
@@ -49,15 +49,15 @@ def _oracle(kw, first, count, fft=256):
 
 
 # (fft_size, the f64_threads values that select the round-6 kernel there, the planar kernel's)
-SIZES = {256: ((0, 260, 262), 261), 512: ((0, 260, 262), 261), 1024: ((263, 264), 261)}
+SIZES = {256: ((0, 260, 262), 261), 512: ((0, 260, 262), 261), 1024: ((263, 264), 261), 2048: ((0, 260), 261)}
 
 
-@pytest.mark.parametrize("fft", [256, 512, 1024])
+@pytest.mark.parametrize("fft", [256, 512, 1024, 2048])
 @pytest.mark.parametrize("case", range(len(INSIDE) + len(OUTSIDE)))
 def test_counts_equal_the_oracle(engine, case, fft):
     kw = (INSIDE + OUTSIDE)[case]
     _set(engine, kw)
-    first, count = (1 << 36) + 1009, 21 if fft < 1024 else 6
+    first, count = (1 << 36) + 1009, 21 if fft < 1024 else (6 if fft == 1024 else 3)
     want_se, want_be, nsym, nbits = _oracle(kw, first, count, fft)
     methods = [_lib.DEMOD_MINDIST] + ([_lib.DEMOD_QAM_SLICER] if kw["mod"] == "qam" else [])
     for method in methods:
@@ -68,14 +68,14 @@ def test_counts_equal_the_oracle(engine, case, fft):
             assert res["sym_errors"] == int(want_se.sum()) and res["sym_errors_sq"] == int((want_se.astype(np.int64) ** 2).sum())
 
 
-@pytest.mark.parametrize("fft", [256, 512, 1024])
+@pytest.mark.parametrize("fft", [256, 512, 1024, 2048])
 @pytest.mark.parametrize("case", range(len(INSIDE)))
 def test_equal_to_the_planar_kernel_over_two_thousand_realizations(engine, case, fft):
     """Both are complex128 statements of the same link with differently rounded transforms: a rounding-level tie may differ once
     in ~1e7 symbols.  Same sums of squares under any split of the range (launch slices are invisible)."""
     kw = INSIDE[case]
     _set(engine, kw)
-    n = 2203 if fft < 1024 else 1100
+    n = 2203 if fft < 1024 else (1100 if fft == 1024 else 600)
     new = SIZES[fft][0][0]
     for method in [_lib.DEMOD_MINDIST] + ([_lib.DEMOD_QAM_SLICER] if kw["mod"] == "qam" else []):
         qw, se, be = _run(engine, kw, 77, n, method, new, fft)
@@ -91,7 +91,7 @@ def test_equal_to_the_planar_kernel_over_two_thousand_realizations(engine, case,
         assert np.array_equal(again[1], se) and np.array_equal(again[2], be)             # bit-identical from run to run
 
 
-@pytest.mark.parametrize("fft", [256, 512, 1024])
+@pytest.mark.parametrize("fft", [256, 512, 1024, 2048])
 def test_benchmark_link_against_the_oracle_at_depth(engine, fft):
     """Config 4's link (4 x 4 MMSE, 64-QAM, OFDM(fft, 16), 25 dB) on the round-6 kernel of the size, both demodulators and both register
     bounds: every per-realization count of 4 096 (256), 2 048 (512), 1 024 (1024) consecutive realizations -- 4.2e6 symbols each -- equal
@@ -113,7 +113,7 @@ def test_singular_channels_are_skipped_like_the_planar_kernel(engine):
     """Zero forcing at infinite SNR over many realizations: whatever the record kernel flags as skipped is skipped by both."""
     kw = dict(mod="qam", M=16, snr_db=300.0, mmse=False)
     _set(engine, kw)
-    for fft in (256, 512, 1024):
+    for fft in (256, 512, 1024, 2048):
         a = _run(engine, kw, 0, 4096, _lib.DEMOD_MINDIST, SIZES[fft][0][0], fft)[0]
         b = _run(engine, kw, 0, 4096, _lib.DEMOD_MINDIST, 261, fft)[0]
         assert a["n_skipped"] == b["n_skipped"] and a["n_realizations"] == b["n_realizations"] and a["sym_errors"] == b["sym_errors"]
