@@ -23,8 +23,9 @@
 //     compile time (slicer, QAM margin certificate, quadrant certificate; walk_f64.hpp: walk_decide), four symbols at a time.
 // A workgroup is four independent wavefronts that share the tables (constellation x 2, Box-Muller): 46 KiB of LDS -> three
 // workgroups per CU, three wavefronts per SIMD at a 168-register bound.
-// Envelope: fft_size 256, 4 x 4, full band (num_used = 256), even cyclic prefix, a constellation with a certificate or the slicer;
-// anything else stays on the planar kernel.
+// 2 x 2: TWO realizations per wavefront (lane = (realization, antenna, group)); the 4 x 4 x 4 contractions take a block-diagonal A.
+// Envelope: fft_size 256, 4 x 4 or 2 x 2, full band (num_used = 256), even cyclic prefix, a constellation with a certificate or the
+// slicer; anything else stays on the planar kernel.
 #include "mimo_planar_common.hpp"
 #include "walk_f64.hpp"
 
@@ -38,20 +39,24 @@ __host__ __device__ __forceinline__ int fw_mtime(int h, int c) { return (c & 3) 
 
 // ABL (MCLE_EXPERIMENTS builds only, option f64_variant: WRONG results by construction): 32 = no label draws / look-ups,
 // 64 = no transmit passes, 128 = no noise draws, 256 = no channel products, 512 = no receive passes, 1024 = no decode
-template <int DEC, int WPS, int ABL = 0>
+// NA = antennas per side (Nt = Nr = NA): 4 = one realization per wavefront; 2 = TWO realizations per wavefront -- lane = (realization,
+// antenna, 16-point group), the contractions on the same instruction with a block-diagonal A operand (lane (row, col) supplies
+// H[col mod 2][row mod 2] of ITS realization where row div 2 = col div 2 mod 2, and 0 elsewhere), per-lane Philox counters.
+template <int NA, int DEC, int WPS, int ABL = 0>
 __global__ __launch_bounds__(256, WPS) void k_run_mimo_ofdm_fw(MimoParams pp, ModemParams<double> mp, uint64_t seed, uint64_t first,
                                                                uint64_t count, const double2* __restrict__ g_tw,
                                                                const double2* __restrict__ g_recs, mcle_counters* counters,
                                                                uint32_t* __restrict__ sym_out, uint32_t* __restrict__ bit_out) {
     using T = double;
-    constexpr int N = 256, NT = 4, NR = 4, kRec = d64_rec<NT, NR>();
+    constexpr int N = 256, NT = NA, NR = NA, kRec = d64_rec<NT, NR>(), RZ = 4 / NA, LPR = 64 / RZ;     // realizations / lanes per realization
+    static_assert(NA == 2 || NA == 4, "geometry");
     extern __shared__ __attribute__((aligned(16))) char fw_smem[];
     T* s_R = reinterpret_cast<T*>(fw_smem);                                  // [4 wavefronts][kFwPlane]
     cx<T>* s_table = reinterpret_cast<cx<T>*>(s_R + 4 * kFwPlane);            // [tab_len] constellation
     cx<T>* s_txtab = s_table + ((mp.M + 1) & ~1);                             // [tab_len] constellation x tx scale
-    cx<T>* s_rec = s_txtab + ((mp.M + 1) & ~1);                               // [4][kRec + 1]
+    cx<T>* s_rec = s_txtab + ((mp.M + 1) & ~1);                               // [4 wavefronts][RZ][kRec + 1]
     constexpr int kBm = (kBmLdsDoubles + 1) & ~1;
-    double* s_bm = reinterpret_cast<double*>(s_rec + 4 * (kRec + 1));         // [kBm] Box-Muller tables
+    double* s_bm = reinterpret_cast<double*>(s_rec + 4 * RZ * (kRec + 1));    // [kBm] Box-Muller tables
     unsigned char* s_lab = reinterpret_cast<unsigned char*>(s_bm + kBm);     // [4][kFwLabBytes] (16-byte aligned: everything before is)
     __shared__ WgTotals totals[4];
 
@@ -75,25 +80,40 @@ __global__ __launch_bounds__(256, WPS) void k_run_mimo_ofdm_fw(MimoParams pp, Mo
     T* s_mine = s_R + w * kFwPlane;
     uint2* s_words = reinterpret_cast<uint2*>(s_mine);                      // [16 registers][64 lanes] word pairs (8 KiB of the plane)
     unsigned char* lab_mine = s_lab + w * kFwLabBytes;
-    cx<T>* rec_mine = s_rec + w * (kRec + 1);
-    const uint64_t stride = (uint64_t)gridDim.x * 4;
+    cx<T>* rec_mine = s_rec + w * RZ * (kRec + 1);
+    const uint64_t stride = (uint64_t)gridDim.x * 4 * RZ;
+    const int rz = lane / LPR, lr = lane - rz * LPR;                        // this lane's realization of the wavefront's RZ, lane within it
     cx<T> rec_next = mk<T>(0, 0);
     {
-        const uint64_t r0 = (uint64_t)blockIdx.x * 4 + w;
-        if (lane < kRec && r0 < count) rec_next = g_recs[r0 * kRec + lane];
+        const uint64_t b0 = ((uint64_t)blockIdx.x * 4 + w) * RZ;
+        const uint64_t r0 = b0 + rz < count ? b0 + rz : b0;
+        if (lr < kRec && r0 < count) rec_next = g_recs[r0 * kRec + lr];
     }
-    for (uint64_t rl = (uint64_t)blockIdx.x * 4 + w; rl < count; rl += stride) {
+    for (uint64_t rl0 = ((uint64_t)blockIdx.x * 4 + w) * RZ; rl0 < count; rl0 += stride) {
+        // (NA = 2: past the end the wavefront's second half repeats the first half's realization -- finite values in the block-diagonal
+        //  contractions' zero blocks -- and is not accounted)
+        const uint64_t rl = rl0 + (uint64_t)rz < count ? rl0 + (uint64_t)rz : rl0;
         const Rng rng(seed, first + rl);
         walk_wave_order();                                                   // (the previous realization's reads of the record are done)
-        if (lane < kRec) {
-            rec_mine[lane] = rec_next;
-            if (rl + stride < count) rec_next = g_recs[(rl + stride) * kRec + lane];
+        if (lr < kRec) {
+            rec_mine[rz * (kRec + 1) + lr] = rec_next;
+            const uint64_t nb = rl0 + stride, nx = nb + rz < count ? nb + rz : nb;
+            if (nx < count) rec_next = g_recs[nx * kRec + lr];
         }
         walk_wave_order();
         const int ln0 = opaque(lane);
-        const cx<T> hA = rec_mine[(ln0 & 3) * NT + (ln0 >> 4)];               // H[h mod 4][a]: the channel contraction's A operand
-        const cx<T> gA = rec_mine[NT * NR + (ln0 & 3) * NR + (ln0 >> 4)];     // G[h mod 4][r]: the decode's
-        const bool skipped = rec_mine[2 * NT * NR].x != 0.0;
+        // A operands of the two contractions: lane (row, col) supplies M[col mod 4][row]; with two realizations per wavefront the
+        // 4 x 4 matrix is block diagonal (row = (realization, antenna), col mod 4 = (realization', antenna'))
+        cx<T> hA, gA;
+        {
+            const int col = ln0 & 3, rowi = ln0 >> 4;
+            const int rzc = col / NA, rr = col % NA, rzr = rowi / NA, aa = rowi % NA;
+            const cx<T>* rc = rec_mine + rzr * (kRec + 1);
+            hA = rc[rr * NT + aa];                                           // H[rr][aa]
+            gA = rc[NT * NR + rr * NR + aa];                                 // G[rr][aa]
+            if (NA < 4 && rzc != rzr) hA = gA = mk<T>(0, 0);
+        }
+        const bool skipped = rec_mine[rz * (kRec + 1) + 2 * NT * NR].x != 0.0;
         unsigned se = 0, be = 0;
         for (int os = 0; os < pp.n_ofdm_sym; ++os) {
             // ---- labels: DATA block `lane` of the symbol = subcarriers d = 4 lane .. 4 lane + 3, four antennas each (full band:
@@ -103,15 +123,18 @@ __global__ __launch_bounds__(256, WPS) void k_run_mimo_ofdm_fw(MimoParams pp, Mo
                 const int t = opaque(lane);
                 Words4 dw;
                 if constexpr (ABL & 32) dw.w[0] = dw.w[1] = dw.w[2] = dw.w[3] = (uint32_t)t * 0x01010101u;
-                else dw = rng.block(STREAM_DATA, (uint32_t)(((uint64_t)os * per_sym) >> 4) + (uint32_t)t);
-                const int u = (t >> 2) ^ 8;
+                else dw = rng.block(STREAM_DATA, (uint32_t)(((uint64_t)os * per_sym) >> 4) + (uint32_t)(t % LPR));
+                // label 4 s + b of block tb sits at stream position p = 16 tb + 4 s + b = d NT + a
+                const int tb = t % LPR;
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
                     const uint32_t wd = dw.w[s] & (mask * 0x01010101u);
-                    const int g = 4 * (t & 3) + s;
-                    unsigned char* dst = lab_mine + g * 16 + u;
 #pragma unroll
-                    for (int a = 0; a < 4; ++a) dst[a * 256] = (unsigned char)(wd >> (8 * a));
+                    for (int b = 0; b < 4; ++b) {
+                        const int p = 16 * tb + 4 * s + b, d = p / NT, a = p % NT;       // (a, and d mod (4 / NT), are compile-time)
+                        const int k = d ^ 128;
+                        lab_mine[((rz * NT + a) * 16 + (k & 15)) * 16 + (k >> 4)] = (unsigned char)(wd >> (8 * b));
+                    }
                 }
                 walk_wave_order();
                 L = *reinterpret_cast<const uint4*>(lab_mine + t * 16);
@@ -164,7 +187,7 @@ __global__ __launch_bounds__(256, WPS) void k_run_mimo_ofdm_fw(MimoParams pp, Mo
             //      8 par .. 8 par + 7 (par = the parity of its sample times), keeps its half, hands over the other ----
             {
                 const int ln = opaque(lane);
-                const int r = ln >> 4, h = ln & 15, par = (h >> 2) & 1;
+                const int r = (ln >> 4) % NR, h = ln & 15, par = (h >> 2) & 1;
                 const uint64_t i0 = (uint64_t)r * row + (uint64_t)os * (N + cp) + cp + (uint64_t)(4 * (h & 3) + ((h >> 2) & 2));   // even
                 uint2* wm = s_words + (8 * par) * 64 + ln;
                 uint2* wp = s_words + (8 * par) * 64 + (ln ^ 4);
@@ -269,19 +292,29 @@ __global__ __launch_bounds__(256, WPS) void k_run_mimo_ofdm_fw(MimoParams pp, Mo
                 se += (unsigned)(v[0].x + v[15].y == 0.5);
             }
         }
-        se = wave_sum_u32(se);
-        be = wave_sum_u32(be);
-        if (lane == 0) wg_account(totals[w], se, be, skipped, rl, sym_out, bit_out);
+        if constexpr (RZ == 1) {
+            se = wave_sum_u32(se);
+            be = wave_sum_u32(be);
+            if (lane == 0) wg_account(totals[w], se, be, skipped, rl0, sym_out, bit_out);
+        } else {                                       // two realizations: the halves' sums land in lanes 0 and 32
+            const unsigned s0 = wave_sum_u32(rz ? 0u : se), b0 = wave_sum_u32(rz ? 0u : be);
+            const unsigned s1 = wave_sum_u32(rz ? se : 0u), b1 = wave_sum_u32(rz ? be : 0u);
+            const bool sk1 = __builtin_amdgcn_readlane((int)skipped, 32) != 0, sk0 = __builtin_amdgcn_readfirstlane((int)skipped) != 0;
+            if (lane == 0) {
+                wg_account(totals[w], s0, b0, sk0, rl0, sym_out, bit_out);
+                if (rl0 + 1 < count) wg_account(totals[w], s1, b1, sk1, rl0 + 1, sym_out, bit_out);
+            }
+        }
     }
     if (lane == 0)
         wg_flush(totals[w], counters, (unsigned long long)per_sym * pp.n_ofdm_sym, (unsigned long long)per_sym * pp.n_ofdm_sym * mp.bits);
 }
 
-template <int WPS, int ABL = 0>
+template <int NA, int WPS, int ABL = 0>
 static int launch_mimo_ofdm_fw(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, uint64_t seed, uint64_t first, uint64_t count,
                                mcle_counters* d_counters, uint32_t* d_sym, uint32_t* d_bit) {
     using T = double;
-    constexpr int N = 256, NT = 4, NR = 4, kRec = d64_rec<NT, NR>();
+    constexpr int N = 256, NT = NA, NR = NA, kRec = d64_rec<NT, NR>(), RZ = 4 / NA;
     int rc;
     void* tw = nullptr;
     if ((rc = ctx->get_twiddles(N, MCLE_F64, &tw))) return rc;
@@ -290,14 +323,14 @@ static int launch_mimo_ofdm_fw(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, uin
     const int dec = walk_dec_kind(ctx, mp);
     mp.grid.G = 0;
     const size_t tab_len = ((size_t)mp.M + 1) & ~(size_t)1;
-    const size_t lds = (size_t)4 * kFwPlane * sizeof(T) + (2 * tab_len + 4 * (kRec + 1)) * sizeof(cx<T>) +
+    const size_t lds = (size_t)4 * kFwPlane * sizeof(T) + (2 * tab_len + 4 * RZ * (kRec + 1)) * sizeof(cx<T>) +
                        (size_t)((kBmLdsDoubles + 1) & ~1) * sizeof(double) + 4 * kFwLabBytes;
     MCLE_REQUIRE(lds + 512 <= (size_t)160 * 1024, "full-wave MIMO-OFDM kernel: %zu B of LDS do not fit", lds);
-    auto kern = k_run_mimo_ofdm_fw<WDEC_SLICER, WPS, ABL>;
+    auto kern = k_run_mimo_ofdm_fw<NA, WDEC_SLICER, WPS, ABL>;
     switch (dec) {
-        case WDEC_QAM_CERT: kern = k_run_mimo_ofdm_fw<WDEC_QAM_CERT, WPS, ABL>; break;
-        case WDEC_QUAD_CERT: kern = k_run_mimo_ofdm_fw<WDEC_QUAD_CERT, WPS, ABL>; break;
-        case WDEC_AXIS4_CERT: kern = k_run_mimo_ofdm_fw<WDEC_AXIS4_CERT, WPS, ABL>; break;
+        case WDEC_QAM_CERT: kern = k_run_mimo_ofdm_fw<NA, WDEC_QAM_CERT, WPS, ABL>; break;
+        case WDEC_QUAD_CERT: kern = k_run_mimo_ofdm_fw<NA, WDEC_QUAD_CERT, WPS, ABL>; break;
+        case WDEC_AXIS4_CERT: kern = k_run_mimo_ofdm_fw<NA, WDEC_AXIS4_CERT, WPS, ABL>; break;
         default: break;
     }
     MCLE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -314,7 +347,7 @@ static int launch_mimo_ofdm_fw(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, uin
         hipLaunchKernelGGL((k_mimo_filters_planar<T, N, NT, NR>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, pp, seed,
                            first + off, n, (cx<T>*)recs);
         MCLE_LAUNCH_CHECK();
-        const unsigned grid = (unsigned)oversubscribed_grid(ctx, resident, (n + 3) / 4, 8, 16);
+        const unsigned grid = (unsigned)oversubscribed_grid(ctx, resident, (n + 4 * RZ - 1) / (4 * RZ), 8, 16);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, ctx->stream, pp, mp, seed, first + off, n, (const cx<T>*)tw,
                            (const cx<T>*)recs, d_counters, d_sym ? d_sym + off : nullptr, d_bit ? d_bit + off : nullptr);
         MCLE_LAUNCH_CHECK();
@@ -325,7 +358,7 @@ static int launch_mimo_ofdm_fw(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, uin
 // 0 = launched; MCLE_E_UNSUPPORTED = outside the envelope (the caller stays on the planar kernel)
 int run_mimo_ofdm_fw(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, uint64_t seed, uint64_t first, uint64_t count,
                      mcle_counters* d_counters, uint32_t* d_sym, uint32_t* d_bit) {
-    if (!(cfg->fft_size == 256 && cfg->nt == 4 && cfg->nr == 4 && cfg->num_used == 256 && (cfg->cp_size & 1) == 0))
+    if (!(cfg->fft_size == 256 && cfg->nt == cfg->nr && (cfg->nt == 4 || cfg->nt == 2) && cfg->num_used == 256 && (cfg->cp_size & 1) == 0))
         return MCLE_E_UNSUPPORTED;
     if (ctx->M > 256) return MCLE_E_UNSUPPORTED;
     {
@@ -334,14 +367,18 @@ int run_mimo_ofdm_fw(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, uint64_t seed
     }
 #ifdef MCLE_EXPERIMENTS
     switch ((int)ctx->opt[MCLE_OPT_F64_VARIANT]) {
-#define MCLE_FW_ABL(V_) case V_: return launch_mimo_ofdm_fw<3, V_>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
+#define MCLE_FW_ABL(V_) case V_: if (cfg->nt == 4) return launch_mimo_ofdm_fw<4, 3, V_>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit); break;
         MCLE_FW_ABL(32) MCLE_FW_ABL(64) MCLE_FW_ABL(128) MCLE_FW_ABL(256) MCLE_FW_ABL(512) MCLE_FW_ABL(1024) MCLE_FW_ABL(2016)
 #undef MCLE_FW_ABL
         default: break;
     }
 #endif
-    if (ctx->opt[MCLE_OPT_F64_THREADS] == 262) return launch_mimo_ofdm_fw<2>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
-    return launch_mimo_ofdm_fw<3>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
+    const bool two = ctx->opt[MCLE_OPT_F64_THREADS] == 262;
+    if (cfg->nt == 2)
+        return two ? launch_mimo_ofdm_fw<2, 2>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit)
+                   : launch_mimo_ofdm_fw<2, 3>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
+    return two ? launch_mimo_ofdm_fw<4, 2>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit)
+               : launch_mimo_ofdm_fw<4, 3>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
 }
 
 }  // namespace mcle

@@ -546,7 +546,7 @@ static int run_mimo_ofdm_planar_t(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, 
     // 10.66 ms per 262 144 realizations against 11.65 for the 512-thread radix-4 form and 12.15 for the 256-thread one,
     // profiles/r04/c4_f64_r16_ab.log).  MCLE_OPT_F64_THREADS: 512 = radix-4, two antennas per thread; 256 = radix-4, four
     // antennas per thread, twiddles in registers.  MCLE_OPT_F64_VARIANT 1 .. 3: timing bounds on the 512-thread form.
-    if (n == 256 && nt == 4 && nr == 4) {
+    if (n == 256 && nt == nr && (nt == 4 || nt == 2)) {
         if constexpr (F64) {
             // round 6: the FULL-WAVE kernel (pipeline_mimo_fw.hip: a realization is one wavefront -- the quarter-wave kernel's register
             // passes without its radix-4 exchange stage, channel AND decode on v_mfma_f64_4x4x4, no workgroup barrier).

@@ -120,3 +120,54 @@ def test_singular_channels_are_skipped_like_the_planar_kernel(engine):
     a = _run(engine, kw, 0, 64, _lib.DEMOD_MINDIST, 260)[0]
     b = _run(engine, kw, 0, 64, _lib.DEMOD_MINDIST, 261)[0]
     assert a["n_skipped"] == b["n_skipped"] and a["n_realizations"] == b["n_realizations"] and a["sym_errors"] == b["sym_errors"]
+
+
+# ---- 2 x 2 at fft_size 256: two realizations per wavefront (pipeline_mimo_fw.hip, NA = 2) ----
+def _run22(engine, kw, first, count, method, threads):
+    nv = 1.0 / omodem.dB2Linear(kw["snr_db"])
+    with engine.options(f64_threads=threads):
+        return engine.run_mimo_ofdm(2, 2, 256, kw.get("cp_size", 16), kw.get("num_used") or 256, kw.get("n_ofdm_sym", 1), nv, SEED,
+                                    first, count, mmse=kw.get("mmse", True), method=method, dtype="f64", per_realization=True)
+
+
+@pytest.mark.parametrize("case", range(len(INSIDE) + len(OUTSIDE)))
+def test_two_by_two_counts_equal_the_oracle(engine, case):
+    """Odd and even counts (an odd count leaves the last wavefront's second half without a realization), every corner of the envelope
+    and requests outside it, all four kernel selections."""
+    kw = (INSIDE + OUTSIDE)[case]
+    _set(engine, kw)
+    for first, count in (((1 << 36) + 77, 23), (5, 1), (900, 8)):
+        okw = dict(mod=kw["mod"], M=kw["M"], nt=2, nr=2, fft_size=256, cp_size=kw.get("cp_size", 16), num_used=kw.get("num_used"),
+                   n_ofdm_sym=kw.get("n_ofdm_sym", 1), snr_db=kw["snr_db"], mmse=kw.get("mmse", True))
+        want = [chains.chain_mimo_ofdm(chains.PhiloxRng(SEED, r), **okw) for r in range(first, first + count)]
+        want_se, want_be = np.array([w["symbol_errors"] for w in want]), np.array([w["bit_errors"] for w in want])
+        for method in [_lib.DEMOD_MINDIST] + ([_lib.DEMOD_QAM_SLICER] if kw["mod"] == "qam" else []):
+            for threads in (0, 260, 262, 261):
+                res, se, be = _run22(engine, kw, first, count, method, threads)
+                assert np.array_equal(se, want_se) and np.array_equal(be, want_be), (case, method, threads, se, want_se)
+                assert res["n_realizations"] == count and res["n_skipped"] == 0 and res["n_symbols"] == want[0]["num_symbols"]
+                assert res["sym_errors"] == int(want_se.sum()) and res["sym_errors_sq"] == int((want_se.astype(np.int64) ** 2).sum())
+
+
+def test_two_by_two_against_the_oracle_and_the_planar_kernel_at_depth(engine):
+    """(256, 2 x 2), 64-QAM, 22 dB: 4 097 realizations (an odd count) against the oracle, both demodulators and register bounds; the
+    planar kernel on the same range; zero forcing at infinite SNR skips what the planar kernel skips."""
+    kw = dict(mod="qam", M=64, snr_db=22.0)
+    _set(engine, kw)
+    first, count = 424242, 4097
+    okw = dict(mod="qam", M=64, nt=2, nr=2, fft_size=256, cp_size=16, num_used=None, n_ofdm_sym=1, snr_db=22.0, mmse=True)
+    want = [chains.chain_mimo_ofdm(chains.PhiloxRng(SEED, r), **okw) for r in range(first, first + count)]
+    want_se, want_be = np.array([w["symbol_errors"] for w in want]), np.array([w["bit_errors"] for w in want])
+    assert want_se.sum() > 1e4
+    for threads in (0, 262):
+        for method in (_lib.DEMOD_MINDIST, _lib.DEMOD_QAM_SLICER):
+            res, se, be = _run22(engine, kw, first, count, method, threads)
+            assert np.array_equal(se, want_se), (threads, method, np.flatnonzero(se != want_se)[:5])
+            assert np.array_equal(be, want_be)
+    pl = _run22(engine, kw, first, count, _lib.DEMOD_MINDIST, 261)
+    assert np.count_nonzero(pl[1] != want_se) <= 1
+    zf = dict(mod="qam", M=16, snr_db=300.0, mmse=False)
+    _set(engine, zf)
+    a = _run22(engine, zf, 0, 4097, _lib.DEMOD_MINDIST, 0)[0]
+    b = _run22(engine, zf, 0, 4097, _lib.DEMOD_MINDIST, 261)[0]
+    assert a["n_skipped"] == b["n_skipped"] and a["n_realizations"] == b["n_realizations"] and a["sym_errors"] == b["sym_errors"]
