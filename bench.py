@@ -642,7 +642,7 @@ def roofline_block(args, dtype, batch, per_launch_s, rate_kernel, d, pmc_source)
                      "B_alg / %s of the staged model and the kernel is bound by the SIMDs' %s datapath%s; "
                      "frac = algorithmic flops (RNG excluded) / peak"
                      % (("%.0f" % (balg / measured)) if measured else "?", "FP64" if dtype == "f64" else "FP32",
-                        " (VALU, plus v_mfma_f64_4x4x4 for the H x contraction of the quarter-wave kernel -- mfma_busy_chip; the "
+                        " (VALU, plus v_mfma_f64_4x4x4 for the H x and G y contractions of the part-wave kernel -- mfma_busy_chip; the "
                         "f64 MFMA forms are no denser than v_fma_f64 and do not overlap with it, DESIGN.md sections 5.5 / 5.10)"
                         if dtype == "f64" else
                         " (VALU; the matrix-core form of this configuration, option f32_mfma, shares that datapath: f32 MFMA and "

@@ -863,18 +863,18 @@ static int launch_run_bd(mcle_ctx* ctx, const mcle_bd_cfg* cfg, const BdParams& 
                            d_sym_err ? d_sym_err + off : nullptr, d_bit_err ? d_bit_err + off : nullptr);                 \
         walked = true;                                                                                                    \
     }
-        if constexpr (sizeof(T) == 8 && R <= 2) {
-            // complex128, two or three users, an even number of columns >= 128: the packed walk of walk_f64.hpp (round 6)
+        if constexpr (R <= 2) {
+            // two or three users, an even number of columns >= 128: the packed walk of walk_f64.hpp (round 6; complex64 since its last day)
             if (kc && link_walk_f64_fits(cfg->n_symbols) && !ctx->opt[MCLE_OPT_WALK_LEGACY]) {
 #define MCLE_BD_PACKED(KC_, ABL_)                                                                                             \
     if (!walked && cfg->K == KC_) {                                                                                           \
-        launch_link_walk_f64<BdWalk<KC_, R>, ABL_>(ctx, mp, cfg->n_symbols, pp.noise_var, seed, first + off, m, (const double2*)recs, \
+        launch_link_walk<T, BdWalk<KC_, R>, ABL_>(ctx, mp, cfg->n_symbols, pp.noise_var, seed, first + off, m, (const cx<T>*)recs, \
                                                    d_counters, d_sym_err ? d_sym_err + off : nullptr,                        \
                                                    d_bit_err ? d_bit_err + off : nullptr);                                   \
         walked = true;                                                                                                        \
     }
 #ifdef MCLE_EXPERIMENTS
-                if constexpr (R == 2) {
+                if constexpr (R == 2 && sizeof(T) == 8) {
                     switch ((int)ctx->opt[MCLE_OPT_F64_VARIANT]) {
                         case 1: MCLE_BD_PACKED(3, 1) break;
                         case 2: MCLE_BD_PACKED(3, 2) break;

@@ -727,17 +727,19 @@ int run_ia_impl(mcle_ctx* ctx, const mcle_ia_cfg* cfg, uint64_t seed, uint64_t f
         const uint64_t cap = (uint64_t)ctx->n_cu * 4 * (sizeof(T) == 4 ? 4 : 3);
         const unsigned grid = (unsigned)oversubscribed_grid(ctx, cap, chunks, 2);     // a chunk is 8-16 realizations; one chunk per workgroup measured 1.5 x slower
         bool walked = false;
-        if constexpr (sizeof(T) == 8) {
-            // complex128, an even number of columns >= 128: the packed walk of walk_f64.hpp (round 6)
+        {
+            // an even number of columns >= 128: the packed walk of walk_f64.hpp (round 6; complex64 since its last day)
             if (link_walk_f64_fits(cfg->n_symbols) && !ctx->opt[MCLE_OPT_WALK_LEGACY]) {
 #ifdef MCLE_EXPERIMENTS
+              if constexpr (sizeof(T) == 8) {
 #define MCLE_IA_ABL(V_) case V_: launch_link_walk_f64<IaWalk, V_>(ctx, mp, cfg->n_symbols, cfg->noise_var, seed, first + off, n, (const double2*)recs, d_counters, d_sym ? d_sym + off : nullptr, d_bit ? d_bit + off : nullptr); walked = true; break;
                 switch ((int)ctx->opt[MCLE_OPT_F64_VARIANT]) { MCLE_IA_ABL(1) MCLE_IA_ABL(2) MCLE_IA_ABL(4) MCLE_IA_ABL(6) MCLE_IA_ABL(8) MCLE_IA_ABL(16) MCLE_IA_ABL(31) default: break; }
 #undef MCLE_IA_ABL
+              }
 #endif
                 if (!walked)
-                    launch_link_walk_f64<IaWalk>(ctx, mp, cfg->n_symbols, cfg->noise_var, seed, first + off, n, (const double2*)recs,
-                                                 d_counters, d_sym ? d_sym + off : nullptr, d_bit ? d_bit + off : nullptr);
+                    launch_link_walk<T, IaWalk>(ctx, mp, cfg->n_symbols, cfg->noise_var, seed, first + off, n, (const cx<T>*)recs,
+                                                d_counters, d_sym ? d_sym + off : nullptr, d_bit ? d_bit + off : nullptr);
                 walked = true;
             }
         }

@@ -33,6 +33,7 @@
 #include "philox.hpp"
 #include "totals.hpp"
 #include "pipe_common.hpp"
+#include "qam_pack.hpp"
 #include "wave_draws.hpp"
 
 namespace mcle {
@@ -41,14 +42,15 @@ enum : int { WDEC_GENERIC = 0, WDEC_SLICER = 1, WDEC_QAM_CERT = 2, WDEC_QUAD_CER
 
 // host: the decision form a launch with these modem parameters compiles to (and, for the on-axis four-point form -- the
 // reference's PSK(4), which has no entry in ModemParams::cert -- its constants in the quadrant certificate's fields)
-inline int walk_dec_kind(const mcle_ctx* ctx, ModemParams<double>& mp) {
+template <typename T> inline int walk_dec_kind(const mcle_ctx* ctx, ModemParams<T>& mp) {
     if (mp.method == MCLE_DEMOD_QAM_SLICER) return WDEC_SLICER;
     if (mp.cert == 1) return WDEC_QAM_CERT;
     if (mp.cert == 2) return WDEC_QUAD_CERT;
     if (mp.method == MCLE_DEMOD_MINDIST && ctx->axis_ok && !ctx->opt[MCLE_OPT_DEMOD_NOCERT]) {
+        // complex64: margin 2 a lo = 2^-14 a^2 against a rounding of <= (9 a)^2 2^-23 = 2^-16.7 a^2 of either metric inside |re|, |im| <= 8 a
         mp.quad_lut = ctx->axis_lut;
-        mp.quad_lo = ctx->axis_a * 0x1p-30;
-        mp.quad_hi = ctx->axis_a * 0x1p+8;
+        mp.quad_lo = (T)(ctx->axis_a * (sizeof(T) == 8 ? 0x1p-30 : 0x1p-15));
+        mp.quad_hi = (T)(ctx->axis_a * (sizeof(T) == 8 ? 0x1p+8 : 8.0));
         return WDEC_AXIS4_CERT;
     }
     return WDEC_GENERIC;
@@ -63,14 +65,14 @@ __device__ __forceinline__ void walk_wave_order() {
 }
 
 // the literal sweep (strict '<': numpy.argmin's first minimum, fundamental.py:241-246), rolled: it runs once in ~1e8 symbols
-__device__ __forceinline__ int walk_sweep(const double2* __restrict__ s_table, int M, double2 r) {
-    double best = (r.x - s_table[0].x) * (r.x - s_table[0].x) + (r.y - s_table[0].y) * (r.y - s_table[0].y);
+template <typename T> __device__ __forceinline__ int walk_sweep(const cx<T>* __restrict__ s_table, int M, cx<T> r) {
+    T best = (r.x - s_table[0].x) * (r.x - s_table[0].x) + (r.y - s_table[0].y) * (r.y - s_table[0].y);
     int idx = 0;
 #pragma unroll 1
     for (int m = 1; m < M; ++m) {
-        const double2 c = s_table[m];
-        const double dx = r.x - c.x, dy = r.y - c.y;
-        const double d = dx * dx + dy * dy;
+        const cx<T> c = s_table[m];
+        const T dx = r.x - c.x, dy = r.y - c.y;
+        const T d = dx * dx + dy * dy;
         if (d < best) {
             best = d;
             idx = m;
@@ -83,6 +85,9 @@ __device__ __forceinline__ int walk_sweep(const double2* __restrict__ s_table, i
 // commute; NaN -> 0 as before) instead of two compares and four selects per axis after it, and both Gray decodes in one register
 // (a byte each, as demod_qam_cert does): ~24 instead of ~36 instructions per decision (profiles/r06/c5_section_table.md).  Same
 // level arithmetic, same labels.
+__device__ __forceinline__ int walk_qam_slicer(float2 r, float scale, int L, int half_bits) {     // (never reached: complex64 packs)
+    return demod_qam_slicer<float>(r, scale, L, half_bits);
+}
 __device__ __forceinline__ int walk_qam_slicer(double2 r, double scale, int L, int half_bits) {
     const double lm1 = (double)(L - 1);
     const double tj = (r.x * scale + lm1) * 0.5 + 0.5, ti = (lm1 - r.y * scale) * 0.5 + 0.5;
@@ -94,11 +99,30 @@ __device__ __forceinline__ int walk_qam_slicer(double2 r, double scale, int L, i
     return (int)(((v >> 8) << half_bits) | (v & 0xFFu));
 }
 
-// N decisions and their error counts.  DEC fixes the form at compile time; the certificates are those of modem.hpp.
-template <int DEC, int N>
-__device__ __forceinline__ void walk_decide(const ModemParams<double>& mp, const double2* __restrict__ s_table,
-                                            const unsigned long long* __restrict__ s_grid, const double2 (&e)[N],
+// N decisions and their error counts.  DEC fixes the form at compile time; the certificates are those of modem.hpp.  complex64:
+// the slicer is the packed level-domain form of the complex64 pipelines (qam_pack.hpp: four decisions per v_cvt_pk_u8_f32 word).
+template <typename T, int DEC, int N>
+__device__ __forceinline__ void walk_decide(const ModemParams<T>& mp, const cx<T>* __restrict__ s_table,
+                                            const unsigned long long* __restrict__ s_grid, const cx<T> (&e)[N],
                                             const int (&tx)[N], unsigned& se, unsigned& be) {
+    if constexpr (DEC == WDEC_SLICER && sizeof(T) == 4) {
+        const QamPack qp = qam_pack(mp);
+#pragma unroll
+        for (int g0 = 0; g0 < N; g0 += 4) {
+            f4q er = {0.f, 0.f, 0.f, 0.f}, ei = {0.f, 0.f, 0.f, 0.f};
+            uint32_t sent = 0u;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (g0 + i < N) {
+                    er[i] = e[g0 + i].x;
+                    ei[i] = e[g0 + i].y;
+                    sent |= (uint32_t)tx[g0 + i] << (8 * i);
+                }
+            const uint32_t live = N - g0 >= 4 ? 0xFFFFFFFFu : ((1u << (8 * ((N - g0) & 3))) - 1u);     // (folds: the loop is unrolled)
+            qam_count4((qam_levels4(er, ei, qp) ^ labels_to_levels(sent, qp)) & live, qp, se, be);
+        }
+        return;
+    }
     int dec[N];
     if constexpr (DEC == WDEC_SLICER) {
 #pragma unroll
@@ -107,15 +131,15 @@ __device__ __forceinline__ void walk_decide(const ModemParams<double>& mp, const
         bool sure[N], all = true;
 #pragma unroll
         for (int j = 0; j < N; ++j) {
-            if constexpr (DEC == WDEC_QAM_CERT) dec[j] = demod_qam_cert<double>(e[j], mp.qam_scale, mp.qam_L, mp.half_bits, sure[j]);
-            else if constexpr (DEC == WDEC_QUAD_CERT) dec[j] = demod_quad_cert<double>(e[j], mp.quad_lut, mp.quad_lo, mp.quad_hi, sure[j]);
-            else dec[j] = demod_axis4_cert<double>(e[j], mp.quad_lut, mp.quad_lo, mp.quad_hi, sure[j]);
+            if constexpr (DEC == WDEC_QAM_CERT) dec[j] = demod_qam_cert<T>(e[j], mp.qam_scale, mp.qam_L, mp.half_bits, sure[j]);
+            else if constexpr (DEC == WDEC_QUAD_CERT) dec[j] = demod_quad_cert<T>(e[j], mp.quad_lut, mp.quad_lo, mp.quad_hi, sure[j]);
+            else dec[j] = demod_axis4_cert<T>(e[j], mp.quad_lut, mp.quad_lo, mp.quad_hi, sure[j]);
             all = all && sure[j];
         }
         if (!all) {
 #pragma unroll
             for (int j = 0; j < N; ++j)
-                if (!sure[j]) dec[j] = walk_sweep(s_table, mp.M, e[j]);
+                if (!sure[j]) dec[j] = walk_sweep<T>(s_table, mp.M, e[j]);
         }
     } else {
 #pragma unroll
@@ -127,6 +151,13 @@ __device__ __forceinline__ void walk_decide(const ModemParams<double>& mp, const
         se += (x != 0u);
         be += __popc(x);
     }
+}
+// (the complex128 kernels of config 4's family call the complex128 form without naming the arithmetic)
+template <int DEC, int N>
+__device__ __forceinline__ void walk_decide(const ModemParams<double>& mp, const double2* __restrict__ s_table,
+                                            const unsigned long long* __restrict__ s_grid, const double2 (&e)[N],
+                                            const int (&tx)[N], unsigned& se, unsigned& be) {
+    walk_decide<double, DEC, N>(mp, s_table, s_grid, e, tx, se, be);
 }
 
 // ---- the two link shapes ------------------------------------------------------------------------------------------------------
@@ -153,21 +184,24 @@ constexpr int kWalkRunBytes = kBlocksPerRun * 16;       // 144: the DATA blocks 
 #ifndef MCLE_WALK_F64_WAVES
 #define MCLE_WALK_F64_WAVES 3       // wavefronts per SIMD the registers are bounded for (A/B: profiles/r06/walk_f64_ab.log)
 #endif
-template <typename P, int DEC, int ABL = 0>
-__global__ __launch_bounds__(64, MCLE_WALK_F64_WAVES) void k_link_walk_f64(ModemParams<double> mp, int n_symbols, double sigma, uint64_t seed,
-                                                        uint64_t first, uint64_t count, const double2* __restrict__ recs,
+// T = double: the kernel described above (name kept in the profiles: k_link_walk<double, ...>).  T = float (round 6, late): the same
+// packing, LDS records and label exchange for the complex64 walks; the decisions of a pass are taken together AFTER its estimates
+// (twelve more registers are cheap in float) -- the slicer four at a time in the packed level domain, the certificates straight-line.
+template <typename T, typename P, int DEC, int ABL = 0>
+__global__ __launch_bounds__(64, sizeof(T) == 4 ? MCLE_F32_WALK_WAVES : MCLE_WALK_F64_WAVES) void k_link_walk(ModemParams<T> mp, int n_symbols, T sigma, uint64_t seed,
+                                                        uint64_t first, uint64_t count, const cx<T>* __restrict__ recs,
                                                         mcle_counters* counters, uint32_t* __restrict__ sym_out,
                                                         uint32_t* __restrict__ bit_out) {
     constexpr int S = P::S, R = P::R, J = P::J, K = P::K, PW = P::PER_WAVE, RUNS = 2 * S;
     extern __shared__ __attribute__((aligned(16))) unsigned char walk_smem[];    // [M] constellation, then the candidate grid (generic form)
-    double2* s_table = reinterpret_cast<double2*>(walk_smem);
-    unsigned long long* s_grid = reinterpret_cast<unsigned long long*>(walk_smem + (size_t)mp.M * sizeof(double2));
-    __shared__ double s_bm[kBmLdsDoubles];                 // Box-Muller tables (bm_f64.hpp)
-    __shared__ double2 s_rec[PW * P::STRIDE];              // the chunk's records
+    cx<T>* s_table = reinterpret_cast<cx<T>*>(walk_smem);
+    unsigned long long* s_grid = reinterpret_cast<unsigned long long*>(walk_smem + (((size_t)mp.M * sizeof(cx<T>) + 15) & ~(size_t)15));
+    __shared__ double s_bm[sizeof(T) == 8 ? kBmLdsDoubles : 1];   // complex128: Box-Muller tables (bm_f64.hpp)
+    __shared__ cx<T> s_rec[PW * P::STRIDE];                // the chunk's records
     __shared__ uint4 s_sym[RUNS * kBlocksPerRun];          // the pass's DATA blocks, run by run
     __shared__ unsigned s_se[PW], s_be[PW];                // error counts of the chunk's realizations
     __shared__ WgTotals totals;
-    bm_tables_to_lds(s_bm, (int)threadIdx.x, (int)blockDim.x);
+    if constexpr (sizeof(T) == 8) bm_tables_to_lds(s_bm, (int)threadIdx.x, (int)blockDim.x);
     load_table(mp, s_table);
     if constexpr (DEC == WDEC_GENERIC) load_grid(mp, s_grid);
     const int lane = threadIdx.x;
@@ -182,7 +216,7 @@ __global__ __launch_bounds__(64, MCLE_WALK_F64_WAVES) void k_link_walk_f64(Modem
         const int nr = (int)(count - rb < (uint64_t)PW ? count - rb : (uint64_t)PW);
         const uint32_t n_pairs = (uint32_t)nr * NP;
         {
-            const double2* src = recs + rb * P::STRIDE;
+            const cx<T>* src = recs + rb * P::STRIDE;
             for (int i = lane; i < nr * P::STRIDE; i += 64) s_rec[i] = src[i];
             if (lane < PW) {
                 s_se[lane] = 0u;
@@ -233,8 +267,10 @@ __global__ __launch_bounds__(64, MCLE_WALK_F64_WAVES) void k_link_walk_f64(Modem
             unsigned se = 0, be = 0;
             if (valid) {
                 const Rng rng(seed, first + rb + rloc);
-                const double2* rc = s_rec + rloc * (uint32_t)P::STRIDE;
-                double2 xa[P::FULL ? S : 1], xb[P::FULL ? S : 1];
+                const cx<T>* rc = s_rec + rloc * (uint32_t)P::STRIDE;
+                cx<T> xa[P::FULL ? S : 1], xb[P::FULL ? S : 1];
+                [[maybe_unused]] cx<T> e_all[sizeof(T) == 4 ? 2 * S : 1];        // complex64: the pass's estimates, decided together below
+                [[maybe_unused]] int tx_all[sizeof(T) == 4 ? 2 * S : 1];
                 if constexpr (P::FULL) {
 #pragma unroll
                     for (int l = 0; l < S; ++l) {
@@ -244,7 +280,7 @@ __global__ __launch_bounds__(64, MCLE_WALK_F64_WAVES) void k_link_walk_f64(Modem
                 }
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
-                    double2 za[R], zb[R];
+                    cx<T> za[R], zb[R];
 #pragma unroll
                     for (int a = 0; a < R; ++a) {
                         const uint32_t bi = ((uint32_t)(k * R + a) * NS + t) >> 1;
@@ -261,50 +297,53 @@ __global__ __launch_bounds__(64, MCLE_WALK_F64_WAVES) void k_link_walk_f64(Modem
                                 b = rng.block(STREAM_NOISE, bi);
                             }
                             if constexpr (ABL & 4) {
-                                za[a] = mk<double>((double)(int)b.w[0] * 1e-10, (double)(int)b.w[1] * 1e-10);
-                                zb[a] = mk<double>((double)(int)b.w[2] * 1e-10, (double)(int)b.w[3] * 1e-10);
-                            } else {
+                                za[a] = mk<T>((T)(int)b.w[0] * (T)1e-10, (T)(int)b.w[1] * (T)1e-10);
+                                zb[a] = mk<T>((T)(int)b.w[2] * (T)1e-10, (T)(int)b.w[3] * (T)1e-10);
+                            } else if constexpr (sizeof(T) == 8) {
                                 za[a] = cn_from_words_lds(b.w[0], b.w[1], sigma, s_bm);
                                 zb[a] = cn_from_words_lds(b.w[2], b.w[3], sigma, s_bm);
+                            } else {
+                                za[a] = cn_from_words(b.w[0], b.w[1], sigma);
+                                zb[a] = cn_from_words(b.w[2], b.w[3], sigma);
                             }
                         }
                     }
-                    double2 e[2 * J];
+                    cx<T> e[2 * J];
                     int tx[2 * J];
 #pragma unroll
                     for (int jj = 0; jj < J; ++jj) {
                         const int s = k * J + jj;
-                        double2 ea, eb;
+                        cx<T> ea, eb;
                         if constexpr (ABL & 8) {          // every noise sample and the symbol stay alive, the multiply-adds go
                             ea = cadd(cadd(za[0], za[R - 1]), P::FULL ? xa[s] : s_table[ta[s]]);
                             eb = cadd(cadd(zb[0], zb[R - 1]), P::FULL ? xb[s] : s_table[tb[s]]);
                         } else if constexpr (P::FULL) {
                             {
-                                const double2 c = rc[P::mix(s, 0)];
+                                const cx<T> c = rc[P::mix(s, 0)];
                                 ea = cmul(c, za[0]);
                                 eb = cmul(c, zb[0]);
                             }
 #pragma unroll
                             for (int a = 1; a < R; ++a) {
-                                const double2 c = rc[P::mix(s, a)];
+                                const cx<T> c = rc[P::mix(s, a)];
                                 ea = cfma4(c, za[a], ea);
                                 eb = cfma4(c, zb[a], eb);
                             }
 #pragma unroll
                             for (int l = 0; l < S; ++l) {
-                                const double2 c = rc[P::gain(s, l)];
+                                const cx<T> c = rc[P::gain(s, l)];
                                 ea = cfma4(c, xa[l], ea);
                                 eb = cfma4(c, xb[l], eb);
                             }
                         } else {
                             {
-                                const double2 c = rc[P::gain(s, s)];
+                                const cx<T> c = rc[P::gain(s, s)];
                                 ea = cmul(c, s_table[ta[s]]);
                                 eb = cmul(c, s_table[tb[s]]);
                             }
 #pragma unroll
                             for (int a = 0; a < R; ++a) {
-                                const double2 c = rc[P::mix(s, a)];
+                                const cx<T> c = rc[P::mix(s, a)];
                                 ea = cfma4(c, za[a], ea);
                                 eb = cfma4(c, zb[a], eb);
                             }
@@ -318,11 +357,19 @@ __global__ __launch_bounds__(64, MCLE_WALK_F64_WAVES) void k_link_walk_f64(Modem
 #pragma unroll
                         for (int j = 0; j < 2 * J; j += 2)      // both components of both estimates stay alive
                             se += (unsigned)(e[j].x + e[j].y > e[j + 1].x + e[j + 1].y) + (unsigned)(tx[j] > tx[j + 1]);
+                    } else if constexpr (sizeof(T) == 8) {
+                        walk_decide<T, DEC, 2 * J>(mp, s_table, s_grid, e, tx, se, be);
                     } else {
-                        walk_decide<DEC, 2 * J>(mp, s_table, s_grid, e, tx, se, be);
+#pragma unroll
+                        for (int j = 0; j < 2 * J; ++j) {
+                            e_all[2 * J * k + j] = e[j];
+                            tx_all[2 * J * k + j] = tx[j];
+                        }
                     }
-                    __builtin_amdgcn_sched_barrier(0);      // user by user: the next user's draws do not start under this one's tail
+                    if constexpr (sizeof(T) == 8)
+                        __builtin_amdgcn_sched_barrier(0);  // user by user: the next user's draws do not start under this one's tail
                 }
+                if constexpr (sizeof(T) == 4 && !(ABL & 16)) walk_decide<T, DEC, 2 * S>(mp, s_table, s_grid, e_all, tx_all, se, be);
             }
             // the pass's counts to the (at most two) realizations it covers: per lane se <= 2 S, be <= 16 S, 64 lanes -- 16 bits each
             {
@@ -360,28 +407,37 @@ __global__ __launch_bounds__(64, MCLE_WALK_F64_WAVES) void k_link_walk_f64(Modem
 // two realizations; label bytes: M <= 256)
 inline bool link_walk_f64_fits(int n_symbols) { return (n_symbols & 1) == 0 && n_symbols >= 128; }
 
-template <typename P, int ABL = 0>
-inline void launch_link_walk_f64(mcle_ctx* ctx, const ModemParams<double>& mp_in, int n_symbols, double noise_var, uint64_t seed,
-                                 uint64_t first, uint64_t count, const double2* recs, mcle_counters* d_counters, uint32_t* d_sym,
-                                 uint32_t* d_bit) {
-    ModemParams<double> mp = mp_in;
+template <typename T, typename P, int ABL = 0>
+inline void launch_link_walk(mcle_ctx* ctx, const ModemParams<T>& mp_in, int n_symbols, double noise_var, uint64_t seed,
+                             uint64_t first, uint64_t count, const cx<T>* recs, mcle_counters* d_counters, uint32_t* d_sym,
+                             uint32_t* d_bit) {
+    ModemParams<T> mp = mp_in;
     const int dec = walk_dec_kind(ctx, mp);
     if (dec != WDEC_GENERIC) mp.grid.G = 0;
-    const size_t lds = (size_t)mp.M * sizeof(double2) + (size_t)mp.grid.G * mp.grid.G * sizeof(unsigned long long);
+    const size_t lds = (((size_t)mp.M * sizeof(cx<T>) + 15) & ~(size_t)15) + (size_t)mp.grid.G * mp.grid.G * sizeof(unsigned long long);
     const uint64_t chunks = (count + P::PER_WAVE - 1) / P::PER_WAVE;
-    const uint64_t cap = (uint64_t)ctx->n_cu * 4 * MCLE_WALK_F64_WAVES;
+    const uint64_t cap = (uint64_t)ctx->n_cu * 4 * (sizeof(T) == 4 ? MCLE_F32_WALK_WAVES : MCLE_WALK_F64_WAVES);
     const unsigned grid = (unsigned)oversubscribed_grid(ctx, cap, chunks, 2);
-    const double sigma = sqrt(noise_var);
-    auto kern = k_link_walk_f64<P, WDEC_GENERIC, ABL>;
+    const T sigma = (T)sqrt(noise_var);
+    auto kern = k_link_walk<T, P, WDEC_GENERIC, ABL>;
     switch (dec) {
-        case WDEC_SLICER: kern = k_link_walk_f64<P, WDEC_SLICER, ABL>; break;
-        case WDEC_QAM_CERT: kern = k_link_walk_f64<P, WDEC_QAM_CERT, ABL>; break;
-        case WDEC_QUAD_CERT: kern = k_link_walk_f64<P, WDEC_QUAD_CERT, ABL>; break;
-        case WDEC_AXIS4_CERT: kern = k_link_walk_f64<P, WDEC_AXIS4_CERT, ABL>; break;
+        case WDEC_SLICER: kern = k_link_walk<T, P, WDEC_SLICER, ABL>; break;
+        case WDEC_QAM_CERT: kern = k_link_walk<T, P, WDEC_QAM_CERT, ABL>; break;
+        case WDEC_QUAD_CERT: kern = k_link_walk<T, P, WDEC_QUAD_CERT, ABL>; break;
+        case WDEC_AXIS4_CERT: kern = k_link_walk<T, P, WDEC_AXIS4_CERT, ABL>; break;
         default: break;
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, ctx->stream, mp, n_symbols, sigma, seed, first, count, recs, d_counters,
                        d_sym, d_bit);
 }
 
+}  // namespace mcle
+
+namespace mcle {
+// (round-6 name of the complex128 launcher, kept for the callers written against it)
+template <typename P, int ABL = 0>
+inline void launch_link_walk_f64(mcle_ctx* ctx, const ModemParams<double>& mp, int n_symbols, double noise_var, uint64_t seed, uint64_t first,
+                                 uint64_t count, const double2* recs, mcle_counters* d_counters, uint32_t* d_sym, uint32_t* d_bit) {
+    launch_link_walk<double, P, ABL>(ctx, mp, n_symbols, noise_var, seed, first, count, recs, d_counters, d_sym, d_bit);
+}
 }  // namespace mcle
