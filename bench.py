@@ -118,8 +118,8 @@ def kernel_name(cfg, dtype):
         return "k_run_mimo_ofdm_pw"                   # quarter-wave decomposition, channel AND decode on the matrix cores (round 6, default)
     if cfg == "c4" and dtype == "f64" and ACTIVE_OPTS.get("f64_threads", 0) in (260, 262):
         return "k_run_mimo_ofdm_qw"                   # the first quarter-wave kernel (VALU decode)
-    if cfg in ("c5", "f6") and dtype == "f64" and not ACTIVE_OPTS.get("walk_legacy"):
-        return "k_link_walk_f64"                      # the packed complex128 walk (round 6, csrc/walk_f64.hpp)
+    if cfg in ("c5", "f6") and not ACTIVE_OPTS.get("walk_legacy"):
+        return "k_link_walk<"                         # the packed walk (round 6, csrc/walk_f64.hpp), either arithmetic
     return (KERNEL_F64 if dtype == "f64" else KERNEL)[cfg]
 
 KERNEL_NOTE = {   # configs whose step is two launches: the time spans both, the counters are the named (dominant) kernel's
@@ -142,10 +142,10 @@ KERNEL_NOTE = {   # configs whose step is two launches: the time spans both, the
           "round 4; option tdl_kernel=1: the matrix-core kernel k_run_ofdm_tdl_mfma) per slice of <= 2 GiB of records; "
           "kernel_ms_per_launch spans them",
     "c5": "a step = k_ia_solve_links (per-lane solve, ~18 % of the time) + k_ia_link (symbol walk); kernel_ms_per_launch spans both",
-    ("c5", "f64"): "a step = k_ia_solve_links<double> (per-lane solve) + k_link_walk_f64<IaWalk, decision form> (round 6: the lane pairs "
+    ("c5", "f64"): "a step = k_ia_solve_links<double> (per-lane solve) + k_link_walk<double, IaWalk, decision form> (round 6: the lane pairs "
                    "of 16 realizations as one index space, csrc/walk_f64.hpp; option walk_legacy=1: k_ia_link<double>); "
                    "kernel_ms_per_launch spans both",
-    ("f6", "f64"): "a step = k_bd_solve_links_static<double> (per-lane solve) + k_link_walk_f64<BdWalk<3, 2>, decision form> (round 6, "
+    ("f6", "f64"): "a step = k_bd_solve_links_static<double> (per-lane solve) + k_link_walk<double, BdWalk<3, 2>, decision form> (round 6, "
                    "csrc/walk_f64.hpp; option walk_legacy=1: k_bd_link<double>); kernel_ms_per_launch spans both",
     "f6": "a step = k_bd_solve_links (per-lane solve) + k_bd_link (symbol walk); kernel_ms_per_launch spans both"}
 # realizations per GPU and step: sized so that a step is >= 15 ms on the fastest kernel of the configuration -- K = 20 steps

@@ -64,6 +64,20 @@ __device__ __forceinline__ void walk_wave_order() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Sum of a 32-bit value over the wavefront WITHOUT the LDS crossbar: a shift-and-add scan inside the rows of sixteen lanes
+// (row_shr 1, 2, 4, 8; lanes without a source add 0), then row_bcast:15 / row_bcast:31 carry the row totals up -- six v_add_u32 with DPP
+// modifiers, the total in lane 63, read back as a scalar.  (wave_sum_u32 = six ds_bpermute_b32 round trips; twice per pass they were
+// most of the walk's skeleton: profiles/r06/walk_f64_ab.log.)
+__device__ __forceinline__ uint32_t walk_wave_total(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);      // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);      // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);      // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);      // row_shr:8: lane 15 of a row = the row's sum
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, true);      // row_bcast:15 into rows 1 and 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, true);      // row_bcast:31 into rows 2 and 3
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 // the literal sweep (strict '<': numpy.argmin's first minimum, fundamental.py:241-246), rolled: it runs once in ~1e8 symbols
 template <typename T> __device__ __forceinline__ int walk_sweep(const cx<T>* __restrict__ s_table, int M, cx<T> r) {
     T best = (r.x - s_table[0].x) * (r.x - s_table[0].x) + (r.y - s_table[0].y) * (r.y - s_table[0].y);
@@ -188,7 +202,7 @@ constexpr int kWalkRunBytes = kBlocksPerRun * 16;       // 144: the DATA blocks 
 // packing, LDS records and label exchange for the complex64 walks; the decisions of a pass are taken together AFTER its estimates
 // (twelve more registers are cheap in float) -- the slicer four at a time in the packed level domain, the certificates straight-line.
 template <typename T, typename P, int DEC, int ABL = 0>
-__global__ __launch_bounds__(64, sizeof(T) == 4 ? MCLE_F32_WALK_WAVES : MCLE_WALK_F64_WAVES) void k_link_walk(ModemParams<T> mp, int n_symbols, T sigma, uint64_t seed,
+__global__ __launch_bounds__(256, sizeof(T) == 4 ? MCLE_F32_WALK_WAVES : MCLE_WALK_F64_WAVES) void k_link_walk(ModemParams<T> mp, int n_symbols, T sigma, uint64_t seed,
                                                         uint64_t first, uint64_t count, const cx<T>* __restrict__ recs,
                                                         mcle_counters* counters, uint32_t* __restrict__ sym_out,
                                                         uint32_t* __restrict__ bit_out) {
@@ -197,21 +211,30 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? MCLE_F32_WALK_WAVES : MCLE_WAL
     cx<T>* s_table = reinterpret_cast<cx<T>*>(walk_smem);
     unsigned long long* s_grid = reinterpret_cast<unsigned long long*>(walk_smem + (((size_t)mp.M * sizeof(cx<T>) + 15) & ~(size_t)15));
     __shared__ double s_bm[sizeof(T) == 8 ? kBmLdsDoubles : 1];   // complex128: Box-Muller tables (bm_f64.hpp)
-    __shared__ cx<T> s_rec[PW * P::STRIDE];                // the chunk's records
-    __shared__ uint4 s_sym[RUNS * kBlocksPerRun];          // the pass's DATA blocks, run by run
-    __shared__ unsigned s_se[PW], s_be[PW];                // error counts of the chunk's realizations
-    __shared__ WgTotals totals;
+    // A workgroup is FOUR independent wavefronts that share the tables and ONE flush of the counters: with one wavefront per
+    // workgroup the six global atomics of wg_flush -- 6 144 workgroups per launch on one cache line, ~9 ns each -- were a third of a
+    // complex64 launch (profiles/r06/walk_grid_sweep.log: the time grew with the grid, not with the work).
+    __shared__ cx<T> s_rec_all[4][PW * P::STRIDE];         // the chunk's records
+    __shared__ uint4 s_sym_all[4][RUNS * kBlocksPerRun];   // the pass's DATA blocks, run by run
+    __shared__ unsigned s_se_all[4][PW], s_be_all[4][PW];  // error counts of the chunk's realizations
+    __shared__ WgTotals totals_all[4];
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    cx<T>* s_rec = s_rec_all[wv];
+    uint4* s_sym = s_sym_all[wv];
+    unsigned* s_se = s_se_all[wv];
+    unsigned* s_be = s_be_all[wv];
+    WgTotals& totals = totals_all[wv];
     if constexpr (sizeof(T) == 8) bm_tables_to_lds(s_bm, (int)threadIdx.x, (int)blockDim.x);
     load_table(mp, s_table);
     if constexpr (DEC == WDEC_GENERIC) load_grid(mp, s_grid);
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const uint32_t NS = (uint32_t)n_symbols, NP = NS >> 1, mask = (uint32_t)(mp.M - 1);
-    if (threadIdx.x == 0) wg_zero(totals);
+    if (lane == 0) wg_zero(totals);
     __syncthreads();
     // producer side of the symbol exchange: lane -> (run, block of the run); run = segment * S + stream
     const int p_run = lane / kBlocksPerRun, p_blk = lane - p_run * kBlocksPerRun;
     const uint64_t n_chunks = (count + PW - 1) / PW;
-    for (uint64_t ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
+    for (uint64_t ch = (uint64_t)blockIdx.x * 4 + wv; ch < n_chunks; ch += (uint64_t)gridDim.x * 4) {
         const uint64_t rb = ch * PW;
         const int nr = (int)(count - rb < (uint64_t)PW ? count - rb : (uint64_t)PW);
         const uint32_t n_pairs = (uint32_t)nr * NP;
@@ -374,16 +397,16 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? MCLE_F32_WALK_WAVES : MCLE_WAL
             // the pass's counts to the (at most two) realizations it covers: per lane se <= 2 S, be <= 16 S, 64 lanes -- 16 bits each
             {
                 const uint32_t w = se | (be << 16);
-                const uint32_t tot = wave_sum_u32(w);
+                const uint32_t tot = walk_wave_total(w);
                 uint32_t hi = 0;
-                if (two_seg) hi = wave_sum_u32(seg ? w : 0u);
-                if (lane == 0) {
+                if (two_seg) hi = walk_wave_total(seg ? w : 0u);
+                if (lane == 0) {                        // (LDS atomics without return: nothing waits for them)
                     const uint32_t lo = tot - hi;
-                    s_se[rlo] += lo & 0xFFFFu;
-                    s_be[rlo] += lo >> 16;
+                    atomicAdd(&s_se[rlo], lo & 0xFFFFu);
+                    atomicAdd(&s_be[rlo], lo >> 16);
                     if (hi) {
-                        s_se[rlo + 1] += hi & 0xFFFFu;
-                        s_be[rlo + 1] += hi >> 16;
+                        atomicAdd(&s_se[rlo + 1], hi & 0xFFFFu);
+                        atomicAdd(&s_be[rlo + 1], hi >> 16);
                     }
                 }
             }
@@ -399,8 +422,19 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? MCLE_F32_WALK_WAVES : MCLE_WAL
                 wg_account(totals, s_se[i], s_be[i], s_rec[i * P::STRIDE + P::OK_AT].x == 0.0, rb + (uint64_t)i, sym_out, bit_out);
         walk_wave_order();
     }
-    if (lane == 0)
-        wg_flush(totals, counters, (unsigned long long)S * NS, (unsigned long long)S * NS * (unsigned long long)mp.bits);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 1; i < 4; ++i) {
+            totals_all[0].se += totals_all[i].se;
+            totals_all[0].se2 += totals_all[i].se2;
+            totals_all[0].be += totals_all[i].be;
+            totals_all[0].be2 += totals_all[i].be2;
+            totals_all[0].ok += totals_all[i].ok;
+            totals_all[0].skip += totals_all[i].skip;
+        }
+        wg_flush(totals_all[0], counters, (unsigned long long)S * NS, (unsigned long long)S * NS * (unsigned long long)mp.bits);
+    }
 }
 
 // host: does this request fit the kernel above?  (an even number of columns, at least 128 of them: a pass then covers at most
@@ -416,8 +450,8 @@ inline void launch_link_walk(mcle_ctx* ctx, const ModemParams<T>& mp_in, int n_s
     if (dec != WDEC_GENERIC) mp.grid.G = 0;
     const size_t lds = (((size_t)mp.M * sizeof(cx<T>) + 15) & ~(size_t)15) + (size_t)mp.grid.G * mp.grid.G * sizeof(unsigned long long);
     const uint64_t chunks = (count + P::PER_WAVE - 1) / P::PER_WAVE;
-    const uint64_t cap = (uint64_t)ctx->n_cu * 4 * (sizeof(T) == 4 ? MCLE_F32_WALK_WAVES : MCLE_WALK_F64_WAVES);
-    const unsigned grid = (unsigned)oversubscribed_grid(ctx, cap, chunks, 2);
+    const uint64_t cap = (uint64_t)ctx->n_cu * (sizeof(T) == 4 ? MCLE_F32_WALK_WAVES : MCLE_WALK_F64_WAVES);     // workgroups of four wavefronts
+    const unsigned grid = (unsigned)oversubscribed_grid(ctx, cap, (chunks + 3) / 4, 2);
     const T sigma = (T)sqrt(noise_var);
     auto kern = k_link_walk<T, P, WDEC_GENERIC, ABL>;
     switch (dec) {
@@ -427,7 +461,7 @@ inline void launch_link_walk(mcle_ctx* ctx, const ModemParams<T>& mp_in, int n_s
         case WDEC_AXIS4_CERT: kern = k_link_walk<T, P, WDEC_AXIS4_CERT, ABL>; break;
         default: break;
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, ctx->stream, mp, n_symbols, sigma, seed, first, count, recs, d_counters,
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, ctx->stream, mp, n_symbols, sigma, seed, first, count, recs, d_counters,
                        d_sym, d_bit);
 }
 

@@ -15,7 +15,7 @@ done
 python - <<'PY'
 import json, csv, glob, subprocess, sys
 out = {}
-for cfg, needle in (("c5", "k_link_walk_f64<"), ("f6", "k_link_walk_f64<")):
+for cfg, needle in (("c5", "k_link_walk<double"), ("f6", "k_link_walk<double")):
     batch = int(subprocess.run([sys.executable, "bench.py", "--profile-spec", cfg + "_f64"], capture_output=True, text=True).stdout.split("--batch")[1].split()[0])
     for v in (0, 1, 2, 4, 6, 8, 16, 31):
         d = json.loads(open("/tmp/wsec/time_%s_%d.json" % (cfg, v)).read())

@@ -1,4 +1,4 @@
-"""GPU: the packed complex128 symbol walk of round 6 (csrc/walk_f64.hpp: the lane pairs of a chunk of realizations as one index
+"""GPU: the packed symbol walk of round 6 (complex128, and complex64 at the end of the file) (csrc/walk_f64.hpp: the lane pairs of a chunk of realizations as one index
 space, decision form fixed at compile time, records in LDS) -- the default of mcle_run_ia / mcle_run_bd in complex128 for an even
 number of columns >= 128 -- against the per-realization walks of rounds 2-5 (option walk_legacy = 1) and against the oracle
 (oracle/chains.py under the same Philox keying).  Every comparison is per realization and exact: the two kernels make the same
@@ -111,3 +111,48 @@ def test_bd_packed_walk_against_the_oracle(engine):
     res, se, be = engine.run_bd(3, 2, 254, 1.0, nv, SEED, first, count, method=_lib.DEMOD_MINDIST, dtype="f64", per_realization=True)
     assert np.array_equal(se, np.array([o["symbol_errors"] for o in out])) and np.array_equal(be, np.array([o["bit_errors"] for o in out]))
     assert res["sym_errors"] > 0
+
+
+# ---- complex64: the same packing (k_link_walk<float>; the estimates of a pass decided together, the slicer in the packed level domain) ----
+def _close32(a, b, n_sym_per_realization, ties=3):
+    """Two complex64 statements of the same link: decisions differ at rounding-level ties only."""
+    (ra, sa, ba), (rb, sb, bb) = a, b
+    n = len(sa)
+    assert ra["n_realizations"] == rb["n_realizations"] == n and ra["n_skipped"] == rb["n_skipped"] and ra["n_symbols"] == rb["n_symbols"]
+    assert np.max(np.abs(sa.astype(np.int64) - sb.astype(np.int64))) <= ties
+    assert abs(int(sa.astype(np.int64).sum()) - int(sb.astype(np.int64).sum())) <= 2e-5 * n * n_sym_per_realization + 3
+    assert abs(int(ba.astype(np.int64).sum()) - int(bb.astype(np.int64).sum())) <= 4e-5 * n * n_sym_per_realization + 4
+
+
+@pytest.mark.parametrize("form", FORMS, ids=lambda f: "%s%d-%d" % (f[0], f[1], f[3]))
+@pytest.mark.parametrize("n_symbols", [128, 130, 200, 1000])
+def test_ia_packed_walk_in_complex64(engine, form, n_symbols):
+    """Against the round-5 complex64 walk (option walk_legacy = 1) and against the complex128 packed walk on the same indices."""
+    mod, M, kind, method = form
+    engine.set_constellation(chains.constellation(mod, M), kind)
+    nv = 1.0 / omodem.dB2Linear(15.0 if M <= 16 else 30.0)
+    for first, count in ((0, 1), (1000, 16 * 37 + 9)):
+        new = engine.run_ia(n_symbols, nv, SEED, first, count, method=method, dtype="f32", per_realization=True)[:3]
+        with engine.options(walk_legacy=1):
+            old = engine.run_ia(n_symbols, nv, SEED, first, count, method=method, dtype="f32", per_realization=True)[:3]
+        f64 = engine.run_ia(n_symbols, nv, SEED, first, count, method=method, dtype="f64", per_realization=True)[:3]
+        _close32(new, old, 3 * n_symbols)
+        _close32(new, f64, 3 * n_symbols)
+
+
+@pytest.mark.parametrize("form", FORMS[:4], ids=lambda f: "%s%d-%d" % (f[0], f[1], f[3]))
+@pytest.mark.parametrize("shape", [(2, 1, 200), (3, 1, 500), (2, 2, 130), (3, 2, 500), (3, 2, 254)])
+def test_bd_packed_walk_in_complex64(engine, form, shape):
+    mod, M, kind, method = form
+    K, nr, n_symbols = shape
+    engine.set_constellation(chains.constellation(mod, M), kind)
+    nv = 1.0 / (10.0 ** 1.0)
+    pl = np.abs(np.random.default_rng(3).normal(1.0, 0.3, (K, K))) + 0.2
+    for first, count, pathloss in ((0, 1, None), (77, 8 * 41 + 5, None), (500, 300, pl)):
+        kw = dict(method=method, per_realization=True, pathloss=pathloss)
+        new = engine.run_bd(K, nr, n_symbols, 1.0, nv, SEED, first, count, dtype="f32", **kw)
+        with engine.options(walk_legacy=1):
+            old = engine.run_bd(K, nr, n_symbols, 1.0, nv, SEED, first, count, dtype="f32", **kw)
+        f64 = engine.run_bd(K, nr, n_symbols, 1.0, nv, SEED, first, count, dtype="f64", **kw)
+        _close32(new, old, K * nr * n_symbols)
+        _close32(new, f64, K * nr * n_symbols, ties=4)
