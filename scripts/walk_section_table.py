@@ -51,7 +51,7 @@ def table(cfg, data, legacy):
     pr0 = whole["per_realization"]
     passes = sh["pairs"] / 64.0
     out = ["# Section table: %s" % sh["title"], "",
-           "`k_link_walk_f64` (csrc/walk_f64.hpp), MCLE_EXPERIMENTS build, `scripts/walk_sections.sh` -> `scripts/walk_section_table.py`.",
+           "`k_link_walk<double, ...>` (csrc/walk_f64.hpp; workgroups of four wavefronts), MCLE_EXPERIMENTS build, `scripts/walk_sections.sh` -> `scripts/walk_section_table.py`.",
            "Whole kernel (solve + walk, HIP events): **%.3f ms per launch = %.3e realizations/s**; %d VALU, %d LDS, %d SALU wave-instructions "
            "per realization (%.0f VALU per pass of 64 lane pairs, %.4g passes per realization)." % (
                whole["kernel_ms_per_launch"], whole["realizations_per_s"], round(pr0["SQ_INSTS_VALU"]), round(pr0["SQ_INSTS_LDS"]),
@@ -82,7 +82,7 @@ def table(cfg, data, legacy):
             umin_s, ratio, note))
     sk = data[cfg + "_31"]
     out.append("| everything above compiled out | %d | %.0f %% | %.3f (the run itself) | | | | | chunk set-up (records to LDS), lane -> pair "
-               "bookkeeping, two masked wave sums and the lane-0 hand-over per pass, accounting; includes the substitutes of all five ablations |" % (
+               "bookkeeping, two masked DPP wave sums and the LDS-atomic hand-over per pass, accounting, ONE flush of the counters per four wavefronts (with one per wavefront this run took 0.60 ms: `walk_grid_sweep.log`); includes the substitutes of all five ablations |" % (
                    round(sk["per_realization"]["SQ_INSTS_VALU"]), 100.0 * sk["per_realization"]["SQ_INSTS_VALU"] / pr0["SQ_INSTS_VALU"],
                    sk["kernel_ms_per_launch"]))
     busy = 4.0 * pr0["SQ_ACTIVE_INST_VALU"] / max(1.0, pr0["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
