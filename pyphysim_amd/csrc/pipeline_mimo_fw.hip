@@ -306,8 +306,7 @@ __global__ __launch_bounds__(256, WPS) void k_run_mimo_ofdm_fw(MimoParams pp, Mo
             }
         }
     }
-    if (lane == 0)
-        wg_flush(totals[w], counters, (unsigned long long)per_sym * pp.n_ofdm_sym, (unsigned long long)per_sym * pp.n_ofdm_sym * mp.bits);
+    wg_flush_waves<4>(totals, counters, (unsigned long long)per_sym * pp.n_ofdm_sym, (unsigned long long)per_sym * pp.n_ofdm_sym * mp.bits);
 }
 
 template <int NA, int WPS, int ABL = 0>

@@ -370,8 +370,7 @@ __global__ __launch_bounds__(64 * (siso_wave_nwv<T, N>()), WPS) void k_run_ofdm_
         be = wave_sum_u32(be);
         if (lane == 0) wg_account(totals[w], se, be, false, rl, sym_out, bit_out);
     }
-    if (lane == 0)
-        wg_flush(totals[w], counters, (unsigned long long)U * pp.n_ofdm_sym, (unsigned long long)U * pp.n_ofdm_sym * mp.bits);
+    wg_flush_waves<NWV>(totals, counters, (unsigned long long)U * pp.n_ofdm_sym, (unsigned long long)U * pp.n_ofdm_sym * mp.bits);   // one flush per workgroup (round 6)
 }
 
 // host side: 0 = launched, MCLE_E_UNSUPPORTED = outside this kernel's envelope (the caller goes on to the batched kernels)
@@ -430,7 +429,9 @@ int run_siso_tdl_wave_w(mcle_ctx* ctx, const SisoTdlParams& pp, int method, uint
         hipLaunchKernelGGL(k_tdl_symbol_polys<T>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream, pp, N + pp.cp,
                            seed, first + off, n, (cx<T>*)recs);
         MCLE_LAUNCH_CHECK();
-        const unsigned grid = (unsigned)oversubscribed_grid(ctx, (uint64_t)ctx->n_cu * per_cu, (n + NWV - 1) / NWV, 12);
+        // (round 6: one flush of the counters per WORKGROUP instead of per wavefront -- a workgroup's fixed cost fell, and the grid that
+        //  wanted >= 12 passes per workgroup now takes 4: +4 % at 131 072 realizations per launch, profiles/r06/grid_sweep_others.log)
+        const unsigned grid = (unsigned)oversubscribed_grid(ctx, (uint64_t)ctx->n_cu * per_cu, (n + NWV - 1) / NWV, 4);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NWV), lds, ctx->stream, pw, mp, seed, first + off, n, (const cx<T>*)tw,
                            (const cx<T>*)recs, d_counters, d_sym ? d_sym + off : nullptr, d_bit ? d_bit + off : nullptr);
         MCLE_LAUNCH_CHECK();

@@ -45,4 +45,26 @@ __device__ __forceinline__ void wg_flush(const WgTotals& t, mcle_counters* count
     }
 }
 
+// A workgroup of NWV independent wavefronts with per-wavefront totals (t[w], written by each wavefront's lane 0): ONE flush.
+// Six global atomics per WAVEFRONT put tens of thousands of atomics per launch on the counters' one cache line (~9 ns each, and a
+// wavefront's slot is held until they are acknowledged): a third of a short kernel's time (round 6, profiles/r06/walk_grid_sweep.log).
+// Call from every thread of the workgroup at kernel end.
+template <int NWV>
+__device__ __forceinline__ void wg_flush_waves(WgTotals (&t)[NWV], mcle_counters* counters, unsigned long long n_sym,
+                                               unsigned long long n_bits) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 1; i < NWV; ++i) {
+            t[0].se += t[i].se;
+            t[0].se2 += t[i].se2;
+            t[0].be += t[i].be;
+            t[0].be2 += t[i].be2;
+            t[0].ok += t[i].ok;
+            t[0].skip += t[i].skip;
+        }
+        wg_flush(t[0], counters, n_sym, n_bits);
+    }
+}
+
 }  // namespace mcle

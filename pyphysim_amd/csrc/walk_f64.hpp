@@ -422,19 +422,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? MCLE_F32_WALK_WAVES : MCLE_WA
                 wg_account(totals, s_se[i], s_be[i], s_rec[i * P::STRIDE + P::OK_AT].x == 0.0, rb + (uint64_t)i, sym_out, bit_out);
         walk_wave_order();
     }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-#pragma unroll
-        for (int i = 1; i < 4; ++i) {
-            totals_all[0].se += totals_all[i].se;
-            totals_all[0].se2 += totals_all[i].se2;
-            totals_all[0].be += totals_all[i].be;
-            totals_all[0].be2 += totals_all[i].be2;
-            totals_all[0].ok += totals_all[i].ok;
-            totals_all[0].skip += totals_all[i].skip;
-        }
-        wg_flush(totals_all[0], counters, (unsigned long long)S * NS, (unsigned long long)S * NS * (unsigned long long)mp.bits);
-    }
+    wg_flush_waves<4>(totals_all, counters, (unsigned long long)S * NS, (unsigned long long)S * NS * (unsigned long long)mp.bits);
 }
 
 // host: does this request fit the kernel above?  (an even number of columns, at least 128 of them: a pass then covers at most
