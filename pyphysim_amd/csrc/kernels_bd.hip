@@ -665,7 +665,8 @@ __global__ __launch_bounds__(64) void k_bd_solve_links_static(BdParams pp, uint6
 // eight-entry arrays in one body the complex64 form spilled 45-52 registers at its 128-register bound (profiles/r03:
 // VALU busy 0.97 on the draw ledger plus spill traffic).
 template <typename T, int R, int KC = 0, int MODE = 0>
-__global__ __launch_bounds__(64, (sizeof(T) == 4 || KC) ? 3 : 2) void k_bd_link(ModemParams<T> mp, BdParams pp, uint64_t seed,
+// (round 6: workgroups of FOUR independent wavefronts, one flush of the counters -- totals.hpp: wg_flush_waves)
+__global__ __launch_bounds__(256, (sizeof(T) == 4 || KC) ? 3 : 2) void k_bd_link(ModemParams<T> mp, BdParams pp, uint64_t seed,
                                                                         uint64_t first, uint64_t count, int per_wave,
                                                                         const cx<T>* __restrict__ recs,
                                                                         mcle_counters* counters,
@@ -678,7 +679,9 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 || KC) ? 3 : 2) void k_bd_link(
     unsigned long long* s_grid = reinterpret_cast<unsigned long long*>(smem);
     __shared__ cx<T> s_table[256];
     __shared__ float4 s_tab4[sizeof(T) == 4 ? 256 : 1];     // {re, im, |c|^2 / 2, 0}: the lockstep searches of modem.hpp
-    __shared__ WgTotals totals;
+    __shared__ WgTotals totals_all[4];
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    WgTotals& totals = totals_all[wv];
     __shared__ double s_bm[sizeof(T) == 8 ? kBmLdsDoubles : 1];   // complex128 Box-Muller tables (bm_f64.hpp)
     if constexpr (sizeof(T) == 8) bm_tables_to_lds(s_bm, (int)threadIdx.x, (int)blockDim.x);
     load_table(mp, s_table);
@@ -688,16 +691,16 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 || KC) ? 3 : 2) void k_bd_link(
             const float2 c = mp.g_table[m];
             s_tab4[m] = make_float4(c.x, c.y, 0.5f * (c.x * c.x + c.y * c.y), 0.f);
         }
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const T sigma = (T)sqrt(pp.noise_var);
     const uint32_t mask = (uint32_t)(mp.M - 1);
     const int NS = pp.n_symbols;
     // f32, min-distance: the R streams of a user searched in lockstep -- directly for constellations of <= 8 points,
     // through the candidate grid otherwise (same decisions as demod_one, one LDS round trip per candidate for all R)
-    if (threadIdx.x == 0) wg_zero(totals);
+    if (lane == 0) wg_zero(totals);
     __syncthreads();
     const uint64_t n_chunks = (count + per_wave - 1) / per_wave;
-    for (uint64_t ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
+    for (uint64_t ch = (uint64_t)blockIdx.x * 4 + wv; ch < n_chunks; ch += (uint64_t)gridDim.x * 4) {
         const uint64_t r_end = (ch + 1) * per_wave < count ? (ch + 1) * per_wave : count;
         for (uint64_t rl = ch * per_wave; rl < r_end; ++rl) {
             const Rng rng(seed, first + rl);
@@ -806,8 +809,7 @@ __global__ __launch_bounds__(64, (sizeof(T) == 4 || KC) ? 3 : 2) void k_bd_link(
             if (lane == 0) wg_account(totals, se, be, !ok, rl, sym_out, bit_out);
         }
     }
-    if (lane == 0)
-        wg_flush(totals, counters, (unsigned long long)n * NS, (unsigned long long)n * NS * mp.bits);
+    wg_flush_waves<4>(totals_all, counters, (unsigned long long)n * NS, (unsigned long long)n * NS * mp.bits);
 }
 
 template <typename T, int R>
@@ -846,9 +848,9 @@ static int launch_run_bd(mcle_ctx* ctx, const mcle_bd_cfg* cfg, const BdParams& 
         const bool kc = R <= 2 && (cfg->K == 2 || cfg->K == 3) && cfg->K * R <= kBdMaxN;
         // the resident set: the wavefronts per SIMD of k_bd_link's __launch_bounds__ (3 for complex64 and the compile-time user
         // counts, 2 otherwise) -- rounds 4-5 sized the complex64 grid for four and ran a partial second wave of workgroups
-        const uint64_t cap = (uint64_t)ctx->n_cu * 4 * ((sizeof(T) == 4 || kc) ? 3 : 2);
+        const uint64_t cap = (uint64_t)ctx->n_cu * ((sizeof(T) == 4 || kc) ? 3 : 2);       // workgroups of four wavefronts
         const uint64_t chunks = (m + per_wave - 1) / per_wave;
-        const unsigned grid = (unsigned)oversubscribed_grid(ctx, cap, chunks, 2);     // a chunk is 8-16 realizations; one chunk per workgroup measured 1.5 x slower
+        const unsigned grid = (unsigned)oversubscribed_grid(ctx, cap, (chunks + 3) / 4, 2);     // a chunk is 8-16 realizations; one chunk per workgroup measured 1.5 x slower
         // demodulator path of the walk (compile-time in the kernel): complex64 min-distance in lockstep -- a sweep for M <= 8,
         // certificate / candidate grid otherwise; everything else one demod_one per stream
         // (round 5: a constellation WITH a certificate -- square QAM, QPSK -- goes through it whatever its size: the application's
@@ -858,7 +860,7 @@ static int launch_run_bd(mcle_ctx* ctx, const mcle_bd_cfg* cfg, const BdParams& 
         bool walked = false;
 #define MCLE_BD_WALK(KC_, MODE_)                                                                                          \
     if (!walked && (KC_ == 0 || (cfg->K == KC_ && KC_ * R <= kBdMaxN)) && mode == MODE_) {                                  \
-        hipLaunchKernelGGL((k_bd_link<T, R, (KC_ * R <= kBdMaxN ? KC_ : 0), (sizeof(T) == 4 ? MODE_ : 0)>), dim3(grid), dim3(64), lds, \
+        hipLaunchKernelGGL((k_bd_link<T, R, (KC_ * R <= kBdMaxN ? KC_ : 0), (sizeof(T) == 4 ? MODE_ : 0)>), dim3(grid), dim3(256), lds, \
                            ctx->stream, mp, pp, seed, first + off, m, per_wave, (const cx<T>*)recs, d_counters,           \
                            d_sym_err ? d_sym_err + off : nullptr, d_bit_err ? d_bit_err + off : nullptr);                 \
         walked = true;                                                                                                    \

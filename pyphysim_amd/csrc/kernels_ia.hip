@@ -552,7 +552,8 @@ __global__ __launch_bounds__(64) void k_ia_solve_links(double noise_var, int sol
 // The symbol walk: one wavefront per `per_wave` consecutive realizations, est_k = sum_l G_kl x_l + U_k . n_k, two
 // columns per lane and pass (wave_draws.hpp).  The record of a realization is wave-uniform (scalar loads).
 template <typename T>
-__global__ __launch_bounds__(64, sizeof(T) == 4 ? MCLE_F32_WALK_WAVES : 3) void k_ia_link(ModemParams<T> mp, int n_symbols, double noise_var,
+// (round 6: workgroups of FOUR independent wavefronts, one flush of the counters -- totals.hpp: wg_flush_waves)
+__global__ __launch_bounds__(256, sizeof(T) == 4 ? MCLE_F32_WALK_WAVES : 3) void k_ia_link(ModemParams<T> mp, int n_symbols, double noise_var,
                                                                         uint64_t seed, uint64_t first, uint64_t count,
                                                                         int per_wave, const cx<T>* __restrict__ recs,
                                                                         mcle_counters* counters,
@@ -571,7 +572,8 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? MCLE_F32_WALK_WAVES : 3) void 
             s_tab4[m] = make_float4(c.x, c.y, 0.5f * (c.x * c.x + c.y * c.y), 0.f);
         }
     const bool lockstep = sizeof(T) == 4 && mp.method == MCLE_DEMOD_MINDIST && (mp.M <= 8 || mp.grid.G > 0);
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const T sigma = (T)sqrt(noise_var);
     const uint32_t mask = (uint32_t)(mp.M - 1);
     const bool packed = sizeof(T) == 4 && mp.method == MCLE_DEMOD_QAM_SLICER;
@@ -579,11 +581,12 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? MCLE_F32_WALK_WAVES : 3) void 
     if constexpr (sizeof(T) == 4) {
         if (packed) qp = qam_pack(mp);
     }
-    __shared__ WgTotals totals;
-    if (threadIdx.x == 0) wg_zero(totals);
+    __shared__ WgTotals totals_all[4];
+    WgTotals& totals = totals_all[wv];
+    if (lane == 0) wg_zero(totals);
     __syncthreads();
     const uint64_t n_chunks = (count + per_wave - 1) / per_wave;
-    for (uint64_t ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
+    for (uint64_t ch = (uint64_t)blockIdx.x * 4 + wv; ch < n_chunks; ch += (uint64_t)gridDim.x * 4) {
         const uint64_t r_end = (ch + 1) * per_wave < count ? (ch + 1) * per_wave : count;
         for (uint64_t rl = ch * per_wave; rl < r_end; ++rl) {
             const Rng rng(seed, first + rl);
@@ -700,8 +703,7 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? MCLE_F32_WALK_WAVES : 3) void 
             if (lane == 0) wg_account(totals, se, be, !ok, rl, sym_out, bit_out);
         }
     }
-    if (lane == 0)
-        wg_flush(totals, counters, 3ull * (unsigned long long)n_symbols, 3ull * (unsigned long long)n_symbols * mp.bits);
+    wg_flush_waves<4>(totals_all, counters, 3ull * (unsigned long long)n_symbols, 3ull * (unsigned long long)n_symbols * mp.bits);
 }
 
 constexpr uint64_t kSolveSlice = 1ull << 20;   // realizations per solve + walk pair: bounds the record buffer (128 MB here)
@@ -724,8 +726,8 @@ int run_ia_impl(mcle_ctx* ctx, const mcle_ia_cfg* cfg, uint64_t seed, uint64_t f
                            (cx<T>*)recs, d_cap ? d_cap + off : nullptr, d_iter ? d_iter + off : nullptr);
         MCLE_LAUNCH_CHECK();
         const uint64_t chunks = (n + per_wave - 1) / per_wave;
-        const uint64_t cap = (uint64_t)ctx->n_cu * 4 * (sizeof(T) == 4 ? 4 : 3);
-        const unsigned grid = (unsigned)oversubscribed_grid(ctx, cap, chunks, 2);     // a chunk is 8-16 realizations; one chunk per workgroup measured 1.5 x slower
+        const uint64_t cap = (uint64_t)ctx->n_cu * (sizeof(T) == 4 ? 4 : 3);                    // workgroups of four wavefronts
+        const unsigned grid = (unsigned)oversubscribed_grid(ctx, cap, (chunks + 3) / 4, 2);     // a chunk is 8-16 realizations; one chunk per workgroup measured 1.5 x slower
         bool walked = false;
         {
             // an even number of columns >= 128: the packed walk of walk_f64.hpp (round 6; complex64 since its last day)
@@ -744,7 +746,7 @@ int run_ia_impl(mcle_ctx* ctx, const mcle_ia_cfg* cfg, uint64_t seed, uint64_t f
             }
         }
         if (!walked)
-            hipLaunchKernelGGL(k_ia_link<T>, dim3(grid), dim3(64), lds, ctx->stream, mp, cfg->n_symbols, cfg->noise_var, seed,
+            hipLaunchKernelGGL(k_ia_link<T>, dim3(grid), dim3(256), lds, ctx->stream, mp, cfg->n_symbols, cfg->noise_var, seed,
                                first + off, n, per_wave, (const cx<T>*)recs, d_counters, d_sym ? d_sym + off : nullptr,
                                d_bit ? d_bit + off : nullptr);
         MCLE_LAUNCH_CHECK();

@@ -185,7 +185,8 @@ template <typename C> __device__ __forceinline__ C mac(C a, C b, C acc) {
 }
 
 template <typename T>
-__global__ __launch_bounds__(64, sizeof(T) == 4 ? MCLE_F32_WALK_WAVES : 2) void k_mimo_flat_link(
+// (round 6: a workgroup is FOUR independent wavefronts sharing the tables and one flush of the counters -- totals.hpp: wg_flush_waves)
+__global__ __launch_bounds__(256, sizeof(T) == 4 ? MCLE_F32_WALK_WAVES : 2) void k_mimo_flat_link(
     ModemParams<T> mp, int scheme, int nt, int nr, int n_symbols, double noise_var, uint64_t seed, uint64_t first,
     uint64_t count, int per_wave, const cx<T>* __restrict__ recs, mcle_counters* counters,
     uint32_t* __restrict__ sym_out, uint32_t* __restrict__ bit_out) {
@@ -202,7 +203,8 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? MCLE_F32_WALK_WAVES : 2) void 
             s_tab4[m] = make_float4(c.x, c.y, 0.5f * (c.x * c.x + c.y * c.y), 0.f);
         }
     const bool lockstep = sizeof(T) == 4 && mp.method == MCLE_DEMOD_MINDIST && (mp.M <= 8 || mp.grid.G > 0);
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const T sigma = (T)sqrt(noise_var);
     const uint32_t mask = (uint32_t)(mp.M - 1);
     const int layers = (scheme == MCLE_MIMO_ALAMOUTI || scheme == MCLE_MIMO_MRT) ? 1 : nt;
@@ -213,11 +215,12 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? MCLE_F32_WALK_WAVES : 2) void 
     if constexpr (sizeof(T) == 4) {
         if (packed) qp = qam_pack(mp);
     }
-    __shared__ WgTotals totals;
-    if (threadIdx.x == 0) wg_zero(totals);
+    __shared__ WgTotals totals_all[4];
+    WgTotals& totals = totals_all[wv];
+    if (lane == 0) wg_zero(totals);
     __syncthreads();
     const uint64_t n_chunks = (count + per_wave - 1) / per_wave;
-    for (uint64_t ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
+    for (uint64_t ch = (uint64_t)blockIdx.x * 4 + wv; ch < n_chunks; ch += (uint64_t)gridDim.x * 4) {
         const uint64_t r_end = (ch + 1) * per_wave < count ? (ch + 1) * per_wave : count;
         for (uint64_t rl = ch * per_wave; rl < r_end; ++rl) {
             const Rng rng(seed, first + rl);
@@ -382,9 +385,7 @@ __global__ __launch_bounds__(64, sizeof(T) == 4 ? MCLE_F32_WALK_WAVES : 2) void 
             if (lane == 0) wg_account(totals, se, be, rec[2 * kFlatMax * kFlatMax].y == (T)0, rl, sym_out, bit_out);
         }
     }
-    if (lane == 0)
-        wg_flush(totals, counters, (unsigned long long)layers * n_symbols,
-                 (unsigned long long)layers * n_symbols * mp.bits);
+    wg_flush_waves<4>(totals_all, counters, (unsigned long long)layers * n_symbols, (unsigned long long)layers * n_symbols * mp.bits);
 }
 
 }  // namespace mcle
@@ -441,7 +442,7 @@ extern "C" int mcle_run_mimo_flat(mcle_ctx* ctx, int dtype, const mcle_mimo_flat
             hipLaunchKernelGGL(k_mimo_flat_setup<float>, dim3(sgrid), dim3(64), 0, ctx->stream, cfg->scheme, nt, nr, filter_nv,
                                seed, first + off, m, (float2*)recs);
             MCLE_LAUNCH_CHECK();
-            hipLaunchKernelGGL(k_mimo_flat_link<float>, dim3((unsigned)(chunks < cap ? chunks : cap)), dim3(64), lds,
+            hipLaunchKernelGGL(k_mimo_flat_link<float>, dim3((unsigned)((chunks + 3) / 4 < cap / 4 ? (chunks + 3) / 4 : cap / 4)), dim3(256), lds,
                                ctx->stream, mp32, cfg->scheme, nt, nr, cfg->n_symbols, cfg->noise_var, seed, first + off, m,
                                per_wave, (const float2*)recs, d_counters, se, be);
         } else {
@@ -449,7 +450,7 @@ extern "C" int mcle_run_mimo_flat(mcle_ctx* ctx, int dtype, const mcle_mimo_flat
             hipLaunchKernelGGL(k_mimo_flat_setup<double>, dim3(sgrid), dim3(64), 0, ctx->stream, cfg->scheme, nt, nr, filter_nv,
                                seed, first + off, m, (double2*)recs);
             MCLE_LAUNCH_CHECK();
-            hipLaunchKernelGGL(k_mimo_flat_link<double>, dim3((unsigned)(chunks < cap ? chunks : cap)), dim3(64), lds,
+            hipLaunchKernelGGL(k_mimo_flat_link<double>, dim3((unsigned)((chunks + 3) / 4 < cap / 4 ? (chunks + 3) / 4 : cap / 4)), dim3(256), lds,
                                ctx->stream, pipe_modem<double>(ctx, cfg->demod_method), cfg->scheme, nt, nr, cfg->n_symbols,
                                cfg->noise_var, seed, first + off, m, per_wave, (const double2*)recs, d_counters, se, be);
         }
