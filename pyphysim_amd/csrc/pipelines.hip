@@ -22,6 +22,7 @@
 #include "totals.hpp"
 #include "pipe_common.hpp"
 #include "qam_pack.hpp"
+#include "walk_f64.hpp"
 
 namespace mcle {
 
@@ -109,6 +110,9 @@ __device__ __forceinline__ float2 flat_equalised(float2 h, float2 s, float2 z) {
 }
 
 // MODE (f32): 0 one demod_one per symbol (any method), 1 packed level-domain slicer, 2 lockstep min-distance search
+// MODE (f64, round 6): 10 + a decision form of walk_f64.hpp fixed at compile time (11 slicer, 12 QAM margin certificate, 13 quadrant,
+// 14 on-axis certificate: walk_decide, four symbols at a time) -- the run-time demod_one per symbol with its method / certificate /
+// grid switches kept 209 scalar registers spilled in this kernel; 0 = that generic form, for constellations without a certificate
 template <typename T, int LR, int MODE>
 __global__ __launch_bounds__(kPipeBlock, (sizeof(T) == 8 && LR == 8) ? 2 : 1) void k_run_flat(FlatParams fp, ModemParams<T> mp, uint64_t seed,
                                                          uint64_t first, uint64_t count, unsigned* __restrict__ ws) {
@@ -246,7 +250,15 @@ __global__ __launch_bounds__(kPipeBlock, (sizeof(T) == 8 && LR == 8) ? 2 : 1) vo
                         r[e] = cadd(s, z[e]);
                     }
                 }
-                if constexpr (MODE == 1) {   // the four decisions in one packed level-domain slice (qam_pack.hpp)
+                if constexpr (sizeof(T) == 8 && MODE >= 10) {
+                    int tx[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        tx[e] = (int)((dwt >> (8 * e)) & 0xFFu);
+                        if (e >= left) r[e] = s_table[tx[e]];       // past the end of the realization: the point itself, no error
+                    }
+                    walk_decide<double, MODE - 10, 4>(mp, s_table, s_grid, r, tx, se, be);
+                } else if constexpr (MODE == 1) {   // the four decisions in one packed level-domain slice (qam_pack.hpp)
                     const f4q re = {r[0].x, r[1].x, r[2].x, r[3].x}, im = {r[0].y, r[1].y, r[2].y, r[3].y};
                     uint32_t x = qam_levels4(re, im, qp) ^ labels_to_levels(dwt, qp);
                     if (left < 4) x &= (1u << (8 * left)) - 1u;
@@ -267,6 +279,13 @@ __global__ __launch_bounds__(kPipeBlock, (sizeof(T) == 8 && LR == 8) ? 2 : 1) vo
                     if constexpr (sizeof(T) == 8) {   // complex128 grid search: the four symbols in lockstep
                         if (mp.method == MCLE_DEMOD_MINDIST && mp.grid.G > 0) {
                             demod_multi_cert(mp, r, dec, [&](int (&d_)[4]) { demod_grid_multi<4>(s_table, s_grid, mp.grid, mp.M, r, d_); });
+                            done = true;
+                        }
+                    }
+                    if constexpr (sizeof(T) == 8) {   // complex128 slicer: the clamp-before-floor form of the walks (walk_f64.hpp, round 6)
+                        if (!done && mp.method == MCLE_DEMOD_QAM_SLICER) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) dec[e] = walk_qam_slicer(r[e], mp.qam_scale, mp.qam_L, mp.half_bits);
                             done = true;
                         }
                     }
@@ -941,7 +960,7 @@ int run_flat_impl(mcle_ctx* ctx, const FlatParams& fp, int method, uint64_t seed
     int rc = pipe_workspace(ctx, count, &ws, &sk);
     if (rc) return rc;
     const uint64_t items = count * (uint64_t)((fp.n_symbols + kChunk - 1) / kChunk);
-    const ModemParams<T> mp = pipe_modem<T>(ctx, method);
+    ModemParams<T> mp = pipe_modem<T>(ctx, method);
     const size_t lds = (size_t)mp.grid.G * mp.grid.G * sizeof(unsigned long long);
     // f32 Jakes links of 8 / 16 rays: the ray sum on the matrix cores (MCLE_OPT_NO_MFMA keeps the VALU recurrence);
     // the f32 kernels are specialised by demodulator (1 packed slicer, 2 lockstep min-distance search, 0 the rest)
@@ -983,8 +1002,13 @@ int run_flat_impl(mcle_ctx* ctx, const FlatParams& fp, int method, uint64_t seed
         // complex128: the same rotation recurrence over a thread's 16 symbols (15 complex products after an exact
         // start: <= 3e-15 relative, against 8 or 16 f64 sincos per symbol); MCLE_OPT_JAKES_DIRECT evaluates every sample
         const int lr64 = !fp.rayleigh_iid && (fp.L == 8 || fp.L == 16) && !ctx->opt[MCLE_OPT_JAKES_DIRECT] ? fp.L : 0;
-        switch (lr64) {
-            case 8: MCLE_FLAT_LAUNCH((k_run_flat<T, 8, 0>)); break;
+        const int dec = lr64 == 8 ? walk_dec_kind(ctx, mp) : WDEC_GENERIC;     // (fills the on-axis certificate's constants into mp)
+        switch (lr64 == 8 ? 80 + dec : lr64) {
+            case 80 + WDEC_SLICER: MCLE_FLAT_LAUNCH((k_run_flat<T, 8, 10 + WDEC_SLICER>)); break;
+            case 80 + WDEC_QAM_CERT: MCLE_FLAT_LAUNCH((k_run_flat<T, 8, 10 + WDEC_QAM_CERT>)); break;
+            case 80 + WDEC_QUAD_CERT: MCLE_FLAT_LAUNCH((k_run_flat<T, 8, 10 + WDEC_QUAD_CERT>)); break;
+            case 80 + WDEC_AXIS4_CERT: MCLE_FLAT_LAUNCH((k_run_flat<T, 8, 10 + WDEC_AXIS4_CERT>)); break;
+            case 80 + WDEC_GENERIC: MCLE_FLAT_LAUNCH((k_run_flat<T, 8, 0>)); break;
             case 16: MCLE_FLAT_LAUNCH((k_run_flat<T, 16, 0>)); break;
             default: MCLE_FLAT_LAUNCH((k_run_flat<T, 0, 0>)); break;
         }
