@@ -116,8 +116,11 @@ enum {
                                       csrc/pipeline_mimo_fw.hip, one realization per wavefront) / the half-wave kernel (512:
                                       csrc/pipeline_mimo_pw.hip, two wavefronts per realization), both with channel AND decode on
                                       v_mfma_f64_4x4x4; 262 = bounded for two wavefronts per SIMD; 261 = the planar radix-4 form of
-                                      rounds 3-5.  (1024, 4x4): 263 / 264 = the quarter-wave decomposition with the decode on the
-                                      matrix cores (pipeline_mimo_pw.hip, NW = 4; three / two wavefronts per SIMD) */
+                                      rounds 3-5; (256, 2x2): the full-wave kernel with two realizations per wavefront; (2048, 4x4): the
+                                      eighth-wave kernel (512 threads).  (1024, 4x4): since the end of round 6 the DEFAULT (0) is the
+                                      quarter-wave decomposition with the decode on the matrix cores as well (pipeline_mimo_pw.hip,
+                                      NW = 4; 263 = the same, explicit; 264 = two wavefronts per SIMD); 260 / 262 select the first
+                                      quarter-wave kernel (pipeline_mimo_qw.hip, VALU decode) */
     MCLE_OPT_BD_RUNTIME_SOLVE = 9, /* 1: the block-diagonalisation pipeline solves with the run-time-sized routine (private
                                       arrays in scratch) also where the compile-time-sized one (K nr <= 6) applies */
     MCLE_OPT_DEMOD_NOCERT = 10,    /* 1: min-distance decisions of a square Gray QAM always through the table search (candidate
@@ -155,7 +158,7 @@ enum {
                                       (k_run_mimo_ofdm_tdl_wave, every 1 <= Nt <= Nr <= 4; default since round 5), 1 = the
                                       workgroup-cooperative kernel of rounds 1-4 (Nt = Nr in {2, 4}), 2 = the wavefront kernels with the
                                       tap polynomials' order at run time also where the parked-coefficient kernel applies (A/B) */
-    MCLE_OPT_WALK_LEGACY = 15,     /* complex128 symbol walks of mcle_run_ia / mcle_run_bd with an even number of columns >= 128 (and, for
+    MCLE_OPT_WALK_LEGACY = 15,     /* symbol walks of mcle_run_ia / mcle_run_bd (either arithmetic) with an even number of columns >= 128 (and, for
                                       block diagonalisation, two or three users of <= 2 antennas): 0 = the packed walk of round 6
                                       (csrc/walk_f64.hpp: the lane pairs of a chunk of realizations as one index space, decision form
                                       fixed at compile time, records in LDS), 1 = the per-realization walks of rounds 2-5 (A/B and
