@@ -30,3 +30,27 @@ for i in range(300):
     b=eng.run_mimo_ofdm(4,4,1024,16,1024,1,0.003,1,0,4096)
     assert a==b
 print("repeat ok", resource.getrusage(resource.RUSAGE_SELF).ru_maxrss)
+
+# round 6: the complex128 kernels of the round (full-wave / part-wave family, packed walks) and the complex64 packed walks --
+# awkward counts, and split invariance: the counters of [0, n) equal the sums over [0, k) and [k, n) for ragged k
+def same_sum(fn, n, k):
+    a, b, c = fn(0, n), fn(0, k), fn(k, n - k)
+    for key in ("sym_errors", "bit_errors", "sym_errors_sq", "bit_errors_sq", "n_realizations", "n_skipped"):
+        assert a[key] == b[key] + c[key], (key, a[key], b[key], c[key])
+    assert a["n_realizations"] + a["n_skipped"] == n
+t = time.time()
+for dt in ("f64", "f32"):
+    for fft, nt in ((256, 4), (256, 2), (512, 4), (1024, 4), (2048, 4)):
+        n = 40961 if fft < 2048 else 8195
+        for k in (1, 7, n // 3, n - 1):
+            same_sum(lambda f, c: eng.run_mimo_ofdm(nt, nt, fft, 16, fft, 1, 0.003, 9, f, c, method=_lib.DEMOD_MINDIST, dtype=dt), n, k)
+    for ns in (128, 130, 200, 1000):
+        for k in (1, 15, 17, 5000):
+            same_sum(lambda f, c: eng.run_ia(ns, 0.01, 9, f, c, dtype=dt), 20011, k)
+            same_sum(lambda f, c: eng.run_bd(3, 2, ns, 1.0, 0.03, 9, f, c, dtype=dt), 10007, k)
+    for count in (1, 63, 65, 1000003):
+        r = eng.run_ia(200, 0.01, 1, 5, count, dtype=dt); assert r["n_realizations"] + r["n_skipped"] == count
+        r = eng.run_bd(3, 2, 500, 1.0, 0.03, 1, 5, count, dtype=dt); assert r["n_realizations"] + r["n_skipped"] == count
+        r = eng.run_mimo_ofdm(4, 4, 256, 16, 256, 1, 0.003, 1, 5, count, dtype=dt); assert r["n_realizations"] + r["n_skipped"] == count
+        r = eng.run_mimo_ofdm(2, 2, 256, 16, 256, 1, 0.003, 1, 5, count, dtype=dt); assert r["n_realizations"] + r["n_skipped"] == count
+print("round-6 stress ok", time.time() - t)
