@@ -43,6 +43,7 @@
 #include "pipe_common.hpp"
 #include "pkcx.hpp"
 #include "totals.hpp"
+#include "walk_f64.hpp"
 #include "wave_lanes.hpp"
 
 namespace mcle {
@@ -563,6 +564,38 @@ __global__ __launch_bounds__(64 * NR, WPS) void k_run_mimo_ofdm_tdl_wave(MimoTdl
 #pragma unroll
                     for (int a = 0; a < NT; ++a) est[j * NT + a] = ok ? cscale(x[a], rx_scale) : mk<T>(0, 0);   // singular: ZF only
                 }
+                // Four streams and a square QAM: the bin's four decisions counted in the LEVEL domain (round 6) -- complex64 by the packed
+                // slicer of the planar kernels (qam_pack.hpp: four decisions per v_cvt_pk_u8_f32 word, ~3 instructions per symbol instead
+                // of ~25), complex128 by walk_qam_count4 (walk_f64.hpp: slicer or margin certificate, ~18 instead of ~27 - 36)
+                bool counted = false;
+                if constexpr (NT == 4 && !(ABL & 16)) {
+                    if constexpr (sizeof(T) == 4) {
+                        if (slicer) {
+                            const QamPack qp = qam_pack(mp);
+#pragma unroll
+                            for (int j = 0; j < BQ; ++j) {
+                                const f4q er = {est[4 * j].x, est[4 * j + 1].x, est[4 * j + 2].x, est[4 * j + 3].x};
+                                const f4q ei = {est[4 * j].y, est[4 * j + 1].y, est[4 * j + 2].y, est[4 * j + 3].y};
+                                const uint32_t x = valid[j] ? (qam_levels4(er, ei, qp) ^ labels_to_levels(sent[j], qp)) : 0u;
+                                qam_count4(x, qp, se, be);
+                            }
+                            counted = true;
+                        }
+                    } else {
+                        if (slicer || (certpath && mp.cert == 1)) {
+#pragma unroll
+                            for (int j = 0; j < BQ; ++j) {
+                                const cx<T> e4[4] = {est[4 * j], est[4 * j + 1], est[4 * j + 2], est[4 * j + 3]};
+                                if (valid[j]) {                  // (a bin outside the band holds no symbols: nothing to certify either)
+                                    if (slicer) walk_qam_count4<false>(mp, s_table, e4, sent[j], se, be);
+                                    else walk_qam_count4<true>(mp, s_table, e4, sent[j], se, be);
+                                }
+                            }
+                            counted = true;
+                        }
+                    }
+                }
+                if (!counted) {
                 int dec[BQ * NT];
                 if constexpr (ABL & 16) {
 #pragma unroll
@@ -591,6 +624,7 @@ __global__ __launch_bounds__(64 * NR, WPS) void k_run_mimo_ofdm_tdl_wave(MimoTdl
                     const unsigned x = valid[i / NT] ? (((sent[i / NT] >> (8 * (i % NT))) & 0xFFu) ^ (unsigned)dec[i]) : 0u;
                     se += (x != 0u);
                     be += __popc(x);
+                }
                 }
             }
         }
