@@ -711,7 +711,18 @@ int launch_mimo_tdl_wave(mcle_ctx* ctx, const MimoTdlParams& pp, int method, uin
 // complex64 3 / complex128 2; 2048: 2 / 1.  Subcarriers per decode work item: 2 where a wavefront has at least two.
 // (complex64 at 1024: three -- 4.47 ms per 83 886 realizations with 12 spilled registers against 4.89 at two, where nothing spills
 //  and the channel's delayed samples are double-buffered, and 4.91 at four: scripts/experiments/r05_calls.txt [call 7])
-template <typename T, int N> constexpr int mimo_tdl_wave_wps() { return N >= 2048 ? (sizeof(T) == 8 ? 1 : 2) : (sizeof(T) == 8 ? 2 : 3); }
+// (round 6: at 256 points the LDS admits more workgroups than that bound and the kernels fit 167 / 127 registers: three / four
+//  wavefronts per SIMD there; at 512 the tighter bounds spill 92 / 29 registers and stay (profiles/r06/f1_family_rates.log))
+#ifndef MCLE_MIMO_TDL_WPS_256_F64
+#define MCLE_MIMO_TDL_WPS_256_F64 3
+#endif
+#ifndef MCLE_MIMO_TDL_WPS_256_F32
+#define MCLE_MIMO_TDL_WPS_256_F32 4
+#endif
+template <typename T, int N> constexpr int mimo_tdl_wave_wps() {
+    if (N <= 256) return sizeof(T) == 8 ? MCLE_MIMO_TDL_WPS_256_F64 : MCLE_MIMO_TDL_WPS_256_F32;
+    return N >= 2048 ? (sizeof(T) == 8 ? 1 : 2) : (sizeof(T) == 8 ? 2 : 3);
+}
 template <int N, int NR> constexpr int mimo_tdl_wave_bq() { return N / (64 * NR) >= 2 ? 2 : 1; }
 // the polynomial order whose coefficients are parked in registers (the order of the benchmark's Doppler in each arithmetic);
 // every other order runs the run-time-order kernels (KT = 0)
