@@ -20,7 +20,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(REPO, "pyphysim_amd", "csrc")
 LLVM = "/opt/rocm/lib/llvm/bin"
 # kernels listed per translation unit (every *.o of the in-tree build is read: `make -C pyphysim_amd/csrc` first)
-PREFIXES = ("k_run_", "k_mimo_filters", "k_tdl_symbol_polys", "k_mimo_tdl_symbol_polys", "k_mimo_flat_", "k_ia_solve_links",
+PREFIXES = ("k_run_", "k_link_walk", "k_mimo_filters", "k_tdl_symbol_polys", "k_mimo_tdl_symbol_polys", "k_mimo_flat_", "k_ia_solve_links",
             "k_ia_link", "k_bd_solve_links", "k_bd_link", "k_ofdm_mod_1024_mfma", "k_ofdm_demod_1024_mfma", "k_jakes_blocks",
             "k_jakes_mfma")
 KEYS = (".vgpr_count", ".agpr_count", ".sgpr_count", ".vgpr_spill_count", ".sgpr_spill_count",
@@ -31,7 +31,11 @@ KEYS = (".vgpr_count", ".agpr_count", ".sgpr_count", ".vgpr_spill_count", ".sgpr
 DEFAULT = [
     # config 4 family (pipeline_mimo_planar.hip: run_mimo_ofdm_planar_t): 1024 with four receive antennas = radix-16 passes
     # (complex128 fused, two per SIMD; complex64 unfused, four), every other shape the radix-4 table
-    r"k_run_mimo_ofdm_qw<3, 0>", r"k_run_mimo_ofdm_planar<double, 1024, [1-4], 4, 4, 2, 12>", r"k_run_mimo_ofdm_planar<float, 1024, [1-4], 4, 4, 4, 4>",
+    # (round 6: complex128 4 x 4 inside the full-band / even-prefix / certificate envelope = the part-wave kernels -- pw<NW, decision form,
+    #  wavefronts per SIMD, 0>: 512 / 1024 at three, 2048 at two -- and at 256 the full-wave kernel fw<antennas, decision form, 3, 0>,
+    #  also for 2 x 2; the planar kernels below serve everything outside that envelope)
+    r"k_run_mimo_ofdm_pw<[24], [1-4], 3, 0>", r"k_run_mimo_ofdm_pw<8, [1-4], 2, 0>", r"k_run_mimo_ofdm_fw<[24], [1-4], 3, 0>",
+    r"k_run_mimo_ofdm_planar<double, 1024, [1-4], 4, 4, 2, 12>", r"k_run_mimo_ofdm_planar<float, 1024, [1-4], 4, 4, 4, 4>",
     r"k_run_mimo_ofdm_planar<(double|float), 256, [12], 2, 2, 2, 0>", r"k_run_mimo_ofdm_planar<(double|float), 256, [1-3], 3, 3, 2, 0>",
     r"k_run_mimo_ofdm_planar<(double|float), 256, [1-4], 4, 2, 3, 0>",
     r"k_run_mimo_ofdm_planar<(double|float), 512, [12], 2, 2, 3, 0>", r"k_run_mimo_ofdm_planar<(double|float), 512, [1-3], 3, 3, 2, 0>",
@@ -49,7 +53,7 @@ DEFAULT = [
     r"k_run_mimo_ofdm_tdl_wave<", r"k_mimo_tdl_symbol_polys<", r"k_run_mimo_ofdm_tdl<(float|double), (64|128), [24]>",
     # configs 1 / 2, config 5, f6, the flat MIMO application
     r"k_run_flat_mfma<", r"k_run_flat<double", r"k_run_flat<float, \d+, 0>", r"k_ia_solve_links<", r"k_ia_link<", r"k_bd_solve_links",
-    r"k_bd_link<", r"k_mimo_flat_",
+    r"k_bd_link<", r"k_mimo_flat_", r"k_link_walk<",     # (round 6: the packed walk for an even number of columns >= 128; k_ia_link / k_bd_link otherwise)
 ]
 
 
