@@ -719,11 +719,29 @@ int launch_mimo_tdl_wave(mcle_ctx* ctx, const MimoTdlParams& pp, int method, uin
 #ifndef MCLE_MIMO_TDL_WPS_256_F32
 #define MCLE_MIMO_TDL_WPS_256_F32 4
 #endif
+// 512 points: ONE bin per decode work item frees the registers for one more wavefront per SIMD -- complex128 three instead of two:
+// 1.09 -> 1.39e7 realizations/s (two bins at three wavefronts spill 92 registers); complex64: MCLE_MIMO_TDL_512_F32_BQ1 (A/B)
+#ifndef MCLE_MIMO_TDL_512_F64_BQ1
+#define MCLE_MIMO_TDL_512_F64_BQ1 1
+#endif
+#ifndef MCLE_MIMO_TDL_512_F32_BQ1
+#define MCLE_MIMO_TDL_512_F32_BQ1 1
+#endif
+#ifndef MCLE_MIMO_TDL_1024_F32_BQ1
+#define MCLE_MIMO_TDL_1024_F32_BQ1 0     // complex64 at 1024: one bin per work item at four wavefronts per SIMD (A/B: 2.026 against 2.033e7, not adopted)
+#endif
 template <typename T, int N> constexpr int mimo_tdl_wave_wps() {
+    if (N == 1024 && sizeof(T) == 4 && MCLE_MIMO_TDL_1024_F32_BQ1) return 4;
+    if (N == 512 && sizeof(T) == 8 && MCLE_MIMO_TDL_512_F64_BQ1) return 3;
+    if (N == 512 && sizeof(T) == 4 && MCLE_MIMO_TDL_512_F32_BQ1) return 4;
     if (N <= 256) return sizeof(T) == 8 ? MCLE_MIMO_TDL_WPS_256_F64 : MCLE_MIMO_TDL_WPS_256_F32;
     return N >= 2048 ? (sizeof(T) == 8 ? 1 : 2) : (sizeof(T) == 8 ? 2 : 3);
 }
 template <int N, int NR> constexpr int mimo_tdl_wave_bq() { return N / (64 * NR) >= 2 ? 2 : 1; }
+template <typename T, int N, int NR> constexpr int mimo_tdl_wave_bq_t() {
+    if (N == 1024 && sizeof(T) == 4 && MCLE_MIMO_TDL_1024_F32_BQ1) return 1;
+    return (N == 512 && ((sizeof(T) == 8 && MCLE_MIMO_TDL_512_F64_BQ1) || (sizeof(T) == 4 && MCLE_MIMO_TDL_512_F32_BQ1))) ? 1 : mimo_tdl_wave_bq<N, NR>();
+}
 // the polynomial order whose coefficients are parked in registers (the order of the benchmark's Doppler in each arithmetic);
 // every other order runs the run-time-order kernels (KT = 0)
 template <typename T> constexpr int mimo_tdl_wave_kf() { return sizeof(T) == 8 ? 5 : 2; }
@@ -735,7 +753,7 @@ int run_mimo_tdl_wave_size(mcle_ctx* ctx, int nt, int nr, const MimoTdlParams& p
     if (KT > 0 && pp.K != KT) return MCLE_E_UNSUPPORTED;
 #define MCLE_WAVE_GEOM(NT_, NR_)                                                                                              \
     if (nt == NT_ && nr == NR_)                                                                                               \
-        return launch_mimo_tdl_wave<T, N, NT_, NR_, KT, mimo_tdl_wave_bq<N, NR_>(), mimo_tdl_wave_wps<T, N>()>(               \
+        return launch_mimo_tdl_wave<T, N, NT_, NR_, KT, mimo_tdl_wave_bq_t<T, N, NR_>(), mimo_tdl_wave_wps<T, N>()>(          \
             ctx, pp, method, seed, first, count, d_counters, d_sym, d_bit);
     MCLE_WAVE_GEOM(1, 1) MCLE_WAVE_GEOM(1, 2) MCLE_WAVE_GEOM(2, 2) MCLE_WAVE_GEOM(1, 3) MCLE_WAVE_GEOM(2, 3) MCLE_WAVE_GEOM(3, 3)
     MCLE_WAVE_GEOM(1, 4) MCLE_WAVE_GEOM(2, 4) MCLE_WAVE_GEOM(3, 4) MCLE_WAVE_GEOM(4, 4)
