@@ -24,6 +24,8 @@
 // A workgroup is four independent wavefronts that share the tables (constellation x 2, Box-Muller): 46 KiB of LDS -> three
 // workgroups per CU, three wavefronts per SIMD at a 168-register bound.
 // 2 x 2: TWO realizations per wavefront (lane = (realization, antenna, group)); the 4 x 4 x 4 contractions take a block-diagonal A.
+// complex64 (k_run_mimo_ofdm_fw<float, ...>): the same kernel with the two contractions as reduce-scatters on the VALU (fw_contract:
+// products per lane, v_permlane32_swap / v_permlane16_swap and adds) -- the f32 MFMA forms have K = 1 and cannot contract across lanes.
 // Envelope: fft_size 256, 4 x 4 or 2 x 2, full band (num_used = 256), even cyclic prefix, a constellation with a certificate or the
 // slicer; anything else stays on the planar kernel.
 #include "mimo_planar_common.hpp"
@@ -42,21 +44,58 @@ __host__ __device__ __forceinline__ int fw_mtime(int h, int c) { return (c & 3) 
 // NA = antennas per side (Nt = Nr = NA): 4 = one realization per wavefront; 2 = TWO realizations per wavefront -- lane = (realization,
 // antenna, 16-point group), the contractions on the same instruction with a block-diagonal A operand (lane (row, col) supplies
 // H[col mod 2][row mod 2] of ITS realization where row div 2 = col div 2 mod 2, and 0 elsewhere), per-lane Philox counters.
-template <int NA, int DEC, int WPS, int ABL = 0>
-__global__ __launch_bounds__(256, WPS) void k_run_mimo_ofdm_fw(MimoParams pp, ModemParams<double> mp, uint64_t seed, uint64_t first,
-                                                               uint64_t count, const double2* __restrict__ g_tw,
-                                                               const double2* __restrict__ g_recs, mcle_counters* counters,
+// lanes l and l ^ 16 exchange (v_permlane16_swap_b32): x = {even rows: own a, odd rows: the partner's b}, y = {even rows: the partner's a,
+// odd rows: own b}
+__device__ __forceinline__ void fw_swap16_pair(float a, float b, float& x, float& y) {
+    const auto v = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    x = __uint_as_float(v[0]);
+    y = __uint_as_float(v[1]);
+}
+// complex64 (the last day of round 6): the contraction over the four lanes of a column as a reduce-scatter on the VALU -- the f32 MFMA
+// forms have K = 1 (no contraction across lanes).  Lane (row k, col) holds x_k and the row-k COLUMN M[0..NA-1][k] of the matrix; every lane
+// forms its NA products, and one (NA = 2) or two (NA = 4) swap-and-add steps leave sum_k M[i][k] x_k + acc_i in lane (row i, col):
+// rows k and k ^ 2 (v_permlane32_swap), then k and k ^ 1 (v_permlane16_swap).  NA = 2: two realizations per wavefront, rows (rz, a):
+// only the second step, which stays inside a realization.
+template <int NA>
+__device__ __forceinline__ float2 fw_contract(const float2 (&Mc)[NA], float2 x, float2 acc) {
+    float2 p[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) p[i] = cmul(Mc[i], x);
+    float x0, y0, x1, y1;
+    if constexpr (NA == 4) {
+        float2 s02, s13;
+        swap32_pair(p[0].x, p[2].x, x0, y0);
+        swap32_pair(p[0].y, p[2].y, x1, y1);
+        s02 = make_float2(x0 + y0, x1 + y1);
+        swap32_pair(p[1].x, p[3].x, x0, y0);
+        swap32_pair(p[1].y, p[3].y, x1, y1);
+        s13 = make_float2(x0 + y0, x1 + y1);
+        fw_swap16_pair(s02.x, s13.x, x0, y0);
+        fw_swap16_pair(s02.y, s13.y, x1, y1);
+    } else {
+        fw_swap16_pair(p[0].x, p[1].x, x0, y0);
+        fw_swap16_pair(p[0].y, p[1].y, x1, y1);
+    }
+    return make_float2((x0 + y0) + acc.x, (x1 + y1) + acc.y);
+}
+
+template <typename T> constexpr int fw_plane_bytes() { return sizeof(T) == 8 ? kFwPlane * 8 : 8192; }   // (>= the 8 KiB of the word-pair hand-over)
+
+template <typename T, int NA, int DEC, int WPS, int ABL = 0>
+__global__ __launch_bounds__(256, WPS) void k_run_mimo_ofdm_fw(MimoParams pp, ModemParams<T> mp, uint64_t seed, uint64_t first,
+                                                               uint64_t count, const cx<T>* __restrict__ g_tw,
+                                                               const cx<T>* __restrict__ g_recs, mcle_counters* counters,
                                                                uint32_t* __restrict__ sym_out, uint32_t* __restrict__ bit_out) {
-    using T = double;
     constexpr int N = 256, NT = NA, NR = NA, kRec = d64_rec<NT, NR>(), RZ = 4 / NA, LPR = 64 / RZ;     // realizations / lanes per realization
     static_assert(NA == 2 || NA == 4, "geometry");
     extern __shared__ __attribute__((aligned(16))) char fw_smem[];
-    T* s_R = reinterpret_cast<T*>(fw_smem);                                  // [4 wavefronts][kFwPlane]
-    cx<T>* s_table = reinterpret_cast<cx<T>*>(s_R + 4 * kFwPlane);            // [tab_len] constellation
+    constexpr int kPlaneT = fw_plane_bytes<T>() / (int)sizeof(T);            // scalars per wavefront plane
+    T* s_R = reinterpret_cast<T*>(fw_smem);                                  // [4 wavefronts][kPlaneT]
+    cx<T>* s_table = reinterpret_cast<cx<T>*>(s_R + 4 * kPlaneT);             // [tab_len] constellation
     cx<T>* s_txtab = s_table + ((mp.M + 1) & ~1);                             // [tab_len] constellation x tx scale
     cx<T>* s_rec = s_txtab + ((mp.M + 1) & ~1);                               // [4 wavefronts][RZ][kRec + 1]
-    constexpr int kBm = (kBmLdsDoubles + 1) & ~1;
-    double* s_bm = reinterpret_cast<double*>(s_rec + 4 * RZ * (kRec + 1));    // [kBm] Box-Muller tables
+    constexpr int kBm = sizeof(T) == 8 ? ((kBmLdsDoubles + 1) & ~1) : 0;
+    double* s_bm = reinterpret_cast<double*>(reinterpret_cast<char*>(s_rec + 4 * RZ * (kRec + 1)) + (sizeof(T) == 4 ? 8 : 0));    // [kBm] Box-Muller tables (complex128)
     unsigned char* s_lab = reinterpret_cast<unsigned char*>(s_bm + kBm);     // [4][kFwLabBytes] (16-byte aligned: everything before is)
     __shared__ WgTotals totals[4];
 
@@ -73,11 +112,11 @@ __global__ __launch_bounds__(256, WPS) void k_run_mimo_ofdm_fw(MimoParams pp, Mo
         s_table[m] = c;
         s_txtab[m] = cscale(c, tx_scale);
     }
-    bm_tables_to_lds(s_bm, tid, 256);
+    if constexpr (sizeof(T) == 8) bm_tables_to_lds(s_bm, tid, 256);
     if (lane == 0) wg_zero(totals[w]);
     __syncthreads();                                                         // the only workgroup barrier: the shared tables
 
-    T* s_mine = s_R + w * kFwPlane;
+    T* s_mine = s_R + w * kPlaneT;
     uint2* s_words = reinterpret_cast<uint2*>(s_mine);                      // [16 registers][64 lanes] word pairs (8 KiB of the plane)
     unsigned char* lab_mine = s_lab + w * kFwLabBytes;
     cx<T>* rec_mine = s_rec + w * RZ * (kRec + 1);
@@ -113,7 +152,18 @@ __global__ __launch_bounds__(256, WPS) void k_run_mimo_ofdm_fw(MimoParams pp, Mo
             gA = rc[NT * NR + rr * NR + aa];                                 // G[rr][aa]
             if (NA < 4 && rzc != rzr) hA = gA = mk<T>(0, 0);
         }
-        const bool skipped = rec_mine[rz * (kRec + 1) + 2 * NT * NR].x != 0.0;
+        // complex64: the lane's COLUMNS of H and G for the VALU contraction (row k = this lane's antenna: H[0..NR-1][k], G[0..NT-1][k])
+        [[maybe_unused]] cx<T> Hc[NA], Gc[NA];
+        if constexpr (sizeof(T) == 4) {
+            const int rowi = ln0 >> 4, rzr = rowi / NA, aa = rowi % NA;
+            const cx<T>* rc = rec_mine + rzr * (kRec + 1);
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                Hc[i] = rc[i * NT + aa];
+                Gc[i] = rc[NT * NR + i * NR + aa];
+            }
+        }
+        const bool skipped = rec_mine[rz * (kRec + 1) + 2 * NT * NR].x != (T)0;
         unsigned se = 0, be = 0;
         for (int os = 0; os < pp.n_ofdm_sym; ++os) {
             // ---- labels: DATA block `lane` of the symbol = subcarriers d = 4 lane .. 4 lane + 3, four antennas each (full band:
@@ -146,7 +196,7 @@ __global__ __launch_bounds__(256, WPS) void k_run_mimo_ofdm_fw(MimoParams pp, Mo
 #pragma unroll
                 for (int u = 0; u < 16; ++u) {
                     const uint32_t lb = (wds[u >> 2] >> (8 * (u & 3))) & 0xFFu;
-                    if constexpr (ABL & 32) v[u] = mk<T>((T)lb, 1.0);
+                    if constexpr (ABL & 32) v[u] = mk<T>((T)lb, (T)1);
                     else v[u] = s_txtab[lb];
                 }
             }
@@ -222,12 +272,14 @@ __global__ __launch_bounds__(256, WPS) void k_run_mimo_ofdm_fw(MimoParams pp, Mo
                         else z = cn_words(nw[cc].x, nw[cc].y, sigma, s_bm);
                         if constexpr (ABL & 256) {
                             v[c] = cadd(v[c], z);
-                        } else {
+                        } else if constexpr (sizeof(T) == 8) {
                             T yr = __builtin_amdgcn_mfma_f64_4x4x4f64(hre, v[c].x, z.x, 0, 0, 0);
                             T yi = __builtin_amdgcn_mfma_f64_4x4x4f64(him, v[c].x, z.y, 0, 0, 0);
                             yr = __builtin_amdgcn_mfma_f64_4x4x4f64(nhim, v[c].y, yr, 0, 0, 0);
                             yi = __builtin_amdgcn_mfma_f64_4x4x4f64(hre, v[c].y, yi, 0, 0, 0);
                             v[c] = mk<T>(yr, yi);
+                        } else {
+                            v[c] = fw_contract<NA>(Hc, v[c], z);
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -279,14 +331,18 @@ __global__ __launch_bounds__(256, WPS) void k_run_mimo_ofdm_fw(MimoParams pp, Mo
 #pragma unroll
                     for (int jj = 0; jj < 4; ++jj) {
                         const int u = 4 * i + jj;
-                        T er = __builtin_amdgcn_mfma_f64_4x4x4f64(gre, v[u].x, 0.0, 0, 0, 0);
-                        T ei = __builtin_amdgcn_mfma_f64_4x4x4f64(gim, v[u].x, 0.0, 0, 0, 0);
-                        er = __builtin_amdgcn_mfma_f64_4x4x4f64(ngim, v[u].y, er, 0, 0, 0);
-                        ei = __builtin_amdgcn_mfma_f64_4x4x4f64(gre, v[u].y, ei, 0, 0, 0);
-                        e[jj] = mk<T>(er, ei);
+                        if constexpr (sizeof(T) == 8) {
+                            T er = __builtin_amdgcn_mfma_f64_4x4x4f64(gre, v[u].x, 0.0, 0, 0, 0);
+                            T ei = __builtin_amdgcn_mfma_f64_4x4x4f64(gim, v[u].x, 0.0, 0, 0, 0);
+                            er = __builtin_amdgcn_mfma_f64_4x4x4f64(ngim, v[u].y, er, 0, 0, 0);
+                            ei = __builtin_amdgcn_mfma_f64_4x4x4f64(gre, v[u].y, ei, 0, 0, 0);
+                            e[jj] = mk<T>(er, ei);
+                        } else {
+                            e[jj] = fw_contract<NA>(Gc, v[u], mk<T>(0, 0));
+                        }
                         tx[jj] = (int)((wds[i] >> (8 * jj)) & 0xFFu);
                     }
-                    walk_decide<DEC, 4>(mp, s_table, nullptr, e, tx, se, be);
+                    walk_decide<T, DEC, 4>(mp, s_table, nullptr, e, tx, se, be);
                 }
             } else {
                 se += (unsigned)(v[0].x + v[15].y == 0.5);
@@ -309,27 +365,26 @@ __global__ __launch_bounds__(256, WPS) void k_run_mimo_ofdm_fw(MimoParams pp, Mo
     wg_flush_waves<4>(totals, counters, (unsigned long long)per_sym * pp.n_ofdm_sym, (unsigned long long)per_sym * pp.n_ofdm_sym * mp.bits);
 }
 
-template <int NA, int WPS, int ABL = 0>
+template <typename T, int NA, int WPS, int ABL = 0>
 static int launch_mimo_ofdm_fw(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, uint64_t seed, uint64_t first, uint64_t count,
                                mcle_counters* d_counters, uint32_t* d_sym, uint32_t* d_bit) {
-    using T = double;
     constexpr int N = 256, NT = NA, NR = NA, kRec = d64_rec<NT, NR>(), RZ = 4 / NA;
     int rc;
     void* tw = nullptr;
-    if ((rc = ctx->get_twiddles(N, MCLE_F64, &tw))) return rc;
+    if ((rc = ctx->get_twiddles(N, sizeof(T) == 8 ? MCLE_F64 : MCLE_F32, &tw))) return rc;
     MimoParams pp{cfg->cp_size, cfg->num_used, cfg->n_ofdm_sym, cfg->mmse, cfg->noise_var};
     ModemParams<T> mp = pipe_modem<T>(ctx, cfg->demod_method);
     const int dec = walk_dec_kind(ctx, mp);
     mp.grid.G = 0;
     const size_t tab_len = ((size_t)mp.M + 1) & ~(size_t)1;
-    const size_t lds = (size_t)4 * kFwPlane * sizeof(T) + (2 * tab_len + 4 * RZ * (kRec + 1)) * sizeof(cx<T>) +
-                       (size_t)((kBmLdsDoubles + 1) & ~1) * sizeof(double) + 4 * kFwLabBytes;
+    const size_t lds = (size_t)4 * fw_plane_bytes<T>() + (2 * tab_len + 4 * RZ * (kRec + 1)) * sizeof(cx<T>) +
+                       (sizeof(T) == 8 ? (size_t)((kBmLdsDoubles + 1) & ~1) * sizeof(double) : 8) + 4 * kFwLabBytes;
     MCLE_REQUIRE(lds + 512 <= (size_t)160 * 1024, "full-wave MIMO-OFDM kernel: %zu B of LDS do not fit", lds);
-    auto kern = k_run_mimo_ofdm_fw<NA, WDEC_SLICER, WPS, ABL>;
+    auto kern = k_run_mimo_ofdm_fw<T, NA, WDEC_SLICER, WPS, ABL>;
     switch (dec) {
-        case WDEC_QAM_CERT: kern = k_run_mimo_ofdm_fw<NA, WDEC_QAM_CERT, WPS, ABL>; break;
-        case WDEC_QUAD_CERT: kern = k_run_mimo_ofdm_fw<NA, WDEC_QUAD_CERT, WPS, ABL>; break;
-        case WDEC_AXIS4_CERT: kern = k_run_mimo_ofdm_fw<NA, WDEC_AXIS4_CERT, WPS, ABL>; break;
+        case WDEC_QAM_CERT: kern = k_run_mimo_ofdm_fw<T, NA, WDEC_QAM_CERT, WPS, ABL>; break;
+        case WDEC_QUAD_CERT: kern = k_run_mimo_ofdm_fw<T, NA, WDEC_QUAD_CERT, WPS, ABL>; break;
+        case WDEC_AXIS4_CERT: kern = k_run_mimo_ofdm_fw<T, NA, WDEC_AXIS4_CERT, WPS, ABL>; break;
         default: break;
     }
     MCLE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -355,7 +410,7 @@ static int launch_mimo_ofdm_fw(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, uin
 }
 
 // 0 = launched; MCLE_E_UNSUPPORTED = outside the envelope (the caller stays on the planar kernel)
-int run_mimo_ofdm_fw(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, uint64_t seed, uint64_t first, uint64_t count,
+int run_mimo_ofdm_fw(mcle_ctx* ctx, int dtype, const mcle_mimo_ofdm_cfg* cfg, uint64_t seed, uint64_t first, uint64_t count,
                      mcle_counters* d_counters, uint32_t* d_sym, uint32_t* d_bit) {
     if (!(cfg->fft_size == 256 && cfg->nt == cfg->nr && (cfg->nt == 4 || cfg->nt == 2) && cfg->num_used == 256 && (cfg->cp_size & 1) == 0))
         return MCLE_E_UNSUPPORTED;
@@ -364,20 +419,29 @@ int run_mimo_ofdm_fw(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, uint64_t seed
         ModemParams<double> mp = pipe_modem<double>(ctx, cfg->demod_method);
         if (walk_dec_kind(ctx, mp) == WDEC_GENERIC) return MCLE_E_UNSUPPORTED;     // no certificate: the planar kernel's candidate grid
     }
+    const bool two = ctx->opt[MCLE_OPT_F64_THREADS] == 262;
+    if (dtype == MCLE_F32) {
+        // complex64: registers bounded for TWO wavefronts per SIMD (nothing spilled): 1.46e8 realizations/s at 4 x 4 and 3.25e8 at 2 x 2 against
+        // 1.30 / 2.69e8 at three (34 - 62 spilled registers) and 1.05 / 2.33e8 at four; the planar kernel: 1.29 / 1.67e8.  262: three.
+        if (cfg->nt == 2)
+            return two ? launch_mimo_ofdm_fw<float, 2, 3>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit)
+                       : launch_mimo_ofdm_fw<float, 2, 2>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
+        return two ? launch_mimo_ofdm_fw<float, 4, 3>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit)
+                   : launch_mimo_ofdm_fw<float, 4, 2>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
+    }
 #ifdef MCLE_EXPERIMENTS
     switch ((int)ctx->opt[MCLE_OPT_F64_VARIANT]) {
-#define MCLE_FW_ABL(V_) case V_: if (cfg->nt == 4) return launch_mimo_ofdm_fw<4, 3, V_>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit); break;
+#define MCLE_FW_ABL(V_) case V_: if (cfg->nt == 4) return launch_mimo_ofdm_fw<double, 4, 3, V_>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit); break;
         MCLE_FW_ABL(32) MCLE_FW_ABL(64) MCLE_FW_ABL(128) MCLE_FW_ABL(256) MCLE_FW_ABL(512) MCLE_FW_ABL(1024) MCLE_FW_ABL(2016)
 #undef MCLE_FW_ABL
         default: break;
     }
 #endif
-    const bool two = ctx->opt[MCLE_OPT_F64_THREADS] == 262;
     if (cfg->nt == 2)
-        return two ? launch_mimo_ofdm_fw<2, 2>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit)
-                   : launch_mimo_ofdm_fw<2, 3>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
-    return two ? launch_mimo_ofdm_fw<4, 2>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit)
-               : launch_mimo_ofdm_fw<4, 3>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
+        return two ? launch_mimo_ofdm_fw<double, 2, 2>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit)
+                   : launch_mimo_ofdm_fw<double, 2, 3>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
+    return two ? launch_mimo_ofdm_fw<double, 4, 2>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit)
+               : launch_mimo_ofdm_fw<double, 4, 3>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
 }
 
 }  // namespace mcle

@@ -527,7 +527,7 @@ int run_mimo_ofdm_qw(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, uint64_t seed
                      mcle_counters* d_counters, uint32_t* d_sym, uint32_t* d_bit);
 
 // pipeline_mimo_fw.hip: one realization per wavefront at fft_size 256 (complex128, 4 x 4; MCLE_E_UNSUPPORTED outside its envelope)
-int run_mimo_ofdm_fw(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, uint64_t seed, uint64_t first, uint64_t count,
+int run_mimo_ofdm_fw(mcle_ctx* ctx, int dtype, const mcle_mimo_ofdm_cfg* cfg, uint64_t seed, uint64_t first, uint64_t count,
                      mcle_counters* d_counters, uint32_t* d_sym, uint32_t* d_bit);
 
 // pipeline_mimo_pw.hip: 1 / NW of the time samples per wavefront at fft_size 512 (NW = 2) and 1024 (NW = 4), decode on the matrix cores
@@ -547,13 +547,13 @@ static int run_mimo_ofdm_planar_t(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, 
     // profiles/r04/c4_f64_r16_ab.log).  MCLE_OPT_F64_THREADS: 512 = radix-4, two antennas per thread; 256 = radix-4, four
     // antennas per thread, twiddles in registers.  MCLE_OPT_F64_VARIANT 1 .. 3: timing bounds on the 512-thread form.
     if (n == 256 && nt == nr && (nt == 4 || nt == 2)) {
-        if constexpr (F64) {
+        {   // (either arithmetic since the last day of round 6: complex64 contracts on the VALU, pipeline_mimo_fw.hip)
             // round 6: the FULL-WAVE kernel (pipeline_mimo_fw.hip: a realization is one wavefront -- the quarter-wave kernel's register
             // passes without its radix-4 exchange stage, channel AND decode on v_mfma_f64_4x4x4, no workgroup barrier).
             // MCLE_OPT_F64_THREADS = 261: the planar radix-4 form of rounds 3-5; 262: full-wave bounded for two wavefronts per SIMD.
             const long long thr = ctx->opt[MCLE_OPT_F64_THREADS];
             if (thr == 0 || thr == 260 || thr == 262) {
-                const int rq = run_mimo_ofdm_fw(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
+                const int rq = run_mimo_ofdm_fw(ctx, F64 ? MCLE_F64 : MCLE_F32, cfg, seed, first, count, d_counters, d_sym, d_bit);
                 if (rq != MCLE_E_UNSUPPORTED) return rq;
             }
         }

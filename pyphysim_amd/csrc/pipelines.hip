@@ -1094,7 +1094,7 @@ int run_tdl_impl(mcle_ctx* ctx, const mcle_ofdm_tdl_cfg* cfg, uint64_t seed, uin
 namespace mcle {
 // pipeline_mimo_mfma.hip: f32, FFT 1024, 4x4 on the matrix cores; MCLE_E_UNSUPPORTED outside that envelope
 // pipeline_mimo_fw.hip: one realization (4 x 4) / two realizations (2 x 2) per wavefront at fft_size 256, complex128
-int run_mimo_ofdm_fw(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, uint64_t seed, uint64_t first, uint64_t count,
+int run_mimo_ofdm_fw(mcle_ctx* ctx, int dtype, const mcle_mimo_ofdm_cfg* cfg, uint64_t seed, uint64_t first, uint64_t count,
                      mcle_counters* d_counters, uint32_t* d_sym, uint32_t* d_bit);
 int run_mimo_ofdm_planar(mcle_ctx* ctx, int dtype, const mcle_mimo_ofdm_cfg* cfg, uint64_t seed, uint64_t first, uint64_t count,
                       mcle_counters* d_counters, uint32_t* d_sym, uint32_t* d_bit);
@@ -1178,11 +1178,11 @@ int mcle_run_mimo_ofdm(mcle_ctx* ctx, int dtype, const mcle_mimo_ofdm_cfg* cfg, 
     // 2x2 at 256 points: the generic kernel (four realizations per 256-thread workgroup) is the faster one -- 1.65 against 1.06e8
     // realizations/s in complex64, 1.01 against 0.98e8 in complex128 (profiles/r05/f32_family_rates.json, f64_family_rates.json)
     const bool generic_is_faster = cfg->fft_size == 256 && cfg->nt == 2 && cfg->nr == 2;
-    if (generic_is_faster && dtype == MCLE_F64) {
+    if (generic_is_faster && !(dtype == MCLE_F32 && ctx->opt[MCLE_OPT_NO_MFMA])) {
         // ... and since round 6 the full-wave kernel (pipeline_mimo_fw.hip, two realizations per wavefront) beats both inside its envelope
         const long long thr = ctx->opt[MCLE_OPT_F64_THREADS];
         if (thr == 0 || thr == 260 || thr == 262) {
-            rc = run_mimo_ofdm_fw(ctx, cfg, seed, first, count, d_counters, d_sym_err, d_bit_err);
+            rc = run_mimo_ofdm_fw(ctx, dtype, cfg, seed, first, count, d_counters, d_sym_err, d_bit_err);
             if (rc != MCLE_E_UNSUPPORTED) return rc;
         }
     }

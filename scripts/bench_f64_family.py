@@ -26,7 +26,7 @@ for fft, nt, nr in ((256, 2, 2), (256, 4, 4), (512, 2, 2), (512, 4, 4), (1024, 2
             ("generic_mindist", 1, _lib.DEMOD_MINDIST, 1)]
     if DT == "f32" and (fft, nt, nr) == (1024, 4, 4):
         legs += [("mfma_mindist", 0, _lib.DEMOD_MINDIST, 0), ("mfma_slicer", 0, _lib.DEMOD_QAM_SLICER, 0)]
-    if DT == "f64" and ((nt == 4 and nr == 4) or (fft, nt, nr) == (256, 2, 2)):
+    if (DT == "f64" and ((nt == 4 and nr == 4) or (fft, nt, nr) == (256, 2, 2))) or (DT == "f32" and (fft, nt, nr) in ((256, 4, 4), (256, 2, 2))):
         # round 6: the default at the 4 x 4 shapes is the full-wave (256) / part-wave (512, 1024, 2048) kernel; the planar form of rounds 3-5 next to it
         legs += [("planar_mindist", 0, _lib.DEMOD_MINDIST, 261), ("planar_slicer", 0, _lib.DEMOD_QAM_SLICER, 261)]
     for name, generic, method, planar in legs:

@@ -171,3 +171,37 @@ def test_two_by_two_against_the_oracle_and_the_planar_kernel_at_depth(engine):
     a = _run22(engine, zf, 0, 4097, _lib.DEMOD_MINDIST, 0)[0]
     b = _run22(engine, zf, 0, 4097, _lib.DEMOD_MINDIST, 261)[0]
     assert a["n_skipped"] == b["n_skipped"] and a["n_realizations"] == b["n_realizations"] and a["sym_errors"] == b["sym_errors"]
+
+
+# ---- complex64 at fft_size 256 (k_run_mimo_ofdm_fw<float, ...>: the contractions as reduce-scatters on the VALU) ----
+@pytest.mark.parametrize("na", [4, 2])
+@pytest.mark.parametrize("case", range(len(INSIDE)))
+def test_complex64_full_wave_against_the_planar_kernel_and_the_oracle(engine, case, na):
+    """The complex64 criteria of tests/test_gpu_planar_f32.py: |dSER| <= 1e-4 against the oracle on 24 realizations, per-realization
+    differences of boundary ties only against the planar complex64 kernel (f64_threads = 261) and against the complex128 full-wave
+    kernel over 1 203 realizations (an odd count: the 2 x 2 form's last wavefront is half empty), both register bounds."""
+    kw = INSIDE[case]
+    _set(engine, kw)
+    nv = 1.0 / omodem.dB2Linear(kw["snr_db"])
+    args = (na, na, 256, kw.get("cp_size", 16), 256, kw.get("n_ofdm_sym", 1), nv, SEED)
+    okw = dict(mod=kw["mod"], M=kw["M"], nt=na, nr=na, fft_size=256, cp_size=kw.get("cp_size", 16), num_used=None,
+               n_ofdm_sym=kw.get("n_ofdm_sym", 1), snr_db=kw["snr_db"], mmse=kw.get("mmse", True))
+    first, n = 4242, 1203
+    want = [chains.chain_mimo_ofdm(chains.PhiloxRng(SEED, r), **okw) for r in range(first, first + 24)]
+    nsym = want[0]["num_symbols"]
+    for method in [_lib.DEMOD_MINDIST] + ([_lib.DEMOD_QAM_SLICER] if kw["mod"] == "qam" else []):
+        run = lambda thr, dt: engine.run_mimo_ofdm(*args, first, n, mmse=kw.get("mmse", True), method=method, dtype=dt, per_realization=True) \
+            if thr is None else None
+        outs = {}
+        for thr in (0, 262, 261):
+            with engine.options(f64_threads=thr):
+                outs[thr] = engine.run_mimo_ofdm(*args, first, n, mmse=kw.get("mmse", True), method=method, dtype="f32", per_realization=True)
+        f64 = engine.run_mimo_ofdm(*args, first, n, mmse=kw.get("mmse", True), method=method, dtype="f64", per_realization=True)
+        for thr in (0, 262):
+            res, se, be = outs[thr]
+            assert res["n_realizations"] + res["n_skipped"] == n and res["n_symbols"] == nsym
+            assert abs(int(se[:24].sum()) - sum(w["symbol_errors"] for w in want)) <= 1e-4 * 24 * nsym + 3
+            for other in (outs[261], f64):
+                assert np.max(np.abs(se.astype(np.int64) - other[1].astype(np.int64))) <= 4
+                assert abs(int(se.astype(np.int64).sum()) - int(other[1].astype(np.int64).sum())) <= 2e-5 * n * nsym + 4
+                assert res["n_skipped"] == other[0]["n_skipped"]
