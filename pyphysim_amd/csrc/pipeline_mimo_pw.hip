@@ -519,7 +519,7 @@ static int launch_mimo_ofdm_pw(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, uin
     const int by_waves = WPS * 4 / NW;                         // wavefronts per SIMD x four SIMDs / wavefronts per workgroup
     if (per_cu > by_waves) per_cu = by_waves;
     const uint64_t resident = (uint64_t)ctx->n_cu * per_cu;
-    const uint64_t kSlice = 1ull << 18;
+    const uint64_t kSlice = 1ull << 20;          // realizations per record kernel + link kernel pair (553 MB of records; 2^18: three more tails per bench step, -0.6 %)
     const uint64_t slice = count < kSlice ? count : kSlice;
     void* recs = nullptr;
     if ((rc = ctx->scratch((size_t)slice * kRec * sizeof(cx<T>), &recs))) return rc;
