@@ -146,15 +146,15 @@ enum {
                                       rounds 2-3) instead of the planar VALU family (k_run_mimo_ofdm_planar<float>: the complex128
                                       kernels on planes of floats, 10-20 % faster at this geometry and the only fast complex64 kernel
                                       at every other one; default since round 4) */
-    MCLE_OPT_TDL_KERNEL = 13,      /* config 3 at fft_size 256 / 512 / 1024 / 2048 with every tap delay inside the cyclic prefix (<= 8 taps,
-                                      <= 256 samples, polynomial order <= 8): 0 = one realization per WAVEFRONT (k_run_ofdm_tdl_wave: no
+    MCLE_OPT_TDL_KERNEL = 13,      /* config 3 at fft_size 256 / 512 / 1024 / 2048 with <= 8 taps reaching <= 256 samples back (inside the cyclic prefix or,
+                                      since round 6, beyond it; polynomial order <= 8): 0 = one realization per WAVEFRONT (k_run_ofdm_tdl_wave: no
                                       workgroup barrier in the loop; radix-16 register passes at 1024, radix-4 stages otherwise) WHERE IT
                                       IS THE FASTER KERNEL (1024; 2048 in complex64; 256 / 512 in complex128 -- default since round 4),
                                       1 = the batched kernels of rounds 1-3 everywhere (four / two realizations per workgroup pass;
                                       complex64 at 1024: matrix cores), 2 = the wavefront kernel wherever it exists, 4 = the same with
                                       the complex64 registers at 1024 bounded for four wavefronts per SIMD instead of three (A/B) */
-    MCLE_OPT_MIMO_TDL_KERNEL = 14, /* frequency-selective MIMO-OFDM (mcle_run_mimo_ofdm_tdl) at fft_size 256 / 512 / 1024 / 2048 with every tap
-                                      delay inside the cyclic prefix (<= 8 taps, <= 256 samples): 0 = one receive antenna per WAVEFRONT
+    MCLE_OPT_MIMO_TDL_KERNEL = 14, /* frequency-selective MIMO-OFDM (mcle_run_mimo_ofdm_tdl) at fft_size 256 / 512 / 1024 / 2048 with <= 8 taps
+                                      reaching <= min(256, fft_size / 2) samples back (inside the cyclic prefix or, since round 6, beyond it): 0 = one receive antenna per WAVEFRONT
                                       (k_run_mimo_ofdm_tdl_wave, every 1 <= Nt <= Nr <= 4; default since round 5), 1 = the
                                       workgroup-cooperative kernel of rounds 1-4 (Nt = Nr in {2, 4}), 2 = the wavefront kernels with the
                                       tap polynomials' order at run time also where the parked-coefficient kernel applies (A/B) */
@@ -431,8 +431,8 @@ typedef struct mcle_mimo_ofdm_cfg {     /* C4: apps/mimo/simulate_mimo.py:68-142
 
 typedef struct mcle_mimo_ofdm_tdl_cfg { /* TdlMimoChannel (fading.py:1290-1333) + per-antenna OFDM +
                                          * one Blast filter per used subcarrier (mimo.py:577-607) */
-    int32_t nt, nr;                     /* fused: every 1 <= nt <= nr <= 4 at fft_size 256 .. 2048 with the taps inside the prefix
-                                         * (cp_size >= last delay <= min(256, fft_size / 2)); nt == nr in {2, 4} at 64 .. 2048 otherwise */
+    int32_t nt, nr;                     /* fused: every 1 <= nt <= nr <= 4 at fft_size 256 .. 2048 with the last delay <= min(256, fft_size / 2)
+                                         * (inside the prefix or beyond it); nt == nr in {2, 4} at 64 .. 2048 otherwise */
     int32_t fft_size, cp_size, num_used, n_ofdm_sym;
     int32_t demod_method;
     int32_t mmse;                       /* 1: MMSE with noise_var; 0: zero forcing */

@@ -16,7 +16,8 @@
 //     receive antenna reads every transmit antenna's time signal), inside the first receive pass between its arithmetic and its
 //     stores (r16_pass BAR: the pass runs from registers while the other antennas finish reading), after the receive transforms;
 //   * the transmit signals in natural order BEHIND THEIR CYCLIC PREFIX (hand-over through registers both ways): x_a[m - d] is
-//     base(antenna, tap) + 64 c, immediate offsets, consecutive lanes on consecutive words;
+//     base(antenna, tap) + 64 c, immediate offsets, consecutive lanes on consecutive words; a tap beyond the prefix finds the
+//     previous symbol's end in front of it (round 6: `s_hist`, written by the lane that held the sample);
 //   * receive antenna r's S Nt tap polynomials parked across the lanes of wavefront r (the record of k_mimo_tdl_symbol_polys<T, true>:
 //     register m / 2, lane 2 (s Nt + a) + m % 2) and read by v_readlane with a scalar lane index: the tap loop is a real loop
 //     (code size: Nt x 16 samples x (2 K + 4) FMAs per trip), the delays sit in one register's lanes too;
@@ -137,6 +138,12 @@ __global__ __launch_bounds__(64 * NR, WPS) void k_run_mimo_ofdm_tdl_wave(MimoTdl
     const int grid_words = grid_lds ? ((mp.grid.G * mp.grid.G + 1) & ~1) : 0;
     unsigned char* s_idx = reinterpret_cast<unsigned char*>(s_grid + grid_words);        // [NT U rounded to 16]
     unsigned* s_part = reinterpret_cast<unsigned*>(s_idx + ((NT * U + 15) & ~15));         // [2][4][2]
+    // A tap beyond the cyclic prefix (inter-symbol interference, round 6): plane positions [0, P - cp) then hold the END OF THE
+    // PREVIOUS SYMBOL -- sample m - d < -cp of the stream is x_prev[N + m - d + cp] -- kept per transmit antenna in `hist`
+    // between the symbols (zeros in front of the first one, channels/fading.py:1092-1118: the filter starts empty)
+    const bool isi = pp.dmax > cp;
+    const int HL = isi ? pitch - N - cp : 0;
+    cx<T>* s_hist = reinterpret_cast<cx<T>*>(s_part + 16);                  // [NT][HL]
     T* pr = s_all + w * 2 * pitch;                                         // transform planes of this antenna: re [0, N), im [N, 2 N)
     T* pi = pr + N;
     cx<T>* xp = reinterpret_cast<cx<T>*>(pr);                              // natural-order signal with prefix, (re, im) interleaved:
@@ -288,7 +295,18 @@ __global__ __launch_bounds__(64 * NR, WPS) void k_run_mimo_ofdm_tdl_wave(MimoTdl
                 for (int c = 0; c < R; ++c) xp[P + gi + 64 * c] = y[c];
 #pragma unroll
                 for (int c = (R > 4 ? R - 4 : 0); c < R; ++c)               // the prefix: the last P samples once more (P <= 256)
-                    if (gi + 64 * c >= N - P) xp[gi + 64 * c - (N - P)] = y[c];
+                    if (gi + 64 * c >= N - P + HL) xp[gi + 64 * c - (N - P)] = y[c];
+                if (isi) {                                                  // in front of the prefix: the previous symbol's end;
+                    cx<T>* hist = s_hist + w * HL;                          // the lane that holds sample e now held it then
+#pragma unroll
+                    for (int c = (R > 4 ? R - 4 : 0); c < R; ++c) {
+                        const int j = gi + 64 * c - (N - HL);
+                        if (j >= 0) {
+                            xp[j] = os > 0 ? hist[j] : mk<T>(0, 0);
+                            hist[j] = y[c];
+                        }
+                    }
+                }
             }
             __syncthreads();                                                // B2: every transmit signal is in place
             // ---- channel: y_r[m] = sum_s sum_a g_sra(x) x_a[m - d_s] for this lane's R samples m = gi + 64 c.  The polynomials of this
@@ -668,7 +686,8 @@ int launch_mimo_tdl_wave(mcle_ctx* ctx, const MimoTdlParams& pp, int method, uin
     const size_t lds = (size_t)NR * 2 * pw.x_elems * sizeof(T) + 2 * (((size_t)mp.M + 1) & ~(size_t)1) * sizeof(cx<T>) +
                        (((size_t)PS + 1) & ~(size_t)1) * sizeof(cx<T>) +
                        (grid_lds ? (((size_t)mp.grid.G * mp.grid.G + 1) & ~(size_t)1) * sizeof(unsigned long long) : 0) +
-                       (((size_t)NT * pp.num_used + 15) & ~(size_t)15) + 16 * sizeof(unsigned);
+                       (((size_t)NT * pp.num_used + 15) & ~(size_t)15) + 16 * sizeof(unsigned) +
+                       (pp.dmax > pp.cp ? (size_t)NT * (pw.x_elems - N - pp.cp) * sizeof(cx<T>) : 0);   // the previous symbol's end
     const size_t lds_static = (sizeof(T) == 8 ? (size_t)kBmLdsDoubles * 8 : 8) + sizeof(WgTotals) + 64;
     if (lds + lds_static > (size_t)160 * 1024) return MCLE_E_UNSUPPORTED;
     auto kern = k_run_mimo_ofdm_tdl_wave<T, N, NT, NR, KT, BQ, WPS, ABL>;

@@ -448,10 +448,11 @@ int run_mimo_tdl_wave_f32_experiment(int code, mcle_ctx* ctx, int nt, int nr, co
                                      uint64_t first, uint64_t count, mcle_counters* d_counters, uint32_t* d_sym, uint32_t* d_bit);
 #endif
 
-// the envelope of the wavefront kernels: fft_size 256 .. 2048, every tap delay inside the cyclic prefix (no inter-symbol
-// interference to carry), <= 8 taps reaching <= 256 samples (and <= N / 2) back
+// the envelope of the wavefront kernels: fft_size 256 .. 2048, <= 8 taps reaching <= 256 samples (and <= N / 2) back -- inside the
+// cyclic prefix or beyond it (round 6: the previous symbol's end is carried in LDS; until then a delay beyond the prefix ran the
+// cooperative kernel, square channels only)
 static bool mimo_tdl_wave_envelope(const MimoTdlParams& pp, int fft_size) {
-    return (fft_size == 256 || fft_size == 512 || fft_size == 1024 || fft_size == 2048) && pp.cp >= pp.dmax && pp.dmax <= 256 &&
+    return (fft_size == 256 || fft_size == 512 || fft_size == 1024 || fft_size == 2048) && pp.dmax <= 256 &&
            pp.dmax <= fft_size / 2 && pp.n_taps <= 8;
 }
 // run_time_order: the run-time-order kernels also where the parked-coefficient kernel applies (MCLE_OPT_MIMO_TDL_KERNEL = 2, A/B)
@@ -574,7 +575,7 @@ extern "C" int mcle_run_mimo_ofdm_tdl(mcle_ctx* ctx, int dtype, const mcle_mimo_
     }
     if (count == 0) return MCLE_OK;
     if ((rc = ctx->bind())) return rc;
-    // one receive antenna per wavefront (round 5; every 1 <= Nt <= Nr <= 4 at fft_size 256 .. 2048 with the taps inside the prefix);
+    // one receive antenna per wavefront (round 5; every 1 <= Nt <= Nr <= 4 at fft_size 256 .. 2048);
     // MCLE_OPT_MIMO_TDL_KERNEL: 1 = the workgroup-cooperative kernel of rounds 1-4 (Nt = Nr in {2, 4}), 2 = run-time-order kernels
     const long long sel = ctx->opt[MCLE_OPT_MIMO_TDL_KERNEL];
 #ifdef MCLE_EXPERIMENTS
@@ -589,7 +590,7 @@ extern "C" int mcle_run_mimo_ofdm_tdl(mcle_ctx* ctx, int dtype, const mcle_mimo_
     }
     if (!(cfg->nt == cfg->nr && (cfg->nt == 2 || cfg->nt == 4))) {
         set_error("fused MIMO-TDL pipeline: %d x %d at fft_size %d with cp %d / largest delay %d / %d taps is outside the wavefront "
-                  "kernels' envelope (fft_size 256 .. 2048, every delay inside the prefix, <= 8 taps) and the cooperative kernel "
+                  "kernels' envelope (fft_size 256 .. 2048, delays <= min(256, fft_size / 2), <= 8 taps) and the cooperative kernel "
                   "takes Nt = Nr in {2, 4} only (use the staged operator chain)",
                   cfg->nt, cfg->nr, cfg->fft_size, cfg->cp_size, pp.dmax, cfg->n_taps);
         return MCLE_E_UNSUPPORTED;

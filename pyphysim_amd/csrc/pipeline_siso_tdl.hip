@@ -798,7 +798,7 @@ int run_siso_tdl_mfma(mcle_ctx* ctx, const SisoTdlParams& pp, int method, uint64
 
 
 // one realization per wavefront (siso_tdl_wave.hpp; pipeline_siso_tdl_wave_f32.hip / _f64.hip): 0 = launched,
-// MCLE_E_UNSUPPORTED = outside its envelope (fft_size 256 / 512 / 1024 / 2048, taps inside the prefix, ...)
+// MCLE_E_UNSUPPORTED = outside its envelope (fft_size 256 / 512 / 1024 / 2048, <= 8 taps reaching <= 256 samples back, ...)
 int run_siso_tdl_wave_f32(mcle_ctx* ctx, int fft_size, const SisoTdlParams& pp, int method, uint64_t seed, uint64_t first, uint64_t count,
                           mcle_counters* d_counters, uint32_t* d_sym, uint32_t* d_bit);
 int run_siso_tdl_wave_f64(mcle_ctx* ctx, int fft_size, const SisoTdlParams& pp, int method, uint64_t seed, uint64_t first, uint64_t count,

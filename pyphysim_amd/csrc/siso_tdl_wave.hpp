@@ -16,7 +16,7 @@
 
 namespace mcle {
 
-// ---- config 3, ONE REALIZATION PER WAVEFRONT (round 4, late): every delayed sample inside the symbol's own prefix ----
+// ---- config 3, ONE REALIZATION PER WAVEFRONT (round 4, late): every delayed sample behind the symbol's own prefix (round 6: or the previous symbol's end) ----
 // The batched kernels above share every transform stage between the 256 threads of a workgroup: a dozen (k_run_ofdm_tdl_batch) or
 // four (k_run_ofdm_tdl_mfma) workgroup barriers per OFDM symbol, and the matrix-core kernel -- the default of rounds 2-3 -- left the
 // SIMDs idle a third of the time (VALU busy 0.54 + MFMA busy 0.16, profiles/r04/c3_mfma_pmc_summary.json).  Here a wavefront owns a
@@ -74,6 +74,12 @@ __global__ __launch_bounds__(64 * (siso_wave_nwv<T, N>()), WPS) void k_run_ofdm_
     cx<T>* s_twk = reinterpret_cast<cx<T>*>(s_grid + ((mp.grid.G * mp.grid.G + 1) & ~1));   // [R][kWaveMaxTaps]
     unsigned char* s_idx_all = reinterpret_cast<unsigned char*>(s_twk + R * kWaveMaxTaps);        // [4][U rounded to 16]
     const int idx_pitch = (U + 15) & ~15;
+    // A tap beyond the cyclic prefix (inter-symbol interference, round 6): positions [0, P - cp) of the signal then hold the END OF
+    // THE PREVIOUS SYMBOL -- sample m - d < -cp of the stream is x_prev[N + m - d + cp] -- kept per wavefront in `hist` between the
+    // symbols (zeros in front of the first one: the channel's filter starts empty, channels/fading.py:1092-1118)
+    const bool isi = pp.dmax > cp;
+    const int HL = isi ? pitch - N - cp : 0;
+    T* s_hist = reinterpret_cast<T*>(s_idx_all + NWV * idx_pitch) + w * 2 * HL;   // [NWV][2][HL]
     T* pr = s_all + w * 2 * pitch;                                         // transform planes: re [0, N), im [N, 2 N)
     T* pi = pr + N;
     T* xr = pr;                                                             // natural-order signal with prefix: re [0, pitch),
@@ -194,10 +200,22 @@ __global__ __launch_bounds__(64 * (siso_wave_nwv<T, N>()), WPS) void k_run_ofdm_
             }
 #pragma unroll
             for (int c = (R > 4 ? R - 4 : 0); c < R; ++c)                   // the prefix: the last P samples once more (P <= 256)
-                if (gi + 64 * c >= N - P) {
+                if (gi + 64 * c >= N - P + HL) {
                     xr[gi + 64 * c - (N - P)] = y[c].x;
                     xi[gi + 64 * c - (N - P)] = y[c].y;
                 }
+            if (isi) {                                                      // in front of the prefix: the previous symbol's end; the
+#pragma unroll                                                              // lane that holds sample e now held it then
+                for (int c = (R > 4 ? R - 4 : 0); c < R; ++c) {
+                    const int j = gi + 64 * c - (N - HL);
+                    if (j >= 0) {
+                        xr[j] = os > 0 ? s_hist[j] : (T)0;
+                        xi[j] = os > 0 ? s_hist[HL + j] : (T)0;
+                        s_hist[j] = y[c].x;
+                        s_hist[HL + j] = y[c].y;
+                    }
+                }
+            }
             r16_wave_sync();
             // ---- channel: y[m] = sum_s g_s(j) x[j],  j = cp + m - d_s, for this lane's R samples m = gi + 64 c ----
 #pragma unroll
@@ -378,7 +396,7 @@ template <typename T, int N, int WPS>
 int run_siso_tdl_wave_w(mcle_ctx* ctx, const SisoTdlParams& pp, int method, uint64_t seed, uint64_t first, uint64_t count,
                         mcle_counters* d_counters, uint32_t* d_sym, uint32_t* d_bit) {
     constexpr int R = N / 64;
-    if (pp.cp < pp.dmax || pp.K > kTdlMaxK) return MCLE_E_UNSUPPORTED;
+    if (pp.K > kTdlMaxK) return MCLE_E_UNSUPPORTED;
     int rc;
     void* tw = nullptr;
     if ((rc = ctx->get_twiddles(N, sizeof(T) == 8 ? MCLE_F64 : MCLE_F32, &tw))) return rc;
@@ -390,7 +408,8 @@ int run_siso_tdl_wave_w(mcle_ctx* ctx, const SisoTdlParams& pp, int method, uint
     constexpr int NWV = siso_wave_nwv<T, N>();
     const size_t lds = (size_t)NWV * 2 * pw.x_elems * sizeof(T) + (((size_t)mp.M + 1) & ~(size_t)1) * sizeof(cx<T>) +
                        (((size_t)mp.grid.G * mp.grid.G + 1) & ~(size_t)1) * sizeof(unsigned long long) + R * kWaveMaxTaps * sizeof(cx<T>) +
-                       NWV * (((size_t)pp.num_used + 15) & ~(size_t)15) + 16;
+                       NWV * (((size_t)pp.num_used + 15) & ~(size_t)15) + 16 +
+                       (pp.dmax > pp.cp ? (size_t)NWV * 2 * (pw.x_elems - N - pp.cp) * sizeof(T) : 0);   // the previous symbol's end
     auto kern = k_run_ofdm_tdl_wave<T, N, 2, WPS>;   // the polynomial order is a compile-time constant (2 .. 8: Doppler x symbol
     switch (pp.K) {                                  // length up to ~0.1 turns in complex64; beyond: the batched kernels)
         case 2: kern = k_run_ofdm_tdl_wave<T, N, 2, WPS>; break;

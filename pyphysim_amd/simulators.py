@@ -240,8 +240,8 @@ class MimoOfdmTdlSimulator(_LinkSimulator):
 
     def _launch(self, current_parameters, first_rep, count, per_realization):
         p = current_parameters
-        # fused kernels: every 1 <= Nt <= Nr <= 4 at fft_size 256 .. 2048 with the taps inside the prefix (one receive antenna per
-        # wavefront, round 5), Nt = Nr in {2, 4} at 64 .. 2048 otherwise; the C ABI reports anything else as unsupported
+        # fused kernels: every 1 <= Nt <= Nr <= 4 at fft_size 256 .. 2048 with delays <= min(256, fft_size / 2) (one receive antenna per
+        # wavefront, round 5; delays beyond the prefix since round 6), Nt = Nr in {2, 4} at 64 .. 2048 otherwise; the C ABI reports anything else as unsupported
         if self.fused and 1 <= p["Nt"] <= p["Nr"] <= 4 and p["fft_size"] in self._FUSED_FFT:
             try:
                 eng = self._bind()

@@ -1,6 +1,6 @@
 """GPU: the frequency-selective MIMO-OFDM link with one receive antenna per WAVEFRONT
-(csrc/mimo_tdl_wave.hpp: k_run_mimo_ofdm_tdl_wave -- the default of mcle_run_mimo_ofdm_tdl since round 5 wherever every tap delay
-sits inside the cyclic prefix; option mimo_tdl_kernel = 1 selects the workgroup-cooperative kernel of rounds 1-4, = 2 the
+(csrc/mimo_tdl_wave.hpp: k_run_mimo_ofdm_tdl_wave -- the default of mcle_run_mimo_ofdm_tdl since round 5, since round 6 also with
+tap delays beyond the cyclic prefix; option mimo_tdl_kernel = 1 selects the workgroup-cooperative kernel of rounds 1-4, = 2 the
 run-time-order form of the wavefront kernel) against the oracle chain (oracle/chains.py::chain_mimo_ofdm_tdl, pinned to the
 reference by tests/golden/f1_mimo_ofdm_tdl.npz) under the same Philox keying, and against the kernel it replaces.
 complex128: per-realization symbol AND bit counts exact; complex64: |dSER| <= 1e-4, boundary ties only.
@@ -170,20 +170,68 @@ def test_wave_kernel_equals_the_cooperative_kernel_over_3000_realizations(engine
         assert abs(res["sym_errors"] - old["sym_errors"]) <= 1e-5 * count * 4096 + 3
 
 
-def test_a_delay_beyond_the_prefix_runs_the_cooperative_kernel_or_reports_unsupported(engine):
-    """Inter-symbol interference through a short prefix is outside the wavefront kernels' envelope: a square channel falls
-    through to the cooperative kernel (exact against the oracle), a rectangular one is reported as a configuration for the
-    staged operator chain (MCLE_E_UNSUPPORTED -> the simulator's 'auto' mode)."""
+# A tap BEYOND the cyclic prefix (inter-symbol interference: the previous symbol's end reaches into this one; zeros in front of the
+# first symbol, channels/fading.py:1092-1118).  Round 6: inside the wavefront kernels' envelope -- every geometry, not only the
+# square ones the cooperative kernel takes.  Delays on both sides of the prefix, a prefix of zero, a delay that is a multiple of 16
+# and one that is not (the history is P - cp samples, P = the largest delay rounded up to 16), histories longer than 64 samples
+# (more than one sample per lane), every transform form (radix-4 at 256 / 512 / 2048, radix-16 passes at 1024).
+ISI_CASES = [
+    (6, dict(mod="qam", M=16, fft_size=256, nt=2, nr=2, snr_db=16.0, cp_size=4, tap_delays_samples=(0, 7, 19),
+             tap_powers_dB=(0.0, -4.0, -9.0), n_ofdm_sym=3, Ts=1e-6, Fd=50.0)),
+    (6, dict(mod="qam", M=16, fft_size=256, nt=2, nr=3, snr_db=16.0, cp_size=4, tap_delays_samples=(0, 7, 19),
+             tap_powers_dB=(0.0, -4.0, -9.0), n_ofdm_sym=3, Ts=1e-6, Fd=50.0)),
+    (6, dict(mod="qam", M=64, fft_size=256, nt=1, nr=4, snr_db=24.0, cp_size=0, tap_delays_samples=(0, 1, 16),
+             tap_powers_dB=(0.0, -6.0, -12.0), n_ofdm_sym=4, Ts=1e-6, num_used=200)),
+    (5, dict(mod="qam", M=16, fft_size=512, nt=3, nr=4, snr_db=18.0, cp_size=9, tap_delays_samples=(0, 9, 10, 100, 131),
+             tap_powers_dB=(0.0, -2.0, -4.0, -6.0, -8.0), n_ofdm_sym=3, Ts=1e-6)),
+    (4, dict(mod="qam", M=64, snr_db=25.0, cp_size=16, tap_delays_samples=(0, 1, 2, 17, 40), n_ofdm_sym=3)),
+    (4, dict(mod="qam", M=16, nt=2, nr=4, snr_db=15.0, cp_size=33, tap_delays_samples=(0, 33, 34, 250), n_ofdm_sym=2,
+             tap_powers_dB=(0.0, -3.0, -5.0, -7.0), method=_lib.DEMOD_QAM_SLICER)),
+    (3, dict(mod="qpsk", M=4, fft_size=2048, nt=2, nr=2, snr_db=10.0, cp_size=17, tap_delays_samples=(0, 5, 90), n_ofdm_sym=2,
+             tap_powers_dB=(0.0, -3.0, -6.0), Fd=5.0)),
+    (3, dict(mod="qam", M=16, fft_size=2048, snr_db=20.0, cp_size=8, tap_delays_samples=(0, 3, 8, 21), n_ofdm_sym=2,
+             tap_powers_dB=(0.0, -3.0, -6.0, -9.0))),
+]
+
+
+@pytest.mark.parametrize("case", range(len(ISI_CASES)))
+def test_a_delay_beyond_the_prefix_against_the_oracle(engine, case):
+    count, kw = ISI_CASES[case]
+    kw = dict(kw)
+    mod, M = kw.pop("mod"), kw.pop("M")
+    _set(engine, mod, M)
+    want_se, want_be, nsym, nbits = _oracle(40, count, mod, M, **kw)
+    res, se, be = _run(engine, 40, count, "f64", **kw)
+    assert res["n_symbols"] == nsym and res["n_bits"] == nbits
+    assert np.array_equal(se, want_se) and np.array_equal(be, want_be), (se, want_se)
+    assert want_se.sum() > 0
+    _, se32, _ = _run(engine, 40, count, "f32", **kw)
+    assert np.max(np.abs(se32.astype(np.int64) - want_se)) <= 3 + 2e-3 * nsym
+    if kw.get("nt", 4) == kw.get("nr", 4) and kw.get("nt", 4) in (2, 4):
+        _, se_o, be_o = _run(engine, 40, count, "f64", kernel=1, **kw)        # the cooperative kernel carries the tail too
+        assert np.array_equal(se, se_o) and np.array_equal(be, be_o)
+    # several passes of a workgroup's realization loop (the history is reset at every first symbol), run-time-order kernels
+    n = 2500 if kw.get("fft_size", 1024) <= 512 else 700
+    a = _run(engine, 7, n, "f64", **kw)
+    b = _run(engine, 7, n, "f64", kernel=2, **kw)
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    assert np.array_equal(a[1][33:33 + count], se) and np.array_equal(a[2][33:33 + count], be)
+
+
+def test_interference_changes_the_counts_and_other_envelope_errors(engine):
+    """The carried tail matters (the same link with the prefix long enough has fewer errors), and what stays outside the fused
+    kernels says so: Nt > Nr has no Blast filter (mimo/mimo.py:264-309 needs full column rank); a delay beyond fft_size / 2 on a
+    rectangular channel is a configuration for the staged operator chain."""
     _set(engine, "qam", 16)
-    kw = dict(fft_size=256, nt=2, nr=2, snr_db=16.0, cp_size=4, tap_delays_samples=(0, 7, 19), tap_powers_dB=(0.0, -4.0, -9.0),
+    kw = dict(fft_size=256, nt=2, nr=3, snr_db=30.0, tap_delays_samples=(0, 7, 19), tap_powers_dB=(0.0, -4.0, -9.0),
               n_ofdm_sym=3, Ts=1e-6, Fd=50.0)
-    want_se, want_be, _, _ = _oracle(40, 6, "qam", 16, **kw)
-    _, se, be = _run(engine, 40, 6, "f64", **kw)
-    assert np.array_equal(se, want_se) and np.array_equal(be, want_be)
-    with pytest.raises(_lib.McleUnsupported):
-        _run(engine, 40, 6, "f64", **dict(kw, nr=3))
+    short = _run(engine, 40, 400, "f64", cp_size=4, **kw)[0]
+    long_ = _run(engine, 40, 400, "f64", cp_size=20, **kw)[0]
+    assert short["sym_errors"] > 3 * long_["sym_errors"] + 100
     with pytest.raises(_lib.McleError):
-        _run(engine, 40, 6, "f64", **dict(kw, nt=3, nr=2))          # Nt > Nr: no Blast filter (mimo/mimo.py:264-309 needs full column rank)
+        _run(engine, 40, 6, "f64", cp_size=4, **dict(kw, nt=3, nr=2))
+    with pytest.raises(_lib.McleUnsupported):
+        _run(engine, 40, 6, "f64", cp_size=4, **dict(kw, tap_delays_samples=(0, 7, 130)))
 
 
 def test_noise_free_link_against_the_oracle(engine):

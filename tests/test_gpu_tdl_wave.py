@@ -101,14 +101,43 @@ def test_wave_kernel_large_sample_and_zero_noise(engine, dtype):
     assert abs(clean["sym_errors"] - ref["sym_errors"]) <= 1e-5 * 4099 * 1024 + 2
 
 
-def test_wave_kernel_envelope(engine):
-    """A tap beyond the cyclic prefix is outside the wavefront kernel's envelope: the call falls through to the batched kernels
-    (same counts with the option on and off)."""
-    engine.set_constellation(chains.constellation("qam", 16), _lib.CONST_QAM)
-    kw = dict(snr_db=22.0, cp_size=4, tap_delays_samples=(0, 3, 9), tap_powers_dB=(0.0, -3.0, -6.0), n_ofdm_sym=2)
-    a = _run(engine, 5, 40, "f64", **kw)
-    b = _run(engine, 5, 40, "f64", wave=0, **kw)
-    assert a[0] == b[0] and np.array_equal(a[1], b[1])
+# A tap BEYOND the cyclic prefix (inter-symbol interference; zeros in front of the first symbol, channels/fading.py:1092-1118): inside
+# the wavefront kernel's envelope since round 6 (the previous symbol's end is carried in LDS; until then such a call fell through to
+# the batched kernels, which stay the other side of this comparison)
+ISI_CASES = [dict(fft=1024, mod="qam", M=16, snr_db=22.0, cp_size=4, tap_delays_samples=(0, 3, 9), tap_powers_dB=(0.0, -3.0, -6.0), n_ofdm_sym=2),
+             dict(fft=1024, mod="qam", M=64, snr_db=30.0, cp_size=16, tap_delays_samples=(0, 1, 17, 40, 200), n_ofdm_sym=3),
+             dict(fft=256, mod="qpsk", M=4, snr_db=12.0, cp_size=0, tap_delays_samples=(0, 16, 100), tap_powers_dB=(0.0, -3.0, -6.0),
+                  n_ofdm_sym=4, num_used=200),
+             dict(fft=512, mod="qam", M=16, snr_db=20.0, cp_size=33, tap_delays_samples=(0, 33, 34, 131), n_ofdm_sym=3,
+                  tap_powers_dB=(0.0, -2.0, -4.0, -6.0), method=_lib.DEMOD_QAM_SLICER),
+             dict(fft=2048, mod="qam", M=16, snr_db=20.0, cp_size=17, tap_delays_samples=(0, 5, 90), tap_powers_dB=(0.0, -3.0, -6.0),
+                  n_ofdm_sym=2)]
+
+
+@pytest.mark.parametrize("case", range(len(ISI_CASES)))
+def test_a_delay_beyond_the_prefix(engine, case):
+    kw = dict(ISI_CASES[case])
+    mod, M, fft = kw.pop("mod"), kw.pop("M"), kw.pop("fft")
+    engine.set_constellation(chains.constellation(mod, M), _lib.CONST_QAM if mod == "qam" else _lib.CONST_GENERIC)
+    first, count = 5, 11
+    okw = dict(mod=mod, M=M, fft_size=fft, cp_size=kw["cp_size"], num_used=kw.get("num_used"), n_ofdm_sym=kw["n_ofdm_sym"],
+               snr_db=kw["snr_db"], Fd=10.0, L=8, tap_powers_dB=kw.get("tap_powers_dB", (0.0, -3.0, -6.0, -9.0, -12.0)),
+               tap_delays_samples=kw["tap_delays_samples"])
+    want = [chains.chain_ofdm_tdl(chains.PhiloxRng(SEED, r), **okw) for r in range(first, first + count)]
+    want_se = np.array([w["symbol_errors"] for w in want], dtype=np.int64)
+    want_be = np.array([w["bit_errors"] for w in want], dtype=np.int64)
+    res, se, be = _run(engine, first, count, "f64", fft=fft, **kw)
+    assert np.array_equal(se, want_se) and np.array_equal(be, want_be), (se, want_se)
+    assert want_se.sum() > 0
+    for dtype in ("f64", "f32"):                          # kernel against kernel over several passes of a wavefront's loop
+        a = _run(engine, 1, 3000, dtype, fft=fft, **kw)
+        b = _run(engine, 1, 3000, dtype, wave=0, fft=fft, **kw)
+        if dtype == "f64":
+            assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+            assert np.array_equal(a[1][4:4 + count], se)
+        else:
+            assert np.max(np.abs(a[1].astype(np.int64) - b[1].astype(np.int64))) <= 3
+            assert abs(a[0]["sym_errors"] - b[0]["sym_errors"]) <= 1e-4 * a[0]["n_symbols"] * 3000 + 2
 
 
 # ---- the other sizes of the wavefront kernel: radix-4 stages on the wavefront's planes (256, 512, 2048; 2048 in complex64) ----
