@@ -151,7 +151,9 @@ enum {
                                       workgroup barrier in the loop; radix-16 register passes at 1024, radix-4 stages otherwise) WHERE IT
                                       IS THE FASTER KERNEL (1024; 2048 in complex64; 256 / 512 in complex128 -- default since round 4),
                                       1 = the batched kernels of rounds 1-3 everywhere (four / two realizations per workgroup pass;
-                                      complex64 at 1024: matrix cores), 2 = the wavefront kernel wherever it exists, 4 = the same with
+                                      complex64 at 1024: matrix cores), 2 = the wavefront kernel wherever it exists, 3 = the same, but at
+                                      2048 points the one-wavefront kernel instead of the round-6 default there, TWO wavefronts per
+                                      realization (k_run_ofdm_tdl_hw: every delay inside the prefix, orders 2 .. 5; A/B), 4 = as 2 with
                                       the complex64 registers at 1024 bounded for four wavefronts per SIMD instead of three (A/B) */
     MCLE_OPT_MIMO_TDL_KERNEL = 14, /* frequency-selective MIMO-OFDM (mcle_run_mimo_ofdm_tdl) at fft_size 256 / 512 / 1024 / 2048 with <= 8 taps
                                       reaching <= min(256, fft_size / 2) samples back (inside the cyclic prefix or, since round 6, beyond it): 0 = one receive antenna per WAVEFRONT

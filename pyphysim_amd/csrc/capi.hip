@@ -219,7 +219,7 @@ int mcle_ctx_set_option(mcle_ctx* ctx, int option, long long value) {
     bool ok = false;
     switch (option) {
         case MCLE_OPT_NO_MFMA: case MCLE_OPT_SINGLE_TDL: case MCLE_OPT_JAKES_DIRECT: case MCLE_OPT_F64_GENERIC: case MCLE_OPT_BD_RUNTIME_SOLVE: case MCLE_OPT_DEMOD_NOCERT: case MCLE_OPT_F32_MFMA: case MCLE_OPT_WALK_LEGACY: ok = value == 0 || value == 1; break;
-        case MCLE_OPT_TDL_KERNEL: ok = value == 0 || value == 1 || value == 2 || value == 4; break;
+        case MCLE_OPT_TDL_KERNEL: ok = value >= 0 && value <= 4; break;
 #ifdef MCLE_EXPERIMENTS
         case MCLE_OPT_MIMO_TDL_KERNEL: ok = value >= 0 && value <= 255; break;
 #else

@@ -820,7 +820,7 @@ int run_siso_tdl_batch_impl(mcle_ctx* ctx, SisoTdlParams pp, int method, uint64_
         // five pairs of small launches)
         const bool faster = true;
         const long long sel = ctx->opt[MCLE_OPT_TDL_KERNEL];
-        if ((sel == 2 || sel == 4 || (sel == 0 && faster)) && !ctx->opt[MCLE_OPT_NO_MFMA]) {
+        if ((sel == 2 || sel == 3 || sel == 4 || (sel == 0 && faster)) && !ctx->opt[MCLE_OPT_NO_MFMA]) {
             rc = sizeof(T) == 8 ? run_siso_tdl_wave_f64(ctx, N, pp, method, seed, first, count, d_counters, d_sym, d_bit)
                                 : run_siso_tdl_wave_f32(ctx, N, pp, method, seed, first, count, d_counters, d_sym, d_bit);
             if (rc != MCLE_E_UNSUPPORTED) return rc;

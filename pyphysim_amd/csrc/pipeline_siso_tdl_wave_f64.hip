@@ -1,4 +1,6 @@
-// pipeline_siso_tdl_wave_f64.hip -- the one-realization-per-wavefront kernels of config 3 (siso_tdl_wave.hpp) in complex128
+// pipeline_siso_tdl_wave_f64.hip -- the wavefront kernels of config 3 (siso_tdl_wave.hpp: one realization per wavefront; siso_tdl_hw.hpp: two
+// wavefronts per realization at 2048 points) in complex128
+#include "siso_tdl_hw.hpp"
 #include "siso_tdl_wave.hpp"
 
 namespace mcle {
@@ -9,7 +11,14 @@ int run_siso_tdl_wave_f64(mcle_ctx* ctx, int fft_size, const SisoTdlParams& pp, 
         case 256: return run_siso_tdl_wave<double, 256>(ctx, pp, method, seed, first, count, d_counters, d_sym, d_bit);
         case 512: return run_siso_tdl_wave<double, 512>(ctx, pp, method, seed, first, count, d_counters, d_sym, d_bit);
         case 1024: return run_siso_tdl_wave<double, 1024>(ctx, pp, method, seed, first, count, d_counters, d_sym, d_bit);
-        case 2048: return run_siso_tdl_wave<double, 2048>(ctx, pp, method, seed, first, count, d_counters, d_sym, d_bit);
+        case 2048: {                 // two wavefronts per realization (siso_tdl_hw.hpp, round 6; two realizations per workgroup share the Box-Muller tables: two workgroups = eight wavefronts per CU);
+                                     // MCLE_OPT_TDL_KERNEL = 3: the one-wavefront kernel (A/B), which also serves what is outside the envelope
+            if (ctx->opt[MCLE_OPT_TDL_KERNEL] != 3) {
+                const int rc = run_siso_tdl_hw<double, 2, 2>(ctx, pp, method, seed, first, count, d_counters, d_sym, d_bit);
+                if (rc != MCLE_E_UNSUPPORTED) return rc;
+            }
+            return run_siso_tdl_wave<double, 2048>(ctx, pp, method, seed, first, count, d_counters, d_sym, d_bit);
+        }
         default: return MCLE_E_UNSUPPORTED;
     }
 }

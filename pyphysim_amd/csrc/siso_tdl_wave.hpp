@@ -465,6 +465,7 @@ int run_siso_tdl_wave(mcle_ctx* ctx, const SisoTdlParams& pp, int method, uint64
     //  3.18 against 2.21 ms per 262 144 realizations).  256 / 512: fewer samples per lane, three to six; 2048: complex64 only, two
     //  (132 KiB of planes per workgroup in complex128: the batched kernel serves that one).
     if constexpr (N == 2048) {       // complex128: two wavefronts per workgroup, two workgroups per CU = one wavefront per SIMD
+        // (round 6: two wavefronts per REALIZATION -- siso_tdl_hw.hpp, tried first by the callers in pipeline_siso_tdl_wave_*.hip)
         if constexpr (sizeof(T) == 8) return run_siso_tdl_wave_w<T, N, 1>(ctx, pp, method, seed, first, count, d_counters, d_sym, d_bit);
         else return run_siso_tdl_wave_w<T, N, 2>(ctx, pp, method, seed, first, count, d_counters, d_sym, d_bit);
     } else if constexpr (N == 1024) {

@@ -180,3 +180,63 @@ def test_wave_kernel_other_sizes(engine, case, fft, dtype):
     a = _run(engine, first, 5, dtype, fft=fft, **kw)
     b = _run(engine, first + 5, count - 5, dtype, fft=fft, **kw)
     assert np.array_equal(np.concatenate([a[1], b[1]]), se) and np.array_equal(np.concatenate([a[2], b[2]]), be)
+
+
+# ---- fft_size 2048 with TWO WAVEFRONTS PER REALIZATION (csrc/siso_tdl_hw.hpp: k_run_ofdm_tdl_hw, the default at 2048 since round 6;
+#      option tdl_kernel = 3: the one-wavefront kernel it replaces there) ----
+HW_CASES = [dict(mod="qpsk", M=4, snr_db=20.0),                                                       # config 3's link at 2048
+            dict(mod="qam", M=16, snr_db=24.0, num_used=1200, n_ofdm_sym=2, cp_size=9,               # partial band, ODD prefix: the
+                 tap_delays_samples=(0, 2, 5, 9), tap_powers_dB=(0.0, -2.0, -5.0, -8.0), Fd=200.0),   # unpaired noise draws
+            dict(mod="qam", M=64, snr_db=30.0, cp_size=64, n_ofdm_sym=3, method=_lib.DEMOD_QAM_SLICER,
+                 tap_delays_samples=(0, 1, 7, 20, 33, 50, 63, 64), tap_powers_dB=(0.0, -1.0, -2.0, -3.0, -4.0, -5.0, -6.0, -7.0)),
+            dict(mod="psk", M=8, snr_db=18.0, cp_size=256, n_ofdm_sym=2, Fd=700.0,                    # the longest reach (256 = the
+                 tap_delays_samples=(0, 1, 128, 255, 256), tap_powers_dB=(0.0, -1.0, -2.0, -3.0, -4.0)),   # parity planes' 128), grid search
+            dict(mod="qam", M=256, snr_db=36.0, cp_size=33, n_ofdm_sym=3, num_used=2, tap_delays_samples=(0, 3),   # odd symbol length: the
+                 tap_powers_dB=(0.0, -4.0)),                                                           # pairing alternates per symbol
+            dict(mod="psk", M=2, snr_db=5.0, cp_size=16, num_used=2046, Fd=1500.0)]
+
+
+@pytest.mark.parametrize("case", range(len(HW_CASES)))
+def test_half_wave_kernel_at_2048_against_the_oracle_and_the_one_wavefront_kernel(engine, case):
+    kw = dict(HW_CASES[case])
+    mod, M = kw.pop("mod"), kw.pop("M")
+    engine.set_constellation(chains.constellation(mod, M), _lib.CONST_QAM if mod == "qam" else _lib.CONST_GENERIC)
+    first, count = (1 << 35) + 99, 9
+    okw = dict(mod=mod, M=M, fft_size=2048, cp_size=kw.get("cp_size", 16), num_used=kw.get("num_used"), n_ofdm_sym=kw.get("n_ofdm_sym", 1),
+               snr_db=kw["snr_db"], Fd=kw.get("Fd", 10.0), L=8, tap_powers_dB=kw.get("tap_powers_dB", (0.0, -3.0, -6.0, -9.0, -12.0)),
+               tap_delays_samples=kw.get("tap_delays_samples", (0, 1, 2, 3, 4)))
+    want = [chains.chain_ofdm_tdl(chains.PhiloxRng(SEED, r), **okw) for r in range(first, first + count)]
+    want_se = np.array([w["symbol_errors"] for w in want], dtype=np.int64)
+    want_be = np.array([w["bit_errors"] for w in want], dtype=np.int64)
+    res, se, be = _run(engine, first, count, "f64", fft=2048, **kw)
+    assert res["n_symbols"] == want[0]["num_symbols"] and res["n_realizations"] == count
+    assert np.array_equal(se, want_se) and np.array_equal(be, want_be), (se, want_se)
+    # kernel against kernel over several passes of a workgroup's loop, an ODD count (the last pair's second slot is not a realization),
+    # one realization, and a split of the range
+    for dtype in ("f64", "f32"):
+        n = 3001
+        a = _run(engine, first - 50, n, dtype, fft=2048, **kw)
+        with engine.options(tdl_kernel=3):
+            b = engine_run_other(engine, first - 50, n, dtype, **kw)
+        if dtype == "f64":
+            assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+            assert np.array_equal(a[1][50:50 + count], se)
+        else:
+            assert np.max(np.abs(a[1].astype(np.int64) - b[1].astype(np.int64))) <= 3
+            assert abs(a[0]["sym_errors"] - b[0]["sym_errors"]) <= 1e-4 * a[0]["n_symbols"] * n + 2
+        one = _run(engine, first - 50 + 7, 1, dtype, fft=2048, **kw)
+        assert one[1][0] == a[1][7] and one[2][0] == a[2][7] and one[0]["n_realizations"] == 1
+        lo, hi = _run(engine, first - 50, 1234, dtype, fft=2048, **kw), _run(engine, first - 50 + 1234, n - 1234, dtype, fft=2048, **kw)
+        assert np.array_equal(np.concatenate([lo[1], hi[1]]), a[1]) and np.array_equal(np.concatenate([lo[2], hi[2]]), a[2])
+
+
+def engine_run_other(engine, first, count, dtype, **kw):
+    """_run without its own tdl_kernel option (the caller chose one)."""
+    from pyphysim_amd.channels import discretize_profile
+    Ts = kw.get("Ts", 1.0 / (15e3 * 1024))
+    p_lin, d_idx = discretize_profile(np.asarray(kw.get("tap_powers_dB", (0.0, -3.0, -6.0, -9.0, -12.0)), dtype=float),
+                                      np.asarray(kw.get("tap_delays_samples", (0, 1, 2, 3, 4)), dtype=float) * Ts, Ts)
+    nv = 1.0 / omodem.dB2Linear(kw.get("snr_db", 20.0))
+    return engine.run_ofdm_tdl(2048, kw.get("cp_size", 16), kw.get("num_used") or 2048, kw.get("n_ofdm_sym", 1), nv, p_lin, d_idx, SEED,
+                               first, count, Fd=kw.get("Fd", 10.0), Ts=Ts, L=kw.get("L", 8), method=kw.get("method", _lib.DEMOD_MINDIST),
+                               dtype=dtype, per_realization=True)
