@@ -782,9 +782,7 @@ int run_siso_tdl_mfma(mcle_ctx* ctx, const SisoTdlParams& pp, int method, uint64
     if ((rc = ctx->scratch((size_t)slice * per_real * sizeof(float2), &recs))) return rc;
     for (uint64_t off = 0; off < count; off += slice) {
         const uint64_t n = count - off < slice ? count - off : slice;
-        const uint64_t threads = n * (uint64_t)pp.n_ofdm_sym * pp.n_taps;
-        hipLaunchKernelGGL(k_tdl_symbol_polys<float>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream, pp,
-                           kF16N + pp.cp, seed, first + off, n, (float2*)recs);
+        launch_tdl_symbol_polys<float>(ctx->stream, pp, kF16N + pp.cp, seed, first + off, n, (float2*)recs);
         MCLE_LAUNCH_CHECK();
         const uint64_t passes = (n + NB - 1) / NB;
         const unsigned grid = (unsigned)oversubscribed_grid(ctx, (uint64_t)ctx->n_cu * per_cu, passes);
@@ -854,9 +852,7 @@ int run_siso_tdl_batch_impl(mcle_ctx* ctx, SisoTdlParams pp, int method, uint64_
     if ((rc = ctx->scratch((size_t)slice * per_real * sizeof(cx<T>), &recs))) return rc;
     for (uint64_t off = 0; off < count; off += slice) {
         const uint64_t n = count - off < slice ? count - off : slice;
-        const uint64_t threads = n * (uint64_t)pp.n_ofdm_sym * pp.n_taps;
-        hipLaunchKernelGGL(k_tdl_symbol_polys<T>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream, pp,
-                           N + pp.cp, seed, first + off, n, (cx<T>*)recs);
+        launch_tdl_symbol_polys<T>(ctx->stream, pp, N + pp.cp, seed, first + off, n, (cx<T>*)recs);
         MCLE_LAUNCH_CHECK();
         const uint64_t passes = (n + NB - 1) / NB;
         const unsigned grid = (unsigned)oversubscribed_grid(ctx, (uint64_t)ctx->n_cu * per_cu, passes);

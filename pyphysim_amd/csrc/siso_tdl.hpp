@@ -26,15 +26,40 @@ struct SisoTdlParams {
 // Record of (realization, symbol): coef [S][K + 1], mean [S] -- S (K + 2) complex values (160 B for config 3 in complex64).
 // W = samples per OFDM symbol (FFT + CP).  Same operations in the same order as the in-kernel form it replaces.
 constexpr int kTdlMaxK = kSisoMaxOrder;
-template <typename T>
+// SH (round 6): the PHASE blocks of a workgroup's G realizations are evaluated ONCE into LDS (2 L S / 4 blocks per realization: 20 for
+// config 3) and every thread reads its 2 L uniforms from there -- with one Philox call per uniform (uniform_at) a thread evaluated 2 L
+// = 16 blocks and used one word of each: 80 block evaluations per realization for 20 blocks.  Same words, same operations after them.
+template <typename T, bool SH = false>
 __global__ __launch_bounds__(256) void k_tdl_symbol_polys(SisoTdlParams pp, int W, uint64_t seed, uint64_t first, uint64_t count,
-                                                          cx<T>* __restrict__ recs) {
+                                                          cx<T>* __restrict__ recs, int G = 0, int NB = 0) {
     const int S = pp.n_taps, L = pp.L, K = pp.K;
-    const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t per_real = (uint64_t)pp.n_ofdm_sym * S;
-    if (q >= count * per_real) return;
-    const uint64_t rl = q / per_real;
-    const int rem = (int)(q - rl * per_real), os = rem / S, s = rem - os * S;
+    const int per = pp.n_ofdm_sym * S;
+    extern __shared__ uint32_t s_phase_words[];                             // SH: [G][4 NB]
+    uint64_t rl;
+    int rem;
+    [[maybe_unused]] const uint32_t* my_words = nullptr;
+    if constexpr (SH) {
+        const uint64_t r0 = (uint64_t)blockIdx.x * G;
+        for (int i = (int)threadIdx.x; i < G * NB; i += 256) {
+            const int g = i / NB, b = i - g * NB;
+            if (r0 + g < count) {
+                const Words4 wq = Rng(seed, first + r0 + g).block(STREAM_PHASE, (uint32_t)b);
+                *reinterpret_cast<uint4*>(s_phase_words + 4 * i) = make_uint4(wq.w[0], wq.w[1], wq.w[2], wq.w[3]);
+            }
+        }
+        __syncthreads();
+        const int g = (int)threadIdx.x / per;
+        rem = (int)threadIdx.x - g * per;
+        rl = r0 + g;
+        if (g >= G || rl >= count) return;
+        my_words = s_phase_words + 4 * NB * g;
+    } else {
+        const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        if (q >= count * (uint64_t)per) return;
+        rl = q / (uint64_t)per;
+        rem = (int)(q - rl * (uint64_t)per);
+    }
+    const int os = rem / S, s = rem - os * S;
     const double xc = 0.5 * (double)(W - 1);
     const double two_pi = 6.283185307179586476925286766559;
     const double tc = pp.Ts + pp.dt * ((double)((uint64_t)os * W) + xc);
@@ -44,8 +69,15 @@ __global__ __launch_bounds__(256) void k_tdl_symbol_polys(SisoTdlParams pp, int 
     for (int m = 0; m <= kTdlMaxK; ++m) ar[m] = ai[m] = 0;
     for (int l = 0; l < L; ++l) {
         const int rq = l * S + s;                                         // PHASE-stream index of phi
-        const double psi_t = uniform_at(rng, STREAM_PHASE, (uint64_t)L * S + rq);
-        const double wd = pp.Fd * cospi(2.0 * uniform_at(rng, STREAM_PHASE, (uint64_t)rq));   // Hz
+        double psi_t, u_phi;
+        if constexpr (SH) {
+            psi_t = (double)my_words[L * S + rq] * 0x1p-32;
+            u_phi = (double)my_words[rq] * 0x1p-32;
+        } else {
+            psi_t = uniform_at(rng, STREAM_PHASE, (uint64_t)L * S + rq);
+            u_phi = uniform_at(rng, STREAM_PHASE, (uint64_t)rq);
+        }
+        const double wd = pp.Fd * cospi(2.0 * u_phi);                     // Hz
         const double ph = fma(wd, tc, psi_t);                             // turns
         const double fr = __builtin_amdgcn_fract(ph);
         T er, ei;
@@ -88,6 +120,23 @@ __global__ __launch_bounds__(256) void k_tdl_symbol_polys(SisoTdlParams pp, int 
             mi += c.y * (T)pp.mom[m];
         }
     rec[S * (K + 1) + s] = mk<T>(mr, mi);
+}
+
+// host: the records of n realizations starting at `first` (one launch on `stream`)
+template <typename T>
+inline void launch_tdl_symbol_polys(hipStream_t stream, const SisoTdlParams& pp, int W, uint64_t seed, uint64_t first, uint64_t n,
+                                    cx<T>* recs) {
+    const int per = pp.n_ofdm_sym * pp.n_taps;
+    const int NB = (2 * pp.L * pp.n_taps + 3) / 4;
+    const int G = per <= 256 ? 256 / per : 0;
+    if (G >= 1 && (size_t)G * NB * 16 <= (size_t)32 * 1024) {
+        hipLaunchKernelGGL((k_tdl_symbol_polys<T, true>), dim3((unsigned)((n + G - 1) / G)), dim3(256), (size_t)G * NB * 16, stream, pp, W, seed,
+                           first, n, recs, G, NB);
+    } else {
+        const uint64_t threads = n * (uint64_t)per;
+        hipLaunchKernelGGL((k_tdl_symbol_polys<T, false>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, pp, W, seed, first, n,
+                           recs, 0, 0);
+    }
 }
 
 

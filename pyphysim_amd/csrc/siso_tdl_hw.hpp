@@ -387,9 +387,7 @@ int run_siso_tdl_hw(mcle_ctx* ctx, const SisoTdlParams& pp, int method, uint64_t
     if (got / one < slice) slice = (got / one / NRW) * NRW;
     for (uint64_t off = 0; off < count; off += slice) {
         const uint64_t n = count - off < slice ? count - off : slice;
-        const uint64_t threads = n * (uint64_t)pp.n_ofdm_sym * pp.n_taps;
-        hipLaunchKernelGGL(k_tdl_symbol_polys<T>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream, pp, N + pp.cp,
-                           seed, first + off, n, (cx<T>*)recs);
+        launch_tdl_symbol_polys<T>(ctx->stream, pp, N + pp.cp, seed, first + off, n, (cx<T>*)recs);
         MCLE_LAUNCH_CHECK();
         const unsigned grid = (unsigned)oversubscribed_grid(ctx, (uint64_t)ctx->n_cu * per_cu, (n + NRW - 1) / NRW, 4);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(128 * NRW), lds, ctx->stream, pw, mp, seed, first + off, n, (const cx<T>*)twN, (const cx<T>*)twH,

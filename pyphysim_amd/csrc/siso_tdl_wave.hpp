@@ -444,9 +444,7 @@ int run_siso_tdl_wave_w(mcle_ctx* ctx, const SisoTdlParams& pp, int method, uint
     if (got / one < slice) slice = (got / one / NWV) * NWV;
     for (uint64_t off = 0; off < count; off += slice) {
         const uint64_t n = count - off < slice ? count - off : slice;
-        const uint64_t threads = n * (uint64_t)pp.n_ofdm_sym * pp.n_taps;
-        hipLaunchKernelGGL(k_tdl_symbol_polys<T>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream, pp, N + pp.cp,
-                           seed, first + off, n, (cx<T>*)recs);
+        launch_tdl_symbol_polys<T>(ctx->stream, pp, N + pp.cp, seed, first + off, n, (cx<T>*)recs);
         MCLE_LAUNCH_CHECK();
         // (round 6: one flush of the counters per WORKGROUP instead of per wavefront -- a workgroup's fixed cost fell, and the grid that
         //  wanted >= 12 passes per workgroup now takes 4: +4 % at 131 072 realizations per launch, profiles/r06/grid_sweep_others.log)
