@@ -1,6 +1,7 @@
 // mimo_tdl_wave.hpp -- SURVEY.md section 8(f).1 (frequency-selective MIMO-OFDM) with ONE RECEIVE ANTENNA PER WAVEFRONT (round 5):
-// k_run_mimo_ofdm_tdl_wave and its launcher; instantiated per arithmetic AND size in ten translation units
-// (pipeline_mimo_tdl_wave_{f32,f64}_{256,512,1024,1024k,2048}.hip; 1024k = the compile-time polynomial order of the benchmark).
+// k_run_mimo_ofdm_tdl_wave and its launcher; instantiated per arithmetic, size AND order mode in sixteen translation units
+// (pipeline_mimo_tdl_wave_{f32,f64}_{256,512,1024,2048}[k].hip; k = the compile-time polynomial order of the benchmark -- at every size
+// since the last day of round 6: the run-time-order kernels issue 1.4 x the vector and 5 x the scalar instructions per subcarrier).
 //
 // Reference path (restated by oracle/chains.py::chain_mimo_ofdm_tdl), as in pipeline_mimo_tdl.hip:
 //   TdlMimoChannel / corrupt_data MIMO branch      channels/fading.py:1290-1333, :1092-1118

@@ -442,6 +442,8 @@ MCLE_MIMO_TDL_WAVE_DECL(run_mimo_tdl_wave_f32_2048)
 MCLE_MIMO_TDL_WAVE_DECL(run_mimo_tdl_wave_f64_256) MCLE_MIMO_TDL_WAVE_DECL(run_mimo_tdl_wave_f64_512)
 MCLE_MIMO_TDL_WAVE_DECL(run_mimo_tdl_wave_f64_1024) MCLE_MIMO_TDL_WAVE_DECL(run_mimo_tdl_wave_f64_1024k)
 MCLE_MIMO_TDL_WAVE_DECL(run_mimo_tdl_wave_f64_2048)
+MCLE_MIMO_TDL_WAVE_DECL(run_mimo_tdl_wave_f32_256k) MCLE_MIMO_TDL_WAVE_DECL(run_mimo_tdl_wave_f32_512k) MCLE_MIMO_TDL_WAVE_DECL(run_mimo_tdl_wave_f32_2048k)
+MCLE_MIMO_TDL_WAVE_DECL(run_mimo_tdl_wave_f64_256k) MCLE_MIMO_TDL_WAVE_DECL(run_mimo_tdl_wave_f64_512k) MCLE_MIMO_TDL_WAVE_DECL(run_mimo_tdl_wave_f64_2048k)
 #undef MCLE_MIMO_TDL_WAVE_DECL
 #ifdef MCLE_EXPERIMENTS
 int run_mimo_tdl_wave_f32_experiment(int code, mcle_ctx* ctx, int nt, int nr, const MimoTdlParams& pp, int method, uint64_t seed,
@@ -461,19 +463,20 @@ static int run_mimo_tdl_wave(mcle_ctx* ctx, int dtype, int fft_size, int nt, int
                              uint32_t* d_bit) {
     const bool f32 = dtype == MCLE_F32;
 #define MCLE_WAVE_CALL(NAME) NAME(ctx, nt, nr, pp, method, seed, first, count, d_counters, d_sym, d_bit)
+    // the parked-coefficient kernels (compile-time polynomial order = the benchmark's) first, the run-time-order kernels otherwise
+#define MCLE_WAVE_SIZE(N_)                                                                                                  \
+    case N_: {                                                                                                              \
+        if (!run_time_order) {                                                                                              \
+            const int rc = f32 ? MCLE_WAVE_CALL(run_mimo_tdl_wave_f32_##N_##k) : MCLE_WAVE_CALL(run_mimo_tdl_wave_f64_##N_##k); \
+            if (rc != MCLE_E_UNSUPPORTED) return rc;                                                                        \
+        }                                                                                                                   \
+        return f32 ? MCLE_WAVE_CALL(run_mimo_tdl_wave_f32_##N_) : MCLE_WAVE_CALL(run_mimo_tdl_wave_f64_##N_);               \
+    }
     switch (fft_size) {
-        case 256: return f32 ? MCLE_WAVE_CALL(run_mimo_tdl_wave_f32_256) : MCLE_WAVE_CALL(run_mimo_tdl_wave_f64_256);
-        case 512: return f32 ? MCLE_WAVE_CALL(run_mimo_tdl_wave_f32_512) : MCLE_WAVE_CALL(run_mimo_tdl_wave_f64_512);
-        case 2048: return f32 ? MCLE_WAVE_CALL(run_mimo_tdl_wave_f32_2048) : MCLE_WAVE_CALL(run_mimo_tdl_wave_f64_2048);
-        case 1024: {
-            if (!run_time_order) {
-                const int rc = f32 ? MCLE_WAVE_CALL(run_mimo_tdl_wave_f32_1024k) : MCLE_WAVE_CALL(run_mimo_tdl_wave_f64_1024k);
-                if (rc != MCLE_E_UNSUPPORTED) return rc;
-            }
-            return f32 ? MCLE_WAVE_CALL(run_mimo_tdl_wave_f32_1024) : MCLE_WAVE_CALL(run_mimo_tdl_wave_f64_1024);
-        }
+        MCLE_WAVE_SIZE(256) MCLE_WAVE_SIZE(512) MCLE_WAVE_SIZE(1024) MCLE_WAVE_SIZE(2048)
         default: return MCLE_E_UNSUPPORTED;
     }
+#undef MCLE_WAVE_SIZE
 #undef MCLE_WAVE_CALL
 }
 
