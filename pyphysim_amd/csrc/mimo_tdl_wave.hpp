@@ -719,7 +719,10 @@ int launch_mimo_tdl_wave(mcle_ctx* ctx, const MimoTdlParams& pp, int method, uin
         hipLaunchKernelGGL((k_mimo_tdl_symbol_polys<T, true>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream, pw,
                            PS, NR * NT, N + pp.cp, seed, first + off, n, (cx<T>*)recs, NT);
         MCLE_LAUNCH_CHECK();
-        const unsigned grid = (unsigned)oversubscribed_grid(ctx, (uint64_t)ctx->n_cu * per_cu, n, 8, 16);
+        // (realizations per workgroup: >= 8, and enough for the counters' flush to disappear at the small shapes -- pipe_common.hpp;
+        //  (256, 2 x 2) complex64: 1.28 -> 1.5e8)
+        const unsigned grid = (unsigned)oversubscribed_grid(ctx, (uint64_t)ctx->n_cu * per_cu, n,
+                                                            flush_min_units(8, sizeof(T) == 4 ? 12800 : 6400, (uint64_t)N * NR), 16);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NR), lds, ctx->stream, pw, mp, seed, first + off, n, (const cx<T>*)tw,
                            (const cx<T>*)recs, d_counters, d_sym ? d_sym + off : nullptr, d_bit ? d_bit + off : nullptr);
         MCLE_LAUNCH_CHECK();

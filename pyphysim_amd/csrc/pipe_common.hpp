@@ -51,6 +51,16 @@ inline uint64_t oversubscribed_grid(const mcle_ctx* ctx, uint64_t resident, uint
     return units < g ? units : g;
 }
 
+// What a workgroup must do per launch for its ONE flush of the counters to disappear: the flush is six atomics on one cache line,
+// ~9 ns each and serialized chip-wide, so `grid` workgroups cost grid x 54 ns whatever else runs -- at 32 768 one-wavefront workgroups
+// of eight realizations each that was 1.8 of the 2.5 ms of a (256, 1 x 2) complex64 launch (profiles/r06/planar_grid_ab.log: 1.06e8
+// realizations/s at the old grid, 3.2e8 with one workgroup per resident slot).  A realization of `samples` = fft_size x receive
+// antennas takes ~ps_per_sample picoseconds of the chip; the workgroup gets enough of them for the flush to stay below ~10 %.
+inline uint64_t flush_min_units(uint64_t base, uint64_t k_samples, uint64_t samples) {
+    const uint64_t m = k_samples / (samples > 0 ? samples : 1);
+    return m > base ? m : base;
+}
+
 template <typename T> ModemParams<T> pipe_modem(const mcle_ctx* ctx, int method) {
     ModemParams<T> p;
     // the candidate grid serves the complex128 kernels too since round 3 (cell from the float-rounded point, the literal f64

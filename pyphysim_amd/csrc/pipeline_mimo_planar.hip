@@ -75,7 +75,11 @@ __global__ __launch_bounds__((N / 4) * (NR / AH), WPS) void k_run_mimo_ofdm_plan
     // transform, 128 = no noise draws, 256 = no H x products, 512 = no receive transform, 1024 = no decode
     constexpr int ABL = VAR & ~31;
     static_assert(!R16 || (N == 1024 && NR == 4 && AH == 4), "radix-16 variant: 1024, four receive antennas, 256 threads");
-    constexpr bool TWR = AH == NR && N == 1024 && !R16;                     // a thread's twiddles in registers
+    // a thread's stage twiddles in registers for the whole kernel: 1024 points with every antenna in one thread (round 3) and, since
+    // the last day of round 6, complex64 at 2048 points (30 registers the 77 - 96-register kernels have; fetched stage by stage they
+    // were 240 gathers per realization: +7 % at 2 x 2, +2 % at 4 x 4).  NOT the other sizes: at 256 / 512 the stage-ahead fetches
+    // already hide, and the registers cost 5 - 9 % (complex64 512 2 x 2: 1.24 -> 1.13e8; complex128: level) -- profiles/r06/c4_pmc.log
+    constexpr bool TWR = !R16 && ((AH == NR && N == 1024) || (N == 2048 && sizeof(T) == 4));
     auto swz = [](int e) { return R16 ? lds_swz16f(e) : lds_swz64(e); };
     static_assert(TB % 64 == 0 && TB <= 1024 && TB >= kRec && NW <= 16, "workgroup");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -500,7 +504,8 @@ static int launch_mimo_ofdm_planar(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg,
         hipLaunchKernelGGL((k_mimo_filters_planar<T, N, NT, NR>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, pp, seed,
                            first + off, n, (cx<T>*)recs);
         MCLE_LAUNCH_CHECK();
-        const unsigned grid = (unsigned)oversubscribed_grid(ctx, resident, n, 8, 16);
+        // (realizations per workgroup: >= 8, and enough for the counters' flush to disappear at the small shapes -- pipe_common.hpp)
+        const unsigned grid = (unsigned)oversubscribed_grid(ctx, resident, n, flush_min_units(8, sizeof(T) == 4 ? 25600 : 12800, (uint64_t)N * NR), 16);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(TB), lds, ctx->stream, pp, mp, seed, first + off, n,
                            (const cx<T>*)tw, (const cx<T>*)recs, d_counters, d_sym ? d_sym + off : nullptr,
                            d_bit ? d_bit + off : nullptr);
@@ -520,7 +525,17 @@ static int launch_mimo_ofdm_planar(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg,
 // complex128 takes 120 - 250: the radix-4 geometries keep the complex128 table's wavefronts-per-SIMD bound (doubling it spilled
 // 10 - 77 registers in every 4-receive-antenna shape), the radix-16 form of the benchmark size runs four workgroups per CU
 // instead of two.
-template <typename T> constexpr int planar_wps(int w64) { return w64; }
+// (last day of round 6: at 256 points, and at 512 with two receive antennas, that bound was the complex128 LDS limit carried over --
+//  those complex64 kernels hold 78 - 93 registers and a quarter of the planes, and ran at 0.47 - 0.69 of their issue slots
+//  (profiles/r06/c4_pmc.log): two more wavefronts per SIMD there, +5 ... +18 %.  NOT elsewhere: 512 points with three receive antennas
+//  LOSE 14 - 37 % at four wavefronts per SIMD, 1024 / 2048 do not move -- profiles/r06/planar_f32_wps_ab.log)
+#ifndef MCLE_PLANAR_F32_WPS_PLUS
+#define MCLE_PLANAR_F32_WPS_PLUS 2
+#endif
+template <typename T> constexpr int planar_wps(int n, int nt, int nr, int w64) {
+    if (sizeof(T) == 4 && w64 <= 3 && ((n == 256 && !(nt == 4 && nr == 4)) || (n == 512 && nr == 2))) return w64 + MCLE_PLANAR_F32_WPS_PLUS;
+    return w64;
+}
 
 // pipeline_mimo_qw.hip: the quarter-wave kernel of the benchmark geometry (complex128; MCLE_E_UNSUPPORTED outside its envelope)
 int run_mimo_ofdm_qw(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, uint64_t seed, uint64_t first, uint64_t count,
@@ -541,7 +556,7 @@ static int run_mimo_ofdm_planar_t(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, 
     const int n = cfg->fft_size, nt = cfg->nt, nr = cfg->nr;
 #define MCLE_F64_GEOM(N_, NT_, NR_, AH_, WPS_)                                                                      \
     if (n == N_ && nt == NT_ && nr == NR_)                                                                          \
-        return launch_mimo_ofdm_planar<T, N_, NT_, NR_, AH_, planar_wps<T>(WPS_)>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
+        return launch_mimo_ofdm_planar<T, N_, NT_, NR_, AH_, planar_wps<T>(N_, NT_, NR_, WPS_)>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
     // (1024, 4 x 4), the benchmark geometry: radix-16 passes, one transform per wavefront, 256 threads (default since round 4:
     // 10.66 ms per 262 144 realizations against 11.65 for the 512-thread radix-4 form and 12.15 for the 256-thread one,
     // profiles/r04/c4_f64_r16_ab.log).  MCLE_OPT_F64_THREADS: 512 = radix-4, two antennas per thread; 256 = radix-4, four
@@ -612,9 +627,9 @@ static int run_mimo_ofdm_planar_t(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg, 
                 return launch_mimo_ofdm_planar<T, 1024, 4, 4, 4, 2, 28>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);   // loads per pass cost more than the eight products)
         }
         if (ctx->opt[MCLE_OPT_F64_THREADS] == 256)
-            return launch_mimo_ofdm_planar<T, 1024, 4, 4, 4, planar_wps<T>(2)>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
+            return launch_mimo_ofdm_planar<T, 1024, 4, 4, 4, 2>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
         if (ctx->opt[MCLE_OPT_F64_THREADS] == 512)
-            return launch_mimo_ofdm_planar<T, 1024, 4, 4, 2, planar_wps<T>(4)>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
+            return launch_mimo_ofdm_planar<T, 1024, 4, 4, 2, 4>(ctx, cfg, seed, first, count, d_counters, d_sym, d_bit);
         if constexpr (!F64) {
             // complex64: the SEPARATE channel stage at a four-wavefront register bound is the fast form (4.88 ms per 262 144
             // realizations; fused 5.08; at a three-wavefront bound 5.26 / 5.47; the matrix-core kernel 5.89 -- min-distance

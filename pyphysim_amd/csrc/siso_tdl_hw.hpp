@@ -389,7 +389,7 @@ int run_siso_tdl_hw(mcle_ctx* ctx, const SisoTdlParams& pp, int method, uint64_t
         const uint64_t n = count - off < slice ? count - off : slice;
         launch_tdl_symbol_polys<T>(ctx->stream, pp, N + pp.cp, seed, first + off, n, (cx<T>*)recs);
         MCLE_LAUNCH_CHECK();
-        const unsigned grid = (unsigned)oversubscribed_grid(ctx, (uint64_t)ctx->n_cu * per_cu, (n + NRW - 1) / NRW, 4);
+        const unsigned grid = (unsigned)oversubscribed_grid(ctx, (uint64_t)ctx->n_cu * per_cu, (n + NRW - 1) / NRW, 4, 16);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(128 * NRW), lds, ctx->stream, pw, mp, seed, first + off, n, (const cx<T>*)twN, (const cx<T>*)twH,
                            (const cx<T>*)recs, d_counters, d_sym ? d_sym + off : nullptr, d_bit ? d_bit + off : nullptr);
         MCLE_LAUNCH_CHECK();

@@ -448,7 +448,7 @@ int run_siso_tdl_wave_w(mcle_ctx* ctx, const SisoTdlParams& pp, int method, uint
         MCLE_LAUNCH_CHECK();
         // (round 6: one flush of the counters per WORKGROUP instead of per wavefront -- a workgroup's fixed cost fell, and the grid that
         //  wanted >= 12 passes per workgroup now takes 4: +4 % at 131 072 realizations per launch, profiles/r06/grid_sweep_others.log)
-        const unsigned grid = (unsigned)oversubscribed_grid(ctx, (uint64_t)ctx->n_cu * per_cu, (n + NWV - 1) / NWV, 4);
+        const unsigned grid = (unsigned)oversubscribed_grid(ctx, (uint64_t)ctx->n_cu * per_cu, (n + NWV - 1) / NWV, 4, 16);   // (sixteen against eight: +1 % at every size)
         hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NWV), lds, ctx->stream, pw, mp, seed, first + off, n, (const cx<T>*)tw,
                            (const cx<T>*)recs, d_counters, d_sym ? d_sym + off : nullptr, d_bit ? d_bit + off : nullptr);
         MCLE_LAUNCH_CHECK();
