@@ -147,6 +147,36 @@ __global__ __launch_bounds__(64 * (siso_wave_nwv<T, N>()), WPS) void k_run_ofdm_
                 r16_wave_sync();
             }
             const uint64_t n_first = (uint64_t)os * U, n_last = n_first + U;
+            // 256 / 512 points, full band: the symbol's N / 16 DATA blocks occupy 16 / 32 lanes -- they store the label bytes, and ALL
+            // 64 lanes then take N / 64 consecutive labels each for the look-ups and the scatter (round 6, last day: the 16 lanes that
+            // drew a block also scattered its sixteen symbols, 128 issue slots at a quarter of the lanes -- 7 % of the 256 kernel)
+            bool scattered = false;
+            if constexpr (N <= 512) {
+                if (U == N) {
+                    constexpr int PER = N / 64;                              // labels per lane: 4 or 8
+                    if (gi < N / 16) {
+                        const Words4 dw = rng.block(STREAM_DATA, (uint32_t)((n_first >> 4) + (uint64_t)gi));
+                        *reinterpret_cast<uint4*>(s_idx + 16 * gi) = make_uint4(dw.w[0] & (mask * 0x01010101u), dw.w[1] & (mask * 0x01010101u),
+                                                                                dw.w[2] & (mask * 0x01010101u), dw.w[3] & (mask * 0x01010101u));
+                    }
+                    r16_wave_sync();
+                    const int d0 = PER * gi;
+                    const int p0 = swz(fft_pos_of_index<N>(ofdm_bin(d0, N, U)));
+                    uint32_t lab[PER / 4];
+#pragma unroll
+                    for (int q = 0; q < PER / 4; ++q) lab[q] = *reinterpret_cast<const uint32_t*>(s_idx + d0 + 4 * q);
+#pragma unroll
+                    for (int j = 0; j < PER; ++j) {
+                        const int tx = (int)((lab[j >> 2] >> ((j & 3) * 8)) & 0xFFu);
+                        const cx<T> c = cscale(s_table[tx], tx_scale);
+                        const int pos = p0 ^ swz(fft_pos_of_index<N>(j));   // bin(d0 + j) = bin(d0) ^ j: digit reversal and swizzle are XOR-linear
+                        pr[pos] = c.x;
+                        pi[pos] = c.y;
+                    }
+                    scattered = true;
+                }
+            }
+            if (!scattered)
             for (uint64_t blk = (n_first >> 4) + gi; blk <= ((n_last - 1) >> 4); blk += 64) {
                 const Words4 dw = rng.block(STREAM_DATA, (uint32_t)blk);
                 if (U == N && (U & 15) == 0) {           // full band on block boundaries: bin(d0 + j) = bin(d0) ^ j, and digit

@@ -1,7 +1,7 @@
 #!/bin/bash
 # counters of config 3's kernels at 1024 / 2048 (one launch of 2^18 realizations each): gpurun_out/tdl_pmc_<group>/
 mkdir -p gpurun_out; export TMPDIR=/tmp
-specs="1024:2:f32 2048:2:f32 2048:3:f32 1024:2:f64 2048:2:f64 2048:3:f64"
+specs=${@:-"1024:2:f32 2048:2:f32 2048:3:f32 1024:2:f64 2048:2:f64 2048:3:f64"}
 i=0
 for pmc in "SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_SALU" \
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_WAIT_ANY SQ_INSTS_SMEM SQ_INSTS_VMEM_RD"; do
