@@ -288,9 +288,18 @@ def self_launch(args):
     """`python bench.py --gpus N` without a launcher: start N ranks of this file under torch.distributed.run."""
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this driver (RCCL needs it)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
-    return subprocess.call(cmd, env=env)
+    # (the port is free when it is picked, not necessarily when the launcher binds it: a launch that dies within seconds -- the
+    #  rendezvous' EADDRINUSE, before any rank has printed anything -- is repeated on another port, twice at most)
+    rc = 1
+    for attempt in range(3):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        t0 = time.time()
+        rc = subprocess.call(cmd, env=env)
+        if rc == 0 or time.time() - t0 > 20.0:
+            break
+        print("bench.py: launcher exited with %d after %.1f s, trying another rendezvous port" % (rc, time.time() - t0), file=sys.stderr)
+    return rc
 
 
 # ---- workloads --------------------------------------------------------------------------------------------------

@@ -129,7 +129,10 @@ inline void launch_tdl_symbol_polys(hipStream_t stream, const SisoTdlParams& pp,
     const int per = pp.n_ofdm_sym * pp.n_taps;
     const int NB = (2 * pp.L * pp.n_taps + 3) / 4;
     const int G = per <= 256 ? 256 / per : 0;
-    if (G >= 1 && (size_t)G * NB * 16 <= (size_t)32 * 1024) {
+#ifndef MCLE_TDL_POLYS_SH
+#define MCLE_TDL_POLYS_SH 1
+#endif
+    if (MCLE_TDL_POLYS_SH && G >= 1 && (size_t)G * NB * 16 <= (size_t)32 * 1024) {
         hipLaunchKernelGGL((k_tdl_symbol_polys<T, true>), dim3((unsigned)((n + G - 1) / G)), dim3(256), (size_t)G * NB * 16, stream, pp, W, seed,
                            first, n, recs, G, NB);
     } else {

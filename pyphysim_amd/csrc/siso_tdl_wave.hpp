@@ -39,6 +39,9 @@ namespace mcle {
 // Same arithmetic as k_run_ofdm_tdl_batch operation for operation outside the transforms and the equaliser's twiddle product
 // (polynomial Horner, tap order, division), so complex128 counts equal the oracle's like that kernel's (tests/test_gpu_tdl_wave.py).
 constexpr int kWaveMaxTaps = 8;
+#ifndef MCLE_TDL_WAVE_MAXF
+#define MCLE_TDL_WAVE_MAXF 16      // workgroups per resident slot, at most
+#endif
 // N = 1024: the radix-16 passes with register hand-over on both sides of the channel.  N = 256 / 512 / 2048: radix-4 stages on the
 // wavefront's planes (fft_r16.hpp: wave_fft_dif / wave_fft_dit, N / 256 butterfly positions per lane and stage), the same
 // hand-over through explicit reads and writes; everything between the transforms is the same code on R = N / 64 samples per lane.
@@ -478,7 +481,7 @@ int run_siso_tdl_wave_w(mcle_ctx* ctx, const SisoTdlParams& pp, int method, uint
         MCLE_LAUNCH_CHECK();
         // (round 6: one flush of the counters per WORKGROUP instead of per wavefront -- a workgroup's fixed cost fell, and the grid that
         //  wanted >= 12 passes per workgroup now takes 4: +4 % at 131 072 realizations per launch, profiles/r06/grid_sweep_others.log)
-        const unsigned grid = (unsigned)oversubscribed_grid(ctx, (uint64_t)ctx->n_cu * per_cu, (n + NWV - 1) / NWV, 4, 16);   // (sixteen against eight: +1 % at every size)
+        const unsigned grid = (unsigned)oversubscribed_grid(ctx, (uint64_t)ctx->n_cu * per_cu, (n + NWV - 1) / NWV, 4, MCLE_TDL_WAVE_MAXF);   // (sixteen against eight: +1 % at every size)
         hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NWV), lds, ctx->stream, pw, mp, seed, first + off, n, (const cx<T>*)tw,
                            (const cx<T>*)recs, d_counters, d_sym ? d_sym + off : nullptr, d_bit ? d_bit + off : nullptr);
         MCLE_LAUNCH_CHECK();
