@@ -36,15 +36,22 @@ DEFAULT = [
     #  also for 2 x 2; the planar kernels below serve everything outside that envelope)
     r"k_run_mimo_ofdm_pw<[24], [1-4], 3, 0>", r"k_run_mimo_ofdm_pw<8, [1-4], 2, 0>", r"k_run_mimo_ofdm_fw<[24], [1-4], 3, 0>",
     r"k_run_mimo_ofdm_planar<double, 1024, [1-4], 4, 4, 2, 12>", r"k_run_mimo_ofdm_planar<float, 1024, [1-4], 4, 4, 4, 4>",
-    r"k_run_mimo_ofdm_planar<(double|float), 256, [12], 2, 2, 2, 0>", r"k_run_mimo_ofdm_planar<(double|float), 256, [1-3], 3, 3, 2, 0>",
-    r"k_run_mimo_ofdm_planar<(double|float), 256, [1-4], 4, 2, 3, 0>",
-    r"k_run_mimo_ofdm_planar<(double|float), 512, [12], 2, 2, 3, 0>", r"k_run_mimo_ofdm_planar<(double|float), 512, [1-3], 3, 3, 2, 0>",
+    # (last day of round 6: complex64 at 256 points, and at 512 with two receive antennas, two more wavefronts per SIMD than the table)
+    r"k_run_mimo_ofdm_planar<double, 256, [12], 2, 2, 2, 0>", r"k_run_mimo_ofdm_planar<double, 256, [1-3], 3, 3, 2, 0>",
+    r"k_run_mimo_ofdm_planar<double, 256, [1-4], 4, 2, 3, 0>",
+    r"k_run_mimo_ofdm_planar<float, 256, [12], 2, 2, 4, 0>", r"k_run_mimo_ofdm_planar<float, 256, [1-3], 3, 3, 4, 0>",
+    r"k_run_mimo_ofdm_planar<float, 256, [1-3], 4, 2, 5, 0>", r"k_run_mimo_ofdm_planar<float, 256, 4, 4, 2, 3, 0>",
+    r"k_run_mimo_ofdm_planar<double, 512, [12], 2, 2, 3, 0>", r"k_run_mimo_ofdm_planar<float, 512, [12], 2, 2, 5, 0>",
+    r"k_run_mimo_ofdm_planar<(double|float), 512, [1-3], 3, 3, 2, 0>",
     r"k_run_mimo_ofdm_planar<(double|float), 512, [1-4], 4, 2, 3, 0>",
     r"k_run_mimo_ofdm_planar<(double|float), 1024, [12], 2, 2, 3, 0>", r"k_run_mimo_ofdm_planar<(double|float), 1024, [1-3], 3, 3, 2, 0>",
     r"k_run_mimo_ofdm_planar<(double|float), 2048, [12], 2, 2, 4, 0>", r"k_run_mimo_ofdm_planar<(double|float), 2048, [1-3], 3, 3, 2, 0>",
     r"k_run_mimo_ofdm_planar<(double|float), 2048, [12], 4, 2, 4, 0>", r"k_run_mimo_ofdm_planar<double, 2048, 3, 4, 2, 4, 0>",
     r"k_run_mimo_ofdm_planar<(double|float), 2048, 4, 4, 4, 2, 0>", r"k_run_mimo_ofdm_planar<float, 2048, 3, 4, 4, 2, 0>", r"k_mimo_filters_planar<",
     # config 3 (pipeline_siso_tdl.hip: the wavefront kernel where it is the faster one, the batched kernels otherwise)
+    # (2048 points since the last day of round 6: two wavefronts per realization, k_run_ofdm_tdl_hw<T, order, wavefronts per SIMD,
+    #  realizations per workgroup>; the one-wavefront kernels there serve a delay beyond the prefix and large constellation tables)
+    r"k_run_ofdm_tdl_hw<float, \d, 3, 1>", r"k_run_ofdm_tdl_hw<double, \d, 2, 2>",
     r"k_run_ofdm_tdl_wave<float, 1024, \d, 3>", r"k_run_ofdm_tdl_wave<float, 2048, \d, 2>", r"k_run_ofdm_tdl_wave<float, 256, \d, 5>",
     r"k_run_ofdm_tdl_wave<float, 512, \d, 4>", r"k_run_ofdm_tdl_wave<double, 256, \d, 4>", r"k_run_ofdm_tdl_wave<double, 512, \d, 3>",
     r"k_run_ofdm_tdl_wave<double, 1024, \d, 2>", r"k_run_ofdm_tdl_wave<double, 2048, \d, 1>",
