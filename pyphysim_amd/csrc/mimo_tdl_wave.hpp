@@ -599,6 +599,13 @@ __global__ __launch_bounds__(64 * NR, WPS) void k_run_mimo_ofdm_tdl_wave(MimoTdl
                                 qam_count4(x, qp, se, be);
                             }
                             counted = true;
+                        } else if (certpath && mp.cert == 1) {      // the margin certificate in the level domain too (last day of round 6)
+#pragma unroll
+                            for (int j = 0; j < BQ; ++j) {
+                                const cx<T> e4[4] = {est[4 * j], est[4 * j + 1], est[4 * j + 2], est[4 * j + 3]};
+                                if (valid[j]) walk_qam_count4<T, true>(mp, s_table, e4, sent[j], se, be);
+                            }
+                            counted = true;
                         }
                     } else {
                         if (slicer || (certpath && mp.cert == 1)) {

@@ -119,35 +119,38 @@ __device__ __forceinline__ int walk_qam_slicer(double2 r, double scale, int L, i
 // instead of ~27 instructions per decision.  CERT: demod_qam_cert's margin test (same t, same clamp, same rint, same bound); a symbol
 // it does not vouch for takes the literal sweep, whose label goes back to the level domain.  !CERT: the slicer's floor(t + 1/2).
 // `sent`: the four labels, a byte each.
-template <bool CERT>
-__device__ __forceinline__ void walk_qam_count4(const ModemParams<double>& mp, const double2* __restrict__ s_table, const double2 (&e)[4],
+template <typename T, bool CERT>
+__device__ __forceinline__ void walk_qam_count4(const ModemParams<T>& mp, const cx<T>* __restrict__ s_table, const cx<T> (&e)[4],
                                                 uint32_t sent, unsigned& se, unsigned& be) {
+    static_assert(sizeof(T) == 8 || CERT, "complex64 slices in the packed form (qam_levels4)");
     const int hb = mp.half_bits;
     const uint32_t fm = (1u << hb) - 1u;
     QamPack qp;
     qp.hb = hb;
     qp.m1 = (((fm >> 1) | ((fm >> 1) << hb)) & 0xFFu) * 0x01010101u;
     qp.m2 = (((fm >> 2) | ((fm >> 2) << hb)) & 0xFFu) * 0x01010101u;
-    const double lm1 = (double)(mp.qam_L - 1), hs = mp.qam_scale * 0.5, hl = lm1 * 0.5;
-    constexpr double lim = 0.5 - 0x1p-30;
+    const T lm1 = (T)(mp.qam_L - 1), hs = mp.qam_scale * (T)0.5, hl = lm1 * (T)0.5;
+    constexpr T lim = sizeof(T) == 8 ? (T)(0.5 - 0x1p-30) : (T)(0.5 - 0x1p-15);      // demod_qam_cert's margins
+    [[maybe_unused]] const T rmax = ((T)16 + hl) / hs;                      // complex64: the certificate's range (wave-uniform)
     uint32_t lv = 0u;
     [[maybe_unused]] bool sure[4], all = true;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         int kj, ki;
         if constexpr (CERT) {                                       // modem.hpp: demod_qam_cert, operation for operation
-            double tj = e[i].x * hs + hl, ti = hl - e[i].y * hs;
-            tj = fmin(fmax(tj, 0.0), lm1);
-            ti = fmin(fmax(ti, 0.0), lm1);
-            const double rj = rint(tj), ri = rint(ti);
+            T tj = e[i].x * hs + hl, ti = hl - e[i].y * hs;
+            tj = fmin(fmax(tj, (T)0), lm1);
+            ti = fmin(fmax(ti, (T)0), lm1);
+            const T rj = rint(tj), ri = rint(ti);
             sure[i] = fabs(tj - rj) <= lim && fabs(ti - ri) <= lim;
+            if constexpr (sizeof(T) == 4) sure[i] = sure[i] && fabs(e[i].x) <= rmax && fabs(e[i].y) <= rmax;
             all = all && sure[i];
             kj = (int)rj;
             ki = (int)ri;
         } else {                                                    // walk_qam_slicer's levels
-            const double tj = (e[i].x * mp.qam_scale + lm1) * 0.5 + 0.5, ti = (lm1 - e[i].y * mp.qam_scale) * 0.5 + 0.5;
-            kj = (int)floor(fmin(fmax(tj, 0.0), lm1));
-            ki = (int)floor(fmin(fmax(ti, 0.0), lm1));
+            const T tj = (e[i].x * mp.qam_scale + lm1) * (T)0.5 + (T)0.5, ti = (lm1 - e[i].y * mp.qam_scale) * (T)0.5 + (T)0.5;
+            kj = (int)floor(fmin(fmax(tj, (T)0), lm1));
+            ki = (int)floor(fmin(fmax(ti, (T)0), lm1));
         }
         lv |= (((uint32_t)ki << hb) | (uint32_t)kj) << (8 * i);
     }
@@ -156,13 +159,19 @@ __device__ __forceinline__ void walk_qam_count4(const ModemParams<double>& mp, c
 #pragma unroll
             for (int i = 0; i < 4; ++i)
                 if (!sure[i]) {
-                    const uint32_t lab = (uint32_t)walk_sweep<double>(s_table, mp.M, e[i]);
+                    const uint32_t lab = (uint32_t)walk_sweep<T>(s_table, mp.M, e[i]);
                     const uint32_t lev = lab ^ ((lab >> 1) & (qp.m1 & 0xFFu));
                     lv = (lv & ~(0xFFu << (8 * i))) | (lev << (8 * i));
                 }
         }
     }
     qam_count4(lv ^ labels_to_levels(sent, qp), qp, se, be);
+}
+// (the complex128 callers that named only the form)
+template <bool CERT>
+__device__ __forceinline__ void walk_qam_count4(const ModemParams<double>& mp, const double2* __restrict__ s_table, const double2 (&e)[4],
+                                                uint32_t sent, unsigned& se, unsigned& be) {
+    walk_qam_count4<double, CERT>(mp, s_table, e, sent, se, be);
 }
 
 // N decisions and their error counts.  DEC fixes the form at compile time; the certificates are those of modem.hpp.  complex64:
@@ -189,12 +198,14 @@ __device__ __forceinline__ void walk_decide(const ModemParams<T>& mp, const cx<T
         }
         return;
     }
-    if constexpr (sizeof(T) == 8 && (DEC == WDEC_SLICER || DEC == WDEC_QAM_CERT) && N % 4 == 0) {      // level-domain counting, four at a time
+    // level-domain counting, four at a time: complex128 both forms; complex64 the margin certificate (last day of round 6: the full-wave
+    // kernel's min-distance rate was 0.84 of its slicer rate, a label and a Gray decode per decision)
+    if constexpr ((sizeof(T) == 8 ? (DEC == WDEC_SLICER || DEC == WDEC_QAM_CERT) : DEC == WDEC_QAM_CERT) && N % 4 == 0) {
 #pragma unroll
         for (int g0 = 0; g0 < N; g0 += 4) {
             const cx<T> e4[4] = {e[g0], e[g0 + 1], e[g0 + 2], e[g0 + 3]};
             const uint32_t sent = (uint32_t)tx[g0] | ((uint32_t)tx[g0 + 1] << 8) | ((uint32_t)tx[g0 + 2] << 16) | ((uint32_t)tx[g0 + 3] << 24);
-            walk_qam_count4<DEC == WDEC_QAM_CERT>(mp, s_table, e4, sent, se, be);
+            walk_qam_count4<T, DEC == WDEC_QAM_CERT>(mp, s_table, e4, sent, se, be);
         }
         return;
     }
