@@ -46,16 +46,28 @@ __host__ __device__ __forceinline__ int mimo_tdl_nq(int K) { return (K + 2) / 2;
 __host__ __device__ __forceinline__ size_t mimo_tdl_wave_rec(int S, int NT, int NR, int K) {
     return (size_t)NR * mimo_tdl_nq(K) * (2 * S * NT) + (size_t)S * NR * NT;
 }
-template <typename T, bool WAVE = false>
+// KT > 0 (last day of round 6): the polynomial order at compile time -- the run-time form walks a ladder of thirteen uniform
+// branches per ray for its `m <= K` guards; I32: count x processes below 2^32, the thread's (realization, process) split in 32-bit
+// arithmetic (the 64-bit division is ~100 instructions).  Same operations on the same values in the same order.
+template <typename T, bool WAVE = false, int KT = 0, bool I32 = false>
 __global__ __launch_bounds__(256) void k_mimo_tdl_symbol_polys(MimoTdlParams pp, int PS, int P1, int W, uint64_t seed,
                                                                uint64_t first, uint64_t count, cx<T>* __restrict__ recs,
                                                                int NT = 0) {
-    const int L = pp.L, K = pp.K;
+    const int L = pp.L, K = KT > 0 ? KT : pp.K;
     const uint64_t per_real = (uint64_t)pp.n_ofdm_sym * PS;
     const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= count * per_real) return;
-    const uint64_t rl = q / per_real;
-    const int rem = (int)(q - rl * per_real), os = rem / PS, p = rem - os * PS;
+    uint64_t rl;
+    int rem;
+    if constexpr (I32) {
+        const uint32_t q32 = (uint32_t)q, pr32 = (uint32_t)per_real, r32 = q32 / pr32;
+        rl = r32;
+        rem = (int)(q32 - r32 * pr32);
+    } else {
+        rl = q / per_real;
+        rem = (int)(q - rl * per_real);
+    }
+    const int os = rem / PS, p = rem - os * PS;
     const double two_pi = 6.283185307179586476925286766559;
     const double xc = 0.5 * (double)(W - 1);
     // WAVE: the polynomial of tap s in the OUTPUT sample's abscissa x' = x + d_s -- the same rays about the centre minus d_s samples
@@ -117,8 +129,8 @@ __global__ __launch_bounds__(256) void k_mimo_tdl_symbol_polys(MimoTdlParams pp,
         }
         const T th = (T)(two_pi * w * pp.dt);                              // rad per sample
 #pragma unroll
-        for (int m = 0; m <= kMaxOrder; ++m)
-            if (m <= K) {
+        for (int m = 0; m <= (KT > 0 ? KT : kMaxOrder); ++m)
+            if (KT > 0 || m <= K) {
                 T pw = 1;                                                  // 1 / m! ...
                 for (int i = 2; i <= m; ++i) pw /= (T)i;
                 for (int i = 0; i < m; ++i) pw *= th;                      // ... x theta^m
@@ -132,8 +144,8 @@ __global__ __launch_bounds__(256) void k_mimo_tdl_symbol_polys(MimoTdlParams pp,
     cx<T>* rec = recs + (rl * pp.n_ofdm_sym + os) * (WAVE ? (uint64_t)mimo_tdl_wave_rec(S, NT, NR, K) : (uint64_t)PS * (K + 2));
     T mr = 0, mi = 0;
 #pragma unroll
-    for (int m = 0; m <= kMaxOrder; ++m)
-        if (m <= K) {
+    for (int m = 0; m <= (KT > 0 ? KT : kMaxOrder); ++m)
+        if (KT > 0 || m <= K) {
             T cr, ci;                                                      // times j^m
             switch (m & 3) {
                 case 0: cr = ar[m]; ci = ai[m]; break;
@@ -154,6 +166,24 @@ __global__ __launch_bounds__(256) void k_mimo_tdl_symbol_polys(MimoTdlParams pp,
         }
     rec[(WAVE ? NR * NQ * LW : PS * (K + 1)) + p] = mk<T>(mr, mi);
 }
-
+// host: the records of n realizations starting at `first` (one launch on `stream`): the compile-time orders of the benchmark's
+// Doppler per arithmetic (2, 5) and the one between, 32-bit index arithmetic where the thread count allows
+template <typename T, bool WAVE>
+inline void launch_mimo_tdl_symbol_polys(hipStream_t stream, const MimoTdlParams& pp, int PS, int P1, int W, uint64_t seed, uint64_t first,
+                                         uint64_t n, cx<T>* recs, int NT) {
+    const uint64_t threads = n * (uint64_t)pp.n_ofdm_sym * PS;
+    const dim3 grid((unsigned)((threads + 255) / 256)), block(256);
+    const bool i32 = threads < (1ull << 32);
+#define MCLE_POLYS_K(KT_)                                                                                                       \
+    if (i32) hipLaunchKernelGGL((k_mimo_tdl_symbol_polys<T, WAVE, KT_, true>), grid, block, 0, stream, pp, PS, P1, W, seed, first, n, recs, NT); \
+    else hipLaunchKernelGGL((k_mimo_tdl_symbol_polys<T, WAVE, KT_, false>), grid, block, 0, stream, pp, PS, P1, W, seed, first, n, recs, NT);
+    switch (pp.K) {
+        case 2: MCLE_POLYS_K(2) break;
+        case 3: MCLE_POLYS_K(3) break;
+        case 5: MCLE_POLYS_K(5) break;
+        default: MCLE_POLYS_K(0) break;
+    }
+#undef MCLE_POLYS_K
+}
 
 }  // namespace mcle

@@ -722,9 +722,7 @@ int launch_mimo_tdl_wave(mcle_ctx* ctx, const MimoTdlParams& pp, int method, uin
     if (got / one < slice) slice = got / one;
     for (uint64_t off = 0; off < count; off += slice) {
         const uint64_t n = count - off < slice ? count - off : slice;
-        const uint64_t threads = n * (uint64_t)pp.n_ofdm_sym * PS;
-        hipLaunchKernelGGL((k_mimo_tdl_symbol_polys<T, true>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream, pw,
-                           PS, NR * NT, N + pp.cp, seed, first + off, n, (cx<T>*)recs, NT);
+        launch_mimo_tdl_symbol_polys<T, true>(ctx->stream, pw, PS, NR * NT, N + pp.cp, seed, first + off, n, (cx<T>*)recs, NT);
         MCLE_LAUNCH_CHECK();
         // (realizations per workgroup: >= 8, and enough for the counters' flush to disappear at the small shapes -- pipe_common.hpp;
         //  (256, 2 x 2) complex64: 1.28 -> 1.5e8)

@@ -418,9 +418,7 @@ int run_mimo_tdl_impl(mcle_ctx* ctx, MimoTdlParams pp, int method, uint64_t seed
     if ((rc = ctx->scratch((size_t)slice * per_real * sizeof(cx<T>), &recs))) return rc;
     for (uint64_t off = 0; off < count; off += slice) {
         const uint64_t n = count - off < slice ? count - off : slice;
-        const uint64_t threads = n * (uint64_t)pp.n_ofdm_sym * PS;
-        hipLaunchKernelGGL(k_mimo_tdl_symbol_polys<T>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream, pp,
-                           (int)PS, NA * NA, N + pp.cp, seed, first + off, n, (cx<T>*)recs);
+        launch_mimo_tdl_symbol_polys<T, false>(ctx->stream, pp, (int)PS, NA * NA, N + pp.cp, seed, first + off, n, (cx<T>*)recs, 0);
         MCLE_LAUNCH_CHECK();
         const unsigned grid = (unsigned)oversubscribed_grid(ctx, (uint64_t)ctx->n_cu * per_cu, n);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(kPipeBlock), lds, ctx->stream, pp, mp, seed, first + off, n,
