@@ -32,6 +32,9 @@ __device__ __forceinline__ void wg_account(WgTotals& t, unsigned se, unsigned be
 }
 __device__ __forceinline__ void wg_flush(const WgTotals& t, mcle_counters* counters, unsigned long long n_sym,
                                          unsigned long long n_bits) {
+#if defined(MCLE_EXPERIMENTS) && defined(MCLE_NO_FLUSH)
+    return;                 // (timing bound: no flush at all -- wrong counters)
+#endif
     if (!counters) return;
     // (a zero is not added: the six words share a cache line and its atomics are serialized chip-wide, ~9 ns each -- `skip` is zero
     //  outside the iterative solvers' outage cases, the error sums at high SNR)
