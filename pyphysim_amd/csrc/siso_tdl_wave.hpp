@@ -504,7 +504,13 @@ int run_siso_tdl_wave(mcle_ctx* ctx, const SisoTdlParams& pp, int method, uint64
         else if (ctx->opt[MCLE_OPT_TDL_KERNEL] == 4) return run_siso_tdl_wave_w<T, N, 4>(ctx, pp, method, seed, first, count, d_counters, d_sym, d_bit);
         else return run_siso_tdl_wave_w<T, N, 3>(ctx, pp, method, seed, first, count, d_counters, d_sym, d_bit);
     } else {        // registers: 96 / 118 (256), 124 / 158 (512) in complex64 (stage twiddles included) / complex128
-        constexpr int W = N == 256 ? (sizeof(T) == 8 ? 4 : 5) : (sizeof(T) == 8 ? 3 : 4);
+#ifndef MCLE_TDL_256_F32_WPS
+#define MCLE_TDL_256_F32_WPS 6      // (six against five: +2.7 % with 9 spilled registers at the 80-register bound; seven: level)
+#endif
+#ifndef MCLE_TDL_256_F64_WPS
+#define MCLE_TDL_256_F64_WPS 5      // (five against four: +2.6 % with 14 spilled at 96)
+#endif
+        constexpr int W = N == 256 ? (sizeof(T) == 8 ? MCLE_TDL_256_F64_WPS : MCLE_TDL_256_F32_WPS) : (sizeof(T) == 8 ? 3 : 4);
         return run_siso_tdl_wave_w<T, N, W>(ctx, pp, method, seed, first, count, d_counters, d_sym, d_bit);
     }
 }

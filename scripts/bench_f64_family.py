@@ -36,8 +36,11 @@ for fft, nt, nr in ((256, 2, 2), (256, 4, 4), (512, 2, 2), (512, 4, 4), (1024, 2
         with eng.options(f64_generic=generic, f32_mfma=0 if planar else 1, f64_threads=261 if planar == 261 else 0):
             run = lambda first: eng.run_mimo_ofdm(nt, nr, fft, 16, fft, 1, nv, 1, first, n, method=method, dtype=DT,
                                                   counters=cnt)
-            run(1 << 30)
-            eng.sync()
+            _t0, _k = __import__('time').time(), 0        # untimed launches until the device has been busy for 60 ms (timed cold, short
+            while _k < 64 and (_k < 1 or __import__('time').time() - _t0 < 0.06):   # launches read 5 - 10 % low: DESIGN 6, round 6)
+                run((1 << 30) + _k * n)
+                eng.sync()
+                _k += 1
             eng.timer_start()
             for s in range(3):
                 run(s * n)

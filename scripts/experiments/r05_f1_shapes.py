@@ -21,8 +21,11 @@ for dt in ("f32", "f64"):
         cnt = eng.new_counters()
         run = lambda first: eng.run_mimo_ofdm_tdl(nt, nr, fft, 16 if fft < 2048 else 32, fft, 1, 10 ** -2.5, p, list(range(5)), 1,
                                                   first, n, Ts=1.0 / (15e3 * fft), method=_lib.DEMOD_QAM_SLICER, dtype=dt, counters=cnt)
-        run(1 << 30)
-        eng.sync()
+        _t0, _k = __import__('time').time(), 0        # untimed launches until the device has been busy for 60 ms (timed cold, short
+        while _k < 64 and (_k < 1 or __import__('time').time() - _t0 < 0.06):   # launches read 5 - 10 % low: DESIGN 6, round 6)
+            run((1 << 30) + _k * n)
+            eng.sync()
+            _k += 1
         eng.timer_start()
         for s in range(3):
             run(s * n)

@@ -20,8 +20,11 @@ for fft in (256, 512, 1024, 2048):
             n = min(262144, max(16384, int(262144 * 4096 / (fft * nr)) // 8192 * 8192))
             cnt = eng.new_counters()
             run = lambda first: eng.run_mimo_ofdm(nt, nr, fft, 16, fft, 1, 10 ** -2.5, 1, first, n, method=_lib.DEMOD_MINDIST, dtype=DT, counters=cnt)
-            run(1 << 30)
-            eng.sync()
+            _t0, _k = __import__('time').time(), 0        # untimed launches until the device has been busy for 60 ms (timed cold, short
+            while _k < 64 and (_k < 1 or __import__('time').time() - _t0 < 0.06):   # launches read 5 - 10 % low: DESIGN 6, round 6)
+                run((1 << 30) + _k * n)
+                eng.sync()
+                _k += 1
             eng.timer_start()
             for s in range(3):
                 run(s * n)

@@ -25,8 +25,11 @@ for dt in ("f32", "f64"):
         cnt = eng.new_counters()
         with eng.options(tdl_kernel=kern):
             run = lambda first: eng.run_ofdm_tdl(fft, 16, fft, 1, 0.01, p_lin, d_idx, 1, first, n, Fd=10.0, Ts=Ts, L=8, dtype=dt, counters=cnt)
-            run(1 << 30)
-            eng.sync()
+            _t0, _k = __import__('time').time(), 0        # untimed launches until the device has been busy for 60 ms (timed cold, short
+            while _k < 64 and (_k < 1 or __import__('time').time() - _t0 < 0.06):   # launches read 5 - 10 % low: DESIGN 6, round 6)
+                run((1 << 30) + _k * n)
+                eng.sync()
+                _k += 1
             eng.timer_start()
             for s in range(4):
                 run(s * n)
