@@ -52,8 +52,8 @@ DEFAULT = [
     # (2048 points since the last day of round 6: two wavefronts per realization, k_run_ofdm_tdl_hw<T, order, wavefronts per SIMD,
     #  realizations per workgroup>; the one-wavefront kernels there serve a delay beyond the prefix and large constellation tables)
     r"k_run_ofdm_tdl_hw<float, \d, 3, 1>", r"k_run_ofdm_tdl_hw<double, \d, 2, 2>",
-    r"k_run_ofdm_tdl_wave<float, 1024, \d, 3>", r"k_run_ofdm_tdl_wave<float, 2048, \d, 2>", r"k_run_ofdm_tdl_wave<float, 256, \d, 5>",
-    r"k_run_ofdm_tdl_wave<float, 512, \d, 4>", r"k_run_ofdm_tdl_wave<double, 256, \d, 4>", r"k_run_ofdm_tdl_wave<double, 512, \d, 3>",
+    r"k_run_ofdm_tdl_wave<float, 1024, \d, 3>", r"k_run_ofdm_tdl_wave<float, 2048, \d, 2>", r"k_run_ofdm_tdl_wave<float, 256, \d, 6>",
+    r"k_run_ofdm_tdl_wave<float, 512, \d, 4>", r"k_run_ofdm_tdl_wave<double, 256, \d, 5>", r"k_run_ofdm_tdl_wave<double, 512, \d, 3>",
     r"k_run_ofdm_tdl_wave<double, 1024, \d, 2>", r"k_run_ofdm_tdl_wave<double, 2048, \d, 1>",
     r"k_run_ofdm_tdl_batch<(float|double), (64|128), \d>", r"k_tdl_symbol_polys<",
     # f1 (pipeline_mimo_tdl.hip): one receive antenna per wavefront inside its envelope, the cooperative kernel for the rest
