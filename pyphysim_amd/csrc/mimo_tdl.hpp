@@ -74,6 +74,8 @@ __global__ __launch_bounds__(256) void k_mimo_tdl_symbol_polys(MimoTdlParams pp,
     const int tap = p / P1;
     const double tc = pp.Ts + pp.dt * ((double)((uint64_t)os * W) + (WAVE ? xc - (double)pp.tap_delay[tap] : xc));
     const Rng rng(seed, first + rl);
+    // (the largest |Doppler phase| any sample of the run can see, in turns)
+    [[maybe_unused]] const bool small_phase = pp.Fd * (pp.Ts + pp.dt * ((double)(pp.n_ofdm_sym + 1) * W + (double)pp.dmax)) < 0.25;
     T ar[kMaxOrder + 1], ai[kMaxOrder + 1];
 #pragma unroll
     for (int m = 0; m <= kMaxOrder; ++m) ar[m] = ai[m] = 0;
@@ -114,20 +116,36 @@ __global__ __launch_bounds__(256) void k_mimo_tdl_symbol_polys(MimoTdlParams pp,
             u_phi = uniform_at(rng, STREAM_PHASE, rq);
         }
         const double psi_t = u_psi;
-        const double w = pp.Fd * cospi(2.0 * u_phi);                       // Hz; cos(phi), phi = 2 pi u
-        const double ph = fma(w, tc, psi_t);                               // turns
-        const double fr = __builtin_amdgcn_fract(ph);
-        T er, ei;
-        if constexpr (sizeof(T) == 8) {
-            double sn, cs;
-            bm_sincos_rad(two_pi * fr, cs, sn);                            // polynomial form (bm_f64.hpp): a third of the library's instructions
-            er = cs;
-            ei = sn;
-        } else {
-            er = __builtin_amdgcn_cosf((float)fr);
-            ei = __builtin_amdgcn_sinf((float)fr);
+        T er, ei, th;
+        bool done = false;
+        if constexpr (sizeof(T) == 4) {
+            // complex64 with the Doppler phase of the whole run below a quarter turn (config f1: 1e-3): the ray's frequency from
+            // v_cos_f32 -- its 1.5e-6 of absolute error is then < 4e-7 turns of phase, below the v_sin / v_cos of the phasor itself --
+            // instead of the f64 cospi (45 instructions per ray, a fifth of this kernel)
+            if (small_phase) {
+                const float wf = (float)pp.Fd * __builtin_amdgcn_cosf((float)u_phi);      // (v_cos_f32 takes turns)
+                const float fr = __builtin_amdgcn_fractf(fmaf(wf, (float)tc, (float)psi_t));
+                er = __builtin_amdgcn_cosf(fr);
+                ei = __builtin_amdgcn_sinf(fr);
+                th = (float)(two_pi * pp.dt) * wf;
+                done = true;
+            }
         }
-        const T th = (T)(two_pi * w * pp.dt);                              // rad per sample
+        if (!done) {
+            const double w = pp.Fd * cospi(2.0 * u_phi);                   // Hz; cos(phi), phi = 2 pi u
+            const double ph = fma(w, tc, psi_t);                           // turns
+            const double fr = __builtin_amdgcn_fract(ph);
+            if constexpr (sizeof(T) == 8) {
+                double sn, cs;
+                bm_sincos_rad(two_pi * fr, cs, sn);                        // polynomial form (bm_f64.hpp): a third of the library's instructions
+                er = cs;
+                ei = sn;
+            } else {
+                er = __builtin_amdgcn_cosf((float)fr);
+                ei = __builtin_amdgcn_sinf((float)fr);
+            }
+            th = (T)(two_pi * w * pp.dt);                                  // rad per sample
+        }
 #pragma unroll
         for (int m = 0; m <= (KT > 0 ? KT : kMaxOrder); ++m)
             if (KT > 0 || m <= K) {
