@@ -64,6 +64,7 @@ __global__ __launch_bounds__(256) void k_tdl_symbol_polys(SisoTdlParams pp, int 
     const double two_pi = 6.283185307179586476925286766559;
     const double tc = pp.Ts + pp.dt * ((double)((uint64_t)os * W) + xc);
     const Rng rng(seed, first + rl);
+    [[maybe_unused]] const bool small_phase = pp.Fd * (pp.Ts + pp.dt * ((double)(pp.n_ofdm_sym + 1) * W + 256.0)) < 0.25;   // turns, any sample of the run
     T ar[kTdlMaxK + 1], ai[kTdlMaxK + 1];
 #pragma unroll
     for (int m = 0; m <= kTdlMaxK; ++m) ar[m] = ai[m] = 0;
@@ -77,20 +78,35 @@ __global__ __launch_bounds__(256) void k_tdl_symbol_polys(SisoTdlParams pp, int 
             psi_t = uniform_at(rng, STREAM_PHASE, (uint64_t)L * S + rq);
             u_phi = uniform_at(rng, STREAM_PHASE, (uint64_t)rq);
         }
-        const double wd = pp.Fd * cospi(2.0 * u_phi);                     // Hz
-        const double ph = fma(wd, tc, psi_t);                             // turns
-        const double fr = __builtin_amdgcn_fract(ph);
-        T er, ei;
-        if constexpr (sizeof(T) == 8) {
-            double sn, cs;
-            sincos(two_pi * fr, &sn, &cs);
-            er = cs;
-            ei = sn;
-        } else {
-            er = __builtin_amdgcn_cosf((float)fr);
-            ei = __builtin_amdgcn_sinf((float)fr);
+        T er, ei, th;
+        bool done = false;
+        if constexpr (sizeof(T) == 4) {
+            // complex64 with the Doppler phase of the whole run below a quarter turn: the ray's frequency from v_cos_f32 (its 1.5e-6 of
+            // absolute error is then < 4e-7 turns of phase) instead of the f64 cospi -- as in k_mimo_tdl_symbol_polys (mimo_tdl.hpp)
+            if (small_phase) {
+                const float wf = (float)pp.Fd * __builtin_amdgcn_cosf((float)u_phi);      // (v_cos_f32 takes turns)
+                const float fr = __builtin_amdgcn_fractf(fmaf(wf, (float)tc, (float)psi_t));
+                er = __builtin_amdgcn_cosf(fr);
+                ei = __builtin_amdgcn_sinf(fr);
+                th = (float)(two_pi * pp.dt) * wf;
+                done = true;
+            }
         }
-        const T th = (T)(two_pi * wd * pp.dt);                            // rad per sample
+        if (!done) {
+            const double wd = pp.Fd * cospi(2.0 * u_phi);                 // Hz
+            const double ph = fma(wd, tc, psi_t);                         // turns
+            const double fr = __builtin_amdgcn_fract(ph);
+            if constexpr (sizeof(T) == 8) {
+                double sn, cs;
+                sincos(two_pi * fr, &sn, &cs);
+                er = cs;
+                ei = sn;
+            } else {
+                er = __builtin_amdgcn_cosf((float)fr);
+                ei = __builtin_amdgcn_sinf((float)fr);
+            }
+            th = (T)(two_pi * wd * pp.dt);                                // rad per sample
+        }
 #pragma unroll
         for (int m = 0; m <= kTdlMaxK; ++m)
             if (m <= K) {
