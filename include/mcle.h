@@ -519,7 +519,10 @@ int mcle_run_mimo_flat(mcle_ctx* ctx, int dtype, const mcle_mimo_flat_cfg* cfg, 
  * polynomial tap model, or for a rectangular geometry outside the envelope named at mcle_mimo_ofdm_tdl_cfg: run the staged operators
  * then.  Device memory: the context's scratch buffer grows to hold the fading records of one launch slice -- 2.5 KiB per
  * realization and symbol in complex64 at five taps of 4 x 4, 7.5 KiB in complex128, at most 4 GiB (+ 25 %) per slice
- * (mcle_run_ofdm_tdl: at most 2 GiB) -- and is kept until the context is destroyed. */
+ * (mcle_run_ofdm_tdl: at most 2 GiB) -- and is kept until the context is destroyed.
+ * complex64 (this function and mcle_run_ofdm_tdl): while the largest Doppler phase of the run, Fd x (Ts + dt x samples of all symbols),
+ * stays below a quarter turn the rays' Doppler frequencies are evaluated in float (v_cos_f32: < 4e-7 turns of phase, below the float
+ * phasor's own rounding); beyond that in double as in complex128. */
 int mcle_run_mimo_ofdm_tdl(mcle_ctx* ctx, int dtype, const mcle_mimo_ofdm_tdl_cfg* cfg, uint64_t seed,
                            uint64_t first, uint64_t count, mcle_counters* d_counters,
                            uint32_t* d_sym_err, uint32_t* d_bit_err);
