@@ -54,3 +54,27 @@ for dt in ("f64", "f32"):
         r = eng.run_mimo_ofdm(4, 4, 256, 16, 256, 1, 0.003, 1, 5, count, dtype=dt); assert r["n_realizations"] + r["n_skipped"] == count
         r = eng.run_mimo_ofdm(2, 2, 256, 16, 256, 1, 0.003, 1, 5, count, dtype=dt); assert r["n_realizations"] + r["n_skipped"] == count
 print("round-6 stress ok", time.time() - t)
+
+# round 6, last day: the kernels and grid rules added then -- config 3 at 2048 with two wavefronts per realization (odd counts: the last
+# pair's second slot is not a realization), delays beyond the prefix in the wavefront kernels, the small shapes whose grids give a
+# workgroup hundreds of realizations, the parked-coefficient f1 kernels off 1024 points; awkward counts and split invariance
+t = time.time()
+for dt in ("f64", "f32"):
+    for fft in (256, 512, 1024, 2048):
+        Tsn = 1 / (15e3 * fft)
+        pn, dn = discretize_profile(np.array([0., -3, -6, -9, -12]), np.arange(5) * Tsn, Tsn)
+        eng.set_constellation(constellation("qpsk", 4), _lib.CONST_GENERIC)
+        for n, k in ((1, 0), (2, 1), (3, 1), (40961, 7), (40961, 20480), (1000003 if fft <= 512 else 100003, 65)):
+            if k:
+                same_sum(lambda f, c: eng.run_ofdm_tdl(fft, 16, fft, 1, 0.01, pn, dn, 9, f, c, Fd=10.0, Ts=Tsn, L=8, dtype=dt), n, k)
+            else:
+                r = eng.run_ofdm_tdl(fft, 16, fft, 1, 0.01, pn, dn, 9, 0, n, Fd=10.0, Ts=Tsn, L=8, dtype=dt); assert r["n_realizations"] == n
+        pi_, di_ = discretize_profile(np.array([0., -3, -6]), np.array([0, 7, 40]) * Tsn, Tsn)      # a delay beyond the prefix
+        same_sum(lambda f, c: eng.run_ofdm_tdl(fft, 16, fft, 3, 0.01, pi_, di_, 9, f, c, Fd=10.0, Ts=Tsn, L=8, dtype=dt), 10007, 333)
+        eng.set_constellation(constellation("qam", 64), _lib.CONST_QAM)
+        for nt, nr in ((1, 2), (2, 2), (2, 3), (2, 4), (4, 4)):
+            n = 20011 if fft <= 512 else 4099
+            same_sum(lambda f, c: eng.run_mimo_ofdm(nt, nr, fft, 16, fft, 1, 0.003, 9, f, c, method=_lib.DEMOD_MINDIST, dtype=dt), n, n // 3)
+            same_sum(lambda f, c: eng.run_mimo_ofdm_tdl(nt, nr, fft, 16, fft, 1, 0.003, pn, dn, 9, f, c, Fd=10.0, Ts=Tsn, L=8, dtype=dt), min(n, 6007), 17)
+        same_sum(lambda f, c: eng.run_mimo_ofdm_tdl(2, 3, fft, 4, fft, 2, 0.003, pi_, di_, 9, f, c, Fd=10.0, Ts=Tsn, L=8, dtype=dt), 2003, 1000)
+print("last-day stress ok", time.time() - t)
