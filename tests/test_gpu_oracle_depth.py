@@ -48,6 +48,23 @@ def test_config3_wave_kernel_over_2048_realizations(engine, dtype):
     _hold(dtype, res, se, be, want_se, want_be, nsym, nbits)
 
 
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_config3_at_2048_points_two_wavefronts_per_realization_over_1024_realizations(engine, dtype):
+    """Config 3's link at fft_size 2048 on k_run_ofdm_tdl_hw (csrc/siso_tdl_hw.hpp, the default there since the last day of round 6):
+    1 025 realizations (an odd count: the last pair's second slot is not a realization) against the oracle, every per-realization
+    count in complex128."""
+    from pyphysim_amd.channels import discretize_profile
+    engine.set_constellation(chains.constellation("qpsk", 4), _lib.CONST_GENERIC)
+    Ts = 1.0 / (15e3 * 2048)
+    kw = dict(mod="qpsk", M=4, fft_size=2048, cp_size=16, num_used=None, n_ofdm_sym=1, snr_db=20.0, Fd=10.0, Ts=Ts, L=8)
+    first, count = 50000, 1025
+    want_se, want_be, nsym, nbits = _oracle(chains.chain_ofdm_tdl, first, count, linear_mean=True, **kw)
+    p_lin, d_idx = discretize_profile(np.array([0.0, -3.0, -6.0, -9.0, -12.0]), np.arange(5) * Ts, Ts)
+    res, se, be = engine.run_ofdm_tdl(2048, 16, 2048, 1, 1.0 / omodem.dB2Linear(20.0), p_lin, d_idx, SEED, first, count, Fd=10.0, Ts=Ts,
+                                      L=8, dtype=dtype, per_realization=True)
+    _hold(dtype, res, se, be, want_se, want_be, nsym, nbits)
+
+
 def test_config3_against_the_literal_mean_of_dfts_over_512_realizations(engine):
     """the 2 048-realization test above runs the oracle with the DFT of the MEAN taps (linearity); the
     reference takes the mean of the per-sample DFTs (channels/fading.py:513-536, modulators/ofdm.py:545-547) -- equal in exact
@@ -79,6 +96,27 @@ def test_f1_against_the_literal_mean_of_dfts_over_48_realizations(engine):
                                            Fd=10.0, Ts=Ts, L=8, mmse=True, method=_lib.DEMOD_MINDIST, dtype="f64",
                                            per_realization=True)
     _hold("f64", res, se, be, want_se, want_be, nsym, nbits)
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("shape", [(256, 4, 4, 256), (512, 2, 3, 160), (2048, 2, 2, 64), (2048, 4, 4, 24)])
+def test_f1_off_the_benchmark_size_on_the_parked_coefficient_kernels(engine, dtype, shape):
+    """The frequency-selective link at 256 / 512 / 2048 points with the benchmark's Doppler per symbol -- the polynomial order at which
+    the parked-coefficient kernels (pipeline_mimo_tdl_wave_*_{256,512,2048}k.hip, the default there since the last day of round 6) are
+    picked, and in complex64 the record kernel's float evaluation of the rays' frequencies: per-realization counts against the oracle."""
+    from pyphysim_amd.channels import discretize_profile
+    fft, nt, nr, count = shape
+    engine.set_constellation(chains.constellation("qam", 64), _lib.CONST_QAM)
+    Ts = 1.0 / (15e3 * fft)
+    cp = 16 if fft < 2048 else 32
+    kw = dict(mod="qam", M=64, nt=nt, nr=nr, fft_size=fft, cp_size=cp, num_used=None, n_ofdm_sym=1, snr_db=25.0, Fd=10.0, Ts=Ts, L=8,
+              tap_powers_dB=(0.0, -3.0, -6.0, -9.0, -12.0), tap_delays_samples=(0, 1, 2, 3, 4), mmse=True)
+    first = 7000 + fft
+    want_se, want_be, nsym, nbits = _oracle(chains.chain_mimo_ofdm_tdl, first, count, linear_mean=True, **kw)
+    p_lin, d_idx = discretize_profile(np.array([0.0, -3.0, -6.0, -9.0, -12.0]), np.arange(5) * Ts, Ts)
+    res, se, be = engine.run_mimo_ofdm_tdl(nt, nr, fft, cp, fft, 1, 1.0 / omodem.dB2Linear(25.0), p_lin, d_idx, SEED, first, count,
+                                           Fd=10.0, Ts=Ts, L=8, mmse=True, method=_lib.DEMOD_MINDIST, dtype=dtype, per_realization=True)
+    _hold(dtype, res, se, be, want_se, want_be, nsym, nbits)
 
 
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
