@@ -94,7 +94,10 @@ __global__ __launch_bounds__(128 * NRW, WPS) void k_run_ofdm_tdl_hw(SisoTdlParam
     const int n_coef = S * (K + 1), rec_len = n_coef + S;
     // the register passes' lane twiddles: complex128 fetches them ahead of each transform (48 registers it does not have across the
     // channel and the noise); complex64 keeps them (24 registers)
-    constexpr bool TWFETCH = true;      // (complex64 with the twiddles resident: 64 spilled registers inside the loop, 4.2 against 5.1e7)
+#ifndef MCLE_HW_F32_TWFETCH
+#define MCLE_HW_F32_TWFETCH 1
+#endif
+    constexpr bool TWFETCH = sizeof(T) == 8 || MCLE_HW_F32_TWFETCH;   // (complex64 with the twiddles resident, 8 spilled registers: 5.85 against 5.87e7)
     R16Tw64<T> tw16;
     if constexpr (!TWFETCH) tw16 = load_r16_tw<T>(g_twH, lane);
     const cx<T> wl = g_twN[fft_index_of_pos<H>(lane)];                       // w2048^(F(lane)): the last stage's twiddle, lane part
