@@ -534,6 +534,10 @@ static int launch_mimo_ofdm_planar(mcle_ctx* ctx, const mcle_mimo_ofdm_cfg* cfg,
 #endif
 template <typename T> constexpr int planar_wps(int n, int nt, int nr, int w64) {
     if (sizeof(T) == 4 && w64 <= 3 && ((n == 256 && !(nt == 4 && nr == 4)) || (n == 512 && nr == 2))) return w64 + MCLE_PLANAR_F32_WPS_PLUS;
+#ifndef MCLE_PLANAR_F64_256_WPS3
+#define MCLE_PLANAR_F64_256_WPS3 0
+#endif
+    if (MCLE_PLANAR_F64_256_WPS3 && sizeof(T) == 8 && n == 256 && nr <= 3 && w64 == 2) return 3;   // (A/B on the last day: +1.5 ... -1.5 %, not adopted)
     return w64;
 }
 
